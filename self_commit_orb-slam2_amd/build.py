@@ -1,0 +1,66 @@
+"""Build helpers: compile liborbx.so (HIP, gfx950 only) and the CPU checkers under oracle/.
+
+`python -m` is awkward with the hyphenated package name, so __graft_entry__.build() imports
+this file by path.  Everything is built IN-TREE so the .so files travel to the GPU box with
+the gpurun snapshot.
+"""
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIB = PKG / "lib" / "liborbx.so"
+HIP_SOURCES = ["orbx_kernels.hip", "orbx_extractor.hip", "orbx_match.hip", "orbx_lba.hip", "orbx_synth.cc"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+             "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target: Path, deps) -> bool:
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(Path(d).stat().st_mtime <= t for d in deps if Path(d).exists())
+
+
+def hipcc_path():
+    for c in ("hipcc", "/opt/rocm/bin/hipcc"):
+        p = shutil.which(c)
+        if p:
+            return p
+    return None
+
+
+def build_liborbx(force=False, verbose=True):
+    srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
+    deps = srcs + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [ROOT / "include" / "orbx.h"]
+    if not force and _newer(LIB, deps):
+        return LIB
+    hipcc = hipcc_path()
+    if hipcc is None:
+        if LIB.exists():
+            return LIB   # GPU box without a compiler: use the prebuilt library from the snapshot
+        raise RuntimeError("hipcc not found and no prebuilt liborbx.so")
+    LIB.parent.mkdir(parents=True, exist_ok=True)
+    cmd = [hipcc] + HIP_FLAGS + ["-o", str(LIB)] + [str(s) for s in srcs]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+def build_oracle(verbose=True):
+    """Compile the CPU checkers (test infrastructure).  oracle/_ref needs /root/reference."""
+    mk = ROOT / "oracle" / "Makefile"
+    if shutil.which("make") is None or shutil.which("g++") is None:
+        return
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.run(["make", "-s", "-f", str(mk), "all"], check=True, stdout=out)
+
+
+def build_all(force=False, verbose=True):
+    build_liborbx(force=force, verbose=verbose)
+    build_oracle(verbose=verbose)
+    return LIB

@@ -1,0 +1,606 @@
+// orbx_extractor.hip -- host side of the extractor C ABI (include/orbx.h).
+//
+// Mirrors ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:92-161,
+// src/ORBextractor.cc:492-609, 1544-1734): the constructor tables are built on the
+// host with the reference's float/double arithmetic, the per-frame work runs as the
+// HIP kernels of orbx_kernels.hip on the handle's stream.  No CPU fallback.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "orbx_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void orbx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *orbx_last_error(void) { return g_err; }
+extern "C" int orbx_version(void) { return 100; }
+
+static const char *kStageNames[] = {"pyramid", "fast_score", "cell_nms", "octree", "orient", "blur", "describe"};
+enum { ST_PYR = 0, ST_FAST, ST_CELLS, ST_OCTREE, ST_ORIENT, ST_BLUR, ST_DESC, ST_COUNT };
+extern "C" const char *orbx_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
+
+namespace {
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n) return ORBX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        ORBX_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+        return ORBX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+inline int round_f(float v) { return (int)lrintf(v); }
+inline int floor_d(double v) { int i = (int)v; return i - (i > v); }
+inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct orbx_extractor {
+    orbx_extractor_config cfg;
+    // ORBextractor tables (src/ORBextractor.cc:499-554)
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> quota;
+    int umax[16];
+    uint32_t taps[7];
+    // current geometry
+    OrbxGeom geom;
+    bool geomValid = false;
+    std::vector<OrbxResizeX> rxHost;
+    std::vector<OrbxResizeY> ryHost;
+    std::vector<uint8_t> binHost;
+    int nodeCap = 512;
+    // device state
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[ST_COUNT + 1] = {};
+    bool profiling = false, timingValid = false;
+    DevBuf<OrbxGeom> geomDev;
+    DevBuf<OrbxResizeX> rxDev;
+    DevBuf<OrbxResizeY> ryDev;
+    DevBuf<uint8_t> binDev, pyr, blur, score, staging, outDesc;
+    DevBuf<int> cellCount, lvlCnt, outCnt, status;
+    DevBuf<uint32_t> cellSlots, ptBuf;
+    DevBuf<OrbxLevelKp> lvlKp;
+    DevBuf<orbx_keypoint> outKp;
+    int allocBatch = 0;
+    // last run
+    int lastBatch = 0;
+    const uint8_t *lastImg0 = nullptr;
+    int lastStride = 0;
+    size_t lastFramePitch = 0;
+    int stagingStride = 0;
+    size_t stagingFramePitch = 0;
+};
+
+namespace {
+
+// ORBextractor::ORBextractor, src/ORBextractor.cc:492-609
+void build_tables(orbx_extractor *h)
+{
+    const int nl = h->cfg.nlevels;
+    const double scaleFactor = h->cfg.scale_factor;   // double member initialised from a float (ORBextractor.h:206)
+    h->scale.assign((size_t)nl, 1.f); h->sigma2.assign((size_t)nl, 1.f);
+    h->invScale.assign((size_t)nl, 1.f); h->invSigma2.assign((size_t)nl, 1.f);
+    h->quota.assign((size_t)nl, 0);
+    for (int i = 1; i < nl; i++) {
+        h->scale[(size_t)i] = (float)(h->scale[(size_t)i - 1] * scaleFactor);
+        h->sigma2[(size_t)i] = h->scale[(size_t)i] * h->scale[(size_t)i];
+    }
+    for (int i = 0; i < nl; i++) {
+        h->invScale[(size_t)i] = 1.0f / h->scale[(size_t)i];
+        h->invSigma2[(size_t)i] = 1.0f / h->sigma2[(size_t)i];
+    }
+    float factor = (float)(1.0f / scaleFactor);
+    float nDesired = h->cfg.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        h->quota[(size_t)l] = round_f(nDesired);
+        sum += h->quota[(size_t)l];
+        nDesired *= factor;
+    }
+    h->quota[(size_t)nl - 1] = std::max(h->cfg.nfeatures - sum, 0);
+    // umax: quarter circle of radius HALF_PATCH_SIZE made symmetric (:579-608)
+    int v, v0;
+    const int vmax = floor_d(ORBX_HALF_PATCH * sqrt(2.f) / 2 + 1);
+    const int vmin = (int)ceil(ORBX_HALF_PATCH * sqrt(2.f) / 2);
+    const double hp2 = ORBX_HALF_PATCH * ORBX_HALF_PATCH;
+    for (v = 0; v <= vmax; ++v) h->umax[v] = (int)lrint(sqrt(hp2 - v * v));
+    for (v = ORBX_HALF_PATCH, v0 = 0; v >= vmin; --v) {
+        while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+        h->umax[v] = v0;
+        ++v0;
+    }
+    static const uint16_t kDefaultTaps[7] = {18, 34, 48, 56, 48, 34, 18};
+    bool zero = true;
+    for (int i = 0; i < 7; i++) zero = zero && h->cfg.gauss_taps[i] == 0;
+    for (int i = 0; i < 7; i++) h->taps[i] = zero ? kDefaultTaps[i] : h->cfg.gauss_taps[i];
+}
+
+// Level sizes (ComputePyramid :1680-1682), cell grid (:1064-1086), initial quadtree nodes
+// (:719-748), cv::resize coefficient tables, tile tables and buffer offsets for W x H.
+int build_geometry(orbx_extractor *h, int W, int H)
+{
+    OrbxGeom &g = h->geom;
+    memset(&g, 0, sizeof(g));
+    const int nl = h->cfg.nlevels;
+    g.nlevels = nl; g.W = W; g.H = H; g.iniTh = h->cfg.ini_th_fast; g.minTh = h->cfg.min_th_fast;
+    for (int i = 0; i < 7; i++) g.taps[i] = h->taps[i];
+    for (int i = 0; i < 16; i++) g.umax[i] = h->umax[i];
+    h->rxHost.clear(); h->ryHost.clear(); h->binHost.clear();
+    size_t off = 0;
+    int cells = 0, slots = 0, kps = 0, ftiles = 0, btiles = 0, maxNodes = 0;
+    for (int l = 0; l < nl; l++) {
+        OrbxLevel &lv = g.lv[l];
+        lv.w = round_f((float)W * h->invScale[(size_t)l]);
+        lv.h = round_f((float)H * h->invScale[(size_t)l]);
+        if (lv.w < 2 * ORBX_BORDER + ORBX_CELL_W || lv.h < 2 * ORBX_BORDER + ORBX_CELL_W) {
+            orbx_set_error("image %dx%d too small for pyramid level %d (%dx%d)", W, H, l, lv.w, lv.h);
+            return ORBX_ERR_ARG;
+        }
+        if (lv.w > 4095 + ORBX_BORDER || lv.h > 4095 + ORBX_BORDER) { orbx_set_error("image too large (max 4111 px per side)"); return ORBX_ERR_ARG; }
+        lv.pitch = (int)align_up((size_t)lv.w, 64);
+        lv.off = (int)off;
+        off += align_up((size_t)lv.pitch * lv.h, 256);
+        const int minB = ORBX_BORDER, maxBX = lv.w - ORBX_BORDER, maxBY = lv.h - ORBX_BORDER;
+        const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+        lv.nCols = (int)(width / (float)ORBX_CELL_W);
+        lv.nRows = (int)(height / (float)ORBX_CELL_W);
+        lv.wCell = (int)ceil(width / lv.nCols);
+        lv.hCell = (int)ceil(height / lv.nRows);
+        lv.cellBase = cells;
+        cells += lv.nCols * lv.nRows;
+        lv.cellCap = ((lv.wCell + 1) / 2) * ((lv.hCell + 1) / 2);
+        lv.slotBase = slots;
+        slots += lv.nCols * lv.nRows * lv.cellCap;
+        lv.quota = h->quota[(size_t)l];
+        lv.nIni = (int)roundf((float)(maxBX - minB) / (maxBY - minB));
+        if (lv.nIni < 1 || lv.nIni > 4) {
+            orbx_set_error("aspect ratio of level %d (%dx%d) gives %d initial quadtree nodes; supported: 1..4", l, lv.w, lv.h, lv.nIni);
+            return ORBX_ERR_ARG;
+        }
+        const float hX = (float)(maxBX - minB) / lv.nIni;
+        for (int i = 0; i <= lv.nIni; i++) lv.iniX[i] = (int)(hX * (float)i);
+        lv.binOff = (int)h->binHost.size();
+        for (int x = 0; x < maxBX - minB; x++) {
+            int b = (int)((float)x / hX);   // vpIniNodes[kp.pt.x/hX], :766
+            h->binHost.push_back((uint8_t)std::min(b, lv.nIni - 1));
+        }
+        lv.kpCap = lv.quota + 3 + 4 * lv.nIni;
+        lv.kpBase = kps;
+        kps += lv.kpCap;
+        maxNodes = std::max(maxNodes, lv.kpCap);
+        if (lv.nCols * lv.nRows > 2048) { orbx_set_error("level %d has %d cells; at most 2048 supported", l, lv.nCols * lv.nRows); return ORBX_ERR_ARG; }
+        lv.fastTilesX = (lv.w - ORBX_EDGE - ORBX_BORDER + 63) / 64;
+        lv.fastTilesY = (lv.h - ORBX_EDGE - ORBX_BORDER + 15) / 16;
+        lv.fastTileBase = ftiles;
+        ftiles += lv.fastTilesX * lv.fastTilesY;
+        lv.blurTilesX = (lv.w + 63) / 64;
+        lv.blurTilesY = (lv.h + 15) / 16;
+        lv.blurTileBase = btiles;
+        btiles += lv.blurTilesX * lv.blurTilesY;
+        lv.scale = h->scale[(size_t)l];
+        lv.patchSize = (int)(ORBX_PATCH * h->scale[(size_t)l]);
+        // cv::resize(INTER_LINEAR) tables from level l-1 (OpenCV resize.cpp, 11-bit fixed point)
+        lv.rxOff = (int)h->rxHost.size();
+        lv.ryOff = (int)h->ryHost.size();
+        if (l > 0) {
+            const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h;
+            const double scale_x = 1. / ((double)lv.w / sw), scale_y = 1. / ((double)lv.h / sh);
+            for (int dx = 0; dx < lv.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = floor_d(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+                OrbxResizeX e;
+                e.sx = (uint16_t)sx; e.a0 = sat_short(round_f((1.f - fx) * 2048)); e.a1 = sat_short(round_f(fx * 2048)); e.pad = 0;
+                h->rxHost.push_back(e);
+            }
+            for (int dy = 0; dy < lv.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = floor_d(fy);
+                fy -= sy;
+                OrbxResizeY e;
+                e.b0 = sat_short(round_f((1.f - fy) * 2048)); e.b1 = sat_short(round_f(fy * 2048));
+                e.y0 = (uint16_t)(sy < 0 ? 0 : (sy < sh ? sy : sh - 1));
+                e.y1 = (uint16_t)(sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1));
+                h->ryHost.push_back(e);
+            }
+        }
+    }
+    g.cellsPerFrame = cells; g.slotsPerFrame = slots; g.kpPerFrame = kps; g.outCap = kps;
+    g.fastTiles = ftiles; g.blurTiles = btiles;
+    g.pyrBytes = align_up(off + 256, 256);
+    if (maxNodes > 2048) { orbx_set_error("per-level feature quota %d exceeds the quadtree node capacity 2048", maxNodes); return ORBX_ERR_ARG; }
+    h->nodeCap = maxNodes <= 512 ? 512 : (maxNodes <= 1024 ? 1024 : 2048);
+    return ORBX_OK;
+}
+
+int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
+{
+    if (W <= 0 || H <= 0 || batch <= 0) { orbx_set_error("bad image size / batch"); return ORBX_ERR_ARG; }
+    if (W > h->cfg.max_width || H > h->cfg.max_height || batch > h->cfg.max_batch) {
+        orbx_set_error("request %dx%d x%d exceeds the handle's configured maximum %dx%d x%d", W, H, batch, h->cfg.max_width,
+                       h->cfg.max_height, h->cfg.max_batch);
+        return ORBX_ERR_CAPACITY;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    if (!h->geomValid || h->geom.W != W || h->geom.H != H) {
+        h->geomValid = false;
+        int rc = build_geometry(h, W, H);
+        if (rc != ORBX_OK) return rc;
+        if ((rc = h->geomDev.ensure(1)) != ORBX_OK) return rc;
+        if ((rc = h->rxDev.ensure(std::max<size_t>(h->rxHost.size(), 1))) != ORBX_OK) return rc;
+        if ((rc = h->ryDev.ensure(std::max<size_t>(h->ryHost.size(), 1))) != ORBX_OK) return rc;
+        if ((rc = h->binDev.ensure(std::max<size_t>(h->binHost.size(), 1))) != ORBX_OK) return rc;
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+        ORBX_HIP_CHECK(hipMemcpy(h->geomDev.p, &h->geom, sizeof(OrbxGeom), hipMemcpyHostToDevice));
+        if (!h->rxHost.empty()) ORBX_HIP_CHECK(hipMemcpy(h->rxDev.p, h->rxHost.data(), h->rxHost.size() * sizeof(OrbxResizeX), hipMemcpyHostToDevice));
+        if (!h->ryHost.empty()) ORBX_HIP_CHECK(hipMemcpy(h->ryDev.p, h->ryHost.data(), h->ryHost.size() * sizeof(OrbxResizeY), hipMemcpyHostToDevice));
+        ORBX_HIP_CHECK(hipMemcpy(h->binDev.p, h->binHost.data(), h->binHost.size(), hipMemcpyHostToDevice));
+        h->geomValid = true;
+        h->allocBatch = 0;   // per-frame sizes changed: re-check every buffer
+    }
+    if (batch > h->allocBatch) {
+        const OrbxGeom &g = h->geom;
+        const size_t B = (size_t)batch;
+        int rc;
+        if ((rc = h->pyr.ensure(B * g.pyrBytes)) != ORBX_OK) return rc;
+        if ((rc = h->blur.ensure(B * g.pyrBytes)) != ORBX_OK) return rc;
+        if ((rc = h->score.ensure(B * g.pyrBytes)) != ORBX_OK) return rc;
+        if ((rc = h->cellCount.ensure(B * g.cellsPerFrame)) != ORBX_OK) return rc;
+        if ((rc = h->cellSlots.ensure(B * g.slotsPerFrame)) != ORBX_OK) return rc;
+        if ((rc = h->ptBuf.ensure(B * g.nlevels * 2 * ORBX_PT_CAP)) != ORBX_OK) return rc;
+        if ((rc = h->lvlKp.ensure(B * g.kpPerFrame)) != ORBX_OK) return rc;
+        if ((rc = h->lvlCnt.ensure(B * g.nlevels)) != ORBX_OK) return rc;
+        if ((rc = h->outKp.ensure(B * g.outCap)) != ORBX_OK) return rc;
+        if ((rc = h->outDesc.ensure(B * g.outCap * 32)) != ORBX_OK) return rc;
+        if ((rc = h->outCnt.ensure(B)) != ORBX_OK) return rc;
+        if ((rc = h->status.ensure(B)) != ORBX_OK) return rc;
+        // the score map is only written inside the detectable window; clear it once so the
+        // parity taps (orbx_debug_download_scores) see zeros elsewhere
+        ORBX_HIP_CHECK(hipMemsetAsync(h->score.p, 0, B * g.pyrBytes, h->stream));
+        h->allocBatch = batch;
+    }
+    return ORBX_OK;
+}
+
+int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H, int stride, size_t framePitch)
+{
+    int rc = ensure_geometry(h, W, H, batch);
+    if (rc != ORBX_OK) return rc;
+    OrbxLaunch L;
+    L.stream = h->stream; L.geomDev = h->geomDev.p; L.geom = &h->geom; L.batch = batch;
+    L.img0 = img0Dev; L.img0Stride = stride; L.img0FramePitch = framePitch;
+    L.pyr = h->pyr.p; L.blur = h->blur.p; L.score = h->score.p; L.blurBytes = h->geom.pyrBytes;
+    L.rx = h->rxDev.p; L.ry = h->ryDev.p; L.binTab = h->binDev.p;
+    L.cellCount = h->cellCount.p; L.cellSlots = h->cellSlots.p; L.ptBuf = h->ptBuf.p;
+    L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outKp = h->outKp.p; L.outDesc = h->outDesc.p; L.outCnt = h->outCnt.p;
+    L.status = h->status.p; L.nodeCap = h->nodeCap;
+    const bool prof = h->profiling;
+    h->timingValid = false;
+    ORBX_HIP_CHECK(hipMemsetAsync(h->status.p, 0, (size_t)batch * sizeof(int), h->stream));
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[0], h->stream));
+    for (int l = 1; l < h->geom.nlevels; l++)
+        if ((rc = orbx_launch_resize(L, l)) != ORBX_OK) return rc;
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_PYR + 1], h->stream));
+    if ((rc = orbx_launch_fast(L)) != ORBX_OK) return rc;
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_FAST + 1], h->stream));
+    if ((rc = orbx_launch_cells(L)) != ORBX_OK) return rc;
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_CELLS + 1], h->stream));
+    if ((rc = orbx_launch_octree(L)) != ORBX_OK) return rc;
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_OCTREE + 1], h->stream));
+    if ((rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_ORIENT + 1], h->stream));
+    if ((rc = orbx_launch_blur(L)) != ORBX_OK) return rc;
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_BLUR + 1], h->stream));
+    if ((rc = orbx_launch_desc(L)) != ORBX_OK) return rc;
+    if (prof) { ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_DESC + 1], h->stream)); h->timingValid = true; }
+    h->lastBatch = batch; h->lastImg0 = img0Dev; h->lastStride = stride; h->lastFramePitch = framePitch;
+    return ORBX_OK;
+}
+
+int check_status(orbx_extractor *h, int batch)
+{
+    std::vector<int> st((size_t)batch);
+    ORBX_HIP_CHECK(hipMemcpy(st.data(), h->status.p, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
+    for (int f = 0; f < batch; f++)
+        if (st[(size_t)f]) {
+            orbx_set_error("frame %d: device capacity error bits 0x%x (1: >%d FAST candidates in a level, 2: quadtree node list, 4: level keypoints)",
+                           f, st[(size_t)f], ORBX_PT_CAP);
+            return ORBX_ERR_CAPACITY;
+        }
+    return ORBX_OK;
+}
+
+int upload(orbx_extractor *h, const uint8_t *const *images, int batch, int W, int H, int stride)
+{
+    if (!images || stride < W) { orbx_set_error("bad image pointer / stride"); return ORBX_ERR_ARG; }
+    const int dstStride = (int)align_up((size_t)W, 64);
+    const size_t fp = align_up((size_t)dstStride * H + 256, 256);
+    int rc = h->staging.ensure(fp * (size_t)batch);
+    if (rc != ORBX_OK) return rc;
+    for (int f = 0; f < batch; f++) {
+        if (!images[f]) { orbx_set_error("image %d is NULL", f); return ORBX_ERR_ARG; }
+        ORBX_HIP_CHECK(hipMemcpy2DAsync(h->staging.p + fp * (size_t)f, (size_t)dstStride, images[f], (size_t)stride, (size_t)W, (size_t)H,
+                                        hipMemcpyHostToDevice, h->stream));
+    }
+    h->stagingStride = dstStride; h->stagingFramePitch = fp;
+    return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extractor **out)
+{
+    if (!cfg || !out) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    *out = nullptr;
+    if (cfg->nlevels < 1 || cfg->nlevels > ORBX_MAX_LEVELS || cfg->nfeatures < 1 || !(cfg->scale_factor > 1.0f) || cfg->min_th_fast < 1 ||
+        cfg->ini_th_fast < cfg->min_th_fast || cfg->ini_th_fast > 255 || cfg->max_width < 1 || cfg->max_height < 1 || cfg->max_batch < 1) {
+        orbx_set_error("bad extractor configuration (need 1<=nlevels<=%d, nfeatures>=1, scale_factor>1, 1<=minTh<=iniTh<=255)", ORBX_MAX_LEVELS);
+        return ORBX_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        orbx_set_error("no HIP device available: liborbx has no CPU fallback");
+        return ORBX_ERR_NODEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { orbx_set_error("device %d out of range (have %d)", cfg->device, ndev); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(cfg->device));
+    orbx_extractor *h = new orbx_extractor();
+    h->cfg = *cfg;
+    build_tables(h);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        orbx_set_error("hipStreamCreate failed");
+        delete h;
+        return ORBX_ERR_HIP;
+    }
+    for (int i = 0; i <= ST_COUNT; i++) (void)hipEventCreate(&h->ev[i]);
+    // validate the largest geometry up front so a bad size fails at construction
+    int rc = build_geometry(h, cfg->max_width, cfg->max_height);
+    if (rc != ORBX_OK) { orbx_extractor_destroy(h); return rc; }
+    h->geomValid = false;
+    *out = h;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_extractor_destroy(orbx_extractor *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->geomDev.release(); h->rxDev.release(); h->ryDev.release(); h->binDev.release(); h->pyr.release(); h->blur.release();
+    h->score.release(); h->staging.release(); h->outDesc.release(); h->cellCount.release(); h->lvlCnt.release(); h->outCnt.release();
+    h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->lvlKp.release(); h->outKp.release();
+    for (int i = 0; i <= ST_COUNT; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int orbx_extractor_tables(const orbx_extractor *h, int *nlevels, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                                     int *features_per_level)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    const int nl = h->cfg.nlevels;
+    if (nlevels) *nlevels = nl;
+    for (int i = 0; i < nl; i++) {
+        if (scale) scale[i] = h->scale[(size_t)i];
+        if (inv_scale) inv_scale[i] = h->invScale[(size_t)i];
+        if (sigma2) sigma2[i] = h->sigma2[(size_t)i];
+        if (inv_sigma2) inv_sigma2[i] = h->invSigma2[(size_t)i];
+        if (features_per_level) features_per_level[i] = h->quota[(size_t)i];
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_capacity(const orbx_extractor *h)
+{
+    if (!h) return ORBX_ERR_ARG;
+    int cap = 0;
+    for (int l = 0; l < h->cfg.nlevels; l++) cap += h->quota[(size_t)l] + 3 + 16;
+    return cap;
+}
+
+extern "C" int orbx_upload_frames(orbx_extractor *h, const uint8_t *const *images, int batch, int width, int height, int stride,
+                                  const void **images_dev, int *dev_stride, size_t *dev_frame_pitch)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    int rc = upload(h, images, batch, width, height, stride);
+    if (rc != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (images_dev) *images_dev = h->staging.p;
+    if (dev_stride) *dev_stride = h->stagingStride;
+    if (dev_frame_pitch) *dev_frame_pitch = h->stagingFramePitch;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch_device(orbx_extractor *h, const void *images_dev, int batch, int width, int height, int stride, size_t frame_pitch)
+{
+    if (!h || !images_dev) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (stride < width || frame_pitch < (size_t)stride * (size_t)(height - 1) + (size_t)width) { orbx_set_error("bad stride / frame pitch"); return ORBX_ERR_ARG; }
+    return run_batch(h, (const uint8_t *)images_dev, batch, width, height, stride, frame_pitch);
+}
+
+extern "C" int orbx_batch_results_device(orbx_extractor *h, const orbx_keypoint **keypoints_dev, const uint8_t **descriptors_dev,
+                                         const int32_t **counts_dev, int *capacity)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
+    if (keypoints_dev) *keypoints_dev = h->outKp.p;
+    if (descriptors_dev) *descriptors_dev = h->outDesc.p;
+    if (counts_dev) *counts_dev = h->outCnt.p;
+    if (capacity) *capacity = h->geom.outCap;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_sync(orbx_extractor *h)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_batch_download(orbx_extractor *h, int batch, orbx_keypoint *keypoints, uint8_t *descriptors, int capacity, int *counts)
+{
+    if (!h || !counts) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (batch <= 0 || batch > h->lastBatch) { orbx_set_error("batch %d not available (last run had %d frames)", batch, h->lastBatch); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    int rc = check_status(h, batch);
+    if (rc != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipMemcpy(counts, h->outCnt.p, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
+    const int cap = h->geom.outCap;
+    for (int f = 0; f < batch; f++) {
+        const int n = counts[f];
+        if (n > capacity) { orbx_set_error("frame %d has %d keypoints but the caller's capacity is %d", f, n, capacity); return ORBX_ERR_CAPACITY; }
+        if (n == 0) continue;
+        if (keypoints) ORBX_HIP_CHECK(hipMemcpy(keypoints + (size_t)f * capacity, h->outKp.p + (size_t)f * cap, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+        if (descriptors) ORBX_HIP_CHECK(hipMemcpy(descriptors + (size_t)f * capacity * 32, h->outDesc.p + (size_t)f * cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *const *images, int batch, int width, int height, int stride,
+                                  orbx_keypoint *keypoints, uint8_t *descriptors, int capacity, int *counts)
+{
+    if (!h || !counts) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    int rc = upload(h, images, batch, width, height, stride);
+    if (rc != ORBX_OK) return rc;
+    rc = run_batch(h, h->staging.p, batch, width, height, h->stagingStride, h->stagingFramePitch);
+    if (rc != ORBX_OK) return rc;
+    return orbx_batch_download(h, batch, keypoints, descriptors, capacity, counts);
+}
+
+extern "C" int orbx_extract(orbx_extractor *h, const uint8_t *image, int width, int height, int stride, orbx_keypoint *keypoints,
+                            uint8_t *descriptors, int capacity, int *count)
+{
+    if (!h || !count) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    *count = 0;
+    if (!image || width <= 0 || height <= 0) return ORBX_OK;   // reference: empty image -> silent return (:1553-1554)
+    const uint8_t *imgs[1] = {image};
+    return orbx_extract_batch(h, imgs, 1, width, height, stride, keypoints, descriptors, capacity, count);
+}
+
+extern "C" int orbx_pyramid_level_size(const orbx_extractor *h, int width, int height, int level, int *w, int *hgt)
+{
+    if (!h || level < 0 || level >= h->cfg.nlevels) { orbx_set_error("bad handle / level"); return ORBX_ERR_ARG; }
+    if (w) *w = round_f((float)width * h->invScale[(size_t)level]);
+    if (hgt) *hgt = round_f((float)height * h->invScale[(size_t)level]);
+    return ORBX_OK;
+}
+
+static int download_plane(orbx_extractor *h, const uint8_t *base, int pitch, int w, int hh, uint8_t *dst, int dst_stride)
+{
+    if (!dst || dst_stride < w) { orbx_set_error("bad destination"); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    ORBX_HIP_CHECK(hipMemcpy2D(dst, (size_t)dst_stride, base, (size_t)pitch, (size_t)w, (size_t)hh, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_download_pyramid(orbx_extractor *h, int frame, int level, int blurred, uint8_t *dst, int dst_stride)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!h->lastBatch || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels) { orbx_set_error("frame/level not available"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    const OrbxLevel &lv = h->geom.lv[level];
+    if (blurred) return download_plane(h, h->blur.p + (size_t)frame * h->geom.pyrBytes + lv.off, lv.pitch, lv.w, lv.h, dst, dst_stride);
+    if (level == 0) return download_plane(h, h->lastImg0 + (size_t)frame * h->lastFramePitch, h->lastStride, lv.w, lv.h, dst, dst_stride);
+    return download_plane(h, h->pyr.p + (size_t)frame * h->geom.pyrBytes + lv.off, lv.pitch, lv.w, lv.h, dst, dst_stride);
+}
+
+extern "C" int orbx_debug_download_scores(orbx_extractor *h, int frame, int level, uint8_t *dst, int dst_stride)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!h->lastBatch || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels) { orbx_set_error("frame/level not available"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    const OrbxLevel &lv = h->geom.lv[level];
+    return download_plane(h, h->score.p + (size_t)frame * h->geom.pyrBytes + lv.off, lv.pitch, lv.w, lv.h, dst, dst_stride);
+}
+
+extern "C" int orbx_debug_download_candidates(orbx_extractor *h, int frame, int level, uint32_t *packed, int cap, int *count)
+{
+    if (!h || !count) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!h->lastBatch || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels) { orbx_set_error("frame/level not available"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    const OrbxGeom &g = h->geom;
+    const OrbxLevel &lv = g.lv[level];
+    const int ncell = lv.nCols * lv.nRows;
+    std::vector<int> cc((size_t)ncell);
+    ORBX_HIP_CHECK(hipMemcpy(cc.data(), h->cellCount.p + (size_t)frame * g.cellsPerFrame + lv.cellBase, (size_t)ncell * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> slots((size_t)ncell * lv.cellCap);
+    ORBX_HIP_CHECK(hipMemcpy(slots.data(), h->cellSlots.p + (size_t)frame * g.slotsPerFrame + lv.slotBase, slots.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int c = 0; c < ncell; c++)
+        for (int k = 0; k < cc[(size_t)c]; k++, n++)
+            if (packed && n < cap) packed[n] = slots[(size_t)c * lv.cellCap + k];
+    *count = n;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_debug_download_level_keypoints(orbx_extractor *h, int frame, int level, orbx_keypoint *kps, int cap, int *count)
+{
+    if (!h || !count) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!h->lastBatch || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels) { orbx_set_error("frame/level not available"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    const OrbxGeom &g = h->geom;
+    const OrbxLevel &lv = g.lv[level];
+    int n = 0;
+    ORBX_HIP_CHECK(hipMemcpy(&n, h->lvlCnt.p + (size_t)frame * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<OrbxLevelKp> tmp((size_t)std::max(n, 1));
+    if (n > 0) ORBX_HIP_CHECK(hipMemcpy(tmp.data(), h->lvlKp.p + (size_t)frame * g.kpPerFrame + lv.kpBase, (size_t)n * sizeof(OrbxLevelKp), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && i < cap && kps; i++) {
+        kps[i].x = tmp[(size_t)i].x; kps[i].y = tmp[(size_t)i].y; kps[i].size = (float)lv.patchSize; kps[i].angle = tmp[(size_t)i].angle;
+        kps[i].response = tmp[(size_t)i].score; kps[i].octave = level; kps[i].class_id = -1;
+    }
+    *count = n;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_set_profiling(orbx_extractor *h, int enable)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    h->profiling = enable != 0;
+    h->timingValid = false;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_last_timing(orbx_extractor *h, float *total_ms, float *stage_ms, int *nstages)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!h->timingValid) { orbx_set_error("no timing: enable profiling before the batch call"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    ORBX_HIP_CHECK(hipEventSynchronize(h->ev[ST_COUNT]));
+    float tot = 0.f;
+    for (int s = 0; s < ST_COUNT; s++) {
+        float ms = 0.f;
+        ORBX_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[s], h->ev[s + 1]));
+        if (stage_ms) stage_ms[s] = ms;
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (nstages) *nstages = ST_COUNT;
+    return ORBX_OK;
+}

@@ -1,0 +1,104 @@
+// orbx_internal.h -- shared host/device definitions of liborbx (gfx950 only).
+#ifndef ORBX_INTERNAL_H
+#define ORBX_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbx.h"
+
+#define ORBX_MAX_LEVELS 12
+#define ORBX_EDGE 19          /* EDGE_THRESHOLD, reference src/ORBextractor.cc:93 */
+#define ORBX_BORDER 16        /* EDGE_THRESHOLD-3 = minBorderX/Y, :1067 */
+#define ORBX_HALF_PATCH 15    /* HALF_PATCH_SIZE, :92 */
+#define ORBX_PATCH 31         /* PATCH_SIZE, :91 */
+#define ORBX_CELL_W 30        /* W, :1060 */
+#define ORBX_PT_CAP 32768     /* most FAST candidates per (frame, level) the quadtree accepts */
+
+/* error bits written by kernels into the per-frame status word */
+#define ORBX_DEV_ERR_PTCAP 1   /* more candidates in a level than ORBX_PT_CAP */
+#define ORBX_DEV_ERR_NODECAP 2 /* quadtree node list overflow (internal)      */
+#define ORBX_DEV_ERR_KPCAP 4   /* level keypoint buffer overflow (internal)   */
+
+struct OrbxResizeX { uint16_t sx; int16_t a0, a1; uint16_t pad; };          /* per dst column */
+struct OrbxResizeY { uint16_t y0, y1; int16_t b0, b1; };                      /* per dst row    */
+
+/* Geometry of one pyramid level for the current image size (host-built, device-read). */
+struct OrbxLevel {
+    int w, h, pitch;        /* level size, row pitch in bytes (levels >= 1; level 0 uses the input stride) */
+    int off;                /* byte offset of the level inside a frame's pyramid block (level 0: unused)   */
+    int nCols, nRows, wCell, hCell;
+    int cellBase;           /* first cell of the level inside a frame's cell array        */
+    int slotBase;           /* first u32 of the level inside a frame's candidate slots    */
+    int cellCap;            /* u32 entries per cell slot                                  */
+    int quota;              /* mnFeaturesPerLevel[level]                                  */
+    int nIni;               /* initial quadtree nodes (1..4)                              */
+    int iniX[5];            /* their x bounds                                             */
+    int binOff;             /* offset of this level's x -> initial-node table (u8)        */
+    int kpBase, kpCap;      /* slice of the per-frame level-keypoint array                */
+    int fastTileBase, fastTilesX, fastTilesY;
+    int blurTileBase, blurTilesX, blurTilesY;
+    int rxOff, ryOff;       /* offsets into the resize tables                             */
+    int patchSize;          /* (int)(PATCH_SIZE*scale), src/ORBextractor.cc:1175          */
+    float scale;            /* mvScaleFactor[level]                                       */
+};
+
+struct OrbxGeom {
+    int nlevels, W, H;
+    int iniTh, minTh;
+    int cellsPerFrame, slotsPerFrame, kpPerFrame, outCap;
+    int fastTiles, blurTiles;
+    size_t pyrBytes;        /* bytes of levels 1.. of one frame */
+    uint32_t taps[7];
+    int umax[16];
+    OrbxLevel lv[ORBX_MAX_LEVELS];
+};
+
+/* level-coordinates keypoint produced by the quadtree + orientation stages */
+struct OrbxLevelKp { uint16_t x, y; uint8_t score, pad[3]; float angle; };
+
+void orbx_set_error(const char *fmt, ...);
+#define ORBX_HIP_CHECK(expr)                                                                           \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            orbx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return ORBX_ERR_HIP;                                                                       \
+        }                                                                                              \
+    } while (0)
+
+/* kernel launchers (orbx_kernels.hip) */
+struct OrbxLaunch {
+    hipStream_t stream;
+    const OrbxGeom *geomDev;
+    const OrbxGeom *geom;         /* host copy */
+    int batch;
+    const uint8_t *img0;          /* device: level 0 of frame f at img0 + f*img0FramePitch */
+    int img0Stride;
+    size_t img0FramePitch;
+    uint8_t *pyr, *blur, *score;  /* device: per frame pyrBytes / blurBytes / scoreBytes    */
+    size_t blurBytes;             /* blurred copy of ALL levels (level 0 included)          */
+    const OrbxResizeX *rx;
+    const OrbxResizeY *ry;
+    const uint8_t *binTab;
+    int *cellCount;
+    uint32_t *cellSlots;
+    uint32_t *ptBuf;              /* 2 * ORBX_PT_CAP u32 per (frame, level) */
+    OrbxLevelKp *lvlKp;
+    int *lvlCnt;                  /* nlevels per frame */
+    orbx_keypoint *outKp;
+    uint8_t *outDesc;
+    int *outCnt;
+    int *status;                  /* per frame error bits */
+    int nodeCap;                  /* 512 / 1024 / 2048 */
+};
+
+int orbx_launch_resize(const OrbxLaunch &L, int level);
+int orbx_launch_fast(const OrbxLaunch &L);
+int orbx_launch_cells(const OrbxLaunch &L);
+int orbx_launch_octree(const OrbxLaunch &L);
+int orbx_launch_orient(const OrbxLaunch &L);
+int orbx_launch_blur(const OrbxLaunch &L);
+int orbx_launch_desc(const OrbxLaunch &L);
+
+#endif

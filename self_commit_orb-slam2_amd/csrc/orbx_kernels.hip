@@ -1,0 +1,824 @@
+// orbx_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ORB extractor.
+//
+// One kernel per stage of ORB_SLAM2::ORBextractor::operator() (reference
+// src/ORBextractor.cc:1544-1668); every launch covers the whole batch
+// (blockIdx.y = frame) and, where the stage has no level-to-level dependency, all
+// pyramid levels at once (blockIdx.x -> (level, tile) through OrbxGeom).
+// Integer / byte work bounded by HBM and VALU issue; no MFMA.
+// Compiled with -ffp-contract=off: the few float expressions must round exactly like
+// the un-fused scalar reference.
+#include "orbx_internal.h"
+
+namespace {
+
+__constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+// FAST-16 circle, OpenCV order (reference call sites src/ORBextractor.cc:1126,1135)
+#define FAST_DX(k) ((k) == 0 ? 0 : (k) == 1 ? 1 : (k) == 2 ? 2 : (k) <= 5 ? 3 : (k) == 6 ? 2 : (k) == 7 ? 1 : (k) == 8 ? 0 : (k) == 9 ? -1 : (k) == 10 ? -2 : (k) <= 13 ? -3 : (k) == 14 ? -2 : -1)
+#define FAST_DY(k) ((k) <= 1 ? 3 : (k) == 2 ? 2 : (k) == 3 ? 1 : (k) == 4 ? 0 : (k) == 5 ? -1 : (k) == 6 ? -2 : (k) <= 9 ? -3 : (k) == 10 ? -2 : (k) == 11 ? -1 : (k) == 12 ? 0 : (k) == 13 ? 1 : (k) == 14 ? 2 : 3)
+
+__device__ __forceinline__ const uint8_t *level_ptr(const OrbxGeom *g, int l, int f, const uint8_t *img0, int img0Stride,
+                                                    size_t img0FramePitch, const uint8_t *pyr, int &pitch)
+{
+    if (l == 0) { pitch = img0Stride; return img0 + (size_t)f * img0FramePitch; }
+    pitch = g->lv[l].pitch;
+    return pyr + (size_t)f * g->pyrBytes + g->lv[l].off;
+}
+
+__device__ __forceinline__ int find_level(const int *base, int nlevels, int idx)
+{
+    int l = 0;
+    for (int i = 1; i < nlevels; i++) if (idx >= base[i]) l = i;
+    return l;
+}
+
+// ------------------------------------------------------------------------------------
+// Pyramid: level L = cv::resize(level L-1, INTER_LINEAR) (src/ORBextractor.cc:1696-1701),
+// 11-bit fixed point; the column/row tables are built on the host with the exact
+// float/double arithmetic of OpenCV's resize (orbx_extractor.hip: build_geometry).
+// One thread -> 4 consecutive dst pixels, one u32 store.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, int level, const uint8_t *__restrict__ img0, int img0Stride,
+                                                size_t img0FramePitch, uint8_t *__restrict__ pyr, const OrbxResizeX *__restrict__ rx,
+                                                const OrbxResizeY *__restrict__ ry)
+{
+    const OrbxLevel &lv = g->lv[level];
+    const int f = blockIdx.z, dy = blockIdx.y;
+    const int dx0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (dx0 >= lv.w) return;
+    int sp;
+    const uint8_t *src = level_ptr(g, level - 1, f, img0, img0Stride, img0FramePitch, pyr, sp);
+    uint8_t *dst = pyr + (size_t)f * g->pyrBytes + lv.off + (size_t)dy * lv.pitch;
+    const OrbxResizeY yy = ry[lv.ryOff + dy];
+    const uint8_t *S0 = src + (size_t)yy.y0 * sp, *S1 = src + (size_t)yy.y1 * sp;
+    const int sw = g->lv[level - 1].w;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int dx = dx0 + k;
+        if (dx < lv.w) {
+            const OrbxResizeX xx = rx[lv.rxOff + dx];
+            int sx = xx.sx, sx1 = sx + 1 < sw ? sx + 1 : sx;
+            int r0 = S0[sx] * xx.a0 + S0[sx1] * xx.a1;
+            int r1 = S1[sx] * xx.a0 + S1[sx1] * xx.a1;
+            int v = (((yy.b0 * (r0 >> 4)) >> 16) + ((yy.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+    }
+    *(uint32_t *)(dst + dx0) = out;   // pitch is a multiple of 4 and >= round_up(w,4)
+}
+
+// ------------------------------------------------------------------------------------
+// FAST-9/16 score map (cv::FAST + cornerScore<16>): one byte per pixel of the detectable
+// window [19,w-19) x [19,h-19) of every level: largest t at which the pixel is still a
+// 9-contiguous corner, or 0 when that is < minThFAST.  `corner at t  <=>  score >= t`,
+// so one map serves both the iniThFAST and the minThFAST pass of the reference
+// (src/ORBextractor.cc:1126-1139).  64x16 pixel tile + 3/4 px halo staged in LDS with
+// aligned u32 row loads.
+// ------------------------------------------------------------------------------------
+#define FT_W 64
+#define FT_H 16
+#define FT_LW 72              /* LDS row: 4 px left halo + 64 + 4 right */
+#define FT_LH (FT_H + 6)
+
+__device__ __forceinline__ int fast_score16(const int *d)
+{
+    // window-of-9 min and max over the circular 16-vector d (d = center - circle pixel)
+    int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    int best = -512;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        best = max(best, max(mn9, -mx9));
+    }
+    return best - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_score(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride,
+                                                    size_t img0FramePitch, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score)
+{
+    __shared__ uint32_t tile[FT_LH * (FT_LW / 4)];
+    const int f = blockIdx.y;
+    int bases[ORBX_MAX_LEVELS];
+    const int nl = g->nlevels;
+    for (int i = 0; i < nl; i++) bases[i] = g->lv[i].fastTileBase;
+    const int l = find_level(bases, nl, blockIdx.x);
+    const OrbxLevel &lv = g->lv[l];
+    const int t = blockIdx.x - lv.fastTileBase;
+    const int tx = t % lv.fastTilesX, ty = t / lv.fastTilesX;
+    const int X0 = ORBX_BORDER + tx * FT_W, Y0 = ORBX_BORDER + ty * FT_H;
+    int pitch;
+    const uint8_t *src = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
+    // stage rows Y0-3 .. Y0+FT_H+2, bytes X0-4 .. X0+67 (X0 is a multiple of 4)
+    for (int i = threadIdx.x; i < FT_LH * (FT_LW / 4); i += 256) {
+        int r = i / (FT_LW / 4), c = i % (FT_LW / 4);
+        int y = Y0 - 3 + r, x = X0 - 4 + 4 * c;
+        uint32_t v = 0;
+        if (y < lv.h && x + 3 < pitch) v = *(const uint32_t *)(src + (size_t)y * pitch + x);
+        else if (y < lv.h) { for (int k = 0; k < 4; k++) if (x + k < lv.w) v |= (uint32_t)src[(size_t)y * pitch + x + k] << (8 * k); }
+        tile[i] = v;
+    }
+    __syncthreads();
+    const uint8_t *tb = (const uint8_t *)tile;
+    const int lx = threadIdx.x & 63, ly0 = (threadIdx.x >> 6) * 4;
+    const int x = X0 + lx;
+    uint8_t *dst = score + (size_t)f * g->pyrBytes + lv.off;
+    const int minTh = g->minTh;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int ly = ly0 + r, y = Y0 + ly;
+        if (x >= lv.w - ORBX_EDGE || y >= lv.h - ORBX_EDGE || x < ORBX_EDGE || y < ORBX_EDGE) continue;
+        const uint8_t *c = tb + (ly + 3) * FT_LW + (lx + 4);
+        const int v = c[0];
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) d[k] = v - (int)c[FAST_DY(k) * FT_LW + FAST_DX(k)];
+        int s = fast_score16(d);
+        dst[(size_t)y * lv.pitch + x] = (uint8_t)(s >= minTh ? s : 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Per-cell detection (ComputeKeyPointsOctTree cell loop, src/ORBextractor.cc:1089-1157):
+// strict 3x3 NMS restricted to the cell's detectable area (what cv::FAST sees of the
+// cell sub-image), iniThFAST survivors or - when there are none - minThFAST survivors,
+// emitted in raster order.  One wave per cell; ordered compaction with __ballot/__popcll.
+// ------------------------------------------------------------------------------------
+#define CT_P 64   /* LDS tile pitch; a cell's detectable area is at most 59x59 (+1 ring) */
+
+__global__ __launch_bounds__(64) void k_cell_nms(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ score, int *__restrict__ cellCount,
+                                                 uint32_t *__restrict__ cellSlots)
+{
+    __shared__ uint8_t tile[CT_P * CT_P];
+    const int f = blockIdx.y, lane = threadIdx.x;
+    int bases[ORBX_MAX_LEVELS];
+    const int nl = g->nlevels;
+    for (int i = 0; i < nl; i++) bases[i] = g->lv[i].cellBase;
+    const int l = find_level(bases, nl, blockIdx.x);
+    const OrbxLevel &lv = g->lv[l];
+    const int cell = blockIdx.x - lv.cellBase;
+    const int cj = cell % lv.nCols, ci = cell / lv.nCols;
+    const int maxBX = lv.w - ORBX_BORDER, maxBY = lv.h - ORBX_BORDER;
+    const int iniX = ORBX_BORDER + cj * lv.wCell, iniY = ORBX_BORDER + ci * lv.hCell;
+    int maxX = min(iniX + lv.wCell + 6, maxBX), maxY = min(iniY + lv.hCell + 6, maxBY);
+    int *cnt = cellCount + (size_t)f * g->cellsPerFrame + blockIdx.x;
+    const int x0 = iniX + 3, x1 = maxX - 3, y0 = iniY + 3, y1 = maxY - 3;
+    const int aw = x1 - x0, ah = y1 - y0;
+    if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || aw <= 0 || ah <= 0) {   // skipped / too small cell (:1101, :1112)
+        if (lane == 0) *cnt = 0;
+        return;
+    }
+    const uint8_t *S = score + (size_t)f * g->pyrBytes + lv.off;
+    const int tw = aw + 2, th = ah + 2;
+    for (int i = lane; i < tw * th; i += 64) {
+        int r = i / tw, c = i % tw;
+        int y = y0 - 1 + r, x = x0 - 1 + c;
+        uint8_t v = 0;
+        if (r > 0 && r < th - 1 && c > 0 && c < tw - 1) v = S[(size_t)y * lv.pitch + x];
+        tile[r * CT_P + c] = v;
+    }
+    __syncthreads();
+    const int iniTh = g->iniTh, n = aw * ah;
+    bool anyIni = false;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+        int p = p0 + lane;
+        if (p < n) {
+            int r = p / aw + 1, c = p % aw + 1;
+            const uint8_t *q = tile + r * CT_P + c;
+            int v = q[0];
+            if (v >= iniTh && v > q[-1] && v > q[1] && v > q[-CT_P - 1] && v > q[-CT_P] && v > q[-CT_P + 1] && v > q[CT_P - 1] &&
+                v > q[CT_P] && v > q[CT_P + 1])
+                anyIni = true;
+        }
+    }
+    const int thr = __any(anyIni) ? iniTh : 1;
+    uint32_t *slot = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase + (size_t)cell * lv.cellCap;
+    int base = 0;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+        int p = p0 + lane;
+        bool keep = false;
+        uint32_t packed = 0;
+        if (p < n) {
+            int r = p / aw, c = p % aw;
+            const uint8_t *q = tile + (r + 1) * CT_P + c + 1;
+            int v = q[0];
+            keep = v >= thr && v > q[-1] && v > q[1] && v > q[-CT_P - 1] && v > q[-CT_P] && v > q[-CT_P + 1] && v > q[CT_P - 1] &&
+                   v > q[CT_P] && v > q[CT_P + 1];
+            packed = (uint32_t)(x0 + c - ORBX_BORDER) | ((uint32_t)(y0 + r - ORBX_BORDER) << 12) | ((uint32_t)v << 24);
+        }
+        unsigned long long m = __ballot(keep);
+        if (keep) {
+            int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (idx < lv.cellCap) slot[idx] = packed;
+        }
+        base += __popcll(m);
+    }
+    if (lane == 0) *cnt = min(base, lv.cellCap);
+}
+
+// ------------------------------------------------------------------------------------
+// Quadtree distribution (DistributeOctTree + DivideNode, src/ORBextractor.cc:635-703,
+// 706-1049).  One workgroup per (frame, level).  The std::list of the reference is an
+// array in LDS; a split step partitions every selected node's point span (kept in two
+// global ping-pong buffers that stay L2 resident) into its 4 children with a stable,
+// fully parallel counting partition: 64-point chunks ("items") are counted with
+// __ballot, chunk counts are prefix-scanned across the workgroup, and points are
+// scattered to parent.start + quadrant offset + rank.  List order, creation order and
+// the "later-created first" tie rule of the careful rounds follow DESIGN.md section 5 /
+// oracle/orb_oracle.cc octree().
+// ------------------------------------------------------------------------------------
+struct OtNode { short x0, y0, x1, y1; int start; int cnt; };   // start bit31 = point buffer id
+
+template <typename T> __device__ __forceinline__ T wave_incl_scan(T v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        T u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// exclusive scan of arr[0..n) in place (LDS), n <= 8*256; returns the total.  All 256 threads call.
+template <typename T> __device__ T block_exscan(T *arr, int n, T *wsum /* >= 5 entries */)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (n + 255) >> 8;
+    const int b = tid * per;
+    T s = 0;
+    for (int k = 0; k < per; k++) if (b + k < n) s += arr[b + k];
+    T inc = wave_incl_scan(s, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    T off = 0;
+    for (int i = 0; i < w; i++) off += wsum[i];
+    T total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    T run = off + inc - s;
+    for (int k = 0; k < per; k++)
+        if (b + k < n) { T v = arr[b + k]; arr[b + k] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ int popc_fields(unsigned long long t)
+{
+    return ((t & 0xffffull) != 0) + (((t >> 16) & 0xffffull) != 0) + (((t >> 32) & 0xffffull) != 0) + ((t >> 48) != 0);
+}
+
+template <int NODECAP>
+__global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, const int *__restrict__ cellCount, const uint32_t *__restrict__ cellSlots,
+                                                const uint8_t *__restrict__ binTab, uint32_t *__restrict__ ptBuf, OrbxLevelKp *__restrict__ lvlKp,
+                                                int *__restrict__ lvlCnt, int *__restrict__ status)
+{
+    constexpr int ITEMCAP = NODECAP + ORBX_PT_CAP / 64;
+    __shared__ OtNode nodes[2][NODECAP];
+    __shared__ unsigned long long itemScan[ITEMCAP + 1];   // packed 4x16 quadrant counts per 64-point chunk
+    __shared__ unsigned short itemCand[ITEMCAP];            // owning candidate of each chunk
+    __shared__ unsigned short candNode[NODECAP];            // candidate r -> node index (list order)
+    __shared__ int candItemBase[NODECAP + 1];
+    __shared__ unsigned long long candTot[NODECAP];
+    __shared__ unsigned short byProc[NODECAP];              // processing rank -> candidate
+    __shared__ int procC[NODECAP];                          // children per candidate in processing order (scan)
+    __shared__ int nodeFlag[NODECAP];                       // scans over the node list
+    __shared__ short nodeCandId[NODECAP];
+    __shared__ unsigned long long wsum64[8];
+    __shared__ int wsum32[8];
+    __shared__ int sh_misc[8];
+    __shared__ unsigned char childCnt[NODECAP];
+    __shared__ unsigned char selFlag[NODECAP];   // per candidate (list-order index r)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = blockIdx.x, f = blockIdx.y;
+    const OrbxLevel &lv = g->lv[l];
+    const int N = lv.quota;
+    uint32_t *P[2];
+    P[0] = ptBuf + ((size_t)f * g->nlevels + l) * 2 * ORBX_PT_CAP;
+    P[1] = P[0] + ORBX_PT_CAP;
+    int *stat = status + f;
+
+    // ---- gather the level's candidates in vToDistributeKeys order (cells row-major) ----
+    const int ncell = lv.nCols * lv.nRows;
+    const int *cc = cellCount + (size_t)f * g->cellsPerFrame + lv.cellBase;
+    int *cellOff = (int *)itemScan;   // reuse (ncell <= 2*ITEMCAP ints)
+    for (int i = tid; i < ncell; i += 256) cellOff[i] = cc[i];
+    __syncthreads();
+    int M = block_exscan(cellOff, ncell, wsum32);
+    if (M > ORBX_PT_CAP) { if (tid == 0) atomicOr(stat, ORBX_DEV_ERR_PTCAP); M = ORBX_PT_CAP; }
+    {
+        const uint32_t *slots = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase;
+        // one wave per cell keeps the copy coalesced
+        for (int c = wave; c < ncell; c += 4) {
+            int n = cc[c], o = cellOff[c];
+            for (int k = lane; k < n; k += 64)
+                if (o + k < ORBX_PT_CAP) P[0][o + k] = slots[(size_t)c * lv.cellCap + k];
+        }
+    }
+    __syncthreads();
+    if (M == 0) { if (tid == 0) lvlCnt[f * g->nlevels + l] = 0; return; }
+
+    // ---- initial nodes (src/ORBextractor.cc:719-788): split a virtual root by x -> node table ----
+    int cur = 0, nn = 0;
+    {
+        const uint8_t *bin = binTab + lv.binOff;
+        const int nItems = (M + 63) >> 6;
+        for (int it = wave; it < nItems; it += 4) {
+            int j = it * 64 + lane;
+            int q = -1;
+            if (j < M) q = bin[P[0][j] & 0xfff];
+            unsigned long long t = 0;
+            for (int Q = 0; Q < 4; Q++) t |= (unsigned long long)__popcll(__ballot(q == Q)) << (16 * Q);
+            if (lane == 0) itemScan[it] = t;
+        }
+        __syncthreads();
+        unsigned long long tot = block_exscan(itemScan, nItems, wsum64);
+        int off[4], acc = 0, cnts[4];
+        for (int Q = 0; Q < 4; Q++) { cnts[Q] = (int)((tot >> (16 * Q)) & 0xffff); off[Q] = acc; acc += cnts[Q]; }
+        for (int it = wave; it < nItems; it += 4) {
+            int j = it * 64 + lane;
+            int q = -1;
+            uint32_t p = 0;
+            if (j < M) { p = P[0][j]; q = bin[p & 0xfff]; }
+            unsigned long long base = itemScan[it];
+            for (int Q = 0; Q < 4; Q++) {
+                unsigned long long m = __ballot(q == Q);
+                if (q == Q) P[1][off[Q] + (int)((base >> (16 * Q)) & 0xffff) + __popcll(m & ((1ull << lane) - 1ull))] = p;
+            }
+        }
+        if (tid == 0) {
+            int k = 0;
+            for (int Q = 0; Q < lv.nIni; Q++)
+                if (cnts[Q] > 0) {
+                    OtNode nd;
+                    nd.x0 = (short)lv.iniX[Q]; nd.x1 = (short)lv.iniX[Q + 1]; nd.y0 = 0; nd.y1 = (short)(lv.h - 2 * ORBX_BORDER);
+                    nd.start = off[Q] | (int)0x80000000; nd.cnt = cnts[Q];
+                    nodes[0][k++] = nd;
+                }
+            sh_misc[0] = k;
+        }
+        __syncthreads();
+        nn = sh_misc[0];
+    }
+
+    // ---- main loop ----
+    bool finish = false, careful = false;
+    while (!finish) {
+        const int prev = nn;
+        OtNode *L = nodes[cur], *Ln = nodes[cur ^ 1];
+        // S1: candidates = nodes with more than one point, in list order
+        for (int i = tid; i < nn; i += 256) nodeFlag[i] = L[i].cnt > 1 ? 1 : 0;
+        __syncthreads();
+        const int ncand = block_exscan(nodeFlag, nn, wsum32);
+        if (ncand == 0) break;   // size unchanged -> bFinish (:907-913)
+        for (int i = tid; i < nn; i += 256) {
+            bool isc = L[i].cnt > 1;
+            nodeCandId[i] = isc ? (short)nodeFlag[i] : (short)-1;
+            if (isc) { candNode[nodeFlag[i]] = (unsigned short)i; candItemBase[nodeFlag[i]] = (L[i].cnt + 63) >> 6; }
+        }
+        __syncthreads();
+        const int nItems = block_exscan(candItemBase, ncand, wsum32);
+        if (tid == 0) candItemBase[ncand] = nItems;
+        __syncthreads();
+        // S2: chunk -> candidate (binary search over candItemBase)
+        for (int it = tid; it < nItems; it += 256) {
+            int lo = 0, hi = ncand - 1;
+            while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (candItemBase[mid] <= it) lo = mid; else hi = mid - 1; }
+            itemCand[it] = (unsigned short)lo;
+        }
+        __syncthreads();
+        // S3: quadrant counts per chunk
+        for (int it = wave; it < nItems; it += 4) {
+            const int r = itemCand[it];
+            const OtNode nd = L[candNode[r]];
+            const int k = it - candItemBase[r];
+            const int j = k * 64 + lane;
+            const uint32_t *src = P[(unsigned)nd.start >> 31] + (nd.start & 0x7fffffff);
+            const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+            int q = -1;
+            if (j < nd.cnt) { uint32_t p = src[j]; int x = p & 0xfff, y = (p >> 12) & 0xfff; q = (x < mx ? 0 : 1) + (y < my ? 0 : 2); }
+            unsigned long long t = 0;
+            for (int Q = 0; Q < 4; Q++) t |= (unsigned long long)__popcll(__ballot(q == Q)) << (16 * Q);
+            if (lane == 0) itemScan[it] = t;
+        }
+        if (tid == 0) itemScan[nItems] = 0;   // becomes the grand total after the exclusive scan
+        __syncthreads();
+        // S4: scan chunk counts; S5: per-candidate quadrant totals
+        block_exscan(itemScan, nItems + 1, wsum64);
+        for (int r = tid; r < ncand; r += 256) candTot[r] = itemScan[candItemBase[r + 1]] - itemScan[candItemBase[r]];
+        __syncthreads();
+        // S6: processing order.  Full pass: list order.  Careful round: (count desc, list position asc).
+        if (!careful) {
+            for (int r = tid; r < ncand; r += 256) byProc[r] = (unsigned short)r;
+        } else {
+            for (int r = tid; r < ncand; r += 256) {
+                const int c = L[candNode[r]].cnt;
+                int rank = 0;
+                for (int s = 0; s < ncand; s++) {
+                    const int cs = L[candNode[s]].cnt;
+                    rank += (cs > c) || (cs == c && s < r);
+                }
+                byProc[rank] = (unsigned short)r;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < ncand; k += 256) procC[k] = popc_fields(candTot[byProc[k]]);
+        __syncthreads();
+        // number of candidates actually split: all (full pass) or up to the first one that
+        // brings the list to >= N nodes (careful round, :1003)
+        int nsel = ncand;
+        if (careful) {
+            if (tid == 0) sh_misc[1] = ncand;
+            __syncthreads();
+            // inclusive growth: size + sum_{i<=k}(c_i - 1) >= N  -> smallest such k
+            int *grow = nodeFlag;   // reuse as scratch (nn >= ncand)
+            for (int k = tid; k < ncand; k += 256) grow[k] = procC[k] - 1;
+            __syncthreads();
+            block_exscan(grow, ncand, wsum32);
+            for (int k = tid; k < ncand; k += 256)
+                if (nn + grow[k] + procC[k] - 1 >= N) atomicMin(&sh_misc[1], k + 1);
+            __syncthreads();
+            nsel = sh_misc[1];
+            __syncthreads();
+        }
+        // creation index of each selected candidate's first child
+        for (int k = tid; k < ncand; k += 256) if (k >= nsel) procC[k] = 0;
+        __syncthreads();
+        // keep per-candidate child count before the scan destroys it
+        for (int k = tid; k < ncand; k += 256) childCnt[k] = (unsigned char)procC[k];
+        __syncthreads();
+        const int totalCreated = block_exscan(procC, ncand, wsum32);
+        // unselected nodes keep their relative order behind the created ones
+        for (int r = tid; r < ncand; r += 256) selFlag[r] = 0;
+        __syncthreads();
+        for (int k = tid; k < nsel; k += 256) selFlag[byProc[k]] = 1;
+        __syncthreads();
+        for (int i = tid; i < nn; i += 256) {
+            int r = nodeCandId[i];
+            nodeFlag[i] = (r >= 0 && selFlag[r]) ? 0 : 1;
+        }
+        __syncthreads();
+        const int nUnsel = block_exscan(nodeFlag, nn, wsum32);
+        const int newN = totalCreated + nUnsel;
+        if (newN > NODECAP) { if (tid == 0) atomicOr(stat, ORBX_DEV_ERR_NODECAP); break; }
+        if (tid == 0) sh_misc[2] = 0;
+        __syncthreads();
+        // S7: write the new list
+        for (int i = tid; i < nn; i += 256) {
+            int r = nodeCandId[i];
+            if (r >= 0 && selFlag[r]) continue;
+            Ln[totalCreated + nodeFlag[i]] = L[i];
+        }
+        int myExpand = 0;
+        for (int k = tid; k < nsel; k += 256) {
+            const int r = byProc[k];
+            const OtNode nd = L[candNode[r]];
+            const unsigned long long t = candTot[r];
+            const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+            const int buf = ((unsigned)nd.start >> 31) ^ 1;
+            int st = nd.start & 0x7fffffff, ci = procC[k];
+            for (int Q = 0; Q < 4; Q++) {
+                int c = (int)((t >> (16 * Q)) & 0xffff);
+                if (c > 0) {
+                    OtNode ch;
+                    ch.x0 = (Q & 1) ? (short)mx : nd.x0; ch.x1 = (Q & 1) ? nd.x1 : (short)mx;
+                    ch.y0 = (Q & 2) ? (short)my : nd.y0; ch.y1 = (Q & 2) ? nd.y1 : (short)my;
+                    ch.start = st | (buf << 31); ch.cnt = c;
+                    Ln[totalCreated - 1 - ci] = ch;   // push_front: later children sit further front
+                    ci++;
+                    if (c > 1) myExpand++;
+                }
+                st += c;
+            }
+        }
+        if (myExpand) atomicAdd(&sh_misc[2], myExpand);
+        // S8: scatter the points of the selected candidates into their children
+        for (int it = wave; it < nItems; it += 4) {
+            const int r = itemCand[it];
+            if (!selFlag[r]) continue;
+            const OtNode nd = L[candNode[r]];
+            const int k = it - candItemBase[r];
+            const int j = k * 64 + lane;
+            const int sb = (unsigned)nd.start >> 31, so = nd.start & 0x7fffffff;
+            const uint32_t *src = P[sb] + so;
+            uint32_t *dst = P[sb ^ 1] + so;
+            const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+            int q = -1;
+            uint32_t p = 0;
+            if (j < nd.cnt) { p = src[j]; int x = p & 0xfff, y = (p >> 12) & 0xfff; q = (x < mx ? 0 : 1) + (y < my ? 0 : 2); }
+            const unsigned long long rel = itemScan[it] - itemScan[candItemBase[r]];
+            const unsigned long long t = candTot[r];
+            int qoff = 0;
+            for (int Q = 0; Q < 4; Q++) {
+                unsigned long long m = __ballot(q == Q);
+                if (q == Q) dst[qoff + (int)((rel >> (16 * Q)) & 0xffff) + __popcll(m & ((1ull << lane) - 1ull))] = p;
+                qoff += (int)((t >> (16 * Q)) & 0xffff);
+            }
+        }
+        __syncthreads();
+        const int nToExpand = sh_misc[2];
+        nn = newN;
+        cur ^= 1;
+        if (nn >= N || nn == prev) finish = true;                       // :907-913, :1007
+        else if (!careful && nn + nToExpand * 3 > N) careful = true;    // :931
+        __syncthreads();
+    }
+
+    // ---- best response per node, first maximum wins (:1018-1048) ----
+    {
+        const OtNode *L = nodes[cur];
+        OrbxLevelKp *out = lvlKp + (size_t)f * g->kpPerFrame + lv.kpBase;
+        if (nn > lv.kpCap) { if (tid == 0) atomicOr(stat, ORBX_DEV_ERR_KPCAP); nn = lv.kpCap; }
+        for (int i = tid; i < nn; i += 256) {
+            const OtNode nd = L[i];
+            const uint32_t *src = P[(unsigned)nd.start >> 31] + (nd.start & 0x7fffffff);
+            uint32_t best = src[0];
+            for (int k = 1; k < nd.cnt; k++) { uint32_t p = src[k]; if ((p >> 24) > (best >> 24)) best = p; }
+            OrbxLevelKp kp;
+            kp.x = (uint16_t)((best & 0xfff) + ORBX_BORDER); kp.y = (uint16_t)(((best >> 12) & 0xfff) + ORBX_BORDER);
+            kp.score = (uint8_t)(best >> 24); kp.pad[0] = kp.pad[1] = kp.pad[2] = 0; kp.angle = 0.f;
+            out[i] = kp;
+        }
+        if (tid == 0) lvlCnt[f * g->nlevels + l] = nn;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Orientation: IC_Angle (src/ORBextractor.cc:108-161) = integer moments over the
+// 749-pixel disc of radius 15 on the UNBLURRED level, then cv::fastAtan2.  One wave per
+// keypoint, lanes stride the disc rows; integer sums are exact in any order.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale,
+                p7 = -0.04432655554792128f * scale;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_orient(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                                const uint8_t *__restrict__ pyr, OrbxLevelKp *__restrict__ lvlKp, const int *__restrict__ lvlCnt)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);   // index into the frame's level-keypoint array
+    if (slot >= g->kpPerFrame) return;
+    int l = 0;
+    for (int i = 1; i < g->nlevels; i++) if (slot >= g->lv[i].kpBase) l = i;
+    const OrbxLevel &lv = g->lv[l];
+    const int i = slot - lv.kpBase;
+    if (i >= lvlCnt[f * g->nlevels + l]) return;
+    OrbxLevelKp *kp = lvlKp + (size_t)f * g->kpPerFrame + slot;
+    int pitch;
+    const uint8_t *img = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
+    const uint8_t *center = img + (size_t)kp->y * pitch + kp->x;
+    int m10 = 0, m01 = 0;
+    // 31 rows x 31 columns box, masked by the disc half-widths umax[|v|]; lane -> (row, 2 column phases)
+    for (int idx = lane; idx < 31 * 31; idx += 64) {
+        int v = idx / 31 - 15, u = idx % 31 - 15;
+        int av = v < 0 ? -v : v;
+        if ((u < 0 ? -u : u) <= g->umax[av]) {
+            int I = center[v * pitch + u];
+            m10 += u * I;
+            m01 += v * I;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    if (lane == 0) kp->angle = fast_atan2_deg((float)m01, (float)m10);
+}
+
+// ------------------------------------------------------------------------------------
+// 7x7 Gaussian, sigma 2, BORDER_REFLECT_101, u8 fixed point (cv::GaussianBlur on the
+// cloned level, src/ORBextractor.cc:1626-1634): horizontal pass exact in 16 bits,
+// vertical in 32, (sum + 2^15) >> 16.  64x16 output tile, rows staged through LDS.
+// ------------------------------------------------------------------------------------
+#define BT_W 64
+#define BT_H 16
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * len - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                              const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur)
+{
+    __shared__ uint8_t in[(BT_H + 6) * (BT_W + 8)];
+    __shared__ uint32_t hz[(BT_H + 6) * BT_W];
+    const int f = blockIdx.y;
+    int bases[ORBX_MAX_LEVELS];
+    const int nl = g->nlevels;
+    for (int i = 0; i < nl; i++) bases[i] = g->lv[i].blurTileBase;
+    const int l = find_level(bases, nl, blockIdx.x);
+    const OrbxLevel &lv = g->lv[l];
+    const int t = blockIdx.x - lv.blurTileBase;
+    const int X0 = (t % lv.blurTilesX) * BT_W, Y0 = (t / lv.blurTilesX) * BT_H;
+    int pitch;
+    const uint8_t *src = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
+    for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
+        int r = i / (BT_W + 6), c = i % (BT_W + 6);
+        int y = reflect101(Y0 - 3 + r, lv.h), x = reflect101(X0 - 3 + c, lv.w);
+        // tiles past the right/bottom edge of the image still need in-range reads
+        y = min(max(y, 0), lv.h - 1); x = min(max(x, 0), lv.w - 1);
+        in[r * (BT_W + 8) + c] = src[(size_t)y * pitch + x];
+    }
+    __syncthreads();
+    const uint32_t k0 = g->taps[0], k1 = g->taps[1], k2 = g->taps[2], k3 = g->taps[3], k4 = g->taps[4], k5 = g->taps[5], k6 = g->taps[6];
+    for (int i = threadIdx.x; i < (BT_H + 6) * BT_W; i += 256) {
+        int r = i / BT_W, c = i % BT_W;
+        const uint8_t *p = in + r * (BT_W + 8) + c;
+        uint32_t s = k0 * p[0] + k1 * p[1] + k2 * p[2] + k3 * p[3] + k4 * p[4] + k5 * p[5] + k6 * p[6];
+        hz[i] = s > 65535u ? 65535u : s;
+    }
+    __syncthreads();
+    uint8_t *dst = blur + (size_t)f * g->pyrBytes + lv.off;
+    for (int i = threadIdx.x; i < BT_H * BT_W; i += 256) {
+        int r = i / BT_W, c = i % BT_W;
+        int x = X0 + c, y = Y0 + r;
+        if (x >= lv.w || y >= lv.h) continue;
+        const uint32_t *p = hz + r * BT_W + c;
+        uint32_t s = k0 * p[0] + k1 * p[BT_W] + k2 * p[2 * BT_W] + k3 * p[3 * BT_W] + k4 * p[4 * BT_W] + k5 * p[5 * BT_W] + k6 * p[6 * BT_W];
+        s = (s + 32768u) >> 16;
+        dst[(size_t)y * lv.pitch + x] = (uint8_t)(s > 255u ? 255u : s);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// rBRIEF-256 (computeOrbDescriptor, src/ORBextractor.cc:173-227) + final KeyPoint
+// (:1175-1190, :1651-1660).  One wave per keypoint: in round r lane l evaluates test pair
+// 64r+l; the 64-bit __ballot of (t0 < t1) IS descriptor bytes 8r..8r+7 in the
+// reference's bit order (bit k of byte i = pair 8i+k).  sin/cos: glibc's sinf/cosf
+// algorithm in double, restated so the device rounds like the libm the reference calls
+// (oracle/prims.h op_sincosf, tests/test_sincos.py).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float sinf_poly_d(double x, double x2, int n, bool neg)
+{
+    // coefficients of glibc 2.35 __sincosf_table[0]; table[1] is its negation (neg)
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        double x3 = x * x2, t1 = s2 + x2 * s3, x7 = x3 * x2, s = x + x3 * s1;
+        return (float)(s + x7 * t1);
+    } else {
+        double k0 = neg ? -c0 : c0, k1 = neg ? -c1 : c1, k2 = neg ? -c2 : c2, k3 = neg ? -c3 : c3, k4 = neg ? -c4 : c4;
+        double x4 = x2 * x2, u2 = k3 + x2 * k4, u1 = k0 + x2 * k1, x6 = x4 * x2, c = u1 + x4 * k2;
+        return (float)(c + x6 * u2);
+    }
+}
+
+__device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs)
+{
+    double x = y;
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
+    if (top < ((0x3f490fdbu >> 20) & 0x7ff)) {   // |y| < pi/4 (abstop12 compare)
+        double x2 = x * x;
+        if (top < ((0x39800000u >> 20) & 0x7ff)) { sn = y; cs = 1.0f; return; }   // |y| < 2^-12
+        sn = sinf_poly_d(x, x2, 0, false);
+        cs = sinf_poly_d(x, x2, 1, false);
+        return;
+    }
+    double r = x * 0x1.45F306DC9C883p+23;
+    int n = ((int)r + 0x800000) >> 24;
+    x = x - n * 0x1.921FB54442D18p0;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    const bool neg = (n & 2) != 0;
+    sn = sinf_poly_d(x * sgn, x * x, n, neg);
+    cs = sinf_poly_d(x * sgn, x * x, n ^ 1, neg);
+}
+
+__global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ blur, const OrbxLevelKp *__restrict__ lvlKp,
+                                                  const int *__restrict__ lvlCnt, orbx_keypoint *__restrict__ outKp, uint8_t *__restrict__ outDesc,
+                                                  int *__restrict__ outCnt)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int *cnts = lvlCnt + f * g->nlevels;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int tot = 0;
+        for (int i = 0; i < g->nlevels; i++) tot += cnts[i];
+        outCnt[f] = tot;
+    }
+    if (slot >= g->kpPerFrame) return;
+    int l = 0;
+    for (int i = 1; i < g->nlevels; i++) if (slot >= g->lv[i].kpBase) l = i;
+    const OrbxLevel &lv = g->lv[l];
+    const int i = slot - lv.kpBase;
+    if (i >= cnts[l]) return;
+    int outIdx = i;
+    for (int k = 0; k < l; k++) outIdx += cnts[k];
+    if (outIdx >= g->outCap) return;
+    const OrbxLevelKp kp = lvlKp[(size_t)f * g->kpPerFrame + slot];
+    const uint8_t *img = blur + (size_t)f * g->pyrBytes + lv.off;
+    const int pitch = lv.pitch;
+    const uint8_t *center = img + (size_t)kp.y * pitch + kp.x;
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    sincosf_glibc(kp.angle * factorPI, b, a);
+    unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * g->outCap + outIdx) * 32);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int8_t *p = c_pattern + 4 * (64 * r + lane);
+        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+        const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
+        const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
+        const int t0 = center[r0 * pitch + c0], t1 = center[r1 * pitch + c1];
+        const unsigned long long m = __ballot(t0 < t1);
+        if (lane == 0) d64[r] = m;
+    }
+    if (lane == 0) {
+        orbx_keypoint o;
+        o.x = l ? (float)kp.x * lv.scale : (float)kp.x;
+        o.y = l ? (float)kp.y * lv.scale : (float)kp.y;
+        o.size = (float)lv.patchSize; o.angle = kp.angle; o.response = (float)kp.score; o.octave = l; o.class_id = -1;
+        outKp[(size_t)f * g->outCap + outIdx] = o;
+    }
+}
+
+}  // namespace
+
+#define LAUNCH_CHECK()                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) { orbx_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); return ORBX_ERR_HIP; } \
+    } while (0)
+
+int orbx_launch_resize(const OrbxLaunch &L, int level)
+{
+    const OrbxLevel &lv = L.geom->lv[level];
+    dim3 grid((unsigned)((lv.w + 1023) / 1024), (unsigned)lv.h, (unsigned)L.batch);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, L.stream, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rx, L.ry);
+    LAUNCH_CHECK();
+    return ORBX_OK;
+}
+
+int orbx_launch_fast(const OrbxLaunch &L)
+{
+    dim3 grid((unsigned)L.geom->fastTiles, (unsigned)L.batch);
+    hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score);
+    LAUNCH_CHECK();
+    return ORBX_OK;
+}
+
+int orbx_launch_cells(const OrbxLaunch &L)
+{
+    dim3 grid((unsigned)L.geom->cellsPerFrame, (unsigned)L.batch);
+    hipLaunchKernelGGL(k_cell_nms, grid, dim3(64), 0, L.stream, L.geomDev, L.score, L.cellCount, L.cellSlots);
+    LAUNCH_CHECK();
+    return ORBX_OK;
+}
+
+int orbx_launch_octree(const OrbxLaunch &L)
+{
+    dim3 grid((unsigned)L.geom->nlevels, (unsigned)L.batch);
+    if (L.nodeCap <= 512)
+        hipLaunchKernelGGL(k_octree<512>, grid, dim3(256), 0, L.stream, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.lvlKp, L.lvlCnt, L.status);
+    else if (L.nodeCap <= 1024)
+        hipLaunchKernelGGL(k_octree<1024>, grid, dim3(256), 0, L.stream, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.lvlKp, L.lvlCnt, L.status);
+    else
+        hipLaunchKernelGGL(k_octree<2048>, grid, dim3(256), 0, L.stream, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.lvlKp, L.lvlCnt, L.status);
+    LAUNCH_CHECK();
+    return ORBX_OK;
+}
+
+int orbx_launch_orient(const OrbxLaunch &L)
+{
+    dim3 grid((unsigned)((L.geom->kpPerFrame + 3) / 4), (unsigned)L.batch);
+    hipLaunchKernelGGL(k_orient, grid, dim3(256), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.lvlKp, L.lvlCnt);
+    LAUNCH_CHECK();
+    return ORBX_OK;
+}
+
+int orbx_launch_blur(const OrbxLaunch &L)
+{
+    dim3 grid((unsigned)L.geom->blurTiles, (unsigned)L.batch);
+    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur);
+    LAUNCH_CHECK();
+    return ORBX_OK;
+}
+
+int orbx_launch_desc(const OrbxLaunch &L)
+{
+    dim3 grid((unsigned)((L.geom->kpPerFrame + 3) / 4), (unsigned)L.batch);
+    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, L.stream, L.geomDev, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc, L.outCnt);
+    LAUNCH_CHECK();
+    return ORBX_OK;
+}

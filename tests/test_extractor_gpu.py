@@ -1,0 +1,98 @@
+"""GPU parity of the HIP extractor against the CPU oracle, stage by stage and end to end.
+
+Bit-exact everywhere: pyramid bytes, FAST score bytes, candidate lists (order included),
+quadtree selection and order, angles as float bit patterns, blurred bytes, descriptors,
+final cv::KeyPoint fields.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    # (W, H, nfeatures) - TUM1.yaml, KITTI00-02.yaml, EuRoC.yaml of the reference
+    (640, 480, 1000),
+    (1241, 376, 2000),
+    (752, 480, 1200),
+]
+
+
+def kp_matrix(k):
+    return np.stack([k["x"], k["y"], k["size"], k["angle"], k["response"], k["octave"].astype(np.float32),
+                     k["class_id"].astype(np.float32)], 1)
+
+
+@pytest.mark.parametrize("W,H,nf", CONFIGS)
+def test_stages_bit_exact(orbx, oracle, W, H, nf):
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2)
+    rst = oracle.restatement(nf)
+    t, q, u = rst.tables()
+    assert (ext.GetScaleFactors().view(np.uint32) == t[0].view(np.uint32)).all()
+    assert (ext.GetInverseScaleFactors().view(np.uint32) == t[1].view(np.uint32)).all()
+    assert (ext.GetScaleSigmaSquares().view(np.uint32) == t[2].view(np.uint32)).all()
+    assert (ext.GetInverseScaleSigmaSquares().view(np.uint32) == t[3].view(np.uint32)).all()
+    assert (ext.features_per_level() == q).all()
+    frames = [orbx.synth_frame(11, W, H), orbx.synth_frame(12, W, H, orbx.SYNTH_LOW_TEXTURE)]
+    kps, desc, counts = ext.extract_batch(frames)
+    for f, im in enumerate(frames):
+        pyr = oracle.pyramid(rst, im)
+        for l in range(8):
+            lv = ext.mvImagePyramid(l, frame=f)
+            assert lv.shape == pyr[l].shape
+            assert (lv == pyr[l]).all(), "pyramid level %d" % l
+            S = oracle.score_map(pyr[l], 7)
+            Sd = ext.debug_scores(l, frame=f)
+            h, w = S.shape
+            assert (Sd[19:h - 19, 19:w - 19] == S[19:h - 19, 19:w - 19]).all(), "score map level %d" % l
+            cand = oracle.cell_candidates(S, 20)
+            cd, n = ext.debug_candidates(l, frame=f)
+            assert n == len(cand) and (cd == cand).all(), "candidates level %d" % l
+            sel = oracle.octree(cand, w, h, int(q[l]))
+            lk = ext.debug_level_keypoints(l, frame=f)
+            assert len(lk) == len(sel), "octree count level %d: %d vs %d" % (l, len(lk), len(sel))
+            packed = ((lk["x"].astype(np.uint32) - 16) | ((lk["y"].astype(np.uint32) - 16) << 12) |
+                      (lk["response"].astype(np.uint32) << 24))
+            assert (packed == sel).all(), "octree selection/order level %d" % l
+            ang = np.array([oracle.ic_angle(rst, pyr[l], x, y) for x, y in zip(lk["x"], lk["y"])], np.float32)
+            assert (ang.view(np.uint32) == lk["angle"].view(np.uint32)).all(), "angles level %d" % l
+            if len(lk):
+                B = oracle.blur(pyr[l])
+                Bd = ext.mvImagePyramid(l, frame=f, blurred=True)
+                assert (B == Bd).all(), "blur level %d" % l
+        ko, do = rst.extract(im)
+        n = int(counts[f])
+        assert n == len(ko)
+        assert (kp_matrix(kps[f, :n]).view(np.uint32) == ko.view(np.uint32)).all(), "final keypoints"
+        assert (desc[f, :n] == do).all(), "descriptors"
+    ext.close()
+
+
+def test_vs_compiled_reference(orbx, oracle):
+    """End to end against oracle/_ref (the unmodified reference source), when it was built."""
+    ref = oracle.reference(1000)
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    ext = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=8)
+    frames = [orbx.synth_frame(100 + i, 640, 480, orbx.SYNTH_LOW_TEXTURE if i % 4 == 3 else 0) for i in range(8)]
+    kps, desc, counts = ext.extract_batch(frames)
+    for f, im in enumerate(frames):
+        ko, do = ref.extract(im)
+        n = int(counts[f])
+        assert n == len(ko)
+        assert (kp_matrix(kps[f, :n]).view(np.uint32) == ko.view(np.uint32)).all()
+        assert (desc[f, :n] == do).all()
+    ext.close()
+
+
+def test_single_image_and_empty(orbx, oracle):
+    ext = orbx.ORBextractor(500, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    k, d = ext(None)
+    assert len(k) == 0 and d.shape == (0, 32)
+    im = orbx.synth_frame(5, 640, 480)
+    k, d = ext(im)
+    ko, do = oracle.restatement(500).extract(im)
+    assert len(k) == len(ko) and (d == do).all()
+    # a flat image yields no keypoints (reference: descriptors.release())
+    k, d = ext(np.full((480, 640), 90, np.uint8))
+    assert len(k) == 0
+    ext.close()
