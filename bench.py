@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of ORB extract + match on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic frames that are already
+resident in HBM: ORBextractor::operator() on every frame of the batch (8-level pyramid,
+FAST, quadtree, IC angle, blur, rBRIEF) followed by the brute-force Hamming
+ORBmatcher::SearchByBoW of every frame against its predecessor in the batch (one
+vocabulary node = all features, i.e. N1 x N2 256-bit distances + ratio test + rotation
+histogram).  Workload = BASELINE.json configs[1]: 256 synthetic 640x480 frames, 1000
+features, 8 levels (TUM1.yaml parameters of the reference).
+
+Multi-GPU: one process per GPU (torchrun), each rank owns its own batch (independent
+frames, no data-path collective), weak scaling; RCCL is used only for the barrier, the MAX
+of the per-rank times and the all-gather of per-rank statistics.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects.  The oracle (oracle/) is only used for the cpu_baseline leg.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def level_pixels(W, H, nlevels=8, scale=1.2):
+    px = []
+    s = np.float32(1.0)
+    for l in range(nlevels):
+        inv = np.float32(1.0) / s
+        px.append(int(np.rint(np.float32(W) * inv)) * int(np.rint(np.float32(H) * inv)))
+        s = np.float32(s * np.float64(np.float32(scale)))
+    return px
+
+
+def algorithmic_bytes(W, H, K, nlevels=8):
+    """stage-wise minimum traffic per frame (bytes), per stage."""
+    px = level_pixels(W, H, nlevels)
+    P, P0, PL = sum(px), px[0], px[-1]
+    return {
+        "pyramid": (P - PL) + (P - P0),        # read every level but the last, write every level but the first
+        "fast_score": P,                        # read every pyramid pixel once
+        "cell_nms": 0,                          # consumes the score map (implementation traffic, not algorithmic)
+        "octree": 0,
+        "orient": 749 * K,                      # 749-pixel disc per keypoint
+        "blur": 2 * P,                          # read + write every level
+        "describe": 512 * K + 32 * K + 28 * K,  # 512 samples, 32-byte descriptor, 28-byte keypoint
+        "match": 32 * (K + K) + 8 * K,          # both descriptor sets once + result per query
+    }
+
+
+def cpu_baseline(orbx, W, H, nf, seconds_budget=12.0):
+    """Reference ORBextractor (oracle/_ref = unmodified source + cvshim) + restated matcher on
+    the host cores of this box, one extractor instance per thread (instances are not
+    re-entrant, reference include/ORBextractor.h:161)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    orc = oracle_lib.Oracle()
+    kind = "reference" if orc.ref is not None else "port"
+    ncores = os.cpu_count() or 1
+    nthreads = min(ncores, 32)
+    per_thread = 6
+    frames = [orbx.synth_frame(9000 + i, W, H) for i in range(per_thread + 1)]
+    # calibrate on one frame so the sample stays within the budget
+    ext0 = orc.reference(nf) if orc.ref is not None else orc.restatement(nf)
+    t0 = time.perf_counter()
+    ext0.extract(frames[0])
+    one = time.perf_counter() - t0
+    per_thread = int(max(2, min(40, seconds_budget / max(one * 1.3, 1e-3))))
+    frames = orbx.synth_sequence(9000, per_thread + 1, W, H)
+    done = [0] * nthreads
+
+    def work(t):
+        ext = orc.reference(nf) if orc.ref is not None else orc.restatement(nf)
+        prev = None
+        for i in range(per_thread + 1):
+            k, d = ext.extract(frames[i])
+            ks = np.zeros(len(k), orbx.KEYPOINT_DTYPE)
+            ks["angle"] = k[:, 3]
+            if prev is not None:
+                oracle_lib.search_by_bow(orc, 0, prev[0], prev[1], ks, d, 0.7, True)
+                done[t] += 1
+            prev = (ks, d)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    total = sum(done)
+    return {"value": round(total / dt, 2), "unit": "frames/s", "cores": nthreads, "kind": kind,
+            "sample": "%d threads x %d frames %dx%d/%d feat, extract (%s) + brute-force SearchByBoW (restated), %.1f s"
+                      % (nthreads, per_thread, W, H, nf, "oracle/_ref: unmodified reference ORBextractor.cc on cvshim" if kind == "reference" else "restatement", dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: liborbx has no CPU fallback"
+    torch.cuda.set_device(local)
+    dev_t = torch.device("cuda", local)
+
+    orbx = importlib.import_module("self_commit_orb-slam2_amd")
+    W, H, B, nf = a.width, a.height, a.batch, a.nfeatures
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local)
+    mt = None if a.no_match else orbx.ORBmatcher(0.7, True, max_features=ext.capacity, max_pairs=B, device=local)
+    # independent frames per rank: seeds offset by rank<<32; every 16th frame low texture
+    # scenes of 16 views translating 3x1 px per view, so consecutive frames really match
+    frames = orbx.synth_sequence((rank << 32) + 1, B, W, H)
+    dev = ext.upload(frames)                       # inputs resident in HBM before the timed region
+    pa = np.arange(B, dtype=np.int32)              # frame i (as "KeyFrame") ...
+    pb = (np.arange(B, dtype=np.int32) + 1) % B    # ... against frame i+1 (as "Frame")
+    fs = None
+
+    def step():
+        nonlocal fs
+        ext.run_device(*dev)
+        if mt is not None:
+            if fs is None:
+                fs = orbx.ORBmatcher.features_of(ext, B)
+            mt.search_by_bow_device(fs, fs, pa, pb, mode=0, after=ext)
+
+    def sync_all():
+        ext.sync()
+        if mt is not None:
+            mt.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync_all()
+    if dist is not None:
+        dist.barrier()
+    sync_all()
+
+    # HIP events on the library's own streams, one event set per call, recorded INSIDE the timed
+    # region and read only after it (nothing is synchronised in between)
+    ext.set_profiling(True)
+    if mt is not None:
+        mt.sync()
+        try:
+            mt.last_timing()     # reset the matcher's running average (warm-up calls)
+        except orbx.OrbxError:
+            pass
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync_all()
+    if dist is not None:
+        dist.barrier()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    _, stage_ms = ext.last_timing()
+    match_ms = mt.last_timing() if mt is not None else 0.0
+    ext.set_profiling(False)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
+    kps, desc, counts = ext.download(B)
+    nm_mean = 0.0
+    if mt is not None:
+        m, d, nm = mt.download(B)
+        nm_mean = float(nm.mean())
+    stats = torch.tensor([float(B * a.steps), elapsed, float(counts.sum())], dtype=torch.float64, device=dev_t)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)       # the one collective of this workload: 24 bytes per rank
+        frames_total = sum(float(g[0]) for g in gathered)
+    else:
+        frames_total = float(B * a.steps)
+    t = float(tmax.item())
+
+    if rank == 0:
+        K = float(counts.mean())
+        alg = algorithmic_bytes(W, H, K)
+        if mt is not None:
+            stage_ms["match"] = match_ms
+        dom = max((k for k in stage_ms if alg.get(k, 0) > 0), key=lambda k: stage_ms[k])
+        bytes_per_launch = alg[dom] * B
+        achieved = bytes_per_launch / (stage_ms[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(stage_ms[dom], 4),
+                    "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                    "whole_path_algorithmic_GBs": round(sum(alg.values()) * B / (sum(stage_ms.values()) * 1e-3) / 1e9, 2)}
+        out = {
+            "metric": "frames/s ORB extract+match (1000 feat, 640x480)" if not a.no_match else "frames/s ORB extract (1000 feat, 640x480)",
+            "value": round(frames_total / t, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "batch of %d synthetic %dx%d frames per GPU, ORB extract (%d feat, 8 levels, FAST 20/7)%s"
+                                   % (B, W, H, nf, "" if a.no_match else " + brute-force Hamming SearchByBoW of consecutive frames"),
+                       "batch_per_gpu": B, "width": W, "height": H, "nfeatures": nf, "parallelism": "frames sharded, %d rank(s)" % world,
+                       "keypoints_per_frame": round(K, 1), "matches_per_pair": round(nm_mean, 1)},
+            "roofline": roofline,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(orbx, W, H, nf)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,10 @@ int orbx_version(void);
 #define ORBX_SYNTH_LOW_TEXTURE 1  /* few shapes, +-2 noise: hits the minThFAST fallback */
 #define ORBX_SYNTH_STEREO_RIGHT 2 /* right view of the same scene, per-shape disparity   */
 int orbx_synth_frame(uint64_t seed, int width, int height, int stride, int flags, uint8_t *dst);
+/* View `view` of scene `seed`: all shapes translated by (dx,dy) pixels, fresh noise per view
+ * (consecutive views share most corners: frame-to-frame matching has something to match). */
+int orbx_synth_frame_ex(uint64_t seed, int view, int dx, int dy, int width, int height, int stride,
+                        int flags, uint8_t *dst);
 
 /* ------------------------------------------------------------------------------------
  * ORB extractor  ==  ORB_SLAM2::ORBextractor
@@ -142,13 +146,90 @@ int orbx_debug_download_scores(orbx_extractor *h, int frame, int level, uint8_t 
 int orbx_debug_download_candidates(orbx_extractor *h, int frame, int level, uint32_t *packed, int cap, int *count);
 int orbx_debug_download_level_keypoints(orbx_extractor *h, int frame, int level, orbx_keypoint *kps, int cap, int *count);
 
-/* Timing of the last orbx_extract_batch_device call, measured with HIP events on the
- * handle's stream: total milliseconds, and per-stage milliseconds in the order given
- * by orbx_stage_name(i).  Only filled when profiling was enabled before the call. */
+/* Kernel timing measured with HIP events on the handle's own stream: average milliseconds
+ * per stage (order given by orbx_stage_name(i)) and their sum, over the batch calls issued
+ * since profiling was enabled (at most the last 64).  Every call keeps its own event set,
+ * so nothing is synchronised inside a timed region; reading waits for the stream. */
 #define ORBX_MAX_STAGES 16
 int orbx_extractor_set_profiling(orbx_extractor *h, int enable);
 int orbx_extractor_last_timing(orbx_extractor *h, float *total_ms, float *stage_ms, int *nstages);
 const char *orbx_stage_name(int stage);
+
+
+/* ------------------------------------------------------------------------------------
+ * ORB matcher  ==  the Hamming paths of ORB_SLAM2::ORBmatcher (+ the Hamming stage of
+ * Frame::ComputeStereoMatches).  The reference walks KeyFrame / MapPoint / Frame objects;
+ * the C ABI takes the same information as flat arrays (INTEGRATION.md shows the
+ * marshalling the class shim does).
+ * ---------------------------------------------------------------------------------- */
+typedef struct orbx_matcher orbx_matcher;
+
+/* ORBmatcher::DescriptorDistance (ORBmatcher.h:65, src/ORBmatcher.cc:1913-1933): 256-bit
+ * Hamming distance of two 32-byte descriptors (host helper, used by the class shim). */
+int orbx_descriptor_distance(const uint8_t *a, const uint8_t *b);
+
+/* Features of `nframes` frames, frame f at index f*capacity.  Device OR host pointers,
+ * depending on the function. */
+typedef struct orbx_feature_set {
+    const orbx_keypoint *keypoints; /* angle/x/y/octave are read (mvKeys / mvKeysUn)             */
+    const uint8_t *descriptors;     /* 32 bytes per feature (mDescriptors)                       */
+    const int32_t *counts;          /* features per frame (N)                                    */
+    const int32_t *groups;          /* DBoW2 node id per feature (FeatureVector, src/Frame.cc:889-892);
+                                       NULL = every feature in one node = brute force            */
+    const uint8_t *valid;           /* 1 = feature has a non-bad MapPoint (src/ORBmatcher.cc:268-274);
+                                       NULL = all valid                                          */
+    int capacity;
+    int nframes;
+} orbx_feature_set;
+
+typedef struct orbx_bow_params {
+    float nn_ratio;        /* mfNNratio  (ORBmatcher.h:57; 0.7 at src/Tracking.cc:1189)          */
+    int check_orientation; /* mbCheckOrientation                                                 */
+    int mode;              /* 0: SearchByBoW(KeyFrame*,Frame&,...)     src/ORBmatcher.cc:230-382,
+                                 result indexed by the Frame feature (value = KeyFrame feature)
+                              1: SearchByBoW(KeyFrame*,KeyFrame*,...)  src/ORBmatcher.cc:656-799,
+                                 result indexed by the KF1 feature (value = KF2 feature)         */
+} orbx_bow_params;
+
+int orbx_matcher_create(int device, int max_features, int max_pairs, orbx_matcher **out);
+void orbx_matcher_destroy(orbx_matcher *m);
+
+/* SearchByBoW for `npairs` independent (A frame, B frame) pairs; A plays the KeyFrame.
+ * a/b hold DEVICE pointers; pairs_a/pairs_b are host arrays of frame indices.  Asynchronous
+ * on the matcher's stream (which first waits for `after_stream_of`, an extractor whose
+ * outputs are being consumed; may be NULL).  Results stay on the device:
+ *   matches[p*stride + slot] = index of the matched feature in the other set or -1,
+ *   dists[p*stride + slot]   = Hamming distance of that match,
+ *   nmatches[p]              = return value of SearchByBoW.                              */
+int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b,
+                              const int32_t *pairs_a, const int32_t *pairs_b, int npairs,
+                              const orbx_bow_params *params, orbx_extractor *after_stream_of);
+
+/* Hamming stage of Frame::ComputeStereoMatches (src/Frame.cc:1041-1216) for `npairs`
+ * (left frame, right frame) pairs: per left keypoint the right keypoint of minimum
+ * descriptor distance among those in its row band (+-2*scale[octave]), within one octave and
+ * with uR in [uL - max_disparity, uL].  dists = bestDist (TH_HIGH=100 when none),
+ * matches = bestIdxR (0 when none), nmatches[p] = #left keypoints with bestDist < 75.       */
+int orbx_stereo_match_device(orbx_matcher *m, const orbx_feature_set *left, const orbx_feature_set *right,
+                             const int32_t *pairs_l, const int32_t *pairs_r, int npairs,
+                             const float *scale_factors, int nlevels, float max_disparity,
+                             orbx_extractor *after_stream_of);
+
+int orbx_matcher_results_device(orbx_matcher *m, const int32_t **matches_dev, const int32_t **dists_dev,
+                                const int32_t **nmatches_dev, int *stride);
+int orbx_matcher_download(orbx_matcher *m, int npairs, int32_t *matches, int32_t *dists, int stride,
+                          int32_t *nmatches);
+int orbx_matcher_sync(orbx_matcher *m);
+
+/* Host-array convenience forms for one pair (upload, run, download). */
+int orbx_search_by_bow(orbx_matcher *m, const orbx_feature_set *a_host, const orbx_feature_set *b_host,
+                       const orbx_bow_params *params, int32_t *matches, int32_t *nmatches);
+int orbx_stereo_match(orbx_matcher *m, const orbx_feature_set *left_host, const orbx_feature_set *right_host,
+                      const float *scale_factors, int nlevels, float max_disparity, int32_t *best_dist,
+                      int32_t *best_idx);
+/* Average kernel milliseconds (HIP events on the matcher's stream) per *_device call since
+ * the previous orbx_matcher_last_timing (at most the last 64 calls). */
+int orbx_matcher_last_timing(orbx_matcher *m, float *total_ms);
 
 #ifdef __cplusplus
 }

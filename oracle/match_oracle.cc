@@ -1,0 +1,170 @@
+// oracle/match_oracle.cc -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement, on flat arrays, of the Hamming matchers of the reference:
+//   ORBmatcher::DescriptorDistance            src/ORBmatcher.cc:1913-1933
+//   ORBmatcher::SearchByBoW(KeyFrame*,Frame&) src/ORBmatcher.cc:230-382
+//   ORBmatcher::SearchByBoW(KeyFrame*,KeyFrame*) src/ORBmatcher.cc:656-799
+//   ORBmatcher::ComputeThreeMaxima            src/ORBmatcher.cc:1866-1908
+//   Frame::ComputeStereoMatches, Hamming stage src/Frame.cc:1041-1216
+// The reference versions walk the live KeyFrame/MapPoint/Frame object graph (mutexes,
+// DBoW2 FeatureVector maps) and cannot be compiled here without OpenCV + DBoW2 + the
+// whole map; "PARITY UNPINNED": no reference test or golden vector exists for them.
+// What is kept literally: the bit-hack distance, scan order (ascending node id, ascending
+// feature index inside a node), strict '<' updates (first minimum wins), the skip of
+// already matched F features, thresholds, ratio test in float, the 30-bin rotation
+// histogram with round() and the three-maxima pruning.
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <map>
+#include <vector>
+
+#define MO_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;   // src/ORBmatcher.cc:49-51
+
+// src/ORBmatcher.cc:1913-1933 (8 x int32 bit-hack popcount)
+int descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        unsigned int v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+// src/ORBmatcher.cc:1866-1908
+void three_maxima(const std::vector<int> *histo, int L, int &ind1, int &ind2, int &ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+typedef std::map<int, std::vector<unsigned> > FeatVec;   // DBoW2::FeatureVector: node id -> ascending feature indices
+
+FeatVec make_featvec(const int32_t *groups, int n)
+{
+    FeatVec fv;
+    for (int i = 0; i < n; i++) fv[groups ? groups[i] : 0].push_back((unsigned)i);   // addFeature keeps ascending order
+    return fv;
+}
+
+}  // namespace
+
+MO_API int mo_descriptor_distance(const uint8_t *a, const uint8_t *b) { return descriptor_distance(a, b); }
+
+// mode 0: SearchByBoW(KeyFrame*, Frame&):  match_out has nB entries (index of the KF feature or -1)
+// mode 1: SearchByBoW(KeyFrame*, KeyFrame*): match_out has nA entries (index of the KF2 feature or -1)
+// validA/validB: 1 where the feature has a non-bad MapPoint (NULL = all valid; validB only used in mode 1).
+MO_API int mo_search_by_bow(int mode, const uint8_t *descA, const float *angleA, const int32_t *groupA, const uint8_t *validA, int nA,
+                            const uint8_t *descB, const float *angleB, const int32_t *groupB, const uint8_t *validB, int nB,
+                            float nnratio, int checkOri, int32_t *match_out)
+{
+    const int nOut = mode == 0 ? nB : nA;
+    for (int i = 0; i < nOut; i++) match_out[i] = -1;
+    std::vector<char> matchedB((size_t)nB, 0);
+    FeatVec fA = make_featvec(groupA, nA), fB = make_featvec(groupB, nB);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;
+    FeatVec::const_iterator ia = fA.begin(), ib = fB.begin();
+    while (ia != fA.end() && ib != fB.end()) {
+        if (ia->first == ib->first) {
+            for (size_t k = 0; k < ia->second.size(); k++) {
+                const unsigned idxA = ia->second[k];
+                if (validA && !validA[idxA]) continue;
+                int best1 = 256, bestIdx = -1, best2 = 256;
+                for (size_t m = 0; m < ib->second.size(); m++) {
+                    const unsigned idxB = ib->second[m];
+                    if (matchedB[idxB]) continue;                         // :288 / :717
+                    if (mode == 1 && validB && !validB[idxB]) continue;   // :717-721
+                    const int dist = descriptor_distance(descA + 32 * (size_t)idxA, descB + 32 * (size_t)idxB);
+                    if (dist < best1) { best2 = best1; best1 = dist; bestIdx = (int)idxB; }
+                    else if (dist < best2) { best2 = dist; }
+                }
+                const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);   // :308 vs :741
+                if (pass && (float)best1 < nnratio * (float)best2) {
+                    matchedB[(size_t)bestIdx] = 1;
+                    const int slot = mode == 0 ? bestIdx : (int)idxA;
+                    match_out[slot] = mode == 0 ? (int)idxA : bestIdx;
+                    if (checkOri) {
+                        float rot = angleA[idxA] - angleB[bestIdx];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(slot);
+                    }
+                    nmatches++;
+                }
+            }
+            ++ia; ++ib;
+        } else if (ia->first < ib->first) ia = fA.lower_bound(ib->first);
+        else ib = fB.lower_bound(ia->first);
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { match_out[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+// Frame::ComputeStereoMatches up to the ORB-distance decision (src/Frame.cc:1041-1216):
+// kp arrays are 7 floats per keypoint {x,y,size,angle,response,octave,class_id};
+// best_dist[iL] = TH_HIGH when no candidate beat it, best_idx[iL] = winning right index (0 if none).
+MO_API void mo_stereo_hamming(const float *kpL, const uint8_t *descL, int nL, const float *kpR, const uint8_t *descR, int nR,
+                              const float *scaleFactors, int nRows, float maxD, int32_t *best_dist, int32_t *best_idx)
+{
+    std::vector<std::vector<size_t> > vRowIndices((size_t)nRows);
+    for (int iR = 0; iR < nR; iR++) {
+        const float kpY = kpR[7 * iR + 1];
+        const float r = 2.0f * scaleFactors[(int)kpR[7 * iR + 5]];
+        const int maxr = (int)ceil(kpY + r), minr = (int)floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[(size_t)yi].push_back((size_t)iR);
+    }
+    const float minD = 0;
+    for (int iL = 0; iL < nL; iL++) {
+        best_dist[iL] = TH_HIGH;
+        best_idx[iL] = 0;
+        const int levelL = (int)kpL[7 * iL + 5];
+        const float vL = kpL[7 * iL + 1], uL = kpL[7 * iL];
+        const std::vector<size_t> &cands = vRowIndices[(size_t)vL];
+        if (cands.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        size_t bestIdxR = 0;
+        for (size_t iC = 0; iC < cands.size(); iC++) {
+            const size_t iR = cands[iC];
+            const int octR = (int)kpR[7 * iR + 5];
+            if (octR < levelL - 1 || octR > levelL + 1) continue;
+            const float uR = kpR[7 * iR];
+            if (uR >= minU && uR <= maxU) {
+                const int dist = descriptor_distance(descL + 32 * (size_t)iL, descR + 32 * iR);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        best_dist[iL] = bestDist;
+        best_idx[iL] = (int32_t)bestIdxR;
+    }
+}

@@ -63,6 +63,7 @@ def load_library():
     L.orbx_stage_name.restype = ctypes.c_char_p
     L.orbx_stage_name.argtypes = [ctypes.c_int]
     L.orbx_synth_frame.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.orbx_synth_frame_ex.argtypes = [ctypes.c_uint64] + [ctypes.c_int] * 7 + [ctypes.c_void_p]
     vp, ci = ctypes.c_void_p, ctypes.c_int
     L.orbx_extractor_create.argtypes = [ctypes.POINTER(ExtractorConfig), ctypes.POINTER(vp)]
     L.orbx_extractor_destroy.argtypes = [vp]
@@ -96,11 +97,22 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def synth_frame(seed, width, height, flags=0):
-    """Deterministic synthetic grayscale frame (orbx_synth_frame)."""
+def synth_frame(seed, width, height, flags=0, view=0, dx=0, dy=0):
+    """Deterministic synthetic grayscale frame (orbx_synth_frame / orbx_synth_frame_ex)."""
     im = np.empty((height, width), np.uint8)
-    _check(load_library().orbx_synth_frame(ctypes.c_uint64(seed), width, height, width, flags, _ptr(im)))
+    _check(load_library().orbx_synth_frame_ex(ctypes.c_uint64(seed), view, dx, dy, width, height, width, flags, _ptr(im)))
     return im
+
+
+def synth_sequence(first_seed, count, width, height, views_per_scene=16, step=(3, 1), low_texture_every=16):
+    """`count` frames: scenes of `views_per_scene` consecutive views translating by `step` px/view
+    (so consecutive frames share corners); every `low_texture_every`-th scene view is low texture."""
+    out = []
+    for i in range(count):
+        scene, view = divmod(i, views_per_scene)
+        flags = SYNTH_LOW_TEXTURE if (low_texture_every and i % low_texture_every == low_texture_every - 1) else 0
+        out.append(synth_frame(first_seed + scene, width, height, flags, view, view * step[0], view * step[1]))
+    return out
 
 
 class ORBextractor:
@@ -259,3 +271,145 @@ class ORBextractor:
         n = ctypes.c_int()
         _check(self._L.orbx_debug_download_level_keypoints(self._h, frame, level, _ptr(out), 4096, ctypes.byref(n)))
         return out[:n.value].copy()
+
+
+# =====================================================================================
+# ORBmatcher (Hamming paths) over the C ABI
+# =====================================================================================
+class FeatureSet(ctypes.Structure):
+    _fields_ = [("keypoints", ctypes.c_void_p), ("descriptors", ctypes.c_void_p), ("counts", ctypes.c_void_p),
+                ("groups", ctypes.c_void_p), ("valid", ctypes.c_void_p), ("capacity", ctypes.c_int), ("nframes", ctypes.c_int)]
+
+
+class BowParams(ctypes.Structure):
+    _fields_ = [("nn_ratio", ctypes.c_float), ("check_orientation", ctypes.c_int), ("mode", ctypes.c_int)]
+
+
+def _bind_matcher(L):
+    if getattr(L, "_matcher_bound", False):
+        return
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.orbx_descriptor_distance.argtypes = [vp, vp]
+    L.orbx_matcher_create.argtypes = [ci, ci, ci, ctypes.POINTER(vp)]
+    L.orbx_matcher_destroy.argtypes = [vp]
+    L.orbx_matcher_destroy.restype = None
+    L.orbx_search_by_bow_device.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, vp, ci, ctypes.POINTER(BowParams), vp]
+    L.orbx_stereo_match_device.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, vp, ci, vp, ci, ctypes.c_float, vp]
+    L.orbx_matcher_results_device.argtypes = [vp, vp, vp, vp, vp]
+    L.orbx_matcher_download.argtypes = [vp, ci, vp, vp, ci, vp]
+    L.orbx_matcher_sync.argtypes = [vp]
+    L.orbx_search_by_bow.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), ctypes.POINTER(BowParams), vp, vp]
+    L.orbx_stereo_match.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, ci, ctypes.c_float, vp, vp]
+    L.orbx_matcher_last_timing.argtypes = [vp, vp]
+    L._matcher_bound = True
+
+
+def DescriptorDistance(a, b):
+    """ORBmatcher::DescriptorDistance (reference include/ORBmatcher.h:65)."""
+    L = load_library()
+    _bind_matcher(L)
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return L.orbx_descriptor_distance(_ptr(a), _ptr(b))
+
+
+def _host_set(kps, desc, groups=None, valid=None):
+    """One frame of host features -> (FeatureSet, keepalive)."""
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = np.array([len(kps)], np.int32)
+    keep = [kps, desc, n]
+    g = v = None
+    if groups is not None:
+        g = np.ascontiguousarray(groups, np.int32)
+        keep.append(g)
+    if valid is not None:
+        v = np.ascontiguousarray(valid, np.uint8)
+        keep.append(v)
+    fs = FeatureSet(kps.ctypes.data, desc.ctypes.data, n.ctypes.data, g.ctypes.data if g is not None else None,
+                    v.ctypes.data if v is not None else None, max(len(kps), 1), 1)
+    return fs, keep
+
+
+class ORBmatcher:
+    """Mirror of the Hamming paths of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:57-215)."""
+    TH_LOW = 50
+    TH_HIGH = 100
+    HISTO_LENGTH = 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, max_features=4096, max_pairs=1, device=0):
+        self._L = load_library()
+        _bind_matcher(self._L)
+        self.nnratio, self.checkOri = float(nnratio), bool(checkOri)
+        self.max_features, self.max_pairs = max_features, max_pairs
+        self._h = ctypes.c_void_p()
+        _check(self._L.orbx_matcher_create(device, max_features, max_pairs, ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbx_matcher_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- single pair, host arrays ----
+    def SearchByBoW(self, kpsA, descA, kpsB, descB, groupsA=None, groupsB=None, validA=None, validB=None, mode=0):
+        """mode 0: (KeyFrame, Frame) -> matches indexed by B;  mode 1: (KF1, KF2) -> indexed by A."""
+        fa, ka = _host_set(kpsA, descA, groupsA, validA)
+        fb, kb = _host_set(kpsB, descB, groupsB, validB)
+        nout = len(kpsB) if mode == 0 else len(kpsA)
+        out = np.full(max(nout, 1), -1, np.int32)
+        nm = ctypes.c_int32()
+        prm = BowParams(self.nnratio, 1 if self.checkOri else 0, mode)
+        _check(self._L.orbx_search_by_bow(self._h, ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(prm), _ptr(out), ctypes.byref(nm)))
+        return nm.value, out[:nout]
+
+    def StereoHamming(self, kpsL, descL, kpsR, descR, scale_factors, max_disparity=float("inf")):
+        fl, kl = _host_set(kpsL, descL)
+        fr, kr = _host_set(kpsR, descR)
+        n = len(kpsL)
+        bd = np.zeros(max(n, 1), np.int32)
+        bi = np.zeros(max(n, 1), np.int32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        _check(self._L.orbx_stereo_match(self._h, ctypes.byref(fl), ctypes.byref(fr), _ptr(sf), len(sf), ctypes.c_float(max_disparity), _ptr(bd), _ptr(bi)))
+        return bd[:n], bi[:n]
+
+    # ---- batched, device resident: features straight from an extractor's last batch ----
+    @staticmethod
+    def features_of(extractor, nframes):
+        k, d, c, cap = extractor.results_device()
+        return FeatureSet(k.value, d.value, c.value, None, None, cap, nframes)
+
+    def search_by_bow_device(self, fsA, fsB, pairsA, pairsB, mode=0, after=None):
+        pa = np.ascontiguousarray(pairsA, np.int32)
+        pb = np.ascontiguousarray(pairsB, np.int32)
+        prm = BowParams(self.nnratio, 1 if self.checkOri else 0, mode)
+        _check(self._L.orbx_search_by_bow_device(self._h, ctypes.byref(fsA), ctypes.byref(fsB), _ptr(pa), _ptr(pb), len(pa), ctypes.byref(prm),
+                                                 after._h if after is not None else None))
+
+    def stereo_match_device(self, fsL, fsR, pairsL, pairsR, scale_factors, max_disparity=float("inf"), after=None):
+        pl = np.ascontiguousarray(pairsL, np.int32)
+        pr = np.ascontiguousarray(pairsR, np.int32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        _check(self._L.orbx_stereo_match_device(self._h, ctypes.byref(fsL), ctypes.byref(fsR), _ptr(pl), _ptr(pr), len(pl), _ptr(sf), len(sf),
+                                                ctypes.c_float(max_disparity), after._h if after is not None else None))
+
+    def sync(self):
+        _check(self._L.orbx_matcher_sync(self._h))
+
+    def download(self, npairs, stride=None):
+        stride = stride or self.max_features
+        m = np.zeros((npairs, stride), np.int32)
+        d = np.zeros((npairs, stride), np.int32)
+        n = np.zeros(npairs, np.int32)
+        _check(self._L.orbx_matcher_download(self._h, npairs, _ptr(m), _ptr(d), stride, _ptr(n)))
+        return m, d, n
+
+    def last_timing(self):
+        t = ctypes.c_float()
+        _check(self._L.orbx_matcher_last_timing(self._h, ctypes.byref(t)))
+        return t.value

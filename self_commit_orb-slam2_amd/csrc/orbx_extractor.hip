@@ -27,6 +27,7 @@ extern "C" const char *orbx_last_error(void) { return g_err; }
 extern "C" int orbx_version(void) { return 100; }
 
 static const char *kStageNames[] = {"pyramid", "fast_score", "cell_nms", "octree", "orient", "blur", "describe"};
+#define ORBX_PROF_RING 64
 enum { ST_PYR = 0, ST_FAST, ST_CELLS, ST_OCTREE, ST_ORIENT, ST_BLUR, ST_DESC, ST_COUNT };
 extern "C" const char *orbx_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
 
@@ -70,8 +71,11 @@ struct orbx_extractor {
     int nodeCap = 512;
     // device state
     hipStream_t stream = nullptr;
-    hipEvent_t ev[ST_COUNT + 1] = {};
-    bool profiling = false, timingValid = false;
+    // profiling: a ring of event sets so that every batch call of a timed region keeps its
+    // own events and nothing has to be read (= synchronised) inside the region
+    hipEvent_t ev[ORBX_PROF_RING][ST_COUNT + 1] = {};
+    bool profiling = false;
+    int profCount = 0;
     DevBuf<OrbxGeom> geomDev;
     DevBuf<OrbxResizeX> rxDev;
     DevBuf<OrbxResizeY> ryDev;
@@ -296,24 +300,24 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outKp = h->outKp.p; L.outDesc = h->outDesc.p; L.outCnt = h->outCnt.p;
     L.status = h->status.p; L.nodeCap = h->nodeCap;
     const bool prof = h->profiling;
-    h->timingValid = false;
+    hipEvent_t *ev = h->ev[h->profCount % ORBX_PROF_RING];
     ORBX_HIP_CHECK(hipMemsetAsync(h->status.p, 0, (size_t)batch * sizeof(int), h->stream));
-    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[0], h->stream));
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[0], h->stream));
     for (int l = 1; l < h->geom.nlevels; l++)
         if ((rc = orbx_launch_resize(L, l)) != ORBX_OK) return rc;
-    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_PYR + 1], h->stream));
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_PYR + 1], h->stream));
     if ((rc = orbx_launch_fast(L)) != ORBX_OK) return rc;
-    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_FAST + 1], h->stream));
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_FAST + 1], h->stream));
     if ((rc = orbx_launch_cells(L)) != ORBX_OK) return rc;
-    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_CELLS + 1], h->stream));
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_CELLS + 1], h->stream));
     if ((rc = orbx_launch_octree(L)) != ORBX_OK) return rc;
-    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_OCTREE + 1], h->stream));
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_OCTREE + 1], h->stream));
     if ((rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
-    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_ORIENT + 1], h->stream));
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_ORIENT + 1], h->stream));
     if ((rc = orbx_launch_blur(L)) != ORBX_OK) return rc;
-    if (prof) ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_BLUR + 1], h->stream));
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_BLUR + 1], h->stream));
     if ((rc = orbx_launch_desc(L)) != ORBX_OK) return rc;
-    if (prof) { ORBX_HIP_CHECK(hipEventRecord(h->ev[ST_DESC + 1], h->stream)); h->timingValid = true; }
+    if (prof) { ORBX_HIP_CHECK(hipEventRecord(ev[ST_DESC + 1], h->stream)); h->profCount++; }
     h->lastBatch = batch; h->lastImg0 = img0Dev; h->lastStride = stride; h->lastFramePitch = framePitch;
     return ORBX_OK;
 }
@@ -349,6 +353,8 @@ int upload(orbx_extractor *h, const uint8_t *const *images, int batch, int W, in
 
 }  // namespace
 
+hipStream_t orbx_extractor_stream_internal(orbx_extractor *h) { return h ? h->stream : nullptr; }
+
 extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extractor **out)
 {
     if (!cfg || !out) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
@@ -373,7 +379,8 @@ extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extr
         delete h;
         return ORBX_ERR_HIP;
     }
-    for (int i = 0; i <= ST_COUNT; i++) (void)hipEventCreate(&h->ev[i]);
+    for (int r = 0; r < ORBX_PROF_RING; r++)
+        for (int i = 0; i <= ST_COUNT; i++) (void)hipEventCreate(&h->ev[r][i]);
     // validate the largest geometry up front so a bad size fails at construction
     int rc = build_geometry(h, cfg->max_width, cfg->max_height);
     if (rc != ORBX_OK) { orbx_extractor_destroy(h); return rc; }
@@ -390,7 +397,8 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     h->geomDev.release(); h->rxDev.release(); h->ryDev.release(); h->binDev.release(); h->pyr.release(); h->blur.release();
     h->score.release(); h->staging.release(); h->outDesc.release(); h->cellCount.release(); h->lvlCnt.release(); h->outCnt.release();
     h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->lvlKp.release(); h->outKp.release();
-    for (int i = 0; i <= ST_COUNT; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (int r = 0; r < ORBX_PROF_RING; r++)
+        for (int i = 0; i <= ST_COUNT; i++) if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -583,22 +591,29 @@ extern "C" int orbx_extractor_set_profiling(orbx_extractor *h, int enable)
 {
     if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
     h->profiling = enable != 0;
-    h->timingValid = false;
+    if (enable) h->profCount = 0;   // averages restart
     return ORBX_OK;
 }
 
 extern "C" int orbx_extractor_last_timing(orbx_extractor *h, float *total_ms, float *stage_ms, int *nstages)
 {
     if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
-    if (!h->timingValid) { orbx_set_error("no timing: enable profiling before the batch call"); return ORBX_ERR_STATE; }
+    if (h->profCount == 0) { orbx_set_error("no timing: enable profiling before the batch calls"); return ORBX_ERR_STATE; }
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
-    ORBX_HIP_CHECK(hipEventSynchronize(h->ev[ST_COUNT]));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    const int n = std::min(h->profCount, ORBX_PROF_RING);
+    float acc[ST_COUNT] = {0};
+    for (int r = 0; r < n; r++)
+        for (int s = 0; s < ST_COUNT; s++) {
+            float ms = 0.f;
+            ORBX_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[r][s], h->ev[r][s + 1]));
+            acc[s] += ms;
+        }
     float tot = 0.f;
     for (int s = 0; s < ST_COUNT; s++) {
-        float ms = 0.f;
-        ORBX_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[s], h->ev[s + 1]));
-        if (stage_ms) stage_ms[s] = ms;
-        tot += ms;
+        acc[s] /= (float)n;
+        if (stage_ms) stage_ms[s] = acc[s];
+        tot += acc[s];
     }
     if (total_ms) *total_ms = tot;
     if (nstages) *nstages = ST_COUNT;

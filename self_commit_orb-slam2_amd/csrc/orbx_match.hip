@@ -1,0 +1,557 @@
+// orbx_match.hip -- 256-bit Hamming matchers on gfx950 (wave64, __ballot/__popcll).
+//
+//   orbx_search_by_bow_device  == ORBmatcher::SearchByBoW, both overloads
+//                                 (reference src/ORBmatcher.cc:230-382, 656-799)
+//   orbx_stereo_match_device   == Hamming stage of Frame::ComputeStereoMatches
+//                                 (reference src/Frame.cc:1041-1216)
+//
+// SearchByBoW is a greedy, order dependent assignment: KeyFrame features are visited in
+// (node id, feature index) order and a Frame feature that has been taken is skipped by
+// every later KeyFrame feature (:288, :717).  The O(N1*N2) part - all descriptor
+// distances - does not depend on that order, so it runs fully parallel and leaves, per
+// KeyFrame feature, its 4 best candidates by (distance, index).  One wave per pair then
+// replays the greedy pass in the reference order over those short lists; whenever fewer
+// than two of the four are still free (and the list was full) it falls back to an exact
+// wave-parallel rescan.  The result is index-exact, including first-minimum-wins ties.
+// VALU/LDS bound (XOR + v_bcnt_u32), not HBM: 144 KB of traffic per 2000x2000 pair.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "orbx_internal.h"
+
+#define TH_HIGH 100       /* src/ORBmatcher.cc:49 */
+#define TH_LOW 50         /* :50 */
+#define HISTO_LENGTH 30   /* :51 */
+#define KEY_EMPTY 0xffffffffu
+#define TOPK 4
+#define MATCH_PROF_RING 64
+
+namespace {
+
+struct FeatDev {   // orbx_feature_set with device pointers
+    const orbx_keypoint *kp;
+    const uint8_t *desc;
+    const int32_t *counts;
+    const int32_t *groups;
+    const uint8_t *valid;
+    int cap;
+};
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(v, o); v = u < v ? u : v; }
+    return v;
+}
+
+__device__ __forceinline__ int hamming256(const unsigned long long a[4], unsigned long long b0, unsigned long long b1, unsigned long long b2,
+                                          unsigned long long b3)
+{
+    return __popcll(a[0] ^ b0) + __popcll(a[1] ^ b1) + __popcll(a[2] ^ b2) + __popcll(a[3] ^ b3);
+}
+
+// processing order of the KeyFrame features: ascending (node id, feature index) = std::map
+// iteration over the FeatureVector, features ascending inside a node.
+__global__ __launch_bounds__(256) void k_bow_order(FeatDev A, const int32_t *__restrict__ pairsA, int32_t *__restrict__ order, int stride)
+{
+    const int p = blockIdx.y, fa = pairsA[p];
+    const int nA = min(A.counts[fa], A.cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nA) return;
+    int32_t *ord = order + (size_t)p * stride;
+    if (!A.groups) { ord[i] = i; return; }
+    const int32_t *g = A.groups + (size_t)fa * A.cap;
+    const int gi = g[i];
+    int rank = 0;
+    for (int k = 0; k < nA; k++) { int gk = g[k]; rank += (gk < gi) || (gk == gi && k < i); }
+    ord[rank] = i;
+}
+
+// top-4 candidates of every A feature by key = dist<<16 | j over the B features of the same
+// node (mode 1: that also carry a valid MapPoint).  B descriptors are staged in LDS as four
+// u64 planes so that consecutive lanes read consecutive 8-byte words (conflict free).
+#define TOPK_ROWS 64   /* A features per block (16 per wave) */
+__global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
+                                                  uint32_t *__restrict__ topk, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int p = blockIdx.y, fa = pairsA[p], fb = pairsB[p];
+    const int nA = min(A.counts[fa], A.cap), nB = min(B.counts[fb], B.cap);
+    const int capB = B.cap;
+    unsigned long long *plane = (unsigned long long *)smem;     // [4][capB]
+    int32_t *gB = (int32_t *)(plane + 4 * (size_t)capB);         // [capB], -2^31 = excluded
+    const int row0 = blockIdx.x * TOPK_ROWS;
+    if (row0 >= nA) return;
+    const unsigned long long *dB = (const unsigned long long *)(B.desc + (size_t)fb * capB * 32);
+    for (int t = threadIdx.x; t < nB * 4; t += 256) { int j = t >> 2, w = t & 3; plane[(size_t)w * capB + j] = dB[t]; }
+    for (int j = threadIdx.x; j < nB; j += 256) {
+        int g = B.groups ? B.groups[(size_t)fb * capB + j] : 0;
+        if (mode == 1 && B.valid && !B.valid[(size_t)fb * capB + j]) g = (int)0x80000000;
+        gB[j] = g;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < TOPK_ROWS; r += 4) {
+        const int i = row0 + r;
+        if (i >= nA) break;
+        const unsigned long long *da = (const unsigned long long *)(A.desc + ((size_t)fa * A.cap + i) * 32);
+        unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
+        const int gA = A.groups ? A.groups[(size_t)fa * A.cap + i] : 0;
+        uint32_t k0 = KEY_EMPTY, k1 = KEY_EMPTY, k2 = KEY_EMPTY, k3 = KEY_EMPTY;
+        for (int j = lane; j < nB; j += 64) {
+            if (gB[j] != gA) continue;
+            int d = hamming256(a, plane[j], plane[(size_t)capB + j], plane[2 * (size_t)capB + j], plane[3 * (size_t)capB + j]);
+            uint32_t key = ((uint32_t)d << 16) | (uint32_t)j;
+            if (key < k3) {
+                k3 = key;
+                if (k3 < k2) { uint32_t t = k2; k2 = k3; k3 = t; }
+                if (k2 < k1) { uint32_t t = k1; k1 = k2; k2 = t; }
+                if (k1 < k0) { uint32_t t = k0; k0 = k1; k1 = t; }
+            }
+        }
+        uint32_t *out = topk + ((size_t)p * stride + i) * TOPK;
+#pragma unroll
+        for (int k = 0; k < TOPK; k++) {
+            uint32_t m = wave_min_u32(k0);
+            if (k0 == m && m != KEY_EMPTY) { k0 = k1; k1 = k2; k2 = k3; k3 = KEY_EMPTY; }   // keys are unique: one lane pops
+            if (lane == 0) out[k] = m;
+        }
+    }
+}
+
+// greedy replay + rotation histogram + three-maxima pruning; one wave per pair.
+__global__ __launch_bounds__(64) void k_bow_greedy(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
+                                                   float nnratio, int checkOri, const uint32_t *__restrict__ topk, const int32_t *__restrict__ order,
+                                                   int32_t *__restrict__ matches, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int hist[HISTO_LENGTH];
+    const int p = blockIdx.x, lane = threadIdx.x, fa = pairsA[p], fb = pairsB[p];
+    const int nA = min(A.counts[fa], A.cap), nB = min(B.counts[fb], B.cap);
+    uint32_t *taken = (uint32_t *)smem;                                  // bitmap over B features
+    unsigned char *binOf = (unsigned char *)(taken + ((B.cap + 31) >> 5));   // per output slot
+    const int nOut = mode == 0 ? nB : nA;
+    int32_t *mout = matches + (size_t)p * stride, *dout = dists + (size_t)p * stride;
+    for (int i = lane; i < stride; i += 64) { mout[i] = -1; dout[i] = 256; }
+    for (int i = lane; i < ((B.cap + 31) >> 5); i += 64) taken[i] = 0;
+    if (lane < HISTO_LENGTH) hist[lane] = 0;
+    __syncthreads();
+    const orbx_keypoint *kA = A.kp + (size_t)fa * A.cap, *kB = B.kp + (size_t)fb * B.cap;
+    const int32_t *ord = order + (size_t)p * stride;
+    const uint32_t *tk = topk + (size_t)p * stride * TOPK;
+    const float factor = HISTO_LENGTH / 360.0f;
+    int total = 0;
+    for (int r = 0; r < nA; r++) {
+        const int i = ord[r];
+        if (A.valid && !A.valid[(size_t)fa * A.cap + i]) continue;
+        uint32_t key = lane < TOPK ? tk[(size_t)i * TOPK + lane] : KEY_EMPTY;
+        const bool present = key != KEY_EMPTY;
+        const int j = (int)(key & 0xffff);
+        const bool free_ = present && !((taken[j >> 5] >> (j & 31)) & 1u);
+        const unsigned mPresent = (unsigned)(__ballot(present) & 0xf), mFree = (unsigned)(__ballot(free_) & 0xf);
+        uint32_t bestKey = KEY_EMPTY;
+        int best2 = 256;
+        if (__popc(mFree) >= 2 || mPresent != 0xf) {
+            if (mFree) {
+                const int la = __ffs(mFree) - 1;
+                bestKey = __shfl(key, la);
+                const unsigned rest = mFree & (mFree - 1);
+                if (rest) best2 = (int)(__shfl(key, __ffs(rest) - 1) >> 16);
+            }
+        } else {
+            // exact rescan over the free B features of this node
+            const unsigned long long *da = (const unsigned long long *)(A.desc + ((size_t)fa * A.cap + i) * 32);
+            unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
+            const int gA = A.groups ? A.groups[(size_t)fa * A.cap + i] : 0;
+            uint32_t k0 = KEY_EMPTY, k1 = KEY_EMPTY;
+            for (int jj = lane; jj < nB; jj += 64) {
+                if ((taken[jj >> 5] >> (jj & 31)) & 1u) continue;
+                if (B.groups && B.groups[(size_t)fb * B.cap + jj] != gA) continue;
+                if (mode == 1 && B.valid && !B.valid[(size_t)fb * B.cap + jj]) continue;
+                const unsigned long long *db = (const unsigned long long *)(B.desc + ((size_t)fb * B.cap + jj) * 32);
+                int d = hamming256(a, db[0], db[1], db[2], db[3]);
+                uint32_t kk = ((uint32_t)d << 16) | (uint32_t)jj;
+                if (kk < k0) { k1 = k0; k0 = kk; } else if (kk < k1) k1 = kk;
+            }
+            bestKey = wave_min_u32(k0);
+            if (k0 == bestKey) k0 = k1;
+            uint32_t second = wave_min_u32(k0);
+            if (second != KEY_EMPTY) best2 = (int)(second >> 16);
+        }
+        if (bestKey == KEY_EMPTY) continue;
+        const int best1 = (int)(bestKey >> 16), bj = (int)(bestKey & 0xffff);
+        const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);
+        if (pass && (float)best1 < nnratio * (float)best2) {
+            if (lane == 0) {
+                taken[bj >> 5] |= 1u << (bj & 31);
+                const int slot = mode == 0 ? bj : i;
+                mout[slot] = mode == 0 ? i : bj;
+                dout[slot] = best1;
+                if (checkOri) {
+                    float rot = kA[i].angle - kB[bj].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    binOf[slot] = (unsigned char)bin;
+                    hist[bin]++;
+                }
+            }
+            total++;
+            __syncthreads();   // single-wave block: orders the LDS bitmap update before the next read
+        }
+    }
+    __syncthreads();
+    if (checkOri) {
+        // ComputeThreeMaxima, src/ORBmatcher.cc:1866-1908
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            const int s = hist[b];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
+            else if (s > max3) { max3 = s; ind3 = b; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        int removed = 0;
+        for (int s = lane; s < nOut; s += 64) {
+            if (mout[s] < 0) continue;
+            const int b = binOf[s];
+            if (b != ind1 && b != ind2 && b != ind3) { mout[s] = -1; dout[s] = 256; removed++; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+        total -= removed;
+    }
+    if (lane == 0) nmatches[p] = total;
+}
+
+// Hamming stage of Frame::ComputeStereoMatches: one wave per left keypoint, lanes over the
+// right keypoints; the row-band / octave / disparity gate is evaluated per candidate exactly
+// as the reference builds vRowIndices (src/Frame.cc:1060-1097, 1145, 1190-1200).
+__global__ __launch_bounds__(256) void k_stereo(FeatDev Lf, FeatDev Rf, const int32_t *__restrict__ pairsL, const int32_t *__restrict__ pairsR,
+                                                const float *__restrict__ scaleFactors, float maxD, int32_t *__restrict__ bestIdx, int32_t *__restrict__ bestDist,
+                                                int32_t *__restrict__ nmatches, int stride)
+{
+    const int p = blockIdx.y, fl = pairsL[p], fr = pairsR[p];
+    const int nL = min(Lf.counts[fl], Lf.cap), nR = min(Rf.counts[fr], Rf.cap);
+    const int lane = threadIdx.x & 63, iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= nL) return;
+    const orbx_keypoint kl = Lf.kp[(size_t)fl * Lf.cap + iL];
+    const int row = (int)kl.y;
+    const float minU = kl.x - maxD, maxU = kl.x - 0.0f;
+    const unsigned long long *da = (const unsigned long long *)(Lf.desc + ((size_t)fl * Lf.cap + iL) * 32);
+    unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
+    uint32_t best = ((uint32_t)TH_HIGH << 16);   // bestDist = TH_HIGH, strict '<' below
+    if (!(maxU < 0)) {
+        const orbx_keypoint *kr = Rf.kp + (size_t)fr * Rf.cap;
+        for (int iR = lane; iR < nR; iR += 64) {
+            const orbx_keypoint k = kr[iR];
+            const float r = 2.0f * scaleFactors[k.octave];
+            const int maxr = (int)ceilf(k.y + r), minr = (int)floorf(k.y - r);
+            if (row < minr || row > maxr) continue;
+            if (k.octave < kl.octave - 1 || k.octave > kl.octave + 1) continue;
+            if (!(k.x >= minU && k.x <= maxU)) continue;
+            const unsigned long long *db = (const unsigned long long *)(Rf.desc + ((size_t)fr * Rf.cap + iR) * 32);
+            const int d = hamming256(a, db[0], db[1], db[2], db[3]);
+            const uint32_t key = ((uint32_t)d << 16) | (uint32_t)iR;
+            if (d < TH_HIGH && key < best) best = key;
+        }
+    }
+    best = wave_min_u32(best);
+    if (lane == 0) {
+        const int d = (int)(best >> 16);
+        bestDist[(size_t)p * stride + iL] = d;
+        bestIdx[(size_t)p * stride + iL] = d < TH_HIGH ? (int)(best & 0xffff) : 0;
+        if (d < (TH_HIGH + TH_LOW) / 2) atomicAdd(&nmatches[p], 1);
+    }
+}
+
+template <typename T> struct MBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n) return ORBX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        ORBX_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+        return ORBX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct orbx_matcher {
+    int device = 0, maxFeatures = 0, maxPairs = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t evDep = nullptr, evDone = nullptr;
+    hipEvent_t ev0[MATCH_PROF_RING] = {}, ev1[MATCH_PROF_RING] = {};   // one pair per *_device call (ring)
+    int profCount = 0;
+    MBuf<int32_t> pairsA, pairsB, order, matches, dists, nmatches;
+    MBuf<uint32_t> topk;
+    MBuf<float> scales;
+    // staging for the host-array convenience calls
+    MBuf<orbx_keypoint> hk[2];
+    MBuf<uint8_t> hd[2], hv[2];
+    MBuf<int32_t> hc[2], hg[2];
+    int lastPairs = 0, lastStride = 0;
+};
+
+extern "C" int orbx_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    int dist = 0;
+    for (int i = 0; i < 4; i++) {
+        unsigned long long x, y;
+        memcpy(&x, a + 8 * i, 8);
+        memcpy(&y, b + 8 * i, 8);
+        dist += __builtin_popcountll(x ^ y);
+    }
+    return dist;
+}
+
+extern "C" int orbx_matcher_create(int device, int max_features, int max_pairs, orbx_matcher **out)
+{
+    if (!out || max_features < 1 || max_features > 65535 || max_pairs < 1) { orbx_set_error("bad matcher arguments (1 <= max_features <= 65535)"); return ORBX_ERR_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { orbx_set_error("no HIP device available: liborbx has no CPU fallback"); return ORBX_ERR_NODEVICE; }
+    if (device < 0 || device >= ndev) { orbx_set_error("device %d out of range", device); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(device));
+    orbx_matcher *m = new orbx_matcher();
+    m->device = device; m->maxFeatures = max_features; m->maxPairs = max_pairs;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
+    (void)hipEventCreateWithFlags(&m->evDep, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&m->evDone, hipEventDisableTiming);
+    for (int r = 0; r < MATCH_PROF_RING; r++) { (void)hipEventCreate(&m->ev0[r]); (void)hipEventCreate(&m->ev1[r]); }
+    const size_t S = (size_t)max_features, P = (size_t)max_pairs;
+    int rc;
+    if ((rc = m->pairsA.ensure(P)) || (rc = m->pairsB.ensure(P)) || (rc = m->order.ensure(P * S)) || (rc = m->matches.ensure(P * S)) ||
+        (rc = m->dists.ensure(P * S)) || (rc = m->nmatches.ensure(P)) || (rc = m->topk.ensure(P * S * TOPK)) || (rc = m->scales.ensure(64))) {
+        orbx_matcher_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_matcher_destroy(orbx_matcher *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    m->pairsA.release(); m->pairsB.release(); m->order.release(); m->matches.release(); m->dists.release(); m->nmatches.release();
+    m->topk.release(); m->scales.release();
+    for (int s = 0; s < 2; s++) { m->hk[s].release(); m->hd[s].release(); m->hv[s].release(); m->hc[s].release(); m->hg[s].release(); }
+    if (m->evDep) (void)hipEventDestroy(m->evDep);
+    if (m->evDone) (void)hipEventDestroy(m->evDone);
+    for (int r = 0; r < MATCH_PROF_RING; r++) { if (m->ev0[r]) (void)hipEventDestroy(m->ev0[r]); if (m->ev1[r]) (void)hipEventDestroy(m->ev1[r]); }
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+static int prep_pairs(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b, const int32_t *pa, const int32_t *pb, int npairs,
+                      orbx_extractor *after)
+{
+    if (!m || !a || !b || !pa || !pb) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (npairs < 1 || npairs > m->maxPairs) { orbx_set_error("npairs %d outside 1..%d", npairs, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (a->capacity > m->maxFeatures || b->capacity > m->maxFeatures || a->capacity < 1 || b->capacity < 1) {
+        orbx_set_error("feature capacity %d/%d exceeds the matcher's max_features %d", a->capacity, b->capacity, m->maxFeatures);
+        return ORBX_ERR_CAPACITY;
+    }
+    if (!a->keypoints || !a->descriptors || !a->counts || !b->keypoints || !b->descriptors || !b->counts) { orbx_set_error("NULL feature arrays"); return ORBX_ERR_ARG; }
+    for (int p = 0; p < npairs; p++)
+        if (pa[p] < 0 || pa[p] >= a->nframes || pb[p] < 0 || pb[p] >= b->nframes) { orbx_set_error("pair %d references a frame out of range", p); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    if (after) {
+        ORBX_HIP_CHECK(hipEventRecord(m->evDep, orbx_extractor_stream_internal(after)));
+        ORBX_HIP_CHECK(hipStreamWaitEvent(m->stream, m->evDep, 0));
+    }
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pairsA.p, pa, (size_t)npairs * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pairsB.p, pb, (size_t)npairs * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    return ORBX_OK;
+}
+
+// The producer's next batch overwrites the feature buffers this call reads: make its stream
+// wait until the match kernels are done (the two handles otherwise run on independent streams).
+static int chain_back(orbx_matcher *m, orbx_extractor *after)
+{
+    if (!after) return ORBX_OK;
+    ORBX_HIP_CHECK(hipEventRecord(m->evDone, m->stream));
+    ORBX_HIP_CHECK(hipStreamWaitEvent(orbx_extractor_stream_internal(after), m->evDone, 0));
+    return ORBX_OK;
+}
+
+static FeatDev to_dev(const orbx_feature_set *s)
+{
+    FeatDev f;
+    f.kp = s->keypoints; f.desc = s->descriptors; f.counts = s->counts; f.groups = s->groups; f.valid = s->valid; f.cap = s->capacity;
+    return f;
+}
+
+#define MLAUNCH_CHECK()                                                                                              \
+    do {                                                                                                             \
+        hipError_t e_ = hipGetLastError();                                                                           \
+        if (e_ != hipSuccess) { orbx_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); return ORBX_ERR_HIP; } \
+    } while (0)
+
+extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b, const int32_t *pairs_a,
+                                         const int32_t *pairs_b, int npairs, const orbx_bow_params *params, orbx_extractor *after)
+{
+    if (!params || (params->mode != 0 && params->mode != 1)) { orbx_set_error("bad bow params"); return ORBX_ERR_ARG; }
+    int rc = prep_pairs(m, a, b, pairs_a, pairs_b, npairs, after);
+    if (rc != ORBX_OK) return rc;
+    const int stride = m->maxFeatures;
+    FeatDev A = to_dev(a), B = to_dev(b);
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    hipLaunchKernelGGL(k_bow_order, dim3((unsigned)((a->capacity + 255) / 256), (unsigned)npairs), dim3(256), 0, m->stream, A, m->pairsA.p, m->order.p, stride);
+    MLAUNCH_CHECK();
+    const size_t ldsTopk = (size_t)b->capacity * (32 + 4);
+    if (ldsTopk > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", b->capacity); return ORBX_ERR_CAPACITY; }
+    if (ldsTopk > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTopk));
+    hipLaunchKernelGGL(k_bow_topk, dim3((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs), dim3(256), ldsTopk, m->stream, A, B,
+                       m->pairsA.p, m->pairsB.p, params->mode, m->topk.p, stride);
+    MLAUNCH_CHECK();
+    const size_t ldsGreedy = (size_t)((b->capacity + 31) / 32) * 4 + (size_t)stride + 16;
+    hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(64), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, params->nn_ratio,
+                       params->check_orientation, m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = npairs; m->lastStride = stride;
+    return chain_back(m, after);
+}
+
+extern "C" int orbx_stereo_match_device(orbx_matcher *m, const orbx_feature_set *left, const orbx_feature_set *right, const int32_t *pairs_l,
+                                        const int32_t *pairs_r, int npairs, const float *scale_factors, int nlevels, float max_disparity,
+                                        orbx_extractor *after)
+{
+    if (!scale_factors || nlevels < 1 || nlevels > 64) { orbx_set_error("bad scale factor table"); return ORBX_ERR_ARG; }
+    int rc = prep_pairs(m, left, right, pairs_l, pairs_r, npairs, after);
+    if (rc != ORBX_OK) return rc;
+    const int stride = m->maxFeatures;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->scales.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    ORBX_HIP_CHECK(hipMemsetAsync(m->nmatches.p, 0, (size_t)npairs * sizeof(int32_t), m->stream));
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    hipLaunchKernelGGL(k_stereo, dim3((unsigned)((left->capacity + 3) / 4), (unsigned)npairs), dim3(256), 0, m->stream, to_dev(left), to_dev(right), m->pairsA.p,
+                       m->pairsB.p, m->scales.p, max_disparity, m->matches.p, m->dists.p, m->nmatches.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = npairs; m->lastStride = stride;
+    return chain_back(m, after);
+}
+
+extern "C" int orbx_matcher_results_device(orbx_matcher *m, const int32_t **matches_dev, const int32_t **dists_dev, const int32_t **nmatches_dev, int *stride)
+{
+    if (!m) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!m->lastPairs) { orbx_set_error("no match call yet"); return ORBX_ERR_STATE; }
+    if (matches_dev) *matches_dev = m->matches.p;
+    if (dists_dev) *dists_dev = m->dists.p;
+    if (nmatches_dev) *nmatches_dev = m->nmatches.p;
+    if (stride) *stride = m->lastStride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_matcher_sync(orbx_matcher *m)
+{
+    if (!m) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_matcher_download(orbx_matcher *m, int npairs, int32_t *matches, int32_t *dists, int stride, int32_t *nmatches)
+{
+    if (!m) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (npairs < 1 || npairs > m->lastPairs) { orbx_set_error("npairs not available"); return ORBX_ERR_STATE; }
+    if (stride < 1 || stride > m->lastStride) { orbx_set_error("bad stride"); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (matches) ORBX_HIP_CHECK(hipMemcpy2D(matches, (size_t)stride * 4, m->matches.p, (size_t)m->lastStride * 4, (size_t)stride * 4, (size_t)npairs, hipMemcpyDeviceToHost));
+    if (dists) ORBX_HIP_CHECK(hipMemcpy2D(dists, (size_t)stride * 4, m->dists.p, (size_t)m->lastStride * 4, (size_t)stride * 4, (size_t)npairs, hipMemcpyDeviceToHost));
+    if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, (size_t)npairs * 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_matcher_last_timing(orbx_matcher *m, float *total_ms)
+{
+    if (!m || !total_ms) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (m->profCount == 0) { orbx_set_error("no timing available"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    const int n = m->profCount < MATCH_PROF_RING ? m->profCount : MATCH_PROF_RING;
+    float acc = 0.f;
+    for (int r = 0; r < n; r++) {
+        float ms = 0.f;
+        ORBX_HIP_CHECK(hipEventElapsedTime(&ms, m->ev0[r], m->ev1[r]));
+        acc += ms;
+    }
+    *total_ms = acc / (float)n;
+    m->profCount = 0;   // the next call starts a new average
+    return ORBX_OK;
+}
+
+// ---- host-array convenience: stage one frame per side, run, download ----
+static int stage_host(orbx_matcher *m, int side, const orbx_feature_set *h, orbx_feature_set *d)
+{
+    if (!h || !h->keypoints || !h->descriptors || !h->counts) { orbx_set_error("NULL feature arrays"); return ORBX_ERR_ARG; }
+    const int n = h->counts[0];
+    if (n < 0 || n > m->maxFeatures) { orbx_set_error("feature count %d exceeds max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    const size_t cap = (size_t)m->maxFeatures;
+    int rc;
+    if ((rc = m->hk[side].ensure(cap)) || (rc = m->hd[side].ensure(cap * 32)) || (rc = m->hc[side].ensure(1)) || (rc = m->hg[side].ensure(cap)) ||
+        (rc = m->hv[side].ensure(cap)))
+        return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hk[side].p, h->keypoints, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[side].p, h->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, m->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hc[side].p, &n, sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    if (h->groups) ORBX_HIP_CHECK(hipMemcpyAsync(m->hg[side].p, h->groups, (size_t)n * 4, hipMemcpyHostToDevice, m->stream));
+    if (h->valid) ORBX_HIP_CHECK(hipMemcpyAsync(m->hv[side].p, h->valid, (size_t)n, hipMemcpyHostToDevice, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));   // `n` lives on this stack frame
+    d->keypoints = m->hk[side].p; d->descriptors = m->hd[side].p; d->counts = m->hc[side].p;
+    d->groups = h->groups ? m->hg[side].p : nullptr; d->valid = h->valid ? m->hv[side].p : nullptr;
+    d->capacity = m->maxFeatures; d->nframes = 1;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_bow(orbx_matcher *m, const orbx_feature_set *a_host, const orbx_feature_set *b_host, const orbx_bow_params *params,
+                                  int32_t *matches, int32_t *nmatches)
+{
+    if (!m || !matches || !nmatches) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    orbx_feature_set da, db;
+    int rc;
+    if ((rc = stage_host(m, 0, a_host, &da)) != ORBX_OK || (rc = stage_host(m, 1, b_host, &db)) != ORBX_OK) return rc;
+    const int32_t zero = 0;
+    if ((rc = orbx_search_by_bow_device(m, &da, &db, &zero, &zero, 1, params, nullptr)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    const int nOut = params->mode == 0 ? b_host->counts[0] : a_host->counts[0];
+    if (nOut > 0) ORBX_HIP_CHECK(hipMemcpy(matches, m->matches.p, (size_t)nOut * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stereo_match(orbx_matcher *m, const orbx_feature_set *left_host, const orbx_feature_set *right_host, const float *scale_factors,
+                                 int nlevels, float max_disparity, int32_t *best_dist, int32_t *best_idx)
+{
+    if (!m || !best_dist || !best_idx) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    orbx_feature_set dl, dr;
+    int rc;
+    if ((rc = stage_host(m, 0, left_host, &dl)) != ORBX_OK || (rc = stage_host(m, 1, right_host, &dr)) != ORBX_OK) return rc;
+    const int32_t zero = 0;
+    if ((rc = orbx_stereo_match_device(m, &dl, &dr, &zero, &zero, 1, scale_factors, nlevels, max_disparity, nullptr)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    const int nL = left_host->counts[0];
+    if (nL > 0) {
+        ORBX_HIP_CHECK(hipMemcpy(best_idx, m->matches.p, (size_t)nL * 4, hipMemcpyDeviceToHost));
+        ORBX_HIP_CHECK(hipMemcpy(best_dist, m->dists.p, (size_t)nL * 4, hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
+}

@@ -71,11 +71,20 @@ inline void fill_tri(uint8_t *img, int W, int H, int stride, const int *vx, cons
 
 extern "C" int orbx_synth_frame(uint64_t seed, int width, int height, int stride, int flags, uint8_t *dst)
 {
+    return orbx_synth_frame_ex(seed, 0, 0, 0, width, height, stride, flags, dst);
+}
+
+// Same scene `seed` seen `view` steps later: every shape is translated by (dx, dy) pixels and
+// the noise stream is re-drawn per view, so consecutive views of one scene share most of
+// their corners (a camera translating in front of a fronto-parallel scene).
+extern "C" int orbx_synth_frame_ex(uint64_t seed, int view, int dx, int dy, int width, int height, int stride, int flags, uint8_t *dst)
+{
     if (!dst || width <= 0 || height <= 0 || stride < width) return ORBX_ERR_ARG;
     const bool low = (flags & ORBX_SYNTH_LOW_TEXTURE) != 0;
     const bool right = (flags & ORBX_SYNTH_STEREO_RIGHT) != 0;
     Rng shapes(0x9E3779B97F4A7C15ULL ^ seed);
-    Rng noise((0xD1B54A32D192ED03ULL ^ (seed * 0x9E3779B97F4A7C15ULL)) + (right ? 0x5851F42D4C957F2DULL : 0));
+    Rng noise((0xD1B54A32D192ED03ULL ^ (seed * 0x9E3779B97F4A7C15ULL)) + (right ? 0x5851F42D4C957F2DULL : 0) +
+              (uint64_t)view * 0xA24BAED4963EE407ULL);
     for (int y = 0; y < height; y++) memset(dst + (size_t)y * stride, 128, (size_t)width);
     const int nrect = low ? 20 : 420, ntri = low ? 7 : 140;
     const int total = nrect + ntri;
@@ -89,14 +98,14 @@ extern "C" int orbx_synth_frame(uint64_t seed, int width, int height, int stride
         if (!is_tri) {
             int w = 4 + (int)shapes.below(90), h = 4 + (int)shapes.below(90);
             int x0 = (int)shapes.below((uint32_t)width) - w / 2, y0 = (int)shapes.below((uint32_t)height) - h / 2;
-            fill_rect(dst, width, height, stride, x0 + shift, y0, w, h, g);
+            fill_rect(dst, width, height, stride, x0 + shift + dx, y0 + dy, w, h, g);
             ri++;
         } else {
             int cx = (int)shapes.below((uint32_t)width), cy = (int)shapes.below((uint32_t)height);
             int vx[3], vy[3];
             for (int i = 0; i < 3; i++) {
-                vx[i] = cx + (int)shapes.below(101) - 50 + shift;
-                vy[i] = cy + (int)shapes.below(101) - 50;
+                vx[i] = cx + (int)shapes.below(101) - 50 + shift + dx;
+                vy[i] = cy + (int)shapes.below(101) - 50 + dy;
             }
             fill_tri(dst, width, height, stride, vx, vy, g);
             ti++;

@@ -142,3 +142,65 @@ class Oracle:
         d = np.zeros(32, np.uint8)
         self.lib.orbo_descriptor(_p(blur), blur.shape[1], int(x), int(y), ctypes.c_float(angle), _p(d))
         return d
+
+
+# ---- Hamming matcher restatements (oracle/match_oracle.cc) ----
+def _kp7(k):
+    """structured orbx keypoints -> 7-float rows as the oracles take them."""
+    return np.ascontiguousarray(np.stack([k["x"], k["y"], k["size"], k["angle"], k["response"], k["octave"].astype(np.float32),
+                                          k["class_id"].astype(np.float32)], 1), np.float32)
+
+
+def _opt(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dt)
+
+
+def search_by_bow(orc, mode, kpsA, descA, kpsB, descB, nnratio, check_ori, groupsA=None, groupsB=None, validA=None, validB=None):
+    lib = orc.lib
+    lib.mo_search_by_bow.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                     ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+    aA = np.ascontiguousarray(kpsA["angle"], np.float32)
+    aB = np.ascontiguousarray(kpsB["angle"], np.float32)
+    dA = np.ascontiguousarray(descA, np.uint8)
+    dB = np.ascontiguousarray(descB, np.uint8)
+    gA, gB, vA, vB = _opt(groupsA, np.int32), _opt(groupsB, np.int32), _opt(validA, np.uint8), _opt(validB, np.uint8)
+    nout = len(kpsB) if mode == 0 else len(kpsA)
+    out = np.full(max(nout, 1), -1, np.int32)
+    P = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    n = lib.mo_search_by_bow(mode, P(dA), P(aA), P(gA), P(vA), len(kpsA), P(dB), P(aB), P(gB), P(vB), len(kpsB),
+                             ctypes.c_float(nnratio), 1 if check_ori else 0, P(out))
+    return n, out[:nout]
+
+
+def stereo_hamming(orc, kpsL, descL, kpsR, descR, scale_factors, nrows, max_d):
+    lib = orc.lib
+    lib.mo_stereo_hamming.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    kl, kr = _kp7(kpsL), _kp7(kpsR)
+    dl, dr = np.ascontiguousarray(descL, np.uint8), np.ascontiguousarray(descR, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    bd = np.zeros(max(len(kl), 1), np.int32)
+    bi = np.zeros(max(len(kl), 1), np.int32)
+    lib.mo_stereo_hamming(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), _p(sf), nrows, ctypes.c_float(max_d), _p(bd), _p(bi))
+    return bd[:len(kl)], bi[:len(kl)]
+
+
+def descriptor_distance(orc, a, b):
+    return orc.lib.mo_descriptor_distance(_p(np.ascontiguousarray(a, np.uint8)), _p(np.ascontiguousarray(b, np.uint8)))
+
+
+# ---- LocalBundleAdjustment restatement (oracle/lba_oracle.cc) ----
+def local_bundle_adjustment(orc, w, stop=None):
+    lib = orc.lib
+    K, P, E = w["K"], w["P"], w["E"]
+    poses_out = np.zeros((K, 16), np.float32)
+    points_out = np.zeros((P, 3), np.float32)
+    chi2 = np.zeros(E, np.float64)
+    outl = np.zeros(E, np.uint8)
+    stats = np.zeros(8, np.float64)
+    lib.lo_local_bundle_adjustment.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 10
+    lib.lo_local_bundle_adjustment(K, _p(w["poses"]), _p(w["fixed"]), _p(w["intr"]), P, _p(w["points"]), E, _p(w["edge_point"]), _p(w["edge_kf"]),
+                                   _p(w["edge_obs"]), _p(w["edge_inv_sigma2"]), None if stop is None else _p(stop), _p(poses_out), _p(points_out),
+                                   _p(chi2), _p(outl), _p(stats))
+    return dict(poses=poses_out, points=points_out, chi2=chi2, outlier=outl, stats=stats)
