@@ -231,6 +231,50 @@ int orbx_stereo_match(orbx_matcher *m, const orbx_feature_set *left_host, const 
  * the previous orbx_matcher_last_timing (at most the last 64 calls). */
 int orbx_matcher_last_timing(orbx_matcher *m, float *total_ms);
 
+
+/* ------------------------------------------------------------------------------------
+ * Local bundle adjustment  ==  the numerical core of Optimizer::LocalBundleAdjustment
+ * (reference include/Optimizer.h:112, src/Optimizer.cc:629-997): g2o BlockSolver_6_3 +
+ * Levenberg-Marquardt with Schur complement, 5 robust (Huber) iterations, outlier
+ * re-classification, 10 non-robust iterations.  The class shim collects the local window
+ * from the KeyFrame/MapPoint graph (src/Optimizer.cc:634-853) into these flat arrays and
+ * writes poses/points/outliers back under the map mutex (:961-996).
+ * Precision at the boundary is float32 like the reference's cv::Mat (src/Converter.cc);
+ * everything inside is FP64.  Contract vs the CPU oracle: |delta| <= 1e-5.
+ * ---------------------------------------------------------------------------------- */
+typedef struct orbx_lba orbx_lba;
+
+typedef struct orbx_lba_problem {
+    int num_keyframes;            /* local + fixed keyframes                                      */
+    const float *poses;           /* [K*16] Tcw, row-major 4x4 (KeyFrame::GetPose)                */
+    const uint8_t *fixed;         /* [K] 1 = fixed vertex (lFixedCameras, or mnId==0)             */
+    const float *intrinsics;      /* [K*5] fx, fy, cx, cy, mbf                                    */
+    int num_points;
+    const float *points;          /* [P*3] MapPoint::GetWorldPos                                  */
+    int num_edges;                /* observations, in optimizer.addEdge order                     */
+    const int32_t *edge_point;    /* [E]                                                          */
+    const int32_t *edge_keyframe; /* [E]                                                          */
+    const float *edge_obs;        /* [E*3] kpUn.pt.x, kpUn.pt.y, mvuRight (<0: monocular edge)    */
+    const float *edge_inv_sigma2; /* [E] mvInvLevelSigma2[kpUn.octave]                            */
+} orbx_lba_problem;
+
+typedef struct orbx_lba_result {
+    float *poses;           /* [K*16] optimised Tcw (fixed keyframes returned unchanged)          */
+    float *points;          /* [P*3]                                                              */
+    double *edge_chi2;      /* [E] e->chi2() as read at src/Optimizer.cc:921-958 (may be NULL)     */
+    uint8_t *edge_outlier;  /* [E] 1 = goes to vToErase (chi2 > 5.991/7.815 or depth <= 0)          */
+    double stats[8];        /* stage1 {iterations, LM trials, chi2 start, chi2 end}, stage2 idem    */
+} orbx_lba_result;
+
+int orbx_lba_create(int device, int max_keyframes, int max_points, int max_edges, orbx_lba **out);
+void orbx_lba_destroy(orbx_lba *h);
+/* stop_flag == pbStopFlag (mbAbortBA): polled before starting, between LM iterations and
+ * between LM trials, like g2o's forceStopFlag; may be NULL. */
+int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *problem, const volatile uint8_t *stop_flag,
+                   orbx_lba_result *result);
+/* Kernel milliseconds (HIP events) spent inside the last orbx_lba_solve and FP64 flop count. */
+int orbx_lba_last_timing(orbx_lba *h, float *device_ms, double *flops);
+
 #ifdef __cplusplus
 }
 #endif

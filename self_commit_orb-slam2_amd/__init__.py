@@ -413,3 +413,74 @@ class ORBmatcher:
         t = ctypes.c_float()
         _check(self._L.orbx_matcher_last_timing(self._h, ctypes.byref(t)))
         return t.value
+
+
+# =====================================================================================
+# Optimizer::LocalBundleAdjustment numerical core over the C ABI
+# =====================================================================================
+class LbaProblem(ctypes.Structure):
+    _fields_ = [("num_keyframes", ctypes.c_int), ("poses", ctypes.c_void_p), ("fixed", ctypes.c_void_p), ("intrinsics", ctypes.c_void_p),
+                ("num_points", ctypes.c_int), ("points", ctypes.c_void_p), ("num_edges", ctypes.c_int), ("edge_point", ctypes.c_void_p),
+                ("edge_keyframe", ctypes.c_void_p), ("edge_obs", ctypes.c_void_p), ("edge_inv_sigma2", ctypes.c_void_p)]
+
+
+class LbaResult(ctypes.Structure):
+    _fields_ = [("poses", ctypes.c_void_p), ("points", ctypes.c_void_p), ("edge_chi2", ctypes.c_void_p), ("edge_outlier", ctypes.c_void_p),
+                ("stats", ctypes.c_double * 8)]
+
+
+def _load_lba_synth():
+    spec = importlib.util.spec_from_file_location("orbx_lba_synth", _PKG / "lba_synth.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+lba_synth = _load_lba_synth()
+
+
+class Optimizer:
+    """Mirror of the static ORB_SLAM2::Optimizer::LocalBundleAdjustment (reference include/Optimizer.h:112)
+    on a flat window (dict as produced by lba_synth.make_window)."""
+
+    def __init__(self, max_keyframes=256, max_points=20000, max_edges=400000, device=0):
+        self._L = load_library()
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        self._L.orbx_lba_create.argtypes = [ci, ci, ci, ci, ctypes.POINTER(vp)]
+        self._L.orbx_lba_destroy.argtypes = [vp]
+        self._L.orbx_lba_destroy.restype = None
+        self._L.orbx_lba_solve.argtypes = [vp, ctypes.POINTER(LbaProblem), vp, ctypes.POINTER(LbaResult)]
+        self._L.orbx_lba_last_timing.argtypes = [vp, vp, vp]
+        self._h = vp()
+        _check(self._L.orbx_lba_create(device, max_keyframes, max_points, max_edges, ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbx_lba_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def LocalBundleAdjustment(self, w, stop_flag=None):
+        K, P, E = w["K"], w["P"], w["E"]
+        arrs = {k: np.ascontiguousarray(w[k]) for k in ("poses", "fixed", "intr", "points", "edge_point", "edge_kf", "edge_obs", "edge_inv_sigma2")}
+        prob = LbaProblem(K, arrs["poses"].ctypes.data, arrs["fixed"].ctypes.data, arrs["intr"].ctypes.data, P, arrs["points"].ctypes.data, E,
+                          arrs["edge_point"].ctypes.data, arrs["edge_kf"].ctypes.data, arrs["edge_obs"].ctypes.data, arrs["edge_inv_sigma2"].ctypes.data)
+        poses = np.zeros((K, 16), np.float32)
+        points = np.zeros((P, 3), np.float32)
+        chi2 = np.zeros(E, np.float64)
+        outl = np.zeros(E, np.uint8)
+        res = LbaResult(poses.ctypes.data, points.ctypes.data, chi2.ctypes.data, outl.ctypes.data)
+        stop = None if stop_flag is None else stop_flag.ctypes.data_as(ctypes.c_void_p)
+        _check(self._L.orbx_lba_solve(self._h, ctypes.byref(prob), stop, ctypes.byref(res)))
+        return dict(poses=poses, points=points, chi2=chi2, outlier=outl, stats=np.array(list(res.stats)))
+
+    def last_timing(self):
+        ms = ctypes.c_float()
+        fl = ctypes.c_double()
+        _check(self._L.orbx_lba_last_timing(self._h, ctypes.byref(ms), ctypes.byref(fl)))
+        return ms.value, fl.value

@@ -1,0 +1,849 @@
+// orbx_lba.hip -- Optimizer::LocalBundleAdjustment's numerical core on gfx950, FP64.
+//
+// Reference: src/Optimizer.cc:698-958 driving g2o (BlockSolver_6_3, Levenberg-Marquardt,
+// Schur complement; Thirdparty/g2o/g2o/core/block_solver.hpp, optimization_algorithm_
+// levenberg.cpp, types/types_six_dof_expmap.cpp, types/se3quat.h).  Mapping:
+//   k_errors      computeActiveErrors + chi2 + Huber rho            (one thread per edge)
+//   k_linearize   linearizeOplus + constructQuadraticForm per edge  (one thread per edge;
+//                 the per-edge blocks J^T W J are written out, no atomics)
+//   k_sum_points  Hll / b_l per landmark  = fixed-order sum over its edges
+//   k_sum_poses   Hpp / b_p per free pose = fixed-order sum over its edges (one WG each)
+//   k_schur_init / k_schur_points   S = Hpp + lambda*I - sum_l B D^-1 B^T (one wave per
+//                 landmark, FP64 atomics into the dense 6Kx6K reduced system)
+//   k_chol_solve  dense Cholesky of S + forward/back substitution   (one workgroup)
+//   k_backsub     x_l = D^-1 (b_l - B^T x_p)                        (one thread per landmark)
+//   k_update      oplus: T <- exp(dx) T, X <- X + dx
+// The LM accept/reject logic runs on the host exactly as optimization_algorithm_
+// levenberg.cpp:61-164 (it needs three scalars per trial) and polls the stop flag like
+// g2o's forceStopFlag.  This path is latency bound (~60 MFLOP per iteration): the
+// deliverable is parity (<= 1e-5) plus keeping every O(E) stage on the device.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "orbx_internal.h"
+
+namespace {
+
+struct DQuat { double x, y, z, w; };
+struct DPose { DQuat q; double t[3]; };
+
+__host__ __device__ inline void quat_normalize_pos(DQuat &q)   // SE3Quat::normalizeRotation, se3quat.h:280-285
+{
+    if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+}
+
+__host__ __device__ inline DQuat quat_from_R(const double R[9])   // Eigen::Quaterniond(Matrix3d)
+{
+    DQuat q;
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (R[7] - R[5]) * t; q.y = (R[2] - R[6]) * t; q.z = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        double v[3];
+        v[i] = 0.5 * t;
+        t = 0.5 / t;
+        q.w = (R[3 * k + j] - R[3 * j + k]) * t;
+        v[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+        v[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    }
+    return q;
+}
+
+__host__ __device__ inline void quat_to_R(const DQuat &q, double R[9])
+{
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+__host__ __device__ inline void quat_rot(const DQuat &q, const double v[3], double o[3])
+{
+    const double ux = 2 * (q.y * v[2] - q.z * v[1]), uy = 2 * (q.z * v[0] - q.x * v[2]), uz = 2 * (q.x * v[1] - q.y * v[0]);
+    o[0] = v[0] + q.w * ux + (q.y * uz - q.z * uy);
+    o[1] = v[1] + q.w * uy + (q.z * ux - q.x * uz);
+    o[2] = v[2] + q.w * uz + (q.x * uy - q.y * ux);
+}
+
+__device__ inline DQuat quat_mul(const DQuat &a, const DQuat &b)
+{
+    DQuat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    return r;
+}
+
+__device__ inline void pose_map(const DPose &T, const double X[3], double o[3])
+{
+    quat_rot(T.q, X, o);
+    o[0] += T.t[0]; o[1] += T.t[1]; o[2] += T.t[2];
+}
+
+// SE3Quat::exp (se3quat.h:223-255) and exp(d)*T (types_six_dof_expmap.h:73-76)
+__device__ inline void pose_oplus(DPose &T, const double d[6])
+{
+    const double *om = d, *up = d + 3;
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double O2[9], R[9], V[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; i++) { R[i] = ((i % 4) == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3.0);
+        for (int i = 0; i < 9; i++) {
+            const double I = (i % 4) == 0 ? 1.0 : 0.0;
+            R[i] = I + a * O[i] + b * O2[i];
+            V[i] = I + b * O[i] + c * O2[i];
+        }
+    }
+    DPose E;
+    E.q = quat_from_R(R);
+    quat_normalize_pos(E.q);
+    for (int i = 0; i < 3; i++) E.t[i] = V[3 * i] * up[0] + V[3 * i + 1] * up[1] + V[3 * i + 2] * up[2];
+    double rt[3];
+    quat_rot(E.q, T.t, rt);
+    DPose N;
+    for (int i = 0; i < 3; i++) N.t[i] = E.t[i] + rt[i];
+    N.q = quat_mul(E.q, T.q);
+    quat_normalize_pos(N.q);
+    T = N;
+}
+
+struct LbaDev {   // device views, all sized by the handle
+    int K, P, E;
+    DPose *pose;
+    double *pt;                 // 3P
+    const double *intr;         // 5K
+    const int *ep, *ek;         // edge -> point / keyframe
+    const double *obs;          // 3E
+    const uint8_t *stereo;      // E
+    const double *info;         // E
+    const uint8_t *active;      // E  (level == 0)
+    const int *poseIdx;         // K: free-pose index or -1
+    const int *ptIdx;           // P: active landmark index or -1
+    double *err;                // 3E, _error as last computed
+    double *rchi;               // E, (robust) chi2 of active edges, 0 otherwise
+    double *edgeBlk;            // 54 per edge: Hll(6) bl(3) Hpp(21) bp(6) Hpl(18)
+};
+
+#define EB_HLL 0
+#define EB_BL 6
+#define EB_HPP 9
+#define EB_BP 30
+#define EB_HPL 36
+#define EB_SIZE 54
+
+// computeError (types_six_dof_expmap.h:90-95, 122-127; cam_project .cpp:141-157)
+__device__ inline void edge_error(const LbaDev &d, int e, double out[3], double *depth)
+{
+    const int k = d.ek[e], l = d.ep[e];
+    const double *in = d.intr + 5 * (size_t)k;
+    double Xc[3];
+    pose_map(d.pose[k], d.pt + 3 * (size_t)l, Xc);
+    if (depth) *depth = Xc[2];
+    if (!d.stereo[e]) {
+        const double u = Xc[0] / Xc[2] * in[0] + in[2], v = Xc[1] / Xc[2] * in[1] + in[3];
+        out[0] = d.obs[3 * (size_t)e] - u; out[1] = d.obs[3 * (size_t)e + 1] - v; out[2] = 0;
+    } else {
+        const float invz = (float)(1.0 / Xc[2]);             // float in the reference (.cpp:151)
+        const double u = Xc[0] * invz * in[0] + in[2], v = Xc[1] * invz * in[1] + in[3];
+        const float bfz = __fmul_rn((float)in[4], invz);     // bf passed as const float& (.cpp:150)
+        out[0] = d.obs[3 * (size_t)e] - u; out[1] = d.obs[3 * (size_t)e + 1] - v; out[2] = d.obs[3 * (size_t)e + 2] - (u - (double)bfz);
+    }
+}
+
+struct Huber { double dMono, dStereo, dsqrMono, dsqrStereo; };
+
+__device__ inline void huber_rho(const Huber &h, bool stereo, double chi, double &rho0, double &rho1)   // robust_kernel_impl.cpp:78-91
+{
+    const double delta = stereo ? h.dStereo : h.dMono, dsqr = stereo ? h.dsqrStereo : h.dsqrMono;
+    if (chi <= dsqr) { rho0 = chi; rho1 = 1.; }
+    else { const double s = sqrt(chi); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
+}
+
+__global__ __launch_bounds__(256) void k_errors(LbaDev d, Huber h, int robust)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.E) return;
+    if (!d.active[e]) { d.rchi[e] = 0; return; }   // _error of inactive edges stays as last computed
+    double r[3];
+    edge_error(d, e, r, nullptr);
+    d.err[3 * (size_t)e] = r[0]; d.err[3 * (size_t)e + 1] = r[1]; d.err[3 * (size_t)e + 2] = r[2];
+    const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * d.info[e];
+    double r0 = chi, r1 = 1;
+    if (robust) huber_rho(h, d.stereo[e] != 0, chi, r0, r1);
+    d.rchi[e] = r0;
+}
+
+// linearizeOplus (.cpp:103-139, 188-234) + constructQuadraticForm (base_binary_edge.hpp:55-119)
+__global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.E || !d.active[e]) return;
+    const int k = d.ek[e], l = d.ep[e];
+    const bool st = d.stereo[e] != 0;
+    const int D = st ? 3 : 2;
+    const double *in = d.intr + 5 * (size_t)k;
+    const double fx = in[0], fy = in[1], bf = in[4];
+    double Xc[3], R[9];
+    pose_map(d.pose[k], d.pt + 3 * (size_t)l, Xc);
+    quat_to_R(d.pose[k].q, R);
+    const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
+    double A[9], B[18];
+    for (int i = 0; i < 9; i++) A[i] = 0;
+    for (int i = 0; i < 18; i++) B[i] = 0;
+    if (!st) {
+        const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 3; j++) A[3 * i + j] = -1. / z * (tmp[3 * i] * R[j] + tmp[3 * i + 1] * R[3 + j] + tmp[3 * i + 2] * R[6 + j]);
+    } else {
+        for (int j = 0; j < 3; j++) {
+            A[j] = -fx * R[j] / z + fx * x * R[6 + j] / z_2;
+            A[3 + j] = -fy * R[3 + j] / z + fy * y * R[6 + j] / z_2;
+            A[6 + j] = A[j] - bf * R[6 + j] / z_2;
+        }
+    }
+    B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx; B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
+    B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy; B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
+    if (st) { B[12] = B[0] - bf * y / z_2; B[13] = B[1] + bf * x / z_2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bf / z_2; }
+    const double w = d.info[e];
+    const double *r = d.err + 3 * (size_t)e;
+    double rw = 1.0;
+    if (robust) { double r0; huber_rho(h, st, (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * w, r0, rw); }
+    const double W = rw * w;
+    double omr[3];
+    for (int i = 0; i < 3; i++) omr[i] = -w * r[i] * rw;
+    double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
+    int o = 0;
+    for (int i = 0; i < 3; i++)
+        for (int j = i; j < 3; j++) { double s = 0; for (int q = 0; q < D; q++) s += A[3 * q + i] * W * A[3 * q + j]; blk[EB_HLL + o++] = s; }
+    for (int i = 0; i < 3; i++) { double s = 0; for (int q = 0; q < D; q++) s += A[3 * q + i] * omr[q]; blk[EB_BL + i] = s; }
+    if (d.poseIdx[k] >= 0) {
+        o = 0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i; j < 6; j++) { double s = 0; for (int q = 0; q < D; q++) s += B[6 * q + i] * W * B[6 * q + j]; blk[EB_HPP + o++] = s; }
+        for (int i = 0; i < 6; i++) { double s = 0; for (int q = 0; q < D; q++) s += B[6 * q + i] * omr[q]; blk[EB_BP + i] = s; }
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 3; j++) { double s = 0; for (int q = 0; q < D; q++) s += B[6 * q + i] * W * A[3 * q + j]; blk[EB_HPL + 3 * i + j] = s; }
+    }
+}
+
+// Hll (9, full symmetric) and b_l (3) of every active landmark: its edges in insertion order
+__global__ __launch_bounds__(256) void k_sum_points(LbaDev d, const int *ptStart, const int *ptEdges, double *Hll, double *bl)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= d.P) return;
+    const int li = d.ptIdx[l];
+    if (li < 0) return;
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int s = ptStart[l]; s < ptStart[l + 1]; s++) {
+        const int e = ptEdges[s];
+        if (!d.active[e]) continue;
+        const double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
+        for (int i = 0; i < 6; i++) H[i] += blk[EB_HLL + i];
+        for (int i = 0; i < 3; i++) b[i] += blk[EB_BL + i];
+    }
+    double *o = Hll + (size_t)li * 9;
+    o[0] = H[0]; o[1] = H[1]; o[2] = H[2]; o[3] = H[1]; o[4] = H[3]; o[5] = H[4]; o[6] = H[2]; o[7] = H[4]; o[8] = H[5];
+    bl[(size_t)li * 3] = b[0]; bl[(size_t)li * 3 + 1] = b[1]; bl[(size_t)li * 3 + 2] = b[2];
+}
+
+// Hpp (36) and b_p (6) of every free pose: one workgroup per keyframe, fixed-shape tree reduction
+__global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart, const int *kfEdges, double *Hpp, double *bp)
+{
+    __shared__ double red[256];
+    const int k = blockIdx.x, pi = d.poseIdx[k];
+    if (pi < 0) return;
+    double acc[27];
+    for (int i = 0; i < 27; i++) acc[i] = 0;
+    for (int s = kfStart[k] + threadIdx.x; s < kfStart[k + 1]; s += 256) {
+        const int e = kfEdges[s];
+        if (!d.active[e]) continue;
+        const double *blk = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPP;
+        for (int i = 0; i < 27; i++) acc[i] += blk[i];
+    }
+    double tot[27];
+    for (int i = 0; i < 27; i++) {
+        red[threadIdx.x] = acc[i];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+        tot[i] = red[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double *H = Hpp + (size_t)pi * 36;
+        int o = 0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i; j < 6; j++) { H[6 * i + j] = tot[o]; H[6 * j + i] = tot[o]; o++; }
+        for (int i = 0; i < 6; i++) bp[(size_t)pi * 6 + i] = tot[21 + i];
+    }
+}
+
+// deterministic sum / max of an array with one workgroup: out[0] = sum, out[1] = max|.|
+__global__ __launch_bounds__(1024) void k_reduce(const double *v, int n, int stride, int offset, double *out)
+{
+    __shared__ double s[1024], m[1024];
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) { const double x = v[(size_t)i * stride + offset]; a += x; b = fmax(b, fabs(x)); }
+    s[threadIdx.x] = a; m[threadIdx.x] = b;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { s[threadIdx.x] += s[threadIdx.x + k]; m[threadIdx.x] = fmax(m[threadIdx.x], m[threadIdx.x + k]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = s[0]; out[1] = m[0]; }
+}
+
+// computeScale (optimization_algorithm_levenberg.cpp:182-189): sum x (lambda x + b) over one vector
+__global__ __launch_bounds__(1024) void k_scale(const double *x, const double *b, int n, double lambda, double *out)
+{
+    __shared__ double s[1024];
+    double a = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) a += x[i] * (lambda * x[i] + b[i]);
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) { if ((int)threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+
+// S = blockdiag(Hpp) + lambda*I ; bs = bp   (setLambda + "_Hpp->add(_Hschur)", block_solver.hpp:363-365, 564-589)
+__global__ __launch_bounds__(256) void k_schur_init(const double *Hpp, const double *bp, int nPose, double lambda, double *S, double *bs)
+{
+    const int n = 6 * nPose;
+    const size_t total = (size_t)n * n;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / n), c = (int)(idx % n);
+        double v = 0;
+        if (r / 6 == c / 6) { v = Hpp[(size_t)(r / 6) * 36 + 6 * (r % 6) + (c % 6)]; if (r == c) v += lambda; }
+        S[idx] = v;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) bs[i] = bp[i];
+}
+
+// per landmark: D^-1, D^-1 b_l, and its Schur contributions (block_solver.hpp:381-439).
+// One wave per landmark; lanes cover (edge pair, 6x6 entry); FP64 atomics into S / bs.
+#define SCHUR_MAX_OBS 64
+__global__ __launch_bounds__(256) void k_schur_points(LbaDev d, const int *ptStart, const int *ptEdges, const double *Hll, const double *bl, double lambda,
+                                                      int nP6, double *Dinv, double *S, double *bs)
+{
+    __shared__ double sBD[4][SCHUR_MAX_OBS * 18];
+    __shared__ int sPose[4][SCHUR_MAX_OBS], sEdge[4][SCHUR_MAX_OBS];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l = blockIdx.x * 4 + wv;
+    if (l >= d.P) return;
+    const int li = d.ptIdx[l];
+    if (li < 0) return;
+    double M[9], I[9];
+    for (int i = 0; i < 9; i++) M[i] = Hll[(size_t)li * 9 + i];
+    M[0] += lambda; M[4] += lambda; M[8] += lambda;
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0 / det;
+    I[0] = c00 * id; I[1] = (M[2] * M[7] - M[1] * M[8]) * id; I[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    I[3] = c01 * id; I[4] = (M[0] * M[8] - M[2] * M[6]) * id; I[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    I[6] = c02 * id; I[7] = (M[1] * M[6] - M[0] * M[7]) * id; I[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+    double db[3];
+    for (int i = 0; i < 3; i++) db[i] = I[3 * i] * bl[(size_t)li * 3] + I[3 * i + 1] * bl[(size_t)li * 3 + 1] + I[3 * i + 2] * bl[(size_t)li * 3 + 2];
+    if (lane < 9) Dinv[(size_t)li * 9 + lane] = I[lane];
+    // free-pose edges of this landmark, in insertion order
+    int n = 0;
+    for (int s = ptStart[l]; s < ptStart[l + 1]; s++) {
+        const int e = ptEdges[s];
+        if (!d.active[e]) continue;
+        const int pi = d.poseIdx[d.ek[e]];
+        if (pi < 0) continue;
+        if (n < SCHUR_MAX_OBS) { if (lane == 0) { sPose[wv][n] = pi; sEdge[wv][n] = e; } n++; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // BD = B * D^-1 (6x3 per edge), bs[i1] -= B * db
+    for (int t = lane; t < n * 6; t += 64) {
+        const int a = t / 6, r = t % 6;
+        const double *B1 = d.edgeBlk + (size_t)sEdge[wv][a] * EB_SIZE + EB_HPL + 3 * r;
+        for (int c = 0; c < 3; c++) sBD[wv][a * 18 + 3 * r + c] = B1[0] * I[c] + B1[1] * I[3 + c] + B1[2] * I[6 + c];
+        atomicAdd(&bs[6 * sPose[wv][a] + r], -(B1[0] * db[0] + B1[1] * db[1] + B1[2] * db[2]));
+    }
+    __builtin_amdgcn_wave_barrier();
+    // S[i1,i2] -= BD_1 * B_2^T for i2 >= i1 (upper triangular block pairs only)
+    const int work = n * n * 36;
+    for (int t = lane; t < work; t += 64) {
+        const int pr = t / 36, rc = t % 36, a1 = pr / n, a2 = pr % n, r = rc / 6, c = rc % 6;
+        const int i1 = sPose[wv][a1], i2 = sPose[wv][a2];
+        if (i2 < i1) continue;
+        const double *BD = sBD[wv] + a1 * 18 + 3 * r;
+        const double *B2 = d.edgeBlk + (size_t)sEdge[wv][a2] * EB_SIZE + EB_HPL + 3 * c;
+        atomicAdd(&S[(size_t)(6 * i1 + r) * nP6 + 6 * i2 + c], -(BD[0] * B2[0] + BD[1] * B2[1] + BD[2] * B2[2]));
+    }
+}
+
+#define CHOL_MAX_N 2048
+// Dense Cholesky of the (upper-authoritative) symmetric S, then S x = bs.  One workgroup.
+// LinearSolverEigen::solve (solvers/linear_solver_eigen.h:94-125) uses a sparse LDLT; the
+// reduced system is SPD here (lambda > 0), a failed pivot reports ok = 0 like info()!=Success.
+__global__ __launch_bounds__(1024) void k_chol_solve(double *S, const double *bs, int n, double *x, int *okFlag)
+{
+    __shared__ double sDiag;
+    __shared__ int sFail;
+    __shared__ double sx[CHOL_MAX_N];
+    const int tid = threadIdx.x;
+    if (tid == 0) sFail = 0;
+    // mirror the upper triangle into the lower one; work on the lower triangle (row-major: L[i][j], j<=i)
+    for (size_t idx = tid; idx < (size_t)n * n; idx += 1024) {
+        const int r = (int)(idx / n), c = (int)(idx % n);
+        if (r > c) S[idx] = S[(size_t)c * n + r];
+    }
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        if (tid == 0) {
+            const double dj = S[(size_t)j * n + j];
+            if (!(dj > 0) || !isfinite(dj)) sFail = 1;
+            sDiag = sqrt(dj);
+        }
+        __syncthreads();
+        if (sFail) break;
+        const double ljj = sDiag;
+        for (int i = j + 1 + tid; i < n; i += 1024) S[(size_t)i * n + j] /= ljj;
+        if (tid == 0) S[(size_t)j * n + j] = ljj;
+        __syncthreads();
+        // trailing update of the lower triangle: A[i][k] -= L[i][j] * L[k][j], j < k <= i
+        const int m = n - j - 1;
+        const int total = m * (m + 1) / 2;
+        for (int t = tid; t < total; t += 1024) {
+            // t -> (ii, kk) with 0 <= kk <= ii < m
+            int ii = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+            while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+            while (ii * (ii + 1) / 2 > t) ii--;
+            const int kk = t - ii * (ii + 1) / 2;
+            const int i = j + 1 + ii, k = j + 1 + kk;
+            S[(size_t)i * n + k] -= S[(size_t)i * n + j] * S[(size_t)k * n + j];
+        }
+        __syncthreads();
+    }
+    if (sFail) { if (tid == 0) *okFlag = 0; return; }
+    // forward then backward substitution by wave 0 (lock-step; the vector lives in LDS)
+    if (tid < 64) {
+        for (int i = tid; i < n; i += 64) sx[i] = bs[i];
+        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < n; j++) {
+            const double yj = sx[j] / S[(size_t)j * n + j];
+            __builtin_amdgcn_wave_barrier();
+            if (tid == 0) sx[j] = yj;
+            for (int i = j + 1 + tid; i < n; i += 64) sx[i] -= S[(size_t)i * n + j] * yj;
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int j = n - 1; j >= 0; j--) {
+            const double xj = sx[j] / S[(size_t)j * n + j];
+            __builtin_amdgcn_wave_barrier();
+            if (tid == 0) sx[j] = xj;
+            for (int i = tid; i < j; i += 64) sx[i] -= S[(size_t)j * n + i] * xj;
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int i = tid; i < n; i += 64) x[i] = sx[i];
+        if (tid == 0) *okFlag = 1;
+    }
+}
+
+// x_l = D^-1 (b_l - B^T x_p)   (block_solver.hpp:459-481)
+__global__ __launch_bounds__(256) void k_backsub(LbaDev d, const int *ptStart, const int *ptEdges, const double *bl, const double *Dinv, const double *xp,
+                                                 double *xl)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= d.P) return;
+    const int li = d.ptIdx[l];
+    if (li < 0) return;
+    double c[3] = {bl[(size_t)li * 3], bl[(size_t)li * 3 + 1], bl[(size_t)li * 3 + 2]};
+    for (int s = ptStart[l]; s < ptStart[l + 1]; s++) {
+        const int e = ptEdges[s];
+        if (!d.active[e]) continue;
+        const int pi = d.poseIdx[d.ek[e]];
+        if (pi < 0) continue;
+        const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL;
+        for (int q = 0; q < 3; q++) { double acc = 0; for (int r = 0; r < 6; r++) acc += B1[3 * r + q] * xp[6 * pi + r]; c[q] -= acc; }
+    }
+    const double *I = Dinv + (size_t)li * 9;
+    for (int i = 0; i < 3; i++) xl[(size_t)li * 3 + i] = I[3 * i] * c[0] + I[3 * i + 1] * c[1] + I[3 * i + 2] * c[2];
+}
+
+__global__ __launch_bounds__(256) void k_update(LbaDev d, const double *xp, const double *xl)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < d.K) {
+        const int pi = d.poseIdx[t];
+        if (pi >= 0) { DPose T = d.pose[t]; pose_oplus(T, xp + 6 * pi); d.pose[t] = T; }
+    }
+    if (t < d.P) {
+        const int li = d.ptIdx[t];
+        if (li >= 0) for (int i = 0; i < 3; i++) d.pt[3 * (size_t)t + i] += xl[(size_t)li * 3 + i];
+    }
+}
+
+template <typename T> struct LBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n) return ORBX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        ORBX_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+        return ORBX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct orbx_lba {
+    int device = 0, maxK = 0, maxP = 0, maxE = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    double flops = 0;
+    LBuf<DPose> pose, poseBak;
+    LBuf<double> pt, ptBak, intr, obs, info, err, rchi, edgeBlk, Hpp, bp, Hll, bl, Dinv, S, bs, xp, xl, red;
+    LBuf<int> ep, ek, ptStart, ptEdges, kfStart, kfEdges, poseIdx, ptIdx, okFlag;
+    LBuf<uint8_t> stereo, active;
+};
+
+extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, int max_edges, orbx_lba **out)
+{
+    if (!out || max_keyframes < 1 || max_points < 1 || max_edges < 1) { orbx_set_error("bad LBA sizes"); return ORBX_ERR_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { orbx_set_error("no HIP device available: liborbx has no CPU fallback"); return ORBX_ERR_NODEVICE; }
+    if (device < 0 || device >= ndev) { orbx_set_error("device %d out of range", device); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(device));
+    orbx_lba *h = new orbx_lba();
+    h->device = device; h->maxK = max_keyframes; h->maxP = max_points; h->maxE = max_edges;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
+    (void)hipEventCreate(&h->ev0);
+    (void)hipEventCreate(&h->ev1);
+    const size_t K = (size_t)max_keyframes, P = (size_t)max_points, E = (size_t)max_edges, n6 = 6 * K;
+    int rc = 0;
+    rc = rc ? rc : h->pose.ensure(K); rc = rc ? rc : h->poseBak.ensure(K); rc = rc ? rc : h->pt.ensure(3 * P); rc = rc ? rc : h->ptBak.ensure(3 * P);
+    rc = rc ? rc : h->intr.ensure(5 * K); rc = rc ? rc : h->obs.ensure(3 * E); rc = rc ? rc : h->info.ensure(E); rc = rc ? rc : h->err.ensure(3 * E);
+    rc = rc ? rc : h->rchi.ensure(E); rc = rc ? rc : h->edgeBlk.ensure(E * EB_SIZE); rc = rc ? rc : h->Hpp.ensure(36 * K); rc = rc ? rc : h->bp.ensure(n6);
+    rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->S.ensure(n6 * n6);
+    rc = rc ? rc : h->bs.ensure(n6); rc = rc ? rc : h->xp.ensure(n6); rc = rc ? rc : h->xl.ensure(3 * P); rc = rc ? rc : h->red.ensure(16);
+    rc = rc ? rc : h->ep.ensure(E); rc = rc ? rc : h->ek.ensure(E); rc = rc ? rc : h->ptStart.ensure(P + 1); rc = rc ? rc : h->ptEdges.ensure(E);
+    rc = rc ? rc : h->kfStart.ensure(K + 1); rc = rc ? rc : h->kfEdges.ensure(E); rc = rc ? rc : h->poseIdx.ensure(K); rc = rc ? rc : h->ptIdx.ensure(P);
+    rc = rc ? rc : h->okFlag.ensure(1); rc = rc ? rc : h->stereo.ensure(E); rc = rc ? rc : h->active.ensure(E);
+    if (rc) { orbx_lba_destroy(h); return rc; }
+    *out = h;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_lba_destroy(orbx_lba *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->pose.release(); h->poseBak.release(); h->pt.release(); h->ptBak.release(); h->intr.release(); h->obs.release(); h->info.release(); h->err.release();
+    h->rchi.release(); h->edgeBlk.release(); h->Hpp.release(); h->bp.release(); h->Hll.release(); h->bl.release(); h->Dinv.release(); h->S.release();
+    h->bs.release(); h->xp.release(); h->xl.release(); h->red.release(); h->ep.release(); h->ek.release(); h->ptStart.release(); h->ptEdges.release();
+    h->kfStart.release(); h->kfEdges.release(); h->poseIdx.release(); h->ptIdx.release(); h->okFlag.release(); h->stereo.release(); h->active.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+namespace {
+
+#define LCHECK()                                                                                                   \
+    do {                                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                                         \
+        if (e_ != hipSuccess) { orbx_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); return ORBX_ERR_HIP; } \
+    } while (0)
+
+struct Ctx {
+    orbx_lba *h;
+    LbaDev d;
+    Huber hub;
+    int robust;
+    int nPose, nPt;
+    const volatile uint8_t *stop;
+    std::vector<uint8_t> level;   // host copy
+    std::vector<int> ep, ek;
+    std::vector<uint8_t> fixed;
+};
+
+int reduce2(Ctx &c, const double *v, int n, int stride, int offset, double out[2])
+{
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, c.h->stream, v, n, stride, offset, c.h->red.p);
+    LCHECK();
+    ORBX_HIP_CHECK(hipMemcpyAsync(out, c.h->red.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c.h->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(c.h->stream));
+    return ORBX_OK;
+}
+
+int errors_and_chi(Ctx &c, double *chi)
+{
+    hipLaunchKernelGGL(k_errors, dim3((unsigned)((c.d.E + 255) / 256)), dim3(256), 0, c.h->stream, c.d, c.hub, c.robust);
+    LCHECK();
+    double o[2];
+    int rc = reduce2(c, c.h->rchi.p, c.d.E, 1, 0, o);
+    *chi = o[0];
+    return rc;
+}
+
+// SparseOptimizer::optimize(iterations) on the edges of level 0 (see oracle/lba_oracle.cc for the CPU twin)
+int optimize(Ctx &c, int iterations, double stats[4])
+{
+    orbx_lba *h = c.h;
+    const int K = c.d.K, P = c.d.P, E = c.d.E;
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    // initializeOptimization(0): active edges/vertices and the index mapping (sparse_optimizer.cpp:166-267)
+    std::vector<uint8_t> active((size_t)E);
+    std::vector<int> poseIdx((size_t)K, -1), ptIdx((size_t)P, -1);
+    std::vector<char> pAct((size_t)K, 0), lAct((size_t)P, 0);
+    int nAct = 0;
+    for (int e = 0; e < E; e++) { active[(size_t)e] = c.level[(size_t)e] == 0; if (active[(size_t)e]) { pAct[(size_t)c.ek[(size_t)e]] = 1; lAct[(size_t)c.ep[(size_t)e]] = 1; nAct++; } }
+    int nPose = 0, nPt = 0;
+    for (int k = 0; k < K; k++) if (pAct[(size_t)k] && !c.fixed[(size_t)k]) poseIdx[(size_t)k] = nPose++;
+    for (int l = 0; l < P; l++) if (lAct[(size_t)l]) ptIdx[(size_t)l] = nPt++;
+    if (nAct == 0 || nPose + nPt == 0) return ORBX_OK;
+    if (6 * nPose > CHOL_MAX_N) { orbx_set_error("%d free keyframes exceed the dense solver limit %d", nPose, CHOL_MAX_N / 6); return ORBX_ERR_CAPACITY; }
+    c.nPose = nPose; c.nPt = nPt;
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->active.p, active.data(), (size_t)E, hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->poseIdx.p, poseIdx.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->ptIdx.p, ptIdx.data(), (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    const int nP6 = 6 * nPose, nL3 = 3 * nPt;
+    const unsigned gE = (unsigned)((E + 255) / 256), gP = (unsigned)((P + 255) / 256);
+    double lambda = 0, ni = 2;
+    int nBad = 0;
+    bool ok = true;
+    for (int it = 0; it < iterations && !(c.stop && *c.stop) && ok; it++) {
+        double currentChi;
+        int rc = errors_and_chi(c, &currentChi);
+        if (rc) return rc;
+        const double iniChi = currentChi;
+        if (it == 0) stats[2] = currentChi;
+        hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
+        LCHECK();
+        hipLaunchKernelGGL(k_sum_points, dim3(gP), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p);
+        LCHECK();
+        hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->Hpp.p, h->bp.p);
+        LCHECK();
+        h->flops += 400.0 * nAct;
+        if (it == 0) {   // computeLambdaInit: tau * max |diag H| (:166-180)
+            double mx = 0, o[2];
+            for (int j = 0; j < 6 && nPose > 0; j++) { if ((rc = reduce2(c, h->Hpp.p, nPose, 36, 7 * j, o))) return rc; mx = std::max(mx, o[1]); }
+            for (int j = 0; j < 3 && nPt > 0; j++) { if ((rc = reduce2(c, h->Hll.p, nPt, 9, 4 * j, o))) return rc; mx = std::max(mx, o[1]); }
+            lambda = 1e-5 * mx; ni = 2; nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            // push()
+            ORBX_HIP_CHECK(hipMemcpyAsync(h->poseBak.p, h->pose.p, (size_t)K * sizeof(DPose), hipMemcpyDeviceToDevice, h->stream));
+            ORBX_HIP_CHECK(hipMemcpyAsync(h->ptBak.p, h->pt.p, (size_t)P * 3 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            int okHost = 1;
+            if (nP6 > 0) {
+                hipLaunchKernelGGL(k_schur_init, dim3(256), dim3(256), 0, h->stream, h->Hpp.p, h->bp.p, nPose, lambda, h->S.p, h->bs.p);
+                LCHECK();
+            }
+            hipLaunchKernelGGL(k_schur_points, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p, lambda,
+                               nP6, h->Dinv.p, h->S.p, h->bs.p);
+            LCHECK();
+            if (nP6 > 0) {
+                hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p);
+                LCHECK();
+                h->flops += (double)nP6 * nP6 * nP6 / 3.0;
+            }
+            hipLaunchKernelGGL(k_backsub, dim3(gP), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->bl.p, h->Dinv.p, h->xp.p, h->xl.p);
+            LCHECK();
+            hipLaunchKernelGGL(k_update, dim3((unsigned)((std::max(K, P) + 255) / 256)), dim3(256), 0, h->stream, c.d, h->xp.p, h->xl.p);
+            LCHECK();
+            h->flops += 250.0 * nAct;
+            double tempChi;
+            if ((rc = errors_and_chi(c, &tempChi))) return rc;
+            if (nP6 > 0) ORBX_HIP_CHECK(hipMemcpy(&okHost, h->okFlag.p, sizeof(int), hipMemcpyDeviceToHost));
+            if (!okHost) tempChi = std::numeric_limits<double>::max();
+            double scale = 0, o1 = 0, o2 = 0;
+            if (nP6 > 0) {
+                hipLaunchKernelGGL(k_scale, dim3(1), dim3(1024), 0, h->stream, h->xp.p, h->bp.p, nP6, lambda, h->red.p + 4);
+                LCHECK();
+            }
+            hipLaunchKernelGGL(k_scale, dim3(1), dim3(1024), 0, h->stream, h->xl.p, h->bl.p, nL3, lambda, h->red.p + 5);
+            LCHECK();
+            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+            if (nP6 > 0) ORBX_HIP_CHECK(hipMemcpy(&o1, h->red.p + 4, sizeof(double), hipMemcpyDeviceToHost));
+            ORBX_HIP_CHECK(hipMemcpy(&o2, h->red.p + 5, sizeof(double), hipMemcpyDeviceToHost));
+            scale = o1 + o2 + 1e-3;
+            rho = (currentChi - tempChi) / scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                // pop(): estimates restored; _error keeps the values of the rejected trial (as in g2o)
+                ORBX_HIP_CHECK(hipMemcpyAsync(h->pose.p, h->poseBak.p, (size_t)K * sizeof(DPose), hipMemcpyDeviceToDevice, h->stream));
+                ORBX_HIP_CHECK(hipMemcpyAsync(h->pt.p, h->ptBak.p, (size_t)P * 3 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            }
+            qmax++;
+            stats[1] += 1;
+        } while (rho < 0 && qmax < 10 && !(c.stop && *c.stop));
+        stats[0] += 1;
+        stats[3] = currentChi;
+        if (qmax == 10 || rho == 0) { ok = false; continue; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) ok = false;
+    }
+    return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_t *stop, orbx_lba_result *res)
+{
+    if (!h || !p || !res || !res->poses || !res->points || !res->edge_outlier) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    const int K = p->num_keyframes, P = p->num_points, E = p->num_edges;
+    if (K < 1 || P < 1 || E < 1 || K > h->maxK || P > h->maxP || E > h->maxE) { orbx_set_error("problem size %d/%d/%d outside the handle's capacity %d/%d/%d", K, P, E, h->maxK, h->maxP, h->maxE); return ORBX_ERR_CAPACITY; }
+    if (!p->poses || !p->fixed || !p->intrinsics || !p->points || !p->edge_point || !p->edge_keyframe || !p->edge_obs || !p->edge_inv_sigma2) { orbx_set_error("NULL problem array"); return ORBX_ERR_ARG; }
+    for (int e = 0; e < E; e++)
+        if (p->edge_point[e] < 0 || p->edge_point[e] >= P || p->edge_keyframe[e] < 0 || p->edge_keyframe[e] >= K) { orbx_set_error("edge %d references a vertex out of range", e); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(h->device));
+    for (int i = 0; i < 8; i++) res->stats[i] = 0;
+    h->flops = 0;
+    // ---- host marshalling: float boundary -> double state (Converter::toSE3Quat / toVector3d) ----
+    std::vector<DPose> pose((size_t)K);
+    std::vector<double> intr((size_t)5 * K), pt((size_t)3 * P), obs((size_t)3 * E), info((size_t)E);
+    std::vector<uint8_t> stereo((size_t)E);
+    for (int k = 0; k < K; k++) {
+        double R[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = p->poses[16 * (size_t)k + 4 * i + j];
+        pose[(size_t)k].q = quat_from_R(R);
+        quat_normalize_pos(pose[(size_t)k].q);
+        for (int i = 0; i < 3; i++) pose[(size_t)k].t[i] = p->poses[16 * (size_t)k + 4 * i + 3];
+        for (int i = 0; i < 5; i++) intr[5 * (size_t)k + i] = p->intrinsics[5 * (size_t)k + i];
+    }
+    for (int i = 0; i < 3 * P; i++) pt[(size_t)i] = p->points[i];
+    Ctx c;
+    c.h = h; c.stop = stop;
+    c.ep.assign(p->edge_point, p->edge_point + E); c.ek.assign(p->edge_keyframe, p->edge_keyframe + E);
+    c.fixed.assign(p->fixed, p->fixed + K);
+    c.level.assign((size_t)E, 0);
+    for (int e = 0; e < E; e++) {
+        for (int i = 0; i < 3; i++) obs[3 * (size_t)e + i] = p->edge_obs[3 * (size_t)e + i];
+        stereo[(size_t)e] = !(p->edge_obs[3 * (size_t)e + 2] < 0);
+        info[(size_t)e] = p->edge_inv_sigma2[e];
+    }
+    // CSR by landmark and by keyframe, edges in insertion order
+    std::vector<int> ptStart((size_t)P + 1, 0), kfStart((size_t)K + 1, 0), ptEdges((size_t)E), kfEdges((size_t)E);
+    for (int e = 0; e < E; e++) { ptStart[(size_t)c.ep[(size_t)e] + 1]++; kfStart[(size_t)c.ek[(size_t)e] + 1]++; }
+    for (int l = 0; l < P; l++) ptStart[(size_t)l + 1] += ptStart[(size_t)l];
+    for (int k = 0; k < K; k++) kfStart[(size_t)k + 1] += kfStart[(size_t)k];
+    {
+        std::vector<int> fp(ptStart.begin(), ptStart.end() - 1), fk(kfStart.begin(), kfStart.end() - 1);
+        for (int e = 0; e < E; e++) { ptEdges[(size_t)fp[(size_t)c.ep[(size_t)e]]++] = e; kfEdges[(size_t)fk[(size_t)c.ek[(size_t)e]]++] = e; }
+    }
+    for (int l = 0; l < P; l++)
+        if (ptStart[(size_t)l + 1] - ptStart[(size_t)l] > SCHUR_MAX_OBS) { orbx_set_error("point %d has more than %d observations", l, SCHUR_MAX_OBS); return ORBX_ERR_CAPACITY; }
+    hipStream_t s = h->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->pose.p, pose.data(), (size_t)K * sizeof(DPose), hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->pt.p, pt.data(), pt.size() * 8, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->intr.p, intr.data(), intr.size() * 8, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->obs.p, obs.data(), obs.size() * 8, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->info.p, info.data(), info.size() * 8, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->stereo.p, stereo.data(), (size_t)E, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->ep.p, c.ep.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->ek.p, c.ek.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->ptStart.p, ptStart.data(), ptStart.size() * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->ptEdges.p, ptEdges.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->kfStart.p, kfStart.data(), kfStart.size() * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->kfEdges.p, kfEdges.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemsetAsync(h->err.p, 0, (size_t)E * 3 * 8, s));
+    ORBX_HIP_CHECK(hipStreamSynchronize(s));
+    LbaDev &d = c.d;
+    d.K = K; d.P = P; d.E = E; d.pose = h->pose.p; d.pt = h->pt.p; d.intr = h->intr.p; d.ep = h->ep.p; d.ek = h->ek.p; d.obs = h->obs.p;
+    d.stereo = h->stereo.p; d.info = h->info.p; d.active = h->active.p; d.poseIdx = h->poseIdx.p; d.ptIdx = h->ptIdx.p; d.err = h->err.p;
+    d.rchi = h->rchi.p; d.edgeBlk = h->edgeBlk.p;
+    const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);   // floats in the reference (src/Optimizer.cc:781-782)
+    c.hub.dMono = thMono; c.hub.dStereo = thStereo;
+    c.hub.dsqrMono = (double)(float)((double)thMono * (double)thMono);        // `float dsqr` member (robust_kernel_impl.h:84)
+    c.hub.dsqrStereo = (double)(float)((double)thStereo * (double)thStereo);
+    ORBX_HIP_CHECK(hipEventRecord(h->ev0, s));
+    std::vector<double> err((size_t)3 * E, 0.0);
+    auto classify = [&](std::vector<uint8_t> &flag, double *chiOut) -> int {
+        // e->chi2() from the stored _error and isDepthPositive() from the CURRENT estimates (src/Optimizer.cc:880-958)
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+        ORBX_HIP_CHECK(hipMemcpy(err.data(), h->err.p, err.size() * 8, hipMemcpyDeviceToHost));
+        ORBX_HIP_CHECK(hipMemcpy(pose.data(), h->pose.p, (size_t)K * sizeof(DPose), hipMemcpyDeviceToHost));
+        ORBX_HIP_CHECK(hipMemcpy(pt.data(), h->pt.p, pt.size() * 8, hipMemcpyDeviceToHost));
+        for (int e = 0; e < E; e++) {
+            const double *r = &err[3 * (size_t)e];
+            const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * info[(size_t)e];
+            double Xc[3];
+            quat_rot(pose[(size_t)c.ek[(size_t)e]].q, &pt[3 * (size_t)c.ep[(size_t)e]], Xc);
+            const double z = Xc[2] + pose[(size_t)c.ek[(size_t)e]].t[2];
+            const double th = stereo[(size_t)e] ? 7.815 : 5.991;
+            flag[(size_t)e] = (chi > th || !(z > 0.0)) ? 1 : 0;
+            if (chiOut) chiOut[e] = chi;
+        }
+        return ORBX_OK;
+    };
+    int rc = ORBX_OK;
+    std::vector<uint8_t> flag((size_t)E, 0);
+    if (!(stop && *stop)) {
+        c.robust = 1;
+        if ((rc = optimize(c, 5, res->stats)) != ORBX_OK) return rc;       // :863-864
+        if (!(stop && *stop)) {
+            if ((rc = classify(flag, nullptr)) != ORBX_OK) return rc;        // :880-912
+            for (int e = 0; e < E; e++) if (flag[(size_t)e]) c.level[(size_t)e] = 1;
+            c.robust = 0;
+            if ((rc = optimize(c, 10, res->stats + 4)) != ORBX_OK) return rc;   // :916-917
+        }
+    }
+    ORBX_HIP_CHECK(hipEventRecord(h->ev1, s));
+    h->timed = true;
+    if ((rc = classify(flag, res->edge_chi2)) != ORBX_OK) return rc;          // :921-958
+    for (int e = 0; e < E; e++) res->edge_outlier[e] = flag[(size_t)e];
+    for (int k = 0; k < K; k++) {                                             // Converter::toCvMat(SE3Quat)
+        double R[9];
+        quat_to_R(pose[(size_t)k].q, R);
+        float *o = res->poses + 16 * (size_t)k;
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o[4 * i + j] = (float)R[3 * i + j]; o[4 * i + 3] = (float)pose[(size_t)k].t[i]; }
+        o[12] = o[13] = o[14] = 0.f; o[15] = 1.f;
+    }
+    for (int i = 0; i < 3 * P; i++) res->points[i] = (float)pt[(size_t)i];
+    return ORBX_OK;
+}
+
+extern "C" int orbx_lba_last_timing(orbx_lba *h, float *device_ms, double *flops)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!h->timed) { orbx_set_error("no solve yet"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->device));
+    ORBX_HIP_CHECK(hipEventSynchronize(h->ev1));
+    if (device_ms) ORBX_HIP_CHECK(hipEventElapsedTime(device_ms, h->ev0, h->ev1));
+    if (flops) *flops = h->flops;
+    return ORBX_OK;
+}

@@ -1,0 +1,151 @@
+"""Local bundle adjustment: the CPU oracle is pinned by (a) analytic Jacobians vs central
+differences and (b) an independent scipy solve of a small window; the HIP path is compared
+to the oracle to 1e-5 (poses, points, residual chi2), as BASELINE.json's north_star states."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+TOL = 1e-5
+
+
+def _P(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _edge_eval(orc, pose, intr, X, obs):
+    err = np.zeros(3)
+    A = np.zeros(9)
+    B = np.zeros(18)
+    orc.lib.lo_edge_eval(_P(pose), _P(intr), _P(X), _P(obs), _P(err), _P(A), _P(B))
+    return err, A.reshape(3, 3), B.reshape(3, 6)
+
+
+def _edge_perturbed(orc, pose, intr, X, obs, d6, dx3):
+    err = np.zeros(3)
+    orc.lib.lo_edge_error_perturbed(_P(pose), _P(intr), _P(X), _P(obs), _P(np.ascontiguousarray(d6)), _P(np.ascontiguousarray(dx3)), _P(err))
+    return err
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_oracle_jacobians_match_central_differences(orbx, oracle, stereo):
+    """g2o ships the numeric fallback (base_binary_edge.hpp:130-199); the analytic Jacobians
+    restated from types_six_dof_expmap.cpp must agree with it."""
+    w = orbx.lba_synth.make_window(K=6, P=40, seed=3, stereo_frac=1.0 if stereo else 0.0, n_fixed=1)
+    rng = np.random.default_rng(0)
+    for e in rng.choice(w["E"], 20, replace=False):
+        pose = w["poses"][w["edge_kf"][e]].copy()
+        intr = w["intr"][w["edge_kf"][e]].copy()
+        X = w["points"][w["edge_point"][e]].astype(np.float64)
+        obs = w["edge_obs"][e].copy()
+        err, A, B = _edge_eval(oracle, pose, intr, X, obs)
+        D = 3 if stereo else 2
+        h = 1e-3 if stereo else 1e-6   # the stereo edge rounds 1/z to float32 (types_six_dof_expmap.cpp:151): needs a coarse step
+        for j in range(3):
+            dx = np.zeros(3); dx[j] = h
+            num = (_edge_perturbed(oracle, pose, intr, X, obs, np.zeros(6), dx) - _edge_perturbed(oracle, pose, intr, X, obs, np.zeros(6), -dx)) / (2 * h)
+            assert np.allclose(num[:D], A[:D, j], rtol=1e-3 if stereo else 1e-5, atol=5e-2 if stereo else 1e-4)
+        for j in range(6):
+            d = np.zeros(6); d[j] = h
+            num = (_edge_perturbed(oracle, pose, intr, X, obs, d, np.zeros(3)) - _edge_perturbed(oracle, pose, intr, X, obs, -d, np.zeros(3))) / (2 * h)
+            assert np.allclose(num[:D], B[:D, j], rtol=1e-3 if stereo else 1e-5, atol=2e-1 if stereo else 1e-3)
+
+
+def test_oracle_reaches_the_scipy_optimum(orbx, oracle):
+    """No outliers, no robust kernel effect: the LM restatement must land on the same
+    least-squares optimum as an independent scipy solve of the same residuals."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    w = orbx.lba_synth.make_window(K=6, P=60, seed=5, outlier_frac=0.0, n_fixed=2, max_obs=6)
+    r = oracle_lib.local_bundle_adjustment(oracle, w)
+    assert r["outlier"].sum() <= 0.05 * w["E"]
+    K, P = w["K"], w["P"]
+    free = [k for k in range(K) if not w["fixed"][k]]
+    keep = r["outlier"] == 0           # stage 2 of the reference only uses the inliers
+
+    def unpack(x):
+        poses = w["poses"].reshape(K, 4, 4).astype(np.float64).copy()
+        for i, k in enumerate(free):
+            rv, t = x[6 * i:6 * i + 3], x[6 * i + 3:6 * i + 6]
+            poses[k, :3, :3] = Rotation.from_rotvec(rv).as_matrix()
+            poses[k, :3, 3] = t
+        pts = x[6 * len(free):].reshape(P, 3)
+        return poses, pts
+
+    def resid(x):
+        poses, pts = unpack(x)
+        k, l = w["edge_kf"][keep], w["edge_point"][keep]
+        Xc = np.einsum("eij,ej->ei", poses[k, :3, :3], pts[l]) + poses[k, :3, 3]
+        intr = w["intr"][k].astype(np.float64)
+        u = intr[:, 0] * Xc[:, 0] / Xc[:, 2] + intr[:, 2]
+        v = intr[:, 1] * Xc[:, 1] / Xc[:, 2] + intr[:, 3]
+        s = np.sqrt(w["edge_inv_sigma2"][keep].astype(np.float64))
+        return np.concatenate([(w["edge_obs"][keep, 0] - u) * s, (w["edge_obs"][keep, 1] - v) * s])
+
+    x0 = []
+    P0 = r["poses"].reshape(K, 4, 4).astype(np.float64)
+    for k in free:
+        x0 += list(Rotation.from_matrix(P0[k, :3, :3]).as_rotvec()) + list(P0[k, :3, 3])
+    x0 = np.array(x0 + list(r["points"].astype(np.float64).ravel()))
+    c0 = (resid(x0) ** 2).sum()
+    sol = least_squares(resid, x0, method="trf", xtol=1e-12, ftol=1e-12, gtol=1e-12, max_nfev=200)
+    c1 = (sol.fun ** 2).sum()
+    # the oracle's 10 LM iterations are already at the optimum scipy converges to
+    assert c1 <= c0 * (1 + 1e-9)
+    assert (c0 - c1) / c0 < 2e-3, (c0, c1)
+    # and chi2 reported by the oracle is the same objective
+    assert abs(r["chi2"][keep].sum() - c0) / c0 < 1e-4
+
+
+def test_oracle_stage_protocol(orbx, oracle):
+    w = orbx.lba_synth.make_window(K=12, P=400, seed=9)
+    r = oracle_lib.local_bundle_adjustment(oracle, w)
+    s = r["stats"]
+    assert 1 <= s[0] <= 5 and 1 <= s[4] <= 10          # optimize(5) then optimize(10), src/Optimizer.cc:863-917
+    assert s[3] < s[2] and s[7] <= s[6]                # robust chi2 decreases in both stages
+    gross = 0.05 * w["E"]
+    assert 0.5 * gross < r["outlier"].sum() < 4 * gross
+    # fixed keyframes come back unchanged, free ones moved towards the truth
+    fx = w["fixed"].astype(bool)
+    assert np.allclose(r["poses"][fx], w["poses"][fx], atol=1e-6)
+    assert np.abs(r["poses"][~fx] - w["true_poses"][~fx]).max() < np.abs(w["poses"][~fx] - w["true_poses"][~fx]).max()
+    # stop flag set before the call: nothing is optimised
+    stop = np.array([1], np.uint8)
+    r2 = oracle_lib.local_bundle_adjustment(oracle, w, stop=stop)
+    assert np.allclose(r2["points"], w["points"]) and r2["stats"][0] == 0
+
+
+def _compare(got, want, w):
+    dp = np.abs(got["poses"].astype(np.float64) - want["poses"]).max()
+    dx = np.abs(got["points"].astype(np.float64) - want["points"]).max()
+    assert dp <= TOL, "pose delta %g" % dp
+    assert dx <= TOL, "point delta %g" % dx
+    assert (got["stats"][[0, 1, 4, 5]] == want["stats"][[0, 1, 4, 5]]).all(), (got["stats"], want["stats"])   # same LM path
+    rel = np.abs(got["stats"][[2, 3, 6, 7]] - want["stats"][[2, 3, 6, 7]]) / np.maximum(want["stats"][[2, 3, 6, 7]], 1.0)
+    assert rel.max() <= TOL, rel
+    dchi = np.abs(got["chi2"] - want["chi2"]) / np.maximum(1.0, want["chi2"])
+    assert dchi.max() <= 1e-4, dchi.max()        # residual chi2 per edge (computed from float32-rounded nothing: double state)
+    # outlier flags may only differ on edges sitting numerically on the threshold
+    diff = got["outlier"] != want["outlier"]
+    th = np.where(w["edge_obs"][:, 2] < 0, 5.991, 7.815)
+    assert (np.abs(want["chi2"][diff] - th[diff]) < 1e-3).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(K=50, P=5000, seed=12345), dict(K=20, P=1500, seed=7, stereo_frac=0.5),
+                                 dict(K=8, P=200, seed=2, stereo_frac=1.0, n_fixed=1)])
+def test_lba_hip_matches_oracle(orbx, oracle, cfg):
+    w = orbx.lba_synth.make_window(**cfg)
+    want = oracle_lib.local_bundle_adjustment(oracle, w)
+    opt = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000)
+    got = opt.LocalBundleAdjustment(w)
+    _compare(got, want, w)
+    ms, flops = opt.last_timing()
+    assert ms > 0 and flops > 0
+    # stop flag honoured before the start (src/Optimizer.cc:858-860)
+    stop = np.array([1], np.uint8)
+    g2 = opt.LocalBundleAdjustment(w, stop_flag=stop)
+    assert g2["stats"][0] == 0 and np.allclose(g2["points"], w["points"])
+    opt.close()
