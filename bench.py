@@ -49,8 +49,7 @@ def algorithmic_bytes(W, H, K, nlevels=8):
     P, P0, PL = sum(px), px[0], px[-1]
     return {
         "pyramid": (P - PL) + (P - P0),        # read every level but the last, write every level but the first
-        "fast_score": P,                        # read every pyramid pixel once
-        "cell_nms": 0,                          # consumes the score map (implementation traffic, not algorithmic)
+        "fast_cells": P,                        # FAST + cell NMS fused: read every pyramid pixel once
         "octree": 0,
         "orient": 749 * K,                      # 749-pixel disc per keypoint
         "blur": 2 * P,                          # read + write every level
@@ -119,37 +118,28 @@ def main():
     a = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a GPU: liborbx has no CPU fallback"
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev_t = torch.device("cuda", local)
-
     orbx = importlib.import_module("self_commit_orb-slam2_amd")
+    grp = orbx.distributed.Group(device=dev_t)       # nccl (= RCCL) when WORLD_SIZE > 1
+    rank, world = grp.rank, grp.world
+
     W, H, B, nf = a.width, a.height, a.batch, a.nfeatures
     ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local)
     mt = None if a.no_match else orbx.ORBmatcher(0.7, True, max_features=ext.capacity, max_pairs=B, device=local)
     # independent frames per rank: seeds offset by rank<<32; every 16th frame low texture
     # scenes of 16 views translating 3x1 px per view, so consecutive frames really match
-    frames = orbx.synth_sequence((rank << 32) + 1, B, W, H)
+    frames = orbx.synth_sequence(grp.seed_base() + 1, B, W, H)
     dev = ext.upload(frames)                       # inputs resident in HBM before the timed region
     pa = np.arange(B, dtype=np.int32)              # frame i (as "KeyFrame") ...
     pb = (np.arange(B, dtype=np.int32) + 1) % B    # ... against frame i+1 (as "Frame")
-    fs = None
 
     def step():
-        nonlocal fs
         ext.run_device(*dev)
         if mt is not None:
-            if fs is None:
-                fs = orbx.ORBmatcher.features_of(ext, B)
+            fs = orbx.ORBmatcher.features_of(ext, B)     # results are double buffered: ask every step
             mt.search_by_bow_device(fs, fs, pa, pb, mode=0, after=ext)
 
     def sync_all():
@@ -161,8 +151,7 @@ def main():
     for _ in range(a.warmup):
         step()
     sync_all()
-    if dist is not None:
-        dist.barrier()
+    grp.barrier()
     sync_all()
 
     # HIP events on the library's own streams, one event set per call, recorded INSIDE the timed
@@ -178,29 +167,19 @@ def main():
     for _ in range(a.steps):
         step()
     sync_all()
-    if dist is not None:
-        dist.barrier()
+    grp.barrier()
     sync_all()
     elapsed = time.perf_counter() - t0
     _, stage_ms = ext.last_timing()
     match_ms = mt.last_timing() if mt is not None else 0.0
     ext.set_profiling(False)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
     kps, desc, counts = ext.download(B)
     nm_mean = 0.0
     if mt is not None:
         m, d, nm = mt.download(B)
         nm_mean = float(nm.mean())
-    stats = torch.tensor([float(B * a.steps), elapsed, float(counts.sum())], dtype=torch.float64, device=dev_t)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)       # the one collective of this workload: 24 bytes per rank
-        frames_total = sum(float(g[0]) for g in gathered)
-    else:
-        frames_total = float(B * a.steps)
-    t = float(tmax.item())
+    t, frames_total, per_rank = grp.aggregate(elapsed, B * a.steps, int(counts.sum()))
 
     if rank == 0:
         K = float(counts.mean())
@@ -229,9 +208,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(orbx, W, H, nf)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

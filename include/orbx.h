@@ -142,6 +142,8 @@ int orbx_download_pyramid(orbx_extractor *h, int frame, int level, int blurred, 
  * order (src/ORBextractor.cc:1089-1157) packed as x | y<<12 | score<<24 relative to the
  * border window origin, and the per-level keypoints after DistributeOctTree + IC_Angle
  * in level coordinates (src/ORBextractor.cc:1167-1198). */
+/* The fused detector keeps FAST scores on chip; enable the taps to also write the score map. */
+int orbx_extractor_set_debug_taps(orbx_extractor *h, int enable);
 int orbx_debug_download_scores(orbx_extractor *h, int frame, int level, uint8_t *dst, int dst_stride);
 int orbx_debug_download_candidates(orbx_extractor *h, int frame, int level, uint32_t *packed, int cap, int *count);
 int orbx_debug_download_level_keypoints(orbx_extractor *h, int frame, int level, orbx_keypoint *kps, int cap, int *count);

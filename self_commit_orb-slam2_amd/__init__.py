@@ -80,6 +80,7 @@ def load_library():
     L.orbx_pyramid_level_size.argtypes = [vp, ci, ci, ci, vp, vp]
     L.orbx_download_pyramid.argtypes = [vp, ci, ci, ci, vp, ci]
     L.orbx_debug_download_scores.argtypes = [vp, ci, ci, vp, ci]
+    L.orbx_extractor_set_debug_taps.argtypes = [vp, ci]
     L.orbx_debug_download_candidates.argtypes = [vp, ci, ci, vp, ci, vp]
     L.orbx_debug_download_level_keypoints.argtypes = [vp, ci, ci, vp, ci, vp]
     L.orbx_extractor_set_profiling.argtypes = [vp, ci]
@@ -230,6 +231,9 @@ class ORBextractor:
         cap = ctypes.c_int()
         _check(self._L.orbx_batch_results_device(self._h, ctypes.byref(k), ctypes.byref(d), ctypes.byref(c), ctypes.byref(cap)))
         return k, d, c, cap.value
+
+    def set_debug_taps(self, on):
+        _check(self._L.orbx_extractor_set_debug_taps(self._h, 1 if on else 0))
 
     def set_profiling(self, on):
         _check(self._L.orbx_extractor_set_profiling(self._h, 1 if on else 0))
@@ -437,6 +441,16 @@ def _load_lba_synth():
 
 
 lba_synth = _load_lba_synth()
+
+
+def _load_sibling(name):
+    spec = importlib.util.spec_from_file_location("orbx_" + name, _PKG / (name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+distributed = _load_sibling("distributed")
 
 
 class Optimizer:

@@ -26,9 +26,9 @@ void orbx_set_error(const char *fmt, ...)
 extern "C" const char *orbx_last_error(void) { return g_err; }
 extern "C" int orbx_version(void) { return 100; }
 
-static const char *kStageNames[] = {"pyramid", "fast_score", "cell_nms", "octree", "orient", "blur", "describe"};
+static const char *kStageNames[] = {"pyramid", "fast_cells", "octree", "orient", "blur", "describe"};
 #define ORBX_PROF_RING 64
-enum { ST_PYR = 0, ST_FAST, ST_CELLS, ST_OCTREE, ST_ORIENT, ST_BLUR, ST_DESC, ST_COUNT };
+enum { ST_PYR = 0, ST_FAST, ST_OCTREE, ST_ORIENT, ST_BLUR, ST_DESC, ST_COUNT };
 extern "C" const char *orbx_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
 
 namespace {
@@ -76,14 +76,21 @@ struct orbx_extractor {
     hipEvent_t ev[ORBX_PROF_RING][ST_COUNT + 1] = {};
     bool profiling = false;
     int profCount = 0;
+    bool debugTaps = false;   // keep the FAST score map for orbx_debug_download_scores
     DevBuf<OrbxGeom> geomDev;
     DevBuf<OrbxResizeX> rxDev;
     DevBuf<OrbxResizeY> ryDev;
-    DevBuf<uint8_t> binDev, pyr, blur, score, staging, outDesc;
-    DevBuf<int> cellCount, lvlCnt, outCnt, status;
+    DevBuf<uint8_t> binDev, pyr, blur, score, staging;
+    DevBuf<int> cellCount, lvlCnt, status;
+    // results are double buffered: a consumer (matcher) may still read batch i while batch i+1 is
+    // extracted; consumerEv[b] = event after which buffer b may be overwritten again
+    DevBuf<uint8_t> outDesc[2];
+    DevBuf<int> outCnt[2];
+    DevBuf<orbx_keypoint> outKp[2];
+    hipEvent_t consumerEv[2] = {nullptr, nullptr};
+    int cur = 0;
     DevBuf<uint32_t> cellSlots, ptBuf;
     DevBuf<OrbxLevelKp> lvlKp;
-    DevBuf<orbx_keypoint> outKp;
     int allocBatch = 0;
     // last run
     int lastBatch = 0;
@@ -197,7 +204,7 @@ int build_geometry(orbx_extractor *h, int W, int H)
         lv.fastTileBase = ftiles;
         ftiles += lv.fastTilesX * lv.fastTilesY;
         lv.blurTilesX = (lv.w + 63) / 64;
-        lv.blurTilesY = (lv.h + 15) / 16;
+        lv.blurTilesY = (lv.h + 31) / 32;
         lv.blurTileBase = btiles;
         btiles += lv.blurTilesX * lv.blurTilesY;
         lv.scale = h->scale[(size_t)l];
@@ -269,19 +276,21 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
         int rc;
         if ((rc = h->pyr.ensure(B * g.pyrBytes)) != ORBX_OK) return rc;
         if ((rc = h->blur.ensure(B * g.pyrBytes)) != ORBX_OK) return rc;
-        if ((rc = h->score.ensure(B * g.pyrBytes)) != ORBX_OK) return rc;
+        if (h->debugTaps && (rc = h->score.ensure(B * g.pyrBytes)) != ORBX_OK) return rc;
         if ((rc = h->cellCount.ensure(B * g.cellsPerFrame)) != ORBX_OK) return rc;
         if ((rc = h->cellSlots.ensure(B * g.slotsPerFrame)) != ORBX_OK) return rc;
         if ((rc = h->ptBuf.ensure(B * g.nlevels * 2 * ORBX_PT_CAP)) != ORBX_OK) return rc;
         if ((rc = h->lvlKp.ensure(B * g.kpPerFrame)) != ORBX_OK) return rc;
         if ((rc = h->lvlCnt.ensure(B * g.nlevels)) != ORBX_OK) return rc;
-        if ((rc = h->outKp.ensure(B * g.outCap)) != ORBX_OK) return rc;
-        if ((rc = h->outDesc.ensure(B * g.outCap * 32)) != ORBX_OK) return rc;
-        if ((rc = h->outCnt.ensure(B)) != ORBX_OK) return rc;
+        for (int b = 0; b < 2; b++) {
+            if ((rc = h->outKp[b].ensure(B * g.outCap)) != ORBX_OK) return rc;
+            if ((rc = h->outDesc[b].ensure(B * g.outCap * 32)) != ORBX_OK) return rc;
+            if ((rc = h->outCnt[b].ensure(B)) != ORBX_OK) return rc;
+        }
         if ((rc = h->status.ensure(B)) != ORBX_OK) return rc;
         // the score map is only written inside the detectable window; clear it once so the
         // parity taps (orbx_debug_download_scores) see zeros elsewhere
-        ORBX_HIP_CHECK(hipMemsetAsync(h->score.p, 0, B * g.pyrBytes, h->stream));
+        if (h->debugTaps) ORBX_HIP_CHECK(hipMemsetAsync(h->score.p, 0, B * g.pyrBytes, h->stream));
         h->allocBatch = batch;
     }
     return ORBX_OK;
@@ -294,10 +303,12 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     OrbxLaunch L;
     L.stream = h->stream; L.geomDev = h->geomDev.p; L.geom = &h->geom; L.batch = batch;
     L.img0 = img0Dev; L.img0Stride = stride; L.img0FramePitch = framePitch;
-    L.pyr = h->pyr.p; L.blur = h->blur.p; L.score = h->score.p; L.blurBytes = h->geom.pyrBytes;
+    L.pyr = h->pyr.p; L.blur = h->blur.p; L.score = h->debugTaps ? h->score.p : nullptr; L.blurBytes = h->geom.pyrBytes;
     L.rx = h->rxDev.p; L.ry = h->ryDev.p; L.binTab = h->binDev.p;
     L.cellCount = h->cellCount.p; L.cellSlots = h->cellSlots.p; L.ptBuf = h->ptBuf.p;
-    L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outKp = h->outKp.p; L.outDesc = h->outDesc.p; L.outCnt = h->outCnt.p;
+    h->cur ^= 1;
+    const int cb = h->cur;
+    L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outKp = h->outKp[cb].p; L.outDesc = h->outDesc[cb].p; L.outCnt = h->outCnt[cb].p;
     L.status = h->status.p; L.nodeCap = h->nodeCap;
     const bool prof = h->profiling;
     hipEvent_t *ev = h->ev[h->profCount % ORBX_PROF_RING];
@@ -306,16 +317,15 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     for (int l = 1; l < h->geom.nlevels; l++)
         if ((rc = orbx_launch_resize(L, l)) != ORBX_OK) return rc;
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_PYR + 1], h->stream));
-    if ((rc = orbx_launch_fast(L)) != ORBX_OK) return rc;
+    if ((rc = orbx_launch_fast_cells(L)) != ORBX_OK) return rc;   // FAST score + cell NMS fused; score map only for the parity taps
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_FAST + 1], h->stream));
-    if ((rc = orbx_launch_cells(L)) != ORBX_OK) return rc;
-    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_CELLS + 1], h->stream));
     if ((rc = orbx_launch_octree(L)) != ORBX_OK) return rc;
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_OCTREE + 1], h->stream));
     if ((rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_ORIENT + 1], h->stream));
     if ((rc = orbx_launch_blur(L)) != ORBX_OK) return rc;
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_BLUR + 1], h->stream));
+    if (h->consumerEv[cb]) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->consumerEv[cb], 0)); h->consumerEv[cb] = nullptr; }
     if ((rc = orbx_launch_desc(L)) != ORBX_OK) return rc;
     if (prof) { ORBX_HIP_CHECK(hipEventRecord(ev[ST_DESC + 1], h->stream)); h->profCount++; }
     h->lastBatch = batch; h->lastImg0 = img0Dev; h->lastStride = stride; h->lastFramePitch = framePitch;
@@ -354,6 +364,7 @@ int upload(orbx_extractor *h, const uint8_t *const *images, int batch, int W, in
 }  // namespace
 
 hipStream_t orbx_extractor_stream_internal(orbx_extractor *h) { return h ? h->stream : nullptr; }
+void orbx_extractor_set_consumer_event_internal(orbx_extractor *h, hipEvent_t ev) { if (h) h->consumerEv[h->cur] = ev; }
 
 extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extractor **out)
 {
@@ -395,8 +406,9 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->geomDev.release(); h->rxDev.release(); h->ryDev.release(); h->binDev.release(); h->pyr.release(); h->blur.release();
-    h->score.release(); h->staging.release(); h->outDesc.release(); h->cellCount.release(); h->lvlCnt.release(); h->outCnt.release();
-    h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->lvlKp.release(); h->outKp.release();
+    h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release();
+    for (int b = 0; b < 2; b++) { h->outDesc[b].release(); h->outCnt[b].release(); h->outKp[b].release(); }
+    h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->lvlKp.release();
     for (int r = 0; r < ORBX_PROF_RING; r++)
         for (int i = 0; i <= ST_COUNT; i++) if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -453,9 +465,9 @@ extern "C" int orbx_batch_results_device(orbx_extractor *h, const orbx_keypoint 
 {
     if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
     if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
-    if (keypoints_dev) *keypoints_dev = h->outKp.p;
-    if (descriptors_dev) *descriptors_dev = h->outDesc.p;
-    if (counts_dev) *counts_dev = h->outCnt.p;
+    if (keypoints_dev) *keypoints_dev = h->outKp[h->cur].p;
+    if (descriptors_dev) *descriptors_dev = h->outDesc[h->cur].p;
+    if (counts_dev) *counts_dev = h->outCnt[h->cur].p;
     if (capacity) *capacity = h->geom.outCap;
     return ORBX_OK;
 }
@@ -476,14 +488,14 @@ extern "C" int orbx_batch_download(orbx_extractor *h, int batch, orbx_keypoint *
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     int rc = check_status(h, batch);
     if (rc != ORBX_OK) return rc;
-    ORBX_HIP_CHECK(hipMemcpy(counts, h->outCnt.p, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
+    ORBX_HIP_CHECK(hipMemcpy(counts, h->outCnt[h->cur].p, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
     const int cap = h->geom.outCap;
     for (int f = 0; f < batch; f++) {
         const int n = counts[f];
         if (n > capacity) { orbx_set_error("frame %d has %d keypoints but the caller's capacity is %d", f, n, capacity); return ORBX_ERR_CAPACITY; }
         if (n == 0) continue;
-        if (keypoints) ORBX_HIP_CHECK(hipMemcpy(keypoints + (size_t)f * capacity, h->outKp.p + (size_t)f * cap, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
-        if (descriptors) ORBX_HIP_CHECK(hipMemcpy(descriptors + (size_t)f * capacity * 32, h->outDesc.p + (size_t)f * cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+        if (keypoints) ORBX_HIP_CHECK(hipMemcpy(keypoints + (size_t)f * capacity, h->outKp[h->cur].p + (size_t)f * cap, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+        if (descriptors) ORBX_HIP_CHECK(hipMemcpy(descriptors + (size_t)f * capacity * 32, h->outDesc[h->cur].p + (size_t)f * cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
     }
     return ORBX_OK;
 }
@@ -537,9 +549,17 @@ extern "C" int orbx_download_pyramid(orbx_extractor *h, int frame, int level, in
     return download_plane(h, h->pyr.p + (size_t)frame * h->geom.pyrBytes + lv.off, lv.pitch, lv.w, lv.h, dst, dst_stride);
 }
 
+extern "C" int orbx_extractor_set_debug_taps(orbx_extractor *h, int enable)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if ((enable != 0) != h->debugTaps) { h->debugTaps = enable != 0; h->allocBatch = 0; }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_debug_download_scores(orbx_extractor *h, int frame, int level, uint8_t *dst, int dst_stride)
 {
     if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!h->debugTaps) { orbx_set_error("score map not kept: call orbx_extractor_set_debug_taps(h, 1) before extracting"); return ORBX_ERR_STATE; }
     if (!h->lastBatch || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels) { orbx_set_error("frame/level not available"); return ORBX_ERR_STATE; }
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
     const OrbxLevel &lv = h->geom.lv[level];

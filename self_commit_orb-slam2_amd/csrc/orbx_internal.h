@@ -96,6 +96,7 @@ struct OrbxLaunch {
 int orbx_launch_resize(const OrbxLaunch &L, int level);
 int orbx_launch_fast(const OrbxLaunch &L);
 int orbx_launch_cells(const OrbxLaunch &L);
+int orbx_launch_fast_cells(const OrbxLaunch &L);   /* fused FAST + cell NMS; L.score may be NULL */
 int orbx_launch_octree(const OrbxLaunch &L);
 int orbx_launch_orient(const OrbxLaunch &L);
 int orbx_launch_blur(const OrbxLaunch &L);
@@ -103,5 +104,8 @@ int orbx_launch_desc(const OrbxLaunch &L);
 
 /* stream of an extractor handle (orbx_extractor.hip), so other handles can order work after it */
 hipStream_t orbx_extractor_stream_internal(orbx_extractor *h);
+/* `ev` (recorded by a consumer on its own stream) guards the result buffer of the LAST batch: the
+ * extractor waits for it before that buffer is overwritten two batches later */
+void orbx_extractor_set_consumer_event_internal(orbx_extractor *h, hipEvent_t ev);
 
 #endif

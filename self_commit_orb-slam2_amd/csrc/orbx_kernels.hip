@@ -38,36 +38,65 @@ __device__ __forceinline__ int find_level(const int *base, int nlevels, int idx)
 // Pyramid: level L = cv::resize(level L-1, INTER_LINEAR) (src/ORBextractor.cc:1696-1701),
 // 11-bit fixed point; the column/row tables are built on the host with the exact
 // float/double arithmetic of OpenCV's resize (orbx_extractor.hip: build_geometry).
-// One thread -> 4 consecutive dst pixels, one u32 store.
+// One thread -> 4 consecutive dst pixels x 4 rows; per source row ONE unaligned 8-byte load
+// covers all eight taps of the four pixels (scale 1.2: span <= 6 bytes), one dword store per row.
 // ------------------------------------------------------------------------------------
+#define RS_ROWS 4   /* dst rows per thread */
 __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, int level, const uint8_t *__restrict__ img0, int img0Stride,
                                                 size_t img0FramePitch, uint8_t *__restrict__ pyr, const OrbxResizeX *__restrict__ rx,
                                                 const OrbxResizeY *__restrict__ ry)
 {
     const OrbxLevel &lv = g->lv[level];
-    const int f = blockIdx.z, dy = blockIdx.y;
-    const int dx0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (dx0 >= lv.w) return;
+    const int f = blockIdx.z;
+    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int dyBase = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS;   // wave-uniform
+    if (dx0 >= lv.w || dyBase >= lv.h) return;
     int sp;
     const uint8_t *src = level_ptr(g, level - 1, f, img0, img0Stride, img0FramePitch, pyr, sp);
-    uint8_t *dst = pyr + (size_t)f * g->pyrBytes + lv.off + (size_t)dy * lv.pitch;
-    const OrbxResizeY yy = ry[lv.ryOff + dy];
-    const uint8_t *S0 = src + (size_t)yy.y0 * sp, *S1 = src + (size_t)yy.y1 * sp;
     const int sw = g->lv[level - 1].w;
-    uint32_t out = 0;
+    // the 4 dst columns of this thread: source column, offset from the first one, coefficients
+    int off[4], off1[4], a0[4], a1[4];
+    int sx0 = 0, span = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        int dx = dx0 + k;
-        if (dx < lv.w) {
-            const OrbxResizeX xx = rx[lv.rxOff + dx];
-            int sx = xx.sx, sx1 = sx + 1 < sw ? sx + 1 : sx;
-            int r0 = S0[sx] * xx.a0 + S0[sx1] * xx.a1;
-            int r1 = S1[sx] * xx.a0 + S1[sx1] * xx.a1;
-            int v = (((yy.b0 * (r0 >> 4)) >> 16) + ((yy.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            out |= (uint32_t)(v & 0xff) << (8 * k);
-        }
+        const int dx = min(dx0 + k, lv.w - 1);
+        const OrbxResizeX xx = rx[lv.rxOff + dx];
+        const int sx = xx.sx, sx1 = sx + 1 < sw ? sx + 1 : sx;
+        if (k == 0) sx0 = sx;
+        off[k] = sx - sx0; off1[k] = sx1 - sx0; a0[k] = xx.a0; a1[k] = xx.a1;
+        span = max(span, off1[k]);
     }
-    *(uint32_t *)(dst + dx0) = out;   // pitch is a multiple of 4 and >= round_up(w,4)
+    const bool wide = span <= 7 && sx0 + 8 <= sw;   // one unaligned 8-byte load per source row covers all taps
+    uint8_t *dstBase = pyr + (size_t)f * g->pyrBytes + lv.off;
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        const int dy = dyBase + r;
+        if (dy >= lv.h) break;
+        const OrbxResizeY yy = ry[lv.ryOff + dy];
+        const uint8_t *S0 = src + (size_t)yy.y0 * sp + sx0, *S1 = src + (size_t)yy.y1 * sp + sx0;
+        uint32_t out = 0;
+        if (wide) {
+            unsigned long long v0, v1;
+            __builtin_memcpy(&v0, S0, 8);
+            __builtin_memcpy(&v1, S1, 8);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int p00 = (int)((v0 >> (8 * off[k])) & 0xff), p01 = (int)((v0 >> (8 * off1[k])) & 0xff);
+                const int p10 = (int)((v1 >> (8 * off[k])) & 0xff), p11 = (int)((v1 >> (8 * off1[k])) & 0xff);
+                const int r0 = p00 * a0[k] + p01 * a1[k], r1 = p10 * a0[k] + p11 * a1[k];
+                const int v = (((yy.b0 * (r0 >> 4)) >> 16) + ((yy.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                out |= (uint32_t)(v & 0xff) << (8 * k);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r0 = S0[off[k]] * a0[k] + S0[off1[k]] * a1[k], r1 = S1[off[k]] * a0[k] + S1[off1[k]] * a1[k];
+                const int v = (((yy.b0 * (r0 >> 4)) >> 16) + ((yy.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                out |= (uint32_t)(v & 0xff) << (8 * k);
+            }
+        }
+        *(uint32_t *)(dstBase + (size_t)dy * lv.pitch + dx0) = out;   // pitch is a multiple of 64 >= round_up(w,4)
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -221,6 +250,251 @@ __global__ __launch_bounds__(64) void k_cell_nms(const OrbxGeom *__restrict__ g,
         base += __popcll(m);
     }
     if (lane == 0) *cnt = min(base, lv.cellCap);
+}
+
+// ------------------------------------------------------------------------------------
+// Fused cell detector: FAST score + per-cell NMS + threshold fallback + ordered emission in
+// ONE kernel, one workgroup per 30-px cell (ComputeKeyPointsOctTree cell loop,
+// src/ORBextractor.cc:1089-1157, with cv::FAST at :1126,1135).  The cell's input window
+// (detectable area + 3 px ring) is staged in LDS, scores never leave the CU: the score map
+// of k_fast_score/k_cell_nms (kept for the parity taps) is not written or re-read, which
+// removes 2 bytes/pixel of HBM traffic and one launch.  Score arithmetic uses packed 16-bit
+// min/max (two circle pixels per VALU op) behind an exact early-out: a 9-arc of the
+// 16-circle contains k or k+8 for every k, so min_k max(d_k, d_k+8) <= t rules out a dark
+// arc and max_k min(d_k, d_k+8) >= -t a bright one.
+// ------------------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s16x2 pk_swap(s16x2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+
+// P[k] = (d_k, d_{k+8}), d = centre - circle pixel.
+// Exact necessary condition for a 9-arc at threshold t (see above): cheap, branch free.
+__device__ __forceinline__ bool fast_possible_packed(const s16x2 *P, int minTh)
+{
+    s16x2 lo = pk_max(P[0], pk_swap(P[0])), hi = pk_min(P[0], pk_swap(P[0]));
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        const s16x2 w = pk_swap(P[k]);
+        lo = pk_min(lo, pk_max(P[k], w));
+        hi = pk_max(hi, pk_min(P[k], w));
+    }
+    return (int)lo.x > minTh || (int)hi.x < -minTh;
+}
+
+// FAST score = max over the 16 arcs of 9 of min(+d) / min(-d), minus 1; 0 when < minTh.
+__device__ __forceinline__ int fast_score_packed(const s16x2 *P, int minTh)
+{
+    s16x2 W[8];   // (d_{k+8}, d_k)
+#pragma unroll
+    for (int k = 0; k < 8; k++) W[k] = pk_swap(P[k]);
+    // windows of 2, 4, 8, 9 consecutive circle pixels starting at k (low half) and k+8 (high half)
+    s16x2 a2[8], b2[8], a4[8], b4[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const s16x2 nx = k < 7 ? P[k + 1] : W[0];
+        a2[k] = pk_min(P[k], nx); b2[k] = pk_max(P[k], nx);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const s16x2 na = k < 6 ? a2[k + 2] : pk_swap(a2[k - 6]), nb = k < 6 ? b2[k + 2] : pk_swap(b2[k - 6]);
+        a4[k] = pk_min(a2[k], na); b4[k] = pk_max(b2[k], nb);
+    }
+    s16x2 best = {-512, -512};
+    const s16x2 zero = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const s16x2 na = k < 4 ? a4[k + 4] : pk_swap(a4[k - 4]), nb = k < 4 ? b4[k + 4] : pk_swap(b4[k - 4]);
+        const s16x2 a9 = pk_min(pk_min(a4[k], na), W[k]);   // min over the 9-arc starting at k / k+8
+        const s16x2 b9 = pk_max(pk_max(b4[k], nb), W[k]);
+        best = pk_max(best, pk_max(a9, zero - b9));
+    }
+    const int sc = max((int)best.x, (int)best.y) - 1;
+    return sc >= minTh ? sc : 0;
+}
+
+#define FC_IP 72   /* input window pitch: up to 59+6 bytes per row */
+#define FC_IR 66   /* input window rows */
+#define FC_SP 72   /* score tile pitch: 4 zero bytes | detectable area | >= 4 zero bytes */
+#define FC_SR 62   /* score tile rows: 1 zero row | area | 1 zero row */
+#define FC_ITERS 4 /* items (row, group of 4 px) per thread: 59 rows x 15 groups <= 4*256 */
+
+// byte b (compile-time) of the three row dwords w[0..2] covering bytes 0..11
+#define FC_BYTE(w, b) (((w)[(b) >> 2] >> (8 * ((b) & 3))) & 0xffu)
+
+__global__ __launch_bounds__(256) void k_fast_cells(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                                    const uint8_t *__restrict__ pyr, uint8_t *__restrict__ scoreDbg, int *__restrict__ cellCount,
+                                                    uint32_t *__restrict__ cellSlots)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t in[FC_IR * (FC_IP / 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t sc[FC_SR * (FC_SP / 4)];
+    __shared__ unsigned short candList[60 * 60];
+    __shared__ int wcnt[4];
+    __shared__ int sAny, sNCand;
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bases[ORBX_MAX_LEVELS];
+    const int nl = g->nlevels;
+    for (int i = 0; i < nl; i++) bases[i] = g->lv[i].cellBase;
+    const int l = find_level(bases, nl, blockIdx.x);
+    const OrbxLevel &lv = g->lv[l];
+    const int cell = blockIdx.x - lv.cellBase;
+    const int cj = cell % lv.nCols, ci = cell / lv.nCols;
+    const int maxBX = lv.w - ORBX_BORDER, maxBY = lv.h - ORBX_BORDER;
+    const int iniX = ORBX_BORDER + cj * lv.wCell, iniY = ORBX_BORDER + ci * lv.hCell;
+    const int maxX = min(iniX + lv.wCell + 6, maxBX), maxY = min(iniY + lv.hCell + 6, maxBY);
+    int *cnt = cellCount + (size_t)f * g->cellsPerFrame + blockIdx.x;
+    const int x0 = iniX + 3, x1 = maxX - 3, y0 = iniY + 3, y1 = maxY - 3;
+    const int aw = x1 - x0, ah = y1 - y0;
+    if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || aw <= 0 || ah <= 0) {   // skipped / degenerate cell (:1101, :1112)
+        if (tid == 0) *cnt = 0;
+        return;
+    }
+    int pitch;
+    const uint8_t *src = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
+    if (tid == 0) { sAny = 0; sNCand = 0; }
+    {   // stage rows y0-3 .. y1+2, bytes x0-3 .. x1+2 (+ up to 3 spill bytes, always inside the row)
+        const int iw = aw + 6, ih = ah + 6, nw = (iw + 3) >> 2;
+        const uint8_t *base = src + (size_t)(y0 - 3) * pitch + (x0 - 3);
+        for (int i = tid; i < ih * nw; i += 256) {
+            const int r = i / nw, c = i - r * nw;
+            uint32_t v;
+            __builtin_memcpy(&v, base + (size_t)r * pitch + 4 * c, 4);   // unaligned dword load
+            in[r * (FC_IP / 4) + c] = v;
+        }
+        for (int i = tid; i < (ah + 2) * (FC_SP / 4); i += 256) sc[i] = 0;
+    }
+    __syncthreads();
+    const int G = (aw + 3) >> 2, nItems = ah * G, minTh = g->minTh, iniTh = g->iniTh;
+    uint8_t *dbg = scoreDbg ? scoreDbg + (size_t)f * g->pyrBytes + lv.off : nullptr;
+    if (dbg)   // parity tap: pixels that fail the pre-test have score 0
+        for (int p = tid; p < aw * ah; p += 256) dbg[(size_t)(y0 + p / aw) * lv.pitch + (x0 + p % aw)] = 0;
+    // ---- phase A: item = (row r, group of 4 px gq).  Pixel j of the group is byte 4gq+3+j of window
+    //      row r+3.  Every pixel gets the cheap exact pre-test; survivors (edge and corner pixels,
+    //      ~10-20 %) are appended to an LDS list so that phase B runs the full score on dense waves. ----
+#pragma unroll
+    for (int it = 0; it < FC_ITERS; it++) {
+        if (256 * it >= nItems) break;
+        const int item = tid + 256 * it;
+        const bool live = item < nItems;
+        const int r = live ? item / G : 0, gq = live ? item - r * G : 0;
+        uint32_t W[7][3];
+#pragma unroll
+        for (int dy = 0; dy < 7; dy++) {
+            const uint32_t *pw = in + (r + dy) * (FC_IP / 4) + gq;
+            W[dy][0] = pw[0]; W[dy][1] = pw[1]; W[dy][2] = pw[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // (v, v) and (x_k, x_{k+8}) as 16-bit pairs straight from the window dwords: one v_perm_b32 each
+            const uint32_t cw = W[3][(j + 3) >> 2];
+            const uint32_t cb = (uint32_t)((j + 3) & 3);
+            const uint32_t vv = __builtin_amdgcn_perm(cw, cw, 0x0c000c00u | cb | ((4u + cb) << 16));
+            s16x2 P[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int ba = j + 3 + FAST_DX(k), bb = j + 3 + FAST_DX(k + 8);
+                const uint32_t wa = W[3 + FAST_DY(k)][ba >> 2], wb = W[3 + FAST_DY(k + 8)][bb >> 2];
+                const uint32_t xx = __builtin_amdgcn_perm(wb, wa, 0x0c000c00u | (uint32_t)(ba & 3) | ((4u + (uint32_t)(bb & 3)) << 16));
+                union { uint32_t u; s16x2 v; } a, b;
+                a.u = vv; b.u = xx;
+                P[k] = a.v - b.v;
+            }
+            const bool cand = live && (4 * gq + j < aw) && fast_possible_packed(P, minTh);
+            const unsigned long long m = __ballot(cand);
+            if (m) {
+                int basep = 0;
+                if (lane == 0) basep = atomicAdd(&sNCand, __popcll(m));
+                basep = __shfl(basep, 0);
+                if (cand) candList[basep + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((r << 6) | (4 * gq + j));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: full FAST score of the surviving pixels ----
+    {
+        const int nc = sNCand;
+        uint8_t *scb = (uint8_t *)sc;
+        const uint8_t *inb = (const uint8_t *)in;
+        for (int i = tid; i < nc; i += 256) {
+            const int code = candList[i], r = code >> 6, c = code & 63;
+            const uint8_t *q = inb + (r + 3) * FC_IP + (c + 3);
+            const int v = q[0];
+            s16x2 P[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                P[k].x = (short)(v - (int)q[FAST_DY(k) * FC_IP + FAST_DX(k)]);
+                P[k].y = (short)(v - (int)q[FAST_DY(k + 8) * FC_IP + FAST_DX(k + 8)]);
+            }
+            const int sco = fast_score_packed(P, minTh);
+            scb[(r + 1) * FC_SP + (c + 4)] = (uint8_t)sco;
+            if (dbg) dbg[(size_t)(y0 + r) * lv.pitch + (x0 + c)] = (uint8_t)sco;
+        }
+    }
+    __syncthreads();
+    // ---- strict 3x3 maxima inside the cell (zero ring = "not a corner of this sub-image") ----
+    uint32_t ctr[FC_ITERS];
+    unsigned nmsMask[FC_ITERS], iniMask[FC_ITERS];
+    bool anyIni = false;
+#pragma unroll
+    for (int it = 0; it < FC_ITERS; it++) {
+        ctr[it] = 0; nmsMask[it] = 0; iniMask[it] = 0;
+        const int item = tid + 256 * it;
+        if (item >= nItems) continue;
+        const int r = item / G, gq = item - r * G;
+        uint32_t N[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            const uint32_t *pw = sc + (r + dy) * (FC_SP / 4) + gq;
+            N[dy][0] = pw[0]; N[dy][1] = pw[1]; N[dy][2] = pw[2];
+        }
+        ctr[it] = N[1][1];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int v = (int)FC_BYTE(N[1], 4 + j);
+            bool mx = v > 0;
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++)
+                    if (dy != 1 || dx != 0) mx = mx && v > (int)FC_BYTE(N[dy], 4 + j + dx);
+            if (mx) { nmsMask[it] |= 1u << j; if (v >= iniTh) { iniMask[it] |= 1u << j; anyIni = true; } }
+        }
+    }
+    if (__any(anyIni) && lane == 0) sAny = 1;
+    __syncthreads();
+    const bool useIni = sAny != 0;   // iniThFAST keypoints exist in the cell -> the minThFAST retry is skipped (:1132)
+    uint32_t *slot = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase + (size_t)cell * lv.cellCap;
+    int base = 0;
+#pragma unroll
+    for (int it = 0; it < FC_ITERS; it++) {
+        if (256 * it >= nItems) break;
+        const int item = tid + 256 * it;
+        const unsigned keep = useIni ? iniMask[it] : nmsMask[it];
+        int below = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long m = __ballot((keep >> j) & 1u);
+            below += __popcll(m & ((1ull << lane) - 1ull));
+            tot += __popcll(m);
+        }
+        if (lane == 0) wcnt[wave] = tot;
+        __syncthreads();
+        int off = base + below;
+        for (int k = 0; k < wave; k++) off += wcnt[k];
+        if (keep) {
+            const int r = item / G, gq = item - r * G;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((keep >> j) & 1u) {
+                    const uint32_t v = (ctr[it] >> (8 * j)) & 0xffu;
+                    if (off < lv.cellCap) slot[off] = (uint32_t)(x0 + 4 * gq + j - ORBX_BORDER) | ((uint32_t)(y0 + r - ORBX_BORDER) << 12) | (v << 24);
+                    off++;
+                }
+        }
+        base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) *cnt = min(base, lv.cellCap);
 }
 
 // ------------------------------------------------------------------------------------
@@ -576,41 +850,58 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 __global__ __launch_bounds__(256) void k_orient(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
                                                 const uint8_t *__restrict__ pyr, OrbxLevelKp *__restrict__ lvlKp, const int *__restrict__ lvlCnt)
 {
-    const int f = blockIdx.y, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);   // index into the frame's level-keypoint array
-    if (slot >= g->kpPerFrame) return;
+    // half a wave per keypoint: lane r of the half owns disc row v = r-15 and reads its 31 bytes
+    // as 8 unaligned dwords (x-15 .. x+16 stays inside the level: 19 <= x < w-19)
+    const int f = blockIdx.y, lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
+    const int slot = blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half;   // index into the frame's level-keypoint array
+    bool live = slot < g->kpPerFrame;
     int l = 0;
-    for (int i = 1; i < g->nlevels; i++) if (slot >= g->lv[i].kpBase) l = i;
+    for (int i = 1; i < g->nlevels; i++) if (live && slot >= g->lv[i].kpBase) l = i;
     const OrbxLevel &lv = g->lv[l];
     const int i = slot - lv.kpBase;
-    if (i >= lvlCnt[f * g->nlevels + l]) return;
-    OrbxLevelKp *kp = lvlKp + (size_t)f * g->kpPerFrame + slot;
-    int pitch;
-    const uint8_t *img = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
-    const uint8_t *center = img + (size_t)kp->y * pitch + kp->x;
+    live = live && i < lvlCnt[f * g->nlevels + l];
     int m10 = 0, m01 = 0;
-    // 31 rows x 31 columns box, masked by the disc half-widths umax[|v|]; lane -> (row, 2 column phases)
-    for (int idx = lane; idx < 31 * 31; idx += 64) {
-        int v = idx / 31 - 15, u = idx % 31 - 15;
-        int av = v < 0 ? -v : v;
-        if ((u < 0 ? -u : u) <= g->umax[av]) {
-            int I = center[v * pitch + u];
-            m10 += u * I;
-            m01 += v * I;
+    OrbxLevelKp *kp = lvlKp + (size_t)f * g->kpPerFrame + (live ? slot : 0);
+    if (live && r < 31) {
+        int pitch;
+        const uint8_t *img = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
+        const int v = r - 15, d = g->umax[v < 0 ? -v : v];
+        const uint8_t *row = img + (size_t)(kp->y + v) * pitch + (kp->x - 15);
+        int s1 = 0, su = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t wd;
+            __builtin_memcpy(&wd, row + 4 * j, 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int u = 4 * j + k - 15;
+                if (u <= 15) {
+                    const int I = ((u < 0 ? -u : u) <= d) ? (int)((wd >> (8 * k)) & 0xff) : 0;
+                    s1 += I;
+                    su += u * I;
+                }
+            }
         }
+        m10 = su;
+        m01 = v * s1;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-    if (lane == 0) kp->angle = fast_atan2_deg((float)m01, (float)m10);
+    for (int o = 16; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    if (live && r == 0) kp->angle = fast_atan2_deg((float)m01, (float)m10);
 }
 
 // ------------------------------------------------------------------------------------
 // 7x7 Gaussian, sigma 2, BORDER_REFLECT_101, u8 fixed point (cv::GaussianBlur on the
 // cloned level, src/ORBextractor.cc:1626-1634): horizontal pass exact in 16 bits,
-// vertical in 32, (sum + 2^15) >> 16.  64x16 output tile, rows staged through LDS.
+// vertical in 32, (sum + 2^15) >> 16.  64x32 output tile per workgroup: the 70x38 input
+// window is staged with aligned dword row loads, every thread produces 4 adjacent pixels per
+// pass (3 LDS dwords in, 2 out / 8 LDS qwords in, one coalesced dword store out).
+// Algorithmic traffic 2 bytes/pixel; the halo makes the read side 1.34x.
 // ------------------------------------------------------------------------------------
 #define BT_W 64
-#define BT_H 16
+#define BT_H 32
+#define BT_IW 18   /* input row: dwords covering X0-4 .. X0+67 */
+#define BT_IH (BT_H + 6)
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -622,8 +913,8 @@ __device__ __forceinline__ int reflect101(int p, int len)
 __global__ __launch_bounds__(256) void k_blur(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
                                               const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur)
 {
-    __shared__ uint8_t in[(BT_H + 6) * (BT_W + 8)];
-    __shared__ uint32_t hz[(BT_H + 6) * BT_W];
+    __shared__ uint32_t in[BT_IH * BT_IW];
+    __shared__ uint32_t hz[BT_IH * (BT_W / 2)];   // u16 pairs
     const int f = blockIdx.y;
     int bases[ORBX_MAX_LEVELS];
     const int nl = g->nlevels;
@@ -632,33 +923,69 @@ __global__ __launch_bounds__(256) void k_blur(const OrbxGeom *__restrict__ g, co
     const OrbxLevel &lv = g->lv[l];
     const int t = blockIdx.x - lv.blurTileBase;
     const int X0 = (t % lv.blurTilesX) * BT_W, Y0 = (t / lv.blurTilesX) * BT_H;
+    const int w = lv.w, h = lv.h;
     int pitch;
     const uint8_t *src = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
-    for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
-        int r = i / (BT_W + 6), c = i % (BT_W + 6);
-        int y = reflect101(Y0 - 3 + r, lv.h), x = reflect101(X0 - 3 + c, lv.w);
-        // tiles past the right/bottom edge of the image still need in-range reads
-        y = min(max(y, 0), lv.h - 1); x = min(max(x, 0), lv.w - 1);
-        in[r * (BT_W + 8) + c] = src[(size_t)y * pitch + x];
+    for (int i = threadIdx.x; i < BT_IH * BT_IW; i += 256) {
+        const int r = i / BT_IW, c = i % BT_IW;
+        int y = reflect101(Y0 - 3 + r, h);
+        y = min(max(y, 0), h - 1);
+        const int x = X0 - 4 + 4 * c;
+        const uint8_t *row = src + (size_t)y * pitch;
+        uint32_t v;
+        if (x >= 0 && x + 3 < w) v = *(const uint32_t *)(row + x);
+        else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { int xx = reflect101(x + k, w); xx = min(max(xx, 0), w - 1); v |= (uint32_t)row[xx] << (8 * k); }
+        }
+        in[i] = v;
     }
     __syncthreads();
     const uint32_t k0 = g->taps[0], k1 = g->taps[1], k2 = g->taps[2], k3 = g->taps[3], k4 = g->taps[4], k5 = g->taps[5], k6 = g->taps[6];
-    for (int i = threadIdx.x; i < (BT_H + 6) * BT_W; i += 256) {
-        int r = i / BT_W, c = i % BT_W;
-        const uint8_t *p = in + r * (BT_W + 8) + c;
-        uint32_t s = k0 * p[0] + k1 * p[1] + k2 * p[2] + k3 * p[3] + k4 * p[4] + k5 * p[5] + k6 * p[6];
-        hz[i] = s > 65535u ? 65535u : s;
+    // horizontal: item (row r, group gq of 4 pixels) reads bytes 4gq+1 .. 4gq+10 of the row
+    for (int i = threadIdx.x; i < BT_IH * (BT_W / 4); i += 256) {
+        const int r = i >> 4, gq = i & 15;
+        const uint32_t *pw = in + r * BT_IW + gq;
+        const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+        uint32_t b[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xff; b[4 + k] = (w1 >> (8 * k)) & 0xff; b[8 + k] = (w2 >> (8 * k)) & 0xff; }
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t sum = k0 * b[1 + j] + k1 * b[2 + j] + k2 * b[3 + j] + k3 * b[4 + j] + k4 * b[5 + j] + k5 * b[6 + j] + k6 * b[7 + j];
+            o[j] = sum > 65535u ? 65535u : sum;
+        }
+        hz[r * (BT_W / 2) + 2 * gq] = o[0] | (o[1] << 16);
+        hz[r * (BT_W / 2) + 2 * gq + 1] = o[2] | (o[3] << 16);
     }
     __syncthreads();
+    // vertical: thread -> 4 adjacent columns x 2 rows
+    const int gq = threadIdx.x & 15, rr = (threadIdx.x >> 4) * 2;
+    const int x = X0 + 4 * gq;
+    if (x >= w) return;
+    uint32_t c0[8], c1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { c0[k] = hz[(rr + k) * (BT_W / 2) + 2 * gq]; c1[k] = hz[(rr + k) * (BT_W / 2) + 2 * gq + 1]; }
     uint8_t *dst = blur + (size_t)f * g->pyrBytes + lv.off;
-    for (int i = threadIdx.x; i < BT_H * BT_W; i += 256) {
-        int r = i / BT_W, c = i % BT_W;
-        int x = X0 + c, y = Y0 + r;
-        if (x >= lv.w || y >= lv.h) continue;
-        const uint32_t *p = hz + r * BT_W + c;
-        uint32_t s = k0 * p[0] + k1 * p[BT_W] + k2 * p[2 * BT_W] + k3 * p[3 * BT_W] + k4 * p[4 * BT_W] + k5 * p[5 * BT_W] + k6 * p[6 * BT_W];
-        s = (s + 32768u) >> 16;
-        dst[(size_t)y * lv.pitch + x] = (uint8_t)(s > 255u ? 255u : s);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int y = Y0 + rr + q;
+        if (y >= h) break;
+        uint32_t outw = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t v[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) { const uint32_t wd = (j < 2) ? c0[q + k] : c1[q + k]; v[k] = (j & 1) ? (wd >> 16) : (wd & 0xffff); }
+            uint32_t sum = k0 * v[0] + k1 * v[1] + k2 * v[2] + k3 * v[3] + k4 * v[4] + k5 * v[5] + k6 * v[6];
+            sum = (sum + 32768u) >> 16;
+            outw |= (sum > 255u ? 255u : sum) << (8 * j);
+        }
+        uint8_t *o = dst + (size_t)y * lv.pitch + x;
+        if (x + 3 < lv.pitch) *(uint32_t *)o = outw;       // pitch is a multiple of 64: bytes beyond w are padding
+        else for (int j = 0; j < 4 && x + j < w; j++) o[j] = (uint8_t)(outw >> (8 * j));
     }
 }
 
@@ -764,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g
 int orbx_launch_resize(const OrbxLaunch &L, int level)
 {
     const OrbxLevel &lv = L.geom->lv[level];
-    dim3 grid((unsigned)((lv.w + 1023) / 1024), (unsigned)lv.h, (unsigned)L.batch);
+    dim3 grid((unsigned)((lv.w + 255) / 256), (unsigned)((lv.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS)), (unsigned)L.batch);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, L.stream, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rx, L.ry);
     LAUNCH_CHECK();
     return ORBX_OK;
@@ -774,6 +1101,14 @@ int orbx_launch_fast(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->fastTiles, (unsigned)L.batch);
     hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score);
+    LAUNCH_CHECK();
+    return ORBX_OK;
+}
+
+int orbx_launch_fast_cells(const OrbxLaunch &L)
+{
+    dim3 grid((unsigned)L.geom->cellsPerFrame, (unsigned)L.batch);
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score, L.cellCount, L.cellSlots);
     LAUNCH_CHECK();
     return ORBX_OK;
 }
@@ -801,7 +1136,7 @@ int orbx_launch_octree(const OrbxLaunch &L)
 
 int orbx_launch_orient(const OrbxLaunch &L)
 {
-    dim3 grid((unsigned)((L.geom->kpPerFrame + 3) / 4), (unsigned)L.batch);
+    dim3 grid((unsigned)((L.geom->kpPerFrame + 7) / 8), (unsigned)L.batch);
     hipLaunchKernelGGL(k_orient, grid, dim3(256), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.lvlKp, L.lvlCnt);
     LAUNCH_CHECK();
     return ORBX_OK;

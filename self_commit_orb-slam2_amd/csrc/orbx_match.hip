@@ -9,9 +9,9 @@
 // (node id, feature index) order and a Frame feature that has been taken is skipped by
 // every later KeyFrame feature (:288, :717).  The O(N1*N2) part - all descriptor
 // distances - does not depend on that order, so it runs fully parallel and leaves, per
-// KeyFrame feature, its 4 best candidates by (distance, index).  One wave per pair then
+// KeyFrame feature, its 8 best candidates by (distance, index).  One wave per pair then
 // replays the greedy pass in the reference order over those short lists; whenever fewer
-// than two of the four are still free (and the list was full) it falls back to an exact
+// than two of the eight are still free (and the list was full) it falls back to an exact
 // wave-parallel rescan.  The result is index-exact, including first-minimum-wins ties.
 // VALU/LDS bound (XOR + v_bcnt_u32), not HBM: 144 KB of traffic per 2000x2000 pair.
 #include <math.h>
@@ -25,7 +25,7 @@
 #define TH_LOW 50         /* :50 */
 #define HISTO_LENGTH 30   /* :51 */
 #define KEY_EMPTY 0xffffffffu
-#define TOPK 4
+#define TOPK 8            /* candidates kept per KeyFrame feature; the exact rescan handles overflow */
 #define MATCH_PROF_RING 64
 
 namespace {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_bow_order(FeatDev A, const int32_t *__r
     ord[rank] = i;
 }
 
-// top-4 candidates of every A feature by key = dist<<16 | j over the B features of the same
+// top-TOPK candidates of every A feature by key = dist<<16 | j over the B features of the same
 // node (mode 1: that also carry a valid MapPoint).  B descriptors are staged in LDS as four
 // u64 planes so that consecutive lanes read consecutive 8-byte words (conflict free).
 #define TOPK_ROWS 64   /* A features per block (16 per wave) */
@@ -99,23 +99,29 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
         const unsigned long long *da = (const unsigned long long *)(A.desc + ((size_t)fa * A.cap + i) * 32);
         unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
         const int gA = A.groups ? A.groups[(size_t)fa * A.cap + i] : 0;
-        uint32_t k0 = KEY_EMPTY, k1 = KEY_EMPTY, k2 = KEY_EMPTY, k3 = KEY_EMPTY;
+        uint32_t kk[TOPK];
+#pragma unroll
+        for (int q = 0; q < TOPK; q++) kk[q] = KEY_EMPTY;
         for (int j = lane; j < nB; j += 64) {
             if (gB[j] != gA) continue;
             int d = hamming256(a, plane[j], plane[(size_t)capB + j], plane[2 * (size_t)capB + j], plane[3 * (size_t)capB + j]);
             uint32_t key = ((uint32_t)d << 16) | (uint32_t)j;
-            if (key < k3) {
-                k3 = key;
-                if (k3 < k2) { uint32_t t = k2; k2 = k3; k3 = t; }
-                if (k2 < k1) { uint32_t t = k1; k1 = k2; k2 = t; }
-                if (k1 < k0) { uint32_t t = k0; k0 = k1; k1 = t; }
+            if (key < kk[TOPK - 1]) {   // sorted insert (ascending)
+                kk[TOPK - 1] = key;
+#pragma unroll
+                for (int q = TOPK - 1; q > 0; q--)
+                    if (kk[q] < kk[q - 1]) { uint32_t t = kk[q - 1]; kk[q - 1] = kk[q]; kk[q] = t; }
             }
         }
         uint32_t *out = topk + ((size_t)p * stride + i) * TOPK;
 #pragma unroll
         for (int k = 0; k < TOPK; k++) {
-            uint32_t m = wave_min_u32(k0);
-            if (k0 == m && m != KEY_EMPTY) { k0 = k1; k1 = k2; k2 = k3; k3 = KEY_EMPTY; }   // keys are unique: one lane pops
+            uint32_t m = wave_min_u32(kk[0]);
+            if (kk[0] == m && m != KEY_EMPTY) {   // keys are unique: exactly one lane pops its head
+#pragma unroll
+                for (int q = 0; q < TOPK - 1; q++) kk[q] = kk[q + 1];
+                kk[TOPK - 1] = KEY_EMPTY;
+            }
             if (lane == 0) out[k] = m;
         }
     }
@@ -137,23 +143,36 @@ __global__ __launch_bounds__(64) void k_bow_greedy(FeatDev A, FeatDev B, const i
     for (int i = lane; i < stride; i += 64) { mout[i] = -1; dout[i] = 256; }
     for (int i = lane; i < ((B.cap + 31) >> 5); i += 64) taken[i] = 0;
     if (lane < HISTO_LENGTH) hist[lane] = 0;
+    // the sequential replay must not wait on HBM/L2: processing order (bit 31 = feature without
+    // a valid MapPoint) and the four candidates of every KeyFrame feature are staged in LDS
+    int32_t *sOrd = (int32_t *)(smem + ((((B.cap + 31) >> 5) * 4 + stride + 15) & ~15));
+    uint32_t *sTk = (uint32_t *)(sOrd + ((A.cap + 3) & ~3));
+    {
+        const int32_t *ord = order + (size_t)p * stride;
+        const uint32_t *tk = topk + (size_t)p * stride * TOPK;
+        for (int r = lane; r < nA; r += 64) {
+            int i = ord[r];
+            if (A.valid && !A.valid[(size_t)fa * A.cap + i]) i |= (int)0x80000000;
+            sOrd[r] = i;
+        }
+        for (int t = lane; t < nA * TOPK; t += 64) sTk[t] = tk[t];
+    }
     __syncthreads();
     const orbx_keypoint *kA = A.kp + (size_t)fa * A.cap, *kB = B.kp + (size_t)fb * B.cap;
-    const int32_t *ord = order + (size_t)p * stride;
-    const uint32_t *tk = topk + (size_t)p * stride * TOPK;
     const float factor = HISTO_LENGTH / 360.0f;
     int total = 0;
     for (int r = 0; r < nA; r++) {
-        const int i = ord[r];
-        if (A.valid && !A.valid[(size_t)fa * A.cap + i]) continue;
-        uint32_t key = lane < TOPK ? tk[(size_t)i * TOPK + lane] : KEY_EMPTY;
+        const int i = sOrd[r];
+        if (i < 0) continue;
+        uint32_t key = lane < TOPK ? sTk[i * TOPK + lane] : KEY_EMPTY;
         const bool present = key != KEY_EMPTY;
         const int j = (int)(key & 0xffff);
         const bool free_ = present && !((taken[j >> 5] >> (j & 31)) & 1u);
-        const unsigned mPresent = (unsigned)(__ballot(present) & 0xf), mFree = (unsigned)(__ballot(free_) & 0xf);
+        const unsigned mAll = (1u << TOPK) - 1u;
+        const unsigned mPresent = (unsigned)(__ballot(present) & mAll), mFree = (unsigned)(__ballot(free_) & mAll);
         uint32_t bestKey = KEY_EMPTY;
         int best2 = 256;
-        if (__popc(mFree) >= 2 || mPresent != 0xf) {
+        if (__popc(mFree) >= 2 || mPresent != mAll) {
             if (mFree) {
                 const int la = __ffs(mFree) - 1;
                 bestKey = __shfl(key, la);
@@ -288,7 +307,8 @@ template <typename T> struct MBuf {
 struct orbx_matcher {
     int device = 0, maxFeatures = 0, maxPairs = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t evDep = nullptr, evDone = nullptr;
+    hipEvent_t evDep = nullptr, evDone[2] = {nullptr, nullptr};
+    int doneSlot = 0;
     hipEvent_t ev0[MATCH_PROF_RING] = {}, ev1[MATCH_PROF_RING] = {};   // one pair per *_device call (ring)
     int profCount = 0;
     MBuf<int32_t> pairsA, pairsB, order, matches, dists, nmatches;
@@ -325,7 +345,8 @@ extern "C" int orbx_matcher_create(int device, int max_features, int max_pairs, 
     m->device = device; m->maxFeatures = max_features; m->maxPairs = max_pairs;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
     (void)hipEventCreateWithFlags(&m->evDep, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&m->evDone, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&m->evDone[0], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&m->evDone[1], hipEventDisableTiming);
     for (int r = 0; r < MATCH_PROF_RING; r++) { (void)hipEventCreate(&m->ev0[r]); (void)hipEventCreate(&m->ev1[r]); }
     const size_t S = (size_t)max_features, P = (size_t)max_pairs;
     int rc;
@@ -347,7 +368,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     m->topk.release(); m->scales.release();
     for (int s = 0; s < 2; s++) { m->hk[s].release(); m->hd[s].release(); m->hv[s].release(); m->hc[s].release(); m->hg[s].release(); }
     if (m->evDep) (void)hipEventDestroy(m->evDep);
-    if (m->evDone) (void)hipEventDestroy(m->evDone);
+    for (int i = 0; i < 2; i++) if (m->evDone[i]) (void)hipEventDestroy(m->evDone[i]);
     for (int r = 0; r < MATCH_PROF_RING; r++) { if (m->ev0[r]) (void)hipEventDestroy(m->ev0[r]); if (m->ev1[r]) (void)hipEventDestroy(m->ev1[r]); }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -375,13 +396,17 @@ static int prep_pairs(orbx_matcher *m, const orbx_feature_set *a, const orbx_fea
     return ORBX_OK;
 }
 
-// The producer's next batch overwrites the feature buffers this call reads: make its stream
-// wait until the match kernels are done (the two handles otherwise run on independent streams).
+// The producer double-buffers its results: the batch extracted next does not touch what this call
+// reads, the one after that does.  Hand the producer an event recorded behind the match kernels; it
+// waits for it right before overwriting this buffer again, so matching batch i overlaps with the
+// extraction of batch i+1 (the greedy replay occupies one wave per CU and is latency bound).
 static int chain_back(orbx_matcher *m, orbx_extractor *after)
 {
     if (!after) return ORBX_OK;
-    ORBX_HIP_CHECK(hipEventRecord(m->evDone, m->stream));
-    ORBX_HIP_CHECK(hipStreamWaitEvent(orbx_extractor_stream_internal(after), m->evDone, 0));
+    hipEvent_t ev = m->evDone[m->doneSlot];
+    m->doneSlot ^= 1;
+    ORBX_HIP_CHECK(hipEventRecord(ev, m->stream));
+    orbx_extractor_set_consumer_event_internal(after, ev);
     return ORBX_OK;
 }
 
@@ -416,7 +441,9 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     hipLaunchKernelGGL(k_bow_topk, dim3((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs), dim3(256), ldsTopk, m->stream, A, B,
                        m->pairsA.p, m->pairsB.p, params->mode, m->topk.p, stride);
     MLAUNCH_CHECK();
-    const size_t ldsGreedy = (size_t)((b->capacity + 31) / 32) * 4 + (size_t)stride + 16;
+    const size_t ldsGreedy = (size_t)((b->capacity + 31) / 32) * 4 + (size_t)stride + 32 + (size_t)(a->capacity + 4) * 4 * (1 + TOPK);
+    if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
+    if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
     hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(64), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, params->nn_ratio,
                        params->check_orientation, m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride);
     MLAUNCH_CHECK();

@@ -1,0 +1,66 @@
+// shim/ORBextractor.h -- drop-in replacement header for the reference's include/ORBextractor.h.
+//
+// Same namespace, class name, constructor, functor signature, getters and the public
+// `mvImagePyramid` member as ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:92-161),
+// so src/Frame.cc, src/Tracking.cc and src/Frame.cc::ComputeStereoMatches compile and behave
+// unchanged; the body marshals to the C ABI of liborbx.so (include/orbx.h) and the work runs
+// on the MI355X.  No CPU fallback: construction throws std::runtime_error without a GPU.
+#ifndef ORBEXTRACTOR_H
+#define ORBEXTRACTOR_H
+
+#include <vector>
+
+#include <opencv/cv.h>
+
+struct orbx_extractor;
+
+namespace ORB_SLAM2
+{
+
+class ORBextractor
+{
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+    ~ORBextractor();
+
+    // Computes the ORB features and descriptors of an image; `mask` is ignored, exactly like
+    // the reference implementation does.
+    void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint> &keypoints, cv::OutputArray descriptors);
+
+    int inline GetLevels() { return nlevels; }
+    float inline GetScaleFactor() { return (float)scaleFactor; }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // Host copy of the image pyramid of the last frame (read by Frame::ComputeStereoMatches).
+    // Set mbKeepHostPyramid = false to skip the device->host copy when nobody reads it
+    // (monocular / RGB-D tracking).
+    std::vector<cv::Mat> mvImagePyramid;
+    bool mbKeepHostPyramid;
+
+    // Device used by extractors constructed afterwards (default 0).
+    static void SetDevice(int device);
+
+private:
+    ORBextractor(const ORBextractor &);
+    ORBextractor &operator=(const ORBextractor &);
+    void EnsureHandle(int width, int height);
+
+    int nfeatures;
+    double scaleFactor;
+    int nlevels;
+    int iniThFAST;
+    int minThFAST;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int> mnFeaturesPerLevel;
+    orbx_extractor *mpHandle;
+    int mMaxW, mMaxH;
+};
+
+} // namespace ORB_SLAM2
+
+#endif

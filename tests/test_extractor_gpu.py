@@ -25,6 +25,7 @@ def kp_matrix(k):
 @pytest.mark.parametrize("W,H,nf", CONFIGS)
 def test_stages_bit_exact(orbx, oracle, W, H, nf):
     ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2)
+    ext.set_debug_taps(True)     # keep the FAST score map (the fused detector does not write it otherwise)
     rst = oracle.restatement(nf)
     t, q, u = rst.tables()
     assert (ext.GetScaleFactors().view(np.uint32) == t[0].view(np.uint32)).all()

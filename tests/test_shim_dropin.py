@@ -1,0 +1,63 @@
+"""Drop-in proof: the reference-compatible C++ class ORB_SLAM2::ORBextractor of shim/ (same
+header surface as reference include/ORBextractor.h:92-161), called exactly like
+Frame::ExtractORB does (src/Frame.cc:503), gives the reference's results and keeps the
+public mvImagePyramid member valid (read by Frame::ComputeStereoMatches)."""
+import ctypes
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+SO = ROOT / "tests" / "libshimtest.so"
+
+
+def build_shim():
+    srcs = [ROOT / "tests" / "shim_wrap.cc", ROOT / "self_commit_orb-slam2_amd" / "shim" / "ORBextractor.cc"]
+    if SO.exists() and all(SO.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+        return
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ to build the shim test wrapper")
+    subprocess.run(["g++", "-std=gnu++11", "-O2", "-fPIC", "-shared", "-I" + str(ROOT / "oracle" / "cvshim"),
+                    "-I" + str(ROOT / "self_commit_orb-slam2_amd" / "shim"), "-I" + str(ROOT / "include"), "-o", str(SO)] +
+                   [str(s) for s in srcs] + ["-L" + str(ROOT / "self_commit_orb-slam2_amd" / "lib"), "-lorbx",
+                                             "-Wl,-rpath," + str(ROOT / "self_commit_orb-slam2_amd" / "lib")], check=True)
+
+
+def test_shim_compiles_against_the_opencv_surface(orbx):
+    """CPU: the class shim builds against the same OpenCV API slice the reference file uses."""
+    orbx.load_library()
+    build_shim()
+    L = ctypes.CDLL(str(SO))
+    assert hasattr(L, "shim_extract")
+
+
+@pytest.mark.gpu
+def test_shim_equals_reference_class(orbx, oracle):
+    orbx.load_library()
+    build_shim()
+    L = ctypes.CDLL(str(SO))
+    L.shim_create.restype = ctypes.c_void_p
+    L.shim_create.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    h = ctypes.c_void_p(L.shim_create(1000, 1.2, 8, 20, 7))
+    assert h.value, "shim constructor failed"
+    chk = oracle.reference(1000) or oracle.restatement(1000)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for seed in (41, 42, 43):
+        W, H = (640, 480) if seed != 43 else (752, 480)      # the handle grows transparently
+        im = orbx.synth_frame(seed, W, H)
+        k = np.zeros((4096, 7), np.float32)
+        d = np.zeros((4096, 32), np.uint8)
+        n = L.shim_extract(h, P(im), W, H, W, P(k), P(d), 4096)
+        ko, do = chk.extract(im)
+        assert n == len(ko) and (k[:n].view(np.uint32) == ko.view(np.uint32)).all() and (d[:n] == do).all()
+        rst = oracle.restatement(1000)
+        pyr = oracle.pyramid(rst, im)
+        for l in range(L.shim_levels(h)):
+            w, hh = ctypes.c_int(), ctypes.c_int()
+            buf = np.zeros(pyr[l].shape, np.uint8)
+            L.shim_pyramid_level(h, l, P(buf), ctypes.byref(w), ctypes.byref(hh))
+            assert (w.value, hh.value) == (pyr[l].shape[1], pyr[l].shape[0]) and (buf == pyr[l]).all()
+    L.shim_destroy(h)
