@@ -6,9 +6,11 @@
 //   ORBmatcher::SearchByBoW(KeyFrame*,KeyFrame*) src/ORBmatcher.cc:656-799
 //   ORBmatcher::ComputeThreeMaxima            src/ORBmatcher.cc:1866-1908
 //   Frame::ComputeStereoMatches, Hamming stage src/Frame.cc:1041-1216
-// The reference versions walk the live KeyFrame/MapPoint/Frame object graph (mutexes,
-// DBoW2 FeatureVector maps) and cannot be compiled here without OpenCV + DBoW2 + the
-// whole map; "PARITY UNPINNED": no reference test or golden vector exists for them.
+//   Frame::ComputeStereoMatches, complete      src/Frame.cc:1026-1420
+// PINNED by the reference itself: oracle/_ref/liborbslam.so is the unmodified
+// src/ORBmatcher.cc + Frame.cc + KeyFrame.cc + MapPoint.cc + DBoW2 compiled against
+// oracle/cvshim, and tests/test_refslam.py checks every function here against it (real
+// KeyFrame / Frame / MapPoint objects) on seeded inputs; tests/golden/ holds its outputs.
 // What is kept literally: the bit-hack distance, scan order (ascending node id, ascending
 // feature index inside a node), strict '<' updates (first minimum wins), the skip of
 // already matched F features, thresholds, ratio test in float, the 30-bin rotation
@@ -17,6 +19,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <vector>
 
@@ -166,5 +169,91 @@ MO_API void mo_stereo_hamming(const float *kpL, const uint8_t *descL, int nL, co
         }
         best_dist[iL] = bestDist;
         best_idx[iL] = (int32_t)bestIdxR;
+    }
+}
+
+
+// Frame::ComputeStereoMatches, complete (src/Frame.cc:1026-1420): Hamming stage as above,
+// then the 11x11 SAD search over +-5 px on the keypoint's pyramid level (:1224-1306), the
+// parabola sub-pixel fit (:1330-1347), the disparity gate (:1355-1378) and the
+// median * 1.5 * 1.4 outlier cut (:1387-1416).  pyrL/pyrR: the nlevels level images (tight
+// rows, sizes lw/lh) concatenated.  mb is what Frame::mb holds when the function runs: 0 in
+// the stereo constructor of this fork (src/Frame.cc:125) => maxD = +inf.
+// Float behaviour kept: round() on float products, SAD distances are exact integers in
+// float, `bestDist = dist` truncates float->int, deltaR/bestuR in float, the 0.01 clamp in
+// double (`uL-0.01`).  An empty vDistIdx is undefined behaviour in the reference
+// (vDistIdx[0] of an empty vector, :1388); here nothing is cut in that case.
+MO_API void mo_compute_stereo_matches(const float *kpL, const uint8_t *descL, int nL, const float *kpR, const uint8_t *descR, int nR,
+                                      const uint8_t *pyrL, const uint8_t *pyrR, const int *lw, const int *lh, int nlevels,
+                                      const float *scaleFactors, const float *invScaleFactors, float mbf, float mb,
+                                      float *uRight, float *depth, int32_t *sad_out)
+{
+    const int nRows = lh[0];
+    std::vector<int32_t> bd((size_t)(nL > 0 ? nL : 1)), bi((size_t)(nL > 0 ? nL : 1));
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    mo_stereo_hamming(kpL, descL, nL, kpR, descR, nR, scaleFactors, nRows, maxD, bd.data(), bi.data());
+    std::vector<size_t> off((size_t)nlevels);
+    size_t o = 0;
+    for (int l = 0; l < nlevels; l++) { off[(size_t)l] = o; o += (size_t)lw[l] * lh[l]; }
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    std::vector<std::pair<int, int> > vDistIdx;
+    for (int iL = 0; iL < nL; iL++) {
+        uRight[iL] = -1.0f;
+        depth[iL] = -1.0f;
+        if (sad_out) sad_out[iL] = -1;
+        // the reference `continue`s before the Hamming loop for an empty row / maxU < 0: bd stays TH_HIGH
+        if (!(bd[(size_t)iL] < thOrbDist)) continue;
+        const int oct = (int)kpL[7 * iL + 5];
+        const float uL = kpL[7 * iL], vL = kpL[7 * iL + 1];
+        const float uR0 = kpR[7 * (size_t)bi[(size_t)iL]];
+        const float scaleFactor = invScaleFactors[oct];
+        const float scaleduL = roundf(uL * scaleFactor);
+        const float scaledvL = roundf(vL * scaleFactor);
+        const float scaleduR0 = roundf(uR0 * scaleFactor);
+        const int w = 5, L = 5;
+        const int W = lw[oct];
+        const uint8_t *imL = pyrL + off[(size_t)oct], *imR = pyrR + off[(size_t)oct];
+        const int cy = (int)scaledvL, cxl = (int)scaleduL;
+        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+        if (iniu < 0 || endu >= W) continue;
+        const int centerL = imL[(size_t)cy * W + cxl];
+        int bestDist = 0x7fffffff, bestincR = 0;
+        float vDists[2 * 5 + 1];
+        for (int incR = -L; incR <= L; incR++) {
+            const int cxr = (int)(scaleduR0 + incR);   // colRange(scaleduR0+incR-w, ...) truncates the float sum
+            const int centerR = imR[(size_t)cy * W + cxr];
+            int sad = 0;
+            for (int dy = -w; dy <= w; dy++)
+                for (int dx = -w; dx <= w; dx++) {
+                    int a = (int)imL[(size_t)(cy + dy) * W + cxl + dx] - centerL;
+                    int b = (int)imR[(size_t)(cy + dy) * W + cxr + dx] - centerR;
+                    sad += a > b ? a - b : b - a;
+                }
+            const float dist = (float)sad;
+            if (dist < bestDist) { bestDist = (int)dist; bestincR = incR; }
+            vDists[L + incR] = dist;
+        }
+        if (bestincR == -L || bestincR == L) continue;
+        const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+        const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+        if (deltaR < -1 || deltaR > 1) continue;
+        float bestuR = scaleFactors[oct] * ((float)scaleduR0 + (float)bestincR + deltaR);
+        float disparity = (uL - bestuR);
+        if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+            depth[iL] = mbf / disparity;
+            uRight[iL] = bestuR;
+            if (sad_out) sad_out[iL] = bestDist;
+            vDistIdx.push_back(std::pair<int, int>(bestDist, iL));
+        }
+    }
+    if (vDistIdx.empty()) return;
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[(size_t)i].first < thDist) break;
+        uRight[vDistIdx[(size_t)i].second] = -1;
+        depth[vDistIdx[(size_t)i].second] = -1;
     }
 }

@@ -1,0 +1,318 @@
+// oracle/refslam_wrap.cc -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// C wrapper around the UNMODIFIED reference classes ORB_SLAM2::{ORBextractor, ORBmatcher,
+// Frame, KeyFrame, MapPoint, Map} and the vendored DBoW2, compiled from where they lie
+// under /root/reference against oracle/cvshim (oracle/Makefile -> oracle/_ref/liborbslam.so).
+// It drives the reference's own object graph, so what the tests compare against is the
+// reference's code path, not a restatement:
+//   orbslam_stereo_frame   Frame::Frame(imLeft, imRight, ...)      src/Frame.cc:100-199
+//                          -> ExtractORB x2 (two std::threads), UndistortKeyPoints,
+//                             Frame::ComputeStereoMatches           src/Frame.cc:1026-1420
+//   orbslam_search_by_bow  ORBmatcher::SearchByBoW(KeyFrame*,Frame&,...)     src/ORBmatcher.cc:230-382
+//                          ORBmatcher::SearchByBoW(KeyFrame*,KeyFrame*,...)  src/ORBmatcher.cc:656-799
+//   orbslam_descriptor_distance  ORBmatcher::DescriptorDistance     src/ORBmatcher.cc:1913-1933
+//   orbslam_voc_* / orbslam_transform   DBoW2 TemplatedVocabulary::create / transform
+//                          (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:507-570, 1127-1262)
+//   orbslam_search_by_projection_*      ORBmatcher::SearchByProjection (src/ORBmatcher.cc:70-175, 1569-1728)
+// Only include/Converter.h (Eigen + g2o types) is replaced, by the one function the compiled
+// files use (toDescriptorVector, src/Converter.cc:38-47).
+//
+// Determinism of DistributeOctTree's pointer tie-break (src/ORBextractor.cc:948): the stereo
+// Frame constructor runs the two extractors on std::threads it creates itself, so the bump
+// arena cannot be switched on around the call like oracle/ref_wrap.cc does.  Instead every
+// thread that is NOT the calling thread gets its own monotone bump chunk on first allocation
+// (while a wrapper call is in flight); chunks come from one big NORESERVE mapping, are never
+// reused, and `delete` of an arena pointer is a no-op, so memory handed to longer-lived
+// objects (mvKeys) stays valid.
+#include <sys/mman.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+
+#include "Frame.h"
+#include "KeyFrame.h"
+#include "Map.h"
+#include "MapPoint.h"
+#include "ORBVocabulary.h"
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+
+// ---------------------------------------------------------------------------------------
+// bump arenas for worker threads
+// ---------------------------------------------------------------------------------------
+namespace {
+const size_t kChunk = (size_t)64 << 20;
+const size_t kRegion = (size_t)64 << 30;
+char *g_region = nullptr;
+std::atomic<size_t> g_next_chunk{0};
+std::atomic<int> g_workers_use_arena{0};
+struct ThreadArena { char *base; size_t off; int state; };   // state 0 unset, 1 active, 2 off
+thread_local ThreadArena t_arena = {nullptr, 0, 0};
+thread_local bool t_is_caller = false;
+
+void region_init()
+{
+    if (g_region) return;
+    void *p = mmap(nullptr, kRegion, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) { fprintf(stderr, "orbslam: cannot reserve the arena region\n"); abort(); }
+    g_region = (char *)p;
+}
+inline bool in_region(void *p) { return g_region && (char *)p >= g_region && (char *)p < g_region + kRegion; }
+struct CallScope {
+    CallScope() { region_init(); t_is_caller = true; t_arena.state = 2; g_workers_use_arena.fetch_add(1); }
+    ~CallScope() { g_workers_use_arena.fetch_sub(1); }
+};
+}  // namespace
+
+#define ORBSLAM_HIDDEN __attribute__((visibility("hidden")))
+ORBSLAM_HIDDEN void *operator new(size_t n)
+{
+    if (t_arena.state == 0) {
+        if (!t_is_caller && g_workers_use_arena.load() > 0) {
+            size_t c = g_next_chunk.fetch_add(1);
+            if ((c + 1) * kChunk > kRegion) { fprintf(stderr, "orbslam: arena region exhausted\n"); abort(); }
+            t_arena.base = g_region + c * kChunk;
+            t_arena.off = 0;
+            t_arena.state = 1;
+        } else if (t_is_caller) {
+            t_arena.state = 2;
+        }
+    }
+    if (t_arena.state == 1) {
+        size_t a = (t_arena.off + 15) & ~(size_t)15;
+        if (a + n > kChunk) { fprintf(stderr, "orbslam: thread arena exhausted\n"); abort(); }
+        t_arena.off = a + n;
+        return t_arena.base + a;
+    }
+    void *p = malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+ORBSLAM_HIDDEN void *operator new[](size_t n) { return operator new(n); }
+ORBSLAM_HIDDEN void operator delete(void *p) noexcept { if (p && !in_region(p)) free(p); }
+ORBSLAM_HIDDEN void operator delete[](void *p) noexcept { operator delete(p); }
+ORBSLAM_HIDDEN void operator delete(void *p, size_t) noexcept { operator delete(p); }
+ORBSLAM_HIDDEN void operator delete[](void *p, size_t) noexcept { operator delete(p); }
+
+// ---------------------------------------------------------------------------------------
+// the one Converter function the compiled reference files call (src/Converter.cc:38-47)
+// ---------------------------------------------------------------------------------------
+namespace ORB_SLAM2 {
+std::vector<cv::Mat> Converter::toDescriptorVector(const cv::Mat &Descriptors)
+{
+    std::vector<cv::Mat> vDesc;
+    vDesc.reserve(Descriptors.rows);
+    for (int j = 0; j < Descriptors.rows; j++) vDesc.push_back(Descriptors.row(j));
+    return vDesc;
+}
+}  // namespace ORB_SLAM2
+
+using namespace ORB_SLAM2;
+
+#define ORBSLAM_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+void put_kp(float *o, const cv::KeyPoint &k)
+{
+    o[0] = k.pt.x; o[1] = k.pt.y; o[2] = k.size; o[3] = k.angle; o[4] = k.response;
+    o[5] = (float)k.octave; o[6] = (float)k.class_id;
+}
+cv::KeyPoint get_kp(const float *o)
+{
+    return cv::KeyPoint(o[0], o[1], o[2], o[3], o[4], (int)o[5], (int)o[6]);
+}
+cv::Mat make_K(float fx, float fy, float cx, float cy)
+{
+    cv::Mat K = cv::Mat::eye(3, 3, CV_32F);
+    K.at<float>(0, 0) = fx; K.at<float>(1, 1) = fy; K.at<float>(0, 2) = cx; K.at<float>(1, 2) = cy;
+    return K;
+}
+
+// A Frame built from flat arrays through the default constructor (src/Frame.cc:47) and the
+// class's public members - what Tracking would hold after the Frame constructor ran.
+struct Camera { float fx, fy, cx, cy, bf; int width, height; };
+void fill_frame(Frame &F, const float *kps, const uint8_t *desc, int n, const int32_t *groups, const Camera &cam,
+                const float *scale_factors, int nlevels)
+{
+    F.mpORBvocabulary = nullptr;
+    F.mpORBextractorLeft = F.mpORBextractorRight = nullptr;
+    F.mTimeStamp = 0;
+    F.mnId = Frame::nNextId++;
+    F.N = n;
+    F.mvKeys.resize(n);
+    for (int i = 0; i < n; i++) F.mvKeys[i] = get_kp(kps + 7 * (size_t)i);
+    F.mvKeysUn = F.mvKeys;
+    F.mvuRight.assign(n, -1.f);
+    F.mvDepth.assign(n, -1.f);
+    F.mDescriptors = cv::Mat(n, 32, CV_8UC1);
+    for (int i = 0; i < n; i++) memcpy(F.mDescriptors.ptr(i), desc + 32 * (size_t)i, 32);
+    F.mvpMapPoints.assign(n, (MapPoint *)nullptr);
+    F.mvbOutlier.assign(n, false);
+    if (groups)
+        for (int i = 0; i < n; i++)
+            if (groups[i] >= 0) F.mFeatVec.addFeature((DBoW2::NodeId)groups[i], (unsigned)i);
+    F.mK = make_K(cam.fx, cam.fy, cam.cx, cam.cy);
+    F.mDistCoef = cv::Mat::zeros(4, 1, CV_32F);
+    Frame::fx = cam.fx; Frame::fy = cam.fy; Frame::cx = cam.cx; Frame::cy = cam.cy;
+    Frame::invfx = 1.0f / cam.fx; Frame::invfy = 1.0f / cam.fy;
+    Frame::mnMinX = 0; Frame::mnMaxX = (float)cam.width; Frame::mnMinY = 0; Frame::mnMaxY = (float)cam.height;
+    Frame::mfGridElementWidthInv = (float)FRAME_GRID_COLS / (Frame::mnMaxX - Frame::mnMinX);
+    Frame::mfGridElementHeightInv = (float)FRAME_GRID_ROWS / (Frame::mnMaxY - Frame::mnMinY);
+    Frame::mbInitialComputations = false;
+    F.mbf = cam.bf; F.mb = cam.bf / cam.fx; F.mThDepth = 40.f * F.mb;
+    F.mnScaleLevels = nlevels;
+    F.mvScaleFactors.assign(scale_factors, scale_factors + nlevels);
+    F.mvInvScaleFactors.resize(nlevels); F.mvLevelSigma2.resize(nlevels); F.mvInvLevelSigma2.resize(nlevels);
+    for (int l = 0; l < nlevels; l++) {
+        F.mvInvScaleFactors[l] = 1.0f / scale_factors[l];
+        F.mvLevelSigma2[l] = scale_factors[l] * scale_factors[l];
+        F.mvInvLevelSigma2[l] = 1.0f / F.mvLevelSigma2[l];
+    }
+    F.mfScaleFactor = nlevels > 1 ? scale_factors[1] : 1.2f;
+    F.mfLogScaleFactor = logf(F.mfScaleFactor);
+    F.mpReferenceKF = nullptr;
+    // grid exactly as Frame::AssignFeaturesToGrid (src/Frame.cc:461-491) would fill it
+    for (int i = 0; i < n; i++) {
+        int gx, gy;
+        if (F.PosInGrid(F.mvKeysUn[i], gx, gy)) F.mGrid[gx][gy].push_back(i);
+    }
+}
+const float kDefaultScales[8] = {1.f, 1.2f, 1.44f, 1.728f, 2.0736f, 2.48832f, 2.985984f, 3.5831808f};
+}  // namespace
+
+ORBSLAM_API int orbslam_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    cv::Mat ma(1, 32, CV_8UC1, (void *)a), mb(1, 32, CV_8UC1, (void *)b);
+    return ORBmatcher::DescriptorDistance(ma, mb);
+}
+
+// Frame::Frame(imLeft, imRight, ...) with two reference extractors.  Keypoints as 7 floats
+// each.  Returns 0; *nL / *nR receive the real counts (only `cap` entries are written).
+ORBSLAM_API int orbslam_stereo_frame(const uint8_t *imL, const uint8_t *imR, int w, int h, int stride, int nfeatures,
+                                     float scaleFactor, int nlevels, int iniTh, int minTh, float fx, float fy, float cx,
+                                     float cy, float bf, float thDepth, float *kpsL, uint8_t *descL, float *kpsR,
+                                     uint8_t *descR, float *uRight, float *depth, int cap, int *nL, int *nR)
+{
+    CallScope scope;
+    ORBextractor *exL = new ORBextractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+    ORBextractor *exR = new ORBextractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+    cv::Mat L(h, w, CV_8UC1, (void *)imL, (size_t)stride), R(h, w, CV_8UC1, (void *)imR, (size_t)stride);
+    cv::Mat K = make_K(fx, fy, cx, cy), dist = cv::Mat::zeros(4, 1, CV_32F);
+    Frame::mbInitialComputations = true;
+    {
+        Frame F(L, R, 0.0, exL, exR, (ORBVocabulary *)nullptr, K, dist, bf, thDepth);
+        *nL = F.N;
+        *nR = (int)F.mvKeysRight.size();
+        for (int i = 0; i < F.N && i < cap; i++) {
+            put_kp(kpsL + 7 * (size_t)i, F.mvKeys[i]);
+            memcpy(descL + 32 * (size_t)i, F.mDescriptors.ptr(i), 32);
+            uRight[i] = F.mvuRight[i];
+            depth[i] = F.mvDepth[i];
+        }
+        for (int i = 0; i < *nR && i < cap; i++) {
+            put_kp(kpsR + 7 * (size_t)i, F.mvKeysRight[i]);
+            memcpy(descR + 32 * (size_t)i, F.mDescriptorsRight.ptr(i), 32);
+        }
+    }
+    delete exL;
+    delete exR;
+    return 0;
+}
+
+// Frame::ComputeStereoMatches on GIVEN features + pyramids (default-constructed Frame whose
+// public members are filled; the extractors only lend their mvImagePyramid).  pyrL/pyrR:
+// nlevels tight u8 images concatenated, sizes in lw/lh.  mb = 0 like in the stereo
+// constructor of this fork (src/Frame.cc:125).
+ORBSLAM_API int orbslam_compute_stereo_matches(const float *kpsL, const uint8_t *descL, int nL, const float *kpsR,
+                                               const uint8_t *descR, int nR, const uint8_t *pyrL, const uint8_t *pyrR,
+                                               const int *lw, const int *lh, int nlevels, const float *scale_factors,
+                                               float bf, float *uRight, float *depth)
+{
+    CallScope scope;
+    ORBextractor *exL = new ORBextractor(1000, 1.2f, nlevels, 20, 7);
+    ORBextractor *exR = new ORBextractor(1000, 1.2f, nlevels, 20, 7);
+    size_t off = 0;
+    for (int l = 0; l < nlevels; l++) {
+        exL->mvImagePyramid[l] = cv::Mat(lh[l], lw[l], CV_8UC1, (void *)(pyrL + off), (size_t)lw[l]);
+        exR->mvImagePyramid[l] = cv::Mat(lh[l], lw[l], CV_8UC1, (void *)(pyrR + off), (size_t)lw[l]);
+        off += (size_t)lw[l] * lh[l];
+    }
+    {
+        Frame F;
+        Camera cam = {500.f, 500.f, (float)lw[0] / 2, (float)lh[0] / 2, bf, lw[0], lh[0]};
+        fill_frame(F, kpsL, descL, nL, nullptr, cam, scale_factors, nlevels);
+        F.mpORBextractorLeft = exL;
+        F.mpORBextractorRight = exR;
+        F.mvKeysRight.resize(nR);
+        for (int i = 0; i < nR; i++) F.mvKeysRight[i] = get_kp(kpsR + 7 * (size_t)i);
+        F.mDescriptorsRight = cv::Mat(nR, 32, CV_8UC1);
+        for (int i = 0; i < nR; i++) memcpy(F.mDescriptorsRight.ptr(i), descR + 32 * (size_t)i, 32);
+        F.mb = 0;
+        F.ComputeStereoMatches();
+        for (int i = 0; i < nL; i++) { uRight[i] = F.mvuRight[i]; depth[i] = F.mvDepth[i]; }
+    }
+    delete exL;
+    delete exR;
+    return 0;
+}
+
+// mode 0: SearchByBoW(KeyFrame* A, Frame& B, vpMapPointMatches): matches[j in B] = index in A or -1
+// mode 1: SearchByBoW(KeyFrame* A, KeyFrame* B, vpMatches12):    matches[i in A] = index in B or -1
+// valid*: 1 = the feature has a (non-bad) MapPoint; NULL = all.  groups*: DBoW2 node id per
+// feature (the FeatureVector), -1 = feature not in the FeatureVector.
+ORBSLAM_API int orbslam_search_by_bow(int mode, const float *kpsA, const uint8_t *descA, int nA, const int32_t *groupsA,
+                                      const uint8_t *validA, const float *kpsB, const uint8_t *descB, int nB,
+                                      const int32_t *groupsB, const uint8_t *validB, float nnratio, int checkOri,
+                                      int32_t *matches)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {500.f, 500.f, 320.f, 240.f, 40.f, 640, 480};
+    Frame FA, FB;
+    fill_frame(FA, kpsA, descA, nA, groupsA, cam, kDefaultScales, 8);
+    fill_frame(FB, kpsB, descB, nB, groupsB, cam, kDefaultScales, 8);
+    FA.mTcw = cv::Mat::eye(4, 4, CV_32F);
+    FB.mTcw = cv::Mat::eye(4, 4, CV_32F);
+    KeyFrame *kfA = new KeyFrame(FA, &map, (KeyFrameDatabase *)nullptr);
+    std::vector<MapPoint *> owned;
+    std::map<MapPoint *, int> indexA, indexB;
+    cv::Mat pos = cv::Mat::zeros(3, 1, CV_32F);
+    pos.at<float>(2) = 1.f;
+    for (int i = 0; i < nA; i++)
+        if (!validA || validA[i]) {
+            MapPoint *mp = new MapPoint(pos, kfA, &map);
+            kfA->AddMapPoint(mp, (size_t)i);
+            indexA[mp] = i;
+            owned.push_back(mp);
+        }
+    ORBmatcher matcher(nnratio, checkOri != 0);
+    int n = 0;
+    KeyFrame *kfB = nullptr;
+    if (mode == 0) {
+        std::vector<MapPoint *> vp;
+        n = matcher.SearchByBoW(kfA, FB, vp);
+        for (int j = 0; j < nB; j++) matches[j] = vp[j] ? indexA[vp[j]] : -1;
+    } else {
+        kfB = new KeyFrame(FB, &map, (KeyFrameDatabase *)nullptr);
+        for (int i = 0; i < nB; i++)
+            if (!validB || validB[i]) {
+                MapPoint *mp = new MapPoint(pos, kfB, &map);
+                kfB->AddMapPoint(mp, (size_t)i);
+                indexB[mp] = i;
+                owned.push_back(mp);
+            }
+        std::vector<MapPoint *> vp;
+        n = matcher.SearchByBoW(kfA, kfB, vp);
+        for (int i = 0; i < nA; i++) matches[i] = vp[i] ? indexB[vp[i]] : -1;
+    }
+    for (size_t i = 0; i < owned.size(); i++) delete owned[i];
+    delete kfA;
+    delete kfB;
+    return n;
+}

@@ -204,3 +204,102 @@ def local_bundle_adjustment(orc, w, stop=None):
                                    _p(w["edge_obs"]), _p(w["edge_inv_sigma2"]), None if stop is None else _p(stop), _p(poses_out), _p(points_out),
                                    _p(chi2), _p(outl), _p(stats))
     return dict(poses=poses_out, points=points_out, chi2=chi2, outlier=outl, stats=stats)
+
+
+# ---- the UNMODIFIED reference matcher / Frame / KeyFrame / MapPoint / DBoW2 sources compiled
+# ---- against oracle/cvshim (oracle/refslam_wrap.cc -> oracle/_ref/liborbslam.so)
+SLAM_SO = ROOT / "oracle" / "_ref" / "liborbslam.so"
+_slam = None
+
+
+def slam_lib():
+    """ctypes handle of oracle/_ref/liborbslam.so, or None when it was never built (it is built
+    in the container that has /root/reference and travels to the GPU box as a binary)."""
+    global _slam
+    if _slam is None and SLAM_SO.exists():
+        _slam = ctypes.CDLL(str(SLAM_SO))
+    return _slam
+
+
+def ref_descriptor_distance(a, b):
+    return slam_lib().orbslam_descriptor_distance(_p(np.ascontiguousarray(a, np.uint8)), _p(np.ascontiguousarray(b, np.uint8)))
+
+
+def ref_search_by_bow(mode, kpsA, descA, kpsB, descB, nnratio, check_ori, groupsA=None, groupsB=None, validA=None, validB=None):
+    """ORBmatcher::SearchByBoW of the reference, driven through real KeyFrame/Frame/MapPoint objects."""
+    lib = slam_lib()
+    lib.orbslam_search_by_bow.argtypes = [ctypes.c_int] + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] * 2 + \
+                                         [ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+    kA, kB = _kp7(kpsA), _kp7(kpsB)
+    dA, dB = np.ascontiguousarray(descA, np.uint8), np.ascontiguousarray(descB, np.uint8)
+    # the reference takes DBoW2 FeatureVectors: no groups = every feature under one node
+    gA = np.zeros(len(kA), np.int32) if groupsA is None else np.ascontiguousarray(groupsA, np.int32)
+    gB = np.zeros(len(kB), np.int32) if groupsB is None else np.ascontiguousarray(groupsB, np.int32)
+    vA, vB = _opt(validA, np.uint8), _opt(validB, np.uint8)
+    nout = len(kB) if mode == 0 else len(kA)
+    out = np.full(max(nout, 1), -1, np.int32)
+    P = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    n = lib.orbslam_search_by_bow(mode, P(kA), P(dA), len(kA), P(gA), P(vA), P(kB), P(dB), len(kB), P(gB), P(vB),
+                                  ctypes.c_float(nnratio), 1 if check_ori else 0, P(out))
+    return n, out[:nout]
+
+
+def ref_stereo_frame(imL, imR, nfeatures, fx, fy, cx, cy, bf, th_depth=35.0, scale=1.2, nlevels=8, ini=20, mn=7, cap=8192):
+    """Frame::Frame(imLeft, imRight, ...) of the reference: both extractions + ComputeStereoMatches."""
+    lib = slam_lib()
+    H, W = imL.shape
+    imL, imR = np.ascontiguousarray(imL), np.ascontiguousarray(imR)
+    kL, kR = np.zeros((cap, 7), np.float32), np.zeros((cap, 7), np.float32)
+    dL, dR = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+    uR, dep = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    nL, nR = ctypes.c_int(), ctypes.c_int()
+    lib.orbslam_stereo_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
+                                        [ctypes.c_float] * 6 + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.orbslam_stereo_frame(_p(imL), _p(imR), W, H, W, nfeatures, scale, nlevels, ini, mn, fx, fy, cx, cy, bf, th_depth,
+                             _p(kL), _p(dL), _p(kR), _p(dR), _p(uR), _p(dep), cap, ctypes.byref(nL), ctypes.byref(nR))
+    a, b = nL.value, nR.value
+    assert a <= cap and b <= cap
+    return dict(kpsL=kL[:a].copy(), descL=dL[:a].copy(), kpsR=kR[:b].copy(), descR=dR[:b].copy(), uRight=uR[:a].copy(), depth=dep[:a].copy())
+
+
+def ref_compute_stereo_matches(kpsL, descL, kpsR, descR, pyrL, pyrR, scale_factors, bf):
+    """Frame::ComputeStereoMatches of the reference on given features and pyramids (lists of 2-D u8 arrays)."""
+    lib = slam_lib()
+    kl = kpsL if kpsL.dtype == np.float32 and kpsL.ndim == 2 else _kp7(kpsL)
+    kr = kpsR if kpsR.dtype == np.float32 and kpsR.ndim == 2 else _kp7(kpsR)
+    kl, kr = np.ascontiguousarray(kl), np.ascontiguousarray(kr)
+    dl, dr = np.ascontiguousarray(descL, np.uint8), np.ascontiguousarray(descR, np.uint8)
+    lw = np.array([p.shape[1] for p in pyrL], np.int32)
+    lh = np.array([p.shape[0] for p in pyrL], np.int32)
+    pl = np.concatenate([np.ascontiguousarray(p).ravel() for p in pyrL])
+    pr = np.concatenate([np.ascontiguousarray(p).ravel() for p in pyrR])
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    uR, dep = np.zeros(max(len(kl), 1), np.float32), np.zeros(max(len(kl), 1), np.float32)
+    lib.orbslam_compute_stereo_matches.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] * 2 + [ctypes.c_void_p] * 4 + \
+                                                  [ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    lib.orbslam_compute_stereo_matches(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), _p(pl), _p(pr), _p(lw), _p(lh), len(pyrL), _p(sf),
+                                       ctypes.c_float(bf), _p(uR), _p(dep))
+    return uR[:len(kl)], dep[:len(kl)]
+
+
+def compute_stereo_matches(orc, kpsL, descL, kpsR, descR, pyrL, pyrR, scale_factors, inv_scale_factors, bf, mb=0.0):
+    """Restatement of the complete Frame::ComputeStereoMatches (oracle/match_oracle.cc)."""
+    lib = orc.lib
+    kl = kpsL if kpsL.dtype == np.float32 and kpsL.ndim == 2 else _kp7(kpsL)
+    kr = kpsR if kpsR.dtype == np.float32 and kpsR.ndim == 2 else _kp7(kpsR)
+    kl, kr = np.ascontiguousarray(kl), np.ascontiguousarray(kr)
+    dl, dr = np.ascontiguousarray(descL, np.uint8), np.ascontiguousarray(descR, np.uint8)
+    lw = np.array([p.shape[1] for p in pyrL], np.int32)
+    lh = np.array([p.shape[0] for p in pyrL], np.int32)
+    pl = np.concatenate([np.ascontiguousarray(p).ravel() for p in pyrL])
+    pr = np.concatenate([np.ascontiguousarray(p).ravel() for p in pyrR])
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    isf = np.ascontiguousarray(inv_scale_factors, np.float32)
+    n = max(len(kl), 1)
+    uR, dep, sad = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    lib.mo_compute_stereo_matches.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] * 2 + [ctypes.c_void_p] * 4 + \
+                                             [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float] + [ctypes.c_void_p] * 3
+    with np.errstate(divide="ignore"):
+        lib.mo_compute_stereo_matches(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), _p(pl), _p(pr), _p(lw), _p(lh), len(pyrL), _p(sf), _p(isf),
+                                      ctypes.c_float(bf), ctypes.c_float(mb), _p(uR), _p(dep), _p(sad))
+    return uR[:len(kl)], dep[:len(kl)], sad[:len(kl)]
