@@ -217,6 +217,24 @@ int orbx_stereo_match_device(orbx_matcher *m, const orbx_feature_set *left, cons
                              const float *scale_factors, int nlevels, float max_disparity,
                              orbx_extractor *after_stream_of);
 
+/* Complete Frame::ComputeStereoMatches (src/Frame.cc:1026-1420) for `npairs` (left frame, right
+ * frame) pairs taken from the LAST batches of two extractor handles (the reference's
+ * mpORBextractorLeft / mpORBextractorRight; both may be the same handle when left and right
+ * frames were extracted in one batch): Hamming stage as orbx_stereo_match_device, then the 11x11
+ * SAD search over +-5 px on the keypoint's pyramid level (the extractor's device-resident
+ * mvImagePyramid), parabola sub-pixel fit, disparity gate and the median*1.5*1.4 outlier cut.
+ *   uright[p*stride + iL] = mvuRight[iL] (-1: no match), depth[...] = mvDepth[iL],
+ *   nmatches[p] = number of left keypoints with a depth; matches/dists = bestIdxR/bestDist.
+ * mbf = Frame::mbf, mb = Frame::mb AS IT IS when ComputeStereoMatches runs: 0 in this fork's
+ * stereo constructor (src/Frame.cc:125, mb is assigned at :197 after the call) => maxD = +inf.
+ * Asynchronous on the matcher's stream, ordered after both extractors; the extractors' next
+ * batch waits for it before their pyramids are overwritten. */
+int orbx_compute_stereo_matches_device(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right,
+                                       const int32_t *frames_l, const int32_t *frames_r, int npairs, float mbf,
+                                       float mb);
+int orbx_stereo_results_device(orbx_matcher *m, const float **uright_dev, const float **depth_dev, int *stride);
+int orbx_stereo_download(orbx_matcher *m, int npairs, float *uright, float *depth, int stride);
+
 int orbx_matcher_results_device(orbx_matcher *m, const int32_t **matches_dev, const int32_t **dists_dev,
                                 const int32_t **nmatches_dev, int *stride);
 int orbx_matcher_download(orbx_matcher *m, int npairs, int32_t *matches, int32_t *dists, int stride,

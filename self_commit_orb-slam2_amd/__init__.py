@@ -300,6 +300,9 @@ def _bind_matcher(L):
     L.orbx_search_by_bow_device.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, vp, ci, ctypes.POINTER(BowParams), vp]
     L.orbx_stereo_match_device.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, vp, ci, vp, ci, ctypes.c_float, vp]
     L.orbx_matcher_results_device.argtypes = [vp, vp, vp, vp, vp]
+    L.orbx_compute_stereo_matches_device.argtypes = [vp, vp, vp, vp, vp, ci, ctypes.c_float, ctypes.c_float]
+    L.orbx_stereo_results_device.argtypes = [vp, vp, vp, vp]
+    L.orbx_stereo_download.argtypes = [vp, ci, vp, vp, ci]
     L.orbx_matcher_download.argtypes = [vp, ci, vp, vp, ci, vp]
     L.orbx_matcher_sync.argtypes = [vp]
     L.orbx_search_by_bow.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), ctypes.POINTER(BowParams), vp, vp]
@@ -401,6 +404,23 @@ class ORBmatcher:
         sf = np.ascontiguousarray(scale_factors, np.float32)
         _check(self._L.orbx_stereo_match_device(self._h, ctypes.byref(fsL), ctypes.byref(fsR), _ptr(pl), _ptr(pr), len(pl), _ptr(sf), len(sf),
                                                 ctypes.c_float(max_disparity), after._h if after is not None else None))
+
+    def compute_stereo_matches_device(self, ext_left, ext_right, frames_l, frames_r, mbf, mb=0.0):
+        """Frame::ComputeStereoMatches (reference src/Frame.cc:1026-1420), complete, on the last batches
+        of two extractor handles (may be the same handle).  mb=0 is what the reference's stereo
+        constructor has when the function runs (src/Frame.cc:125)."""
+        fl = np.ascontiguousarray(frames_l, np.int32)
+        fr = np.ascontiguousarray(frames_r, np.int32)
+        _check(self._L.orbx_compute_stereo_matches_device(self._h, ext_left._h, ext_right._h, _ptr(fl), _ptr(fr), len(fl),
+                                                          ctypes.c_float(mbf), ctypes.c_float(mb)))
+
+    def download_stereo(self, npairs, stride=None):
+        """(mvuRight, mvDepth) per pair, -1 where the reference leaves -1."""
+        stride = stride or self.max_features
+        u = np.zeros((npairs, stride), np.float32)
+        z = np.zeros((npairs, stride), np.float32)
+        _check(self._L.orbx_stereo_download(self._h, npairs, _ptr(u), _ptr(z), stride))
+        return u, z
 
     def sync(self):
         _check(self._L.orbx_matcher_sync(self._h))

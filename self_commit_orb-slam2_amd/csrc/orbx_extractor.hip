@@ -88,6 +88,7 @@ struct orbx_extractor {
     DevBuf<int> outCnt[2];
     DevBuf<orbx_keypoint> outKp[2];
     hipEvent_t consumerEv[2] = {nullptr, nullptr};
+    hipEvent_t pyrConsumerEv = nullptr;   // a consumer still reads the (single buffered) pyramid of the last batch
     int cur = 0;
     DevBuf<uint32_t> cellSlots, ptBuf;
     DevBuf<OrbxLevelKp> lvlKp;
@@ -312,6 +313,7 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     L.status = h->status.p; L.nodeCap = h->nodeCap;
     const bool prof = h->profiling;
     hipEvent_t *ev = h->ev[h->profCount % ORBX_PROF_RING];
+    if (h->pyrConsumerEv) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->pyrConsumerEv, 0)); h->pyrConsumerEv = nullptr; }
     ORBX_HIP_CHECK(hipMemsetAsync(h->status.p, 0, (size_t)batch * sizeof(int), h->stream));
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[0], h->stream));
     for (int l = 1; l < h->geom.nlevels; l++)
@@ -365,6 +367,18 @@ int upload(orbx_extractor *h, const uint8_t *const *images, int batch, int W, in
 
 hipStream_t orbx_extractor_stream_internal(orbx_extractor *h) { return h ? h->stream : nullptr; }
 void orbx_extractor_set_consumer_event_internal(orbx_extractor *h, hipEvent_t ev) { if (h) h->consumerEv[h->cur] = ev; }
+void orbx_extractor_set_pyramid_consumer_event_internal(orbx_extractor *h, hipEvent_t ev) { if (h) h->pyrConsumerEv = ev; }
+int orbx_extractor_last_batch_view_internal(orbx_extractor *h, OrbxLastBatchView *v)
+{
+    if (!h || !v) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
+    v->batch = h->lastBatch; v->nlevels = h->geom.nlevels; v->cap = h->geom.outCap;
+    v->kp = h->outKp[h->cur].p; v->desc = h->outDesc[h->cur].p; v->counts = h->outCnt[h->cur].p;
+    v->img0 = h->lastImg0; v->img0Stride = h->lastStride; v->img0FramePitch = h->lastFramePitch;
+    v->pyr = h->pyr.p; v->pyrBytes = h->geom.pyrBytes; v->geomDev = h->geomDev.p; v->geom = &h->geom;
+    v->scale = h->scale.data(); v->invScale = h->invScale.data();
+    return ORBX_OK;
+}
 
 extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extractor **out)
 {

@@ -108,4 +108,26 @@ hipStream_t orbx_extractor_stream_internal(orbx_extractor *h);
  * extractor waits for it before that buffer is overwritten two batches later */
 void orbx_extractor_set_consumer_event_internal(orbx_extractor *h, hipEvent_t ev);
 
+
+/* Device view of the LAST batch of an extractor: results + the unblurred pyramid (what the
+ * reference keeps in ORBextractor::mvImagePyramid, read by Frame::ComputeStereoMatches). */
+struct OrbxLastBatchView {
+    int batch, nlevels, cap;
+    const orbx_keypoint *kp;     /* [batch*cap]            */
+    const uint8_t *desc;         /* [batch*cap*32]         */
+    const int32_t *counts;       /* [batch]                */
+    const uint8_t *img0;         /* level 0 = caller's input frames */
+    int img0Stride;
+    size_t img0FramePitch;
+    const uint8_t *pyr;          /* levels >= 1, frame f at pyr + f*pyrBytes + lv[l].off, pitch lv[l].pitch */
+    size_t pyrBytes;
+    const OrbxGeom *geomDev;
+    const OrbxGeom *geom;        /* host copy */
+    const float *scale, *invScale; /* host tables, nlevels entries */
+};
+int orbx_extractor_last_batch_view_internal(orbx_extractor *h, OrbxLastBatchView *v);
+/* `ev` guards the PYRAMID of the last batch (single buffered): the next batch waits for it before
+ * its first kernel */
+void orbx_extractor_set_pyramid_consumer_event_internal(orbx_extractor *h, hipEvent_t ev);
+
 #endif

@@ -287,6 +287,195 @@ __global__ __launch_bounds__(256) void k_stereo(FeatDev Lf, FeatDev Rf, const in
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Complete Frame::ComputeStereoMatches (src/Frame.cc:1026-1420).
+// k_stereo_full: one wave per left keypoint.
+//   1. Hamming stage exactly as k_stereo (row band / octave / disparity gate, first minimum wins).
+//   2. if bestDist < (TH_HIGH+TH_LOW)/2: 11x11 SAD of the centre-normalised left window against
+//      the right window shifted by -5..+5 px on the keypoint's pyramid level (:1224-1306);
+//      lane = (shift s, row group q): 55 lanes, 3/2/2/2/2 rows of 11 pixels each.
+//   3. parabola fit, sub-pixel uR, disparity gate, depth (:1330-1378); float arithmetic in the
+//      reference's order (-ffp-contract=off), the 0.01 clamp in double like `uL-0.01`.
+// k_stereo_cut: one workgroup per pair; median of the accepted SAD values by a two-pass byte
+// radix select (SAD <= 121*510 < 2^16), then the `median*1.5*1.4` cut (:1387-1416).
+// ---------------------------------------------------------------------------------------------
+struct PyrDev {
+    const uint8_t *img0;
+    int img0Stride;
+    size_t img0FramePitch;
+    const uint8_t *pyr;
+    size_t pyrBytes;
+    const OrbxGeom *geom;
+};
+
+__device__ __forceinline__ const uint8_t *level_ptr(const PyrDev &P, int f, int l, int &pitch, int &w)
+{
+    w = P.geom->lv[l].w;
+    if (l == 0) { pitch = P.img0Stride; return P.img0 + (size_t)f * P.img0FramePitch; }
+    pitch = P.geom->lv[l].pitch;
+    return P.pyr + (size_t)f * P.pyrBytes + P.geom->lv[l].off;
+}
+
+__global__ __launch_bounds__(256) void k_stereo_full(FeatDev Lf, FeatDev Rf, PyrDev PL, PyrDev PR, const int32_t *__restrict__ pairsL,
+                                                     const int32_t *__restrict__ pairsR, const float *__restrict__ scaleFactors,
+                                                     const float *__restrict__ invScaleFactors, float mbf, float mb, int32_t *__restrict__ bestIdx,
+                                                     int32_t *__restrict__ bestDist, float *__restrict__ uRight, float *__restrict__ depth,
+                                                     int32_t *__restrict__ sadOut, int stride)
+{
+    const int p = blockIdx.y, fl = pairsL[p], fr = pairsR[p];
+    const int nL = min(Lf.counts[fl], Lf.cap), nR = min(Rf.counts[fr], Rf.cap);
+    const int lane = threadIdx.x & 63, iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= nL) return;
+    const orbx_keypoint kl = Lf.kp[(size_t)fl * Lf.cap + iL];
+    const int row = (int)kl.y;
+    const float minZ = mb, minD = 0.0f;
+    const float maxD = mbf / minZ;
+    const float minU = kl.x - maxD, maxU = kl.x - minD;
+    const unsigned long long *da = (const unsigned long long *)(Lf.desc + ((size_t)fl * Lf.cap + iL) * 32);
+    unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
+    uint32_t best = ((uint32_t)TH_HIGH << 16);
+    const orbx_keypoint *kr = Rf.kp + (size_t)fr * Rf.cap;
+    if (!(maxU < 0)) {
+        for (int iR = lane; iR < nR; iR += 64) {
+            const orbx_keypoint k = kr[iR];
+            const float r = 2.0f * scaleFactors[k.octave];
+            const int maxr = (int)ceilf(k.y + r), minr = (int)floorf(k.y - r);
+            if (row < minr || row > maxr) continue;
+            if (k.octave < kl.octave - 1 || k.octave > kl.octave + 1) continue;
+            if (!(k.x >= minU && k.x <= maxU)) continue;
+            const unsigned long long *db = (const unsigned long long *)(Rf.desc + ((size_t)fr * Rf.cap + iR) * 32);
+            const int d = hamming256(a, db[0], db[1], db[2], db[3]);
+            const uint32_t key = ((uint32_t)d << 16) | (uint32_t)iR;
+            if (d < TH_HIGH && key < best) best = key;
+        }
+    }
+    best = wave_min_u32(best);
+    const int bd = (int)(best >> 16);
+    const size_t o = (size_t)p * stride + iL;
+    float outU = -1.0f, outZ = -1.0f;
+    int outSad = -1;
+    if (bd < (TH_HIGH + TH_LOW) / 2) {            // wave-uniform
+        const int bidx = (int)(best & 0xffff);
+        const int oct = kl.octave;
+        const float uR0 = kr[bidx].x;
+        const float sf = invScaleFactors[oct];
+        const float scaleduL = roundf(kl.x * sf), scaledvL = roundf(kl.y * sf), scaleduR0 = roundf(uR0 * sf);
+        const int w = 5, L = 5;
+        int pitchL, pitchR, WL, WR;
+        const uint8_t *imL = level_ptr(PL, fl, oct, pitchL, WL);
+        const uint8_t *imR = level_ptr(PR, fr, oct, pitchR, WR);
+        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+        if (!(iniu < 0 || endu >= (float)WR)) {
+            const int cy = (int)scaledvL, cxl = (int)scaleduL;
+            int part = 0;
+            if (lane < 55) {
+                const int s = lane % 11, q = lane / 11;
+                const int cxr = (int)(scaleduR0 + (float)(s - L));
+                const int cL = imL[(size_t)cy * pitchL + cxl], cR = imR[(size_t)cy * pitchR + cxr];
+                for (int rr = q; rr < 11; rr += 5) {
+                    const uint8_t *pl = imL + (size_t)(cy + rr - w) * pitchL + (cxl - w);
+                    const uint8_t *pr = imR + (size_t)(cy + rr - w) * pitchR + (cxr - w);
+#pragma unroll
+                    for (int c = 0; c < 11; c++) {
+                        const int va = (int)pl[c] - cL, vb = (int)pr[c] - cR;
+                        const int df = va - vb;
+                        part += df < 0 ? -df : df;
+                    }
+                }
+            }
+            // total per shift: lanes s, s+11, s+22, s+33, s+44
+            int tot = 0;
+#pragma unroll
+            for (int q = 0; q < 5; q++) tot += __shfl(part, (lane % 11) + 11 * q);
+            float vD[11];
+#pragma unroll
+            for (int s = 0; s < 11; s++) vD[s] = (float)__shfl(tot, s);
+            int bestSad = 0x7fffffff, bestinc = 0;
+#pragma unroll
+            for (int s = 0; s < 11; s++)
+                if (vD[s] < (float)bestSad) { bestSad = (int)vD[s]; bestinc = s - L; }
+            if (!(bestinc == -L || bestinc == L)) {
+                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int s = 1; s < 10; s++)
+                    if (s == bestinc + L) { d1 = vD[s - 1]; d2 = vD[s]; d3 = vD[s + 1]; }
+                const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = scaleFactors[oct] * ((float)scaleduR0 + (float)bestinc + deltaR);
+                    float disparity = kl.x - bestuR;
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) { disparity = (float)0.01; bestuR = (float)((double)kl.x - 0.01); }
+                        outZ = mbf / disparity;
+                        outU = bestuR;
+                        outSad = bestSad;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        bestDist[o] = bd;
+        bestIdx[o] = bd < TH_HIGH ? (int)(best & 0xffff) : 0;
+        uRight[o] = outU;
+        depth[o] = outZ;
+        sadOut[o] = outSad;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stereo_cut(FeatDev Lf, const int32_t *__restrict__ pairsL, const int32_t *__restrict__ sad,
+                                                    float *__restrict__ uRight, float *__restrict__ depth, int32_t *__restrict__ nmatches, int stride)
+{
+    __shared__ int hist[256];
+    __shared__ int sel[4];   // count, chosen high byte, rank inside it, median
+    const int p = blockIdx.x, fl = pairsL[p], t = threadIdx.x;
+    const int nL = min(Lf.counts[fl], Lf.cap);
+    const int32_t *sd = sad + (size_t)p * stride;
+    hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < nL; i += 256) { const int v = sd[i]; if (v >= 0) atomicAdd(&hist[(v >> 8) & 255], 1); }
+    __syncthreads();
+    if (t == 0) {
+        int n = 0;
+        for (int b = 0; b < 256; b++) n += hist[b];
+        sel[0] = n;
+        int rank = n / 2, acc = 0, hb = 0;   // vDistIdx[size/2] of the ascending sort (:1387-1388)
+        for (int b = 0; b < 256; b++) { if (acc + hist[b] > rank) { hb = b; break; } acc += hist[b]; }
+        sel[1] = hb; sel[2] = rank - acc;
+    }
+    __syncthreads();
+    const int n = sel[0], hb = sel[1];
+    if (n == 0) { if (t == 0) nmatches[p] = 0; return; }   // reference: undefined behaviour (vDistIdx[0] of an empty vector); nothing to cut
+    __syncthreads();
+    hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < nL; i += 256) { const int v = sd[i]; if (v >= 0 && ((v >> 8) & 255) == hb) atomicAdd(&hist[v & 255], 1); }
+    __syncthreads();
+    if (t == 0) {
+        int rank = sel[2], acc = 0, lb = 0;
+        for (int b = 0; b < 256; b++) { if (acc + hist[b] > rank) { lb = b; break; } acc += hist[b]; }
+        sel[3] = (hb << 8) | lb;
+    }
+    __syncthreads();
+    const float median = (float)sel[3];
+    const float thDist = 1.5f * 1.4f * median;
+    int kept = 0;
+    for (int i = t; i < nL; i += 256) {
+        const int v = sd[i];
+        if (v < 0) continue;
+        if ((float)v < thDist) kept++;
+        else { uRight[(size_t)p * stride + i] = -1.0f; depth[(size_t)p * stride + i] = -1.0f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+    __syncthreads();
+    if (t == 0) hist[0] = 0;
+    __syncthreads();
+    if ((t & 63) == 0) atomicAdd(&hist[0], kept);
+    __syncthreads();
+    if (t == 0) nmatches[p] = hist[0];
+}
+
 template <typename T> struct MBuf {
     T *p = nullptr;
     size_t n = 0;
@@ -313,7 +502,10 @@ struct orbx_matcher {
     int profCount = 0;
     MBuf<int32_t> pairsA, pairsB, order, matches, dists, nmatches;
     MBuf<uint32_t> topk;
-    MBuf<float> scales;
+    MBuf<float> scales, uright, depth;
+    MBuf<int32_t> sad;
+    hipEvent_t evDep2 = nullptr, evPyr[2] = {nullptr, nullptr};
+    int lastStereoPairs = 0;
     // staging for the host-array convenience calls
     MBuf<orbx_keypoint> hk[2];
     MBuf<uint8_t> hd[2], hv[2];
@@ -345,13 +537,17 @@ extern "C" int orbx_matcher_create(int device, int max_features, int max_pairs, 
     m->device = device; m->maxFeatures = max_features; m->maxPairs = max_pairs;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
     (void)hipEventCreateWithFlags(&m->evDep, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&m->evDep2, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&m->evPyr[0], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&m->evPyr[1], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&m->evDone[0], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&m->evDone[1], hipEventDisableTiming);
     for (int r = 0; r < MATCH_PROF_RING; r++) { (void)hipEventCreate(&m->ev0[r]); (void)hipEventCreate(&m->ev1[r]); }
     const size_t S = (size_t)max_features, P = (size_t)max_pairs;
     int rc;
     if ((rc = m->pairsA.ensure(P)) || (rc = m->pairsB.ensure(P)) || (rc = m->order.ensure(P * S)) || (rc = m->matches.ensure(P * S)) ||
-        (rc = m->dists.ensure(P * S)) || (rc = m->nmatches.ensure(P)) || (rc = m->topk.ensure(P * S * TOPK)) || (rc = m->scales.ensure(64))) {
+        (rc = m->dists.ensure(P * S)) || (rc = m->nmatches.ensure(P)) || (rc = m->topk.ensure(P * S * TOPK)) || (rc = m->scales.ensure(128)) ||
+        (rc = m->uright.ensure(P * S)) || (rc = m->depth.ensure(P * S)) || (rc = m->sad.ensure(P * S))) {
         orbx_matcher_destroy(m);
         return rc;
     }
@@ -365,7 +561,9 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->pairsA.release(); m->pairsB.release(); m->order.release(); m->matches.release(); m->dists.release(); m->nmatches.release();
-    m->topk.release(); m->scales.release();
+    m->topk.release(); m->scales.release(); m->uright.release(); m->depth.release(); m->sad.release();
+    if (m->evDep2) (void)hipEventDestroy(m->evDep2);
+    for (int i = 0; i < 2; i++) if (m->evPyr[i]) (void)hipEventDestroy(m->evPyr[i]);
     for (int s = 0; s < 2; s++) { m->hk[s].release(); m->hd[s].release(); m->hv[s].release(); m->hc[s].release(); m->hg[s].release(); }
     if (m->evDep) (void)hipEventDestroy(m->evDep);
     for (int i = 0; i < 2; i++) if (m->evDone[i]) (void)hipEventDestroy(m->evDone[i]);
@@ -472,6 +670,72 @@ extern "C" int orbx_stereo_match_device(orbx_matcher *m, const orbx_feature_set 
     m->profCount++;
     m->lastPairs = npairs; m->lastStride = stride;
     return chain_back(m, after);
+}
+
+extern "C" int orbx_compute_stereo_matches_device(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, const int32_t *frames_l,
+                                                  const int32_t *frames_r, int npairs, float mbf, float mb)
+{
+    if (!m || !left || !right || !frames_l || !frames_r) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    OrbxLastBatchView vl, vr;
+    int rc;
+    if ((rc = orbx_extractor_last_batch_view_internal(left, &vl)) != ORBX_OK || (rc = orbx_extractor_last_batch_view_internal(right, &vr)) != ORBX_OK) return rc;
+    if (vl.nlevels != vr.nlevels || vl.geom->W != vr.geom->W || vl.geom->H != vr.geom->H) {
+        orbx_set_error("left and right extractors differ in geometry (%dx%d/%d vs %dx%d/%d)", vl.geom->W, vl.geom->H, vl.nlevels, vr.geom->W, vr.geom->H, vr.nlevels);
+        return ORBX_ERR_ARG;
+    }
+    if (vl.nlevels > 64) { orbx_set_error("too many levels"); return ORBX_ERR_ARG; }
+    orbx_feature_set fl = {vl.kp, vl.desc, vl.counts, nullptr, nullptr, vl.cap, vl.batch};
+    orbx_feature_set fr = {vr.kp, vr.desc, vr.counts, nullptr, nullptr, vr.cap, vr.batch};
+    rc = prep_pairs(m, &fl, &fr, frames_l, frames_r, npairs, left);
+    if (rc != ORBX_OK) return rc;
+    if (right != left) {
+        ORBX_HIP_CHECK(hipEventRecord(m->evDep2, orbx_extractor_stream_internal(right)));
+        ORBX_HIP_CHECK(hipStreamWaitEvent(m->stream, m->evDep2, 0));
+    }
+    const int stride = m->maxFeatures, nl = vl.nlevels;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->scales.p, vl.scale, (size_t)nl * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->scales.p + 64, vl.invScale, (size_t)nl * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    PyrDev PL = {vl.img0, vl.img0Stride, vl.img0FramePitch, vl.pyr, vl.pyrBytes, vl.geomDev};
+    PyrDev PR = {vr.img0, vr.img0Stride, vr.img0FramePitch, vr.pyr, vr.pyrBytes, vr.geomDev};
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    hipLaunchKernelGGL(k_stereo_full, dim3((unsigned)((vl.cap + 3) / 4), (unsigned)npairs), dim3(256), 0, m->stream, to_dev(&fl), to_dev(&fr), PL, PR, m->pairsA.p,
+                       m->pairsB.p, m->scales.p, m->scales.p + 64, mbf, mb, m->matches.p, m->dists.p, m->uright.p, m->depth.p, m->sad.p, stride);
+    MLAUNCH_CHECK();
+    hipLaunchKernelGGL(k_stereo_cut, dim3((unsigned)npairs), dim3(256), 0, m->stream, to_dev(&fl), m->pairsA.p, m->sad.p, m->uright.p, m->depth.p, m->nmatches.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = npairs; m->lastStride = stride; m->lastStereoPairs = npairs;
+    // the pyramids are single buffered: the extractors' next batch waits for these kernels
+    ORBX_HIP_CHECK(hipEventRecord(m->evPyr[0], m->stream));
+    orbx_extractor_set_pyramid_consumer_event_internal(left, m->evPyr[0]);
+    if (right != left) orbx_extractor_set_pyramid_consumer_event_internal(right, m->evPyr[0]);
+    rc = chain_back(m, left);
+    if (rc == ORBX_OK && right != left) rc = chain_back(m, right);
+    return rc;
+}
+
+extern "C" int orbx_stereo_results_device(orbx_matcher *m, const float **uright_dev, const float **depth_dev, int *stride)
+{
+    if (!m) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!m->lastStereoPairs) { orbx_set_error("no orbx_compute_stereo_matches_device call yet"); return ORBX_ERR_STATE; }
+    if (uright_dev) *uright_dev = m->uright.p;
+    if (depth_dev) *depth_dev = m->depth.p;
+    if (stride) *stride = m->lastStride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stereo_download(orbx_matcher *m, int npairs, float *uright, float *depth, int stride)
+{
+    if (!m) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (npairs < 1 || npairs > m->lastStereoPairs) { orbx_set_error("npairs not available"); return ORBX_ERR_STATE; }
+    if (stride < 1 || stride > m->lastStride) { orbx_set_error("bad stride"); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (uright) ORBX_HIP_CHECK(hipMemcpy2D(uright, (size_t)stride * 4, m->uright.p, (size_t)m->lastStride * 4, (size_t)stride * 4, (size_t)npairs, hipMemcpyDeviceToHost));
+    if (depth) ORBX_HIP_CHECK(hipMemcpy2D(depth, (size_t)stride * 4, m->depth.p, (size_t)m->lastStride * 4, (size_t)stride * 4, (size_t)npairs, hipMemcpyDeviceToHost));
+    return ORBX_OK;
 }
 
 extern "C" int orbx_matcher_results_device(orbx_matcher *m, const int32_t **matches_dev, const int32_t **dists_dev, const int32_t **nmatches_dev, int *stride)

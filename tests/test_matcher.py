@@ -148,3 +148,53 @@ def test_stereo_hamming_and_frame_match_on_real_features(orbx, oracle):
         assert nm[p] == wn and (m[p, :nb] == wm).all()
     mt.close()
     ext.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,nf,bf,two_handles", [(1241, 376, 2000, 386.1448, False), (752, 480, 1200, 47.9064, True), (640, 480, 1000, 40.0, False)])
+def test_compute_stereo_matches_hip_bit_exact(orbx, oracle, W, H, nf, bf, two_handles):
+    """Complete Frame::ComputeStereoMatches on the device (Hamming + SAD + sub-pixel + median cut)
+    vs the restatement and, when oracle/_ref/liborbslam.so travelled with the snapshot, vs the
+    reference's own stereo Frame constructor.  mvuRight / mvDepth compared as bit patterns."""
+    seeds = [31, 32, 47]
+    lefts = [orbx.synth_frame(s, W, H) for s in seeds]
+    rights = [orbx.synth_frame(s, W, H, orbx.SYNTH_STEREO_RIGHT) for s in seeds]
+    n = len(seeds)
+    if two_handles:      # the reference's model: one extractor per eye (src/Tracking.cc:179-187)
+        eL = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=n)
+        eR = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=n)
+        dl, dr = eL.upload(lefts), eR.upload(rights)
+        eL.run_device(*dl)
+        eR.run_device(*dr)
+        fl, fr = list(range(n)), list(range(n))
+    else:                # both eyes in one batch: frames 0..n-1 left, n..2n-1 right
+        eL = eR = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * n)
+        d = eL.upload(lefts + rights)
+        eL.run_device(*d)
+        fl, fr = list(range(n)), list(range(n, 2 * n))
+    mt = orbx.ORBmatcher(0.7, True, max_features=eL.capacity, max_pairs=n)
+    mt.compute_stereo_matches_device(eL, eR, fl, fr, bf, 0.0)
+    uR, dep = mt.download_stereo(n)
+    bi, bd, nm = mt.download(n)
+    kL, dL, cL = eL.download(eL_b := (n if two_handles else 2 * n))
+    kR, dR, cR = (eR.download(n) if two_handles else (kL, dL, cL))
+    rst = oracle.restatement(nf)
+    t, _, _ = rst.tables()
+    slam = oracle_lib.slam_lib()
+    for p in range(n):
+        a, b = fl[p], fr[p]
+        na, nb = int(cL[a]), int(cR[b])
+        pyrL, pyrR = oracle.pyramid(rst, lefts[p]), oracle.pyramid(rst, rights[p])
+        wu, wz, _ = oracle_lib.compute_stereo_matches(oracle, kL[a, :na], dL[a, :na], kR[b, :nb], dR[b, :nb], pyrL, pyrR, t[0], t[1], bf, 0.0)
+        assert (uR[p, :na].view(np.uint32) == wu.view(np.uint32)).all(), p
+        assert (dep[p, :na].view(np.uint32) == wz.view(np.uint32)).all(), p
+        assert nm[p] == int((wu >= 0).sum()) and nm[p] > 100
+        if slam is not None:
+            ref = oracle_lib.ref_stereo_frame(lefts[p], rights[p], nf, 500.0, 500.0, W / 2, H / 2, bf)
+            assert len(ref["uRight"]) == na
+            assert (uR[p, :na].view(np.uint32) == ref["uRight"].view(np.uint32)).all()
+            assert (dep[p, :na].view(np.uint32) == ref["depth"].view(np.uint32)).all()
+    mt.close()
+    eL.close()
+    if two_handles:
+        eR.close()
