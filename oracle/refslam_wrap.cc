@@ -225,6 +225,7 @@ ORBSLAM_API int orbslam_stereo_frame(const uint8_t *imL, const uint8_t *imR, int
     return 0;
 }
 
+#ifndef ORBSLAM_HIP   // pokes host pyramids into the reference extractor; meaningless for the device-resident shim
 // Frame::ComputeStereoMatches on GIVEN features + pyramids (default-constructed Frame whose
 // public members are filled; the extractors only lend their mvImagePyramid).  pyrL/pyrR:
 // nlevels tight u8 images concatenated, sizes in lw/lh.  mb = 0 like in the stereo
@@ -261,6 +262,8 @@ ORBSLAM_API int orbslam_compute_stereo_matches(const float *kpsL, const uint8_t 
     delete exR;
     return 0;
 }
+
+#endif
 
 // mode 0: SearchByBoW(KeyFrame* A, Frame& B, vpMapPointMatches): matches[j in B] = index in A or -1
 // mode 1: SearchByBoW(KeyFrame* A, KeyFrame* B, vpMatches12):    matches[i in A] = index in B or -1

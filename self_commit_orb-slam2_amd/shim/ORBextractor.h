@@ -44,6 +44,9 @@ public:
 
     // Device used by extractors constructed afterwards (default 0).
     static void SetDevice(int device);
+    // liborbx handle holding the device-resident results and pyramid of the last frame
+    // (consumed by the HIP body of Frame::ComputeStereoMatches, shim/Frame_hip.cc).
+    orbx_extractor *Handle() const { return mpHandle; }
 
 private:
     ORBextractor(const ORBextractor &);

@@ -212,6 +212,10 @@ SLAM_SO = ROOT / "oracle" / "_ref" / "liborbslam.so"
 _slam = None
 
 
+SLAM_HIP_SO = ROOT / "oracle" / "_ref" / "liborbslam_hip.so"
+_slam_hip = None
+
+
 def slam_lib():
     """ctypes handle of oracle/_ref/liborbslam.so, or None when it was never built (it is built
     in the container that has /root/reference and travels to the GPU box as a binary)."""
@@ -221,13 +225,22 @@ def slam_lib():
     return _slam
 
 
-def ref_descriptor_distance(a, b):
-    return slam_lib().orbslam_descriptor_distance(_p(np.ascontiguousarray(a, np.uint8)), _p(np.ascontiguousarray(b, np.uint8)))
+def slam_hip_lib():
+    """The DROP-IN build: the same reference sources with shim/ORBextractor + the HIP bodies of
+    SearchByBoW / DescriptorDistance / ComputeStereoMatches linked in (oracle/Makefile)."""
+    global _slam_hip
+    if _slam_hip is None and SLAM_HIP_SO.exists():
+        _slam_hip = ctypes.CDLL(str(SLAM_HIP_SO))
+    return _slam_hip
 
 
-def ref_search_by_bow(mode, kpsA, descA, kpsB, descB, nnratio, check_ori, groupsA=None, groupsB=None, validA=None, validB=None):
+def ref_descriptor_distance(a, b, lib=None):
+    return (lib or slam_lib()).orbslam_descriptor_distance(_p(np.ascontiguousarray(a, np.uint8)), _p(np.ascontiguousarray(b, np.uint8)))
+
+
+def ref_search_by_bow(mode, kpsA, descA, kpsB, descB, nnratio, check_ori, groupsA=None, groupsB=None, validA=None, validB=None, lib=None):
     """ORBmatcher::SearchByBoW of the reference, driven through real KeyFrame/Frame/MapPoint objects."""
-    lib = slam_lib()
+    lib = lib or slam_lib()
     lib.orbslam_search_by_bow.argtypes = [ctypes.c_int] + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] * 2 + \
                                          [ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
     kA, kB = _kp7(kpsA), _kp7(kpsB)
@@ -244,9 +257,9 @@ def ref_search_by_bow(mode, kpsA, descA, kpsB, descB, nnratio, check_ori, groups
     return n, out[:nout]
 
 
-def ref_stereo_frame(imL, imR, nfeatures, fx, fy, cx, cy, bf, th_depth=35.0, scale=1.2, nlevels=8, ini=20, mn=7, cap=8192):
+def ref_stereo_frame(imL, imR, nfeatures, fx, fy, cx, cy, bf, th_depth=35.0, scale=1.2, nlevels=8, ini=20, mn=7, cap=8192, lib=None):
     """Frame::Frame(imLeft, imRight, ...) of the reference: both extractions + ComputeStereoMatches."""
-    lib = slam_lib()
+    lib = lib or slam_lib()
     H, W = imL.shape
     imL, imR = np.ascontiguousarray(imL), np.ascontiguousarray(imR)
     kL, kR = np.zeros((cap, 7), np.float32), np.zeros((cap, 7), np.float32)

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/slam/*.npz from the COMPILED REFERENCE matcher / Frame sources
+(oracle/_ref/liborbslam.so = unmodified src/ORBmatcher.cc, Frame.cc, KeyFrame.cc, MapPoint.cc,
+Map.cc + DBoW2 on oracle/cvshim, driven through real KeyFrame/Frame/MapPoint objects).
+
+    make -f oracle/Makefile all && python tools/gen_golden_slam.py
+
+stereo_*:  Frame::Frame(imLeft, imRight, ...) -> mvuRight / mvDepth (ComputeStereoMatches)
+bow_*:     ORBmatcher::SearchByBoW, both overloads, on the features of two views of a scene,
+           brute force (one vocabulary node) and with 10 synthetic node ids + MapPoint masks.
+"""
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib  # noqa: E402
+
+orbx = importlib.import_module("self_commit_orb-slam2_amd")
+
+STEREO = [("stereo_kitti_1241x376_2000", 1241, 376, 2000, [41, 42], 386.1448),
+          ("stereo_euroc_752x480_1200", 752, 480, 1200, [43], 47.9064)]
+BOW = [("bow_tum1_640x480_1000", 640, 480, 1000, 51), ("bow_kitti_1241x376_2000", 1241, 376, 2000, 52)]
+
+
+def synth_groups(desc, n_nodes=10):
+    """deterministic stand-in for DBoW2 node ids: a hash of the first descriptor byte pair"""
+    return ((desc[:, 0].astype(np.int32) * 7 + desc[:, 1].astype(np.int32)) % n_nodes).astype(np.int32)
+
+
+def synth_valid(desc, mod):
+    return ((desc[:, 2].astype(np.int32) + desc[:, 3].astype(np.int32)) % mod != 0).astype(np.uint8)
+
+
+def kps_struct(k7):
+    k = np.zeros(len(k7), orbx.KEYPOINT_DTYPE)
+    for j, c in enumerate(("x", "y", "size", "angle", "response")):
+        k[c] = k7[:, j]
+    k["octave"] = k7[:, 5].astype(np.int32)
+    k["class_id"] = k7[:, 6].astype(np.int32)
+    return k
+
+
+def main():
+    assert oracle_lib.slam_lib() is not None, "build oracle/_ref first (needs /root/reference)"
+    orc = oracle_lib.Oracle()
+    out = ROOT / "tests" / "golden" / "slam"
+    out.mkdir(parents=True, exist_ok=True)
+    for name, W, H, nf, seeds, bf in STEREO:
+        data = {"W": W, "H": H, "nfeatures": nf, "seeds": np.array(seeds, np.int64), "bf": np.float32(bf)}
+        for i, s in enumerate(seeds):
+            imL = orbx.synth_frame(s, W, H)
+            imR = orbx.synth_frame(s, W, H, orbx.SYNTH_STEREO_RIGHT)
+            r = oracle_lib.ref_stereo_frame(imL, imR, nf, 500.0, 500.0, W / 2, H / 2, bf)
+            data["uRight_%d" % i] = r["uRight"]
+            data["depth_%d" % i] = r["depth"]
+            data["nR_%d" % i] = np.int32(len(r["kpsR"]))
+        np.savez_compressed(out / (name + ".npz"), **data)
+        print(name, [int((data["uRight_%d" % i] >= 0).sum()) for i in range(len(seeds))])
+    for name, W, H, nf, seed in BOW:
+        ref = orc.reference(nf)
+        imA = orbx.synth_frame(seed, W, H, 0, 0, 0, 0)
+        imB = orbx.synth_frame(seed, W, H, 0, 1, 3, 1)
+        kA, dA = ref.extract(imA)
+        kB, dB = ref.extract(imB)
+        sA, sB = kps_struct(kA), kps_struct(kB)
+        data = {"W": W, "H": H, "nfeatures": nf, "seed": np.int64(seed)}
+        gA, gB = synth_groups(dA), synth_groups(dB)
+        vA, vB = synth_valid(dA, 5), synth_valid(dB, 7)
+        for mode in (0, 1):
+            n, m = oracle_lib.ref_search_by_bow(mode, sA, dA, sB, dB, 0.7, True)
+            data["brute_n_%d" % mode], data["brute_m_%d" % mode] = np.int32(n), m
+            n, m = oracle_lib.ref_search_by_bow(mode, sA, dA, sB, dB, 0.7, True, gA, gB, vA, vB if mode == 1 else None)
+            data["nodes_n_%d" % mode], data["nodes_m_%d" % mode] = np.int32(n), m
+        np.savez_compressed(out / (name + ".npz"), **data)
+        print(name, [int(data["brute_n_%d" % m]) for m in (0, 1)], [int(data["nodes_n_%d" % m]) for m in (0, 1)])
+
+
+if __name__ == "__main__":
+    main()
