@@ -158,7 +158,7 @@ int build_geometry(orbx_extractor *h, int W, int H)
     for (int i = 0; i < 16; i++) g.umax[i] = h->umax[i];
     h->rxHost.clear(); h->ryHost.clear(); h->binHost.clear();
     size_t off = 0;
-    int cells = 0, slots = 0, kps = 0, ftiles = 0, btiles = 0, maxNodes = 0;
+    int cells = 0, slots = 0, kps = 0, btiles = 0, maxNodes = 0, maxWCell = 0, maxHCell = 0;
     for (int l = 0; l < nl; l++) {
         OrbxLevel &lv = g.lv[l];
         lv.w = round_f((float)W * h->invScale[(size_t)l]);
@@ -200,10 +200,8 @@ int build_geometry(orbx_extractor *h, int W, int H)
         kps += lv.kpCap;
         maxNodes = std::max(maxNodes, lv.kpCap);
         if (lv.nCols * lv.nRows > 2048) { orbx_set_error("level %d has %d cells; at most 2048 supported", l, lv.nCols * lv.nRows); return ORBX_ERR_ARG; }
-        lv.fastTilesX = (lv.w - ORBX_EDGE - ORBX_BORDER + 63) / 64;
-        lv.fastTilesY = (lv.h - ORBX_EDGE - ORBX_BORDER + 15) / 16;
-        lv.fastTileBase = ftiles;
-        ftiles += lv.fastTilesX * lv.fastTilesY;
+        maxWCell = std::max(maxWCell, lv.wCell);
+        maxHCell = std::max(maxHCell, lv.hCell);
         lv.blurTilesX = (lv.w + 63) / 64;
         lv.blurTilesY = (lv.h + 31) / 32;
         lv.blurTileBase = btiles;
@@ -239,7 +237,14 @@ int build_geometry(orbx_extractor *h, int W, int H)
         }
     }
     g.cellsPerFrame = cells; g.slotsPerFrame = slots; g.kpPerFrame = kps; g.outCap = kps;
-    g.fastTiles = ftiles; g.blurTiles = btiles;
+    g.blurTiles = btiles;
+    // LDS carve-up of k_fast_cells (one wave per cell): row pitch 16*segments+16 bytes for both tiles
+    g.fcSegMax = (maxWCell + 15) / 16;
+    if (g.fcSegMax > 4 || maxHCell > 63) { orbx_set_error("cell %dx%d larger than the detector supports", maxWCell, maxHCell); return ORBX_ERR_ARG; }
+    const int fcPitch = 16 * g.fcSegMax + 16;
+    g.fcInBytes = fcPitch * (maxHCell + 6);
+    g.fcScBytes = fcPitch * (maxHCell + 2);
+    g.fcLdsBytes = g.fcInBytes + g.fcScBytes + (int)align_up((size_t)maxWCell * maxHCell * 2, 16);
     g.pyrBytes = align_up(off + 256, 256);
     if (maxNodes > 2048) { orbx_set_error("per-level feature quota %d exceeds the quadtree node capacity 2048", maxNodes); return ORBX_ERR_ARG; }
     h->nodeCap = maxNodes <= 512 ? 512 : (maxNodes <= 1024 ? 1024 : 2048);
@@ -388,6 +393,12 @@ extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extr
         cfg->ini_th_fast < cfg->min_th_fast || cfg->ini_th_fast > 255 || cfg->max_width < 1 || cfg->max_height < 1 || cfg->max_batch < 1) {
         orbx_set_error("bad extractor configuration (need 1<=nlevels<=%d, nfeatures>=1, scale_factor>1, 1<=minTh<=iniTh<=255)", ORBX_MAX_LEVELS);
         return ORBX_ERR_ARG;
+    }
+    {   // 8.8 fixed-point Gaussian taps: bytes, and a sum <= 257 keeps the 16-bit horizontal pass from saturating
+        unsigned sum = 0;
+        bool ok = true;
+        for (int i = 0; i < 7; i++) { sum += cfg->gauss_taps[i]; ok = ok && cfg->gauss_taps[i] <= 255; }
+        if (sum != 0 && (!ok || sum > 257)) { orbx_set_error("gauss_taps must be <= 255 each and sum to <= 257 (got sum %u)", sum); return ORBX_ERR_ARG; }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {

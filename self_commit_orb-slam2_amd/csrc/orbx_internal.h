@@ -36,7 +36,6 @@ struct OrbxLevel {
     int iniX[5];            /* their x bounds                                             */
     int binOff;             /* offset of this level's x -> initial-node table (u8)        */
     int kpBase, kpCap;      /* slice of the per-frame level-keypoint array                */
-    int fastTileBase, fastTilesX, fastTilesY;
     int blurTileBase, blurTilesX, blurTilesY;
     int rxOff, ryOff;       /* offsets into the resize tables                             */
     int patchSize;          /* (int)(PATCH_SIZE*scale), src/ORBextractor.cc:1175          */
@@ -47,7 +46,9 @@ struct OrbxGeom {
     int nlevels, W, H;
     int iniTh, minTh;
     int cellsPerFrame, slotsPerFrame, kpPerFrame, outCap;
-    int fastTiles, blurTiles;
+    int blurTiles;
+    int fcSegMax;           /* widest cell of any level in 16-px segments (k_fast_cells template argument) */
+    int fcInBytes, fcScBytes, fcLdsBytes;   /* LDS carve-up of k_fast_cells: input window, score tile, total */
     size_t pyrBytes;        /* bytes of levels 1.. of one frame */
     uint32_t taps[7];
     int umax[16];
@@ -94,9 +95,7 @@ struct OrbxLaunch {
 };
 
 int orbx_launch_resize(const OrbxLaunch &L, int level);
-int orbx_launch_fast(const OrbxLaunch &L);
-int orbx_launch_cells(const OrbxLaunch &L);
-int orbx_launch_fast_cells(const OrbxLaunch &L);   /* fused FAST + cell NMS; L.score may be NULL */
+int orbx_launch_fast_cells(const OrbxLaunch &L);   /* FAST score + cell NMS + emission; L.score (parity tap) may be NULL */
 int orbx_launch_octree(const OrbxLaunch &L);
 int orbx_launch_orient(const OrbxLaunch &L);
 int orbx_launch_blur(const OrbxLaunch &L);

@@ -34,6 +34,16 @@ __device__ __forceinline__ int find_level(const int *base, int nlevels, int idx)
     return l;
 }
 
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
 // ------------------------------------------------------------------------------------
 // Pyramid: level L = cv::resize(level L-1, INTER_LINEAR) (src/ORBextractor.cc:1696-1701),
 // 11-bit fixed point; the column/row tables are built on the host with the exact
@@ -42,20 +52,35 @@ __device__ __forceinline__ int find_level(const int *base, int nlevels, int idx)
 // covers all eight taps of the four pixels (scale 1.2: span <= 6 bytes), one dword store per row.
 // ------------------------------------------------------------------------------------
 #define RS_ROWS 4   /* dst rows per thread */
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+    union { uint32_t u; u16x2 v; } x, y;
+    x.u = a; y.u = b;
+    return __builtin_amdgcn_udot2(x.v, y.v, c, false);   // v_dot2_u32_u16: a.lo*b.lo + a.hi*b.hi + c
+}
+
+// Horizontal taps of one pixel = ONE v_perm_b32 (two bytes of the 8-byte source window -> a u16
+// pair, selector fixed per thread) + ONE v_dot2_u32_u16 against (a0, a1); the vertical blend keeps
+// OpenCV's two truncating >>16 terms.
 __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, int level, const uint8_t *__restrict__ img0, int img0Stride,
                                                 size_t img0FramePitch, uint8_t *__restrict__ pyr, const OrbxResizeX *__restrict__ rx,
                                                 const OrbxResizeY *__restrict__ ry)
 {
     const OrbxLevel &lv = g->lv[level];
     const int f = blockIdx.z;
-    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int dyBase = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS;   // wave-uniform
-    if (dx0 >= lv.w || dyBase >= lv.h) return;
+    // flat item = (row group, column group of 4 px): no lane idles on a ragged right edge
+    const int G = (lv.w + 3) >> 2, RG = (lv.h + RS_ROWS - 1) / RS_ROWS;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= G * RG) return;
+    const int rg = item / G;
+    const int dx0 = (item - rg * G) * 4, dyBase = rg * RS_ROWS;
     int sp;
     const uint8_t *src = level_ptr(g, level - 1, f, img0, img0Stride, img0FramePitch, pyr, sp);
     const int sw = g->lv[level - 1].w;
     // the 4 dst columns of this thread: source column, offset from the first one, coefficients
-    int off[4], off1[4], a0[4], a1[4];
+    int off[4], off1[4];
+    uint32_t sel[4], coef[4];
     int sx0 = 0, span = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -63,8 +88,10 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
         const OrbxResizeX xx = rx[lv.rxOff + dx];
         const int sx = xx.sx, sx1 = sx + 1 < sw ? sx + 1 : sx;
         if (k == 0) sx0 = sx;
-        off[k] = sx - sx0; off1[k] = sx1 - sx0; a0[k] = xx.a0; a1[k] = xx.a1;
+        off[k] = sx - sx0; off1[k] = sx1 - sx0;
         span = max(span, off1[k]);
+        sel[k] = 0x0c000c00u | (uint32_t)(off[k] & 7) | ((uint32_t)(off1[k] & 7) << 16);   // (byte off, 0, byte off1, 0)
+        coef[k] = (uint32_t)(uint16_t)xx.a0 | ((uint32_t)(uint16_t)xx.a1 << 16);           // 0 <= a0, a1 <= 2048
     }
     const bool wide = span <= 7 && sx0 + 8 <= sw;   // one unaligned 8-byte load per source row covers all taps
     uint8_t *dstBase = pyr + (size_t)f * g->pyrBytes + lv.off;
@@ -74,25 +101,26 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
         if (dy >= lv.h) break;
         const OrbxResizeY yy = ry[lv.ryOff + dy];
         const uint8_t *S0 = src + (size_t)yy.y0 * sp + sx0, *S1 = src + (size_t)yy.y1 * sp + sx0;
+        const uint32_t b0 = (uint32_t)yy.b0, b1 = (uint32_t)yy.b1;   // 0 <= b <= 2048
         uint32_t out = 0;
         if (wide) {
-            unsigned long long v0, v1;
-            __builtin_memcpy(&v0, S0, 8);
-            __builtin_memcpy(&v1, S1, 8);
+            uint32_t v0[2], v1[2];
+            __builtin_memcpy(v0, S0, 8);
+            __builtin_memcpy(v1, S1, 8);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int p00 = (int)((v0 >> (8 * off[k])) & 0xff), p01 = (int)((v0 >> (8 * off1[k])) & 0xff);
-                const int p10 = (int)((v1 >> (8 * off[k])) & 0xff), p11 = (int)((v1 >> (8 * off1[k])) & 0xff);
-                const int r0 = p00 * a0[k] + p01 * a1[k], r1 = p10 * a0[k] + p11 * a1[k];
-                const int v = (((yy.b0 * (r0 >> 4)) >> 16) + ((yy.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                out |= (uint32_t)(v & 0xff) << (8 * k);
+                const uint32_t r0 = udot2(__builtin_amdgcn_perm(v0[1], v0[0], sel[k]), coef[k], 0u);
+                const uint32_t r1 = udot2(__builtin_amdgcn_perm(v1[1], v1[0], sel[k]), coef[k], 0u);
+                const uint32_t v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2;
+                out |= (v & 0xffu) << (8 * k);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int r0 = S0[off[k]] * a0[k] + S0[off1[k]] * a1[k], r1 = S1[off[k]] * a0[k] + S1[off1[k]] * a1[k];
-                const int v = (((yy.b0 * (r0 >> 4)) >> 16) + ((yy.b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                out |= (uint32_t)(v & 0xff) << (8 * k);
+                const uint32_t r0 = udot2((uint32_t)S0[off[k]] | ((uint32_t)S0[off1[k]] << 16), coef[k], 0u);
+                const uint32_t r1 = udot2((uint32_t)S1[off[k]] | ((uint32_t)S1[off1[k]] << 16), coef[k], 0u);
+                const uint32_t v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2;
+                out |= (v & 0xffu) << (8 * k);
             }
         }
         *(uint32_t *)(dstBase + (size_t)dy * lv.pitch + dx0) = out;   // pitch is a multiple of 64 >= round_up(w,4)
@@ -100,238 +128,66 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
 }
 
 // ------------------------------------------------------------------------------------
-// FAST-9/16 score map (cv::FAST + cornerScore<16>): one byte per pixel of the detectable
-// window [19,w-19) x [19,h-19) of every level: largest t at which the pixel is still a
-// 9-contiguous corner, or 0 when that is < minThFAST.  `corner at t  <=>  score >= t`,
-// so one map serves both the iniThFAST and the minThFAST pass of the reference
-// (src/ORBextractor.cc:1126-1139).  64x16 pixel tile + 3/4 px halo staged in LDS with
-// aligned u32 row loads.
-// ------------------------------------------------------------------------------------
-#define FT_W 64
-#define FT_H 16
-#define FT_LW 72              /* LDS row: 4 px left halo + 64 + 4 right */
-#define FT_LH (FT_H + 6)
-
-__device__ __forceinline__ int fast_score16(const int *d)
-{
-    // window-of-9 min and max over the circular 16-vector d (d = center - circle pixel)
-    int mn2[16], mx2[16], mn4[16], mx4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-    int best = -512;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-        best = max(best, max(mn9, -mx9));
-    }
-    return best - 1;
-}
-
-__global__ __launch_bounds__(256) void k_fast_score(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride,
-                                                    size_t img0FramePitch, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score)
-{
-    __shared__ uint32_t tile[FT_LH * (FT_LW / 4)];
-    const int f = blockIdx.y;
-    int bases[ORBX_MAX_LEVELS];
-    const int nl = g->nlevels;
-    for (int i = 0; i < nl; i++) bases[i] = g->lv[i].fastTileBase;
-    const int l = find_level(bases, nl, blockIdx.x);
-    const OrbxLevel &lv = g->lv[l];
-    const int t = blockIdx.x - lv.fastTileBase;
-    const int tx = t % lv.fastTilesX, ty = t / lv.fastTilesX;
-    const int X0 = ORBX_BORDER + tx * FT_W, Y0 = ORBX_BORDER + ty * FT_H;
-    int pitch;
-    const uint8_t *src = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
-    // stage rows Y0-3 .. Y0+FT_H+2, bytes X0-4 .. X0+67 (X0 is a multiple of 4)
-    for (int i = threadIdx.x; i < FT_LH * (FT_LW / 4); i += 256) {
-        int r = i / (FT_LW / 4), c = i % (FT_LW / 4);
-        int y = Y0 - 3 + r, x = X0 - 4 + 4 * c;
-        uint32_t v = 0;
-        if (y < lv.h && x + 3 < pitch) v = *(const uint32_t *)(src + (size_t)y * pitch + x);
-        else if (y < lv.h) { for (int k = 0; k < 4; k++) if (x + k < lv.w) v |= (uint32_t)src[(size_t)y * pitch + x + k] << (8 * k); }
-        tile[i] = v;
-    }
-    __syncthreads();
-    const uint8_t *tb = (const uint8_t *)tile;
-    const int lx = threadIdx.x & 63, ly0 = (threadIdx.x >> 6) * 4;
-    const int x = X0 + lx;
-    uint8_t *dst = score + (size_t)f * g->pyrBytes + lv.off;
-    const int minTh = g->minTh;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int ly = ly0 + r, y = Y0 + ly;
-        if (x >= lv.w - ORBX_EDGE || y >= lv.h - ORBX_EDGE || x < ORBX_EDGE || y < ORBX_EDGE) continue;
-        const uint8_t *c = tb + (ly + 3) * FT_LW + (lx + 4);
-        const int v = c[0];
-        int d[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) d[k] = v - (int)c[FAST_DY(k) * FT_LW + FAST_DX(k)];
-        int s = fast_score16(d);
-        dst[(size_t)y * lv.pitch + x] = (uint8_t)(s >= minTh ? s : 0);
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// Per-cell detection (ComputeKeyPointsOctTree cell loop, src/ORBextractor.cc:1089-1157):
-// strict 3x3 NMS restricted to the cell's detectable area (what cv::FAST sees of the
-// cell sub-image), iniThFAST survivors or - when there are none - minThFAST survivors,
-// emitted in raster order.  One wave per cell; ordered compaction with __ballot/__popcll.
-// ------------------------------------------------------------------------------------
-#define CT_P 64   /* LDS tile pitch; a cell's detectable area is at most 59x59 (+1 ring) */
-
-__global__ __launch_bounds__(64) void k_cell_nms(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ score, int *__restrict__ cellCount,
-                                                 uint32_t *__restrict__ cellSlots)
-{
-    __shared__ uint8_t tile[CT_P * CT_P];
-    const int f = blockIdx.y, lane = threadIdx.x;
-    int bases[ORBX_MAX_LEVELS];
-    const int nl = g->nlevels;
-    for (int i = 0; i < nl; i++) bases[i] = g->lv[i].cellBase;
-    const int l = find_level(bases, nl, blockIdx.x);
-    const OrbxLevel &lv = g->lv[l];
-    const int cell = blockIdx.x - lv.cellBase;
-    const int cj = cell % lv.nCols, ci = cell / lv.nCols;
-    const int maxBX = lv.w - ORBX_BORDER, maxBY = lv.h - ORBX_BORDER;
-    const int iniX = ORBX_BORDER + cj * lv.wCell, iniY = ORBX_BORDER + ci * lv.hCell;
-    int maxX = min(iniX + lv.wCell + 6, maxBX), maxY = min(iniY + lv.hCell + 6, maxBY);
-    int *cnt = cellCount + (size_t)f * g->cellsPerFrame + blockIdx.x;
-    const int x0 = iniX + 3, x1 = maxX - 3, y0 = iniY + 3, y1 = maxY - 3;
-    const int aw = x1 - x0, ah = y1 - y0;
-    if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || aw <= 0 || ah <= 0) {   // skipped / too small cell (:1101, :1112)
-        if (lane == 0) *cnt = 0;
-        return;
-    }
-    const uint8_t *S = score + (size_t)f * g->pyrBytes + lv.off;
-    const int tw = aw + 2, th = ah + 2;
-    for (int i = lane; i < tw * th; i += 64) {
-        int r = i / tw, c = i % tw;
-        int y = y0 - 1 + r, x = x0 - 1 + c;
-        uint8_t v = 0;
-        if (r > 0 && r < th - 1 && c > 0 && c < tw - 1) v = S[(size_t)y * lv.pitch + x];
-        tile[r * CT_P + c] = v;
-    }
-    __syncthreads();
-    const int iniTh = g->iniTh, n = aw * ah;
-    bool anyIni = false;
-    for (int p0 = 0; p0 < n; p0 += 64) {
-        int p = p0 + lane;
-        if (p < n) {
-            int r = p / aw + 1, c = p % aw + 1;
-            const uint8_t *q = tile + r * CT_P + c;
-            int v = q[0];
-            if (v >= iniTh && v > q[-1] && v > q[1] && v > q[-CT_P - 1] && v > q[-CT_P] && v > q[-CT_P + 1] && v > q[CT_P - 1] &&
-                v > q[CT_P] && v > q[CT_P + 1])
-                anyIni = true;
-        }
-    }
-    const int thr = __any(anyIni) ? iniTh : 1;
-    uint32_t *slot = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase + (size_t)cell * lv.cellCap;
-    int base = 0;
-    for (int p0 = 0; p0 < n; p0 += 64) {
-        int p = p0 + lane;
-        bool keep = false;
-        uint32_t packed = 0;
-        if (p < n) {
-            int r = p / aw, c = p % aw;
-            const uint8_t *q = tile + (r + 1) * CT_P + c + 1;
-            int v = q[0];
-            keep = v >= thr && v > q[-1] && v > q[1] && v > q[-CT_P - 1] && v > q[-CT_P] && v > q[-CT_P + 1] && v > q[CT_P - 1] &&
-                   v > q[CT_P] && v > q[CT_P + 1];
-            packed = (uint32_t)(x0 + c - ORBX_BORDER) | ((uint32_t)(y0 + r - ORBX_BORDER) << 12) | ((uint32_t)v << 24);
-        }
-        unsigned long long m = __ballot(keep);
-        if (keep) {
-            int idx = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (idx < lv.cellCap) slot[idx] = packed;
-        }
-        base += __popcll(m);
-    }
-    if (lane == 0) *cnt = min(base, lv.cellCap);
-}
-
-// ------------------------------------------------------------------------------------
-// Fused cell detector: FAST score + per-cell NMS + threshold fallback + ordered emission in
-// ONE kernel, one workgroup per 30-px cell (ComputeKeyPointsOctTree cell loop,
-// src/ORBextractor.cc:1089-1157, with cv::FAST at :1126,1135).  The cell's input window
-// (detectable area + 3 px ring) is staged in LDS, scores never leave the CU: the score map
-// of k_fast_score/k_cell_nms (kept for the parity taps) is not written or re-read, which
-// removes 2 bytes/pixel of HBM traffic and one launch.  Score arithmetic uses packed 16-bit
-// min/max (two circle pixels per VALU op) behind an exact early-out: a 9-arc of the
-// 16-circle contains k or k+8 for every k, so min_k max(d_k, d_k+8) <= t rules out a dark
-// arc and max_k min(d_k, d_k+8) >= -t a bright one.
+// Cell detector: FAST-9/16 score + per-cell 3x3 NMS + threshold fallback + raster-ordered emission
+// (ComputeKeyPointsOctTree cell loop, src/ORBextractor.cc:1089-1157, with cv::FAST at :1126,1135).
+// ONE WAVE PER 30-px CELL; the cell's input window (detectable area + 3 px ring) and its score
+// tile live in LDS, scores never reach HBM.  `corner at t  <=>  score >= t`, so one score serves
+// both the iniThFAST and the minThFAST pass of the reference.
+//   A  pre-test, all pixels: lane = (row, 16-px segment), 7 x 24-byte window in registers, two
+//      horizontally adjacent centres per packed-u16 op.  A 9-arc of the 16-circle contains k or
+//      k+8 for every k, so  v - max_k min(x_k, x_k+8) > t  (dark arc)  or
+//      min_k max(x_k, x_k+8) - v > t  (bright arc)  is necessary; survivors (edges, corners) are
+//      appended to an LDS list - in raster order, because the lanes are.
+//   B  full score of the survivors on dense waves: 9-arc min / max as min3(min3) chains.
+//   C  strict 3x3 maximum inside the cell (zero ring = "not a corner of this sub-image"),
+//      iniThFAST survivors or - when the cell has none - all of them (:1132), ordered __ballot
+//      compaction into the cell's slot.
+// VALU bound (profiles/): ~1.4k wave-instructions per cell.
 // ------------------------------------------------------------------------------------
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ s16x2 pk_swap(s16x2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 
-// P[k] = (d_k, d_{k+8}), d = centre - circle pixel.
-// Exact necessary condition for a 9-arc at threshold t (see above): cheap, branch free.
-__device__ __forceinline__ bool fast_possible_packed(const s16x2 *P, int minTh)
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
 {
-    s16x2 lo = pk_max(P[0], pk_swap(P[0])), hi = pk_min(P[0], pk_swap(P[0]));
-#pragma unroll
-    for (int k = 1; k < 8; k++) {
-        const s16x2 w = pk_swap(P[k]);
-        lo = pk_min(lo, pk_max(P[k], w));
-        hi = pk_max(hi, pk_min(P[k], w));
-    }
-    return (int)lo.x > minTh || (int)hi.x < -minTh;
+    union { uint32_t u; u16x2 v; } x, y, z;
+    x.u = a; y.u = b; z.v = __builtin_elementwise_min(x.v, y.v);
+    return z.u;
 }
-
-// FAST score = max over the 16 arcs of 9 of min(+d) / min(-d), minus 1; 0 when < minTh.
-__device__ __forceinline__ int fast_score_packed(const s16x2 *P, int minTh)
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
 {
-    s16x2 W[8];   // (d_{k+8}, d_k)
-#pragma unroll
-    for (int k = 0; k < 8; k++) W[k] = pk_swap(P[k]);
-    // windows of 2, 4, 8, 9 consecutive circle pixels starting at k (low half) and k+8 (high half)
-    s16x2 a2[8], b2[8], a4[8], b4[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const s16x2 nx = k < 7 ? P[k + 1] : W[0];
-        a2[k] = pk_min(P[k], nx); b2[k] = pk_max(P[k], nx);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const s16x2 na = k < 6 ? a2[k + 2] : pk_swap(a2[k - 6]), nb = k < 6 ? b2[k + 2] : pk_swap(b2[k - 6]);
-        a4[k] = pk_min(a2[k], na); b4[k] = pk_max(b2[k], nb);
-    }
-    s16x2 best = {-512, -512};
-    const s16x2 zero = {0, 0};
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const s16x2 na = k < 4 ? a4[k + 4] : pk_swap(a4[k - 4]), nb = k < 4 ? b4[k + 4] : pk_swap(b4[k - 4]);
-        const s16x2 a9 = pk_min(pk_min(a4[k], na), W[k]);   // min over the 9-arc starting at k / k+8
-        const s16x2 b9 = pk_max(pk_max(b4[k], nb), W[k]);
-        best = pk_max(best, pk_max(a9, zero - b9));
-    }
-    const int sc = max((int)best.x, (int)best.y) - 1;
-    return sc >= minTh ? sc : 0;
+    union { uint32_t u; u16x2 v; } x, y, z;
+    x.u = a; y.u = b; z.v = __builtin_elementwise_max(x.v, y.v);
+    return z.u;
 }
-
-#define FC_IP 72   /* input window pitch: up to 59+6 bytes per row */
-#define FC_IR 66   /* input window rows */
-#define FC_SP 72   /* score tile pitch: 4 zero bytes | detectable area | >= 4 zero bytes */
-#define FC_SR 62   /* score tile rows: 1 zero row | area | 1 zero row */
-#define FC_ITERS 4 /* items (row, group of 4 px) per thread: 59 rows x 15 groups <= 4*256 */
-
-// byte b (compile-time) of the three row dwords w[0..2] covering bytes 0..11
-#define FC_BYTE(w, b) (((w)[(b) >> 2] >> (8 * ((b) & 3))) & 0xffu)
-
-__global__ __launch_bounds__(256) void k_fast_cells(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
-                                                    const uint8_t *__restrict__ pyr, uint8_t *__restrict__ scoreDbg, int *__restrict__ cellCount,
-                                                    uint32_t *__restrict__ cellSlots)
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t in[FC_IR * (FC_IP / 4)];
-    __shared__ __attribute__((aligned(16))) uint32_t sc[FC_SR * (FC_SP / 4)];
-    __shared__ unsigned short candList[60 * 60];
-    __shared__ int wcnt[4];
-    __shared__ int sAny, sNCand;
-    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    union { uint32_t u; s16x2 v; } x, y, z;
+    x.u = a; y.u = b; z.v = x.v - y.v;
+    return z.u;
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
+{
+    union { uint32_t u; s16x2 v; } x, y, z;
+    x.u = a; y.u = b; z.v = __builtin_elementwise_max(x.v, y.v);
+    return z.u;
+}
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }   // v_min3_i32
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }   // v_max3_i32
+
+// bytes (b, b+1) of the 24-byte window row W[0..5] as a u16 pair; b is a compile-time constant <= 20
+#define FC_PAIR(W, b) __builtin_amdgcn_perm((W)[((b) >> 2) + 1 > 5 ? 5 : ((b) >> 2) + 1], (W)[(b) >> 2], \
+                                            0x0c000c00u | (uint32_t)((b) & 3) | ((uint32_t)(((b) & 3) + 1) << 16))
+
+template <int SEGMAX>   // widest cell of the geometry in 16-px segments (1..4)
+__global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                                   const uint8_t *__restrict__ pyr, uint8_t *__restrict__ scoreDbg, int *__restrict__ cellCount,
+                                                   uint32_t *__restrict__ cellSlots)
+{
+    constexpr int P = 16 * SEGMAX + 16;   // LDS row pitch in bytes of both tiles
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *inT = lds;                                   // (ah+6) x P: input window, tile (0,0) = pixel (x0-3, y0-3)
+    uint8_t *scT = lds + g->fcInBytes;                    // (ah+2) x P: scores, area pixel (c, r) at byte (r+1)*P + c+4
+    unsigned short *cand = (unsigned short *)(scT + g->fcScBytes);
+    const int f = blockIdx.y, lane = threadIdx.x;
     int bases[ORBX_MAX_LEVELS];
     const int nl = g->nlevels;
     for (int i = 0; i < nl; i++) bases[i] = g->lv[i].cellBase;
@@ -346,155 +202,138 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbxGeom *__restrict__
     const int x0 = iniX + 3, x1 = maxX - 3, y0 = iniY + 3, y1 = maxY - 3;
     const int aw = x1 - x0, ah = y1 - y0;
     if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || aw <= 0 || ah <= 0) {   // skipped / degenerate cell (:1101, :1112)
-        if (tid == 0) *cnt = 0;
+        if (lane == 0) *cnt = 0;
         return;
     }
     int pitch;
     const uint8_t *src = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
-    if (tid == 0) { sAny = 0; sNCand = 0; }
     {   // stage rows y0-3 .. y1+2, bytes x0-3 .. x1+2 (+ up to 3 spill bytes, always inside the row)
-        const int iw = aw + 6, ih = ah + 6, nw = (iw + 3) >> 2;
+        const int ih = ah + 6, nw = (aw + 6 + 3) >> 2;
         const uint8_t *base = src + (size_t)(y0 - 3) * pitch + (x0 - 3);
-        for (int i = tid; i < ih * nw; i += 256) {
-            const int r = i / nw, c = i - r * nw;
+        int r = lane / nw, c = lane - r * nw;
+        const int dr = 64 / nw, dc = 64 - dr * nw;
+        while (r < ih) {
             uint32_t v;
             __builtin_memcpy(&v, base + (size_t)r * pitch + 4 * c, 4);   // unaligned dword load
-            in[r * (FC_IP / 4) + c] = v;
+            *(uint32_t *)(inT + r * P + 4 * c) = v;
+            r += dr; c += dc;
+            if (c >= nw) { c -= nw; r++; }
         }
-        for (int i = tid; i < (ah + 2) * (FC_SP / 4); i += 256) sc[i] = 0;
+        uint32_t *z = (uint32_t *)scT;
+        for (int i = lane; i < (ah + 2) * (P / 4); i += 64) z[i] = 0;
     }
     __syncthreads();
-    const int G = (aw + 3) >> 2, nItems = ah * G, minTh = g->minTh, iniTh = g->iniTh;
+    const int minTh = g->minTh, iniTh = g->iniTh;
     uint8_t *dbg = scoreDbg ? scoreDbg + (size_t)f * g->pyrBytes + lv.off : nullptr;
     if (dbg)   // parity tap: pixels that fail the pre-test have score 0
-        for (int p = tid; p < aw * ah; p += 256) dbg[(size_t)(y0 + p / aw) * lv.pitch + (x0 + p % aw)] = 0;
-    // ---- phase A: item = (row r, group of 4 px gq).  Pixel j of the group is byte 4gq+3+j of window
-    //      row r+3.  Every pixel gets the cheap exact pre-test; survivors (edge and corner pixels,
-    //      ~10-20 %) are appended to an LDS list so that phase B runs the full score on dense waves. ----
-#pragma unroll
-    for (int it = 0; it < FC_ITERS; it++) {
-        if (256 * it >= nItems) break;
-        const int item = tid + 256 * it;
-        const bool live = item < nItems;
-        const int r = live ? item / G : 0, gq = live ? item - r * G : 0;
-        uint32_t W[7][3];
+        for (int p = lane; p < aw * ah; p += 64) dbg[(size_t)(y0 + p / aw) * lv.pitch + (x0 + p % aw)] = 0;
+
+    // ---- phase A ----
+    const int S = (aw + 15) >> 4;                                           // segments per row (1..SEGMAX)
+    const int rpp = S == 1 ? 64 : S == 2 ? 32 : S == 3 ? 21 : 16;           // rows per pass
+    const int rl = S == 1 ? lane : S == 2 ? (lane >> 1) : S == 3 ? ((lane * 43) >> 7) : (lane >> 2);
+    const int seg = lane - rl * S, c0 = 16 * seg;
+    const uint32_t colMask = (aw - c0 >= 16) ? 0xffffu : (aw - c0 <= 0 ? 0u : ((1u << (aw - c0)) - 1u));
+    int nc = 0;
+    for (int rowBase = 0; rowBase < ah; rowBase += rpp) {
+        const int r = rowBase + rl;
+        const bool live = rl < rpp && r < ah;
+        const uint8_t *wp = inT + min(r, ah - 1) * P + c0;
+        uint32_t W[7][6];
 #pragma unroll
         for (int dy = 0; dy < 7; dy++) {
-            const uint32_t *pw = in + (r + dy) * (FC_IP / 4) + gq;
-            W[dy][0] = pw[0]; W[dy][1] = pw[1]; W[dy][2] = pw[2];
+            const uint4 a = *(const uint4 *)(wp + dy * P);
+            const uint2 b = *(const uint2 *)(wp + dy * P + 16);
+            W[dy][0] = a.x; W[dy][1] = a.y; W[dy][2] = a.z; W[dy][3] = a.w; W[dy][4] = b.x; W[dy][5] = b.y;
         }
+        uint32_t mask = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            // (v, v) and (x_k, x_{k+8}) as 16-bit pairs straight from the window dwords: one v_perm_b32 each
-            const uint32_t cw = W[3][(j + 3) >> 2];
-            const uint32_t cb = (uint32_t)((j + 3) & 3);
-            const uint32_t vv = __builtin_amdgcn_perm(cw, cw, 0x0c000c00u | cb | ((4u + cb) << 16));
-            s16x2 P[8];
+        for (int j = 0; j < 16; j += 2) {
+            uint32_t A = 0u, B = 0x00ff00ffu;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int ba = j + 3 + FAST_DX(k), bb = j + 3 + FAST_DX(k + 8);
-                const uint32_t wa = W[3 + FAST_DY(k)][ba >> 2], wb = W[3 + FAST_DY(k + 8)][bb >> 2];
-                const uint32_t xx = __builtin_amdgcn_perm(wb, wa, 0x0c000c00u | (uint32_t)(ba & 3) | ((4u + (uint32_t)(bb & 3)) << 16));
-                union { uint32_t u; s16x2 v; } a, b;
-                a.u = vv; b.u = xx;
-                P[k] = a.v - b.v;
+                const uint32_t xa = FC_PAIR(W[3 + FAST_DY(k)], j + 3 + FAST_DX(k));
+                const uint32_t xb = FC_PAIR(W[3 + FAST_DY(k + 8)], j + 3 + FAST_DX(k + 8));
+                A = pk_max_u16(A, pk_min_u16(xa, xb));
+                B = pk_min_u16(B, pk_max_u16(xa, xb));
             }
-            const bool cand = live && (4 * gq + j < aw) && fast_possible_packed(P, minTh);
-            const unsigned long long m = __ballot(cand);
-            if (m) {
-                int basep = 0;
-                if (lane == 0) basep = atomicAdd(&sNCand, __popcll(m));
-                basep = __shfl(basep, 0);
-                if (cand) candList[basep + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((r << 6) | (4 * gq + j));
-            }
+            const uint32_t vv = FC_PAIR(W[3], j + 3);
+            const uint32_t m = pk_max_i16(pk_sub_i16(vv, A), pk_sub_i16(B, vv));
+            mask |= ((int)(short)(m & 0xffffu) > minTh ? 1u : 0u) << j;
+            mask |= ((int)(short)(m >> 16) > minTh ? 1u : 0u) << (j + 1);
         }
+        mask = live ? (mask & colMask) : 0u;
+        const int cntL = __popc(mask);
+        const int incl = wave_incl_scan_i(cntL, lane);
+        int o = nc + incl - cntL;
+        while (mask) {
+            const int bpos = __ffs(mask) - 1;
+            mask &= mask - 1;
+            cand[o++] = (unsigned short)((r << 6) | (c0 + bpos));
+        }
+        nc += __shfl(incl, 63);
     }
     __syncthreads();
+
     // ---- phase B: full FAST score of the surviving pixels ----
-    {
-        const int nc = sNCand;
-        uint8_t *scb = (uint8_t *)sc;
-        const uint8_t *inb = (const uint8_t *)in;
-        for (int i = tid; i < nc; i += 256) {
-            const int code = candList[i], r = code >> 6, c = code & 63;
-            const uint8_t *q = inb + (r + 3) * FC_IP + (c + 3);
-            const int v = q[0];
-            s16x2 P[8];
+    for (int i = lane; i < nc; i += 64) {
+        const int code = cand[i], r = code >> 6, c = code & 63;
+        const uint8_t *q = inT + r * P + c;          // window byte of circle offset (dx, dy): q[(dy+3)*P + dx+3]
+        const int v = q[3 * P + 3];
+        int x[16];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                P[k].x = (short)(v - (int)q[FAST_DY(k) * FC_IP + FAST_DX(k)]);
-                P[k].y = (short)(v - (int)q[FAST_DY(k + 8) * FC_IP + FAST_DX(k + 8)]);
-            }
-            const int sco = fast_score_packed(P, minTh);
-            scb[(r + 1) * FC_SP + (c + 4)] = (uint8_t)sco;
-            if (dbg) dbg[(size_t)(y0 + r) * lv.pitch + (x0 + c)] = (uint8_t)sco;
+        for (int k = 0; k < 16; k++) x[k] = q[(3 + FAST_DY(k)) * P + 3 + FAST_DX(k)];
+        int a3[16], b3[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            a3[k] = min3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+            b3[k] = max3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
         }
+        int maxA = 0, minB = 255;   // max over the 16 arcs of min(x), min over the arcs of max(x)
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            const int a9 = min3i(a3[k], a3[(k + 3) & 15], a3[(k + 6) & 15]), a9n = min3i(a3[k + 1], a3[(k + 4) & 15], a3[(k + 7) & 15]);
+            const int b9 = max3i(b3[k], b3[(k + 3) & 15], b3[(k + 6) & 15]), b9n = max3i(b3[k + 1], b3[(k + 4) & 15], b3[(k + 7) & 15]);
+            maxA = max3i(maxA, a9, a9n);
+            minB = min3i(minB, b9, b9n);
+        }
+        // dark arc: all x < v - t  <=>  t < v - max(x);  bright arc: all x > v + t  <=>  t < min(x) - v;  score = largest such t
+        int sco = max(v - minB, maxA - v) - 1;
+        sco = sco >= minTh ? sco : 0;
+        scT[(r + 1) * P + c + 4] = (uint8_t)sco;
+        if (dbg) dbg[(size_t)(y0 + r) * lv.pitch + (x0 + c)] = (uint8_t)sco;
     }
     __syncthreads();
-    // ---- strict 3x3 maxima inside the cell (zero ring = "not a corner of this sub-image") ----
-    uint32_t ctr[FC_ITERS];
-    unsigned nmsMask[FC_ITERS], iniMask[FC_ITERS];
+
+    // ---- phase C: strict 3x3 maxima, threshold choice, ordered emission ----
     bool anyIni = false;
-#pragma unroll
-    for (int it = 0; it < FC_ITERS; it++) {
-        ctr[it] = 0; nmsMask[it] = 0; iniMask[it] = 0;
-        const int item = tid + 256 * it;
-        if (item >= nItems) continue;
-        const int r = item / G, gq = item - r * G;
-        uint32_t N[3][3];
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++) {
-            const uint32_t *pw = sc + (r + dy) * (FC_SP / 4) + gq;
-            N[dy][0] = pw[0]; N[dy][1] = pw[1]; N[dy][2] = pw[2];
-        }
-        ctr[it] = N[1][1];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int v = (int)FC_BYTE(N[1], 4 + j);
-            bool mx = v > 0;
-#pragma unroll
-            for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-                for (int dx = -1; dx <= 1; dx++)
-                    if (dy != 1 || dx != 0) mx = mx && v > (int)FC_BYTE(N[dy], 4 + j + dx);
-            if (mx) { nmsMask[it] |= 1u << j; if (v >= iniTh) { iniMask[it] |= 1u << j; anyIni = true; } }
-        }
+    for (int i = lane; i < nc; i += 64) {
+        const int code = cand[i], r = code >> 6, c = code & 63;
+        const uint8_t *sp = scT + (r + 1) * P + c + 4;
+        const int v = sp[0];
+        const bool nms = v > 0 && v > sp[-1] && v > sp[1] && v > sp[-P - 1] && v > sp[-P] && v > sp[-P + 1] && v > sp[P - 1] && v > sp[P] && v > sp[P + 1];
+        const bool ini = nms && v >= iniTh;
+        cand[i] = (unsigned short)(code | (nms ? 0x1000 : 0) | (ini ? 0x2000 : 0));   // own entry: no cross-lane hazard
+        anyIni = anyIni || ini;
     }
-    if (__any(anyIni) && lane == 0) sAny = 1;
-    __syncthreads();
-    const bool useIni = sAny != 0;   // iniThFAST keypoints exist in the cell -> the minThFAST retry is skipped (:1132)
+    const int keepBit = __any(anyIni) ? 0x2000 : 0x1000;   // iniThFAST keypoints exist -> the minThFAST retry is skipped (:1132)
     uint32_t *slot = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase + (size_t)cell * lv.cellCap;
     int base = 0;
-#pragma unroll
-    for (int it = 0; it < FC_ITERS; it++) {
-        if (256 * it >= nItems) break;
-        const int item = tid + 256 * it;
-        const unsigned keep = useIni ? iniMask[it] : nmsMask[it];
-        int below = 0, tot = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned long long m = __ballot((keep >> j) & 1u);
-            below += __popcll(m & ((1ull << lane) - 1ull));
-            tot += __popcll(m);
-        }
-        if (lane == 0) wcnt[wave] = tot;
-        __syncthreads();
-        int off = base + below;
-        for (int k = 0; k < wave; k++) off += wcnt[k];
+    for (int i0 = 0; i0 < nc; i0 += 64) {
+        const int i = i0 + lane;
+        bool keep = false;
+        int code = 0;
+        if (i < nc) { code = cand[i]; keep = (code & keepBit) != 0; }
+        const unsigned long long m = __ballot(keep);
         if (keep) {
-            const int r = item / G, gq = item - r * G;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if ((keep >> j) & 1u) {
-                    const uint32_t v = (ctr[it] >> (8 * j)) & 0xffu;
-                    if (off < lv.cellCap) slot[off] = (uint32_t)(x0 + 4 * gq + j - ORBX_BORDER) | ((uint32_t)(y0 + r - ORBX_BORDER) << 12) | (v << 24);
-                    off++;
-                }
+            const int r = (code >> 6) & 63, c = code & 63;
+            const uint32_t v = scT[(r + 1) * P + c + 4];
+            const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (idx < lv.cellCap) slot[idx] = (uint32_t)(x0 + c - ORBX_BORDER) | ((uint32_t)(y0 + r - ORBX_BORDER) << 12) | (v << 24);
         }
-        base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
+        base += __popcll(m);
     }
-    if (tid == 0) *cnt = min(base, lv.cellCap);
+    if (lane == 0) *cnt = min(base, lv.cellCap);
 }
 
 // ------------------------------------------------------------------------------------
@@ -943,46 +782,56 @@ __global__ __launch_bounds__(256) void k_blur(const OrbxGeom *__restrict__ g, co
     }
     __syncthreads();
     const uint32_t k0 = g->taps[0], k1 = g->taps[1], k2 = g->taps[2], k3 = g->taps[3], k4 = g->taps[4], k5 = g->taps[5], k6 = g->taps[6];
-    // horizontal: item (row r, group gq of 4 pixels) reads bytes 4gq+1 .. 4gq+10 of the row
-    for (int i = threadIdx.x; i < BT_IH * (BT_W / 4); i += 256) {
-        const int r = i >> 4, gq = i & 15;
-        const uint32_t *pw = in + r * BT_IW + gq;
-        const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
-        uint32_t b[12];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xff; b[4 + k] = (w1 >> (8 * k)) & 0xff; b[8 + k] = (w2 >> (8 * k)) & 0xff; }
-        uint32_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t sum = k0 * b[1 + j] + k1 * b[2 + j] + k2 * b[3 + j] + k3 * b[4 + j] + k4 * b[5 + j] + k5 * b[6 + j] + k6 * b[7 + j];
-            o[j] = sum > 65535u ? 65535u : sum;
+    // horizontal: item (row r, group gq of 4 pixels) reads bytes 4gq+1 .. 4gq+10 of the row.  Pixel j =
+    // taps 0..3 . bytes (1+j .. 4+j)  +  taps 4..6 . bytes (5+j .. 7+j): two v_dot4_u32_u8 on byte
+    // windows cut out with v_alignbyte_b32.  Taps are <= 255 and sum to <= 257 (checked when the handle
+    // is created), so the 16-bit horizontal sums cannot saturate.
+    {
+        const uint32_t TL = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), TH = k4 | (k5 << 8) | (k6 << 16);
+        for (int i = threadIdx.x; i < BT_IH * (BT_W / 4); i += 256) {
+            const int r = i >> 4, gq = i & 15;
+            const uint32_t *pw = in + r * BT_IW + gq;
+            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+            const uint32_t o0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), TL, 0u, false), false);
+            const uint32_t o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), TL, 0u, false), false);
+            const uint32_t o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), TL, 0u, false), false);
+            const uint32_t o3 = __builtin_amdgcn_udot4(w2, TH, __builtin_amdgcn_udot4(w1, TL, 0u, false), false);
+            hz[r * (BT_W / 2) + 2 * gq] = o0 | (o1 << 16);
+            hz[r * (BT_W / 2) + 2 * gq + 1] = o2 | (o3 << 16);
         }
-        hz[r * (BT_W / 2) + 2 * gq] = o[0] | (o[1] << 16);
-        hz[r * (BT_W / 2) + 2 * gq + 1] = o[2] | (o[3] << 16);
     }
     __syncthreads();
-    // vertical: thread -> 4 adjacent columns x 2 rows
+    // vertical: thread -> 4 adjacent columns x 2 rows.  Vertically adjacent 16-bit sums of one column
+    // are paired with one v_perm_b32, then 4 v_dot2_u32_u16 per output ((k0,k1) (k2,k3) (k4,k5) (k6,0)),
+    // the +2^15 rounding rides in the accumulator input.
     const int gq = threadIdx.x & 15, rr = (threadIdx.x >> 4) * 2;
     const int x = X0 + 4 * gq;
     if (x >= w) return;
     uint32_t c0[8], c1[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) { c0[k] = hz[(rr + k) * (BT_W / 2) + 2 * gq]; c1[k] = hz[(rr + k) * (BT_W / 2) + 2 * gq + 1]; }
+    const uint32_t V01 = k0 | (k1 << 16), V23 = k2 | (k3 << 16), V45 = k4 | (k5 << 16), V6 = k6;
+    uint32_t res[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t selp = (j & 1) ? 0x07060302u : 0x05040100u;   // (h[r], h[r+1]) of column j as a u16 pair
+        uint32_t P[8];
+#pragma unroll
+        for (int k = 0; k < 7; k++) P[k] = (j < 2) ? __builtin_amdgcn_perm(c0[k + 1], c0[k], selp) : __builtin_amdgcn_perm(c1[k + 1], c1[k], selp);
+        P[7] = (j < 2) ? __builtin_amdgcn_perm(c0[7], c0[7], selp) : __builtin_amdgcn_perm(c1[7], c1[7], selp);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t sum = udot2(P[q + 6], V6, udot2(P[q + 4], V45, udot2(P[q + 2], V23, udot2(P[q], V01, 32768u))));
+            const uint32_t v = sum >> 16;
+            res[q][j] = v > 255u ? 255u : v;
+        }
+    }
     uint8_t *dst = blur + (size_t)f * g->pyrBytes + lv.off;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int y = Y0 + rr + q;
         if (y >= h) break;
-        uint32_t outw = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t v[7];
-#pragma unroll
-            for (int k = 0; k < 7; k++) { const uint32_t wd = (j < 2) ? c0[q + k] : c1[q + k]; v[k] = (j & 1) ? (wd >> 16) : (wd & 0xffff); }
-            uint32_t sum = k0 * v[0] + k1 * v[1] + k2 * v[2] + k3 * v[3] + k4 * v[4] + k5 * v[5] + k6 * v[6];
-            sum = (sum + 32768u) >> 16;
-            outw |= (sum > 255u ? 255u : sum) << (8 * j);
-        }
+        const uint32_t outw = res[q][0] | (res[q][1] << 8) | (res[q][2] << 16) | (res[q][3] << 24);
         uint8_t *o = dst + (size_t)y * lv.pitch + x;
         if (x + 3 < lv.pitch) *(uint32_t *)o = outw;       // pitch is a multiple of 64: bytes beyond w are padding
         else for (int j = 0; j < 4 && x + j < w; j++) o[j] = (uint8_t)(outw >> (8 * j));
@@ -1091,16 +940,9 @@ __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g
 int orbx_launch_resize(const OrbxLaunch &L, int level)
 {
     const OrbxLevel &lv = L.geom->lv[level];
-    dim3 grid((unsigned)((lv.w + 255) / 256), (unsigned)((lv.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS)), (unsigned)L.batch);
+    const int items = ((lv.w + 3) >> 2) * ((lv.h + RS_ROWS - 1) / RS_ROWS);
+    dim3 grid((unsigned)((items + 255) / 256), 1u, (unsigned)L.batch);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, L.stream, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rx, L.ry);
-    LAUNCH_CHECK();
-    return ORBX_OK;
-}
-
-int orbx_launch_fast(const OrbxLaunch &L)
-{
-    dim3 grid((unsigned)L.geom->fastTiles, (unsigned)L.batch);
-    hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score);
     LAUNCH_CHECK();
     return ORBX_OK;
 }
@@ -1108,15 +950,17 @@ int orbx_launch_fast(const OrbxLaunch &L)
 int orbx_launch_fast_cells(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->cellsPerFrame, (unsigned)L.batch);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score, L.cellCount, L.cellSlots);
-    LAUNCH_CHECK();
-    return ORBX_OK;
-}
-
-int orbx_launch_cells(const OrbxLaunch &L)
-{
-    dim3 grid((unsigned)L.geom->cellsPerFrame, (unsigned)L.batch);
-    hipLaunchKernelGGL(k_cell_nms, grid, dim3(64), 0, L.stream, L.geomDev, L.score, L.cellCount, L.cellSlots);
+    const size_t ldsBytes = (size_t)L.geom->fcLdsBytes;
+#define FC_LAUNCH(SM)                                                                                                                          \
+    hipLaunchKernelGGL(k_fast_cells<SM>, grid, dim3(64), ldsBytes, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score, \
+                       L.cellCount, L.cellSlots)
+    switch (L.geom->fcSegMax) {
+    case 1: FC_LAUNCH(1); break;
+    case 2: FC_LAUNCH(2); break;
+    case 3: FC_LAUNCH(3); break;
+    default: FC_LAUNCH(4); break;
+    }
+#undef FC_LAUNCH
     LAUNCH_CHECK();
     return ORBX_OK;
 }
