@@ -109,8 +109,11 @@ int orbx_extract_batch(orbx_extractor *h, const uint8_t *const *images, int batc
                        int capacity, int *counts);
 
 /* Device-resident batch: images_dev points to DEVICE memory, frame f at
- * images_dev + f*frame_pitch (rows `stride` bytes apart).  Runs asynchronously on the
- * handle's stream; results stay in handle-owned device buffers until downloaded. */
+ * images_dev + f*frame_pitch (rows `stride` bytes apart); the buffer spans batch*frame_pitch
+ * bytes.  Runs asynchronously on the handle's stream; results stay in handle-owned device
+ * buffers until downloaded.  Rows padded to stride >= round_up(width,4)+12 (and frame_pitch >=
+ * stride*height) let the pyramid kernel read aligned windows everywhere (faster); tight rows
+ * are handled too. */
 int orbx_extract_batch_device(orbx_extractor *h, const void *images_dev, int batch, int width,
                               int height, int stride, size_t frame_pitch);
 /* Device pointers of the last batch's results: keypoints[f*cap + i], descriptors

@@ -65,8 +65,6 @@ struct orbx_extractor {
     // current geometry
     OrbxGeom geom;
     bool geomValid = false;
-    std::vector<OrbxResizeX> rxHost;
-    std::vector<OrbxResizeY> ryHost;
     std::vector<uint8_t> binHost;
     int nodeCap = 512;
     // device state
@@ -78,8 +76,6 @@ struct orbx_extractor {
     int profCount = 0;
     bool debugTaps = false;   // keep the FAST score map for orbx_debug_download_scores
     DevBuf<OrbxGeom> geomDev;
-    DevBuf<OrbxResizeX> rxDev;
-    DevBuf<OrbxResizeY> ryDev;
     DevBuf<uint8_t> binDev, pyr, blur, score, staging;
     DevBuf<int> cellCount, lvlCnt, status;
     // results are double buffered: a consumer (matcher) may still read batch i while batch i+1 is
@@ -156,7 +152,7 @@ int build_geometry(orbx_extractor *h, int W, int H)
     g.nlevels = nl; g.W = W; g.H = H; g.iniTh = h->cfg.ini_th_fast; g.minTh = h->cfg.min_th_fast;
     for (int i = 0; i < 7; i++) g.taps[i] = h->taps[i];
     for (int i = 0; i < 16; i++) g.umax[i] = h->umax[i];
-    h->rxHost.clear(); h->ryHost.clear(); h->binHost.clear();
+    h->binHost.clear();
     size_t off = 0;
     int cells = 0, slots = 0, kps = 0, btiles = 0, maxNodes = 0, maxWCell = 0, maxHCell = 0;
     for (int l = 0; l < nl; l++) {
@@ -168,7 +164,7 @@ int build_geometry(orbx_extractor *h, int W, int H)
             return ORBX_ERR_ARG;
         }
         if (lv.w > 4095 + ORBX_BORDER || lv.h > 4095 + ORBX_BORDER) { orbx_set_error("image too large (max 4111 px per side)"); return ORBX_ERR_ARG; }
-        lv.pitch = (int)align_up((size_t)lv.w, 64);
+        lv.pitch = (int)align_up((size_t)lv.w + 16, 64);   // >= 16 readable bytes behind every row (k_resize reads aligned 12-byte windows)
         lv.off = (int)off;
         off += align_up((size_t)lv.pitch * lv.h, 256);
         const int minB = ORBX_BORDER, maxBX = lv.w - ORBX_BORDER, maxBY = lv.h - ORBX_BORDER;
@@ -208,32 +204,12 @@ int build_geometry(orbx_extractor *h, int W, int H)
         btiles += lv.blurTilesX * lv.blurTilesY;
         lv.scale = h->scale[(size_t)l];
         lv.patchSize = (int)(ORBX_PATCH * h->scale[(size_t)l]);
-        // cv::resize(INTER_LINEAR) tables from level l-1 (OpenCV resize.cpp, 11-bit fixed point)
-        lv.rxOff = (int)h->rxHost.size();
-        lv.ryOff = (int)h->ryHost.size();
+        // cv::resize(INTER_LINEAR) from level l-1: the kernel evaluates OpenCV's index / coefficient
+        // arithmetic itself (k_resize: resize_coef), only the double inverse scales come from here
+        lv.rsScaleX = lv.rsScaleY = 1.0;
         if (l > 0) {
-            const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h;
-            const double scale_x = 1. / ((double)lv.w / sw), scale_y = 1. / ((double)lv.h / sh);
-            for (int dx = 0; dx < lv.w; dx++) {
-                float fx = (float)((dx + 0.5) * scale_x - 0.5);
-                int sx = floor_d(fx);
-                fx -= sx;
-                if (sx < 0) { fx = 0; sx = 0; }
-                if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-                OrbxResizeX e;
-                e.sx = (uint16_t)sx; e.a0 = sat_short(round_f((1.f - fx) * 2048)); e.a1 = sat_short(round_f(fx * 2048)); e.pad = 0;
-                h->rxHost.push_back(e);
-            }
-            for (int dy = 0; dy < lv.h; dy++) {
-                float fy = (float)((dy + 0.5) * scale_y - 0.5);
-                int sy = floor_d(fy);
-                fy -= sy;
-                OrbxResizeY e;
-                e.b0 = sat_short(round_f((1.f - fy) * 2048)); e.b1 = sat_short(round_f(fy * 2048));
-                e.y0 = (uint16_t)(sy < 0 ? 0 : (sy < sh ? sy : sh - 1));
-                e.y1 = (uint16_t)(sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1));
-                h->ryHost.push_back(e);
-            }
+            lv.rsScaleX = 1. / ((double)lv.w / g.lv[l - 1].w);
+            lv.rsScaleY = 1. / ((double)lv.h / g.lv[l - 1].h);
         }
     }
     g.cellsPerFrame = cells; g.slotsPerFrame = slots; g.kpPerFrame = kps; g.outCap = kps;
@@ -265,13 +241,9 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
         int rc = build_geometry(h, W, H);
         if (rc != ORBX_OK) return rc;
         if ((rc = h->geomDev.ensure(1)) != ORBX_OK) return rc;
-        if ((rc = h->rxDev.ensure(std::max<size_t>(h->rxHost.size(), 1))) != ORBX_OK) return rc;
-        if ((rc = h->ryDev.ensure(std::max<size_t>(h->ryHost.size(), 1))) != ORBX_OK) return rc;
         if ((rc = h->binDev.ensure(std::max<size_t>(h->binHost.size(), 1))) != ORBX_OK) return rc;
         ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
         ORBX_HIP_CHECK(hipMemcpy(h->geomDev.p, &h->geom, sizeof(OrbxGeom), hipMemcpyHostToDevice));
-        if (!h->rxHost.empty()) ORBX_HIP_CHECK(hipMemcpy(h->rxDev.p, h->rxHost.data(), h->rxHost.size() * sizeof(OrbxResizeX), hipMemcpyHostToDevice));
-        if (!h->ryHost.empty()) ORBX_HIP_CHECK(hipMemcpy(h->ryDev.p, h->ryHost.data(), h->ryHost.size() * sizeof(OrbxResizeY), hipMemcpyHostToDevice));
         ORBX_HIP_CHECK(hipMemcpy(h->binDev.p, h->binHost.data(), h->binHost.size(), hipMemcpyHostToDevice));
         h->geomValid = true;
         h->allocBatch = 0;   // per-frame sizes changed: re-check every buffer
@@ -310,7 +282,7 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     L.stream = h->stream; L.geomDev = h->geomDev.p; L.geom = &h->geom; L.batch = batch;
     L.img0 = img0Dev; L.img0Stride = stride; L.img0FramePitch = framePitch;
     L.pyr = h->pyr.p; L.blur = h->blur.p; L.score = h->debugTaps ? h->score.p : nullptr; L.blurBytes = h->geom.pyrBytes;
-    L.rx = h->rxDev.p; L.ry = h->ryDev.p; L.binTab = h->binDev.p;
+    L.binTab = h->binDev.p;
     L.cellCount = h->cellCount.p; L.cellSlots = h->cellSlots.p; L.ptBuf = h->ptBuf.p;
     h->cur ^= 1;
     const int cb = h->cur;
@@ -355,7 +327,7 @@ int check_status(orbx_extractor *h, int batch)
 int upload(orbx_extractor *h, const uint8_t *const *images, int batch, int W, int H, int stride)
 {
     if (!images || stride < W) { orbx_set_error("bad image pointer / stride"); return ORBX_ERR_ARG; }
-    const int dstStride = (int)align_up((size_t)W, 64);
+    const int dstStride = (int)align_up((size_t)W + 16, 64);   // same row padding as the pyramid levels
     const size_t fp = align_up((size_t)dstStride * H + 256, 256);
     int rc = h->staging.ensure(fp * (size_t)batch);
     if (rc != ORBX_OK) return rc;
@@ -430,7 +402,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->geomDev.release(); h->rxDev.release(); h->ryDev.release(); h->binDev.release(); h->pyr.release(); h->blur.release();
+    h->geomDev.release(); h->binDev.release(); h->pyr.release(); h->blur.release();
     h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release();
     for (int b = 0; b < 2; b++) { h->outDesc[b].release(); h->outCnt[b].release(); h->outKp[b].release(); }
     h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->lvlKp.release();

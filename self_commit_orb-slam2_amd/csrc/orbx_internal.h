@@ -20,9 +20,6 @@
 #define ORBX_DEV_ERR_NODECAP 2 /* quadtree node list overflow (internal)      */
 #define ORBX_DEV_ERR_KPCAP 4   /* level keypoint buffer overflow (internal)   */
 
-struct OrbxResizeX { uint16_t sx; int16_t a0, a1; uint16_t pad; };          /* per dst column */
-struct OrbxResizeY { uint16_t y0, y1; int16_t b0, b1; };                      /* per dst row    */
-
 /* Geometry of one pyramid level for the current image size (host-built, device-read). */
 struct OrbxLevel {
     int w, h, pitch;        /* level size, row pitch in bytes (levels >= 1; level 0 uses the input stride) */
@@ -37,7 +34,7 @@ struct OrbxLevel {
     int binOff;             /* offset of this level's x -> initial-node table (u8)        */
     int kpBase, kpCap;      /* slice of the per-frame level-keypoint array                */
     int blurTileBase, blurTilesX, blurTilesY;
-    int rxOff, ryOff;       /* offsets into the resize tables                             */
+    double rsScaleX, rsScaleY; /* cv::resize inverse scale from level l-1: 1.0 / ((double)w / w_prev)  */
     int patchSize;          /* (int)(PATCH_SIZE*scale), src/ORBextractor.cc:1175          */
     float scale;            /* mvScaleFactor[level]                                       */
 };
@@ -79,8 +76,6 @@ struct OrbxLaunch {
     size_t img0FramePitch;
     uint8_t *pyr, *blur, *score;  /* device: per frame pyrBytes / blurBytes / scoreBytes    */
     size_t blurBytes;             /* blurred copy of ALL levels (level 0 included)          */
-    const OrbxResizeX *rx;
-    const OrbxResizeY *ry;
     const uint8_t *binTab;
     int *cellCount;
     uint32_t *cellSlots;

@@ -70,60 +70,69 @@ __global__ __launch_bounds__(256) void k_bow_order(FeatDev A, const int32_t *__r
 }
 
 // top-TOPK candidates of every A feature by key = dist<<16 | j over the B features of the same
-// node (mode 1: that also carry a valid MapPoint).  B descriptors are staged in LDS as four
-// u64 planes so that consecutive lanes read consecutive 8-byte words (conflict free).
-#define TOPK_ROWS 64   /* A features per block (16 per wave) */
+// node (mode 1: that also carry a valid MapPoint).  LANE = one A feature: its descriptor lives in
+// 8 VGPRs, the B descriptor of iteration j is wave-uniform and comes in through the scalar cache
+// (s_load_dwordx8), so a distance is 8 x (v_xor_b32 + v_bcnt_u32_b32) and nothing else.
+// Distance cut-off: a candidate at distance d >= dcut can never be accepted as best
+// (d > TH_LOW) and, as second best, can never fail the ratio test of an acceptable best
+// (nnratio * d > TH_LOW >= best, orbx_search_by_bow_device computes dcut in the float arithmetic
+// of the test); dropping it leaves the greedy replay bit-identical and makes list updates rare.
+// The per-lane list starts filled with the sentinel dcut<<16, so "key < kk[TOPK-1]" is the whole test.
+#define TOPK_ROWS 256   /* A features per block: one per lane */
+template <bool FILTER>   // B side has node ids and/or a validity mask (staged in LDS)
 __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
-                                                  uint32_t *__restrict__ topk, int stride)
+                                                  uint32_t dcut, uint32_t *__restrict__ topk, int stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int p = blockIdx.y, fa = pairsA[p], fb = pairsB[p];
     const int nA = min(A.counts[fa], A.cap), nB = min(B.counts[fb], B.cap);
     const int capB = B.cap;
-    unsigned long long *plane = (unsigned long long *)smem;     // [4][capB]
-    int32_t *gB = (int32_t *)(plane + 4 * (size_t)capB);         // [capB], -2^31 = excluded
     const int row0 = blockIdx.x * TOPK_ROWS;
     if (row0 >= nA) return;
-    const unsigned long long *dB = (const unsigned long long *)(B.desc + (size_t)fb * capB * 32);
-    for (int t = threadIdx.x; t < nB * 4; t += 256) { int j = t >> 2, w = t & 3; plane[(size_t)w * capB + j] = dB[t]; }
-    for (int j = threadIdx.x; j < nB; j += 256) {
-        int g = B.groups ? B.groups[(size_t)fb * capB + j] : 0;
-        if (mode == 1 && B.valid && !B.valid[(size_t)fb * capB + j]) g = (int)0x80000000;
-        gB[j] = g;
+    int32_t *gB = (int32_t *)smem;   // [capB] node id, 0x80000000 = excluded (FILTER only)
+    if (FILTER) {
+        for (int j = threadIdx.x; j < nB; j += 256) {
+            int gq = B.groups ? B.groups[(size_t)fb * capB + j] : 0;
+            if (mode == 1 && B.valid && !B.valid[(size_t)fb * capB + j]) gq = (int)0x80000000;
+            gB[j] = gq;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < TOPK_ROWS; r += 4) {
-        const int i = row0 + r;
-        if (i >= nA) break;
-        const unsigned long long *da = (const unsigned long long *)(A.desc + ((size_t)fa * A.cap + i) * 32);
-        unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
-        const int gA = A.groups ? A.groups[(size_t)fa * A.cap + i] : 0;
-        uint32_t kk[TOPK];
+    if (row0 + (int)(threadIdx.x & ~63u) >= nA) return;   // whole wave beyond the last A feature
+    const int i = row0 + threadIdx.x;
+    const bool live = i < nA;
+    const uint32_t *da = (const uint32_t *)(A.desc + ((size_t)fa * A.cap + (live ? i : nA - 1)) * 32);
+    const uint32_t a0 = da[0], a1 = da[1], a2 = da[2], a3 = da[3], a4 = da[4], a5 = da[5], a6 = da[6], a7 = da[7];
+    const int gA = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live ? i : nA - 1)] : 0;
+    const uint32_t sentinel = dcut << 16;
+    uint32_t kk[TOPK];
 #pragma unroll
-        for (int q = 0; q < TOPK; q++) kk[q] = KEY_EMPTY;
-        for (int j = lane; j < nB; j += 64) {
-            if (gB[j] != gA) continue;
-            int d = hamming256(a, plane[j], plane[(size_t)capB + j], plane[2 * (size_t)capB + j], plane[3 * (size_t)capB + j]);
-            uint32_t key = ((uint32_t)d << 16) | (uint32_t)j;
-            if (key < kk[TOPK - 1]) {   // sorted insert (ascending)
+    for (int q = 0; q < TOPK; q++) kk[q] = live ? sentinel : 0u;   // dead lanes never insert
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    const u32x8 *__restrict__ dB = (const u32x8 *)(B.desc + (size_t)fb * capB * 32);   // wave-uniform addresses: s_load_dwordx8
+    u32x8 nxt = dB[0];
+    for (int j = 0; j < nB; j++) {
+        const u32x8 b = nxt;
+        nxt = dB[min(j + 1, nB - 1)];   // the next descriptor is in flight while this one is compared
+        int d = __popc(a0 ^ b[0]);
+        d += __popc(a1 ^ b[1]); d += __popc(a2 ^ b[2]); d += __popc(a3 ^ b[3]);
+        d += __popc(a4 ^ b[4]); d += __popc(a5 ^ b[5]); d += __popc(a6 ^ b[6]); d += __popc(a7 ^ b[7]);
+        const uint32_t key = ((uint32_t)d << 16) | (uint32_t)j;
+        bool ok = key < kk[TOPK - 1];
+        if (FILTER) ok = ok && gB[j] == gA;
+        if (__any(ok)) {
+            if (ok) {   // sorted insert (ascending)
                 kk[TOPK - 1] = key;
 #pragma unroll
                 for (int q = TOPK - 1; q > 0; q--)
-                    if (kk[q] < kk[q - 1]) { uint32_t t = kk[q - 1]; kk[q - 1] = kk[q]; kk[q] = t; }
+                    if (kk[q] < kk[q - 1]) { const uint32_t t = kk[q - 1]; kk[q - 1] = kk[q]; kk[q] = t; }
             }
         }
+    }
+    if (live) {
         uint32_t *out = topk + ((size_t)p * stride + i) * TOPK;
 #pragma unroll
-        for (int k = 0; k < TOPK; k++) {
-            uint32_t m = wave_min_u32(kk[0]);
-            if (kk[0] == m && m != KEY_EMPTY) {   // keys are unique: exactly one lane pops its head
-#pragma unroll
-                for (int q = 0; q < TOPK - 1; q++) kk[q] = kk[q + 1];
-                kk[TOPK - 1] = KEY_EMPTY;
-            }
-            if (lane == 0) out[k] = m;
-        }
+        for (int k = 0; k < TOPK; k++) out[k] = kk[k] >= sentinel ? KEY_EMPTY : kk[k];
     }
 }
 
@@ -633,11 +642,18 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
     hipLaunchKernelGGL(k_bow_order, dim3((unsigned)((a->capacity + 255) / 256), (unsigned)npairs), dim3(256), 0, m->stream, A, m->pairsA.p, m->order.p, stride);
     MLAUNCH_CHECK();
-    const size_t ldsTopk = (size_t)b->capacity * (32 + 4);
-    if (ldsTopk > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", b->capacity); return ORBX_ERR_CAPACITY; }
-    if (ldsTopk > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTopk));
-    hipLaunchKernelGGL(k_bow_topk, dim3((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs), dim3(256), ldsTopk, m->stream, A, B,
-                       m->pairsA.p, m->pairsB.p, params->mode, m->topk.p, stride);
+    // first distance that can neither be accepted as best nor veto an acceptable best in the ratio test
+    // `(float)best < nnratio * (float)second` (src/ORBmatcher.cc:309, 741), see k_bow_topk
+    uint32_t dcut = TH_LOW + 1;
+    while (dcut < 257 && !(params->nn_ratio * (float)dcut > (float)TH_LOW)) dcut++;
+    const bool filter = b->groups != nullptr || (params->mode == 1 && b->valid != nullptr);
+    const size_t ldsTopk = filter ? (size_t)b->capacity * 4 : 0;
+    if (ldsTopk > 64 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", b->capacity); return ORBX_ERR_CAPACITY; }
+    const dim3 gridTopk((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs);
+    if (filter)
+        hipLaunchKernelGGL(k_bow_topk<true>, gridTopk, dim3(256), ldsTopk, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride);
+    else
+        hipLaunchKernelGGL(k_bow_topk<false>, gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride);
     MLAUNCH_CHECK();
     const size_t ldsGreedy = (size_t)((b->capacity + 31) / 32) * 4 + (size_t)stride + 32 + (size_t)(a->capacity + 4) * 4 * (1 + TOPK);
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
