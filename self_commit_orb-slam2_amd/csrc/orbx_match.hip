@@ -70,69 +70,111 @@ __global__ __launch_bounds__(256) void k_bow_order(FeatDev A, const int32_t *__r
 }
 
 // top-TOPK candidates of every A feature by key = dist<<16 | j over the B features of the same
-// node (mode 1: that also carry a valid MapPoint).  LANE = one A feature: its descriptor lives in
-// 8 VGPRs, the B descriptor of iteration j is wave-uniform and comes in through the scalar cache
-// (s_load_dwordx8), so a distance is 8 x (v_xor_b32 + v_bcnt_u32_b32) and nothing else.
+// node (mode 1: that also carry a valid MapPoint).  LANE = TWO A features (descriptors in 16
+// VGPRs); the B descriptors are staged through LDS in tiles of 1024 and read with wave-uniform
+// (broadcast) ds_read_b128, so one LDS fetch feeds 128 distances and a distance is
+// 8 x (v_xor_b32 + v_bcnt_u32_b32) + key + min.
 // Distance cut-off: a candidate at distance d >= dcut can never be accepted as best
 // (d > TH_LOW) and, as second best, can never fail the ratio test of an acceptable best
 // (nnratio * d > TH_LOW >= best, orbx_search_by_bow_device computes dcut in the float arithmetic
 // of the test); dropping it leaves the greedy replay bit-identical and makes list updates rare.
-// The per-lane list starts filled with the sentinel dcut<<16, so "key < kk[TOPK-1]" is the whole test.
-#define TOPK_ROWS 256   /* A features per block: one per lane */
-template <bool FILTER>   // B side has node ids and/or a validity mask (staged in LDS)
+// The per-lane lists start filled with the sentinel dcut<<16, so "key < kk[TOPK-1]" is the whole
+// test, evaluated once per 4 B features on the minimum of the keys.
+#define TOPK_ROWS 512   /* A features per block: two per lane */
+#define TOPK_TILE 1024  /* B features per LDS tile */
+
+__device__ __forceinline__ void topk_insert(uint32_t (&kk)[TOPK], uint32_t key)
+{
+    kk[TOPK - 1] = key;
+#pragma unroll
+    for (int q = TOPK - 1; q > 0; q--)
+        if (kk[q] < kk[q - 1]) { const uint32_t t = kk[q - 1]; kk[q - 1] = kk[q]; kk[q] = t; }
+}
+
+template <bool FILTER>   // B side has node ids and/or a validity mask
 __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
                                                   uint32_t dcut, uint32_t *__restrict__ topk, int stride)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint4 sB[TOPK_TILE * 2];     // 32-byte descriptors
+    __shared__ int32_t sG[TOPK_TILE];       // node id, 0x80000000 = excluded (FILTER only)
     const int p = blockIdx.y, fa = pairsA[p], fb = pairsB[p];
     const int nA = min(A.counts[fa], A.cap), nB = min(B.counts[fb], B.cap);
     const int capB = B.cap;
     const int row0 = blockIdx.x * TOPK_ROWS;
     if (row0 >= nA) return;
-    int32_t *gB = (int32_t *)smem;   // [capB] node id, 0x80000000 = excluded (FILTER only)
-    if (FILTER) {
-        for (int j = threadIdx.x; j < nB; j += 256) {
-            int gq = B.groups ? B.groups[(size_t)fb * capB + j] : 0;
-            if (mode == 1 && B.valid && !B.valid[(size_t)fb * capB + j]) gq = (int)0x80000000;
-            gB[j] = gq;
-        }
-        __syncthreads();
-    }
-    if (row0 + (int)(threadIdx.x & ~63u) >= nA) return;   // whole wave beyond the last A feature
-    const int i = row0 + threadIdx.x;
-    const bool live = i < nA;
-    const uint32_t *da = (const uint32_t *)(A.desc + ((size_t)fa * A.cap + (live ? i : nA - 1)) * 32);
-    const uint32_t a0 = da[0], a1 = da[1], a2 = da[2], a3 = da[3], a4 = da[4], a5 = da[5], a6 = da[6], a7 = da[7];
-    const int gA = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live ? i : nA - 1)] : 0;
+    const int tid = threadIdx.x;
+    const int i0 = row0 + tid, i1 = row0 + 256 + tid;
+    const bool live0 = i0 < nA, live1 = i1 < nA;
+    const uint32_t *da0 = (const uint32_t *)(A.desc + ((size_t)fa * A.cap + (live0 ? i0 : nA - 1)) * 32);
+    const uint32_t *da1 = (const uint32_t *)(A.desc + ((size_t)fa * A.cap + (live1 ? i1 : nA - 1)) * 32);
+    uint32_t a[8], c[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) { a[w] = da0[w]; c[w] = da1[w]; }
+    const int gA0 = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live0 ? i0 : nA - 1)] : 0;
+    const int gA1 = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live1 ? i1 : nA - 1)] : 0;
     const uint32_t sentinel = dcut << 16;
-    uint32_t kk[TOPK];
+    uint32_t k0[TOPK], k1[TOPK];
 #pragma unroll
-    for (int q = 0; q < TOPK; q++) kk[q] = live ? sentinel : 0u;   // dead lanes never insert
-    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-    const u32x8 *__restrict__ dB = (const u32x8 *)(B.desc + (size_t)fb * capB * 32);   // wave-uniform addresses: s_load_dwordx8
-    u32x8 nxt = dB[0];
-    for (int j = 0; j < nB; j++) {
-        const u32x8 b = nxt;
-        nxt = dB[min(j + 1, nB - 1)];   // the next descriptor is in flight while this one is compared
-        int d = __popc(a0 ^ b[0]);
-        d += __popc(a1 ^ b[1]); d += __popc(a2 ^ b[2]); d += __popc(a3 ^ b[3]);
-        d += __popc(a4 ^ b[4]); d += __popc(a5 ^ b[5]); d += __popc(a6 ^ b[6]); d += __popc(a7 ^ b[7]);
-        const uint32_t key = ((uint32_t)d << 16) | (uint32_t)j;
-        bool ok = key < kk[TOPK - 1];
-        if (FILTER) ok = ok && gB[j] == gA;
-        if (__any(ok)) {
-            if (ok) {   // sorted insert (ascending)
-                kk[TOPK - 1] = key;
+    for (int q = 0; q < TOPK; q++) { k0[q] = live0 ? sentinel : 0u; k1[q] = live1 ? sentinel : 0u; }   // dead rows never insert
+    const uint4 *gD = (const uint4 *)(B.desc + (size_t)fb * capB * 32);
+    for (int t0 = 0; t0 < nB; t0 += TOPK_TILE) {
+        const int nt = min(TOPK_TILE, nB - t0), ntPad = (nt + 3) & ~3;
+        __syncthreads();
+        for (int t = tid; t < 2 * ntPad; t += 256) sB[t] = t < 2 * nt ? gD[2 * (size_t)t0 + t] : make_uint4(0u, 0u, 0u, 0u);
+        if (FILTER)
+            for (int j = tid; j < ntPad; j += 256) {
+                int gq = (int)0x80000000;
+                if (j < nt) {
+                    gq = B.groups ? B.groups[(size_t)fb * capB + t0 + j] : 0;
+                    if (mode == 1 && B.valid && !B.valid[(size_t)fb * capB + t0 + j]) gq = (int)0x80000000;
+                }
+                sG[j] = gq;
+            }
+        __syncthreads();
+        for (int j0 = 0; j0 < ntPad; j0 += 4) {
+            uint32_t key0[4], key1[4], m0 = 0xffffffffu, m1 = 0xffffffffu;
 #pragma unroll
-                for (int q = TOPK - 1; q > 0; q--)
-                    if (kk[q] < kk[q - 1]) { const uint32_t t = kk[q - 1]; kk[q - 1] = kk[q]; kk[q] = t; }
+            for (int u = 0; u < 4; u++) {
+                const uint4 lo = sB[2 * (j0 + u)], hi = sB[2 * (j0 + u) + 1];   // wave-uniform address: LDS broadcast
+                int d0 = __popc(a[0] ^ lo.x), d1 = __popc(c[0] ^ lo.x);
+                d0 += __popc(a[1] ^ lo.y); d1 += __popc(c[1] ^ lo.y);
+                d0 += __popc(a[2] ^ lo.z); d1 += __popc(c[2] ^ lo.z);
+                d0 += __popc(a[3] ^ lo.w); d1 += __popc(c[3] ^ lo.w);
+                d0 += __popc(a[4] ^ hi.x); d1 += __popc(c[4] ^ hi.x);
+                d0 += __popc(a[5] ^ hi.y); d1 += __popc(c[5] ^ hi.y);
+                d0 += __popc(a[6] ^ hi.z); d1 += __popc(c[6] ^ hi.z);
+                d0 += __popc(a[7] ^ hi.w); d1 += __popc(c[7] ^ hi.w);
+                const uint32_t j = (uint32_t)(t0 + j0 + u);
+                uint32_t ka = ((uint32_t)d0 << 16) | j, kb = ((uint32_t)d1 << 16) | j;
+                if (FILTER) {
+                    const int gq = sG[j0 + u];
+                    ka = gq == gA0 ? ka : 0xffffffffu;
+                    kb = gq == gA1 ? kb : 0xffffffffu;
+                } else if (j0 + u >= nt) { ka = 0xffffffffu; kb = 0xffffffffu; }   // wave-uniform (zero padding of the tile)
+                key0[u] = ka; key1[u] = kb;
+                m0 = min(m0, ka); m1 = min(m1, kb);
+            }
+            if (__any(m0 < k0[TOPK - 1] || m1 < k1[TOPK - 1])) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool ok0 = key0[u] < k0[TOPK - 1], ok1 = key1[u] < k1[TOPK - 1];
+                    if (__any(ok0 || ok1)) {
+                        if (ok0) topk_insert(k0, key0[u]);
+                        if (ok1) topk_insert(k1, key1[u]);
+                    }
+                }
             }
         }
     }
-    if (live) {
-        uint32_t *out = topk + ((size_t)p * stride + i) * TOPK;
+    if (live0) {
+        uint32_t *out = topk + ((size_t)p * stride + i0) * TOPK;
 #pragma unroll
-        for (int k = 0; k < TOPK; k++) out[k] = kk[k] >= sentinel ? KEY_EMPTY : kk[k];
+        for (int k = 0; k < TOPK; k++) out[k] = k0[k] >= sentinel ? KEY_EMPTY : k0[k];
+    }
+    if (live1) {
+        uint32_t *out = topk + ((size_t)p * stride + i1) * TOPK;
+#pragma unroll
+        for (int k = 0; k < TOPK; k++) out[k] = k1[k] >= sentinel ? KEY_EMPTY : k1[k];
     }
 }
 
@@ -647,11 +689,9 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     uint32_t dcut = TH_LOW + 1;
     while (dcut < 257 && !(params->nn_ratio * (float)dcut > (float)TH_LOW)) dcut++;
     const bool filter = b->groups != nullptr || (params->mode == 1 && b->valid != nullptr);
-    const size_t ldsTopk = filter ? (size_t)b->capacity * 4 : 0;
-    if (ldsTopk > 64 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", b->capacity); return ORBX_ERR_CAPACITY; }
     const dim3 gridTopk((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs);
     if (filter)
-        hipLaunchKernelGGL(k_bow_topk<true>, gridTopk, dim3(256), ldsTopk, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride);
+        hipLaunchKernelGGL(k_bow_topk<true>, gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride);
     else
         hipLaunchKernelGGL(k_bow_topk<false>, gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride);
     MLAUNCH_CHECK();
