@@ -775,14 +775,20 @@ __global__ __launch_bounds__(256) void k_orient(const OrbxGeom *__restrict__ g, 
 // ------------------------------------------------------------------------------------
 // 7x7 Gaussian, sigma 2, BORDER_REFLECT_101, u8 fixed point (cv::GaussianBlur on the
 // cloned level, src/ORBextractor.cc:1626-1634): horizontal pass exact in 16 bits,
-// vertical in 32, (sum + 2^15) >> 16.  64x32 output tile per workgroup: the 70x38 input
-// window is staged with aligned dword row loads, every thread produces 4 adjacent pixels per
-// pass (3 LDS dwords in, 2 out / 8 LDS qwords in, one coalesced dword store out).
-// Algorithmic traffic 2 bytes/pixel; the halo makes the read side 1.34x.
+// vertical in 32, (sum + 2^15) >> 16.
+// ONE WAVE per 64x32 output tile.  The 80-byte x 38-row input window is staged in LDS with
+// 16-byte loads; lane = (4-column group, 8-row group) then runs BOTH passes in registers:
+//   horizontal, 14 rows x 4 px: taps 0..3 . bytes + taps 4..6 . bytes = two v_dot4_u32_u8 on byte
+//     windows cut out with v_alignbyte_b32;
+//   vertical, 8 rows x 4 px: vertically adjacent 16-bit sums of a column paired by one
+//     v_perm_b32, four v_dot2_u32_u16 per output, the +2^15 rounding rides in the accumulator.
+// Taps are <= 255 and sum to <= 257 (checked at handle creation): the 16-bit sums cannot saturate.
+// ~19 VALU lane-instructions per pixel; algorithmic traffic 2 bytes/pixel, the halo makes the
+// read side 1.48x.
 // ------------------------------------------------------------------------------------
 #define BT_W 64
 #define BT_H 32
-#define BT_IW 18   /* input row: dwords covering X0-4 .. X0+67 */
+#define BT_P 80                 /* LDS row pitch in bytes: x = X0-8 .. X0+71 */
 #define BT_IH (BT_H + 6)
 
 __device__ __forceinline__ int reflect101(int p, int len)
@@ -792,12 +798,11 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_blur(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
-                                              const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur)
+__global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                             const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur)
 {
-    __shared__ uint32_t in[BT_IH * BT_IW];
-    __shared__ uint32_t hz[BT_IH * (BT_W / 2)];   // u16 pairs
-    const int f = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) uint32_t in[BT_IH * (BT_P / 4)];
+    const int f = blockIdx.y, lane = threadIdx.x;
     int bases[ORBX_MAX_LEVELS];
     const int nl = g->nlevels;
     for (int i = 0; i < nl; i++) bases[i] = g->lv[i].blurTileBase;
@@ -808,76 +813,75 @@ __global__ __launch_bounds__(256) void k_blur(const OrbxGeom *__restrict__ g, co
     const int w = lv.w, h = lv.h;
     int pitch;
     const uint8_t *src = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
-    for (int i = threadIdx.x; i < BT_IH * BT_IW; i += 256) {
-        const int r = i / BT_IW, c = i % BT_IW;
-        int y = reflect101(Y0 - 3 + r, h);
-        y = min(max(y, 0), h - 1);
-        const int x = X0 - 4 + 4 * c;
-        const uint8_t *row = src + (size_t)y * pitch;
-        uint32_t v;
-        if (x >= 0 && x + 3 < w) v = *(const uint32_t *)(row + x);
-        else {
-            v = 0;
+    // ---- stage: item = (row r, 16-byte chunk c); interior chunks are one 16-byte load ----
 #pragma unroll
-            for (int k = 0; k < 4; k++) { int xx = reflect101(x + k, w); xx = min(max(xx, 0), w - 1); v |= (uint32_t)row[xx] << (8 * k); }
+    for (int it = 0; it < 3; it++) {
+        const int item = lane + 64 * it;
+        if (item < BT_IH * 5) {
+            const int r = (item * 205) >> 10, c = item - 5 * r;   // item / 5 (exact for item < 1024)
+            int y = reflect101(Y0 - 3 + r, h);
+            y = min(max(y, 0), h - 1);
+            const int x = X0 - 8 + 16 * c;
+            const uint8_t *row = src + (size_t)y * pitch;
+            uint4 v;
+            if (x >= 0 && x + 15 < w) __builtin_memcpy(&v, row + x, 16);
+            else {
+                uint32_t q[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    q[d] = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { int xx = reflect101(x + 4 * d + k, w); xx = min(max(xx, 0), w - 1); q[d] |= (uint32_t)row[xx] << (8 * k); }
+                }
+                v = make_uint4(q[0], q[1], q[2], q[3]);
+            }
+            *(uint4 *)(in + r * (BT_P / 4) + 4 * c) = v;
         }
-        in[i] = v;
     }
     __syncthreads();
     const uint32_t k0 = g->taps[0], k1 = g->taps[1], k2 = g->taps[2], k3 = g->taps[3], k4 = g->taps[4], k5 = g->taps[5], k6 = g->taps[6];
-    // horizontal: item (row r, group gq of 4 pixels) reads bytes 4gq+1 .. 4gq+10 of the row.  Pixel j =
-    // taps 0..3 . bytes (1+j .. 4+j)  +  taps 4..6 . bytes (5+j .. 7+j): two v_dot4_u32_u8 on byte
-    // windows cut out with v_alignbyte_b32.  Taps are <= 255 and sum to <= 257 (checked when the handle
-    // is created), so the 16-bit horizontal sums cannot saturate.
-    {
-        const uint32_t TL = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), TH = k4 | (k5 << 8) | (k6 << 16);
-        for (int i = threadIdx.x; i < BT_IH * (BT_W / 4); i += 256) {
-            const int r = i >> 4, gq = i & 15;
-            const uint32_t *pw = in + r * BT_IW + gq;
-            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
-            const uint32_t o0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), TL, 0u, false), false);
-            const uint32_t o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), TL, 0u, false), false);
-            const uint32_t o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), TL, 0u, false), false);
-            const uint32_t o3 = __builtin_amdgcn_udot4(w2, TH, __builtin_amdgcn_udot4(w1, TL, 0u, false), false);
-            hz[r * (BT_W / 2) + 2 * gq] = o0 | (o1 << 16);
-            hz[r * (BT_W / 2) + 2 * gq + 1] = o2 | (o3 << 16);
-        }
-    }
-    __syncthreads();
-    // vertical: thread -> 4 adjacent columns x 2 rows.  Vertically adjacent 16-bit sums of one column
-    // are paired with one v_perm_b32, then 4 v_dot2_u32_u16 per output ((k0,k1) (k2,k3) (k4,k5) (k6,0)),
-    // the +2^15 rounding rides in the accumulator input.
-    const int gq = threadIdx.x & 15, rr = (threadIdx.x >> 4) * 2;
+    const int gq = lane & 15, rg = lane >> 4;
     const int x = X0 + 4 * gq;
-    if (x >= w) return;
-    uint32_t c0[8], c1[8];
+    if (x >= w || Y0 + 8 * rg >= h) return;
+    // ---- horizontal: rows 8rg .. 8rg+13 of the window; pixel j of the group = bytes 1+j .. 7+j of (w0,w1,w2) ----
+    const uint32_t TL = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), TH = k4 | (k5 << 8) | (k6 << 16);
+    uint32_t c0[14], c1[14];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { c0[k] = hz[(rr + k) * (BT_W / 2) + 2 * gq]; c1[k] = hz[(rr + k) * (BT_W / 2) + 2 * gq + 1]; }
+    for (int r = 0; r < 14; r++) {
+        const uint32_t *pw = in + (8 * rg + r) * (BT_P / 4) + gq + 1;
+        const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+        const uint32_t o0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), TL, 0u, false), false);
+        const uint32_t o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), TL, 0u, false), false);
+        const uint32_t o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), TL, 0u, false), false);
+        const uint32_t o3 = __builtin_amdgcn_udot4(w2, TH, __builtin_amdgcn_udot4(w1, TL, 0u, false), false);
+        c0[r] = o0 | (o1 << 16);
+        c1[r] = o2 | (o3 << 16);
+    }
+    // ---- vertical ----
     const uint32_t V01 = k0 | (k1 << 16), V23 = k2 | (k3 << 16), V45 = k4 | (k5 << 16), V6 = k6;
-    uint32_t res[2][4];
+    uint32_t outw[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) outw[q] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t selp = (j & 1) ? 0x07060302u : 0x05040100u;   // (h[r], h[r+1]) of column j as a u16 pair
-        uint32_t P[8];
+        uint32_t P[14];
 #pragma unroll
-        for (int k = 0; k < 7; k++) P[k] = (j < 2) ? __builtin_amdgcn_perm(c0[k + 1], c0[k], selp) : __builtin_amdgcn_perm(c1[k + 1], c1[k], selp);
-        P[7] = (j < 2) ? __builtin_amdgcn_perm(c0[7], c0[7], selp) : __builtin_amdgcn_perm(c1[7], c1[7], selp);
+        for (int k = 0; k < 13; k++) P[k] = (j < 2) ? __builtin_amdgcn_perm(c0[k + 1], c0[k], selp) : __builtin_amdgcn_perm(c1[k + 1], c1[k], selp);
+        P[13] = (j < 2) ? __builtin_amdgcn_perm(c0[13], c0[13], selp) : __builtin_amdgcn_perm(c1[13], c1[13], selp);
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < 8; q++) {
             const uint32_t sum = udot2(P[q + 6], V6, udot2(P[q + 4], V45, udot2(P[q + 2], V23, udot2(P[q], V01, 32768u))));
-            const uint32_t v = sum >> 16;
-            res[q][j] = v > 255u ? 255u : v;
+            const uint32_t v = min(sum >> 16, 255u);
+            outw[q] |= v << (8 * j);
         }
     }
     uint8_t *dst = blur + (size_t)f * g->pyrBytes + lv.off;
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int y = Y0 + rr + q;
+    for (int q = 0; q < 8; q++) {
+        const int y = Y0 + 8 * rg + q;
         if (y >= h) break;
-        const uint32_t outw = res[q][0] | (res[q][1] << 8) | (res[q][2] << 16) | (res[q][3] << 24);
-        uint8_t *o = dst + (size_t)y * lv.pitch + x;
-        if (x + 3 < lv.pitch) *(uint32_t *)o = outw;       // pitch is a multiple of 64: bytes beyond w are padding
-        else for (int j = 0; j < 4 && x + j < w; j++) o[j] = (uint8_t)(outw >> (8 * j));
+        *(uint32_t *)(dst + (size_t)y * lv.pitch + x) = outw[q];   // pitch >= round_up(w,4): bytes beyond w are padding
     }
 }
 
@@ -1037,7 +1041,7 @@ int orbx_launch_orient(const OrbxLaunch &L)
 int orbx_launch_blur(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->blurTiles, (unsigned)L.batch);
-    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur);
+    hipLaunchKernelGGL(k_blur, grid, dim3(64), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur);
     LAUNCH_CHECK();
     return ORBX_OK;
 }
