@@ -178,100 +178,120 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
     }
 }
 
-// greedy replay + rotation histogram + three-maxima pruning; one wave per pair.
-__global__ __launch_bounds__(64) void k_bow_greedy(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
-                                                   float nnratio, int checkOri, const uint32_t *__restrict__ topk, const int32_t *__restrict__ order,
-                                                   int32_t *__restrict__ matches, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride)
+// greedy replay + rotation histogram + three-maxima pruning; one workgroup per pair.  All four
+// waves stage the processing order and the candidate lists into LDS, then wave 0 alone replays
+// the reference's sequential pass (nothing in that loop waits on global memory: accepted matches
+// are recorded in LDS), and the rotation histogram (keypoint angles from HBM) is built in
+// parallel afterwards.
+__global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
+                                                    float nnratio, int checkOri, const uint32_t *__restrict__ topk, const int32_t *__restrict__ order,
+                                                    int32_t *__restrict__ matches, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int hist[HISTO_LENGTH];
-    const int p = blockIdx.x, lane = threadIdx.x, fa = pairsA[p], fb = pairsB[p];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, fa = pairsA[p], fb = pairsB[p];
     const int nA = min(A.counts[fa], A.cap), nB = min(B.counts[fb], B.cap);
-    uint32_t *taken = (uint32_t *)smem;                                  // bitmap over B features
-    unsigned char *binOf = (unsigned char *)(taken + ((B.cap + 31) >> 5));   // per output slot
+    // LDS: B bitmap | candidate lists | results per output slot | processing order (u16, 0xffff = no valid MapPoint)
+    uint32_t *taken = (uint32_t *)smem;
+    uint32_t *sTk = (uint32_t *)(smem + (((((B.cap + 31) >> 5) * 4) + 15) & ~15));
+    uint32_t *sRes = sTk + (size_t)A.cap * TOPK;                            // 0 = unmatched, else (dist << 16 | partner) + 1, later | rotation bin << 26
+    unsigned short *sOrd = (unsigned short *)(sRes + stride);
     const int nOut = mode == 0 ? nB : nA;
     int32_t *mout = matches + (size_t)p * stride, *dout = dists + (size_t)p * stride;
-    for (int i = lane; i < stride; i += 64) { mout[i] = -1; dout[i] = 256; }
-    for (int i = lane; i < ((B.cap + 31) >> 5); i += 64) taken[i] = 0;
-    if (lane < HISTO_LENGTH) hist[lane] = 0;
-    // the sequential replay must not wait on HBM/L2: processing order (bit 31 = feature without
-    // a valid MapPoint) and the four candidates of every KeyFrame feature are staged in LDS
-    int32_t *sOrd = (int32_t *)(smem + ((((B.cap + 31) >> 5) * 4 + stride + 15) & ~15));
-    uint32_t *sTk = (uint32_t *)(sOrd + ((A.cap + 3) & ~3));
+    for (int i = tid; i < stride; i += 256) sRes[i] = 0;
+    for (int i = tid; i < ((B.cap + 31) >> 5); i += 256) taken[i] = 0;
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
     {
         const int32_t *ord = order + (size_t)p * stride;
-        const uint32_t *tk = topk + (size_t)p * stride * TOPK;
-        for (int r = lane; r < nA; r += 64) {
+        const uint4 *tk = (const uint4 *)(topk + (size_t)p * stride * TOPK);
+        for (int r = tid; r < nA; r += 256) {
             int i = ord[r];
-            if (A.valid && !A.valid[(size_t)fa * A.cap + i]) i |= (int)0x80000000;
-            sOrd[r] = i;
+            if (A.valid && !A.valid[(size_t)fa * A.cap + i]) i = 0xffff;
+            sOrd[r] = (unsigned short)i;
         }
-        for (int t = lane; t < nA * TOPK; t += 64) sTk[t] = tk[t];
+        for (int t = tid; t < nA * (TOPK / 4); t += 256) ((uint4 *)sTk)[t] = tk[t];
     }
     __syncthreads();
-    const orbx_keypoint *kA = A.kp + (size_t)fa * A.cap, *kB = B.kp + (size_t)fb * B.cap;
-    const float factor = HISTO_LENGTH / 360.0f;
     int total = 0;
-    for (int r = 0; r < nA; r++) {
-        const int i = sOrd[r];
-        if (i < 0) continue;
-        uint32_t key = lane < TOPK ? sTk[i * TOPK + lane] : KEY_EMPTY;
-        const bool present = key != KEY_EMPTY;
-        const int j = (int)(key & 0xffff);
-        const bool free_ = present && !((taken[j >> 5] >> (j & 31)) & 1u);
-        const unsigned mAll = (1u << TOPK) - 1u;
-        const unsigned mPresent = (unsigned)(__ballot(present) & mAll), mFree = (unsigned)(__ballot(free_) & mAll);
-        uint32_t bestKey = KEY_EMPTY;
-        int best2 = 256;
-        if (__popc(mFree) >= 2 || mPresent != mAll) {
-            if (mFree) {
-                const int la = __ffs(mFree) - 1;
-                bestKey = __shfl(key, la);
-                const unsigned rest = mFree & (mFree - 1);
-                if (rest) best2 = (int)(__shfl(key, __ffs(rest) - 1) >> 16);
-            }
-        } else {
-            // exact rescan over the free B features of this node
-            const unsigned long long *da = (const unsigned long long *)(A.desc + ((size_t)fa * A.cap + i) * 32);
-            unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
-            const int gA = A.groups ? A.groups[(size_t)fa * A.cap + i] : 0;
-            uint32_t k0 = KEY_EMPTY, k1 = KEY_EMPTY;
-            for (int jj = lane; jj < nB; jj += 64) {
-                if ((taken[jj >> 5] >> (jj & 31)) & 1u) continue;
-                if (B.groups && B.groups[(size_t)fb * B.cap + jj] != gA) continue;
-                if (mode == 1 && B.valid && !B.valid[(size_t)fb * B.cap + jj]) continue;
-                const unsigned long long *db = (const unsigned long long *)(B.desc + ((size_t)fb * B.cap + jj) * 32);
-                int d = hamming256(a, db[0], db[1], db[2], db[3]);
-                uint32_t kk = ((uint32_t)d << 16) | (uint32_t)jj;
-                if (kk < k0) { k1 = k0; k0 = kk; } else if (kk < k1) k1 = kk;
-            }
-            bestKey = wave_min_u32(k0);
-            if (k0 == bestKey) k0 = k1;
-            uint32_t second = wave_min_u32(k0);
-            if (second != KEY_EMPTY) best2 = (int)(second >> 16);
-        }
-        if (bestKey == KEY_EMPTY) continue;
-        const int best1 = (int)(bestKey >> 16), bj = (int)(bestKey & 0xffff);
-        const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);
-        if (pass && (float)best1 < nnratio * (float)best2) {
-            if (lane == 0) {
-                taken[bj >> 5] |= 1u << (bj & 31);
-                const int slot = mode == 0 ? bj : i;
-                mout[slot] = mode == 0 ? i : bj;
-                dout[slot] = best1;
-                if (checkOri) {
-                    float rot = kA[i].angle - kB[bj].angle;
-                    if (rot < 0.0f) rot += 360.0f;
-                    int bin = (int)roundf(rot * factor);
-                    if (bin == HISTO_LENGTH) bin = 0;
-                    binOf[slot] = (unsigned char)bin;
-                    hist[bin]++;
+    if (tid < 64) {
+        for (int r = 0; r < nA; r++) {
+            const int i = sOrd[r];
+            if (i == 0xffff) continue;
+            uint32_t key = lane < TOPK ? sTk[i * TOPK + lane] : KEY_EMPTY;
+            const bool present = key != KEY_EMPTY;
+            const int j = (int)(key & 0xffff);
+            const bool free_ = present && !((taken[j >> 5] >> (j & 31)) & 1u);
+            const unsigned mAll = (1u << TOPK) - 1u;
+            const unsigned mPresent = (unsigned)(__ballot(present) & mAll), mFree = (unsigned)(__ballot(free_) & mAll);
+            uint32_t bestKey = KEY_EMPTY;
+            int best2 = 256;
+            if (__popc(mFree) >= 2 || mPresent != mAll) {
+                if (mFree) {
+                    const int la = __ffs(mFree) - 1;
+                    bestKey = __shfl(key, la);
+                    const unsigned rest = mFree & (mFree - 1);
+                    if (rest) best2 = (int)(__shfl(key, __ffs(rest) - 1) >> 16);
                 }
+            } else {
+                // exact rescan over the free B features of this node
+                const unsigned long long *da = (const unsigned long long *)(A.desc + ((size_t)fa * A.cap + i) * 32);
+                unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
+                const int gA = A.groups ? A.groups[(size_t)fa * A.cap + i] : 0;
+                uint32_t k0 = KEY_EMPTY, k1 = KEY_EMPTY;
+                for (int jj = lane; jj < nB; jj += 64) {
+                    if ((taken[jj >> 5] >> (jj & 31)) & 1u) continue;
+                    if (B.groups && B.groups[(size_t)fb * B.cap + jj] != gA) continue;
+                    if (mode == 1 && B.valid && !B.valid[(size_t)fb * B.cap + jj]) continue;
+                    const unsigned long long *db = (const unsigned long long *)(B.desc + ((size_t)fb * B.cap + jj) * 32);
+                    int d = hamming256(a, db[0], db[1], db[2], db[3]);
+                    uint32_t kk = ((uint32_t)d << 16) | (uint32_t)jj;
+                    if (kk < k0) { k1 = k0; k0 = kk; } else if (kk < k1) k1 = kk;
+                }
+                bestKey = wave_min_u32(k0);
+                if (k0 == bestKey) k0 = k1;
+                uint32_t second = wave_min_u32(k0);
+                if (second != KEY_EMPTY) best2 = (int)(second >> 16);
             }
-            total++;
-            __syncthreads();   // single-wave block: orders the LDS bitmap update before the next read
+            if (bestKey == KEY_EMPTY) continue;
+            const int best1 = (int)(bestKey >> 16), bj = (int)(bestKey & 0xffff);
+            const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);
+            if (pass && (float)best1 < nnratio * (float)best2) {
+                if (lane == 0) {
+                    taken[bj >> 5] |= 1u << (bj & 31);
+                    const int slot = mode == 0 ? bj : i;
+                    sRes[slot] = (((uint32_t)best1 << 16) | (uint32_t)(mode == 0 ? i : bj)) + 1u;
+                }
+                total++;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the bitmap update is read by every lane in the next step
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
+    __syncthreads();
+    // ---- results + rotation histogram (src/ORBmatcher.cc:318-332, 750-758), all 256 threads ----
+    const orbx_keypoint *kA = A.kp + (size_t)fa * A.cap, *kB = B.kp + (size_t)fb * B.cap;
+    const float factor = HISTO_LENGTH / 360.0f;
+    for (int s = tid; s < stride; s += 256) {
+        const uint32_t rv = s < nOut ? sRes[s] : 0u;
+        int mval = -1, dval = 256;
+        if (rv) {
+            const uint32_t v = rv - 1u;
+            mval = (int)(v & 0xffff); dval = (int)(v >> 16);
+            if (checkOri) {
+                const int i = mode == 0 ? mval : s, bj = mode == 0 ? s : mval;
+                float rot = kA[i].angle - kB[bj].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                sRes[s] = rv | ((uint32_t)bin << 26);
+                atomicAdd(&hist[bin], 1);
+            }
+        }
+        mout[s] = mval; dout[s] = dval;
+    }
+    __syncthreads();
+    __shared__ int sRemoved;
+    if (tid == 0) sRemoved = 0;
     __syncthreads();
     if (checkOri) {
         // ComputeThreeMaxima, src/ORBmatcher.cc:1866-1908
@@ -285,16 +305,17 @@ __global__ __launch_bounds__(64) void k_bow_greedy(FeatDev A, FeatDev B, const i
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         int removed = 0;
-        for (int s = lane; s < nOut; s += 64) {
-            if (mout[s] < 0) continue;
-            const int b = binOf[s];
+        for (int s = tid; s < nOut; s += 256) {
+            if (!sRes[s]) continue;
+            const int b = (int)(sRes[s] >> 26);
             if (b != ind1 && b != ind2 && b != ind3) { mout[s] = -1; dout[s] = 256; removed++; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
-        total -= removed;
+        if (lane == 0 && removed) atomicAdd(&sRemoved, removed);
     }
-    if (lane == 0) nmatches[p] = total;
+    __syncthreads();
+    if (tid == 0) nmatches[p] = total - sRemoved;
 }
 
 // Hamming stage of Frame::ComputeStereoMatches: one wave per left keypoint, lanes over the
@@ -695,10 +716,10 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     else
         hipLaunchKernelGGL(k_bow_topk<false>, gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride);
     MLAUNCH_CHECK();
-    const size_t ldsGreedy = (size_t)((b->capacity + 31) / 32) * 4 + (size_t)stride + 32 + (size_t)(a->capacity + 4) * 4 * (1 + TOPK);
+    const size_t ldsGreedy = (size_t)((b->capacity + 31) / 32) * 4 + 32 + (size_t)a->capacity * 4 * TOPK + (size_t)stride * 4 + (size_t)(a->capacity + 8) * 2;
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
     if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
-    hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(64), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, params->nn_ratio,
+    hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(256), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, params->nn_ratio,
                        params->check_orientation, m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride);
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
