@@ -58,6 +58,32 @@ def algorithmic_bytes(W, H, K, nlevels=8):
     }
 
 
+# stage of the HIP-event timing -> kernel name in the rocprofv3 summaries under profiles/
+STAGE_KERNEL = {"pyramid": "k_resize (7 launches)", "fast_cells": "k_fast_cells", "octree": "k_octree", "orient": "k_orient", "blur": "k_blur",
+                "describe": "k_describe", "match_distances": "k_bow_topk", "match_replay": "k_bow_greedy"}
+
+
+def pmc_traffic(stage, frames_per_launch):
+    """HBM bytes per launch of the stage's kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE,
+    separate rocprofv3 --pmc runs of this same command, tools/run_profiles.sh + tools/summarize_profile.py,
+    FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).  None when no pass is committed for
+    this launch size."""
+    p = ROOT / "profiles" / "latest_hbm_traffic.json"
+    if not p.exists():
+        return None
+    try:
+        t = json.loads(p.read_text())
+    except ValueError:
+        return None
+    if t.get("_frames_per_launch") != frames_per_launch:
+        return None
+    name = STAGE_KERNEL.get(stage, "").split(" ")[0]
+    for k, v in t.items():
+        if isinstance(v, dict) and k.split("<")[0] == name:
+            return int(v["hbm_bytes_per_launch"] * (7 if stage == "pyramid" else 1))
+    return None
+
+
 def cpu_baseline(orbx, W, H, nf, seconds_budget=12.0):
     """Reference ORBextractor (oracle/_ref = unmodified source + cvshim) + restated matcher on
     the host cores of this box, one extractor instance per thread (instances are not
@@ -75,7 +101,7 @@ def cpu_baseline(orbx, W, H, nf, seconds_budget=12.0):
     t0 = time.perf_counter()
     ext0.extract(frames[0])
     one = time.perf_counter() - t0
-    per_thread = int(max(2, min(40, seconds_budget / max(one * 1.3, 1e-3))))
+    per_thread = int(max(2, min(200, seconds_budget / max(one * 1.3, 1e-3))))
     frames = orbx.synth_sequence(9000, per_thread + 1, W, H)
     done = [0] * nthreads
 
@@ -190,6 +216,7 @@ def main():
             stage_ms[k] = stage_ms.get(k, 0.0) + v / NS
         e.set_profiling(False)
     match_ms = float(np.mean([m.last_timing() for m in mts])) if mt is not None else 0.0
+    match_split = np.mean([m.last_kernel_timing() for m in mts], axis=0) if mt is not None else (0.0, 0.0)
     counts = np.concatenate([e.download(Bs)[2] for e in exts])
     nm_mean = 0.0
     if mt is not None:
@@ -200,12 +227,15 @@ def main():
         K = float(counts.mean())
         alg = algorithmic_bytes(W, H, K)
         if mt is not None:
-            stage_ms["match"] = match_ms
+            stage_ms["match_distances"] = float(match_split[0])   # k_bow_order + k_bow_topk
+            stage_ms["match_replay"] = float(match_split[1])      # k_bow_greedy (sequential greedy assignment, latency bound)
+            alg["match_distances"] = alg.pop("match")
+            alg["match_replay"] = 8 * int(K)                      # reads the candidate lists' heads, writes one result per query
         dom = max((k for k in stage_ms if alg.get(k, 0) > 0), key=lambda k: stage_ms[k])
         bytes_per_launch = alg[dom] * Bs                      # one launch of a part covers Bs frames
         achieved = bytes_per_launch / (stage_ms[dom] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        roofline = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, Bs),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(stage_ms[dom], 4),
                     "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                     "frames_per_launch": Bs,

@@ -308,6 +308,7 @@ def _bind_matcher(L):
     L.orbx_search_by_bow.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), ctypes.POINTER(BowParams), vp, vp]
     L.orbx_stereo_match.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, ci, ctypes.c_float, vp, vp]
     L.orbx_matcher_last_timing.argtypes = [vp, vp]
+    L.orbx_matcher_last_kernel_timing.argtypes = [vp, vp, vp]
     L._matcher_bound = True
 
 
@@ -437,6 +438,12 @@ class ORBmatcher:
         t = ctypes.c_float()
         _check(self._L.orbx_matcher_last_timing(self._h, ctypes.byref(t)))
         return t.value
+
+    def last_kernel_timing(self):
+        """(distance kernels ms, greedy replay ms) of the SearchByBoW calls averaged by the last last_timing()."""
+        a, b = ctypes.c_float(), ctypes.c_float()
+        _check(self._L.orbx_matcher_last_kernel_timing(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
 
 # =====================================================================================

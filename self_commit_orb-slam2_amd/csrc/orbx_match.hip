@@ -571,6 +571,9 @@ struct orbx_matcher {
     hipEvent_t evDep = nullptr, evDone[2] = {nullptr, nullptr};
     int doneSlot = 0;
     hipEvent_t ev0[MATCH_PROF_RING] = {}, ev1[MATCH_PROF_RING] = {};   // one pair per *_device call (ring)
+    hipEvent_t evMid[MATCH_PROF_RING] = {};                             // SearchByBoW: between the distance kernel and the greedy replay
+    bool midValid[MATCH_PROF_RING] = {};
+    float lastDistanceMs = 0.f, lastReplayMs = 0.f;
     int profCount = 0;
     MBuf<int32_t> pairsA, pairsB, order, matches, dists, nmatches;
     MBuf<uint32_t> topk;
@@ -614,7 +617,7 @@ extern "C" int orbx_matcher_create(int device, int max_features, int max_pairs, 
     (void)hipEventCreateWithFlags(&m->evPyr[1], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&m->evDone[0], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&m->evDone[1], hipEventDisableTiming);
-    for (int r = 0; r < MATCH_PROF_RING; r++) { (void)hipEventCreate(&m->ev0[r]); (void)hipEventCreate(&m->ev1[r]); }
+    for (int r = 0; r < MATCH_PROF_RING; r++) { (void)hipEventCreate(&m->ev0[r]); (void)hipEventCreate(&m->ev1[r]); (void)hipEventCreate(&m->evMid[r]); }
     const size_t S = (size_t)max_features, P = (size_t)max_pairs;
     int rc;
     if ((rc = m->pairsA.ensure(P)) || (rc = m->pairsB.ensure(P)) || (rc = m->order.ensure(P * S)) || (rc = m->matches.ensure(P * S)) ||
@@ -639,7 +642,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     for (int s = 0; s < 2; s++) { m->hk[s].release(); m->hd[s].release(); m->hv[s].release(); m->hc[s].release(); m->hg[s].release(); }
     if (m->evDep) (void)hipEventDestroy(m->evDep);
     for (int i = 0; i < 2; i++) if (m->evDone[i]) (void)hipEventDestroy(m->evDone[i]);
-    for (int r = 0; r < MATCH_PROF_RING; r++) { if (m->ev0[r]) (void)hipEventDestroy(m->ev0[r]); if (m->ev1[r]) (void)hipEventDestroy(m->ev1[r]); }
+    for (int r = 0; r < MATCH_PROF_RING; r++) { if (m->ev0[r]) (void)hipEventDestroy(m->ev0[r]); if (m->ev1[r]) (void)hipEventDestroy(m->ev1[r]); if (m->evMid[r]) (void)hipEventDestroy(m->evMid[r]); }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -716,6 +719,8 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     else
         hipLaunchKernelGGL(k_bow_topk<false>, gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride);
     MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->evMid[slot], m->stream));
+    m->midValid[slot] = true;
     const size_t ldsGreedy = (size_t)((b->capacity + 31) / 32) * 4 + 32 + (size_t)a->capacity * 4 * TOPK + (size_t)stride * 4 + (size_t)(a->capacity + 8) * 2;
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
     if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
@@ -740,6 +745,7 @@ extern "C" int orbx_stereo_match_device(orbx_matcher *m, const orbx_feature_set 
     ORBX_HIP_CHECK(hipMemsetAsync(m->nmatches.p, 0, (size_t)npairs * sizeof(int32_t), m->stream));
     const int slot = m->profCount % MATCH_PROF_RING;
     ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
     hipLaunchKernelGGL(k_stereo, dim3((unsigned)((left->capacity + 3) / 4), (unsigned)npairs), dim3(256), 0, m->stream, to_dev(left), to_dev(right), m->pairsA.p,
                        m->pairsB.p, m->scales.p, max_disparity, m->matches.p, m->dists.p, m->nmatches.p, stride);
     MLAUNCH_CHECK();
@@ -776,6 +782,7 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher *m, orbx_extracto
     PyrDev PR = {vr.img0, vr.img0Stride, vr.img0FramePitch, vr.pyr, vr.pyrBytes, vr.geomDev};
     const int slot = m->profCount % MATCH_PROF_RING;
     ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
     hipLaunchKernelGGL(k_stereo_full, dim3((unsigned)((vl.cap + 3) / 4), (unsigned)npairs), dim3(256), 0, m->stream, to_dev(&fl), to_dev(&fr), PL, PR, m->pairsA.p,
                        m->pairsB.p, m->scales.p, m->scales.p + 64, mbf, mb, m->matches.p, m->dists.p, m->uright.p, m->depth.p, m->sad.p, stride);
     MLAUNCH_CHECK();
@@ -854,14 +861,31 @@ extern "C" int orbx_matcher_last_timing(orbx_matcher *m, float *total_ms)
     ORBX_HIP_CHECK(hipSetDevice(m->device));
     ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
     const int n = m->profCount < MATCH_PROF_RING ? m->profCount : MATCH_PROF_RING;
-    float acc = 0.f;
+    float acc = 0.f, accD = 0.f, accR = 0.f;
+    int nMid = 0;
     for (int r = 0; r < n; r++) {
         float ms = 0.f;
         ORBX_HIP_CHECK(hipEventElapsedTime(&ms, m->ev0[r], m->ev1[r]));
         acc += ms;
+        if (m->midValid[r]) {
+            float a = 0.f, b = 0.f;
+            ORBX_HIP_CHECK(hipEventElapsedTime(&a, m->ev0[r], m->evMid[r]));
+            ORBX_HIP_CHECK(hipEventElapsedTime(&b, m->evMid[r], m->ev1[r]));
+            accD += a; accR += b; nMid++;
+        }
     }
     *total_ms = acc / (float)n;
+    m->lastDistanceMs = nMid ? accD / (float)nMid : 0.f;
+    m->lastReplayMs = nMid ? accR / (float)nMid : 0.f;
     m->profCount = 0;   // the next call starts a new average
+    return ORBX_OK;
+}
+
+extern "C" int orbx_matcher_last_kernel_timing(orbx_matcher *m, float *distance_ms, float *replay_ms)
+{
+    if (!m) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (distance_ms) *distance_ms = m->lastDistanceMs;
+    if (replay_ms) *replay_ms = m->lastReplayMs;
     return ORBX_OK;
 }
 
