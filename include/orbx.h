@@ -180,7 +180,8 @@ typedef struct orbx_feature_set {
     const uint8_t *descriptors;     /* 32 bytes per feature (mDescriptors)                       */
     const int32_t *counts;          /* features per frame (N)                                    */
     const int32_t *groups;          /* DBoW2 node id per feature (FeatureVector, src/Frame.cc:889-892);
-                                       NULL = every feature in one node = brute force            */
+                                       negative = the feature is not filed in the FeatureVector and
+                                       is never matched; NULL = every feature in one node = brute force */
     const uint8_t *valid;           /* 1 = feature has a non-bad MapPoint (src/ORBmatcher.cc:268-274);
                                        NULL = all valid                                          */
     int capacity;
@@ -256,6 +257,37 @@ int orbx_matcher_last_timing(orbx_matcher *m, float *total_ms);
 /* Split of the SearchByBoW calls averaged by the previous orbx_matcher_last_timing: the distance /
  * candidate-list kernels (k_bow_order + k_bow_topk) and the greedy replay (k_bow_greedy). */
 int orbx_matcher_last_kernel_timing(orbx_matcher *m, float *distance_ms, float *replay_ms);
+
+
+/* ------------------------------------------------------------------------------------
+ * Bag of words  ==  DBoW2::TemplatedVocabulary<FORB::TDescriptor,FORB>::transform, the work of
+ * Frame::ComputeBoW / KeyFrame::ComputeBoW (reference src/Frame.cc:880-896,
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1262): per feature the word id, the word
+ * weight and the node `levelsup` levels above the leaf - the FeatureVector key that gates
+ * ORBmatcher::SearchByBoW, directly usable as orbx_feature_set.groups.
+ * ---------------------------------------------------------------------------------- */
+typedef struct orbx_vocabulary orbx_vocabulary;
+
+/* The tree as flat arrays, as ORBVocabulary::loadFromTextFile builds it
+ * (TemplatedVocabulary.h:1338-1420): node 0 = root, parent[i] < i, the children of a node are
+ * its child ids in ascending order, word ids count the leaves in node-id order.
+ * descriptors: 32 bytes per node (root unused), weights: one double per node (leaves: word weight). */
+int orbx_vocabulary_create(int device, int k, int L, int num_nodes, const int32_t *parent, const uint8_t *is_leaf,
+                           const uint8_t *descriptors, const double *weights, orbx_vocabulary **out);
+void orbx_vocabulary_destroy(orbx_vocabulary *v);
+int orbx_vocabulary_words(const orbx_vocabulary *v);
+/* transform() of every feature of the extractor's LAST batch, on the extractor's stream (ordered
+ * behind the extraction and ahead of any consumer that orders itself behind the extractor).
+ * Results stay on the device, laid out like the extractor's results (feature i of frame f at
+ * f*capacity + i): word id, FeatureVector node id (-1 when the word's weight is 0: the reference
+ * does not file such a feature, :1160-1166) and the word weight. */
+int orbx_bow_transform_device(orbx_vocabulary *v, orbx_extractor *ext, int levelsup);
+int orbx_bow_results_device(orbx_vocabulary *v, const int32_t **word_dev, const int32_t **node_dev,
+                            const double **weight_dev, int *capacity);
+int orbx_bow_download(orbx_vocabulary *v, orbx_extractor *ext, int batch, int32_t *word, int32_t *node, double *weight);
+/* Host-array form for n descriptors (upload, run, download). */
+int orbx_bow_transform(orbx_vocabulary *v, const uint8_t *descriptors, int n, int levelsup, int32_t *word,
+                       int32_t *node, double *weight);
 
 
 /* ------------------------------------------------------------------------------------

@@ -64,7 +64,10 @@ typedef std::map<int, std::vector<unsigned> > FeatVec;   // DBoW2::FeatureVector
 FeatVec make_featvec(const int32_t *groups, int n)
 {
     FeatVec fv;
-    for (int i = 0; i < n; i++) fv[groups ? groups[i] : 0].push_back((unsigned)i);   // addFeature keeps ascending order
+    for (int i = 0; i < n; i++) {
+        const int g = groups ? groups[i] : 0;
+        if (g >= 0) fv[g].push_back((unsigned)i);   // addFeature keeps ascending order; negative = not filed (word weight 0)
+    }
     return fv;
 }
 
@@ -255,5 +258,42 @@ MO_API void mo_compute_stereo_matches(const float *kpL, const uint8_t *descL, in
         if (vDistIdx[(size_t)i].first < thDist) break;
         uRight[vDistIdx[(size_t)i].second] = -1;
         depth[vDistIdx[(size_t)i].second] = -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// DBoW2 TemplatedVocabulary::transform on a flat tree (Thirdparty/DBoW2/DBoW2/
+// TemplatedVocabulary.h:1127-1262, FORB::distance FORB.cpp:81-101).  Node 0 is the root;
+// parent[i] < i; the children of a node are its child ids in ascending order (what
+// loadFromTextFile builds, :1378-1420).  From the root: pick the child of minimum Hamming
+// distance, FIRST minimum wins (strict '<', :1219-1229), until a leaf; node_out = the node
+// reached at depth L - levelsup (0 when that is <= 0, unchanged... the reference leaves *nid
+// untouched when the leaf is reached before that depth: the wrapper initialises it to 0).
+// PINNED against the compiled reference (oracle/_ref/liborbslam.so) in tests/test_bow_transform.py.
+// ---------------------------------------------------------------------------------------
+MO_API void mo_voc_transform(int num_nodes, const int32_t *parent, const uint8_t *is_leaf, const uint8_t *node_desc, const double *node_weight,
+                             const int32_t *node_word, int L, const uint8_t *desc, int n, int levelsup, int32_t *word, int32_t *node,
+                             double *weight)
+{
+    std::vector<std::vector<int> > children((size_t)num_nodes);
+    for (int i = 1; i < num_nodes; i++) children[(size_t)parent[i]].push_back(i);
+    const int nid_level = L - levelsup;
+    for (int f = 0; f < n; f++) {
+        const uint8_t *d = desc + 32 * (size_t)f;
+        int final_id = 0, current_level = 0, nid = 0;
+        do {
+            ++current_level;
+            const std::vector<int> &ch = children[(size_t)final_id];
+            final_id = ch[0];
+            int best = descriptor_distance(d, node_desc + 32 * (size_t)final_id);
+            for (size_t c = 1; c < ch.size(); c++) {
+                const int dd = descriptor_distance(d, node_desc + 32 * (size_t)ch[c]);
+                if (dd < best) { best = dd; final_id = ch[c]; }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (!is_leaf[final_id]);
+        word[f] = node_word[final_id];
+        weight[f] = node_weight[final_id];
+        node[f] = nid;
     }
 }

@@ -319,3 +319,53 @@ ORBSLAM_API int orbslam_search_by_bow(int mode, const float *kpsA, const uint8_t
     delete kfB;
     return n;
 }
+
+// ---------------------------------------------------------------------------------------
+// DBoW2 vocabulary: TemplatedVocabulary::loadFromTextFile + transform
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1420, 1127-1262), i.e. what
+// Frame::ComputeBoW runs (src/Frame.cc:880-896: transform(vCurrentDesc, mBowVec, mFeatVec, 4)).
+// ---------------------------------------------------------------------------------------
+namespace {
+// the single-feature transform is protected (TemplatedVocabulary.h:330-340)
+struct VocAccess : public ORBVocabulary {
+    void transform1(const cv::Mat &f, DBoW2::WordId &id, DBoW2::WordValue &w, DBoW2::NodeId *nid, int levelsup) const { transform(f, id, w, nid, levelsup); }
+};
+}  // namespace
+
+ORBSLAM_API void *orbslam_voc_load(const char *path)
+{
+    CallScope scope;
+    VocAccess *v = new VocAccess();
+    if (!v->loadFromTextFile(path)) { delete v; return nullptr; }
+    return v;
+}
+ORBSLAM_API void orbslam_voc_destroy(void *h) { delete (VocAccess *)h; }
+ORBSLAM_API int orbslam_voc_size(void *h) { return (int)((VocAccess *)h)->size(); }
+
+// Per feature: word id, weight and the node id at `levelsup` levels above the leaf (single-feature
+// transform); plus the BowVector (ascending word id) and, per feature, the FeatureVector node it
+// was filed under (-1: not filed, i.e. word weight 0) of the vector form.
+ORBSLAM_API int orbslam_voc_transform(void *h, const uint8_t *desc, int n, int levelsup, int32_t *word, int32_t *node, double *weight,
+                                      int32_t *bow_ids, double *bow_vals, int bow_cap, int32_t *fv_node)
+{
+    CallScope scope;
+    VocAccess *voc = (VocAccess *)h;
+    cv::Mat D(n, 32, CV_8UC1);
+    for (int i = 0; i < n; i++) memcpy(D.ptr(i), desc + 32 * (size_t)i, 32);
+    std::vector<cv::Mat> feats = Converter::toDescriptorVector(D);
+    for (int i = 0; i < n; i++) {
+        DBoW2::WordId wid = 0; DBoW2::WordValue w = 0; DBoW2::NodeId nid = 0;
+        voc->transform1(feats[(size_t)i], wid, w, &nid, levelsup);
+        word[i] = (int32_t)wid; weight[i] = w; node[i] = (int32_t)nid;
+        fv_node[i] = -1;
+    }
+    DBoW2::BowVector bv;
+    DBoW2::FeatureVector fv;
+    voc->transform(feats, bv, fv, levelsup);
+    int nb = 0;
+    for (DBoW2::BowVector::const_iterator it = bv.begin(); it != bv.end(); ++it, ++nb)
+        if (nb < bow_cap) { bow_ids[nb] = (int32_t)it->first; bow_vals[nb] = it->second; }
+    for (DBoW2::FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it)
+        for (size_t k = 0; k < it->second.size(); k++) fv_node[it->second[k]] = (int32_t)it->first;
+    return nb;
+}

@@ -449,6 +449,67 @@ class ORBmatcher:
 # =====================================================================================
 # Optimizer::LocalBundleAdjustment numerical core over the C ABI
 # =====================================================================================
+class Vocabulary:
+    """DBoW2 vocabulary tree on the device: transform() == TemplatedVocabulary::transform
+    (reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1262), i.e. Frame::ComputeBoW."""
+
+    def __init__(self, voc, device=0):
+        self._L = load_library()
+        L = self._L
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        L.orbx_vocabulary_create.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ctypes.POINTER(vp)]
+        L.orbx_vocabulary_destroy.argtypes = [vp]
+        L.orbx_vocabulary_destroy.restype = None
+        L.orbx_vocabulary_words.argtypes = [vp]
+        L.orbx_bow_transform_device.argtypes = [vp, vp, ci]
+        L.orbx_bow_results_device.argtypes = [vp, vp, vp, vp, vp]
+        L.orbx_bow_download.argtypes = [vp, vp, ci, vp, vp, vp]
+        L.orbx_bow_transform.argtypes = [vp, vp, ci, ci, vp, vp, vp]
+        self._h = vp()
+        par = np.ascontiguousarray(voc["parent"], np.int32)
+        leaf = np.ascontiguousarray(voc["is_leaf"], np.uint8)
+        desc = np.ascontiguousarray(voc["desc"], np.uint8)
+        wt = np.ascontiguousarray(voc["weight"], np.float64)
+        _check(L.orbx_vocabulary_create(device, int(voc["k"]), int(voc["L"]), len(par), _ptr(par), _ptr(leaf), _ptr(desc), _ptr(wt), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbx_vocabulary_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return self._L.orbx_vocabulary_words(self._h)
+
+    def transform(self, descriptors, levelsup=4):
+        """(word id, FeatureVector node id or -1, word weight) per descriptor."""
+        d = np.ascontiguousarray(descriptors, np.uint8)
+        n = len(d)
+        w, nd, wt = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+        _check(self._L.orbx_bow_transform(self._h, _ptr(d), n, levelsup, _ptr(w), _ptr(nd), _ptr(wt)))
+        return w[:n], nd[:n], wt[:n]
+
+    def transform_device(self, extractor, levelsup=4):
+        _check(self._L.orbx_bow_transform_device(self._h, extractor._h, levelsup))
+
+    def groups_device(self):
+        """device pointer of the FeatureVector node ids of the last transform_device (orbx_feature_set.groups)."""
+        nd, cap = ctypes.c_void_p(), ctypes.c_int()
+        _check(self._L.orbx_bow_results_device(self._h, None, ctypes.byref(nd), None, ctypes.byref(cap)))
+        return nd, cap.value
+
+    def download(self, extractor, batch):
+        _, cap = self.groups_device()
+        w, nd, wt = np.zeros((batch, cap), np.int32), np.zeros((batch, cap), np.int32), np.zeros((batch, cap), np.float64)
+        _check(self._L.orbx_bow_download(self._h, extractor._h, batch, _ptr(w), _ptr(nd), _ptr(wt)))
+        return w, nd, wt
+
+
 class LbaProblem(ctypes.Structure):
     _fields_ = [("num_keyframes", ctypes.c_int), ("poses", ctypes.c_void_p), ("fixed", ctypes.c_void_p), ("intrinsics", ctypes.c_void_p),
                 ("num_points", ctypes.c_int), ("points", ctypes.c_void_p), ("num_edges", ctypes.c_int), ("edge_point", ctypes.c_void_p),
@@ -478,6 +539,7 @@ def _load_sibling(name):
 
 
 distributed = _load_sibling("distributed")
+voc_synth = _load_sibling("voc_synth")
 
 
 class Optimizer:

@@ -1,0 +1,207 @@
+// orbx_bow.hip -- DBoW2 vocabulary-tree descent on gfx950.
+//
+//   orbx_bow_transform*  ==  DBoW2::TemplatedVocabulary<FORB::TDescriptor,FORB>::transform
+//                            (reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1262),
+//                            the work of Frame::ComputeBoW / KeyFrame::ComputeBoW
+//                            (src/Frame.cc:880-896, src/KeyFrame.cc:80-88).
+//
+// Per feature: from the root pick the child of minimum Hamming distance (FORB::distance,
+// FORB.cpp:81-101; first minimum wins, strict '<' at TemplatedVocabulary.h:1219-1229) until a
+// leaf: word id + weight, and the node passed at depth L - levelsup = the FeatureVector key that
+// gates ORBmatcher::SearchByBoW.  k*L = 60 distances per feature with the stock vocabulary:
+// integer VALU + dependent gathers; the tree (35 MB of descriptors at k=10, L=6) lives in HBM /
+// Infinity Cache with the children of a node stored contiguously.
+// One thread per feature, descriptor in 8 VGPRs.
+#include <string.h>
+
+#include <vector>
+
+#include "orbx_internal.h"
+
+namespace {
+
+struct VocNode { int32_t childStart, childCount, word, pad; };   // word >= 0: leaf
+
+__global__ __launch_bounds__(256) void k_bow_transform(const VocNode *__restrict__ nodes, const int32_t *__restrict__ childList,
+                                                       const uint4 *__restrict__ childDesc, const double *__restrict__ nodeWeight, int nidLevel,
+                                                       const uint8_t *__restrict__ desc, const int32_t *__restrict__ counts, int cap, int32_t *__restrict__ word,
+                                                       int32_t *__restrict__ node, double *__restrict__ weight)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = counts ? min(counts[f], cap) : cap;
+    if (i >= n) return;
+    const uint4 *dp = (const uint4 *)(desc + ((size_t)f * cap + i) * 32);
+    const uint4 a0 = dp[0], a1 = dp[1];
+    int cur = 0, level = 0, nid = 0;
+    VocNode nd = nodes[0];
+    while (nd.word < 0) {
+        ++level;
+        int best = 0x7fffffff, bestPos = nd.childStart;
+        for (int c = 0; c < nd.childCount; c++) {
+            const uint4 b0 = childDesc[2 * (size_t)(nd.childStart + c)], b1 = childDesc[2 * (size_t)(nd.childStart + c) + 1];
+            const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+                          __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+            if (d < best) { best = d; bestPos = nd.childStart + c; }
+        }
+        cur = childList[bestPos];
+        if (level == nidLevel) nid = cur;
+        nd = nodes[cur];
+    }
+    const double w = nodeWeight[cur];
+    const size_t o = (size_t)f * cap + i;
+    word[o] = nd.word;
+    weight[o] = w;
+    node[o] = w > 0 ? nid : -1;   // features whose word has weight 0 are not filed in the FeatureVector (:1160-1166)
+}
+
+template <typename T> struct VBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n) return ORBX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        ORBX_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+        return ORBX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct orbx_vocabulary {
+    int device = 0, k = 0, L = 0, numNodes = 0, numWords = 0;
+    hipStream_t stream = nullptr;   // host-array form only; the device form runs on the extractor's stream
+    VBuf<VocNode> nodes;
+    VBuf<int32_t> childList;
+    VBuf<uint4> childDesc;
+    VBuf<double> nodeWeight;
+    // results, double buffered in lockstep with the extractor's result buffers
+    VBuf<int32_t> word[2], node[2];
+    VBuf<double> weight[2];
+    int cur = 0, lastBatch = 0, lastCap = 0;
+    VBuf<uint8_t> hostDesc;
+};
+
+extern "C" int orbx_vocabulary_create(int device, int k, int L, int num_nodes, const int32_t *parent, const uint8_t *is_leaf, const uint8_t *descriptors,
+                                      const double *weights, orbx_vocabulary **out)
+{
+    if (!out || !parent || !is_leaf || !descriptors || !weights || num_nodes < 2 || k < 1 || L < 1) { orbx_set_error("bad vocabulary arguments"); return ORBX_ERR_ARG; }
+    *out = nullptr;
+    std::vector<std::vector<int32_t> > children((size_t)num_nodes);
+    for (int i = 1; i < num_nodes; i++) {
+        if (parent[i] < 0 || parent[i] >= i) { orbx_set_error("node %d: parent %d must be a smaller node id", i, parent[i]); return ORBX_ERR_ARG; }
+        if (is_leaf[parent[i]]) { orbx_set_error("node %d hangs under leaf %d", i, parent[i]); return ORBX_ERR_ARG; }
+        children[(size_t)parent[i]].push_back(i);   // ascending id = the order loadFromTextFile builds (TemplatedVocabulary.h:1378-1420)
+    }
+    std::vector<VocNode> nodes((size_t)num_nodes);
+    std::vector<int32_t> childList;
+    int words = 0;
+    for (int i = 0; i < num_nodes; i++) {
+        nodes[(size_t)i].childStart = (int32_t)childList.size();
+        nodes[(size_t)i].childCount = (int32_t)children[(size_t)i].size();
+        nodes[(size_t)i].pad = 0;
+        const bool leaf = i > 0 && is_leaf[i];
+        if (!leaf && children[(size_t)i].empty()) { orbx_set_error("inner node %d has no children", i); return ORBX_ERR_ARG; }
+        nodes[(size_t)i].word = leaf ? words++ : -1;   // word ids in node-id order (:1407-1414)
+        childList.insert(childList.end(), children[(size_t)i].begin(), children[(size_t)i].end());
+    }
+    std::vector<uint8_t> cdesc(childList.size() * 32);
+    for (size_t c = 0; c < childList.size(); c++) memcpy(&cdesc[32 * c], descriptors + 32 * (size_t)childList[c], 32);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { orbx_set_error("no HIP device available: liborbx has no CPU fallback"); return ORBX_ERR_NODEVICE; }
+    if (device < 0 || device >= ndev) { orbx_set_error("device %d out of range", device); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(device));
+    orbx_vocabulary *v = new orbx_vocabulary();
+    v->device = device; v->k = k; v->L = L; v->numNodes = num_nodes; v->numWords = words;
+    int rc;
+    if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess) { delete v; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
+    if ((rc = v->nodes.ensure(nodes.size())) || (rc = v->childList.ensure(childList.size())) || (rc = v->childDesc.ensure(childList.size() * 2)) ||
+        (rc = v->nodeWeight.ensure((size_t)num_nodes))) {
+        orbx_vocabulary_destroy(v);
+        return rc;
+    }
+    ORBX_HIP_CHECK(hipMemcpy(v->nodes.p, nodes.data(), nodes.size() * sizeof(VocNode), hipMemcpyHostToDevice));
+    ORBX_HIP_CHECK(hipMemcpy(v->childList.p, childList.data(), childList.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    ORBX_HIP_CHECK(hipMemcpy(v->childDesc.p, cdesc.data(), cdesc.size(), hipMemcpyHostToDevice));
+    ORBX_HIP_CHECK(hipMemcpy(v->nodeWeight.p, weights, (size_t)num_nodes * sizeof(double), hipMemcpyHostToDevice));
+    *out = v;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v)
+{
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    if (v->stream) { (void)hipStreamSynchronize(v->stream); (void)hipStreamDestroy(v->stream); }
+    v->nodes.release(); v->childList.release(); v->childDesc.release(); v->nodeWeight.release(); v->hostDesc.release();
+    for (int b = 0; b < 2; b++) { v->word[b].release(); v->node[b].release(); v->weight[b].release(); }
+    delete v;
+}
+
+extern "C" int orbx_vocabulary_words(const orbx_vocabulary *v) { return v ? v->numWords : ORBX_ERR_ARG; }
+
+static int launch_transform(orbx_vocabulary *v, hipStream_t stream, const uint8_t *desc, const int32_t *counts, int batch, int cap, int levelsup)
+{
+    int rc;
+    v->cur ^= 1;
+    const int b = v->cur;
+    const size_t n = (size_t)batch * cap;
+    if ((rc = v->word[b].ensure(n)) || (rc = v->node[b].ensure(n)) || (rc = v->weight[b].ensure(n))) return rc;
+    hipLaunchKernelGGL(k_bow_transform, dim3((unsigned)((cap + 255) / 256), (unsigned)batch), dim3(256), 0, stream, v->nodes.p, v->childList.p, v->childDesc.p,
+                       v->nodeWeight.p, v->L - levelsup, desc, counts, cap, v->word[b].p, v->node[b].p, v->weight[b].p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+    v->lastBatch = batch; v->lastCap = cap;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_bow_transform_device(orbx_vocabulary *v, orbx_extractor *ext, int levelsup)
+{
+    if (!v || !ext) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    OrbxLastBatchView view;
+    int rc = orbx_extractor_last_batch_view_internal(ext, &view);
+    if (rc != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipSetDevice(v->device));
+    // same stream as the extraction: ordered behind it, and ahead of every consumer that orders itself behind the extractor
+    return launch_transform(v, orbx_extractor_stream_internal(ext), view.desc, view.counts, view.batch, view.cap, levelsup);
+}
+
+extern "C" int orbx_bow_results_device(orbx_vocabulary *v, const int32_t **word_dev, const int32_t **node_dev, const double **weight_dev, int *capacity)
+{
+    if (!v) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!v->lastBatch) { orbx_set_error("no transform has run yet"); return ORBX_ERR_STATE; }
+    if (word_dev) *word_dev = v->word[v->cur].p;
+    if (node_dev) *node_dev = v->node[v->cur].p;
+    if (weight_dev) *weight_dev = v->weight[v->cur].p;
+    if (capacity) *capacity = v->lastCap;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_bow_download(orbx_vocabulary *v, orbx_extractor *ext, int batch, int32_t *word, int32_t *node, double *weight)
+{
+    if (!v) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (batch < 1 || batch > v->lastBatch) { orbx_set_error("batch not available"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(v->device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(ext ? orbx_extractor_stream_internal(ext) : v->stream));
+    const size_t n = (size_t)batch * v->lastCap;
+    const int b = v->cur;
+    if (word) ORBX_HIP_CHECK(hipMemcpy(word, v->word[b].p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (node) ORBX_HIP_CHECK(hipMemcpy(node, v->node[b].p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (weight) ORBX_HIP_CHECK(hipMemcpy(weight, v->weight[b].p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_bow_transform(orbx_vocabulary *v, const uint8_t *descriptors, int n, int levelsup, int32_t *word, int32_t *node, double *weight)
+{
+    if (!v || (n > 0 && !descriptors)) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (n <= 0) return ORBX_OK;
+    ORBX_HIP_CHECK(hipSetDevice(v->device));
+    int rc = v->hostDesc.ensure((size_t)n * 32);
+    if (rc != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(v->hostDesc.p, descriptors, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
+    if ((rc = launch_transform(v, v->stream, v->hostDesc.p, nullptr, 1, n, levelsup)) != ORBX_OK) return rc;
+    return orbx_bow_download(v, nullptr, 1, word, node, weight);
+}

@@ -113,9 +113,10 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
     const int gA0 = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live0 ? i0 : nA - 1)] : 0;
     const int gA1 = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live1 ? i1 : nA - 1)] : 0;
     const uint32_t sentinel = dcut << 16;
+    const bool act0 = live0 && !(FILTER && gA0 < 0), act1 = live1 && !(FILTER && gA1 < 0);   // unfiled A features keep empty lists
     uint32_t k0[TOPK], k1[TOPK];
 #pragma unroll
-    for (int q = 0; q < TOPK; q++) { k0[q] = live0 ? sentinel : 0u; k1[q] = live1 ? sentinel : 0u; }   // dead rows never insert
+    for (int q = 0; q < TOPK; q++) { k0[q] = act0 ? sentinel : 0u; k1[q] = act1 ? sentinel : 0u; }   // inactive rows never insert
     const uint4 *gD = (const uint4 *)(B.desc + (size_t)fb * capB * 32);
     for (int t0 = 0; t0 < nB; t0 += TOPK_TILE) {
         const int nt = min(TOPK_TILE, nB - t0), ntPad = (nt + 3) & ~3;
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
                 int gq = (int)0x80000000;
                 if (j < nt) {
                     gq = B.groups ? B.groups[(size_t)fb * capB + t0 + j] : 0;
+                    if (gq < 0) gq = (int)0x80000000;   // negative node id = not filed in the FeatureVector: never matched
                     if (mode == 1 && B.valid && !B.valid[(size_t)fb * capB + t0 + j]) gq = (int)0x80000000;
                 }
                 sG[j] = gq;
@@ -169,12 +171,12 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
     if (live0) {
         uint32_t *out = topk + ((size_t)p * stride + i0) * TOPK;
 #pragma unroll
-        for (int k = 0; k < TOPK; k++) out[k] = k0[k] >= sentinel ? KEY_EMPTY : k0[k];
+        for (int k = 0; k < TOPK; k++) out[k] = (!act0 || k0[k] >= sentinel) ? KEY_EMPTY : k0[k];
     }
     if (live1) {
         uint32_t *out = topk + ((size_t)p * stride + i1) * TOPK;
 #pragma unroll
-        for (int k = 0; k < TOPK; k++) out[k] = k1[k] >= sentinel ? KEY_EMPTY : k1[k];
+        for (int k = 0; k < TOPK; k++) out[k] = (!act1 || k1[k] >= sentinel) ? KEY_EMPTY : k1[k];
     }
 }
 

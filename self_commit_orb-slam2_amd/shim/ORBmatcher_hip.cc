@@ -54,11 +54,10 @@ orbx_matcher *Matcher(int need)
 }
 
 // DBoW2::FeatureVector (node id -> feature indices) as one node id per feature.  Features the
-// vocabulary did not place get `missing`; the two sides use different negative ids so that
-// they never meet.
-void FlatGroups(const DBoW2::FeatureVector &fv, int N, int32_t missing, std::vector<int32_t> &g)
+// vocabulary did not file (word weight 0) get -1: the C ABI never matches a negative node id.
+void FlatGroups(const DBoW2::FeatureVector &fv, int N, std::vector<int32_t> &g)
 {
-    g.assign((size_t)(N > 0 ? N : 1), missing);
+    g.assign((size_t)(N > 0 ? N : 1), -1);
     for (DBoW2::FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it)
         for (size_t k = 0; k < it->second.size(); k++)
             if ((int)it->second[k] < N) g[it->second[k]] = (int32_t)it->first;
@@ -84,8 +83,8 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
     const int NA = (int)vpMapPointsKF.size(), NB = F.N;
     if (NA == 0 || NB == 0) return 0;
     std::vector<int32_t> gA, gB;
-    FlatGroups(pKF->mFeatVec, NA, -2, gA);
-    FlatGroups(F.mFeatVec, NB, -1, gB);
+    FlatGroups(pKF->mFeatVec, NA, gA);
+    FlatGroups(F.mFeatVec, NB, gB);
     std::vector<uint8_t> validA;
     ValidMask(vpMapPointsKF, validA);
     orbx_feature_set a = {(const orbx_keypoint *)&pKF->mvKeysUn[0], pKF->mDescriptors.data, &NA, &gA[0], &validA[0], NA, 1};   // kp angle: :318
@@ -109,8 +108,8 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint
     const int NA = (int)vpMapPoints1.size(), NB = (int)vpMapPoints2.size();
     if (NA == 0 || NB == 0) return 0;
     std::vector<int32_t> gA, gB;
-    FlatGroups(pKF1->mFeatVec, NA, -2, gA);
-    FlatGroups(pKF2->mFeatVec, NB, -1, gB);
+    FlatGroups(pKF1->mFeatVec, NA, gA);
+    FlatGroups(pKF2->mFeatVec, NB, gB);
     std::vector<uint8_t> validA, validB;
     ValidMask(vpMapPoints1, validA);
     ValidMask(vpMapPoints2, validB);

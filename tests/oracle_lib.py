@@ -316,3 +316,66 @@ def compute_stereo_matches(orc, kpsL, descL, kpsR, descR, pyrL, pyrR, scale_fact
         lib.mo_compute_stereo_matches(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), _p(pl), _p(pr), _p(lw), _p(lh), len(pyrL), _p(sf), _p(isf),
                                       ctypes.c_float(bf), ctypes.c_float(mb), _p(uR), _p(dep), _p(sad))
     return uR[:len(kl)], dep[:len(kl)], sad[:len(kl)]
+
+
+# ---- DBoW2 vocabulary transform: restatement (oracle/match_oracle.cc) and the compiled reference ----
+def voc_transform(orc, voc, descriptors, levelsup):
+    lib = orc.lib
+    d = np.ascontiguousarray(descriptors, np.uint8)
+    n = len(d)
+    word, node, weight = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+    par, leaf = np.ascontiguousarray(voc["parent"], np.int32), np.ascontiguousarray(voc["is_leaf"], np.uint8)
+    nd, wt = np.ascontiguousarray(voc["desc"], np.uint8), np.ascontiguousarray(voc["weight"], np.float64)
+    wid = np.full(len(par), -1, np.int32)
+    wid[leaf > 0] = np.arange(int((leaf > 0).sum()), dtype=np.int32)     # word ids count the leaves in node-id order
+    lib.mo_voc_transform.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
+    lib.mo_voc_transform(len(par), _p(par), _p(leaf), _p(nd), _p(wt), _p(wid), int(voc["L"]), _p(d), n, levelsup, _p(word), _p(node), _p(weight))
+    return word[:n], node[:n], weight[:n]
+
+
+def bow_vector(word, weight):
+    """BowVector of the reference's vector transform for TF_IDF/TF weighting + L1 scoring
+    (TemplatedVocabulary.h:1146-1178, BowVector.cpp:62-84): per word the weight added once per
+    occurrence in feature order, then divided by the L1 norm summed in ascending word-id order."""
+    acc = {}
+    for w, v in zip(word, weight):
+        if v > 0:
+            acc[int(w)] = acc.get(int(w), 0.0) + float(v)
+    ids = sorted(acc)
+    norm = 0.0
+    for i in ids:
+        norm += abs(acc[i])
+    vals = [acc[i] / norm if norm > 0 else acc[i] for i in ids]
+    return np.array(ids, np.int32), np.array(vals, np.float64)
+
+
+class RefVocabulary:
+    """ORBVocabulary of the compiled reference, loaded through its own loadFromTextFile."""
+
+    def __init__(self, path, lib=None):
+        self.lib = lib or slam_lib()
+        self.lib.orbslam_voc_load.restype = ctypes.c_void_p
+        self.lib.orbslam_voc_load.argtypes = [ctypes.c_char_p]
+        self.lib.orbslam_voc_destroy.argtypes = [ctypes.c_void_p]
+        self.lib.orbslam_voc_size.argtypes = [ctypes.c_void_p]
+        self.h = ctypes.c_void_p(self.lib.orbslam_voc_load(str(path).encode()))
+        assert self.h.value, "loadFromTextFile failed"
+
+    def __del__(self):
+        try:
+            self.lib.orbslam_voc_destroy(self.h)
+        except Exception:
+            pass
+
+    def size(self):
+        return self.lib.orbslam_voc_size(self.h)
+
+    def transform(self, descriptors, levelsup):
+        d = np.ascontiguousarray(descriptors, np.uint8)
+        n = len(d)
+        word, node, fvn = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        weight = np.zeros(n, np.float64)
+        bi, bv = np.zeros(n + 1, np.int32), np.zeros(n + 1, np.float64)
+        self.lib.orbslam_voc_transform.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]
+        nb = self.lib.orbslam_voc_transform(self.h, _p(d), n, levelsup, _p(word), _p(node), _p(weight), _p(bi), _p(bv), n + 1, _p(fvn))
+        return dict(word=word, node=node, weight=weight, bow_ids=bi[:nb].copy(), bow_vals=bv[:nb].copy(), fv_node=fvn)

@@ -36,12 +36,7 @@ def test_search_by_bow_restatement_equals_reference(orbx, oracle, mode, groups, 
             gB[rng.random(len(kB)) < 0.05] = -1
             vA = (rng.random(len(kA)) < 0.8).astype(np.uint8)
             vB = (rng.random(len(kB)) < 0.9).astype(np.uint8)
-        if groups:
-            # -1 on both sides must never meet: the C ABI contract gives them distinct ids
-            gA2, gB2 = gA.copy(), gB.copy()
-            gA2[gA2 < 0] = -2
-        else:
-            gA2 = gB2 = None
+        gA2, gB2 = gA, gB     # negative node id = not filed in the FeatureVector (both in the C ABI and in the restatement)
         want_n, want = oracle_lib.ref_search_by_bow(mode, kA, dA, kB, dB, ratio, ori, gA, gB, vA, vB if mode == 1 else None)
         got_n, got = oracle_lib.search_by_bow(oracle, mode, kA, dA, kB, dB, ratio, ori, gA2, gB2, vA, vB if mode == 1 else None)
         assert got_n == want_n, (trial, got_n, want_n)
