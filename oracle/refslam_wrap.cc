@@ -369,3 +369,38 @@ ORBSLAM_API int orbslam_voc_transform(void *h, const uint8_t *desc, int n, int l
         for (size_t k = 0; k < it->second.size(); k++) fv_node[it->second[k]] = (int32_t)it->first;
     return nb;
 }
+
+// Frame::ComputeBoW (src/Frame.cc:880-896) and KeyFrame::ComputeBoW (src/KeyFrame.cc:80-88) on a
+// Frame / KeyFrame holding the given descriptors and this vocabulary.  which = 0: Frame, 1: KeyFrame.
+// Outputs: BowVector (ascending word id) and, per feature, the FeatureVector node (-1 = not filed).
+ORBSLAM_API int orbslam_compute_bow(void *voc, int which, const uint8_t *desc, int n, int32_t *bow_ids, double *bow_vals, int bow_cap, int32_t *fv_node)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {500.f, 500.f, 320.f, 240.f, 40.f, 640, 480};
+    std::vector<float> kps((size_t)(n > 0 ? n : 1) * 7, 0.f);
+    for (int i = 0; i < n; i++) { kps[7 * (size_t)i] = 100.f; kps[7 * (size_t)i + 1] = 100.f; }
+    Frame F;
+    fill_frame(F, kps.data(), desc, n, nullptr, cam, kDefaultScales, 8);
+    F.mpORBvocabulary = (ORBVocabulary *)(VocAccess *)voc;
+    F.mTcw = cv::Mat::eye(4, 4, CV_32F);
+    const DBoW2::BowVector *bv = nullptr;
+    const DBoW2::FeatureVector *fv = nullptr;
+    KeyFrame *kf = nullptr;
+    if (which == 0) {
+        F.ComputeBoW();
+        bv = &F.mBowVec; fv = &F.mFeatVec;
+    } else {
+        kf = new KeyFrame(F, &map, (KeyFrameDatabase *)nullptr);
+        kf->ComputeBoW();
+        bv = &kf->mBowVec; fv = &kf->mFeatVec;
+    }
+    for (int i = 0; i < n; i++) fv_node[i] = -1;
+    int nb = 0;
+    for (DBoW2::BowVector::const_iterator it = bv->begin(); it != bv->end(); ++it, ++nb)
+        if (nb < bow_cap) { bow_ids[nb] = (int32_t)it->first; bow_vals[nb] = it->second; }
+    for (DBoW2::FeatureVector::const_iterator it = fv->begin(); it != fv->end(); ++it)
+        for (size_t k = 0; k < it->second.size(); k++) fv_node[it->second[k]] = (int32_t)it->first;
+    delete kf;
+    return nb;
+}

@@ -1,0 +1,111 @@
+// shim/BoW_hip.cc -- HIP bodies for ORB_SLAM2::Frame::ComputeBoW and KeyFrame::ComputeBoW.
+//
+// Compiled against the REFERENCE's own headers.  Replaces the bodies of
+//     void Frame::ComputeBoW()        src/Frame.cc:880-896
+//     void KeyFrame::ComputeBoW()     src/KeyFrame.cc:80-88
+// i.e. `mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)`: the k*L Hamming
+// distances per feature of the tree descent run on the MI355X (orbx_bow_transform, csrc/orbx_bow.hip),
+// the two std::map results are then filled with DBoW2's own BowVector / FeatureVector methods in
+// the order of the reference's loop (TemplatedVocabulary.h:1146-1196), so they are bit-identical.
+// The device copy of the tree is built once per ORBVocabulary object from its (protected) node
+// table, reached through a pointer-to-member of a derived accessor - no change to DBoW2.
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "Frame.h"
+#include "KeyFrame.h"
+#include "orbx.h"
+
+static unsigned long gBoWCalls = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_compute_bow_calls(void) { return gBoWCalls; }
+
+namespace ORB_SLAM2
+{
+
+namespace
+{
+struct VocAccess : public ORBVocabulary {
+    static DBoW2::GeneralScoring *Scoring(const ORBVocabulary &v) { return v.*(&VocAccess::m_scoring_object); }
+    // the node table as the flat arrays of orbx_vocabulary_create (Node is a protected nested type)
+    static void Flatten(const ORBVocabulary &v, std::vector<int32_t> &parent, std::vector<uint8_t> &leaf, std::vector<uint8_t> &desc, std::vector<double> &weight)
+    {
+        const std::vector<Node> &nodes = v.*(&VocAccess::m_nodes);
+        const size_t n = nodes.size();
+        parent.resize(n); leaf.resize(n); weight.resize(n); desc.assign(n * 32, 0);
+        for (size_t i = 0; i < n; i++) {
+            parent[i] = (int32_t)nodes[i].parent;
+            leaf[i] = (i > 0 && nodes[i].isLeaf()) ? 1 : 0;
+            weight[i] = nodes[i].weight;
+            if (i > 0 && !nodes[i].descriptor.empty()) memcpy(&desc[32 * i], nodes[i].descriptor.ptr<unsigned char>(), 32);
+        }
+    }
+};
+
+std::mutex gVocMutex;
+std::map<const ORBVocabulary *, orbx_vocabulary *> gVocs;
+
+orbx_vocabulary *DeviceVocabulary(const ORBVocabulary *voc)
+{
+    std::unique_lock<std::mutex> lock(gVocMutex);
+    std::map<const ORBVocabulary *, orbx_vocabulary *>::iterator it = gVocs.find(voc);
+    if (it != gVocs.end()) return it->second;
+    std::vector<int32_t> parent;
+    std::vector<uint8_t> leaf, desc;
+    std::vector<double> weight;
+    VocAccess::Flatten(*voc, parent, leaf, desc, weight);
+    const int n = (int)parent.size();
+    orbx_vocabulary *dv = 0;
+    if (orbx_vocabulary_create(0, voc->getBranchingFactor(), voc->getDepthLevels(), n, &parent[0], &leaf[0], &desc[0], &weight[0], &dv) != ORBX_OK)
+        throw std::runtime_error(std::string("ComputeBoW (orbx): ") + orbx_last_error());
+    gVocs[voc] = dv;
+    return dv;
+}
+
+// TemplatedVocabulary::transform(features, v, fv, levelsup), :1127-1196, with the per-feature
+// descent done on the device.
+void Transform(const ORBVocabulary *voc, const cv::Mat &descriptors, DBoW2::BowVector &v, DBoW2::FeatureVector &fv, int levelsup)
+{
+    __atomic_add_fetch(&gBoWCalls, 1, __ATOMIC_RELAXED);
+    v.clear();
+    fv.clear();
+    if (voc->empty()) return;
+    const int n = descriptors.rows;
+    std::vector<int32_t> word((size_t)(n > 0 ? n : 1)), node((size_t)(n > 0 ? n : 1));
+    std::vector<double> weight((size_t)(n > 0 ? n : 1));
+    std::vector<unsigned char> flat((size_t)(n > 0 ? n : 1) * 32);
+    for (int i = 0; i < n; i++) memcpy(&flat[32 * (size_t)i], descriptors.ptr<unsigned char>(i), 32);
+    if (orbx_bow_transform(DeviceVocabulary(voc), &flat[0], n, levelsup, &word[0], &node[0], &weight[0]) != ORBX_OK)
+        throw std::runtime_error(std::string("ComputeBoW (orbx): ") + orbx_last_error());
+    DBoW2::LNorm norm;
+    const bool must = VocAccess::Scoring(*voc)->mustNormalize(norm);
+    const DBoW2::WeightingType wt = voc->getWeightingType();
+    const bool tf = wt == DBoW2::TF || wt == DBoW2::TF_IDF;
+    for (int i = 0; i < n; i++) {
+        if (weight[(size_t)i] > 0) {
+            if (tf) v.addWeight((DBoW2::WordId)word[(size_t)i], weight[(size_t)i]);          // :1160
+            else v.addIfNotExist((DBoW2::WordId)word[(size_t)i], weight[(size_t)i]);         // :1187
+            fv.addFeature((DBoW2::NodeId)node[(size_t)i], (unsigned int)i);                  // :1161
+        }
+    }
+    if (tf && !v.empty() && !must) {                                                          // :1165-1171
+        const double nd = v.size();
+        for (DBoW2::BowVector::iterator vit = v.begin(); vit != v.end(); vit++) vit->second /= nd;
+    }
+    if (must) v.normalize(norm);                                                              // :1196
+}
+}  // namespace
+
+void Frame::ComputeBoW()
+{
+    if (mBowVec.empty()) Transform(mpORBvocabulary, mDescriptors, mBowVec, mFeatVec, 4);      // src/Frame.cc:883-894
+}
+
+void KeyFrame::ComputeBoW()
+{
+    if (mBowVec.empty() || mFeatVec.empty()) Transform(mpORBvocabulary, mDescriptors, mBowVec, mFeatVec, 4);   // src/KeyFrame.cc:82-87
+}
+
+}  // namespace ORB_SLAM2

@@ -379,3 +379,13 @@ class RefVocabulary:
         self.lib.orbslam_voc_transform.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]
         nb = self.lib.orbslam_voc_transform(self.h, _p(d), n, levelsup, _p(word), _p(node), _p(weight), _p(bi), _p(bv), n + 1, _p(fvn))
         return dict(word=word, node=node, weight=weight, bow_ids=bi[:nb].copy(), bow_vals=bv[:nb].copy(), fv_node=fvn)
+
+    def compute_bow(self, descriptors, which=0):
+        """Frame::ComputeBoW (which=0) / KeyFrame::ComputeBoW (which=1) on an object holding these descriptors."""
+        d = np.ascontiguousarray(descriptors, np.uint8)
+        n = len(d)
+        fvn = np.zeros(n, np.int32)
+        bi, bv = np.zeros(n + 1, np.int32), np.zeros(n + 1, np.float64)
+        self.lib.orbslam_compute_bow.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        nb = self.lib.orbslam_compute_bow(self.h, which, _p(d), n, _p(bi), _p(bv), n + 1, _p(fvn))
+        return dict(bow_ids=bi[:nb].copy(), bow_vals=bv[:nb].copy(), fv_node=fvn)

@@ -75,3 +75,26 @@ def test_stereo_frame_dropin_equals_reference(orbx, W, H, nf, seed, bf):
     for k in ("descL", "descR"):
         assert (got[k] == want[k]).all(), k
     assert (want["uRight"] >= 0).sum() > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1])
+def test_compute_bow_dropin_equals_reference(orbx, tmp_path, which):
+    """Frame::ComputeBoW / KeyFrame::ComputeBoW with the HIP tree descent vs DBoW2's own transform,
+    both through the reference's ORBVocabulary loaded from the same text file."""
+    from test_bow_transform import _descs
+    orbx.load_library()
+    hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
+    hip.orbx_shim_compute_bow_calls.restype = ctypes.c_ulong
+    voc = orbx.voc_synth.make_vocabulary(10, 5, 31)
+    path = tmp_path / "voc.txt"
+    orbx.voc_synth.write_text(voc, path)
+    vr, vh = oracle_lib.RefVocabulary(path, lib=ref), oracle_lib.RefVocabulary(path, lib=hip)
+    before = hip.orbx_shim_compute_bow_calls()
+    for seed in (1, 2):
+        d = _descs(orbx, voc, 2000, seed)
+        want, got = vr.compute_bow(d, which), vh.compute_bow(d, which)
+        assert (got["fv_node"] == want["fv_node"]).all() and (want["fv_node"] >= 0).sum() > 1000
+        assert (got["bow_ids"] == want["bow_ids"]).all()
+        assert (got["bow_vals"].view(np.uint64) == want["bow_vals"].view(np.uint64)).all()
+    assert hip.orbx_shim_compute_bow_calls() - before == 2
