@@ -239,6 +239,46 @@ int orbx_compute_stereo_matches_device(orbx_matcher *m, orbx_extractor *left, or
 int orbx_stereo_results_device(orbx_matcher *m, const float **uright_dev, const float **depth_dev, int *stride);
 int orbx_stereo_download(orbx_matcher *m, int npairs, float *uright, float *depth, int stride);
 
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+ * (ORBmatcher.h, src/ORBmatcher.cc:70-175; called by Tracking::SearchLocalPoints, src/Tracking.cc:1616)
+ * including Frame::GetFeaturesInArea and the 64x48 feature grid (src/Frame.cc:741-877).
+ * The Frame side is passed as arrays of the frame's members, the MapPoint side as what
+ * Frame::isInFrustum left in every MapPoint.  Feature i of frame f at f*capacity + i. */
+typedef struct orbx_projection_frame {
+    const orbx_keypoint *keypoints_un; /* mvKeysUn                                                   */
+    const uint8_t *descriptors;        /* mDescriptors                                               */
+    const float *u_right;              /* mvuRight (<= 0: no stereo coordinate)                      */
+    const uint8_t *occupied;           /* 1 = mvpMapPoints[i] holds a MapPoint with Observations()>0
+                                          (src/ORBmatcher.cc:110-112); NULL = none                   */
+    const int32_t *counts;             /* N per frame                                                */
+    int capacity, nframes;
+    float min_x, min_y;                /* Frame::mnMinX, mnMinY                                      */
+    float grid_width_inv, grid_height_inv; /* Frame::mfGridElementWidthInv / HeightInv              */
+} orbx_projection_frame;
+
+typedef struct orbx_projection_points {
+    const float *proj_x, *proj_y, *proj_xr; /* MapPoint::mTrackProjX / mTrackProjY / mTrackProjXR    */
+    const int32_t *scale_level;        /* mnTrackScaleLevel                                          */
+    const float *view_cos;             /* mTrackViewCos                                              */
+    const uint8_t *in_view;            /* mbTrackInView && !isBad()                                  */
+    const uint8_t *has_observations;   /* Observations()>0: the point blocks its feature for the
+                                          points that follow; NULL = all                             */
+    const uint8_t *descriptors;        /* GetDescriptor(), 32 bytes                                  */
+    const int32_t *counts;             /* points per frame                                           */
+    int capacity;
+} orbx_projection_points;
+
+/* Device-pointer form for `frame->nframes` independent (frame, point list) problems; results:
+ * matches[f*stride + i] = index of the point written into F.mvpMapPoints[i] by the call or -1,
+ * nmatches[f] = return value (orbx_matcher_results_device / orbx_matcher_download). */
+int orbx_search_by_projection_device(orbx_matcher *m, const orbx_projection_frame *frame,
+                                     const orbx_projection_points *points, const float *scale_factors, int nlevels,
+                                     float th, float nn_ratio);
+/* Host-array form for one frame (counts[0] entries each): upload, run, download. */
+int orbx_search_by_projection(orbx_matcher *m, const orbx_projection_frame *frame_host,
+                              const orbx_projection_points *points_host, const float *scale_factors, int nlevels,
+                              float th, float nn_ratio, int32_t *assigned, int32_t *nmatches);
+
 int orbx_matcher_results_device(orbx_matcher *m, const int32_t **matches_dev, const int32_t **dists_dev,
                                 const int32_t **nmatches_dev, int *stride);
 int orbx_matcher_download(orbx_matcher *m, int npairs, int32_t *matches, int32_t *dists, int stride,

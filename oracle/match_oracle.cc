@@ -297,3 +297,95 @@ MO_API void mo_voc_transform(int num_nodes, const int32_t *parent, const uint8_t
         node[f] = nid;
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+// (src/ORBmatcher.cc:70-175) with Frame::GetFeaturesInArea (src/Frame.cc:741-850) and
+// Frame::PosInGrid / AssignFeaturesToGrid (:461-491, 853-877) on flat arrays.
+//   frame side : mvKeysUn (7 floats each), mDescriptors, mvuRight, occupied[idx] = 1 when
+//                F.mvpMapPoints[idx] holds a MapPoint with Observations()>0 at entry, grid bounds
+//   point side : what Frame::isInFrustum left in each MapPoint (mTrackProjX/Y/XR, mnTrackScaleLevel,
+//                mTrackViewCos, mbTrackInView && !isBad()), has_obs = Observations()>0, descriptor
+// assigned[idx] = index of the MapPoint written into F.mvpMapPoints[idx] by this call, else -1.
+// PINNED against the compiled reference in tests/test_projection.py.
+// ---------------------------------------------------------------------------------------
+namespace {
+const int GRID_COLS = 64, GRID_ROWS = 48;   // include/Frame.h:55-60
+}
+
+MO_API int mo_search_by_projection(const float *kpUn, const uint8_t *desc, const float *uRight, const uint8_t *occupied_in, int n, float minX, float minY,
+                                   float gridWInv, float gridHInv, const float *scaleFactors, const float *projX, const float *projY,
+                                   const float *projXR, const int32_t *level, const float *viewCos, const uint8_t *inView, const uint8_t *hasObs,
+                                   const uint8_t *mpDesc, int m, float th, float nnratio, int32_t *assigned)
+{
+    // AssignFeaturesToGrid: cell lists hold feature indices in ascending order
+    std::vector<std::vector<size_t> > grid((size_t)GRID_COLS * GRID_ROWS);
+    for (int i = 0; i < n; i++) {
+        const int posX = (int)roundf((kpUn[7 * i] - minX) * gridWInv), posY = (int)roundf((kpUn[7 * i + 1] - minY) * gridHInv);
+        if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
+        grid[(size_t)posX * GRID_ROWS + posY].push_back((size_t)i);
+    }
+    std::vector<uint8_t> occupied(occupied_in, occupied_in + n);
+    for (int i = 0; i < n; i++) assigned[i] = -1;
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < m; iMP++) {
+        if (!inView[iMP]) continue;
+        const int nPredictedLevel = level[iMP];
+        float r = viewCos[iMP] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos, :178-185
+        if (bFactor) r *= th;
+        const float x = projX[iMP], y = projY[iMP], rr = r * scaleFactors[nPredictedLevel];
+        const int minLevel = nPredictedLevel - 1, maxLevel = nPredictedLevel;
+        // GetFeaturesInArea
+        std::vector<size_t> vIndices;
+        do {
+            const int nMinCellX = std::max(0, (int)floor((x - minX - rr) * gridWInv));
+            if (nMinCellX >= GRID_COLS) break;
+            const int nMaxCellX = std::min(GRID_COLS - 1, (int)ceil((x - minX + rr) * gridWInv));
+            if (nMaxCellX < 0) break;
+            const int nMinCellY = std::max(0, (int)floor((y - minY - rr) * gridHInv));
+            if (nMinCellY >= GRID_ROWS) break;
+            const int nMaxCellY = std::min(GRID_ROWS - 1, (int)ceil((y - minY + rr) * gridHInv));
+            if (nMaxCellY < 0) break;
+            const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+                for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                    const std::vector<size_t> &vCell = grid[(size_t)ix * GRID_ROWS + iy];
+                    for (size_t j = 0; j < vCell.size(); j++) {
+                        const float *kp = kpUn + 7 * vCell[j];
+                        const int oct = (int)kp[5];
+                        if (bCheckLevels) {
+                            if (oct < minLevel) continue;
+                            if (maxLevel >= 0 && oct > maxLevel) continue;
+                        }
+                        const float distx = kp[0] - x, disty = kp[1] - y;
+                        if (fabs(distx) < rr && fabs(disty) < rr) vIndices.push_back(vCell[j]);
+                    }
+                }
+        } while (0);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t v = 0; v < vIndices.size(); v++) {
+            const size_t idx = vIndices[v];
+            if (occupied[idx]) continue;                                   // mvpMapPoints[idx] && Observations()>0, :110-112
+            if (uRight[idx] > 0) {
+                const float er = fabs(projXR[iMP] - uRight[idx]);
+                if (er > rr) continue;
+            }
+            const int dist = descriptor_distance(mpDesc + 32 * (size_t)iMP, desc + 32 * idx);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel;
+                bestLevel = (int)kpUn[7 * idx + 5]; bestIdx = (int)idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = (int)kpUn[7 * idx + 5]; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            assigned[bestIdx] = iMP;                                       // F.mvpMapPoints[bestIdx]=pMP
+            occupied[(size_t)bestIdx] = hasObs[iMP] ? 1 : 0;               // what the check at :110-112 will see from now on
+            nmatches++;
+        }
+    }
+    return nmatches;
+}

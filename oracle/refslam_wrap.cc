@@ -404,3 +404,57 @@ ORBSLAM_API int orbslam_compute_bow(void *voc, int which, const uint8_t *desc, i
     delete kf;
     return nb;
 }
+
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+// (src/ORBmatcher.cc:70-175) on a real Frame and real MapPoints.  The MapPoints get their
+// descriptor from the Frame-based constructor (src/MapPoint.cc:83-118) and their tracking
+// fields (public members, normally written by Frame::isInFrustum) from the arrays.
+ORBSLAM_API int orbslam_search_by_projection(const float *kpUn, const uint8_t *desc, const float *uRight, const uint8_t *occupied, int n, int width,
+                                             int height, const float *scaleFactors, int nlevels, const float *projX, const float *projY,
+                                             const float *projXR, const int32_t *level, const float *viewCos, const uint8_t *inView,
+                                             const uint8_t *hasObs, const uint8_t *mpDesc, int m, float th, float nnratio, int32_t *assigned)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {500.f, 500.f, (float)width / 2, (float)height / 2, 40.f, width, height};
+    Frame F;
+    fill_frame(F, kpUn, desc, n, nullptr, cam, scaleFactors, nlevels);
+    for (int i = 0; i < n; i++) F.mvuRight[(size_t)i] = uRight[i];
+    F.SetPose(cv::Mat::eye(4, 4, CV_32F));
+    // a helper Frame lends the MapPoints their descriptors (MapPoint(Pos, pMap, pFrame, idxF))
+    std::vector<float> hk((size_t)(m > 0 ? m : 1) * 7, 0.f);
+    Frame H;
+    fill_frame(H, hk.data(), mpDesc, m, nullptr, cam, scaleFactors, nlevels);
+    H.SetPose(cv::Mat::eye(4, 4, CV_32F));
+    KeyFrame *kf = new KeyFrame(H, &map, (KeyFrameDatabase *)nullptr);
+    cv::Mat pos = cv::Mat::zeros(3, 1, CV_32F);
+    pos.at<float>(2) = 1.f;
+    std::vector<MapPoint *> mps((size_t)m), owned;
+    std::map<MapPoint *, int> index;
+    for (int i = 0; i < m; i++) {
+        MapPoint *mp = new MapPoint(pos, &map, &H, i);
+        mp->mTrackProjX = projX[i]; mp->mTrackProjY = projY[i]; mp->mTrackProjXR = projXR[i];
+        mp->mnTrackScaleLevel = level[i]; mp->mTrackViewCos = viewCos[i]; mp->mbTrackInView = inView[i] != 0;
+        if (hasObs[i]) mp->AddObservation(kf, (size_t)i);
+        mps[(size_t)i] = mp; index[mp] = i; owned.push_back(mp);
+    }
+    // features that already carry a MapPoint with observations
+    for (int i = 0; i < n; i++)
+        if (occupied[i]) {
+            MapPoint *mp = new MapPoint(pos, &map, &H, 0);
+            mp->AddObservation(kf, 0);
+            F.mvpMapPoints[(size_t)i] = mp;
+            index[mp] = -2;
+            owned.push_back(mp);
+        }
+    ORBmatcher matcher(nnratio, true);
+    const int nm = matcher.SearchByProjection(F, mps, th);
+    for (int i = 0; i < n; i++) {
+        MapPoint *mp = F.mvpMapPoints[(size_t)i];
+        const int k = mp ? index[mp] : -1;
+        assigned[i] = k >= 0 ? k : -1;
+    }
+    for (size_t i = 0; i < owned.size(); i++) delete owned[i];
+    delete kf;
+    return nm;
+}

@@ -285,6 +285,18 @@ class FeatureSet(ctypes.Structure):
                 ("groups", ctypes.c_void_p), ("valid", ctypes.c_void_p), ("capacity", ctypes.c_int), ("nframes", ctypes.c_int)]
 
 
+class ProjectionFrame(ctypes.Structure):
+    _fields_ = [("keypoints_un", ctypes.c_void_p), ("descriptors", ctypes.c_void_p), ("u_right", ctypes.c_void_p), ("occupied", ctypes.c_void_p),
+                ("counts", ctypes.c_void_p), ("capacity", ctypes.c_int), ("nframes", ctypes.c_int), ("min_x", ctypes.c_float), ("min_y", ctypes.c_float),
+                ("grid_width_inv", ctypes.c_float), ("grid_height_inv", ctypes.c_float)]
+
+
+class ProjectionPoints(ctypes.Structure):
+    _fields_ = [("proj_x", ctypes.c_void_p), ("proj_y", ctypes.c_void_p), ("proj_xr", ctypes.c_void_p), ("scale_level", ctypes.c_void_p),
+                ("view_cos", ctypes.c_void_p), ("in_view", ctypes.c_void_p), ("has_observations", ctypes.c_void_p), ("descriptors", ctypes.c_void_p),
+                ("counts", ctypes.c_void_p), ("capacity", ctypes.c_int)]
+
+
 class BowParams(ctypes.Structure):
     _fields_ = [("nn_ratio", ctypes.c_float), ("check_orientation", ctypes.c_int), ("mode", ctypes.c_int)]
 
@@ -308,6 +320,7 @@ def _bind_matcher(L):
     L.orbx_search_by_bow.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), ctypes.POINTER(BowParams), vp, vp]
     L.orbx_stereo_match.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, ci, ctypes.c_float, vp, vp]
     L.orbx_matcher_last_timing.argtypes = [vp, vp]
+    L.orbx_search_by_projection.argtypes = [vp, ctypes.POINTER(ProjectionFrame), ctypes.POINTER(ProjectionPoints), vp, ci, ctypes.c_float, ctypes.c_float, vp, vp]
     L.orbx_matcher_last_kernel_timing.argtypes = [vp, vp, vp]
     L._matcher_bound = True
 
@@ -375,6 +388,35 @@ class ORBmatcher:
         prm = BowParams(self.nnratio, 1 if self.checkOri else 0, mode)
         _check(self._L.orbx_search_by_bow(self._h, ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(prm), _ptr(out), ctypes.byref(nm)))
         return nm.value, out[:nout]
+
+    def SearchByProjection(self, frame, points, th, nnratio=None):
+        """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (reference src/ORBmatcher.cc:70-175).
+        frame: dict(kps (structured mvKeysUn), desc, u_right, occupied, scale_factors, width, height[, min_x, min_y]);
+        points: dict(proj_x, proj_y, proj_xr, level, view_cos, in_view, has_obs, desc).
+        Returns (nmatches, assigned[n]) with assigned[i] = index of the point put into mvpMapPoints[i] or -1."""
+        k = np.ascontiguousarray(frame["kps"], KEYPOINT_DTYPE)
+        n = len(k)
+        d = np.ascontiguousarray(frame["desc"], np.uint8)
+        ur = np.ascontiguousarray(frame["u_right"], np.float32)
+        occ = np.ascontiguousarray(frame["occupied"], np.uint8)
+        sf = np.ascontiguousarray(frame["scale_factors"], np.float32)
+        minx, miny = np.float32(frame.get("min_x", 0.0)), np.float32(frame.get("min_y", 0.0))
+        maxx, maxy = np.float32(frame.get("max_x", frame["width"])), np.float32(frame.get("max_y", frame["height"]))
+        gw, gh = np.float32(64) / (maxx - minx), np.float32(48) / (maxy - miny)      # src/Frame.cc:181-182
+        cn, cm = np.array([n], np.int32), np.array([len(points["proj_x"])], np.int32)
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        px, py, pxr, vc = f32(points["proj_x"]), f32(points["proj_y"]), f32(points["proj_xr"]), f32(points["view_cos"])
+        lvl = np.ascontiguousarray(points["level"], np.int32)
+        inv, obs = np.ascontiguousarray(points["in_view"], np.uint8), np.ascontiguousarray(points["has_obs"], np.uint8)
+        md = np.ascontiguousarray(points["desc"], np.uint8)
+        F = ProjectionFrame(_ptr(k).value, _ptr(d).value, _ptr(ur).value, _ptr(occ).value, _ptr(cn).value, n, 1, float(minx), float(miny), float(gw), float(gh))
+        P = ProjectionPoints(_ptr(px).value, _ptr(py).value, _ptr(pxr).value, _ptr(lvl).value, _ptr(vc).value, _ptr(inv).value, _ptr(obs).value,
+                             _ptr(md).value, _ptr(cm).value, int(cm[0]))
+        out = np.full(max(n, 1), -1, np.int32)
+        nm = ctypes.c_int32()
+        _check(self._L.orbx_search_by_projection(self._h, ctypes.byref(F), ctypes.byref(P), _ptr(sf), len(sf), ctypes.c_float(th),
+                                                 ctypes.c_float(self.nnratio if nnratio is None else nnratio), _ptr(out), ctypes.byref(nm)))
+        return nm.value, out[:n]
 
     def StereoHamming(self, kpsL, descL, kpsR, descR, scale_factors, max_disparity=float("inf")):
         fl, kl = _host_set(kpsL, descL)

@@ -550,6 +550,180 @@ __global__ __launch_bounds__(256) void k_stereo_cut(FeatDev Lf, const int32_t *_
     if (t == 0) nmatches[p] = hist[0];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+// (src/ORBmatcher.cc:70-175), the matcher of Tracking::SearchLocalPoints, with
+// Frame::GetFeaturesInArea (src/Frame.cc:741-850) and the 64x48 feature grid (:461-491, 853-877).
+// The grid is never materialised: a feature's cell is round((pt - min) * inv) and "in the search
+// window" is the same cell-range + |dx|,|dy| < r test the reference applies, evaluated per
+// (map point, feature); the reference's candidate order (cell column, cell row, feature index)
+// becomes the low half of a 64-bit key whose high half is the Hamming distance.
+// k_proj_topk:   wave per map point, lanes over the frame's features -> its 8 smallest keys.
+// k_proj_greedy: workgroup per frame; wave 0 replays the map points in order (a feature taken by a
+//                point with observations blocks later points, :110-112), 8 points per 512-byte list
+//                fetch, exact wave-parallel rescan when a full list has fewer than two free entries.
+// ---------------------------------------------------------------------------------------------
+#define KEY64_EMPTY 0xffffffffffffffffull
+#define GRID_COLS 64   /* include/Frame.h:60 */
+#define GRID_ROWS 48   /* include/Frame.h:55 */
+
+struct ProjFrameDev { const orbx_keypoint *kp; const uint8_t *desc; const float *uRight; const uint8_t *occupied; const int32_t *counts; int cap;
+                      float minX, minY, gwInv, ghInv; };
+struct ProjPointsDev { const float *px, *py, *pxr; const int32_t *level; const float *viewCos; const uint8_t *inView, *hasObs, *desc; const int32_t *counts; int cap; };
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long u = __shfl_xor(v, o); v = u < v ? u : v; }
+    return v;
+}
+
+// gate + key of feature idx for one map point; KEY64_EMPTY when the feature is not a candidate
+struct ProjQuery { float x, y, rr, xr; int minLevel, maxLevel, cx0, cx1, cy0, cy1; bool any; unsigned long long d[4]; };
+
+__device__ __forceinline__ ProjQuery proj_query(const ProjFrameDev &F, const ProjPointsDev &P, size_t pi, const float *scaleFactors, float th)
+{
+    ProjQuery q;
+    const int lvl = P.level[pi];
+    float r = (double)P.viewCos[pi] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos, :178-185
+    if (th != 1.0f) r *= th;
+    q.x = P.px[pi]; q.y = P.py[pi]; q.xr = P.pxr[pi];
+    q.rr = r * scaleFactors[lvl];
+    q.minLevel = lvl - 1; q.maxLevel = lvl;
+    const int nMinCellX = max(0, (int)floorf((q.x - F.minX - q.rr) * F.gwInv)), nMaxCellX = min(GRID_COLS - 1, (int)ceilf((q.x - F.minX + q.rr) * F.gwInv));
+    const int nMinCellY = max(0, (int)floorf((q.y - F.minY - q.rr) * F.ghInv)), nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((q.y - F.minY + q.rr) * F.ghInv));
+    q.any = !(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0);
+    q.cx0 = nMinCellX; q.cx1 = nMaxCellX; q.cy0 = nMinCellY; q.cy1 = nMaxCellY;
+    const unsigned long long *dp = (const unsigned long long *)(P.desc + pi * 32);
+    q.d[0] = dp[0]; q.d[1] = dp[1]; q.d[2] = dp[2]; q.d[3] = dp[3];
+    return q;
+}
+
+__device__ __forceinline__ unsigned long long proj_key(const ProjFrameDev &F, size_t fbase, int idx, const ProjQuery &q)
+{
+    const orbx_keypoint k = F.kp[fbase + idx];
+    const int cx = (int)roundf((k.x - F.minX) * F.gwInv), cy = (int)roundf((k.y - F.minY) * F.ghInv);   // PosInGrid, :866-867
+    if (cx < q.cx0 || cx > q.cx1 || cy < q.cy0 || cy > q.cy1) return KEY64_EMPTY;   // (also: feature outside the grid)
+    if (k.octave < q.minLevel || k.octave > q.maxLevel) return KEY64_EMPTY;
+    const float distx = k.x - q.x, disty = k.y - q.y;
+    if (!(fabsf(distx) < q.rr && fabsf(disty) < q.rr)) return KEY64_EMPTY;
+    const float ur = F.uRight[fbase + idx];
+    if (ur > 0) { const float er = fabsf(q.xr - ur); if (er > q.rr) return KEY64_EMPTY; }
+    const unsigned long long *db = (const unsigned long long *)(F.desc + (fbase + idx) * 32);
+    const int dist = hamming256(q.d, db[0], db[1], db[2], db[3]);
+    return ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)idx;
+}
+
+__global__ __launch_bounds__(256) void k_proj_topk(ProjFrameDev F, ProjPointsDev P, const float *__restrict__ scaleFactors, float th,
+                                                   unsigned long long *__restrict__ topk)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
+    if (i >= m) return;
+    const size_t pi = (size_t)f * P.cap + i, fbase = (size_t)f * F.cap;
+    unsigned long long *out = topk + pi * TOPK;
+    if (!P.inView[pi]) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
+    const ProjQuery q = proj_query(F, P, pi, scaleFactors, th);
+    unsigned long long kk[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; t++) kk[t] = KEY64_EMPTY;
+    if (q.any)
+        for (int idx = lane; idx < n; idx += 64) {
+            const unsigned long long key = proj_key(F, fbase, idx, q);
+            if (key < kk[TOPK - 1]) {
+                kk[TOPK - 1] = key;
+#pragma unroll
+                for (int t = TOPK - 1; t > 0; t--)
+                    if (kk[t] < kk[t - 1]) { const unsigned long long v = kk[t - 1]; kk[t - 1] = kk[t]; kk[t] = v; }
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < TOPK; k++) {
+        const unsigned long long mn = wave_min_u64(kk[0]);
+        if (kk[0] == mn && mn != KEY64_EMPTY) {   // keys are unique: exactly one lane pops its head
+#pragma unroll
+            for (int t = 0; t < TOPK - 1; t++) kk[t] = kk[t + 1];
+            kk[TOPK - 1] = KEY64_EMPTY;
+        }
+        if (lane == 0) out[k] = mn;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_proj_greedy(ProjFrameDev F, ProjPointsDev P, const float *__restrict__ scaleFactors, float th, float nnratio,
+                                                     const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
+                                                     int32_t *__restrict__ nmatches, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
+    unsigned char *occ = smem;                  // [cap] 1 = the feature holds a MapPoint with observations
+    unsigned char *oct = smem + F.cap;          // [cap] octave of the feature
+    const size_t fbase = (size_t)f * F.cap, pbase = (size_t)f * P.cap;
+    int32_t *aout = assigned + (size_t)f * stride;
+    for (int i = tid; i < stride; i += 256) aout[i] = -1;
+    for (int i = tid; i < n; i += 256) { occ[i] = F.occupied ? F.occupied[fbase + i] : 0; oct[i] = (unsigned char)F.kp[fbase + i].octave; }
+    __syncthreads();
+    if (tid >= 64) return;
+    int total = 0;
+    const unsigned long long *tk = topk + pbase * TOPK;
+    unsigned long long nextKeys = (0 < m) ? tk[min((size_t)lane, (size_t)m * TOPK - 1)] : KEY64_EMPTY;
+    for (int i0 = 0; i0 < m; i0 += 8) {
+        const unsigned long long keys = nextKeys;   // lists of map points i0 .. i0+7, lane = 8*(i-i0) + rank
+        {
+            const size_t nx = (size_t)(i0 + 8) * TOPK + lane;
+            nextKeys = (i0 + 8 < m) ? tk[min(nx, (size_t)m * TOPK - 1)] : KEY64_EMPTY;   // in flight while these 8 points are replayed
+        }
+        for (int j = 0; j < 8 && i0 + j < m; j++) {
+            const int i = i0 + j;
+            const size_t pi = pbase + i;
+            if (!P.inView[pi]) continue;
+            const unsigned long long key = __shfl(keys, 8 * j + (lane & 7));   // lanes 0..7 hold the list of point i
+            const bool present = lane < TOPK && key != KEY64_EMPTY;
+            const int idx = (int)(key & 0xffff);
+            const bool free_ = present && !occ[idx];
+            const unsigned mAll = (1u << TOPK) - 1u;
+            const unsigned mPresent = (unsigned)(__ballot(present) & mAll), mFree = (unsigned)(__ballot(free_) & mAll);
+            unsigned long long k1 = KEY64_EMPTY, k2 = KEY64_EMPTY;
+            if (__popc(mFree) >= 2 || mPresent != mAll) {
+                if (mFree) {
+                    k1 = __shfl(key, __ffs(mFree) - 1);
+                    const unsigned rest = mFree & (mFree - 1);
+                    if (rest) k2 = __shfl(key, __ffs(rest) - 1);
+                }
+            } else {
+                // exact rescan: the two smallest keys among the features that are still free
+                const ProjQuery q = proj_query(F, P, pi, scaleFactors, th);
+                unsigned long long a = KEY64_EMPTY, b = KEY64_EMPTY;
+                if (q.any)
+                    for (int x = lane; x < n; x += 64) {
+                        if (occ[x]) continue;
+                        const unsigned long long kx = proj_key(F, fbase, x, q);
+                        if (kx < a) { b = a; a = kx; } else if (kx < b) b = kx;
+                    }
+                k1 = wave_min_u64(a);
+                if (a == k1) a = b;
+                k2 = wave_min_u64(a);
+            }
+            if (k1 == KEY64_EMPTY) continue;
+            const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xffff);
+            const int bestDist2 = k2 == KEY64_EMPTY ? 256 : (int)(k2 >> 32);
+            const int bestLevel = oct[bestIdx], bestLevel2 = k2 == KEY64_EMPTY ? -1 : (int)oct[(int)(k2 & 0xffff)];
+            if (bestDist <= TH_HIGH) {
+                if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+                if (lane == 0) {
+                    aout[bestIdx] = i;                                  // F.mvpMapPoints[bestIdx] = pMP
+                    occ[bestIdx] = P.hasObs ? P.hasObs[pi] : 1;         // what :110-112 sees from now on
+                }
+                total++;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (lane == 0) nmatches[f] = total;
+}
+
 template <typename T> struct MBuf {
     T *p = nullptr;
     size_t n = 0;
@@ -579,7 +753,11 @@ struct orbx_matcher {
     int profCount = 0;
     MBuf<int32_t> pairsA, pairsB, order, matches, dists, nmatches;
     MBuf<uint32_t> topk;
-    MBuf<float> scales, uright, depth;
+    MBuf<float> scales, uright, depth, pf[2];          // pf: projection staging (floats)
+    MBuf<unsigned long long> topk64;
+    MBuf<uint8_t> pb[2];
+    MBuf<int32_t> pi32[2];
+    MBuf<orbx_keypoint> pkp;
     MBuf<int32_t> sad;
     hipEvent_t evDep2 = nullptr, evPyr[2] = {nullptr, nullptr};
     int lastStereoPairs = 0;
@@ -639,6 +817,8 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->pairsA.release(); m->pairsB.release(); m->order.release(); m->matches.release(); m->dists.release(); m->nmatches.release();
     m->topk.release(); m->scales.release(); m->uright.release(); m->depth.release(); m->sad.release();
+    m->topk64.release(); m->pkp.release();
+    for (int q = 0; q < 2; q++) { m->pf[q].release(); m->pb[q].release(); m->pi32[q].release(); }
     if (m->evDep2) (void)hipEventDestroy(m->evDep2);
     for (int i = 0; i < 2; i++) if (m->evPyr[i]) (void)hipEventDestroy(m->evPyr[i]);
     for (int s = 0; s < 2; s++) { m->hk[s].release(); m->hd[s].release(); m->hv[s].release(); m->hc[s].release(); m->hg[s].release(); }
@@ -821,6 +1001,92 @@ extern "C" int orbx_stereo_download(orbx_matcher *m, int npairs, float *uright, 
     ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
     if (uright) ORBX_HIP_CHECK(hipMemcpy2D(uright, (size_t)stride * 4, m->uright.p, (size_t)m->lastStride * 4, (size_t)stride * 4, (size_t)npairs, hipMemcpyDeviceToHost));
     if (depth) ORBX_HIP_CHECK(hipMemcpy2D(depth, (size_t)stride * 4, m->depth.p, (size_t)m->lastStride * 4, (size_t)stride * 4, (size_t)npairs, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+static int proj_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjPointsDev &P, int nframes, const float *scale_factors, int nlevels, float th,
+                       float nnratio)
+{
+    if (nframes < 1 || nframes > m->maxPairs) { orbx_set_error("nframes %d outside 1..%d", nframes, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (F.cap < 1 || F.cap > m->maxFeatures || F.cap > 65535 || P.cap < 1) { orbx_set_error("bad capacities (features %d, points %d)", F.cap, P.cap); return ORBX_ERR_CAPACITY; }
+    if (!scale_factors || nlevels < 1 || nlevels > 64) { orbx_set_error("bad scale factor table"); return ORBX_ERR_ARG; }
+    int rc = m->topk64.ensure((size_t)nframes * P.cap * TOPK);
+    if (rc != ORBX_OK) return rc;
+    const int stride = m->maxFeatures;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->scales.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_proj_topk, dim3((unsigned)((P.cap + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, F, P, m->scales.p, th, m->topk64.p);
+    MLAUNCH_CHECK();
+    const size_t lds = (size_t)F.cap * 2 + 16;
+    if (lds > 64 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_proj_greedy, dim3((unsigned)nframes), dim3(256), lds, m->stream, F, P, m->scales.p, th, nnratio, m->topk64.p, m->matches.p,
+                       m->nmatches.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = nframes; m->lastStride = stride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_projection_device(orbx_matcher *m, const orbx_projection_frame *frame, const orbx_projection_points *points,
+                                                const float *scale_factors, int nlevels, float th, float nn_ratio)
+{
+    if (!m || !frame || !points) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!frame->keypoints_un || !frame->descriptors || !frame->u_right || !frame->counts || !points->proj_x || !points->proj_y || !points->proj_xr ||
+        !points->scale_level || !points->view_cos || !points->in_view || !points->descriptors || !points->counts) {
+        orbx_set_error("NULL array in the projection arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ProjFrameDev F = {frame->keypoints_un, frame->descriptors, frame->u_right, frame->occupied, frame->counts, frame->capacity,
+                      frame->min_x, frame->min_y, frame->grid_width_inv, frame->grid_height_inv};
+    ProjPointsDev P = {points->proj_x, points->proj_y, points->proj_xr, points->scale_level, points->view_cos, points->in_view, points->has_observations,
+                       points->descriptors, points->counts, points->capacity};
+    return proj_launch(m, F, P, frame->nframes, scale_factors, nlevels, th, nn_ratio);
+}
+
+// host-array form for one frame: upload, run, download
+extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_projection_frame *fr, const orbx_projection_points *pt, const float *scale_factors,
+                                         int nlevels, float th, float nn_ratio, int32_t *assigned, int32_t *nmatches)
+{
+    if (!m || !fr || !pt || !assigned) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!fr->counts || !pt->counts) { orbx_set_error("NULL counts"); return ORBX_ERR_ARG; }
+    const int n = fr->counts[0], mm = pt->counts[0];
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < n; i++) assigned[i] = -1;
+    if (n <= 0 || mm <= 0) return ORBX_OK;
+    if (n > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    // staging: frame side in pkp / hd[0] / pf[0] / pb[0], point side in pf[1] (5 float arrays) / pi32[1] / pb[1] (in_view, has_obs, descriptors)
+    if ((rc = m->pkp.ensure((size_t)n)) || (rc = m->hd[0].ensure((size_t)n * 32)) || (rc = m->pf[0].ensure((size_t)n)) || (rc = m->pb[0].ensure((size_t)n)) ||
+        (rc = m->pi32[0].ensure(2)) || (rc = m->pf[1].ensure((size_t)mm * 4)) || (rc = m->pi32[1].ensure((size_t)mm)) || (rc = m->pb[1].ensure((size_t)mm * 34)))
+        return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, fr->keypoints_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[0].p, fr->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[0].p, fr->u_right, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (fr->occupied) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[0].p, fr->occupied, (size_t)n, hipMemcpyHostToDevice, st));
+    const int32_t cnt[2] = {n, mm};
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, pt->proj_x, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + mm, pt->proj_y, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 2 * (size_t)mm, pt->proj_xr, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 3 * (size_t)mm, pt->view_cos, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p, pt->scale_level, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p, pt->descriptors, (size_t)mm * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)mm * 32, pt->in_view, (size_t)mm, hipMemcpyHostToDevice, st));
+    if (pt->has_observations) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)mm * 33, pt->has_observations, (size_t)mm, hipMemcpyHostToDevice, st));
+    ProjFrameDev F = {m->pkp.p, m->hd[0].p, m->pf[0].p, fr->occupied ? m->pb[0].p : nullptr, m->pi32[0].p, n, fr->min_x, fr->min_y, fr->grid_width_inv,
+                      fr->grid_height_inv};
+    ProjPointsDev P = {m->pf[1].p, m->pf[1].p + mm, m->pf[1].p + 2 * (size_t)mm, m->pi32[1].p, m->pf[1].p + 3 * (size_t)mm, m->pb[1].p + (size_t)mm * 32,
+                       pt->has_observations ? m->pb[1].p + (size_t)mm * 33 : nullptr, m->pb[1].p, m->pi32[0].p + 1, mm};
+    if ((rc = proj_launch(m, F, P, 1, scale_factors, nlevels, th, nn_ratio)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    ORBX_HIP_CHECK(hipMemcpy(assigned, m->matches.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 

@@ -5,12 +5,15 @@
 //     int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&)       src/ORBmatcher.cc:230-382
 //     int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&)    src/ORBmatcher.cc:656-799
 //     int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)            src/ORBmatcher.cc:1913-1933
+//     int ORBmatcher::SearchByProjection(Frame&, const std::vector<MapPoint*>&, float)   src/ORBmatcher.cc:70-175
 // A maintainer deletes those three bodies from src/ORBmatcher.cc and adds this file to the
 // source list; the test build keeps src/ORBmatcher.cc untouched and weakens
 // the three symbols in its object file instead (oracle/Makefile, target liborbslam_hip.so).
 // Everything the reference reads from the object graph is marshalled into the flat arrays of
 // include/orbx.h; the order-dependent greedy assignment, the ratio test and the rotation
 // histogram run on the device and are index-exact (tests/test_dropin_slam.py).
+#include <string.h>
+
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -20,6 +23,8 @@
 
 // number of SearchByBoW calls served by this file (lets the drop-in test prove that the HIP
 // bodies, not the reference's, were linked)
+static unsigned long gSearchByProjectionCalls = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_by_projection_calls(void) { return gSearchByProjectionCalls; }
 static unsigned long gSearchByBoWCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_by_bow_calls(void) { return gSearchByBoWCalls; }
 
@@ -122,6 +127,42 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint
         throw std::runtime_error(std::string("ORBmatcher::SearchByBoW (orbx): ") + orbx_last_error());
     for (int i = 0; i < NA; i++)
         if (match[(size_t)i] >= 0) vpMatches12[(size_t)i] = vpMapPoints2[(size_t)match[(size_t)i]];                           // :745
+    return nmatches;
+}
+
+// Tracking::SearchLocalPoints (src/Tracking.cc:1616): the MapPoints carry what Frame::isInFrustum
+// computed (mTrackProjX/Y/XR, mnTrackScaleLevel, mTrackViewCos, mbTrackInView); the frame side is
+// mvKeysUn / mDescriptors / mvuRight, the grid constants and which features already hold a MapPoint
+// with observations (:110-112).  The greedy pass (a feature taken by an observed point blocks later
+// points) is replayed on the device in the reference's order.
+int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th)
+{
+    __atomic_add_fetch(&gSearchByProjectionCalls, 1, __ATOMIC_RELAXED);
+    const int N = F.N, M = (int)vpMapPoints.size();
+    if (N == 0 || M == 0) return 0;
+    std::vector<uint8_t> occupied((size_t)N), inView((size_t)M), hasObs((size_t)M), mpDesc((size_t)M * 32, 0);
+    for (int i = 0; i < N; i++) occupied[(size_t)i] = (F.mvpMapPoints[(size_t)i] && F.mvpMapPoints[(size_t)i]->Observations() > 0) ? 1 : 0;
+    std::vector<float> px((size_t)M), py((size_t)M), pxr((size_t)M), vc((size_t)M);
+    std::vector<int32_t> lvl((size_t)M);
+    for (int i = 0; i < M; i++) {
+        MapPoint *pMP = vpMapPoints[(size_t)i];
+        inView[(size_t)i] = (pMP->mbTrackInView && !pMP->isBad()) ? 1 : 0;                 // :79-84
+        if (!inView[(size_t)i]) continue;
+        px[(size_t)i] = pMP->mTrackProjX; py[(size_t)i] = pMP->mTrackProjY; pxr[(size_t)i] = pMP->mTrackProjXR;
+        lvl[(size_t)i] = pMP->mnTrackScaleLevel; vc[(size_t)i] = pMP->mTrackViewCos;
+        hasObs[(size_t)i] = pMP->Observations() > 0 ? 1 : 0;
+        const cv::Mat d = pMP->GetDescriptor();                                            // :106
+        memcpy(&mpDesc[32 * (size_t)i], d.ptr<unsigned char>(), 32);
+    }
+    orbx_projection_frame fr = {(const orbx_keypoint *)&F.mvKeysUn[0], F.mDescriptors.data, &F.mvuRight[0], &occupied[0], &N, N, 1,
+                                Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv};
+    orbx_projection_points pt = {&px[0], &py[0], &pxr[0], &lvl[0], &vc[0], &inView[0], &hasObs[0], &mpDesc[0], &M, M};
+    std::vector<int32_t> assigned((size_t)N);
+    int32_t nmatches = 0;
+    if (orbx_search_by_projection(Matcher(N), &fr, &pt, &F.mvScaleFactors[0], (int)F.mvScaleFactors.size(), th, mfNNratio, &assigned[0], &nmatches) != ORBX_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbx): ") + orbx_last_error());
+    for (int i = 0; i < N; i++)
+        if (assigned[(size_t)i] >= 0) F.mvpMapPoints[(size_t)i] = vpMapPoints[(size_t)assigned[(size_t)i]];               // :165
     return nmatches;
 }
 

@@ -389,3 +389,41 @@ class RefVocabulary:
         self.lib.orbslam_compute_bow.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         nb = self.lib.orbslam_compute_bow(self.h, which, _p(d), n, _p(bi), _p(bv), n + 1, _p(fvn))
         return dict(bow_ids=bi[:nb].copy(), bow_vals=bv[:nb].copy(), fv_node=fvn)
+
+
+# ---- ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th): restatement and compiled reference ----
+def _proj_args(fr, pts):
+    k7 = np.ascontiguousarray(fr["kps7"], np.float32)
+    return dict(k7=k7, desc=np.ascontiguousarray(fr["desc"], np.uint8), uR=np.ascontiguousarray(fr["u_right"], np.float32),
+                occ=np.ascontiguousarray(fr["occupied"], np.uint8), sf=np.ascontiguousarray(fr["scale_factors"], np.float32),
+                px=np.ascontiguousarray(pts["proj_x"], np.float32), py=np.ascontiguousarray(pts["proj_y"], np.float32),
+                pxr=np.ascontiguousarray(pts["proj_xr"], np.float32), lvl=np.ascontiguousarray(pts["level"], np.int32),
+                vc=np.ascontiguousarray(pts["view_cos"], np.float32), inv=np.ascontiguousarray(pts["in_view"], np.uint8),
+                obs=np.ascontiguousarray(pts["has_obs"], np.uint8), md=np.ascontiguousarray(pts["desc"], np.uint8))
+
+
+def search_by_projection(orc, fr, pts, th, nnratio):
+    a = _proj_args(fr, pts)
+    n, m = len(a["k7"]), len(a["px"])
+    W, H = fr["width"], fr["height"]
+    out = np.full(max(n, 1), -1, np.int32)
+    lib = orc.lib
+    lib.mo_search_by_projection.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_float] * 4 + [ctypes.c_void_p] * 9 + \
+                                           [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+    gw, gh = np.float32(64) / np.float32(W), np.float32(48) / np.float32(H)
+    nm = lib.mo_search_by_projection(_p(a["k7"]), _p(a["desc"]), _p(a["uR"]), _p(a["occ"]), n, 0.0, 0.0, float(gw), float(gh), _p(a["sf"]), _p(a["px"]), _p(a["py"]),
+                                     _p(a["pxr"]), _p(a["lvl"]), _p(a["vc"]), _p(a["inv"]), _p(a["obs"]), _p(a["md"]), m, th, nnratio, _p(out))
+    return nm, out[:n]
+
+
+def ref_search_by_projection(fr, pts, th, nnratio, lib=None):
+    lib = lib or slam_lib()
+    a = _proj_args(fr, pts)
+    n, m = len(a["k7"]), len(a["px"])
+    out = np.full(max(n, 1), -1, np.int32)
+    lib.orbslam_search_by_projection.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 8 + \
+                                                [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+    nm = lib.orbslam_search_by_projection(_p(a["k7"]), _p(a["desc"]), _p(a["uR"]), _p(a["occ"]), n, fr["width"], fr["height"], _p(a["sf"]), len(a["sf"]),
+                                          _p(a["px"]), _p(a["py"]), _p(a["pxr"]), _p(a["lvl"]), _p(a["vc"]), _p(a["inv"]), _p(a["obs"]), _p(a["md"]), m, th,
+                                          nnratio, _p(out))
+    return nm, out[:n]

@@ -98,3 +98,20 @@ def test_compute_bow_dropin_equals_reference(orbx, tmp_path, which):
         assert (got["bow_ids"] == want["bow_ids"]).all()
         assert (got["bow_vals"].view(np.uint64) == want["bow_vals"].view(np.uint64)).all()
     assert hip.orbx_shim_compute_bow_calls() - before == 2
+
+
+@pytest.mark.gpu
+def test_search_by_projection_dropin_equals_reference(orbx):
+    """ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) with the HIP body vs the
+    reference body, both on a real Frame and real MapPoints."""
+    from test_projection import make_case
+    orbx.load_library()
+    hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
+    hip.orbx_shim_search_by_projection_calls.restype = ctypes.c_ulong
+    before = hip.orbx_shim_search_by_projection_calls()
+    for seed, crowded, th in ((11, False, 1.0), (12, True, 3.0), (13, False, 5.0)):
+        fr, pts = make_case(seed, crowded=crowded)
+        want_n, want = oracle_lib.ref_search_by_projection(fr, pts, th, 0.8, lib=ref)
+        got_n, got = oracle_lib.ref_search_by_projection(fr, pts, th, 0.8, lib=hip)
+        assert got_n == want_n and (got == want).all() and want_n > 200
+    assert hip.orbx_shim_search_by_projection_calls() - before == 3

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Measured numbers for the BASELINE.json configs that are not bench.py's headline line:
+  config 2  batch of 256 synthetic 640x480 frames, extract only
+  config 3  KITTI-shaped stereo 1241x376, 2000 features: extract L+R + complete ComputeStereoMatches,
+            and + brute-force SearchByBoW L<->R
+  config 5  LocalBundleAdjustment on the synthetic 50-KF / 5000-point window (GPU vs the CPU oracle)
+Prints one JSON line per config.  GPU box only (python tools/bench_configs.py)."""
+import importlib
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+orbx = importlib.import_module("self_commit_orb-slam2_amd")
+
+
+def timed(fn, sync, steps, warmup=3):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def config2(B=256, W=640, H=480, nf=1000, parts=2):
+    Bs = B // parts
+    exts = [orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=Bs) for _ in range(parts)]
+    frames = orbx.synth_sequence(1, B, W, H)
+    devs = [e.upload(frames[k * Bs:(k + 1) * Bs]) for k, e in enumerate(exts)]
+    dt = timed(lambda: [e.run_device(*d) for e, d in zip(exts, devs)], lambda: [e.sync() for e in exts], 20)
+    return {"config": "2: 256 x 640x480 extract only", "frames_per_s": round(B / dt, 1), "ms_per_batch": round(dt * 1e3, 3)}
+
+
+def config3(pairs=64, W=1241, H=376, nf=2000, bf=386.1448):
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * pairs)
+    lefts = [orbx.synth_frame(1000 + i, W, H) for i in range(pairs)]
+    rights = [orbx.synth_frame(1000 + i, W, H, orbx.SYNTH_STEREO_RIGHT) for i in range(pairs)]
+    dev = ext.upload(lefts + rights)
+    mt = orbx.ORBmatcher(0.7, True, max_features=ext.capacity, max_pairs=pairs)
+    fl, fr = np.arange(pairs, dtype=np.int32), np.arange(pairs, 2 * pairs, dtype=np.int32)
+
+    def step_stereo():
+        ext.run_device(*dev)
+        mt.compute_stereo_matches_device(ext, ext, fl, fr, bf, 0.0)
+
+    def step_bow():
+        ext.run_device(*dev)
+        fs = orbx.ORBmatcher.features_of(ext, 2 * pairs)
+        mt.search_by_bow_device(fs, fs, fl, fr, mode=0, after=ext)
+
+    sync = lambda: (ext.sync(), mt.sync())
+    dt1 = timed(step_stereo, sync, 10)
+    u, z = mt.download_stereo(pairs)
+    _, _, counts = ext.download(2 * pairs)
+    dt2 = timed(step_bow, sync, 10)
+    return {"config": "3: KITTI-shaped stereo 1241x376, 2000 feat", "stereo_pairs_per_s_extract_plus_ComputeStereoMatches": round(pairs / dt1, 1),
+            "stereo_pairs_per_s_extract_plus_bruteforce_SearchByBoW": round(pairs / dt2, 1), "keypoints_per_image": round(float(counts.mean()), 1),
+            "depths_per_pair": round(float((u >= 0).sum() / pairs), 1)}
+
+
+def config5():
+    import oracle_lib
+    w = orbx.lba_synth.make_window(K=50, P=5000, seed=12345)
+    opt = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000)
+    for _ in range(2):
+        got = opt.LocalBundleAdjustment(w)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        got = opt.LocalBundleAdjustment(w)
+    wall = (time.perf_counter() - t0) / 5
+    ms, flops = opt.last_timing()
+    orc = oracle_lib.Oracle()
+    t0 = time.perf_counter()
+    want = oracle_lib.local_bundle_adjustment(orc, w)
+    cpu = time.perf_counter() - t0
+    return {"config": "5: LBA 50 KF / 5000 points / %d edges" % w["E"], "gpu_wall_ms": round(wall * 1e3, 2), "gpu_kernel_ms": round(ms, 2),
+            "fp64_gflops": round(flops / (ms * 1e-3) / 1e9, 1), "cpu_oracle_ms_1_core": round(cpu * 1e3, 1),
+            "max_abs_pose_diff": float(np.abs(got["poses"].astype(np.float64) - want["poses"]).max()),
+            "max_abs_point_diff": float(np.abs(got["points"].astype(np.float64) - want["points"]).max())}
+
+
+if __name__ == "__main__":
+    for fn in (config2, config3, config5):
+        print(json.dumps(fn()), flush=True)
