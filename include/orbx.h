@@ -279,6 +279,33 @@ int orbx_search_by_projection(orbx_matcher *m, const orbx_projection_frame *fram
                               const orbx_projection_points *points_host, const float *scale_factors, int nlevels,
                               float th, float nn_ratio, int32_t *assigned, int32_t *nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th,
+ * const bool bMono) (src/ORBmatcher.cc:1569-1728; Tracking::TrackWithMotionModel,
+ * src/Tracking.cc:1433-1441).  Last-frame side, feature i of frame f at f*capacity + i: */
+typedef struct orbx_projection_last {
+    const uint8_t *valid;            /* 1 = LastFrame.mvpMapPoints[i] != NULL && !mvbOutlier[i]             */
+    const float *world_pos;          /* [3] MapPoint::GetWorldPos()                                         */
+    const uint8_t *descriptors;      /* MapPoint::GetDescriptor(), 32 bytes                                 */
+    const uint8_t *has_observations; /* Observations()>0; NULL = all                                        */
+    const int32_t *octave;           /* LastFrame.mvKeys[i].octave                                          */
+    const float *angle;              /* LastFrame.mvKeysUn[i].angle                                         */
+    const int32_t *counts;           /* LastFrame.N per frame                                               */
+    int capacity;
+    const float *tcw_current;        /* [16] per frame: CurrentFrame.mTcw, row-major                        */
+    const float *tcw_last;           /* [16] per frame: LastFrame.mTcw                                      */
+    float fx, fy, cx, cy, mbf, mb;   /* CurrentFrame.fx .. mb                                               */
+    float max_x, max_y;              /* Frame::mnMaxX, mnMaxY (min_x/min_y are in orbx_projection_frame)    */
+} orbx_projection_last;
+/* matches[f*stride + i2] = last-frame feature whose MapPoint ends up in CurrentFrame.mvpMapPoints[i2],
+ * -1 = the call did not touch the feature, -2 = assigned and then cleared by the rotation-histogram
+ * pruning (the reference stores NULL there, :1718); nmatches[f] = return value. */
+int orbx_search_by_projection_last_device(orbx_matcher *m, const orbx_projection_frame *frame,
+                                          const orbx_projection_last *last, const float *scale_factors, int nlevels,
+                                          float th, int b_mono, int check_orientation);
+int orbx_search_by_projection_last(orbx_matcher *m, const orbx_projection_frame *frame_host,
+                                   const orbx_projection_last *last_host, const float *scale_factors, int nlevels,
+                                   float th, int b_mono, int check_orientation, int32_t *assigned, int32_t *nmatches);
+
 int orbx_matcher_results_device(orbx_matcher *m, const int32_t **matches_dev, const int32_t **dists_dev,
                                 const int32_t **nmatches_dev, int *stride);
 int orbx_matcher_download(orbx_matcher *m, int npairs, int32_t *matches, int32_t *dists, int stride,

@@ -413,6 +413,19 @@ inline MatExpr operator*(const Mat &a, const Mat &b)
 {
     assert(a.cols == b.rows && a.type() == b.type() && a.channels() == 1);
     Mat m(a.rows, b.cols, a.type());
+    if (a.depth() == CV_32F && a.cols >= 2 && a.cols <= 4) {
+        // OpenCV's gemm has a dedicated path for inner dimensions 2..4 that evaluates
+        // a0*b0 + a1*b1 (+ a2*b2 (+ a3*b3)) in the element type, left to right (matmul.dispatch.cpp,
+        // "if( flags == 0 && 2 <= len && len <= 4 ...") - the 3x3 * 3x1 products of the projection code
+        // (src/ORBmatcher.cc:1609) take it.  Restated from memory: parity unpinned at the OpenCV level.
+        for (int i = 0; i < a.rows; i++)
+            for (int j = 0; j < b.cols; j++) {
+                float s = a.at<float>(i, 0) * b.at<float>(0, j);
+                for (int k = 1; k < a.cols; k++) s = s + a.at<float>(i, k) * b.at<float>(k, j);
+                m.at<float>(i, j) = s;
+            }
+        return MatExpr(m);
+    }
     for (int i = 0; i < a.rows; i++)
         for (int j = 0; j < b.cols; j++) {
             double s = 0;

@@ -389,3 +389,132 @@ MO_API int mo_search_by_projection(const float *kpUn, const uint8_t *desc, const
     }
     return nmatches;
 }
+
+// ---------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th,
+// const bool bMono) (src/ORBmatcher.cc:1569-1728), the matcher of Tracking::TrackWithMotionModel.
+// Last-frame side per feature i: valid[i] = mvpMapPoints[i] != NULL && !mvbOutlier[i], the
+// MapPoint's world position, descriptor and Observations()>0, mvKeys[i].octave, mvKeysUn[i].angle.
+// Projection arithmetic in float, left to right, no contraction (the small-matrix path of
+// OpenCV's gemm as restated in oracle/cvshim).  assigned[i2] = last-frame feature whose MapPoint
+// was written into CurrentFrame.mvpMapPoints[i2]; -1 = untouched, -2 = written and then cleared by the
+// rotation pruning.
+// ---------------------------------------------------------------------------------------
+MO_API int mo_search_by_projection_last(const float *kpUn, const uint8_t *desc, const float *uRight, const uint8_t *occupied_in, int n, float minX,
+                                        float minY, float maxX, float maxY, float gridWInv, float gridHInv, const float *scaleFactors,
+                                        const float *TcwCur, const float *TcwLast, float fx, float fy, float cx, float cy, float mbf, float mb,
+                                        const uint8_t *lastValid, const float *lastPos, const uint8_t *lastDesc, const uint8_t *lastHasObs,
+                                        const int32_t *lastOctave, const float *lastAngle, int nLast, float th, int bMono, int checkOri,
+                                        int32_t *assigned)
+{
+    std::vector<std::vector<size_t> > grid((size_t)GRID_COLS * GRID_ROWS);
+    for (int i = 0; i < n; i++) {
+        const int posX = (int)roundf((kpUn[7 * i] - minX) * gridWInv), posY = (int)roundf((kpUn[7 * i + 1] - minY) * gridHInv);
+        if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
+        grid[(size_t)posX * GRID_ROWS + posY].push_back((size_t)i);
+    }
+    std::vector<uint8_t> occupied(occupied_in, occupied_in + n);
+    for (int i = 0; i < n; i++) assigned[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;
+    // Rcw, tcw of the current frame; twc = -Rcw^T * tcw; tlc = Rlw*twc + tlw  (:1586-1596)
+    const float *Rc = TcwCur, *Rl = TcwLast;   // row-major 4x4
+    float twc[3], tlc[3];
+    for (int r = 0; r < 3; r++) {
+        float s = (-Rc[0 * 4 + r]) * Rc[0 * 4 + 3];
+        s = s + (-Rc[1 * 4 + r]) * Rc[1 * 4 + 3];
+        s = s + (-Rc[2 * 4 + r]) * Rc[2 * 4 + 3];
+        twc[r] = s;
+    }
+    for (int r = 0; r < 3; r++) {
+        float s = Rl[r * 4 + 0] * twc[0];
+        s = s + Rl[r * 4 + 1] * twc[1];
+        s = s + Rl[r * 4 + 2] * twc[2];
+        tlc[r] = s + Rl[r * 4 + 3];
+    }
+    const bool bForward = tlc[2] > mb && !bMono, bBackward = -tlc[2] > mb && !bMono;
+    for (int i = 0; i < nLast; i++) {
+        if (!lastValid[i]) continue;
+        const float *X = lastPos + 3 * (size_t)i;
+        float x3Dc[3];
+        for (int r = 0; r < 3; r++) {
+            float s = Rc[r * 4 + 0] * X[0];
+            s = s + Rc[r * 4 + 1] * X[1];
+            s = s + Rc[r * 4 + 2] * X[2];
+            x3Dc[r] = s + Rc[r * 4 + 3];
+        }
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = 1.0 / x3Dc[2];
+        if (invzc < 0) continue;
+        float u = fx * xc * invzc + cx, v = fy * yc * invzc + cy;
+        if (u < minX || u > maxX) continue;
+        if (v < minY || v > maxY) continue;
+        const int nLastOctave = lastOctave[i];
+        const float radius = th * scaleFactors[nLastOctave];
+        int minLevel, maxLevel;
+        if (bForward) { minLevel = nLastOctave; maxLevel = -1; }
+        else if (bBackward) { minLevel = 0; maxLevel = nLastOctave; }
+        else { minLevel = nLastOctave - 1; maxLevel = nLastOctave + 1; }
+        std::vector<size_t> vIndices2;
+        do {
+            const int nMinCellX = std::max(0, (int)floor((u - minX - radius) * gridWInv));
+            if (nMinCellX >= GRID_COLS) break;
+            const int nMaxCellX = std::min(GRID_COLS - 1, (int)ceil((u - minX + radius) * gridWInv));
+            if (nMaxCellX < 0) break;
+            const int nMinCellY = std::max(0, (int)floor((v - minY - radius) * gridHInv));
+            if (nMinCellY >= GRID_ROWS) break;
+            const int nMaxCellY = std::min(GRID_ROWS - 1, (int)ceil((v - minY + radius) * gridHInv));
+            if (nMaxCellY < 0) break;
+            const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+                for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                    const std::vector<size_t> &vCell = grid[(size_t)ix * GRID_ROWS + iy];
+                    for (size_t j = 0; j < vCell.size(); j++) {
+                        const float *kp = kpUn + 7 * vCell[j];
+                        const int oct = (int)kp[5];
+                        if (bCheckLevels) {
+                            if (oct < minLevel) continue;
+                            if (maxLevel >= 0 && oct > maxLevel) continue;
+                        }
+                        const float distx = kp[0] - u, disty = kp[1] - v;
+                        if (fabs(distx) < radius && fabs(disty) < radius) vIndices2.push_back(vCell[j]);
+                    }
+                }
+        } while (0);
+        if (vIndices2.empty()) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t k = 0; k < vIndices2.size(); k++) {
+            const size_t i2 = vIndices2[k];
+            if (occupied[i2]) continue;
+            if (uRight[i2] > 0) {
+                const float ur = u - mbf * invzc;
+                const float er = fabs(ur - uRight[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = descriptor_distance(lastDesc + 32 * (size_t)i, desc + 32 * i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            assigned[bestIdx2] = i;
+            occupied[(size_t)bestIdx2] = lastHasObs[i] ? 1 : 0;
+            nmatches++;
+            if (checkOri) {
+                float rot = lastAngle[i] - kpUn[7 * bestIdx2 + 3];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { assigned[rotHist[i][j]] = -2; nmatches--; }   // -2: assigned, then set to NULL (:1718)
+        }
+    }
+    return nmatches;
+}

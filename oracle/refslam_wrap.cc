@@ -458,3 +458,60 @@ ORBSLAM_API int orbslam_search_by_projection(const float *kpUn, const uint8_t *d
     delete kf;
     return nm;
 }
+
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+// (src/ORBmatcher.cc:1569-1728) on two real Frames; the last frame's MapPoints are real objects
+// with the given world positions, descriptors (Frame-based constructor) and observation state.
+ORBSLAM_API int orbslam_search_by_projection_last(const float *kpUn, const uint8_t *desc, const float *uRight, const uint8_t *occupied, int n, int width,
+                                                  int height, const float *scaleFactors, int nlevels, const float *TcwCur, const float *TcwLast, float fx,
+                                                  float fy, float cx, float cy, float bf, const uint8_t *lastValid, const float *lastPos,
+                                                  const uint8_t *lastDesc, const uint8_t *lastHasObs, const float *lastKps, int nLast, float th, int bMono,
+                                                  int checkOri, int32_t *assigned)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {fx, fy, cx, cy, bf, width, height};
+    Frame C, L;
+    fill_frame(C, kpUn, desc, n, nullptr, cam, scaleFactors, nlevels);
+    for (int i = 0; i < n; i++) C.mvuRight[(size_t)i] = uRight[i];
+    fill_frame(L, lastKps, lastDesc, nLast, nullptr, cam, scaleFactors, nlevels);
+    cv::Mat Tc(4, 4, CV_32F), Tl(4, 4, CV_32F);
+    memcpy(Tc.data, TcwCur, 64);
+    memcpy(Tl.data, TcwLast, 64);
+    C.SetPose(Tc);
+    L.SetPose(Tl);
+    KeyFrame *kf = new KeyFrame(L, &map, (KeyFrameDatabase *)nullptr);
+    std::vector<MapPoint *> owned;
+    std::map<MapPoint *, int> index;
+    for (int i = 0; i < nLast; i++) {
+        // every last-frame feature gets a MapPoint when lastValid != 0; value 2 marks it as an outlier of the last frame
+        if (!lastValid[i]) continue;
+        cv::Mat pos(3, 1, CV_32F);
+        memcpy(pos.data, lastPos + 3 * (size_t)i, 12);
+        MapPoint *mp = new MapPoint(pos, &map, &L, i);
+        if (lastHasObs[i]) mp->AddObservation(kf, (size_t)i);
+        L.mvpMapPoints[(size_t)i] = mp;
+        L.mvbOutlier[(size_t)i] = lastValid[i] == 2;
+        index[mp] = i;
+        owned.push_back(mp);
+    }
+    cv::Mat zero = cv::Mat::zeros(3, 1, CV_32F);
+    for (int i = 0; i < n; i++)
+        if (occupied[i]) {
+            MapPoint *mp = new MapPoint(zero, &map, &L, 0);
+            mp->AddObservation(kf, 0);
+            C.mvpMapPoints[(size_t)i] = mp;
+            index[mp] = -2;
+            owned.push_back(mp);
+        }
+    ORBmatcher matcher(0.9f, checkOri != 0);
+    const int nm = matcher.SearchByProjection(C, L, th, bMono != 0);
+    for (int i = 0; i < n; i++) {
+        MapPoint *mp = C.mvpMapPoints[(size_t)i];
+        const int k = mp ? index[mp] : -1;
+        assigned[i] = k >= 0 ? k : -1;
+    }
+    for (size_t i = 0; i < owned.size(); i++) delete owned[i];
+    delete kf;
+    return nm;
+}

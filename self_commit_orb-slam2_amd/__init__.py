@@ -297,6 +297,13 @@ class ProjectionPoints(ctypes.Structure):
                 ("counts", ctypes.c_void_p), ("capacity", ctypes.c_int)]
 
 
+class ProjectionLast(ctypes.Structure):
+    _fields_ = [("valid", ctypes.c_void_p), ("world_pos", ctypes.c_void_p), ("descriptors", ctypes.c_void_p), ("has_observations", ctypes.c_void_p),
+                ("octave", ctypes.c_void_p), ("angle", ctypes.c_void_p), ("counts", ctypes.c_void_p), ("capacity", ctypes.c_int),
+                ("tcw_current", ctypes.c_void_p), ("tcw_last", ctypes.c_void_p), ("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float),
+                ("cy", ctypes.c_float), ("mbf", ctypes.c_float), ("mb", ctypes.c_float), ("max_x", ctypes.c_float), ("max_y", ctypes.c_float)]
+
+
 class BowParams(ctypes.Structure):
     _fields_ = [("nn_ratio", ctypes.c_float), ("check_orientation", ctypes.c_int), ("mode", ctypes.c_int)]
 
@@ -320,6 +327,7 @@ def _bind_matcher(L):
     L.orbx_search_by_bow.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), ctypes.POINTER(BowParams), vp, vp]
     L.orbx_stereo_match.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, ci, ctypes.c_float, vp, vp]
     L.orbx_matcher_last_timing.argtypes = [vp, vp]
+    L.orbx_search_by_projection_last.argtypes = [vp, ctypes.POINTER(ProjectionFrame), ctypes.POINTER(ProjectionLast), vp, ci, ctypes.c_float, ci, ci, vp, vp]
     L.orbx_search_by_projection.argtypes = [vp, ctypes.POINTER(ProjectionFrame), ctypes.POINTER(ProjectionPoints), vp, ci, ctypes.c_float, ctypes.c_float, vp, vp]
     L.orbx_matcher_last_kernel_timing.argtypes = [vp, vp, vp]
     L._matcher_bound = True
@@ -416,6 +424,40 @@ class ORBmatcher:
         nm = ctypes.c_int32()
         _check(self._L.orbx_search_by_projection(self._h, ctypes.byref(F), ctypes.byref(P), _ptr(sf), len(sf), ctypes.c_float(th),
                                                  ctypes.c_float(self.nnratio if nnratio is None else nnratio), _ptr(out), ctypes.byref(nm)))
+        return nm.value, out[:n]
+
+    def SearchByProjectionLast(self, frame, last, th, mono):
+        """ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (reference
+        src/ORBmatcher.cc:1569-1728).  frame: as SearchByProjection plus Tcw (4x4) and cam (fx, fy, cx, cy, bf);
+        last: dict(Tcw, valid, pos, desc, has_obs, kps (structured; octave of mvKeys, angle of mvKeysUn)).
+        Returns (nmatches, assigned[n]): assigned[i2] = last-frame feature whose MapPoint is in mvpMapPoints[i2], or -1."""
+        k = np.ascontiguousarray(frame["kps"], KEYPOINT_DTYPE)
+        n = len(k)
+        d = np.ascontiguousarray(frame["desc"], np.uint8)
+        ur = np.ascontiguousarray(frame["u_right"], np.float32)
+        occ = np.ascontiguousarray(frame["occupied"], np.uint8)
+        sf = np.ascontiguousarray(frame["scale_factors"], np.float32)
+        minx, miny = np.float32(frame.get("min_x", 0.0)), np.float32(frame.get("min_y", 0.0))
+        maxx, maxy = np.float32(frame.get("max_x", frame["width"])), np.float32(frame.get("max_y", frame["height"]))
+        gw, gh = np.float32(64) / (maxx - minx), np.float32(48) / (maxy - miny)
+        lk = np.ascontiguousarray(last["kps"], KEYPOINT_DTYPE)
+        nl = len(lk)
+        cn, cl = np.array([n], np.int32), np.array([nl], np.int32)
+        valid = np.ascontiguousarray(last["valid"], np.uint8)
+        pos = np.ascontiguousarray(last["pos"], np.float32)
+        ld = np.ascontiguousarray(last["desc"], np.uint8)
+        obs = np.ascontiguousarray(last["has_obs"], np.uint8)
+        octv = np.ascontiguousarray(lk["octave"], np.int32)
+        ang = np.ascontiguousarray(lk["angle"], np.float32)
+        tc, tl = np.ascontiguousarray(frame["Tcw"], np.float32), np.ascontiguousarray(last["Tcw"], np.float32)
+        fx, fy, cx, cy, bf = [np.float32(v) for v in frame["cam"]]
+        F = ProjectionFrame(_ptr(k).value, _ptr(d).value, _ptr(ur).value, _ptr(occ).value, _ptr(cn).value, n, 1, float(minx), float(miny), float(gw), float(gh))
+        Ls = ProjectionLast(_ptr(valid).value, _ptr(pos).value, _ptr(ld).value, _ptr(obs).value, _ptr(octv).value, _ptr(ang).value, _ptr(cl).value, nl,
+                            _ptr(tc).value, _ptr(tl).value, float(fx), float(fy), float(cx), float(cy), float(bf), float(bf / fx), float(maxx), float(maxy))
+        out = np.full(max(n, 1), -1, np.int32)
+        nm = ctypes.c_int32()
+        _check(self._L.orbx_search_by_projection_last(self._h, ctypes.byref(F), ctypes.byref(Ls), _ptr(sf), len(sf), ctypes.c_float(th), 1 if mono else 0,
+                                                      1 if self.checkOri else 0, _ptr(out), ctypes.byref(nm)))
         return nm.value, out[:n]
 
     def StereoHamming(self, kpsL, descL, kpsR, descR, scale_factors, max_disparity=float("inf")):

@@ -605,7 +605,7 @@ __device__ __forceinline__ unsigned long long proj_key(const ProjFrameDev &F, si
     const orbx_keypoint k = F.kp[fbase + idx];
     const int cx = (int)roundf((k.x - F.minX) * F.gwInv), cy = (int)roundf((k.y - F.minY) * F.ghInv);   // PosInGrid, :866-867
     if (cx < q.cx0 || cx > q.cx1 || cy < q.cy0 || cy > q.cy1) return KEY64_EMPTY;   // (also: feature outside the grid)
-    if (k.octave < q.minLevel || k.octave > q.maxLevel) return KEY64_EMPTY;
+    if (k.octave < q.minLevel || (q.maxLevel >= 0 && k.octave > q.maxLevel)) return KEY64_EMPTY;   // GetFeaturesInArea bCheckLevels, :814-822
     const float distx = k.x - q.x, disty = k.y - q.y;
     if (!(fabsf(distx) < q.rr && fabsf(disty) < q.rr)) return KEY64_EMPTY;
     const float ur = F.uRight[fbase + idx];
@@ -722,6 +722,217 @@ __global__ __launch_bounds__(256) void k_proj_greedy(ProjFrameDev F, ProjPointsD
         }
     }
     if (lane == 0) nmatches[f] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)
+// (src/ORBmatcher.cc:1569-1728), the matcher of Tracking::TrackWithMotionModel: every MapPoint of
+// the last frame is projected with the current pose (float arithmetic in the reference's order),
+// searched in a window whose pyramid-level range depends on forward / backward motion, and given
+// to the free feature of minimum distance; rotation histogram pruning at the end.
+// ---------------------------------------------------------------------------------------------
+struct ProjLastDev { const uint8_t *valid; const float *pos; const uint8_t *desc, *hasObs; const int32_t *octave; const float *angle; const int32_t *counts;
+                     int cap; const float *tcwCur, *tcwLast; float fx, fy, cx, cy, mbf, mb, maxX, maxY; };
+
+__device__ __forceinline__ void proj_motion(const float *Rc, const float *Rl, float mb, int bMono, bool &bForward, bool &bBackward)
+{
+    float twc[3], tlcz;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        float s = (-Rc[0 * 4 + r]) * Rc[0 * 4 + 3];
+        s = s + (-Rc[1 * 4 + r]) * Rc[1 * 4 + 3];
+        s = s + (-Rc[2 * 4 + r]) * Rc[2 * 4 + 3];
+        twc[r] = s;
+    }
+    {
+        float s = Rl[2 * 4 + 0] * twc[0];
+        s = s + Rl[2 * 4 + 1] * twc[1];
+        s = s + Rl[2 * 4 + 2] * twc[2];
+        tlcz = s + Rl[2 * 4 + 3];
+    }
+    bForward = tlcz > mb && !bMono;
+    bBackward = -tlcz > mb && !bMono;
+}
+
+// query of last-frame feature li; false when the point is skipped before the window search (:1604-1633)
+__device__ __forceinline__ bool proj_last_query(const ProjFrameDev &F, const ProjLastDev &L, int f, size_t li, const float *scaleFactors, float th,
+                                                bool bForward, bool bBackward, ProjQuery &q)
+{
+    if (L.valid[li] != 1) return false;
+    const float *Rc = L.tcwCur + 16 * (size_t)f, *X = L.pos + 3 * li;
+    float x3Dc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        float s = Rc[r * 4 + 0] * X[0];
+        s = s + Rc[r * 4 + 1] * X[1];
+        s = s + Rc[r * 4 + 2] * X[2];
+        x3Dc[r] = s + Rc[r * 4 + 3];
+    }
+    const float invzc = (float)(1.0 / (double)x3Dc[2]);
+    if (invzc < 0) return false;
+    const float u = L.fx * x3Dc[0] * invzc + L.cx, v = L.fy * x3Dc[1] * invzc + L.cy;
+    if (u < F.minX || u > L.maxX) return false;
+    if (v < F.minY || v > L.maxY) return false;
+    const int oct = L.octave[li];
+    const float radius = th * scaleFactors[oct];
+    q.x = u; q.y = v; q.rr = radius; q.xr = u - L.mbf * invzc;
+    if (bForward) { q.minLevel = oct; q.maxLevel = -1; }
+    else if (bBackward) { q.minLevel = 0; q.maxLevel = oct; }
+    else { q.minLevel = oct - 1; q.maxLevel = oct + 1; }
+    const int nMinCellX = max(0, (int)floorf((u - F.minX - radius) * F.gwInv)), nMaxCellX = min(GRID_COLS - 1, (int)ceilf((u - F.minX + radius) * F.gwInv));
+    const int nMinCellY = max(0, (int)floorf((v - F.minY - radius) * F.ghInv)), nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((v - F.minY + radius) * F.ghInv));
+    q.any = !(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0);
+    q.cx0 = nMinCellX; q.cx1 = nMaxCellX; q.cy0 = nMinCellY; q.cy1 = nMaxCellY;
+    const unsigned long long *dp = (const unsigned long long *)(L.desc + li * 32);
+    q.d[0] = dp[0]; q.d[1] = dp[1]; q.d[2] = dp[2]; q.d[3] = dp[3];
+    return q.any;
+}
+
+__global__ __launch_bounds__(256) void k_proj_last_topk(ProjFrameDev F, ProjLastDev L, const float *__restrict__ scaleFactors, float th, int bMono,
+                                                        unsigned long long *__restrict__ topk)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(F.counts[f], F.cap), nl = min(L.counts[f], L.cap);
+    if (i >= nl) return;
+    const size_t li = (size_t)f * L.cap + i, fbase = (size_t)f * F.cap;
+    unsigned long long *out = topk + li * TOPK;
+    bool bForward, bBackward;
+    proj_motion(L.tcwCur + 16 * (size_t)f, L.tcwLast + 16 * (size_t)f, L.mb, bMono, bForward, bBackward);
+    ProjQuery q;
+    if (!proj_last_query(F, L, f, li, scaleFactors, th, bForward, bBackward, q)) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
+    unsigned long long kk[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; t++) kk[t] = KEY64_EMPTY;
+    for (int idx = lane; idx < n; idx += 64) {
+        const unsigned long long key = proj_key(F, fbase, idx, q);
+        if (key < kk[TOPK - 1]) {
+            kk[TOPK - 1] = key;
+#pragma unroll
+            for (int t = TOPK - 1; t > 0; t--)
+                if (kk[t] < kk[t - 1]) { const unsigned long long v = kk[t - 1]; kk[t - 1] = kk[t]; kk[t] = v; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TOPK; k++) {
+        const unsigned long long mn = wave_min_u64(kk[0]);
+        if (kk[0] == mn && mn != KEY64_EMPTY) {
+#pragma unroll
+            for (int t = 0; t < TOPK - 1; t++) kk[t] = kk[t + 1];
+            kk[TOPK - 1] = KEY64_EMPTY;
+        }
+        if (lane == 0) out[k] = mn;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_proj_last_greedy(ProjFrameDev F, ProjLastDev L, const float *__restrict__ scaleFactors, float th, int bMono,
+                                                          int checkOri, const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
+                                                          int32_t *__restrict__ nmatches, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int sTotal, sRemoved;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = min(F.counts[f], F.cap), nl = min(L.counts[f], L.cap);
+    unsigned char *occ = smem;                              // [cap]
+    int32_t *sAsg = (int32_t *)(smem + ((F.cap + 15) & ~15));   // [cap] last-frame feature given to current feature i2, or -1
+    uint32_t *sEv = (uint32_t *)(sAsg + F.cap);             // [L.cap] accepted assignments in order: point << 16 | feature
+    const size_t fbase = (size_t)f * F.cap, lbase = (size_t)f * L.cap;
+    int32_t *aout = assigned + (size_t)f * stride;
+    for (int i = tid; i < F.cap; i += 256) { sAsg[i] = -1; occ[i] = (i < n && F.occupied) ? F.occupied[fbase + i] : 0; }
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) { sTotal = 0; sRemoved = 0; }
+    __syncthreads();
+    if (tid < 64) {
+        bool bForward, bBackward;
+        proj_motion(L.tcwCur + 16 * (size_t)f, L.tcwLast + 16 * (size_t)f, L.mb, bMono, bForward, bBackward);
+        int total = 0;
+        const unsigned long long *tk = topk + lbase * TOPK;
+        unsigned long long nextKeys = (0 < nl) ? tk[min((size_t)lane, (size_t)nl * TOPK - 1)] : KEY64_EMPTY;
+        for (int i0 = 0; i0 < nl; i0 += 8) {
+            const unsigned long long keys = nextKeys;
+            {
+                const size_t nx = (size_t)(i0 + 8) * TOPK + lane;
+                nextKeys = (i0 + 8 < nl) ? tk[min(nx, (size_t)nl * TOPK - 1)] : KEY64_EMPTY;
+            }
+            for (int j = 0; j < 8 && i0 + j < nl; j++) {
+                const int i = i0 + j;
+                const unsigned long long key = __shfl(keys, 8 * j + (lane & 7));
+                const bool present = lane < TOPK && key != KEY64_EMPTY;
+                const unsigned mAll = (1u << TOPK) - 1u;
+                const unsigned mPresent = (unsigned)(__ballot(present) & mAll);
+                if (!mPresent) continue;                    // skipped point or empty window
+                const bool free_ = present && !occ[(int)(key & 0xffff)];
+                const unsigned mFree = (unsigned)(__ballot(free_) & mAll);
+                unsigned long long k1 = KEY64_EMPTY;
+                if (mFree) k1 = __shfl(key, __ffs(mFree) - 1);
+                else if (mPresent == mAll) {
+                    // every listed candidate is taken and the list was full: exact rescan for the best free one
+                    ProjQuery q;
+                    unsigned long long a = KEY64_EMPTY;
+                    if (proj_last_query(F, L, f, lbase + i, scaleFactors, th, bForward, bBackward, q))
+                        for (int x = lane; x < n; x += 64) {
+                            if (occ[x]) continue;
+                            const unsigned long long kx = proj_key(F, fbase, x, q);
+                            a = kx < a ? kx : a;
+                        }
+                    k1 = wave_min_u64(a);
+                }
+                if (k1 == KEY64_EMPTY) continue;
+                const int bestDist = (int)(k1 >> 32), bestIdx2 = (int)(k1 & 0xffff);
+                if (bestDist <= TH_HIGH) {
+                    if (lane == 0) {
+                        sAsg[bestIdx2] = i;                                     // CurrentFrame.mvpMapPoints[bestIdx2] = pMP
+                        occ[bestIdx2] = L.hasObs ? L.hasObs[lbase + i] : 1;
+                        sEv[total] = ((uint32_t)i << 16) | (uint32_t)bestIdx2;
+                    }
+                    total++;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (lane == 0) sTotal = total;
+    }
+    __syncthreads();
+    // rotation histogram over the ACCEPTED assignments in the order they were made (:1694-1704): a
+    // feature whose first holder had no observations can be re-assigned later and then sits in two
+    // bins; pruning a bin clears the feature whichever holder put it there (:1712-1722).
+    const float factor = HISTO_LENGTH / 360.0f;
+    if (checkOri) {
+        const int nev = sTotal;
+        for (int e = tid; e < nev; e += 256) {
+            const uint32_t ev = sEv[e];
+            const int li = (int)(ev >> 16), i2 = (int)(ev & 0xffff);
+            float rot = L.angle[lbase + li] - F.kp[fbase + i2].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            sEv[e] = (ev & 0xffffu) | ((uint32_t)bin << 16);   // keep feature + bin
+            atomicAdd(&hist[bin], 1);
+        }
+        __syncthreads();
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            const int sN = hist[b];
+            if (sN > max1) { max3 = max2; max2 = max1; max1 = sN; ind3 = ind2; ind2 = ind1; ind1 = b; }
+            else if (sN > max2) { max3 = max2; max2 = sN; ind3 = ind2; ind2 = b; }
+            else if (sN > max3) { max3 = sN; ind3 = b; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        int removed = 0;
+        for (int e = tid; e < nev; e += 256) {
+            const uint32_t ev = sEv[e];
+            const int b = (int)(ev >> 16);
+            if (b != ind1 && b != ind2 && b != ind3) { sAsg[ev & 0xffffu] = -2; removed++; }   // -2: assigned, then cleared (:1718)
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+        if (lane == 0 && removed) atomicAdd(&sRemoved, removed);
+    }
+    __syncthreads();
+    for (int i = tid; i < stride; i += 256) aout[i] = i < n ? sAsg[i] : -1;
+    if (tid == 0) nmatches[f] = sTotal - sRemoved;
 }
 
 template <typename T> struct MBuf {
@@ -1084,6 +1295,95 @@ extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_projection_
     ProjPointsDev P = {m->pf[1].p, m->pf[1].p + mm, m->pf[1].p + 2 * (size_t)mm, m->pi32[1].p, m->pf[1].p + 3 * (size_t)mm, m->pb[1].p + (size_t)mm * 32,
                        pt->has_observations ? m->pb[1].p + (size_t)mm * 33 : nullptr, m->pb[1].p, m->pi32[0].p + 1, mm};
     if ((rc = proj_launch(m, F, P, 1, scale_factors, nlevels, th, nn_ratio)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    ORBX_HIP_CHECK(hipMemcpy(assigned, m->matches.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+static int proj_last_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjLastDev &L, int nframes, const float *scale_factors, int nlevels, float th,
+                            int b_mono, int check_ori)
+{
+    if (nframes < 1 || nframes > m->maxPairs) { orbx_set_error("nframes %d outside 1..%d", nframes, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (F.cap < 1 || F.cap > m->maxFeatures || F.cap > 65535 || L.cap < 1 || L.cap > 65535) { orbx_set_error("bad capacities (features %d, last %d)", F.cap, L.cap); return ORBX_ERR_CAPACITY; }
+    if (!scale_factors || nlevels < 1 || nlevels > 64) { orbx_set_error("bad scale factor table"); return ORBX_ERR_ARG; }
+    int rc = m->topk64.ensure((size_t)nframes * L.cap * TOPK);
+    if (rc != ORBX_OK) return rc;
+    const int stride = m->maxFeatures;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->scales.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_proj_last_topk, dim3((unsigned)((L.cap + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, F, L, m->scales.p, th, b_mono, m->topk64.p);
+    MLAUNCH_CHECK();
+    const size_t lds = (size_t)((F.cap + 15) & ~15) + (size_t)F.cap * 4 + (size_t)L.cap * 4 + 16;
+    if (lds > 160 * 1024) { orbx_set_error("capacities too large for the LDS tile"); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_last_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_proj_last_greedy, dim3((unsigned)nframes), dim3(256), lds, m->stream, F, L, m->scales.p, th, b_mono, check_ori, m->topk64.p,
+                       m->matches.p, m->nmatches.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = nframes; m->lastStride = stride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_projection_last_device(orbx_matcher *m, const orbx_projection_frame *frame, const orbx_projection_last *last,
+                                                     const float *scale_factors, int nlevels, float th, int b_mono, int check_orientation)
+{
+    if (!m || !frame || !last) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!frame->keypoints_un || !frame->descriptors || !frame->u_right || !frame->counts || !last->valid || !last->world_pos || !last->descriptors ||
+        !last->octave || !last->angle || !last->counts || !last->tcw_current || !last->tcw_last) {
+        orbx_set_error("NULL array in the projection arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ProjFrameDev F = {frame->keypoints_un, frame->descriptors, frame->u_right, frame->occupied, frame->counts, frame->capacity,
+                      frame->min_x, frame->min_y, frame->grid_width_inv, frame->grid_height_inv};
+    ProjLastDev L = {last->valid, last->world_pos, last->descriptors, last->has_observations, last->octave, last->angle, last->counts, last->capacity,
+                     last->tcw_current, last->tcw_last, last->fx, last->fy, last->cx, last->cy, last->mbf, last->mb, last->max_x, last->max_y};
+    return proj_last_launch(m, F, L, frame->nframes, scale_factors, nlevels, th, b_mono, check_orientation);
+}
+
+extern "C" int orbx_search_by_projection_last(orbx_matcher *m, const orbx_projection_frame *fr, const orbx_projection_last *ls, const float *scale_factors,
+                                              int nlevels, float th, int b_mono, int check_orientation, int32_t *assigned, int32_t *nmatches)
+{
+    if (!m || !fr || !ls || !assigned) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!fr->counts || !ls->counts) { orbx_set_error("NULL counts"); return ORBX_ERR_ARG; }
+    const int n = fr->counts[0], nl = ls->counts[0];
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < n; i++) assigned[i] = -1;
+    if (n <= 0 || nl <= 0) return ORBX_OK;
+    if (n > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    // staging: frame side as in orbx_search_by_projection; last side: pf[1] = pos(3) | angle(1) | tcw cur(16) | tcw last(16), pi32[1] = octave,
+    // pb[1] = descriptors(32) | valid(1) | has_obs(1)
+    if ((rc = m->pkp.ensure((size_t)n)) || (rc = m->hd[0].ensure((size_t)n * 32)) || (rc = m->pf[0].ensure((size_t)n)) || (rc = m->pb[0].ensure((size_t)n)) ||
+        (rc = m->pi32[0].ensure(2)) || (rc = m->pf[1].ensure((size_t)nl * 4 + 32)) || (rc = m->pi32[1].ensure((size_t)nl)) || (rc = m->pb[1].ensure((size_t)nl * 34)))
+        return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, fr->keypoints_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[0].p, fr->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[0].p, fr->u_right, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (fr->occupied) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[0].p, fr->occupied, (size_t)n, hipMemcpyHostToDevice, st));
+    const int32_t cnt[2] = {n, nl};
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+    float *pf = m->pf[1].p;
+    ORBX_HIP_CHECK(hipMemcpyAsync(pf, ls->world_pos, (size_t)nl * 12, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(pf + 3 * (size_t)nl, ls->angle, (size_t)nl * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(pf + 4 * (size_t)nl, ls->tcw_current, 64, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(pf + 4 * (size_t)nl + 16, ls->tcw_last, 64, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p, ls->octave, (size_t)nl * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p, ls->descriptors, (size_t)nl * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)nl * 32, ls->valid, (size_t)nl, hipMemcpyHostToDevice, st));
+    if (ls->has_observations) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)nl * 33, ls->has_observations, (size_t)nl, hipMemcpyHostToDevice, st));
+    ProjFrameDev F = {m->pkp.p, m->hd[0].p, m->pf[0].p, fr->occupied ? m->pb[0].p : nullptr, m->pi32[0].p, n, fr->min_x, fr->min_y, fr->grid_width_inv,
+                      fr->grid_height_inv};
+    ProjLastDev L = {m->pb[1].p + (size_t)nl * 32, pf, m->pb[1].p, ls->has_observations ? m->pb[1].p + (size_t)nl * 33 : nullptr, m->pi32[1].p,
+                     pf + 3 * (size_t)nl, m->pi32[0].p + 1, nl, pf + 4 * (size_t)nl, pf + 4 * (size_t)nl + 16, ls->fx, ls->fy, ls->cx, ls->cy, ls->mbf, ls->mb,
+                     ls->max_x, ls->max_y};
+    if ((rc = proj_last_launch(m, F, L, 1, scale_factors, nlevels, th, b_mono, check_orientation)) != ORBX_OK) return rc;
     ORBX_HIP_CHECK(hipStreamSynchronize(st));
     ORBX_HIP_CHECK(hipMemcpy(assigned, m->matches.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));

@@ -6,6 +6,7 @@
 //     int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&)    src/ORBmatcher.cc:656-799
 //     int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)            src/ORBmatcher.cc:1913-1933
 //     int ORBmatcher::SearchByProjection(Frame&, const std::vector<MapPoint*>&, float)   src/ORBmatcher.cc:70-175
+//     int ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)              src/ORBmatcher.cc:1569-1728
 // A maintainer deletes those three bodies from src/ORBmatcher.cc and adds this file to the
 // source list; the test build keeps src/ORBmatcher.cc untouched and weakens
 // the three symbols in its object file instead (oracle/Makefile, target liborbslam_hip.so).
@@ -163,6 +164,51 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
         throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbx): ") + orbx_last_error());
     for (int i = 0; i < N; i++)
         if (assigned[(size_t)i] >= 0) F.mvpMapPoints[(size_t)i] = vpMapPoints[(size_t)assigned[(size_t)i]];               // :165
+    return nmatches;
+}
+
+// Tracking::TrackWithMotionModel (src/Tracking.cc:1433-1441): the last frame's MapPoints are
+// projected with the current pose on the device (float arithmetic in the reference's order).
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+{
+    __atomic_add_fetch(&gSearchByProjectionCalls, 1, __ATOMIC_RELAXED);
+    const int N = CurrentFrame.N, NL = LastFrame.N;
+    if (N == 0 || NL == 0) return 0;
+    std::vector<uint8_t> occupied((size_t)N), valid((size_t)NL, 0), hasObs((size_t)NL, 0), lastDesc((size_t)NL * 32, 0);
+    for (int i = 0; i < N; i++)
+        occupied[(size_t)i] = (CurrentFrame.mvpMapPoints[(size_t)i] && CurrentFrame.mvpMapPoints[(size_t)i]->Observations() > 0) ? 1 : 0;   // :1647-1649
+    std::vector<float> pos((size_t)NL * 3, 0.f), angle((size_t)NL);
+    std::vector<int32_t> octave((size_t)NL);
+    for (int i = 0; i < NL; i++) {
+        octave[(size_t)i] = LastFrame.mvKeys[(size_t)i].octave;                            // :1628
+        angle[(size_t)i] = LastFrame.mvKeysUn[(size_t)i].angle;                            // :1694
+        MapPoint *pMP = LastFrame.mvpMapPoints[(size_t)i];
+        if (!pMP || LastFrame.mvbOutlier[(size_t)i]) continue;                             // :1604-1608
+        valid[(size_t)i] = 1;
+        const cv::Mat x3Dw = pMP->GetWorldPos();
+        for (int k = 0; k < 3; k++) pos[3 * (size_t)i + k] = x3Dw.at<float>(k);
+        hasObs[(size_t)i] = pMP->Observations() > 0 ? 1 : 0;
+        const cv::Mat d = pMP->GetDescriptor();
+        memcpy(&lastDesc[32 * (size_t)i], d.ptr<unsigned char>(), 32);
+    }
+    float tc[16], tl[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) { tc[4 * r + c] = CurrentFrame.mTcw.at<float>(r, c); tl[4 * r + c] = LastFrame.mTcw.at<float>(r, c); }
+    orbx_projection_frame fr = {(const orbx_keypoint *)&CurrentFrame.mvKeysUn[0], CurrentFrame.mDescriptors.data, &CurrentFrame.mvuRight[0], &occupied[0],
+                                &N, N, 1, Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv};
+    orbx_projection_last ls = {&valid[0], &pos[0], &lastDesc[0], &hasObs[0], &octave[0], &angle[0], &NL, NL, tc, tl,
+                               Frame::fx, Frame::fy, Frame::cx, Frame::cy, CurrentFrame.mbf, CurrentFrame.mb, Frame::mnMaxX, Frame::mnMaxY};
+    std::vector<int32_t> assigned((size_t)N);
+    int32_t nmatches = 0;
+    if (orbx_search_by_projection_last(Matcher(N > NL ? N : NL), &fr, &ls, &CurrentFrame.mvScaleFactors[0], (int)CurrentFrame.mvScaleFactors.size(), th,
+                                       bMono ? 1 : 0, mbCheckOrientation ? 1 : 0, &assigned[0], &nmatches) != ORBX_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbx): ") + orbx_last_error());
+    // the reference writes mvpMapPoints[bestIdx2] = pMP as it goes and NULLs the pruned ones (:1688, :1718): features it never
+    // touched keep what they held
+    for (int i2 = 0; i2 < N; i2++) {
+        if (assigned[(size_t)i2] >= 0) CurrentFrame.mvpMapPoints[(size_t)i2] = LastFrame.mvpMapPoints[(size_t)assigned[(size_t)i2]];
+        else if (assigned[(size_t)i2] == -2) CurrentFrame.mvpMapPoints[(size_t)i2] = static_cast<MapPoint *>(NULL);
+    }
     return nmatches;
 }
 

@@ -427,3 +427,50 @@ def ref_search_by_projection(fr, pts, th, nnratio, lib=None):
                                           _p(a["px"]), _p(a["py"]), _p(a["pxr"]), _p(a["lvl"]), _p(a["vc"]), _p(a["inv"]), _p(a["obs"]), _p(a["md"]), m, th,
                                           nnratio, _p(out))
     return nm, out[:n]
+
+
+# ---- ORBmatcher::SearchByProjection(Frame &Current, const Frame &Last, th, bMono): restatement and compiled reference ----
+def _last_args(fr, last):
+    a = dict(k7=np.ascontiguousarray(fr["kps7"], np.float32), desc=np.ascontiguousarray(fr["desc"], np.uint8),
+             uR=np.ascontiguousarray(fr["u_right"], np.float32), occ=np.ascontiguousarray(fr["occupied"], np.uint8),
+             sf=np.ascontiguousarray(fr["scale_factors"], np.float32), Tc=np.ascontiguousarray(fr["Tcw"], np.float32),
+             Tl=np.ascontiguousarray(last["Tcw"], np.float32), lv=np.ascontiguousarray(last["valid"], np.uint8),
+             lp=np.ascontiguousarray(last["pos"], np.float32), ld=np.ascontiguousarray(last["desc"], np.uint8),
+             lo=np.ascontiguousarray(last["has_obs"], np.uint8), lk=np.ascontiguousarray(last["kps7"], np.float32))
+    return a
+
+
+def search_by_projection_last(orc, fr, last, th, mono, check_ori):
+    a = _last_args(fr, last)
+    n, nl = len(a["k7"]), len(a["lk"])
+    W, H = np.float32(fr["width"]), np.float32(fr["height"])
+    cam = fr["cam"]
+    fx, fy, cx, cy, bf = [np.float32(v) for v in cam]
+    mb = bf / fx
+    out = np.full(max(n, 1), -1, np.int32)
+    valid = (a["lv"] == 1).astype(np.uint8)                 # 2 = outlier of the last frame: skipped (:1608)
+    octave = np.ascontiguousarray(a["lk"][:, 5].astype(np.int32))
+    angle = np.ascontiguousarray(a["lk"][:, 3])
+    lib = orc.lib
+    F = ctypes.c_float
+    lib.mo_search_by_projection_last.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] + [F] * 6 + [ctypes.c_void_p] * 3 + [F] * 6 + [ctypes.c_void_p] * 6 + \
+                                                [ctypes.c_int, F, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    nm = lib.mo_search_by_projection_last(_p(a["k7"]), _p(a["desc"]), _p(a["uR"]), _p(a["occ"]), n, 0.0, 0.0, float(W), float(H), float(np.float32(64) / W),
+                                          float(np.float32(48) / H), _p(a["sf"]), _p(a["Tc"]), _p(a["Tl"]), float(fx), float(fy), float(cx), float(cy), float(bf),
+                                          float(mb), _p(valid), _p(a["lp"]), _p(a["ld"]), _p(a["lo"]), _p(octave), _p(angle), nl, th, int(mono), int(check_ori), _p(out))
+    return nm, out[:n]
+
+
+def ref_search_by_projection_last(fr, last, th, mono, check_ori, lib=None):
+    lib = lib or slam_lib()
+    a = _last_args(fr, last)
+    n, nl = len(a["k7"]), len(a["lk"])
+    fx, fy, cx, cy, bf = [float(np.float32(v)) for v in fr["cam"]]
+    out = np.full(max(n, 1), -1, np.int32)
+    F = ctypes.c_float
+    lib.orbslam_search_by_projection_last.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + \
+                                                     [F] * 5 + [ctypes.c_void_p] * 5 + [ctypes.c_int, F, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    nm = lib.orbslam_search_by_projection_last(_p(a["k7"]), _p(a["desc"]), _p(a["uR"]), _p(a["occ"]), n, fr["width"], fr["height"], _p(a["sf"]), len(a["sf"]),
+                                               _p(a["Tc"]), _p(a["Tl"]), fx, fy, cx, cy, bf, _p(a["lv"]), _p(a["lp"]), _p(a["ld"]), _p(a["lo"]), _p(a["lk"]), nl,
+                                               th, int(mono), int(check_ori), _p(out))
+    return nm, out[:n]

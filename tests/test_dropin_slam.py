@@ -115,3 +115,20 @@ def test_search_by_projection_dropin_equals_reference(orbx):
         got_n, got = oracle_lib.ref_search_by_projection(fr, pts, th, 0.8, lib=hip)
         assert got_n == want_n and (got == want).all() and want_n > 200
     assert hip.orbx_shim_search_by_projection_calls() - before == 3
+
+
+@pytest.mark.gpu
+def test_search_by_projection_last_frame_dropin_equals_reference(orbx):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) with the HIP body vs the
+    reference body on two real Frames whose MapPoints are real objects."""
+    from test_projection import make_last_case
+    orbx.load_library()
+    hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
+    hip.orbx_shim_search_by_projection_calls.restype = ctypes.c_ulong
+    before = hip.orbx_shim_search_by_projection_calls()
+    for seed, mz, crowded, th, mono in ((41, 0.0, False, 7.0, 0), (42, 0.5, True, 15.0, 0), (43, -0.5, False, 7.0, 0), (44, 0.5, False, 15.0, 1)):
+        fr, last = make_last_case(seed, mz, crowded=crowded)
+        want_n, want = oracle_lib.ref_search_by_projection_last(fr, last, th, mono, 1, lib=ref)
+        got_n, got = oracle_lib.ref_search_by_projection_last(fr, last, th, mono, 1, lib=hip)
+        assert got_n == want_n and (got == want).all() and want_n > 150
+    assert hip.orbx_shim_search_by_projection_calls() - before == 4

@@ -81,3 +81,84 @@ def test_hip_equals_restatement_and_reference(orbx, oracle, seed, crowded, th, r
     e_n, e = mt.SearchByProjection(frame, {k: v[:0] for k, v in pts.items()}, th)
     assert e_n == 0 and (e == -1).all()
     mt.close()
+
+
+# ---------------- SearchByProjection(CurrentFrame, LastFrame, th, bMono) ----------------
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def make_last_case(seed, motion_z=0.0, n=1500, nl=1400, W=640, H=480, crowded=False):
+    rng = np.random.default_rng(seed)
+    fr, _ = make_case(seed, n=n, m=4, W=W, H=H, crowded=crowded)
+    cam = (517.3, 516.5, 318.6, 255.3, 40.0)
+    fx, fy, cx, cy, bf = cam
+    Tc = np.eye(4)
+    Tc[:3, :3] = _rot(0.01, -0.02, 0.015)
+    Tc[:3, 3] = [0.05, -0.02, 0.1]
+    Tl = np.eye(4)
+    Tl[:3, :3] = _rot(0.0, 0.01, 0.0)
+    # tlc.z = (Rlw*twc + tlw).z decides forward / backward against mb = bf/fx (~0.077)
+    twc = -Tc[:3, :3].T @ Tc[:3, 3]
+    Tl[:3, 3] = -Tl[:3, :3] @ twc + np.array([0.0, 0.0, motion_z])
+    k7 = fr["kps7"]
+    src = rng.integers(0, n, nl)
+    z = rng.uniform(1.0, 8.0, nl)
+    u = k7[src, 0] + rng.normal(0, 2.0, nl)
+    v = k7[src, 1] + rng.normal(0, 2.0, nl)
+    Xc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], 1)
+    behind = rng.random(nl) < 0.03
+    Xc[behind, 2] *= -1                                       # invzc < 0
+    Xw = (Tc[:3, :3].T @ (Xc - Tc[:3, 3]).T).T
+    ld = fr["desc"][src].copy()
+    for i in range(nl):
+        for b in rng.integers(0, 256, rng.integers(0, 40)):
+            ld[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    lk = np.zeros((nl, 7), np.float32)
+    lk[:, 0], lk[:, 1] = u, v
+    lk[:, 2] = 31
+    lk[:, 3] = (k7[src, 3] + rng.normal(0, 5, nl)) % 360
+    wild = rng.random(nl) < 0.15                               # inconsistent rotations: pruned by the histogram
+    lk[wild, 3] = rng.uniform(0, 360, int(wild.sum()))
+    lk[:, 5] = np.clip(k7[src, 5] + rng.integers(-1, 2, nl), 0, 7)
+    lk[:, 6] = -1
+    valid = np.ones(nl, np.uint8)
+    valid[rng.random(nl) < 0.15] = 0                           # no MapPoint
+    valid[rng.random(nl) < 0.05] = 2                           # outlier of the last frame
+    fr = dict(fr, Tcw=Tc.astype(np.float32), cam=cam)
+    last = dict(Tcw=Tl.astype(np.float32), valid=valid, pos=Xw.astype(np.float32), desc=ld, has_obs=(rng.random(nl) < 0.9).astype(np.uint8), kps7=lk)
+    return fr, last
+
+
+LAST_CASES = [(21, 0.0, False, 7.0, 0, 1), (22, 0.5, False, 15.0, 0, 1), (23, -0.5, False, 7.0, 0, 1), (24, 0.5, False, 15.0, 1, 1),
+              (25, 0.0, True, 7.0, 0, 0), (26, 0.5, True, 15.0, 0, 1)]
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref/liborbslam.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed,mz,crowded,th,mono,ori", LAST_CASES)
+def test_last_frame_restatement_equals_reference(oracle, seed, mz, crowded, th, mono, ori):
+    fr, last = make_last_case(seed, mz, crowded=crowded)
+    want_n, want = oracle_lib.ref_search_by_projection_last(fr, last, th, mono, ori)
+    got_n, got = oracle_lib.search_by_projection_last(oracle, fr, last, th, mono, ori)
+    assert got_n == want_n and (np.maximum(got, -1) == want).all()      # -2 (assigned, then pruned) reads back as NULL from the Frame
+    assert want_n > 150 and (not ori or (got == -2).any())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,mz,crowded,th,mono,ori", LAST_CASES + [(27, -0.5, True, 15.0, 0, 1)])
+def test_last_frame_hip_equals_restatement_and_reference(orbx, oracle, seed, mz, crowded, th, mono, ori):
+    fr, last = make_last_case(seed, mz, crowded=crowded)
+    want_n, want = oracle_lib.search_by_projection_last(oracle, fr, last, th, mono, ori)
+    mt = orbx.ORBmatcher(0.9, bool(ori), max_features=2048)
+    frame = dict(fr, kps=_struct_kps(orbx, fr["kps7"]))
+    lastd = dict(last, kps=_struct_kps(orbx, last["kps7"]), valid=(last["valid"] == 1).astype(np.uint8))
+    got_n, got = mt.SearchByProjectionLast(frame, lastd, th, mono)
+    assert got_n == want_n and (got == want).all()
+    if HAVE_REF:
+        ref_n, ref = oracle_lib.ref_search_by_projection_last(fr, last, th, mono, ori)
+        assert got_n == ref_n and (np.maximum(got, -1) == ref).all()
+    mt.close()
