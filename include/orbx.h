@@ -400,6 +400,34 @@ int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *problem, const volatile 
 /* Kernel milliseconds (HIP events) spent inside the last orbx_lba_solve and FP64 flop count. */
 int orbx_lba_last_timing(orbx_lba *h, float *device_ms, double *flops);
 
+
+/* ------------------------------------------------------------------------------------
+ * Motion-only bundle adjustment  ==  Optimizer::PoseOptimization(Frame *pFrame)
+ * (reference include/Optimizer.h, src/Optimizer.cc:363-605; called by every Track* function of
+ * Tracking): one SE3 vertex, unary EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose
+ * edges with Huber kernels, 4 rounds of 10 Levenberg iterations each restarted from the initial
+ * pose, inlier re-classification between rounds (chi2 > 5.991 / 7.815).  A batch of independent
+ * frames is solved by one kernel launch (one workgroup per frame, no host round trip).
+ * Feature i of frame f at f*capacity + i; only features that have a MapPoint are passed. */
+typedef struct orbx_pose_optimizer orbx_pose_optimizer;
+typedef struct orbx_pose_problem {
+    int num_frames, capacity;
+    const float *poses;        /* [B*16] pFrame->mTcw, row-major                                  */
+    const float *cameras;      /* [B*5]  fx, fy, cx, cy, mbf                                      */
+    const int32_t *counts;     /* [B]    features with a MapPoint (nInitialCorrespondences)        */
+    const float *world_points; /* [B*cap*3] MapPoint::GetWorldPos()                                */
+    const float *observations; /* [B*cap*3] kpUn.pt.x, kpUn.pt.y, mvuRight (< 0: monocular edge)   */
+    const float *inv_sigma2;   /* [B*cap]   mvInvLevelSigma2[kpUn.octave]                          */
+} orbx_pose_problem;
+int orbx_pose_optimizer_create(int device, int max_frames, int max_features, orbx_pose_optimizer **out);
+void orbx_pose_optimizer_destroy(orbx_pose_optimizer *h);
+/* poses_out [B*16] = pFrame->mTcw after SetPose; outlier [B*cap] = pFrame->mvbOutlier of the passed
+ * features; inliers [B] = the return value (nInitialCorrespondences - nBad); stats [B*8] = per round
+ * {LM iterations, final robustified chi2}.  Any output may be NULL.  Contract vs the CPU oracle:
+ * |delta pose| <= 1e-5, identical outlier flags. */
+int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_problem *problem, float *poses_out, uint8_t *outlier,
+                           int32_t *inliers, double *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,7 @@ struct Problem {
     std::vector<int> level;        // 0 active, 1 excluded
     std::vector<double> err;       // 3E, last computed _error
     bool robust;
+    bool onlyPose = false;         // unary EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose edges (PoseOptimization): points are constants
     // Huber deltas: thHuberMono/Stereo are FLOATS (src/Optimizer.cc:781-782); dsqr is a float
     // member of this fork's RobustKernelHuber (robust_kernel_impl.h:84)
     double deltaMono, deltaStereo;
@@ -166,10 +167,11 @@ void edge_error(const Problem &p, int e, double out[3])
         const double u = Xc[0] / Xc[2] * in[0] + in[2], v = Xc[1] / Xc[2] * in[1] + in[3];   // project2d then *f + c
         out[0] = p.obs[3 * (size_t)e] - u; out[1] = p.obs[3 * (size_t)e + 1] - v; out[2] = 0;
     } else {
-        const float invz = (float)(1.0 / Xc[2]);   // `const float invz = 1.0f/trans_xyz[2]` (.cpp:151): double divide, rounded to float
+        const float invz = (float)(1.0 / Xc[2]);   // `const float invz = 1.0f/trans_xyz[2]` (.cpp:151, :300): double divide, rounded to float
         const double u = Xc[0] * invz * in[0] + in[2], v = Xc[1] * invz * in[1] + in[3];
-        const float bfz = (float)in[4] * invz;     // bf arrives as `const float&` (.cpp:150): float*float product
-        const double ur = u - (double)bfz;
+        // binary edge: bf arrives as `const float&` (.cpp:150): float*float product; OnlyPose edge: `double bf` member (.h:201, .cpp:304)
+        const double bfz = p.onlyPose ? in[4] * (double)invz : (double)((float)in[4] * invz);
+        const double ur = u - bfz;
         out[0] = p.obs[3 * (size_t)e] - u; out[1] = p.obs[3 * (size_t)e + 1] - v; out[2] = p.obs[3 * (size_t)e + 2] - ur;
     }
 }
@@ -200,6 +202,15 @@ void edge_jacobians(const Problem &p, int e, double A[9], double B[18])
     const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
     memset(A, 0, 9 * sizeof(double));
     memset(B, 0, 18 * sizeof(double));
+    if (p.onlyPose) {   // EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose::linearizeOplus (.cpp:266-288, 335-367): reciprocal forms
+        const double invz = 1.0 / z, invz_2 = invz * invz;
+        B[0] = x * y * invz_2 * fx; B[1] = -(1 + (x * x * invz_2)) * fx; B[2] = y * invz * fx; B[3] = -invz * fx; B[4] = 0; B[5] = x * invz_2 * fx;
+        B[6] = (1 + y * y * invz_2) * fy; B[7] = -x * y * invz_2 * fy; B[8] = -x * invz * fy; B[9] = 0; B[10] = -invz * fy; B[11] = y * invz_2 * fy;
+        if (p.stereo[e]) {
+            B[12] = B[0] - bf * y * invz_2; B[13] = B[1] + bf * x * invz_2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bf * invz_2;
+        }
+        return;
+    }
     if (!p.stereo[e]) {
         const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
         for (int i = 0; i < 2; i++)
@@ -261,7 +272,7 @@ int optimize(Problem &p, int iterations, const volatile uint8_t *stop, Stats *st
     for (size_t a = 0; a < act.size(); a++) { poseAct[(size_t)p.ek[act[a]]] = 1; ptAct[(size_t)p.ep[act[a]]] = 1; }
     int nPose = 0, nPt = 0;
     for (int k = 0; k < p.K; k++) if (poseAct[(size_t)k] && !p.fixed[(size_t)k]) poseIdx[(size_t)k] = nPose++;
-    for (int l = 0; l < p.P; l++) if (ptAct[(size_t)l]) ptIdx[(size_t)l] = nPt++;
+    for (int l = 0; l < p.P; l++) if (ptAct[(size_t)l] && !p.onlyPose) ptIdx[(size_t)l] = nPt++;
     if (st) { st->iters = 0; st->trials = 0; st->chi0 = st->chi1 = 0; st->lambda = 0; }
     if (act.empty() || nPose + nPt == 0) return 0;
     const int nP6 = 6 * nPose;
@@ -300,7 +311,7 @@ int optimize(Problem &p, int iterations, const volatile uint8_t *stop, Stats *st
             double omr[3];
             for (int d = 0; d < 3; d++) omr[d] = -w * p.err[3 * (size_t)e + d] * rw;   // omega_r = -Omega*e, then *= rho[1]
             const int li = ptIdx[(size_t)p.ep[e]], pi = poseIdx[(size_t)p.ek[e]];
-            for (int i = 0; i < 3; i++) {
+            for (int i = 0; i < 3 && li >= 0; i++) {
                 for (int j = 0; j < 3; j++) { double s = 0; for (int d = 0; d < D; d++) s += A[3 * d + i] * W * A[3 * d + j]; Hll[(size_t)li * 9 + 3 * i + j] += s; }
                 double s = 0; for (int d = 0; d < D; d++) s += A[3 * d + i] * omr[d]; bl[(size_t)li * 3 + i] += s;
             }
@@ -343,7 +354,8 @@ int optimize(Problem &p, int iterations, const volatile uint8_t *stop, Stats *st
             }
             // per landmark: its free-pose edges
             std::vector<std::vector<int> > byPt((size_t)nPt);
-            for (size_t a = 0; a < act.size(); a++) if (poseIdx[(size_t)p.ek[act[a]]] >= 0) byPt[(size_t)ptIdx[(size_t)p.ep[act[a]]]].push_back((int)a);
+            for (size_t a = 0; a < act.size(); a++)
+                if (poseIdx[(size_t)p.ek[act[a]]] >= 0 && ptIdx[(size_t)p.ep[act[a]]] >= 0) byPt[(size_t)ptIdx[(size_t)p.ep[act[a]]]].push_back((int)a);
             for (int l = 0; l < nPt; l++) {
                 const double *I = &Dinv[(size_t)l * 9];
                 for (size_t u = 0; u < byPt[(size_t)l].size(); u++) {
@@ -371,6 +383,7 @@ int optimize(Problem &p, int iterations, const volatile uint8_t *stop, Stats *st
                     const int i1 = poseIdx[(size_t)p.ek[act[a]]];
                     if (i1 < 0) continue;
                     const int l = ptIdx[(size_t)p.ep[act[a]]];
+                    if (l < 0) continue;
                     const double *B1 = &Hpl[a * 18];
                     for (int c = 0; c < 3; c++) { double s = 0; for (int r = 0; r < 6; r++) s += B1[3 * r + c] * xp[(size_t)6 * i1 + r]; cl[(size_t)l * 3 + c] -= s; }
                 }
@@ -520,4 +533,69 @@ LO_API void lo_edge_error_perturbed(const float *pose16, const float *intr5, con
     p.stereo.assign(1, !(obs3[2] < 0));
     p.info.assign(1, 1.0);
     edge_error(p, 0, err3);
+}
+
+
+// Optimizer::PoseOptimization(Frame *pFrame) (src/Optimizer.cc:363-605): motion-only BA of one frame.
+// One VertexSE3Expmap, unary EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose per feature that
+// has a MapPoint (obs[3i+2] < 0: monocular), Huber kernels (deltas sqrt(5.991) / sqrt(7.815) as floats),
+// BlockSolver_6_3 + LinearSolverDense + Levenberg.  Four rounds of optimize(10), EVERY round restarting from
+// the frame's initial pose (:520) on the edges currently classified as inliers; after each round the
+// edges are re-classified with chi2 > 5.991 / 7.815 read as FLOAT (:533, :563; inliers keep the error of
+// the last LM evaluation, outliers are re-evaluated), the robust kernels are dropped after the third.
+// Returns nInitialCorrespondences - nBad; pose_out = pFrame->mTcw after SetPose(:598-601).
+// PARITY UNPINNED (g2o needs Eigen); cross-checked against scipy in tests/test_pose_optimization.py.
+LO_API int lo_pose_optimization(const float *pose16, const float *cam5, int n, const float *Xw, const float *obs, const float *inv_sigma2,
+                                float *pose_out16, uint8_t *outlier, double *stats)
+{
+    Problem p;
+    p.K = 1; p.P = n; p.E = n; p.onlyPose = true;
+    p.pose.resize(1); p.fixed.assign(1, 0); p.intr.resize(5); p.pt.resize((size_t)3 * n);
+    auto load_pose = [&]() {
+        double R[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = pose16[4 * i + j];
+        p.pose[0].q = quat_from_R(R);
+        quat_normalize_pos(p.pose[0].q);
+        for (int i = 0; i < 3; i++) p.pose[0].t[i] = pose16[4 * i + 3];
+    };
+    load_pose();
+    for (int i = 0; i < 5; i++) p.intr[(size_t)i] = cam5[i];
+    for (int i = 0; i < 3 * n; i++) p.pt[(size_t)i] = Xw[i];
+    p.ep.resize((size_t)n); p.ek.assign((size_t)n, 0);
+    p.obs.resize((size_t)3 * n); p.stereo.resize((size_t)n); p.info.resize((size_t)n); p.level.assign((size_t)n, 0); p.err.assign((size_t)3 * n, 0.0);
+    for (int e = 0; e < n; e++) {
+        p.ep[(size_t)e] = e;
+        for (int i = 0; i < 3; i++) p.obs[3 * (size_t)e + i] = obs[3 * (size_t)e + i];
+        p.stereo[(size_t)e] = !(obs[3 * (size_t)e + 2] < 0);      // mvuRight < 0 -> monocular (:404)
+        p.info[(size_t)e] = inv_sigma2[e];
+        outlier[e] = 0;
+    }
+    const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);
+    p.deltaMono = thMono; p.deltaStereo = thStereo;
+    p.dsqrMono = (float)(p.deltaMono * p.deltaMono); p.dsqrStereo = (float)(p.deltaStereo * p.deltaStereo);
+    if (stats) for (int i = 0; i < 8; i++) stats[i] = 0;
+    if (n < 3) { memcpy(pose_out16, pose16, 64); return 0; }      // :509-510
+    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+    int nBad = 0;
+    p.robust = true;
+    for (int it = 0; it < 4; it++) {
+        load_pose();                                                // :520
+        Stats st = {0, 0, 0, 0, 0};
+        optimize(p, 10, nullptr, &st);                              // :521-522
+        if (stats) { stats[2 * it] = st.iters; stats[2 * it + 1] = st.chi1; }
+        nBad = 0;
+        for (int e = 0; e < n; e++) {
+            if (outlier[e]) edge_error(p, e, &p.err[3 * (size_t)e]);   // :529-532
+            const float chi2 = (float)edge_chi2(p, e);
+            if (chi2 > (p.stereo[(size_t)e] ? chi2Stereo : chi2Mono)) { outlier[e] = 1; p.level[(size_t)e] = 1; nBad++; }
+            else { outlier[e] = 0; p.level[(size_t)e] = 0; }
+        }
+        if (it == 2) p.robust = false;                               // e->setRobustKernel(0), :547-548
+        if (n < 10) break;                                           // optimizer.edges().size()<10, :589-590
+    }
+    double R[9];
+    quat_to_R(p.pose[0].q, R);
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) pose_out16[4 * i + j] = (float)R[3 * i + j]; pose_out16[4 * i + 3] = (float)p.pose[0].t[i]; }
+    pose_out16[12] = pose_out16[13] = pose_out16[14] = 0.f; pose_out16[15] = 1.f;
+    return n - nBad;
 }

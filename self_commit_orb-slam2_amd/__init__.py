@@ -626,6 +626,57 @@ distributed = _load_sibling("distributed")
 voc_synth = _load_sibling("voc_synth")
 
 
+class PoseProblem(ctypes.Structure):
+    _fields_ = [("num_frames", ctypes.c_int), ("capacity", ctypes.c_int), ("poses", ctypes.c_void_p), ("cameras", ctypes.c_void_p), ("counts", ctypes.c_void_p),
+                ("world_points", ctypes.c_void_p), ("observations", ctypes.c_void_p), ("inv_sigma2", ctypes.c_void_p)]
+
+
+class PoseOptimizer:
+    """Optimizer::PoseOptimization(Frame*) (reference src/Optimizer.cc:363-605) for a batch of independent frames."""
+
+    def __init__(self, max_frames=64, max_features=4096, device=0):
+        self._L = load_library()
+        L = self._L
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        L.orbx_pose_optimizer_create.argtypes = [ci, ci, ci, ctypes.POINTER(vp)]
+        L.orbx_pose_optimizer_destroy.argtypes = [vp]
+        L.orbx_pose_optimizer_destroy.restype = None
+        L.orbx_pose_optimization.argtypes = [vp, ctypes.POINTER(PoseProblem), vp, vp, vp, vp]
+        self._h = vp()
+        _check(L.orbx_pose_optimizer_create(device, max_frames, max_features, ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbx_pose_optimizer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def PoseOptimization(self, frames):
+        """frames: list of dict(pose (4x4), cam (fx,fy,cx,cy,bf), Xw (n,3), obs (n,3; uR<0 mono), inv_sigma2 (n)).
+        Returns list of dict(pose, outlier, inliers, stats)."""
+        B = len(frames)
+        cap = max(1, max(len(f["Xw"]) for f in frames))
+        poses = np.zeros((B, 16), np.float32)
+        cams = np.zeros((B, 5), np.float32)
+        counts = np.zeros(B, np.int32)
+        Xw, obs, inv = np.zeros((B, cap, 3), np.float32), np.zeros((B, cap, 3), np.float32), np.zeros((B, cap), np.float32)
+        for i, f in enumerate(frames):
+            n = len(f["Xw"])
+            poses[i] = np.asarray(f["pose"], np.float32).reshape(16)
+            cams[i] = np.asarray(f["cam"], np.float32)
+            counts[i] = n
+            Xw[i, :n], obs[i, :n], inv[i, :n] = f["Xw"], f["obs"], f["inv_sigma2"]
+        P = PoseProblem(B, cap, _ptr(poses).value, _ptr(cams).value, _ptr(counts).value, _ptr(Xw).value, _ptr(obs).value, _ptr(inv).value)
+        po, outl, inl, st = np.zeros((B, 16), np.float32), np.zeros((B, cap), np.uint8), np.zeros(B, np.int32), np.zeros((B, 8), np.float64)
+        _check(self._L.orbx_pose_optimization(self._h, ctypes.byref(P), _ptr(po), _ptr(outl), _ptr(inl), _ptr(st)))
+        return [dict(pose=po[i].reshape(4, 4), outlier=outl[i, :counts[i]], inliers=int(inl[i]), stats=st[i]) for i in range(B)]
+
+
 class Optimizer:
     """Mirror of the static ORB_SLAM2::Optimizer::LocalBundleAdjustment (reference include/Optimizer.h:112)
     on a flat window (dict as produced by lba_synth.make_window)."""

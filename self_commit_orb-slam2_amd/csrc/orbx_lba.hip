@@ -498,6 +498,275 @@ __global__ __launch_bounds__(256) void k_update(LbaDev d, const double *xp, cons
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Optimizer::PoseOptimization(Frame*) (reference src/Optimizer.cc:363-605): motion-only BA.  ONE
+// KERNEL, one workgroup per frame: the whole 4-round / 10-iteration / 10-trial Levenberg loop of g2o
+// (OptimizationAlgorithmLevenberg::solve, optimization_algorithm_levenberg.cpp:61-164) runs on the
+// device, edges strided over the 256 threads, the 6x6 system reduced through LDS and solved by one
+// thread, no host round trip.  FP64 throughout; frames of a batch are independent.
+// ---------------------------------------------------------------------------------------------
+struct PoseOptDev {
+    const float *pose0;      // [B*16] pFrame->mTcw
+    const float *cam;        // [B*5] fx fy cx cy mbf
+    const float *Xw;         // [B*cap*3] MapPoint::GetWorldPos of the features that have a MapPoint
+    const float *obs;        // [B*cap*3] kpUn.pt.x, kpUn.pt.y, mvuRight (< 0: monocular edge)
+    const float *invS2;      // [B*cap]   mvInvLevelSigma2[kpUn.octave]
+    const int32_t *counts;   // [B]
+    int cap;
+    double *err;             // [B*cap*3] scratch: _error of every edge (kept between rounds like g2o keeps it)
+    float *poseOut;          // [B*16]
+    uint8_t *outlier;        // [B*cap]  pFrame->mvbOutlier of those features
+    int32_t *ret;            // [B] nInitialCorrespondences - nBad
+    double *stats;           // [B*8] per round: iterations, final (robustified) chi2
+};
+
+#define PO_NRED 28   /* 21 upper-triangle entries of H + 6 of b + chi2 */
+
+__device__ inline void po_edge_error(const DPose &T, const double in[5], const float *Xw, const float *obs, bool stereo, double out[3])
+{
+    const double X[3] = {(double)Xw[0], (double)Xw[1], (double)Xw[2]};
+    double Xc[3];
+    pose_map(T, X, Xc);
+    if (!stereo) {   // EdgeSE3ProjectXYZOnlyPose::computeError / cam_project (types_six_dof_expmap.h:150-157, .cpp:290-296)
+        const double u = Xc[0] / Xc[2] * in[0] + in[2], v = Xc[1] / Xc[2] * in[1] + in[3];
+        out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v; out[2] = 0;
+    } else {         // EdgeStereoSE3ProjectXYZOnlyPose (.cpp:299-306): float invz, double bf
+        const float invz = (float)(1.0 / Xc[2]);
+        const double u = Xc[0] * invz * in[0] + in[2], v = Xc[1] * invz * in[1] + in[3];
+        out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v; out[2] = (double)obs[2] - (u - in[4] * (double)invz);
+    }
+}
+
+__device__ inline void po_block_reduce(double *v, double (*red)[PO_NRED], int n, int tid)
+{
+    // v[0..n) per thread -> red[0][0..n) summed over the workgroup
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = 0; k < n; k++) {
+        double x = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if (lane == 0) red[wave][k] = x;
+    }
+    __syncthreads();
+    if (tid < n) red[0][tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
+{
+    __shared__ DPose pose, savePose;
+    __shared__ double red[4][PO_NRED];
+    __shared__ double sH[36], sb[6], sx[6];
+    __shared__ double sLambda, sNi, sCur, sRho;
+    __shared__ int sOk, sIterOk, sNBad;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = min(P.counts[f], P.cap);
+    const size_t base = (size_t)f * P.cap;
+    const float *Xw = P.Xw + base * 3, *obs = P.obs + base * 3, *invS2 = P.invS2 + base;
+    double *err = P.err + base * 3;
+    uint8_t *outl = P.outlier + base;
+    double in[5];
+    for (int i = 0; i < 5; i++) in[i] = (double)P.cam[5 * (size_t)f + i];
+    const float *p0 = P.pose0 + 16 * (size_t)f;
+    for (int e = tid; e < n; e += 256) outl[e] = 0;
+    if (tid < 8) P.stats[8 * (size_t)f + tid] = 0;
+    if (n < 3) {   // :509-510
+        if (tid < 16) P.poseOut[16 * (size_t)f + tid] = p0[tid];
+        if (tid == 0) P.ret[f] = 0;
+        return;
+    }
+    __syncthreads();
+    for (int round = 0; round < 4; round++) {
+        const bool robust = round < 3;   // kernels are removed while classifying after the third round (:547-548)
+        if (tid == 0) {                  // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw)), :520
+            double R[9];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = (double)p0[4 * i + j];
+            pose.q = quat_from_R(R);
+            quat_normalize_pos(pose.q);
+            for (int i = 0; i < 3; i++) pose.t[i] = (double)p0[4 * i + 3];
+            sIterOk = 1; sNBad = 0;
+        }
+        __syncthreads();
+        int nAct = 0;
+        for (int e = tid; e < n; e += 256) nAct += outl[e] ? 0 : 1;
+        {
+            double v[1] = {(double)nAct};
+            po_block_reduce(v, red, 1, tid);
+            nAct = (int)red[0][0];
+            __syncthreads();
+        }
+        int itersDone = 0;
+        double lastChi = 0;
+        for (int it = 0; it < 10 && nAct > 0; it++) {
+            if (!sIterOk) break;
+            // ---- computeActiveErrors + robust chi2, buildSystem
+            const DPose T = pose;
+            double acc[PO_NRED];
+            for (int k = 0; k < PO_NRED; k++) acc[k] = 0;
+            for (int e = tid; e < n; e += 256) {
+                if (outl[e]) continue;
+                const bool st = !(obs[3 * e + 2] < 0);
+                double r[3];
+                po_edge_error(T, in, Xw + 3 * e, obs + 3 * e, st, r);
+                err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
+                const double w = (double)invS2[e];
+                const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * w;
+                double r0 = chi, r1 = 1;
+                if (robust) huber_rho(hub, st, chi, r0, r1);
+                acc[27] += r0;
+                // linearizeOplus (.cpp:266-288, 335-367)
+                const double X[3] = {(double)Xw[3 * e], (double)Xw[3 * e + 1], (double)Xw[3 * e + 2]};
+                double Xc[3];
+                pose_map(T, X, Xc);
+                const double x = Xc[0], y = Xc[1], invz = 1.0 / Xc[2], invz_2 = invz * invz, fx = in[0], fy = in[1], bf = in[4];
+                double J[18];
+                J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
+                J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+                J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2;
+                const int D = st ? 3 : 2;
+                const double W = r1 * w;
+                int k = 0;
+                for (int i = 0; i < 6; i++)
+                    for (int j = i; j < 6; j++, k++) {
+                        double sacc = 0;
+                        for (int d = 0; d < D; d++) sacc += J[6 * d + i] * W * J[6 * d + j];
+                        acc[k] += sacc;
+                    }
+                for (int i = 0; i < 6; i++) {
+                    double sacc = 0;
+                    for (int d = 0; d < D; d++) sacc += J[6 * d + i] * (-w * r[d] * r1);
+                    acc[21 + i] += sacc;
+                }
+            }
+            po_block_reduce(acc, red, PO_NRED, tid);
+            if (tid == 0) {
+                int k = 0;
+                for (int i = 0; i < 6; i++)
+                    for (int j = i; j < 6; j++, k++) { sH[6 * i + j] = red[0][k]; sH[6 * j + i] = red[0][k]; }
+                for (int i = 0; i < 6; i++) sb[i] = red[0][21 + i];
+                sCur = red[0][27];
+                if (it == 0) {   // computeLambdaInit (:166-180)
+                    double mx = 0;
+                    for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(sH[7 * i]));
+                    sLambda = 1e-5 * mx; sNi = 2;
+                }
+            }
+            __syncthreads();
+            const double iniChi = sCur;
+            int qmax = 0;
+            do {
+                if (tid == 0) {
+                    savePose = pose;   // push()
+                    // (H + lambda I) x = b by LDL^T; "isPositive" like LinearSolverDense (linear_solver_dense.h:99-103)
+                    double A[36];
+                    for (int i = 0; i < 36; i++) A[i] = sH[i];
+                    for (int i = 0; i < 6; i++) A[7 * i] += sLambda;
+                    double Dg[6];
+                    bool ok = true;
+                    for (int j = 0; j < 6 && ok; j++) {
+                        double dj = A[7 * j];
+                        for (int k = 0; k < j; k++) dj -= A[6 * j + k] * A[6 * j + k] * Dg[k];
+                        if (!(dj > 0) || !isfinite(dj)) { ok = false; break; }
+                        Dg[j] = dj;
+                        for (int i = j + 1; i < 6; i++) {
+                            double lij = A[6 * i + j];
+                            for (int k = 0; k < j; k++) lij -= A[6 * i + k] * A[6 * j + k] * Dg[k];
+                            A[6 * i + j] = lij / dj;
+                        }
+                    }
+                    double xx[6];
+                    if (ok) {
+                        for (int i = 0; i < 6; i++) { double sacc = sb[i]; for (int k = 0; k < i; k++) sacc -= A[6 * i + k] * xx[k]; xx[i] = sacc; }
+                        for (int i = 0; i < 6; i++) xx[i] /= Dg[i];
+                        for (int i = 5; i >= 0; i--) { double sacc = xx[i]; for (int k = i + 1; k < 6; k++) sacc -= A[6 * k + i] * xx[k]; xx[i] = sacc; }
+                        for (int i = 0; i < 6; i++) sx[i] = xx[i];
+                    }
+                    sOk = ok ? 1 : 0;
+                    pose_oplus(pose, sx);   // g2o applies the (possibly stale) x even when the solve failed; pop() restores
+                }
+                __syncthreads();
+                const DPose T2 = pose;
+                double cacc[1] = {0};
+                for (int e = tid; e < n; e += 256) {
+                    if (outl[e]) continue;
+                    const bool st = !(obs[3 * e + 2] < 0);
+                    double r[3];
+                    po_edge_error(T2, in, Xw + 3 * e, obs + 3 * e, st, r);
+                    err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
+                    const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * (double)invS2[e];
+                    double r0 = chi, r1 = 1;
+                    if (robust) huber_rho(hub, st, chi, r0, r1);
+                    cacc[0] += r0;
+                }
+                po_block_reduce(cacc, red, 1, tid);
+                if (tid == 0) {
+                    double tempChi = red[0][0];
+                    if (!sOk) tempChi = 1.7976931348623157e308;
+                    double rho = sCur - tempChi, scale = 0;
+                    for (int j = 0; j < 6; j++) scale += sx[j] * (sLambda * sx[j] + sb[j]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    if (rho > 0 && isfinite(tempChi)) {
+                        double alpha = 1. - pow((2 * rho - 1), 3.0);
+                        alpha = fmin(alpha, 2. / 3.);
+                        sLambda *= fmax(1. / 3., alpha);
+                        sNi = 2;
+                        sCur = tempChi;
+                    } else {
+                        sLambda *= sNi;
+                        sNi *= 2;
+                        pose = savePose;   // pop()
+                    }
+                    sRho = rho;
+                }
+                __syncthreads();
+                qmax++;
+            } while (sRho < 0 && qmax < 10);
+            itersDone++;
+            lastChi = sCur;
+            if (tid == 0) {
+                if (qmax == 10 || sRho == 0) sIterOk = 0;
+                else {
+                    if ((iniChi - sCur) * 1e3 < iniChi) sNBad++; else sNBad = 0;
+                    if (sNBad >= 3) sIterOk = 0;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { P.stats[8 * (size_t)f + 2 * round] = itersDone; P.stats[8 * (size_t)f + 2 * round + 1] = lastChi; }
+        // ---- classification (:526-587): outliers are re-evaluated at the final pose, inliers keep their last _error
+        const DPose Tf = pose;
+        int nb = 0;
+        for (int e = tid; e < n; e += 256) {
+            const bool st = !(obs[3 * e + 2] < 0);
+            if (outl[e]) {
+                double r[3];
+                po_edge_error(Tf, in, Xw + 3 * e, obs + 3 * e, st, r);
+                err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
+            }
+            const float chi2 = (float)((err[3 * e] * err[3 * e] + err[3 * e + 1] * err[3 * e + 1] + err[3 * e + 2] * err[3 * e + 2]) * (double)invS2[e]);
+            const bool bad = chi2 > (st ? 7.815f : 5.991f);
+            outl[e] = bad ? 1 : 0;
+            nb += bad ? 1 : 0;
+        }
+        {
+            double v[1] = {(double)nb};
+            po_block_reduce(v, red, 1, tid);
+            if (tid == 0) P.ret[f] = n - (int)red[0][0];
+            __syncthreads();
+        }
+        if (n < 10) break;   // optimizer.edges().size() < 10, :589-590
+    }
+    if (tid == 0) {   // Converter::toCvMat(SE3Quat) + SetPose, :594-601
+        double R[9];
+        quat_to_R(pose.q, R);
+        float *o = P.poseOut + 16 * (size_t)f;
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o[4 * i + j] = (float)R[3 * i + j]; o[4 * i + 3] = (float)pose.t[i]; }
+        o[12] = o[13] = o[14] = 0.f; o[15] = 1.f;
+    }
+}
+
 template <typename T> struct LBuf {
     T *p = nullptr;
     size_t n = 0;
@@ -834,6 +1103,79 @@ extern "C" int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *p, const vola
         o[12] = o[13] = o[14] = 0.f; o[15] = 1.f;
     }
     for (int i = 0; i < 3 * P; i++) res->points[i] = (float)pt[(size_t)i];
+    return ORBX_OK;
+}
+
+// ---- PoseOptimization: its own small handle (stream + staging), batch of independent frames ----
+struct orbx_pose_optimizer {
+    int device = 0, maxFrames = 0, maxFeatures = 0;
+    hipStream_t stream = nullptr;
+    LBuf<float> pose0, cam, Xw, obs, invS2, poseOut;
+    LBuf<int32_t> counts, ret;
+    LBuf<uint8_t> outlier;
+    LBuf<double> err, stats;
+};
+
+extern "C" int orbx_pose_optimizer_create(int device, int max_frames, int max_features, orbx_pose_optimizer **out)
+{
+    if (!out || max_frames < 1 || max_features < 1) { orbx_set_error("bad pose optimizer arguments"); return ORBX_ERR_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { orbx_set_error("no HIP device available: liborbx has no CPU fallback"); return ORBX_ERR_NODEVICE; }
+    if (device < 0 || device >= ndev) { orbx_set_error("device %d out of range", device); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(device));
+    orbx_pose_optimizer *h = new orbx_pose_optimizer();
+    h->device = device; h->maxFrames = max_frames; h->maxFeatures = max_features;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
+    const size_t B = (size_t)max_frames, N = (size_t)max_frames * max_features;
+    int rc;
+    if ((rc = h->pose0.ensure(B * 16)) || (rc = h->cam.ensure(B * 5)) || (rc = h->Xw.ensure(N * 3)) || (rc = h->obs.ensure(N * 3)) || (rc = h->invS2.ensure(N)) ||
+        (rc = h->poseOut.ensure(B * 16)) || (rc = h->counts.ensure(B)) || (rc = h->ret.ensure(B)) || (rc = h->outlier.ensure(N)) || (rc = h->err.ensure(N * 3)) ||
+        (rc = h->stats.ensure(B * 8))) {
+        orbx_pose_optimizer_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_pose_optimizer_destroy(orbx_pose_optimizer *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    h->pose0.release(); h->cam.release(); h->Xw.release(); h->obs.release(); h->invS2.release(); h->poseOut.release(); h->counts.release(); h->ret.release();
+    h->outlier.release(); h->err.release(); h->stats.release();
+    delete h;
+}
+
+extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_problem *p, float *poses_out, uint8_t *outlier, int32_t *inliers, double *stats)
+{
+    if (!h || !p || !p->poses || !p->cameras || !p->counts || !p->world_points || !p->observations || !p->inv_sigma2) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    const int B = p->num_frames, cap = p->capacity;
+    if (B < 1 || B > h->maxFrames || cap < 1 || cap > h->maxFeatures) { orbx_set_error("problem (%d frames x %d features) exceeds the handle (%d x %d)", B, cap, h->maxFrames, h->maxFeatures); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const size_t N = (size_t)B * cap;
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->pose0.p, p->poses, (size_t)B * 64, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->cam.p, p->cameras, (size_t)B * 20, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->counts.p, p->counts, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->Xw.p, p->world_points, N * 12, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->obs.p, p->observations, N * 12, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->invS2.p, p->inv_sigma2, N * 4, hipMemcpyHostToDevice, st));
+    PoseOptDev D = {h->pose0.p, h->cam.p, h->Xw.p, h->obs.p, h->invS2.p, h->counts.p, cap, h->err.p, h->poseOut.p, h->outlier.p, h->ret.p, h->stats.p};
+    const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);   // deltaMono / deltaStereo are floats (:389-390)
+    Huber hub;
+    hub.dMono = thMono; hub.dStereo = thStereo;
+    hub.dsqrMono = (float)(hub.dMono * hub.dMono); hub.dsqrStereo = (float)(hub.dStereo * hub.dStereo);   // dsqr is a float member in this fork
+    hipLaunchKernelGGL(k_pose_opt, dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    if (poses_out) ORBX_HIP_CHECK(hipMemcpy(poses_out, h->poseOut.p, (size_t)B * 64, hipMemcpyDeviceToHost));
+    if (outlier) ORBX_HIP_CHECK(hipMemcpy(outlier, h->outlier.p, N, hipMemcpyDeviceToHost));
+    if (inliers) ORBX_HIP_CHECK(hipMemcpy(inliers, h->ret.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    if (stats) ORBX_HIP_CHECK(hipMemcpy(stats, h->stats.p, (size_t)B * 64, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 

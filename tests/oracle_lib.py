@@ -474,3 +474,16 @@ def ref_search_by_projection_last(fr, last, th, mono, check_ori, lib=None):
                                                _p(a["Tc"]), _p(a["Tl"]), fx, fy, cx, cy, bf, _p(a["lv"]), _p(a["lp"]), _p(a["ld"]), _p(a["lo"]), _p(a["lk"]), nl,
                                                th, int(mono), int(check_ori), _p(out))
     return nm, out[:n]
+
+
+# ---- Optimizer::PoseOptimization restatement (oracle/lba_oracle.cc) ----
+def pose_optimization(orc, fr):
+    lib = orc.lib
+    pose = np.ascontiguousarray(np.asarray(fr["pose"], np.float32).reshape(16))
+    cam = np.ascontiguousarray(fr["cam"], np.float32)
+    Xw, obs, inv = np.ascontiguousarray(fr["Xw"], np.float32), np.ascontiguousarray(fr["obs"], np.float32), np.ascontiguousarray(fr["inv_sigma2"], np.float32)
+    n = len(Xw)
+    out, outl, st = np.zeros(16, np.float32), np.zeros(max(n, 1), np.uint8), np.zeros(8, np.float64)
+    lib.lo_pose_optimization.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
+    ret = lib.lo_pose_optimization(_p(pose), _p(cam), n, _p(Xw), _p(obs), _p(inv), _p(out), _p(outl), _p(st))
+    return dict(pose=out.reshape(4, 4), outlier=outl[:n], inliers=ret, stats=st)
