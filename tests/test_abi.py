@@ -31,6 +31,11 @@ def test_no_cpu_fallback(orbx):
     with pytest.raises(orbx.OrbxError) as e:
         orbx.ORBextractor(1000, 1.2, 8, 20, 7)
     assert e.value.code == -4   # ORBX_ERR_NODEVICE
+    for make in (lambda: orbx.ORBmatcher(0.7, True), lambda: orbx.Optimizer(), lambda: orbx.PoseOptimizer(),
+                 lambda: orbx.Vocabulary(orbx.voc_synth.make_vocabulary(4, 2, 1))):
+        with pytest.raises(orbx.OrbxError) as e:
+            make()
+        assert e.value.code == -4
 
 
 def test_synth_frame_deterministic(orbx):
