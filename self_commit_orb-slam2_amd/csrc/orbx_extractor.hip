@@ -195,7 +195,7 @@ int build_geometry(orbx_extractor *h, int W, int H)
         lv.kpBase = kps;
         kps += lv.kpCap;
         maxNodes = std::max(maxNodes, lv.kpCap);
-        if (lv.nCols * lv.nRows > 2048) { orbx_set_error("level %d has %d cells; at most 2048 supported", l, lv.nCols * lv.nRows); return ORBX_ERR_ARG; }
+        if (lv.nCols * lv.nRows > ORBX_PT_CAP) { orbx_set_error("level %d has %d cells; at most %d supported", l, lv.nCols * lv.nRows, ORBX_PT_CAP); return ORBX_ERR_ARG; }
         maxWCell = std::max(maxWCell, lv.wCell);
         maxHCell = std::max(maxHCell, lv.hCell);
         lv.blurTilesX = (lv.w + 63) / 64;

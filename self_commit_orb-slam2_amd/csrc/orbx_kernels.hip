@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
     // ---- gather the level's candidates in vToDistributeKeys order (cells row-major) ----
     const int ncell = lv.nCols * lv.nRows;
     const int *cc = cellCount + (size_t)f * g->cellsPerFrame + lv.cellBase;
-    int *cellOff = (int *)itemScan;   // reuse (ncell <= 2*ITEMCAP ints)
+    int *cellOff = (int *)P[1];       // scratch: the second point buffer is not written before the initial-node partition below
     for (int i = tid; i < ncell; i += 256) cellOff[i] = cc[i];
     __syncthreads();
     int M = block_exscan(cellOff, ncell, wsum32);

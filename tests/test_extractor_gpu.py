@@ -4,6 +4,8 @@ Bit-exact everywhere: pyramid bytes, FAST score bytes, candidate lists (order in
 quadtree selection and order, angles as float bit patterns, blurred bytes, descriptors,
 final cv::KeyPoint fields.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -96,4 +98,53 @@ def test_single_image_and_empty(orbx, oracle):
     # a flat image yields no keypoints (reference: descriptors.release())
     k, d = ext(np.full((480, 640), 90, np.uint8))
     assert len(k) == 0
+    ext.close()
+
+
+# Ragged / extreme geometries: widths and heights that are not multiples of anything, the smallest image the
+# 8-level pyramid accepts, a large frame, other pyramid settings, tight (unpadded) caller strides.  End to end
+# (keypoints as bit patterns + descriptors) against the CPU restatement, which is itself pinned to the compiled reference.
+ODD = [
+    # W, H, nfeatures, scale, levels, iniTh, minTh
+    (641, 479, 1000, 1.2, 8, 20, 7),
+    (333, 251, 500, 1.2, 8, 20, 7),       # smallest level is 93x70: single-column cell grids, wide cells
+    (227, 227, 300, 1.2, 8, 20, 7),       # near the minimum the 8-level pyramid accepts
+    (1920, 1080, 2000, 1.2, 8, 20, 7),
+    (1023, 769, 1500, 1.2, 8, 12, 5),
+    (640, 480, 2000, 1.2, 8, 20, 7),      # the 2*nFeatures monocular-initialisation extractor (src/Tracking.cc:192)
+    (640, 480, 1000, 1.5, 4, 20, 7),
+    (500, 375, 800, 1.1, 12, 20, 7),
+]
+
+
+@pytest.mark.parametrize("W,H,nf,sf,nl,ini,mn", ODD)
+def test_ragged_geometries_bit_exact(orbx, oracle, W, H, nf, sf, nl, ini, mn):
+    ext = orbx.ORBextractor(nf, sf, nl, ini, mn, max_width=W, max_height=H, max_batch=3)
+    rst = oracle.restatement(nf, sf, nl, ini, mn)
+    frames = [orbx.synth_frame(100 + W + i, W, H, orbx.SYNTH_LOW_TEXTURE if i == 2 else 0) for i in range(3)]
+    kps, desc, counts = ext.extract_batch(frames)
+    for f, im in enumerate(frames):
+        ko, do = rst.extract(im)
+        n = int(counts[f])
+        assert n == len(ko), (f, n, len(ko))
+        assert (kp_matrix(kps[f, :n]).view(np.uint32) == ko.view(np.uint32)).all(), f
+        assert (desc[f, :n] == do).all(), f
+    ext.close()
+
+
+def test_tight_device_stride(orbx, oracle):
+    """orbx_extract_batch_device on the caller's own device buffer with stride == width (no row padding):
+    the pyramid kernel must take its safe path and still be bit-exact."""
+    import torch
+    W, H, nf, B = 641, 480, 1000, 2
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
+    frames = [orbx.synth_frame(300 + i, W, H) for i in range(B)]
+    buf = torch.from_numpy(np.stack(frames)).cuda()              # tight: stride W, frame pitch W*H
+    ext.run_device(ctypes.c_void_p(buf.data_ptr()), W, W * H, (B, W, H))
+    kps, desc, counts = ext.download(B)
+    rst = oracle.restatement(nf)
+    for f, im in enumerate(frames):
+        ko, do = rst.extract(im)
+        n = int(counts[f])
+        assert n == len(ko) and (kp_matrix(kps[f, :n]).view(np.uint32) == ko.view(np.uint32)).all() and (desc[f, :n] == do).all()
     ext.close()
