@@ -401,67 +401,191 @@ __global__ __launch_bounds__(256) void k_schur_points(LbaDev d, const int *ptSta
 // Dense Cholesky of the (upper-authoritative) symmetric S, then S x = bs.  One workgroup.
 // LinearSolverEigen::solve (solvers/linear_solver_eigen.h:94-125) uses a sparse LDLT; the
 // reduced system is SPD here (lambda > 0), a failed pivot reports ok = 0 like info()!=Success.
+// Blocked right-looking Cholesky S = L L^T + the two triangular solves, one workgroup.  A panel of NB
+// columns (all rows below the diagonal block) lives in LDS while it is factorised (two LDS barriers per
+// column instead of three global round trips), is written back once, and updates the trailing matrix
+// in one parallel sweep; the substitutions reuse the same panels.  n <= CHOL_MAX_N, NB*n*8 bytes of LDS.
+template <int NB>
 __global__ __launch_bounds__(1024) void k_chol_solve(double *S, const double *bs, int n, double *x, int *okFlag)
 {
-    __shared__ double sDiag;
-    __shared__ int sFail;
+    extern __shared__ __attribute__((aligned(16))) double panel[];   // [rows][NB], rows = n - p0
     __shared__ double sx[CHOL_MAX_N];
+    __shared__ int sFail;
     const int tid = threadIdx.x;
     if (tid == 0) sFail = 0;
-    // mirror the upper triangle into the lower one; work on the lower triangle (row-major: L[i][j], j<=i)
-    for (size_t idx = tid; idx < (size_t)n * n; idx += 1024) {
-        const int r = (int)(idx / n), c = (int)(idx % n);
-        if (r > c) S[idx] = S[(size_t)c * n + r];
+    for (int i = tid; i < n; i += 1024) sx[i] = bs[i];
+    // the upper triangle is authoritative on entry (block_solver.hpp builds upper blocks): mirror it, eight
+    // independent elements per thread in flight
+    for (int base = tid; base < n * n; base += 1024 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * 1024, r = idx / n, c = idx - r * n;
+            v[u] = (idx < n * n && r > c) ? S[(size_t)c * n + r] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = base + u * 1024, r = idx / n, c = idx - r * n;
+            if (idx < n * n && r > c) S[idx] = v[u];
+        }
     }
     __syncthreads();
-    for (int j = 0; j < n; j++) {
-        if (tid == 0) {
-            const double dj = S[(size_t)j * n + j];
-            if (!(dj > 0) || !isfinite(dj)) sFail = 1;
-            sDiag = sqrt(dj);
+    for (int p0 = 0; p0 < n; p0 += NB) {
+        const int nb = min(NB, n - p0), rows = n - p0;
+        for (int idx = tid; idx < rows * nb; idx += 1024) { const int r = idx / nb, c = idx - r * nb; panel[r * NB + c] = S[(size_t)(p0 + r) * n + p0 + c]; }
+        __syncthreads();
+        // (1) diagonal block L11 by ONE wave.  Full panel: lane r keeps row r in registers and the column
+        //     entries travel by __shfl (no LDS round trip, no barrier); partial last panel: column by column in LDS.
+        if (tid < 64) {
+            if (nb == NB) {
+                const int r = tid & (NB - 1);   // lanes >= NB mirror a row and write nothing
+                double a[NB];
+#pragma unroll
+                for (int c = 0; c < NB; c++) a[c] = panel[r * NB + c];
+                bool bad = false;
+#pragma unroll
+                for (int c = 0; c < NB; c++) {
+                    const double dj = __shfl(a[c], c);
+                    if (!(dj > 0) || !isfinite(dj)) bad = true;   // wave-uniform
+                    const double ljj = sqrt(dj);
+                    a[c] = r > c ? a[c] / ljj : (r == c ? ljj : a[c]);
+#pragma unroll
+                    for (int c2 = c + 1; c2 < NB; c2++) {
+                        const double l2 = __shfl(a[c], c2);
+                        if (r >= c2) a[c2] -= a[c] * l2;
+                    }
+                }
+                if (bad) { if (tid == 0) sFail = 1; }
+                else if (tid < NB) {
+#pragma unroll
+                    for (int c = 0; c < NB; c++) if (c <= r) panel[r * NB + c] = a[c];
+                }
+            } else {
+                for (int c = 0; c < nb; c++) {
+                    const double dj = panel[c * NB + c];
+                    if (!(dj > 0) || !isfinite(dj)) { if (tid == 0) sFail = 1; break; }   // wave-uniform
+                    const double ljj = sqrt(dj);
+                    __builtin_amdgcn_wave_barrier();
+                    for (int r = c + 1 + tid; r < nb; r += 64) panel[r * NB + c] /= ljj;
+                    if (tid == 0) panel[c * NB + c] = ljj;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    const int ncol = nb - c - 1;
+                    for (int idx = tid; idx < ncol * ncol; idx += 64) {
+                        const int c2 = c + 1 + idx / ncol, r = c + 1 + idx % ncol;
+                        if (r >= c2) panel[r * NB + c2] -= panel[r * NB + c] * panel[c2 * NB + c];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
         __syncthreads();
         if (sFail) break;
-        const double ljj = sDiag;
-        for (int i = j + 1 + tid; i < n; i += 1024) S[(size_t)i * n + j] /= ljj;
-        if (tid == 0) S[(size_t)j * n + j] = ljj;
+        // (2) rows below the diagonal block, one thread per row: L21[r][:] = A21[r][:] * L11^-T (no barrier: rows are independent)
+        for (int r = nb + tid; r < rows; r += 1024) {
+            double *pr = panel + r * NB;
+            if (nb == NB) {   // full panel: the row lives in registers, L11 is read as LDS broadcasts
+                double v[NB];
+#pragma unroll
+                for (int c = 0; c < NB; c++) v[c] = pr[c];
+#pragma unroll
+                for (int c = 0; c < NB; c++) {
+                    double acc = v[c];
+#pragma unroll
+                    for (int k = 0; k < c; k++) acc -= v[k] * panel[c * NB + k];
+                    v[c] = acc / panel[c * NB + c];
+                }
+#pragma unroll
+                for (int c = 0; c < NB; c++) pr[c] = v[c];
+            } else {
+                for (int c = 0; c < nb; c++) {
+                    double acc = pr[c];
+                    for (int k = 0; k < c; k++) acc -= pr[k] * panel[c * NB + k];
+                    pr[c] = acc / panel[c * NB + c];
+                }
+            }
+        }
         __syncthreads();
-        // trailing update of the lower triangle: A[i][k] -= L[i][j] * L[k][j], j < k <= i
-        const int m = n - j - 1;
-        const int total = m * (m + 1) / 2;
-        for (int t = tid; t < total; t += 1024) {
-            // t -> (ii, kk) with 0 <= kk <= ii < m
-            int ii = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-            while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-            while (ii * (ii + 1) / 2 > t) ii--;
-            const int kk = t - ii * (ii + 1) / 2;
-            const int i = j + 1 + ii, k = j + 1 + kk;
-            S[(size_t)i * n + k] -= S[(size_t)i * n + j] * S[(size_t)k * n + j];
+        if (sFail) break;
+        // forward substitution with this panel: y[p0..p0+nb) then b[r] -= sum_c L[r][c] y[c] for the rows below
+        if (tid < 64) {
+            for (int c = 0; c < nb; c++) {
+                const double yc = sx[p0 + c] / panel[c * NB + c];
+                __builtin_amdgcn_wave_barrier();
+                if (tid == 0) sx[p0 + c] = yc;
+                for (int r = c + 1 + tid; r < nb; r += 64) sx[p0 + r] -= panel[r * NB + c] * yc;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int r = nb + tid; r < rows; r += 1024) {
+            double acc = 0;
+            for (int c = 0; c < nb; c++) acc += panel[r * NB + c] * sx[p0 + c];
+            sx[p0 + r] -= acc;
+        }
+        // write the factorised panel back, update the trailing matrix (lower triangle)
+        for (int idx = tid; idx < rows * nb; idx += 1024) { const int r = idx / nb, c = idx - r * nb; S[(size_t)(p0 + r) * n + p0 + c] = panel[r * NB + c]; }
+        // trailing update of the lower triangle in 4x4 register tiles: 8 LDS reads feed 16 multiply-adds
+        const int m = rows - nb, mt = (m + 3) >> 2;
+        for (int tIdx = tid; tIdx < mt * mt; tIdx += 1024) {
+            const int i4 = tIdx / mt, k4 = tIdx - i4 * mt;
+            if (k4 > i4) continue;
+            double acc[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int w = 0; w < 4; w++) acc[u][w] = 0;
+            const double *pa = panel + (nb + 4 * i4) * NB, *pb = panel + (nb + 4 * k4) * NB;
+            // rows past the end of the panel are never stored; clamp their reads into the panel
+            const int ra[4] = {0, min(1, m - 1 - 4 * i4) * NB, min(2, m - 1 - 4 * i4) * NB, min(3, m - 1 - 4 * i4) * NB};
+            const int rb[4] = {0, min(1, m - 1 - 4 * k4) * NB, min(2, m - 1 - 4 * k4) * NB, min(3, m - 1 - 4 * k4) * NB};
+            for (int c = 0; c < nb; c++) {
+                double a[4], bq[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { a[u] = pa[ra[u] + c]; bq[u] = pb[rb[u] + c]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++) acc[u][w] += a[u] * bq[w];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const int i = 4 * i4 + u, k = 4 * k4 + w;
+                    if (i < m && k <= i) S[(size_t)(p0 + nb + i) * n + p0 + nb + k] -= acc[u][w];
+                }
         }
         __syncthreads();
     }
     if (sFail) { if (tid == 0) *okFlag = 0; return; }
-    // forward then backward substitution by wave 0 (lock-step; the vector lives in LDS)
-    if (tid < 64) {
-        for (int i = tid; i < n; i += 64) sx[i] = bs[i];
-        __builtin_amdgcn_wave_barrier();
-        for (int j = 0; j < n; j++) {
-            const double yj = sx[j] / S[(size_t)j * n + j];
-            __builtin_amdgcn_wave_barrier();
-            if (tid == 0) sx[j] = yj;
-            for (int i = j + 1 + tid; i < n; i += 64) sx[i] -= S[(size_t)i * n + j] * yj;
-            __builtin_amdgcn_wave_barrier();
+    // backward substitution L^T x = y, panels from the last to the first
+    const int npan = (n + NB - 1) / NB;
+    for (int pi = npan - 1; pi >= 0; pi--) {
+        const int p0 = pi * NB, nb = min(NB, n - p0), rows = n - p0;
+        for (int idx = tid; idx < rows * nb; idx += 1024) { const int r = idx / nb, c = idx - r * nb; panel[r * NB + c] = S[(size_t)(p0 + r) * n + p0 + c]; }
+        __syncthreads();
+        // x[p0+c] needs y[p0+c] - sum_{r>c, r in panel} L[r][c] x[r] - sum_{rows below the panel} L[r][c] x[r]
+        if (tid < nb) {
+            double acc = 0;
+            for (int r = nb; r < rows; r++) acc += panel[r * NB + tid] * sx[p0 + r];
+            sx[p0 + tid] -= acc;
         }
-        for (int j = n - 1; j >= 0; j--) {
-            const double xj = sx[j] / S[(size_t)j * n + j];
-            __builtin_amdgcn_wave_barrier();
-            if (tid == 0) sx[j] = xj;
-            for (int i = tid; i < j; i += 64) sx[i] -= S[(size_t)j * n + i] * xj;
-            __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        if (tid < 64) {
+            for (int c = nb - 1; c >= 0; c--) {
+                const double xc = sx[p0 + c] / panel[c * NB + c];
+                __builtin_amdgcn_wave_barrier();
+                if (tid == 0) sx[p0 + c] = xc;
+                for (int r = tid; r < c; r += 64) sx[p0 + r] -= panel[c * NB + r] * xc;
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        for (int i = tid; i < n; i += 64) x[i] = sx[i];
-        if (tid == 0) *okFlag = 1;
+        __syncthreads();
     }
+    for (int i = tid; i < n; i += 1024) x[i] = sx[i];
+    if (tid == 0) *okFlag = 1;
 }
 
 // x_l = D^-1 (b_l - B^T x_p)   (block_solver.hpp:459-481)
@@ -939,7 +1063,22 @@ int optimize(Ctx &c, int iterations, double stats[4])
                                nP6, h->Dinv.p, h->S.p, h->bs.p);
             LCHECK();
             if (nP6 > 0) {
-                hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p);
+                {   // widest panel whose n x NB doubles fit next to the solution vector in LDS
+                    const size_t budget = 120 * 1024;
+                    if ((size_t)nP6 * 32 * 8 <= budget) {
+                        const size_t lds = (size_t)nP6 * 32 * 8;
+                        if (lds > 32 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_solve<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        hipLaunchKernelGGL(k_chol_solve<32>, dim3(1), dim3(1024), lds, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p);
+                    } else if ((size_t)nP6 * 16 * 8 <= budget) {
+                        const size_t lds = (size_t)nP6 * 16 * 8;
+                        ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_solve<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        hipLaunchKernelGGL(k_chol_solve<16>, dim3(1), dim3(1024), lds, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p);
+                    } else {
+                        const size_t lds = (size_t)nP6 * 4 * 8;
+                        ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        hipLaunchKernelGGL(k_chol_solve<4>, dim3(1), dim3(1024), lds, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p);
+                    }
+                }
                 LCHECK();
                 h->flops += (double)nP6 * nP6 * nP6 / 3.0;
             }
