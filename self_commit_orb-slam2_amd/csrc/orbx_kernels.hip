@@ -952,26 +952,37 @@ __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g
     const OrbxLevelKp kp = lvlKp[(size_t)f * g->kpPerFrame + slot];
     const uint8_t *img = blur + (size_t)f * g->pyrBytes + lv.off;
     const int pitch = lv.pitch;
+    const float lvScale = lv.scale;          // read before the gathers: nothing after them should wait on memory but the stores
+    const int lvPatch = lv.patchSize;
     const uint8_t *center = img + (size_t)kp.y * pitch + kp.x;
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     sincosf_glibc(kp.angle * factorPI, b, a);
     unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * g->outCap + outIdx) * 32);
+    // three dependent memory levels in total: the four pattern words, then the eight samples, then the stores
+    // (a store between the rounds would fence the next round's loads behind it)
+    uint32_t pat[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) pat[r] = *(const uint32_t *)(c_pattern + 4 * (64 * r + lane));
+    int t0[4], t1[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int8_t *p = c_pattern + 4 * (64 * r + lane);
-        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+        const float x0 = (float)(int8_t)(pat[r] & 0xff), y0 = (float)(int8_t)((pat[r] >> 8) & 0xff);
+        const float x1 = (float)(int8_t)((pat[r] >> 16) & 0xff), y1 = (float)(int8_t)(pat[r] >> 24);
         const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
-        const int t0 = center[r0 * pitch + c0], t1 = center[r1 * pitch + c1];
-        const unsigned long long m = __ballot(t0 < t1);
-        if (lane == 0) d64[r] = m;
+        t0[r] = center[r0 * pitch + c0];
+        t1[r] = center[r1 * pitch + c1];
     }
+    unsigned long long bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) bits[r] = __ballot(t0[r] < t1[r]);
+    if (lane < 4) d64[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
     if (lane == 0) {
         orbx_keypoint o;
-        o.x = l ? (float)kp.x * lv.scale : (float)kp.x;
-        o.y = l ? (float)kp.y * lv.scale : (float)kp.y;
-        o.size = (float)lv.patchSize; o.angle = kp.angle; o.response = (float)kp.score; o.octave = l; o.class_id = -1;
+        o.x = l ? (float)kp.x * lvScale : (float)kp.x;
+        o.y = l ? (float)kp.y * lvScale : (float)kp.y;
+        o.size = (float)lvPatch; o.angle = kp.angle; o.response = (float)kp.score; o.octave = l; o.class_id = -1;
         outKp[(size_t)f * g->outCap + outIdx] = o;
     }
 }
