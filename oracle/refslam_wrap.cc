@@ -515,3 +515,114 @@ ORBSLAM_API int orbslam_search_by_projection_last(const float *kpUn, const uint8
     delete kf;
     return nm;
 }
+
+#ifdef ORBSLAM_HIP
+// ---------------------------------------------------------------------------------------
+// Optimizer::LocalBundleAdjustment / PoseOptimization exist only in the drop-in build (g2o needs
+// Eigen, so the all-reference library has no Optimizer): shim/Optimizer_hip.cc on a REAL map built
+// from flat arrays - KeyFrames, MapPoints, observations, covisibility graph (KeyFrame::UpdateConnections).
+// ---------------------------------------------------------------------------------------
+#include "../self_commit_orb-slam2_amd/shim/Optimizer.h"
+
+// obs: E rows {point, keyframe, u, v, uR (<0 mono), octave}.  ref_kf = the keyframe LocalMapping just inserted.
+// Outputs: poses_out [K*16], points_out [P*3], erased [E] (the observation was removed as an outlier),
+// kf_role [K] (1 local, 2 fixed, 0 untouched).
+ORBSLAM_API int orbslam_local_ba(int K, const float *poses, const float *cam5, int P, const float *points, int E, const float *obs, int ref_kf,
+                                 const float *scaleFactors, int nlevels, int width, int height, float *poses_out, float *points_out, uint8_t *erased,
+                                 uint8_t *kf_role)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {cam5[0], cam5[1], cam5[2], cam5[3], cam5[4], width, height};
+    KeyFrame::nNextId = 0;   // the first keyframe of a map has id 0 and stays fixed (src/Optimizer.cc:722)
+    std::vector<std::vector<int> > kfObs((size_t)K);
+    for (int e = 0; e < E; e++) kfObs[(size_t)obs[6 * (size_t)e + 1]].push_back(e);
+    std::vector<KeyFrame *> kfs((size_t)K);
+    std::vector<int> obsIdx((size_t)E);
+    for (int k = 0; k < K; k++) {
+        const int n = (int)kfObs[(size_t)k].size();
+        std::vector<float> kps((size_t)(n > 0 ? n : 1) * 7, 0.f);
+        std::vector<uint8_t> desc((size_t)(n > 0 ? n : 1) * 32, 0);
+        for (int i = 0; i < n; i++) {
+            const float *o = obs + 6 * (size_t)kfObs[(size_t)k][(size_t)i];
+            float *kp = &kps[7 * (size_t)i];
+            kp[0] = o[2]; kp[1] = o[3]; kp[2] = 31.f; kp[3] = 0.f; kp[4] = 20.f; kp[5] = o[5]; kp[6] = -1.f;
+            obsIdx[(size_t)kfObs[(size_t)k][(size_t)i]] = i;
+        }
+        Frame F;
+        fill_frame(F, kps.data(), desc.data(), n, nullptr, cam, scaleFactors, nlevels);
+        for (int i = 0; i < n; i++) F.mvuRight[(size_t)i] = obs[6 * (size_t)kfObs[(size_t)k][(size_t)i] + 4];
+        cv::Mat T(4, 4, CV_32F);
+        memcpy(T.data, poses + 16 * (size_t)k, 64);
+        F.SetPose(T);
+        kfs[(size_t)k] = new KeyFrame(F, &map, (KeyFrameDatabase *)nullptr);
+        map.AddKeyFrame(kfs[(size_t)k]);
+    }
+    std::vector<MapPoint *> mps((size_t)P, (MapPoint *)nullptr);
+    for (int e = 0; e < E; e++) {
+        const int l = (int)obs[6 * (size_t)e], k = (int)obs[6 * (size_t)e + 1];
+        if (!mps[(size_t)l]) {
+            cv::Mat pos(3, 1, CV_32F);
+            memcpy(pos.data, points + 3 * (size_t)l, 12);
+            mps[(size_t)l] = new MapPoint(pos, kfs[(size_t)k], &map);
+            map.AddMapPoint(mps[(size_t)l]);
+        }
+        mps[(size_t)l]->AddObservation(kfs[(size_t)k], (size_t)obsIdx[(size_t)e]);
+        kfs[(size_t)k]->AddMapPoint(mps[(size_t)l], (size_t)obsIdx[(size_t)e]);
+    }
+    for (int k = 0; k < K; k++) kfs[(size_t)k]->UpdateConnections();
+    bool stop = false;
+    Optimizer::LocalBundleAdjustment(kfs[(size_t)ref_kf], &stop, &map);
+    for (int k = 0; k < K; k++) {
+        const cv::Mat T = kfs[(size_t)k]->GetPose();
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) poses_out[16 * (size_t)k + 4 * r + c] = T.at<float>(r, c);
+        kf_role[k] = kfs[(size_t)k]->mnBALocalForKF == kfs[(size_t)ref_kf]->mnId ? 1 : (kfs[(size_t)k]->mnBAFixedForKF == kfs[(size_t)ref_kf]->mnId ? 2 : 0);
+    }
+    for (int l = 0; l < P; l++) {
+        if (!mps[(size_t)l]) { memcpy(points_out + 3 * (size_t)l, points + 3 * (size_t)l, 12); continue; }
+        const cv::Mat X = mps[(size_t)l]->GetWorldPos();
+        for (int i = 0; i < 3; i++) points_out[3 * (size_t)l + i] = X.at<float>(i);
+    }
+    for (int e = 0; e < E; e++) {
+        const int l = (int)obs[6 * (size_t)e], k = (int)obs[6 * (size_t)e + 1];
+        erased[e] = mps[(size_t)l]->IsInKeyFrame(kfs[(size_t)k]) ? 0 : 1;
+    }
+    for (int l = 0; l < P; l++) delete mps[(size_t)l];
+    for (int k = 0; k < K; k++) delete kfs[(size_t)k];
+    return 0;
+}
+
+// Optimizer::PoseOptimization on a real Frame whose features all carry MapPoints.
+// kobs: n rows {u, v, uR (<0 mono), octave}.  Returns the function's return value.
+ORBSLAM_API int orbslam_pose_optimization(const float *pose16, const float *cam5, int n, const float *Xw, const float *kobs, const float *scaleFactors,
+                                          int nlevels, int width, int height, float *pose_out, uint8_t *outlier)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {cam5[0], cam5[1], cam5[2], cam5[3], cam5[4], width, height};
+    std::vector<float> kps((size_t)(n > 0 ? n : 1) * 7, 0.f);
+    std::vector<uint8_t> desc((size_t)(n > 0 ? n : 1) * 32, 0);
+    for (int i = 0; i < n; i++) { float *kp = &kps[7 * (size_t)i]; kp[0] = kobs[4 * (size_t)i]; kp[1] = kobs[4 * (size_t)i + 1]; kp[2] = 31.f; kp[5] = kobs[4 * (size_t)i + 3]; kp[6] = -1.f; }
+    Frame F;
+    fill_frame(F, kps.data(), desc.data(), n, nullptr, cam, scaleFactors, nlevels);
+    for (int i = 0; i < n; i++) F.mvuRight[(size_t)i] = kobs[4 * (size_t)i + 2];
+    cv::Mat T(4, 4, CV_32F);
+    memcpy(T.data, pose16, 64);
+    F.SetPose(T);
+    KeyFrame *kf = new KeyFrame(F, &map, (KeyFrameDatabase *)nullptr);
+    std::vector<MapPoint *> owned;
+    for (int i = 0; i < n; i++) {
+        cv::Mat pos(3, 1, CV_32F);
+        memcpy(pos.data, Xw + 3 * (size_t)i, 12);
+        MapPoint *mp = new MapPoint(pos, kf, &map);
+        F.mvpMapPoints[(size_t)i] = mp;
+        owned.push_back(mp);
+    }
+    const int ret = Optimizer::PoseOptimization(&F);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose_out[4 * r + c] = F.mTcw.at<float>(r, c);
+    for (int i = 0; i < n; i++) outlier[i] = F.mvbOutlier[(size_t)i] ? 1 : 0;
+    for (size_t i = 0; i < owned.size(); i++) delete owned[i];
+    delete kf;
+    return ret;
+}
+#endif

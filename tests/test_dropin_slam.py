@@ -132,3 +132,106 @@ def test_search_by_projection_last_frame_dropin_equals_reference(orbx):
         got_n, got = oracle_lib.ref_search_by_projection_last(fr, last, th, mono, 1, lib=hip)
         assert got_n == want_n and (got == want).all() and want_n > 150
     assert hip.orbx_shim_search_by_projection_calls() - before == 4
+
+
+def _octaves(inv_s2):
+    return np.rint(np.log(1.0 / inv_s2.astype(np.float64)) / (2 * np.log(1.2))).astype(np.int32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,stereo", [(5, 0.0), (6, 0.4)])
+def test_local_bundle_adjustment_dropin_on_a_real_map(orbx, oracle, seed, stereo):
+    """Optimizer::LocalBundleAdjustment (shim/Optimizer_hip.cc) on a real Map: KeyFrames, MapPoints,
+    observations and the covisibility graph are the reference's objects; the result is compared with the
+    CPU restatement run on the same window flattened independently here (which keyframes are local /
+    fixed follows from the reference's covisibility rule, re-derived below)."""
+    orbx.load_library()
+    hip = oracle_lib.slam_hip_lib()
+    hip.orbx_shim_lba_calls.restype = ctypes.c_ulong
+    before = hip.orbx_shim_lba_calls()
+    w = orbx.lba_synth.make_window(K=16, P=1200, seed=seed, max_obs=5, n_fixed=0, stereo_frac=stereo)
+    K, P, E = w["K"], w["P"], w["E"]
+    sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    octv = _octaves(w["edge_inv_sigma2"])
+    obs6 = np.ascontiguousarray(np.stack([w["edge_point"], w["edge_kf"], w["edge_obs"][:, 0], w["edge_obs"][:, 1], w["edge_obs"][:, 2], octv], 1), np.float32)
+    cam5 = np.ascontiguousarray(w["intr"][0], np.float32)
+    ref_kf = K - 1
+    poses_out, points_out = np.zeros((K, 16), np.float32), np.zeros((P, 3), np.float32)
+    erased, role = np.zeros(E, np.uint8), np.zeros(K, np.uint8)
+    _p = oracle_lib._p
+    hip.orbslam_local_ba.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+    hip.orbslam_local_ba(K, _p(w["poses"]), _p(cam5), P, _p(w["points"]), E, _p(obs6), ref_kf, _p(sf), 8, 640, 480, _p(poses_out), _p(points_out), _p(erased), _p(role))
+    assert hip.orbx_shim_lba_calls() - before == 1
+    # ---- the reference's window rule, re-derived: neighbours = keyframes sharing >= 15 points with ref_kf (KeyFrame::UpdateConnections, th = 15)
+    seen = np.zeros((K, P), bool)
+    seen[w["edge_kf"], w["edge_point"]] = True
+    shared = (seen & seen[ref_kf]).sum(1)
+    shared[ref_kf] = 0
+    neigh = shared >= 15 if (shared >= 15).any() else (shared == shared.max())
+    local = neigh.copy(); local[ref_kf] = True
+    local_pts = seen[local].any(0)
+    fixed_kf = seen[:, local_pts].any(1) & ~local
+    want_role = np.where(local, 1, np.where(fixed_kf, 2, 0))
+    assert (role == want_role).all(), (role, want_role)
+    # ---- flatten the same window for the restatement
+    kf_list = list(np.flatnonzero(local)) + list(np.flatnonzero(fixed_kf))
+    kf_new = {int(k): i for i, k in enumerate(kf_list)}
+    pt_list = np.flatnonzero(local_pts)
+    pt_new = -np.ones(P, np.int64); pt_new[pt_list] = np.arange(len(pt_list))
+    sel = local_pts[w["edge_point"]]
+    inv = (np.float32(1.0) / (sf[octv] * sf[octv])).astype(np.float32)       # Frame::mvInvLevelSigma2 as fill_frame builds it
+    fx = np.array([1 if (k == 0 or fixed_kf[k]) else 0 for k in kf_list], np.uint8)
+    prob = dict(K=len(kf_list), P=len(pt_list), E=int(sel.sum()), poses=np.ascontiguousarray(w["poses"][kf_list]), fixed=fx,
+                intr=np.ascontiguousarray(w["intr"][kf_list]), points=np.ascontiguousarray(w["points"][pt_list]),
+                edge_point=np.ascontiguousarray(pt_new[w["edge_point"][sel]].astype(np.int32)),
+                edge_kf=np.array([kf_new[int(k)] for k in w["edge_kf"][sel]], np.int32),
+                edge_obs=np.ascontiguousarray(w["edge_obs"][sel]), edge_inv_sigma2=np.ascontiguousarray(inv[sel]))
+    want = oracle_lib.local_bundle_adjustment(oracle, prob)
+    assert np.abs(poses_out[kf_list].astype(np.float64) - want["poses"]).max() <= 1e-5
+    assert np.abs(points_out[pt_list].astype(np.float64) - want["points"]).max() <= 1e-5
+    untouched = np.setdiff1d(np.arange(K), kf_list)
+    assert (poses_out[untouched] == w["poses"][untouched]).all() and (points_out[~local_pts] == w["points"][~local_pts]).all()
+    # every outlier observation is erased (:966-975).  MapPoint::EraseObservation additionally turns a point with <= 2 remaining
+    # observations bad, which removes ALL its observations (src/MapPoint.cc:176-215): those extra erasures must belong to
+    # points that lost an outlier observation.
+    er, out = erased[sel].astype(bool), want["outlier"].astype(bool)
+    th = np.where(prob["edge_obs"][:, 2] < 0, 5.991, 7.815)
+    miss = out & ~er
+    assert (np.abs(want["chi2"][miss] - th[miss]) < 1e-3).all()
+    pts_with_outlier = np.unique(prob["edge_point"][out])
+    extra = er & ~out
+    assert np.isin(prob["edge_point"][extra], pts_with_outlier).all()
+    assert erased[~sel].sum() == 0 and out.sum() > 10
+    # the optimisation really moved towards the truth
+    err0 = np.abs(w["poses"][kf_list].astype(np.float64) - w["true_poses"][kf_list]).max()
+    err1 = np.abs(poses_out[kf_list].astype(np.float64) - w["true_poses"][kf_list]).max()
+    assert err1 < 0.5 * err0
+
+
+@pytest.mark.gpu
+def test_pose_optimization_dropin_on_a_real_frame(orbx, oracle):
+    from test_pose_optimization import make_frame
+    orbx.load_library()
+    hip = oracle_lib.slam_hip_lib()
+    hip.orbx_shim_pose_optimization_calls.restype = ctypes.c_ulong
+    before = hip.orbx_shim_pose_optimization_calls()
+    rng = np.random.default_rng(3)
+    sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    _p = oracle_lib._p
+    for seed in (31, 32):
+        fr = make_frame(seed, n=700)
+        n = len(fr["Xw"])
+        octv = _octaves(fr["inv_sigma2"])
+        fr["inv_sigma2"] = (np.float32(1.0) / (sf[octv] * sf[octv])).astype(np.float32)    # what the Frame holds
+        kobs = np.ascontiguousarray(np.concatenate([fr["obs"], octv[:, None].astype(np.float32)], 1), np.float32)
+        pose = np.ascontiguousarray(fr["pose"].reshape(16), np.float32)
+        cam5 = np.ascontiguousarray(fr["cam"], np.float32)
+        out, outl = np.zeros(16, np.float32), np.zeros(n, np.uint8)
+        hip.orbslam_pose_optimization.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        ret = hip.orbslam_pose_optimization(_p(pose), _p(cam5), n, _p(np.ascontiguousarray(fr["Xw"], np.float32)), _p(kobs), _p(sf), 8, 640, 480, _p(out), _p(outl))
+        want = oracle_lib.pose_optimization(oracle, fr)
+        assert ret == want["inliers"] and (outl == want["outlier"]).all()
+        assert np.abs(out.reshape(4, 4).astype(np.float64) - want["pose"]).max() <= 1e-5
+    assert hip.orbx_shim_pose_optimization_calls() - before == 2
