@@ -223,7 +223,7 @@ int build_geometry(orbx_extractor *h, int W, int H)
     g.fcLdsBytes = g.fcInBytes + g.fcScBytes + (int)align_up((size_t)maxWCell * maxHCell * 2, 16);
     g.pyrBytes = align_up(off + 256, 256);
     if (maxNodes > 2048) { orbx_set_error("per-level feature quota %d exceeds the quadtree node capacity 2048", maxNodes); return ORBX_ERR_ARG; }
-    h->nodeCap = maxNodes <= 512 ? 512 : (maxNodes <= 1024 ? 1024 : 2048);
+    h->nodeCap = maxNodes <= 256 ? 256 : (maxNodes <= 512 ? 512 : (maxNodes <= 1024 ? 1024 : 2048));
     return ORBX_OK;
 }
 

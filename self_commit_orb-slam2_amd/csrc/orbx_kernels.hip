@@ -1031,7 +1031,9 @@ int orbx_launch_fast_cells(const OrbxLaunch &L)
 int orbx_launch_octree(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->nlevels, (unsigned)L.batch);
-    if (L.nodeCap <= 512)
+    if (L.nodeCap <= 256)   // 1000 features at 640x480: 224 nodes at most; half the LDS, twice the resident quadtrees per CU
+        hipLaunchKernelGGL(k_octree<256>, grid, dim3(256), 0, L.stream, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.lvlKp, L.lvlCnt, L.status);
+    else if (L.nodeCap <= 512)
         hipLaunchKernelGGL(k_octree<512>, grid, dim3(256), 0, L.stream, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.lvlKp, L.lvlCnt, L.status);
     else if (L.nodeCap <= 1024)
         hipLaunchKernelGGL(k_octree<1024>, grid, dim3(256), 0, L.stream, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.lvlKp, L.lvlCnt, L.status);
