@@ -180,120 +180,141 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
     }
 }
 
-// greedy replay + rotation histogram + three-maxima pruning; one workgroup per pair.  All four
-// waves stage the processing order and the candidate lists into LDS, then wave 0 alone replays
-// the reference's sequential pass (nothing in that loop waits on global memory: accepted matches
-// are recorded in LDS), and the rotation histogram (keypoint angles from HBM) is built in
-// parallel afterwards.
+// greedy replay + rotation histogram + three-maxima pruning; one workgroup per pair.
+//
+// The reference's pass over the A features is sequential only through the "already matched" flag
+// of the B features (src/ORBmatcher.cc:276-279, 722-724).  Number the A features by their position
+// r in the processing order: the decision of rank r is a function of the decisions of the ranks
+// below r only, so the sequential result is the UNIQUE fixed point of
+//     dec[r] = decide(candidates of r that no accepted rank r' < r has chosen)
+// (induction on r).  The kernel iterates that map for all ranks in parallel: owner[b] = lowest
+// accepted rank currently choosing b (LDS atomicMin), then every rank re-decides with "b is free
+// iff owner[b] >= r", until a round changes nothing.  After round t the ranks < t are final, so it
+// terminates; in practice conflicts are sparse and a handful of rounds suffice, instead of one
+// dependent step per feature.  A rank whose (full) candidate list has fewer than two free entries
+// left cannot be decided from the list: those ranks are queued and one wave each rescans all of B
+// exactly, as before.
 __global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
                                                     float nnratio, int checkOri, const uint32_t *__restrict__ topk, const int32_t *__restrict__ order,
                                                     int32_t *__restrict__ matches, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int hist[HISTO_LENGTH];
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, fa = pairsA[p], fb = pairsB[p];
+    __shared__ int sChanged, sQueued, sTotal, sRemoved;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, fa = pairsA[p], fb = pairsB[p];
     const int nA = min(A.counts[fa], A.cap), nB = min(B.counts[fb], B.cap);
-    // LDS: B bitmap | candidate lists | results per output slot | processing order (u16, 0xffff = no valid MapPoint)
-    uint32_t *taken = (uint32_t *)smem;
-    uint32_t *sTk = (uint32_t *)(smem + (((((B.cap + 31) >> 5) * 4) + 15) & ~15));
-    uint32_t *sRes = sTk + (size_t)A.cap * TOPK;                            // 0 = unmatched, else (dist << 16 | partner) + 1, later | rotation bin << 26
-    unsigned short *sOrd = (unsigned short *)(sRes + stride);
-    const int nOut = mode == 0 ? nB : nA;
+    // LDS: owner[B.cap] | dec[A.cap] (KEY_EMPTY = no match, else dist << 16 | b, later | rotation bin << 26) | order (u16) | rescan queue (u16)
+    uint32_t *owner = (uint32_t *)smem;
+    uint32_t *dec = owner + B.cap;
+    unsigned short *sOrd = (unsigned short *)(dec + A.cap);
+    unsigned short *queue = sOrd + ((A.cap + 7) & ~7);
     int32_t *mout = matches + (size_t)p * stride, *dout = dists + (size_t)p * stride;
-    for (int i = tid; i < stride; i += 256) sRes[i] = 0;
-    for (int i = tid; i < ((B.cap + 31) >> 5); i += 256) taken[i] = 0;
+    const uint4 *tk = (const uint4 *)(topk + (size_t)p * stride * TOPK);
     if (tid < HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) { sTotal = 0; sRemoved = 0; }
     {
         const int32_t *ord = order + (size_t)p * stride;
-        const uint4 *tk = (const uint4 *)(topk + (size_t)p * stride * TOPK);
         for (int r = tid; r < nA; r += 256) {
             int i = ord[r];
             if (A.valid && !A.valid[(size_t)fa * A.cap + i]) i = 0xffff;
             sOrd[r] = (unsigned short)i;
+            dec[r] = KEY_EMPTY;
         }
-        for (int t = tid; t < nA * (TOPK / 4); t += 256) ((uint4 *)sTk)[t] = tk[t];
     }
-    __syncthreads();
-    int total = 0;
-    if (tid < 64) {
-        for (int r = 0; r < nA; r++) {
+    for (int s = tid; s < stride; s += 256) { mout[s] = -1; dout[s] = 256; }
+    for (;;) {
+        for (int j = tid; j < nB; j += 256) owner[j] = 0xffffffffu;
+        if (tid == 0) { sChanged = 0; sQueued = 0; }
+        __syncthreads();
+        for (int r = tid; r < nA; r += 256) {
+            const uint32_t d = dec[r];
+            if (d != KEY_EMPTY) atomicMin(&owner[d & 0xffff], (uint32_t)r);
+        }
+        __syncthreads();
+        bool changed = false;
+        for (int r = tid; r < nA; r += 256) {
             const int i = sOrd[r];
             if (i == 0xffff) continue;
-            uint32_t key = lane < TOPK ? sTk[i * TOPK + lane] : KEY_EMPTY;
-            const bool present = key != KEY_EMPTY;
-            const int j = (int)(key & 0xffff);
-            const bool free_ = present && !((taken[j >> 5] >> (j & 31)) & 1u);
-            const unsigned mAll = (1u << TOPK) - 1u;
-            const unsigned mPresent = (unsigned)(__ballot(present) & mAll), mFree = (unsigned)(__ballot(free_) & mAll);
+            const uint4 q0 = tk[i * 2], q1 = tk[i * 2 + 1];
+            const uint32_t keys[TOPK] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
             uint32_t bestKey = KEY_EMPTY;
-            int best2 = 256;
-            if (__popc(mFree) >= 2 || mPresent != mAll) {
-                if (mFree) {
-                    const int la = __ffs(mFree) - 1;
-                    bestKey = __shfl(key, la);
-                    const unsigned rest = mFree & (mFree - 1);
-                    if (rest) best2 = (int)(__shfl(key, __ffs(rest) - 1) >> 16);
+            int best2 = 256, nfree = 0;
+#pragma unroll
+            for (int k = 0; k < TOPK; k++) {
+                const uint32_t key = keys[k];
+                const bool fr = key != KEY_EMPTY && owner[key & 0xffff] >= (uint32_t)r;
+                if (fr) {
+                    if (nfree == 0) bestKey = key;
+                    else if (nfree == 1) best2 = (int)(key >> 16);
+                    nfree++;
                 }
-            } else {
-                // exact rescan over the free B features of this node
-                const unsigned long long *da = (const unsigned long long *)(A.desc + ((size_t)fa * A.cap + i) * 32);
-                unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
-                const int gA = A.groups ? A.groups[(size_t)fa * A.cap + i] : 0;
-                uint32_t k0 = KEY_EMPTY, k1 = KEY_EMPTY;
-                for (int jj = lane; jj < nB; jj += 64) {
-                    if ((taken[jj >> 5] >> (jj & 31)) & 1u) continue;
-                    if (B.groups && B.groups[(size_t)fb * B.cap + jj] != gA) continue;
-                    if (mode == 1 && B.valid && !B.valid[(size_t)fb * B.cap + jj]) continue;
-                    const unsigned long long *db = (const unsigned long long *)(B.desc + ((size_t)fb * B.cap + jj) * 32);
-                    int d = hamming256(a, db[0], db[1], db[2], db[3]);
-                    uint32_t kk = ((uint32_t)d << 16) | (uint32_t)jj;
-                    if (kk < k0) { k1 = k0; k0 = kk; } else if (kk < k1) k1 = kk;
-                }
-                bestKey = wave_min_u32(k0);
-                if (k0 == bestKey) k0 = k1;
-                uint32_t second = wave_min_u32(k0);
-                if (second != KEY_EMPTY) best2 = (int)(second >> 16);
             }
-            if (bestKey == KEY_EMPTY) continue;
-            const int best1 = (int)(bestKey >> 16), bj = (int)(bestKey & 0xffff);
-            const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);
-            if (pass && (float)best1 < nnratio * (float)best2) {
-                if (lane == 0) {
-                    taken[bj >> 5] |= 1u << (bj & 31);
-                    const int slot = mode == 0 ? bj : i;
-                    sRes[slot] = (((uint32_t)best1 << 16) | (uint32_t)(mode == 0 ? i : bj)) + 1u;
-                }
-                total++;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the bitmap update is read by every lane in the next step
-                __builtin_amdgcn_wave_barrier();
+            if (nfree < 2 && keys[TOPK - 1] != KEY_EMPTY) { queue[atomicAdd(&sQueued, 1)] = (unsigned short)r; continue; }
+            uint32_t nd = KEY_EMPTY;
+            if (bestKey != KEY_EMPTY) {
+                const int best1 = (int)(bestKey >> 16);
+                const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);
+                if (pass && (float)best1 < nnratio * (float)best2) nd = bestKey;
             }
+            if (nd != dec[r]) { dec[r] = nd; changed = true; }
         }
+        if (changed) sChanged = 1;
+        __syncthreads();
+        // exact rescans: one wave per queued rank, lanes over the B features of its node
+        const int nq = sQueued;
+        for (int q = wv; q < nq; q += 4) {
+            const int r = queue[q], i = sOrd[r];
+            const unsigned long long *da = (const unsigned long long *)(A.desc + ((size_t)fa * A.cap + i) * 32);
+            unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
+            const int gA = A.groups ? A.groups[(size_t)fa * A.cap + i] : 0;
+            uint32_t k0 = KEY_EMPTY, k1 = KEY_EMPTY;
+            for (int jj = lane; jj < nB; jj += 64) {
+                if (owner[jj] < (uint32_t)r) continue;
+                if (B.groups && B.groups[(size_t)fb * B.cap + jj] != gA) continue;
+                if (mode == 1 && B.valid && !B.valid[(size_t)fb * B.cap + jj]) continue;
+                const unsigned long long *db = (const unsigned long long *)(B.desc + ((size_t)fb * B.cap + jj) * 32);
+                int d = hamming256(a, db[0], db[1], db[2], db[3]);
+                uint32_t kk = ((uint32_t)d << 16) | (uint32_t)jj;
+                if (kk < k0) { k1 = k0; k0 = kk; } else if (kk < k1) k1 = kk;
+            }
+            const uint32_t bestKey = wave_min_u32(k0);
+            if (k0 == bestKey) k0 = k1;
+            const uint32_t second = wave_min_u32(k0);
+            uint32_t nd = KEY_EMPTY;
+            if (bestKey != KEY_EMPTY) {
+                const int best1 = (int)(bestKey >> 16), best2 = second != KEY_EMPTY ? (int)(second >> 16) : 256;
+                const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);
+                if (pass && (float)best1 < nnratio * (float)best2) nd = bestKey;
+            }
+            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChanged = 1; }
+        }
+        __syncthreads();
+        const int again = sChanged;
+        __syncthreads();
+        if (!again) break;
     }
-    __syncthreads();
-    // ---- results + rotation histogram (src/ORBmatcher.cc:318-332, 750-758), all 256 threads ----
+    // ---- results + rotation histogram (src/ORBmatcher.cc:318-332, 750-758) ----
     const orbx_keypoint *kA = A.kp + (size_t)fa * A.cap, *kB = B.kp + (size_t)fb * B.cap;
     const float factor = HISTO_LENGTH / 360.0f;
-    for (int s = tid; s < stride; s += 256) {
-        const uint32_t rv = s < nOut ? sRes[s] : 0u;
-        int mval = -1, dval = 256;
-        if (rv) {
-            const uint32_t v = rv - 1u;
-            mval = (int)(v & 0xffff); dval = (int)(v >> 16);
-            if (checkOri) {
-                const int i = mode == 0 ? mval : s, bj = mode == 0 ? s : mval;
-                float rot = kA[i].angle - kB[bj].angle;
-                if (rot < 0.0f) rot += 360.0f;
-                int bin = (int)roundf(rot * factor);
-                if (bin == HISTO_LENGTH) bin = 0;
-                sRes[s] = rv | ((uint32_t)bin << 26);
-                atomicAdd(&hist[bin], 1);
-            }
+    int total = 0;
+    for (int r = tid; r < nA; r += 256) {
+        const uint32_t d = dec[r];
+        if (d == KEY_EMPTY) continue;
+        const int i = sOrd[r], bj = (int)(d & 0xffff), slot = mode == 0 ? bj : i;
+        mout[slot] = mode == 0 ? i : bj; dout[slot] = (int)(d >> 16);
+        total++;
+        if (checkOri) {
+            float rot = kA[i].angle - kB[bj].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            dec[r] = d | ((uint32_t)bin << 26);
+            atomicAdd(&hist[bin], 1);
         }
-        mout[s] = mval; dout[s] = dval;
     }
-    __syncthreads();
-    __shared__ int sRemoved;
-    if (tid == 0) sRemoved = 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if (lane == 0 && total) atomicAdd(&sTotal, total);
     __syncthreads();
     if (checkOri) {
         // ComputeThreeMaxima, src/ORBmatcher.cc:1866-1908
@@ -307,17 +328,21 @@ __global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const 
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         int removed = 0;
-        for (int s = tid; s < nOut; s += 256) {
-            if (!sRes[s]) continue;
-            const int b = (int)(sRes[s] >> 26);
-            if (b != ind1 && b != ind2 && b != ind3) { mout[s] = -1; dout[s] = 256; removed++; }
+        for (int r = tid; r < nA; r += 256) {       // same rank -> thread mapping as the writes above
+            const uint32_t d = dec[r];
+            if (d == KEY_EMPTY) continue;
+            const int b = (int)(d >> 26);
+            if (b != ind1 && b != ind2 && b != ind3) {
+                const int slot = mode == 0 ? (int)(d & 0xffff) : (int)sOrd[r];
+                mout[slot] = -1; dout[slot] = 256; removed++;
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
         if (lane == 0 && removed) atomicAdd(&sRemoved, removed);
     }
     __syncthreads();
-    if (tid == 0) nmatches[p] = total - sRemoved;
+    if (tid == 0) nmatches[p] = sTotal - sRemoved;
 }
 
 // Hamming stage of Frame::ComputeStereoMatches: one wave per left keypoint, lanes over the
@@ -1114,7 +1139,7 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->evMid[slot], m->stream));
     m->midValid[slot] = true;
-    const size_t ldsGreedy = (size_t)((b->capacity + 31) / 32) * 4 + 32 + (size_t)a->capacity * 4 * TOPK + (size_t)stride * 4 + (size_t)(a->capacity + 8) * 2;
+    const size_t ldsGreedy = (size_t)b->capacity * 4 + (size_t)a->capacity * 4 + (size_t)((a->capacity + 7) & ~7) * 2 * 2;
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
     if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
     hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(256), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, params->nn_ratio,
