@@ -358,6 +358,49 @@ int orbx_bow_transform(orbx_vocabulary *v, const uint8_t *descriptors, int n, in
 
 
 /* ------------------------------------------------------------------------------------
+ * Rest of the Frame constructor  ==  Frame::UndistortKeyPoints (reference src/Frame.cc:899-947),
+ * Frame::ComputeImageBounds (:950-1004) and Frame::AssignFeaturesToGrid / PosInGrid
+ * (:460-491, 868-878); called from both Frame constructors (src/Frame.cc:181, 210, 234 and
+ * 422-456).  One handle per camera (mK, mDistCoef).
+ * ---------------------------------------------------------------------------------- */
+#define ORBX_FRAME_GRID_COLS 64 /* FRAME_GRID_COLS, include/Frame.h:55-60 */
+#define ORBX_FRAME_GRID_ROWS 48 /* FRAME_GRID_ROWS                         */
+typedef struct orbx_frame_ops orbx_frame_ops;
+typedef struct orbx_camera {
+    float fx, fy, cx, cy; /* mK                                                                   */
+    float dist[5];        /* mDistCoef: k1 k2 p1 p2 [k3]; dist[0] == 0 means "already rectified",
+                             the reference's own test (src/Frame.cc:901, 953)                     */
+    int ndist;            /* 4 or 5 (src/Tracking.cc:127-136 appends k3 only when non-zero)       */
+} orbx_camera;
+/* The statics PosInGrid reads (src/Frame.cc:868-878): Frame::mnMinX, mnMinY,
+ * mfGridElementWidthInv = 64/(mnMaxX-mnMinX), mfGridElementHeightInv = 48/(mnMaxY-mnMinY) (:326-327). */
+typedef struct orbx_frame_grid {
+    float min_x, min_y, width_inv, height_inv;
+} orbx_frame_grid;
+
+int orbx_frame_ops_create(int device, const orbx_camera *camera, orbx_frame_ops **out);
+void orbx_frame_ops_destroy(orbx_frame_ops *h);
+/* Frame::ComputeImageBounds(imLeft): bounds = mnMinX, mnMaxX, mnMinY, mnMaxY for a cols x rows image. */
+int orbx_frame_image_bounds(orbx_frame_ops *h, int cols, int rows, float *bounds);
+/* Frame::UndistortKeyPoints on n host keypoints (upload, run, download): kp_un[i] = keypoints[i]
+ * with pt replaced by the undistorted point. */
+int orbx_frame_undistort(orbx_frame_ops *h, const orbx_keypoint *keypoints, int n, orbx_keypoint *kp_un);
+/* Frame::AssignFeaturesToGrid on n host mvKeysUn: mGrid as CSR, cell = x*ORBX_FRAME_GRID_ROWS + y,
+ * grid_offsets[cell .. cell+1] (64*48+1 entries) delimit the feature indices of mGrid[x][y] inside
+ * grid_indices[n], in the reference's push_back (= ascending) order. */
+int orbx_frame_assign_grid(orbx_frame_ops *h, const orbx_frame_grid *grid, const orbx_keypoint *kp_un, int n,
+                           int32_t *grid_offsets, int32_t *grid_indices);
+/* Both, fused, for every frame of the extractor's LAST batch on the extractor's stream.  Results stay
+ * on the device: mvKeysUn laid out like the extractor's keypoints (feature i of frame f at
+ * f*capacity + i), grid_offsets[f*(64*48+1) + ...], grid_indices[f*capacity + ...]. */
+int orbx_frame_finish_device(orbx_frame_ops *h, orbx_extractor *ext, const orbx_frame_grid *grid);
+int orbx_frame_results_device(orbx_frame_ops *h, const orbx_keypoint **kp_un_dev, const int32_t **grid_offsets_dev,
+                              const int32_t **grid_indices_dev, int *capacity);
+int orbx_frame_download(orbx_frame_ops *h, orbx_extractor *ext, int batch, orbx_keypoint *kp_un, int32_t *grid_offsets,
+                        int32_t *grid_indices);
+
+
+/* ------------------------------------------------------------------------------------
  * Local bundle adjustment  ==  the numerical core of Optimizer::LocalBundleAdjustment
  * (reference include/Optimizer.h:112, src/Optimizer.cc:629-997): g2o BlockSolver_6_3 +
  * Levenberg-Marquardt with Schur complement, 5 robust (Huber) iterations, outlier

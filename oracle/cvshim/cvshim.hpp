@@ -583,10 +583,33 @@ inline void GaussianBlur(InputArray _src, OutputArray _dst, Size ksize, double s
 
 // Only reached with non-zero distortion coefficients (src/Frame.cc:905-912 returns early
 // otherwise); the synthetic cameras of the tests are distortion free.
-inline void undistortPoints(InputArray, OutputArray, InputArray, InputArray, InputArray = _InputArray(), InputArray = _InputArray())
+// cv::undistortPoints for the one form the reference uses (src/Frame.cc:925-931, 972): N x 1
+// CV_32FC2 points, 3x3 K, 4/5/8 distortion coefficients, empty R, P = 3x3; dst may be src.
+inline void undistortPoints(InputArray _src, OutputArray _dst, InputArray _K, InputArray _dist, InputArray _R = _InputArray(),
+                            InputArray _P = _InputArray())
 {
-    fprintf(stderr, "cvshim: cv::undistortPoints is not provided (distortion-free cameras only)\n");
-    abort();
+    Mat src = _src.getMat(), Km = _K.getMat(), dist = _dist.getMat(), P = _P.getMat();
+    assert(src.type() == CV_32FC2 && src.isContinuous() && (src.cols == 1 || src.rows == 1));
+    assert(_R.empty() && Km.rows == 3 && Km.cols == 3);
+    double K[9], RR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K[3 * i + j] = Km.get(i, j);
+    int iters = 0;
+    if (!dist.empty()) {
+        const int nd = dist.rows * dist.cols;
+        assert((dist.rows == 1 || dist.cols == 1) && (nd == 4 || nd == 5 || nd == 8));
+        for (int i = 0; i < nd; i++) k[i] = dist.rows == 1 ? dist.get(0, i) : dist.get(i, 0);
+        iters = 5;
+    }
+    if (!P.empty()) {
+        // cvMatMul(PP, RR, RR) with RR = identity: every entry is PP[i][j]*1 plus exact zeros
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) RR[3 * i + j] = P.get(i, j);
+    }
+    const int n = src.rows * src.cols;
+    std::vector<float> out((size_t)2 * n);
+    op_undistort_points((const float *)src.data, out.data(), n, K, k, RR, iters);
+    Mat &dst = _dst.getMatRef();
+    if (!(dst.data && dst.type() == CV_32FC2 && dst.rows == src.rows && dst.cols == src.cols)) dst.create(src.rows, src.cols, CV_32FC2);
+    memcpy(dst.data, out.data(), out.size() * sizeof(float));
 }
 
 struct KeyPointsFilter {

@@ -518,3 +518,60 @@ MO_API int mo_search_by_projection_last(const float *kpUn, const uint8_t *desc, 
     }
     return nmatches;
 }
+
+// ---------------------------------------------------------------------------------------
+// Frame::UndistortKeyPoints (src/Frame.cc:899-947), Frame::ComputeImageBounds (:950-1004),
+// the grid constants of the constructor (src/Frame.cc:326-327) and
+// Frame::AssignFeaturesToGrid / PosInGrid (:460-491, 868-878) on flat arrays.
+// cam = fx, fy, cx, cy; dist = ndist (4 or 5) coefficients k1 k2 p1 p2 [k3] as stored in
+// mDistCoef (float).  bounds = mnMinX, mnMaxX, mnMinY, mnMaxY; grid as CSR over
+// cell = x*48 + y with the indices of a cell in ascending order (= push_back order).
+// cv::undistortPoints is prims.h's op_undistort_points (parity unpinned at that level).
+// ---------------------------------------------------------------------------------------
+#include "prims.h"
+
+namespace {
+
+void undistort(const float *src, float *dst, int n, const float *cam, const float *dist, int ndist)
+{
+    double K[9] = {cam[0], 0, cam[2], 0, cam[1], cam[3], 0, 0, 1}, k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ndist; i++) k[i] = dist[i];
+    op_undistort_points(src, dst, n, K, k, K, 5);
+}
+}  // namespace
+
+MO_API void mo_frame_finish(const float *kp, int n, const float *cam, const float *dist, int ndist, int cols, int rows, float *kpUn,
+                            float *bounds, float *gridInv, int32_t *gridOff, int32_t *gridIdx)
+{
+    const bool distorted = dist[0] != 0.0f;   // :901, :953
+    std::vector<float> xy((size_t)2 * std::max(n, 1));
+    for (int i = 0; i < n; i++) { xy[2 * i] = kp[7 * i]; xy[2 * i + 1] = kp[7 * i + 1]; }
+    if (distorted) undistort(xy.data(), xy.data(), n, cam, dist, ndist);
+    for (int i = 0; i < n; i++) {
+        memcpy(kpUn + 7 * (size_t)i, kp + 7 * (size_t)i, 7 * sizeof(float));
+        kpUn[7 * (size_t)i] = xy[2 * i]; kpUn[7 * (size_t)i + 1] = xy[2 * i + 1];
+    }
+    if (distorted) {
+        float c[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows};
+        undistort(c, c, 4, cam, dist, ndist);
+        bounds[0] = std::min(c[0], c[4]); bounds[1] = std::max(c[2], c[6]);
+        bounds[2] = std::min(c[1], c[3]); bounds[3] = std::max(c[5], c[7]);
+    } else {
+        bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows;
+    }
+    gridInv[0] = (float)GRID_COLS / (float)(bounds[1] - bounds[0]);
+    gridInv[1] = (float)GRID_ROWS / (float)(bounds[3] - bounds[2]);
+    std::vector<std::vector<int32_t> > grid((size_t)GRID_COLS * GRID_ROWS);
+    for (int i = 0; i < n; i++) {
+        const int px = (int)round((kpUn[7 * (size_t)i] - bounds[0]) * gridInv[0]);
+        const int py = (int)round((kpUn[7 * (size_t)i + 1] - bounds[2]) * gridInv[1]);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+        grid[(size_t)px * GRID_ROWS + py].push_back(i);
+    }
+    int o = 0;
+    for (int c = 0; c < GRID_COLS * GRID_ROWS; c++) {
+        gridOff[c] = o;
+        for (size_t t = 0; t < grid[(size_t)c].size(); t++) gridIdx[o++] = grid[(size_t)c][t];
+    }
+    gridOff[GRID_COLS * GRID_ROWS] = o;
+}

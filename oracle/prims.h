@@ -241,6 +241,36 @@ static inline void op_gauss7_u8(const uint8_t *src, int w, int h, size_t sstep,
     free(hb);
 }
 
+/* ---- cv::undistortPoints(src, dst, K, distCoeffs, R = noArray(), P) for CV_32FC2 points
+ * (calib3d/imgproc undistort.cpp, cvUndistortPoints of OpenCV 2.4.x .. 3.3: FIVE fixed
+ * iterations of the inverse distortion model, everything in double, result stored as
+ * float; later versions add a convergence criterion -- un-vendored and unpinned like the
+ * rest of this file).  K: 3x3 camera matrix, k[8] = k1 k2 p1 p2 k3 k4 k5 k6 (zeros when
+ * absent), RR = P * R (3x3).  iters = 5 when distortion coefficients are given, else 0. */
+static inline void op_undistort_points(const float *src, float *dst, int n, const double *K, const double *k,
+                                       const double *RR, int iters)
+{
+    const double fx = K[0], fy = K[4], ifx = 1. / fx, ify = 1. / fy, cx = K[2], cy = K[5];
+    for (int i = 0; i < n; i++) {
+        double x = src[2 * i], y = src[2 * i + 1], x0, y0;
+        x0 = x = (x - cx) * ifx;
+        y0 = y = (y - cy) * ify;
+        for (int j = 0; j < iters; j++) {
+            double r2 = x * x + y * y;
+            double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        double xx = RR[0] * x + RR[1] * y + RR[2];
+        double yy = RR[3] * x + RR[4] * y + RR[5];
+        double ww = 1. / (RR[6] * x + RR[7] * y + RR[8]);
+        dst[2 * i] = (float)(xx * ww);
+        dst[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
 /* ---- glibc 2.35 sinf/cosf (sysdeps/ieee754/flt-32/s_sincosf.h, s_sinf.c, s_cosf.c;
  * the Arm optimized-routines algorithm) restated for |x| < 120: double polynomial,
  * one multiply-subtract range reduction, result rounded to float.  The reference

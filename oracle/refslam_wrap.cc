@@ -68,6 +68,19 @@ struct CallScope {
     CallScope() { region_init(); t_is_caller = true; t_arena.state = 2; g_workers_use_arena.fetch_add(1); }
     ~CallScope() { g_workers_use_arena.fetch_sub(1); }
 };
+// The monocular Frame constructor extracts on the CALLING thread: give it a fresh bump chunk for
+// the duration of the constructor so that DistributeOctTree sees allocation-ordered addresses there too.
+struct CallerArena {
+    CallerArena()
+    {
+        size_t c = g_next_chunk.fetch_add(1);
+        if ((c + 1) * kChunk > kRegion) { fprintf(stderr, "orbslam: arena region exhausted\n"); abort(); }
+        t_arena.base = g_region + c * kChunk;
+        t_arena.off = 0;
+        t_arena.state = 1;
+    }
+    ~CallerArena() { t_arena.state = 2; }
+};
 }  // namespace
 
 #define ORBSLAM_HIDDEN __attribute__((visibility("hidden")))
@@ -222,6 +235,46 @@ ORBSLAM_API int orbslam_stereo_frame(const uint8_t *imL, const uint8_t *imR, int
     }
     delete exL;
     delete exR;
+    return 0;
+}
+
+// Frame::Frame(imGray, ...) (monocular constructor, src/Frame.cc:345-457): ExtractORB,
+// UndistortKeyPoints (:899-947), ComputeImageBounds (:950-1004), AssignFeaturesToGrid (:460-491).
+// dist: ndist (4 or 5) coefficients k1 k2 p1 p2 [k3].  bounds = mnMinX, mnMaxX, mnMinY, mnMaxY,
+// gridInv = mfGridElementWidthInv / HeightInv; grid as CSR over cell = x*FRAME_GRID_ROWS + y:
+// gridOff[64*48+1], gridIdx[N] = the contents of mGrid[x][y] in push_back order.
+ORBSLAM_API int orbslam_mono_frame(const uint8_t *im, int w, int h, int stride, int nfeatures, float scaleFactor, int nlevels,
+                                   int iniTh, int minTh, float fx, float fy, float cx, float cy, const float *dist, int ndist,
+                                   float *kps, float *kpsUn, uint8_t *desc, int cap, float *bounds, float *gridInv,
+                                   int32_t *gridOff, int32_t *gridIdx, int *n)
+{
+    CallScope scope;
+    ORBextractor *ex = new ORBextractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+    cv::Mat I(h, w, CV_8UC1, (void *)im, (size_t)stride);
+    cv::Mat K = make_K(fx, fy, cx, cy), D(ndist, 1, CV_32F);
+    for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
+    Frame::mbInitialComputations = true;
+    {
+        CallerArena arena;
+        Frame F(I, 0.0, ex, (ORBVocabulary *)nullptr, K, D, 40.0f, 40.0f);
+        *n = F.N;
+        for (int i = 0; i < F.N && i < cap; i++) {
+            put_kp(kps + 7 * (size_t)i, F.mvKeys[i]);
+            put_kp(kpsUn + 7 * (size_t)i, F.mvKeysUn[i]);
+            memcpy(desc + 32 * (size_t)i, F.mDescriptors.ptr(i), 32);
+        }
+        bounds[0] = Frame::mnMinX; bounds[1] = Frame::mnMaxX; bounds[2] = Frame::mnMinY; bounds[3] = Frame::mnMaxY;
+        gridInv[0] = Frame::mfGridElementWidthInv; gridInv[1] = Frame::mfGridElementHeightInv;
+        int o = 0;
+        for (int x = 0; x < FRAME_GRID_COLS; x++)
+            for (int y = 0; y < FRAME_GRID_ROWS; y++) {
+                gridOff[x * FRAME_GRID_ROWS + y] = o;
+                for (size_t t = 0; t < F.mGrid[x][y].size(); t++, o++)
+                    if (o < cap) gridIdx[o] = (int32_t)F.mGrid[x][y][t];
+            }
+        gridOff[FRAME_GRID_COLS * FRAME_GRID_ROWS] = o;
+    }
+    delete ex;
     return 0;
 }
 

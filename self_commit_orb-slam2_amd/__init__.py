@@ -594,6 +594,101 @@ class Vocabulary:
         return w, nd, wt
 
 
+class Camera(ctypes.Structure):
+    """orbx_camera: mK and mDistCoef (k1 k2 p1 p2 [k3])."""
+    _fields_ = [("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float), ("cy", ctypes.c_float),
+                ("dist", ctypes.c_float * 5), ("ndist", ctypes.c_int)]
+
+
+FRAME_GRID_COLS, FRAME_GRID_ROWS = 64, 48
+
+
+class FrameGrid(ctypes.Structure):
+    """orbx_frame_grid: Frame::mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv."""
+    _fields_ = [("min_x", ctypes.c_float), ("min_y", ctypes.c_float), ("width_inv", ctypes.c_float), ("height_inv", ctypes.c_float)]
+
+    @classmethod
+    def from_bounds(cls, bounds):
+        """the grid constants as the Frame constructor derives them from the image bounds (src/Frame.cc:326-327)"""
+        b = np.asarray(bounds, np.float32)
+        return cls(float(b[0]), float(b[2]), float(np.float32(FRAME_GRID_COLS) / np.float32(b[1] - b[0])),
+                   float(np.float32(FRAME_GRID_ROWS) / np.float32(b[3] - b[2])))
+
+
+class FrameOps:
+    """Frame::UndistortKeyPoints, ComputeImageBounds and AssignFeaturesToGrid on the device
+    (reference src/Frame.cc:899-1004, 460-491) for one camera (mK, mDistCoef)."""
+
+    def __init__(self, fx, fy, cx, cy, dist, device=0):
+        self._L = load_library()
+        L = self._L
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        L.orbx_frame_ops_create.argtypes = [ci, vp, ctypes.POINTER(vp)]
+        L.orbx_frame_ops_destroy.argtypes = [vp]
+        L.orbx_frame_ops_destroy.restype = None
+        L.orbx_frame_image_bounds.argtypes = [vp, ci, ci, vp]
+        L.orbx_frame_undistort.argtypes = [vp, vp, ci, vp]
+        L.orbx_frame_assign_grid.argtypes = [vp, vp, vp, ci, vp, vp]
+        L.orbx_frame_finish_device.argtypes = [vp, vp, vp]
+        L.orbx_frame_results_device.argtypes = [vp, vp, vp, vp, vp]
+        L.orbx_frame_download.argtypes = [vp, vp, ci, vp, vp, vp]
+        cam = Camera(fx, fy, cx, cy)
+        dist = [float(d) for d in dist]
+        for i, d in enumerate(dist[:5]):
+            cam.dist[i] = d
+        cam.ndist = len(dist)
+        self._h = vp()
+        _check(L.orbx_frame_ops_create(device, ctypes.byref(cam), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbx_frame_ops_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ComputeImageBounds(self, cols, rows):
+        """mnMinX, mnMaxX, mnMinY, mnMaxY."""
+        b = np.zeros(4, np.float32)
+        _check(self._L.orbx_frame_image_bounds(self._h, cols, rows, _ptr(b)))
+        return b
+
+    def UndistortKeyPoints(self, keypoints):
+        kp = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE)
+        un = np.zeros(max(len(kp), 1), KEYPOINT_DTYPE)
+        _check(self._L.orbx_frame_undistort(self._h, _ptr(kp), len(kp), _ptr(un)))
+        return un[:len(kp)]
+
+    def AssignFeaturesToGrid(self, keypoints_un, grid):
+        """mGrid as CSR: offsets[64*48+1] over cell = x*48 + y, indices in push_back order."""
+        kp = np.ascontiguousarray(keypoints_un, dtype=KEYPOINT_DTYPE)
+        off = np.zeros(FRAME_GRID_COLS * FRAME_GRID_ROWS + 1, np.int32)
+        idx = np.zeros(max(len(kp), 1), np.int32)
+        _check(self._L.orbx_frame_assign_grid(self._h, ctypes.byref(grid), _ptr(kp), len(kp), _ptr(off), _ptr(idx)))
+        return off, idx[:off[-1]]
+
+    def finish_device(self, extractor, grid):
+        """both, fused, on the extractor's last batch (device resident)"""
+        _check(self._L.orbx_frame_finish_device(self._h, extractor._h, ctypes.byref(grid)))
+
+    def keypoints_un_device(self):
+        kp, cap = ctypes.c_void_p(), ctypes.c_int()
+        _check(self._L.orbx_frame_results_device(self._h, ctypes.byref(kp), None, None, ctypes.byref(cap)))
+        return kp, cap.value
+
+    def download(self, extractor, batch):
+        _, cap = self.keypoints_un_device()
+        un = np.zeros((batch, cap), KEYPOINT_DTYPE)
+        off = np.zeros((batch, FRAME_GRID_COLS * FRAME_GRID_ROWS + 1), np.int32)
+        idx = np.zeros((batch, cap), np.int32)
+        _check(self._L.orbx_frame_download(self._h, extractor._h, batch, _ptr(un), _ptr(off), _ptr(idx)))
+        return un, off, idx
+
+
 class LbaProblem(ctypes.Structure):
     _fields_ = [("num_keyframes", ctypes.c_int), ("poses", ctypes.c_void_p), ("fixed", ctypes.c_void_p), ("intrinsics", ctypes.c_void_p),
                 ("num_points", ctypes.c_int), ("points", ctypes.c_void_p), ("num_edges", ctypes.c_int), ("edge_point", ctypes.c_void_p),

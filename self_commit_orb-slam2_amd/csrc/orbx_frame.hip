@@ -1,0 +1,297 @@
+// orbx_frame.hip -- the rest of the Frame constructor on gfx950.
+//
+//   orbx_frame_undistort     ==  Frame::UndistortKeyPoints    (reference src/Frame.cc:899-947)
+//   orbx_frame_image_bounds  ==  Frame::ComputeImageBounds    (src/Frame.cc:950-1004)
+//   orbx_frame_assign_grid   ==  Frame::AssignFeaturesToGrid  (src/Frame.cc:460-491, PosInGrid :868-878)
+//   orbx_frame_finish_device ==  the first and the last fused, on an extractor's device-resident batch
+//
+// cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) is OpenCV's fixed five-iteration
+// inverse of the radial/tangential model, evaluated in double from float inputs and stored as
+// float (cvUndistortPoints; un-vendored, see DESIGN.md section 3 "parity unpinned").  The
+// operation order below is that function's; the library is built with -ffp-contract=off and
+// double division is IEEE, so the device result equals the host result bit for bit.
+//
+// One workgroup per frame: undistort + cell id per keypoint, then the 64x48 grid as CSR
+// (cell = x*48 + y as in mGrid[x][y]; indices of a cell ascending = push_back order):
+// LDS histogram, scan, unordered scatter, per-cell insertion sort (cells hold < 1 feature on
+// average).  A few hundred bytes per keypoint and ~200 FP64 flops: negligible next to the
+// extraction it follows on the same stream.
+#include <string.h>
+
+#include "orbx_internal.h"
+
+namespace {
+
+const int GC = ORBX_FRAME_GRID_COLS, GR = ORBX_FRAME_GRID_ROWS, NCELL = GC * GR;
+
+struct CamDev {
+    double fx, fy, cx, cy, k[8];
+    int distorted;
+};
+
+__device__ __forceinline__ void undistort_point(const CamDev &c, float u, float v, float *ou, float *ov)
+{
+    const double ifx = 1. / c.fx, ify = 1. / c.fy;
+    double x = u, y = v, x0, y0;
+    x0 = x = (x - c.cx) * ifx;
+    y0 = y = (y - c.cy) * ify;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((c.k[7] * r2 + c.k[6]) * r2 + c.k[5]) * r2) / (1 + ((c.k[4] * r2 + c.k[1]) * r2 + c.k[0]) * r2);
+        const double deltaX = 2 * c.k[2] * x * y + c.k[3] * (r2 + 2 * x * x);
+        const double deltaY = c.k[2] * (r2 + 2 * y * y) + 2 * c.k[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    // P = K, R = I: RR = K
+    const double xx = c.fx * x + 0.0 * y + c.cx;
+    const double yy = 0.0 * x + c.fy * y + c.cy;
+    const double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    *ou = (float)(xx * ww);
+    *ov = (float)(yy * ww);
+}
+
+__global__ void k_undistort_corners(CamDev c, float cols, float rows, float *out)
+{
+    const int t = threadIdx.x;
+    if (t >= 4) return;
+    const float u = (t & 1) ? cols : 0.0f, v = (t & 2) ? rows : 0.0f;   // (0,0) (cols,0) (0,rows) (cols,rows), src/Frame.cc:961-968
+    undistort_point(c, u, v, out + 2 * t, out + 2 * t + 1);
+}
+
+// undistort: kp -> kpUn (else kp is already mvKeysUn and kpUn may be NULL); grid: build the CSR
+__global__ __launch_bounds__(256) void k_frame_finish(CamDev c, orbx_frame_grid g, int undistort, int grid, const orbx_keypoint *__restrict__ kp,
+                                                      const int32_t *__restrict__ counts, int cap, orbx_keypoint *__restrict__ kpUn,
+                                                      int32_t *__restrict__ gridOff, int32_t *__restrict__ gridIdx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int sWave[4];
+    int *cnt = (int *)smem;                                   // [NCELL] counts, then cursors
+    int *off = cnt + NCELL;                                   // [NCELL + 1]
+    unsigned short *cell = (unsigned short *)(off + NCELL + 1 + 1);   // [cap]
+    int *sorted = (int *)(cell + ((cap + 7) & ~7));           // [cap]
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = counts ? min(counts[f], cap) : cap;
+    const orbx_keypoint *in = kp + (size_t)f * cap;
+    for (int t = tid; t < NCELL; t += 256) cnt[t] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        orbx_keypoint k = in[i];
+        if (undistort) {
+            if (c.distorted) undistort_point(c, k.x, k.y, &k.x, &k.y);   // else mvKeysUn = mvKeys, src/Frame.cc:901-905
+            kpUn[(size_t)f * cap + i] = k;
+        }
+        if (grid) {
+            // PosInGrid, src/Frame.cc:868-878 (round() of a float: half away from zero)
+            const int px = (int)roundf((k.x - g.min_x) * g.width_inv), py = (int)roundf((k.y - g.min_y) * g.height_inv);
+            int ce = 0xffff;
+            if (!(px < 0 || px >= GC || py < 0 || py >= GR)) { ce = px * GR + py; atomicAdd(&cnt[ce], 1); }
+            cell[i] = (unsigned short)ce;
+        }
+    }
+    if (!grid) return;
+    __syncthreads();
+    // exclusive scan of the NCELL counts: 12 consecutive cells per thread
+    const int PER = NCELL / 256;
+    int local = 0;
+    for (int t = 0; t < PER; t++) local += cnt[tid * PER + t];
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) sWave[wv] = incl;
+    __syncthreads();
+    int base = incl - local;
+    for (int w = 0; w < wv; w++) base += sWave[w];
+    for (int t = 0; t < PER; t++) { const int cval = cnt[tid * PER + t]; off[tid * PER + t] = base; base += cval; }
+    if (tid == 255) off[NCELL] = base;
+    __syncthreads();
+    for (int t = tid; t < NCELL; t += 256) cnt[t] = off[t];   // cursors
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int ce = cell[i];
+        if (ce != 0xffff) sorted[atomicAdd(&cnt[ce], 1)] = i;
+    }
+    __syncthreads();
+    for (int ce = tid; ce < NCELL; ce += 256) {
+        const int b = off[ce], e = off[ce + 1];
+        for (int a = b + 1; a < e; a++) {
+            const int v = sorted[a];
+            int q = a - 1;
+            while (q >= b && sorted[q] > v) { sorted[q + 1] = sorted[q]; q--; }
+            sorted[q + 1] = v;
+        }
+    }
+    __syncthreads();
+    int32_t *go = gridOff + (size_t)f * (NCELL + 1), *gi = gridIdx + (size_t)f * cap;
+    for (int t = tid; t <= NCELL; t += 256) go[t] = off[t];
+    const int total = off[NCELL];
+    for (int t = tid; t < total; t += 256) gi[t] = sorted[t];
+}
+
+template <typename T> struct FBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n) return ORBX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        ORBX_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+        return ORBX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct orbx_frame_ops {
+    int device = 0;
+    hipStream_t stream = nullptr;   // host-array forms and the corner pass; the device form runs on the extractor's stream
+    CamDev cam;
+    // results, double buffered in lockstep with the extractor's result buffers
+    FBuf<orbx_keypoint> kpUn[2];
+    FBuf<int32_t> gridOff[2], gridIdx[2];
+    int cur = 0, lastBatch = 0, lastCap = 0;
+    FBuf<orbx_keypoint> hostKp;
+    FBuf<int32_t> hostCount;
+    FBuf<float> corners;
+};
+
+extern "C" int orbx_frame_ops_create(int device, const orbx_camera *cam, orbx_frame_ops **out)
+{
+    if (!out || !cam) { orbx_set_error("bad frame-ops arguments"); return ORBX_ERR_ARG; }
+    *out = nullptr;
+    if (cam->ndist != 4 && cam->ndist != 5) { orbx_set_error("ndist must be 4 or 5 (k1 k2 p1 p2 [k3]), got %d", cam->ndist); return ORBX_ERR_ARG; }
+    if (!(cam->fx != 0.0f) || !(cam->fy != 0.0f)) { orbx_set_error("focal length must be non-zero"); return ORBX_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { orbx_set_error("no HIP device available: liborbx has no CPU fallback"); return ORBX_ERR_NODEVICE; }
+    if (device < 0 || device >= ndev) { orbx_set_error("device %d out of range", device); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(device));
+    orbx_frame_ops *h = new orbx_frame_ops();
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
+    CamDev &c = h->cam;
+    c.fx = cam->fx; c.fy = cam->fy; c.cx = cam->cx; c.cy = cam->cy;
+    for (int i = 0; i < 8; i++) c.k[i] = i < cam->ndist ? (double)cam->dist[i] : 0.0;
+    c.distorted = cam->dist[0] != 0.0f;   // the reference's test, src/Frame.cc:901, 953
+    int rc = h->corners.ensure(8);
+    if (rc == ORBX_OK) rc = h->hostCount.ensure(1);
+    if (rc != ORBX_OK) { orbx_frame_ops_destroy(h); return rc; }
+    *out = h;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_frame_ops_destroy(orbx_frame_ops *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    for (int b = 0; b < 2; b++) { h->kpUn[b].release(); h->gridOff[b].release(); h->gridIdx[b].release(); }
+    h->hostKp.release(); h->hostCount.release(); h->corners.release();
+    delete h;
+}
+
+// Frame::ComputeImageBounds, src/Frame.cc:950-1004
+extern "C" int orbx_frame_image_bounds(orbx_frame_ops *h, int cols, int rows, float *bounds)
+{
+    if (!h || !bounds || cols < 1 || rows < 1) { orbx_set_error("bad argument"); return ORBX_ERR_ARG; }
+    if (!h->cam.distorted) {
+        bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows;
+        return ORBX_OK;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(h->device));
+    float hc[8];
+    hipLaunchKernelGGL(k_undistort_corners, dim3(1), dim3(64), 0, h->stream, h->cam, (float)cols, (float)rows, h->corners.p);
+    ORBX_HIP_CHECK(hipMemcpyAsync(hc, h->corners.p, sizeof(hc), hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    bounds[0] = hc[0] < hc[4] ? hc[0] : hc[4];   // mnMinX = min(top-left.x, bottom-left.x)
+    bounds[1] = hc[2] > hc[6] ? hc[2] : hc[6];   // mnMaxX = max(top-right.x, bottom-right.x)
+    bounds[2] = hc[1] < hc[3] ? hc[1] : hc[3];   // mnMinY = min(top-left.y, top-right.y)
+    bounds[3] = hc[5] > hc[7] ? hc[5] : hc[7];   // mnMaxY = max(bottom-left.y, bottom-right.y)
+    return ORBX_OK;
+}
+
+static int launch_finish(orbx_frame_ops *h, hipStream_t stream, const orbx_frame_grid *grid, bool undistort, const orbx_keypoint *kp, const int32_t *counts,
+                         int batch, int cap)
+{
+    int rc;
+    if (cap < 1 || cap > 0xfff0) { orbx_set_error("feature capacity %d out of range", cap); return ORBX_ERR_CAPACITY; }
+    h->cur ^= 1;
+    const int b = h->cur;
+    if (undistort && (rc = h->kpUn[b].ensure((size_t)batch * cap))) return rc;
+    if (grid && ((rc = h->gridOff[b].ensure((size_t)batch * (NCELL + 1))) || (rc = h->gridIdx[b].ensure((size_t)batch * cap)))) return rc;
+    const size_t lds = (size_t)(2 * NCELL + 2) * 4 + (size_t)((cap + 7) & ~7) * 2 + (size_t)cap * 4;
+    if (lds > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", cap); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_frame_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    orbx_frame_grid g = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (grid) g = *grid;
+    hipLaunchKernelGGL(k_frame_finish, dim3((unsigned)batch), dim3(256), lds, stream, h->cam, g, undistort ? 1 : 0, grid ? 1 : 0, kp, counts, cap,
+                       undistort ? h->kpUn[b].p : nullptr, grid ? h->gridOff[b].p : nullptr, grid ? h->gridIdx[b].p : nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+    h->lastBatch = batch; h->lastCap = cap;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_frame_finish_device(orbx_frame_ops *h, orbx_extractor *ext, const orbx_frame_grid *grid)
+{
+    if (!h || !ext || !grid) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    OrbxLastBatchView view;
+    int rc = orbx_extractor_last_batch_view_internal(ext, &view);
+    if (rc != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipSetDevice(h->device));
+    return launch_finish(h, orbx_extractor_stream_internal(ext), grid, true, view.kp, view.counts, view.batch, view.cap);
+}
+
+extern "C" int orbx_frame_results_device(orbx_frame_ops *h, const orbx_keypoint **kp_un_dev, const int32_t **grid_offsets_dev, const int32_t **grid_indices_dev,
+                                         int *capacity)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!h->lastBatch) { orbx_set_error("no frame has been finished yet"); return ORBX_ERR_STATE; }
+    if (kp_un_dev) *kp_un_dev = h->kpUn[h->cur].p;
+    if (grid_offsets_dev) *grid_offsets_dev = h->gridOff[h->cur].p;
+    if (grid_indices_dev) *grid_indices_dev = h->gridIdx[h->cur].p;
+    if (capacity) *capacity = h->lastCap;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_frame_download(orbx_frame_ops *h, orbx_extractor *ext, int batch, orbx_keypoint *kp_un, int32_t *grid_offsets, int32_t *grid_indices)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (batch < 1 || batch > h->lastBatch) { orbx_set_error("batch not available"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(ext ? orbx_extractor_stream_internal(ext) : h->stream));
+    const int b = h->cur;
+    if (kp_un) ORBX_HIP_CHECK(hipMemcpy(kp_un, h->kpUn[b].p, (size_t)batch * h->lastCap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+    if (grid_offsets) ORBX_HIP_CHECK(hipMemcpy(grid_offsets, h->gridOff[b].p, (size_t)batch * (NCELL + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (grid_indices) ORBX_HIP_CHECK(hipMemcpy(grid_indices, h->gridIdx[b].p, (size_t)batch * h->lastCap * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+static int host_form(orbx_frame_ops *h, const orbx_frame_grid *grid, bool undistort, const orbx_keypoint *keypoints, int n, orbx_keypoint *kp_un,
+                     int32_t *grid_offsets, int32_t *grid_indices)
+{
+    ORBX_HIP_CHECK(hipSetDevice(h->device));
+    const int cap = n > 0 ? n : 1;
+    int rc = h->hostKp.ensure((size_t)cap);
+    if (rc != ORBX_OK) return rc;
+    if (n > 0) ORBX_HIP_CHECK(hipMemcpyAsync(h->hostKp.p, keypoints, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->hostCount.p, &n, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if ((rc = launch_finish(h, h->stream, grid, undistort, h->hostKp.p, h->hostCount.p, 1, cap)) != ORBX_OK) return rc;
+    return orbx_frame_download(h, nullptr, 1, undistort && n > 0 ? kp_un : nullptr, grid ? grid_offsets : nullptr, grid && n > 0 ? grid_indices : nullptr);
+}
+
+extern "C" int orbx_frame_undistort(orbx_frame_ops *h, const orbx_keypoint *keypoints, int n, orbx_keypoint *kp_un)
+{
+    if (!h || n < 0 || (n > 0 && (!keypoints || !kp_un))) { orbx_set_error("bad argument"); return ORBX_ERR_ARG; }
+    if (n == 0) return ORBX_OK;
+    return host_form(h, nullptr, true, keypoints, n, kp_un, nullptr, nullptr);
+}
+
+extern "C" int orbx_frame_assign_grid(orbx_frame_ops *h, const orbx_frame_grid *grid, const orbx_keypoint *kp_un, int n, int32_t *grid_offsets,
+                                      int32_t *grid_indices)
+{
+    if (!h || !grid || !grid_offsets || n < 0 || (n > 0 && (!kp_un || !grid_indices))) { orbx_set_error("bad argument"); return ORBX_ERR_ARG; }
+    return host_form(h, grid, false, kp_un, n, nullptr, grid_offsets, grid_indices);
+}

@@ -487,3 +487,43 @@ def pose_optimization(orc, fr):
     lib.lo_pose_optimization.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
     ret = lib.lo_pose_optimization(_p(pose), _p(cam), n, _p(Xw), _p(obs), _p(inv), _p(out), _p(outl), _p(st))
     return dict(pose=out.reshape(4, 4), outlier=outl[:n], inliers=ret, stats=st)
+
+
+NCELL = 64 * 48
+
+
+def ref_mono_frame(im, nfeatures, fx, fy, cx, cy, dist, scale=1.2, nlevels=8, ini=20, mn=7, cap=8192, lib=None):
+    """Frame::Frame(imGray, ...) of the reference: extraction + UndistortKeyPoints + ComputeImageBounds +
+    AssignFeaturesToGrid.  Returns mvKeys, mvKeysUn (n x 7 float), descriptors, bounds, gridInv, grid CSR."""
+    lib = lib or slam_lib()
+    H, W = im.shape
+    im = np.ascontiguousarray(im)
+    k, ku = np.zeros((cap, 7), np.float32), np.zeros((cap, 7), np.float32)
+    d = np.zeros((cap, 32), np.uint8)
+    dist = np.ascontiguousarray(dist, np.float32)
+    bounds, ginv = np.zeros(4, np.float32), np.zeros(2, np.float32)
+    off, idx = np.zeros(NCELL + 1, np.int32), np.zeros(cap, np.int32)
+    n = ctypes.c_int()
+    lib.orbslam_mono_frame.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
+                                      [ctypes.c_float] * 4 + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 5
+    lib.orbslam_mono_frame(_p(im), W, H, W, nfeatures, scale, nlevels, ini, mn, fx, fy, cx, cy, _p(dist), len(dist),
+                           _p(k), _p(ku), _p(d), cap, _p(bounds), _p(ginv), _p(off), _p(idx), ctypes.byref(n))
+    n = n.value
+    assert n <= cap
+    return dict(kps=k[:n].copy(), kpsUn=ku[:n].copy(), desc=d[:n].copy(), bounds=bounds, gridInv=ginv, gridOff=off, gridIdx=idx[:off[-1]].copy())
+
+
+def frame_finish(orc, kps7, cam, dist, cols, rows):
+    """Restatement of UndistortKeyPoints + ComputeImageBounds + AssignFeaturesToGrid (oracle/match_oracle.cc)."""
+    lib = orc.lib
+    k = np.ascontiguousarray(kps7, np.float32).reshape(-1, 7)
+    n = len(k)
+    cam = np.ascontiguousarray(cam, np.float32)
+    dist = np.ascontiguousarray(dist, np.float32)
+    ku = np.zeros((max(n, 1), 7), np.float32)
+    bounds, ginv = np.zeros(4, np.float32), np.zeros(2, np.float32)
+    off, idx = np.zeros(NCELL + 1, np.int32), np.zeros(max(n, 1), np.int32)
+    lib.mo_frame_finish.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5
+    lib.mo_frame_finish.restype = None
+    lib.mo_frame_finish(_p(k), n, _p(cam), _p(dist), len(dist), cols, rows, _p(ku), _p(bounds), _p(ginv), _p(off), _p(idx))
+    return dict(kpsUn=ku[:n], bounds=bounds, gridInv=ginv, gridOff=off, gridIdx=idx[:off[-1]].copy())

@@ -2,8 +2,8 @@
 reference's own Frame.cc / KeyFrame.cc / MapPoint.cc / Map.cc / ORBmatcher.cc / DBoW2, built
 UNMODIFIED, with exactly the change INTEGRATION.md describes: shim/ORBextractor.{h,cc} instead of
 the reference's extractor and the HIP bodies of ORBmatcher::SearchByBoW (both overloads),
-ORBmatcher::DescriptorDistance and Frame::ComputeStereoMatches (shim/ORBmatcher_hip.cc,
-shim/Frame_hip.cc) linked over the reference's.  The same C driver (oracle/refslam_wrap.cc) then
+ORBmatcher::DescriptorDistance, Frame::ComputeStereoMatches, UndistortKeyPoints, ComputeImageBounds
+and AssignFeaturesToGrid (shim/ORBmatcher_hip.cc, shim/Frame_hip.cc) linked over the reference's.  The same C driver (oracle/refslam_wrap.cc) then
 builds real KeyFrame / Frame / MapPoint objects in both libraries; every output must be identical
 to the all-reference build (liborbslam.so)."""
 import ctypes
@@ -75,6 +75,31 @@ def test_stereo_frame_dropin_equals_reference(orbx, W, H, nf, seed, bf):
     for k in ("descL", "descR"):
         assert (got[k] == want[k]).all(), k
     assert (want["uRight"] >= 0).sum() > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,K,dist,seed", [
+    (640, 480, (517.306408, 516.469215, 318.643040, 255.313989), (0.262383, -0.953104, -0.005358, 0.002628, 1.163314), 71),   # TUM1.yaml
+    (752, 480, (458.654, 457.296, 367.215, 248.375), (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05), 72),            # EuRoC.yaml
+    (640, 480, (535.4, 539.2, 320.1, 247.6), (0.0, 0.0, 0.0, 0.0), 73)])                                                     # TUM3.yaml (rectified)
+def test_mono_frame_dropin_equals_reference(orbx, W, H, K, dist, seed):
+    """Frame::Frame(imGray, ...): shim extractor + the HIP UndistortKeyPoints / ComputeImageBounds /
+    AssignFeaturesToGrid, vs the all-reference constructor: mvKeys, mvKeysUn, bounds, mGrid."""
+    orbx.load_library()
+    hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
+    names = ("orbx_shim_undistort_calls", "orbx_shim_image_bounds_calls", "orbx_shim_assign_grid_calls")
+    for n in names:
+        getattr(hip, n).restype = ctypes.c_ulong
+    before = [getattr(hip, n)() for n in names]
+    im = orbx.synth_frame(seed, W, H)
+    want = oracle_lib.ref_mono_frame(im, 1000, K[0], K[1], K[2], K[3], dist, lib=ref)
+    got = oracle_lib.ref_mono_frame(im, 1000, K[0], K[1], K[2], K[3], dist, lib=hip)
+    assert [getattr(hip, n)() - b for n, b in zip(names, before)] == [1, 1, 1], "the HIP bodies were not the ones linked"
+    for k in ("kps", "kpsUn", "bounds", "gridInv"):
+        assert got[k].shape == want[k].shape and (got[k].view(np.uint32) == want[k].view(np.uint32)).all(), k
+    for k in ("desc", "gridOff", "gridIdx"):
+        assert (got[k] == want[k]).all(), k
+    assert want["gridOff"][-1] > 900
 
 
 @pytest.mark.gpu

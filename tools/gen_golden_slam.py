@@ -6,6 +6,7 @@ Map.cc + DBoW2 on oracle/cvshim, driven through real KeyFrame/Frame/MapPoint obj
     make -f oracle/Makefile all && python tools/gen_golden_slam.py
 
 stereo_*:  Frame::Frame(imLeft, imRight, ...) -> mvuRight / mvDepth (ComputeStereoMatches)
+mono_*:    Frame::Frame(imGray, ...) -> mvKeysUn (UndistortKeyPoints), image bounds, mGrid (AssignFeaturesToGrid)
 bow_*:     ORBmatcher::SearchByBoW, both overloads, on the features of two views of a scene,
            brute force (one vocabulary node) and with 10 synthetic node ids + MapPoint masks.
 """
@@ -24,6 +25,10 @@ orbx = importlib.import_module("self_commit_orb-slam2_amd")
 
 STEREO = [("stereo_kitti_1241x376_2000", 1241, 376, 2000, [41, 42], 386.1448),
           ("stereo_euroc_752x480_1200", 752, 480, 1200, [43], 47.9064)]
+# monocular Frame constructor: name, W, H, nfeatures, seed, fx, fy, cx, cy, mDistCoef (Examples/Monocular/*.yaml)
+MONO = [("mono_tum1_640x480_1000", 640, 480, 1000, 61, 517.306408, 516.469215, 318.643040, 255.313989, [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]),
+        ("mono_euroc_752x480_1000", 752, 480, 1000, 62, 458.654, 457.296, 367.215, 248.375, [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05]),
+        ("mono_tum3_640x480_1000", 640, 480, 1000, 63, 535.4, 539.2, 320.1, 247.6, [0.0, 0.0, 0.0, 0.0])]
 BOW = [("bow_tum1_640x480_1000", 640, 480, 1000, 51), ("bow_kitti_1241x376_2000", 1241, 376, 2000, 52)]
 
 
@@ -61,6 +66,14 @@ def main():
             data["nR_%d" % i] = np.int32(len(r["kpsR"]))
         np.savez_compressed(out / (name + ".npz"), **data)
         print(name, [int((data["uRight_%d" % i] >= 0).sum()) for i in range(len(seeds))])
+    for name, W, H, nf, seed, fx, fy, cx, cy, dist in MONO:
+        im = orbx.synth_frame(seed, W, H)
+        r = oracle_lib.ref_mono_frame(im, nf, fx, fy, cx, cy, dist)
+        data = {"W": W, "H": H, "nfeatures": nf, "seed": np.int64(seed), "cam": np.array([fx, fy, cx, cy], np.float32),
+                "dist": np.array(dist, np.float32), "kps": r["kps"], "kpsUn": r["kpsUn"], "bounds": r["bounds"], "gridInv": r["gridInv"],
+                "gridOff": r["gridOff"], "gridIdx": r["gridIdx"]}
+        np.savez_compressed(out / (name + ".npz"), **data)
+        print(name, len(r["kps"]), r["bounds"], int(r["gridOff"][-1]))
     for name, W, H, nf, seed in BOW:
         ref = orc.reference(nf)
         imA = orbx.synth_frame(seed, W, H, 0, 0, 0, 0)
