@@ -83,12 +83,23 @@ __global__ __launch_bounds__(256) void k_bow_order(FeatDev A, const int32_t *__r
 #define TOPK_ROWS 512   /* A features per block: two per lane */
 #define TOPK_TILE 1024  /* B features per LDS tile */
 
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+// insert into an ascending list, dropping its largest element: a min/max chain (2 ops per slot,
+// no compares or selects).  A key >= kk[TOPK-1] leaves the list unchanged, so no predication is needed.
 __device__ __forceinline__ void topk_insert(uint32_t (&kk)[TOPK], uint32_t key)
 {
-    kk[TOPK - 1] = key;
 #pragma unroll
-    for (int q = TOPK - 1; q > 0; q--)
-        if (kk[q] < kk[q - 1]) { const uint32_t t = kk[q - 1]; kk[q - 1] = kk[q]; kk[q] = t; }
+    for (int q = 0; q < TOPK; q++) {
+        const uint32_t lo = min(kk[q], key);
+        key = max(kk[q], key);
+        kk[q] = lo;
+    }
 }
 
 template <bool FILTER>   // B side has node ids and/or a validity mask
@@ -138,14 +149,15 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint4 lo = sB[2 * (j0 + u)], hi = sB[2 * (j0 + u) + 1];   // wave-uniform address: LDS broadcast
-                int d0 = __popc(a[0] ^ lo.x), d1 = __popc(c[0] ^ lo.x);
-                d0 += __popc(a[1] ^ lo.y); d1 += __popc(c[1] ^ lo.y);
-                d0 += __popc(a[2] ^ lo.z); d1 += __popc(c[2] ^ lo.z);
-                d0 += __popc(a[3] ^ lo.w); d1 += __popc(c[3] ^ lo.w);
-                d0 += __popc(a[4] ^ hi.x); d1 += __popc(c[4] ^ hi.x);
-                d0 += __popc(a[5] ^ hi.y); d1 += __popc(c[5] ^ hi.y);
-                d0 += __popc(a[6] ^ hi.z); d1 += __popc(c[6] ^ hi.z);
-                d0 += __popc(a[7] ^ hi.w); d1 += __popc(c[7] ^ hi.w);
+                // v_bcnt_u32_b32 adds its second operand: one instruction per word instead of bcnt + add tree
+                uint32_t d0 = bcnt_acc(a[0] ^ lo.x, 0u), d1 = bcnt_acc(c[0] ^ lo.x, 0u);
+                d0 = bcnt_acc(a[1] ^ lo.y, d0); d1 = bcnt_acc(c[1] ^ lo.y, d1);
+                d0 = bcnt_acc(a[2] ^ lo.z, d0); d1 = bcnt_acc(c[2] ^ lo.z, d1);
+                d0 = bcnt_acc(a[3] ^ lo.w, d0); d1 = bcnt_acc(c[3] ^ lo.w, d1);
+                d0 = bcnt_acc(a[4] ^ hi.x, d0); d1 = bcnt_acc(c[4] ^ hi.x, d1);
+                d0 = bcnt_acc(a[5] ^ hi.y, d0); d1 = bcnt_acc(c[5] ^ hi.y, d1);
+                d0 = bcnt_acc(a[6] ^ hi.z, d0); d1 = bcnt_acc(c[6] ^ hi.z, d1);
+                d0 = bcnt_acc(a[7] ^ hi.w, d0); d1 = bcnt_acc(c[7] ^ hi.w, d1);
                 const uint32_t j = (uint32_t)(t0 + j0 + u);
                 uint32_t ka = ((uint32_t)d0 << 16) | j, kb = ((uint32_t)d1 << 16) | j;
                 if (FILTER) {
@@ -159,10 +171,9 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
             if (__any(m0 < k0[TOPK - 1] || m1 < k1[TOPK - 1])) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const bool ok0 = key0[u] < k0[TOPK - 1], ok1 = key1[u] < k1[TOPK - 1];
-                    if (__any(ok0 || ok1)) {
-                        if (ok0) topk_insert(k0, key0[u]);
-                        if (ok1) topk_insert(k1, key1[u]);
+                    if (__any(key0[u] < k0[TOPK - 1] || key1[u] < k1[TOPK - 1])) {
+                        topk_insert(k0, key0[u]);
+                        topk_insert(k1, key1[u]);
                     }
                 }
             }
