@@ -211,6 +211,33 @@ int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set *a, const 
                               const int32_t *pairs_a, const int32_t *pairs_b, int npairs,
                               const orbx_bow_params *params, orbx_extractor *after_stream_of);
 
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)
+ * (src/ORBmatcher.cc:810-1017; LocalMapping::CreateNewMapPoints, src/LocalMapping.cc:332).  The
+ * feature sets are the two KeyFrames: keypoints = mvKeysUn, groups = mFeatVec node ids,
+ * valid = 1 where the feature may be matched: it has NO MapPoint and, when bOnlyStereo, mvuRight >= 0
+ * (:845-855, 867-876).  Acceptance per KF1 feature, in FeatureVector order: among the still unmatched
+ * KF2 features of its node with dist <= TH_LOW that pass the epipole gate (:888-895, both monocular)
+ * and CheckDistEpipolarLine (:188-227), the smallest distance, the LAST one among equals (:880);
+ * then the rotation histogram.  matches[p*stride + i] = KF2 feature of KF1 feature i or -1
+ * (vMatchedPairs = the non-negative entries in ascending i), nmatches[p] = return value. */
+typedef struct orbx_triangulation_params {
+    const float *f12;           /* HOST [9*npairs]: F12 row-major as LocalMapping::ComputeF12 returns it   */
+    const float *epipole;       /* HOST [2*npairs]: ex, ey = KF1's centre projected into KF2 (:817-826)    */
+    const uint8_t *stereo_a;    /* pKF1->mvuRight[i] >= 0, laid out like set a (device pointer in the
+                                   _device form, host pointer in the host form); NULL = monocular          */
+    const uint8_t *stereo_b;    /* same for pKF2                                                           */
+    const float *scale_factors; /* HOST pKF2->mvScaleFactors[nlevels]                                      */
+    const float *level_sigma2;  /* HOST pKF2->mvLevelSigma2[nlevels]                                       */
+    int nlevels;
+    int check_orientation;      /* mbCheckOrientation                                                      */
+} orbx_triangulation_params;
+int orbx_search_for_triangulation_device(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b,
+                                         const int32_t *pairs_a, const int32_t *pairs_b, int npairs,
+                                         const orbx_triangulation_params *params, orbx_extractor *after_stream_of);
+/* Host-array form for one KeyFrame pair (upload, run, download): matches12[a->counts[0]]. */
+int orbx_search_for_triangulation(orbx_matcher *m, const orbx_feature_set *a_host, const orbx_feature_set *b_host,
+                                  const orbx_triangulation_params *params_host, int32_t *matches12, int32_t *nmatches);
+
 /* Hamming stage of Frame::ComputeStereoMatches (src/Frame.cc:1041-1216) for `npairs`
  * (left frame, right frame) pairs: per left keypoint the right keypoint of minimum
  * descriptor distance among those in its row band (+-2*scale[octave]), within one octave and

@@ -575,3 +575,80 @@ MO_API void mo_frame_finish(const float *kp, int n, const float *cam, const floa
     }
     gridOff[GRID_COLS * GRID_ROWS] = o;
 }
+
+// ---------------------------------------------------------------------------------------
+// ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:810-1017 (+ CheckDistEpipolarLine :188-227).
+// Flat arrays; ex, ey (:817-826) are inputs.  hasMp*: feature holds a MapPoint; uRight*: mvuRight.
+// sf / sigma2: pKF2->mvScaleFactors / mvLevelSigma2.  matches12[i] = KF2 feature or -1.
+// ---------------------------------------------------------------------------------------
+MO_API int mo_search_for_triangulation(const float *kpA, const uint8_t *descA, const int32_t *groupA, const uint8_t *hasMpA, const float *uRightA, int nA,
+                                       const float *kpB, const uint8_t *descB, const int32_t *groupB, const uint8_t *hasMpB, const float *uRightB, int nB,
+                                       const float *F12, float ex, float ey, const float *sf, const float *sigma2, int onlyStereo, int checkOri,
+                                       int32_t *matches12)
+{
+    FeatVec fv1 = make_featvec(groupA, nA), fv2 = make_featvec(groupB, nB);
+    int nmatches = 0;
+    std::vector<char> matched2((size_t)nB, 0);
+    for (int i = 0; i < nA; i++) matches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;
+    FeatVec::const_iterator f1 = fv1.begin(), f2 = fv2.begin();
+    while (f1 != fv1.end() && f2 != fv2.end()) {
+        if (f1->first == f2->first) {
+            for (size_t i1 = 0; i1 < f1->second.size(); i1++) {
+                const int idx1 = f1->second[i1];
+                if (hasMpA && hasMpA[idx1]) continue;                                        // :845-848
+                const bool st1 = uRightA[idx1] >= 0;
+                if (onlyStereo && !st1) continue;                                            // :852-855
+                const float *k1 = kpA + 7 * (size_t)idx1;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (size_t i2 = 0; i2 < f2->second.size(); i2++) {
+                    const int idx2 = f2->second[i2];
+                    if (matched2[(size_t)idx2] || (hasMpB && hasMpB[idx2])) continue;        // :867-870
+                    const bool st2 = uRightB[idx2] >= 0;
+                    if (onlyStereo && !st2) continue;
+                    const int dist = descriptor_distance(descA + 32 * (size_t)idx1, descB + 32 * (size_t)idx2);
+                    if (dist > TH_LOW || dist > bestDist) continue;                          // :880
+                    const float *k2 = kpB + 7 * (size_t)idx2;
+                    const int oct2 = (int)k2[5];
+                    if (!st1 && !st2) {                                                      // :888-895
+                        const float distex = ex - k2[0], distey = ey - k2[1];
+                        if (distex * distex + distey * distey < 100 * sf[oct2]) continue;
+                    }
+                    // CheckDistEpipolarLine, :188-227
+                    const float a = k1[0] * F12[0] + k1[1] * F12[3] + F12[6];
+                    const float b = k1[0] * F12[1] + k1[1] * F12[4] + F12[7];
+                    const float c = k1[0] * F12[2] + k1[1] * F12[5] + F12[8];
+                    const float num = a * k2[0] + b * k2[1] + c;
+                    const float den = a * a + b * b;
+                    if (den == 0) continue;
+                    const float dsqr = num * num / den;
+                    if (dsqr < 3.84 * sigma2[oct2]) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    matches12[idx1] = bestIdx2;
+                    matched2[(size_t)bestIdx2] = 1;
+                    nmatches++;
+                    if (checkOri) {
+                        float rot = k1[3] - kpB[7 * (size_t)bestIdx2 + 3];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                }
+            }
+            ++f1; ++f2;
+        } else if (f1->first < f2->first) f1 = fv1.lower_bound(f2->first);
+        else f2 = fv2.lower_bound(f1->first);
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}

@@ -373,6 +373,58 @@ ORBSLAM_API int orbslam_search_by_bow(int mode, const float *kpsA, const uint8_t
     return n;
 }
 
+// ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo), src/ORBmatcher.cc:810-1017,
+// on two real KeyFrames.  hasMp*: 1 = the feature holds a MapPoint (is skipped); uRight*: mvuRight;
+// Tcw*: row-major 4x4 poses.  matches12[i] = KF2 feature or -1 (from vMatchedPairs); epipole[2] receives
+// ex, ey evaluated with the same cv::Mat expressions as :817-826.
+ORBSLAM_API int orbslam_search_for_triangulation(const float *kpsA, const uint8_t *descA, int nA, const int32_t *groupsA,
+                                                 const uint8_t *hasMpA, const float *uRightA, const float *TcwA, const float *kpsB,
+                                                 const uint8_t *descB, int nB, const int32_t *groupsB, const uint8_t *hasMpB,
+                                                 const float *uRightB, const float *TcwB, const float *F12, int onlyStereo,
+                                                 int checkOri, int32_t *matches12, float *epipole)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {500.f, 500.f, 320.f, 240.f, 40.f, 640, 480};
+    Frame FA, FB;
+    fill_frame(FA, kpsA, descA, nA, groupsA, cam, kDefaultScales, 8);
+    fill_frame(FB, kpsB, descB, nB, groupsB, cam, kDefaultScales, 8);
+    for (int i = 0; i < nA; i++) FA.mvuRight[i] = uRightA[i];
+    for (int i = 0; i < nB; i++) FB.mvuRight[i] = uRightB[i];
+    FA.mTcw = cv::Mat(4, 4, CV_32F);
+    FB.mTcw = cv::Mat(4, 4, CV_32F);
+    for (int i = 0; i < 16; i++) { FA.mTcw.at<float>(i / 4, i % 4) = TcwA[i]; FB.mTcw.at<float>(i / 4, i % 4) = TcwB[i]; }
+    KeyFrame *kfA = new KeyFrame(FA, &map, (KeyFrameDatabase *)nullptr);
+    KeyFrame *kfB = new KeyFrame(FB, &map, (KeyFrameDatabase *)nullptr);
+    std::vector<MapPoint *> owned;
+    cv::Mat pos = cv::Mat::zeros(3, 1, CV_32F);
+    pos.at<float>(2) = 1.f;
+    for (int i = 0; i < nA; i++)
+        if (hasMpA && hasMpA[i]) { MapPoint *mp = new MapPoint(pos, kfA, &map); kfA->AddMapPoint(mp, (size_t)i); owned.push_back(mp); }
+    for (int i = 0; i < nB; i++)
+        if (hasMpB && hasMpB[i]) { MapPoint *mp = new MapPoint(pos, kfB, &map); kfB->AddMapPoint(mp, (size_t)i); owned.push_back(mp); }
+    cv::Mat F(3, 3, CV_32F);
+    for (int i = 0; i < 9; i++) F.at<float>(i / 3, i % 3) = F12[i];
+    {
+        cv::Mat Cw = kfA->GetCameraCenter();
+        cv::Mat R2w = kfB->GetRotation();
+        cv::Mat t2w = kfB->GetTranslation();
+        cv::Mat C2 = R2w * Cw + t2w;
+        const float invz = 1.0f / C2.at<float>(2);
+        epipole[0] = kfB->fx * C2.at<float>(0) * invz + kfB->cx;
+        epipole[1] = kfB->fy * C2.at<float>(1) * invz + kfB->cy;
+    }
+    ORBmatcher matcher(0.6f, checkOri != 0);
+    std::vector<std::pair<size_t, size_t> > pairs;
+    const int n = matcher.SearchForTriangulation(kfA, kfB, F, pairs, onlyStereo != 0);
+    for (int i = 0; i < nA; i++) matches12[i] = -1;
+    for (size_t k = 0; k < pairs.size(); k++) matches12[pairs[k].first] = (int32_t)pairs[k].second;
+    for (size_t i = 0; i < owned.size(); i++) delete owned[i];
+    delete kfA;
+    delete kfB;
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------
 // DBoW2 vocabulary: TemplatedVocabulary::loadFromTextFile + transform
 // (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1420, 1127-1262), i.e. what

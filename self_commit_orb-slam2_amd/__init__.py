@@ -317,6 +317,7 @@ def _bind_matcher(L):
     L.orbx_matcher_destroy.argtypes = [vp]
     L.orbx_matcher_destroy.restype = None
     L.orbx_search_by_bow_device.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, vp, ci, ctypes.POINTER(BowParams), vp]
+    L.orbx_search_for_triangulation.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, vp, vp]
     L.orbx_stereo_match_device.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), vp, vp, ci, vp, ci, ctypes.c_float, vp]
     L.orbx_matcher_results_device.argtypes = [vp, vp, vp, vp, vp]
     L.orbx_compute_stereo_matches_device.argtypes = [vp, vp, vp, vp, vp, ci, ctypes.c_float, ctypes.c_float]
@@ -360,6 +361,11 @@ def _host_set(kps, desc, groups=None, valid=None):
     return fs, keep
 
 
+class TriangulationParams(ctypes.Structure):
+    _fields_ = [("f12", ctypes.c_void_p), ("epipole", ctypes.c_void_p), ("stereo_a", ctypes.c_void_p), ("stereo_b", ctypes.c_void_p),
+                ("scale_factors", ctypes.c_void_p), ("level_sigma2", ctypes.c_void_p), ("nlevels", ctypes.c_int), ("check_orientation", ctypes.c_int)]
+
+
 class ORBmatcher:
     """Mirror of the Hamming paths of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:57-215)."""
     TH_LOW = 50
@@ -396,6 +402,32 @@ class ORBmatcher:
         prm = BowParams(self.nnratio, 1 if self.checkOri else 0, mode)
         _check(self._L.orbx_search_by_bow(self._h, ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(prm), _ptr(out), ctypes.byref(nm)))
         return nm.value, out[:nout]
+
+    def SearchForTriangulation(self, kf1, kf2, F12, epipole, scale_factors, level_sigma2, only_stereo=False):
+        """ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (reference
+        src/ORBmatcher.cc:810-1017).  kf*: dict(kps (structured mvKeysUn), desc, groups (mFeatVec node ids),
+        has_mp (feature holds a MapPoint), u_right (mvuRight)); epipole = (ex, ey) of :817-826;
+        scale_factors / level_sigma2 of pKF2.  Returns (nmatches, matches12[n1]) with matches12[i] = KF2 feature or -1."""
+        sets, keep, flags = [], [], []
+        for kf in (kf1, kf2):
+            ur = np.asarray(kf["u_right"], np.float32)
+            st = np.ascontiguousarray(ur >= 0, np.uint8)
+            ok = np.asarray(kf["has_mp"], np.uint8) == 0
+            if only_stereo:
+                ok = ok & (st != 0)
+            fs, k = _host_set(kf["kps"], kf["desc"], kf["groups"], ok.astype(np.uint8))
+            sets.append(fs); keep.append(k); flags.append(st)
+        f12 = np.ascontiguousarray(F12, np.float32).reshape(9)
+        epi = np.ascontiguousarray(epipole, np.float32).reshape(2)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        s2 = np.ascontiguousarray(level_sigma2, np.float32)
+        prm = TriangulationParams(f12.ctypes.data, epi.ctypes.data, flags[0].ctypes.data, flags[1].ctypes.data, sf.ctypes.data, s2.ctypes.data,
+                                   len(sf), 1 if self.checkOri else 0)
+        n1 = len(kf1["kps"])
+        out = np.full(max(n1, 1), -1, np.int32)
+        nm = ctypes.c_int32()
+        _check(self._L.orbx_search_for_triangulation(self._h, ctypes.byref(sets[0]), ctypes.byref(sets[1]), ctypes.byref(prm), _ptr(out), ctypes.byref(nm)))
+        return nm.value, out[:n1]
 
     def SearchByProjection(self, frame, points, th, nnratio=None):
         """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (reference src/ORBmatcher.cc:70-175).

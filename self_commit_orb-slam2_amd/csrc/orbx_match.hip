@@ -90,6 +90,33 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
     return r;
 }
 
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:810-1017): the per-candidate geometry.
+struct TriDev {
+    const float *f12;      // [9] per pair, row-major
+    const float *epipole;  // [2] per pair: ex, ey (:824-826)
+    const uint8_t *stereoA, *stereoB;   // mvuRight >= 0, laid out like the feature sets; NULL = monocular
+    float epiTh[ORBX_MAX_LEVELS];       // 100*pKF2->mvScaleFactors[octave] (:893)
+    double chiTh[ORBX_MAX_LEVELS];      // 3.84*pKF2->mvLevelSigma2[octave] (:224), a double product in the reference
+};
+
+// the epipole gate (:888-895) and CheckDistEpipolarLine (:188-227), float operation order of the reference
+__device__ __forceinline__ bool tri_geom_ok(const TriDev &T, int p, const orbx_keypoint &k1, bool st1, const orbx_keypoint &k2, bool st2)
+{
+    if (!st1 && !st2) {
+        const float distex = T.epipole[2 * p] - k2.x, distey = T.epipole[2 * p + 1] - k2.y;
+        if (distex * distex + distey * distey < T.epiTh[k2.octave]) return false;
+    }
+    const float *F = T.f12 + 9 * p;
+    const float a = k1.x * F[0] + k1.y * F[3] + F[6];
+    const float b = k1.x * F[1] + k1.y * F[4] + F[7];
+    const float c = k1.x * F[2] + k1.y * F[5] + F[8];
+    const float num = a * k2.x + b * k2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return (double)dsqr < T.chiTh[k2.octave];
+}
+
 // insert into an ascending list, dropping its largest element: a min/max chain (2 ops per slot,
 // no compares or selects).  A key >= kk[TOPK-1] leaves the list unchanged, so no predication is needed.
 __device__ __forceinline__ void topk_insert(uint32_t (&kk)[TOPK], uint32_t key)
@@ -102,9 +129,12 @@ __device__ __forceinline__ void topk_insert(uint32_t (&kk)[TOPK], uint32_t key)
     }
 }
 
-template <bool FILTER>   // B side has node ids and/or a validity mask
+// TRI (SearchForTriangulation): among equal distances the LAST candidate in scan order wins
+// (`dist>bestDist` skips, :880), so the key carries 0xffff - j; a candidate below the list threshold
+// is inserted only if it passes the epipole gate and the epipolar-line test.
+template <bool FILTER, bool TRI>   // FILTER: B side has node ids and/or a validity mask
 __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
-                                                  uint32_t dcut, uint32_t *__restrict__ topk, int stride)
+                                                  uint32_t dcut, uint32_t *__restrict__ topk, int stride, TriDev T)
 {
     __shared__ uint4 sB[TOPK_TILE * 2];     // 32-byte descriptors
     __shared__ int32_t sG[TOPK_TILE];       // node id, 0x80000000 = excluded (FILTER only)
@@ -139,7 +169,7 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
                 if (j < nt) {
                     gq = B.groups ? B.groups[(size_t)fb * capB + t0 + j] : 0;
                     if (gq < 0) gq = (int)0x80000000;   // negative node id = not filed in the FeatureVector: never matched
-                    if (mode == 1 && B.valid && !B.valid[(size_t)fb * capB + t0 + j]) gq = (int)0x80000000;
+                    if (mode >= 1 && B.valid && !B.valid[(size_t)fb * capB + t0 + j]) gq = (int)0x80000000;
                 }
                 sG[j] = gq;
             }
@@ -158,7 +188,7 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
                 d0 = bcnt_acc(a[5] ^ hi.y, d0); d1 = bcnt_acc(c[5] ^ hi.y, d1);
                 d0 = bcnt_acc(a[6] ^ hi.z, d0); d1 = bcnt_acc(c[6] ^ hi.z, d1);
                 d0 = bcnt_acc(a[7] ^ hi.w, d0); d1 = bcnt_acc(c[7] ^ hi.w, d1);
-                const uint32_t j = (uint32_t)(t0 + j0 + u);
+                const uint32_t j = TRI ? 0xffffu - (uint32_t)(t0 + j0 + u) : (uint32_t)(t0 + j0 + u);
                 uint32_t ka = ((uint32_t)d0 << 16) | j, kb = ((uint32_t)d1 << 16) | j;
                 if (FILTER) {
                     const int gq = sG[j0 + u];
@@ -172,8 +202,25 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (__any(key0[u] < k0[TOPK - 1] || key1[u] < k1[TOPK - 1])) {
-                        topk_insert(k0, key0[u]);
-                        topk_insert(k1, key1[u]);
+                        uint32_t ins0 = key0[u], ins1 = key1[u];
+                        if (TRI) {
+                            const int jb = t0 + j0 + u;
+                            const orbx_keypoint k2 = B.kp[(size_t)fb * capB + jb];
+                            const bool st2 = T.stereoB && T.stereoB[(size_t)fb * capB + jb];
+                            bool pass0 = false, pass1 = false;
+                            if (ins0 < k0[TOPK - 1]) {
+                                const size_t ia = (size_t)fa * A.cap + i0;
+                                pass0 = tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], k2, st2);
+                            }
+                            if (ins1 < k1[TOPK - 1]) {
+                                const size_t ia = (size_t)fa * A.cap + i1;
+                                pass1 = tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], k2, st2);
+                            }
+                            ins0 = pass0 ? ins0 : 0xffffffffu;
+                            ins1 = pass1 ? ins1 : 0xffffffffu;
+                        }
+                        topk_insert(k0, ins0);
+                        topk_insert(k1, ins1);
                     }
                 }
             }
@@ -207,7 +254,7 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
 // exactly, as before.
 __global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
                                                     float nnratio, int checkOri, const uint32_t *__restrict__ topk, const int32_t *__restrict__ order,
-                                                    int32_t *__restrict__ matches, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride)
+                                                    int32_t *__restrict__ matches, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride, TriDev T)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int hist[HISTO_LENGTH];
@@ -253,19 +300,24 @@ __global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const 
 #pragma unroll
             for (int k = 0; k < TOPK; k++) {
                 const uint32_t key = keys[k];
-                const bool fr = key != KEY_EMPTY && owner[key & 0xffff] >= (uint32_t)r;
+                const uint32_t bidx = mode == 2 ? 0xffffu - (key & 0xffffu) : (key & 0xffffu);   // mode 2 keys carry 0xffff - j
+                const bool fr = key != KEY_EMPTY && owner[bidx] >= (uint32_t)r;
                 if (fr) {
-                    if (nfree == 0) bestKey = key;
+                    if (nfree == 0) bestKey = (key & 0xffff0000u) | bidx;
                     else if (nfree == 1) best2 = (int)(key >> 16);
                     nfree++;
                 }
             }
-            if (nfree < 2 && keys[TOPK - 1] != KEY_EMPTY) { queue[atomicAdd(&sQueued, 1)] = (unsigned short)r; continue; }
+            // mode 2 (SearchForTriangulation) has no ratio test: the best free candidate decides alone
+            if (nfree < (mode == 2 ? 1 : 2) && keys[TOPK - 1] != KEY_EMPTY) { queue[atomicAdd(&sQueued, 1)] = (unsigned short)r; continue; }
             uint32_t nd = KEY_EMPTY;
             if (bestKey != KEY_EMPTY) {
                 const int best1 = (int)(bestKey >> 16);
-                const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);
-                if (pass && (float)best1 < nnratio * (float)best2) nd = bestKey;
+                if (mode == 2) nd = bestKey;
+                else {
+                    const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);
+                    if (pass && (float)best1 < nnratio * (float)best2) nd = bestKey;
+                }
             }
             if (nd != dec[r]) { dec[r] = nd; changed = true; }
         }
@@ -282,20 +334,29 @@ __global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const 
             for (int jj = lane; jj < nB; jj += 64) {
                 if (owner[jj] < (uint32_t)r) continue;
                 if (B.groups && B.groups[(size_t)fb * B.cap + jj] != gA) continue;
-                if (mode == 1 && B.valid && !B.valid[(size_t)fb * B.cap + jj]) continue;
+                if (mode >= 1 && B.valid && !B.valid[(size_t)fb * B.cap + jj]) continue;
                 const unsigned long long *db = (const unsigned long long *)(B.desc + ((size_t)fb * B.cap + jj) * 32);
                 int d = hamming256(a, db[0], db[1], db[2], db[3]);
                 uint32_t kk = ((uint32_t)d << 16) | (uint32_t)jj;
+                if (mode == 2) {
+                    if (d > TH_LOW) continue;
+                    const size_t ia = (size_t)fa * A.cap + i;
+                    if (!tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], B.kp[(size_t)fb * B.cap + jj], T.stereoB && T.stereoB[(size_t)fb * B.cap + jj])) continue;
+                    kk = ((uint32_t)d << 16) | (0xffffu - (uint32_t)jj);   // equal distances: the later feature wins (:880)
+                }
                 if (kk < k0) { k1 = k0; k0 = kk; } else if (kk < k1) k1 = kk;
             }
-            const uint32_t bestKey = wave_min_u32(k0);
+            uint32_t bestKey = wave_min_u32(k0);
             if (k0 == bestKey) k0 = k1;
             const uint32_t second = wave_min_u32(k0);
             uint32_t nd = KEY_EMPTY;
             if (bestKey != KEY_EMPTY) {
                 const int best1 = (int)(bestKey >> 16), best2 = second != KEY_EMPTY ? (int)(second >> 16) : 256;
-                const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);
-                if (pass && (float)best1 < nnratio * (float)best2) nd = bestKey;
+                if (mode == 2) nd = (bestKey & 0xffff0000u) | (0xffffu - (bestKey & 0xffffu));
+                else {
+                    const bool pass = mode == 0 ? (best1 <= TH_LOW) : (best1 < TH_LOW);
+                    if (pass && (float)best1 < nnratio * (float)best2) nd = bestKey;
+                }
             }
             if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChanged = 1; }
         }
@@ -1012,6 +1073,8 @@ struct orbx_matcher {
     MBuf<orbx_keypoint> hk[2];
     MBuf<uint8_t> hd[2], hv[2];
     MBuf<int32_t> hc[2], hg[2];
+    MBuf<uint8_t> hs[2];                               // SearchForTriangulation: stereo flags (host form)
+    MBuf<float> triGeom;                               // F12 + epipole per pair
     int lastPairs = 0, lastStride = 0;
 };
 
@@ -1068,7 +1131,8 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     for (int q = 0; q < 2; q++) { m->pf[q].release(); m->pb[q].release(); m->pi32[q].release(); }
     if (m->evDep2) (void)hipEventDestroy(m->evDep2);
     for (int i = 0; i < 2; i++) if (m->evPyr[i]) (void)hipEventDestroy(m->evPyr[i]);
-    for (int s = 0; s < 2; s++) { m->hk[s].release(); m->hd[s].release(); m->hv[s].release(); m->hc[s].release(); m->hg[s].release(); }
+    for (int s = 0; s < 2; s++) { m->hk[s].release(); m->hd[s].release(); m->hv[s].release(); m->hc[s].release(); m->hg[s].release(); m->hs[s].release(); }
+    m->triGeom.release();
     if (m->evDep) (void)hipEventDestroy(m->evDep);
     for (int i = 0; i < 2; i++) if (m->evDone[i]) (void)hipEventDestroy(m->evDone[i]);
     for (int r = 0; r < MATCH_PROF_RING; r++) { if (m->ev0[r]) (void)hipEventDestroy(m->ev0[r]); if (m->ev1[r]) (void)hipEventDestroy(m->ev1[r]); if (m->evMid[r]) (void)hipEventDestroy(m->evMid[r]); }
@@ -1144,9 +1208,9 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     const bool filter = b->groups != nullptr || (params->mode == 1 && b->valid != nullptr);
     const dim3 gridTopk((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs);
     if (filter)
-        hipLaunchKernelGGL(k_bow_topk<true>, gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride);
+        hipLaunchKernelGGL((k_bow_topk<true, false>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
     else
-        hipLaunchKernelGGL(k_bow_topk<false>, gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride);
+        hipLaunchKernelGGL((k_bow_topk<false, false>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->evMid[slot], m->stream));
     m->midValid[slot] = true;
@@ -1154,7 +1218,7 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
     if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
     hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(256), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, params->nn_ratio,
-                       params->check_orientation, m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride);
+                       params->check_orientation, m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride, TriDev());
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
     m->profCount++;
@@ -1529,6 +1593,75 @@ extern "C" int orbx_search_by_bow(orbx_matcher *m, const orbx_feature_set *a_hos
     ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
     const int nOut = params->mode == 0 ? b_host->counts[0] : a_host->counts[0];
     if (nOut > 0) ORBX_HIP_CHECK(hipMemcpy(matches, m->matches.p, (size_t)nOut * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:810-1017: the SearchByBoW machinery (node order,
+// candidate lists, fixed-point replay, rotation histogram) with the triangulation acceptance rule.
+extern "C" int orbx_search_for_triangulation_device(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b, const int32_t *pairs_a,
+                                                    const int32_t *pairs_b, int npairs, const orbx_triangulation_params *params, orbx_extractor *after)
+{
+    if (!params || !params->f12 || !params->epipole || !params->scale_factors || !params->level_sigma2) { orbx_set_error("bad triangulation params"); return ORBX_ERR_ARG; }
+    if (params->nlevels < 1 || params->nlevels > ORBX_MAX_LEVELS) { orbx_set_error("nlevels %d outside 1..%d", params->nlevels, ORBX_MAX_LEVELS); return ORBX_ERR_ARG; }
+    int rc = prep_pairs(m, a, b, pairs_a, pairs_b, npairs, after);
+    if (rc != ORBX_OK) return rc;
+    if ((rc = m->triGeom.ensure((size_t)11 * m->maxPairs)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->triGeom.p, params->f12, (size_t)9 * npairs * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->triGeom.p + (size_t)9 * m->maxPairs, params->epipole, (size_t)2 * npairs * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    TriDev T = TriDev();
+    T.f12 = m->triGeom.p; T.epipole = m->triGeom.p + (size_t)9 * m->maxPairs;
+    T.stereoA = params->stereo_a; T.stereoB = params->stereo_b;
+    for (int l = 0; l < params->nlevels; l++) {
+        T.epiTh[l] = 100 * params->scale_factors[l];     // int * float, :893
+        T.chiTh[l] = 3.84 * params->level_sigma2[l];     // double * float, :224
+    }
+    const int stride = m->maxFeatures;
+    FeatDev A = to_dev(a), B = to_dev(b);
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    hipLaunchKernelGGL(k_bow_order, dim3((unsigned)((a->capacity + 255) / 256), (unsigned)npairs), dim3(256), 0, m->stream, A, m->pairsA.p, m->order.p, stride);
+    MLAUNCH_CHECK();
+    const dim3 gridTopk((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs);
+    // only dist <= TH_LOW can be accepted (:880) and there is no second-best test: cut at TH_LOW + 1
+    hipLaunchKernelGGL((k_bow_topk<true, true>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, 2, (uint32_t)(TH_LOW + 1), m->topk.p, stride, T);
+    MLAUNCH_CHECK();
+    m->midValid[slot] = false;
+    const size_t ldsGreedy = (size_t)b->capacity * 4 + (size_t)a->capacity * 4 + (size_t)((a->capacity + 7) & ~7) * 2 * 2;
+    if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
+    if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
+    hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(256), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, 2, 0.0f, params->check_orientation,
+                       m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride, T);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = npairs; m->lastStride = stride;
+    return chain_back(m, after);
+}
+
+extern "C" int orbx_search_for_triangulation(orbx_matcher *m, const orbx_feature_set *a_host, const orbx_feature_set *b_host,
+                                             const orbx_triangulation_params *params_host, int32_t *matches12, int32_t *nmatches)
+{
+    if (!m || !params_host || !matches12 || !nmatches) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    orbx_feature_set da, db;
+    int rc;
+    if ((rc = stage_host(m, 0, a_host, &da)) != ORBX_OK || (rc = stage_host(m, 1, b_host, &db)) != ORBX_OK) return rc;
+    orbx_triangulation_params P = *params_host;
+    const uint8_t *hostFlags[2] = {params_host->stereo_a, params_host->stereo_b};
+    const int cnt[2] = {a_host->counts[0], b_host->counts[0]};
+    const uint8_t *devFlags[2] = {nullptr, nullptr};
+    for (int sd = 0; sd < 2; sd++) {
+        if (!hostFlags[sd]) continue;
+        if ((rc = m->hs[sd].ensure((size_t)m->maxFeatures)) != ORBX_OK) return rc;
+        if (cnt[sd] > 0) ORBX_HIP_CHECK(hipMemcpyAsync(m->hs[sd].p, hostFlags[sd], (size_t)cnt[sd], hipMemcpyHostToDevice, m->stream));
+        devFlags[sd] = m->hs[sd].p;
+    }
+    P.stereo_a = devFlags[0]; P.stereo_b = devFlags[1];
+    const int32_t zero = 0;
+    if ((rc = orbx_search_for_triangulation_device(m, &da, &db, &zero, &zero, 1, &P, nullptr)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (cnt[0] > 0) ORBX_HIP_CHECK(hipMemcpy(matches12, m->matches.p, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost));
     ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }

@@ -7,6 +7,7 @@
 //     int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)            src/ORBmatcher.cc:1913-1933
 //     int ORBmatcher::SearchByProjection(Frame&, const std::vector<MapPoint*>&, float)   src/ORBmatcher.cc:70-175
 //     int ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)              src/ORBmatcher.cc:1569-1728
+//     int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat, std::vector<std::pair<size_t,size_t> >&, bool)   src/ORBmatcher.cc:810-1017
 // A maintainer deletes those three bodies from src/ORBmatcher.cc and adds this file to the
 // source list; the test build keeps src/ORBmatcher.cc untouched and weakens
 // the three symbols in its object file instead (oracle/Makefile, target liborbslam_hip.so).
@@ -26,6 +27,8 @@
 // bodies, not the reference's, were linked)
 static unsigned long gSearchByProjectionCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_by_projection_calls(void) { return gSearchByProjectionCalls; }
+static unsigned long gTriangulationCalls = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_for_triangulation_calls(void) { return gTriangulationCalls; }
 static unsigned long gSearchByBoWCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_by_bow_calls(void) { return gSearchByBoWCalls; }
 
@@ -128,6 +131,51 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint
         throw std::runtime_error(std::string("ORBmatcher::SearchByBoW (orbx): ") + orbx_last_error());
     for (int i = 0; i < NA; i++)
         if (match[(size_t)i] >= 0) vpMatches12[(size_t)i] = vpMapPoints2[(size_t)match[(size_t)i]];                           // :745
+    return nmatches;
+}
+
+// LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:332): features of the two KeyFrames that hold
+// no MapPoint yet, matched inside their vocabulary nodes under the epipolar constraint of F12.
+int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> > &vMatchedPairs,
+                                       const bool bOnlyStereo)
+{
+    __atomic_add_fetch(&gTriangulationCalls, 1, __ATOMIC_RELAXED);
+    // the epipole of KF1 in KF2, :817-826 (cv::Mat arithmetic of the reference, unchanged)
+    cv::Mat Cw = pKF1->GetCameraCenter();
+    cv::Mat R2w = pKF2->GetRotation();
+    cv::Mat t2w = pKF2->GetTranslation();
+    cv::Mat C2 = R2w * Cw + t2w;
+    const float invz = 1.0f / C2.at<float>(2);
+    const float epipole[2] = {pKF2->fx * C2.at<float>(0) * invz + pKF2->cx, pKF2->fy * C2.at<float>(1) * invz + pKF2->cy};
+    vMatchedPairs.clear();
+    const int NA = pKF1->N, NB = pKF2->N;
+    if (NA == 0 || NB == 0) return 0;
+    std::vector<int32_t> gA, gB;
+    FlatGroups(pKF1->mFeatVec, NA, gA);
+    FlatGroups(pKF2->mFeatVec, NB, gB);
+    std::vector<uint8_t> okA((size_t)NA), okB((size_t)NB), stA((size_t)NA), stB((size_t)NB);
+    for (int i = 0; i < NA; i++) {
+        stA[(size_t)i] = pKF1->mvuRight[(size_t)i] >= 0 ? 1 : 0;                                                    // :850
+        okA[(size_t)i] = (!pKF1->GetMapPoint((size_t)i) && (!bOnlyStereo || stA[(size_t)i])) ? 1 : 0;              // :845-855
+    }
+    for (int i = 0; i < NB; i++) {
+        stB[(size_t)i] = pKF2->mvuRight[(size_t)i] >= 0 ? 1 : 0;                                                    // :872
+        okB[(size_t)i] = (!pKF2->GetMapPoint((size_t)i) && (!bOnlyStereo || stB[(size_t)i])) ? 1 : 0;              // :867-876
+    }
+    float f12[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) f12[3 * r + c] = F12.at<float>(r, c);
+    orbx_feature_set a = {(const orbx_keypoint *)&pKF1->mvKeysUn[0], pKF1->mDescriptors.data, &NA, &gA[0], &okA[0], NA, 1};
+    orbx_feature_set b = {(const orbx_keypoint *)&pKF2->mvKeysUn[0], pKF2->mDescriptors.data, &NB, &gB[0], &okB[0], NB, 1};
+    orbx_triangulation_params prm = {f12, epipole, &stA[0], &stB[0], &pKF2->mvScaleFactors[0], &pKF2->mvLevelSigma2[0],
+                                     (int)pKF2->mvScaleFactors.size(), mbCheckOrientation ? 1 : 0};
+    std::vector<int32_t> match((size_t)NA);
+    int32_t nmatches = 0;
+    if (orbx_search_for_triangulation(Matcher(NA > NB ? NA : NB), &a, &b, &prm, &match[0], &nmatches) != ORBX_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchForTriangulation (orbx): ") + orbx_last_error());
+    vMatchedPairs.reserve((size_t)nmatches);                                                                          // :1005-1014
+    for (int i = 0; i < NA; i++)
+        if (match[(size_t)i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match[(size_t)i]));
     return nmatches;
 }
 

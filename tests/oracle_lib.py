@@ -527,3 +527,39 @@ def frame_finish(orc, kps7, cam, dist, cols, rows):
     lib.mo_frame_finish.restype = None
     lib.mo_frame_finish(_p(k), n, _p(cam), _p(dist), len(dist), cols, rows, _p(ku), _p(bounds), _p(ginv), _p(off), _p(idx))
     return dict(kpsUn=ku[:n], bounds=bounds, gridInv=ginv, gridOff=off, gridIdx=idx[:off[-1]].copy())
+
+
+def _tri_arrays(kf):
+    k = np.ascontiguousarray(_kp7(kf["kps"]) if np.asarray(kf["kps"]).dtype.names else kf["kps"], np.float32)
+    return (k, np.ascontiguousarray(kf["desc"], np.uint8), np.ascontiguousarray(kf["groups"], np.int32),
+            np.ascontiguousarray(kf["has_mp"], np.uint8), np.ascontiguousarray(kf["u_right"], np.float32))
+
+
+def search_for_triangulation(orc, kf1, kf2, F12, epipole, sf, sigma2, only_stereo, check_ori):
+    """Restatement of ORBmatcher::SearchForTriangulation (oracle/match_oracle.cc)."""
+    lib = orc.lib
+    a, b = _tri_arrays(kf1), _tri_arrays(kf2)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sf, s2 = np.ascontiguousarray(sf, np.float32), np.ascontiguousarray(sigma2, np.float32)
+    out = np.full(max(len(a[0]), 1), -1, np.int32)
+    lib.mo_search_for_triangulation.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    n = lib.mo_search_for_triangulation(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), len(a[0]), _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]), _p(b[4]), len(b[0]),
+                                        _p(F), float(epipole[0]), float(epipole[1]), _p(sf), _p(s2), 1 if only_stereo else 0, 1 if check_ori else 0, _p(out))
+    return n, out[:len(a[0])]
+
+
+def ref_search_for_triangulation(kf1, kf2, Tcw1, Tcw2, F12, only_stereo, check_ori, lib=None):
+    """ORBmatcher::SearchForTriangulation of the reference on two real KeyFrames (default camera 500/500/320/240,
+    scale factors 1.2^l).  Returns (nmatches, matches12, (ex, ey))."""
+    lib = lib or slam_lib()
+    a, b = _tri_arrays(kf1), _tri_arrays(kf2)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    T1, T2 = np.ascontiguousarray(Tcw1, np.float32).reshape(16), np.ascontiguousarray(Tcw2, np.float32).reshape(16)
+    out = np.full(max(len(a[0]), 1), -1, np.int32)
+    epi = np.zeros(2, np.float32)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.orbslam_search_for_triangulation.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, vp, vp]
+    n = lib.orbslam_search_for_triangulation(_p(a[0]), _p(a[1]), len(a[0]), _p(a[2]), _p(a[3]), _p(a[4]), _p(T1), _p(b[0]), _p(b[1]), len(b[0]), _p(b[2]), _p(b[3]),
+                                             _p(b[4]), _p(T2), _p(F), 1 if only_stereo else 0, 1 if check_ori else 0, _p(out), _p(epi))
+    return n, out[:len(a[0])], epi

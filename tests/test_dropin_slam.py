@@ -164,6 +164,23 @@ def _octaves(inv_s2):
 
 
 @pytest.mark.gpu
+def test_search_for_triangulation_dropin_equals_reference(orbx):
+    """ORBmatcher::SearchForTriangulation on two real KeyFrames (poses, mFeatVec, MapPoints, mvuRight): the shim
+    computes the epipole with the reference's cv::Mat expressions and runs the matching on the device."""
+    from test_triangulation import CASES, _scene
+    orbx.load_library()
+    hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
+    hip.orbx_shim_search_for_triangulation_calls.restype = ctypes.c_ulong
+    before = hip.orbx_shim_search_for_triangulation_calls()
+    for seed, forward, stereo, only_stereo, ori in CASES:
+        kf1, kf2, T1, T2, F12 = _scene(orbx, 40 + seed, forward=forward, stereo_frac=stereo)
+        want_n, want, epi_w = oracle_lib.ref_search_for_triangulation(kf1, kf2, T1, T2, F12, only_stereo, ori, lib=ref)
+        got_n, got, epi_g = oracle_lib.ref_search_for_triangulation(kf1, kf2, T1, T2, F12, only_stereo, ori, lib=hip)
+        assert got_n == want_n and (got == want).all() and want_n > 30
+    assert hip.orbx_shim_search_for_triangulation_calls() - before == len(CASES), "the HIP body was not the one linked"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed,stereo", [(5, 0.0), (6, 0.4)])
 def test_local_bundle_adjustment_dropin_on_a_real_map(orbx, oracle, seed, stereo):
     """Optimizer::LocalBundleAdjustment (shim/Optimizer_hip.cc) on a real Map: KeyFrames, MapPoints,
