@@ -333,6 +333,38 @@ int orbx_search_by_projection_last(orbx_matcher *m, const orbx_projection_frame 
                                    const orbx_projection_last *last_host, const float *scale_factors, int nlevels,
                                    float th, int b_mono, int check_orientation, int32_t *assigned, int32_t *nmatches);
 
+/* ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:1020-1177; LocalMapping::SearchInNeighbors)
+ * and ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:1179-1312; LoopClosing): the search of
+ * steps 2-3 for every map point - KeyFrame::GetFeaturesInArea(u, v, radius), the level gate, for the
+ * first overload the chi-square gate on the reprojection error (:1111-1135, chi2_gate = 1) and the
+ * feature of minimum Hamming distance (first minimum in GetFeaturesInArea order).  What couples the
+ * map points in the reference's loop (isBad / IsInKeyFrame, Replace, AddObservation, :1036-1040,
+ * 1150-1172) is sequential pointer surgery and stays with the caller, evaluated in order on the result.
+ * kf: mvKeysUn, mDescriptors, mvuRight and the grid statics of the KeyFrame (`occupied` is not read). */
+typedef struct orbx_fuse_points {
+    const float *u, *v;          /* projection of the map point into the KeyFrame (:1056-1060)          */
+    const float *ur;             /* u - bf*invz (:1066); read only with chi2_gate                       */
+    const int32_t *level;        /* nPredictedLevel = pMP->PredictScale(dist3D, pKF) (:1090)            */
+    const float *radius;         /* th*pKF->mvScaleFactors[nPredictedLevel] (:1093)                     */
+    const uint8_t *active;       /* 1 = the point reached step 2 (gates :1036-1088); NULL = all         */
+    const uint8_t *descriptors;  /* pMP->GetDescriptor(), 32 bytes                                      */
+    const int32_t *counts;       /* points per KeyFrame                                                 */
+    int capacity;
+    float kf_min_x, kf_min_y;    /* (float)pKF->mnMinX / mnMinY: KeyFrame stores the bounds as int
+                                    (include/KeyFrame.h), and its GetFeaturesInArea computes the cell window
+                                    with them, while mGrid was filed with the Frame's float bounds
+                                    (kf->min_x / min_y)                                                  */
+} orbx_fuse_points;
+/* Device-pointer form for kf->nframes independent (KeyFrame, point list) problems; results:
+ * matches[f*stride + i] = bestIdx of point i or -1, dists[f*stride + i] = bestDist (256 when none)
+ * (orbx_matcher_results_device / orbx_matcher_download); the caller fuses when bestDist <= TH_LOW (:1148).
+ * inv_level_sigma2: HOST pKF->mvInvLevelSigma2[nlevels]. */
+int orbx_fuse_search_device(orbx_matcher *m, const orbx_projection_frame *kf, const orbx_fuse_points *points,
+                            const float *inv_level_sigma2, int nlevels, int chi2_gate);
+/* Host-array form for one KeyFrame (counts[0] entries each): best_idx / best_dist per map point. */
+int orbx_fuse_search(orbx_matcher *m, const orbx_projection_frame *kf_host, const orbx_fuse_points *points_host,
+                     const float *inv_level_sigma2, int nlevels, int chi2_gate, int32_t *best_idx, int32_t *best_dist);
+
 int orbx_matcher_results_device(orbx_matcher *m, const int32_t **matches_dev, const int32_t **dists_dev,
                                 const int32_t **nmatches_dev, int *stride);
 int orbx_matcher_download(orbx_matcher *m, int npairs, int32_t *matches, int32_t *dists, int stride,

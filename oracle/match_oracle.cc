@@ -652,3 +652,64 @@ MO_API int mo_search_for_triangulation(const float *kpA, const uint8_t *descA, c
     }
     return nmatches;
 }
+
+// ---------------------------------------------------------------------------------------
+// ORBmatcher::Fuse (both overloads), steps 2-3 (src/ORBmatcher.cc:1093-1146, 1258-1276) with
+// KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:752-796) on flat arrays: per map point the feature of
+// minimum distance (strict '<': the first minimum in cell-major order wins) among the features in the
+// window that pass the level gate and, with chi2Gate, the reprojection gate.  bestDist 256 when none.
+// ---------------------------------------------------------------------------------------
+MO_API void mo_fuse_best(const float *kpUn, const uint8_t *desc, const float *uRight, int n, float minX, float minY, float kfMinX, float kfMinY,
+                         float gwInv, float ghInv,
+                         const float *invSigma2, const float *pu, const float *pv, const float *pur, const int32_t *plevel, const float *pradius,
+                         const uint8_t *pactive, const uint8_t *pdesc, int m, int chi2Gate, int32_t *bestIdx, int32_t *bestDist)
+{
+    std::vector<std::vector<int> > grid((size_t)GRID_COLS * GRID_ROWS);   // as AssignFeaturesToGrid files it
+    for (int i = 0; i < n; i++) {
+        const int px = (int)round((kpUn[7 * (size_t)i] - minX) * gwInv), py = (int)round((kpUn[7 * (size_t)i + 1] - minY) * ghInv);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+        grid[(size_t)px * GRID_ROWS + py].push_back(i);
+    }
+    for (int p = 0; p < m; p++) {
+        bestIdx[p] = -1; bestDist[p] = 256;
+        if (pactive && !pactive[p]) continue;
+        const float x = pu[p], y = pv[p], r = pradius[p];
+        const int lvl = plevel[p];
+        // KeyFrame::GetFeaturesInArea with the KeyFrame's int bounds (kfMinX = (float)(int)mnMinX), src/KeyFrame.cc:760-775
+        const int cx0 = std::max(0, (int)floor((x - kfMinX - r) * gwInv));
+        if (cx0 >= GRID_COLS) continue;
+        const int cx1 = std::min(GRID_COLS - 1, (int)ceil((x - kfMinX + r) * gwInv));
+        if (cx1 < 0) continue;
+        const int cy0 = std::max(0, (int)floor((y - kfMinY - r) * ghInv));
+        if (cy0 >= GRID_ROWS) continue;
+        const int cy1 = std::min(GRID_ROWS - 1, (int)ceil((y - kfMinY + r) * ghInv));
+        if (cy1 < 0) continue;
+        int best = 256, bidx = -1;
+        for (int ix = cx0; ix <= cx1; ix++)
+            for (int iy = cy0; iy <= cy1; iy++) {
+                const std::vector<int> &cell = grid[(size_t)ix * GRID_ROWS + iy];
+                for (size_t j = 0; j < cell.size(); j++) {
+                    const int idx = cell[j];
+                    const float *k = kpUn + 7 * (size_t)idx;
+                    const float distx = k[0] - x, disty = k[1] - y;
+                    if (!(fabs(distx) < r && fabs(disty) < r)) continue;
+                    const int kl = (int)k[5];
+                    if (kl < lvl - 1 || kl > lvl) continue;
+                    if (chi2Gate) {
+                        const float ex = x - k[0], ey = y - k[1];
+                        if (uRight[idx] >= 0) {
+                            const float er = pur[p] - uRight[idx];
+                            const float e2 = ex * ex + ey * ey + er * er;
+                            if (e2 * invSigma2[kl] > 7.8) continue;
+                        } else {
+                            const float e2 = ex * ex + ey * ey;
+                            if (e2 * invSigma2[kl] > 5.99) continue;
+                        }
+                    }
+                    const int dist = descriptor_distance(pdesc + 32 * (size_t)p, desc + 32 * (size_t)idx);
+                    if (dist < best) { best = dist; bidx = idx; }
+                }
+            }
+        bestIdx[p] = bidx; bestDist[p] = best;
+    }
+}

@@ -426,6 +426,129 @@ ORBSLAM_API int orbslam_search_for_triangulation(const float *kpsA, const uint8_
 }
 
 // ---------------------------------------------------------------------------------------
+// ORBmatcher::Fuse, src/ORBmatcher.cc:1020-1177 (overload 1) and 1179-1312 (overload 2, Sim3),
+// on a real target KeyFrame and real MapPoints.
+//   target KeyFrame: kps/desc/uRight (n features), pose Tcw; kfHolder[i] >= 0: the feature already holds
+//     "existing" MapPoint number kfHolder[i] (nExist of them, existObs[k] extra observations each).
+//   candidates: nCand MapPoints created with MapPoint(Pos, pMap, pFrame, idxF) from a source frame
+//     (pose TcwSrc, keypoints srcKps -> octave -> min/max distance, descriptor candDesc[c]) plus
+//     candObs[c] further observations; list[j] = candidate id or -1 (NULL pointer), nList entries.
+//   probe != 0: the target holds no MapPoints and Fuse is called once per candidate with a one-element
+//     vector; probeIdx[c] = feature the reference attached it to (or -1); state is undone in between.
+//   probe == 0: one Fuse call on the list; holder[i] = -1 / candidate id / 1000000 + existing id,
+//     candBad[c], replaced[c] = what GetReplaced() maps to (same coding, -1 none),
+//     for overload 2 replacePoint[j] likewise.
+//   prep[6*c ..] = u, v, ur, level, radius, active of candidate c evaluated with the reference's own
+//     expressions (:1040-1093 / :1212-1258) against the untouched target.
+// ---------------------------------------------------------------------------------------
+ORBSLAM_API int orbslam_fuse(int overload, const float *kps, const uint8_t *desc, const float *uRight, int n, const float *Tcw, const float *Scw,
+                             const int32_t *kfHolder, int nExist, const int32_t *existObs, const float *srcKps, const float *TcwSrc,
+                             const float *candPos, const uint8_t *candDesc, const int32_t *candObs, int nCand, const int32_t *list, int nList,
+                             float th, int probe, int32_t *probeIdx, int32_t *holder, uint8_t *candBad, int32_t *replaced, int32_t *replacePoint,
+                             float *prep)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {500.f, 500.f, 320.f, 240.f, 40.f, 640, 480};
+    Frame FT, FS;
+    fill_frame(FT, kps, desc, n, nullptr, cam, kDefaultScales, 8);
+    for (int i = 0; i < n; i++) FT.mvuRight[(size_t)i] = uRight[i];
+    FT.mTcw = cv::Mat(4, 4, CV_32F);
+    for (int i = 0; i < 16; i++) FT.mTcw.at<float>(i / 4, i % 4) = Tcw[i];
+    fill_frame(FS, srcKps, candDesc, nCand, nullptr, cam, kDefaultScales, 8);
+    cv::Mat Tsrc(4, 4, CV_32F);
+    for (int i = 0; i < 16; i++) Tsrc.at<float>(i / 4, i % 4) = TcwSrc[i];
+    FS.SetPose(Tsrc);
+    KeyFrame *kfT = new KeyFrame(FT, &map, (KeyFrameDatabase *)nullptr);
+    KeyFrame *kfS = new KeyFrame(FS, &map, (KeyFrameDatabase *)nullptr);
+    KeyFrame *extra[4];
+    for (int k = 0; k < 4; k++) extra[k] = new KeyFrame(FS, &map, (KeyFrameDatabase *)nullptr);
+    std::vector<MapPoint *> cand((size_t)nCand), exist((size_t)nExist), owned;
+    std::map<MapPoint *, int> code;
+    for (int c = 0; c < nCand; c++) {
+        cv::Mat pos(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) pos.at<float>(k) = candPos[3 * c + k];
+        MapPoint *mp = new MapPoint(pos, &map, &FS, c);
+        mp->AddObservation(kfS, (size_t)c);
+        kfS->AddMapPoint(mp, (size_t)c);
+        for (int k = 0; k < candObs[c] && k < 4; k++) { mp->AddObservation(extra[k], (size_t)c); extra[k]->AddMapPoint(mp, (size_t)c); }
+        cand[(size_t)c] = mp; code[mp] = c; owned.push_back(mp);
+    }
+    if (!probe)
+        for (int k = 0; k < nExist; k++) {
+            cv::Mat pos = cv::Mat::zeros(3, 1, CV_32F);
+            pos.at<float>(2) = 2.f + k;
+            MapPoint *mp = new MapPoint(pos, &map, &FS, 0);
+            for (int e = 0; e < existObs[k] && e < 4; e++) mp->AddObservation(extra[e], (size_t)(nCand > 1 ? 1 + (k % (nCand - 1)) : 0));
+            exist[(size_t)k] = mp; code[mp] = 1000000 + k; owned.push_back(mp);
+        }
+    if (!probe)
+        for (int i = 0; i < n; i++)
+            if (kfHolder[i] >= 0) { exist[(size_t)kfHolder[i]]->AddObservation(kfT, (size_t)i); kfT->AddMapPoint(exist[(size_t)kfHolder[i]], (size_t)i); }
+    // ---- the reference's per-point preparation, evaluated with its own expressions ----
+    cv::Mat Rcw, tcw, Ow, ScwM;
+    if (overload == 1) { Rcw = kfT->GetRotation(); tcw = kfT->GetTranslation(); Ow = kfT->GetCameraCenter(); }
+    else {
+        ScwM = cv::Mat(4, 4, CV_32F);
+        for (int i = 0; i < 16; i++) ScwM.at<float>(i / 4, i % 4) = Scw[i];
+        cv::Mat sRcw = ScwM.rowRange(0, 3).colRange(0, 3);
+        const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+        Rcw = sRcw / scw;
+        tcw = ScwM.rowRange(0, 3).col(3) / scw;
+        Ow = -Rcw.t() * tcw;
+    }
+    for (int c = 0; c < nCand; c++) {
+        float *o = prep + 6 * (size_t)c;
+        for (int k = 0; k < 6; k++) o[k] = 0.f;
+        MapPoint *pMP = cand[(size_t)c];
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0f) continue;
+        float invz;
+        if (overload == 1) invz = 1 / p3Dc.at<float>(2); else invz = 1.0 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz, y = p3Dc.at<float>(1) * invz;
+        const float u = kfT->fx * x + kfT->cx, v = kfT->fy * y + kfT->cy;
+        if (!kfT->IsInImage(u, v)) continue;
+        const float ur = u - kfT->mbf * invz;
+        const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist3D = cv::norm(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) continue;
+        const int lvl = pMP->PredictScale(dist3D, kfT);
+        o[0] = u; o[1] = v; o[2] = ur; o[3] = (float)lvl; o[4] = th * kfT->mvScaleFactors[lvl]; o[5] = 1.f;
+    }
+    ORBmatcher matcher(0.6f, true);
+    int nFused = 0;
+    if (probe) {
+        for (int c = 0; c < nCand; c++) {
+            std::vector<MapPoint *> one(1, cand[(size_t)c]), rep(1, (MapPoint *)nullptr);
+            if (overload == 1) matcher.Fuse(kfT, one, th); else matcher.Fuse(kfT, ScwM, one, th, rep);
+            const int idx = cand[(size_t)c]->GetIndexInKeyFrame(kfT);
+            probeIdx[c] = idx;
+            if (idx >= 0) { kfT->EraseMapPointMatch((size_t)idx); cand[(size_t)c]->EraseObservation(kfT); nFused++; }
+        }
+    } else {
+        std::vector<MapPoint *> vp((size_t)nList), rep((size_t)nList, (MapPoint *)nullptr);
+        for (int j = 0; j < nList; j++) vp[(size_t)j] = list[j] >= 0 ? cand[(size_t)list[j]] : (MapPoint *)nullptr;
+        nFused = overload == 1 ? matcher.Fuse(kfT, vp, th) : matcher.Fuse(kfT, ScwM, vp, th, rep);
+        for (int i = 0; i < n; i++) { MapPoint *mp = kfT->GetMapPoint((size_t)i); holder[i] = mp ? code[mp] : -1; }
+        for (int c = 0; c < nCand; c++) {
+            candBad[c] = cand[(size_t)c]->isBad() ? 1 : 0;
+            MapPoint *r = cand[(size_t)c]->GetReplaced();
+            replaced[c] = r ? code[r] : -1;
+        }
+        for (int j = 0; j < nList; j++) replacePoint[j] = rep[(size_t)j] ? code[rep[(size_t)j]] : -1;
+    }
+    for (size_t i = 0; i < owned.size(); i++) delete owned[i];
+    delete kfT;
+    delete kfS;
+    for (int k = 0; k < 4; k++) delete extra[k];
+    return nFused;
+}
+
+// ---------------------------------------------------------------------------------------
 // DBoW2 vocabulary: TemplatedVocabulary::loadFromTextFile + transform
 // (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1420, 1127-1262), i.e. what
 // Frame::ComputeBoW runs (src/Frame.cc:880-896: transform(vCurrentDesc, mBowVec, mFeatVec, 4)).

@@ -361,6 +361,12 @@ def _host_set(kps, desc, groups=None, valid=None):
     return fs, keep
 
 
+class FusePoints(ctypes.Structure):
+    _fields_ = [("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("ur", ctypes.c_void_p), ("level", ctypes.c_void_p), ("radius", ctypes.c_void_p),
+                ("active", ctypes.c_void_p), ("descriptors", ctypes.c_void_p), ("counts", ctypes.c_void_p), ("capacity", ctypes.c_int),
+                ("kf_min_x", ctypes.c_float), ("kf_min_y", ctypes.c_float)]
+
+
 class TriangulationParams(ctypes.Structure):
     _fields_ = [("f12", ctypes.c_void_p), ("epipole", ctypes.c_void_p), ("stereo_a", ctypes.c_void_p), ("stereo_b", ctypes.c_void_p),
                 ("scale_factors", ctypes.c_void_p), ("level_sigma2", ctypes.c_void_p), ("nlevels", ctypes.c_int), ("check_orientation", ctypes.c_int)]
@@ -428,6 +434,35 @@ class ORBmatcher:
         nm = ctypes.c_int32()
         _check(self._L.orbx_search_for_triangulation(self._h, ctypes.byref(sets[0]), ctypes.byref(sets[1]), ctypes.byref(prm), _ptr(out), ctypes.byref(nm)))
         return nm.value, out[:n1]
+
+    def FuseSearch(self, kf, points, chi2_gate=True):
+        """Steps 2-3 of ORBmatcher::Fuse (reference src/ORBmatcher.cc:1093-1146 / 1258-1276): per map point the KeyFrame
+        feature of minimum Hamming distance inside GetFeaturesInArea(u, v, radius) that passes the level gate and
+        (first overload, chi2_gate) the reprojection gate.  kf: dict(kps (mvKeysUn), desc, u_right, inv_level_sigma2,
+        width, height[, min_x, min_y, max_x, max_y]); points: dict(u, v, ur, level, radius, active, desc).
+        Returns (best_idx[m], best_dist[m]); the caller fuses where best_dist <= TH_LOW."""
+        k = np.ascontiguousarray(kf["kps"], KEYPOINT_DTYPE)
+        n = len(k)
+        d = np.ascontiguousarray(kf["desc"], np.uint8)
+        ur = np.ascontiguousarray(kf["u_right"], np.float32)
+        s2 = np.ascontiguousarray(kf["inv_level_sigma2"], np.float32)
+        minx, miny = np.float32(kf.get("min_x", 0.0)), np.float32(kf.get("min_y", 0.0))
+        maxx, maxy = np.float32(kf.get("max_x", kf["width"])), np.float32(kf.get("max_y", kf["height"]))
+        gw, gh = np.float32(64) / (maxx - minx), np.float32(48) / (maxy - miny)
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        pu, pv, pur, prad = f32(points["u"]), f32(points["v"]), f32(points["ur"]), f32(points["radius"])
+        m = len(pu)
+        lvl = np.ascontiguousarray(points["level"], np.int32)
+        act = np.ascontiguousarray(points["active"], np.uint8)
+        pd = np.ascontiguousarray(points["desc"], np.uint8)
+        cn, cm = np.array([n], np.int32), np.array([m], np.int32)
+        fr = ProjectionFrame(k.ctypes.data, d.ctypes.data, ur.ctypes.data, None, cn.ctypes.data, max(n, 1), 1, minx, miny, gw, gh)
+        pt = FusePoints(pu.ctypes.data, pv.ctypes.data, pur.ctypes.data, lvl.ctypes.data, prad.ctypes.data, act.ctypes.data, pd.ctypes.data, cm.ctypes.data,
+                        max(m, 1), float(np.float32(int(minx))), float(np.float32(int(miny))))
+        bi, bd = np.full(max(m, 1), -1, np.int32), np.full(max(m, 1), 256, np.int32)
+        self._L.orbx_fuse_search.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _check(self._L.orbx_fuse_search(self._h, ctypes.byref(fr), ctypes.byref(pt), _ptr(s2), len(s2), 1 if chi2_gate else 0, _ptr(bi), _ptr(bd)))
+        return bi[:m], bd[:m]
 
     def SearchByProjection(self, frame, points, th, nnratio=None):
         """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (reference src/ORBmatcher.cc:70-175).

@@ -1315,6 +1315,150 @@ extern "C" int orbx_stereo_download(orbx_matcher *m, int npairs, float *uright, 
     return ORBX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::Fuse, both overloads (src/ORBmatcher.cc:1020-1177, 1179-1312): the search of steps 2-3,
+// i.e. KeyFrame::GetFeaturesInArea(u, v, radius) (src/KeyFrame.cc:752-796), the level gate
+// (:1107-1108, 1262-1263), for the first overload the chi-square gate on the reprojection error
+// (:1111-1135) and the minimum Hamming distance with strict '<' (first minimum in the cell-major
+// order of GetFeaturesInArea).  The map points are independent of each other here (the reference's
+// loop only couples them through Replace / AddObservation, which stay on the host in the shim).
+// One wave per map point, lanes over the KeyFrame's features.
+// ---------------------------------------------------------------------------------------------
+struct FusePointsDev { const float *u, *v, *ur; const int32_t *level; const float *radius; const uint8_t *active, *desc; const int32_t *counts; int cap;
+                       float kfMinX, kfMinY; };
+struct FuseLevels { float invSigma2[ORBX_MAX_LEVELS]; };
+
+__global__ __launch_bounds__(256) void k_fuse_best(ProjFrameDev F, FusePointsDev P, FuseLevels LV, int chi2Gate, int32_t *__restrict__ bestIdx,
+                                                   int32_t *__restrict__ bestDist, int stride)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
+    if (i >= m) return;
+    const size_t pi = (size_t)f * P.cap + i, fbase = (size_t)f * F.cap;
+    unsigned long long best = KEY64_EMPTY;
+    if (!P.active || P.active[pi]) {
+        const float x = P.u[pi], y = P.v[pi], r = P.radius[pi], xr = chi2Gate ? P.ur[pi] : 0.0f;
+        const int lvl = P.level[pi];
+        // the window uses the KeyFrame's (int) bounds, KeyFrame.cc:760-775; the cells were filed with the Frame's float bounds
+        const int cx0 = max(0, (int)floorf((x - P.kfMinX - r) * F.gwInv)), cx1 = min(GRID_COLS - 1, (int)ceilf((x - P.kfMinX + r) * F.gwInv));
+        const int cy0 = max(0, (int)floorf((y - P.kfMinY - r) * F.ghInv)), cy1 = min(GRID_ROWS - 1, (int)ceilf((y - P.kfMinY + r) * F.ghInv));
+        if (!(cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0)) {
+            const unsigned long long *dp = (const unsigned long long *)(P.desc + pi * 32);
+            const unsigned long long d[4] = {dp[0], dp[1], dp[2], dp[3]};
+            for (int idx = lane; idx < n; idx += 64) {
+                const orbx_keypoint k = F.kp[fbase + idx];
+                const int cx = (int)roundf((k.x - F.minX) * F.gwInv), cy = (int)roundf((k.y - F.minY) * F.ghInv);   // the cell AssignFeaturesToGrid filed it in
+                if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) continue;
+                const float distx = k.x - x, disty = k.y - y;
+                if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;                                             // KeyFrame.cc:786-790
+                if (k.octave < lvl - 1 || k.octave > lvl) continue;                                               // :1107-1108
+                if (chi2Gate) {
+                    const float kr = F.uRight[fbase + idx];
+                    const float ex = x - k.x, ey = y - k.y;
+                    if (kr >= 0) {
+                        const float er = xr - kr;
+                        const float e2 = ex * ex + ey * ey + er * er;
+                        if ((double)(e2 * LV.invSigma2[k.octave]) > 7.8) continue;                                // :1123
+                    } else {
+                        const float e2 = ex * ex + ey * ey;
+                        if ((double)(e2 * LV.invSigma2[k.octave]) > 5.99) continue;                               // :1134
+                    }
+                }
+                const unsigned long long *db = (const unsigned long long *)(F.desc + (fbase + idx) * 32);
+                const int dist = hamming256(d, db[0], db[1], db[2], db[3]);
+                const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)idx;
+                best = key < best ? key : best;
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) {
+        const size_t o = (size_t)f * stride + i;
+        bestIdx[o] = best == KEY64_EMPTY ? -1 : (int)(best & 0xffff);
+        bestDist[o] = best == KEY64_EMPTY ? 256 : (int)(best >> 32);
+    }
+}
+
+static int fuse_launch(orbx_matcher *m, const ProjFrameDev &F, const FusePointsDev &P, int nframes, const float *inv_level_sigma2, int nlevels, int chi2_gate)
+{
+    if (nframes < 1 || nframes > m->maxPairs) { orbx_set_error("nframes %d outside 1..%d", nframes, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (F.cap < 1 || F.cap > 65535 || P.cap < 1 || P.cap > m->maxFeatures) {
+        orbx_set_error("bad capacities (features %d, points %d, matcher max_features %d)", F.cap, P.cap, m->maxFeatures);
+        return ORBX_ERR_CAPACITY;
+    }
+    if (!inv_level_sigma2 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS) { orbx_set_error("bad level table"); return ORBX_ERR_ARG; }
+    FuseLevels LV;
+    for (int l = 0; l < ORBX_MAX_LEVELS; l++) LV.invSigma2[l] = l < nlevels ? inv_level_sigma2[l] : 0.0f;
+    const int stride = m->maxFeatures;
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_fuse_best, dim3((unsigned)((P.cap + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, F, P, LV, chi2_gate, m->matches.p, m->dists.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = nframes; m->lastStride = stride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_fuse_search_device(orbx_matcher *m, const orbx_projection_frame *kf, const orbx_fuse_points *pts, const float *inv_level_sigma2, int nlevels,
+                                       int chi2_gate)
+{
+    if (!m || !kf || !pts) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!kf->keypoints_un || !kf->descriptors || !kf->counts || (chi2_gate && (!kf->u_right || !pts->ur)) || !pts->u || !pts->v || !pts->level || !pts->radius ||
+        !pts->descriptors || !pts->counts) {
+        orbx_set_error("NULL array in the fuse arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ProjFrameDev F = {kf->keypoints_un, kf->descriptors, kf->u_right, nullptr, kf->counts, kf->capacity, kf->min_x, kf->min_y, kf->grid_width_inv, kf->grid_height_inv};
+    FusePointsDev P = {pts->u, pts->v, pts->ur, pts->level, pts->radius, pts->active, pts->descriptors, pts->counts, pts->capacity, pts->kf_min_x, pts->kf_min_y};
+    return fuse_launch(m, F, P, kf->nframes, inv_level_sigma2, nlevels, chi2_gate);
+}
+
+// host-array form for one KeyFrame: upload, run, download
+extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_projection_frame *kf, const orbx_fuse_points *pt, const float *inv_level_sigma2, int nlevels,
+                                int chi2_gate, int32_t *best_idx, int32_t *best_dist)
+{
+    if (!m || !kf || !pt || !best_idx || !best_dist) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!kf->counts || !pt->counts) { orbx_set_error("NULL counts"); return ORBX_ERR_ARG; }
+    const int n = kf->counts[0], mm = pt->counts[0];
+    for (int i = 0; i < mm; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (n <= 0 || mm <= 0) return ORBX_OK;
+    if (mm > m->maxFeatures) { orbx_set_error("%d map points exceed the matcher's max_features %d", mm, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    if (!kf->keypoints_un || !kf->descriptors || (chi2_gate && (!kf->u_right || !pt->ur)) || !pt->u || !pt->v || !pt->level || !pt->radius || !pt->descriptors) {
+        orbx_set_error("NULL array in the fuse arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    // staging: KeyFrame side in pkp / hd[0] / pf[0]; point side in pf[1] (u, v, ur, radius) / pi32[1] (level) / pb[1] (descriptors, active)
+    if ((rc = m->pkp.ensure((size_t)n)) || (rc = m->hd[0].ensure((size_t)n * 32)) || (rc = m->pf[0].ensure((size_t)n)) || (rc = m->pi32[0].ensure(2)) ||
+        (rc = m->pf[1].ensure((size_t)mm * 4)) || (rc = m->pi32[1].ensure((size_t)mm)) || (rc = m->pb[1].ensure((size_t)mm * 33)))
+        return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, kf->keypoints_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[0].p, kf->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    if (kf->u_right) ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[0].p, kf->u_right, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    const int32_t cnt[2] = {n, mm};
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, pt->u, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + mm, pt->v, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    if (pt->ur) ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 2 * (size_t)mm, pt->ur, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 3 * (size_t)mm, pt->radius, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p, pt->level, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p, pt->descriptors, (size_t)mm * 32, hipMemcpyHostToDevice, st));
+    if (pt->active) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)mm * 32, pt->active, (size_t)mm, hipMemcpyHostToDevice, st));
+    ProjFrameDev F = {m->pkp.p, m->hd[0].p, m->pf[0].p, nullptr, m->pi32[0].p, n, kf->min_x, kf->min_y, kf->grid_width_inv, kf->grid_height_inv};
+    FusePointsDev P = {m->pf[1].p, m->pf[1].p + mm, m->pf[1].p + 2 * (size_t)mm, m->pi32[1].p, m->pf[1].p + 3 * (size_t)mm,
+                       pt->active ? m->pb[1].p + (size_t)mm * 32 : nullptr, m->pb[1].p, m->pi32[0].p + 1, mm, pt->kf_min_x, pt->kf_min_y};
+    if ((rc = fuse_launch(m, F, P, 1, inv_level_sigma2, nlevels, chi2_gate)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    ORBX_HIP_CHECK(hipMemcpy(best_idx, m->matches.p, (size_t)mm * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_CHECK(hipMemcpy(best_dist, m->dists.p, (size_t)mm * 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
 static int proj_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjPointsDev &P, int nframes, const float *scale_factors, int nlevels, float th,
                        float nnratio)
 {

@@ -8,6 +8,8 @@
 //     int ORBmatcher::SearchByProjection(Frame&, const std::vector<MapPoint*>&, float)   src/ORBmatcher.cc:70-175
 //     int ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)              src/ORBmatcher.cc:1569-1728
 //     int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat, std::vector<std::pair<size_t,size_t> >&, bool)   src/ORBmatcher.cc:810-1017
+//     int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                                                src/ORBmatcher.cc:1020-1177
+//     int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, std::vector<MapPoint*>&)              src/ORBmatcher.cc:1179-1312
 // A maintainer deletes those three bodies from src/ORBmatcher.cc and adds this file to the
 // source list; the test build keeps src/ORBmatcher.cc untouched and weakens
 // the three symbols in its object file instead (oracle/Makefile, target liborbslam_hip.so).
@@ -27,6 +29,8 @@
 // bodies, not the reference's, were linked)
 static unsigned long gSearchByProjectionCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_by_projection_calls(void) { return gSearchByProjectionCalls; }
+static unsigned long gFuseCalls = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_fuse_calls(void) { return gFuseCalls; }
 static unsigned long gTriangulationCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_for_triangulation_calls(void) { return gTriangulationCalls; }
 static unsigned long gSearchByBoWCalls = 0;
@@ -177,6 +181,165 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
     for (int i = 0; i < NA; i++)
         if (match[(size_t)i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match[(size_t)i]));
     return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fuse, both overloads.  Per map point the reference (1) projects it and applies the visibility gates,
+// (2) searches the KeyFrame's features around the projection, (3) rewires pointers.  (1) is a handful
+// of cv::Mat expressions per point and PredictScale (a libm log): kept verbatim on the host; (2) is the
+// data-parallel part: one orbx_fuse_search call for the whole list; (3) stays the reference's code,
+// run in list order on the results.  A point that is bad or already in the KeyFrame when the call
+// starts is still so at its turn (Replace only ever removes points from play), so filtering (1)+(2)
+// up front does not change what (3) sees.
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+struct FuseArrays {
+    std::vector<float> u, v, ur, radius;
+    std::vector<int32_t> level, bestIdx, bestDist;
+    std::vector<uint8_t> active, desc;
+    explicit FuseArrays(size_t n) : u(n), v(n), ur(n), radius(n), level(n), bestIdx(n, -1), bestDist(n, 256), active(n, 0), desc(n * 32, 0) {}
+};
+
+void FuseSearch(KeyFrame *pKF, FuseArrays &A, int n, int chi2Gate)
+{
+    if (n == 0 || pKF->N == 0) return;
+    const int N = pKF->N;
+    orbx_projection_frame kf = {(const orbx_keypoint *)&pKF->mvKeysUn[0], pKF->mDescriptors.data, &pKF->mvuRight[0], 0, &N, N, 1,
+                                Frame::mnMinX, Frame::mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv};   // what filed mGrid
+    orbx_fuse_points pt = {&A.u[0], &A.v[0], &A.ur[0], &A.level[0], &A.radius[0], &A.active[0], &A.desc[0], &n, n,
+                           (float)pKF->mnMinX, (float)pKF->mnMinY};                                                         // what the window uses
+    if (orbx_fuse_search(Matcher(N > n ? N : n), &kf, &pt, &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), chi2Gate, &A.bestIdx[0],
+                         &A.bestDist[0]) != ORBX_OK)
+        throw std::runtime_error(std::string("ORBmatcher::Fuse (orbx): ") + orbx_last_error());
+}
+}  // namespace
+
+int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th)
+{
+    __atomic_add_fetch(&gFuseCalls, 1, __ATOMIC_RELAXED);
+    cv::Mat Rcw = pKF->GetRotation();
+    cv::Mat tcw = pKF->GetTranslation();
+    const float &fx = pKF->fx;
+    const float &fy = pKF->fy;
+    const float &cx = pKF->cx;
+    const float &cy = pKF->cy;
+    const float &bf = pKF->mbf;
+    cv::Mat Ow = pKF->GetCameraCenter();
+    const int nMPs = (int)vpMapPoints.size();
+    FuseArrays A((size_t)nMPs);
+    for (int i = 0; i < nMPs; i++) {                                            // step 1, :1032-1093
+        MapPoint *pMP = vpMapPoints[(size_t)i];
+        if (!pMP) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0f) continue;
+        const float invz = 1 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz;
+        const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float ur = u - bf * invz;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist3D = cv::norm(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) continue;
+        int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        const cv::Mat dMP = pMP->GetDescriptor();
+        A.u[(size_t)i] = u; A.v[(size_t)i] = v; A.ur[(size_t)i] = ur; A.level[(size_t)i] = nPredictedLevel; A.radius[(size_t)i] = radius;
+        A.active[(size_t)i] = 1;
+        memcpy(&A.desc[32 * (size_t)i], dMP.ptr<unsigned char>(), 32);
+    }
+    FuseSearch(pKF, A, nMPs, 1);                                                // steps 2-3, :1093-1146
+    int nFused = 0;
+    for (int i = 0; i < nMPs; i++) {                                            // :1148-1174, in list order
+        MapPoint *pMP = vpMapPoints[(size_t)i];
+        if (!pMP) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+        if (!A.active[(size_t)i]) continue;
+        const int bestDist = A.bestDist[(size_t)i], bestIdx = A.bestIdx[(size_t)i];
+        if (bestDist <= TH_LOW) {
+            MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bestIdx);
+                pKF->AddMapPoint(pMP, bestIdx);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
+}
+
+int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint)
+{
+    __atomic_add_fetch(&gFuseCalls, 1, __ATOMIC_RELAXED);
+    const float &fx = pKF->fx;
+    const float &fy = pKF->fy;
+    const float &cx = pKF->cx;
+    const float &cy = pKF->cy;
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();
+    const int nPoints = (int)vpPoints.size();
+    FuseArrays A((size_t)nPoints);
+    for (int iMP = 0; iMP < nPoints; iMP++) {                                   // :1205-1258
+        MapPoint *pMP = vpPoints[(size_t)iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0f) continue;
+        const float invz = 1.0 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz;
+        const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist3D = cv::norm(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        const cv::Mat dMP = pMP->GetDescriptor();
+        A.u[(size_t)iMP] = u; A.v[(size_t)iMP] = v; A.level[(size_t)iMP] = nPredictedLevel; A.radius[(size_t)iMP] = radius;
+        A.active[(size_t)iMP] = 1;
+        memcpy(&A.desc[32 * (size_t)iMP], dMP.ptr<unsigned char>(), 32);
+    }
+    FuseSearch(pKF, A, nPoints, 0);                                             // :1258-1276
+    int nFused = 0;
+    for (int iMP = 0; iMP < nPoints; iMP++) {                                   // :1278-1306
+        if (!A.active[(size_t)iMP]) continue;
+        MapPoint *pMP = vpPoints[(size_t)iMP];
+        const int bestDist = A.bestDist[(size_t)iMP], bestIdx = A.bestIdx[(size_t)iMP];
+        if (bestDist <= TH_LOW) {
+            MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) vpReplacePoint[(size_t)iMP] = pMPinKF;
+            } else {
+                pMP->AddObservation(pKF, bestIdx);
+                pKF->AddMapPoint(pMP, bestIdx);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
 }
 
 // Tracking::SearchLocalPoints (src/Tracking.cc:1616): the MapPoints carry what Frame::isInFrustum

@@ -563,3 +563,57 @@ def ref_search_for_triangulation(kf1, kf2, Tcw1, Tcw2, F12, only_stereo, check_o
     n = lib.orbslam_search_for_triangulation(_p(a[0]), _p(a[1]), len(a[0]), _p(a[2]), _p(a[3]), _p(a[4]), _p(T1), _p(b[0]), _p(b[1]), len(b[0]), _p(b[2]), _p(b[3]),
                                              _p(b[4]), _p(T2), _p(F), 1 if only_stereo else 0, 1 if check_ori else 0, _p(out), _p(epi))
     return n, out[:len(a[0])], epi
+
+
+def fuse_best(orc, kf, pts, chi2_gate):
+    """Restatement of steps 2-3 of ORBmatcher::Fuse (oracle/match_oracle.cc): (best_idx, best_dist) per map point."""
+    lib = orc.lib
+    k = np.ascontiguousarray(_kp7(kf["kps"]) if np.asarray(kf["kps"]).dtype.names else kf["kps"], np.float32)
+    n = len(k)
+    d = np.ascontiguousarray(kf["desc"], np.uint8)
+    ur = np.ascontiguousarray(kf["u_right"], np.float32)
+    s2 = np.ascontiguousarray(kf["inv_level_sigma2"], np.float32)
+    minx, miny = np.float32(kf.get("min_x", 0.0)), np.float32(kf.get("min_y", 0.0))
+    maxx, maxy = np.float32(kf.get("max_x", kf["width"])), np.float32(kf.get("max_y", kf["height"]))
+    gw, gh = np.float32(64) / (maxx - minx), np.float32(48) / (maxy - miny)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    pu, pv, pur, prad = f32(pts["u"]), f32(pts["v"]), f32(pts["ur"]), f32(pts["radius"])
+    m = len(pu)
+    lvl = np.ascontiguousarray(pts["level"], np.int32)
+    act = np.ascontiguousarray(pts["active"], np.uint8)
+    pd = np.ascontiguousarray(pts["desc"], np.uint8)
+    bi, bd = np.full(max(m, 1), -1, np.int32), np.full(max(m, 1), 256, np.int32)
+    vp, cf, ci = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+    lib.mo_fuse_best.argtypes = [vp, vp, vp, ci, cf, cf, cf, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp]
+    lib.mo_fuse_best.restype = None
+    lib.mo_fuse_best(_p(k), _p(d), _p(ur), n, minx, miny, float(np.float32(int(minx))), float(np.float32(int(miny))), gw, gh, _p(s2), _p(pu), _p(pv), _p(pur),
+                     _p(lvl), _p(prad), _p(act), _p(pd), m, 1 if chi2_gate else 0, _p(bi), _p(bd))
+    return bi[:m], bd[:m]
+
+
+def ref_fuse(overload, kf, Tcw, Scw, holder, exist_obs, src_kps, Tcw_src, cand_pos, cand_desc, cand_obs, lst, th, probe, lib=None):
+    """ORBmatcher::Fuse of the reference on a real target KeyFrame / real MapPoints (oracle/refslam_wrap.cc:orbslam_fuse)."""
+    lib = lib or slam_lib()
+    k = np.ascontiguousarray(_kp7(kf["kps"]) if np.asarray(kf["kps"]).dtype.names else kf["kps"], np.float32)
+    n = len(k)
+    d = np.ascontiguousarray(kf["desc"], np.uint8)
+    ur = np.ascontiguousarray(kf["u_right"], np.float32)
+    T, S, Ts = (np.ascontiguousarray(a, np.float32).reshape(16) for a in (Tcw, Scw, Tcw_src))
+    holder = np.ascontiguousarray(holder, np.int32)
+    exist_obs = np.ascontiguousarray(exist_obs, np.int32)
+    sk = np.ascontiguousarray(_kp7(src_kps) if np.asarray(src_kps).dtype.names else src_kps, np.float32)
+    cp, cd, co = np.ascontiguousarray(cand_pos, np.float32), np.ascontiguousarray(cand_desc, np.uint8), np.ascontiguousarray(cand_obs, np.int32)
+    nc = len(cp)
+    lst = np.ascontiguousarray(lst, np.int32)
+    probe_idx = np.full(max(nc, 1), -1, np.int32)
+    hold_out = np.full(max(n, 1), -1, np.int32)
+    bad, repl = np.zeros(max(nc, 1), np.uint8), np.full(max(nc, 1), -1, np.int32)
+    rep_pt = np.full(max(len(lst), 1), -1, np.int32)
+    prep = np.zeros((max(nc, 1), 6), np.float32)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.orbslam_fuse.argtypes = [ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, ci, ctypes.c_float, ci, vp, vp, vp, vp, vp, vp]
+    nf = lib.orbslam_fuse(overload, _p(k), _p(d), _p(ur), n, _p(T), _p(S), _p(holder), len(exist_obs), _p(exist_obs), _p(sk), _p(Ts), _p(cp), _p(cd), _p(co), nc,
+                          _p(lst), len(lst), th, 1 if probe else 0, _p(probe_idx), _p(hold_out), _p(bad), _p(repl), _p(rep_pt), _p(prep))
+    pts = dict(u=prep[:nc, 0].copy(), v=prep[:nc, 1].copy(), ur=prep[:nc, 2].copy(), level=prep[:nc, 3].astype(np.int32), radius=prep[:nc, 4].copy(),
+               active=(prep[:nc, 5] > 0).astype(np.uint8), desc=cd)
+    return dict(nfused=nf, probe_idx=probe_idx[:nc], holder=hold_out[:n], bad=bad[:nc], replaced=repl[:nc], replace_point=rep_pt[:len(lst)], points=pts)

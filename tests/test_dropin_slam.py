@@ -164,6 +164,37 @@ def _octaves(inv_s2):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("overload,seed", [(1, 51), (1, 52), (2, 53)])
+def test_fuse_dropin_equals_reference(orbx, overload, seed):
+    """ORBmatcher::Fuse on a real target KeyFrame that already holds MapPoints (with more or fewer observations than the
+    candidates: both Replace directions), a list with NULL entries and duplicates: identical pointer surgery."""
+    from test_fuse import _scene, _sim3
+    orbx.load_library()
+    hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
+    hip.orbx_shim_fuse_calls.restype = ctypes.c_ulong
+    before = hip.orbx_shim_fuse_calls()
+    kf, Tt, sk, Ts, P, cdesc, rng = _scene(orbx, seed)
+    n, nc = len(kf["kps"]), len(P)
+    n_exist = 120
+    holder = np.full(n, -1, np.int32)
+    holder[rng.choice(n, n_exist, replace=False)] = np.arange(n_exist)
+    exist_obs = rng.integers(0, 5, n_exist).astype(np.int32)
+    cand_obs = rng.integers(0, 4, nc).astype(np.int32)
+    lst = np.concatenate([rng.permutation(nc), rng.integers(0, nc, 60)]).astype(np.int32)     # duplicates at the end
+    lst[rng.choice(len(lst), 25, replace=False)] = -1 if overload == 1 else lst[0]            # NULL entries (overload 2 dereferences every entry)
+    out = [oracle_lib.ref_fuse(overload, kf, Tt, _sim3(Tt), holder, exist_obs, sk, Ts, P, cdesc, cand_obs, lst, 3.0, False, lib=L) for L in (ref, hip)]
+    assert hip.orbx_shim_fuse_calls() - before == 1, "the HIP body was not the one linked"
+    want, got = out
+    assert got["nfused"] == want["nfused"] and want["nfused"] > 200
+    for k in ("holder", "bad", "replaced", "replace_point"):
+        assert (got[k] == want[k]).all(), k
+    if overload == 1:
+        assert want["bad"].sum() > 5 and (want["holder"] >= 1000000).sum() < n_exist          # candidates and existing points were both replaced
+    else:
+        assert (want["replace_point"] >= 0).sum() > 5
+
+
+@pytest.mark.gpu
 def test_search_for_triangulation_dropin_equals_reference(orbx):
     """ORBmatcher::SearchForTriangulation on two real KeyFrames (poses, mFeatVec, MapPoints, mvuRight): the shim
     computes the epipole with the reference's cv::Mat expressions and runs the matching on the device."""
