@@ -588,6 +588,174 @@ __global__ __launch_bounds__(1024) void k_chol_solve(double *S, const double *bs
     if (tid == 0) *okFlag = 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-workgroup right-looking Cholesky for the larger reduced systems (n >= CHOL_MULTI_MIN_N): the
+// single-workgroup kernel above is latency bound (one CU, ~20 barriers per panel); here every panel
+// step is two launches on the same stream,
+//   k_chol_panel   each workgroup factors the 32x32 diagonal block redundantly, solves 64 rows of the panel
+//                  below it against L11 and applies the panel to the right-hand side;
+//   k_chol_update  trailing matrix -= L21 L21^T, one 32x32 tile of the lower triangle per workgroup,
+// and the substitution L^T x = y is one last single-workgroup kernel.  L is written to its own buffer
+// (workgroups read the diagonal block of S while workgroup 0 stores L11), the solved part of y likewise.
+// ---------------------------------------------------------------------------------------------
+#define CHOL_MULTI_MIN_N 96
+#define CNB 32
+
+__global__ __launch_bounds__(256) void k_chol_prep(double *S, const double *bs, int n, double *ywork, int *okFlag)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx == 0) *okFlag = 1;
+    if (idx < n) ywork[idx] = bs[idx];
+    if (idx >= n * n) return;
+    const int r = idx / n, c = idx - r * n;
+    if (r > c) S[idx] = S[(size_t)c * n + r];   // the upper triangle is authoritative on entry
+}
+
+// One LDS tile holds the diagonal block (rows 0..31), the right-hand side of the panel as row 32 (forward
+// substitution is the same recurrence as a row of L) and this workgroup's 64 rows of the panel below (rows 33..96);
+// every elimination step scales column c and applies one rank-1 update to the whole tile, 12 elements per thread
+// read in one batch.  Loops stay rolled over LDS: the fully unrolled register formulation makes the compiler hoist
+// ~500 loop-invariant LDS reads and spill ~700 VGPRs.
+#define CPR (CNB + 1 + 64)   /* tile rows */
+__global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ S, double *__restrict__ L, int n, int p0, double *ywork, double *ysol, int *okFlag)
+{
+    __shared__ double T[CPR][CNB + 1];
+    __shared__ double sdiag[CNB], sinv[CNB];
+    __shared__ int sBad;
+    const int tid = threadIdx.x, nb = min(CNB, n - p0);
+    const int r0 = p0 + nb + blockIdx.x * 64;   // first row of this workgroup's part of the panel below
+    if (tid == 0) sBad = 0;
+    {   // all global loads in flight together: 97 x 32 values, 13 per thread
+        double v[13];
+#pragma unroll
+        for (int q = 0; q < 13; q++) {
+            const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
+            double x = 0.0;
+            if (r < CNB) x = (r < nb && c <= r) ? S[(size_t)(p0 + r) * n + p0 + c] : (r == c ? 1.0 : 0.0);   // identity pad past nb
+            else if (r == CNB) x = c < nb ? ywork[p0 + c] : 0.0;
+            else if (r < CPR && r0 + (r - CNB - 1) < n && c < nb) x = S[(size_t)(r0 + r - CNB - 1) * n + p0 + c];
+            v[q] = x;
+        }
+#pragma unroll
+        for (int q = 0; q < 13; q++) { const int idx = tid + 256 * q; if ((idx >> 5) < CPR) T[idx >> 5][idx & 31] = v[q]; }
+    }
+    __syncthreads();
+    const int tr = tid >> 3, tc = tid & 7;
+    for (int c = 0; c < nb; c++) {
+        const double dj = T[c][c];
+        if (!(dj > 0) || !isfinite(dj)) { if (tid == 0) sBad = 1; }
+        const double inv = rsqrt(dj);
+        // scale column c below the diagonal (the diagonal entry itself is kept aside: nobody reads T[c][c] again)
+        if (c + 1 + tid < CPR) T[c + 1 + tid][c] *= inv;
+        if (tid == 0) { sdiag[c] = dj * inv; sinv[c] = inv; }
+        __syncthreads();
+        double lr[3], lc[4], a[3][4];
+#pragma unroll
+        for (int u = 0; u < 3; u++) lr[u] = T[min(c + 1 + tr + 32 * u, CPR - 1)][c];
+#pragma unroll
+        for (int w = 0; w < 4; w++) lc[w] = T[min(c + 1 + tc + 8 * w, CNB - 1)][c];
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) a[u][w] = T[min(c + 1 + tr + 32 * u, CPR - 1)][min(c + 1 + tc + 8 * w, CNB - 1)];
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int r = c + 1 + tr + 32 * u, c2 = c + 1 + tc + 8 * w;
+                if (r < CPR && c2 < nb && (r >= CNB || c2 <= r)) T[r][c2] = a[u][w] - lr[u] * lc[w];
+            }
+        __syncthreads();
+    }
+    if (sBad && blockIdx.x == 0 && tid == 0) *okFlag = 0;   // not positive definite: the results are discarded by the host
+    // results: L11 and y from workgroup 0, the rows below from every workgroup; b of the rows below -= L21 y
+    for (int idx = tid; idx < CPR * CNB; idx += 256) {
+        const int r = idx >> 5, c = idx & 31;
+        if (c >= nb) continue;
+        if (r < CNB) {
+            if (blockIdx.x == 0 && r < nb && c <= r) L[(size_t)(p0 + r) * n + p0 + c] = r == c ? sdiag[c] : T[r][c];
+        } else if (r == CNB) {
+            if (blockIdx.x == 0) ysol[p0 + c] = T[CNB][c];
+        } else if (r0 + (r - CNB - 1) < n) L[(size_t)(r0 + r - CNB - 1) * n + p0 + c] = T[r][c];
+    }
+    if (tid < 64 && r0 + tid < n) {
+        double dot = 0;
+        for (int c = 0; c < nb; c++) dot += T[CNB + 1 + tid][c] * T[CNB][c];
+        ywork[r0 + tid] -= dot;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ S, const double *__restrict__ L, int n, int p0)
+{
+    const int I = blockIdx.y, K = blockIdx.x;
+    if (K > I) return;
+    __shared__ double la[CNB][CNB + 1], lb[CNB][CNB + 1];
+    const int base = p0 + CNB, tid = threadIdx.x;   // an update only follows a full panel
+    for (int idx = tid; idx < CNB * CNB; idx += 256) {
+        const int r = idx >> 5, c = idx & 31;
+        const int ra = base + CNB * I + r, rb = base + CNB * K + r;
+        la[r][c] = ra < n ? L[(size_t)ra * n + p0 + c] : 0.0;
+        lb[r][c] = rb < n ? L[(size_t)rb * n + p0 + c] : 0.0;
+    }
+    __syncthreads();
+    const int ti = (tid >> 4) * 2, tk = (tid & 15) * 2;
+    double acc[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll 8
+    for (int c = 0; c < CNB; c++) {
+        const double a0 = la[ti][c], a1 = la[ti + 1][c], b0 = lb[tk][c], b1 = lb[tk + 1][c];
+        acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            const int row = base + CNB * I + ti + u, col = base + CNB * K + tk + w;
+            if (row < n && col <= row) S[(size_t)row * n + col] -= acc[u][w];
+        }
+}
+
+// L^T x = y, panels from the last to the first; x in LDS
+__global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict__ L, const double *__restrict__ ysol, int n, double *__restrict__ x)
+{
+    __shared__ double sx[CHOL_MAX_N];
+    __shared__ double part[32][CNB + 1];
+    __shared__ double l11[CNB][CNB + 1];
+    const int tid = threadIdx.x, c = tid & 31, pt = tid >> 5;
+    for (int i = tid; i < n; i += 1024) sx[i] = ysol[i];
+    __syncthreads();
+    const int npan = (n + CNB - 1) / CNB;
+    for (int pi = npan - 1; pi >= 0; pi--) {
+        const int p0 = pi * CNB, nb = min(CNB, n - p0);
+        double acc = 0;
+        if (c < nb)
+            for (int r = p0 + nb + pt; r < n; r += 32) acc += L[(size_t)r * n + p0 + c] * sx[r];
+        part[pt][c] = acc;
+        {
+            const int r = tid >> 5, cc = tid & 31;
+            l11[r][cc] = (r < nb && cc <= r) ? L[(size_t)(p0 + r) * n + p0 + cc] : 0.0;
+        }
+        __syncthreads();
+        if (tid < nb) {
+            double t = 0;
+            for (int q = 0; q < 32; q++) t += part[q][tid];
+            sx[p0 + tid] -= t;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            for (int cc = nb - 1; cc >= 0; cc--) {
+                const double xc = sx[p0 + cc] / l11[cc][cc];
+                __builtin_amdgcn_wave_barrier();
+                if (tid == 0) sx[p0 + cc] = xc;
+                if (tid < cc) sx[p0 + tid] -= l11[cc][tid] * xc;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 1024) x[i] = sx[i];
+}
+
 // x_l = D^-1 (b_l - B^T x_p)   (block_solver.hpp:459-481)
 __global__ __launch_bounds__(256) void k_backsub(LbaDev d, const int *ptStart, const int *ptEdges, const double *bl, const double *Dinv, const double *xp,
                                                  double *xl)
@@ -916,6 +1084,7 @@ struct orbx_lba {
     double flops = 0;
     LBuf<DPose> pose, poseBak;
     LBuf<double> pt, ptBak, intr, obs, info, err, rchi, edgeBlk, Hpp, bp, Hll, bl, Dinv, S, bs, xp, xl, red;
+    LBuf<double> Lmat, ywork, ysol;   // multi-workgroup Cholesky: the factor and the two halves of the right-hand side
     LBuf<int> ep, ek, ptStart, ptEdges, kfStart, kfEdges, poseIdx, ptIdx, okFlag;
     LBuf<uint8_t> stereo, active;
 };
@@ -938,7 +1107,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     rc = rc ? rc : h->pose.ensure(K); rc = rc ? rc : h->poseBak.ensure(K); rc = rc ? rc : h->pt.ensure(3 * P); rc = rc ? rc : h->ptBak.ensure(3 * P);
     rc = rc ? rc : h->intr.ensure(5 * K); rc = rc ? rc : h->obs.ensure(3 * E); rc = rc ? rc : h->info.ensure(E); rc = rc ? rc : h->err.ensure(3 * E);
     rc = rc ? rc : h->rchi.ensure(E); rc = rc ? rc : h->edgeBlk.ensure(E * EB_SIZE); rc = rc ? rc : h->Hpp.ensure(36 * K); rc = rc ? rc : h->bp.ensure(n6);
-    rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->S.ensure(n6 * n6);
+    rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->S.ensure(n6 * n6); rc = rc ? rc : h->Lmat.ensure(n6 * n6); rc = rc ? rc : h->ywork.ensure(n6); rc = rc ? rc : h->ysol.ensure(n6);
     rc = rc ? rc : h->bs.ensure(n6); rc = rc ? rc : h->xp.ensure(n6); rc = rc ? rc : h->xl.ensure(3 * P); rc = rc ? rc : h->red.ensure(16);
     rc = rc ? rc : h->ep.ensure(E); rc = rc ? rc : h->ek.ensure(E); rc = rc ? rc : h->ptStart.ensure(P + 1); rc = rc ? rc : h->ptEdges.ensure(E);
     rc = rc ? rc : h->kfStart.ensure(K + 1); rc = rc ? rc : h->kfEdges.ensure(E); rc = rc ? rc : h->poseIdx.ensure(K); rc = rc ? rc : h->ptIdx.ensure(P);
@@ -954,7 +1123,7 @@ extern "C" void orbx_lba_destroy(orbx_lba *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->pose.release(); h->poseBak.release(); h->pt.release(); h->ptBak.release(); h->intr.release(); h->obs.release(); h->info.release(); h->err.release();
-    h->rchi.release(); h->edgeBlk.release(); h->Hpp.release(); h->bp.release(); h->Hll.release(); h->bl.release(); h->Dinv.release(); h->S.release();
+    h->rchi.release(); h->edgeBlk.release(); h->Hpp.release(); h->bp.release(); h->Hll.release(); h->bl.release(); h->Dinv.release(); h->S.release(); h->Lmat.release(); h->ywork.release(); h->ysol.release();
     h->bs.release(); h->xp.release(); h->xl.release(); h->red.release(); h->ep.release(); h->ek.release(); h->ptStart.release(); h->ptEdges.release();
     h->kfStart.release(); h->kfEdges.release(); h->poseIdx.release(); h->ptIdx.release(); h->okFlag.release(); h->stereo.release(); h->active.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1063,7 +1232,20 @@ int optimize(Ctx &c, int iterations, double stats[4])
                                nP6, h->Dinv.p, h->S.p, h->bs.p);
             LCHECK();
             if (nP6 > 0) {
-                {   // widest panel whose n x NB doubles fit next to the solution vector in LDS
+                if (nP6 >= CHOL_MULTI_MIN_N) {
+                    const int n = nP6;
+                    hipLaunchKernelGGL(k_chol_prep, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, h->stream, h->S.p, h->bs.p, n, h->ywork.p, h->okFlag.p);
+                    for (int p0 = 0; p0 < n; p0 += CNB) {
+                        const int nb = std::min(CNB, n - p0), below = n - p0 - nb;
+                        hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, (below + 63) / 64)), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0, h->ywork.p,
+                                           h->ysol.p, h->okFlag.p);
+                        if (below > 0) {
+                            const unsigned T = (unsigned)((below + CNB - 1) / CNB);
+                            hipLaunchKernelGGL(k_chol_update, dim3(T, T), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0);
+                        }
+                    }
+                    hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
+                } else {   // widest panel whose n x NB doubles fit next to the solution vector in LDS
                     const size_t budget = 120 * 1024;
                     if ((size_t)nP6 * 32 * 8 <= budget) {
                         const size_t lds = (size_t)nP6 * 32 * 8;
