@@ -548,6 +548,57 @@ ORBSLAM_API int orbslam_fuse(int overload, const float *kps, const uint8_t *desc
     return nFused;
 }
 
+// ORBmatcher::SearchBySim3, src/ORBmatcher.cc:1314-1523, on two real KeyFrames whose features all hold real
+// MapPoints (MapPoint(Pos, pMap, pFrame, idxF) + observation).  pre12[i] >= 0: vpMatches12[i] starts as the
+// MapPoint of KF2 feature pre12[i].  matches12[i] = KF2 feature whose MapPoint ends up in vpMatches12[i], or -1.
+ORBSLAM_API int orbslam_search_by_sim3(const float *kps1, const uint8_t *desc1, const float *pos1, int n1, const float *Tcw1, const float *kps2,
+                                       const uint8_t *desc2, const float *pos2, int n2, const float *Tcw2, const int32_t *pre12, float s12,
+                                       const float *R12, const float *t12, float th, int32_t *matches12)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {500.f, 500.f, 320.f, 240.f, 40.f, 640, 480};
+    Frame F1, F2;
+    fill_frame(F1, kps1, desc1, n1, nullptr, cam, kDefaultScales, 8);
+    fill_frame(F2, kps2, desc2, n2, nullptr, cam, kDefaultScales, 8);
+    cv::Mat T1(4, 4, CV_32F), T2(4, 4, CV_32F), R(3, 3, CV_32F), t(3, 1, CV_32F);
+    for (int i = 0; i < 16; i++) { T1.at<float>(i / 4, i % 4) = Tcw1[i]; T2.at<float>(i / 4, i % 4) = Tcw2[i]; }
+    for (int i = 0; i < 9; i++) R.at<float>(i / 3, i % 3) = R12[i];
+    for (int i = 0; i < 3; i++) t.at<float>(i) = t12[i];
+    F1.SetPose(T1);
+    F2.SetPose(T2);
+    KeyFrame *kf1 = new KeyFrame(F1, &map, (KeyFrameDatabase *)nullptr);
+    KeyFrame *kf2 = new KeyFrame(F2, &map, (KeyFrameDatabase *)nullptr);
+    std::vector<MapPoint *> mp1((size_t)n1), mp2((size_t)n2);
+    std::map<MapPoint *, int> index2;
+    for (int i = 0; i < n1; i++) {
+        cv::Mat pos(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) pos.at<float>(k) = pos1[3 * i + k];
+        mp1[(size_t)i] = new MapPoint(pos, &map, &F1, i);
+        mp1[(size_t)i]->AddObservation(kf1, (size_t)i);
+        kf1->AddMapPoint(mp1[(size_t)i], (size_t)i);
+    }
+    for (int i = 0; i < n2; i++) {
+        cv::Mat pos(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) pos.at<float>(k) = pos2[3 * i + k];
+        mp2[(size_t)i] = new MapPoint(pos, &map, &F2, i);
+        mp2[(size_t)i]->AddObservation(kf2, (size_t)i);
+        kf2->AddMapPoint(mp2[(size_t)i], (size_t)i);
+        index2[mp2[(size_t)i]] = i;
+    }
+    std::vector<MapPoint *> vp12((size_t)n1, (MapPoint *)nullptr);
+    for (int i = 0; i < n1; i++)
+        if (pre12[i] >= 0) vp12[(size_t)i] = mp2[(size_t)pre12[i]];
+    ORBmatcher matcher(0.75f, true);
+    const int n = matcher.SearchBySim3(kf1, kf2, vp12, s12, R, t, th);
+    for (int i = 0; i < n1; i++) matches12[i] = vp12[(size_t)i] ? index2[vp12[(size_t)i]] : -1;
+    for (int i = 0; i < n1; i++) delete mp1[(size_t)i];
+    for (int i = 0; i < n2; i++) delete mp2[(size_t)i];
+    delete kf1;
+    delete kf2;
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------
 // DBoW2 vocabulary: TemplatedVocabulary::loadFromTextFile + transform
 // (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1420, 1127-1262), i.e. what

@@ -10,6 +10,7 @@
 //     int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat, std::vector<std::pair<size_t,size_t> >&, bool)   src/ORBmatcher.cc:810-1017
 //     int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                                                src/ORBmatcher.cc:1020-1177
 //     int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, std::vector<MapPoint*>&)              src/ORBmatcher.cc:1179-1312
+//     int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&, const float&, const cv::Mat&, const cv::Mat&, float)   src/ORBmatcher.cc:1314-1523
 // A maintainer deletes those three bodies from src/ORBmatcher.cc and adds this file to the
 // source list; the test build keeps src/ORBmatcher.cc untouched and weakens
 // the three symbols in its object file instead (oracle/Makefile, target liborbslam_hip.so).
@@ -29,6 +30,8 @@
 // bodies, not the reference's, were linked)
 static unsigned long gSearchByProjectionCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_by_projection_calls(void) { return gSearchByProjectionCalls; }
+static unsigned long gSim3Calls = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_by_sim3_calls(void) { return gSim3Calls; }
 static unsigned long gFuseCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_fuse_calls(void) { return gFuseCalls; }
 static unsigned long gTriangulationCalls = 0;
@@ -340,6 +343,97 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &
         }
     }
     return nFused;
+}
+
+// LoopClosing::ComputeSim3 (src/LoopClosing.cc): the MapPoints of each KeyFrame are carried into the other
+// one with the Sim3 estimate and searched there; a match must be mutual.  The two searches are the Fuse
+// search without the chi-square gate (level gate, first minimum in GetFeaturesInArea order), accepted up to
+// TH_HIGH; the per-point preparation is the reference's own host code.
+namespace
+{
+// one direction of :1352-1427 / :1430-1504: points of pKFa searched in pKFb; Rcw/tcw of pKFa, (sR, t) into pKFb's camera
+void Sim3Direction(KeyFrame *pKFb, const std::vector<MapPoint *> &vpMapPointsA, const std::vector<bool> &vbAlreadyMatchedA, const cv::Mat &Raw,
+                   const cv::Mat &taw, const cv::Mat &sRba, const cv::Mat &tba, float fx, float fy, float cx, float cy, float th, int thDist,
+                   std::vector<int> &vnMatchA)
+{
+    const int NA = (int)vpMapPointsA.size();
+    FuseArrays A((size_t)NA);
+    for (int i = 0; i < NA; i++) {
+        MapPoint *pMP = vpMapPointsA[(size_t)i];
+        if (!pMP || vbAlreadyMatchedA[(size_t)i]) continue;
+        if (pMP->isBad()) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dca = Raw * p3Dw + taw;
+        cv::Mat p3Dcb = sRba * p3Dca + tba;
+        if (p3Dcb.at<float>(2) < 0.0) continue;
+        const float invz = 1.0 / p3Dcb.at<float>(2);
+        const float x = p3Dcb.at<float>(0) * invz;
+        const float y = p3Dcb.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKFb->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        const float dist3D = cv::norm(p3Dcb);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist3D, pKFb);
+        const float radius = th * pKFb->mvScaleFactors[nPredictedLevel];
+        const cv::Mat dMP = pMP->GetDescriptor();
+        A.u[(size_t)i] = u; A.v[(size_t)i] = v; A.level[(size_t)i] = nPredictedLevel; A.radius[(size_t)i] = radius;
+        A.active[(size_t)i] = 1;
+        memcpy(&A.desc[32 * (size_t)i], dMP.ptr<unsigned char>(), 32);
+    }
+    FuseSearch(pKFb, A, NA, 0);
+    for (int i = 0; i < NA; i++)
+        if (A.active[(size_t)i] && A.bestDist[(size_t)i] <= thDist) vnMatchA[(size_t)i] = A.bestIdx[(size_t)i];
+}
+}  // namespace
+
+int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12,
+                             const float th)
+{
+    __atomic_add_fetch(&gSim3Calls, 1, __ATOMIC_RELAXED);
+    const float &fx = pKF1->fx;
+    const float &fy = pKF1->fy;
+    const float &cx = pKF1->cx;
+    const float &cy = pKF1->cy;
+    cv::Mat R1w = pKF1->GetRotation();
+    cv::Mat t1w = pKF1->GetTranslation();
+    cv::Mat R2w = pKF2->GetRotation();
+    cv::Mat t2w = pKF2->GetTranslation();
+    cv::Mat sR12 = s12 * R12;
+    cv::Mat sR21 = (1.0 / s12) * R12.t();
+    cv::Mat t21 = -sR21 * t12;
+    const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const int N1 = (int)vpMapPoints1.size();
+    const std::vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N2 = (int)vpMapPoints2.size();
+    std::vector<bool> vbAlreadyMatched1((size_t)N1, false);
+    std::vector<bool> vbAlreadyMatched2((size_t)N2, false);
+    for (int i = 0; i < N1; i++) {                                              // :1337-1348
+        MapPoint *pMP = vpMatches12[(size_t)i];
+        if (pMP) {
+            vbAlreadyMatched1[(size_t)i] = true;
+            int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+            if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[(size_t)idx2] = true;
+        }
+    }
+    std::vector<int> vnMatch1((size_t)N1, -1);
+    std::vector<int> vnMatch2((size_t)N2, -1);
+    Sim3Direction(pKF2, vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, fx, fy, cx, cy, th, TH_HIGH, vnMatch1);   // :1352-1427
+    Sim3Direction(pKF1, vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, fx, fy, cx, cy, th, TH_HIGH, vnMatch2);   // :1430-1504
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {                                           // :1507-1521
+        int idx2 = vnMatch1[(size_t)i1];
+        if (idx2 >= 0) {
+            int idx1 = vnMatch2[(size_t)idx2];
+            if (idx1 == i1) {
+                vpMatches12[(size_t)i1] = vpMapPoints2[(size_t)idx2];
+                nFound++;
+            }
+        }
+    }
+    return nFound;
 }
 
 // Tracking::SearchLocalPoints (src/Tracking.cc:1616): the MapPoints carry what Frame::isInFrustum

@@ -617,3 +617,20 @@ def ref_fuse(overload, kf, Tcw, Scw, holder, exist_obs, src_kps, Tcw_src, cand_p
     pts = dict(u=prep[:nc, 0].copy(), v=prep[:nc, 1].copy(), ur=prep[:nc, 2].copy(), level=prep[:nc, 3].astype(np.int32), radius=prep[:nc, 4].copy(),
                active=(prep[:nc, 5] > 0).astype(np.uint8), desc=cd)
     return dict(nfused=nf, probe_idx=probe_idx[:nc], holder=hold_out[:n], bad=bad[:nc], replaced=repl[:nc], replace_point=rep_pt[:len(lst)], points=pts)
+
+
+def ref_search_by_sim3(kf1, pos1, Tcw1, kf2, pos2, Tcw2, pre12, s12, R12, t12, th, lib=None):
+    """ORBmatcher::SearchBySim3 of the reference on two real KeyFrames whose features all hold MapPoints."""
+    lib = lib or slam_lib()
+    k1 = np.ascontiguousarray(_kp7(kf1["kps"]), np.float32)
+    k2 = np.ascontiguousarray(_kp7(kf2["kps"]), np.float32)
+    d1, d2 = np.ascontiguousarray(kf1["desc"], np.uint8), np.ascontiguousarray(kf2["desc"], np.uint8)
+    p1, p2 = np.ascontiguousarray(pos1, np.float32), np.ascontiguousarray(pos2, np.float32)
+    T1, T2 = np.ascontiguousarray(Tcw1, np.float32).reshape(16), np.ascontiguousarray(Tcw2, np.float32).reshape(16)
+    pre = np.ascontiguousarray(pre12, np.int32)
+    R, t = np.ascontiguousarray(R12, np.float32).reshape(9), np.ascontiguousarray(t12, np.float32).reshape(3)
+    out = np.full(max(len(k1), 1), -1, np.int32)
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    lib.orbslam_search_by_sim3.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, cf, vp, vp, cf, vp]
+    n = lib.orbslam_search_by_sim3(_p(k1), _p(d1), _p(p1), len(k1), _p(T1), _p(k2), _p(d2), _p(p2), len(k2), _p(T2), _p(pre), s12, _p(R), _p(t), th, _p(out))
+    return n, out[:len(k1)]

@@ -195,6 +195,51 @@ def test_fuse_dropin_equals_reference(orbx, overload, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [61, 62])
+def test_search_by_sim3_dropin_equals_reference(orbx, seed):
+    """ORBmatcher::SearchBySim3: two KeyFrames that see the same structure through their own MapPoints, related by a
+    Sim3; the mutual-consistency matches must be the reference's."""
+    from test_fuse import SF, _pose
+    orbx.load_library()
+    hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
+    hip.orbx_shim_search_by_sim3_calls.restype = ctypes.c_ulong
+    before = hip.orbx_shim_search_by_sim3_calls()
+    rng = np.random.default_rng(seed)
+    n = 800
+    T1, T2 = _pose(rng), _pose(rng)
+    P = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(3, 9, n)], 1).astype(np.float32)
+    def view(T, perm, noise):
+        Pc = P @ T[:3, :3].T + T[:3, 3]
+        uv = Pc[:, :2] / Pc[:, 2:3] * 500 + np.array([320, 240])
+        k = np.zeros(n, orbx.KEYPOINT_DTYPE)
+        k["x"], k["y"] = uv[:, 0] + rng.normal(0, noise, n), uv[:, 1] + rng.normal(0, noise, n)
+        k["size"], k["class_id"], k["octave"] = 31, -1, np.clip(np.round(np.log(np.linalg.norm(Pc, axis=1) / 3.0) / np.log(1.2)), 0, 7)
+        return k[perm]
+    perm2 = rng.permutation(n)
+    from test_matcher import _rand_desc
+    base = _rand_desc(rng, n)
+    d2 = base.copy()
+    fl = rng.integers(0, 256, (n, 30))
+    for i in range(n):
+        for b in fl[i][: rng.integers(0, 30)]:
+            d2[i, b >> 3] ^= 1 << (b & 7)
+    kf1 = dict(kps=view(T1, np.arange(n), 0.5), desc=base)
+    kf2 = dict(kps=view(T2, perm2, 0.5), desc=d2[perm2])
+    pos2 = (P + rng.normal(0, 0.01, P.shape).astype(np.float32))[perm2]
+    R12 = T1[:3, :3] @ T2[:3, :3].T
+    t12 = T1[:3, 3] - R12 @ T2[:3, 3]
+    pre = np.full(n, -1, np.int32)
+    inv2 = np.argsort(perm2)
+    pre[:40] = inv2[:40]                                           # matches SearchByBoW already found
+    args = (kf1, P, T1, kf2, pos2, T2, pre, 1.01, R12, t12 * 1.01, 7.5)
+    want_n, want = oracle_lib.ref_search_by_sim3(*args, lib=ref)
+    got_n, got = oracle_lib.ref_search_by_sim3(*args, lib=hip)
+    assert hip.orbx_shim_search_by_sim3_calls() - before == 1, "the HIP body was not the one linked"
+    assert got_n == want_n and (got == want).all()
+    assert want_n > 200 and (want[40:] < 0).sum() > 50
+
+
+@pytest.mark.gpu
 def test_search_for_triangulation_dropin_equals_reference(orbx):
     """ORBmatcher::SearchForTriangulation on two real KeyFrames (poses, mFeatVec, MapPoints, mvuRight): the shim
     computes the epipole with the reference's cv::Mat expressions and runs the matching on the device."""
