@@ -365,6 +365,32 @@ int orbx_fuse_search_device(orbx_matcher *m, const orbx_projection_frame *kf, co
 int orbx_fuse_search(orbx_matcher *m, const orbx_projection_frame *kf_host, const orbx_fuse_points *points_host,
                      const float *inv_level_sigma2, int nlevels, int chi2_gate, int32_t *best_idx, int32_t *best_dist);
 
+/* Greedy area search: the loops of ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th)
+ * (loop closing, src/ORBmatcher.cc:388-513) and SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th,
+ * ORBdist) (relocalisation, :1731-1864) after their per-point preparation (:410-452 / :1755-1790, cv::Mat
+ * expressions and PredictScale, kept on the host by the shim).  Queries are processed in order; query i
+ * takes the feature of minimum Hamming distance (first minimum in GetFeaturesInArea order) among the
+ * features inside GetFeaturesInArea(u, v, radius[, min_level, max_level]) that are not blocked - blocked
+ * from the start (frame->occupied: vpMatched[idx] / CurrentFrame.mvpMapPoints[i2] non-NULL) or taken by an
+ * earlier query - provided that distance is <= max_dist (TH_LOW / ORBdist); the feature is then blocked.
+ * Level gate: octave < min_level or (max_level >= 0 and octave > max_level) rejects (Frame::GetFeaturesInArea,
+ * src/Frame.cc:741-850; the KeyFrame variants pass [level-1, level], :469-470). */
+typedef struct orbx_area_queries {
+    const float *u, *v, *radius;
+    const int32_t *min_level, *max_level;
+    const uint8_t *active;       /* 1 = the point reached the search; NULL = all                            */
+    const uint8_t *descriptors;  /* pMP->GetDescriptor(), 32 bytes                                          */
+    const int32_t *counts;       /* queries per frame                                                       */
+    int capacity;
+    float window_min_x, window_min_y; /* bounds used for the cell window: Frame::mnMinX/Y, or (float) of the
+                                         KeyFrame's int mnMinX/Y (see orbx_fuse_points)                     */
+} orbx_area_queries;
+/* results: matches[f*stride + i] = feature taken by query i or -1, dists[...] its distance (256 when none),
+ * nmatches[f] = number of queries that took a feature. */
+int orbx_area_search_greedy_device(orbx_matcher *m, const orbx_projection_frame *frame, const orbx_area_queries *queries, int max_dist);
+int orbx_area_search_greedy(orbx_matcher *m, const orbx_projection_frame *frame_host, const orbx_area_queries *queries_host, int max_dist,
+                            int32_t *assigned, int32_t *dists, int32_t *nmatches);
+
 int orbx_matcher_results_device(orbx_matcher *m, const int32_t **matches_dev, const int32_t **dists_dev,
                                 const int32_t **nmatches_dev, int *stride);
 int orbx_matcher_download(orbx_matcher *m, int npairs, int32_t *matches, int32_t *dists, int stride,

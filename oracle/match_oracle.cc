@@ -713,3 +713,56 @@ MO_API void mo_fuse_best(const float *kpUn, const uint8_t *desc, const float *uR
         bestIdx[p] = bidx; bestDist[p] = best;
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// The search loops of ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:
+// 453-510) and SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:1790-1826) on flat arrays:
+// queries in order, GetFeaturesInArea window (window bounds winMinX/Y, cells filed with minX/minY), level gate,
+// blocked features skipped, strict '<' minimum, accept when <= maxDist and block the feature.
+// ---------------------------------------------------------------------------------------
+MO_API int mo_area_search_greedy(const float *kpUn, const uint8_t *desc, const uint8_t *blocked0, int n, float minX, float minY, float winMinX, float winMinY,
+                                 float gwInv, float ghInv, const float *qu, const float *qv, const float *qr, const int32_t *qmin, const int32_t *qmax,
+                                 const uint8_t *qactive, const uint8_t *qdesc, int m, int maxDist, int32_t *assigned, int32_t *dists)
+{
+    std::vector<std::vector<int> > grid((size_t)GRID_COLS * GRID_ROWS);
+    for (int i = 0; i < n; i++) {
+        const int px = (int)round((kpUn[7 * (size_t)i] - minX) * gwInv), py = (int)round((kpUn[7 * (size_t)i + 1] - minY) * ghInv);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+        grid[(size_t)px * GRID_ROWS + py].push_back(i);
+    }
+    std::vector<char> blocked((size_t)std::max(n, 1), 0);
+    for (int i = 0; i < n; i++) blocked[(size_t)i] = blocked0 ? (char)blocked0[i] : 0;
+    int nmatches = 0;
+    for (int p = 0; p < m; p++) {
+        assigned[p] = -1; dists[p] = 256;
+        if (qactive && !qactive[p]) continue;
+        const float x = qu[p], y = qv[p], r = qr[p];
+        const int cx0 = std::max(0, (int)floor((x - winMinX - r) * gwInv));
+        if (cx0 >= GRID_COLS) continue;
+        const int cx1 = std::min(GRID_COLS - 1, (int)ceil((x - winMinX + r) * gwInv));
+        if (cx1 < 0) continue;
+        const int cy0 = std::max(0, (int)floor((y - winMinY - r) * ghInv));
+        if (cy0 >= GRID_ROWS) continue;
+        const int cy1 = std::min(GRID_ROWS - 1, (int)ceil((y - winMinY + r) * ghInv));
+        if (cy1 < 0) continue;
+        int best = 256, bidx = -1;
+        for (int ix = cx0; ix <= cx1; ix++)
+            for (int iy = cy0; iy <= cy1; iy++) {
+                const std::vector<int> &cell = grid[(size_t)ix * GRID_ROWS + iy];
+                for (size_t j = 0; j < cell.size(); j++) {
+                    const int idx = cell[j];
+                    const float *k = kpUn + 7 * (size_t)idx;
+                    const int kl = (int)k[5];
+                    if (kl < qmin[p]) continue;
+                    if (qmax[p] >= 0 && kl > qmax[p]) continue;
+                    const float distx = k[0] - x, disty = k[1] - y;
+                    if (!(fabs(distx) < r && fabs(disty) < r)) continue;
+                    if (blocked[(size_t)idx]) continue;
+                    const int dist = descriptor_distance(qdesc + 32 * (size_t)p, desc + 32 * (size_t)idx);
+                    if (dist < best) { best = dist; bidx = idx; }
+                }
+            }
+        if (best <= maxDist) { assigned[p] = bidx; dists[p] = best; blocked[(size_t)bidx] = 1; nmatches++; }
+    }
+    return nmatches;
+}

@@ -487,7 +487,7 @@ ORBSLAM_API int orbslam_fuse(int overload, const float *kps, const uint8_t *desc
             if (kfHolder[i] >= 0) { exist[(size_t)kfHolder[i]]->AddObservation(kfT, (size_t)i); kfT->AddMapPoint(exist[(size_t)kfHolder[i]], (size_t)i); }
     // ---- the reference's per-point preparation, evaluated with its own expressions ----
     cv::Mat Rcw, tcw, Ow, ScwM;
-    if (overload == 1) { Rcw = kfT->GetRotation(); tcw = kfT->GetTranslation(); Ow = kfT->GetCameraCenter(); }
+    if (overload == 1 || overload >= 4) { Rcw = kfT->GetRotation(); tcw = kfT->GetTranslation(); Ow = kfT->GetCameraCenter(); }
     else {
         ScwM = cv::Mat(4, 4, CV_32F);
         for (int i = 0; i < 16; i++) ScwM.at<float>(i / 4, i % 4) = Scw[i];
@@ -501,11 +501,30 @@ ORBSLAM_API int orbslam_fuse(int overload, const float *kps, const uint8_t *desc
         float *o = prep + 6 * (size_t)c;
         for (int k = 0; k < 6; k++) o[k] = 0.f;
         MapPoint *pMP = cand[(size_t)c];
+        if (overload >= 4) {   // the relocalisation overload prepares differently, :1755-1790
+            cv::Mat x3Dw = pMP->GetWorldPos();
+            cv::Mat x3Dc = Rcw * x3Dw + tcw;
+            const float xc = x3Dc.at<float>(0);
+            const float yc = x3Dc.at<float>(1);
+            const float invzc = 1.0 / x3Dc.at<float>(2);
+            const float u = FT.fx * xc * invzc + FT.cx;
+            const float v = FT.fy * yc * invzc + FT.cy;
+            if (u < FT.mnMinX || u > FT.mnMaxX) continue;
+            if (v < FT.mnMinY || v > FT.mnMaxY) continue;
+            cv::Mat PO = x3Dw - Ow;
+            float dist3D = cv::norm(PO);
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            int lvl = pMP->PredictScale(dist3D, &FT);
+            o[0] = u; o[1] = v; o[2] = 0.f; o[3] = (float)lvl; o[4] = th * FT.mvScaleFactors[lvl]; o[5] = 1.f;
+            continue;
+        }
         cv::Mat p3Dw = pMP->GetWorldPos();
         cv::Mat p3Dc = Rcw * p3Dw + tcw;
         if (p3Dc.at<float>(2) < 0.0f) continue;
         float invz;
-        if (overload == 1) invz = 1 / p3Dc.at<float>(2); else invz = 1.0 / p3Dc.at<float>(2);
+        if (overload == 1 || overload == 3) invz = 1 / p3Dc.at<float>(2); else invz = 1.0 / p3Dc.at<float>(2);   // :1050 / :424 vs :1222
         const float x = p3Dc.at<float>(0) * invz, y = p3Dc.at<float>(1) * invz;
         const float u = kfT->fx * x + kfT->cx, v = kfT->fy * y + kfT->cy;
         if (!kfT->IsInImage(u, v)) continue;
@@ -529,6 +548,37 @@ ORBSLAM_API int orbslam_fuse(int overload, const float *kps, const uint8_t *desc
             probeIdx[c] = idx;
             if (idx >= 0) { kfT->EraseMapPointMatch((size_t)idx); cand[(size_t)c]->EraseObservation(kfT); nFused++; }
         }
+    } else if (overload == 3) {
+        // ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:388-513 (loop closing):
+        // vpMatched starts from kfHolder (>= 0: existing point, <= -2: candidate -2-kfHolder[i]); list = vpPoints
+        std::vector<MapPoint *> vp((size_t)nList), vpMatched((size_t)n, (MapPoint *)nullptr);
+        for (int j = 0; j < nList; j++) vp[(size_t)j] = cand[(size_t)list[j]];
+        for (int i = 0; i < n; i++) {
+            if (kfHolder[i] >= 0) { kfT->EraseMapPointMatch((size_t)i); vpMatched[(size_t)i] = exist[(size_t)kfHolder[i]]; }
+            else if (kfHolder[i] <= -2) vpMatched[(size_t)i] = cand[(size_t)(-2 - kfHolder[i])];
+        }
+        nFused = matcher.SearchByProjection(kfT, ScwM, vp, vpMatched, (int)th);
+        for (int i = 0; i < n; i++) holder[i] = vpMatched[(size_t)i] ? code[vpMatched[(size_t)i]] : -1;
+        for (size_t i = 0; i < owned.size(); i++) delete owned[i];
+        delete kfT; delete kfS;
+        for (int k = 0; k < 4; k++) delete extra[k];
+        return nFused;
+    } else if (overload >= 4) {
+        // (overload 4: mbCheckOrientation on, 5: off)
+        // ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), :1731-1864 (relocalisation): the target
+        // is a Frame holding kfHolder's points, pKF = the source KeyFrame whose feature c holds candidate c, list = sAlreadyFound
+        FT.SetPose(FT.mTcw.clone());
+        for (int i = 0; i < n; i++)
+            if (kfHolder[i] >= 0) FT.mvpMapPoints[(size_t)i] = exist[(size_t)kfHolder[i]];
+        std::set<MapPoint *> found;
+        for (int j = 0; j < nList; j++) found.insert(cand[(size_t)list[j]]);
+        ORBmatcher m2(0.9f, overload == 4);
+        nFused = m2.SearchByProjection(FT, kfS, found, th, 100);
+        for (int i = 0; i < n; i++) holder[i] = FT.mvpMapPoints[(size_t)i] ? code[FT.mvpMapPoints[(size_t)i]] : -1;
+        for (size_t i = 0; i < owned.size(); i++) delete owned[i];
+        delete kfT; delete kfS;
+        for (int k = 0; k < 4; k++) delete extra[k];
+        return nFused;
     } else {
         std::vector<MapPoint *> vp((size_t)nList), rep((size_t)nList, (MapPoint *)nullptr);
         for (int j = 0; j < nList; j++) vp[(size_t)j] = list[j] >= 0 ? cand[(size_t)list[j]] : (MapPoint *)nullptr;

@@ -367,6 +367,12 @@ class FusePoints(ctypes.Structure):
                 ("kf_min_x", ctypes.c_float), ("kf_min_y", ctypes.c_float)]
 
 
+class AreaQueries(ctypes.Structure):
+    _fields_ = [("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("radius", ctypes.c_void_p), ("min_level", ctypes.c_void_p), ("max_level", ctypes.c_void_p),
+                ("active", ctypes.c_void_p), ("descriptors", ctypes.c_void_p), ("counts", ctypes.c_void_p), ("capacity", ctypes.c_int),
+                ("window_min_x", ctypes.c_float), ("window_min_y", ctypes.c_float)]
+
+
 class TriangulationParams(ctypes.Structure):
     _fields_ = [("f12", ctypes.c_void_p), ("epipole", ctypes.c_void_p), ("stereo_a", ctypes.c_void_p), ("stereo_b", ctypes.c_void_p),
                 ("scale_factors", ctypes.c_void_p), ("level_sigma2", ctypes.c_void_p), ("nlevels", ctypes.c_int), ("check_orientation", ctypes.c_int)]
@@ -463,6 +469,35 @@ class ORBmatcher:
         self._L.orbx_fuse_search.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _check(self._L.orbx_fuse_search(self._h, ctypes.byref(fr), ctypes.byref(pt), _ptr(s2), len(s2), 1 if chi2_gate else 0, _ptr(bi), _ptr(bd)))
         return bi[:m], bd[:m]
+
+    def AreaSearchGreedy(self, frame, queries, max_dist):
+        """The search loops of ORBmatcher::SearchByProjection(pKF, Scw, ...) (loop closing, reference src/ORBmatcher.cc:453-510)
+        and SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (relocalisation, :1790-1826).
+        frame: dict(kps (mvKeysUn), desc, blocked, width, height[, min_x, ...]); queries: dict(u, v, radius, min_level,
+        max_level, active, desc[, window_int_bounds]).  Returns (nmatches, assigned[m], dists[m])."""
+        k = np.ascontiguousarray(frame["kps"], KEYPOINT_DTYPE)
+        n = len(k)
+        d = np.ascontiguousarray(frame["desc"], np.uint8)
+        blk = np.ascontiguousarray(frame["blocked"], np.uint8)
+        minx, miny = np.float32(frame.get("min_x", 0.0)), np.float32(frame.get("min_y", 0.0))
+        maxx, maxy = np.float32(frame.get("max_x", frame["width"])), np.float32(frame.get("max_y", frame["height"]))
+        gw, gh = np.float32(64) / (maxx - minx), np.float32(48) / (maxy - miny)
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        qu, qv, qr = f32(queries["u"]), f32(queries["v"]), f32(queries["radius"])
+        m = len(qu)
+        lo, hi = np.ascontiguousarray(queries["min_level"], np.int32), np.ascontiguousarray(queries["max_level"], np.int32)
+        act = np.ascontiguousarray(queries["active"], np.uint8)
+        qd = np.ascontiguousarray(queries["desc"], np.uint8)
+        cn, cm = np.array([n], np.int32), np.array([m], np.int32)
+        wx, wy = (np.float32(int(minx)), np.float32(int(miny))) if queries.get("window_int_bounds") else (minx, miny)
+        fr = ProjectionFrame(k.ctypes.data, d.ctypes.data, None, blk.ctypes.data, cn.ctypes.data, max(n, 1), 1, minx, miny, gw, gh)
+        q = AreaQueries(qu.ctypes.data, qv.ctypes.data, qr.ctypes.data, lo.ctypes.data, hi.ctypes.data, act.ctypes.data, qd.ctypes.data, cm.ctypes.data,
+                        max(m, 1), float(wx), float(wy))
+        asg, dst = np.full(max(m, 1), -1, np.int32), np.full(max(m, 1), 256, np.int32)
+        nm = ctypes.c_int32()
+        self._L.orbx_area_search_greedy.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
+        _check(self._L.orbx_area_search_greedy(self._h, ctypes.byref(fr), ctypes.byref(q), int(max_dist), _ptr(asg), _ptr(dst), ctypes.byref(nm)))
+        return nm.value, asg[:m], dst[:m]
 
     def SearchByProjection(self, frame, points, th, nnratio=None):
         """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (reference src/ORBmatcher.cc:70-175).

@@ -1459,6 +1459,249 @@ extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_projection_frame *kf
     return ORBX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Greedy area search: ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (loop closing,
+// src/ORBmatcher.cc:388-513) and SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)
+// (relocalisation, :1731-1864) after their per-point preparation: the queries are processed in order, each
+// takes the feature of minimum distance among those in its GetFeaturesInArea window that pass the level
+// gate and are not blocked (blocked at the start, or taken by an earlier query), if that distance is
+// <= max_dist.  Candidate lists (top-8 by distance || cell order || index, blocking ignored) come from
+// k_area_topk; k_area_greedy replays the sequence as the unique fixed point of "query r takes its best
+// candidate that no accepted query < r took" (see k_bow_greedy), with an exact rescan for exhausted lists.
+// ---------------------------------------------------------------------------------------------
+struct AreaQueriesDev { const float *u, *v, *radius; const int32_t *minLevel, *maxLevel; const uint8_t *active, *desc; const int32_t *counts; int cap;
+                        float winMinX, winMinY; };
+struct AreaQuery { float x, y, r; int minLevel, maxLevel, cx0, cx1, cy0, cy1; bool any; unsigned long long d[4]; };
+
+__device__ __forceinline__ AreaQuery area_query(const ProjFrameDev &F, const AreaQueriesDev &Q, size_t qi)
+{
+    AreaQuery q;
+    q.x = Q.u[qi]; q.y = Q.v[qi]; q.r = Q.radius[qi];
+    q.minLevel = Q.minLevel[qi]; q.maxLevel = Q.maxLevel[qi];
+    const int x0 = max(0, (int)floorf((q.x - Q.winMinX - q.r) * F.gwInv)), x1 = min(GRID_COLS - 1, (int)ceilf((q.x - Q.winMinX + q.r) * F.gwInv));
+    const int y0 = max(0, (int)floorf((q.y - Q.winMinY - q.r) * F.ghInv)), y1 = min(GRID_ROWS - 1, (int)ceilf((q.y - Q.winMinY + q.r) * F.ghInv));
+    q.any = !(x0 >= GRID_COLS || x1 < 0 || y0 >= GRID_ROWS || y1 < 0);
+    q.cx0 = x0; q.cx1 = x1; q.cy0 = y0; q.cy1 = y1;
+    const unsigned long long *dp = (const unsigned long long *)(Q.desc + qi * 32);
+    q.d[0] = dp[0]; q.d[1] = dp[1]; q.d[2] = dp[2]; q.d[3] = dp[3];
+    return q;
+}
+
+__device__ __forceinline__ unsigned long long area_key(const ProjFrameDev &F, size_t fbase, int idx, const AreaQuery &q)
+{
+    const orbx_keypoint k = F.kp[fbase + idx];
+    const int cx = (int)roundf((k.x - F.minX) * F.gwInv), cy = (int)roundf((k.y - F.minY) * F.ghInv);   // the cell AssignFeaturesToGrid filed it in
+    if (cx < q.cx0 || cx > q.cx1 || cy < q.cy0 || cy > q.cy1) return KEY64_EMPTY;
+    if (k.octave < q.minLevel || (q.maxLevel >= 0 && k.octave > q.maxLevel)) return KEY64_EMPTY;
+    const float distx = k.x - q.x, disty = k.y - q.y;
+    if (!(fabsf(distx) < q.r && fabsf(disty) < q.r)) return KEY64_EMPTY;
+    const unsigned long long *db = (const unsigned long long *)(F.desc + (fbase + idx) * 32);
+    const int dist = hamming256(q.d, db[0], db[1], db[2], db[3]);
+    return ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)idx;
+}
+
+__global__ __launch_bounds__(256) void k_area_topk(ProjFrameDev F, AreaQueriesDev Q, unsigned long long *__restrict__ topk)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(F.counts[f], F.cap), m = min(Q.counts[f], Q.cap);
+    if (i >= m) return;
+    const size_t qi = (size_t)f * Q.cap + i, fbase = (size_t)f * F.cap;
+    unsigned long long *out = topk + qi * TOPK;
+    if (Q.active && !Q.active[qi]) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
+    const AreaQuery q = area_query(F, Q, qi);
+    unsigned long long kk[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; t++) kk[t] = KEY64_EMPTY;
+    if (q.any)
+        for (int idx = lane; idx < n; idx += 64) {
+            const unsigned long long key = area_key(F, fbase, idx, q);
+            if (key < kk[TOPK - 1]) {
+                kk[TOPK - 1] = key;
+#pragma unroll
+                for (int t = TOPK - 1; t > 0; t--)
+                    if (kk[t] < kk[t - 1]) { const unsigned long long v = kk[t - 1]; kk[t - 1] = kk[t]; kk[t] = v; }
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < TOPK; k++) {
+        const unsigned long long mn = wave_min_u64(kk[0]);
+        if (kk[0] == mn && mn != KEY64_EMPTY) {   // keys are unique: exactly one lane pops its head
+#pragma unroll
+            for (int t = 0; t < TOPK - 1; t++) kk[t] = kk[t + 1];
+            kk[TOPK - 1] = KEY64_EMPTY;
+        }
+        if (lane == 0) out[k] = mn;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_area_greedy(ProjFrameDev F, AreaQueriesDev Q, int maxDist, const unsigned long long *__restrict__ topk,
+                                                     int32_t *__restrict__ assigned, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int sChanged, sQueued, sTotal;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = min(F.counts[f], F.cap), m = min(Q.counts[f], Q.cap);
+    // LDS: owner[F.cap] (0 = blocked from the start, else 1 + lowest accepted query taking the feature, ~0 = free) | dec[Q.cap] | queue (u16)
+    uint32_t *owner = (uint32_t *)smem;
+    uint32_t *dec = owner + F.cap;                        // KEY_EMPTY or dist << 16 | feature
+    unsigned short *queue = (unsigned short *)(dec + Q.cap);
+    const size_t fbase = (size_t)f * F.cap, qbase = (size_t)f * Q.cap;
+    const unsigned long long *tk = topk + qbase * TOPK;
+    int32_t *aout = assigned + (size_t)f * stride, *dout = dists + (size_t)f * stride;
+    for (int i = tid; i < m; i += 256) dec[i] = KEY_EMPTY;
+    if (tid == 0) sTotal = 0;
+    for (;;) {
+        for (int j = tid; j < n; j += 256) owner[j] = (F.occupied && F.occupied[fbase + j]) ? 0u : 0xffffffffu;
+        if (tid == 0) { sChanged = 0; sQueued = 0; }
+        __syncthreads();
+        for (int r = tid; r < m; r += 256) {
+            const uint32_t d = dec[r];
+            if (d != KEY_EMPTY) atomicMin(&owner[d & 0xffff], (uint32_t)r + 1u);
+        }
+        __syncthreads();
+        bool changed = false;
+        for (int r = tid; r < m; r += 256) {
+            if (Q.active && !Q.active[qbase + r]) continue;
+            uint32_t nd = KEY_EMPTY;
+            bool full = true, found = false;
+#pragma unroll
+            for (int k = 0; k < TOPK; k++) {
+                const unsigned long long key = tk[(size_t)r * TOPK + k];
+                if (key == KEY64_EMPTY) { full = false; continue; }
+                const uint32_t idx = (uint32_t)(key & 0xffff);
+                if (!found && owner[idx] > (uint32_t)r) {   // free for this query: not blocked and not taken by an earlier one
+                    found = true;
+                    const uint32_t dist = (uint32_t)(key >> 32);
+                    if ((int)dist <= maxDist) nd = (dist << 16) | idx;
+                }
+            }
+            if (!found && full) { queue[atomicAdd(&sQueued, 1)] = (unsigned short)r; continue; }
+            if (nd != dec[r]) { dec[r] = nd; changed = true; }
+        }
+        if (changed) sChanged = 1;
+        __syncthreads();
+        const int nq = sQueued;
+        for (int qq = wv; qq < nq; qq += 4) {   // exact rescan over the free features
+            const int r = queue[qq];
+            const AreaQuery q = area_query(F, Q, qbase + r);
+            unsigned long long best = KEY64_EMPTY;
+            for (int idx = lane; idx < n; idx += 64) {
+                if (!(owner[idx] > (uint32_t)r)) continue;
+                const unsigned long long key = area_key(F, fbase, idx, q);
+                best = key < best ? key : best;
+            }
+            best = wave_min_u64(best);
+            uint32_t nd = KEY_EMPTY;
+            if (best != KEY64_EMPTY && (int)(best >> 32) <= maxDist) nd = ((uint32_t)(best >> 32) << 16) | (uint32_t)(best & 0xffff);
+            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChanged = 1; }
+        }
+        __syncthreads();
+        const int again = sChanged;
+        __syncthreads();
+        if (!again) break;
+    }
+    int total = 0;
+    for (int r = tid; r < stride; r += 256) {
+        const uint32_t d = r < m ? dec[r] : KEY_EMPTY;
+        aout[r] = d == KEY_EMPTY ? -1 : (int)(d & 0xffff);
+        dout[r] = d == KEY_EMPTY ? 256 : (int)(d >> 16);
+        total += d != KEY_EMPTY;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if (lane == 0 && total) atomicAdd(&sTotal, total);
+    __syncthreads();
+    if (tid == 0) nmatches[f] = sTotal;
+}
+
+static int area_launch(orbx_matcher *m, const ProjFrameDev &F, const AreaQueriesDev &Q, int nframes, int max_dist)
+{
+    if (nframes < 1 || nframes > m->maxPairs) { orbx_set_error("nframes %d outside 1..%d", nframes, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (F.cap < 1 || F.cap > 65535 || Q.cap < 1 || Q.cap > m->maxFeatures || Q.cap > 65535) {
+        orbx_set_error("bad capacities (features %d, queries %d, matcher max_features %d)", F.cap, Q.cap, m->maxFeatures);
+        return ORBX_ERR_CAPACITY;
+    }
+    int rc = m->topk64.ensure((size_t)nframes * Q.cap * TOPK);
+    if (rc != ORBX_OK) return rc;
+    const int stride = m->maxFeatures;
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_area_topk, dim3((unsigned)((Q.cap + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, F, Q, m->topk64.p);
+    MLAUNCH_CHECK();
+    const size_t lds = (size_t)F.cap * 4 + (size_t)Q.cap * 4 + (size_t)Q.cap * 2 + 16;
+    if (lds > 160 * 1024) { orbx_set_error("capacities too large for the LDS tile"); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_area_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_area_greedy, dim3((unsigned)nframes), dim3(256), lds, m->stream, F, Q, max_dist, m->topk64.p, m->matches.p, m->dists.p, m->nmatches.p,
+                       stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = nframes; m->lastStride = stride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_area_search_greedy_device(orbx_matcher *m, const orbx_projection_frame *frame, const orbx_area_queries *q, int max_dist)
+{
+    if (!m || !frame || !q) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!frame->keypoints_un || !frame->descriptors || !frame->counts || !q->u || !q->v || !q->radius || !q->min_level || !q->max_level || !q->descriptors ||
+        !q->counts) {
+        orbx_set_error("NULL array in the area-search arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ProjFrameDev F = {frame->keypoints_un, frame->descriptors, frame->u_right, frame->occupied, frame->counts, frame->capacity,
+                      frame->min_x, frame->min_y, frame->grid_width_inv, frame->grid_height_inv};
+    AreaQueriesDev Q = {q->u, q->v, q->radius, q->min_level, q->max_level, q->active, q->descriptors, q->counts, q->capacity, q->window_min_x, q->window_min_y};
+    return area_launch(m, F, Q, frame->nframes, max_dist);
+}
+
+// host-array form for one frame: upload, run, download
+extern "C" int orbx_area_search_greedy(orbx_matcher *m, const orbx_projection_frame *fr, const orbx_area_queries *q, int max_dist, int32_t *assigned,
+                                       int32_t *dists, int32_t *nmatches)
+{
+    if (!m || !fr || !q || !assigned) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!fr->counts || !q->counts) { orbx_set_error("NULL counts"); return ORBX_ERR_ARG; }
+    const int n = fr->counts[0], mm = q->counts[0];
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < mm; i++) { assigned[i] = -1; if (dists) dists[i] = 256; }
+    if (n <= 0 || mm <= 0) return ORBX_OK;
+    if (mm > m->maxFeatures) { orbx_set_error("%d queries exceed the matcher's max_features %d", mm, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    if (!fr->keypoints_un || !fr->descriptors || !q->u || !q->v || !q->radius || !q->min_level || !q->max_level || !q->descriptors) {
+        orbx_set_error("NULL array in the area-search arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    // staging: frame side in pkp / hd[0] / pb[0]; query side in pf[1] (u, v, radius) / pi32[1] (min, max level) / pb[1] (descriptors, active)
+    if ((rc = m->pkp.ensure((size_t)n)) || (rc = m->hd[0].ensure((size_t)n * 32)) || (rc = m->pb[0].ensure((size_t)n)) || (rc = m->pi32[0].ensure(2)) ||
+        (rc = m->pf[1].ensure((size_t)mm * 3)) || (rc = m->pi32[1].ensure((size_t)mm * 2)) || (rc = m->pb[1].ensure((size_t)mm * 33)))
+        return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, fr->keypoints_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[0].p, fr->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    if (fr->occupied) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[0].p, fr->occupied, (size_t)n, hipMemcpyHostToDevice, st));
+    const int32_t cnt[2] = {n, mm};
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, q->u, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + mm, q->v, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 2 * (size_t)mm, q->radius, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p, q->min_level, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p + mm, q->max_level, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p, q->descriptors, (size_t)mm * 32, hipMemcpyHostToDevice, st));
+    if (q->active) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)mm * 32, q->active, (size_t)mm, hipMemcpyHostToDevice, st));
+    ProjFrameDev F = {m->pkp.p, m->hd[0].p, nullptr, fr->occupied ? m->pb[0].p : nullptr, m->pi32[0].p, n, fr->min_x, fr->min_y, fr->grid_width_inv,
+                      fr->grid_height_inv};
+    AreaQueriesDev Q = {m->pf[1].p, m->pf[1].p + mm, m->pf[1].p + 2 * (size_t)mm, m->pi32[1].p, m->pi32[1].p + mm,
+                        q->active ? m->pb[1].p + (size_t)mm * 32 : nullptr, m->pb[1].p, m->pi32[0].p + 1, mm, q->window_min_x, q->window_min_y};
+    if ((rc = area_launch(m, F, Q, 1, max_dist)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    ORBX_HIP_CHECK(hipMemcpy(assigned, m->matches.p, (size_t)mm * 4, hipMemcpyDeviceToHost));
+    if (dists) ORBX_HIP_CHECK(hipMemcpy(dists, m->dists.p, (size_t)mm * 4, hipMemcpyDeviceToHost));
+    if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
 static int proj_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjPointsDev &P, int nframes, const float *scale_factors, int nlevels, float th,
                        float nnratio)
 {

@@ -7,6 +7,8 @@
 //     int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)            src/ORBmatcher.cc:1913-1933
 //     int ORBmatcher::SearchByProjection(Frame&, const std::vector<MapPoint*>&, float)   src/ORBmatcher.cc:70-175
 //     int ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)              src/ORBmatcher.cc:1569-1728
+//     int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, std::vector<MapPoint*>&, int)   src/ORBmatcher.cc:388-513
+//     int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const std::set<MapPoint*>&, float, int)                         src/ORBmatcher.cc:1731-1864
 //     int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat, std::vector<std::pair<size_t,size_t> >&, bool)   src/ORBmatcher.cc:810-1017
 //     int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                                                src/ORBmatcher.cc:1020-1177
 //     int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, std::vector<MapPoint*>&)              src/ORBmatcher.cc:1179-1312
@@ -434,6 +436,160 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoin
         }
     }
     return nFound;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The two remaining projection searches: loop closing (LoopClosing::ComputeSim3 / CorrectLoop) and
+// relocalisation (Tracking::Relocalization).  Same split as Fuse: the reference's per-point preparation on the
+// host, one orbx_area_search_greedy call for the order-dependent search, the reference's bookkeeping after it.
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+struct AreaArrays {
+    std::vector<float> u, v, radius;
+    std::vector<int32_t> lo, hi, assigned, dist;
+    std::vector<uint8_t> active, desc;
+    explicit AreaArrays(size_t n) : u(n), v(n), radius(n), lo(n), hi(n), assigned(n, -1), dist(n, 256), active(n, 0), desc(n * 32, 0) {}
+};
+}  // namespace
+
+int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th)
+{
+    __atomic_add_fetch(&gSearchByProjectionCalls, 1, __ATOMIC_RELAXED);
+    const float &fx = pKF->fx;
+    const float &fy = pKF->fy;
+    const float &cx = pKF->cx;
+    const float &cy = pKF->cy;
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    std::set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPoint *>(NULL));
+    const int nPoints = (int)vpPoints.size(), N = pKF->N;
+    if (nPoints == 0 || N == 0) return 0;
+    AreaArrays A((size_t)nPoints);
+    for (int iMP = 0; iMP < nPoints; iMP++) {                                   // :405-452
+        MapPoint *pMP = vpPoints[(size_t)iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0) continue;
+        const float invz = 1 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz;
+        const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist = cv::norm(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist) continue;
+        int nPredictedLevel = pMP->PredictScale(dist, pKF);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        const cv::Mat dMP = pMP->GetDescriptor();
+        A.u[(size_t)iMP] = u; A.v[(size_t)iMP] = v; A.radius[(size_t)iMP] = radius;
+        A.lo[(size_t)iMP] = nPredictedLevel - 1; A.hi[(size_t)iMP] = nPredictedLevel;   // :469-470
+        A.active[(size_t)iMP] = 1;
+        memcpy(&A.desc[32 * (size_t)iMP], dMP.ptr<unsigned char>(), 32);
+    }
+    std::vector<uint8_t> blocked((size_t)N);
+    for (int i = 0; i < N; i++) blocked[(size_t)i] = vpMatched[(size_t)i] ? 1 : 0;                                              // :465-466
+    orbx_projection_frame kf = {(const orbx_keypoint *)&pKF->mvKeysUn[0], pKF->mDescriptors.data, 0, &blocked[0], &N, N, 1,
+                                Frame::mnMinX, Frame::mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv};
+    orbx_area_queries q = {&A.u[0], &A.v[0], &A.radius[0], &A.lo[0], &A.hi[0], &A.active[0], &A.desc[0], &nPoints, nPoints,
+                           (float)pKF->mnMinX, (float)pKF->mnMinY};
+    int32_t nm = 0;
+    if (orbx_area_search_greedy(Matcher(N > nPoints ? N : nPoints), &kf, &q, TH_LOW, &A.assigned[0], &A.dist[0], &nm) != ORBX_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbx): ") + orbx_last_error());
+    int nmatches = 0;
+    for (int iMP = 0; iMP < nPoints; iMP++)                                                                                     // :505-509
+        if (A.assigned[(size_t)iMP] >= 0) { vpMatched[(size_t)A.assigned[(size_t)iMP]] = vpPoints[(size_t)iMP]; nmatches++; }
+    return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist)
+{
+    __atomic_add_fetch(&gSearchByProjectionCalls, 1, __ATOMIC_RELAXED);
+    int nmatches = 0;
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat Ow = -Rcw.t() * tcw;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+    const float factor = HISTO_LENGTH / 360.0f;
+    const std::vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
+    const int nPoints = (int)vpMPs.size(), N = CurrentFrame.N;
+    if (nPoints == 0 || N == 0) return 0;
+    AreaArrays A((size_t)nPoints);
+    for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {                    // :1747-1790
+        MapPoint *pMP = vpMPs[i];
+        if (pMP) {
+            if (!pMP->isBad() && !sAlreadyFound.count(pMP)) {
+                cv::Mat x3Dw = pMP->GetWorldPos();
+                cv::Mat x3Dc = Rcw * x3Dw + tcw;
+                const float xc = x3Dc.at<float>(0);
+                const float yc = x3Dc.at<float>(1);
+                const float invzc = 1.0 / x3Dc.at<float>(2);
+                const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+                const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+                if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+                if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+                cv::Mat PO = x3Dw - Ow;
+                float dist3D = cv::norm(PO);
+                const float maxDistance = pMP->GetMaxDistanceInvariance();
+                const float minDistance = pMP->GetMinDistanceInvariance();
+                if (dist3D < minDistance || dist3D > maxDistance) continue;
+                int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+                const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
+                const cv::Mat dMP = pMP->GetDescriptor();
+                A.u[i] = u; A.v[i] = v; A.radius[i] = radius;
+                A.lo[i] = nPredictedLevel - 1; A.hi[i] = nPredictedLevel + 1;   // :1792
+                A.active[i] = 1;
+                memcpy(&A.desc[32 * i], dMP.ptr<unsigned char>(), 32);
+            }
+        }
+    }
+    std::vector<uint8_t> blocked((size_t)N);
+    for (int i = 0; i < N; i++) blocked[(size_t)i] = CurrentFrame.mvpMapPoints[(size_t)i] ? 1 : 0;                              // :1805-1806
+    orbx_projection_frame fr = {(const orbx_keypoint *)&CurrentFrame.mvKeysUn[0], CurrentFrame.mDescriptors.data, 0, &blocked[0], &N, N, 1,
+                                Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv};
+    orbx_area_queries q = {&A.u[0], &A.v[0], &A.radius[0], &A.lo[0], &A.hi[0], &A.active[0], &A.desc[0], &nPoints, nPoints, Frame::mnMinX, Frame::mnMinY};
+    int32_t nm = 0;
+    if (orbx_area_search_greedy(Matcher(N > nPoints ? N : nPoints), &fr, &q, ORBdist, &A.assigned[0], &A.dist[0], &nm) != ORBX_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbx): ") + orbx_last_error());
+    for (int i = 0; i < nPoints; i++) {                                         // :1819-1840, in the reference's order
+        const int bestIdx2 = A.assigned[(size_t)i];
+        if (bestIdx2 < 0) continue;
+        CurrentFrame.mvpMapPoints[(size_t)bestIdx2] = vpMPs[(size_t)i];
+        nmatches++;
+        if (mbCheckOrientation) {
+            float rot = pKF->mvKeysUn[(size_t)i].angle - CurrentFrame.mvKeysUn[(size_t)bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back(bestIdx2);
+        }
+    }
+    if (mbCheckOrientation) {                                                   // :1844-1861
+        int ind1 = -1;
+        int ind2 = -1;
+        int ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i != ind1 && i != ind2 && i != ind3) {
+                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                    CurrentFrame.mvpMapPoints[(size_t)rotHist[i][j]] = NULL;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    return nmatches;
 }
 
 // Tracking::SearchLocalPoints (src/Tracking.cc:1616): the MapPoints carry what Frame::isInFrustum

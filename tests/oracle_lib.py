@@ -634,3 +634,28 @@ def ref_search_by_sim3(kf1, pos1, Tcw1, kf2, pos2, Tcw2, pre12, s12, R12, t12, t
     lib.orbslam_search_by_sim3.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, cf, vp, vp, cf, vp]
     n = lib.orbslam_search_by_sim3(_p(k1), _p(d1), _p(p1), len(k1), _p(T1), _p(k2), _p(d2), _p(p2), len(k2), _p(T2), _p(pre), s12, _p(R), _p(t), th, _p(out))
     return n, out[:len(k1)]
+
+
+def area_search_greedy(orc, frame, queries, max_dist):
+    """Restatement of the greedy area search (oracle/match_oracle.cc:mo_area_search_greedy)."""
+    lib = orc.lib
+    k = np.ascontiguousarray(_kp7(frame["kps"]) if np.asarray(frame["kps"]).dtype.names else frame["kps"], np.float32)
+    n = len(k)
+    d = np.ascontiguousarray(frame["desc"], np.uint8)
+    blk = np.ascontiguousarray(frame["blocked"], np.uint8)
+    minx, miny = np.float32(frame.get("min_x", 0.0)), np.float32(frame.get("min_y", 0.0))
+    maxx, maxy = np.float32(frame.get("max_x", frame["width"])), np.float32(frame.get("max_y", frame["height"]))
+    gw, gh = np.float32(64) / (maxx - minx), np.float32(48) / (maxy - miny)
+    wx, wy = (np.float32(int(minx)), np.float32(int(miny))) if queries.get("window_int_bounds") else (minx, miny)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    qu, qv, qr = f32(queries["u"]), f32(queries["v"]), f32(queries["radius"])
+    m = len(qu)
+    lo, hi = np.ascontiguousarray(queries["min_level"], np.int32), np.ascontiguousarray(queries["max_level"], np.int32)
+    act = np.ascontiguousarray(queries["active"], np.uint8)
+    qd = np.ascontiguousarray(queries["desc"], np.uint8)
+    asg, dst = np.full(max(m, 1), -1, np.int32), np.full(max(m, 1), 256, np.int32)
+    vp, cf, ci = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+    lib.mo_area_search_greedy.argtypes = [vp, vp, vp, ci, cf, cf, cf, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp]
+    nm = lib.mo_area_search_greedy(_p(k), _p(d), _p(blk), n, minx, miny, wx, wy, gw, gh, _p(qu), _p(qv), _p(qr), _p(lo), _p(hi), _p(act), _p(qd), m, int(max_dist),
+                                   _p(asg), _p(dst))
+    return nm, asg[:m], dst[:m]

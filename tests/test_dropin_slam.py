@@ -240,6 +240,30 @@ def test_search_by_sim3_dropin_equals_reference(orbx, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("overload,seed", [(3, 71), (4, 72), (5, 73)])
+def test_remaining_search_by_projection_dropin_equals_reference(orbx, overload, seed):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (loop closing, 3) and SearchByProjection(CurrentFrame, pKF,
+    sAlreadyFound, th, ORBdist) (relocalisation; 4 with, 5 without the rotation histogram) on real objects."""
+    from test_area_search import _setup
+    from test_fuse import _sim3
+    orbx.load_library()
+    hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
+    hip.orbx_shim_search_by_projection_calls.restype = ctypes.c_ulong
+    before = hip.orbx_shim_search_by_projection_calls()
+    kf, Tt, sk, Ts, P, cdesc, holder, lst, rng = _setup(orbx, seed, 3 if overload == 3 else 4)
+    if overload == 4:
+        n, nc = len(kf["kps"]), len(P)
+        kf["kps"]["angle"][:] = 10.0                                  # a dominant rotation bin plus outliers: the pruning removes matches
+        sk["angle"] = np.where(rng.random(nc) < 0.8, 40.0, rng.uniform(0, 360, nc))
+    out = [oracle_lib.ref_fuse(overload, kf, Tt, _sim3(Tt), holder, np.ones(150, np.int32), sk, Ts, P, cdesc, np.full(len(P), 1, np.int32), lst, 8.0, False, lib=L)
+           for L in (ref, hip)]
+    assert hip.orbx_shim_search_by_projection_calls() - before == 1, "the HIP body was not the one linked"
+    want, got = out
+    assert got["nfused"] == want["nfused"] and (got["holder"] == want["holder"]).all()
+    assert want["nfused"] > 100
+
+
+@pytest.mark.gpu
 def test_search_for_triangulation_dropin_equals_reference(orbx):
     """ORBmatcher::SearchForTriangulation on two real KeyFrames (poses, mFeatVec, MapPoints, mvuRight): the shim
     computes the epipole with the reference's cv::Mat expressions and runs the matching on the device."""
