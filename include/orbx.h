@@ -391,6 +391,17 @@ int orbx_area_search_greedy_device(orbx_matcher *m, const orbx_projection_frame 
 int orbx_area_search_greedy(orbx_matcher *m, const orbx_projection_frame *frame_host, const orbx_area_queries *queries_host, int max_dist,
                             int32_t *assigned, int32_t *dists, int32_t *nmatches);
 
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
+ * (src/ORBmatcher.cc:515-654; Tracking::MonocularInitialization, src/Tracking.cc:944).  f1: mvKeysUn and
+ * descriptors of the reference frame; f2: the current frame with its grid statics; prev_matched_xy: vbPrevMatched
+ * (x, y per F1 feature, laid out like f1).  matches[f*stride + i1] = vnMatches12[i1], nmatches[f] = return value;
+ * the caller refreshes vbPrevMatched from the matches (:646-650). */
+int orbx_search_for_initialization_device(orbx_matcher *m, const orbx_feature_set *f1, const orbx_projection_frame *f2,
+                                          const float *prev_matched_xy, int window_size, float nn_ratio, int check_orientation);
+int orbx_search_for_initialization(orbx_matcher *m, const orbx_feature_set *f1_host, const orbx_projection_frame *f2_host,
+                                   const float *prev_matched_xy, int window_size, float nn_ratio, int check_orientation,
+                                   int32_t *matches12, int32_t *nmatches);
+
 int orbx_matcher_results_device(orbx_matcher *m, const int32_t **matches_dev, const int32_t **dists_dev,
                                 const int32_t **nmatches_dev, int *stride);
 int orbx_matcher_download(orbx_matcher *m, int npairs, int32_t *matches, int32_t *dists, int stride,

@@ -766,3 +766,83 @@ MO_API int mo_area_search_greedy(const float *kpUn, const uint8_t *desc, const u
     }
     return nmatches;
 }
+
+// ---------------------------------------------------------------------------------------
+// ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:515-654, on flat arrays (F2 grid filed with
+// minX/minY, Frame::GetFeaturesInArea(x, y, windowSize, 0, 0)).  prevXY is vbPrevMatched (not updated here).
+// ---------------------------------------------------------------------------------------
+MO_API int mo_search_for_initialization(const float *kp1, const uint8_t *desc1, int n1, const float *kp2, const uint8_t *desc2, int n2, float minX, float minY,
+                                        float gwInv, float ghInv, const float *prevXY, int windowSize, float nnratio, int checkOri, int32_t *matches12)
+{
+    std::vector<std::vector<int> > grid((size_t)GRID_COLS * GRID_ROWS);
+    for (int i = 0; i < n2; i++) {
+        const int px = (int)round((kp2[7 * (size_t)i] - minX) * gwInv), py = (int)round((kp2[7 * (size_t)i + 1] - minY) * ghInv);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+        grid[(size_t)px * GRID_ROWS + py].push_back(i);
+    }
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;
+    std::vector<int> matchedDistance((size_t)std::max(n2, 1), 2147483647), matches21((size_t)std::max(n2, 1), -1);
+    for (int i1 = 0; i1 < n1; i1++) {
+        const float *k1 = kp1 + 7 * (size_t)i1;
+        const int level1 = (int)k1[5];
+        if (level1 > 0) continue;
+        const float x = prevXY[2 * (size_t)i1], y = prevXY[2 * (size_t)i1 + 1], r = (float)windowSize;
+        const int cx0 = std::max(0, (int)floor((x - minX - r) * gwInv));
+        if (cx0 >= GRID_COLS) continue;
+        const int cx1 = std::min(GRID_COLS - 1, (int)ceil((x - minX + r) * gwInv));
+        if (cx1 < 0) continue;
+        const int cy0 = std::max(0, (int)floor((y - minY - r) * ghInv));
+        if (cy0 >= GRID_ROWS) continue;
+        const int cy1 = std::min(GRID_ROWS - 1, (int)ceil((y - minY + r) * ghInv));
+        if (cy1 < 0) continue;
+        int bestDist = 2147483647, bestDist2 = 2147483647, bestIdx2 = -1;
+        for (int ix = cx0; ix <= cx1; ix++)
+            for (int iy = cy0; iy <= cy1; iy++) {
+                const std::vector<int> &cell = grid[(size_t)ix * GRID_ROWS + iy];
+                for (size_t j = 0; j < cell.size(); j++) {
+                    const int i2 = cell[j];
+                    const float *k2 = kp2 + 7 * (size_t)i2;
+                    const int oct = (int)k2[5];
+                    if (oct < level1) continue;          // bCheckLevels is true here (maxLevel = 0 >= 0), src/Frame.cc:814-822
+                    if (oct > level1) continue;
+                    const float distx = k2[0] - x, disty = k2[1] - y;
+                    if (!(fabs(distx) < r && fabs(disty) < r)) continue;
+                    const int dist = descriptor_distance(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+                    if (matchedDistance[(size_t)i2] <= dist) continue;
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+            }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (matches21[(size_t)bestIdx2] >= 0) { matches12[matches21[(size_t)bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2;
+                matches21[(size_t)bestIdx2] = i1;
+                matchedDistance[(size_t)bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOri) {
+                    float rot = k1[3] - kp2[7 * (size_t)bestIdx2 + 3];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                const int idx1 = rotHist[i][j];
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    return nmatches;
+}

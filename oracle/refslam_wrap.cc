@@ -649,6 +649,24 @@ ORBSLAM_API int orbslam_search_by_sim3(const float *kps1, const uint8_t *desc1, 
     return n;
 }
 
+// ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:515-654, on two real Frames.  prevXY: vbPrevMatched in and out.
+ORBSLAM_API int orbslam_search_for_initialization(const float *kps1, const uint8_t *desc1, int n1, const float *kps2, const uint8_t *desc2, int n2,
+                                                  float *prevXY, int windowSize, float nnratio, int checkOri, int32_t *matches12)
+{
+    CallScope scope;
+    Camera cam = {500.f, 500.f, 320.f, 240.f, 40.f, 640, 480};
+    Frame F1, F2;
+    fill_frame(F1, kps1, desc1, n1, nullptr, cam, kDefaultScales, 8);
+    fill_frame(F2, kps2, desc2, n2, nullptr, cam, kDefaultScales, 8);
+    std::vector<cv::Point2f> prev((size_t)n1);
+    for (int i = 0; i < n1; i++) prev[(size_t)i] = cv::Point2f(prevXY[2 * i], prevXY[2 * i + 1]);
+    std::vector<int> m12;
+    ORBmatcher matcher(nnratio, checkOri != 0);
+    const int n = matcher.SearchForInitialization(F1, F2, prev, m12, windowSize);
+    for (int i = 0; i < n1; i++) { matches12[i] = m12[(size_t)i]; prevXY[2 * i] = prev[(size_t)i].x; prevXY[2 * i + 1] = prev[(size_t)i].y; }
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------
 // DBoW2 vocabulary: TemplatedVocabulary::loadFromTextFile + transform
 // (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1420, 1127-1262), i.e. what

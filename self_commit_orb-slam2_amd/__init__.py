@@ -499,6 +499,30 @@ class ORBmatcher:
         _check(self._L.orbx_area_search_greedy(self._h, ctypes.byref(fr), ctypes.byref(q), int(max_dist), _ptr(asg), _ptr(dst), ctypes.byref(nm)))
         return nm.value, asg[:m], dst[:m]
 
+    def SearchForInitialization(self, f1, f2, prev_matched, window_size=10):
+        """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (reference src/ORBmatcher.cc:515-654).
+        f1 / f2: dict(kps (mvKeysUn), desc); f2 also width, height[, min_x, ...]; prev_matched: (n1, 2) float array (updated copy returned).
+        Returns (nmatches, vnMatches12, vbPrevMatched)."""
+        fs1, keep1 = _host_set(f1["kps"], f1["desc"])
+        k2 = np.ascontiguousarray(f2["kps"], KEYPOINT_DTYPE)
+        d2 = np.ascontiguousarray(f2["desc"], np.uint8)
+        n1, n2 = len(f1["kps"]), len(k2)
+        minx, miny = np.float32(f2.get("min_x", 0.0)), np.float32(f2.get("min_y", 0.0))
+        maxx, maxy = np.float32(f2.get("max_x", f2["width"])), np.float32(f2.get("max_y", f2["height"]))
+        gw, gh = np.float32(64) / (maxx - minx), np.float32(48) / (maxy - miny)
+        cn = np.array([n2], np.int32)
+        fr = ProjectionFrame(k2.ctypes.data, d2.ctypes.data, None, None, cn.ctypes.data, max(n2, 1), 1, minx, miny, gw, gh)
+        prev = np.ascontiguousarray(prev_matched, np.float32).reshape(-1, 2).copy()
+        out = np.full(max(n1, 1), -1, np.int32)
+        nm = ctypes.c_int32()
+        self._L.orbx_search_for_initialization.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _check(self._L.orbx_search_for_initialization(self._h, ctypes.byref(fs1), ctypes.byref(fr), _ptr(prev), int(window_size), self.nnratio,
+                                                      1 if self.checkOri else 0, _ptr(out), ctypes.byref(nm)))
+        out = out[:n1]
+        ok = out >= 0
+        prev[ok, 0], prev[ok, 1] = k2["x"][out[ok]], k2["y"][out[ok]]          # :646-650
+        return nm.value, out, prev
+
     def SearchByProjection(self, frame, points, th, nnratio=None):
         """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (reference src/ORBmatcher.cc:70-175).
         frame: dict(kps (structured mvKeysUn), desc, u_right, occupied, scale_factors, width, height[, min_x, min_y]);

@@ -1702,6 +1702,182 @@ extern "C" int orbx_area_search_greedy(orbx_matcher *m, const orbx_projection_fr
     return ORBX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:515-654, Tracking::MonocularInitialization): level-0
+// features of F1 look for their best / second best F2 feature inside a window around vbPrevMatched; a candidate
+// is skipped when the F2 feature is already held at a distance <= its own (vMatchedDistance, :566), an accepted
+// match overrides the previous holder (:590-594).  That state makes every step depend on all earlier ones in a
+// way no candidate list can precompute, and the function runs once per frame only until the map is initialised:
+// one workgroup per frame pair walks the F1 features in order and evaluates each window with all 256 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_search_init(FeatDev A, ProjFrameDev F2, const float *__restrict__ prevXY, float window, float nnratio, int checkOri,
+                                                     int32_t *__restrict__ matches, int8_t *__restrict__ bins, int32_t *__restrict__ nmatches, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long sBest[4], sSecond[4];
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int sTotal;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n1 = min(A.counts[f], A.cap), n2 = min(F2.counts[f], F2.cap);
+    unsigned short *holderDist = (unsigned short *)smem;   // vMatchedDistance, 0xffff = INT_MAX
+    unsigned short *match21 = holderDist + F2.cap;         // vnMatches21, 0xffff = -1
+    const size_t abase = (size_t)f * A.cap, fbase = (size_t)f * F2.cap;
+    int32_t *m12 = matches + (size_t)f * stride;
+    int8_t *bin12 = bins + (size_t)f * stride;
+    for (int i = tid; i < n2; i += 256) { holderDist[i] = 0xffff; match21[i] = 0xffff; }
+    for (int i = tid; i < stride; i += 256) { m12[i] = -1; bin12[i] = -1; }
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) sTotal = 0;
+    __syncthreads();
+    const float factor = HISTO_LENGTH / 360.0f;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const orbx_keypoint k1 = A.kp[abase + i1];
+        if (k1.octave > 0) continue;                                                             // :535-537 (uniform)
+        const float x = prevXY[2 * (abase + i1)], y = prevXY[2 * (abase + i1) + 1], r = window;
+        // Frame::GetFeaturesInArea(x, y, r, 0, 0), src/Frame.cc:741-850
+        const int cx0 = max(0, (int)floorf((x - F2.minX - r) * F2.gwInv)), cx1 = min(GRID_COLS - 1, (int)ceilf((x - F2.minX + r) * F2.gwInv));
+        const int cy0 = max(0, (int)floorf((y - F2.minY - r) * F2.ghInv)), cy1 = min(GRID_ROWS - 1, (int)ceilf((y - F2.minY + r) * F2.ghInv));
+        if (cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0) continue;                // (uniform)
+        const unsigned long long *dp = (const unsigned long long *)(A.desc + (abase + i1) * 32);
+        const unsigned long long d[4] = {dp[0], dp[1], dp[2], dp[3]};
+        unsigned long long k0 = KEY64_EMPTY, kk1 = KEY64_EMPTY;
+        for (int i2 = tid; i2 < n2; i2 += 256) {
+            const orbx_keypoint k = F2.kp[fbase + i2];
+            const int cx = (int)roundf((k.x - F2.minX) * F2.gwInv), cy = (int)roundf((k.y - F2.minY) * F2.ghInv);
+            if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) continue;
+            if (k.octave < 0 || k.octave > 0) continue;                                          // minLevel = maxLevel = level1 = 0
+            const float distx = k.x - x, disty = k.y - y;
+            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+            const unsigned long long *db = (const unsigned long long *)(F2.desc + (fbase + i2) * 32);
+            const int dist = hamming256(d, db[0], db[1], db[2], db[3]);
+            if ((int)holderDist[i2] <= dist) continue;                                           // :566 (0xffff stands for INT_MAX)
+            const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)i2;
+            if (key < k0) { kk1 = k0; k0 = key; } else if (key < kk1) kk1 = key;
+        }
+        {
+            const unsigned long long b = wave_min_u64(k0);
+            if (k0 == b && b != KEY64_EMPTY) k0 = kk1;
+            const unsigned long long s2 = wave_min_u64(k0);
+            if (lane == 0) { sBest[wv] = b; sSecond[wv] = s2; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = KEY64_EMPTY, s2 = KEY64_EMPTY;
+            for (int w = 0; w < 4; w++) {
+                const unsigned long long c0 = sBest[w], c1 = sSecond[w];
+                if (c0 < b) { s2 = b < c1 ? b : c1; b = c0; s2 = s2 < c1 ? s2 : c1; }
+                else { s2 = c0 < s2 ? c0 : s2; }
+            }
+            if (b != KEY64_EMPTY) {
+                const int bestDist = (int)(b >> 32), bestIdx2 = (int)(b & 0xffff);
+                const float second = s2 == KEY64_EMPTY ? (float)2147483647 : (float)(int)(s2 >> 32);   // (float)INT_MAX, :576
+                if (bestDist <= TH_LOW && (float)bestDist < second * nnratio) {
+                    if (match21[bestIdx2] != 0xffff) { m12[match21[bestIdx2]] = -1; sTotal--; }      // :590-594
+                    m12[i1] = bestIdx2;
+                    match21[bestIdx2] = (unsigned short)i1;
+                    holderDist[bestIdx2] = (unsigned short)bestDist;
+                    sTotal++;
+                    if (checkOri) {
+                        float rot = k1.angle - F2.kp[fbase + bestIdx2].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        bin12[i1] = (int8_t)bin;
+                        hist[bin]++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (checkOri) {
+        // ComputeThreeMaxima over the counts of ALL accepted events (an overridden match stays in its bin, :606)
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            const int sN = hist[b];
+            if (sN > max1) { max3 = max2; max2 = max1; max1 = sN; ind3 = ind2; ind2 = ind1; ind1 = b; }
+            else if (sN > max2) { max3 = max2; max2 = sN; ind3 = ind2; ind2 = b; }
+            else if (sN > max3) { max3 = sN; ind3 = b; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        __threadfence_block();
+        int removed = 0;
+        for (int i = tid; i < n1; i += 256) {
+            const int b = bin12[i];
+            if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && m12[i] >= 0) { m12[i] = -1; removed++; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+        if (lane == 0 && removed) atomicSub(&sTotal, removed);
+    }
+    __syncthreads();
+    if (tid == 0) nmatches[f] = sTotal;
+}
+
+extern "C" int orbx_search_for_initialization_device(orbx_matcher *m, const orbx_feature_set *f1, const orbx_projection_frame *f2, const float *prev_matched_xy,
+                                                     int window_size, float nn_ratio, int check_orientation)
+{
+    if (!m || !f1 || !f2 || !prev_matched_xy) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!f1->keypoints || !f1->descriptors || !f1->counts || !f2->keypoints_un || !f2->descriptors || !f2->counts) { orbx_set_error("NULL feature arrays"); return ORBX_ERR_ARG; }
+    const int nframes = f2->nframes;
+    if (nframes < 1 || nframes > m->maxPairs || f1->nframes != nframes) { orbx_set_error("frame counts %d/%d outside 1..%d", f1->nframes, nframes, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (f1->capacity < 1 || f1->capacity > m->maxFeatures || f2->capacity < 1 || f2->capacity > 65534) { orbx_set_error("bad capacities (%d, %d)", f1->capacity, f2->capacity); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc = m->pb[0].ensure((size_t)m->maxPairs * m->maxFeatures);
+    if (rc != ORBX_OK) return rc;
+    FeatDev A = to_dev(f1);
+    ProjFrameDev F = {f2->keypoints_un, f2->descriptors, nullptr, nullptr, f2->counts, f2->capacity, f2->min_x, f2->min_y, f2->grid_width_inv, f2->grid_height_inv};
+    const int stride = m->maxFeatures;
+    const size_t lds = (size_t)f2->capacity * 4 + 16;
+    if (lds > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", f2->capacity); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_search_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_search_init, dim3((unsigned)nframes), dim3(256), lds, m->stream, A, F, prev_matched_xy, (float)window_size, nn_ratio, check_orientation,
+                       m->matches.p, (int8_t *)m->pb[0].p, m->nmatches.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = nframes; m->lastStride = stride;
+    return ORBX_OK;
+}
+
+static int stage_host(orbx_matcher *m, int side, const orbx_feature_set *h, orbx_feature_set *d);
+
+// host-array form for one frame pair: upload, run, download
+extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_feature_set *f1_host, const orbx_projection_frame *f2_host, const float *prev_matched_xy,
+                                              int window_size, float nn_ratio, int check_orientation, int32_t *matches12, int32_t *nmatches)
+{
+    if (!m || !f1_host || !f2_host || !matches12 || !nmatches) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!f1_host->counts || !f2_host->counts) { orbx_set_error("NULL counts"); return ORBX_ERR_ARG; }
+    const int n1 = f1_host->counts[0], n2 = f2_host->counts[0];
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 <= 0 || n2 <= 0) return ORBX_OK;
+    if (!prev_matched_xy || !f2_host->keypoints_un || !f2_host->descriptors) { orbx_set_error("NULL array"); return ORBX_ERR_ARG; }
+    if (n2 > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n2, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    orbx_feature_set d1;
+    int rc;
+    if ((rc = stage_host(m, 0, f1_host, &d1)) != ORBX_OK) return rc;
+    if ((rc = m->pkp.ensure((size_t)n2)) || (rc = m->hd[1].ensure((size_t)n2 * 32)) || (rc = m->pi32[0].ensure(2)) || (rc = m->pf[1].ensure((size_t)m->maxFeatures * 2)))
+        return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, f2_host->keypoints_un, (size_t)n2 * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[1].p, f2_host->descriptors, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, &n2, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, prev_matched_xy, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+    orbx_projection_frame d2 = *f2_host;
+    d2.keypoints_un = m->pkp.p; d2.descriptors = m->hd[1].p; d2.u_right = nullptr; d2.occupied = nullptr; d2.counts = m->pi32[0].p; d2.capacity = n2; d2.nframes = 1;
+    if ((rc = orbx_search_for_initialization_device(m, &d1, &d2, m->pf[1].p, window_size, nn_ratio, check_orientation)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    ORBX_HIP_CHECK(hipMemcpy(matches12, m->matches.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
 static int proj_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjPointsDev &P, int nframes, const float *scale_factors, int nlevels, float th,
                        float nnratio)
 {

@@ -12,6 +12,7 @@
 //     int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat, std::vector<std::pair<size_t,size_t> >&, bool)   src/ORBmatcher.cc:810-1017
 //     int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                                                src/ORBmatcher.cc:1020-1177
 //     int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, std::vector<MapPoint*>&)              src/ORBmatcher.cc:1179-1312
+//     int ORBmatcher::SearchForInitialization(Frame&, Frame&, std::vector<cv::Point2f>&, std::vector<int>&, int)               src/ORBmatcher.cc:515-654
 //     int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&, const float&, const cv::Mat&, const cv::Mat&, float)   src/ORBmatcher.cc:1314-1523
 // A maintainer deletes those three bodies from src/ORBmatcher.cc and adds this file to the
 // source list; the test build keeps src/ORBmatcher.cc untouched and weakens
@@ -32,6 +33,8 @@
 // bodies, not the reference's, were linked)
 static unsigned long gSearchByProjectionCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_by_projection_calls(void) { return gSearchByProjectionCalls; }
+static unsigned long gInitCalls = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_for_initialization_calls(void) { return gInitCalls; }
 static unsigned long gSim3Calls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_by_sim3_calls(void) { return gSim3Calls; }
 static unsigned long gFuseCalls = 0;
@@ -43,6 +46,46 @@ extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search
 
 namespace ORB_SLAM2
 {
+
+// ---------------------------------------------------------------------------------------------
+// With every search function below defined here, src/ORBmatcher.cc leaves the build entirely; what remains
+// of it are the constants, the constructor and three small helpers (src/ORBmatcher.cc:49-58, 178-227, 1866-1908).
+// ---------------------------------------------------------------------------------------------
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+float ORBmatcher::RadiusByViewingCos(const float &viewCos) { return viewCos > 0.998 ? 2.5 : 4.0; }
+
+bool ORBmatcher::CheckDistEpipolarLine(const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const cv::Mat &F12, const KeyFrame *pKF2)
+{
+    // the epipolar line of kp1 in the second image, l = x1' F12 = [a b c], and the squared distance of kp2 to it
+    const float a = kp1.pt.x * F12.at<float>(0, 0) + kp1.pt.y * F12.at<float>(1, 0) + F12.at<float>(2, 0);
+    const float b = kp1.pt.x * F12.at<float>(0, 1) + kp1.pt.y * F12.at<float>(1, 1) + F12.at<float>(2, 1);
+    const float c = kp1.pt.x * F12.at<float>(0, 2) + kp1.pt.y * F12.at<float>(1, 2) + F12.at<float>(2, 2);
+    const float num = a * kp2.pt.x + b * kp2.pt.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * pKF2->mvLevelSigma2[kp2.octave];
+}
+
+void ORBmatcher::ComputeThreeMaxima(std::vector<int> *histo, const int L, int &ind1, int &ind2, int &ind3)
+{
+    int best[3] = {0, 0, 0};
+    int *ind[3] = {&ind1, &ind2, &ind3};
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        int slot = s > best[0] ? 0 : (s > best[1] ? 1 : (s > best[2] ? 2 : 3));
+        for (int k = 2; k > slot; k--) { best[k] = best[k - 1]; *ind[k] = *ind[k - 1]; }
+        if (slot < 3) { best[slot] = s; *ind[slot] = i; }
+    }
+    if (best[1] < 0.1f * (float)best[0]) { ind2 = -1; ind3 = -1; }
+    else if (best[2] < 0.1f * (float)best[0]) ind3 = -1;
+}
+
 
 static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint must be the 28-byte layout of orbx_keypoint");
 
@@ -589,6 +632,28 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
             }
         }
     }
+    return nmatches;
+}
+
+// Tracking::MonocularInitialization (src/Tracking.cc:944): the whole order-dependent search runs on the device.
+int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize)
+{
+    __atomic_add_fetch(&gInitCalls, 1, __ATOMIC_RELAXED);
+    const int N1 = (int)F1.mvKeysUn.size(), N2 = (int)F2.mvKeysUn.size();
+    vnMatches12 = std::vector<int>((size_t)N1, -1);                              // :518
+    if (N1 == 0 || N2 == 0) return 0;
+    std::vector<float> prev((size_t)N1 * 2);
+    for (int i = 0; i < N1; i++) { prev[2 * (size_t)i] = vbPrevMatched[(size_t)i].x; prev[2 * (size_t)i + 1] = vbPrevMatched[(size_t)i].y; }
+    orbx_feature_set f1 = {(const orbx_keypoint *)&F1.mvKeysUn[0], F1.mDescriptors.data, &N1, 0, 0, N1, 1};
+    orbx_projection_frame f2 = {(const orbx_keypoint *)&F2.mvKeysUn[0], F2.mDescriptors.data, 0, 0, &N2, N2, 1,
+                                Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv};
+    std::vector<int32_t> match((size_t)N1);
+    int32_t nmatches = 0;
+    if (orbx_search_for_initialization(Matcher(N1 > N2 ? N1 : N2), &f1, &f2, &prev[0], windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, &match[0], &nmatches) != ORBX_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchForInitialization (orbx): ") + orbx_last_error());
+    for (int i1 = 0; i1 < N1; i1++) vnMatches12[(size_t)i1] = match[(size_t)i1];
+    for (size_t i1 = 0, iend1 = vnMatches12.size(); i1 < iend1; i1++)           // :646-650
+        if (vnMatches12[i1] >= 0) vbPrevMatched[i1] = F2.mvKeysUn[(size_t)vnMatches12[i1]].pt;
     return nmatches;
 }
 

@@ -659,3 +659,29 @@ def area_search_greedy(orc, frame, queries, max_dist):
     nm = lib.mo_area_search_greedy(_p(k), _p(d), _p(blk), n, minx, miny, wx, wy, gw, gh, _p(qu), _p(qv), _p(qr), _p(lo), _p(hi), _p(act), _p(qd), m, int(max_dist),
                                    _p(asg), _p(dst))
     return nm, asg[:m], dst[:m]
+
+
+def search_for_initialization(orc, f1, f2, prev, window, nnratio, check_ori):
+    """Restatement of ORBmatcher::SearchForInitialization (oracle/match_oracle.cc); bounds 0..640 x 0..480."""
+    lib = orc.lib
+    k1, k2 = np.ascontiguousarray(_kp7(f1["kps"]), np.float32), np.ascontiguousarray(_kp7(f2["kps"]), np.float32)
+    d1, d2 = np.ascontiguousarray(f1["desc"], np.uint8), np.ascontiguousarray(f2["desc"], np.uint8)
+    prev = np.ascontiguousarray(prev, np.float32).reshape(-1, 2)
+    out = np.full(max(len(k1), 1), -1, np.int32)
+    vp, cf, ci = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+    lib.mo_search_for_initialization.argtypes = [vp, vp, ci, vp, vp, ci, cf, cf, cf, cf, vp, ci, cf, ci, vp]
+    n = lib.mo_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), 0.0, 0.0, np.float32(64) / np.float32(640), np.float32(48) / np.float32(480),
+                                         _p(prev), window, nnratio, 1 if check_ori else 0, _p(out))
+    return n, out[:len(k1)]
+
+
+def ref_search_for_initialization(f1, f2, prev, window, nnratio, check_ori, lib=None):
+    lib = lib or slam_lib()
+    k1, k2 = np.ascontiguousarray(_kp7(f1["kps"]), np.float32), np.ascontiguousarray(_kp7(f2["kps"]), np.float32)
+    d1, d2 = np.ascontiguousarray(f1["desc"], np.uint8), np.ascontiguousarray(f2["desc"], np.uint8)
+    prev = np.ascontiguousarray(prev, np.float32).reshape(-1, 2).copy()
+    out = np.full(max(len(k1), 1), -1, np.int32)
+    vp, cf, ci = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+    lib.orbslam_search_for_initialization.argtypes = [vp, vp, ci, vp, vp, ci, vp, ci, cf, ci, vp]
+    n = lib.orbslam_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(prev), window, nnratio, 1 if check_ori else 0, _p(out))
+    return n, out[:len(k1)], prev
