@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Measured numbers for the BASELINE.json configs that are not bench.py's headline line:
   config 2  batch of 256 synthetic 640x480 frames, extract only
+  config 2b the same batch through the device-resident tracking front end (undistort/grid, BoW transform, SearchByBoW in nodes)
   config 3  KITTI-shaped stereo 1241x376, 2000 features: extract L+R + complete ComputeStereoMatches,
             and + brute-force SearchByBoW L<->R
   config 5  LocalBundleAdjustment on the synthetic 50-KF / 5000-point window (GPU vs the CPU oracle)
@@ -37,6 +38,41 @@ def config2(B=256, W=640, H=480, nf=1000, parts=2):
     devs = [e.upload(frames[k * Bs:(k + 1) * Bs]) for k, e in enumerate(exts)]
     dt = timed(lambda: [e.run_device(*d) for e, d in zip(exts, devs)], lambda: [e.sync() for e in exts], 20)
     return {"config": "2: 256 x 640x480 extract only", "frames_per_s": round(B / dt, 1), "ms_per_batch": round(dt * 1e3, 3)}
+
+
+def config2b(B=256, W=640, H=480, nf=1000, parts=2):
+    """The tracking front end, device resident: extract -> UndistortKeyPoints + AssignFeaturesToGrid (TUM1 camera) ->
+    DBoW2 transform (synthetic k=10, L=4 vocabulary, levelsup=2: 100 FeatureVector nodes) -> SearchByBoW(KeyFrame, Frame)
+    of consecutive frames inside their vocabulary nodes.  No host round trip between the stages."""
+    Bs = B // parts
+    voc_np = orbx.voc_synth.make_vocabulary(10, 4, 7, ragged=False)
+    frames = orbx.synth_sequence(1, B, W, H)
+    exts, ops, vocs, mts, devs, grids = [], [], [], [], [], []
+    for k in range(parts):
+        e = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=Bs)
+        o = orbx.FrameOps(517.306408, 516.469215, 318.643040, 255.313989, [0.262383, -0.953104, -0.005358, 0.002628, 1.163314])
+        exts.append(e); ops.append(o); vocs.append(orbx.Vocabulary(voc_np))
+        mts.append(orbx.ORBmatcher(0.7, True, max_features=e.capacity, max_pairs=Bs))
+        devs.append(e.upload(frames[k * Bs:(k + 1) * Bs]))
+        grids.append(orbx.FrameGrid.from_bounds(o.ComputeImageBounds(W, H)))
+    pa = np.arange(Bs, dtype=np.int32)
+    pb = (pa + 1) % Bs
+
+    def step():
+        for e, o, v, m, d, g in zip(exts, ops, vocs, mts, devs, grids):
+            e.run_device(*d)
+            o.finish_device(e, g)
+            v.transform_device(e, 2)
+            kd, dd, cd, cap = e.results_device()
+            ku, _ = o.keypoints_un_device()
+            nd, _ = v.groups_device()
+            fs = orbx.FeatureSet(ku.value, dd.value, cd.value, nd.value, None, cap, Bs)
+            m.search_by_bow_device(fs, fs, pa, pb, mode=0, after=e)
+
+    dt = timed(step, lambda: [x.sync() for x in exts + mts], 20)
+    _, _, nm = mts[0].download(Bs)
+    return {"config": "2b: 256 x 640x480 extract + undistort/grid + BoW transform (k=10,L=4) + SearchByBoW in vocabulary nodes",
+            "frames_per_s": round(B / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "matches_per_pair": round(float(np.mean(nm)), 1)}
 
 
 def config3(pairs=64, W=1241, H=376, nf=2000, bf=386.1448):
@@ -88,5 +124,5 @@ def config5():
 
 
 if __name__ == "__main__":
-    for fn in (config2, config3, config5):
+    for fn in (config2, config2b, config3, config5):
         print(json.dumps(fn()), flush=True)
