@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "liborbx.so"
-HIP_SOURCES = ["orbx_kernels.hip", "orbx_extractor.hip", "orbx_match.hip", "orbx_lba.hip", "orbx_bow.hip", "orbx_frame.hip", "orbx_synth.cc"]
+HIP_SOURCES = ["orbx_kernels.hip", "orbx_extractor.hip", "orbx_match.hip", "orbx_match_proj.hip", "orbx_lba.hip", "orbx_bow.hip", "orbx_frame.hip", "orbx_synth.cc"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
              "-Wall", "-Wno-unused-function"]
 

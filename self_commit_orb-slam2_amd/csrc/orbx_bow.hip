@@ -54,35 +54,20 @@ __global__ __launch_bounds__(256) void k_bow_transform(const VocNode *__restrict
     node[o] = w > 0 ? nid : -1;   // features whose word has weight 0 are not filed in the FeatureVector (:1160-1166)
 }
 
-template <typename T> struct VBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    int ensure(size_t count)
-    {
-        if (count <= n) return ORBX_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
-        ORBX_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
-        n = count;
-        return ORBX_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
-
 }  // namespace
 
 struct orbx_vocabulary {
     int device = 0, k = 0, L = 0, numNodes = 0, numWords = 0;
     hipStream_t stream = nullptr;   // host-array form only; the device form runs on the extractor's stream
-    VBuf<VocNode> nodes;
-    VBuf<int32_t> childList;
-    VBuf<uint4> childDesc;
-    VBuf<double> nodeWeight;
+    OrbxDevBuf<VocNode> nodes;
+    OrbxDevBuf<int32_t> childList;
+    OrbxDevBuf<uint4> childDesc;
+    OrbxDevBuf<double> nodeWeight;
     // results, double buffered in lockstep with the extractor's result buffers
-    VBuf<int32_t> word[2], node[2];
-    VBuf<double> weight[2];
+    OrbxDevBuf<int32_t> word[2], node[2];
+    OrbxDevBuf<double> weight[2];
     int cur = 0, lastBatch = 0, lastCap = 0;
-    VBuf<uint8_t> hostDesc;
+    OrbxDevBuf<uint8_t> hostDesc;
 };
 
 extern "C" int orbx_vocabulary_create(int device, int k, int L, int num_nodes, const int32_t *parent, const uint8_t *is_leaf, const uint8_t *descriptors,

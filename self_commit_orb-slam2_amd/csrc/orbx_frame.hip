@@ -128,21 +128,6 @@ __global__ __launch_bounds__(256) void k_frame_finish(CamDev c, orbx_frame_grid 
     for (int t = tid; t < total; t += 256) gi[t] = sorted[t];
 }
 
-template <typename T> struct FBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    int ensure(size_t count)
-    {
-        if (count <= n) return ORBX_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
-        ORBX_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
-        n = count;
-        return ORBX_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
-
 }  // namespace
 
 struct orbx_frame_ops {
@@ -150,12 +135,12 @@ struct orbx_frame_ops {
     hipStream_t stream = nullptr;   // host-array forms and the corner pass; the device form runs on the extractor's stream
     CamDev cam;
     // results, double buffered in lockstep with the extractor's result buffers
-    FBuf<orbx_keypoint> kpUn[2];
-    FBuf<int32_t> gridOff[2], gridIdx[2];
+    OrbxDevBuf<orbx_keypoint> kpUn[2];
+    OrbxDevBuf<int32_t> gridOff[2], gridIdx[2];
     int cur = 0, lastBatch = 0, lastCap = 0;
-    FBuf<orbx_keypoint> hostKp;
-    FBuf<int32_t> hostCount;
-    FBuf<float> corners;
+    OrbxDevBuf<orbx_keypoint> hostKp;
+    OrbxDevBuf<int32_t> hostCount;
+    OrbxDevBuf<float> corners;
 };
 
 extern "C" int orbx_frame_ops_create(int device, const orbx_camera *cam, orbx_frame_ops **out)

@@ -103,6 +103,22 @@ hipStream_t orbx_extractor_stream_internal(orbx_extractor *h);
 void orbx_extractor_set_consumer_event_internal(orbx_extractor *h, hipEvent_t ev);
 
 
+/* Grow-only device array owned by a handle (hipMalloc on demand, never shrinks, released by the handle's destroy). */
+template <typename T> struct OrbxDevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n) return ORBX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        ORBX_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+        return ORBX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
 /* Device view of the LAST batch of an extractor: results + the unblurred pyramid (what the
  * reference keeps in ORBextractor::mvImagePyramid, read by Frame::ComputeStereoMatches). */
 struct OrbxLastBatchView {

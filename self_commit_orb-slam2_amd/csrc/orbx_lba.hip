@@ -1059,21 +1059,6 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
     }
 }
 
-template <typename T> struct LBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    int ensure(size_t count)
-    {
-        if (count <= n) return ORBX_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
-        ORBX_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
-        n = count;
-        return ORBX_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
-
 }  // namespace
 
 struct orbx_lba {
@@ -1082,11 +1067,11 @@ struct orbx_lba {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     double flops = 0;
-    LBuf<DPose> pose, poseBak;
-    LBuf<double> pt, ptBak, intr, obs, info, err, rchi, edgeBlk, Hpp, bp, Hll, bl, Dinv, S, bs, xp, xl, red;
-    LBuf<double> Lmat, ywork, ysol;   // multi-workgroup Cholesky: the factor and the two halves of the right-hand side
-    LBuf<int> ep, ek, ptStart, ptEdges, kfStart, kfEdges, poseIdx, ptIdx, okFlag;
-    LBuf<uint8_t> stereo, active;
+    OrbxDevBuf<DPose> pose, poseBak;
+    OrbxDevBuf<double> pt, ptBak, intr, obs, info, err, rchi, edgeBlk, Hpp, bp, Hll, bl, Dinv, S, bs, xp, xl, red;
+    OrbxDevBuf<double> Lmat, ywork, ysol;   // multi-workgroup Cholesky: the factor and the two halves of the right-hand side
+    OrbxDevBuf<int> ep, ek, ptStart, ptEdges, kfStart, kfEdges, poseIdx, ptIdx, okFlag;
+    OrbxDevBuf<uint8_t> stereo, active;
 };
 
 extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, int max_edges, orbx_lba **out)
@@ -1431,10 +1416,10 @@ extern "C" int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *p, const vola
 struct orbx_pose_optimizer {
     int device = 0, maxFrames = 0, maxFeatures = 0;
     hipStream_t stream = nullptr;
-    LBuf<float> pose0, cam, Xw, obs, invS2, poseOut;
-    LBuf<int32_t> counts, ret;
-    LBuf<uint8_t> outlier;
-    LBuf<double> err, stats;
+    OrbxDevBuf<float> pose0, cam, Xw, obs, invS2, poseOut;
+    OrbxDevBuf<int32_t> counts, ret;
+    OrbxDevBuf<uint8_t> outlier;
+    OrbxDevBuf<double> err, stats;
 };
 
 extern "C" int orbx_pose_optimizer_create(int device, int max_frames, int max_features, orbx_pose_optimizer **out)

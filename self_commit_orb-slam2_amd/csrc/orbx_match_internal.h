@@ -1,0 +1,95 @@
+// orbx_match_internal.h -- shared by orbx_match.hip (SearchByBoW, SearchForTriangulation, stereo) and orbx_match_proj.hip
+// (the projection / area searches): constants, device-side views and helpers, and the matcher handle.
+#ifndef ORBX_MATCH_INTERNAL_H
+#define ORBX_MATCH_INTERNAL_H
+
+#include "orbx_internal.h"
+
+#define TH_HIGH 100       /* src/ORBmatcher.cc:49 */
+#define TH_LOW 50         /* :50 */
+#define HISTO_LENGTH 30   /* :51 */
+#define KEY_EMPTY 0xffffffffu
+#define TOPK 8            /* candidates kept per KeyFrame feature; the exact rescan handles overflow */
+#define MATCH_PROF_RING 64
+
+#define KEY64_EMPTY 0xffffffffffffffffull
+#define GRID_COLS 64   /* include/Frame.h:60 */
+#define GRID_ROWS 48   /* include/Frame.h:55 */
+
+struct FeatDev {   // orbx_feature_set with device pointers
+    const orbx_keypoint *kp;
+    const uint8_t *desc;
+    const int32_t *counts;
+    const int32_t *groups;
+    const uint8_t *valid;
+    int cap;
+};
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(v, o); v = u < v ? u : v; }
+    return v;
+}
+
+__device__ __forceinline__ int hamming256(const unsigned long long a[4], unsigned long long b0, unsigned long long b1, unsigned long long b2,
+                                          unsigned long long b3)
+{
+    return __popcll(a[0] ^ b0) + __popcll(a[1] ^ b1) + __popcll(a[2] ^ b2) + __popcll(a[3] ^ b3);
+}
+
+struct ProjFrameDev { const orbx_keypoint *kp; const uint8_t *desc; const float *uRight; const uint8_t *occupied; const int32_t *counts; int cap;
+                      float minX, minY, gwInv, ghInv; };
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long u = __shfl_xor(v, o); v = u < v ? u : v; }
+    return v;
+}
+
+struct orbx_matcher {
+    int device = 0, maxFeatures = 0, maxPairs = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t evDep = nullptr, evDone[2] = {nullptr, nullptr};
+    int doneSlot = 0;
+    hipEvent_t ev0[MATCH_PROF_RING] = {}, ev1[MATCH_PROF_RING] = {};   // one pair per *_device call (ring)
+    hipEvent_t evMid[MATCH_PROF_RING] = {};                             // SearchByBoW: between the distance kernel and the greedy replay
+    bool midValid[MATCH_PROF_RING] = {};
+    float lastDistanceMs = 0.f, lastReplayMs = 0.f;
+    int profCount = 0;
+    OrbxDevBuf<int32_t> pairsA, pairsB, order, matches, dists, nmatches;
+    OrbxDevBuf<uint32_t> topk;
+    OrbxDevBuf<float> scales, uright, depth, pf[2];          // pf: projection staging (floats)
+    OrbxDevBuf<unsigned long long> topk64;
+    OrbxDevBuf<uint8_t> pb[2];
+    OrbxDevBuf<int32_t> pi32[2];
+    OrbxDevBuf<orbx_keypoint> pkp;
+    OrbxDevBuf<int32_t> sad;
+    hipEvent_t evDep2 = nullptr, evPyr[2] = {nullptr, nullptr};
+    int lastStereoPairs = 0;
+    // staging for the host-array convenience calls
+    OrbxDevBuf<orbx_keypoint> hk[2];
+    OrbxDevBuf<uint8_t> hd[2], hv[2];
+    OrbxDevBuf<int32_t> hc[2], hg[2];
+    OrbxDevBuf<uint8_t> hs[2];                               // SearchForTriangulation: stereo flags (host form)
+    OrbxDevBuf<float> triGeom;                               // F12 + epipole per pair
+    int lastPairs = 0, lastStride = 0;
+};
+
+#define MLAUNCH_CHECK()                                                                                              \
+    do {                                                                                                             \
+        hipError_t e_ = hipGetLastError();                                                                           \
+        if (e_ != hipSuccess) { orbx_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); return ORBX_ERR_HIP; } \
+    } while (0)
+
+// host helpers defined in orbx_match.hip
+namespace orbx_match {
+int prep_pairs(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b, const int32_t *pa, const int32_t *pb, int npairs, orbx_extractor *after);
+int chain_back(orbx_matcher *m, orbx_extractor *after);
+FeatDev to_dev(const orbx_feature_set *s);
+/* stage one frame of host features into the matcher's staging buffers (side 0 / 1) */
+int stage_host(orbx_matcher *m, int side, const orbx_feature_set *h, orbx_feature_set *d);
+}  // namespace orbx_match
+
+#endif

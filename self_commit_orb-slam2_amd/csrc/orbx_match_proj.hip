@@ -1,0 +1,1125 @@
+// orbx_match_proj.hip -- the projection-guided matchers of ORBmatcher on gfx950: SearchByProjection (all four overloads),
+// Fuse (both), SearchBySim3 (through the Fuse search) and SearchForInitialization.  A feature's grid cell and the
+// GetFeaturesInArea window are evaluated arithmetically per (query, feature); candidate order = 64-bit key
+// distance || cell column || cell row || index.  See orbx_match.hip for SearchByBoW / SearchForTriangulation / stereo.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "orbx_match_internal.h"
+
+using namespace orbx_match;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
+// (src/ORBmatcher.cc:70-175), the matcher of Tracking::SearchLocalPoints, with
+// Frame::GetFeaturesInArea (src/Frame.cc:741-850) and the 64x48 feature grid (:461-491, 853-877).
+// The grid is never materialised: a feature's cell is round((pt - min) * inv) and "in the search
+// window" is the same cell-range + |dx|,|dy| < r test the reference applies, evaluated per
+// (map point, feature); the reference's candidate order (cell column, cell row, feature index)
+// becomes the low half of a 64-bit key whose high half is the Hamming distance.
+// k_proj_topk:   wave per map point, lanes over the frame's features -> its 8 smallest keys.
+// k_proj_greedy: workgroup per frame; wave 0 replays the map points in order (a feature taken by a
+//                point with observations blocks later points, :110-112), 8 points per 512-byte list
+//                fetch, exact wave-parallel rescan when a full list has fewer than two free entries.
+// ---------------------------------------------------------------------------------------------
+struct ProjPointsDev { const float *px, *py, *pxr; const int32_t *level; const float *viewCos; const uint8_t *inView, *hasObs, *desc; const int32_t *counts; int cap; };
+
+// gate + key of feature idx for one map point; KEY64_EMPTY when the feature is not a candidate
+struct ProjQuery { float x, y, rr, xr; int minLevel, maxLevel, cx0, cx1, cy0, cy1; bool any; unsigned long long d[4]; };
+
+__device__ __forceinline__ ProjQuery proj_query(const ProjFrameDev &F, const ProjPointsDev &P, size_t pi, const float *scaleFactors, float th)
+{
+    ProjQuery q;
+    const int lvl = P.level[pi];
+    float r = (double)P.viewCos[pi] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos, :178-185
+    if (th != 1.0f) r *= th;
+    q.x = P.px[pi]; q.y = P.py[pi]; q.xr = P.pxr[pi];
+    q.rr = r * scaleFactors[lvl];
+    q.minLevel = lvl - 1; q.maxLevel = lvl;
+    const int nMinCellX = max(0, (int)floorf((q.x - F.minX - q.rr) * F.gwInv)), nMaxCellX = min(GRID_COLS - 1, (int)ceilf((q.x - F.minX + q.rr) * F.gwInv));
+    const int nMinCellY = max(0, (int)floorf((q.y - F.minY - q.rr) * F.ghInv)), nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((q.y - F.minY + q.rr) * F.ghInv));
+    q.any = !(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0);
+    q.cx0 = nMinCellX; q.cx1 = nMaxCellX; q.cy0 = nMinCellY; q.cy1 = nMaxCellY;
+    const unsigned long long *dp = (const unsigned long long *)(P.desc + pi * 32);
+    q.d[0] = dp[0]; q.d[1] = dp[1]; q.d[2] = dp[2]; q.d[3] = dp[3];
+    return q;
+}
+
+__device__ __forceinline__ unsigned long long proj_key(const ProjFrameDev &F, size_t fbase, int idx, const ProjQuery &q)
+{
+    const orbx_keypoint k = F.kp[fbase + idx];
+    const int cx = (int)roundf((k.x - F.minX) * F.gwInv), cy = (int)roundf((k.y - F.minY) * F.ghInv);   // PosInGrid, :866-867
+    if (cx < q.cx0 || cx > q.cx1 || cy < q.cy0 || cy > q.cy1) return KEY64_EMPTY;   // (also: feature outside the grid)
+    if (k.octave < q.minLevel || (q.maxLevel >= 0 && k.octave > q.maxLevel)) return KEY64_EMPTY;   // GetFeaturesInArea bCheckLevels, :814-822
+    const float distx = k.x - q.x, disty = k.y - q.y;
+    if (!(fabsf(distx) < q.rr && fabsf(disty) < q.rr)) return KEY64_EMPTY;
+    const float ur = F.uRight[fbase + idx];
+    if (ur > 0) { const float er = fabsf(q.xr - ur); if (er > q.rr) return KEY64_EMPTY; }
+    const unsigned long long *db = (const unsigned long long *)(F.desc + (fbase + idx) * 32);
+    const int dist = hamming256(q.d, db[0], db[1], db[2], db[3]);
+    return ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)idx;
+}
+
+__global__ __launch_bounds__(256) void k_proj_topk(ProjFrameDev F, ProjPointsDev P, const float *__restrict__ scaleFactors, float th,
+                                                   unsigned long long *__restrict__ topk)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
+    if (i >= m) return;
+    const size_t pi = (size_t)f * P.cap + i, fbase = (size_t)f * F.cap;
+    unsigned long long *out = topk + pi * TOPK;
+    if (!P.inView[pi]) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
+    const ProjQuery q = proj_query(F, P, pi, scaleFactors, th);
+    unsigned long long kk[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; t++) kk[t] = KEY64_EMPTY;
+    if (q.any)
+        for (int idx = lane; idx < n; idx += 64) {
+            const unsigned long long key = proj_key(F, fbase, idx, q);
+            if (key < kk[TOPK - 1]) {
+                kk[TOPK - 1] = key;
+#pragma unroll
+                for (int t = TOPK - 1; t > 0; t--)
+                    if (kk[t] < kk[t - 1]) { const unsigned long long v = kk[t - 1]; kk[t - 1] = kk[t]; kk[t] = v; }
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < TOPK; k++) {
+        const unsigned long long mn = wave_min_u64(kk[0]);
+        if (kk[0] == mn && mn != KEY64_EMPTY) {   // keys are unique: exactly one lane pops its head
+#pragma unroll
+            for (int t = 0; t < TOPK - 1; t++) kk[t] = kk[t + 1];
+            kk[TOPK - 1] = KEY64_EMPTY;
+        }
+        if (lane == 0) out[k] = mn;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_proj_greedy(ProjFrameDev F, ProjPointsDev P, const float *__restrict__ scaleFactors, float th, float nnratio,
+                                                     const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
+                                                     int32_t *__restrict__ nmatches, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
+    unsigned char *occ = smem;                  // [cap] 1 = the feature holds a MapPoint with observations
+    unsigned char *oct = smem + F.cap;          // [cap] octave of the feature
+    const size_t fbase = (size_t)f * F.cap, pbase = (size_t)f * P.cap;
+    int32_t *aout = assigned + (size_t)f * stride;
+    for (int i = tid; i < stride; i += 256) aout[i] = -1;
+    for (int i = tid; i < n; i += 256) { occ[i] = F.occupied ? F.occupied[fbase + i] : 0; oct[i] = (unsigned char)F.kp[fbase + i].octave; }
+    __syncthreads();
+    if (tid >= 64) return;
+    int total = 0;
+    const unsigned long long *tk = topk + pbase * TOPK;
+    unsigned long long nextKeys = (0 < m) ? tk[min((size_t)lane, (size_t)m * TOPK - 1)] : KEY64_EMPTY;
+    for (int i0 = 0; i0 < m; i0 += 8) {
+        const unsigned long long keys = nextKeys;   // lists of map points i0 .. i0+7, lane = 8*(i-i0) + rank
+        {
+            const size_t nx = (size_t)(i0 + 8) * TOPK + lane;
+            nextKeys = (i0 + 8 < m) ? tk[min(nx, (size_t)m * TOPK - 1)] : KEY64_EMPTY;   // in flight while these 8 points are replayed
+        }
+        for (int j = 0; j < 8 && i0 + j < m; j++) {
+            const int i = i0 + j;
+            const size_t pi = pbase + i;
+            if (!P.inView[pi]) continue;
+            const unsigned long long key = __shfl(keys, 8 * j + (lane & 7));   // lanes 0..7 hold the list of point i
+            const bool present = lane < TOPK && key != KEY64_EMPTY;
+            const int idx = (int)(key & 0xffff);
+            const bool free_ = present && !occ[idx];
+            const unsigned mAll = (1u << TOPK) - 1u;
+            const unsigned mPresent = (unsigned)(__ballot(present) & mAll), mFree = (unsigned)(__ballot(free_) & mAll);
+            unsigned long long k1 = KEY64_EMPTY, k2 = KEY64_EMPTY;
+            if (__popc(mFree) >= 2 || mPresent != mAll) {
+                if (mFree) {
+                    k1 = __shfl(key, __ffs(mFree) - 1);
+                    const unsigned rest = mFree & (mFree - 1);
+                    if (rest) k2 = __shfl(key, __ffs(rest) - 1);
+                }
+            } else {
+                // exact rescan: the two smallest keys among the features that are still free
+                const ProjQuery q = proj_query(F, P, pi, scaleFactors, th);
+                unsigned long long a = KEY64_EMPTY, b = KEY64_EMPTY;
+                if (q.any)
+                    for (int x = lane; x < n; x += 64) {
+                        if (occ[x]) continue;
+                        const unsigned long long kx = proj_key(F, fbase, x, q);
+                        if (kx < a) { b = a; a = kx; } else if (kx < b) b = kx;
+                    }
+                k1 = wave_min_u64(a);
+                if (a == k1) a = b;
+                k2 = wave_min_u64(a);
+            }
+            if (k1 == KEY64_EMPTY) continue;
+            const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xffff);
+            const int bestDist2 = k2 == KEY64_EMPTY ? 256 : (int)(k2 >> 32);
+            const int bestLevel = oct[bestIdx], bestLevel2 = k2 == KEY64_EMPTY ? -1 : (int)oct[(int)(k2 & 0xffff)];
+            if (bestDist <= TH_HIGH) {
+                if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+                if (lane == 0) {
+                    aout[bestIdx] = i;                                  // F.mvpMapPoints[bestIdx] = pMP
+                    occ[bestIdx] = P.hasObs ? P.hasObs[pi] : 1;         // what :110-112 sees from now on
+                }
+                total++;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (lane == 0) nmatches[f] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)
+// (src/ORBmatcher.cc:1569-1728), the matcher of Tracking::TrackWithMotionModel: every MapPoint of
+// the last frame is projected with the current pose (float arithmetic in the reference's order),
+// searched in a window whose pyramid-level range depends on forward / backward motion, and given
+// to the free feature of minimum distance; rotation histogram pruning at the end.
+// ---------------------------------------------------------------------------------------------
+struct ProjLastDev { const uint8_t *valid; const float *pos; const uint8_t *desc, *hasObs; const int32_t *octave; const float *angle; const int32_t *counts;
+                     int cap; const float *tcwCur, *tcwLast; float fx, fy, cx, cy, mbf, mb, maxX, maxY; };
+
+__device__ __forceinline__ void proj_motion(const float *Rc, const float *Rl, float mb, int bMono, bool &bForward, bool &bBackward)
+{
+    float twc[3], tlcz;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        float s = (-Rc[0 * 4 + r]) * Rc[0 * 4 + 3];
+        s = s + (-Rc[1 * 4 + r]) * Rc[1 * 4 + 3];
+        s = s + (-Rc[2 * 4 + r]) * Rc[2 * 4 + 3];
+        twc[r] = s;
+    }
+    {
+        float s = Rl[2 * 4 + 0] * twc[0];
+        s = s + Rl[2 * 4 + 1] * twc[1];
+        s = s + Rl[2 * 4 + 2] * twc[2];
+        tlcz = s + Rl[2 * 4 + 3];
+    }
+    bForward = tlcz > mb && !bMono;
+    bBackward = -tlcz > mb && !bMono;
+}
+
+// query of last-frame feature li; false when the point is skipped before the window search (:1604-1633)
+__device__ __forceinline__ bool proj_last_query(const ProjFrameDev &F, const ProjLastDev &L, int f, size_t li, const float *scaleFactors, float th,
+                                                bool bForward, bool bBackward, ProjQuery &q)
+{
+    if (L.valid[li] != 1) return false;
+    const float *Rc = L.tcwCur + 16 * (size_t)f, *X = L.pos + 3 * li;
+    float x3Dc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        float s = Rc[r * 4 + 0] * X[0];
+        s = s + Rc[r * 4 + 1] * X[1];
+        s = s + Rc[r * 4 + 2] * X[2];
+        x3Dc[r] = s + Rc[r * 4 + 3];
+    }
+    const float invzc = (float)(1.0 / (double)x3Dc[2]);
+    if (invzc < 0) return false;
+    const float u = L.fx * x3Dc[0] * invzc + L.cx, v = L.fy * x3Dc[1] * invzc + L.cy;
+    if (u < F.minX || u > L.maxX) return false;
+    if (v < F.minY || v > L.maxY) return false;
+    const int oct = L.octave[li];
+    const float radius = th * scaleFactors[oct];
+    q.x = u; q.y = v; q.rr = radius; q.xr = u - L.mbf * invzc;
+    if (bForward) { q.minLevel = oct; q.maxLevel = -1; }
+    else if (bBackward) { q.minLevel = 0; q.maxLevel = oct; }
+    else { q.minLevel = oct - 1; q.maxLevel = oct + 1; }
+    const int nMinCellX = max(0, (int)floorf((u - F.minX - radius) * F.gwInv)), nMaxCellX = min(GRID_COLS - 1, (int)ceilf((u - F.minX + radius) * F.gwInv));
+    const int nMinCellY = max(0, (int)floorf((v - F.minY - radius) * F.ghInv)), nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((v - F.minY + radius) * F.ghInv));
+    q.any = !(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0);
+    q.cx0 = nMinCellX; q.cx1 = nMaxCellX; q.cy0 = nMinCellY; q.cy1 = nMaxCellY;
+    const unsigned long long *dp = (const unsigned long long *)(L.desc + li * 32);
+    q.d[0] = dp[0]; q.d[1] = dp[1]; q.d[2] = dp[2]; q.d[3] = dp[3];
+    return q.any;
+}
+
+__global__ __launch_bounds__(256) void k_proj_last_topk(ProjFrameDev F, ProjLastDev L, const float *__restrict__ scaleFactors, float th, int bMono,
+                                                        unsigned long long *__restrict__ topk)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(F.counts[f], F.cap), nl = min(L.counts[f], L.cap);
+    if (i >= nl) return;
+    const size_t li = (size_t)f * L.cap + i, fbase = (size_t)f * F.cap;
+    unsigned long long *out = topk + li * TOPK;
+    bool bForward, bBackward;
+    proj_motion(L.tcwCur + 16 * (size_t)f, L.tcwLast + 16 * (size_t)f, L.mb, bMono, bForward, bBackward);
+    ProjQuery q;
+    if (!proj_last_query(F, L, f, li, scaleFactors, th, bForward, bBackward, q)) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
+    unsigned long long kk[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; t++) kk[t] = KEY64_EMPTY;
+    for (int idx = lane; idx < n; idx += 64) {
+        const unsigned long long key = proj_key(F, fbase, idx, q);
+        if (key < kk[TOPK - 1]) {
+            kk[TOPK - 1] = key;
+#pragma unroll
+            for (int t = TOPK - 1; t > 0; t--)
+                if (kk[t] < kk[t - 1]) { const unsigned long long v = kk[t - 1]; kk[t - 1] = kk[t]; kk[t] = v; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TOPK; k++) {
+        const unsigned long long mn = wave_min_u64(kk[0]);
+        if (kk[0] == mn && mn != KEY64_EMPTY) {
+#pragma unroll
+            for (int t = 0; t < TOPK - 1; t++) kk[t] = kk[t + 1];
+            kk[TOPK - 1] = KEY64_EMPTY;
+        }
+        if (lane == 0) out[k] = mn;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_proj_last_greedy(ProjFrameDev F, ProjLastDev L, const float *__restrict__ scaleFactors, float th, int bMono,
+                                                          int checkOri, const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
+                                                          int32_t *__restrict__ nmatches, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int sTotal, sRemoved;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = min(F.counts[f], F.cap), nl = min(L.counts[f], L.cap);
+    unsigned char *occ = smem;                              // [cap]
+    int32_t *sAsg = (int32_t *)(smem + ((F.cap + 15) & ~15));   // [cap] last-frame feature given to current feature i2, or -1
+    uint32_t *sEv = (uint32_t *)(sAsg + F.cap);             // [L.cap] accepted assignments in order: point << 16 | feature
+    const size_t fbase = (size_t)f * F.cap, lbase = (size_t)f * L.cap;
+    int32_t *aout = assigned + (size_t)f * stride;
+    for (int i = tid; i < F.cap; i += 256) { sAsg[i] = -1; occ[i] = (i < n && F.occupied) ? F.occupied[fbase + i] : 0; }
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) { sTotal = 0; sRemoved = 0; }
+    __syncthreads();
+    if (tid < 64) {
+        bool bForward, bBackward;
+        proj_motion(L.tcwCur + 16 * (size_t)f, L.tcwLast + 16 * (size_t)f, L.mb, bMono, bForward, bBackward);
+        int total = 0;
+        const unsigned long long *tk = topk + lbase * TOPK;
+        unsigned long long nextKeys = (0 < nl) ? tk[min((size_t)lane, (size_t)nl * TOPK - 1)] : KEY64_EMPTY;
+        for (int i0 = 0; i0 < nl; i0 += 8) {
+            const unsigned long long keys = nextKeys;
+            {
+                const size_t nx = (size_t)(i0 + 8) * TOPK + lane;
+                nextKeys = (i0 + 8 < nl) ? tk[min(nx, (size_t)nl * TOPK - 1)] : KEY64_EMPTY;
+            }
+            for (int j = 0; j < 8 && i0 + j < nl; j++) {
+                const int i = i0 + j;
+                const unsigned long long key = __shfl(keys, 8 * j + (lane & 7));
+                const bool present = lane < TOPK && key != KEY64_EMPTY;
+                const unsigned mAll = (1u << TOPK) - 1u;
+                const unsigned mPresent = (unsigned)(__ballot(present) & mAll);
+                if (!mPresent) continue;                    // skipped point or empty window
+                const bool free_ = present && !occ[(int)(key & 0xffff)];
+                const unsigned mFree = (unsigned)(__ballot(free_) & mAll);
+                unsigned long long k1 = KEY64_EMPTY;
+                if (mFree) k1 = __shfl(key, __ffs(mFree) - 1);
+                else if (mPresent == mAll) {
+                    // every listed candidate is taken and the list was full: exact rescan for the best free one
+                    ProjQuery q;
+                    unsigned long long a = KEY64_EMPTY;
+                    if (proj_last_query(F, L, f, lbase + i, scaleFactors, th, bForward, bBackward, q))
+                        for (int x = lane; x < n; x += 64) {
+                            if (occ[x]) continue;
+                            const unsigned long long kx = proj_key(F, fbase, x, q);
+                            a = kx < a ? kx : a;
+                        }
+                    k1 = wave_min_u64(a);
+                }
+                if (k1 == KEY64_EMPTY) continue;
+                const int bestDist = (int)(k1 >> 32), bestIdx2 = (int)(k1 & 0xffff);
+                if (bestDist <= TH_HIGH) {
+                    if (lane == 0) {
+                        sAsg[bestIdx2] = i;                                     // CurrentFrame.mvpMapPoints[bestIdx2] = pMP
+                        occ[bestIdx2] = L.hasObs ? L.hasObs[lbase + i] : 1;
+                        sEv[total] = ((uint32_t)i << 16) | (uint32_t)bestIdx2;
+                    }
+                    total++;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (lane == 0) sTotal = total;
+    }
+    __syncthreads();
+    // rotation histogram over the ACCEPTED assignments in the order they were made (:1694-1704): a
+    // feature whose first holder had no observations can be re-assigned later and then sits in two
+    // bins; pruning a bin clears the feature whichever holder put it there (:1712-1722).
+    const float factor = HISTO_LENGTH / 360.0f;
+    if (checkOri) {
+        const int nev = sTotal;
+        for (int e = tid; e < nev; e += 256) {
+            const uint32_t ev = sEv[e];
+            const int li = (int)(ev >> 16), i2 = (int)(ev & 0xffff);
+            float rot = L.angle[lbase + li] - F.kp[fbase + i2].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            sEv[e] = (ev & 0xffffu) | ((uint32_t)bin << 16);   // keep feature + bin
+            atomicAdd(&hist[bin], 1);
+        }
+        __syncthreads();
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            const int sN = hist[b];
+            if (sN > max1) { max3 = max2; max2 = max1; max1 = sN; ind3 = ind2; ind2 = ind1; ind1 = b; }
+            else if (sN > max2) { max3 = max2; max2 = sN; ind3 = ind2; ind2 = b; }
+            else if (sN > max3) { max3 = sN; ind3 = b; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        int removed = 0;
+        for (int e = tid; e < nev; e += 256) {
+            const uint32_t ev = sEv[e];
+            const int b = (int)(ev >> 16);
+            if (b != ind1 && b != ind2 && b != ind3) { sAsg[ev & 0xffffu] = -2; removed++; }   // -2: assigned, then cleared (:1718)
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+        if (lane == 0 && removed) atomicAdd(&sRemoved, removed);
+    }
+    __syncthreads();
+    for (int i = tid; i < stride; i += 256) aout[i] = i < n ? sAsg[i] : -1;
+    if (tid == 0) nmatches[f] = sTotal - sRemoved;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::Fuse, both overloads (src/ORBmatcher.cc:1020-1177, 1179-1312): the search of steps 2-3,
+// i.e. KeyFrame::GetFeaturesInArea(u, v, radius) (src/KeyFrame.cc:752-796), the level gate
+// (:1107-1108, 1262-1263), for the first overload the chi-square gate on the reprojection error
+// (:1111-1135) and the minimum Hamming distance with strict '<' (first minimum in the cell-major
+// order of GetFeaturesInArea).  The map points are independent of each other here (the reference's
+// loop only couples them through Replace / AddObservation, which stay on the host in the shim).
+// One wave per map point, lanes over the KeyFrame's features.
+// ---------------------------------------------------------------------------------------------
+struct FusePointsDev { const float *u, *v, *ur; const int32_t *level; const float *radius; const uint8_t *active, *desc; const int32_t *counts; int cap;
+                       float kfMinX, kfMinY; };
+struct FuseLevels { float invSigma2[ORBX_MAX_LEVELS]; };
+
+__global__ __launch_bounds__(256) void k_fuse_best(ProjFrameDev F, FusePointsDev P, FuseLevels LV, int chi2Gate, int32_t *__restrict__ bestIdx,
+                                                   int32_t *__restrict__ bestDist, int stride)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
+    if (i >= m) return;
+    const size_t pi = (size_t)f * P.cap + i, fbase = (size_t)f * F.cap;
+    unsigned long long best = KEY64_EMPTY;
+    if (!P.active || P.active[pi]) {
+        const float x = P.u[pi], y = P.v[pi], r = P.radius[pi], xr = chi2Gate ? P.ur[pi] : 0.0f;
+        const int lvl = P.level[pi];
+        // the window uses the KeyFrame's (int) bounds, KeyFrame.cc:760-775; the cells were filed with the Frame's float bounds
+        const int cx0 = max(0, (int)floorf((x - P.kfMinX - r) * F.gwInv)), cx1 = min(GRID_COLS - 1, (int)ceilf((x - P.kfMinX + r) * F.gwInv));
+        const int cy0 = max(0, (int)floorf((y - P.kfMinY - r) * F.ghInv)), cy1 = min(GRID_ROWS - 1, (int)ceilf((y - P.kfMinY + r) * F.ghInv));
+        if (!(cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0)) {
+            const unsigned long long *dp = (const unsigned long long *)(P.desc + pi * 32);
+            const unsigned long long d[4] = {dp[0], dp[1], dp[2], dp[3]};
+            for (int idx = lane; idx < n; idx += 64) {
+                const orbx_keypoint k = F.kp[fbase + idx];
+                const int cx = (int)roundf((k.x - F.minX) * F.gwInv), cy = (int)roundf((k.y - F.minY) * F.ghInv);   // the cell AssignFeaturesToGrid filed it in
+                if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) continue;
+                const float distx = k.x - x, disty = k.y - y;
+                if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;                                             // KeyFrame.cc:786-790
+                if (k.octave < lvl - 1 || k.octave > lvl) continue;                                               // :1107-1108
+                if (chi2Gate) {
+                    const float kr = F.uRight[fbase + idx];
+                    const float ex = x - k.x, ey = y - k.y;
+                    if (kr >= 0) {
+                        const float er = xr - kr;
+                        const float e2 = ex * ex + ey * ey + er * er;
+                        if ((double)(e2 * LV.invSigma2[k.octave]) > 7.8) continue;                                // :1123
+                    } else {
+                        const float e2 = ex * ex + ey * ey;
+                        if ((double)(e2 * LV.invSigma2[k.octave]) > 5.99) continue;                               // :1134
+                    }
+                }
+                const unsigned long long *db = (const unsigned long long *)(F.desc + (fbase + idx) * 32);
+                const int dist = hamming256(d, db[0], db[1], db[2], db[3]);
+                const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)idx;
+                best = key < best ? key : best;
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) {
+        const size_t o = (size_t)f * stride + i;
+        bestIdx[o] = best == KEY64_EMPTY ? -1 : (int)(best & 0xffff);
+        bestDist[o] = best == KEY64_EMPTY ? 256 : (int)(best >> 32);
+    }
+}
+
+static int fuse_launch(orbx_matcher *m, const ProjFrameDev &F, const FusePointsDev &P, int nframes, const float *inv_level_sigma2, int nlevels, int chi2_gate)
+{
+    if (nframes < 1 || nframes > m->maxPairs) { orbx_set_error("nframes %d outside 1..%d", nframes, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (F.cap < 1 || F.cap > 65535 || P.cap < 1 || P.cap > m->maxFeatures) {
+        orbx_set_error("bad capacities (features %d, points %d, matcher max_features %d)", F.cap, P.cap, m->maxFeatures);
+        return ORBX_ERR_CAPACITY;
+    }
+    if (!inv_level_sigma2 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS) { orbx_set_error("bad level table"); return ORBX_ERR_ARG; }
+    FuseLevels LV;
+    for (int l = 0; l < ORBX_MAX_LEVELS; l++) LV.invSigma2[l] = l < nlevels ? inv_level_sigma2[l] : 0.0f;
+    const int stride = m->maxFeatures;
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_fuse_best, dim3((unsigned)((P.cap + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, F, P, LV, chi2_gate, m->matches.p, m->dists.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = nframes; m->lastStride = stride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_fuse_search_device(orbx_matcher *m, const orbx_projection_frame *kf, const orbx_fuse_points *pts, const float *inv_level_sigma2, int nlevels,
+                                       int chi2_gate)
+{
+    if (!m || !kf || !pts) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!kf->keypoints_un || !kf->descriptors || !kf->counts || (chi2_gate && (!kf->u_right || !pts->ur)) || !pts->u || !pts->v || !pts->level || !pts->radius ||
+        !pts->descriptors || !pts->counts) {
+        orbx_set_error("NULL array in the fuse arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ProjFrameDev F = {kf->keypoints_un, kf->descriptors, kf->u_right, nullptr, kf->counts, kf->capacity, kf->min_x, kf->min_y, kf->grid_width_inv, kf->grid_height_inv};
+    FusePointsDev P = {pts->u, pts->v, pts->ur, pts->level, pts->radius, pts->active, pts->descriptors, pts->counts, pts->capacity, pts->kf_min_x, pts->kf_min_y};
+    return fuse_launch(m, F, P, kf->nframes, inv_level_sigma2, nlevels, chi2_gate);
+}
+
+// host-array form for one KeyFrame: upload, run, download
+extern "C" int orbx_fuse_search(orbx_matcher *m, const orbx_projection_frame *kf, const orbx_fuse_points *pt, const float *inv_level_sigma2, int nlevels,
+                                int chi2_gate, int32_t *best_idx, int32_t *best_dist)
+{
+    if (!m || !kf || !pt || !best_idx || !best_dist) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!kf->counts || !pt->counts) { orbx_set_error("NULL counts"); return ORBX_ERR_ARG; }
+    const int n = kf->counts[0], mm = pt->counts[0];
+    for (int i = 0; i < mm; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (n <= 0 || mm <= 0) return ORBX_OK;
+    if (mm > m->maxFeatures) { orbx_set_error("%d map points exceed the matcher's max_features %d", mm, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    if (!kf->keypoints_un || !kf->descriptors || (chi2_gate && (!kf->u_right || !pt->ur)) || !pt->u || !pt->v || !pt->level || !pt->radius || !pt->descriptors) {
+        orbx_set_error("NULL array in the fuse arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    // staging: KeyFrame side in pkp / hd[0] / pf[0]; point side in pf[1] (u, v, ur, radius) / pi32[1] (level) / pb[1] (descriptors, active)
+    if ((rc = m->pkp.ensure((size_t)n)) || (rc = m->hd[0].ensure((size_t)n * 32)) || (rc = m->pf[0].ensure((size_t)n)) || (rc = m->pi32[0].ensure(2)) ||
+        (rc = m->pf[1].ensure((size_t)mm * 4)) || (rc = m->pi32[1].ensure((size_t)mm)) || (rc = m->pb[1].ensure((size_t)mm * 33)))
+        return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, kf->keypoints_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[0].p, kf->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    if (kf->u_right) ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[0].p, kf->u_right, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    const int32_t cnt[2] = {n, mm};
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, pt->u, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + mm, pt->v, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    if (pt->ur) ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 2 * (size_t)mm, pt->ur, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 3 * (size_t)mm, pt->radius, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p, pt->level, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p, pt->descriptors, (size_t)mm * 32, hipMemcpyHostToDevice, st));
+    if (pt->active) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)mm * 32, pt->active, (size_t)mm, hipMemcpyHostToDevice, st));
+    ProjFrameDev F = {m->pkp.p, m->hd[0].p, m->pf[0].p, nullptr, m->pi32[0].p, n, kf->min_x, kf->min_y, kf->grid_width_inv, kf->grid_height_inv};
+    FusePointsDev P = {m->pf[1].p, m->pf[1].p + mm, m->pf[1].p + 2 * (size_t)mm, m->pi32[1].p, m->pf[1].p + 3 * (size_t)mm,
+                       pt->active ? m->pb[1].p + (size_t)mm * 32 : nullptr, m->pb[1].p, m->pi32[0].p + 1, mm, pt->kf_min_x, pt->kf_min_y};
+    if ((rc = fuse_launch(m, F, P, 1, inv_level_sigma2, nlevels, chi2_gate)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    ORBX_HIP_CHECK(hipMemcpy(best_idx, m->matches.p, (size_t)mm * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_CHECK(hipMemcpy(best_dist, m->dists.p, (size_t)mm * 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Greedy area search: ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (loop closing,
+// src/ORBmatcher.cc:388-513) and SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)
+// (relocalisation, :1731-1864) after their per-point preparation: the queries are processed in order, each
+// takes the feature of minimum distance among those in its GetFeaturesInArea window that pass the level
+// gate and are not blocked (blocked at the start, or taken by an earlier query), if that distance is
+// <= max_dist.  Candidate lists (top-8 by distance || cell order || index, blocking ignored) come from
+// k_area_topk; k_area_greedy replays the sequence as the unique fixed point of "query r takes its best
+// candidate that no accepted query < r took" (see k_bow_greedy), with an exact rescan for exhausted lists.
+// ---------------------------------------------------------------------------------------------
+struct AreaQueriesDev { const float *u, *v, *radius; const int32_t *minLevel, *maxLevel; const uint8_t *active, *desc; const int32_t *counts; int cap;
+                        float winMinX, winMinY; };
+struct AreaQuery { float x, y, r; int minLevel, maxLevel, cx0, cx1, cy0, cy1; bool any; unsigned long long d[4]; };
+
+__device__ __forceinline__ AreaQuery area_query(const ProjFrameDev &F, const AreaQueriesDev &Q, size_t qi)
+{
+    AreaQuery q;
+    q.x = Q.u[qi]; q.y = Q.v[qi]; q.r = Q.radius[qi];
+    q.minLevel = Q.minLevel[qi]; q.maxLevel = Q.maxLevel[qi];
+    const int x0 = max(0, (int)floorf((q.x - Q.winMinX - q.r) * F.gwInv)), x1 = min(GRID_COLS - 1, (int)ceilf((q.x - Q.winMinX + q.r) * F.gwInv));
+    const int y0 = max(0, (int)floorf((q.y - Q.winMinY - q.r) * F.ghInv)), y1 = min(GRID_ROWS - 1, (int)ceilf((q.y - Q.winMinY + q.r) * F.ghInv));
+    q.any = !(x0 >= GRID_COLS || x1 < 0 || y0 >= GRID_ROWS || y1 < 0);
+    q.cx0 = x0; q.cx1 = x1; q.cy0 = y0; q.cy1 = y1;
+    const unsigned long long *dp = (const unsigned long long *)(Q.desc + qi * 32);
+    q.d[0] = dp[0]; q.d[1] = dp[1]; q.d[2] = dp[2]; q.d[3] = dp[3];
+    return q;
+}
+
+__device__ __forceinline__ unsigned long long area_key(const ProjFrameDev &F, size_t fbase, int idx, const AreaQuery &q)
+{
+    const orbx_keypoint k = F.kp[fbase + idx];
+    const int cx = (int)roundf((k.x - F.minX) * F.gwInv), cy = (int)roundf((k.y - F.minY) * F.ghInv);   // the cell AssignFeaturesToGrid filed it in
+    if (cx < q.cx0 || cx > q.cx1 || cy < q.cy0 || cy > q.cy1) return KEY64_EMPTY;
+    if (k.octave < q.minLevel || (q.maxLevel >= 0 && k.octave > q.maxLevel)) return KEY64_EMPTY;
+    const float distx = k.x - q.x, disty = k.y - q.y;
+    if (!(fabsf(distx) < q.r && fabsf(disty) < q.r)) return KEY64_EMPTY;
+    const unsigned long long *db = (const unsigned long long *)(F.desc + (fbase + idx) * 32);
+    const int dist = hamming256(q.d, db[0], db[1], db[2], db[3]);
+    return ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)idx;
+}
+
+__global__ __launch_bounds__(256) void k_area_topk(ProjFrameDev F, AreaQueriesDev Q, unsigned long long *__restrict__ topk)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(F.counts[f], F.cap), m = min(Q.counts[f], Q.cap);
+    if (i >= m) return;
+    const size_t qi = (size_t)f * Q.cap + i, fbase = (size_t)f * F.cap;
+    unsigned long long *out = topk + qi * TOPK;
+    if (Q.active && !Q.active[qi]) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
+    const AreaQuery q = area_query(F, Q, qi);
+    unsigned long long kk[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; t++) kk[t] = KEY64_EMPTY;
+    if (q.any)
+        for (int idx = lane; idx < n; idx += 64) {
+            const unsigned long long key = area_key(F, fbase, idx, q);
+            if (key < kk[TOPK - 1]) {
+                kk[TOPK - 1] = key;
+#pragma unroll
+                for (int t = TOPK - 1; t > 0; t--)
+                    if (kk[t] < kk[t - 1]) { const unsigned long long v = kk[t - 1]; kk[t - 1] = kk[t]; kk[t] = v; }
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < TOPK; k++) {
+        const unsigned long long mn = wave_min_u64(kk[0]);
+        if (kk[0] == mn && mn != KEY64_EMPTY) {   // keys are unique: exactly one lane pops its head
+#pragma unroll
+            for (int t = 0; t < TOPK - 1; t++) kk[t] = kk[t + 1];
+            kk[TOPK - 1] = KEY64_EMPTY;
+        }
+        if (lane == 0) out[k] = mn;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_area_greedy(ProjFrameDev F, AreaQueriesDev Q, int maxDist, const unsigned long long *__restrict__ topk,
+                                                     int32_t *__restrict__ assigned, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int sChanged, sQueued, sTotal;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = min(F.counts[f], F.cap), m = min(Q.counts[f], Q.cap);
+    // LDS: owner[F.cap] (0 = blocked from the start, else 1 + lowest accepted query taking the feature, ~0 = free) | dec[Q.cap] | queue (u16)
+    uint32_t *owner = (uint32_t *)smem;
+    uint32_t *dec = owner + F.cap;                        // KEY_EMPTY or dist << 16 | feature
+    unsigned short *queue = (unsigned short *)(dec + Q.cap);
+    const size_t fbase = (size_t)f * F.cap, qbase = (size_t)f * Q.cap;
+    const unsigned long long *tk = topk + qbase * TOPK;
+    int32_t *aout = assigned + (size_t)f * stride, *dout = dists + (size_t)f * stride;
+    for (int i = tid; i < m; i += 256) dec[i] = KEY_EMPTY;
+    if (tid == 0) sTotal = 0;
+    for (;;) {
+        for (int j = tid; j < n; j += 256) owner[j] = (F.occupied && F.occupied[fbase + j]) ? 0u : 0xffffffffu;
+        if (tid == 0) { sChanged = 0; sQueued = 0; }
+        __syncthreads();
+        for (int r = tid; r < m; r += 256) {
+            const uint32_t d = dec[r];
+            if (d != KEY_EMPTY) atomicMin(&owner[d & 0xffff], (uint32_t)r + 1u);
+        }
+        __syncthreads();
+        bool changed = false;
+        for (int r = tid; r < m; r += 256) {
+            if (Q.active && !Q.active[qbase + r]) continue;
+            uint32_t nd = KEY_EMPTY;
+            bool full = true, found = false;
+#pragma unroll
+            for (int k = 0; k < TOPK; k++) {
+                const unsigned long long key = tk[(size_t)r * TOPK + k];
+                if (key == KEY64_EMPTY) { full = false; continue; }
+                const uint32_t idx = (uint32_t)(key & 0xffff);
+                if (!found && owner[idx] > (uint32_t)r) {   // free for this query: not blocked and not taken by an earlier one
+                    found = true;
+                    const uint32_t dist = (uint32_t)(key >> 32);
+                    if ((int)dist <= maxDist) nd = (dist << 16) | idx;
+                }
+            }
+            if (!found && full) { queue[atomicAdd(&sQueued, 1)] = (unsigned short)r; continue; }
+            if (nd != dec[r]) { dec[r] = nd; changed = true; }
+        }
+        if (changed) sChanged = 1;
+        __syncthreads();
+        const int nq = sQueued;
+        for (int qq = wv; qq < nq; qq += 4) {   // exact rescan over the free features
+            const int r = queue[qq];
+            const AreaQuery q = area_query(F, Q, qbase + r);
+            unsigned long long best = KEY64_EMPTY;
+            for (int idx = lane; idx < n; idx += 64) {
+                if (!(owner[idx] > (uint32_t)r)) continue;
+                const unsigned long long key = area_key(F, fbase, idx, q);
+                best = key < best ? key : best;
+            }
+            best = wave_min_u64(best);
+            uint32_t nd = KEY_EMPTY;
+            if (best != KEY64_EMPTY && (int)(best >> 32) <= maxDist) nd = ((uint32_t)(best >> 32) << 16) | (uint32_t)(best & 0xffff);
+            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChanged = 1; }
+        }
+        __syncthreads();
+        const int again = sChanged;
+        __syncthreads();
+        if (!again) break;
+    }
+    int total = 0;
+    for (int r = tid; r < stride; r += 256) {
+        const uint32_t d = r < m ? dec[r] : KEY_EMPTY;
+        aout[r] = d == KEY_EMPTY ? -1 : (int)(d & 0xffff);
+        dout[r] = d == KEY_EMPTY ? 256 : (int)(d >> 16);
+        total += d != KEY_EMPTY;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if (lane == 0 && total) atomicAdd(&sTotal, total);
+    __syncthreads();
+    if (tid == 0) nmatches[f] = sTotal;
+}
+
+static int area_launch(orbx_matcher *m, const ProjFrameDev &F, const AreaQueriesDev &Q, int nframes, int max_dist)
+{
+    if (nframes < 1 || nframes > m->maxPairs) { orbx_set_error("nframes %d outside 1..%d", nframes, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (F.cap < 1 || F.cap > 65535 || Q.cap < 1 || Q.cap > m->maxFeatures || Q.cap > 65535) {
+        orbx_set_error("bad capacities (features %d, queries %d, matcher max_features %d)", F.cap, Q.cap, m->maxFeatures);
+        return ORBX_ERR_CAPACITY;
+    }
+    int rc = m->topk64.ensure((size_t)nframes * Q.cap * TOPK);
+    if (rc != ORBX_OK) return rc;
+    const int stride = m->maxFeatures;
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_area_topk, dim3((unsigned)((Q.cap + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, F, Q, m->topk64.p);
+    MLAUNCH_CHECK();
+    const size_t lds = (size_t)F.cap * 4 + (size_t)Q.cap * 4 + (size_t)Q.cap * 2 + 16;
+    if (lds > 160 * 1024) { orbx_set_error("capacities too large for the LDS tile"); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_area_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_area_greedy, dim3((unsigned)nframes), dim3(256), lds, m->stream, F, Q, max_dist, m->topk64.p, m->matches.p, m->dists.p, m->nmatches.p,
+                       stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = nframes; m->lastStride = stride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_area_search_greedy_device(orbx_matcher *m, const orbx_projection_frame *frame, const orbx_area_queries *q, int max_dist)
+{
+    if (!m || !frame || !q) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!frame->keypoints_un || !frame->descriptors || !frame->counts || !q->u || !q->v || !q->radius || !q->min_level || !q->max_level || !q->descriptors ||
+        !q->counts) {
+        orbx_set_error("NULL array in the area-search arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ProjFrameDev F = {frame->keypoints_un, frame->descriptors, frame->u_right, frame->occupied, frame->counts, frame->capacity,
+                      frame->min_x, frame->min_y, frame->grid_width_inv, frame->grid_height_inv};
+    AreaQueriesDev Q = {q->u, q->v, q->radius, q->min_level, q->max_level, q->active, q->descriptors, q->counts, q->capacity, q->window_min_x, q->window_min_y};
+    return area_launch(m, F, Q, frame->nframes, max_dist);
+}
+
+// host-array form for one frame: upload, run, download
+extern "C" int orbx_area_search_greedy(orbx_matcher *m, const orbx_projection_frame *fr, const orbx_area_queries *q, int max_dist, int32_t *assigned,
+                                       int32_t *dists, int32_t *nmatches)
+{
+    if (!m || !fr || !q || !assigned) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!fr->counts || !q->counts) { orbx_set_error("NULL counts"); return ORBX_ERR_ARG; }
+    const int n = fr->counts[0], mm = q->counts[0];
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < mm; i++) { assigned[i] = -1; if (dists) dists[i] = 256; }
+    if (n <= 0 || mm <= 0) return ORBX_OK;
+    if (mm > m->maxFeatures) { orbx_set_error("%d queries exceed the matcher's max_features %d", mm, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    if (!fr->keypoints_un || !fr->descriptors || !q->u || !q->v || !q->radius || !q->min_level || !q->max_level || !q->descriptors) {
+        orbx_set_error("NULL array in the area-search arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    // staging: frame side in pkp / hd[0] / pb[0]; query side in pf[1] (u, v, radius) / pi32[1] (min, max level) / pb[1] (descriptors, active)
+    if ((rc = m->pkp.ensure((size_t)n)) || (rc = m->hd[0].ensure((size_t)n * 32)) || (rc = m->pb[0].ensure((size_t)n)) || (rc = m->pi32[0].ensure(2)) ||
+        (rc = m->pf[1].ensure((size_t)mm * 3)) || (rc = m->pi32[1].ensure((size_t)mm * 2)) || (rc = m->pb[1].ensure((size_t)mm * 33)))
+        return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, fr->keypoints_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[0].p, fr->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    if (fr->occupied) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[0].p, fr->occupied, (size_t)n, hipMemcpyHostToDevice, st));
+    const int32_t cnt[2] = {n, mm};
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, q->u, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + mm, q->v, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 2 * (size_t)mm, q->radius, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p, q->min_level, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p + mm, q->max_level, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p, q->descriptors, (size_t)mm * 32, hipMemcpyHostToDevice, st));
+    if (q->active) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)mm * 32, q->active, (size_t)mm, hipMemcpyHostToDevice, st));
+    ProjFrameDev F = {m->pkp.p, m->hd[0].p, nullptr, fr->occupied ? m->pb[0].p : nullptr, m->pi32[0].p, n, fr->min_x, fr->min_y, fr->grid_width_inv,
+                      fr->grid_height_inv};
+    AreaQueriesDev Q = {m->pf[1].p, m->pf[1].p + mm, m->pf[1].p + 2 * (size_t)mm, m->pi32[1].p, m->pi32[1].p + mm,
+                        q->active ? m->pb[1].p + (size_t)mm * 32 : nullptr, m->pb[1].p, m->pi32[0].p + 1, mm, q->window_min_x, q->window_min_y};
+    if ((rc = area_launch(m, F, Q, 1, max_dist)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    ORBX_HIP_CHECK(hipMemcpy(assigned, m->matches.p, (size_t)mm * 4, hipMemcpyDeviceToHost));
+    if (dists) ORBX_HIP_CHECK(hipMemcpy(dists, m->dists.p, (size_t)mm * 4, hipMemcpyDeviceToHost));
+    if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:515-654, Tracking::MonocularInitialization): level-0
+// features of F1 look for their best / second best F2 feature inside a window around vbPrevMatched; a candidate
+// is skipped when the F2 feature is already held at a distance <= its own (vMatchedDistance, :566), an accepted
+// match overrides the previous holder (:590-594).  That state makes every step depend on all earlier ones in a
+// way no candidate list can precompute, and the function runs once per frame only until the map is initialised:
+// one workgroup per frame pair walks the F1 features in order and evaluates each window with all 256 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_search_init(FeatDev A, ProjFrameDev F2, const float *__restrict__ prevXY, float window, float nnratio, int checkOri,
+                                                     int32_t *__restrict__ matches, int8_t *__restrict__ bins, int32_t *__restrict__ nmatches, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long sBest[4], sSecond[4];
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int sTotal;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n1 = min(A.counts[f], A.cap), n2 = min(F2.counts[f], F2.cap);
+    unsigned short *holderDist = (unsigned short *)smem;   // vMatchedDistance, 0xffff = INT_MAX
+    unsigned short *match21 = holderDist + F2.cap;         // vnMatches21, 0xffff = -1
+    const size_t abase = (size_t)f * A.cap, fbase = (size_t)f * F2.cap;
+    int32_t *m12 = matches + (size_t)f * stride;
+    int8_t *bin12 = bins + (size_t)f * stride;
+    for (int i = tid; i < n2; i += 256) { holderDist[i] = 0xffff; match21[i] = 0xffff; }
+    for (int i = tid; i < stride; i += 256) { m12[i] = -1; bin12[i] = -1; }
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) sTotal = 0;
+    __syncthreads();
+    const float factor = HISTO_LENGTH / 360.0f;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const orbx_keypoint k1 = A.kp[abase + i1];
+        if (k1.octave > 0) continue;                                                             // :535-537 (uniform)
+        const float x = prevXY[2 * (abase + i1)], y = prevXY[2 * (abase + i1) + 1], r = window;
+        // Frame::GetFeaturesInArea(x, y, r, 0, 0), src/Frame.cc:741-850
+        const int cx0 = max(0, (int)floorf((x - F2.minX - r) * F2.gwInv)), cx1 = min(GRID_COLS - 1, (int)ceilf((x - F2.minX + r) * F2.gwInv));
+        const int cy0 = max(0, (int)floorf((y - F2.minY - r) * F2.ghInv)), cy1 = min(GRID_ROWS - 1, (int)ceilf((y - F2.minY + r) * F2.ghInv));
+        if (cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0) continue;                // (uniform)
+        const unsigned long long *dp = (const unsigned long long *)(A.desc + (abase + i1) * 32);
+        const unsigned long long d[4] = {dp[0], dp[1], dp[2], dp[3]};
+        unsigned long long k0 = KEY64_EMPTY, kk1 = KEY64_EMPTY;
+        for (int i2 = tid; i2 < n2; i2 += 256) {
+            const orbx_keypoint k = F2.kp[fbase + i2];
+            const int cx = (int)roundf((k.x - F2.minX) * F2.gwInv), cy = (int)roundf((k.y - F2.minY) * F2.ghInv);
+            if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) continue;
+            if (k.octave < 0 || k.octave > 0) continue;                                          // minLevel = maxLevel = level1 = 0
+            const float distx = k.x - x, disty = k.y - y;
+            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+            const unsigned long long *db = (const unsigned long long *)(F2.desc + (fbase + i2) * 32);
+            const int dist = hamming256(d, db[0], db[1], db[2], db[3]);
+            if ((int)holderDist[i2] <= dist) continue;                                           // :566 (0xffff stands for INT_MAX)
+            const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)i2;
+            if (key < k0) { kk1 = k0; k0 = key; } else if (key < kk1) kk1 = key;
+        }
+        {
+            const unsigned long long b = wave_min_u64(k0);
+            if (k0 == b && b != KEY64_EMPTY) k0 = kk1;
+            const unsigned long long s2 = wave_min_u64(k0);
+            if (lane == 0) { sBest[wv] = b; sSecond[wv] = s2; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = KEY64_EMPTY, s2 = KEY64_EMPTY;
+            for (int w = 0; w < 4; w++) {
+                const unsigned long long c0 = sBest[w], c1 = sSecond[w];
+                if (c0 < b) { s2 = b < c1 ? b : c1; b = c0; s2 = s2 < c1 ? s2 : c1; }
+                else { s2 = c0 < s2 ? c0 : s2; }
+            }
+            if (b != KEY64_EMPTY) {
+                const int bestDist = (int)(b >> 32), bestIdx2 = (int)(b & 0xffff);
+                const float second = s2 == KEY64_EMPTY ? (float)2147483647 : (float)(int)(s2 >> 32);   // (float)INT_MAX, :576
+                if (bestDist <= TH_LOW && (float)bestDist < second * nnratio) {
+                    if (match21[bestIdx2] != 0xffff) { m12[match21[bestIdx2]] = -1; sTotal--; }      // :590-594
+                    m12[i1] = bestIdx2;
+                    match21[bestIdx2] = (unsigned short)i1;
+                    holderDist[bestIdx2] = (unsigned short)bestDist;
+                    sTotal++;
+                    if (checkOri) {
+                        float rot = k1.angle - F2.kp[fbase + bestIdx2].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        bin12[i1] = (int8_t)bin;
+                        hist[bin]++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (checkOri) {
+        // ComputeThreeMaxima over the counts of ALL accepted events (an overridden match stays in its bin, :606)
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            const int sN = hist[b];
+            if (sN > max1) { max3 = max2; max2 = max1; max1 = sN; ind3 = ind2; ind2 = ind1; ind1 = b; }
+            else if (sN > max2) { max3 = max2; max2 = sN; ind3 = ind2; ind2 = b; }
+            else if (sN > max3) { max3 = sN; ind3 = b; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        __threadfence_block();
+        int removed = 0;
+        for (int i = tid; i < n1; i += 256) {
+            const int b = bin12[i];
+            if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && m12[i] >= 0) { m12[i] = -1; removed++; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+        if (lane == 0 && removed) atomicSub(&sTotal, removed);
+    }
+    __syncthreads();
+    if (tid == 0) nmatches[f] = sTotal;
+}
+
+extern "C" int orbx_search_for_initialization_device(orbx_matcher *m, const orbx_feature_set *f1, const orbx_projection_frame *f2, const float *prev_matched_xy,
+                                                     int window_size, float nn_ratio, int check_orientation)
+{
+    if (!m || !f1 || !f2 || !prev_matched_xy) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!f1->keypoints || !f1->descriptors || !f1->counts || !f2->keypoints_un || !f2->descriptors || !f2->counts) { orbx_set_error("NULL feature arrays"); return ORBX_ERR_ARG; }
+    const int nframes = f2->nframes;
+    if (nframes < 1 || nframes > m->maxPairs || f1->nframes != nframes) { orbx_set_error("frame counts %d/%d outside 1..%d", f1->nframes, nframes, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (f1->capacity < 1 || f1->capacity > m->maxFeatures || f2->capacity < 1 || f2->capacity > 65534) { orbx_set_error("bad capacities (%d, %d)", f1->capacity, f2->capacity); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc = m->pb[0].ensure((size_t)m->maxPairs * m->maxFeatures);
+    if (rc != ORBX_OK) return rc;
+    FeatDev A = to_dev(f1);
+    ProjFrameDev F = {f2->keypoints_un, f2->descriptors, nullptr, nullptr, f2->counts, f2->capacity, f2->min_x, f2->min_y, f2->grid_width_inv, f2->grid_height_inv};
+    const int stride = m->maxFeatures;
+    const size_t lds = (size_t)f2->capacity * 4 + 16;
+    if (lds > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", f2->capacity); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_search_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_search_init, dim3((unsigned)nframes), dim3(256), lds, m->stream, A, F, prev_matched_xy, (float)window_size, nn_ratio, check_orientation,
+                       m->matches.p, (int8_t *)m->pb[0].p, m->nmatches.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = nframes; m->lastStride = stride;
+    return ORBX_OK;
+}
+
+
+// host-array form for one frame pair: upload, run, download
+extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_feature_set *f1_host, const orbx_projection_frame *f2_host, const float *prev_matched_xy,
+                                              int window_size, float nn_ratio, int check_orientation, int32_t *matches12, int32_t *nmatches)
+{
+    if (!m || !f1_host || !f2_host || !matches12 || !nmatches) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!f1_host->counts || !f2_host->counts) { orbx_set_error("NULL counts"); return ORBX_ERR_ARG; }
+    const int n1 = f1_host->counts[0], n2 = f2_host->counts[0];
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 <= 0 || n2 <= 0) return ORBX_OK;
+    if (!prev_matched_xy || !f2_host->keypoints_un || !f2_host->descriptors) { orbx_set_error("NULL array"); return ORBX_ERR_ARG; }
+    if (n2 > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n2, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    orbx_feature_set d1;
+    int rc;
+    if ((rc = stage_host(m, 0, f1_host, &d1)) != ORBX_OK) return rc;
+    if ((rc = m->pkp.ensure((size_t)n2)) || (rc = m->hd[1].ensure((size_t)n2 * 32)) || (rc = m->pi32[0].ensure(2)) || (rc = m->pf[1].ensure((size_t)m->maxFeatures * 2)))
+        return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, f2_host->keypoints_un, (size_t)n2 * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[1].p, f2_host->descriptors, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, &n2, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, prev_matched_xy, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+    orbx_projection_frame d2 = *f2_host;
+    d2.keypoints_un = m->pkp.p; d2.descriptors = m->hd[1].p; d2.u_right = nullptr; d2.occupied = nullptr; d2.counts = m->pi32[0].p; d2.capacity = n2; d2.nframes = 1;
+    if ((rc = orbx_search_for_initialization_device(m, &d1, &d2, m->pf[1].p, window_size, nn_ratio, check_orientation)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    ORBX_HIP_CHECK(hipMemcpy(matches12, m->matches.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+static int proj_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjPointsDev &P, int nframes, const float *scale_factors, int nlevels, float th,
+                       float nnratio)
+{
+    if (nframes < 1 || nframes > m->maxPairs) { orbx_set_error("nframes %d outside 1..%d", nframes, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (F.cap < 1 || F.cap > m->maxFeatures || F.cap > 65535 || P.cap < 1) { orbx_set_error("bad capacities (features %d, points %d)", F.cap, P.cap); return ORBX_ERR_CAPACITY; }
+    if (!scale_factors || nlevels < 1 || nlevels > 64) { orbx_set_error("bad scale factor table"); return ORBX_ERR_ARG; }
+    int rc = m->topk64.ensure((size_t)nframes * P.cap * TOPK);
+    if (rc != ORBX_OK) return rc;
+    const int stride = m->maxFeatures;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->scales.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_proj_topk, dim3((unsigned)((P.cap + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, F, P, m->scales.p, th, m->topk64.p);
+    MLAUNCH_CHECK();
+    const size_t lds = (size_t)F.cap * 2 + 16;
+    if (lds > 64 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_proj_greedy, dim3((unsigned)nframes), dim3(256), lds, m->stream, F, P, m->scales.p, th, nnratio, m->topk64.p, m->matches.p,
+                       m->nmatches.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = nframes; m->lastStride = stride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_projection_device(orbx_matcher *m, const orbx_projection_frame *frame, const orbx_projection_points *points,
+                                                const float *scale_factors, int nlevels, float th, float nn_ratio)
+{
+    if (!m || !frame || !points) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!frame->keypoints_un || !frame->descriptors || !frame->u_right || !frame->counts || !points->proj_x || !points->proj_y || !points->proj_xr ||
+        !points->scale_level || !points->view_cos || !points->in_view || !points->descriptors || !points->counts) {
+        orbx_set_error("NULL array in the projection arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ProjFrameDev F = {frame->keypoints_un, frame->descriptors, frame->u_right, frame->occupied, frame->counts, frame->capacity,
+                      frame->min_x, frame->min_y, frame->grid_width_inv, frame->grid_height_inv};
+    ProjPointsDev P = {points->proj_x, points->proj_y, points->proj_xr, points->scale_level, points->view_cos, points->in_view, points->has_observations,
+                       points->descriptors, points->counts, points->capacity};
+    return proj_launch(m, F, P, frame->nframes, scale_factors, nlevels, th, nn_ratio);
+}
+
+// host-array form for one frame: upload, run, download
+extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_projection_frame *fr, const orbx_projection_points *pt, const float *scale_factors,
+                                         int nlevels, float th, float nn_ratio, int32_t *assigned, int32_t *nmatches)
+{
+    if (!m || !fr || !pt || !assigned) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!fr->counts || !pt->counts) { orbx_set_error("NULL counts"); return ORBX_ERR_ARG; }
+    const int n = fr->counts[0], mm = pt->counts[0];
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < n; i++) assigned[i] = -1;
+    if (n <= 0 || mm <= 0) return ORBX_OK;
+    if (n > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    // staging: frame side in pkp / hd[0] / pf[0] / pb[0], point side in pf[1] (5 float arrays) / pi32[1] / pb[1] (in_view, has_obs, descriptors)
+    if ((rc = m->pkp.ensure((size_t)n)) || (rc = m->hd[0].ensure((size_t)n * 32)) || (rc = m->pf[0].ensure((size_t)n)) || (rc = m->pb[0].ensure((size_t)n)) ||
+        (rc = m->pi32[0].ensure(2)) || (rc = m->pf[1].ensure((size_t)mm * 4)) || (rc = m->pi32[1].ensure((size_t)mm)) || (rc = m->pb[1].ensure((size_t)mm * 34)))
+        return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, fr->keypoints_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[0].p, fr->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[0].p, fr->u_right, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (fr->occupied) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[0].p, fr->occupied, (size_t)n, hipMemcpyHostToDevice, st));
+    const int32_t cnt[2] = {n, mm};
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, pt->proj_x, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + mm, pt->proj_y, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 2 * (size_t)mm, pt->proj_xr, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 3 * (size_t)mm, pt->view_cos, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p, pt->scale_level, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p, pt->descriptors, (size_t)mm * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)mm * 32, pt->in_view, (size_t)mm, hipMemcpyHostToDevice, st));
+    if (pt->has_observations) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)mm * 33, pt->has_observations, (size_t)mm, hipMemcpyHostToDevice, st));
+    ProjFrameDev F = {m->pkp.p, m->hd[0].p, m->pf[0].p, fr->occupied ? m->pb[0].p : nullptr, m->pi32[0].p, n, fr->min_x, fr->min_y, fr->grid_width_inv,
+                      fr->grid_height_inv};
+    ProjPointsDev P = {m->pf[1].p, m->pf[1].p + mm, m->pf[1].p + 2 * (size_t)mm, m->pi32[1].p, m->pf[1].p + 3 * (size_t)mm, m->pb[1].p + (size_t)mm * 32,
+                       pt->has_observations ? m->pb[1].p + (size_t)mm * 33 : nullptr, m->pb[1].p, m->pi32[0].p + 1, mm};
+    if ((rc = proj_launch(m, F, P, 1, scale_factors, nlevels, th, nn_ratio)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    ORBX_HIP_CHECK(hipMemcpy(assigned, m->matches.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+static int proj_last_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjLastDev &L, int nframes, const float *scale_factors, int nlevels, float th,
+                            int b_mono, int check_ori)
+{
+    if (nframes < 1 || nframes > m->maxPairs) { orbx_set_error("nframes %d outside 1..%d", nframes, m->maxPairs); return ORBX_ERR_CAPACITY; }
+    if (F.cap < 1 || F.cap > m->maxFeatures || F.cap > 65535 || L.cap < 1 || L.cap > 65535) { orbx_set_error("bad capacities (features %d, last %d)", F.cap, L.cap); return ORBX_ERR_CAPACITY; }
+    if (!scale_factors || nlevels < 1 || nlevels > 64) { orbx_set_error("bad scale factor table"); return ORBX_ERR_ARG; }
+    int rc = m->topk64.ensure((size_t)nframes * L.cap * TOPK);
+    if (rc != ORBX_OK) return rc;
+    const int stride = m->maxFeatures;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->scales.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    const int slot = m->profCount % MATCH_PROF_RING;
+    ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
+    m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_proj_last_topk, dim3((unsigned)((L.cap + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, F, L, m->scales.p, th, b_mono, m->topk64.p);
+    MLAUNCH_CHECK();
+    const size_t lds = (size_t)((F.cap + 15) & ~15) + (size_t)F.cap * 4 + (size_t)L.cap * 4 + 16;
+    if (lds > 160 * 1024) { orbx_set_error("capacities too large for the LDS tile"); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_last_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_proj_last_greedy, dim3((unsigned)nframes), dim3(256), lds, m->stream, F, L, m->scales.p, th, b_mono, check_ori, m->topk64.p,
+                       m->matches.p, m->nmatches.p, stride);
+    MLAUNCH_CHECK();
+    ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
+    m->profCount++;
+    m->lastPairs = nframes; m->lastStride = stride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_projection_last_device(orbx_matcher *m, const orbx_projection_frame *frame, const orbx_projection_last *last,
+                                                     const float *scale_factors, int nlevels, float th, int b_mono, int check_orientation)
+{
+    if (!m || !frame || !last) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!frame->keypoints_un || !frame->descriptors || !frame->u_right || !frame->counts || !last->valid || !last->world_pos || !last->descriptors ||
+        !last->octave || !last->angle || !last->counts || !last->tcw_current || !last->tcw_last) {
+        orbx_set_error("NULL array in the projection arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    ProjFrameDev F = {frame->keypoints_un, frame->descriptors, frame->u_right, frame->occupied, frame->counts, frame->capacity,
+                      frame->min_x, frame->min_y, frame->grid_width_inv, frame->grid_height_inv};
+    ProjLastDev L = {last->valid, last->world_pos, last->descriptors, last->has_observations, last->octave, last->angle, last->counts, last->capacity,
+                     last->tcw_current, last->tcw_last, last->fx, last->fy, last->cx, last->cy, last->mbf, last->mb, last->max_x, last->max_y};
+    return proj_last_launch(m, F, L, frame->nframes, scale_factors, nlevels, th, b_mono, check_orientation);
+}
+
+extern "C" int orbx_search_by_projection_last(orbx_matcher *m, const orbx_projection_frame *fr, const orbx_projection_last *ls, const float *scale_factors,
+                                              int nlevels, float th, int b_mono, int check_orientation, int32_t *assigned, int32_t *nmatches)
+{
+    if (!m || !fr || !ls || !assigned) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!fr->counts || !ls->counts) { orbx_set_error("NULL counts"); return ORBX_ERR_ARG; }
+    const int n = fr->counts[0], nl = ls->counts[0];
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < n; i++) assigned[i] = -1;
+    if (n <= 0 || nl <= 0) return ORBX_OK;
+    if (n > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    // staging: frame side as in orbx_search_by_projection; last side: pf[1] = pos(3) | angle(1) | tcw cur(16) | tcw last(16), pi32[1] = octave,
+    // pb[1] = descriptors(32) | valid(1) | has_obs(1)
+    if ((rc = m->pkp.ensure((size_t)n)) || (rc = m->hd[0].ensure((size_t)n * 32)) || (rc = m->pf[0].ensure((size_t)n)) || (rc = m->pb[0].ensure((size_t)n)) ||
+        (rc = m->pi32[0].ensure(2)) || (rc = m->pf[1].ensure((size_t)nl * 4 + 32)) || (rc = m->pi32[1].ensure((size_t)nl)) || (rc = m->pb[1].ensure((size_t)nl * 34)))
+        return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, fr->keypoints_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[0].p, fr->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[0].p, fr->u_right, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (fr->occupied) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[0].p, fr->occupied, (size_t)n, hipMemcpyHostToDevice, st));
+    const int32_t cnt[2] = {n, nl};
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+    float *pf = m->pf[1].p;
+    ORBX_HIP_CHECK(hipMemcpyAsync(pf, ls->world_pos, (size_t)nl * 12, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(pf + 3 * (size_t)nl, ls->angle, (size_t)nl * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(pf + 4 * (size_t)nl, ls->tcw_current, 64, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(pf + 4 * (size_t)nl + 16, ls->tcw_last, 64, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p, ls->octave, (size_t)nl * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p, ls->descriptors, (size_t)nl * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)nl * 32, ls->valid, (size_t)nl, hipMemcpyHostToDevice, st));
+    if (ls->has_observations) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)nl * 33, ls->has_observations, (size_t)nl, hipMemcpyHostToDevice, st));
+    ProjFrameDev F = {m->pkp.p, m->hd[0].p, m->pf[0].p, fr->occupied ? m->pb[0].p : nullptr, m->pi32[0].p, n, fr->min_x, fr->min_y, fr->grid_width_inv,
+                      fr->grid_height_inv};
+    ProjLastDev L = {m->pb[1].p + (size_t)nl * 32, pf, m->pb[1].p, ls->has_observations ? m->pb[1].p + (size_t)nl * 33 : nullptr, m->pi32[1].p,
+                     pf + 3 * (size_t)nl, m->pi32[0].p + 1, nl, pf + 4 * (size_t)nl, pf + 4 * (size_t)nl + 16, ls->fx, ls->fy, ls->cx, ls->cy, ls->mbf, ls->mb,
+                     ls->max_x, ls->max_y};
+    if ((rc = proj_last_launch(m, F, L, 1, scale_factors, nlevels, th, b_mono, check_orientation)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    ORBX_HIP_CHECK(hipMemcpy(assigned, m->matches.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
