@@ -536,6 +536,13 @@ void orbx_lba_destroy(orbx_lba *h);
  * between LM trials, like g2o's forceStopFlag; may be NULL. */
 int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *problem, const volatile uint8_t *stop_flag,
                    orbx_lba_result *result);
+/* Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (reference src/Optimizer.cc:55-84, 86-360; Tracking::
+ * CreateInitialMapMonocular with 20 iterations, LoopClosing::RunGlobalBundleAdjustment with 10): the same graph
+ * and solver as the local window, one optimize(iterations) with Huber kernels iff robust, no outlier pass.
+ * problem: every non-bad KeyFrame (fixed[k] = mnId == 0) and MapPoint with its observations; result as
+ * orbx_lba_solve (edge_outlier / edge_chi2 = the final classification, informative only here). */
+int orbx_bundle_adjustment(orbx_lba *h, const orbx_lba_problem *problem, int iterations, int robust,
+                           const volatile uint8_t *stop_flag, orbx_lba_result *result);
 /* Kernel milliseconds (HIP events) spent inside the last orbx_lba_solve and FP64 flop count. */
 int orbx_lba_last_timing(orbx_lba *h, float *device_ms, double *flops);
 

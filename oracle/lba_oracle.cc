@@ -432,10 +432,11 @@ int optimize(Problem &p, int iterations, const volatile uint8_t *stop, Stats *st
 // intr:  K x 5 float {fx,fy,cx,cy,bf};  points: P x 3 float;  edge_obs: E x 3 float {u,v,uR (<0: monocular)}
 // Outputs: poses_out K x 16 float, points_out P x 3 float, edge_chi2 E double (e->chi2() as LocalBundleAdjustment
 // reads it at :921-958), edge_outlier E (chi2 > 5.991/7.815 or depth <= 0), stats[8] doubles.
-LO_API int lo_local_bundle_adjustment(int K, const float *poses, const uint8_t *fixed, const float *intr, int P, const float *points, int E,
-                                      const int32_t *edge_point, const int32_t *edge_kf, const float *edge_obs, const float *edge_inv_sigma2,
-                                      const volatile uint8_t *stop, float *poses_out, float *points_out, double *edge_chi2_out,
-                                      uint8_t *edge_outlier, double *stats)
+// iters1 LM iterations (Huber kernels when robust1); with secondStage the LocalBundleAdjustment continuation: outlier
+// classification, then 10 iterations without kernels on the inliers.
+static int run_ba(int K, const float *poses, const uint8_t *fixed, const float *intr, int P, const float *points, int E, const int32_t *edge_point,
+                  const int32_t *edge_kf, const float *edge_obs, const float *edge_inv_sigma2, const volatile uint8_t *stop, int iters1, bool robust1,
+                  bool secondStage, float *poses_out, float *points_out, double *edge_chi2_out, uint8_t *edge_outlier, double *stats)
 {
     Problem p;
     p.K = K; p.P = P; p.E = E;
@@ -461,9 +462,9 @@ LO_API int lo_local_bundle_adjustment(int K, const float *poses, const uint8_t *
     p.dsqrMono = (float)(p.deltaMono * p.deltaMono); p.dsqrStereo = (float)(p.deltaStereo * p.deltaStereo);
     Stats s1 = {0, 0, 0, 0, 0}, s2 = {0, 0, 0, 0, 0};
     if (!(stop && *stop)) {
-        p.robust = true;
-        optimize(p, 5, stop, &s1);                                   // :863-864
-        if (!(stop && *stop)) {
+        p.robust = robust1;
+        optimize(p, iters1, stop, &s1);                              // :863-864 (LBA), :247 (BundleAdjustment)
+        if (secondStage && !(stop && *stop)) {
             for (int e = 0; e < E; e++) {                            // :880-912
                 const double th = p.stereo[(size_t)e] ? 7.815 : 5.991;
                 if (edge_chi2(p, e) > th || !depth_positive(p, e)) p.level[(size_t)e] = 1;
@@ -490,6 +491,26 @@ LO_API int lo_local_bundle_adjustment(int K, const float *poses, const uint8_t *
         stats[4] = s2.iters; stats[5] = s2.trials; stats[6] = s2.chi0; stats[7] = s2.chi1;
     }
     return 0;
+}
+
+LO_API int lo_local_bundle_adjustment(int K, const float *poses, const uint8_t *fixed, const float *intr, int P, const float *points, int E,
+                                      const int32_t *edge_point, const int32_t *edge_kf, const float *edge_obs, const float *edge_inv_sigma2,
+                                      const volatile uint8_t *stop, float *poses_out, float *points_out, double *edge_chi2_out,
+                                      uint8_t *edge_outlier, double *stats)
+{
+    return run_ba(K, poses, fixed, intr, P, points, E, edge_point, edge_kf, edge_obs, edge_inv_sigma2, stop, 5, true, true, poses_out, points_out, edge_chi2_out,
+                  edge_outlier, stats);
+}
+
+// Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (src/Optimizer.cc:55-84, 86-360): the same graph, ONE optimize(nIterations)
+// with Huber kernels iff bRobust (:175-180, 201-206), no outlier pass.  Same array conventions as above.
+LO_API int lo_bundle_adjustment(int K, const float *poses, const uint8_t *fixed, const float *intr, int P, const float *points, int E,
+                                const int32_t *edge_point, const int32_t *edge_kf, const float *edge_obs, const float *edge_inv_sigma2,
+                                const volatile uint8_t *stop, int iterations, int robust, float *poses_out, float *points_out, double *edge_chi2_out,
+                                uint8_t *edge_outlier, double *stats)
+{
+    return run_ba(K, poses, fixed, intr, P, points, E, edge_point, edge_kf, edge_obs, edge_inv_sigma2, stop, iterations, robust != 0, false, poses_out, points_out,
+                  edge_chi2_out, edge_outlier, stats);
 }
 
 // test hooks: error and analytic Jacobians of one edge at a given state (for the central-difference check)

@@ -939,6 +939,72 @@ ORBSLAM_API int orbslam_local_ba(int K, const float *poses, const float *cam5, i
     return 0;
 }
 
+// Optimizer::GlobalBundleAdjustemnt on a real Map built like orbslam_local_ba's.  nLoopKF == 0: results are read from
+// GetPose() / GetWorldPos(); otherwise from mTcwGBA / mPosGBA (and the live estimates must be untouched: `untouched` = 1).
+ORBSLAM_API int orbslam_global_ba(int K, const float *poses, const float *cam5, int P, const float *points, int E, const float *obs, const float *scaleFactors,
+                                  int nlevels, int width, int height, int iterations, int robust, int nLoopKF, float *poses_out, float *points_out,
+                                  int *untouched)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {cam5[0], cam5[1], cam5[2], cam5[3], cam5[4], width, height};
+    KeyFrame::nNextId = 0;
+    std::vector<std::vector<int> > kfObs((size_t)K);
+    for (int e = 0; e < E; e++) kfObs[(size_t)obs[6 * (size_t)e + 1]].push_back(e);
+    std::vector<KeyFrame *> kfs((size_t)K);
+    std::vector<int> obsIdx((size_t)E);
+    for (int k = 0; k < K; k++) {
+        const int n = (int)kfObs[(size_t)k].size();
+        std::vector<float> kps((size_t)(n > 0 ? n : 1) * 7, 0.f);
+        std::vector<uint8_t> desc((size_t)(n > 0 ? n : 1) * 32, 0);
+        for (int i = 0; i < n; i++) {
+            const float *o = obs + 6 * (size_t)kfObs[(size_t)k][(size_t)i];
+            float *kp = &kps[7 * (size_t)i];
+            kp[0] = o[2]; kp[1] = o[3]; kp[2] = 31.f; kp[3] = 0.f; kp[4] = 20.f; kp[5] = o[5]; kp[6] = -1.f;
+            obsIdx[(size_t)kfObs[(size_t)k][(size_t)i]] = i;
+        }
+        Frame F;
+        fill_frame(F, kps.data(), desc.data(), n, nullptr, cam, scaleFactors, nlevels);
+        for (int i = 0; i < n; i++) F.mvuRight[(size_t)i] = obs[6 * (size_t)kfObs[(size_t)k][(size_t)i] + 4];
+        cv::Mat T(4, 4, CV_32F);
+        memcpy(T.data, poses + 16 * (size_t)k, 64);
+        F.SetPose(T);
+        kfs[(size_t)k] = new KeyFrame(F, &map, (KeyFrameDatabase *)nullptr);
+        map.AddKeyFrame(kfs[(size_t)k]);
+    }
+    std::vector<MapPoint *> mps((size_t)P, (MapPoint *)nullptr);
+    for (int e = 0; e < E; e++) {
+        const int l = (int)obs[6 * (size_t)e], k = (int)obs[6 * (size_t)e + 1];
+        if (!mps[(size_t)l]) {
+            cv::Mat pos(3, 1, CV_32F);
+            memcpy(pos.data, points + 3 * (size_t)l, 12);
+            mps[(size_t)l] = new MapPoint(pos, kfs[(size_t)k], &map);
+            map.AddMapPoint(mps[(size_t)l]);
+        }
+        mps[(size_t)l]->AddObservation(kfs[(size_t)k], (size_t)obsIdx[(size_t)e]);
+        kfs[(size_t)k]->AddMapPoint(mps[(size_t)l], (size_t)obsIdx[(size_t)e]);
+    }
+    Optimizer::GlobalBundleAdjustemnt(&map, iterations, (bool *)nullptr, (unsigned long)nLoopKF, robust != 0);
+    *untouched = 1;
+    for (int k = 0; k < K; k++) {
+        const cv::Mat T = nLoopKF == 0 ? kfs[(size_t)k]->GetPose() : kfs[(size_t)k]->mTcwGBA;
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) poses_out[16 * (size_t)k + 4 * r + c] = T.at<float>(r, c);
+        if (nLoopKF != 0) {
+            const cv::Mat L = kfs[(size_t)k]->GetPose();
+            for (int i = 0; i < 16; i++) if (L.at<float>(i / 4, i % 4) != poses[16 * (size_t)k + i]) *untouched = 0;
+            if (kfs[(size_t)k]->mnBAGlobalForKF != (unsigned long)nLoopKF) *untouched = 0;
+        }
+    }
+    for (int l = 0; l < P; l++) {
+        if (!mps[(size_t)l]) { memcpy(points_out + 3 * (size_t)l, points + 3 * (size_t)l, 12); continue; }
+        const cv::Mat X = nLoopKF == 0 ? mps[(size_t)l]->GetWorldPos() : mps[(size_t)l]->mPosGBA;
+        for (int i = 0; i < 3; i++) points_out[3 * (size_t)l + i] = X.at<float>(i);
+    }
+    for (int l = 0; l < P; l++) delete mps[(size_t)l];
+    for (int k = 0; k < K; k++) delete kfs[(size_t)k];
+    return 0;
+}
+
 // Optimizer::PoseOptimization on a real Frame whose features all carry MapPoints.
 // kobs: n rows {u, v, uR (<0 mono), octave}.  Returns the function's return value.
 ORBSLAM_API int orbslam_pose_optimization(const float *pose16, const float *cam5, int n, const float *Xw, const float *kobs, const float *scaleFactors,

@@ -924,7 +924,7 @@ class Optimizer:
         except Exception:
             pass
 
-    def LocalBundleAdjustment(self, w, stop_flag=None):
+    def LocalBundleAdjustment(self, w, stop_flag=None, iterations=None, robust=True):
         K, P, E = w["K"], w["P"], w["E"]
         arrs = {k: np.ascontiguousarray(w[k]) for k in ("poses", "fixed", "intr", "points", "edge_point", "edge_kf", "edge_obs", "edge_inv_sigma2")}
         prob = LbaProblem(K, arrs["poses"].ctypes.data, arrs["fixed"].ctypes.data, arrs["intr"].ctypes.data, P, arrs["points"].ctypes.data, E,
@@ -935,8 +935,16 @@ class Optimizer:
         outl = np.zeros(E, np.uint8)
         res = LbaResult(poses.ctypes.data, points.ctypes.data, chi2.ctypes.data, outl.ctypes.data)
         stop = None if stop_flag is None else stop_flag.ctypes.data_as(ctypes.c_void_p)
-        _check(self._L.orbx_lba_solve(self._h, ctypes.byref(prob), stop, ctypes.byref(res)))
+        if iterations is None:
+            _check(self._L.orbx_lba_solve(self._h, ctypes.byref(prob), stop, ctypes.byref(res)))
+        else:
+            self._L.orbx_bundle_adjustment.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+            _check(self._L.orbx_bundle_adjustment(self._h, ctypes.byref(prob), int(iterations), 1 if robust else 0, stop, ctypes.byref(res)))
         return dict(poses=poses, points=points, chi2=chi2, outlier=outl, stats=np.array(list(res.stats)))
+
+    def BundleAdjustment(self, w, iterations=5, robust=True, stop_flag=None):
+        """Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (reference src/Optimizer.cc:55-360) on the same flat problem layout."""
+        return self.LocalBundleAdjustment(w, stop_flag, iterations=iterations, robust=robust)
 
     def last_timing(self):
         ms = ctypes.c_float()

@@ -1297,7 +1297,9 @@ int optimize(Ctx &c, int iterations, double stats[4])
 
 }  // namespace
 
-extern "C" int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_t *stop, orbx_lba_result *res)
+// iters1 LM iterations (Huber kernels when robust1); with secondStage the LocalBundleAdjustment continuation (outlier
+// classification + 10 iterations without kernels on the inliers)
+static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_t *stop, orbx_lba_result *res, int iters1, bool robust1, bool secondStage)
 {
     if (!h || !p || !res || !res->poses || !res->points || !res->edge_outlier) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     const int K = p->num_keyframes, P = p->num_points, E = p->num_edges;
@@ -1388,9 +1390,9 @@ extern "C" int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *p, const vola
     int rc = ORBX_OK;
     std::vector<uint8_t> flag((size_t)E, 0);
     if (!(stop && *stop)) {
-        c.robust = 1;
-        if ((rc = optimize(c, 5, res->stats)) != ORBX_OK) return rc;       // :863-864
-        if (!(stop && *stop)) {
+        c.robust = robust1 ? 1 : 0;
+        if ((rc = optimize(c, iters1, res->stats)) != ORBX_OK) return rc;       // :863-864 (LBA), :247 (BundleAdjustment)
+        if (secondStage && !(stop && *stop)) {
             if ((rc = classify(flag, nullptr)) != ORBX_OK) return rc;        // :880-912
             for (int e = 0; e < E; e++) if (flag[(size_t)e]) c.level[(size_t)e] = 1;
             c.robust = 0;
@@ -1410,6 +1412,17 @@ extern "C" int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *p, const vola
     }
     for (int i = 0; i < 3 * P; i++) res->points[i] = (float)pt[(size_t)i];
     return ORBX_OK;
+}
+
+extern "C" int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_t *stop, orbx_lba_result *res)
+{
+    return lba_run(h, p, stop, res, 5, true, true);
+}
+
+extern "C" int orbx_bundle_adjustment(orbx_lba *h, const orbx_lba_problem *p, int iterations, int robust, const volatile uint8_t *stop, orbx_lba_result *res)
+{
+    if (iterations < 0) { orbx_set_error("negative iteration count"); return ORBX_ERR_ARG; }
+    return lba_run(h, p, stop, res, iterations, robust != 0, false);
 }
 
 // ---- PoseOptimization: its own small handle (stream + staging), batch of independent frames ----

@@ -3,6 +3,8 @@
 //
 //     void Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*)     src/Optimizer.cc:629-997
 //     int  Optimizer::PoseOptimization(Frame*)                           src/Optimizer.cc:363-605
+//     void Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust)   src/Optimizer.cc:86-360
+//     void Optimizer::GlobalBundleAdjustemnt(pMap, ...)                  src/Optimizer.cc:55-84
 // The window / correspondence collection and the write-back under the map mutex follow the reference
 // line by line; the g2o block in between (graph construction, 5 + 10 Levenberg iterations with the
 // Schur complement, outlier re-classification) is one orbx_lba_solve / orbx_pose_optimization call on
@@ -17,7 +19,8 @@
 #include "Optimizer.h"   // the reference's include/Optimizer.h; shim/Optimizer.h where g2o / Eigen are not installed
 #include "orbx.h"
 
-static unsigned long gLbaCalls = 0, gPoseOptCalls = 0;
+static unsigned long gLbaCalls = 0, gPoseOptCalls = 0, gBaCalls = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_bundle_adjustment_calls(void) { return gBaCalls; }
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_lba_calls(void) { return gLbaCalls; }
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_pose_optimization_calls(void) { return gPoseOptCalls; }
 
@@ -156,6 +159,102 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
         for (int i = 0; i < 3; i++) X.at<float>(i) = pointsOut[3 * l + i];
         mps[l]->SetWorldPos(X);
         mps[l]->UpdateNormalAndDepth();
+    }
+}
+
+void Optimizer::GlobalBundleAdjustemnt(Map *pMap, int nIterations, bool *pbStopFlag, const unsigned long nLoopKF, const bool bRobust)
+{
+    std::vector<KeyFrame *> vpKFs = pMap->GetAllKeyFrames();       // :79-82
+    std::vector<MapPoint *> vpMP = pMap->GetAllMapPoints();
+    BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust);
+}
+
+void Optimizer::BundleAdjustment(const std::vector<KeyFrame *> &vpKFs, const std::vector<MapPoint *> &vpMP, int nIterations, bool *pbStopFlag,
+                                 const unsigned long nLoopKF, const bool bRobust)
+{
+    __atomic_add_fetch(&gBaCalls, 1, __ATOMIC_RELAXED);
+    std::vector<bool> vbNotIncludedMP(vpMP.size());
+    // ---- vertices: every non-bad KeyFrame, keyframe 0 fixed (:120-132)
+    std::vector<KeyFrame *> kfs;
+    std::map<KeyFrame *, int> kfIndex;
+    std::vector<uint8_t> fixed;
+    long unsigned int maxKFid = 0;
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+        KeyFrame *pKF = vpKFs[i];
+        if (pKF->isBad()) continue;
+        kfIndex[pKF] = (int)kfs.size(); kfs.push_back(pKF); fixed.push_back(pKF->mnId == 0 ? 1 : 0);
+        if (pKF->mnId > maxKFid) maxKFid = pKF->mnId;
+    }
+    std::vector<float> poses(kfs.size() * 16), intr(kfs.size() * 5);
+    for (size_t k = 0; k < kfs.size(); k++) {
+        const cv::Mat Tcw = kfs[k]->GetPose();
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) poses[16 * k + 4 * r + c] = Tcw.at<float>(r, c);
+        const float in5[5] = {kfs[k]->fx, kfs[k]->fy, kfs[k]->cx, kfs[k]->cy, kfs[k]->mbf};
+        for (int i = 0; i < 5; i++) intr[5 * k + i] = in5[i];
+    }
+    // ---- points and edges in optimizer.addEdge order (:137-232); a point without edges is left out (:233-241)
+    std::vector<MapPoint *> mps;
+    std::vector<float> points, obs, invS2;
+    std::vector<int32_t> ep, ek;
+    for (size_t i = 0; i < vpMP.size(); i++) {
+        MapPoint *pMP = vpMP[i];
+        vbNotIncludedMP[i] = true;
+        if (pMP->isBad()) continue;
+        const std::map<KeyFrame *, size_t> observations = pMP->GetObservations();
+        int nEdges = 0;
+        const int l = (int)mps.size();
+        for (std::map<KeyFrame *, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); mit++) {
+            KeyFrame *pKF = mit->first;
+            if (pKF->isBad() || pKF->mnId > maxKFid) continue;                                   // :156-157
+            std::map<KeyFrame *, int>::const_iterator kit = kfIndex.find(pKF);
+            if (kit == kfIndex.end()) continue;   // (the reference would dereference a missing vertex here; vpKFs always holds the observers)
+            nEdges++;
+            const cv::KeyPoint &kpUn = pKF->mvKeysUn[mit->second];
+            ep.push_back((int32_t)l); ek.push_back(kit->second);
+            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(pKF->mvuRight[mit->second]);   // < 0: monocular edge (:164)
+            invS2.push_back(pKF->mvInvLevelSigma2[kpUn.octave]);
+        }
+        if (nEdges == 0) continue;
+        vbNotIncludedMP[i] = false;
+        const cv::Mat X = pMP->GetWorldPos();
+        for (int k = 0; k < 3; k++) points.push_back(X.at<float>(k));
+        mps.push_back(pMP);
+    }
+    if (kfs.empty() || mps.empty() || ep.empty()) return;
+    const int K = (int)kfs.size(), P = (int)mps.size(), E = (int)ep.size();
+    if (!tLba.h || K > tLba.kf || P > tLba.pt || E > tLba.ed) {
+        if (tLba.h) { orbx_lba_destroy(tLba.h); tLba.h = 0; }
+        tLba.kf = std::max(2 * K, 64); tLba.pt = std::max(2 * P, 4096); tLba.ed = std::max(2 * E, 65536);
+        if (orbx_lba_create(0, tLba.kf, tLba.pt, tLba.ed, &tLba.h) != ORBX_OK) Fail("BundleAdjustment");
+    }
+    orbx_lba_problem prob = {K, &poses[0], &fixed[0], &intr[0], P, &points[0], E, &ep[0], &ek[0], &obs[0], &invS2[0]};
+    std::vector<float> posesOut(poses.size()), pointsOut(points.size());
+    std::vector<uint8_t> outlier((size_t)E);
+    orbx_lba_result res = {&posesOut[0], &pointsOut[0], NULL, &outlier[0], {0}};
+    if (orbx_bundle_adjustment(tLba.h, &prob, nIterations, bRobust ? 1 : 0, (const volatile uint8_t *)pbStopFlag, &res) != ORBX_OK) Fail("BundleAdjustment");
+    // ---- write-back (:252-302)
+    for (size_t k = 0; k < kfs.size(); k++) {
+        KeyFrame *pKF = kfs[k];
+        if (nLoopKF == 0) pKF->SetPose(PoseMat(&posesOut[16 * k]));
+        else {
+            pKF->mTcwGBA.create(4, 4, CV_32F);
+            PoseMat(&posesOut[16 * k]).copyTo(pKF->mTcwGBA);
+            pKF->mnBAGlobalForKF = nLoopKF;
+        }
+    }
+    for (size_t l = 0; l < mps.size(); l++) {
+        MapPoint *pMP = mps[l];
+        cv::Mat X(3, 1, CV_32F);
+        for (int i = 0; i < 3; i++) X.at<float>(i) = pointsOut[3 * l + i];
+        if (nLoopKF == 0) {
+            pMP->SetWorldPos(X);
+            pMP->UpdateNormalAndDepth();
+        } else {
+            pMP->mPosGBA.create(3, 1, CV_32F);
+            X.copyTo(pMP->mPosGBA);
+            pMP->mnBAGlobalForKF = nLoopKF;
+        }
     }
 }
 

@@ -206,6 +206,20 @@ def local_bundle_adjustment(orc, w, stop=None):
     return dict(poses=poses_out, points=points_out, chi2=chi2, outlier=outl, stats=stats)
 
 
+def bundle_adjustment(orc, w, iterations, robust, stop=None):
+    """Restatement of Optimizer::BundleAdjustment (oracle/lba_oracle.cc:lo_bundle_adjustment)."""
+    lib = orc.lib
+    K, P, E = w["K"], w["P"], w["E"]
+    poses_out, points_out = np.zeros((K, 16), np.float32), np.zeros((P, 3), np.float32)
+    chi2, outl, stats = np.zeros(E, np.float64), np.zeros(E, np.uint8), np.zeros(8, np.float64)
+    lib.lo_bundle_adjustment.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5 + \
+                                        [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
+    lib.lo_bundle_adjustment(K, _p(w["poses"]), _p(w["fixed"]), _p(w["intr"]), P, _p(w["points"]), E, _p(w["edge_point"]), _p(w["edge_kf"]),
+                             _p(w["edge_obs"]), _p(w["edge_inv_sigma2"]), None if stop is None else _p(stop), int(iterations), 1 if robust else 0,
+                             _p(poses_out), _p(points_out), _p(chi2), _p(outl), _p(stats))
+    return dict(poses=poses_out, points=points_out, chi2=chi2, outlier=outl, stats=stats)
+
+
 # ---- the UNMODIFIED reference matcher / Frame / KeyFrame / MapPoint / DBoW2 sources compiled
 # ---- against oracle/cvshim (oracle/refslam_wrap.cc -> oracle/_ref/liborbslam.so)
 SLAM_SO = ROOT / "oracle" / "_ref" / "liborbslam.so"

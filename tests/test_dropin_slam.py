@@ -352,6 +352,41 @@ def test_local_bundle_adjustment_dropin_on_a_real_map(orbx, oracle, seed, stereo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,stereo,iters,robust,loop_kf", [(8, 0.0, 20, True, 0), (9, 0.4, 10, False, 7)])
+def test_global_bundle_adjustment_dropin_on_a_real_map(orbx, oracle, seed, stereo, iters, robust, loop_kf):
+    """Optimizer::GlobalBundleAdjustemnt / BundleAdjustment (shim/Optimizer_hip.cc) on a real Map, against the CPU restatement of the
+    same graph; with nLoopKF != 0 the results go to mTcwGBA / mPosGBA and the live estimates stay untouched (src/Optimizer.cc:262-300)."""
+    orbx.load_library()
+    hip = oracle_lib.slam_hip_lib()
+    hip.orbx_shim_bundle_adjustment_calls.restype = ctypes.c_ulong
+    before = hip.orbx_shim_bundle_adjustment_calls()
+    w = orbx.lba_synth.make_window(K=14, P=900, seed=seed, max_obs=6, n_fixed=0, stereo_frac=stereo)
+    K, P, E = w["K"], w["P"], w["E"]
+    sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    octv = _octaves(w["edge_inv_sigma2"])
+    obs6 = np.ascontiguousarray(np.stack([w["edge_point"], w["edge_kf"], w["edge_obs"][:, 0], w["edge_obs"][:, 1], w["edge_obs"][:, 2], octv], 1), np.float32)
+    cam5 = np.ascontiguousarray(w["intr"][0], np.float32)
+    poses_out, points_out = np.zeros((K, 16), np.float32), np.zeros((P, 3), np.float32)
+    untouched = ctypes.c_int(0)
+    _p = oracle_lib._p
+    ci, vp = ctypes.c_int, ctypes.c_void_p
+    hip.orbslam_global_ba.argtypes = [ci, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp]
+    hip.orbslam_global_ba(K, _p(w["poses"]), _p(cam5), P, _p(w["points"]), E, _p(obs6), _p(sf), 8, 640, 480, iters, 1 if robust else 0, loop_kf, _p(poses_out),
+                          _p(points_out), ctypes.byref(untouched))
+    assert hip.orbx_shim_bundle_adjustment_calls() - before == 1 and untouched.value == 1
+    # the same graph for the restatement: keyframe 0 fixed (mnId == 0), float32 information as fill_frame builds it
+    w2 = dict(w)
+    fixed = np.zeros(K, np.uint8); fixed[0] = 1
+    w2["fixed"] = fixed
+    w2["edge_inv_sigma2"] = (np.float32(1.0) / (sf[octv] * sf[octv])).astype(np.float32)
+    want = oracle_lib.bundle_adjustment(oracle, w2, iters, robust)
+    seen = np.zeros(P, bool); seen[w["edge_point"]] = True
+    assert np.abs(poses_out.astype(np.float64) - want["poses"]).max() <= 1e-5
+    assert np.abs(points_out[seen].astype(np.float64) - want["points"][seen]).max() <= 1e-5
+    assert np.abs(want["poses"] - w["poses"]).max() > 1e-3                      # the optimisation did move things
+
+
+@pytest.mark.gpu
 def test_pose_optimization_dropin_on_a_real_frame(orbx, oracle):
     from test_pose_optimization import make_frame
     orbx.load_library()

@@ -149,3 +149,31 @@ def test_lba_hip_matches_oracle(orbx, oracle, cfg):
     g2 = opt.LocalBundleAdjustment(w, stop_flag=stop)
     assert g2["stats"][0] == 0 and np.allclose(g2["points"], w["points"])
     opt.close()
+
+
+def test_oracle_bundle_adjustment_protocol(orbx, oracle):
+    """Optimizer::BundleAdjustment = one optimize(nIterations), Huber kernels iff bRobust, no second stage
+    (reference src/Optimizer.cc:86-360)."""
+    w = orbx.lba_synth.make_window(K=12, P=400, seed=9, n_fixed=1)
+    r = oracle_lib.bundle_adjustment(oracle, w, 20, True)
+    s = r["stats"]
+    assert 1 <= s[0] <= 20 and s[4] == 0 and s[5] == 0 and s[3] < s[2]
+    r5 = oracle_lib.bundle_adjustment(oracle, w, 5, True)
+    lba = oracle_lib.local_bundle_adjustment(oracle, w)
+    assert r5["stats"][0] == lba["stats"][0] and np.isclose(r5["stats"][3], lba["stats"][3])    # identical to LBA's first stage
+    nr = oracle_lib.bundle_adjustment(oracle, w, 10, False)
+    assert nr["stats"][2] > r["stats"][2]            # without kernels the gross outliers count fully in chi2
+    r0 = oracle_lib.bundle_adjustment(oracle, w, 0, True)
+    assert np.allclose(r0["points"], w["points"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,iters,robust", [(dict(K=50, P=5000, seed=12345, n_fixed=1), 10, True), (dict(K=20, P=1500, seed=7, stereo_frac=0.5, n_fixed=1), 20, False),
+                                              (dict(K=8, P=200, seed=2, stereo_frac=1.0, n_fixed=1), 20, True)])
+def test_bundle_adjustment_hip_matches_oracle(orbx, oracle, cfg, iters, robust):
+    w = orbx.lba_synth.make_window(**cfg)
+    want = oracle_lib.bundle_adjustment(oracle, w, iters, robust)
+    opt = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000)
+    got = opt.BundleAdjustment(w, iters, robust)
+    _compare(got, want, w)
+    opt.close()
