@@ -306,6 +306,41 @@ int orbx_search_by_projection(orbx_matcher *m, const orbx_projection_frame *fram
                               const orbx_projection_points *points_host, const float *scale_factors, int nlevels,
                               float th, float nn_ratio, int32_t *assigned, int32_t *nmatches);
 
+/* Frame::isInFrustum(pMP, viewingCosLimit) (reference src/Frame.cc:608-742) for a list of map points per frame: the
+ * loop of Tracking::SearchLocalPoints (src/Tracking.cc:1580-1613) that prepares SearchByProjection(F, vpMapPoints, th).
+ * Outputs are laid out like orbx_projection_points (point i of frame f at f*capacity + i), so that
+ * orbx_frustum_results_device feeds orbx_search_by_projection_device without a host round trip:
+ * in_view = mbTrackInView, proj_x / proj_y / proj_xr = mTrackProjX / Y / XR, scale_level = mnTrackScaleLevel,
+ * view_cos = mTrackViewCos (only written where in_view). */
+typedef struct orbx_frustum_frame {
+    const float *tcw;                 /* [16] per frame: mTcw row-major (mRcw, mtcw, mOw follow as in Frame::UpdatePoseMatrices) */
+    float fx, fy, cx, cy, mbf;        /* Frame statics                                                             */
+    float min_x, max_x, min_y, max_y; /* mnMinX .. mnMaxY                                                          */
+    const float *ratio_thresholds;    /* HOST [nlevels-1] from orbx_predict_scale_thresholds(mfLogScaleFactor, ..) */
+    int nlevels;                      /* mnScaleLevels                                                             */
+    int nframes;
+} orbx_frustum_frame;
+typedef struct orbx_map_points {
+    const float *world_pos;     /* [3] GetWorldPos()                                                                */
+    const float *normal;        /* [3] GetNormal()                                                                  */
+    const float *max_distance;  /* mfMaxDistance (GetMaxDistanceInvariance()/1.2f)                                  */
+    const float *min_distance;  /* mfMinDistance                                                                    */
+    const int32_t *counts;      /* points per frame                                                                 */
+    int capacity;
+} orbx_map_points;
+/* MapPoint::PredictScale (src/MapPoint.cc:571-586) without a device logarithm: thresholds[k] = the largest float ratio
+ * mfMaxDistance/dist that the reference's ceil(log(ratio)/mfLogScaleFactor) still maps to level <= k (k = 0..nlevels-2),
+ * tabulated on the host with the libm log the reference itself calls. */
+int orbx_predict_scale_thresholds(float log_scale_factor, int nlevels, float *thresholds);
+int orbx_is_in_frustum_device(orbx_matcher *m, const orbx_frustum_frame *frame, const orbx_map_points *points,
+                              float viewing_cos_limit);
+int orbx_frustum_results_device(orbx_matcher *m, const float **proj_x, const float **proj_y, const float **proj_xr,
+                                const int32_t **scale_level, const float **view_cos, const uint8_t **in_view);
+/* Host-array form for one frame (points->counts[0] points). */
+int orbx_is_in_frustum(orbx_matcher *m, const orbx_frustum_frame *frame_host, const orbx_map_points *points_host,
+                       float viewing_cos_limit, float *proj_x, float *proj_y, float *proj_xr, int32_t *scale_level,
+                       float *view_cos, uint8_t *in_view);
+
 /* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th,
  * const bool bMono) (src/ORBmatcher.cc:1569-1728; Tracking::TrackWithMotionModel,
  * src/Tracking.cc:1433-1441).  Last-frame side, feature i of frame f at f*capacity + i: */

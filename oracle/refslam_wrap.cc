@@ -667,6 +667,48 @@ ORBSLAM_API int orbslam_search_for_initialization(const float *kps1, const uint8
     return n;
 }
 
+// Frame::isInFrustum (src/Frame.cc:608-742) on a real Frame and real MapPoints (created from a source frame with pose
+// TcwSrc: that fixes their normal and distance range).  Outputs per point: inView, the mTrack* fields, and the point's
+// normal / mfMaxDistance / mfMinDistance as the reference computed them (inputs of the device version).
+namespace {
+struct MapPointAccess : public MapPoint {
+    static float MaxD(MapPoint *p) { return static_cast<MapPointAccess *>(p)->mfMaxDistance; }
+    static float MinD(MapPoint *p) { return static_cast<MapPointAccess *>(p)->mfMinDistance; }
+};
+}  // namespace
+ORBSLAM_API int orbslam_is_in_frustum(const float *Tcw, const float *TcwSrc, const float *srcKps, const float *pos, int n, float cosLimit, uint8_t *inView,
+                                      float *projX, float *projY, float *projXR, int32_t *level, float *viewCos, float *normal, float *maxD, float *minD,
+                                      float *logScaleFactor)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {500.f, 500.f, 320.f, 240.f, 40.f, 640, 480};
+    std::vector<uint8_t> desc((size_t)(n > 0 ? n : 1) * 32, 0);
+    Frame FS, F;
+    fill_frame(FS, srcKps, desc.data(), n, nullptr, cam, kDefaultScales, 8);
+    fill_frame(F, srcKps, desc.data(), 0, nullptr, cam, kDefaultScales, 8);
+    cv::Mat Ts(4, 4, CV_32F), T(4, 4, CV_32F);
+    for (int i = 0; i < 16; i++) { Ts.at<float>(i / 4, i % 4) = TcwSrc[i]; T.at<float>(i / 4, i % 4) = Tcw[i]; }
+    FS.SetPose(Ts);
+    F.SetPose(T);
+    *logScaleFactor = F.mfLogScaleFactor;
+    int nIn = 0;
+    for (int i = 0; i < n; i++) {
+        cv::Mat p(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) p.at<float>(k) = pos[3 * i + k];
+        MapPoint *mp = new MapPoint(p, &map, &FS, i);
+        const cv::Mat nv = mp->GetNormal();
+        for (int k = 0; k < 3; k++) normal[3 * i + k] = nv.at<float>(k);
+        maxD[i] = MapPointAccess::MaxD(mp); minD[i] = MapPointAccess::MinD(mp);
+        const bool in = F.isInFrustum(mp, cosLimit);
+        inView[i] = (in && mp->mbTrackInView) ? 1 : 0;
+        projX[i] = mp->mTrackProjX; projY[i] = mp->mTrackProjY; projXR[i] = mp->mTrackProjXR; level[i] = mp->mnTrackScaleLevel; viewCos[i] = mp->mTrackViewCos;
+        nIn += in;
+        delete mp;
+    }
+    return nIn;
+}
+
 // ---------------------------------------------------------------------------------------
 // DBoW2 vocabulary: TemplatedVocabulary::loadFromTextFile + transform
 // (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1420, 1127-1262), i.e. what

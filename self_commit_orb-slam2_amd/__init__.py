@@ -373,6 +373,26 @@ class AreaQueries(ctypes.Structure):
                 ("window_min_x", ctypes.c_float), ("window_min_y", ctypes.c_float)]
 
 
+class FrustumFrame(ctypes.Structure):
+    _fields_ = [("tcw", ctypes.c_void_p), ("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float), ("cy", ctypes.c_float), ("mbf", ctypes.c_float),
+                ("min_x", ctypes.c_float), ("max_x", ctypes.c_float), ("min_y", ctypes.c_float), ("max_y", ctypes.c_float), ("ratio_thresholds", ctypes.c_void_p),
+                ("nlevels", ctypes.c_int), ("nframes", ctypes.c_int)]
+
+
+class MapPoints(ctypes.Structure):
+    _fields_ = [("world_pos", ctypes.c_void_p), ("normal", ctypes.c_void_p), ("max_distance", ctypes.c_void_p), ("min_distance", ctypes.c_void_p),
+                ("counts", ctypes.c_void_p), ("capacity", ctypes.c_int)]
+
+
+def predict_scale_thresholds(log_scale_factor, nlevels):
+    """orbx_predict_scale_thresholds: the float ratios at which MapPoint::PredictScale changes level (host, libm log)."""
+    L = load_library()
+    out = np.zeros(max(nlevels - 1, 1), np.float32)
+    L.orbx_predict_scale_thresholds.argtypes = [ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+    _check(L.orbx_predict_scale_thresholds(ctypes.c_float(log_scale_factor), nlevels, _ptr(out)))
+    return out[:nlevels - 1]
+
+
 class TriangulationParams(ctypes.Structure):
     _fields_ = [("f12", ctypes.c_void_p), ("epipole", ctypes.c_void_p), ("stereo_a", ctypes.c_void_p), ("stereo_b", ctypes.c_void_p),
                 ("scale_factors", ctypes.c_void_p), ("level_sigma2", ctypes.c_void_p), ("nlevels", ctypes.c_int), ("check_orientation", ctypes.c_int)]
@@ -522,6 +542,24 @@ class ORBmatcher:
         ok = out >= 0
         prev[ok, 0], prev[ok, 1] = k2["x"][out[ok]], k2["y"][out[ok]]          # :646-650
         return nm.value, out, prev
+
+    def isInFrustum(self, Tcw, cam, bounds, log_scale_factor, nlevels, points, viewing_cos_limit):
+        """Frame::isInFrustum (reference src/Frame.cc:608-742) for a list of map points.  cam = (fx, fy, cx, cy, mbf), bounds = (mnMinX, mnMaxX,
+        mnMinY, mnMaxY), points: dict(pos (n,3), normal (n,3), max_distance, min_distance).  Returns dict(in_view, proj_x, proj_y, proj_xr, level, view_cos)."""
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        th = predict_scale_thresholds(log_scale_factor, nlevels)
+        pos, nrm = np.ascontiguousarray(points["pos"], np.float32), np.ascontiguousarray(points["normal"], np.float32)
+        mx, mn = np.ascontiguousarray(points["max_distance"], np.float32), np.ascontiguousarray(points["min_distance"], np.float32)
+        n = len(mx)
+        cnt = np.array([n], np.int32)
+        fr = FrustumFrame(T.ctypes.data, cam[0], cam[1], cam[2], cam[3], cam[4], bounds[0], bounds[1], bounds[2], bounds[3], th.ctypes.data, nlevels, 1)
+        mp = MapPoints(pos.ctypes.data, nrm.ctypes.data, mx.ctypes.data, mn.ctypes.data, cnt.ctypes.data, max(n, 1))
+        f = lambda: np.zeros(max(n, 1), np.float32)
+        px, py, pxr, vc, lvl, iv = f(), f(), f(), f(), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.uint8)
+        self._L.orbx_is_in_frustum.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 6
+        _check(self._L.orbx_is_in_frustum(self._h, ctypes.byref(fr), ctypes.byref(mp), ctypes.c_float(viewing_cos_limit), _ptr(px), _ptr(py), _ptr(pxr), _ptr(lvl),
+                                          _ptr(vc), _ptr(iv)))
+        return dict(in_view=iv[:n], proj_x=px[:n], proj_y=py[:n], proj_xr=pxr[:n], level=lvl[:n], view_cos=vc[:n])
 
     def SearchByProjection(self, frame, points, th, nnratio=None):
         """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (reference src/ORBmatcher.cc:70-175).

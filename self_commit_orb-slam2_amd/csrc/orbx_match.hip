@@ -677,7 +677,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     if (m->evDep2) (void)hipEventDestroy(m->evDep2);
     for (int i = 0; i < 2; i++) if (m->evPyr[i]) (void)hipEventDestroy(m->evPyr[i]);
     for (int s = 0; s < 2; s++) { m->hk[s].release(); m->hd[s].release(); m->hv[s].release(); m->hc[s].release(); m->hg[s].release(); m->hs[s].release(); }
-    m->triGeom.release();
+    m->triGeom.release(); m->frProj.release(); m->frLevel.release(); m->frInView.release();
     if (m->evDep) (void)hipEventDestroy(m->evDep);
     for (int i = 0; i < 2; i++) if (m->evDone[i]) (void)hipEventDestroy(m->evDone[i]);
     for (int r = 0; r < MATCH_PROF_RING; r++) { if (m->ev0[r]) (void)hipEventDestroy(m->ev0[r]); if (m->ev1[r]) (void)hipEventDestroy(m->ev1[r]); if (m->evMid[r]) (void)hipEventDestroy(m->evMid[r]); }

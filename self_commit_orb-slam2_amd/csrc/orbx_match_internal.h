@@ -74,6 +74,11 @@ struct orbx_matcher {
     OrbxDevBuf<int32_t> hc[2], hg[2];
     OrbxDevBuf<uint8_t> hs[2];                               // SearchForTriangulation: stereo flags (host form)
     OrbxDevBuf<float> triGeom;                               // F12 + epipole per pair
+    // Frame::isInFrustum results (proj_x | proj_y | proj_xr | view_cos, level, in_view), orbx_projection_points layout
+    OrbxDevBuf<float> frProj;
+    OrbxDevBuf<int32_t> frLevel;
+    OrbxDevBuf<uint8_t> frInView;
+    size_t frCount = 0;
     int lastPairs = 0, lastStride = 0;
 };
 

@@ -1123,3 +1123,155 @@ extern "C" int orbx_search_by_projection_last(orbx_matcher *m, const orbx_projec
     return ORBX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Frame::isInFrustum (src/Frame.cc:608-742) for a list of map points per frame, the loop of
+// Tracking::SearchLocalPoints (src/Tracking.cc:1580-1613) that feeds SearchByProjection(F, vpMapPoints, th):
+// projection with mRcw / mtcw, image-bounds, distance-range and viewing-angle gates, MapPoint::PredictScale,
+// and the mTrack* fields.  Arithmetic in the reference's order: 3x3 * 3x1 products in float left to right
+// (OpenCV's small-matrix gemm path, see oracle/cvshim), cv::norm and Mat::dot accumulate in double.
+// PredictScale's ceil(log(ratio)/mfLogScaleFactor) is evaluated WITHOUT a device logarithm: the host tabulates,
+// with the same libm log the reference calls, the largest float ratio that still maps to each level
+// (orbx_predict_scale_thresholds; exact as long as that log is monotonic), the device compares.
+// ---------------------------------------------------------------------------------------------
+struct FrustumDev {
+    const float *tcw;        // [16] per frame
+    float fx, fy, cx, cy, mbf, minX, maxX, minY, maxY, cosLimit;
+    int nlevels;
+    float ratioTh[ORBX_MAX_LEVELS];   // ratioTh[k] = largest ratio with PredictScale <= k, k = 0 .. nlevels-2
+};
+struct MapPointsDev { const float *pos, *normal, *maxDist, *minDist; const int32_t *counts; int cap; };
+
+__global__ __launch_bounds__(256) void k_is_in_frustum(FrustumDev Fr, MapPointsDev M, float *__restrict__ projX, float *__restrict__ projY, float *__restrict__ projXR,
+                                                       int32_t *__restrict__ level, float *__restrict__ viewCosOut, uint8_t *__restrict__ inView)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int m = min(M.counts[f], M.cap);
+    if (i >= m) return;
+    const size_t pi = (size_t)f * M.cap + i;
+    inView[pi] = 0;                                                              // :615
+    const float *T = Fr.tcw + 16 * (size_t)f, *P = M.pos + 3 * pi;
+    float Pc[3], Ow[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        float s = T[r * 4 + 0] * P[0];
+        s = s + T[r * 4 + 1] * P[1];
+        s = s + T[r * 4 + 2] * P[2];
+        Pc[r] = s + T[r * 4 + 3];                                                // mRcw*P + mtcw, :627
+        float o = (-T[0 * 4 + r]) * T[0 * 4 + 3];                                // mOw = -mRcw.t()*mtcw, src/Frame.cc:598
+        o = o + (-T[1 * 4 + r]) * T[1 * 4 + 3];
+        o = o + (-T[2 * 4 + r]) * T[2 * 4 + 3];
+        Ow[r] = o;
+    }
+    if (Pc[2] < 0.0f) return;                                                    // :635
+    const float invz = 1.0f / Pc[2];
+    const float u = Fr.fx * Pc[0] * invz + Fr.cx, v = Fr.fy * Pc[1] * invz + Fr.cy;
+    if (u < Fr.minX || u > Fr.maxX) return;                                      // :653-656
+    if (v < Fr.minY || v > Fr.maxY) return;
+    const float maxDistance = 1.2f * M.maxDist[pi], minDistance = 0.8f * M.minDist[pi];   // Get{Max,Min}DistanceInvariance, src/MapPoint.cc:523-533
+    const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+    const float dist = (float)sqrt((double)PO[0] * (double)PO[0] + (double)PO[1] * (double)PO[1] + (double)PO[2] * (double)PO[2]);   // cv::norm, :677
+    if (dist < minDistance || dist > maxDistance) return;                        // :680
+    const float *Pn = M.normal + 3 * pi;
+    const double dot = (double)PO[0] * (double)Pn[0] + (double)PO[1] * (double)Pn[1] + (double)PO[2] * (double)Pn[2];
+    const float viewCos = (float)(dot / (double)dist);                           // :697
+    if (viewCos < Fr.cosLimit) return;
+    const float ratio = M.maxDist[pi] / dist;                                    // MapPoint::PredictScale, src/MapPoint.cc:571-586
+    int lvl = Fr.nlevels - 1;
+    for (int k = Fr.nlevels - 2; k >= 0; k--)
+        if (!(ratio > Fr.ratioTh[k])) lvl = k;
+    inView[pi] = 1;
+    projX[pi] = u; projXR[pi] = u - Fr.mbf * invz; projY[pi] = v; level[pi] = lvl; viewCosOut[pi] = viewCos;   // :721-731
+}
+
+// largest float r with ceil(log((double)r) / (double)log_scale_factor) <= k, for k = 0 .. nlevels-2 (host, libm)
+extern "C" int orbx_predict_scale_thresholds(float log_scale_factor, int nlevels, float *thresholds)
+{
+    if (!thresholds || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !(log_scale_factor > 0.0f)) { orbx_set_error("bad PredictScale arguments"); return ORBX_ERR_ARG; }
+    for (int k = 0; k + 1 < nlevels; k++) {
+        uint32_t lo = 0x00800000u, hi = 0x7f7fffffu;   // positive normal floats are ordered like their bit patterns
+        while (lo < hi) {                               // invariant: f(lo) <= k (ratio 1.2e-38 maps far below 0)
+            const uint32_t mid = lo + (hi - lo + 1) / 2;
+            float r;
+            memcpy(&r, &mid, 4);
+            const double n = ceil(log((double)r) / (double)log_scale_factor);
+            if (n <= (double)k) lo = mid; else hi = mid - 1;
+        }
+        memcpy(&thresholds[k], &lo, 4);
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_is_in_frustum_device(orbx_matcher *m, const orbx_frustum_frame *frame, const orbx_map_points *points, float viewing_cos_limit)
+{
+    if (!m || !frame || !points) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!frame->tcw || !frame->ratio_thresholds || !points->world_pos || !points->normal || !points->max_distance || !points->min_distance || !points->counts) {
+        orbx_set_error("NULL array in the frustum arguments");
+        return ORBX_ERR_ARG;
+    }
+    if (frame->nframes < 1 || frame->nframes > m->maxPairs || points->capacity < 1 || frame->nlevels < 1 || frame->nlevels > ORBX_MAX_LEVELS) {
+        orbx_set_error("bad frustum sizes");
+        return ORBX_ERR_CAPACITY;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    const size_t n = (size_t)frame->nframes * points->capacity;
+    int rc;
+    if ((rc = m->frProj.ensure(4 * n)) || (rc = m->frLevel.ensure(n)) || (rc = m->frInView.ensure(n))) return rc;
+    FrustumDev Fr;
+    Fr.tcw = frame->tcw; Fr.fx = frame->fx; Fr.fy = frame->fy; Fr.cx = frame->cx; Fr.cy = frame->cy; Fr.mbf = frame->mbf;
+    Fr.minX = frame->min_x; Fr.maxX = frame->max_x; Fr.minY = frame->min_y; Fr.maxY = frame->max_y; Fr.cosLimit = viewing_cos_limit; Fr.nlevels = frame->nlevels;
+    for (int k = 0; k < ORBX_MAX_LEVELS; k++) Fr.ratioTh[k] = k + 1 < frame->nlevels ? frame->ratio_thresholds[k] : 0.0f;
+    MapPointsDev M = {points->world_pos, points->normal, points->max_distance, points->min_distance, points->counts, points->capacity};
+    hipLaunchKernelGGL(k_is_in_frustum, dim3((unsigned)((points->capacity + 255) / 256), (unsigned)frame->nframes), dim3(256), 0, m->stream, Fr, M, m->frProj.p,
+                       m->frProj.p + n, m->frProj.p + 2 * n, m->frLevel.p, m->frProj.p + 3 * n, m->frInView.p);
+    MLAUNCH_CHECK();
+    m->frCount = n;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_frustum_results_device(orbx_matcher *m, const float **proj_x, const float **proj_y, const float **proj_xr, const int32_t **scale_level,
+                                           const float **view_cos, const uint8_t **in_view)
+{
+    if (!m) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    if (!m->frCount) { orbx_set_error("no frustum test has run yet"); return ORBX_ERR_STATE; }
+    const size_t n = m->frCount;
+    if (proj_x) *proj_x = m->frProj.p;
+    if (proj_y) *proj_y = m->frProj.p + n;
+    if (proj_xr) *proj_xr = m->frProj.p + 2 * n;
+    if (view_cos) *view_cos = m->frProj.p + 3 * n;
+    if (scale_level) *scale_level = m->frLevel.p;
+    if (in_view) *in_view = m->frInView.p;
+    return ORBX_OK;
+}
+
+// host-array form for one frame: upload, run, download
+extern "C" int orbx_is_in_frustum(orbx_matcher *m, const orbx_frustum_frame *frame_host, const orbx_map_points *points_host, float viewing_cos_limit, float *proj_x,
+                                  float *proj_y, float *proj_xr, int32_t *scale_level, float *view_cos, uint8_t *in_view)
+{
+    if (!m || !frame_host || !points_host || !points_host->counts || !in_view) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    const int mm = points_host->counts[0];
+    if (mm <= 0) return ORBX_OK;
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    if ((rc = m->pf[0].ensure(16)) || (rc = m->pf[1].ensure((size_t)mm * 8)) || (rc = m->pi32[0].ensure(2))) return rc;
+    hipStream_t st = m->stream;
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[0].p, frame_host->tcw, 16 * sizeof(float), hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, points_host->world_pos, (size_t)mm * 12, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 3 * (size_t)mm, points_host->normal, (size_t)mm * 12, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 6 * (size_t)mm, points_host->max_distance, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 7 * (size_t)mm, points_host->min_distance, (size_t)mm * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, &mm, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    orbx_frustum_frame fd = *frame_host;
+    fd.tcw = m->pf[0].p; fd.nframes = 1;
+    orbx_map_points pd = {m->pf[1].p, m->pf[1].p + 3 * (size_t)mm, m->pf[1].p + 6 * (size_t)mm, m->pf[1].p + 7 * (size_t)mm, m->pi32[0].p, mm};
+    if ((rc = orbx_is_in_frustum_device(m, &fd, &pd, viewing_cos_limit)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    const size_t n = (size_t)mm;
+    if (proj_x) ORBX_HIP_CHECK(hipMemcpy(proj_x, m->frProj.p, n * 4, hipMemcpyDeviceToHost));
+    if (proj_y) ORBX_HIP_CHECK(hipMemcpy(proj_y, m->frProj.p + n, n * 4, hipMemcpyDeviceToHost));
+    if (proj_xr) ORBX_HIP_CHECK(hipMemcpy(proj_xr, m->frProj.p + 2 * n, n * 4, hipMemcpyDeviceToHost));
+    if (view_cos) ORBX_HIP_CHECK(hipMemcpy(view_cos, m->frProj.p + 3 * n, n * 4, hipMemcpyDeviceToHost));
+    if (scale_level) ORBX_HIP_CHECK(hipMemcpy(scale_level, m->frLevel.p, n * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_CHECK(hipMemcpy(in_view, m->frInView.p, n, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}

@@ -699,3 +699,22 @@ def ref_search_for_initialization(f1, f2, prev, window, nnratio, check_ori, lib=
     lib.orbslam_search_for_initialization.argtypes = [vp, vp, ci, vp, vp, ci, vp, ci, cf, ci, vp]
     n = lib.orbslam_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), _p(prev), window, nnratio, 1 if check_ori else 0, _p(out))
     return n, out[:len(k1)], prev
+
+
+def ref_is_in_frustum(Tcw, Tcw_src, src_kps, pos, cos_limit, lib=None):
+    """Frame::isInFrustum of the reference per map point (points created from a source frame)."""
+    lib = lib or slam_lib()
+    sk = np.ascontiguousarray(_kp7(src_kps) if np.asarray(src_kps).dtype.names else src_kps, np.float32)
+    pos = np.ascontiguousarray(pos, np.float32)
+    n = len(pos)
+    T, Ts = np.ascontiguousarray(Tcw, np.float32).reshape(16), np.ascontiguousarray(Tcw_src, np.float32).reshape(16)
+    iv = np.zeros(max(n, 1), np.uint8)
+    f = lambda k=1: np.zeros((max(n, 1), k) if k > 1 else max(n, 1), np.float32)
+    px, py, pxr, vc, nrm, mx, mn = f(), f(), f(), f(), f(3), f(), f()
+    lvl = np.zeros(max(n, 1), np.int32)
+    lsf = ctypes.c_float()
+    vp = ctypes.c_void_p
+    lib.orbslam_is_in_frustum.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_float] + [vp] * 10
+    nin = lib.orbslam_is_in_frustum(_p(T), _p(Ts), _p(sk), _p(pos), n, cos_limit, _p(iv), _p(px), _p(py), _p(pxr), _p(lvl), _p(vc), _p(nrm), _p(mx), _p(mn), ctypes.byref(lsf))
+    return dict(n_in=nin, in_view=iv[:n], proj_x=px[:n], proj_y=py[:n], proj_xr=pxr[:n], level=lvl[:n], view_cos=vc[:n], normal=nrm[:n], max_distance=mx[:n],
+                min_distance=mn[:n], log_scale_factor=lsf.value)
