@@ -123,6 +123,61 @@ def config5():
             "max_abs_point_diff": float(np.abs(got["points"].astype(np.float64) - want["points"]).max())}
 
 
+def config6(B=256, n=400):
+    """Optimizer::PoseOptimization for a batch of independent frames (one kernel, one workgroup per frame) vs the CPU restatement."""
+    import oracle_lib
+    from test_pose_optimization import make_frame
+    frames = [make_frame(100 + i, n=n) for i in range(B)]
+    po = orbx.PoseOptimizer(max_frames=B, max_features=n)
+    for _ in range(2):
+        got = po.PoseOptimization(frames)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        got = po.PoseOptimization(frames)
+    wall = (time.perf_counter() - t0) / 5
+    orc = oracle_lib.Oracle()
+    t0 = time.perf_counter()
+    want = [oracle_lib.pose_optimization(orc, f) for f in frames[:32]]
+    cpu = (time.perf_counter() - t0) / 32
+    dmax = max(float(np.abs(g["pose"].astype(np.float64) - w["pose"]).max()) for g, w in zip(got[:32], want))
+    return {"config": "6: PoseOptimization, batch of %d frames x %d correspondences (host arrays in / out)" % (B, n), "frames_per_s": round(B / wall, 1),
+            "ms_per_batch": round(wall * 1e3, 3), "cpu_oracle_ms_per_frame_1_core": round(cpu * 1e3, 3), "max_abs_pose_diff": dmax}
+
+
+def config7(n=2000, m=4000):
+    """Tracking back end on one frame (host-array forms, upload included): Frame::isInFrustum over m map points, then
+    ORBmatcher::SearchByProjection(F, vpMapPoints, th) of the visible ones against n features."""
+    rng = np.random.default_rng(5)
+    mt = orbx.ORBmatcher(0.8, True, max_features=max(n, m))
+    T = np.eye(4, dtype=np.float32)
+    P = np.stack([rng.uniform(-4, 4, m), rng.uniform(-3, 3, m), rng.uniform(1, 10, m)], 1).astype(np.float32)
+    nrm = (-P / np.linalg.norm(P, axis=1, keepdims=True)).astype(np.float32)
+    d = np.linalg.norm(P, axis=1).astype(np.float32)
+    pts = dict(pos=P, normal=-nrm, max_distance=d * 1.5, min_distance=d * 0.4)
+    lsf = float(np.float32(np.log(np.float32(1.2))))
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    k = np.zeros(n, orbx.KEYPOINT_DTYPE)
+    k["x"], k["y"], k["octave"], k["size"], k["class_id"] = rng.uniform(0, 640, n), rng.uniform(0, 480, n), rng.integers(0, 8, n), 31, -1
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    mdesc = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+
+    def step():
+        r = mt.isInFrustum(T, (500.0, 500.0, 320.0, 240.0, 40.0), (0.0, 640.0, 0.0, 480.0), lsf, 8, pts, 0.5)
+        frame = dict(kps=k, desc=desc, u_right=np.full(n, -1, np.float32), occupied=np.zeros(n, np.uint8), scale_factors=sf, width=640, height=480)
+        points = dict(proj_x=r["proj_x"], proj_y=r["proj_y"], proj_xr=r["proj_xr"], level=r["level"], view_cos=r["view_cos"], in_view=r["in_view"],
+                      has_obs=np.ones(m, np.uint8), desc=mdesc)
+        return r, mt.SearchByProjection(frame, points, 3.0)
+
+    for _ in range(3):
+        r, (nm, _) = step()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    dt = (time.perf_counter() - t0) / 10
+    return {"config": "7: isInFrustum (%d map points) + SearchByProjection (%d features), one frame, host arrays" % (m, n), "ms_per_frame": round(dt * 1e3, 3),
+            "points_in_view": int(r["in_view"].sum())}
+
+
 if __name__ == "__main__":
-    for fn in (config2, config2b, config3, config5):
+    for fn in (config2, config2b, config3, config5, config6, config7):
         print(json.dumps(fn()), flush=True)
