@@ -90,16 +90,24 @@ __device__ __forceinline__ bool tri_geom_ok(const TriDev &T, int p, const orbx_k
     return (double)dsqr < T.chiTh[k2.octave];
 }
 
-// insert into an ascending list, dropping its largest element: a min/max chain (2 ops per slot,
-// no compares or selects).  A key >= kk[TOPK-1] leaves the list unchanged, so no predication is needed.
+// insert into an ascending list, dropping its largest element: slot q of the new list is the median of its old
+// neighbours kk[q-1], kk[q] and the key (one v_med3_u32 per slot, all independent, no compares or selects).
+// A key >= kk[TOPK-1] leaves the list unchanged, so no predication is needed.
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ void topk_insert(uint32_t (&kk)[TOPK], uint32_t key)
 {
+    uint32_t nk[TOPK];
+    nk[0] = min(kk[0], key);
 #pragma unroll
-    for (int q = 0; q < TOPK; q++) {
-        const uint32_t lo = min(kk[q], key);
-        key = max(kk[q], key);
-        kk[q] = lo;
-    }
+    for (int q = 1; q < TOPK; q++) nk[q] = med3_u32(kk[q - 1], kk[q], key);
+#pragma unroll
+    for (int q = 0; q < TOPK; q++) kk[q] = nk[q];
 }
 
 // TRI (SearchForTriangulation): among equal distances the LAST candidate in scan order wins
@@ -192,8 +200,9 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
                             ins0 = pass0 ? ins0 : 0xffffffffu;
                             ins1 = pass1 ? ins1 : 0xffffffffu;
                         }
-                        topk_insert(k0, ins0);
-                        topk_insert(k1, ins1);
+                        // events are sparse (a few lanes per wave): usually only one of the two rows has one
+                        if (__any(ins0 < k0[TOPK - 1])) topk_insert(k0, ins0);
+                        if (__any(ins1 < k1[TOPK - 1])) topk_insert(k1, ins1);
                     }
                 }
             }
