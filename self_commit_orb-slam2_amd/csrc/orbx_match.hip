@@ -17,6 +17,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "orbx_match_internal.h"
@@ -155,7 +156,9 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
                 sG[j] = gq;
             }
         __syncthreads();
-        for (int j0 = 0; j0 < ntPad; j0 += 4) {
+        // four B features per step; only the last step of a tile can contain padding (TAIL): its check stays out of the main loop
+        auto group = [&](const int j0, auto tailTag) {
+            constexpr bool TAIL = decltype(tailTag)::value;
             uint32_t key0[4], key1[4], m0 = 0xffffffffu, m1 = 0xffffffffu;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
                     const int gq = sG[j0 + u];
                     ka = gq == gA0 ? ka : 0xffffffffu;
                     kb = gq == gA1 ? kb : 0xffffffffu;
-                } else if (j0 + u >= nt) { ka = 0xffffffffu; kb = 0xffffffffu; }   // wave-uniform (zero padding of the tile)
+                } else if (TAIL && j0 + u >= nt) { ka = 0xffffffffu; kb = 0xffffffffu; }   // wave-uniform (zero padding of the tile)
                 key0[u] = ka; key1[u] = kb;
                 m0 = min(m0, ka); m1 = min(m1, kb);
             }
@@ -206,7 +209,10 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
                     }
                 }
             }
-        }
+        };
+        int j0 = 0;
+        for (; j0 + 4 <= nt; j0 += 4) group(j0, std::false_type());
+        if (j0 < ntPad) group(j0, std::true_type());
     }
     if (live0) {
         uint32_t *out = topk + ((size_t)p * stride + i0) * TOPK;
