@@ -278,6 +278,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
     const int seg = lane - rl * S, c0 = 16 * seg;
     const uint32_t colMask = (aw - c0 >= 16) ? 0xffffu : (aw - c0 <= 0 ? 0u : ((1u << (aw - c0)) - 1u));
     int nc = 0;
+    const uint32_t thrPk = (uint32_t)(minTh & 0xffff) * 0x00010001u;
     for (int rowBase = 0; rowBase < ah; rowBase += rpp) {
         const int r = rowBase + rl;
         const bool live = rl < rpp && r < ah;
@@ -302,9 +303,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
             }
             const uint32_t vv = FC_PAIR(W[3], j + 3);
             const uint32_t m = pk_max_i16(pk_sub_i16(vv, A), pk_sub_i16(B, vv));
-            mask |= ((int)(short)(m & 0xffffu) > minTh ? 1u : 0u) << j;
-            mask |= ((int)(short)(m >> 16) > minTh ? 1u : 0u) << (j + 1);
+            // m > minTh  <=>  minTh - m < 0: the two sign bits go to bit j (pixel j) and bit 16 + j (pixel j + 1)
+            mask |= ((pk_sub_i16(thrPk, m) >> 15) & 0x00010001u) << j;
         }
+        mask = (mask & 0x5555u) | ((mask >> 15) & 0xaaaau);
         mask = live ? (mask & colMask) : 0u;
         const int cntL = __popc(mask);
         const int incl = wave_incl_scan_i(cntL, lane);
