@@ -407,7 +407,7 @@ int orbx_fuse_search(orbx_matcher *m, const orbx_projection_frame *kf_host, cons
  * takes the feature of minimum Hamming distance (first minimum in GetFeaturesInArea order) among the
  * features inside GetFeaturesInArea(u, v, radius[, min_level, max_level]) that are not blocked - blocked
  * from the start (frame->occupied: vpMatched[idx] / CurrentFrame.mvpMapPoints[i2] non-NULL) or taken by an
- * earlier query - provided that distance is <= max_dist (TH_LOW / ORBdist); the feature is then blocked.
+ * earlier query - provided that distance is <= max_dist (TH_LOW / ORBdist, < 256); the feature is then blocked.
  * Level gate: octave < min_level or (max_level >= 0 and octave > max_level) rejects (Frame::GetFeaturesInArea,
  * src/Frame.cc:741-850; the KeyFrame variants pass [level-1, level], :469-470). */
 typedef struct orbx_area_queries {

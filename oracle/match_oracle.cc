@@ -762,7 +762,7 @@ MO_API int mo_area_search_greedy(const float *kpUn, const uint8_t *desc, const u
                     if (dist < best) { best = dist; bidx = idx; }
                 }
             }
-        if (best <= maxDist) { assigned[p] = bidx; dists[p] = best; blocked[(size_t)bidx] = 1; nmatches++; }
+        if (bidx >= 0 && best <= maxDist) { assigned[p] = bidx; dists[p] = best; blocked[(size_t)bidx] = 1; nmatches++; }   // (maxDist is < 256 in the reference)
     }
     return nmatches;
 }
