@@ -32,7 +32,8 @@ def test_no_cpu_fallback(orbx):
         orbx.ORBextractor(1000, 1.2, 8, 20, 7)
     assert e.value.code == -4   # ORBX_ERR_NODEVICE
     for make in (lambda: orbx.ORBmatcher(0.7, True), lambda: orbx.Optimizer(), lambda: orbx.PoseOptimizer(),
-                 lambda: orbx.Vocabulary(orbx.voc_synth.make_vocabulary(4, 2, 1))):
+                 lambda: orbx.Vocabulary(orbx.voc_synth.make_vocabulary(4, 2, 1)),
+                 lambda: orbx.FrameOps(500.0, 500.0, 320.0, 240.0, [0.1, 0.0, 0.0, 0.0])):
         with pytest.raises(orbx.OrbxError) as e:
             make()
         assert e.value.code == -4
@@ -45,3 +46,35 @@ def test_synth_frame_deterministic(orbx):
     assert (a == b).all() and (a != c).any()
     lo = orbx.synth_frame(42, 640, 480, orbx.SYNTH_LOW_TEXTURE)
     assert lo.std() < a.std()
+
+
+def test_null_handles_and_bad_arguments_are_errors_not_crashes(orbx):
+    """Every entry point validates its handle / pointers before touching a device: negative status + message, no crash (runs without a GPU)."""
+    L = orbx.load_library()
+    vp = ctypes.c_void_p
+    none = vp(None)
+    calls = [
+        (L.orbx_search_by_bow_device, [none] * 5 + [1, none, none]),
+        (L.orbx_search_for_triangulation_device, [none] * 5 + [1, none, none]),
+        (L.orbx_fuse_search_device, [none, none, none, none, 8, 1]),
+        (L.orbx_area_search_greedy_device, [none, none, none, 50]),
+        (L.orbx_search_for_initialization_device, [none, none, none, none, 10, ctypes.c_float(0.9), 1]),
+        (L.orbx_is_in_frustum_device, [none, none, none, ctypes.c_float(0.5)]),
+        (L.orbx_search_by_projection_device, [none, none, none, none, 8, ctypes.c_float(1.0), ctypes.c_float(0.8)]),
+        (L.orbx_frame_finish_device, [none, none, none]),
+        (L.orbx_bow_transform_device, [none, none, 4]),
+        (L.orbx_lba_solve, [none, none, none, none]),
+        (L.orbx_bundle_adjustment, [none, none, 5, 1, none, none]),
+        (L.orbx_pose_optimization, [none] * 6),
+        (L.orbx_matcher_sync, [none]),
+    ]
+    for fn, args in calls:
+        fn.restype = ctypes.c_int
+        fn.argtypes = None
+        assert fn(*args) < 0, fn.__name__
+        assert len(L.orbx_last_error()) > 0
+    th = (ctypes.c_float * 8)()
+    L.orbx_predict_scale_thresholds.argtypes = [ctypes.c_float, ctypes.c_int, vp]
+    assert L.orbx_predict_scale_thresholds(ctypes.c_float(0.1823), 0, th) < 0          # nlevels out of range
+    assert L.orbx_predict_scale_thresholds(ctypes.c_float(-1.0), 8, th) < 0            # log of a scale factor <= 1
+    assert L.orbx_predict_scale_thresholds(ctypes.c_float(0.1823), 8, th) == 0 and th[0] == 1.0   # ratio <= 1 is level 0
