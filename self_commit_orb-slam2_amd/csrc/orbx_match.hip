@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
 // dependent step per feature.  A rank whose (full) candidate list has fewer than two free entries
 // left cannot be decided from the list: those ranks are queued and one wave each rescans all of B
 // exactly, as before.
-__global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
+#define GREEDY_THREADS 1024   /* a row per thread for up to 1024 features: every round of the fixed point is one parallel sweep */
+__global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
                                                     float nnratio, int checkOri, const uint32_t *__restrict__ topk, const int32_t *__restrict__ order,
                                                     int32_t *__restrict__ matches, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride, TriDev T)
 {
@@ -260,25 +261,25 @@ __global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const 
     if (tid == 0) { sTotal = 0; sRemoved = 0; }
     {
         const int32_t *ord = order + (size_t)p * stride;
-        for (int r = tid; r < nA; r += 256) {
+        for (int r = tid; r < nA; r += GREEDY_THREADS) {
             int i = ord[r];
             if (A.valid && !A.valid[(size_t)fa * A.cap + i]) i = 0xffff;
             sOrd[r] = (unsigned short)i;
             dec[r] = KEY_EMPTY;
         }
     }
-    for (int s = tid; s < stride; s += 256) { mout[s] = -1; dout[s] = 256; }
+    for (int s = tid; s < stride; s += GREEDY_THREADS) { mout[s] = -1; dout[s] = 256; }
     for (;;) {
-        for (int j = tid; j < nB; j += 256) owner[j] = 0xffffffffu;
+        for (int j = tid; j < nB; j += GREEDY_THREADS) owner[j] = 0xffffffffu;
         if (tid == 0) { sChanged = 0; sQueued = 0; }
         __syncthreads();
-        for (int r = tid; r < nA; r += 256) {
+        for (int r = tid; r < nA; r += GREEDY_THREADS) {
             const uint32_t d = dec[r];
             if (d != KEY_EMPTY) atomicMin(&owner[d & 0xffff], (uint32_t)r);
         }
         __syncthreads();
         bool changed = false;
-        for (int r = tid; r < nA; r += 256) {
+        for (int r = tid; r < nA; r += GREEDY_THREADS) {
             const int i = sOrd[r];
             if (i == 0xffff) continue;
             const uint4 q0 = tk[i * 2], q1 = tk[i * 2 + 1];
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const 
         __syncthreads();
         // exact rescans: one wave per queued rank, lanes over the B features of its node
         const int nq = sQueued;
-        for (int q = wv; q < nq; q += 4) {
+        for (int q = wv; q < nq; q += GREEDY_THREADS / 64) {
             const int r = queue[q], i = sOrd[r];
             const unsigned long long *da = (const unsigned long long *)(A.desc + ((size_t)fa * A.cap + i) * 32);
             unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const 
     const orbx_keypoint *kA = A.kp + (size_t)fa * A.cap, *kB = B.kp + (size_t)fb * B.cap;
     const float factor = HISTO_LENGTH / 360.0f;
     int total = 0;
-    for (int r = tid; r < nA; r += 256) {
+    for (int r = tid; r < nA; r += GREEDY_THREADS) {
         const uint32_t d = dec[r];
         if (d == KEY_EMPTY) continue;
         const int i = sOrd[r], bj = (int)(d & 0xffff), slot = mode == 0 ? bj : i;
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256) void k_bow_greedy(FeatDev A, FeatDev B, const 
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         int removed = 0;
-        for (int r = tid; r < nA; r += 256) {       // same rank -> thread mapping as the writes above
+        for (int r = tid; r < nA; r += GREEDY_THREADS) {       // same rank -> thread mapping as the writes above
             const uint32_t d = dec[r];
             if (d == KEY_EMPTY) continue;
             const int b = (int)(d >> 26);
@@ -775,7 +776,7 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     const size_t ldsGreedy = (size_t)b->capacity * 4 + (size_t)a->capacity * 4 + (size_t)((a->capacity + 7) & ~7) * 2 * 2;
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
     if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
-    hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(256), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, params->nn_ratio,
+    hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(GREEDY_THREADS), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, params->nn_ratio,
                        params->check_orientation, m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride, TriDev());
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
@@ -1015,7 +1016,7 @@ extern "C" int orbx_search_for_triangulation_device(orbx_matcher *m, const orbx_
     const size_t ldsGreedy = (size_t)b->capacity * 4 + (size_t)a->capacity * 4 + (size_t)((a->capacity + 7) & ~7) * 2 * 2;
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
     if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
-    hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(256), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, 2, 0.0f, params->check_orientation,
+    hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(GREEDY_THREADS), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, 2, 0.0f, params->check_orientation,
                        m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride, T);
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
