@@ -53,7 +53,8 @@ struct OrbxGeom {
 };
 
 /* level-coordinates keypoint produced by the quadtree + orientation stages */
-struct OrbxLevelKp { uint16_t x, y; uint8_t score, pad[3]; float angle; };
+/* ca / sb = cos / sin of the angle as the reference's libm rounds them; k_orient fills them with the angle */
+struct OrbxLevelKp { uint16_t x, y; uint8_t score, pad[3]; float angle, ca, sb; };
 
 void orbx_set_error(const char *fmt, ...);
 #define ORBX_HIP_CHECK(expr)                                                                           \

@@ -699,17 +699,54 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
             for (int k = 1; k < nd.cnt; k++) { uint32_t p = src[k]; if ((p >> 24) > (best >> 24)) best = p; }
             OrbxLevelKp kp;
             kp.x = (uint16_t)((best & 0xfff) + ORBX_BORDER); kp.y = (uint16_t)(((best >> 12) & 0xfff) + ORBX_BORDER);
-            kp.score = (uint8_t)(best >> 24); kp.pad[0] = kp.pad[1] = kp.pad[2] = 0; kp.angle = 0.f;
+            kp.score = (uint8_t)(best >> 24); kp.pad[0] = kp.pad[1] = kp.pad[2] = 0; kp.angle = 0.f; kp.ca = 1.f; kp.sb = 0.f;
             out[i] = kp;
         }
         if (tid == 0) lvlCnt[f * g->nlevels + l] = nn;
     }
 }
 
+// sin/cos of the keypoint angle: glibc's sinf/cosf algorithm in double, restated so the device
+// rounds like the libm the reference calls (oracle/prims.h op_sincosf, tests/test_sincos.py).
+__device__ __forceinline__ float sinf_poly_d(double x, double x2, int n, bool neg)
+{
+    // coefficients of glibc 2.35 __sincosf_table[0]; table[1] is its negation (neg)
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        double x3 = x * x2, t1 = s2 + x2 * s3, x7 = x3 * x2, s = x + x3 * s1;
+        return (float)(s + x7 * t1);
+    } else {
+        double k0 = neg ? -c0 : c0, k1 = neg ? -c1 : c1, k2 = neg ? -c2 : c2, k3 = neg ? -c3 : c3, k4 = neg ? -c4 : c4;
+        double x4 = x2 * x2, u2 = k3 + x2 * k4, u1 = k0 + x2 * k1, x6 = x4 * x2, c = u1 + x4 * k2;
+        return (float)(c + x6 * u2);
+    }
+}
+
+__device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs)
+{
+    double x = y;
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
+    if (top < ((0x3f490fdbu >> 20) & 0x7ff)) {   // |y| < pi/4 (abstop12 compare)
+        double x2 = x * x;
+        if (top < ((0x39800000u >> 20) & 0x7ff)) { sn = y; cs = 1.0f; return; }   // |y| < 2^-12
+        sn = sinf_poly_d(x, x2, 0, false);
+        cs = sinf_poly_d(x, x2, 1, false);
+        return;
+    }
+    double r = x * 0x1.45F306DC9C883p+23;
+    int n = ((int)r + 0x800000) >> 24;
+    x = x - n * 0x1.921FB54442D18p0;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    const bool neg = (n & 2) != 0;
+    sn = sinf_poly_d(x * sgn, x * x, n, neg);
+    cs = sinf_poly_d(x * sgn, x * x, n ^ 1, neg);
+}
+
 // ------------------------------------------------------------------------------------
 // Orientation: IC_Angle (src/ORBextractor.cc:108-161) = integer moments over the
-// 749-pixel disc of radius 15 on the UNBLURRED level, then cv::fastAtan2.  One wave per
-// keypoint, lanes stride the disc rows; integer sums are exact in any order.
+// 749-pixel disc of radius 15 on the UNBLURRED level, then cv::fastAtan2.  Half a wave per
+// keypoint, lanes own the disc rows; integer sums are exact in any order.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
@@ -771,7 +808,20 @@ __global__ __launch_bounds__(256) void k_orient(const OrbxGeom *__restrict__ g, 
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-    if (live && r == 0) kp->angle = fast_atan2_deg((float)m01, (float)m10);
+    // the eight moment pairs of the block meet in LDS; eight lanes of wave 0 then do the scalar tail
+    // (fastAtan2 and the sin/cos rBRIEF steers with, src/ORBextractor.cc:135-138) once per keypoint
+    // instead of once per wave
+    __shared__ int sMom[8][3];
+    if (r == 0) { int *m = sMom[(threadIdx.x >> 6) * 2 + half]; m[0] = m01; m[1] = m10; m[2] = live ? slot : -1; }
+    __syncthreads();
+    if (threadIdx.x < 8 && sMom[threadIdx.x][2] >= 0) {
+        OrbxLevelKp *o = lvlKp + (size_t)f * g->kpPerFrame + sMom[threadIdx.x][2];
+        const float ang = fast_atan2_deg((float)sMom[threadIdx.x][0], (float)sMom[threadIdx.x][1]);
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        float sn, cs;
+        sincosf_glibc(ang * factorPI, sn, cs);
+        o->angle = ang; o->ca = cs; o->sb = sn;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -891,45 +941,9 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
 // rBRIEF-256 (computeOrbDescriptor, src/ORBextractor.cc:173-227) + final KeyPoint
 // (:1175-1190, :1651-1660).  One wave per keypoint: in round r lane l evaluates test pair
 // 64r+l; the 64-bit __ballot of (t0 < t1) IS descriptor bytes 8r..8r+7 in the
-// reference's bit order (bit k of byte i = pair 8i+k).  sin/cos: glibc's sinf/cosf
-// algorithm in double, restated so the device rounds like the libm the reference calls
-// (oracle/prims.h op_sincosf, tests/test_sincos.py).
+// reference's bit order (bit k of byte i = pair 8i+k).  cos/sin of the angle come with
+// the keypoint from k_orient (sincosf_glibc above).
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ float sinf_poly_d(double x, double x2, int n, bool neg)
-{
-    // coefficients of glibc 2.35 __sincosf_table[0]; table[1] is its negation (neg)
-    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
-    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
-    if ((n & 1) == 0) {
-        double x3 = x * x2, t1 = s2 + x2 * s3, x7 = x3 * x2, s = x + x3 * s1;
-        return (float)(s + x7 * t1);
-    } else {
-        double k0 = neg ? -c0 : c0, k1 = neg ? -c1 : c1, k2 = neg ? -c2 : c2, k3 = neg ? -c3 : c3, k4 = neg ? -c4 : c4;
-        double x4 = x2 * x2, u2 = k3 + x2 * k4, u1 = k0 + x2 * k1, x6 = x4 * x2, c = u1 + x4 * k2;
-        return (float)(c + x6 * u2);
-    }
-}
-
-__device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs)
-{
-    double x = y;
-    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
-    if (top < ((0x3f490fdbu >> 20) & 0x7ff)) {   // |y| < pi/4 (abstop12 compare)
-        double x2 = x * x;
-        if (top < ((0x39800000u >> 20) & 0x7ff)) { sn = y; cs = 1.0f; return; }   // |y| < 2^-12
-        sn = sinf_poly_d(x, x2, 0, false);
-        cs = sinf_poly_d(x, x2, 1, false);
-        return;
-    }
-    double r = x * 0x1.45F306DC9C883p+23;
-    int n = ((int)r + 0x800000) >> 24;
-    x = x - n * 0x1.921FB54442D18p0;
-    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
-    const bool neg = (n & 2) != 0;
-    sn = sinf_poly_d(x * sgn, x * x, n, neg);
-    cs = sinf_poly_d(x * sgn, x * x, n ^ 1, neg);
-}
-
 __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ blur, const OrbxLevelKp *__restrict__ lvlKp,
                                                   const int *__restrict__ lvlCnt, orbx_keypoint *__restrict__ outKp, uint8_t *__restrict__ outDesc,
                                                   int *__restrict__ outCnt)
@@ -957,9 +971,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g
     const float lvScale = lv.scale;          // read before the gathers: nothing after them should wait on memory but the stores
     const int lvPatch = lv.patchSize;
     const uint8_t *center = img + (size_t)kp.y * pitch + kp.x;
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    float a, b;
-    sincosf_glibc(kp.angle * factorPI, b, a);
+    const float a = kp.ca, b = kp.sb;        // cos, sin of the angle (k_orient)
     unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * g->outCap + outIdx) * 32);
     // three dependent memory levels in total: the four pattern words, then the eight samples, then the stores
     // (a store between the rounds would fence the next round's loads behind it)
