@@ -140,18 +140,19 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
     uint32_t k0[TOPK], k1[TOPK];
 #pragma unroll
     for (int q = 0; q < TOPK; q++) { k0[q] = act0 ? sentinel : 0u; k1[q] = act1 ? sentinel : 0u; }   // inactive rows never insert
+    uint32_t t0 = k0[TOPK - 1] >> 16, t1 = k1[TOPK - 1] >> 16;   // distance part of each list's threshold
     const uint4 *gD = (const uint4 *)(B.desc + (size_t)fb * capB * 32);
-    for (int t0 = 0; t0 < nB; t0 += TOPK_TILE) {
-        const int nt = min(TOPK_TILE, nB - t0), ntPad = (nt + 3) & ~3;
+    for (int t0base = 0; t0base < nB; t0base += TOPK_TILE) {
+        const int nt = min(TOPK_TILE, nB - t0base), ntPad = (nt + 3) & ~3;
         __syncthreads();
-        for (int t = tid; t < 2 * ntPad; t += 256) sB[t] = t < 2 * nt ? gD[2 * (size_t)t0 + t] : make_uint4(0u, 0u, 0u, 0u);
+        for (int t = tid; t < 2 * ntPad; t += 256) sB[t] = t < 2 * nt ? gD[2 * (size_t)t0base + t] : make_uint4(0u, 0u, 0u, 0u);
         if (FILTER)
             for (int j = tid; j < ntPad; j += 256) {
                 int gq = (int)0x80000000;
                 if (j < nt) {
-                    gq = B.groups ? B.groups[(size_t)fb * capB + t0 + j] : 0;
+                    gq = B.groups ? B.groups[(size_t)fb * capB + t0base + j] : 0;
                     if (gq < 0) gq = (int)0x80000000;   // negative node id = not filed in the FeatureVector: never matched
-                    if (mode >= 1 && B.valid && !B.valid[(size_t)fb * capB + t0 + j]) gq = (int)0x80000000;
+                    if (mode >= 1 && B.valid && !B.valid[(size_t)fb * capB + t0base + j]) gq = (int)0x80000000;
                 }
                 sG[j] = gq;
             }
@@ -159,7 +160,10 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
         // four B features per step; only the last step of a tile can contain padding (TAIL): its check stays out of the main loop
         auto group = [&](const int j0, auto tailTag) {
             constexpr bool TAIL = decltype(tailTag)::value;
-            uint32_t key0[4], key1[4], m0 = 0xffffffffu, m1 = 0xffffffffu;
+            // the event test runs on the bare distances (the list threshold's distance t0 / t1): the key
+            // dist << 16 | j is only formed for the few candidates that reach the list.  An excluded
+            // candidate carries distance 0xffff, above every threshold (dcut <= 257).
+            uint32_t dd0[4], dd1[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint4 lo = sB[2 * (j0 + u)], hi = sB[2 * (j0 + u) + 1];   // wave-uniform address: LDS broadcast
@@ -172,23 +176,25 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
                 d0 = bcnt_acc(a[5] ^ hi.y, d0); d1 = bcnt_acc(c[5] ^ hi.y, d1);
                 d0 = bcnt_acc(a[6] ^ hi.z, d0); d1 = bcnt_acc(c[6] ^ hi.z, d1);
                 d0 = bcnt_acc(a[7] ^ hi.w, d0); d1 = bcnt_acc(c[7] ^ hi.w, d1);
-                const uint32_t j = TRI ? 0xffffu - (uint32_t)(t0 + j0 + u) : (uint32_t)(t0 + j0 + u);
-                uint32_t ka = ((uint32_t)d0 << 16) | j, kb = ((uint32_t)d1 << 16) | j;
                 if (FILTER) {
                     const int gq = sG[j0 + u];
-                    ka = gq == gA0 ? ka : 0xffffffffu;
-                    kb = gq == gA1 ? kb : 0xffffffffu;
-                } else if (TAIL && j0 + u >= nt) { ka = 0xffffffffu; kb = 0xffffffffu; }   // wave-uniform (zero padding of the tile)
-                key0[u] = ka; key1[u] = kb;
-                m0 = min(m0, ka); m1 = min(m1, kb);
+                    d0 = gq == gA0 ? d0 : 0xffffu;
+                    d1 = gq == gA1 ? d1 : 0xffffu;
+                } else if (TAIL && j0 + u >= nt) { d0 = 0xffffu; d1 = 0xffffu; }   // wave-uniform (zero padding of the tile)
+                dd0[u] = d0; dd1[u] = d1;
             }
-            if (__any(m0 < k0[TOPK - 1] || m1 < k1[TOPK - 1])) {
+            const uint32_t m0 = min(min(dd0[0], min(dd0[1], dd0[2])), dd0[3]), m1 = min(min(dd1[0], min(dd1[1], dd1[2])), dd1[3]);
+            // plain scan order: an equal distance with a later j has the larger key, so only d < t can enter;
+            // TRI keys carry 0xffff - j, an equal distance with a later j enters: d <= t (conservative at the sentinel)
+            auto reaches = [](uint32_t d, uint32_t t) { return TRI ? d <= t : d < t; };
+            if (__any(reaches(m0, t0) || reaches(m1, t1))) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    if (__any(key0[u] < k0[TOPK - 1] || key1[u] < k1[TOPK - 1])) {
-                        uint32_t ins0 = key0[u], ins1 = key1[u];
+                    if (__any(reaches(dd0[u], t0) || reaches(dd1[u], t1))) {
+                        const uint32_t j = TRI ? 0xffffu - (uint32_t)(t0base + j0 + u) : (uint32_t)(t0base + j0 + u);
+                        uint32_t ins0 = (dd0[u] << 16) | j, ins1 = (dd1[u] << 16) | j;
                         if (TRI) {
-                            const int jb = t0 + j0 + u;
+                            const int jb = t0base + j0 + u;
                             const orbx_keypoint k2 = B.kp[(size_t)fb * capB + jb];
                             const bool st2 = T.stereoB && T.stereoB[(size_t)fb * capB + jb];
                             bool pass0 = false, pass1 = false;
@@ -204,8 +210,8 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
                             ins1 = pass1 ? ins1 : 0xffffffffu;
                         }
                         // events are sparse (a few lanes per wave): usually only one of the two rows has one
-                        if (__any(ins0 < k0[TOPK - 1])) topk_insert(k0, ins0);
-                        if (__any(ins1 < k1[TOPK - 1])) topk_insert(k1, ins1);
+                        if (__any(ins0 < k0[TOPK - 1])) { topk_insert(k0, ins0); t0 = k0[TOPK - 1] >> 16; }
+                        if (__any(ins1 < k1[TOPK - 1])) { topk_insert(k1, ins1); t1 = k1[TOPK - 1] >> 16; }
                     }
                 }
             }
