@@ -89,6 +89,13 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
+__device__ __forceinline__ int med3_i32(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ void topk_insert(uint32_t (&kk)[TOPK], uint32_t key)
 {
     // in place, last slot first: slot q only needs the OLD kk[q - 1], which is updated after it
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256) void k_bow_topk_mx(FeatDev A, FeatDev B, const
 #pragma unroll
     for (int q = 0; q < TOPK; q++) { k0[q] = act0 ? sentinel : 0u; k1[q] = act1 ? sentinel : 0u; }
     // a candidate can enter the list iff dot > td: ham < thr (ham <= thr for TRI, whose ties go to the later j)
-    auto dot_threshold = [](uint32_t k7, int pq, bool act) { return act ? pq - (int)(k7 >> 16) - (TRI ? 1 : 0) : 0x7fffffff; };
+    auto dot_threshold = [](uint32_t k7, int pq, bool act) { return act ? pq - (int)(k7 >> 16) - (TRI ? 1 : 0) : 4096; };   // 4096: no dot reaches it
     int td0 = dot_threshold(k0[TOPK - 1], pq0, act0), td1 = dot_threshold(k1[TOPK - 1], pq1, act1);
 
     // ---- B side: widen a tile of MX_TT descriptors into LDS (thread = a quarter descriptor) ----
@@ -201,42 +208,72 @@ __global__ __launch_bounds__(256) void k_bow_topk_mx(FeatDev A, FeatDev B, const
     };
 
     // ---- epilogue of one 32 x 32 block of dots for one column block ----
+    // One insertion sequence serves ALL lanes of the wave at once, so the harvest works per lane, not per
+    // accumulator register: v = dot * 16 + (15 - r) carries the register index below the dot, a
+    // top-2 tree (max / med3) yields each lane's best and second-best candidate of the block, and
+    // the two are offered to the lists in turn.  A lane with three or more candidates in one block
+    // is rare; its remaining ones are walked in descending order of v.
+    constexpr int V_MASKED = -4096 * 16;   // excluded candidate: below every threshold (|dot| <= 256), no overflow in v
     auto harvest = [&](v16i acc, const int jbase, const int buf, const int mb, uint32_t (&kk)[TOPK], int &td, const int pq, const int gA, const int qi) {
         // jbase = index of accumulator row 0 of this lane's half: register r is B feature jbase + (r & 3) + 8 (r >> 2)
+        int v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = acc[r] * 16 + (15 - r);
         if (FILTER) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int4 g = *(const int4 *)(&sG[buf][mb * 32 + 8 * q + 4 * h]);
-                acc[4 * q + 0] = g.x == gA ? acc[4 * q + 0] : (int)0x80000000;
-                acc[4 * q + 1] = g.y == gA ? acc[4 * q + 1] : (int)0x80000000;
-                acc[4 * q + 2] = g.z == gA ? acc[4 * q + 2] : (int)0x80000000;
-                acc[4 * q + 3] = g.w == gA ? acc[4 * q + 3] : (int)0x80000000;
+                v[4 * q + 0] = g.x == gA ? v[4 * q + 0] : V_MASKED;
+                v[4 * q + 1] = g.y == gA ? v[4 * q + 1] : V_MASKED;
+                v[4 * q + 2] = g.z == gA ? v[4 * q + 2] : V_MASKED;
+                v[4 * q + 3] = g.w == gA ? v[4 * q + 3] : V_MASKED;
             }
         } else if (jbase - 4 * h + 32 > nB) {   // wave-uniform: the last row block is ragged, its zero rows are not candidates
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = jbase + (r & 3) + 8 * (r >> 2) < nB ? acc[r] : (int)0x80000000;
+            for (int r = 0; r < 16; r++) v[r] = jbase + (r & 3) + 8 * (r >> 2) < nB ? v[r] : V_MASKED;
         }
-        int mx = max(max(acc[0], acc[1]), acc[2]);
+        // (largest, second largest) of the 16: pairs, then three rounds of merges m1 = max(a1, b1), m2 = med3(a1, b1, max(a2, b2))
+        int t1[8], t2[8];
 #pragma unroll
-        for (int r = 3; r < 15; r += 2) mx = max(max(mx, acc[r]), acc[r + 1]);
-        mx = max(mx, acc[15]);
-        if (__any(mx > td)) {
+        for (int i = 0; i < 8; i++) { t1[i] = max(v[2 * i], v[2 * i + 1]); t2[i] = min(v[2 * i], v[2 * i + 1]); }
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                if (__any(acc[r] > td)) {
-                    const int jb = jbase + (r & 3) + 8 * (r >> 2);
-                    const uint32_t jk = TRI ? 0xffffu - (uint32_t)jb : (uint32_t)jb;
-                    uint32_t ins = acc[r] > td ? (((uint32_t)(pq - acc[r]) << 16) | jk) : 0xffffffffu;
-                    if (TRI) {
-                        bool pass = false;
-                        if (ins < kk[TOPK - 1]) {
-                            const size_t ia = (size_t)fa * A.cap + qi, ib = (size_t)fb * capB + jb;
-                            pass = tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], B.kp[ib], T.stereoB && T.stereoB[ib]);
-                        }
-                        ins = pass ? ins : 0xffffffffu;
-                    }
-                    // without the geometry test an event always enters (ham < thr  =>  key < kk[TOPK-1])
-                    if (!TRI || __any(ins < kk[TOPK - 1])) { topk_insert(kk, ins); td = pq - (int)(kk[TOPK - 1] >> 16) - (TRI ? 1 : 0); }   // inactive lanes: list stays 0, td = pq (- 1), which no dot exceeds (TRI: the key test rejects it)
+        for (int n = 4; n >= 1; n >>= 1)
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                const int a1 = t1[i], a2 = t2[i], b1 = t1[i + n], b2 = t2[i + n];
+                t1[i] = max(a1, b1);
+                t2[i] = med3_i32(a1, b1, max(a2, b2));
+            }
+        int tdv = td * 16 + 15;   // v > tdv  <=>  dot > td
+        auto offer = [&](const int m) {
+            const int r = 15 - (m & 15), jb = jbase + (r & 3) + 2 * (r & 12);
+            const uint32_t jk = TRI ? 0xffffu - (uint32_t)jb : (uint32_t)jb;
+            uint32_t ins = m > tdv ? (((uint32_t)(pq - (m >> 4)) << 16) | jk) : 0xffffffffu;
+            if (TRI) {
+                bool pass = false;
+                if (ins < kk[TOPK - 1]) {
+                    const size_t ia = (size_t)fa * A.cap + qi, ib = (size_t)fb * capB + jb;
+                    pass = tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], B.kp[ib], T.stereoB && T.stereoB[ib]);
+                }
+                ins = pass ? ins : 0xffffffffu;
+            }
+            topk_insert(kk, ins);
+            // inactive lanes: the list stays 0 and td becomes pq (- 1), which no dot exceeds (TRI: the key test rejects a tie)
+            td = pq - (int)(kk[TOPK - 1] >> 16) - (TRI ? 1 : 0);
+            tdv = td * 16 + 15;
+        };
+        if (__any(t1[0] > tdv)) {
+            offer(t1[0]);
+            if (__any(t2[0] > tdv)) {
+                offer(t2[0]);
+                int bound = t2[0];
+                for (;;) {
+                    int m = V_MASKED;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) m = max(m, v[r] < bound ? v[r] : V_MASKED);
+                    if (!__any(m > tdv)) break;
+                    offer(m);
+                    bound = m;
                 }
             }
         }
