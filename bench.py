@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
+    ap.add_argument("--split", action="store_true", help="cut every batch into --streams parts (one launch per part) instead of "
+                    "alternating whole batches over the handle pairs")
     ap.add_argument("--streams", type=int, default=2, help="the batch is split over this many extractor/matcher handle pairs (HIP streams) "
                     "so that the latency-bound stages of one part overlap the VALU-bound stages of another")
     a = ap.parse_args()
@@ -156,26 +158,38 @@ def main():
 
     W, H, B, nf = a.width, a.height, a.batch, a.nfeatures
     NS = max(1, min(a.streams, B))
-    while B % NS:
-        NS -= 1
-    Bs = B // NS                                    # frames per part
+    if a.split:
+        while B % NS:
+            NS -= 1
+        Bs = B // NS                                # frames per launch: the batch is cut into NS parts, one per handle pair
+    else:
+        Bs = B                                      # every launch covers the whole batch; consecutive steps alternate handle pairs
     exts = [orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=Bs, device=local) for _ in range(NS)]
     mts = [None if a.no_match else orbx.ORBmatcher(0.7, True, max_features=exts[0].capacity, max_pairs=Bs, device=local) for _ in range(NS)]
     ext, mt = exts[0], mts[0]
     # independent frames per rank: seeds offset by rank<<32; every 16th frame low texture
     # scenes of 16 views translating 3x1 px per view, so consecutive frames really match
     frames = orbx.synth_sequence(grp.seed_base() + 1, B, W, H)
-    devs = [e.upload(frames[k * Bs:(k + 1) * Bs]) for k, e in enumerate(exts)]   # inputs resident in HBM before the timed region
+    # inputs resident in HBM before the timed region (alternating handles each hold their own copy of the batch)
+    devs = [e.upload(frames[k * Bs:(k + 1) * Bs] if a.split else frames) for k, e in enumerate(exts)]
     pa = np.arange(Bs, dtype=np.int32)              # frame i (as "KeyFrame") ...
-    pb = (np.arange(Bs, dtype=np.int32) + 1) % Bs   # ... against frame i+1 (as "Frame"), inside its part
+    pb = (np.arange(Bs, dtype=np.int32) + 1) % Bs   # ... against frame i+1 (as "Frame"), inside its launch
+    issued = [0]
 
     def step():
-        for e, d in zip(exts, devs):
-            e.run_device(*d)
-        for e, m in zip(exts, mts):
-            if m is not None:
-                fs = orbx.ORBmatcher.features_of(e, Bs)     # results are double buffered: ask every step
-                m.search_by_bow_device(fs, fs, pa, pb, mode=0, after=e)
+        # one pass of the hot path over one batch of B frames.  Nothing is synchronised between steps, so with
+        # two handle pairs (two HIP stream pairs) the kernels of consecutive batches overlap on the GPU.
+        if a.split:
+            todo = list(range(NS))
+        else:
+            todo = [issued[0] % NS]
+            issued[0] += 1
+        for k in todo:
+            exts[k].run_device(*devs[k])
+        for k in todo:
+            if mts[k] is not None:
+                fs = orbx.ORBmatcher.features_of(exts[k], Bs)     # results are double buffered: ask every step
+                mts[k].search_by_bow_device(fs, fs, pa, pb, mode=0, after=exts[k])
 
     def sync_all():
         for e in exts:
@@ -210,17 +224,24 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     # per-launch kernel time of every stage: each part's launch covers Bs frames
-    stage_ms = {}
-    for e in exts:
-        for k, v in e.last_timing()[1].items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v / NS
+    stage_ms, timed = {}, []
+    for k, e in enumerate(exts):
+        try:
+            tm = e.last_timing()[1]
+        except orbx.OrbxError:            # a handle pair that no timed step used (steps < streams)
+            tm = None
         e.set_profiling(False)
-    match_ms = float(np.mean([m.last_timing() for m in mts])) if mt is not None else 0.0
-    match_split = np.mean([m.last_kernel_timing() for m in mts], axis=0) if mt is not None else (0.0, 0.0)
-    counts = np.concatenate([e.download(Bs)[2] for e in exts])
+        if tm:
+            timed.append(k)
+            for kk, v in tm.items():
+                stage_ms[kk] = stage_ms.get(kk, 0.0) + v
+    stage_ms = {kk: v / max(1, len(timed)) for kk, v in stage_ms.items()}
+    match_split = np.mean([mts[k].last_kernel_timing() for k in timed], axis=0) if (mt is not None and timed) else (0.0, 0.0)
+    parts = range(NS) if a.split else range(1)            # alternating handles hold the same batch: count it once
+    counts = np.concatenate([exts[k].download(Bs)[2] for k in parts])
     nm_mean = 0.0
     if mt is not None:
-        nm_mean = float(np.mean([m.download(Bs)[2].mean() for m in mts]))
+        nm_mean = float(np.mean([mts[k].download(Bs)[2].mean() for k in parts]))
     t, frames_total, per_rank = grp.aggregate(elapsed, B * a.steps, int(counts.sum()))
 
     if rank == 0:

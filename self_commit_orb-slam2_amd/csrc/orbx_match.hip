@@ -44,13 +44,25 @@ __global__ __launch_bounds__(256) void k_bow_order(FeatDev A, const int32_t *__r
 }
 
 // top-TOPK candidates of every A feature by key = dist<<16 | j over the B features of the same
-// node (mode 1: that also carry a valid MapPoint): k_bow_topk_mx below.
+// node (mode 1: that also carry a valid MapPoint).  LANE = TWO A features (descriptors in 16
+// VGPRs); the B descriptors are staged through LDS in tiles of 1024 and read with wave-uniform
+// (broadcast) ds_read_b128, so one LDS fetch feeds 128 distances and a distance is
+// 8 x (v_xor_b32 + v_bcnt_u32_b32) + key + min.
 // Distance cut-off: a candidate at distance d >= dcut can never be accepted as best
 // (d > TH_LOW) and, as second best, can never fail the ratio test of an acceptable best
 // (nnratio * d > TH_LOW >= best, orbx_search_by_bow_device computes dcut in the float arithmetic
-// of the test); dropping it leaves the greedy replay bit-identical and makes list updates rarer.
+// of the test); dropping it leaves the greedy replay bit-identical and makes list updates rare.
 // The per-lane lists start filled with the sentinel dcut<<16, so "key < kk[TOPK-1]" is the whole
-// admission test.
+// test, evaluated once per 4 B features on the minimum of the keys.
+#define TOPK_ROWS 512   /* A features per block: two per lane */
+#define TOPK_TILE 1024  /* B features per LDS tile */
+
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
 
 // ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:810-1017): the per-candidate geometry.
 struct TriDev {
@@ -89,13 +101,6 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
-__device__ __forceinline__ int med3_i32(int a, int b, int c)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 __device__ __forceinline__ void topk_insert(uint32_t (&kk)[TOPK], uint32_t key)
 {
     // in place, last slot first: slot q only needs the OLD kk[q - 1], which is updated after it
@@ -104,224 +109,122 @@ __device__ __forceinline__ void topk_insert(uint32_t (&kk)[TOPK], uint32_t key)
     kk[0] = min(kk[0], key);
 }
 
-// ------------------------------------------------------------------------------------
-// Candidate lists on the matrix cores.  All-pairs Hamming distance IS a matrix product:
-// with the A-side descriptor a as +-1 bytes (a' = 2a - 1) and the B-side descriptor b as 0/1 bytes,
-//     a' . b = 2|a & b| - |b|      and      ham(a, b) = |a| + |b| - 2|a & b| = |a| - a' . b,
-// so for a fixed A feature the distance order is the reverse order of the int32 dot product and
-// v_mfma_i32_32x32x32_i8 (exact integer arithmetic) replaces 16 VALU instructions per pair by
-// 1/128 of an MFMA.  The bits are widened to bytes on the fly: the A side once per wave into 64
-// VGPRs, the B side once per block and tile into LDS - nothing widened ever reaches HBM.
-//   MFMA rows (first operand)   = 32 B features, read from the LDS tile with one ds_read_b128
-//                                 per lane and k-step (row pitch 272 B: the 2-way minimum),
-//   MFMA columns (second op.)   = 32 A features, lane & 31; a wave owns two column blocks, so a
-//                                 row fragment feeds two MFMAs,
-//   accumulators                = lane (col, half) holds the dots of ITS A feature with 16 of the
-//                                 32 B features: rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-// Lane l and lane l ^ 32 therefore keep separate ascending lists for the same A feature over
-// disjoint B features; the lists are merged once at the end (the union of two top-8 sets holds
-// the top 8).  The per-tile epilogue is a max3 tree over the 16 dots and one compare against the
-// list threshold turned into a dot: `ham < thr  <=>  dot > |a| - thr`.
-// The k index a byte lands on inside the instruction does not matter as long as both operands
-// use the same rule, and they do (same function of lane >> 5 and byte number).
 // TRI (SearchForTriangulation): among equal distances the LAST candidate in scan order wins
 // (`dist>bestDist` skips, :880), so the key carries 0xffff - j; a candidate below the list threshold
 // is inserted only if it passes the epipole gate and the epipolar-line test.
-// FILTER: the B side has node ids and/or a validity mask.
-// ------------------------------------------------------------------------------------
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-#define MX_QB 256       /* A features per block: 4 waves x 2 column blocks */
-#define MX_TT 64        /* B features per LDS tile: two row blocks */
-#define MX_PITCH 272    /* bytes per widened B row */
-
-// bits 4n .. 4n+3 of w as four bytes of 0 / 1 (the four shifted copies of the nibble do not overlap)
-__device__ __forceinline__ uint32_t nib_bytes(uint32_t w, int n) { return (((w >> (4 * n)) & 0xfu) * 0x00204081u) & 0x01010101u; }
-// bytes 0 / 1 -> 0xff (-1) / 0x01
-__device__ __forceinline__ uint32_t pm_bytes(uint32_t v) { const uint32_t z = v ^ 0x01010101u; return v | ((z << 8) - z); }
-
-template <bool FILTER, bool TRI>
-__global__ __launch_bounds__(256) void k_bow_topk_mx(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
-                                                     uint32_t dcut, uint32_t *__restrict__ topk, int stride, TriDev T)
+template <bool FILTER, bool TRI>   // FILTER: B side has node ids and/or a validity mask
+__global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
+                                                  uint32_t dcut, uint32_t *__restrict__ topk, int stride, TriDev T)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t sT[2][MX_TT * MX_PITCH];
-    __shared__ __attribute__((aligned(16))) int32_t sG[2][MX_TT];   // node id, 0x80000000 = excluded (FILTER only)
+    __shared__ uint4 sB[TOPK_TILE * 2];     // 32-byte descriptors
+    __shared__ int32_t sG[TOPK_TILE];       // node id, 0x80000000 = excluded (FILTER only)
     const int p = blockIdx.y, fa = pairsA[p], fb = pairsB[p];
     const int nA = min(A.counts[fa], A.cap), nB = min(B.counts[fb], B.cap);
     const int capB = B.cap;
-    const int row0 = blockIdx.x * MX_QB;
+    const int row0 = blockIdx.x * TOPK_ROWS;
     if (row0 >= nA) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5, col = lane & 31;
+    const int tid = threadIdx.x;
+    const int i0 = row0 + tid, i1 = row0 + 256 + tid;
+    const bool live0 = i0 < nA, live1 = i1 < nA;
+    const uint32_t *da0 = (const uint32_t *)(A.desc + ((size_t)fa * A.cap + (live0 ? i0 : nA - 1)) * 32);
+    const uint32_t *da1 = (const uint32_t *)(A.desc + ((size_t)fa * A.cap + (live1 ? i1 : nA - 1)) * 32);
+    uint32_t a[8], c[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) { a[w] = da0[w]; c[w] = da1[w]; }
+    const int gA0 = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live0 ? i0 : nA - 1)] : 0;
+    const int gA1 = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live1 ? i1 : nA - 1)] : 0;
     const uint32_t sentinel = dcut << 16;
-
-    // ---- A side: two features per lane (one per column block), widened to +-1 bytes ----
-    v4i qf0[8], qf1[8];
-    int pq0 = 0, pq1 = 0;
-    const int qi0 = row0 + wv * 64 + col, qi1 = qi0 + 32;
-    const bool live0 = qi0 < nA, live1 = qi1 < nA;
-    {
-        const uint32_t *d0 = (const uint32_t *)(A.desc + ((size_t)fa * A.cap + (live0 ? qi0 : nA - 1)) * 32);
-        const uint32_t *d1 = (const uint32_t *)(A.desc + ((size_t)fa * A.cap + (live1 ? qi1 : nA - 1)) * 32);
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const uint32_t w0 = d0[s], w1 = d1[s];
-            pq0 += __popc(w0); pq1 += __popc(w1);
-            const uint32_t b0 = w0 >> (16 * h), b1 = w1 >> (16 * h);
-#pragma unroll
-            for (int n = 0; n < 4; n++) { qf0[s][n] = (int)pm_bytes(nib_bytes(b0, n)); qf1[s][n] = (int)pm_bytes(nib_bytes(b1, n)); }
-        }
-    }
-    const int gA0 = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live0 ? qi0 : nA - 1)] : 0;
-    const int gA1 = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live1 ? qi1 : nA - 1)] : 0;
     const bool act0 = live0 && !(FILTER && gA0 < 0), act1 = live1 && !(FILTER && gA1 < 0);   // unfiled A features keep empty lists
     uint32_t k0[TOPK], k1[TOPK];
 #pragma unroll
-    for (int q = 0; q < TOPK; q++) { k0[q] = act0 ? sentinel : 0u; k1[q] = act1 ? sentinel : 0u; }
-    // a candidate can enter the list iff dot > td: ham < thr (ham <= thr for TRI, whose ties go to the later j)
-    auto dot_threshold = [](uint32_t k7, int pq, bool act) { return act ? pq - (int)(k7 >> 16) - (TRI ? 1 : 0) : 4096; };   // 4096: no dot reaches it
-    int td0 = dot_threshold(k0[TOPK - 1], pq0, act0), td1 = dot_threshold(k1[TOPK - 1], pq1, act1);
-
-    // ---- B side: widen a tile of MX_TT descriptors into LDS (thread = a quarter descriptor) ----
-    // fetch() only issues the global loads; widen() runs after the MFMAs of the current tile, so the
-    // load latency hides behind them
-    const int sr = tid >> 2, spart = tid & 3;
-    auto fetch = [&](const int tb, uint2 &w, int &gq) {
-        const int nt = min(MX_TT, nB - tb);
-        w = make_uint2(0u, 0u);
-        if (sr < nt) w = *(const uint2 *)(B.desc + ((size_t)fb * capB + tb + sr) * 32 + 8 * spart);
-        if (FILTER && tid < MX_TT) {
-            gq = (int)0x80000000;
-            if (tid < nt) {
-                gq = B.groups ? B.groups[(size_t)fb * capB + tb + tid] : 0;
-                if (gq < 0) gq = (int)0x80000000;   // negative node id = not filed in the FeatureVector: never matched
-                if (mode >= 1 && B.valid && !B.valid[(size_t)fb * capB + tb + tid]) gq = (int)0x80000000;
-            }
-        }
-    };
-    auto widen = [&](const uint2 w, const int gq, const int buf) {
-        uint8_t *dst = sT[buf] + sr * MX_PITCH + 64 * spart;
-        *(uint4 *)(dst) = make_uint4(nib_bytes(w.x, 0), nib_bytes(w.x, 1), nib_bytes(w.x, 2), nib_bytes(w.x, 3));
-        *(uint4 *)(dst + 16) = make_uint4(nib_bytes(w.x, 4), nib_bytes(w.x, 5), nib_bytes(w.x, 6), nib_bytes(w.x, 7));
-        *(uint4 *)(dst + 32) = make_uint4(nib_bytes(w.y, 0), nib_bytes(w.y, 1), nib_bytes(w.y, 2), nib_bytes(w.y, 3));
-        *(uint4 *)(dst + 48) = make_uint4(nib_bytes(w.y, 4), nib_bytes(w.y, 5), nib_bytes(w.y, 6), nib_bytes(w.y, 7));
-        if (FILTER && tid < MX_TT) sG[buf][tid] = gq;
-    };
-
-    // ---- epilogue of one 32 x 32 block of dots for one column block ----
-    // One insertion sequence serves ALL lanes of the wave at once, so the harvest works per lane, not per
-    // accumulator register: v = dot * 16 + (15 - r) carries the register index below the dot, a
-    // top-2 tree (max / med3) yields each lane's best and second-best candidate of the block, and
-    // the two are offered to the lists in turn.  A lane with three or more candidates in one block
-    // is rare; its remaining ones are walked in descending order of v.
-    constexpr int V_MASKED = -4096 * 16;   // excluded candidate: below every threshold (|dot| <= 256), no overflow in v
-    auto harvest = [&](v16i acc, const int jbase, const int buf, const int mb, uint32_t (&kk)[TOPK], int &td, const int pq, const int gA, const int qi) {
-        // jbase = index of accumulator row 0 of this lane's half: register r is B feature jbase + (r & 3) + 8 (r >> 2)
-        int v[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = acc[r] * 16 + (15 - r);
-        if (FILTER) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int4 g = *(const int4 *)(&sG[buf][mb * 32 + 8 * q + 4 * h]);
-                v[4 * q + 0] = g.x == gA ? v[4 * q + 0] : V_MASKED;
-                v[4 * q + 1] = g.y == gA ? v[4 * q + 1] : V_MASKED;
-                v[4 * q + 2] = g.z == gA ? v[4 * q + 2] : V_MASKED;
-                v[4 * q + 3] = g.w == gA ? v[4 * q + 3] : V_MASKED;
-            }
-        } else if (jbase - 4 * h + 32 > nB) {   // wave-uniform: the last row block is ragged, its zero rows are not candidates
-#pragma unroll
-            for (int r = 0; r < 16; r++) v[r] = jbase + (r & 3) + 8 * (r >> 2) < nB ? v[r] : V_MASKED;
-        }
-        // (largest, second largest) of the 16: pairs, then three rounds of merges m1 = max(a1, b1), m2 = med3(a1, b1, max(a2, b2))
-        int t1[8], t2[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) { t1[i] = max(v[2 * i], v[2 * i + 1]); t2[i] = min(v[2 * i], v[2 * i + 1]); }
-#pragma unroll
-        for (int n = 4; n >= 1; n >>= 1)
-#pragma unroll
-            for (int i = 0; i < n; i++) {
-                const int a1 = t1[i], a2 = t2[i], b1 = t1[i + n], b2 = t2[i + n];
-                t1[i] = max(a1, b1);
-                t2[i] = med3_i32(a1, b1, max(a2, b2));
-            }
-        int tdv = td * 16 + 15;   // v > tdv  <=>  dot > td
-        auto offer = [&](const int m) {
-            const int r = 15 - (m & 15), jb = jbase + (r & 3) + 2 * (r & 12);
-            const uint32_t jk = TRI ? 0xffffu - (uint32_t)jb : (uint32_t)jb;
-            uint32_t ins = m > tdv ? (((uint32_t)(pq - (m >> 4)) << 16) | jk) : 0xffffffffu;
-            if (TRI) {
-                bool pass = false;
-                if (ins < kk[TOPK - 1]) {
-                    const size_t ia = (size_t)fa * A.cap + qi, ib = (size_t)fb * capB + jb;
-                    pass = tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], B.kp[ib], T.stereoB && T.stereoB[ib]);
-                }
-                ins = pass ? ins : 0xffffffffu;
-            }
-            topk_insert(kk, ins);
-            // inactive lanes: the list stays 0 and td becomes pq (- 1), which no dot exceeds (TRI: the key test rejects a tie)
-            td = pq - (int)(kk[TOPK - 1] >> 16) - (TRI ? 1 : 0);
-            tdv = td * 16 + 15;
-        };
-        if (__any(t1[0] > tdv)) {
-            offer(t1[0]);
-            if (__any(t2[0] > tdv)) {
-                offer(t2[0]);
-                int bound = t2[0];
-                for (;;) {
-                    int m = V_MASKED;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) m = max(m, v[r] < bound ? v[r] : V_MASKED);
-                    if (!__any(m > tdv)) break;
-                    offer(m);
-                    bound = m;
-                }
-            }
-        }
-    };
-
-    uint2 wNext;
-    int gNext = 0;
-    fetch(0, wNext, gNext);
-    widen(wNext, gNext, 0);
-    __syncthreads();
-    int buf = 0;
-    for (int tb = 0; tb < nB; tb += MX_TT, buf ^= 1) {
-        const bool more = tb + MX_TT < nB;
-        if (more) fetch(tb + MX_TT, wNext, gNext);
-#pragma unroll
-        for (int mb = 0; mb < MX_TT / 32; mb++) {
-            if (tb + mb * 32 >= nB) break;
-            const uint8_t *src = sT[buf] + (mb * 32 + col) * MX_PITCH + 16 * h;
-            v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const v4i tf = *(const v4i *)(src + 32 * s);
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf1[s], acc1, 0, 0, 0);
-            }
-            const int jbase = tb + mb * 32 + 4 * h;
-            harvest(acc0, jbase, buf, mb, k0, td0, pq0, gA0, qi0);
-            harvest(acc1, jbase, buf, mb, k1, td1, pq1, gA1, qi1);
-        }
-        if (more) widen(wNext, gNext, buf ^ 1);
+    for (int q = 0; q < TOPK; q++) { k0[q] = act0 ? sentinel : 0u; k1[q] = act1 ? sentinel : 0u; }   // inactive rows never insert
+    uint32_t t0 = k0[TOPK - 1] >> 16, t1 = k1[TOPK - 1] >> 16;   // distance part of each list's threshold
+    const uint4 *gD = (const uint4 *)(B.desc + (size_t)fb * capB * 32);
+    for (int t0base = 0; t0base < nB; t0base += TOPK_TILE) {
+        const int nt = min(TOPK_TILE, nB - t0base), ntPad = (nt + 3) & ~3;
         __syncthreads();
-    }
-
-    // ---- merge the two halves of every A feature and write the list ----
-    {
-        uint32_t o0[TOPK], o1[TOPK];
+        for (int t = tid; t < 2 * ntPad; t += 256) sB[t] = t < 2 * nt ? gD[2 * (size_t)t0base + t] : make_uint4(0u, 0u, 0u, 0u);
+        if (FILTER)
+            for (int j = tid; j < ntPad; j += 256) {
+                int gq = (int)0x80000000;
+                if (j < nt) {
+                    gq = B.groups ? B.groups[(size_t)fb * capB + t0base + j] : 0;
+                    if (gq < 0) gq = (int)0x80000000;   // negative node id = not filed in the FeatureVector: never matched
+                    if (mode >= 1 && B.valid && !B.valid[(size_t)fb * capB + t0base + j]) gq = (int)0x80000000;
+                }
+                sG[j] = gq;
+            }
+        __syncthreads();
+        // four B features per step; only the last step of a tile can contain padding (TAIL): its check stays out of the main loop
+        auto group = [&](const int j0, auto tailTag) {
+            constexpr bool TAIL = decltype(tailTag)::value;
+            // the event test runs on the bare distances (the list threshold's distance t0 / t1): the key
+            // dist << 16 | j is only formed for the few candidates that reach the list.  An excluded
+            // candidate carries distance 0xffff, above every threshold (dcut <= 257).
+            uint32_t dd0[4], dd1[4];
 #pragma unroll
-        for (int q = 0; q < TOPK; q++) { o0[q] = __shfl_xor(k0[q], 32); o1[q] = __shfl_xor(k1[q], 32); }
+            for (int u = 0; u < 4; u++) {
+                const uint4 lo = sB[2 * (j0 + u)], hi = sB[2 * (j0 + u) + 1];   // wave-uniform address: LDS broadcast
+                // v_bcnt_u32_b32 adds its second operand: one instruction per word instead of bcnt + add tree
+                uint32_t d0 = bcnt_acc(a[0] ^ lo.x, 0u), d1 = bcnt_acc(c[0] ^ lo.x, 0u);
+                d0 = bcnt_acc(a[1] ^ lo.y, d0); d1 = bcnt_acc(c[1] ^ lo.y, d1);
+                d0 = bcnt_acc(a[2] ^ lo.z, d0); d1 = bcnt_acc(c[2] ^ lo.z, d1);
+                d0 = bcnt_acc(a[3] ^ lo.w, d0); d1 = bcnt_acc(c[3] ^ lo.w, d1);
+                d0 = bcnt_acc(a[4] ^ hi.x, d0); d1 = bcnt_acc(c[4] ^ hi.x, d1);
+                d0 = bcnt_acc(a[5] ^ hi.y, d0); d1 = bcnt_acc(c[5] ^ hi.y, d1);
+                d0 = bcnt_acc(a[6] ^ hi.z, d0); d1 = bcnt_acc(c[6] ^ hi.z, d1);
+                d0 = bcnt_acc(a[7] ^ hi.w, d0); d1 = bcnt_acc(c[7] ^ hi.w, d1);
+                if (FILTER) {
+                    const int gq = sG[j0 + u];
+                    d0 = gq == gA0 ? d0 : 0xffffu;
+                    d1 = gq == gA1 ? d1 : 0xffffu;
+                } else if (TAIL && j0 + u >= nt) { d0 = 0xffffu; d1 = 0xffffu; }   // wave-uniform (zero padding of the tile)
+                dd0[u] = d0; dd1[u] = d1;
+            }
+            const uint32_t m0 = min(min(dd0[0], min(dd0[1], dd0[2])), dd0[3]), m1 = min(min(dd1[0], min(dd1[1], dd1[2])), dd1[3]);
+            // plain scan order: an equal distance with a later j has the larger key, so only d < t can enter;
+            // TRI keys carry 0xffff - j, an equal distance with a later j enters: d <= t (conservative at the sentinel)
+            auto reaches = [](uint32_t d, uint32_t t) { return TRI ? d <= t : d < t; };
+            if (__any(reaches(m0, t0) || reaches(m1, t1))) {
 #pragma unroll
-        for (int q = 0; q < TOPK; q++) { topk_insert(k0, o0[q]); topk_insert(k1, o1[q]); }
+                for (int u = 0; u < 4; u++) {
+                    if (__any(reaches(dd0[u], t0) || reaches(dd1[u], t1))) {
+                        const uint32_t j = TRI ? 0xffffu - (uint32_t)(t0base + j0 + u) : (uint32_t)(t0base + j0 + u);
+                        uint32_t ins0 = (dd0[u] << 16) | j, ins1 = (dd1[u] << 16) | j;
+                        if (TRI) {
+                            const int jb = t0base + j0 + u;
+                            const orbx_keypoint k2 = B.kp[(size_t)fb * capB + jb];
+                            const bool st2 = T.stereoB && T.stereoB[(size_t)fb * capB + jb];
+                            bool pass0 = false, pass1 = false;
+                            if (ins0 < k0[TOPK - 1]) {
+                                const size_t ia = (size_t)fa * A.cap + i0;
+                                pass0 = tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], k2, st2);
+                            }
+                            if (ins1 < k1[TOPK - 1]) {
+                                const size_t ia = (size_t)fa * A.cap + i1;
+                                pass1 = tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], k2, st2);
+                            }
+                            ins0 = pass0 ? ins0 : 0xffffffffu;
+                            ins1 = pass1 ? ins1 : 0xffffffffu;
+                        }
+                        // events are sparse (a few lanes per wave): usually only one of the two rows has one
+                        if (__any(ins0 < k0[TOPK - 1])) { topk_insert(k0, ins0); t0 = k0[TOPK - 1] >> 16; }
+                        if (__any(ins1 < k1[TOPK - 1])) { topk_insert(k1, ins1); t1 = k1[TOPK - 1] >> 16; }
+                    }
+                }
+            }
+        };
+        int j0 = 0;
+        for (; j0 + 4 <= nt; j0 += 4) group(j0, std::false_type());
+        if (j0 < ntPad) group(j0, std::true_type());
     }
-    if (h == 0 && live0) {
-        uint32_t *out = topk + ((size_t)p * stride + qi0) * TOPK;
+    if (live0) {
+        uint32_t *out = topk + ((size_t)p * stride + i0) * TOPK;
 #pragma unroll
         for (int k = 0; k < TOPK; k++) out[k] = (!act0 || k0[k] >= sentinel) ? KEY_EMPTY : k0[k];
     }
-    if (h == 0 && live1) {
-        uint32_t *out = topk + ((size_t)p * stride + qi1) * TOPK;
+    if (live1) {
+        uint32_t *out = topk + ((size_t)p * stride + i1) * TOPK;
 #pragma unroll
         for (int k = 0; k < TOPK; k++) out[k] = (!act1 || k1[k] >= sentinel) ? KEY_EMPTY : k1[k];
     }
@@ -866,11 +769,11 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     uint32_t dcut = TH_LOW + 1;
     while (dcut < 257 && !(params->nn_ratio * (float)dcut > (float)TH_LOW)) dcut++;
     const bool filter = b->groups != nullptr || (params->mode == 1 && b->valid != nullptr);
-    const dim3 gridTopk((unsigned)((a->capacity + MX_QB - 1) / MX_QB), (unsigned)npairs);
+    const dim3 gridTopk((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs);
     if (filter)
-        hipLaunchKernelGGL((k_bow_topk_mx<true, false>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
+        hipLaunchKernelGGL((k_bow_topk<true, false>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
     else
-        hipLaunchKernelGGL((k_bow_topk_mx<false, false>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
+        hipLaunchKernelGGL((k_bow_topk<false, false>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->evMid[slot], m->stream));
     m->midValid[slot] = true;
@@ -1109,9 +1012,9 @@ extern "C" int orbx_search_for_triangulation_device(orbx_matcher *m, const orbx_
     ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
     hipLaunchKernelGGL(k_bow_order, dim3((unsigned)((a->capacity + 255) / 256), (unsigned)npairs), dim3(256), 0, m->stream, A, m->pairsA.p, m->order.p, stride);
     MLAUNCH_CHECK();
-    const dim3 gridTopk((unsigned)((a->capacity + MX_QB - 1) / MX_QB), (unsigned)npairs);
+    const dim3 gridTopk((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs);
     // only dist <= TH_LOW can be accepted (:880) and there is no second-best test: cut at TH_LOW + 1
-    hipLaunchKernelGGL((k_bow_topk_mx<true, true>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, 2, (uint32_t)(TH_LOW + 1), m->topk.p, stride, T);
+    hipLaunchKernelGGL((k_bow_topk<true, true>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, 2, (uint32_t)(TH_LOW + 1), m->topk.p, stride, T);
     MLAUNCH_CHECK();
     m->midValid[slot] = false;
     const size_t ldsGreedy = (size_t)b->capacity * 4 + (size_t)a->capacity * 4 + (size_t)((a->capacity + 7) & ~7) * 2 * 2;
