@@ -66,6 +66,7 @@ struct orbx_extractor {
     OrbxGeom geom;
     bool geomValid = false;
     std::vector<uint8_t> binHost;
+    std::vector<uint32_t> rsHost;   // cv::resize tables of all levels (build_resize_tables)
     int nodeCap = 512;
     // device state
     hipStream_t stream = nullptr;
@@ -77,6 +78,7 @@ struct orbx_extractor {
     bool debugTaps = false;   // keep the FAST score map for orbx_debug_download_scores
     DevBuf<OrbxGeom> geomDev;
     DevBuf<uint8_t> binDev, pyr, blur, score, staging;
+    DevBuf<uint32_t> rsDev;
     DevBuf<int> cellCount, lvlCnt, status;
     // results are double buffered: a consumer (matcher) may still read batch i while batch i+1 is
     // extracted; consumerEv[b] = event after which buffer b may be overwritten again
@@ -144,6 +146,64 @@ void build_tables(orbx_extractor *h)
 
 // Level sizes (ComputePyramid :1680-1682), cell grid (:1064-1086), initial quadtree nodes
 // (:719-748), cv::resize coefficient tables, tile tables and buffer offsets for W x H.
+// OpenCV resize.cpp (INTER_LINEAR, 8-bit): source index and the two 11-bit coefficients of destination
+// index d.  fx = (float)((d+0.5)*scale - 0.5) with the product and the difference in double, floor,
+// fraction in float, cvRound((1-fx)*2048) / cvRound(fx*2048), saturate_cast<short>.  Columns reset the
+// coefficients at both borders; rows only clamp the indices.  (IEEE arithmetic, no contraction.)
+static void resize_coef_host(int d, double scale, int slen, bool isX, int &s0, int &c0, int &c1)
+{
+    float fx = (float)(((double)d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (isX) {
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= slen - 1) { fx = 0.f; sx = slen - 1; }
+    }
+    s0 = sx;
+    c0 = std::min(std::max((int)lrintf((1.f - fx) * 2048.f), -32768), 32767);
+    c1 = std::min(std::max((int)lrintf(fx * 2048.f), -32768), 32767);
+}
+
+// Tables k_resize reads instead of redoing that arithmetic in every thread.
+//   columns: 12 u32 per group of 4 destination columns:
+//     [0] first source column sx0   [1] largest tap offset from sx0 (span)
+//     [2..5] v_perm selectors of the 4 columns (tap bytes off, off1 inside the 8-byte window; valid when span <= 7)
+//     [6..9] coefficient pairs a0 | a1 << 16      [10] the four `off` as bytes   [11] the four `off1` as bytes
+//   rows: 2 u32 per destination row: clamped source rows y0 | y1 << 16, coefficients b0 | b1 << 16
+static void build_resize_tables(std::vector<uint32_t> &tab, OrbxLevel &lv, int sw, int sh)
+{
+    while (tab.size() % 4) tab.push_back(0u);     // 16-byte aligned groups
+    lv.rsColOff = (int)tab.size();
+    const int G = (lv.w + 3) >> 2;
+    for (int gi = 0; gi < G; gi++) {
+        uint32_t e[12] = {0};
+        int sx0 = 0, span = 0;
+        for (int k = 0; k < 4; k++) {
+            const int dx = std::min(4 * gi + k, lv.w - 1);
+            int sx, a0, a1;
+            resize_coef_host(dx, lv.rsScaleX, sw, true, sx, a0, a1);
+            const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+            if (k == 0) sx0 = sx;
+            const int off = sx - sx0, off1 = sx1 - sx0;
+            span = std::max(span, off1);
+            e[2 + k] = 0x0c000c00u | (uint32_t)(off & 7) | ((uint32_t)(off1 & 7) << 16);
+            e[6 + k] = (uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16);
+            e[10] |= (uint32_t)(off & 0xff) << (8 * k);
+            e[11] |= (uint32_t)(off1 & 0xff) << (8 * k);
+        }
+        e[0] = (uint32_t)sx0; e[1] = (uint32_t)span;
+        tab.insert(tab.end(), e, e + 12);
+    }
+    lv.rsRowOff = (int)tab.size();
+    for (int dy = 0; dy < lv.h; dy++) {
+        int sy, b0, b1;
+        resize_coef_host(dy, lv.rsScaleY, sh, false, sy, b0, b1);
+        const int y0 = std::min(std::max(sy, 0), sh - 1), y1 = std::min(std::max(sy + 1, 0), sh - 1);
+        tab.push_back((uint32_t)y0 | ((uint32_t)y1 << 16));
+        tab.push_back((uint32_t)(uint16_t)b0 | ((uint32_t)(uint16_t)b1 << 16));
+    }
+}
+
 int build_geometry(orbx_extractor *h, int W, int H)
 {
     OrbxGeom &g = h->geom;
@@ -153,6 +213,7 @@ int build_geometry(orbx_extractor *h, int W, int H)
     for (int i = 0; i < 7; i++) g.taps[i] = h->taps[i];
     for (int i = 0; i < 16; i++) g.umax[i] = h->umax[i];
     h->binHost.clear();
+    h->rsHost.clear();
     size_t off = 0;
     int cells = 0, slots = 0, kps = 0, btiles = 0, maxNodes = 0, maxWCell = 0, maxHCell = 0;
     for (int l = 0; l < nl; l++) {
@@ -204,12 +265,13 @@ int build_geometry(orbx_extractor *h, int W, int H)
         btiles += lv.blurTilesX * lv.blurTilesY;
         lv.scale = h->scale[(size_t)l];
         lv.patchSize = (int)(ORBX_PATCH * h->scale[(size_t)l]);
-        // cv::resize(INTER_LINEAR) from level l-1: the kernel evaluates OpenCV's index / coefficient
-        // arithmetic itself (k_resize: resize_coef), only the double inverse scales come from here
+        // cv::resize(INTER_LINEAR) from level l-1: OpenCV's index / coefficient arithmetic is tabulated here
         lv.rsScaleX = lv.rsScaleY = 1.0;
+        lv.rsColOff = lv.rsRowOff = 0;
         if (l > 0) {
             lv.rsScaleX = 1. / ((double)lv.w / g.lv[l - 1].w);
             lv.rsScaleY = 1. / ((double)lv.h / g.lv[l - 1].h);
+            build_resize_tables(h->rsHost, lv, g.lv[l - 1].w, g.lv[l - 1].h);
         }
     }
     g.cellsPerFrame = cells; g.slotsPerFrame = slots; g.kpPerFrame = kps; g.outCap = kps;
@@ -242,9 +304,11 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
         if (rc != ORBX_OK) return rc;
         if ((rc = h->geomDev.ensure(1)) != ORBX_OK) return rc;
         if ((rc = h->binDev.ensure(std::max<size_t>(h->binHost.size(), 1))) != ORBX_OK) return rc;
+        if ((rc = h->rsDev.ensure(std::max<size_t>(h->rsHost.size(), 4))) != ORBX_OK) return rc;
         ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
         ORBX_HIP_CHECK(hipMemcpy(h->geomDev.p, &h->geom, sizeof(OrbxGeom), hipMemcpyHostToDevice));
         ORBX_HIP_CHECK(hipMemcpy(h->binDev.p, h->binHost.data(), h->binHost.size(), hipMemcpyHostToDevice));
+        ORBX_HIP_CHECK(hipMemcpy(h->rsDev.p, h->rsHost.data(), h->rsHost.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         h->geomValid = true;
         h->allocBatch = 0;   // per-frame sizes changed: re-check every buffer
     }
@@ -283,6 +347,7 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     L.img0 = img0Dev; L.img0Stride = stride; L.img0FramePitch = framePitch;
     L.pyr = h->pyr.p; L.blur = h->blur.p; L.score = h->debugTaps ? h->score.p : nullptr; L.blurBytes = h->geom.pyrBytes;
     L.binTab = h->binDev.p;
+    L.rsTab = h->rsDev.p;
     L.cellCount = h->cellCount.p; L.cellSlots = h->cellSlots.p; L.ptBuf = h->ptBuf.p;
     h->cur ^= 1;
     const int cb = h->cur;
@@ -402,7 +467,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->geomDev.release(); h->binDev.release(); h->pyr.release(); h->blur.release();
+    h->geomDev.release(); h->binDev.release(); h->rsDev.release(); h->pyr.release(); h->blur.release();
     h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release();
     for (int b = 0; b < 2; b++) { h->outDesc[b].release(); h->outCnt[b].release(); h->outKp[b].release(); }
     h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->lvlKp.release();

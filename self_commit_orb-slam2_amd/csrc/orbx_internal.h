@@ -35,6 +35,7 @@ struct OrbxLevel {
     int kpBase, kpCap;      /* slice of the per-frame level-keypoint array                */
     int blurTileBase, blurTilesX, blurTilesY;
     double rsScaleX, rsScaleY; /* cv::resize inverse scale from level l-1: 1.0 / ((double)w / w_prev)  */
+    int rsColOff, rsRowOff; /* u32 offsets of this level's cv::resize tables (levels >= 1), see build_resize_tables */
     int patchSize;          /* (int)(PATCH_SIZE*scale), src/ORBextractor.cc:1175          */
     float scale;            /* mvScaleFactor[level]                                       */
 };
@@ -78,6 +79,7 @@ struct OrbxLaunch {
     uint8_t *pyr, *blur, *score;  /* device: per frame pyrBytes / blurBytes / scoreBytes    */
     size_t blurBytes;             /* blurred copy of ALL levels (level 0 included)          */
     const uint8_t *binTab;
+    const uint32_t *rsTab;        /* cv::resize index / coefficient tables of all levels */
     int *cellCount;
     uint32_t *cellSlots;
     uint32_t *ptBuf;              /* 2 * ORBX_PT_CAP u32 per (frame, level) */

@@ -60,32 +60,17 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_udot2(x.v, y.v, c, false);   // v_dot2_u32_u16: a.lo*b.lo + a.hi*b.hi + c
 }
 
-// OpenCV resize.cpp (INTER_LINEAR, 8-bit): source index and the two 11-bit coefficients of
-// destination index d.  fx = (float)((d+0.5)*scale - 0.5) with the product and the difference in
-// double, floor, fraction in float, cvRound((1-fx)*2048) / cvRound(fx*2048), saturate_cast<short>.
-// IEEE double/float arithmetic without contraction: the device reproduces the host values bit
-// for bit, so no table has to be fetched before the (dependent) source loads can be issued.
-__device__ __forceinline__ void resize_coef(int d, double scale, int slen, bool isX, int &s0, int &c0, int &c1)
-{
-    float fx = (float)(((double)d + 0.5) * scale - 0.5);
-    int sx = (int)floorf(fx);
-    fx -= (float)sx;
-    if (isX) {   // columns: coefficients reset at both borders; rows only clamp the index (done by the caller)
-        if (sx < 0) { fx = 0.f; sx = 0; }
-        if (sx >= slen - 1) { fx = 0.f; sx = slen - 1; }
-    }
-    s0 = sx;
-    c0 = min(max(__float2int_rn((1.f - fx) * 2048.f), -32768), 32767);
-    c1 = min(max(__float2int_rn(fx * 2048.f), -32768), 32767);
-}
-
+// cv::resize(INTER_LINEAR, 8-bit) from level l-1.  OpenCV's index / coefficient arithmetic (double
+// product, float fraction, cvRound to 11 bits, border rules) is evaluated once per level on the host
+// (orbx_extractor.hip: build_resize_tables); a thread fetches its column group's 12 words and one
+// word pair per row instead of ~25 VALU instructions each.
 // Horizontal taps of one pixel = ONE v_perm_b32 (two bytes of the 8-byte source window -> a u16
-// pair, selector fixed per thread) + ONE v_dot2_u32_u16 against (a0, a1); the vertical blend keeps
+// pair, selector from the table) + ONE v_dot2_u32_u16 against (a0, a1); the vertical blend keeps
 // OpenCV's two truncating >>16 terms.  Thread = 4 dst columns x 8 dst rows, 16 independent 8-byte
 // loads in flight.
 template <bool PADDED>   // source rows readable 11 bytes past the last pixel: every thread takes the aligned path
 __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, int level, const uint8_t *__restrict__ img0, int img0Stride,
-                                                size_t img0FramePitch, uint8_t *__restrict__ pyr)
+                                                size_t img0FramePitch, uint8_t *__restrict__ pyr, const uint32_t *__restrict__ rsTab)
 {
     const OrbxLevel &lv = g->lv[level];
     const int f = blockIdx.z;
@@ -93,44 +78,29 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
     const int G = (lv.w + 3) >> 2, RG = (lv.h + RS_ROWS - 1) / RS_ROWS;
     const int item = blockIdx.x * 256 + threadIdx.x;
     if (item >= G * RG) return;
-    const int rg = item / G;
-    const int dx0 = (item - rg * G) * 4, dyBase = rg * RS_ROWS;
+    const int rg = item / G, cg = item - rg * G;
+    const int dx0 = cg * 4, dyBase = rg * RS_ROWS;
     int sp;
     const uint8_t *src = level_ptr(g, level - 1, f, img0, img0Stride, img0FramePitch, pyr, sp);
-    const int sw = g->lv[level - 1].w, sh = g->lv[level - 1].h;
-    const double scaleX = lv.rsScaleX, scaleY = lv.rsScaleY;
-    // the 4 dst columns of this thread: source column, offset from the first one, coefficients
-    int off[4], off1[4];
-    uint32_t sel[4], coef[4];
-    int sx0 = 0, span = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int dx = min(dx0 + k, lv.w - 1);
-        int sx, a0, a1;
-        resize_coef(dx, scaleX, sw, true, sx, a0, a1);
-        const int sx1 = sx + 1 < sw ? sx + 1 : sx;
-        if (k == 0) sx0 = sx;
-        off[k] = sx - sx0; off1[k] = sx1 - sx0;
-        span = max(span, off1[k]);
-        sel[k] = 0x0c000c00u | (uint32_t)(off[k] & 7) | ((uint32_t)(off1[k] & 7) << 16);   // (byte off, 0, byte off1, 0)
-        coef[k] = (uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16);                 // 0 <= a0, a1 <= 2048
-    }
+    const int sw = g->lv[level - 1].w;
+    const uint32_t *ct = rsTab + lv.rsColOff + 12 * cg;
+    const uint4 c0 = *(const uint4 *)ct, c1 = *(const uint4 *)(ct + 4), c2 = *(const uint4 *)(ct + 8);
+    const int sx0 = (int)c0.x, span = (int)c0.y;
+    const uint32_t sel[4] = {c0.z, c0.w, c1.x, c1.y}, coef[4] = {c1.z, c1.w, c2.x, c2.y};   // 0 <= a0, a1 <= 2048
+    const uint2 *rt = (const uint2 *)(rsTab + lv.rsRowOff);
     // all taps inside 8 bytes from sx0, and the 12 aligned bytes that contain them inside the row pitch
     const int sxa = sx0 & ~3;
     const uint32_t mis = (uint32_t)(sx0 & 3);
     const bool wide = span <= 7 && (PADDED || sxa + 12 <= sw);
     uint8_t *dstBase = pyr + (size_t)f * g->pyrBytes + lv.off;
-    uint32_t v0[RS_ROWS][2], v1[RS_ROWS][2], bb0[RS_ROWS], bb1[RS_ROWS];
     if (wide) {
+        uint32_t v0[RS_ROWS][2], v1[RS_ROWS][2], bb[RS_ROWS];
 #pragma unroll
         for (int r = 0; r < RS_ROWS; r++) {
-            const int dy = min(dyBase + r, lv.h - 1);
-            int sy, b0, b1;
-            resize_coef(dy, scaleY, sh, false, sy, b0, b1);       // rows: no coefficient reset at the far edge, only index clamping
-            const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
-            bb0[r] = (uint32_t)b0; bb1[r] = (uint32_t)b1;
+            const uint2 t = rt[min(dyBase + r, lv.h - 1)];       // rows: no coefficient reset at the far edge, only index clamping
+            bb[r] = t.y;
             // 8 source bytes from byte sx0: three ALIGNED dwords + two v_alignbyte_b32
-            const uint32_t *p0 = (const uint32_t *)(src + (size_t)y0 * sp + sxa), *p1 = (const uint32_t *)(src + (size_t)y1 * sp + sxa);
+            const uint32_t *p0 = (const uint32_t *)(src + (size_t)(t.x & 0xffffu) * sp + sxa), *p1 = (const uint32_t *)(src + (size_t)(t.x >> 16) * sp + sxa);
             const uint32_t a0_ = p0[0], a1_ = p0[1], a2_ = p0[2], c0_ = p1[0], c1_ = p1[1], c2_ = p1[2];
             v0[r][0] = __builtin_amdgcn_alignbyte(a1_, a0_, mis); v0[r][1] = __builtin_amdgcn_alignbyte(a2_, a1_, mis);
             v1[r][0] = __builtin_amdgcn_alignbyte(c1_, c0_, mis); v1[r][1] = __builtin_amdgcn_alignbyte(c2_, c1_, mis);
@@ -139,12 +109,13 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
         for (int r = 0; r < RS_ROWS; r++) {
             const int dy = dyBase + r;
             if (dy >= lv.h) break;
+            const uint32_t b0 = bb[r] & 0xffffu, b1 = bb[r] >> 16;
             uint32_t out = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t r0 = udot2(__builtin_amdgcn_perm(v0[r][1], v0[r][0], sel[k]), coef[k], 0u);
                 const uint32_t r1 = udot2(__builtin_amdgcn_perm(v1[r][1], v1[r][0], sel[k]), coef[k], 0u);
-                const uint32_t v = (((bb0[r] * (r0 >> 4)) >> 16) + ((bb1[r] * (r1 >> 4)) >> 16) + 2u) >> 2;
+                const uint32_t v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2;
                 out |= (v & 0xffu) << (8 * k);
             }
             *(uint32_t *)(dstBase + (size_t)dy * lv.pitch + dx0) = out;   // pitch is a multiple of 64 >= round_up(w,4)
@@ -153,16 +124,16 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
         for (int r = 0; r < RS_ROWS; r++) {
             const int dy = dyBase + r;
             if (dy >= lv.h) break;
-            int sy, b0, b1;
-            resize_coef(dy, scaleY, sh, false, sy, b0, b1);
-            const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
-            const uint8_t *S0 = src + (size_t)y0 * sp + sx0, *S1 = src + (size_t)y1 * sp + sx0;
+            const uint2 t = rt[dy];
+            const uint32_t b0 = t.y & 0xffffu, b1 = t.y >> 16;
+            const uint8_t *S0 = src + (size_t)(t.x & 0xffffu) * sp + sx0, *S1 = src + (size_t)(t.x >> 16) * sp + sx0;
             uint32_t out = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t r0 = udot2((uint32_t)S0[off[k]] | ((uint32_t)S0[off1[k]] << 16), coef[k], 0u);
-                const uint32_t r1 = udot2((uint32_t)S1[off[k]] | ((uint32_t)S1[off1[k]] << 16), coef[k], 0u);
-                const uint32_t v = ((((uint32_t)b0 * (r0 >> 4)) >> 16) + (((uint32_t)b1 * (r1 >> 4)) >> 16) + 2u) >> 2;
+                const int off = (int)((c2.z >> (8 * k)) & 0xffu), off1 = (int)((c2.w >> (8 * k)) & 0xffu);
+                const uint32_t r0 = udot2((uint32_t)S0[off] | ((uint32_t)S0[off1] << 16), coef[k], 0u);
+                const uint32_t r1 = udot2((uint32_t)S1[off] | ((uint32_t)S1[off1] << 16), coef[k], 0u);
+                const uint32_t v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2;
                 out |= (v & 0xffu) << (8 * k);
             }
             *(uint32_t *)(dstBase + (size_t)dy * lv.pitch + dx0) = out;
@@ -1017,9 +988,9 @@ int orbx_launch_resize(const OrbxLaunch &L, int level)
     // pyramid levels are allocated with >= 16 spare bytes per row; the caller's level-0 rows only when the stride says so
     const bool padded = level > 1 || (L.img0Stride >= ((L.geom->lv[0].w + 3) & ~3) + 12 && L.img0FramePitch >= (size_t)L.img0Stride * (size_t)L.geom->lv[0].h);
     if (padded)
-        hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, L.stream, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr);
+        hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, L.stream, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rsTab);
     else
-        hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, L.stream, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr);
+        hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, L.stream, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rsTab);
     LAUNCH_CHECK();
     return ORBX_OK;
 }
