@@ -920,7 +920,8 @@ __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g
                                                   int *__restrict__ outCnt)
 {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the wave number is uniform: told to the compiler, the level lookup, the counts and the keypoint record become scalar work
+    const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int *cnts = lvlCnt + f * g->nlevels;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int tot = 0;
