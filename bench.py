@@ -143,8 +143,8 @@ def main():
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
     ap.add_argument("--split", action="store_true", help="cut every batch into --streams parts (one launch per part) instead of "
                     "alternating whole batches over the handle pairs")
-    ap.add_argument("--streams", type=int, default=2, help="the batch is split over this many extractor/matcher handle pairs (HIP streams) "
-                    "so that the latency-bound stages of one part overlap the VALU-bound stages of another")
+    ap.add_argument("--streams", type=int, default=3, help="extractor/matcher handle pairs (HIP stream pairs) that take the batches in turn, so that "
+                    "the latency-bound stages of one batch overlap the VALU-bound stages of the others (3 measured best: 2 -> 180k, 3 -> 187k, 4 -> 174k)")
     a = ap.parse_args()
 
     import torch
@@ -237,6 +237,16 @@ def main():
                 stage_ms[kk] = stage_ms.get(kk, 0.0) + v
     stage_ms = {kk: v / max(1, len(timed)) for kk, v in stage_ms.items()}
     match_split = np.mean([mts[k].last_kernel_timing() for k in timed], axis=0) if (mt is not None and timed) else (0.0, 0.0)
+    # the same stages with nothing else on the GPU: one handle pair, synchronised after every call (outside the timed region)
+    alone_ms = {}
+    if timed:
+        k0 = timed[0]
+        exts[k0].set_profiling(True)
+        for _ in range(3):
+            exts[k0].run_device(*devs[k0])
+            exts[k0].sync()
+        alone_ms = dict(exts[k0].last_timing()[1])
+        exts[k0].set_profiling(False)
     parts = range(NS) if a.split else range(1)            # alternating handles hold the same batch: count it once
     counts = np.concatenate([exts[k].download(Bs)[2] for k in parts])
     nm_mean = 0.0
@@ -260,6 +270,10 @@ def main():
                     "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(stage_ms[dom], 4),
                     "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                     "frames_per_launch": Bs,
+                    # the same kernel when the other stream pairs are idle (3 synchronised calls after the timed region)
+                    "uncontended": ({"avg_launch_ms": round(alone_ms[dom], 4), "achieved": round(bytes_per_launch / (alone_ms[dom] * 1e-3) / 1e9, 2),
+                                     "frac": round(bytes_per_launch / (alone_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} if alone_ms.get(dom) else None),
+                    "uncontended_stage_ms": {k: round(v, 4) for k, v in alone_ms.items()},
                     "whole_path_algorithmic_GBs": round(sum(alg.values()) * Bs / (sum(stage_ms.values()) * 1e-3) / 1e9, 2)}
         out = {
             "metric": "frames/s ORB extract+match (1000 feat, 640x480)" if not a.no_match else "frames/s ORB extract (1000 feat, 640x480)",
