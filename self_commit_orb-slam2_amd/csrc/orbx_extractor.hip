@@ -96,6 +96,8 @@ struct orbx_extractor {
     const uint8_t *lastImg0 = nullptr;
     int lastStride = 0;
     size_t lastFramePitch = 0;
+    uint8_t *hostStaging = nullptr;   // pinned: rows packed at the device layout when hipMemcpy2D would crawl
+    size_t hostStagingBytes = 0;
     int stagingStride = 0;
     size_t stagingFramePitch = 0;
 };
@@ -396,10 +398,28 @@ int upload(orbx_extractor *h, const uint8_t *const *images, int batch, int W, in
     const size_t fp = align_up((size_t)dstStride * H + 256, 256);
     int rc = h->staging.ensure(fp * (size_t)batch);
     if (rc != ORBX_OK) return rc;
-    for (int f = 0; f < batch; f++) {
+    for (int f = 0; f < batch; f++)
         if (!images[f]) { orbx_set_error("image %d is NULL", f); return ORBX_ERR_ARG; }
-        ORBX_HIP_CHECK(hipMemcpy2DAsync(h->staging.p + fp * (size_t)f, (size_t)dstStride, images[f], (size_t)stride, (size_t)W, (size_t)H,
-                                        hipMemcpyHostToDevice, h->stream));
+    if ((W & 3) || (stride & 3)) {
+        // hipMemcpy2D from pageable memory takes a row-by-row path for widths that are not a multiple of 4
+        // (measured: 2.8 ms for one 1241x376 frame against 0.03 ms for 640x480): lay the rows out at the
+        // device pitch in a pinned buffer and move the batch with ONE copy
+        const size_t bytes = fp * (size_t)batch;
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));   // the previous batch's copy has left the pinned buffer
+        if (bytes > h->hostStagingBytes) {
+            if (h->hostStaging) (void)hipHostFree(h->hostStaging);
+            h->hostStaging = nullptr; h->hostStagingBytes = 0;
+            ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostStaging, bytes, hipHostMallocDefault));
+            h->hostStagingBytes = bytes;
+        }
+        for (int f = 0; f < batch; f++)
+            for (int y = 0; y < H; y++)
+                memcpy(h->hostStaging + fp * (size_t)f + (size_t)y * dstStride, images[f] + (size_t)y * stride, (size_t)W);
+        ORBX_HIP_CHECK(hipMemcpyAsync(h->staging.p, h->hostStaging, bytes, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int f = 0; f < batch; f++)
+            ORBX_HIP_CHECK(hipMemcpy2DAsync(h->staging.p + fp * (size_t)f, (size_t)dstStride, images[f], (size_t)stride, (size_t)W, (size_t)H,
+                                            hipMemcpyHostToDevice, h->stream));
     }
     h->stagingStride = dstStride; h->stagingFramePitch = fp;
     return ORBX_OK;
@@ -468,6 +488,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->geomDev.release(); h->binDev.release(); h->rsDev.release(); h->pyr.release(); h->blur.release();
+    if (h->hostStaging) { (void)hipHostFree(h->hostStaging); h->hostStaging = nullptr; h->hostStagingBytes = 0; }
     h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release();
     for (int b = 0; b < 2; b++) { h->outDesc[b].release(); h->outCnt[b].release(); h->outKp[b].release(); }
     h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->lvlKp.release();
