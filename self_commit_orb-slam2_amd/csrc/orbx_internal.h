@@ -3,6 +3,7 @@
 #define ORBX_INTERNAL_H
 
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <stdint.h>
 
 #include "../../include/orbx.h"
@@ -120,6 +121,44 @@ template <typename T> struct OrbxDevBuf {
         return ORBX_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+/* Host arrays of one call packed into ONE pinned buffer and moved with ONE copy: a dozen small
+ * hipMemcpyAsync calls from pageable memory cost more than the kernels of a single-frame call.
+ * begin(total) sizes both sides, put() copies a host array in and returns where it will live on the
+ * device, flush() issues the copy.  The caller synchronises the stream before the next begin()
+ * (every host-array entry point ends with a synchronous download). */
+struct OrbxHostStage {
+    uint8_t *host = nullptr;
+    size_t hostBytes = 0, used = 0;
+    OrbxDevBuf<uint8_t> dev;
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    int begin(size_t total)
+    {
+        used = 0;
+        int rc = dev.ensure(total ? total : 256);
+        if (rc != ORBX_OK) return rc;
+        if (total > hostBytes) {
+            if (host) (void)hipHostFree(host);
+            host = nullptr; hostBytes = 0;
+            ORBX_HIP_CHECK(hipHostMalloc((void **)&host, total, hipHostMallocDefault));
+            hostBytes = total;
+        }
+        return ORBX_OK;
+    }
+    template <typename T> T *put(const T *src, size_t count)
+    {
+        T *d = (T *)(dev.p + used);
+        if (src && count) memcpy(host + used, src, count * sizeof(T));
+        used += padded(count * sizeof(T));
+        return d;
+    }
+    int flush(hipStream_t st)
+    {
+        if (used) ORBX_HIP_CHECK(hipMemcpyAsync(dev.p, host, used, hipMemcpyHostToDevice, st));
+        return ORBX_OK;
+    }
+    void release() { if (host) (void)hipHostFree(host); host = nullptr; hostBytes = 0; used = 0; dev.release(); }
 };
 
 /* Device view of the LAST batch of an extractor: results + the unblurred pyramid (what the

@@ -691,6 +691,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->pairsA.release(); m->pairsB.release(); m->order.release(); m->matches.release(); m->dists.release(); m->nmatches.release();
+    m->hostStage.release(); m->projDec.release(); m->projQueue.release();
     m->topk.release(); m->scales.release(); m->uright.release(); m->depth.release(); m->sad.release();
     m->topk64.release(); m->pkp.release();
     for (int q = 0; q < 2; q++) { m->pf[q].release(); m->pb[q].release(); m->pi32[q].release(); }

@@ -65,6 +65,8 @@ struct orbx_matcher {
     OrbxDevBuf<uint8_t> pb[2];
     OrbxDevBuf<int32_t> pi32[2];
     OrbxDevBuf<orbx_keypoint> pkp;
+    OrbxDevBuf<uint32_t> projDec, projQueue;   // k_proj_greedy: chosen feature per map point, rescan queue
+    OrbxHostStage hostStage;     // host-array entry points: all inputs of a call in one pinned buffer, one copy
     OrbxDevBuf<int32_t> sad;
     hipEvent_t evDep2 = nullptr, evPyr[2] = {nullptr, nullptr};
     int lastStereoPairs = 0;

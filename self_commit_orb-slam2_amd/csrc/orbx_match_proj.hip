@@ -99,78 +99,119 @@ __global__ __launch_bounds__(256) void k_proj_topk(ProjFrameDev F, ProjPointsDev
     }
 }
 
-__global__ __launch_bounds__(256) void k_proj_greedy(ProjFrameDev F, ProjPointsDev P, const float *__restrict__ scaleFactors, float th, float nnratio,
-                                                     const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
-                                                     int32_t *__restrict__ nmatches, int stride)
+// Replay of the reference's sequential pass over the map points (src/ORBmatcher.cc:70-175).  The pass is
+// sequential only through F.mvpMapPoints: a feature that already holds a MapPoint WITH observations is
+// skipped (:110-112), and an accepted point writes itself into its best feature (:169).  As in
+// k_bow_greedy the result is the unique fixed point of
+//     dec[r] = decide(candidates of point r that no accepted, observation-carrying point r' < r has taken)
+// and the kernel iterates that map for all points in parallel: owner[b] = lowest such r' currently
+// choosing feature b (LDS atomicMin), every point re-decides with "b is free iff owner[b] >= r", until
+// a round changes nothing.  A point whose FULL candidate list has fewer than two free entries cannot be
+// decided from the list: those points are queued and one wave each rescans all features exactly.
+// An accepted point without observations does not block its feature (:110-112), later points may
+// overwrite it: the feature ends up with the LAST point that chose it (atomicMax at the end).
+#define PROJ_GREEDY_THREADS 1024
+#define PROJ_NONE 0xffffffffu
+__global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_greedy(ProjFrameDev F, ProjPointsDev P, const float *__restrict__ scaleFactors, float th, float nnratio,
+                                                                     const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
+                                                                     int32_t *__restrict__ nmatches, int stride, uint32_t *__restrict__ decBuf,
+                                                                     uint32_t *__restrict__ queueBuf)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    __shared__ int sChanged, sQueued, sTotal;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
-    unsigned char *occ = smem;                  // [cap] 1 = the feature holds a MapPoint with observations
-    unsigned char *oct = smem + F.cap;          // [cap] octave of the feature
+    uint32_t *owner = (uint32_t *)smem;                          // [cap]
+    unsigned char *occ = smem + (size_t)F.cap * 4;               // [cap] 1 = the feature holds a MapPoint with observations on entry
+    unsigned char *oct = occ + F.cap;                            // [cap] octave of the feature
     const size_t fbase = (size_t)f * F.cap, pbase = (size_t)f * P.cap;
+    uint32_t *dec = decBuf + pbase, *queue = queueBuf + pbase;   // chosen feature of every point / rescan queue (global: P.cap is not bounded by LDS)
     int32_t *aout = assigned + (size_t)f * stride;
-    for (int i = tid; i < stride; i += 256) aout[i] = -1;
-    for (int i = tid; i < n; i += 256) { occ[i] = F.occupied ? F.occupied[fbase + i] : 0; oct[i] = (unsigned char)F.kp[fbase + i].octave; }
-    __syncthreads();
-    if (tid >= 64) return;
-    int total = 0;
+    for (int i = tid; i < stride; i += PROJ_GREEDY_THREADS) aout[i] = -1;
+    for (int i = tid; i < n; i += PROJ_GREEDY_THREADS) { occ[i] = F.occupied ? F.occupied[fbase + i] : 0; oct[i] = (unsigned char)F.kp[fbase + i].octave; }
+    for (int r = tid; r < m; r += PROJ_GREEDY_THREADS) dec[r] = PROJ_NONE;
+    if (tid == 0) sTotal = 0;
     const unsigned long long *tk = topk + pbase * TOPK;
-    unsigned long long nextKeys = (0 < m) ? tk[min((size_t)lane, (size_t)m * TOPK - 1)] : KEY64_EMPTY;
-    for (int i0 = 0; i0 < m; i0 += 8) {
-        const unsigned long long keys = nextKeys;   // lists of map points i0 .. i0+7, lane = 8*(i-i0) + rank
-        {
-            const size_t nx = (size_t)(i0 + 8) * TOPK + lane;
-            nextKeys = (i0 + 8 < m) ? tk[min(nx, (size_t)m * TOPK - 1)] : KEY64_EMPTY;   // in flight while these 8 points are replayed
+    // acceptance of the best / second best free candidate (:150-168)
+    auto decide = [&](unsigned long long k1, unsigned long long k2) -> uint32_t {
+        if (k1 == KEY64_EMPTY) return PROJ_NONE;
+        const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xffff);
+        const int bestDist2 = k2 == KEY64_EMPTY ? 256 : (int)(k2 >> 32);
+        const int bestLevel = oct[bestIdx], bestLevel2 = k2 == KEY64_EMPTY ? -1 : (int)oct[(int)(k2 & 0xffff)];
+        if (bestDist > TH_HIGH) return PROJ_NONE;
+        if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) return PROJ_NONE;
+        return (uint32_t)bestIdx;
+    };
+    for (;;) {
+        __syncthreads();
+        for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = 0xffffffffu;
+        if (tid == 0) { sChanged = 0; sQueued = 0; }
+        __syncthreads();
+        for (int r = tid; r < m; r += PROJ_GREEDY_THREADS) {
+            const uint32_t d = dec[r];
+            if (d != PROJ_NONE && (!P.hasObs || P.hasObs[pbase + r])) atomicMin(&owner[d], (uint32_t)r);
         }
-        for (int j = 0; j < 8 && i0 + j < m; j++) {
-            const int i = i0 + j;
-            const size_t pi = pbase + i;
-            if (!P.inView[pi]) continue;
-            const unsigned long long key = __shfl(keys, 8 * j + (lane & 7));   // lanes 0..7 hold the list of point i
-            const bool present = lane < TOPK && key != KEY64_EMPTY;
-            const int idx = (int)(key & 0xffff);
-            const bool free_ = present && !occ[idx];
-            const unsigned mAll = (1u << TOPK) - 1u;
-            const unsigned mPresent = (unsigned)(__ballot(present) & mAll), mFree = (unsigned)(__ballot(free_) & mAll);
+        __syncthreads();
+        bool changed = false;
+        for (int r = tid; r < m; r += PROJ_GREEDY_THREADS) {
+            if (!P.inView[pbase + r]) continue;
+            const ulonglong2 *lp = (const ulonglong2 *)(tk + (size_t)r * TOPK);
+            const ulonglong2 q0 = lp[0], q1 = lp[1], q2 = lp[2], q3 = lp[3];
+            const unsigned long long keys[TOPK] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
             unsigned long long k1 = KEY64_EMPTY, k2 = KEY64_EMPTY;
-            if (__popc(mFree) >= 2 || mPresent != mAll) {
-                if (mFree) {
-                    k1 = __shfl(key, __ffs(mFree) - 1);
-                    const unsigned rest = mFree & (mFree - 1);
-                    if (rest) k2 = __shfl(key, __ffs(rest) - 1);
+            int nfree = 0;
+#pragma unroll
+            for (int k = 0; k < TOPK; k++) {
+                const unsigned long long key = keys[k];
+                const int idx = (int)(key & 0xffff);
+                if (key != KEY64_EMPTY && !occ[idx] && owner[idx] >= (uint32_t)r) {
+                    if (nfree == 0) k1 = key; else if (nfree == 1) k2 = key;
+                    nfree++;
                 }
-            } else {
-                // exact rescan: the two smallest keys among the features that are still free
-                const ProjQuery q = proj_query(F, P, pi, scaleFactors, th);
-                unsigned long long a = KEY64_EMPTY, b = KEY64_EMPTY;
-                if (q.any)
-                    for (int x = lane; x < n; x += 64) {
-                        if (occ[x]) continue;
-                        const unsigned long long kx = proj_key(F, fbase, x, q);
-                        if (kx < a) { b = a; a = kx; } else if (kx < b) b = kx;
-                    }
-                k1 = wave_min_u64(a);
-                if (a == k1) a = b;
-                k2 = wave_min_u64(a);
             }
-            if (k1 == KEY64_EMPTY) continue;
-            const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xffff);
-            const int bestDist2 = k2 == KEY64_EMPTY ? 256 : (int)(k2 >> 32);
-            const int bestLevel = oct[bestIdx], bestLevel2 = k2 == KEY64_EMPTY ? -1 : (int)oct[(int)(k2 & 0xffff)];
-            if (bestDist <= TH_HIGH) {
-                if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
-                if (lane == 0) {
-                    aout[bestIdx] = i;                                  // F.mvpMapPoints[bestIdx] = pMP
-                    occ[bestIdx] = P.hasObs ? P.hasObs[pi] : 1;         // what :110-112 sees from now on
-                }
-                total++;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-            }
+            if (nfree < 2 && keys[TOPK - 1] != KEY64_EMPTY) { queue[atomicAdd(&sQueued, 1)] = (uint32_t)r; continue; }   // full list, exhausted
+            const uint32_t nd = decide(k1, k2);
+            if (nd != dec[r]) { dec[r] = nd; changed = true; }
         }
+        if (changed) sChanged = 1;
+        __syncthreads();
+        // exact rescans: one wave per queued point, the two smallest keys among the features that are free for it
+        const int nq = sQueued;
+        for (int qi = wv; qi < nq; qi += PROJ_GREEDY_THREADS / 64) {
+            const int r = (int)queue[qi];
+            const ProjQuery q = proj_query(F, P, pbase + r, scaleFactors, th);
+            unsigned long long a = KEY64_EMPTY, b = KEY64_EMPTY;
+            if (q.any)
+                for (int x = lane; x < n; x += 64) {
+                    if (occ[x] || owner[x] < (uint32_t)r) continue;
+                    const unsigned long long kx = proj_key(F, fbase, x, q);
+                    if (kx < a) { b = a; a = kx; } else if (kx < b) b = kx;
+                }
+            const unsigned long long k1 = wave_min_u64(a);
+            if (a == k1) a = b;
+            const unsigned long long k2 = wave_min_u64(a);
+            const uint32_t nd = decide(k1, k2);
+            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChanged = 1; }
+        }
+        __syncthreads();
+        const int again = sChanged;
+        if (!again) break;
     }
-    if (lane == 0) nmatches[f] = total;
+    // F.mvpMapPoints[bestIdx] = pMP in rank order: the last point that chose a feature keeps it
+    __syncthreads();
+    for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = 0u;
+    __syncthreads();
+    int total = 0;
+    for (int r = tid; r < m; r += PROJ_GREEDY_THREADS) {
+        const uint32_t d = dec[r];
+        if (d != PROJ_NONE) { atomicMax(&owner[d], (uint32_t)r + 1u); total++; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if (lane == 0 && total) atomicAdd(&sTotal, total);
+    __syncthreads();
+    for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) if (owner[j]) aout[j] = (int32_t)owner[j] - 1;
+    if (tid == 0) nmatches[f] = sTotal;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -963,10 +1004,12 @@ static int proj_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjPointsD
     m->midValid[slot] = false;
     hipLaunchKernelGGL(k_proj_topk, dim3((unsigned)((P.cap + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, F, P, m->scales.p, th, m->topk64.p);
     MLAUNCH_CHECK();
-    const size_t lds = (size_t)F.cap * 2 + 16;
-    if (lds > 64 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_proj_greedy, dim3((unsigned)nframes), dim3(256), lds, m->stream, F, P, m->scales.p, th, nnratio, m->topk64.p, m->matches.p,
-                       m->nmatches.p, stride);
+    const size_t lds = (size_t)F.cap * 6 + 16;
+    if (lds > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile of the projection replay", F.cap); return ORBX_ERR_CAPACITY; }
+    if ((rc = m->projDec.ensure((size_t)nframes * P.cap)) != ORBX_OK || (rc = m->projQueue.ensure((size_t)nframes * P.cap)) != ORBX_OK) return rc;
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_proj_greedy, dim3((unsigned)nframes), dim3(PROJ_GREEDY_THREADS), lds, m->stream, F, P, m->scales.p, th, nnratio, m->topk64.p, m->matches.p,
+                       m->nmatches.p, stride, m->projDec.p, m->projQueue.p);
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
     m->profCount++;
@@ -1004,29 +1047,25 @@ extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_projection_
     if (n > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
     ORBX_HIP_CHECK(hipSetDevice(m->device));
     int rc;
-    // staging: frame side in pkp / hd[0] / pf[0] / pb[0], point side in pf[1] (5 float arrays) / pi32[1] / pb[1] (in_view, has_obs, descriptors)
-    if ((rc = m->pkp.ensure((size_t)n)) || (rc = m->hd[0].ensure((size_t)n * 32)) || (rc = m->pf[0].ensure((size_t)n)) || (rc = m->pb[0].ensure((size_t)n)) ||
-        (rc = m->pi32[0].ensure(2)) || (rc = m->pf[1].ensure((size_t)mm * 4)) || (rc = m->pi32[1].ensure((size_t)mm)) || (rc = m->pb[1].ensure((size_t)mm * 34)))
-        return rc;
+    // all thirteen input arrays through one pinned buffer and one copy
     hipStream_t st = m->stream;
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, fr->keypoints_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[0].p, fr->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[0].p, fr->u_right, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    if (fr->occupied) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[0].p, fr->occupied, (size_t)n, hipMemcpyHostToDevice, st));
+    OrbxHostStage &hs = m->hostStage;
+    const size_t N = (size_t)n, M = (size_t)mm;
+    const size_t total = hs.padded(N * sizeof(orbx_keypoint)) + hs.padded(N * 32) + hs.padded(N * 4) + hs.padded(N) + hs.padded(8) + 5 * hs.padded(M * 4) +
+                         hs.padded(M * 32) + 2 * hs.padded(M);
+    if ((rc = hs.begin(total)) != ORBX_OK) return rc;
     const int32_t cnt[2] = {n, mm};
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, pt->proj_x, (size_t)mm * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + mm, pt->proj_y, (size_t)mm * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 2 * (size_t)mm, pt->proj_xr, (size_t)mm * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 3 * (size_t)mm, pt->view_cos, (size_t)mm * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p, pt->scale_level, (size_t)mm * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p, pt->descriptors, (size_t)mm * 32, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)mm * 32, pt->in_view, (size_t)mm, hipMemcpyHostToDevice, st));
-    if (pt->has_observations) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)mm * 33, pt->has_observations, (size_t)mm, hipMemcpyHostToDevice, st));
-    ProjFrameDev F = {m->pkp.p, m->hd[0].p, m->pf[0].p, fr->occupied ? m->pb[0].p : nullptr, m->pi32[0].p, n, fr->min_x, fr->min_y, fr->grid_width_inv,
-                      fr->grid_height_inv};
-    ProjPointsDev P = {m->pf[1].p, m->pf[1].p + mm, m->pf[1].p + 2 * (size_t)mm, m->pi32[1].p, m->pf[1].p + 3 * (size_t)mm, m->pb[1].p + (size_t)mm * 32,
-                       pt->has_observations ? m->pb[1].p + (size_t)mm * 33 : nullptr, m->pb[1].p, m->pi32[0].p + 1, mm};
+    const orbx_keypoint *dKp = hs.put(fr->keypoints_un, N);
+    const uint8_t *dDesc = hs.put(fr->descriptors, N * 32);
+    const float *dUr = hs.put(fr->u_right, N);
+    const uint8_t *dOcc = hs.put(fr->occupied, N);
+    const int32_t *dCnt = hs.put(cnt, 2);
+    const float *dPx = hs.put(pt->proj_x, M), *dPy = hs.put(pt->proj_y, M), *dPxr = hs.put(pt->proj_xr, M), *dCos = hs.put(pt->view_cos, M);
+    const int32_t *dLvl = hs.put(pt->scale_level, M);
+    const uint8_t *dPd = hs.put(pt->descriptors, M * 32), *dIn = hs.put(pt->in_view, M), *dObs = hs.put(pt->has_observations, M);
+    if ((rc = hs.flush(st)) != ORBX_OK) return rc;
+    ProjFrameDev F = {dKp, dDesc, dUr, fr->occupied ? dOcc : nullptr, dCnt, n, fr->min_x, fr->min_y, fr->grid_width_inv, fr->grid_height_inv};
+    ProjPointsDev P = {dPx, dPy, dPxr, dLvl, dCos, dIn, pt->has_observations ? dObs : nullptr, dPd, dCnt + 1, mm};
     if ((rc = proj_launch(m, F, P, 1, scale_factors, nlevels, th, nn_ratio)) != ORBX_OK) return rc;
     ORBX_HIP_CHECK(hipStreamSynchronize(st));
     ORBX_HIP_CHECK(hipMemcpy(assigned, m->matches.p, (size_t)n * 4, hipMemcpyDeviceToHost));

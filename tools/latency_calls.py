@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Latency of the single-frame, host-array forms of the drop-in calls (what Tracking.cc / LocalMapping.cc
+would see per frame through the shim): each timed call includes its uploads and downloads."""
+import importlib, sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+orbx = importlib.import_module("self_commit_orb-slam2_amd")
+
+
+def bench(name, fn, n=30, warm=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts = np.array(ts) * 1e3
+    print("%-58s median %.3f ms  min %.3f ms" % (name, np.median(ts), ts.min()), flush=True)
+
+
+W, H, nf = 640, 480, 1000
+fr = orbx.synth_sequence(3, 4, W, H)
+ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=1)
+bench("ORBextractor::operator() 640x480/1000", lambda: ext(fr[0]))
+kA, dA = ext(fr[0])
+kB, dB = ext(fr[1])
+mt = orbx.ORBmatcher(0.7, True, max_features=4096, max_pairs=1)
+bench("ORBmatcher::SearchByBoW (one node, %d x %d)" % (len(kA), len(kB)), lambda: mt.SearchByBoW(kA, dA, kB, dB))
+grp = (np.arange(len(kA)) % 50).astype(np.int32)
+grpB = (np.arange(len(kB)) % 50).astype(np.int32)
+bench("ORBmatcher::SearchByBoW (50 nodes)", lambda: mt.SearchByBoW(kA, dA, kB, dB, groupsA=grp, groupsB=grpB))
+
+rng = np.random.default_rng(5)
+n, m = len(kB), 4000
+T = np.eye(4, dtype=np.float32)
+P = np.stack([rng.uniform(-4, 4, m), rng.uniform(-3, 3, m), rng.uniform(1, 10, m)], 1).astype(np.float32)
+nrm = (-P / np.linalg.norm(P, axis=1, keepdims=True)).astype(np.float32)
+d = np.linalg.norm(P, axis=1).astype(np.float32)
+pts = dict(pos=P, normal=-nrm, max_distance=d * 1.5, min_distance=d * 0.4)
+lsf = float(np.float32(np.log(np.float32(1.2))))
+sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+mdesc = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+frus = lambda: mt.isInFrustum(T, (500.0, 500.0, 320.0, 240.0, 40.0), (0.0, 640.0, 0.0, 480.0), lsf, 8, pts, 0.5)
+bench("Frame::isInFrustum x %d map points" % m, frus)
+r = frus()
+frame = dict(kps=kB, desc=dB, u_right=np.full(n, -1, np.float32), occupied=np.zeros(n, np.uint8), scale_factors=sf, width=W, height=H)
+points = dict(proj_x=r["proj_x"], proj_y=r["proj_y"], proj_xr=r["proj_xr"], level=r["level"], view_cos=r["view_cos"], in_view=r["in_view"],
+              has_obs=np.ones(m, np.uint8), desc=mdesc)
+bench("ORBmatcher::SearchByProjection(F, %d points, th=3)" % m, lambda: mt.SearchByProjection(frame, points, 3.0))
+
+cam = orbx.Camera(fx=517.3, fy=516.5, cx=318.6, cy=255.3, k1=0.2624, k2=-0.9531, p1=-0.0054, p2=0.0026, k3=1.1633)
+try:
+    fo = orbx.FrameOps(cam, max_features=4096)
+    b = fo.ComputeImageBounds(W, H)
+    g = orbx.FrameGrid.from_bounds(b)
+    bench("Frame::UndistortKeyPoints", lambda: fo.UndistortKeyPoints(kB))
+    ku = fo.UndistortKeyPoints(kB)
+    bench("Frame::AssignFeaturesToGrid", lambda: fo.AssignFeaturesToGrid(ku, g))
+except Exception as e:   # signature drift in this helper script must not hide the other numbers
+    print("FrameOps skipped:", e)
