@@ -314,93 +314,109 @@ __global__ __launch_bounds__(256) void k_proj_last_topk(ProjFrameDev F, ProjLast
     }
 }
 
-__global__ __launch_bounds__(256) void k_proj_last_greedy(ProjFrameDev F, ProjLastDev L, const float *__restrict__ scaleFactors, float th, int bMono,
-                                                          int checkOri, const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
-                                                          int32_t *__restrict__ nmatches, int stride)
+// The same parallel fixed point as k_proj_greedy (the pass over the last frame's points is sequential only
+// through CurrentFrame.mvpMapPoints, :1660-1662 / :1689); a point takes its best free candidate alone, there
+// is no second-best test.
+__global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_last_greedy(ProjFrameDev F, ProjLastDev L, const float *__restrict__ scaleFactors, float th, int bMono,
+                                                                          int checkOri, const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
+                                                                          int32_t *__restrict__ nmatches, int stride, uint32_t *__restrict__ decBuf,
+                                                                          uint32_t *__restrict__ queueBuf)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int hist[HISTO_LENGTH];
-    __shared__ int sTotal, sRemoved;
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    __shared__ int sTotal, sRemoved, sChanged, sQueued;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = min(F.counts[f], F.cap), nl = min(L.counts[f], L.cap);
-    unsigned char *occ = smem;                              // [cap]
-    int32_t *sAsg = (int32_t *)(smem + ((F.cap + 15) & ~15));   // [cap] last-frame feature given to current feature i2, or -1
-    uint32_t *sEv = (uint32_t *)(sAsg + F.cap);             // [L.cap] accepted assignments in order: point << 16 | feature
+    uint32_t *owner = (uint32_t *)smem;                     // [cap] lowest observation-carrying point choosing the feature; later: its final holder
+    unsigned char *occ = smem + (size_t)F.cap * 4;          // [cap]
     const size_t fbase = (size_t)f * F.cap, lbase = (size_t)f * L.cap;
+    uint32_t *dec = decBuf + lbase, *queue = queueBuf + lbase;
     int32_t *aout = assigned + (size_t)f * stride;
-    for (int i = tid; i < F.cap; i += 256) { sAsg[i] = -1; occ[i] = (i < n && F.occupied) ? F.occupied[fbase + i] : 0; }
+    for (int i = tid; i < F.cap; i += PROJ_GREEDY_THREADS) occ[i] = (i < n && F.occupied) ? F.occupied[fbase + i] : 0;
+    for (int r = tid; r < nl; r += PROJ_GREEDY_THREADS) dec[r] = PROJ_NONE;
     if (tid < HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) { sTotal = 0; sRemoved = 0; }
-    __syncthreads();
-    if (tid < 64) {
-        bool bForward, bBackward;
-        proj_motion(L.tcwCur + 16 * (size_t)f, L.tcwLast + 16 * (size_t)f, L.mb, bMono, bForward, bBackward);
-        int total = 0;
-        const unsigned long long *tk = topk + lbase * TOPK;
-        unsigned long long nextKeys = (0 < nl) ? tk[min((size_t)lane, (size_t)nl * TOPK - 1)] : KEY64_EMPTY;
-        for (int i0 = 0; i0 < nl; i0 += 8) {
-            const unsigned long long keys = nextKeys;
-            {
-                const size_t nx = (size_t)(i0 + 8) * TOPK + lane;
-                nextKeys = (i0 + 8 < nl) ? tk[min(nx, (size_t)nl * TOPK - 1)] : KEY64_EMPTY;
-            }
-            for (int j = 0; j < 8 && i0 + j < nl; j++) {
-                const int i = i0 + j;
-                const unsigned long long key = __shfl(keys, 8 * j + (lane & 7));
-                const bool present = lane < TOPK && key != KEY64_EMPTY;
-                const unsigned mAll = (1u << TOPK) - 1u;
-                const unsigned mPresent = (unsigned)(__ballot(present) & mAll);
-                if (!mPresent) continue;                    // skipped point or empty window
-                const bool free_ = present && !occ[(int)(key & 0xffff)];
-                const unsigned mFree = (unsigned)(__ballot(free_) & mAll);
-                unsigned long long k1 = KEY64_EMPTY;
-                if (mFree) k1 = __shfl(key, __ffs(mFree) - 1);
-                else if (mPresent == mAll) {
-                    // every listed candidate is taken and the list was full: exact rescan for the best free one
-                    ProjQuery q;
-                    unsigned long long a = KEY64_EMPTY;
-                    if (proj_last_query(F, L, f, lbase + i, scaleFactors, th, bForward, bBackward, q))
-                        for (int x = lane; x < n; x += 64) {
-                            if (occ[x]) continue;
-                            const unsigned long long kx = proj_key(F, fbase, x, q);
-                            a = kx < a ? kx : a;
-                        }
-                    k1 = wave_min_u64(a);
-                }
-                if (k1 == KEY64_EMPTY) continue;
-                const int bestDist = (int)(k1 >> 32), bestIdx2 = (int)(k1 & 0xffff);
-                if (bestDist <= TH_HIGH) {
-                    if (lane == 0) {
-                        sAsg[bestIdx2] = i;                                     // CurrentFrame.mvpMapPoints[bestIdx2] = pMP
-                        occ[bestIdx2] = L.hasObs ? L.hasObs[lbase + i] : 1;
-                        sEv[total] = ((uint32_t)i << 16) | (uint32_t)bestIdx2;
-                    }
-                    total++;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
+    bool bForward, bBackward;
+    proj_motion(L.tcwCur + 16 * (size_t)f, L.tcwLast + 16 * (size_t)f, L.mb, bMono, bForward, bBackward);
+    const unsigned long long *tk = topk + lbase * TOPK;
+    for (;;) {
+        __syncthreads();
+        for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = 0xffffffffu;
+        if (tid == 0) { sChanged = 0; sQueued = 0; }
+        __syncthreads();
+        for (int r = tid; r < nl; r += PROJ_GREEDY_THREADS) {
+            const uint32_t d = dec[r];
+            if (d != PROJ_NONE && (!L.hasObs || L.hasObs[lbase + r])) atomicMin(&owner[d], (uint32_t)r);
         }
-        if (lane == 0) sTotal = total;
+        __syncthreads();
+        bool changed = false;
+        for (int r = tid; r < nl; r += PROJ_GREEDY_THREADS) {
+            const ulonglong2 *lp = (const ulonglong2 *)(tk + (size_t)r * TOPK);
+            const ulonglong2 q0 = lp[0], q1 = lp[1], q2 = lp[2], q3 = lp[3];
+            const unsigned long long keys[TOPK] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+            if (keys[0] == KEY64_EMPTY) continue;                       // skipped point or empty window
+            unsigned long long k1 = KEY64_EMPTY;
+#pragma unroll
+            for (int k = TOPK - 1; k >= 0; k--) {
+                const unsigned long long key = keys[k];
+                const int idx = (int)(key & 0xffff);
+                if (key != KEY64_EMPTY && !occ[idx] && owner[idx] >= (uint32_t)r) k1 = key;   // ends on the first free entry
+            }
+            if (k1 == KEY64_EMPTY && keys[TOPK - 1] != KEY64_EMPTY) { queue[atomicAdd(&sQueued, 1)] = (uint32_t)r; continue; }   // full list, all taken
+            const uint32_t nd = (k1 != KEY64_EMPTY && (int)(k1 >> 32) <= TH_HIGH) ? (uint32_t)(k1 & 0xffff) : PROJ_NONE;
+            if (nd != dec[r]) { dec[r] = nd; changed = true; }
+        }
+        if (changed) sChanged = 1;
+        __syncthreads();
+        const int nq = sQueued;
+        for (int qi = wv; qi < nq; qi += PROJ_GREEDY_THREADS / 64) {
+            const int r = (int)queue[qi];
+            ProjQuery q;
+            unsigned long long a = KEY64_EMPTY;
+            if (proj_last_query(F, L, f, lbase + r, scaleFactors, th, bForward, bBackward, q))
+                for (int x = lane; x < n; x += 64) {
+                    if (occ[x] || owner[x] < (uint32_t)r) continue;
+                    const unsigned long long kx = proj_key(F, fbase, x, q);
+                    a = kx < a ? kx : a;
+                }
+            const unsigned long long k1 = wave_min_u64(a);
+            const uint32_t nd = (k1 != KEY64_EMPTY && (int)(k1 >> 32) <= TH_HIGH) ? (uint32_t)(k1 & 0xffff) : PROJ_NONE;
+            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChanged = 1; }
+        }
+        __syncthreads();
+        const int again = sChanged;
+        if (!again) break;
     }
+    // CurrentFrame.mvpMapPoints[bestIdx2] = pMP in point order: the last chooser holds the feature (owner := holder + 1, 0 = none)
     __syncthreads();
-    // rotation histogram over the ACCEPTED assignments in the order they were made (:1694-1704): a
-    // feature whose first holder had no observations can be re-assigned later and then sits in two
-    // bins; pruning a bin clears the feature whichever holder put it there (:1712-1722).
+    for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = 0u;
+    __syncthreads();
+    // rotation histogram over the ACCEPTED assignments (:1694-1704): a feature whose first holder had no
+    // observations can be re-assigned later and then sits in two bins; pruning a bin clears the feature
+    // whichever holder put it there (:1712-1722).
     const float factor = HISTO_LENGTH / 360.0f;
-    if (checkOri) {
-        const int nev = sTotal;
-        for (int e = tid; e < nev; e += 256) {
-            const uint32_t ev = sEv[e];
-            const int li = (int)(ev >> 16), i2 = (int)(ev & 0xffff);
-            float rot = L.angle[lbase + li] - F.kp[fbase + i2].angle;
+    int total = 0;
+    for (int r = tid; r < nl; r += PROJ_GREEDY_THREADS) {
+        const uint32_t d = dec[r];
+        if (d == PROJ_NONE) continue;
+        atomicMax(&owner[d], (uint32_t)r + 1u);
+        total++;
+        if (checkOri) {
+            float rot = L.angle[lbase + r] - F.kp[fbase + d].angle;
             if (rot < 0.0f) rot += 360.0f;
             int bin = (int)roundf(rot * factor);
             if (bin == HISTO_LENGTH) bin = 0;
-            sEv[e] = (ev & 0xffffu) | ((uint32_t)bin << 16);   // keep feature + bin
+            dec[r] = d | ((uint32_t)bin << 16);   // keep feature + bin (F.cap <= 65535)
             atomicAdd(&hist[bin], 1);
         }
-        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if (lane == 0 && total) atomicAdd(&sTotal, total);
+    __syncthreads();
+    for (int j = tid; j < stride; j += PROJ_GREEDY_THREADS) aout[j] = (j < n && owner[j]) ? (int32_t)owner[j] - 1 : -1;
+    __syncthreads();
+    if (checkOri) {
         int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
         for (int b = 0; b < HISTO_LENGTH; b++) {
             const int sN = hist[b];
@@ -411,17 +427,17 @@ __global__ __launch_bounds__(256) void k_proj_last_greedy(ProjFrameDev F, ProjLa
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         int removed = 0;
-        for (int e = tid; e < nev; e += 256) {
-            const uint32_t ev = sEv[e];
-            const int b = (int)(ev >> 16);
-            if (b != ind1 && b != ind2 && b != ind3) { sAsg[ev & 0xffffu] = -2; removed++; }   // -2: assigned, then cleared (:1718)
+        for (int r = tid; r < nl; r += PROJ_GREEDY_THREADS) {      // same point -> thread mapping as the pass above
+            const uint32_t d = dec[r];
+            if (d == PROJ_NONE) continue;
+            const int b = (int)(d >> 16);
+            if (b != ind1 && b != ind2 && b != ind3) { aout[d & 0xffffu] = -2; removed++; }   // -2: assigned, then cleared (:1718)
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
         if (lane == 0 && removed) atomicAdd(&sRemoved, removed);
     }
     __syncthreads();
-    for (int i = tid; i < stride; i += 256) aout[i] = i < n ? sAsg[i] : -1;
     if (tid == 0) nmatches[f] = sTotal - sRemoved;
 }
 
@@ -1088,11 +1104,12 @@ static int proj_last_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjLa
     m->midValid[slot] = false;
     hipLaunchKernelGGL(k_proj_last_topk, dim3((unsigned)((L.cap + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, F, L, m->scales.p, th, b_mono, m->topk64.p);
     MLAUNCH_CHECK();
-    const size_t lds = (size_t)((F.cap + 15) & ~15) + (size_t)F.cap * 4 + (size_t)L.cap * 4 + 16;
+    const size_t lds = (size_t)F.cap * 5 + 16;
     if (lds > 160 * 1024) { orbx_set_error("capacities too large for the LDS tile"); return ORBX_ERR_CAPACITY; }
+    if ((rc = m->projDec.ensure((size_t)nframes * L.cap)) != ORBX_OK || (rc = m->projQueue.ensure((size_t)nframes * L.cap)) != ORBX_OK) return rc;
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_last_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_proj_last_greedy, dim3((unsigned)nframes), dim3(256), lds, m->stream, F, L, m->scales.p, th, b_mono, check_ori, m->topk64.p,
-                       m->matches.p, m->nmatches.p, stride);
+    hipLaunchKernelGGL(k_proj_last_greedy, dim3((unsigned)nframes), dim3(PROJ_GREEDY_THREADS), lds, m->stream, F, L, m->scales.p, th, b_mono, check_ori, m->topk64.p,
+                       m->matches.p, m->nmatches.p, stride, m->projDec.p, m->projQueue.p);
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
     m->profCount++;

@@ -61,3 +61,21 @@ try:
     bench("Frame::AssignFeaturesToGrid", lambda: fo.AssignFeaturesToGrid(ku, g))
 except Exception as e:   # signature drift in this helper script must not hide the other numbers
     print("FrameOps skipped:", e)
+
+# ---- the remaining single-frame calls, on the inputs of the parity tests ----
+sys.path.insert(0, str(ROOT / "tests"))
+try:
+    import test_projection as tp, test_search_init as tsi, test_pose_optimization as tpo
+    frl, last = tp.make_last_case(21, 0.0)
+    mtl = orbx.ORBmatcher(0.9, True, max_features=2048)
+    framel = dict(frl, kps=tp._struct_kps(orbx, frl["kps7"]))
+    lastd = dict(last, kps=tp._struct_kps(orbx, last["kps7"]), valid=(last["valid"] == 1).astype(np.uint8))
+    bench("ORBmatcher::SearchByProjection(Current, Last) %d x %d" % (len(framel["kps"]), len(lastd["kps"])), lambda: mtl.SearchByProjectionLast(framel, lastd, 7.0, 0))
+    f1, f2, prev = tsi._frames(orbx, 11, n=1500)
+    mti = orbx.ORBmatcher(0.9, True, max_features=1500)
+    bench("ORBmatcher::SearchForInitialization 1500 x 1500, window 100", lambda: mti.SearchForInitialization(f1, f2, prev, 100))
+    pf = [tpo.make_frame(10, n=600)]
+    po = orbx.PoseOptimizer(max_frames=8, max_features=2048)
+    bench("Optimizer::PoseOptimization, one frame, 600 correspondences", lambda: po.PoseOptimization(pf))
+except Exception as e:
+    print("skipped:", repr(e))

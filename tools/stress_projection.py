@@ -33,5 +33,24 @@ for c in range(cases):
         print("MISMATCH case", c, n, m, crowded, th, ratio, got_n, want_n, int((got != want).sum()))
     if mt2 is not mt:
         mt2.close()
-print("stress_projection: %d cases, %d mismatches, %.1f s" % (cases, bad, time.time() - t0))
+# ---- SearchByProjection(CurrentFrame, LastFrame, th, bMono): k_proj_last_greedy ----
+for c in range(cases):
+    rng = np.random.default_rng(5000 + c)
+    n = int(rng.choice([60, 300, 1500]))
+    nl = int(rng.choice([20, 800, 1400, 1900]))
+    crowded = bool(rng.integers(0, 2))
+    th = float(rng.choice([7.0, 15.0, 30.0]))
+    mono, ori = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    fr, last = tp.make_last_case(3000 + c, float(rng.choice([0.0, 0.5, -0.5])), n=n, nl=nl, crowded=crowded)
+    last["has_obs"] = (rng.random(nl) < rng.choice([0.0, 0.5, 1.0])).astype(np.uint8)
+    fr["occupied"] = (rng.random(n) < rng.choice([0.0, 0.1, 0.6])).astype(np.uint8)
+    want_n, want = oracle_lib.search_by_projection_last(orc, fr, last, th, mono, ori)
+    mtl = orbx.ORBmatcher(0.9, bool(ori), max_features=2048)
+    got_n, got = mtl.SearchByProjectionLast(dict(fr, kps=tp._struct_kps(orbx, fr["kps7"])),
+                                            dict(last, kps=tp._struct_kps(orbx, last["kps7"]), valid=(last["valid"] == 1).astype(np.uint8)), th, mono)
+    if got_n != want_n or not (got == want).all():
+        bad += 1
+        print("MISMATCH last case", c, n, nl, crowded, th, mono, ori, got_n, want_n, int((got != want).sum()))
+    mtl.close()
+print("stress_projection: 2 x %d cases, %d mismatches, %.1f s" % (cases, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
