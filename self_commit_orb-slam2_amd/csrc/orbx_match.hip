@@ -950,23 +950,29 @@ extern "C" int orbx_matcher_last_kernel_timing(orbx_matcher *m, float *distance_
 namespace orbx_match {
 int stage_host(orbx_matcher *m, int side, const orbx_feature_set *h, orbx_feature_set *d)
 {
+    // the five arrays of a side go through the pinned staging buffer and ONE copy (ten small copies from pageable memory
+    // cost more than the kernels of a single-pair call): side 0 opens the buffer, sized for two full feature sets
     if (!h || !h->keypoints || !h->descriptors || !h->counts) { orbx_set_error("NULL feature arrays"); return ORBX_ERR_ARG; }
     const int n = h->counts[0];
     if (n < 0 || n > m->maxFeatures) { orbx_set_error("feature count %d exceeds max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    OrbxHostStage &hs = m->hostStage;
     const size_t cap = (size_t)m->maxFeatures;
     int rc;
-    if ((rc = m->hk[side].ensure(cap)) || (rc = m->hd[side].ensure(cap * 32)) || (rc = m->hc[side].ensure(1)) || (rc = m->hg[side].ensure(cap)) ||
-        (rc = m->hv[side].ensure(cap)))
-        return rc;
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->hk[side].p, h->keypoints, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[side].p, h->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, m->stream));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->hc[side].p, &n, sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
-    if (h->groups) ORBX_HIP_CHECK(hipMemcpyAsync(m->hg[side].p, h->groups, (size_t)n * 4, hipMemcpyHostToDevice, m->stream));
-    if (h->valid) ORBX_HIP_CHECK(hipMemcpyAsync(m->hv[side].p, h->valid, (size_t)n, hipMemcpyHostToDevice, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));   // `n` lives on this stack frame
-    d->keypoints = m->hk[side].p; d->descriptors = m->hd[side].p; d->counts = m->hc[side].p;
-    d->groups = h->groups ? m->hg[side].p : nullptr; d->valid = h->valid ? m->hv[side].p : nullptr;
+    if (side == 0) {
+        const size_t perSide = hs.padded(cap * sizeof(orbx_keypoint)) + hs.padded(cap * 32) + hs.padded(4) + hs.padded(cap * 4) + hs.padded(cap);
+        ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));   // the previous call's copy has left the pinned buffer
+        if ((rc = hs.begin(2 * perSide)) != ORBX_OK) return rc;
+    }
+    const size_t first = hs.used;
+    const int32_t cnt = n;
+    d->keypoints = hs.put(h->keypoints, (size_t)n);
+    d->descriptors = hs.put(h->descriptors, (size_t)n * 32);
+    d->counts = hs.put(&cnt, 1);
+    const int32_t *g = hs.put(h->groups, h->groups ? (size_t)n : 0);
+    const uint8_t *v = hs.put(h->valid, h->valid ? (size_t)n : 0);
+    d->groups = h->groups ? g : nullptr; d->valid = h->valid ? v : nullptr;
     d->capacity = m->maxFeatures; d->nframes = 1;
+    ORBX_HIP_CHECK(hipMemcpyAsync(hs.dev.p + first, hs.host + first, hs.used - first, hipMemcpyHostToDevice, m->stream));
     return ORBX_OK;
 }
 }  // namespace orbx_match
