@@ -205,7 +205,6 @@ __global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust
     if (e >= d.E || !d.active[e]) return;
     const int k = d.ek[e], l = d.ep[e];
     const bool st = d.stereo[e] != 0;
-    const int D = st ? 3 : 2;
     const double *in = d.intr + 5 * (size_t)k;
     const double fx = in[0], fy = in[1], bf = in[4];
     double Xc[3], R[9];
@@ -213,13 +212,18 @@ __global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust
     quat_to_R(d.pose[k].q, R);
     const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
     double A[9], B[18];
+#pragma unroll
     for (int i = 0; i < 9; i++) A[i] = 0;
+#pragma unroll
     for (int i = 0; i < 18; i++) B[i] = 0;
     if (!st) {
         const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+#pragma unroll
         for (int i = 0; i < 2; i++)
+#pragma unroll
             for (int j = 0; j < 3; j++) A[3 * i + j] = -1. / z * (tmp[3 * i] * R[j] + tmp[3 * i + 1] * R[3 + j] + tmp[3 * i + 2] * R[6 + j]);
     } else {
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             A[j] = -fx * R[j] / z + fx * x * R[6 + j] / z_2;
             A[3 + j] = -fy * R[3 + j] / z + fy * y * R[6 + j] / z_2;
@@ -235,20 +239,35 @@ __global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust
     if (robust) { double r0; huber_rho(h, st, (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * w, r0, rw); }
     const double W = rw * w;
     double omr[3];
+#pragma unroll
     for (int i = 0; i < 3; i++) omr[i] = -w * r[i] * rw;
     double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
-    int o = 0;
-    for (int i = 0; i < 3; i++)
-        for (int j = i; j < 3; j++) { double s = 0; for (int q = 0; q < D; q++) s += A[3 * q + i] * W * A[3 * q + j]; blk[EB_HLL + o++] = s; }
-    for (int i = 0; i < 3; i++) { double s = 0; for (int q = 0; q < D; q++) s += A[3 * q + i] * omr[q]; blk[EB_BL + i] = s; }
-    if (d.poseIdx[k] >= 0) {
-        o = 0;
-        for (int i = 0; i < 6; i++)
-            for (int j = i; j < 6; j++) { double s = 0; for (int q = 0; q < D; q++) s += B[6 * q + i] * W * B[6 * q + j]; blk[EB_HPP + o++] = s; }
-        for (int i = 0; i < 6; i++) { double s = 0; for (int q = 0; q < D; q++) s += B[6 * q + i] * omr[q]; blk[EB_BP + i] = s; }
-        for (int i = 0; i < 6; i++)
-            for (int j = 0; j < 3; j++) { double s = 0; for (int q = 0; q < D; q++) s += B[6 * q + i] * W * A[3 * q + j]; blk[EB_HPL + 3 * i + j] = s; }
+    // sums over the error dimension: rows 0, 1 and - for a stereo edge - 2, in that order from 0 like the reference's
+    // loops; everything unrolled so that A / B are registers (a runtime row count puts them into scratch memory)
+#define LIN_DOT(expr0, expr1, expr2) ([&] { double s_ = 0; s_ += (expr0); s_ += (expr1); if (st) s_ += (expr2); return s_; }())
+    {
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = i; j < 3; j++) blk[EB_HLL + o++] = LIN_DOT(A[i] * W * A[j], A[3 + i] * W * A[3 + j], A[6 + i] * W * A[6 + j]);
     }
+#pragma unroll
+    for (int i = 0; i < 3; i++) blk[EB_BL + i] = LIN_DOT(A[i] * omr[0], A[3 + i] * omr[1], A[6 + i] * omr[2]);
+    if (d.poseIdx[k] >= 0) {
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++) blk[EB_HPP + o++] = LIN_DOT(B[i] * W * B[j], B[6 + i] * W * B[6 + j], B[12 + i] * W * B[12 + j]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) blk[EB_BP + i] = LIN_DOT(B[i] * omr[0], B[6 + i] * omr[1], B[12 + i] * omr[2]);
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) blk[EB_HPL + 3 * i + j] = LIN_DOT(B[i] * W * A[j], B[6 + i] * W * A[3 + j], B[12 + i] * W * A[6 + j]);
+    }
+#undef LIN_DOT
 }
 
 // Hll (9, full symmetric) and b_l (3) of every active landmark: its edges in insertion order
@@ -271,34 +290,36 @@ __global__ __launch_bounds__(256) void k_sum_points(LbaDev d, const int *ptStart
     bl[(size_t)li * 3] = b[0]; bl[(size_t)li * 3 + 1] = b[1]; bl[(size_t)li * 3 + 2] = b[2];
 }
 
-// Hpp (36) and b_p (6) of every free pose: one workgroup per keyframe, fixed-shape tree reduction
+// Hpp (36) and b_p (6) of every free pose: one workgroup per keyframe, fixed-shape tree reduction (the 27 values
+// go down the same 256 -> 1 tree together: 8 barriers instead of 8 per value, same pairing, same sums)
 __global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart, const int *kfEdges, double *Hpp, double *bp)
 {
-    __shared__ double red[256];
-    const int k = blockIdx.x, pi = d.poseIdx[k];
+    __shared__ double red[27][256];
+    const int k = blockIdx.x, pi = d.poseIdx[k], tid = threadIdx.x;
     if (pi < 0) return;
     double acc[27];
+#pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
-    for (int s = kfStart[k] + threadIdx.x; s < kfStart[k + 1]; s += 256) {
+    for (int s = kfStart[k] + tid; s < kfStart[k + 1]; s += 256) {
         const int e = kfEdges[s];
         if (!d.active[e]) continue;
         const double *blk = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPP;
+#pragma unroll
         for (int i = 0; i < 27; i++) acc[i] += blk[i];
     }
-    double tot[27];
-    for (int i = 0; i < 27; i++) {
-        red[threadIdx.x] = acc[i];
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-        tot[i] = red[0];
+#pragma unroll
+    for (int i = 0; i < 27; i++) red[i][tid] = acc[i];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        for (int w = tid; w < 27 * s; w += 256) { const int i = w / s, t = w - i * s; red[i][t] += red[i][t + s]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         double *H = Hpp + (size_t)pi * 36;
         int o = 0;
         for (int i = 0; i < 6; i++)
-            for (int j = i; j < 6; j++) { H[6 * i + j] = tot[o]; H[6 * j + i] = tot[o]; o++; }
-        for (int i = 0; i < 6; i++) bp[(size_t)pi * 6 + i] = tot[21 + i];
+            for (int j = i; j < 6; j++) { H[6 * i + j] = red[o][0]; H[6 * j + i] = red[o][0]; o++; }
+        for (int i = 0; i < 6; i++) bp[(size_t)pi * 6 + i] = red[21 + i][0];
     }
 }
 
@@ -830,18 +851,19 @@ __device__ inline void po_edge_error(const DPose &T, const double in[5], const f
     }
 }
 
-__device__ inline void po_block_reduce(double *v, double (*red)[PO_NRED], int n, int tid)
+template <int N> __device__ inline void po_block_reduce(double (&v)[N], double (*red)[PO_NRED], int tid)
 {
-    // v[0..n) per thread -> red[0][0..n) summed over the workgroup
+    // v[0..N) per thread -> red[0][0..N) summed over the workgroup (N is a template argument: v stays in registers)
     const int lane = tid & 63, wave = tid >> 6;
-    for (int k = 0; k < n; k++) {
+#pragma unroll
+    for (int k = 0; k < N; k++) {
         double x = v[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
         if (lane == 0) red[wave][k] = x;
     }
     __syncthreads();
-    if (tid < n) red[0][tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < N) red[0][tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     __syncthreads();
 }
 
@@ -884,7 +906,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         for (int e = tid; e < n; e += 256) nAct += outl[e] ? 0 : 1;
         {
             double v[1] = {(double)nAct};
-            po_block_reduce(v, red, 1, tid);
+            po_block_reduce(v, red, tid);
             nAct = (int)red[0][0];
             __syncthreads();
         }
@@ -895,6 +917,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
             // ---- computeActiveErrors + robust chi2, buildSystem
             const DPose T = pose;
             double acc[PO_NRED];
+#pragma unroll
             for (int k = 0; k < PO_NRED; k++) acc[k] = 0;
             for (int e = tid; e < n; e += 256) {
                 if (outl[e]) continue;
@@ -916,22 +939,33 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                 J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
                 J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
                 J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2;
-                const int D = st ? 3 : 2;
+                // rows 0, 1 and - for a stereo edge - 2, summed in that order from 0 like the reference's loop over the
+                // error dimension; everything unrolled so that J / acc are registers (a runtime row count puts J into
+                // scratch memory and costs ~40k cycles per edge)
                 const double W = r1 * w;
-                int k = 0;
-                for (int i = 0; i < 6; i++)
-                    for (int j = i; j < 6; j++, k++) {
-                        double sacc = 0;
-                        for (int d = 0; d < D; d++) sacc += J[6 * d + i] * W * J[6 * d + j];
-                        acc[k] += sacc;
-                    }
+                {
+                    int k = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = i; j < 6; j++, k++) {
+                            double sacc = 0;
+                            sacc += J[i] * W * J[j];
+                            sacc += J[6 + i] * W * J[6 + j];
+                            if (st) sacc += J[12 + i] * W * J[12 + j];
+                            acc[k] += sacc;
+                        }
+                }
+#pragma unroll
                 for (int i = 0; i < 6; i++) {
                     double sacc = 0;
-                    for (int d = 0; d < D; d++) sacc += J[6 * d + i] * (-w * r[d] * r1);
+                    sacc += J[i] * (-w * r[0] * r1);
+                    sacc += J[6 + i] * (-w * r[1] * r1);
+                    if (st) sacc += J[12 + i] * (-w * r[2] * r1);
                     acc[21 + i] += sacc;
                 }
             }
-            po_block_reduce(acc, red, PO_NRED, tid);
+            po_block_reduce(acc, red, tid);
             if (tid == 0) {
                 int k = 0;
                 for (int i = 0; i < 6; i++)
@@ -951,27 +985,50 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                 if (tid == 0) {
                     savePose = pose;   // push()
                     // (H + lambda I) x = b by LDL^T; "isPositive" like LinearSolverDense (linear_solver_dense.h:99-103)
+                    // every loop fully unrolled, no early exit: A / Dg / xx stay in registers (with runtime indices they live in
+                    // scratch memory and this one-thread solve costs ~40 us per trial).  After a failed pivot the remaining
+                    // arithmetic runs on garbage, exactly the values the reference never looks at (ok == false).
                     double A[36];
+#pragma unroll
                     for (int i = 0; i < 36; i++) A[i] = sH[i];
+#pragma unroll
                     for (int i = 0; i < 6; i++) A[7 * i] += sLambda;
                     double Dg[6];
                     bool ok = true;
-                    for (int j = 0; j < 6 && ok; j++) {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
                         double dj = A[7 * j];
+#pragma unroll
                         for (int k = 0; k < j; k++) dj -= A[6 * j + k] * A[6 * j + k] * Dg[k];
-                        if (!(dj > 0) || !isfinite(dj)) { ok = false; break; }
+                        ok = ok && (dj > 0) && isfinite(dj);
                         Dg[j] = dj;
+#pragma unroll
                         for (int i = j + 1; i < 6; i++) {
                             double lij = A[6 * i + j];
+#pragma unroll
                             for (int k = 0; k < j; k++) lij -= A[6 * i + k] * A[6 * j + k] * Dg[k];
                             A[6 * i + j] = lij / dj;
                         }
                     }
                     double xx[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        double sacc = sb[i];
+#pragma unroll
+                        for (int k = 0; k < i; k++) sacc -= A[6 * i + k] * xx[k];
+                        xx[i] = sacc;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 6; i++) xx[i] /= Dg[i];
+#pragma unroll
+                    for (int i = 5; i >= 0; i--) {
+                        double sacc = xx[i];
+#pragma unroll
+                        for (int k = i + 1; k < 6; k++) sacc -= A[6 * k + i] * xx[k];
+                        xx[i] = sacc;
+                    }
                     if (ok) {
-                        for (int i = 0; i < 6; i++) { double sacc = sb[i]; for (int k = 0; k < i; k++) sacc -= A[6 * i + k] * xx[k]; xx[i] = sacc; }
-                        for (int i = 0; i < 6; i++) xx[i] /= Dg[i];
-                        for (int i = 5; i >= 0; i--) { double sacc = xx[i]; for (int k = i + 1; k < 6; k++) sacc -= A[6 * k + i] * xx[k]; xx[i] = sacc; }
+#pragma unroll
                         for (int i = 0; i < 6; i++) sx[i] = xx[i];
                     }
                     sOk = ok ? 1 : 0;
@@ -991,7 +1048,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     if (robust) huber_rho(hub, st, chi, r0, r1);
                     cacc[0] += r0;
                 }
-                po_block_reduce(cacc, red, 1, tid);
+                po_block_reduce(cacc, red, tid);
                 if (tid == 0) {
                     double tempChi = red[0][0];
                     if (!sOk) tempChi = 1.7976931348623157e308;
@@ -1044,7 +1101,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         }
         {
             double v[1] = {(double)nb};
-            po_block_reduce(v, red, 1, tid);
+            po_block_reduce(v, red, tid);
             if (tid == 0) P.ret[f] = n - (int)red[0][0];
             __syncthreads();
         }
