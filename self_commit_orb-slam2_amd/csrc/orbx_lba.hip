@@ -661,31 +661,40 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ S
         for (int q = 0; q < 13; q++) { const int idx = tid + 256 * q; if ((idx >> 5) < CPR) T[idx >> 5][idx & 31] = v[q]; }
     }
     __syncthreads();
-    const int tr = tid >> 3, tc = tid & 7;
+    // Waves 0-1: the 32x32 diagonal block, right-looking, one rank-1 update per column.
+    // Waves 2-3: the rows below it (right-hand side + 64 panel rows) never feed back into the block, so their
+    // elimination is a triangular solve: ONE THREAD PER ROW computes its entry of column c as soon as that column of
+    // L11 is final, subtracting the products in the same order k = 0 .. c-1 in which the rank-1 updates would have
+    // arrived (identical rounding) - hidden behind the block's own update instead of 65 more rows going through every
+    // synchronised step.
+    const int lowRow = (tid >= 128 && tid - 128 < CPR - CNB) ? CNB + tid - 128 : -1;
     for (int c = 0; c < nb; c++) {
         const double dj = T[c][c];
         if (!(dj > 0) || !isfinite(dj)) { if (tid == 0) sBad = 1; }
         const double inv = rsqrt(dj);
         // scale column c below the diagonal (the diagonal entry itself is kept aside: nobody reads T[c][c] again)
-        if (c + 1 + tid < CPR) T[c + 1 + tid][c] *= inv;
+        if (c + 1 + tid < CNB) T[c + 1 + tid][c] *= inv;
         if (tid == 0) { sdiag[c] = dj * inv; sinv[c] = inv; }
         __syncthreads();
-        double lr[3], lc[4], a[3][4];
+        if (tid < 128) {
+            // lower triangle of the trailing block: element (r, c2), c < c2 <= r < CNB
+            const int r = c + 1 + (tid >> 2);
 #pragma unroll
-        for (int u = 0; u < 3; u++) lr[u] = T[min(c + 1 + tr + 32 * u, CPR - 1)][c];
-#pragma unroll
-        for (int w = 0; w < 4; w++) lc[w] = T[min(c + 1 + tc + 8 * w, CNB - 1)][c];
-#pragma unroll
-        for (int u = 0; u < 3; u++)
-#pragma unroll
-            for (int w = 0; w < 4; w++) a[u][w] = T[min(c + 1 + tr + 32 * u, CPR - 1)][min(c + 1 + tc + 8 * w, CNB - 1)];
-#pragma unroll
-        for (int u = 0; u < 3; u++)
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const int r = c + 1 + tr + 32 * u, c2 = c + 1 + tc + 8 * w;
-                if (r < CPR && c2 < nb && (r >= CNB || c2 <= r)) T[r][c2] = a[u][w] - lr[u] * lc[w];
+            for (int w = 0; w < 8; w++) {
+                const int c2 = c + 1 + (tid & 3) + 4 * w;
+                if (r < CNB && c2 < nb && c2 <= r) T[r][c2] = T[r][c2] - T[r][c] * T[c2][c];
             }
+        } else if (lowRow >= 0) {
+            // all 2 x 32 operands in flight at once (reads past k = c are in bounds and unused): the chain that is left
+            // is the c dependent subtractions
+            double xr[CNB], lc[CNB];
+#pragma unroll
+            for (int k = 0; k < CNB; k++) { xr[k] = T[lowRow][k]; lc[k] = T[c][k]; }
+            double a = T[lowRow][c];
+#pragma unroll
+            for (int k = 0; k < CNB; k++) if (k < c) a = a - xr[k] * lc[k];
+            T[lowRow][c] = a * inv;
+        }
         __syncthreads();
     }
     if (sBad && blockIdx.x == 0 && tid == 0) *okFlag = 0;   // not positive definite: the results are discarded by the host
