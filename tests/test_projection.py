@@ -162,3 +162,34 @@ def test_last_frame_hip_equals_restatement_and_reference(orbx, oracle, seed, mz,
         ref_n, ref = oracle_lib.ref_search_by_projection_last(fr, last, th, mono, ori)
         assert got_n == ref_n and (np.maximum(got, -1) == ref).all()
     mt.close()
+
+
+# ---------------- replays under contention (k_proj_greedy / k_proj_last_greedy are parallel fixed points) ----------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(10))
+def test_hip_replays_under_contention(orbx, oracle, case):
+    """Many map points per feature, few distinct descriptors, points without observations (which do not block a feature
+    and are overwritten later) and occupied features: the regime where the order of the reference's loop decides."""
+    rng = np.random.default_rng(7000 + case)
+    n = int(rng.choice([40, 150, 900]))
+    m = int(rng.choice([500, 3000, 6000]))
+    th = float(rng.choice([3.0, 8.0, 15.0]))
+    fr, pts = make_case(7100 + case, n=n, m=m, crowded=bool(case & 1))
+    pts["has_obs"] = (rng.random(m) < [0.0, 0.5, 1.0][case % 3]).astype(np.uint8)
+    fr["occupied"] = (rng.random(n) < [0.0, 0.1, 0.6][(case // 3) % 3]).astype(np.uint8)
+    want_n, want = oracle_lib.search_by_projection(oracle, fr, pts, th, 0.8)
+    mt = orbx.ORBmatcher(0.8, True, max_features=2048)
+    got_n, got = mt.SearchByProjection(dict(fr, kps=_struct_kps(orbx, fr["kps7"])), pts, th)
+    assert got_n == want_n and (got == want).all()
+    mt.close()
+    nl = int(rng.choice([800, 1900]))
+    fr2, last = make_last_case(7200 + case, float(rng.choice([0.0, 0.5, -0.5])), n=max(n, 60), nl=nl, crowded=bool(case & 1))
+    last["has_obs"] = (rng.random(nl) < [0.0, 0.5, 1.0][case % 3]).astype(np.uint8)
+    fr2["occupied"] = (rng.random(len(fr2["kps7"])) < 0.2).astype(np.uint8)
+    mono, ori = case & 1, (case >> 1) & 1
+    want_n, want = oracle_lib.search_by_projection_last(oracle, fr2, last, 15.0, mono, ori)
+    mt = orbx.ORBmatcher(0.9, bool(ori), max_features=2048)
+    got_n, got = mt.SearchByProjectionLast(dict(fr2, kps=_struct_kps(orbx, fr2["kps7"])),
+                                           dict(last, kps=_struct_kps(orbx, last["kps7"]), valid=(last["valid"] == 1).astype(np.uint8)), 15.0, mono)
+    assert got_n == want_n and (got == want).all()
+    mt.close()
