@@ -193,3 +193,44 @@ def test_hip_replays_under_contention(orbx, oracle, case):
                                            dict(last, kps=_struct_kps(orbx, last["kps7"]), valid=(last["valid"] == 1).astype(np.uint8)), 15.0, mono)
     assert got_n == want_n and (got == want).all()
     mt.close()
+
+
+@pytest.mark.gpu
+def test_hip_device_form_batch_of_frames(orbx, oracle):
+    """orbx_search_by_projection_device with nframes = 3 (device pointers, frames of different sizes padded to the capacity):
+    every frame must equal its single-frame result."""
+    import ctypes
+    import torch
+    cases = [make_case(8001, n=900, m=2500, crowded=True), make_case(8002, n=300, m=4000), make_case(8003, n=1500, m=100)]
+    B, capF, capP, th, ratio = 3, 1600, 4096, 5.0, 0.8
+    mt = orbx.ORBmatcher(ratio, True, max_features=capF, max_pairs=B)
+    k = np.zeros((B, capF), orbx.KEYPOINT_DTYPE)
+    desc = np.zeros((B, capF, 32), np.uint8); ur = np.zeros((B, capF), np.float32); occ = np.zeros((B, capF), np.uint8)
+    px = np.zeros((B, capP), np.float32); py = px.copy(); pxr = px.copy(); vc = px.copy()
+    lvl = np.zeros((B, capP), np.int32); inv = np.zeros((B, capP), np.uint8); obs = inv.copy(); md = np.zeros((B, capP, 32), np.uint8)
+    cn, cm = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    for f, (fr, pts) in enumerate(cases):
+        n, m = len(fr["kps7"]), len(pts["proj_x"])
+        cn[f], cm[f] = n, m
+        k[f, :n] = _struct_kps(orbx, fr["kps7"]); desc[f, :n] = fr["desc"]; ur[f, :n] = fr["u_right"]; occ[f, :n] = fr["occupied"]
+        px[f, :m], py[f, :m], pxr[f, :m], vc[f, :m] = pts["proj_x"], pts["proj_y"], pts["proj_xr"], pts["view_cos"]
+        lvl[f, :m], inv[f, :m], obs[f, :m], md[f, :m] = pts["level"], pts["in_view"], pts["has_obs"], pts["desc"]
+    keep = []
+    def dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+        keep.append(t)
+        return t.data_ptr()
+    W, H = cases[0][0]["width"], cases[0][0]["height"]
+    F = orbx.ProjectionFrame(dev(k), dev(desc), dev(ur), dev(occ), dev(cn), capF, B, 0.0, 0.0, float(np.float32(64) / np.float32(W)), float(np.float32(48) / np.float32(H)))
+    P = orbx.ProjectionPoints(dev(px), dev(py), dev(pxr), dev(lvl), dev(vc), dev(inv), dev(obs), dev(md), dev(cm), capP)
+    torch.cuda.synchronize()
+    sf = np.ascontiguousarray(SCALES, np.float32)
+    rc = mt._L.orbx_search_by_projection_device(mt._h, ctypes.byref(F), ctypes.byref(P), sf.ctypes.data_as(ctypes.c_void_p), len(sf), ctypes.c_float(th), ctypes.c_float(ratio))
+    assert rc == 0
+    got, _, got_n = mt.download(B)
+    for f, (fr, pts) in enumerate(cases):
+        want_n, want = oracle_lib.search_by_projection(oracle, fr, pts, th, ratio)
+        n = len(fr["kps7"])
+        assert got_n[f] == want_n and (got[f, :n] == want).all(), f
+        assert (got[f, n:] == -1).all()
+    mt.close()
