@@ -295,7 +295,8 @@ typedef struct orbx_projection_points {
     int capacity;
 } orbx_projection_points;
 
-/* Device-pointer form for `frame->nframes` independent (frame, point list) problems; results:
+/* Device-pointer form for `frame->nframes` independent (frame, point list) problems (the replay keeps 6 bytes of LDS
+ * per feature slot: frame->capacity <= 27000, ORBX_ERR_CAPACITY beyond); results:
  * matches[f*stride + i] = index of the point written into F.mvpMapPoints[i] by the call or -1,
  * nmatches[f] = return value (orbx_matcher_results_device / orbx_matcher_download). */
 int orbx_search_by_projection_device(orbx_matcher *m, const orbx_projection_frame *frame,
