@@ -834,18 +834,89 @@ extern "C" int orbx_area_search_greedy(orbx_matcher *m, const orbx_projection_fr
 // ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:515-654, Tracking::MonocularInitialization): level-0
 // features of F1 look for their best / second best F2 feature inside a window around vbPrevMatched; a candidate
 // is skipped when the F2 feature is already held at a distance <= its own (vMatchedDistance, :566), an accepted
-// match overrides the previous holder (:590-594).  That state makes every step depend on all earlier ones in a
-// way no candidate list can precompute, and the function runs once per frame only until the map is initialised:
-// one workgroup per frame pair walks the F1 features in order and evaluates each window with all 256 threads.
+// match overrides the previous holder (:590-594).
+//   k_init_topk   (parallel, one wave per F1 feature) the window / level / distance part, which does not depend on
+//                 that state: the 8 smallest keys dist << 32 | cell | i2 below the distance cut-off (a candidate at
+//                 distance >= dcut can neither be accepted nor veto an acceptable best in the ratio test);
+//   k_search_init (one wave per frame pair) walks the F1 features in order over those lists, applies the
+//                 vMatchedDistance filter and the override; a FULL list with fewer than two usable entries is
+//                 re-evaluated exactly against all of F2.
 // ---------------------------------------------------------------------------------------------
+struct InitQuery { float x, y, r; int cx0, cx1, cy0, cy1; bool any; unsigned long long d[4]; };
+
+__device__ __forceinline__ InitQuery init_query(const FeatDev &A, const ProjFrameDev &F2, size_t ai, const float *prevXY, float window)
+{
+    InitQuery q;
+    q.any = false;
+    const orbx_keypoint k1 = A.kp[ai];
+    if (k1.octave > 0) return q;                                                               // :535-537
+    q.x = prevXY[2 * ai]; q.y = prevXY[2 * ai + 1]; q.r = window;
+    // Frame::GetFeaturesInArea(x, y, r, 0, 0), src/Frame.cc:741-850
+    q.cx0 = max(0, (int)floorf((q.x - F2.minX - q.r) * F2.gwInv)); q.cx1 = min(GRID_COLS - 1, (int)ceilf((q.x - F2.minX + q.r) * F2.gwInv));
+    q.cy0 = max(0, (int)floorf((q.y - F2.minY - q.r) * F2.ghInv)); q.cy1 = min(GRID_ROWS - 1, (int)ceilf((q.y - F2.minY + q.r) * F2.ghInv));
+    if (q.cx0 >= GRID_COLS || q.cx1 < 0 || q.cy0 >= GRID_ROWS || q.cy1 < 0) return q;
+    const unsigned long long *dp = (const unsigned long long *)(A.desc + ai * 32);
+    q.d[0] = dp[0]; q.d[1] = dp[1]; q.d[2] = dp[2]; q.d[3] = dp[3];
+    q.any = true;
+    return q;
+}
+
+// key of F2 feature i2 for the query, KEY64_EMPTY when it is not in the window / not on level 0
+__device__ __forceinline__ unsigned long long init_key(const ProjFrameDev &F2, size_t fbase, int i2, const InitQuery &q)
+{
+    const orbx_keypoint k = F2.kp[fbase + i2];
+    const int cx = (int)roundf((k.x - F2.minX) * F2.gwInv), cy = (int)roundf((k.y - F2.minY) * F2.ghInv);
+    if (cx < q.cx0 || cx > q.cx1 || cy < q.cy0 || cy > q.cy1) return KEY64_EMPTY;
+    if (k.octave < 0 || k.octave > 0) return KEY64_EMPTY;                                      // minLevel = maxLevel = level1 = 0
+    const float distx = k.x - q.x, disty = k.y - q.y;
+    if (!(fabsf(distx) < q.r && fabsf(disty) < q.r)) return KEY64_EMPTY;
+    const unsigned long long *db = (const unsigned long long *)(F2.desc + (fbase + i2) * 32);
+    const int dist = hamming256(q.d, db[0], db[1], db[2], db[3]);
+    return ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)i2;
+}
+
+__global__ __launch_bounds__(256) void k_init_topk(FeatDev A, ProjFrameDev F2, const float *__restrict__ prevXY, float window, int dcut,
+                                                   unsigned long long *__restrict__ topk)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n1 = min(A.counts[f], A.cap), n2 = min(F2.counts[f], F2.cap);
+    if (i1 >= n1) return;
+    const size_t ai = (size_t)f * A.cap + i1, fbase = (size_t)f * F2.cap;
+    unsigned long long *out = topk + ai * TOPK;
+    const InitQuery q = init_query(A, F2, ai, prevXY, window);
+    unsigned long long kk[TOPK];
+#pragma unroll
+    for (int t = 0; t < TOPK; t++) kk[t] = KEY64_EMPTY;
+    if (q.any)
+        for (int i2 = lane; i2 < n2; i2 += 64) {
+            const unsigned long long key = init_key(F2, fbase, i2, q);
+            if (key < kk[TOPK - 1] && (int)(key >> 32) < dcut) {
+                kk[TOPK - 1] = key;
+#pragma unroll
+                for (int t = TOPK - 1; t > 0; t--)
+                    if (kk[t] < kk[t - 1]) { const unsigned long long v = kk[t - 1]; kk[t - 1] = kk[t]; kk[t] = v; }
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < TOPK; k++) {
+        const unsigned long long mn = wave_min_u64(kk[0]);
+        if (kk[0] == mn && mn != KEY64_EMPTY) {   // keys are unique: exactly one lane pops its head
+#pragma unroll
+            for (int t = 0; t < TOPK - 1; t++) kk[t] = kk[t + 1];
+            kk[TOPK - 1] = KEY64_EMPTY;
+        }
+        if (lane == 0) out[k] = mn;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_search_init(FeatDev A, ProjFrameDev F2, const float *__restrict__ prevXY, float window, float nnratio, int checkOri,
-                                                     int32_t *__restrict__ matches, int8_t *__restrict__ bins, int32_t *__restrict__ nmatches, int stride)
+                                                     const unsigned long long *__restrict__ topk, int32_t *__restrict__ matches, int8_t *__restrict__ bins,
+                                                     int32_t *__restrict__ nmatches, int stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned long long sBest[4], sSecond[4];
     __shared__ int hist[HISTO_LENGTH];
     __shared__ int sTotal;
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n1 = min(A.counts[f], A.cap), n2 = min(F2.counts[f], F2.cap);
     unsigned short *holderDist = (unsigned short *)smem;   // vMatchedDistance, 0xffff = INT_MAX
     unsigned short *match21 = holderDist + F2.cap;         // vnMatches21, 0xffff = -1
@@ -858,66 +929,73 @@ __global__ __launch_bounds__(256) void k_search_init(FeatDev A, ProjFrameDev F2,
     if (tid == 0) sTotal = 0;
     __syncthreads();
     const float factor = HISTO_LENGTH / 360.0f;
-    for (int i1 = 0; i1 < n1; i1++) {
-        const orbx_keypoint k1 = A.kp[abase + i1];
-        if (k1.octave > 0) continue;                                                             // :535-537 (uniform)
-        const float x = prevXY[2 * (abase + i1)], y = prevXY[2 * (abase + i1) + 1], r = window;
-        // Frame::GetFeaturesInArea(x, y, r, 0, 0), src/Frame.cc:741-850
-        const int cx0 = max(0, (int)floorf((x - F2.minX - r) * F2.gwInv)), cx1 = min(GRID_COLS - 1, (int)ceilf((x - F2.minX + r) * F2.gwInv));
-        const int cy0 = max(0, (int)floorf((y - F2.minY - r) * F2.ghInv)), cy1 = min(GRID_ROWS - 1, (int)ceilf((y - F2.minY + r) * F2.ghInv));
-        if (cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0) continue;                // (uniform)
-        const unsigned long long *dp = (const unsigned long long *)(A.desc + (abase + i1) * 32);
-        const unsigned long long d[4] = {dp[0], dp[1], dp[2], dp[3]};
-        unsigned long long k0 = KEY64_EMPTY, kk1 = KEY64_EMPTY;
-        for (int i2 = tid; i2 < n2; i2 += 256) {
-            const orbx_keypoint k = F2.kp[fbase + i2];
-            const int cx = (int)roundf((k.x - F2.minX) * F2.gwInv), cy = (int)roundf((k.y - F2.minY) * F2.ghInv);
-            if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) continue;
-            if (k.octave < 0 || k.octave > 0) continue;                                          // minLevel = maxLevel = level1 = 0
-            const float distx = k.x - x, disty = k.y - y;
-            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
-            const unsigned long long *db = (const unsigned long long *)(F2.desc + (fbase + i2) * 32);
-            const int dist = hamming256(d, db[0], db[1], db[2], db[3]);
-            if ((int)holderDist[i2] <= dist) continue;                                           // :566 (0xffff stands for INT_MAX)
-            const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)i2;
-            if (key < k0) { kk1 = k0; k0 = key; } else if (key < kk1) kk1 = key;
-        }
-        {
-            const unsigned long long b = wave_min_u64(k0);
-            if (k0 == b && b != KEY64_EMPTY) k0 = kk1;
-            const unsigned long long s2 = wave_min_u64(k0);
-            if (lane == 0) { sBest[wv] = b; sSecond[wv] = s2; }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long b = KEY64_EMPTY, s2 = KEY64_EMPTY;
-            for (int w = 0; w < 4; w++) {
-                const unsigned long long c0 = sBest[w], c1 = sSecond[w];
-                if (c0 < b) { s2 = b < c1 ? b : c1; b = c0; s2 = s2 < c1 ? s2 : c1; }
-                else { s2 = c0 < s2 ? c0 : s2; }
+    if (tid < 64) {
+        int total = 0;
+        const unsigned long long *tk = topk + abase * TOPK;
+        unsigned long long nextKeys = (0 < n1) ? tk[min((size_t)lane, (size_t)n1 * TOPK - 1)] : KEY64_EMPTY;
+        for (int i0 = 0; i0 < n1; i0 += 8) {
+            const unsigned long long keys = nextKeys;   // lists of features i0 .. i0+7, lane = 8*(i1-i0) + rank
+            {
+                const size_t nx = (size_t)(i0 + 8) * TOPK + lane;
+                nextKeys = (i0 + 8 < n1) ? tk[min(nx, (size_t)n1 * TOPK - 1)] : KEY64_EMPTY;   // in flight while these 8 are replayed
             }
-            if (b != KEY64_EMPTY) {
+            for (int j = 0; j < 8 && i0 + j < n1; j++) {
+                const int i1 = i0 + j;
+                const unsigned long long key = __shfl(keys, 8 * j + (lane & 7));   // lanes 0..7 hold the list of feature i1
+                const bool present = lane < TOPK && key != KEY64_EMPTY;
+                const unsigned mAll = (1u << TOPK) - 1u;
+                const unsigned mPresent = (unsigned)(__ballot(present) & mAll);
+                if (!mPresent) continue;                                            // higher level, empty window or nothing below the cut-off
+                const bool usable = present && !((int)holderDist[(int)(key & 0xffff)] <= (int)(key >> 32));   // :566 (0xffff stands for INT_MAX)
+                const unsigned mUse = (unsigned)(__ballot(usable) & mAll);
+                unsigned long long b = KEY64_EMPTY, s2 = KEY64_EMPTY;
+                if (__popc(mUse) >= 2 || mPresent != mAll) {
+                    if (mUse) {
+                        b = __shfl(key, __ffs(mUse) - 1);
+                        const unsigned rest = mUse & (mUse - 1);
+                        if (rest) s2 = __shfl(key, __ffs(rest) - 1);
+                    }
+                } else {
+                    // full list, fewer than two usable entries: the two smallest usable keys over all of F2
+                    const InitQuery q = init_query(A, F2, abase + i1, prevXY, window);
+                    unsigned long long k0 = KEY64_EMPTY, kk1 = KEY64_EMPTY;
+                    if (q.any)
+                        for (int i2 = lane; i2 < n2; i2 += 64) {
+                            const unsigned long long kx = init_key(F2, fbase, i2, q);
+                            if (kx == KEY64_EMPTY || (int)holderDist[i2] <= (int)(kx >> 32)) continue;
+                            if (kx < k0) { kk1 = k0; k0 = kx; } else if (kx < kk1) kk1 = kx;
+                        }
+                    b = wave_min_u64(k0);
+                    if (k0 == b) k0 = kk1;
+                    s2 = wave_min_u64(k0);
+                }
+                if (b == KEY64_EMPTY) continue;
                 const int bestDist = (int)(b >> 32), bestIdx2 = (int)(b & 0xffff);
                 const float second = s2 == KEY64_EMPTY ? (float)2147483647 : (float)(int)(s2 >> 32);   // (float)INT_MAX, :576
                 if (bestDist <= TH_LOW && (float)bestDist < second * nnratio) {
-                    if (match21[bestIdx2] != 0xffff) { m12[match21[bestIdx2]] = -1; sTotal--; }      // :590-594
-                    m12[i1] = bestIdx2;
-                    match21[bestIdx2] = (unsigned short)i1;
-                    holderDist[bestIdx2] = (unsigned short)bestDist;
-                    sTotal++;
-                    if (checkOri) {
-                        float rot = k1.angle - F2.kp[fbase + bestIdx2].angle;
-                        if (rot < 0.0f) rot += 360.0f;
-                        int bin = (int)roundf(rot * factor);
-                        if (bin == HISTO_LENGTH) bin = 0;
-                        bin12[i1] = (int8_t)bin;
-                        hist[bin]++;
+                    if (lane == 0) {
+                        if (match21[bestIdx2] != 0xffff) { m12[match21[bestIdx2]] = -1; total--; }      // :590-594
+                        m12[i1] = bestIdx2;
+                        match21[bestIdx2] = (unsigned short)i1;
+                        holderDist[bestIdx2] = (unsigned short)bestDist;
+                        total++;
+                        if (checkOri) {
+                            float rot = A.kp[abase + i1].angle - F2.kp[fbase + bestIdx2].angle;
+                            if (rot < 0.0f) rot += 360.0f;
+                            int bin = (int)roundf(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            bin12[i1] = (int8_t)bin;
+                            hist[bin]++;
+                        }
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
-        __syncthreads();
+        if (lane == 0) sTotal = total;
     }
+    __syncthreads();
     if (checkOri) {
         // ComputeThreeMaxima over the counts of ALL accepted events (an overridden match stays in its bin, :606)
         int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -960,11 +1038,18 @@ extern "C" int orbx_search_for_initialization_device(orbx_matcher *m, const orbx
     const size_t lds = (size_t)f2->capacity * 4 + 16;
     if (lds > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", f2->capacity); return ORBX_ERR_CAPACITY; }
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_search_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if ((rc = m->topk64.ensure((size_t)nframes * f1->capacity * TOPK)) != ORBX_OK) return rc;
+    // first distance that can neither be accepted (> TH_LOW) nor veto an acceptable best in `(float)bestDist < (float)bestDist2 * mfNNratio` (:580)
+    int dcut = TH_LOW + 1;
+    while (dcut < 257 && !((float)dcut * nn_ratio > (float)TH_LOW)) dcut++;
     const int slot = m->profCount % MATCH_PROF_RING;
     ORBX_HIP_CHECK(hipEventRecord(m->ev0[slot], m->stream));
     m->midValid[slot] = false;
+    hipLaunchKernelGGL(k_init_topk, dim3((unsigned)((f1->capacity + 3) / 4), (unsigned)nframes), dim3(256), 0, m->stream, A, F, prev_matched_xy, (float)window_size, dcut,
+                       m->topk64.p);
+    MLAUNCH_CHECK();
     hipLaunchKernelGGL(k_search_init, dim3((unsigned)nframes), dim3(256), lds, m->stream, A, F, prev_matched_xy, (float)window_size, nn_ratio, check_orientation,
-                       m->matches.p, (int8_t *)m->pb[0].p, m->nmatches.p, stride);
+                       m->topk64.p, m->matches.p, (int8_t *)m->pb[0].p, m->nmatches.p, stride);
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
     m->profCount++;
