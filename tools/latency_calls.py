@@ -51,16 +51,33 @@ points = dict(proj_x=r["proj_x"], proj_y=r["proj_y"], proj_xr=r["proj_xr"], leve
               has_obs=np.ones(m, np.uint8), desc=mdesc)
 bench("ORBmatcher::SearchByProjection(F, %d points, th=3)" % m, lambda: mt.SearchByProjection(frame, points, 3.0))
 
-cam = orbx.Camera(fx=517.3, fy=516.5, cx=318.6, cy=255.3, k1=0.2624, k2=-0.9531, p1=-0.0054, p2=0.0026, k3=1.1633)
 try:
-    fo = orbx.FrameOps(cam, max_features=4096)
+    fo = orbx.FrameOps(517.3, 516.5, 318.6, 255.3, (0.2624, -0.9531, -0.0054, 0.0026, 1.1633))
     b = fo.ComputeImageBounds(W, H)
     g = orbx.FrameGrid.from_bounds(b)
-    bench("Frame::UndistortKeyPoints", lambda: fo.UndistortKeyPoints(kB))
+    bench("Frame::UndistortKeyPoints (%d)" % len(kB), lambda: fo.UndistortKeyPoints(kB))
     ku = fo.UndistortKeyPoints(kB)
     bench("Frame::AssignFeaturesToGrid", lambda: fo.AssignFeaturesToGrid(ku, g))
 except Exception as e:   # signature drift in this helper script must not hide the other numbers
-    print("FrameOps skipped:", e)
+    print("FrameOps skipped:", repr(e))
+try:
+    V = orbx.Vocabulary(orbx.voc_synth.make_vocabulary(10, 4, 1))
+    bench("ORBVocabulary::transform (k=10, L=4, %d descriptors)" % len(dB), lambda: V.transform(dB, 4))
+except Exception as e:
+    print("Vocabulary skipped:", repr(e))
+try:
+    WS, HS = 1241, 376
+    frs = orbx.synth_sequence(9, 2, WS, HS)
+    exs = orbx.ORBextractor(2000, 1.2, 8, 20, 7, max_width=WS, max_height=HS, max_batch=2)
+    mts = orbx.ORBmatcher(0.7, True, max_features=exs.capacity, max_pairs=1)
+    def stereo():
+        dv = exs.upload(frs)
+        exs.run_device(*dv)
+        mts.compute_stereo_matches_device(exs, exs, [0], [1], 386.1448, 0.0)
+        return mts.download_stereo(1)
+    bench("stereo Frame: extract L+R 1241x376/2000 + ComputeStereoMatches", stereo)
+except Exception as e:
+    print("stereo skipped:", repr(e))
 
 # ---- the remaining single-frame calls, on the inputs of the parity tests ----
 sys.path.insert(0, str(ROOT / "tests"))
