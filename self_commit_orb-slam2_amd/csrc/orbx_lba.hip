@@ -146,7 +146,7 @@ struct LbaDev {   // device views, all sized by the handle
     const int *ptIdx;           // P: active landmark index or -1
     double *err;                // 3E, _error as last computed
     double *rchi;               // E, (robust) chi2 of active edges, 0 otherwise
-    double *edgeBlk;            // 54 per edge: Hll(6) bl(3) Hpp(21) bp(6) Hpl(18)
+    double *edgeBlk;            // 72 per edge: Hll(6) bl(3) Hpp(21) bp(6) Hpl(18) BD(18)
 };
 
 #define EB_HLL 0
@@ -154,7 +154,8 @@ struct LbaDev {   // device views, all sized by the handle
 #define EB_HPP 9
 #define EB_BP 30
 #define EB_HPL 36
-#define EB_SIZE 54
+#define EB_BD 54     /* B * D^-1 of the current trial (k_schur_points -> k_schur_rows) */
+#define EB_SIZE 72
 
 // computeError (types_six_dof_expmap.h:90-95, 122-127; cam_project .cpp:141-157)
 __device__ inline void edge_error(const LbaDev &d, int e, double out[3], double *depth)
@@ -364,20 +365,18 @@ __global__ __launch_bounds__(256) void k_schur_init(const double *Hpp, const dou
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) bs[i] = bp[i];
 }
 
-// per landmark: D^-1, D^-1 b_l, and its Schur contributions (block_solver.hpp:381-439).
-// One wave per landmark; lanes cover (edge pair, 6x6 entry); FP64 atomics into S / bs.
-#define SCHUR_MAX_OBS 64
+// per landmark: D^-1, D^-1 b_l and B D^-1 of its edges
+// (block_solver.hpp:381-439).  One wave per landmark, lanes over (edge, row).
 __global__ __launch_bounds__(256) void k_schur_points(LbaDev d, const int *ptStart, const int *ptEdges, const double *Hll, const double *bl, double lambda,
-                                                      int nP6, double *Dinv, double *S, double *bs)
+                                                      double *Dinv, double *Ddb)
 {
-    __shared__ double sBD[4][SCHUR_MAX_OBS * 18];
-    __shared__ int sPose[4][SCHUR_MAX_OBS], sEdge[4][SCHUR_MAX_OBS];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l = blockIdx.x * 4 + wv;
     if (l >= d.P) return;
     const int li = d.ptIdx[l];
     if (li < 0) return;
     double M[9], I[9];
+#pragma unroll
     for (int i = 0; i < 9; i++) M[i] = Hll[(size_t)li * 9 + i];
     M[0] += lambda; M[4] += lambda; M[8] += lambda;
     const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
@@ -386,36 +385,80 @@ __global__ __launch_bounds__(256) void k_schur_points(LbaDev d, const int *ptSta
     I[3] = c01 * id; I[4] = (M[0] * M[8] - M[2] * M[6]) * id; I[5] = (M[2] * M[3] - M[0] * M[5]) * id;
     I[6] = c02 * id; I[7] = (M[1] * M[6] - M[0] * M[7]) * id; I[8] = (M[0] * M[4] - M[1] * M[3]) * id;
     double db[3];
+#pragma unroll
     for (int i = 0; i < 3; i++) db[i] = I[3 * i] * bl[(size_t)li * 3] + I[3 * i + 1] * bl[(size_t)li * 3 + 1] + I[3 * i + 2] * bl[(size_t)li * 3 + 2];
-    if (lane < 9) Dinv[(size_t)li * 9 + lane] = I[lane];
-    // free-pose edges of this landmark, in insertion order
-    int n = 0;
-    for (int s = ptStart[l]; s < ptStart[l + 1]; s++) {
-        const int e = ptEdges[s];
+    if (lane < 9) {
+        double v = I[0];
+#pragma unroll
+        for (int i = 1; i < 9; i++) v = lane == i ? I[i] : v;
+        Dinv[(size_t)li * 9 + lane] = v;
+    }
+    if (lane < 3) Ddb[(size_t)l * 3 + lane] = lane == 0 ? db[0] : (lane == 1 ? db[1] : db[2]);   // D^-1 b_l, applied to bs by k_schur_rows
+    // BD = B * D^-1 (6x3 per free-pose edge)
+    const int s0 = ptStart[l], nE = ptStart[l + 1] - s0;
+    for (int t = lane; t < nE * 6; t += 64) {
+        const int a = t / 6, r = t - 6 * a, e = ptEdges[s0 + a];
         if (!d.active[e]) continue;
         const int pi = d.poseIdx[d.ek[e]];
         if (pi < 0) continue;
-        if (n < SCHUR_MAX_OBS) { if (lane == 0) { sPose[wv][n] = pi; sEdge[wv][n] = e; } n++; }
+        double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
+        const double *B1 = blk + EB_HPL + 3 * r;
+#pragma unroll
+        for (int c = 0; c < 3; c++) blk[EB_BD + 3 * r + c] = B1[0] * I[c] + B1[1] * I[3 + c] + B1[2] * I[6 + c];
     }
-    __builtin_amdgcn_wave_barrier();
-    // BD = B * D^-1 (6x3 per edge), bs[i1] -= B * db
-    for (int t = lane; t < n * 6; t += 64) {
-        const int a = t / 6, r = t % 6;
-        const double *B1 = d.edgeBlk + (size_t)sEdge[wv][a] * EB_SIZE + EB_HPL + 3 * r;
-        for (int c = 0; c < 3; c++) sBD[wv][a * 18 + 3 * r + c] = B1[0] * I[c] + B1[1] * I[3 + c] + B1[2] * I[6 + c];
-        atomicAdd(&bs[6 * sPose[wv][a] + r], -(B1[0] * db[0] + B1[1] * db[1] + B1[2] * db[2]));
+}
+
+// S[i1, i2] -= (B_1 D^-1) B_2^T for every pair of free-pose observations of a landmark, i2 >= i1 (upper block
+// triangle, k_chol_prep mirrors it).  Block row i1 of S belongs to keyframe i1: gridDim.y workgroups per keyframe
+// walk its edges (16 lanes per edge, one lane per second observation), accumulate the row in LDS with
+// ds_add_f64 and add it to S once - 6 x n global atomics per workgroup instead of 36 per observation pair.
+__global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart, const int *kfEdges, const int *ptStart, const int *ptEdges, int nP6,
+                                                    const double *__restrict__ Ddb, double *S, double *bs)
+{
+    extern __shared__ __attribute__((aligned(16))) double row[];   // [6][nP6], then 6 entries of bs
+    const int k = blockIdx.x, pi = d.poseIdx[k], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (pi < 0) return;
+    for (int i = tid; i < 6 * nP6 + 6; i += 256) row[i] = 0.0;
+    __syncthreads();
+    // a wave works on four edges of the keyframe at once: 16 lanes per edge, one lane per second observation of the
+    // landmark (the index lookups are done once per pair, the 6x6 block comes out of 36 registers)
+    const int sub = lane >> 4, a = lane & 15, stride = 16 * gridDim.y;
+    for (int s = kfStart[k] + (blockIdx.y * 4 + wv) * 4 + sub; s < kfStart[k + 1]; s += stride) {
+        const int e = kfEdges[s];
+        if (!d.active[e]) continue;
+        const double *pBD = d.edgeBlk + (size_t)e * EB_SIZE + EB_BD;
+        double BD[18];
+#pragma unroll
+        for (int i = 0; i < 18; i++) BD[i] = pBD[i];
+        const int l = d.ep[e], s0 = ptStart[l], nE = ptStart[l + 1] - s0;
+        if (a < 6) {   // bs[i1] -= B * (D^-1 b_l): 300 addresses for all edges of the window, so it goes through the LDS row as well
+            const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL + 3 * a, *db = Ddb + (size_t)l * 3;
+            unsafeAtomicAdd(&row[6 * nP6 + a], -(B1[0] * db[0] + B1[1] * db[1] + B1[2] * db[2]));
+        }
+        for (int a2 = a; a2 < nE; a2 += 16) {
+            const int e2 = ptEdges[s0 + a2];
+            if (!d.active[e2]) continue;
+            const int i2 = d.poseIdx[d.ek[e2]];
+            if (i2 < pi) continue;                      // also: fixed keyframe (-1)
+            const double *pB2 = d.edgeBlk + (size_t)e2 * EB_SIZE + EB_HPL;
+            double B2[18];
+#pragma unroll
+            for (int i = 0; i < 18; i++) B2[i] = pB2[i];
+            double *dst = row + 6 * i2;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    unsafeAtomicAdd(&dst[r * nP6 + c], -(BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]));   // ds_add_f64
+        }
     }
-    __builtin_amdgcn_wave_barrier();
-    // S[i1,i2] -= BD_1 * B_2^T for i2 >= i1 (upper triangular block pairs only)
-    const int work = n * n * 36;
-    for (int t = lane; t < work; t += 64) {
-        const int pr = t / 36, rc = t % 36, a1 = pr / n, a2 = pr % n, r = rc / 6, c = rc % 6;
-        const int i1 = sPose[wv][a1], i2 = sPose[wv][a2];
-        if (i2 < i1) continue;
-        const double *BD = sBD[wv] + a1 * 18 + 3 * r;
-        const double *B2 = d.edgeBlk + (size_t)sEdge[wv][a2] * EB_SIZE + EB_HPL + 3 * c;
-        atomicAdd(&S[(size_t)(6 * i1 + r) * nP6 + 6 * i2 + c], -(BD[0] * B2[0] + BD[1] * B2[1] + BD[2] * B2[2]));
+    __syncthreads();
+    for (int i = tid; i < 6 * nP6; i += 256) {
+        const int r = i / nP6, col = i - r * nP6;
+        const double v = row[i];
+        if (col >= 6 * pi && v != 0.0) unsafeAtomicAdd(&S[(size_t)(6 * pi + r) * nP6 + col], v);
     }
+    if (tid < 6 && row[6 * nP6 + tid] != 0.0) unsafeAtomicAdd(&bs[6 * pi + tid], row[6 * nP6 + tid]);
 }
 
 #define CHOL_MAX_N 2048
@@ -1134,7 +1177,7 @@ struct orbx_lba {
     bool timed = false;
     double flops = 0;
     OrbxDevBuf<DPose> pose, poseBak;
-    OrbxDevBuf<double> pt, ptBak, intr, obs, info, err, rchi, edgeBlk, Hpp, bp, Hll, bl, Dinv, S, bs, xp, xl, red;
+    OrbxDevBuf<double> pt, ptBak, intr, obs, info, err, rchi, edgeBlk, Hpp, bp, Hll, bl, Dinv, Ddb, S, bs, xp, xl, red;
     OrbxDevBuf<double> Lmat, ywork, ysol;   // multi-workgroup Cholesky: the factor and the two halves of the right-hand side
     OrbxDevBuf<int> ep, ek, ptStart, ptEdges, kfStart, kfEdges, poseIdx, ptIdx, okFlag;
     OrbxDevBuf<uint8_t> stereo, active;
@@ -1158,7 +1201,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     rc = rc ? rc : h->pose.ensure(K); rc = rc ? rc : h->poseBak.ensure(K); rc = rc ? rc : h->pt.ensure(3 * P); rc = rc ? rc : h->ptBak.ensure(3 * P);
     rc = rc ? rc : h->intr.ensure(5 * K); rc = rc ? rc : h->obs.ensure(3 * E); rc = rc ? rc : h->info.ensure(E); rc = rc ? rc : h->err.ensure(3 * E);
     rc = rc ? rc : h->rchi.ensure(E); rc = rc ? rc : h->edgeBlk.ensure(E * EB_SIZE); rc = rc ? rc : h->Hpp.ensure(36 * K); rc = rc ? rc : h->bp.ensure(n6);
-    rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->S.ensure(n6 * n6); rc = rc ? rc : h->Lmat.ensure(n6 * n6); rc = rc ? rc : h->ywork.ensure(n6); rc = rc ? rc : h->ysol.ensure(n6);
+    rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->Ddb.ensure(3 * P); rc = rc ? rc : h->S.ensure(n6 * n6); rc = rc ? rc : h->Lmat.ensure(n6 * n6); rc = rc ? rc : h->ywork.ensure(n6); rc = rc ? rc : h->ysol.ensure(n6);
     rc = rc ? rc : h->bs.ensure(n6); rc = rc ? rc : h->xp.ensure(n6); rc = rc ? rc : h->xl.ensure(3 * P); rc = rc ? rc : h->red.ensure(16);
     rc = rc ? rc : h->ep.ensure(E); rc = rc ? rc : h->ek.ensure(E); rc = rc ? rc : h->ptStart.ensure(P + 1); rc = rc ? rc : h->ptEdges.ensure(E);
     rc = rc ? rc : h->kfStart.ensure(K + 1); rc = rc ? rc : h->kfEdges.ensure(E); rc = rc ? rc : h->poseIdx.ensure(K); rc = rc ? rc : h->ptIdx.ensure(P);
@@ -1174,7 +1217,7 @@ extern "C" void orbx_lba_destroy(orbx_lba *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->pose.release(); h->poseBak.release(); h->pt.release(); h->ptBak.release(); h->intr.release(); h->obs.release(); h->info.release(); h->err.release();
-    h->rchi.release(); h->edgeBlk.release(); h->Hpp.release(); h->bp.release(); h->Hll.release(); h->bl.release(); h->Dinv.release(); h->S.release(); h->Lmat.release(); h->ywork.release(); h->ysol.release();
+    h->rchi.release(); h->edgeBlk.release(); h->Hpp.release(); h->bp.release(); h->Hll.release(); h->bl.release(); h->Dinv.release(); h->Ddb.release(); h->S.release(); h->Lmat.release(); h->ywork.release(); h->ysol.release();
     h->bs.release(); h->xp.release(); h->xl.release(); h->red.release(); h->ep.release(); h->ek.release(); h->ptStart.release(); h->ptEdges.release();
     h->kfStart.release(); h->kfEdges.release(); h->poseIdx.release(); h->ptIdx.release(); h->okFlag.release(); h->stereo.release(); h->active.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1280,8 +1323,15 @@ int optimize(Ctx &c, int iterations, double stats[4])
                 LCHECK();
             }
             hipLaunchKernelGGL(k_schur_points, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p, lambda,
-                               nP6, h->Dinv.p, h->S.p, h->bs.p);
+                               h->Dinv.p, h->Ddb.p);
             LCHECK();
+            if (nP6 > 0) {
+                const size_t ldsRows = (size_t)(6 * nP6 + 6) * sizeof(double);
+                if (ldsRows > 150 * 1024) { orbx_set_error("%d free keyframes exceed the Schur row tile (max %d)", nPose, (int)(150 * 1024 / 288)); return ORBX_ERR_CAPACITY; }
+                if (ldsRows > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
+                hipLaunchKernelGGL(k_schur_rows, dim3((unsigned)K, 16u), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, h->bs.p);
+                LCHECK();
+            }
             if (nP6 > 0) {
                 if (nP6 >= CHOL_MULTI_MIN_N) {
                     const int n = nP6;
@@ -1408,8 +1458,6 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
         std::vector<int> fp(ptStart.begin(), ptStart.end() - 1), fk(kfStart.begin(), kfStart.end() - 1);
         for (int e = 0; e < E; e++) { ptEdges[(size_t)fp[(size_t)c.ep[(size_t)e]]++] = e; kfEdges[(size_t)fk[(size_t)c.ek[(size_t)e]]++] = e; }
     }
-    for (int l = 0; l < P; l++)
-        if (ptStart[(size_t)l + 1] - ptStart[(size_t)l] > SCHUR_MAX_OBS) { orbx_set_error("point %d has more than %d observations", l, SCHUR_MAX_OBS); return ORBX_ERR_CAPACITY; }
     hipStream_t s = h->stream;
     ORBX_HIP_CHECK(hipMemcpyAsync(h->pose.p, pose.data(), (size_t)K * sizeof(DPose), hipMemcpyHostToDevice, s));
     ORBX_HIP_CHECK(hipMemcpyAsync(h->pt.p, pt.data(), pt.size() * 8, hipMemcpyHostToDevice, s));
