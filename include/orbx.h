@@ -576,7 +576,9 @@ int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *problem, const volatile 
  * CreateInitialMapMonocular with 20 iterations, LoopClosing::RunGlobalBundleAdjustment with 10): the same graph
  * and solver as the local window, one optimize(iterations) with Huber kernels iff robust, no outlier pass.
  * problem: every non-bad KeyFrame (fixed[k] = mnId == 0) and MapPoint with its observations; result as
- * orbx_lba_solve (edge_outlier / edge_chi2 = the final classification, informative only here). */
+ * orbx_lba_solve (edge_outlier / edge_chi2 = the final classification, informative only here).
+ * Both entry points keep one block row of the reduced system (6 x 6*free keyframes doubles) in LDS: at most 530 free
+ * keyframes, ORBX_ERR_CAPACITY beyond (the reduced system is dense here, 530 keyframes are a 3180 x 3180 factorisation). */
 int orbx_bundle_adjustment(orbx_lba *h, const orbx_lba_problem *problem, int iterations, int robust,
                            const volatile uint8_t *stop_flag, orbx_lba_result *result);
 /* Kernel milliseconds (HIP events) spent inside the last orbx_lba_solve and FP64 flop count. */
