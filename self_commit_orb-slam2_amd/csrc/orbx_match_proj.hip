@@ -1394,25 +1394,37 @@ extern "C" int orbx_is_in_frustum(orbx_matcher *m, const orbx_frustum_frame *fra
     if (mm <= 0) return ORBX_OK;
     ORBX_HIP_CHECK(hipSetDevice(m->device));
     int rc;
-    if ((rc = m->pf[0].ensure(16)) || (rc = m->pf[1].ensure((size_t)mm * 8)) || (rc = m->pi32[0].ensure(2))) return rc;
+    // inputs through the pinned staging buffer and one copy; the results come back into the same pinned buffer
+    // (three copies that need no bounce buffer) and are handed out from there
     hipStream_t st = m->stream;
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[0].p, frame_host->tcw, 16 * sizeof(float), hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p, points_host->world_pos, (size_t)mm * 12, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 3 * (size_t)mm, points_host->normal, (size_t)mm * 12, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 6 * (size_t)mm, points_host->max_distance, (size_t)mm * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[1].p + 7 * (size_t)mm, points_host->min_distance, (size_t)mm * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, &mm, sizeof(int32_t), hipMemcpyHostToDevice, st));
-    orbx_frustum_frame fd = *frame_host;
-    fd.tcw = m->pf[0].p; fd.nframes = 1;
-    orbx_map_points pd = {m->pf[1].p, m->pf[1].p + 3 * (size_t)mm, m->pf[1].p + 6 * (size_t)mm, m->pf[1].p + 7 * (size_t)mm, m->pi32[0].p, mm};
-    if ((rc = orbx_is_in_frustum_device(m, &fd, &pd, viewing_cos_limit)) != ORBX_OK) return rc;
-    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    OrbxHostStage &hs = m->hostStage;
     const size_t n = (size_t)mm;
-    if (proj_x) ORBX_HIP_CHECK(hipMemcpy(proj_x, m->frProj.p, n * 4, hipMemcpyDeviceToHost));
-    if (proj_y) ORBX_HIP_CHECK(hipMemcpy(proj_y, m->frProj.p + n, n * 4, hipMemcpyDeviceToHost));
-    if (proj_xr) ORBX_HIP_CHECK(hipMemcpy(proj_xr, m->frProj.p + 2 * n, n * 4, hipMemcpyDeviceToHost));
-    if (view_cos) ORBX_HIP_CHECK(hipMemcpy(view_cos, m->frProj.p + 3 * n, n * 4, hipMemcpyDeviceToHost));
-    if (scale_level) ORBX_HIP_CHECK(hipMemcpy(scale_level, m->frLevel.p, n * 4, hipMemcpyDeviceToHost));
-    ORBX_HIP_CHECK(hipMemcpy(in_view, m->frInView.p, n, hipMemcpyDeviceToHost));
+    const size_t inBytes = hs.padded(64) + 2 * hs.padded(n * 12) + 2 * hs.padded(n * 4) + hs.padded(4), outBytes = hs.padded(n * 16) + hs.padded(n * 4) + hs.padded(n);
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    if ((rc = hs.begin(inBytes > outBytes ? inBytes : outBytes)) != ORBX_OK) return rc;
+    const int32_t cnt = mm;
+    orbx_frustum_frame fd = *frame_host;
+    fd.tcw = hs.put(frame_host->tcw, 16); fd.nframes = 1;
+    orbx_map_points pd;
+    pd.world_pos = hs.put(points_host->world_pos, n * 3);
+    pd.normal = hs.put(points_host->normal, n * 3);
+    pd.max_distance = hs.put(points_host->max_distance, n);
+    pd.min_distance = hs.put(points_host->min_distance, n);
+    pd.counts = hs.put(&cnt, 1);
+    pd.capacity = mm;
+    if ((rc = hs.flush(st)) != ORBX_OK) return rc;
+    if ((rc = orbx_is_in_frustum_device(m, &fd, &pd, viewing_cos_limit)) != ORBX_OK) return rc;
+    uint8_t *hp = hs.host, *hl = hp + hs.padded(n * 16), *hv = hl + hs.padded(n * 4);
+    ORBX_HIP_CHECK(hipMemcpyAsync(hp, m->frProj.p, n * 16, hipMemcpyDeviceToHost, st));     // stream order: after the kernel, which has consumed the inputs
+    ORBX_HIP_CHECK(hipMemcpyAsync(hl, m->frLevel.p, n * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(hv, m->frInView.p, n, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    const float *pp = (const float *)hp;
+    if (proj_x) memcpy(proj_x, pp, n * 4);
+    if (proj_y) memcpy(proj_y, pp + n, n * 4);
+    if (proj_xr) memcpy(proj_xr, pp + 2 * n, n * 4);
+    if (view_cos) memcpy(view_cos, pp + 3 * n, n * 4);
+    if (scale_level) memcpy(scale_level, hl, n * 4);
+    memcpy(in_view, hv, n);
     return ORBX_OK;
 }
