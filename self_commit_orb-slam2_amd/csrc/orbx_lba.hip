@@ -1543,10 +1543,11 @@ extern "C" int orbx_bundle_adjustment(orbx_lba *h, const orbx_lba_problem *p, in
 struct orbx_pose_optimizer {
     int device = 0, maxFrames = 0, maxFeatures = 0;
     hipStream_t stream = nullptr;
-    OrbxDevBuf<float> pose0, cam, Xw, obs, invS2, poseOut;
-    OrbxDevBuf<int32_t> counts, ret;
+    OrbxDevBuf<float> poseOut;
+    OrbxDevBuf<int32_t> ret;
     OrbxDevBuf<uint8_t> outlier;
     OrbxDevBuf<double> err, stats;
+    OrbxHostStage hostStage;   // inputs of a call in one pinned copy, results back through the same pinned buffer
 };
 
 extern "C" int orbx_pose_optimizer_create(int device, int max_frames, int max_features, orbx_pose_optimizer **out)
@@ -1562,9 +1563,7 @@ extern "C" int orbx_pose_optimizer_create(int device, int max_frames, int max_fe
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
     const size_t B = (size_t)max_frames, N = (size_t)max_frames * max_features;
     int rc;
-    if ((rc = h->pose0.ensure(B * 16)) || (rc = h->cam.ensure(B * 5)) || (rc = h->Xw.ensure(N * 3)) || (rc = h->obs.ensure(N * 3)) || (rc = h->invS2.ensure(N)) ||
-        (rc = h->poseOut.ensure(B * 16)) || (rc = h->counts.ensure(B)) || (rc = h->ret.ensure(B)) || (rc = h->outlier.ensure(N)) || (rc = h->err.ensure(N * 3)) ||
-        (rc = h->stats.ensure(B * 8))) {
+    if ((rc = h->poseOut.ensure(B * 16)) || (rc = h->ret.ensure(B)) || (rc = h->outlier.ensure(N)) || (rc = h->err.ensure(N * 3)) || (rc = h->stats.ensure(B * 8))) {
         orbx_pose_optimizer_destroy(h);
         return rc;
     }
@@ -1577,8 +1576,8 @@ extern "C" void orbx_pose_optimizer_destroy(orbx_pose_optimizer *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    h->pose0.release(); h->cam.release(); h->Xw.release(); h->obs.release(); h->invS2.release(); h->poseOut.release(); h->counts.release(); h->ret.release();
-    h->outlier.release(); h->err.release(); h->stats.release();
+    h->poseOut.release(); h->ret.release();
+    h->outlier.release(); h->err.release(); h->stats.release(); h->hostStage.release();
     delete h;
 }
 
@@ -1590,13 +1589,17 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     ORBX_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     const size_t N = (size_t)B * cap;
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->pose0.p, p->poses, (size_t)B * 64, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->cam.p, p->cameras, (size_t)B * 20, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->counts.p, p->counts, (size_t)B * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->Xw.p, p->world_points, N * 12, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->obs.p, p->observations, N * 12, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->invS2.p, p->inv_sigma2, N * 4, hipMemcpyHostToDevice, st));
-    PoseOptDev D = {h->pose0.p, h->cam.p, h->Xw.p, h->obs.p, h->invS2.p, h->counts.p, cap, h->err.p, h->poseOut.p, h->outlier.p, h->ret.p, h->stats.p};
+    OrbxHostStage &hs = h->hostStage;
+    const size_t inBytes = hs.padded((size_t)B * 64) + hs.padded((size_t)B * 20) + hs.padded((size_t)B * 4) + 2 * hs.padded(N * 12) + hs.padded(N * 4);
+    const size_t outBytes = hs.padded((size_t)B * 64) + hs.padded(N) + hs.padded((size_t)B * 4) + hs.padded((size_t)B * 64);
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    int rcs = hs.begin(inBytes > outBytes ? inBytes : outBytes);
+    if (rcs != ORBX_OK) return rcs;
+    const float *dPose = hs.put(p->poses, (size_t)B * 16), *dCam = hs.put(p->cameras, (size_t)B * 5);
+    const int32_t *dCnt = hs.put(p->counts, (size_t)B);
+    const float *dXw = hs.put(p->world_points, N * 3), *dObs = hs.put(p->observations, N * 3), *dInv = hs.put(p->inv_sigma2, N);
+    if ((rcs = hs.flush(st)) != ORBX_OK) return rcs;
+    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, h->err.p, h->poseOut.p, h->outlier.p, h->ret.p, h->stats.p};
     const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);   // deltaMono / deltaStereo are floats (:389-390)
     Huber hub;
     hub.dMono = thMono; hub.dStereo = thStereo;
@@ -1604,11 +1607,17 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     hipLaunchKernelGGL(k_pose_opt, dim3((unsigned)B), dim3(256), 0, st, D, hub);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+    // results: four copies into the pinned buffer (stream order: after the kernel, which has consumed the inputs), one synchronisation
+    uint8_t *o0 = hs.host, *o1 = o0 + hs.padded((size_t)B * 64), *o2 = o1 + hs.padded(N), *o3 = o2 + hs.padded((size_t)B * 4);
+    if (poses_out) ORBX_HIP_CHECK(hipMemcpyAsync(o0, h->poseOut.p, (size_t)B * 64, hipMemcpyDeviceToHost, st));
+    if (outlier) ORBX_HIP_CHECK(hipMemcpyAsync(o1, h->outlier.p, N, hipMemcpyDeviceToHost, st));
+    if (inliers) ORBX_HIP_CHECK(hipMemcpyAsync(o2, h->ret.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    if (stats) ORBX_HIP_CHECK(hipMemcpyAsync(o3, h->stats.p, (size_t)B * 64, hipMemcpyDeviceToHost, st));
     ORBX_HIP_CHECK(hipStreamSynchronize(st));
-    if (poses_out) ORBX_HIP_CHECK(hipMemcpy(poses_out, h->poseOut.p, (size_t)B * 64, hipMemcpyDeviceToHost));
-    if (outlier) ORBX_HIP_CHECK(hipMemcpy(outlier, h->outlier.p, N, hipMemcpyDeviceToHost));
-    if (inliers) ORBX_HIP_CHECK(hipMemcpy(inliers, h->ret.p, (size_t)B * 4, hipMemcpyDeviceToHost));
-    if (stats) ORBX_HIP_CHECK(hipMemcpy(stats, h->stats.p, (size_t)B * 64, hipMemcpyDeviceToHost));
+    if (poses_out) memcpy(poses_out, o0, (size_t)B * 64);
+    if (outlier) memcpy(outlier, o1, N);
+    if (inliers) memcpy(inliers, o2, (size_t)B * 4);
+    if (stats) memcpy(stats, o3, (size_t)B * 64);
     return ORBX_OK;
 }
 
