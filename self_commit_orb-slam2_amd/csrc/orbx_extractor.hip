@@ -571,14 +571,29 @@ extern "C" int orbx_batch_download(orbx_extractor *h, int batch, orbx_keypoint *
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     int rc = check_status(h, batch);
     if (rc != ORBX_OK) return rc;
-    ORBX_HIP_CHECK(hipMemcpy(counts, h->outCnt[h->cur].p, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
+    // the result arrays come back whole through the pinned buffer (three copies without a bounce buffer instead of two
+    // pageable copies per frame) and are handed out from there
     const int cap = h->geom.outCap;
+    const size_t B = (size_t)batch, offKp = align_up(B * sizeof(int), 256), offDesc = offKp + align_up(B * cap * sizeof(orbx_keypoint), 256),
+                 bytes = offDesc + B * cap * 32;
+    if (bytes > h->hostStagingBytes) {
+        if (h->hostStaging) (void)hipHostFree(h->hostStaging);
+        h->hostStaging = nullptr; h->hostStagingBytes = 0;
+        ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostStaging, bytes, hipHostMallocDefault));
+        h->hostStagingBytes = bytes;
+    }
+    uint8_t *hp = h->hostStaging;
+    ORBX_HIP_CHECK(hipMemcpyAsync(hp, h->outCnt[h->cur].p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (keypoints) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offKp, h->outKp[h->cur].p, B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->stream));
+    if (descriptors) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offDesc, h->outDesc[h->cur].p, B * cap * 32, hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    memcpy(counts, hp, B * sizeof(int));
     for (int f = 0; f < batch; f++) {
         const int n = counts[f];
         if (n > capacity) { orbx_set_error("frame %d has %d keypoints but the caller's capacity is %d", f, n, capacity); return ORBX_ERR_CAPACITY; }
         if (n == 0) continue;
-        if (keypoints) ORBX_HIP_CHECK(hipMemcpy(keypoints + (size_t)f * capacity, h->outKp[h->cur].p + (size_t)f * cap, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
-        if (descriptors) ORBX_HIP_CHECK(hipMemcpy(descriptors + (size_t)f * capacity * 32, h->outDesc[h->cur].p + (size_t)f * cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+        if (keypoints) memcpy(keypoints + (size_t)f * capacity, hp + offKp + (size_t)f * cap * sizeof(orbx_keypoint), (size_t)n * sizeof(orbx_keypoint));
+        if (descriptors) memcpy(descriptors + (size_t)f * capacity * 32, hp + offDesc + (size_t)f * cap * 32, (size_t)n * 32);
     }
     return ORBX_OK;
 }
