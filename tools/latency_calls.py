@@ -96,3 +96,28 @@ try:
     bench("Optimizer::PoseOptimization, one frame, 600 correspondences", lambda: po.PoseOptimization(pf))
 except Exception as e:
     print("skipped:", repr(e))
+
+# ---- LocalMapping / LoopClosing side ----
+try:
+    import test_fuse as tf, test_triangulation as tt
+    SF = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    kf, Tt, sk, Ts, P, cdesc, rng = tf._scene(orbx, 13, nc=3000, nextra=1500)
+    nc = len(P)
+    Pc = P @ Tt[:3, :3].T + Tt[:3, 3]
+    z = np.where(np.abs(Pc[:, 2]) < 1e-3, 1e-3, Pc[:, 2])
+    lvl = rng.integers(0, 8, nc).astype(np.int32)
+    pts = dict(u=(Pc[:, 0] / z * 500 + 320).astype(np.float32), v=(Pc[:, 1] / z * 500 + 240).astype(np.float32),
+               ur=(Pc[:, 0] / z * 500 + 320 - 40.0 / z).astype(np.float32), level=lvl, radius=(3.0 * SF[lvl]).astype(np.float32),
+               active=(rng.random(nc) < 0.9).astype(np.uint8), desc=cdesc)
+    mtf = orbx.ORBmatcher(0.6, True, max_features=max(len(kf["kps"]), nc, 64))
+    bench("ORBmatcher::Fuse search, %d points x %d features" % (nc, len(kf["kps"])), lambda: mtf.FuseSearch(kf, pts, True))
+    q = dict(u=pts["u"], v=pts["v"], radius=(6.0 * SF[lvl]).astype(np.float32), min_level=lvl - 1, max_level=(lvl + 1).astype(np.int32),
+             active=pts["active"], desc=cdesc, window_int_bounds=False)
+    frame = dict(kps=kf["kps"], desc=kf["desc"], blocked=np.zeros(len(kf["kps"]), np.uint8), width=640, height=480)
+    bench("SearchByProjection (loop / reloc overloads) greedy area search", lambda: mtf.AreaSearchGreedy(frame, q, 100))
+    k1, k2, T1, T2, F12 = tt._scene(orbx, 12, n=2000, forward=False, stereo_frac=0.3)
+    mtt = orbx.ORBmatcher(0.6, False, max_features=2048)
+    epi = np.array([5000.0, 300.0], np.float32)
+    bench("ORBmatcher::SearchForTriangulation 2000 x 2000", lambda: mtt.SearchForTriangulation(k1, k2, F12, epi, tt.SF, tt.SIGMA2, False))
+except Exception as e:
+    print("LocalMapping part skipped:", repr(e))
