@@ -221,20 +221,21 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
     }
     int pitch;
     const uint8_t *src = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
-    {   // stage rows y0-3 .. y1+2, bytes x0-3 .. x1+2 (+ up to 3 spill bytes, always inside the row)
-        const int ih = ah + 6, nw = (aw + 6 + 3) >> 2;
+    {   // stage rows y0-3 .. y1+2, bytes x0-3 .. x1+2 in 8-byte units (+ up to 7 spill bytes: x1+10 <= w-9 stays inside the row,
+        // aw+13 < P inside the LDS row)
+        const int ih = ah + 6, nw = (aw + 6 + 7) >> 3;
         const uint8_t *base = src + (size_t)(y0 - 3) * pitch + (x0 - 3);
         int r = lane / nw, c = lane - r * nw;
         const int dr = 64 / nw, dc = 64 - dr * nw;
         while (r < ih) {
-            uint32_t v;
-            __builtin_memcpy(&v, base + (size_t)r * pitch + 4 * c, 4);   // unaligned dword load
-            *(uint32_t *)(inT + r * P + 4 * c) = v;
+            uint2 v;
+            __builtin_memcpy(&v, base + (size_t)r * pitch + 8 * c, 8);   // unaligned 8-byte load
+            *(uint2 *)(inT + r * P + 8 * c) = v;
             r += dr; c += dc;
             if (c >= nw) { c -= nw; r++; }
         }
-        uint32_t *z = (uint32_t *)scT;
-        for (int i = lane; i < (ah + 2) * (P / 4); i += 64) z[i] = 0;
+        uint4 *z = (uint4 *)scT;
+        for (int i = lane; i < (ah + 2) * (P / 16); i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
     const int minTh = g->minTh, iniTh = g->iniTh;
