@@ -191,6 +191,8 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b,
 #define FC_PAIR(W, b) __builtin_amdgcn_perm((W)[((b) >> 2) + 1 > 5 ? 5 : ((b) >> 2) + 1], (W)[(b) >> 2], \
                                             0x0c000c00u | (uint32_t)((b) & 3) | ((uint32_t)(((b) & 3) + 1) << 16))
 
+__constant__ int c_inv16[10] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282};   // ceil(2^16 / n)
+
 template <int SEGMAX>   // widest cell of the geometry in 16-px segments (1..4)
 __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
                                                    const uint8_t *__restrict__ pyr, uint8_t *__restrict__ scoreDbg, int *__restrict__ cellCount,
@@ -225,8 +227,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
         // aw+13 < P inside the LDS row)
         const int ih = ah + 6, nw = (aw + 6 + 7) >> 3;
         const uint8_t *base = src + (size_t)(y0 - 3) * pitch + (x0 - 3);
-        int r = lane / nw, c = lane - r * nw;
-        const int dr = 64 / nw, dc = 64 - dr * nw;
+        // lane / nw and 64 / nw without the integer-division sequence: nw <= 9 here, and x * ceil(2^16 / nw) >> 16 == x / nw for x <= 64
+        const int inv = c_inv16[nw];                      // uniform index: a scalar load
+        int r = (lane * inv) >> 16, c = lane - r * nw;
+        const int dr = (64 * inv) >> 16, dc = 64 - dr * nw;
         while (r < ih) {
             uint2 v;
             __builtin_memcpy(&v, base + (size_t)r * pitch + 8 * c, 8);   // unaligned 8-byte load
