@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
 //   C  strict 3x3 maximum inside the cell (zero ring = "not a corner of this sub-image"),
 //      iniThFAST survivors or - when the cell has none - all of them (:1132), ordered __ballot
 //      compaction into the cell's slot.
-// VALU bound (profiles/): ~1.4k wave-instructions per cell.
+// VALU bound (profiles/): ~1.05k wave-instructions per cell.
 // ------------------------------------------------------------------------------------
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
