@@ -14,8 +14,14 @@
 //   orbslam_voc_* / orbslam_transform   DBoW2 TemplatedVocabulary::create / transform
 //                          (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:507-570, 1127-1262)
 //   orbslam_search_by_projection_*      ORBmatcher::SearchByProjection (src/ORBmatcher.cc:70-175, 1569-1728)
-// Only include/Converter.h (Eigen + g2o types) is replaced, by the one function the compiled
-// files use (toDescriptorVector, src/Converter.cc:38-47).
+//   orbslam_local_ba / orbslam_global_ba / orbslam_pose_optimization
+//                          Optimizer::LocalBundleAdjustment / GlobalBundleAdjustemnt / PoseOptimization
+//                          (src/Optimizer.cc:629-997, 55-360, 363-605) on a real Map / Frame: in the all-reference
+//                          library that is the reference's own src/Optimizer.cc + src/Converter.cc + the vendored
+//                          g2o, compiled unmodified against oracle/eigenshim; in the drop-in library it is
+//                          shim/Optimizer_hip.cc.
+//   orbslam_g2o_lba        the vendored g2o driven directly (graph of src/Optimizer.cc:698-958) with FP64 results and
+//                          per-edge chi2: pins oracle/lba_oracle.cc below float32 resolution.
 //
 // Determinism of DistributeOctTree's pointer tie-break (src/ORBextractor.cc:948): the stereo
 // Frame constructor runs the two extractors on std::threads it creates itself, so the bump
@@ -35,6 +41,7 @@
 #include <new>
 #include <vector>
 
+#include "Converter.h"
 #include "Frame.h"
 #include "KeyFrame.h"
 #include "Map.h"
@@ -112,19 +119,6 @@ ORBSLAM_HIDDEN void operator delete(void *p) noexcept { if (p && !in_region(p)) 
 ORBSLAM_HIDDEN void operator delete[](void *p) noexcept { operator delete(p); }
 ORBSLAM_HIDDEN void operator delete(void *p, size_t) noexcept { operator delete(p); }
 ORBSLAM_HIDDEN void operator delete[](void *p, size_t) noexcept { operator delete(p); }
-
-// ---------------------------------------------------------------------------------------
-// the one Converter function the compiled reference files call (src/Converter.cc:38-47)
-// ---------------------------------------------------------------------------------------
-namespace ORB_SLAM2 {
-std::vector<cv::Mat> Converter::toDescriptorVector(const cv::Mat &Descriptors)
-{
-    std::vector<cv::Mat> vDesc;
-    vDesc.reserve(Descriptors.rows);
-    for (int j = 0; j < Descriptors.rows; j++) vDesc.push_back(Descriptors.row(j));
-    return vDesc;
-}
-}  // namespace ORB_SLAM2
 
 using namespace ORB_SLAM2;
 
@@ -905,13 +899,17 @@ ORBSLAM_API int orbslam_search_by_projection_last(const float *kpUn, const uint8
     return nm;
 }
 
-#ifdef ORBSLAM_HIP
 // ---------------------------------------------------------------------------------------
-// Optimizer::LocalBundleAdjustment / PoseOptimization exist only in the drop-in build (g2o needs
-// Eigen, so the all-reference library has no Optimizer): shim/Optimizer_hip.cc on a REAL map built
+// Optimizer::LocalBundleAdjustment / GlobalBundleAdjustemnt / PoseOptimization on a REAL map built
 // from flat arrays - KeyFrames, MapPoints, observations, covisibility graph (KeyFrame::UpdateConnections).
+// All-reference library: the reference's src/Optimizer.cc + g2o (unmodified, oracle/eigenshim);
+// drop-in library: shim/Optimizer_hip.cc.
 // ---------------------------------------------------------------------------------------
+#ifdef ORBSLAM_HIP
 #include "../self_commit_orb-slam2_amd/shim/Optimizer.h"
+#else
+#include "Optimizer.h"
+#endif
 
 // obs: E rows {point, keyframe, u, v, uR (<0 mono), octave}.  ref_kf = the keyframe LocalMapping just inserted.
 // Outputs: poses_out [K*16], points_out [P*3], erased [E] (the observation was removed as an outlier),
@@ -1080,4 +1078,3 @@ ORBSLAM_API int orbslam_pose_optimization(const float *pose16, const float *cam5
     delete kf;
     return ret;
 }
-#endif
