@@ -434,6 +434,9 @@ int optimize(Problem &p, int iterations, const volatile uint8_t *stop, Stats *st
 // reads it at :921-958), edge_outlier E (chi2 > 5.991/7.815 or depth <= 0), stats[8] doubles.
 // iters1 LM iterations (Huber kernels when robust1); with secondStage the LocalBundleAdjustment continuation: outlier
 // classification, then 10 iterations without kernels on the inliers.
+// optional FP64 taps of the final state (set by lo_ba_f64 around a run): poses K x 12 (R row-major, t), points P x 3
+static thread_local double *g_poses_d = nullptr, *g_points_d = nullptr;
+
 static int run_ba(int K, const float *poses, const uint8_t *fixed, const float *intr, int P, const float *points, int E, const int32_t *edge_point,
                   const int32_t *edge_kf, const float *edge_obs, const float *edge_inv_sigma2, const volatile uint8_t *stop, int iters1, bool robust1,
                   bool secondStage, float *poses_out, float *points_out, double *edge_chi2_out, uint8_t *edge_outlier, double *stats)
@@ -457,7 +460,8 @@ static int run_ba(int K, const float *poses, const uint8_t *fixed, const float *
         p.stereo[(size_t)e] = !(edge_obs[3 * (size_t)e + 2] < 0);   // mvuRight < 0 -> monocular (src/Optimizer.cc:797)
         p.info[(size_t)e] = edge_inv_sigma2[e];
     }
-    const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);
+    // LocalBundleAdjustment: sqrt(5.991) (src/Optimizer.cc:764-765); BundleAdjustment: sqrt(5.99) (:141-142)
+    const float thMono = (float)sqrt(secondStage ? 5.991 : 5.99), thStereo = (float)sqrt(7.815);
     p.deltaMono = thMono; p.deltaStereo = thStereo;
     p.dsqrMono = (float)(p.deltaMono * p.deltaMono); p.dsqrStereo = (float)(p.deltaStereo * p.deltaStereo);
     Stats s1 = {0, 0, 0, 0, 0}, s2 = {0, 0, 0, 0, 0};
@@ -486,6 +490,14 @@ static int run_ba(int K, const float *poses, const uint8_t *fixed, const float *
         o[12] = o[13] = o[14] = 0.f; o[15] = 1.f;
     }
     for (int i = 0; i < 3 * P; i++) points_out[i] = (float)p.pt[(size_t)i];
+    if (g_poses_d)
+        for (int k = 0; k < K; k++) {
+            double R[9];
+            quat_to_R(p.pose[(size_t)k].q, R);
+            for (int i = 0; i < 9; i++) g_poses_d[12 * (size_t)k + i] = R[i];
+            for (int i = 0; i < 3; i++) g_poses_d[12 * (size_t)k + 9 + i] = p.pose[(size_t)k].t[i];
+        }
+    if (g_points_d) for (int i = 0; i < 3 * P; i++) g_points_d[i] = p.pt[(size_t)i];
     if (stats) {
         stats[0] = s1.iters; stats[1] = s1.trials; stats[2] = s1.chi0; stats[3] = s1.chi1;
         stats[4] = s2.iters; stats[5] = s2.trials; stats[6] = s2.chi0; stats[7] = s2.chi1;
@@ -511,6 +523,21 @@ LO_API int lo_bundle_adjustment(int K, const float *poses, const uint8_t *fixed,
 {
     return run_ba(K, poses, fixed, intr, P, points, E, edge_point, edge_kf, edge_obs, edge_inv_sigma2, stop, iterations, robust != 0, false, poses_out, points_out,
                   edge_chi2_out, edge_outlier, stats);
+}
+
+// The same two functions with the FP64 state exposed (poses_d K x 12: R row-major then t; points_d P x 3), for the comparison
+// with the reference's g2o below float32 resolution (oracle/refslam_wrap.cc: orbslam_g2o_ba).  secondStage selects
+// LocalBundleAdjustment (iters1 = 5, robust) or BundleAdjustment.
+LO_API int lo_ba_f64(int K, const float *poses, const uint8_t *fixed, const float *intr, int P, const float *points, int E, const int32_t *edge_point,
+                     const int32_t *edge_kf, const float *edge_obs, const float *edge_inv_sigma2, int iters1, int robust1, int secondStage, double *poses_d,
+                     double *points_d, double *edge_chi2_out, uint8_t *edge_outlier, double *stats)
+{
+    std::vector<float> po((size_t)16 * (K > 0 ? K : 1)), xo((size_t)3 * (P > 0 ? P : 1));
+    g_poses_d = poses_d; g_points_d = points_d;
+    const int r = run_ba(K, poses, fixed, intr, P, points, E, edge_point, edge_kf, edge_obs, edge_inv_sigma2, nullptr, iters1, robust1 != 0, secondStage != 0,
+                         po.data(), xo.data(), edge_chi2_out, edge_outlier, stats);
+    g_poses_d = g_points_d = nullptr;
+    return r;
 }
 
 // test hooks: error and analytic Jacobians of one edge at a given state (for the central-difference check)

@@ -1078,3 +1078,112 @@ ORBSLAM_API int orbslam_pose_optimization(const float *pose16, const float *cam5
     delete kf;
     return ret;
 }
+
+#ifndef ORBSLAM_HIP
+// ---------------------------------------------------------------------------------------
+// The vendored g2o driven directly on a flattened window (same arrays as oracle/lba_oracle.cc's
+// lo_local_bundle_adjustment / lo_bundle_adjustment), graph and schedule as src/Optimizer.cc:698-958
+// (secondStage != 0) or :86-251 (secondStage == 0) build them - but with the FP64 state and the per-edge
+// chi2 readable, which the reference's own functions round to float32 before anybody can see them.
+// Outputs: poses_d K x 12 (R row-major, t), points_d P x 3, chi2 E (e->chi2() as :921-958 reads it),
+// outlier E, iters[2] = return values of the two optimize() calls.
+// ---------------------------------------------------------------------------------------
+#include "Thirdparty/g2o/g2o/core/block_solver.h"
+#include "Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.h"
+#include "Thirdparty/g2o/g2o/core/robust_kernel_impl.h"
+#include "Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h"
+#include "Thirdparty/g2o/g2o/types/types_six_dof_expmap.h"
+
+ORBSLAM_API int orbslam_g2o_ba(int K, const float *poses, const uint8_t *fixed, const float *intr, int P, const float *points, int E,
+                               const int32_t *edge_point, const int32_t *edge_kf, const float *edge_obs, const float *edge_inv_sigma2, int iters1,
+                               int robust1, int secondStage, double *poses_d, double *points_d, double *chi2, uint8_t *outlier, int *iters)
+{
+    g2o::SparseOptimizer optimizer;
+    g2o::BlockSolver_6_3::LinearSolverType *linearSolver = new g2o::LinearSolverEigen<g2o::BlockSolver_6_3::PoseMatrixType>();
+    g2o::BlockSolver_6_3 *solver_ptr = new g2o::BlockSolver_6_3(linearSolver);
+    g2o::OptimizationAlgorithmLevenberg *solver = new g2o::OptimizationAlgorithmLevenberg(solver_ptr);
+    optimizer.setAlgorithm(solver);
+    std::vector<bool> ptUsed((size_t)P, false);
+    for (int e = 0; e < E; e++) ptUsed[(size_t)edge_point[e]] = true;
+    for (int k = 0; k < K; k++) {
+        cv::Mat T(4, 4, CV_32F);
+        memcpy(T.data, poses + 16 * (size_t)k, 64);
+        g2o::VertexSE3Expmap *v = new g2o::VertexSE3Expmap();
+        v->setEstimate(Converter::toSE3Quat(T));
+        v->setId(k);
+        v->setFixed(fixed[k] != 0);
+        optimizer.addVertex(v);
+    }
+    for (int l = 0; l < P; l++) {
+        if (!ptUsed[(size_t)l]) continue;
+        cv::Mat X(3, 1, CV_32F);
+        memcpy(X.data, points + 3 * (size_t)l, 12);
+        g2o::VertexSBAPointXYZ *v = new g2o::VertexSBAPointXYZ();
+        v->setEstimate(Converter::toVector3d(X));
+        v->setId(K + l);
+        v->setMarginalized(true);
+        optimizer.addVertex(v);
+    }
+    const float thHuberMono = sqrt(secondStage ? 5.991 : 5.99), thHuberStereo = sqrt(7.815);   // src/Optimizer.cc:764-765 / :141-142
+    std::vector<g2o::EdgeSE3ProjectXYZ *> mono((size_t)E, (g2o::EdgeSE3ProjectXYZ *)nullptr);
+    std::vector<g2o::EdgeStereoSE3ProjectXYZ *> stereo((size_t)E, (g2o::EdgeStereoSE3ProjectXYZ *)nullptr);
+    for (int e = 0; e < E; e++) {
+        const float *o = edge_obs + 3 * (size_t)e, *c = intr + 5 * (size_t)edge_kf[e];
+        const float invSigma2 = edge_inv_sigma2[e];
+        if (o[2] < 0) {
+            Eigen::Matrix<double, 2, 1> obs;
+            obs << o[0], o[1];
+            g2o::EdgeSE3ProjectXYZ *ed = new g2o::EdgeSE3ProjectXYZ();
+            ed->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex *>(optimizer.vertex(K + edge_point[e])));
+            ed->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex *>(optimizer.vertex(edge_kf[e])));
+            ed->setMeasurement(obs);
+            ed->setInformation(Eigen::Matrix2d::Identity() * invSigma2);
+            if (robust1) { g2o::RobustKernelHuber *rk = new g2o::RobustKernelHuber; ed->setRobustKernel(rk); rk->setDelta(thHuberMono); }
+            ed->fx = c[0]; ed->fy = c[1]; ed->cx = c[2]; ed->cy = c[3];
+            optimizer.addEdge(ed);
+            mono[(size_t)e] = ed;
+        } else {
+            Eigen::Matrix<double, 3, 1> obs;
+            obs << o[0], o[1], o[2];
+            g2o::EdgeStereoSE3ProjectXYZ *ed = new g2o::EdgeStereoSE3ProjectXYZ();
+            ed->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex *>(optimizer.vertex(K + edge_point[e])));
+            ed->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex *>(optimizer.vertex(edge_kf[e])));
+            ed->setMeasurement(obs);
+            Eigen::Matrix3d Info = Eigen::Matrix3d::Identity() * invSigma2;
+            ed->setInformation(Info);
+            if (robust1) { g2o::RobustKernelHuber *rk = new g2o::RobustKernelHuber; ed->setRobustKernel(rk); rk->setDelta(thHuberStereo); }
+            ed->fx = c[0]; ed->fy = c[1]; ed->cx = c[2]; ed->cy = c[3]; ed->bf = c[4];
+            optimizer.addEdge(ed);
+            stereo[(size_t)e] = ed;
+        }
+    }
+    optimizer.initializeOptimization();
+    iters[0] = optimizer.optimize(iters1);
+    iters[1] = 0;
+    if (secondStage) {
+        for (int e = 0; e < E; e++) {
+            if (mono[(size_t)e]) { g2o::EdgeSE3ProjectXYZ *ed = mono[(size_t)e]; if (ed->chi2() > 5.991 || !ed->isDepthPositive()) ed->setLevel(1); ed->setRobustKernel(0); }
+            else { g2o::EdgeStereoSE3ProjectXYZ *ed = stereo[(size_t)e]; if (ed->chi2() > 7.815 || !ed->isDepthPositive()) ed->setLevel(1); ed->setRobustKernel(0); }
+        }
+        optimizer.initializeOptimization(0);
+        iters[1] = optimizer.optimize(10);
+    }
+    for (int e = 0; e < E; e++) {
+        if (mono[(size_t)e]) { g2o::EdgeSE3ProjectXYZ *ed = mono[(size_t)e]; chi2[e] = ed->chi2(); outlier[e] = (ed->chi2() > 5.991 || !ed->isDepthPositive()) ? 1 : 0; }
+        else { g2o::EdgeStereoSE3ProjectXYZ *ed = stereo[(size_t)e]; chi2[e] = ed->chi2(); outlier[e] = (ed->chi2() > 7.815 || !ed->isDepthPositive()) ? 1 : 0; }
+    }
+    for (int k = 0; k < K; k++) {
+        g2o::VertexSE3Expmap *v = static_cast<g2o::VertexSE3Expmap *>(optimizer.vertex(k));
+        const g2o::SE3Quat T = v->estimate();
+        const Eigen::Matrix3d R = T.rotation().toRotationMatrix();
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) poses_d[12 * (size_t)k + 3 * i + j] = R(i, j);
+        for (int i = 0; i < 3; i++) poses_d[12 * (size_t)k + 9 + i] = T.translation()[i];
+    }
+    for (int l = 0; l < P; l++) {
+        if (!ptUsed[(size_t)l]) { for (int i = 0; i < 3; i++) points_d[3 * (size_t)l + i] = points[3 * (size_t)l + i]; continue; }
+        g2o::VertexSBAPointXYZ *v = static_cast<g2o::VertexSBAPointXYZ *>(optimizer.vertex(K + l));
+        for (int i = 0; i < 3; i++) points_d[3 * (size_t)l + i] = v->estimate()[i];
+    }
+    return 0;
+}
+#endif

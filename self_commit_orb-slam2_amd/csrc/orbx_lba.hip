@@ -1477,7 +1477,8 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     d.K = K; d.P = P; d.E = E; d.pose = h->pose.p; d.pt = h->pt.p; d.intr = h->intr.p; d.ep = h->ep.p; d.ek = h->ek.p; d.obs = h->obs.p;
     d.stereo = h->stereo.p; d.info = h->info.p; d.active = h->active.p; d.poseIdx = h->poseIdx.p; d.ptIdx = h->ptIdx.p; d.err = h->err.p;
     d.rchi = h->rchi.p; d.edgeBlk = h->edgeBlk.p;
-    const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);   // floats in the reference (src/Optimizer.cc:781-782)
+    // float deltas; LocalBundleAdjustment uses sqrt(5.991) (src/Optimizer.cc:764-765), BundleAdjustment sqrt(5.99) (:141-142)
+    const float thMono = (float)sqrt(secondStage ? 5.991 : 5.99), thStereo = (float)sqrt(7.815);
     c.hub.dMono = thMono; c.hub.dStereo = thStereo;
     c.hub.dsqrMono = (double)(float)((double)thMono * (double)thMono);        // `float dsqr` member (robust_kernel_impl.h:84)
     c.hub.dsqrStereo = (double)(float)((double)thStereo * (double)thStereo);

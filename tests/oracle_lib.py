@@ -718,3 +718,135 @@ def ref_is_in_frustum(Tcw, Tcw_src, src_kps, pos, cos_limit, lib=None):
     nin = lib.orbslam_is_in_frustum(_p(T), _p(Ts), _p(sk), _p(pos), n, cos_limit, _p(iv), _p(px), _p(py), _p(pxr), _p(lvl), _p(vc), _p(nrm), _p(mx), _p(mn), ctypes.byref(lsf))
     return dict(n_in=nin, in_view=iv[:n], proj_x=px[:n], proj_y=py[:n], proj_xr=pxr[:n], level=lvl[:n], view_cos=vc[:n], normal=nrm[:n], max_distance=mx[:n],
                 min_distance=mn[:n], log_scale_factor=lsf.value)
+
+
+# ---- the reference's Optimizer (src/Optimizer.cc + vendored g2o, unmodified, on oracle/eigenshim) on real Map / Frame objects,
+# ---- or shim/Optimizer_hip.cc when `lib` is the drop-in build; both through oracle/refslam_wrap.cc
+SCALE_FACTORS = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+
+
+def octaves_of(inv_s2):
+    return np.rint(np.log(1.0 / np.asarray(inv_s2, np.float64)) / (2 * np.log(1.2))).astype(np.int32)
+
+
+def _map_arrays(w):
+    octv = octaves_of(w["edge_inv_sigma2"])
+    obs6 = np.ascontiguousarray(np.stack([w["edge_point"], w["edge_kf"], w["edge_obs"][:, 0], w["edge_obs"][:, 1], w["edge_obs"][:, 2], octv], 1), np.float32)
+    return octv, obs6, np.ascontiguousarray(w["intr"][0], np.float32)
+
+
+def ref_local_ba_on_map(w, ref_kf, lib=None):
+    """Optimizer::LocalBundleAdjustment(kfs[ref_kf], &stop, &map) on a real Map built from the window `w`
+    (oracle/refslam_wrap.cc: orbslam_local_ba).  Returns poses (K x 16 f32), points (P x 3 f32), erased (E), role (K)."""
+    lib = lib or slam_lib()
+    K, P, E = w["K"], w["P"], w["E"]
+    octv, obs6, cam5 = _map_arrays(w)
+    poses_out, points_out = np.zeros((K, 16), np.float32), np.zeros((P, 3), np.float32)
+    erased, role = np.zeros(E, np.uint8), np.zeros(K, np.uint8)
+    lib.orbslam_local_ba.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+    lib.orbslam_local_ba(K, _p(w["poses"]), _p(cam5), P, _p(w["points"]), E, _p(obs6), int(ref_kf), _p(SCALE_FACTORS), 8, 640, 480, _p(poses_out), _p(points_out),
+                         _p(erased), _p(role))
+    return dict(poses=poses_out, points=points_out, erased=erased, role=role)
+
+
+def local_window_of(w, ref_kf):
+    """The reference's window rule re-derived on the arrays (KeyFrame::UpdateConnections th = 15, src/Optimizer.cc:629-697): local keyframes =
+    ref_kf + keyframes sharing >= 15 points with it (or the best one), local points = everything they see, fixed = other observers.
+    Returns (role K, flattened problem for the restatement / the C ABI, kf_list, pt_list, sel = edges inside the window)."""
+    K, P = w["K"], w["P"]
+    seen = np.zeros((K, P), bool)
+    seen[w["edge_kf"], w["edge_point"]] = True
+    shared = (seen & seen[ref_kf]).sum(1)
+    shared[ref_kf] = 0
+    neigh = shared >= 15 if (shared >= 15).any() else (shared == shared.max())
+    local = neigh.copy(); local[ref_kf] = True
+    local_pts = seen[local].any(0)
+    fixed_kf = seen[:, local_pts].any(1) & ~local
+    role = np.where(local, 1, np.where(fixed_kf, 2, 0))
+    kf_list = list(np.flatnonzero(local)) + list(np.flatnonzero(fixed_kf))
+    kf_new = {int(k): i for i, k in enumerate(kf_list)}
+    pt_list = np.flatnonzero(local_pts)
+    pt_new = -np.ones(P, np.int64); pt_new[pt_list] = np.arange(len(pt_list))
+    sel = local_pts[w["edge_point"]]
+    octv = octaves_of(w["edge_inv_sigma2"])
+    inv = (np.float32(1.0) / (SCALE_FACTORS[octv] * SCALE_FACTORS[octv])).astype(np.float32)       # Frame::mvInvLevelSigma2 as fill_frame builds it
+    fx = np.array([1 if (k == 0 or fixed_kf[k]) else 0 for k in kf_list], np.uint8)
+    prob = dict(K=len(kf_list), P=len(pt_list), E=int(sel.sum()), poses=np.ascontiguousarray(w["poses"][kf_list]), fixed=fx,
+                intr=np.ascontiguousarray(w["intr"][kf_list]), points=np.ascontiguousarray(w["points"][pt_list]),
+                edge_point=np.ascontiguousarray(pt_new[w["edge_point"][sel]].astype(np.int32)),
+                edge_kf=np.array([kf_new[int(k)] for k in w["edge_kf"][sel]], np.int32),
+                edge_obs=np.ascontiguousarray(w["edge_obs"][sel]), edge_inv_sigma2=np.ascontiguousarray(inv[sel]))
+    return role, prob, kf_list, pt_list, sel
+
+
+def ref_global_ba_on_map(w, iters, robust, loop_kf, lib=None):
+    """Optimizer::GlobalBundleAdjustemnt(&map, iters, NULL, loop_kf, robust) on a real Map (orbslam_global_ba)."""
+    lib = lib or slam_lib()
+    K, P, E = w["K"], w["P"], w["E"]
+    octv, obs6, cam5 = _map_arrays(w)
+    poses_out, points_out = np.zeros((K, 16), np.float32), np.zeros((P, 3), np.float32)
+    untouched = ctypes.c_int(0)
+    ci, vp = ctypes.c_int, ctypes.c_void_p
+    lib.orbslam_global_ba.argtypes = [ci, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp]
+    lib.orbslam_global_ba(K, _p(w["poses"]), _p(cam5), P, _p(w["points"]), E, _p(obs6), _p(SCALE_FACTORS), 8, 640, 480, int(iters), 1 if robust else 0, int(loop_kf),
+                          _p(poses_out), _p(points_out), ctypes.byref(untouched))
+    return dict(poses=poses_out, points=points_out, untouched=untouched.value)
+
+
+def global_problem_of(w):
+    """The graph GlobalBundleAdjustemnt builds from that Map, for the restatement: keyframe 0 fixed, float32 information of the octave."""
+    w2 = dict(w)
+    fixed = np.zeros(w["K"], np.uint8); fixed[0] = 1
+    octv = octaves_of(w["edge_inv_sigma2"])
+    w2["fixed"] = fixed
+    w2["edge_inv_sigma2"] = (np.float32(1.0) / (SCALE_FACTORS[octv] * SCALE_FACTORS[octv])).astype(np.float32)
+    return w2
+
+
+def ref_pose_optimization_on_frame(fr, lib=None):
+    """Optimizer::PoseOptimization(&F) on a real Frame whose features carry MapPoints (orbslam_pose_optimization).
+    fr["inv_sigma2"] is replaced by what the Frame holds for the octave (float32 1 / sf^2)."""
+    lib = lib or slam_lib()
+    n = len(fr["Xw"])
+    octv = octaves_of(fr["inv_sigma2"])
+    fr["inv_sigma2"] = (np.float32(1.0) / (SCALE_FACTORS[octv] * SCALE_FACTORS[octv])).astype(np.float32)
+    kobs = np.ascontiguousarray(np.concatenate([fr["obs"], octv[:, None].astype(np.float32)], 1), np.float32)
+    pose = np.ascontiguousarray(np.asarray(fr["pose"], np.float32).reshape(16))
+    cam5 = np.ascontiguousarray(fr["cam"], np.float32)
+    out, outl = np.zeros(16, np.float32), np.zeros(max(n, 1), np.uint8)
+    lib.orbslam_pose_optimization.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    ret = lib.orbslam_pose_optimization(_p(pose), _p(cam5), n, _p(np.ascontiguousarray(fr["Xw"], np.float32)), _p(kobs), _p(SCALE_FACTORS), 8, 640, 480, _p(out), _p(outl))
+    return dict(pose=out.reshape(4, 4), outlier=outl[:n], inliers=ret)
+
+
+def _ba_f64(fn, w, iters1, robust1, second_stage):
+    K, P, E = w["K"], w["P"], w["E"]
+    poses_d, points_d = np.zeros((K, 12), np.float64), np.zeros((P, 3), np.float64)
+    chi2, outl = np.zeros(E, np.float64), np.zeros(E, np.uint8)
+    return K, P, E, poses_d, points_d, chi2, outl
+
+
+def g2o_ba_f64(w, iters1=5, robust1=True, second_stage=True):
+    """The vendored g2o driven directly (oracle/refslam_wrap.cc: orbslam_g2o_ba): FP64 poses (R, t), points, per-edge chi2."""
+    lib = slam_lib()
+    K, P, E, poses_d, points_d, chi2, outl = _ba_f64(None, w, iters1, robust1, second_stage)
+    iters = np.zeros(2, np.int32)
+    ci, vp = ctypes.c_int, ctypes.c_void_p
+    lib.orbslam_g2o_ba.argtypes = [ci, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]
+    lib.orbslam_g2o_ba(K, _p(w["poses"]), _p(w["fixed"]), _p(w["intr"]), P, _p(w["points"]), E, _p(w["edge_point"]), _p(w["edge_kf"]), _p(w["edge_obs"]),
+                       _p(w["edge_inv_sigma2"]), int(iters1), 1 if robust1 else 0, 1 if second_stage else 0, _p(poses_d), _p(points_d), _p(chi2), _p(outl), _p(iters))
+    return dict(poses=poses_d, points=points_d, chi2=chi2, outlier=outl, iters=iters)
+
+
+def ba_f64(orc, w, iters1=5, robust1=True, second_stage=True):
+    """The restatement with its FP64 state exposed (oracle/lba_oracle.cc: lo_ba_f64)."""
+    lib = orc.lib
+    K, P, E, poses_d, points_d, chi2, outl = _ba_f64(None, w, iters1, robust1, second_stage)
+    stats = np.zeros(8, np.float64)
+    ci, vp = ctypes.c_int, ctypes.c_void_p
+    lib.lo_ba_f64.argtypes = [ci, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]
+    lib.lo_ba_f64(K, _p(w["poses"]), _p(w["fixed"]), _p(w["intr"]), P, _p(w["points"]), E, _p(w["edge_point"]), _p(w["edge_kf"]), _p(w["edge_obs"]),
+                  _p(w["edge_inv_sigma2"]), int(iters1), 1 if robust1 else 0, 1 if second_stage else 0, _p(poses_d), _p(points_d), _p(chi2), _p(outl), _p(stats))
+    return dict(poses=poses_d, points=points_d, chi2=chi2, outlier=outl, iters=stats[[0, 4]].astype(np.int32), stats=stats)

@@ -126,11 +126,11 @@ def _compare(got, want, w):
     rel = np.abs(got["stats"][[2, 3, 6, 7]] - want["stats"][[2, 3, 6, 7]]) / np.maximum(want["stats"][[2, 3, 6, 7]], 1.0)
     assert rel.max() <= TOL, rel
     dchi = np.abs(got["chi2"] - want["chi2"]) / np.maximum(1.0, want["chi2"])
-    assert dchi.max() <= 1e-4, dchi.max()        # residual chi2 per edge (computed from float32-rounded nothing: double state)
+    assert dchi.max() <= TOL, dchi.max()         # residual chi2 per edge within 1e-5 (north_star)
     # outlier flags may only differ on edges sitting numerically on the threshold
     diff = got["outlier"] != want["outlier"]
     th = np.where(w["edge_obs"][:, 2] < 0, 5.991, 7.815)
-    assert (np.abs(want["chi2"][diff] - th[diff]) < 1e-3).all()
+    assert (np.abs(want["chi2"][diff] - th[diff]) <= TOL * th[diff]).all()
 
 
 @pytest.mark.gpu
