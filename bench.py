@@ -4,17 +4,23 @@
 One "step" = one pass of the hot path over one batch of synthetic frames that are already
 resident in HBM: ORBextractor::operator() on every frame of the batch (8-level pyramid,
 FAST, quadtree, IC angle, blur, rBRIEF) followed by the brute-force Hamming
-ORBmatcher::SearchByBoW of every frame against its predecessor in the batch (one
+ORBmatcher::SearchByBoW of every frame against its successor in the batch (one
 vocabulary node = all features, i.e. N1 x N2 256-bit distances + ratio test + rotation
-histogram).  Workload = BASELINE.json configs[1]: 256 synthetic 640x480 frames, 1000
-features, 8 levels (TUM1.yaml parameters of the reference).
+histogram).  Default workload = BASELINE.json configs[1]: 256 synthetic 640x480 frames, 1000
+features, 8 levels (TUM1.yaml parameters of the reference).  `--workload sequence` =
+configs[3]: every rank owns ONE synthetic sequence of --seq-len (512) frames, resident as
+256-frame batches; a step is one pass over the whole sequence.  `--workload stereo` = configs[2]
+(KITTI-shaped 1241x376 stereo pairs, 2000 features, extract L+R + the L<->R Hamming match), and
+`--workload lba` = configs[4] (50-KF / 5000-point local BA window); those two print their own metric.
 
-Multi-GPU: one process per GPU (torchrun), each rank owns its own batch (independent
-frames, no data-path collective), weak scaling; RCCL is used only for the barrier, the MAX
-of the per-rank times and the all-gather of per-rank statistics.
+Multi-GPU: one process per GPU, each rank owns its own frames (seeds offset by rank<<32, no
+data-path collective), weak scaling; RCCL carries the barrier, the MAX of the per-rank times,
+one all-reduce that proves the rank count and ONE 24-byte all-gather of per-rank statistics.
+`python bench.py --gpus N` started WITHOUT a launcher spawns the N ranks itself (torch.distributed.run,
+127.0.0.1); started under torchrun (the driver's way) it checks WORLD_SIZE == N.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
-`cpu_baseline` objects.  The oracle (oracle/) is only used for the cpu_baseline leg.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (+ `roofline_valu`)
+and `cpu_baseline` objects.  The oracle (oracle/) is only used for the cpu_baseline leg.
 """
 import argparse
 import importlib
@@ -31,6 +37,9 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# VALU issue ceiling: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles per SIMD (integer / packed ops, measured with
+# tools/ubench_valu.hip: v_perm / v_pk_min / v_bcnt / v_dot4 / v_sad all issue at ~4 cycles), 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
 
 
 def level_pixels(W, H, nlevels=8, scale=1.2):
@@ -59,136 +68,164 @@ def algorithmic_bytes(W, H, K, nlevels=8):
 
 
 # stage of the HIP-event timing -> kernel name in the rocprofv3 summaries under profiles/
-STAGE_KERNEL = {"pyramid": "k_resize (7 launches)", "fast_cells": "k_fast_cells", "octree": "k_octree", "orient": "k_orient", "blur": "k_blur",
+STAGE_KERNEL = {"pyramid": "k_pyramid", "fast_cells": "k_fast_cells", "octree": "k_octree", "orient": "k_orient", "blur": "k_blur",
                 "describe": "k_describe", "match_distances": "k_bow_topk", "match_replay": "k_bow_greedy"}
 
 
-def pmc_traffic(stage, frames_per_launch):
-    """HBM bytes per launch of the stage's kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE,
-    separate rocprofv3 --pmc runs of this same command, tools/run_profiles.sh + tools/summarize_profile.py,
-    FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).  None when no pass is committed for
-    this launch size."""
-    p = ROOT / "profiles" / "latest_hbm_traffic.json"
+def _profile_json(name):
+    p = ROOT / "profiles" / name
     if not p.exists():
         return None
     try:
-        t = json.loads(p.read_text())
+        return json.loads(p.read_text())
     except ValueError:
         return None
-    if t.get("_frames_per_launch") != frames_per_launch:
+
+
+def pmc_traffic(stage, frames_per_launch):
+    """HBM bytes per launch of the stage's kernel(s) from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
+    runs of this same command, tools/run_profiles.sh + tools/summarize_profile.py; units and the gfx950 corrections as
+    profiles/README.md states them).  None when no pass is committed for this launch size."""
+    t = _profile_json("latest_hbm_traffic.json")
+    if not t or t.get("_frames_per_launch") != frames_per_launch:
         return None
-    name = STAGE_KERNEL.get(stage, "").split(" ")[0]
+    name = STAGE_KERNEL.get(stage, "")
+    tot, found = 0, False
     for k, v in t.items():
-        if isinstance(v, dict) and k.split("<")[0] == name:
-            return int(v["hbm_bytes_per_launch"] * (7 if stage == "pyramid" else 1))
-    return None
+        if isinstance(v, dict) and k.split("<")[0].split("(")[0] == name:
+            tot += int(v["hbm_bytes_per_launch"] * v.get("launches_per_batch", 1))
+            found = True
+    return tot if found else None
 
 
-def cpu_baseline(orbx, W, H, nf, seconds_budget=12.0):
-    """Reference ORBextractor (oracle/_ref = unmodified source + cvshim) + restated matcher on
-    the host cores of this box, one extractor instance per thread (instances are not
-    re-entrant, reference include/ORBextractor.h:161)."""
+def pmc_valu(stage, frames_per_launch):
+    """VALU wave-instructions per launch of the stage's kernel(s) (SQ_INSTS_VALU pass, profiles/latest_sq_counters.json)."""
+    t = _profile_json("latest_sq_counters.json")
+    if not t or t.get("_frames_per_launch") != frames_per_launch:
+        return None
+    name = STAGE_KERNEL.get(stage, "")
+    tot, found = 0, False
+    for k, v in t.items():
+        if isinstance(v, dict) and k.split("<")[0].split("(")[0] == name:
+            tot += int(v["valu_insts_per_launch"] * v.get("launches_per_batch", 1))
+            found = True
+    return tot if found else None
+
+
+def cpu_baseline(orbx, W, H, nf, seconds_budget=10.0):
+    """Reference ORBextractor (oracle/_ref = unmodified source + cvshim) + restated matcher on the host cores of this box:
+    (1) ONE thread = the reference's own monocular threading (src/Frame.cc:394), (2) one extractor instance per thread on all
+    cores (instances are not re-entrant, reference include/ORBextractor.h:161)."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib
     orc = oracle_lib.Oracle()
     kind = "reference" if orc.ref is not None else "port"
     ncores = os.cpu_count() or 1
     nthreads = min(ncores, 32)
-    per_thread = 6
-    frames = [orbx.synth_frame(9000 + i, W, H) for i in range(per_thread + 1)]
-    # calibrate on one frame so the sample stays within the budget
-    ext0 = orc.reference(nf) if orc.ref is not None else orc.restatement(nf)
+    mk = (lambda: orc.reference(nf)) if orc.ref is not None else (lambda: orc.restatement(nf))
+    # calibrate on one frame so that both samples stay within the budget
+    ext0 = mk()
+    f0 = orbx.synth_frame(9000, W, H)
     t0 = time.perf_counter()
-    ext0.extract(frames[0])
+    ext0.extract(f0)
     one = time.perf_counter() - t0
     per_thread = int(max(2, min(200, seconds_budget / max(one * 1.3, 1e-3))))
     frames = orbx.synth_sequence(9000, per_thread + 1, W, H)
-    done = [0] * nthreads
 
-    def work(t):
-        ext = orc.reference(nf) if orc.ref is not None else orc.restatement(nf)
-        prev = None
-        for i in range(per_thread + 1):
-            k, d = ext.extract(frames[i])
-            ks = np.zeros(len(k), orbx.KEYPOINT_DTYPE)
-            ks["angle"] = k[:, 3]
-            if prev is not None:
-                oracle_lib.search_by_bow(orc, 0, prev[0], prev[1], ks, d, 0.7, True)
-                done[t] += 1
-            prev = (ks, d)
+    def run(nthr, nfr):
+        done = [0] * nthr
 
-    th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
-    t0 = time.perf_counter()
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    dt = time.perf_counter() - t0
-    total = sum(done)
-    return {"value": round(total / dt, 2), "unit": "frames/s", "cores": nthreads, "kind": kind,
-            "sample": "%d threads x %d frames %dx%d/%d feat, extract (%s) + brute-force SearchByBoW (restated), %.1f s"
-                      % (nthreads, per_thread, W, H, nf, "oracle/_ref: unmodified reference ORBextractor.cc on cvshim" if kind == "reference" else "restatement", dt)}
+        def work(t):
+            ext = mk()
+            prev = None
+            for i in range(nfr + 1):
+                k, d = ext.extract(frames[i])
+                ks = np.zeros(len(k), orbx.KEYPOINT_DTYPE)
+                ks["angle"] = k[:, 3]
+                if prev is not None:
+                    oracle_lib.search_by_bow(orc, 0, prev[0], prev[1], ks, d, 0.7, True)
+                    done[t] += 1
+                prev = (ks, d)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(nthr)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t0
+        return sum(done) / dt, dt
+    single, dt1 = run(1, min(per_thread, max(2, int(4.0 / max(one * 1.3, 1e-3)))))
+    multi, dtn = run(nthreads, per_thread)
+    src = "oracle/_ref: unmodified reference ORBextractor.cc on cvshim" if kind == "reference" else "restatement"
+    return {"value": round(multi, 2), "unit": "frames/s", "cores": nthreads, "kind": kind,
+            "single_thread": {"value": round(single, 2), "cores": 1, "note": "the reference's own monocular threading (src/Frame.cc:394)", "seconds": round(dt1, 1)},
+            "sample": "%d threads x %d frames %dx%d/%d feat, extract (%s) + brute-force SearchByBoW (restated), %.1f s" % (nthreads, per_thread, W, H, nf, src, dtn),
+            "caveat": "cvshim's OpenCV primitives are scalar C++; a stock SIMD OpenCV build is faster, so this is a lower bound on stock ORB-SLAM2 CPU throughput"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
-    ap.add_argument("--split", action="store_true", help="cut every batch into --streams parts (one launch per part) instead of "
-                    "alternating whole batches over the handle pairs")
-    ap.add_argument("--streams", type=int, default=3, help="extractor/matcher handle pairs (HIP stream pairs) that take the batches in turn, so that "
-                    "the latency-bound stages of one batch overlap the VALU-bound stages of the others (3 measured best: 2 -> 180k, 3 -> 187k, 4 -> 174k)")
-    a = ap.parse_args()
+def measured_copy_bandwidth(torch, dev):
+    """Device-to-device copy of 1 GiB: (read + write bytes) / time = what this box's HBM delivers to a plain streaming kernel."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    del a, b
+    return 2 * n / (ms * 1e-3) / 1e9
 
-    import torch
-    assert torch.cuda.is_available(), "bench.py needs a GPU: liborbx has no CPU fallback"
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev_t = torch.device("cuda", local)
-    orbx = importlib.import_module("self_commit_orb-slam2_amd")
-    grp = orbx.distributed.Group(device=dev_t)       # nccl (= RCCL) when WORLD_SIZE > 1
+
+def resident_batches(orbx, torch, dev, ext, frames, B):
+    """Frames as device-resident batches in the extractor's input layout (row stride / frame pitch as orbx_upload_frames lays them out);
+    the memory is a torch tensor, shared read-only by every handle."""
+    _, stride, pitch, (_, W, H) = ext.upload(frames[:1])
+    out = []
+    for b in range(0, len(frames), B):
+        host = np.zeros((B, pitch), np.uint8)
+        for i, im in enumerate(frames[b:b + B]):
+            rows = host[i, :stride * H].reshape(H, stride)
+            rows[:, :W] = im
+        t = torch.from_numpy(host).to(dev)
+        out.append((t, (ctypes_ptr(t), stride, pitch, (B, W, H))))
+    return out
+
+
+def ctypes_ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
     rank, world = grp.rank, grp.world
-
     W, H, B, nf = a.width, a.height, a.batch, a.nfeatures
-    NS = max(1, min(a.streams, B))
-    if a.split:
-        while B % NS:
-            NS -= 1
-        Bs = B // NS                                # frames per launch: the batch is cut into NS parts, one per handle pair
-    else:
-        Bs = B                                      # every launch covers the whole batch; consecutive steps alternate handle pairs
-    exts = [orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=Bs, device=local) for _ in range(NS)]
-    mts = [None if a.no_match else orbx.ORBmatcher(0.7, True, max_features=exts[0].capacity, max_pairs=Bs, device=local) for _ in range(NS)]
-    ext, mt = exts[0], mts[0]
-    # independent frames per rank: seeds offset by rank<<32 (SURVEY 8d); every 16th frame low texture
-    # scenes of 16 views translating 3x1 px per view, so consecutive frames really match
-    frames = orbx.synth_sequence(grp.seed_base() + 1, B, W, H)
-    # inputs resident in HBM before the timed region (alternating handles each hold their own copy of the batch)
-    devs = [e.upload(frames[k * Bs:(k + 1) * Bs] if a.split else frames) for k, e in enumerate(exts)]
-    pa = np.arange(Bs, dtype=np.int32)              # frame i (as "KeyFrame") ...
-    pb = (np.arange(Bs, dtype=np.int32) + 1) % Bs   # ... against frame i+1 (as "Frame"), inside its launch
+    NS = max(1, a.streams)
+    nbatches = 1 if a.workload == "batch" else max(1, a.seq_len // B)
+    exts = [orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local) for _ in range(NS)]
+    mts = [None if a.no_match else orbx.ORBmatcher(0.7, True, max_features=exts[0].capacity, max_pairs=B, device=local) for _ in range(NS)]
+    mt = mts[0]
+    # independent frames per rank: seeds offset by rank<<32 (SURVEY 8d); scenes of 16 views translating 3x1 px per view, so
+    # consecutive frames really match; every 16th frame low texture
+    frames = orbx.synth_sequence(grp.seed_base() + 1, B * nbatches, W, H)
+    batches = resident_batches(orbx, torch, dev_t, exts[0], frames, B)     # inputs resident in HBM before the timed region
+    pa = np.arange(B, dtype=np.int32)              # frame i (as "KeyFrame") ...
+    pb = (np.arange(B, dtype=np.int32) + 1) % B    # ... against frame i+1 (as "Frame"), inside its launch
     issued = [0]
 
     def step():
-        # one pass of the hot path over one batch of B frames.  Nothing is synchronised between steps, so with
-        # two handle pairs (two HIP stream pairs) the kernels of consecutive batches overlap on the GPU.
-        if a.split:
-            todo = list(range(NS))
-        else:
-            todo = [issued[0] % NS]
+        # one pass of the hot path over the rank's frames.  Nothing is synchronised between launches: consecutive batches go to
+        # alternating handle pairs (HIP stream pairs), so their kernels overlap on the GPU.
+        for bi in range(nbatches):
+            k = issued[0] % NS
             issued[0] += 1
-        for k in todo:
-            exts[k].run_device(*devs[k])
-        for k in todo:
+            exts[k].run_device(*batches[bi][1])
             if mts[k] is not None:
-                fs = orbx.ORBmatcher.features_of(exts[k], Bs)     # results are double buffered: ask every step
+                fs = orbx.ORBmatcher.features_of(exts[k], B)     # results are double buffered: ask every step
                 mts[k].search_by_bow_device(fs, fs, pa, pb, mode=0, after=exts[k])
 
     def sync_all():
@@ -223,7 +260,7 @@ def main():
     grp.barrier()
     sync_all()
     elapsed = time.perf_counter() - t0
-    # per-launch kernel time of every stage: each part's launch covers Bs frames
+    # per-launch kernel time of every stage inside the overlapped pipeline: each launch covers B frames
     stage_ms, timed = {}, []
     for k, e in enumerate(exts):
         try:
@@ -237,57 +274,209 @@ def main():
                 stage_ms[kk] = stage_ms.get(kk, 0.0) + v
     stage_ms = {kk: v / max(1, len(timed)) for kk, v in stage_ms.items()}
     match_split = np.mean([mts[k].last_kernel_timing() for k in timed], axis=0) if (mt is not None and timed) else (0.0, 0.0)
-    # the same stages with nothing else on the GPU: one handle pair, synchronised after every call (outside the timed region)
-    alone_ms = {}
+    # the same stages with nothing else on the GPU: one handle pair, synchronised after every call (outside the timed region).
+    # This is what `rocprofv3 --kernel-trace --stats` of a --streams 1 run reports as the kernels' average durations.
+    alone_ms, alone_match = {}, (0.0, 0.0)
     if timed:
         k0 = timed[0]
         exts[k0].set_profiling(True)
+        if mts[k0] is not None:
+            mts[k0].sync()
+            try:
+                mts[k0].last_timing()
+            except orbx.OrbxError:
+                pass
         for _ in range(3):
-            exts[k0].run_device(*devs[k0])
+            exts[k0].run_device(*batches[0][1])
             exts[k0].sync()
+            if mts[k0] is not None:
+                fs = orbx.ORBmatcher.features_of(exts[k0], B)
+                mts[k0].search_by_bow_device(fs, fs, pa, pb, mode=0, after=exts[k0])
+                mts[k0].sync()
         alone_ms = dict(exts[k0].last_timing()[1])
+        if mts[k0] is not None:
+            mts[k0].last_timing()
+            alone_match = mts[k0].last_kernel_timing()
         exts[k0].set_profiling(False)
-    parts = range(NS) if a.split else range(1)            # alternating handles hold the same batch: count it once
-    counts = np.concatenate([exts[k].download(Bs)[2] for k in parts])
-    nm_mean = 0.0
-    if mt is not None:
-        nm_mean = float(np.mean([mts[k].download(Bs)[2].mean() for k in parts]))
-    t, frames_total, per_rank = grp.aggregate(elapsed, B * a.steps, int(counts.sum()))
+    last = (issued[0] - 1) % NS
+    counts = exts[last].download(B)[2]
+    status = [int(e.status()) for e in exts] if hasattr(exts[0], "status") else []
+    nm_mean = float(mts[last].download(B)[2].mean()) if mt is not None else 0.0
+    t, frames_total, per_rank = grp.aggregate(elapsed, B * nbatches * a.steps, int(counts.sum()) * nbatches * a.steps)
 
-    if rank == 0:
-        K = float(counts.mean())
-        alg = algorithmic_bytes(W, H, K)
-        if mt is not None:
-            stage_ms["match_distances"] = float(match_split[0])   # k_bow_order + k_bow_topk
-            stage_ms["match_replay"] = float(match_split[1])      # k_bow_greedy (sequential greedy assignment, latency bound)
-            alg["match_distances"] = alg.pop("match")
-            alg["match_replay"] = 8 * int(K)                      # reads the candidate lists' heads, writes one result per query
-        dom = max((k for k in stage_ms if alg.get(k, 0) > 0), key=lambda k: stage_ms[k])
-        bytes_per_launch = alg[dom] * Bs                      # one launch of a part covers Bs frames
-        achieved = bytes_per_launch / (stage_ms[dom] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, Bs),
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(stage_ms[dom], 4),
-                    "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-                    "frames_per_launch": Bs,
-                    # the same kernel when the other stream pairs are idle (3 synchronised calls after the timed region)
-                    "uncontended": ({"avg_launch_ms": round(alone_ms[dom], 4), "achieved": round(bytes_per_launch / (alone_ms[dom] * 1e-3) / 1e9, 2),
-                                     "frac": round(bytes_per_launch / (alone_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} if alone_ms.get(dom) else None),
-                    "uncontended_stage_ms": {k: round(v, 4) for k, v in alone_ms.items()},
-                    "whole_path_algorithmic_GBs": round(sum(alg.values()) * Bs / (sum(stage_ms.values()) * 1e-3) / 1e9, 2)}
-        out = {
-            "metric": "frames/s ORB extract+match (1000 feat, 640x480)" if not a.no_match else "frames/s ORB extract (1000 feat, 640x480)",
-            "value": round(frames_total / t, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic %dx%d frames per GPU, ORB extract (%d feat, 8 levels, FAST 20/7)%s"
-                                   % (B, W, H, nf, "" if a.no_match else " + brute-force Hamming SearchByBoW of consecutive frames"),
-                       "batch_per_gpu": B, "streams": NS, "width": W, "height": H, "nfeatures": nf, "parallelism": "frames sharded, %d rank(s)" % world,
-                       "keypoints_per_frame": round(K, 1), "matches_per_pair": round(nm_mean, 1)},
-            "roofline": roofline,
-        }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(orbx, W, H, nf)
+    if rank != 0:
+        return None
+    K = float(counts.mean())
+    alg = algorithmic_bytes(W, H, K)
+    if mt is not None:
+        stage_ms["match_distances"] = float(match_split[0])   # k_bow_order + k_bow_topk
+        stage_ms["match_replay"] = float(match_split[1])      # k_bow_greedy (sequential greedy assignment, latency bound)
+        alone_ms["match_distances"], alone_ms["match_replay"] = float(alone_match[0]), float(alone_match[1])
+        alg["match_distances"] = alg.pop("match")
+        alg["match_replay"] = 8 * int(K)                      # reads the candidate lists' heads, writes one result per query
+    else:
+        alg.pop("match")
+    # dominant kernel = the longest stage when nothing else runs (= rocprofv3's per-kernel average of a --streams 1 run; the contended
+    # event spans below additionally contain the time a launch waits behind the other stream pairs' workgroups)
+    ref_ms = alone_ms if alone_ms else stage_ms
+    dom = max((k for k in ref_ms if alg.get(k, 0) > 0), key=lambda k: ref_ms[k])
+    bytes_per_launch = alg[dom] * B
+    achieved = bytes_per_launch / (ref_ms[dom] * 1e-3) / 1e9
+    copy_bw = measured_copy_bandwidth(torch, dev_t)
+    whole_bytes = sum(alg.values()) * B * nbatches
+    whole_gbs = whole_bytes / (t / a.steps) / 1e9
+    roofline = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, B),
+                "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(ref_ms[dom], 4), "frames_per_launch": B,
+                "timing": "HIP events on the library's stream, launches synchronised (no other stream active)",
+                "contended": {"avg_launch_ms": round(stage_ms.get(dom, 0.0), 4),
+                              "achieved": round(bytes_per_launch / (max(stage_ms.get(dom, 0.0), 1e-9) * 1e-3) / 1e9, 2),
+                              "note": "event span of the same launch inside the %d-stream pipeline (includes queueing behind the other streams)" % NS},
+                "stage_ms_alone": {k: round(v, 4) for k, v in alone_ms.items()},
+                "stage_ms_contended": {k: round(v, 4) for k, v in stage_ms.items()},
+                "stage_frac_of_hbm_peak_alone": {k: round(alg[k] * B / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in alone_ms.items() if alg.get(k, 0) > 0 and v > 0},
+                "measured_copy_GBs": round(copy_bw, 1), "frac_of_measured_copy": round(achieved / copy_bw, 5),
+                "whole_path": {"algorithmic_bytes_per_frame": int(sum(alg.values())), "achieved": round(whole_gbs, 2), "frac": round(whole_gbs / HBM_PEAK_GBS, 5),
+                               "note": "all stages' algorithmic bytes / wall time per step (the driver-visible rate)"}}
+    # the bound the path actually runs into: VALU issue (integer byte arithmetic), from the committed SQ_INSTS_VALU pass
+    valu = {k: pmc_valu(k, B) for k in alg}
+    roofline_valu = None
+    if any(v for v in valu.values()):
+        tot = sum(v for v in valu.values() if v)
+        octree_valu = pmc_valu("octree", B) or 0
+        tot += octree_valu
+        rate = tot * nbatches / (t / a.steps) / 1e9
+        dv = valu.get(dom)
+        roofline_valu = {"bound": "valu_issue", "unit": "G wave-instr/s", "peak": round(VALU_PEAK_GINST, 1),
+                         "achieved": round(rate, 2), "frac": round(rate / VALU_PEAK_GINST, 4),
+                         "valu_insts_per_batch": int(tot), "source": "profiles/latest_sq_counters.json (SQ_INSTS_VALU pass of this command)",
+                         "dominant_kernel": ({"kernel": STAGE_KERNEL.get(dom, dom), "valu_insts_per_launch": int(dv),
+                                              "frac_alone": round(dv / (ref_ms[dom] * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)} if dv else None)}
+    metric = "frames/s ORB extract+match (1000 feat, 640x480)" if not a.no_match else "frames/s ORB extract (1000 feat, 640x480)"
+    wl = ("batch of %d synthetic %dx%d frames per GPU" % (B, W, H)) if a.workload == "batch" else \
+         ("one synthetic sequence of %d %dx%d frames per GPU (BASELINE config 4), resident as %d batches of %d" % (B * nbatches, W, H, nbatches, B))
+    out = {
+        "metric": metric, "value": round(frames_total / t, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": wl + ", ORB extract (%d feat, 8 levels, FAST 20/7)%s" % (nf, "" if a.no_match else " + brute-force Hamming SearchByBoW of consecutive frames"),
+                   "batch_per_gpu": B, "batches_per_step": nbatches, "streams": NS, "width": W, "height": H, "nfeatures": nf,
+                   "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
+                   "keypoints_per_frame": round(K, 1), "matches_per_pair": round(nm_mean, 1)},
+        "ranks": dict(rank_info, per_rank=[{"frames": r[0], "seconds": round(r[1], 6), "keypoints": r[2], "frames_per_s": round(r[0] / r[1], 1)} for r in per_rank]),
+        "roofline": roofline,
+    }
+    if roofline_valu:
+        out["roofline_valu"] = roofline_valu
+    if status:
+        out["config"]["device_status"] = status
+    return out
+
+
+def bench_stereo(a, orbx, torch, grp, dev_t, local, rank_info):
+    """BASELINE configs[2]: KITTI-shaped stereo pairs 1241x376, 2000 features: extract left + right, then the L<->R Hamming match of
+    Frame::ComputeStereoMatches (complete: row bands, SAD refinement, median cut) on the device."""
+    W, H, nf = 1241, 376, 2000
+    B = a.batch if a.batch != 256 else 64                  # pairs per batch
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B, device=local)   # KITTI00-02.yaml:41-50
+    mt = orbx.ORBmatcher(0.7, True, max_features=ext.capacity, max_pairs=B, device=local)
+    seeds = [grp.seed_base() + 100 + i for i in range(B)]
+    frames = [orbx.synth_frame(s, W, H) for s in seeds] + [orbx.synth_frame(s, W, H, orbx.SYNTH_STEREO_RIGHT) for s in seeds]
+    dev = resident_batches(orbx, torch, dev_t, ext, frames, 2 * B)[0]
+    fl, fr = np.arange(B, dtype=np.int32), np.arange(B, 2 * B, dtype=np.int32)
+    bf = 386.1448                                         # KITTI00-02.yaml:25
+
+    def step():
+        ext.run_device(*dev[1])                           # left and right images of the batch in one launch set
+        mt.compute_stereo_matches_device(ext, ext, fl, fr, bf, 0.0)
+
+    def sync_all():
+        ext.sync(); mt.sync(); torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        step()
+    sync_all(); grp.barrier(); sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync_all(); grp.barrier(); sync_all()
+    elapsed = time.perf_counter() - t0
+    u, z = mt.download_stereo(B)
+    cnt = ext.download(2 * B)[2]
+    t, total, per_rank = grp.aggregate(elapsed, B * a.steps, int(cnt.sum()))
+    if grp.rank != 0:
+        return None
+    return {"metric": "stereo pairs/s ORB extract L+R + ComputeStereoMatches (2000 feat, 1241x376)", "value": round(total / t, 1), "unit": "pairs/s",
+            "n_gpus": grp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: batch of %d KITTI-shaped stereo pairs, extract left + right (2000 feat) + L<->R match on the device" % B,
+                       "keypoints_per_image": round(float(cnt.mean()), 1), "stereo_matches_per_pair": round(float((u >= 0).sum(1).mean()), 1)},
+            "ranks": dict(rank_info, per_rank=[{"pairs": r[0], "seconds": round(r[1], 6)} for r in per_rank])}
+
+
+def bench_lba(a, orbx, torch, grp, dev_t, local, rank_info):
+    """BASELINE configs[4]: Optimizer::LocalBundleAdjustment on the synthetic 50-KF / 5000-point window (replicas only: a window does not shard)."""
+    w = orbx.lba_synth.make_window(K=50, P=5000, seed=12345 + grp.rank)
+    opt = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000, device=local)
+    for _ in range(a.warmup):
+        opt.LocalBundleAdjustment(w)
+    grp.barrier()
+    t0 = time.perf_counter()
+    kern = []
+    for _ in range(a.steps):
+        opt.LocalBundleAdjustment(w)
+        kern.append(opt.last_timing()[0])
+    grp.barrier()
+    elapsed = time.perf_counter() - t0
+    ms, flops = opt.last_timing()
+    t, total, per_rank = grp.aggregate(elapsed, a.steps, w["E"])
+    if grp.rank != 0:
+        return None
+    return {"metric": "local BA windows/s (50 KF / 5000 points)", "value": round(total / t, 2), "unit": "windows/s", "n_gpus": grp.world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "config": {"workload": "BASELINE config 5: LocalBundleAdjustment, %d keyframes, %d points, %d edges; replicas only" % (w["K"], w["P"], w["E"]),
+                                            "kernel_ms": round(float(np.mean(kern)), 4), "fp64_gflops": round(flops / (ms * 1e-3) / 1e9, 2) if ms > 0 else None},
+            "ranks": dict(rank_info, per_rank=[{"windows": r[0], "seconds": round(r[1], 6)} for r in per_rank])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--workload", choices=["batch", "sequence", "stereo", "lba"], default="batch",
+                    help="batch = BASELINE configs[1] (+ match; the metric); sequence = configs[3]; stereo = configs[2]; lba = configs[4]")
+    ap.add_argument("--seq-len", type=int, default=512, help="frames per sequence of --workload sequence")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
+    ap.add_argument("--streams", type=int, default=3, help="extractor/matcher handle pairs (HIP stream pairs) that take the batches in turn, so that "
+                    "the latency-bound stages of one batch overlap the VALU-bound stages of the others")
+    a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: spawn the N ranks exactly as the contract launches them, one per GPU, and pass the result through
+        dist_mod = importlib.import_module("self_commit_orb-slam2_amd.distributed")
+        r = dist_mod.launch(a.gpus, [str(Path(__file__).resolve())] + sys.argv[1:])
+        sys.exit(r.returncode)
+
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU: liborbx has no CPU fallback"
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert local < torch.cuda.device_count(), "rank %d has no GPU (%d visible)" % (local, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dev_t = torch.device("cuda", local)
+    orbx = importlib.import_module("self_commit_orb-slam2_amd")
+    grp = orbx.distributed.Group(device=dev_t)       # nccl (= RCCL) when WORLD_SIZE > 1
+    rank_info = grp.check(a.gpus)                    # WORLD_SIZE == --gpus, and an RCCL all-reduce of ones sees every rank
+
+    fn = {"batch": bench_extract_match, "sequence": bench_extract_match, "stereo": bench_stereo, "lba": bench_lba}[a.workload]
+    out = fn(a, orbx, torch, grp, dev_t, local, rank_info)
+    if grp.rank == 0:
+        if not a.no_cpu_baseline and grp.world == 1 and a.workload in ("batch", "sequence"):
+            out["cpu_baseline"] = cpu_baseline(orbx, a.width, a.height, a.nfeatures)
         print(json.dumps(out), flush=True)
     grp.close()
 

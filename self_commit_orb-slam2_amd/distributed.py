@@ -8,8 +8,33 @@ extracts and matches its own batch.  The only communication of a run is
 over `torch.distributed` - backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 import os
+import socket
+import subprocess
+import sys
 
 import torch
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(nproc, argv, env=None, timeout=None, capture=False):
+    """Spawn `nproc` ranks of `argv` (a script path + its arguments) on this node, exactly as the bench contract
+    launches them: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P <argv>.  Used by `python bench.py --gpus N` when it is started without a launcher, and by the
+    CPU (gloo) test of the same path.  Returns the CompletedProcess."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port())] + list(argv)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    e.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=e, timeout=timeout, stdout=subprocess.PIPE if capture else None, stderr=subprocess.PIPE if capture else None,
+                          text=True if capture else None)
 
 
 class Group:
@@ -30,6 +55,25 @@ class Group:
                 kw["device_id"] = self.device
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
+            self.backend = backend
+        else:
+            self.backend = None
+
+    def check(self, expected_world):
+        """The process group really has `expected_world` ranks: world size as launched, and an all-reduce of ones over the
+        backend (RCCL on GPUs) sums to it.  Returns {"backend", "world", "allreduce_ones"}; raises otherwise."""
+        if self.world != int(expected_world):
+            raise RuntimeError("launched with WORLD_SIZE=%d but %d ranks were asked for" % (self.world, int(expected_world)))
+        ones = self.world
+        if self.dist is not None:
+            if self.dist.get_world_size() != self.world:
+                raise RuntimeError("process group has %d ranks, expected %d" % (self.dist.get_world_size(), self.world))
+            t = torch.ones(1, dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(t)
+            ones = int(round(float(t.item())))
+            if ones != self.world:
+                raise RuntimeError("%s all-reduce saw %d ranks, expected %d" % (self.backend, ones, self.world))
+        return {"backend": self.backend or "none", "world": self.world, "allreduce_ones": ones}
 
     def seed_base(self):
         """Seeds of rank r start at r<<32: every rank renders different frames."""

@@ -57,6 +57,31 @@ def test_two_ranks_gloo():
     assert abs(outs[0]["total"] / outs[0]["t"] - 400.0) < 1e-9
 
 
+def test_two_ranks_through_the_bench_spawn_path(orbx):
+    """`python bench.py --gpus N` without a launcher calls distributed.launch (torch.distributed.run, 127.0.0.1, one rank per
+    GPU); the same call here with the gloo worker: both ranks come up, the rank count is checked by an all-reduce."""
+    import json
+    r = orbx.distributed.launch(2, [str(ROOT / "tests" / "dist_worker.py"), "2"], timeout=300, capture=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    outs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    assert [d["rank"] for d in outs] == [0, 1]
+    for d in outs:
+        assert d["info"] == {"backend": "gloo", "world": 2, "allreduce_ones": 2}
+        assert abs(d["t"] - 0.75) < 1e-12 and d["total"] == 300
+    assert outs[0]["checksum"] != outs[1]["checksum"]
+    # a rank count that does not match what was asked for is an error, not a silent n_gpus: 1
+    bad = orbx.distributed.launch(2, [str(ROOT / "tests" / "dist_worker.py"), "3"], timeout=300, capture=True)
+    assert bad.returncode != 0 and "ranks were asked for" in bad.stderr
+
+
+def test_bench_refuses_a_mismatched_world(orbx):
+    grp = orbx.distributed.Group()
+    import pytest
+    with pytest.raises(RuntimeError):
+        grp.check(8)
+    assert grp.check(1) == {"backend": "none", "world": 1, "allreduce_ones": 1}
+
+
 def test_single_rank_needs_no_process_group(orbx):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         os.environ.pop(k, None)
