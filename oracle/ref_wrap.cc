@@ -29,8 +29,13 @@ struct Arena {
 thread_local Arena g_arena = {nullptr, 0, 0, false};
 const size_t kArenaBytes = (size_t)1 << 31;   // 2 GiB of address space per thread, touched lazily
 
+// orbref_set_arena(0): leave the allocator alone (stock glibc malloc, what a real ORB-SLAM2 binary runs with) - used only to
+// MEASURE how far the allocator-dependent tie-break of src/ORBextractor.cc:948 moves the result (tests/test_tie_rule.py).
+bool g_use_arena = true;
+
 void arena_begin()
 {
+    if (!g_use_arena) { g_arena.active = false; return; }
     if (!g_arena.base) {
         g_arena.base = (char *)malloc(kArenaBytes);
         if (!g_arena.base) { fprintf(stderr, "orbref: arena malloc failed\n"); abort(); }
@@ -79,6 +84,8 @@ public:
 }  // namespace
 
 #define ORBREF_API extern "C" __attribute__((visibility("default")))
+
+ORBREF_API void orbref_set_arena(int on) { g_use_arena = on != 0; }
 
 ORBREF_API void *orbref_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
 {

@@ -412,14 +412,21 @@ __global__ __launch_bounds__(256) void k_schur_points(LbaDev d, const int *ptSta
 // triangle, k_chol_prep mirrors it).  Block row i1 of S belongs to keyframe i1: gridDim.y workgroups per keyframe
 // walk its edges (16 lanes per edge, one lane per second observation), accumulate the row in LDS with
 // ds_add_f64 and add it to S once - 6 x n global atomics per workgroup instead of 36 per observation pair.
+// GLOBAL = true: the block row does not fit into LDS (more than ~530 free keyframes, i.e. a global bundle adjustment of a large map):
+// the same walk with the FP64 atomics going straight to S / bs.
+template <bool GLOBAL>
 __global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart, const int *kfEdges, const int *ptStart, const int *ptEdges, int nP6,
                                                     const double *__restrict__ Ddb, double *S, double *bs)
 {
-    extern __shared__ __attribute__((aligned(16))) double row[];   // [6][nP6], then 6 entries of bs
+    extern __shared__ __attribute__((aligned(16))) double rowLds[];   // [6][nP6], then 6 entries of bs
     const int k = blockIdx.x, pi = d.poseIdx[k], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (pi < 0) return;
-    for (int i = tid; i < 6 * nP6 + 6; i += 256) row[i] = 0.0;
-    __syncthreads();
+    double *row = GLOBAL ? S + (size_t)(6 * pi) * nP6 : rowLds;      // GLOBAL: "row" is the block row of S itself
+    double *rowB = GLOBAL ? bs + 6 * pi : rowLds + 6 * nP6;
+    if (!GLOBAL) {
+        for (int i = tid; i < 6 * nP6 + 6; i += 256) rowLds[i] = 0.0;
+        __syncthreads();
+    }
     // a wave works on four edges of the keyframe at once: 16 lanes per edge, one lane per second observation of the
     // landmark (the index lookups are done once per pair, the 6x6 block comes out of 36 registers)
     const int sub = lane >> 4, a = lane & 15, stride = 16 * gridDim.y;
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart
         const int l = d.ep[e], s0 = ptStart[l], nE = ptStart[l + 1] - s0;
         if (a < 6) {   // bs[i1] -= B * (D^-1 b_l): 300 addresses for all edges of the window, so it goes through the LDS row as well
             const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL + 3 * a, *db = Ddb + (size_t)l * 3;
-            unsafeAtomicAdd(&row[6 * nP6 + a], -(B1[0] * db[0] + B1[1] * db[1] + B1[2] * db[2]));
+            unsafeAtomicAdd(&rowB[a], -(B1[0] * db[0] + B1[1] * db[1] + B1[2] * db[2]));
         }
         for (int a2 = a; a2 < nE; a2 += 16) {
             const int e2 = ptEdges[s0 + a2];
@@ -449,9 +456,10 @@ __global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart
             for (int r = 0; r < 6; r++)
 #pragma unroll
                 for (int c = 0; c < 6; c++)
-                    unsafeAtomicAdd(&dst[r * nP6 + c], -(BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]));   // ds_add_f64
+                    unsafeAtomicAdd(&dst[(size_t)r * nP6 + c], -(BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]));   // ds_add_f64
         }
     }
+    if (GLOBAL) return;
     __syncthreads();
     for (int i = tid; i < 6 * nP6; i += 256) {
         const int r = i / nP6, col = i - r * nP6;
@@ -461,7 +469,9 @@ __global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart
     if (tid < 6 && row[6 * nP6 + tid] != 0.0) unsafeAtomicAdd(&bs[6 * pi + tid], row[6 * nP6 + tid]);
 }
 
-#define CHOL_MAX_N 2048
+#define CHOL_MAX_N 128          /* k_chol_solve serves n < CHOL_MULTI_MIN_N only */
+#define CHOL_LDS_X 2048         /* k_chol_backsub keeps the solution vector in LDS up to this n, in global memory above */
+#define CHOL_DENSE_MAX_N 24576  /* 4096 free keyframes: S and L are n x n doubles each (4.8 GB at the limit), indices stay below 2^31 */
 // Dense Cholesky of the (upper-authoritative) symmetric S, then S x = bs.  One workgroup.
 // LinearSolverEigen::solve (solvers/linear_solver_eigen.h:94-125) uses a sparse LDLT; the
 // reduced system is SPD here (lambda > 0), a failed pivot reports ok = 0 like info()!=Success.
@@ -788,20 +798,29 @@ __global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ S, con
 }
 
 // L^T x = y, panels from the last to the first; x in LDS
-__global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict__ L, const double *__restrict__ ysol, int n, double *__restrict__ x)
+// XG = true (n > CHOL_LDS_X): the vector lives in x itself; one workgroup, so __syncthreads() orders the accesses, and they are made
+// at agent scope so that no wave reads a stale line of the per-CU vector cache.
+template <bool XG> struct XVec {
+    double *p;
+    __device__ double get(int i) const { return XG ? __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[i]; }
+    __device__ void set(int i, double v) const { if (XG) __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else p[i] = v; }
+};
+template <bool XG>
+__global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict__ L, const double *__restrict__ ysol, int n, double *x)
 {
-    __shared__ double sx[CHOL_MAX_N];
+    __shared__ double sxLds[XG ? 1 : CHOL_LDS_X];
     __shared__ double part[32][CNB + 1];
     __shared__ double l11[CNB][CNB + 1];
     const int tid = threadIdx.x, c = tid & 31, pt = tid >> 5;
-    for (int i = tid; i < n; i += 1024) sx[i] = ysol[i];
+    XVec<XG> sx = {XG ? x : sxLds};
+    for (int i = tid; i < n; i += 1024) sx.set(i, ysol[i]);
     __syncthreads();
     const int npan = (n + CNB - 1) / CNB;
     for (int pi = npan - 1; pi >= 0; pi--) {
         const int p0 = pi * CNB, nb = min(CNB, n - p0);
         double acc = 0;
         if (c < nb)
-            for (int r = p0 + nb + pt; r < n; r += 32) acc += L[(size_t)r * n + p0 + c] * sx[r];
+            for (int r = p0 + nb + pt; r < n; r += 32) acc += L[(size_t)r * n + p0 + c] * sx.get(r);
         part[pt][c] = acc;
         {
             const int r = tid >> 5, cc = tid & 31;
@@ -811,22 +830,22 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict_
         if (tid < nb) {
             double t = 0;
             for (int q = 0; q < 32; q++) t += part[q][tid];
-            sx[p0 + tid] -= t;
+            sx.set(p0 + tid, sx.get(p0 + tid) - t);
         }
         __syncthreads();
         if (tid < 64) {
             for (int cc = nb - 1; cc >= 0; cc--) {
-                const double xc = sx[p0 + cc] / l11[cc][cc];
+                const double xc = sx.get(p0 + cc) / l11[cc][cc];
                 __builtin_amdgcn_wave_barrier();
-                if (tid == 0) sx[p0 + cc] = xc;
-                if (tid < cc) sx[p0 + tid] -= l11[cc][tid] * xc;
+                if (tid == 0) sx.set(p0 + cc, xc);
+                if (tid < cc) sx.set(p0 + tid, sx.get(p0 + tid) - l11[cc][tid] * xc);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();
     }
-    for (int i = tid; i < n; i += 1024) x[i] = sx[i];
+    if (!XG) for (int i = tid; i < n; i += 1024) x[i] = sxLds[i];
 }
 
 // x_l = D^-1 (b_l - B^T x_p)   (block_solver.hpp:459-481)
@@ -1201,7 +1220,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     rc = rc ? rc : h->pose.ensure(K); rc = rc ? rc : h->poseBak.ensure(K); rc = rc ? rc : h->pt.ensure(3 * P); rc = rc ? rc : h->ptBak.ensure(3 * P);
     rc = rc ? rc : h->intr.ensure(5 * K); rc = rc ? rc : h->obs.ensure(3 * E); rc = rc ? rc : h->info.ensure(E); rc = rc ? rc : h->err.ensure(3 * E);
     rc = rc ? rc : h->rchi.ensure(E); rc = rc ? rc : h->edgeBlk.ensure(E * EB_SIZE); rc = rc ? rc : h->Hpp.ensure(36 * K); rc = rc ? rc : h->bp.ensure(n6);
-    rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->Ddb.ensure(3 * P); rc = rc ? rc : h->S.ensure(n6 * n6); rc = rc ? rc : h->Lmat.ensure(n6 * n6); rc = rc ? rc : h->ywork.ensure(n6); rc = rc ? rc : h->ysol.ensure(n6);
+    rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->Ddb.ensure(3 * P); rc = rc ? rc : h->ywork.ensure(n6); rc = rc ? rc : h->ysol.ensure(n6);
     rc = rc ? rc : h->bs.ensure(n6); rc = rc ? rc : h->xp.ensure(n6); rc = rc ? rc : h->xl.ensure(3 * P); rc = rc ? rc : h->red.ensure(16);
     rc = rc ? rc : h->ep.ensure(E); rc = rc ? rc : h->ek.ensure(E); rc = rc ? rc : h->ptStart.ensure(P + 1); rc = rc ? rc : h->ptEdges.ensure(E);
     rc = rc ? rc : h->kfStart.ensure(K + 1); rc = rc ? rc : h->kfEdges.ensure(E); rc = rc ? rc : h->poseIdx.ensure(K); rc = rc ? rc : h->ptIdx.ensure(P);
@@ -1281,8 +1300,14 @@ int optimize(Ctx &c, int iterations, double stats[4])
     for (int k = 0; k < K; k++) if (pAct[(size_t)k] && !c.fixed[(size_t)k]) poseIdx[(size_t)k] = nPose++;
     for (int l = 0; l < P; l++) if (lAct[(size_t)l]) ptIdx[(size_t)l] = nPt++;
     if (nAct == 0 || nPose + nPt == 0) return ORBX_OK;
-    if (6 * nPose > CHOL_MAX_N) { orbx_set_error("%d free keyframes exceed the dense solver limit %d", nPose, CHOL_MAX_N / 6); return ORBX_ERR_CAPACITY; }
+    if (6 * nPose > CHOL_DENSE_MAX_N) { orbx_set_error("%d free keyframes exceed the dense reduced-system limit %d", nPose, CHOL_DENSE_MAX_N / 6); return ORBX_ERR_CAPACITY; }
     c.nPose = nPose; c.nPt = nPt;
+    {   // the reduced system and its factor are sized by the FREE keyframes of this call (grow-only), checked before anything is allocated
+        const size_t nn = (size_t)(6 * nPose) * (size_t)(6 * nPose);
+        int rc = h->S.ensure(nn ? nn : 1);
+        rc = rc ? rc : h->Lmat.ensure(nn ? nn : 1);
+        if (rc) return rc;
+    }
     ORBX_HIP_CHECK(hipMemcpyAsync(h->active.p, active.data(), (size_t)E, hipMemcpyHostToDevice, h->stream));
     ORBX_HIP_CHECK(hipMemcpyAsync(h->poseIdx.p, poseIdx.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, h->stream));
     ORBX_HIP_CHECK(hipMemcpyAsync(h->ptIdx.p, ptIdx.data(), (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1327,9 +1352,12 @@ int optimize(Ctx &c, int iterations, double stats[4])
             LCHECK();
             if (nP6 > 0) {
                 const size_t ldsRows = (size_t)(6 * nP6 + 6) * sizeof(double);
-                if (ldsRows > 150 * 1024) { orbx_set_error("%d free keyframes exceed the Schur row tile (max %d)", nPose, (int)(150 * 1024 / 288)); return ORBX_ERR_CAPACITY; }
-                if (ldsRows > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
-                hipLaunchKernelGGL(k_schur_rows, dim3((unsigned)K, 16u), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, h->bs.p);
+                if (ldsRows > 150 * 1024) {      // > ~530 free keyframes: the block row no longer fits into LDS
+                    hipLaunchKernelGGL(k_schur_rows<true>, dim3((unsigned)K, 16u), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, h->bs.p);
+                } else {
+                    if (ldsRows > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
+                    hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, 16u), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, h->bs.p);
+                }
                 LCHECK();
             }
             if (nP6 > 0) {
@@ -1345,7 +1373,8 @@ int optimize(Ctx &c, int iterations, double stats[4])
                             hipLaunchKernelGGL(k_chol_update, dim3(T, T), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0);
                         }
                     }
-                    hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
+                    if (n <= CHOL_LDS_X) hipLaunchKernelGGL(k_chol_backsub<false>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
+                    else hipLaunchKernelGGL(k_chol_backsub<true>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
                 } else {   // widest panel whose n x NB doubles fit next to the solution vector in LDS
                     const size_t budget = 120 * 1024;
                     if ((size_t)nP6 * 32 * 8 <= budget) {

@@ -44,13 +44,17 @@ struct VocAccess : public ORBVocabulary {
     }
 };
 
+// One device vocabulary per ORBVocabulary object.  An orbx_vocabulary handle is NOT re-entrant (its scratch / result buffers are
+// member state, like every orbx handle: "one call at a time per handle", include/orbx.h), but Tracking (Frame::ComputeBoW) and
+// LocalMapping / LoopClosing (KeyFrame::ComputeBoW) share the vocabulary: `call` serialises the orbx_bow_transform calls on it.
+struct DeviceVoc { orbx_vocabulary *h; std::mutex call; DeviceVoc() : h(0) {} };
 std::mutex gVocMutex;
-std::map<const ORBVocabulary *, orbx_vocabulary *> gVocs;
+std::map<const ORBVocabulary *, DeviceVoc *> gVocs;
 
-orbx_vocabulary *DeviceVocabulary(const ORBVocabulary *voc)
+DeviceVoc *DeviceVocabulary(const ORBVocabulary *voc)
 {
     std::unique_lock<std::mutex> lock(gVocMutex);
-    std::map<const ORBVocabulary *, orbx_vocabulary *>::iterator it = gVocs.find(voc);
+    std::map<const ORBVocabulary *, DeviceVoc *>::iterator it = gVocs.find(voc);
     if (it != gVocs.end()) return it->second;
     std::vector<int32_t> parent;
     std::vector<uint8_t> leaf, desc;
@@ -60,8 +64,10 @@ orbx_vocabulary *DeviceVocabulary(const ORBVocabulary *voc)
     orbx_vocabulary *dv = 0;
     if (orbx_vocabulary_create(0, voc->getBranchingFactor(), voc->getDepthLevels(), n, &parent[0], &leaf[0], &desc[0], &weight[0], &dv) != ORBX_OK)
         throw std::runtime_error(std::string("ComputeBoW (orbx): ") + orbx_last_error());
-    gVocs[voc] = dv;
-    return dv;
+    DeviceVoc *d = new DeviceVoc();
+    d->h = dv;
+    gVocs[voc] = d;
+    return d;
 }
 
 // TemplatedVocabulary::transform(features, v, fv, levelsup), :1127-1196, with the per-feature
@@ -77,8 +83,12 @@ void Transform(const ORBVocabulary *voc, const cv::Mat &descriptors, DBoW2::BowV
     std::vector<double> weight((size_t)(n > 0 ? n : 1));
     std::vector<unsigned char> flat((size_t)(n > 0 ? n : 1) * 32);
     for (int i = 0; i < n; i++) memcpy(&flat[32 * (size_t)i], descriptors.ptr<unsigned char>(i), 32);
-    if (orbx_bow_transform(DeviceVocabulary(voc), &flat[0], n, levelsup, &word[0], &node[0], &weight[0]) != ORBX_OK)
-        throw std::runtime_error(std::string("ComputeBoW (orbx): ") + orbx_last_error());
+    {
+        DeviceVoc *dv = DeviceVocabulary(voc);
+        std::unique_lock<std::mutex> call(dv->call);      // the whole call: upload, descent, download into OUR vectors
+        if (orbx_bow_transform(dv->h, &flat[0], n, levelsup, &word[0], &node[0], &weight[0]) != ORBX_OK)
+            throw std::runtime_error(std::string("ComputeBoW (orbx): ") + orbx_last_error());
+    }
     DBoW2::LNorm norm;
     const bool must = VocAccess::Scoring(*voc)->mustNormalize(norm);
     const DBoW2::WeightingType wt = voc->getWeightingType();

@@ -10,6 +10,7 @@
 // Schur complement, outlier re-classification) is one orbx_lba_solve / orbx_pose_optimization call on
 // flat arrays.  Precision at the boundary is float32 like the reference's cv::Mat (src/Converter.cc).
 #include <algorithm>
+#include <iostream>
 #include <list>
 #include <map>
 #include <stdexcept>
@@ -46,6 +47,10 @@ struct ThreadPoseOpt {
 thread_local ThreadPoseOpt tPose;
 
 void Fail(const char *what) { throw std::runtime_error(std::string("Optimizer::") + what + " (orbx): " + orbx_last_error()); }
+// BundleAdjustment runs on a detached std::thread of LoopClosing (RunGlobalBundleAdjustment): an exception leaving it would end
+// the process in std::terminate.  A failed call reports and leaves the map exactly as it was (what a g2o run that made no
+// progress does as well).
+bool Report(const char *what) { std::cerr << "Optimizer::" << what << " (orbx): " << orbx_last_error() << " - map left unchanged" << std::endl; return false; }
 
 cv::Mat PoseMat(const float *p16)
 {
@@ -120,8 +125,10 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
         for (std::map<KeyFrame *, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); mit++) {
             KeyFrame *pKFi = mit->first;
             if (pKFi->isBad()) continue;                                                        // :783
+            const std::map<KeyFrame *, int>::const_iterator kit = kfIndex.find(pKFi);
+            if (kit == kfIndex.end()) continue;   // an observer that became visible after the window was collected (the reference would dereference a missing vertex)
             const cv::KeyPoint &kpUn = pKFi->mvKeysUn[mit->second];
-            ep.push_back((int32_t)l); ek.push_back(kfIndex[pKFi]);
+            ep.push_back((int32_t)l); ek.push_back(kit->second);
             obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(pKFi->mvuRight[mit->second]);   // < 0: monocular edge (:788)
             invS2.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);
             edgeOwner.push_back(std::make_pair(pKFi, mps[l]));
@@ -226,16 +233,17 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame *> &vpKFs, const std
     if (!tLba.h || K > tLba.kf || P > tLba.pt || E > tLba.ed) {
         if (tLba.h) { orbx_lba_destroy(tLba.h); tLba.h = 0; }
         tLba.kf = std::max(2 * K, 64); tLba.pt = std::max(2 * P, 4096); tLba.ed = std::max(2 * E, 65536);
-        if (orbx_lba_create(0, tLba.kf, tLba.pt, tLba.ed, &tLba.h) != ORBX_OK) Fail("BundleAdjustment");
+        if (orbx_lba_create(0, tLba.kf, tLba.pt, tLba.ed, &tLba.h) != ORBX_OK) { Report("BundleAdjustment"); return; }
     }
     orbx_lba_problem prob = {K, &poses[0], &fixed[0], &intr[0], P, &points[0], E, &ep[0], &ek[0], &obs[0], &invS2[0]};
     std::vector<float> posesOut(poses.size()), pointsOut(points.size());
     std::vector<uint8_t> outlier((size_t)E);
     orbx_lba_result res = {&posesOut[0], &pointsOut[0], NULL, &outlier[0], {0}};
-    if (orbx_bundle_adjustment(tLba.h, &prob, nIterations, bRobust ? 1 : 0, (const volatile uint8_t *)pbStopFlag, &res) != ORBX_OK) Fail("BundleAdjustment");
-    // ---- write-back (:252-302)
+    if (orbx_bundle_adjustment(tLba.h, &prob, nIterations, bRobust ? 1 : 0, (const volatile uint8_t *)pbStopFlag, &res) != ORBX_OK) { Report("BundleAdjustment"); return; }
+    // ---- write-back (:252-302); the bad flags are re-read here as the reference does (:258, :280): LocalMapping culls concurrently
     for (size_t k = 0; k < kfs.size(); k++) {
         KeyFrame *pKF = kfs[k];
+        if (pKF->isBad()) continue;
         if (nLoopKF == 0) pKF->SetPose(PoseMat(&posesOut[16 * k]));
         else {
             pKF->mTcwGBA.create(4, 4, CV_32F);
@@ -245,6 +253,7 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame *> &vpKFs, const std
     }
     for (size_t l = 0; l < mps.size(); l++) {
         MapPoint *pMP = mps[l];
+        if (pMP->isBad()) continue;
         cv::Mat X(3, 1, CV_32F);
         for (int i = 0; i < 3; i++) X.at<float>(i) = pointsOut[3 * l + i];
         if (nLoopKF == 0) {

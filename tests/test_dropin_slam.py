@@ -126,6 +126,42 @@ def test_compute_bow_dropin_equals_reference(orbx, tmp_path, which):
 
 
 @pytest.mark.gpu
+def test_compute_bow_two_threads_share_one_vocabulary(orbx, tmp_path):
+    """Tracking (Frame::ComputeBoW) and LocalMapping (KeyFrame::ComputeBoW) share the ORBVocabulary, hence the one device
+    vocabulary handle, which is not re-entrant: two threads hammering it with different feature counts must each get the
+    reference's result (shim/BoW_hip.cc serialises the orbx_bow_transform calls per vocabulary)."""
+    import threading
+    from test_bow_transform import _descs
+    orbx.load_library()
+    hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
+    voc = orbx.voc_synth.make_vocabulary(10, 5, 33)
+    path = tmp_path / "voc.txt"
+    orbx.voc_synth.write_text(voc, path)
+    vr, vh = oracle_lib.RefVocabulary(path, lib=ref), oracle_lib.RefVocabulary(path, lib=hip)
+    sets = [_descs(orbx, voc, n, 40 + i) for i, n in enumerate((2000, 300, 1500, 37))]
+    want = [[vr.compute_bow(d, which) for d in sets] for which in (0, 1)]
+    errors = []
+
+    def work(which):
+        try:
+            for rep in range(25):
+                for i, d in enumerate(sets):
+                    got = vh.compute_bow(d, which)
+                    w = want[which][i]
+                    if not ((got["fv_node"] == w["fv_node"]).all() and (got["bow_ids"] == w["bow_ids"]).all()
+                            and (got["bow_vals"].view(np.uint64) == w["bow_vals"].view(np.uint64)).all()):
+                        errors.append((which, rep, i))
+        except Exception as e:                      # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=work, args=(w,)) for w in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:5]
+
+
+@pytest.mark.gpu
 def test_search_by_projection_dropin_equals_reference(orbx):
     """ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) with the HIP body vs the
     reference body, both on a real Frame and real MapPoints."""

@@ -177,3 +177,17 @@ def test_bundle_adjustment_hip_matches_oracle(orbx, oracle, cfg, iters, robust):
     got = opt.BundleAdjustment(w, iters, robust)
     _compare(got, want, w)
     opt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,iters", [(360, 3), (560, 2)])
+def test_bundle_adjustment_beyond_the_lds_limits(orbx, oracle, K, iters):
+    """GlobalBundleAdjustemnt of a larger map: more than 341 free keyframes (the back-substitution vector leaves LDS) and more than
+    530 (the Schur block rows are accumulated in HBM).  The reference (g2o sparse) has no such limits; neither may the drop-in."""
+    w = orbx.lba_synth.make_window(K=K, P=4000, seed=77, n_fixed=1, max_obs=12)
+    assert (w["fixed"] == 0).sum() > (341 if K == 360 else 530)
+    want = oracle_lib.bundle_adjustment(oracle, w, iters, True)
+    opt = orbx.Optimizer(max_keyframes=K, max_points=4096, max_edges=w["E"] + 1)
+    got = opt.BundleAdjustment(w, iters, True)
+    _compare(got, want, w)
+    opt.close()
