@@ -132,6 +132,15 @@ int orbx_upload_frames(orbx_extractor *h, const uint8_t *const *images, int batc
                        int height, int stride, const void **images_dev, int *dev_stride,
                        size_t *dev_frame_pitch);
 int orbx_extractor_sync(orbx_extractor *h);
+/* Capacity status of the last batch WITHOUT downloading it (a device-resident pipeline never calls orbx_batch_download, which is
+ * where a host consumer learns about an overflow): waits for the stream, *bits = OR over the frames of
+ *   1 = more than 32768 FAST candidates in one pyramid level, 2 = quadtree node list, 4 = level keypoint buffer (internal sizes).
+ * 0 = every frame is complete.  The reference has no such limits (std::vector grows): a set bit means the results of that batch
+ * are NOT the reference's.  orbx_batch_status_device: the same words on the device, status_dev[f] per frame and
+ * status_dev[batch] for the whole batch.  Matcher / frame calls that are chained behind an extractor (`after` argument) pick
+ * the batch word up on the device, and their own download calls return ORBX_ERR_CAPACITY when it is set. */
+int orbx_extractor_status(orbx_extractor *h, int32_t *bits);
+int orbx_batch_status_device(orbx_extractor *h, const int32_t **status_dev, int *batch);
 
 /* std::vector<cv::Mat> mvImagePyramid (ORBextractor.h:161, read by
  * Frame::ComputeStereoMatches, src/Frame.cc:1044,1248,1272,1281): size and bytes of

@@ -77,6 +77,8 @@ def load_library():
     L.orbx_batch_download.argtypes = [vp, ci, vp, vp, ci, vp]
     L.orbx_upload_frames.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp]
     L.orbx_extractor_sync.argtypes = [vp]
+    L.orbx_extractor_status.argtypes = [vp, vp]
+    L.orbx_batch_status_device.argtypes = [vp, vp, vp]
     L.orbx_pyramid_level_size.argtypes = [vp, ci, ci, ci, vp, vp]
     L.orbx_download_pyramid.argtypes = [vp, ci, ci, ci, vp, ci]
     L.orbx_debug_download_scores.argtypes = [vp, ci, ci, vp, ci]
@@ -231,6 +233,12 @@ class ORBextractor:
         cap = ctypes.c_int()
         _check(self._L.orbx_batch_results_device(self._h, ctypes.byref(k), ctypes.byref(d), ctypes.byref(c), ctypes.byref(cap)))
         return k, d, c, cap.value
+
+    def status(self):
+        """Capacity bits of the last batch (0 = complete), without downloading it: orbx_extractor_status."""
+        bits = ctypes.c_int32()
+        _check(self._L.orbx_extractor_status(self._h, ctypes.byref(bits)))
+        return bits.value
 
     def set_debug_taps(self, on):
         _check(self._L.orbx_extractor_set_debug_taps(self._h, 1 if on else 0))

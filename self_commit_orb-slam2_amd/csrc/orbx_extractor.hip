@@ -331,7 +331,7 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
             if ((rc = h->outDesc[b].ensure(B * g.outCap * 32)) != ORBX_OK) return rc;
             if ((rc = h->outCnt[b].ensure(B)) != ORBX_OK) return rc;
         }
-        if ((rc = h->status.ensure(B)) != ORBX_OK) return rc;
+        if ((rc = h->status.ensure(B + 1)) != ORBX_OK) return rc;   // per frame + one word for the whole batch
         // the score map is only written inside the detectable window; clear it once so the
         // parity taps (orbx_debug_download_scores) see zeros elsewhere
         if (h->debugTaps) ORBX_HIP_CHECK(hipMemsetAsync(h->score.p, 0, B * g.pyrBytes, h->stream));
@@ -358,7 +358,7 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     const bool prof = h->profiling;
     hipEvent_t *ev = h->ev[h->profCount % ORBX_PROF_RING];
     if (h->pyrConsumerEv) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->pyrConsumerEv, 0)); h->pyrConsumerEv = nullptr; }
-    ORBX_HIP_CHECK(hipMemsetAsync(h->status.p, 0, (size_t)batch * sizeof(int), h->stream));
+    ORBX_HIP_CHECK(hipMemsetAsync(h->status.p, 0, (size_t)(batch + 1) * sizeof(int), h->stream));
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[0], h->stream));
     for (int l = 1; l < h->geom.nlevels; l++)
         if ((rc = orbx_launch_resize(L, l)) != ORBX_OK) return rc;
@@ -554,6 +554,30 @@ extern "C" int orbx_batch_results_device(orbx_extractor *h, const orbx_keypoint 
     if (capacity) *capacity = h->geom.outCap;
     return ORBX_OK;
 }
+
+extern "C" int orbx_extractor_status(orbx_extractor *h, int32_t *bits)
+{
+    if (!h || !bits) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    int v = 0;
+    ORBX_HIP_CHECK(hipMemcpy(&v, h->status.p + h->lastBatch, sizeof(int), hipMemcpyDeviceToHost));
+    *bits = v;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_batch_status_device(orbx_extractor *h, const int32_t **status_dev, int *batch)
+{
+    if (!h || !status_dev) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
+    *status_dev = h->status.p;
+    if (batch) *batch = h->lastBatch;
+    return ORBX_OK;
+}
+
+/* device word of the last batch (status[lastBatch]) for consumers ordered behind this handle's stream */
+const int *orbx_extractor_status_word_internal(orbx_extractor *h) { return h && h->lastBatch ? h->status.p + h->lastBatch : nullptr; }
 
 extern "C" int orbx_extractor_sync(orbx_extractor *h)
 {

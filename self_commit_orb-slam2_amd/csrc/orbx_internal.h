@@ -105,6 +105,8 @@ hipStream_t orbx_extractor_stream_internal(orbx_extractor *h);
 /* `ev` (recorded by a consumer on its own stream) guards the result buffer of the LAST batch: the
  * extractor waits for it before that buffer is overwritten two batches later */
 void orbx_extractor_set_consumer_event_internal(orbx_extractor *h, hipEvent_t ev);
+/* device word holding the OR of the capacity bits of the producer's last batch (nullptr before the first batch) */
+const int *orbx_extractor_status_word_internal(orbx_extractor *h);
 
 
 /* Grow-only device array owned by a handle (hipMalloc on demand, never shrinks, released by the handle's destroy). */

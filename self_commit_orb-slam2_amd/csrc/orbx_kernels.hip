@@ -435,7 +435,8 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
     uint32_t *P[2];
     P[0] = ptBuf + ((size_t)f * g->nlevels + l) * 2 * ORBX_PT_CAP;
     P[1] = P[0] + ORBX_PT_CAP;
-    int *stat = status + f;
+    int *stat = status + f;          // per-frame word; status[gridDim.y] collects the whole batch (device-visible for resident consumers)
+    int *statAll = status + gridDim.y;
 
     // ---- gather the level's candidates in vToDistributeKeys order (cells row-major) ----
     const int ncell = lv.nCols * lv.nRows;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
     for (int i = tid; i < ncell; i += 256) cellOff[i] = cc[i];
     __syncthreads();
     int M = block_exscan(cellOff, ncell, wsum32);
-    if (M > ORBX_PT_CAP) { if (tid == 0) atomicOr(stat, ORBX_DEV_ERR_PTCAP); M = ORBX_PT_CAP; }
+    if (M > ORBX_PT_CAP) { if (tid == 0) { atomicOr(stat, ORBX_DEV_ERR_PTCAP); atomicOr(statAll, ORBX_DEV_ERR_PTCAP); } M = ORBX_PT_CAP; }
     {
         const uint32_t *slots = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase;
         // one wave per cell keeps the copy coalesced
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
         __syncthreads();
         const int nUnsel = block_exscan(nodeFlag, nn, wsum32);
         const int newN = totalCreated + nUnsel;
-        if (newN > NODECAP) { if (tid == 0) atomicOr(stat, ORBX_DEV_ERR_NODECAP); break; }
+        if (newN > NODECAP) { if (tid == 0) { atomicOr(stat, ORBX_DEV_ERR_NODECAP); atomicOr(statAll, ORBX_DEV_ERR_NODECAP); } break; }
         if (tid == 0) sh_misc[2] = 0;
         __syncthreads();
         // S7: write the new list
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
     {
         const OtNode *L = nodes[cur];
         OrbxLevelKp *out = lvlKp + (size_t)f * g->kpPerFrame + lv.kpBase;
-        if (nn > lv.kpCap) { if (tid == 0) atomicOr(stat, ORBX_DEV_ERR_KPCAP); nn = lv.kpCap; }
+        if (nn > lv.kpCap) { if (tid == 0) { atomicOr(stat, ORBX_DEV_ERR_KPCAP); atomicOr(statAll, ORBX_DEV_ERR_KPCAP); } nn = lv.kpCap; }
         for (int i = tid; i < nn; i += 256) {
             const OtNode nd = L[i];
             const uint32_t *src = P[(unsigned)nd.start >> 31] + (nd.start & 0x7fffffff);

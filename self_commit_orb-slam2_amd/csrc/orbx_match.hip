@@ -693,7 +693,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     m->pairsA.release(); m->pairsB.release(); m->order.release(); m->matches.release(); m->dists.release(); m->nmatches.release();
     m->hostStage.release(); m->projDec.release(); m->projQueue.release();
     m->topk.release(); m->scales.release(); m->uright.release(); m->depth.release(); m->sad.release();
-    m->topk64.release(); m->pkp.release();
+    m->topk64.release(); m->pkp.release(); m->producerStatus.release();
     for (int q = 0; q < 2; q++) { m->pf[q].release(); m->pb[q].release(); m->pi32[q].release(); }
     if (m->evDep2) (void)hipEventDestroy(m->evDep2);
     for (int i = 0; i < 2; i++) if (m->evPyr[i]) (void)hipEventDestroy(m->evPyr[i]);
@@ -706,7 +706,37 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     delete m;
 }
 
+// a consumer chained behind an extractor inherits its capacity word on the device (no host round trip); the consumer's download reports it
+__global__ void k_status_or(int *dst, const int *src) { if (*src) atomicOr(dst, *src); }
+
 namespace orbx_match {
+
+int inherit_status(orbx_matcher *m, orbx_extractor *after)
+{
+    if (!after) return ORBX_OK;
+    const int *w = orbx_extractor_status_word_internal(after);
+    if (!w) return ORBX_OK;
+    if (!m->producerStatus.p) {
+        int rc = m->producerStatus.ensure(1);
+        if (rc != ORBX_OK) return rc;
+        ORBX_HIP_CHECK(hipMemsetAsync(m->producerStatus.p, 0, sizeof(int), m->stream));
+    }
+    hipLaunchKernelGGL(k_status_or, dim3(1), dim3(1), 0, m->stream, m->producerStatus.p, w);
+    return ORBX_OK;
+}
+
+// checked by the download entry points (the stream has been synchronised): clears the word
+int check_producer_status(orbx_matcher *m)
+{
+    if (!m->producerStatus.p) return ORBX_OK;
+    int v = 0;
+    ORBX_HIP_CHECK(hipMemcpy(&v, m->producerStatus.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (!v) return ORBX_OK;
+    ORBX_HIP_CHECK(hipMemset(m->producerStatus.p, 0, sizeof(int)));
+    orbx_set_error("the extractor batch these results were computed from overflowed a device capacity (bits 0x%x: 1 = >%d FAST candidates in a level, "
+                   "2 = quadtree node list, 4 = level keypoints): results are not the reference's", v, 32768);
+    return ORBX_ERR_CAPACITY;
+}
 
 int prep_pairs(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b, const int32_t *pa, const int32_t *pb, int npairs,
                       orbx_extractor *after)
@@ -724,6 +754,8 @@ int prep_pairs(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_se
     if (after) {
         ORBX_HIP_CHECK(hipEventRecord(m->evDep, orbx_extractor_stream_internal(after)));
         ORBX_HIP_CHECK(hipStreamWaitEvent(m->stream, m->evDep, 0));
+        int rcs = inherit_status(m, after);
+        if (rcs != ORBX_OK) return rcs;
     }
     ORBX_HIP_CHECK(hipMemcpyAsync(m->pairsA.p, pa, (size_t)npairs * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
     ORBX_HIP_CHECK(hipMemcpyAsync(m->pairsB.p, pb, (size_t)npairs * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
@@ -831,6 +863,7 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher *m, orbx_extracto
     if (right != left) {
         ORBX_HIP_CHECK(hipEventRecord(m->evDep2, orbx_extractor_stream_internal(right)));
         ORBX_HIP_CHECK(hipStreamWaitEvent(m->stream, m->evDep2, 0));
+        if ((rc = inherit_status(m, right)) != ORBX_OK) return rc;
     }
     const int stride = m->maxFeatures, nl = vl.nlevels;
     ORBX_HIP_CHECK(hipMemcpyAsync(m->scales.p, vl.scale, (size_t)nl * sizeof(float), hipMemcpyHostToDevice, m->stream));
@@ -874,6 +907,7 @@ extern "C" int orbx_stereo_download(orbx_matcher *m, int npairs, float *uright, 
     if (stride < 1 || stride > m->lastStride) { orbx_set_error("bad stride"); return ORBX_ERR_ARG; }
     ORBX_HIP_CHECK(hipSetDevice(m->device));
     ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    { int rcs = orbx_match::check_producer_status(m); if (rcs != ORBX_OK) return rcs; }
     if (uright) ORBX_HIP_CHECK(hipMemcpy2D(uright, (size_t)stride * 4, m->uright.p, (size_t)m->lastStride * 4, (size_t)stride * 4, (size_t)npairs, hipMemcpyDeviceToHost));
     if (depth) ORBX_HIP_CHECK(hipMemcpy2D(depth, (size_t)stride * 4, m->depth.p, (size_t)m->lastStride * 4, (size_t)stride * 4, (size_t)npairs, hipMemcpyDeviceToHost));
     return ORBX_OK;
@@ -905,6 +939,7 @@ extern "C" int orbx_matcher_download(orbx_matcher *m, int npairs, int32_t *match
     if (stride < 1 || stride > m->lastStride) { orbx_set_error("bad stride"); return ORBX_ERR_ARG; }
     ORBX_HIP_CHECK(hipSetDevice(m->device));
     ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    { int rcs = orbx_match::check_producer_status(m); if (rcs != ORBX_OK) return rcs; }
     if (matches) ORBX_HIP_CHECK(hipMemcpy2D(matches, (size_t)stride * 4, m->matches.p, (size_t)m->lastStride * 4, (size_t)stride * 4, (size_t)npairs, hipMemcpyDeviceToHost));
     if (dists) ORBX_HIP_CHECK(hipMemcpy2D(dists, (size_t)stride * 4, m->dists.p, (size_t)m->lastStride * 4, (size_t)stride * 4, (size_t)npairs, hipMemcpyDeviceToHost));
     if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, (size_t)npairs * 4, hipMemcpyDeviceToHost));

@@ -82,6 +82,7 @@ struct orbx_matcher {
     OrbxDevBuf<uint8_t> frInView;
     size_t frCount = 0;
     int lastPairs = 0, lastStride = 0;
+    OrbxDevBuf<int> producerStatus;   // OR of the capacity words of the extractors this handle's calls were chained behind
 };
 
 #define MLAUNCH_CHECK()                                                                                              \
@@ -94,6 +95,8 @@ struct orbx_matcher {
 namespace orbx_match {
 int prep_pairs(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b, const int32_t *pa, const int32_t *pb, int npairs, orbx_extractor *after);
 int chain_back(orbx_matcher *m, orbx_extractor *after);
+int inherit_status(orbx_matcher *m, orbx_extractor *after);
+int check_producer_status(orbx_matcher *m);
 FeatDev to_dev(const orbx_feature_set *s);
 /* stage one frame of host features into the matcher's staging buffers (side 0 / 1) */
 int stage_host(orbx_matcher *m, int side, const orbx_feature_set *h, orbx_feature_set *d);
