@@ -146,6 +146,9 @@ int orbx_batch_status_device(orbx_extractor *h, const int32_t **status_dev, int 
  * Frame::ComputeStereoMatches, src/Frame.cc:1044,1248,1272,1281): size and bytes of
  * pyramid level `level` of frame `frame` of the last call.  blurred=1 returns the
  * Gaussian-blurred copy the descriptors were sampled from (src/ORBextractor.cc:1626-1634). */
+/* Every level of frame `frame` of the last call in one device->host transfer: dst[l] receives level l (rows dst_strides[l] bytes
+ * apart), l = 0..nlevels-1.  This is what refills the public mvImagePyramid member in shim/ORBextractor.cc. */
+int orbx_download_pyramid_all(orbx_extractor *h, int frame, uint8_t *const *dst, const int *dst_strides, int nlevels);
 int orbx_pyramid_level_size(const orbx_extractor *h, int width, int height, int level, int *w, int *hgt);
 int orbx_download_pyramid(orbx_extractor *h, int frame, int level, int blurred, uint8_t *dst, int dst_stride);
 

@@ -100,6 +100,8 @@ struct orbx_extractor {
     size_t hostStagingBytes = 0;
     int stagingStride = 0;
     size_t stagingFramePitch = 0;
+    uint8_t *hostOut = nullptr;       // pinned: results / pyramid on their way to the caller's arrays
+    size_t hostOutBytes = 0;
 };
 
 namespace {
@@ -489,6 +491,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->geomDev.release(); h->binDev.release(); h->rsDev.release(); h->pyr.release(); h->blur.release();
     if (h->hostStaging) { (void)hipHostFree(h->hostStaging); h->hostStaging = nullptr; h->hostStagingBytes = 0; }
+    if (h->hostOut) { (void)hipHostFree(h->hostOut); h->hostOut = nullptr; h->hostOutBytes = 0; }
     h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release();
     for (int b = 0; b < 2; b++) { h->outDesc[b].release(); h->outCnt[b].release(); h->outKp[b].release(); }
     h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->lvlKp.release();
@@ -587,30 +590,42 @@ extern "C" int orbx_extractor_sync(orbx_extractor *h)
     return ORBX_OK;
 }
 
+static int ensure_host_out(orbx_extractor *h, size_t bytes)
+{
+    if (bytes <= h->hostOutBytes) return ORBX_OK;
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->hostOut) (void)hipHostFree(h->hostOut);
+    h->hostOut = nullptr; h->hostOutBytes = 0;
+    ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostOut, bytes, hipHostMallocDefault));
+    h->hostOutBytes = bytes;
+    return ORBX_OK;
+}
+
 extern "C" int orbx_batch_download(orbx_extractor *h, int batch, orbx_keypoint *keypoints, uint8_t *descriptors, int capacity, int *counts)
 {
     if (!h || !counts) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     if (batch <= 0 || batch > h->lastBatch) { orbx_set_error("batch %d not available (last run had %d frames)", batch, h->lastBatch); return ORBX_ERR_STATE; }
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
-    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-    int rc = check_status(h, batch);
-    if (rc != ORBX_OK) return rc;
-    // the result arrays come back whole through the pinned buffer (three copies without a bounce buffer instead of two
-    // pageable copies per frame) and are handed out from there
+    // Counts, status words and the result arrays come back whole through ONE pinned buffer, enqueued behind the kernels and
+    // followed by ONE synchronisation (a single-frame call is latency bound: every extra sync / blocking copy costs 10-20 us).
     const int cap = h->geom.outCap;
-    const size_t B = (size_t)batch, offKp = align_up(B * sizeof(int), 256), offDesc = offKp + align_up(B * cap * sizeof(orbx_keypoint), 256),
-                 bytes = offDesc + B * cap * 32;
-    if (bytes > h->hostStagingBytes) {
-        if (h->hostStaging) (void)hipHostFree(h->hostStaging);
-        h->hostStaging = nullptr; h->hostStagingBytes = 0;
-        ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostStaging, bytes, hipHostMallocDefault));
-        h->hostStagingBytes = bytes;
-    }
-    uint8_t *hp = h->hostStaging;
+    const size_t B = (size_t)batch, offSt = align_up(B * sizeof(int), 256), offKp = offSt + align_up((B + 1) * sizeof(int), 256),
+                 offDesc = offKp + align_up(B * cap * sizeof(orbx_keypoint), 256), bytes = offDesc + B * cap * 32;
+    int rc = ensure_host_out(h, bytes);
+    if (rc != ORBX_OK) return rc;
+    uint8_t *hp = h->hostOut;
     ORBX_HIP_CHECK(hipMemcpyAsync(hp, h->outCnt[h->cur].p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(hp + offSt, h->status.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (keypoints) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offKp, h->outKp[h->cur].p, B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->stream));
     if (descriptors) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offDesc, h->outDesc[h->cur].p, B * cap * 32, hipMemcpyDeviceToHost, h->stream));
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    const int *st = (const int *)(hp + offSt);
+    for (int f = 0; f < batch; f++)
+        if (st[f]) {
+            orbx_set_error("frame %d: device capacity error bits 0x%x (1: >%d FAST candidates in a level, 2: quadtree node list, 4: level keypoints)", f, st[f],
+                           ORBX_PT_CAP);
+            return ORBX_ERR_CAPACITY;
+        }
     memcpy(counts, hp, B * sizeof(int));
     for (int f = 0; f < batch; f++) {
         const int n = counts[f];
@@ -618,6 +633,31 @@ extern "C" int orbx_batch_download(orbx_extractor *h, int batch, orbx_keypoint *
         if (n == 0) continue;
         if (keypoints) memcpy(keypoints + (size_t)f * capacity, hp + offKp + (size_t)f * cap * sizeof(orbx_keypoint), (size_t)n * sizeof(orbx_keypoint));
         if (descriptors) memcpy(descriptors + (size_t)f * capacity * 32, hp + offDesc + (size_t)f * cap * 32, (size_t)n * 32);
+    }
+    return ORBX_OK;
+}
+
+// All pyramid levels of one frame of the last call in ONE device->host copy (levels 1.. are contiguous in the handle's pyramid
+// buffer; level 0 is the input image) through pinned memory: what shim/ORBextractor.cc needs to refill the public mvImagePyramid
+// (eight pageable hipMemcpy2D calls cost ~9 ms per frame, this one ~0.1 ms).
+extern "C" int orbx_download_pyramid_all(orbx_extractor *h, int frame, uint8_t *const *dst, const int *dst_strides, int nlevels)
+{
+    if (!h || !dst || !dst_strides) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!h->lastBatch || frame < 0 || frame >= h->lastBatch || nlevels != h->geom.nlevels) { orbx_set_error("frame / level count not available"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    const OrbxGeom &g = h->geom;
+    const size_t img0Bytes = (size_t)h->lastStride * (size_t)(g.lv[0].h - 1) + (size_t)g.lv[0].w, off0 = align_up(g.pyrBytes, 256);
+    int rc = ensure_host_out(h, off0 + img0Bytes);
+    if (rc != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->hostOut, h->pyr.p + (size_t)frame * g.pyrBytes, g.pyrBytes, hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->hostOut + off0, h->lastImg0 + (size_t)frame * h->lastFramePitch, img0Bytes, hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < nlevels; l++) {
+        const OrbxLevel &lv = g.lv[l];
+        if (!dst[l] || dst_strides[l] < lv.w) { orbx_set_error("bad destination for level %d", l); return ORBX_ERR_ARG; }
+        const uint8_t *src = l == 0 ? h->hostOut + off0 : h->hostOut + lv.off;
+        const size_t pitch = l == 0 ? (size_t)h->lastStride : (size_t)lv.pitch;
+        for (int y = 0; y < lv.h; y++) memcpy(dst[l] + (size_t)y * dst_strides[l], src + (size_t)y * pitch, (size_t)lv.w);
     }
     return ORBX_OK;
 }

@@ -23,8 +23,8 @@ static void Fail(const char *what)
 }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
-    : mbKeepHostPyramid(true), nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST),
-      minThFAST(_minThFAST), mpHandle(0), mMaxW(0), mMaxH(0)
+    : mbKeepHostPyramid(false), nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST),
+      minThFAST(_minThFAST), mpHandle(0), mMaxW(0), mMaxH(0), mLastW(0), mLastH(0)
 {
     mvImagePyramid.resize(nlevels);
     // The tables come from the library so that getters and kernels can never disagree.
@@ -74,23 +74,34 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     else {
         _descriptors.create(n, 32, CV_8U);
         cv::Mat d = _descriptors.getMat();
-        for (int i = 0; i < n; i++) memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
+        if (d.isContinuous()) memcpy(d.data, &desc[0], (size_t)n * 32);
+        else for (int i = 0; i < n; i++) memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
     }
-    _keypoints.clear();
-    _keypoints.reserve(n);
+    _keypoints.resize((size_t)n);
     for (int i = 0; i < n; i++) {
         const orbx_keypoint &k = kps[(size_t)i];
-        _keypoints.push_back(cv::KeyPoint(k.x, k.y, k.size, k.angle, k.response, k.octave, k.class_id));
+        cv::KeyPoint &o = _keypoints[(size_t)i];
+        o.pt.x = k.x; o.pt.y = k.y; o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.class_id;
     }
-    if (mbKeepHostPyramid) {
-        for (int level = 0; level < nlevels; ++level) {
-            int w = 0, h = 0;
-            orbx_pyramid_level_size(mpHandle, image.cols, image.rows, level, &w, &h);
-            mvImagePyramid[level].create(h, w, CV_8UC1);
-            cv::Mat &m = mvImagePyramid[level];
-            if (orbx_download_pyramid(mpHandle, 0, level, 0, m.data, (int)m.step) != ORBX_OK) Fail("pyramid");
-        }
+    mLastW = image.cols; mLastH = image.rows;
+    if (mbKeepHostPyramid) DownloadImagePyramid();
+}
+
+// mvImagePyramid of the last frame, on demand: the pyramid stays on the device (where shim/Frame_hip.cc's ComputeStereoMatches reads
+// it) until the next operator() call.
+void ORBextractor::DownloadImagePyramid()
+{
+    if (!mpHandle || mLastW <= 0) return;
+    std::vector<unsigned char *> ptr((size_t)nlevels);
+    std::vector<int> step((size_t)nlevels);
+    for (int level = 0; level < nlevels; ++level) {
+        int w = 0, h = 0;
+        orbx_pyramid_level_size(mpHandle, mLastW, mLastH, level, &w, &h);
+        mvImagePyramid[level].create(h, w, CV_8UC1);
+        ptr[(size_t)level] = mvImagePyramid[level].data;
+        step[(size_t)level] = (int)mvImagePyramid[level].step;
     }
+    if (orbx_download_pyramid_all(mpHandle, 0, &ptr[0], &step[0], nlevels) != ORBX_OK) Fail("pyramid");
 }
 
 } // namespace ORB_SLAM2

@@ -36,11 +36,13 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // Host copy of the image pyramid of the last frame (read by Frame::ComputeStereoMatches).
-    // Set mbKeepHostPyramid = false to skip the device->host copy when nobody reads it
-    // (monocular / RGB-D tracking).
+    // Host copy of the image pyramid of the last frame.  The reference's only reader is Frame::ComputeStereoMatches
+    // (src/Frame.cc:1044,1248); with shim/Frame_hip.cc linked that function reads the DEVICE pyramid, so the copy is off by
+    // default.  A build that keeps the reference's own ComputeStereoMatches sets mbKeepHostPyramid = true (every call then ends
+    // with one ~1 MB device->host transfer), anything else that wants the images calls DownloadImagePyramid() when it does.
     std::vector<cv::Mat> mvImagePyramid;
     bool mbKeepHostPyramid;
+    void DownloadImagePyramid();
 
     // Device used by extractors constructed afterwards (default 0).
     static void SetDevice(int device);
@@ -61,7 +63,7 @@ private:
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
     std::vector<int> mnFeaturesPerLevel;
     orbx_extractor *mpHandle;
-    int mMaxW, mMaxH;
+    int mMaxW, mMaxH, mLastW, mLastH;
 };
 
 } // namespace ORB_SLAM2

@@ -32,6 +32,7 @@ extern "C" int shim_extract(void *h, const unsigned char *img, int w, int hgt, i
 extern "C" int shim_pyramid_level(void *h, int level, unsigned char *dst, int *w, int *hgt)
 {
     ORB_SLAM2::ORBextractor *e = (ORB_SLAM2::ORBextractor *)h;
+    if (level == 0) e->DownloadImagePyramid();      // on demand (the copy is off by default)
     const cv::Mat &m = e->mvImagePyramid[level];
     *w = m.cols; *hgt = m.rows;
     for (int y = 0; y < m.rows; y++) memcpy(dst + (size_t)y * m.cols, m.ptr(y), (size_t)m.cols);
@@ -39,3 +40,53 @@ extern "C" int shim_pyramid_level(void *h, int level, unsigned char *dst, int *w
 }
 
 extern "C" int shim_levels(void *h) { return ((ORB_SLAM2::ORBextractor *)h)->GetLevels(); }
+
+// Latency of the reference's call shape, one frame per call on one thread (tools/latency_shim.py): mean / median microseconds of
+// `iters` calls of (*extractor)(im, cv::Mat(), keys, desc) cycling through `nimg` images; keep_pyr sets mbKeepHostPyramid.
+#include <algorithm>
+#include <chrono>
+extern "C" int shim_bench(void *h, const unsigned char *const *imgs, int nimg, int w, int hgt, int stride, int iters, int keep_pyr, double *mean_us,
+                          double *median_us, int *nkeys)
+{
+    ORB_SLAM2::ORBextractor *e = (ORB_SLAM2::ORBextractor *)h;
+    e->mbKeepHostPyramid = keep_pyr != 0;
+    std::vector<cv::KeyPoint> keys;
+    cv::Mat d;
+    std::vector<double> t((size_t)iters);
+    for (int i = -5; i < iters; i++) {
+        cv::Mat im(hgt, w, CV_8UC1, (void *)imgs[(i + 5) % nimg], (size_t)stride);
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        (*e)(im, cv::Mat(), keys, d);
+        const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
+        if (i >= 0) t[(size_t)i] = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    }
+    double s = 0;
+    for (int i = 0; i < iters; i++) s += t[(size_t)i];
+    std::sort(t.begin(), t.end());
+    *mean_us = s / iters; *median_us = t[(size_t)iters / 2]; *nkeys = (int)keys.size();
+    return 0;
+}
+
+// The multi-handle recipe: `nthreads` threads, each with its OWN ORBextractor (instances are not re-entrant - the reference's are not
+// either, include/ORBextractor.h:161: the stereo Frame constructor runs two on two threads, src/Frame.cc:159-167), each calling
+// operator() `iters` times back to back.  Returns the aggregate frames/s.
+#include <thread>
+extern "C" double shim_bench_threads(int nthreads, int nf, const unsigned char *const *imgs, int nimg, int w, int hgt, int stride, int iters)
+{
+    std::vector<ORB_SLAM2::ORBextractor *> ex;
+    for (int t = 0; t < nthreads; t++) ex.push_back(new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7));
+    auto work = [&](int t, int n) {
+        std::vector<cv::KeyPoint> keys;
+        cv::Mat d;
+        for (int i = 0; i < n; i++) {
+            cv::Mat im(hgt, w, CV_8UC1, (void *)imgs[(i + t) % nimg], (size_t)stride);
+            (*ex[(size_t)t])(im, cv::Mat(), keys, d);
+        }
+    };
+    { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, 10); for (auto &x : th) x.join(); }   // warm-up
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, iters); for (auto &x : th) x.join(); }
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t t = 0; t < ex.size(); t++) delete ex[t];
+    return (double)nthreads * iters / s;
+}

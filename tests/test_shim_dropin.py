@@ -20,7 +20,7 @@ def build_shim():
         return
     if shutil.which("g++") is None:
         pytest.skip("no g++ to build the shim test wrapper")
-    subprocess.run(["g++", "-std=gnu++11", "-O2", "-fPIC", "-shared", "-I" + str(ROOT / "oracle" / "cvshim"),
+    subprocess.run(["g++", "-std=gnu++11", "-O2", "-fPIC", "-shared", "-pthread", "-I" + str(ROOT / "oracle" / "cvshim"),
                     "-I" + str(ROOT / "self_commit_orb-slam2_amd" / "shim"), "-I" + str(ROOT / "include"), "-o", str(SO)] +
                    [str(s) for s in srcs] + ["-L" + str(ROOT / "self_commit_orb-slam2_amd" / "lib"), "-lorbx",
                                              "-Wl,-rpath," + str(ROOT / "self_commit_orb-slam2_amd" / "lib")], check=True)
