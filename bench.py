@@ -68,7 +68,7 @@ def algorithmic_bytes(W, H, K, nlevels=8):
 
 
 # stage of the HIP-event timing -> kernel name in the rocprofv3 summaries under profiles/
-STAGE_KERNEL = {"pyramid": "k_pyramid", "fast_cells": "k_fast_cells", "octree": "k_octree", "orient": "k_orient", "blur": "k_blur",
+STAGE_KERNEL = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "octree": "k_octree", "orient": "k_orient", "blur": "k_blur",
                 "describe": "k_describe", "match_distances": "k_bow_topk", "match_replay": "k_bow_greedy"}
 
 

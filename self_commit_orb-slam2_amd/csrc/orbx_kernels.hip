@@ -68,15 +68,34 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
 // pair, selector from the table) + ONE v_dot2_u32_u16 against (a0, a1); the vertical blend keeps
 // OpenCV's two truncating >>16 terms.  Thread = 4 dst columns x 8 dst rows, 16 independent 8-byte
 // loads in flight.
+// ---------------------------------------------------------------------------------------------
+// XCD-aware block mapping.  The dispatcher places linear block b on XCD b % 8 (observed, MI355X guide; a pure speed assumption,
+// never a correctness one), and every XCD has its own 4 MiB L2.  With the natural (item, frame) order, horizontally adjacent
+// tiles / cells of an image - which share the 128-byte lines that their 80-byte window rows straddle, and their halos - run on
+// eight different XCDs, each of which fetches the shared lines from the fabric again (rocprofv3 FETCH_SIZE: 4.4x the level
+// pixels for k_blur, 4.7x for k_fast_cells, 5.2x for k_describe's gathers).  This bijection hands every XCD one CONTIGUOUS range
+// of the (frame, item) space instead, so neighbours meet in one L2 and a frame's images are fetched by one XCD.
+//   linear = by * gx + bx;  XCD x owns [x*q + min(x, r), ...) with q = total / 8, r = total % 8;  slot = linear / 8.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void xcd_remap(int gx, int total, int linear, int &bx, int &by)
+{
+    const int xcd = linear & 7, slot = linear >> 3, q = total >> 3, r = total & 7;
+    const int t = xcd * q + min(xcd, r) + slot;
+    by = t / gx;
+    bx = t - by * gx;
+}
+#define XCD_REMAP_XY(BX, BY) int BX, BY; xcd_remap((int)gridDim.x, (int)(gridDim.x * gridDim.y), (int)(blockIdx.y * gridDim.x + blockIdx.x), BX, BY)
+
 template <bool PADDED>   // source rows readable 11 bytes past the last pixel: every thread takes the aligned path
 __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, int level, const uint8_t *__restrict__ img0, int img0Stride,
                                                 size_t img0FramePitch, uint8_t *__restrict__ pyr, const uint32_t *__restrict__ rsTab)
 {
     const OrbxLevel &lv = g->lv[level];
-    const int f = blockIdx.z;
+    int bx, f;
+    xcd_remap((int)gridDim.x, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x + blockIdx.x), bx, f);
     // flat item = (row group, column group of 4 px): no lane idles on a ragged right edge
     const int G = (lv.w + 3) >> 2, RG = (lv.h + RS_ROWS - 1) / RS_ROWS;
-    const int item = blockIdx.x * 256 + threadIdx.x;
+    const int item = bx * 256 + threadIdx.x;
     if (item >= G * RG) return;
     const int rg = item / G, cg = item - rg * G;
     const int dx0 = cg * 4, dyBase = rg * RS_ROWS;
@@ -203,18 +222,19 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
     uint8_t *inT = lds;                                   // (ah+6) x P: input window, tile (0,0) = pixel (x0-3, y0-3)
     uint8_t *scT = lds + g->fcInBytes;                    // (ah+2) x P: scores, area pixel (c, r) at byte (r+1)*P + c+4
     unsigned short *cand = (unsigned short *)(scT + g->fcScBytes);
-    const int f = blockIdx.y, lane = threadIdx.x;
+    XCD_REMAP_XY(bx, f);
+    const int lane = threadIdx.x;
     int bases[ORBX_MAX_LEVELS];
     const int nl = g->nlevels;
     for (int i = 0; i < nl; i++) bases[i] = g->lv[i].cellBase;
-    const int l = find_level(bases, nl, blockIdx.x);
+    const int l = find_level(bases, nl, bx);
     const OrbxLevel &lv = g->lv[l];
-    const int cell = blockIdx.x - lv.cellBase;
+    const int cell = bx - lv.cellBase;
     const int cj = cell % lv.nCols, ci = cell / lv.nCols;
     const int maxBX = lv.w - ORBX_BORDER, maxBY = lv.h - ORBX_BORDER;
     const int iniX = ORBX_BORDER + cj * lv.wCell, iniY = ORBX_BORDER + ci * lv.hCell;
     const int maxX = min(iniX + lv.wCell + 6, maxBX), maxY = min(iniY + lv.hCell + 6, maxBY);
-    int *cnt = cellCount + (size_t)f * g->cellsPerFrame + blockIdx.x;
+    int *cnt = cellCount + (size_t)f * g->cellsPerFrame + bx;
     const int x0 = iniX + 3, x1 = maxX - 3, y0 = iniY + 3, y1 = maxY - 3;
     const int aw = x1 - x0, ah = y1 - y0;
     if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || aw <= 0 || ah <= 0) {   // skipped / degenerate cell (:1101, :1112)
@@ -750,8 +770,9 @@ __global__ __launch_bounds__(256) void k_orient(const OrbxGeom *__restrict__ g, 
 {
     // half a wave per keypoint: lane r of the half owns disc row v = r-15 and reads its 31 bytes
     // as 8 unaligned dwords (x-15 .. x+16 stays inside the level: 19 <= x < w-19)
-    const int f = blockIdx.y, lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
-    const int slot = blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half;   // index into the frame's level-keypoint array
+    XCD_REMAP_XY(bx, f);
+    const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
+    const int slot = bx * 8 + (threadIdx.x >> 6) * 2 + half;   // index into the frame's level-keypoint array
     bool live = slot < g->kpPerFrame;
     int l = 0;
     for (int i = 1; i < g->nlevels; i++) if (live && slot >= g->lv[i].kpBase) l = i;
@@ -831,13 +852,14 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
                                              const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur)
 {
     __shared__ __attribute__((aligned(16))) uint32_t in[BT_IH * (BT_P / 4)];
-    const int f = blockIdx.y, lane = threadIdx.x;
+    XCD_REMAP_XY(bx, f);
+    const int lane = threadIdx.x;
     int bases[ORBX_MAX_LEVELS];
     const int nl = g->nlevels;
     for (int i = 0; i < nl; i++) bases[i] = g->lv[i].blurTileBase;
-    const int l = find_level(bases, nl, blockIdx.x);
+    const int l = find_level(bases, nl, bx);
     const OrbxLevel &lv = g->lv[l];
-    const int t = blockIdx.x - lv.blurTileBase;
+    const int t = bx - lv.blurTileBase;
     const int X0 = (t % lv.blurTilesX) * BT_W, Y0 = (t / lv.blurTilesX) * BT_H;
     const int w = lv.w, h = lv.h;
     int pitch;
@@ -925,11 +947,12 @@ __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g
                                                   const int *__restrict__ lvlCnt, orbx_keypoint *__restrict__ outKp, uint8_t *__restrict__ outDesc,
                                                   int *__restrict__ outCnt)
 {
-    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    XCD_REMAP_XY(bx, f);
+    const int lane = threadIdx.x & 63;
     // the wave number is uniform: told to the compiler, the level lookup, the counts and the keypoint record become scalar work
-    const int slot = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int slot = bx * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int *cnts = lvlCnt + f * g->nlevels;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bx == 0 && threadIdx.x == 0) {
         int tot = 0;
         for (int i = 0; i < g->nlevels; i++) tot += cnts[i];
         outCnt[f] = tot;
