@@ -351,6 +351,38 @@ __global__ __launch_bounds__(1024) void k_scale(const double *x, const double *b
     if (threadIdx.x == 0) out[0] = s[0];
 }
 
+// The three reductions an LM trial ends with, in ONE launch and with the summation orders of k_reduce / k_scale (so the values are
+// the same bits): out[0] = sum rchi (activeRobustChi2), out[4] = sum xp (lambda xp + bp), out[5] = sum xl (lambda xl + bl).
+__global__ __launch_bounds__(1024) void k_trial_reduce(const double *rchi, int E, const double *xp, const double *bp, int nP6, const double *xl, const double *bl,
+                                                       int nL3, double lambda, double *out)
+{
+    __shared__ double s0[1024], s1[1024], s2[1024];
+    double a = 0, b = 0, c = 0;
+    for (int i = threadIdx.x; i < E; i += 1024) a += rchi[i];
+    for (int i = threadIdx.x; i < nP6; i += 1024) b += xp[i] * (lambda * xp[i] + bp[i]);
+    for (int i = threadIdx.x; i < nL3; i += 1024) c += xl[i] * (lambda * xl[i] + bl[i]);
+    s0[threadIdx.x] = a; s1[threadIdx.x] = b; s2[threadIdx.x] = c;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { s0[threadIdx.x] += s0[threadIdx.x + k]; s1[threadIdx.x] += s1[threadIdx.x + k]; s2[threadIdx.x] += s2[threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = s0[0]; out[4] = s1[0]; out[5] = s2[0]; }
+}
+
+// computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180): out[2] = max |diagonal entry| over the pose and landmark blocks
+__global__ __launch_bounds__(1024) void k_diag_max(const double *Hpp, int nPose, const double *Hll, int nPt, double *out)
+{
+    __shared__ double m[1024];
+    double b = 0;
+    for (int i = threadIdx.x; i < 6 * nPose; i += 1024) b = fmax(b, fabs(Hpp[(size_t)(i / 6) * 36 + 7 * (i % 6)]));
+    for (int i = threadIdx.x; i < 3 * nPt; i += 1024) b = fmax(b, fabs(Hll[(size_t)(i / 3) * 9 + 4 * (i % 3)]));
+    m[threadIdx.x] = b;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) { if ((int)threadIdx.x < k) m[threadIdx.x] = fmax(m[threadIdx.x], m[threadIdx.x + k]); __syncthreads(); }
+    if (threadIdx.x == 0) out[2] = m[0];
+}
+
 // S = blockdiag(Hpp) + lambda*I ; bs = bp   (setLambda + "_Hpp->add(_Hschur)", block_solver.hpp:363-365, 564-589)
 __global__ __launch_bounds__(256) void k_schur_init(const double *Hpp, const double *bp, int nPose, double lambda, double *S, double *bs)
 {
@@ -766,6 +798,96 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ S
         for (int c = 0; c < nb; c++) dot += T[CNB + 1 + tid][c] * T[CNB][c];
         ywork[r0 + tid] -= dot;
     }
+}
+
+// Second form of the panel step (the one launched): nothing goes through synchronised column steps.
+//   wave 0      factors the 32x32 diagonal block in REGISTERS - lane r keeps row r, the pivot column travels by v_readlane (__shfl
+//               with a constant lane), no LDS round trip and no barrier inside the 32 dependent steps (~2 us instead of ~19);
+//   waves 1-2   one thread per row of the panel below (64 rows per workgroup) and one for the right-hand side: the row sits in 32
+//               registers, is loaded while wave 0 factors, and is eliminated by forward substitution against L11 read from LDS
+//               as broadcasts, products subtracted in the order k = 0 .. c-1.
+// One barrier between the two phases, one before the right-hand-side update of the rows below.
+// value of lane `src` (compile-time constant after unrolling) as a scalar broadcast: two v_readlane_b32 instead of two ds_bpermute_b32
+__device__ __forceinline__ double readlane_f64(double v, int src)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffu), src), hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(192) void k_chol_panel2(const double *__restrict__ S, double *__restrict__ L, int n, int p0, double *ywork, double *ysol, int *okFlag)
+{
+    __shared__ double Ld[CNB][CNB + 1];   // L11 below the diagonal
+    __shared__ double sinv[CNB];          // 1 / L11[c][c]
+    __shared__ double sy[CNB];            // solved right-hand side of this panel
+    __shared__ int sBad;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nb = min(CNB, n - p0);
+    const int r0 = p0 + nb + blockIdx.x * 64;   // first row of this workgroup's part of the panel below
+    if (tid == 64) sBad = 0;
+    double x[CNB];
+    const int j = tid - 64;                      // row thread: 0..63 panel rows, 64 = right-hand side
+    const bool isRow = j >= 0 && j < 64 && r0 + j < n, isRhs = j == 64;
+    if (wave == 0) {
+        const int r = lane & (CNB - 1);          // lanes >= 32 mirror a row and write nothing
+        double a[CNB];
+#pragma unroll
+        for (int c = 0; c < CNB; c++) a[c] = (r < nb && c <= r) ? S[(size_t)(p0 + r) * n + p0 + c] : (r == c ? 1.0 : 0.0);   // identity pad past nb
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < CNB; c++) {
+            const double dj = readlane_f64(a[c], c);
+            if (!(dj > 0) || !isfinite(dj)) bad = true;          // wave-uniform
+            const double inv = rsqrt(dj);
+            a[c] = r > c ? a[c] * inv : (r == c ? dj * inv : a[c]);
+            if (lane == 0) sinv[c] = inv;
+#pragma unroll
+            for (int c2 = c + 1; c2 < CNB; c2++) {
+                const double l2 = readlane_f64(a[c], c2);
+                if (r >= c2) a[c2] -= a[c] * l2;
+            }
+        }
+        if (lane < CNB) {
+#pragma unroll
+            for (int c = 0; c < CNB; c++) {
+                if (c < r) Ld[r][c] = a[c];
+                if (blockIdx.x == 0 && r < nb && c <= r) L[(size_t)(p0 + r) * n + p0 + c] = a[c];
+            }
+        }
+        if (bad && lane == 0) sBad = 1;
+    } else if (isRow) {
+        const double *src = S + (size_t)(r0 + j) * n + p0;
+#pragma unroll
+        for (int c = 0; c < CNB; c++) x[c] = c < nb ? src[c] : 0.0;
+    } else if (isRhs) {
+#pragma unroll
+        for (int c = 0; c < CNB; c++) x[c] = c < nb ? ywork[p0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (isRow || isRhs) {
+#pragma unroll
+        for (int c = 0; c < CNB; c++) {
+            double sacc = x[c];
+#pragma unroll
+            for (int k = 0; k < c; k++) sacc -= x[k] * Ld[c][k];
+            x[c] = sacc * sinv[c];
+        }
+        if (isRow) {
+            double *dst = L + (size_t)(r0 + j) * n + p0;
+#pragma unroll
+            for (int c = 0; c < CNB; c++) if (c < nb) dst[c] = x[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < CNB; c++) { sy[c] = x[c]; if (blockIdx.x == 0 && c < nb) ysol[p0 + c] = x[c]; }
+        }
+    }
+    __syncthreads();
+    if (isRow) {   // b of the rows below -= L21 y
+        double dot = 0;
+#pragma unroll
+        for (int c = 0; c < CNB; c++) dot += x[c] * sy[c];
+        ywork[r0 + j] -= dot;
+    }
+    if (sBad && blockIdx.x == 0 && tid == 0) *okFlag = 0;   // not positive definite: the results are discarded by the host
 }
 
 __global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ S, const double *__restrict__ L, int n, int p0)
@@ -1200,6 +1322,7 @@ struct orbx_lba {
     OrbxDevBuf<double> Lmat, ywork, ysol;   // multi-workgroup Cholesky: the factor and the two halves of the right-hand side
     OrbxDevBuf<int> ep, ek, ptStart, ptEdges, kfStart, kfEdges, poseIdx, ptIdx, okFlag;
     OrbxDevBuf<uint8_t> stereo, active;
+    double *hostRed = nullptr;   // pinned: {chi, -, diag max, -, scale_p, scale_l, okFlag (as int)} of a trial, read back with ONE synchronisation
 };
 
 extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, int max_edges, orbx_lba **out)
@@ -1215,6 +1338,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
+    if (hipHostMalloc((void **)&h->hostRed, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) { orbx_lba_destroy(h); orbx_set_error("hipHostMalloc failed"); return ORBX_ERR_HIP; }
     const size_t K = (size_t)max_keyframes, P = (size_t)max_points, E = (size_t)max_edges, n6 = 6 * K;
     int rc = 0;
     rc = rc ? rc : h->pose.ensure(K); rc = rc ? rc : h->poseBak.ensure(K); rc = rc ? rc : h->pt.ensure(3 * P); rc = rc ? rc : h->ptBak.ensure(3 * P);
@@ -1242,6 +1366,7 @@ extern "C" void orbx_lba_destroy(orbx_lba *h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->hostRed) (void)hipHostFree(h->hostRed);
     delete h;
 }
 
@@ -1317,12 +1442,19 @@ int optimize(Ctx &c, int iterations, double stats[4])
     double lambda = 0, ni = 2;
     int nBad = 0;
     bool ok = true;
+    // Host synchronisations are what this loop costs (every one is ~10-20 us of idle GPU): the chi2 of an iteration start is taken over
+    // from the accepted trial that produced the state (the same kernel on the same inputs gives the same bits), the initial lambda
+    // comes from ONE reduction, and a trial reads its three sums and the Cholesky flag back together, once.
+    bool errorsFresh = false;      // d.err / rchi hold the errors of the CURRENT state and freshChi their robust sum
+    double freshChi = 0;
     for (int it = 0; it < iterations && !(c.stop && *c.stop) && ok; it++) {
-        double currentChi;
-        int rc = errors_and_chi(c, &currentChi);
-        if (rc) return rc;
-        const double iniChi = currentChi;
-        if (it == 0) stats[2] = currentChi;
+        double currentChi = freshChi;
+        if (!errorsFresh) {
+            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
+            LCHECK();
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->stream, h->rchi.p, E, 1, 0, h->red.p);
+            LCHECK();
+        }
         hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
         LCHECK();
         hipLaunchKernelGGL(k_sum_points, dim3(gP), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p);
@@ -1331,11 +1463,17 @@ int optimize(Ctx &c, int iterations, double stats[4])
         LCHECK();
         h->flops += 400.0 * nAct;
         if (it == 0) {   // computeLambdaInit: tau * max |diag H| (:166-180)
-            double mx = 0, o[2];
-            for (int j = 0; j < 6 && nPose > 0; j++) { if ((rc = reduce2(c, h->Hpp.p, nPose, 36, 7 * j, o))) return rc; mx = std::max(mx, o[1]); }
-            for (int j = 0; j < 3 && nPt > 0; j++) { if ((rc = reduce2(c, h->Hll.p, nPt, 9, 4 * j, o))) return rc; mx = std::max(mx, o[1]); }
-            lambda = 1e-5 * mx; ni = 2; nBad = 0;
+            hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(1024), 0, h->stream, h->Hpp.p, nPose, h->Hll.p, nPt, h->red.p);
+            LCHECK();
         }
+        if (!errorsFresh || it == 0) {
+            ORBX_HIP_CHECK(hipMemcpyAsync(h->hostRed, h->red.p, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+            if (!errorsFresh) currentChi = h->hostRed[0];
+            if (it == 0) { lambda = 1e-5 * h->hostRed[2]; ni = 2; nBad = 0; }
+        }
+        const double iniChi = currentChi;
+        if (it == 0) stats[2] = currentChi;
         double rho = 0;
         int qmax = 0;
         do {
@@ -1366,7 +1504,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
                     hipLaunchKernelGGL(k_chol_prep, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, h->stream, h->S.p, h->bs.p, n, h->ywork.p, h->okFlag.p);
                     for (int p0 = 0; p0 < n; p0 += CNB) {
                         const int nb = std::min(CNB, n - p0), below = n - p0 - nb;
-                        hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, (below + 63) / 64)), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0, h->ywork.p,
+                        hipLaunchKernelGGL(k_chol_panel2, dim3((unsigned)std::max(1, (below + 63) / 64)), dim3(192), 0, h->stream, h->S.p, h->Lmat.p, n, p0, h->ywork.p,
                                            h->ysol.p, h->okFlag.p);
                         if (below > 0) {
                             const unsigned T = (unsigned)((below + CNB - 1) / CNB);
@@ -1399,20 +1537,18 @@ int optimize(Ctx &c, int iterations, double stats[4])
             hipLaunchKernelGGL(k_update, dim3((unsigned)((std::max(K, P) + 255) / 256)), dim3(256), 0, h->stream, c.d, h->xp.p, h->xl.p);
             LCHECK();
             h->flops += 250.0 * nAct;
-            double tempChi;
-            if ((rc = errors_and_chi(c, &tempChi))) return rc;
-            if (nP6 > 0) ORBX_HIP_CHECK(hipMemcpy(&okHost, h->okFlag.p, sizeof(int), hipMemcpyDeviceToHost));
-            if (!okHost) tempChi = std::numeric_limits<double>::max();
-            double scale = 0, o1 = 0, o2 = 0;
-            if (nP6 > 0) {
-                hipLaunchKernelGGL(k_scale, dim3(1), dim3(1024), 0, h->stream, h->xp.p, h->bp.p, nP6, lambda, h->red.p + 4);
-                LCHECK();
-            }
-            hipLaunchKernelGGL(k_scale, dim3(1), dim3(1024), 0, h->stream, h->xl.p, h->bl.p, nL3, lambda, h->red.p + 5);
+            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
             LCHECK();
-            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-            if (nP6 > 0) ORBX_HIP_CHECK(hipMemcpy(&o1, h->red.p + 4, sizeof(double), hipMemcpyDeviceToHost));
-            ORBX_HIP_CHECK(hipMemcpy(&o2, h->red.p + 5, sizeof(double), hipMemcpyDeviceToHost));
+            hipLaunchKernelGGL(k_trial_reduce, dim3(1), dim3(1024), 0, h->stream, h->rchi.p, E, h->xp.p, h->bp.p, nP6, h->xl.p, h->bl.p, nL3, lambda, h->red.p);
+            LCHECK();
+            ORBX_HIP_CHECK(hipMemcpyAsync(h->hostRed, h->red.p, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (nP6 > 0) ORBX_HIP_CHECK(hipMemcpyAsync(h->hostRed + 8, h->okFlag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));      // the one synchronisation of the trial
+            double tempChi = h->hostRed[0];
+            if (nP6 > 0) okHost = *(const int *)(h->hostRed + 8);
+            if (!okHost) tempChi = std::numeric_limits<double>::max();
+            double scale = 0;
+            const double o1 = nP6 > 0 ? h->hostRed[4] : 0.0, o2 = h->hostRed[5];
             scale = o1 + o2 + 1e-3;
             rho = (currentChi - tempChi) / scale;
             if (rho > 0 && std::isfinite(tempChi)) {
@@ -1421,9 +1557,11 @@ int optimize(Ctx &c, int iterations, double stats[4])
                 lambda *= std::max(1. / 3., alpha);
                 ni = 2;
                 currentChi = tempChi;
+                errorsFresh = true; freshChi = tempChi;       // d.err / rchi are those of the state just accepted
             } else {
                 lambda *= ni;
                 ni *= 2;
+                errorsFresh = false;
                 // pop(): estimates restored; _error keeps the values of the rejected trial (as in g2o)
                 ORBX_HIP_CHECK(hipMemcpyAsync(h->pose.p, h->poseBak.p, (size_t)K * sizeof(DPose), hipMemcpyDeviceToDevice, h->stream));
                 ORBX_HIP_CHECK(hipMemcpyAsync(h->pt.p, h->ptBak.p, (size_t)P * 3 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
