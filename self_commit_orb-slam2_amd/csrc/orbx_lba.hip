@@ -717,96 +717,6 @@ __global__ __launch_bounds__(256) void k_chol_prep(double *S, const double *bs, 
     if (r > c) S[idx] = S[(size_t)c * n + r];   // the upper triangle is authoritative on entry
 }
 
-// One LDS tile holds the diagonal block (rows 0..31), the right-hand side of the panel as row 32 (forward
-// substitution is the same recurrence as a row of L) and this workgroup's 64 rows of the panel below (rows 33..96);
-// every elimination step scales column c and applies one rank-1 update to the whole tile, 12 elements per thread
-// read in one batch.  Loops stay rolled over LDS: the fully unrolled register formulation makes the compiler hoist
-// ~500 loop-invariant LDS reads and spill ~700 VGPRs.
-#define CPR (CNB + 1 + 64)   /* tile rows */
-__global__ __launch_bounds__(256) void k_chol_panel(const double *__restrict__ S, double *__restrict__ L, int n, int p0, double *ywork, double *ysol, int *okFlag)
-{
-    __shared__ double T[CPR][CNB + 1];
-    __shared__ double sdiag[CNB], sinv[CNB];
-    __shared__ int sBad;
-    const int tid = threadIdx.x, nb = min(CNB, n - p0);
-    const int r0 = p0 + nb + blockIdx.x * 64;   // first row of this workgroup's part of the panel below
-    if (tid == 0) sBad = 0;
-    {   // all global loads in flight together: 97 x 32 values, 13 per thread
-        double v[13];
-#pragma unroll
-        for (int q = 0; q < 13; q++) {
-            const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
-            double x = 0.0;
-            if (r < CNB) x = (r < nb && c <= r) ? S[(size_t)(p0 + r) * n + p0 + c] : (r == c ? 1.0 : 0.0);   // identity pad past nb
-            else if (r == CNB) x = c < nb ? ywork[p0 + c] : 0.0;
-            else if (r < CPR && r0 + (r - CNB - 1) < n && c < nb) x = S[(size_t)(r0 + r - CNB - 1) * n + p0 + c];
-            v[q] = x;
-        }
-#pragma unroll
-        for (int q = 0; q < 13; q++) { const int idx = tid + 256 * q; if ((idx >> 5) < CPR) T[idx >> 5][idx & 31] = v[q]; }
-    }
-    __syncthreads();
-    // Waves 0-1: the 32x32 diagonal block, right-looking, one rank-1 update per column.
-    // Waves 2-3: the rows below it (right-hand side + 64 panel rows) never feed back into the block, so their
-    // elimination is a triangular solve: ONE THREAD PER ROW computes its entry of column c as soon as that column of
-    // L11 is final, subtracting the products in the same order k = 0 .. c-1 in which the rank-1 updates would have
-    // arrived (identical rounding) - hidden behind the block's own update instead of 65 more rows going through every
-    // synchronised step.
-    const int lowRow = (tid >= 128 && tid - 128 < CPR - CNB) ? CNB + tid - 128 : -1;
-    for (int c = 0; c < nb; c++) {
-        const double dj = T[c][c];
-        if (!(dj > 0) || !isfinite(dj)) { if (tid == 0) sBad = 1; }
-        const double inv = rsqrt(dj);
-        // scale column c below the diagonal (the diagonal entry itself is kept aside: nobody reads T[c][c] again)
-        if (c + 1 + tid < CNB) T[c + 1 + tid][c] *= inv;
-        if (tid == 0) { sdiag[c] = dj * inv; sinv[c] = inv; }
-        __syncthreads();
-        if (tid < 128) {
-            // lower triangle of the trailing block: element (r, c2), c < c2 <= r < CNB
-            const int r = c + 1 + (tid >> 2);
-#pragma unroll
-            for (int w = 0; w < 8; w++) {
-                const int c2 = c + 1 + (tid & 3) + 4 * w;
-                if (r < CNB && c2 < nb && c2 <= r) T[r][c2] = T[r][c2] - T[r][c] * T[c2][c];
-            }
-        } else if (lowRow >= 0) {
-            // all 2 x 32 operands in flight at once (reads past k = c are in bounds and unused): the chain that is left
-            // is the c dependent subtractions
-            double xr[CNB], lc[CNB];
-#pragma unroll
-            for (int k = 0; k < CNB; k++) { xr[k] = T[lowRow][k]; lc[k] = T[c][k]; }
-            double a = T[lowRow][c];
-#pragma unroll
-            for (int k = 0; k < CNB; k++) if (k < c) a = a - xr[k] * lc[k];
-            T[lowRow][c] = a * inv;
-        }
-        __syncthreads();
-    }
-    if (sBad && blockIdx.x == 0 && tid == 0) *okFlag = 0;   // not positive definite: the results are discarded by the host
-    // results: L11 and y from workgroup 0, the rows below from every workgroup; b of the rows below -= L21 y
-    for (int idx = tid; idx < CPR * CNB; idx += 256) {
-        const int r = idx >> 5, c = idx & 31;
-        if (c >= nb) continue;
-        if (r < CNB) {
-            if (blockIdx.x == 0 && r < nb && c <= r) L[(size_t)(p0 + r) * n + p0 + c] = r == c ? sdiag[c] : T[r][c];
-        } else if (r == CNB) {
-            if (blockIdx.x == 0) ysol[p0 + c] = T[CNB][c];
-        } else if (r0 + (r - CNB - 1) < n) L[(size_t)(r0 + r - CNB - 1) * n + p0 + c] = T[r][c];
-    }
-    if (tid < 64 && r0 + tid < n) {
-        double dot = 0;
-        for (int c = 0; c < nb; c++) dot += T[CNB + 1 + tid][c] * T[CNB][c];
-        ywork[r0 + tid] -= dot;
-    }
-}
-
-// Second form of the panel step (the one launched): nothing goes through synchronised column steps.
-//   wave 0      factors the 32x32 diagonal block in REGISTERS - lane r keeps row r, the pivot column travels by v_readlane (__shfl
-//               with a constant lane), no LDS round trip and no barrier inside the 32 dependent steps (~2 us instead of ~19);
-//   waves 1-2   one thread per row of the panel below (64 rows per workgroup) and one for the right-hand side: the row sits in 32
-//               registers, is loaded while wave 0 factors, and is eliminated by forward substitution against L11 read from LDS
-//               as broadcasts, products subtracted in the order k = 0 .. c-1.
-// One barrier between the two phases, one before the right-hand-side update of the rows below.
 // value of lane `src` (compile-time constant after unrolling) as a scalar broadcast: two v_readlane_b32 instead of two ds_bpermute_b32
 __device__ __forceinline__ double readlane_f64(double v, int src)
 {
@@ -815,7 +725,15 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(192) void k_chol_panel2(const double *__restrict__ S, double *__restrict__ L, int n, int p0, double *ywork, double *ysol, int *okFlag)
+// The panel step: nothing goes through synchronised column steps (a version with the 32x32 block in LDS and two workgroup
+// barriers per column took 31 us per panel, this one ~17).
+//   wave 0      factors the 32x32 diagonal block in REGISTERS - lane r keeps row r, the pivot column travels by v_readlane
+//               (readlane_f64 above), no LDS round trip and no barrier inside the 32 dependent steps;
+//   waves 1-2   one thread per row of the panel below (64 rows per workgroup) and one for the right-hand side: the row sits in 32
+//               registers, is loaded while wave 0 factors, and is eliminated by forward substitution against L11 read from LDS
+//               as broadcasts, products subtracted in the order k = 0 .. c-1.
+// One barrier between the two phases, one before the right-hand-side update of the rows below.
+__global__ __launch_bounds__(192) void k_chol_panel(const double *__restrict__ S, double *__restrict__ L, int n, int p0, double *ywork, double *ysol, int *okFlag)
 {
     __shared__ double Ld[CNB][CNB + 1];   // L11 below the diagonal
     __shared__ double sinv[CNB];          // 1 / L11[c][c]
@@ -1504,7 +1422,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
                     hipLaunchKernelGGL(k_chol_prep, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, h->stream, h->S.p, h->bs.p, n, h->ywork.p, h->okFlag.p);
                     for (int p0 = 0; p0 < n; p0 += CNB) {
                         const int nb = std::min(CNB, n - p0), below = n - p0 - nb;
-                        hipLaunchKernelGGL(k_chol_panel2, dim3((unsigned)std::max(1, (below + 63) / 64)), dim3(192), 0, h->stream, h->S.p, h->Lmat.p, n, p0, h->ywork.p,
+                        hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, (below + 63) / 64)), dim3(192), 0, h->stream, h->S.p, h->Lmat.p, n, p0, h->ywork.p,
                                            h->ysol.p, h->okFlag.p);
                         if (below > 0) {
                             const unsigned T = (unsigned)((below + CNB - 1) / CNB);
