@@ -160,7 +160,8 @@ def test_oracle_bundle_adjustment_protocol(orbx, oracle):
     assert 1 <= s[0] <= 20 and s[4] == 0 and s[5] == 0 and s[3] < s[2]
     r5 = oracle_lib.bundle_adjustment(oracle, w, 5, True)
     lba = oracle_lib.local_bundle_adjustment(oracle, w)
-    assert r5["stats"][0] == lba["stats"][0] and np.isclose(r5["stats"][3], lba["stats"][3])    # identical to LBA's first stage
+    # LBA's first stage is the same schedule up to the monocular Huber delta (sqrt(5.99) here, sqrt(5.991) there: src/Optimizer.cc:141 / :764)
+    assert r5["stats"][0] == lba["stats"][0] and np.isclose(r5["stats"][3], lba["stats"][3], rtol=1e-3) and r5["stats"][3] != lba["stats"][3]
     nr = oracle_lib.bundle_adjustment(oracle, w, 10, False)
     assert nr["stats"][2] > r["stats"][2]            # without kernels the gross outliers count fully in chi2
     r0 = oracle_lib.bundle_adjustment(oracle, w, 0, True)
