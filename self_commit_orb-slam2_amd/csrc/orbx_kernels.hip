@@ -273,8 +273,16 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
     const int rl = S == 1 ? lane : S == 2 ? (lane >> 1) : S == 3 ? ((lane * 43) >> 7) : (lane >> 2);
     const int seg = lane - rl * S, c0 = 16 * seg;
     const uint32_t colMask = (aw - c0 >= 16) ? 0xffffu : (aw - c0 <= 0 ? 0u : ((1u << (aw - c0)) - 1u));
-    int nc = 0;
-    const uint32_t thrPk = (uint32_t)(minTh & 0xffff) * 0x00010001u;
+    // The reference runs FAST at iniThFAST and only a cell without any keypoint again at minThFAST (:1126-1136).  Here too: the first
+    // pass pre-tests against iniThFAST - a third of the survivors of a minThFAST pre-test on textured images, and the exact score of
+    // the survivors (phase B) is ~40 % of the kernel - and scores below iniThFAST count as "not a corner", exactly what the
+    // reference's first cv::FAST call sees; only when no iniThFAST keypoint survives the NMS does the cell run again at minThFAST.
+    // (With the parity taps on, the single minThFAST pass writes the full score map.)
+    int nc = 0, th = dbg ? minTh : iniTh;
+    bool anyIni = false;
+    for (;;) {
+    nc = 0;
+    const uint32_t thrPk = (uint32_t)(th & 0xffff) * 0x00010001u;
     for (int rowBase = 0; rowBase < ah; rowBase += rpp) {
         const int r = rowBase + rl;
         const bool live = rl < rpp && r < ah;
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
             }
             const uint32_t vv = FC_PAIR(W[3], j + 3);
             const uint32_t m = pk_max_i16(pk_sub_i16(vv, A), pk_sub_i16(B, vv));
-            // m > minTh  <=>  minTh - m < 0: the two sign bits go to bit j (pixel j) and bit 16 + j (pixel j + 1)
+            // m > th  <=>  th - m < 0: the two sign bits go to bit j (pixel j) and bit 16 + j (pixel j + 1)
             mask |= ((pk_sub_i16(thrPk, m) >> 15) & 0x00010001u) << j;
         }
         mask = (mask & 0x5555u) | ((mask >> 15) & 0xaaaau);
@@ -340,14 +348,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
         }
         // dark arc: all x < v - t  <=>  t < v - max(x);  bright arc: all x > v + t  <=>  t < min(x) - v;  score = largest such t
         int sco = max(v - minB, maxA - v) - 1;
-        sco = sco >= minTh ? sco : 0;
+        sco = sco >= th ? sco : 0;
         scT[(r + 1) * P + c + 4] = (uint8_t)sco;
         if (dbg) dbg[(size_t)(y0 + r) * lv.pitch + (x0 + c)] = (uint8_t)sco;
     }
     __syncthreads();
 
     // ---- phase C: strict 3x3 maxima, threshold choice, ordered emission ----
-    bool anyIni = false;
+    anyIni = false;
     for (int i = lane; i < nc; i += 64) {
         const int code = cand[i], r = code >> 6, c = code & 63;
         const uint8_t *sp = scT + (r + 1) * P + c + 4;
@@ -357,7 +365,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
         cand[i] = (unsigned short)(code | (nms ? 0x1000 : 0) | (ini ? 0x2000 : 0));   // own entry: no cross-lane hazard
         anyIni = anyIni || ini;
     }
-    const int keepBit = __any(anyIni) ? 0x2000 : 0x1000;   // iniThFAST keypoints exist -> the minThFAST retry is skipped (:1132)
+    anyIni = __any(anyIni);
+    if (anyIni || th == minTh) break;
+    th = minTh;           // :1132-1136: nothing at iniThFAST -> the whole cell again at minThFAST
+    __syncthreads();      // (single wave: orders the LDS list / score tile reuse)
+    }
+    const int keepBit = anyIni ? 0x2000 : 0x1000;   // iniThFAST keypoints exist -> the minThFAST retry is skipped (:1132)
     uint32_t *slot = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase + (size_t)cell * lv.cellCap;
     int base = 0;
     for (int i0 = 0; i0 < nc; i0 += 64) {
