@@ -57,7 +57,8 @@ def build_oracle(verbose=True):
     if shutil.which("make") is None or shutil.which("g++") is None:
         return
     out = None if verbose else subprocess.DEVNULL
-    subprocess.run(["make", "-s", "-f", str(mk), "all"], check=True, stdout=out)
+    jobs = str(max(1, min(16, os.cpu_count() or 1)))      # ~45 translation units since the vendored g2o joined the reference build
+    subprocess.run(["make", "-s", "-j", jobs, "-f", str(mk), "all"], check=True, stdout=out)
 
 
 def build_all(force=False, verbose=True):
