@@ -34,6 +34,20 @@ def hipcc_path():
 
 
 def build_liborbx(force=False, verbose=True):
+    """Several ranks of one node may import the package at the same moment (bench.py --gpus N): the staleness check and the
+    compilation run under an exclusive file lock, and the library is linked to a temporary name and renamed into place, so
+    no rank ever dlopens a half-written file."""
+    import fcntl
+    LIB.parent.mkdir(parents=True, exist_ok=True)
+    with open(LIB.parent / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_liborbx_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_liborbx_locked(force, verbose):
     srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
     deps = srcs + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [ROOT / "include" / "orbx.h"]
     if not force and _newer(LIB, deps):
@@ -44,10 +58,12 @@ def build_liborbx(force=False, verbose=True):
             return LIB   # GPU box without a compiler: use the prebuilt library from the snapshot
         raise RuntimeError("hipcc not found and no prebuilt liborbx.so")
     LIB.parent.mkdir(parents=True, exist_ok=True)
-    cmd = [hipcc] + HIP_FLAGS + ["-o", str(LIB)] + [str(s) for s in srcs]
+    tmp = LIB.with_suffix(".so.tmp%d" % os.getpid())
+    cmd = [hipcc] + HIP_FLAGS + ["-o", str(tmp)] + [str(s) for s in srcs]
     if verbose:
-        print("[build]", " ".join(cmd), flush=True)
+        print("[build]", " ".join(cmd).replace(str(tmp), str(LIB)), flush=True)
     subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB)
     return LIB
 
 
