@@ -332,6 +332,14 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
                 "contended": {"avg_launch_ms": round(stage_ms.get(dom, 0.0), 4),
                               "achieved": round(bytes_per_launch / (max(stage_ms.get(dom, 0.0), 1e-9) * 1e-3) / 1e9, 2),
                               "note": "event span of the same launch inside the %d-stream pipeline (includes queueing behind the other streams)" % NS},
+                "dominant_by_contended_span": (lambda d2: {"kernel": STAGE_KERNEL.get(d2, d2) + (" (7 launches)" if d2 == "pyramid" else ""),
+                                                          "span_ms": round(stage_ms[d2], 4), "achieved": round(alg[d2] * B / (stage_ms[d2] * 1e-3) / 1e9, 2),
+                                                          "frac": round(alg[d2] * B / (stage_ms[d2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                                          "note": "the stage with the longest event span inside the pipeline of this command (what a rocprofv3 trace of this "
+                                                                  "command ranks first by total kernel time); for the seven dependent k_resize launches the span is mostly queueing"})(
+                    max((k for k in stage_ms if alg.get(k, 0) > 0), key=lambda k: stage_ms[k])),
+                "rocprof": {"alone": "profiles/*_streams1_kernel_stats.csv = rocprofv3 --kernel-trace --stats of `bench.py --streams 1` (average durations = stage_ms_alone)",
+                            "this_command": "profiles/*_kernel_stats.csv of this command (durations stretched by the concurrency of the three streams)"},
                 "stage_ms_alone": {k: round(v, 4) for k, v in alone_ms.items()},
                 "stage_ms_contended": {k: round(v, 4) for k, v in stage_ms.items()},
                 "stage_frac_of_hbm_peak_alone": {k: round(alg[k] * B / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in alone_ms.items() if alg.get(k, 0) > 0 and v > 0},

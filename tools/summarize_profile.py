@@ -41,6 +41,12 @@ def main():
         w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
         for r in ks:
             w.writerow([r[0], r[1], "%.3f" % r[2], "%.3f" % r[3], "%.2f" % r[4]])
+    if (src / "trace1" / "bench_results.db").exists():      # the one-stream run: every kernel alone
+        with open(str(dst) + "_streams1_kernel_stats.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
+            for r in kernel_stats(src / "trace1" / "bench_results.db"):
+                w.writerow([r[0], r[1], "%.3f" % r[2], "%.3f" % r[3], "%.2f" % r[4]])
     fe = pmc(src / "pmc_fetch" / "bench_results.db", "FETCH_SIZE") if (src / "pmc_fetch" / "bench_results.db").exists() else {}
     wr = pmc(src / "pmc_write" / "bench_results.db", "WRITE_SIZE") if (src / "pmc_write" / "bench_results.db").exists() else {}
     with open(str(dst) + "_hbm_traffic.csv", "w", newline="") as f:
