@@ -8,7 +8,7 @@
 //                 the per-edge blocks J^T W J are written out, no atomics)
 //   k_sum_points  Hll / b_l per landmark  = fixed-order sum over its edges
 //   k_sum_poses   Hpp / b_p per free pose = fixed-order sum over its edges (one WG each)
-//   k_schur_init / k_schur_points   S = Hpp + lambda*I - sum_l B D^-1 B^T (one wave per
+//   k_schur_setup (init + points)   S = Hpp + lambda*I - sum_l B D^-1 B^T (one wave per
 //                 landmark, FP64 atomics into the dense 6Kx6K reduced system)
 //   k_chol_solve  dense Cholesky of S + forward/back substitution   (one workgroup)
 //   k_backsub     x_l = D^-1 (b_l - B^T x_p)                        (one thread per landmark)
@@ -384,26 +384,26 @@ __global__ __launch_bounds__(1024) void k_diag_max(const double *Hpp, int nPose,
 }
 
 // S = blockdiag(Hpp) + lambda*I ; bs = bp   (setLambda + "_Hpp->add(_Hschur)", block_solver.hpp:363-365, 564-589)
-__global__ __launch_bounds__(256) void k_schur_init(const double *Hpp, const double *bp, int nPose, double lambda, double *S, double *bs)
+__device__ __forceinline__ void schur_init_part(int block, int nblocks, const double *Hpp, const double *bp, int nPose, double lambda, double *S, double *bs)
 {
     const int n = 6 * nPose;
     const size_t total = (size_t)n * n;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    for (size_t idx = (size_t)block * 256 + threadIdx.x; idx < total; idx += (size_t)nblocks * 256) {
         const int r = (int)(idx / n), c = (int)(idx % n);
         double v = 0;
         if (r / 6 == c / 6) { v = Hpp[(size_t)(r / 6) * 36 + 6 * (r % 6) + (c % 6)]; if (r == c) v += lambda; }
         S[idx] = v;
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) bs[i] = bp[i];
+    for (int i = block * 256 + threadIdx.x; i < n; i += nblocks * 256) bs[i] = bp[i];
 }
 
 // per landmark: D^-1, D^-1 b_l and B D^-1 of its edges
 // (block_solver.hpp:381-439).  One wave per landmark, lanes over (edge, row).
-__global__ __launch_bounds__(256) void k_schur_points(LbaDev d, const int *ptStart, const int *ptEdges, const double *Hll, const double *bl, double lambda,
-                                                      double *Dinv, double *Ddb)
+__device__ __forceinline__ void schur_points_part(int block, const LbaDev &d, const int *ptStart, const int *ptEdges, const double *Hll, const double *bl, double lambda,
+                                                  double *Dinv, double *Ddb)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int l = blockIdx.x * 4 + wv;
+    const int l = block * 4 + wv;
     if (l >= d.P) return;
     const int li = d.ptIdx[l];
     if (li < 0) return;
@@ -438,6 +438,15 @@ __global__ __launch_bounds__(256) void k_schur_points(LbaDev d, const int *ptSta
 #pragma unroll
         for (int c = 0; c < 3; c++) blk[EB_BD + 3 * r + c] = B1[0] * I[c] + B1[1] * I[3 + c] + B1[2] * I[6 + c];
     }
+}
+
+// The two independent preparations of a trial in ONE launch (every launch of this latency-bound loop costs ~3 us of gap besides its
+// own run time): blocks [0, nInit) initialise S / bs, the rest handle four landmarks each.
+__global__ __launch_bounds__(256) void k_schur_setup(LbaDev d, int nInit, const double *Hpp, const double *bp, int nPose, const int *ptStart, const int *ptEdges,
+                                                     const double *Hll, const double *bl, double lambda, double *S, double *bs, double *Dinv, double *Ddb)
+{
+    if ((int)blockIdx.x < nInit) schur_init_part((int)blockIdx.x, nInit, Hpp, bp, nPose, lambda, S, bs);
+    else schur_points_part((int)blockIdx.x - nInit, d, ptStart, ptEdges, Hll, bl, lambda, Dinv, Ddb);
 }
 
 // S[i1, i2] -= (B_1 D^-1) B_2^T for every pair of free-pose observations of a landmark, i2 >= i1 (upper block
@@ -889,15 +898,25 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict_
 }
 
 // x_l = D^-1 (b_l - B^T x_p)   (block_solver.hpp:459-481)
-__global__ __launch_bounds__(256) void k_backsub(LbaDev d, const int *ptStart, const int *ptEdges, const double *bl, const double *Dinv, const double *xp,
-                                                 double *xl)
+// x_l, push() and update(x) in one launch: thread t computes the increment of landmark t (k_backsub), saves the estimates of
+// keyframe t / landmark t (SparseOptimizer::push, sparse_optimizer.cpp:502-506: every vertex) and applies the increments (oplus).
+__global__ __launch_bounds__(256) void k_backsub_update(LbaDev d, const int *ptStart, const int *ptEdges, const double *bl, const double *Dinv, const double *xp,
+                                                        double *xl, DPose *poseBak, double *ptBak)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= d.P) return;
-    const int li = d.ptIdx[l];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < d.K) {
+        DPose T = d.pose[t];
+        poseBak[t] = T;
+        const int pi = d.poseIdx[t];
+        if (pi >= 0) { pose_oplus(T, xp + 6 * pi); d.pose[t] = T; }
+    }
+    if (t >= d.P) return;
+    double X[3] = {d.pt[3 * (size_t)t], d.pt[3 * (size_t)t + 1], d.pt[3 * (size_t)t + 2]};
+    for (int i = 0; i < 3; i++) ptBak[3 * (size_t)t + i] = X[i];
+    const int li = d.ptIdx[t];
     if (li < 0) return;
     double c[3] = {bl[(size_t)li * 3], bl[(size_t)li * 3 + 1], bl[(size_t)li * 3 + 2]};
-    for (int s = ptStart[l]; s < ptStart[l + 1]; s++) {
+    for (int s = ptStart[t]; s < ptStart[t + 1]; s++) {
         const int e = ptEdges[s];
         if (!d.active[e]) continue;
         const int pi = d.poseIdx[d.ek[e]];
@@ -906,19 +925,10 @@ __global__ __launch_bounds__(256) void k_backsub(LbaDev d, const int *ptStart, c
         for (int q = 0; q < 3; q++) { double acc = 0; for (int r = 0; r < 6; r++) acc += B1[3 * r + q] * xp[6 * pi + r]; c[q] -= acc; }
     }
     const double *I = Dinv + (size_t)li * 9;
-    for (int i = 0; i < 3; i++) xl[(size_t)li * 3 + i] = I[3 * i] * c[0] + I[3 * i + 1] * c[1] + I[3 * i + 2] * c[2];
-}
-
-__global__ __launch_bounds__(256) void k_update(LbaDev d, const double *xp, const double *xl)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < d.K) {
-        const int pi = d.poseIdx[t];
-        if (pi >= 0) { DPose T = d.pose[t]; pose_oplus(T, xp + 6 * pi); d.pose[t] = T; }
-    }
-    if (t < d.P) {
-        const int li = d.ptIdx[t];
-        if (li >= 0) for (int i = 0; i < 3; i++) d.pt[3 * (size_t)t + i] += xl[(size_t)li * 3 + i];
+    for (int i = 0; i < 3; i++) {
+        const double x = I[3 * i] * c[0] + I[3 * i + 1] * c[1] + I[3 * i + 2] * c[2];
+        xl[(size_t)li * 3 + i] = x;
+        d.pt[3 * (size_t)t + i] = X[i] + x;
     }
 }
 
@@ -1395,17 +1405,14 @@ int optimize(Ctx &c, int iterations, double stats[4])
         double rho = 0;
         int qmax = 0;
         do {
-            // push()
-            ORBX_HIP_CHECK(hipMemcpyAsync(h->poseBak.p, h->pose.p, (size_t)K * sizeof(DPose), hipMemcpyDeviceToDevice, h->stream));
-            ORBX_HIP_CHECK(hipMemcpyAsync(h->ptBak.p, h->pt.p, (size_t)P * 3 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            // (push() happens inside k_backsub_update, right before the estimates are changed)
             int okHost = 1;
-            if (nP6 > 0) {
-                hipLaunchKernelGGL(k_schur_init, dim3(256), dim3(256), 0, h->stream, h->Hpp.p, h->bp.p, nPose, lambda, h->S.p, h->bs.p);
+            {
+                const int nInit = nP6 > 0 ? 64 : 0;
+                hipLaunchKernelGGL(k_schur_setup, dim3((unsigned)(nInit + (P + 3) / 4)), dim3(256), 0, h->stream, c.d, nInit, h->Hpp.p, h->bp.p, nPose, h->ptStart.p,
+                                   h->ptEdges.p, h->Hll.p, h->bl.p, lambda, h->S.p, h->bs.p, h->Dinv.p, h->Ddb.p);
                 LCHECK();
             }
-            hipLaunchKernelGGL(k_schur_points, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p, lambda,
-                               h->Dinv.p, h->Ddb.p);
-            LCHECK();
             if (nP6 > 0) {
                 const size_t ldsRows = (size_t)(6 * nP6 + 6) * sizeof(double);
                 if (ldsRows > 150 * 1024) {      // > ~530 free keyframes: the block row no longer fits into LDS
@@ -1450,9 +1457,8 @@ int optimize(Ctx &c, int iterations, double stats[4])
                 LCHECK();
                 h->flops += (double)nP6 * nP6 * nP6 / 3.0;
             }
-            hipLaunchKernelGGL(k_backsub, dim3(gP), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->bl.p, h->Dinv.p, h->xp.p, h->xl.p);
-            LCHECK();
-            hipLaunchKernelGGL(k_update, dim3((unsigned)((std::max(K, P) + 255) / 256)), dim3(256), 0, h->stream, c.d, h->xp.p, h->xl.p);
+            hipLaunchKernelGGL(k_backsub_update, dim3((unsigned)((std::max(K, P) + 255) / 256)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->bl.p,
+                               h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p);
             LCHECK();
             h->flops += 250.0 * nAct;
             hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
