@@ -422,7 +422,10 @@ def bench_stereo(a, orbx, torch, grp, dev_t, local, rank_info):
 
 
 def bench_lba(a, orbx, torch, grp, dev_t, local, rank_info):
-    """BASELINE configs[4]: Optimizer::LocalBundleAdjustment on the synthetic 50-KF / 5000-point window (replicas only: a window does not shard)."""
+    """BASELINE configs[4]: Optimizer::LocalBundleAdjustment on the synthetic 50-KF / 5000-point window (replicas only: a window does not
+    shard).  `value` = windows/s of ONE window at a time (what LocalMapping does: latency); `concurrent` = the same with --streams
+    independent windows in flight on as many handles / host threads (a window occupies a few CUs at a time: the LM loop is a chain of
+    small dependent kernels), i.e. what a batch of independent maps gets."""
     w = orbx.lba_synth.make_window(K=50, P=5000, seed=12345 + grp.rank)
     opt = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000, device=local)
     for _ in range(a.warmup):
@@ -436,13 +439,31 @@ def bench_lba(a, orbx, torch, grp, dev_t, local, rank_info):
     grp.barrier()
     elapsed = time.perf_counter() - t0
     ms, flops = opt.last_timing()
+    # ---- S windows in flight (outside the timed region of `value`)
+    S = max(1, a.streams)
+    opts = [opt] + [orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000, device=local) for _ in range(S - 1)]
+    ws = [w] + [orbx.lba_synth.make_window(K=50, P=5000, seed=777 + 13 * i + grp.rank) for i in range(S - 1)]
+    for o, x in zip(opts[1:], ws[1:]):
+        o.LocalBundleAdjustment(x)
+
+    def work(i):
+        for _ in range(a.steps):
+            opts[i].LocalBundleAdjustment(ws[i])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(S)]
+    tc = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    conc = S * a.steps / (time.perf_counter() - tc)
     t, total, per_rank = grp.aggregate(elapsed, a.steps, w["E"])
     if grp.rank != 0:
         return None
     return {"metric": "local BA windows/s (50 KF / 5000 points)", "value": round(total / t, 2), "unit": "windows/s", "n_gpus": grp.world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "config": {"workload": "BASELINE config 5: LocalBundleAdjustment, %d keyframes, %d points, %d edges; replicas only" % (w["K"], w["P"], w["E"]),
-                                            "kernel_ms": round(float(np.mean(kern)), 4), "fp64_gflops": round(flops / (ms * 1e-3) / 1e9, 2) if ms > 0 else None},
+                                            "kernel_ms": round(float(np.mean(kern)), 4), "fp64_gflops": round(flops / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
+                                            "concurrent": {"windows_in_flight": S, "windows_per_s": round(conc, 1)}},
             "ranks": dict(rank_info, per_rank=[{"windows": r[0], "seconds": round(r[1], 6)} for r in per_rank])}
 
 
