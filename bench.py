@@ -350,9 +350,7 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
     valu = {k: pmc_valu(k, B) for k in alg}
     roofline_valu = None
     if any(v for v in valu.values()):
-        tot = sum(v for v in valu.values() if v)
-        octree_valu = pmc_valu("octree", B) or 0
-        tot += octree_valu
+        tot = sum(v for v in valu.values() if v)      # (alg has an "octree" key with 0 bytes: the quadtree's instructions are in the sum)
         rate = tot * nbatches / (t / a.steps) / 1e9
         dv = valu.get(dom)
         roofline_valu = {"bound": "valu_issue", "unit": "G wave-instr/s", "peak": round(VALU_PEAK_GINST, 1),
