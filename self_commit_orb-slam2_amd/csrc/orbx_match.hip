@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void k_bow_order(FeatDev A, const int32_t *__r
 // of the test); dropping it leaves the greedy replay bit-identical and makes list updates rare.
 // The per-lane lists start filled with the sentinel dcut<<16, so "key < kk[TOPK-1]" is the whole
 // test, evaluated once per 4 B features on the minimum of the keys.
-#define TOPK_ROWS 512   /* A features per block: two per lane */
+#define TOPK_NROW 1      /* A features per lane in k_bow_topk (1: 4096 waves per 256 pairs x 1000 features instead of 2048) */
+#define TOPK_ROWS (256 * TOPK_NROW)   /* A features per block */
 #define TOPK_TILE 1024  /* B features per LDS tile */
 
 __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
@@ -112,7 +113,7 @@ __device__ __forceinline__ void topk_insert(uint32_t (&kk)[TOPK], uint32_t key)
 // TRI (SearchForTriangulation): among equal distances the LAST candidate in scan order wins
 // (`dist>bestDist` skips, :880), so the key carries 0xffff - j; a candidate below the list threshold
 // is inserted only if it passes the epipole gate and the epipolar-line test.
-template <bool FILTER, bool TRI>   // FILTER: B side has node ids and/or a validity mask
+template <bool FILTER, bool TRI, int NROW>   // FILTER: B side has node ids and/or a validity mask; NROW: A features per lane (2: fewer LDS reads per distance, 1: twice the waves)
 __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
                                                   uint32_t dcut, uint32_t *__restrict__ topk, int stride, TriDev T)
 {
@@ -121,24 +122,28 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
     const int p = blockIdx.y, fa = pairsA[p], fb = pairsB[p];
     const int nA = min(A.counts[fa], A.cap), nB = min(B.counts[fb], B.cap);
     const int capB = B.cap;
-    const int row0 = blockIdx.x * TOPK_ROWS;
+    const int row0 = blockIdx.x * (256 * NROW);
     if (row0 >= nA) return;
     const int tid = threadIdx.x;
-    const int i0 = row0 + tid, i1 = row0 + 256 + tid;
-    const bool live0 = i0 < nA, live1 = i1 < nA;
-    const uint32_t *da0 = (const uint32_t *)(A.desc + ((size_t)fa * A.cap + (live0 ? i0 : nA - 1)) * 32);
-    const uint32_t *da1 = (const uint32_t *)(A.desc + ((size_t)fa * A.cap + (live1 ? i1 : nA - 1)) * 32);
-    uint32_t a[8], c[8];
-#pragma unroll
-    for (int w = 0; w < 8; w++) { a[w] = da0[w]; c[w] = da1[w]; }
-    const int gA0 = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live0 ? i0 : nA - 1)] : 0;
-    const int gA1 = (FILTER && A.groups) ? A.groups[(size_t)fa * A.cap + (live1 ? i1 : nA - 1)] : 0;
+    int ir[NROW];
+    bool live[NROW], act[NROW];
+    uint32_t a[NROW][8], kk[NROW][TOPK], th[NROW];
+    int gA[NROW];
     const uint32_t sentinel = dcut << 16;
-    const bool act0 = live0 && !(FILTER && gA0 < 0), act1 = live1 && !(FILTER && gA1 < 0);   // unfiled A features keep empty lists
-    uint32_t k0[TOPK], k1[TOPK];
 #pragma unroll
-    for (int q = 0; q < TOPK; q++) { k0[q] = act0 ? sentinel : 0u; k1[q] = act1 ? sentinel : 0u; }   // inactive rows never insert
-    uint32_t t0 = k0[TOPK - 1] >> 16, t1 = k1[TOPK - 1] >> 16;   // distance part of each list's threshold
+    for (int r = 0; r < NROW; r++) {
+        ir[r] = row0 + 256 * r + tid;
+        live[r] = ir[r] < nA;
+        const size_t ia = (size_t)fa * A.cap + (live[r] ? ir[r] : nA - 1);
+        const uint32_t *da = (const uint32_t *)(A.desc + ia * 32);
+#pragma unroll
+        for (int w = 0; w < 8; w++) a[r][w] = da[w];
+        gA[r] = (FILTER && A.groups) ? A.groups[ia] : 0;
+        act[r] = live[r] && !(FILTER && gA[r] < 0);      // unfiled A features keep empty lists
+#pragma unroll
+        for (int q = 0; q < TOPK; q++) kk[r][q] = act[r] ? sentinel : 0u;   // inactive rows never insert
+        th[r] = kk[r][TOPK - 1] >> 16;                   // distance part of the list's threshold
+    }
     const uint4 *gD = (const uint4 *)(B.desc + (size_t)fb * capB * 32);
     for (int t0base = 0; t0base < nB; t0base += TOPK_TILE) {
         const int nt = min(TOPK_TILE, nB - t0base), ntPad = (nt + 3) & ~3;
@@ -158,58 +163,68 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
         // four B features per step; only the last step of a tile can contain padding (TAIL): its check stays out of the main loop
         auto group = [&](const int j0, auto tailTag) {
             constexpr bool TAIL = decltype(tailTag)::value;
-            // the event test runs on the bare distances (the list threshold's distance t0 / t1): the key
+            // the event test runs on the bare distances (the list threshold's distance th[r]): the key
             // dist << 16 | j is only formed for the few candidates that reach the list.  An excluded
             // candidate carries distance 0xffff, above every threshold (dcut <= 257).
-            uint32_t dd0[4], dd1[4];
+            uint32_t dd[NROW][4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint4 lo = sB[2 * (j0 + u)], hi = sB[2 * (j0 + u) + 1];   // wave-uniform address: LDS broadcast
+                const uint32_t bw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                uint32_t d[NROW];
                 // v_bcnt_u32_b32 adds its second operand: one instruction per word instead of bcnt + add tree
-                uint32_t d0 = bcnt_acc(a[0] ^ lo.x, 0u), d1 = bcnt_acc(c[0] ^ lo.x, 0u);
-                d0 = bcnt_acc(a[1] ^ lo.y, d0); d1 = bcnt_acc(c[1] ^ lo.y, d1);
-                d0 = bcnt_acc(a[2] ^ lo.z, d0); d1 = bcnt_acc(c[2] ^ lo.z, d1);
-                d0 = bcnt_acc(a[3] ^ lo.w, d0); d1 = bcnt_acc(c[3] ^ lo.w, d1);
-                d0 = bcnt_acc(a[4] ^ hi.x, d0); d1 = bcnt_acc(c[4] ^ hi.x, d1);
-                d0 = bcnt_acc(a[5] ^ hi.y, d0); d1 = bcnt_acc(c[5] ^ hi.y, d1);
-                d0 = bcnt_acc(a[6] ^ hi.z, d0); d1 = bcnt_acc(c[6] ^ hi.z, d1);
-                d0 = bcnt_acc(a[7] ^ hi.w, d0); d1 = bcnt_acc(c[7] ^ hi.w, d1);
+#pragma unroll
+                for (int r = 0; r < NROW; r++) d[r] = bcnt_acc(a[r][0] ^ bw[0], 0u);
+#pragma unroll
+                for (int w = 1; w < 8; w++)
+#pragma unroll
+                    for (int r = 0; r < NROW; r++) d[r] = bcnt_acc(a[r][w] ^ bw[w], d[r]);
                 if (FILTER) {
                     const int gq = sG[j0 + u];
-                    d0 = gq == gA0 ? d0 : 0xffffu;
-                    d1 = gq == gA1 ? d1 : 0xffffu;
-                } else if (TAIL && j0 + u >= nt) { d0 = 0xffffu; d1 = 0xffffu; }   // wave-uniform (zero padding of the tile)
-                dd0[u] = d0; dd1[u] = d1;
+#pragma unroll
+                    for (int r = 0; r < NROW; r++) d[r] = gq == gA[r] ? d[r] : 0xffffu;
+                } else if (TAIL && j0 + u >= nt) {   // wave-uniform (zero padding of the tile)
+#pragma unroll
+                    for (int r = 0; r < NROW; r++) d[r] = 0xffffu;
+                }
+#pragma unroll
+                for (int r = 0; r < NROW; r++) dd[r][u] = d[r];
             }
-            const uint32_t m0 = min(min(dd0[0], min(dd0[1], dd0[2])), dd0[3]), m1 = min(min(dd1[0], min(dd1[1], dd1[2])), dd1[3]);
             // plain scan order: an equal distance with a later j has the larger key, so only d < t can enter;
             // TRI keys carry 0xffff - j, an equal distance with a later j enters: d <= t (conservative at the sentinel)
             auto reaches = [](uint32_t d, uint32_t t) { return TRI ? d <= t : d < t; };
-            if (__any(reaches(m0, t0) || reaches(m1, t1))) {
+            bool any4 = false;
+#pragma unroll
+            for (int r = 0; r < NROW; r++) any4 = any4 || reaches(min(min(dd[r][0], min(dd[r][1], dd[r][2])), dd[r][3]), th[r]);
+            if (__any(any4)) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    if (__any(reaches(dd0[u], t0) || reaches(dd1[u], t1))) {
+                    bool anyU = false;
+#pragma unroll
+                    for (int r = 0; r < NROW; r++) anyU = anyU || reaches(dd[r][u], th[r]);
+                    if (__any(anyU)) {
                         const uint32_t j = TRI ? 0xffffu - (uint32_t)(t0base + j0 + u) : (uint32_t)(t0base + j0 + u);
-                        uint32_t ins0 = (dd0[u] << 16) | j, ins1 = (dd1[u] << 16) | j;
+                        uint32_t ins[NROW];
+#pragma unroll
+                        for (int r = 0; r < NROW; r++) ins[r] = (dd[r][u] << 16) | j;
                         if (TRI) {
                             const int jb = t0base + j0 + u;
                             const orbx_keypoint k2 = B.kp[(size_t)fb * capB + jb];
                             const bool st2 = T.stereoB && T.stereoB[(size_t)fb * capB + jb];
-                            bool pass0 = false, pass1 = false;
-                            if (ins0 < k0[TOPK - 1]) {
-                                const size_t ia = (size_t)fa * A.cap + i0;
-                                pass0 = tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], k2, st2);
+#pragma unroll
+                            for (int r = 0; r < NROW; r++) {
+                                bool pass = false;
+                                if (ins[r] < kk[r][TOPK - 1]) {
+                                    const size_t ia = (size_t)fa * A.cap + ir[r];
+                                    pass = tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], k2, st2);
+                                }
+                                ins[r] = pass ? ins[r] : 0xffffffffu;
                             }
-                            if (ins1 < k1[TOPK - 1]) {
-                                const size_t ia = (size_t)fa * A.cap + i1;
-                                pass1 = tri_geom_ok(T, p, A.kp[ia], T.stereoA && T.stereoA[ia], k2, st2);
-                            }
-                            ins0 = pass0 ? ins0 : 0xffffffffu;
-                            ins1 = pass1 ? ins1 : 0xffffffffu;
                         }
-                        // events are sparse (a few lanes per wave): usually only one of the two rows has one
-                        if (__any(ins0 < k0[TOPK - 1])) { topk_insert(k0, ins0); t0 = k0[TOPK - 1] >> 16; }
-                        if (__any(ins1 < k1[TOPK - 1])) { topk_insert(k1, ins1); t1 = k1[TOPK - 1] >> 16; }
+                        // events are sparse (a few lanes per wave): usually only one of the rows has one
+#pragma unroll
+                        for (int r = 0; r < NROW; r++)
+                            if (__any(ins[r] < kk[r][TOPK - 1])) { topk_insert(kk[r], ins[r]); th[r] = kk[r][TOPK - 1] >> 16; }
                     }
                 }
             }
@@ -218,16 +233,13 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
         for (; j0 + 4 <= nt; j0 += 4) group(j0, std::false_type());
         if (j0 < ntPad) group(j0, std::true_type());
     }
-    if (live0) {
-        uint32_t *out = topk + ((size_t)p * stride + i0) * TOPK;
 #pragma unroll
-        for (int k = 0; k < TOPK; k++) out[k] = (!act0 || k0[k] >= sentinel) ? KEY_EMPTY : k0[k];
-    }
-    if (live1) {
-        uint32_t *out = topk + ((size_t)p * stride + i1) * TOPK;
+    for (int r = 0; r < NROW; r++)
+        if (live[r]) {
+            uint32_t *out = topk + ((size_t)p * stride + ir[r]) * TOPK;
 #pragma unroll
-        for (int k = 0; k < TOPK; k++) out[k] = (!act1 || k1[k] >= sentinel) ? KEY_EMPTY : k1[k];
-    }
+            for (int k = 0; k < TOPK; k++) out[k] = (!act[r] || kk[r][k] >= sentinel) ? KEY_EMPTY : kk[r][k];
+        }
 }
 
 // greedy replay + rotation histogram + three-maxima pruning; one workgroup per pair.
@@ -804,9 +816,9 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     const bool filter = b->groups != nullptr || (params->mode == 1 && b->valid != nullptr);
     const dim3 gridTopk((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs);
     if (filter)
-        hipLaunchKernelGGL((k_bow_topk<true, false>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
+        hipLaunchKernelGGL((k_bow_topk<true, false, TOPK_NROW>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
     else
-        hipLaunchKernelGGL((k_bow_topk<false, false>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
+        hipLaunchKernelGGL((k_bow_topk<false, false, TOPK_NROW>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->evMid[slot], m->stream));
     m->midValid[slot] = true;
@@ -1056,7 +1068,7 @@ extern "C" int orbx_search_for_triangulation_device(orbx_matcher *m, const orbx_
     MLAUNCH_CHECK();
     const dim3 gridTopk((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs);
     // only dist <= TH_LOW can be accepted (:880) and there is no second-best test: cut at TH_LOW + 1
-    hipLaunchKernelGGL((k_bow_topk<true, true>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, 2, (uint32_t)(TH_LOW + 1), m->topk.p, stride, T);
+    hipLaunchKernelGGL((k_bow_topk<true, true, TOPK_NROW>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, 2, (uint32_t)(TH_LOW + 1), m->topk.p, stride, T);
     MLAUNCH_CHECK();
     m->midValid[slot] = false;
     const size_t ldsGreedy = (size_t)b->capacity * 4 + (size_t)a->capacity * 4 + (size_t)((a->capacity + 7) & ~7) * 2 * 2;
