@@ -492,6 +492,8 @@ def main():
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU: liborbx has no CPU fallback"
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ORBX_BENCH_SHARE_GPU") == "1":      # plumbing check on a 1-GPU box: every rank on device 0, ORBX_DIST_BACKEND=gloo (RCCL refuses two ranks per GPU)
+        local = local % torch.cuda.device_count()
     assert local < torch.cuda.device_count(), "rank %d has no GPU (%d visible)" % (local, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev_t = torch.device("cuda", local)

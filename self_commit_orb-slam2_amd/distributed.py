@@ -28,13 +28,18 @@ def launch(nproc, argv, env=None, timeout=None, capture=False):
     launches them: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P <argv>.  Used by `python bench.py --gpus N` when it is started without a launcher, and by the
     CPU (gloo) test of the same path.  Returns the CompletedProcess."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)), "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port())] + list(argv)
     e = dict(os.environ if env is None else env)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
     e.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=e, timeout=timeout, stdout=subprocess.PIPE if capture else None, stderr=subprocess.PIPE if capture else None,
-                          text=True if capture else None)
+    r = None
+    for attempt in range(3):                              # the free port is found and released before torchrun binds it: retry a lost race
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port())] + list(argv)
+        r = subprocess.run(cmd, env=e, timeout=timeout, stdout=subprocess.PIPE if capture else None, stderr=subprocess.PIPE if capture else None,
+                           text=True if capture else None)
+        if r.returncode == 0 or not capture or "ddress already in use" not in (r.stderr or ""):
+            break
+    return r
 
 
 class Group:
@@ -49,7 +54,9 @@ class Group:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             if backend is None:
-                backend = "nccl" if self.device.type == "cuda" else "gloo"
+                backend = os.environ.get("ORBX_DIST_BACKEND") or ("nccl" if self.device.type == "cuda" else "gloo")
+            if backend == "gloo":
+                self.device = torch.device("cpu")      # gloo moves host tensors (CPU tests; a GPU box where the ranks share one device)
             kw = {}
             if backend == "nccl":
                 kw["device_id"] = self.device
