@@ -384,6 +384,23 @@ __global__ __launch_bounds__(1024) void k_diag_max(const double *Hpp, int nPose,
 }
 
 // S = blockdiag(Hpp) + lambda*I ; bs = bp   (setLambda + "_Hpp->add(_Hschur)", block_solver.hpp:363-365, 564-589)
+// e->chi2() from the stored _error and isDepthPositive() from the CURRENT estimates (src/Optimizer.cc:880-958): flag = outlier
+__global__ __launch_bounds__(256) void k_classify(LbaDev d, uint8_t *flag, double *chiOut)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.E) return;
+    const double *r = d.err + 3 * (size_t)e;
+    const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * d.info[e];
+    const DPose T = d.pose[d.ek[e]];
+    const double X[3] = {d.pt[3 * (size_t)d.ep[e]], d.pt[3 * (size_t)d.ep[e] + 1], d.pt[3 * (size_t)d.ep[e] + 2]};
+    double Xc[3];
+    quat_rot(T.q, X, Xc);
+    const double z = Xc[2] + T.t[2];
+    const double th = d.stereo[e] ? 7.815 : 5.991;
+    flag[e] = (chi > th || !(z > 0.0)) ? 1 : 0;
+    if (chiOut) chiOut[e] = chi;
+}
+
 __device__ __forceinline__ void schur_init_part(int block, int nblocks, const double *Hpp, const double *bp, int nPose, double lambda, double *S, double *bs)
 {
     const int n = 6 * nPose;
@@ -1250,6 +1267,10 @@ struct orbx_lba {
     OrbxDevBuf<double> Lmat, ywork, ysol;   // multi-workgroup Cholesky: the factor and the two halves of the right-hand side
     OrbxDevBuf<int> ep, ek, ptStart, ptEdges, kfStart, kfEdges, poseIdx, ptIdx, okFlag;
     OrbxDevBuf<uint8_t> stereo, active;
+    uint8_t *hostIO = nullptr;   // pinned: the marshalled inputs of a call on their way up, flags / chi2 / estimates on their way down
+    size_t hostIOBytes = 0;
+    OrbxDevBuf<uint8_t> flagDev;
+    OrbxDevBuf<double> chiDev;
     double *hostRed = nullptr;   // pinned: {chi, -, diag max, -, scale_p, scale_l, okFlag (as int)} of a trial, read back with ONE synchronisation
 };
 
@@ -1295,6 +1316,8 @@ extern "C" void orbx_lba_destroy(orbx_lba *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->hostRed) (void)hipHostFree(h->hostRed);
+    if (h->hostIO) (void)hipHostFree(h->hostIO);
+    h->flagDev.release(); h->chiDev.release();
     delete h;
 }
 
@@ -1517,19 +1540,43 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     ORBX_HIP_CHECK(hipSetDevice(h->device));
     for (int i = 0; i < 8; i++) res->stats[i] = 0;
     h->flops = 0;
-    // ---- host marshalling: float boundary -> double state (Converter::toSE3Quat / toVector3d) ----
-    std::vector<DPose> pose((size_t)K);
-    std::vector<double> intr((size_t)5 * K), pt((size_t)3 * P), obs((size_t)3 * E), info((size_t)E);
-    std::vector<uint8_t> stereo((size_t)E);
+    // ---- host marshalling: float boundary -> double state (Converter::toSE3Quat / toVector3d), written straight into ONE pinned
+    // buffer (copies from pageable vectors are staged and synchronous: a dozen of them cost 0.3 ms of a 5 ms call) ----
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t oPose = 0, oIntr = oPose + pad((size_t)K * sizeof(DPose)), oPt = oIntr + pad((size_t)5 * K * 8), oObs = oPt + pad((size_t)3 * P * 8),
+                 oInfo = oObs + pad((size_t)3 * E * 8), oSt = oInfo + pad((size_t)E * 8), oEp = oSt + pad((size_t)E), oEk = oEp + pad((size_t)E * 4),
+                 oPs = oEk + pad((size_t)E * 4), oPe = oPs + pad(((size_t)P + 1) * 4), oKs = oPe + pad((size_t)E * 4), oKe = oKs + pad(((size_t)K + 1) * 4),
+                 inBytes = oKe + pad((size_t)E * 4);
+    const size_t dFlag = 0, dChi = dFlag + pad((size_t)E), dPose = dChi + pad((size_t)E * 8), dPt = dPose + pad((size_t)K * sizeof(DPose)),
+                 outBytes = dPt + pad((size_t)3 * P * 8);
+    {
+        const size_t need = std::max(inBytes, outBytes);
+        if (need > h->hostIOBytes) {
+            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+            if (h->hostIO) (void)hipHostFree(h->hostIO);
+            h->hostIO = nullptr; h->hostIOBytes = 0;
+            ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostIO, need, hipHostMallocDefault));
+            h->hostIOBytes = need;
+        }
+        int rcb = h->flagDev.ensure((size_t)E);
+        rcb = rcb ? rcb : h->chiDev.ensure((size_t)E);
+        if (rcb) return rcb;
+    }
+    uint8_t *io = h->hostIO;
+    DPose *pose = (DPose *)(io + oPose);
+    double *intr = (double *)(io + oIntr), *pt = (double *)(io + oPt), *obs = (double *)(io + oObs), *info = (double *)(io + oInfo);
+    uint8_t *stereo = io + oSt;
+    int *epH = (int *)(io + oEp), *ekH = (int *)(io + oEk), *ptStart = (int *)(io + oPs), *ptEdges = (int *)(io + oPe), *kfStart = (int *)(io + oKs),
+        *kfEdges = (int *)(io + oKe);
     for (int k = 0; k < K; k++) {
         double R[9];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = p->poses[16 * (size_t)k + 4 * i + j];
-        pose[(size_t)k].q = quat_from_R(R);
-        quat_normalize_pos(pose[(size_t)k].q);
-        for (int i = 0; i < 3; i++) pose[(size_t)k].t[i] = p->poses[16 * (size_t)k + 4 * i + 3];
+        pose[k].q = quat_from_R(R);
+        quat_normalize_pos(pose[k].q);
+        for (int i = 0; i < 3; i++) pose[k].t[i] = p->poses[16 * (size_t)k + 4 * i + 3];
         for (int i = 0; i < 5; i++) intr[5 * (size_t)k + i] = p->intrinsics[5 * (size_t)k + i];
     }
-    for (int i = 0; i < 3 * P; i++) pt[(size_t)i] = p->points[i];
+    for (int i = 0; i < 3 * P; i++) pt[i] = p->points[i];
     Ctx c;
     c.h = h; c.stop = stop;
     c.ep.assign(p->edge_point, p->edge_point + E); c.ek.assign(p->edge_keyframe, p->edge_keyframe + E);
@@ -1537,33 +1584,35 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     c.level.assign((size_t)E, 0);
     for (int e = 0; e < E; e++) {
         for (int i = 0; i < 3; i++) obs[3 * (size_t)e + i] = p->edge_obs[3 * (size_t)e + i];
-        stereo[(size_t)e] = !(p->edge_obs[3 * (size_t)e + 2] < 0);
-        info[(size_t)e] = p->edge_inv_sigma2[e];
+        stereo[e] = !(p->edge_obs[3 * (size_t)e + 2] < 0);
+        info[e] = p->edge_inv_sigma2[e];
+        epH[e] = p->edge_point[e]; ekH[e] = p->edge_keyframe[e];
     }
     // CSR by landmark and by keyframe, edges in insertion order
-    std::vector<int> ptStart((size_t)P + 1, 0), kfStart((size_t)K + 1, 0), ptEdges((size_t)E), kfEdges((size_t)E);
-    for (int e = 0; e < E; e++) { ptStart[(size_t)c.ep[(size_t)e] + 1]++; kfStart[(size_t)c.ek[(size_t)e] + 1]++; }
-    for (int l = 0; l < P; l++) ptStart[(size_t)l + 1] += ptStart[(size_t)l];
-    for (int k = 0; k < K; k++) kfStart[(size_t)k + 1] += kfStart[(size_t)k];
+    for (int l = 0; l <= P; l++) ptStart[l] = 0;
+    for (int k = 0; k <= K; k++) kfStart[k] = 0;
+    for (int e = 0; e < E; e++) { ptStart[epH[e] + 1]++; kfStart[ekH[e] + 1]++; }
+    for (int l = 0; l < P; l++) ptStart[l + 1] += ptStart[l];
+    for (int k = 0; k < K; k++) kfStart[k + 1] += kfStart[k];
     {
-        std::vector<int> fp(ptStart.begin(), ptStart.end() - 1), fk(kfStart.begin(), kfStart.end() - 1);
-        for (int e = 0; e < E; e++) { ptEdges[(size_t)fp[(size_t)c.ep[(size_t)e]]++] = e; kfEdges[(size_t)fk[(size_t)c.ek[(size_t)e]]++] = e; }
+        std::vector<int> fp(ptStart, ptStart + P), fk(kfStart, kfStart + K);
+        for (int e = 0; e < E; e++) { ptEdges[fp[(size_t)epH[e]]++] = e; kfEdges[fk[(size_t)ekH[e]]++] = e; }
     }
     hipStream_t s = h->stream;
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->pose.p, pose.data(), (size_t)K * sizeof(DPose), hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->pt.p, pt.data(), pt.size() * 8, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->intr.p, intr.data(), intr.size() * 8, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->obs.p, obs.data(), obs.size() * 8, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->info.p, info.data(), info.size() * 8, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->stereo.p, stereo.data(), (size_t)E, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->ep.p, c.ep.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->ek.p, c.ek.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->ptStart.p, ptStart.data(), ptStart.size() * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->ptEdges.p, ptEdges.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->kfStart.p, kfStart.data(), kfStart.size() * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->kfEdges.p, kfEdges.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->pose.p, pose, (size_t)K * sizeof(DPose), hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->pt.p, pt, (size_t)3 * P * 8, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->intr.p, intr, (size_t)5 * K * 8, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->obs.p, obs, (size_t)3 * E * 8, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->info.p, info, (size_t)E * 8, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->stereo.p, stereo, (size_t)E, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->ep.p, epH, (size_t)E * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->ek.p, ekH, (size_t)E * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->ptStart.p, ptStart, ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->ptEdges.p, ptEdges, (size_t)E * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->kfStart.p, kfStart, ((size_t)K + 1) * 4, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipMemcpyAsync(h->kfEdges.p, kfEdges, (size_t)E * 4, hipMemcpyHostToDevice, s));
     ORBX_HIP_CHECK(hipMemsetAsync(h->err.p, 0, (size_t)E * 3 * 8, s));
-    ORBX_HIP_CHECK(hipStreamSynchronize(s));
+    ORBX_HIP_CHECK(hipStreamSynchronize(s));     // the pinned buffer is reused for the results below
     LbaDev &d = c.d;
     d.K = K; d.P = P; d.E = E; d.pose = h->pose.p; d.pt = h->pt.p; d.intr = h->intr.p; d.ep = h->ep.p; d.ek = h->ek.p; d.obs = h->obs.p;
     d.stereo = h->stereo.p; d.info = h->info.p; d.active = h->active.p; d.poseIdx = h->poseIdx.p; d.ptIdx = h->ptIdx.p; d.err = h->err.p;
@@ -1574,23 +1623,20 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     c.hub.dsqrMono = (double)(float)((double)thMono * (double)thMono);        // `float dsqr` member (robust_kernel_impl.h:84)
     c.hub.dsqrStereo = (double)(float)((double)thStereo * (double)thStereo);
     ORBX_HIP_CHECK(hipEventRecord(h->ev0, s));
-    std::vector<double> err((size_t)3 * E, 0.0);
-    auto classify = [&](std::vector<uint8_t> &flag, double *chiOut) -> int {
-        // e->chi2() from the stored _error and isDepthPositive() from the CURRENT estimates (src/Optimizer.cc:880-958)
-        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-        ORBX_HIP_CHECK(hipMemcpy(err.data(), h->err.p, err.size() * 8, hipMemcpyDeviceToHost));
-        ORBX_HIP_CHECK(hipMemcpy(pose.data(), h->pose.p, (size_t)K * sizeof(DPose), hipMemcpyDeviceToHost));
-        ORBX_HIP_CHECK(hipMemcpy(pt.data(), h->pt.p, pt.size() * 8, hipMemcpyDeviceToHost));
-        for (int e = 0; e < E; e++) {
-            const double *r = &err[3 * (size_t)e];
-            const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * info[(size_t)e];
-            double Xc[3];
-            quat_rot(pose[(size_t)c.ek[(size_t)e]].q, &pt[3 * (size_t)c.ep[(size_t)e]], Xc);
-            const double z = Xc[2] + pose[(size_t)c.ek[(size_t)e]].t[2];
-            const double th = stereo[(size_t)e] ? 7.815 : 5.991;
-            flag[(size_t)e] = (chi > th || !(z > 0.0)) ? 1 : 0;
-            if (chiOut) chiOut[e] = chi;
+    // classification on the device (k_classify); only the flags come back between the stages, the rest with the final results
+    const unsigned gEc = (unsigned)((E + 255) / 256);
+    auto classify = [&](std::vector<uint8_t> &flag, bool final) -> int {
+        hipLaunchKernelGGL(k_classify, dim3(gEc), dim3(256), 0, h->stream, c.d, h->flagDev.p, final && res->edge_chi2 ? h->chiDev.p : nullptr);
+        LCHECK();
+        ORBX_HIP_CHECK(hipMemcpyAsync(io + dFlag, h->flagDev.p, (size_t)E, hipMemcpyDeviceToHost, h->stream));
+        if (final) {
+            if (res->edge_chi2) ORBX_HIP_CHECK(hipMemcpyAsync(io + dChi, h->chiDev.p, (size_t)E * 8, hipMemcpyDeviceToHost, h->stream));
+            ORBX_HIP_CHECK(hipMemcpyAsync(io + dPose, h->pose.p, (size_t)K * sizeof(DPose), hipMemcpyDeviceToHost, h->stream));
+            ORBX_HIP_CHECK(hipMemcpyAsync(io + dPt, h->pt.p, (size_t)3 * P * 8, hipMemcpyDeviceToHost, h->stream));
         }
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+        memcpy(flag.data(), io + dFlag, (size_t)E);
+        if (final && res->edge_chi2) memcpy(res->edge_chi2, io + dChi, (size_t)E * 8);
         return ORBX_OK;
     };
     int rc = ORBX_OK;
@@ -1599,7 +1645,7 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
         c.robust = robust1 ? 1 : 0;
         if ((rc = optimize(c, iters1, res->stats)) != ORBX_OK) return rc;       // :863-864 (LBA), :247 (BundleAdjustment)
         if (secondStage && !(stop && *stop)) {
-            if ((rc = classify(flag, nullptr)) != ORBX_OK) return rc;        // :880-912
+            if ((rc = classify(flag, false)) != ORBX_OK) return rc;          // :880-912
             for (int e = 0; e < E; e++) if (flag[(size_t)e]) c.level[(size_t)e] = 1;
             c.robust = 0;
             if ((rc = optimize(c, 10, res->stats + 4)) != ORBX_OK) return rc;   // :916-917
@@ -1607,16 +1653,17 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     }
     ORBX_HIP_CHECK(hipEventRecord(h->ev1, s));
     h->timed = true;
-    if ((rc = classify(flag, res->edge_chi2)) != ORBX_OK) return rc;          // :921-958
+    if ((rc = classify(flag, true)) != ORBX_OK) return rc;                    // :921-958
     for (int e = 0; e < E; e++) res->edge_outlier[e] = flag[(size_t)e];
+    pose = (DPose *)(io + dPose); pt = (double *)(io + dPt);                  // final estimates (pinned read-back)
     for (int k = 0; k < K; k++) {                                             // Converter::toCvMat(SE3Quat)
         double R[9];
-        quat_to_R(pose[(size_t)k].q, R);
+        quat_to_R(pose[k].q, R);
         float *o = res->poses + 16 * (size_t)k;
-        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o[4 * i + j] = (float)R[3 * i + j]; o[4 * i + 3] = (float)pose[(size_t)k].t[i]; }
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o[4 * i + j] = (float)R[3 * i + j]; o[4 * i + 3] = (float)pose[k].t[i]; }
         o[12] = o[13] = o[14] = 0.f; o[15] = 1.f;
     }
-    for (int i = 0; i < 3 * P; i++) res->points[i] = (float)pt[(size_t)i];
+    for (int i = 0; i < 3 * P; i++) res->points[i] = (float)pt[i];
     return ORBX_OK;
 }
 
