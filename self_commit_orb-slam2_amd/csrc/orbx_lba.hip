@@ -759,15 +759,40 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
 //               registers, is loaded while wave 0 factors, and is eliminated by forward substitution against L11 read from LDS
 //               as broadcasts, products subtracted in the order k = 0 .. c-1.
 // One barrier between the two phases, one before the right-hand-side update of the rows below.
+// 1 / sqrt(x) for the pivots: v_rsq_f64 (~26 bits) + two Newton steps y += y/2 (1 - x y^2), instead of the library routine, which sits
+// on the 32-step critical path of the block
+__device__ __forceinline__ double pivot_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const double e = __builtin_fma(-x * y, y, 1.0);
+        y = __builtin_fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
 __global__ __launch_bounds__(192) void k_chol_panel(const double *__restrict__ S, double *__restrict__ L, int n, int p0, double *ywork, double *ysol, int *okFlag)
 {
-    __shared__ double Ld[CNB][CNB + 1];   // L11 below the diagonal
-    __shared__ double sinv[CNB];          // 1 / L11[c][c]
-    __shared__ double sy[CNB];            // solved right-hand side of this panel
+    __shared__ double Ld[CNB][CNB + 1];      // diagonal block in, L11 (lower incl. diagonal) out
+    __shared__ double Tt[65][CNB + 1];       // this workgroup's 64 rows of the panel below + the right-hand side as row 64: in and out
+    __shared__ double sinv[CNB];             // 1 / L11[c][c]
     __shared__ int sBad;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nb = min(CNB, n - p0);
     const int r0 = p0 + nb + blockIdx.x * 64;   // first row of this workgroup's part of the panel below
     if (tid == 64) sBad = 0;
+    // global memory is only touched by the whole workgroup, a row segment of 32 doubles per 32 threads (a thread walking its own row
+    // makes every load instruction of the wave touch 64 different lines)
+    for (int idx = tid; idx < CNB * CNB; idx += 192) {
+        const int r = idx >> 5, c = idx & 31;
+        Ld[r][c] = (r < nb && c <= r) ? S[(size_t)(p0 + r) * n + p0 + c] : (r == c ? 1.0 : 0.0);   // identity pad past nb
+    }
+    for (int idx = tid; idx < 64 * CNB; idx += 192) {
+        const int r = idx >> 5, c = idx & 31;
+        Tt[r][c] = (r0 + r < n && c < nb) ? S[(size_t)(r0 + r) * n + p0 + c] : 0.0;
+    }
+    if (tid < CNB) Tt[64][tid] = tid < nb ? ywork[p0 + tid] : 0.0;
+    __syncthreads();
     double x[CNB];
     const int j = tid - 64;                      // row thread: 0..63 panel rows, 64 = right-hand side
     const bool isRow = j >= 0 && j < 64 && r0 + j < n, isRhs = j == 64;
@@ -775,36 +800,31 @@ __global__ __launch_bounds__(192) void k_chol_panel(const double *__restrict__ S
         const int r = lane & (CNB - 1);          // lanes >= 32 mirror a row and write nothing
         double a[CNB];
 #pragma unroll
-        for (int c = 0; c < CNB; c++) a[c] = (r < nb && c <= r) ? S[(size_t)(p0 + r) * n + p0 + c] : (r == c ? 1.0 : 0.0);   // identity pad past nb
+        for (int c = 0; c < CNB; c++) a[c] = Ld[r][c];
         bool bad = false;
 #pragma unroll
         for (int c = 0; c < CNB; c++) {
             const double dj = readlane_f64(a[c], c);
             if (!(dj > 0) || !isfinite(dj)) bad = true;          // wave-uniform
-            const double inv = rsqrt(dj);
-            a[c] = r > c ? a[c] * inv : (r == c ? dj * inv : a[c]);
+            const double inv = pivot_rsqrt(dj);
+            a[c] = r == c ? dj * inv : a[c] * inv;
             if (lane == 0) sinv[c] = inv;
+            // no predicate on r >= c2: the entries above the diagonal of a lane's row turn into garbage that nothing reads (the
+            // pivots and the broadcast factors all come from the lower triangle), and a predicated FMA costs an exec-mask round trip
 #pragma unroll
             for (int c2 = c + 1; c2 < CNB; c2++) {
                 const double l2 = readlane_f64(a[c], c2);
-                if (r >= c2) a[c2] -= a[c] * l2;
+                a[c2] = __builtin_fma(-a[c], l2, a[c2]);    // fused: the factorisation is not part of the bit-level contract (1e-5 vs g2o)
             }
         }
         if (lane < CNB) {
 #pragma unroll
-            for (int c = 0; c < CNB; c++) {
-                if (c < r) Ld[r][c] = a[c];
-                if (blockIdx.x == 0 && r < nb && c <= r) L[(size_t)(p0 + r) * n + p0 + c] = a[c];
-            }
+            for (int c = 0; c < CNB; c++) if (c <= r) Ld[r][c] = a[c];
         }
         if (bad && lane == 0) sBad = 1;
-    } else if (isRow) {
-        const double *src = S + (size_t)(r0 + j) * n + p0;
+    } else if (isRow || isRhs) {
 #pragma unroll
-        for (int c = 0; c < CNB; c++) x[c] = c < nb ? src[c] : 0.0;
-    } else if (isRhs) {
-#pragma unroll
-        for (int c = 0; c < CNB; c++) x[c] = c < nb ? ywork[p0 + c] : 0.0;
+        for (int c = 0; c < CNB; c++) x[c] = Tt[j][c];
     }
     __syncthreads();
     if (isRow || isRhs) {
@@ -812,26 +832,31 @@ __global__ __launch_bounds__(192) void k_chol_panel(const double *__restrict__ S
         for (int c = 0; c < CNB; c++) {
             double sacc = x[c];
 #pragma unroll
-            for (int k = 0; k < c; k++) sacc -= x[k] * Ld[c][k];
+            for (int k = 0; k < c; k++) sacc = __builtin_fma(-x[k], Ld[c][k], sacc);
             x[c] = sacc * sinv[c];
         }
-        if (isRow) {
-            double *dst = L + (size_t)(r0 + j) * n + p0;
 #pragma unroll
-            for (int c = 0; c < CNB; c++) if (c < nb) dst[c] = x[c];
-        } else {
-#pragma unroll
-            for (int c = 0; c < CNB; c++) { sy[c] = x[c]; if (blockIdx.x == 0 && c < nb) ysol[p0 + c] = x[c]; }
-        }
+        for (int c = 0; c < CNB; c++) Tt[j][c] = x[c];
     }
     __syncthreads();
     if (isRow) {   // b of the rows below -= L21 y
         double dot = 0;
 #pragma unroll
-        for (int c = 0; c < CNB; c++) dot += x[c] * sy[c];
+        for (int c = 0; c < CNB; c++) dot += x[c] * Tt[64][c];
         ywork[r0 + j] -= dot;
     }
-    if (sBad && blockIdx.x == 0 && tid == 0) *okFlag = 0;   // not positive definite: the results are discarded by the host
+    for (int idx = tid; idx < 64 * CNB; idx += 192) {
+        const int r = idx >> 5, c = idx & 31;
+        if (r0 + r < n && c < nb) L[(size_t)(r0 + r) * n + p0 + c] = Tt[r][c];
+    }
+    if (blockIdx.x == 0) {      // L11 and the solved right-hand side of this panel
+        for (int idx = tid; idx < CNB * CNB; idx += 192) {
+            const int r = idx >> 5, c = idx & 31;
+            if (r < nb && c <= r) L[(size_t)(p0 + r) * n + p0 + c] = Ld[r][c];
+        }
+        if (tid < nb) ysol[p0 + tid] = Tt[64][tid];
+        if (sBad && tid == 0) *okFlag = 0;   // not positive definite: the results are discarded by the host
+    }
 }
 
 __global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ S, const double *__restrict__ L, int n, int p0)
@@ -852,7 +877,8 @@ __global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ S, con
 #pragma unroll 8
     for (int c = 0; c < CNB; c++) {
         const double a0 = la[ti][c], a1 = la[ti + 1][c], b0 = lb[tk][c], b1 = lb[tk + 1][c];
-        acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+        acc[0][0] = __builtin_fma(a0, b0, acc[0][0]); acc[0][1] = __builtin_fma(a0, b1, acc[0][1]);
+        acc[1][0] = __builtin_fma(a1, b0, acc[1][0]); acc[1][1] = __builtin_fma(a1, b1, acc[1][1]);
     }
 #pragma unroll
     for (int u = 0; u < 2; u++)
