@@ -926,14 +926,21 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict_
         }
         __syncthreads();
         if (tid < 64) {
-            for (int cc = nb - 1; cc >= 0; cc--) {
-                const double xc = sx.get(p0 + cc) / l11[cc][cc];
-                __builtin_amdgcn_wave_barrier();
-                if (tid == 0) sx.set(p0 + cc, xc);
-                if (tid < cc) sx.set(p0 + tid, sx.get(p0 + tid) - l11[cc][tid] * xc);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+            // L11^T x = y inside one wave, in registers: lane t keeps x_t and column t of L11; step cc broadcasts the finished x_cc
+            // (v_readlane) and every lane below subtracts its product - no LDS round trip, no division on the 32-step chain (the
+            // reciprocal diagonals are formed up front, all lanes at once)
+            const int t = tid & (CNB - 1);
+            double lcol[CNB];
+#pragma unroll
+            for (int cc = 0; cc < CNB; cc++) lcol[cc] = (cc > t && cc < nb) ? l11[cc][t] : 0.0;
+            const double inv = t < nb ? 1.0 / l11[t][t] : 1.0;
+            double xv = t < nb ? sx.get(p0 + t) : 0.0;
+#pragma unroll
+            for (int cc = CNB - 1; cc >= 0; cc--) {
+                const double xc = readlane_f64(xv * inv, cc);
+                xv = t == cc ? xc : __builtin_fma(-lcol[cc], xc, xv);
             }
+            if (tid < nb) sx.set(p0 + tid, xv);
         }
         __syncthreads();
     }
