@@ -272,23 +272,39 @@ __global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust
 }
 
 // Hll (9, full symmetric) and b_l (3) of every active landmark: its edges in insertion order
+__device__ __forceinline__ double sum16(double x)
+{
+    // sum over the 16 lanes of a landmark's group (xor butterfly inside the group)
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) x += __shfl_xor(x, o, 16);
+    return x;
+}
+
+// 16 lanes per landmark (a landmark has ~12 observations: one thread walking them serially leaves the launch at 20 waves and a
+// dozen dependent loads deep), partial sums combined by a butterfly inside the group
 __global__ __launch_bounds__(256) void k_sum_points(LbaDev d, const int *ptStart, const int *ptEdges, double *Hll, double *bl)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.x * 16 + (threadIdx.x >> 4), a = threadIdx.x & 15;
     if (l >= d.P) return;
     const int li = d.ptIdx[l];
     if (li < 0) return;
-    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-    for (int s = ptStart[l]; s < ptStart[l + 1]; s++) {
+    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // H (6) then b (3)
+    for (int s = ptStart[l] + a; s < ptStart[l + 1]; s += 16) {
         const int e = ptEdges[s];
         if (!d.active[e]) continue;
         const double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
-        for (int i = 0; i < 6; i++) H[i] += blk[EB_HLL + i];
-        for (int i = 0; i < 3; i++) b[i] += blk[EB_BL + i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] += blk[EB_HLL + i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) v[6 + i] += blk[EB_BL + i];
     }
-    double *o = Hll + (size_t)li * 9;
-    o[0] = H[0]; o[1] = H[1]; o[2] = H[2]; o[3] = H[1]; o[4] = H[3]; o[5] = H[4]; o[6] = H[2]; o[7] = H[4]; o[8] = H[5];
-    bl[(size_t)li * 3] = b[0]; bl[(size_t)li * 3 + 1] = b[1]; bl[(size_t)li * 3 + 2] = b[2];
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[i] = sum16(v[i]);
+    if (a == 0) {
+        double *o = Hll + (size_t)li * 9;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[1]; o[4] = v[3]; o[5] = v[4]; o[6] = v[2]; o[7] = v[4]; o[8] = v[5];
+        bl[(size_t)li * 3] = v[6]; bl[(size_t)li * 3 + 1] = v[7]; bl[(size_t)li * 3 + 2] = v[8];
+    }
 }
 
 // Hpp (36) and b_p (6) of every free pose: one workgroup per keyframe, fixed-shape tree reduction (the 27 values
@@ -953,27 +969,34 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict_
 __global__ __launch_bounds__(256) void k_backsub_update(LbaDev d, const int *ptStart, const int *ptEdges, const double *bl, const double *Dinv, const double *xp,
                                                         double *xl, DPose *poseBak, double *ptBak)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < d.K) {
-        DPose T = d.pose[t];
-        poseBak[t] = T;
-        const int pi = d.poseIdx[t];
-        if (pi >= 0) { pose_oplus(T, xp + 6 * pi); d.pose[t] = T; }
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < d.K) {                                   // keyframe g
+        DPose T = d.pose[g];
+        poseBak[g] = T;
+        const int pi = d.poseIdx[g];
+        if (pi >= 0) { pose_oplus(T, xp + 6 * pi); d.pose[g] = T; }
     }
+    const int t = g >> 4, a = g & 15;                // landmark t, 16 lanes per landmark
     if (t >= d.P) return;
+    const int li = d.ptIdx[t];
+    double c[3] = {0, 0, 0};
+    if (li >= 0)
+        for (int s = ptStart[t] + a; s < ptStart[t + 1]; s += 16) {
+            const int e = ptEdges[s];
+            if (!d.active[e]) continue;
+            const int pi = d.poseIdx[d.ek[e]];
+            if (pi < 0) continue;
+            const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL;
+#pragma unroll
+            for (int q = 0; q < 3; q++) { double acc = 0; for (int r = 0; r < 6; r++) acc += B1[3 * r + q] * xp[6 * pi + r]; c[q] += acc; }
+        }
+#pragma unroll
+    for (int q = 0; q < 3; q++) c[q] = sum16(c[q]);
+    if (a != 0) return;
     double X[3] = {d.pt[3 * (size_t)t], d.pt[3 * (size_t)t + 1], d.pt[3 * (size_t)t + 2]};
     for (int i = 0; i < 3; i++) ptBak[3 * (size_t)t + i] = X[i];
-    const int li = d.ptIdx[t];
     if (li < 0) return;
-    double c[3] = {bl[(size_t)li * 3], bl[(size_t)li * 3 + 1], bl[(size_t)li * 3 + 2]};
-    for (int s = ptStart[t]; s < ptStart[t + 1]; s++) {
-        const int e = ptEdges[s];
-        if (!d.active[e]) continue;
-        const int pi = d.poseIdx[d.ek[e]];
-        if (pi < 0) continue;
-        const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL;
-        for (int q = 0; q < 3; q++) { double acc = 0; for (int r = 0; r < 6; r++) acc += B1[3 * r + q] * xp[6 * pi + r]; c[q] -= acc; }
-    }
+    for (int q = 0; q < 3; q++) c[q] = bl[(size_t)li * 3 + q] - c[q];
     const double *I = Dinv + (size_t)li * 9;
     for (int i = 0; i < 3; i++) {
         const double x = I[3 * i] * c[0] + I[3 * i + 1] * c[1] + I[3 * i + 2] * c[2];
@@ -1422,7 +1445,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
     ORBX_HIP_CHECK(hipMemcpyAsync(h->ptIdx.p, ptIdx.data(), (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream));
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     const int nP6 = 6 * nPose, nL3 = 3 * nPt;
-    const unsigned gE = (unsigned)((E + 255) / 256), gP = (unsigned)((P + 255) / 256);
+    const unsigned gE = (unsigned)((E + 255) / 256);
     double lambda = 0, ni = 2;
     int nBad = 0;
     bool ok = true;
@@ -1441,7 +1464,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
         }
         hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
         LCHECK();
-        hipLaunchKernelGGL(k_sum_points, dim3(gP), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p);
+        hipLaunchKernelGGL(k_sum_points, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p);
         LCHECK();
         hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->Hpp.p, h->bp.p);
         LCHECK();
@@ -1513,7 +1536,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
                 LCHECK();
                 h->flops += (double)nP6 * nP6 * nP6 / 3.0;
             }
-            hipLaunchKernelGGL(k_backsub_update, dim3((unsigned)((std::max(K, P) + 255) / 256)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->bl.p,
+            hipLaunchKernelGGL(k_backsub_update, dim3((unsigned)((std::max(K, 16 * P) + 255) / 256)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->bl.p,
                                h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p);
             LCHECK();
             h->flops += 250.0 * nAct;
