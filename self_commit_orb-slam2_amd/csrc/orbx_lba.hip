@@ -799,13 +799,22 @@ __global__ __launch_bounds__(192) void k_chol_panel(const double *__restrict__ S
     if (tid == 64) sBad = 0;
     // global memory is only touched by the whole workgroup, a row segment of 32 doubles per 32 threads (a thread walking its own row
     // makes every load instruction of the wave touch 64 different lines)
-    for (int idx = tid; idx < CNB * CNB; idx += 192) {
-        const int r = idx >> 5, c = idx & 31;
-        Ld[r][c] = (r < nb && c <= r) ? S[(size_t)(p0 + r) * n + p0 + c] : (r == c ? 1.0 : 0.0);   // identity pad past nb
-    }
-    for (int idx = tid; idx < 64 * CNB; idx += 192) {
-        const int r = idx >> 5, c = idx & 31;
-        Tt[r][c] = (r0 + r < n && c < nb) ? S[(size_t)(r0 + r) * n + p0 + c] : 0.0;
+    {   // all 17 loads of a thread in flight before the first LDS store (a load -> store loop pays the memory latency per iteration)
+        double vd[6], vt[11];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const int idx = tid + 192 * q, r = idx >> 5, c = idx & 31;
+            vd[q] = (idx < CNB * CNB && r < nb && c <= r) ? S[(size_t)(p0 + r) * n + p0 + c] : (r == c ? 1.0 : 0.0);   // identity pad past nb
+        }
+#pragma unroll
+        for (int q = 0; q < 11; q++) {
+            const int idx = tid + 192 * q, r = idx >> 5, c = idx & 31;
+            vt[q] = (idx < 64 * CNB && r0 + r < n && c < nb) ? S[(size_t)(r0 + r) * n + p0 + c] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) { const int idx = tid + 192 * q; if (idx < CNB * CNB) Ld[idx >> 5][idx & 31] = vd[q]; }
+#pragma unroll
+        for (int q = 0; q < 11; q++) { const int idx = tid + 192 * q; if (idx < 64 * CNB) Tt[idx >> 5][idx & 31] = vt[q]; }
     }
     if (tid < CNB) Tt[64][tid] = tid < nb ? ywork[p0 + tid] : 0.0;
     __syncthreads();
