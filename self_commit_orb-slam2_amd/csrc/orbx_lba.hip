@@ -739,10 +739,11 @@ __global__ __launch_bounds__(1024) void k_chol_solve(double *S, const double *bs
 // ---------------------------------------------------------------------------------------------
 // Multi-workgroup right-looking Cholesky for the larger reduced systems (n >= CHOL_MULTI_MIN_N): the
 // single-workgroup kernel above is latency bound (one CU, ~20 barriers per panel); here every panel
-// step is two launches on the same stream,
-//   k_chol_panel   each workgroup factors the 32x32 diagonal block redundantly, solves 64 rows of the panel
-//                  below it against L11 and applies the panel to the right-hand side;
-//   k_chol_update  trailing matrix -= L21 L21^T, one 32x32 tile of the lower triangle per workgroup,
+// step is ONE launch (k_chol_step) in which
+//   the panel workgroups    factor the 32x32 diagonal block (each redundantly), solve 64 rows of the panel below it against L11
+//                           and apply the panel to the right-hand side,
+//   the other workgroups    subtract the PREVIOUS panel's L21 L21^T from the trailing matrix beyond this block column, one 32x32
+//                           tile of the lower triangle each,
 // and the substitution L^T x = y is one last single-workgroup kernel.  L is written to its own buffer
 // (workgroups read the diagonal block of S while workgroup 0 stores L11), the solved part of y likewise.
 // ---------------------------------------------------------------------------------------------
@@ -788,36 +789,108 @@ __device__ __forceinline__ double pivot_rsqrt(double x)
     return y;
 }
 
-__global__ __launch_bounds__(192) void k_chol_panel(const double *__restrict__ S, double *__restrict__ L, int n, int p0, double *ywork, double *ysol, int *okFlag)
+// One step of the factorisation = ONE launch with two kinds of workgroups:
+//   blocks [0, nPW)   PANEL of block column p: first apply the previous panel's update to their own part of the column
+//                     (S[rows, p] -= L[rows, p-1] L[p-rows, p-1]^T, a 4x4 register tile per thread out of LDS), then factor the
+//                     diagonal block and solve the rows below as described above;
+//   the other blocks  the REST of the previous panel's trailing update, block columns > p, one 32x32 tile each.
+// The two kinds touch disjoint parts of S and only read L[:, p-1], so they need no order between them: the trailing update no
+// longer sits between two panels (15 dependent launches per factorisation become 8) and runs while the panel's serial chain does.
+__global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, double *__restrict__ L, int n, int p0, int nPW, int T1, double *ywork, double *ysol, int *okFlag)
 {
-    __shared__ double Ld[CNB][CNB + 1];      // diagonal block in, L11 (lower incl. diagonal) out
-    __shared__ double Tt[65][CNB + 1];       // this workgroup's 64 rows of the panel below + the right-hand side as row 64: in and out
+    __shared__ double Ld[CNB][CNB + 1];      // diagonal block in, L11 (lower incl. diagonal) out      | update role: la
+    __shared__ double Tt[65][CNB + 1];       // 64 rows of the panel below + the right-hand side (row 64) | update role: lb (first 32 rows)
+    __shared__ double LpD[CNB][CNB + 1];     // previous panel, rows of this diagonal block
+    __shared__ double LpR[64][CNB + 1];      // previous panel, this workgroup's rows
     __shared__ double sinv[CNB];             // 1 / L11[c][c]
     __shared__ int sBad;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nb = min(CNB, n - p0);
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= nPW) {
+        // ---- rest of the trailing update of the previous panel (q0 = p0 - 32): tiles (I, K), I >= K >= 1, relative to row/column p0
+        const int u = (int)blockIdx.x - nPW, K = 1 + u % T1, I = 1 + u / T1;
+        if (K > I) return;
+        const int q0 = p0 - CNB;
+        double(*la)[CNB + 1] = Ld;
+        double(*lb)[CNB + 1] = Tt;
+        for (int idx = tid; idx < CNB * CNB; idx += 256) {
+            const int r = idx >> 5, c = idx & 31;
+            const int ra = p0 + CNB * I + r, rb = p0 + CNB * K + r;
+            la[r][c] = ra < n ? L[(size_t)ra * n + q0 + c] : 0.0;
+            lb[r][c] = rb < n ? L[(size_t)rb * n + q0 + c] : 0.0;
+        }
+        __syncthreads();
+        const int ti = (tid >> 4) * 2, tk = (tid & 15) * 2;
+        double acc[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll 8
+        for (int c = 0; c < CNB; c++) {
+            const double a0 = la[ti][c], a1 = la[ti + 1][c], b0 = lb[tk][c], b1 = lb[tk + 1][c];
+            acc[0][0] = __builtin_fma(a0, b0, acc[0][0]); acc[0][1] = __builtin_fma(a0, b1, acc[0][1]);
+            acc[1][0] = __builtin_fma(a1, b0, acc[1][0]); acc[1][1] = __builtin_fma(a1, b1, acc[1][1]);
+        }
+#pragma unroll
+        for (int uu = 0; uu < 2; uu++)
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+                const int row = p0 + CNB * I + ti + uu, col = p0 + CNB * K + tk + w;
+                if (row < n && col <= row) S[(size_t)row * n + col] -= acc[uu][w];
+            }
+        return;
+    }
+    // ---- panel of block column p
+    const int wave = tid >> 6, lane = tid & 63, nb = min(CNB, n - p0);
     const int r0 = p0 + nb + blockIdx.x * 64;   // first row of this workgroup's part of the panel below
+    const bool hasPrev = p0 > 0;
     if (tid == 64) sBad = 0;
-    // global memory is only touched by the whole workgroup, a row segment of 32 doubles per 32 threads (a thread walking its own row
-    // makes every load instruction of the wave touch 64 different lines)
-    {   // all 17 loads of a thread in flight before the first LDS store (a load -> store loop pays the memory latency per iteration)
-        double vd[6], vt[11];
+    {   // global memory is only touched by the whole workgroup, a row segment of 32 doubles per 32 threads, all loads of a thread in
+        // flight before its first LDS store
+        double vd[4], vt[8], pd[4], pr[8];
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const int idx = tid + 192 * q, r = idx >> 5, c = idx & 31;
-            vd[q] = (idx < CNB * CNB && r < nb && c <= r) ? S[(size_t)(p0 + r) * n + p0 + c] : (r == c ? 1.0 : 0.0);   // identity pad past nb
+        for (int q = 0; q < 4; q++) {
+            const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
+            vd[q] = (r < nb && c <= r) ? S[(size_t)(p0 + r) * n + p0 + c] : (r == c ? 1.0 : 0.0);   // identity pad past nb
+            pd[q] = (hasPrev && r < nb) ? L[(size_t)(p0 + r) * n + p0 - CNB + c] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 11; q++) {
-            const int idx = tid + 192 * q, r = idx >> 5, c = idx & 31;
-            vt[q] = (idx < 64 * CNB && r0 + r < n && c < nb) ? S[(size_t)(r0 + r) * n + p0 + c] : 0.0;
+        for (int q = 0; q < 8; q++) {
+            const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
+            vt[q] = (r0 + r < n && c < nb) ? S[(size_t)(r0 + r) * n + p0 + c] : 0.0;
+            pr[q] = (hasPrev && r0 + r < n) ? L[(size_t)(r0 + r) * n + p0 - CNB + c] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 6; q++) { const int idx = tid + 192 * q; if (idx < CNB * CNB) Ld[idx >> 5][idx & 31] = vd[q]; }
+        for (int q = 0; q < 4; q++) { const int idx = tid + 256 * q; Ld[idx >> 5][idx & 31] = vd[q]; LpD[idx >> 5][idx & 31] = pd[q]; }
 #pragma unroll
-        for (int q = 0; q < 11; q++) { const int idx = tid + 192 * q; if (idx < 64 * CNB) Tt[idx >> 5][idx & 31] = vt[q]; }
+        for (int q = 0; q < 8; q++) { const int idx = tid + 256 * q; Tt[idx >> 5][idx & 31] = vt[q]; LpR[idx >> 5][idx & 31] = pr[q]; }
     }
     if (tid < CNB) Tt[64][tid] = tid < nb ? ywork[p0 + tid] : 0.0;
     __syncthreads();
+    if (hasPrev && tid < 192) {   // own part of the previous panel's update: 4x4 tile per thread (128 threads: the 64 rows, 64 threads: the diagonal block)
+        const bool isD = tid >= 128;
+        const int t2 = isD ? tid - 128 : tid;
+        const int tr = (t2 >> 3) * 4, tc = (t2 & 7) * 4;
+        double acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int jx = 0; jx < 4; jx++) acc[i][jx] = 0;
+#pragma unroll 4
+        for (int k = 0; k < CNB; k++) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { av[i] = isD ? LpD[tr + i][k] : LpR[tr + i][k]; bv[i] = LpD[tc + i][k]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int jx = 0; jx < 4; jx++) acc[i][jx] = __builtin_fma(av[i], bv[jx], acc[i][jx]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int jx = 0; jx < 4; jx++) {
+                if (isD) { if (tc + jx <= tr + i && tr + i < nb) Ld[tr + i][tc + jx] -= acc[i][jx]; }
+                else if (tc + jx < nb) Tt[tr + i][tc + jx] -= acc[i][jx];
+            }
+    }
+    if (hasPrev) __syncthreads();
     double x[CNB];
     const int j = tid - 64;                      // row thread: 0..63 panel rows, 64 = right-hand side
     const bool isRow = j >= 0 && j < 64 && r0 + j < n, isRhs = j == 64;
@@ -870,48 +943,18 @@ __global__ __launch_bounds__(192) void k_chol_panel(const double *__restrict__ S
         for (int c = 0; c < CNB; c++) dot += x[c] * Tt[64][c];
         ywork[r0 + j] -= dot;
     }
-    for (int idx = tid; idx < 64 * CNB; idx += 192) {
+    for (int idx = tid; idx < 64 * CNB; idx += 256) {
         const int r = idx >> 5, c = idx & 31;
         if (r0 + r < n && c < nb) L[(size_t)(r0 + r) * n + p0 + c] = Tt[r][c];
     }
     if (blockIdx.x == 0) {      // L11 and the solved right-hand side of this panel
-        for (int idx = tid; idx < CNB * CNB; idx += 192) {
+        for (int idx = tid; idx < CNB * CNB; idx += 256) {
             const int r = idx >> 5, c = idx & 31;
             if (r < nb && c <= r) L[(size_t)(p0 + r) * n + p0 + c] = Ld[r][c];
         }
         if (tid < nb) ysol[p0 + tid] = Tt[64][tid];
         if (sBad && tid == 0) *okFlag = 0;   // not positive definite: the results are discarded by the host
     }
-}
-
-__global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ S, const double *__restrict__ L, int n, int p0)
-{
-    const int I = blockIdx.y, K = blockIdx.x;
-    if (K > I) return;
-    __shared__ double la[CNB][CNB + 1], lb[CNB][CNB + 1];
-    const int base = p0 + CNB, tid = threadIdx.x;   // an update only follows a full panel
-    for (int idx = tid; idx < CNB * CNB; idx += 256) {
-        const int r = idx >> 5, c = idx & 31;
-        const int ra = base + CNB * I + r, rb = base + CNB * K + r;
-        la[r][c] = ra < n ? L[(size_t)ra * n + p0 + c] : 0.0;
-        lb[r][c] = rb < n ? L[(size_t)rb * n + p0 + c] : 0.0;
-    }
-    __syncthreads();
-    const int ti = (tid >> 4) * 2, tk = (tid & 15) * 2;
-    double acc[2][2] = {{0, 0}, {0, 0}};
-#pragma unroll 8
-    for (int c = 0; c < CNB; c++) {
-        const double a0 = la[ti][c], a1 = la[ti + 1][c], b0 = lb[tk][c], b1 = lb[tk + 1][c];
-        acc[0][0] = __builtin_fma(a0, b0, acc[0][0]); acc[0][1] = __builtin_fma(a0, b1, acc[0][1]);
-        acc[1][0] = __builtin_fma(a1, b0, acc[1][0]); acc[1][1] = __builtin_fma(a1, b1, acc[1][1]);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int w = 0; w < 2; w++) {
-            const int row = base + CNB * I + ti + u, col = base + CNB * K + tk + w;
-            if (row < n && col <= row) S[(size_t)row * n + col] -= acc[u][w];
-        }
 }
 
 // L^T x = y, panels from the last to the first; x in LDS
@@ -1517,12 +1560,10 @@ int optimize(Ctx &c, int iterations, double stats[4])
                     hipLaunchKernelGGL(k_chol_prep, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, h->stream, h->S.p, h->bs.p, n, h->ywork.p, h->okFlag.p);
                     for (int p0 = 0; p0 < n; p0 += CNB) {
                         const int nb = std::min(CNB, n - p0), below = n - p0 - nb;
-                        hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)std::max(1, (below + 63) / 64)), dim3(192), 0, h->stream, h->S.p, h->Lmat.p, n, p0, h->ywork.p,
+                        const int nPW = std::max(1, (below + 63) / 64);
+                        const int T1 = p0 > 0 ? (n - p0 + CNB - 1) / CNB - 1 : 0;        // tile rows / columns beyond block column p that still await the previous panel's update
+                        hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nPW + T1 * T1)), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0, nPW, std::max(T1, 1), h->ywork.p,
                                            h->ysol.p, h->okFlag.p);
-                        if (below > 0) {
-                            const unsigned T = (unsigned)((below + CNB - 1) / CNB);
-                            hipLaunchKernelGGL(k_chol_update, dim3(T, T), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0);
-                        }
                     }
                     if (n <= CHOL_LDS_X) hipLaunchKernelGGL(k_chol_backsub<false>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
                     else hipLaunchKernelGGL(k_chol_backsub<true>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
