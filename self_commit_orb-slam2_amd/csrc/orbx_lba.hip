@@ -1550,7 +1550,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
                     hipLaunchKernelGGL(k_schur_rows<true>, dim3((unsigned)K, 16u), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, h->bs.p);
                 } else {
                     if (ldsRows > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
-                    hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, 16u), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, h->bs.p);
+                    hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, 32u), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, h->bs.p);
                 }
                 LCHECK();
             }
