@@ -367,23 +367,51 @@ __global__ __launch_bounds__(1024) void k_scale(const double *x, const double *b
     if (threadIdx.x == 0) out[0] = s[0];
 }
 
-// The three reductions an LM trial ends with, in ONE launch and with the summation orders of k_reduce / k_scale (so the values are
-// the same bits): out[0] = sum rchi (activeRobustChi2), out[4] = sum xp (lambda xp + bp), out[5] = sum xl (lambda xl + bl).
-__global__ __launch_bounds__(1024) void k_trial_reduce(const double *rchi, int E, const double *xp, const double *bp, int nP6, const double *xl, const double *bl,
-                                                       int nL3, double lambda, double *out)
+// The three reductions an LM trial ends with, in ONE launch: out[0] = sum rchi (activeRobustChi2), out[4] = sum xp (lambda xp + bp),
+// out[5] = sum xl (lambda xl + bl).  TR_BLOCKS workgroups sum contiguous chunks (fixed order: thread-strided partial sums, wave
+// butterfly, waves in order), the last one to finish adds the TR_BLOCKS partials in block order - deterministic, one launch, and 60k
+// values are no longer walked by a single workgroup (22 us before).  scratch: 3 * TR_BLOCKS doubles + one counter behind them.
+#define TR_BLOCKS 48
+__device__ __forceinline__ double wave_sum(double x)
 {
-    __shared__ double s0[1024], s1[1024], s2[1024];
-    double a = 0, b = 0, c = 0;
-    for (int i = threadIdx.x; i < E; i += 1024) a += rchi[i];
-    for (int i = threadIdx.x; i < nP6; i += 1024) b += xp[i] * (lambda * xp[i] + bp[i]);
-    for (int i = threadIdx.x; i < nL3; i += 1024) c += xl[i] * (lambda * xl[i] + bl[i]);
-    s0[threadIdx.x] = a; s1[threadIdx.x] = b; s2[threadIdx.x] = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+__global__ __launch_bounds__(256) void k_trial_reduce(const double *rchi, int E, const double *xp, const double *bp, int nP6, const double *xl, const double *bl,
+                                                      int nL3, double lambda, double *out, double *scratch)
+{
+    __shared__ double sw[3][4];
+    __shared__ int sLast;
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto chunk = [&](int n, int &lo, int &hi) { const int per = (n + TR_BLOCKS - 1) / TR_BLOCKS; lo = min(n, b * per); hi = min(n, lo + per); };
+    int lo, hi;
+    double v0 = 0, v1 = 0, v2 = 0;
+    chunk(E, lo, hi);
+    for (int i = lo + tid; i < hi; i += 256) v0 += rchi[i];
+    chunk(nP6, lo, hi);
+    for (int i = lo + tid; i < hi; i += 256) v1 += xp[i] * (lambda * xp[i] + bp[i]);
+    chunk(nL3, lo, hi);
+    for (int i = lo + tid; i < hi; i += 256) v2 += xl[i] * (lambda * xl[i] + bl[i]);
+    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
+    if (lane == 0) { sw[0][wave] = v0; sw[1][wave] = v1; sw[2][wave] = v2; }
     __syncthreads();
-    for (int k = 512; k > 0; k >>= 1) {
-        if ((int)threadIdx.x < k) { s0[threadIdx.x] += s0[threadIdx.x + k]; s1[threadIdx.x] += s1[threadIdx.x + k]; s2[threadIdx.x] += s2[threadIdx.x + k]; }
-        __syncthreads();
+    if (tid < 3) scratch[tid * TR_BLOCKS + b] = sw[tid][0] + sw[tid][1] + sw[tid][2] + sw[tid][3];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int *cnt = (unsigned int *)(scratch + 3 * TR_BLOCKS);
+        sLast = atomicAdd(cnt, 1u) == TR_BLOCKS - 1;
     }
-    if (threadIdx.x == 0) { out[0] = s0[0]; out[4] = s1[0]; out[5] = s2[0]; }
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();
+    if (tid < 3) {
+        double t = 0;
+        for (int k = 0; k < TR_BLOCKS; k++) t += __hip_atomic_load(scratch + tid * TR_BLOCKS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[tid == 0 ? 0 : 3 + tid] = t;
+    }
+    if (tid == 0) *(unsigned int *)(scratch + 3 * TR_BLOCKS) = 0u;   // ready for the next launch (stream order)
 }
 
 // computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180): out[2] = max |diagonal entry| over the pose and landmark blocks
@@ -1402,7 +1430,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     rc = rc ? rc : h->intr.ensure(5 * K); rc = rc ? rc : h->obs.ensure(3 * E); rc = rc ? rc : h->info.ensure(E); rc = rc ? rc : h->err.ensure(3 * E);
     rc = rc ? rc : h->rchi.ensure(E); rc = rc ? rc : h->edgeBlk.ensure(E * EB_SIZE); rc = rc ? rc : h->Hpp.ensure(36 * K); rc = rc ? rc : h->bp.ensure(n6);
     rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->Ddb.ensure(3 * P); rc = rc ? rc : h->ywork.ensure(n6); rc = rc ? rc : h->ysol.ensure(n6);
-    rc = rc ? rc : h->bs.ensure(n6); rc = rc ? rc : h->xp.ensure(n6); rc = rc ? rc : h->xl.ensure(3 * P); rc = rc ? rc : h->red.ensure(16);
+    rc = rc ? rc : h->bs.ensure(n6); rc = rc ? rc : h->xp.ensure(n6); rc = rc ? rc : h->xl.ensure(3 * P); rc = rc ? rc : h->red.ensure(16 + 3 * TR_BLOCKS + 2);
     rc = rc ? rc : h->ep.ensure(E); rc = rc ? rc : h->ek.ensure(E); rc = rc ? rc : h->ptStart.ensure(P + 1); rc = rc ? rc : h->ptEdges.ensure(E);
     rc = rc ? rc : h->kfStart.ensure(K + 1); rc = rc ? rc : h->kfEdges.ensure(E); rc = rc ? rc : h->poseIdx.ensure(K); rc = rc ? rc : h->ptIdx.ensure(P);
     rc = rc ? rc : h->okFlag.ensure(1); rc = rc ? rc : h->stereo.ensure(E); rc = rc ? rc : h->active.ensure(E);
@@ -1592,7 +1620,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
             h->flops += 250.0 * nAct;
             hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
             LCHECK();
-            hipLaunchKernelGGL(k_trial_reduce, dim3(1), dim3(1024), 0, h->stream, h->rchi.p, E, h->xp.p, h->bp.p, nP6, h->xl.p, h->bl.p, nL3, lambda, h->red.p);
+            hipLaunchKernelGGL(k_trial_reduce, dim3(TR_BLOCKS), dim3(256), 0, h->stream, h->rchi.p, E, h->xp.p, h->bp.p, nP6, h->xl.p, h->bl.p, nL3, lambda, h->red.p, h->red.p + 16);
             LCHECK();
             ORBX_HIP_CHECK(hipMemcpyAsync(h->hostRed, h->red.p, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             if (nP6 > 0) ORBX_HIP_CHECK(hipMemcpyAsync(h->hostRed + 8, h->okFlag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1718,6 +1746,7 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     ORBX_HIP_CHECK(hipMemcpyAsync(h->kfStart.p, kfStart, ((size_t)K + 1) * 4, hipMemcpyHostToDevice, s));
     ORBX_HIP_CHECK(hipMemcpyAsync(h->kfEdges.p, kfEdges, (size_t)E * 4, hipMemcpyHostToDevice, s));
     ORBX_HIP_CHECK(hipMemsetAsync(h->err.p, 0, (size_t)E * 3 * 8, s));
+    ORBX_HIP_CHECK(hipMemsetAsync(h->red.p + 16 + 3 * TR_BLOCKS, 0, 2 * sizeof(double), s));   // k_trial_reduce's arrival counter
     ORBX_HIP_CHECK(hipStreamSynchronize(s));     // the pinned buffer is reused for the results below
     LbaDev &d = c.d;
     d.K = K; d.P = P; d.E = E; d.pose = h->pose.p; d.pt = h->pt.p; d.intr = h->intr.p; d.ep = h->ep.p; d.ek = h->ek.p; d.obs = h->obs.p;
