@@ -1141,8 +1141,38 @@ template <int N> __device__ inline void po_block_reduce(double (&v)[N], double (
     __syncthreads();
 }
 
+// The 28 sums of an iteration (21 entries of H, 6 of b, chi2) through a transposed LDS tile instead of 28 x 6 double shuffles per thread
+// (6 us of an 11 us iteration): thread t stores its 28 values at [k][t], 224 threads add 32 consecutive entries each, 28 threads
+// add the 8 parts - fixed order, three barriers, no cross-lane traffic.  Index (k, t) -> k * 264 + (t >> 5) * 33 + (t & 31).
+#define PO_TP 264
+__device__ __forceinline__ void po_block_reduce28(const double (&v)[PO_NRED], double *redT, double (*part)[9], double (*red)[PO_NRED], int tid)
+{
+    const int slot = (tid >> 5) * 33 + (tid & 31);
+#pragma unroll
+    for (int k = 0; k < 28; k++) redT[k * PO_TP + slot] = v[k];
+    __syncthreads();
+    if (tid < 224) {
+        const int k = tid >> 3, p = tid & 7;
+        const double *src = redT + k * PO_TP + p * 33;
+        double sacc = 0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) sacc += src[i];
+        part[k][p] = sacc;
+    }
+    __syncthreads();
+    if (tid < 28) {
+        double sacc = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) sacc += part[tid][q];
+        red[0][tid] = sacc;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
 {
+    __shared__ double redT[28 * PO_TP];
+    __shared__ double part28[28][9];
     __shared__ DPose pose, savePose;
     __shared__ double red[4][PO_NRED];
     __shared__ double sH[36], sb[6], sx[6];
@@ -1239,7 +1269,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     acc[21 + i] += sacc;
                 }
             }
-            po_block_reduce(acc, red, tid);
+            po_block_reduce28(acc, redT, part28, red, tid);
             if (tid == 0) {
                 int k = 0;
                 for (int i = 0; i < 6; i++)
@@ -1267,7 +1297,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     for (int i = 0; i < 36; i++) A[i] = sH[i];
 #pragma unroll
                     for (int i = 0; i < 6; i++) A[7 * i] += sLambda;
-                    double Dg[6];
+                    double Dg[6], Di[6];   // pivots and their reciprocals (6 divisions instead of 21 on this one-thread chain)
                     bool ok = true;
 #pragma unroll
                     for (int j = 0; j < 6; j++) {
@@ -1276,12 +1306,13 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                         for (int k = 0; k < j; k++) dj -= A[6 * j + k] * A[6 * j + k] * Dg[k];
                         ok = ok && (dj > 0) && isfinite(dj);
                         Dg[j] = dj;
+                        Di[j] = 1.0 / dj;
 #pragma unroll
                         for (int i = j + 1; i < 6; i++) {
                             double lij = A[6 * i + j];
 #pragma unroll
                             for (int k = 0; k < j; k++) lij -= A[6 * i + k] * A[6 * j + k] * Dg[k];
-                            A[6 * i + j] = lij / dj;
+                            A[6 * i + j] = lij * Di[j];
                         }
                     }
                     double xx[6];
@@ -1293,7 +1324,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                         xx[i] = sacc;
                     }
 #pragma unroll
-                    for (int i = 0; i < 6; i++) xx[i] /= Dg[i];
+                    for (int i = 0; i < 6; i++) xx[i] *= Di[i];
 #pragma unroll
                     for (int i = 5; i >= 0; i--) {
                         double sacc = xx[i];
