@@ -481,11 +481,13 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
     if (M > ORBX_PT_CAP) { if (tid == 0) { atomicOr(stat, ORBX_DEV_ERR_PTCAP); atomicOr(statAll, ORBX_DEV_ERR_PTCAP); } M = ORBX_PT_CAP; }
     {
         const uint32_t *slots = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase;
-        // one wave per cell keeps the copy coalesced
-        for (int c = wave; c < ncell; c += 4) {
-            int n = cc[c], o = cellOff[c];
-            for (int k = lane; k < n; k += 64)
-                if (o + k < ORBX_PT_CAP) P[0][o + k] = slots[(size_t)c * lv.cellCap + k];
+        // one THREAD per cell: a cell holds a handful of candidates, and a wave walking the cells one after the other pays a memory
+        // round trip per cell (84 dependent round trips for the 336 cells of a 640x480 level: 33 us of a single frame's 100 us quadtree)
+        for (int c = tid; c < ncell; c += 256) {
+            const int n = cc[c], o = cellOff[c];
+            const uint32_t *sc = slots + (size_t)c * lv.cellCap;
+            for (int k = 0; k < n; k++)
+                if (o + k < ORBX_PT_CAP) P[0][o + k] = sc[k];
         }
     }
     __syncthreads();
@@ -560,19 +562,34 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
             itemCand[it] = (unsigned short)lo;
         }
         __syncthreads();
-        // S3: quadrant counts per chunk
-        for (int it = wave; it < nItems; it += 4) {
-            const int r = itemCand[it];
-            const OtNode nd = L[candNode[r]];
-            const int k = it - candItemBase[r];
-            const int j = k * 64 + lane;
-            const uint32_t *src = P[(unsigned)nd.start >> 31] + (nd.start & 0x7fffffff);
-            const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-            int q = -1;
-            if (j < nd.cnt) { uint32_t p = src[j]; int x = p & 0xfff, y = (p >> 12) & 0xfff; q = (x < mx ? 0 : 1) + (y < my ? 0 : 2); }
-            unsigned long long t = 0;
-            for (int Q = 0; Q < 4; Q++) t |= (unsigned long long)__popcll(__ballot(q == Q)) << (16 * Q);
-            if (lane == 0) itemScan[it] = t;
+        // S3: quadrant counts per chunk; a wave takes four chunks at a time so that their (independent) point loads are in flight together
+        for (int it0 = wave; it0 < nItems; it0 += 16) {
+            uint32_t pv[4];
+            int qv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int it = it0 + 4 * u;
+                pv[u] = 0; qv[u] = -2;
+                if (it < nItems) {
+                    const int r = itemCand[it];
+                    const OtNode nd = L[candNode[r]];
+                    const int j = (it - candItemBase[r]) * 64 + lane;
+                    qv[u] = -1;
+                    if (j < nd.cnt) { pv[u] = (P[(unsigned)nd.start >> 31] + (nd.start & 0x7fffffff))[j]; qv[u] = 0; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int it = it0 + 4 * u;
+                if (qv[u] == -2) continue;       // wave-uniform
+                const OtNode nd = L[candNode[itemCand[it]]];
+                const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+                int q = -1;
+                if (qv[u] == 0) { const int x = pv[u] & 0xfff, y = (pv[u] >> 12) & 0xfff; q = (x < mx ? 0 : 1) + (y < my ? 0 : 2); }
+                unsigned long long t = 0;
+                for (int Q = 0; Q < 4; Q++) t |= (unsigned long long)__popcll(__ballot(q == Q)) << (16 * Q);
+                if (lane == 0) itemScan[it] = t;
+            }
         }
         if (tid == 0) itemScan[nItems] = 0;   // becomes the grand total after the exclusive scan
         __syncthreads();
@@ -665,27 +682,44 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
             }
         }
         if (myExpand) atomicAdd(&sh_misc[2], myExpand);
-        // S8: scatter the points of the selected candidates into their children
-        for (int it = wave; it < nItems; it += 4) {
-            const int r = itemCand[it];
-            if (!selFlag[r]) continue;
-            const OtNode nd = L[candNode[r]];
-            const int k = it - candItemBase[r];
-            const int j = k * 64 + lane;
-            const int sb = (unsigned)nd.start >> 31, so = nd.start & 0x7fffffff;
-            const uint32_t *src = P[sb] + so;
-            uint32_t *dst = P[sb ^ 1] + so;
-            const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-            int q = -1;
-            uint32_t p = 0;
-            if (j < nd.cnt) { p = src[j]; int x = p & 0xfff, y = (p >> 12) & 0xfff; q = (x < mx ? 0 : 1) + (y < my ? 0 : 2); }
-            const unsigned long long rel = itemScan[it] - itemScan[candItemBase[r]];
-            const unsigned long long t = candTot[r];
-            int qoff = 0;
-            for (int Q = 0; Q < 4; Q++) {
-                unsigned long long m = __ballot(q == Q);
-                if (q == Q) dst[qoff + (int)((rel >> (16 * Q)) & 0xffff) + __popcll(m & ((1ull << lane) - 1ull))] = p;
-                qoff += (int)((t >> (16 * Q)) & 0xffff);
+        // S8: scatter the points of the selected candidates into their children (four chunks per wave in flight, as in S3)
+        for (int it0 = wave; it0 < nItems; it0 += 16) {
+            uint32_t pv[4];
+            int qv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int it = it0 + 4 * u;
+                pv[u] = 0; qv[u] = -2;
+                if (it < nItems) {
+                    const int r = itemCand[it];
+                    if (selFlag[r]) {
+                        const OtNode nd = L[candNode[r]];
+                        const int j = (it - candItemBase[r]) * 64 + lane;
+                        qv[u] = -1;
+                        if (j < nd.cnt) { pv[u] = (P[(unsigned)nd.start >> 31] + (nd.start & 0x7fffffff))[j]; qv[u] = 0; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int it = it0 + 4 * u;
+                if (qv[u] == -2) continue;       // wave-uniform: no chunk, or its candidate is not split in this round
+                const int r = itemCand[it];
+                const OtNode nd = L[candNode[r]];
+                const int sb = (unsigned)nd.start >> 31, so = nd.start & 0x7fffffff;
+                uint32_t *dst = P[sb ^ 1] + so;
+                const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+                int q = -1;
+                const uint32_t p = pv[u];
+                if (qv[u] == 0) { const int x = p & 0xfff, y = (p >> 12) & 0xfff; q = (x < mx ? 0 : 1) + (y < my ? 0 : 2); }
+                const unsigned long long rel = itemScan[it] - itemScan[candItemBase[r]];
+                const unsigned long long t = candTot[r];
+                int qoff = 0;
+                for (int Q = 0; Q < 4; Q++) {
+                    unsigned long long m = __ballot(q == Q);
+                    if (q == Q) dst[qoff + (int)((rel >> (16 * Q)) & 0xffff) + __popcll(m & ((1ull << lane) - 1ull))] = p;
+                    qoff += (int)((t >> (16 * Q)) & 0xffff);
+                }
             }
         }
         __syncthreads();
