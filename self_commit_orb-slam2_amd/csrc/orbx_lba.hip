@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -185,18 +186,37 @@ __device__ inline void huber_rho(const Huber &h, bool stereo, double chi, double
     else { const double s = sqrt(chi); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
 }
 
-__global__ __launch_bounds__(256) void k_errors(LbaDev d, Huber h, int robust)
+// sum over the workgroup in a fixed order (lanes by butterfly, the four waves in order); the result is valid in thread 0
+__device__ __forceinline__ double block_sum256(double v, double *sw /* 4 */)
 {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sw[0] + sw[1] + sw[2] + sw[3];
+}
+
+// partChi[blockIdx.x] = this workgroup's share of activeRobustChi2 (summed in block order by k_trial_finish)
+__global__ __launch_bounds__(256) void k_errors(LbaDev d, Huber h, int robust, double *partChi)
+{
+    __shared__ double sw[4];
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= d.E) return;
-    if (!d.active[e]) { d.rchi[e] = 0; return; }   // _error of inactive edges stays as last computed
-    double r[3];
-    edge_error(d, e, r, nullptr);
-    d.err[3 * (size_t)e] = r[0]; d.err[3 * (size_t)e + 1] = r[1]; d.err[3 * (size_t)e + 2] = r[2];
-    const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * d.info[e];
-    double r0 = chi, r1 = 1;
-    if (robust) huber_rho(h, d.stereo[e] != 0, chi, r0, r1);
-    d.rchi[e] = r0;
+    double r0 = 0;
+    if (e < d.E) {
+        if (!d.active[e]) d.rchi[e] = 0;   // _error of inactive edges stays as last computed
+        else {
+            double r[3];
+            edge_error(d, e, r, nullptr);
+            d.err[3 * (size_t)e] = r[0]; d.err[3 * (size_t)e + 1] = r[1]; d.err[3 * (size_t)e + 2] = r[2];
+            const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * d.info[e];
+            double r1 = 1;
+            r0 = chi;
+            if (robust) huber_rho(h, d.stereo[e] != 0, chi, r0, r1);
+            d.rchi[e] = r0;
+        }
+    }
+    const double t = block_sum256(r0, sw);
+    if (threadIdx.x == 0) partChi[blockIdx.x] = t;
 }
 
 // linearizeOplus (.cpp:103-139, 188-234) + constructQuadraticForm (base_binary_edge.hpp:55-119)
@@ -340,78 +360,68 @@ __global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart,
     }
 }
 
-// deterministic sum / max of an array with one workgroup: out[0] = sum, out[1] = max|.|
-__global__ __launch_bounds__(1024) void k_reduce(const double *v, int n, int stride, int offset, double *out)
-{
-    __shared__ double s[1024], m[1024];
-    double a = 0, b = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) { const double x = v[(size_t)i * stride + offset]; a += x; b = fmax(b, fabs(x)); }
-    s[threadIdx.x] = a; m[threadIdx.x] = b;
-    __syncthreads();
-    for (int k = 512; k > 0; k >>= 1) {
-        if ((int)threadIdx.x < k) { s[threadIdx.x] += s[threadIdx.x + k]; m[threadIdx.x] = fmax(m[threadIdx.x], m[threadIdx.x + k]); }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { out[0] = s[0]; out[1] = m[0]; }
-}
-
-// computeScale (optimization_algorithm_levenberg.cpp:182-189): sum x (lambda x + b) over one vector
-__global__ __launch_bounds__(1024) void k_scale(const double *x, const double *b, int n, double lambda, double *out)
-{
-    __shared__ double s[1024];
-    double a = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) a += x[i] * (lambda * x[i] + b[i]);
-    s[threadIdx.x] = a;
-    __syncthreads();
-    for (int k = 512; k > 0; k >>= 1) { if ((int)threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k]; __syncthreads(); }
-    if (threadIdx.x == 0) out[0] = s[0];
-}
-
-// The three reductions an LM trial ends with, in ONE launch: out[0] = sum rchi (activeRobustChi2), out[4] = sum xp (lambda xp + bp),
-// out[5] = sum xl (lambda xl + bl).  TR_BLOCKS workgroups sum contiguous chunks (fixed order: thread-strided partial sums, wave
-// butterfly, waves in order), the last one to finish adds the TR_BLOCKS partials in block order - deterministic, one launch, and 60k
-// values are no longer walked by a single workgroup (22 us before).  scratch: 3 * TR_BLOCKS doubles + one counter behind them.
-#define TR_BLOCKS 48
+// The three sums an LM trial ends with: host[0] = sum rchi (activeRobustChi2), host[4] = sum xp (lambda xp + bp), host[5] = sum xl (lambda
+// xl + bl), host[8] = the Cholesky flag.  k_errors and k_backsub_update leave one partial per workgroup; this single workgroup adds them
+// in block order (deterministic) and writes the results STRAIGHT INTO PINNED HOST MEMORY, the sequence number last (after a system-scope
+// fence): the host polls that word instead of queueing a device-to-host copy and synchronising the stream (a copy kernel, two API calls
+// and ~15 us of idle GPU per trial before).
 __device__ __forceinline__ double wave_sum(double x)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
     return x;
 }
-__global__ __launch_bounds__(256) void k_trial_reduce(const double *rchi, int E, const double *xp, const double *bp, int nP6, const double *xl, const double *bl,
-                                                      int nL3, double lambda, double *out, double *scratch)
+__global__ __launch_bounds__(256) void k_trial_finish(const double *partChi, int nChi, const double *partL, int nL, const double *xp, const double *bp, int nP6,
+                                                      double lambda, const int *okFlag, const double *diagMax, double *host, double seq)
 {
     __shared__ double sw[3][4];
-    __shared__ int sLast;
-    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6;
-    auto chunk = [&](int n, int &lo, int &hi) { const int per = (n + TR_BLOCKS - 1) / TR_BLOCKS; lo = min(n, b * per); hi = min(n, lo + per); };
-    int lo, hi;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double v0 = 0, v1 = 0, v2 = 0;
-    chunk(E, lo, hi);
-    for (int i = lo + tid; i < hi; i += 256) v0 += rchi[i];
-    chunk(nP6, lo, hi);
-    for (int i = lo + tid; i < hi; i += 256) v1 += xp[i] * (lambda * xp[i] + bp[i]);
-    chunk(nL3, lo, hi);
-    for (int i = lo + tid; i < hi; i += 256) v2 += xl[i] * (lambda * xl[i] + bl[i]);
+    for (int i = tid; i < nChi; i += 256) v0 += partChi[i];
+    for (int i = tid; i < nP6; i += 256) v1 += xp[i] * (lambda * xp[i] + bp[i]);
+    for (int i = tid; i < nL; i += 256) v2 += partL[i];
     v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
     if (lane == 0) { sw[0][wave] = v0; sw[1][wave] = v1; sw[2][wave] = v2; }
     __syncthreads();
-    if (tid < 3) scratch[tid * TR_BLOCKS + b] = sw[tid][0] + sw[tid][1] + sw[tid][2] + sw[tid][3];
-    __threadfence();
-    __syncthreads();
     if (tid == 0) {
-        unsigned int *cnt = (unsigned int *)(scratch + 3 * TR_BLOCKS);
-        sLast = atomicAdd(cnt, 1u) == TR_BLOCKS - 1;
+        host[0] = sw[0][0] + sw[0][1] + sw[0][2] + sw[0][3];
+        host[4] = sw[1][0] + sw[1][1] + sw[1][2] + sw[1][3];
+        host[5] = sw[2][0] + sw[2][1] + sw[2][2] + sw[2][3];
+        host[8] = okFlag ? (double)*okFlag : 1.0;
+        if (diagMax) host[2] = diagMax[2];
+        __threadfence_system();
+        __hip_atomic_store(host + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __syncthreads();
-    if (!sLast) return;
-    __threadfence();
-    if (tid < 3) {
-        double t = 0;
-        for (int k = 0; k < TR_BLOCKS; k++) t += __hip_atomic_load(scratch + tid * TR_BLOCKS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        out[tid == 0 ? 0 : 3 + tid] = t;
+}
+
+// The marshalled inputs of a call arrive as ONE host-to-device copy of the pinned staging buffer; this kernel distributes the segments
+// to their device arrays (a dozen hipMemcpyAsync calls and two memsets before: ~5 us of GPU and ~4 us of host time each).
+#define UNPACK_MAX 16
+struct UnpackSegs {
+    unsigned long long src[UNPACK_MAX];   // byte offset in the arena (256-byte aligned)
+    void *dst[UNPACK_MAX];                // device array (hipMalloc alignment); nullptr src offset ~0ull = fill with zero
+    unsigned long long bytes[UNPACK_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_unpack(const uint8_t *arena, UnpackSegs sg)
+{
+    const size_t stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (int i = 0; i < sg.n; i++) {
+        const size_t nb = sg.bytes[i], nw = nb >> 3;
+        const bool zero = sg.src[i] == ~0ull;
+        const unsigned long long *s8 = (const unsigned long long *)(arena + (zero ? 0 : sg.src[i]));
+        unsigned long long *d8 = (unsigned long long *)sg.dst[i];
+        for (size_t w = t0; w < nw; w += stride) d8[w] = zero ? 0ull : s8[w];
+        if (t0 < (nb & 7)) ((uint8_t *)sg.dst[i])[8 * nw + t0] = zero ? (uint8_t)0 : (arena + sg.src[i])[8 * nw + t0];
     }
-    if (tid == 0) *(unsigned int *)(scratch + 3 * TR_BLOCKS) = 0u;   // ready for the next launch (stream order)
+}
+
+// pop() of a rejected trial: the estimates saved by k_backsub_update come back (one launch instead of two copies)
+__global__ __launch_bounds__(256) void k_restore(LbaDev d, const DPose *poseBak, const double *ptBak)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < d.K) d.pose[g] = poseBak[g];
+    if (g < 3 * d.P) d.pt[g] = ptBak[g];
 }
 
 // computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180): out[2] = max |diagonal entry| over the pose and landmark blocks
@@ -429,9 +439,12 @@ __global__ __launch_bounds__(1024) void k_diag_max(const double *Hpp, int nPose,
 
 // S = blockdiag(Hpp) + lambda*I ; bs = bp   (setLambda + "_Hpp->add(_Hschur)", block_solver.hpp:363-365, 564-589)
 // e->chi2() from the stored _error and isDepthPositive() from the CURRENT estimates (src/Optimizer.cc:880-958): flag = outlier
-__global__ __launch_bounds__(256) void k_classify(LbaDev d, uint8_t *flag, double *chiOut)
+// poseOut / ptOut (final call): the estimates copied next to the flags, so that ONE device-to-host copy brings everything back
+__global__ __launch_bounds__(256) void k_classify(LbaDev d, uint8_t *flag, double *chiOut, DPose *poseOut, double *ptOut)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
+    if (poseOut && e < d.K) poseOut[e] = d.pose[e];
+    if (ptOut && e < 3 * d.P) ptOut[e] = d.pt[e];
     if (e >= d.E) return;
     const double *r = d.err + 3 * (size_t)e;
     const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * d.info[e];
@@ -1047,8 +1060,9 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict_
 // x_l, push() and update(x) in one launch: thread t computes the increment of landmark t (k_backsub), saves the estimates of
 // keyframe t / landmark t (SparseOptimizer::push, sparse_optimizer.cpp:502-506: every vertex) and applies the increments (oplus).
 __global__ __launch_bounds__(256) void k_backsub_update(LbaDev d, const int *ptStart, const int *ptEdges, const double *bl, const double *Dinv, const double *xp,
-                                                        double *xl, DPose *poseBak, double *ptBak)
+                                                        double *xl, DPose *poseBak, double *ptBak, double lambda, double *partL)
 {
+    __shared__ double sw[4];
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g < d.K) {                                   // keyframe g
         DPose T = d.pose[g];
@@ -1057,32 +1071,39 @@ __global__ __launch_bounds__(256) void k_backsub_update(LbaDev d, const int *ptS
         if (pi >= 0) { pose_oplus(T, xp + 6 * pi); d.pose[g] = T; }
     }
     const int t = g >> 4, a = g & 15;                // landmark t, 16 lanes per landmark
-    if (t >= d.P) return;
-    const int li = d.ptIdx[t];
-    double c[3] = {0, 0, 0};
-    if (li >= 0)
-        for (int s = ptStart[t] + a; s < ptStart[t + 1]; s += 16) {
-            const int e = ptEdges[s];
-            if (!d.active[e]) continue;
-            const int pi = d.poseIdx[d.ek[e]];
-            if (pi < 0) continue;
-            const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL;
+    double sc = 0;                                   // this thread's share of sum xl (lambda xl + bl)
+    if (t < d.P) {
+        const int li = d.ptIdx[t];
+        double c[3] = {0, 0, 0};
+        if (li >= 0)
+            for (int s = ptStart[t] + a; s < ptStart[t + 1]; s += 16) {
+                const int e = ptEdges[s];
+                if (!d.active[e]) continue;
+                const int pi = d.poseIdx[d.ek[e]];
+                if (pi < 0) continue;
+                const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL;
 #pragma unroll
-            for (int q = 0; q < 3; q++) { double acc = 0; for (int r = 0; r < 6; r++) acc += B1[3 * r + q] * xp[6 * pi + r]; c[q] += acc; }
+                for (int q = 0; q < 3; q++) { double acc = 0; for (int r = 0; r < 6; r++) acc += B1[3 * r + q] * xp[6 * pi + r]; c[q] += acc; }
+            }
+#pragma unroll
+        for (int q = 0; q < 3; q++) c[q] = sum16(c[q]);
+        if (a == 0) {
+            double X[3] = {d.pt[3 * (size_t)t], d.pt[3 * (size_t)t + 1], d.pt[3 * (size_t)t + 2]};
+            for (int i = 0; i < 3; i++) ptBak[3 * (size_t)t + i] = X[i];
+            if (li >= 0) {
+                for (int q = 0; q < 3; q++) c[q] = bl[(size_t)li * 3 + q] - c[q];
+                const double *I = Dinv + (size_t)li * 9;
+                for (int i = 0; i < 3; i++) {
+                    const double x = I[3 * i] * c[0] + I[3 * i + 1] * c[1] + I[3 * i + 2] * c[2];
+                    xl[(size_t)li * 3 + i] = x;
+                    d.pt[3 * (size_t)t + i] = X[i] + x;
+                    sc += x * (lambda * x + bl[(size_t)li * 3 + i]);
+                }
+            }
         }
-#pragma unroll
-    for (int q = 0; q < 3; q++) c[q] = sum16(c[q]);
-    if (a != 0) return;
-    double X[3] = {d.pt[3 * (size_t)t], d.pt[3 * (size_t)t + 1], d.pt[3 * (size_t)t + 2]};
-    for (int i = 0; i < 3; i++) ptBak[3 * (size_t)t + i] = X[i];
-    if (li < 0) return;
-    for (int q = 0; q < 3; q++) c[q] = bl[(size_t)li * 3 + q] - c[q];
-    const double *I = Dinv + (size_t)li * 9;
-    for (int i = 0; i < 3; i++) {
-        const double x = I[3 * i] * c[0] + I[3 * i + 1] * c[1] + I[3 * i + 2] * c[2];
-        xl[(size_t)li * 3 + i] = x;
-        d.pt[3 * (size_t)t + i] = X[i] + x;
     }
+    const double tot = block_sum256(sc, sw);
+    if (threadIdx.x == 0) partL[blockIdx.x] = tot;
 }
 
 
@@ -1436,8 +1457,10 @@ struct orbx_lba {
     OrbxDevBuf<uint8_t> stereo, active;
     uint8_t *hostIO = nullptr;   // pinned: the marshalled inputs of a call on their way up, flags / chi2 / estimates on their way down
     size_t hostIOBytes = 0;
-    OrbxDevBuf<uint8_t> flagDev;
-    OrbxDevBuf<double> chiDev;
+    OrbxDevBuf<uint8_t> flagDev, inArena;
+    OrbxDevBuf<double> partChi, partL;   // per-workgroup partial sums of k_errors / k_backsub_update
+    double *hostRedDev = nullptr;        // device view of hostRed
+    double seq = 0;                      // sequence number of the last k_trial_finish
     double *hostRed = nullptr;   // pinned: {chi, -, diag max, -, scale_p, scale_l, okFlag (as int)} of a trial, read back with ONE synchronisation
 };
 
@@ -1454,17 +1477,20 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
-    if (hipHostMalloc((void **)&h->hostRed, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) { orbx_lba_destroy(h); orbx_set_error("hipHostMalloc failed"); return ORBX_ERR_HIP; }
+    if (hipHostMalloc((void **)&h->hostRed, 16 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&h->hostRedDev, h->hostRed, 0) != hipSuccess) { orbx_lba_destroy(h); orbx_set_error("hipHostMalloc (mapped) failed"); return ORBX_ERR_HIP; }
+    for (int i = 0; i < 16; i++) h->hostRed[i] = 0;
     const size_t K = (size_t)max_keyframes, P = (size_t)max_points, E = (size_t)max_edges, n6 = 6 * K;
     int rc = 0;
     rc = rc ? rc : h->pose.ensure(K); rc = rc ? rc : h->poseBak.ensure(K); rc = rc ? rc : h->pt.ensure(3 * P); rc = rc ? rc : h->ptBak.ensure(3 * P);
     rc = rc ? rc : h->intr.ensure(5 * K); rc = rc ? rc : h->obs.ensure(3 * E); rc = rc ? rc : h->info.ensure(E); rc = rc ? rc : h->err.ensure(3 * E);
     rc = rc ? rc : h->rchi.ensure(E); rc = rc ? rc : h->edgeBlk.ensure(E * EB_SIZE); rc = rc ? rc : h->Hpp.ensure(36 * K); rc = rc ? rc : h->bp.ensure(n6);
     rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->Ddb.ensure(3 * P); rc = rc ? rc : h->ywork.ensure(n6); rc = rc ? rc : h->ysol.ensure(n6);
-    rc = rc ? rc : h->bs.ensure(n6); rc = rc ? rc : h->xp.ensure(n6); rc = rc ? rc : h->xl.ensure(3 * P); rc = rc ? rc : h->red.ensure(16 + 3 * TR_BLOCKS + 2);
+    rc = rc ? rc : h->bs.ensure(n6); rc = rc ? rc : h->xp.ensure(n6); rc = rc ? rc : h->xl.ensure(3 * P); rc = rc ? rc : h->red.ensure(16);
     rc = rc ? rc : h->ep.ensure(E); rc = rc ? rc : h->ek.ensure(E); rc = rc ? rc : h->ptStart.ensure(P + 1); rc = rc ? rc : h->ptEdges.ensure(E);
     rc = rc ? rc : h->kfStart.ensure(K + 1); rc = rc ? rc : h->kfEdges.ensure(E); rc = rc ? rc : h->poseIdx.ensure(K); rc = rc ? rc : h->ptIdx.ensure(P);
     rc = rc ? rc : h->okFlag.ensure(1); rc = rc ? rc : h->stereo.ensure(E); rc = rc ? rc : h->active.ensure(E);
+    rc = rc ? rc : h->partChi.ensure((E + 255) / 256); rc = rc ? rc : h->partL.ensure((std::max(K, 16 * P) + 255) / 256);
     if (rc) { orbx_lba_destroy(h); return rc; }
     *out = h;
     return ORBX_OK;
@@ -1484,7 +1510,7 @@ extern "C" void orbx_lba_destroy(orbx_lba *h)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->hostRed) (void)hipHostFree(h->hostRed);
     if (h->hostIO) (void)hipHostFree(h->hostIO);
-    h->flagDev.release(); h->chiDev.release();
+    h->flagDev.release(); h->partChi.release(); h->partL.release(); h->inArena.release();
     delete h;
 }
 
@@ -1508,23 +1534,26 @@ struct Ctx {
     std::vector<uint8_t> fixed;
 };
 
-int reduce2(Ctx &c, const double *v, int n, int stride, int offset, double out[2])
+// Waits for the sequence number k_trial_finish stores into pinned memory after its results.  The word is polled; the stream is queried
+// now and then so that a failed launch surfaces as an error instead of a hang.
+int wait_seq(orbx_lba *h, double seq)
 {
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, c.h->stream, v, n, stride, offset, c.h->red.p);
-    LCHECK();
-    ORBX_HIP_CHECK(hipMemcpyAsync(out, c.h->red.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c.h->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(c.h->stream));
+    volatile double *flag = h->hostRed + 15;
+    for (unsigned spins = 1;; spins++) {
+        if (*flag == seq) break;
+        if ((spins & 0x3fff) == 0) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) {
+                if (*flag == seq) break;
+                orbx_set_error("LBA: the stream drained without the trial results");
+                return ORBX_ERR_HIP;
+            }
+            if (q != hipErrorNotReady) { orbx_set_error("LBA: %s", hipGetErrorString(q)); return ORBX_ERR_HIP; }
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     return ORBX_OK;
-}
-
-int errors_and_chi(Ctx &c, double *chi)
-{
-    hipLaunchKernelGGL(k_errors, dim3((unsigned)((c.d.E + 255) / 256)), dim3(256), 0, c.h->stream, c.d, c.hub, c.robust);
-    LCHECK();
-    double o[2];
-    int rc = reduce2(c, c.h->rchi.p, c.d.E, 1, 0, o);
-    *chi = o[0];
-    return rc;
 }
 
 // SparseOptimizer::optimize(iterations) on the edges of level 0 (see oracle/lba_oracle.cc for the CPU twin)
@@ -1534,14 +1563,21 @@ int optimize(Ctx &c, int iterations, double stats[4])
     const int K = c.d.K, P = c.d.P, E = c.d.E;
     stats[0] = stats[1] = stats[2] = stats[3] = 0;
     // initializeOptimization(0): active edges/vertices and the index mapping (sparse_optimizer.cpp:166-267)
-    std::vector<uint8_t> active((size_t)E);
-    std::vector<int> poseIdx((size_t)K, -1), ptIdx((size_t)P, -1);
+    // written straight into the pinned staging buffer (idle between the upload of a call and its results): one copy, one k_unpack, no
+    // synchronisation - the next host write to the buffer is behind the read-back of this stage's results
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t oAct = 0, oPi = pad((size_t)E), oLi = oPi + pad((size_t)K * 4), idxBytes = oLi + pad((size_t)P * 4);
+    if (idxBytes > h->hostIOBytes || idxBytes > h->inArena.n) { orbx_set_error("LBA staging buffer too small"); return ORBX_ERR_CAPACITY; }
+    uint8_t *active = h->hostIO + oAct;
+    int *poseIdx = (int *)(h->hostIO + oPi), *ptIdx = (int *)(h->hostIO + oLi);
+    for (int k = 0; k < K; k++) poseIdx[k] = -1;
+    for (int l = 0; l < P; l++) ptIdx[l] = -1;
     std::vector<char> pAct((size_t)K, 0), lAct((size_t)P, 0);
     int nAct = 0;
-    for (int e = 0; e < E; e++) { active[(size_t)e] = c.level[(size_t)e] == 0; if (active[(size_t)e]) { pAct[(size_t)c.ek[(size_t)e]] = 1; lAct[(size_t)c.ep[(size_t)e]] = 1; nAct++; } }
+    for (int e = 0; e < E; e++) { active[e] = c.level[(size_t)e] == 0; if (active[e]) { pAct[(size_t)c.ek[(size_t)e]] = 1; lAct[(size_t)c.ep[(size_t)e]] = 1; nAct++; } }
     int nPose = 0, nPt = 0;
-    for (int k = 0; k < K; k++) if (pAct[(size_t)k] && !c.fixed[(size_t)k]) poseIdx[(size_t)k] = nPose++;
-    for (int l = 0; l < P; l++) if (lAct[(size_t)l]) ptIdx[(size_t)l] = nPt++;
+    for (int k = 0; k < K; k++) if (pAct[(size_t)k] && !c.fixed[(size_t)k]) poseIdx[k] = nPose++;
+    for (int l = 0; l < P; l++) if (lAct[(size_t)l]) ptIdx[l] = nPt++;
     if (nAct == 0 || nPose + nPt == 0) return ORBX_OK;
     if (6 * nPose > CHOL_DENSE_MAX_N) { orbx_set_error("%d free keyframes exceed the dense reduced-system limit %d", nPose, CHOL_DENSE_MAX_N / 6); return ORBX_ERR_CAPACITY; }
     c.nPose = nPose; c.nPt = nPt;
@@ -1551,11 +1587,17 @@ int optimize(Ctx &c, int iterations, double stats[4])
         rc = rc ? rc : h->Lmat.ensure(nn ? nn : 1);
         if (rc) return rc;
     }
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->active.p, active.data(), (size_t)E, hipMemcpyHostToDevice, h->stream));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->poseIdx.p, poseIdx.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->ptIdx.p, ptIdx.data(), (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-    const int nP6 = 6 * nPose, nL3 = 3 * nPt;
+    {
+        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p, h->hostIO, idxBytes, hipMemcpyHostToDevice, h->stream));
+        UnpackSegs sg;
+        sg.src[0] = oAct; sg.dst[0] = h->active.p; sg.bytes[0] = (size_t)E;
+        sg.src[1] = oPi; sg.dst[1] = h->poseIdx.p; sg.bytes[1] = (size_t)K * 4;
+        sg.src[2] = oLi; sg.dst[2] = h->ptIdx.p; sg.bytes[2] = (size_t)P * 4;
+        sg.n = 3;
+        hipLaunchKernelGGL(k_unpack, dim3(64), dim3(256), 0, h->stream, (const uint8_t *)h->inArena.p, sg);
+        LCHECK();
+    }
+    const int nP6 = 6 * nPose;
     const unsigned gE = (unsigned)((E + 255) / 256);
     double lambda = 0, ni = 2;
     int nBad = 0;
@@ -1568,9 +1610,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
     for (int it = 0; it < iterations && !(c.stop && *c.stop) && ok; it++) {
         double currentChi = freshChi;
         if (!errorsFresh) {
-            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
-            LCHECK();
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->stream, h->rchi.p, E, 1, 0, h->red.p);
+            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p);
             LCHECK();
         }
         hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
@@ -1585,8 +1625,12 @@ int optimize(Ctx &c, int iterations, double stats[4])
             LCHECK();
         }
         if (!errorsFresh || it == 0) {
-            ORBX_HIP_CHECK(hipMemcpyAsync(h->hostRed, h->red.p, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+            const double seq = (h->seq += 1.0);
+            hipLaunchKernelGGL(k_trial_finish, dim3(1), dim3(256), 0, h->stream, h->partChi.p, (int)gE, (const double *)nullptr, 0, (const double *)nullptr, (const double *)nullptr, 0,
+                               0.0, (const int *)nullptr, it == 0 ? h->red.p : (const double *)nullptr, h->hostRedDev, seq);
+            LCHECK();
+            int rcw = wait_seq(h, seq);
+            if (rcw) return rcw;
             if (!errorsFresh) currentChi = h->hostRed[0];
             if (it == 0) { lambda = 1e-5 * h->hostRed[2]; ni = 2; nBad = 0; }
         }
@@ -1645,19 +1689,23 @@ int optimize(Ctx &c, int iterations, double stats[4])
                 LCHECK();
                 h->flops += (double)nP6 * nP6 * nP6 / 3.0;
             }
-            hipLaunchKernelGGL(k_backsub_update, dim3((unsigned)((std::max(K, 16 * P) + 255) / 256)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->bl.p,
-                               h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p);
+            const unsigned gU = (unsigned)((std::max(K, 16 * P) + 255) / 256);
+            hipLaunchKernelGGL(k_backsub_update, dim3(gU), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->bl.p,
+                               h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p, lambda, h->partL.p);
             LCHECK();
             h->flops += 250.0 * nAct;
-            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
+            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p);
             LCHECK();
-            hipLaunchKernelGGL(k_trial_reduce, dim3(TR_BLOCKS), dim3(256), 0, h->stream, h->rchi.p, E, h->xp.p, h->bp.p, nP6, h->xl.p, h->bl.p, nL3, lambda, h->red.p, h->red.p + 16);
+            const double seq = (h->seq += 1.0);
+            hipLaunchKernelGGL(k_trial_finish, dim3(1), dim3(256), 0, h->stream, h->partChi.p, (int)gE, h->partL.p, (int)gU, h->xp.p, h->bp.p, nP6, lambda,
+                               nP6 > 0 ? h->okFlag.p : (const int *)nullptr, (const double *)nullptr, h->hostRedDev, seq);
             LCHECK();
-            ORBX_HIP_CHECK(hipMemcpyAsync(h->hostRed, h->red.p, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            if (nP6 > 0) ORBX_HIP_CHECK(hipMemcpyAsync(h->hostRed + 8, h->okFlag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));      // the one synchronisation of the trial
+            {   // the one wait of the trial: results and sequence number arrive in pinned memory
+                int rcw = wait_seq(h, seq);
+                if (rcw) return rcw;
+            }
             double tempChi = h->hostRed[0];
-            if (nP6 > 0) okHost = *(const int *)(h->hostRed + 8);
+            if (nP6 > 0) okHost = h->hostRed[8] != 0.0;
             if (!okHost) tempChi = std::numeric_limits<double>::max();
             double scale = 0;
             const double o1 = nP6 > 0 ? h->hostRed[4] : 0.0, o2 = h->hostRed[5];
@@ -1675,8 +1723,8 @@ int optimize(Ctx &c, int iterations, double stats[4])
                 ni *= 2;
                 errorsFresh = false;
                 // pop(): estimates restored; _error keeps the values of the rejected trial (as in g2o)
-                ORBX_HIP_CHECK(hipMemcpyAsync(h->pose.p, h->poseBak.p, (size_t)K * sizeof(DPose), hipMemcpyDeviceToDevice, h->stream));
-                ORBX_HIP_CHECK(hipMemcpyAsync(h->pt.p, h->ptBak.p, (size_t)P * 3 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+                hipLaunchKernelGGL(k_restore, dim3((unsigned)((std::max(K, 3 * P) + 255) / 256)), dim3(256), 0, h->stream, c.d, h->poseBak.p, h->ptBak.p);
+                LCHECK();
             }
             qmax++;
             stats[1] += 1;
@@ -1723,8 +1771,7 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
             ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostIO, need, hipHostMallocDefault));
             h->hostIOBytes = need;
         }
-        int rcb = h->flagDev.ensure((size_t)E);
-        rcb = rcb ? rcb : h->chiDev.ensure((size_t)E);
+        int rcb = h->flagDev.ensure(outBytes);
         if (rcb) return rcb;
     }
     uint8_t *io = h->hostIO;
@@ -1764,20 +1811,22 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
         for (int e = 0; e < E; e++) { ptEdges[fp[(size_t)epH[e]]++] = e; kfEdges[fk[(size_t)ekH[e]]++] = e; }
     }
     hipStream_t s = h->stream;
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->pose.p, pose, (size_t)K * sizeof(DPose), hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->pt.p, pt, (size_t)3 * P * 8, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->intr.p, intr, (size_t)5 * K * 8, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->obs.p, obs, (size_t)3 * E * 8, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->info.p, info, (size_t)E * 8, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->stereo.p, stereo, (size_t)E, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->ep.p, epH, (size_t)E * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->ek.p, ekH, (size_t)E * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->ptStart.p, ptStart, ((size_t)P + 1) * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->ptEdges.p, ptEdges, (size_t)E * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->kfStart.p, kfStart, ((size_t)K + 1) * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemcpyAsync(h->kfEdges.p, kfEdges, (size_t)E * 4, hipMemcpyHostToDevice, s));
-    ORBX_HIP_CHECK(hipMemsetAsync(h->err.p, 0, (size_t)E * 3 * 8, s));
-    ORBX_HIP_CHECK(hipMemsetAsync(h->red.p + 16 + 3 * TR_BLOCKS, 0, 2 * sizeof(double), s));   // k_trial_reduce's arrival counter
+    {   // one copy of the whole staging buffer, one kernel that distributes it (and clears _error)
+        int rca = h->inArena.ensure(inBytes);
+        if (rca) return rca;
+        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p, io, inBytes, hipMemcpyHostToDevice, s));
+        UnpackSegs sg;
+        int ns = 0;
+        auto seg = [&](size_t off, void *dst, size_t bytes) { sg.src[ns] = off; sg.dst[ns] = dst; sg.bytes[ns] = bytes; ns++; };
+        seg(oPose, h->pose.p, (size_t)K * sizeof(DPose)); seg(oPt, h->pt.p, (size_t)3 * P * 8); seg(oIntr, h->intr.p, (size_t)5 * K * 8);
+        seg(oObs, h->obs.p, (size_t)3 * E * 8); seg(oInfo, h->info.p, (size_t)E * 8); seg(oSt, h->stereo.p, (size_t)E);
+        seg(oEp, h->ep.p, (size_t)E * 4); seg(oEk, h->ek.p, (size_t)E * 4); seg(oPs, h->ptStart.p, ((size_t)P + 1) * 4);
+        seg(oPe, h->ptEdges.p, (size_t)E * 4); seg(oKs, h->kfStart.p, ((size_t)K + 1) * 4); seg(oKe, h->kfEdges.p, (size_t)E * 4);
+        seg(~(size_t)0, h->err.p, (size_t)E * 3 * 8);
+        sg.n = ns;
+        hipLaunchKernelGGL(k_unpack, dim3(256), dim3(256), 0, s, (const uint8_t *)h->inArena.p, sg);
+        LCHECK();
+    }
     ORBX_HIP_CHECK(hipStreamSynchronize(s));     // the pinned buffer is reused for the results below
     LbaDev &d = c.d;
     d.K = K; d.P = P; d.E = E; d.pose = h->pose.p; d.pt = h->pt.p; d.intr = h->intr.p; d.ep = h->ep.p; d.ek = h->ek.p; d.obs = h->obs.p;
@@ -1790,16 +1839,13 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     c.hub.dsqrStereo = (double)(float)((double)thStereo * (double)thStereo);
     ORBX_HIP_CHECK(hipEventRecord(h->ev0, s));
     // classification on the device (k_classify); only the flags come back between the stages, the rest with the final results
-    const unsigned gEc = (unsigned)((E + 255) / 256);
+    const unsigned gEc = (unsigned)((std::max(E, std::max(K, 3 * P)) + 255) / 256);
     auto classify = [&](std::vector<uint8_t> &flag, bool final) -> int {
-        hipLaunchKernelGGL(k_classify, dim3(gEc), dim3(256), 0, h->stream, c.d, h->flagDev.p, final && res->edge_chi2 ? h->chiDev.p : nullptr);
+        uint8_t *oa = h->flagDev.p;     // device image of the result layout dFlag | dChi | dPose | dPt
+        hipLaunchKernelGGL(k_classify, dim3(gEc), dim3(256), 0, h->stream, c.d, oa + dFlag, final && res->edge_chi2 ? (double *)(oa + dChi) : (double *)nullptr,
+                           final ? (DPose *)(oa + dPose) : (DPose *)nullptr, final ? (double *)(oa + dPt) : (double *)nullptr);
         LCHECK();
-        ORBX_HIP_CHECK(hipMemcpyAsync(io + dFlag, h->flagDev.p, (size_t)E, hipMemcpyDeviceToHost, h->stream));
-        if (final) {
-            if (res->edge_chi2) ORBX_HIP_CHECK(hipMemcpyAsync(io + dChi, h->chiDev.p, (size_t)E * 8, hipMemcpyDeviceToHost, h->stream));
-            ORBX_HIP_CHECK(hipMemcpyAsync(io + dPose, h->pose.p, (size_t)K * sizeof(DPose), hipMemcpyDeviceToHost, h->stream));
-            ORBX_HIP_CHECK(hipMemcpyAsync(io + dPt, h->pt.p, (size_t)3 * P * 8, hipMemcpyDeviceToHost, h->stream));
-        }
+        ORBX_HIP_CHECK(hipMemcpyAsync(io, oa, final ? outBytes : (size_t)E, hipMemcpyDeviceToHost, h->stream));
         ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
         memcpy(flag.data(), io + dFlag, (size_t)E);
         if (final && res->edge_chi2) memcpy(res->edge_chi2, io + dChi, (size_t)E * 8);
