@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -1458,6 +1459,7 @@ struct orbx_lba {
     uint8_t *hostIO = nullptr;   // pinned: the marshalled inputs of a call on their way up, flags / chi2 / estimates on their way down
     size_t hostIOBytes = 0;
     OrbxDevBuf<uint8_t> flagDev, inArena;
+    std::vector<int> csrFill;            // host scratch of the adjacency-list build
     OrbxDevBuf<double> partChi, partL;   // per-workgroup partial sums of k_errors / k_backsub_update
     double *hostRedDev = nullptr;        // device view of hostRed
     double seq = 0;                      // sequence number of the last k_trial_finish
@@ -1530,8 +1532,10 @@ struct Ctx {
     int nPose, nPt;
     const volatile uint8_t *stop;
     std::vector<uint8_t> level;   // host copy
-    std::vector<int> ep, ek;
-    std::vector<uint8_t> fixed;
+    const int *ep, *ek;           // the caller's edge arrays (validated)
+    const uint8_t *fixed;
+    size_t idxOff = 0;            // where the index arrays of a stage are staged: behind the inputs, in the pinned buffer and in the arena
+    std::function<int()> beforeSums;   // work deferred until the first kernel that walks the adjacency lists (see lba_run)
 };
 
 // Waits for the sequence number k_trial_finish stores into pinned memory after its results.  The word is polled; the stream is queried
@@ -1566,17 +1570,17 @@ int optimize(Ctx &c, int iterations, double stats[4])
     // written straight into the pinned staging buffer (idle between the upload of a call and its results): one copy, one k_unpack, no
     // synchronisation - the next host write to the buffer is behind the read-back of this stage's results
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t oAct = 0, oPi = pad((size_t)E), oLi = oPi + pad((size_t)K * 4), idxBytes = oLi + pad((size_t)P * 4);
-    if (idxBytes > h->hostIOBytes || idxBytes > h->inArena.n) { orbx_set_error("LBA staging buffer too small"); return ORBX_ERR_CAPACITY; }
+    const size_t oAct = c.idxOff, oPi = oAct + pad((size_t)E), oLi = oPi + pad((size_t)K * 4), idxEnd = oLi + pad((size_t)P * 4);
+    if (idxEnd > h->hostIOBytes || idxEnd > h->inArena.n) { orbx_set_error("LBA staging buffer too small"); return ORBX_ERR_CAPACITY; }
     uint8_t *active = h->hostIO + oAct;
     int *poseIdx = (int *)(h->hostIO + oPi), *ptIdx = (int *)(h->hostIO + oLi);
     for (int k = 0; k < K; k++) poseIdx[k] = -1;
     for (int l = 0; l < P; l++) ptIdx[l] = -1;
     std::vector<char> pAct((size_t)K, 0), lAct((size_t)P, 0);
     int nAct = 0;
-    for (int e = 0; e < E; e++) { active[e] = c.level[(size_t)e] == 0; if (active[e]) { pAct[(size_t)c.ek[(size_t)e]] = 1; lAct[(size_t)c.ep[(size_t)e]] = 1; nAct++; } }
+    for (int e = 0; e < E; e++) { active[e] = c.level[(size_t)e] == 0; if (active[e]) { pAct[(size_t)c.ek[e]] = 1; lAct[(size_t)c.ep[e]] = 1; nAct++; } }
     int nPose = 0, nPt = 0;
-    for (int k = 0; k < K; k++) if (pAct[(size_t)k] && !c.fixed[(size_t)k]) poseIdx[k] = nPose++;
+    for (int k = 0; k < K; k++) if (pAct[(size_t)k] && !c.fixed[k]) poseIdx[k] = nPose++;
     for (int l = 0; l < P; l++) if (lAct[(size_t)l]) ptIdx[l] = nPt++;
     if (nAct == 0 || nPose + nPt == 0) return ORBX_OK;
     if (6 * nPose > CHOL_DENSE_MAX_N) { orbx_set_error("%d free keyframes exceed the dense reduced-system limit %d", nPose, CHOL_DENSE_MAX_N / 6); return ORBX_ERR_CAPACITY; }
@@ -1588,7 +1592,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
         if (rc) return rc;
     }
     {
-        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p, h->hostIO, idxBytes, hipMemcpyHostToDevice, h->stream));
+        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p + oAct, h->hostIO + oAct, idxEnd - oAct, hipMemcpyHostToDevice, h->stream));
         UnpackSegs sg;
         sg.src[0] = oAct; sg.dst[0] = h->active.p; sg.bytes[0] = (size_t)E;
         sg.src[1] = oPi; sg.dst[1] = h->poseIdx.p; sg.bytes[1] = (size_t)K * 4;
@@ -1615,6 +1619,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
         }
         hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
         LCHECK();
+        if (c.beforeSums) { int rcd = c.beforeSums(); c.beforeSums = nullptr; if (rcd) return rcd; }
         hipLaunchKernelGGL(k_sum_points, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p);
         LCHECK();
         hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->Hpp.p, h->bp.p);
@@ -1748,8 +1753,6 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     const int K = p->num_keyframes, P = p->num_points, E = p->num_edges;
     if (K < 1 || P < 1 || E < 1 || K > h->maxK || P > h->maxP || E > h->maxE) { orbx_set_error("problem size %d/%d/%d outside the handle's capacity %d/%d/%d", K, P, E, h->maxK, h->maxP, h->maxE); return ORBX_ERR_CAPACITY; }
     if (!p->poses || !p->fixed || !p->intrinsics || !p->points || !p->edge_point || !p->edge_keyframe || !p->edge_obs || !p->edge_inv_sigma2) { orbx_set_error("NULL problem array"); return ORBX_ERR_ARG; }
-    for (int e = 0; e < E; e++)
-        if (p->edge_point[e] < 0 || p->edge_point[e] >= P || p->edge_keyframe[e] < 0 || p->edge_keyframe[e] >= K) { orbx_set_error("edge %d references a vertex out of range", e); return ORBX_ERR_ARG; }
     ORBX_HIP_CHECK(hipSetDevice(h->device));
     for (int i = 0; i < 8; i++) res->stats[i] = 0;
     h->flops = 0;
@@ -1760,10 +1763,11 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
                  oInfo = oObs + pad((size_t)3 * E * 8), oSt = oInfo + pad((size_t)E * 8), oEp = oSt + pad((size_t)E), oEk = oEp + pad((size_t)E * 4),
                  oPs = oEk + pad((size_t)E * 4), oPe = oPs + pad(((size_t)P + 1) * 4), oKs = oPe + pad((size_t)E * 4), oKe = oKs + pad(((size_t)K + 1) * 4),
                  inBytes = oKe + pad((size_t)E * 4);
+    const size_t idxBytes = pad((size_t)E) + pad((size_t)K * 4) + pad((size_t)P * 4);   // optimize(): active | poseIdx | ptIdx behind the inputs
     const size_t dFlag = 0, dChi = dFlag + pad((size_t)E), dPose = dChi + pad((size_t)E * 8), dPt = dPose + pad((size_t)K * sizeof(DPose)),
                  outBytes = dPt + pad((size_t)3 * P * 8);
     {
-        const size_t need = std::max(inBytes, outBytes);
+        const size_t need = std::max(inBytes + idxBytes, outBytes);
         if (need > h->hostIOBytes) {
             ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
             if (h->hostIO) (void)hipHostFree(h->hostIO);
@@ -1772,8 +1776,13 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
             h->hostIOBytes = need;
         }
         int rcb = h->flagDev.ensure(outBytes);
+        rcb = rcb ? rcb : h->inArena.ensure(inBytes + idxBytes);
         if (rcb) return rcb;
     }
+    // The pinned buffer is written in the order it is sent: (1) estimates, observations and edge ends - copied and unpacked while the
+    // host goes on, (2) the index arrays of the first optimize() stage, (3) the adjacency lists (CSR by landmark and by keyframe),
+    // built while the device already computes errors and Jacobians and sent right before the first kernel that walks them.  Nothing
+    // waits for a copy: the results come back into the front of the same buffer long after the device has consumed all of it.
     uint8_t *io = h->hostIO;
     DPose *pose = (DPose *)(io + oPose);
     double *intr = (double *)(io + oIntr), *pt = (double *)(io + oPt), *obs = (double *)(io + oObs), *info = (double *)(io + oInfo);
@@ -1789,45 +1798,58 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
         for (int i = 0; i < 5; i++) intr[5 * (size_t)k + i] = p->intrinsics[5 * (size_t)k + i];
     }
     for (int i = 0; i < 3 * P; i++) pt[i] = p->points[i];
-    Ctx c;
-    c.h = h; c.stop = stop;
-    c.ep.assign(p->edge_point, p->edge_point + E); c.ek.assign(p->edge_keyframe, p->edge_keyframe + E);
-    c.fixed.assign(p->fixed, p->fixed + K);
-    c.level.assign((size_t)E, 0);
-    for (int e = 0; e < E; e++) {
-        for (int i = 0; i < 3; i++) obs[3 * (size_t)e + i] = p->edge_obs[3 * (size_t)e + i];
-        stereo[e] = !(p->edge_obs[3 * (size_t)e + 2] < 0);
-        info[e] = p->edge_inv_sigma2[e];
-        epH[e] = p->edge_point[e]; ekH[e] = p->edge_keyframe[e];
-    }
-    // CSR by landmark and by keyframe, edges in insertion order
     for (int l = 0; l <= P; l++) ptStart[l] = 0;
     for (int k = 0; k <= K; k++) kfStart[k] = 0;
-    for (int e = 0; e < E; e++) { ptStart[epH[e] + 1]++; kfStart[ekH[e] + 1]++; }
-    for (int l = 0; l < P; l++) ptStart[l + 1] += ptStart[l];
-    for (int k = 0; k < K; k++) kfStart[k + 1] += kfStart[k];
-    {
-        std::vector<int> fp(ptStart, ptStart + P), fk(kfStart, kfStart + K);
-        for (int e = 0; e < E; e++) { ptEdges[fp[(size_t)epH[e]]++] = e; kfEdges[fk[(size_t)ekH[e]]++] = e; }
+    for (int e = 0; e < E; e++) {
+        const int l = p->edge_point[e], k = p->edge_keyframe[e];
+        if (l < 0 || l >= P || k < 0 || k >= K) { orbx_set_error("edge %d references a vertex out of range", e); return ORBX_ERR_ARG; }
+        const float *ob = p->edge_obs + 3 * (size_t)e;
+        obs[3 * (size_t)e] = ob[0]; obs[3 * (size_t)e + 1] = ob[1]; obs[3 * (size_t)e + 2] = ob[2];
+        stereo[e] = !(ob[2] < 0);
+        info[e] = p->edge_inv_sigma2[e];
+        epH[e] = l; ekH[e] = k;
+        ptStart[l + 1]++; kfStart[k + 1]++;      // row lengths of the adjacency lists (finished in beforeSums)
     }
     hipStream_t s = h->stream;
-    {   // one copy of the whole staging buffer, one kernel that distributes it (and clears _error)
-        int rca = h->inArena.ensure(inBytes);
-        if (rca) return rca;
-        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p, io, inBytes, hipMemcpyHostToDevice, s));
+    ORBX_HIP_CHECK(hipEventRecord(h->ev0, s));
+    {
+        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p, io, oPs, hipMemcpyHostToDevice, s));
         UnpackSegs sg;
         int ns = 0;
         auto seg = [&](size_t off, void *dst, size_t bytes) { sg.src[ns] = off; sg.dst[ns] = dst; sg.bytes[ns] = bytes; ns++; };
         seg(oPose, h->pose.p, (size_t)K * sizeof(DPose)); seg(oPt, h->pt.p, (size_t)3 * P * 8); seg(oIntr, h->intr.p, (size_t)5 * K * 8);
         seg(oObs, h->obs.p, (size_t)3 * E * 8); seg(oInfo, h->info.p, (size_t)E * 8); seg(oSt, h->stereo.p, (size_t)E);
-        seg(oEp, h->ep.p, (size_t)E * 4); seg(oEk, h->ek.p, (size_t)E * 4); seg(oPs, h->ptStart.p, ((size_t)P + 1) * 4);
-        seg(oPe, h->ptEdges.p, (size_t)E * 4); seg(oKs, h->kfStart.p, ((size_t)K + 1) * 4); seg(oKe, h->kfEdges.p, (size_t)E * 4);
+        seg(oEp, h->ep.p, (size_t)E * 4); seg(oEk, h->ek.p, (size_t)E * 4);
         seg(~(size_t)0, h->err.p, (size_t)E * 3 * 8);
         sg.n = ns;
         hipLaunchKernelGGL(k_unpack, dim3(256), dim3(256), 0, s, (const uint8_t *)h->inArena.p, sg);
         LCHECK();
     }
-    ORBX_HIP_CHECK(hipStreamSynchronize(s));     // the pinned buffer is reused for the results below
+    Ctx c;
+    c.h = h; c.stop = stop;
+    c.ep = p->edge_point; c.ek = p->edge_keyframe; c.fixed = p->fixed;
+    c.level.assign((size_t)E, 0);
+    c.idxOff = inBytes;
+    c.beforeSums = [=]() -> int {
+        // CSR by landmark and by keyframe, edges in insertion order
+        for (int l = 0; l < P; l++) ptStart[l + 1] += ptStart[l];
+        for (int k = 0; k < K; k++) kfStart[k + 1] += kfStart[k];
+        h->csrFill.resize((size_t)P + (size_t)K);
+        int *fp = h->csrFill.data(), *fk = fp + P;
+        for (int l = 0; l < P; l++) fp[l] = ptStart[l];
+        for (int k = 0; k < K; k++) fk[k] = kfStart[k];
+        for (int e = 0; e < E; e++) { ptEdges[fp[epH[e]]++] = e; kfEdges[fk[ekH[e]]++] = e; }
+        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p + oPs, io + oPs, inBytes - oPs, hipMemcpyHostToDevice, s));
+        UnpackSegs sg;
+        int ns = 0;
+        auto seg = [&](size_t off, void *dst, size_t bytes) { sg.src[ns] = off; sg.dst[ns] = dst; sg.bytes[ns] = bytes; ns++; };
+        seg(oPs, h->ptStart.p, ((size_t)P + 1) * 4); seg(oPe, h->ptEdges.p, (size_t)E * 4); seg(oKs, h->kfStart.p, ((size_t)K + 1) * 4);
+        seg(oKe, h->kfEdges.p, (size_t)E * 4);
+        sg.n = ns;
+        hipLaunchKernelGGL(k_unpack, dim3(64), dim3(256), 0, s, (const uint8_t *)h->inArena.p, sg);
+        LCHECK();
+        return ORBX_OK;
+    };
     LbaDev &d = c.d;
     d.K = K; d.P = P; d.E = E; d.pose = h->pose.p; d.pt = h->pt.p; d.intr = h->intr.p; d.ep = h->ep.p; d.ek = h->ek.p; d.obs = h->obs.p;
     d.stereo = h->stereo.p; d.info = h->info.p; d.active = h->active.p; d.poseIdx = h->poseIdx.p; d.ptIdx = h->ptIdx.p; d.err = h->err.p;
@@ -1837,7 +1859,6 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     c.hub.dMono = thMono; c.hub.dStereo = thStereo;
     c.hub.dsqrMono = (double)(float)((double)thMono * (double)thMono);        // `float dsqr` member (robust_kernel_impl.h:84)
     c.hub.dsqrStereo = (double)(float)((double)thStereo * (double)thStereo);
-    ORBX_HIP_CHECK(hipEventRecord(h->ev0, s));
     // classification on the device (k_classify); only the flags come back between the stages, the rest with the final results
     const unsigned gEc = (unsigned)((std::max(E, std::max(K, 3 * P)) + 255) / 256);
     auto classify = [&](std::vector<uint8_t> &flag, bool final) -> int {
