@@ -791,6 +791,7 @@ __global__ __launch_bounds__(1024) void k_chol_solve(double *S, const double *bs
 // ---------------------------------------------------------------------------------------------
 #define CHOL_MULTI_MIN_N 96
 #define CNB 32
+#define CHOL_RPW 63          /* panel rows per workgroup of k_chol_step: one wave, lane 63 carries the right-hand side */
 
 __global__ __launch_bounds__(256) void k_chol_prep(double *S, const double *bs, int n, double *ywork, int *okFlag)
 {
@@ -818,17 +819,13 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
 //               registers, is loaded while wave 0 factors, and is eliminated by forward substitution against L11 read from LDS
 //               as broadcasts, products subtracted in the order k = 0 .. c-1.
 // One barrier between the two phases, one before the right-hand-side update of the rows below.
-// 1 / sqrt(x) for the pivots: v_rsq_f64 (~26 bits) + two Newton steps y += y/2 (1 - x y^2), instead of the library routine, which sits
-// on the 32-step critical path of the block
+// 1 / sqrt(x) for the pivots: v_rsq_f64 (~26 bits) + one Newton step y += y/2 (1 - x y^2), instead of the library routine: every
+// dependent FP64 operation on the pivot chain costs ~16 cycles, and the factor is not part of the bit-level contract (1e-5 vs g2o)
 __device__ __forceinline__ double pivot_rsqrt(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const double e = __builtin_fma(-x * y, y, 1.0);
-        y = __builtin_fma(0.5 * y, e, y);
-    }
-    return y;
+    const double e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(0.5 * y, e, y);
 }
 
 // One step of the factorisation = ONE launch with two kinds of workgroups:
@@ -841,10 +838,9 @@ __device__ __forceinline__ double pivot_rsqrt(double x)
 __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, double *__restrict__ L, int n, int p0, int nPW, int T1, double *ywork, double *ysol, int *okFlag)
 {
     __shared__ double Ld[CNB][CNB + 1];      // diagonal block in, L11 (lower incl. diagonal) out      | update role: la
-    __shared__ double Tt[65][CNB + 1];       // 64 rows of the panel below + the right-hand side (row 64) | update role: lb (first 32 rows)
+    __shared__ double Tt[64][CNB + 1];       // 63 rows of the panel below + the right-hand side (row 63) | update role: lb (first 32 rows)
     __shared__ __attribute__((aligned(16))) double LpD[CNB][CNB + 1];     // previous panel, rows of this diagonal block; afterwards the column exchange buffer of the block factorisation
     __shared__ double LpR[64][CNB + 1];      // previous panel, this workgroup's rows
-    __shared__ double sinv[CNB];             // 1 / L11[c][c]
     __shared__ int sBad;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nPW) {
@@ -880,11 +876,11 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
     }
     // ---- panel of block column p
     const int wave = tid >> 6, lane = tid & 63, nb = min(CNB, n - p0);
-    const int r0 = p0 + nb + blockIdx.x * 64;   // first row of this workgroup's part of the panel below
+    const int r0 = p0 + nb + blockIdx.x * CHOL_RPW;   // first row of this workgroup's part of the panel below
     const bool hasPrev = p0 > 0;
     if (tid == 64) sBad = 0;
     {   // global memory is only touched by the whole workgroup, a row segment of 32 doubles per 32 threads, all loads of a thread in
-        // flight before its first LDS store
+        // flight before its first LDS store.  Row CHOL_RPW (= 63) of Tt is the right-hand side of this panel.
         double vd[4], vt[8], pd[4], pr[8];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -895,17 +891,17 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
-            vt[q] = (r0 + r < n && c < nb) ? S[(size_t)(r0 + r) * n + p0 + c] : 0.0;
-            pr[q] = (hasPrev && r0 + r < n) ? L[(size_t)(r0 + r) * n + p0 - CNB + c] : 0.0;
+            const bool row = r < CHOL_RPW && r0 + r < n;
+            vt[q] = r == CHOL_RPW ? (c < nb ? ywork[p0 + c] : 0.0) : ((row && c < nb) ? S[(size_t)(r0 + r) * n + p0 + c] : 0.0);
+            pr[q] = (hasPrev && row) ? L[(size_t)(r0 + r) * n + p0 - CNB + c] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) { const int idx = tid + 256 * q; Ld[idx >> 5][idx & 31] = vd[q]; LpD[idx >> 5][idx & 31] = pd[q]; }
 #pragma unroll
         for (int q = 0; q < 8; q++) { const int idx = tid + 256 * q; Tt[idx >> 5][idx & 31] = vt[q]; LpR[idx >> 5][idx & 31] = pr[q]; }
     }
-    if (tid < CNB) Tt[64][tid] = tid < nb ? ywork[p0 + tid] : 0.0;
     __syncthreads();
-    if (hasPrev && tid < 192) {   // own part of the previous panel's update: 4x4 tile per thread (128 threads: the 64 rows, 64 threads: the diagonal block)
+    if (hasPrev && tid < 192) {   // own part of the previous panel's update: 4x4 tile per thread (128 threads: the rows below, 64 threads: the diagonal block)
         const bool isD = tid >= 128;
         const int t2 = isD ? tid - 128 : tid;
         const int tr = (t2 >> 3) * 4, tc = (t2 & 7) * 4;
@@ -929,34 +925,45 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
 #pragma unroll
             for (int jx = 0; jx < 4; jx++) {
                 if (isD) { if (tc + jx <= tr + i && tr + i < nb) Ld[tr + i][tc + jx] -= acc[i][jx]; }
-                else if (tc + jx < nb) Tt[tr + i][tc + jx] -= acc[i][jx];
+                else if (tc + jx < nb) Tt[tr + i][tc + jx] -= acc[i][jx];      // (row 63, the right-hand side: its LpR row is zero)
             }
     }
     if (hasPrev) __syncthreads();
-    double x[CNB];
-    const int j = tid - 64;                      // row thread: 0..63 panel rows, 64 = right-hand side
-    const bool isRow = j >= 0 && j < 64 && r0 + j < n, isRhs = j == 64;
     if (wave == 0) {
-        // Blocked by four columns, all 64 lanes: lane = (row r, half hf) keeps A[r][16 hf .. 16 hf + 15] in registers.  Per block the 4x4
-        // diagonal part travels by v_readlane and is factored redundantly by every lane (wave-uniform scalars), every lane eliminates
-        // its own row against it, and the four finished column entries go through a small LDS buffer ONCE (rows up to the block's
-        // last one stored as zero, which also masks the finished columns and the upper triangle); the rank-4 update of the remaining
-        // columns reads its multipliers back as 16-byte broadcasts.  8 exchange rounds and 8 x 4 dependent pivots instead of 32
-        // column steps with two v_readlane per multiply-add (9.2 us per panel before, measured with s_memrealtime).
+        // ONE WAVE, no barrier inside: the diagonal block and this workgroup's rows below it are eliminated together, blocked by four
+        // columns.  Lane = (row r, half hf) keeps A[r][16 hf .. 16 hf + 15] of the diagonal block in registers AND lane = panel row
+        // keeps its whole row (32 registers; lane 63: the right-hand side).  Per block the 4x4 diagonal part travels by v_readlane
+        // and is factored redundantly by every lane (wave-uniform scalars), every lane eliminates its own entries against it, the
+        // four finished columns of the diagonal block go through a small LDS buffer ONCE (rows up to the block's last one stored as
+        // zero, which also masks the finished columns and the upper triangle), and the rank-4 updates - of the rest of the block and
+        // of the rest of the panel rows - read their multipliers back as 16-byte broadcasts.  8 exchange rounds and 8 x 4 dependent
+        // pivots instead of 32 column steps with two v_readlane per multiply-add followed by a separate forward substitution of the
+        // rows (9.2 + 3.3 us per panel before, measured with s_memrealtime).
         const int r = lane & 31, hf = lane >> 5;
-        double(*cb4)[4] = (double(*)[4]) & LpD[0][0];     // [64][4]: rows 0..31 live, 32..63 the dump of the half that does not own the block
-        double a[16];
+        double(*cbBase)[4] = (double(*)[4]) & LpD[0][0];  // 2 x [64][4] (alternating): rows 0..31 live, 32..63 the dump of the half that does not own the block
+        double a[16], x[CNB];
 #pragma unroll
         for (int q = 0; q < 16; q++) a[q] = Ld[r][16 * hf + q];
+#pragma unroll
+        for (int c = 0; c < CNB; c++) x[c] = Tt[lane][c];
         bool bad = false;
+        const bool ywLive = lane < CHOL_RPW && r0 + lane < n;
+        const double yw = ywLive ? ywork[r0 + lane] : 0.0;     // in flight during the elimination
 #pragma unroll
         for (int cb = 0; cb < CNB / 4; cb++) {
             const int c0 = 4 * cb, hc = c0 >> 4, j0 = c0 & 15;
+            double(*cb4)[4] = cbBase + 64 * (cb & 1);
+            // ---- region A: the pivot chain of this block (every dependent FP64 operation ~16 cycles, nothing to overlap it with inside
+            // the diagonal block) next to the rank-4 update of the PANEL ROWS by the previous block, which only this block's own
+            // elimination of x[c0..c0+3] waits for.  Scheduling barriers keep the compiler from merging more than that (without them
+            // it hoists the loads of all eight blocks and spills 700 registers).
             double d[4][4], inv[4];
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int k = 0; k <= i; k++) d[i][k] = readlane_f64(a[j0 + k], c0 + i + 32 * hc);
+            double(*cbp)[4] = cbBase + 64 * ((cb + 1) & 1);    // the previous block's columns
+            const int p = c0 - 4, nq = CNB - c0, chunk = (nq + 3) / 4;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const double piv = d[k][k];
@@ -969,9 +976,16 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
                 for (int i = k + 1; i < 4; i++)
 #pragma unroll
                     for (int m = k + 1; m <= i; m++) d[i][m] = __builtin_fma(-d[i][k], d[m][k], d[i][m]);
+                if (cb > 0) {   // a quarter of the previous block's rank-4 update of the panel rows rides on this pivot's latency
+#pragma unroll
+                    for (int q = c0 + k * chunk; q < min(c0 + (k + 1) * chunk, CNB); q++) {      // multipliers L[q][p..p+3], the same address for every lane
+                        const double2 m01 = *(const double2 *)cbp[q], m23 = *(const double2 *)(cbp[q] + 2);
+                        x[q] = __builtin_fma(-x[p + 3], m23.y, __builtin_fma(-x[p + 2], m23.x, __builtin_fma(-x[p + 1], m01.y, __builtin_fma(-x[p], m01.x, x[q]))));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (lane == 0) { sinv[c0] = inv[0]; sinv[c0 + 1] = inv[1]; sinv[c0 + 2] = inv[2]; sinv[c0 + 3] = inv[3]; }
-            // own row against the block (rows of the block itself reproduce d[][] in their lower part)
+            // own entries against the block (rows of the block itself reproduce d[][] in their lower part)
             double l[4];
             l[0] = a[j0] * inv[0];
             l[1] = __builtin_fma(-l[0], d[1][0], a[j0 + 1]) * inv[1];
@@ -980,14 +994,19 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
             const bool own = hf == hc;
 #pragma unroll
             for (int k = 0; k < 4; k++) a[j0 + k] = own ? l[k] : a[j0 + k];
+            x[c0] = x[c0] * inv[0];
+            x[c0 + 1] = __builtin_fma(-x[c0], d[1][0], x[c0 + 1]) * inv[1];
+            x[c0 + 2] = __builtin_fma(-x[c0 + 1], d[2][1], __builtin_fma(-x[c0], d[2][0], x[c0 + 2])) * inv[2];
+            x[c0 + 3] = __builtin_fma(-x[c0 + 2], d[3][2], __builtin_fma(-x[c0 + 1], d[3][1], __builtin_fma(-x[c0], d[3][0], x[c0 + 3]))) * inv[3];
             if (cb == CNB / 4 - 1) break;        // nothing left to update
             const bool below = r > c0 + 3;
             double *wr = cb4[own ? r : 32 + r];
             *(double2 *)wr = make_double2(below ? l[0] : 0.0, below ? l[1] : 0.0);
             *(double2 *)(wr + 2) = make_double2(below ? l[2] : 0.0, below ? l[3] : 0.0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- region B: the rest of the diagonal block (no fence needed: the LDS executes the instructions of a wave in order)
             const double2 lr01 = *(const double2 *)cb4[r], lr23 = *(const double2 *)(cb4[r] + 2);
 #pragma unroll
             for (int q = (c0 < 16 ? 0 : j0 + 4); q < 16; q++) {
@@ -995,36 +1014,21 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
                 const double2 m01 = *(const double2 *)mp, m23 = *(const double2 *)(mp + 2);
                 a[q] = __builtin_fma(-lr23.y, m23.y, __builtin_fma(-lr23.x, m23.x, __builtin_fma(-lr01.y, m01.y, __builtin_fma(-lr01.x, m01.x, a[q]))));
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();      // the buffer is rewritten by the next block
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int q = 0; q < 16; q++) if (16 * hf + q <= r) Ld[r][16 * hf + q] = a[q];
+#pragma unroll
+        for (int c = 0; c < CNB; c++) Tt[lane][c] = x[c];
         if (bad && lane == 0) sBad = 1;
-    } else if (isRow || isRhs) {
+        // b of the rows below -= L21 y   (y = the solved right-hand side in lane 63)
+        double dot[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < CNB; c++) x[c] = Tt[j][c];
+        for (int c = 0; c < CNB; c++) dot[c & 3] = __builtin_fma(x[c], readlane_f64(x[c], CHOL_RPW), dot[c & 3]);
+        if (ywLive) ywork[r0 + lane] = yw - ((dot[0] + dot[1]) + (dot[2] + dot[3]));
     }
     __syncthreads();
-    if (isRow || isRhs) {
-#pragma unroll
-        for (int c = 0; c < CNB; c++) {
-            double sacc = x[c];
-#pragma unroll
-            for (int k = 0; k < c; k++) sacc = __builtin_fma(-x[k], Ld[c][k], sacc);
-            x[c] = sacc * sinv[c];
-        }
-#pragma unroll
-        for (int c = 0; c < CNB; c++) Tt[j][c] = x[c];
-    }
-    __syncthreads();
-    if (isRow) {   // b of the rows below -= L21 y
-        double dot = 0;
-#pragma unroll
-        for (int c = 0; c < CNB; c++) dot += x[c] * Tt[64][c];
-        ywork[r0 + j] -= dot;
-    }
-    for (int idx = tid; idx < 64 * CNB; idx += 256) {
+    for (int idx = tid; idx < CHOL_RPW * CNB; idx += 256) {
         const int r = idx >> 5, c = idx & 31;
         if (r0 + r < n && c < nb) L[(size_t)(r0 + r) * n + p0 + c] = Tt[r][c];
     }
@@ -1033,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
             const int r = idx >> 5, c = idx & 31;
             if (r < nb && c <= r) L[(size_t)(p0 + r) * n + p0 + c] = Ld[r][c];
         }
-        if (tid < nb) ysol[p0 + tid] = Tt[64][tid];
+        if (tid < nb) ysol[p0 + tid] = Tt[CHOL_RPW][tid];
         if (sBad && tid == 0) *okFlag = 0;   // not positive definite: the results are discarded by the host
     }
 }
@@ -1707,7 +1711,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
                     hipLaunchKernelGGL(k_chol_prep, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, h->stream, h->S.p, h->bs.p, n, h->ywork.p, h->okFlag.p);
                     for (int p0 = 0; p0 < n; p0 += CNB) {
                         const int nb = std::min(CNB, n - p0), below = n - p0 - nb;
-                        const int nPW = std::max(1, (below + 63) / 64);
+                        const int nPW = std::max(1, (below + CHOL_RPW - 1) / CHOL_RPW);
                         const int T1 = p0 > 0 ? (n - p0 + CNB - 1) / CNB - 1 : 0;        // tile rows / columns beyond block column p that still await the previous panel's update
                         hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nPW + T1 * T1)), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0, nPW, std::max(T1, 1), h->ywork.p,
                                            h->ysol.p, h->okFlag.p);
