@@ -839,8 +839,8 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
 {
     __shared__ double Ld[CNB][CNB + 1];      // diagonal block in, L11 (lower incl. diagonal) out      | update role: la
     __shared__ double Tt[64][CNB + 1];       // 63 rows of the panel below + the right-hand side (row 63) | update role: lb (first 32 rows)
-    __shared__ __attribute__((aligned(16))) double LpD[CNB][CNB + 1];     // previous panel, rows of this diagonal block; afterwards the column exchange buffer of the block factorisation
-    __shared__ double LpR[64][CNB + 1];      // previous panel, this workgroup's rows
+    __shared__ __attribute__((aligned(16))) double LpD[CNB][CNB + 2];     // previous panel, rows of this diagonal block; afterwards the column exchange buffer of the block factorisation
+    __shared__ double LpR[64][CNB + 2];      // previous panel, this workgroup's rows (pitch 34: conflict-free MFMA operand reads)
     __shared__ int sBad;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nPW) {
@@ -901,32 +901,35 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
         for (int q = 0; q < 8; q++) { const int idx = tid + 256 * q; Tt[idx >> 5][idx & 31] = vt[q]; LpR[idx >> 5][idx & 31] = pr[q]; }
     }
     __syncthreads();
-    if (hasPrev && tid < 192) {   // own part of the previous panel's update: 4x4 tile per thread (128 threads: the rows below, 64 threads: the diagonal block)
-        const bool isD = tid >= 128;
-        const int t2 = isD ? tid - 128 : tid;
-        const int tr = (t2 >> 3) * 4, tc = (t2 & 7) * 4;
-        double acc[4][4];
+    if (hasPrev) {
+        // own part of the previous panel's update on the matrix cores: C -= A B^T as v_mfma_f64_16x16x4_f64 (layout checked by
+        // tools/ubench_mfma_f64.hip: A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16], D lane l element v = D[4 v + l / 16][l % 16]).
+        // Wave w takes the two 16x16 tiles of panel rows 16 w .. 16 w + 15 and, waves 0..2, one of the three lower tiles of the
+        // diagonal block; 8 instructions (K = 32) per tile, the accumulator starts as C and A is negated.  The row pitch of 34
+        // doubles makes the operand reads conflict free.  (3.5 us as 4x4 register tiles on the vector ALUs before.)
+        const int li = lane & 15, lk = lane >> 4;
+        typedef double d4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int t = 0; t < 3; t++) {
+            const bool isD = t == 2;
+            if (isD && wave == 3) break;
+            const int rt = isD ? (wave + 1) >> 1 : wave, ct = isD ? wave >> 1 : t;      // diagonal tiles: (0,0), (1,0), (1,1)
+            d4_t acc;
 #pragma unroll
-            for (int jx = 0; jx < 4; jx++) acc[i][jx] = 0;
-#pragma unroll 4
-        for (int k = 0; k < CNB; k++) {
-            double av[4], bv[4];
+            for (int v = 0; v < 4; v++) acc[v] = isD ? Ld[16 * rt + 4 * v + lk][16 * ct + li] : Tt[16 * rt + 4 * v + lk][16 * ct + li];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { av[i] = isD ? LpD[tr + i][k] : LpR[tr + i][k]; bv[i] = LpD[tc + i][k]; }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int jx = 0; jx < 4; jx++) acc[i][jx] = __builtin_fma(av[i], bv[jx], acc[i][jx]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int jx = 0; jx < 4; jx++) {
-                if (isD) { if (tc + jx <= tr + i && tr + i < nb) Ld[tr + i][tc + jx] -= acc[i][jx]; }
-                else if (tc + jx < nb) Tt[tr + i][tc + jx] -= acc[i][jx];      // (row 63, the right-hand side: its LpR row is zero)
+            for (int k4 = 0; k4 < CNB / 4; k4++) {
+                const double av = isD ? LpD[16 * rt + li][4 * k4 + lk] : LpR[16 * rt + li][4 * k4 + lk];
+                const double bv = LpD[16 * ct + li][4 * k4 + lk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, bv, acc, 0, 0, 0);
             }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int rr = 16 * rt + 4 * v + lk, cc = 16 * ct + li;
+                if (isD) { if (cc <= rr && rr < nb) Ld[rr][cc] = acc[v]; }
+                else if (cc < nb) Tt[rr][cc] = acc[v];      // (row 63, the right-hand side: its LpR row is zero)
+            }
+        }
     }
     if (hasPrev) __syncthreads();
     if (wave == 0) {
