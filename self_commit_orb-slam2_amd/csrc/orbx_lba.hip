@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <atomic>
 #include <functional>
+#include <type_traits>
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -835,7 +836,8 @@ __device__ __forceinline__ double pivot_rsqrt(double x)
 //   the other blocks  the REST of the previous panel's trailing update, block columns > p, one 32x32 tile each.
 // The two kinds touch disjoint parts of S and only read L[:, p-1], so they need no order between them: the trailing update no
 // longer sits between two panels (15 dependent launches per factorisation become 8) and runs while the panel's serial chain does.
-__global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, double *__restrict__ L, int n, int p0, int nPW, int T1, double *ywork, double *ysol, int *okFlag)
+__global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, double *__restrict__ L, int n, int p0, int nPW, int T1, double *ywork, double *ysol, int *okFlag,
+                                                   double *__restrict__ diagInv /* 1 / L[i][i], for the substitution kernel */)
 {
     __shared__ double Ld[CNB][CNB + 1];      // diagonal block in, L11 (lower incl. diagonal) out      | update role: la
     __shared__ double Tt[64][CNB + 1];       // 63 rows of the panel below + the right-hand side (row 63) | update role: lb (first 32 rows)
@@ -950,6 +952,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
 #pragma unroll
         for (int c = 0; c < CNB; c++) x[c] = Tt[lane][c];
         bool bad = false;
+        double invOwn = 1.0;
         const bool ywLive = lane < CHOL_RPW && r0 + lane < n;
         const double yw = ywLive ? ywork[r0 + lane] : 0.0;     // in flight during the elimination
 #pragma unroll
@@ -988,6 +991,8 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int k = 0; k < 4; k++) invOwn = lane == c0 + k ? inv[k] : invOwn;      // lane c collects 1 / L[c][c] (no store on the chain)
             // own entries against the block (rows of the block itself reproduce d[][] in their lower part)
             double l[4];
             l[0] = a[j0] * inv[0];
@@ -1024,6 +1029,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
 #pragma unroll
         for (int c = 0; c < CNB; c++) Tt[lane][c] = x[c];
         if (bad && lane == 0) sBad = 1;
+        if (blockIdx.x == 0 && lane < CNB) diagInv[p0 + lane] = invOwn;      // (the buffer is padded to a multiple of 32)
         // b of the rows below -= L21 y   (y = the solved right-hand side in lane 63)
         double dot[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1101,6 +1107,81 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict_
         __syncthreads();
     }
     if (!XG) for (int i = tid; i < n; i += 1024) x[i] = sxLds[i];
+}
+
+// L^T x = y for n <= 32 NP (the local-BA sizes), latency version: the kernel above waits for its loads of L once per panel (~3 us
+// each, 30 us for 50 keyframes); here nothing on the serial chain touches global memory.  Column oriented: after the 32 unknowns
+// of panel p are solved (one wave, registers + v_readlane as above, the reciprocal diagonal folded into the columns beforehand),
+// every thread adds its share of  L[p rows][col]^T x_p  to a register accumulator of ITS column (thread = (column, third of the 32
+// rows)); the row block of L it needs was requested two panels earlier and sits in registers.  The three accumulators of a column
+// meet in LDS only when that column's panel is next.  Two (LDS-only) barriers per panel.
+// Workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() is a workgroup-scope release + acquire and makes
+// the compiler wait for vmcnt(0) as well, i.e. for every global load in flight - exactly the prefetches the kernel below keeps
+// outstanding across its barriers.  Only LDS data is exchanged at these barriers.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NP>
+__global__ __launch_bounds__(1024) void k_chol_backsub_reg(const double *__restrict__ L, const double *__restrict__ ysol, const double *__restrict__ diagInv, int n, double *x)
+{
+    constexpr int CW = 32 * NP, RQ = 11;       // columns, rows per thread and panel (3 x 11 >= 32)
+    __shared__ double y[CW], di[CW], part[3][CNB], l11s[2][CNB][CNB + 1], xs[CNB + 1];
+    const int tid = threadIdx.x, col = tid % CW, rq = tid / CW, lane = tid & 63;
+    const bool upd = rq < 3 && tid < 3 * CW;
+    double lv[NP][RQ], ld[NP], accs[2] = {0, 0};
+    auto request = [&](auto P) {       // row block and diagonal block of panel P (compile-time index)
+        constexpr int pp = decltype(P)::value;
+        const int p0 = CNB * pp;
+#pragma unroll
+        for (int k = 0; k < RQ; k++) {
+            const int rr = RQ * rq + k;
+            lv[pp][k] = (upd && rr < CNB && p0 + rr < n && col < p0) ? L[(size_t)(p0 + rr) * n + col] : 0.0;
+        }
+        const int r = tid >> 5, cc = tid & 31;
+        ld[pp] = (p0 + r < n && cc < r) ? L[(size_t)(p0 + r) * n + p0 + cc] : 0.0;   // strictly lower part: the reciprocal diagonal comes from diagInv
+    };
+    request(std::integral_constant<int, NP - 1>());
+    if (NP > 1) request(std::integral_constant<int, (NP > 1 ? NP - 2 : 0)>());
+    for (int i = tid; i < CW; i += 1024) { y[i] = i < n ? ysol[i] : 0.0; di[i] = i < n ? diagInv[i] : 1.0; }
+    if (tid == 0) xs[CNB] = 0.0;
+#pragma unroll
+    for (int pp = NP - 1; pp >= 0; pp--) {
+        const int p0 = CNB * pp;
+        l11s[pp & 1][tid >> 5][tid & 31] = ld[pp];
+        if (upd && col >= p0 && col < p0 + CNB) part[rq][col - p0] = accs[0] + accs[1];
+        lds_barrier();
+        if (tid < 64) {
+            const int t = lane & (CNB - 1);
+            const double inv = di[p0 + t];
+            double xv = (y[p0 + t] - ((part[0][t] + part[1][t]) + part[2][t])) * inv;      // scaled unknown: x_t once every later one is subtracted
+            // column t of L11 in two halves of 16 registers (the prefetched row blocks need the rest of the 128 a thread may use)
+#pragma unroll
+            for (int hh = 1; hh >= 0; hh--) {
+                double lc[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) lc[k] = l11s[pp & 1][16 * hh + k][t] * inv;      // unconditional (a guarded load becomes a branch per element): zero on and above the diagonal
+#pragma unroll
+                for (int k = 15; k >= 0; k--) {
+                    const int cc = 16 * hh + k;
+                    xv = __builtin_fma(-lc[k], readlane_f64(xv, cc), xv);      // (lc = 0 for the lanes t >= cc: they keep their value)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (tid < CNB) { xs[t] = xv; y[p0 + t] = xv; }
+        }
+        lds_barrier();
+        if (pp > 0) {
+#pragma unroll
+            for (int k = 0; k < RQ; k++) accs[k & 1] = __builtin_fma(lv[pp][k], xs[min(RQ * rq + k, CNB)], accs[k & 1]);   // (rows past 31: lv = 0, xs[32] = 0)
+        }
+        if (pp >= 2) {
+            switch (pp) {   // compile-time panel index for the register arrays
+#define ORBX_REQ(Q) case Q + 2: if (Q + 2 <= NP - 1) request(std::integral_constant<int, (Q <= NP - 1 ? Q : 0)>()); break;
+                ORBX_REQ(0) ORBX_REQ(1) ORBX_REQ(2) ORBX_REQ(3) ORBX_REQ(4) ORBX_REQ(5) ORBX_REQ(6) ORBX_REQ(7)
+#undef ORBX_REQ
+            }
+        }
+    }
+    for (int i = tid; i < n; i += 1024) x[i] = y[i];
 }
 
 // x_l = D^-1 (b_l - B^T x_p)   (block_solver.hpp:459-481)
@@ -1499,7 +1580,7 @@ struct orbx_lba {
     double flops = 0;
     OrbxDevBuf<DPose> pose, poseBak;
     OrbxDevBuf<double> pt, ptBak, intr, obs, info, err, rchi, edgeBlk, Hpp, bp, Hll, bl, Dinv, Ddb, S, bs, xp, xl, red;
-    OrbxDevBuf<double> Lmat, ywork, ysol;   // multi-workgroup Cholesky: the factor and the two halves of the right-hand side
+    OrbxDevBuf<double> Lmat, ywork, ysol, diagInv;   // multi-workgroup Cholesky: the factor and the two halves of the right-hand side
     OrbxDevBuf<int> ep, ek, ptStart, ptEdges, kfStart, kfEdges, poseIdx, ptIdx, okFlag;
     OrbxDevBuf<uint8_t> stereo, active;
     uint8_t *hostIO = nullptr;   // pinned: the marshalled inputs of a call on their way up, flags / chi2 / estimates on their way down
@@ -1533,7 +1614,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     rc = rc ? rc : h->pose.ensure(K); rc = rc ? rc : h->poseBak.ensure(K); rc = rc ? rc : h->pt.ensure(3 * P); rc = rc ? rc : h->ptBak.ensure(3 * P);
     rc = rc ? rc : h->intr.ensure(5 * K); rc = rc ? rc : h->obs.ensure(3 * E); rc = rc ? rc : h->info.ensure(E); rc = rc ? rc : h->err.ensure(3 * E);
     rc = rc ? rc : h->rchi.ensure(E); rc = rc ? rc : h->edgeBlk.ensure(E * EB_SIZE); rc = rc ? rc : h->Hpp.ensure(36 * K); rc = rc ? rc : h->bp.ensure(n6);
-    rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->Ddb.ensure(3 * P); rc = rc ? rc : h->ywork.ensure(n6); rc = rc ? rc : h->ysol.ensure(n6);
+    rc = rc ? rc : h->Hll.ensure(9 * P); rc = rc ? rc : h->bl.ensure(3 * P); rc = rc ? rc : h->Dinv.ensure(9 * P); rc = rc ? rc : h->Ddb.ensure(3 * P); rc = rc ? rc : h->ywork.ensure(n6); rc = rc ? rc : h->ysol.ensure(n6); rc = rc ? rc : h->diagInv.ensure(n6 + CNB);
     rc = rc ? rc : h->bs.ensure(n6); rc = rc ? rc : h->xp.ensure(n6); rc = rc ? rc : h->xl.ensure(3 * P); rc = rc ? rc : h->red.ensure(16);
     rc = rc ? rc : h->ep.ensure(E); rc = rc ? rc : h->ek.ensure(E); rc = rc ? rc : h->ptStart.ensure(P + 1); rc = rc ? rc : h->ptEdges.ensure(E);
     rc = rc ? rc : h->kfStart.ensure(K + 1); rc = rc ? rc : h->kfEdges.ensure(E); rc = rc ? rc : h->poseIdx.ensure(K); rc = rc ? rc : h->ptIdx.ensure(P);
@@ -1550,7 +1631,7 @@ extern "C" void orbx_lba_destroy(orbx_lba *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->pose.release(); h->poseBak.release(); h->pt.release(); h->ptBak.release(); h->intr.release(); h->obs.release(); h->info.release(); h->err.release();
-    h->rchi.release(); h->edgeBlk.release(); h->Hpp.release(); h->bp.release(); h->Hll.release(); h->bl.release(); h->Dinv.release(); h->Ddb.release(); h->S.release(); h->Lmat.release(); h->ywork.release(); h->ysol.release();
+    h->rchi.release(); h->edgeBlk.release(); h->Hpp.release(); h->bp.release(); h->Hll.release(); h->bl.release(); h->Dinv.release(); h->Ddb.release(); h->S.release(); h->Lmat.release(); h->ywork.release(); h->ysol.release(); h->diagInv.release();
     h->bs.release(); h->xp.release(); h->xl.release(); h->red.release(); h->ep.release(); h->ek.release(); h->ptStart.release(); h->ptEdges.release();
     h->kfStart.release(); h->kfEdges.release(); h->poseIdx.release(); h->ptIdx.release(); h->okFlag.release(); h->stereo.release(); h->active.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1717,9 +1798,12 @@ int optimize(Ctx &c, int iterations, double stats[4])
                         const int nPW = std::max(1, (below + CHOL_RPW - 1) / CHOL_RPW);
                         const int T1 = p0 > 0 ? (n - p0 + CNB - 1) / CNB - 1 : 0;        // tile rows / columns beyond block column p that still await the previous panel's update
                         hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nPW + T1 * T1)), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0, nPW, std::max(T1, 1), h->ywork.p,
-                                           h->ysol.p, h->okFlag.p);
+                                           h->ysol.p, h->okFlag.p, h->diagInv.p);
                     }
-                    if (n <= CHOL_LDS_X) hipLaunchKernelGGL(k_chol_backsub<false>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
+                    if (n <= 128) hipLaunchKernelGGL(k_chol_backsub_reg<4>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
+                    else if (n <= 224) hipLaunchKernelGGL(k_chol_backsub_reg<7>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
+                    else if (n <= 320) hipLaunchKernelGGL(k_chol_backsub_reg<10>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
+                    else if (n <= CHOL_LDS_X) hipLaunchKernelGGL(k_chol_backsub<false>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
                     else hipLaunchKernelGGL(k_chol_backsub<true>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
                 } else {   // widest panel whose n x NB doubles fit next to the solution vector in LDS
                     const size_t budget = 120 * 1024;
