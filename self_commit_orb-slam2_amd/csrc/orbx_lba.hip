@@ -1738,12 +1738,12 @@ int optimize(Ctx &c, int iterations, double stats[4])
     // comes from ONE reduction, and a trial reads its three sums and the Cholesky flag back together, once.
     bool errorsFresh = false;      // d.err / rchi hold the errors of the CURRENT state and freshChi their robust sum
     double freshChi = 0;
-    for (int it = 0; it < iterations && !(c.stop && *c.stop) && ok; it++) {
-        double currentChi = freshChi;
-        if (!errorsFresh) {
-            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p);
-            LCHECK();
-        }
+    // The linearisation of the NEXT iteration is queued behind a trial before its result is known (almost every trial of a bundle
+    // adjustment is accepted, and the host round trip - results in pinned memory, decision, launch - would otherwise leave the device
+    // idle for ~15 us per iteration).  It overwrites H and b of the state the trial started from; after a rejected trial that is
+    // retried they are rebuilt from the restored estimates (same kernels, same inputs, same bits).
+    bool linearized = false, rebuild = false;
+    auto linearize = [&]() -> int {
         hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
         LCHECK();
         if (c.beforeSums) { int rcd = c.beforeSums(); c.beforeSums = nullptr; if (rcd) return rcd; }
@@ -1752,6 +1752,16 @@ int optimize(Ctx &c, int iterations, double stats[4])
         hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->Hpp.p, h->bp.p);
         LCHECK();
         h->flops += 400.0 * nAct;
+        return ORBX_OK;
+    };
+    for (int it = 0; it < iterations && !(c.stop && *c.stop) && ok; it++) {
+        double currentChi = freshChi;
+        if (!errorsFresh) {
+            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p);
+            LCHECK();
+        }
+        if (!linearized) { int rcl = linearize(); if (rcl) return rcl; }
+        linearized = false;
         if (it == 0) {   // computeLambdaInit: tau * max |diag H| (:166-180)
             hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(1024), 0, h->stream, h->Hpp.p, nPose, h->Hll.p, nPt, h->red.p);
             LCHECK();
@@ -1773,6 +1783,13 @@ int optimize(Ctx &c, int iterations, double stats[4])
         do {
             // (push() happens inside k_backsub_update, right before the estimates are changed)
             int okHost = 1;
+            if (rebuild) {   // a speculative linearisation was made on a state that has been rejected since: H and b of the restored one again
+                hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p);
+                LCHECK();
+                int rcl = linearize();
+                if (rcl) return rcl;
+                rebuild = false;
+            }
             {
                 const int nInit = nP6 > 0 ? 64 : 0;
                 hipLaunchKernelGGL(k_schur_setup, dim3((unsigned)(nInit + (P + 3) / 4)), dim3(256), 0, h->stream, c.d, nInit, h->Hpp.p, h->bp.p, nPose, h->ptStart.p,
@@ -1835,6 +1852,9 @@ int optimize(Ctx &c, int iterations, double stats[4])
             hipLaunchKernelGGL(k_trial_finish, dim3(1), dim3(256), 0, h->stream, h->partChi.p, (int)gE, h->partL.p, (int)gU, h->xp.p, h->bp.p, nP6, lambda,
                                nP6 > 0 ? h->okFlag.p : (const int *)nullptr, (const double *)nullptr, h->hostRedDev, seq);
             LCHECK();
+            // speculate unless this can be the last iteration of the stage (iteration budget, or two unproductive ones so far)
+            const bool spec = it + 1 < iterations && nBad < 2 && !(c.stop && *c.stop);
+            if (spec) { int rcl = linearize(); if (rcl) return rcl; }
             {   // the one wait of the trial: results and sequence number arrive in pinned memory
                 int rcw = wait_seq(h, seq);
                 if (rcw) return rcw;
@@ -1853,7 +1873,9 @@ int optimize(Ctx &c, int iterations, double stats[4])
                 ni = 2;
                 currentChi = tempChi;
                 errorsFresh = true; freshChi = tempChi;       // d.err / rchi are those of the state just accepted
+                linearized = spec;
             } else {
+                rebuild = spec;
                 lambda *= ni;
                 ni *= 2;
                 errorsFresh = false;
