@@ -418,6 +418,135 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *arena, UnpackSegs
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Adjacency lists (CSR by keyframe and by landmark, edges ascending inside a row - the order a stable host-side counting sort
+// gives, so the sums that walk them keep their bits) built ON THE DEVICE from the row starts the host gets for free while it
+// marshals the edges: the host-side scatter cost ~100 us per 60k edges, which the device had to wait for after its first kernels.
+//   keyframe rows (long, few keys): chunks of 1024 edges count their keys (k_csr_kf_count), a scan over the chunks per key gives
+//     every chunk its first slot in every row (k_csr_kf_scan), and one wave per chunk places its edges in order - a ballot per
+//     distinct key of a 64-edge slice, rank = popcount of the lower lanes (k_csr_kf_fill);
+//   landmark rows (short): unordered fill with an atomic slot counter, then every edge counts the smaller edge ids of its row.
+// ---------------------------------------------------------------------------------------------
+#define CSR_CHUNK 1024
+__global__ __launch_bounds__(256) void k_csr_kf_count(const int *__restrict__ ek, int E, int K, int *__restrict__ chunkCnt)
+{
+    extern __shared__ int csrLds[];
+    for (int i = threadIdx.x; i < K; i += 256) csrLds[i] = 0;
+    __syncthreads();
+    const int e0 = blockIdx.x * CSR_CHUNK;
+    for (int i = threadIdx.x; i < CSR_CHUNK; i += 256)
+        if (e0 + i < E) atomicAdd(&csrLds[ek[e0 + i]], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += 256) chunkCnt[(size_t)blockIdx.x * K + i] = csrLds[i];
+}
+
+__global__ __launch_bounds__(256) void k_csr_kf_scan(const int *__restrict__ kfStart, int K, int nChunk, int *chunkCnt)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    int run = kfStart[k];
+    for (int c = 0; c < nChunk; c++) { const int t = chunkCnt[(size_t)c * K + k]; chunkCnt[(size_t)c * K + k] = run; run += t; }
+}
+
+__global__ __launch_bounds__(64) void k_csr_kf_fill(const int *__restrict__ ek, int E, int K, const int *__restrict__ chunkBase, int *__restrict__ kfEdges)
+{
+    extern __shared__ int csrLds[];   // next free slot of every row for this chunk
+    const int lane = threadIdx.x;
+    for (int i = lane; i < K; i += 64) csrLds[i] = chunkBase[(size_t)blockIdx.x * K + i];
+    __syncthreads();
+    for (int sub = 0; sub < CSR_CHUNK / 64; sub++) {
+        const int e = blockIdx.x * CSR_CHUNK + sub * 64 + lane;
+        const int key = e < E ? ek[e] : -1;
+        bool todo = key >= 0;
+        for (;;) {
+            const unsigned long long act = __ballot(todo);
+            if (!act) break;
+            const int leader = __ffsll((long long)act) - 1;
+            const int lk = __shfl(key, leader);
+            const bool mine = todo && key == lk;
+            const unsigned long long m = __ballot(mine);
+            const int first = csrLds[lk];
+            if (mine) { kfEdges[first + __popcll(m & ((1ull << lane) - 1ull))] = e; todo = false; }
+            if (lane == leader) csrLds[lk] = first + __popcll(m);      // (one wave: the LDS keeps the order of its accesses)
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_csr_pt_fill(const int *__restrict__ ep, int E, const int *__restrict__ ptStart, int *fill, int *__restrict__ ptTmp)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int l = ep[e];
+    ptTmp[ptStart[l] + atomicAdd(&fill[l], 1)] = e;
+}
+
+__global__ __launch_bounds__(256) void k_csr_pt_rank(const int *__restrict__ ep, int E, const int *__restrict__ ptStart, const int *__restrict__ ptTmp, int *__restrict__ ptEdges)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int l = ep[e], s0 = ptStart[l], m = ptStart[l + 1] - s0;
+    int rank = 0;
+    for (int i = 0; i < m; i++) rank += ptTmp[s0 + i] < e;
+    ptEdges[s0 + rank] = e;
+}
+
+// initializeOptimization(level 0) on the device (sparse_optimizer.cpp:166-267): active[e] = edge not flagged as an outlier by the previous
+// stage (flag == nullptr: all), a vertex takes part when one of its edges does, free keyframes and landmarks are numbered in order.
+// One workgroup; the three counts go to pinned memory like the sums of a trial (host[10..12], sequence number last).  Before, the
+// flags went to the host, through three O(E) loops and back: ~120 us of idle device between the two stages of a local BA.
+__device__ __forceinline__ int block_incl_scan1024(int v, int *wsum /* 17 */, int *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(x, o); if (lane >= o) x += u; }
+    __syncthreads();                       // wsum may still be read from the previous call
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int i = 0; i < 16; i++) { const int t = wsum[i]; if (i < w) off += t; tot += t; }
+    *total = tot;
+    return x + off;
+}
+__global__ __launch_bounds__(1024) void k_stage_prep(int K, int P, int E, const int *__restrict__ ep, const int *__restrict__ ek, const uint8_t *__restrict__ flag,
+                                                     const uint8_t *__restrict__ fixed, uint8_t *active, int *poseIdx, int *ptIdx, int *pAct, int *lAct, double *host, double seq)
+{
+    __shared__ int wsum[17];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < K; k += 1024) pAct[k] = 0;
+    for (int l = tid; l < P; l += 1024) lAct[l] = 0;
+    __syncthreads();
+    int nAct = 0;
+    for (int e = tid; e < E; e += 1024) {
+        const bool a = flag ? flag[e] == 0 : true;
+        active[e] = a ? 1 : 0;
+        if (a) { pAct[ek[e]] = 1; lAct[ep[e]] = 1; nAct++; }      // (concurrent stores of the same value)
+    }
+    __threadfence_block();
+    __syncthreads();
+    int nPose = 0, nPt = 0, tot;
+    for (int k0 = 0; k0 < K; k0 += 1024) {
+        const int k = k0 + tid;
+        const int f = (k < K && __hip_atomic_load(pAct + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) && !fixed[k]) ? 1 : 0;
+        const int inc = block_incl_scan1024(f, wsum, &tot);
+        if (k < K) poseIdx[k] = f ? nPose + inc - 1 : -1;
+        nPose += tot;
+    }
+    for (int l0 = 0; l0 < P; l0 += 1024) {
+        const int l = l0 + tid;
+        const int f = (l < P && __hip_atomic_load(lAct + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) ? 1 : 0;
+        const int inc = block_incl_scan1024(f, wsum, &tot);
+        if (l < P) ptIdx[l] = f ? nPt + inc - 1 : -1;
+        nPt += tot;
+    }
+    block_incl_scan1024(nAct, wsum, &tot);
+    if (tid == 0) {
+        host[10] = (double)nPose; host[11] = (double)nPt; host[12] = (double)tot;
+        __threadfence_system();
+        __hip_atomic_store(host + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // pop() of a rejected trial: the estimates saved by k_backsub_update come back (one launch instead of two copies)
 __global__ __launch_bounds__(256) void k_restore(LbaDev d, const DPose *poseBak, const double *ptBak)
 {
@@ -1585,8 +1714,8 @@ struct orbx_lba {
     OrbxDevBuf<uint8_t> stereo, active;
     uint8_t *hostIO = nullptr;   // pinned: the marshalled inputs of a call on their way up, flags / chi2 / estimates on their way down
     size_t hostIOBytes = 0;
-    OrbxDevBuf<uint8_t> flagDev, inArena;
-    std::vector<int> csrFill;            // host scratch of the adjacency-list build
+    OrbxDevBuf<uint8_t> flagDev, inArena, fixedDev;
+    OrbxDevBuf<int> csrCnt, ptTmp, fillP, pActF, lActF;   // adjacency-list builder and stage preparation (device side)
     OrbxDevBuf<double> partChi, partL;   // per-workgroup partial sums of k_errors / k_backsub_update
     double *hostRedDev = nullptr;        // device view of hostRed
     double seq = 0;                      // sequence number of the last k_trial_finish
@@ -1619,6 +1748,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     rc = rc ? rc : h->ep.ensure(E); rc = rc ? rc : h->ek.ensure(E); rc = rc ? rc : h->ptStart.ensure(P + 1); rc = rc ? rc : h->ptEdges.ensure(E);
     rc = rc ? rc : h->kfStart.ensure(K + 1); rc = rc ? rc : h->kfEdges.ensure(E); rc = rc ? rc : h->poseIdx.ensure(K); rc = rc ? rc : h->ptIdx.ensure(P);
     rc = rc ? rc : h->okFlag.ensure(1); rc = rc ? rc : h->stereo.ensure(E); rc = rc ? rc : h->active.ensure(E);
+    rc = rc ? rc : h->fixedDev.ensure(K); rc = rc ? rc : h->ptTmp.ensure(E); rc = rc ? rc : h->fillP.ensure(P); rc = rc ? rc : h->pActF.ensure(K); rc = rc ? rc : h->lActF.ensure(P);
     rc = rc ? rc : h->partChi.ensure((E + 255) / 256); rc = rc ? rc : h->partL.ensure((std::max(K, 16 * P) + 255) / 256);
     if (rc) { orbx_lba_destroy(h); return rc; }
     *out = h;
@@ -1639,7 +1769,7 @@ extern "C" void orbx_lba_destroy(orbx_lba *h)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->hostRed) (void)hipHostFree(h->hostRed);
     if (h->hostIO) (void)hipHostFree(h->hostIO);
-    h->flagDev.release(); h->partChi.release(); h->partL.release(); h->inArena.release();
+    h->flagDev.release(); h->partChi.release(); h->partL.release(); h->inArena.release(); h->fixedDev.release(); h->csrCnt.release(); h->ptTmp.release(); h->fillP.release(); h->pActF.release(); h->lActF.release();
     delete h;
 }
 
@@ -1658,11 +1788,8 @@ struct Ctx {
     int robust;
     int nPose, nPt;
     const volatile uint8_t *stop;
-    std::vector<uint8_t> level;   // host copy
-    const int *ep, *ek;           // the caller's edge arrays (validated)
-    const uint8_t *fixed;
-    size_t idxOff = 0;            // where the index arrays of a stage are staged: behind the inputs, in the pinned buffer and in the arena
-    std::function<int()> beforeSums;   // work deferred until the first kernel that walks the adjacency lists (see lba_run)
+    const uint8_t *stageFlags = nullptr;   // device: outlier flags of the previous stage (level 1 edges), nullptr = every edge takes part
+    int nPose0 = 0, nPt0 = 0;              // vertex counts of a stage without flags, known to the host from the row lengths
 };
 
 // Waits for the sequence number k_trial_finish stores into pinned memory after its results.  The word is polled; the stream is queried
@@ -1693,22 +1820,20 @@ int optimize(Ctx &c, int iterations, double stats[4])
     orbx_lba *h = c.h;
     const int K = c.d.K, P = c.d.P, E = c.d.E;
     stats[0] = stats[1] = stats[2] = stats[3] = 0;
-    // initializeOptimization(0): active edges/vertices and the index mapping (sparse_optimizer.cpp:166-267)
-    // written straight into the pinned staging buffer (idle between the upload of a call and its results): one copy, one k_unpack, no
-    // synchronisation - the next host write to the buffer is behind the read-back of this stage's results
-    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t oAct = c.idxOff, oPi = oAct + pad((size_t)E), oLi = oPi + pad((size_t)K * 4), idxEnd = oLi + pad((size_t)P * 4);
-    if (idxEnd > h->hostIOBytes || idxEnd > h->inArena.n) { orbx_set_error("LBA staging buffer too small"); return ORBX_ERR_CAPACITY; }
-    uint8_t *active = h->hostIO + oAct;
-    int *poseIdx = (int *)(h->hostIO + oPi), *ptIdx = (int *)(h->hostIO + oLi);
-    for (int k = 0; k < K; k++) poseIdx[k] = -1;
-    for (int l = 0; l < P; l++) ptIdx[l] = -1;
-    std::vector<char> pAct((size_t)K, 0), lAct((size_t)P, 0);
-    int nAct = 0;
-    for (int e = 0; e < E; e++) { active[e] = c.level[(size_t)e] == 0; if (active[e]) { pAct[(size_t)c.ek[e]] = 1; lAct[(size_t)c.ep[e]] = 1; nAct++; } }
-    int nPose = 0, nPt = 0;
-    for (int k = 0; k < K; k++) if (pAct[(size_t)k] && !c.fixed[k]) poseIdx[k] = nPose++;
-    for (int l = 0; l < P; l++) if (lAct[(size_t)l]) ptIdx[l] = nPt++;
+    // initializeOptimization(0): active edges / vertices and the index mapping (sparse_optimizer.cpp:166-267), on the device
+    int nPose, nPt, nAct;
+    {
+        const double seq = (h->seq += 1.0);
+        hipLaunchKernelGGL(k_stage_prep, dim3(1), dim3(1024), 0, h->stream, K, P, E, (const int *)h->ep.p, (const int *)h->ek.p, c.stageFlags, (const uint8_t *)h->fixedDev.p,
+                           h->active.p, h->poseIdx.p, h->ptIdx.p, h->pActF.p, h->lActF.p, h->hostRedDev, seq);
+        LCHECK();
+        if (!c.stageFlags) { nPose = c.nPose0; nPt = c.nPt0; nAct = E; }      // nothing to wait for
+        else {
+            int rcw = wait_seq(h, seq);
+            if (rcw) return rcw;
+            nPose = (int)h->hostRed[10]; nPt = (int)h->hostRed[11]; nAct = (int)h->hostRed[12];
+        }
+    }
     if (nAct == 0 || nPose + nPt == 0) return ORBX_OK;
     if (6 * nPose > CHOL_DENSE_MAX_N) { orbx_set_error("%d free keyframes exceed the dense reduced-system limit %d", nPose, CHOL_DENSE_MAX_N / 6); return ORBX_ERR_CAPACITY; }
     c.nPose = nPose; c.nPt = nPt;
@@ -1717,16 +1842,6 @@ int optimize(Ctx &c, int iterations, double stats[4])
         int rc = h->S.ensure(nn ? nn : 1);
         rc = rc ? rc : h->Lmat.ensure(nn ? nn : 1);
         if (rc) return rc;
-    }
-    {
-        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p + oAct, h->hostIO + oAct, idxEnd - oAct, hipMemcpyHostToDevice, h->stream));
-        UnpackSegs sg;
-        sg.src[0] = oAct; sg.dst[0] = h->active.p; sg.bytes[0] = (size_t)E;
-        sg.src[1] = oPi; sg.dst[1] = h->poseIdx.p; sg.bytes[1] = (size_t)K * 4;
-        sg.src[2] = oLi; sg.dst[2] = h->ptIdx.p; sg.bytes[2] = (size_t)P * 4;
-        sg.n = 3;
-        hipLaunchKernelGGL(k_unpack, dim3(64), dim3(256), 0, h->stream, (const uint8_t *)h->inArena.p, sg);
-        LCHECK();
     }
     const int nP6 = 6 * nPose;
     const unsigned gE = (unsigned)((E + 255) / 256);
@@ -1746,7 +1861,6 @@ int optimize(Ctx &c, int iterations, double stats[4])
     auto linearize = [&]() -> int {
         hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
         LCHECK();
-        if (c.beforeSums) { int rcd = c.beforeSums(); c.beforeSums = nullptr; if (rcd) return rcd; }
         hipLaunchKernelGGL(k_sum_points, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p);
         LCHECK();
         hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->Hpp.p, h->bp.p);
@@ -1913,13 +2027,14 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t oPose = 0, oIntr = oPose + pad((size_t)K * sizeof(DPose)), oPt = oIntr + pad((size_t)5 * K * 8), oObs = oPt + pad((size_t)3 * P * 8),
                  oInfo = oObs + pad((size_t)3 * E * 8), oSt = oInfo + pad((size_t)E * 8), oEp = oSt + pad((size_t)E), oEk = oEp + pad((size_t)E * 4),
-                 oPs = oEk + pad((size_t)E * 4), oPe = oPs + pad(((size_t)P + 1) * 4), oKs = oPe + pad((size_t)E * 4), oKe = oKs + pad(((size_t)K + 1) * 4),
-                 inBytes = oKe + pad((size_t)E * 4);
-    const size_t idxBytes = pad((size_t)E) + pad((size_t)K * 4) + pad((size_t)P * 4);   // optimize(): active | poseIdx | ptIdx behind the inputs
+                 oPs = oEk + pad((size_t)E * 4), oKs = oPs + pad(((size_t)P + 1) * 4), oFx = oKs + pad(((size_t)K + 1) * 4), inBytes = oFx + pad((size_t)K);
     const size_t dFlag = 0, dChi = dFlag + pad((size_t)E), dPose = dChi + pad((size_t)E * 8), dPt = dPose + pad((size_t)K * sizeof(DPose)),
                  outBytes = dPt + pad((size_t)3 * P * 8);
+    const int nChunk = (E + CSR_CHUNK - 1) / CSR_CHUNK;
+    const size_t csrLds = (size_t)K * sizeof(int);
+    if (csrLds > 150 * 1024) { orbx_set_error("%d keyframes exceed the adjacency-list builder's limit %d", K, 150 * 1024 / 4); return ORBX_ERR_CAPACITY; }
     {
-        const size_t need = std::max(inBytes + idxBytes, outBytes);
+        const size_t need = std::max(inBytes, outBytes);
         if (need > h->hostIOBytes) {
             ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
             if (h->hostIO) (void)hipHostFree(h->hostIO);
@@ -1928,19 +2043,18 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
             h->hostIOBytes = need;
         }
         int rcb = h->flagDev.ensure(outBytes);
-        rcb = rcb ? rcb : h->inArena.ensure(inBytes + idxBytes);
+        rcb = rcb ? rcb : h->inArena.ensure(inBytes);
+        rcb = rcb ? rcb : h->csrCnt.ensure((size_t)nChunk * (size_t)K);
         if (rcb) return rcb;
     }
-    // The pinned buffer is written in the order it is sent: (1) estimates, observations and edge ends - copied and unpacked while the
-    // host goes on, (2) the index arrays of the first optimize() stage, (3) the adjacency lists (CSR by landmark and by keyframe),
-    // built while the device already computes errors and Jacobians and sent right before the first kernel that walks them.  Nothing
-    // waits for a copy: the results come back into the front of the same buffer long after the device has consumed all of it.
+    // The host only converts (float boundary -> double state) and counts; everything goes up in ONE copy of the pinned buffer, one
+    // kernel distributes it, and the adjacency lists and the index mapping of the stages are made on the device.  Nothing waits for
+    // the copy: the results come back into the front of the same buffer long after the device has consumed it.
     uint8_t *io = h->hostIO;
     DPose *pose = (DPose *)(io + oPose);
     double *intr = (double *)(io + oIntr), *pt = (double *)(io + oPt), *obs = (double *)(io + oObs), *info = (double *)(io + oInfo);
-    uint8_t *stereo = io + oSt;
-    int *epH = (int *)(io + oEp), *ekH = (int *)(io + oEk), *ptStart = (int *)(io + oPs), *ptEdges = (int *)(io + oPe), *kfStart = (int *)(io + oKs),
-        *kfEdges = (int *)(io + oKe);
+    uint8_t *stereo = io + oSt, *fixedH = io + oFx;
+    int *epH = (int *)(io + oEp), *ekH = (int *)(io + oEk), *ptStart = (int *)(io + oPs), *kfStart = (int *)(io + oKs);
     for (int k = 0; k < K; k++) {
         double R[9];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = p->poses[16 * (size_t)k + 4 * i + j];
@@ -1948,6 +2062,7 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
         quat_normalize_pos(pose[k].q);
         for (int i = 0; i < 3; i++) pose[k].t[i] = p->poses[16 * (size_t)k + 4 * i + 3];
         for (int i = 0; i < 5; i++) intr[5 * (size_t)k + i] = p->intrinsics[5 * (size_t)k + i];
+        fixedH[k] = p->fixed[k] ? 1 : 0;
     }
     for (int i = 0; i < 3 * P; i++) pt[i] = p->points[i];
     for (int l = 0; l <= P; l++) ptStart[l] = 0;
@@ -1960,48 +2075,41 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
         stereo[e] = !(ob[2] < 0);
         info[e] = p->edge_inv_sigma2[e];
         epH[e] = l; ekH[e] = k;
-        ptStart[l + 1]++; kfStart[k + 1]++;      // row lengths of the adjacency lists (finished in beforeSums)
+        ptStart[l + 1]++; kfStart[k + 1]++;      // row lengths of the adjacency lists
     }
+    Ctx c;
+    c.h = h; c.stop = stop;
+    for (int l = 0; l < P; l++) { c.nPt0 += ptStart[l + 1] > 0; ptStart[l + 1] += ptStart[l]; }                       // row starts; vertices with an edge
+    for (int k = 0; k < K; k++) { c.nPose0 += kfStart[k + 1] > 0 && !fixedH[k]; kfStart[k + 1] += kfStart[k]; }
     hipStream_t s = h->stream;
     ORBX_HIP_CHECK(hipEventRecord(h->ev0, s));
     {
-        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p, io, oPs, hipMemcpyHostToDevice, s));
+        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p, io, inBytes, hipMemcpyHostToDevice, s));
         UnpackSegs sg;
         int ns = 0;
         auto seg = [&](size_t off, void *dst, size_t bytes) { sg.src[ns] = off; sg.dst[ns] = dst; sg.bytes[ns] = bytes; ns++; };
         seg(oPose, h->pose.p, (size_t)K * sizeof(DPose)); seg(oPt, h->pt.p, (size_t)3 * P * 8); seg(oIntr, h->intr.p, (size_t)5 * K * 8);
         seg(oObs, h->obs.p, (size_t)3 * E * 8); seg(oInfo, h->info.p, (size_t)E * 8); seg(oSt, h->stereo.p, (size_t)E);
         seg(oEp, h->ep.p, (size_t)E * 4); seg(oEk, h->ek.p, (size_t)E * 4);
+        seg(oPs, h->ptStart.p, ((size_t)P + 1) * 4); seg(oKs, h->kfStart.p, ((size_t)K + 1) * 4); seg(oFx, h->fixedDev.p, (size_t)K);
         seg(~(size_t)0, h->err.p, (size_t)E * 3 * 8);
+        seg(~(size_t)0, h->fillP.p, (size_t)P * 4);
         sg.n = ns;
         hipLaunchKernelGGL(k_unpack, dim3(256), dim3(256), 0, s, (const uint8_t *)h->inArena.p, sg);
         LCHECK();
-    }
-    Ctx c;
-    c.h = h; c.stop = stop;
-    c.ep = p->edge_point; c.ek = p->edge_keyframe; c.fixed = p->fixed;
-    c.level.assign((size_t)E, 0);
-    c.idxOff = inBytes;
-    c.beforeSums = [=]() -> int {
-        // CSR by landmark and by keyframe, edges in insertion order
-        for (int l = 0; l < P; l++) ptStart[l + 1] += ptStart[l];
-        for (int k = 0; k < K; k++) kfStart[k + 1] += kfStart[k];
-        h->csrFill.resize((size_t)P + (size_t)K);
-        int *fp = h->csrFill.data(), *fk = fp + P;
-        for (int l = 0; l < P; l++) fp[l] = ptStart[l];
-        for (int k = 0; k < K; k++) fk[k] = kfStart[k];
-        for (int e = 0; e < E; e++) { ptEdges[fp[epH[e]]++] = e; kfEdges[fk[ekH[e]]++] = e; }
-        ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p + oPs, io + oPs, inBytes - oPs, hipMemcpyHostToDevice, s));
-        UnpackSegs sg;
-        int ns = 0;
-        auto seg = [&](size_t off, void *dst, size_t bytes) { sg.src[ns] = off; sg.dst[ns] = dst; sg.bytes[ns] = bytes; ns++; };
-        seg(oPs, h->ptStart.p, ((size_t)P + 1) * 4); seg(oPe, h->ptEdges.p, (size_t)E * 4); seg(oKs, h->kfStart.p, ((size_t)K + 1) * 4);
-        seg(oKe, h->kfEdges.p, (size_t)E * 4);
-        sg.n = ns;
-        hipLaunchKernelGGL(k_unpack, dim3(64), dim3(256), 0, s, (const uint8_t *)h->inArena.p, sg);
+        // adjacency lists
+        if (csrLds > 48 * 1024) {
+            ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_csr_kf_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)csrLds));
+            ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_csr_kf_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)csrLds));
+        }
+        const unsigned gE = (unsigned)((E + 255) / 256);
+        hipLaunchKernelGGL(k_csr_kf_count, dim3((unsigned)nChunk), dim3(256), csrLds, s, (const int *)h->ek.p, E, K, h->csrCnt.p);
+        hipLaunchKernelGGL(k_csr_kf_scan, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, (const int *)h->kfStart.p, K, nChunk, h->csrCnt.p);
+        hipLaunchKernelGGL(k_csr_kf_fill, dim3((unsigned)nChunk), dim3(64), csrLds, s, (const int *)h->ek.p, E, K, (const int *)h->csrCnt.p, h->kfEdges.p);
+        hipLaunchKernelGGL(k_csr_pt_fill, dim3(gE), dim3(256), 0, s, (const int *)h->ep.p, E, (const int *)h->ptStart.p, h->fillP.p, h->ptTmp.p);
+        hipLaunchKernelGGL(k_csr_pt_rank, dim3(gE), dim3(256), 0, s, (const int *)h->ep.p, E, (const int *)h->ptStart.p, (const int *)h->ptTmp.p, h->ptEdges.p);
         LCHECK();
-        return ORBX_OK;
-    };
+    }
     LbaDev &d = c.d;
     d.K = K; d.P = P; d.E = E; d.pose = h->pose.p; d.pt = h->pt.p; d.intr = h->intr.p; d.ep = h->ep.p; d.ek = h->ek.p; d.obs = h->obs.p;
     d.stereo = h->stereo.p; d.info = h->info.p; d.active = h->active.p; d.poseIdx = h->poseIdx.p; d.ptIdx = h->ptIdx.p; d.err = h->err.p;
@@ -2013,33 +2121,30 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     c.hub.dsqrStereo = (double)(float)((double)thStereo * (double)thStereo);
     // classification on the device (k_classify); only the flags come back between the stages, the rest with the final results
     const unsigned gEc = (unsigned)((std::max(E, std::max(K, 3 * P)) + 255) / 256);
-    auto classify = [&](std::vector<uint8_t> &flag, bool final) -> int {
-        uint8_t *oa = h->flagDev.p;     // device image of the result layout dFlag | dChi | dPose | dPt
-        hipLaunchKernelGGL(k_classify, dim3(gEc), dim3(256), 0, h->stream, c.d, oa + dFlag, final && res->edge_chi2 ? (double *)(oa + dChi) : (double *)nullptr,
-                           final ? (DPose *)(oa + dPose) : (DPose *)nullptr, final ? (double *)(oa + dPt) : (double *)nullptr);
-        LCHECK();
-        ORBX_HIP_CHECK(hipMemcpyAsync(io, oa, final ? outBytes : (size_t)E, hipMemcpyDeviceToHost, h->stream));
-        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-        memcpy(flag.data(), io + dFlag, (size_t)E);
-        if (final && res->edge_chi2) memcpy(res->edge_chi2, io + dChi, (size_t)E * 8);
-        return ORBX_OK;
-    };
+    uint8_t *oa = h->flagDev.p;     // device image of the result layout dFlag | dChi | dPose | dPt
     int rc = ORBX_OK;
-    std::vector<uint8_t> flag((size_t)E, 0);
     if (!(stop && *stop)) {
         c.robust = robust1 ? 1 : 0;
         if ((rc = optimize(c, iters1, res->stats)) != ORBX_OK) return rc;       // :863-864 (LBA), :247 (BundleAdjustment)
         if (secondStage && !(stop && *stop)) {
-            if ((rc = classify(flag, false)) != ORBX_OK) return rc;          // :880-912
-            for (int e = 0; e < E; e++) if (flag[(size_t)e]) c.level[(size_t)e] = 1;
+            // :880-912: the outlier flags stay on the device, the second stage starts from them (k_stage_prep)
+            hipLaunchKernelGGL(k_classify, dim3(gEc), dim3(256), 0, h->stream, c.d, oa + dFlag, (double *)nullptr, (DPose *)nullptr, (double *)nullptr);
+            LCHECK();
+            c.stageFlags = oa + dFlag;
             c.robust = 0;
             if ((rc = optimize(c, 10, res->stats + 4)) != ORBX_OK) return rc;   // :916-917
         }
     }
     ORBX_HIP_CHECK(hipEventRecord(h->ev1, s));
     h->timed = true;
-    if ((rc = classify(flag, true)) != ORBX_OK) return rc;                    // :921-958
-    for (int e = 0; e < E; e++) res->edge_outlier[e] = flag[(size_t)e];
+    // :921-958: final classification, chi2 and estimates in one kernel and one copy
+    hipLaunchKernelGGL(k_classify, dim3(gEc), dim3(256), 0, h->stream, c.d, oa + dFlag, res->edge_chi2 ? (double *)(oa + dChi) : (double *)nullptr, (DPose *)(oa + dPose),
+                       (double *)(oa + dPt));
+    LCHECK();
+    ORBX_HIP_CHECK(hipMemcpyAsync(io, oa, outBytes, hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    memcpy(res->edge_outlier, io + dFlag, (size_t)E);
+    if (res->edge_chi2) memcpy(res->edge_chi2, io + dChi, (size_t)E * 8);
     pose = (DPose *)(io + dPose); pt = (double *)(io + dPt);                  // final estimates (pinned read-back)
     for (int k = 0; k < K; k++) {                                             // Converter::toCvMat(SE3Quat)
         double R[9];
