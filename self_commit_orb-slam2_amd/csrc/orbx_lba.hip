@@ -422,54 +422,58 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *arena, UnpackSegs
 // Adjacency lists (CSR by keyframe and by landmark, edges ascending inside a row - the order a stable host-side counting sort
 // gives, so the sums that walk them keep their bits) built ON THE DEVICE from the row starts the host gets for free while it
 // marshals the edges: the host-side scatter cost ~100 us per 60k edges, which the device had to wait for after its first kernels.
-//   keyframe rows (long, few keys): chunks of 1024 edges count their keys (k_csr_kf_count), a scan over the chunks per key gives
-//     every chunk its first slot in every row (k_csr_kf_scan), and one wave per chunk places its edges in order - a ballot per
-//     distinct key of a 64-edge slice, rank = popcount of the lower lanes (k_csr_kf_fill);
+//   keyframe rows (long, few keys): chunks of 256 edges count their keys (k_csr_kf_count), a scan over the chunks per key gives
+//     every chunk its first slot in every row (k_csr_kf_scan), and every edge adds the number of earlier edges of its chunk with
+//     the same key (k_csr_kf_fill);
 //   landmark rows (short): unordered fill with an atomic slot counter, then every edge counts the smaller edge ids of its row.
 // ---------------------------------------------------------------------------------------------
-#define CSR_CHUNK 1024
+#define CSR_CHUNK 256
 __global__ __launch_bounds__(256) void k_csr_kf_count(const int *__restrict__ ek, int E, int K, int *__restrict__ chunkCnt)
 {
     extern __shared__ int csrLds[];
     for (int i = threadIdx.x; i < K; i += 256) csrLds[i] = 0;
     __syncthreads();
-    const int e0 = blockIdx.x * CSR_CHUNK;
-    for (int i = threadIdx.x; i < CSR_CHUNK; i += 256)
-        if (e0 + i < E) atomicAdd(&csrLds[ek[e0 + i]], 1);
+    const int e = blockIdx.x * CSR_CHUNK + threadIdx.x;
+    if (e < E) atomicAdd(&csrLds[ek[e]], 1);
     __syncthreads();
     for (int i = threadIdx.x; i < K; i += 256) chunkCnt[(size_t)blockIdx.x * K + i] = csrLds[i];
 }
 
+// one workgroup per key: exclusive scan of its counts over the chunks, starting at the row start
 __global__ __launch_bounds__(256) void k_csr_kf_scan(const int *__restrict__ kfStart, int K, int nChunk, int *chunkCnt)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    __shared__ int wsum[4];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int run = kfStart[k];
-    for (int c = 0; c < nChunk; c++) { const int t = chunkCnt[(size_t)c * K + k]; chunkCnt[(size_t)c * K + k] = run; run += t; }
+    for (int c0 = 0; c0 < nChunk; c0 += 256) {
+        const int c = c0 + tid;
+        const int v = c < nChunk ? chunkCnt[(size_t)c * K + k] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(x, o); if (lane >= o) x += u; }
+        __syncthreads();
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int off = 0;
+        for (int i = 0; i < w; i++) off += wsum[i];
+        if (c < nChunk) chunkCnt[(size_t)c * K + k] = run + off + x - v;
+        run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
 }
 
-__global__ __launch_bounds__(64) void k_csr_kf_fill(const int *__restrict__ ek, int E, int K, const int *__restrict__ chunkBase, int *__restrict__ kfEdges)
+// slot of edge e = first slot of its chunk in its row + the number of earlier edges of the chunk with the same keyframe (counted by
+// walking the chunk's keys in LDS, the same address for every lane)
+__global__ __launch_bounds__(256) void k_csr_kf_fill(const int *__restrict__ ek, int E, int K, const int *__restrict__ chunkBase, int *__restrict__ kfEdges)
 {
-    extern __shared__ int csrLds[];   // next free slot of every row for this chunk
-    const int lane = threadIdx.x;
-    for (int i = lane; i < K; i += 64) csrLds[i] = chunkBase[(size_t)blockIdx.x * K + i];
+    __shared__ int keys[CSR_CHUNK];
+    const int tid = threadIdx.x, e = blockIdx.x * CSR_CHUNK + tid;
+    const int key = e < E ? ek[e] : -1;
+    keys[tid] = key;
     __syncthreads();
-    for (int sub = 0; sub < CSR_CHUNK / 64; sub++) {
-        const int e = blockIdx.x * CSR_CHUNK + sub * 64 + lane;
-        const int key = e < E ? ek[e] : -1;
-        bool todo = key >= 0;
-        for (;;) {
-            const unsigned long long act = __ballot(todo);
-            if (!act) break;
-            const int leader = __ffsll((long long)act) - 1;
-            const int lk = __shfl(key, leader);
-            const bool mine = todo && key == lk;
-            const unsigned long long m = __ballot(mine);
-            const int first = csrLds[lk];
-            if (mine) { kfEdges[first + __popcll(m & ((1ull << lane) - 1ull))] = e; todo = false; }
-            if (lane == leader) csrLds[lk] = first + __popcll(m);      // (one wave: the LDS keeps the order of its accesses)
-        }
-    }
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < CSR_CHUNK; j++) rank += (j < tid && keys[j] == key) ? 1 : 0;
+    if (e < E) kfEdges[chunkBase[(size_t)blockIdx.x * K + key] + rank] = e;
 }
 
 __global__ __launch_bounds__(256) void k_csr_pt_fill(const int *__restrict__ ep, int E, const int *__restrict__ ptStart, int *fill, int *__restrict__ ptTmp)
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(256) void k_csr_pt_rank(const int *__restrict__ ep,
 
 // initializeOptimization(level 0) on the device (sparse_optimizer.cpp:166-267): active[e] = edge not flagged as an outlier by the previous
 // stage (flag == nullptr: all), a vertex takes part when one of its edges does, free keyframes and landmarks are numbered in order.
-// One workgroup; the three counts go to pinned memory like the sums of a trial (host[10..12], sequence number last).  Before, the
+// The three counts go to pinned memory like the sums of a trial (host[10..12], sequence number last).  Before, the
 // flags went to the host, through three O(E) loops and back: ~120 us of idle device between the two stages of a local BA.
 __device__ __forceinline__ int block_incl_scan1024(int v, int *wsum /* 17 */, int *total)
 {
@@ -508,37 +512,46 @@ __device__ __forceinline__ int block_incl_scan1024(int v, int *wsum /* 17 */, in
     *total = tot;
     return x + off;
 }
-__global__ __launch_bounds__(1024) void k_stage_prep(int K, int P, int E, const int *__restrict__ ep, const int *__restrict__ ek, const uint8_t *__restrict__ flag,
-                                                     const uint8_t *__restrict__ fixed, uint8_t *active, int *poseIdx, int *ptIdx, int *pAct, int *lAct, double *host, double seq)
+// (a) wide: active flags, vertex marks (stamped with the stage number, so that nothing has to be cleared between the stages), per-workgroup counts
+__global__ __launch_bounds__(256) void k_stage_mark(int E, const int *__restrict__ ep, const int *__restrict__ ek, const uint8_t *__restrict__ flag, uint8_t *__restrict__ active,
+                                                    int *pAct, int *lAct, int stamp, int *__restrict__ partCnt)
+{
+    __shared__ int sw[4];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    int a = 0;
+    if (e < E) {
+        a = flag ? flag[e] == 0 : 1;
+        active[e] = (uint8_t)a;
+        if (a) { pAct[ek[e]] = stamp; lAct[ep[e]] = stamp; }      // (concurrent stores of the same value)
+    }
+    const int n = __popcll(__ballot(a != 0));
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) partCnt[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+// (b) one workgroup: numbering of the free keyframes and the active landmarks, the counts to the host
+__global__ __launch_bounds__(1024) void k_stage_index(int K, int P, const uint8_t *__restrict__ fixed, const int *__restrict__ pAct, const int *__restrict__ lAct, int stamp,
+                                                      int *__restrict__ poseIdx, int *__restrict__ ptIdx, const int *__restrict__ partCnt, int nPart, double *host, double seq)
 {
     __shared__ int wsum[17];
     const int tid = threadIdx.x;
-    for (int k = tid; k < K; k += 1024) pAct[k] = 0;
-    for (int l = tid; l < P; l += 1024) lAct[l] = 0;
-    __syncthreads();
-    int nAct = 0;
-    for (int e = tid; e < E; e += 1024) {
-        const bool a = flag ? flag[e] == 0 : true;
-        active[e] = a ? 1 : 0;
-        if (a) { pAct[ek[e]] = 1; lAct[ep[e]] = 1; nAct++; }      // (concurrent stores of the same value)
-    }
-    __threadfence_block();
-    __syncthreads();
     int nPose = 0, nPt = 0, tot;
     for (int k0 = 0; k0 < K; k0 += 1024) {
         const int k = k0 + tid;
-        const int f = (k < K && __hip_atomic_load(pAct + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) && !fixed[k]) ? 1 : 0;
+        const int f = (k < K && pAct[k] == stamp && !fixed[k]) ? 1 : 0;
         const int inc = block_incl_scan1024(f, wsum, &tot);
         if (k < K) poseIdx[k] = f ? nPose + inc - 1 : -1;
         nPose += tot;
     }
     for (int l0 = 0; l0 < P; l0 += 1024) {
         const int l = l0 + tid;
-        const int f = (l < P && __hip_atomic_load(lAct + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) ? 1 : 0;
+        const int f = (l < P && lAct[l] == stamp) ? 1 : 0;
         const int inc = block_incl_scan1024(f, wsum, &tot);
         if (l < P) ptIdx[l] = f ? nPt + inc - 1 : -1;
         nPt += tot;
     }
+    int nAct = 0;
+    for (int i = tid; i < nPart; i += 1024) nAct += partCnt[i];
     block_incl_scan1024(nAct, wsum, &tot);
     if (tid == 0) {
         host[10] = (double)nPose; host[11] = (double)nPt; host[12] = (double)tot;
@@ -1824,8 +1837,12 @@ int optimize(Ctx &c, int iterations, double stats[4])
     int nPose, nPt, nAct;
     {
         const double seq = (h->seq += 1.0);
-        hipLaunchKernelGGL(k_stage_prep, dim3(1), dim3(1024), 0, h->stream, K, P, E, (const int *)h->ep.p, (const int *)h->ek.p, c.stageFlags, (const uint8_t *)h->fixedDev.p,
-                           h->active.p, h->poseIdx.p, h->ptIdx.p, h->pActF.p, h->lActF.p, h->hostRedDev, seq);
+        const int stamp = c.stageFlags ? 2 : 1;
+        const unsigned gM = (unsigned)((E + 255) / 256);
+        hipLaunchKernelGGL(k_stage_mark, dim3(gM), dim3(256), 0, h->stream, E, (const int *)h->ep.p, (const int *)h->ek.p, c.stageFlags, h->active.p, h->pActF.p, h->lActF.p, stamp,
+                           h->csrCnt.p);      // (the chunk counters of the adjacency-list builder are free again: >= E / 256 entries)
+        hipLaunchKernelGGL(k_stage_index, dim3(1), dim3(1024), 0, h->stream, K, P, (const uint8_t *)h->fixedDev.p, (const int *)h->pActF.p, (const int *)h->lActF.p, stamp,
+                           h->poseIdx.p, h->ptIdx.p, (const int *)h->csrCnt.p, (int)gM, h->hostRedDev, seq);
         LCHECK();
         if (!c.stageFlags) { nPose = c.nPose0; nPt = c.nPt0; nAct = E; }      // nothing to wait for
         else {
@@ -2093,19 +2110,18 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
         seg(oEp, h->ep.p, (size_t)E * 4); seg(oEk, h->ek.p, (size_t)E * 4);
         seg(oPs, h->ptStart.p, ((size_t)P + 1) * 4); seg(oKs, h->kfStart.p, ((size_t)K + 1) * 4); seg(oFx, h->fixedDev.p, (size_t)K);
         seg(~(size_t)0, h->err.p, (size_t)E * 3 * 8);
-        seg(~(size_t)0, h->fillP.p, (size_t)P * 4);
+        seg(~(size_t)0, h->fillP.p, (size_t)P * 4); seg(~(size_t)0, h->pActF.p, (size_t)K * 4); seg(~(size_t)0, h->lActF.p, (size_t)P * 4);
         sg.n = ns;
         hipLaunchKernelGGL(k_unpack, dim3(256), dim3(256), 0, s, (const uint8_t *)h->inArena.p, sg);
         LCHECK();
         // adjacency lists
         if (csrLds > 48 * 1024) {
             ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_csr_kf_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)csrLds));
-            ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_csr_kf_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)csrLds));
         }
         const unsigned gE = (unsigned)((E + 255) / 256);
         hipLaunchKernelGGL(k_csr_kf_count, dim3((unsigned)nChunk), dim3(256), csrLds, s, (const int *)h->ek.p, E, K, h->csrCnt.p);
-        hipLaunchKernelGGL(k_csr_kf_scan, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, (const int *)h->kfStart.p, K, nChunk, h->csrCnt.p);
-        hipLaunchKernelGGL(k_csr_kf_fill, dim3((unsigned)nChunk), dim3(64), csrLds, s, (const int *)h->ek.p, E, K, (const int *)h->csrCnt.p, h->kfEdges.p);
+        hipLaunchKernelGGL(k_csr_kf_scan, dim3((unsigned)K), dim3(256), 0, s, (const int *)h->kfStart.p, K, nChunk, h->csrCnt.p);
+        hipLaunchKernelGGL(k_csr_kf_fill, dim3((unsigned)nChunk), dim3(256), 0, s, (const int *)h->ek.p, E, K, (const int *)h->csrCnt.p, h->kfEdges.p);
         hipLaunchKernelGGL(k_csr_pt_fill, dim3(gE), dim3(256), 0, s, (const int *)h->ep.p, E, (const int *)h->ptStart.p, h->fillP.p, h->ptTmp.p);
         hipLaunchKernelGGL(k_csr_pt_rank, dim3(gE), dim3(256), 0, s, (const int *)h->ep.p, E, (const int *)h->ptStart.p, (const int *)h->ptTmp.p, h->ptEdges.p);
         LCHECK();
