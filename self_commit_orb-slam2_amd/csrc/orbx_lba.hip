@@ -52,18 +52,27 @@ __host__ __device__ inline DQuat quat_from_R(const double R[9])   // Eigen::Quat
         t = 0.5 / t;
         q.x = (R[7] - R[5]) * t; q.y = (R[2] - R[6]) * t; q.z = (R[3] - R[1]) * t;
     } else {
+        // Eigen's branch on the largest diagonal entry, written out per case: runtime indices into R would put the matrix into scratch
+        // memory (a global-memory round trip on the one-thread chain of every update)
         int i = 0;
         if (R[4] > R[0]) i = 1;
-        if (R[8] > R[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-        double v[3];
-        v[i] = 0.5 * t;
-        t = 0.5 / t;
-        q.w = (R[3 * k + j] - R[3 * j + k]) * t;
-        v[j] = (R[3 * j + i] + R[3 * i + j]) * t;
-        v[k] = (R[3 * k + i] + R[3 * i + k]) * t;
-        q.x = v[0]; q.y = v[1]; q.z = v[2];
+        if (R[8] > (i ? R[4] : R[0])) i = 2;
+        if (i == 0) {          // j = 1, k = 2
+            t = sqrt(R[0] - R[4] - R[8] + 1.0);
+            q.x = 0.5 * t;
+            t = 0.5 / t;
+            q.w = (R[7] - R[5]) * t; q.y = (R[3] + R[1]) * t; q.z = (R[6] + R[2]) * t;
+        } else if (i == 1) {   // j = 2, k = 0
+            t = sqrt(R[4] - R[8] - R[0] + 1.0);
+            q.y = 0.5 * t;
+            t = 0.5 / t;
+            q.w = (R[2] - R[6]) * t; q.z = (R[7] + R[5]) * t; q.x = (R[1] + R[3]) * t;
+        } else {               // j = 0, k = 1
+            t = sqrt(R[8] - R[0] - R[4] + 1.0);
+            q.z = 0.5 * t;
+            t = 0.5 / t;
+            q.w = (R[3] - R[1]) * t; q.x = (R[2] + R[6]) * t; q.y = (R[5] + R[7]) * t;
+        }
     }
     return q;
 }
@@ -1416,6 +1425,15 @@ __device__ inline void po_edge_error(const DPose &T, const double in[5], const f
     }
 }
 
+// 1 / x: v_rcp_f64 + two Newton steps (the IEEE division sequence is ~40 dependent instructions; six of them sat on the one-thread
+// 6x6 solve of every trial)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+    return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
+
 template <int N> __device__ inline void po_block_reduce(double (&v)[N], double (*red)[PO_NRED], int tid)
 {
     // v[0..N) per thread -> red[0][0..N) summed over the workgroup (N is a template argument: v stays in registers)
@@ -1460,6 +1478,10 @@ __device__ __forceinline__ void po_block_reduce28(const double (&v)[PO_NRED], do
     __syncthreads();
 }
 
+// NE = edges per thread: the correspondences of a frame and their _error live in REGISTERS for the whole call (thread t owns edges
+// t, t + 256, ...): the 40 build / 40+ error passes of a call do no global memory access at all (each one waited ~1 us for its loads
+// and the per-edge divisions before: 4.4 + 2.3 us of a 13 us iteration).
+template <int NE>
 __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
 {
     __shared__ double redT[28 * PO_TP];
@@ -1473,17 +1495,27 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
     const int n = min(P.counts[f], P.cap);
     const size_t base = (size_t)f * P.cap;
     const float *Xw = P.Xw + base * 3, *obs = P.obs + base * 3, *invS2 = P.invS2 + base;
-    double *err = P.err + base * 3;
     uint8_t *outl = P.outlier + base;
     double in[5];
     for (int i = 0; i < 5; i++) in[i] = (double)P.cam[5 * (size_t)f + i];
     const float *p0 = P.pose0 + 16 * (size_t)f;
-    for (int e = tid; e < n; e += 256) outl[e] = 0;
     if (tid < 8) P.stats[8 * (size_t)f + tid] = 0;
     if (n < 3) {   // :509-510
+        if (tid < n) outl[tid] = 0;
         if (tid < 16) P.poseOut[16 * (size_t)f + tid] = p0[tid];
         if (tid == 0) P.ret[f] = 0;
         return;
+    }
+    float xw[NE][3], ob[NE][3], is2[NE];
+    double er[NE][3];
+    unsigned outM = 0;            // bit j: edge tid + 256 j is an outlier (level 1)
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+        const int e = tid + 256 * j;
+        const bool live = e < n;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { xw[j][i] = live ? Xw[3 * e + i] : 0.f; ob[j][i] = live ? obs[3 * e + i] : 0.f; er[j][i] = 0; }
+        is2[j] = live ? invS2[e] : 0.f;
     }
     __syncthreads();
     for (int round = 0; round < 4; round++) {
@@ -1498,7 +1530,8 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         }
         __syncthreads();
         int nAct = 0;
-        for (int e = tid; e < n; e += 256) nAct += outl[e] ? 0 : 1;
+#pragma unroll
+        for (int j = 0; j < NE; j++) nAct += (tid + 256 * j < n && !((outM >> j) & 1u)) ? 1 : 0;
         {
             double v[1] = {(double)nAct};
             po_block_reduce(v, red, tid);
@@ -1514,19 +1547,20 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
             double acc[PO_NRED];
 #pragma unroll
             for (int k = 0; k < PO_NRED; k++) acc[k] = 0;
-            for (int e = tid; e < n; e += 256) {
-                if (outl[e]) continue;
-                const bool st = !(obs[3 * e + 2] < 0);
+#pragma unroll
+            for (int j = 0; j < NE; j++) {
+                if (tid + 256 * j >= n || ((outM >> j) & 1u)) continue;
+                const bool st = !(ob[j][2] < 0);
                 double r[3];
-                po_edge_error(T, in, Xw + 3 * e, obs + 3 * e, st, r);
-                err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
-                const double w = (double)invS2[e];
+                po_edge_error(T, in, xw[j], ob[j], st, r);
+                er[j][0] = r[0]; er[j][1] = r[1]; er[j][2] = r[2];
+                const double w = (double)is2[j];
                 const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * w;
                 double r0 = chi, r1 = 1;
                 if (robust) huber_rho(hub, st, chi, r0, r1);
                 acc[27] += r0;
                 // linearizeOplus (.cpp:266-288, 335-367)
-                const double X[3] = {(double)Xw[3 * e], (double)Xw[3 * e + 1], (double)Xw[3 * e + 2]};
+                const double X[3] = {(double)xw[j][0], (double)xw[j][1], (double)xw[j][2]};
                 double Xc[3];
                 pose_map(T, X, Xc);
                 const double x = Xc[0], y = Xc[1], invz = 1.0 / Xc[2], invz_2 = invz * invz, fx = in[0], fy = in[1], bf = in[4];
@@ -1597,7 +1631,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                         for (int k = 0; k < j; k++) dj -= A[6 * j + k] * A[6 * j + k] * Dg[k];
                         ok = ok && (dj > 0) && isfinite(dj);
                         Dg[j] = dj;
-                        Di[j] = 1.0 / dj;
+                        Di[j] = fast_rcp(dj);
 #pragma unroll
                         for (int i = j + 1; i < 6; i++) {
                             double lij = A[6 * i + j];
@@ -1633,13 +1667,14 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                 __syncthreads();
                 const DPose T2 = pose;
                 double cacc[1] = {0};
-                for (int e = tid; e < n; e += 256) {
-                    if (outl[e]) continue;
-                    const bool st = !(obs[3 * e + 2] < 0);
+#pragma unroll
+                for (int j = 0; j < NE; j++) {
+                    if (tid + 256 * j >= n || ((outM >> j) & 1u)) continue;
+                    const bool st = !(ob[j][2] < 0);
                     double r[3];
-                    po_edge_error(T2, in, Xw + 3 * e, obs + 3 * e, st, r);
-                    err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
-                    const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * (double)invS2[e];
+                    po_edge_error(T2, in, xw[j], ob[j], st, r);
+                    er[j][0] = r[0]; er[j][1] = r[1]; er[j][2] = r[2];
+                    const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * (double)is2[j];
                     double r0 = chi, r1 = 1;
                     if (robust) huber_rho(hub, st, chi, r0, r1);
                     cacc[0] += r0;
@@ -1653,7 +1688,8 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     scale += 1e-3;
                     rho /= scale;
                     if (rho > 0 && isfinite(tempChi)) {
-                        double alpha = 1. - pow((2 * rho - 1), 3.0);
+                        const double t2r = 2 * rho - 1;
+                        double alpha = 1. - t2r * t2r * t2r;      // (pow(x, 3) in the reference; the library call costs ~0.5 us on this one-thread section)
                         alpha = fmin(alpha, 2. / 3.);
                         sLambda *= fmax(1. / 3., alpha);
                         sNi = 2;
@@ -1683,16 +1719,18 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         // ---- classification (:526-587): outliers are re-evaluated at the final pose, inliers keep their last _error
         const DPose Tf = pose;
         int nb = 0;
-        for (int e = tid; e < n; e += 256) {
-            const bool st = !(obs[3 * e + 2] < 0);
-            if (outl[e]) {
+#pragma unroll
+        for (int j = 0; j < NE; j++) {
+            if (tid + 256 * j >= n) continue;
+            const bool st = !(ob[j][2] < 0);
+            if ((outM >> j) & 1u) {
                 double r[3];
-                po_edge_error(Tf, in, Xw + 3 * e, obs + 3 * e, st, r);
-                err[3 * e] = r[0]; err[3 * e + 1] = r[1]; err[3 * e + 2] = r[2];
+                po_edge_error(Tf, in, xw[j], ob[j], st, r);
+                er[j][0] = r[0]; er[j][1] = r[1]; er[j][2] = r[2];
             }
-            const float chi2 = (float)((err[3 * e] * err[3 * e] + err[3 * e + 1] * err[3 * e + 1] + err[3 * e + 2] * err[3 * e + 2]) * (double)invS2[e]);
+            const float chi2 = (float)((er[j][0] * er[j][0] + er[j][1] * er[j][1] + er[j][2] * er[j][2]) * (double)is2[j]);
             const bool bad = chi2 > (st ? 7.815f : 5.991f);
-            outl[e] = bad ? 1 : 0;
+            outM = bad ? (outM | (1u << j)) : (outM & ~(1u << j));
             nb += bad ? 1 : 0;
         }
         {
@@ -1703,6 +1741,9 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         }
         if (n < 10) break;   // optimizer.edges().size() < 10, :589-590
     }
+#pragma unroll
+    for (int j = 0; j < NE; j++)
+        if (tid + 256 * j < n) outl[tid + 256 * j] = (uint8_t)((outM >> j) & 1u);      // pFrame->mvbOutlier
     if (tid == 0) {   // Converter::toCvMat(SE3Quat) + SetPose, :594-601
         double R[9];
         quat_to_R(pose.q, R);
@@ -2249,7 +2290,13 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     Huber hub;
     hub.dMono = thMono; hub.dStereo = thStereo;
     hub.dsqrMono = (float)(hub.dMono * hub.dMono); hub.dsqrStereo = (float)(hub.dStereo * hub.dStereo);   // dsqr is a float member in this fork
-    hipLaunchKernelGGL(k_pose_opt, dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    int maxCount = 0;
+    for (int i = 0; i < B; i++) maxCount = std::max(maxCount, std::min((int)p->counts[i], cap));
+    if (maxCount > 256 * 16) { orbx_set_error("%d correspondences in a frame exceed the pose optimizer's limit %d", maxCount, 256 * 16); return ORBX_ERR_CAPACITY; }
+    if (maxCount <= 256 * 2) hipLaunchKernelGGL(k_pose_opt<2>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (maxCount <= 256 * 4) hipLaunchKernelGGL(k_pose_opt<4>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (maxCount <= 256 * 8) hipLaunchKernelGGL(k_pose_opt<8>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else hipLaunchKernelGGL(k_pose_opt<16>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     // results: four copies into the pinned buffer (stream order: after the kernel, which has consumed the inputs), one synchronisation
