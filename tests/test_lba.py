@@ -169,6 +169,20 @@ def test_oracle_bundle_adjustment_protocol(orbx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(K=12, P=400, seed=1, n_fixed=2, pose_noise=(np.deg2rad(6.0), 0.25), point_noise=0.25, stereo_frac=0.3),
+                                 dict(K=12, P=400, seed=6, n_fixed=2, pose_noise=(np.deg2rad(12.0), 0.5), point_noise=0.4, stereo_frac=0.3)])
+def test_lba_with_rejected_trials(orbx, oracle, cfg):
+    """Badly initialised windows: Levenberg trials are rejected (more trials than iterations), i.e. the pop() / retry path - and, in the
+    HIP driver, the rebuild of H and b after a speculative linearisation on a state that was rejected."""
+    w = orbx.lba_synth.make_window(**cfg)
+    want = oracle_lib.local_bundle_adjustment(oracle, w)
+    assert want["stats"][1] + want["stats"][5] > want["stats"][0] + want["stats"][4], want["stats"]
+    opt = orbx.Optimizer(max_keyframes=16, max_points=512, max_edges=8192)
+    _compare(opt.LocalBundleAdjustment(w), want, w)
+    opt.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg,iters,robust", [(dict(K=50, P=5000, seed=12345, n_fixed=1), 10, True), (dict(K=20, P=1500, seed=7, stereo_frac=0.5, n_fixed=1), 20, False),
                                               (dict(K=8, P=200, seed=2, stereo_frac=1.0, n_fixed=1), 20, True)])
 def test_bundle_adjustment_hip_matches_oracle(orbx, oracle, cfg, iters, robust):

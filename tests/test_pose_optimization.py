@@ -1,7 +1,7 @@
-"""Optimizer::PoseOptimization (reference src/Optimizer.cc:363-605): motion-only BA.  g2o needs
-Eigen, which this container does not have, so the reference cannot be built here (parity unpinned):
-the CPU restatement (oracle/lba_oracle.cc) is checked against ground truth and an independent scipy
-solve, and the HIP kernel against the restatement (|delta pose| <= 1e-5, identical outlier flags)."""
+"""Optimizer::PoseOptimization (reference src/Optimizer.cc:363-605): motion-only BA.  The CPU restatement (oracle/lba_oracle.cc)
+is pinned to the reference's own PoseOptimization + g2o, compiled unmodified on oracle/eigenshim (tests/test_optimizer_ref.py); here
+it is also checked against ground truth and an independent scipy solve, and the HIP kernel against the restatement (|delta pose|
+<= 1e-5, identical outlier flags)."""
 import numpy as np
 import pytest
 
@@ -84,4 +84,29 @@ def test_pose_optimization_hip_matches_oracle(orbx, oracle):
         # same LM path; the 3-strikes stop rule ((chi_start - chi_end)*1e3 < chi_start) sits on rounding noise once converged,
         # so the iteration count of a round may differ by one
         assert np.abs(got[i]["stats"][0::2] - want["stats"][0::2]).max() <= 1, (i, got[i]["stats"], want["stats"])
+    opt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nmax", [300, 900, 2000, 3500])
+def test_pose_optimization_every_kernel_variant(orbx, oracle, nmax):
+    """k_pose_opt keeps a frame's correspondences in registers, 2 / 4 / 8 / 16 per thread by the largest frame of the batch: one batch
+    per variant, each with a small frame next to the largest one."""
+    frames = [make_frame(70 + nmax, n=nmax, stereo_frac=0.4), make_frame(71 + nmax, n=max(12, nmax // 7), stereo_frac=0.6)]
+    opt = orbx.PoseOptimizer(max_frames=2, max_features=4096)
+    got = opt.PoseOptimization(frames)
+    for i, fr in enumerate(frames):
+        want = oracle_lib.pose_optimization(oracle, fr)
+        assert np.abs(got[i]["pose"].astype(np.float64) - want["pose"]).max() <= 1e-5, i
+        assert got[i]["inliers"] == want["inliers"], i
+        assert (got[i]["outlier"] != want["outlier"]).sum() == 0, i
+    opt.close()
+
+
+@pytest.mark.gpu
+def test_pose_optimization_rejects_more_than_4096_correspondences(orbx):
+    fr = make_frame(5, n=4200)
+    opt = orbx.PoseOptimizer(max_frames=1, max_features=4200)
+    with pytest.raises(Exception):
+        opt.PoseOptimization([fr])
     opt.close()
