@@ -340,37 +340,67 @@ __global__ __launch_bounds__(256) void k_sum_points(LbaDev d, const int *ptStart
     }
 }
 
-// Hpp (36) and b_p (6) of every free pose: one workgroup per keyframe, fixed-shape tree reduction (the 27 values
-// go down the same 256 -> 1 tree together: 8 barriers instead of 8 per value, same pairing, same sums)
-__global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart, const int *kfEdges, double *Hpp, double *bp)
+// Hpp (36) and b_p (6) of every free pose.  SP_SPLIT workgroups per keyframe sum a contiguous quarter of its edges each (the 27 values
+// go through a transposed LDS tile: thread t stores at [k][t], 216 threads add 32 consecutive entries, 27 threads add the 8 parts - a
+// fixed order, two barriers instead of the eight of a 256 -> 1 tree per value); k_sum_poses_fin adds the SP_SPLIT partial results in order.  One workgroup per keyframe walked ~5 edges x 27 gathered doubles per thread in series:
+// 16 us with 50 workgroups on a 256-CU device.
+#define SP_SPLIT 4
+#define SP_TP 264
+__global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart, const int *kfEdges, double *part /* K x SP_SPLIT x 27 */)
 {
-    __shared__ double red[27][256];
-    const int k = blockIdx.x, pi = d.poseIdx[k], tid = threadIdx.x;
+    __shared__ double redT[27 * SP_TP];
+    __shared__ double part8[27][9];
+    const int k = blockIdx.x, y = blockIdx.y, pi = d.poseIdx[k], tid = threadIdx.x;
     if (pi < 0) return;
+    const int s0 = kfStart[k], n = kfStart[k + 1] - s0, per = (n + SP_SPLIT - 1) / SP_SPLIT;
+    const int lo = s0 + min(n, y * per), hi = s0 + min(n, (y + 1) * per);
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
-    for (int s = kfStart[k] + tid; s < kfStart[k + 1]; s += 256) {
+    for (int s = lo + tid; s < hi; s += 256) {
         const int e = kfEdges[s];
         if (!d.active[e]) continue;
         const double *blk = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPP;
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] += blk[i];
     }
+    const int slot = (tid >> 5) * 33 + (tid & 31);
 #pragma unroll
-    for (int i = 0; i < 27; i++) red[i][tid] = acc[i];
+    for (int i = 0; i < 27; i++) redT[i * SP_TP + slot] = acc[i];
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        for (int w = tid; w < 27 * s; w += 256) { const int i = w / s, t = w - i * s; red[i][t] += red[i][t + s]; }
-        __syncthreads();
+    if (tid < 216) {
+        const int i = tid >> 3, p = tid & 7;
+        const double *src = redT + i * SP_TP + p * 33;
+        double sacc = 0;
+#pragma unroll
+        for (int q = 0; q < 32; q++) sacc += src[q];
+        part8[i][p] = sacc;
     }
-    if (tid == 0) {
-        double *H = Hpp + (size_t)pi * 36;
-        int o = 0;
-        for (int i = 0; i < 6; i++)
-            for (int j = i; j < 6; j++) { H[6 * i + j] = red[o][0]; H[6 * j + i] = red[o][0]; o++; }
-        for (int i = 0; i < 6; i++) bp[(size_t)pi * 6 + i] = red[21 + i][0];
+    __syncthreads();
+    if (tid < 27) {
+        double sacc = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) sacc += part8[tid][q];
+        part[((size_t)k * SP_SPLIT + y) * 27 + tid] = sacc;
     }
+}
+// ... and the SP_SPLIT partial results added in order by a second small launch (a "last workgroup adds" inside the first one needs a
+// device-scope release, i.e. a write-back of the L2 - right after k_linearize has left 34 MB of dirty lines there: 28 us instead of 16)
+__global__ __launch_bounds__(256) void k_sum_poses_fin(LbaDev d, const double *__restrict__ part, double *__restrict__ Hpp, double *__restrict__ bp)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x, k = idx >> 5, v = idx & 31;
+    if (k >= d.K || v >= 27) return;
+    const int pi = d.poseIdx[k];
+    if (pi < 0) return;
+    double t = 0;
+    for (int q = 0; q < SP_SPLIT; q++) t += part[((size_t)k * SP_SPLIT + q) * 27 + v];
+    if (v >= 21) { bp[(size_t)pi * 6 + v - 21] = t; return; }
+    // entry v of the upper triangle in row-major order -> (i, j)
+    int i = 0, o = v;
+    while (o >= 6 - i) { o -= 6 - i; i++; }
+    const int j = i + o;
+    Hpp[(size_t)pi * 36 + 6 * i + j] = t;
+    Hpp[(size_t)pi * 36 + 6 * j + i] = t;
 }
 
 // The three sums an LM trial ends with: host[0] = sum rchi (activeRobustChi2), host[4] = sum xp (lambda xp + bp), host[5] = sum xl (lambda
@@ -672,14 +702,15 @@ __device__ __forceinline__ void schur_points_part(int block, const LbaDev &d, co
 // The two independent preparations of a trial in ONE launch (every launch of this latency-bound loop costs ~3 us of gap besides its
 // own run time): blocks [0, nInit) initialise S / bs, the rest handle four landmarks each.
 __global__ __launch_bounds__(256) void k_schur_setup(LbaDev d, int nInit, const double *Hpp, const double *bp, int nPose, const int *ptStart, const int *ptEdges,
-                                                     const double *Hll, const double *bl, double lambda, double *S, double *bs, double *Dinv, double *Ddb)
+                                                     const double *Hll, const double *bl, double lambda, double *S, double *bs, double *Dinv, double *Ddb, int *okFlag)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *okFlag = 1;      // the factorisation clears it at a failed pivot
     if ((int)blockIdx.x < nInit) schur_init_part((int)blockIdx.x, nInit, Hpp, bp, nPose, lambda, S, bs);
     else schur_points_part((int)blockIdx.x - nInit, d, ptStart, ptEdges, Hll, bl, lambda, Dinv, Ddb);
 }
 
-// S[i1, i2] -= (B_1 D^-1) B_2^T for every pair of free-pose observations of a landmark, i2 >= i1 (upper block
-// triangle, k_chol_prep mirrors it).  Block row i1 of S belongs to keyframe i1: gridDim.y workgroups per keyframe
+// S[i1, i2] -= (B_1 D^-1) B_2^T for every pair of free-pose observations of a landmark, i2 <= i1 (the LOWER block
+// triangle, which is what the Cholesky kernels read: no mirroring pass).  Block row i1 of S belongs to keyframe i1: gridDim.y workgroups per keyframe
 // walk its edges (16 lanes per edge, one lane per second observation), accumulate the row in LDS with
 // ds_add_f64 and add it to S once - 6 x n global atomics per workgroup instead of 36 per observation pair.
 // GLOBAL = true: the block row does not fit into LDS (more than ~530 free keyframes, i.e. a global bundle adjustment of a large map):
@@ -716,7 +747,7 @@ __global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart
             const int e2 = ptEdges[s0 + a2];
             if (!d.active[e2]) continue;
             const int i2 = d.poseIdx[d.ek[e2]];
-            if (i2 < pi) continue;                      // also: fixed keyframe (-1)
+            if (i2 < 0 || i2 > pi) continue;            // lower block triangle only; -1 = fixed keyframe
             const double *pB2 = d.edgeBlk + (size_t)e2 * EB_SIZE + EB_HPL;
             double B2[18];
 #pragma unroll
@@ -734,7 +765,7 @@ __global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart
     for (int i = tid; i < 6 * nP6; i += 256) {
         const int r = i / nP6, col = i - r * nP6;
         const double v = row[i];
-        if (col >= 6 * pi && v != 0.0) unsafeAtomicAdd(&S[(size_t)(6 * pi + r) * nP6 + col], v);
+        if (col < 6 * pi + 6 && v != 0.0) unsafeAtomicAdd(&S[(size_t)(6 * pi + r) * nP6 + col], v);
     }
     if (tid < 6 && row[6 * nP6 + tid] != 0.0) unsafeAtomicAdd(&bs[6 * pi + tid], row[6 * nP6 + tid]);
 }
@@ -742,7 +773,7 @@ __global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart
 #define CHOL_MAX_N 128          /* k_chol_solve serves n < CHOL_MULTI_MIN_N only */
 #define CHOL_LDS_X 2048         /* k_chol_backsub keeps the solution vector in LDS up to this n, in global memory above */
 #define CHOL_DENSE_MAX_N 24576  /* 4096 free keyframes: S and L are n x n doubles each (4.8 GB at the limit), indices stay below 2^31 */
-// Dense Cholesky of the (upper-authoritative) symmetric S, then S x = bs.  One workgroup.
+// Dense Cholesky of the symmetric S (lower triangle read), then S x = bs.  One workgroup.
 // LinearSolverEigen::solve (solvers/linear_solver_eigen.h:94-125) uses a sparse LDLT; the
 // reduced system is SPD here (lambda > 0), a failed pivot reports ok = 0 like info()!=Success.
 // Blocked right-looking Cholesky S = L L^T + the two triangular solves, one workgroup.  A panel of NB
@@ -758,21 +789,6 @@ __global__ __launch_bounds__(1024) void k_chol_solve(double *S, const double *bs
     const int tid = threadIdx.x;
     if (tid == 0) sFail = 0;
     for (int i = tid; i < n; i += 1024) sx[i] = bs[i];
-    // the upper triangle is authoritative on entry (block_solver.hpp builds upper blocks): mirror it, eight
-    // independent elements per thread in flight
-    for (int base = tid; base < n * n; base += 1024 * 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int idx = base + u * 1024, r = idx / n, c = idx - r * n;
-            v[u] = (idx < n * n && r > c) ? S[(size_t)c * n + r] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int idx = base + u * 1024, r = idx / n, c = idx - r * n;
-            if (idx < n * n && r > c) S[idx] = v[u];
-        }
-    }
     __syncthreads();
     for (int p0 = 0; p0 < n; p0 += NB) {
         const int nb = min(NB, n - p0), rows = n - p0;
@@ -946,16 +962,6 @@ __global__ __launch_bounds__(1024) void k_chol_solve(double *S, const double *bs
 #define CHOL_MULTI_MIN_N 96
 #define CNB 32
 #define CHOL_RPW 63          /* panel rows per workgroup of k_chol_step: one wave, lane 63 carries the right-hand side */
-
-__global__ __launch_bounds__(256) void k_chol_prep(double *S, const double *bs, int n, double *ywork, int *okFlag)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx == 0) *okFlag = 1;
-    if (idx < n) ywork[idx] = bs[idx];
-    if (idx >= n * n) return;
-    const int r = idx / n, c = idx - r * n;
-    if (r > c) S[idx] = S[(size_t)c * n + r];   // the upper triangle is authoritative on entry
-}
 
 // value of lane `src` (compile-time constant after unrolling) as a scalar broadcast: two v_readlane_b32 instead of two ds_bpermute_b32
 __device__ __forceinline__ double readlane_f64(double v, int src)
@@ -1770,6 +1776,7 @@ struct orbx_lba {
     uint8_t *hostIO = nullptr;   // pinned: the marshalled inputs of a call on their way up, flags / chi2 / estimates on their way down
     size_t hostIOBytes = 0;
     OrbxDevBuf<uint8_t> flagDev, inArena, fixedDev;
+    OrbxDevBuf<double> spPart;           // k_sum_poses: SP_SPLIT partial results per keyframe
     OrbxDevBuf<int> csrCnt, ptTmp, fillP, pActF, lActF;   // adjacency-list builder and stage preparation (device side)
     OrbxDevBuf<double> partChi, partL;   // per-workgroup partial sums of k_errors / k_backsub_update
     double *hostRedDev = nullptr;        // device view of hostRed
@@ -1803,6 +1810,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     rc = rc ? rc : h->ep.ensure(E); rc = rc ? rc : h->ek.ensure(E); rc = rc ? rc : h->ptStart.ensure(P + 1); rc = rc ? rc : h->ptEdges.ensure(E);
     rc = rc ? rc : h->kfStart.ensure(K + 1); rc = rc ? rc : h->kfEdges.ensure(E); rc = rc ? rc : h->poseIdx.ensure(K); rc = rc ? rc : h->ptIdx.ensure(P);
     rc = rc ? rc : h->okFlag.ensure(1); rc = rc ? rc : h->stereo.ensure(E); rc = rc ? rc : h->active.ensure(E);
+    rc = rc ? rc : h->spPart.ensure(K * SP_SPLIT * 27);
     rc = rc ? rc : h->fixedDev.ensure(K); rc = rc ? rc : h->ptTmp.ensure(E); rc = rc ? rc : h->fillP.ensure(P); rc = rc ? rc : h->pActF.ensure(K); rc = rc ? rc : h->lActF.ensure(P);
     rc = rc ? rc : h->partChi.ensure((E + 255) / 256); rc = rc ? rc : h->partL.ensure((std::max(K, 16 * P) + 255) / 256);
     if (rc) { orbx_lba_destroy(h); return rc; }
@@ -1824,7 +1832,7 @@ extern "C" void orbx_lba_destroy(orbx_lba *h)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->hostRed) (void)hipHostFree(h->hostRed);
     if (h->hostIO) (void)hipHostFree(h->hostIO);
-    h->flagDev.release(); h->partChi.release(); h->partL.release(); h->inArena.release(); h->fixedDev.release(); h->csrCnt.release(); h->ptTmp.release(); h->fillP.release(); h->pActF.release(); h->lActF.release();
+    h->flagDev.release(); h->partChi.release(); h->partL.release(); h->inArena.release(); h->fixedDev.release(); h->csrCnt.release(); h->ptTmp.release(); h->fillP.release(); h->pActF.release(); h->lActF.release(); h->spPart.release();
     delete h;
 }
 
@@ -1922,7 +1930,8 @@ int optimize(Ctx &c, int iterations, double stats[4])
         LCHECK();
         hipLaunchKernelGGL(k_sum_points, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p);
         LCHECK();
-        hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->Hpp.p, h->bp.p);
+        hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K, SP_SPLIT), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->spPart.p);
+        hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p);
         LCHECK();
         h->flops += 400.0 * nAct;
         return ORBX_OK;
@@ -1963,26 +1972,27 @@ int optimize(Ctx &c, int iterations, double stats[4])
                 if (rcl) return rcl;
                 rebuild = false;
             }
+            // the right-hand side of the reduced system is accumulated where the solver updates it in place (multi-workgroup Cholesky: ywork)
+            double *const bsDev = nP6 >= CHOL_MULTI_MIN_N ? h->ywork.p : h->bs.p;
             {
                 const int nInit = nP6 > 0 ? 64 : 0;
                 hipLaunchKernelGGL(k_schur_setup, dim3((unsigned)(nInit + (P + 3) / 4)), dim3(256), 0, h->stream, c.d, nInit, h->Hpp.p, h->bp.p, nPose, h->ptStart.p,
-                                   h->ptEdges.p, h->Hll.p, h->bl.p, lambda, h->S.p, h->bs.p, h->Dinv.p, h->Ddb.p);
+                                   h->ptEdges.p, h->Hll.p, h->bl.p, lambda, h->S.p, bsDev, h->Dinv.p, h->Ddb.p, h->okFlag.p);
                 LCHECK();
             }
             if (nP6 > 0) {
                 const size_t ldsRows = (size_t)(6 * nP6 + 6) * sizeof(double);
                 if (ldsRows > 150 * 1024) {      // > ~530 free keyframes: the block row no longer fits into LDS
-                    hipLaunchKernelGGL(k_schur_rows<true>, dim3((unsigned)K, 16u), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, h->bs.p);
+                    hipLaunchKernelGGL(k_schur_rows<true>, dim3((unsigned)K, 16u), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, bsDev);
                 } else {
                     if (ldsRows > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
-                    hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, 32u), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, h->bs.p);
+                    hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, 32u), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, bsDev);
                 }
                 LCHECK();
             }
             if (nP6 > 0) {
                 if (nP6 >= CHOL_MULTI_MIN_N) {
                     const int n = nP6;
-                    hipLaunchKernelGGL(k_chol_prep, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, h->stream, h->S.p, h->bs.p, n, h->ywork.p, h->okFlag.p);
                     for (int p0 = 0; p0 < n; p0 += CNB) {
                         const int nb = std::min(CNB, n - p0), below = n - p0 - nb;
                         const int nPW = std::max(1, (below + CHOL_RPW - 1) / CHOL_RPW);
