@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <atomic>
 #include <functional>
+#include <thread>
 #include <type_traits>
 #include <cmath>
 #include <limits>
@@ -1871,6 +1872,7 @@ int wait_seq(orbx_lba *h, double seq)
             }
             if (q != hipErrorNotReady) { orbx_set_error("LBA: %s", hipGetErrorString(q)); return ORBX_ERR_HIP; }
         }
+        if (spins > 4096 && (spins & 63) == 0) std::this_thread::yield();      // a result normally arrives within ~300 us; do not starve other threads of an oversubscribed host
         __builtin_ia32_pause();
     }
     std::atomic_thread_fence(std::memory_order_acquire);
