@@ -182,6 +182,37 @@ def test_lba_with_rejected_trials(orbx, oracle, cfg):
     opt.close()
 
 
+def _with_unused_vertices(w):
+    """The same window with one more keyframe and two more landmarks that no edge references (rows of length 0 in the adjacency lists,
+    vertices that initializeOptimization leaves out)."""
+    w = dict(w)
+    K, P = w["K"], w["P"]
+    w["poses"] = np.concatenate([w["poses"], w["poses"][-1:]]).copy()
+    w["intr"] = np.concatenate([w["intr"], w["intr"][-1:]]).copy()
+    w["fixed"] = np.concatenate([w["fixed"], np.zeros(1, np.uint8)])
+    w["points"] = np.concatenate([w["points"], np.array([[0.3, 0.1, 0.2], [9.0, 9.0, 9.0]], w["points"].dtype)]).copy()
+    w["K"], w["P"] = K + 1, P + 2
+    return w
+
+
+@pytest.mark.gpu
+def test_lba_edge_cases(orbx, oracle):
+    """Shapes the device-side preparation (adjacency lists, index mapping) must get right: every keyframe fixed (structure-only, no
+    reduced system), vertices without edges, fewer edges than one workgroup."""
+    opt = orbx.Optimizer(max_keyframes=16, max_points=512, max_edges=8192)
+    w = orbx.lba_synth.make_window(K=6, P=120, seed=21, n_fixed=6, stereo_frac=0.5)
+    assert w["fixed"].all()
+    _compare(opt.LocalBundleAdjustment(w), oracle_lib.local_bundle_adjustment(oracle, w), w)
+    w = _with_unused_vertices(orbx.lba_synth.make_window(K=7, P=150, seed=22, n_fixed=1, stereo_frac=0.3))
+    got, want = opt.LocalBundleAdjustment(w), oracle_lib.local_bundle_adjustment(oracle, w)
+    _compare(got, want, w)
+    assert np.allclose(got["poses"][-1].ravel(), w["poses"][-1].ravel(), atol=1e-6) and np.allclose(got["points"][-2:], w["points"][-2:])
+    w = orbx.lba_synth.make_window(K=3, P=12, seed=23, n_fixed=1, max_obs=3)
+    assert w["E"] < 64
+    _compare(opt.LocalBundleAdjustment(w), oracle_lib.local_bundle_adjustment(oracle, w), w)
+    opt.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg,iters,robust", [(dict(K=50, P=5000, seed=12345, n_fixed=1), 10, True), (dict(K=20, P=1500, seed=7, stereo_frac=0.5, n_fixed=1), 20, False),
                                               (dict(K=8, P=200, seed=2, stereo_frac=1.0, n_fixed=1), 20, True)])
