@@ -36,11 +36,42 @@ namespace {
 struct DQuat { double x, y, z, w; };
 struct DPose { DQuat q; double t[3]; };
 
+// Square roots and quotients of the pose update (SE3Quat::exp, normalizeRotation) sit on one-thread serial sections of the LM loops, where
+// every dependent FP64 instruction costs ~16 cycles and an IEEE sqrt / division sequence 25-40 of them: on the device they are v_rsq_f64 /
+// v_rcp_f64 + two Newton steps (<= 1 ulp; the estimates are not part of the bit-level contract, 1e-5 vs g2o).  The host keeps libm.
+__host__ __device__ __forceinline__ double fast_rcp(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+    return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+#else
+    return 1.0 / x;
+#endif
+}
+__host__ __device__ __forceinline__ double fast_rsqrt(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
+    return __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ORBX_SQRT(x) ((x) > 0 ? (x) * fast_rsqrt(x) : 0.0)
+#else
+#define ORBX_SQRT(x) sqrt(x)
+#endif
+#define ORBX_RCP(x) fast_rcp(x)
+#define ORBX_RSQRT(x) fast_rsqrt(x)
+
 __host__ __device__ inline void quat_normalize_pos(DQuat &q)   // SE3Quat::normalizeRotation, se3quat.h:280-285
 {
     if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
-    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+    const double ni = ORBX_RSQRT(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    q.x *= ni; q.y *= ni; q.z *= ni; q.w *= ni;
 }
 
 __host__ __device__ inline DQuat quat_from_R(const double R[9])   // Eigen::Quaterniond(Matrix3d)
@@ -48,9 +79,9 @@ __host__ __device__ inline DQuat quat_from_R(const double R[9])   // Eigen::Quat
     DQuat q;
     double t = R[0] + R[4] + R[8];
     if (t > 0) {
-        t = sqrt(t + 1.0);
+        t = ORBX_SQRT(t + 1.0);
         q.w = 0.5 * t;
-        t = 0.5 / t;
+        t = 0.5 * ORBX_RCP(t);
         q.x = (R[7] - R[5]) * t; q.y = (R[2] - R[6]) * t; q.z = (R[3] - R[1]) * t;
     } else {
         // Eigen's branch on the largest diagonal entry, written out per case: runtime indices into R would put the matrix into scratch
@@ -59,19 +90,19 @@ __host__ __device__ inline DQuat quat_from_R(const double R[9])   // Eigen::Quat
         if (R[4] > R[0]) i = 1;
         if (R[8] > (i ? R[4] : R[0])) i = 2;
         if (i == 0) {          // j = 1, k = 2
-            t = sqrt(R[0] - R[4] - R[8] + 1.0);
+            t = ORBX_SQRT(R[0] - R[4] - R[8] + 1.0);
             q.x = 0.5 * t;
-            t = 0.5 / t;
+            t = 0.5 * ORBX_RCP(t);
             q.w = (R[7] - R[5]) * t; q.y = (R[3] + R[1]) * t; q.z = (R[6] + R[2]) * t;
         } else if (i == 1) {   // j = 2, k = 0
-            t = sqrt(R[4] - R[8] - R[0] + 1.0);
+            t = ORBX_SQRT(R[4] - R[8] - R[0] + 1.0);
             q.y = 0.5 * t;
-            t = 0.5 / t;
+            t = 0.5 * ORBX_RCP(t);
             q.w = (R[2] - R[6]) * t; q.z = (R[7] + R[5]) * t; q.x = (R[1] + R[3]) * t;
         } else {               // j = 0, k = 1
-            t = sqrt(R[8] - R[0] - R[4] + 1.0);
+            t = ORBX_SQRT(R[8] - R[0] - R[4] + 1.0);
             q.z = 0.5 * t;
-            t = 0.5 / t;
+            t = 0.5 * ORBX_RCP(t);
             q.w = (R[3] - R[1]) * t; q.x = (R[2] + R[6]) * t; q.y = (R[5] + R[7]) * t;
         }
     }
@@ -117,7 +148,7 @@ __device__ inline void pose_map(const DPose &T, const double X[3], double o[3])
 __device__ inline void pose_oplus(DPose &T, const double d[6])
 {
     const double *om = d, *up = d + 3;
-    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double theta = ORBX_SQRT(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
     const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
     double O2[9], R[9], V[9];
     for (int i = 0; i < 3; i++)
@@ -127,7 +158,8 @@ __device__ inline void pose_oplus(DPose &T, const double d[6])
     } else {
         double sn, cs;
         sincos(theta, &sn, &cs);      // one argument reduction; theta^3 as two products instead of pow(theta, 3) (a ~150-instruction call on a serial section)
-        const double a = sn / theta, b = (1 - cs) / (theta * theta), c = (theta - sn) / (theta * theta * theta);
+        const double it = ORBX_RCP(theta), it2 = it * it;
+        const double a = sn * it, b = (1 - cs) * it2, c = (theta - sn) * (it2 * it);
         for (int i = 0; i < 9; i++) {
             const double I = (i % 4) == 0 ? 1.0 : 0.0;
             R[i] = I + a * O[i] + b * O2[i];
@@ -1432,15 +1464,6 @@ __device__ inline void po_edge_error(const DPose &T, const double in[5], const f
         const double u = Xc[0] * invz * in[0] + in[2], v = Xc[1] * invz * in[1] + in[3];
         out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v; out[2] = (double)obs[2] - (u - in[4] * (double)invz);
     }
-}
-
-// 1 / x: v_rcp_f64 + two Newton steps (the IEEE division sequence is ~40 dependent instructions; six of them sat on the one-thread
-// 6x6 solve of every trial)
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double y = __builtin_amdgcn_rcp(x);
-    y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
-    return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
 }
 
 template <int N> __device__ inline void po_block_reduce(double (&v)[N], double (*red)[PO_NRED], int tid)
