@@ -1457,10 +1457,11 @@ __device__ inline void po_edge_error(const DPose &T, const double in[5], const f
     double Xc[3];
     pose_map(T, X, Xc);
     if (!stereo) {   // EdgeSE3ProjectXYZOnlyPose::computeError / cam_project (types_six_dof_expmap.h:150-157, .cpp:290-296)
-        const double u = Xc[0] / Xc[2] * in[0] + in[2], v = Xc[1] / Xc[2] * in[1] + in[3];
+        const double iz = fast_rcp(Xc[2]);      // (<= 1 ulp from the reference's two divisions; 40 error passes of ~3 edges per thread in series)
+        const double u = Xc[0] * iz * in[0] + in[2], v = Xc[1] * iz * in[1] + in[3];
         out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v; out[2] = 0;
     } else {         // EdgeStereoSE3ProjectXYZOnlyPose (.cpp:299-306): float invz, double bf
-        const float invz = (float)(1.0 / Xc[2]);
+        const float invz = (float)fast_rcp(Xc[2]);
         const double u = Xc[0] * invz * in[0] + in[2], v = Xc[1] * invz * in[1] + in[3];
         out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v; out[2] = (double)obs[2] - (u - in[4] * (double)invz);
     }
@@ -1595,7 +1596,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                 const double X[3] = {(double)xw[j][0], (double)xw[j][1], (double)xw[j][2]};
                 double Xc[3];
                 pose_map(T, X, Xc);
-                const double x = Xc[0], y = Xc[1], invz = 1.0 / Xc[2], invz_2 = invz * invz, fx = in[0], fy = in[1], bf = in[4];
+                const double x = Xc[0], y = Xc[1], invz = fast_rcp(Xc[2]), invz_2 = invz * invz, fx = in[0], fy = in[1], bf = in[4];
                 double J[18];
                 J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
                 J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
