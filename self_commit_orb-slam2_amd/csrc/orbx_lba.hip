@@ -2322,7 +2322,13 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     const int32_t *dCnt = hs.put(p->counts, (size_t)B);
     const float *dXw = hs.put(p->world_points, N * 3), *dObs = hs.put(p->observations, N * 3), *dInv = hs.put(p->inv_sigma2, N);
     if ((rcs = hs.flush(st)) != ORBX_OK) return rcs;
-    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, h->err.p, h->poseOut.p, h->outlier.p, h->ret.p, h->stats.p};
+    // the results are written by the kernel straight into the pinned staging buffer (a few hundred bytes per frame over the fabric, behind the
+    // inputs, which the device has copied out of it by then): four device-to-host copies less on a 0.25 ms call
+    uint8_t *o0 = hs.host, *o1 = o0 + hs.padded((size_t)B * 64), *o2 = o1 + hs.padded(N), *o3 = o2 + hs.padded((size_t)B * 4);
+    uint8_t *hostDev = nullptr;
+    ORBX_HIP_CHECK(hipHostGetDevicePointer((void **)&hostDev, hs.host, 0));
+    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, h->err.p, (float *)(hostDev + (o0 - hs.host)), hostDev + (o1 - hs.host), (int32_t *)(hostDev + (o2 - hs.host)),
+                    (double *)(hostDev + (o3 - hs.host))};
     const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);   // deltaMono / deltaStereo are floats (:389-390)
     Huber hub;
     hub.dMono = thMono; hub.dStereo = thStereo;
@@ -2336,12 +2342,6 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     else hipLaunchKernelGGL(k_pose_opt<16>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
-    // results: four copies into the pinned buffer (stream order: after the kernel, which has consumed the inputs), one synchronisation
-    uint8_t *o0 = hs.host, *o1 = o0 + hs.padded((size_t)B * 64), *o2 = o1 + hs.padded(N), *o3 = o2 + hs.padded((size_t)B * 4);
-    if (poses_out) ORBX_HIP_CHECK(hipMemcpyAsync(o0, h->poseOut.p, (size_t)B * 64, hipMemcpyDeviceToHost, st));
-    if (outlier) ORBX_HIP_CHECK(hipMemcpyAsync(o1, h->outlier.p, N, hipMemcpyDeviceToHost, st));
-    if (inliers) ORBX_HIP_CHECK(hipMemcpyAsync(o2, h->ret.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    if (stats) ORBX_HIP_CHECK(hipMemcpyAsync(o3, h->stats.p, (size_t)B * 64, hipMemcpyDeviceToHost, st));
     ORBX_HIP_CHECK(hipStreamSynchronize(st));
     if (poses_out) memcpy(poses_out, o0, (size_t)B * 64);
     if (outlier) memcpy(outlier, o1, N);
