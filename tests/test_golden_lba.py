@@ -29,7 +29,7 @@ def _gen():
 
 
 def test_golden_present():
-    assert len(G2O) >= 6 and len(LBA_MAP) >= 3 and len(GBA_MAP) >= 2 and len(POSE) >= 6
+    assert len(G2O) >= 8 and len(LBA_MAP) >= 3 and len(GBA_MAP) >= 2 and len(POSE) >= 7
 
 
 def _window(orbx, z):
@@ -159,11 +159,16 @@ def test_hip_matches_pose_optimization_golden(orbx):
     for fr in frames:
         octv = oracle_lib.octaves_of(fr["inv_sigma2"])
         fr["inv_sigma2"] = (np.float32(1.0) / (oracle_lib.SCALE_FACTORS[octv] * oracle_lib.SCALE_FACTORS[octv])).astype(np.float32)
-    opt = orbx.PoseOptimizer(max_frames=8, max_features=2048)
+    opt = orbx.PoseOptimizer(max_frames=8, max_features=4096)
     got = opt.PoseOptimization(frames)
     for i, z in enumerate(zs):
         assert np.abs(got[i]["pose"].astype(np.float64) - z["pose"]).max() <= TOL, i
         assert got[i]["inliers"] == int(z["inliers"]) and (got[i]["outlier"] == z["outlier"]).all(), i
+    # one frame per call: every register variant of the kernel (2 / 4 / 8 / 16 correspondences per thread) against the reference
+    for i, z in enumerate(zs):
+        g1 = opt.PoseOptimization([frames[i]])[0]
+        assert np.abs(g1["pose"].astype(np.float64) - z["pose"]).max() <= TOL, i
+        assert g1["inliers"] == int(z["inliers"]) and (g1["outlier"] == z["outlier"]).all(), i
     opt.close()
     # and through the drop-in shim on a real Frame
     hip = oracle_lib.slam_hip_lib()

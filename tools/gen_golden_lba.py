@@ -37,8 +37,11 @@ G2O = [("g2o_config5_50kf", dict(K=50, P=5000, seed=12345), (5, True, True)),
        ("g2o_stereo_8kf", dict(K=8, P=200, seed=2, stereo_frac=1.0, n_fixed=1), (5, True, True)),
        ("g2o_ba_config5_50kf", dict(K=50, P=5000, seed=12345, n_fixed=1), (10, True, False)),
        ("g2o_ba_mixed_20kf", dict(K=20, P=1500, seed=7, stereo_frac=0.5, n_fixed=1), (20, False, False)),
-       ("g2o_ba_stereo_8kf", dict(K=8, P=200, seed=2, stereo_frac=1.0, n_fixed=1), (20, True, False))]
-POSE = [("pose_%d" % i, 10 + i, n, st) for i, (n, st) in enumerate([(600, 0.5), (1500, 0.0), (40, 1.0), (8, 0.5), (2, 0.5), (300, 0.3)])]
+       ("g2o_ba_stereo_8kf", dict(K=8, P=200, seed=2, stereo_frac=1.0, n_fixed=1), (20, True, False)),
+       # badly initialised windows: Levenberg trials are rejected and retried (pop() / restore path)
+       ("g2o_rejected_12kf_a", dict(K=12, P=400, seed=1, n_fixed=2, pose_noise=[0.10471975511965977, 0.25], point_noise=0.25, stereo_frac=0.3), (5, True, True)),
+       ("g2o_rejected_12kf_b", dict(K=12, P=400, seed=6, n_fixed=2, pose_noise=[0.20943951023931953, 0.5], point_noise=0.4, stereo_frac=0.3), (5, True, True))]
+POSE = [("pose_%d" % i, 10 + i, n, st) for i, (n, st) in enumerate([(600, 0.5), (1500, 0.0), (40, 1.0), (8, 0.5), (2, 0.5), (300, 0.3), (3500, 0.4)])]
 
 
 def window_crc(w):
@@ -57,6 +60,11 @@ def frame_crc(fr):
 
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    only = sys.argv[sys.argv.index("--only") + 1:] if "--only" in sys.argv else None      # regenerate just these files (npz archives carry timestamps)
+    global LBA_MAP, GBA_MAP, G2O, POSE
+    if only:
+        LBA_MAP = [e for e in LBA_MAP if e[0] in only]; GBA_MAP = [e for e in GBA_MAP if e[0] in only]
+        G2O = [e for e in G2O if e[0] in only]; POSE = [e for e in POSE if e[0] in only]
     for name, cfg in LBA_MAP:
         w = orbx.lba_synth.make_window(**cfg)
         r = oracle_lib.ref_local_ba_on_map(w, w["K"] - 1)
