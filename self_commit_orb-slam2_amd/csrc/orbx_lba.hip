@@ -1445,7 +1445,6 @@ struct PoseOptDev {
     const float *invS2;      // [B*cap]   mvInvLevelSigma2[kpUn.octave]
     const int32_t *counts;   // [B]
     int cap;
-    double *err;             // [B*cap*3] scratch: _error of every edge (kept between rounds like g2o keeps it)
     float *poseOut;          // [B*16]
     uint8_t *outlier;        // [B*cap]  pFrame->mvbOutlier of those features
     int32_t *ret;            // [B] nInitialCorrespondences - nBad
@@ -2269,11 +2268,7 @@ extern "C" int orbx_bundle_adjustment(orbx_lba *h, const orbx_lba_problem *p, in
 struct orbx_pose_optimizer {
     int device = 0, maxFrames = 0, maxFeatures = 0;
     hipStream_t stream = nullptr;
-    OrbxDevBuf<float> poseOut;
-    OrbxDevBuf<int32_t> ret;
-    OrbxDevBuf<uint8_t> outlier;
-    OrbxDevBuf<double> err, stats;
-    OrbxHostStage hostStage;   // inputs of a call in one pinned copy, results back through the same pinned buffer
+    OrbxHostStage hostStage;   // inputs of a call in one pinned copy; the kernel writes the results straight into the same pinned buffer
 };
 
 extern "C" int orbx_pose_optimizer_create(int device, int max_frames, int max_features, orbx_pose_optimizer **out)
@@ -2287,12 +2282,6 @@ extern "C" int orbx_pose_optimizer_create(int device, int max_frames, int max_fe
     orbx_pose_optimizer *h = new orbx_pose_optimizer();
     h->device = device; h->maxFrames = max_frames; h->maxFeatures = max_features;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
-    const size_t B = (size_t)max_frames, N = (size_t)max_frames * max_features;
-    int rc;
-    if ((rc = h->poseOut.ensure(B * 16)) || (rc = h->ret.ensure(B)) || (rc = h->outlier.ensure(N)) || (rc = h->err.ensure(N * 3)) || (rc = h->stats.ensure(B * 8))) {
-        orbx_pose_optimizer_destroy(h);
-        return rc;
-    }
     *out = h;
     return ORBX_OK;
 }
@@ -2302,8 +2291,7 @@ extern "C" void orbx_pose_optimizer_destroy(orbx_pose_optimizer *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    h->poseOut.release(); h->ret.release();
-    h->outlier.release(); h->err.release(); h->stats.release(); h->hostStage.release();
+    h->hostStage.release();
     delete h;
 }
 
@@ -2330,7 +2318,7 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     uint8_t *o0 = hs.host, *o1 = o0 + hs.padded((size_t)B * 64), *o2 = o1 + hs.padded(N), *o3 = o2 + hs.padded((size_t)B * 4);
     uint8_t *hostDev = nullptr;
     ORBX_HIP_CHECK(hipHostGetDevicePointer((void **)&hostDev, hs.host, 0));
-    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, h->err.p, (float *)(hostDev + (o0 - hs.host)), hostDev + (o1 - hs.host), (int32_t *)(hostDev + (o2 - hs.host)),
+    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, (float *)(hostDev + (o0 - hs.host)), hostDev + (o1 - hs.host), (int32_t *)(hostDev + (o2 - hs.host)),
                     (double *)(hostDev + (o3 - hs.host))};
     const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);   // deltaMono / deltaStereo are floats (:389-390)
     Huber hub;
