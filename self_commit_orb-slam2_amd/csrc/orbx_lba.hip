@@ -571,6 +571,27 @@ __global__ __launch_bounds__(256) void k_csr_pt_rank(const int *__restrict__ ep,
     ptEdges[s0 + rank] = e;
 }
 
+// What k_schur_rows needs per slot of the keyframe lists without chasing five dependent indices (edge -> landmark -> row -> partner edge ->
+// keyframe -> free-pose index, ~1.5 us each on a device that the launch does not fill): the landmark row of every keyframe-list slot
+// (static per call) and, per stage, the free-pose index of the edge in every landmark-list slot (-1: inactive edge or fixed keyframe).
+__global__ __launch_bounds__(256) void k_csr_rows(int E, const int *__restrict__ ep, const int *__restrict__ kfEdges, const int *__restrict__ ptStart, int *__restrict__ kfRowS0,
+                                                  int *__restrict__ kfRowN)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= E) return;
+    const int l = ep[kfEdges[s]], s0 = ptStart[l];
+    kfRowS0[s] = s0;
+    kfRowN[s] = ptStart[l + 1] - s0;
+}
+__global__ __launch_bounds__(256) void k_stage_pairs(int E, const int *__restrict__ ek, const int *__restrict__ ptEdges, const uint8_t *__restrict__ active,
+                                                     const int *__restrict__ poseIdx, int *__restrict__ ptPi)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= E) return;
+    const int e2 = ptEdges[j];
+    ptPi[j] = active[e2] ? poseIdx[ek[e2]] : -1;
+}
+
 // initializeOptimization(level 0) on the device (sparse_optimizer.cpp:166-267): active[e] = edge not flagged as an outlier by the previous
 // stage (flag == nullptr: all), a vertex takes part when one of its edges does, free keyframes and landmarks are numbered in order.
 // The three counts go to pinned memory like the sums of a trial (host[10..12], sequence number last).  Before, the
@@ -752,8 +773,8 @@ __global__ __launch_bounds__(256) void k_schur_setup(LbaDev d, int nInit, const 
 // GLOBAL = true: the block row does not fit into LDS (more than ~530 free keyframes, i.e. a global bundle adjustment of a large map):
 // the same walk with the FP64 atomics going straight to S / bs.
 template <bool GLOBAL>
-__global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart, const int *kfEdges, const int *ptStart, const int *ptEdges, int nP6,
-                                                    const double *__restrict__ Ddb, double *S, double *bs)
+__global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart, const int *kfEdges, const int *__restrict__ kfRowS0, const int *__restrict__ kfRowN,
+                                                    const int *ptEdges, const int *__restrict__ ptPi, int nP6, const double *__restrict__ Ddb, double *S, double *bs)
 {
     extern __shared__ __attribute__((aligned(16))) double rowLds[];   // [6][nP6], then 6 entries of bs
     const int k = blockIdx.x, pi = d.poseIdx[k], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -768,22 +789,23 @@ __global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart
     // landmark (the index lookups are done once per pair, the 6x6 block comes out of 36 registers)
     const int sub = lane >> 4, a = lane & 15, stride = 16 * gridDim.y;
     for (int s = kfStart[k] + (blockIdx.y * 4 + wv) * 4 + sub; s < kfStart[k + 1]; s += stride) {
-        const int e = kfEdges[s];
+        // three dependent round trips instead of eight: slot -> (edge | landmark row) -> (partner edge, its free-pose index) -> its block
+        const int e = kfEdges[s], s0 = kfRowS0[s], nE = kfRowN[s];
+        int e2v[1], i2v[1];                                   // first partner of this lane, requested before anything else is waited for
+        e2v[0] = a < nE ? ptEdges[s0 + a] : 0; i2v[0] = a < nE ? ptPi[s0 + a] : -1;
         if (!d.active[e]) continue;
         const double *pBD = d.edgeBlk + (size_t)e * EB_SIZE + EB_BD;
         double BD[18];
 #pragma unroll
         for (int i = 0; i < 18; i++) BD[i] = pBD[i];
-        const int l = d.ep[e], s0 = ptStart[l], nE = ptStart[l + 1] - s0;
         if (a < 6) {   // bs[i1] -= B * (D^-1 b_l): 300 addresses for all edges of the window, so it goes through the LDS row as well
-            const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL + 3 * a, *db = Ddb + (size_t)l * 3;
+            const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL + 3 * a, *db = Ddb + (size_t)d.ep[e] * 3;
             unsafeAtomicAdd(&rowB[a], -(B1[0] * db[0] + B1[1] * db[1] + B1[2] * db[2]));
         }
         for (int a2 = a; a2 < nE; a2 += 16) {
-            const int e2 = ptEdges[s0 + a2];
-            if (!d.active[e2]) continue;
-            const int i2 = d.poseIdx[d.ek[e2]];
-            if (i2 < 0 || i2 > pi) continue;            // lower block triangle only; -1 = fixed keyframe
+            const int e2 = a2 == a ? e2v[0] : ptEdges[s0 + a2];
+            const int i2 = a2 == a ? i2v[0] : ptPi[s0 + a2];
+            if (i2 < 0 || i2 > pi) continue;            // lower block triangle only; -1 = inactive edge or fixed keyframe
             const double *pB2 = d.edgeBlk + (size_t)e2 * EB_SIZE + EB_HPL;
             double B2[18];
 #pragma unroll
@@ -1804,7 +1826,7 @@ struct orbx_lba {
     size_t hostIOBytes = 0;
     OrbxDevBuf<uint8_t> flagDev, inArena, fixedDev;
     OrbxDevBuf<double> spPart;           // k_sum_poses: SP_SPLIT partial results per keyframe
-    OrbxDevBuf<int> csrCnt, ptTmp, fillP, pActF, lActF;   // adjacency-list builder and stage preparation (device side)
+    OrbxDevBuf<int> csrCnt, ptTmp, fillP, pActF, lActF, kfRowS0, kfRowN, ptPi;   // adjacency-list builder and stage preparation (device side)
     OrbxDevBuf<double> partChi, partL;   // per-workgroup partial sums of k_errors / k_backsub_update
     double *hostRedDev = nullptr;        // device view of hostRed
     double seq = 0;                      // sequence number of the last k_trial_finish
@@ -1838,6 +1860,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     rc = rc ? rc : h->kfStart.ensure(K + 1); rc = rc ? rc : h->kfEdges.ensure(E); rc = rc ? rc : h->poseIdx.ensure(K); rc = rc ? rc : h->ptIdx.ensure(P);
     rc = rc ? rc : h->okFlag.ensure(1); rc = rc ? rc : h->stereo.ensure(E); rc = rc ? rc : h->active.ensure(E);
     rc = rc ? rc : h->spPart.ensure(K * SP_SPLIT * 27);
+    rc = rc ? rc : h->kfRowS0.ensure(E); rc = rc ? rc : h->kfRowN.ensure(E); rc = rc ? rc : h->ptPi.ensure(E);
     rc = rc ? rc : h->fixedDev.ensure(K); rc = rc ? rc : h->ptTmp.ensure(E); rc = rc ? rc : h->fillP.ensure(P); rc = rc ? rc : h->pActF.ensure(K); rc = rc ? rc : h->lActF.ensure(P);
     rc = rc ? rc : h->partChi.ensure((E + 255) / 256); rc = rc ? rc : h->partL.ensure((std::max(K, 16 * P) + 255) / 256);
     if (rc) { orbx_lba_destroy(h); return rc; }
@@ -1859,7 +1882,7 @@ extern "C" void orbx_lba_destroy(orbx_lba *h)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->hostRed) (void)hipHostFree(h->hostRed);
     if (h->hostIO) (void)hipHostFree(h->hostIO);
-    h->flagDev.release(); h->partChi.release(); h->partL.release(); h->inArena.release(); h->fixedDev.release(); h->csrCnt.release(); h->ptTmp.release(); h->fillP.release(); h->pActF.release(); h->lActF.release(); h->spPart.release();
+    h->flagDev.release(); h->partChi.release(); h->partL.release(); h->inArena.release(); h->fixedDev.release(); h->csrCnt.release(); h->ptTmp.release(); h->fillP.release(); h->pActF.release(); h->lActF.release(); h->kfRowS0.release(); h->kfRowN.release(); h->ptPi.release(); h->spPart.release();
     delete h;
 }
 
@@ -1921,6 +1944,8 @@ int optimize(Ctx &c, int iterations, double stats[4])
                            h->csrCnt.p);      // (the chunk counters of the adjacency-list builder are free again: >= E / 256 entries)
         hipLaunchKernelGGL(k_stage_index, dim3(1), dim3(1024), 0, h->stream, K, P, (const uint8_t *)h->fixedDev.p, (const int *)h->pActF.p, (const int *)h->lActF.p, stamp,
                            h->poseIdx.p, h->ptIdx.p, (const int *)h->csrCnt.p, (int)gM, h->hostRedDev, seq);
+        hipLaunchKernelGGL(k_stage_pairs, dim3(gM), dim3(256), 0, h->stream, E, (const int *)h->ek.p, (const int *)h->ptEdges.p, (const uint8_t *)h->active.p, (const int *)h->poseIdx.p,
+                           h->ptPi.p);
         LCHECK();
         if (!c.stageFlags) { nPose = c.nPose0; nPt = c.nPt0; nAct = E; }      // nothing to wait for
         else {
@@ -2011,10 +2036,10 @@ int optimize(Ctx &c, int iterations, double stats[4])
             if (nP6 > 0) {
                 const size_t ldsRows = (size_t)(6 * nP6 + 6) * sizeof(double);
                 if (ldsRows > 150 * 1024) {      // > ~530 free keyframes: the block row no longer fits into LDS
-                    hipLaunchKernelGGL(k_schur_rows<true>, dim3((unsigned)K, 16u), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, bsDev);
+                    hipLaunchKernelGGL(k_schur_rows<true>, dim3((unsigned)K, 16u), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, (const int *)h->kfRowS0.p, (const int *)h->kfRowN.p, h->ptEdges.p, (const int *)h->ptPi.p, nP6, h->Ddb.p, h->S.p, bsDev);
                 } else {
                     if (ldsRows > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
-                    hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, 32u), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->ptStart.p, h->ptEdges.p, nP6, h->Ddb.p, h->S.p, bsDev);
+                    hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, 32u), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, (const int *)h->kfRowS0.p, (const int *)h->kfRowN.p, h->ptEdges.p, (const int *)h->ptPi.p, nP6, h->Ddb.p, h->S.p, bsDev);
                 }
                 LCHECK();
             }
@@ -2204,6 +2229,7 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
         hipLaunchKernelGGL(k_csr_kf_fill, dim3((unsigned)nChunk), dim3(256), 0, s, (const int *)h->ek.p, E, K, (const int *)h->csrCnt.p, h->kfEdges.p);
         hipLaunchKernelGGL(k_csr_pt_fill, dim3(gE), dim3(256), 0, s, (const int *)h->ep.p, E, (const int *)h->ptStart.p, h->fillP.p, h->ptTmp.p);
         hipLaunchKernelGGL(k_csr_pt_rank, dim3(gE), dim3(256), 0, s, (const int *)h->ep.p, E, (const int *)h->ptStart.p, (const int *)h->ptTmp.p, h->ptEdges.p);
+        hipLaunchKernelGGL(k_csr_rows, dim3(gE), dim3(256), 0, s, E, (const int *)h->ep.p, (const int *)h->kfEdges.p, (const int *)h->ptStart.p, h->kfRowS0.p, h->kfRowN.p);
         LCHECK();
     }
     LbaDev &d = c.d;
