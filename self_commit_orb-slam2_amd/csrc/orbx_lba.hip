@@ -1029,14 +1029,9 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-// The panel step: nothing goes through synchronised column steps (a version with the 32x32 block in LDS and two workgroup
-// barriers per column took 31 us per panel, this one ~17).
-//   wave 0      factors the 32x32 diagonal block in REGISTERS - lane r keeps row r, the pivot column travels by v_readlane
-//               (readlane_f64 above), no LDS round trip and no barrier inside the 32 dependent steps;
-//   waves 1-2   one thread per row of the panel below (64 rows per workgroup) and one for the right-hand side: the row sits in 32
-//               registers, is loaded while wave 0 factors, and is eliminated by forward substitution against L11 read from LDS
-//               as broadcasts, products subtracted in the order k = 0 .. c-1.
-// One barrier between the two phases, one before the right-hand-side update of the rows below.
+// The panel step: nothing goes through synchronised column steps (a version with the 32x32 block in LDS and two workgroup barriers
+// per column took 31 us per panel; a wave factoring the block in registers with one v_readlane pair per multiply-add and a second wave
+// eliminating the rows afterwards 17; the blocked one-wave elimination inside k_chol_step below ~6 of the 15 us a panel launch takes).
 // 1 / sqrt(x) for the pivots: v_rsq_f64 (~26 bits) + one Newton step y += y/2 (1 - x y^2), instead of the library routine: every
 // dependent FP64 operation on the pivot chain costs ~16 cycles, and the factor is not part of the bit-level contract (1e-5 vs g2o)
 __device__ __forceinline__ double pivot_rsqrt(double x)
