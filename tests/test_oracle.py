@@ -135,3 +135,84 @@ def test_octree_array_form_equals_std_list(oracle):
         a = oracle.octree(packed, w, h, N)
         b = oracle.ref_octree(ref, packed, w, h, N)
         assert len(a) == len(b) and (a == b).all(), "trial %d" % trial
+
+
+# ------------------------------------------------------------------------------------------------
+# The three OpenCV primitives are restated (OpenCV is not vendored in the reference and not installed here: parity unpinned).  These
+# checks hold the restatements to the primitives' MATHEMATICAL definitions, computed independently in numpy - not to OpenCV's code.
+def _fast9_bruteforce(im, t):
+    """FAST-9/16 by definition: corner iff 9 contiguous circle pixels are all > v + t or all < v - t; score = the largest t for which
+    the pixel is still a corner (0 if it is none at threshold t)."""
+    dx = [0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1]
+    dy = [-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3]
+    H, W = im.shape
+    v = im[3:H - 3, 3:W - 3].astype(np.int32)
+    ring = np.stack([im[3 + dy[k]:H - 3 + dy[k], 3 + dx[k]:W - 3 + dx[k]].astype(np.int32) for k in range(16)], 0)
+    ring2 = np.concatenate([ring, ring[:8]], 0)
+    best = np.full(v.shape, -1, np.int32)
+    for s in range(16):                                    # arc of 9 starting at s
+        arc = ring2[s:s + 9]
+        best = np.maximum(best, np.maximum(arc.min(0) - v, v - arc.max(0)))      # bright arc: min(arc) - v > t ; dark arc: v - max(arc) > t
+    score = np.where(best - 1 >= t, best - 1, 0)           # corner at t <=> best > t ; largest such t is best - 1
+    out = np.zeros(im.shape, np.int32)
+    out[3:H - 3, 3:W - 3] = score
+    return out
+
+
+@pytest.mark.parametrize("seed,t", [(1, 7), (2, 20), (3, 1), (4, 40)])
+def test_fast_score_equals_the_definition(oracle, seed, t):
+    rng = np.random.default_rng(seed)
+    im = rng.integers(0, 256, (61, 83)).astype(np.uint8)
+    im[20:40, 30:60] = (im[20:40, 30:60] // 8 + 100).astype(np.uint8)      # a low-contrast patch next to noise
+    S = oracle.score_map(im, t).astype(np.int32)
+    want = _fast9_bruteforce(im, t)
+    assert (S[3:-3, 3:-3] == np.minimum(want, 255)[3:-3, 3:-3]).all()
+
+
+def test_gaussian_blur_against_the_real_valued_filter(oracle):
+    """cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101): the fixed-point result vs the float64 separable filter with
+    getGaussianKernel's formula exp(-x^2 / (2 sigma^2)) normalised to 1."""
+    rng = np.random.default_rng(5)
+    im = rng.integers(0, 256, (45, 70)).astype(np.uint8)
+    x = np.arange(-3, 4, dtype=np.float64)
+    k = np.exp(-x * x / 8.0)
+    k /= k.sum()
+    p = np.pad(im.astype(np.float64), 3, mode="reflect")      # numpy 'reflect' == BORDER_REFLECT_101
+    h = sum(k[i] * p[:, i:i + 70] for i in range(7))
+    ref = sum(k[i] * h[i:i + 45, :] for i in range(7))
+    got = oracle.blur(im).astype(np.float64)
+    # the 8-bit taps (18 34 48 56 48 34 18) / 256 are the real kernel (17.96 33.56 48.82 55.32 ...) / 256 rounded so that they sum to 1:
+    # up to 0.82 / 256 apart, i.e. at most ~1.2 grey levels on white noise; against the taps themselves only the final rounding remains
+    assert np.abs(k * 256 - np.array([18, 34, 48, 56, 48, 34, 18])).max() < 0.85
+    assert np.abs(got - ref).max() <= 1.5 and np.abs(got - ref).mean() < 0.4
+    kt = np.array([18, 34, 48, 56, 48, 34, 18], np.float64) / 256
+    h = sum(kt[i] * p[:, i:i + 70] for i in range(7))
+    ref_taps = sum(kt[i] * h[i:i + 45, :] for i in range(7))
+    assert np.abs(got - ref_taps).max() <= 0.5 + 1e-9
+
+
+def test_resize_within_one_level_of_real_valued_bilinear(oracle):
+    """cv::resize(INTER_LINEAR): source coordinate (dst + 0.5) * scale - 0.5 with scale = src / dst, clamped at the borders; the 11-bit
+    fixed-point result vs float64 bilinear interpolation, level 0 -> level 1 of the 640x480 pyramid."""
+    rng = np.random.default_rng(6)
+    im = rng.integers(0, 256, (480, 640)).astype(np.uint8)
+    ext = oracle.restatement(1000)
+    lv1 = oracle.pyramid(ext, im)[1].astype(np.float64)
+    h1, w1 = lv1.shape
+
+    def axis(n_dst, n_src):
+        s = (np.arange(n_dst) + 0.5) * (n_src / n_dst) - 0.5
+        i0 = np.floor(s).astype(np.int64)
+        f = s - i0
+        f = np.where(i0 < 0, 0.0, f)
+        i0 = np.clip(i0, 0, n_src - 1)
+        i1 = np.clip(i0 + 1, 0, n_src - 1)
+        return i0, i1, f
+
+    y0, y1, fy = axis(h1, 480)
+    x0, x1, fx = axis(w1, 640)
+    a = im.astype(np.float64)
+    top = a[y0][:, x0] * (1 - fx) + a[y0][:, x1] * fx
+    bot = a[y1][:, x0] * (1 - fx) + a[y1][:, x1] * fx
+    ref = top * (1 - fy)[:, None] + bot * fy[:, None]
+    assert np.abs(lv1 - ref).max() <= 1.0 and np.abs(lv1 - ref).mean() < 0.3
