@@ -131,3 +131,29 @@ def test_bad_arguments(orbx):
         orbx.FrameOps(500, 500, 320, 240, [0.1, 0, 0])      # 3 coefficients: not a form mDistCoef takes
     with pytest.raises(Exception):
         orbx.FrameOps(0, 500, 320, 240, [0.1, 0, 0, 0])
+
+
+@pytest.mark.parametrize("cam", ["tum1", "tum2", "euroc"])
+def test_restated_undistort_inverts_the_distortion_model(oracle, cam):
+    """cv::undistortPoints is restated (OpenCV is not available: parity unpinned at that level).  Independent check by the definition:
+    pushing the undistorted points through the forward Brown-Conrady model (k1 k2 p1 p2 k3) must give the measured pixels back - the
+    five fixed-point iterations of the inverse converge to well under a hundredth of a pixel for these cameras inside the image."""
+    W, H, K, dist = CAMS[cam]
+    rng = np.random.default_rng(11)
+    k7 = _kps7(rng, 800, W, H)
+    un = oracle_lib.frame_finish(oracle, k7, K, dist, W, H)["kpsUn"]
+    fx, fy, cx, cy = K
+    d = list(dist) + [0.0] * (5 - len(dist))
+    k1, k2, p1, p2, k3 = d
+    x = (un[:, 0].astype(np.float64) - cx) / fx
+    y = (un[:, 1].astype(np.float64) - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    u, v = fx * xd + cx, fy * yd + cy
+    err = np.hypot(u - k7[:, 0], v - k7[:, 1])
+    # five iterations, like OpenCV 2.4 / 3.x: converged for the TUM cameras; the strongly distorted EuRoC camera (k1 = -0.28) keeps up to 0.3 px
+    # at the image corners - a property of the reference's OpenCV call, reproduced here
+    assert err.max() < (0.5 if cam == "euroc" else 0.02), err.max()
+    assert np.median(err) < 0.01
