@@ -384,26 +384,31 @@ def bench_stereo(a, orbx, torch, grp, dev_t, local, rank_info):
     Frame::ComputeStereoMatches (complete: row bands, SAD refinement, median cut) on the device."""
     W, H, nf = 1241, 376, 2000
     B = a.batch if a.batch != 256 else 64                  # pairs per batch
-    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B, device=local)   # KITTI00-02.yaml:41-50
-    mt = orbx.ORBmatcher(0.7, True, max_features=ext.capacity, max_pairs=B, device=local)
+    NS = max(1, a.streams)                                # handle pairs (= HIP stream pairs) that take the batches in turn, as in the default workload
+    exts = [orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B, device=local) for _ in range(NS)]   # KITTI00-02.yaml:41-50
+    mts = [orbx.ORBmatcher(0.7, True, max_features=exts[0].capacity, max_pairs=B, device=local) for _ in range(NS)]
+    ext, mt = exts[0], mts[0]
     seeds = [grp.seed_base() + 100 + i for i in range(B)]
     frames = [orbx.synth_frame(s, W, H) for s in seeds] + [orbx.synth_frame(s, W, H, orbx.SYNTH_STEREO_RIGHT) for s in seeds]
-    dev = resident_batches(orbx, torch, dev_t, ext, frames, 2 * B)[0]
+    devs = [resident_batches(orbx, torch, dev_t, e, frames, 2 * B)[0] for e in exts]
     fl, fr = np.arange(B, dtype=np.int32), np.arange(B, 2 * B, dtype=np.int32)
     bf = 386.1448                                         # KITTI00-02.yaml:25
 
-    def step():
-        ext.run_device(*dev[1])                           # left and right images of the batch in one launch set
-        mt.compute_stereo_matches_device(ext, ext, fl, fr, bf, 0.0)
+    def step(i):
+        k = i % NS
+        exts[k].run_device(*devs[k][1])                   # left and right images of the batch in one launch set
+        mts[k].compute_stereo_matches_device(exts[k], exts[k], fl, fr, bf, 0.0)
 
     def sync_all():
-        ext.sync(); mt.sync(); torch.cuda.synchronize()
-    for _ in range(a.warmup):
-        step()
+        for e, m in zip(exts, mts):
+            e.sync(); m.sync()
+        torch.cuda.synchronize()
+    for i in range(a.warmup + NS):
+        step(i)
     sync_all(); grp.barrier(); sync_all()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    for i in range(a.steps):
+        step(i)
     sync_all(); grp.barrier(); sync_all()
     elapsed = time.perf_counter() - t0
     u, z = mt.download_stereo(B)
@@ -414,7 +419,7 @@ def bench_stereo(a, orbx, torch, grp, dev_t, local, rank_info):
     return {"metric": "stereo pairs/s ORB extract L+R + ComputeStereoMatches (2000 feat, 1241x376)", "value": round(total / t, 1), "unit": "pairs/s",
             "n_gpus": grp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: batch of %d KITTI-shaped stereo pairs, extract left + right (2000 feat) + L<->R match on the device" % B,
+            "config": {"workload": "BASELINE config 3: batch of %d KITTI-shaped stereo pairs, extract left + right (2000 feat) + L<->R match on the device" % B, "streams": NS,
                        "keypoints_per_image": round(float(cnt.mean()), 1), "stereo_matches_per_pair": round(float((u >= 0).sum(1).mean()), 1)},
             "ranks": dict(rank_info, per_rank=[{"pairs": r[0], "seconds": round(r[1], 6)} for r in per_rank])}
 
