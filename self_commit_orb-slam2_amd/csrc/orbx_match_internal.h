@@ -68,6 +68,7 @@ struct orbx_matcher {
     OrbxDevBuf<uint32_t> projDec, projQueue;   // k_proj_greedy: chosen feature per map point, rescan queue
     OrbxHostStage hostStage;     // host-array entry points: all inputs of a call in one pinned buffer, one copy
     OrbxDevBuf<int32_t> sad;
+    OrbxDevBuf<int32_t> stRowStart, stRowList;   // ComputeStereoMatches: vRowIndices of the right frames (k_stereo_rows)
     hipEvent_t evDep2 = nullptr, evPyr[2] = {nullptr, nullptr};
     int lastStereoPairs = 0;
     // staging for the host-array convenience calls
