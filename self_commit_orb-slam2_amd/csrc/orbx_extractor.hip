@@ -82,9 +82,12 @@ struct orbx_extractor {
     DevBuf<int> cellCount, lvlCnt, status;
     // results are double buffered: a consumer (matcher) may still read batch i while batch i+1 is
     // extracted; consumerEv[b] = event after which buffer b may be overwritten again
-    DevBuf<uint8_t> outDesc[2];
-    DevBuf<int> outCnt[2];
-    DevBuf<orbx_keypoint> outKp[2];
+    // counts | keypoints | descriptors of a buffer live in ONE allocation, so that a whole-batch read-back is one copy
+    DevBuf<uint8_t> outArena[2];
+    int *outCntP[2] = {nullptr, nullptr};
+    orbx_keypoint *outKpP[2] = {nullptr, nullptr};
+    uint8_t *outDescP[2] = {nullptr, nullptr};
+    size_t arenaKpOff = 0, arenaDescOff = 0, arenaBytes = 0;
     hipEvent_t consumerEv[2] = {nullptr, nullptr};
     hipEvent_t pyrConsumerEv = nullptr;   // a consumer still reads the (single buffered) pyramid of the last batch
     int cur = 0;
@@ -328,10 +331,14 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
         if ((rc = h->ptBuf.ensure(B * g.nlevels * 2 * ORBX_PT_CAP)) != ORBX_OK) return rc;
         if ((rc = h->lvlKp.ensure(B * g.kpPerFrame)) != ORBX_OK) return rc;
         if ((rc = h->lvlCnt.ensure(B * g.nlevels)) != ORBX_OK) return rc;
+        h->arenaKpOff = align_up(B * sizeof(int), 256);
+        h->arenaDescOff = h->arenaKpOff + align_up(B * g.outCap * sizeof(orbx_keypoint), 256);
+        h->arenaBytes = h->arenaDescOff + B * g.outCap * 32;
         for (int b = 0; b < 2; b++) {
-            if ((rc = h->outKp[b].ensure(B * g.outCap)) != ORBX_OK) return rc;
-            if ((rc = h->outDesc[b].ensure(B * g.outCap * 32)) != ORBX_OK) return rc;
-            if ((rc = h->outCnt[b].ensure(B)) != ORBX_OK) return rc;
+            if ((rc = h->outArena[b].ensure(h->arenaBytes)) != ORBX_OK) return rc;
+            h->outCntP[b] = (int *)h->outArena[b].p;
+            h->outKpP[b] = (orbx_keypoint *)(h->outArena[b].p + h->arenaKpOff);
+            h->outDescP[b] = h->outArena[b].p + h->arenaDescOff;
         }
         if ((rc = h->status.ensure(B + 1)) != ORBX_OK) return rc;   // per frame + one word for the whole batch
         // the score map is only written inside the detectable window; clear it once so the
@@ -355,7 +362,7 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     L.cellCount = h->cellCount.p; L.cellSlots = h->cellSlots.p; L.ptBuf = h->ptBuf.p;
     h->cur ^= 1;
     const int cb = h->cur;
-    L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outKp = h->outKp[cb].p; L.outDesc = h->outDesc[cb].p; L.outCnt = h->outCnt[cb].p;
+    L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outKp = h->outKpP[cb]; L.outDesc = h->outDescP[cb]; L.outCnt = h->outCntP[cb];
     L.status = h->status.p; L.nodeCap = h->nodeCap;
     const bool prof = h->profiling;
     hipEvent_t *ev = h->ev[h->profCount % ORBX_PROF_RING];
@@ -437,7 +444,7 @@ int orbx_extractor_last_batch_view_internal(orbx_extractor *h, OrbxLastBatchView
     if (!h || !v) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
     v->batch = h->lastBatch; v->nlevels = h->geom.nlevels; v->cap = h->geom.outCap;
-    v->kp = h->outKp[h->cur].p; v->desc = h->outDesc[h->cur].p; v->counts = h->outCnt[h->cur].p;
+    v->kp = h->outKpP[h->cur]; v->desc = h->outDescP[h->cur]; v->counts = h->outCntP[h->cur];
     v->img0 = h->lastImg0; v->img0Stride = h->lastStride; v->img0FramePitch = h->lastFramePitch;
     v->pyr = h->pyr.p; v->pyrBytes = h->geom.pyrBytes; v->geomDev = h->geomDev.p; v->geom = &h->geom;
     v->scale = h->scale.data(); v->invScale = h->invScale.data();
@@ -493,7 +500,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     if (h->hostStaging) { (void)hipHostFree(h->hostStaging); h->hostStaging = nullptr; h->hostStagingBytes = 0; }
     if (h->hostOut) { (void)hipHostFree(h->hostOut); h->hostOut = nullptr; h->hostOutBytes = 0; }
     h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release();
-    for (int b = 0; b < 2; b++) { h->outDesc[b].release(); h->outCnt[b].release(); h->outKp[b].release(); }
+    for (int b = 0; b < 2; b++) h->outArena[b].release();
     h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->lvlKp.release();
     for (int r = 0; r < ORBX_PROF_RING; r++)
         for (int i = 0; i <= ST_COUNT; i++) if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
@@ -551,9 +558,9 @@ extern "C" int orbx_batch_results_device(orbx_extractor *h, const orbx_keypoint 
 {
     if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
     if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
-    if (keypoints_dev) *keypoints_dev = h->outKp[h->cur].p;
-    if (descriptors_dev) *descriptors_dev = h->outDesc[h->cur].p;
-    if (counts_dev) *counts_dev = h->outCnt[h->cur].p;
+    if (keypoints_dev) *keypoints_dev = h->outKpP[h->cur];
+    if (descriptors_dev) *descriptors_dev = h->outDescP[h->cur];
+    if (counts_dev) *counts_dev = h->outCntP[h->cur];
     if (capacity) *capacity = h->geom.outCap;
     return ORBX_OK;
 }
@@ -609,15 +616,20 @@ extern "C" int orbx_batch_download(orbx_extractor *h, int batch, orbx_keypoint *
     // Counts, status words and the result arrays come back whole through ONE pinned buffer, enqueued behind the kernels and
     // followed by ONE synchronisation (a single-frame call is latency bound: every extra sync / blocking copy costs 10-20 us).
     const int cap = h->geom.outCap;
-    const size_t B = (size_t)batch, offSt = align_up(B * sizeof(int), 256), offKp = offSt + align_up((B + 1) * sizeof(int), 256),
-                 offDesc = offKp + align_up(B * cap * sizeof(orbx_keypoint), 256), bytes = offDesc + B * cap * 32;
+    const size_t B = (size_t)batch;
+    const bool whole = batch == h->allocBatch && keypoints && descriptors;      // the buffer's own layout: one copy brings counts, keypoints and descriptors
+    const size_t offKp = whole ? h->arenaKpOff : align_up(B * sizeof(int), 256), offDesc = whole ? h->arenaDescOff : offKp + align_up(B * cap * sizeof(orbx_keypoint), 256),
+                 offSt = offDesc + align_up(B * cap * 32, 256), bytes = offSt + align_up((B + 1) * sizeof(int), 256);
     int rc = ensure_host_out(h, bytes);
     if (rc != ORBX_OK) return rc;
     uint8_t *hp = h->hostOut;
-    ORBX_HIP_CHECK(hipMemcpyAsync(hp, h->outCnt[h->cur].p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (whole) ORBX_HIP_CHECK(hipMemcpyAsync(hp, h->outArena[h->cur].p, h->arenaBytes, hipMemcpyDeviceToHost, h->stream));
+    else {
+        ORBX_HIP_CHECK(hipMemcpyAsync(hp, h->outCntP[h->cur], B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (keypoints) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offKp, h->outKpP[h->cur], B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->stream));
+        if (descriptors) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offDesc, h->outDescP[h->cur], B * cap * 32, hipMemcpyDeviceToHost, h->stream));
+    }
     ORBX_HIP_CHECK(hipMemcpyAsync(hp + offSt, h->status.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (keypoints) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offKp, h->outKp[h->cur].p, B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->stream));
-    if (descriptors) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offDesc, h->outDesc[h->cur].p, B * cap * 32, hipMemcpyDeviceToHost, h->stream));
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     const int *st = (const int *)(hp + offSt);
     for (int f = 0; f < batch; f++)
