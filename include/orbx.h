@@ -92,7 +92,19 @@ int orbx_extractor_tables(const orbx_extractor *h, int *nlevels, float *scale, f
                           float *sigma2, float *inv_sigma2, int *features_per_level);
 /* Upper bound of keypoints one frame can yield: sum over levels of quota+3
  * (octree exit conditions, src/ORBextractor.cc:910,1003). */
+/* The same tables without a handle (and without a device): what ORBextractor::ORBextractor computes from
+ * (nfeatures, scaleFactor, nlevels) alone (src/ORBextractor.cc:499-554).  Only cfg->nfeatures / scale_factor / nlevels are read.
+ * The drop-in constructor uses it so that the getters are valid even when no HIP device can be opened (the reference's
+ * constructor cannot fail). */
+int orbx_extractor_tables_for(const orbx_extractor_config *cfg, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                              int *features_per_level);
 int orbx_extractor_capacity(const orbx_extractor *h);
+
+/* ORBextractor::operator() for one host image WITHOUT the copy into caller arrays: *keypoints / *descriptors point into the
+ * handle's pinned result buffer (count entries / count*32 bytes), valid until the next call on this handle.  The drop-in functor
+ * (shim/ORBextractor.cc) converts to cv::KeyPoint / cv::Mat straight from there.  Empty image: ORBX_OK, *count = 0. */
+int orbx_extract_view(orbx_extractor *h, const uint8_t *image, int width, int height, int stride, const orbx_keypoint **keypoints,
+                      const uint8_t **descriptors, int *count);
 
 /* ORBextractor::operator() (ORBextractor.h:110, src/ORBextractor.cc:1544-1668) for one
  * host image.  `keypoints` / `descriptors` hold `capacity` entries / capacity*32 bytes;

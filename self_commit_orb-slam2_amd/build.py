@@ -48,18 +48,37 @@ def build_liborbx(force=False, verbose=True):
 
 
 def _build_liborbx_locked(force, verbose):
+    """One object per source (compiled in parallel, only the stale ones), then one link: a kernel edit costs the compile of its own
+    file, not of all eight."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
-    deps = srcs + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [ROOT / "include" / "orbx.h"]
-    if not force and _newer(LIB, deps):
+    common = list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [ROOT / "include" / "orbx.h"]
+    if not force and _newer(LIB, srcs + common):
         return LIB
     hipcc = hipcc_path()
     if hipcc is None:
         if LIB.exists():
             return LIB   # GPU box without a compiler: use the prebuilt library from the snapshot
         raise RuntimeError("hipcc not found and no prebuilt liborbx.so")
-    LIB.parent.mkdir(parents=True, exist_ok=True)
+    objdir = LIB.parent / "obj"
+    objdir.mkdir(parents=True, exist_ok=True)
+    cflags = [f for f in HIP_FLAGS if f != "-shared"]
+    jobs = []
+    for s in srcs:
+        o = objdir / (s.name + ".o")
+        if force or not _newer(o, [s] + common):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [hipcc] + cflags + ["-c", "-o", str(o), str(s)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(compile_one, jobs))
     tmp = LIB.with_suffix(".so.tmp%d" % os.getpid())
-    cmd = [hipcc] + HIP_FLAGS + ["-o", str(tmp)] + [str(s) for s in srcs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp)] + [str(objdir / (s.name + ".o")) for s in srcs]
     if verbose:
         print("[build]", " ".join(cmd).replace(str(tmp), str(LIB)), flush=True)
     subprocess.run(cmd, check=True)

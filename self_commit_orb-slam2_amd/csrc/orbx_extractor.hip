@@ -82,9 +82,10 @@ struct orbx_extractor {
     DevBuf<int> cellCount, lvlCnt, status;
     // results are double buffered: a consumer (matcher) may still read batch i while batch i+1 is
     // extracted; consumerEv[b] = event after which buffer b may be overwritten again
-    // counts | keypoints | descriptors of a buffer live in ONE allocation, so that a whole-batch read-back is one copy
+    // counts | capacity words | keypoints | descriptors of a buffer live in ONE allocation, so that a whole-batch read-back is one copy
     DevBuf<uint8_t> outArena[2];
     int *outCntP[2] = {nullptr, nullptr};
+    int *outStP[2] = {nullptr, nullptr};      // [allocBatch + 1]: per frame, then (at [batch of the call]) the OR over the batch
     orbx_keypoint *outKpP[2] = {nullptr, nullptr};
     uint8_t *outDescP[2] = {nullptr, nullptr};
     size_t arenaKpOff = 0, arenaDescOff = 0, arenaBytes = 0;
@@ -331,12 +332,13 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
         if ((rc = h->ptBuf.ensure(B * g.nlevels * 2 * ORBX_PT_CAP)) != ORBX_OK) return rc;
         if ((rc = h->lvlKp.ensure(B * g.kpPerFrame)) != ORBX_OK) return rc;
         if ((rc = h->lvlCnt.ensure(B * g.nlevels)) != ORBX_OK) return rc;
-        h->arenaKpOff = align_up(B * sizeof(int), 256);
+        h->arenaKpOff = align_up((2 * B + 1) * sizeof(int), 256);
         h->arenaDescOff = h->arenaKpOff + align_up(B * g.outCap * sizeof(orbx_keypoint), 256);
         h->arenaBytes = h->arenaDescOff + B * g.outCap * 32;
         for (int b = 0; b < 2; b++) {
             if ((rc = h->outArena[b].ensure(h->arenaBytes)) != ORBX_OK) return rc;
             h->outCntP[b] = (int *)h->outArena[b].p;
+            h->outStP[b] = h->outCntP[b] + B;
             h->outKpP[b] = (orbx_keypoint *)(h->outArena[b].p + h->arenaKpOff);
             h->outDescP[b] = h->outArena[b].p + h->arenaDescOff;
         }
@@ -363,7 +365,7 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     h->cur ^= 1;
     const int cb = h->cur;
     L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outKp = h->outKpP[cb]; L.outDesc = h->outDescP[cb]; L.outCnt = h->outCntP[cb];
-    L.status = h->status.p; L.nodeCap = h->nodeCap;
+    L.status = h->status.p; L.outStatus = h->outStP[cb]; L.nodeCap = h->nodeCap;
     const bool prof = h->profiling;
     hipEvent_t *ev = h->ev[h->profCount % ORBX_PROF_RING];
     if (h->pyrConsumerEv) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->pyrConsumerEv, 0)); h->pyrConsumerEv = nullptr; }
@@ -384,19 +386,6 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     if ((rc = orbx_launch_desc(L)) != ORBX_OK) return rc;
     if (prof) { ORBX_HIP_CHECK(hipEventRecord(ev[ST_DESC + 1], h->stream)); h->profCount++; }
     h->lastBatch = batch; h->lastImg0 = img0Dev; h->lastStride = stride; h->lastFramePitch = framePitch;
-    return ORBX_OK;
-}
-
-int check_status(orbx_extractor *h, int batch)
-{
-    std::vector<int> st((size_t)batch);
-    ORBX_HIP_CHECK(hipMemcpy(st.data(), h->status.p, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
-    for (int f = 0; f < batch; f++)
-        if (st[(size_t)f]) {
-            orbx_set_error("frame %d: device capacity error bits 0x%x (1: >%d FAST candidates in a level, 2: quadtree node list, 4: level keypoints)",
-                           f, st[(size_t)f], ORBX_PT_CAP);
-            return ORBX_ERR_CAPACITY;
-        }
     return ORBX_OK;
 }
 
@@ -524,6 +513,22 @@ extern "C" int orbx_extractor_tables(const orbx_extractor *h, int *nlevels, floa
     return ORBX_OK;
 }
 
+extern "C" int orbx_extractor_tables_for(const orbx_extractor_config *cfg, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2, int *features_per_level)
+{
+    if (!cfg || cfg->nlevels < 1 || cfg->nlevels > ORBX_MAX_LEVELS || cfg->nfeatures < 1 || !(cfg->scale_factor > 1.0f)) { orbx_set_error("bad extractor configuration"); return ORBX_ERR_ARG; }
+    orbx_extractor tmp;           // host tables only: no device, no stream
+    tmp.cfg = *cfg;
+    build_tables(&tmp);
+    for (int i = 0; i < cfg->nlevels; i++) {
+        if (scale) scale[i] = tmp.scale[(size_t)i];
+        if (inv_scale) inv_scale[i] = tmp.invScale[(size_t)i];
+        if (sigma2) sigma2[i] = tmp.sigma2[(size_t)i];
+        if (inv_sigma2) inv_sigma2[i] = tmp.invSigma2[(size_t)i];
+        if (features_per_level) features_per_level[i] = tmp.quota[(size_t)i];
+    }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extractor_capacity(const orbx_extractor *h)
 {
     if (!h) return ORBX_ERR_ARG;
@@ -572,7 +577,7 @@ extern "C" int orbx_extractor_status(orbx_extractor *h, int32_t *bits)
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     int v = 0;
-    ORBX_HIP_CHECK(hipMemcpy(&v, h->status.p + h->lastBatch, sizeof(int), hipMemcpyDeviceToHost));
+    ORBX_HIP_CHECK(hipMemcpy(&v, h->outStP[h->cur] + h->lastBatch, sizeof(int), hipMemcpyDeviceToHost));
     *bits = v;
     return ORBX_OK;
 }
@@ -581,13 +586,14 @@ extern "C" int orbx_batch_status_device(orbx_extractor *h, const int32_t **statu
 {
     if (!h || !status_dev) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
-    *status_dev = h->status.p;
+    *status_dev = h->outStP[h->cur];
     if (batch) *batch = h->lastBatch;
     return ORBX_OK;
 }
 
-/* device word of the last batch (status[lastBatch]) for consumers ordered behind this handle's stream */
-const int *orbx_extractor_status_word_internal(orbx_extractor *h) { return h && h->lastBatch ? h->status.p + h->lastBatch : nullptr; }
+/* device word of the last batch (OR of its frames' capacity bits) for consumers ordered behind this handle's stream: it lives in the
+ * batch's result buffer, so the consumer event that guards the results guards it too */
+const int *orbx_extractor_status_word_internal(orbx_extractor *h) { return h && h->lastBatch ? h->outStP[h->cur] + h->lastBatch : nullptr; }
 
 extern "C" int orbx_extractor_sync(orbx_extractor *h)
 {
@@ -608,36 +614,48 @@ static int ensure_host_out(orbx_extractor *h, size_t bytes)
     return ORBX_OK;
 }
 
-extern "C" int orbx_batch_download(orbx_extractor *h, int batch, orbx_keypoint *keypoints, uint8_t *descriptors, int capacity, int *counts)
+// Counts, capacity words and the result arrays come back whole through ONE pinned buffer, enqueued behind the kernels and
+// followed by ONE synchronisation (a single-frame call is latency bound: every extra sync / blocking copy costs 10-20 us).
+// -> offsets of the keypoints / descriptors inside h->hostOut (counts at 0); checks the capacity words.
+static int fetch_results(orbx_extractor *h, int batch, bool wantKp, bool wantDesc, size_t *offKpOut, size_t *offDescOut)
 {
-    if (!h || !counts) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
-    if (batch <= 0 || batch > h->lastBatch) { orbx_set_error("batch %d not available (last run had %d frames)", batch, h->lastBatch); return ORBX_ERR_STATE; }
-    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
-    // Counts, status words and the result arrays come back whole through ONE pinned buffer, enqueued behind the kernels and
-    // followed by ONE synchronisation (a single-frame call is latency bound: every extra sync / blocking copy costs 10-20 us).
     const int cap = h->geom.outCap;
     const size_t B = (size_t)batch;
-    const bool whole = batch == h->allocBatch && keypoints && descriptors;      // the buffer's own layout: one copy brings counts, keypoints and descriptors
+    const bool whole = batch == h->allocBatch && wantKp && wantDesc;      // the buffer's own layout: one copy brings counts, capacity words, keypoints and descriptors
     const size_t offKp = whole ? h->arenaKpOff : align_up(B * sizeof(int), 256), offDesc = whole ? h->arenaDescOff : offKp + align_up(B * cap * sizeof(orbx_keypoint), 256),
-                 offSt = offDesc + align_up(B * cap * 32, 256), bytes = offSt + align_up((B + 1) * sizeof(int), 256);
+                 offSt = whole ? B * sizeof(int) : offDesc + align_up(B * cap * 32, 256), bytes = whole ? h->arenaBytes : offSt + align_up((B + 1) * sizeof(int), 256);
     int rc = ensure_host_out(h, bytes);
     if (rc != ORBX_OK) return rc;
     uint8_t *hp = h->hostOut;
     if (whole) ORBX_HIP_CHECK(hipMemcpyAsync(hp, h->outArena[h->cur].p, h->arenaBytes, hipMemcpyDeviceToHost, h->stream));
     else {
         ORBX_HIP_CHECK(hipMemcpyAsync(hp, h->outCntP[h->cur], B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        if (keypoints) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offKp, h->outKpP[h->cur], B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->stream));
-        if (descriptors) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offDesc, h->outDescP[h->cur], B * cap * 32, hipMemcpyDeviceToHost, h->stream));
+        if (wantKp) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offKp, h->outKpP[h->cur], B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->stream));
+        if (wantDesc) ORBX_HIP_CHECK(hipMemcpyAsync(hp + offDesc, h->outDescP[h->cur], B * cap * 32, hipMemcpyDeviceToHost, h->stream));
+        ORBX_HIP_CHECK(hipMemcpyAsync(hp + offSt, h->outStP[h->cur], B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
-    ORBX_HIP_CHECK(hipMemcpyAsync(hp + offSt, h->status.p, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     const int *st = (const int *)(hp + offSt);
     for (int f = 0; f < batch; f++)
         if (st[f]) {
-            orbx_set_error("frame %d: device capacity error bits 0x%x (1: >%d FAST candidates in a level, 2: quadtree node list, 4: level keypoints)", f, st[f],
-                           ORBX_PT_CAP);
+            orbx_set_error("frame %d: device capacity error bits 0x%x (1: FAST candidates of a level, 2: quadtree node list, 4: level keypoints)", f, st[f]);
             return ORBX_ERR_CAPACITY;
         }
+    *offKpOut = offKp; *offDescOut = offDesc;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_batch_download(orbx_extractor *h, int batch, orbx_keypoint *keypoints, uint8_t *descriptors, int capacity, int *counts)
+{
+    if (!h || !counts) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (batch <= 0 || batch > h->lastBatch) { orbx_set_error("batch %d not available (last run had %d frames)", batch, h->lastBatch); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    const int cap = h->geom.outCap;
+    const size_t B = (size_t)batch;
+    size_t offKp = 0, offDesc = 0;
+    int rc = fetch_results(h, batch, keypoints != nullptr, descriptors != nullptr, &offKp, &offDesc);
+    if (rc != ORBX_OK) return rc;
+    const uint8_t *hp = h->hostOut;
     memcpy(counts, hp, B * sizeof(int));
     for (int f = 0; f < batch; f++) {
         const int n = counts[f];
@@ -694,6 +712,26 @@ extern "C" int orbx_extract(orbx_extractor *h, const uint8_t *image, int width, 
     if (!image || width <= 0 || height <= 0) return ORBX_OK;   // reference: empty image -> silent return (:1553-1554)
     const uint8_t *imgs[1] = {image};
     return orbx_extract_batch(h, imgs, 1, width, height, stride, keypoints, descriptors, capacity, count);
+}
+
+extern "C" int orbx_extract_view(orbx_extractor *h, const uint8_t *image, int width, int height, int stride, const orbx_keypoint **keypoints,
+                                 const uint8_t **descriptors, int *count)
+{
+    if (!h || !count || !keypoints || !descriptors) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    *count = 0; *keypoints = nullptr; *descriptors = nullptr;
+    if (!image || width <= 0 || height <= 0) return ORBX_OK;   // reference: empty image -> silent return (:1553-1554)
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    const uint8_t *imgs[1] = {image};
+    int rc = upload(h, imgs, 1, width, height, stride);
+    if (rc != ORBX_OK) return rc;
+    rc = run_batch(h, h->staging.p, 1, width, height, h->stagingStride, h->stagingFramePitch);
+    if (rc != ORBX_OK) return rc;
+    size_t offKp = 0, offDesc = 0;
+    if ((rc = fetch_results(h, 1, true, true, &offKp, &offDesc)) != ORBX_OK) return rc;
+    *count = *(const int *)h->hostOut;
+    *keypoints = (const orbx_keypoint *)(h->hostOut + offKp);
+    *descriptors = h->hostOut + offDesc;
+    return ORBX_OK;
 }
 
 extern "C" int orbx_pyramid_level_size(const orbx_extractor *h, int width, int height, int level, int *w, int *hgt)

@@ -138,6 +138,7 @@ struct orbx_frame_ops {
     OrbxDevBuf<orbx_keypoint> kpUn[2];
     OrbxDevBuf<int32_t> gridOff[2], gridIdx[2];
     int cur = 0, lastBatch = 0, lastCap = 0;
+    const int *producerWord[2] = {nullptr, nullptr};   // capacity word of the extractor batch behind result buffer b (device form only)
     OrbxDevBuf<orbx_keypoint> hostKp;
     OrbxDevBuf<int32_t> hostCount;
     OrbxDevBuf<float> corners;
@@ -226,7 +227,10 @@ extern "C" int orbx_frame_finish_device(orbx_frame_ops *h, orbx_extractor *ext, 
     int rc = orbx_extractor_last_batch_view_internal(ext, &view);
     if (rc != ORBX_OK) return rc;
     ORBX_HIP_CHECK(hipSetDevice(h->device));
-    return launch_finish(h, orbx_extractor_stream_internal(ext), grid, true, view.kp, view.counts, view.batch, view.cap);
+    rc = launch_finish(h, orbx_extractor_stream_internal(ext), grid, true, view.kp, view.counts, view.batch, view.cap);
+    // the capacity word of the batch these results come from (it lives in the extractor's result buffer): orbx_frame_download reports it
+    h->producerWord[h->cur] = rc == ORBX_OK ? orbx_extractor_status_word_internal(ext) : nullptr;
+    return rc;
 }
 
 extern "C" int orbx_frame_results_device(orbx_frame_ops *h, const orbx_keypoint **kp_un_dev, const int32_t **grid_offsets_dev, const int32_t **grid_indices_dev,
@@ -248,6 +252,14 @@ extern "C" int orbx_frame_download(orbx_frame_ops *h, orbx_extractor *ext, int b
     ORBX_HIP_CHECK(hipSetDevice(h->device));
     ORBX_HIP_CHECK(hipStreamSynchronize(ext ? orbx_extractor_stream_internal(ext) : h->stream));
     const int b = h->cur;
+    if (ext && h->producerWord[b]) {
+        int v = 0;
+        ORBX_HIP_CHECK(hipMemcpy(&v, h->producerWord[b], sizeof(int), hipMemcpyDeviceToHost));
+        if (v) {
+            orbx_set_error("the extractor batch these results were computed from overflowed a device capacity (bits 0x%x): results are not the reference's", v);
+            return ORBX_ERR_CAPACITY;
+        }
+    }
     if (kp_un) ORBX_HIP_CHECK(hipMemcpy(kp_un, h->kpUn[b].p, (size_t)batch * h->lastCap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
     if (grid_offsets) ORBX_HIP_CHECK(hipMemcpy(grid_offsets, h->gridOff[b].p, (size_t)batch * (NCELL + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (grid_indices) ORBX_HIP_CHECK(hipMemcpy(grid_indices, h->gridIdx[b].p, (size_t)batch * h->lastCap * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -264,6 +276,7 @@ static int host_form(orbx_frame_ops *h, const orbx_frame_grid *grid, bool undist
     if (n > 0) ORBX_HIP_CHECK(hipMemcpyAsync(h->hostKp.p, keypoints, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, h->stream));
     ORBX_HIP_CHECK(hipMemcpyAsync(h->hostCount.p, &n, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     if ((rc = launch_finish(h, h->stream, grid, undistort, h->hostKp.p, h->hostCount.p, 1, cap)) != ORBX_OK) return rc;
+    h->producerWord[h->cur] = nullptr;
     return orbx_frame_download(h, nullptr, 1, undistort && n > 0 ? kp_un : nullptr, grid ? grid_offsets : nullptr, grid && n > 0 ? grid_indices : nullptr);
 }
 

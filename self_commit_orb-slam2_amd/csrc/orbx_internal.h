@@ -89,7 +89,8 @@ struct OrbxLaunch {
     orbx_keypoint *outKp;
     uint8_t *outDesc;
     int *outCnt;
-    int *status;                  /* per frame error bits */
+    int *status;                  /* per frame error bits (scratch of the running batch; [batch] = OR over the batch) */
+    int *outStatus;               /* snapshot of `status` in the result buffer (written by k_describe, guarded like the results) */
     int nodeCap;                  /* 512 / 1024 / 2048 */
 };
 

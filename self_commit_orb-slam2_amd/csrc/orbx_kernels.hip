@@ -995,7 +995,7 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ blur, const OrbxLevelKp *__restrict__ lvlKp,
                                                   const int *__restrict__ lvlCnt, orbx_keypoint *__restrict__ outKp, uint8_t *__restrict__ outDesc,
-                                                  int *__restrict__ outCnt)
+                                                  int *__restrict__ outCnt, const int *__restrict__ status, int *__restrict__ outStatus)
 {
     XCD_REMAP_XY(bx, f);
     const int lane = threadIdx.x & 63;
@@ -1006,6 +1006,10 @@ __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g
         int tot = 0;
         for (int i = 0; i < g->nlevels; i++) tot += cnts[i];
         outCnt[f] = tot;
+        // the capacity words travel with the results: the running batch's words are cleared by the NEXT batch, a consumer of this
+        // result buffer reads the snapshot (which the producer only overwrites behind the consumer's event, like the results)
+        outStatus[f] = status[f];
+        if (f == 0) outStatus[gridDim.y] = status[gridDim.y];
     }
     if (slot >= g->kpPerFrame) return;
     int l = 0;
@@ -1127,7 +1131,7 @@ int orbx_launch_blur(const OrbxLaunch &L)
 int orbx_launch_desc(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)((L.geom->kpPerFrame + 3) / 4), (unsigned)L.batch);
-    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, L.stream, L.geomDev, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc, L.outCnt);
+    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, L.stream, L.geomDev, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc, L.outCnt, L.status, L.outStatus);
     LAUNCH_CHECK();
     return ORBX_OK;
 }

@@ -771,11 +771,12 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
 }
 
 // a consumer chained behind an extractor inherits its capacity word on the device (no host round trip); the consumer's download reports it
-__global__ void k_status_or(int *dst, const int *src) { if (*src) atomicOr(dst, *src); }
+// (`first` producer of a call overwrites the word - a consumer's status describes the call it belongs to, not its history -, a second one ORs)
+__global__ void k_status_or(int *dst, const int *src, int first) { if (first) *dst = *src; else if (*src) atomicOr(dst, *src); }
 
 namespace orbx_match {
 
-int inherit_status(orbx_matcher *m, orbx_extractor *after)
+int inherit_status(orbx_matcher *m, orbx_extractor *after, bool first)
 {
     if (!after) return ORBX_OK;
     const int *w = orbx_extractor_status_word_internal(after);
@@ -785,7 +786,7 @@ int inherit_status(orbx_matcher *m, orbx_extractor *after)
         if (rc != ORBX_OK) return rc;
         ORBX_HIP_CHECK(hipMemsetAsync(m->producerStatus.p, 0, sizeof(int), m->stream));
     }
-    hipLaunchKernelGGL(k_status_or, dim3(1), dim3(1), 0, m->stream, m->producerStatus.p, w);
+    hipLaunchKernelGGL(k_status_or, dim3(1), dim3(1), 0, m->stream, m->producerStatus.p, w, first ? 1 : 0);
     return ORBX_OK;
 }
 
@@ -818,9 +819,10 @@ int prep_pairs(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_se
     if (after) {
         ORBX_HIP_CHECK(hipEventRecord(m->evDep, orbx_extractor_stream_internal(after)));
         ORBX_HIP_CHECK(hipStreamWaitEvent(m->stream, m->evDep, 0));
-        int rcs = inherit_status(m, after);
+        int rcs = inherit_status(m, after, true);
         if (rcs != ORBX_OK) return rcs;
-    }
+    } else if (m->producerStatus.p)      // not chained: the word of an earlier chained call does not belong to these results
+        ORBX_HIP_CHECK(hipMemsetAsync(m->producerStatus.p, 0, sizeof(int), m->stream));
     ORBX_HIP_CHECK(hipMemcpyAsync(m->pairsA.p, pa, (size_t)npairs * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
     ORBX_HIP_CHECK(hipMemcpyAsync(m->pairsB.p, pb, (size_t)npairs * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
     return ORBX_OK;
@@ -927,7 +929,7 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher *m, orbx_extracto
     if (right != left) {
         ORBX_HIP_CHECK(hipEventRecord(m->evDep2, orbx_extractor_stream_internal(right)));
         ORBX_HIP_CHECK(hipStreamWaitEvent(m->stream, m->evDep2, 0));
-        if ((rc = inherit_status(m, right)) != ORBX_OK) return rc;
+        if ((rc = inherit_status(m, right, false)) != ORBX_OK) return rc;
     }
     const int stride = m->maxFeatures, nl = vl.nlevels;
     ORBX_HIP_CHECK(hipMemcpyAsync(m->scales.p, vl.scale, (size_t)nl * sizeof(float), hipMemcpyHostToDevice, m->stream));

@@ -96,7 +96,7 @@ struct orbx_matcher {
 namespace orbx_match {
 int prep_pairs(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b, const int32_t *pa, const int32_t *pb, int npairs, orbx_extractor *after);
 int chain_back(orbx_matcher *m, orbx_extractor *after);
-int inherit_status(orbx_matcher *m, orbx_extractor *after);
+int inherit_status(orbx_matcher *m, orbx_extractor *after, bool first = true);
 int check_producer_status(orbx_matcher *m);
 FeatDev to_dev(const orbx_feature_set *s);
 /* stage one frame of host features into the matcher's staging buffers (side 0 / 1) */

@@ -21,6 +21,9 @@
 #include <map>
 #include <mutex>
 
+// tells shim/ORBextractor.cc that ComputeStereoMatches reads the pyramid on the device: no host copy of mvImagePyramid per frame
+extern "C" __attribute__((visibility("default"))) int orbx_shim_device_stereo_linked = 1;
+
 static unsigned long gStereoCalls = 0, gUndistortCalls = 0, gBoundsCalls = 0, gGridCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_undistort_calls(void) { return gUndistortCalls; }
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_image_bounds_calls(void) { return gBoundsCalls; }

@@ -1,15 +1,21 @@
 // shim/ORBextractor.cc -- ORB_SLAM2::ORBextractor over liborbx (see ORBextractor.h).
 //
 // Error conventions follow the reference (src/ORBextractor.cc:1544-1668): empty image ->
-// silent return, outputs untouched; no keypoints -> descriptors.release().  A device error
-// cannot be reported through the void functor, so it throws std::runtime_error with
-// orbx_last_error() (the reference would have asserted / crashed in the same situation).
+// silent return, outputs untouched; no keypoints -> descriptors.release().  The reference's
+// constructor and functor never throw and have no error channel: a device error here is
+// written to std::cerr (as the reference reports its own failures, e.g. src/System.cc:61) and
+// the call returns with the outputs untouched, like the empty-image case.
 #include "ORBextractor.h"
 
-#include <stdexcept>
-#include <string>
+#include <iostream>
 
 #include "orbx.h"
+
+// Defined (non-zero) by shim/Frame_hip.cc: Frame::ComputeStereoMatches then reads the pyramid on the
+// device.  When that file is NOT linked - a build that swaps only the extractor and keeps the reference's
+// own ComputeStereoMatches, which reads mvImagePyramid (src/Frame.cc:1044,1248,1272,1281) - the symbol is
+// absent and every operator() refills the public member, as the reference's does.
+extern "C" __attribute__((weak)) int orbx_shim_device_stereo_linked;
 
 namespace ORB_SLAM2
 {
@@ -17,17 +23,24 @@ namespace ORB_SLAM2
 static int gDevice = 0;
 void ORBextractor::SetDevice(int device) { gDevice = device; }
 
-static void Fail(const char *what)
+static bool Fail(const char *what)
 {
-    throw std::runtime_error(std::string("ORBextractor (orbx): ") + what + ": " + orbx_last_error());
+    std::cerr << "ORBextractor (orbx): " << what << " failed: " << orbx_last_error() << std::endl;
+    return false;
 }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
-    : mbKeepHostPyramid(false), nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST),
-      minThFAST(_minThFAST), mpHandle(0), mMaxW(0), mMaxH(0), mLastW(0), mLastH(0)
+    : mbKeepHostPyramid(!(&orbx_shim_device_stereo_linked && orbx_shim_device_stereo_linked)), nfeatures(_nfeatures), scaleFactor(_scaleFactor),
+      nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mpHandle(0), mMaxW(0), mMaxH(0), mLastW(0), mLastH(0)
 {
     mvImagePyramid.resize(nlevels);
-    // The tables come from the library so that getters and kernels can never disagree.
+    // The tables come from the library so that getters and kernels can never disagree (no device needed for them).
+    mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels);
+    orbx_extractor_config cfg = orbx_extractor_config();
+    cfg.nfeatures = nfeatures; cfg.scale_factor = (float)scaleFactor; cfg.nlevels = nlevels;
+    if (nlevels > 0 && orbx_extractor_tables_for(&cfg, &mvScaleFactor[0], &mvInvScaleFactor[0], &mvLevelSigma2[0], &mvInvLevelSigma2[0], &mnFeaturesPerLevel[0]) != ORBX_OK)
+        Fail("tables");
     EnsureHandle(640, 480);
 }
 
@@ -36,9 +49,9 @@ ORBextractor::~ORBextractor()
     if (mpHandle) orbx_extractor_destroy(mpHandle);
 }
 
-void ORBextractor::EnsureHandle(int width, int height)
+bool ORBextractor::EnsureHandle(int width, int height)
 {
-    if (mpHandle && width <= mMaxW && height <= mMaxH) return;
+    if (mpHandle && width <= mMaxW && height <= mMaxH) return true;
     if (mpHandle) { orbx_extractor_destroy(mpHandle); mpHandle = 0; }
     orbx_extractor_config cfg = orbx_extractor_config();
     cfg.nfeatures = nfeatures; cfg.scale_factor = (float)scaleFactor; cfg.nlevels = nlevels;
@@ -46,14 +59,9 @@ void ORBextractor::EnsureHandle(int width, int height)
     cfg.max_width = width > mMaxW ? width : mMaxW;
     cfg.max_height = height > mMaxH ? height : mMaxH;
     cfg.max_batch = 1; cfg.device = gDevice;
-    if (orbx_extractor_create(&cfg, &mpHandle) != ORBX_OK) Fail("create");
+    if (orbx_extractor_create(&cfg, &mpHandle) != ORBX_OK) { mpHandle = 0; return Fail("create"); }
     mMaxW = cfg.max_width; mMaxH = cfg.max_height;
-    mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
-    mnFeaturesPerLevel.resize(nlevels);
-    int nl = 0;
-    if (orbx_extractor_tables(mpHandle, &nl, &mvScaleFactor[0], &mvInvScaleFactor[0], &mvLevelSigma2[0], &mvInvLevelSigma2[0],
-                              &mnFeaturesPerLevel[0]) != ORBX_OK)
-        Fail("tables");
+    return true;
 }
 
 void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors)
@@ -61,25 +69,25 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (_image.empty()) return;
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1);
-    EnsureHandle(image.cols, image.rows);
+    if (!EnsureHandle(image.cols, image.rows)) return;
 
-    const int cap = orbx_extractor_capacity(mpHandle);
-    std::vector<orbx_keypoint> kps((size_t)cap);
-    std::vector<unsigned char> desc((size_t)cap * 32);
+    // results arrive in the handle's pinned buffer; they are converted straight from there
+    const orbx_keypoint *kps = 0;
+    const unsigned char *desc = 0;
     int n = 0;
-    if (orbx_extract(mpHandle, image.data, image.cols, image.rows, (int)image.step, &kps[0], &desc[0], cap, &n) != ORBX_OK) Fail("extract");
+    if (orbx_extract_view(mpHandle, image.data, image.cols, image.rows, (int)image.step, &kps, &desc, &n) != ORBX_OK) { Fail("extract"); return; }
 
     if (n == 0)
         _descriptors.release();
     else {
         _descriptors.create(n, 32, CV_8U);
         cv::Mat d = _descriptors.getMat();
-        if (d.isContinuous()) memcpy(d.data, &desc[0], (size_t)n * 32);
-        else for (int i = 0; i < n; i++) memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
+        if (d.isContinuous()) memcpy(d.data, desc, (size_t)n * 32);
+        else for (int i = 0; i < n; i++) memcpy(d.ptr(i), desc + (size_t)i * 32, 32);
     }
     _keypoints.resize((size_t)n);
     for (int i = 0; i < n; i++) {
-        const orbx_keypoint &k = kps[(size_t)i];
+        const orbx_keypoint &k = kps[i];
         cv::KeyPoint &o = _keypoints[(size_t)i];
         o.pt.x = k.x; o.pt.y = k.y; o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.class_id;
     }
@@ -87,8 +95,6 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (mbKeepHostPyramid) DownloadImagePyramid();
 }
 
-// mvImagePyramid of the last frame, on demand: the pyramid stays on the device (where shim/Frame_hip.cc's ComputeStereoMatches reads
-// it) until the next operator() call.
 void ORBextractor::DownloadImagePyramid()
 {
     if (!mpHandle || mLastW <= 0) return;

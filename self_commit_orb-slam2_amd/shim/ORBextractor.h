@@ -37,9 +37,10 @@ public:
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
     // Host copy of the image pyramid of the last frame.  The reference's only reader is Frame::ComputeStereoMatches
-    // (src/Frame.cc:1044,1248); with shim/Frame_hip.cc linked that function reads the DEVICE pyramid, so the copy is off by
-    // default.  A build that keeps the reference's own ComputeStereoMatches sets mbKeepHostPyramid = true (every call then ends
-    // with one ~1 MB device->host transfer), anything else that wants the images calls DownloadImagePyramid() when it does.
+    // (src/Frame.cc:1044,1248).  Safe by default: mbKeepHostPyramid starts TRUE - every call refills the member with one ~1 MB
+    // device->host transfer (~0.1 ms), exactly what a build that swaps only the extractor needs - and starts FALSE only when
+    // shim/Frame_hip.cc is linked into the same binary (it defines orbx_shim_device_stereo_linked): that ComputeStereoMatches reads
+    // the DEVICE pyramid.  Anything else that wants the images then calls DownloadImagePyramid() when it does.
     std::vector<cv::Mat> mvImagePyramid;
     bool mbKeepHostPyramid;
     void DownloadImagePyramid();
@@ -53,7 +54,7 @@ public:
 private:
     ORBextractor(const ORBextractor &);
     ORBextractor &operator=(const ORBextractor &);
-    void EnsureHandle(int width, int height);
+    bool EnsureHandle(int width, int height);
 
     int nfeatures;
     double scaleFactor;
