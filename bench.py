@@ -20,7 +20,13 @@ one all-reduce that proves the rank count and ONE 24-byte all-gather of per-rank
 127.0.0.1); started under torchrun (the driver's way) it checks WORLD_SIZE == N.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (+ `roofline_valu`)
-and `cpu_baseline` objects.  The oracle (oracle/) is only used for the cpu_baseline leg.
+and `cpu_baseline` objects.  The oracle (oracle/) is only used for the cpu_baseline legs.
+
+The default command (`python bench.py --gpus 1`) measures the headline metric first (timed region and
+workload as BASELINE.json's metric names them) and AFTER it, outside that timed region, the other
+BASELINE configs on the same GPU, each with its own `roofline` and `cpu_baseline`, under `workloads`:
+`extract_only` (configs[1] as written: extraction alone), `stereo_1241x376` (configs[2]) and `lba_50kf`
+(configs[4]).  `--no-workloads` skips them.
 """
 import argparse
 import importlib
@@ -72,21 +78,44 @@ STAGE_KERNEL = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "octree": "
                 "describe": "k_describe", "match_distances": "k_bow_topk", "match_replay": "k_bow_greedy"}
 
 
+def csrc_sha():
+    """Hash of the kernel sources the library was built from (csrc/ travels with the library).  The PMC summaries under profiles/
+    carry the hash of the tree they were measured on (tools/run_profiles.sh writes it on the GPU box); counters of an older
+    kernel are not reported as this run's traffic."""
+    import hashlib
+    h = hashlib.sha256()
+    d = ROOT / "self_commit_orb-slam2_amd" / "csrc"
+    for f in sorted(list(d.glob("*.hip")) + list(d.glob("*.h")) + list(d.glob("*.inc")) + list(d.glob("*.cc"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+_STALE = []
+
+
 def _profile_json(name):
     p = ROOT / "profiles" / name
     if not p.exists():
         return None
     try:
-        return json.loads(p.read_text())
+        t = json.loads(p.read_text())
     except ValueError:
         return None
+    if t.get("_csrc_sha") != csrc_sha():
+        if name not in _STALE:
+            _STALE.append(name)
+            print("bench.py: profiles/%s was measured on other kernel sources (%s, built tree %s): its counters are not reported" %
+                  (name, t.get("_csrc_sha"), csrc_sha()), file=sys.stderr)
+        return None
+    return t
 
 
-def pmc_traffic(stage, frames_per_launch):
+def pmc_traffic(stage, frames_per_launch, name="latest_hbm_traffic.json"):
     """HBM bytes per launch of the stage's kernel(s) from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
     runs of this same command, tools/run_profiles.sh + tools/summarize_profile.py; units and the gfx950 corrections as
     profiles/README.md states them).  None when no pass is committed for this launch size."""
-    t = _profile_json("latest_hbm_traffic.json")
+    t = _profile_json(name)
     if not t or t.get("_frames_per_launch") != frames_per_launch:
         return None
     name = STAGE_KERNEL.get(stage, "")
@@ -204,8 +233,8 @@ def ctypes_ptr(t):
 def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
     rank, world = grp.rank, grp.world
     W, H, B, nf = a.width, a.height, a.batch, a.nfeatures
-    NS = max(1, a.streams)
-    nbatches = 1 if a.workload == "batch" else max(1, a.seq_len // B)
+    NS = 1 if a.alone else max(1, a.streams)
+    nbatches = max(1, a.batches_per_step) if a.workload == "batch" else max(1, a.seq_len // B)
     exts = [orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local) for _ in range(NS)]
     mts = [None if a.no_match else orbx.ORBmatcher(0.7, True, max_features=exts[0].capacity, max_pairs=B, device=local) for _ in range(NS)]
     mt = mts[0]
@@ -224,9 +253,13 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
             k = issued[0] % NS
             issued[0] += 1
             exts[k].run_device(*batches[bi][1])
+            if a.alone:
+                exts[k].sync()       # --alone (profiling aid): nothing of another call is ever on the GPU next to a kernel
             if mts[k] is not None:
                 fs = orbx.ORBmatcher.features_of(exts[k], B)     # results are double buffered: ask every step
                 mts[k].search_by_bow_device(fs, fs, pa, pb, mode=0, after=exts[k])
+                if a.alone:
+                    mts[k].sync()
 
     def sync_all():
         for e in exts:
@@ -298,6 +331,25 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
             mts[k0].last_timing()
             alone_match = mts[k0].last_kernel_timing()
         exts[k0].set_profiling(False)
+    # BASELINE configs[1] as written (extraction alone), measured after the headline's timed region with the same handles and inputs
+    extract_only = None
+    if a.workloads and world == 1 and not a.no_match:
+        def xstep():
+            for bi in range(nbatches):
+                k = issued[0] % NS
+                issued[0] += 1
+                exts[k].run_device(*batches[bi][1])
+        for _ in range(2):
+            xstep()
+        sync_all()
+        tx = time.perf_counter()
+        for _ in range(a.steps):
+            xstep()
+        sync_all()
+        tx = time.perf_counter() - tx
+        extract_only = {"metric": "frames/s ORB extract (1000 feat, 640x480)", "value": round(B * nbatches * a.steps / tx, 1), "unit": "frames/s",
+                        "ms_per_step": round(tx / a.steps * 1e3, 4), "steps": a.steps, "config": {"workload": "BASELINE config 2: the same %d resident batches of %d frames, "
+                        "extraction only (no matcher), %d stream(s)" % (nbatches, B, NS)}}
     last = (issued[0] - 1) % NS
     counts = exts[last].download(B)[2]
     status = [int(e.status()) for e in exts] if hasattr(exts[0], "status") else []
@@ -359,7 +411,7 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
                          "dominant_kernel": ({"kernel": STAGE_KERNEL.get(dom, dom), "valu_insts_per_launch": int(dv),
                                               "frac_alone": round(dv / (ref_ms[dom] * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)} if dv else None)}
     metric = "frames/s ORB extract+match (1000 feat, 640x480)" if not a.no_match else "frames/s ORB extract (1000 feat, 640x480)"
-    wl = ("batch of %d synthetic %dx%d frames per GPU" % (B, W, H)) if a.workload == "batch" else \
+    wl = ("batch of %d synthetic %dx%d frames per GPU (%d distinct resident batches per step, one launch set per batch)" % (B, W, H, nbatches)) if a.workload == "batch" else \
          ("one synthetic sequence of %d %dx%d frames per GPU (BASELINE config 4), resident as %d batches of %d" % (B * nbatches, W, H, nbatches, B))
     out = {
         "metric": metric, "value": round(frames_total / t, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -376,7 +428,57 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
         out["roofline_valu"] = roofline_valu
     if status:
         out["config"]["device_status"] = status
+    if extract_only:
+        # roofline of the extraction alone: same dominant kernel, same launches (the matcher is the only thing removed)
+        xb = sum(v for k, v in alg.items() if not k.startswith("match")) * B * nbatches
+        extract_only["roofline"] = {"bound": "hbm", "kernel": roofline["kernel"], "achieved": roofline["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roofline["frac"],
+                                    "traffic": roofline["traffic"], "whole_path_GBs": round(xb / (extract_only["ms_per_step"] * 1e-3) / 1e9, 1),
+                                    "note": "same launches as the headline line minus the matcher: the dominant kernel and its duration alone are the headline's"}
+        out["workloads"] = {"extract_only": extract_only}
+    if _STALE:
+        out["roofline"]["traffic_note"] = "profiles/%s measured on other kernel sources: counters withheld" % ", ".join(_STALE)
     return out
+
+
+def stereo_cpu_baseline(orbx, W, H, nf, bf, seconds_budget=8.0):
+    """The reference's own stereo Frame constructor (oracle/_ref/liborbslam.so: src/Frame.cc:118-199 = two ORBextractor threads, src/Frame.cc:159-167, +
+    Frame::ComputeStereoMatches, :1026-1420, all compiled unmodified on cvshim) on the same synthetic pairs: one constructor at a time (what System::TrackStereo
+    does), and one per two host threads on all cores."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    lib = oracle_lib.slam_lib()
+    if lib is None:
+        return None
+    fx, fy, cx, cy = 718.856, 718.856, 607.1928, 185.2157      # KITTI00-02.yaml:9-12
+    pairs = [(orbx.synth_frame(7000 + i, W, H), orbx.synth_frame(7000 + i, W, H, orbx.SYNTH_STEREO_RIGHT)) for i in range(8)]
+    t0 = time.perf_counter()
+    oracle_lib.ref_stereo_frame(pairs[0][0], pairs[0][1], nf, fx, fy, cx, cy, bf, lib=lib)
+    one = time.perf_counter() - t0
+    ncores = os.cpu_count() or 1
+    nthr = max(1, min(ncores, 32) // 2)                          # every constructor runs two extractor threads of its own
+
+    def run(nt, per):
+        def work(t):
+            for i in range(per):
+                oracle_lib.ref_stereo_frame(*pairs[(t + i) % len(pairs)], nf, fx, fy, cx, cy, bf, lib=lib)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(nt)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t0
+        return nt * per / dt, dt
+    n1 = int(max(2, min(40, 0.3 * seconds_budget / max(one, 1e-3))))
+    single, dt1 = run(1, n1)
+    nn = int(max(2, min(40, 0.7 * seconds_budget / max(one * 1.5, 1e-3))))
+    multi, dtn = run(nthr, nn)
+    return {"value": round(multi, 2), "unit": "pairs/s", "cores": 2 * nthr, "kind": "reference",
+            "single": {"value": round(single, 2), "cores": 2, "note": "one stereo Frame constructor at a time = the reference's own threading (two extractor threads, src/Frame.cc:159-167)",
+                       "seconds": round(dt1, 1)},
+            "sample": "%d concurrent stereo Frame constructors x %d pairs %dx%d/%d feat (oracle/_ref/liborbslam.so: unmodified ORBextractor.cc + Frame.cc on cvshim), %.1f s" %
+                      (nthr, nn, W, H, nf, dtn),
+            "caveat": "cvshim's OpenCV primitives are scalar C++; a stock SIMD OpenCV build is faster, so this is a lower bound on stock ORB-SLAM2 CPU throughput"}
 
 
 def bench_stereo(a, orbx, torch, grp, dev_t, local, rank_info):
@@ -384,7 +486,7 @@ def bench_stereo(a, orbx, torch, grp, dev_t, local, rank_info):
     Frame::ComputeStereoMatches (complete: row bands, SAD refinement, median cut) on the device."""
     W, H, nf = 1241, 376, 2000
     B = a.batch if a.batch != 256 else 64                  # pairs per batch
-    NS = max(1, a.streams)                                # handle pairs (= HIP stream pairs) that take the batches in turn, as in the default workload
+    NS = 1 if a.alone else max(1, a.streams)              # handle pairs (= HIP stream pairs) that take the batches in turn, as in the default workload
     exts = [orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B, device=local) for _ in range(NS)]   # KITTI00-02.yaml:41-50
     mts = [orbx.ORBmatcher(0.7, True, max_features=exts[0].capacity, max_pairs=B, device=local) for _ in range(NS)]
     ext, mt = exts[0], mts[0]
@@ -394,34 +496,90 @@ def bench_stereo(a, orbx, torch, grp, dev_t, local, rank_info):
     fl, fr = np.arange(B, dtype=np.int32), np.arange(B, 2 * B, dtype=np.int32)
     bf = 386.1448                                         # KITTI00-02.yaml:25
 
-    def step(i):
+    def step(i, alone=False):
         k = i % NS
         exts[k].run_device(*devs[k][1])                   # left and right images of the batch in one launch set
+        if alone:
+            exts[k].sync()
         mts[k].compute_stereo_matches_device(exts[k], exts[k], fl, fr, bf, 0.0)
+        if alone:
+            mts[k].sync()
 
     def sync_all():
         for e, m in zip(exts, mts):
             e.sync(); m.sync()
         torch.cuda.synchronize()
     for i in range(a.warmup + NS):
-        step(i)
+        step(i, a.alone)
     sync_all(); grp.barrier(); sync_all()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        step(i)
+        step(i, a.alone)
     sync_all(); grp.barrier(); sync_all()
     elapsed = time.perf_counter() - t0
+    # ONE handle pair, every step synchronised: the latency chain of a 64-pair batch (what a caller that waits for each batch's result gets; this is
+    # the "17k pairs/s" figure of tools/bench_configs.py, against the pipelined `value` of three handle pairs)
+    nchain = max(3, a.steps // 2)
+    sync_all()
+    tcs = time.perf_counter()
+    for i in range(nchain):
+        step(0, False)
+        mts[0].sync()
+    chain = (time.perf_counter() - tcs) / nchain
+    # every stage with nothing else on the GPU (HIP events on the library's streams, calls synchronised)
+    ext.set_profiling(True)
+    mt.sync()
+    try:
+        mt.last_timing()
+    except orbx.OrbxError:
+        pass
+    for _ in range(3):
+        step(0, True)
+    alone = dict(ext.last_timing()[1])
+    alone["stereo_match"] = float(mt.last_timing())
+    ext.set_profiling(False)
     u, z = mt.download_stereo(B)
     cnt = ext.download(2 * B)[2]
     t, total, per_rank = grp.aggregate(elapsed, B * a.steps, int(cnt.sum()))
     if grp.rank != 0:
         return None
-    return {"metric": "stereo pairs/s ORB extract L+R + ComputeStereoMatches (2000 feat, 1241x376)", "value": round(total / t, 1), "unit": "pairs/s",
-            "n_gpus": grp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: batch of %d KITTI-shaped stereo pairs, extract left + right (2000 feat) + L<->R match on the device" % B, "streams": NS,
-                       "keypoints_per_image": round(float(cnt.mean()), 1), "stereo_matches_per_pair": round(float((u >= 0).sum(1).mean()), 1)},
-            "ranks": dict(rank_info, per_rank=[{"pairs": r[0], "seconds": round(r[1], 6)} for r in per_rank])}
+    K = float(cnt.mean())
+    nmatch = float((u >= 0).sum(1).mean())
+    alg = algorithmic_bytes(W, H, K)
+    alg.pop("match")
+    per_image = sum(alg.values())
+    # Frame::ComputeStereoMatches per pair (both descriptor sets once + one result per left keypoint) + the SAD windows of the refined
+    # matches (11x11 left patch, 11 rows x 21 columns right strip, src/Frame.cc:1248-1292) + mvuRight / mvDepth
+    alg_match = 32 * (K + K) + 8 * K + (121 + 231) * nmatch + 8 * K
+    stage_alg = {k: v * 2 * B for k, v in alg.items()}
+    stage_alg["stereo_match"] = alg_match * B
+    dom = max((k for k in alone if stage_alg.get(k, 0) > 0), key=lambda k: alone[k])
+    achieved = stage_alg[dom] / (alone[dom] * 1e-3) / 1e9
+    kern = dict(STAGE_KERNEL, stereo_match="k_stereo_rows + k_stereo_full + k_stereo_cut")
+    whole = (per_image * 2 + alg_match) * total / t / 1e9
+    roof = {"bound": "hbm", "kernel": kern.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": pmc_traffic(dom, 2 * B, "latest_stereo_hbm_traffic.json"), "algorithmic_bytes_per_launch": int(stage_alg[dom]), "avg_launch_ms": round(alone[dom], 4),
+            "images_per_launch": 2 * B, "algorithmic_bytes_per_image": int(per_image), "algorithmic_bytes_per_pair": int(per_image * 2 + alg_match),
+            "timing": "HIP events on the library's streams, calls synchronised (no other stream active)",
+            "stage_ms_alone": {k: round(v, 4) for k, v in alone.items()},
+            "stage_frac_of_hbm_peak_alone": {k: round(stage_alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in alone.items() if stage_alg.get(k, 0) > 0 and v > 0},
+            "whole_path": {"achieved": round(whole, 2), "frac": round(whole / HBM_PEAK_GBS, 5)},
+            "rocprof": "profiles/*_stereo_kernel_stats.csv (this workload, pipelined) and *_stereo_alone_kernel_stats.csv (--alone: average durations = stage_ms_alone)"}
+    out = {"metric": "stereo pairs/s ORB extract L+R + ComputeStereoMatches (2000 feat, 1241x376)", "value": round(total / t, 1), "unit": "pairs/s",
+           "images_per_s": round(2 * total / t, 1),
+           "n_gpus": grp.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "BASELINE config 3: batch of %d KITTI-shaped stereo pairs, extract left + right (2000 feat) + L<->R match on the device" % B, "streams": NS,
+                      "keypoints_per_image": round(K, 1), "stereo_matches_per_pair": round(nmatch, 1)},
+           "single_handle_synchronised": {"pairs_per_s": round(B / chain, 1), "ms_per_batch": round(chain * 1e3, 3), "sum_of_stages_alone_ms": round(sum(alone.values()), 3),
+                                          "note": "one handle pair, the host waits for every batch: the latency chain (stage sum + launch gaps + the host's issue time); "
+                                                  "`value` overlaps %d such chains on %d stream pairs" % (NS, NS)},
+           "ranks": dict(rank_info, per_rank=[{"pairs": r[0], "seconds": round(r[1], 6)} for r in per_rank]), "roofline": roof}
+    if not a.no_cpu_baseline and grp.world == 1:
+        cb = stereo_cpu_baseline(orbx, W, H, nf, bf)
+        if cb:
+            out["cpu_baseline"] = cb
+    return out
 
 
 def bench_lba(a, orbx, torch, grp, dev_t, local, rank_info):
@@ -464,20 +622,32 @@ def bench_lba(a, orbx, torch, grp, dev_t, local, rank_info):
         return None
     cpu = None
     if not a.no_cpu_baseline and grp.world == 1:
-        # the CPU restatement of the same two-stage LM (oracle/lba_oracle.cc, pinned to the reference's Optimizer.cc + g2o to 1e-15): one core,
-        # as g2o's solver is single threaded in ORB-SLAM2
+        # (1) the REFERENCE: the vendored g2o (Thirdparty/g2o, compiled unmodified on oracle/eigenshim) driven with the graph and the two-stage
+        #     schedule of Optimizer::LocalBundleAdjustment (src/Optimizer.cc:629-997; oracle/refslam_wrap.cc: orbslam_g2o_ba), one core - g2o's
+        #     solver is single threaded in ORB-SLAM2;  (2) the restatement of the same LM (oracle/lba_oracle.cc, pinned to (1) to 1e-15)
         sys.path.insert(0, str(ROOT / "tests"))
         import oracle_lib
         orc = oracle_lib.Oracle()
-        oracle_lib.local_bundle_adjustment(orc, w)
-        n, tc0 = 0, time.perf_counter()
-        while n < 40 and time.perf_counter() - tc0 < 8.0:
-            oracle_lib.local_bundle_adjustment(orc, w)
-            n += 1
-        dt = time.perf_counter() - tc0
-        cpu = {"value": round(n / dt, 2), "unit": "windows/s", "cores": 1, "kind": "port", "sample": "%d windows of the same problem, %.1f s" % (n, dt),
-               "caveat": "the restatement solves the reduced system with a dense Cholesky; the reference's g2o uses a sparse LDLT (its build under oracle/_ref runs on "
-                         "the eigenshim, an unoptimised Eigen stand-in, and is not a fair timing)"}
+
+        def timed(fn, budget, nmax):
+            fn()
+            n, tc0 = 0, time.perf_counter()
+            while n < nmax and time.perf_counter() - tc0 < budget:
+                fn()
+                n += 1
+            return n, time.perf_counter() - tc0
+        n, dt = timed(lambda: oracle_lib.local_bundle_adjustment(orc, w), 6.0, 40)
+        port = {"value": round(n / dt, 2), "unit": "windows/s", "cores": 1, "kind": "port", "sample": "%d windows of the same problem, %.1f s" % (n, dt),
+                "note": "oracle/lba_oracle.cc: restatement of the two-stage LM with a dense Cholesky of the reduced system"}
+        cpu = port
+        if oracle_lib.slam_lib() is not None:
+            n2, dt2 = timed(lambda: oracle_lib.g2o_ba_f64(w), 8.0, 20)
+            cpu = {"value": round(n2 / dt2, 2), "unit": "windows/s", "cores": 1, "kind": "reference", "sample": "%d windows of the same problem, %.1f s" % (n2, dt2),
+                   "note": "oracle/_ref/liborbslam.so: the reference's vendored g2o (BlockSolver_6_3 + LinearSolverEigen + Levenberg, sparse LDLT) compiled unmodified, "
+                           "same graph and schedule as Optimizer::LocalBundleAdjustment (src/Optimizer.cc:629-997)",
+                   "caveat": "built on oracle/eigenshim, an unoptimised stand-in for Eigen (eager loops, no SIMD kernels): slower than a stock Eigen build, a lower bound "
+                             "on the reference's CPU speed",
+                   "restatement": port}
     gflops = flops / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     FP64_PEAK_TF = 256 * 4 * 16 * 2 * 2.4e9 / 1e12      # 256 CUs x 4 SIMDs x 16 FP64 lanes x FMA x 2.4 GHz = 78.6 TFLOP/s (vector = matrix rate on MI355X)
     roof = {"bound": "mfma", "kernel": "whole LM loop (72 x k_chol_step = 46 % of the kernel time, profiles/*_lba_kernel_stats.csv)", "achieved": round(gflops / 1e3, 4),
@@ -509,6 +679,11 @@ def main():
     ap.add_argument("--seq-len", type=int, default=512, help="frames per sequence of --workload sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
+    ap.add_argument("--batches-per-step", type=int, default=8, help="distinct resident batches of --batch frames a step of the default workload passes over "
+                    "(8 x 256 x 640x480 = 630 MB of input, more than the 256 MiB Infinity Cache; the timed region of 20 steps is ~0.2 s)")
+    ap.add_argument("--no-workloads", dest="workloads", action="store_false", help="headline metric only: skip the extract-only / stereo / LBA legs measured after it")
+    ap.add_argument("--alone", action="store_true", help="profiling aid: ONE handle pair and a synchronisation after every call, so that a rocprofv3 kernel trace of this "
+                    "command holds every kernel's duration with nothing else on the GPU (profiles/*_alone_kernel_stats.csv)")
     ap.add_argument("--streams", type=int, default=3, help="extractor/matcher handle pairs (HIP stream pairs) that take the batches in turn, so that "
                     "the latency-bound stages of one batch overlap the VALU-bound stages of the others")
     a = ap.parse_args()
@@ -532,12 +707,28 @@ def main():
     rank_info = grp.check(a.gpus)                    # WORLD_SIZE == --gpus, and an RCCL all-reduce of ones sees every rank
 
     fn = {"batch": bench_extract_match, "sequence": bench_extract_match, "stereo": bench_stereo, "lba": bench_lba}[a.workload]
+    if a.workload != "batch" or grp.world > 1:
+        a.workloads = False                          # the other configs are N = 1 lines riding on the default command
     out = fn(a, orbx, torch, grp, dev_t, local, rank_info)
+    if grp.rank == 0 and a.workloads:
+        # BASELINE configs[2] and configs[4] on the same GPU, after (outside) the headline's timed region; same step / warm-up counts
+        import copy
+        for key, f2, st in (("stereo_1241x376", bench_stereo, max(a.steps, 12)), ("lba_50kf", bench_lba, max(a.steps, 10))):
+            a2 = copy.copy(a)
+            a2.steps, a2.warmup, a2.batch = st, max(a.warmup, 2), 256
+            try:
+                r = f2(a2, orbx, torch, grp, dev_t, local, rank_info)
+                for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "ranks", "warmup"):
+                    r.pop(k, None)
+                out.setdefault("workloads", {})[key] = r
+            except Exception as e:                   # a failing side leg must not take the headline line with it
+                out.setdefault("workloads", {})[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    grp.close()                                      # (ranks > 0 are done; rank 0 alone times the host baseline below)
     if grp.rank == 0:
-        if not a.no_cpu_baseline and grp.world == 1 and a.workload in ("batch", "sequence"):
-            out["cpu_baseline"] = cpu_baseline(orbx, a.width, a.height, a.nfeatures)
-        print(json.dumps(out), flush=True)
-    grp.close()
+        if not a.no_cpu_baseline and a.workload in ("batch", "sequence"):
+            # N > 1: a short sample, so that the line of every N carries the host number of the same run
+            out["cpu_baseline"] = cpu_baseline(orbx, a.width, a.height, a.nfeatures, seconds_budget=10.0 if grp.world == 1 else 4.0)
+        orbx.distributed.emit(out)                   # one write(2) for the whole line
 
 
 if __name__ == "__main__":

@@ -42,6 +42,32 @@ def launch(nproc, argv, env=None, timeout=None, capture=False):
     return r
 
 
+def emit(obj):
+    """One JSON line on stdout in ONE write(2): ranks that share the launcher's pipe cannot interleave inside a line (writes of up to
+    PIPE_BUF = 4096 bytes are atomic; longer lines - bench.py's - come from rank 0 only)."""
+    import json
+    sys.stdout.flush()
+    os.write(1, (json.dumps(obj) + "\n").encode())
+
+
+def parse_json_objects(text):
+    """Every top-level JSON object in `text`, wherever the line breaks fell."""
+    import json
+    dec, out, i = json.JSONDecoder(), [], 0
+    while True:
+        i = text.find("{", i)
+        if i < 0:
+            return out
+        try:
+            obj, j = dec.raw_decode(text, i)
+        except ValueError:
+            i += 1
+            continue
+        if isinstance(obj, dict):
+            out.append(obj)
+        i = j
+
+
 class Group:
     def __init__(self, backend=None, device=None):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -49,7 +75,10 @@ class Group:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
         self.device = device if device is not None else torch.device("cpu")
-        if self.world > 1:
+        # a process group exists whenever a launcher started us - also with ONE rank (`torchrun --nproc-per-node 1`): the RCCL
+        # initialisation, all-reduce, all-gather and barrier of an N-GPU run are then exercised on a 1-GPU box too
+        launched = "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("ORBX_DIST_FORCE") == "1"
+        if self.world > 1 or launched:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")

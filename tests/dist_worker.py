@@ -16,5 +16,5 @@ checksum = int(sum(int(f.astype("int64").sum()) for f in frames))
 grp.barrier()
 elapsed = 0.5 + 0.25 * grp.rank                 # rank 1 is the slow one
 t, total, rows = grp.aggregate(elapsed, 100 * (grp.rank + 1), 1000 + grp.rank)
-print(json.dumps({"rank": grp.rank, "world": grp.world, "t": t, "total": total, "rows": rows, "checksum": checksum, "info": info}), flush=True)
+orbx.distributed.emit({"rank": grp.rank, "world": grp.world, "t": t, "total": total, "rows": rows, "checksum": checksum, "info": info})
 grp.close()

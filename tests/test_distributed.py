@@ -63,7 +63,7 @@ def test_two_ranks_through_the_bench_spawn_path(orbx):
     import json
     r = orbx.distributed.launch(2, [str(ROOT / "tests" / "dist_worker.py"), "2"], timeout=300, capture=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    outs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    outs = sorted((d for d in orbx.distributed.parse_json_objects(r.stdout) if "rank" in d), key=lambda d: d["rank"])
     assert [d["rank"] for d in outs] == [0, 1]
     for d in outs:
         assert d["info"] == {"backend": "gloo", "world": 2, "allreduce_ones": 2}

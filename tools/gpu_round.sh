@@ -1,0 +1,23 @@
+#!/bin/bash
+# One gpurun call's worth of measurements: GPU tests, the default bench line, the RCCL (nccl) run with one rank, profiles.
+#   tools/gpu_round.sh <tag> [run_profiles selectors...]
+set -u
+TAG=${1:-r03}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+O=$ROOT/gpurun_out
+mkdir -p $O
+cd $ROOT
+timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_$TAG.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu_$TAG.log
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc $?"; cut -c1-400 $O/bench_$TAG.json
+# RCCL for real: one rank under the launcher the driver uses, backend nccl (init with device_id, all-reduce, all-gather, barriers)
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 \
+    --no-workloads --no-cpu-baseline > $O/bench_${TAG}_nccl_world1.json 2> $O/bench_${TAG}_nccl_world1.err; echo "nccl rc $?"
+python - <<PY
+import json
+try:
+    d = json.loads(open("$O/bench_${TAG}_nccl_world1.json").read().strip().splitlines()[-1])
+    print("nccl world1:", d["value"], d["ranks"])
+except Exception as e:
+    print("nccl world1 line unreadable:", e)
+PY
+if [ $# -gt 0 ]; then bash tools/run_profiles.sh $TAG "$@"; fi
