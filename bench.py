@@ -469,9 +469,11 @@ def stereo_cpu_baseline(orbx, W, H, nf, bf, seconds_budget=8.0):
             x.join()
         dt = time.perf_counter() - t0
         return nt * per / dt, dt
-    n1 = int(max(2, min(40, 0.3 * seconds_budget / max(one, 1e-3))))
+    # (oracle/refslam_wrap.cc gives every extractor thread the reference spawns a fresh 64 MiB bump chunk out of 1024 - the quadtree's pointer
+    # tie-break, DESIGN section 3 - and never reuses one: the sample stays well below 500 constructors per process)
+    n1 = int(max(2, min(16, 0.3 * seconds_budget / max(one, 1e-3))))
     single, dt1 = run(1, n1)
-    nn = int(max(2, min(40, 0.7 * seconds_budget / max(one * 1.5, 1e-3))))
+    nn = int(max(2, min(320 // nthr, 0.7 * seconds_budget / max(one * 1.5, 1e-3))))
     multi, dtn = run(nthr, nn)
     return {"value": round(multi, 2), "unit": "pairs/s", "cores": 2 * nthr, "kind": "reference",
             "single": {"value": round(single, 2), "cores": 2, "note": "one stereo Frame constructor at a time = the reference's own threading (two extractor threads, src/Frame.cc:159-167)",

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -106,9 +107,19 @@ struct orbx_extractor {
     size_t stagingFramePitch = 0;
     uint8_t *hostOut = nullptr;       // pinned: results / pyramid on their way to the caller's arrays
     size_t hostOutBytes = 0;
+    // The single-frame host call (ORBextractor::operator()) as ONE hipGraph per result buffer: upload from the pinned staging
+    // buffer, the 12 kernels, the read-back of the result arena into pinned memory.  A frame is then one hipGraphLaunch + one
+    // hipStreamSynchronize instead of ~16 runtime calls (each 5-10 us of host time under the runtime's lock: they, not the
+    // kernels, bounded the call - and serialised extractors on different threads).
+    hipGraph_t sgGraph[2] = {nullptr, nullptr};
+    hipGraphExec_t sgExec[2] = {nullptr, nullptr};
+    bool sgValid = false;
+    bool sgDisabled = false;          // ORBX_NO_GRAPH=1, or capture / instantiation failed once: plain stream launches
 };
 
 namespace {
+
+void invalidate_single_graph(orbx_extractor *h);
 
 // ORBextractor::ORBextractor, src/ORBextractor.cc:492-609
 void build_tables(orbx_extractor *h)
@@ -308,6 +319,7 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
     if (!h->geomValid || h->geom.W != W || h->geom.H != H) {
         h->geomValid = false;
+        invalidate_single_graph(h);
         int rc = build_geometry(h, W, H);
         if (rc != ORBX_OK) return rc;
         if ((rc = h->geomDev.ensure(1)) != ORBX_OK) return rc;
@@ -321,6 +333,7 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
         h->allocBatch = 0;   // per-frame sizes changed: re-check every buffer
     }
     if (batch > h->allocBatch) {
+        invalidate_single_graph(h);       // buffers move
         const OrbxGeom &g = h->geom;
         const size_t B = (size_t)batch;
         int rc;
@@ -351,21 +364,35 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
     return ORBX_OK;
 }
 
-int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H, int stride, size_t framePitch)
+void fill_launch(orbx_extractor *h, OrbxLaunch &L, const uint8_t *img0Dev, int batch, int stride, size_t framePitch, int cb)
 {
-    int rc = ensure_geometry(h, W, H, batch);
-    if (rc != ORBX_OK) return rc;
-    OrbxLaunch L;
     L.stream = h->stream; L.geomDev = h->geomDev.p; L.geom = &h->geom; L.batch = batch;
     L.img0 = img0Dev; L.img0Stride = stride; L.img0FramePitch = framePitch;
     L.pyr = h->pyr.p; L.blur = h->blur.p; L.score = h->debugTaps ? h->score.p : nullptr; L.blurBytes = h->geom.pyrBytes;
     L.binTab = h->binDev.p;
     L.rsTab = h->rsDev.p;
     L.cellCount = h->cellCount.p; L.cellSlots = h->cellSlots.p; L.ptBuf = h->ptBuf.p;
-    h->cur ^= 1;
-    const int cb = h->cur;
     L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outKp = h->outKpP[cb]; L.outDesc = h->outDescP[cb]; L.outCnt = h->outCntP[cb];
     L.status = h->status.p; L.outStatus = h->outStP[cb]; L.nodeCap = h->nodeCap;
+}
+
+void invalidate_single_graph(orbx_extractor *h)
+{
+    for (int b = 0; b < 2; b++) {
+        if (h->sgExec[b]) { (void)hipGraphExecDestroy(h->sgExec[b]); h->sgExec[b] = nullptr; }
+        if (h->sgGraph[b]) { (void)hipGraphDestroy(h->sgGraph[b]); h->sgGraph[b] = nullptr; }
+    }
+    h->sgValid = false;
+}
+
+int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H, int stride, size_t framePitch)
+{
+    int rc = ensure_geometry(h, W, H, batch);
+    if (rc != ORBX_OK) return rc;
+    OrbxLaunch L;
+    h->cur ^= 1;
+    const int cb = h->cur;
+    fill_launch(h, L, img0Dev, batch, stride, framePitch, cb);
     const bool prof = h->profiling;
     hipEvent_t *ev = h->ev[h->profCount % ORBX_PROF_RING];
     if (h->pyrConsumerEv) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->pyrConsumerEv, 0)); h->pyrConsumerEv = nullptr; }
@@ -464,6 +491,7 @@ extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extr
     ORBX_HIP_CHECK(hipSetDevice(cfg->device));
     orbx_extractor *h = new orbx_extractor();
     h->cfg = *cfg;
+    { const char *ng = getenv("ORBX_NO_GRAPH"); h->sgDisabled = ng && ng[0] == '1'; }
     build_tables(h);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         orbx_set_error("hipStreamCreate failed");
@@ -485,6 +513,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    invalidate_single_graph(h);
     h->geomDev.release(); h->binDev.release(); h->rsDev.release(); h->pyr.release(); h->blur.release();
     if (h->hostStaging) { (void)hipHostFree(h->hostStaging); h->hostStaging = nullptr; h->hostStagingBytes = 0; }
     if (h->hostOut) { (void)hipHostFree(h->hostOut); h->hostOut = nullptr; h->hostOutBytes = 0; }
@@ -609,6 +638,7 @@ static int ensure_host_out(orbx_extractor *h, size_t bytes)
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     if (h->hostOut) (void)hipHostFree(h->hostOut);
     h->hostOut = nullptr; h->hostOutBytes = 0;
+    invalidate_single_graph(h);           // the read-back node targets this buffer
     ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostOut, bytes, hipHostMallocDefault));
     h->hostOutBytes = bytes;
     return ORBX_OK;
@@ -642,6 +672,93 @@ static int fetch_results(orbx_extractor *h, int batch, bool wantKp, bool wantDes
             return ORBX_ERR_CAPACITY;
         }
     *offKpOut = offKp; *offDescOut = offDesc;
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One host frame in, results in pinned memory out: the body of ORBextractor::operator() for a handle created with max_batch = 1
+// (shim/ORBextractor.cc).  The frame's rows are laid out at the device pitch in the pinned staging buffer, then ONE graph launch
+// replays  upload -> status clear -> 7 x k_resize -> k_fast_cells -> k_octree -> k_orient -> k_blur -> k_describe -> read-back
+// with the pointers of result buffer `cb` baked in (one graph per buffer), followed by one synchronisation.
+// ---------------------------------------------------------------------------------------------
+static int build_single_graph(orbx_extractor *h)
+{
+    const size_t fp = h->stagingFramePitch;
+    for (int cb = 0; cb < 2; cb++) {
+        OrbxLaunch L;
+        fill_launch(h, L, h->staging.p, 1, h->stagingStride, fp, cb);
+        ORBX_HIP_CHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+        int rc = ORBX_OK;
+        hipError_t e = hipMemcpyAsync(h->staging.p, h->hostStaging, fp, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(h->status.p, 0, 2 * sizeof(int), h->stream);
+        for (int l = 1; l < h->geom.nlevels && e == hipSuccess && rc == ORBX_OK; l++) rc = orbx_launch_resize(L, l);
+        if (e == hipSuccess && rc == ORBX_OK) rc = orbx_launch_fast_cells(L);
+        if (e == hipSuccess && rc == ORBX_OK) rc = orbx_launch_octree(L);
+        if (e == hipSuccess && rc == ORBX_OK) rc = orbx_launch_orient(L);
+        if (e == hipSuccess && rc == ORBX_OK) rc = orbx_launch_blur(L);
+        if (e == hipSuccess && rc == ORBX_OK) rc = orbx_launch_desc(L);
+        if (e == hipSuccess && rc == ORBX_OK) e = hipMemcpyAsync(h->hostOut, h->outArena[cb].p, h->arenaBytes, hipMemcpyDeviceToHost, h->stream);
+        hipGraph_t g = nullptr;
+        const hipError_t e2 = hipStreamEndCapture(h->stream, &g);     // always end the capture, also after an error inside it
+        if (e != hipSuccess || e2 != hipSuccess || rc != ORBX_OK || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            return ORBX_ERR_HIP;
+        }
+        h->sgGraph[cb] = g;
+        if (hipGraphInstantiate(&h->sgExec[cb], g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return ORBX_ERR_HIP; }
+    }
+    h->sgValid = true;
+    return ORBX_OK;
+}
+
+static int extract_single_host(orbx_extractor *h, const uint8_t *image, int W, int H, int stride, size_t *offKpOut, size_t *offDescOut)
+{
+    if (stride < W) { orbx_set_error("bad image pointer / stride"); return ORBX_ERR_ARG; }
+    int rc = ensure_geometry(h, W, H, 1);
+    if (rc != ORBX_OK) return rc;
+    const bool graphOk = !h->sgDisabled && !h->profiling && !h->debugTaps && h->allocBatch == 1;
+    if (!graphOk) {
+        const uint8_t *imgs[1] = {image};
+        if ((rc = upload(h, imgs, 1, W, H, stride)) != ORBX_OK) return rc;
+        if ((rc = run_batch(h, h->staging.p, 1, W, H, h->stagingStride, h->stagingFramePitch)) != ORBX_OK) return rc;
+        return fetch_results(h, 1, true, true, offKpOut, offDescOut);
+    }
+    const int dstStride = (int)align_up((size_t)W + 16, 64);
+    const size_t fp = align_up((size_t)dstStride * H + 256, 256);
+    if (!h->sgValid || h->stagingStride != dstStride || h->stagingFramePitch != fp || fp > h->hostStagingBytes || h->arenaBytes > h->hostOutBytes) {
+        // (re)build: every buffer the graph names must exist first, outside the capture
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+        invalidate_single_graph(h);
+        if ((rc = h->staging.ensure(fp)) != ORBX_OK) return rc;
+        if (fp > h->hostStagingBytes) {
+            if (h->hostStaging) (void)hipHostFree(h->hostStaging);
+            h->hostStaging = nullptr; h->hostStagingBytes = 0;
+            ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostStaging, fp, hipHostMallocDefault));
+            h->hostStagingBytes = fp;
+        }
+        if ((rc = ensure_host_out(h, h->arenaBytes)) != ORBX_OK) return rc;
+        h->stagingStride = dstStride; h->stagingFramePitch = fp;
+        if (build_single_graph(h) != ORBX_OK) {       // no graph support for this sequence: fall back to stream launches for good
+            invalidate_single_graph(h);
+            h->sgDisabled = true;
+            return extract_single_host(h, image, W, H, stride, offKpOut, offDescOut);
+        }
+    }
+    for (int y = 0; y < H; y++) memcpy(h->hostStaging + (size_t)y * dstStride, image + (size_t)y * stride, (size_t)W);
+    h->cur ^= 1;
+    const int cb = h->cur;
+    if (h->pyrConsumerEv) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->pyrConsumerEv, 0)); h->pyrConsumerEv = nullptr; }
+    if (h->consumerEv[cb]) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->consumerEv[cb], 0)); h->consumerEv[cb] = nullptr; }
+    ORBX_HIP_CHECK(hipGraphLaunch(h->sgExec[cb], h->stream));
+    h->lastBatch = 1; h->lastImg0 = h->staging.p; h->lastStride = dstStride; h->lastFramePitch = fp;
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    const int st = ((const int *)h->hostOut)[1];      // arena of a one-frame handle: count | frame word | batch word | ...
+    if (st) {
+        orbx_set_error("frame 0: device capacity error bits 0x%x (1: FAST candidates of a level, 2: quadtree node list, 4: level keypoints)", st);
+        return ORBX_ERR_CAPACITY;
+    }
+    *offKpOut = h->arenaKpOff; *offDescOut = h->arenaDescOff;
     return ORBX_OK;
 }
 
@@ -697,6 +814,18 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *const *image
 {
     if (!h || !counts) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    if (batch == 1 && h->cfg.max_batch == 1 && images && images[0] && keypoints && descriptors) {
+        // the single-frame call of a one-frame handle: one graph launch (extract_single_host), then the copy into the caller's arrays
+        size_t offKp = 0, offDesc = 0;
+        int rc1 = extract_single_host(h, images[0], width, height, stride, &offKp, &offDesc);
+        if (rc1 != ORBX_OK) return rc1;
+        const int n = *(const int *)h->hostOut;
+        if (n > capacity) { orbx_set_error("frame 0 has %d keypoints but the caller's capacity is %d", n, capacity); return ORBX_ERR_CAPACITY; }
+        counts[0] = n;
+        memcpy(keypoints, h->hostOut + offKp, (size_t)n * sizeof(orbx_keypoint));
+        memcpy(descriptors, h->hostOut + offDesc, (size_t)n * 32);
+        return ORBX_OK;
+    }
     int rc = upload(h, images, batch, width, height, stride);
     if (rc != ORBX_OK) return rc;
     rc = run_batch(h, h->staging.p, batch, width, height, h->stagingStride, h->stagingFramePitch);
@@ -721,13 +850,9 @@ extern "C" int orbx_extract_view(orbx_extractor *h, const uint8_t *image, int wi
     *count = 0; *keypoints = nullptr; *descriptors = nullptr;
     if (!image || width <= 0 || height <= 0) return ORBX_OK;   // reference: empty image -> silent return (:1553-1554)
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
-    const uint8_t *imgs[1] = {image};
-    int rc = upload(h, imgs, 1, width, height, stride);
-    if (rc != ORBX_OK) return rc;
-    rc = run_batch(h, h->staging.p, 1, width, height, h->stagingStride, h->stagingFramePitch);
-    if (rc != ORBX_OK) return rc;
     size_t offKp = 0, offDesc = 0;
-    if ((rc = fetch_results(h, 1, true, true, &offKp, &offDesc)) != ORBX_OK) return rc;
+    int rc = extract_single_host(h, image, width, height, stride, &offKp, &offDesc);
+    if (rc != ORBX_OK) return rc;
     *count = *(const int *)h->hostOut;
     *keypoints = (const orbx_keypoint *)(h->hostOut + offKp);
     *descriptors = h->hostOut + offDesc;
@@ -764,7 +889,7 @@ extern "C" int orbx_download_pyramid(orbx_extractor *h, int frame, int level, in
 extern "C" int orbx_extractor_set_debug_taps(orbx_extractor *h, int enable)
 {
     if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
-    if ((enable != 0) != h->debugTaps) { h->debugTaps = enable != 0; h->allocBatch = 0; }
+    if ((enable != 0) != h->debugTaps) { h->debugTaps = enable != 0; h->allocBatch = 0; invalidate_single_graph(h); }
     return ORBX_OK;
 }
 

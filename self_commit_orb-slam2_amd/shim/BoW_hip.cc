@@ -30,6 +30,24 @@ namespace
 struct VocAccess : public ORBVocabulary {
     static DBoW2::GeneralScoring *Scoring(const ORBVocabulary &v) { return v.*(&VocAccess::m_scoring_object); }
     // the node table as the flat arrays of orbx_vocabulary_create (Node is a protected nested type)
+    // Cheap identity of the tree's CONTENT: size, shape and 64 sampled nodes (parent, weight, descriptor).  The device copy is cached per
+    // ORBVocabulary address; the reference keeps one vocabulary for the life of the process, but an object destroyed and another one
+    // created at the same address (tests do that) must not be served the old tree.
+    static unsigned long long Fingerprint(const ORBVocabulary &v)
+    {
+        const std::vector<Node> &nodes = v.*(&VocAccess::m_nodes);
+        unsigned long long h = 1469598103934665603ull;
+        const auto mix = [&h](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+        const size_t n = nodes.size();
+        const int k = v.getBranchingFactor(), L = v.getDepthLevels();
+        mix(&n, sizeof(n)); mix(&k, sizeof(k)); mix(&L, sizeof(L));
+        for (size_t s = 0; s < 64 && n > 0; s++) {
+            const Node &nd = nodes[(size_t)((unsigned long long)s * (n - 1) / 63)];
+            mix(&nd.parent, sizeof(nd.parent)); mix(&nd.weight, sizeof(nd.weight));
+            if (!nd.descriptor.empty()) mix(nd.descriptor.ptr<unsigned char>(), 32);
+        }
+        return h;
+    }
     static void Flatten(const ORBVocabulary &v, std::vector<int32_t> &parent, std::vector<uint8_t> &leaf, std::vector<uint8_t> &desc, std::vector<double> &weight)
     {
         const std::vector<Node> &nodes = v.*(&VocAccess::m_nodes);
@@ -47,15 +65,21 @@ struct VocAccess : public ORBVocabulary {
 // One device vocabulary per ORBVocabulary object.  An orbx_vocabulary handle is NOT re-entrant (its scratch / result buffers are
 // member state, like every orbx handle: "one call at a time per handle", include/orbx.h), but Tracking (Frame::ComputeBoW) and
 // LocalMapping / LoopClosing (KeyFrame::ComputeBoW) share the vocabulary: `call` serialises the orbx_bow_transform calls on it.
-struct DeviceVoc { orbx_vocabulary *h; std::mutex call; DeviceVoc() : h(0) {} };
+struct DeviceVoc { orbx_vocabulary *h; unsigned long long fp; std::mutex call; DeviceVoc() : h(0), fp(0) {} };
 std::mutex gVocMutex;
 std::map<const ORBVocabulary *, DeviceVoc *> gVocs;
 
 DeviceVoc *DeviceVocabulary(const ORBVocabulary *voc)
 {
     std::unique_lock<std::mutex> lock(gVocMutex);
+    const unsigned long long fp = VocAccess::Fingerprint(*voc);
     std::map<const ORBVocabulary *, DeviceVoc *>::iterator it = gVocs.find(voc);
-    if (it != gVocs.end()) return it->second;
+    if (it != gVocs.end()) {
+        if (it->second->fp == fp) return it->second;
+        // another vocabulary now lives at this address: rebuild the device copy (wait for a call still running on the old one)
+        std::unique_lock<std::mutex> call(it->second->call);
+        if (it->second->h) { orbx_vocabulary_destroy(it->second->h); it->second->h = 0; }
+    }
     std::vector<int32_t> parent;
     std::vector<uint8_t> leaf, desc;
     std::vector<double> weight;
@@ -64,8 +88,8 @@ DeviceVoc *DeviceVocabulary(const ORBVocabulary *voc)
     orbx_vocabulary *dv = 0;
     if (orbx_vocabulary_create(0, voc->getBranchingFactor(), voc->getDepthLevels(), n, &parent[0], &leaf[0], &desc[0], &weight[0], &dv) != ORBX_OK)
         throw std::runtime_error(std::string("ComputeBoW (orbx): ") + orbx_last_error());
-    DeviceVoc *d = new DeviceVoc();
-    d->h = dv;
+    DeviceVoc *d = it != gVocs.end() ? it->second : new DeviceVoc();
+    d->h = dv; d->fp = fp;
     gVocs[voc] = d;
     return d;
 }
