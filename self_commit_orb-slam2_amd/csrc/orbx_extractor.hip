@@ -93,7 +93,7 @@ struct orbx_extractor {
     hipEvent_t consumerEv[2] = {nullptr, nullptr};
     hipEvent_t pyrConsumerEv = nullptr;   // a consumer still reads the (single buffered) pyramid of the last batch
     int cur = 0;
-    DevBuf<uint32_t> cellSlots, ptBuf;
+    DevBuf<uint32_t> cellSlots, ptBuf, labBuf;
     DevBuf<OrbxLevelKp> lvlKp;
     int allocBatch = 0;
     // last run
@@ -275,7 +275,6 @@ int build_geometry(orbx_extractor *h, int W, int H)
         lv.kpBase = kps;
         kps += lv.kpCap;
         maxNodes = std::max(maxNodes, lv.kpCap);
-        if (lv.nCols * lv.nRows > ORBX_PT_CAP) { orbx_set_error("level %d has %d cells; at most %d supported", l, lv.nCols * lv.nRows, ORBX_PT_CAP); return ORBX_ERR_ARG; }
         maxWCell = std::max(maxWCell, lv.wCell);
         maxHCell = std::max(maxHCell, lv.hCell);
         lv.blurTilesX = (lv.w + 63) / 64;
@@ -342,7 +341,8 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
         if (h->debugTaps && (rc = h->score.ensure(B * g.pyrBytes)) != ORBX_OK) return rc;
         if ((rc = h->cellCount.ensure(B * g.cellsPerFrame)) != ORBX_OK) return rc;
         if ((rc = h->cellSlots.ensure(B * g.slotsPerFrame)) != ORBX_OK) return rc;
-        if ((rc = h->ptBuf.ensure(B * g.nlevels * 2 * ORBX_PT_CAP)) != ORBX_OK) return rc;
+        if ((rc = h->ptBuf.ensure(B * g.slotsPerFrame)) != ORBX_OK) return rc;     // every candidate the detector can emit: no capacity error
+        if ((rc = h->labBuf.ensure(B * g.slotsPerFrame)) != ORBX_OK) return rc;
         if ((rc = h->lvlKp.ensure(B * g.kpPerFrame)) != ORBX_OK) return rc;
         if ((rc = h->lvlCnt.ensure(B * g.nlevels)) != ORBX_OK) return rc;
         h->arenaKpOff = align_up((2 * B + 1) * sizeof(int), 256);
@@ -371,7 +371,7 @@ void fill_launch(orbx_extractor *h, OrbxLaunch &L, const uint8_t *img0Dev, int b
     L.pyr = h->pyr.p; L.blur = h->blur.p; L.score = h->debugTaps ? h->score.p : nullptr; L.blurBytes = h->geom.pyrBytes;
     L.binTab = h->binDev.p;
     L.rsTab = h->rsDev.p;
-    L.cellCount = h->cellCount.p; L.cellSlots = h->cellSlots.p; L.ptBuf = h->ptBuf.p;
+    L.cellCount = h->cellCount.p; L.cellSlots = h->cellSlots.p; L.ptBuf = h->ptBuf.p; L.labBuf = h->labBuf.p;
     L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outKp = h->outKpP[cb]; L.outDesc = h->outDescP[cb]; L.outCnt = h->outCntP[cb];
     L.status = h->status.p; L.outStatus = h->outStP[cb]; L.nodeCap = h->nodeCap;
 }
@@ -519,7 +519,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     if (h->hostOut) { (void)hipHostFree(h->hostOut); h->hostOut = nullptr; h->hostOutBytes = 0; }
     h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release();
     for (int b = 0; b < 2; b++) h->outArena[b].release();
-    h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->lvlKp.release();
+    h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->labBuf.release(); h->lvlKp.release();
     for (int r = 0; r < ORBX_PROF_RING; r++)
         for (int i = 0; i <= ST_COUNT; i++) if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -683,30 +683,42 @@ static int fetch_results(orbx_extractor *h, int batch, bool wantKp, bool wantDes
 // ---------------------------------------------------------------------------------------------
 static int build_single_graph(orbx_extractor *h)
 {
+    // explicit node API (no stream capture - see emit() in orbx_kernels.hip).  The DAG:
+    //   upload -> status clear -> k_resize x7 -> k_fast_cells -> k_octree -> k_orient --.
+    //                                      `----> k_blur ---------------------------------+-> k_describe -> read-back
+    // (the blur of the finished pyramid runs next to the detector / quadtree chain, which is latency bound at one frame)
     const size_t fp = h->stagingFramePitch;
     for (int cb = 0; cb < 2; cb++) {
         OrbxLaunch L;
         fill_launch(h, L, h->staging.p, 1, h->stagingStride, fp, cb);
-        ORBX_HIP_CHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-        int rc = ORBX_OK;
-        hipError_t e = hipMemcpyAsync(h->staging.p, h->hostStaging, fp, hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(h->status.p, 0, 2 * sizeof(int), h->stream);
-        for (int l = 1; l < h->geom.nlevels && e == hipSuccess && rc == ORBX_OK; l++) rc = orbx_launch_resize(L, l);
-        if (e == hipSuccess && rc == ORBX_OK) rc = orbx_launch_fast_cells(L);
-        if (e == hipSuccess && rc == ORBX_OK) rc = orbx_launch_octree(L);
-        if (e == hipSuccess && rc == ORBX_OK) rc = orbx_launch_orient(L);
-        if (e == hipSuccess && rc == ORBX_OK) rc = orbx_launch_blur(L);
-        if (e == hipSuccess && rc == ORBX_OK) rc = orbx_launch_desc(L);
-        if (e == hipSuccess && rc == ORBX_OK) e = hipMemcpyAsync(h->hostOut, h->outArena[cb].p, h->arenaBytes, hipMemcpyDeviceToHost, h->stream);
         hipGraph_t g = nullptr;
-        const hipError_t e2 = hipStreamEndCapture(h->stream, &g);     // always end the capture, also after an error inside it
-        if (e != hipSuccess || e2 != hipSuccess || rc != ORBX_OK || !g) {
-            if (g) (void)hipGraphDestroy(g);
-            (void)hipGetLastError();
-            return ORBX_ERR_HIP;
-        }
+        ORBX_HIP_CHECK(hipGraphCreate(&g, 0));
         h->sgGraph[cb] = g;
-        if (hipGraphInstantiate(&h->sgExec[cb], g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return ORBX_ERR_HIP; }
+        hipGraphNode_t nUp = nullptr, nClr = nullptr, nPyr = nullptr, nChain = nullptr, nBlur = nullptr, nDesc = nullptr, nDown = nullptr;
+        ORBX_HIP_CHECK(hipGraphAddMemcpyNode1D(&nUp, g, nullptr, 0, h->staging.p, h->hostStaging, fp, hipMemcpyHostToDevice));
+        hipMemsetParams mp;
+        memset(&mp, 0, sizeof(mp));
+        mp.dst = h->status.p; mp.elementSize = sizeof(int); mp.width = 2; mp.height = 1; mp.pitch = 2 * sizeof(int); mp.value = 0;
+        ORBX_HIP_CHECK(hipGraphAddMemsetNode(&nClr, g, &nUp, 1, &mp));
+        L.graph = g;
+        int rc;
+        nPyr = nClr;
+        for (int l = 1; l < h->geom.nlevels; l++) {
+            L.deps[0] = nPyr; L.ndeps = 1; L.node = &nPyr;
+            if ((rc = orbx_launch_resize(L, l)) != ORBX_OK) return rc;
+        }
+        L.deps[0] = nPyr; L.ndeps = 1; L.node = &nChain;
+        if ((rc = orbx_launch_fast_cells(L)) != ORBX_OK) return rc;
+        L.deps[0] = nChain;
+        if ((rc = orbx_launch_octree(L)) != ORBX_OK) return rc;
+        L.deps[0] = nChain;
+        if ((rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
+        L.deps[0] = nPyr; L.node = &nBlur;
+        if ((rc = orbx_launch_blur(L)) != ORBX_OK) return rc;
+        L.deps[0] = nChain; L.deps[1] = nBlur; L.ndeps = 2; L.node = &nDesc;
+        if ((rc = orbx_launch_desc(L)) != ORBX_OK) return rc;
+        ORBX_HIP_CHECK(hipGraphAddMemcpyNode1D(&nDown, g, &nDesc, 1, h->hostOut, h->outArena[cb].p, h->arenaBytes, hipMemcpyDeviceToHost));
+        ORBX_HIP_CHECK(hipGraphInstantiate(&h->sgExec[cb], g, nullptr, nullptr, 0));
     }
     h->sgValid = true;
     return ORBX_OK;

@@ -14,10 +14,9 @@
 #define ORBX_HALF_PATCH 15    /* HALF_PATCH_SIZE, :92 */
 #define ORBX_PATCH 31         /* PATCH_SIZE, :91 */
 #define ORBX_CELL_W 30        /* W, :1060 */
-#define ORBX_PT_CAP 32768     /* most FAST candidates per (frame, level) the quadtree accepts */
 
 /* error bits written by kernels into the per-frame status word */
-#define ORBX_DEV_ERR_PTCAP 1   /* more candidates in a level than ORBX_PT_CAP */
+#define ORBX_DEV_ERR_PTCAP 1   /* (unused since the quadtree's point arrays are sized for the worst case) */
 #define ORBX_DEV_ERR_NODECAP 2 /* quadtree node list overflow (internal)      */
 #define ORBX_DEV_ERR_KPCAP 4   /* level keypoint buffer overflow (internal)   */
 
@@ -83,7 +82,7 @@ struct OrbxLaunch {
     const uint32_t *rsTab;        /* cv::resize index / coefficient tables of all levels */
     int *cellCount;
     uint32_t *cellSlots;
-    uint32_t *ptBuf;              /* 2 * ORBX_PT_CAP u32 per (frame, level) */
+    uint32_t *ptBuf, *labBuf;     /* quadtree: candidates of a level in list order and their node labels; slotsPerFrame u32 per frame each */
     OrbxLevelKp *lvlKp;
     int *lvlCnt;                  /* nlevels per frame */
     orbx_keypoint *outKp;
@@ -91,7 +90,13 @@ struct OrbxLaunch {
     int *outCnt;
     int *status;                  /* per frame error bits (scratch of the running batch; [batch] = OR over the batch) */
     int *outStatus;               /* snapshot of `status` in the result buffer (written by k_describe, guarded like the results) */
-    int nodeCap;                  /* 512 / 1024 / 2048 */
+    int nodeCap;                  /* 256 / 512 / 1024 / 2048 */
+    /* graph construction (single-frame call): when `graph` is set, a launcher adds a kernel node that depends on deps[0..ndeps)
+     * and returns it in *node instead of launching on `stream` */
+    hipGraph_t graph = nullptr;
+    hipGraphNode_t deps[2] = {nullptr, nullptr};
+    int ndeps = 0;
+    hipGraphNode_t *node = nullptr;
 };
 
 int orbx_launch_resize(const OrbxLaunch &L, int level);

@@ -395,16 +395,27 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
 
 // ------------------------------------------------------------------------------------
 // Quadtree distribution (DistributeOctTree + DivideNode, src/ORBextractor.cc:635-703,
-// 706-1049).  One workgroup per (frame, level).  The std::list of the reference is an
-// array in LDS; a split step partitions every selected node's point span (kept in two
-// global ping-pong buffers that stay L2 resident) into its 4 children with a stable,
-// fully parallel counting partition: 64-point chunks ("items") are counted with
-// __ballot, chunk counts are prefix-scanned across the workgroup, and points are
-// scattered to parent.start + quadrant offset + rank.  List order, creation order and
-// the "later-created first" tie rule of the careful rounds follow DESIGN.md section 5 /
-// oracle/orb_oracle.cc octree().
+// 706-1049).  One workgroup per (frame, level).
+//
+// Points never move.  Every point carries the index of the node that holds it (its LABEL); a
+// node is a box + a point count in an LDS array that IS the reference's std::list (list
+// order, creation order and the "later-created first" tie rule of the careful rounds follow
+// DESIGN.md section 5 / oracle/orb_oracle.cc octree()).  A split round is
+//   node phase   per candidate (count > 1) the four quadrant counts are already known (qc, filled by
+//                the previous point pass): children per candidate, creation indices by ONE scan,
+//                [careful rounds: processing order = rank by (count desc, list position asc), the
+//                first candidates that bring the list to >= N nodes], new list = reversed children
+//                ++ untouched nodes, and a table  map[old node][quadrant] -> new node;
+//   point pass   label = map[label][quadrant of the point in its old box]; if the new node has more
+//                than one point, its quadrant counter for the next round gets the point (LDS atomic).
+// The split is a stable partition in the reference, so the points of a node are always in the order
+// of the candidate list: "first maximum wins" (:1029-1041) = largest (response, -original index),
+// one LDS atomicMax per point at the end.  No sorting, no scatter, no per-chunk bookkeeping:
+// 5 workgroup barriers per full pass and 9 per careful round (the previous partition-based kernel
+// needed ~25), and no limit on the number of candidates (the point arrays are sized for the
+// worst case, every second pixel in both directions a maximum).
 // ------------------------------------------------------------------------------------
-struct OtNode { short x0, y0, x1, y1; int start; int cnt; };   // start bit31 = point buffer id
+struct OtBox { short x0, y0, x1, y1; };
 
 template <typename T> __device__ __forceinline__ T wave_incl_scan(T v, int lane)
 {
@@ -416,7 +427,7 @@ template <typename T> __device__ __forceinline__ T wave_incl_scan(T v, int lane)
     return v;
 }
 
-// exclusive scan of arr[0..n) in place (LDS), n <= 8*256; returns the total.  All 256 threads call.
+// exclusive scan of arr[0..n) in place (LDS); returns the total.  All 256 threads call.
 template <typename T> __device__ T block_exscan(T *arr, int n, T *wsum /* >= 5 entries */)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -437,316 +448,248 @@ template <typename T> __device__ T block_exscan(T *arr, int n, T *wsum /* >= 5 e
     return total;
 }
 
-__device__ __forceinline__ int popc_fields(unsigned long long t)
+// Two exclusive scans at once over entries that the calling thread FILLS itself: thread t owns the contiguous entries
+// [t*per, (t+1)*per), fill(i, a, b) produces entry i of both arrays, so no barrier is needed between filling and scanning.
+template <typename F> __device__ __forceinline__ void block_fill_exscan2(int *A, int *B, int n, int *wsA, int *wsB, int &totA, int &totB, F fill)
 {
-    return ((t & 0xffffull) != 0) + (((t >> 16) & 0xffffull) != 0) + (((t >> 32) & 0xffffull) != 0) + ((t >> 48) != 0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (n + 255) >> 8;
+    const int b = tid * per;
+    int sa = 0, sb = 0;
+    for (int k = 0; k < per; k++)
+        if (b + k < n) { int a, c; fill(b + k, a, c); A[b + k] = a; B[b + k] = c; sa += a; sb += c; }
+    const int incA = wave_incl_scan(sa, lane), incB = wave_incl_scan(sb, lane);
+    if (lane == 63) { wsA[w] = incA; wsB[w] = incB; }
+    __syncthreads();
+    int offA = 0, offB = 0;
+    for (int i = 0; i < w; i++) { offA += wsA[i]; offB += wsB[i]; }
+    totA = wsA[0] + wsA[1] + wsA[2] + wsA[3];
+    totB = wsB[0] + wsB[1] + wsB[2] + wsB[3];
+    int runA = offA + incA - sa, runB = offB + incB - sb;
+    for (int k = 0; k < per; k++)
+        if (b + k < n) { const int a = A[b + k], c = B[b + k]; A[b + k] = runA; B[b + k] = runB; runA += a; runB += c; }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int ot_quadrant(uint32_t p, const OtBox b)
+{
+    const int mx = b.x0 + ((b.x1 - b.x0 + 1) >> 1), my = b.y0 + ((b.y1 - b.y0 + 1) >> 1);   // x0 + ceil(w / 2), :640-641
+    const int x = (int)(p & 0xfffu), y = (int)((p >> 12) & 0xfffu);
+    return (x < mx ? 0 : 1) + (y < my ? 0 : 2);
 }
 
 template <int NODECAP>
 __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, const int *__restrict__ cellCount, const uint32_t *__restrict__ cellSlots,
-                                                const uint8_t *__restrict__ binTab, uint32_t *__restrict__ ptBuf, OrbxLevelKp *__restrict__ lvlKp,
-                                                int *__restrict__ lvlCnt, int *__restrict__ status)
+                                                const uint8_t *__restrict__ binTab, uint32_t *__restrict__ ptBuf, uint32_t *__restrict__ labBuf,
+                                                OrbxLevelKp *__restrict__ lvlKp, int *__restrict__ lvlCnt, int *__restrict__ status)
 {
-    constexpr int ITEMCAP = NODECAP + ORBX_PT_CAP / 64;
-    __shared__ OtNode nodes[2][NODECAP];
-    __shared__ unsigned long long itemScan[ITEMCAP + 1];   // packed 4x16 quadrant counts per 64-point chunk
-    __shared__ unsigned short itemCand[ITEMCAP];            // owning candidate of each chunk
-    __shared__ unsigned short candNode[NODECAP];            // candidate r -> node index (list order)
-    __shared__ int candItemBase[NODECAP + 1];
-    __shared__ unsigned long long candTot[NODECAP];
-    __shared__ unsigned short byProc[NODECAP];              // processing rank -> candidate
-    __shared__ int procC[NODECAP];                          // children per candidate in processing order (scan)
-    __shared__ int nodeFlag[NODECAP];                       // scans over the node list
-    __shared__ short nodeCandId[NODECAP];
-    __shared__ unsigned long long wsum64[8];
-    __shared__ int wsum32[8];
+    __shared__ OtBox box[2][NODECAP];
+    __shared__ int cnt[2][NODECAP];
+    __shared__ uint32_t qc[2][NODECAP][4];          // quadrant counts of the nodes with more than one point, per list
+    __shared__ unsigned short nmap[NODECAP][4];     // old node, quadrant -> new node
+    __shared__ int scanA[NODECAP];                  // children created before slot k (processing order)
+    __shared__ int scanB[NODECAP];                  // untouched nodes before node i (list order)
+    __shared__ unsigned short byProc[NODECAP];      // careful rounds: processing rank -> node
+    __shared__ unsigned char sel[NODECAP];          // node is split in this round
+    __shared__ int wsA[8], wsB[8];
     __shared__ int sh_misc[8];
-    __shared__ unsigned char childCnt[NODECAP];
-    __shared__ unsigned char selFlag[NODECAP];   // per candidate (list-order index r)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int l = blockIdx.x, f = blockIdx.y;
     const OrbxLevel &lv = g->lv[l];
     const int N = lv.quota;
-    uint32_t *P[2];
-    P[0] = ptBuf + ((size_t)f * g->nlevels + l) * 2 * ORBX_PT_CAP;
-    P[1] = P[0] + ORBX_PT_CAP;
+    uint32_t *pts = ptBuf + (size_t)f * g->slotsPerFrame + lv.slotBase;    // capacity = cells x slots per cell: every candidate the detector can emit
+    uint32_t *lab = labBuf + (size_t)f * g->slotsPerFrame + lv.slotBase;
     int *stat = status + f;          // per-frame word; status[gridDim.y] collects the whole batch (device-visible for resident consumers)
     int *statAll = status + gridDim.y;
 
     // ---- gather the level's candidates in vToDistributeKeys order (cells row-major) ----
     const int ncell = lv.nCols * lv.nRows;
     const int *cc = cellCount + (size_t)f * g->cellsPerFrame + lv.cellBase;
-    int *cellOff = (int *)P[1];       // scratch: the second point buffer is not written before the initial-node partition below
+    int *cellOff = (int *)lab;        // scratch: labels are written after the gather
     for (int i = tid; i < ncell; i += 256) cellOff[i] = cc[i];
+    if (tid < 8) sh_misc[tid] = 0;
     __syncthreads();
-    int M = block_exscan(cellOff, ncell, wsum32);
-    if (M > ORBX_PT_CAP) { if (tid == 0) { atomicOr(stat, ORBX_DEV_ERR_PTCAP); atomicOr(statAll, ORBX_DEV_ERR_PTCAP); } M = ORBX_PT_CAP; }
+    const int M = block_exscan(cellOff, ncell, wsA);
     {
         const uint32_t *slots = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase;
         // one THREAD per cell: a cell holds a handful of candidates, and a wave walking the cells one after the other pays a memory
-        // round trip per cell (84 dependent round trips for the 336 cells of a 640x480 level: 33 us of a single frame's 100 us quadtree)
+        // round trip per cell
         for (int c = tid; c < ncell; c += 256) {
             const int n = cc[c], o = cellOff[c];
             const uint32_t *sc = slots + (size_t)c * lv.cellCap;
-            for (int k = 0; k < n; k++)
-                if (o + k < ORBX_PT_CAP) P[0][o + k] = sc[k];
+            for (int k = 0; k < n; k++) pts[o + k] = sc[k];
         }
     }
     __syncthreads();
     if (M == 0) { if (tid == 0) lvlCnt[f * g->nlevels + l] = 0; return; }
 
-    // ---- initial nodes (src/ORBextractor.cc:719-788): split a virtual root by x -> node table ----
-    int cur = 0, nn = 0;
+    // ---- initial nodes (src/ORBextractor.cc:719-788): the root split by x; empty ones are erased ----
+    int cur = 0, nn = 0, ncand = 0;
     {
         const uint8_t *bin = binTab + lv.binOff;
-        const int nItems = (M + 63) >> 6;
-        for (int it = wave; it < nItems; it += 4) {
-            int j = it * 64 + lane;
-            int q = -1;
-            if (j < M) q = bin[P[0][j] & 0xfff];
-            unsigned long long t = 0;
-            for (int Q = 0; Q < 4; Q++) t |= (unsigned long long)__popcll(__ballot(q == Q)) << (16 * Q);
-            if (lane == 0) itemScan[it] = t;
+        int c4[4] = {0, 0, 0, 0};
+        for (int j0 = 0; j0 < M; j0 += 256) {
+            const int j = j0 + tid;
+            const int q = j < M ? (int)bin[pts[j] & 0xfff] : -1;
+#pragma unroll
+            for (int Q = 0; Q < 4; Q++) c4[Q] += __popcll(__ballot(q == Q));
+        }
+        if (lane == 0)
+#pragma unroll
+            for (int Q = 0; Q < 4; Q++) if (c4[Q]) atomicAdd(&sh_misc[4 + Q], c4[Q]);
+        __syncthreads();
+        int idx[4], k = 0;
+        for (int Q = 0; Q < 4; Q++) { idx[Q] = -1; if (Q < lv.nIni && sh_misc[4 + Q] > 0) idx[Q] = k++; }
+        nn = k;
+        if (tid < 4 && idx[tid] >= 0) {
+            OtBox b;
+            b.x0 = (short)lv.iniX[tid]; b.x1 = (short)lv.iniX[tid + 1]; b.y0 = 0; b.y1 = (short)(lv.h - 2 * ORBX_BORDER);
+            box[0][idx[tid]] = b; cnt[0][idx[tid]] = sh_misc[4 + tid];
+            qc[0][idx[tid]][0] = qc[0][idx[tid]][1] = qc[0][idx[tid]][2] = qc[0][idx[tid]][3] = 0u;
+        }
+        for (int Q = 0; Q < 4; Q++) if (idx[Q] >= 0 && sh_misc[4 + Q] > 1) ncand++;
+        if (tid < 4) wsB[4 + tid] = idx[tid];      // bin -> node (a runtime-indexed register array would live in scratch memory)
+        __syncthreads();
+        for (int j = tid; j < M; j += 256) {
+            const uint32_t p = pts[j];
+            const int nd = wsB[4 + bin[p & 0xfff]];
+            lab[j] = (uint32_t)nd;
+            if (cnt[0][nd] > 1) atomicAdd(&qc[0][nd][ot_quadrant(p, box[0][nd])], 1u);
         }
         __syncthreads();
-        unsigned long long tot = block_exscan(itemScan, nItems, wsum64);
-        int off[4], acc = 0, cnts[4];
-        for (int Q = 0; Q < 4; Q++) { cnts[Q] = (int)((tot >> (16 * Q)) & 0xffff); off[Q] = acc; acc += cnts[Q]; }
-        for (int it = wave; it < nItems; it += 4) {
-            int j = it * 64 + lane;
-            int q = -1;
-            uint32_t p = 0;
-            if (j < M) { p = P[0][j]; q = bin[p & 0xfff]; }
-            unsigned long long base = itemScan[it];
-            for (int Q = 0; Q < 4; Q++) {
-                unsigned long long m = __ballot(q == Q);
-                if (q == Q) P[1][off[Q] + (int)((base >> (16 * Q)) & 0xffff) + __popcll(m & ((1ull << lane) - 1ull))] = p;
-            }
-        }
-        if (tid == 0) {
-            int k = 0;
-            for (int Q = 0; Q < lv.nIni; Q++)
-                if (cnts[Q] > 0) {
-                    OtNode nd;
-                    nd.x0 = (short)lv.iniX[Q]; nd.x1 = (short)lv.iniX[Q + 1]; nd.y0 = 0; nd.y1 = (short)(lv.h - 2 * ORBX_BORDER);
-                    nd.start = off[Q] | (int)0x80000000; nd.cnt = cnts[Q];
-                    nodes[0][k++] = nd;
-                }
-            sh_misc[0] = k;
-        }
-        __syncthreads();
-        nn = sh_misc[0];
     }
 
-    // ---- main loop ----
-    bool finish = false, careful = false;
-    while (!finish) {
+    // ---- split rounds ----
+    bool careful = false;
+    while (ncand > 0) {            // no candidate: the pass changes nothing, "size unchanged" -> bFinish (:907-913)
+        const int nxt = cur ^ 1;
         const int prev = nn;
-        OtNode *L = nodes[cur], *Ln = nodes[cur ^ 1];
-        // S1: candidates = nodes with more than one point, in list order
-        for (int i = tid; i < nn; i += 256) nodeFlag[i] = L[i].cnt > 1 ? 1 : 0;
-        __syncthreads();
-        const int ncand = block_exscan(nodeFlag, nn, wsum32);
-        if (ncand == 0) break;   // size unchanged -> bFinish (:907-913)
-        for (int i = tid; i < nn; i += 256) {
-            bool isc = L[i].cnt > 1;
-            nodeCandId[i] = isc ? (short)nodeFlag[i] : (short)-1;
-            if (isc) { candNode[nodeFlag[i]] = (unsigned short)i; candItemBase[nodeFlag[i]] = (L[i].cnt + 63) >> 6; }
-        }
-        __syncthreads();
-        const int nItems = block_exscan(candItemBase, ncand, wsum32);
-        if (tid == 0) candItemBase[ncand] = nItems;
-        __syncthreads();
-        // S2: chunk -> candidate (binary search over candItemBase)
-        for (int it = tid; it < nItems; it += 256) {
-            int lo = 0, hi = ncand - 1;
-            while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (candItemBase[mid] <= it) lo = mid; else hi = mid - 1; }
-            itemCand[it] = (unsigned short)lo;
-        }
-        __syncthreads();
-        // S3: quadrant counts per chunk; a wave takes four chunks at a time so that their (independent) point loads are in flight together
-        for (int it0 = wave; it0 < nItems; it0 += 16) {
-            uint32_t pv[4];
-            int qv[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int it = it0 + 4 * u;
-                pv[u] = 0; qv[u] = -2;
-                if (it < nItems) {
-                    const int r = itemCand[it];
-                    const OtNode nd = L[candNode[r]];
-                    const int j = (it - candItemBase[r]) * 64 + lane;
-                    qv[u] = -1;
-                    if (j < nd.cnt) { pv[u] = (P[(unsigned)nd.start >> 31] + (nd.start & 0x7fffffff))[j]; qv[u] = 0; }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int it = it0 + 4 * u;
-                if (qv[u] == -2) continue;       // wave-uniform
-                const OtNode nd = L[candNode[itemCand[it]]];
-                const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-                int q = -1;
-                if (qv[u] == 0) { const int x = pv[u] & 0xfff, y = (pv[u] >> 12) & 0xfff; q = (x < mx ? 0 : 1) + (y < my ? 0 : 2); }
-                unsigned long long t = 0;
-                for (int Q = 0; Q < 4; Q++) t |= (unsigned long long)__popcll(__ballot(q == Q)) << (16 * Q);
-                if (lane == 0) itemScan[it] = t;
-            }
-        }
-        if (tid == 0) itemScan[nItems] = 0;   // becomes the grand total after the exclusive scan
-        __syncthreads();
-        // S4: scan chunk counts; S5: per-candidate quadrant totals
-        block_exscan(itemScan, nItems + 1, wsum64);
-        for (int r = tid; r < ncand; r += 256) candTot[r] = itemScan[candItemBase[r + 1]] - itemScan[candItemBase[r]];
-        __syncthreads();
-        // S6: processing order.  Full pass: list order.  Careful round: (count desc, list position asc).
+        int nsel, totalCreated, nUnsel;
         if (!careful) {
-            for (int r = tid; r < ncand; r += 256) byProc[r] = (unsigned short)r;
+            // full pass: every candidate is split, in list order (slot k = node k)
+            nsel = nn;
+            block_fill_exscan2(scanA, scanB, nn, wsA, wsB, totalCreated, nUnsel, [&](int i, int &a, int &b) {
+                const bool isc = cnt[cur][i] > 1;
+                sel[i] = isc ? 1 : 0;
+                a = isc ? (qc[cur][i][0] != 0) + (qc[cur][i][1] != 0) + (qc[cur][i][2] != 0) + (qc[cur][i][3] != 0) : 0;
+                b = isc ? 0 : 1;
+            });
         } else {
-            for (int r = tid; r < ncand; r += 256) {
-                const int c = L[candNode[r]].cnt;
-                int rank = 0;
-                for (int s = 0; s < ncand; s++) {
-                    const int cs = L[candNode[s]].cnt;
-                    rank += (cs > c) || (cs == c && s < r);
+            // careful round (:934-1011): candidates by (count desc, list position asc) - the list position encodes the creation order, so
+            // the reference's pointer tie-break is an integer compare -, split until the list reaches N nodes
+            for (int i = tid; i < nn; i += 256) {
+                sel[i] = 0;
+                const int c = cnt[cur][i];
+                if (c > 1) {
+                    int rank = 0;
+                    for (int s = 0; s < nn; s++) {
+                        const int cs = cnt[cur][s];
+                        rank += (cs > c) || (cs == c && s < i);
+                    }
+                    byProc[rank] = (unsigned short)i;
                 }
-                byProc[rank] = (unsigned short)r;
             }
-        }
-        __syncthreads();
-        for (int k = tid; k < ncand; k += 256) procC[k] = popc_fields(candTot[byProc[k]]);
-        __syncthreads();
-        // number of candidates actually split: all (full pass) or up to the first one that
-        // brings the list to >= N nodes (careful round, :1003)
-        int nsel = ncand;
-        if (careful) {
             if (tid == 0) sh_misc[1] = ncand;
             __syncthreads();
-            // inclusive growth: size + sum_{i<=k}(c_i - 1) >= N  -> smallest such k
-            int *grow = nodeFlag;   // reuse as scratch (nn >= ncand)
-            for (int k = tid; k < ncand; k += 256) grow[k] = procC[k] - 1;
-            __syncthreads();
-            block_exscan(grow, ncand, wsum32);
-            for (int k = tid; k < ncand; k += 256)
-                if (nn + grow[k] + procC[k] - 1 >= N) atomicMin(&sh_misc[1], k + 1);
+            int totAll, dummy;
+            block_fill_exscan2(scanA, scanB, ncand, wsA, wsB, totAll, dummy, [&](int k, int &a, int &b) {
+                const int i = byProc[k];
+                a = (qc[cur][i][0] != 0) + (qc[cur][i][1] != 0) + (qc[cur][i][2] != 0) + (qc[cur][i][3] != 0);
+                b = a;          // children of slot k, kept next to its exclusive prefix
+            });
+            // smallest k with  nn + sum_{j<=k}(children_j - 1) >= N  (:1003); scanB[k] is exclusive too: children_k = next prefix - this one
+            for (int k = tid; k < ncand; k += 256) {
+                const int ck = (k + 1 < ncand ? scanA[k + 1] : totAll) - scanA[k];
+                if (nn + scanA[k] + ck - (k + 1) >= N) atomicMin(&sh_misc[1], k + 1);
+            }
             __syncthreads();
             nsel = sh_misc[1];
+            totalCreated = nsel < ncand ? scanA[nsel] : totAll;
+            for (int k = tid; k < nsel; k += 256) sel[byProc[k]] = 1;
             __syncthreads();
+            int dummy2;
+            block_fill_exscan2(scanB, scanB, nn, wsA, wsB, dummy2, nUnsel, [&](int i, int &a, int &b) { a = b = sel[i] ? 0 : 1; });
         }
-        // creation index of each selected candidate's first child
-        for (int k = tid; k < ncand; k += 256) if (k >= nsel) procC[k] = 0;
-        __syncthreads();
-        // keep per-candidate child count before the scan destroys it
-        for (int k = tid; k < ncand; k += 256) childCnt[k] = (unsigned char)procC[k];
-        __syncthreads();
-        const int totalCreated = block_exscan(procC, ncand, wsum32);
-        // unselected nodes keep their relative order behind the created ones
-        for (int r = tid; r < ncand; r += 256) selFlag[r] = 0;
-        __syncthreads();
-        for (int k = tid; k < nsel; k += 256) selFlag[byProc[k]] = 1;
-        __syncthreads();
-        for (int i = tid; i < nn; i += 256) {
-            int r = nodeCandId[i];
-            nodeFlag[i] = (r >= 0 && selFlag[r]) ? 0 : 1;
-        }
-        __syncthreads();
-        const int nUnsel = block_exscan(nodeFlag, nn, wsum32);
         const int newN = totalCreated + nUnsel;
         if (newN > NODECAP) { if (tid == 0) { atomicOr(stat, ORBX_DEV_ERR_NODECAP); atomicOr(statAll, ORBX_DEV_ERR_NODECAP); } break; }
-        if (tid == 0) sh_misc[2] = 0;
-        __syncthreads();
-        // S7: write the new list
+        // ---- the new list: reversed children (push_front of each child, :676-699 / :964-1000) ++ the untouched nodes in their old order ----
+        int myCand = 0, myExpand = 0;
         for (int i = tid; i < nn; i += 256) {
-            int r = nodeCandId[i];
-            if (r >= 0 && selFlag[r]) continue;
-            Ln[totalCreated + nodeFlag[i]] = L[i];
+            if (sel[i]) continue;
+            const int pos = totalCreated + scanB[i];
+            box[nxt][pos] = box[cur][i];
+            const int c = cnt[cur][i];
+            cnt[nxt][pos] = c;
+            if (c > 1) {     // an unsplit candidate keeps its points, hence its quadrant counts
+                myCand++;
+                qc[nxt][pos][0] = qc[cur][i][0]; qc[nxt][pos][1] = qc[cur][i][1]; qc[nxt][pos][2] = qc[cur][i][2]; qc[nxt][pos][3] = qc[cur][i][3];
+            }
+            nmap[i][0] = nmap[i][1] = nmap[i][2] = nmap[i][3] = (unsigned short)pos;
         }
-        int myExpand = 0;
         for (int k = tid; k < nsel; k += 256) {
-            const int r = byProc[k];
-            const OtNode nd = L[candNode[r]];
-            const unsigned long long t = candTot[r];
-            const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-            const int buf = ((unsigned)nd.start >> 31) ^ 1;
-            int st = nd.start & 0x7fffffff, ci = procC[k];
+            const int i = careful ? (int)byProc[k] : k;
+            if (!sel[i]) continue;
+            const OtBox nd = box[cur][i];
+            const short mx = (short)(nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1)), my = (short)(nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1));
+            int ci = scanA[k];
+#pragma unroll
             for (int Q = 0; Q < 4; Q++) {
-                int c = (int)((t >> (16 * Q)) & 0xffff);
+                const int c = (int)qc[cur][i][Q];
                 if (c > 0) {
-                    OtNode ch;
-                    ch.x0 = (Q & 1) ? (short)mx : nd.x0; ch.x1 = (Q & 1) ? nd.x1 : (short)mx;
-                    ch.y0 = (Q & 2) ? (short)my : nd.y0; ch.y1 = (Q & 2) ? nd.y1 : (short)my;
-                    ch.start = st | (buf << 31); ch.cnt = c;
-                    Ln[totalCreated - 1 - ci] = ch;   // push_front: later children sit further front
+                    const int pos = totalCreated - 1 - ci;     // later children sit further front
                     ci++;
+                    OtBox ch;
+                    ch.x0 = (Q & 1) ? mx : nd.x0; ch.x1 = (Q & 1) ? nd.x1 : mx;
+                    ch.y0 = (Q & 2) ? my : nd.y0; ch.y1 = (Q & 2) ? nd.y1 : my;
+                    box[nxt][pos] = ch; cnt[nxt][pos] = c;
+                    qc[nxt][pos][0] = qc[nxt][pos][1] = qc[nxt][pos][2] = qc[nxt][pos][3] = 0u;
+                    nmap[i][Q] = (unsigned short)pos;
                     if (c > 1) myExpand++;
                 }
-                st += c;
             }
         }
         if (myExpand) atomicAdd(&sh_misc[2], myExpand);
-        // S8: scatter the points of the selected candidates into their children (four chunks per wave in flight, as in S3)
-        for (int it0 = wave; it0 < nItems; it0 += 16) {
-            uint32_t pv[4];
-            int qv[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int it = it0 + 4 * u;
-                pv[u] = 0; qv[u] = -2;
-                if (it < nItems) {
-                    const int r = itemCand[it];
-                    if (selFlag[r]) {
-                        const OtNode nd = L[candNode[r]];
-                        const int j = (it - candItemBase[r]) * 64 + lane;
-                        qv[u] = -1;
-                        if (j < nd.cnt) { pv[u] = (P[(unsigned)nd.start >> 31] + (nd.start & 0x7fffffff))[j]; qv[u] = 0; }
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int it = it0 + 4 * u;
-                if (qv[u] == -2) continue;       // wave-uniform: no chunk, or its candidate is not split in this round
-                const int r = itemCand[it];
-                const OtNode nd = L[candNode[r]];
-                const int sb = (unsigned)nd.start >> 31, so = nd.start & 0x7fffffff;
-                uint32_t *dst = P[sb ^ 1] + so;
-                const int mx = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), my = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-                int q = -1;
-                const uint32_t p = pv[u];
-                if (qv[u] == 0) { const int x = p & 0xfff, y = (p >> 12) & 0xfff; q = (x < mx ? 0 : 1) + (y < my ? 0 : 2); }
-                const unsigned long long rel = itemScan[it] - itemScan[candItemBase[r]];
-                const unsigned long long t = candTot[r];
-                int qoff = 0;
-                for (int Q = 0; Q < 4; Q++) {
-                    unsigned long long m = __ballot(q == Q);
-                    if (q == Q) dst[qoff + (int)((rel >> (16 * Q)) & 0xffff) + __popcll(m & ((1ull << lane) - 1ull))] = p;
-                    qoff += (int)((t >> (16 * Q)) & 0xffff);
-                }
-            }
-        }
+        if (myCand) atomicAdd(&sh_misc[3], myCand);
         __syncthreads();
         const int nToExpand = sh_misc[2];
-        nn = newN;
-        cur ^= 1;
-        if (nn >= N || nn == prev) finish = true;                       // :907-913, :1007
-        else if (!careful && nn + nToExpand * 3 > N) careful = true;    // :931
+        ncand = nToExpand + sh_misc[3];
+        const bool finish = newN >= N || newN == prev;                   // :907-913, :1007
+        // ---- point pass: new labels; points of freshly created nodes with more than one point feed the next round's counts ----
+        for (int j = tid; j < M; j += 256) {
+            const int nd = (int)lab[j];
+            if (!sel[nd]) { lab[j] = nmap[nd][0]; continue; }
+            const uint32_t p = pts[j];
+            const int nl = nmap[nd][ot_quadrant(p, box[cur][nd])];
+            lab[j] = (uint32_t)nl;
+            if (!finish && cnt[nxt][nl] > 1) atomicAdd(&qc[nxt][nl][ot_quadrant(p, box[nxt][nl])], 1u);
+        }
         __syncthreads();
+        if (tid == 0) { sh_misc[2] = 0; sh_misc[3] = 0; }
+        nn = newN;
+        cur = nxt;
+        if (finish) break;
+        if (!careful && nn + nToExpand * 3 > N) careful = true;         // :931
     }
 
-    // ---- best response per node, first maximum wins (:1018-1048) ----
+    // ---- best response per node, first maximum wins (:1018-1048): largest (response, -candidate index) ----
     {
-        const OtNode *L = nodes[cur];
+        uint32_t *best = &qc[cur ^ 1][0][0];     // free now: one word per node
         OrbxLevelKp *out = lvlKp + (size_t)f * g->kpPerFrame + lv.kpBase;
         if (nn > lv.kpCap) { if (tid == 0) { atomicOr(stat, ORBX_DEV_ERR_KPCAP); atomicOr(statAll, ORBX_DEV_ERR_KPCAP); } nn = lv.kpCap; }
+        __syncthreads();
+        for (int i = tid; i < NODECAP; i += 256) best[i] = 0u;
+        __syncthreads();
+        for (int j = tid; j < M; j += 256) {
+            const uint32_t nd = lab[j];
+            if (nd < (uint32_t)NODECAP) atomicMax(&best[nd], (pts[j] & 0xff000000u) | (0x00ffffffu - (uint32_t)j));
+        }
+        __syncthreads();
         for (int i = tid; i < nn; i += 256) {
-            const OtNode nd = L[i];
-            const uint32_t *src = P[(unsigned)nd.start >> 31] + (nd.start & 0x7fffffff);
-            uint32_t best = src[0];
-            for (int k = 1; k < nd.cnt; k++) { uint32_t p = src[k]; if ((p >> 24) > (best >> 24)) best = p; }
+            const uint32_t b = pts[0x00ffffffu - (best[i] & 0x00ffffffu)];
             OrbxLevelKp kp;
-            kp.x = (uint16_t)((best & 0xfff) + ORBX_BORDER); kp.y = (uint16_t)(((best >> 12) & 0xfff) + ORBX_BORDER);
-            kp.score = (uint8_t)(best >> 24); kp.pad[0] = kp.pad[1] = kp.pad[2] = 0; kp.angle = 0.f; kp.ca = 1.f; kp.sb = 0.f;
+            kp.x = (uint16_t)((b & 0xfff) + ORBX_BORDER); kp.y = (uint16_t)(((b >> 12) & 0xfff) + ORBX_BORDER);
+            kp.score = (uint8_t)(b >> 24); kp.pad[0] = kp.pad[1] = kp.pad[2] = 0; kp.angle = 0.f; kp.ca = 1.f; kp.sb = 0.f;
             out[i] = kp;
         }
         if (tid == 0) lvlCnt[f * g->nlevels + l] = nn;
@@ -1058,11 +1001,38 @@ __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g
 
 }  // namespace
 
-#define LAUNCH_CHECK()                                                                        \
-    do {                                                                                      \
-        hipError_t e_ = hipGetLastError();                                                    \
-        if (e_ != hipSuccess) { orbx_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); return ORBX_ERR_HIP; } \
-    } while (0)
+// Every kernel of the extractor goes out through emit(): onto the stream (batches), or as a kernel node of a hipGraph under
+// construction (the single-frame graph of orbx_extractor.hip: L.graph set; the node depends on L.deps[0..ndeps) and is returned
+// in L.node).  The graph is built with the explicit node API, not by stream capture: a capture is invalidated by what OTHER
+// threads do on the device meanwhile (two extractors on two threads is the reference's stereo constructor, src/Frame.cc:159-167).
+#include <tuple>
+#include <utility>
+
+template <typename... KArgs, size_t... I>
+static int emit_impl(const OrbxLaunch &L, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, std::tuple<KArgs...> &t, std::index_sequence<I...>)
+{
+    void *args[] = {(void *)&std::get<I>(t)...};
+    if (L.graph) {
+        hipKernelNodeParams p;
+        memset(&p, 0, sizeof(p));
+        p.func = (void *)kern; p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = (unsigned)lds; p.kernelParams = args; p.extra = nullptr;
+        hipGraphNode_t node = nullptr;
+        const hipError_t e = hipGraphAddKernelNode(&node, L.graph, L.ndeps ? L.deps : nullptr, (size_t)L.ndeps, &p);
+        if (e != hipSuccess) { orbx_set_error("hipGraphAddKernelNode failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+        *L.node = node;
+        return ORBX_OK;
+    }
+    const hipError_t e = hipLaunchKernel((const void *)kern, grid, block, args, lds, L.stream);
+    if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+    return ORBX_OK;
+}
+
+template <typename... KArgs, typename... Args>
+static int emit(const OrbxLaunch &L, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, Args... args)
+{
+    std::tuple<KArgs...> t(static_cast<KArgs>(args)...);      // the kernel's exact parameter types, addressable
+    return emit_impl(L, kern, grid, block, lds, t, std::index_sequence_for<KArgs...>());
+}
 
 int orbx_launch_resize(const OrbxLaunch &L, int level)
 {
@@ -1071,67 +1041,49 @@ int orbx_launch_resize(const OrbxLaunch &L, int level)
     dim3 grid((unsigned)((items + 255) / 256), 1u, (unsigned)L.batch);
     // pyramid levels are allocated with >= 16 spare bytes per row; the caller's level-0 rows only when the stride says so
     const bool padded = level > 1 || (L.img0Stride >= ((L.geom->lv[0].w + 3) & ~3) + 12 && L.img0FramePitch >= (size_t)L.img0Stride * (size_t)L.geom->lv[0].h);
-    if (padded)
-        hipLaunchKernelGGL(k_resize<true>, grid, dim3(256), 0, L.stream, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rsTab);
-    else
-        hipLaunchKernelGGL(k_resize<false>, grid, dim3(256), 0, L.stream, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rsTab);
-    LAUNCH_CHECK();
-    return ORBX_OK;
+    if (padded) return emit(L, k_resize<true>, grid, dim3(256), 0, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rsTab);
+    return emit(L, k_resize<false>, grid, dim3(256), 0, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rsTab);
 }
 
 int orbx_launch_fast_cells(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->cellsPerFrame, (unsigned)L.batch);
     const size_t ldsBytes = (size_t)L.geom->fcLdsBytes;
-#define FC_LAUNCH(SM)                                                                                                                          \
-    hipLaunchKernelGGL(k_fast_cells<SM>, grid, dim3(64), ldsBytes, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score, \
-                       L.cellCount, L.cellSlots)
+#define FC_LAUNCH(SM) return emit(L, k_fast_cells<SM>, grid, dim3(64), ldsBytes, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score, L.cellCount, L.cellSlots)
     switch (L.geom->fcSegMax) {
-    case 1: FC_LAUNCH(1); break;
-    case 2: FC_LAUNCH(2); break;
-    case 3: FC_LAUNCH(3); break;
-    default: FC_LAUNCH(4); break;
+    case 1: FC_LAUNCH(1);
+    case 2: FC_LAUNCH(2);
+    case 3: FC_LAUNCH(3);
+    default: FC_LAUNCH(4);
     }
 #undef FC_LAUNCH
-    LAUNCH_CHECK();
-    return ORBX_OK;
 }
 
 int orbx_launch_octree(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->nlevels, (unsigned)L.batch);
-    if (L.nodeCap <= 256)   // 1000 features at 640x480: 224 nodes at most; half the LDS, twice the resident quadtrees per CU
-        hipLaunchKernelGGL(k_octree<256>, grid, dim3(256), 0, L.stream, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.lvlKp, L.lvlCnt, L.status);
-    else if (L.nodeCap <= 512)
-        hipLaunchKernelGGL(k_octree<512>, grid, dim3(256), 0, L.stream, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.lvlKp, L.lvlCnt, L.status);
-    else if (L.nodeCap <= 1024)
-        hipLaunchKernelGGL(k_octree<1024>, grid, dim3(256), 0, L.stream, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.lvlKp, L.lvlCnt, L.status);
-    else
-        hipLaunchKernelGGL(k_octree<2048>, grid, dim3(256), 0, L.stream, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.lvlKp, L.lvlCnt, L.status);
-    LAUNCH_CHECK();
-    return ORBX_OK;
+#define OT_LAUNCH(NC) return emit(L, k_octree<NC>, grid, dim3(256), 0, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.labBuf, L.lvlKp, L.lvlCnt, L.status)
+    if (L.nodeCap <= 256) OT_LAUNCH(256);   // 1000 features at 640x480: 224 nodes at most; a fraction of the LDS, more resident quadtrees per CU
+    if (L.nodeCap <= 512) OT_LAUNCH(512);
+    if (L.nodeCap <= 1024) OT_LAUNCH(1024);
+    OT_LAUNCH(2048);
+#undef OT_LAUNCH
 }
 
 int orbx_launch_orient(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)((L.geom->kpPerFrame + 7) / 8), (unsigned)L.batch);
-    hipLaunchKernelGGL(k_orient, grid, dim3(256), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.lvlKp, L.lvlCnt);
-    LAUNCH_CHECK();
-    return ORBX_OK;
+    return emit(L, k_orient, grid, dim3(256), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.lvlKp, L.lvlCnt);
 }
 
 int orbx_launch_blur(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->blurTiles, (unsigned)L.batch);
-    hipLaunchKernelGGL(k_blur, grid, dim3(64), 0, L.stream, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur);
-    LAUNCH_CHECK();
-    return ORBX_OK;
+    return emit(L, k_blur, grid, dim3(64), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur);
 }
 
 int orbx_launch_desc(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)((L.geom->kpPerFrame + 3) / 4), (unsigned)L.batch);
-    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, L.stream, L.geomDev, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc, L.outCnt, L.status, L.outStatus);
-    LAUNCH_CHECK();
-    return ORBX_OK;
+    return emit(L, k_describe, grid, dim3(256), 0, L.geomDev, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc, L.outCnt, L.status, L.outStatus);
 }

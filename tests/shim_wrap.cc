@@ -71,10 +71,10 @@ extern "C" int shim_bench(void *h, const unsigned char *const *imgs, int nimg, i
 // either, include/ORBextractor.h:161: the stereo Frame constructor runs two on two threads, src/Frame.cc:159-167), each calling
 // operator() `iters` times back to back.  Returns the aggregate frames/s.
 #include <thread>
-extern "C" double shim_bench_threads(int nthreads, int nf, const unsigned char *const *imgs, int nimg, int w, int hgt, int stride, int iters)
+extern "C" double shim_bench_threads(int nthreads, int nf, const unsigned char *const *imgs, int nimg, int w, int hgt, int stride, int iters, int keep_pyr)
 {
     std::vector<ORB_SLAM2::ORBextractor *> ex;
-    for (int t = 0; t < nthreads; t++) ex.push_back(new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7));
+    for (int t = 0; t < nthreads; t++) { ex.push_back(new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7)); ex.back()->mbKeepHostPyramid = keep_pyr != 0; }
     auto work = [&](int t, int n) {
         std::vector<cv::KeyPoint> keys;
         cv::Mat d;

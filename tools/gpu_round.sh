@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 O=$ROOT/gpurun_out
 mkdir -p $O
 cd $ROOT
-timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_$TAG.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu_$TAG.log
+timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu_$TAG.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu_$TAG.log
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc $?"; cut -c1-400 $O/bench_$TAG.json
 # RCCL for real: one rank under the launcher the driver uses, backend nccl (init with device_id, all-reduce, all-gather, barriers)
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 \

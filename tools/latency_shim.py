@@ -27,10 +27,11 @@ for (W, H, nf) in ((640, 480, 1000), (1241, 376, 2000)):
     L.shim_destroy(h)
 
 L.shim_bench_threads.restype = ctypes.c_double
-L.shim_bench_threads.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+L.shim_bench_threads.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 frames = orbx.synth_sequence(7, 8, 640, 480)
 arr = (ctypes.c_void_p * 8)(*[f.ctypes.data for f in frames])
-for nt in (1, 2, 4, 8):
-    fps = L.shim_bench_threads(nt, 1000, arr, 8, 640, 480, 640, 400)
-    print(json.dumps({"call": "ORBextractor::operator() via shim (C++), one extractor per thread", "size": "640x480", "nfeatures": 1000, "threads": nt,
-                      "frames_per_s": round(fps, 1)}))
+for keep in (0, 1):      # 0: the full drop-in (shim/Frame_hip.cc linked, the stereo matcher reads the device pyramid); 1: extractor-only swap (mvImagePyramid refilled per call)
+    for nt in (1, 2, 4, 8, 16):
+        fps = L.shim_bench_threads(nt, 1000, arr, 8, 640, 480, 640, 400, keep)
+        print(json.dumps({"call": "ORBextractor::operator() via shim (C++), one extractor per thread", "size": "640x480", "nfeatures": 1000, "threads": nt,
+                          "host_pyramid": bool(keep), "frames_per_s": round(fps, 1)}))
