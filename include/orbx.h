@@ -146,9 +146,10 @@ int orbx_upload_frames(orbx_extractor *h, const uint8_t *const *images, int batc
 int orbx_extractor_sync(orbx_extractor *h);
 /* Capacity status of the last batch WITHOUT downloading it (a device-resident pipeline never calls orbx_batch_download, which is
  * where a host consumer learns about an overflow): waits for the stream, *bits = OR over the frames of
- *   1 = more than 32768 FAST candidates in one pyramid level, 2 = quadtree node list, 4 = level keypoint buffer (internal sizes).
- * 0 = every frame is complete.  The reference has no such limits (std::vector grows): a set bit means the results of that batch
- * are NOT the reference's.  orbx_batch_status_device: the same words on the device, status_dev[f] per frame and
+ *   2 = quadtree node list, 4 = level keypoint buffer (internal invariants: the list never exceeds the level's quota + 3; bit 1,
+ *   the former per-level candidate limit, no longer exists - the quadtree's point arrays hold every candidate the detector can emit).
+ * 0 = every frame is complete: always, unless an internal invariant is broken; a set bit means the results of that batch are NOT
+ * the reference's.  orbx_batch_status_device: the same words on the device, status_dev[f] per frame and
  * status_dev[batch] for the whole batch.  Matcher / frame calls that are chained behind an extractor (`after` argument) pick
  * the batch word up on the device, and their own download calls return ORBX_ERR_CAPACITY when it is set. */
 int orbx_extractor_status(orbx_extractor *h, int32_t *bits);
