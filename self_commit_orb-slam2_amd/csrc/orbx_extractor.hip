@@ -684,15 +684,13 @@ static int fetch_results(orbx_extractor *h, int batch, bool wantKp, bool wantDes
 // ---------------------------------------------------------------------------------------------
 static int build_single_graph(orbx_extractor *h)
 {
-    // explicit node API (no stream capture - see emit() in orbx_kernels.hip).  The DAG:
-    //   upload -> status clear -> k_resize x7 -> k_fast_cells -> k_octree -> k_orient --.
-    //                                      `----> k_blur ---------------------------------+-> k_describe -> read-back
-    // (the blur of the finished pyramid runs next to the detector / quadtree chain, which is latency bound at one frame)
+    // explicit node API (no stream capture - see emit() in orbx_kernels.hip), ONE chain:
+    //   upload -> status clear -> k_resize x7 -> k_fast_cells -> k_octree -> k_orient -> k_blur -> k_describe -> read-back
+    // (measured: a second branch for k_blur next to the detector chain makes hipGraphLaunch use internal side streams - 166 us per frame
+    // instead of 127 for this chain, and concurrent launches of such graphs from several threads crashed inside the runtime)
     const size_t fp = h->stagingFramePitch;
     static std::mutex buildMutex;                 // graphs of different handles are built one at a time (first call of every handle)
     std::lock_guard<std::mutex> lock(buildMutex);
-    const char *lin = getenv("ORBX_GRAPH_LINEAR");
-    const bool linear = lin && lin[0] == '1';     // experiment switch: one chain, no parallel branch
     for (int cb = 0; cb < 2; cb++) {
         OrbxLaunch L;
         fill_launch(h, L, h->staging.p, 1, h->stagingStride, fp, cb);
@@ -718,10 +716,9 @@ static int build_single_graph(orbx_extractor *h)
         if ((rc = orbx_launch_octree(L)) != ORBX_OK) return rc;
         L.deps[0] = nChain;
         if ((rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
-        L.deps[0] = linear ? nChain : nPyr; L.node = &nBlur;
+        L.deps[0] = nChain; L.node = &nBlur;
         if ((rc = orbx_launch_blur(L)) != ORBX_OK) return rc;
-        L.deps[0] = nChain; L.deps[1] = nBlur; L.ndeps = 2; L.node = &nDesc;
-        if (linear) { L.deps[0] = nBlur; L.ndeps = 1; }
+        L.deps[0] = nBlur; L.node = &nDesc;
         if ((rc = orbx_launch_desc(L)) != ORBX_OK) return rc;
         ORBX_HIP_CHECK(hipGraphAddMemcpyNode1D(&nDown, g, &nDesc, 1, h->hostOut, h->outArena[cb].p, h->arenaBytes, hipMemcpyDeviceToHost));
         ORBX_HIP_CHECK(hipGraphInstantiate(&h->sgExec[cb], g, nullptr, nullptr, 0));
