@@ -115,7 +115,8 @@ struct orbx_extractor {
     hipGraph_t sgGraph[2] = {nullptr, nullptr};
     hipGraphExec_t sgExec[2] = {nullptr, nullptr};
     bool sgValid = false;
-    bool sgDisabled = false;          // ORBX_NO_GRAPH=1, or capture / instantiation failed once: plain stream launches
+    bool sgDisabled = false;          // ORBX_NO_GRAPH=1, or graph construction failed once: plain stream launches
+    bool splitDescribe = false;       // ORBX_SPLIT_DESCRIBE=1 (measurement switch): k_orient + k_describe instead of the fused kernel
 };
 
 namespace {
@@ -406,12 +407,12 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_FAST + 1], h->stream));
     if ((rc = orbx_launch_octree(L)) != ORBX_OK) return rc;
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_OCTREE + 1], h->stream));
-    if ((rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
-    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_ORIENT + 1], h->stream));
+    if (h->splitDescribe && (rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_ORIENT + 1], h->stream));      // (fused form: orientation is part of the descriptor kernel, this span is empty)
     if ((rc = orbx_launch_blur(L)) != ORBX_OK) return rc;
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_BLUR + 1], h->stream));
     if (h->consumerEv[cb]) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->consumerEv[cb], 0)); h->consumerEv[cb] = nullptr; }
-    if ((rc = orbx_launch_desc(L)) != ORBX_OK) return rc;
+    if ((rc = h->splitDescribe ? orbx_launch_desc(L) : orbx_launch_orient_describe(L)) != ORBX_OK) return rc;
     if (prof) { ORBX_HIP_CHECK(hipEventRecord(ev[ST_DESC + 1], h->stream)); h->profCount++; }
     h->lastBatch = batch; h->lastImg0 = img0Dev; h->lastStride = stride; h->lastFramePitch = framePitch;
     return ORBX_OK;
@@ -493,6 +494,7 @@ extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extr
     orbx_extractor *h = new orbx_extractor();
     h->cfg = *cfg;
     { const char *ng = getenv("ORBX_NO_GRAPH"); h->sgDisabled = ng && ng[0] == '1'; }
+    { const char *sd = getenv("ORBX_SPLIT_DESCRIBE"); h->splitDescribe = sd && sd[0] == '1'; }
     build_tables(h);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         orbx_set_error("hipStreamCreate failed");
@@ -715,11 +717,11 @@ static int build_single_graph(orbx_extractor *h)
         L.deps[0] = nChain;
         if ((rc = orbx_launch_octree(L)) != ORBX_OK) return rc;
         L.deps[0] = nChain;
-        if ((rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
+        if (h->splitDescribe && (rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
         L.deps[0] = nChain; L.node = &nBlur;
         if ((rc = orbx_launch_blur(L)) != ORBX_OK) return rc;
         L.deps[0] = nBlur; L.node = &nDesc;
-        if ((rc = orbx_launch_desc(L)) != ORBX_OK) return rc;
+        if ((rc = h->splitDescribe ? orbx_launch_desc(L) : orbx_launch_orient_describe(L)) != ORBX_OK) return rc;
         ORBX_HIP_CHECK(hipGraphAddMemcpyNode1D(&nDown, g, &nDesc, 1, h->hostOut, h->outArena[cb].p, h->arenaBytes, hipMemcpyDeviceToHost));
         ORBX_HIP_CHECK(hipGraphInstantiate(&h->sgExec[cb], g, nullptr, nullptr, 0));
     }

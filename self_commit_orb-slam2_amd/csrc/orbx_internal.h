@@ -105,6 +105,7 @@ int orbx_launch_octree(const OrbxLaunch &L);
 int orbx_launch_orient(const OrbxLaunch &L);
 int orbx_launch_blur(const OrbxLaunch &L);
 int orbx_launch_desc(const OrbxLaunch &L);
+int orbx_launch_orient_describe(const OrbxLaunch &L);   /* IC_Angle + rBRIEF + final KeyPoint in one pass (after the blur) */
 
 /* stream of an extractor handle (orbx_extractor.hip), so other handles can order work after it */
 hipStream_t orbx_extractor_stream_internal(orbx_extractor *h);

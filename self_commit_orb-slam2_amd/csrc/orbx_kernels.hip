@@ -999,6 +999,147 @@ __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Orientation + descriptor in one pass over the keypoints (IC_Angle, src/ORBextractor.cc:108-161, then
+// computeOrbDescriptor, :173-227, and the final KeyPoint, :1175-1190 / :1651-1660).  One wave per
+// keypoint, four per workgroup.  Everything a keypoint needs from HBM is requested up front with
+// row-wise dword loads whose addresses depend on the keypoint alone:
+//   the 31 x 31 disc of the UNBLURRED level   lane = (disc row, half row): 16 bytes each, integer moments in registers;
+//   the 37 x 37 patch of the BLURRED level    (rotated test points stay within 18.39 px: |coordinate| <= 18) as
+//                                              37 rows x 10 aligned dwords -> LDS.
+// The steered 512 samples are then LDS byte reads: the former kernel issued them as 8 scattered byte gathers per lane
+// AFTER the angle was known (three dependent memory levels, up to 64 cache lines per instruction); now one memory
+// round trip covers both stages and a load instruction touches ~7 lines.  fastAtan2 and the libm-exact sin / cos run
+// once per workgroup on four lanes (one per keypoint) between two barriers instead of on all 64 lanes of every wave.
+// ------------------------------------------------------------------------------------
+#define OD_WPB 4
+#define OD_R 18
+#define OD_DW 10
+#define OD_ROWS (2 * OD_R + 1)
+#define OD_PATCH_DW (OD_ROWS * OD_DW)
+
+__global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                                                 const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, OrbxLevelKp *__restrict__ lvlKp,
+                                                                 const int *__restrict__ lvlCnt, orbx_keypoint *__restrict__ outKp, uint8_t *__restrict__ outDesc,
+                                                                 int *__restrict__ outCnt, const int *__restrict__ status, int *__restrict__ outStatus)
+{
+    __shared__ uint32_t sPatch[OD_WPB][OD_PATCH_DW + 2];
+    __shared__ uint32_t sPat[256];
+    __shared__ int sMom[OD_WPB][3];
+    __shared__ float sTrig[OD_WPB][3];
+    XCD_REMAP_XY(bx, f);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // uniform: the keypoint bookkeeping below is scalar work
+    sPat[threadIdx.x] = ((const uint32_t *)c_pattern)[threadIdx.x];              // the 256 test pairs (x0, y0, x1, y1 as int8), once per workgroup
+    const int slot = bx * OD_WPB + wv;
+    const int *cnts = lvlCnt + f * g->nlevels;
+    if (bx == 0 && threadIdx.x == 0) {
+        int tot = 0;
+        for (int i = 0; i < g->nlevels; i++) tot += cnts[i];
+        outCnt[f] = tot;
+        // the capacity words travel with the results: the running batch's words are cleared by the NEXT batch, a consumer of this
+        // result buffer reads the snapshot (which the producer only overwrites behind the consumer's event, like the results)
+        outStatus[f] = status[f];
+        if (f == 0) outStatus[gridDim.y] = status[gridDim.y];
+    }
+    bool live = slot < g->kpPerFrame;
+    int l = 0;
+    for (int i = 1; i < g->nlevels; i++) if (live && slot >= g->lv[i].kpBase) l = i;
+    const OrbxLevel &lv = g->lv[l];
+    const int i = slot - lv.kpBase;
+    live = live && i < cnts[l];
+    int outIdx = i;
+    for (int k = 0; k < l; k++) outIdx += cnts[k];
+    live = live && outIdx < g->outCap;
+    const size_t kpi = (size_t)f * g->kpPerFrame + (live ? slot : 0);
+    const int kx = live ? (int)lvlKp[kpi].x : 0, ky = live ? (int)lvlKp[kpi].y : 0, ksc = live ? (int)lvlKp[kpi].score : 0;
+    const int xa = (kx - OD_R) & ~3;
+    int m10 = 0, m01 = 0;
+    uint32_t pw[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    if (live) {
+        int up;
+        const uint8_t *unb = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, up);
+        const uint8_t *bl = blur + (size_t)f * g->pyrBytes + lv.off;
+        const int bp = lv.pitch;
+        // disc row r = lane / 2, bytes x - 15 + 16 * half .. + 15 (19 <= x < w - 19: inside the level)
+        const int r = lane >> 1, hf = lane & 1;
+        uint32_t wd[4] = {0u, 0u, 0u, 0u};
+        if (r < 31) {
+            const uint8_t *row = unb + (size_t)(ky + r - 15) * up + (kx - 15 + 16 * hf);
+#pragma unroll
+            for (int j = 0; j < 4; j++) __builtin_memcpy(&wd[j], row + 4 * j, 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            const int item = lane + 64 * t;
+            if (item < OD_PATCH_DW) {
+                const int pr = (item * 205) >> 11, pc = item - OD_DW * pr;      // item / 10
+                pw[t] = *(const uint32_t *)(bl + (size_t)(ky - OD_R + pr) * bp + xa + 4 * pc);
+            }
+        }
+        if (r < 31) {
+            const int v = r - 15, d = g->umax[v < 0 ? -v : v];
+            int s1 = 0, su = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int u = 16 * hf + 4 * j + k - 15;                      // hf is a lane value: u = c - 15 or c + 1
+                    const int I = ((u < 0 ? -u : u) <= d && u <= 15) ? (int)((wd[j] >> (8 * k)) & 0xff) : 0;
+                    s1 += I;
+                    su += u * I;
+                }
+            m10 = su;
+            m01 = v * s1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    if (lane == 0) { sMom[wv][0] = m01; sMom[wv][1] = m10; sMom[wv][2] = live ? slot : -1; }
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            const int item = lane + 64 * t;
+            if (item < OD_PATCH_DW) sPatch[wv][item] = pw[t];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < OD_WPB && sMom[threadIdx.x][2] >= 0) {
+        const float ang = fast_atan2_deg((float)sMom[threadIdx.x][0], (float)sMom[threadIdx.x][1]);
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        float sn, cs;
+        sincosf_glibc(ang * factorPI, sn, cs);
+        sTrig[threadIdx.x][0] = cs; sTrig[threadIdx.x][1] = sn; sTrig[threadIdx.x][2] = ang;
+        OrbxLevelKp *o = lvlKp + (size_t)f * g->kpPerFrame + sMom[threadIdx.x][2];
+        o->angle = ang; o->ca = cs; o->sb = sn;        // (read back by the stage taps and by nothing else)
+    }
+    __syncthreads();
+    if (!live) return;
+    const float a = sTrig[wv][0], b = sTrig[wv][1];
+    const uint8_t *pb = (const uint8_t *)sPatch[wv] + OD_R * (4 * OD_DW) + (kx - xa);     // the keypoint's own pixel
+    unsigned long long bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t pat = sPat[64 * r + lane];
+        const float x0 = (float)(int8_t)(pat & 0xff), y0 = (float)(int8_t)((pat >> 8) & 0xff);
+        const float x1 = (float)(int8_t)((pat >> 16) & 0xff), y1 = (float)(int8_t)(pat >> 24);
+        const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
+        const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
+        const int t0 = pb[r0 * (4 * OD_DW) + c0], t1 = pb[r1 * (4 * OD_DW) + c1];
+        bits[r] = __ballot(t0 < t1);
+    }
+    unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * g->outCap + outIdx) * 32);
+    if (lane < 4) d64[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+    if (lane == 0) {
+        orbx_keypoint o;
+        const float sc = lv.scale;
+        o.x = l ? (float)kx * sc : (float)kx;
+        o.y = l ? (float)ky * sc : (float)ky;
+        o.size = (float)lv.patchSize; o.angle = sTrig[wv][2]; o.response = (float)ksc; o.octave = l; o.class_id = -1;
+        outKp[(size_t)f * g->outCap + outIdx] = o;
+    }
+}
+
 }  // namespace
 
 // Every kernel of the extractor goes out through emit(): onto the stream (batches), or as a kernel node of a hipGraph under
@@ -1086,4 +1227,11 @@ int orbx_launch_desc(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)((L.geom->kpPerFrame + 3) / 4), (unsigned)L.batch);
     return emit(L, k_describe, grid, dim3(256), 0, L.geomDev, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc, L.outCnt, L.status, L.outStatus);
+}
+
+int orbx_launch_orient_describe(const OrbxLaunch &L)
+{
+    dim3 grid((unsigned)((L.geom->kpPerFrame + OD_WPB - 1) / OD_WPB), (unsigned)L.batch);
+    return emit(L, k_orient_describe, grid, dim3(64 * OD_WPB), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc,
+                L.outCnt, L.status, L.outStatus);
 }
