@@ -74,8 +74,18 @@ def algorithmic_bytes(W, H, K, nlevels=8):
 
 
 # stage of the HIP-event timing -> kernel name in the rocprofv3 summaries under profiles/
-STAGE_KERNEL = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "octree": "k_octree", "orient": "k_orient", "blur": "k_blur",
-                "describe": "k_describe", "match_distances": "k_bow_topk", "match_replay": "k_bow_greedy"}
+STAGE_KERNEL = {"pyramid": "k_resize", "fast_cells": "k_fast_cells", "octree": "k_octree", "blur": "k_blur",
+                "describe": "k_orient_describe", "match_distances": "k_bow_topk", "match_replay": "k_bow_greedy"}
+
+
+def merge_orient(alg, *stage_dicts):
+    """IC_Angle and the descriptor are ONE kernel (k_orient_describe): the extractor's "orient" event span is empty.  Its algorithmic
+    bytes (the 749-pixel disc per keypoint) are counted with the descriptor stage."""
+    if "orient" in alg:
+        alg["describe"] = alg.get("describe", 0) + alg.pop("orient")
+    for d in stage_dicts:
+        if d and "orient" in d:
+            d["describe"] = d.get("describe", 0.0) + d.pop("orient")
 
 
 def csrc_sha():
@@ -360,6 +370,7 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
         return None
     K = float(counts.mean())
     alg = algorithmic_bytes(W, H, K)
+    merge_orient(alg, stage_ms, alone_ms)
     if mt is not None:
         stage_ms["match_distances"] = float(match_split[0])   # k_bow_order + k_bow_topk
         stage_ms["match_replay"] = float(match_split[1])      # k_bow_greedy (sequential greedy assignment, latency bound)
@@ -549,6 +560,7 @@ def bench_stereo(a, orbx, torch, grp, dev_t, local, rank_info):
     nmatch = float((u >= 0).sum(1).mean())
     alg = algorithmic_bytes(W, H, K)
     alg.pop("match")
+    merge_orient(alg, alone)
     per_image = sum(alg.values())
     # Frame::ComputeStereoMatches per pair (both descriptor sets once + one result per left keypoint) + the SAD windows of the refined
     # matches (11x11 left patch, 11 rows x 21 columns right strip, src/Frame.cc:1248-1292) + mvuRight / mvDepth

@@ -109,14 +109,13 @@ struct orbx_extractor {
     uint8_t *hostOut = nullptr;       // pinned: results / pyramid on their way to the caller's arrays
     size_t hostOutBytes = 0;
     // The single-frame host call (ORBextractor::operator()) as ONE hipGraph per result buffer: upload from the pinned staging
-    // buffer, the 12 kernels, the read-back of the result arena into pinned memory.  A frame is then one hipGraphLaunch + one
+    // buffer, the 11 kernels, the read-back of the result arena into pinned memory.  A frame is then one hipGraphLaunch + one
     // hipStreamSynchronize instead of ~16 runtime calls (each 5-10 us of host time under the runtime's lock: they, not the
     // kernels, bounded the call - and serialised extractors on different threads).
     hipGraph_t sgGraph[2] = {nullptr, nullptr};
     hipGraphExec_t sgExec[2] = {nullptr, nullptr};
     bool sgValid = false;
     bool sgDisabled = false;          // ORBX_NO_GRAPH=1, or graph construction failed once: plain stream launches
-    bool splitDescribe = false;       // ORBX_SPLIT_DESCRIBE=1 (measurement switch): k_orient + k_describe instead of the fused kernel
 };
 
 namespace {
@@ -346,7 +345,7 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
         if ((rc = h->ptBuf.ensure(B * g.slotsPerFrame)) != ORBX_OK) return rc;     // every candidate the detector can emit: no capacity error
         if ((rc = h->labBuf.ensure(B * g.slotsPerFrame)) != ORBX_OK) return rc;
         if ((rc = h->lvlKp.ensure(B * g.kpPerFrame)) != ORBX_OK) return rc;
-        if ((rc = h->lvlCnt.ensure(B * g.nlevels)) != ORBX_OK) return rc;
+        if ((rc = h->lvlCnt.ensure(B * g.nlevels + 16)) != ORBX_OK) return rc;      // (+16: the descriptor kernel reads a frame's counts as ORBX_MAX_LEVELS unconditional words)
         h->arenaKpOff = align_up((2 * B + 1) * sizeof(int), 256);
         h->arenaDescOff = h->arenaKpOff + align_up(B * g.outCap * sizeof(orbx_keypoint), 256);
         h->arenaBytes = h->arenaDescOff + B * g.outCap * 32;
@@ -407,12 +406,11 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_FAST + 1], h->stream));
     if ((rc = orbx_launch_octree(L)) != ORBX_OK) return rc;
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_OCTREE + 1], h->stream));
-    if (h->splitDescribe && (rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
-    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_ORIENT + 1], h->stream));      // (fused form: orientation is part of the descriptor kernel, this span is empty)
+    if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_ORIENT + 1], h->stream));      // (orientation is part of the descriptor kernel: this span is empty)
     if ((rc = orbx_launch_blur(L)) != ORBX_OK) return rc;
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_BLUR + 1], h->stream));
     if (h->consumerEv[cb]) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->consumerEv[cb], 0)); h->consumerEv[cb] = nullptr; }
-    if ((rc = h->splitDescribe ? orbx_launch_desc(L) : orbx_launch_orient_describe(L)) != ORBX_OK) return rc;
+    if ((rc = orbx_launch_orient_describe(L)) != ORBX_OK) return rc;
     if (prof) { ORBX_HIP_CHECK(hipEventRecord(ev[ST_DESC + 1], h->stream)); h->profCount++; }
     h->lastBatch = batch; h->lastImg0 = img0Dev; h->lastStride = stride; h->lastFramePitch = framePitch;
     return ORBX_OK;
@@ -494,7 +492,6 @@ extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extr
     orbx_extractor *h = new orbx_extractor();
     h->cfg = *cfg;
     { const char *ng = getenv("ORBX_NO_GRAPH"); h->sgDisabled = ng && ng[0] == '1'; }
-    { const char *sd = getenv("ORBX_SPLIT_DESCRIBE"); h->splitDescribe = sd && sd[0] == '1'; }
     build_tables(h);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         orbx_set_error("hipStreamCreate failed");
@@ -681,13 +678,13 @@ static int fetch_results(orbx_extractor *h, int batch, bool wantKp, bool wantDes
 // ---------------------------------------------------------------------------------------------
 // One host frame in, results in pinned memory out: the body of ORBextractor::operator() for a handle created with max_batch = 1
 // (shim/ORBextractor.cc).  The frame's rows are laid out at the device pitch in the pinned staging buffer, then ONE graph launch
-// replays  upload -> status clear -> 7 x k_resize -> k_fast_cells -> k_octree -> k_orient -> k_blur -> k_describe -> read-back
+// replays  upload -> status clear -> 7 x k_resize -> k_fast_cells -> k_octree -> k_blur -> k_orient_describe -> read-back
 // with the pointers of result buffer `cb` baked in (one graph per buffer), followed by one synchronisation.
 // ---------------------------------------------------------------------------------------------
 static int build_single_graph(orbx_extractor *h)
 {
     // explicit node API (no stream capture - see emit() in orbx_kernels.hip), ONE chain:
-    //   upload -> status clear -> k_resize x7 -> k_fast_cells -> k_octree -> k_orient -> k_blur -> k_describe -> read-back
+    //   upload -> status clear -> k_resize x7 -> k_fast_cells -> k_octree -> k_blur -> k_orient_describe -> read-back
     // (measured: a second branch for k_blur next to the detector chain makes hipGraphLaunch use internal side streams - 166 us per frame
     // instead of 127 for this chain, and concurrent launches of such graphs from several threads crashed inside the runtime)
     const size_t fp = h->stagingFramePitch;
@@ -716,12 +713,10 @@ static int build_single_graph(orbx_extractor *h)
         if ((rc = orbx_launch_fast_cells(L)) != ORBX_OK) return rc;
         L.deps[0] = nChain;
         if ((rc = orbx_launch_octree(L)) != ORBX_OK) return rc;
-        L.deps[0] = nChain;
-        if (h->splitDescribe && (rc = orbx_launch_orient(L)) != ORBX_OK) return rc;
         L.deps[0] = nChain; L.node = &nBlur;
         if ((rc = orbx_launch_blur(L)) != ORBX_OK) return rc;
         L.deps[0] = nBlur; L.node = &nDesc;
-        if ((rc = h->splitDescribe ? orbx_launch_desc(L) : orbx_launch_orient_describe(L)) != ORBX_OK) return rc;
+        if ((rc = orbx_launch_orient_describe(L)) != ORBX_OK) return rc;
         ORBX_HIP_CHECK(hipGraphAddMemcpyNode1D(&nDown, g, &nDesc, 1, h->hostOut, h->outArena[cb].p, h->arenaBytes, hipMemcpyDeviceToHost));
         ORBX_HIP_CHECK(hipGraphInstantiate(&h->sgExec[cb], g, nullptr, nullptr, 0));
     }

@@ -102,9 +102,7 @@ struct OrbxLaunch {
 int orbx_launch_resize(const OrbxLaunch &L, int level);
 int orbx_launch_fast_cells(const OrbxLaunch &L);   /* FAST score + cell NMS + emission; L.score (parity tap) may be NULL */
 int orbx_launch_octree(const OrbxLaunch &L);
-int orbx_launch_orient(const OrbxLaunch &L);
 int orbx_launch_blur(const OrbxLaunch &L);
-int orbx_launch_desc(const OrbxLaunch &L);
 int orbx_launch_orient_describe(const OrbxLaunch &L);   /* IC_Angle + rBRIEF + final KeyPoint in one pass (after the blur) */
 
 /* stream of an extractor handle (orbx_extractor.hip), so other handles can order work after it */

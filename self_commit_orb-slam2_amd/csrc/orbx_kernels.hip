@@ -495,7 +495,10 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
     __shared__ int sh_misc[8];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int l = blockIdx.x, f = blockIdx.y;
+    // (level, frame) through the same XCD bijection as the detector before and the descriptor kernel after this stage: a frame's
+    // candidates were written, and its keypoints will be read, by the XCD that owns the frame's range - in the natural order
+    // block (l, f) lands on XCD l, and both hand-overs cross the fabric
+    XCD_REMAP_XY(l, f);
     const OrbxLevel &lv = g->lv[l];
     const int N = lv.quota;
     uint32_t *pts = ptBuf + (size_t)f * g->slotsPerFrame + lv.slotBase;    // capacity = cells x slots per cell: every candidate the detector can emit
@@ -758,63 +761,6 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
-__global__ __launch_bounds__(256) void k_orient(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
-                                                const uint8_t *__restrict__ pyr, OrbxLevelKp *__restrict__ lvlKp, const int *__restrict__ lvlCnt)
-{
-    // half a wave per keypoint: lane r of the half owns disc row v = r-15 and reads its 31 bytes
-    // as 8 unaligned dwords (x-15 .. x+16 stays inside the level: 19 <= x < w-19)
-    XCD_REMAP_XY(bx, f);
-    const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31;
-    const int slot = bx * 8 + (threadIdx.x >> 6) * 2 + half;   // index into the frame's level-keypoint array
-    bool live = slot < g->kpPerFrame;
-    int l = 0;
-    for (int i = 1; i < g->nlevels; i++) if (live && slot >= g->lv[i].kpBase) l = i;
-    const OrbxLevel &lv = g->lv[l];
-    const int i = slot - lv.kpBase;
-    live = live && i < lvlCnt[f * g->nlevels + l];
-    int m10 = 0, m01 = 0;
-    OrbxLevelKp *kp = lvlKp + (size_t)f * g->kpPerFrame + (live ? slot : 0);
-    if (live && r < 31) {
-        int pitch;
-        const uint8_t *img = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
-        const int v = r - 15, d = g->umax[v < 0 ? -v : v];
-        const uint8_t *row = img + (size_t)(kp->y + v) * pitch + (kp->x - 15);
-        int s1 = 0, su = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint32_t wd;
-            __builtin_memcpy(&wd, row + 4 * j, 4);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int u = 4 * j + k - 15;
-                if (u <= 15) {
-                    const int I = ((u < 0 ? -u : u) <= d) ? (int)((wd >> (8 * k)) & 0xff) : 0;
-                    s1 += I;
-                    su += u * I;
-                }
-            }
-        }
-        m10 = su;
-        m01 = v * s1;
-    }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-    // the eight moment pairs of the block meet in LDS; eight lanes of wave 0 then do the scalar tail
-    // (fastAtan2 and the sin/cos rBRIEF steers with, src/ORBextractor.cc:135-138) once per keypoint
-    // instead of once per wave
-    __shared__ int sMom[8][3];
-    if (r == 0) { int *m = sMom[(threadIdx.x >> 6) * 2 + half]; m[0] = m01; m[1] = m10; m[2] = live ? slot : -1; }
-    __syncthreads();
-    if (threadIdx.x < 8 && sMom[threadIdx.x][2] >= 0) {
-        OrbxLevelKp *o = lvlKp + (size_t)f * g->kpPerFrame + sMom[threadIdx.x][2];
-        const float ang = fast_atan2_deg((float)sMom[threadIdx.x][0], (float)sMom[threadIdx.x][1]);
-        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-        float sn, cs;
-        sincosf_glibc(ang * factorPI, sn, cs);
-        o->angle = ang; o->ca = cs; o->sb = sn;
-    }
-}
-
 // ------------------------------------------------------------------------------------
 // 7x7 Gaussian, sigma 2, BORDER_REFLECT_101, u8 fixed point (cv::GaussianBlur on the
 // cloned level, src/ORBextractor.cc:1626-1634): horizontal pass exact in 16 bits,
@@ -930,76 +876,6 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
 }
 
 // ------------------------------------------------------------------------------------
-// rBRIEF-256 (computeOrbDescriptor, src/ORBextractor.cc:173-227) + final KeyPoint
-// (:1175-1190, :1651-1660).  One wave per keypoint: in round r lane l evaluates test pair
-// 64r+l; the 64-bit __ballot of (t0 < t1) IS descriptor bytes 8r..8r+7 in the
-// reference's bit order (bit k of byte i = pair 8i+k).  cos/sin of the angle come with
-// the keypoint from k_orient (sincosf_glibc above).
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ blur, const OrbxLevelKp *__restrict__ lvlKp,
-                                                  const int *__restrict__ lvlCnt, orbx_keypoint *__restrict__ outKp, uint8_t *__restrict__ outDesc,
-                                                  int *__restrict__ outCnt, const int *__restrict__ status, int *__restrict__ outStatus)
-{
-    XCD_REMAP_XY(bx, f);
-    const int lane = threadIdx.x & 63;
-    // the wave number is uniform: told to the compiler, the level lookup, the counts and the keypoint record become scalar work
-    const int slot = bx * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int *cnts = lvlCnt + f * g->nlevels;
-    if (bx == 0 && threadIdx.x == 0) {
-        int tot = 0;
-        for (int i = 0; i < g->nlevels; i++) tot += cnts[i];
-        outCnt[f] = tot;
-        // the capacity words travel with the results: the running batch's words are cleared by the NEXT batch, a consumer of this
-        // result buffer reads the snapshot (which the producer only overwrites behind the consumer's event, like the results)
-        outStatus[f] = status[f];
-        if (f == 0) outStatus[gridDim.y] = status[gridDim.y];
-    }
-    if (slot >= g->kpPerFrame) return;
-    int l = 0;
-    for (int i = 1; i < g->nlevels; i++) if (slot >= g->lv[i].kpBase) l = i;
-    const OrbxLevel &lv = g->lv[l];
-    const int i = slot - lv.kpBase;
-    if (i >= cnts[l]) return;
-    int outIdx = i;
-    for (int k = 0; k < l; k++) outIdx += cnts[k];
-    if (outIdx >= g->outCap) return;
-    const OrbxLevelKp kp = lvlKp[(size_t)f * g->kpPerFrame + slot];
-    const uint8_t *img = blur + (size_t)f * g->pyrBytes + lv.off;
-    const int pitch = lv.pitch;
-    const float lvScale = lv.scale;          // read before the gathers: nothing after them should wait on memory but the stores
-    const int lvPatch = lv.patchSize;
-    const uint8_t *center = img + (size_t)kp.y * pitch + kp.x;
-    const float a = kp.ca, b = kp.sb;        // cos, sin of the angle (k_orient)
-    unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * g->outCap + outIdx) * 32);
-    // three dependent memory levels in total: the four pattern words, then the eight samples, then the stores
-    // (a store between the rounds would fence the next round's loads behind it)
-    uint32_t pat[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) pat[r] = *(const uint32_t *)(c_pattern + 4 * (64 * r + lane));
-    int t0[4], t1[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const float x0 = (float)(int8_t)(pat[r] & 0xff), y0 = (float)(int8_t)((pat[r] >> 8) & 0xff);
-        const float x1 = (float)(int8_t)((pat[r] >> 16) & 0xff), y1 = (float)(int8_t)(pat[r] >> 24);
-        const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
-        const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
-        t0[r] = center[r0 * pitch + c0];
-        t1[r] = center[r1 * pitch + c1];
-    }
-    unsigned long long bits[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) bits[r] = __ballot(t0[r] < t1[r]);
-    if (lane < 4) d64[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-    if (lane == 0) {
-        orbx_keypoint o;
-        o.x = l ? (float)kp.x * lvScale : (float)kp.x;
-        o.y = l ? (float)kp.y * lvScale : (float)kp.y;
-        o.size = (float)lvPatch; o.angle = kp.angle; o.response = (float)kp.score; o.octave = l; o.class_id = -1;
-        outKp[(size_t)f * g->outCap + outIdx] = o;
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // Orientation + descriptor in one pass over the keypoints (IC_Angle, src/ORBextractor.cc:108-161, then
 // computeOrbDescriptor, :173-227, and the final KeyPoint, :1175-1190 / :1651-1660).  One wave per
 // keypoint, four per workgroup.  Everything a keypoint needs from HBM is requested up front with
@@ -1012,13 +888,23 @@ __global__ __launch_bounds__(256) void k_describe(const OrbxGeom *__restrict__ g
 // round trip covers both stages and a load instruction touches ~7 lines.  fastAtan2 and the libm-exact sin / cos run
 // once per workgroup on four lanes (one per keypoint) between two barriers instead of on all 64 lanes of every wave.
 // ------------------------------------------------------------------------------------
+// per-level constants of the geometry as a kernel ARGUMENT: the level lookup and the addresses come from a few wide scalar loads of the
+// kernarg segment instead of a chain of dependent loads through OrbxGeom (the prologue is most of a wave's latency here)
+struct OdLevels {
+    int nlevels, kpPerFrame, outCap, pad;
+    unsigned long long pyrBytes;
+    int kpBase[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], patch[ORBX_MAX_LEVELS];
+    float scale[ORBX_MAX_LEVELS];
+    int umax[16];
+};
+
 #define OD_WPB 4
 #define OD_R 18
 #define OD_DW 10
 #define OD_ROWS (2 * OD_R + 1)
 #define OD_PATCH_DW (OD_ROWS * OD_DW)
 
-__global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+__global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels A, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
                                                                  const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, OrbxLevelKp *__restrict__ lvlKp,
                                                                  const int *__restrict__ lvlCnt, orbx_keypoint *__restrict__ outKp, uint8_t *__restrict__ outDesc,
                                                                  int *__restrict__ outCnt, const int *__restrict__ status, int *__restrict__ outStatus)
@@ -1032,60 +918,69 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OrbxGeom 
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // uniform: the keypoint bookkeeping below is scalar work
     sPat[threadIdx.x] = ((const uint32_t *)c_pattern)[threadIdx.x];              // the 256 test pairs (x0, y0, x1, y1 as int8), once per workgroup
     const int slot = bx * OD_WPB + wv;
-    const int *cnts = lvlCnt + f * g->nlevels;
+    const int *cnts = lvlCnt + f * A.nlevels;
     if (bx == 0 && threadIdx.x == 0) {
         int tot = 0;
-        for (int i = 0; i < g->nlevels; i++) tot += cnts[i];
+        for (int i = 0; i < A.nlevels; i++) tot += cnts[i];
         outCnt[f] = tot;
         // the capacity words travel with the results: the running batch's words are cleared by the NEXT batch, a consumer of this
         // result buffer reads the snapshot (which the producer only overwrites behind the consumer's event, like the results)
         outStatus[f] = status[f];
         if (f == 0) outStatus[gridDim.y] = status[gridDim.y];
     }
-    bool live = slot < g->kpPerFrame;
-    int l = 0;
-    for (int i = 1; i < g->nlevels; i++) if (live && slot >= g->lv[i].kpBase) l = i;
-    const OrbxLevel &lv = g->lv[l];
-    const int i = slot - lv.kpBase;
-    live = live && i < cnts[l];
-    int outIdx = i;
-    for (int k = 0; k < l; k++) outIdx += cnts[k];
-    live = live && outIdx < g->outCap;
-    const size_t kpi = (size_t)f * g->kpPerFrame + (live ? slot : 0);
-    const int kx = live ? (int)lvlKp[kpi].x : 0, ky = live ? (int)lvlKp[kpi].y : 0, ksc = live ? (int)lvlKp[kpi].score : 0;
+    // Is the slot in use?  (Measured: requesting the keypoint record and the pixels BEFORE the counts are known - clamped coordinates for
+    // the ~7 % unused slots - shortens the dependent chain by one level but is 7 % slower: 0.242 vs 0.226 ms per 256 frames.)
+    bool inRange = slot < A.kpPerFrame;
+    int l = 0, kb = 0;
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++) {
+        const bool ge = i < A.nlevels && slot >= A.kpBase[i];
+        l = ge ? i : l; kb = ge ? A.kpBase[i] : kb;
+    }
+    int cn[ORBX_MAX_LEVELS];
+#pragma unroll
+    for (int i = 0; i < ORBX_MAX_LEVELS; i++) cn[i] = cnts[i];       // unconditional (the array is padded): a few wide scalar loads
+    int outIdx = slot - kb, pre = 0, cl = cn[0];
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++) {
+        pre += cn[i - 1];
+        if (i == l) { outIdx += pre; cl = cn[i]; }
+    }
+    inRange = inRange && slot - kb < cl && outIdx < A.outCap;
+    const bool live = inRange;
+    const uint2 kraw = *(const uint2 *)&lvlKp[(size_t)f * A.kpPerFrame + (inRange ? slot : 0)];     // x | y << 16, score | pad: the first 8 bytes of OrbxLevelKp
+    const int kx = (int)(kraw.x & 0xffffu), ky = (int)(kraw.x >> 16);
+    const int ksc = (int)(kraw.y & 0xffu);
     const int xa = (kx - OD_R) & ~3;
     int m10 = 0, m01 = 0;
-    uint32_t pw[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-    if (live) {
-        int up;
-        const uint8_t *unb = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, up);
-        const uint8_t *bl = blur + (size_t)f * g->pyrBytes + lv.off;
-        const int bp = lv.pitch;
-        // disc row r = lane / 2, bytes x - 15 + 16 * half .. + 15 (19 <= x < w - 19: inside the level)
+    uint2 pw[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    if (inRange) {
+        const int bp = A.pitch[l], up = l ? bp : img0Stride;
+        const uint8_t *unb = l ? pyr + (size_t)f * A.pyrBytes + A.off[l] : img0 + (size_t)f * img0FramePitch;
+        const uint8_t *bl = blur + (size_t)f * A.pyrBytes + A.off[l];
+        // disc row r = lane / 2, bytes x - 15 + 16 * half .. + 15 (19 <= x < w - 19: inside the level): ONE 16-byte load per lane
         const int r = lane >> 1, hf = lane & 1;
-        uint32_t wd[4] = {0u, 0u, 0u, 0u};
-        if (r < 31) {
-            const uint8_t *row = unb + (size_t)(ky + r - 15) * up + (kx - 15 + 16 * hf);
+        uint4 wd = make_uint4(0u, 0u, 0u, 0u);
+        if (r < 31) __builtin_memcpy(&wd, unb + (size_t)(ky + r - 15) * up + (kx - 15 + 16 * hf), 16);
+        // patch: 37 rows x 5 aligned 8-byte units
 #pragma unroll
-            for (int j = 0; j < 4; j++) __builtin_memcpy(&wd[j], row + 4 * j, 4);
-        }
-#pragma unroll
-        for (int t = 0; t < 6; t++) {
+        for (int t = 0; t < 3; t++) {
             const int item = lane + 64 * t;
-            if (item < OD_PATCH_DW) {
-                const int pr = (item * 205) >> 11, pc = item - OD_DW * pr;      // item / 10
-                pw[t] = *(const uint32_t *)(bl + (size_t)(ky - OD_R + pr) * bp + xa + 4 * pc);
+            if (item < OD_ROWS * (OD_DW / 2)) {
+                const int pr = (item * 205) >> 10, pc = item - (OD_DW / 2) * pr;      // item / 5
+                __builtin_memcpy(&pw[t], bl + (size_t)(ky - OD_R + pr) * bp + xa + 8 * pc, 8);
             }
         }
         if (r < 31) {
-            const int v = r - 15, d = g->umax[v < 0 ? -v : v];
+            const int v = r - 15, d = A.umax[v < 0 ? -v : v];
+            const uint32_t w4[4] = {wd.x, wd.y, wd.z, wd.w};
             int s1 = 0, su = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int u = 16 * hf + 4 * j + k - 15;                      // hf is a lane value: u = c - 15 or c + 1
-                    const int I = ((u < 0 ? -u : u) <= d && u <= 15) ? (int)((wd[j] >> (8 * k)) & 0xff) : 0;
+                    const int I = ((u < 0 ? -u : u) <= d && u <= 15) ? (int)((w4[j] >> (8 * k)) & 0xff) : 0;
                     s1 += I;
                     su += u * I;
                 }
@@ -1098,9 +993,9 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OrbxGeom 
     if (lane == 0) { sMom[wv][0] = m01; sMom[wv][1] = m10; sMom[wv][2] = live ? slot : -1; }
     if (live) {
 #pragma unroll
-        for (int t = 0; t < 6; t++) {
+        for (int t = 0; t < 3; t++) {
             const int item = lane + 64 * t;
-            if (item < OD_PATCH_DW) sPatch[wv][item] = pw[t];
+            if (item < OD_ROWS * (OD_DW / 2)) *(uint2 *)&sPatch[wv][2 * item] = pw[t];
         }
     }
     __syncthreads();
@@ -1110,7 +1005,7 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OrbxGeom 
         float sn, cs;
         sincosf_glibc(ang * factorPI, sn, cs);
         sTrig[threadIdx.x][0] = cs; sTrig[threadIdx.x][1] = sn; sTrig[threadIdx.x][2] = ang;
-        OrbxLevelKp *o = lvlKp + (size_t)f * g->kpPerFrame + sMom[threadIdx.x][2];
+        OrbxLevelKp *o = lvlKp + (size_t)f * A.kpPerFrame + sMom[threadIdx.x][2];
         o->angle = ang; o->ca = cs; o->sb = sn;        // (read back by the stage taps and by nothing else)
     }
     __syncthreads();
@@ -1128,15 +1023,15 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OrbxGeom 
         const int t0 = pb[r0 * (4 * OD_DW) + c0], t1 = pb[r1 * (4 * OD_DW) + c1];
         bits[r] = __ballot(t0 < t1);
     }
-    unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * g->outCap + outIdx) * 32);
+    unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * A.outCap + outIdx) * 32);
     if (lane < 4) d64[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
     if (lane == 0) {
         orbx_keypoint o;
-        const float sc = lv.scale;
+        const float sc = A.scale[l];
         o.x = l ? (float)kx * sc : (float)kx;
         o.y = l ? (float)ky * sc : (float)ky;
-        o.size = (float)lv.patchSize; o.angle = sTrig[wv][2]; o.response = (float)ksc; o.octave = l; o.class_id = -1;
-        outKp[(size_t)f * g->outCap + outIdx] = o;
+        o.size = (float)A.patch[l]; o.angle = sTrig[wv][2]; o.response = (float)ksc; o.octave = l; o.class_id = -1;
+        outKp[(size_t)f * A.outCap + outIdx] = o;
     }
 }
 
@@ -1211,27 +1106,21 @@ int orbx_launch_octree(const OrbxLaunch &L)
 #undef OT_LAUNCH
 }
 
-int orbx_launch_orient(const OrbxLaunch &L)
-{
-    dim3 grid((unsigned)((L.geom->kpPerFrame + 7) / 8), (unsigned)L.batch);
-    return emit(L, k_orient, grid, dim3(256), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.lvlKp, L.lvlCnt);
-}
-
 int orbx_launch_blur(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->blurTiles, (unsigned)L.batch);
     return emit(L, k_blur, grid, dim3(64), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur);
 }
 
-int orbx_launch_desc(const OrbxLaunch &L)
-{
-    dim3 grid((unsigned)((L.geom->kpPerFrame + 3) / 4), (unsigned)L.batch);
-    return emit(L, k_describe, grid, dim3(256), 0, L.geomDev, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc, L.outCnt, L.status, L.outStatus);
-}
-
 int orbx_launch_orient_describe(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)((L.geom->kpPerFrame + OD_WPB - 1) / OD_WPB), (unsigned)L.batch);
-    return emit(L, k_orient_describe, grid, dim3(64 * OD_WPB), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc,
+    const OrbxGeom &g = *L.geom;
+    OdLevels A;
+    memset(&A, 0, sizeof(A));
+    A.nlevels = g.nlevels; A.kpPerFrame = g.kpPerFrame; A.outCap = g.outCap; A.pyrBytes = g.pyrBytes;
+    for (int l = 0; l < g.nlevels; l++) { A.kpBase[l] = g.lv[l].kpBase; A.off[l] = g.lv[l].off; A.pitch[l] = g.lv[l].pitch; A.patch[l] = g.lv[l].patchSize; A.scale[l] = g.lv[l].scale; }
+    for (int i = 0; i < 16; i++) A.umax[i] = g.umax[i];
+    return emit(L, k_orient_describe, grid, dim3(64 * OD_WPB), 0, A, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc,
                 L.outCnt, L.status, L.outStatus);
 }
