@@ -367,6 +367,30 @@ int orbx_is_in_frustum(orbx_matcher *m, const orbx_frustum_frame *frame_host, co
                        float viewing_cos_limit, float *proj_x, float *proj_y, float *proj_xr, int32_t *scale_level,
                        float *view_cos, uint8_t *in_view);
 
+/* Tracking::SearchLocalPoints (src/Tracking.cc:1760-1830) as ONE device chain for one frame: Frame::isInFrustum over the local
+ * map points (src/Frame.cc:608-742, the loop at src/Tracking.cc:1791-1811) feeding ORBmatcher::SearchByProjection(Frame&,
+ * vector<MapPoint*>&, th) (src/ORBmatcher.cc:70-175; :1828) without the mTrack* fields ever visiting the host: one upload of the
+ * frame side, the pose and the points' map data, k_is_in_frustum -> k_proj_topk -> k_proj_greedy, one read-back.
+ * `points_host` lists the points the reference's loop would test (not yet seen in this frame, not bad), in list order.
+ * Outputs: assigned[i] (frame->counts[0] entries) = index of the point written into F.mvpMapPoints[i] or -1, *nmatches = the
+ * search's return value; per point the fields Frame::isInFrustum leaves in the MapPoint: in_view = mbTrackInView (= the function's
+ * return value: IncreaseVisible() / nToMatch bookkeeping is the caller's), proj_x / proj_y / proj_xr / scale_level / view_cos
+ * (written where in_view; any of the five may be NULL). */
+typedef struct orbx_local_points {
+    const float *world_pos;          /* [3] GetWorldPos()                                   */
+    const float *normal;             /* [3] GetNormal()                                     */
+    const float *max_distance;       /* mfMaxDistance                                       */
+    const float *min_distance;       /* mfMinDistance                                       */
+    const uint8_t *descriptors;      /* GetDescriptor(), 32 bytes                           */
+    const uint8_t *has_observations; /* Observations()>0; NULL = all                        */
+    int count;
+} orbx_local_points;
+int orbx_search_local_points(orbx_matcher *m, const orbx_projection_frame *frame_host, const orbx_frustum_frame *pose_host,
+                             const orbx_local_points *points_host, const float *scale_factors, int nlevels,
+                             float viewing_cos_limit, float th, float nn_ratio, int32_t *assigned, int32_t *nmatches,
+                             uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr, int32_t *scale_level,
+                             float *view_cos);
+
 /* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th,
  * const bool bMono) (src/ORBmatcher.cc:1569-1728; Tracking::TrackWithMotionModel,
  * src/Tracking.cc:1433-1441).  Last-frame side, feature i of frame f at f*capacity + i: */

@@ -703,6 +703,85 @@ ORBSLAM_API int orbslam_is_in_frustum(const float *Tcw, const float *TcwSrc, con
     return nIn;
 }
 
+// Tracking::SearchLocalPoints (src/Tracking.cc:1760-1830) on a real Frame and real MapPoints.  Tracking.cc itself cannot be compiled here
+// (Viewer / Pangolin), so the all-reference build runs the function's three steps as they stand there - step 1 over F.mvpMapPoints,
+// Frame::isInFrustum per local point, ORBmatcher(0.8).SearchByProjection(F, points, th) - and the drop-in build runs
+// shim/SearchLocalPoints.h's SearchLocalPointsHIP, the one-call device body a maintainer would put into that function.
+// pre[j] = map point already held by feature j of the current frame (-1: none); bad[i]: the point was SetBadFlag()ed.
+#ifdef ORBSLAM_HIP
+#include "../self_commit_orb-slam2_amd/shim/SearchLocalPoints.h"
+#endif
+namespace {
+struct MapPointVisible : public MapPoint { static int Visible(MapPoint *p) { return static_cast<MapPointVisible *>(p)->mnVisible; } };
+}  // namespace
+ORBSLAM_API int orbslam_search_local_points(const float *kpUn, const uint8_t *desc, const float *uRight, int n, const float *Tcw, const float *TcwSrc,
+                                            const float *srcKps, const uint8_t *srcDesc, const float *pos, int m, const int32_t *pre, const uint8_t *bad,
+                                            const uint8_t *hasObs, int th, int32_t *assigned, uint8_t *inView, float *projX, float *projY, float *projXR,
+                                            int32_t *level, float *viewCos, int32_t *visible)
+{
+    CallScope scope;
+    Map map;
+    Camera cam = {500.f, 500.f, 320.f, 240.f, 40.f, 640, 480};
+    Frame FS, F;
+    fill_frame(FS, srcKps, srcDesc, m, nullptr, cam, kDefaultScales, 8);
+    fill_frame(F, kpUn, desc, n, nullptr, cam, kDefaultScales, 8);
+    for (int i = 0; i < n; i++) F.mvuRight[(size_t)i] = uRight[i];
+    cv::Mat Ts(4, 4, CV_32F), T(4, 4, CV_32F);
+    for (int i = 0; i < 16; i++) { Ts.at<float>(i / 4, i % 4) = TcwSrc[i]; T.at<float>(i / 4, i % 4) = Tcw[i]; }
+    FS.SetPose(Ts);
+    F.SetPose(T);
+    KeyFrame *kf = new KeyFrame(FS, &map, (KeyFrameDatabase *)nullptr);
+    std::vector<MapPoint *> local((size_t)m);
+    std::map<MapPoint *, int> index;
+    for (int i = 0; i < m; i++) {
+        cv::Mat p(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) p.at<float>(k) = pos[3 * i + k];
+        MapPoint *mp = new MapPoint(p, &map, &FS, i);
+        if (hasObs[i]) mp->AddObservation(kf, (size_t)i);
+        local[(size_t)i] = mp; index[mp] = i;
+    }
+    for (int j = 0; j < n; j++)
+        if (pre[j] >= 0) F.mvpMapPoints[(size_t)j] = local[(size_t)pre[j]];
+    for (int i = 0; i < m; i++)
+        if (bad[i]) local[(size_t)i]->SetBadFlag();
+    int nm = 0;
+#ifdef ORBSLAM_HIP
+    nm = SearchLocalPointsHIP(F, local, th);
+#else
+    for (std::vector<MapPoint *>::iterator vit = F.mvpMapPoints.begin(), vend = F.mvpMapPoints.end(); vit != vend; vit++) {      // src/Tracking.cc:1765-1784
+        MapPoint *pMP = *vit;
+        if (pMP) {
+            if (pMP->isBad()) *vit = static_cast<MapPoint *>(NULL);
+            else { pMP->IncreaseVisible(); pMP->mnLastFrameSeen = F.mnId; pMP->mbTrackInView = false; }
+        }
+    }
+    int nToMatch = 0;
+    for (std::vector<MapPoint *>::iterator vit = local.begin(), vend = local.end(); vit != vend; vit++) {                         // :1791-1811
+        MapPoint *pMP = *vit;
+        if (pMP->mnLastFrameSeen == F.mnId) continue;
+        if (pMP->isBad()) continue;
+        if (F.isInFrustum(pMP, 0.5)) { pMP->IncreaseVisible(); nToMatch++; }
+    }
+    if (nToMatch > 0) {                                                                                                           // :1814-1829
+        ORBmatcher matcher(0.8);
+        nm = matcher.SearchByProjection(F, local, th);
+    }
+#endif
+    for (int j = 0; j < n; j++) {
+        MapPoint *mp = F.mvpMapPoints[(size_t)j];
+        assigned[j] = mp ? index[mp] : -1;
+    }
+    for (int i = 0; i < m; i++) {
+        MapPoint *mp = local[(size_t)i];
+        inView[i] = mp->mbTrackInView ? 1 : 0;
+        projX[i] = mp->mTrackProjX; projY[i] = mp->mTrackProjY; projXR[i] = mp->mTrackProjXR; level[i] = mp->mnTrackScaleLevel; viewCos[i] = mp->mTrackViewCos;
+        visible[i] = MapPointVisible::Visible(mp);
+    }
+    for (int i = 0; i < m; i++) delete local[(size_t)i];
+    delete kf;
+    return nm;
+}
+
 // ---------------------------------------------------------------------------------------
 // DBoW2 vocabulary: TemplatedVocabulary::loadFromTextFile + transform
 // (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1420, 1127-1262), i.e. what

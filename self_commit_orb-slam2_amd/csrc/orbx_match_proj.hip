@@ -1428,3 +1428,73 @@ extern "C" int orbx_is_in_frustum(orbx_matcher *m, const orbx_frustum_frame *fra
     memcpy(in_view, hv, n);
     return ORBX_OK;
 }
+
+
+// Tracking::SearchLocalPoints as one device chain (include/orbx.h): the frustum kernel's outputs are the projection search's inputs.
+extern "C" int orbx_search_local_points(orbx_matcher *m, const orbx_projection_frame *fr, const orbx_frustum_frame *pose, const orbx_local_points *pt,
+                                        const float *scale_factors, int nlevels, float viewing_cos_limit, float th, float nn_ratio, int32_t *assigned,
+                                        int32_t *nmatches, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr, int32_t *scale_level, float *view_cos)
+{
+    if (!m || !fr || !pose || !pt || !assigned || !in_view) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!fr->counts || !pose->tcw || !pose->ratio_thresholds) { orbx_set_error("NULL array in the frame arguments"); return ORBX_ERR_ARG; }
+    const int n = fr->counts[0], mm = pt->count;
+    if (n > 0 && (!fr->keypoints_un || !fr->descriptors || !fr->u_right)) { orbx_set_error("NULL array in the frame arguments"); return ORBX_ERR_ARG; }
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < n; i++) assigned[i] = -1;
+    if (mm <= 0) return ORBX_OK;
+    if (!pt->world_pos || !pt->normal || !pt->max_distance || !pt->min_distance || !pt->descriptors) { orbx_set_error("NULL array in the point arguments"); return ORBX_ERR_ARG; }
+    if (n <= 0) {      // a frame without features: the reference still runs Frame::isInFrustum over the points
+        const int32_t cm = mm;
+        orbx_map_points mp = {pt->world_pos, pt->normal, pt->max_distance, pt->min_distance, &cm, mm};
+        return orbx_is_in_frustum(m, pose, &mp, viewing_cos_limit, proj_x, proj_y, proj_xr, scale_level, view_cos, in_view);
+    }
+    if (n > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    hipStream_t st = m->stream;
+    OrbxHostStage &hs = m->hostStage;
+    const size_t N = (size_t)n, M = (size_t)mm;
+    const size_t inBytes = hs.padded(N * sizeof(orbx_keypoint)) + hs.padded(N * 32) + hs.padded(N * 4) + hs.padded(N) + hs.padded(8) + hs.padded(64) + 2 * hs.padded(M * 12) +
+                           2 * hs.padded(M * 4) + hs.padded(M * 32) + hs.padded(M);
+    const size_t offLvl = hs.padded(M * 16), offIn = offLvl + hs.padded(M * 4), offAs = offIn + hs.padded(M), offNm = offAs + hs.padded(N * 4), outBytes = offNm + hs.padded(4);
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    if ((rc = hs.begin(inBytes > outBytes ? inBytes : outBytes)) != ORBX_OK) return rc;
+    const int32_t cnt[2] = {n, mm};
+    const orbx_keypoint *dKp = hs.put(fr->keypoints_un, N);
+    const uint8_t *dDesc = hs.put(fr->descriptors, N * 32);
+    const float *dUr = hs.put(fr->u_right, N);
+    const uint8_t *dOcc = hs.put(fr->occupied, N);
+    const int32_t *dCnt = hs.put(cnt, 2);
+    orbx_frustum_frame fd = *pose;
+    fd.tcw = hs.put(pose->tcw, 16); fd.nframes = 1;
+    orbx_map_points pd;
+    pd.world_pos = hs.put(pt->world_pos, M * 3);
+    pd.normal = hs.put(pt->normal, M * 3);
+    pd.max_distance = hs.put(pt->max_distance, M);
+    pd.min_distance = hs.put(pt->min_distance, M);
+    pd.counts = dCnt + 1;
+    pd.capacity = mm;
+    const uint8_t *dPd = hs.put(pt->descriptors, M * 32), *dObs = hs.put(pt->has_observations, M);
+    if ((rc = hs.flush(st)) != ORBX_OK) return rc;
+    if ((rc = orbx_is_in_frustum_device(m, &fd, &pd, viewing_cos_limit)) != ORBX_OK) return rc;
+    ProjFrameDev F = {dKp, dDesc, dUr, fr->occupied ? dOcc : nullptr, dCnt, n, fr->min_x, fr->min_y, fr->grid_width_inv, fr->grid_height_inv};
+    ProjPointsDev P = {m->frProj.p, m->frProj.p + M, m->frProj.p + 2 * M, m->frLevel.p, m->frProj.p + 3 * M, m->frInView.p, pt->has_observations ? dObs : nullptr, dPd, dCnt + 1, mm};
+    if ((rc = proj_launch(m, F, P, 1, scale_factors, nlevels, th, nn_ratio)) != ORBX_OK) return rc;
+    uint8_t *hp = hs.host;        // stream order: the kernels have consumed the uploaded inputs before these copies land in the same pinned buffer
+    ORBX_HIP_CHECK(hipMemcpyAsync(hp, m->frProj.p, M * 16, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(hp + offLvl, m->frLevel.p, M * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(hp + offIn, m->frInView.p, M, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(hp + offAs, m->matches.p, N * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_CHECK(hipMemcpyAsync(hp + offNm, m->nmatches.p, 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    const float *pp = (const float *)hp;
+    if (proj_x) memcpy(proj_x, pp, M * 4);
+    if (proj_y) memcpy(proj_y, pp + M, M * 4);
+    if (proj_xr) memcpy(proj_xr, pp + 2 * M, M * 4);
+    if (view_cos) memcpy(view_cos, pp + 3 * M, M * 4);
+    if (scale_level) memcpy(scale_level, hp + offLvl, M * 4);
+    memcpy(in_view, hp + offIn, M);
+    memcpy(assigned, hp + offAs, N * 4);
+    if (nmatches) memcpy(nmatches, hp + offNm, 4);
+    return ORBX_OK;
+}

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "ORBmatcher.h"
+#include "SearchLocalPoints.h"
 #include "orbx.h"
 
 // number of SearchByBoW calls served by this file (lets the drop-in test prove that the HIP
@@ -41,6 +42,8 @@ static unsigned long gFuseCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_fuse_calls(void) { return gFuseCalls; }
 static unsigned long gTriangulationCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_for_triangulation_calls(void) { return gTriangulationCalls; }
+static unsigned long gLocalPointsCalls = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_local_points_calls(void) { return gLocalPointsCalls; }
 static unsigned long gSearchByBoWCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_search_by_bow_calls(void) { return gSearchByBoWCalls; }
 
@@ -735,6 +738,87 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
         if (assigned[(size_t)i2] >= 0) CurrentFrame.mvpMapPoints[(size_t)i2] = LastFrame.mvpMapPoints[(size_t)assigned[(size_t)i2]];
         else if (assigned[(size_t)i2] == -2) CurrentFrame.mvpMapPoints[(size_t)i2] = static_cast<MapPoint *>(NULL);
     }
+    return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tracking::SearchLocalPoints (src/Tracking.cc:1760-1830) - see shim/SearchLocalPoints.h.
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+// mfMaxDistance / mfMinDistance are protected (include/MapPoint.h:231-232); GetMaxDistanceInvariance() returns 1.2f * mfMaxDistance, which
+// does not divide back exactly.  Read under the mutex the getters take.
+struct MapPointDistances : public MapPoint {
+    static void Get(MapPoint *p, float &mx, float &mn)
+    {
+        MapPointDistances *q = static_cast<MapPointDistances *>(p);
+        unique_lock<mutex> lock(q->mMutexPos);
+        mx = q->mfMaxDistance; mn = q->mfMinDistance;
+    }
+};
+}  // namespace
+
+int SearchLocalPointsHIP(Frame &F, const std::vector<MapPoint *> &vpLocalMapPoints, int th, float nnratio, float viewingCosLimit)
+{
+    __atomic_add_fetch(&gLocalPointsCalls, 1, __ATOMIC_RELAXED);
+    for (std::vector<MapPoint *>::iterator vit = F.mvpMapPoints.begin(), vend = F.mvpMapPoints.end(); vit != vend; vit++) {     // step 1, :1765-1784
+        MapPoint *pMP = *vit;
+        if (!pMP) continue;
+        if (pMP->isBad()) *vit = static_cast<MapPoint *>(NULL);
+        else { pMP->IncreaseVisible(); pMP->mnLastFrameSeen = F.mnId; pMP->mbTrackInView = false; }
+    }
+    // step 2 (:1791-1811): the points Frame::isInFrustum would be asked about, in list order
+    std::vector<int> idx;
+    idx.reserve(vpLocalMapPoints.size());
+    for (size_t i = 0; i < vpLocalMapPoints.size(); i++) {
+        MapPoint *pMP = vpLocalMapPoints[i];
+        if (pMP->mnLastFrameSeen == F.mnId) continue;
+        if (pMP->isBad()) continue;
+        idx.push_back((int)i);
+    }
+    const int M = (int)idx.size(), N = F.N;
+    if (M == 0) return 0;
+    std::vector<float> pos((size_t)M * 3), nrm((size_t)M * 3), mx((size_t)M), mn((size_t)M);
+    std::vector<uint8_t> desc((size_t)M * 32), hasObs((size_t)M);
+    for (int k = 0; k < M; k++) {
+        MapPoint *pMP = vpLocalMapPoints[(size_t)idx[(size_t)k]];
+        const cv::Mat P = pMP->GetWorldPos(), Pn = pMP->GetNormal();
+        for (int c = 0; c < 3; c++) { pos[3 * (size_t)k + c] = P.at<float>(c); nrm[3 * (size_t)k + c] = Pn.at<float>(c); }
+        MapPointDistances::Get(pMP, mx[(size_t)k], mn[(size_t)k]);
+        hasObs[(size_t)k] = pMP->Observations() > 0 ? 1 : 0;
+        const cv::Mat d = pMP->GetDescriptor();
+        memcpy(&desc[32 * (size_t)k], d.ptr<unsigned char>(), 32);
+    }
+    const int nFeat = N > 0 ? N : 1;
+    std::vector<uint8_t> occupied((size_t)nFeat, 0), inView((size_t)M, 0);
+    for (int i = 0; i < N; i++) occupied[(size_t)i] = (F.mvpMapPoints[(size_t)i] && F.mvpMapPoints[(size_t)i]->Observations() > 0) ? 1 : 0;   // src/ORBmatcher.cc:110-112
+    std::vector<float> px((size_t)M), py((size_t)M), pxr((size_t)M), vc((size_t)M);
+    std::vector<int32_t> lvl((size_t)M), assigned((size_t)nFeat, -1);
+    float tcw[16], ratioTh[64];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) tcw[4 * r + c] = F.mTcw.at<float>(r, c);
+    if (orbx_predict_scale_thresholds(F.mfLogScaleFactor, F.mnScaleLevels, ratioTh) != ORBX_OK)
+        throw std::runtime_error(std::string("SearchLocalPoints (orbx): ") + orbx_last_error());
+    int32_t nmatches = 0;
+    {
+        orbx_projection_frame fr = {N > 0 ? (const orbx_keypoint *)&F.mvKeysUn[0] : 0, N > 0 ? F.mDescriptors.data : 0, N > 0 ? &F.mvuRight[0] : 0, &occupied[0], &N, nFeat, 1,
+                                    Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv};
+        orbx_frustum_frame pose = {tcw, Frame::fx, Frame::fy, Frame::cx, Frame::cy, F.mbf, Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY, ratioTh, F.mnScaleLevels, 1};
+        orbx_local_points pts = {&pos[0], &nrm[0], &mx[0], &mn[0], &desc[0], &hasObs[0], M};
+        if (orbx_search_local_points(Matcher(N > M ? N : M), &fr, &pose, &pts, &F.mvScaleFactors[0], (int)F.mvScaleFactors.size(), viewingCosLimit, (float)th, nnratio,
+                                     &assigned[0], &nmatches, &inView[0], &px[0], &py[0], &pxr[0], &lvl[0], &vc[0]) != ORBX_OK)
+            throw std::runtime_error(std::string("SearchLocalPoints (orbx): ") + orbx_last_error());
+    }
+    for (int k = 0; k < M; k++) {                                                   // what Frame::isInFrustum leaves in the MapPoint, :615, :721-731
+        MapPoint *pMP = vpLocalMapPoints[(size_t)idx[(size_t)k]];
+        pMP->mbTrackInView = inView[(size_t)k] != 0;
+        if (!inView[(size_t)k]) continue;
+        pMP->mTrackProjX = px[(size_t)k]; pMP->mTrackProjXR = pxr[(size_t)k]; pMP->mTrackProjY = py[(size_t)k];
+        pMP->mnTrackScaleLevel = lvl[(size_t)k]; pMP->mTrackViewCos = vc[(size_t)k];
+        pMP->IncreaseVisible();                                                     // :1807
+    }
+    for (int i = 0; i < N; i++)
+        if (assigned[(size_t)i] >= 0) F.mvpMapPoints[(size_t)i] = vpLocalMapPoints[(size_t)idx[(size_t)assigned[(size_t)i]]];     // src/ORBmatcher.cc:165
     return nmatches;
 }
 
