@@ -392,6 +392,11 @@ class MapPoints(ctypes.Structure):
                 ("counts", ctypes.c_void_p), ("capacity", ctypes.c_int)]
 
 
+class LocalPoints(ctypes.Structure):
+    _fields_ = [("world_pos", ctypes.c_void_p), ("normal", ctypes.c_void_p), ("max_distance", ctypes.c_void_p), ("min_distance", ctypes.c_void_p),
+                ("descriptors", ctypes.c_void_p), ("has_observations", ctypes.c_void_p), ("count", ctypes.c_int)]
+
+
 def predict_scale_thresholds(log_scale_factor, nlevels):
     """orbx_predict_scale_thresholds: the float ratios at which MapPoint::PredictScale changes level (host, libm log)."""
     L = load_library()
@@ -597,6 +602,38 @@ class ORBmatcher:
         _check(self._L.orbx_search_by_projection(self._h, ctypes.byref(F), ctypes.byref(P), _ptr(sf), len(sf), ctypes.c_float(th),
                                                  ctypes.c_float(self.nnratio if nnratio is None else nnratio), _ptr(out), ctypes.byref(nm)))
         return nm.value, out[:n]
+
+    def SearchLocalPoints(self, frame, Tcw, cam, log_scale_factor, points, th, nnratio=None, viewing_cos_limit=0.5):
+        """Tracking::SearchLocalPoints (reference src/Tracking.cc:1760-1830) as one device chain (orbx_search_local_points): Frame::isInFrustum over
+        `points` (dict pos, normal, max_distance, min_distance, desc, has_obs) and SearchByProjection(F, points, th) on the frame (dict as in
+        SearchByProjection); cam = (fx, fy, cx, cy, mbf).  Returns (nmatches, assigned[n], dict(in_view, proj_x, proj_y, proj_xr, level, view_cos))."""
+        k = np.ascontiguousarray(frame["kps"], KEYPOINT_DTYPE)
+        n = len(k)
+        d = np.ascontiguousarray(frame["desc"], np.uint8)
+        ur = np.ascontiguousarray(frame["u_right"], np.float32)
+        occ = np.ascontiguousarray(frame["occupied"], np.uint8)
+        sf = np.ascontiguousarray(frame["scale_factors"], np.float32)
+        minx, miny = np.float32(frame.get("min_x", 0.0)), np.float32(frame.get("min_y", 0.0))
+        maxx, maxy = np.float32(frame.get("max_x", frame["width"])), np.float32(frame.get("max_y", frame["height"]))
+        gw, gh = np.float32(64) / (maxx - minx), np.float32(48) / (maxy - miny)
+        cn = np.array([n], np.int32)
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        thr = predict_scale_thresholds(log_scale_factor, len(sf))
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        pos, nrm, mx, mn = f32(points["pos"]), f32(points["normal"]), f32(points["max_distance"]), f32(points["min_distance"])
+        md, obs = np.ascontiguousarray(points["desc"], np.uint8), np.ascontiguousarray(points["has_obs"], np.uint8)
+        m = len(mx)
+        F = ProjectionFrame(_ptr(k).value, _ptr(d).value, _ptr(ur).value, _ptr(occ).value, _ptr(cn).value, max(n, 1), 1, float(minx), float(miny), float(gw), float(gh))
+        fr = FrustumFrame(T.ctypes.data, cam[0], cam[1], cam[2], cam[3], cam[4], float(minx), float(maxx), float(miny), float(maxy), thr.ctypes.data, len(sf), 1)
+        P = LocalPoints(pos.ctypes.data, nrm.ctypes.data, mx.ctypes.data, mn.ctypes.data, md.ctypes.data, obs.ctypes.data, m)
+        out, nm = np.full(max(n, 1), -1, np.int32), ctypes.c_int32()
+        z = lambda dt: np.zeros(max(m, 1), dt)
+        iv, px, py, pxr, lvl, vc = z(np.uint8), z(np.float32), z(np.float32), z(np.float32), z(np.int32), z(np.float32)
+        self._L.orbx_search_local_points.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float] + [ctypes.c_void_p] * 8
+        _check(self._L.orbx_search_local_points(self._h, ctypes.byref(F), ctypes.byref(fr), ctypes.byref(P), _ptr(sf), len(sf), ctypes.c_float(viewing_cos_limit),
+                                                ctypes.c_float(th), ctypes.c_float(self.nnratio if nnratio is None else nnratio), _ptr(out), ctypes.byref(nm),
+                                                _ptr(iv), _ptr(px), _ptr(py), _ptr(pxr), _ptr(lvl), _ptr(vc)))
+        return nm.value, out[:n], dict(in_view=iv[:m], proj_x=px[:m], proj_y=py[:m], proj_xr=pxr[:m], level=lvl[:m], view_cos=vc[:m])
 
     def SearchByProjectionLast(self, frame, last, th, mono):
         """ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (reference

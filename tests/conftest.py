@@ -25,3 +25,14 @@ def oracle():
     """CPU checkers (test infrastructure): restatement + compiled reference when present."""
     import oracle_lib
     return oracle_lib.Oracle()
+
+
+@pytest.fixture(autouse=True)
+def _native_backtrace_on_crash():
+    """Debug aid: ORBX_SEGV_BT=<path of a .so exporting segv_bt_install()> (re)installs a SIGSEGV / SIGABRT handler that prints the native
+    backtrace before every test (the HIP runtime replaces handlers installed earlier)."""
+    p = os.environ.get("ORBX_SEGV_BT")
+    if p:
+        import ctypes
+        ctypes.CDLL(p).segv_bt_install()
+    yield

@@ -108,3 +108,37 @@ def test_search_local_points_edge_cases(orbx):
     asked = sc["bad"] == 0
     assert got["nm"] == want["nm"] == 0 and (got["in_view"][asked] == want["in_view"][asked]).all() and (got["visible"] == want["visible"]).all()
     assert (want["in_view"][asked] == 1).sum() > 20
+
+
+def _struct_kps(orbx, k7):
+    k = np.zeros(len(k7), orbx.KEYPOINT_DTYPE)
+    for j, c in enumerate(("x", "y", "size", "angle", "response")):
+        k[c] = k7[:, j]
+    k["octave"], k["class_id"] = k7[:, 5].astype(np.int32), k7[:, 6].astype(np.int32)
+    return k
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(oracle_lib.slam_lib() is None, reason="oracle/_ref/liborbslam.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed,th", [(31, 1.0), (32, 4.0)])
+def test_chained_call_equals_the_two_calls(orbx, seed, th):
+    """orbx_search_local_points (C ABI) = orbx_is_in_frustum followed by orbx_search_by_projection on its outputs, without the round trip."""
+    fr, sc = _scene(orbx, seed)
+    from test_frustum import _setup
+    _, _, sk, _ = _setup(orbx, seed, len(sc["pos"]))
+    r = oracle_lib.ref_is_in_frustum(sc["T"], sc["Ts"], sk, sc["pos"], 0.5)       # normals / distance ranges of MapPoints created from the source frame
+    mt = orbx.ORBmatcher(0.8, True, max_features=4096)
+    frame = dict(kps=_struct_kps(orbx, fr["k7"]), desc=fr["desc"], u_right=fr["u_right"], occupied=(fr["pre"] >= 0).astype(np.uint8),
+                 scale_factors=oracle_lib.SCALE_FACTORS, width=640, height=480)
+    pts = dict(pos=sc["pos"], normal=r["normal"], max_distance=r["max_distance"], min_distance=r["min_distance"], desc=sc["src_desc"], has_obs=sc["has_obs"])
+    cam = (500.0, 500.0, 320.0, 240.0, 40.0)
+    for rep in range(3):                                                           # (staging buffers are reused across calls)
+        nm, assigned, fv = mt.SearchLocalPoints(frame, sc["T"], cam, r["log_scale_factor"], pts, th)
+        two = mt.isInFrustum(sc["T"], cam, (0.0, 640.0, 0.0, 480.0), r["log_scale_factor"], 8, pts, 0.5)
+        assert (fv["in_view"] == two["in_view"]).all() and (two["in_view"] == r["in_view"]).all()
+        ok = two["in_view"] > 0
+        for k in ("proj_x", "proj_y", "proj_xr", "view_cos"):
+            assert (fv[k][ok].view(np.uint32) == two[k][ok].view(np.uint32)).all(), k
+        assert (fv["level"][ok] == two["level"][ok]).all()
+        n2, a2 = mt.SearchByProjection(frame, dict(two, desc=sc["src_desc"], has_obs=sc["has_obs"]), th)
+        assert nm == n2 and (assigned == a2).all() and nm > 100
