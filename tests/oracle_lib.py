@@ -244,6 +244,10 @@ def slam_hip_lib():
     SearchByBoW / DescriptorDistance / ComputeStereoMatches linked in (oracle/Makefile)."""
     global _slam_hip
     if _slam_hip is None and SLAM_HIP_SO.exists():
+        # liborbx.so (and with it the HIP / HSA runtime) is loaded on its own FIRST: brought in as a mere dependency of this library it
+        # would share its lookup scope (see oracle/exports.map for what that did to operator new before the checker libraries hid theirs)
+        import importlib
+        importlib.import_module("self_commit_orb-slam2_amd").load_library()
         _slam_hip = ctypes.CDLL(str(SLAM_HIP_SO))
     return _slam_hip
 

@@ -12,7 +12,7 @@ import pytest
 import oracle_lib
 from test_frustum import _setup
 
-HAVE_REF = oracle_lib.slam_lib() is not None and oracle_lib.slam_hip_lib() is not None
+HAVE_REF = oracle_lib.SLAM_SO.exists() and oracle_lib.SLAM_HIP_SO.exists()      # (libraries are loaded inside the tests, liborbx.so first)
 
 
 def _call(lib, fr, sc, th):
