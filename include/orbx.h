@@ -39,18 +39,6 @@ const char *orbx_last_error(void);
 int orbx_version(void);
 
 /* ------------------------------------------------------------------------------------
- * Synthetic input frames (host, integer-only, deterministic).  Not part of the
- * reference: datasets are absent, every benchmark/parity input comes from here.
- * ---------------------------------------------------------------------------------- */
-#define ORBX_SYNTH_LOW_TEXTURE 1  /* few shapes, +-2 noise: hits the minThFAST fallback */
-#define ORBX_SYNTH_STEREO_RIGHT 2 /* right view of the same scene, per-shape disparity   */
-int orbx_synth_frame(uint64_t seed, int width, int height, int stride, int flags, uint8_t *dst);
-/* View `view` of scene `seed`: all shapes translated by (dx,dy) pixels, fresh noise per view
- * (consecutive views share most corners: frame-to-frame matching has something to match). */
-int orbx_synth_frame_ex(uint64_t seed, int view, int dx, int dy, int width, int height, int stride,
-                        int flags, uint8_t *dst);
-
-/* ------------------------------------------------------------------------------------
  * ORB extractor  ==  ORB_SLAM2::ORBextractor
  * ---------------------------------------------------------------------------------- */
 typedef struct orbx_extractor orbx_extractor;

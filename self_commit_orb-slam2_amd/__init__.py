@@ -62,8 +62,6 @@ def load_library():
     L.orbx_last_error.restype = ctypes.c_char_p
     L.orbx_stage_name.restype = ctypes.c_char_p
     L.orbx_stage_name.argtypes = [ctypes.c_int]
-    L.orbx_synth_frame.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    L.orbx_synth_frame_ex.argtypes = [ctypes.c_uint64] + [ctypes.c_int] * 7 + [ctypes.c_void_p]
     vp, ci = ctypes.c_void_p, ctypes.c_int
     L.orbx_extractor_create.argtypes = [ctypes.POINTER(ExtractorConfig), ctypes.POINTER(vp)]
     L.orbx_extractor_destroy.argtypes = [vp]
@@ -91,6 +89,17 @@ def load_library():
     return L
 
 
+_synth = None
+
+
+def _synth_lib():
+    global _synth
+    if _synth is None:
+        _synth = ctypes.CDLL(str(build_mod.build_synth(verbose=False)))
+        _synth.orbx_synth_frame_ex.argtypes = [ctypes.c_uint64] + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+    return _synth
+
+
 def _check(rc):
     if rc != ORBX_OK:
         raise OrbxError(rc, load_library().orbx_last_error().decode("utf-8", "replace"))
@@ -101,9 +110,10 @@ def _ptr(a):
 
 
 def synth_frame(seed, width, height, flags=0, view=0, dx=0, dy=0):
-    """Deterministic synthetic grayscale frame (orbx_synth_frame / orbx_synth_frame_ex)."""
+    """Deterministic synthetic grayscale frame (synth/orbx_synth.cc in liborbx_synth.so: a test / bench helper, not part of liborbx.so)."""
     im = np.empty((height, width), np.uint8)
-    _check(load_library().orbx_synth_frame_ex(ctypes.c_uint64(seed), view, dx, dy, width, height, width, flags, _ptr(im)))
+    if _synth_lib().orbx_synth_frame_ex(ctypes.c_uint64(seed), view, dx, dy, width, height, width, flags, _ptr(im)) != ORBX_OK:
+        raise ValueError("bad synthetic frame arguments")
     return im
 
 

@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "liborbx.so"
-HIP_SOURCES = ["orbx_kernels.hip", "orbx_extractor.hip", "orbx_match.hip", "orbx_match_proj.hip", "orbx_lba.hip", "orbx_bow.hip", "orbx_frame.hip", "orbx_synth.cc"]
+HIP_SOURCES = ["orbx_kernels.hip", "orbx_extractor.hip", "orbx_match.hip", "orbx_match_proj.hip", "orbx_lba.hip", "orbx_bow.hip", "orbx_frame.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
              "-Wall", "-Wno-unused-function"]
 
@@ -86,6 +86,29 @@ def _build_liborbx_locked(force, verbose):
     return LIB
 
 
+SYNTH_LIB = PKG / "lib" / "liborbx_synth.so"
+
+
+def build_synth(verbose=True):
+    """Synthetic test / bench frames (synth/orbx_synth.cc): a host-only helper library of its own, NOT part of liborbx.so."""
+    src = [PKG / "synth" / "orbx_synth.cc", PKG / "synth" / "orbx_synth.h"]
+    if _newer(SYNTH_LIB, src):
+        return SYNTH_LIB
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        if SYNTH_LIB.exists():
+            return SYNTH_LIB
+        raise RuntimeError("no C++ compiler and no prebuilt liborbx_synth.so")
+    SYNTH_LIB.parent.mkdir(parents=True, exist_ok=True)
+    tmp = SYNTH_LIB.with_suffix(".so.tmp%d" % os.getpid())
+    cmd = [cxx, "-O2", "-std=c++11", "-fPIC", "-shared", "-o", str(tmp), str(src[0])]
+    if verbose:
+        print("[build]", " ".join(cmd).replace(str(tmp), str(SYNTH_LIB)), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, SYNTH_LIB)
+    return SYNTH_LIB
+
+
 def build_oracle(verbose=True):
     """Compile the CPU checkers (test infrastructure).  oracle/_ref needs /root/reference."""
     mk = ROOT / "oracle" / "Makefile"
@@ -98,5 +121,6 @@ def build_oracle(verbose=True):
 
 def build_all(force=False, verbose=True):
     build_liborbx(force=force, verbose=verbose)
+    build_synth(verbose=verbose)
     build_oracle(verbose=verbose)
     return LIB

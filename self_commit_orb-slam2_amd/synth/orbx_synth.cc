@@ -11,7 +11,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#include "../../include/orbx.h"
+#include "orbx_synth.h"
 
 namespace {
 
@@ -79,7 +79,7 @@ extern "C" int orbx_synth_frame(uint64_t seed, int width, int height, int stride
 // their corners (a camera translating in front of a fronto-parallel scene).
 extern "C" int orbx_synth_frame_ex(uint64_t seed, int view, int dx, int dy, int width, int height, int stride, int flags, uint8_t *dst)
 {
-    if (!dst || width <= 0 || height <= 0 || stride < width) return ORBX_ERR_ARG;
+    if (!dst || width <= 0 || height <= 0 || stride < width) return -1;
     const bool low = (flags & ORBX_SYNTH_LOW_TEXTURE) != 0;
     const bool right = (flags & ORBX_SYNTH_STEREO_RIGHT) != 0;
     Rng shapes(0x9E3779B97F4A7C15ULL ^ seed);
@@ -119,5 +119,5 @@ extern "C" int orbx_synth_frame_ex(uint64_t seed, int view, int dx, int dy, int 
             row[x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
         }
     }
-    return ORBX_OK;
+    return 0;
 }
