@@ -11,9 +11,38 @@
 
 namespace {
 
-__constant__ int8_t c_pattern[1024] = {
+// rBRIEF test pairs (reference src/ORBextractor.cc:231-489) and the disc of IC_Angle (umax, :579-608 for HALF_PATCH_SIZE 15) as the
+// tables k_orient_describe copies into LDS: built at compile time from the generated pattern / the half-widths.
+struct OdTables {
+    float pat[256][4];          // test pair t: x0, x1, y0, y1 (the rotation is packed FP32 arithmetic on both points of a pair)
+    uint32_t disc[64][4];       // lane = (disc row r = lane / 2, half): byte mask of its 16-byte row segment, |u| <= umax[|r - 15|]
+};
+constexpr int8_t kPattern[1024] = {
 #include "orb_pattern.inc"
 };
+constexpr int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};      // checked against the host table at handle creation
+constexpr OdTables make_od_tables()
+{
+    OdTables t{};
+    for (int i = 0; i < 256; i++) {
+        t.pat[i][0] = (float)kPattern[4 * i]; t.pat[i][2] = (float)kPattern[4 * i + 1];
+        t.pat[i][1] = (float)kPattern[4 * i + 2]; t.pat[i][3] = (float)kPattern[4 * i + 3];
+    }
+    for (int ml = 0; ml < 64; ml++)
+        for (int j = 0; j < 4; j++) {
+            const int mr = ml >> 1, mh = ml & 1;
+            uint32_t m = 0u;
+            if (mr < 31) {
+                const int v = mr - 15, d = kUmax[v < 0 ? -v : v];
+                const int lo = mh ? 0 : 15 - d, hi = mh ? d - 1 : 15;      // valid bytes c of the segment: u = c - 15 (left half) / c + 1 (right half)
+                for (int k = 0; k < 4; k++)
+                    if (4 * j + k >= lo && 4 * j + k <= hi) m |= 0xffu << (8 * k);
+            }
+            t.disc[ml][j] = m;
+        }
+    return t;
+}
+__constant__ OdTables c_od = make_od_tables();
 
 // FAST-16 circle, OpenCV order (reference call sites src/ORBextractor.cc:1126,1135)
 #define FAST_DX(k) ((k) == 0 ? 0 : (k) == 1 ? 1 : (k) == 2 ? 2 : (k) <= 5 ? 3 : (k) == 6 ? 2 : (k) == 7 ? 1 : (k) == 8 ? 0 : (k) == 9 ? -1 : (k) == 10 ? -2 : (k) <= 13 ? -3 : (k) == 14 ? -2 : -1)
@@ -888,6 +917,19 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
 // round trip covers both stages and a load instruction touches ~7 lines.  fastAtan2 and the libm-exact sin / cos run
 // once per workgroup on four lanes (one per keypoint) between two barriers instead of on all 64 lanes of every wave.
 // ------------------------------------------------------------------------------------
+// sum over the 64 lanes with data-parallel-primitive adds (one VALU instruction per step, no LDS crossbar): quad, half row, row, then the
+// two row broadcasts of gfx9; the total lands in lane 63 and is returned as a scalar
+__device__ __forceinline__ int wave_sum_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);     // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);     // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // per-level constants of the geometry as a kernel ARGUMENT: the level lookup and the addresses come from a few wide scalar loads of the
 // kernarg segment instead of a chain of dependent loads through OrbxGeom (the prologue is most of a wave's latency here)
 struct OdLevels {
@@ -895,7 +937,6 @@ struct OdLevels {
     unsigned long long pyrBytes;
     int kpBase[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], patch[ORBX_MAX_LEVELS];
     float scale[ORBX_MAX_LEVELS];
-    int umax[16];
 };
 
 #define OD_WPB 4
@@ -910,13 +951,17 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
                                                                  int *__restrict__ outCnt, const int *__restrict__ status, int *__restrict__ outStatus)
 {
     __shared__ uint32_t sPatch[OD_WPB][OD_PATCH_DW + 2];
-    __shared__ uint32_t sPat[256];
+    __shared__ __attribute__((aligned(16))) float sPat[256][4];                  // test pair t as floats: x0, x1, y0, y1
+    __shared__ __attribute__((aligned(16))) uint32_t sDisc[64][4];               // byte masks of the disc: lane (row, half) x 4 dwords
     __shared__ int sMom[OD_WPB][3];
     __shared__ float sTrig[OD_WPB][3];
     XCD_REMAP_XY(bx, f);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // uniform: the keypoint bookkeeping below is scalar work
-    sPat[threadIdx.x] = ((const uint32_t *)c_pattern)[threadIdx.x];              // the 256 test pairs (x0, y0, x1, y1 as int8), once per workgroup
+    if (threadIdx.x < 256) {     // once per workgroup: both constant tables into LDS
+        *(float4 *)sPat[threadIdx.x] = *(const float4 *)c_od.pat[threadIdx.x];
+        ((uint32_t *)sDisc)[threadIdx.x] = ((const uint32_t *)c_od.disc)[threadIdx.x];
+    }
     const int slot = bx * OD_WPB + wv;
     const int *cnts = lvlCnt + f * A.nlevels;
     if (bx == 0 && threadIdx.x == 0) {
@@ -954,14 +999,13 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
     const int xa = (kx - OD_R) & ~3;
     int m10 = 0, m01 = 0;
     uint2 pw[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    uint4 wd = make_uint4(0u, 0u, 0u, 0u);
+    const int r = lane >> 1, hf = lane & 1;      // disc row r, bytes x - 15 + 16 * half .. + 15 (19 <= x < w - 19: inside the level)
     if (inRange) {
         const int bp = A.pitch[l], up = l ? bp : img0Stride;
         const uint8_t *unb = l ? pyr + (size_t)f * A.pyrBytes + A.off[l] : img0 + (size_t)f * img0FramePitch;
         const uint8_t *bl = blur + (size_t)f * A.pyrBytes + A.off[l];
-        // disc row r = lane / 2, bytes x - 15 + 16 * half .. + 15 (19 <= x < w - 19: inside the level): ONE 16-byte load per lane
-        const int r = lane >> 1, hf = lane & 1;
-        uint4 wd = make_uint4(0u, 0u, 0u, 0u);
-        if (r < 31) __builtin_memcpy(&wd, unb + (size_t)(ky + r - 15) * up + (kx - 15 + 16 * hf), 16);
+        if (r < 31) __builtin_memcpy(&wd, unb + (size_t)(ky + r - 15) * up + (kx - 15 + 16 * hf), 16);     // ONE 16-byte load per lane
         // patch: 37 rows x 5 aligned 8-byte units
 #pragma unroll
         for (int t = 0; t < 3; t++) {
@@ -971,25 +1015,21 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
                 __builtin_memcpy(&pw[t], bl + (size_t)(ky - OD_R + pr) * bp + xa + 8 * pc, 8);
             }
         }
-        if (r < 31) {
-            const int v = r - 15, d = A.umax[v < 0 ? -v : v];
-            const uint32_t w4[4] = {wd.x, wd.y, wd.z, wd.w};
-            int s1 = 0, su = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int u = 16 * hf + 4 * j + k - 15;                      // hf is a lane value: u = c - 15 or c + 1
-                    const int I = ((u < 0 ? -u : u) <= d && u <= 15) ? (int)((w4[j] >> (8 * k)) & 0xff) : 0;
-                    s1 += I;
-                    su += u * I;
-                }
-            m10 = su;
-            m01 = v * s1;
-        }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    __syncthreads();           // the tables are in LDS (the pixel loads are in flight meanwhile)
+    if (inRange && r < 31) {
+        // integer moments of the row segment: sum I and sum (u + 15) I as v_dot4_u32_u8 over the masked bytes, u + 15 = c (left half) / c + 16 (right half)
+        const uint4 mk = *(const uint4 *)sDisc[lane];
+        const uint32_t wb = hf ? 0x10101010u : 0u;
+        uint32_t s1 = 0u, sw = 0u;
+        s1 = __builtin_amdgcn_udot4(wd.x & mk.x, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.x & mk.x, 0x03020100u + wb, sw, false);
+        s1 = __builtin_amdgcn_udot4(wd.y & mk.y, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.y & mk.y, 0x07060504u + wb, sw, false);
+        s1 = __builtin_amdgcn_udot4(wd.z & mk.z, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.z & mk.z, 0x0b0a0908u + wb, sw, false);
+        s1 = __builtin_amdgcn_udot4(wd.w & mk.w, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.w & mk.w, 0x0f0e0d0cu + wb, sw, false);
+        m10 = (int)sw - 15 * (int)s1;
+        m01 = (r - 15) * (int)s1;
+    }
+    m10 = wave_sum_dpp(m10); m01 = wave_sum_dpp(m01);        // totals as wave-uniform scalars
     if (lane == 0) { sMom[wv][0] = m01; sMom[wv][1] = m10; sMom[wv][2] = live ? slot : -1; }
     if (live) {
 #pragma unroll
@@ -1013,15 +1053,19 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
     const float a = sTrig[wv][0], b = sTrig[wv][1];
     const uint8_t *pb = (const uint8_t *)sPatch[wv] + OD_R * (4 * OD_DW) + (kx - xa);     // the keypoint's own pixel
     unsigned long long bits[4];
+    typedef float f2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t pat = sPat[64 * r + lane];
-        const float x0 = (float)(int8_t)(pat & 0xff), y0 = (float)(int8_t)((pat >> 8) & 0xff);
-        const float x1 = (float)(int8_t)((pat >> 16) & 0xff), y1 = (float)(int8_t)(pat >> 24);
-        const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
-        const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
-        const int t0 = pb[r0 * (4 * OD_DW) + c0], t1 = pb[r1 * (4 * OD_DW) + c1];
-        bits[r] = __ballot(t0 < t1);
+    for (int rd = 0; rd < 4; rd++) {
+        // both points of test pair 64 rd + lane at once (v_pk_mul_f32 / v_pk_add_f32: every product and sum is rounded on its own, exactly
+        // like the scalar expressions of src/ORBextractor.cc:192-193 compiled without contraction)
+        const float4 pt = *(const float4 *)sPat[64 * rd + lane];
+        const f2_t xs = {pt.x, pt.y}, ys = {pt.z, pt.w};
+        const f2_t rr = xs * b + ys * a, cc = xs * a - ys * b;
+        // cvRound of both coordinates, then row * 40 + column: small integers, exact in float
+        const int o0 = (int)__builtin_fmaf(__builtin_rintf(rr.x), (float)(4 * OD_DW), __builtin_rintf(cc.x));
+        const int o1 = (int)__builtin_fmaf(__builtin_rintf(rr.y), (float)(4 * OD_DW), __builtin_rintf(cc.y));
+        const int t0 = pb[o0], t1 = pb[o1];
+        bits[rd] = __ballot(t0 < t1);
     }
     unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * A.outCap + outIdx) * 32);
     if (lane < 4) d64[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
@@ -1120,7 +1164,8 @@ int orbx_launch_orient_describe(const OrbxLaunch &L)
     memset(&A, 0, sizeof(A));
     A.nlevels = g.nlevels; A.kpPerFrame = g.kpPerFrame; A.outCap = g.outCap; A.pyrBytes = g.pyrBytes;
     for (int l = 0; l < g.nlevels; l++) { A.kpBase[l] = g.lv[l].kpBase; A.off[l] = g.lv[l].off; A.pitch[l] = g.lv[l].pitch; A.patch[l] = g.lv[l].patchSize; A.scale[l] = g.lv[l].scale; }
-    for (int i = 0; i < 16; i++) A.umax[i] = g.umax[i];
+    for (int i = 0; i < 16; i++)
+        if (g.umax[i] != kUmax[i]) { orbx_set_error("disc half-widths differ from the compiled table"); return ORBX_ERR_STATE; }
     return emit(L, k_orient_describe, grid, dim3(64 * OD_WPB), 0, A, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc,
                 L.outCnt, L.status, L.outStatus);
 }
