@@ -81,7 +81,7 @@ struct orbx_extractor {
     DevBuf<OrbxGeom> geomDev;
     DevBuf<uint8_t> binDev, pyr, blur, score, staging;
     DevBuf<uint32_t> rsDev;
-    DevBuf<int> cellCount, lvlCnt, status;
+    DevBuf<int> cellCount, lvlCnt, lvlBase, status;
     // results are double buffered: a consumer (matcher) may still read batch i while batch i+1 is
     // extracted; consumerEv[b] = event after which buffer b may be overwritten again
     // counts | capacity words | keypoints | descriptors of a buffer live in ONE allocation, so that a whole-batch read-back is one copy
@@ -345,7 +345,8 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
         if ((rc = h->ptBuf.ensure(B * g.slotsPerFrame)) != ORBX_OK) return rc;     // every candidate the detector can emit: no capacity error
         if ((rc = h->labBuf.ensure(B * g.slotsPerFrame)) != ORBX_OK) return rc;
         if ((rc = h->lvlKp.ensure(B * g.kpPerFrame)) != ORBX_OK) return rc;
-        if ((rc = h->lvlCnt.ensure(B * g.nlevels + 16)) != ORBX_OK) return rc;      // (+16: the descriptor kernel reads a frame's counts as ORBX_MAX_LEVELS unconditional words)
+        if ((rc = h->lvlCnt.ensure(B * g.nlevels)) != ORBX_OK) return rc;
+        if ((rc = h->lvlBase.ensure(B * g.nlevels)) != ORBX_OK) return rc;
         h->arenaKpOff = align_up((2 * B + 1) * sizeof(int), 256);
         h->arenaDescOff = h->arenaKpOff + align_up(B * g.outCap * sizeof(orbx_keypoint), 256);
         h->arenaBytes = h->arenaDescOff + B * g.outCap * 32;
@@ -373,7 +374,7 @@ void fill_launch(orbx_extractor *h, OrbxLaunch &L, const uint8_t *img0Dev, int b
     L.binTab = h->binDev.p;
     L.rsTab = h->rsDev.p;
     L.cellCount = h->cellCount.p; L.cellSlots = h->cellSlots.p; L.ptBuf = h->ptBuf.p; L.labBuf = h->labBuf.p;
-    L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outKp = h->outKpP[cb]; L.outDesc = h->outDescP[cb]; L.outCnt = h->outCntP[cb];
+    L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outBase = h->lvlBase.p; L.outKp = h->outKpP[cb]; L.outDesc = h->outDescP[cb]; L.outCnt = h->outCntP[cb];
     L.status = h->status.p; L.outStatus = h->outStP[cb]; L.nodeCap = h->nodeCap;
 }
 
@@ -517,7 +518,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     h->geomDev.release(); h->binDev.release(); h->rsDev.release(); h->pyr.release(); h->blur.release();
     if (h->hostStaging) { (void)hipHostFree(h->hostStaging); h->hostStaging = nullptr; h->hostStagingBytes = 0; }
     if (h->hostOut) { (void)hipHostFree(h->hostOut); h->hostOut = nullptr; h->hostOutBytes = 0; }
-    h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release();
+    h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release(); h->lvlBase.release();
     for (int b = 0; b < 2; b++) h->outArena[b].release();
     h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->labBuf.release(); h->lvlKp.release();
     for (int r = 0; r < ORBX_PROF_RING; r++)

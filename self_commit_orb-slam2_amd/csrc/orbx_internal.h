@@ -85,6 +85,7 @@ struct OrbxLaunch {
     uint32_t *ptBuf, *labBuf;     /* quadtree: candidates of a level in list order and their node labels; slotsPerFrame u32 per frame each */
     OrbxLevelKp *lvlKp;
     int *lvlCnt;                  /* nlevels per frame */
+    int *outBase;                 /* nlevels per frame: first output index of each level's keypoints (k_blur -> k_orient_describe) */
     orbx_keypoint *outKp;
     uint8_t *outDesc;
     int *outCnt;

@@ -817,11 +817,18 @@ __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
-                                             const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur)
+                                             const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, const int *__restrict__ lvlCnt, int *__restrict__ outBase)
 {
     __shared__ __attribute__((aligned(16))) uint32_t in[BT_IH * (BT_P / 4)];
     XCD_REMAP_XY(bx, f);
     const int lane = threadIdx.x;
+    if (bx == 0 && lane == 0) {
+        // rides along (the quadtree precedes this kernel, the descriptor kernel follows it): where each level's keypoints start in the frame's
+        // output list (level 0..n-1 in order, src/ORBextractor.cc:1577-1668), so that the per-keypoint waves of k_orient_describe need two
+        // scalar loads instead of a prefix sum over the levels each
+        int run = 0;
+        for (int i = 0; i < g->nlevels; i++) { outBase[f * g->nlevels + i] = run; run += lvlCnt[f * g->nlevels + i]; }
+    }
     int bases[ORBX_MAX_LEVELS];
     const int nl = g->nlevels;
     for (int i = 0; i < nl; i++) bases[i] = g->lv[i].blurTileBase;
@@ -947,8 +954,9 @@ struct OdLevels {
 
 __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels A, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
                                                                  const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, OrbxLevelKp *__restrict__ lvlKp,
-                                                                 const int *__restrict__ lvlCnt, orbx_keypoint *__restrict__ outKp, uint8_t *__restrict__ outDesc,
-                                                                 int *__restrict__ outCnt, const int *__restrict__ status, int *__restrict__ outStatus)
+                                                                 const int *__restrict__ lvlCnt, const int *__restrict__ outBase, orbx_keypoint *__restrict__ outKp,
+                                                                 uint8_t *__restrict__ outDesc, int *__restrict__ outCnt, const int *__restrict__ status,
+                                                                 int *__restrict__ outStatus)
 {
     __shared__ uint32_t sPatch[OD_WPB][OD_PATCH_DW + 2];
     __shared__ __attribute__((aligned(16))) float sPat[256][4];                  // test pair t as floats: x0, x1, y0, y1
@@ -978,20 +986,13 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
     bool inRange = slot < A.kpPerFrame;
     int l = 0, kb = 0;
 #pragma unroll
-    for (int i = 1; i < ORBX_MAX_LEVELS; i++) {
-        const bool ge = i < A.nlevels && slot >= A.kpBase[i];
-        l = ge ? i : l; kb = ge ? A.kpBase[i] : kb;
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++) {      // (entries past the last level hold INT_MAX)
+        const bool ge = slot >= A.kpBase[i];
+        l += ge ? 1 : 0; kb = ge ? A.kpBase[i] : kb;
     }
-    int cn[ORBX_MAX_LEVELS];
-#pragma unroll
-    for (int i = 0; i < ORBX_MAX_LEVELS; i++) cn[i] = cnts[i];       // unconditional (the array is padded): a few wide scalar loads
-    int outIdx = slot - kb, pre = 0, cl = cn[0];
-#pragma unroll
-    for (int i = 1; i < ORBX_MAX_LEVELS; i++) {
-        pre += cn[i - 1];
-        if (i == l) { outIdx += pre; cl = cn[i]; }
-    }
-    inRange = inRange && slot - kb < cl && outIdx < A.outCap;
+    const int idx = slot - kb;
+    const int outIdx = outBase[f * A.nlevels + l] + idx;                             // level prefix from k_blur
+    inRange = inRange && idx < cnts[l] && outIdx < A.outCap;
     const bool live = inRange;
     const uint2 kraw = *(const uint2 *)&lvlKp[(size_t)f * A.kpPerFrame + (inRange ? slot : 0)];     // x | y << 16, score | pad: the first 8 bytes of OrbxLevelKp
     const int kx = (int)(kraw.x & 0xffffu), ky = (int)(kraw.x >> 16);
@@ -1153,7 +1154,7 @@ int orbx_launch_octree(const OrbxLaunch &L)
 int orbx_launch_blur(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->blurTiles, (unsigned)L.batch);
-    return emit(L, k_blur, grid, dim3(64), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur);
+    return emit(L, k_blur, grid, dim3(64), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlCnt, L.outBase);
 }
 
 int orbx_launch_orient_describe(const OrbxLaunch &L)
@@ -1163,9 +1164,10 @@ int orbx_launch_orient_describe(const OrbxLaunch &L)
     OdLevels A;
     memset(&A, 0, sizeof(A));
     A.nlevels = g.nlevels; A.kpPerFrame = g.kpPerFrame; A.outCap = g.outCap; A.pyrBytes = g.pyrBytes;
+    for (int l = 0; l < ORBX_MAX_LEVELS; l++) A.kpBase[l] = 0x7fffffff;
     for (int l = 0; l < g.nlevels; l++) { A.kpBase[l] = g.lv[l].kpBase; A.off[l] = g.lv[l].off; A.pitch[l] = g.lv[l].pitch; A.patch[l] = g.lv[l].patchSize; A.scale[l] = g.lv[l].scale; }
     for (int i = 0; i < 16; i++)
         if (g.umax[i] != kUmax[i]) { orbx_set_error("disc half-widths differ from the compiled table"); return ORBX_ERR_STATE; }
-    return emit(L, k_orient_describe, grid, dim3(64 * OD_WPB), 0, A, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.outKp, L.outDesc,
+    return emit(L, k_orient_describe, grid, dim3(64 * OD_WPB), 0, A, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.outBase, L.outKp, L.outDesc,
                 L.outCnt, L.status, L.outStatus);
 }
