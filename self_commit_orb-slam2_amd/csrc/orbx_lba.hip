@@ -2351,11 +2351,12 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     hub.dsqrMono = (float)(hub.dMono * hub.dMono); hub.dsqrStereo = (float)(hub.dStereo * hub.dStereo);   // dsqr is a float member in this fork
     int maxCount = 0;
     for (int i = 0; i < B; i++) maxCount = std::max(maxCount, std::min((int)p->counts[i], cap));
-    if (maxCount > 256 * 16) { orbx_set_error("%d correspondences in a frame exceed the pose optimizer's limit %d", maxCount, 256 * 16); return ORBX_ERR_CAPACITY; }
+    if (maxCount > 256 * 32) { orbx_set_error("%d correspondences in a frame exceed the pose optimizer's limit %d", maxCount, 256 * 32); return ORBX_ERR_CAPACITY; }
     if (maxCount <= 256 * 2) hipLaunchKernelGGL(k_pose_opt<2>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
     else if (maxCount <= 256 * 4) hipLaunchKernelGGL(k_pose_opt<4>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
     else if (maxCount <= 256 * 8) hipLaunchKernelGGL(k_pose_opt<8>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
-    else hipLaunchKernelGGL(k_pose_opt<16>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (maxCount <= 256 * 16) hipLaunchKernelGGL(k_pose_opt<16>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else hipLaunchKernelGGL(k_pose_opt<32>, dim3((unsigned)B), dim3(256), 0, st, D, hub);      // up to 8192 correspondences: 32 per thread, one wave per SIMD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     ORBX_HIP_CHECK(hipStreamSynchronize(st));

@@ -78,3 +78,22 @@ def test_null_handles_and_bad_arguments_are_errors_not_crashes(orbx):
     assert L.orbx_predict_scale_thresholds(ctypes.c_float(0.1823), 0, th) < 0          # nlevels out of range
     assert L.orbx_predict_scale_thresholds(ctypes.c_float(-1.0), 8, th) < 0            # log of a scale factor <= 1
     assert L.orbx_predict_scale_thresholds(ctypes.c_float(0.1823), 8, th) == 0 and th[0] == 1.0   # ratio <= 1 is level 0
+
+
+def test_extractor_tables_without_a_device(orbx, oracle):
+    """orbx_extractor_tables_for: ORBextractor's constructor tables (src/ORBextractor.cc:499-554) from the configuration alone - what the drop-in
+    constructor serves its getters from even when no HIP device can be opened - equal the compiled reference's (the restatement's, where
+    oracle/_ref is not built) bit for bit, on a box without a GPU."""
+    import numpy as np
+    L = orbx.load_library()
+    for nf, sf, nl in ((1000, 1.2, 8), (2000, 1.2, 8), (1200, 1.2, 8), (500, 1.5, 5), (3000, 1.1, 12), (1, 2.0, 1)):
+        cfg = orbx.ExtractorConfig(nf, sf, nl, 20, 7, 0, 0, 0, 0)
+        t = [np.zeros(nl, np.float32) for _ in range(4)]
+        q = np.zeros(nl, np.int32)
+        L.orbx_extractor_tables_for.argtypes = [ctypes.c_void_p] * 6
+        assert L.orbx_extractor_tables_for(ctypes.byref(cfg), *[a.ctypes.data_as(ctypes.c_void_p) for a in t], q.ctypes.data_as(ctypes.c_void_p)) == 0
+        ext = oracle.reference(nf, sf, nl) if oracle.ref is not None else oracle.restatement(nf, sf, nl)
+        wt, wq, _ = ext.tables()
+        assert all((a.view(np.uint32) == b.view(np.uint32)).all() for a, b in zip(t, wt)) and (q == wq).all() and q.sum() >= nf
+    bad = orbx.ExtractorConfig(1000, 1.0, 8, 20, 7, 0, 0, 0, 0)
+    assert L.orbx_extractor_tables_for(ctypes.byref(bad), None, None, None, None, None) < 0
