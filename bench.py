@@ -123,7 +123,7 @@ def _profile_json(name):
 
 def pmc_traffic(stage, frames_per_launch, name="latest_hbm_traffic.json"):
     """HBM bytes per launch of the stage's kernel(s) from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
-    runs of this same command, tools/run_profiles.sh + tools/summarize_profile.py; units and the gfx950 corrections as
+    runs of this same command, tools/run_profiles.sh + tools/summarize_all.py; units and the gfx950 corrections as
     profiles/README.md states them).  None when no pass is committed for this launch size."""
     t = _profile_json(name)
     if not t or t.get("_frames_per_launch") != frames_per_launch:
