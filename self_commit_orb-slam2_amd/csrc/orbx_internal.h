@@ -54,7 +54,7 @@ struct OrbxGeom {
 };
 
 /* level-coordinates keypoint produced by the quadtree + orientation stages */
-/* ca / sb = cos / sin of the angle as the reference's libm rounds them; k_orient fills them with the angle */
+/* ca / sb = cos / sin of the angle as the reference's libm rounds them; k_orient_describe fills them with the angle (read back by the stage taps only) */
 struct OrbxLevelKp { uint16_t x, y; uint8_t score, pad[3]; float angle, ca, sb; };
 
 void orbx_set_error(const char *fmt, ...);
@@ -90,7 +90,7 @@ struct OrbxLaunch {
     uint8_t *outDesc;
     int *outCnt;
     int *status;                  /* per frame error bits (scratch of the running batch; [batch] = OR over the batch) */
-    int *outStatus;               /* snapshot of `status` in the result buffer (written by k_describe, guarded like the results) */
+    int *outStatus;               /* snapshot of `status` in the result buffer (written by k_orient_describe, guarded like the results) */
     int nodeCap;                  /* 256 / 512 / 1024 / 2048 */
     /* graph construction (single-frame call): when `graph` is set, a launcher adds a kernel node that depends on deps[0..ndeps)
      * and returns it in *node instead of launching on `stream` */

@@ -1,10 +1,11 @@
 // orbx_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ORB extractor.
 //
-// One kernel per stage of ORB_SLAM2::ORBextractor::operator() (reference
-// src/ORBextractor.cc:1544-1668); every launch covers the whole batch
-// (blockIdx.y = frame) and, where the stage has no level-to-level dependency, all
-// pyramid levels at once (blockIdx.x -> (level, tile) through OrbxGeom).
-// Integer / byte work bounded by HBM and VALU issue; no MFMA (DESIGN.md section 4).
+// The stages of ORB_SLAM2::ORBextractor::operator() (reference src/ORBextractor.cc:1544-1668) as
+// k_resize (x7), k_fast_cells, k_octree, k_blur, k_orient_describe; every launch covers the whole
+// batch (blockIdx.y = frame) and, where the stage has no level-to-level dependency, all pyramid
+// levels at once (blockIdx.x -> (level, tile) through OrbxGeom).  All launches go through emit():
+// onto a stream, or as nodes of the single-frame hipGraph.
+// Integer / byte work bounded by HBM and VALU issue; no MFMA (DESIGN.md section 5).
 // Compiled with -ffp-contract=off: the few float expressions must round exactly like
 // the un-fused scalar reference.
 #include "orbx_internal.h"
@@ -102,7 +103,7 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
 // never a correctness one), and every XCD has its own 4 MiB L2.  With the natural (item, frame) order, horizontally adjacent
 // tiles / cells of an image - which share the 128-byte lines that their 80-byte window rows straddle, and their halos - run on
 // eight different XCDs, each of which fetches the shared lines from the fabric again (rocprofv3 FETCH_SIZE: 4.4x the level
-// pixels for k_blur, 4.7x for k_fast_cells, 5.2x for k_describe's gathers).  This bijection hands every XCD one CONTIGUOUS range
+// pixels for k_blur, 4.7x for k_fast_cells, 5.2x for the descriptor kernel's gathers).  This bijection hands every XCD one CONTIGUOUS range
 // of the (frame, item) space instead, so neighbours meet in one L2 and a frame's images are fetched by one XCD.
 //   linear = by * gx + bx;  XCD x owns [x*q + min(x, r), ...) with q = total / 8, r = total % 8;  slot = linear / 8.
 // ---------------------------------------------------------------------------------------------
