@@ -114,6 +114,9 @@ ODD = [
     (640, 480, 2000, 1.2, 8, 20, 7),      # the 2*nFeatures monocular-initialisation extractor (src/Tracking.cc:192)
     (640, 480, 1000, 1.5, 4, 20, 7),
     (500, 375, 800, 1.1, 12, 20, 7),
+    (1920, 1080, 5000, 1.2, 8, 20, 7),    # level quotas above 1024: the 2048-node quadtree
+    (640, 480, 30, 1.2, 8, 20, 7),        # quotas of 2 .. 7 keypoints per level
+    (640, 480, 800, 1.2, 1, 20, 7),       # a single level
 ]
 
 
@@ -130,6 +133,13 @@ def test_ragged_geometries_bit_exact(orbx, oracle, W, H, nf, sf, nl, ini, mn):
         assert (kp_matrix(kps[f, :n]).view(np.uint32) == ko.view(np.uint32)).all(), f
         assert (desc[f, :n] == do).all(), f
     ext.close()
+    # the same geometry through the single-frame call of a one-frame handle (one hipGraph launch per frame), twice: both result buffers
+    one = orbx.ORBextractor(nf, sf, nl, ini, mn, max_width=W, max_height=H)
+    for f in (0, 1):
+        k, d = one(frames[f])
+        ko, do = rst.extract(frames[f])
+        assert len(k) == len(ko) and (kp_matrix(k).view(np.uint32) == ko.view(np.uint32)).all() and (d == do).all(), f
+    one.close()
 
 
 def test_tight_device_stride(orbx, oracle):
