@@ -703,6 +703,16 @@ ORBSLAM_API int orbslam_is_in_frustum(const float *Tcw, const float *TcwSrc, con
     return nIn;
 }
 
+#ifdef ORBSLAM_HIP
+// default of the drop-in extractor's mbKeepHostPyramid in THIS library, where shim/Frame_hip.cc is linked (its ComputeStereoMatches reads the
+// device pyramid, so the per-frame host copy is off)
+ORBSLAM_API int orbslam_extractor_keeps_host_pyramid()
+{
+    ORBextractor e(1000, 1.2f, 8, 20, 7);
+    return e.mbKeepHostPyramid ? 1 : 0;
+}
+#endif
+
 // Tracking::SearchLocalPoints (src/Tracking.cc:1760-1830) on a real Frame and real MapPoints.  Tracking.cc itself cannot be compiled here
 // (Viewer / Pangolin), so the all-reference build runs the function's three steps as they stand there - step 1 over F.mvpMapPoints,
 // Frame::isInFrustum per local point, ORBmatcher(0.8).SearchByProjection(F, points, th) - and the drop-in build runs

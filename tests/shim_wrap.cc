@@ -41,6 +41,17 @@ extern "C" int shim_pyramid_level(void *h, int level, unsigned char *dst, int *w
 
 extern "C" int shim_levels(void *h) { return ((ORB_SLAM2::ORBextractor *)h)->GetLevels(); }
 
+// what the reference's own Frame::ComputeStereoMatches would find in the public member right after operator() (src/Frame.cc:1044,1248): the
+// flag's default, and the size of a level WITHOUT an explicit DownloadImagePyramid()
+extern "C" int shim_keeps_host_pyramid(void *h) { return ((ORB_SLAM2::ORBextractor *)h)->mbKeepHostPyramid ? 1 : 0; }
+extern "C" int shim_pyramid_level_as_is(void *h, int level, unsigned char *dst, int *w, int *hgt)
+{
+    const cv::Mat &m = ((ORB_SLAM2::ORBextractor *)h)->mvImagePyramid[level];
+    *w = m.cols; *hgt = m.rows;
+    for (int y = 0; y < m.rows; y++) memcpy(dst + (size_t)y * m.cols, m.ptr(y), (size_t)m.cols);
+    return 0;
+}
+
 // Latency of the reference's call shape, one frame per call on one thread (tools/latency_shim.py): mean / median microseconds of
 // `iters` calls of (*extractor)(im, cv::Mat(), keys, desc) cycling through `nimg` images; keep_pyr sets mbKeepHostPyramid.
 #include <algorithm>

@@ -61,3 +61,35 @@ def test_shim_equals_reference_class(orbx, oracle):
             L.shim_pyramid_level(h, l, P(buf), ctypes.byref(w), ctypes.byref(hh))
             assert (w.value, hh.value) == (pyr[l].shape[1], pyr[l].shape[0]) and (buf == pyr[l]).all()
     L.shim_destroy(h)
+
+
+@pytest.mark.gpu
+def test_host_pyramid_is_kept_unless_the_device_stereo_body_is_linked(orbx, oracle):
+    """A build that swaps ONLY the extractor keeps the reference's Frame::ComputeStereoMatches, which reads the public mvImagePyramid right
+    after operator() (src/Frame.cc:1044,1248): in this wrapper library shim/Frame_hip.cc is not linked, so mbKeepHostPyramid must default to
+    true and every call must leave the current frame's pyramid in the member - no explicit download, no stale frame.  (In
+    oracle/_ref/liborbslam_hip.so, where Frame_hip.cc IS linked, the default is false: tests/test_dropin_slam.py's stereo constructor test
+    runs in that configuration.)"""
+    orbx.load_library()
+    build_shim()
+    L = ctypes.CDLL(str(SO))
+    L.shim_create.restype = ctypes.c_void_p
+    L.shim_create.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    h = ctypes.c_void_p(L.shim_create(1000, 1.2, 8, 20, 7))
+    assert h.value and L.shim_keeps_host_pyramid(h) == 1
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rst = oracle.restatement(1000)
+    for seed in (51, 52):
+        im = orbx.synth_frame(seed, 640, 480)
+        k, d = np.zeros((4096, 7), np.float32), np.zeros((4096, 32), np.uint8)
+        assert L.shim_extract(h, P(im), 640, 480, 640, P(k), P(d), 4096) > 500
+        pyr = oracle.pyramid(rst, im)
+        for l in range(8):
+            w, hh = ctypes.c_int(), ctypes.c_int()
+            buf = np.zeros(pyr[l].shape, np.uint8)
+            L.shim_pyramid_level_as_is(h, l, P(buf), ctypes.byref(w), ctypes.byref(hh))
+            assert (w.value, hh.value) == (pyr[l].shape[1], pyr[l].shape[0]) and (buf == pyr[l]).all(), (seed, l)
+    L.shim_destroy(h)
+    hip = __import__("oracle_lib").slam_hip_lib()
+    if hip is not None:
+        assert hip.orbslam_extractor_keeps_host_pyramid() == 0
