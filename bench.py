@@ -401,7 +401,7 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
                                                           "note": "the stage with the longest event span inside the pipeline of this command (what a rocprofv3 trace of this "
                                                                   "command ranks first by total kernel time); for the seven dependent k_resize launches the span is mostly queueing"})(
                     max((k for k in stage_ms if alg.get(k, 0) > 0), key=lambda k: stage_ms[k])),
-                "rocprof": {"alone": "profiles/*_streams1_kernel_stats.csv = rocprofv3 --kernel-trace --stats of `bench.py --streams 1` (average durations = stage_ms_alone)",
+                "rocprof": {"alone": "profiles/*_alone_kernel_stats.csv = rocprofv3 --kernel-trace --stats of `bench.py --alone` (every launch synchronised; average durations = stage_ms_alone)",
                             "this_command": "profiles/*_kernel_stats.csv of this command (durations stretched by the concurrency of the three streams)"},
                 "stage_ms_alone": {k: round(v, 4) for k, v in alone_ms.items()},
                 "stage_ms_contended": {k: round(v, 4) for k, v in stage_ms.items()},

@@ -8,6 +8,11 @@ O=$ROOT/gpurun_out
 mkdir -p $O
 cd $ROOT
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu_$TAG.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu_$TAG.log
+# profiles first: the bench line below reads the counters of THIS build (profiles/latest_*.json, stamped with the hash of csrc/)
+if [ $# -gt 0 ]; then
+    bash tools/run_profiles.sh $TAG "$@"
+    cp $O/prof_$TAG/summary/latest_*.json $ROOT/profiles/ 2>/dev/null
+fi
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc $?"; cut -c1-400 $O/bench_$TAG.json
 # RCCL for real: one rank under the launcher the driver uses, backend nccl (init with device_id, all-reduce, all-gather, barriers)
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 \
@@ -20,4 +25,3 @@ try:
 except Exception as e:
     print("nccl world1 line unreadable:", e)
 PY
-if [ $# -gt 0 ]; then bash tools/run_profiles.sh $TAG "$@"; fi
