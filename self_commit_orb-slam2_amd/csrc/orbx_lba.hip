@@ -1067,8 +1067,9 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
         for (int idx = tid; idx < CNB * CNB; idx += 256) {
             const int r = idx >> 5, c = idx & 31;
             const int ra = p0 + CNB * I + r, rb = p0 + CNB * K + r;
-            la[r][c] = ra < n ? L[(size_t)ra * n + q0 + c] : 0.0;
-            lb[r][c] = rb < n ? L[(size_t)rb * n + q0 + c] : 0.0;
+            const double va = L[(size_t)min(ra, n - 1) * n + q0 + c], vb = L[(size_t)min(rb, n - 1) * n + q0 + c];      // (unconditional loads, see the panel's staging)
+            la[r][c] = ra < n ? va : 0.0;
+            lb[r][c] = rb < n ? vb : 0.0;
         }
         __syncthreads();
         const int ti = (tid >> 4) * 2, tk = (tid & 15) * 2;
@@ -1093,26 +1094,40 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
     const int r0 = p0 + nb + blockIdx.x * CHOL_RPW;   // first row of this workgroup's part of the panel below
     const bool hasPrev = p0 > 0;
     if (tid == 64) sBad = 0;
-    {   // global memory is only touched by the whole workgroup, a row segment of 32 doubles per 32 threads, all loads of a thread in
-        // flight before its first LDS store.  Row CHOL_RPW (= 63) of Tt is the right-hand side of this panel.
+    {   // global memory is only touched by the whole workgroup, a row segment of 32 doubles per 32 threads.  Every load is UNCONDITIONAL from a
+        // clamped (always valid) address and masked afterwards: predicated loads sit in their own exec regions, which the compiler does not
+        // merge, so each waited for its data before the next was issued - 24 dependent round trips to rows that the previous launch's
+        // workgroups wrote on other XCDs (s_memrealtime: 6.6 us of staging per launch; with all loads in flight one round trip).
         double vd[4], vt[8], pd[4], pr[8];
+        const int qc = hasPrev ? p0 - CNB : 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
-            vd[q] = (r < nb && c <= r) ? S[(size_t)(p0 + r) * n + p0 + c] : (r == c ? 1.0 : 0.0);   // identity pad past nb
-            pd[q] = (hasPrev && r < nb) ? L[(size_t)(p0 + r) * n + p0 - CNB + c] : 0.0;
+            const size_t row = (size_t)(p0 + min(r, nb - 1)) * n;
+            vd[q] = S[row + p0 + min(c, nb - 1)];
+            pd[q] = L[row + qc + c];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
+            const size_t row = (size_t)min(r0 + r, n - 1) * n;
+            const double *src = r == CHOL_RPW ? ywork + p0 + min(c, nb - 1) : S + row + p0 + min(c, nb - 1);
+            vt[q] = *src;
+            pr[q] = L[row + qc + c];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
+            Ld[r][c] = (r < nb && c <= r) ? vd[q] : (r == c ? 1.0 : 0.0);   // identity pad past nb
+            LpD[r][c] = (hasPrev && r < nb) ? pd[q] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
             const bool row = r < CHOL_RPW && r0 + r < n;
-            vt[q] = r == CHOL_RPW ? (c < nb ? ywork[p0 + c] : 0.0) : ((row && c < nb) ? S[(size_t)(r0 + r) * n + p0 + c] : 0.0);
-            pr[q] = (hasPrev && row) ? L[(size_t)(r0 + r) * n + p0 - CNB + c] : 0.0;
+            Tt[r][c] = ((r == CHOL_RPW || row) && c < nb) ? vt[q] : 0.0;
+            LpR[r][c] = (hasPrev && row) ? pr[q] : 0.0;
         }
-#pragma unroll
-        for (int q = 0; q < 4; q++) { const int idx = tid + 256 * q; Ld[idx >> 5][idx & 31] = vd[q]; LpD[idx >> 5][idx & 31] = pd[q]; }
-#pragma unroll
-        for (int q = 0; q < 8; q++) { const int idx = tid + 256 * q; Tt[idx >> 5][idx & 31] = vt[q]; LpR[idx >> 5][idx & 31] = pr[q]; }
     }
     __syncthreads();
     if (hasPrev) {
