@@ -1031,7 +1031,9 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
 
 // The panel step: nothing goes through synchronised column steps (a version with the 32x32 block in LDS and two workgroup barriers
 // per column took 31 us per panel; a wave factoring the block in registers with one v_readlane pair per multiply-add and a second wave
-// eliminating the rows afterwards 17; the blocked one-wave elimination inside k_chol_step below ~6 of the 15 us a panel launch takes).
+// eliminating the rows afterwards 17; the blocked one-wave elimination inside k_chol_step below 7.9 of the 12.6 us a panel launch takes
+// - s_memrealtime, round 3: staging 1.3, MFMA update 1.5, elimination 7.85, store 1.1; the panel rows' share of the elimination is 1-2 us,
+// the rest is the diagonal block's chain of 8 x (4 pivots, exchange through LDS, rank-4 update)).
 // 1 / sqrt(x) for the pivots: v_rsq_f64 (~26 bits) + one Newton step y += y/2 (1 - x y^2), instead of the library routine: every
 // dependent FP64 operation on the pivot chain costs ~16 cycles, and the factor is not part of the bit-level contract (1e-5 vs g2o)
 __device__ __forceinline__ double pivot_rsqrt(double x)
