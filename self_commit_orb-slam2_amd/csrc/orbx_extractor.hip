@@ -69,6 +69,9 @@ struct orbx_extractor {
     bool geomValid = false;
     std::vector<uint8_t> binHost;
     std::vector<uint32_t> rsHost;   // cv::resize tables of all levels (build_resize_tables)
+    // k_pyramid_tiles (single-frame call): per (tile, level) rectangles, planned from rsHost when the single-frame graph is built
+    OrbxDevBuf<OrbxPyrTile> ptDev;
+    int ptTiles = 0, ptLds = 0, ptTab = 0;       // 0 tiles: no plan (one level, taps wider than 8 bytes, LDS budget) -> the per-level launches
     int nodeCap = 512;
     // device state
     hipStream_t stream = nullptr;
@@ -515,7 +518,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     invalidate_single_graph(h);
-    h->geomDev.release(); h->binDev.release(); h->rsDev.release(); h->pyr.release(); h->blur.release();
+    h->geomDev.release(); h->binDev.release(); h->rsDev.release(); h->ptDev.release(); h->pyr.release(); h->blur.release();
     if (h->hostStaging) { (void)hipHostFree(h->hostStaging); h->hostStaging = nullptr; h->hostStagingBytes = 0; }
     if (h->hostOut) { (void)hipHostFree(h->hostOut); h->hostOut = nullptr; h->hostOutBytes = 0; }
     h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release(); h->lvlBase.release();
@@ -676,6 +679,71 @@ static int fetch_results(orbx_extractor *h, int batch, bool wantKp, bool wantDes
     return ORBX_OK;
 }
 
+// Plan of k_pyramid_tiles for the current geometry: a gx x gy grid of tiles (~12 px at the deepest level), for every tile and level
+// the rectangle it owns (grid boundaries scaled to the level, x rounded down to multiples of 4) and the rectangle it computes =
+// own + what its computed rectangle of the NEXT level reads according to the resize tables (columns: first source column and span of
+// every group of 4; rows: the two source rows).  False: no plan (the caller uses the per-level launches).
+static bool plan_pyramid_tiles(orbx_extractor *h, std::vector<OrbxPyrTile> &out, int &tiles, int &bufBytes, int &tabBytes)
+{
+    const OrbxGeom &g = h->geom;
+    const int nl = g.nlevels;
+    if (nl < 2) return false;
+    int gx = std::max(1, g.lv[nl - 1].w / 12), gy = std::max(1, g.lv[nl - 1].h / 12);
+    while (gx * gy > 1024) { if (gx >= gy) gx = (gx + 1) / 2; else gy = (gy + 1) / 2; }
+    auto bx = [&](int L, int i) { return i >= gx ? ((g.lv[L].w + 3) & ~3) : (int)((long long)i * g.lv[L].w / gx) & ~3; };
+    auto by = [&](int L, int j) { return j >= gy ? g.lv[L].h : (int)((long long)j * g.lv[L].h / gy); };
+    out.assign((size_t)gx * gy * nl, OrbxPyrTile{0, 0, 0, 0, 0, 0, 0, 0});
+    size_t maxBuf = 0, maxTab = 0;
+    for (int j = 0; j < gy; j++)
+        for (int i = 0; i < gx; i++) {
+            OrbxPyrTile *tt = out.data() + ((size_t)j * gx + i) * nl;
+            size_t tabSum = 0;
+            for (int L = nl - 1; L >= 0; L--) {
+                int x0 = 0, x1 = 0, y0 = 0, y1 = 0;          // computed rectangle, empty so far
+                if (L > 0) { x0 = bx(L, i); x1 = bx(L, i + 1); y0 = by(L, j); y1 = by(L, j + 1); }
+                OrbxPyrTile &t = tt[L];
+                t.ox0 = (short)x0; t.ox1 = (short)x1; t.oy0 = (short)y0; t.oy1 = (short)y1;
+                if (x1 <= x0 || y1 <= y0) { x0 = x1 = y0 = y1 = 0; t.ox0 = t.ox1 = t.oy0 = t.oy1 = 0; }
+                if (L < nl - 1) {
+                    const OrbxPyrTile &n = tt[L + 1];
+                    if (n.cx1 > n.cx0 && n.cy1 > n.cy0) {
+                        const OrbxLevel &ln = g.lv[L + 1];
+                        int nx0 = 1 << 30, nx1 = 0, ny0 = 1 << 30, ny1 = 0;
+                        for (int gq = n.cx0 >> 2; gq < n.cx1 >> 2; gq++) {
+                            const uint32_t *ct = h->rsHost.data() + ln.rsColOff + 12 * gq;
+                            if ((int)ct[1] > 7) return false;                      // taps of a group wider than the 8-byte window
+                            nx0 = std::min(nx0, (int)ct[0]);
+                            nx1 = std::max(nx1, (int)ct[0] + (int)ct[1] + 1);
+                        }
+                        for (int y = n.cy0; y < n.cy1; y++) {
+                            const uint32_t ty = h->rsHost[(size_t)ln.rsRowOff + 2 * y];
+                            ny0 = std::min(ny0, (int)(ty & 0xffffu));
+                            ny1 = std::max(ny1, (int)(ty >> 16) + 1);
+                        }
+                        if (x1 <= x0) { x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1; }
+                        else { x0 = std::min(x0, nx0); x1 = std::max(x1, nx1); y0 = std::min(y0, ny0); y1 = std::max(y1, ny1); }
+                    }
+                }
+                x0 &= ~3; x1 = (x1 + 3) & ~3;
+                t.cx0 = (short)x0; t.cx1 = (short)x1; t.cy0 = (short)y0; t.cy1 = (short)y1;
+                if (y1 - y0 > 255 || x1 - x0 > 1020) return false;
+                const size_t pitch = (size_t)((x1 - x0 + 12 + 7) & ~7);               // PT_PITCH of orbx_kernels.hip
+                if (L == 0 && pitch * (size_t)(y1 - y0) > 2048 * 8) return false;      // level-0 window: at most 8 eight-byte units per thread (PT_WIN_ITEMS)
+                if (L > 0) {      // table slices staged in LDS: 48 bytes per column group, 8 per row, one item per thread and level
+                    const int ng = (x1 - x0) >> 2, ch = y1 - y0;
+                    if (3 * ng + ch > 256) return false;
+                    tabSum += (size_t)48 * ng + (((size_t)8 * ch + 15) & ~(size_t)15);
+                }
+                maxBuf = std::max(maxBuf, pitch * (size_t)(y1 - y0) + 16);
+            }
+            maxTab = std::max(maxTab, tabSum);
+        }
+    maxBuf = align_up(maxBuf, 16);
+    if (2 * maxBuf + maxTab > 96 * 1024) return false;
+    tiles = gx * gy; bufBytes = (int)maxBuf; tabBytes = (int)align_up(maxTab + 16, 16);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // One host frame in, results in pinned memory out: the body of ORBextractor::operator() for a handle created with max_batch = 1
 // (shim/ORBextractor.cc).  The frame's rows are laid out at the device pitch in the pinned staging buffer, then ONE graph launch
@@ -691,6 +759,16 @@ static int build_single_graph(orbx_extractor *h)
     const size_t fp = h->stagingFramePitch;
     static std::mutex buildMutex;                 // graphs of different handles are built one at a time (first call of every handle)
     std::lock_guard<std::mutex> lock(buildMutex);
+    {   // the pyramid as ONE node (k_pyramid_tiles) where the geometry has a plan; ORBX_PYR_LEVELS=1: one node per level (measurement switch)
+        std::vector<OrbxPyrTile> plan;
+        const char *e = getenv("ORBX_PYR_LEVELS");
+        h->ptTiles = 0;
+        if (!(e && e[0] == '1') && plan_pyramid_tiles(h, plan, h->ptTiles, h->ptLds, h->ptTab)) {
+            int rc = h->ptDev.ensure(plan.size());
+            if (rc != ORBX_OK) return rc;
+            ORBX_HIP_CHECK(hipMemcpy(h->ptDev.p, plan.data(), plan.size() * sizeof(OrbxPyrTile), hipMemcpyHostToDevice));
+        } else h->ptTiles = 0;
+    }
     for (int cb = 0; cb < 2; cb++) {
         OrbxLaunch L;
         fill_launch(h, L, h->staging.p, 1, h->stagingStride, fp, cb);
@@ -706,10 +784,15 @@ static int build_single_graph(orbx_extractor *h)
         L.graph = g;
         int rc;
         nPyr = nClr;
-        for (int l = 1; l < h->geom.nlevels; l++) {
+        if (h->ptTiles > 0) {
+            L.pyrTiles = h->ptDev.p; L.pyrTileCount = h->ptTiles; L.pyrTileBuf = h->ptLds; L.pyrTileTab = h->ptTab;
             L.deps[0] = nPyr; L.ndeps = 1; L.node = &nPyr;
-            if ((rc = orbx_launch_resize(L, l)) != ORBX_OK) return rc;
-        }
+            if ((rc = orbx_launch_pyramid_tiles(L)) != ORBX_OK) return rc;
+        } else
+            for (int l = 1; l < h->geom.nlevels; l++) {
+                L.deps[0] = nPyr; L.ndeps = 1; L.node = &nPyr;
+                if ((rc = orbx_launch_resize(L, l)) != ORBX_OK) return rc;
+            }
         L.deps[0] = nPyr; L.ndeps = 1; L.node = &nChain;
         if ((rc = orbx_launch_fast_cells(L)) != ORBX_OK) return rc;
         L.deps[0] = nChain;

@@ -53,6 +53,11 @@ struct OrbxGeom {
     OrbxLevel lv[ORBX_MAX_LEVELS];
 };
 
+/* One workgroup's share of one pyramid level in k_pyramid_tiles (single-frame call): the rectangle it COMPUTES (what its part of
+ * the next level reads, united with what it owns; x bounds multiples of 4) and the rectangle it OWNS (stores to the pyramid buffer).
+ * Level 0: only the computed rectangle, = the window of the input image it stages. */
+struct OrbxPyrTile { short cx0, cy0, cx1, cy1, ox0, oy0, ox1, oy1; };
+
 /* level-coordinates keypoint produced by the quadtree + orientation stages */
 /* ca / sb = cos / sin of the angle as the reference's libm rounds them; k_orient_describe fills them with the angle (read back by the stage taps only) */
 struct OrbxLevelKp { uint16_t x, y; uint8_t score, pad[3]; float angle, ca, sb; };
@@ -94,6 +99,7 @@ struct OrbxLaunch {
     int nodeCap;                  /* 256 / 512 / 1024 / 2048 */
     /* graph construction (single-frame call): when `graph` is set, a launcher adds a kernel node that depends on deps[0..ndeps)
      * and returns it in *node instead of launching on `stream` */
+    const OrbxPyrTile *pyrTiles = nullptr; int pyrTileCount = 0, pyrTileBuf = 0, pyrTileTab = 0;   /* k_pyramid_tiles plan (single-frame call): bytes of one of its two LDS image buffers, bytes of its LDS table slices */
     hipGraph_t graph = nullptr;
     hipGraphNode_t deps[2] = {nullptr, nullptr};
     int ndeps = 0;
@@ -101,6 +107,7 @@ struct OrbxLaunch {
 };
 
 int orbx_launch_resize(const OrbxLaunch &L, int level);
+int orbx_launch_pyramid_tiles(const OrbxLaunch &L);   /* all levels of ONE frame in one launch (L.pyrTiles) */
 int orbx_launch_fast_cells(const OrbxLaunch &L);   /* FAST score + cell NMS + emission; L.score (parity tap) may be NULL */
 int orbx_launch_octree(const OrbxLaunch &L);
 int orbx_launch_blur(const OrbxLaunch &L);

@@ -191,6 +191,126 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
 }
 
 // ------------------------------------------------------------------------------------
+// The whole pyramid of ONE frame in one launch (single-frame call).  Seven dependent k_resize launches of a few
+// workgroups each are ~4.3 us apiece on an otherwise idle device - launch, one memory round trip, store - whatever the
+// level's size.  Here a workgroup takes one tile of the image through ALL levels inside LDS: it stages the window of
+// level 0 that its share of the deepest level depends on, and computes level after level the rectangle the next level
+// reads (host-planned per tile and level from the same resize tables, OrbxPyrTile; neighbouring workgroups recompute
+// each other's halos - the device is idle, the redundancy is free), storing the part it owns.  Same tables, same
+// arithmetic as k_resize's 8-byte-window path, source = LDS.
+// ------------------------------------------------------------------------------------
+#define PT_PITCH(cw) (((cw) + 12 + 7) & ~7)      /* LDS row pitch of a computed rectangle: 12 readable bytes behind every group window */
+#define PT_WIN_ITEMS 8          /* 8-byte units of the level-0 window per thread (all requested before the first is stored); the plan keeps windows below 16 KB */
+__global__ __launch_bounds__(256) void k_pyramid_tiles(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, uint8_t *__restrict__ pyr,
+                                                       const uint32_t *__restrict__ rsTab, const OrbxPyrTile *__restrict__ tiles, int bufBytes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // two image buffers of bufBytes (level parity), then the table slices of all levels
+    const int nl = g->nlevels, tid = threadIdx.x;
+    const OrbxPyrTile *tt = tiles + (size_t)blockIdx.x * nl;
+    uint8_t *tab = lds + 2 * bufBytes;
+    // rectangles and level parameters of the level loop out of LDS too: a scalar load from global memory at the top of every level is a
+    // dependent ~0.7 us each, seven times
+    __shared__ OrbxPyrTile sT[ORBX_MAX_LEVELS];
+    __shared__ int sLv[ORBX_MAX_LEVELS][2];
+    if (tid < nl) { sT[tid] = tt[tid]; sLv[tid][0] = g->lv[tid].off; sLv[tid][1] = g->lv[tid].pitch; }
+    // ---- ONE memory round trip for everything the tile needs: the table slices of all levels (column groups of the computed rectangle: 48 bytes
+    // each; its rows: 8 bytes each; at most one item per thread and level, requested for all levels before the first one is stored - a loop over
+    // the levels would wait for each level's data before asking for the next) and the window of level 0
+    {
+        uint4 cv[ORBX_MAX_LEVELS];
+        int dstOff[ORBX_MAX_LEVELS];
+        bool colItem[ORBX_MAX_LEVELS];
+        int run = 0;
+#pragma unroll
+        for (int L = 1; L < ORBX_MAX_LEVELS; L++) {
+            const int Lc = min(L, nl - 1);       // (levels past the last: the last one again, not stored - every load unconditional)
+            const OrbxPyrTile t = tt[Lc];
+            const OrbxLevel &lv = g->lv[Lc];
+            const int ng = (t.cx1 - t.cx0) >> 2, ch = t.cy1 - t.cy0, nc = 3 * ng;
+            const bool isCol = tid < nc;
+            const int i = isCol ? tid : min(tid - nc, max(ch - 1, 0));
+            const uint32_t *srcw = isCol ? rsTab + lv.rsColOff + 12 * (t.cx0 >> 2) + 4 * i : rsTab + lv.rsRowOff + 2 * (t.cy0 + i);
+            const uint2 lo = *(const uint2 *)srcw, hi = *(const uint2 *)(isCol ? srcw + 2 : srcw);      // (row items are 8 bytes)
+            cv[L] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            colItem[L] = isCol;
+            dstOff[L] = (L < nl && tid < nc + ch) ? (isCol ? run + 16 * i : run + 16 * nc + 8 * i) : -1;
+            if (L < nl) run += 16 * nc + ((8 * ch + 15) & ~15);
+        }
+        const OrbxPyrTile t0 = tt[0];
+        const int ch0 = t0.cy1 - t0.cy0, P0 = PT_PITCH(t0.cx1 - t0.cx0), nu = P0 >> 3, nitem = ch0 * nu;      // (planned: nitem <= 256 * PT_WIN_ITEMS)
+        uint2 wv[PT_WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PT_WIN_ITEMS; k++) {      // (the staging rows are readable past the window: pitch >= W + 16, 256 spare bytes behind the frame)
+            const int idx = min(tid + 256 * k, nitem - 1), r = idx / nu, c = idx - r * nu;
+            __builtin_memcpy(&wv[k], img0 + (size_t)(t0.cy0 + r) * img0Stride + t0.cx0 + 8 * c, 8);
+        }
+#pragma unroll
+        for (int k = 0; k < PT_WIN_ITEMS; k++) {
+            const int idx = tid + 256 * k, r = idx / nu, c = idx - r * nu;
+            if (idx < nitem) *(uint2 *)(lds + r * P0 + 8 * c) = wv[k];
+        }
+#pragma unroll
+        for (int L = 1; L < ORBX_MAX_LEVELS; L++)
+            if (dstOff[L] >= 0) {
+                if (colItem[L]) *(uint4 *)(tab + dstOff[L]) = cv[L];
+                else *(uint2 *)(tab + dstOff[L]) = make_uint2(cv[L].x, cv[L].y);
+            }
+    }
+    __syncthreads();
+    int run = 0;
+    for (int L = 1; L < nl; L++) {
+        const OrbxPyrTile s = sT[L - 1], t = sT[L];
+        const int lvOff = sLv[L][0], lvPitch = sLv[L][1];
+        const int sP = PT_PITCH(s.cx1 - s.cx0), dP = PT_PITCH(t.cx1 - t.cx0);
+        const uint8_t *src = lds + ((L - 1) & 1) * bufBytes;
+        uint8_t *dst = lds + (L & 1) * bufBytes;
+        const int ng = (t.cx1 - t.cx0) >> 2, ch = t.cy1 - t.cy0;
+        const uint4 *ctab = (const uint4 *)(tab + run);
+        const uint2 *rtab = (const uint2 *)(tab + run + 48 * ng);
+        run += 48 * ng + ((8 * ch + 15) & ~15);
+        if (ng > 0 && ch > 0) {
+            // thread = (column group, row phase): the group's twelve table words once per level, one row-table pair per row, both out of LDS
+            // tid / ng and 256 / ng without the integer-division sequences (three of them were a third of a small level's time with one wave
+            // per SIMD): float quotient, corrected by one step either way (exact for operands below 2^12)
+            const float rng = __builtin_amdgcn_rcpf((float)ng);
+            int rph = (int)((float)tid * rng), rpp = (int)(256.f * rng);
+            rph += (rph + 1) * ng <= tid ? 1 : 0; rph -= rph * ng > tid ? 1 : 0;
+            rpp += (rpp + 1) * ng <= 256 ? 1 : 0; rpp -= rpp * ng > 256 ? 1 : 0;
+            const int gi = tid - rph * ng;
+            if (rph < rpp) {
+                const int X = t.cx0 + 4 * gi;
+                const uint4 c0 = ctab[3 * gi], c1 = ctab[3 * gi + 1], c2 = ctab[3 * gi + 2];
+                const int sx0 = (int)c0.x, xoff = (sx0 & ~3) - s.cx0;      // (s.cx0 is a multiple of 4: the window stays dword aligned)
+                const uint32_t mis = (uint32_t)(sx0 & 3);
+                const uint32_t sel[4] = {c0.z, c0.w, c1.x, c1.y}, coef[4] = {c1.z, c1.w, c2.x, c2.y};
+                const bool ownX = X >= t.ox0 && X < t.ox1;
+                uint8_t *gdst = pyr + lvOff;
+                for (int r = rph; r < ch; r += rpp) {
+                    const int Y = t.cy0 + r;
+                    const uint2 tr = rtab[r];
+                    const uint32_t b0 = tr.y & 0xffffu, b1 = tr.y >> 16;
+                    const uint32_t *p0 = (const uint32_t *)(src + ((int)(tr.x & 0xffffu) - s.cy0) * sP + xoff), *p1 = (const uint32_t *)(src + ((int)(tr.x >> 16) - s.cy0) * sP + xoff);
+                    const uint32_t a0_ = p0[0], a1_ = p0[1], a2_ = p0[2], d0_ = p1[0], d1_ = p1[1], d2_ = p1[2];
+                    const uint32_t v00 = __builtin_amdgcn_alignbyte(a1_, a0_, mis), v01 = __builtin_amdgcn_alignbyte(a2_, a1_, mis);
+                    const uint32_t v10 = __builtin_amdgcn_alignbyte(d1_, d0_, mis), v11 = __builtin_amdgcn_alignbyte(d2_, d1_, mis);
+                    uint32_t out = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t r0 = udot2(__builtin_amdgcn_perm(v01, v00, sel[k]), coef[k], 0u);
+                        const uint32_t r1 = udot2(__builtin_amdgcn_perm(v11, v10, sel[k]), coef[k], 0u);
+                        const uint32_t v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2;
+                        out |= (v & 0xffu) << (8 * k);
+                    }
+                    *(uint32_t *)(dst + r * dP + 4 * gi) = out;
+                    if (ownX && Y >= t.oy0 && Y < t.oy1) *(uint32_t *)(gdst + (size_t)Y * lvPitch + X) = out;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Cell detector: FAST-9/16 score + per-cell 3x3 NMS + threshold fallback + raster-ordered emission
 // (ComputeKeyPointsOctTree cell loop, src/ORBextractor.cc:1089-1157, with cv::FAST at :1126,1135).
 // ONE WAVE PER 30-px CELL; the cell's input window (detectable area + 3 px ring) and its score
@@ -1133,6 +1253,16 @@ int orbx_launch_resize(const OrbxLaunch &L, int level)
     const bool padded = level > 1 || (L.img0Stride >= ((L.geom->lv[0].w + 3) & ~3) + 12 && L.img0FramePitch >= (size_t)L.img0Stride * (size_t)L.geom->lv[0].h);
     if (padded) return emit(L, k_resize<true>, grid, dim3(256), 0, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rsTab);
     return emit(L, k_resize<false>, grid, dim3(256), 0, L.geomDev, level, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rsTab);
+}
+
+int orbx_launch_pyramid_tiles(const OrbxLaunch &L)
+{
+    const size_t ldsBytes = 2 * (size_t)L.pyrTileBuf + (size_t)L.pyrTileTab;
+    if (ldsBytes > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k_pyramid_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+        if (e != hipSuccess) { orbx_set_error("hipFuncSetAttribute(k_pyramid_tiles) failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+    }
+    return emit(L, k_pyramid_tiles, dim3((unsigned)L.pyrTileCount), dim3(256), ldsBytes, L.geomDev, L.img0, L.img0Stride, L.pyr, L.rsTab, L.pyrTiles, L.pyrTileBuf);
 }
 
 int orbx_launch_fast_cells(const OrbxLaunch &L)

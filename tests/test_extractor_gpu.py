@@ -139,6 +139,10 @@ def test_ragged_geometries_bit_exact(orbx, oracle, W, H, nf, sf, nl, ini, mn):
         k, d = one(frames[f])
         ko, do = rst.extract(frames[f])
         assert len(k) == len(ko) and (kp_matrix(k).view(np.uint32) == ko.view(np.uint32)).all() and (d == do).all(), f
+        # ... and every byte of its pyramid (one k_pyramid_tiles launch: all levels of the frame tile by tile inside LDS)
+        pyr = oracle.pyramid(rst, frames[f])
+        for l in range(nl):
+            assert (one.mvImagePyramid(l) == pyr[l]).all(), "single-frame pyramid, level %d" % l
     one.close()
 
 

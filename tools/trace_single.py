@@ -11,10 +11,17 @@ cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
 rows = list(con.execute("select name, start, end from kernels order by start"))
 # the last k_orient_describe ends a frame; walk back to the k_resize run that starts it
 names = [r[0] for r in rows]
-last = max(i for i, n in enumerate(names) if "k_orient_describe" in n)
-first = last
-while first > 0 and "k_orient_describe" not in names[first - 1]:
-    first -= 1
+pt = [i for i, n in enumerate(names) if "k_pyramid_tiles" in n]
+if pt:      # the last frame that went through the single-frame graph (one k_pyramid_tiles node); frames run with stage timers use the per-level launches
+    first = pt[-1]
+    last = min(i for i, n in enumerate(names) if i > first and "k_orient_describe" in n)
+    while first > 0 and "k_orient_describe" not in names[first - 1]:
+        first -= 1
+else:
+    last = max(i for i, n in enumerate(names) if "k_orient_describe" in n)
+    first = last
+    while first > 0 and "k_orient_describe" not in names[first - 1]:
+        first -= 1
 t0 = rows[first][1]
 for n, s, e in rows[first:last + 1]:
     short = n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
