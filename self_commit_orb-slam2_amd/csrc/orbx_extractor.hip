@@ -747,13 +747,14 @@ static bool plan_pyramid_tiles(orbx_extractor *h, std::vector<OrbxPyrTile> &out,
 // ---------------------------------------------------------------------------------------------
 // One host frame in, results in pinned memory out: the body of ORBextractor::operator() for a handle created with max_batch = 1
 // (shim/ORBextractor.cc).  The frame's rows are laid out at the device pitch in the pinned staging buffer, then ONE graph launch
-// replays  upload -> status clear -> 7 x k_resize -> k_fast_cells -> k_octree -> k_blur -> k_orient_describe -> read-back
+// replays  upload -> k_pyramid_tiles (all levels, one launch) -> k_fast_cells -> k_octree -> k_blur -> k_orient_describe -> read-back
 // with the pointers of result buffer `cb` baked in (one graph per buffer), followed by one synchronisation.
 // ---------------------------------------------------------------------------------------------
 static int build_single_graph(orbx_extractor *h)
 {
     // explicit node API (no stream capture - see emit() in orbx_kernels.hip), ONE chain:
-    //   upload -> status clear -> k_resize x7 -> k_fast_cells -> k_octree -> k_blur -> k_orient_describe -> read-back
+    //   upload -> k_pyramid_tiles (clears the status words; without a tile plan: status clear -> k_resize per level) -> k_fast_cells -> k_octree -> k_blur
+    //   -> k_orient_describe -> read-back
     // (measured: a second branch for k_blur next to the detector chain makes hipGraphLaunch use internal side streams - 166 us per frame
     // instead of 127 for this chain, and concurrent launches of such graphs from several threads crashed inside the runtime)
     const size_t fp = h->stagingFramePitch;
@@ -780,7 +781,8 @@ static int build_single_graph(orbx_extractor *h)
         hipMemsetParams mp;
         memset(&mp, 0, sizeof(mp));
         mp.dst = h->status.p; mp.elementSize = sizeof(int); mp.width = 2; mp.height = 1; mp.pitch = 2 * sizeof(int); mp.value = 0;
-        ORBX_HIP_CHECK(hipGraphAddMemsetNode(&nClr, g, &nUp, 1, &mp));
+        if (h->ptTiles > 0) nClr = nUp;      // k_pyramid_tiles clears the two status words itself
+        else ORBX_HIP_CHECK(hipGraphAddMemsetNode(&nClr, g, &nUp, 1, &mp));
         L.graph = g;
         int rc;
         nPyr = nClr;

@@ -202,12 +202,13 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
 #define PT_PITCH(cw) (((cw) + 12 + 7) & ~7)      /* LDS row pitch of a computed rectangle: 12 readable bytes behind every group window */
 #define PT_WIN_ITEMS 8          /* 8-byte units of the level-0 window per thread (all requested before the first is stored); the plan keeps windows below 16 KB */
 __global__ __launch_bounds__(256) void k_pyramid_tiles(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, uint8_t *__restrict__ pyr,
-                                                       const uint32_t *__restrict__ rsTab, const OrbxPyrTile *__restrict__ tiles, int bufBytes)
+                                                       const uint32_t *__restrict__ rsTab, const OrbxPyrTile *__restrict__ tiles, int bufBytes, int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // two image buffers of bufBytes (level parity), then the table slices of all levels
     const int nl = g->nlevels, tid = threadIdx.x;
     const OrbxPyrTile *tt = tiles + (size_t)blockIdx.x * nl;
     uint8_t *tab = lds + 2 * bufBytes;
+    if (blockIdx.x == 0 && threadIdx.x < 2) status[threadIdx.x] = 0;      // the frame's capacity word and the batch word (first kernel of the chain: no memset node)
     // rectangles and level parameters of the level loop out of LDS too: a scalar load from global memory at the top of every level is a
     // dependent ~0.7 us each, seven times
     __shared__ OrbxPyrTile sT[ORBX_MAX_LEVELS];
@@ -1262,7 +1263,7 @@ int orbx_launch_pyramid_tiles(const OrbxLaunch &L)
         const hipError_t e = hipFuncSetAttribute((const void *)k_pyramid_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e != hipSuccess) { orbx_set_error("hipFuncSetAttribute(k_pyramid_tiles) failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     }
-    return emit(L, k_pyramid_tiles, dim3((unsigned)L.pyrTileCount), dim3(256), ldsBytes, L.geomDev, L.img0, L.img0Stride, L.pyr, L.rsTab, L.pyrTiles, L.pyrTileBuf);
+    return emit(L, k_pyramid_tiles, dim3((unsigned)L.pyrTileCount), dim3(256), ldsBytes, L.geomDev, L.img0, L.img0Stride, L.pyr, L.rsTab, L.pyrTiles, L.pyrTileBuf, L.status);
 }
 
 int orbx_launch_fast_cells(const OrbxLaunch &L)
