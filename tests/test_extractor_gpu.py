@@ -162,3 +162,35 @@ def test_tight_device_stride(orbx, oracle):
         n = int(counts[f])
         assert n == len(ko) and (kp_matrix(kps[f, :n]).view(np.uint32) == ko.view(np.uint32)).all() and (desc[f, :n] == do).all()
     ext.close()
+
+
+def test_single_frame_pyramid_equals_batch_pyramid_on_random_geometries(orbx):
+    """k_pyramid_tiles (the single-frame call: a host-planned tile grid taken through all levels inside LDS) against the per-level
+    k_resize launches of the batch path (itself checked against the oracle above) on random image sizes, level counts and scale factors:
+    every byte of every level - tile boundaries, halos, right / bottom borders, levels whose tiles own nothing.  Also the blurred copy and
+    the results, which read the pyramid."""
+    rng = np.random.default_rng(20260926)
+    done = 0
+    for trial in range(40):
+        W, H = int(rng.integers(120, 1500)), int(rng.integers(120, 1100))
+        nl = int(rng.integers(2, 11))
+        sf = float(rng.choice([1.1, 1.15, 1.2, 1.25, 1.3, 1.4, 1.5, 1.6]))
+        if min(W, H) / sf ** (nl - 1) < 64 or not (0.26 < (W / sf ** (nl - 1) - 32) / max(H / sf ** (nl - 1) - 32, 1) < 4.4):
+            continue            # (level too small for a cell grid / aspect ratio outside 1..4 initial quadtree nodes: rejected at handle creation)
+        nf = int(rng.integers(100, 1500))
+        try:
+            one = orbx.ORBextractor(nf, sf, nl, 20, 7, max_width=W, max_height=H)
+            two = orbx.ORBextractor(nf, sf, nl, 20, 7, max_width=W, max_height=H, max_batch=2)
+            im = orbx.synth_frame(900 + trial, W, H)
+            k1, d1 = one(im)
+            k2, d2, c2 = two.extract_batch([im, im])
+        except RuntimeError:
+            continue            # geometry outside the documented limits
+        n = int(c2[0])
+        assert len(k1) == n and (kp_matrix(k1).view(np.uint32) == kp_matrix(k2[0, :n]).view(np.uint32)).all() and (d1 == d2[0, :n]).all(), (W, H, nl, sf)
+        for l in range(nl):
+            assert (one.mvImagePyramid(l) == two.mvImagePyramid(l)).all(), ("pyramid", W, H, nl, sf, l)
+            assert (one.mvImagePyramid(l, blurred=True) == two.mvImagePyramid(l, blurred=True)).all(), ("blurred", W, H, nl, sf, l)
+        one.close(); two.close()
+        done += 1
+    assert done >= 12
