@@ -663,6 +663,18 @@ def bench_lba(a, orbx, torch, grp, dev_t, local, rank_info):
                              "on the reference's CPU speed",
                    "restatement": port}
     gflops = flops / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    launches = None      # kernel launches per window, from the committed rocprofv3 kernel trace of this workload (k_unpack runs once per window)
+    try:
+        import csv
+        f = sorted((ROOT / "profiles").glob("r*_lba_kernel_stats.csv"))[-1]
+        rows = list(csv.DictReader(open(f)))
+        wins = [int(r["calls"]) for r in rows if r["kernel"].startswith("k_unpack")]
+        if wins and wins[0] > 0:
+            chol = sum(int(r["calls"]) for r in rows if r["kernel"].startswith("k_chol_step"))
+            launches = {"per_window": round(sum(int(r["calls"]) for r in rows if r["kernel"].startswith("k_")) / wins[0], 1),
+                        "k_chol_step_per_window": round(chol / wins[0], 1), "source": "profiles/" + f.name}
+    except Exception:
+        launches = None
     FP64_PEAK_TF = 256 * 4 * 16 * 2 * 2.4e9 / 1e12      # 256 CUs x 4 SIMDs x 16 FP64 lanes x FMA x 2.4 GHz = 78.6 TFLOP/s (vector = matrix rate on MI355X)
     roof = {"bound": "mfma", "kernel": "whole LM loop (72 x k_chol_step = 46 % of the kernel time, profiles/*_lba_kernel_stats.csv)", "achieved": round(gflops / 1e3, 4),
             "peak": round(FP64_PEAK_TF, 1), "unit": "TFLOP/s", "frac": round(gflops / 1e3 / FP64_PEAK_TF, 5), "traffic": None,
@@ -672,7 +684,7 @@ def bench_lba(a, orbx, torch, grp, dev_t, local, rank_info):
             "warmup": a.warmup, "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "config": {"workload": "BASELINE config 5: LocalBundleAdjustment, %d keyframes, %d points, %d edges; replicas only" % (w["K"], w["P"], w["E"]),
                                             "kernel_ms": round(float(np.mean(kern)), 4), "fp64_gflops": round(flops / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
-                                            "concurrent": {"windows_in_flight": S, "windows_per_s": round(conc, 1)}},
+                                            "launches": launches, "concurrent": {"windows_in_flight": S, "windows_per_s": round(conc, 1)}},
             "ranks": dict(rank_info, per_rank=[{"windows": r[0], "seconds": round(r[1], 6)} for r in per_rank]), "roofline": roof}
     if cpu:
         out["cpu_baseline"] = cpu

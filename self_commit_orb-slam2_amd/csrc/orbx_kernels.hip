@@ -8,6 +8,7 @@
 // Integer / byte work bounded by HBM and VALU issue; no MFMA.
 // Compiled with -ffp-contract=off: the few float expressions must round exactly like
 // the un-fused scalar reference.
+#include <algorithm>
 #include "orbx_internal.h"
 
 namespace {
@@ -1259,9 +1260,16 @@ int orbx_launch_resize(const OrbxLaunch &L, int level)
 int orbx_launch_pyramid_tiles(const OrbxLaunch &L)
 {
     const size_t ldsBytes = 2 * (size_t)L.pyrTileBuf + (size_t)L.pyrTileTab;
-    if (ldsBytes > 48 * 1024) {
+    // the attribute belongs to the function, not to the handle: only ever raised (graphs of other handles keep their larger nodes valid);
+    // callers build one graph at a time (build_single_graph's mutex)
+    static size_t ldsGranted[64];      // per device (0 = nothing beyond the default 48 KB yet)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t &granted = ldsGranted[dev & 63];
+    if (ldsBytes > std::max<size_t>(granted, 48 * 1024)) {
         const hipError_t e = hipFuncSetAttribute((const void *)k_pyramid_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e != hipSuccess) { orbx_set_error("hipFuncSetAttribute(k_pyramid_tiles) failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+        granted = ldsBytes;
     }
     return emit(L, k_pyramid_tiles, dim3((unsigned)L.pyrTileCount), dim3(256), ldsBytes, L.geomDev, L.img0, L.img0Stride, L.pyr, L.rsTab, L.pyrTiles, L.pyrTileBuf, L.status);
 }
