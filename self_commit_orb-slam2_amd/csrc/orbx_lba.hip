@@ -268,12 +268,11 @@ __global__ __launch_bounds__(256) void k_errors(LbaDev d, Huber h, int robust, d
     if (threadIdx.x == 0) partChi[blockIdx.x] = t;
 }
 
-// linearizeOplus (.cpp:103-139, 188-234) + constructQuadraticForm (base_binary_edge.hpp:55-119)
-__global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust)
+// linearizeOplus (.cpp:103-139, 188-234): the Jacobians of one active edge (A: 3x3 w.r.t. the landmark, B: 3x6 w.r.t. the pose; row 2 only for a
+// stereo edge), the robust weight and -Omega r rho'.  One body for k_linearize and for the fused sums (k_lin_sums), so that both produce the same bits.
+__device__ __forceinline__ void edge_linearize(const LbaDev &d, const Huber &h, int robust, int e, int k, int l, bool &stOut, double (&A)[9], double (&B)[18], double &W,
+                                               double (&omr)[3])
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= d.E || !d.active[e]) return;
-    const int k = d.ek[e], l = d.ep[e];
     const bool st = d.stereo[e] != 0;
     const double *in = d.intr + 5 * (size_t)k;
     const double fx = in[0], fy = in[1], bf = in[4];
@@ -281,7 +280,6 @@ __global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust
     pose_map(d.pose[k], d.pt + 3 * (size_t)l, Xc);
     quat_to_R(d.pose[k].q, R);
     const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
-    double A[9], B[18];
 #pragma unroll
     for (int i = 0; i < 9; i++) A[i] = 0;
 #pragma unroll
@@ -307,14 +305,27 @@ __global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust
     const double *r = d.err + 3 * (size_t)e;
     double rw = 1.0;
     if (robust) { double r0; huber_rho(h, st, (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * w, r0, rw); }
-    const double W = rw * w;
-    double omr[3];
+    W = rw * w;
 #pragma unroll
     for (int i = 0; i < 3; i++) omr[i] = -w * r[i] * rw;
-    double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
-    // sums over the error dimension: rows 0, 1 and - for a stereo edge - 2, in that order from 0 like the reference's
-    // loops; everything unrolled so that A / B are registers (a runtime row count puts them into scratch memory)
+    stOut = st;
+}
+
+// sums over the error dimension: rows 0, 1 and - for a stereo edge - 2, in that order from 0 like the reference's loops
+// (constructQuadraticForm, base_binary_edge.hpp:55-119); everything unrolled so that A / B are registers
 #define LIN_DOT(expr0, expr1, expr2) ([&] { double s_ = 0; s_ += (expr0); s_ += (expr1); if (st) s_ += (expr2); return s_; }())
+
+// linearizeOplus + constructQuadraticForm with every block of every edge written out (the launch-per-stage form; k_lin_sums below computes the
+// same blocks inside the sums that consume them)
+__global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.E || !d.active[e]) return;
+    const int k = d.ek[e], l = d.ep[e];
+    bool st;
+    double A[9], B[18], W, omr[3];
+    edge_linearize(d, h, robust, e, k, l, st, A, B, W, omr);
+    double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
     {
         int o = 0;
 #pragma unroll
@@ -337,7 +348,6 @@ __global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust
 #pragma unroll
             for (int j = 0; j < 3; j++) blk[EB_HPL + 3 * i + j] = LIN_DOT(B[i] * W * A[j], B[6 + i] * W * A[3 + j], B[12 + i] * W * A[6 + j]);
     }
-#undef LIN_DOT
 }
 
 // Hll (9, full symmetric) and b_l (3) of every active landmark: its edges in insertion order
@@ -420,6 +430,95 @@ __global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart,
         part[((size_t)k * SP_SPLIT + y) * 27 + tid] = sacc;
     }
 }
+// k_linearize + k_sum_points + k_sum_poses as ONE launch.  The three were 16 + 5.7 + 6.1 us of every LM trial's critical path (the
+// speculative linearisation is what the device runs while the host decides about the trial) and moved 26 MB of per-edge blocks through HBM,
+// written once and gathered back once.  Here the sums compute the blocks of their edges themselves (edge_linearize: identical expressions,
+// identical bits; the pose and intrinsics arrays they need instead are a few KB), in the same order as before; only Hpl, which the Schur
+// kernels read per trial, is still written (by the keyframe side, which visits every active edge of a free keyframe exactly once).
+//   blocks [0, K * SP_SPLIT)     the keyframe sums (k_sum_poses' body; first: they are the longer ones)
+//   the rest                     the landmark sums (k_sum_points' body), 16 lanes per landmark
+__global__ __launch_bounds__(256) void k_lin_sums(LbaDev d, Huber h, int robust, const int *ptStart, const int *ptEdges, double *Hll, double *bl, const int *kfStart,
+                                                  const int *kfEdges, double *part /* K x SP_SPLIT x 27 */)
+{
+    __shared__ double redT[27 * SP_TP];
+    __shared__ double part8[27][9];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= d.K * SP_SPLIT) {
+        const int l = ((int)blockIdx.x - d.K * SP_SPLIT) * 16 + (tid >> 4), a = tid & 15;
+        if (l >= d.P) return;
+        const int li = d.ptIdx[l];
+        if (li < 0) return;
+        double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // H (6) then b (3)
+        for (int s = ptStart[l] + a; s < ptStart[l + 1]; s += 16) {
+            const int e = ptEdges[s];
+            if (!d.active[e]) continue;
+            bool st;
+            double A[9], B[18], W, omr[3];
+            edge_linearize(d, h, robust, e, d.ek[e], l, st, A, B, W, omr);
+            int o = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = i; j < 3; j++) v[o++] += LIN_DOT(A[i] * W * A[j], A[3 + i] * W * A[3 + j], A[6 + i] * W * A[6 + j]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) v[6 + i] += LIN_DOT(A[i] * omr[0], A[3 + i] * omr[1], A[6 + i] * omr[2]);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) v[i] = sum16(v[i]);
+        if (a == 0) {
+            double *o = Hll + (size_t)li * 9;
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[1]; o[4] = v[3]; o[5] = v[4]; o[6] = v[2]; o[7] = v[4]; o[8] = v[5];
+            bl[(size_t)li * 3] = v[6]; bl[(size_t)li * 3 + 1] = v[7]; bl[(size_t)li * 3 + 2] = v[8];
+        }
+        return;
+    }
+    const int k = (int)blockIdx.x / SP_SPLIT, y = (int)blockIdx.x % SP_SPLIT, pi = d.poseIdx[k];
+    if (pi < 0) return;
+    const int s0 = kfStart[k], n = kfStart[k + 1] - s0, per = (n + SP_SPLIT - 1) / SP_SPLIT;
+    const int lo = s0 + min(n, y * per), hi = s0 + min(n, (y + 1) * per);
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) acc[i] = 0;
+    for (int s = lo + tid; s < hi; s += 256) {
+        const int e = kfEdges[s];
+        if (!d.active[e]) continue;
+        bool st;
+        double A[9], B[18], W, omr[3];
+        edge_linearize(d, h, robust, e, k, d.ep[e], st, A, B, W, omr);
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++) acc[o++] += LIN_DOT(B[i] * W * B[j], B[6 + i] * W * B[6 + j], B[12 + i] * W * B[12 + j]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc[21 + i] += LIN_DOT(B[i] * omr[0], B[6 + i] * omr[1], B[12 + i] * omr[2]);
+        double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) blk[EB_HPL + 3 * i + j] = LIN_DOT(B[i] * W * A[j], B[6 + i] * W * A[3 + j], B[12 + i] * W * A[6 + j]);
+    }
+    const int slot = (tid >> 5) * 33 + (tid & 31);
+#pragma unroll
+    for (int i = 0; i < 27; i++) redT[i * SP_TP + slot] = acc[i];
+    __syncthreads();
+    if (tid < 216) {
+        const int i = tid >> 3, p = tid & 7;
+        const double *src = redT + i * SP_TP + p * 33;
+        double sacc = 0;
+#pragma unroll
+        for (int q = 0; q < 32; q++) sacc += src[q];
+        part8[i][p] = sacc;
+    }
+    __syncthreads();
+    if (tid < 27) {
+        double sacc = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) sacc += part8[tid][q];
+        part[((size_t)k * SP_SPLIT + y) * 27 + tid] = sacc;
+    }
+}
+#undef LIN_DOT
 // ... and the SP_SPLIT partial results added in order by a second small launch (a "last workgroup adds" inside the first one needs a
 // device-scope release, i.e. a write-back of the L2 - right after k_linearize has left 34 MB of dirty lines there: 28 us instead of 16)
 __global__ __launch_bounds__(256) void k_sum_poses_fin(LbaDev d, const double *__restrict__ part, double *__restrict__ Hpp, double *__restrict__ bp)
@@ -1832,6 +1931,7 @@ struct orbx_lba {
     OrbxDevBuf<DPose> pose, poseBak;
     OrbxDevBuf<double> pt, ptBak, intr, obs, info, err, rchi, edgeBlk, Hpp, bp, Hll, bl, Dinv, Ddb, S, bs, xp, xl, red;
     OrbxDevBuf<double> Lmat, ywork, ysol, diagInv;   // multi-workgroup Cholesky: the factor and the two halves of the right-hand side
+    bool linSplit = false;                           // ORBX_LBA_SPLIT=1 (measurement switch): k_linearize, k_sum_points, k_sum_poses as separate launches
     OrbxDevBuf<int> ep, ek, ptStart, ptEdges, kfStart, kfEdges, poseIdx, ptIdx, okFlag;
     OrbxDevBuf<uint8_t> stereo, active;
     uint8_t *hostIO = nullptr;   // pinned: the marshalled inputs of a call on their way up, flags / chi2 / estimates on their way down
@@ -1855,6 +1955,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     ORBX_HIP_CHECK(hipSetDevice(device));
     orbx_lba *h = new orbx_lba();
     h->device = device; h->maxK = max_keyframes; h->maxP = max_points; h->maxE = max_edges;
+    { const char *e = getenv("ORBX_LBA_SPLIT"); h->linSplit = e && e[0] == '1'; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
@@ -1995,6 +2096,14 @@ int optimize(Ctx &c, int iterations, double stats[4])
     // count, can differ from run to run (never observed on the goldens; the contract is 1e-5 against g2o, tests/test_golden_lba.py).
     bool linearized = false, rebuild = false;
     auto linearize = [&]() -> int {
+        if (!h->linSplit) {      // Jacobians inside the sums that consume them: one launch + the ordered add of the keyframe partials
+            hipLaunchKernelGGL(k_lin_sums, dim3((unsigned)(K * SP_SPLIT + (P + 15) / 16)), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->ptStart.p, h->ptEdges.p, h->Hll.p,
+                               h->bl.p, h->kfStart.p, h->kfEdges.p, h->spPart.p);
+            hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p);
+            LCHECK();
+            h->flops += 400.0 * nAct;
+            return ORBX_OK;
+        }
         hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
         LCHECK();
         hipLaunchKernelGGL(k_sum_points, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p);
