@@ -7,10 +7,11 @@
 //                 keyframe / by landmark, edges ascending) built on the device
 //   k_stage_mark / k_stage_index        initializeOptimization(level 0): active edges, free-pose / landmark numbering
 //   k_errors      computeActiveErrors + chi2 + Huber rho (one thread per edge, per-workgroup partial sums of the robust chi2)
-//   k_linearize   linearizeOplus + constructQuadraticForm per edge (one thread per edge; the per-edge blocks J^T W J are written
-//                 out, no atomics)
-//   k_sum_points  Hll / b_l per landmark = fixed-order sum over its edges (16 lanes per landmark)
-//   k_sum_poses (+ _fin)  Hpp / b_p per free pose = fixed-order sum over its edges (four workgroups per keyframe, ordered second pass)
+//   k_lin_sums (+ k_sum_poses_fin)      linearizeOplus + constructQuadraticForm inside the sums that consume them: Hll / b_l per landmark (16 lanes
+//                 per landmark) and Hpp / b_p per free pose (four workgroups per keyframe, ordered second pass) as fixed-order sums over
+//                 their edges, the Jacobian blocks computed where they are added (no atomics; only Hpl is written per edge, for the Schur
+//                 kernels).  k_linearize / k_sum_points / k_sum_poses: the same as three launches with every block written out
+//                 (ORBX_LBA_SPLIT=1, measurement switch)
 //   k_schur_setup / k_schur_rows        S = Hpp + lambda I - sum_l B D^-1 B^T as its lower block triangle, block row per keyframe in LDS
 //   k_chol_step (one launch per 32-column panel) / k_chol_backsub_reg   dense Cholesky of S + substitutions (n >= 96; k_chol_solve:
 //                 one workgroup for the small systems, k_chol_backsub above n = 320)
