@@ -237,3 +237,25 @@ def test_bundle_adjustment_beyond_the_lds_limits(orbx, oracle, K, iters):
     got = opt.BundleAdjustment(w, iters, True)
     _compare(got, want, w)
     opt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(K=50, P=5000, seed=12345), dict(K=12, P=400, seed=6, n_fixed=2, pose_noise=(np.deg2rad(12.0), 0.5), point_noise=0.4, stereo_frac=0.3)])
+def test_fused_linearisation_equals_the_split_one(orbx, cfg, monkeypatch):
+    """k_lin_sums (the Jacobian blocks computed inside the landmark / keyframe sums) against k_linearize + k_sum_points + k_sum_poses (every block written
+    out per edge; ORBX_LBA_SPLIT=1, read when the handle is created).  H and b come out of the same expressions in the same order; the reduced system is
+    summed with FP64 atomics in an order that varies from run to run, so the two solves are compared like two runs of one path: identical iteration and
+    trial counts in both stages, identical outlier flags, estimates and residuals equal to 1e-10 - on a well conditioned window and on one with rejected
+    trials."""
+    w = orbx.lba_synth.make_window(**cfg)
+    fused = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000)
+    monkeypatch.setenv("ORBX_LBA_SPLIT", "1")
+    split = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000)
+    monkeypatch.delenv("ORBX_LBA_SPLIT")
+    a, b = fused.LocalBundleAdjustment(w), split.LocalBundleAdjustment(w)
+    sa, sb = np.asarray(a["stats"]), np.asarray(b["stats"])
+    assert (sa[[0, 1, 4, 5]] == sb[[0, 1, 4, 5]]).all(), (sa, sb)
+    assert (np.asarray(a["outlier"]) == np.asarray(b["outlier"])).all()
+    for key in ("poses", "points", "chi2"):
+        assert np.allclose(a[key], b[key], rtol=1e-10, atol=1e-10), key
+    fused.close(); split.close()
