@@ -1452,10 +1452,13 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int NP>
 __global__ __launch_bounds__(1024) void k_chol_backsub_reg(const double *__restrict__ L, const double *__restrict__ ysol, const double *__restrict__ diagInv, int n, double *x)
 {
-    constexpr int CW = 32 * NP, RQ = 11;       // columns, rows per thread and panel (3 x 11 >= 32)
-    __shared__ double y[CW], di[CW], part[3][CNB], l11s[2][CNB][CNB + 1], xs[CNB + 1];
+    // columns; row groups of the 1024 threads (3 above 256 columns, else 4); rows per thread and panel (3 x 11, 4 x 8 >= 32).  With four groups a
+    // thread keeps 8 instead of 11 prefetched values per panel in flight: no register spill - and a spill reload inside the panel loop is followed by
+    // s_waitcnt vmcnt(0), which also waits for every prefetched row block (1.8 us per panel instead of the substitution's own ~1)
+    constexpr int CW = 32 * NP, RG = 1024 / CW >= 4 ? 4 : 1024 / CW, RQ = (CNB + RG - 1) / RG;
+    __shared__ double y[CW], di[CW], part[4][CNB], l11s[2][CNB][CNB + 1], xs[CNB + 1];
     const int tid = threadIdx.x, col = tid % CW, rq = tid / CW, lane = tid & 63;
-    const bool upd = rq < 3 && tid < 3 * CW;
+    const bool upd = rq < RG && tid < RG * CW;
     double lv[NP][RQ], ld[NP], accs[2] = {0, 0};
     auto request = [&](auto P) {       // row block and diagonal block of panel P (compile-time index)
         constexpr int pp = decltype(P)::value;
@@ -1481,7 +1484,7 @@ __global__ __launch_bounds__(1024) void k_chol_backsub_reg(const double *__restr
         if (tid < 64) {
             const int t = lane & (CNB - 1);
             const double inv = di[p0 + t];
-            double xv = (y[p0 + t] - ((part[0][t] + part[1][t]) + part[2][t])) * inv;      // scaled unknown: x_t once every later one is subtracted
+            double xv = (y[p0 + t] - ((part[0][t] + part[1][t]) + (RG > 3 ? part[2][t] + part[3][t] : part[2][t]))) * inv;      // scaled unknown: x_t once every later one is subtracted
             // column t of L11 in two halves of 16 registers (the prefetched row blocks need the rest of the 128 a thread may use)
 #pragma unroll
             for (int hh = 1; hh >= 0; hh--) {
@@ -2181,6 +2184,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
                     }
                     if (n <= 128) hipLaunchKernelGGL(k_chol_backsub_reg<4>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
                     else if (n <= 224) hipLaunchKernelGGL(k_chol_backsub_reg<7>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
+                    else if (n <= 256) hipLaunchKernelGGL(k_chol_backsub_reg<8>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
                     else if (n <= 320) hipLaunchKernelGGL(k_chol_backsub_reg<10>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
                     else if (n <= CHOL_LDS_X) hipLaunchKernelGGL(k_chol_backsub<false>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
                     else hipLaunchKernelGGL(k_chol_backsub<true>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
