@@ -1158,6 +1158,9 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
     __shared__ __attribute__((aligned(16))) double LpD[CNB][CNB + 2];     // previous panel, rows of this diagonal block; afterwards the column exchange buffer of the block factorisation
     __shared__ double LpR[64][CNB + 2];      // previous panel, this workgroup's rows (pitch 34: conflict-free MFMA operand reads)
     __shared__ int sBad;
+    __shared__ __attribute__((aligned(16))) double cbx[CNB / 4][CNB][4];   // per 4-column block: L[q][c0 .. c0 + 3] of the 32 rows (zero up to the block's last row)
+    __shared__ __attribute__((aligned(16))) double dpub[CNB / 4][12];       // per block: the factored 4x4 diagonal part (6 sub-diagonal entries) and the 4 reciprocal pivots
+    __shared__ int xReady;                                                // blocks published by the wave of the diagonal block
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nPW) {
         // ---- rest of the trailing update of the previous panel (q0 = p0 - 32): tiles (I, K), I >= K >= 1, relative to row/column p0
@@ -1195,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
     const int wave = tid >> 6, lane = tid & 63, nb = min(CNB, n - p0);
     const int r0 = p0 + nb + blockIdx.x * CHOL_RPW;   // first row of this workgroup's part of the panel below
     const bool hasPrev = p0 > 0;
-    if (tid == 64) sBad = 0;
+    if (tid == 64) { sBad = 0; xReady = 0; }
     {   // global memory is only touched by the whole workgroup, a row segment of 32 doubles per 32 threads.  Every load is UNCONDITIONAL from a
         // clamped (always valid) address and masked afterwards: predicated loads sit in their own exec regions, which the compiler does not
         // merge, so each waited for its data before the next was issued - 24 dependent round trips to rows that the previous launch's
@@ -1264,41 +1267,32 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
     }
     if (hasPrev) __syncthreads();
     if (wave == 0) {
-        // ONE WAVE, no barrier inside: the diagonal block and this workgroup's rows below it are eliminated together, blocked by four
-        // columns.  Lane = (row r, half hf) keeps A[r][16 hf .. 16 hf + 15] of the diagonal block in registers AND lane = panel row
-        // keeps its whole row (32 registers; lane 63: the right-hand side).  Per block the 4x4 diagonal part travels by v_readlane
-        // and is factored redundantly by every lane (wave-uniform scalars), every lane eliminates its own entries against it, the
-        // four finished columns of the diagonal block go through a small LDS buffer ONCE (rows up to the block's last one stored as
-        // zero, which also masks the finished columns and the upper triangle), and the rank-4 updates - of the rest of the block and
-        // of the rest of the panel rows - read their multipliers back as 16-byte broadcasts.  8 exchange rounds and 8 x 4 dependent
-        // pivots instead of 32 column steps with two v_readlane per multiply-add followed by a separate forward substitution of the
-        // rows (9.2 + 3.3 us per panel before, measured with s_memrealtime).
+        // THE DIAGONAL BLOCK on one wave, no barrier inside, blocked by four columns.  Lane = (row r, half hf) keeps A[r][16 hf .. 16 hf + 15] in
+        // registers.  Per block the 4x4 diagonal part travels by v_readlane and is factored redundantly by every lane (wave-uniform scalars), every
+        // lane eliminates its own entries against it, the four finished columns go through LDS ONCE (rows up to the block's last one stored as zero,
+        // which also masks the finished columns and the upper triangle; one buffer per block, cbx[cb], because the wave of the panel rows below
+        // reads them too, at its own pace), and the rank-4 update of the rest of the block reads its multipliers back as 16-byte broadcasts.
+        // 8 exchange rounds and 8 x 4 dependent pivots instead of 32 column steps.  History (s_memrealtime per panel): columns in LDS with two
+        // barriers each 31 us; a register wave with v_readlane per multiply-add + a second wave for the rows afterwards 17; this blocked wave with
+        // the panel rows inside it 7.9; with the rows on their own wave (below) 5.
         const int r = lane & 31, hf = lane >> 5;
-        double(*cbBase)[4] = (double(*)[4]) & LpD[0][0];  // 2 x [64][4] (alternating): rows 0..31 live, 32..63 the dump of the half that does not own the block
-        double a[16], x[CNB];
+        double(*cbDump)[4] = (double(*)[4]) & LpD[0][0];  // [32][4]: where the half that does not own a block's columns drops its (unused) values
+        double a[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) a[q] = Ld[r][16 * hf + q];
-#pragma unroll
-        for (int c = 0; c < CNB; c++) x[c] = Tt[lane][c];
         bool bad = false;
         double invOwn = 1.0;
-        const bool ywLive = lane < CHOL_RPW && r0 + lane < n;
-        const double yw = ywLive ? ywork[r0 + lane] : 0.0;     // in flight during the elimination
 #pragma unroll
         for (int cb = 0; cb < CNB / 4; cb++) {
             const int c0 = 4 * cb, hc = c0 >> 4, j0 = c0 & 15;
-            double(*cb4)[4] = cbBase + 64 * (cb & 1);
-            // ---- region A: the pivot chain of this block (every dependent FP64 operation ~16 cycles, nothing to overlap it with inside
-            // the diagonal block) next to the rank-4 update of the PANEL ROWS by the previous block, which only this block's own
-            // elimination of x[c0..c0+3] waits for.  Scheduling barriers keep the compiler from merging more than that (without them
-            // it hoists the loads of all eight blocks and spills 700 registers).
+            double(*cb4)[4] = cbx[cb];
+            // ---- region A: the pivot chain of this block (every dependent FP64 operation ~16 cycles).  Scheduling barriers keep the compiler from
+            // merging the blocks (without them it hoists the loads of all eight and spills).
             double d[4][4], inv[4];
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int k = 0; k <= i; k++) d[i][k] = readlane_f64(a[j0 + k], c0 + i + 32 * hc);
-            double(*cbp)[4] = cbBase + 64 * ((cb + 1) & 1);    // the previous block's columns
-            const int p = c0 - 4, nq = CNB - c0, chunk = (nq + 3) / 4;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const double piv = d[k][k];
@@ -1311,13 +1305,6 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
                 for (int i = k + 1; i < 4; i++)
 #pragma unroll
                     for (int m = k + 1; m <= i; m++) d[i][m] = __builtin_fma(-d[i][k], d[m][k], d[i][m]);
-                if (cb > 0) {   // a quarter of the previous block's rank-4 update of the panel rows rides on this pivot's latency
-#pragma unroll
-                    for (int q = c0 + k * chunk; q < min(c0 + (k + 1) * chunk, CNB); q++) {      // multipliers L[q][p..p+3], the same address for every lane
-                        const double2 m01 = *(const double2 *)cbp[q], m23 = *(const double2 *)(cbp[q] + 2);
-                        x[q] = __builtin_fma(-x[p + 3], m23.y, __builtin_fma(-x[p + 2], m23.x, __builtin_fma(-x[p + 1], m01.y, __builtin_fma(-x[p], m01.x, x[q]))));
-                    }
-                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -1331,18 +1318,20 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
             const bool own = hf == hc;
 #pragma unroll
             for (int k = 0; k < 4; k++) a[j0 + k] = own ? l[k] : a[j0 + k];
-            x[c0] = x[c0] * inv[0];
-            x[c0 + 1] = __builtin_fma(-x[c0], d[1][0], x[c0 + 1]) * inv[1];
-            x[c0 + 2] = __builtin_fma(-x[c0 + 1], d[2][1], __builtin_fma(-x[c0], d[2][0], x[c0 + 2])) * inv[2];
-            x[c0 + 3] = __builtin_fma(-x[c0 + 2], d[3][2], __builtin_fma(-x[c0 + 1], d[3][1], __builtin_fma(-x[c0], d[3][0], x[c0 + 3]))) * inv[3];
-            if (cb == CNB / 4 - 1) break;        // nothing left to update
+            if (lane == 0) {      // what the wave of the panel rows needs of this block besides the columns below
+                *(double2 *)&dpub[cb][0] = make_double2(d[1][0], d[2][0]); *(double2 *)&dpub[cb][2] = make_double2(d[2][1], d[3][0]);
+                *(double2 *)&dpub[cb][4] = make_double2(d[3][1], d[3][2]); *(double2 *)&dpub[cb][6] = make_double2(inv[0], inv[1]);
+                *(double2 *)&dpub[cb][8] = make_double2(inv[2], inv[3]);
+            }
             const bool below = r > c0 + 3;
-            double *wr = cb4[own ? r : 32 + r];
+            double *wr = own ? cb4[r] : cbDump[r];
             *(double2 *)wr = make_double2(below ? l[0] : 0.0, below ? l[1] : 0.0);
             *(double2 *)(wr + 2) = make_double2(below ? l[2] : 0.0, below ? l[3] : 0.0);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&xReady, cb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // block cb is published
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (cb == CNB / 4 - 1) break;        // nothing left to update
             // ---- region B: the rest of the diagonal block (no fence needed: the LDS executes the instructions of a wave in order)
             const double2 lr01 = *(const double2 *)cb4[r], lr23 = *(const double2 *)(cb4[r] + 2);
 #pragma unroll
@@ -1355,10 +1344,39 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
         }
 #pragma unroll
         for (int q = 0; q < 16; q++) if (16 * hf + q <= r) Ld[r][16 * hf + q] = a[q];
-#pragma unroll
-        for (int c = 0; c < CNB; c++) Tt[lane][c] = x[c];
         if (bad && lane == 0) sBad = 1;
         if (blockIdx.x == 0 && lane < CNB) diagInv[p0 + lane] = invOwn;      // (the buffer is padded to a multiple of 32)
+    } else if (wave == 1) {
+        // THE PANEL ROWS on a second wave (another SIMD): lane = panel row with its 32 entries in registers, lane 63 the right-hand side.  It follows
+        // the diagonal block's wave one block behind: as soon as block cb is published (its four columns of L11 in cbx[cb], the factored 4x4 part and
+        // the reciprocal pivots in dpub[cb]; a counter in LDS, polled) it solves its four entries and applies the rank-4 update to the rest of its
+        // row.  The elimination wave is bound by instruction issue, not by latency (~1300 FP64 operations, 420 ds_read_b128, the AGPR traffic of
+        // 500 live registers in 19 k cycles): the rows' share - 450 multiply-adds and 290 of the LDS reads - now issues next to it instead of inside it.
+        double x[CNB];
+#pragma unroll
+        for (int c = 0; c < CNB; c++) x[c] = Tt[lane][c];
+        const bool ywLive = lane < CHOL_RPW && r0 + lane < n;
+        const double yw = ywLive ? ywork[r0 + lane] : 0.0;     // in flight during the elimination
+#pragma unroll
+        for (int cb = 0; cb < CNB / 4; cb++) {
+            const int c0 = 4 * cb;
+            while (__hip_atomic_load(&xReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= cb) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const double2 p0_ = *(const double2 *)&dpub[cb][0], p1_ = *(const double2 *)&dpub[cb][2], p2_ = *(const double2 *)&dpub[cb][4],
+                          p3_ = *(const double2 *)&dpub[cb][6], p4_ = *(const double2 *)&dpub[cb][8];
+            const double d10 = p0_.x, d20 = p0_.y, d21 = p1_.x, d30 = p1_.y, d31 = p2_.x, d32 = p2_.y, i0 = p3_.x, i1 = p3_.y, i2 = p4_.x, i3 = p4_.y;
+            x[c0] = x[c0] * i0;
+            x[c0 + 1] = __builtin_fma(-x[c0], d10, x[c0 + 1]) * i1;
+            x[c0 + 2] = __builtin_fma(-x[c0 + 1], d21, __builtin_fma(-x[c0], d20, x[c0 + 2])) * i2;
+            x[c0 + 3] = __builtin_fma(-x[c0 + 2], d32, __builtin_fma(-x[c0 + 1], d31, __builtin_fma(-x[c0], d30, x[c0 + 3]))) * i3;
+#pragma unroll
+            for (int q = c0 + 4; q < CNB; q++) {      // multipliers L[q][c0 .. c0 + 3], the same address for every lane
+                const double2 m01 = *(const double2 *)cbx[cb][q], m23 = *(const double2 *)(cbx[cb][q] + 2);
+                x[q] = __builtin_fma(-x[c0 + 3], m23.y, __builtin_fma(-x[c0 + 2], m23.x, __builtin_fma(-x[c0 + 1], m01.y, __builtin_fma(-x[c0], m01.x, x[q]))));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CNB; c++) Tt[lane][c] = x[c];
         // b of the rows below -= L21 y   (y = the solved right-hand side in lane 63)
         double dot[4] = {0, 0, 0, 0};
 #pragma unroll
