@@ -579,13 +579,27 @@ __global__ __launch_bounds__(256) void k_trial_finish(const double *partChi, int
 struct UnpackSegs {
     unsigned long long src[UNPACK_MAX];   // byte offset in the arena (256-byte aligned)
     void *dst[UNPACK_MAX];                // device array (hipMalloc alignment); nullptr src offset ~0ull = fill with zero
-    unsigned long long bytes[UNPACK_MAX];
+    unsigned long long bytes[UNPACK_MAX]; // kind 0: bytes to copy / clear; kind 1, 2: number of elements
+    int kind[UNPACK_MAX];                 // 0: copy / clear; 1: float -> double (the boundary's float arrays travel as floats: 1 MB less per 60k edges on the
+                                          // way up, and the host does a memcpy instead of a conversion loop); 2: stereo flag of every observation triplet, !(obs[2] < 0)
     int n;
 };
 __global__ __launch_bounds__(256) void k_unpack(const uint8_t *arena, UnpackSegs sg)
 {
     const size_t stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     for (int i = 0; i < sg.n; i++) {
+        if (sg.kind[i] == 1) {
+            const float *sf = (const float *)(arena + sg.src[i]);
+            double *dd = (double *)sg.dst[i];
+            for (size_t w = t0; w < sg.bytes[i]; w += stride) dd[w] = (double)sf[w];
+            continue;
+        }
+        if (sg.kind[i] == 2) {
+            const float *sf = (const float *)(arena + sg.src[i]);
+            uint8_t *db = (uint8_t *)sg.dst[i];
+            for (size_t w = t0; w < sg.bytes[i]; w += stride) db[w] = !(sf[3 * w + 2] < 0);
+            continue;
+        }
         const size_t nb = sg.bytes[i], nw = nb >> 3;
         const bool zero = sg.src[i] == ~0ull;
         const unsigned long long *s8 = (const unsigned long long *)(arena + (zero ? 0 : sg.src[i]));
@@ -2296,7 +2310,7 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     // buffer (copies from pageable vectors are staged and synchronous: a dozen of them cost 0.3 ms of a 5 ms call) ----
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t oPose = 0, oIntr = oPose + pad((size_t)K * sizeof(DPose)), oPt = oIntr + pad((size_t)5 * K * 8), oObs = oPt + pad((size_t)3 * P * 8),
-                 oInfo = oObs + pad((size_t)3 * E * 8), oSt = oInfo + pad((size_t)E * 8), oEp = oSt + pad((size_t)E), oEk = oEp + pad((size_t)E * 4),
+                 oInfo = oObs + pad((size_t)3 * E * 4), oEp = oInfo + pad((size_t)E * 4), oEk = oEp + pad((size_t)E * 4),      // observations / information as floats
                  oPs = oEk + pad((size_t)E * 4), oKs = oPs + pad(((size_t)P + 1) * 4), oFx = oKs + pad(((size_t)K + 1) * 4), inBytes = oFx + pad((size_t)K);
     const size_t dFlag = 0, dChi = dFlag + pad((size_t)E), dPose = dChi + pad((size_t)E * 8), dPt = dPose + pad((size_t)K * sizeof(DPose)),
                  outBytes = dPt + pad((size_t)3 * P * 8);
@@ -2322,8 +2336,8 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     // the copy: the results come back into the front of the same buffer long after the device has consumed it.
     uint8_t *io = h->hostIO;
     DPose *pose = (DPose *)(io + oPose);
-    double *intr = (double *)(io + oIntr), *pt = (double *)(io + oPt), *obs = (double *)(io + oObs), *info = (double *)(io + oInfo);
-    uint8_t *stereo = io + oSt, *fixedH = io + oFx;
+    double *intr = (double *)(io + oIntr), *pt = (double *)(io + oPt);
+    uint8_t *fixedH = io + oFx;
     int *epH = (int *)(io + oEp), *ekH = (int *)(io + oEk), *ptStart = (int *)(io + oPs), *kfStart = (int *)(io + oKs);
     for (int k = 0; k < K; k++) {
         double R[9];
@@ -2337,15 +2351,16 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     for (int i = 0; i < 3 * P; i++) pt[i] = p->points[i];
     for (int l = 0; l <= P; l++) ptStart[l] = 0;
     for (int k = 0; k <= K; k++) kfStart[k] = 0;
+    // the edge arrays travel as they are (float observations / information, int ids): four memcpy; the device converts and derives the stereo flags
+    // (k_unpack).  The host only checks the ids and counts the row lengths of the adjacency lists.
+    memcpy(io + oObs, p->edge_obs, (size_t)3 * E * sizeof(float));
+    memcpy(io + oInfo, p->edge_inv_sigma2, (size_t)E * sizeof(float));
+    memcpy(epH, p->edge_point, (size_t)E * sizeof(int));
+    memcpy(ekH, p->edge_keyframe, (size_t)E * sizeof(int));
     for (int e = 0; e < E; e++) {
-        const int l = p->edge_point[e], k = p->edge_keyframe[e];
+        const int l = epH[e], k = ekH[e];
         if (l < 0 || l >= P || k < 0 || k >= K) { orbx_set_error("edge %d references a vertex out of range", e); return ORBX_ERR_ARG; }
-        const float *ob = p->edge_obs + 3 * (size_t)e;
-        obs[3 * (size_t)e] = ob[0]; obs[3 * (size_t)e + 1] = ob[1]; obs[3 * (size_t)e + 2] = ob[2];
-        stereo[e] = !(ob[2] < 0);
-        info[e] = p->edge_inv_sigma2[e];
-        epH[e] = l; ekH[e] = k;
-        ptStart[l + 1]++; kfStart[k + 1]++;      // row lengths of the adjacency lists
+        ptStart[l + 1]++; kfStart[k + 1]++;
     }
     Ctx c;
     c.h = h; c.stop = stop;
@@ -2357,9 +2372,9 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
         ORBX_HIP_CHECK(hipMemcpyAsync(h->inArena.p, io, inBytes, hipMemcpyHostToDevice, s));
         UnpackSegs sg;
         int ns = 0;
-        auto seg = [&](size_t off, void *dst, size_t bytes) { sg.src[ns] = off; sg.dst[ns] = dst; sg.bytes[ns] = bytes; ns++; };
+        auto seg = [&](size_t off, void *dst, size_t bytes, int kind = 0) { sg.src[ns] = off; sg.dst[ns] = dst; sg.bytes[ns] = bytes; sg.kind[ns] = kind; ns++; };
         seg(oPose, h->pose.p, (size_t)K * sizeof(DPose)); seg(oPt, h->pt.p, (size_t)3 * P * 8); seg(oIntr, h->intr.p, (size_t)5 * K * 8);
-        seg(oObs, h->obs.p, (size_t)3 * E * 8); seg(oInfo, h->info.p, (size_t)E * 8); seg(oSt, h->stereo.p, (size_t)E);
+        seg(oObs, h->obs.p, (size_t)3 * E, 1); seg(oInfo, h->info.p, (size_t)E, 1); seg(oObs, h->stereo.p, (size_t)E, 2);
         seg(oEp, h->ep.p, (size_t)E * 4); seg(oEk, h->ek.p, (size_t)E * 4);
         seg(oPs, h->ptStart.p, ((size_t)P + 1) * 4); seg(oKs, h->kfStart.p, ((size_t)K + 1) * 4); seg(oFx, h->fixedDev.p, (size_t)K);
         seg(~(size_t)0, h->err.p, (size_t)E * 3 * 8);
