@@ -197,16 +197,23 @@ struct LbaDev {   // device views, all sized by the handle
     const int *ptIdx;           // P: active landmark index or -1
     double *err;                // 3E, _error as last computed
     double *rchi;               // E, (robust) chi2 of active edges, 0 otherwise
-    double *edgeBlk;            // 72 per edge: Hll(6) bl(3) Hpp(21) bp(6) Hpl(18) BD(18)
+    double *edgeBlk;            // 72 per edge in three dense arrays: Hpl(18) | BD(18) | Hll(6) bl(3) Hpp(21) bp(6)  (eb_hpl / eb_bd / eb_rest)
 };
 
+// Layout of d.edgeBlk: three dense arrays over the edges, not one record per edge - the Schur kernels gather Hpl of partner edges all over the window
+// (60k x ~6 partners per trial); out of 576-byte records that was two or three cache lines for 144 useful bytes and a 34 MB footprint, as an array of its
+// own Hpl is 8.6 MB.
+//   [0, 18 E)      Hpl, 18 per edge            (eb_hpl)
+//   [18 E, 36 E)   B * D^-1 of the current trial (eb_bd; k_schur_setup -> k_schur_rows)
+//   [36 E, 72 E)   Hll(6) bl(3) Hpp(21) bp(6), 36 per edge (eb_rest; only written by the launch-per-stage form, ORBX_LBA_SPLIT=1)
 #define EB_HLL 0
 #define EB_BL 6
 #define EB_HPP 9
 #define EB_BP 30
-#define EB_HPL 36
-#define EB_BD 54     /* B * D^-1 of the current trial (k_schur_points -> k_schur_rows) */
 #define EB_SIZE 72
+__device__ __forceinline__ double *eb_hpl(const LbaDev &d, int e) { return d.edgeBlk + (size_t)e * 18; }
+__device__ __forceinline__ double *eb_bd(const LbaDev &d, int e) { return d.edgeBlk + (size_t)d.E * 18 + (size_t)e * 18; }
+__device__ __forceinline__ double *eb_rest(const LbaDev &d, int e) { return d.edgeBlk + (size_t)d.E * 36 + (size_t)e * 36; }
 
 // computeError (types_six_dof_expmap.h:90-95, 122-127; cam_project .cpp:141-157)
 __device__ inline void edge_error(const LbaDev &d, int e, double out[3], double *depth)
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust
     bool st;
     double A[9], B[18], W, omr[3];
     edge_linearize(d, h, robust, e, k, l, st, A, B, W, omr);
-    double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
+    double *blk = eb_rest(d, e), *hpl = eb_hpl(d, e);
     {
         int o = 0;
 #pragma unroll
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = 0; j < 3; j++) blk[EB_HPL + 3 * i + j] = LIN_DOT(B[i] * W * A[j], B[6 + i] * W * A[3 + j], B[12 + i] * W * A[6 + j]);
+            for (int j = 0; j < 3; j++) hpl[3 * i + j] = LIN_DOT(B[i] * W * A[j], B[6 + i] * W * A[3 + j], B[12 + i] * W * A[6 + j]);
     }
 }
 
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(256) void k_sum_points(LbaDev d, const int *ptStart
     for (int s = ptStart[l] + a; s < ptStart[l + 1]; s += 16) {
         const int e = ptEdges[s];
         if (!d.active[e]) continue;
-        const double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
+        const double *blk = eb_rest(d, e);
 #pragma unroll
         for (int i = 0; i < 6; i++) v[i] += blk[EB_HLL + i];
 #pragma unroll
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart,
     for (int s = lo + tid; s < hi; s += 256) {
         const int e = kfEdges[s];
         if (!d.active[e]) continue;
-        const double *blk = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPP;
+        const double *blk = eb_rest(d, e) + EB_HPP;
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] += blk[i];
     }
@@ -493,11 +500,11 @@ __global__ __launch_bounds__(256) void k_lin_sums(LbaDev d, Huber h, int robust,
             for (int j = i; j < 6; j++) acc[o++] += LIN_DOT(B[i] * W * B[j], B[6 + i] * W * B[6 + j], B[12 + i] * W * B[12 + j]);
 #pragma unroll
         for (int i = 0; i < 6; i++) acc[21 + i] += LIN_DOT(B[i] * omr[0], B[6 + i] * omr[1], B[12 + i] * omr[2]);
-        double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
+        double *hpl = eb_hpl(d, e);
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = 0; j < 3; j++) blk[EB_HPL + 3 * i + j] = LIN_DOT(B[i] * W * A[j], B[6 + i] * W * A[3 + j], B[12 + i] * W * A[6 + j]);
+            for (int j = 0; j < 3; j++) hpl[3 * i + j] = LIN_DOT(B[i] * W * A[j], B[6 + i] * W * A[3 + j], B[12 + i] * W * A[6 + j]);
     }
     const int slot = (tid >> 5) * 33 + (tid & 31);
 #pragma unroll
@@ -863,10 +870,10 @@ __device__ __forceinline__ void schur_points_part(int block, const LbaDev &d, co
         if (!d.active[e]) continue;
         const int pi = d.poseIdx[d.ek[e]];
         if (pi < 0) continue;
-        double *blk = d.edgeBlk + (size_t)e * EB_SIZE;
-        const double *B1 = blk + EB_HPL + 3 * r;
+        double *bd = eb_bd(d, e);
+        const double *B1 = eb_hpl(d, e) + 3 * r;
 #pragma unroll
-        for (int c = 0; c < 3; c++) blk[EB_BD + 3 * r + c] = B1[0] * I[c] + B1[1] * I[3 + c] + B1[2] * I[6 + c];
+        for (int c = 0; c < 3; c++) bd[3 * r + c] = B1[0] * I[c] + B1[1] * I[3 + c] + B1[2] * I[6 + c];
     }
 }
 
@@ -887,7 +894,7 @@ __global__ __launch_bounds__(256) void k_schur_setup(LbaDev d, int nInit, const 
 // GLOBAL = true: the block row does not fit into LDS (more than ~530 free keyframes, i.e. a global bundle adjustment of a large map):
 // the same walk with the FP64 atomics going straight to S / bs.
 template <bool GLOBAL>
-__global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart, const int *kfEdges, const int *__restrict__ kfRowS0, const int *__restrict__ kfRowN,
+__global__ __launch_bounds__(256, 6) void k_schur_rows(LbaDev d, const int *kfStart, const int *kfEdges, const int *__restrict__ kfRowS0, const int *__restrict__ kfRowN,
                                                     const int *ptEdges, const int *__restrict__ ptPi, int nP6, const double *__restrict__ Ddb, double *S, double *bs)
 {
     extern __shared__ __attribute__((aligned(16))) double rowLds[];   // [6][nP6], then 6 entries of bs
@@ -908,28 +915,29 @@ __global__ __launch_bounds__(256) void k_schur_rows(LbaDev d, const int *kfStart
         int e2v[1], i2v[1];                                   // first partner of this lane, requested before anything else is waited for
         e2v[0] = a < nE ? ptEdges[s0 + a] : 0; i2v[0] = a < nE ? ptPi[s0 + a] : -1;
         if (!d.active[e]) continue;
-        const double *pBD = d.edgeBlk + (size_t)e * EB_SIZE + EB_BD;
+        const double *pBD = eb_bd(d, e);
         double BD[18];
 #pragma unroll
         for (int i = 0; i < 18; i++) BD[i] = pBD[i];
         if (a < 6) {   // bs[i1] -= B * (D^-1 b_l): 300 addresses for all edges of the window, so it goes through the LDS row as well
-            const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL + 3 * a, *db = Ddb + (size_t)d.ep[e] * 3;
+            const double *B1 = eb_hpl(d, e) + 3 * a, *db = Ddb + (size_t)d.ep[e] * 3;
             unsafeAtomicAdd(&rowB[a], -(B1[0] * db[0] + B1[1] * db[1] + B1[2] * db[2]));
         }
         for (int a2 = a; a2 < nE; a2 += 16) {
             const int e2 = a2 == a ? e2v[0] : ptEdges[s0 + a2];
             const int i2 = a2 == a ? i2v[0] : ptPi[s0 + a2];
             if (i2 < 0 || i2 > pi) continue;            // lower block triangle only; -1 = inactive edge or fixed keyframe
-            const double *pB2 = d.edgeBlk + (size_t)e2 * EB_SIZE + EB_HPL;
-            double B2[18];
-#pragma unroll
-            for (int i = 0; i < 18; i++) B2[i] = pB2[i];
+            // the partner's block one row (= one column of the 6x6 result) at a time: with all 18 values of it next to the 18 of BD the kernel needs 110
+            // registers, four waves per SIMD, and its 1600 workgroups run in two rounds of ~14 us (s_memrealtime: the workgroups of the last y-splits start
+            // when the first ones end); the loop itself is three dependent memory round trips per step, i.e. it wants residency, not registers
+            const double *pB2 = eb_hpl(d, e2);
             double *dst = row + 6 * i2;
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+            for (int c = 0; c < 6; c++) {
+                const double b0 = pB2[3 * c], b1 = pB2[3 * c + 1], b2 = pB2[3 * c + 2];
 #pragma unroll
-                for (int c = 0; c < 6; c++)
-                    unsafeAtomicAdd(&dst[(size_t)r * nP6 + c], -(BD[3 * r] * B2[3 * c] + BD[3 * r + 1] * B2[3 * c + 1] + BD[3 * r + 2] * B2[3 * c + 2]));   // ds_add_f64
+                for (int r = 0; r < 6; r++) unsafeAtomicAdd(&dst[(size_t)r * nP6 + c], -(BD[3 * r] * b0 + BD[3 * r + 1] * b1 + BD[3 * r + 2] * b2));   // ds_add_f64
+            }
         }
     }
     if (GLOBAL) return;
@@ -1573,7 +1581,7 @@ __global__ __launch_bounds__(256) void k_backsub_update(LbaDev d, const int *ptS
                 if (!d.active[e]) continue;
                 const int pi = d.poseIdx[d.ek[e]];
                 if (pi < 0) continue;
-                const double *B1 = d.edgeBlk + (size_t)e * EB_SIZE + EB_HPL;
+                const double *B1 = eb_hpl(d, e);
 #pragma unroll
                 for (int q = 0; q < 3; q++) { double acc = 0; for (int r = 0; r < 6; r++) acc += B1[3 * r + q] * xp[6 * pi + r]; c[q] += acc; }
             }
@@ -1967,6 +1975,7 @@ struct orbx_lba {
     OrbxDevBuf<DPose> pose, poseBak;
     OrbxDevBuf<double> pt, ptBak, intr, obs, info, err, rchi, edgeBlk, Hpp, bp, Hll, bl, Dinv, Ddb, S, bs, xp, xl, red;
     OrbxDevBuf<double> Lmat, ywork, ysol, diagInv;   // multi-workgroup Cholesky: the factor and the two halves of the right-hand side
+    int numCU = 256;                                 // compute units of the device (residency of k_schur_rows)
     bool linSplit = false;                           // ORBX_LBA_SPLIT=1 (measurement switch): k_linearize, k_sum_points, k_sum_poses as separate launches
     OrbxDevBuf<int> ep, ek, ptStart, ptEdges, kfStart, kfEdges, poseIdx, ptIdx, okFlag;
     OrbxDevBuf<uint8_t> stereo, active;
@@ -1992,6 +2001,7 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     orbx_lba *h = new orbx_lba();
     h->device = device; h->maxK = max_keyframes; h->maxP = max_points; h->maxE = max_edges;
     { const char *e = getenv("ORBX_LBA_SPLIT"); h->linSplit = e && e[0] == '1'; }
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) h->numCU = cu; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
@@ -2196,11 +2206,15 @@ int optimize(Ctx &c, int iterations, double stats[4])
             }
             if (nP6 > 0) {
                 const size_t ldsRows = (size_t)(6 * nP6 + 6) * sizeof(double);
+                // y-splits per keyframe so that ALL workgroups are resident at once (six per CU at the kernel's 80 registers, fewer where the LDS row is
+                // long): a step of the edge loop is three dependent memory round trips, ~5 us, and a second round of workgroups costs a whole one
+                const int perCU = std::max(1, std::min(6, (int)(150 * 1024 / std::max<size_t>(ldsRows, 1))));
+                const int ySplit = std::max(4, std::min(32, perCU * h->numCU / std::max(K, 1)));
                 if (ldsRows > 150 * 1024) {      // > ~530 free keyframes: the block row no longer fits into LDS
                     hipLaunchKernelGGL(k_schur_rows<true>, dim3((unsigned)K, 16u), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, (const int *)h->kfRowS0.p, (const int *)h->kfRowN.p, h->ptEdges.p, (const int *)h->ptPi.p, nP6, h->Ddb.p, h->S.p, bsDev);
                 } else {
                     if (ldsRows > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
-                    hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, 32u), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, (const int *)h->kfRowS0.p, (const int *)h->kfRowN.p, h->ptEdges.p, (const int *)h->ptPi.p, nP6, h->Ddb.p, h->S.p, bsDev);
+                    hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, (unsigned)ySplit), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, (const int *)h->kfRowS0.p, (const int *)h->kfRowN.p, h->ptEdges.p, (const int *)h->ptPi.p, nP6, h->Ddb.p, h->S.p, bsDev);
                 }
                 LCHECK();
             }
