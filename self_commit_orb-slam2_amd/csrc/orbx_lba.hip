@@ -863,28 +863,46 @@ __device__ __forceinline__ void schur_points_part(int block, const LbaDev &d, co
         Dinv[(size_t)li * 9 + lane] = v;
     }
     if (lane < 3) Ddb[(size_t)l * 3 + lane] = lane == 0 ? db[0] : (lane == 1 ? db[1] : db[2]);   // D^-1 b_l, applied to bs by k_schur_rows
-    // BD = B * D^-1 (6x3 per free-pose edge)
-    const int s0 = ptStart[l], nE = ptStart[l + 1] - s0;
-    for (int t = lane; t < nE * 6; t += 64) {
-        const int a = t / 6, r = t - 6 * a, e = ptEdges[s0 + a];
-        if (!d.active[e]) continue;
-        const int pi = d.poseIdx[d.ek[e]];
-        if (pi < 0) continue;
-        double *bd = eb_bd(d, e);
-        const double *B1 = eb_hpl(d, e) + 3 * r;
-#pragma unroll
-        for (int c = 0; c < 3; c++) bd[3 * r + c] = B1[0] * I[c] + B1[1] * I[3 + c] + B1[2] * I[6 + c];
-    }
 }
 
-// The two independent preparations of a trial in ONE launch (every launch of this latency-bound loop costs ~3 us of gap besides its
-// own run time): blocks [0, nInit) initialise S / bs, the rest handle four landmarks each.
+// BD = B * D^-1 (6x3 per active edge of a free keyframe), one thread per edge.  The inverse of the landmark's damped 3x3 block is recomputed from
+// Hll here (9 loads, ~40 operations) instead of being taken from the landmark's wave: a wave walking the ~12 edges of its landmark, six rows each,
+// was two steps of four dependent loads (slot -> edge -> keyframe -> free-pose index -> block) behind the inverse; per edge everything but
+// edge -> landmark -> active index -> Hll is independent.
+__device__ __forceinline__ void schur_edges_part(int block, const LbaDev &d, const double *Hll, double lambda)
+{
+    const int e = block * 256 + threadIdx.x;
+    if (e >= d.E || !d.active[e]) return;
+    if (d.poseIdx[d.ek[e]] < 0) return;
+    const int li = d.ptIdx[d.ep[e]];
+    if (li < 0) return;
+    double M[9], I[9], B[18];
+    const double *hp = eb_hpl(d, e);
+#pragma unroll
+    for (int i = 0; i < 18; i++) B[i] = hp[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) M[i] = Hll[(size_t)li * 9 + i];
+    M[0] += lambda; M[4] += lambda; M[8] += lambda;
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0 / det;
+    I[0] = c00 * id; I[1] = (M[2] * M[7] - M[1] * M[8]) * id; I[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    I[3] = c01 * id; I[4] = (M[0] * M[8] - M[2] * M[6]) * id; I[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    I[6] = c02 * id; I[7] = (M[1] * M[6] - M[0] * M[7]) * id; I[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+    double *bd = eb_bd(d, e);
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) bd[3 * r + c] = B[3 * r] * I[c] + B[3 * r + 1] * I[3 + c] + B[3 * r + 2] * I[6 + c];
+}
+
 __global__ __launch_bounds__(256) void k_schur_setup(LbaDev d, int nInit, const double *Hpp, const double *bp, int nPose, const int *ptStart, const int *ptEdges,
                                                      const double *Hll, const double *bl, double lambda, double *S, double *bs, double *Dinv, double *Ddb, int *okFlag)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *okFlag = 1;      // the factorisation clears it at a failed pivot
+    const int nPtB = (d.P + 3) / 4;
     if ((int)blockIdx.x < nInit) schur_init_part((int)blockIdx.x, nInit, Hpp, bp, nPose, lambda, S, bs);
-    else schur_points_part((int)blockIdx.x - nInit, d, ptStart, ptEdges, Hll, bl, lambda, Dinv, Ddb);
+    else if ((int)blockIdx.x < nInit + nPtB) schur_points_part((int)blockIdx.x - nInit, d, ptStart, ptEdges, Hll, bl, lambda, Dinv, Ddb);
+    else schur_edges_part((int)blockIdx.x - nInit - nPtB, d, Hll, lambda);
 }
 
 // S[i1, i2] -= (B_1 D^-1) B_2^T for every pair of free-pose observations of a landmark, i2 <= i1 (the LOWER block
@@ -2200,7 +2218,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
             double *const bsDev = nP6 >= CHOL_MULTI_MIN_N ? h->ywork.p : h->bs.p;
             {
                 const int nInit = nP6 > 0 ? 64 : 0;
-                hipLaunchKernelGGL(k_schur_setup, dim3((unsigned)(nInit + (P + 3) / 4)), dim3(256), 0, h->stream, c.d, nInit, h->Hpp.p, h->bp.p, nPose, h->ptStart.p,
+                hipLaunchKernelGGL(k_schur_setup, dim3((unsigned)(nInit + (P + 3) / 4 + (nP6 > 0 ? (E + 255) / 256 : 0))), dim3(256), 0, h->stream, c.d, nInit, h->Hpp.p, h->bp.p, nPose, h->ptStart.p,
                                    h->ptEdges.p, h->Hll.p, h->bl.p, lambda, h->S.p, bsDev, h->Dinv.p, h->Ddb.p, h->okFlag.p);
                 LCHECK();
             }
