@@ -1577,8 +1577,8 @@ __global__ __launch_bounds__(1024) void k_chol_backsub_reg(const double *__restr
 // x_l = D^-1 (b_l - B^T x_p)   (block_solver.hpp:459-481)
 // x_l, push() and update(x) in one launch: thread t computes the increment of landmark t (k_backsub), saves the estimates of
 // keyframe t / landmark t (SparseOptimizer::push, sparse_optimizer.cpp:502-506: every vertex) and applies the increments (oplus).
-__global__ __launch_bounds__(256) void k_backsub_update(LbaDev d, const int *ptStart, const int *ptEdges, const double *bl, const double *Dinv, const double *xp,
-                                                        double *xl, DPose *poseBak, double *ptBak, double lambda, double *partL)
+__global__ __launch_bounds__(256) void k_backsub_update(LbaDev d, const int *ptStart, const int *ptEdges, const int *__restrict__ ptPi, const double *bl, const double *Dinv,
+                                                        const double *xp, double *xl, DPose *poseBak, double *ptBak, double lambda, double *partL)
 {
     __shared__ double sw[4];
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -1595,9 +1595,7 @@ __global__ __launch_bounds__(256) void k_backsub_update(LbaDev d, const int *ptS
         double c[3] = {0, 0, 0};
         if (li >= 0)
             for (int s = ptStart[t] + a; s < ptStart[t + 1]; s += 16) {
-                const int e = ptEdges[s];
-                if (!d.active[e]) continue;
-                const int pi = d.poseIdx[d.ek[e]];
+                const int e = ptEdges[s], pi = ptPi[s];      // the stage's per-slot free-pose index: -1 = inactive edge or fixed keyframe (two dependent loads less)
                 if (pi < 0) continue;
                 const double *B1 = eb_hpl(d, e);
 #pragma unroll
@@ -2272,7 +2270,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
                 h->flops += (double)nP6 * nP6 * nP6 / 3.0;
             }
             const unsigned gU = (unsigned)((std::max(K, 16 * P) + 255) / 256);
-            hipLaunchKernelGGL(k_backsub_update, dim3(gU), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->bl.p,
+            hipLaunchKernelGGL(k_backsub_update, dim3(gU), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, (const int *)h->ptPi.p, h->bl.p,
                                h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p, lambda, h->partL.p);
             LCHECK();
             h->flops += 250.0 * nAct;
