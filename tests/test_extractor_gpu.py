@@ -194,3 +194,40 @@ def test_single_frame_pyramid_equals_batch_pyramid_on_random_geometries(orbx):
         one.close(); two.close()
         done += 1
     assert done >= 12
+
+
+def test_single_frame_calls_from_eight_threads(orbx):
+    """Eight threads, one one-frame extractor each (the reference's rule: one ORBextractor per thread, include/ORBextractor.h:161; its stereo
+    constructor uses two), every call one hipGraph launch: the graphs are built concurrently on first use (serialised inside the library), replayed
+    concurrently afterwards; two image sizes so that handles of different geometry - different k_pyramid_tiles plans and LDS sizes - interleave.
+    Every result must equal the one a single thread gets."""
+    import threading
+    sizes = [(640, 480, 1000), (752, 480, 1200)]
+    frames = {sz: [orbx.synth_frame(500 + i, sz[0], sz[1]) for i in range(6)] for sz in sizes}
+    want = {}
+    for sz in sizes:
+        ref = orbx.ORBextractor(sz[2], 1.2, 8, 20, 7, max_width=sz[0], max_height=sz[1])
+        want[sz] = [ref(im) for im in frames[sz]]
+        ref.close()
+    errors = []
+
+    def work(t):
+        sz = sizes[t % 2]
+        try:
+            ext = orbx.ORBextractor(sz[2], 1.2, 8, 20, 7, max_width=sz[0], max_height=sz[1])
+            for rep in range(5):
+                for i, im in enumerate(frames[sz]):
+                    k, d = ext(im)
+                    kw, dw = want[sz][i]
+                    if len(k) != len(kw) or not (kp_matrix(k).view(np.uint32) == kp_matrix(kw).view(np.uint32)).all() or not (d == dw).all():
+                        errors.append((t, rep, i))
+            ext.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:5]
