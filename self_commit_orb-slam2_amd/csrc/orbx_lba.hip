@@ -558,10 +558,11 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 __global__ __launch_bounds__(256) void k_trial_finish(const double *partChi, int nChi, const double *partL, int nL, const double *xp, const double *bp, int nP6,
-                                                      double lambda, const int *okFlag, const double *diagMax, double *host, double seq)
+                                                      double lambda, const int *okFlag, const double *diagMax, double *host, double seq, int chiSlot, const double *lamSrc)
 {
     __shared__ double sw[3][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (lamSrc) lambda = 1e-5 * lamSrc[2];      // first trial of a stage: computeLambdaInit's value straight from k_diag_max (the host learns it with this trial's results)
     double v0 = 0, v1 = 0, v2 = 0;
     for (int i = tid; i < nChi; i += 256) v0 += partChi[i];
     for (int i = tid; i < nP6; i += 256) v1 += xp[i] * (lambda * xp[i] + bp[i]);
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256) void k_trial_finish(const double *partChi, int
     if (lane == 0) { sw[0][wave] = v0; sw[1][wave] = v1; sw[2][wave] = v2; }
     __syncthreads();
     if (tid == 0) {
-        host[0] = sw[0][0] + sw[0][1] + sw[0][2] + sw[0][3];
+        host[chiSlot] = sw[0][0] + sw[0][1] + sw[0][2] + sw[0][3];
         host[4] = sw[1][0] + sw[1][1] + sw[1][2] + sw[1][3];
         host[5] = sw[2][0] + sw[2][1] + sw[2][2] + sw[2][3];
         host[8] = okFlag ? (double)*okFlag : 1.0;
@@ -896,8 +897,9 @@ __device__ __forceinline__ void schur_edges_part(int block, const LbaDev &d, con
 }
 
 __global__ __launch_bounds__(256) void k_schur_setup(LbaDev d, int nInit, const double *Hpp, const double *bp, int nPose, const int *ptStart, const int *ptEdges,
-                                                     const double *Hll, const double *bl, double lambda, double *S, double *bs, double *Dinv, double *Ddb, int *okFlag)
+                                                     const double *Hll, const double *bl, double lambda, double *S, double *bs, double *Dinv, double *Ddb, int *okFlag, const double *lamSrc)
 {
+    if (lamSrc) lambda = 1e-5 * lamSrc[2];      // (see k_trial_finish)
     if (blockIdx.x == 0 && threadIdx.x == 0) *okFlag = 1;      // the factorisation clears it at a failed pivot
     const int nPtB = (d.P + 3) / 4;
     if ((int)blockIdx.x < nInit) schur_init_part((int)blockIdx.x, nInit, Hpp, bp, nPose, lambda, S, bs);
@@ -1578,8 +1580,9 @@ __global__ __launch_bounds__(1024) void k_chol_backsub_reg(const double *__restr
 // x_l, push() and update(x) in one launch: thread t computes the increment of landmark t (k_backsub), saves the estimates of
 // keyframe t / landmark t (SparseOptimizer::push, sparse_optimizer.cpp:502-506: every vertex) and applies the increments (oplus).
 __global__ __launch_bounds__(256) void k_backsub_update(LbaDev d, const int *ptStart, const int *ptEdges, const int *__restrict__ ptPi, const double *bl, const double *Dinv,
-                                                        const double *xp, double *xl, DPose *poseBak, double *ptBak, double lambda, double *partL)
+                                                        const double *xp, double *xl, DPose *poseBak, double *ptBak, double lambda, double *partL, const double *lamSrc)
 {
+    if (lamSrc) lambda = 1e-5 * lamSrc[2];      // (see k_trial_finish)
     __shared__ double sw[4];
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g < d.K) {                                   // keyframe g
@@ -2188,18 +2191,25 @@ int optimize(Ctx &c, int iterations, double stats[4])
             hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(1024), 0, h->stream, h->Hpp.p, nPose, h->Hll.p, nPt, h->red.p);
             LCHECK();
         }
+        // First iteration of a stage: the chi2 of the start and computeLambdaInit's lambda are NOT waited for - the first trial takes lambda from the device
+        // (k_diag_max's result), the chi2 goes to its own slot of the pinned results, and the host reads both when the trial's results arrive (one host
+        // round trip per stage less: the device sat idle for its ~20 us).
+        bool deferred = false;
+        const bool chiFromDevice = !errorsFresh;
         if (!errorsFresh || it == 0) {
             const double seq = (h->seq += 1.0);
             hipLaunchKernelGGL(k_trial_finish, dim3(1), dim3(256), 0, h->stream, h->partChi.p, (int)gE, (const double *)nullptr, 0, (const double *)nullptr, (const double *)nullptr, 0,
-                               0.0, (const int *)nullptr, it == 0 ? h->red.p : (const double *)nullptr, h->hostRedDev, seq);
+                               0.0, (const int *)nullptr, it == 0 ? h->red.p : (const double *)nullptr, h->hostRedDev, seq, it == 0 ? 6 : 0, (const double *)nullptr);
             LCHECK();
-            int rcw = wait_seq(h, seq);
-            if (rcw) return rcw;
-            if (!errorsFresh) currentChi = h->hostRed[0];
-            if (it == 0) { lambda = 1e-5 * h->hostRed[2]; ni = 2; nBad = 0; }
+            if (it == 0) deferred = true;
+            else {
+                int rcw = wait_seq(h, seq);
+                if (rcw) return rcw;
+                if (!errorsFresh) currentChi = h->hostRed[0];
+            }
         }
-        const double iniChi = currentChi;
-        if (it == 0) stats[2] = currentChi;
+        double iniChi = currentChi;
+        if (it == 0 && !deferred) stats[2] = currentChi;
         double rho = 0;
         int qmax = 0;
         do {
@@ -2217,7 +2227,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
             {
                 const int nInit = nP6 > 0 ? 64 : 0;
                 hipLaunchKernelGGL(k_schur_setup, dim3((unsigned)(nInit + (P + 3) / 4 + (nP6 > 0 ? (E + 255) / 256 : 0))), dim3(256), 0, h->stream, c.d, nInit, h->Hpp.p, h->bp.p, nPose, h->ptStart.p,
-                                   h->ptEdges.p, h->Hll.p, h->bl.p, lambda, h->S.p, bsDev, h->Dinv.p, h->Ddb.p, h->okFlag.p);
+                                   h->ptEdges.p, h->Hll.p, h->bl.p, lambda, h->S.p, bsDev, h->Dinv.p, h->Ddb.p, h->okFlag.p, deferred ? (const double *)h->red.p : (const double *)nullptr);
                 LCHECK();
             }
             if (nP6 > 0) {
@@ -2271,14 +2281,14 @@ int optimize(Ctx &c, int iterations, double stats[4])
             }
             const unsigned gU = (unsigned)((std::max(K, 16 * P) + 255) / 256);
             hipLaunchKernelGGL(k_backsub_update, dim3(gU), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, (const int *)h->ptPi.p, h->bl.p,
-                               h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p, lambda, h->partL.p);
+                               h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p, lambda, h->partL.p, deferred ? (const double *)h->red.p : (const double *)nullptr);
             LCHECK();
             h->flops += 250.0 * nAct;
             hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p);
             LCHECK();
             const double seq = (h->seq += 1.0);
             hipLaunchKernelGGL(k_trial_finish, dim3(1), dim3(256), 0, h->stream, h->partChi.p, (int)gE, h->partL.p, (int)gU, h->xp.p, h->bp.p, nP6, lambda,
-                               nP6 > 0 ? h->okFlag.p : (const int *)nullptr, (const double *)nullptr, h->hostRedDev, seq);
+                               nP6 > 0 ? h->okFlag.p : (const int *)nullptr, (const double *)nullptr, h->hostRedDev, seq, 0, deferred ? (const double *)h->red.p : (const double *)nullptr);
             LCHECK();
             // speculate unless this can be the last iteration of the stage (iteration budget, or two unproductive ones so far)
             const bool spec = it + 1 < iterations && nBad < 2 && !(c.stop && *c.stop);
@@ -2286,6 +2296,12 @@ int optimize(Ctx &c, int iterations, double stats[4])
             {   // the one wait of the trial: results and sequence number arrive in pinned memory
                 int rcw = wait_seq(h, seq);
                 if (rcw) return rcw;
+            }
+            if (deferred) {      // what the first iteration did not wait for
+                if (chiFromDevice) currentChi = h->hostRed[6];
+                lambda = 1e-5 * h->hostRed[2]; ni = 2; nBad = 0;
+                iniChi = currentChi; stats[2] = currentChi;
+                deferred = false;
             }
             double tempChi = h->hostRed[0];
             if (nP6 > 0) okHost = h->hostRed[8] != 0.0;
