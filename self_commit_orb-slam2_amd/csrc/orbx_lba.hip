@@ -398,15 +398,16 @@ __global__ __launch_bounds__(256) void k_sum_points(LbaDev d, const int *ptStart
 // go through a transposed LDS tile: thread t stores at [k][t], 216 threads add 32 consecutive entries, 27 threads add the 8 parts - a
 // fixed order, two barriers instead of the eight of a 256 -> 1 tree per value); k_sum_poses_fin adds the SP_SPLIT partial results in order.  One workgroup per keyframe walked ~5 edges x 27 gathered doubles per thread in series:
 // 16 us with 50 workgroups on a 256-CU device.
-#define SP_SPLIT 4
+#define SP_SPLIT 8        /* most workgroups per keyframe (size of the partial-sum array); the number used per call (spSplit) gives every thread of a
+                             workgroup at most ONE edge of the longest keyframe row: a second step for a few threads costs the whole dependent chain again */
 #define SP_TP 264
-__global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart, const int *kfEdges, double *part /* K x SP_SPLIT x 27 */)
+__global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart, const int *kfEdges, double *part /* K x SP_SPLIT x 27 */, int spSplit)
 {
     __shared__ double redT[27 * SP_TP];
     __shared__ double part8[27][9];
     const int k = blockIdx.x, y = blockIdx.y, pi = d.poseIdx[k], tid = threadIdx.x;
     if (pi < 0) return;
-    const int s0 = kfStart[k], n = kfStart[k + 1] - s0, per = (n + SP_SPLIT - 1) / SP_SPLIT;
+    const int s0 = kfStart[k], n = kfStart[k + 1] - s0, per = (n + spSplit - 1) / spSplit;
     const int lo = s0 + min(n, y * per), hi = s0 + min(n, (y + 1) * per);
     double acc[27];
 #pragma unroll
@@ -446,13 +447,13 @@ __global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart,
 //   blocks [0, K * SP_SPLIT)     the keyframe sums (k_sum_poses' body; first: they are the longer ones)
 //   the rest                     the landmark sums (k_sum_points' body), 16 lanes per landmark
 __global__ __launch_bounds__(256) void k_lin_sums(LbaDev d, Huber h, int robust, const int *ptStart, const int *ptEdges, double *Hll, double *bl, const int *kfStart,
-                                                  const int *kfEdges, double *part /* K x SP_SPLIT x 27 */)
+                                                  const int *kfEdges, double *part /* K x SP_SPLIT x 27 */, int spSplit)
 {
     __shared__ double redT[27 * SP_TP];
     __shared__ double part8[27][9];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= d.K * SP_SPLIT) {
-        const int l = ((int)blockIdx.x - d.K * SP_SPLIT) * 16 + (tid >> 4), a = tid & 15;
+    if ((int)blockIdx.x >= d.K * spSplit) {
+        const int l = ((int)blockIdx.x - d.K * spSplit) * 16 + (tid >> 4), a = tid & 15;
         if (l >= d.P) return;
         const int li = d.ptIdx[l];
         if (li < 0) return;
@@ -480,9 +481,9 @@ __global__ __launch_bounds__(256) void k_lin_sums(LbaDev d, Huber h, int robust,
         }
         return;
     }
-    const int k = (int)blockIdx.x / SP_SPLIT, y = (int)blockIdx.x % SP_SPLIT, pi = d.poseIdx[k];
+    const int k = (int)blockIdx.x / spSplit, y = (int)blockIdx.x % spSplit, pi = d.poseIdx[k];
     if (pi < 0) return;
-    const int s0 = kfStart[k], n = kfStart[k + 1] - s0, per = (n + SP_SPLIT - 1) / SP_SPLIT;
+    const int s0 = kfStart[k], n = kfStart[k + 1] - s0, per = (n + spSplit - 1) / spSplit;
     const int lo = s0 + min(n, y * per), hi = s0 + min(n, (y + 1) * per);
     double acc[27];
 #pragma unroll
@@ -529,14 +530,14 @@ __global__ __launch_bounds__(256) void k_lin_sums(LbaDev d, Huber h, int robust,
 #undef LIN_DOT
 // ... and the SP_SPLIT partial results added in order by a second small launch (a "last workgroup adds" inside the first one needs a
 // device-scope release, i.e. a write-back of the L2 - right after k_linearize has left 34 MB of dirty lines there: 28 us instead of 16)
-__global__ __launch_bounds__(256) void k_sum_poses_fin(LbaDev d, const double *__restrict__ part, double *__restrict__ Hpp, double *__restrict__ bp)
+__global__ __launch_bounds__(256) void k_sum_poses_fin(LbaDev d, const double *__restrict__ part, double *__restrict__ Hpp, double *__restrict__ bp, int spSplit)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x, k = idx >> 5, v = idx & 31;
     if (k >= d.K || v >= 27) return;
     const int pi = d.poseIdx[k];
     if (pi < 0) return;
     double t = 0;
-    for (int q = 0; q < SP_SPLIT; q++) t += part[((size_t)k * SP_SPLIT + q) * 27 + v];
+    for (int q = 0; q < spSplit; q++) t += part[((size_t)k * SP_SPLIT + q) * 27 + v];
     if (v >= 21) { bp[(size_t)pi * 6 + v - 21] = t; return; }
     // entry v of the upper triangle in row-major order -> (i, j)
     int i = 0, o = v;
@@ -2081,6 +2082,7 @@ struct Ctx {
     const volatile uint8_t *stop;
     const uint8_t *stageFlags = nullptr;   // device: outlier flags of the previous stage (level 1 edges), nullptr = every edge takes part
     int nPose0 = 0, nPt0 = 0;              // vertex counts of a stage without flags, known to the host from the row lengths
+    int spSplit = 4;                       // workgroups per keyframe in k_lin_sums: ceil(longest keyframe row / 256), 1 .. SP_SPLIT
 };
 
 // Waits for the sequence number k_trial_finish stores into pinned memory after its results.  The word is polled; the stream is queried
@@ -2162,9 +2164,9 @@ int optimize(Ctx &c, int iterations, double stats[4])
     bool linearized = false, rebuild = false;
     auto linearize = [&]() -> int {
         if (!h->linSplit) {      // Jacobians inside the sums that consume them: one launch + the ordered add of the keyframe partials
-            hipLaunchKernelGGL(k_lin_sums, dim3((unsigned)(K * SP_SPLIT + (P + 15) / 16)), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->ptStart.p, h->ptEdges.p, h->Hll.p,
-                               h->bl.p, h->kfStart.p, h->kfEdges.p, h->spPart.p);
-            hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p);
+            hipLaunchKernelGGL(k_lin_sums, dim3((unsigned)(K * c.spSplit + (P + 15) / 16)), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->ptStart.p, h->ptEdges.p, h->Hll.p,
+                               h->bl.p, h->kfStart.p, h->kfEdges.p, h->spPart.p, c.spSplit);
+            hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p, c.spSplit);
             LCHECK();
             h->flops += 400.0 * nAct;
             return ORBX_OK;
@@ -2173,8 +2175,8 @@ int optimize(Ctx &c, int iterations, double stats[4])
         LCHECK();
         hipLaunchKernelGGL(k_sum_points, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p);
         LCHECK();
-        hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K, SP_SPLIT), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->spPart.p);
-        hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p);
+        hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K, (unsigned)c.spSplit), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->spPart.p, c.spSplit);
+        hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p, c.spSplit);
         LCHECK();
         h->flops += 400.0 * nAct;
         return ORBX_OK;
@@ -2411,6 +2413,11 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     Ctx c;
     c.h = h; c.stop = stop;
     for (int l = 0; l < P; l++) { c.nPt0 += ptStart[l + 1] > 0; ptStart[l + 1] += ptStart[l]; }                       // row starts; vertices with an edge
+    {
+        int longest = 0;
+        for (int k = 0; k < K; k++) longest = std::max(longest, kfStart[k + 1]);
+        c.spSplit = std::max(1, std::min(SP_SPLIT, (longest + 255) / 256));
+    }
     for (int k = 0; k < K; k++) { c.nPose0 += kfStart[k + 1] > 0 && !fixedH[k]; kfStart[k + 1] += kfStart[k]; }
     hipStream_t s = h->stream;
     ORBX_HIP_CHECK(hipEventRecord(h->ev0, s));
