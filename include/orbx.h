@@ -614,8 +614,9 @@ int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *problem, const volatile 
  * and solver as the local window, one optimize(iterations) with Huber kernels iff robust, no outlier pass.
  * problem: every non-bad KeyFrame (fixed[k] = mnId == 0) and MapPoint with its observations; result as
  * orbx_lba_solve (edge_outlier / edge_chi2 = the final classification, informative only here).
- * Both entry points keep one block row of the reduced system (6 x 6*free keyframes doubles) in LDS: at most 530 free
- * keyframes, ORBX_ERR_CAPACITY beyond (the reduced system is dense here, 530 keyframes are a 3180 x 3180 factorisation). */
+ * The reduced (keyframe) system is DENSE here: its lower triangle is factored by the blocked Cholesky of csrc/orbx_lba.hip, up to
+ * 24576 unknowns = 4096 free keyframes (CHOL_DENSE_MAX_N), ORBX_ERR_CAPACITY beyond.  Up to ~530 free keyframes a block row of
+ * the Schur complement is accumulated in LDS; larger windows take the global-memory path (tested at 560 keyframes). */
 int orbx_bundle_adjustment(orbx_lba *h, const orbx_lba_problem *problem, int iterations, int robust,
                            const volatile uint8_t *stop_flag, orbx_lba_result *result);
 /* Kernel milliseconds (HIP events) spent inside the last orbx_lba_solve and FP64 flop count. */

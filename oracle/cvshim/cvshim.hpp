@@ -151,6 +151,13 @@ public:
     }
     Mat(const Mat &m) : rows(m.rows), cols(m.cols), step(m.step), data(m.data), rc_(m.rc_), type_(m.type_) { if (rc_) __atomic_add_fetch(rc_, 1, __ATOMIC_RELAXED); }
     ~Mat() { release(); }
+#ifdef CVSHIM_CALLER_DECLS
+    // COMPILE-ONLY declarations for the callers of the drop-in surface (src/Tracking.cc, src/LocalMapping.cc: `make callers`,
+    // -fsyntax-only); never linked, never executed
+    explicit Mat(const Point3_<float> &);
+    void resize(size_t);
+    void convertTo(Mat &dst, int rtype, double alpha) const;
+#endif
     Mat &operator=(const Mat &m)
     {
         if (this != &m) {
@@ -645,6 +652,25 @@ public:
 };
 template <typename T> inline FileStorage &operator<<(FileStorage &fs, const T &) { abort(); return fs; }
 
+#ifdef CVSHIM_CALLER_DECLS
+// compile-only (see class Mat): colour conversion of the input images (src/Tracking.cc:256-383), cv::SVD of the essential-matrix
+// check (src/LocalMapping.cc:481)
+enum { CV_RGB2GRAY_ = 7 };
+void cvtColor(InputArray, OutputArray, int);
+struct SVD {
+    enum { MODIFY_A = 1, NO_UV = 2, FULL_UV = 4 };
+    static void compute(InputArray, OutputArray, OutputArray, OutputArray, int flags = 0);
+};
+#endif
+
 }  // namespace cv
+
+#ifdef CVSHIM_CALLER_DECLS
+#define CV_BGR2GRAY 6
+#define CV_RGB2GRAY 7
+#define CV_BGRA2GRAY 10
+#define CV_RGBA2GRAY 11
+struct CvMat;      // include/PnPsolver.h names the C API type in member declarations only
+#endif
 
 #endif

@@ -47,14 +47,26 @@ def build_liborbx(force=False, verbose=True):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def _flags_stamp(hipcc):
+    import hashlib
+    try:
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        ver = ""
+    return hashlib.sha256((" ".join(HIP_FLAGS) + "\n" + ver).encode()).hexdigest()
+
+
+def _stamp_matches(hipcc):
+    f = LIB.parent / "obj" / "flags.stamp"
+    return f.exists() and f.read_text() == _flags_stamp(hipcc)
+
+
 def _build_liborbx_locked(force, verbose):
     """One object per source (compiled in parallel, only the stale ones), then one link: a kernel edit costs the compile of its own
     file, not of all eight."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
     common = list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [ROOT / "include" / "orbx.h"]
-    if not force and _newer(LIB, srcs + common):
-        return LIB
     hipcc = hipcc_path()
     if hipcc is None:
         if LIB.exists():
@@ -62,6 +74,14 @@ def _build_liborbx_locked(force, verbose):
         raise RuntimeError("hipcc not found and no prebuilt liborbx.so")
     objdir = LIB.parent / "obj"
     objdir.mkdir(parents=True, exist_ok=True)
+    # objects are only as good as the flags and the compiler they came from (bit-exactness hangs on -ffp-contract=off): both are
+    # hashed into a stamp next to the objects, and a different (or missing) stamp recompiles everything
+    stamp = _flags_stamp(hipcc)
+    stamp_file = objdir / "flags.stamp"
+    if not _stamp_matches(hipcc):
+        force = True
+    if not force and _newer(LIB, srcs + common):
+        return LIB
     cflags = [f for f in HIP_FLAGS if f != "-shared"]
     jobs = []
     for s in srcs:
@@ -83,6 +103,7 @@ def _build_liborbx_locked(force, verbose):
         print("[build]", " ".join(cmd).replace(str(tmp), str(LIB)), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(tmp, LIB)
+    stamp_file.write_text(stamp)
     return LIB
 
 

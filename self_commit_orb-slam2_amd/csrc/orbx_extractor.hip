@@ -308,6 +308,15 @@ int build_geometry(orbx_extractor *h, int W, int H)
     g.pyrBytes = align_up(off + 256, 256);
     if (maxNodes > 2048) { orbx_set_error("per-level feature quota %d exceeds the quadtree node capacity 2048", maxNodes); return ORBX_ERR_ARG; }
     h->nodeCap = maxNodes <= 256 ? 256 : (maxNodes <= 512 ? 512 : (maxNodes <= 1024 ? 1024 : 2048));
+    // k_octree's careful rounds sort nodes by a 32-bit key (candidate count << log2 nodeCap | position): the count of one node - at most
+    // every candidate slot of its level - has to fit the remaining bits (2^21 at 2048 nodes: ~8.4 Mpixel levels; 2^24 at 256)
+    const long long keyLimit = 1ll << (32 - (h->nodeCap == 256 ? 8 : h->nodeCap == 512 ? 9 : h->nodeCap == 1024 ? 10 : 11));
+    for (int l = 0; l < nl; l++)
+        if ((long long)g.lv[l].nCols * g.lv[l].nRows * g.lv[l].cellCap >= keyLimit) {
+            orbx_set_error("level %d (%dx%d) can hold %lld FAST candidates, the quadtree's sort key %lld at %d nodes per level", l, g.lv[l].w, g.lv[l].h,
+                           (long long)g.lv[l].nCols * g.lv[l].nRows * g.lv[l].cellCap, keyLimit - 1, h->nodeCap);
+            return ORBX_ERR_ARG;
+        }
     return ORBX_OK;
 }
 

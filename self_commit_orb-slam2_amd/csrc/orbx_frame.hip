@@ -138,7 +138,10 @@ struct orbx_frame_ops {
     OrbxDevBuf<orbx_keypoint> kpUn[2];
     OrbxDevBuf<int32_t> gridOff[2], gridIdx[2];
     int cur = 0, lastBatch = 0, lastCap = 0;
-    const int *producerWord[2] = {nullptr, nullptr};   // capacity word of the extractor batch behind result buffer b (device form only)
+    // capacity word of the extractor batch behind result buffer b (device form only): COPIED into this handle's own memory on the
+    // extractor's stream when the frame is finished - the extractor may grow, reuse or free its result buffers before the download
+    OrbxDevBuf<int> producerCopy;
+    bool producerValid[2] = {false, false};
     OrbxDevBuf<orbx_keypoint> hostKp;
     OrbxDevBuf<int32_t> hostCount;
     OrbxDevBuf<float> corners;
@@ -174,7 +177,7 @@ extern "C" void orbx_frame_ops_destroy(orbx_frame_ops *h)
     (void)hipSetDevice(h->device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     for (int b = 0; b < 2; b++) { h->kpUn[b].release(); h->gridOff[b].release(); h->gridIdx[b].release(); }
-    h->hostKp.release(); h->hostCount.release(); h->corners.release();
+    h->hostKp.release(); h->hostCount.release(); h->corners.release(); h->producerCopy.release();
     delete h;
 }
 
@@ -229,7 +232,13 @@ extern "C" int orbx_frame_finish_device(orbx_frame_ops *h, orbx_extractor *ext, 
     ORBX_HIP_CHECK(hipSetDevice(h->device));
     rc = launch_finish(h, orbx_extractor_stream_internal(ext), grid, true, view.kp, view.counts, view.batch, view.cap);
     // the capacity word of the batch these results come from (it lives in the extractor's result buffer): orbx_frame_download reports it
-    h->producerWord[h->cur] = rc == ORBX_OK ? orbx_extractor_status_word_internal(ext) : nullptr;
+    h->producerValid[h->cur] = false;
+    const int *word = rc == ORBX_OK ? orbx_extractor_status_word_internal(ext) : nullptr;
+    if (word) {
+        if ((rc = h->producerCopy.ensure(2)) != ORBX_OK) return rc;
+        ORBX_HIP_CHECK(hipMemcpyAsync(h->producerCopy.p + h->cur, word, sizeof(int), hipMemcpyDeviceToDevice, orbx_extractor_stream_internal(ext)));
+        h->producerValid[h->cur] = true;
+    }
     return rc;
 }
 
@@ -252,9 +261,9 @@ extern "C" int orbx_frame_download(orbx_frame_ops *h, orbx_extractor *ext, int b
     ORBX_HIP_CHECK(hipSetDevice(h->device));
     ORBX_HIP_CHECK(hipStreamSynchronize(ext ? orbx_extractor_stream_internal(ext) : h->stream));
     const int b = h->cur;
-    if (ext && h->producerWord[b]) {
+    if (ext && h->producerValid[b]) {
         int v = 0;
-        ORBX_HIP_CHECK(hipMemcpy(&v, h->producerWord[b], sizeof(int), hipMemcpyDeviceToHost));
+        ORBX_HIP_CHECK(hipMemcpy(&v, h->producerCopy.p + b, sizeof(int), hipMemcpyDeviceToHost));
         if (v) {
             orbx_set_error("the extractor batch these results were computed from overflowed a device capacity (bits 0x%x): results are not the reference's", v);
             return ORBX_ERR_CAPACITY;
@@ -276,7 +285,7 @@ static int host_form(orbx_frame_ops *h, const orbx_frame_grid *grid, bool undist
     if (n > 0) ORBX_HIP_CHECK(hipMemcpyAsync(h->hostKp.p, keypoints, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, h->stream));
     ORBX_HIP_CHECK(hipMemcpyAsync(h->hostCount.p, &n, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     if ((rc = launch_finish(h, h->stream, grid, undistort, h->hostKp.p, h->hostCount.p, 1, cap)) != ORBX_OK) return rc;
-    h->producerWord[h->cur] = nullptr;
+    h->producerValid[h->cur] = false;
     return orbx_frame_download(h, nullptr, 1, undistort && n > 0 ? kp_un : nullptr, grid ? grid_offsets : nullptr, grid && n > 0 ? grid_indices : nullptr);
 }
 

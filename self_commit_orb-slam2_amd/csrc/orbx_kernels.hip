@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
     __shared__ unsigned short nmap[NODECAP][4];     // old node, quadrant -> new node
     __shared__ int scanA[NODECAP];                  // children created before slot k (processing order)
     __shared__ int scanB[NODECAP];                  // untouched nodes before node i (list order)
-    __shared__ __attribute__((aligned(16))) uint32_t key[NODECAP];     // careful rounds: (count << 12) | (4095 - list position) of a candidate, 0 otherwise
+    __shared__ __attribute__((aligned(16))) uint32_t key[NODECAP];     // careful rounds: (count << log2 NODECAP) | (NODECAP - 1 - list position) of a candidate, 0 otherwise
     __shared__ unsigned short byProc[NODECAP];      // careful rounds: processing rank -> node
     __shared__ unsigned char sel[NODECAP];          // node is split in this round
     __shared__ int wsA[8], wsB[8];
@@ -734,11 +734,14 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
         } else {
             // careful round (:934-1011): candidates by (count desc, list position asc) - the list position encodes the creation order, so
             // the reference's pointer tie-break is an integer compare -, split until the list reaches N nodes
-            // One key per candidate, (count << 12) | (4095 - position): larger key = earlier; the rank is the number of larger keys, counted
-            // four keys per LDS read (a scalar loop over the counts took 4 us of a 9 us round at 217 nodes, 15 of 20 us at 434)
+            // One key per candidate, (count << log2 NODECAP) | (NODECAP - 1 - position): larger key = earlier; the rank is the number of larger
+            // keys, counted four keys per LDS read (a scalar loop over the counts took 4 us of a 9 us round at 217 nodes, 15 of 20 us at 434).
+            // The count field is 32 - log2 NODECAP bits wide (2^21 candidates in one node at NODECAP 2048, 2^24 at 256): build_geometry
+            // (orbx_extractor.hip) refuses a level whose worst-case candidate count does not fit.
+            constexpr int KEY_SHIFT = NODECAP == 256 ? 8 : NODECAP == 512 ? 9 : NODECAP == 1024 ? 10 : 11;
             for (int i = tid; i < ((nn + 3) & ~3); i += 256) {
                 const int c = i < nn ? cnt[cur][i] : 0;
-                key[i] = c > 1 ? ((uint32_t)c << 12) | (uint32_t)(4095 - i) : 0u;
+                key[i] = c > 1 ? ((uint32_t)c << KEY_SHIFT) | (uint32_t)(NODECAP - 1 - i) : 0u;
                 if (i < nn) sel[i] = 0;
             }
             if (tid == 0) sh_misc[1] = ncand;

@@ -1438,6 +1438,11 @@ extern "C" int orbx_search_local_points(orbx_matcher *m, const orbx_projection_f
     if (!m || !fr || !pose || !pt || !assigned || !in_view) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     if (!fr->counts || !pose->tcw || !pose->ratio_thresholds) { orbx_set_error("NULL array in the frame arguments"); return ORBX_ERR_ARG; }
     const int n = fr->counts[0], mm = pt->count;
+    // pose->nlevels bounds the level k_is_in_frustum predicts, nlevels the scale factors k_proj_topk reads for it
+    if (!scale_factors || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || pose->nlevels != nlevels) {
+        orbx_set_error("scale_factors has %d levels, the frustum arguments name %d (must be equal, 1..%d)", nlevels, pose->nlevels, ORBX_MAX_LEVELS);
+        return ORBX_ERR_ARG;
+    }
     if (n > 0 && (!fr->keypoints_un || !fr->descriptors || !fr->u_right)) { orbx_set_error("NULL array in the frame arguments"); return ORBX_ERR_ARG; }
     if (nmatches) *nmatches = 0;
     for (int i = 0; i < n; i++) assigned[i] = -1;

@@ -3,11 +3,15 @@
 // Error conventions follow the reference (src/ORBextractor.cc:1544-1668): empty image ->
 // silent return, outputs untouched; no keypoints -> descriptors.release().  The reference's
 // constructor and functor never throw and have no error channel: a device error here is
-// written to std::cerr (as the reference reports its own failures, e.g. src/System.cc:61) and
-// the call returns with the outputs untouched, like the empty-image case.
+// written to std::cerr (as the reference reports its own failures, e.g. src/System.cc:61), counted
+// (ErrorCount / LastError) and the call returns with EMPTY outputs - not with whatever the
+// caller's vectors held from the previous frame.  sbThrowOnError / ORBX_SHIM_FATAL=1: throw instead.
 #include "ORBextractor.h"
 
+#include <cstdlib>
+#include <cstring>
 #include <iostream>
+#include <stdexcept>
 
 #include "orbx.h"
 
@@ -23,15 +27,21 @@ namespace ORB_SLAM2
 static int gDevice = 0;
 void ORBextractor::SetDevice(int device) { gDevice = device; }
 
-static bool Fail(const char *what)
+static bool EnvFatal() { const char *e = getenv("ORBX_SHIM_FATAL"); return e && e[0] == '1'; }
+bool ORBextractor::sbThrowOnError = EnvFatal();
+
+bool ORBextractor::Fail(const char *what)
 {
-    std::cerr << "ORBextractor (orbx): " << what << " failed: " << orbx_last_error() << std::endl;
+    mLastError = std::string(what) + " failed: " + orbx_last_error();
+    ++mnErrors;
+    std::cerr << "ORBextractor (orbx): " << mLastError << std::endl;
+    if (sbThrowOnError) throw std::runtime_error("ORBextractor (orbx): " + mLastError);
     return false;
 }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : mbKeepHostPyramid(!(&orbx_shim_device_stereo_linked && orbx_shim_device_stereo_linked)), nfeatures(_nfeatures), scaleFactor(_scaleFactor),
-      nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mpHandle(0), mMaxW(0), mMaxH(0), mLastW(0), mLastH(0)
+      nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mpHandle(0), mMaxW(0), mMaxH(0), mLastW(0), mLastH(0), mnErrors(0), mbDead(false)
 {
     mvImagePyramid.resize(nlevels);
     // The tables come from the library so that getters and kernels can never disagree (no device needed for them).
@@ -52,6 +62,7 @@ ORBextractor::~ORBextractor()
 bool ORBextractor::EnsureHandle(int width, int height)
 {
     if (mpHandle && width <= mMaxW && height <= mMaxH) return true;
+    if (mbDead) return false;          // no device at construction: counted once per call in operator(), not re-opened per frame
     if (mpHandle) { orbx_extractor_destroy(mpHandle); mpHandle = 0; }
     orbx_extractor_config cfg = orbx_extractor_config();
     cfg.nfeatures = nfeatures; cfg.scale_factor = (float)scaleFactor; cfg.nlevels = nlevels;
@@ -59,7 +70,8 @@ bool ORBextractor::EnsureHandle(int width, int height)
     cfg.max_width = width > mMaxW ? width : mMaxW;
     cfg.max_height = height > mMaxH ? height : mMaxH;
     cfg.max_batch = 1; cfg.device = gDevice;
-    if (orbx_extractor_create(&cfg, &mpHandle) != ORBX_OK) { mpHandle = 0; return Fail("create"); }
+    const int rc = orbx_extractor_create(&cfg, &mpHandle);
+    if (rc != ORBX_OK) { mpHandle = 0; mbDead = rc == ORBX_ERR_NODEVICE; return Fail("create"); }
     mMaxW = cfg.max_width; mMaxH = cfg.max_height;
     return true;
 }
@@ -69,13 +81,21 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (_image.empty()) return;
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1);
-    if (!EnsureHandle(image.cols, image.rows)) return;
+    if (!EnsureHandle(image.cols, image.rows)) {
+        _keypoints.clear(); _descriptors.release();
+        if (mbDead) { ++mnErrors; if (sbThrowOnError) throw std::runtime_error("ORBextractor (orbx): " + mLastError); }
+        return;
+    }
 
     // results arrive in the handle's pinned buffer; they are converted straight from there
     const orbx_keypoint *kps = 0;
     const unsigned char *desc = 0;
     int n = 0;
-    if (orbx_extract_view(mpHandle, image.data, image.cols, image.rows, (int)image.step, &kps, &desc, &n) != ORBX_OK) { Fail("extract"); return; }
+    if (orbx_extract_view(mpHandle, image.data, image.cols, image.rows, (int)image.step, &kps, &desc, &n) != ORBX_OK) {
+        _keypoints.clear(); _descriptors.release();       // never the previous frame's data
+        Fail("extract");
+        return;
+    }
 
     if (n == 0)
         _descriptors.release();

@@ -4,10 +4,13 @@
 // `mvImagePyramid` member as ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:92-161),
 // so src/Frame.cc, src/Tracking.cc and src/Frame.cc::ComputeStereoMatches compile and behave
 // unchanged; the body marshals to the C ABI of liborbx.so (include/orbx.h) and the work runs
-// on the MI355X.  No CPU fallback: construction throws std::runtime_error without a GPU.
+// on the MI355X.  No CPU fallback, and - like the reference's constructor and functor - nothing throws by default: without a GPU, or
+// on a device error, operator() returns EMPTY outputs, counts the failure (ErrorCount / LastError) and writes it to std::cerr;
+// sbThrowOnError = true (or ORBX_SHIM_FATAL=1 in the environment) turns every such failure into a std::runtime_error instead.
 #ifndef ORBEXTRACTOR_H
 #define ORBEXTRACTOR_H
 
+#include <string>
 #include <vector>
 
 #include <opencv/cv.h>
@@ -45,6 +48,14 @@ public:
     bool mbKeepHostPyramid;
     void DownloadImagePyramid();
 
+    // Error channel (the reference has none: include/ORBextractor.h:92-161).  A failed call leaves `keypoints` EMPTY and `descriptors`
+    // released - never the previous frame's data -, increments ErrorCount() and keeps the message; a host program polls these instead of
+    // scraping stderr.  A device that could not be opened at construction is not retried on every frame (Dead()).
+    int ErrorCount() const { return mnErrors; }
+    const std::string &LastError() const { return mLastError; }
+    bool Dead() const { return mbDead; }
+    static bool sbThrowOnError;     // default: false, or true when ORBX_SHIM_FATAL=1 is set in the environment
+
     // Device used by extractors constructed afterwards (default 0).
     static void SetDevice(int device);
     // liborbx handle holding the device-resident results and pyramid of the last frame
@@ -55,6 +66,7 @@ private:
     ORBextractor(const ORBextractor &);
     ORBextractor &operator=(const ORBextractor &);
     bool EnsureHandle(int width, int height);
+    bool Fail(const char *what);
 
     int nfeatures;
     double scaleFactor;
@@ -65,6 +77,9 @@ private:
     std::vector<int> mnFeaturesPerLevel;
     orbx_extractor *mpHandle;
     int mMaxW, mMaxH, mLastW, mLastH;
+    int mnErrors;
+    bool mbDead;
+    std::string mLastError;
 };
 
 } // namespace ORB_SLAM2

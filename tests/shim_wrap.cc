@@ -101,3 +101,21 @@ extern "C" double shim_bench_threads(int nthreads, int nf, const unsigned char *
     for (size_t t = 0; t < ex.size(); t++) delete ex[t];
     return (double)nthreads * iters / s;
 }
+
+// Error channel of the drop-in class (shim/ORBextractor.h: ErrorCount / LastError / Dead / sbThrowOnError).  `stale` keypoints are put into
+// the caller's vector before the call: a failed call must hand back EMPTY outputs, never the previous frame's.
+extern "C" int shim_error_count(void *h) { return ((ORB_SLAM2::ORBextractor *)h)->ErrorCount(); }
+extern "C" int shim_dead(void *h) { return ((ORB_SLAM2::ORBextractor *)h)->Dead() ? 1 : 0; }
+extern "C" const char *shim_last_error(void *h) { return ((ORB_SLAM2::ORBextractor *)h)->LastError().c_str(); }
+extern "C" void shim_set_throw(int on) { ORB_SLAM2::ORBextractor::sbThrowOnError = on != 0; }
+extern "C" int shim_extract_over_stale_outputs(void *h, const unsigned char *img, int w, int hgt, int stride, int stale, int *desc_rows)
+{
+    ORB_SLAM2::ORBextractor *e = (ORB_SLAM2::ORBextractor *)h;
+    cv::Mat im(hgt, w, CV_8UC1, (void *)img, (size_t)stride);
+    std::vector<cv::KeyPoint> keys((size_t)stale);
+    cv::Mat d(stale > 0 ? stale : 1, 32, CV_8U);
+    int thrown = 0;
+    try { (*e)(im, cv::Mat(), keys, d); } catch (const std::exception &) { thrown = 1; }
+    *desc_rows = d.rows;
+    return thrown ? -1 - (int)keys.size() : (int)keys.size();
+}

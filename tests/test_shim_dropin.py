@@ -93,3 +93,33 @@ def test_host_pyramid_is_kept_unless_the_device_stereo_body_is_linked(orbx, orac
     hip = __import__("oracle_lib").slam_hip_lib()
     if hip is not None:
         assert hip.orbslam_extractor_keeps_host_pyramid() == 0
+
+
+def test_a_failed_call_returns_empty_outputs_and_is_countable(orbx):
+    """No GPU in this process: the drop-in class must not hand the previous frame's keypoints back (its outputs are cleared), counts the
+    failure, keeps the message, does not re-open the device on every frame, and throws only when asked to."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the failure path needs a process without a device")
+    orbx.load_library()
+    build_shim()
+    L = ctypes.CDLL(str(SO))
+    L.shim_create.restype = ctypes.c_void_p
+    L.shim_create.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.shim_last_error.restype = ctypes.c_char_p
+    h = ctypes.c_void_p(L.shim_create(1000, 1.2, 8, 20, 7))
+    assert h.value, "the constructor must not throw without a device"
+    assert L.shim_dead(h) == 1 and L.shim_error_count(h) == 1 and b"no HIP device" in L.shim_last_error(h)
+    im = orbx.synth_frame(5, 640, 480)
+    rows = ctypes.c_int(-1)
+    for call in range(3):
+        n = L.shim_extract_over_stale_outputs(h, im.ctypes.data_as(ctypes.c_void_p), 640, 480, 640, 7, ctypes.byref(rows))
+        assert n == 0 and rows.value == 0, "stale keypoints / descriptors survived a failed call"
+        assert L.shim_error_count(h) == 2 + call
+    L.shim_set_throw(1)
+    try:
+        n = L.shim_extract_over_stale_outputs(h, im.ctypes.data_as(ctypes.c_void_p), 640, 480, 640, 7, ctypes.byref(rows))
+        assert n < 0, "sbThrowOnError: the failure must surface as an exception"
+    finally:
+        L.shim_set_throw(0)
+    L.shim_destroy(h)
