@@ -255,11 +255,12 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
     pa = np.arange(B, dtype=np.int32)              # frame i (as "KeyFrame") ...
     pb = (np.arange(B, dtype=np.int32) + 1) % B    # ... against frame i+1 (as "Frame"), inside its launch
     issued = [0]
+    passes = [1]
 
     def step():
-        # one pass of the hot path over the rank's frames.  Nothing is synchronised between launches: consecutive batches go to
-        # alternating handle pairs (HIP stream pairs), so their kernels overlap on the GPU.
-        for bi in range(nbatches):
+        # one pass of the hot path over the rank's frames (N > 1: `passes` of them, see below).  Nothing is synchronised between
+        # launches: consecutive batches go to alternating handle pairs (HIP stream pairs), so their kernels overlap on the GPU.
+        for bi in [b for _ in range(passes[0]) for b in range(nbatches)]:
             k = issued[0] % NS
             issued[0] += 1
             exts[k].run_device(*batches[bi][1])
@@ -282,6 +283,15 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
     for _ in range(a.warmup):
         step()
     sync_all()
+    if world > 1:
+        # N > 1: the timed region of K steps must be long against the skew with which N processes leave a barrier (the driver's
+        # --steps 20 are 0.16 s per rank at one pass): every step passes over the resident batches `passes` times so that the region
+        # is >= ~1 s; all ranks use the MAX of their estimates.  Per-GPU work per step is the same at every N > 1 (weak scaling).
+        tw = time.perf_counter()
+        step()
+        sync_all()
+        est = max(time.perf_counter() - tw, 1e-4)
+        passes[0] = grp.max_int(max(1, int(np.ceil(1.0 / (est * max(1, a.steps))))))
     grp.barrier()
     sync_all()
 
@@ -299,10 +309,12 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    issue_s = time.perf_counter() - t0      # host time spent issuing the launches (a rank where this approaches `elapsed` is host bound)
     sync_all()
     grp.barrier()
     sync_all()
     elapsed = time.perf_counter() - t0
+    nbatches_timed = nbatches * passes[0]
     # per-launch kernel time of every stage inside the overlapped pipeline: each launch covers B frames
     stage_ms, timed = {}, []
     for k, e in enumerate(exts):
@@ -364,7 +376,8 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
     counts = exts[last].download(B)[2]
     status = [int(e.status()) for e in exts] if hasattr(exts[0], "status") else []
     nm_mean = float(mts[last].download(B)[2].mean()) if mt is not None else 0.0
-    t, frames_total, per_rank = grp.aggregate(elapsed, B * nbatches * a.steps, int(counts.sum()) * nbatches * a.steps)
+    t, frames_total, per_rank = grp.aggregate(elapsed, B * nbatches_timed * a.steps, int(counts.sum()) * nbatches_timed * a.steps, issue_s,
+                                              extra=(rank_info.get("numa_node", -1), rank_info.get("bound_cores", 0)))
 
     if rank != 0:
         return None
@@ -386,7 +399,7 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
     bytes_per_launch = alg[dom] * B
     achieved = bytes_per_launch / (ref_ms[dom] * 1e-3) / 1e9
     copy_bw = measured_copy_bandwidth(torch, dev_t)
-    whole_bytes = sum(alg.values()) * B * nbatches
+    whole_bytes = sum(alg.values()) * B * nbatches_timed
     whole_gbs = whole_bytes / (t / a.steps) / 1e9
     roofline = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, B),
@@ -414,7 +427,7 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
     roofline_valu = None
     if any(v for v in valu.values()):
         tot = sum(v for v in valu.values() if v)      # (alg has an "octree" key with 0 bytes: the quadtree's instructions are in the sum)
-        rate = tot * nbatches / (t / a.steps) / 1e9
+        rate = tot * nbatches_timed / (t / a.steps) / 1e9
         dv = valu.get(dom)
         roofline_valu = {"bound": "valu_issue", "unit": "G wave-instr/s", "peak": round(VALU_PEAK_GINST, 1),
                          "achieved": round(rate, 2), "frac": round(rate / VALU_PEAK_GINST, 4),
@@ -429,10 +442,13 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
         "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": wl + ", ORB extract (%d feat, 8 levels, FAST 20/7)%s" % (nf, "" if a.no_match else " + brute-force Hamming SearchByBoW of consecutive frames"),
-                   "batch_per_gpu": B, "batches_per_step": nbatches, "streams": NS, "width": W, "height": H, "nfeatures": nf,
+                   "batch_per_gpu": B, "batches_per_step": nbatches, "passes_per_step": passes[0], "streams": NS, "width": W, "height": H, "nfeatures": nf,
                    "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
                    "keypoints_per_frame": round(K, 1), "matches_per_pair": round(nm_mean, 1)},
-        "ranks": dict(rank_info, per_rank=[{"frames": r[0], "seconds": round(r[1], 6), "keypoints": r[2], "frames_per_s": round(r[0] / r[1], 1)} for r in per_rank]),
+        "ranks": dict({k: v for k, v in rank_info.items() if k not in ("numa_node", "bound_cores")},
+                      per_rank=[{"frames": r[0], "seconds": round(r[1], 6), "keypoints": r[2], "frames_per_s": round(r[0] / r[1], 1),
+                                 "launch_issue_seconds": round(r[3], 6), "issue_frac": round(r[3] / r[1], 3), "numa_node": int(r[4]), "bound_cores": int(r[5]),
+                                 "device": (rank_info.get("devices") or [None] * len(per_rank))[i]} for i, r in enumerate(per_rank)]),
         "roofline": roofline,
     }
     if roofline_valu:
@@ -734,6 +750,18 @@ def main():
     orbx = importlib.import_module("self_commit_orb-slam2_amd")
     grp = orbx.distributed.Group(device=dev_t)       # nccl (= RCCL) when WORLD_SIZE > 1
     rank_info = grp.check(a.gpus)                    # WORLD_SIZE == --gpus, and an RCCL all-reduce of ones sees every rank
+    # every rank names its GPU (UUID @ PCI address): N ranks must sit on N DISTINCT devices, otherwise the run fails here instead of
+    # producing an "N-GPU" line measured on fewer GPUs (ORBX_BENCH_SHARE_GPU=1: the 1-GPU plumbing mode, marked in the line)
+    ident = orbx.distributed.device_identity(local)
+    shared = os.environ.get("ORBX_BENCH_SHARE_GPU") == "1"
+    rank_info["devices"] = grp.gather_identities("%s@%s" % (ident["uuid"], ident["pci_bus_id"]), allow_shared=shared)
+    rank_info["distinct_devices"] = len(set(rank_info["devices"]))
+    if shared:
+        rank_info["shared_gpu_plumbing_mode"] = True
+    # N > 1: each rank on the host cores of its GPU's NUMA node (restored before rank 0's cpu_baseline, which uses every core)
+    affinity0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    bind = orbx.distributed.bind_to_numa(ident["numa_node"], grp.rank, grp.world) if grp.world > 1 else {"numa_node": ident["numa_node"], "cores": len(affinity0 or ()), "policy": "none (single rank)"}
+    rank_info["numa_node"], rank_info["bound_cores"], rank_info["affinity_policy"] = bind["numa_node"], bind["cores"], bind["policy"]
 
     fn = {"batch": bench_extract_match, "sequence": bench_extract_match, "stereo": bench_stereo, "lba": bench_lba}[a.workload]
     if a.workload != "batch" or grp.world > 1:
@@ -753,6 +781,11 @@ def main():
             except Exception as e:                   # a failing side leg must not take the headline line with it
                 out.setdefault("workloads", {})[key] = {"error": "%s: %s" % (type(e).__name__, e)}
     grp.close()                                      # (ranks > 0 are done; rank 0 alone times the host baseline below)
+    if affinity0 is not None:
+        try:
+            os.sched_setaffinity(0, affinity0)
+        except OSError:
+            pass
     if grp.rank == 0:
         if not a.no_cpu_baseline and a.workload in ("batch", "sequence"):
             # N > 1: a short sample, so that the line of every N carries the host number of the same run

@@ -4,7 +4,9 @@ Independent frames / frame pairs are the unit of work: ev
 extracts and matches its own batch.  The only communication of a run is
   * barriers around the timed region,
   * MAX over ranks of the elapsed time,
-  * ONE all-gather of {frames, seconds, keypoints} per rank (24 bytes),
+  * ONE all-gather of {frames, seconds, keypoints, launch-issue seconds} per rank (32 bytes),
+  * before the timed region: an all-reduce of ones (rank count), an all-gather of every rank's device identity (64 bytes per rank:
+    two ranks on one GPU are an error, not a scaling result) and a MAX all-reduce of the passes per step,
 over `torch.distributed` - backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 import os
@@ -40,6 +42,61 @@ def launch(nproc, argv, env=None, timeout=None, capture=False):
         if r.returncode == 0 or not capture or "ddress already in use" not in (r.stderr or ""):
             break
     return r
+
+
+def device_identity(local):
+    """What tells two GPUs apart: UUID and PCI address of CUDA/HIP device `local` (torch), plus the NUMA node the PCI function hangs on."""
+    import torch
+    p = torch.cuda.get_device_properties(local)
+    bus = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    uuid = str(getattr(p, "uuid", "")) or bus
+    node = -1
+    try:
+        with open("/sys/bus/pci/devices/%s/numa_node" % bus) as f:
+            node = int(f.read().strip())
+    except (OSError, ValueError):
+        pass
+    return {"uuid": uuid, "pci_bus_id": bus, "name": p.name, "numa_node": node}
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_numa(node, rank, world):
+    """Pin this process to the host cores next to its GPU: the cores of NUMA node `node` (read from the GPU's PCI function); ranks whose
+    GPUs hang on the same node share that node's cores.  Without NUMA information (node < 0: single-socket box, container without
+    /sys) the allowed cores are cut into `world` contiguous slices and rank r takes slice r.  Every rank issues ~20 kernel launches
+    per millisecond from Python: a rank whose thread migrates across sockets shows up as a slow rank.
+    -> {"numa_node", "cores": how many, "policy"}; never raises (no affinity support: policy "none")."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return {"numa_node": node, "cores": 0, "policy": "none"}
+    want, policy = None, "none"
+    if node >= 0:
+        try:
+            with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+                want = sorted(_parse_cpulist(f.read()) & set(allowed))
+            policy = "numa_node_of_gpu"
+        except (OSError, ValueError):
+            want = None
+    if not want and world > 1 and len(allowed) >= world:
+        per = len(allowed) // world
+        want, policy = allowed[rank * per:(rank + 1) * per], "even_slices"
+    if want:
+        try:
+            os.sched_setaffinity(0, want)
+        except OSError:
+            return {"numa_node": node, "cores": len(allowed), "policy": "none"}
+        return {"numa_node": node, "cores": len(want), "policy": policy}
+    return {"numa_node": node, "cores": len(allowed), "policy": "none"}
 
 
 def emit(obj):
@@ -111,6 +168,28 @@ class Group:
                 raise RuntimeError("%s all-reduce saw %d ranks, expected %d" % (self.backend, ones, self.world))
         return {"backend": self.backend or "none", "world": self.world, "allreduce_ones": ones}
 
+    def gather_identities(self, identity, allow_shared=False):
+        """All-gather of every rank's device identity (a short string: GPU UUID / PCI address) -> list by rank.  Two ranks naming the
+        same device raise (an "8-GPU" line measured on fewer GPUs must not exist) unless allow_shared (the 1-GPU plumbing mode)."""
+        raw = identity.encode()[:64].ljust(64, b"\0")
+        mine = torch.tensor(list(raw), dtype=torch.uint8, device=self.device)
+        if self.dist is None:
+            return [identity]
+        rows = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(rows, mine)
+        ids = [bytes(r.tolist()).rstrip(b"\0").decode(errors="replace") for r in rows]
+        if len(set(ids)) != len(ids) and not allow_shared:
+            raise RuntimeError("ranks share a device: %s" % ", ".join("rank %d = %s" % (i, d) for i, d in enumerate(ids)))
+        return ids
+
+    def max_int(self, v):
+        """MAX over ranks of a small integer (the passes per step every rank must agree on)."""
+        if self.dist is None:
+            return int(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(round(float(t.item())))
+
     def seed_base(self):
         """Seeds of rank r start at r<<32: every rank renders different frames."""
         return self.rank << 32
@@ -119,15 +198,18 @@ class Group:
         if self.dist is not None:
             self.dist.barrier()
 
-    def aggregate(self, elapsed, nframes, nkeypoints):
-        """-> (max elapsed over ranks, total frames, per-rank [frames, seconds, keypoints] rows)."""
+    def aggregate(self, elapsed, nframes, nkeypoints, issue_seconds=0.0, extra=()):
+        """-> (max elapsed over ranks, total frames, per-rank [frames, seconds, keypoints, launch-issue seconds] rows).  The last column
+        is the host time the rank spent issuing its launches inside the timed region: a rank whose issue time approaches its elapsed
+        time is host bound, not GPU bound."""
         t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
-        stats = torch.tensor([float(nframes), float(elapsed), float(nkeypoints)], dtype=torch.float64, device=self.device)
+        stats = torch.tensor([float(nframes), float(elapsed), float(nkeypoints), float(issue_seconds)] + [float(x) for x in extra], dtype=torch.float64,
+                             device=self.device)      # (`extra`: further per-rank columns, e.g. NUMA node and bound cores; same length on every rank)
         if self.dist is None:
             return float(elapsed), float(nframes), [stats.tolist()]
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         rows = [torch.zeros_like(stats) for _ in range(self.world)]
-        self.dist.all_gather(rows, stats)      # the one collective of this workload: 24 bytes per rank
+        self.dist.all_gather(rows, stats)      # the one collective of this workload: 32 bytes per rank
         rows = [r.tolist() for r in rows]
         return float(t.item()), sum(r[0] for r in rows), rows
 
