@@ -94,6 +94,31 @@ int orbx_extractor_capacity(const orbx_extractor *h);
 int orbx_extract_view(orbx_extractor *h, const uint8_t *image, int width, int height, int stride, const orbx_keypoint **keypoints,
                       const uint8_t **descriptors, int *count);
 
+/* The same call, plus the host copy of the image pyramid the reference keeps in the public member mvImagePyramid
+ * (include/ORBextractor.h:161; read by Frame::ComputeStereoMatches, src/Frame.cc:1044,1248,1272,1281): `pyramid` (may be NULL = not
+ * wanted) receives VIEWS into the handle's pinned memory - level 0 is the handle's staged copy of the caller's image, levels >= 1
+ * arrive with the results of the same launch set (no second transfer, no second wait, no host copy) -, valid until the next call on
+ * this handle.  Rows of level l are stride[l] bytes apart. */
+#define ORBX_PYRAMID_MAX_LEVELS 12
+typedef struct orbx_host_pyramid {
+    const uint8_t *level[ORBX_PYRAMID_MAX_LEVELS];
+    int width[ORBX_PYRAMID_MAX_LEVELS], height[ORBX_PYRAMID_MAX_LEVELS], stride[ORBX_PYRAMID_MAX_LEVELS];
+    int nlevels;
+} orbx_host_pyramid;
+int orbx_extract_view_pyramid(orbx_extractor *h, const uint8_t *image, int width, int height, int stride, const orbx_keypoint **keypoints,
+                              const uint8_t **descriptors, int *count, orbx_host_pyramid *pyramid);
+
+/* Single-frame calls (orbx_extract_view*, orbx_extract, orbx_extract_batch with one frame on a max_batch = 1 handle) that are inside the
+ * library at the same moment - from different handles on different threads, same device / configuration / image size - are COMBINED
+ * into one launch set on a shared engine (csrc/orbx_extractor.hip: "the combiner"); each call returns exactly what it would have
+ * returned alone.  A lone caller never waits for company.  ORBX_COMBINE=0 in the environment gives every handle its own graph instead;
+ * ORBX_COMBINE_MAX (16) = most frames per set, ORBX_COMBINE_ENGINES (2) = sets in flight.
+ * orbx_extractor_expect_partner: a one-shot hint for the NEXT call on `h` - `partner`'s call is about to arrive (the other extractor
+ * thread of the stereo Frame constructor, src/Frame.cc:159-167): the set waits for it (at most 0.3 ms) instead of leaving without it.
+ * orbx_combiner_stats: launch sets and frames served so far for h's configuration (frames / batches = mean set size). */
+int orbx_extractor_expect_partner(orbx_extractor *h, orbx_extractor *partner);
+int orbx_combiner_stats(const orbx_extractor *h, int64_t *batches, int64_t *frames, int *engines);
+
 /* ORBextractor::operator() (ORBextractor.h:110, src/ORBextractor.cc:1544-1668) for one
  * host image.  `keypoints` / `descriptors` hold `capacity` entries / capacity*32 bytes;
  * *count receives the real number (<= orbx_extractor_capacity()).  An empty image

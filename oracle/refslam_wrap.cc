@@ -232,6 +232,41 @@ ORBSLAM_API int orbslam_stereo_frame(const uint8_t *imL, const uint8_t *imR, int
     return 0;
 }
 
+// Timing of the stereo constructor as the reference calls it (src/Tracking.cc:GrabImageStereo -> Frame::Frame(imLeft, imRight, ...),
+// src/Frame.cc:100-199): two PERSISTENT extractors (Tracking owns them for the whole run), `iters` constructions cycling through `nimg`
+// image pairs after 5 untimed ones.  In liborbslam.so this times the reference's CPU path, in liborbslam_hip.so the drop-in (two
+// extractor threads -> one combined launch set, ComputeStereoMatches on the device).  No arena scope: allocation order plays no role here.
+#include <algorithm>
+#include <chrono>
+ORBSLAM_API int orbslam_stereo_frame_bench(const uint8_t *const *imL, const uint8_t *const *imR, int nimg, int w, int h, int stride, int nfeatures,
+                                           float scaleFactor, int nlevels, int iniTh, int minTh, float fx, float fy, float cx, float cy, float bf,
+                                           float thDepth, int iters, double *mean_us, double *median_us, int *nLeft, int *nMatched)
+{
+    ORBextractor *exL = new ORBextractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+    ORBextractor *exR = new ORBextractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+    cv::Mat K = make_K(fx, fy, cx, cy), dist = cv::Mat::zeros(4, 1, CV_32F);
+    Frame::mbInitialComputations = true;
+    std::vector<double> t((size_t)std::max(iters, 1));
+    int nl = 0, nm = 0;
+    for (int i = -5; i < iters; i++) {
+        const int k = (i + 5) % nimg;
+        cv::Mat L(h, w, CV_8UC1, (void *)imL[k], (size_t)stride), R(h, w, CV_8UC1, (void *)imR[k], (size_t)stride);
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        Frame F(L, R, 0.0, exL, exR, (ORBVocabulary *)nullptr, K, dist, bf, thDepth);
+        const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
+        if (i >= 0) t[(size_t)i] = std::chrono::duration<double, std::micro>(t1 - t0).count();
+        nl = F.N; nm = 0;
+        for (int j = 0; j < F.N; j++) nm += F.mvuRight[j] >= 0.0f;
+    }
+    double sum = 0;
+    for (int i = 0; i < iters; i++) sum += t[(size_t)i];
+    std::sort(t.begin(), t.begin() + iters);
+    *mean_us = sum / std::max(iters, 1); *median_us = t[(size_t)iters / 2]; *nLeft = nl; *nMatched = nm;
+    delete exL;
+    delete exR;
+    return 0;
+}
+
 // Frame::Frame(imGray, ...) (monocular constructor, src/Frame.cc:345-457): ExtractORB,
 // UndistortKeyPoints (:899-947), ComputeImageBounds (:950-1004), AssignFeaturesToGrid (:460-491).
 // dist: ndist (4 or 5) coefficients k1 k2 p1 p2 [k3].  bounds = mnMinX, mnMaxX, mnMinY, mnMaxY,

@@ -70,6 +70,9 @@ def load_library():
     L.orbx_extractor_capacity.argtypes = [vp]
     L.orbx_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp]
     L.orbx_extract_batch.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp]
+    L.orbx_extract_view_pyramid.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp]
+    L.orbx_extractor_expect_partner.argtypes = [vp, vp]
+    L.orbx_combiner_stats.argtypes = [vp, vp, vp, vp]
     L.orbx_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_size_t]
     L.orbx_batch_results_device.argtypes = [vp, vp, vp, vp, vp]
     L.orbx_batch_download.argtypes = [vp, ci, vp, vp, ci, vp]
@@ -126,6 +129,11 @@ def synth_sequence(first_seed, count, width, height, views_per_scene=16, step=(3
         flags = SYNTH_LOW_TEXTURE if (low_texture_every and i % low_texture_every == low_texture_every - 1) else 0
         out.append(synth_frame(first_seed + scene, width, height, flags, view, view * step[0], view * step[1]))
     return out
+
+
+class HostPyramid(ctypes.Structure):
+    """orbx_host_pyramid (include/orbx.h)."""
+    _fields_ = [("level", ctypes.c_void_p * 12), ("width", ctypes.c_int * 12), ("height", ctypes.c_int * 12), ("stride", ctypes.c_int * 12), ("nlevels", ctypes.c_int)]
 
 
 class ORBextractor:
@@ -196,6 +204,35 @@ class ORBextractor:
         kps, desc, counts = self.extract_batch([image])
         n = int(counts[0])
         return kps[0, :n].copy(), desc[0, :n].copy()
+
+    def extract_with_pyramid(self, image):
+        """operator() + the host pyramid of the same call (orbx_extract_view_pyramid): (keypoints, descriptors, [level 0, level 1, ...]);
+        the arrays are copies of the handle's pinned views."""
+        image = np.ascontiguousarray(image)
+        H, W = image.shape
+        kp, dp, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int()
+        pyr = HostPyramid()
+        _check(self._L.orbx_extract_view_pyramid(self._h, _ptr(image), W, H, W, ctypes.byref(kp), ctypes.byref(dp), ctypes.byref(n), ctypes.byref(pyr)))
+        self._last_size = (W, H)
+        cnt = n.value
+        kps = np.ctypeslib.as_array(ctypes.cast(kp, ctypes.POINTER(ctypes.c_uint8)), shape=(cnt * KEYPOINT_DTYPE.itemsize,)).view(KEYPOINT_DTYPE).copy() if cnt else np.zeros(0, KEYPOINT_DTYPE)
+        desc = np.ctypeslib.as_array(ctypes.cast(dp, ctypes.POINTER(ctypes.c_uint8)), shape=(cnt, 32)).copy() if cnt else np.zeros((0, 32), np.uint8)
+        levels = []
+        for l in range(pyr.nlevels):
+            w, h, st = pyr.width[l], pyr.height[l], pyr.stride[l]
+            buf = np.ctypeslib.as_array(ctypes.cast(pyr.level[l], ctypes.POINTER(ctypes.c_uint8)), shape=((h - 1) * st + w,))
+            levels.append(np.lib.stride_tricks.as_strided(buf, shape=(h, w), strides=(st, 1)).copy())
+        return kps, desc, levels
+
+    def expect_partner(self, other):
+        """One-shot hint: `other`'s single-frame call is about to arrive on another thread (orbx_extractor_expect_partner)."""
+        _check(self._L.orbx_extractor_expect_partner(self._h, other._h if other is not None else None))
+
+    def combiner_stats(self):
+        """(launch sets, frames, engines) served so far for this handle's configuration and image size."""
+        b, f, e = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        _check(self._L.orbx_combiner_stats(self._h, ctypes.byref(b), ctypes.byref(f), ctypes.byref(e)))
+        return b.value, f.value, e.value
 
     def extract_batch(self, images):
         B = len(images)

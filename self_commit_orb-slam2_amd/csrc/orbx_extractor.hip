@@ -11,7 +11,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "orbx_internal.h"
@@ -119,6 +123,14 @@ struct orbx_extractor {
     hipGraphExec_t sgExec[2] = {nullptr, nullptr};
     bool sgValid = false;
     bool sgDisabled = false;          // ORBX_NO_GRAPH=1, or graph construction failed once: plain stream launches
+    // combined single-frame calls (the combiner below): the shared engine set of this handle's (device, configuration, image size)
+    struct Combiner *comb = nullptr;
+    bool combDisabled = false;        // ORBX_COMBINE=0, or the engines could not be built: the handle's own graph
+    orbx_extractor *expectPartner = nullptr;   // one-shot hint: the next call's batch should wait (briefly) for this handle's call
+    bool isEngine = false;
+    size_t hostPyrOff = 0;            // pinned copy of the pyramid (levels >= 1) inside hostOut, behind the result arena
+    bool hostPyrValid = false;        // ... and whether the last call filled it
+    bool lastCombined = false;        // the last call ran on a shared engine: this handle's `blur` buffer (a parity tap) was not written
 };
 
 namespace {
@@ -426,6 +438,7 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     if ((rc = orbx_launch_orient_describe(L)) != ORBX_OK) return rc;
     if (prof) { ORBX_HIP_CHECK(hipEventRecord(ev[ST_DESC + 1], h->stream)); h->profCount++; }
     h->lastBatch = batch; h->lastImg0 = img0Dev; h->lastStride = stride; h->lastFramePitch = framePitch;
+    h->lastCombined = false;
     return ORBX_OK;
 }
 
@@ -505,6 +518,7 @@ extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extr
     orbx_extractor *h = new orbx_extractor();
     h->cfg = *cfg;
     { const char *ng = getenv("ORBX_NO_GRAPH"); h->sgDisabled = ng && ng[0] == '1'; }
+    { const char *nc = getenv("ORBX_COMBINE"); h->combDisabled = nc && nc[0] == '0'; }
     build_tables(h);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         orbx_set_error("hipStreamCreate failed");
@@ -759,6 +773,8 @@ static bool plan_pyramid_tiles(orbx_extractor *h, std::vector<OrbxPyrTile> &out,
 // replays  upload -> k_pyramid_tiles (all levels, one launch) -> k_fast_cells -> k_octree -> k_blur -> k_orient_describe -> read-back
 // with the pointers of result buffer `cb` baked in (one graph per buffer), followed by one synchronisation.
 // ---------------------------------------------------------------------------------------------
+static std::mutex g_graphBuildMutex;
+
 static int build_single_graph(orbx_extractor *h)
 {
     // explicit node API (no stream capture - see emit() in orbx_kernels.hip), ONE chain:
@@ -767,8 +783,7 @@ static int build_single_graph(orbx_extractor *h)
     // (measured: a second branch for k_blur next to the detector chain makes hipGraphLaunch use internal side streams - 166 us per frame
     // instead of 127 for this chain, and concurrent launches of such graphs from several threads crashed inside the runtime)
     const size_t fp = h->stagingFramePitch;
-    static std::mutex buildMutex;                 // graphs of different handles are built one at a time (first call of every handle)
-    std::lock_guard<std::mutex> lock(buildMutex);
+    std::lock_guard<std::mutex> lock(g_graphBuildMutex);      // graphs of different handles are built one at a time (first call of every handle)
     {   // the pyramid as ONE node (k_pyramid_tiles) where the geometry has a plan; ORBX_PYR_LEVELS=1: one node per level (measurement switch)
         std::vector<OrbxPyrTile> plan;
         const char *e = getenv("ORBX_PYR_LEVELS");
@@ -819,53 +834,379 @@ static int build_single_graph(orbx_extractor *h)
     return ORBX_OK;
 }
 
-static int extract_single_host(orbx_extractor *h, const uint8_t *image, int W, int H, int stride, size_t *offKpOut, size_t *offDescOut)
+// ---------------------------------------------------------------------------------------------
+// THE COMBINER.  ORBextractor::operator() is a one-frame, synchronous call (reference include/ORBextractor.h:110; callers
+// src/Frame.cc:159-167, 394, 503), and one frame occupies a fraction of the device for ~0.1 ms of mostly dependent latency.  Calls that
+// are inside the library AT THE SAME MOMENT - the left / right extractor threads of the stereo Frame constructor, the tracking threads
+// of several sequences - are therefore merged into ONE launch set of n frames on a shared ENGINE (an extractor handle with
+// max_batch = ORBX_COMBINE_MAX, its own stream, one graph per n):
+//     k_comb_upload (members' pinned frames -> engine) -> k_pyramid_tiles -> k_fast_cells -> k_octree -> k_blur -> k_orient_describe
+//     -> k_comb_finish (engine -> every member's device buffers + pinned result arena [+ pinned pyramid])
+// Protocol ("group commit"): a caller stages its frame in its own pinned buffer (in parallel with the others), then joins the OPEN batch
+// of its (device, configuration, image size); the first to join is the batch's leader.  The leader launches as soon as an engine is free
+// and nobody else is on the way in (callers announce themselves before they copy their frame) - a lone caller never waits -, bounded by
+// COMB_WAIT_US; while all engines are busy, arrivals keep joining, so the batch size follows the load.  A handle whose call was given a
+// partner hint (orbx_extractor_expect_partner: the stereo constructor's other extractor) is waited for up to COMB_PARTNER_US.  The
+// leader synchronises the engine's stream and releases the followers.  Every member ends up with exactly the state a call of its own
+// would have left: results of the frame in its double-buffered arena on the device and in pinned memory, its pyramid and level 0 on the
+// device (ComputeStereoMatches, SearchByBoW chained behind it), so nothing downstream can tell the difference.
+// ---------------------------------------------------------------------------------------------
+#define COMB_MAX_LIMIT 64
+#define COMB_WAIT_US 40.0
+#define COMB_PARTNER_US 300.0
+
+struct CombEngine {
+    orbx_extractor *eng = nullptr;
+    OrbxCombMember *tab = nullptr;           // pinned; read by the first and the last kernel of a batch
+    const OrbxCombMember *tabDev = nullptr;
+    hipGraph_t graph[COMB_MAX_LIMIT + 1] = {};
+    hipGraphExec_t exec[COMB_MAX_LIMIT + 1] = {};
+    bool planned = false, busy = false;      // busy: under Combiner::mu
+};
+
+struct CombBatch {
+    orbx_extractor *m[COMB_MAX_LIMIT];
+    bool wantPyr[COMB_MAX_LIMIT];
+    int n = 0;
+    std::vector<orbx_extractor *> waitFor;   // partners announced by members and not here yet
+    std::atomic<int> done{0};
+    int rc = ORBX_OK;
+    char err[256] = "";
+};
+
+struct Combiner {
+    orbx_extractor_config cfg;               // of the members (max_batch / max sizes aside)
+    int W = 0, H = 0, maxB = 16, maxEngines = 2;
+    int dstStride = 0;
+    size_t fp = 0, kpOff = 0, descOff = 0;
+    std::mutex mu;
+    std::atomic<int> entering{0};
+    std::shared_ptr<CombBatch> open;
+    std::vector<CombEngine *> engines;
+    std::atomic<long> batches{0}, frames{0};
+};
+
+static std::mutex g_combMu;
+static std::vector<Combiner *> g_combs;
+
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+static inline double now_us()
 {
-    if (stride < W) { orbx_set_error("bad image pointer / stride"); return ORBX_ERR_ARG; }
-    int rc = ensure_geometry(h, W, H, 1);
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static int env_int(const char *name, int dflt, int lo, int hi)
+{
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const int v = atoi(e);
+    return v < lo ? lo : v > hi ? hi : v;
+}
+
+static bool comb_cfg_equal(const orbx_extractor_config &a, const orbx_extractor_config &b)
+{
+    return a.device == b.device && a.nfeatures == b.nfeatures && a.scale_factor == b.scale_factor && a.nlevels == b.nlevels && a.ini_th_fast == b.ini_th_fast &&
+           a.min_th_fast == b.min_th_fast && memcmp(a.gauss_taps, b.gauss_taps, sizeof(a.gauss_taps)) == 0;
+}
+
+// the shared engine set for h's configuration at W x H (created on first use; lives until the process ends)
+static Combiner *combiner_for(orbx_extractor *h, int W, int H)
+{
+    if (h->comb && h->comb->W == W && h->comb->H == H) return h->comb;
+    std::lock_guard<std::mutex> lock(g_combMu);
+    for (Combiner *c : g_combs)
+        if (c->W == W && c->H == H && comb_cfg_equal(c->cfg, h->cfg)) return h->comb = c;
+    Combiner *c = new Combiner();
+    c->cfg = h->cfg; c->W = W; c->H = H;
+    c->maxB = env_int("ORBX_COMBINE_MAX", 16, 1, COMB_MAX_LIMIT);
+    c->maxEngines = env_int("ORBX_COMBINE_ENGINES", 2, 1, 8);
+    c->dstStride = (int)align_up((size_t)W + 16, 64);
+    c->fp = align_up((size_t)c->dstStride * H + 256, 256);
+    g_combs.push_back(c);
+    return h->comb = c;
+}
+
+// one more engine (the leader that found every existing one busy calls this WITHOUT Combiner::mu; engines are created one at a time)
+static int comb_new_engine(Combiner *C, CombEngine **out)
+{
+    static std::mutex createMu;
+    std::lock_guard<std::mutex> lock(createMu);
+    orbx_extractor_config cfg = C->cfg;
+    cfg.max_width = C->W; cfg.max_height = C->H; cfg.max_batch = C->maxB;
+    orbx_extractor *e = nullptr;
+    int rc = orbx_extractor_create(&cfg, &e);
     if (rc != ORBX_OK) return rc;
-    const bool graphOk = !h->sgDisabled && !h->profiling && !h->debugTaps && h->allocBatch == 1;
-    if (!graphOk) {
-        const uint8_t *imgs[1] = {image};
-        if ((rc = upload(h, imgs, 1, W, H, stride)) != ORBX_OK) return rc;
-        if ((rc = run_batch(h, h->staging.p, 1, W, H, h->stagingStride, h->stagingFramePitch)) != ORBX_OK) return rc;
-        return fetch_results(h, 1, true, true, offKpOut, offDescOut);
+    e->isEngine = true; e->combDisabled = true;
+    CombEngine *E = new CombEngine();
+    E->eng = e;
+    auto fail = [&](int code) { orbx_extractor_destroy(e); if (E->tab) (void)hipHostFree(E->tab); delete E; return code; };
+    if ((rc = ensure_geometry(e, C->W, C->H, C->maxB)) != ORBX_OK) return fail(rc);
+    if ((rc = e->staging.ensure(C->fp * (size_t)C->maxB)) != ORBX_OK) return fail(rc);
+    if (hipHostMalloc((void **)&E->tab, sizeof(OrbxCombMember) * (size_t)C->maxB, hipHostMallocDefault) != hipSuccess) { orbx_set_error("hipHostMalloc (member table) failed"); return fail(ORBX_ERR_HIP); }
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, E->tab, 0) != hipSuccess) { orbx_set_error("hipHostGetDevicePointer (member table) failed"); return fail(ORBX_ERR_HIP); }
+    E->tabDev = (const OrbxCombMember *)dp;
+    // the members' arenas have the one-frame layout (ensure_geometry with batch 1): same capacity, same offsets for all of them
+    C->kpOff = align_up(3 * sizeof(int), 256);
+    C->descOff = C->kpOff + align_up((size_t)e->geom.outCap * sizeof(orbx_keypoint), 256);
+    *out = E;
+    return ORBX_OK;
+}
+
+// the launch set of n combined frames as one graph on engine E (built the first time a batch of n members meets on E)
+static int comb_build_graph(Combiner *C, CombEngine *E, int n)
+{
+    orbx_extractor *e = E->eng;
+    std::lock_guard<std::mutex> lock(g_graphBuildMutex);
+    if (!E->planned) {
+        std::vector<OrbxPyrTile> plan;
+        const char *pl = getenv("ORBX_PYR_LEVELS");
+        e->ptTiles = 0;
+        if (!(pl && pl[0] == '1') && plan_pyramid_tiles(e, plan, e->ptTiles, e->ptLds, e->ptTab)) {
+            int rc = e->ptDev.ensure(plan.size());
+            if (rc != ORBX_OK) return rc;
+            ORBX_HIP_CHECK(hipMemcpy(e->ptDev.p, plan.data(), plan.size() * sizeof(OrbxPyrTile), hipMemcpyHostToDevice));
+        } else e->ptTiles = 0;
+        E->planned = true;
     }
-    const int dstStride = (int)align_up((size_t)W + 16, 64);
-    const size_t fp = align_up((size_t)dstStride * H + 256, 256);
-    if (!h->sgValid || h->stagingStride != dstStride || h->stagingFramePitch != fp || fp > h->hostStagingBytes || h->arenaBytes > h->hostOutBytes) {
-        // (re)build: every buffer the graph names must exist first, outside the capture
+    OrbxLaunch L;
+    fill_launch(e, L, e->staging.p, n, C->dstStride, C->fp, 0);
+    L.combTab = E->tabDev; L.combKpOff = C->kpOff; L.combDescOff = C->descOff;
+    hipGraph_t g = nullptr;
+    ORBX_HIP_CHECK(hipGraphCreate(&g, 0));
+    E->graph[n] = g;
+    L.graph = g;
+    hipGraphNode_t cur = nullptr, nxt = nullptr;
+    int rc;
+    L.ndeps = 0; L.node = &nxt;
+    if ((rc = orbx_launch_comb_upload(L, e->staging.p)) != ORBX_OK) return rc;
+    cur = nxt;
+    auto chain = [&](int r) { if (r == ORBX_OK) cur = nxt; return r; };
+    L.ndeps = 1;
+    if (e->ptTiles > 0) {
+        L.pyrTiles = e->ptDev.p; L.pyrTileCount = e->ptTiles; L.pyrTileBuf = e->ptLds; L.pyrTileTab = e->ptTab;
+        L.deps[0] = cur;
+        if ((rc = chain(orbx_launch_pyramid_tiles(L))) != ORBX_OK) return rc;
+    } else {
+        hipMemsetParams mp;
+        memset(&mp, 0, sizeof(mp));
+        mp.dst = e->status.p; mp.elementSize = sizeof(int); mp.width = (size_t)n + 1; mp.height = 1; mp.pitch = ((size_t)n + 1) * sizeof(int); mp.value = 0;
+        ORBX_HIP_CHECK(hipGraphAddMemsetNode(&nxt, g, &cur, 1, &mp));
+        cur = nxt;
+        for (int l = 1; l < e->geom.nlevels; l++) {
+            L.deps[0] = cur;
+            if ((rc = chain(orbx_launch_resize(L, l))) != ORBX_OK) return rc;
+        }
+    }
+    L.deps[0] = cur; if ((rc = chain(orbx_launch_fast_cells(L))) != ORBX_OK) return rc;
+    L.deps[0] = cur; if ((rc = chain(orbx_launch_octree(L))) != ORBX_OK) return rc;
+    L.deps[0] = cur; if ((rc = chain(orbx_launch_blur(L))) != ORBX_OK) return rc;
+    L.deps[0] = cur; if ((rc = chain(orbx_launch_orient_describe(L))) != ORBX_OK) return rc;
+    L.deps[0] = cur; if ((rc = chain(orbx_launch_comb_finish(L))) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipGraphInstantiate(&E->exec[n], g, nullptr, nullptr, 0));
+    return ORBX_OK;
+}
+
+// the frame's rows at the device pitch in the handle's pinned staging buffer (what every single-frame path uploads from, and what
+// level 0 of the host pyramid points at)
+static int stage_rows(orbx_extractor *h, const uint8_t *image, int W, int H, int stride, int dstStride, size_t fp)
+{
+    if (fp > h->hostStagingBytes) {
         ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-        invalidate_single_graph(h);
-        if ((rc = h->staging.ensure(fp)) != ORBX_OK) return rc;
-        if (fp > h->hostStagingBytes) {
-            if (h->hostStaging) (void)hipHostFree(h->hostStaging);
-            h->hostStaging = nullptr; h->hostStagingBytes = 0;
-            ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostStaging, fp, hipHostMallocDefault));
-            h->hostStagingBytes = fp;
-        }
-        if ((rc = ensure_host_out(h, h->arenaBytes)) != ORBX_OK) return rc;
-        h->stagingStride = dstStride; h->stagingFramePitch = fp;
-        if (build_single_graph(h) != ORBX_OK) {       // no graph support for this sequence: fall back to stream launches for good
-            invalidate_single_graph(h);
-            h->sgDisabled = true;
-            return extract_single_host(h, image, W, H, stride, offKpOut, offDescOut);
-        }
+        invalidate_single_graph(h);           // its upload node reads this buffer
+        if (h->hostStaging) (void)hipHostFree(h->hostStaging);
+        h->hostStaging = nullptr; h->hostStagingBytes = 0;
+        ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostStaging, fp, hipHostMallocDefault));
+        h->hostStagingBytes = fp;
     }
-    for (int y = 0; y < H; y++) memcpy(h->hostStaging + (size_t)y * dstStride, image + (size_t)y * stride, (size_t)W);
-    h->cur ^= 1;
-    const int cb = h->cur;
-    if (h->pyrConsumerEv) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->pyrConsumerEv, 0)); h->pyrConsumerEv = nullptr; }
-    if (h->consumerEv[cb]) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->consumerEv[cb], 0)); h->consumerEv[cb] = nullptr; }
-    ORBX_HIP_CHECK(hipGraphLaunch(h->sgExec[cb], h->stream));
-    h->lastBatch = 1; h->lastImg0 = h->staging.p; h->lastStride = dstStride; h->lastFramePitch = fp;
-    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (stride == dstStride) memcpy(h->hostStaging, image, (size_t)dstStride * (size_t)(H - 1) + (size_t)W);
+    else for (int y = 0; y < H; y++) memcpy(h->hostStaging + (size_t)y * dstStride, image + (size_t)y * stride, (size_t)W);
+    return ORBX_OK;
+}
+
+static int check_single_status(orbx_extractor *h, size_t *offKpOut, size_t *offDescOut)
+{
     const int st = ((const int *)h->hostOut)[1];      // arena of a one-frame handle: count | frame word | batch word | ...
     if (st) {
         orbx_set_error("frame 0: device capacity error bits 0x%x (1: FAST candidates of a level, 2: quadtree node list, 4: level keypoints)", st);
         return ORBX_ERR_CAPACITY;
     }
     *offKpOut = h->arenaKpOff; *offDescOut = h->arenaDescOff;
+    return ORBX_OK;
+}
+
+// The leader of batch B (Combiner::mu held through `lk` on entry, released on return): wait for an engine and for whoever is on the
+// way in, close the batch, run it, release the followers.
+static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::unique_lock<std::mutex> &lk)
+{
+    const double t0 = now_us();
+    CombEngine *E = nullptr;
+    for (;;) {
+        E = nullptr;
+        for (CombEngine *x : C->engines) if (!x->busy) { E = x; break; }
+        const bool full = B->n >= C->maxB;
+        const bool quiet = C->entering.load(std::memory_order_acquire) == 0 && B->waitFor.empty();
+        const bool timeUp = now_us() - t0 > (B->waitFor.empty() ? COMB_WAIT_US : COMB_PARTNER_US);
+        if (E && (full || quiet || timeUp)) break;
+        if (!E && (int)C->engines.size() < C->maxEngines) {
+            // every engine is busy (or none exists yet) and one more is allowed: build it while the batch keeps collecting members
+            lk.unlock();
+            CombEngine *ne = nullptr;
+            const int rcE = comb_new_engine(C, &ne);
+            lk.lock();
+            if (rcE == ORBX_OK) C->engines.push_back(ne);
+            else if (C->engines.empty()) {      // no engine at all: the batch's members fall back to their own graphs
+                C->open.reset();
+                B->rc = ORBX_ERR_STATE;
+                snprintf(B->err, sizeof(B->err), "%s", orbx_last_error());
+                lk.unlock();
+                B->done.store(1, std::memory_order_release);
+                return;
+            } else C->maxEngines = (int)C->engines.size();      // (no memory for another one: live with what exists)
+            continue;
+        }
+        lk.unlock(); cpu_relax(); lk.lock();
+    }
+    C->open.reset();                    // later arrivals start the next batch (and elect its leader)
+    E->busy = true;
+    const int n = B->n;
+    lk.unlock();
+    int lrc = ORBX_OK;
+    for (int i = 0; i < n; i++) {
+        orbx_extractor *mh = B->m[i];
+        OrbxCombMember &t = E->tab[i];
+        t.hostImg = mh->hostStaging; t.devImg = mh->staging.p; t.devPyr = mh->pyr.p;
+        t.devArena = mh->outArena[mh->cur].p; t.hostOut = mh->hostOut;
+        t.hostPyr = B->wantPyr[i] ? mh->hostOut + mh->hostPyrOff : nullptr;
+    }
+    if (!E->exec[n]) lrc = comb_build_graph(C, E, n);
+    if (lrc == ORBX_OK) {
+        hipError_t he = hipGraphLaunch(E->exec[n], E->eng->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(E->eng->stream);
+        if (he != hipSuccess) { orbx_set_error("combined batch of %d frames failed: %s", n, hipGetErrorString(he)); lrc = ORBX_ERR_HIP; }
+    }
+    B->rc = lrc;
+    if (lrc != ORBX_OK) snprintf(B->err, sizeof(B->err), "%s", orbx_last_error());
+    C->batches.fetch_add(1, std::memory_order_relaxed); C->frames.fetch_add(n, std::memory_order_relaxed);
+    lk.lock();
+    E->busy = false;
+    lk.unlock();
+    B->done.store(1, std::memory_order_release);
+}
+
+// One call through the combiner.  ORBX_ERR_STATE + combDisabled: the engines cannot be built here, the caller takes the handle's own path.
+static int extract_single_combined(orbx_extractor *h, const uint8_t *image, int W, int H, int stride, bool wantPyr, size_t *offKpOut, size_t *offDescOut)
+{
+    Combiner *C = combiner_for(h, W, H);
+    const int dstStride = C->dstStride;
+    const size_t fp = C->fp;
+    int rc;
+    // the member's own buffers (nothing of an earlier call is in flight: calls on a handle are synchronous)
+    if ((rc = h->staging.ensure(fp)) != ORBX_OK) return rc;
+    h->hostPyrOff = align_up(h->arenaBytes, 256);
+    if ((rc = ensure_host_out(h, h->hostPyrOff + h->geom.pyrBytes)) != ORBX_OK) return rc;
+    C->entering.fetch_add(1, std::memory_order_acq_rel);        // "on my way in": a leader about to launch waits for the copy below
+    if ((rc = stage_rows(h, image, W, H, stride, dstStride, fp)) != ORBX_OK) { C->entering.fetch_sub(1); return rc; }
+    h->stagingStride = dstStride; h->stagingFramePitch = fp;
+    h->cur ^= 1;
+    const int cb = h->cur;
+    // consumers of this handle's buffers on other streams (a matcher chained behind the previous frames): the engine's stream knows nothing of
+    // them, the host waits (they finished long ago in a synchronous caller)
+    if (h->pyrConsumerEv) { (void)hipEventSynchronize(h->pyrConsumerEv); h->pyrConsumerEv = nullptr; }
+    if (h->consumerEv[cb]) { (void)hipEventSynchronize(h->consumerEv[cb]); h->consumerEv[cb] = nullptr; }
+
+    std::unique_lock<std::mutex> lk(C->mu);
+    while (C->open && C->open->n >= C->maxB) { lk.unlock(); cpu_relax(); lk.lock(); }      // a full batch waiting for an engine: the next one
+    C->entering.fetch_sub(1, std::memory_order_acq_rel);
+    const bool leader = !C->open;
+    if (leader) C->open = std::make_shared<CombBatch>();
+    std::shared_ptr<CombBatch> B = C->open;
+    const int slot = B->n++;
+    B->m[slot] = h; B->wantPyr[slot] = wantPyr;
+    B->waitFor.erase(std::remove(B->waitFor.begin(), B->waitFor.end(), h), B->waitFor.end());
+    if (h->expectPartner) {
+        orbx_extractor *p = h->expectPartner;
+        h->expectPartner = nullptr;
+        bool here = false;
+        for (int i = 0; i < B->n; i++) here = here || B->m[i] == p;
+        if (!here && p != h) B->waitFor.push_back(p);
+    }
+    if (!leader) {
+        lk.unlock();
+        for (int spins = 0; !B->done.load(std::memory_order_acquire); spins++) { if (spins < 20000) cpu_relax(); else std::this_thread::yield(); }
+    } else comb_lead(C, B, lk);
+    if (B->rc != ORBX_OK) {
+        if (B->rc == ORBX_ERR_STATE) h->combDisabled = true;
+        orbx_set_error("%s", B->err);
+        h->cur ^= 1;                        // nothing was written: the previous results stay current
+        return B->rc;
+    }
+    h->lastBatch = 1; h->lastImg0 = h->staging.p; h->lastStride = dstStride; h->lastFramePitch = fp;
+    h->hostPyrValid = wantPyr; h->lastCombined = true;
+    return check_single_status(h, offKpOut, offDescOut);
+}
+
+static int extract_single_host(orbx_extractor *h, const uint8_t *image, int W, int H, int stride, bool wantPyr, size_t *offKpOut, size_t *offDescOut)
+{
+    if (stride < W) { orbx_set_error("bad image pointer / stride"); return ORBX_ERR_ARG; }
+    int rc = ensure_geometry(h, W, H, 1);
+    if (rc != ORBX_OK) return rc;
+    const int dstStride = (int)align_up((size_t)W + 16, 64);
+    const size_t fp = align_up((size_t)dstStride * H + 256, 256);
+    h->hostPyrValid = false;
+    const bool graphOk = !h->sgDisabled && !h->profiling && !h->debugTaps && h->allocBatch == 1;
+    if (graphOk && !h->combDisabled) {
+        rc = extract_single_combined(h, image, W, H, stride, wantPyr, offKpOut, offDescOut);
+        if (!(rc == ORBX_ERR_STATE && h->combDisabled)) return rc;      // (engines unavailable: the handle's own graph below, from now on)
+    }
+    h->hostPyrOff = align_up(h->arenaBytes, 256);
+    if (!graphOk) {
+        if ((rc = h->staging.ensure(fp)) != ORBX_OK) return rc;
+        if ((rc = stage_rows(h, image, W, H, stride, dstStride, fp)) != ORBX_OK) return rc;
+        h->stagingStride = dstStride; h->stagingFramePitch = fp;
+        if (wantPyr && (rc = ensure_host_out(h, h->hostPyrOff + h->geom.pyrBytes)) != ORBX_OK) return rc;      // (before the results land in it)
+        ORBX_HIP_CHECK(hipMemcpyAsync(h->staging.p, h->hostStaging, fp, hipMemcpyHostToDevice, h->stream));
+        if ((rc = run_batch(h, h->staging.p, 1, W, H, h->stagingStride, h->stagingFramePitch)) != ORBX_OK) return rc;
+        if ((rc = fetch_results(h, 1, true, true, offKpOut, offDescOut)) != ORBX_OK) return rc;
+    } else {
+        if (!h->sgValid || h->stagingStride != dstStride || h->stagingFramePitch != fp || fp > h->hostStagingBytes || h->hostPyrOff + h->geom.pyrBytes > h->hostOutBytes) {
+            // (re)build: every buffer the graph names must exist first, outside the capture
+            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+            invalidate_single_graph(h);
+            if ((rc = h->staging.ensure(fp)) != ORBX_OK) return rc;
+            if (fp > h->hostStagingBytes) {
+                if (h->hostStaging) (void)hipHostFree(h->hostStaging);
+                h->hostStaging = nullptr; h->hostStagingBytes = 0;
+                ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostStaging, fp, hipHostMallocDefault));
+                h->hostStagingBytes = fp;
+            }
+            if ((rc = ensure_host_out(h, h->hostPyrOff + h->geom.pyrBytes)) != ORBX_OK) return rc;
+            h->stagingStride = dstStride; h->stagingFramePitch = fp;
+            if (build_single_graph(h) != ORBX_OK) {       // no graph support for this sequence: fall back to stream launches for good
+                invalidate_single_graph(h);
+                h->sgDisabled = true;
+                return extract_single_host(h, image, W, H, stride, wantPyr, offKpOut, offDescOut);
+            }
+        }
+        if ((rc = stage_rows(h, image, W, H, stride, dstStride, fp)) != ORBX_OK) return rc;
+        h->cur ^= 1;
+        const int cb = h->cur;
+        if (h->pyrConsumerEv) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->pyrConsumerEv, 0)); h->pyrConsumerEv = nullptr; }
+        if (h->consumerEv[cb]) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->consumerEv[cb], 0)); h->consumerEv[cb] = nullptr; }
+        ORBX_HIP_CHECK(hipGraphLaunch(h->sgExec[cb], h->stream));
+        h->lastCombined = false;
+        h->lastBatch = 1; h->lastImg0 = h->staging.p; h->lastStride = dstStride; h->lastFramePitch = fp;
+        if (wantPyr) ORBX_HIP_CHECK(hipMemcpyAsync(h->hostOut + h->hostPyrOff, h->pyr.p, h->geom.pyrBytes, hipMemcpyDeviceToHost, h->stream));
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if ((rc = check_single_status(h, offKpOut, offDescOut)) != ORBX_OK) return rc;
+        h->hostPyrValid = wantPyr;
+        return ORBX_OK;
+    }
+    if (wantPyr) {      // the plain-launch path (profiling / parity taps): one more copy and wait
+        ORBX_HIP_CHECK(hipMemcpyAsync(h->hostOut + h->hostPyrOff, h->pyr.p, h->geom.pyrBytes, hipMemcpyDeviceToHost, h->stream));
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->hostPyrValid = true;
+    }
     return ORBX_OK;
 }
 
@@ -924,7 +1265,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *const *image
     if (batch == 1 && h->cfg.max_batch == 1 && images && images[0] && keypoints && descriptors) {
         // the single-frame call of a one-frame handle: one graph launch (extract_single_host), then the copy into the caller's arrays
         size_t offKp = 0, offDesc = 0;
-        int rc1 = extract_single_host(h, images[0], width, height, stride, &offKp, &offDesc);
+        int rc1 = extract_single_host(h, images[0], width, height, stride, false, &offKp, &offDesc);
         if (rc1 != ORBX_OK) return rc1;
         const int n = *(const int *)h->hostOut;
         if (n > capacity) { orbx_set_error("frame 0 has %d keypoints but the caller's capacity is %d", n, capacity); return ORBX_ERR_CAPACITY; }
@@ -950,19 +1291,54 @@ extern "C" int orbx_extract(orbx_extractor *h, const uint8_t *image, int width, 
     return orbx_extract_batch(h, imgs, 1, width, height, stride, keypoints, descriptors, capacity, count);
 }
 
-extern "C" int orbx_extract_view(orbx_extractor *h, const uint8_t *image, int width, int height, int stride, const orbx_keypoint **keypoints,
-                                 const uint8_t **descriptors, int *count)
+extern "C" int orbx_extract_view_pyramid(orbx_extractor *h, const uint8_t *image, int width, int height, int stride, const orbx_keypoint **keypoints,
+                                         const uint8_t **descriptors, int *count, orbx_host_pyramid *pyramid)
 {
     if (!h || !count || !keypoints || !descriptors) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     *count = 0; *keypoints = nullptr; *descriptors = nullptr;
+    if (pyramid) memset(pyramid, 0, sizeof(*pyramid));
     if (!image || width <= 0 || height <= 0) return ORBX_OK;   // reference: empty image -> silent return (:1553-1554)
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
     size_t offKp = 0, offDesc = 0;
-    int rc = extract_single_host(h, image, width, height, stride, &offKp, &offDesc);
+    int rc = extract_single_host(h, image, width, height, stride, pyramid != nullptr, &offKp, &offDesc);
     if (rc != ORBX_OK) return rc;
     *count = *(const int *)h->hostOut;
     *keypoints = (const orbx_keypoint *)(h->hostOut + offKp);
     *descriptors = h->hostOut + offDesc;
+    if (pyramid) {
+        // level 0 = the handle's pinned copy of the caller's image (rows at the staging pitch), levels >= 1 = the pinned copy of the device
+        // pyramid, in its layout: views, nothing is copied again
+        const OrbxGeom &g = h->geom;
+        pyramid->nlevels = g.nlevels;
+        for (int l = 0; l < g.nlevels && l < ORBX_PYRAMID_MAX_LEVELS; l++) {
+            pyramid->width[l] = g.lv[l].w; pyramid->height[l] = g.lv[l].h;
+            pyramid->stride[l] = l ? g.lv[l].pitch : h->stagingStride;
+            pyramid->level[l] = l ? h->hostOut + h->hostPyrOff + g.lv[l].off : h->hostStaging;
+        }
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_view(orbx_extractor *h, const uint8_t *image, int width, int height, int stride, const orbx_keypoint **keypoints,
+                                 const uint8_t **descriptors, int *count)
+{
+    return orbx_extract_view_pyramid(h, image, width, height, stride, keypoints, descriptors, count, nullptr);
+}
+
+extern "C" int orbx_extractor_expect_partner(orbx_extractor *h, orbx_extractor *partner)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    h->expectPartner = partner;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_combiner_stats(const orbx_extractor *h, int64_t *batches, int64_t *frames, int *engines)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    const Combiner *c = h->comb;
+    if (batches) *batches = c ? (int64_t)c->batches.load() : 0;
+    if (frames) *frames = c ? (int64_t)c->frames.load() : 0;
+    if (engines) *engines = c ? (int)c->engines.size() : 0;      // (a racy read while calls are in flight: a statistic)
     return ORBX_OK;
 }
 
@@ -988,6 +1364,10 @@ extern "C" int orbx_download_pyramid(orbx_extractor *h, int frame, int level, in
     if (!h->lastBatch || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels) { orbx_set_error("frame/level not available"); return ORBX_ERR_STATE; }
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
     const OrbxLevel &lv = h->geom.lv[level];
+    if (blurred && h->lastCombined) {
+        orbx_set_error("the blurred pyramid of a combined single-frame call stays on the shared engine: enable orbx_extractor_set_debug_taps (or ORBX_COMBINE=0) to keep it");
+        return ORBX_ERR_STATE;
+    }
     if (blurred) return download_plane(h, h->blur.p + (size_t)frame * h->geom.pyrBytes + lv.off, lv.pitch, lv.w, lv.h, dst, dst_stride);
     if (level == 0) return download_plane(h, h->lastImg0 + (size_t)frame * h->lastFramePitch, h->lastStride, lv.w, lv.h, dst, dst_stride);
     return download_plane(h, h->pyr.p + (size_t)frame * h->geom.pyrBytes + lv.off, lv.pitch, lv.w, lv.h, dst, dst_stride);
@@ -1014,6 +1394,7 @@ extern "C" int orbx_debug_download_candidates(orbx_extractor *h, int frame, int 
 {
     if (!h || !count) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     if (!h->lastBatch || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels) { orbx_set_error("frame/level not available"); return ORBX_ERR_STATE; }
+    if (h->lastCombined) { orbx_set_error("stage taps of a combined single-frame call stay on the shared engine: enable orbx_extractor_set_debug_taps first"); return ORBX_ERR_STATE; }
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     const OrbxGeom &g = h->geom;
@@ -1035,6 +1416,7 @@ extern "C" int orbx_debug_download_level_keypoints(orbx_extractor *h, int frame,
 {
     if (!h || !count) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     if (!h->lastBatch || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels) { orbx_set_error("frame/level not available"); return ORBX_ERR_STATE; }
+    if (h->lastCombined) { orbx_set_error("stage taps of a combined single-frame call stay on the shared engine: enable orbx_extractor_set_debug_taps first"); return ORBX_ERR_STATE; }
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     const OrbxGeom &g = h->geom;

@@ -58,6 +58,18 @@ struct OrbxGeom {
  * Level 0: only the computed rectangle, = the window of the input image it stages. */
 struct OrbxPyrTile { short cx0, cy0, cx1, cy1, ox0, oy0, ox1, oy1; };
 
+/* One member of a COMBINED single-frame batch (orbx_extractor.hip: the combiner): where the frame comes from and where its results go.
+ * The table lives in pinned host memory; k_comb_upload / k_comb_finish read it, so the graph that replays a batch of n frames
+ * names no member and serves whichever n callers happen to arrive together. */
+struct OrbxCombMember {
+    const uint8_t *hostImg;   /* member's pinned staging buffer: the frame's rows at the device pitch                 */
+    uint8_t *devImg;          /* member's device copy of the frame (level 0 for the device-resident consumers)       */
+    uint8_t *devPyr;          /* member's device pyramid, levels >= 1                                                */
+    uint8_t *devArena;        /* member's result arena in the one-frame layout: count | 2 status words | kps | desc  */
+    uint8_t *hostOut;         /* the same arena in the member's pinned memory                                        */
+    uint8_t *hostPyr;         /* pinned copy of the pyramid (levels >= 1, device layout), NULL = not wanted          */
+};
+
 /* level-coordinates keypoint produced by the quadtree + orientation stages */
 /* ca / sb = cos / sin of the angle as the reference's libm rounds them; k_orient_describe fills them with the angle (read back by the stage taps only) */
 struct OrbxLevelKp { uint16_t x, y; uint8_t score, pad[3]; float angle, ca, sb; };
@@ -99,6 +111,8 @@ struct OrbxLaunch {
     int nodeCap;                  /* 256 / 512 / 1024 / 2048 */
     /* graph construction (single-frame call): when `graph` is set, a launcher adds a kernel node that depends on deps[0..ndeps)
      * and returns it in *node instead of launching on `stream` */
+    const OrbxCombMember *combTab = nullptr;      /* combined single-frame batches: member table (pinned host memory) */
+    size_t combKpOff = 0, combDescOff = 0;        /* one-frame arena layout of the members */
     const OrbxPyrTile *pyrTiles = nullptr; int pyrTileCount = 0, pyrTileBuf = 0, pyrTileTab = 0;   /* k_pyramid_tiles plan (single-frame call): bytes of one of its two LDS image buffers, bytes of its LDS table slices */
     hipGraph_t graph = nullptr;
     hipGraphNode_t deps[2] = {nullptr, nullptr};
@@ -107,7 +121,9 @@ struct OrbxLaunch {
 };
 
 int orbx_launch_resize(const OrbxLaunch &L, int level);
-int orbx_launch_pyramid_tiles(const OrbxLaunch &L);   /* all levels of ONE frame in one launch (L.pyrTiles) */
+int orbx_launch_pyramid_tiles(const OrbxLaunch &L);   /* all levels of a frame in one launch (L.pyrTiles); single frames and small combined batches */
+int orbx_launch_comb_upload(const OrbxLaunch &L, uint8_t *stagingDev);   /* members' pinned frames -> the engine's staging area (L.combTab) */
+int orbx_launch_comb_finish(const OrbxLaunch &L);     /* the engine's results / pyramid / frames -> every member's device and pinned buffers */
 int orbx_launch_fast_cells(const OrbxLaunch &L);   /* FAST score + cell NMS + emission; L.score (parity tap) may be NULL */
 int orbx_launch_octree(const OrbxLaunch &L);
 int orbx_launch_blur(const OrbxLaunch &L);

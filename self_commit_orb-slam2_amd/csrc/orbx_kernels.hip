@@ -202,14 +202,19 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
 // ------------------------------------------------------------------------------------
 #define PT_PITCH(cw) (((cw) + 12 + 7) & ~7)      /* LDS row pitch of a computed rectangle: 12 readable bytes behind every group window */
 #define PT_WIN_ITEMS 8          /* 8-byte units of the level-0 window per thread (all requested before the first is stored); the plan keeps windows below 16 KB */
-__global__ __launch_bounds__(256) void k_pyramid_tiles(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, uint8_t *__restrict__ pyr,
-                                                       const uint32_t *__restrict__ rsTab, const OrbxPyrTile *__restrict__ tiles, int bufBytes, int *__restrict__ status)
+__global__ __launch_bounds__(256) void k_pyramid_tiles(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                                       uint8_t *__restrict__ pyr, const uint32_t *__restrict__ rsTab, const OrbxPyrTile *__restrict__ tiles, int bufBytes,
+                                                       int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // two image buffers of bufBytes (level parity), then the table slices of all levels
     const int nl = g->nlevels, tid = threadIdx.x;
     const OrbxPyrTile *tt = tiles + (size_t)blockIdx.x * nl;
     uint8_t *tab = lds + 2 * bufBytes;
-    if (blockIdx.x == 0 && threadIdx.x < 2) status[threadIdx.x] = 0;      // the frame's capacity word and the batch word (first kernel of the chain: no memset node)
+    // blockIdx.y = frame of a (small) batch: the single-frame call, or the frames of concurrent callers combined into one launch set
+    img0 += (size_t)blockIdx.y * img0FramePitch;
+    pyr += (size_t)blockIdx.y * g->pyrBytes;
+    // the frames' capacity words and the batch word (first kernel of the chain: no memset node)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { status[blockIdx.y] = 0; if (blockIdx.y == 0) status[gridDim.y] = 0; }
     // rectangles and level parameters of the level loop out of LDS too: a scalar load from global memory at the top of every level is a
     // dependent ~0.7 us each, seven times
     __shared__ OrbxPyrTile sT[ORBX_MAX_LEVELS];
@@ -1214,6 +1219,70 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Combined single-frame batches (orbx_extractor.hip: the combiner).  ORBextractor::operator() is a one-frame call (reference
+// include/ORBextractor.h:110); when several callers - the two extractor threads of the stereo Frame constructor, src/Frame.cc:159-167,
+// or the tracking threads of several sequences - are inside it at the same moment, their frames run as ONE launch set on a shared
+// engine.  These two kernels are the set's first and last node: they move the frames in from, and the results out to, the members'
+// own buffers named by a table in pinned memory (the engine's graph is the same whoever the members are).
+// k_comb_upload: blockIdx.y = member; its pinned staging buffer (rows already at the device pitch) -> frame slot y of the engine's
+// staging area, 16 bytes per lane, four loads in flight per lane (the reads cross PCIe).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_comb_upload(const OrbxCombMember *__restrict__ tab, uint8_t *__restrict__ staging, size_t framePitch)
+{
+    const uint4 *src = (const uint4 *)tab[blockIdx.y].hostImg;
+    uint4 *dst = (uint4 *)(staging + (size_t)blockIdx.y * framePitch);
+    const size_t n = framePitch >> 4, stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+// k_comb_finish: blockIdx.y = member.  Frame y of the engine's result arena -> the member's arena in its one-frame layout, on the device
+// (what SearchByBoW / ComputeStereoMatches chained behind the extractor read) and in pinned memory (what operator() converts to
+// cv::KeyPoint / cv::Mat); the engine's pyramid and frame slot -> the member's device pyramid / level 0 (and, if asked for, the pinned
+// pyramid copy behind the public mvImagePyramid).  Only the frame's real keypoints are moved, not the arena's capacity.
+__global__ __launch_bounds__(256) void k_comb_finish(const OrbxCombMember *__restrict__ tab, const int *__restrict__ engCnt, const int *__restrict__ engSt,
+                                                     const orbx_keypoint *__restrict__ engKp, const uint8_t *__restrict__ engDesc, int cap, const uint8_t *__restrict__ engPyr,
+                                                     size_t pyrBytes, const uint8_t *__restrict__ engImg, size_t framePitch, size_t kpOff, size_t descOff)
+{
+    const int f = blockIdx.y;
+    const OrbxCombMember m = tab[f];
+    const int cnt = min(engCnt[f], cap);
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if (tid == 0) {
+        const int st = engSt[f];      // the member's "batch" is its own frame: another member's capacity bits are not its business
+        int *d = (int *)m.devArena, *h = (int *)m.hostOut;
+        d[0] = cnt; d[1] = st; d[2] = st;
+        h[0] = cnt; h[1] = st; h[2] = st;
+    }
+    {   // keypoints: 28-byte records, frame f starts at a multiple of 4 bytes only -> dwords
+        const uint32_t *s = (const uint32_t *)(engKp + (size_t)f * cap);
+        uint32_t *d = (uint32_t *)(m.devArena + kpOff), *h = (uint32_t *)(m.hostOut + kpOff);
+        for (size_t i = tid; i < (size_t)cnt * 7; i += stride) { const uint32_t v = s[i]; d[i] = v; h[i] = v; }
+    }
+    {   // descriptors: 32 bytes each
+        const uint4 *s = (const uint4 *)(engDesc + (size_t)f * cap * 32);
+        uint4 *d = (uint4 *)(m.devArena + descOff), *h = (uint4 *)(m.hostOut + descOff);
+        for (size_t i = tid; i < (size_t)cnt * 2; i += stride) { const uint4 v = s[i]; d[i] = v; h[i] = v; }
+    }
+    {   // pyramid levels >= 1 (device layout, padding included: one flat copy)
+        const uint4 *s = (const uint4 *)(engPyr + (size_t)f * pyrBytes);
+        uint4 *d = (uint4 *)m.devPyr, *h = (uint4 *)m.hostPyr;
+        const size_t n = pyrBytes >> 4;
+        if (h) for (size_t i = tid; i < n; i += stride) { const uint4 v = s[i]; d[i] = v; h[i] = v; }
+        else for (size_t i = tid; i < n; i += stride) d[i] = s[i];
+    }
+    {   // level 0 = the frame itself
+        const uint4 *s = (const uint4 *)(engImg + (size_t)f * framePitch);
+        uint4 *d = (uint4 *)m.devImg;
+        for (size_t i = tid; i < (framePitch >> 4); i += stride) d[i] = s[i];
+    }
+}
+
 }  // namespace
 
 // Every kernel of the extractor goes out through emit(): onto the stream (batches), or as a kernel node of a hipGraph under
@@ -1274,7 +1343,23 @@ int orbx_launch_pyramid_tiles(const OrbxLaunch &L)
         if (e != hipSuccess) { orbx_set_error("hipFuncSetAttribute(k_pyramid_tiles) failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
         granted = ldsBytes;
     }
-    return emit(L, k_pyramid_tiles, dim3((unsigned)L.pyrTileCount), dim3(256), ldsBytes, L.geomDev, L.img0, L.img0Stride, L.pyr, L.rsTab, L.pyrTiles, L.pyrTileBuf, L.status);
+    return emit(L, k_pyramid_tiles, dim3((unsigned)L.pyrTileCount, (unsigned)L.batch), dim3(256), ldsBytes, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.rsTab,
+                L.pyrTiles, L.pyrTileBuf, L.status);
+}
+
+int orbx_launch_comb_upload(const OrbxLaunch &L, uint8_t *stagingDev)
+{
+    const size_t units = L.img0FramePitch >> 4;
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((units + 1023) / 1024, 1), 256);      // four 16-byte units per thread
+    return emit(L, k_comb_upload, dim3(blocks, (unsigned)L.batch), dim3(256), 0, L.combTab, stagingDev, L.img0FramePitch);
+}
+
+int orbx_launch_comb_finish(const OrbxLaunch &L)
+{
+    const size_t units = (L.geom->pyrBytes + L.img0FramePitch) >> 4;
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((units + 511) / 512, 1), 256);
+    return emit(L, k_comb_finish, dim3(blocks, (unsigned)L.batch), dim3(256), 0, L.combTab, L.outCnt, L.outStatus, L.outKp, L.outDesc, L.geom->outCap, L.pyr, L.geom->pyrBytes, L.img0,
+                L.img0FramePitch, L.combKpOff, L.combDescOff);
 }
 
 int orbx_launch_fast_cells(const OrbxLaunch &L)

@@ -1,5 +1,5 @@
 // shim/Frame_hip.cc -- HIP bodies for ORB_SLAM2::Frame::ComputeStereoMatches, UndistortKeyPoints,
-// ComputeImageBounds and AssignFeaturesToGrid.
+// ComputeImageBounds and AssignFeaturesToGrid (+ Frame::ExtractORB with the stereo pair hint).
 //
 // Compiled against the REFERENCE's own include/Frame.h with shim/ORBextractor.h in place of
 // include/ORBextractor.h.  Replaces the body of
@@ -43,6 +43,24 @@ struct ThreadStereo {
 };
 thread_local ThreadStereo tStereo;
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------
+//     void Frame::ExtractORB(int flag, const cv::Mat &im)                     src/Frame.cc:494-512
+// The reference's body, plus one line: in the stereo constructor the two calls run on two threads (src/Frame.cc:159-167), and each
+// tells liborbx that the other extractor's call is on its way, so that both frames run as ONE launch set (include/orbx.h:
+// orbx_extractor_expect_partner).  Monocular / RGB-D frames (mpORBextractorRight == NULL, :283, :394) give no hint and never wait.
+// ---------------------------------------------------------------------------------------------
+static unsigned long gExtractCalls = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_extract_orb_calls(void) { return gExtractCalls; }
+
+void Frame::ExtractORB(int flag, const cv::Mat &im)
+{
+    __atomic_add_fetch(&gExtractCalls, 1, __ATOMIC_RELAXED);
+    if (mpORBextractorLeft && mpORBextractorRight)
+        (flag == 0 ? mpORBextractorLeft : mpORBextractorRight)->ExpectPartner(flag == 0 ? mpORBextractorRight : mpORBextractorLeft);
+    if (flag == 0) (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors);
+    else (*mpORBextractorRight)(im, cv::Mat(), mvKeysRight, mDescriptorsRight);
+}
 
 void Frame::ComputeStereoMatches()
 {

@@ -91,7 +91,8 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     const orbx_keypoint *kps = 0;
     const unsigned char *desc = 0;
     int n = 0;
-    if (orbx_extract_view(mpHandle, image.data, image.cols, image.rows, (int)image.step, &kps, &desc, &n) != ORBX_OK) {
+    orbx_host_pyramid pyr;
+    if (orbx_extract_view_pyramid(mpHandle, image.data, image.cols, image.rows, (int)image.step, &kps, &desc, &n, mbKeepHostPyramid ? &pyr : 0) != ORBX_OK) {
         _keypoints.clear(); _descriptors.release();       // never the previous frame's data
         Fail("extract");
         return;
@@ -112,7 +113,18 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
         o.pt.x = k.x; o.pt.y = k.y; o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.class_id;
     }
     mLastW = image.cols; mLastH = image.rows;
-    if (mbKeepHostPyramid) DownloadImagePyramid();
+    if (mbKeepHostPyramid) {
+        // the pyramid came back with the results (same launch set, same wait): the public member becomes VIEWS of the handle's pinned
+        // memory - level 0 is the staged copy of `image` -, valid until the next call, which is how long the reference's member holds a
+        // frame's pyramid too (ComputePyramid overwrites it, src/ORBextractor.cc:1680-1733)
+        for (int level = 0; level < nlevels && level < pyr.nlevels; ++level)
+            mvImagePyramid[level] = cv::Mat(pyr.height[level], pyr.width[level], CV_8UC1, (void *)pyr.level[level], (size_t)pyr.stride[level]);
+    }
+}
+
+void ORBextractor::ExpectPartner(ORBextractor *other)
+{
+    if (mpHandle) orbx_extractor_expect_partner(mpHandle, other ? other->mpHandle : 0);
 }
 
 void ORBextractor::DownloadImagePyramid()

@@ -40,13 +40,20 @@ public:
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
     // Host copy of the image pyramid of the last frame.  The reference's only reader is Frame::ComputeStereoMatches
-    // (src/Frame.cc:1044,1248).  Safe by default: mbKeepHostPyramid starts TRUE - every call refills the member with one ~1 MB
-    // device->host transfer (~0.1 ms), exactly what a build that swaps only the extractor needs - and starts FALSE only when
-    // shim/Frame_hip.cc is linked into the same binary (it defines orbx_shim_device_stereo_linked): that ComputeStereoMatches reads
-    // the DEVICE pyramid.  Anything else that wants the images then calls DownloadImagePyramid() when it does.
+    // (src/Frame.cc:1044,1248).  Safe by default: mbKeepHostPyramid starts TRUE - every call leaves the frame's pyramid in the member,
+    // as VIEWS of the handle's pinned memory that the launch set itself filled (levels >= 1; level 0 is the staged copy of the input):
+    // no second transfer, no second wait, no host copy; valid until the next call on this extractor -, exactly what a build that swaps
+    // only the extractor needs - and starts FALSE only when shim/Frame_hip.cc is linked into the same binary (it defines
+    // orbx_shim_device_stereo_linked): that ComputeStereoMatches reads the DEVICE pyramid.  Anything else that wants the images then
+    // calls DownloadImagePyramid() when it does (owning copies).
     std::vector<cv::Mat> mvImagePyramid;
     bool mbKeepHostPyramid;
     void DownloadImagePyramid();
+
+    // One-shot hint for the next operator() call: `other`'s call is about to arrive on another thread (the stereo Frame constructor runs the
+    // left and the right extractor on two threads, src/Frame.cc:159-167); liborbx then runs both frames as one launch set.  Set by the HIP
+    // body of Frame::ExtractORB (shim/Frame_hip.cc); harmless when the partner never comes (the call leaves after 0.3 ms).
+    void ExpectPartner(ORBextractor *other);
 
     // Error channel (the reference has none: include/ORBextractor.h:92-161).  A failed call leaves `keypoints` EMPTY and `descriptors`
     // released - never the previous frame's data -, increments ErrorCount() and keeps the message; a host program polls these instead of

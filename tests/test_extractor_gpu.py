@@ -167,8 +167,8 @@ def test_tight_device_stride(orbx, oracle):
 def test_single_frame_pyramid_equals_batch_pyramid_on_random_geometries(orbx):
     """k_pyramid_tiles (the single-frame call: a host-planned tile grid taken through all levels inside LDS) against the per-level
     k_resize launches of the batch path (itself checked against the oracle above) on random image sizes, level counts and scale factors:
-    every byte of every level - tile boundaries, halos, right / bottom borders, levels whose tiles own nothing.  Also the blurred copy and
-    the results, which read the pyramid."""
+    every byte of every level - tile boundaries, halos, right / bottom borders, levels whose tiles own nothing.  Also the results, which
+    read the pyramid and its blurred copy."""
     rng = np.random.default_rng(20260926)
     done = 0
     for trial in range(40):
@@ -190,44 +190,119 @@ def test_single_frame_pyramid_equals_batch_pyramid_on_random_geometries(orbx):
         assert len(k1) == n and (kp_matrix(k1).view(np.uint32) == kp_matrix(k2[0, :n]).view(np.uint32)).all() and (d1 == d2[0, :n]).all(), (W, H, nl, sf)
         for l in range(nl):
             assert (one.mvImagePyramid(l) == two.mvImagePyramid(l)).all(), ("pyramid", W, H, nl, sf, l)
-            assert (one.mvImagePyramid(l, blurred=True) == two.mvImagePyramid(l, blurred=True)).all(), ("blurred", W, H, nl, sf, l)
+        # (the blurred copy of a single-frame call stays on the shared engine; the descriptors above were sampled from it)
         one.close(); two.close()
         done += 1
     assert done >= 12
 
 
-def test_single_frame_calls_from_eight_threads(orbx):
-    """Eight threads, one one-frame extractor each (the reference's rule: one ORBextractor per thread, include/ORBextractor.h:161; its stereo
-    constructor uses two), every call one hipGraph launch: the graphs are built concurrently on first use (serialised inside the library), replayed
-    concurrently afterwards; two image sizes so that handles of different geometry - different k_pyramid_tiles plans and LDS sizes - interleave.
-    Every result must equal the one a single thread gets."""
+def test_single_frame_calls_from_sixteen_threads_are_combined(orbx):
+    """Sixteen threads, one one-frame extractor each (the reference's rule: one ORBextractor per thread, include/ORBextractor.h:161; its stereo
+    constructor uses two), three image geometries interleaved: calls that are inside the library at the same moment are COMBINED into one
+    launch set per geometry (csrc/orbx_extractor.hip, "the combiner"); the engines and their per-size graphs are built concurrently on first
+    use.  Every call - keypoints, descriptors AND the host pyramid that comes back with them - must equal what the batch path (no combiner:
+    a max_batch = 2 handle, itself checked against the oracle above) gives for the same frame."""
     import threading
-    sizes = [(640, 480, 1000), (752, 480, 1200)]
+    sizes = [(640, 480, 1000), (752, 480, 1200), (1241, 376, 2000)]
     frames = {sz: [orbx.synth_frame(500 + i, sz[0], sz[1]) for i in range(6)] for sz in sizes}
-    want = {}
+    want, wantPyr = {}, {}
     for sz in sizes:
-        ref = orbx.ORBextractor(sz[2], 1.2, 8, 20, 7, max_width=sz[0], max_height=sz[1])
-        want[sz] = [ref(im) for im in frames[sz]]
+        ref = orbx.ORBextractor(sz[2], 1.2, 8, 20, 7, max_width=sz[0], max_height=sz[1], max_batch=2)
+        want[sz], wantPyr[sz] = [], []
+        for im in frames[sz]:
+            k, d, c = ref.extract_batch([im, im])
+            want[sz].append((k[0, :c[0]].copy(), d[0, :c[0]].copy()))
+            wantPyr[sz].append([ref.mvImagePyramid(l).copy() for l in range(8)])
         ref.close()
-    errors = []
+    errors, stats = [], {}
+    NT, REPS = 16, 5
+    start = threading.Barrier(NT)
 
     def work(t):
-        sz = sizes[t % 2]
+        sz = sizes[t % 3] if t >= 4 else sizes[0]       # 8 threads on 640x480, 4 + 4 on the other two
         try:
             ext = orbx.ORBextractor(sz[2], 1.2, 8, 20, 7, max_width=sz[0], max_height=sz[1])
-            for rep in range(5):
+            start.wait()
+            for rep in range(REPS):
                 for i, im in enumerate(frames[sz]):
-                    k, d = ext(im)
+                    if (rep + t) % 2:
+                        k, d, pyr = ext.extract_with_pyramid(im)
+                    else:
+                        (k, d), pyr = ext(im), None
                     kw, dw = want[sz][i]
                     if len(k) != len(kw) or not (kp_matrix(k).view(np.uint32) == kp_matrix(kw).view(np.uint32)).all() or not (d == dw).all():
-                        errors.append((t, rep, i))
+                        errors.append((t, rep, i, "results"))
+                    if pyr is not None and not all(p.shape == w.shape and (p == w).all() for p, w in zip(pyr, wantPyr[sz][i])):
+                        errors.append((t, rep, i, "pyramid"))
+                    # the device-resident state of the member is the frame's too (what a matcher chained behind the call reads)
+                    if rep == REPS - 1 and i == 5 and not (ext.mvImagePyramid(3) == wantPyr[sz][i][3]).all():
+                        errors.append((t, rep, i, "device pyramid"))
+            stats[sz] = ext.combiner_stats()
             ext.close()
         except Exception as e:      # noqa: BLE001
             errors.append((t, repr(e)))
 
-    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    th = [threading.Thread(target=work, args=(t,)) for t in range(NT)]
     for x in th:
         x.start()
     for x in th:
         x.join()
     assert not errors, errors[:5]
+    for sz, (batches, nframes, engines) in stats.items():
+        assert nframes >= 4 * REPS * 6 and 1 <= batches <= nframes and 1 <= engines <= 2, (sz, batches, nframes, engines)
+    b0, f0, _ = stats[sizes[0]]
+    assert f0 > b0, "eight threads on one geometry never met in a launch set: %d frames in %d sets" % (f0, b0)
+
+
+def test_a_partner_hint_makes_one_launch_set_of_two(orbx):
+    """The stereo Frame constructor's two extractor threads (src/Frame.cc:159-167): each call announces the other
+    (orbx_extractor_expect_partner, set by the HIP body of Frame::ExtractORB), and the pair runs as ONE set of two frames - bit-identical to
+    two separate calls.  Python threads leave a barrier with some jitter; the hint waits 0.3 ms at most, so most (not all) trials must merge."""
+    import threading
+    W, H, nf = 1241, 376, 2000
+    left = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H)
+    right = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H)
+    imgs = [orbx.synth_frame(700 + i, W, H) for i in range(4)]
+    want = [left(im) for im in imgs]
+    merged, trials = 0, 12
+    for trial in range(trials):
+        b0, f0, _ = left.combiner_stats()
+        out = {}
+        bar = threading.Barrier(2)
+
+        def run(name, ext, other, im):
+            ext.expect_partner(other)
+            bar.wait()
+            out[name] = ext(im)
+        ta = threading.Thread(target=run, args=("l", left, right, imgs[trial % 4]))
+        tb = threading.Thread(target=run, args=("r", right, left, imgs[(trial + 1) % 4]))
+        ta.start(); tb.start(); ta.join(); tb.join()
+        b1, f1, _ = left.combiner_stats()
+        assert f1 - f0 == 2
+        merged += (b1 - b0) == 1
+        for name, idx in (("l", trial % 4), ("r", (trial + 1) % 4)):
+            k, d = out[name]
+            assert len(k) == len(want[idx][0]) and (kp_matrix(k).view(np.uint32) == kp_matrix(want[idx][0]).view(np.uint32)).all() and (d == want[idx][1]).all()
+    assert merged >= trials // 2, "only %d of %d announced pairs ran as one launch set" % (merged, trials)
+    # a hint whose partner never calls costs a bounded wait and nothing else
+    left.expect_partner(right)
+    k, d = left(imgs[0])
+    assert len(k) == len(want[0][0]) and (d == want[0][1]).all()
+    left.close(); right.close()
+
+
+def test_the_handles_own_graph_still_serves_single_frames(orbx, monkeypatch):
+    """ORBX_COMBINE=0: the one-frame call on the handle's own graph (the path every call took before the combiner existed) - same results,
+    same host pyramid."""
+    monkeypatch.setenv("ORBX_COMBINE", "0")
+    W, H = 752, 480
+    ext = orbx.ORBextractor(1200, 1.2, 8, 20, 7, max_width=W, max_height=H)
+    ref = orbx.ORBextractor(1200, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2)
+    for seed in (3, 4):
+        im = orbx.synth_frame(seed, W, H)
+        k, d, pyr = ext.extract_with_pyramid(im)
+        kb, db, cb = ref.extract_batch([im, im])
+        assert len(k) == cb[0] and (kp_matrix(k).view(np.uint32) == kp_matrix(kb[0, :cb[0]]).view(np.uint32)).all() and (d == db[0, :cb[0]]).all()
+        assert all((pyr[l] == ref.mvImagePyramid(l)).all() for l in range(8))
+    assert ext.combiner_stats()[1] == 0
+    ext.close(); ref.close()

@@ -1,37 +1,130 @@
 #!/usr/bin/env python3
-"""Latency of the REAL drop-in call: ORB_SLAM2::ORBextractor::operator() of shim/ORBextractor.cc (C++, the reference's call shape
-(*extractor)(im, cv::Mat(), keys, desc), src/Frame.cc:503), one frame per call on one thread, host image in, std::vector<cv::KeyPoint>
-+ cv::Mat descriptors out.  Timed inside C++ (tests/shim_wrap.cc: shim_bench).  Prints one JSON line per configuration."""
-import ctypes, importlib, json, sys
+"""Latency / throughput of the REAL drop-in surface, timed inside C++:
+
+  * ORB_SLAM2::ORBextractor::operator() of shim/ORBextractor.cc in the reference's call shape (*extractor)(im, cv::Mat(), keys, desc)
+    (src/Frame.cc:503): host image in, std::vector<cv::KeyPoint> + cv::Mat descriptors out (tests/shim_wrap.cc: shim_bench) - one thread,
+    with and without the host pyramid (mbKeepHostPyramid, the default of a build that swaps only the extractor);
+  * the same call from 1..16 threads, one extractor per thread (shim_bench_threads): concurrent calls are combined into one launch set
+    per geometry inside liborbx (csrc/orbx_extractor.hip, "the combiner"); ORBX_COMBINE=0 = every handle its own graph (round 3);
+  * the reference's stereo Frame constructor (src/Frame.cc:100-199: two extractor threads + ComputeStereoMatches) in
+    oracle/_ref/liborbslam_hip.so (drop-in) and, a few iterations, in oracle/_ref/liborbslam.so (the reference's own CPU path on cvshim).
+
+`measure(orbx, quick)` returns the numbers as a dict (bench.py puts a digest of it into the driver-visible line); run as a script it
+prints one JSON line per configuration (profiles/*_latency_shim.jsonl)."""
+import ctypes
+import importlib
+import json
+import os
+import sys
 from pathlib import Path
-import numpy as np
+
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-orbx = importlib.import_module("self_commit_orb-slam2_amd")
-orbx.load_library()
-import test_shim_dropin as tsd
-tsd.build_shim()
-L = ctypes.CDLL(str(tsd.SO))
-L.shim_create.restype = ctypes.c_void_p
-L.shim_create.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-for (W, H, nf) in ((640, 480, 1000), (1241, 376, 2000)):
+
+
+def _shim_lib(orbx):
+    orbx.load_library()
+    import test_shim_dropin as tsd
+    tsd.build_shim()
+    L = ctypes.CDLL(str(tsd.SO))
+    L.shim_create.restype = ctypes.c_void_p
+    L.shim_create.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.shim_destroy.argtypes = [ctypes.c_void_p]
+    L.shim_bench.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                             ctypes.c_void_p, ctypes.c_void_p]
+    L.shim_bench_threads.restype = ctypes.c_double
+    L.shim_bench_threads.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    return L
+
+
+def one_thread(orbx, L, W, H, nf, iters):
+    rows = []
     h = ctypes.c_void_p(L.shim_create(nf, 1.2, 8, 20, 7))
     frames = orbx.synth_sequence(7, 8, W, H)
     arr = (ctypes.c_void_p * 8)(*[f.ctypes.data for f in frames])
     for keep in (0, 1):
         mean, med, nk = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-        L.shim_bench(h, arr, 8, W, H, W, 300, keep, ctypes.byref(mean), ctypes.byref(med), ctypes.byref(nk))
-        print(json.dumps({"call": "ORBextractor::operator() via shim (C++)", "size": "%dx%d" % (W, H), "nfeatures": nf, "host_pyramid": bool(keep),
-                          "mean_us": round(mean.value, 1), "median_us": round(med.value, 1), "frames_per_s_one_thread": round(1e6 / mean.value, 1),
-                          "keypoints": nk.value}))
+        L.shim_bench(h, arr, 8, W, H, W, iters, keep, ctypes.byref(mean), ctypes.byref(med), ctypes.byref(nk))
+        rows.append({"call": "ORBextractor::operator() via shim (C++)", "size": "%dx%d" % (W, H), "nfeatures": nf, "host_pyramid": bool(keep),
+                     "combiner": os.environ.get("ORBX_COMBINE", "1") != "0", "mean_us": round(mean.value, 1), "median_us": round(med.value, 1),
+                     "frames_per_s_one_thread": round(1e6 / mean.value, 1), "keypoints": nk.value})
     L.shim_destroy(h)
+    return rows
 
-L.shim_bench_threads.restype = ctypes.c_double
-L.shim_bench_threads.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-frames = orbx.synth_sequence(7, 8, 640, 480)
-arr = (ctypes.c_void_p * 8)(*[f.ctypes.data for f in frames])
-for keep in (0, 1):      # 0: the full drop-in (shim/Frame_hip.cc linked, the stereo matcher reads the device pyramid); 1: extractor-only swap (mvImagePyramid refilled per call)
-    for nt in (1, 2, 4, 8, 16):
-        fps = L.shim_bench_threads(nt, 1000, arr, 8, 640, 480, 640, 400, keep)
-        print(json.dumps({"call": "ORBextractor::operator() via shim (C++), one extractor per thread", "size": "640x480", "nfeatures": 1000, "threads": nt,
-                          "host_pyramid": bool(keep), "frames_per_s": round(fps, 1)}))
+
+def threads(orbx, L, nts, iters, keeps=(0, 1)):
+    rows = []
+    frames = orbx.synth_sequence(7, 8, 640, 480)
+    arr = (ctypes.c_void_p * 8)(*[f.ctypes.data for f in frames])
+    for keep in keeps:      # 0: the full drop-in (shim/Frame_hip.cc linked, the stereo matcher reads the device pyramid); 1: extractor-only swap (mvImagePyramid per call)
+        for nt in nts:
+            fps = L.shim_bench_threads(nt, 1000, arr, 8, 640, 480, 640, iters, keep)
+            rows.append({"call": "ORBextractor::operator() via shim (C++), one extractor per thread", "size": "640x480", "nfeatures": 1000, "threads": nt,
+                         "host_pyramid": bool(keep), "combiner": os.environ.get("ORBX_COMBINE", "1") != "0", "frames_per_s": round(fps, 1)})
+    return rows
+
+
+def stereo_frame(orbx, iters_hip, iters_ref):
+    """Frame::Frame(imLeft, imRight, ...) of the reference, 1241x376 / 2000 features, in the drop-in library and in the all-reference one."""
+    import oracle_lib
+    rows = []
+    W, H, nf = 1241, 376, 2000
+    fr = orbx.synth_sequence(9, 8, W, H, views_per_scene=2, step=(6, 0))      # pairs: view 0 = left, view 1 = right (6 px disparity)
+    aL = (ctypes.c_void_p * 4)(*[fr[2 * i].ctypes.data for i in range(4)])
+    aR = (ctypes.c_void_p * 4)(*[fr[2 * i + 1].ctypes.data for i in range(4)])
+    for name, lib, iters in (("liborbslam_hip.so (drop-in)", oracle_lib.slam_hip_lib(), iters_hip), ("liborbslam.so (reference CPU path on cvshim)", oracle_lib.slam_lib(), iters_ref)):
+        if lib is None or iters <= 0:
+            continue
+        lib.orbslam_stereo_frame_bench.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
+            [ctypes.c_float] * 6 + [ctypes.c_int] + [ctypes.c_void_p] * 4
+        mean, med, nl, nm = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
+        lib.orbslam_stereo_frame_bench(aL, aR, 4, W, H, W, nf, 1.2, 8, 20, 7, 718.856, 718.856, 607.19, 185.2, 386.1448, 35.0, iters, ctypes.byref(mean), ctypes.byref(med),
+                                       ctypes.byref(nl), ctypes.byref(nm))
+        rows.append({"call": "Frame::Frame(imLeft, imRight, ...) = 2 x ExtractORB on two threads + ComputeStereoMatches", "library": name, "size": "%dx%d" % (W, H),
+                     "nfeatures": nf, "combiner": os.environ.get("ORBX_COMBINE", "1") != "0", "mean_us": round(mean.value, 1), "median_us": round(med.value, 1),
+                     "keypoints_left": nl.value, "stereo_matches": nm.value})
+    return rows
+
+
+def measure(orbx, quick=False):
+    """-> {"rows": [...], "digest": {...}}; quick = the few numbers bench.py's digest needs (a couple of seconds)."""
+    L = _shim_lib(orbx)
+    rows = []
+    it1, itn = (150, 120) if quick else (300, 400)
+    rows += one_thread(orbx, L, 640, 480, 1000, it1)
+    if not quick:
+        rows += one_thread(orbx, L, 1241, 376, 2000, it1)
+    rows += threads(orbx, L, (8, 16) if quick else (1, 2, 4, 8, 16), itn, keeps=(0,) if quick else (0, 1))
+    try:
+        rows += stereo_frame(orbx, 100 if quick else 300, 0 if quick else 8)
+    except Exception as e:      # noqa: BLE001  (the drop-in library is only there when oracle/_ref was built)
+        rows.append({"call": "stereo Frame constructor", "error": repr(e)})
+    if not quick:
+        os.environ["ORBX_COMBINE"] = "0"      # read when a handle is created: the round-3 behaviour (one graph per handle) beside the combiner's
+        try:
+            rows += one_thread(orbx, L, 640, 480, 1000, it1)
+            rows += threads(orbx, L, (1, 8, 16), itn, keeps=(0,))
+            rows += stereo_frame(orbx, 200, 0)
+        finally:
+            del os.environ["ORBX_COMBINE"]
+
+    def pick(**kw):
+        for r in rows:
+            if all(r.get(k) == v for k, v in kw.items()):
+                return r
+        return {}
+    dig = {"us_1thread": pick(size="640x480", host_pyramid=False, combiner=True).get("mean_us"),
+           "us_1thread_hostpyr": pick(size="640x480", host_pyramid=True, combiner=True).get("mean_us"),
+           "fps_8threads": pick(threads=8, host_pyramid=False, combiner=True).get("frames_per_s"),
+           "fps_16threads": pick(threads=16, host_pyramid=False, combiner=True).get("frames_per_s"),
+           "stereo_frame_ctor_us": pick(library="liborbslam_hip.so (drop-in)", combiner=True).get("mean_us"),
+           "source": "tools/latency_shim.py: C++ loops over the reference's call shapes (tests/shim_wrap.cc, oracle/refslam_wrap.cc)"}
+    return {"rows": rows, "digest": dig}
+
+
+if __name__ == "__main__":
+    orbx = importlib.import_module("self_commit_orb-slam2_amd")
+    out = measure(orbx, quick="--quick" in sys.argv)
+    for r in out["rows"]:
+        print(json.dumps(r), flush=True)
+    print(json.dumps({"digest": out["digest"]}), flush=True)
