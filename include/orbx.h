@@ -118,6 +118,9 @@ int orbx_extract_view_pyramid(orbx_extractor *h, const uint8_t *image, int width
  * orbx_combiner_stats: launch sets and frames served so far for h's configuration (frames / batches = mean set size). */
 int orbx_extractor_expect_partner(orbx_extractor *h, orbx_extractor *partner);
 int orbx_combiner_stats(const orbx_extractor *h, int64_t *batches, int64_t *frames, int *engines);
+/* Microseconds summed so far over h's configuration: us4[0] staging copies (per call), [1] leaders' wait for an engine / for company,
+ * [2] graph launch calls, [3] device time + synchronisation (per launch set).  A measurement aid (tools/latency_shim.py). */
+int orbx_combiner_profile(const orbx_extractor *h, double *us4);
 
 /* ORBextractor::operator() (ORBextractor.h:110, src/ORBextractor.cc:1544-1668) for one
  * host image.  `keypoints` / `descriptors` hold `capacity` entries / capacity*32 bytes;

@@ -861,14 +861,16 @@ struct CombEngine {
     const OrbxCombMember *tabDev = nullptr;
     hipGraph_t graph[COMB_MAX_LIMIT + 1] = {};
     hipGraphExec_t exec[COMB_MAX_LIMIT + 1] = {};
-    bool planned = false, busy = false;      // busy: under Combiner::mu
+    bool planned = false;
+    std::atomic<int> busy{0};                // taken (under Combiner::mu) by a leader, released by it without the lock
 };
 
 struct CombBatch {
     orbx_extractor *m[COMB_MAX_LIMIT];
     bool wantPyr[COMB_MAX_LIMIT];
-    int n = 0;
-    std::vector<orbx_extractor *> waitFor;   // partners announced by members and not here yet
+    int n = 0;                               // under Combiner::mu
+    std::vector<orbx_extractor *> waitFor;   // partners announced by members and not here yet (under Combiner::mu)
+    std::atomic<int> nNow{0}, waiting{0};    // copies of n and waitFor.size() for the leader, which polls without the lock
     std::atomic<int> done{0};
     int rc = ORBX_OK;
     char err[256] = "";
@@ -882,8 +884,11 @@ struct Combiner {
     std::mutex mu;
     std::atomic<int> entering{0};
     std::shared_ptr<CombBatch> open;
-    std::vector<CombEngine *> engines;
+    CombEngine *engines[8] = {};             // only ever appended to (by the one waiting leader); read without the lock up to nEngines
+    std::atomic<int> nEngines{0};
     std::atomic<long> batches{0}, frames{0};
+    // where the calls' time goes (microseconds, summed over calls / launch sets): staging copy, leader's wait, graph launch call, device + sync
+    std::atomic<long> usStage{0}, usWait{0}, usLaunch{0}, usSync{0};
 };
 
 static std::mutex g_combMu;
@@ -1041,36 +1046,48 @@ static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::uni
 {
     const double t0 = now_us();
     CombEngine *E = nullptr;
+    // The leader polls WITHOUT the lock - a thread that re-takes a mutex in a loop starves the ones sleeping on it (the joiners) -: engines
+    // are taken by compare-and-swap, the batch's size and pending partners are mirrored in atomics; the lock is taken once, to close the batch.
+    lk.unlock();
     for (;;) {
-        E = nullptr;
-        for (CombEngine *x : C->engines) if (!x->busy) { E = x; break; }
-        const bool full = B->n >= C->maxB;
-        const bool quiet = C->entering.load(std::memory_order_acquire) == 0 && B->waitFor.empty();
-        const bool timeUp = now_us() - t0 > (B->waitFor.empty() ? COMB_WAIT_US : COMB_PARTNER_US);
-        if (E && (full || quiet || timeUp)) break;
-        if (!E && (int)C->engines.size() < C->maxEngines) {
+        const int ne = C->nEngines.load(std::memory_order_acquire);
+        CombEngine *cand = nullptr;
+        for (int i = 0; i < ne && !cand; i++) if (!C->engines[i]->busy.load(std::memory_order_acquire)) cand = C->engines[i];
+        if (cand) {
+            const int waiting = B->waiting.load(std::memory_order_acquire);
+            const bool full = B->nNow.load(std::memory_order_acquire) >= C->maxB;
+            const bool quiet = C->entering.load(std::memory_order_acquire) == 0 && waiting == 0;
+            const bool timeUp = now_us() - t0 > (waiting ? COMB_PARTNER_US : COMB_WAIT_US);
+            if (full || quiet || timeUp) {
+                int expected = 0;
+                if (cand->busy.compare_exchange_strong(expected, 1, std::memory_order_acq_rel)) { E = cand; break; }
+                continue;
+            }
+        } else if (ne < C->maxEngines) {
             // every engine is busy (or none exists yet) and one more is allowed: build it while the batch keeps collecting members
-            lk.unlock();
-            CombEngine *ne = nullptr;
-            const int rcE = comb_new_engine(C, &ne);
-            lk.lock();
-            if (rcE == ORBX_OK) C->engines.push_back(ne);
-            else if (C->engines.empty()) {      // no engine at all: the batch's members fall back to their own graphs
+            CombEngine *fresh = nullptr;
+            const int rcE = comb_new_engine(C, &fresh);
+            if (rcE == ORBX_OK) {
+                C->engines[ne] = fresh;
+                C->nEngines.store(ne + 1, std::memory_order_release);
+            } else if (ne == 0) {      // no engine at all: the batch's members fall back to their own graphs
+                lk.lock();
                 C->open.reset();
+                lk.unlock();
                 B->rc = ORBX_ERR_STATE;
                 snprintf(B->err, sizeof(B->err), "%s", orbx_last_error());
-                lk.unlock();
                 B->done.store(1, std::memory_order_release);
                 return;
-            } else C->maxEngines = (int)C->engines.size();      // (no memory for another one: live with what exists)
+            } else C->maxEngines = ne;      // (no memory for another one: live with what exists)
             continue;
         }
-        lk.unlock(); cpu_relax(); lk.lock();
+        cpu_relax();
     }
+    lk.lock();
     C->open.reset();                    // later arrivals start the next batch (and elect its leader)
-    E->busy = true;
     const int n = B->n;
     lk.unlock();
+    C->usWait.fetch_add((long)(now_us() - t0), std::memory_order_relaxed);
     int lrc = ORBX_OK;
     for (int i = 0; i < n; i++) {
         orbx_extractor *mh = B->m[i];
@@ -1081,16 +1098,17 @@ static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::uni
     }
     if (!E->exec[n]) lrc = comb_build_graph(C, E, n);
     if (lrc == ORBX_OK) {
+        const double tL = now_us();
         hipError_t he = hipGraphLaunch(E->exec[n], E->eng->stream);
+        const double tY = now_us();
         if (he == hipSuccess) he = hipStreamSynchronize(E->eng->stream);
+        C->usLaunch.fetch_add((long)(tY - tL), std::memory_order_relaxed); C->usSync.fetch_add((long)(now_us() - tY), std::memory_order_relaxed);
         if (he != hipSuccess) { orbx_set_error("combined batch of %d frames failed: %s", n, hipGetErrorString(he)); lrc = ORBX_ERR_HIP; }
     }
     B->rc = lrc;
     if (lrc != ORBX_OK) snprintf(B->err, sizeof(B->err), "%s", orbx_last_error());
     C->batches.fetch_add(1, std::memory_order_relaxed); C->frames.fetch_add(n, std::memory_order_relaxed);
-    lk.lock();
-    E->busy = false;
-    lk.unlock();
+    E->busy.store(0, std::memory_order_release);
     B->done.store(1, std::memory_order_release);
 }
 
@@ -1106,7 +1124,9 @@ static int extract_single_combined(orbx_extractor *h, const uint8_t *image, int 
     h->hostPyrOff = align_up(h->arenaBytes, 256);
     if ((rc = ensure_host_out(h, h->hostPyrOff + h->geom.pyrBytes)) != ORBX_OK) return rc;
     C->entering.fetch_add(1, std::memory_order_acq_rel);        // "on my way in": a leader about to launch waits for the copy below
+    const double tS = now_us();
     if ((rc = stage_rows(h, image, W, H, stride, dstStride, fp)) != ORBX_OK) { C->entering.fetch_sub(1); return rc; }
+    C->usStage.fetch_add((long)(now_us() - tS), std::memory_order_relaxed);
     h->stagingStride = dstStride; h->stagingFramePitch = fp;
     h->cur ^= 1;
     const int cb = h->cur;
@@ -1131,6 +1151,8 @@ static int extract_single_combined(orbx_extractor *h, const uint8_t *image, int 
         for (int i = 0; i < B->n; i++) here = here || B->m[i] == p;
         if (!here && p != h) B->waitFor.push_back(p);
     }
+    B->waiting.store((int)B->waitFor.size(), std::memory_order_release);
+    B->nNow.store(B->n, std::memory_order_release);
     if (!leader) {
         lk.unlock();
         for (int spins = 0; !B->done.load(std::memory_order_acquire); spins++) { if (spins < 20000) cpu_relax(); else std::this_thread::yield(); }
@@ -1332,13 +1354,22 @@ extern "C" int orbx_extractor_expect_partner(orbx_extractor *h, orbx_extractor *
     return ORBX_OK;
 }
 
+extern "C" int orbx_combiner_profile(const orbx_extractor *h, double *us4)
+{
+    if (!h || !us4) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    const Combiner *c = h->comb;
+    us4[0] = c ? (double)c->usStage.load() : 0; us4[1] = c ? (double)c->usWait.load() : 0;
+    us4[2] = c ? (double)c->usLaunch.load() : 0; us4[3] = c ? (double)c->usSync.load() : 0;
+    return ORBX_OK;
+}
+
 extern "C" int orbx_combiner_stats(const orbx_extractor *h, int64_t *batches, int64_t *frames, int *engines)
 {
     if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
     const Combiner *c = h->comb;
     if (batches) *batches = c ? (int64_t)c->batches.load() : 0;
     if (frames) *frames = c ? (int64_t)c->frames.load() : 0;
-    if (engines) *engines = c ? (int)c->engines.size() : 0;      // (a racy read while calls are in flight: a statistic)
+    if (engines) *engines = c ? c->nEngines.load() : 0;
     return ORBX_OK;
 }
 

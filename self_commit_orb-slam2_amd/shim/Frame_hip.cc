@@ -24,6 +24,37 @@
 // tells shim/ORBextractor.cc that ComputeStereoMatches reads the pyramid on the device: no host copy of mvImagePyramid per frame
 extern "C" __attribute__((visibility("default"))) int orbx_shim_device_stereo_linked = 1;
 
+// Where a Frame constructor spends its time (tools/latency_shim.py): accumulated wall time of every replaced member function.
+#include <chrono>
+enum { P_EXTRACT = 0, P_UNDISTORT, P_STEREO, P_BOUNDS, P_GRID, P_COUNT };
+static double gProfUs[P_COUNT];
+static unsigned long gProfCalls[P_COUNT];
+static std::mutex gProfMutex;
+namespace {
+struct ShimTimer {
+    int idx;
+    std::chrono::steady_clock::time_point t0;
+    explicit ShimTimer(int i) : idx(i), t0(std::chrono::steady_clock::now()) {}
+    ~ShimTimer()
+    {
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lock(gProfMutex);
+        gProfUs[idx] += us; gProfCalls[idx]++;
+    }
+};
+}  // namespace
+// idx: 0 ExtractORB (per call: two per stereo frame, concurrent), 1 UndistortKeyPoints, 2 ComputeStereoMatches, 3 ComputeImageBounds, 4 AssignFeaturesToGrid;
+// reset != 0 clears the counters after reading
+extern "C" __attribute__((visibility("default"))) int orbx_shim_profile(int idx, int reset, double *total_us, unsigned long *calls)
+{
+    if (idx < 0 || idx >= P_COUNT) return -1;
+    std::lock_guard<std::mutex> lock(gProfMutex);
+    if (total_us) *total_us = gProfUs[idx];
+    if (calls) *calls = gProfCalls[idx];
+    if (reset) { gProfUs[idx] = 0; gProfCalls[idx] = 0; }
+    return 0;
+}
+
 static unsigned long gStereoCalls = 0, gUndistortCalls = 0, gBoundsCalls = 0, gGridCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_undistort_calls(void) { return gUndistortCalls; }
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_image_bounds_calls(void) { return gBoundsCalls; }
@@ -56,6 +87,7 @@ extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_extrac
 void Frame::ExtractORB(int flag, const cv::Mat &im)
 {
     __atomic_add_fetch(&gExtractCalls, 1, __ATOMIC_RELAXED);
+    ShimTimer timer(P_EXTRACT);
     if (mpORBextractorLeft && mpORBextractorRight)
         (flag == 0 ? mpORBextractorLeft : mpORBextractorRight)->ExpectPartner(flag == 0 ? mpORBextractorRight : mpORBextractorLeft);
     if (flag == 0) (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors);
@@ -65,6 +97,7 @@ void Frame::ExtractORB(int flag, const cv::Mat &im)
 void Frame::ComputeStereoMatches()
 {
     __atomic_add_fetch(&gStereoCalls, 1, __ATOMIC_RELAXED);
+    ShimTimer timer(P_STEREO);
     mvuRight = std::vector<float>(N, -1.0f);   // :1029-1030
     mvDepth = std::vector<float>(N, -1.0f);
     if (N == 0) return;
@@ -134,6 +167,7 @@ std::mutex gCallMutex;   // a handle is not re-entrant (include/orbx.h); frames 
 void Frame::UndistortKeyPoints()
 {
     __atomic_add_fetch(&gUndistortCalls, 1, __ATOMIC_RELAXED);
+    ShimTimer timer(P_UNDISTORT);
     if (mDistCoef.at<float>(0) == 0.0) {   // :901-905
         mvKeysUn = mvKeys;
         return;
@@ -158,6 +192,7 @@ void Frame::UndistortKeyPoints()
 void Frame::ComputeImageBounds(const cv::Mat &imLeft)
 {
     __atomic_add_fetch(&gBoundsCalls, 1, __ATOMIC_RELAXED);
+    ShimTimer timer(P_BOUNDS);
     float b[4];
     orbx_frame_ops *h = FrameOpsFor(mK, mDistCoef);
     std::lock_guard<std::mutex> lock(gCallMutex);
@@ -169,6 +204,7 @@ void Frame::ComputeImageBounds(const cv::Mat &imLeft)
 void Frame::AssignFeaturesToGrid()
 {
     __atomic_add_fetch(&gGridCalls, 1, __ATOMIC_RELAXED);
+    ShimTimer timer(P_GRID);
     std::vector<orbx_keypoint> in;
     Pack(mvKeysUn, in);
     std::vector<int32_t> off((size_t)FRAME_GRID_COLS * FRAME_GRID_ROWS + 1), idx((size_t)(N > 0 ? N : 1));

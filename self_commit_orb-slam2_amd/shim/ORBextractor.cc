@@ -135,6 +135,7 @@ void ORBextractor::DownloadImagePyramid()
     for (int level = 0; level < nlevels; ++level) {
         int w = 0, h = 0;
         orbx_pyramid_level_size(mpHandle, mLastW, mLastH, level, &w, &h);
+        mvImagePyramid[level].release();             // (a view of the handle's pinned memory from the last call: an owning copy now)
         mvImagePyramid[level].create(h, w, CV_8UC1);
         ptr[(size_t)level] = mvImagePyramid[level].data;
         step[(size_t)level] = (int)mvImagePyramid[level].step;

@@ -5,6 +5,9 @@
 #include <vector>
 
 #include "ORBextractor.h"
+#include "orbx.h"
+#include <cstdio>
+#include <cstdlib>
 
 extern "C" void *shim_create(int nf, float sf, int nl, int ini, int mn)
 {
@@ -98,6 +101,16 @@ extern "C" double shim_bench_threads(int nthreads, int nf, const unsigned char *
     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, iters); for (auto &x : th) x.join(); }
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("ORBX_SHIM_BENCH_STATS")) {      // how the calls met inside liborbx: launch sets, frames, engines
+        long long nb = 0, nfr = 0;
+        int ne = 0;
+        orbx_combiner_stats(ex[0]->Handle(), (int64_t *)&nb, (int64_t *)&nfr, &ne);
+        double us[4] = {0, 0, 0, 0};
+        orbx_combiner_profile(ex[0]->Handle(), us);
+        fprintf(stderr, "[shim_bench_threads] %d threads: %lld frames in %lld launch sets (mean %.2f), %d engine(s); since the engines exist: staging %.1f us/frame, "
+                "leader wait %.1f, launch call %.1f, device + sync %.1f us/set; wall %.1f us/frame\n", nthreads, nfr, nb, nb ? (double)nfr / nb : 0.0, ne,
+                nfr ? us[0] / nfr : 0.0, nb ? us[1] / nb : 0.0, nb ? us[2] / nb : 0.0, nb ? us[3] / nb : 0.0, 1e6 * s / ((double)nthreads * iters));
+    }
     for (size_t t = 0; t < ex.size(); t++) delete ex[t];
     return (double)nthreads * iters / s;
 }

@@ -78,11 +78,24 @@ def stereo_frame(orbx, iters_hip, iters_ref):
         lib.orbslam_stereo_frame_bench.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
             [ctypes.c_float] * 6 + [ctypes.c_int] + [ctypes.c_void_p] * 4
         mean, med, nl, nm = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
+        prof = hasattr(lib, "orbx_shim_profile")
+        if prof:
+            lib.orbx_shim_profile.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+            for i in range(5):
+                lib.orbx_shim_profile(i, 1, None, None)
         lib.orbslam_stereo_frame_bench(aL, aR, 4, W, H, W, nf, 1.2, 8, 20, 7, 718.856, 718.856, 607.19, 185.2, 386.1448, 35.0, iters, ctypes.byref(mean), ctypes.byref(med),
                                        ctypes.byref(nl), ctypes.byref(nm))
         rows.append({"call": "Frame::Frame(imLeft, imRight, ...) = 2 x ExtractORB on two threads + ComputeStereoMatches", "library": name, "size": "%dx%d" % (W, H),
                      "nfeatures": nf, "combiner": os.environ.get("ORBX_COMBINE", "1") != "0", "mean_us": round(mean.value, 1), "median_us": round(med.value, 1),
                      "keypoints_left": nl.value, "stereo_matches": nm.value})
+        if prof:      # mean microseconds per constructor inside every replaced member function (ExtractORB: per call, two concurrent calls per frame)
+            br = {}
+            for i, nm_ in enumerate(("ExtractORB_per_call", "UndistortKeyPoints", "ComputeStereoMatches", "ComputeImageBounds", "AssignFeaturesToGrid")):
+                us, calls = ctypes.c_double(), ctypes.c_ulong()
+                lib.orbx_shim_profile(i, 1, ctypes.byref(us), ctypes.byref(calls))
+                if calls.value:
+                    br[nm_] = round(us.value / calls.value, 1)
+            rows[-1]["breakdown_us"] = br
     return rows
 
 
