@@ -114,13 +114,17 @@ int orbx_extract_view_pyramid(orbx_extractor *h, const uint8_t *image, int width
  * returned alone.  A lone caller never waits for company.  ORBX_COMBINE=0 in the environment gives every handle its own graph instead;
  * ORBX_COMBINE_MAX (16) = most frames per set, ORBX_COMBINE_ENGINES (2) = sets in flight.
  * orbx_extractor_expect_partner: a one-shot hint for the NEXT call on `h` - `partner`'s call is about to arrive (the other extractor
- * thread of the stereo Frame constructor, src/Frame.cc:159-167): the set waits for it (at most 0.3 ms) instead of leaving without it.
+ * thread of the stereo Frame constructor, src/Frame.cc:159-167): with ORBX_COMBINE_PARTNER_US=<us> in the environment the set waits that
+ * long for it instead of leaving without it.  Off by default: measured on the reference's constructor, the 30-40 us between its two
+ * thread starts cost more than the second launch set saves (the second call simply takes the other engine).
  * orbx_combiner_stats: launch sets and frames served so far for h's configuration (frames / batches = mean set size). */
 int orbx_extractor_expect_partner(orbx_extractor *h, orbx_extractor *partner);
 int orbx_combiner_stats(const orbx_extractor *h, int64_t *batches, int64_t *frames, int *engines);
 /* Microseconds summed so far over h's configuration: us4[0] staging copies (per call), [1] leaders' wait for an engine / for company,
  * [2] graph launch calls, [3] device time + synchronisation (per launch set).  A measurement aid (tools/latency_shim.py). */
 int orbx_combiner_profile(const orbx_extractor *h, double *us4);
+int orbx_combiner_reset_stats(orbx_extractor *h);
+int orbx_combiner_histogram(const orbx_extractor *h, int maxn, int64_t *sets, double *mean_us);   /* sets[n], mean_us[n] for n = 0..maxn frames per launch set */
 
 /* ORBextractor::operator() (ORBextractor.h:110, src/ORBextractor.cc:1544-1668) for one
  * host image.  `keypoints` / `descriptors` hold `capacity` entries / capacity*32 bytes;
@@ -306,6 +310,11 @@ int orbx_compute_stereo_matches_device(orbx_matcher *m, orbx_extractor *left, or
                                        float mb);
 int orbx_stereo_results_device(orbx_matcher *m, const float **uright_dev, const float **depth_dev, int *stride);
 int orbx_stereo_download(orbx_matcher *m, int npairs, float *uright, float *depth, int stride);
+/* Frame::ComputeStereoMatches (src/Frame.cc:1026-1420) for ONE stereo frame whose left / right image were extracted by the two
+ * extractors' last single-frame calls (orbx_extract_view* / orbx_extract: the stereo Frame constructor, src/Frame.cc:159-168):
+ * uright[i] / depth[i] = mvuRight / mvDepth of left keypoint i, i < n.  Synchronous; the latency form of
+ * orbx_compute_stereo_matches_device + orbx_stereo_download (same kernels, three launches and one wait instead of ~22 runtime calls). */
+int orbx_stereo_frame(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, float mbf, float mb, float *uright, float *depth, int n);
 
 /* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
  * (ORBmatcher.h, src/ORBmatcher.cc:70-175; called by Tracking::SearchLocalPoints, src/Tracking.cc:1616)

@@ -378,6 +378,7 @@ def _bind_matcher(L):
     L.orbx_compute_stereo_matches_device.argtypes = [vp, vp, vp, vp, vp, ci, ctypes.c_float, ctypes.c_float]
     L.orbx_stereo_results_device.argtypes = [vp, vp, vp, vp]
     L.orbx_stereo_download.argtypes = [vp, ci, vp, vp, ci]
+    L.orbx_stereo_frame.argtypes = [vp, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, ci]
     L.orbx_matcher_download.argtypes = [vp, ci, vp, vp, ci, vp]
     L.orbx_matcher_sync.argtypes = [vp]
     L.orbx_search_by_bow.argtypes = [vp, ctypes.POINTER(FeatureSet), ctypes.POINTER(FeatureSet), ctypes.POINTER(BowParams), vp, vp]
@@ -754,6 +755,14 @@ class ORBmatcher:
         fr = np.ascontiguousarray(frames_r, np.int32)
         _check(self._L.orbx_compute_stereo_matches_device(self._h, ext_left._h, ext_right._h, _ptr(fl), _ptr(fr), len(fl),
                                                           ctypes.c_float(mbf), ctypes.c_float(mb)))
+
+    def stereo_frame(self, ext_left, ext_right, mbf, mb=0.0, n=None):
+        """Frame::ComputeStereoMatches of ONE stereo frame, after the two extractors' single-frame calls (orbx_stereo_frame): (mvuRight, mvDepth)."""
+        n = self.max_features if n is None else int(n)
+        u = np.full(n, -1.0, np.float32)
+        z = np.full(n, -1.0, np.float32)
+        _check(self._L.orbx_stereo_frame(self._h, ext_left._h, ext_right._h, ctypes.c_float(mbf), ctypes.c_float(mb), _ptr(u), _ptr(z), n))
+        return u, z
 
     def download_stereo(self, npairs, stride=None):
         """(mvuRight, mvDepth) per pair, -1 where the reference leaves -1."""

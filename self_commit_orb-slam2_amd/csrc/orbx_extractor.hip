@@ -130,6 +130,7 @@ struct orbx_extractor {
     bool isEngine = false;
     size_t hostPyrOff = 0;            // pinned copy of the pyramid (levels >= 1) inside hostOut, behind the result arena
     bool hostPyrValid = false;        // ... and whether the last call filled it
+    bool hostSynced = false;          // the last call was a synchronous single-frame call: complete when it returned, capacity word in hostOut[1]
     bool lastCombined = false;        // the last call ran on a shared engine: this handle's `blur` buffer (a parity tap) was not written
 };
 
@@ -438,7 +439,7 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     if ((rc = orbx_launch_orient_describe(L)) != ORBX_OK) return rc;
     if (prof) { ORBX_HIP_CHECK(hipEventRecord(ev[ST_DESC + 1], h->stream)); h->profCount++; }
     h->lastBatch = batch; h->lastImg0 = img0Dev; h->lastStride = stride; h->lastFramePitch = framePitch;
-    h->lastCombined = false;
+    h->lastCombined = false; h->hostSynced = false;
     return ORBX_OK;
 }
 
@@ -479,6 +480,14 @@ int upload(orbx_extractor *h, const uint8_t *const *images, int batch, int W, in
 }  // namespace
 
 hipStream_t orbx_extractor_stream_internal(orbx_extractor *h) { return h ? h->stream : nullptr; }
+/* true: the handle's last call was a synchronous single-frame call - its results are complete (no event to wait for) and *status is its
+ * capacity word, read from the pinned result arena */
+bool orbx_extractor_host_complete_internal(orbx_extractor *h, int *status)
+{
+    if (!h || !h->hostSynced || !h->lastBatch || !h->hostOut) return false;
+    if (status) *status = ((const int *)h->hostOut)[1];
+    return true;
+}
 void orbx_extractor_set_consumer_event_internal(orbx_extractor *h, hipEvent_t ev) { if (h) h->consumerEv[h->cur] = ev; }
 void orbx_extractor_set_pyramid_consumer_event_internal(orbx_extractor *h, hipEvent_t ev) { if (h) h->pyrConsumerEv = ev; }
 int orbx_extractor_last_batch_view_internal(orbx_extractor *h, OrbxLastBatchView *v)
@@ -853,7 +862,17 @@ static int build_single_graph(orbx_extractor *h)
 // ---------------------------------------------------------------------------------------------
 #define COMB_MAX_LIMIT 64
 #define COMB_WAIT_US 40.0
-#define COMB_PARTNER_US 300.0
+// How long a set waits for a partner that a member announced (orbx_extractor_expect_partner).  Default 0 = not at all.  Measured on the
+// reference's stereo constructor (two std::threads started one after the other, src/Frame.cc:159-167; 1241x376, 2000 features): the right
+// extractor's call arrives 30-40 us after the left one's; waiting for it and running ONE set of two frames makes ExtractORB 275 us per call
+// (constructor 410 us), not waiting - the second call takes the other engine, whose stream sits on a hardware queue of its own - 255 us
+// (358 us), every handle on its own graph (ORBX_COMBINE=0) 214 us (347 us).  The skew, not the launch count, is what the pair pays for.
+// ORBX_COMBINE_PARTNER_US=<microseconds> turns the wait on (a caller whose two calls arrive together, e.g. from a thread pool).
+static double comb_partner_us()
+{
+    const char *e = getenv("ORBX_COMBINE_PARTNER_US");
+    return e && *e ? atof(e) : 0.0;
+}
 
 struct CombEngine {
     orbx_extractor *eng = nullptr;
@@ -871,6 +890,7 @@ struct CombBatch {
     int n = 0;                               // under Combiner::mu
     std::vector<orbx_extractor *> waitFor;   // partners announced by members and not here yet (under Combiner::mu)
     std::atomic<int> nNow{0}, waiting{0};    // copies of n and waitFor.size() for the leader, which polls without the lock
+    std::atomic<int> uploaded[COMB_MAX_LIMIT] = {};   // member's own upload of its frame: 0 none, 1 in flight, 2 complete
     std::atomic<int> done{0};
     int rc = ORBX_OK;
     char err[256] = "";
@@ -883,12 +903,14 @@ struct Combiner {
     size_t fp = 0, kpOff = 0, descOff = 0;
     std::mutex mu;
     std::atomic<int> entering{0};
+    std::atomic<int> active{0};              // calls inside the combiner right now (staging, waiting, in flight): the concurrency the set size follows
     std::shared_ptr<CombBatch> open;
     CombEngine *engines[8] = {};             // only ever appended to (by the one waiting leader); read without the lock up to nEngines
     std::atomic<int> nEngines{0};
     std::atomic<long> batches{0}, frames{0};
     // where the calls' time goes (microseconds, summed over calls / launch sets): staging copy, leader's wait, graph launch call, device + sync
     std::atomic<long> usStage{0}, usWait{0}, usLaunch{0}, usSync{0};
+    std::atomic<long> setsByN[COMB_MAX_LIMIT + 1] = {}, usByN[COMB_MAX_LIMIT + 1] = {};      // launch sets of n frames, and their device + sync time
 };
 
 static std::mutex g_combMu;
@@ -944,6 +966,21 @@ static int comb_new_engine(Combiner *C, CombEngine **out)
     e->isEngine = true; e->combDisabled = true;
     CombEngine *E = new CombEngine();
     E->eng = e;
+    {   // The runtime spreads streams over a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order, and every
+        // handle of this library owns a stream: whether two engines' streams land on different queues - i.e. whether their launch sets
+        // overlap at all - was a matter of luck (measured: sets of one frame on two engines took 167-172 us each instead of 96 when they
+        // shared a queue).  Streams of another PRIORITY come from a queue pool of their own: the second engine takes the high one.
+        // ORBX_COMBINE_PRIO=0: plain streams for all.
+        const char *pe = getenv("ORBX_COMBINE_PRIO");
+        if (!(pe && pe[0] == '0') && C->nEngines.load() == 1) {
+            int lo = 0, hi = 0;
+            hipStream_t ps = nullptr;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, hi) == hipSuccess) {
+                (void)hipStreamDestroy(e->stream);
+                e->stream = ps;
+            }
+        }
+    }
     auto fail = [&](int code) { orbx_extractor_destroy(e); if (E->tab) (void)hipHostFree(E->tab); delete E; return code; };
     if ((rc = ensure_geometry(e, C->W, C->H, C->maxB)) != ORBX_OK) return fail(rc);
     if ((rc = e->staging.ensure(C->fp * (size_t)C->maxB)) != ORBX_OK) return fail(rc);
@@ -1055,15 +1092,28 @@ static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::uni
         for (int i = 0; i < ne && !cand; i++) if (!C->engines[i]->busy.load(std::memory_order_acquire)) cand = C->engines[i];
         if (cand) {
             const int waiting = B->waiting.load(std::memory_order_acquire);
-            const bool full = B->nNow.load(std::memory_order_acquire) >= C->maxB;
+            // set size: the callers present share the engines - with E engines a set takes 1/E of them and leaves at once, so that the sets
+            // of the others overlap it (16 threads on 2 engines: sets of 5-8 in flight side by side, 65k frames/s; one set of 16 at a time:
+            // 45k; one engine: 42-52k).  A lone caller's share is itself: it never waits.
+            const int share = (C->active.load(std::memory_order_acquire) + C->maxEngines - 1) / C->maxEngines;
+            const int nNow = B->nNow.load(std::memory_order_acquire);
+            const bool full = nNow >= C->maxB || (waiting == 0 && nNow >= std::max(1, share));
             const bool quiet = C->entering.load(std::memory_order_acquire) == 0 && waiting == 0;
-            const bool timeUp = now_us() - t0 > (waiting ? COMB_PARTNER_US : COMB_WAIT_US);
+            const bool timeUp = now_us() - t0 > (waiting ? comb_partner_us() : COMB_WAIT_US);
             if (full || quiet || timeUp) {
                 int expected = 0;
                 if (cand->busy.compare_exchange_strong(expected, 1, std::memory_order_acq_rel)) { E = cand; break; }
                 continue;
             }
-        } else if (ne < C->maxEngines) {
+        } else if (ne >= C->maxEngines) {
+            // every engine is busy and no more may be built: the leader's own frame goes up meanwhile, like the followers' (see the caller)
+            orbx_extractor *me = B->m[0];
+            const int up = B->uploaded[0].load(std::memory_order_relaxed);
+            if (up == 0) {
+                B->uploaded[0].store(1, std::memory_order_release);
+                if (hipMemcpyAsync(me->staging.p, me->hostStaging, C->fp, hipMemcpyHostToDevice, me->stream) != hipSuccess) B->uploaded[0].store(3, std::memory_order_release);
+            } else if (up == 1 && hipStreamQuery(me->stream) == hipSuccess) B->uploaded[0].store(2, std::memory_order_release);
+        } else {
             // every engine is busy (or none exists yet) and one more is allowed: build it while the batch keeps collecting members
             CombEngine *fresh = nullptr;
             const int rcE = comb_new_engine(C, &fresh);
@@ -1092,7 +1142,10 @@ static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::uni
     for (int i = 0; i < n; i++) {
         orbx_extractor *mh = B->m[i];
         OrbxCombMember &t = E->tab[i];
-        t.hostImg = mh->hostStaging; t.devImg = mh->staging.p; t.devPyr = mh->pyr.p;
+        const int up = B->uploaded[i].load(std::memory_order_acquire);
+        t.srcImg = up == 2 ? mh->staging.p : mh->hostStaging;
+        t.devImg = (up == 0 || up == 3) ? mh->staging.p : nullptr;
+        t.devPyr = mh->pyr.p;
         t.devArena = mh->outArena[mh->cur].p; t.hostOut = mh->hostOut;
         t.hostPyr = B->wantPyr[i] ? mh->hostOut + mh->hostPyrOff : nullptr;
     }
@@ -1102,14 +1155,27 @@ static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::uni
         hipError_t he = hipGraphLaunch(E->exec[n], E->eng->stream);
         const double tY = now_us();
         if (he == hipSuccess) he = hipStreamSynchronize(E->eng->stream);
-        C->usLaunch.fetch_add((long)(tY - tL), std::memory_order_relaxed); C->usSync.fetch_add((long)(now_us() - tY), std::memory_order_relaxed);
+        const long usS = (long)(now_us() - tY);
+        C->usLaunch.fetch_add((long)(tY - tL), std::memory_order_relaxed); C->usSync.fetch_add(usS, std::memory_order_relaxed);
+        C->setsByN[n].fetch_add(1, std::memory_order_relaxed); C->usByN[n].fetch_add(usS, std::memory_order_relaxed);
         if (he != hipSuccess) { orbx_set_error("combined batch of %d frames failed: %s", n, hipGetErrorString(he)); lrc = ORBX_ERR_HIP; }
     }
     B->rc = lrc;
     if (lrc != ORBX_OK) snprintf(B->err, sizeof(B->err), "%s", orbx_last_error());
     C->batches.fetch_add(1, std::memory_order_relaxed); C->frames.fetch_add(n, std::memory_order_relaxed);
     E->busy.store(0, std::memory_order_release);
+    if (B->uploaded[0].load() == 1 && hipStreamSynchronize(B->m[0]->stream) != hipSuccess && B->rc == ORBX_OK) {
+        // (the leader's own upload was still in flight when the set was launched: it has to be complete before its buffers are reused)
+        B->rc = ORBX_ERR_HIP; snprintf(B->err, sizeof(B->err), "upload of the leader's frame failed");
+    }
     B->done.store(1, std::memory_order_release);
+}
+
+static bool comb_engine_free(const Combiner *C)
+{
+    const int ne = C->nEngines.load(std::memory_order_acquire);
+    for (int i = 0; i < ne; i++) if (!C->engines[i]->busy.load(std::memory_order_acquire)) return true;
+    return ne < C->maxEngines && ne == 0;      // (no engine yet: the first one is about to be built, nobody waits for a busy one)
 }
 
 // One call through the combiner.  ORBX_ERR_STATE + combDisabled: the engines cannot be built here, the caller takes the handle's own path.
@@ -1123,6 +1189,11 @@ static int extract_single_combined(orbx_extractor *h, const uint8_t *image, int 
     if ((rc = h->staging.ensure(fp)) != ORBX_OK) return rc;
     h->hostPyrOff = align_up(h->arenaBytes, 256);
     if ((rc = ensure_host_out(h, h->hostPyrOff + h->geom.pyrBytes)) != ORBX_OK) return rc;
+    struct ActiveScope {
+        Combiner *c;
+        explicit ActiveScope(Combiner *cc) : c(cc) { c->active.fetch_add(1, std::memory_order_acq_rel); }
+        ~ActiveScope() { c->active.fetch_sub(1, std::memory_order_acq_rel); }
+    } activeScope(C);
     C->entering.fetch_add(1, std::memory_order_acq_rel);        // "on my way in": a leader about to launch waits for the copy below
     const double tS = now_us();
     if ((rc = stage_rows(h, image, W, H, stride, dstStride, fp)) != ORBX_OK) { C->entering.fetch_sub(1); return rc; }
@@ -1155,7 +1226,16 @@ static int extract_single_combined(orbx_extractor *h, const uint8_t *image, int 
     B->nNow.store(B->n, std::memory_order_release);
     if (!leader) {
         lk.unlock();
+        if (!comb_engine_free(C)) {
+            // every engine is busy: this call waits for one anyway, so its frame goes up NOW, on the handle's own stream (a DMA that overlaps
+            // the launch set in flight), and the set's first kernel gathers it on the device instead of reading it across PCIe
+            B->uploaded[slot].store(1, std::memory_order_release);
+            if (hipMemcpyAsync(h->staging.p, h->hostStaging, fp, hipMemcpyHostToDevice, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess)
+                B->uploaded[slot].store(2, std::memory_order_release);
+            // (on an error the state stays 1: the set reads the pinned copy, and this member's device copy is rewritten by nobody - flagged below)
+        }
         for (int spins = 0; !B->done.load(std::memory_order_acquire); spins++) { if (spins < 20000) cpu_relax(); else std::this_thread::yield(); }
+        if (B->uploaded[slot].load() == 1) { orbx_set_error("upload of the frame failed"); h->cur ^= 1; return ORBX_ERR_HIP; }
     } else comb_lead(C, B, lk);
     if (B->rc != ORBX_OK) {
         if (B->rc == ORBX_ERR_STATE) h->combDisabled = true;
@@ -1168,7 +1248,15 @@ static int extract_single_combined(orbx_extractor *h, const uint8_t *image, int 
     return check_single_status(h, offKpOut, offDescOut);
 }
 
+static int extract_single_host_impl(orbx_extractor *h, const uint8_t *image, int W, int H, int stride, bool wantPyr, size_t *offKpOut, size_t *offDescOut);
 static int extract_single_host(orbx_extractor *h, const uint8_t *image, int W, int H, int stride, bool wantPyr, size_t *offKpOut, size_t *offDescOut)
+{
+    const int rc = extract_single_host_impl(h, image, W, H, stride, wantPyr, offKpOut, offDescOut);
+    if (rc == ORBX_OK && h->allocBatch == 1) h->hostSynced = true;      // every single-frame path ends with a synchronisation: nothing of this call is in flight any more
+    return rc;
+}
+
+static int extract_single_host_impl(orbx_extractor *h, const uint8_t *image, int W, int H, int stride, bool wantPyr, size_t *offKpOut, size_t *offDescOut)
 {
     if (stride < W) { orbx_set_error("bad image pointer / stride"); return ORBX_ERR_ARG; }
     int rc = ensure_geometry(h, W, H, 1);
@@ -1207,7 +1295,7 @@ static int extract_single_host(orbx_extractor *h, const uint8_t *image, int W, i
             if (build_single_graph(h) != ORBX_OK) {       // no graph support for this sequence: fall back to stream launches for good
                 invalidate_single_graph(h);
                 h->sgDisabled = true;
-                return extract_single_host(h, image, W, H, stride, wantPyr, offKpOut, offDescOut);
+                return extract_single_host_impl(h, image, W, H, stride, wantPyr, offKpOut, offDescOut);
             }
         }
         if ((rc = stage_rows(h, image, W, H, stride, dstStride, fp)) != ORBX_OK) return rc;
@@ -1360,6 +1448,29 @@ extern "C" int orbx_combiner_profile(const orbx_extractor *h, double *us4)
     const Combiner *c = h->comb;
     us4[0] = c ? (double)c->usStage.load() : 0; us4[1] = c ? (double)c->usWait.load() : 0;
     us4[2] = c ? (double)c->usLaunch.load() : 0; us4[3] = c ? (double)c->usSync.load() : 0;
+    return ORBX_OK;
+}
+
+/* launch sets of n frames (n = 0 .. maxn) and the mean device + synchronisation time of one, in microseconds */
+extern "C" int orbx_combiner_histogram(const orbx_extractor *h, int maxn, int64_t *sets, double *mean_us)
+{
+    if (!h || !sets || !mean_us || maxn < 0) { orbx_set_error("bad argument"); return ORBX_ERR_ARG; }
+    const Combiner *c = h->comb;
+    for (int n = 0; n <= maxn; n++) {
+        const long k = (c && n <= COMB_MAX_LIMIT) ? c->setsByN[n].load() : 0;
+        sets[n] = k;
+        mean_us[n] = k ? (double)c->usByN[n].load() / (double)k : 0.0;
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_combiner_reset_stats(orbx_extractor *h)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    Combiner *c = h->comb;
+    if (!c) return ORBX_OK;
+    c->batches = 0; c->frames = 0; c->usStage = 0; c->usWait = 0; c->usLaunch = 0; c->usSync = 0;
+    for (int n = 0; n <= COMB_MAX_LIMIT; n++) { c->setsByN[n] = 0; c->usByN[n] = 0; }
     return ORBX_OK;
 }
 

@@ -62,8 +62,10 @@ struct OrbxPyrTile { short cx0, cy0, cx1, cy1, ox0, oy0, ox1, oy1; };
  * The table lives in pinned host memory; k_comb_upload / k_comb_finish read it, so the graph that replays a batch of n frames
  * names no member and serves whichever n callers happen to arrive together. */
 struct OrbxCombMember {
-    const uint8_t *hostImg;   /* member's pinned staging buffer: the frame's rows at the device pitch                 */
-    uint8_t *devImg;          /* member's device copy of the frame (level 0 for the device-resident consumers)       */
+    const uint8_t *srcImg;    /* the frame's rows at the device pitch: the member's pinned staging buffer (read across PCIe), or its
+                                 device copy when the member's own upload - started while it waited for the engine - is complete      */
+    uint8_t *devImg;          /* member's device copy of the frame (level 0 for the device-resident consumers) to fill, NULL = the
+                                 member uploads (has uploaded) it itself                                                             */
     uint8_t *devPyr;          /* member's device pyramid, levels >= 1                                                */
     uint8_t *devArena;        /* member's result arena in the one-frame layout: count | 2 status words | kps | desc  */
     uint8_t *hostOut;         /* the same arena in the member's pinned memory                                        */
@@ -131,6 +133,7 @@ int orbx_launch_orient_describe(const OrbxLaunch &L);   /* IC_Angle + rBRIEF + f
 
 /* stream of an extractor handle (orbx_extractor.hip), so other handles can order work after it */
 hipStream_t orbx_extractor_stream_internal(orbx_extractor *h);
+bool orbx_extractor_host_complete_internal(orbx_extractor *h, int *status);
 /* `ev` (recorded by a consumer on its own stream) guards the result buffer of the LAST batch: the
  * extractor waits for it before that buffer is overwritten two batches later */
 void orbx_extractor_set_consumer_event_internal(orbx_extractor *h, hipEvent_t ev);

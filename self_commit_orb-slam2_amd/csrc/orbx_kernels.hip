@@ -83,6 +83,7 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
 // covers all eight taps of the four pixels (scale 1.2: span <= 6 bytes), one dword store per row.
 // ------------------------------------------------------------------------------------
 #define RS_ROWS 8   /* dst rows per thread */
+#define ORBX_OCTREE_COPY_BLOCKS 48
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -213,6 +214,9 @@ __global__ __launch_bounds__(256) void k_pyramid_tiles(const OrbxGeom *__restric
     // blockIdx.y = frame of a (small) batch: the single-frame call, or the frames of concurrent callers combined into one launch set
     img0 += (size_t)blockIdx.y * img0FramePitch;
     pyr += (size_t)blockIdx.y * g->pyrBytes;
+    // (measured and not kept: a second store of every level straight into the caller's pinned pyramid copy - 4-byte stores in ~44-byte runs
+    // cross PCIe badly: the call took 126 us instead of 115 with a 16-byte-per-lane copy at the end of the chain; the copy now rides in the
+    // quadtree's launch, k_octree)
     // the frames' capacity words and the batch word (first kernel of the chain: no memset node)
     if (blockIdx.x == 0 && threadIdx.x == 0) { status[blockIdx.y] = 0; if (blockIdx.y == 0) status[gridDim.y] = 0; }
     // rectangles and level parameters of the level loop out of LDS too: a scalar load from global memory at the top of every level is a
@@ -638,7 +642,8 @@ __device__ __forceinline__ int ot_quadrant(uint32_t p, const OtBox b)
 template <int NODECAP>
 __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, const int *__restrict__ cellCount, const uint32_t *__restrict__ cellSlots,
                                                 const uint8_t *__restrict__ binTab, uint32_t *__restrict__ ptBuf, uint32_t *__restrict__ labBuf,
-                                                OrbxLevelKp *__restrict__ lvlKp, int *__restrict__ lvlCnt, int *__restrict__ status)
+                                                OrbxLevelKp *__restrict__ lvlKp, int *__restrict__ lvlCnt, int *__restrict__ status,
+                                                const OrbxCombMember *__restrict__ comb, const uint8_t *__restrict__ engPyr)
 {
     __shared__ OtBox box[2][NODECAP];
     __shared__ int cnt[2][NODECAP];
@@ -657,6 +662,17 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
     // candidates were written, and its keypoints will be read, by the XCD that owns the frame's range - in the natural order
     // block (l, f) lands on XCD l, and both hand-overs cross the fabric
     XCD_REMAP_XY(l, f);
+    if (l >= g->nlevels) {
+        // Combined single-frame calls (comb != NULL, gridDim.x = nlevels + copy blocks): the quadtree is eight latency-bound workgroups per
+        // frame on an otherwise idle device, so the caller's HOST pyramid copy (the public mvImagePyramid; levels >= 1 in the device layout,
+        // 16 bytes per lane across PCIe) travels in the same launch, next to it, instead of as ~19 us at the end of the chain.
+        uint4 *dst = (uint4 *)comb[f].hostPyr;
+        if (!dst) return;
+        const uint4 *src = (const uint4 *)(engPyr + (size_t)f * g->pyrBytes);
+        const size_t n = g->pyrBytes >> 4, stride = (size_t)(gridDim.x - g->nlevels) * 256;
+        for (size_t i = (size_t)(l - g->nlevels) * 256 + tid; i < n; i += stride) dst[i] = src[i];
+        return;
+    }
     const OrbxLevel &lv = g->lv[l];
     const int N = lv.quota;
     uint32_t *pts = ptBuf + (size_t)f * g->slotsPerFrame + lv.slotBase;    // capacity = cells x slots per cell: every candidate the detector can emit
@@ -1225,12 +1241,14 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
 // or the tracking threads of several sequences - are inside it at the same moment, their frames run as ONE launch set on a shared
 // engine.  These two kernels are the set's first and last node: they move the frames in from, and the results out to, the members'
 // own buffers named by a table in pinned memory (the engine's graph is the same whoever the members are).
-// k_comb_upload: blockIdx.y = member; its pinned staging buffer (rows already at the device pitch) -> frame slot y of the engine's
-// staging area, 16 bytes per lane, four loads in flight per lane (the reads cross PCIe).
+// k_comb_upload: blockIdx.y = member; its frame (rows already at the device pitch) -> frame slot y of the engine's staging area, 16 bytes
+// per lane, four loads in flight per lane.  The source is the member's pinned staging buffer - the reads cross PCIe: 14 us for one
+// 640x480 frame, but 66 us for eight, with the whole chain waiting behind them - or, when the member had to wait for the engine anyway
+// and uploaded its frame meanwhile on its own stream (DMA, overlapping the previous launch set), the member's device copy.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_comb_upload(const OrbxCombMember *__restrict__ tab, uint8_t *__restrict__ staging, size_t framePitch)
 {
-    const uint4 *src = (const uint4 *)tab[blockIdx.y].hostImg;
+    const uint4 *src = (const uint4 *)tab[blockIdx.y].srcImg;
     uint4 *dst = (uint4 *)(staging + (size_t)blockIdx.y * framePitch);
     const size_t n = framePitch >> 4, stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1247,7 +1265,7 @@ __global__ __launch_bounds__(256) void k_comb_upload(const OrbxCombMember *__res
 // pyramid copy behind the public mvImagePyramid).  Only the frame's real keypoints are moved, not the arena's capacity.
 __global__ __launch_bounds__(256) void k_comb_finish(const OrbxCombMember *__restrict__ tab, const int *__restrict__ engCnt, const int *__restrict__ engSt,
                                                      const orbx_keypoint *__restrict__ engKp, const uint8_t *__restrict__ engDesc, int cap, const uint8_t *__restrict__ engPyr,
-                                                     size_t pyrBytes, const uint8_t *__restrict__ engImg, size_t framePitch, size_t kpOff, size_t descOff)
+                                                     size_t pyrBytes, const uint8_t *__restrict__ engImg, size_t framePitch, size_t kpOff, size_t descOff, int hostPyrHere)
 {
     const int f = blockIdx.y;
     const OrbxCombMember m = tab[f];
@@ -1271,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_comb_finish(const OrbxCombMember *__res
     }
     {   // pyramid levels >= 1 (device layout, padding included: one flat copy)
         const uint4 *s = (const uint4 *)(engPyr + (size_t)f * pyrBytes);
-        uint4 *d = (uint4 *)m.devPyr, *h = (uint4 *)m.hostPyr;
+        uint4 *d = (uint4 *)m.devPyr, *h = hostPyrHere ? (uint4 *)m.hostPyr : nullptr;      // (k_pyramid_tiles stores the host copy itself where it runs)
         const size_t n = pyrBytes >> 4;
         if (h) for (size_t i = tid; i < n; i += stride) { const uint4 v = s[i]; d[i] = v; h[i] = v; }
         else for (size_t i = tid; i < n; i += stride) d[i] = s[i];
@@ -1279,7 +1297,7 @@ __global__ __launch_bounds__(256) void k_comb_finish(const OrbxCombMember *__res
     {   // level 0 = the frame itself
         const uint4 *s = (const uint4 *)(engImg + (size_t)f * framePitch);
         uint4 *d = (uint4 *)m.devImg;
-        for (size_t i = tid; i < (framePitch >> 4); i += stride) d[i] = s[i];
+        if (d) for (size_t i = tid; i < (framePitch >> 4); i += stride) d[i] = s[i];
     }
 }
 
@@ -1359,7 +1377,7 @@ int orbx_launch_comb_finish(const OrbxLaunch &L)
     const size_t units = (L.geom->pyrBytes + L.img0FramePitch) >> 4;
     const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((units + 511) / 512, 1), 256);
     return emit(L, k_comb_finish, dim3(blocks, (unsigned)L.batch), dim3(256), 0, L.combTab, L.outCnt, L.outStatus, L.outKp, L.outDesc, L.geom->outCap, L.pyr, L.geom->pyrBytes, L.img0,
-                L.img0FramePitch, L.combKpOff, L.combDescOff);
+                L.img0FramePitch, L.combKpOff, L.combDescOff, 0);      // (the host pyramid copy rides in the quadtree's launch)
 }
 
 int orbx_launch_fast_cells(const OrbxLaunch &L)
@@ -1378,8 +1396,10 @@ int orbx_launch_fast_cells(const OrbxLaunch &L)
 
 int orbx_launch_octree(const OrbxLaunch &L)
 {
-    dim3 grid((unsigned)L.geom->nlevels, (unsigned)L.batch);
-#define OT_LAUNCH(NC) return emit(L, k_octree<NC>, grid, dim3(256), 0, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.labBuf, L.lvlKp, L.lvlCnt, L.status)
+    // (combined single-frame calls: 48 more workgroups per frame carry the host pyramid copy, see the kernel)
+    dim3 grid((unsigned)(L.geom->nlevels + (L.combTab ? ORBX_OCTREE_COPY_BLOCKS : 0)), (unsigned)L.batch);
+#define OT_LAUNCH(NC) return emit(L, k_octree<NC>, grid, dim3(256), 0, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.labBuf, L.lvlKp, L.lvlCnt, L.status, L.combTab, \
+                                  (const uint8_t *)L.pyr)
     if (L.nodeCap <= 256) OT_LAUNCH(256);   // 1000 features at 640x480: 224 nodes at most; a fraction of the LDS, more resident quadtrees per CU
     if (L.nodeCap <= 512) OT_LAUNCH(512);
     if (L.nodeCap <= 1024) OT_LAUNCH(1024);

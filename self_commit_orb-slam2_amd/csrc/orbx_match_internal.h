@@ -71,6 +71,13 @@ struct orbx_matcher {
     OrbxDevBuf<int32_t> stRowStart, stRowList;   // ComputeStereoMatches: vRowIndices of the right frames (k_stereo_rows)
     hipEvent_t evDep2 = nullptr, evPyr[2] = {nullptr, nullptr};
     int lastStereoPairs = 0;
+    // orbx_stereo_frame (one stereo frame, host-synchronous): scale tables as last uploaded, a device zero for the pair arrays, pinned results
+    float sfScales[128] = {};
+    int sfLevels = 0;
+    OrbxDevBuf<int32_t> sfZero;
+    OrbxDevBuf<float> sfScalesDev;               // its own copy of the tables: the other calls overwrite `scales`
+    float *sfHost = nullptr, *sfHostDev = nullptr;   // pinned: uright | depth, written by the kernels across PCIe
+    size_t sfHostFloats = 0;
     // staging for the host-array convenience calls
     OrbxDevBuf<orbx_keypoint> hk[2];
     OrbxDevBuf<uint8_t> hd[2], hv[2];

@@ -109,9 +109,7 @@ void Frame::ComputeStereoMatches()
             throw std::runtime_error(std::string("Frame::ComputeStereoMatches (orbx): ") + orbx_last_error());
         tStereo.cap = need;
     }
-    const int32_t zero = 0;
-    if (orbx_compute_stereo_matches_device(tStereo.h, hl, hr, &zero, &zero, 1, mbf, mb) != ORBX_OK ||
-        orbx_stereo_download(tStereo.h, 1, &mvuRight[0], &mvDepth[0], N) != ORBX_OK)
+    if (orbx_stereo_frame(tStereo.h, hl, hr, mbf, mb, &mvuRight[0], &mvDepth[0], N) != ORBX_OK)
         throw std::runtime_error(std::string("Frame::ComputeStereoMatches (orbx): ") + orbx_last_error());
 }
 

@@ -51,8 +51,8 @@ public:
     void DownloadImagePyramid();
 
     // One-shot hint for the next operator() call: `other`'s call is about to arrive on another thread (the stereo Frame constructor runs the
-    // left and the right extractor on two threads, src/Frame.cc:159-167); liborbx then runs both frames as one launch set.  Set by the HIP
-    // body of Frame::ExtractORB (shim/Frame_hip.cc); harmless when the partner never comes (the call leaves after 0.3 ms).
+    // left and the right extractor on two threads, src/Frame.cc:159-167); with ORBX_COMBINE_PARTNER_US set, liborbx runs both frames as one
+    // launch set (off by default: include/orbx.h says why).  Set by the HIP body of Frame::ExtractORB (shim/Frame_hip.cc).
     void ExpectPartner(ORBextractor *other);
 
     // Error channel (the reference has none: include/ORBextractor.h:92-161).  A failed call leaves `keypoints` EMPTY and `descriptors`

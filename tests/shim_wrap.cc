@@ -98,6 +98,7 @@ extern "C" double shim_bench_threads(int nthreads, int nf, const unsigned char *
         }
     };
     { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, 10); for (auto &x : th) x.join(); }   // warm-up
+    orbx_combiner_reset_stats(ex[0]->Handle());
     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, iters); for (auto &x : th) x.join(); }
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -110,6 +111,12 @@ extern "C" double shim_bench_threads(int nthreads, int nf, const unsigned char *
         fprintf(stderr, "[shim_bench_threads] %d threads: %lld frames in %lld launch sets (mean %.2f), %d engine(s); since the engines exist: staging %.1f us/frame, "
                 "leader wait %.1f, launch call %.1f, device + sync %.1f us/set; wall %.1f us/frame\n", nthreads, nfr, nb, nb ? (double)nfr / nb : 0.0, ne,
                 nfr ? us[0] / nfr : 0.0, nb ? us[1] / nb : 0.0, nb ? us[2] / nb : 0.0, nb ? us[3] / nb : 0.0, 1e6 * s / ((double)nthreads * iters));
+        int64_t sets[33];
+        double mus[33];
+        orbx_combiner_histogram(ex[0]->Handle(), 32, sets, mus);
+        fprintf(stderr, "    sets by size (n: count @ mean us):");
+        for (int n = 1; n <= 32; n++) if (sets[n]) fprintf(stderr, " %d: %lld @ %.0f;", n, (long long)sets[n], mus[n]);
+        fprintf(stderr, "\n");
     }
     for (size_t t = 0; t < ex.size(); t++) delete ex[t];
     return (double)nthreads * iters / s;

@@ -254,11 +254,13 @@ def test_single_frame_calls_from_sixteen_threads_are_combined(orbx):
     assert f0 > b0, "eight threads on one geometry never met in a launch set: %d frames in %d sets" % (f0, b0)
 
 
-def test_a_partner_hint_makes_one_launch_set_of_two(orbx):
+def test_a_partner_hint_makes_one_launch_set_of_two(orbx, monkeypatch):
     """The stereo Frame constructor's two extractor threads (src/Frame.cc:159-167): each call announces the other
-    (orbx_extractor_expect_partner, set by the HIP body of Frame::ExtractORB), and the pair runs as ONE set of two frames - bit-identical to
-    two separate calls.  Python threads leave a barrier with some jitter; the hint waits 0.3 ms at most, so most (not all) trials must merge."""
+    (orbx_extractor_expect_partner, set by the HIP body of Frame::ExtractORB); with ORBX_COMBINE_PARTNER_US set, the pair runs as ONE set of two
+    frames - bit-identical to two separate calls.  (The wait is OFF by default: at the reference's thread-start skew it costs more than the
+    second launch set it saves - csrc/orbx_extractor.hip.)  Python threads leave a barrier with some jitter; most (not all) trials must merge."""
     import threading
+    monkeypatch.setenv("ORBX_COMBINE_PARTNER_US", "300")
     W, H, nf = 1241, 376, 2000
     left = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H)
     right = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H)

@@ -198,3 +198,41 @@ def test_compute_stereo_matches_hip_bit_exact(orbx, oracle, W, H, nf, bf, two_ha
     eL.close()
     if two_handles:
         eR.close()
+
+
+@pytest.mark.gpu
+def test_stereo_frame_of_two_single_frame_calls(orbx, oracle):
+    """The stereo Frame constructor's shape (src/Frame.cc:159-168): two one-frame extractors on two threads - their calls announce each other
+    and run as one launch set -, then orbx_stereo_frame (the latency form of ComputeStereoMatches: no events, pinned results).  mvuRight /
+    mvDepth as bit patterns against the restatement, for several frames in a row on the same handles (double-buffered member arenas, the
+    cached scale tables and the pinned result buffer all carry over from frame to frame)."""
+    import threading
+    W, H, nf, bf = 1241, 376, 2000, 386.1448
+    eL = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H)
+    eR = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H)
+    mt = orbx.ORBmatcher(0.7, True, max_features=eL.capacity, max_pairs=1)
+    rst = oracle.restatement(nf)
+    t, _, _ = rst.tables()
+    for seed in (31, 32, 47, 31):
+        left, right = orbx.synth_frame(seed, W, H), orbx.synth_frame(seed, W, H, orbx.SYNTH_STEREO_RIGHT)
+        out = {}
+
+        def run(name, ext, other, im):
+            ext.expect_partner(other)
+            out[name] = ext(im)
+        th = [threading.Thread(target=run, args=("l", eL, eR, left)), threading.Thread(target=run, args=("r", eR, eL, right))]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        (kL, dL), (kR, dR) = out["l"], out["r"]
+        u, z = mt.stereo_frame(eL, eR, bf, 0.0, n=len(kL))
+        pyrL, pyrR = oracle.pyramid(rst, left), oracle.pyramid(rst, right)
+        wu, wz, _ = oracle_lib.compute_stereo_matches(oracle, kL, dL, kR, dR, pyrL, pyrR, t[0], t[1], bf, 0.0)
+        assert (u.view(np.uint32) == wu.view(np.uint32)).all() and (z.view(np.uint32) == wz.view(np.uint32)).all(), seed
+        assert int((wu >= 0).sum()) > 100
+        # the general entry point on the same two handles gives the same answer (and leaves the fast path's cached tables alone)
+        mt.compute_stereo_matches_device(eL, eR, [0], [0], bf, 0.0)
+        u2, z2 = mt.download_stereo(1)
+        assert (u2[0, :len(kL)].view(np.uint32) == u.view(np.uint32)).all() and (z2[0, :len(kL)].view(np.uint32) == z.view(np.uint32)).all()
+    mt.close(); eL.close(); eR.close()
