@@ -12,14 +12,16 @@
 //                 their edges, the Jacobian blocks computed where they are added (no atomics; only Hpl is written per edge, for the Schur
 //                 kernels).  k_linearize / k_sum_points / k_sum_poses: the same as three launches with every block written out
 //                 (ORBX_LBA_SPLIT=1, measurement switch)
-//   k_schur_setup / k_schur_rows        S = Hpp + lambda I - sum_l B D^-1 B^T as its lower block triangle, block row per keyframe in LDS
+//   k_schur_setup / k_schur_rows / k_schur_fin   S = Hpp + lambda I - sum_l B D^-1 B^T as its lower block triangle, block row per keyframe in LDS,
+//                 summed in 64-bit fixed point (order independent: bit-reproducible), its right-hand side in ordered partial sums
 //   k_chol_step (one launch per 32-column panel) / k_chol_backsub_reg   dense Cholesky of S + substitutions (n >= 96; k_chol_solve:
 //                 one workgroup for the small systems, k_chol_backsub above n = 320)
 //   k_backsub_update   x_l = D^-1 (b_l - B^T x_p), push(), oplus: T <- exp(dx) T, X <- X + dx; partial sums of the gain denominator
-//   k_trial_finish     the three sums of a trial + the Cholesky flag into pinned memory, sequence number last (the host polls it)
-//   k_restore, k_classify   pop() of a rejected trial; outlier flags / chi2 / estimates of the result
-// The LM accept/reject logic runs on the host exactly as optimization_algorithm_levenberg.cpp:61-164 (it needs three scalars per
-// trial) and polls the stop flag like g2o's forceStopFlag.  This path is latency bound (~45 MFLOP per iteration): the deliverable
+//   k_lm_begin / k_lm_decide   the Levenberg-Marquardt state machine of optimization_algorithm_levenberg.cpp:61-164 ON THE DEVICE: lambda, rho,
+//                 accept / reject, the iteration's and the stage's termination tests; state mirrored into pinned memory, sequence number
+//                 last (the host polls it once per optimize(n), not once per trial); every launch of a trial that is not needed returns at once
+//   k_restore, k_classify   pop() of a rejected trial (gated by the decision); outlier flags / chi2 / estimates of the result
+// The stop flag (g2o's forceStopFlag) is a pinned word the waiting host keeps current.  This path is latency bound (~45 MFLOP per iteration): the deliverable
 // is parity (<= 1e-5 vs the reference's own Optimizer.cc + g2o, tests/test_optimizer_ref.py, tests/golden/lba) plus every O(E)
 // stage on the device and as few dependent latencies as possible (DESIGN.md section 7 has the measured history).
 #include <math.h>
@@ -253,9 +255,10 @@ __device__ __forceinline__ double block_sum256(double v, double *sw /* 4 */)
     return sw[0] + sw[1] + sw[2] + sw[3];
 }
 
-// partChi[blockIdx.x] = this workgroup's share of activeRobustChi2 (summed in block order by k_trial_finish)
-__global__ __launch_bounds__(256) void k_errors(LbaDev d, Huber h, int robust, double *partChi)
+// partChi[blockIdx.x] = this workgroup's share of activeRobustChi2 (summed in block order by k_lm_begin / k_lm_decide)
+__global__ __launch_bounds__(256) void k_errors(LbaDev d, Huber h, int robust, double *partChi, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     __shared__ double sw[4];
     const int e = blockIdx.x * 256 + threadIdx.x;
     double r0 = 0;
@@ -325,8 +328,9 @@ __device__ __forceinline__ void edge_linearize(const LbaDev &d, const Huber &h, 
 
 // linearizeOplus + constructQuadraticForm with every block of every edge written out (the launch-per-stage form; k_lin_sums below computes the
 // same blocks inside the sums that consume them)
-__global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust)
+__global__ __launch_bounds__(256) void k_linearize(LbaDev d, Huber h, int robust, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= d.E || !d.active[e]) return;
     const int k = d.ek[e], l = d.ep[e];
@@ -369,8 +373,9 @@ __device__ __forceinline__ double sum16(double x)
 
 // 16 lanes per landmark (a landmark has ~12 observations: one thread walking them serially leaves the launch at 20 waves and a
 // dozen dependent loads deep), partial sums combined by a butterfly inside the group
-__global__ __launch_bounds__(256) void k_sum_points(LbaDev d, const int *ptStart, const int *ptEdges, double *Hll, double *bl)
+__global__ __launch_bounds__(256) void k_sum_points(LbaDev d, const int *ptStart, const int *ptEdges, double *Hll, double *bl, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     const int l = blockIdx.x * 16 + (threadIdx.x >> 4), a = threadIdx.x & 15;
     if (l >= d.P) return;
     const int li = d.ptIdx[l];
@@ -401,8 +406,9 @@ __global__ __launch_bounds__(256) void k_sum_points(LbaDev d, const int *ptStart
 #define SP_SPLIT 8        /* most workgroups per keyframe (size of the partial-sum array); the number used per call (spSplit) gives every thread of a
                              workgroup at most ONE edge of the longest keyframe row: a second step for a few threads costs the whole dependent chain again */
 #define SP_TP 264
-__global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart, const int *kfEdges, double *part /* K x SP_SPLIT x 27 */, int spSplit)
+__global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart, const int *kfEdges, double *part /* K x SP_SPLIT x 27 */, int spSplit, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     __shared__ double redT[27 * SP_TP];
     __shared__ double part8[27][9];
     const int k = blockIdx.x, y = blockIdx.y, pi = d.poseIdx[k], tid = threadIdx.x;
@@ -447,8 +453,9 @@ __global__ __launch_bounds__(256) void k_sum_poses(LbaDev d, const int *kfStart,
 //   blocks [0, K * SP_SPLIT)     the keyframe sums (k_sum_poses' body; first: they are the longer ones)
 //   the rest                     the landmark sums (k_sum_points' body), 16 lanes per landmark
 __global__ __launch_bounds__(256) void k_lin_sums(LbaDev d, Huber h, int robust, const int *ptStart, const int *ptEdges, double *Hll, double *bl, const int *kfStart,
-                                                  const int *kfEdges, double *part /* K x SP_SPLIT x 27 */, int spSplit)
+                                                  const int *kfEdges, double *part /* K x SP_SPLIT x 27 */, int spSplit, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     __shared__ double redT[27 * SP_TP];
     __shared__ double part8[27][9];
     const int tid = threadIdx.x;
@@ -530,8 +537,9 @@ __global__ __launch_bounds__(256) void k_lin_sums(LbaDev d, Huber h, int robust,
 #undef LIN_DOT
 // ... and the SP_SPLIT partial results added in order by a second small launch (a "last workgroup adds" inside the first one needs a
 // device-scope release, i.e. a write-back of the L2 - right after k_linearize has left 34 MB of dirty lines there: 28 us instead of 16)
-__global__ __launch_bounds__(256) void k_sum_poses_fin(LbaDev d, const double *__restrict__ part, double *__restrict__ Hpp, double *__restrict__ bp, int spSplit)
+__global__ __launch_bounds__(256) void k_sum_poses_fin(LbaDev d, const double *__restrict__ part, double *__restrict__ Hpp, double *__restrict__ bp, int spSplit, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     const int idx = blockIdx.x * 256 + threadIdx.x, k = idx >> 5, v = idx & 31;
     if (k >= d.K || v >= 27) return;
     const int pi = d.poseIdx[k];
@@ -547,23 +555,121 @@ __global__ __launch_bounds__(256) void k_sum_poses_fin(LbaDev d, const double *_
     Hpp[(size_t)pi * 36 + 6 * j + i] = t;
 }
 
-// The three sums an LM trial ends with: host[0] = sum rchi (activeRobustChi2), host[4] = sum xp (lambda xp + bp), host[5] = sum xl (lambda
-// xl + bl), host[8] = the Cholesky flag.  k_errors and k_backsub_update leave one partial per workgroup; this single workgroup adds them
-// in block order (deterministic) and writes the results STRAIGHT INTO PINNED HOST MEMORY, the sequence number last (after a system-scope
-// fence): the host polls that word instead of queueing a device-to-host copy and synchronising the stream (a copy kernel, two API calls
-// and ~15 us of idle GPU per trial before).
+// ---------------------------------------------------------------------------------------------
+// Levenberg-Marquardt ON THE DEVICE (g2o: optimization_algorithm_levenberg.cpp:61-164, sparse_optimizer.cpp:350-424).  lambda, the
+// Nielsen factor, the chi2 bookkeeping and the accept / restore decision of every trial live in LmState; the kernels of a trial take
+// lambda from there, k_lm_decide ends a trial (the three sums, rho, accept or reject, the iteration's and the stage's termination tests),
+// k_restore runs only behind a rejected trial, and every launch of a trial the stage turns out not to need returns at once (the `gate`
+// argument of the kernels).  The host therefore enqueues a whole optimize(n) - n trials, one per iteration, which is what a bundle
+// adjustment near its optimum takes - WITHOUT waiting for any of them, then reads the state once; only when a trial was rejected somewhere
+// does it add trials one by one.  (Before: one host round trip per trial, ~10-20 us of idle device each, 9 per window.)
+// The state is mirrored into pinned memory by every decision, the sequence number last; the stop flag (pbStopFlag) is a pinned word that
+// the waiting host keeps equal to the caller's flag.
+// ---------------------------------------------------------------------------------------------
+struct LmState {
+    double lambda, ni, currentChi, iniChi, rho, chi0, tempChi;
+    int it, qmax, nBad, ok, done, lastRejected, relin, trials, iters, maxIters;
+};
+
 __device__ __forceinline__ double wave_sum(double x)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
     return x;
 }
-__global__ __launch_bounds__(256) void k_trial_finish(const double *partChi, int nChi, const double *partL, int nL, const double *xp, const double *bp, int nP6,
-                                                      double lambda, const int *okFlag, const double *diagMax, double *host, double seq, int chiSlot, const double *lamSrc)
+
+__device__ __forceinline__ void lm_mirror(const LmState *st, double *host, double seq, double o1, double o2, double okf)
+{
+    host[0] = st->tempChi; host[1] = st->currentChi; host[2] = st->lambda; host[3] = st->rho; host[4] = o1; host[5] = o2; host[6] = st->chi0;
+    host[7] = (double)st->iters; host[8] = okf; host[9] = (double)st->trials; host[13] = (double)st->done; host[14] = (double)st->it;
+    __threadfence_system();
+    __hip_atomic_store(host + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// start of optimize(maxIters): chi2 of the start (k_errors' partial sums, in block order), computeLambdaInit (:166-180: tau = 1e-5 times
+// the largest diagonal entry, from k_diag_max), counters cleared
+__global__ __launch_bounds__(256) void k_lm_begin(LmState *st, const double *partChi, int nChi, const double *diagMax, int maxIters, const volatile int *stopHost, double *host,
+                                                  double seq, unsigned long long *scaleBits)
+{
+    __shared__ double sw[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 6) scaleBits[tid] = 0ull;      // (the maxima of the Schur scale: raised by the next k_schur_setup)
+    double v0 = 0;
+    for (int i = tid; i < nChi; i += 256) v0 += partChi[i];
+    v0 = wave_sum(v0);
+    if (lane == 0) sw[wave] = v0;
+    __syncthreads();
+    if (tid == 0) {
+        const double chi = sw[0] + sw[1] + sw[2] + sw[3];
+        st->lambda = 1e-5 * diagMax[2]; st->ni = 2; st->currentChi = chi; st->iniChi = chi; st->chi0 = chi; st->tempChi = chi; st->rho = 0;
+        st->it = 0; st->qmax = 0; st->nBad = 0; st->ok = 1; st->lastRejected = 0; st->relin = 0; st->trials = 0; st->iters = 0; st->maxIters = maxIters;
+        st->done = (maxIters <= 0 || (stopHost && *stopHost)) ? 1 : 0;
+        lm_mirror(st, host, seq, 0.0, 0.0, 1.0);
+    }
+}
+
+// The decision of one trial (one thread): rho, accept or reject, the iteration's and the stage's termination tests.  -> 1 = rejected.
+__device__ __forceinline__ int lm_decide_thread0(LmState *st, double tempChi, double o1, double o2, int okf, bool stop, double *host, double seq)
+{
+    const double lambda = st->lambda;
+    if (!okf) tempChi = 1.7976931348623157e308;      // std::numeric_limits<double>::max(): "solver failed" (:110-113)
+    const double scale = o1 + o2 + 1e-3;
+    const double rho = (st->currentChi - tempChi) / scale;
+    st->tempChi = tempChi; st->rho = rho;
+    st->trials += 1;
+    int qmax = st->qmax + 1;
+    if (rho > 0 && isfinite(tempChi)) {      // accept (:120-131)
+        // pow(2 rho - 1, 3) as the host's libm rounds it (correctly rounded in all but knife-edge cases): the cube in double-double
+        const double a3 = 2 * rho - 1;
+        const double p2 = a3 * a3, e2 = __builtin_fma(a3, a3, -p2), p3 = p2 * a3, e3 = __builtin_fma(p2, a3, -p3);
+        double alpha = 1. - (p3 + (e3 + e2 * a3));
+        alpha = fmin(alpha, 2. / 3.);
+        st->lambda = lambda * fmax(1. / 3., alpha);
+        st->ni = 2;
+        st->currentChi = tempChi;
+        st->lastRejected = 0;
+    } else {                                 // reject (:132-141): the estimates come back (below), lambda grows
+        st->lambda = lambda * st->ni;
+        st->ni *= 2;
+        st->lastRejected = 1;
+    }
+    bool done = false;
+    if (!(rho < 0 && qmax < 10 && !stop)) {  // the iteration ends (do-while of :98-146)
+        st->iters += 1;
+        bool ok = true;
+        if (qmax == 10 || rho == 0) ok = false;                      // :148-151 (terminate)
+        else {
+            if ((st->iniChi - st->currentChi) * 1e3 < st->iniChi) st->nBad += 1; else st->nBad = 0;      // the stall test of SparseOptimizer::optimize as this fork runs it
+            if (st->nBad >= 3) ok = false;
+        }
+        st->ok = ok ? 1 : 0;
+        st->it += 1;
+        qmax = 0;
+        st->iniChi = st->currentChi;
+        done = !(st->it < st->maxIters && !stop && ok);
+    }
+    st->qmax = qmax;
+    st->done = done ? 1 : 0;
+    st->relin = (!st->lastRejected && !done) ? 1 : 0;      // H and b at the new estimates: only behind an accepted trial that is not the last
+    lm_mirror(st, host, seq, o1, o2, (double)okf);
+    return st->lastRejected;
+}
+
+// end of a trial: partChi / partL = the per-workgroup shares of activeRobustChi2 and of sum xl (lambda xl + bl) (k_errors, k_backsub_update),
+// added in block order; xp (lambda xp + bp) summed here; okFlag = the factorisation's.
+__global__ __launch_bounds__(256) void k_lm_decide(LmState *st, const double *partChi, int nChi, const double *partL, int nL, const double *xp, const double *bp, int nP6,
+                                                   const int *okFlag, const volatile int *stopHost, double *host, double seq, LbaDev d, const DPose *poseBak, const double *ptBak,
+                                                   unsigned long long *scaleBits)
 {
     __shared__ double sw[3][4];
+    __shared__ int sRejected;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (lamSrc) lambda = 1e-5 * lamSrc[2];      // first trial of a stage: computeLambdaInit's value straight from k_diag_max (the host learns it with this trial's results)
+    if (tid < 6) scaleBits[tid] = 0ull;      // (the maxima of the Schur scale: raised again by the next k_schur_setup)
+    if (st->done) {      // a trial the stage did not need: only the sequence number moves (the host may be waiting for this very launch)
+        if (tid == 0) { __threadfence_system(); __hip_atomic_store(host + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        return;
+    }
+    const double lambda = st->lambda;
     double v0 = 0, v1 = 0, v2 = 0;
     for (int i = tid; i < nChi; i += 256) v0 += partChi[i];
     for (int i = tid; i < nP6; i += 256) v1 += xp[i] * (lambda * xp[i] + bp[i]);
@@ -572,13 +678,18 @@ __global__ __launch_bounds__(256) void k_trial_finish(const double *partChi, int
     if (lane == 0) { sw[0][wave] = v0; sw[1][wave] = v1; sw[2][wave] = v2; }
     __syncthreads();
     if (tid == 0) {
-        host[chiSlot] = sw[0][0] + sw[0][1] + sw[0][2] + sw[0][3];
-        host[4] = sw[1][0] + sw[1][1] + sw[1][2] + sw[1][3];
-        host[5] = sw[2][0] + sw[2][1] + sw[2][2] + sw[2][3];
-        host[8] = okFlag ? (double)*okFlag : 1.0;
-        if (diagMax) host[2] = diagMax[2];
-        __threadfence_system();
-        __hip_atomic_store(host + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const double tempChi = sw[0][0] + sw[0][1] + sw[0][2] + sw[0][3];
+        const double o1 = nP6 > 0 ? sw[1][0] + sw[1][1] + sw[1][2] + sw[1][3] : 0.0, o2 = sw[2][0] + sw[2][1] + sw[2][2] + sw[2][3];
+        const int okf = (nP6 > 0 && okFlag) ? *okFlag : 1;
+        sRejected = lm_decide_thread0(st, tempChi, o1, o2, okf, stopHost && *stopHost, host, seq);
+    }
+    __syncthreads();
+    // pop() of a rejected trial: the estimates saved by k_backsub_update come back, here (a launch of its own was ~4 us per trial, accepted
+    // or not).  H, b and the stored errors are those of the state the trial started from - nothing was linearised since - so the next
+    // trial, with its larger lambda, needs nothing else; _error keeps the values of the rejected trial, as in g2o.
+    if (sRejected) {
+        for (int g = tid; g < d.K; g += 256) d.pose[g] = poseBak[g];
+        for (int g = tid; g < 3 * d.P; g += 256) d.pt[g] = ptBak[g];
     }
 }
 
@@ -782,8 +893,9 @@ __global__ __launch_bounds__(1024) void k_stage_index(int K, int P, const uint8_
 }
 
 // pop() of a rejected trial: the estimates saved by k_backsub_update come back (one launch instead of two copies)
-__global__ __launch_bounds__(256) void k_restore(LbaDev d, const DPose *poseBak, const double *ptBak)
+__global__ __launch_bounds__(256) void k_restore(LbaDev d, const DPose *poseBak, const double *ptBak, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g < d.K) d.pose[g] = poseBak[g];
     if (g < 3 * d.P) d.pt[g] = ptBak[g];
@@ -821,19 +933,6 @@ __global__ __launch_bounds__(256) void k_classify(LbaDev d, uint8_t *flag, doubl
     const double th = d.stereo[e] ? 7.815 : 5.991;
     flag[e] = (chi > th || !(z > 0.0)) ? 1 : 0;
     if (chiOut) chiOut[e] = chi;
-}
-
-__device__ __forceinline__ void schur_init_part(int block, int nblocks, const double *Hpp, const double *bp, int nPose, double lambda, double *S, double *bs)
-{
-    const int n = 6 * nPose;
-    const size_t total = (size_t)n * n;
-    for (size_t idx = (size_t)block * 256 + threadIdx.x; idx < total; idx += (size_t)nblocks * 256) {
-        const int r = (int)(idx / n), c = (int)(idx % n);
-        double v = 0;
-        if (r / 6 == c / 6) { v = Hpp[(size_t)(r / 6) * 36 + 6 * (r % 6) + (c % 6)]; if (r == c) v += lambda; }
-        S[idx] = v;
-    }
-    for (int i = block * 256 + threadIdx.x; i < n; i += nblocks * 256) bs[i] = bp[i];
 }
 
 // per landmark: D^-1, D^-1 b_l and B D^-1 of its edges
@@ -897,39 +996,91 @@ __device__ __forceinline__ void schur_edges_part(int block, const LbaDev &d, con
         for (int c = 0; c < 3; c++) bd[3 * r + c] = B[3 * r] * I[c] + B[3 * r + 1] * I[3 + c] + B[3 * r + 2] * I[6 + c];
 }
 
-__global__ __launch_bounds__(256) void k_schur_setup(LbaDev d, int nInit, const double *Hpp, const double *bp, int nPose, const int *ptStart, const int *ptEdges,
-                                                     const double *Hll, const double *bl, double lambda, double *S, double *bs, double *Dinv, double *Ddb, int *okFlag, const double *lamSrc)
+// Fixed-point scale of the Schur accumulation (k_schur_rows): q[r] = smallest integer with sqrt(max_i Hpp_i[r][r]) <= 2^q[r], r = 0..5.
+// Every term (B_1 D^-1 B_2^T)[r][c] of every observation pair is bounded by sqrt(Hpp_1[r][r] Hpp_2[c][c]) <= 2^(q[r] + q[c]): D^-1 is positive
+// definite (Cauchy-Schwarz), and B D^-1 B^T of one edge is at most that edge's own share of Hpp (the landmark's block contains the edge's).
+// The maxima are kept as the bit patterns of non-negative doubles (integer order = numeric order; a maximum does not depend on the order
+// it is taken in): scaleBits[r], cleared by k_lm_begin / k_lm_decide, raised here by the workgroups that produce Hpp.
+__device__ __forceinline__ int schur_q(unsigned long long bits)
 {
-    if (lamSrc) lambda = 1e-5 * lamSrc[2];      // (see k_trial_finish)
+    const double h = __longlong_as_double((long long)bits);
+    if (!(h > 0) || !(h < 1.7e308)) return 0;
+    const int e = ilogb(h);
+    return (e + 2) >> 1;      // = ceil((e + 1) / 2): 2^(2q) >= 2^(e + 1) > h
+}
+
+// The ordered add of the keyframe partial sums (= k_sum_poses_fin, which the start of a stage still launches on its own for k_diag_max)
+// as the first workgroups of k_schur_setup: Hpp / b_p of every free pose from the SP_SPLIT partial results, and the scale maxima.
+__device__ __forceinline__ void schur_poses_part(int block, const LbaDev &d, const double *__restrict__ part, int spSplit, double *__restrict__ Hpp, double *__restrict__ bp,
+                                                 unsigned long long *scaleBits)
+{
+    const int idx = block * 256 + threadIdx.x, k = idx >> 5, v = idx & 31;
+    if (k >= d.K || v >= 27) return;
+    const int pi = d.poseIdx[k];
+    if (pi < 0) return;
+    double t = 0;
+    for (int q = 0; q < spSplit; q++) t += part[((size_t)k * SP_SPLIT + q) * 27 + v];
+    if (v >= 21) { bp[(size_t)pi * 6 + v - 21] = t; return; }
+    int i = 0, o = v;
+    while (o >= 6 - i) { o -= 6 - i; i++; }
+    const int j = i + o;
+    Hpp[(size_t)pi * 36 + 6 * i + j] = t;
+    Hpp[(size_t)pi * 36 + 6 * j + i] = t;
+    if (i == j) atomicMax(&scaleBits[i], (unsigned long long)__double_as_longlong(fabs(t)));
+}
+
+__global__ __launch_bounds__(256) void k_schur_setup(LbaDev d, int nInit, const double *Hpp, const double *bp, int nPose, const int *ptStart, const int *ptEdges,
+                                                     const double *Hll, const double *bl, double lambda, double *S, double *bs, double *Dinv, double *Ddb, int *okFlag, const double *lamSrc,
+                                                     unsigned long long *scaleBits, const double *spPart, int spSplit, double *HppOut, double *bpOut, const int *gate, int want)
+{
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
+    if (lamSrc) lambda = *lamSrc;      // the stage's lambda lives on the device (LmState, k_lm_decide)
     if (blockIdx.x == 0 && threadIdx.x == 0) *okFlag = 1;      // the factorisation clears it at a failed pivot
     const int nPtB = (d.P + 3) / 4;
-    if ((int)blockIdx.x < nInit) schur_init_part((int)blockIdx.x, nInit, Hpp, bp, nPose, lambda, S, bs);
+    if ((int)blockIdx.x < nInit) schur_poses_part((int)blockIdx.x, d, spPart, spSplit, HppOut, bpOut, scaleBits);      // (S and bs themselves are produced by k_schur_fin)
     else if ((int)blockIdx.x < nInit + nPtB) schur_points_part((int)blockIdx.x - nInit, d, ptStart, ptEdges, Hll, bl, lambda, Dinv, Ddb);
     else schur_edges_part((int)blockIdx.x - nInit - nPtB, d, Hll, lambda);
 }
 
 // S[i1, i2] -= (B_1 D^-1) B_2^T for every pair of free-pose observations of a landmark, i2 <= i1 (the LOWER block
 // triangle, which is what the Cholesky kernels read: no mirroring pass).  Block row i1 of S belongs to keyframe i1: gridDim.y workgroups per keyframe
-// walk its edges (16 lanes per edge, one lane per second observation), accumulate the row in LDS with
-// ds_add_f64 and add it to S once - 6 x n global atomics per workgroup instead of 36 per observation pair.
+// walk its edges (16 lanes per edge, one lane per second observation) and accumulate the row in LDS, then add it to the global accumulator once.
+// BIT-REPRODUCIBLE: the sums are taken in 64-bit FIXED POINT - integer addition is associative, so neither the order in which the waves of
+// a workgroup reach an LDS cell nor the order in which the workgroups reach a global one can change a bit (the former ds_add_f64 / FP64
+// global atomics made S, the step and - with rho near 0 - the trial count vary from run to run).  A term t of block entry [r][c] is rounded
+// to a multiple of 2^(q[r] + q[c] - 49) (k_schur_setup: |t| <= 2^(q[r] + q[c])) by ONE addition, MAGIC - t with MAGIC = 1.5 * 2^52, whose
+// mantissa then holds the integer; up to 2^12 terms per cell fit the 64-bit sum.  Resolution: 2^-49 of the bound, i.e. double precision
+// relative to sqrt(Hpp[r][r] Hpp[c][c]) of the best-observed keyframe.  k_schur_fin turns the sums into S = Hpp + lambda I - (...) .
+// The right-hand side bs[i1] -= B (D^-1 b_l) has no such bound at hand: every lane sums its own edges in their fixed order, the 16 lane
+// groups of a workgroup are added in order, and k_schur_fin adds the workgroups' partial results in order.
 // GLOBAL = true: the block row does not fit into LDS (more than ~530 free keyframes, i.e. a global bundle adjustment of a large map):
-// the same walk with the FP64 atomics going straight to S / bs.
+// the same walk with the integer atomics going straight to the global accumulator.
+#define SCHUR_MAGIC 6755399441055744.0          /* 1.5 * 2^52 */
+#define SCHUR_MAGIC_BITS 0x4338000000000000ll
 template <bool GLOBAL>
 __global__ __launch_bounds__(256, 6) void k_schur_rows(LbaDev d, const int *kfStart, const int *kfEdges, const int *__restrict__ kfRowS0, const int *__restrict__ kfRowN,
-                                                    const int *ptEdges, const int *__restrict__ ptPi, int nP6, const double *__restrict__ Ddb, double *S, double *bs)
+                                                    const int *ptEdges, const int *__restrict__ ptPi, int nP6, const double *__restrict__ Ddb, unsigned long long *Sacc,
+                                                    double *bsPart, const unsigned long long *__restrict__ scaleBits, const int *gate, int want)
 {
-    extern __shared__ __attribute__((aligned(16))) double rowLds[];   // [6][nP6], then 6 entries of bs
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
+    extern __shared__ __attribute__((aligned(16))) unsigned long long rowLds[];   // [6][nP6] fixed-point sums
+    __shared__ double bsRed[16][6];
     const int k = blockIdx.x, pi = d.poseIdx[k], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (pi < 0) return;
-    double *row = GLOBAL ? S + (size_t)(6 * pi) * nP6 : rowLds;      // GLOBAL: "row" is the block row of S itself
-    double *rowB = GLOBAL ? bs + 6 * pi : rowLds + 6 * nP6;
+    unsigned long long *row = GLOBAL ? Sacc + (size_t)(6 * pi) * nP6 : rowLds;      // GLOBAL: "row" is the block row of the accumulator itself
     if (!GLOBAL) {
-        for (int i = tid; i < 6 * nP6 + 6; i += 256) rowLds[i] = 0.0;
+        for (int i = tid; i < 6 * nP6; i += 256) rowLds[i] = 0ull;
         __syncthreads();
     }
+    // 2^(24 - q[r]) for the rows of B_1 D^-1 and 2^(25 - q[c]) for the rows of B_2: the products come out in units of 2^(q[r] + q[c] - 49)
+    // (applied with v_ldexp_f64 from six scalar exponents: twelve scale factors in vector registers made the kernel spill at its 80)
+    int qa[6], qb[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { const int q = __builtin_amdgcn_readfirstlane(schur_q(scaleBits[i])); qa[i] = 24 - q; qb[i] = 25 - q; }
     // a wave works on four edges of the keyframe at once: 16 lanes per edge, one lane per second observation of the
     // landmark (the index lookups are done once per pair, the 6x6 block comes out of 36 registers)
     const int sub = lane >> 4, a = lane & 15, stride = 16 * gridDim.y;
+    double accB = 0.0;      // lane a < 6: row a of this lane group's share of bs[i1]
     for (int s = kfStart[k] + (blockIdx.y * 4 + wv) * 4 + sub; s < kfStart[k + 1]; s += stride) {
         // three dependent round trips instead of eight: slot -> (edge | landmark row) -> (partner edge, its free-pose index) -> its block
         const int e = kfEdges[s], s0 = kfRowS0[s], nE = kfRowN[s];
@@ -939,10 +1090,10 @@ __global__ __launch_bounds__(256, 6) void k_schur_rows(LbaDev d, const int *kfSt
         const double *pBD = eb_bd(d, e);
         double BD[18];
 #pragma unroll
-        for (int i = 0; i < 18; i++) BD[i] = pBD[i];
-        if (a < 6) {   // bs[i1] -= B * (D^-1 b_l): 300 addresses for all edges of the window, so it goes through the LDS row as well
+        for (int i = 0; i < 18; i++) BD[i] = ldexp(pBD[i], qa[i / 3]);      // (a power of two: exact)
+        if (a < 6) {   // bs[i1] -= B * (D^-1 b_l)
             const double *B1 = eb_hpl(d, e) + 3 * a, *db = Ddb + (size_t)d.ep[e] * 3;
-            unsafeAtomicAdd(&rowB[a], -(B1[0] * db[0] + B1[1] * db[1] + B1[2] * db[2]));
+            accB -= B1[0] * db[0] + B1[1] * db[1] + B1[2] * db[2];
         }
         for (int a2 = a; a2 < nE; a2 += 16) {
             const int e2 = a2 == a ? e2v[0] : ptEdges[s0 + a2];
@@ -952,23 +1103,72 @@ __global__ __launch_bounds__(256, 6) void k_schur_rows(LbaDev d, const int *kfSt
             // registers, four waves per SIMD, and its 1600 workgroups run in two rounds of ~14 us (s_memrealtime: the workgroups of the last y-splits start
             // when the first ones end); the loop itself is three dependent memory round trips per step, i.e. it wants residency, not registers
             const double *pB2 = eb_hpl(d, e2);
-            double *dst = row + 6 * i2;
+            unsigned long long *dst = row + 6 * i2;
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-                const double b0 = pB2[3 * c], b1 = pB2[3 * c + 1], b2 = pB2[3 * c + 2];
+                const double b0 = ldexp(pB2[3 * c], qb[c]), b1 = ldexp(pB2[3 * c + 1], qb[c]), b2 = ldexp(pB2[3 * c + 2], qb[c]);
 #pragma unroll
-                for (int r = 0; r < 6; r++) unsafeAtomicAdd(&dst[(size_t)r * nP6 + c], -(BD[3 * r] * b0 + BD[3 * r + 1] * b1 + BD[3 * r + 2] * b2));   // ds_add_f64
+                for (int r = 0; r < 6; r++) {
+                    const double t = SCHUR_MAGIC - (BD[3 * r] * b0 + BD[3 * r + 1] * b1 + BD[3 * r + 2] * b2);      // the rounding to the fixed-point grid
+                    atomicAdd(&dst[(size_t)r * nP6 + c], (unsigned long long)(__double_as_longlong(t) - SCHUR_MAGIC_BITS));   // ds_add_u64
+                }
             }
         }
     }
-    if (GLOBAL) return;
+    // the lane groups' shares of bs[i1], added in group order
+    if (a < 6) bsRed[wv * 4 + sub][a] = accB;
     __syncthreads();
+    if (tid < 6) {
+        double t = 0.0;
+#pragma unroll
+        for (int gq = 0; gq < 16; gq++) t += bsRed[gq][tid];
+        bsPart[((size_t)k * gridDim.y + blockIdx.y) * 6 + tid] = t;
+    }
+    if (GLOBAL) return;
     for (int i = tid; i < 6 * nP6; i += 256) {
         const int r = i / nP6, col = i - r * nP6;
-        const double v = row[i];
-        if (col < 6 * pi + 6 && v != 0.0) unsafeAtomicAdd(&S[(size_t)(6 * pi + r) * nP6 + col], v);
+        const unsigned long long v = rowLds[i];
+        if (col < 6 * pi + 6 && v != 0ull) atomicAdd(&Sacc[(size_t)(6 * pi + r) * nP6 + col], v);
     }
-    if (tid < 6 && row[6 * nP6 + tid] != 0.0) unsafeAtomicAdd(&bs[6 * pi + tid], row[6 * nP6 + tid]);
+}
+
+// S = blockdiag(Hpp) + lambda I - (fixed-point sums, converted and cleared for the next trial); bs = bp + the workgroups' partial sums in order
+// ("_Hpp->add(_Hschur)", block_solver.hpp:363-365, 564-589).  One launch behind k_schur_rows.
+__global__ __launch_bounds__(256) void k_schur_fin(LbaDev d, const double *Hpp, const double *bp, int nPose, double lambda, const double *lamSrc, unsigned long long *Sacc,
+                                                   const double *bsPart, int ySplit, const unsigned long long *__restrict__ scaleBits, double *S, double *bs, const int *gate, int want)
+{
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
+    if (lamSrc) lambda = *lamSrc;
+    const int n = 6 * nPose;
+    // blockIdx.y = block row (6 rows of S), blockIdx.x * 256 + thread = column: no divisions, coalesced rows
+    const int c = blockIdx.x * 256 + threadIdx.x, br = blockIdx.y;
+    if (br < nPose && c < n) {
+        const int cm = c % 6, qc = schur_q(scaleBits[cm]);
+        const bool diagBlock = c / 6 == br;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) {
+            const size_t idx = (size_t)(6 * br + rr) * n + c;
+            double v = 0;
+            if (diagBlock) { v = Hpp[(size_t)br * 36 + 6 * rr + cm]; if (rr == cm) v += lambda; }
+            const long long acc = (long long)Sacc[idx];
+            if (acc != 0) { v += ldexp((double)acc, schur_q(scaleBits[rr]) + qc - 49); Sacc[idx] = 0ull; }
+            S[idx] = v;
+        }
+    }
+    if (blockIdx.y == gridDim.y - 1 && blockIdx.x == 0)      // (one extra block row: the right-hand side)
+        for (int i = threadIdx.x; i < 6 * d.K; i += 256) {
+            const int k = i / 6, r = i - 6 * k, pi = d.poseIdx[k];
+            if (pi < 0) continue;
+            // all partial sums requested at once (clamped addresses, unconditional loads), then added in order: a load per step of the
+            // dependent chain was 30 L2 round trips = 18 us for this one workgroup
+            double pv[32];
+#pragma unroll
+            for (int y = 0; y < 32; y++) pv[y] = bsPart[((size_t)k * ySplit + min(y, ySplit - 1)) * 6 + r];
+            double t = bp[6 * pi + r];
+#pragma unroll
+            for (int y = 0; y < 32; y++) t += y < ySplit ? pv[y] : 0.0;
+            bs[6 * pi + r] = t;
+        }
 }
 
 #define CHOL_MAX_N 128          /* k_chol_solve serves n < CHOL_MULTI_MIN_N only */
@@ -982,8 +1182,9 @@ __global__ __launch_bounds__(256, 6) void k_schur_rows(LbaDev d, const int *kfSt
 // column instead of three global round trips), is written back once, and updates the trailing matrix
 // in one parallel sweep; the substitutions reuse the same panels.  n <= CHOL_MAX_N, NB*n*8 bytes of LDS.
 template <int NB>
-__global__ __launch_bounds__(1024) void k_chol_solve(double *S, const double *bs, int n, double *x, int *okFlag)
+__global__ __launch_bounds__(1024) void k_chol_solve(double *S, const double *bs, int n, double *x, int *okFlag, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     extern __shared__ __attribute__((aligned(16))) double panel[];   // [rows][NB], rows = n - p0
     __shared__ double sx[CHOL_MAX_N];
     __shared__ int sFail;
@@ -1194,8 +1395,9 @@ __device__ __forceinline__ double pivot_rsqrt(double x)
 // The two kinds touch disjoint parts of S and only read L[:, p-1], so they need no order between them: the trailing update no
 // longer sits between two panels (15 dependent launches per factorisation become 8) and runs while the panel's serial chain does.
 __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, double *__restrict__ L, int n, int p0, int nPW, int T1, double *ywork, double *ysol, int *okFlag,
-                                                   double *__restrict__ diagInv /* 1 / L[i][i], for the substitution kernel */)
+                                                   double *__restrict__ diagInv /* 1 / L[i][i], for the substitution kernel */, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     __shared__ double Ld[CNB][CNB + 1];      // diagonal block in, L11 (lower incl. diagonal) out      | update role: la
     __shared__ double Tt[64][CNB + 1];       // 63 rows of the panel below + the right-hand side (row 63) | update role: lb (first 32 rows)
     __shared__ __attribute__((aligned(16))) double LpD[CNB][CNB + 2];     // previous panel, rows of this diagonal block; afterwards the column exchange buffer of the block factorisation
@@ -1450,8 +1652,9 @@ template <bool XG> struct XVec {
     __device__ void set(int i, double v) const { if (XG) __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else p[i] = v; }
 };
 template <bool XG>
-__global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict__ L, const double *__restrict__ ysol, int n, double *x)
+__global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict__ L, const double *__restrict__ ysol, int n, double *x, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     __shared__ double sxLds[XG ? 1 : CHOL_LDS_X];
     __shared__ double part[32][CNB + 1];
     __shared__ double l11[CNB][CNB + 1];
@@ -1511,8 +1714,9 @@ __global__ __launch_bounds__(1024) void k_chol_backsub(const double *__restrict_
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int NP>
-__global__ __launch_bounds__(1024) void k_chol_backsub_reg(const double *__restrict__ L, const double *__restrict__ ysol, const double *__restrict__ diagInv, int n, double *x)
+__global__ __launch_bounds__(1024) void k_chol_backsub_reg(const double *__restrict__ L, const double *__restrict__ ysol, const double *__restrict__ diagInv, int n, double *x, const int *gate, int want)
 {
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     // columns; row groups of the 1024 threads (3 above 256 columns, else 4); rows per thread and panel (3 x 11, 4 x 8 >= 32).  With four groups a
     // thread keeps 8 instead of 11 prefetched values per panel in flight: no register spill - and a spill reload inside the panel loop is followed by
     // s_waitcnt vmcnt(0), which also waits for every prefetched row block (1.8 us per panel instead of the substitution's own ~1)
@@ -1581,9 +1785,10 @@ __global__ __launch_bounds__(1024) void k_chol_backsub_reg(const double *__restr
 // x_l, push() and update(x) in one launch: thread t computes the increment of landmark t (k_backsub), saves the estimates of
 // keyframe t / landmark t (SparseOptimizer::push, sparse_optimizer.cpp:502-506: every vertex) and applies the increments (oplus).
 __global__ __launch_bounds__(256) void k_backsub_update(LbaDev d, const int *ptStart, const int *ptEdges, const int *__restrict__ ptPi, const double *bl, const double *Dinv,
-                                                        const double *xp, double *xl, DPose *poseBak, double *ptBak, double lambda, double *partL, const double *lamSrc)
+                                                        const double *xp, double *xl, DPose *poseBak, double *ptBak, double lambda, double *partL, const double *lamSrc, const int *gate, int want)
 {
-    if (lamSrc) lambda = 1e-5 * lamSrc[2];      // (see k_trial_finish)
+    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
+    if (lamSrc) lambda = *lamSrc;      // the stage's lambda lives on the device (LmState, k_lm_decide)
     __shared__ double sw[4];
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g < d.K) {                                   // keyframe g
@@ -2005,8 +2210,13 @@ struct orbx_lba {
     OrbxDevBuf<double> spPart;           // k_sum_poses: SP_SPLIT partial results per keyframe
     OrbxDevBuf<int> csrCnt, ptTmp, fillP, pActF, lActF, kfRowS0, kfRowN, ptPi;   // adjacency-list builder and stage preparation (device side)
     OrbxDevBuf<double> partChi, partL;   // per-workgroup partial sums of k_errors / k_backsub_update
+    OrbxDevBuf<unsigned long long> Sacc; // fixed-point sums of the Schur complement (k_schur_rows -> k_schur_fin), all zero between trials
+    OrbxDevBuf<double> bsPart;           // K x 32 x 6: the workgroups' shares of the reduced right-hand side
+    OrbxDevBuf<unsigned long long> scaleBits;   // max |Hpp[r][r]| over the free poses as bit patterns, r = 0..5: the fixed-point scale (k_schur_setup)
+    OrbxDevBuf<LmState> lm;              // Levenberg-Marquardt state of the running stage (device side)
+    int *hostStop = nullptr, *hostStopDev = nullptr;   // pinned: the caller's stop flag as the device sees it (the waiting host keeps it current)
     double *hostRedDev = nullptr;        // device view of hostRed
-    double seq = 0;                      // sequence number of the last k_trial_finish
+    double seq = 0;                      // last sequence number handed out (k_stage_index, k_lm_begin, k_lm_decide)
     double *hostRed = nullptr;   // pinned: {chi, -, diag max, -, scale_p, scale_l, okFlag (as int)} of a trial, read back with ONE synchronisation
 };
 
@@ -2028,6 +2238,9 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     if (hipHostMalloc((void **)&h->hostRed, 16 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&h->hostRedDev, h->hostRed, 0) != hipSuccess) { orbx_lba_destroy(h); orbx_set_error("hipHostMalloc (mapped) failed"); return ORBX_ERR_HIP; }
     for (int i = 0; i < 16; i++) h->hostRed[i] = 0;
+    if (hipHostMalloc((void **)&h->hostStop, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&h->hostStopDev, h->hostStop, 0) != hipSuccess) { orbx_lba_destroy(h); orbx_set_error("hipHostMalloc (mapped) failed"); return ORBX_ERR_HIP; }
+    h->hostStop[0] = 0;
     const size_t K = (size_t)max_keyframes, P = (size_t)max_points, E = (size_t)max_edges, n6 = 6 * K;
     int rc = 0;
     rc = rc ? rc : h->pose.ensure(K); rc = rc ? rc : h->poseBak.ensure(K); rc = rc ? rc : h->pt.ensure(3 * P); rc = rc ? rc : h->ptBak.ensure(3 * P);
@@ -2041,6 +2254,8 @@ extern "C" int orbx_lba_create(int device, int max_keyframes, int max_points, in
     rc = rc ? rc : h->spPart.ensure(K * SP_SPLIT * 27);
     rc = rc ? rc : h->kfRowS0.ensure(E); rc = rc ? rc : h->kfRowN.ensure(E); rc = rc ? rc : h->ptPi.ensure(E);
     rc = rc ? rc : h->fixedDev.ensure(K); rc = rc ? rc : h->ptTmp.ensure(E); rc = rc ? rc : h->fillP.ensure(P); rc = rc ? rc : h->pActF.ensure(K); rc = rc ? rc : h->lActF.ensure(P);
+    rc = rc ? rc : h->lm.ensure(1);
+    rc = rc ? rc : h->bsPart.ensure(K * 32 * 6); rc = rc ? rc : h->scaleBits.ensure(8);
     rc = rc ? rc : h->partChi.ensure((E + 255) / 256); rc = rc ? rc : h->partL.ensure((std::max(K, 16 * P) + 255) / 256);
     if (rc) { orbx_lba_destroy(h); return rc; }
     *out = h;
@@ -2060,8 +2275,11 @@ extern "C" void orbx_lba_destroy(orbx_lba *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->hostRed) (void)hipHostFree(h->hostRed);
+    if (h->hostStop) (void)hipHostFree(h->hostStop);
+    h->lm.release();
     if (h->hostIO) (void)hipHostFree(h->hostIO);
     h->flagDev.release(); h->partChi.release(); h->partL.release(); h->inArena.release(); h->fixedDev.release(); h->csrCnt.release(); h->ptTmp.release(); h->fillP.release(); h->pActF.release(); h->lActF.release(); h->kfRowS0.release(); h->kfRowN.release(); h->ptPi.release(); h->spPart.release();
+    h->Sacc.release(); h->bsPart.release(); h->scaleBits.release();
     delete h;
 }
 
@@ -2085,17 +2303,19 @@ struct Ctx {
     int spSplit = 4;                       // workgroups per keyframe in k_lin_sums: ceil(longest keyframe row / 256), 1 .. SP_SPLIT
 };
 
-// Waits for the sequence number k_trial_finish stores into pinned memory after its results.  The word is polled; the stream is queried
-// now and then so that a failed launch surfaces as an error instead of a hang.
-int wait_seq(orbx_lba *h, double seq)
+// Waits until the sequence number in pinned memory has reached `seq` (k_stage_index, k_lm_begin and k_lm_decide store theirs after their
+// results; the numbers only grow).  The word is polled; meanwhile the caller's stop flag is copied into the pinned word the device reads,
+// and the stream is queried now and then so that a failed launch surfaces as an error instead of a hang.
+int wait_seq(orbx_lba *h, double seq, const volatile uint8_t *stop = nullptr)
 {
     volatile double *flag = h->hostRed + 15;
     for (unsigned spins = 1;; spins++) {
-        if (*flag == seq) break;
+        if (*flag >= seq) break;
+        if (stop && *stop && !h->hostStop[0]) { h->hostStop[0] = 1; std::atomic_thread_fence(std::memory_order_release); }
         if ((spins & 0x3fff) == 0) {
             const hipError_t q = hipStreamQuery(h->stream);
             if (q == hipSuccess) {
-                if (*flag == seq) break;
+                if (*flag >= seq) break;
                 orbx_set_error("LBA: the stream drained without the trial results");
                 return ORBX_ERR_HIP;
             }
@@ -2129,7 +2349,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
         LCHECK();
         if (!c.stageFlags) { nPose = c.nPose0; nPt = c.nPt0; nAct = E; }      // nothing to wait for
         else {
-            int rcw = wait_seq(h, seq);
+            int rcw = wait_seq(h, seq, c.stop);
             if (rcw) return rcw;
             nPose = (int)h->hostRed[10]; nPt = (int)h->hostRed[11]; nAct = (int)h->hostRed[12];
         }
@@ -2141,203 +2361,162 @@ int optimize(Ctx &c, int iterations, double stats[4])
         const size_t nn = (size_t)(6 * nPose) * (size_t)(6 * nPose);
         int rc = h->S.ensure(nn ? nn : 1);
         rc = rc ? rc : h->Lmat.ensure(nn ? nn : 1);
+        rc = rc ? rc : h->Sacc.ensure(nn ? nn : 1);
         if (rc) return rc;
+        // the fixed-point accumulator is all zero between trials (k_schur_fin clears what it reads); cleared here as well, so that a call
+        // that was aborted between the two kernels leaves nothing behind
+        ORBX_HIP_CHECK(hipMemsetAsync(h->Sacc.p, 0, (nn ? nn : 1) * sizeof(unsigned long long), h->stream));
     }
+    if (iterations <= 0 || (c.stop && *c.stop)) return ORBX_OK;      // (the loop of sparse_optimizer.cpp:370 does not run)
     const int nP6 = 6 * nPose;
     const unsigned gE = (unsigned)((E + 255) / 256);
-    double lambda = 0, ni = 2;
-    int nBad = 0;
-    bool ok = true;
-    // Host synchronisations are what this loop costs (every one is ~10-20 us of idle GPU): the chi2 of an iteration start is taken over
-    // from the accepted trial that produced the state (the same kernel on the same inputs gives the same bits), the initial lambda
-    // comes from ONE reduction, and a trial reads its three sums and the Cholesky flag back together, once.
-    bool errorsFresh = false;      // d.err / rchi hold the errors of the CURRENT state and freshChi their robust sum
-    double freshChi = 0;
-    // The linearisation of the NEXT iteration is queued behind a trial before its result is known (almost every trial of a bundle
-    // adjustment is accepted, and the host round trip - results in pinned memory, decision, launch - would otherwise leave the device
-    // idle for ~15 us per iteration).  It overwrites H and b of the state the trial started from; after a rejected trial that is
-    // retried they are rebuilt from the restored estimates (same kernels, same inputs, same bits).
-    // What IS reproducible to the bit: chi2, H and b (ordered partial sums).  What is NOT: the Schur complement S and its right-hand side
-    // are accumulated with FP64 atomics (ds_add_f64 in LDS, global atomics above ~530 keyframes) in an order that varies from run to run, so
-    // the step x differs in its last bits between runs; an accept / reject decision with rho within that noise of 0, and with it the trial
-    // count, can differ from run to run (never observed on the goldens; the contract is 1e-5 against g2o, tests/test_golden_lba.py).
-    bool linearized = false, rebuild = false;
-    auto linearize = [&]() -> int {
+    LmState *st = h->lm.p;
+    const double *lam = &st->lambda;
+    const int *gDone = &st->done, *gLin = &st->relin;
+    // What is reproducible to the bit: everything.  chi2, H and b are ordered partial sums, the Schur complement is accumulated in fixed point
+    // (k_schur_rows), its right-hand side in ordered partial sums, the decisions are taken by one thread (k_lm_decide).
+    auto linearize = [&]() -> int {      // H and b at the new estimates, for the next trial: only behind an accepted trial, and not when the stage is over
         if (!h->linSplit) {      // Jacobians inside the sums that consume them: one launch + the ordered add of the keyframe partials
             hipLaunchKernelGGL(k_lin_sums, dim3((unsigned)(K * c.spSplit + (P + 15) / 16)), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->ptStart.p, h->ptEdges.p, h->Hll.p,
-                               h->bl.p, h->kfStart.p, h->kfEdges.p, h->spPart.p, c.spSplit);
-            hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p, c.spSplit);
-            LCHECK();
-            h->flops += 400.0 * nAct;
+                               h->bl.p, h->kfStart.p, h->kfEdges.p, h->spPart.p, c.spSplit, gLin, 1);
+            LCHECK();      // (the ordered add of the keyframe partials is the first part of the next k_schur_setup)
             return ORBX_OK;
         }
-        hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust);
+        hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, gLin, 1);
         LCHECK();
-        hipLaunchKernelGGL(k_sum_points, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p);
+        hipLaunchKernelGGL(k_sum_points, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p, gLin, 1);
         LCHECK();
-        hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K, (unsigned)c.spSplit), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->spPart.p, c.spSplit);
-        hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p, c.spSplit);
+        hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K, (unsigned)c.spSplit), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->spPart.p, c.spSplit, gLin, 1);
         LCHECK();
-        h->flops += 400.0 * nAct;
         return ORBX_OK;
     };
-    for (int it = 0; it < iterations && !(c.stop && *c.stop) && ok; it++) {
-        double currentChi = freshChi;
-        if (!errorsFresh) {
-            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p);
-            LCHECK();
+    // ---- start of the stage: errors and chi2 of the start, H and b, computeLambdaInit, the LM state (nothing is waited for)
+    h->hostStop[0] = 0;
+    {
+        // (the state's `done` of the previous stage is still set: the first launches are not gated)
+        hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p, (const int *)nullptr, 0);
+        LCHECK();
+        if (!h->linSplit) {
+            hipLaunchKernelGGL(k_lin_sums, dim3((unsigned)(K * c.spSplit + (P + 15) / 16)), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->ptStart.p, h->ptEdges.p, h->Hll.p,
+                               h->bl.p, h->kfStart.p, h->kfEdges.p, h->spPart.p, c.spSplit, (const int *)nullptr, 0);
+        } else {
+            hipLaunchKernelGGL(k_linearize, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, (const int *)nullptr, 0);
+            hipLaunchKernelGGL(k_sum_points, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, h->Hll.p, h->bl.p, (const int *)nullptr, 0);
+            hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K, (unsigned)c.spSplit), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->spPart.p, c.spSplit, (const int *)nullptr, 0);
         }
-        if (!linearized) { int rcl = linearize(); if (rcl) return rcl; }
-        linearized = false;
-        if (it == 0) {   // computeLambdaInit: tau * max |diag H| (:166-180)
-            hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(1024), 0, h->stream, h->Hpp.p, nPose, h->Hll.p, nPt, h->red.p);
-            LCHECK();
-        }
-        // First iteration of a stage: the chi2 of the start and computeLambdaInit's lambda are NOT waited for - the first trial takes lambda from the device
-        // (k_diag_max's result), the chi2 goes to its own slot of the pinned results, and the host reads both when the trial's results arrive (one host
-        // round trip per stage less: the device sat idle for its ~20 us).
-        bool deferred = false;
-        const bool chiFromDevice = !errorsFresh;
-        if (!errorsFresh || it == 0) {
-            const double seq = (h->seq += 1.0);
-            hipLaunchKernelGGL(k_trial_finish, dim3(1), dim3(256), 0, h->stream, h->partChi.p, (int)gE, (const double *)nullptr, 0, (const double *)nullptr, (const double *)nullptr, 0,
-                               0.0, (const int *)nullptr, it == 0 ? h->red.p : (const double *)nullptr, h->hostRedDev, seq, it == 0 ? 6 : 0, (const double *)nullptr);
-            LCHECK();
-            if (it == 0) deferred = true;
-            else {
-                int rcw = wait_seq(h, seq);
-                if (rcw) return rcw;
-                if (!errorsFresh) currentChi = h->hostRed[0];
-            }
-        }
-        double iniChi = currentChi;
-        if (it == 0 && !deferred) stats[2] = currentChi;
-        double rho = 0;
-        int qmax = 0;
-        do {
-            // (push() happens inside k_backsub_update, right before the estimates are changed)
-            int okHost = 1;
-            if (rebuild) {   // a speculative linearisation was made on a state that has been rejected since: H and b of the restored one again
-                hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p);
-                LCHECK();
-                int rcl = linearize();
-                if (rcl) return rcl;
-                rebuild = false;
-            }
-            // the right-hand side of the reduced system is accumulated where the solver updates it in place (multi-workgroup Cholesky: ywork)
-            double *const bsDev = nP6 >= CHOL_MULTI_MIN_N ? h->ywork.p : h->bs.p;
-            {
-                const int nInit = nP6 > 0 ? 64 : 0;
-                hipLaunchKernelGGL(k_schur_setup, dim3((unsigned)(nInit + (P + 3) / 4 + (nP6 > 0 ? (E + 255) / 256 : 0))), dim3(256), 0, h->stream, c.d, nInit, h->Hpp.p, h->bp.p, nPose, h->ptStart.p,
-                                   h->ptEdges.p, h->Hll.p, h->bl.p, lambda, h->S.p, bsDev, h->Dinv.p, h->Ddb.p, h->okFlag.p, deferred ? (const double *)h->red.p : (const double *)nullptr);
-                LCHECK();
-            }
-            if (nP6 > 0) {
-                const size_t ldsRows = (size_t)(6 * nP6 + 6) * sizeof(double);
-                // y-splits per keyframe so that ALL workgroups are resident at once (six per CU at the kernel's 80 registers, fewer where the LDS row is
-                // long): a step of the edge loop is three dependent memory round trips, ~5 us, and a second round of workgroups costs a whole one
-                const int perCU = std::max(1, std::min(6, (int)(150 * 1024 / std::max<size_t>(ldsRows, 1))));
-                const int ySplit = std::max(4, std::min(32, perCU * h->numCU / std::max(K, 1)));
-                if (ldsRows > 150 * 1024) {      // > ~530 free keyframes: the block row no longer fits into LDS
-                    hipLaunchKernelGGL(k_schur_rows<true>, dim3((unsigned)K, 16u), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, (const int *)h->kfRowS0.p, (const int *)h->kfRowN.p, h->ptEdges.p, (const int *)h->ptPi.p, nP6, h->Ddb.p, h->S.p, bsDev);
-                } else {
-                    if (ldsRows > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
-                    hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, (unsigned)ySplit), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, (const int *)h->kfRowS0.p, (const int *)h->kfRowN.p, h->ptEdges.p, (const int *)h->ptPi.p, nP6, h->Ddb.p, h->S.p, bsDev);
-                }
-                LCHECK();
-            }
-            if (nP6 > 0) {
-                if (nP6 >= CHOL_MULTI_MIN_N) {
-                    const int n = nP6;
-                    for (int p0 = 0; p0 < n; p0 += CNB) {
-                        const int nb = std::min(CNB, n - p0), below = n - p0 - nb;
-                        const int nPW = std::max(1, (below + CHOL_RPW - 1) / CHOL_RPW);
-                        const int T1 = p0 > 0 ? (n - p0 + CNB - 1) / CNB - 1 : 0;        // tile rows / columns beyond block column p that still await the previous panel's update
-                        hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nPW + T1 * T1)), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0, nPW, std::max(T1, 1), h->ywork.p,
-                                           h->ysol.p, h->okFlag.p, h->diagInv.p);
-                    }
-                    if (n <= 128) hipLaunchKernelGGL(k_chol_backsub_reg<4>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
-                    else if (n <= 224) hipLaunchKernelGGL(k_chol_backsub_reg<7>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
-                    else if (n <= 256) hipLaunchKernelGGL(k_chol_backsub_reg<8>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
-                    else if (n <= 320) hipLaunchKernelGGL(k_chol_backsub_reg<10>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p);
-                    else if (n <= CHOL_LDS_X) hipLaunchKernelGGL(k_chol_backsub<false>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
-                    else hipLaunchKernelGGL(k_chol_backsub<true>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p);
-                } else {   // widest panel whose n x NB doubles fit next to the solution vector in LDS
-                    const size_t budget = 120 * 1024;
-                    if ((size_t)nP6 * 32 * 8 <= budget) {
-                        const size_t lds = (size_t)nP6 * 32 * 8;
-                        if (lds > 32 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_solve<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        hipLaunchKernelGGL(k_chol_solve<32>, dim3(1), dim3(1024), lds, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p);
-                    } else if ((size_t)nP6 * 16 * 8 <= budget) {
-                        const size_t lds = (size_t)nP6 * 16 * 8;
-                        ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_solve<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        hipLaunchKernelGGL(k_chol_solve<16>, dim3(1), dim3(1024), lds, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p);
-                    } else {
-                        const size_t lds = (size_t)nP6 * 4 * 8;
-                        ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        hipLaunchKernelGGL(k_chol_solve<4>, dim3(1), dim3(1024), lds, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p);
-                    }
-                }
-                LCHECK();
-                h->flops += (double)nP6 * nP6 * nP6 / 3.0;
-            }
-            const unsigned gU = (unsigned)((std::max(K, 16 * P) + 255) / 256);
-            hipLaunchKernelGGL(k_backsub_update, dim3(gU), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, (const int *)h->ptPi.p, h->bl.p,
-                               h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p, lambda, h->partL.p, deferred ? (const double *)h->red.p : (const double *)nullptr);
-            LCHECK();
-            h->flops += 250.0 * nAct;
-            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p);
-            LCHECK();
-            const double seq = (h->seq += 1.0);
-            hipLaunchKernelGGL(k_trial_finish, dim3(1), dim3(256), 0, h->stream, h->partChi.p, (int)gE, h->partL.p, (int)gU, h->xp.p, h->bp.p, nP6, lambda,
-                               nP6 > 0 ? h->okFlag.p : (const int *)nullptr, (const double *)nullptr, h->hostRedDev, seq, 0, deferred ? (const double *)h->red.p : (const double *)nullptr);
-            LCHECK();
-            // speculate unless this can be the last iteration of the stage (iteration budget, or two unproductive ones so far)
-            const bool spec = it + 1 < iterations && nBad < 2 && !(c.stop && *c.stop);
-            if (spec) { int rcl = linearize(); if (rcl) return rcl; }
-            {   // the one wait of the trial: results and sequence number arrive in pinned memory
-                int rcw = wait_seq(h, seq);
-                if (rcw) return rcw;
-            }
-            if (deferred) {      // what the first iteration did not wait for
-                if (chiFromDevice) currentChi = h->hostRed[6];
-                lambda = 1e-5 * h->hostRed[2]; ni = 2; nBad = 0;
-                iniChi = currentChi; stats[2] = currentChi;
-                deferred = false;
-            }
-            double tempChi = h->hostRed[0];
-            if (nP6 > 0) okHost = h->hostRed[8] != 0.0;
-            if (!okHost) tempChi = std::numeric_limits<double>::max();
-            double scale = 0;
-            const double o1 = nP6 > 0 ? h->hostRed[4] : 0.0, o2 = h->hostRed[5];
-            scale = o1 + o2 + 1e-3;
-            rho = (currentChi - tempChi) / scale;
-            if (rho > 0 && std::isfinite(tempChi)) {
-                double alpha = 1. - pow((2 * rho - 1), 3);
-                alpha = std::min(alpha, 2. / 3.);
-                lambda *= std::max(1. / 3., alpha);
-                ni = 2;
-                currentChi = tempChi;
-                errorsFresh = true; freshChi = tempChi;       // d.err / rchi are those of the state just accepted
-                linearized = spec;
-            } else {
-                rebuild = spec;
-                lambda *= ni;
-                ni *= 2;
-                errorsFresh = false;
-                // pop(): estimates restored; _error keeps the values of the rejected trial (as in g2o)
-                hipLaunchKernelGGL(k_restore, dim3((unsigned)((std::max(K, 3 * P) + 255) / 256)), dim3(256), 0, h->stream, c.d, h->poseBak.p, h->ptBak.p);
-                LCHECK();
-            }
-            qmax++;
-            stats[1] += 1;
-        } while (rho < 0 && qmax < 10 && !(c.stop && *c.stop));
-        stats[0] += 1;
-        stats[3] = currentChi;
-        if (qmax == 10 || rho == 0) { ok = false; continue; }
-        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
-        if (nBad >= 3) ok = false;
+        hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p, c.spSplit, (const int *)nullptr, 0);
+        hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(1024), 0, h->stream, h->Hpp.p, nPose, h->Hll.p, nPt, h->red.p);
+        const double seq = (h->seq += 1.0);
+        hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(256), 0, h->stream, st, (const double *)h->partChi.p, (int)gE, (const double *)h->red.p, iterations, (const volatile int *)h->hostStopDev,
+                           h->hostRedDev, seq, h->scaleBits.p);
+        LCHECK();
     }
+    // ---- one Levenberg trial in two halves
+    // the right-hand side of the reduced system is accumulated where the solver updates it in place (multi-workgroup Cholesky: ywork)
+    double *const bsDev = nP6 >= CHOL_MULTI_MIN_N ? h->ywork.p : h->bs.p;
+    // first half of a trial: the reduced system S, bs from H, b and lambda (three launches)
+    auto trialSchur = [&]() -> int {
+        {
+            const int nInit = nP6 > 0 ? (32 * K + 255) / 256 : 0;      // the first workgroups: Hpp / b_p from the keyframe partial sums, and the fixed-point scale
+            hipLaunchKernelGGL(k_schur_setup, dim3((unsigned)(nInit + (P + 3) / 4 + (nP6 > 0 ? (E + 255) / 256 : 0))), dim3(256), 0, h->stream, c.d, nInit, h->Hpp.p, h->bp.p, nPose, h->ptStart.p,
+                               h->ptEdges.p, h->Hll.p, h->bl.p, 0.0, h->S.p, bsDev, h->Dinv.p, h->Ddb.p, h->okFlag.p, lam, h->scaleBits.p, (const double *)h->spPart.p, c.spSplit, h->Hpp.p, h->bp.p,
+                               gDone, 0);
+            LCHECK();
+        }
+        if (nP6 > 0) {
+            const size_t ldsRows = (size_t)(6 * nP6) * sizeof(unsigned long long);
+            // y-splits per keyframe so that ALL workgroups are resident at once (six per CU at the kernel's 80 registers, fewer where the LDS row is
+            // long): a step of the edge loop is three dependent memory round trips, ~5 us, and a second round of workgroups costs a whole one
+            const int perCU = std::max(1, std::min(6, (int)(150 * 1024 / std::max<size_t>(ldsRows, 1))));
+            const int ySplit = std::max(4, std::min(32, perCU * h->numCU / std::max(K, 1)));
+            int ys = ySplit;
+            if (ldsRows > 150 * 1024) {      // > ~530 free keyframes: the block row no longer fits into LDS
+                ys = 16;
+                hipLaunchKernelGGL(k_schur_rows<true>, dim3((unsigned)K, 16u), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, (const int *)h->kfRowS0.p, (const int *)h->kfRowN.p, h->ptEdges.p, (const int *)h->ptPi.p, nP6, h->Ddb.p, h->Sacc.p, h->bsPart.p, (const unsigned long long *)h->scaleBits.p, gDone, 0);
+            } else {
+                if (ldsRows > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
+                hipLaunchKernelGGL(k_schur_rows<false>, dim3((unsigned)K, (unsigned)ySplit), dim3(256), ldsRows, h->stream, c.d, h->kfStart.p, h->kfEdges.p, (const int *)h->kfRowS0.p, (const int *)h->kfRowN.p, h->ptEdges.p, (const int *)h->ptPi.p, nP6, h->Ddb.p, h->Sacc.p, h->bsPart.p, (const unsigned long long *)h->scaleBits.p, gDone, 0);
+            }
+            LCHECK();
+            // S and bs from the sums (and the accumulator cleared for the next trial)
+            hipLaunchKernelGGL(k_schur_fin, dim3((unsigned)((nP6 + 255) / 256), (unsigned)(nPose + 1)), dim3(256), 0, h->stream, c.d, (const double *)h->Hpp.p, (const double *)h->bp.p, nPose, 0.0,
+                               lam, h->Sacc.p, (const double *)h->bsPart.p, ys, (const unsigned long long *)h->scaleBits.p, h->S.p, bsDev, gDone, 0);
+            LCHECK();
+        }
+        return ORBX_OK;
+    };
+    // second half: factorisation and solve, update, errors, the decision, and - for the next trial - the restore of a rejected update and H, b
+    // at the estimates the decision left.  *seqOut = the decision's sequence number.
+    auto trialSolve = [&](double *seqOut) -> int {
+        if (nP6 > 0) {
+            if (nP6 >= CHOL_MULTI_MIN_N) {
+                const int n = nP6;
+                for (int p0 = 0; p0 < n; p0 += CNB) {
+                    const int nb = std::min(CNB, n - p0), below = n - p0 - nb;
+                    const int nPW = std::max(1, (below + CHOL_RPW - 1) / CHOL_RPW);
+                    const int T1 = p0 > 0 ? (n - p0 + CNB - 1) / CNB - 1 : 0;        // tile rows / columns beyond block column p that still await the previous panel's update
+                    hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nPW + T1 * T1)), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0, nPW, std::max(T1, 1), h->ywork.p,
+                                       h->ysol.p, h->okFlag.p, h->diagInv.p, gDone, 0);
+                }
+                if (n <= 128) hipLaunchKernelGGL(k_chol_backsub_reg<4>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p, gDone, 0);
+                else if (n <= 224) hipLaunchKernelGGL(k_chol_backsub_reg<7>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p, gDone, 0);
+                else if (n <= 256) hipLaunchKernelGGL(k_chol_backsub_reg<8>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p, gDone, 0);
+                else if (n <= 320) hipLaunchKernelGGL(k_chol_backsub_reg<10>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p, gDone, 0);
+                else if (n <= CHOL_LDS_X) hipLaunchKernelGGL(k_chol_backsub<false>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p, gDone, 0);
+                else hipLaunchKernelGGL(k_chol_backsub<true>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, n, h->xp.p, gDone, 0);
+            } else {   // widest panel whose n x NB doubles fit next to the solution vector in LDS
+                const size_t budget = 120 * 1024;
+                if ((size_t)nP6 * 32 * 8 <= budget) {
+                    const size_t lds = (size_t)nP6 * 32 * 8;
+                    if (lds > 32 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_solve<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(k_chol_solve<32>, dim3(1), dim3(1024), lds, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p, gDone, 0);
+                } else if ((size_t)nP6 * 16 * 8 <= budget) {
+                    const size_t lds = (size_t)nP6 * 16 * 8;
+                    ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_solve<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(k_chol_solve<16>, dim3(1), dim3(1024), lds, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p, gDone, 0);
+                } else {
+                    const size_t lds = (size_t)nP6 * 4 * 8;
+                    ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chol_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(k_chol_solve<4>, dim3(1), dim3(1024), lds, h->stream, h->S.p, h->bs.p, nP6, h->xp.p, h->okFlag.p, gDone, 0);
+                }
+            }
+            LCHECK();
+        }
+        // (push() happens inside k_backsub_update, right before the estimates are changed)
+        const unsigned gU = (unsigned)((std::max(K, 16 * P) + 255) / 256);
+        hipLaunchKernelGGL(k_backsub_update, dim3(gU), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, (const int *)h->ptPi.p, h->bl.p,
+                           h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p, 0.0, h->partL.p, lam, gDone, 0);
+        LCHECK();
+        hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p, gDone, 0);
+        LCHECK();
+        const double seq = (h->seq += 1.0);
+        hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(256), 0, h->stream, st, (const double *)h->partChi.p, (int)gE, (const double *)h->partL.p, (int)gU, (const double *)h->xp.p,
+                           (const double *)h->bp.p, nP6, nP6 > 0 ? (const int *)h->okFlag.p : (const int *)nullptr, (const volatile int *)h->hostStopDev, h->hostRedDev, seq, c.d,
+                           (const DPose *)h->poseBak.p, (const double *)h->ptBak.p, h->scaleBits.p);
+        LCHECK();
+        // (a rejected update is taken back inside k_lm_decide); H and b at the new estimates behind an accepted trial
+        int rcl = linearize();
+        if (rcl) return rcl;
+        h->flops += 400.0 * nAct + 250.0 * nAct + (double)nP6 * nP6 * nP6 / 3.0;
+        *seqOut = seq;
+        return ORBX_OK;
+    };
+    // The host never lets the device wait for it: behind the decision of trial t it has already queued the restore / errors / linearisation and
+    // the Schur half of trial t + 1 (~40 us of device work) when it starts to wait for that decision, and queues the solve half of t + 1 while
+    // those run.  A stage that ends leaves those seven launches to fall through (~4 us each); a whole trial enqueued in advance would cost
+    // twenty (measured: every trial of both stages up front, 15 per window where 9 are needed: 2.08 ms per window instead of 1.87).
+    int rct = trialSchur();
+    if (rct) return rct;
+    for (int t = 0;; t++) {
+        double seqT = 0;
+        if ((rct = trialSolve(&seqT)) != ORBX_OK) return rct;
+        if ((rct = trialSchur()) != ORBX_OK) return rct;      // of trial t + 1, speculatively
+        int rcw = wait_seq(h, seqT, c.stop);
+        if (rcw) return rcw;
+        if (h->hostRed[13] != 0.0) break;      // done
+        if (t >= 10 * iterations + 10) { orbx_set_error("LBA: the Levenberg loop did not terminate"); return ORBX_ERR_STATE; }
+    }
+    stats[0] = h->hostRed[7]; stats[1] = h->hostRed[9]; stats[2] = h->hostRed[6]; stats[3] = h->hostRed[1];
     return ORBX_OK;
 }
 

@@ -259,3 +259,25 @@ def test_fused_linearisation_equals_the_split_one(orbx, cfg, monkeypatch):
     for key in ("poses", "points", "chi2"):
         assert np.allclose(a[key], b[key], rtol=1e-10, atol=1e-10), key
     fused.close(); split.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,runs", [(dict(K=50, P=5000, seed=12345), 100),
+                                      (dict(K=12, P=400, seed=6, n_fixed=2, pose_noise=(np.deg2rad(12.0), 0.5), point_noise=0.4, stereo_frac=0.3), 40)])
+def test_lba_is_reproducible(orbx, cfg, runs):
+    """The same window again and again, on one handle and on a fresh one: identical LM path (iterations, trials, chi2 to the last bit) and
+    identical float32 outputs, per-edge chi2 and outlier flags.  The Schur complement is accumulated in 64-bit fixed point (integer sums do
+    not depend on the order in which workgroups and waves arrive - the former FP64 atomics did) and its right-hand side in ordered partial
+    sums (csrc/orbx_lba.hip: k_schur_rows / k_schur_fin); everything else was ordered before.  The second window goes through rejected trials."""
+    w = orbx.lba_synth.make_window(**cfg)
+    opt = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000)
+    first = opt.LocalBundleAdjustment(w)
+    for run in range(1, runs):
+        if run == runs // 2:      # a fresh handle (fresh allocations, another stream) must land on the same bits as well
+            opt.close()
+            opt = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000)
+        got = opt.LocalBundleAdjustment(w)
+        assert (np.asarray(got["stats"]).view(np.uint64) == np.asarray(first["stats"]).view(np.uint64)).all(), (run, got["stats"], first["stats"])
+        assert (got["poses"].view(np.uint32) == first["poses"].view(np.uint32)).all() and (got["points"].view(np.uint32) == first["points"].view(np.uint32)).all(), run
+        assert (np.asarray(got["chi2"], np.float64).view(np.uint64) == np.asarray(first["chi2"], np.float64).view(np.uint64)).all() and (got["outlier"] == first["outlier"]).all(), run
+    opt.close()
