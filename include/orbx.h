@@ -37,6 +37,9 @@ extern "C" {
 const char *orbx_last_error(void);
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int orbx_version(void);
+/* "<uuid>@<pci address>" of HIP device `device` into identity[capacity >= 64] and the NUMA node of its PCI function (-1 = unknown; may be
+ * NULL): what a multi-process run uses to prove that its N ranks sit on N distinct GPUs (bench.py).  Creates no stream. */
+int orbx_device_identity(int device, char *identity, int capacity, int *numa_node);
 
 /* ------------------------------------------------------------------------------------
  * ORB extractor  ==  ORB_SLAM2::ORBextractor

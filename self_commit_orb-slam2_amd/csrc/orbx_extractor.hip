@@ -502,6 +502,33 @@ int orbx_extractor_last_batch_view_internal(orbx_extractor *h, OrbxLastBatchView
     return ORBX_OK;
 }
 
+// "<uuid>@<pci domain:bus:device.function>" of HIP device `device` (what tells two GPUs apart; bench.py's ranks all-gather it), and the NUMA
+// node its PCI function hangs on (-1: unknown).  Touches the HIP runtime only through hipGetDeviceProperties: no stream, no context of another
+// library is created (a torch.cuda query before the timed region moved bench.py's own streams to other hardware queues: -13 % throughput).
+extern "C" int orbx_device_identity(int device, char *identity, int capacity, int *numa_node)
+{
+    if (!identity || capacity < 64) { orbx_set_error("identity buffer too small (need 64 bytes)"); return ORBX_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { orbx_set_error("no HIP device available"); return ORBX_ERR_NODEVICE; }
+    if (device < 0 || device >= ndev) { orbx_set_error("device %d out of range (have %d)", device, ndev); return ORBX_ERR_ARG; }
+    hipDeviceProp_t p;
+    ORBX_HIP_CHECK(hipGetDeviceProperties(&p, device));
+    char uuid[40];
+    static const char *hex = "0123456789abcdef";
+    for (int i = 0; i < 16; i++) { uuid[2 * i] = hex[((unsigned char)p.uuid.bytes[i]) >> 4]; uuid[2 * i + 1] = hex[((unsigned char)p.uuid.bytes[i]) & 15]; }
+    uuid[32] = 0;
+    char bus[32];
+    snprintf(bus, sizeof(bus), "%04x:%02x:%02x.0", p.pciDomainID, p.pciBusID, p.pciDeviceID);
+    snprintf(identity, (size_t)capacity, "%s@%s", uuid, bus);
+    if (numa_node) {
+        *numa_node = -1;
+        char path[96];
+        snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+        if (FILE *f = fopen(path, "r")) { int v = -1; if (fscanf(f, "%d", &v) == 1) *numa_node = v; fclose(f); }
+    }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extractor **out)
 {
     if (!cfg || !out) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }

@@ -1025,21 +1025,28 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
     const int x = X0 + 4 * gq;
     if (x >= w || Y0 + 8 * rg >= h) return;
     // ---- horizontal: rows 8rg .. 8rg+13 of the window; pixel j of the group = bytes 1+j .. 7+j of (w0,w1,w2) ----
-    const uint32_t TL = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), TH = k4 | (k5 << 8) | (k6 << 16);
+    // The TAPS are shifted, not the data: pixel j's seven taps sit at bytes 1+j .. 7+j of a 12-byte tap vector (uniform: scalar registers), so
+    // a pixel is two or three v_dot4_u32_u8 on the window words as loaded - 10 per row of four pixels, where byte-aligning the window for every
+    // pixel first took 6 v_alignbyte_b32 + 8 v_dot4.
+    const uint32_t A0 = (k0 << 8) | (k1 << 16) | (k2 << 24), A1 = k3 | (k4 << 8) | (k5 << 16) | (k6 << 24);                      // j = 0: w0, w1
+    const uint32_t B0 = (k0 << 16) | (k1 << 24), B1 = k2 | (k3 << 8) | (k4 << 16) | (k5 << 24), B2 = k6;                           // j = 1: w0, w1, w2
+    const uint32_t C0 = k0 << 24, C1 = k1 | (k2 << 8) | (k3 << 16) | (k4 << 24), C2 = k5 | (k6 << 8);                              // j = 2: w0, w1, w2
+    const uint32_t D1 = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), D2 = k4 | (k5 << 8) | (k6 << 16);                                // j = 3: w1, w2
     uint32_t c0[14], c1[14];
 #pragma unroll
     for (int r = 0; r < 14; r++) {
         const uint32_t *pw = in + (8 * rg + r) * (BT_P / 4) + gq + 1;
         const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
-        const uint32_t o0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), TL, 0u, false), false);
-        const uint32_t o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), TL, 0u, false), false);
-        const uint32_t o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), TH, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), TL, 0u, false), false);
-        const uint32_t o3 = __builtin_amdgcn_udot4(w2, TH, __builtin_amdgcn_udot4(w1, TL, 0u, false), false);
+        const uint32_t o0 = __builtin_amdgcn_udot4(w1, A1, __builtin_amdgcn_udot4(w0, A0, 0u, false), false);
+        const uint32_t o1 = __builtin_amdgcn_udot4(w2, B2, __builtin_amdgcn_udot4(w1, B1, __builtin_amdgcn_udot4(w0, B0, 0u, false), false), false);
+        const uint32_t o2 = __builtin_amdgcn_udot4(w2, C2, __builtin_amdgcn_udot4(w1, C1, __builtin_amdgcn_udot4(w0, C0, 0u, false), false), false);
+        const uint32_t o3 = __builtin_amdgcn_udot4(w2, D2, __builtin_amdgcn_udot4(w1, D1, 0u, false), false);
         c0[r] = o0 | (o1 << 16);
         c1[r] = o2 | (o3 << 16);
     }
     // ---- vertical ----
     const uint32_t V01 = k0 | (k1 << 16), V23 = k2 | (k3 << 16), V45 = k4 | (k5 << 16), V6 = k6;
+    const bool clampNeeded = k0 + k1 + k2 + k3 + k4 + k5 + k6 > 256u;      // (uniform)
     uint32_t outw[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) outw[q] = 0;
@@ -1050,11 +1057,15 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
 #pragma unroll
         for (int k = 0; k < 13; k++) P[k] = (j < 2) ? __builtin_amdgcn_perm(c0[k + 1], c0[k], selp) : __builtin_amdgcn_perm(c1[k + 1], c1[k], selp);
         P[13] = (j < 2) ? __builtin_amdgcn_perm(c0[13], c0[13], selp) : __builtin_amdgcn_perm(c1[13], c1[13], selp);
+        // (sum + 32768) >> 16 is byte 2 of the sum, and with taps that add up to at most 256 it cannot exceed 255 (65280 * 256 + 32768 <
+        // 2^24): ONE v_perm_b32 drops that byte into byte j of the output word (shift, clamp and shift-or before).  Taps summing to 257
+        // (the configuration allows them) keep the clamp.
+        const uint32_t selo = j == 0 ? 0x03020106u : j == 1 ? 0x03020600u : j == 2 ? 0x03060100u : 0x06020100u;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const uint32_t sum = udot2(P[q + 6], V6, udot2(P[q + 4], V45, udot2(P[q + 2], V23, udot2(P[q], V01, 32768u))));
-            const uint32_t v = min(sum >> 16, 255u);
-            outw[q] |= v << (8 * j);
+            if (clampNeeded) outw[q] |= min(sum >> 16, 255u) << (8 * j);
+            else outw[q] = __builtin_amdgcn_perm(sum, outw[q], selo);
         }
     }
     uint8_t *dst = blur + (size_t)f * g->pyrBytes + lv.off;

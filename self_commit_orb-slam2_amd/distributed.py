@@ -45,18 +45,21 @@ def launch(nproc, argv, env=None, timeout=None, capture=False):
 
 
 def device_identity(local):
-    """What tells two GPUs apart: UUID and PCI address of CUDA/HIP device `local` (torch), plus the NUMA node the PCI function hangs on."""
-    import torch
-    p = torch.cuda.get_device_properties(local)
-    bus = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
-    uuid = str(getattr(p, "uuid", "")) or bus
-    node = -1
-    try:
-        with open("/sys/bus/pci/devices/%s/numa_node" % bus) as f:
-            node = int(f.read().strip())
-    except (OSError, ValueError):
-        pass
-    return {"uuid": uuid, "pci_bus_id": bus, "name": p.name, "numa_node": node}
+    """What tells two GPUs apart: UUID and PCI address of HIP device `local`, plus the NUMA node its PCI function hangs on - from liborbx
+    (orbx_device_identity), NOT from torch: a torch.cuda query here initialises torch's runtime before bench.py's handles create their
+    streams, which moved those to other hardware queues and cost 13 % of the headline throughput."""
+    import ctypes
+    import importlib
+    L = importlib.import_module(os.path.basename(os.path.dirname(os.path.abspath(__file__)))).load_library()      # (this file is loaded by path)
+    buf = ctypes.create_string_buffer(96)
+    node = ctypes.c_int(-1)
+    L.orbx_device_identity.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+    rc = L.orbx_device_identity(int(local), buf, 96, ctypes.byref(node))
+    if rc != 0:
+        raise RuntimeError("orbx_device_identity(%d): %s" % (local, L.orbx_last_error().decode("utf-8", "replace")))
+    ident = buf.value.decode()
+    uuid, _, bus = ident.partition("@")
+    return {"uuid": uuid, "pci_bus_id": bus, "numa_node": node.value}
 
 
 def _parse_cpulist(text):
@@ -171,10 +174,11 @@ class Group:
     def gather_identities(self, identity, allow_shared=False):
         """All-gather of every rank's device identity (a short string: GPU UUID / PCI address) -> list by rank.  Two ranks naming the
         same device raise (an "8-GPU" line measured on fewer GPUs must not exist) unless allow_shared (the 1-GPU plumbing mode)."""
+        if self.dist is None:
+            return [identity]      # (and no device tensor: anything that initialises torch's runtime before bench.py's handles exist moves their streams to
+                                   # other hardware queues - measured: 220k instead of 252k frames/s)
         raw = identity.encode()[:64].ljust(64, b"\0")
         mine = torch.tensor(list(raw), dtype=torch.uint8, device=self.device)
-        if self.dist is None:
-            return [identity]
         rows = [torch.zeros_like(mine) for _ in range(self.world)]
         self.dist.all_gather(rows, mine)
         ids = [bytes(r.tolist()).rstrip(b"\0").decode(errors="replace") for r in rows]
