@@ -43,9 +43,31 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-# VALU issue ceiling: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles per SIMD (integer / packed ops, measured with
-# tools/ubench_valu.hip: v_perm / v_pk_min / v_bcnt / v_dot4 / v_sad all issue at ~4 cycles), 2.4 GHz
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+
+
+def valu_evidence():
+    """VALU issue ceilings in G wave64-instructions/s for the chip (256 CUs x 4 SIMDs), with where they come from:
+    profiles/r04_valu_issue.txt = the raw output of tools/ubench_valu.hip on the MI355X (27 opcodes, cycles per wave-instruction per SIMD from the
+    kernel's duration, clock measured in the kernel): two classes, ~2.2 cycles (add / sub / and / xor / f32 add / fma) and ~4.1 cycles (shifts, min / max,
+    bcnt, perm, alignbyte, dot2 / dot4, sad, mad, bfe, three-operand and packed ops - what the byte kernels here are made of);
+    profiles/r04_valu_mix.json = the static opcode mix of every kernel priced with that table (tools/valu_mix.py).  The guide's figure
+    (MI355X_MICROARCH.md, "Wave scheduling": 2 cycles per wave64 instruction) is carried beside them."""
+    clk, c_half, c_full, mix = 2.4, 4.0, 2.2, {}
+    src = []
+    try:
+        d = json.loads((ROOT / "profiles" / "r04_valu_mix.json").read_text())
+        clk, c_half, c_full = float(d["clock_GHz_median"]), float(d["cycles_half_rate_class"]), float(d["cycles_full_rate_class"])
+        mix = {k: float(v["cycles_per_instr_static_mix"]) for k, v in d["kernels"].items()}
+        src = ["profiles/r04_valu_issue.txt (tools/ubench_valu.hip, raw)", "profiles/r04_valu_mix.json (tools/valu_mix.py)"]
+    except Exception:
+        src = ["built-in defaults: profiles/r04_valu_mix.json not readable"]
+    simds = 256 * 4
+    return {"clock_GHz": clk, "cycles_half_rate_class": c_half, "cycles_full_rate_class": c_full, "mix": mix, "evidence": src,
+            "peak_half_rate": simds * clk / c_half, "peak_full_rate": simds * clk / c_full, "peak_guide_2cycle": simds * 2.4 / 2.0}
+
+
+VALU = valu_evidence()
+VALU_PEAK_GINST = VALU["peak_half_rate"]      # the class the byte / packed-16 kernels of this path are made of (measured)
 
 
 def level_pixels(W, H, nlevels=8, scale=1.2):
@@ -429,8 +451,20 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
         tot = sum(v for v in valu.values() if v)      # (alg has an "octree" key with 0 bytes: the quadtree's instructions are in the sum)
         rate = tot * nbatches_timed / (t / a.steps) / 1e9
         dv = valu.get(dom)
+        # the same instructions priced kernel by kernel with the static opcode mix: seconds per batch if every SIMD issued without a bubble
+        def kcyc(stage):
+            kn = STAGE_KERNEL.get(stage, stage).split("<")[0].split(" ")[0]
+            return VALU["mix"].get(kn, VALU["cycles_half_rate_class"])
+        t_mix = sum(v * kcyc(k) for k, v in valu.items() if v) / (256 * 4 * VALU["clock_GHz"] * 1e9)
+        peak_mix = tot / t_mix / 1e9 if t_mix > 0 else VALU_PEAK_GINST
         roofline_valu = {"bound": "valu_issue", "unit": "G wave-instr/s", "peak": round(VALU_PEAK_GINST, 1),
                          "achieved": round(rate, 2), "frac": round(rate / VALU_PEAK_GINST, 4),
+                         "peak_basis": "measured: %.2f cycles per wave64 instruction per SIMD for the half-rate class (shifts, min / max, bcnt, perm, alignbyte, dot2 / dot4, sad, "
+                                       "packed-16), %.2f for add / sub / and / xor / f32 add / fma, at %.2f GHz" % (VALU["cycles_half_rate_class"], VALU["cycles_full_rate_class"], VALU["clock_GHz"]),
+                         "evidence": VALU["evidence"],
+                         "peak_static_mix": round(peak_mix, 1), "frac_static_mix": round(rate / peak_mix, 4),
+                         "peak_guide_2cycle": round(VALU["peak_guide_2cycle"], 1), "frac_guide_2cycle": round(rate / VALU["peak_guide_2cycle"], 4),
+                         "cycles_per_instr_static_mix": {STAGE_KERNEL.get(k, k): round(kcyc(k), 2) for k, v in valu.items() if v},
                          "valu_insts_per_batch": int(tot), "source": "profiles/latest_sq_counters.json (SQ_INSTS_VALU pass of this command)",
                          "dominant_kernel": ({"kernel": STAGE_KERNEL.get(dom, dom), "valu_insts_per_launch": int(dv),
                                               "frac_alone": round(dv / (ref_ms[dom] * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)} if dv else None)}
@@ -693,7 +727,7 @@ def bench_lba(a, orbx, torch, grp, dev_t, local, rank_info):
     except Exception:
         launches = None
     FP64_PEAK_TF = 256 * 4 * 16 * 2 * 2.4e9 / 1e12      # 256 CUs x 4 SIMDs x 16 FP64 lanes x FMA x 2.4 GHz = 78.6 TFLOP/s (vector = matrix rate on MI355X)
-    roof = {"bound": "mfma", "kernel": "whole LM loop (%s x k_chol_step = %s %% of the kernel time, profiles/*_lba_kernel_stats.csv)"
+    roof = {"bound": "latency (fp64)", "kernel": "whole LM loop (%s x k_chol_step = %s %% of the kernel time, profiles/*_lba_kernel_stats.csv)"
                                        % (("%g" % launches["k_chol_step_per_window"], "%g" % launches["k_chol_step_percent_of_kernel_time"]) if launches else ("72", "~49")),
             "achieved": round(gflops / 1e3, 4),
             "peak": round(FP64_PEAK_TF, 1), "unit": "TFLOP/s", "frac": round(gflops / 1e3 / FP64_PEAK_TF, 5), "traffic": None,
@@ -708,6 +742,24 @@ def bench_lba(a, orbx, torch, grp, dev_t, local, rank_info):
     if cpu:
         out["cpu_baseline"] = cpu
     return out
+
+
+def host_io_batch(orbx, a, local, seconds=1.0):
+    """orbx_extract_batch as the C ABI declares it for host callers: host image pointers in, host keypoint / descriptor arrays out, every call
+    synchronous - upload, the batch's launch set and the download of the whole result arena all inside the timed region (PCIe both ways)."""
+    W, H, B, nf = a.width, a.height, min(a.batch, 256), a.nfeatures
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local)
+    frames = orbx.synth_sequence(991, B, W, H)
+    ext.extract_batch(frames)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        kps, desc, counts = ext.extract_batch(frames)
+        n += 1
+    dt = time.perf_counter() - t0
+    cap = ext.capacity
+    ext.close()
+    return {"frames_per_s": round(n * B / dt, 1), "batch": B, "ms_per_batch": round(dt / n * 1e3, 3), "keypoints_per_frame": round(float(counts.mean()), 1),
+            "note": "host pointers in, host arrays out, synchronous (includes the Python harness allocating the %d MB result arrays per call)" % ((B * cap * 60) >> 20)}
 
 
 def main():
@@ -780,6 +832,30 @@ def main():
                 out.setdefault("workloads", {})[key] = r
             except Exception as e:                   # a failing side leg must not take the headline line with it
                 out.setdefault("workloads", {})[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if grp.rank == 0 and a.workloads and out is not None:
+        # Everything the side legs measured, once more as a COMPACT digest inside `config` (the driver's parser keeps `config` and `roofline`
+        # verbatim and drops unknown top-level keys): BASELINE configs 2 / 3 / 5, the batch entry point with host pointers in and host arrays
+        # out (PCIe both ways), and the surface the reference can actually call - ORBextractor::operator() and the stereo Frame constructor
+        # through the C++ shim, timed by C++ loops (tools/latency_shim.py).
+        w = out.get("workloads", {})
+        st, lb, xo = w.get("stereo_1241x376", {}) or {}, w.get("lba_50kf", {}) or {}, w.get("extract_only", {}) or {}
+        dig = {"extract_only": {"frames_per_s": xo.get("value")},
+               "stereo": {"pairs_per_s": st.get("value"), "frac_hbm": (st.get("roofline") or {}).get("frac"),
+                          "cpu_ref_pairs_per_s": (st.get("cpu_baseline") or {}).get("value"), "cpu_ref_one_ctor_pairs_per_s": ((st.get("cpu_baseline") or {}).get("single") or {}).get("value")},
+               "lba": {"ms_per_window": lb.get("ms_per_step"), "windows_per_s_3_in_flight": ((lb.get("config") or {}).get("concurrent") or {}).get("windows_per_s"),
+                       "frac_fp64": (lb.get("roofline") or {}).get("frac"), "cpu_ref_g2o_windows_per_s": (lb.get("cpu_baseline") or {}).get("value"),
+                       "cpu_port_windows_per_s": ((lb.get("cpu_baseline") or {}).get("restatement") or {}).get("value")}}
+        try:
+            dig["host_io_batch"] = host_io_batch(orbx, a, local)
+        except Exception as e:
+            dig["host_io_batch"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            sys.path.insert(0, str(ROOT / "tools"))
+            import latency_shim
+            dig["dropin"] = latency_shim.measure(orbx, quick=True)["digest"]
+        except Exception as e:
+            dig["dropin"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["config"]["workloads_digest"] = dig
     grp.close()                                      # (ranks > 0 are done; rank 0 alone times the host baseline below)
     if affinity0 is not None:
         try:

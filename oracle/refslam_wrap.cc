@@ -1311,3 +1311,261 @@ ORBSLAM_API int orbslam_g2o_ba(int K, const float *poses, const uint8_t *fixed, 
     return 0;
 }
 #endif
+
+// ---------------------------------------------------------------------------------------
+// A SEQUENCE through the tracking front end and the local mapper's optimiser, on the reference's own objects and in the reference's
+// call order - what a single-call test cannot see: state that survives from call to call (in the drop-in library: the extractor's
+// double-buffered result arenas and pinned views, the combiner's engines, thread-local matcher handles, the cached device vocabulary,
+// the optimiser handles).  Per frame i (src/Tracking.cc: Track -> TrackReferenceKeyFrame :1180-1230 -> TrackLocalMap :1700-1830):
+//     Frame F(im_i, ..., extractor, voc, K, dist, bf, thDepth)              monocular constructor: ExtractORB, UndistortKeyPoints, grid
+//     F.ComputeBoW();  F.SetPose(last pose);  ORBmatcher(0.7, true).SearchByBoW(refKF, F, matches);  F.mvpMapPoints = matches
+//     Optimizer::PoseOptimization(&F);  outliers dropped as :1213-1229
+//     SearchLocalPoints over all map points (isInFrustum + SearchByProjection(F, points, th = 1); the drop-in: SearchLocalPointsHIP)
+//     Optimizer::PoseOptimization(&F)
+//     every `kfEvery`-th frame: KeyFrame from F, new MapPoints for its unmatched keypoints on the scene plane z = planeZ (the synthetic
+//     frames are translating views of one plane), ComputeBoW, UpdateConnections, Optimizer::LocalBundleAdjustment(pKF, &stop, &map)
+// Everything is recorded per step.  `force` (NULL in the first, all-reference run): the optimiser outputs of ANOTHER run - poses after
+// both PoseOptimization calls, keyframe poses / point positions after every LocalBundleAdjustment - which REPLACE this run's own after they
+// have been recorded, so that the drop-in run continues from the reference's exact floats and every index / bit-pattern output of the
+// following steps can be compared exactly (the optimisers agree to 1e-5, not to the bit).
+// Record layout: rec[frame][64] doubles; lba events: lbaKf[event][maxKf][17] (mnId + 16), lbaPt[event][maxPt][4] (mnId + xyz).
+// ---------------------------------------------------------------------------------------
+namespace {
+uint64_t fnv(uint64_t h, const void *p, size_t n)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+// KeyFrames and MapPoints of a sequence come out of ONE monotone pool: the reference keys containers by object ADDRESS
+// (MapPoint::mObservations is a std::map<KeyFrame*, size_t>; UpdateNormalAndDepth sums the observation normals in that order, and a float sum of
+// three or more terms depends on it), so with malloc'ed objects its own results differ from process to process and between the two libraries;
+// addresses that grow with the creation order make the order the same everywhere.  (Objects are never deleted: test process.)
+char *g_seq_pool = nullptr;
+size_t g_seq_off = 0;
+const size_t kSeqPool = (size_t)256 << 20;
+void *seq_alloc(size_t n)
+{
+    if (!g_seq_pool) g_seq_pool = (char *)malloc(kSeqPool);
+    g_seq_off = (g_seq_off + 63) & ~(size_t)63;
+    if (!g_seq_pool || g_seq_off + n > kSeqPool) { fprintf(stderr, "orbslam_sequence: object pool exhausted\n"); abort(); }
+    void *p = g_seq_pool + g_seq_off;
+    g_seq_off += n;
+    return p;
+}
+bool by_id_mp(MapPoint *a, MapPoint *b) { return a->mnId < b->mnId; }
+bool by_id_kf(KeyFrame *a, KeyFrame *b) { return a->mnId < b->mnId; }
+double hash_as_double(uint64_t h) { return (double)(h >> 12); }      // 52 bits: exact in a double
+}  // namespace
+
+ORBSLAM_API int orbslam_sequence(const uint8_t *const *images, int nframes, int w, int h, int stride, int nfeatures, void *vocHandle, float fx, float fy, float cx,
+                                 float cy, float planeZ, int kfEvery, const double *force, const float *forceLbaKf, const float *forceLbaPt, double *rec, float *lbaKf,
+                                 float *lbaPt, int maxKf, int maxPt, int *nLbaEvents)
+{
+    CallScope scope;
+    ORBVocabulary *voc = (ORBVocabulary *)vocHandle;
+    ORBextractor *ex = new ORBextractor(nfeatures, 1.2f, 8, 20, 7);
+    cv::Mat K = make_K(fx, fy, cx, cy), dist = cv::Mat::zeros(4, 1, CV_32F);
+    Frame::mbInitialComputations = true;
+    Frame::nNextId = 0; KeyFrame::nNextId = 0; MapPoint::nNextId = 0;
+    g_seq_off = 0;      // (a new sequence reuses the pool: the objects of the previous one are abandoned with their Map)
+    Map &map = *new Map();
+    KeyFrame *refKF = nullptr;
+    cv::Mat lastPose = cv::Mat::eye(4, 4, CV_32F);
+    int events = 0;
+    auto add_keyframe = [&](Frame &F) -> KeyFrame * {
+        KeyFrame *pKF = new (seq_alloc(sizeof(KeyFrame))) KeyFrame(F, &map, (KeyFrameDatabase *)nullptr);
+        cv::Mat Rwc = pKF->GetRotation().t(), Ow = pKF->GetCameraCenter();
+        for (int j = 0; j < F.N; j++) {
+            MapPoint *pMP = F.mvpMapPoints[(size_t)j];
+            if (pMP && !pMP->isBad()) { pMP->AddObservation(pKF, (size_t)j); pMP->ComputeDistinctiveDescriptors(); pMP->UpdateNormalAndDepth(); continue; }
+            // a new point where the keypoint's ray meets the scene plane z = planeZ (world)
+            const cv::KeyPoint &kp = F.mvKeysUn[(size_t)j];
+            cv::Mat ray(3, 1, CV_32F);
+            ray.at<float>(0) = (kp.pt.x - cx) / fx; ray.at<float>(1) = (kp.pt.y - cy) / fy; ray.at<float>(2) = 1.f;
+            cv::Mat rw = Rwc * ray;
+            const float s = (planeZ - Ow.at<float>(2)) / rw.at<float>(2);
+            if (!(s > 0.1f)) continue;
+            cv::Mat X = Ow + rw * s;
+            MapPoint *pNew = new (seq_alloc(sizeof(MapPoint))) MapPoint(X, pKF, &map);
+            pNew->AddObservation(pKF, (size_t)j);
+            pKF->AddMapPoint(pNew, (size_t)j);
+            pNew->ComputeDistinctiveDescriptors();
+            pNew->UpdateNormalAndDepth();
+            map.AddMapPoint(pNew);
+            F.mvpMapPoints[(size_t)j] = pNew;
+        }
+        pKF->ComputeBoW();
+        pKF->UpdateConnections();
+        map.AddKeyFrame(pKF);
+        return pKF;
+    };
+    auto pose_rec = [](const cv::Mat &T, double *o) { for (int i = 0; i < 16; i++) o[i] = T.at<float>(i / 4, i % 4); };
+    auto pose_set = [](const double *o) { cv::Mat T(4, 4, CV_32F); for (int i = 0; i < 16; i++) T.at<float>(i / 4, i % 4) = (float)o[i]; return T; };
+    for (int i = 0; i < nframes; i++) {
+        double *r = rec + 64 * (size_t)i;
+        for (int q = 0; q < 64; q++) r[q] = 0;
+        cv::Mat I(h, w, CV_8UC1, (void *)images[i], (size_t)stride);
+        Frame F;
+        {
+            CallerArena arena;
+            F = Frame(I, (double)i, ex, voc, K, dist, 40.0f, 40.0f);
+        }
+        uint64_t hk = 1469598103934665603ull;
+        for (int j = 0; j < F.N; j++) { float q[7]; put_kp(q, F.mvKeys[(size_t)j]); hk = fnv(hk, q, sizeof(q)); hk = fnv(hk, F.mDescriptors.ptr(j), 32); }
+        r[0] = F.N; r[1] = hash_as_double(hk);
+        {   // what the constructor leaves besides the features: undistorted keypoints and the grid (Frame::AssignFeaturesToGrid, push_back order)
+            uint64_t hg = 1469598103934665603ull;
+            for (int j = 0; j < F.N; j++) { float q[7]; put_kp(q, F.mvKeysUn[(size_t)j]); hg = fnv(hg, q, sizeof(q)); }
+            for (int gx = 0; gx < FRAME_GRID_COLS; gx++)
+                for (int gy = 0; gy < FRAME_GRID_ROWS; gy++) {
+                    const std::vector<size_t> &cell = F.mGrid[gx][gy];
+                    const size_t cnt = cell.size();
+                    hg = fnv(hg, &cnt, sizeof(cnt));
+                    for (size_t q = 0; q < cnt; q++) hg = fnv(hg, &cell[q], sizeof(size_t));
+                }
+            r[52] = hash_as_double(hg);
+        }
+        F.ComputeBoW();
+        uint64_t hb = 1469598103934665603ull;
+        for (DBoW2::BowVector::const_iterator it = F.mBowVec.begin(); it != F.mBowVec.end(); ++it) { hb = fnv(hb, &it->first, sizeof(it->first)); hb = fnv(hb, &it->second, sizeof(it->second)); }
+        for (DBoW2::FeatureVector::const_iterator it = F.mFeatVec.begin(); it != F.mFeatVec.end(); ++it) {
+            hb = fnv(hb, &it->first, sizeof(it->first));
+            for (size_t q = 0; q < it->second.size(); q++) hb = fnv(hb, &it->second[q], sizeof(unsigned));
+        }
+        r[2] = (double)F.mBowVec.size(); r[3] = hash_as_double(hb);
+        if (i == 0) {
+            F.SetPose(cv::Mat::eye(4, 4, CV_32F));
+            refKF = add_keyframe(F);
+            r[4] = (double)map.MapPointsInMap();
+            lastPose = F.mTcw.clone();
+            continue;
+        }
+        F.SetPose(lastPose);
+        F.mpReferenceKF = refKF;
+        // ---- TrackReferenceKeyFrame
+        ORBmatcher matcher(0.7f, true);
+        std::vector<MapPoint *> vm;
+        const int nm = matcher.SearchByBoW(refKF, F, vm);
+        F.mvpMapPoints = vm;
+        uint64_t hm = 1469598103934665603ull;
+        for (int j = 0; j < F.N; j++) { const long id = F.mvpMapPoints[(size_t)j] ? (long)F.mvpMapPoints[(size_t)j]->mnId : -1; hm = fnv(hm, &id, sizeof(id)); }
+        r[5] = nm; r[6] = hash_as_double(hm);
+        const int in1 = Optimizer::PoseOptimization(&F);
+        r[7] = in1;
+        pose_rec(F.mTcw, r + 8);                                 // r[8..23]
+        uint64_t ho = 1469598103934665603ull;
+        for (int j = 0; j < F.N; j++) { const unsigned char o = F.mvbOutlier[(size_t)j] ? 1 : 0; ho = fnv(ho, &o, 1); }
+        r[24] = hash_as_double(ho);
+        if (force) F.SetPose(pose_set(force + 64 * (size_t)i + 8));
+        for (int j = 0; j < F.N; j++)                            // src/Tracking.cc:1213-1229
+            if (F.mvpMapPoints[(size_t)j] && F.mvbOutlier[(size_t)j]) {
+                MapPoint *pMP = F.mvpMapPoints[(size_t)j];
+                F.mvpMapPoints[(size_t)j] = nullptr; F.mvbOutlier[(size_t)j] = false;
+                pMP->mbTrackInView = false; pMP->mnLastFrameSeen = F.mnId;
+            }
+        // ---- TrackLocalMap: SearchLocalPoints over the whole (small) map, then the second pose optimisation
+        std::vector<MapPoint *> local = map.GetAllMapPoints();
+        std::sort(local.begin(), local.end(), by_id_mp);
+        {   // the map as SearchLocalPoints is about to see it: positions, normals, descriptors, flags of every point
+            uint64_t hp = 1469598103934665603ull;
+            for (size_t q = 0; q < local.size(); q++) {
+                MapPoint *pMP = local[q];
+                cv::Mat X = pMP->GetWorldPos(), Nn = pMP->GetNormal(), D = pMP->GetDescriptor();
+                hp = fnv(hp, X.data, 12); hp = fnv(hp, Nn.data, 12); hp = fnv(hp, D.data, 32);
+                const float d0 = pMP->GetMinDistanceInvariance(), d1 = pMP->GetMaxDistanceInvariance();
+                const int ob = pMP->Observations();
+                const unsigned char bd = pMP->isBad() ? 1 : 0, seen = pMP->mnLastFrameSeen == F.mnId ? 1 : 0;
+                hp = fnv(hp, &d0, 4); hp = fnv(hp, &d1, 4); hp = fnv(hp, &ob, 4); hp = fnv(hp, &bd, 1); hp = fnv(hp, &seen, 1);
+            }
+            r[53] = hash_as_double(hp);
+        }
+        int nm2 = 0;
+#ifdef ORBSLAM_HIP
+        nm2 = SearchLocalPointsHIP(F, local, 1);
+#else
+        for (std::vector<MapPoint *>::iterator vit = F.mvpMapPoints.begin(), vend = F.mvpMapPoints.end(); vit != vend; vit++) {      // src/Tracking.cc:1765-1784
+            MapPoint *pMP = *vit;
+            if (pMP) {
+                if (pMP->isBad()) *vit = static_cast<MapPoint *>(NULL);
+                else { pMP->IncreaseVisible(); pMP->mnLastFrameSeen = F.mnId; pMP->mbTrackInView = false; }
+            }
+        }
+        int nToMatch = 0;
+        for (std::vector<MapPoint *>::iterator vit = local.begin(), vend = local.end(); vit != vend; vit++) {                         // :1791-1811
+            MapPoint *pMP = *vit;
+            if (pMP->mnLastFrameSeen == F.mnId) continue;
+            if (pMP->isBad()) continue;
+            if (F.isInFrustum(pMP, 0.5)) { pMP->IncreaseVisible(); nToMatch++; }
+        }
+        if (nToMatch > 0) {                                                                                                           // :1814-1829
+            ORBmatcher m2(0.8);
+            nm2 = m2.SearchByProjection(F, local, 1);
+        }
+#endif
+        uint64_t h2 = 1469598103934665603ull;
+        for (int j = 0; j < F.N; j++) { const long id = F.mvpMapPoints[(size_t)j] ? (long)F.mvpMapPoints[(size_t)j]->mnId : -1; h2 = fnv(h2, &id, sizeof(id)); }
+        uint64_t hv = 1469598103934665603ull;
+        for (size_t q = 0; q < local.size(); q++) {
+            const unsigned char v = local[q]->mbTrackInView ? 1 : 0;
+            hv = fnv(hv, &v, 1);
+            if (v) { hv = fnv(hv, &local[q]->mTrackProjX, 4); hv = fnv(hv, &local[q]->mTrackProjY, 4); hv = fnv(hv, &local[q]->mnTrackScaleLevel, 4); }
+        }
+        r[25] = nm2; r[26] = hash_as_double(h2); r[27] = hash_as_double(hv); r[28] = (double)local.size();
+        const int in2 = Optimizer::PoseOptimization(&F);
+        r[29] = in2;
+        pose_rec(F.mTcw, r + 30);                                // r[30..45]
+        uint64_t ho2 = 1469598103934665603ull;
+        for (int j = 0; j < F.N; j++) { const unsigned char o = F.mvbOutlier[(size_t)j] ? 1 : 0; ho2 = fnv(ho2, &o, 1); }
+        r[46] = hash_as_double(ho2);
+        if (force) F.SetPose(pose_set(force + 64 * (size_t)i + 30));
+        for (int j = 0; j < F.N; j++)
+            if (F.mvpMapPoints[(size_t)j] && F.mvbOutlier[(size_t)j]) { F.mvpMapPoints[(size_t)j] = nullptr; F.mvbOutlier[(size_t)j] = false; }
+        lastPose = F.mTcw.clone();
+        // ---- a keyframe and the local bundle adjustment (src/LocalMapping.cc:123)
+        if (kfEvery > 0 && i % kfEvery == 0 && events < 64) {
+            KeyFrame *pKF = add_keyframe(F);
+            bool stop = false;
+            Optimizer::LocalBundleAdjustment(pKF, &stop, &map);
+            std::vector<KeyFrame *> kfs = map.GetAllKeyFrames();
+            std::sort(kfs.begin(), kfs.end(), by_id_kf);
+            std::vector<MapPoint *> pts = map.GetAllMapPoints();
+            std::sort(pts.begin(), pts.end(), by_id_mp);
+            float *ok = lbaKf + (size_t)events * maxKf * 17, *op = lbaPt + (size_t)events * maxPt * 4;
+            int nk = 0, np = 0, nobs = 0;
+            for (size_t q = 0; q < kfs.size() && nk < maxKf; q++, nk++) {
+                cv::Mat T = kfs[q]->GetPose();
+                ok[17 * nk] = (float)kfs[q]->mnId;
+                for (int e = 0; e < 16; e++) ok[17 * nk + 1 + e] = T.at<float>(e / 4, e % 4);
+            }
+            for (size_t q = 0; q < pts.size() && np < maxPt; q++, np++) {
+                cv::Mat X = pts[q]->GetWorldPos();
+                op[4 * np] = (float)pts[q]->mnId; op[4 * np + 1] = X.at<float>(0); op[4 * np + 2] = X.at<float>(1); op[4 * np + 3] = X.at<float>(2);
+                nobs += pts[q]->Observations();
+            }
+            r[47] = 1; r[48] = nk; r[49] = np; r[50] = nobs; r[51] = events;
+            if (forceLbaKf && forceLbaPt) {      // continue from the other run's optimiser output
+                const float *fk = forceLbaKf + (size_t)events * maxKf * 17, *fp = forceLbaPt + (size_t)events * maxPt * 4;
+                for (int q = 0; q < nk; q++) {
+                    cv::Mat T(4, 4, CV_32F);
+                    for (int e = 0; e < 16; e++) T.at<float>(e / 4, e % 4) = fk[17 * q + 1 + e];
+                    kfs[(size_t)q]->SetPose(T);
+                }
+                for (int q = 0; q < np; q++) {
+                    cv::Mat X(3, 1, CV_32F);
+                    X.at<float>(0) = fp[4 * q + 1]; X.at<float>(1) = fp[4 * q + 2]; X.at<float>(2) = fp[4 * q + 3];
+                    pts[(size_t)q]->SetWorldPos(X);
+                    pts[(size_t)q]->UpdateNormalAndDepth();
+                }
+            } else
+                for (size_t q = 0; q < pts.size(); q++) pts[q]->UpdateNormalAndDepth();
+            refKF = pKF;
+            lastPose = pKF->GetPose();
+            events++;
+        }
+    }
+    *nLbaEvents = events;
+    delete ex;
+    return 0;
+}
+
