@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
                 const uint32_t r0 = udot2(__builtin_amdgcn_perm(v0[r][1], v0[r][0], sel[k]), coef[k], 0u);
                 const uint32_t r1 = udot2(__builtin_amdgcn_perm(v1[r][1], v1[r][0], sel[k]), coef[k], 0u);
                 const uint32_t v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2;
-                out |= (v & 0xffu) << (8 * k);
+                out |= v << (8 * k);      // v <= 255: a0 + a1 and b0 + b1 are 2048 (+-1 from cvRound), so the blend of two bytes cannot reach 256
             }
             *(uint32_t *)(dstBase + (size_t)dy * lv.pitch + dx0) = out;   // pitch is a multiple of 64 >= round_up(w,4)
         }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxGeom *__restrict__ g, 
                 const uint32_t r0 = udot2((uint32_t)S0[off] | ((uint32_t)S0[off1] << 16), coef[k], 0u);
                 const uint32_t r1 = udot2((uint32_t)S1[off] | ((uint32_t)S1[off1] << 16), coef[k], 0u);
                 const uint32_t v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2;
-                out |= (v & 0xffu) << (8 * k);
+                out |= v << (8 * k);      // v <= 255: a0 + a1 and b0 + b1 are 2048 (+-1 from cvRound), so the blend of two bytes cannot reach 256
             }
             *(uint32_t *)(dstBase + (size_t)dy * lv.pitch + dx0) = out;
         }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void k_pyramid_tiles(const OrbxGeom *__restric
                         const uint32_t r0 = udot2(__builtin_amdgcn_perm(v01, v00, sel[k]), coef[k], 0u);
                         const uint32_t r1 = udot2(__builtin_amdgcn_perm(v11, v10, sel[k]), coef[k], 0u);
                         const uint32_t v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2;
-                        out |= (v & 0xffu) << (8 * k);
+                        out |= v << (8 * k);      // v <= 255: a0 + a1 and b0 + b1 are 2048 (+-1 from cvRound), so the blend of two bytes cannot reach 256
                     }
                     *(uint32_t *)(dst + r * dP + 4 * gi) = out;
                     if (ownX && Y >= t.oy0 && Y < t.oy1) *(uint32_t *)(gdst + (size_t)Y * lvPitch + X) = out;
@@ -971,6 +971,7 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+template <bool CLAMP>      // taps that add up to more than 256 (the configuration allows 257): the output needs its clamp
 __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
                                              const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, const int *__restrict__ lvlCnt, int *__restrict__ outBase)
 {
@@ -1007,19 +1008,47 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
             uint4 v;
             if (x >= 0 && x + 15 < w) __builtin_memcpy(&v, row + x, 16);
             else {
-                uint32_t q[4];
+                // a chunk that sticks out of the row: ONE load at the nearest position inside it, the bytes moved to where they belong.  What lies
+                // outside the image is written afterwards (the three mirrored pixels on either side, below); the rest of the window's margin is
+                // never read by a tap.  (The former byte-by-byte BORDER_REFLECT_101 was 170 instructions per chunk for the whole wave - a third of
+                // the kernel's instructions, since almost half of all tiles touch an edge.)
+                const int xs = min(max(x, 0), w - 16), d = x - xs;      // d = -8 at the left edge, 1 .. at the right one
+                uint4 sv;
+                __builtin_memcpy(&sv, row + xs, 16);
+                if (d < 0) v = make_uint4(0u, 0u, sv.x, sv.y);
+                else {
+                    const uint32_t sw[8] = {sv.x, sv.y, sv.z, sv.w, 0u, 0u, 0u, 0u};
+                    const int q = min(d >> 2, 4), bsh = d & 3;
+                    uint32_t o[4];
 #pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    q[d] = 0;
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t lo = 0u, hi = 0u;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { int xx = reflect101(x + 4 * d + k, w); xx = min(max(xx, 0), w - 1); q[d] |= (uint32_t)row[xx] << (8 * k); }
+                        for (int t = 0; t < 8; t++) { lo = (k + q == t) ? sw[t] : lo; hi = (k + q + 1 == t) ? sw[t] : hi; }
+                        o[k] = bsh == 0 ? lo : bsh == 1 ? __builtin_amdgcn_alignbyte(hi, lo, 1) : bsh == 2 ? __builtin_amdgcn_alignbyte(hi, lo, 2) : __builtin_amdgcn_alignbyte(hi, lo, 3);
+                    }
+                    v = make_uint4(o[0], o[1], o[2], o[3]);
                 }
-                v = make_uint4(q[0], q[1], q[2], q[3]);
             }
             *(uint4 *)(in + r * (BT_P / 4) + 4 * c) = v;
         }
     }
     __syncthreads();
+    if (X0 == 0 || X0 + BT_W + 3 > w) {
+        // BORDER_REFLECT_101 in x for the three pixels a 7-tap filter reads beyond either edge: x = -1, -2, -3 <- 1, 2, 3 and x = w, w + 1, w + 2 <- w - 2,
+        // w - 3, w - 4 (window byte of pixel x: x - X0 + 8).  One lane per window row; the rows themselves were mirrored when they were loaded.
+        uint8_t *inb = (uint8_t *)in;
+        if (lane < BT_IH) {
+            uint8_t *rowb = inb + lane * BT_P;
+            if (X0 == 0) { rowb[7] = rowb[9]; rowb[6] = rowb[10]; rowb[5] = rowb[11]; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int xo = w + k - X0 + 8, xi = w - 2 - k - X0 + 8;
+                if (xo >= 0 && xo < BT_P && xi >= 0 && xi < BT_P) rowb[xo] = rowb[xi];
+            }
+        }
+        __syncthreads();
+    }
     const uint32_t k0 = g->taps[0], k1 = g->taps[1], k2 = g->taps[2], k3 = g->taps[3], k4 = g->taps[4], k5 = g->taps[5], k6 = g->taps[6];
     const int gq = lane & 15, rg = lane >> 4;
     const int x = X0 + 4 * gq;
@@ -1046,7 +1075,6 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
     }
     // ---- vertical ----
     const uint32_t V01 = k0 | (k1 << 16), V23 = k2 | (k3 << 16), V45 = k4 | (k5 << 16), V6 = k6;
-    const bool clampNeeded = k0 + k1 + k2 + k3 + k4 + k5 + k6 > 256u;      // (uniform)
     uint32_t outw[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) outw[q] = 0;
@@ -1064,7 +1092,7 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const uint32_t sum = udot2(P[q + 6], V6, udot2(P[q + 4], V45, udot2(P[q + 2], V23, udot2(P[q], V01, 32768u))));
-            if (clampNeeded) outw[q] |= min(sum >> 16, 255u) << (8 * j);
+            if (CLAMP) outw[q] |= min(sum >> 16, 255u) << (8 * j);
             else outw[q] = __builtin_amdgcn_perm(sum, outw[q], selo);
         }
     }
@@ -1421,7 +1449,10 @@ int orbx_launch_octree(const OrbxLaunch &L)
 int orbx_launch_blur(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->blurTiles, (unsigned)L.batch);
-    return emit(L, k_blur, grid, dim3(64), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlCnt, L.outBase);
+    unsigned tapSum = 0;
+    for (int i = 0; i < 7; i++) tapSum += L.geom->taps[i];
+    if (tapSum > 256u) return emit(L, k_blur<true>, grid, dim3(64), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlCnt, L.outBase);
+    return emit(L, k_blur<false>, grid, dim3(64), 0, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlCnt, L.outBase);
 }
 
 int orbx_launch_orient_describe(const OrbxLaunch &L)
