@@ -1068,8 +1068,18 @@ static int comb_build_graph(Combiner *C, CombEngine *E, int n)
         }
     }
     L.deps[0] = cur; if ((rc = chain(orbx_launch_fast_cells(L))) != ORBX_OK) return rc;
-    L.deps[0] = cur; if ((rc = chain(orbx_launch_octree(L))) != ORBX_OK) return rc;
-    L.deps[0] = cur; if ((rc = chain(orbx_launch_blur(L))) != ORBX_OK) return rc;
+    bool fused = false;
+    {   // quadtree, host pyramid copy and blur as one node where k_octree_blur applies (ORBX_COMBINE_FUSE=0: separate nodes, measurement switch)
+        const char *fe = getenv("ORBX_COMBINE_FUSE");
+        L.deps[0] = cur; L.node = &nxt;
+        nxt = nullptr;
+        if (!(fe && fe[0] == '0') && (rc = orbx_launch_octree_blur(L, &fused)) != ORBX_OK) return rc;
+        if (fused) cur = nxt;
+    }
+    if (!fused) {
+        L.deps[0] = cur; if ((rc = chain(orbx_launch_octree(L))) != ORBX_OK) return rc;
+        L.deps[0] = cur; if ((rc = chain(orbx_launch_blur(L))) != ORBX_OK) return rc;
+    }
     L.deps[0] = cur; if ((rc = chain(orbx_launch_orient_describe(L))) != ORBX_OK) return rc;
     L.deps[0] = cur; if ((rc = chain(orbx_launch_comb_finish(L))) != ORBX_OK) return rc;
     ORBX_HIP_CHECK(hipGraphInstantiate(&E->exec[n], g, nullptr, nullptr, 0));

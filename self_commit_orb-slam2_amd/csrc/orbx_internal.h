@@ -129,6 +129,7 @@ int orbx_launch_comb_finish(const OrbxLaunch &L);     /* the engine's results / 
 int orbx_launch_fast_cells(const OrbxLaunch &L);   /* FAST score + cell NMS + emission; L.score (parity tap) may be NULL */
 int orbx_launch_octree(const OrbxLaunch &L);
 int orbx_launch_blur(const OrbxLaunch &L);
+int orbx_launch_octree_blur(const OrbxLaunch &L, bool *fused);   /* combined single-frame calls: quadtree + host pyramid copy + blur in one launch */
 int orbx_launch_orient_describe(const OrbxLaunch &L);   /* IC_Angle + rBRIEF + final KeyPoint in one pass (after the blur) */
 
 /* stream of an extractor handle (orbx_extractor.hip), so other handles can order work after it */

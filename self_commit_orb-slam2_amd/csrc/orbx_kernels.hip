@@ -639,11 +639,12 @@ __device__ __forceinline__ int ot_quadrant(uint32_t p, const OtBox b)
     return (x < mx ? 0 : 1) + (y < my ? 0 : 2);
 }
 
+// The quadtree of ONE (level, frame): the body shared by k_octree (batches: one workgroup per (level, frame) through the XCD bijection) and by
+// k_octree_blur (combined single-frame calls: the blur's tiles and the host pyramid copy ride in the same launch).
 template <int NODECAP>
-__global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, const int *__restrict__ cellCount, const uint32_t *__restrict__ cellSlots,
-                                                const uint8_t *__restrict__ binTab, uint32_t *__restrict__ ptBuf, uint32_t *__restrict__ labBuf,
-                                                OrbxLevelKp *__restrict__ lvlKp, int *__restrict__ lvlCnt, int *__restrict__ status,
-                                                const OrbxCombMember *__restrict__ comb, const uint8_t *__restrict__ engPyr)
+__device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, const int *__restrict__ cellCount, const uint32_t *__restrict__ cellSlots,
+                                            const uint8_t *__restrict__ binTab, uint32_t *__restrict__ ptBuf, uint32_t *__restrict__ labBuf,
+                                            OrbxLevelKp *__restrict__ lvlKp, int *__restrict__ lvlCnt, int *__restrict__ status, const int l, const int f, const int nframes)
 {
     __shared__ OtBox box[2][NODECAP];
     __shared__ int cnt[2][NODECAP];
@@ -658,27 +659,12 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
     __shared__ int sh_misc[8];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    // (level, frame) through the same XCD bijection as the detector before and the descriptor kernel after this stage: a frame's
-    // candidates were written, and its keypoints will be read, by the XCD that owns the frame's range - in the natural order
-    // block (l, f) lands on XCD l, and both hand-overs cross the fabric
-    XCD_REMAP_XY(l, f);
-    if (l >= g->nlevels) {
-        // Combined single-frame calls (comb != NULL, gridDim.x = nlevels + copy blocks): the quadtree is eight latency-bound workgroups per
-        // frame on an otherwise idle device, so the caller's HOST pyramid copy (the public mvImagePyramid; levels >= 1 in the device layout,
-        // 16 bytes per lane across PCIe) travels in the same launch, next to it, instead of as ~19 us at the end of the chain.
-        uint4 *dst = (uint4 *)comb[f].hostPyr;
-        if (!dst) return;
-        const uint4 *src = (const uint4 *)(engPyr + (size_t)f * g->pyrBytes);
-        const size_t n = g->pyrBytes >> 4, stride = (size_t)(gridDim.x - g->nlevels) * 256;
-        for (size_t i = (size_t)(l - g->nlevels) * 256 + tid; i < n; i += stride) dst[i] = src[i];
-        return;
-    }
     const OrbxLevel &lv = g->lv[l];
     const int N = lv.quota;
     uint32_t *pts = ptBuf + (size_t)f * g->slotsPerFrame + lv.slotBase;    // capacity = cells x slots per cell: every candidate the detector can emit
     uint32_t *lab = labBuf + (size_t)f * g->slotsPerFrame + lv.slotBase;
-    int *stat = status + f;          // per-frame word; status[gridDim.y] collects the whole batch (device-visible for resident consumers)
-    int *statAll = status + gridDim.y;
+    int *stat = status + f;          // per-frame word; status[nframes] collects the whole batch (device-visible for resident consumers)
+    int *statAll = status + nframes;
 
     // ---- gather the level's candidates in vToDistributeKeys order (cells row-major) ----
     const int ncell = lv.nCols * lv.nRows;
@@ -883,6 +869,36 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
     }
 }
 
+// the caller's HOST pyramid copy of frame f (the public mvImagePyramid; levels >= 1 in the device layout, 16 bytes per lane across PCIe), chunk `chunk` of `nchunks`
+__device__ __forceinline__ void host_pyramid_copy(const OrbxGeom *__restrict__ g, const OrbxCombMember *__restrict__ comb, const uint8_t *__restrict__ engPyr, int f, int chunk, int nchunks)
+{
+    uint4 *dst = (uint4 *)comb[f].hostPyr;
+    if (!dst) return;
+    const uint4 *src = (const uint4 *)(engPyr + (size_t)f * g->pyrBytes);
+    const size_t n = g->pyrBytes >> 4, stride = (size_t)nchunks * 256;
+    for (size_t i = (size_t)chunk * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+template <int NODECAP>
+__global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, const int *__restrict__ cellCount, const uint32_t *__restrict__ cellSlots,
+                                                const uint8_t *__restrict__ binTab, uint32_t *__restrict__ ptBuf, uint32_t *__restrict__ labBuf,
+                                                OrbxLevelKp *__restrict__ lvlKp, int *__restrict__ lvlCnt, int *__restrict__ status,
+                                                const OrbxCombMember *__restrict__ comb, const uint8_t *__restrict__ engPyr)
+{
+    // (level, frame) through the same XCD bijection as the detector before and the descriptor kernel after this stage: a frame's
+    // candidates were written, and its keypoints will be read, by the XCD that owns the frame's range - in the natural order
+    // block (l, f) lands on XCD l, and both hand-overs cross the fabric
+    XCD_REMAP_XY(l, f);
+    if (l >= g->nlevels) {
+        // Combined single-frame calls (comb != NULL, gridDim.x = nlevels + copy blocks): the quadtree is eight latency-bound workgroups per
+        // frame on an otherwise idle device, so the caller's host pyramid copy travels in the same launch, next to it, instead of as ~19 us
+        // at the end of the chain.
+        host_pyramid_copy(g, comb, engPyr, f, l - g->nlevels, (int)gridDim.x - g->nlevels);
+        return;
+    }
+    octree_body<NODECAP>(g, cellCount, cellSlots, binTab, ptBuf, labBuf, lvlKp, lvlCnt, status, l, f, (int)gridDim.y);
+}
+
 // sin/cos of the keypoint angle: glibc's sinf/cosf algorithm in double, restated so the device
 // rounds like the libm the reference calls (oracle/prims.h op_sincosf, tests/test_sincos.py).
 __device__ __forceinline__ float sinf_poly_d(double x, double x2, int n, bool neg)
@@ -971,20 +987,14 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// One 64 x 32 tile of the blurred pyramid by ONE wave: the body shared by k_blur (batches: one single-wave workgroup per tile) and k_octree_blur
+// (combined single-frame calls: four tiles per 256-thread workgroup, next to the quadtree's workgroups).  `in` = the wave's own LDS window,
+// `store` = false for the padding waves of the last workgroup (they run through the same barriers and store nothing).
 template <bool CLAMP>      // taps that add up to more than 256 (the configuration allows 257): the output needs its clamp
-__global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
-                                             const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, const int *__restrict__ lvlCnt, int *__restrict__ outBase)
+__device__ __forceinline__ void blur_body(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                          const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, const int bx, const int f, uint32_t *__restrict__ in, const int lane,
+                                          const bool store)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t in[BT_IH * (BT_P / 4)];
-    XCD_REMAP_XY(bx, f);
-    const int lane = threadIdx.x;
-    if (bx == 0 && lane == 0) {
-        // rides along (the quadtree precedes this kernel, the descriptor kernel follows it): where each level's keypoints start in the frame's
-        // output list (level 0..n-1 in order, src/ORBextractor.cc:1577-1668), so that the per-keypoint waves of k_orient_describe need two
-        // scalar loads instead of a prefix sum over the levels each
-        int run = 0;
-        for (int i = 0; i < g->nlevels; i++) { outBase[f * g->nlevels + i] = run; run += lvlCnt[f * g->nlevels + i]; }
-    }
     int bases[ORBX_MAX_LEVELS];
     const int nl = g->nlevels;
     for (int i = 0; i < nl; i++) bases[i] = g->lv[i].blurTileBase;
@@ -1047,12 +1057,12 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
                 if (xo >= 0 && xo < BT_P && xi >= 0 && xi < BT_P) rowb[xo] = rowb[xi];
             }
         }
-        __syncthreads();
     }
+    __syncthreads();      // (unconditional: in k_octree_blur four waves with different tiles share the workgroup's barriers)
     const uint32_t k0 = g->taps[0], k1 = g->taps[1], k2 = g->taps[2], k3 = g->taps[3], k4 = g->taps[4], k5 = g->taps[5], k6 = g->taps[6];
     const int gq = lane & 15, rg = lane >> 4;
     const int x = X0 + 4 * gq;
-    if (x >= w || Y0 + 8 * rg >= h) return;
+    if (!store || x >= w || Y0 + 8 * rg >= h) return;
     // ---- horizontal: rows 8rg .. 8rg+13 of the window; pixel j of the group = bytes 1+j .. 7+j of (w0,w1,w2) ----
     // The TAPS are shifted, not the data: pixel j's seven taps sit at bytes 1+j .. 7+j of a 12-byte tap vector (uniform: scalar registers), so
     // a pixel is two or three v_dot4_u32_u8 on the window words as loaded - 10 per row of four pixels, where byte-aligning the window for every
@@ -1103,6 +1113,43 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
         if (y >= h) break;
         *(uint32_t *)(dst + (size_t)y * lv.pitch + x) = outw[q];   // pitch >= round_up(w,4): bytes beyond w are padding
     }
+}
+
+template <bool CLAMP>
+__global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                             const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, const int *__restrict__ lvlCnt, int *__restrict__ outBase)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t in[BT_IH * (BT_P / 4)];
+    XCD_REMAP_XY(bx, f);
+    if (bx == 0 && threadIdx.x == 0 && outBase) {
+        // rides along in the batch path (the quadtree precedes this kernel, the descriptor kernel follows it): where each level's keypoints start in the
+        // frame's output list (level 0..n-1 in order, src/ORBextractor.cc:1577-1668), so that the 270k per-keypoint waves of k_orient_describe need two scalar
+        // loads instead of a prefix sum each (its own per-workgroup prefix, used by the combined single-frame calls, costs a batch 3.5 % of that kernel)
+        int run = 0;
+        for (int i = 0; i < g->nlevels; i++) { outBase[f * g->nlevels + i] = run; run += lvlCnt[f * g->nlevels + i]; }
+    }
+    blur_body<CLAMP>(g, img0, img0Stride, img0FramePitch, pyr, blur, bx, f, in, (int)threadIdx.x, true);
+}
+
+// Combined single-frame calls: quadtree, host pyramid copy AND blur in one launch.  The quadtree is eight workgroups of dependent latency
+// (~30 us for a 640x480 level 0) on a device that has nothing else to do; the blur needs nothing from it (the descriptor kernel takes the
+// level prefix of the output list from the counts itself), so its tiles - four per workgroup, one wave each - run beside it instead of
+// behind it: one kernel boundary and the blur's own ~7-13 us off the chain of every launch set.  Batches keep the separate launches
+// (k_octree's 20 KB of LDS per workgroup would cap the blur's occupancy there).  blockIdx.x: [0, nlevels) quadtree, then the copy
+// workgroups, then the blur workgroups; blockIdx.y = frame.
+template <int NODECAP, bool CLAMP>
+__global__ __launch_bounds__(256) void k_octree_blur(const OrbxGeom *__restrict__ g, const int *__restrict__ cellCount, const uint32_t *__restrict__ cellSlots,
+                                                     const uint8_t *__restrict__ binTab, uint32_t *__restrict__ ptBuf, uint32_t *__restrict__ labBuf,
+                                                     OrbxLevelKp *__restrict__ lvlKp, int *__restrict__ lvlCnt, int *__restrict__ status,
+                                                     const OrbxCombMember *__restrict__ comb, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                                     uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t blurLds[];      // 4 windows of BT_IH x BT_P bytes (the blur role)
+    const int bx = (int)blockIdx.x, f = (int)blockIdx.y, nl = g->nlevels;
+    if (bx < nl) { octree_body<NODECAP>(g, cellCount, cellSlots, binTab, ptBuf, labBuf, lvlKp, lvlCnt, status, bx, f, (int)gridDim.y); return; }
+    if (bx < nl + ORBX_OCTREE_COPY_BLOCKS) { host_pyramid_copy(g, comb, pyr, f, bx - nl, ORBX_OCTREE_COPY_BLOCKS); return; }
+    const int wv = (int)(threadIdx.x >> 6), tile = __builtin_amdgcn_readfirstlane((bx - nl - ORBX_OCTREE_COPY_BLOCKS) * 4 + wv);      // (uniform in the wave: scalar bookkeeping)
+    blur_body<CLAMP>(g, img0, img0Stride, img0FramePitch, pyr, blur, min(tile, g->blurTiles - 1), f, blurLds + wv * (BT_IH * (BT_P / 4)), (int)(threadIdx.x & 63), tile < g->blurTiles);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1156,6 +1203,7 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
     __shared__ __attribute__((aligned(16))) float sPat[256][4];                  // test pair t as floats: x0, x1, y0, y1
     __shared__ __attribute__((aligned(16))) uint32_t sDisc[64][4];               // byte masks of the disc: lane (row, half) x 4 dwords
     __shared__ int sMom[OD_WPB][3];
+    __shared__ int sBase[ORBX_MAX_LEVELS];
     __shared__ float sTrig[OD_WPB][3];
     XCD_REMAP_XY(bx, f);
     const int lane = threadIdx.x & 63;
@@ -1166,6 +1214,13 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
     }
     const int slot = bx * OD_WPB + wv;
     const int *cnts = lvlCnt + f * A.nlevels;
+    // where each level's keypoints start in the frame's output list (level 0 .. n-1 in order, src/ORBextractor.cc:1577-1668): once per workgroup,
+    // lane = level, into LDS (k_blur's first workgroup used to leave it in global memory; the blur no longer has to run behind the quadtree for it)
+    if (!outBase && threadIdx.x < (unsigned)A.nlevels) {      // (batches: k_blur's first workgroup left the prefix in outBase)
+        int run = 0;
+        for (int i = 0; i < (int)threadIdx.x; i++) run += cnts[i];
+        sBase[threadIdx.x] = run;
+    }
     if (bx == 0 && threadIdx.x == 0) {
         int tot = 0;
         for (int i = 0; i < A.nlevels; i++) tot += cnts[i];
@@ -1185,8 +1240,7 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
         l += ge ? 1 : 0; kb = ge ? A.kpBase[i] : kb;
     }
     const int idx = slot - kb;
-    const int outIdx = outBase[f * A.nlevels + l] + idx;                             // level prefix from k_blur
-    inRange = inRange && idx < cnts[l] && outIdx < A.outCap;
+    inRange = inRange && idx < cnts[l];
     const bool live = inRange;
     const uint2 kraw = *(const uint2 *)&lvlKp[(size_t)f * A.kpPerFrame + (inRange ? slot : 0)];     // x | y << 16, score | pad: the first 8 bytes of OrbxLevelKp
     const int kx = (int)(kraw.x & 0xffffu), ky = (int)(kraw.x >> 16);
@@ -1262,6 +1316,8 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
         const int t0 = pb[o0], t1 = pb[o1];
         bits[rd] = __ballot(t0 < t1);
     }
+    const int outIdx = (outBase ? outBase[f * A.nlevels + l] : sBase[l]) + idx;      // (< outCap: the output capacity is the sum of the levels' capacities)
+    if (outIdx >= A.outCap) return;
     unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * A.outCap + outIdx) * 32);
     if (lane < 4) d64[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
     if (lane == 0) {
@@ -1446,6 +1502,25 @@ int orbx_launch_octree(const OrbxLaunch &L)
 #undef OT_LAUNCH
 }
 
+// combined single-frame calls: quadtree + host pyramid copy + blur as ONE launch (k_octree_blur); *fused = false where that kernel does not
+// apply (large per-level quotas: the quadtree's LDS leaves no room for the blur windows) and the caller launches the two stages separately
+int orbx_launch_octree_blur(const OrbxLaunch &L, bool *fused)
+{
+    *fused = false;
+    if (!L.combTab || L.nodeCap > 512) return ORBX_OK;
+    unsigned tapSum = 0;
+    for (int i = 0; i < 7; i++) tapSum += L.geom->taps[i];
+    const dim3 grid((unsigned)(L.geom->nlevels + ORBX_OCTREE_COPY_BLOCKS + (L.geom->blurTiles + 3) / 4), (unsigned)L.batch);
+    const size_t lds = (size_t)4 * BT_IH * BT_P;
+    *fused = true;
+#define OB_LAUNCH(NC, CL) return emit(L, k_octree_blur<NC, CL>, grid, dim3(256), lds, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.labBuf, L.lvlKp, L.lvlCnt, L.status, L.combTab, \
+                                      L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur)
+    if (L.nodeCap <= 256) { if (tapSum > 256u) OB_LAUNCH(256, true); OB_LAUNCH(256, false); }
+    if (tapSum > 256u) OB_LAUNCH(512, true);
+    OB_LAUNCH(512, false);
+#undef OB_LAUNCH
+}
+
 int orbx_launch_blur(const OrbxLaunch &L)
 {
     dim3 grid((unsigned)L.geom->blurTiles, (unsigned)L.batch);
@@ -1466,6 +1541,6 @@ int orbx_launch_orient_describe(const OrbxLaunch &L)
     for (int l = 0; l < g.nlevels; l++) { A.kpBase[l] = g.lv[l].kpBase; A.off[l] = g.lv[l].off; A.pitch[l] = g.lv[l].pitch; A.patch[l] = g.lv[l].patchSize; A.scale[l] = g.lv[l].scale; }
     for (int i = 0; i < 16; i++)
         if (g.umax[i] != kUmax[i]) { orbx_set_error("disc half-widths differ from the compiled table"); return ORBX_ERR_STATE; }
-    return emit(L, k_orient_describe, grid, dim3(64 * OD_WPB), 0, A, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.outBase, L.outKp, L.outDesc,
+    return emit(L, k_orient_describe, grid, dim3(64 * OD_WPB), 0, A, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.combTab ? (const int *)nullptr : (const int *)L.outBase, L.outKp, L.outDesc,
                 L.outCnt, L.status, L.outStatus);
 }
