@@ -318,6 +318,12 @@ int orbx_stereo_download(orbx_matcher *m, int npairs, float *uright, float *dept
  * uright[i] / depth[i] = mvuRight / mvDepth of left keypoint i, i < n.  Synchronous; the latency form of
  * orbx_compute_stereo_matches_device + orbx_stereo_download (same kernels, three launches and one wait instead of ~22 runtime calls). */
 int orbx_stereo_frame(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, float mbf, float mb, float *uright, float *depth, int n);
+/* The same call in two halves: _begin launches and returns at once, _end waits and copies mvuRight / mvDepth out.  Neither extractor may
+ * be called in between.  shim/Frame_hip.cc begins on the extractor thread that finishes last in the stereo constructor (src/Frame.cc:
+ * 159-167), before that thread converts its keypoints, and ends in Frame::ComputeStereoMatches (:168): the match runs while the host
+ * fills mvKeysRight and joins the threads. */
+int orbx_stereo_frame_begin(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, float mbf, float mb);
+int orbx_stereo_frame_end(orbx_matcher *m, float *uright, float *depth, int n);
 
 /* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)
  * (ORBmatcher.h, src/ORBmatcher.cc:70-175; called by Tracking::SearchLocalPoints, src/Tracking.cc:1616)
@@ -607,6 +613,13 @@ int orbx_frame_results_device(orbx_frame_ops *h, const orbx_keypoint **kp_un_dev
                               const int32_t **grid_indices_dev, int *capacity);
 int orbx_frame_download(orbx_frame_ops *h, orbx_extractor *ext, int batch, orbx_keypoint *kp_un, int32_t *grid_offsets,
                         int32_t *grid_indices);
+/* Latency form for ONE frame that `ext`'s last single-frame call extracted (the Frame constructors, src/Frame.cc:168-234, 394-456):
+ * _begin launches the fused kernel on the handle's own stream, reading the keypoints where the extractor left them on the device and
+ * writing mvKeysUn / the grid into the handle's pinned memory, and returns at once (grid == NULL: undistort only); _end waits and hands
+ * out pointers INTO that pinned memory, valid until the next call on the handle: kp_un (NULL when the camera is not distorted: mvKeysUn
+ * = mvKeys, src/Frame.cc:901-905), grid_offsets[64*48+1], grid_indices[n].  `ext` must not be called in between. */
+int orbx_frame_finish_begin(orbx_frame_ops *h, orbx_extractor *ext, const orbx_frame_grid *grid);
+int orbx_frame_finish_end(orbx_frame_ops *h, const orbx_keypoint **kp_un, const int32_t **grid_offsets, const int32_t **grid_indices, int *n);
 
 
 /* ------------------------------------------------------------------------------------

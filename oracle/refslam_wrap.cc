@@ -201,6 +201,12 @@ ORBSLAM_API int orbslam_descriptor_distance(const uint8_t *a, const uint8_t *b)
 
 // Frame::Frame(imLeft, imRight, ...) with two reference extractors.  Keypoints as 7 floats
 // each.  Returns 0; *nL / *nR receive the real counts (only `cap` entries are written).
+// Test switch: 0 (default) = every frame wrapper below starts from Frame::mbInitialComputations = true (the first frame of a run: image
+// bounds and grid statics are computed, src/Frame.cc:203-221); 1 = the statics of the previous call are kept, i.e. the wrapper builds a
+// LATER frame of the same camera - the path every frame but the first takes.
+static int g_keep_statics = 0;
+ORBSLAM_API void orbslam_keep_frame_statics(int keep) { g_keep_statics = keep; }
+
 ORBSLAM_API int orbslam_stereo_frame(const uint8_t *imL, const uint8_t *imR, int w, int h, int stride, int nfeatures,
                                      float scaleFactor, int nlevels, int iniTh, int minTh, float fx, float fy, float cx,
                                      float cy, float bf, float thDepth, float *kpsL, uint8_t *descL, float *kpsR,
@@ -211,7 +217,7 @@ ORBSLAM_API int orbslam_stereo_frame(const uint8_t *imL, const uint8_t *imR, int
     ORBextractor *exR = new ORBextractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
     cv::Mat L(h, w, CV_8UC1, (void *)imL, (size_t)stride), R(h, w, CV_8UC1, (void *)imR, (size_t)stride);
     cv::Mat K = make_K(fx, fy, cx, cy), dist = cv::Mat::zeros(4, 1, CV_32F);
-    Frame::mbInitialComputations = true;
+    if (!g_keep_statics) Frame::mbInitialComputations = true;
     {
         Frame F(L, R, 0.0, exL, exR, (ORBVocabulary *)nullptr, K, dist, bf, thDepth);
         *nL = F.N;
@@ -238,6 +244,8 @@ ORBSLAM_API int orbslam_stereo_frame(const uint8_t *imL, const uint8_t *imR, int
 // extractor threads -> one combined launch set, ComputeStereoMatches on the device).  No arena scope: allocation order plays no role here.
 #include <algorithm>
 #include <chrono>
+extern "C" void orbx_shim_trace_mark(const char *name) __attribute__((weak));      // shim/Frame_hip.cc (the drop-in library only)
+static inline void trace_mark(const char *name) { if (orbx_shim_trace_mark) orbx_shim_trace_mark(name); }
 ORBSLAM_API int orbslam_stereo_frame_bench(const uint8_t *const *imL, const uint8_t *const *imR, int nimg, int w, int h, int stride, int nfeatures,
                                            float scaleFactor, int nlevels, int iniTh, int minTh, float fx, float fy, float cx, float cy, float bf,
                                            float thDepth, int iters, double *mean_us, double *median_us, int *nLeft, int *nMatched)
@@ -252,8 +260,10 @@ ORBSLAM_API int orbslam_stereo_frame_bench(const uint8_t *const *imL, const uint
         const int k = (i + 5) % nimg;
         cv::Mat L(h, w, CV_8UC1, (void *)imL[k], (size_t)stride), R(h, w, CV_8UC1, (void *)imR[k], (size_t)stride);
         const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        trace_mark("Frame::Frame(stereo) called");
         Frame F(L, R, 0.0, exL, exR, (ORBVocabulary *)nullptr, K, dist, bf, thDepth);
         const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
+        trace_mark("Frame::Frame(stereo) returned");
         if (i >= 0) t[(size_t)i] = std::chrono::duration<double, std::micro>(t1 - t0).count();
         nl = F.N; nm = 0;
         for (int j = 0; j < F.N; j++) nm += F.mvuRight[j] >= 0.0f;
@@ -261,6 +271,9 @@ ORBSLAM_API int orbslam_stereo_frame_bench(const uint8_t *const *imL, const uint
     double sum = 0;
     for (int i = 0; i < iters; i++) sum += t[(size_t)i];
     std::sort(t.begin(), t.begin() + iters);
+    if (getenv("ORBSLAM_BENCH_QUANTILES") && iters >= 10)
+        fprintf(stderr, "[orbslam_stereo_frame_bench] %d constructors: min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us\n", iters, t[0], t[(size_t)iters / 10],
+                t[(size_t)iters / 2], t[(size_t)iters * 9 / 10], t[(size_t)iters * 99 / 100], t[(size_t)iters - 1]);
     *mean_us = sum / std::max(iters, 1); *median_us = t[(size_t)iters / 2]; *nLeft = nl; *nMatched = nm;
     delete exL;
     delete exR;
@@ -282,7 +295,7 @@ ORBSLAM_API int orbslam_mono_frame(const uint8_t *im, int w, int h, int stride, 
     cv::Mat I(h, w, CV_8UC1, (void *)im, (size_t)stride);
     cv::Mat K = make_K(fx, fy, cx, cy), D(ndist, 1, CV_32F);
     for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
-    Frame::mbInitialComputations = true;
+    if (!g_keep_statics) Frame::mbInitialComputations = true;
     {
         CallerArena arena;
         Frame F(I, 0.0, ex, (ORBVocabulary *)nullptr, K, D, 40.0f, 40.0f);

@@ -488,6 +488,7 @@ bool orbx_extractor_host_complete_internal(orbx_extractor *h, int *status)
     if (status) *status = ((const int *)h->hostOut)[1];
     return true;
 }
+int orbx_extractor_host_count_internal(orbx_extractor *h) { return h && h->hostOut ? ((const int *)h->hostOut)[0] : 0; }
 void orbx_extractor_set_consumer_event_internal(orbx_extractor *h, hipEvent_t ev) { if (h) h->consumerEv[h->cur] = ev; }
 void orbx_extractor_set_pyramid_consumer_event_internal(orbx_extractor *h, hipEvent_t ev) { if (h) h->pyrConsumerEv = ev; }
 int orbx_extractor_last_batch_view_internal(orbx_extractor *h, OrbxLastBatchView *v)

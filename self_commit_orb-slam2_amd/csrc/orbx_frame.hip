@@ -18,6 +18,9 @@
 // extraction it follows on the same stream.
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
+
 #include "orbx_internal.h"
 
 namespace {
@@ -60,12 +63,17 @@ __global__ void k_undistort_corners(CamDev c, float cols, float rows, float *out
 }
 
 // undistort: kp -> kpUn (else kp is already mvKeysUn and kpUn may be NULL); grid: build the CSR
-__global__ __launch_bounds__(256) void k_frame_finish(CamDev c, orbx_frame_grid g, int undistort, int grid, const orbx_keypoint *__restrict__ kp,
-                                                      const int32_t *__restrict__ counts, int cap, orbx_keypoint *__restrict__ kpUn,
-                                                      int32_t *__restrict__ gridOff, int32_t *__restrict__ gridIdx)
+// FT threads per frame (1024: the kernel is one workgroup's chain of dependent steps - histogram, scan, scatter, sort, write-out -, sixteen
+// waves shorten every one of them; 24 -> 11 us for 2000 keypoints).  doneFlag != NULL (latency form, one frame): doneSeq is written there
+// - pinned host memory - after the last result, the host polls it instead of synchronising the stream.
+#define FT 1024
+static_assert(NCELL % FT == 0, "cells per thread");
+__global__ __launch_bounds__(FT) void k_frame_finish(CamDev c, orbx_frame_grid g, int undistort, int grid, const orbx_keypoint *__restrict__ kp,
+                                                     const int32_t *__restrict__ counts, int cap, orbx_keypoint *__restrict__ kpUn,
+                                                     int32_t *__restrict__ gridOff, int32_t *__restrict__ gridIdx, int *__restrict__ doneFlag, int doneSeq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int sWave[4];
+    __shared__ int sWave[FT / 64];
     int *cnt = (int *)smem;                                   // [NCELL] counts, then cursors
     int *off = cnt + NCELL;                                   // [NCELL + 1]
     unsigned short *cell = (unsigned short *)(off + NCELL + 1 + 1);   // [cap]
@@ -73,9 +81,9 @@ __global__ __launch_bounds__(256) void k_frame_finish(CamDev c, orbx_frame_grid 
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = counts ? min(counts[f], cap) : cap;
     const orbx_keypoint *in = kp + (size_t)f * cap;
-    for (int t = tid; t < NCELL; t += 256) cnt[t] = 0;
+    for (int t = tid; t < NCELL; t += FT) cnt[t] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += FT) {
         orbx_keypoint k = in[i];
         if (undistort) {
             if (c.distorted) undistort_point(c, k.x, k.y, &k.x, &k.y);   // else mvKeysUn = mvKeys, src/Frame.cc:901-905
@@ -89,10 +97,17 @@ __global__ __launch_bounds__(256) void k_frame_finish(CamDev c, orbx_frame_grid 
             cell[i] = (unsigned short)ce;
         }
     }
-    if (!grid) return;
+    if (!grid) {
+        if (doneFlag) {
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(doneFlag, doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     __syncthreads();
     // exclusive scan of the NCELL counts: 12 consecutive cells per thread
-    const int PER = NCELL / 256;
+    const int PER = NCELL / FT;
     int local = 0;
     for (int t = 0; t < PER; t++) local += cnt[tid * PER + t];
     int incl = local;
@@ -103,16 +118,16 @@ __global__ __launch_bounds__(256) void k_frame_finish(CamDev c, orbx_frame_grid 
     int base = incl - local;
     for (int w = 0; w < wv; w++) base += sWave[w];
     for (int t = 0; t < PER; t++) { const int cval = cnt[tid * PER + t]; off[tid * PER + t] = base; base += cval; }
-    if (tid == 255) off[NCELL] = base;
+    if (tid == FT - 1) off[NCELL] = base;
     __syncthreads();
-    for (int t = tid; t < NCELL; t += 256) cnt[t] = off[t];   // cursors
+    for (int t = tid; t < NCELL; t += FT) cnt[t] = off[t];   // cursors
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += FT) {
         const int ce = cell[i];
         if (ce != 0xffff) sorted[atomicAdd(&cnt[ce], 1)] = i;
     }
     __syncthreads();
-    for (int ce = tid; ce < NCELL; ce += 256) {
+    for (int ce = tid; ce < NCELL; ce += FT) {
         const int b = off[ce], e = off[ce + 1];
         for (int a = b + 1; a < e; a++) {
             const int v = sorted[a];
@@ -123,9 +138,14 @@ __global__ __launch_bounds__(256) void k_frame_finish(CamDev c, orbx_frame_grid 
     }
     __syncthreads();
     int32_t *go = gridOff + (size_t)f * (NCELL + 1), *gi = gridIdx + (size_t)f * cap;
-    for (int t = tid; t <= NCELL; t += 256) go[t] = off[t];
+    for (int t = tid; t <= NCELL; t += FT) go[t] = off[t];
     const int total = off[NCELL];
-    for (int t = tid; t < total; t += 256) gi[t] = sorted[t];
+    for (int t = tid; t < total; t += FT) gi[t] = sorted[t];
+    if (doneFlag) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(doneFlag, doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace
@@ -144,6 +164,11 @@ struct orbx_frame_ops {
     bool producerValid[2] = {false, false};
     uint8_t *hostIO = nullptr, *hostIODev = nullptr;   // pinned: inputs and outputs of the host-array forms, read / written by the kernel itself
     size_t hostIOBytes = 0;
+    // orbx_frame_finish_begin .. _end: offsets of mvKeysUn / grid offsets / grid indices inside hostIO, the frame's keypoint count
+    int pending = 0, pendingN = 0;
+    bool pendingUn = false, pendingGrid = false;
+    size_t pendUn = 0, pendOff = 0, pendIdx = 0, pendFlag = 0;
+    int pendSeq = 0;
     OrbxDevBuf<orbx_keypoint> hostKp;
     OrbxDevBuf<int32_t> hostCount;
     OrbxDevBuf<float> corners;
@@ -218,8 +243,8 @@ static int launch_finish(orbx_frame_ops *h, hipStream_t stream, const orbx_frame
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_frame_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     orbx_frame_grid g = {0.0f, 0.0f, 0.0f, 0.0f};
     if (grid) g = *grid;
-    hipLaunchKernelGGL(k_frame_finish, dim3((unsigned)batch), dim3(256), lds, stream, h->cam, g, undistort ? 1 : 0, grid ? 1 : 0, kp, counts, cap,
-                       undistort ? h->kpUn[b].p : nullptr, grid ? h->gridOff[b].p : nullptr, grid ? h->gridIdx[b].p : nullptr);
+    hipLaunchKernelGGL(k_frame_finish, dim3((unsigned)batch), dim3(FT), lds, stream, h->cam, g, undistort ? 1 : 0, grid ? 1 : 0, kp, counts, cap,
+                       undistort ? h->kpUn[b].p : nullptr, grid ? h->gridOff[b].p : nullptr, grid ? h->gridIdx[b].p : nullptr, (int *)nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     h->lastBatch = batch; h->lastCap = cap;
@@ -286,6 +311,7 @@ static int host_form(orbx_frame_ops *h, const orbx_frame_grid *grid, bool undist
                      int32_t *grid_offsets, int32_t *grid_indices)
 {
     ORBX_HIP_CHECK(hipSetDevice(h->device));
+    h->pending = 0;      // (the pinned buffer is reused: a frame begun with orbx_frame_finish_begin and not ended is dropped)
     const int cap = n > 0 ? n : 1;
     if (cap > 0xfff0) { orbx_set_error("feature capacity %d out of range", cap); return ORBX_ERR_CAPACITY; }
     const size_t A = 256, szKp = ((size_t)cap * sizeof(orbx_keypoint) + A - 1) / A * A, szIdx = ((size_t)cap * 4 + A - 1) / A * A, szOff = ((size_t)(NCELL + 1) * 4 + A - 1) / A * A;
@@ -308,14 +334,87 @@ static int host_form(orbx_frame_ops *h, const orbx_frame_grid *grid, bool undist
     orbx_frame_grid g = {0.0f, 0.0f, 0.0f, 0.0f};
     if (grid) g = *grid;
     uint8_t *d = h->hostIODev;
-    hipLaunchKernelGGL(k_frame_finish, dim3(1), dim3(256), lds, h->stream, h->cam, g, undistort ? 1 : 0, grid ? 1 : 0, (const orbx_keypoint *)(d + oIn), (const int32_t *)(d + oCnt), cap,
-                       undistort ? (orbx_keypoint *)(d + oUn) : nullptr, grid ? (int32_t *)(d + oOff) : nullptr, grid ? (int32_t *)(d + oIdx) : nullptr);
+    hipLaunchKernelGGL(k_frame_finish, dim3(1), dim3(FT), lds, h->stream, h->cam, g, undistort ? 1 : 0, grid ? 1 : 0, (const orbx_keypoint *)(d + oIn), (const int32_t *)(d + oCnt), cap,
+                       undistort ? (orbx_keypoint *)(d + oUn) : nullptr, grid ? (int32_t *)(d + oOff) : nullptr, grid ? (int32_t *)(d + oIdx) : nullptr, (int *)nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     if (undistort && n > 0 && kp_un) memcpy(kp_un, h->hostIO + oUn, (size_t)n * sizeof(orbx_keypoint));
     if (grid && grid_offsets) memcpy(grid_offsets, h->hostIO + oOff, (size_t)(NCELL + 1) * 4);
     if (grid && n > 0 && grid_indices) memcpy(grid_indices, h->hostIO + oIdx, (size_t)n * 4);
+    return ORBX_OK;
+}
+
+// The latency form behind the Frame constructors (include/orbx.h): input = the extractor's device-resident keypoints of its last single-frame
+// call, output = this handle's pinned memory, written by the kernel itself; nothing is waited for here.
+extern "C" int orbx_frame_finish_begin(orbx_frame_ops *h, orbx_extractor *ext, const orbx_frame_grid *grid)
+{
+    if (!h || !ext) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    h->pending = 0;
+    int st = 0;
+    if (!orbx_extractor_host_complete_internal(ext, &st)) { orbx_set_error("the extractor's last call was not a completed single-frame call"); return ORBX_ERR_STATE; }
+    if (st) { orbx_set_error("the extractor call these features come from overflowed a device capacity (bits 0x%x): results are not the reference's", st); return ORBX_ERR_CAPACITY; }
+    OrbxLastBatchView view;
+    int rc = orbx_extractor_last_batch_view_internal(ext, &view);
+    if (rc != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipSetDevice(h->device));
+    const int cap = view.cap, n = orbx_extractor_host_count_internal(ext);
+    if (cap < 1 || cap > 0xfff0 || n > cap) { orbx_set_error("feature capacity %d out of range", cap); return ORBX_ERR_CAPACITY; }
+    const bool undist = h->cam.distorted != 0;
+    if (!undist && !grid) { h->pending = 1; h->pendingN = n; h->pendingUn = h->pendingGrid = false; return ORBX_OK; }      // (nothing to compute)
+    const size_t A = 256, szKp = ((size_t)cap * sizeof(orbx_keypoint) + A - 1) / A * A, szIdx = ((size_t)cap * 4 + A - 1) / A * A, szOff = ((size_t)(NCELL + 1) * 4 + A - 1) / A * A;
+    const size_t oUn = 0, oOff = oUn + szKp, oIdx = oOff + szOff, oFlag = oIdx + szIdx, total = oFlag + A + szKp + A;      // (+ the host-array forms' input area: one buffer serves both)
+    if (total > h->hostIOBytes) {
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->hostIO) (void)hipHostFree(h->hostIO);
+        h->hostIO = nullptr; h->hostIOBytes = 0;
+        ORBX_HIP_CHECK(hipHostMalloc((void **)&h->hostIO, total, hipHostMallocDefault));
+        void *dp = nullptr;
+        ORBX_HIP_CHECK(hipHostGetDevicePointer(&dp, h->hostIO, 0));
+        h->hostIODev = (uint8_t *)dp;
+        h->hostIOBytes = total;
+    }
+    const size_t lds = (size_t)(2 * NCELL + 2) * 4 + (size_t)((cap + 7) & ~7) * 2 + (size_t)cap * 4;
+    if (lds > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", cap); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_frame_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    orbx_frame_grid g = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (grid) g = *grid;
+    uint8_t *d = h->hostIODev;
+    const int seq = ++h->pendSeq;
+    *(volatile int *)(h->hostIO + oFlag) = 0;
+    hipLaunchKernelGGL(k_frame_finish, dim3(1), dim3(FT), lds, h->stream, h->cam, g, undist ? 1 : 0, grid ? 1 : 0, view.kp, view.counts, cap,
+                       undist ? (orbx_keypoint *)(d + oUn) : nullptr, grid ? (int32_t *)(d + oOff) : nullptr, grid ? (int32_t *)(d + oIdx) : nullptr, (int *)(d + oFlag), seq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+    h->pending = 2; h->pendingN = n; h->pendingUn = undist; h->pendingGrid = grid != nullptr;
+    h->pendUn = oUn; h->pendOff = oOff; h->pendIdx = oIdx; h->pendFlag = oFlag;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_frame_finish_end(orbx_frame_ops *h, const orbx_keypoint **kp_un, const int32_t **grid_offsets, const int32_t **grid_indices, int *n)
+{
+    if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
+    const int pending = h->pending;
+    h->pending = 0;
+    if (!pending) { orbx_set_error("no frame has been begun"); return ORBX_ERR_STATE; }
+    if (pending == 2) {      // the kernel's completion word in pinned memory (written behind its last result); the stream only if that takes implausibly long
+        const volatile int *flag = (const volatile int *)(h->hostIO + h->pendFlag);
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        bool arrived = false;
+        for (int spin = 0; !(arrived = *flag == h->pendSeq); spin++) {
+            __builtin_ia32_pause();
+            if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!arrived) {
+            ORBX_HIP_CHECK(hipSetDevice(h->device));
+            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+        }
+    }
+    if (kp_un) *kp_un = h->pendingUn ? (const orbx_keypoint *)(h->hostIO + h->pendUn) : nullptr;
+    if (grid_offsets) *grid_offsets = h->pendingGrid ? (const int32_t *)(h->hostIO + h->pendOff) : nullptr;
+    if (grid_indices) *grid_indices = h->pendingGrid ? (const int32_t *)(h->hostIO + h->pendIdx) : nullptr;
+    if (n) *n = h->pendingN;
     return ORBX_OK;
 }
 

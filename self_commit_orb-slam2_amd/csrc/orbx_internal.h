@@ -135,6 +135,7 @@ int orbx_launch_orient_describe(const OrbxLaunch &L);   /* IC_Angle + rBRIEF + f
 /* stream of an extractor handle (orbx_extractor.hip), so other handles can order work after it */
 hipStream_t orbx_extractor_stream_internal(orbx_extractor *h);
 bool orbx_extractor_host_complete_internal(orbx_extractor *h, int *status);
+int orbx_extractor_host_count_internal(orbx_extractor *h);      // keypoints of frame 0 of a host-complete call (its pinned result arena)
 /* `ev` (recorded by a consumer on its own stream) guards the result buffer of the LAST batch: the
  * extractor waits for it before that buffer is overwritten two batches later */
 void orbx_extractor_set_consumer_event_internal(orbx_extractor *h, hipEvent_t ev);

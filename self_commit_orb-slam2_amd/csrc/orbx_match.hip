@@ -17,6 +17,9 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
+
 #include <type_traits>
 #include <vector>
 
@@ -544,30 +547,57 @@ __global__ __launch_bounds__(256) void k_stereo_rows(FeatDev Rf, const int32_t *
     }
 }
 
-__global__ __launch_bounds__(256) void k_stereo_full(FeatDev Lf, FeatDev Rf, PyrDev PL, PyrDev PR, const int32_t *__restrict__ pairsL,
-                                                     const int32_t *__restrict__ pairsR, const float *__restrict__ scaleFactors,
-                                                     const float *__restrict__ invScaleFactors, float mbf, float mb, int32_t *__restrict__ bestIdx,
-                                                     int32_t *__restrict__ bestDist, float *__restrict__ uRight, float *__restrict__ depth,
-                                                     int32_t *__restrict__ sadOut, int stride, const int32_t *__restrict__ rowStart, const int32_t *__restrict__ rowList, int H,
-                                                     int listCap)
+// one wave = one left keypoint iL of pair p (left frame fl, right frame fr): candidates of its row, best descriptor, SAD refinement
+// SCAN = false: the candidates of a row come from the table k_stereo_rows built (rowStart / rowList); SCAN = true (256 threads = four left
+// keypoints per workgroup, pair 0): the workgroup collects them itself in `lds` ([4][listCap] indices), see k_stereo_scan.
+template <bool SCAN>
+__device__ __forceinline__ void stereo_full_body(const int iL, const int p, const int fl, const int fr, const FeatDev &Lf, const FeatDev &Rf, const PyrDev &PL, const PyrDev &PR,
+                                                 const float *__restrict__ scaleFactors, const float *__restrict__ invScaleFactors, float mbf, float mb,
+                                                 int32_t *__restrict__ bestIdx, int32_t *__restrict__ bestDist, float *__restrict__ uRight, float *__restrict__ depth,
+                                                 int32_t *__restrict__ sadOut, int stride, const int32_t *__restrict__ rowStart, const int32_t *__restrict__ rowList, int H,
+                                                 int listCap, int *lds)
 {
-    const int p = blockIdx.y, fl = pairsL[p], fr = pairsR[p];
     const int nL = min(Lf.counts[fl], Lf.cap);
-    const int lane = threadIdx.x & 63, iL = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (iL >= nL) return;
-    const orbx_keypoint kl = Lf.kp[(size_t)fl * Lf.cap + iL];
+    const int lane = threadIdx.x & 63;
+    const bool active = iL < nL;                               // (wave-uniform)
+    if (!SCAN && !active) return;
+    const orbx_keypoint kl = Lf.kp[(size_t)fl * Lf.cap + (active ? iL : 0)];
     const int row = (int)kl.y;
     const float minZ = mb, minD = 0.0f;
     const float maxD = mbf / minZ;
     const float minU = kl.x - maxD, maxU = kl.x - minD;
-    const unsigned long long *da = (const unsigned long long *)(Lf.desc + ((size_t)fl * Lf.cap + iL) * 32);
+    const unsigned long long *da = (const unsigned long long *)(Lf.desc + ((size_t)fl * Lf.cap + (active ? iL : 0)) * 32);
     unsigned long long a[4] = {da[0], da[1], da[2], da[3]};
     uint32_t best = ((uint32_t)TH_HIGH << 16);
     const orbx_keypoint *kr = Rf.kp + (size_t)fr * Rf.cap;
-    if (!(maxU < 0) && row >= 0 && row < H) {
-        const int32_t *rs = rowStart + (size_t)p * (H + 1), *rl = rowList + (size_t)p * listCap;
-        const int c1 = min(rs[row + 1], listCap);
-        for (int c = rs[row] + lane; c < c1; c += 64) {        // vCandidates = vRowIndices[vL]
+    const bool rowOk = active && !(maxU < 0) && row >= 0 && row < H;
+    const int32_t *rl = nullptr;
+    int c0 = 0, c1 = 0;
+    if (SCAN) {
+        __shared__ int sRow[4], sCnt[4];
+        const int wv = threadIdx.x >> 6;
+        if (lane == 0) { sRow[wv] = rowOk ? row : -1; sCnt[wv] = 0; }
+        __syncthreads();
+        const int r0 = sRow[0], r1 = sRow[1], r2 = sRow[2], r3 = sRow[3];
+        const int nR = min(Rf.counts[fr], Rf.cap);
+        for (int iR = threadIdx.x; iR < nR; iR += 256) {       // vRowIndices (src/Frame.cc:1179-1196), the four rows this workgroup needs
+            const float ky = kr[iR].y, r = 2.0f * scaleFactors[kr[iR].octave];
+            const int maxr = min((int)ceilf(ky + r), H - 1), minr = max((int)floorf(ky - r), 0);
+            if (r0 >= minr && r0 <= maxr) { const int pos = atomicAdd(&sCnt[0], 1); if (pos < listCap) lds[pos] = iR; }
+            if (r1 >= minr && r1 <= maxr) { const int pos = atomicAdd(&sCnt[1], 1); if (pos < listCap) lds[listCap + pos] = iR; }
+            if (r2 >= minr && r2 <= maxr) { const int pos = atomicAdd(&sCnt[2], 1); if (pos < listCap) lds[2 * listCap + pos] = iR; }
+            if (r3 >= minr && r3 <= maxr) { const int pos = atomicAdd(&sCnt[3], 1); if (pos < listCap) lds[3 * listCap + pos] = iR; }
+        }
+        __syncthreads();
+        if (!active) return;
+        rl = lds + wv * listCap; c1 = min(sCnt[wv], listCap);
+    } else if (rowOk) {
+        const int32_t *rs = rowStart + (size_t)p * (H + 1);
+        rl = rowList + (size_t)p * listCap;
+        c0 = rs[row]; c1 = min(rs[row + 1], listCap);
+    }
+    {
+        for (int c = c0 + lane; c < c1; c += 64) {             // vCandidates = vRowIndices[vL]
             const int iR = rl[c];
             const orbx_keypoint k = kr[iR];
             if (k.octave < kl.octave - 1 || k.octave > kl.octave + 1) continue;
@@ -651,6 +681,18 @@ __global__ __launch_bounds__(256) void k_stereo_full(FeatDev Lf, FeatDev Rf, Pyr
     }
 }
 
+__global__ __launch_bounds__(256) void k_stereo_full(FeatDev Lf, FeatDev Rf, PyrDev PL, PyrDev PR, const int32_t *__restrict__ pairsL,
+                                                     const int32_t *__restrict__ pairsR, const float *__restrict__ scaleFactors,
+                                                     const float *__restrict__ invScaleFactors, float mbf, float mb, int32_t *__restrict__ bestIdx,
+                                                     int32_t *__restrict__ bestDist, float *__restrict__ uRight, float *__restrict__ depth,
+                                                     int32_t *__restrict__ sadOut, int stride, const int32_t *__restrict__ rowStart, const int32_t *__restrict__ rowList, int H,
+                                                     int listCap)
+{
+    const int p = blockIdx.y;
+    stereo_full_body<false>(blockIdx.x * 4 + (threadIdx.x >> 6), p, pairsL[p], pairsR[p], Lf, Rf, PL, PR, scaleFactors, invScaleFactors, mbf, mb, bestIdx, bestDist, uRight,
+                            depth, sadOut, stride, rowStart, rowList, H, listCap, nullptr);
+}
+
 __global__ __launch_bounds__(256) void k_stereo_cut(FeatDev Lf, const int32_t *__restrict__ pairsL, const int32_t *__restrict__ sad,
                                                     float *__restrict__ uRight, float *__restrict__ depth, int32_t *__restrict__ nmatches, int stride)
 {
@@ -702,6 +744,116 @@ __global__ __launch_bounds__(256) void k_stereo_cut(FeatDev Lf, const int32_t *_
     if ((t & 63) == 0) atomicAdd(&hist[0], kept);
     __syncthreads();
     if (t == 0) nmatches[p] = hist[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// ONE stereo frame (pair 0 = frame 0 of both extractors): the latency form behind orbx_stereo_frame_begin, two launches.  The three
+// kernels above cost 19 + 8 + 13 us of device time plus two launch gaps for a 1241x376 / 2000-feature frame, most of it ONE workgroup's
+// dependent latency (k_stereo_rows, k_stereo_cut).  Here
+//   k_stereo_scan     = k_stereo_full without a row table: every workgroup walks the right keypoints once (8 per thread) and collects, in
+//                       LDS, those whose band holds the row of one of its four left keypoints (vRowIndices[vL], src/Frame.cc:1179-1196,
+//                       evaluated where it is needed); 500 workgroups x 2000 band tests is nothing next to a kernel and a launch gap;
+//   k_stereo_cut_one  = k_stereo_cut with the values in registers, the two 256-bin rank searches as wave scans instead of one thread's
+//                       loops, and `seq` written into pinned host memory behind the last result: the host polls that word.
+// (One launch with grid-wide hand-offs - workgroup 0 builds the table, the last one cuts - was tried first: agent-scope release / acquire
+// on this eight-XCD part writes back / invalidates L2 per workgroup; 304 us per call, and every concurrent kernel slowed down with it.)
+// Same arithmetic, same outputs as the three kernels (tests/test_matcher.py::test_stereo_frame_of_two_single_frame_calls).
+// ---------------------------------------------------------------------------------------------
+#define STEREO_ONE_REG 16      // sad values a thread keeps in registers (features <= 256 * 16; beyond: the three kernels)
+
+// rank search in a 256-bin histogram (LDS), wave 0: the bin b with prefix(b) <= rank < prefix(b) + hist[b]; returns (b, rank - prefix(b), total) to all of wave 0
+__device__ __forceinline__ void rank_bin_wave0(const int *hist, int rank, int lane, int *bin, int *within, int *total)
+{
+    const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    const int s4 = h0 + h1 + h2 + h3;
+    int inc = s4;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    const int exc = inc - s4;
+    *total = __shfl(inc, 63);
+    int b = -1, w = 0;
+    if (rank >= exc && rank < inc) {
+        int a = exc;
+        if (rank < a + h0) { b = 4 * lane; w = rank - a; }
+        else if (rank < (a += h0) + h1) { b = 4 * lane + 1; w = rank - a; }
+        else if (rank < (a += h1) + h2) { b = 4 * lane + 2; w = rank - a; }
+        else { a += h2; b = 4 * lane + 3; w = rank - a; }
+    }
+    const unsigned long long m = __ballot(b >= 0);
+    const int src = m ? __ffsll((long long)m) - 1 : 0;
+    *bin = __shfl(b, src); *within = __shfl(w, src);
+    if (!m) { *bin = 0; *within = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_stereo_scan(FeatDev Lf, FeatDev Rf, PyrDev PL, PyrDev PR, const float *__restrict__ scaleFactors,
+                                                     const float *__restrict__ invScaleFactors, float mbf, float mb, int32_t *__restrict__ bestIdx,
+                                                     int32_t *__restrict__ bestDist, float *__restrict__ uRight, float *__restrict__ depth, int32_t *__restrict__ sadOut,
+                                                     int stride, int H, int listCap)
+{
+    extern __shared__ int sdyn[];         // [4][listCap] candidate lists of the four left keypoints
+    stereo_full_body<true>(blockIdx.x * 4 + (threadIdx.x >> 6), 0, 0, 0, Lf, Rf, PL, PR, scaleFactors, invScaleFactors, mbf, mb, bestIdx, bestDist, uRight, depth, sadOut, stride,
+                           nullptr, nullptr, H, listCap, sdyn);
+}
+
+__global__ __launch_bounds__(256) void k_stereo_cut_one(FeatDev Lf, const int32_t *__restrict__ sadIn, float *__restrict__ uRight, float *__restrict__ depth,
+                                                        int32_t *__restrict__ nmatches, int *__restrict__ hostFlag, int seq)
+{
+    __shared__ int hist[256];
+    __shared__ int sel[4];
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nL = min(Lf.counts[0], Lf.cap);
+    int sv[STEREO_ONE_REG];
+    hist[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < STEREO_ONE_REG; j++) {
+        const int i = tid + 256 * j;
+        sv[j] = i < nL ? sadIn[i] : -1;
+        if (sv[j] >= 0) atomicAdd(&hist[(sv[j] >> 8) & 255], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int n = 0, b0, w0, hb = 0, within = 0, tot;
+        rank_bin_wave0(hist, 0, lane, &b0, &w0, &n);             // (the total; rank = n / 2 needs it)
+        rank_bin_wave0(hist, n / 2, lane, &hb, &within, &tot);   // vDistIdx[size/2] of the ascending sort (:1387-1388): its high byte
+        if (tid == 0) { sel[0] = n; sel[1] = hb; sel[2] = within; }
+    }
+    __syncthreads();
+    const int n = sel[0], hb = sel[1];
+    int kept = 0;
+    if (n > 0) {                                                  // (n == 0: nothing to cut, as k_stereo_cut)
+        __syncthreads();
+        hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < STEREO_ONE_REG; j++) if (sv[j] >= 0 && ((sv[j] >> 8) & 255) == hb) atomicAdd(&hist[sv[j] & 255], 1);
+        __syncthreads();
+        if (tid < 64) {
+            int lb, w1, tot;
+            rank_bin_wave0(hist, sel[2], lane, &lb, &w1, &tot);
+            if (tid == 0) sel[3] = (hb << 8) | lb;
+        }
+        __syncthreads();
+        const float median = (float)sel[3];
+        const float thDist = 1.5f * 1.4f * median;
+#pragma unroll
+        for (int j = 0; j < STEREO_ONE_REG; j++) {
+            const int v = sv[j], i = tid + 256 * j;
+            if (v < 0) continue;
+            if ((float)v < thDist) kept++;
+            else { uRight[i] = -1.0f; depth[i] = -1.0f; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+        if (lane == 0) wsum[wv] = kept;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        nmatches[0] = n > 0 ? wsum[0] + wsum[1] + wsum[2] + wsum[3] : 0;
+        __hip_atomic_store(hostFlag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 
@@ -974,14 +1126,19 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher *m, orbx_extracto
 // words are read from pinned memory; the scale tables and the pair indices stay on the device from call to call; mvuRight / mvDepth are
 // written by the kernels straight into pinned memory.  Three launches and one synchronisation (the general call + download: ~22 runtime
 // calls, 0.16-0.19 ms per frame).  Falls back to the general path when a producer's last call was not a single-frame call.
-extern "C" int orbx_stereo_frame(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, float mbf, float mb, float *uright, float *depth, int n)
+// begin: everything up to and including the launches (returns at once); end: the wait and the copy out of pinned memory.  Between the two the
+// producers must not be called (their buffers are being read).  shim/Frame_hip.cc begins from the extractor thread that finishes LAST in the
+// stereo constructor - before that thread converts its keypoints for the caller - and ends in Frame::ComputeStereoMatches.
+extern "C" int orbx_stereo_frame_begin(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, float mbf, float mb)
 {
-    if (!m || !left || !right || !uright || !depth || n < 0) { orbx_set_error("bad argument"); return ORBX_ERR_ARG; }
+    if (!m || !left || !right) { orbx_set_error("bad argument"); return ORBX_ERR_ARG; }
+    m->sfPending = 0;
     int stL = 0, stR = 0;
     if (!orbx_extractor_host_complete_internal(left, &stL) || !orbx_extractor_host_complete_internal(right, &stR) || left == right) {
         const int32_t zero = 0;
         int rc = orbx_compute_stereo_matches_device(m, left, right, &zero, &zero, 1, mbf, mb);
-        return rc != ORBX_OK ? rc : orbx_stereo_download(m, 1, uright, depth, n < m->maxFeatures ? n : m->maxFeatures);
+        if (rc == ORBX_OK) m->sfPending = 2;      // (the general path: orbx_stereo_frame_end downloads)
+        return rc;
     }
     if (stL | stR) {
         orbx_set_error("the extractor call these features come from overflowed a device capacity (bits 0x%x): results are not the reference's", stL | stR);
@@ -1015,13 +1172,15 @@ extern "C" int orbx_stereo_frame(orbx_matcher *m, orbx_extractor *left, orbx_ext
     }
     const size_t S = (size_t)m->maxFeatures;
     if (m->sfHostFloats < 2 * S) {
+        ORBX_HIP_CHECK(hipStreamSynchronize(st));
         if (m->sfHost) (void)hipHostFree(m->sfHost);
         m->sfHost = nullptr; m->sfHostFloats = 0;
-        ORBX_HIP_CHECK(hipHostMalloc((void **)&m->sfHost, 2 * S * sizeof(float), hipHostMallocDefault));
+        ORBX_HIP_CHECK(hipHostMalloc((void **)&m->sfHost, (2 * S + 16) * sizeof(float), hipHostMallocDefault));      // uright | depth | completion word
         void *dp = nullptr;
         ORBX_HIP_CHECK(hipHostGetDevicePointer(&dp, m->sfHost, 0));
         m->sfHostDev = (float *)dp;
         m->sfHostFloats = 2 * S;
+        *(volatile int *)(m->sfHost + 2 * S) = 0;
     }
     orbx_feature_set fl = {vl.kp, vl.desc, vl.counts, nullptr, nullptr, vl.cap, vl.batch};
     orbx_feature_set fr = {vr.kp, vr.desc, vr.counts, nullptr, nullptr, vr.cap, vr.batch};
@@ -1035,6 +1194,25 @@ extern "C" int orbx_stereo_frame(orbx_matcher *m, orbx_extractor *left, orbx_ext
     const int32_t *zero = m->sfZero.p;
     float *dU = m->sfHostDev, *dD = m->sfHostDev + S;
     const float *sc = m->sfScalesDev.p;
+    m->sfFlagSeq = 0;
+    {   // two launches (k_stereo_scan, k_stereo_cut_one); ORBX_STEREO_ONE=0: the three kernels of the batched path (measurement switch)
+        const char *e = getenv("ORBX_STEREO_ONE");
+        const int scanCap = vr.cap;                              // a row's candidate list can hold every right keypoint
+        const size_t lds1 = (size_t)4 * scanCap * sizeof(int);
+        if (!(e && e[0] == '0') && vl.cap <= 256 * STEREO_ONE_REG && lds1 <= 96 * 1024) {
+            if (lds1 > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_stereo_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+            const int seq = ++m->sfSeq;
+            hipLaunchKernelGGL(k_stereo_scan, dim3((unsigned)((vl.cap + 3) / 4)), dim3(256), lds1, st, to_dev(&fl), to_dev(&fr), PL, PR, sc, sc + 64, mbf, mb, m->matches.p, m->dists.p,
+                               dU, dD, m->sad.p, stride, H, scanCap);
+            MLAUNCH_CHECK();
+            hipLaunchKernelGGL(k_stereo_cut_one, dim3(1), dim3(256), 0, st, to_dev(&fl), (const int32_t *)m->sad.p, dU, dD, m->nmatches.p, (int *)(m->sfHostDev + 2 * S), seq);
+            MLAUNCH_CHECK();
+            m->sfFlagSeq = seq;
+            m->lastPairs = 1; m->lastStride = stride;
+            m->sfPending = 1;
+            return ORBX_OK;
+        }
+    }
     hipLaunchKernelGGL(k_stereo_rows, dim3(1), dim3(256), lds, st, to_dev(&fr), zero, sc, H, m->stRowStart.p, m->stRowList.p, listCap);
     MLAUNCH_CHECK();
     hipLaunchKernelGGL(k_stereo_full, dim3((unsigned)((vl.cap + 3) / 4), 1u), dim3(256), 0, st, to_dev(&fl), to_dev(&fr), PL, PR, zero, zero, sc, sc + 64, mbf, mb,
@@ -1042,12 +1220,43 @@ extern "C" int orbx_stereo_frame(orbx_matcher *m, orbx_extractor *left, orbx_ext
     MLAUNCH_CHECK();
     hipLaunchKernelGGL(k_stereo_cut, dim3(1), dim3(256), 0, st, to_dev(&fl), zero, m->sad.p, dU, dD, m->nmatches.p, stride);
     MLAUNCH_CHECK();
-    ORBX_HIP_CHECK(hipStreamSynchronize(st));      // complete on return: the extractors may overwrite their buffers at will
-    const size_t cnt = (size_t)(n < stride ? n : stride);
+    m->lastPairs = 1; m->lastStride = stride;
+    m->sfPending = 1;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stereo_frame_end(orbx_matcher *m, float *uright, float *depth, int n)
+{
+    if (!m || !uright || !depth || n < 0) { orbx_set_error("bad argument"); return ORBX_ERR_ARG; }
+    const int pending = m->sfPending;
+    m->sfPending = 0;
+    if (!pending) { orbx_set_error("no stereo frame has been begun"); return ORBX_ERR_STATE; }
+    if (pending == 2) return orbx_stereo_download(m, 1, uright, depth, n < m->maxFeatures ? n : m->maxFeatures);
+    const size_t S = (size_t)m->maxFeatures, cnt = (size_t)n < S ? (size_t)n : S;
+    bool arrived = false;
+    if (m->sfFlagSeq) {      // k_stereo_one writes its sequence number into pinned memory behind its last result: no runtime call on the way out
+        const volatile int *flag = (const volatile int *)(m->sfHost + 2 * S);
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        for (int spin = 0; !(arrived = *flag == m->sfFlagSeq); spin++) {
+            __builtin_ia32_pause();
+            if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!arrived) {
+        ORBX_HIP_CHECK(hipSetDevice(m->device));
+        ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));      // complete on return: the extractors may overwrite their buffers at will
+    }
     memcpy(uright, m->sfHost, cnt * sizeof(float));
     memcpy(depth, m->sfHost + S, cnt * sizeof(float));
-    m->lastPairs = 1; m->lastStride = stride;
     return ORBX_OK;
+}
+
+extern "C" int orbx_stereo_frame(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, float mbf, float mb, float *uright, float *depth, int n)
+{
+    if (!m || !left || !right || !uright || !depth || n < 0) { orbx_set_error("bad argument"); return ORBX_ERR_ARG; }
+    const int rc = orbx_stereo_frame_begin(m, left, right, mbf, mb);
+    return rc != ORBX_OK ? rc : orbx_stereo_frame_end(m, uright, depth, n);
 }
 
 extern "C" int orbx_stereo_results_device(orbx_matcher *m, const float **uright_dev, const float **depth_dev, int *stride)

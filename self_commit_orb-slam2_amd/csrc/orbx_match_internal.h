@@ -78,6 +78,8 @@ struct orbx_matcher {
     OrbxDevBuf<float> sfScalesDev;               // its own copy of the tables: the other calls overwrite `scales`
     float *sfHost = nullptr, *sfHostDev = nullptr;   // pinned: uright | depth, written by the kernels across PCIe
     size_t sfHostFloats = 0;
+    int sfSeq = 0, sfFlagSeq = 0;                 // k_stereo_one: call counter; the value the kernel of the pending call writes into the pinned completion word (0: none)
+    int sfPending = 0;                            // orbx_stereo_frame_begin .. _end: 0 none, 1 launched (results land in sfHost), 2 the general path ran (download at the end)
     // staging for the host-array convenience calls
     OrbxDevBuf<orbx_keypoint> hk[2];
     OrbxDevBuf<uint8_t> hd[2], hv[2];

@@ -1,5 +1,5 @@
 // shim/Frame_hip.cc -- HIP bodies for ORB_SLAM2::Frame::ComputeStereoMatches, UndistortKeyPoints,
-// ComputeImageBounds and AssignFeaturesToGrid (+ Frame::ExtractORB with the stereo pair hint).
+// ComputeImageBounds and AssignFeaturesToGrid (+ Frame::ExtractORB, which starts them early).
 //
 // Compiled against the REFERENCE's own include/Frame.h with shim/ORBextractor.h in place of
 // include/ORBextractor.h.  Replaces the body of
@@ -18,8 +18,13 @@
 #include "Frame.h"
 #include "orbx.h"
 
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 
 // tells shim/ORBextractor.cc that ComputeStereoMatches reads the pyramid on the device: no host copy of mvImagePyramid per frame
 extern "C" __attribute__((visibility("default"))) int orbx_shim_device_stereo_linked = 1;
@@ -55,6 +60,36 @@ extern "C" __attribute__((visibility("default"))) int orbx_shim_profile(int idx,
     return 0;
 }
 
+// Timeline of a constructor (tools/latency_shim.py --trace): orbx_shim_trace(1) starts recording (name, thread, microseconds) marks,
+// orbx_shim_trace_dump prints them relative to the first one.  Off: one relaxed load per mark.
+static std::atomic<int> gTraceOn(0), gTraceN(0);
+struct TraceEv { const char *name; double us; unsigned long tid; };
+static TraceEv gTrace[1024];
+extern "C" __attribute__((visibility("default"))) void orbx_shim_trace_mark(const char *name)
+{
+    if (!gTraceOn.load(std::memory_order_relaxed)) return;
+    const int i = gTraceN.fetch_add(1);
+    if (i >= 1024) return;
+    gTrace[i].name = name;
+    gTrace[i].us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    gTrace[i].tid = (unsigned long)std::hash<std::thread::id>()(std::this_thread::get_id()) % 1000;
+}
+extern "C" __attribute__((visibility("default"))) void orbx_shim_trace(int on) { gTraceN.store(0); gTraceOn.store(on); }
+extern "C" __attribute__((visibility("default"))) int orbx_shim_trace_dump(char *buf, int cap)
+{
+    int n = gTraceN.load(), o = 0;
+    if (n > 1024) n = 1024;
+    for (int i = 0; i < n && o < cap - 96; i++)
+        o += snprintf(buf + o, (size_t)(cap - o), "%9.1f us  [thread %03lu]  %s\n", gTrace[i].us - gTrace[0].us, gTrace[i].tid, gTrace[i].name);
+    if (cap > 0) buf[o < cap ? o : cap - 1] = 0;
+    return n;
+}
+#define TRACE(name) orbx_shim_trace_mark(name)
+
+// how often the early start was what produced a frame's mvKeysUn + mGrid / its stereo match (the tests check that the path they mean to test ran)
+static unsigned long gEarlyFills = 0, gEarlyStereo = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_early_fills(void) { return gEarlyFills; }
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_early_stereo(void) { return gEarlyStereo; }
 static unsigned long gStereoCalls = 0, gUndistortCalls = 0, gBoundsCalls = 0, gGridCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_undistort_calls(void) { return gUndistortCalls; }
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_image_bounds_calls(void) { return gBoundsCalls; }
@@ -66,89 +101,6 @@ namespace ORB_SLAM2
 
 namespace
 {
-struct ThreadStereo {
-    orbx_matcher *h;
-    int cap;
-    ThreadStereo() : h(0), cap(0) {}
-    ~ThreadStereo() { if (h) orbx_matcher_destroy(h); }
-};
-thread_local ThreadStereo tStereo;
-}  // namespace
-
-// ---------------------------------------------------------------------------------------------
-//     void Frame::ExtractORB(int flag, const cv::Mat &im)                     src/Frame.cc:494-512
-// The reference's body, plus one line: in the stereo constructor the two calls run on two threads (src/Frame.cc:159-167), and each
-// tells liborbx that the other extractor's call is on its way, so that both frames run as ONE launch set (include/orbx.h:
-// orbx_extractor_expect_partner).  Monocular / RGB-D frames (mpORBextractorRight == NULL, :283, :394) give no hint and never wait.
-// ---------------------------------------------------------------------------------------------
-static unsigned long gExtractCalls = 0;
-extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_extract_orb_calls(void) { return gExtractCalls; }
-
-void Frame::ExtractORB(int flag, const cv::Mat &im)
-{
-    __atomic_add_fetch(&gExtractCalls, 1, __ATOMIC_RELAXED);
-    ShimTimer timer(P_EXTRACT);
-    if (mpORBextractorLeft && mpORBextractorRight)
-        (flag == 0 ? mpORBextractorLeft : mpORBextractorRight)->ExpectPartner(flag == 0 ? mpORBextractorRight : mpORBextractorLeft);
-    if (flag == 0) (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors);
-    else (*mpORBextractorRight)(im, cv::Mat(), mvKeysRight, mDescriptorsRight);
-}
-
-void Frame::ComputeStereoMatches()
-{
-    __atomic_add_fetch(&gStereoCalls, 1, __ATOMIC_RELAXED);
-    ShimTimer timer(P_STEREO);
-    mvuRight = std::vector<float>(N, -1.0f);   // :1029-1030
-    mvDepth = std::vector<float>(N, -1.0f);
-    if (N == 0) return;
-    orbx_extractor *hl = mpORBextractorLeft->Handle(), *hr = mpORBextractorRight->Handle();
-    const int need = orbx_extractor_capacity(hl);
-    if (!tStereo.h || tStereo.cap < need) {
-        if (tStereo.h) { orbx_matcher_destroy(tStereo.h); tStereo.h = 0; }
-        if (orbx_matcher_create(0, need, 1, &tStereo.h) != ORBX_OK)
-            throw std::runtime_error(std::string("Frame::ComputeStereoMatches (orbx): ") + orbx_last_error());
-        tStereo.cap = need;
-    }
-    if (orbx_stereo_frame(tStereo.h, hl, hr, mbf, mb, &mvuRight[0], &mvDepth[0], N) != ORBX_OK)
-        throw std::runtime_error(std::string("Frame::ComputeStereoMatches (orbx): ") + orbx_last_error());
-}
-
-// ---------------------------------------------------------------------------------------------
-//     void Frame::UndistortKeyPoints()                    src/Frame.cc:899-947
-//     void Frame::ComputeImageBounds(const cv::Mat &)     src/Frame.cc:950-1004
-//     void Frame::AssignFeaturesToGrid()                  src/Frame.cc:460-491
-// One device handle per camera (mK, mDistCoef), shared by the threads that build frames.
-// ---------------------------------------------------------------------------------------------
-namespace
-{
-struct CamKey {
-    float v[10];
-    bool operator<(const CamKey &o) const
-    {
-        for (int i = 0; i < 10; i++) if (v[i] != o.v[i]) return v[i] < o.v[i];
-        return false;
-    }
-};
-std::mutex gOpsMutex;
-std::map<CamKey, orbx_frame_ops *> gOps;
-
-orbx_frame_ops *FrameOpsFor(const cv::Mat &K, const cv::Mat &D)
-{
-    orbx_camera cam;
-    cam.fx = K.at<float>(0, 0); cam.fy = K.at<float>(1, 1); cam.cx = K.at<float>(0, 2); cam.cy = K.at<float>(1, 2);
-    cam.ndist = D.rows * D.cols;
-    if (cam.ndist != 4 && cam.ndist != 5) throw std::runtime_error("Frame (orbx): mDistCoef must hold 4 or 5 coefficients");
-    for (int i = 0; i < 5; i++) cam.dist[i] = i < cam.ndist ? D.at<float>(i) : 0.0f;
-    CamKey key = {{cam.fx, cam.fy, cam.cx, cam.cy, cam.dist[0], cam.dist[1], cam.dist[2], cam.dist[3], cam.dist[4], (float)cam.ndist}};
-    std::lock_guard<std::mutex> lock(gOpsMutex);
-    std::map<CamKey, orbx_frame_ops *>::iterator it = gOps.find(key);
-    if (it != gOps.end()) return it->second;
-    orbx_frame_ops *h = 0;
-    if (orbx_frame_ops_create(0, &cam, &h) != ORBX_OK) throw std::runtime_error(std::string("Frame (orbx): ") + orbx_last_error());
-    gOps[key] = h;
-    return h;
-}
-
 // cv::KeyPoint <-> orbx_keypoint
 void Pack(const std::vector<cv::KeyPoint> &in, std::vector<orbx_keypoint> &out)
 {
@@ -159,13 +111,221 @@ void Pack(const std::vector<cv::KeyPoint> &in, std::vector<orbx_keypoint> &out)
         o.x = k.pt.x; o.y = k.pt.y; o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.class_id;
     }
 }
+
+struct CamKey {
+    float v[10];
+    bool operator<(const CamKey &o) const
+    {
+        for (int i = 0; i < 10; i++) if (v[i] != o.v[i]) return v[i] < o.v[i];
+        return false;
+    }
+    bool operator==(const CamKey &o) const { return memcmp(v, o.v, sizeof(v)) == 0; }
+};
+
+bool CameraOf(const cv::Mat &K, const cv::Mat &D, orbx_camera &cam, CamKey &key)
+{
+    cam.fx = K.at<float>(0, 0); cam.fy = K.at<float>(1, 1); cam.cx = K.at<float>(0, 2); cam.cy = K.at<float>(1, 2);
+    cam.ndist = D.rows * D.cols;
+    if (cam.ndist != 4 && cam.ndist != 5) return false;
+    for (int i = 0; i < 5; i++) cam.dist[i] = i < cam.ndist ? D.at<float>(i) : 0.0f;
+    const CamKey k = {{cam.fx, cam.fy, cam.cx, cam.cy, cam.dist[0], cam.dist[1], cam.dist[2], cam.dist[3], cam.dist[4], (float)cam.ndist}};
+    key = k;
+    return true;
+}
+
+// One device handle per camera (mK, mDistCoef), shared by the threads that build frames: the host-array forms.
+std::mutex gOpsMutex;
+std::map<CamKey, orbx_frame_ops *> gOps;
+orbx_frame_ops *FrameOpsFor(const cv::Mat &K, const cv::Mat &D)
+{
+    orbx_camera cam;
+    CamKey key;
+    if (!CameraOf(K, D, cam, key)) throw std::runtime_error("Frame (orbx): mDistCoef must hold 4 or 5 coefficients");
+    std::lock_guard<std::mutex> lock(gOpsMutex);
+    std::map<CamKey, orbx_frame_ops *>::iterator it = gOps.find(key);
+    if (it != gOps.end()) return it->second;
+    orbx_frame_ops *h = 0;
+    if (orbx_frame_ops_create(0, &cam, &h) != ORBX_OK) throw std::runtime_error(std::string("Frame (orbx): ") + orbx_last_error());
+    gOps[key] = h;
+    return h;
+}
 std::mutex gCallMutex;   // a handle is not re-entrant (include/orbx.h); frames are built by one thread at a time in the reference
+
+// ---------------------------------------------------------------------------------------------
+// What the constructors do after the extraction - UndistortKeyPoints, ComputeStereoMatches, AssignFeaturesToGrid (src/Frame.cc:181-234,
+// 422-456) - needs only the extractors' results, and those are on the device the moment the extraction call's wait returns, while the
+// host still has to convert keypoints for the caller, join its threads and walk through the constructor.  So the replaced
+// Frame::ExtractORB STARTS that work from inside the extractor call (ORBextractor::SetPostExtract: after the device is done, before the
+// conversion), and the member functions the constructor calls later only collect it:
+//   left image done  -> undistortion + grid of the left keypoints launched (orbx_frame_finish_begin); collected at the end of the same
+//                       ExtractORB call - the left thread finishes 30-40 us before the right one, which was started after it -, where
+//                       mvKeysUn and mGrid are filled;  UndistortKeyPoints() / AssignFeaturesToGrid() find them done and return;
+//   both images done -> the stereo match launched by whichever thread is second (orbx_stereo_frame_begin);  ComputeStereoMatches()
+//                       waits for it and copies mvuRight / mvDepth.
+// Every member function keeps its complete body for a caller that reaches it any other way (first frame: the grid statics do not exist
+// yet, src/Frame.cc:203-221; a failed launch; ORBX_SHIM_EARLY=0).  State per LEFT extractor (a Frame is built by one constructor at a time
+// per extractor: the handle is not re-entrant), hung on the shim's ORBextractor object.
+// ---------------------------------------------------------------------------------------------
+struct FrameAssist {
+    std::atomic<int> arrivals, pairFailed;
+    orbx_matcher *stereo;
+    int stereoCap;
+    const Frame *stereoFor;          // the frame whose match is in flight (begun, not ended)
+    orbx_frame_ops *ops;             // latency form (orbx_frame_finish_begin / _end); its own handle: nobody else's calls interleave
+    CamKey opsKey;
+    const Frame *finishFor;          // the frame whose mvKeysUn / mGrid were filled by ExtractORB
+    int finishN;
+    orbx_frame_grid finishGrid;
+    FrameAssist() : arrivals(0), pairFailed(0), stereo(0), stereoCap(0), stereoFor(0), ops(0), finishFor(0), finishN(0) { memset(&opsKey, 0, sizeof(opsKey)); memset(&finishGrid, 0, sizeof(finishGrid)); }
+    ~FrameAssist() { if (stereo) orbx_matcher_destroy(stereo); if (ops) orbx_frame_ops_destroy(ops); }
+};
+void FreeAssist(void *p) { delete (FrameAssist *)p; }
+std::mutex gAssistMutex;
+FrameAssist *AssistOf(ORBextractor *left)
+{
+    FrameAssist *a = (FrameAssist *)__atomic_load_n(&left->mpFrameAssist, __ATOMIC_ACQUIRE);
+    if (a) return a;
+    std::lock_guard<std::mutex> lock(gAssistMutex);
+    a = (FrameAssist *)__atomic_load_n(&left->mpFrameAssist, __ATOMIC_ACQUIRE);
+    if (!a) {
+        a = new FrameAssist();
+        left->mpFrameAssistFree = &FreeAssist;
+        __atomic_store_n(&left->mpFrameAssist, (void *)a, __ATOMIC_RELEASE);
+    }
+    return a;
+}
+bool EarlyStart()
+{
+    const char *e = getenv("ORBX_SHIM_EARLY");      // (read per call: the tests switch it)
+    return !(e && e[0] == '0');
+}
+bool EnsureStereoMatcher(FrameAssist *A, orbx_extractor *hl)
+{
+    const int need = orbx_extractor_capacity(hl);
+    if (A->stereo && A->stereoCap >= need) return true;
+    if (A->stereo) { orbx_matcher_destroy(A->stereo); A->stereo = 0; }
+    if (orbx_matcher_create(0, need, 1, &A->stereo) != ORBX_OK) { A->stereo = 0; return false; }
+    A->stereoCap = need;
+    return true;
+}
+
+struct PostCtx {
+    Frame *F;
+    int flag;
+    FrameAssist *A;
+    bool finishBegun;
+    orbx_frame_grid grid;
+};
+
+// ORBextractor::SetPostExtract hook of Frame::ExtractORB: on the extractor's thread, the device has just finished this image (never throws)
+void PostExtract(void *vc, bool ok)
+{
+    PostCtx *c = (PostCtx *)vc;
+    Frame *F = c->F;
+    FrameAssist *A = c->A;
+    TRACE(c->flag == 0 ? "left: device done" : "right: device done");
+    if (c->flag == 0 && ok && !Frame::mbInitialComputations) {
+        orbx_camera cam;
+        CamKey key;
+        if (CameraOf(F->mK, F->mDistCoef, cam, key)) {
+            if (A->ops && !(A->opsKey == key)) { orbx_frame_ops_destroy(A->ops); A->ops = 0; }
+            if (!A->ops && orbx_frame_ops_create(0, &cam, &A->ops) == ORBX_OK) A->opsKey = key;
+            const orbx_frame_grid g = {Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv};
+            if (A->ops && orbx_frame_finish_begin(A->ops, F->mpORBextractorLeft->Handle(), &g) == ORBX_OK) { c->finishBegun = true; c->grid = g; }
+        }
+    }
+    if (F->mpORBextractorRight) {      // the stereo constructor: two calls per frame, the second one to finish starts the match
+        if (!ok) A->pairFailed.store(1);
+        if (A->arrivals.fetch_add(1) == 1) {
+            A->arrivals.store(0);
+            const bool failed = A->pairFailed.exchange(0) != 0;
+            orbx_extractor *hl = F->mpORBextractorLeft->Handle(), *hr = F->mpORBextractorRight->Handle();
+            if (!failed && hl && hr && EnsureStereoMatcher(A, hl) && orbx_stereo_frame_begin(A->stereo, hl, hr, F->mbf, F->mb) == ORBX_OK) A->stereoFor = F;
+            TRACE("stereo match launched");
+        }
+    }
+}
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+//     void Frame::ExtractORB(int flag, const cv::Mat &im)                     src/Frame.cc:494-512
+// The reference's body (one functor call) + the early start described above.
+// ---------------------------------------------------------------------------------------------
+static unsigned long gExtractCalls = 0;
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_extract_orb_calls(void) { return gExtractCalls; }
+
+void Frame::ExtractORB(int flag, const cv::Mat &im)
+{
+    __atomic_add_fetch(&gExtractCalls, 1, __ATOMIC_RELAXED);
+    ShimTimer timer(P_EXTRACT);
+    TRACE(flag == 0 ? "left: ExtractORB enters" : "right: ExtractORB enters");
+    ORBextractor *ex = flag == 0 ? mpORBextractorLeft : mpORBextractorRight;
+    PostCtx ctx = {this, flag, 0, false, {0.0f, 0.0f, 0.0f, 0.0f}};
+    if (EarlyStart() && mpORBextractorLeft && ex) {
+        ctx.A = AssistOf(mpORBextractorLeft);
+        if (flag == 0) { ctx.A->finishFor = 0; ctx.A->stereoFor = 0; }      // (whatever an abandoned constructor left behind)
+        ex->SetPostExtract(&PostExtract, &ctx);
+    }
+    if (mpORBextractorLeft && mpORBextractorRight)
+        (flag == 0 ? mpORBextractorLeft : mpORBextractorRight)->ExpectPartner(flag == 0 ? mpORBextractorRight : mpORBextractorLeft);
+    if (flag == 0) (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors);
+    else (*mpORBextractorRight)(im, cv::Mat(), mvKeysRight, mDescriptorsRight);
+    TRACE(flag == 0 ? "left: keypoints converted" : "right: keypoints converted");
+    if (!ctx.finishBegun) return;
+    // the left image's undistorted keypoints and grid, launched before the conversion above: mvKeysUn (src/Frame.cc:899-947) and mGrid (:460-491)
+    FrameAssist *A = ctx.A;
+    const orbx_keypoint *un = 0;
+    const int32_t *off = 0, *idx = 0;
+    int n = 0;
+    if (orbx_frame_finish_end(A->ops, &un, &off, &idx, &n) != ORBX_OK || n != (int)mvKeys.size() || !off || (n > 0 && !idx)) return;
+    TRACE("left: undistortion + grid arrived");
+    mvKeysUn = mvKeys;
+    if (un) for (int i = 0; i < n; i++) { mvKeysUn[(size_t)i].pt.x = un[i].x; mvKeysUn[(size_t)i].pt.y = un[i].y; }
+    for (int x = 0; x < FRAME_GRID_COLS; x++)
+        for (int y = 0; y < FRAME_GRID_ROWS; y++) {
+            const int c = x * FRAME_GRID_ROWS + y;
+            mGrid[x][y].assign(idx + off[c], idx + off[c + 1]);
+        }
+    A->finishN = n; A->finishGrid = ctx.grid; A->finishFor = this;
+    TRACE("left: mvKeysUn + mGrid filled");
+}
+
+void Frame::ComputeStereoMatches()
+{
+    __atomic_add_fetch(&gStereoCalls, 1, __ATOMIC_RELAXED);
+    ShimTimer timer(P_STEREO);
+    TRACE("ComputeStereoMatches enters");
+    mvuRight = std::vector<float>(N, -1.0f);   // :1029-1030
+    mvDepth = std::vector<float>(N, -1.0f);
+    TRACE("ComputeStereoMatches: vectors initialised");
+    FrameAssist *A = AssistOf(mpORBextractorLeft);
+    const bool begun = A->stereoFor == this;
+    A->stereoFor = 0;
+    if (N == 0) return;
+    orbx_extractor *hl = mpORBextractorLeft->Handle(), *hr = mpORBextractorRight->Handle();
+    if (begun) __atomic_add_fetch(&gEarlyStereo, 1, __ATOMIC_RELAXED);
+    else {
+        if (!EnsureStereoMatcher(A, hl) || orbx_stereo_frame_begin(A->stereo, hl, hr, mbf, mb) != ORBX_OK)
+            throw std::runtime_error(std::string("Frame::ComputeStereoMatches (orbx): ") + orbx_last_error());
+    }
+    if (orbx_stereo_frame_end(A->stereo, &mvuRight[0], &mvDepth[0], N) != ORBX_OK)
+        throw std::runtime_error(std::string("Frame::ComputeStereoMatches (orbx): ") + orbx_last_error());
+    TRACE("ComputeStereoMatches returns");
+}
+
+// ---------------------------------------------------------------------------------------------
+//     void Frame::UndistortKeyPoints()                    src/Frame.cc:899-947
+//     void Frame::ComputeImageBounds(const cv::Mat &)     src/Frame.cc:950-1004
+//     void Frame::AssignFeaturesToGrid()                  src/Frame.cc:460-491
+// ---------------------------------------------------------------------------------------------
 void Frame::UndistortKeyPoints()
 {
     __atomic_add_fetch(&gUndistortCalls, 1, __ATOMIC_RELAXED);
     ShimTimer timer(P_UNDISTORT);
+    if (EarlyStart() && mpORBextractorLeft) {
+        const FrameAssist *A = AssistOf(mpORBextractorLeft);
+        if (A->finishFor == this && A->finishN == N && (int)mvKeysUn.size() == N) return;      // filled by ExtractORB
+    }
     if (mDistCoef.at<float>(0) == 0.0) {   // :901-905
         mvKeysUn = mvKeys;
         return;
@@ -203,10 +363,16 @@ void Frame::AssignFeaturesToGrid()
 {
     __atomic_add_fetch(&gGridCalls, 1, __ATOMIC_RELAXED);
     ShimTimer timer(P_GRID);
+    const orbx_frame_grid g = {mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv};   // what PosInGrid reads, :868-878
+    if (EarlyStart() && mpORBextractorLeft) {
+        FrameAssist *A = AssistOf(mpORBextractorLeft);
+        const bool filled = A->finishFor == this && A->finishN == N && memcmp(&A->finishGrid, &g, sizeof(g)) == 0;
+        A->finishFor = 0;
+        if (filled) { __atomic_add_fetch(&gEarlyFills, 1, __ATOMIC_RELAXED); TRACE("AssignFeaturesToGrid: already filled"); return; }      // by ExtractORB, from the same statics
+    }
     std::vector<orbx_keypoint> in;
     Pack(mvKeysUn, in);
     std::vector<int32_t> off((size_t)FRAME_GRID_COLS * FRAME_GRID_ROWS + 1), idx((size_t)(N > 0 ? N : 1));
-    const orbx_frame_grid g = {mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv};   // what PosInGrid reads, :868-878
     orbx_frame_ops *h = FrameOpsFor(mK, mDistCoef);
     {
         std::lock_guard<std::mutex> lock(gCallMutex);

@@ -40,8 +40,9 @@ bool ORBextractor::Fail(const char *what)
 }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
-    : mbKeepHostPyramid(!(&orbx_shim_device_stereo_linked && orbx_shim_device_stereo_linked)), nfeatures(_nfeatures), scaleFactor(_scaleFactor),
-      nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mpHandle(0), mMaxW(0), mMaxH(0), mLastW(0), mLastH(0), mnErrors(0), mbDead(false)
+    : mbKeepHostPyramid(!(&orbx_shim_device_stereo_linked && orbx_shim_device_stereo_linked)), mpFrameAssist(0), mpFrameAssistFree(0), nfeatures(_nfeatures), scaleFactor(_scaleFactor),
+      nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mpHandle(0), mMaxW(0), mMaxH(0), mLastW(0), mLastH(0), mPostFn(0), mPostCtx(0), mnErrors(0),
+      mbDead(false)
 {
     mvImagePyramid.resize(nlevels);
     // The tables come from the library so that getters and kernels can never disagree (no device needed for them).
@@ -56,6 +57,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 
 ORBextractor::~ORBextractor()
 {
+    if (mpFrameAssist && mpFrameAssistFree) mpFrameAssistFree(mpFrameAssist);      // (its handles read this extractor's buffers: first)
     if (mpHandle) orbx_extractor_destroy(mpHandle);
 }
 
@@ -78,6 +80,13 @@ bool ORBextractor::EnsureHandle(int width, int height)
 
 void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors)
 {
+    // the one-shot hook of this call (SetPostExtract): taken now, run exactly once on every path out of the device call
+    struct PostHook {
+        PostExtractFn fn; void *ctx; bool ran;
+        void run(bool ok) { if (fn && !ran) { ran = true; fn(ctx, ok); } }
+        ~PostHook() { run(false); }
+    } post = {mPostFn, mPostCtx, false};
+    mPostFn = 0; mPostCtx = 0;
     if (_image.empty()) return;
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1);
@@ -97,6 +106,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
         Fail("extract");
         return;
     }
+    post.run(true);
 
     if (n == 0)
         _descriptors.release();

@@ -55,6 +55,17 @@ public:
     // launch set (off by default: include/orbx.h says why).  Set by the HIP body of Frame::ExtractORB (shim/Frame_hip.cc).
     void ExpectPartner(ORBextractor *other);
 
+    // One-shot hook for the next operator() call: run on the calling thread when the device has finished the frame (ok) or the call has
+    // failed (!ok), BEFORE the results are converted into the caller's containers - whatever the hook launches overlaps that conversion.
+    // shim/Frame_hip.cc starts the rest of the Frame constructor from it (UndistortKeyPoints / AssignFeaturesToGrid of the left image,
+    // ComputeStereoMatches once both images are done).  Always called exactly once per operator() call it was set for.
+    typedef void (*PostExtractFn)(void *ctx, bool ok);
+    void SetPostExtract(PostExtractFn fn, void *ctx) { mPostFn = fn; mPostCtx = ctx; }
+    // Opaque per-extractor state of shim/Frame_hip.cc (its matcher / frame-ops handles for frames built with this extractor as the left
+    // one); freed with the extractor.
+    void *mpFrameAssist;
+    void (*mpFrameAssistFree)(void *);
+
     // Error channel (the reference has none: include/ORBextractor.h:92-161).  A failed call leaves `keypoints` EMPTY and `descriptors`
     // released - never the previous frame's data -, increments ErrorCount() and keeps the message; a host program polls these instead of
     // scraping stderr.  A device that could not be opened at construction is not retried on every frame (Dead()).
@@ -84,6 +95,8 @@ private:
     std::vector<int> mnFeaturesPerLevel;
     orbx_extractor *mpHandle;
     int mMaxW, mMaxH, mLastW, mLastH;
+    PostExtractFn mPostFn;
+    void *mPostCtx;
     int mnErrors;
     bool mbDead;
     std::string mLastError;

@@ -97,7 +97,7 @@ extern "C" double shim_bench_threads(int nthreads, int nf, const unsigned char *
             (*ex[(size_t)t])(im, cv::Mat(), keys, d);
         }
     };
-    { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, 10); for (auto &x : th) x.join(); }   // warm-up
+    { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, 40); for (auto &x : th) x.join(); }   // warm-up (the launch-set graphs of the sizes this load produces are built on first use)
     orbx_combiner_reset_stats(ex[0]->Handle());
     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, iters); for (auto &x : th) x.join(); }

@@ -57,19 +57,26 @@ def test_search_by_bow_dropin_equals_reference(orbx, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("early", [True, False])
 @pytest.mark.parametrize("W,H,nf,seed,bf", [(1241, 376, 2000, 61, 386.1448), (752, 480, 1200, 62, 47.9064)])
-def test_stereo_frame_dropin_equals_reference(orbx, W, H, nf, seed, bf):
+def test_stereo_frame_dropin_equals_reference(orbx, monkeypatch, W, H, nf, seed, bf, early):
     """Frame::Frame(imLeft, imRight, ...): two shim extractors on the reference's two threads +
-    the HIP ComputeStereoMatches, vs the all-reference constructor."""
+    the HIP ComputeStereoMatches, vs the all-reference constructor.  early: the match is launched by the extractor thread that
+    finishes second and only collected by ComputeStereoMatches (shim/Frame_hip.cc); ORBX_SHIM_EARLY=0: launched by the member function."""
     orbx.load_library()
     hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
     hip.orbx_shim_compute_stereo_matches_calls.restype = ctypes.c_ulong
+    hip.orbx_shim_early_stereo.restype = ctypes.c_ulong
+    if not early:
+        monkeypatch.setenv("ORBX_SHIM_EARLY", "0")
     before = hip.orbx_shim_compute_stereo_matches_calls()
+    before_early = hip.orbx_shim_early_stereo()
     imL = orbx.synth_frame(seed, W, H)
     imR = orbx.synth_frame(seed, W, H, orbx.SYNTH_STEREO_RIGHT)
     want = oracle_lib.ref_stereo_frame(imL, imR, nf, 500.0, 500.0, W / 2, H / 2, bf, lib=ref)
     got = oracle_lib.ref_stereo_frame(imL, imR, nf, 500.0, 500.0, W / 2, H / 2, bf, lib=hip)
     assert hip.orbx_shim_compute_stereo_matches_calls() - before == 1
+    assert hip.orbx_shim_early_stereo() - before_early == (1 if early else 0)
     for k in ("kpsL", "kpsR", "uRight", "depth"):
         assert got[k].shape == want[k].shape and (got[k].view(np.uint32) == want[k].view(np.uint32)).all(), k
     for k in ("descL", "descR"):
@@ -100,6 +107,42 @@ def test_mono_frame_dropin_equals_reference(orbx, W, H, K, dist, seed):
     for k in ("desc", "gridOff", "gridIdx"):
         assert (got[k] == want[k]).all(), k
     assert want["gridOff"][-1] > 900
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("early", [True, False])
+@pytest.mark.parametrize("W,H,K,dist,seed", [
+    (640, 480, (517.306408, 516.469215, 318.643040, 255.313989), (0.262383, -0.953104, -0.005358, 0.002628, 1.163314), 74),   # TUM1.yaml
+    (1241, 376, (718.856, 718.856, 607.1928, 185.2157), (0.0, 0.0, 0.0, 0.0), 75)])                                          # KITTI00-02.yaml (rectified)
+def test_later_mono_frames_dropin_equal_reference(orbx, monkeypatch, W, H, K, dist, seed, early):
+    """Every frame but the first of a run (Frame::mbInitialComputations false: bounds and grid statics exist, src/Frame.cc:203-221).  In the
+    drop-in library the left image's mvKeysUn and mGrid are then computed from inside the extractor call and filled by Frame::ExtractORB
+    (shim/Frame_hip.cc); UndistortKeyPoints / AssignFeaturesToGrid are still called by the constructor and find them done.
+    ORBX_SHIM_EARLY=0: the member functions do the work themselves.  Both against the all-reference constructor, frame by frame."""
+    orbx.load_library()
+    hip, ref = oracle_lib.slam_hip_lib(), oracle_lib.slam_lib()
+    names = ("orbx_shim_undistort_calls", "orbx_shim_assign_grid_calls", "orbx_shim_early_fills")
+    for n in names:
+        getattr(hip, n).restype = ctypes.c_ulong
+    if not early:
+        monkeypatch.setenv("ORBX_SHIM_EARLY", "0")
+    ims = [orbx.synth_frame(seed + 10 * i, W, H) for i in range(3)]
+    try:
+        for i, im in enumerate(ims):
+            for lib in (ref, hip):
+                lib.orbslam_keep_frame_statics(1 if i else 0)
+            before = [getattr(hip, n)() for n in names]
+            want = oracle_lib.ref_mono_frame(im, 1500, K[0], K[1], K[2], K[3], dist, lib=ref)
+            got = oracle_lib.ref_mono_frame(im, 1500, K[0], K[1], K[2], K[3], dist, lib=hip)
+            assert [getattr(hip, n)() - b for n, b in zip(names, before)] == [1, 1, 1 if (early and i) else 0], i
+            for k in ("kps", "kpsUn", "bounds", "gridInv"):
+                assert got[k].shape == want[k].shape and (got[k].view(np.uint32) == want[k].view(np.uint32)).all(), (i, k)
+            for k in ("desc", "gridOff", "gridIdx"):
+                assert (got[k] == want[k]).all(), (i, k)
+            assert want["gridOff"][-1] > 900
+    finally:
+        for lib in (ref, hip):
+            lib.orbslam_keep_frame_statics(0)
 
 
 @pytest.mark.gpu

@@ -99,11 +99,37 @@ def stereo_frame(orbx, iters_hip, iters_ref):
     return rows
 
 
+def trace_stereo(orbx):
+    """Timeline of the drop-in stereo constructor (marks set by shim/Frame_hip.cc and oracle/refslam_wrap.cc), last frames of a short run."""
+    import oracle_lib
+    lib = oracle_lib.slam_hip_lib()
+    if lib is None or not hasattr(lib, "orbx_shim_trace"):
+        return ""
+    stereo_frame(orbx, 50, 0)                                   # engines, graphs and statics exist
+    W, H, nf = 1241, 376, 2000
+    fr = orbx.synth_sequence(9, 8, W, H, views_per_scene=2, step=(6, 0))
+    aL = (ctypes.c_void_p * 4)(*[fr[2 * i].ctypes.data for i in range(4)])
+    aR = (ctypes.c_void_p * 4)(*[fr[2 * i + 1].ctypes.data for i in range(4)])
+    mean, med, nl, nm = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
+    lib.orbx_shim_trace.argtypes = [ctypes.c_int]
+    lib.orbx_shim_trace(1)
+    lib.orbslam_stereo_frame_bench(aL, aR, 4, W, H, W, nf, 1.2, 8, 20, 7, 718.856, 718.856, 607.19, 185.2, 386.1448, 35.0, 3, ctypes.byref(mean), ctypes.byref(med),
+                                   ctypes.byref(nl), ctypes.byref(nm))
+    lib.orbx_shim_trace(0) if False else None
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.orbx_shim_trace_dump.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.orbx_shim_trace_dump(buf, len(buf))
+    lines = buf.value.decode().splitlines()
+    # the last constructor only (the statics' first-frame path and the warm-up calls are above it)
+    starts = [i for i, l in enumerate(lines) if "Frame::Frame(stereo) called" in l]
+    return "\n".join(lines[starts[-1]:]) if starts else "\n".join(lines)
+
+
 def measure(orbx, quick=False):
     """-> {"rows": [...], "digest": {...}}; quick = the few numbers bench.py's digest needs (a couple of seconds)."""
     L = _shim_lib(orbx)
     rows = []
-    it1, itn = (150, 120) if quick else (300, 400)
+    it1, itn = (150, 250) if quick else (300, 400)
     rows += one_thread(orbx, L, 640, 480, 1000, it1)
     if not quick:
         rows += one_thread(orbx, L, 1241, 376, 2000, it1)
@@ -137,6 +163,9 @@ def measure(orbx, quick=False):
 
 if __name__ == "__main__":
     orbx = importlib.import_module("self_commit_orb-slam2_amd")
+    if "--trace" in sys.argv:
+        print(trace_stereo(orbx))
+        sys.exit(0)
     out = measure(orbx, quick="--quick" in sys.argv)
     for r in out["rows"]:
         print(json.dumps(r), flush=True)
