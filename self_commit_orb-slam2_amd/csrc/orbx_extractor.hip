@@ -75,6 +75,7 @@ struct orbx_extractor {
     std::vector<uint32_t> rsHost;   // cv::resize tables of all levels (build_resize_tables)
     // k_pyramid_tiles (single-frame call): per (tile, level) rectangles, planned from rsHost when the single-frame graph is built
     OrbxDevBuf<OrbxPyrTile> ptDev;
+    int ptBatchW = 0, ptBatchH = 0;              // geometry the plan below was made for by run_batch (ORBX_BATCH_PYR_TILES)
     int ptTiles = 0, ptLds = 0, ptTab = 0;       // 0 tiles: no plan (one level, taps wider than 8 bytes, LDS budget) -> the per-level launches
     int nodeCap = 512;
     // device state
@@ -134,6 +135,7 @@ struct orbx_extractor {
     bool lastCombined = false;        // the last call ran on a shared engine: this handle's `blur` buffer (a parity tap) was not written
 };
 
+static bool plan_pyramid_tiles(orbx_extractor *h, std::vector<OrbxPyrTile> &out, int &tiles, int &bufBytes, int &tabBytes);      // (below; run_batch plans too)
 namespace {
 
 void invalidate_single_graph(orbx_extractor *h);
@@ -425,8 +427,27 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     if (h->pyrConsumerEv) { ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, h->pyrConsumerEv, 0)); h->pyrConsumerEv = nullptr; }
     ORBX_HIP_CHECK(hipMemsetAsync(h->status.p, 0, (size_t)(batch + 1) * sizeof(int), h->stream));
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[0], h->stream));
-    for (int l = 1; l < h->geom.nlevels; l++)
-        if ((rc = orbx_launch_resize(L, l)) != ORBX_OK) return rc;
+    static const bool batchTiles = getenv("ORBX_BATCH_PYR_TILES") && getenv("ORBX_BATCH_PYR_TILES")[0] == '1';
+    bool tiled = false;
+    if (batchTiles && h->allocBatch > 1) {      // (measurement switch: the one-launch pyramid of the single-frame paths for a whole batch)
+        if (h->ptBatchW != W || h->ptBatchH != H) {
+            std::vector<OrbxPyrTile> plan;
+            h->ptTiles = 0;
+            if (plan_pyramid_tiles(h, plan, h->ptTiles, h->ptLds, h->ptTab)) {
+                if ((rc = h->ptDev.ensure(plan.size())) != ORBX_OK) return rc;
+                ORBX_HIP_CHECK(hipMemcpy(h->ptDev.p, plan.data(), plan.size() * sizeof(OrbxPyrTile), hipMemcpyHostToDevice));
+            } else h->ptTiles = 0;
+            h->ptBatchW = W; h->ptBatchH = H;
+        }
+        if (h->ptTiles > 0) {
+            L.pyrTiles = h->ptDev.p; L.pyrTileCount = h->ptTiles; L.pyrTileBuf = h->ptLds; L.pyrTileTab = h->ptTab;
+            if ((rc = orbx_launch_pyramid_tiles(L)) != ORBX_OK) return rc;
+            tiled = true;
+        }
+    }
+    if (!tiled)
+        for (int l = 1; l < h->geom.nlevels; l++)
+            if ((rc = orbx_launch_resize(L, l)) != ORBX_OK) return rc;
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_PYR + 1], h->stream));
     if ((rc = orbx_launch_fast_cells(L)) != ORBX_OK) return rc;   // FAST score + cell NMS fused; score map only for the parity taps
     if (prof) ORBX_HIP_CHECK(hipEventRecord(ev[ST_FAST + 1], h->stream));

@@ -245,6 +245,158 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same lists for the unfiltered case (one node = brute force: BASELINE's headline match) on the MATRIX CORES.
+// All-pairs Hamming distance is an inner product: with a = 1 - 2 A in {+1, -1} and b = B in {0, 1} per bit,
+//     sum_k b_jk a_ik = |B_j| - 2 A_i . B_j,      d(A_i, B_j) = |A_i| + sum_k b_jk a_ik          (exact in i8 x i8 -> i32)
+// so a 32 x 32 tile of distances is eight v_mfma_i32_32x32x32_i8 (K = 256 bits) instead of 1024 x 8 x (v_xor + v_bcnt): 16.4 k
+// multiply-adds per 32-cycle matrix instruction against 64 lanes x one 32-bit word per 4-cycle vector instruction.
+// One WAVE = 64 A features (two stripes of 32, kept as +-1 bytes in 64 registers: the MFMA's B operand, column = lane & 31 = the A
+// feature) against all B features in tiles of 32 (the MFMA's A operand, row = lane & 31 = the B feature); waves do not talk to each
+// other - no staging through LDS, no barrier in the loop (a first version that expanded the tile once per workgroup into LDS spent 52 us
+// per batch in barriers and LDS round trips alone).  Which bit is which k is free as long as both operands agree: lane half g = lane >> 5
+// takes bytes 16 g .. 16 g + 15 of the descriptor, step t of them bytes 2 t, 2 t + 1 - so a lane loads ONE dwordx4 per tile and turns
+// each of its nibbles into four 0 / 1 bytes with a table in LDS that has one column per lane (two vector instructions and a conflict-free
+// ds_read_b32 per nibble instead of three vector instructions).
+// The accumulator of a lane holds ONE A feature (its column) x 16 of the tile's B features (rows (v & 3) + 8 (v >> 2) + 4 g): the list
+// logic of k_bow_topk stays per lane - `acc < th - |A_i|`, first on group minima, the key only for the rare candidate that reaches the
+// list, ascending j per lane -, and the two lanes that share an A feature merge their lists at the end.
+// Bit-identical lists to k_bow_topk<false, false> (tests/test_matcher.py); ORBX_MATCH_MFMA=0 selects the VALU kernel.
+// ---------------------------------------------------------------------------------------------
+typedef int mfma_v4i __attribute__((ext_vector_type(4)));
+typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t nib01(uint32_t n) { return __umul24(n, 0x00204081u) & 0x01010101u; }      // 4 bits -> 4 bytes of 0 / 1
+
+__global__ __launch_bounds__(256, 3) void k_bow_topk_mfma(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, uint32_t dcut,
+                                                       uint32_t *__restrict__ topk, int stride, int dbg)
+{
+    __shared__ uint32_t sLut[16 * 64];    // [nibble][lane]: the nibble's four bits as four bytes, one copy per lane - every read is conflict free (a 256-entry
+                                          // byte table read with ds_read_b64 at data-dependent addresses kept the LDS busy 4.6 k cycles per tile and CU)
+    const int p = blockIdx.y, fa = pairsA[p], fb = pairsB[p];
+    const int nA = min(A.counts[fa], A.cap), nB = min(B.counts[fb], B.cap);
+    const int capB = B.cap;
+    const int row0 = blockIdx.x * 256;
+    if (row0 >= nA) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 5, c = lane & 31;
+    for (int e = tid; e < 16 * 64; e += 256) sLut[e] = nib01((uint32_t)e >> 6);
+    __syncthreads();
+    if (row0 + 64 * wv >= nA) return;     // (no barrier below)
+    const uint32_t sentinel = dcut << 16;
+    const char *lut = (const char *)sLut;
+    const uint32_t lane4 = (uint32_t)lane << 2;
+    mfma_v4i a[2][8];
+    uint32_t kk[2][TOPK];
+    int iA[2], nAc[2], T[2];
+    bool live[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        iA[s] = row0 + 64 * wv + 32 * s + c;
+        live[s] = iA[s] < nA;
+        const uint4 *da = (const uint4 *)(A.desc + ((size_t)fa * A.cap + (live[s] ? iA[s] : nA - 1)) * 32);
+        const uint4 lo = da[0], hi = da[1];
+        nAc[s] = __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
+        const uint4 mine = g ? hi : lo;
+        const uint32_t w[4] = {mine.x, mine.y, mine.z, mine.w};
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const uint32_t two = (w[t >> 1] >> (16 * (t & 1))) & 0xffffu;
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[s][t][q] = (int)__builtin_amdgcn_perm(0u, 0x0000ff01u, nib01((two >> (4 * q)) & 15u));      // bit 0 -> +1, bit 1 -> -1
+        }
+#pragma unroll
+        for (int q = 0; q < TOPK; q++) kk[s][q] = live[s] ? sentinel : 0u;      // rows beyond nA never insert (d >= 0 > their threshold)
+        T[s] = (int)(kk[s][TOPK - 1] >> 16) - nAc[s];                          // d < th  <=>  acc < th - |A_i|
+    }
+    const uint4 *gD = (const uint4 *)(B.desc + (size_t)fb * capB * 32);
+    const int ntiles = (nB + 31) >> 5;
+    auto load_raw = [&](int tile) { const int j = tile * 32 + c; return j < nB ? gD[(size_t)j * 2 + g] : make_uint4(0u, 0u, 0u, 0u); };
+    // Candidates that reach a list (d below the list's current 8th distance) are frequent - consecutive frames of one scene produce ~13 per
+    // stripe and tile, 18 k pairs below dcut per 1000 x 1000 pair - but sparse per lane (0.2 per stripe and tile).  Finding them register by
+    // register with wave-wide tests costs a scalar branch per register (two versions of that ran at 154-157 us per batch: the branches, not
+    // the arithmetic).  So the tile is handled WITHOUT branches: every lane runs its sixteen keys through a five-slot sorted buffer that starts
+    // filled with the list's threshold key (a key at or above the threshold never enters: no compare, no select), 2 + 5 instructions per
+    // register; afterwards the occupied slots are inserted into the lists with wave-wide insertions - slot 0 about once per stripe and tile,
+    // slot 1 for 2 % of the lanes, ... - and a fifth occupied slot (a lane with five candidates in one tile, which may have lost a sixth)
+    // sends the stripe through the exact path: all sixteen keys, one insertion each.
+    uint4 raw = load_raw(0);
+    auto one_tile = [&](const int tile, auto lastTag) {
+        constexpr bool LAST = decltype(lastTag)::value;      // the last tile may hold rows beyond nB (all-zero descriptors): excluded explicitly
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+        if (!LAST) raw = load_raw(tile + 1);                  // in flight during this tile
+        mfma_v4i b[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const uint32_t ww = w[t >> 1];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int sh = 16 * (t & 1) + 4 * q - 8;       // nibble value to bits 8..11: the table row, 256 bytes each
+                const uint32_t off = ((sh >= 0 ? ww >> sh : ww << -sh) & 0xf00u) | lane4;
+                b[t][q] = (int)*(const uint32_t *)(lut + off);
+            }
+        }
+        mfma_v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+        if (!(dbg & 2)) {
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[t], a[0][t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[t], a[1][t], acc1, 0, 0, 0);
+            }
+        } else { acc0[0] = b[0][0] + b[1][1] + b[2][2] + b[3][3] + b[4][0] + b[5][1] + b[6][2] + b[7][3]; acc1[0] = acc0[0] + 1000; }
+        if (dbg & 1) { if (acc0[3] + acc1[5] == 0x12345678) kk[0][0] = 0; return; }
+        const uint32_t jb = (uint32_t)(tile * 32 + 4 * g);      // row of accumulator register v: jb | (v & 3) | 8 (v >> 2)  (disjoint bits)
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const mfma_v16i &acc = s ? acc1 : acc0;
+            const uint32_t Tkey = (uint32_t)(T[s] + nAc[s]) << 16;      // the list's threshold distance as a key: d < th  <=>  key < Tkey
+            auto key_of = [&](int v) {
+                const uint32_t cv = (uint32_t)((v & 3) | (8 * (v >> 2)));
+                const uint32_t k = ((uint32_t)(nAc[s] + acc[v]) << 16) | jb | cv;
+                return (LAST && !((int)(jb | cv) < nB)) ? 0xffffffffu : k;
+            };
+            uint32_t q0 = Tkey, q1 = Tkey, q2 = Tkey, q3 = Tkey, q4 = Tkey;
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const uint32_t k = key_of(v);
+                q4 = med3_u32(q3, q4, k); q3 = med3_u32(q2, q3, k); q2 = med3_u32(q1, q2, k); q1 = med3_u32(q0, q1, k);
+                q0 = min(q0, k);
+            }
+            if (__any(q0 < Tkey)) {
+                if (__any(q4 < Tkey)) {
+#pragma unroll
+                    for (int v = 0; v < 16; v++) { const uint32_t k = key_of(v); topk_insert(kk[s], k < Tkey ? k : 0xffffffffu); }
+                } else {
+                    topk_insert(kk[s], q0 < Tkey ? q0 : 0xffffffffu);
+                    if (__any(q1 < Tkey)) {
+                        topk_insert(kk[s], q1 < Tkey ? q1 : 0xffffffffu);
+                        if (__any(q2 < Tkey)) {
+                            topk_insert(kk[s], q2 < Tkey ? q2 : 0xffffffffu);
+                            if (__any(q3 < Tkey)) topk_insert(kk[s], q3 < Tkey ? q3 : 0xffffffffu);
+                        }
+                    }
+                }
+                T[s] = (int)(kk[s][TOPK - 1] >> 16) - nAc[s];
+            }
+        }
+    };
+    for (int tile = 0; tile + 1 < ntiles; tile++) one_tile(tile, std::false_type());
+    if (ntiles > 0) one_tile(ntiles - 1, std::true_type());
+    // the two lanes of an A feature (rows 4 g .. of every tile each): merge the lists, lane half 0 writes
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        uint32_t other[TOPK];
+#pragma unroll
+        for (int q = 0; q < TOPK; q++) other[q] = (uint32_t)__shfl((int)kk[s][q], lane ^ 32);
+#pragma unroll
+        for (int q = 0; q < TOPK; q++) topk_insert(kk[s], other[q]);
+        if (g == 0 && live[s]) {
+            uint32_t *out = topk + ((size_t)p * stride + iA[s]) * TOPK;
+#pragma unroll
+            for (int k = 0; k < TOPK; k++) out[k] = kk[s][k] >= sentinel ? KEY_EMPTY : kk[s][k];
+        }
+    }
+}
+
 // greedy replay + rotation histogram + three-maxima pruning; one workgroup per pair.
 //
 // The reference's pass over the A features is sequential only through the "already matched" flag
@@ -1025,8 +1177,12 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     const dim3 gridTopk((unsigned)((a->capacity + TOPK_ROWS - 1) / TOPK_ROWS), (unsigned)npairs);
     if (filter)
         hipLaunchKernelGGL((k_bow_topk<true, false, TOPK_NROW>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
-    else
-        hipLaunchKernelGGL((k_bow_topk<false, false, TOPK_NROW>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
+    else {
+        static const bool mfma = !(getenv("ORBX_MATCH_MFMA") && getenv("ORBX_MATCH_MFMA")[0] == '0');
+        static const int dbg = getenv("ORBX_MFMA_DEBUG") ? atoi(getenv("ORBX_MFMA_DEBUG")) : 0;
+        if (mfma) hipLaunchKernelGGL(k_bow_topk_mfma, dim3((unsigned)((a->capacity + 255) / 256), (unsigned)npairs), dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, dcut, m->topk.p, stride, dbg);
+        else hipLaunchKernelGGL((k_bow_topk<false, false, TOPK_NROW>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
+    }
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->evMid[slot], m->stream));
     m->midValid[slot] = true;
