@@ -277,9 +277,9 @@ void Frame::ExtractORB(int flag, const cv::Mat &im)
     const orbx_keypoint *un = 0;
     const int32_t *off = 0, *idx = 0;
     int n = 0;
+    mvKeysUn = mvKeys;      // (while the kernel runs; UndistortKeyPoints() rebuilds it if the early results are not used)
     if (orbx_frame_finish_end(A->ops, &un, &off, &idx, &n) != ORBX_OK || n != (int)mvKeys.size() || !off || (n > 0 && !idx)) return;
     TRACE("left: undistortion + grid arrived");
-    mvKeysUn = mvKeys;
     if (un) for (int i = 0; i < n; i++) { mvKeysUn[(size_t)i].pt.x = un[i].x; mvKeysUn[(size_t)i].pt.y = un[i].y; }
     for (int x = 0; x < FRAME_GRID_COLS; x++)
         for (int y = 0; y < FRAME_GRID_ROWS; y++) {
