@@ -186,12 +186,9 @@ extern "C" int orbx_frame_ops_create(int device, const orbx_camera *cam, orbx_fr
     ORBX_HIP_CHECK(hipSetDevice(device));
     orbx_frame_ops *h = new orbx_frame_ops();
     h->device = device;
-    {   // a high-priority stream: the latency forms launch one small kernel next to another thread's extraction (the stereo constructor), and
-        // streams of that priority sit on hardware queues of their own (csrc/orbx_extractor.hip, comb_new_engine)
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi) != hipSuccess) h->stream = nullptr;
-    }
-    if (!h->stream && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
+    // (a plain stream: on a high-priority one - tried for the latency forms - the kernel shared a hardware queue with the combiner's second engines,
+    // which are the other high-priority streams of the process: the stereo constructor went from 265 to 390 us once a second image size had been used)
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
     CamDev &c = h->cam;
     c.fx = cam->fx; c.fy = cam->fy; c.cx = cam->cx; c.cy = cam->cy;
     for (int i = 0; i < 8; i++) c.k[i] = i < cam->ndist ? (double)cam->dist[i] : 0.0;

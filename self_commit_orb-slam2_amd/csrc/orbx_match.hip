@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256) void k_bow_topk(FeatDev A, FeatDev B, const in
 // The accumulator of a lane holds ONE A feature (its column) x 16 of the tile's B features (rows (v & 3) + 8 (v >> 2) + 4 g): the list
 // logic of k_bow_topk stays per lane - `acc < th - |A_i|`, first on group minima, the key only for the rare candidate that reaches the
 // list, ascending j per lane -, and the two lanes that share an A feature merge their lists at the end.
-// Bit-identical lists to k_bow_topk<false, false> (tests/test_matcher.py); ORBX_MATCH_MFMA=0 selects the VALU kernel.
+// Bit-identical lists to k_bow_topk<false, false> (tests/test_matcher.py).  NOT the default: BASELINE's north_star wants the Hamming match on
+// popcount-class wavefront primitives; ORBX_MATCH_MFMA=1 selects this kernel (bench.py reports its rate beside the headline).
 // ---------------------------------------------------------------------------------------------
 typedef int mfma_v4i __attribute__((ext_vector_type(4)));
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
@@ -1178,7 +1179,11 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     if (filter)
         hipLaunchKernelGGL((k_bow_topk<true, false, TOPK_NROW>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());
     else {
-        static const bool mfma = !(getenv("ORBX_MATCH_MFMA") && getenv("ORBX_MATCH_MFMA")[0] == '0');
+        // BASELINE's north_star asks for the Hamming match on __popcll-class wavefront primitives, not on the matrix cores: k_bow_topk is what
+        // runs.  ORBX_MATCH_MFMA=1 (read per call) selects k_bow_topk_mfma, the same lists from v_mfma_i32_32x32x32_i8 - a measured alternative
+        // (DESIGN.md section 7), bit-identical, not the default.
+        const char *em = getenv("ORBX_MATCH_MFMA");
+        const bool mfma = em && em[0] == '1';
         static const int dbg = getenv("ORBX_MFMA_DEBUG") ? atoi(getenv("ORBX_MFMA_DEBUG")) : 0;
         if (mfma) hipLaunchKernelGGL(k_bow_topk_mfma, dim3((unsigned)((a->capacity + 255) / 256), (unsigned)npairs), dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, dcut, m->topk.p, stride, dbg);
         else hipLaunchKernelGGL((k_bow_topk<false, false, TOPK_NROW>), gridTopk, dim3(256), 0, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, dcut, m->topk.p, stride, TriDev());

@@ -70,6 +70,30 @@ def test_config3_stereo_batch_extract_and_search_by_bow_left_right(orbx, oracle)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("W,H,nf,B", [(640, 480, 1000, 64), (1241, 376, 2000, 8)])
+def test_matrix_core_candidate_lists_equal_the_popcount_ones(orbx, monkeypatch, W, H, nf, B):
+    """k_bow_topk_mfma (ORBX_MATCH_MFMA=1: Hamming distances as v_mfma_i32_32x32x32_i8 products) against k_bow_topk (the default) on extracted
+    frames of one scene - consecutive views, the headline's workload: every match index, distance and count identical, both modes."""
+    frames = orbx.synth_sequence(900, B, W, H)
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
+    mt = orbx.ORBmatcher(0.7, True, max_features=ext.capacity, max_pairs=B - 1)
+    ext.run_device(*ext.upload(frames))
+    ext.sync()                         # (the matcher below is not chained to the extractor: its stream knows nothing of this batch)
+    fs = orbx.ORBmatcher.features_of(ext, B)
+    fa, fb = np.arange(B - 1, dtype=np.int32), np.arange(1, B, dtype=np.int32)
+    for mode in (0, 1):
+        res = {}
+        for sw in ("0", "1"):
+            monkeypatch.setenv("ORBX_MATCH_MFMA", sw)
+            mt.search_by_bow_device(fs, fs, fa, fb, mode=mode)
+            res[sw] = [x.copy() for x in mt.download(B - 1)]
+        for x, y in zip(res["0"], res["1"]):
+            assert x.shape == y.shape and (x == y).all(), mode
+        assert res["0"][2].mean() > 100
+    mt.close(); ext.close()
+
+
+@pytest.mark.gpu
 def test_white_noise_is_extracted_like_the_reference(orbx):
     """White noise gives > 100k FAST candidates in level 0 of a 1241x376 frame.  The reference's std::vectors just grow
     (src/ORBextractor.cc:1075 only reserves); the quadtree's point arrays are sized for the worst case - every second pixel in both

@@ -1,5 +1,7 @@
 """Hamming matchers: known-answer tests on CPU (oracle + host helper), index-exact parity of
 the HIP path against the oracle on the GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -75,9 +77,14 @@ def _noisy_pair(rng, n, orbx, flip_bits=18, extra=200):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mfma", [False, True])
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("groups", [False, True])
-def test_search_by_bow_hip_index_exact(orbx, oracle, mode, groups):
+def test_search_by_bow_hip_index_exact(orbx, oracle, monkeypatch, mode, groups, mfma):
+    """mfma: the unfiltered (brute-force) candidate lists from k_bow_topk_mfma (ORBX_MATCH_MFMA=1, a measured alternative, not the
+    default; with groups the switch changes nothing: the filtered kernel is the popcount one)."""
+    if mfma:
+        monkeypatch.setenv("ORBX_MATCH_MFMA", "1")
     rng = np.random.default_rng(10 + mode + 2 * groups)
     mt = orbx.ORBmatcher(0.7, True, max_features=2600)
     for trial in range(6):
@@ -106,10 +113,15 @@ def test_search_by_bow_degenerate_ties(orbx, oracle):
     dB = np.repeat(base, 50, axis=0)[rng.permutation(400)]
     kA, kB = _kps(rng, len(dA), orbx), _kps(rng, len(dB), orbx)
     mt = orbx.ORBmatcher(0.95, False, max_features=512)
-    for mode in (0, 1):
-        want_n, want = oracle_lib.search_by_bow(oracle, mode, kA, dA, kB, dB, 0.95, False)
-        got_n, got = mt.SearchByBoW(kA, dA, kB, dB, mode=mode)
-        assert got_n == want_n and (got == want).all()
+    for mfma in ("0", "1"):          # (both candidate-list kernels: popcount and matrix cores)
+        os.environ["ORBX_MATCH_MFMA"] = mfma
+        try:
+            for mode in (0, 1):
+                want_n, want = oracle_lib.search_by_bow(oracle, mode, kA, dA, kB, dB, 0.95, False)
+                got_n, got = mt.SearchByBoW(kA, dA, kB, dB, mode=mode)
+                assert got_n == want_n and (got == want).all(), (mfma, mode)
+        finally:
+            del os.environ["ORBX_MATCH_MFMA"]
     mt.close()
 
 

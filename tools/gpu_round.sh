@@ -16,6 +16,8 @@ fi
 # the drop-in surface as the reference calls it (C++ loops): one thread, 1..16 threads, the stereo Frame constructor; every single-call latency; the VALU issue table
 ORBX_SHIM_BENCH_STATS=1 timeout 400 python tools/latency_shim.py > $O/latency_shim_$TAG.jsonl 2> $O/latency_shim_$TAG.err; echo "latency_shim rc $?"
 timeout 300 python tools/latency_calls.py > $O/latency_calls_$TAG.txt 2>&1; echo "latency_calls rc $?"
+# the stereo Frame constructor of the drop-in library: timeline of one constructor, quantiles of 300, per-kernel device times
+(timeout 200 python tools/latency_shim.py --trace; ORBSLAM_BENCH_QUANTILES=1 timeout 200 python tools/prof_stereo_ctor.py 300; ORBX_SHIM_EARLY=0 ORBSLAM_BENCH_QUANTILES=1 timeout 200 python tools/prof_stereo_ctor.py 300; bash tools/kernel_times.sh sc_$TAG python $ROOT/tools/prof_stereo_ctor.py 300) > $O/stereo_ctor_$TAG.txt 2>&1; echo "stereo ctor rc $?"
 if [ -x tools/_build/ubench_valu ]; then (echo "# rocm-smi before:"; rocm-smi --showclocks 2>/dev/null | grep -i sclk | head -2; tools/_build/ubench_valu; echo "# rocm-smi after:"; rocm-smi --showclocks 2>/dev/null | grep -i sclk | head -2) > $O/valu_issue_$TAG.txt 2>&1; fi
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc $?"; cut -c1-400 $O/bench_$TAG.json
 # RCCL for real: one rank under the launcher the driver uses, backend nccl (init with device_id, all-reduce, all-gather, barriers)

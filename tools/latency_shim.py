@@ -157,6 +157,7 @@ def measure(orbx, quick=False):
            "fps_8threads": pick(threads=8, host_pyramid=False, combiner=True).get("frames_per_s"),
            "fps_16threads": pick(threads=16, host_pyramid=False, combiner=True).get("frames_per_s"),
            "stereo_frame_ctor_us": pick(library="liborbslam_hip.so (drop-in)", combiner=True).get("mean_us"),
+           "stereo_frame_ctor_median_us": pick(library="liborbslam_hip.so (drop-in)", combiner=True).get("median_us"),
            "source": "tools/latency_shim.py: C++ loops over the reference's call shapes (tests/shim_wrap.cc, oracle/refslam_wrap.cc)"}
     return {"rows": rows, "digest": dig}
 
