@@ -799,16 +799,16 @@ def host_io_batch(orbx, a, local, seconds=1.0):
     W, H, B, nf = a.width, a.height, min(a.batch, 256), a.nfeatures
     ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local)
     frames = orbx.synth_sequence(991, B, W, H)
-    ext.extract_batch(frames)
+    res = ext.extract_batch(frames)
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        kps, desc, counts = ext.extract_batch(frames)
+        kps, desc, counts = ext.extract_batch(frames, out=res)
         n += 1
     dt = time.perf_counter() - t0
     cap = ext.capacity
     ext.close()
     return {"frames_per_s": round(n * B / dt, 1), "batch": B, "ms_per_batch": round(dt / n * 1e3, 3), "keypoints_per_frame": round(float(counts.mean()), 1),
-            "note": "host pointers in, host arrays out, synchronous (includes the Python harness allocating the %d MB result arrays per call)" % ((B * cap * 60) >> 20)}
+            "note": "host pointers in (pageable), host arrays out, synchronous: %d MB up and %d MB of result arrays down per call; the result arrays are reused" % ((B * W * H) >> 20, (B * cap * 60) >> 20)}
 
 
 def main():

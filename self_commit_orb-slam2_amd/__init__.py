@@ -234,15 +234,20 @@ class ORBextractor:
         _check(self._L.orbx_combiner_stats(self._h, ctypes.byref(b), ctypes.byref(f), ctypes.byref(e)))
         return b.value, f.value, e.value
 
-    def extract_batch(self, images):
+    def extract_batch(self, images, out=None):
+        """out = (kps, desc, counts) of an earlier call: the result arrays are reused (a caller in a loop; allocating and zeroing 60 bytes x
+        capacity x batch per call costs as much as the call)."""
         B = len(images)
         H, W = images[0].shape
         imgs = [np.ascontiguousarray(im) for im in images]
         arr = (ctypes.c_void_p * B)(*[im.ctypes.data for im in imgs])
         cap = self.capacity
-        kps = np.zeros((B, cap), KEYPOINT_DTYPE)
-        desc = np.zeros((B, cap, 32), np.uint8)
-        counts = np.zeros(B, np.int32)
+        if out is not None and out[0].shape == (B, cap) and out[1].shape == (B, cap, 32) and out[2].shape == (B,):
+            kps, desc, counts = out
+        else:
+            kps = np.zeros((B, cap), KEYPOINT_DTYPE)
+            desc = np.zeros((B, cap, 32), np.uint8)
+            counts = np.zeros(B, np.int32)
         _check(self._L.orbx_extract_batch(self._h, arr, B, W, H, W, _ptr(kps), _ptr(desc), cap, _ptr(counts)))
         self._last_size = (W, H)
         return kps, desc, counts
