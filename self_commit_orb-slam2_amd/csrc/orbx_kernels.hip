@@ -588,20 +588,20 @@ template <typename T> __device__ __forceinline__ T wave_incl_scan(T v, int lane)
     return v;
 }
 
-// exclusive scan of arr[0..n) in place (LDS); returns the total.  All 256 threads call.
-template <typename T> __device__ T block_exscan(T *arr, int n, T *wsum /* >= 5 entries */)
+// exclusive scan of arr[0..n) in place (LDS); returns the total.  All BT threads of the workgroup call.
+template <int BT = 256, typename T> __device__ T block_exscan(T *arr, int n, T *wsum /* >= BT / 64 entries */)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int per = (n + 255) >> 8;
+    const int per = (n + BT - 1) / BT;
     const int b = tid * per;
     T s = 0;
     for (int k = 0; k < per; k++) if (b + k < n) s += arr[b + k];
     T inc = wave_incl_scan(s, lane);
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    T off = 0;
-    for (int i = 0; i < w; i++) off += wsum[i];
-    T total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    T off = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < BT / 64; i++) { const T v = wsum[i]; off += i < w ? v : (T)0; total += v; }
     T run = off + inc - s;
     for (int k = 0; k < per; k++)
         if (b + k < n) { T v = arr[b + k]; arr[b + k] = run; run += v; }
@@ -611,10 +611,10 @@ template <typename T> __device__ T block_exscan(T *arr, int n, T *wsum /* >= 5 e
 
 // Two exclusive scans at once over entries that the calling thread FILLS itself: thread t owns the contiguous entries
 // [t*per, (t+1)*per), fill(i, a, b) produces entry i of both arrays, so no barrier is needed between filling and scanning.
-template <typename F> __device__ __forceinline__ void block_fill_exscan2(int *A, int *B, int n, int *wsA, int *wsB, int &totA, int &totB, F fill)
+template <int BT = 256, typename F> __device__ __forceinline__ void block_fill_exscan2(int *A, int *B, int n, int *wsA, int *wsB, int &totA, int &totB, F fill)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int per = (n + 255) >> 8;
+    const int per = (n + BT - 1) / BT;
     const int b = tid * per;
     int sa = 0, sb = 0;
     for (int k = 0; k < per; k++)
@@ -623,9 +623,9 @@ template <typename F> __device__ __forceinline__ void block_fill_exscan2(int *A,
     if (lane == 63) { wsA[w] = incA; wsB[w] = incB; }
     __syncthreads();
     int offA = 0, offB = 0;
-    for (int i = 0; i < w; i++) { offA += wsA[i]; offB += wsB[i]; }
-    totA = wsA[0] + wsA[1] + wsA[2] + wsA[3];
-    totB = wsB[0] + wsB[1] + wsB[2] + wsB[3];
+    totA = 0; totB = 0;
+#pragma unroll
+    for (int i = 0; i < BT / 64; i++) { const int va = wsA[i], vb = wsB[i]; offA += i < w ? va : 0; offB += i < w ? vb : 0; totA += va; totB += vb; }
     int runA = offA + incA - sa, runB = offB + incB - sb;
     for (int k = 0; k < per; k++)
         if (b + k < n) { const int a = A[b + k], c = B[b + k]; A[b + k] = runA; B[b + k] = runB; runA += a; runB += c; }
@@ -641,7 +641,7 @@ __device__ __forceinline__ int ot_quadrant(uint32_t p, const OtBox b)
 
 // The quadtree of ONE (level, frame): the body shared by k_octree (batches: one workgroup per (level, frame) through the XCD bijection) and by
 // k_octree_blur (combined single-frame calls: the blur's tiles and the host pyramid copy ride in the same launch).
-template <int NODECAP>
+template <int NODECAP, int BT>      // BT = threads of the workgroup (256 in batches: 2048 quadtrees per launch; 1024 in the single-frame launch sets: eight)
 __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, const int *__restrict__ cellCount, const uint32_t *__restrict__ cellSlots,
                                             const uint8_t *__restrict__ binTab, uint32_t *__restrict__ ptBuf, uint32_t *__restrict__ labBuf,
                                             OrbxLevelKp *__restrict__ lvlKp, int *__restrict__ lvlCnt, int *__restrict__ status, const int l, const int f, const int nframes)
@@ -655,7 +655,7 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
     __shared__ __attribute__((aligned(16))) uint32_t key[NODECAP];     // careful rounds: (count << log2 NODECAP) | (NODECAP - 1 - list position) of a candidate, 0 otherwise
     __shared__ unsigned short byProc[NODECAP];      // careful rounds: processing rank -> node
     __shared__ unsigned char sel[NODECAP];          // node is split in this round
-    __shared__ int wsA[8], wsB[8];
+    __shared__ int wsA[16], wsB[16];
     __shared__ int sh_misc[8];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -670,15 +670,15 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
     const int ncell = lv.nCols * lv.nRows;
     const int *cc = cellCount + (size_t)f * g->cellsPerFrame + lv.cellBase;
     int *cellOff = (int *)lab;        // scratch: labels are written after the gather
-    for (int i = tid; i < ncell; i += 256) cellOff[i] = cc[i];
+    for (int i = tid; i < ncell; i += BT) cellOff[i] = cc[i];
     if (tid < 8) sh_misc[tid] = 0;
     __syncthreads();
-    const int M = block_exscan(cellOff, ncell, wsA);
+    const int M = block_exscan<BT>(cellOff, ncell, wsA);
     {
         const uint32_t *slots = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase;
         // one THREAD per cell: a cell holds a handful of candidates, and a wave walking the cells one after the other pays a memory
         // round trip per cell
-        for (int c = tid; c < ncell; c += 256) {
+        for (int c = tid; c < ncell; c += BT) {
             const int n = cc[c], o = cellOff[c];
             const uint32_t *sc = slots + (size_t)c * lv.cellCap;
             for (int k = 0; k < n; k++) pts[o + k] = sc[k];
@@ -692,7 +692,7 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
     {
         const uint8_t *bin = binTab + lv.binOff;
         int c4[4] = {0, 0, 0, 0};
-        for (int j0 = 0; j0 < M; j0 += 256) {
+        for (int j0 = 0; j0 < M; j0 += BT) {
             const int j = j0 + tid;
             const int q = j < M ? (int)bin[pts[j] & 0xfff] : -1;
 #pragma unroll
@@ -714,7 +714,7 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
         for (int Q = 0; Q < 4; Q++) if (idx[Q] >= 0 && sh_misc[4 + Q] > 1) ncand++;
         if (tid < 4) wsB[4 + tid] = idx[tid];      // bin -> node (a runtime-indexed register array would live in scratch memory)
         __syncthreads();
-        for (int j = tid; j < M; j += 256) {
+        for (int j = tid; j < M; j += BT) {
             const uint32_t p = pts[j];
             const int nd = wsB[4 + bin[p & 0xfff]];
             lab[j] = (uint32_t)nd;
@@ -732,7 +732,7 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
         if (!careful) {
             // full pass: every candidate is split, in list order (slot k = node k)
             nsel = nn;
-            block_fill_exscan2(scanA, scanB, nn, wsA, wsB, totalCreated, nUnsel, [&](int i, int &a, int &b) {
+            block_fill_exscan2<BT>(scanA, scanB, nn, wsA, wsB, totalCreated, nUnsel, [&](int i, int &a, int &b) {
                 const bool isc = cnt[cur][i] > 1;
                 sel[i] = isc ? 1 : 0;
                 a = isc ? (qc[cur][i][0] != 0) + (qc[cur][i][1] != 0) + (qc[cur][i][2] != 0) + (qc[cur][i][3] != 0) : 0;
@@ -746,14 +746,14 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
             // The count field is 32 - log2 NODECAP bits wide (2^21 candidates in one node at NODECAP 2048, 2^24 at 256): build_geometry
             // (orbx_extractor.hip) refuses a level whose worst-case candidate count does not fit.
             constexpr int KEY_SHIFT = NODECAP == 256 ? 8 : NODECAP == 512 ? 9 : NODECAP == 1024 ? 10 : 11;
-            for (int i = tid; i < ((nn + 3) & ~3); i += 256) {
+            for (int i = tid; i < ((nn + 3) & ~3); i += BT) {
                 const int c = i < nn ? cnt[cur][i] : 0;
                 key[i] = c > 1 ? ((uint32_t)c << KEY_SHIFT) | (uint32_t)(NODECAP - 1 - i) : 0u;
                 if (i < nn) sel[i] = 0;
             }
             if (tid == 0) sh_misc[1] = ncand;
             __syncthreads();
-            for (int i = tid; i < nn; i += 256) {
+            for (int i = tid; i < nn; i += BT) {
                 const uint32_t ki = key[i];
                 if (ki) {
                     int rank = 0;
@@ -766,29 +766,29 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
             }
             __syncthreads();
             int totAll, dummy;
-            block_fill_exscan2(scanA, scanB, ncand, wsA, wsB, totAll, dummy, [&](int k, int &a, int &b) {
+            block_fill_exscan2<BT>(scanA, scanB, ncand, wsA, wsB, totAll, dummy, [&](int k, int &a, int &b) {
                 const int i = byProc[k];
                 a = (qc[cur][i][0] != 0) + (qc[cur][i][1] != 0) + (qc[cur][i][2] != 0) + (qc[cur][i][3] != 0);
                 b = a;          // children of slot k, kept next to its exclusive prefix
             });
             // smallest k with  nn + sum_{j<=k}(children_j - 1) >= N  (:1003); scanB[k] is exclusive too: children_k = next prefix - this one
-            for (int k = tid; k < ncand; k += 256) {
+            for (int k = tid; k < ncand; k += BT) {
                 const int ck = (k + 1 < ncand ? scanA[k + 1] : totAll) - scanA[k];
                 if (nn + scanA[k] + ck - (k + 1) >= N) atomicMin(&sh_misc[1], k + 1);
             }
             __syncthreads();
             nsel = sh_misc[1];
             totalCreated = nsel < ncand ? scanA[nsel] : totAll;
-            for (int k = tid; k < nsel; k += 256) sel[byProc[k]] = 1;
+            for (int k = tid; k < nsel; k += BT) sel[byProc[k]] = 1;
             __syncthreads();
             int dummy2;
-            block_fill_exscan2(scanB, scanB, nn, wsA, wsB, dummy2, nUnsel, [&](int i, int &a, int &b) { a = b = sel[i] ? 0 : 1; });
+            block_fill_exscan2<BT>(scanB, scanB, nn, wsA, wsB, dummy2, nUnsel, [&](int i, int &a, int &b) { a = b = sel[i] ? 0 : 1; });
         }
         const int newN = totalCreated + nUnsel;
         if (newN > NODECAP) { if (tid == 0) { atomicOr(stat, ORBX_DEV_ERR_NODECAP); atomicOr(statAll, ORBX_DEV_ERR_NODECAP); } break; }
         // ---- the new list: reversed children (push_front of each child, :676-699 / :964-1000) ++ the untouched nodes in their old order ----
         int myCand = 0, myExpand = 0;
-        for (int i = tid; i < nn; i += 256) {
+        for (int i = tid; i < nn; i += BT) {
             if (sel[i]) continue;
             const int pos = totalCreated + scanB[i];
             box[nxt][pos] = box[cur][i];
@@ -800,7 +800,7 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
             }
             nmap[i][0] = nmap[i][1] = nmap[i][2] = nmap[i][3] = (unsigned short)pos;
         }
-        for (int k = tid; k < nsel; k += 256) {
+        for (int k = tid; k < nsel; k += BT) {
             const int i = careful ? (int)byProc[k] : k;
             if (!sel[i]) continue;
             const OtBox nd = box[cur][i];
@@ -829,7 +829,7 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
         ncand = nToExpand + sh_misc[3];
         const bool finish = newN >= N || newN == prev;                   // :907-913, :1007
         // ---- point pass: new labels; points of freshly created nodes with more than one point feed the next round's counts ----
-        for (int j = tid; j < M; j += 256) {
+        for (int j = tid; j < M; j += BT) {
             const int nd = (int)lab[j];
             if (!sel[nd]) { lab[j] = nmap[nd][0]; continue; }
             const uint32_t p = pts[j];
@@ -851,14 +851,14 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
         OrbxLevelKp *out = lvlKp + (size_t)f * g->kpPerFrame + lv.kpBase;
         if (nn > lv.kpCap) { if (tid == 0) { atomicOr(stat, ORBX_DEV_ERR_KPCAP); atomicOr(statAll, ORBX_DEV_ERR_KPCAP); } nn = lv.kpCap; }
         __syncthreads();
-        for (int i = tid; i < NODECAP; i += 256) best[i] = 0u;
+        for (int i = tid; i < NODECAP; i += BT) best[i] = 0u;
         __syncthreads();
-        for (int j = tid; j < M; j += 256) {
+        for (int j = tid; j < M; j += BT) {
             const uint32_t nd = lab[j];
             if (nd < (uint32_t)NODECAP) atomicMax(&best[nd], (pts[j] & 0xff000000u) | (0x00ffffffu - (uint32_t)j));
         }
         __syncthreads();
-        for (int i = tid; i < nn; i += 256) {
+        for (int i = tid; i < nn; i += BT) {
             const uint32_t b = pts[0x00ffffffu - (best[i] & 0x00ffffffu)];
             OrbxLevelKp kp;
             kp.x = (uint16_t)((b & 0xfff) + ORBX_BORDER); kp.y = (uint16_t)(((b >> 12) & 0xfff) + ORBX_BORDER);
@@ -875,8 +875,8 @@ __device__ __forceinline__ void host_pyramid_copy(const OrbxGeom *__restrict__ g
     uint4 *dst = (uint4 *)comb[f].hostPyr;
     if (!dst) return;
     const uint4 *src = (const uint4 *)(engPyr + (size_t)f * g->pyrBytes);
-    const size_t n = g->pyrBytes >> 4, stride = (size_t)nchunks * 256;
-    for (size_t i = (size_t)chunk * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    const size_t n = g->pyrBytes >> 4, bt = blockDim.x, stride = (size_t)nchunks * bt;
+    for (size_t i = (size_t)chunk * bt + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
 template <int NODECAP>
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256) void k_octree(const OrbxGeom *__restrict__ g, 
         host_pyramid_copy(g, comb, engPyr, f, l - g->nlevels, (int)gridDim.x - g->nlevels);
         return;
     }
-    octree_body<NODECAP>(g, cellCount, cellSlots, binTab, ptBuf, labBuf, lvlKp, lvlCnt, status, l, f, (int)gridDim.y);
+    octree_body<NODECAP, 256>(g, cellCount, cellSlots, binTab, ptBuf, labBuf, lvlKp, lvlCnt, status, l, f, (int)gridDim.y);
 }
 
 // sin/cos of the keypoint angle: glibc's sinf/cosf algorithm in double, restated so the device
@@ -1137,18 +1137,19 @@ __global__ __launch_bounds__(64) void k_blur(const OrbxGeom *__restrict__ g, con
 // behind it: one kernel boundary and the blur's own ~7-13 us off the chain of every launch set.  Batches keep the separate launches
 // (k_octree's 20 KB of LDS per workgroup would cap the blur's occupancy there).  blockIdx.x: [0, nlevels) quadtree, then the copy
 // workgroups, then the blur workgroups; blockIdx.y = frame.
+#define OB_THREADS 1024      /* sixteen waves: the quadtree's passes over a level's candidates (3000 at level 0 of a 1241x376 frame) take a quarter of the steps */
 template <int NODECAP, bool CLAMP>
-__global__ __launch_bounds__(256) void k_octree_blur(const OrbxGeom *__restrict__ g, const int *__restrict__ cellCount, const uint32_t *__restrict__ cellSlots,
+__global__ __launch_bounds__(OB_THREADS) void k_octree_blur(const OrbxGeom *__restrict__ g, const int *__restrict__ cellCount, const uint32_t *__restrict__ cellSlots,
                                                      const uint8_t *__restrict__ binTab, uint32_t *__restrict__ ptBuf, uint32_t *__restrict__ labBuf,
                                                      OrbxLevelKp *__restrict__ lvlKp, int *__restrict__ lvlCnt, int *__restrict__ status,
                                                      const OrbxCombMember *__restrict__ comb, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
                                                      uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t blurLds[];      // 4 windows of BT_IH x BT_P bytes (the blur role)
+    extern __shared__ __attribute__((aligned(16))) uint32_t blurLds[];      // OB_THREADS / 64 windows of BT_IH x BT_P bytes (the blur role)
     const int bx = (int)blockIdx.x, f = (int)blockIdx.y, nl = g->nlevels;
-    if (bx < nl) { octree_body<NODECAP>(g, cellCount, cellSlots, binTab, ptBuf, labBuf, lvlKp, lvlCnt, status, bx, f, (int)gridDim.y); return; }
+    if (bx < nl) { octree_body<NODECAP, OB_THREADS>(g, cellCount, cellSlots, binTab, ptBuf, labBuf, lvlKp, lvlCnt, status, bx, f, (int)gridDim.y); return; }
     if (bx < nl + ORBX_OCTREE_COPY_BLOCKS) { host_pyramid_copy(g, comb, pyr, f, bx - nl, ORBX_OCTREE_COPY_BLOCKS); return; }
-    const int wv = (int)(threadIdx.x >> 6), tile = __builtin_amdgcn_readfirstlane((bx - nl - ORBX_OCTREE_COPY_BLOCKS) * 4 + wv);      // (uniform in the wave: scalar bookkeeping)
+    const int wv = (int)(threadIdx.x >> 6), tile = __builtin_amdgcn_readfirstlane((bx - nl - ORBX_OCTREE_COPY_BLOCKS) * (OB_THREADS / 64) + wv);      // (uniform in the wave: scalar bookkeeping)
     blur_body<CLAMP>(g, img0, img0Stride, img0FramePitch, pyr, blur, min(tile, g->blurTiles - 1), f, blurLds + wv * (BT_IH * (BT_P / 4)), (int)(threadIdx.x & 63), tile < g->blurTiles);
 }
 
@@ -1510,10 +1511,24 @@ int orbx_launch_octree_blur(const OrbxLaunch &L, bool *fused)
     if (!L.combTab || L.nodeCap > 512) return ORBX_OK;
     unsigned tapSum = 0;
     for (int i = 0; i < 7; i++) tapSum += L.geom->taps[i];
-    const dim3 grid((unsigned)(L.geom->nlevels + ORBX_OCTREE_COPY_BLOCKS + (L.geom->blurTiles + 3) / 4), (unsigned)L.batch);
-    const size_t lds = (size_t)4 * BT_IH * BT_P;
+    const int tpb = OB_THREADS / 64;      // blur tiles per workgroup
+    const dim3 grid((unsigned)(L.geom->nlevels + ORBX_OCTREE_COPY_BLOCKS + (L.geom->blurTiles + tpb - 1) / tpb), (unsigned)L.batch);
+    const size_t lds = (size_t)tpb * BT_IH * BT_P;
+    {   // (static quadtree arrays + the blur windows: above the default 64 KB of dynamic + static LDS per workgroup)
+        static bool granted[2][2];
+        const int a = L.nodeCap <= 256 ? 0 : 1;
+        unsigned ts = 0;
+        for (int i = 0; i < 7; i++) ts += L.geom->taps[i];
+        const int b = ts > 256u ? 1 : 0;
+        if (!granted[a][b]) {
+            const void *fn = a == 0 ? (b ? (const void *)k_octree_blur<256, true> : (const void *)k_octree_blur<256, false>) : (b ? (const void *)k_octree_blur<512, true> : (const void *)k_octree_blur<512, false>);
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { orbx_set_error("hipFuncSetAttribute(k_octree_blur) failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+            granted[a][b] = true;
+        }
+    }
     *fused = true;
-#define OB_LAUNCH(NC, CL) return emit(L, k_octree_blur<NC, CL>, grid, dim3(256), lds, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.labBuf, L.lvlKp, L.lvlCnt, L.status, L.combTab, \
+#define OB_LAUNCH(NC, CL) return emit(L, k_octree_blur<NC, CL>, grid, dim3(OB_THREADS), lds, L.geomDev, L.cellCount, L.cellSlots, L.binTab, L.ptBuf, L.labBuf, L.lvlKp, L.lvlCnt, L.status, L.combTab, \
                                       L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur)
     if (L.nodeCap <= 256) { if (tapSum > 256u) OB_LAUNCH(256, true); OB_LAUNCH(256, false); }
     if (tapSum > 256u) OB_LAUNCH(512, true);
