@@ -70,14 +70,14 @@ __global__ void k_undistort_corners(CamDev c, float cols, float rows, float *out
 static_assert(NCELL % FT == 0, "cells per thread");
 __global__ __launch_bounds__(FT) void k_frame_finish(CamDev c, orbx_frame_grid g, int undistort, int grid, const orbx_keypoint *__restrict__ kp,
                                                      const int32_t *__restrict__ counts, int cap, orbx_keypoint *__restrict__ kpUn,
-                                                     int32_t *__restrict__ gridOff, int32_t *__restrict__ gridIdx, int *__restrict__ doneFlag, int doneSeq)
+                                                     int32_t *__restrict__ gridOff, int32_t *__restrict__ gridIdx, int *__restrict__ doneFlag, int doneSeq, int wide)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int sWave[FT / 64];
     int *cnt = (int *)smem;                                   // [NCELL] counts, then cursors
     int *off = cnt + NCELL;                                   // [NCELL + 1]
-    unsigned short *cell = (unsigned short *)(off + NCELL + 1 + 1);   // [cap]
-    int *sorted = (int *)(cell + ((cap + 7) & ~7));           // [cap]
+    unsigned short *cell = (unsigned short *)(off + NCELL + 4);       // [cap]  (off padded to a multiple of four entries: 16-byte rows for the write-out)
+    int *sorted = (int *)(cell + ((cap + 7) & ~7));           // [cap rounded up to 4]
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = counts ? min(counts[f], cap) : cap;
     const orbx_keypoint *in = kp + (size_t)f * cap;
@@ -138,9 +138,17 @@ __global__ __launch_bounds__(FT) void k_frame_finish(CamDev c, orbx_frame_grid g
     }
     __syncthreads();
     int32_t *go = gridOff + (size_t)f * (NCELL + 1), *gi = gridIdx + (size_t)f * cap;
-    for (int t = tid; t <= NCELL; t += FT) go[t] = off[t];
+    // 16 bytes per lane: in the latency form the destination is pinned host memory, and four-byte stores across PCIe made the release below
+    // wait 6-8 us for their completion (s_memrealtime: 7 of the kernel's 16 us); the rows and the buffers are padded to multiples of four entries
+    // (wide: one frame, 16-byte aligned destinations padded to multiples of four entries - the latency forms; the batched form packs the frames)
     const int total = off[NCELL];
-    for (int t = tid; t < total; t += FT) gi[t] = sorted[t];
+    if (wide) {
+        for (int t = tid; t < (NCELL + 4) / 4; t += FT) ((uint4 *)go)[t] = ((const uint4 *)off)[t];
+        for (int t = tid; t < (total + 3) / 4; t += FT) ((uint4 *)gi)[t] = ((const uint4 *)sorted)[t];
+    } else {
+        for (int t = tid; t <= NCELL; t += FT) go[t] = off[t];
+        for (int t = tid; t < total; t += FT) gi[t] = sorted[t];
+    }
     if (doneFlag) {
         __threadfence_system();
         __syncthreads();
@@ -240,13 +248,13 @@ static int launch_finish(orbx_frame_ops *h, hipStream_t stream, const orbx_frame
     const int b = h->cur;
     if (undistort && (rc = h->kpUn[b].ensure((size_t)batch * cap))) return rc;
     if (grid && ((rc = h->gridOff[b].ensure((size_t)batch * (NCELL + 1))) || (rc = h->gridIdx[b].ensure((size_t)batch * cap)))) return rc;
-    const size_t lds = (size_t)(2 * NCELL + 2) * 4 + (size_t)((cap + 7) & ~7) * 2 + (size_t)cap * 4;
+    const size_t lds = (size_t)(2 * NCELL + 4) * 4 + (size_t)((cap + 7) & ~7) * 2 + (size_t)((cap + 3) & ~3) * 4;
     if (lds > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", cap); return ORBX_ERR_CAPACITY; }
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_frame_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     orbx_frame_grid g = {0.0f, 0.0f, 0.0f, 0.0f};
     if (grid) g = *grid;
     hipLaunchKernelGGL(k_frame_finish, dim3((unsigned)batch), dim3(FT), lds, stream, h->cam, g, undistort ? 1 : 0, grid ? 1 : 0, kp, counts, cap,
-                       undistort ? h->kpUn[b].p : nullptr, grid ? h->gridOff[b].p : nullptr, grid ? h->gridIdx[b].p : nullptr, (int *)nullptr, 0);
+                       undistort ? h->kpUn[b].p : nullptr, grid ? h->gridOff[b].p : nullptr, grid ? h->gridIdx[b].p : nullptr, (int *)nullptr, 0, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     h->lastBatch = batch; h->lastCap = cap;
@@ -330,14 +338,14 @@ static int host_form(orbx_frame_ops *h, const orbx_frame_grid *grid, bool undist
     }
     if (n > 0) memcpy(h->hostIO + oIn, keypoints, (size_t)n * sizeof(orbx_keypoint));
     *(int32_t *)(h->hostIO + oCnt) = n;
-    const size_t lds = (size_t)(2 * NCELL + 2) * 4 + (size_t)((cap + 7) & ~7) * 2 + (size_t)cap * 4;
+    const size_t lds = (size_t)(2 * NCELL + 4) * 4 + (size_t)((cap + 7) & ~7) * 2 + (size_t)((cap + 3) & ~3) * 4;
     if (lds > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", cap); return ORBX_ERR_CAPACITY; }
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_frame_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     orbx_frame_grid g = {0.0f, 0.0f, 0.0f, 0.0f};
     if (grid) g = *grid;
     uint8_t *d = h->hostIODev;
     hipLaunchKernelGGL(k_frame_finish, dim3(1), dim3(FT), lds, h->stream, h->cam, g, undistort ? 1 : 0, grid ? 1 : 0, (const orbx_keypoint *)(d + oIn), (const int32_t *)(d + oCnt), cap,
-                       undistort ? (orbx_keypoint *)(d + oUn) : nullptr, grid ? (int32_t *)(d + oOff) : nullptr, grid ? (int32_t *)(d + oIdx) : nullptr, (int *)nullptr, 0);
+                       undistort ? (orbx_keypoint *)(d + oUn) : nullptr, grid ? (int32_t *)(d + oOff) : nullptr, grid ? (int32_t *)(d + oIdx) : nullptr, (int *)nullptr, 0, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -376,7 +384,7 @@ extern "C" int orbx_frame_finish_begin(orbx_frame_ops *h, orbx_extractor *ext, c
         h->hostIODev = (uint8_t *)dp;
         h->hostIOBytes = total;
     }
-    const size_t lds = (size_t)(2 * NCELL + 2) * 4 + (size_t)((cap + 7) & ~7) * 2 + (size_t)cap * 4;
+    const size_t lds = (size_t)(2 * NCELL + 4) * 4 + (size_t)((cap + 7) & ~7) * 2 + (size_t)((cap + 3) & ~3) * 4;
     if (lds > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", cap); return ORBX_ERR_CAPACITY; }
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_frame_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     orbx_frame_grid g = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -385,7 +393,7 @@ extern "C" int orbx_frame_finish_begin(orbx_frame_ops *h, orbx_extractor *ext, c
     const int seq = ++h->pendSeq;
     *(volatile int *)(h->hostIO + oFlag) = 0;
     hipLaunchKernelGGL(k_frame_finish, dim3(1), dim3(FT), lds, h->stream, h->cam, g, undist ? 1 : 0, grid ? 1 : 0, view.kp, view.counts, cap,
-                       undist ? (orbx_keypoint *)(d + oUn) : nullptr, grid ? (int32_t *)(d + oOff) : nullptr, grid ? (int32_t *)(d + oIdx) : nullptr, (int *)(d + oFlag), seq);
+                       undist ? (orbx_keypoint *)(d + oUn) : nullptr, grid ? (int32_t *)(d + oOff) : nullptr, grid ? (int32_t *)(d + oIdx) : nullptr, (int *)(d + oFlag), seq, 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     h->pending = 2; h->pendingN = n; h->pendingUn = undist; h->pendingGrid = grid != nullptr;
