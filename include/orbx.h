@@ -254,7 +254,10 @@ void orbx_matcher_destroy(orbx_matcher *m);
  * outputs are being consumed; may be NULL).  Results stay on the device:
  *   matches[p*stride + slot] = index of the matched feature in the other set or -1,
  *   dists[p*stride + slot]   = Hamming distance of that match,
- *   nmatches[p]              = return value of SearchByBoW.                              */
+ *   nmatches[p]              = return value of SearchByBoW.
+ * The Hamming distances are XOR + population count on the vector ALUs (DescriptorDistance, src/ORBmatcher.cc:1913-1933).  Environment
+ * ORBX_MATCH_MFMA=1 (read per call) takes the candidate lists of the unfiltered case - no node ids, no validity mask - from the matrix
+ * cores instead (v_mfma_i32_32x32x32_i8 on +-1 / 0-1 bytes: bit-identical results); a measured alternative, not the default.            */
 int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b,
                               const int32_t *pairs_a, const int32_t *pairs_b, int npairs,
                               const orbx_bow_params *params, orbx_extractor *after_stream_of);
