@@ -842,9 +842,8 @@ def main():
 
     # The surface the reference's callers can actually call (ORBextractor::operator(), the stereo Frame constructor through the C++ shim) is
     # timed FIRST, in a process of its own, before this process creates a HIP context: the reference's callers are a C++ program with nothing
-    # else on the device, and a second process with queues on the same GPU - even an idle one: torch's context here - costs the stereo
-    # constructor 120 us (its two launch sets, the match and the frame-finish kernel are then time-sliced against the other process's queues
-    # by the hardware scheduler; measured 245-275 us alone, 360-400 us beside this process; the one-thread call is 105 us either way).
+    # else on the device.  (Which hardware queues the library's streams land on depends on what else created streams before: the stereo
+    # constructor - two launch sets, the match and the frame-finish kernel side by side - moves by +-25 us with it, the one-thread call does not.)
     dropin_digest = None
     if a.workloads and a.workload == "batch" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus == 1:
         try:
