@@ -945,6 +945,23 @@ class FrameOps:
         """both, fused, on the extractor's last batch (device resident)"""
         _check(self._L.orbx_frame_finish_device(self._h, extractor._h, ctypes.byref(grid)))
 
+    def finish_frame(self, extractor, grid=None):
+        """Latency form for ONE frame that `extractor`'s last single-frame call extracted (orbx_frame_finish_begin + _end): the kernel reads
+        the keypoints on the device and writes into pinned memory.  -> (mvKeysUn or None when the camera is not distorted, offsets, indices, n);
+        offsets / indices are None without a grid."""
+        L = self._L
+        vp = ctypes.c_void_p
+        L.orbx_frame_finish_begin.argtypes = [vp, vp, vp]
+        L.orbx_frame_finish_end.argtypes = [vp, vp, vp, vp, vp]
+        _check(L.orbx_frame_finish_begin(self._h, extractor._h, ctypes.byref(grid) if grid is not None else None))
+        un, off, idx, n = vp(), vp(), vp(), ctypes.c_int()
+        _check(L.orbx_frame_finish_end(self._h, ctypes.byref(un), ctypes.byref(off), ctypes.byref(idx), ctypes.byref(n)))
+        n = n.value
+        kun = np.ctypeslib.as_array(ctypes.cast(un, ctypes.POINTER(ctypes.c_uint8)), shape=(max(n, 1) * KEYPOINT_DTYPE.itemsize,)).view(KEYPOINT_DTYPE)[:n].copy() if un.value else None
+        o = np.ctypeslib.as_array(ctypes.cast(off, ctypes.POINTER(ctypes.c_int32)), shape=(FRAME_GRID_COLS * FRAME_GRID_ROWS + 1,)).copy() if off.value else None
+        i = np.ctypeslib.as_array(ctypes.cast(idx, ctypes.POINTER(ctypes.c_int32)), shape=(max(n, 1),))[:int(o[-1])].copy() if (idx.value and o is not None) else None
+        return kun, o, i, n
+
     def keypoints_un_device(self):
         kp, cap = ctypes.c_void_p(), ctypes.c_int()
         _check(self._L.orbx_frame_results_device(self._h, ctypes.byref(kp), None, None, ctypes.byref(cap)))

@@ -3,6 +3,8 @@
 reference's monocular Frame constructor (gpu).  Bit-exact floats, index-exact grid."""
 from pathlib import Path
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -123,6 +125,38 @@ def test_hip_finish_device_on_extractor_batch(orbx, oracle):
         assert (off[f] == want["gridOff"]).all()
         assert (idx[f][:off[f][-1]] == want["gridIdx"]).all()
     ops.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cam", ["tum1", "tum3"])      # distorted / rectified (mvKeysUn = mvKeys: no undistorted keypoints come back)
+def test_hip_finish_frame_latency_form(orbx, oracle, cam):
+    """orbx_frame_finish_begin / _end: the frame a single-frame extractor call left on the device, results in pinned memory (what the drop-in
+    Frame constructors use), against the restatement; also without a grid, and the state error of an _end without a _begin."""
+    W, H, K, dist = CAMS[cam]
+    ext = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=W, max_height=H)
+    ops = orbx.FrameOps(K[0], K[1], K[2], K[3], dist)
+    grid = orbx.FrameGrid.from_bounds(ops.ComputeImageBounds(W, H))
+    for seed in (31, 32, 33):
+        kps, desc = ext.extract_with_pyramid(orbx.synth_frame(seed, W, H))[:2]
+        n = len(kps)
+        k7 = np.stack([kps[c].astype(np.float32) for c in ("x", "y", "size", "angle", "response", "octave", "class_id")], 1)
+        want = oracle_lib.frame_finish(oracle, k7, K, dist, W, H)
+        un, off, idx, cnt = ops.finish_frame(ext, grid)
+        assert cnt == n and n > 800
+        if float(dist[0]) == 0.0:
+            assert un is None
+        else:
+            got7 = np.stack([un[c].astype(np.float32) for c in ("x", "y", "size", "angle", "response", "octave", "class_id")], 1)
+            assert (got7.view(np.uint32) == want["kpsUn"].view(np.uint32)).all()
+        assert (off == want["gridOff"]).all() and (idx == want["gridIdx"]).all()
+        un2, off2, idx2, cnt2 = ops.finish_frame(ext, None)      # undistortion only
+        assert off2 is None and idx2 is None and cnt2 == n
+        if un is not None:
+            assert (un2.view(np.uint8) == un.view(np.uint8)).all()
+    with pytest.raises(orbx.OrbxError):
+        ops._L.orbx_frame_finish_end.argtypes = [ctypes.c_void_p] * 5
+        orbx._check(ops._L.orbx_frame_finish_end(ops._h, None, None, None, None))      # nothing begun
+    ops.close(); ext.close()
 
 
 @pytest.mark.gpu
