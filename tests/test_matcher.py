@@ -1,5 +1,6 @@
 """Hamming matchers: known-answer tests on CPU (oracle + host helper), index-exact parity of
 the HIP path against the oracle on the GPU."""
+import ctypes
 import os
 
 import numpy as np
@@ -247,4 +248,19 @@ def test_stereo_frame_of_two_single_frame_calls(orbx, oracle):
         mt.compute_stereo_matches_device(eL, eR, [0], [0], bf, 0.0)
         u2, z2 = mt.download_stereo(1)
         assert (u2[0, :len(kL)].view(np.uint32) == u.view(np.uint32)).all() and (z2[0, :len(kL)].view(np.uint32) == z.view(np.uint32)).all()
+        # the two halves apart (what the drop-in constructor does: begin on an extractor thread, end in ComputeStereoMatches), and with the
+        # three kernels of the batched path instead of the two of the latency form: the same bits
+        L = mt._L
+        L.orbx_stereo_frame_begin.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+        L.orbx_stereo_frame_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        for one in ("1", "0"):
+            os.environ["ORBX_STEREO_ONE"] = one
+            try:
+                assert L.orbx_stereo_frame_begin(mt._h, eL._h, eR._h, bf, 0.0) == 0
+                u3, z3 = np.full(len(kL), -7.0, np.float32), np.full(len(kL), -7.0, np.float32)
+                assert L.orbx_stereo_frame_end(mt._h, u3.ctypes.data, z3.ctypes.data, len(kL)) == 0
+            finally:
+                del os.environ["ORBX_STEREO_ONE"]
+            assert (u3.view(np.uint32) == u.view(np.uint32)).all() and (z3.view(np.uint32) == z.view(np.uint32)).all(), one
+        assert L.orbx_stereo_frame_end(mt._h, u3.ctypes.data, z3.ctypes.data, len(kL)) != 0      # nothing begun: a state error, not stale results
     mt.close(); eL.close(); eR.close()
