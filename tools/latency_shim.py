@@ -134,6 +134,8 @@ def measure(orbx, quick=False):
     if not quick:
         rows += one_thread(orbx, L, 1241, 376, 2000, it1)
     rows += threads(orbx, L, (8, 16) if quick else (1, 2, 4, 8, 16), itn, keeps=(0,) if quick else (0, 1))
+    if quick:
+        rows += threads(orbx, L, (16,), itn, keeps=(1,))
     try:
         rows += stereo_frame(orbx, 100 if quick else 300, 0 if quick else 8)
     except Exception as e:      # noqa: BLE001  (the drop-in library is only there when oracle/_ref was built)
@@ -156,6 +158,7 @@ def measure(orbx, quick=False):
            "us_1thread_hostpyr": pick(size="640x480", host_pyramid=True, combiner=True).get("mean_us"),
            "fps_8threads": pick(threads=8, host_pyramid=False, combiner=True).get("frames_per_s"),
            "fps_16threads": pick(threads=16, host_pyramid=False, combiner=True).get("frames_per_s"),
+           "fps_16threads_hostpyr": pick(threads=16, host_pyramid=True, combiner=True).get("frames_per_s"),
            "stereo_frame_ctor_us": pick(library="liborbslam_hip.so (drop-in)", combiner=True).get("mean_us"),
            "stereo_frame_ctor_median_us": pick(library="liborbslam_hip.so (drop-in)", combiner=True).get("median_us"),
            "source": "tools/latency_shim.py: C++ loops over the reference's call shapes (tests/shim_wrap.cc, oracle/refslam_wrap.cc)"}
