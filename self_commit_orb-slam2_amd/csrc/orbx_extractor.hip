@@ -73,6 +73,7 @@ struct orbx_extractor {
     bool geomValid = false;
     std::vector<uint8_t> binHost;
     std::vector<uint32_t> rsHost;   // cv::resize tables of all levels (build_resize_tables)
+    std::vector<OrbxFcCell> fcHost; // k_fast_cells: one entry per cell of a frame
     // k_pyramid_tiles (single-frame call): per (tile, level) rectangles, planned from rsHost when the single-frame graph is built
     OrbxDevBuf<OrbxPyrTile> ptDev;
     int ptBatchW = 0, ptBatchH = 0;              // geometry the plan below was made for by run_batch (ORBX_BATCH_PYR_TILES)
@@ -89,6 +90,7 @@ struct orbx_extractor {
     DevBuf<OrbxGeom> geomDev;
     DevBuf<uint8_t> binDev, pyr, blur, score, staging;
     DevBuf<uint32_t> rsDev;
+    DevBuf<OrbxFcCell> fcDev;
     DevBuf<int> cellCount, lvlCnt, lvlBase, status;
     // results are double buffered: a consumer (matcher) may still read batch i while batch i+1 is
     // extracted; consumerEv[b] = event after which buffer b may be overwritten again
@@ -314,12 +316,40 @@ int build_geometry(orbx_extractor *h, int W, int H)
     g.cellsPerFrame = cells; g.slotsPerFrame = slots; g.kpPerFrame = kps; g.outCap = kps;
     g.blurTiles = btiles;
     // LDS carve-up of k_fast_cells (one wave per cell): row pitch 16*segments+16 bytes for both tiles
-    g.fcSegMax = (maxWCell + 15) / 16;
-    if (g.fcSegMax > 4 || maxHCell > 63) { orbx_set_error("cell %dx%d larger than the detector supports", maxWCell, maxHCell); return ORBX_ERR_ARG; }
-    const int fcPitch = 16 * g.fcSegMax + 16;
-    g.fcInBytes = fcPitch * (maxHCell + 6);
-    g.fcScBytes = fcPitch * (maxHCell + 2);
+    if (maxWCell > 64 || maxHCell > 63) { orbx_set_error("cell %dx%d larger than the detector supports", maxWCell, maxHCell); return ORBX_ERR_ARG; }
+    // window rows: the widest window (aw + 6 rounded up to 16) and the widest pre-test read (16 * segments + 8); score rows: aw + 6
+    g.fcPitch = maxWCell <= 32 ? 48 : maxWCell <= 48 ? 64 : 80;
+    g.fcScPitch = maxWCell <= 42 ? 48 : 80;
+    { const char *pe = getenv("ORBX_FC_PITCH"); if (pe && atoi(pe) == 80 && g.fcPitch == 64) g.fcPitch = 80; }      // (developer knob)
+    {
+        const int units = (maxHCell + 6) * ((maxWCell + 6 + 15) / 16), ns = (units + 63) / 64;      // 16-byte window units per lane
+        g.fcNS = ns <= 2 ? 2 : ns <= 3 ? 3 : ns <= 4 ? 4 : 6;
+    }
+    g.fcInBytes = g.fcPitch * (maxHCell + 6);
+    g.fcScBytes = g.fcScPitch * (maxHCell + 2);
     g.fcLdsBytes = g.fcInBytes + g.fcScBytes + (int)align_up((size_t)maxWCell * maxHCell * 2, 16);
+    // the detector's cell table (ComputeKeyPointsOctTree's cell loop, src/ORBextractor.cc:1089-1123)
+    h->fcHost.assign((size_t)cells, OrbxFcCell{});
+    for (int l = 0; l < nl; l++) {
+        const OrbxLevel &lv = g.lv[l];
+        const int maxBX = lv.w - ORBX_BORDER, maxBY = lv.h - ORBX_BORDER;
+        for (int ci = 0; ci < lv.nRows; ci++)
+            for (int cj = 0; cj < lv.nCols; cj++) {
+                const int cell = ci * lv.nCols + cj;
+                OrbxFcCell &e = h->fcHost[(size_t)lv.cellBase + cell];
+                const int iniX = ORBX_BORDER + cj * lv.wCell, iniY = ORBX_BORDER + ci * lv.hCell;
+                const int maxX = std::min(iniX + lv.wCell + 6, maxBX), maxY = std::min(iniY + lv.hCell + 6, maxBY);
+                const int x0 = iniX + 3, x1 = maxX - 3, y0 = iniY + 3, y1 = maxY - 3, aw = x1 - x0, ah = y1 - y0;
+                const bool valid = !(iniY >= maxBY - 3 || iniX >= maxBX - 6 || aw <= 0 || ah <= 0);      // :1101, :1112
+                // (a skipped cell stands in as the 1 x 1 area at the level's first detectable pixel: the kernel's unconditional window loads stay valid)
+                e.xy = valid ? ((uint32_t)x0 | ((uint32_t)y0 << 16)) : ((uint32_t)ORBX_EDGE | ((uint32_t)ORBX_EDGE << 16));
+                const int ew = valid ? aw : 1, eh = valid ? ah : 1, nu = (ew + 6 + 15) / 16;
+                e.dim = (uint32_t)ew | ((uint32_t)eh << 8) | ((uint32_t)l << 16) | (valid ? 1u << 24 : 0u);
+                e.inv = (uint32_t)((65536 + nu - 1) / nu); e.units = (uint32_t)nu | ((uint32_t)((eh + 6) * nu) << 8);
+                e.pitch = lv.pitch; e.off = (uint32_t)lv.off;
+                e.slot = (uint32_t)(lv.slotBase + cell * lv.cellCap); e.cap = (uint32_t)lv.cellCap;
+            }
+    }
     g.pyrBytes = align_up(off + 256, 256);
     if (maxNodes > 2048) { orbx_set_error("per-level feature quota %d exceeds the quadtree node capacity 2048", maxNodes); return ORBX_ERR_ARG; }
     h->nodeCap = maxNodes <= 256 ? 256 : (maxNodes <= 512 ? 512 : (maxNodes <= 1024 ? 1024 : 2048));
@@ -352,10 +382,12 @@ int ensure_geometry(orbx_extractor *h, int W, int H, int batch)
         if ((rc = h->geomDev.ensure(1)) != ORBX_OK) return rc;
         if ((rc = h->binDev.ensure(std::max<size_t>(h->binHost.size(), 1))) != ORBX_OK) return rc;
         if ((rc = h->rsDev.ensure(std::max<size_t>(h->rsHost.size(), 4))) != ORBX_OK) return rc;
+        if ((rc = h->fcDev.ensure(std::max<size_t>(h->fcHost.size(), 1))) != ORBX_OK) return rc;
         ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
         ORBX_HIP_CHECK(hipMemcpy(h->geomDev.p, &h->geom, sizeof(OrbxGeom), hipMemcpyHostToDevice));
         ORBX_HIP_CHECK(hipMemcpy(h->binDev.p, h->binHost.data(), h->binHost.size(), hipMemcpyHostToDevice));
         ORBX_HIP_CHECK(hipMemcpy(h->rsDev.p, h->rsHost.data(), h->rsHost.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ORBX_HIP_CHECK(hipMemcpy(h->fcDev.p, h->fcHost.data(), h->fcHost.size() * sizeof(OrbxFcCell), hipMemcpyHostToDevice));
         h->geomValid = true;
         h->allocBatch = 0;   // per-frame sizes changed: re-check every buffer
     }
@@ -400,6 +432,7 @@ void fill_launch(orbx_extractor *h, OrbxLaunch &L, const uint8_t *img0Dev, int b
     L.pyr = h->pyr.p; L.blur = h->blur.p; L.score = h->debugTaps ? h->score.p : nullptr; L.blurBytes = h->geom.pyrBytes;
     L.binTab = h->binDev.p;
     L.rsTab = h->rsDev.p;
+    L.fcCells = h->fcDev.p;
     L.cellCount = h->cellCount.p; L.cellSlots = h->cellSlots.p; L.ptBuf = h->ptBuf.p; L.labBuf = h->labBuf.p;
     L.lvlKp = h->lvlKp.p; L.lvlCnt = h->lvlCnt.p; L.outBase = h->lvlBase.p; L.outKp = h->outKpP[cb]; L.outDesc = h->outDescP[cb]; L.outCnt = h->outCntP[cb];
     L.status = h->status.p; L.outStatus = h->outStP[cb]; L.nodeCap = h->nodeCap;
@@ -632,7 +665,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     invalidate_single_graph(h);
-    h->geomDev.release(); h->binDev.release(); h->rsDev.release(); h->ptDev.release(); h->pyr.release(); h->blur.release();
+    h->geomDev.release(); h->binDev.release(); h->rsDev.release(); h->fcDev.release(); h->ptDev.release(); h->pyr.release(); h->blur.release();
     if (h->hostStaging) { (void)hipHostFree(h->hostStaging); h->hostStaging = nullptr; h->hostStagingBytes = 0; }
     if (h->hostOut) { (void)hipHostFree(h->hostOut); h->hostOut = nullptr; h->hostOutBytes = 0; }
     h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release(); h->lvlBase.release();

@@ -45,13 +45,27 @@ struct OrbxGeom {
     int iniTh, minTh;
     int cellsPerFrame, slotsPerFrame, kpPerFrame, outCap;
     int blurTiles;
-    int fcSegMax;           /* widest cell of any level in 16-px segments (k_fast_cells template argument) */
+    int fcPitch, fcScPitch, fcNS;   /* k_fast_cells template arguments: LDS row pitch of the window (48 / 64 / 80) and of the score tile (48 / 80), 16-byte window units per lane (2 / 3 / 4 / 6) */
     int fcInBytes, fcScBytes, fcLdsBytes;   /* LDS carve-up of k_fast_cells: input window, score tile, total */
     size_t pyrBytes;        /* bytes of levels 1.. of one frame */
     uint32_t taps[7];
     int umax[16];
     OrbxLevel lv[ORBX_MAX_LEVELS];
 };
+
+/* Everything k_fast_cells needs to know about one 30-px cell (src/ORBextractor.cc:1089-1123), built with the geometry: one 32-byte scalar load per
+ * cell instead of a chain of dependent loads through OrbxGeom and three integer divisions. */
+struct OrbxFcCell {
+    uint32_t xy;            /* x0 | y0 << 16: first pixel of the cell's detection area (= iniX + 3, iniY + 3), level coordinates          */
+    uint32_t dim;           /* aw | ah << 8 | level << 16 | valid << 24: size of the detection area; valid = 0: the reference skips the cell (1 x 1 stand-in) */
+    int32_t pitch;          /* row pitch of the level (the pyramid block's; level 0 pixels are read at the caller's stride)                 */
+    uint32_t off;           /* byte offset of the level inside a frame's pyramid block                                                     */
+    uint32_t slot;          /* first u32 of the cell inside a frame's candidate slots                                                      */
+    uint32_t cap;           /* u32 entries of the cell's slot                                                                              */
+    uint32_t inv;           /* ceil(2^16 / nu), nu = 16-byte units per window row = (aw + 6 + 15) / 16: u * inv >> 16 == u / nu for u < 2^12 */
+    uint32_t units;         /* nu | (window rows * nu) << 8                                                                                */
+};
+#define ORBX_FC_CELLS_PER_WAVE 4
 
 /* One workgroup's share of one pyramid level in k_pyramid_tiles (single-frame call): the rectangle it COMPUTES (what its part of
  * the next level reads, united with what it owns; x bounds multiples of 4) and the rectangle it OWNS (stores to the pyramid buffer).
@@ -99,6 +113,7 @@ struct OrbxLaunch {
     size_t blurBytes;             /* blurred copy of ALL levels (level 0 included)          */
     const uint8_t *binTab;
     const uint32_t *rsTab;        /* cv::resize index / coefficient tables of all levels */
+    const OrbxFcCell *fcCells;    /* k_fast_cells: one entry per cell of a frame */
     int *cellCount;
     uint32_t *cellSlots;
     uint32_t *ptBuf, *labBuf;     /* quadtree: candidates of a level in list order and their node labels; slotsPerFrame u32 per frame each */

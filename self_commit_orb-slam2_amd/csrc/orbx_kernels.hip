@@ -374,65 +374,103 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b,
 #define FC_PAIR(W, b) __builtin_amdgcn_perm((W)[((b) >> 2) + 1 > 5 ? 5 : ((b) >> 2) + 1], (W)[(b) >> 2], \
                                             0x0c000c00u | (uint32_t)((b) & 3) | ((uint32_t)(((b) & 3) + 1) << 16))
 
-__constant__ int c_inv16[10] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282};   // ceil(2^16 / n)
 
-template <int SEGMAX>   // widest cell of the geometry in 16-px segments (1..4)
-__global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ g, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
-                                                   const uint8_t *__restrict__ pyr, uint8_t *__restrict__ scoreDbg, int *__restrict__ cellCount,
-                                                   uint32_t *__restrict__ cellSlots)
+// PROF (tools/fast_phases.py, never in a product launch): s_memtime stamps at the phase boundaries, per cell (= per pass of the wave's loop) into
+// one 16-word record per cell behind a 32-word header: 0 prologue  1 staging + zeroing  2 A: windows + pre-test  3 A: scan + list append  4 B  5 C
+//   6..9 = 2..5 of the minThFAST retry  10 emission  11 stamp cost  12 retried  13 survivors of the first pre-test  14 of the retry's  15 candidates emitted
+#define FC_STAMP(i) do { if (PROF) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tPrev; tPrev = __builtin_amdgcn_s_memtime(); pacc[11] += tPrev - t_; } } while (0)
+
+__device__ __forceinline__ uint4 load16u(const uint8_t *p)      // unaligned 16-byte load (global_load_dwordx4)
 {
-    constexpr int P = 16 * SEGMAX + 16;   // LDS row pitch in bytes of both tiles
+    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+    const u32x4_u v = *(const u32x4_u *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// inclusive prefix sum over the 64 lanes with data-parallel-primitive adds: four shifts inside the rows of 16, then the two row broadcasts of gfx9
+// (six VALU instructions; __shfl_up is six dependent LDS-crossbar round trips)
+__device__ __forceinline__ int wave_incl_scan_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// P = LDS row pitch of both tiles, an ODD multiple of 16 bytes (48 for cells up to 32 px wide, 80 up to 64): the rows of a window land on all 32 banks.
+// NS = 16-byte units of a cell's window per lane (window rows x units per row <= 64 NS), K (an argument) = cells per wave.
+// A wave takes K consecutive cells of a frame through the phases one after the other; everything it needs to know about a cell is ONE 32-byte table
+// entry (OrbxFcCell, built with the geometry: the v1 prologue - a chain of ~12 dependent scalar loads through OrbxGeom and three integer divisions - was
+// 28 % of a wave's lifetime, profiles/r05a_fast_phases.txt), and the window of cell k+1 is requested before the phases of cell k run and stored into LDS
+// after them (v1: three dependent load -> store round trips per cell, 18 % of the lifetime).
+template <int P, int SP, int NS, bool PROF = false>
+__global__ __launch_bounds__(64) void k_fast_cells(const OrbxFcCell *__restrict__ cells, int K, int cellsPerFrame, int slotsPerFrame, size_t pyrBytes, int iniTh, int minTh,
+                                                   int inBytes, int scBytes, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                                   const uint8_t *__restrict__ pyr, uint8_t *__restrict__ scoreDbg, int *__restrict__ cellCount,
+                                                   uint32_t *__restrict__ cellSlots, unsigned long long *__restrict__ prof)
+{
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *inT = lds;                                   // (ah+6) x P: input window, tile (0,0) = pixel (x0-3, y0-3)
-    uint8_t *scT = lds + g->fcInBytes;                    // (ah+2) x P: scores, area pixel (c, r) at byte (r+1)*P + c+4
-    unsigned short *cand = (unsigned short *)(scT + g->fcScBytes);
+    uint8_t *scT = lds + inBytes;                         // (ah+2) x SP: scores, area pixel (c, r) at byte (r+1)*SP + c+4
+    unsigned short *cand = (unsigned short *)(scT + scBytes);
+    unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tPrev = 0;
+    if (PROF) tPrev = __builtin_amdgcn_s_memtime();
     XCD_REMAP_XY(bx, f);
     const int lane = threadIdx.x;
-    int bases[ORBX_MAX_LEVELS];
-    const int nl = g->nlevels;
-    for (int i = 0; i < nl; i++) bases[i] = g->lv[i].cellBase;
-    const int l = find_level(bases, nl, bx);
-    const OrbxLevel &lv = g->lv[l];
-    const int cell = bx - lv.cellBase;
-    const int cj = cell % lv.nCols, ci = cell / lv.nCols;
-    const int maxBX = lv.w - ORBX_BORDER, maxBY = lv.h - ORBX_BORDER;
-    const int iniX = ORBX_BORDER + cj * lv.wCell, iniY = ORBX_BORDER + ci * lv.hCell;
-    const int maxX = min(iniX + lv.wCell + 6, maxBX), maxY = min(iniY + lv.hCell + 6, maxBY);
-    int *cnt = cellCount + (size_t)f * g->cellsPerFrame + bx;
-    const int x0 = iniX + 3, x1 = maxX - 3, y0 = iniY + 3, y1 = maxY - 3;
-    const int aw = x1 - x0, ah = y1 - y0;
-    if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || aw <= 0 || ah <= 0) {   // skipped / degenerate cell (:1101, :1112)
-        if (lane == 0) *cnt = 0;
-        return;
-    }
-    int pitch;
-    const uint8_t *src = level_ptr(g, l, f, img0, img0Stride, img0FramePitch, pyr, pitch);
-    {   // stage rows y0-3 .. y1+2, bytes x0-3 .. x1+2 in 8-byte units (+ up to 7 spill bytes: x1+10 <= w-9 stays inside the row,
-        // aw+13 < P inside the LDS row)
-        const int ih = ah + 6, nw = (aw + 6 + 7) >> 3;
-        const uint8_t *base = src + (size_t)(y0 - 3) * pitch + (x0 - 3);
-        // lane / nw and 64 / nw without the integer-division sequence: nw <= 9 here, and x * ceil(2^16 / nw) >> 16 == x / nw for x <= 64
-        const int inv = c_inv16[nw];                      // uniform index: a scalar load
-        int r = (lane * inv) >> 16, c = lane - r * nw;
-        const int dr = (64 * inv) >> 16, dc = 64 - dr * nw;
-        while (r < ih) {
-            uint2 v;
-            __builtin_memcpy(&v, base + (size_t)r * pitch + 8 * c, 8);   // unaligned 8-byte load
-            *(uint2 *)(inT + r * P + 8 * c) = v;
-            r += dr; c += dc;
-            if (c >= nw) { c -= nw; r++; }
-        }
+    const int cFirst = bx * K, cEnd = min(cFirst + K, cellsPerFrame);
+    const uint8_t *frame0 = img0 + (size_t)f * img0FramePitch, *frameP = pyr + (size_t)f * pyrBytes;
+    // window of a cell: rows y0-3 .. y1+2, bytes x0-3 .. in units of 16 (the last unit spills up to 15 bytes past x1+2: x1+18 <= w-1 stays inside the
+    // row); unit u = (row u / nu, column u % nu), all of a lane's units requested back to back.  (Skipped cells carry a 1 x 1 area: their loads are
+    // valid and unused - unconditional loads keep the units in registers; behind a branch the compiler parks them in scratch memory and waits.)
+    uint4 wv[NS];
+    int wo[NS];               // where each unit goes in the LDS window (-1: none), kept from the request to the store
+#define FC_REQUEST(E) do { \
+        const int lvl_ = (int)(((E).dim >> 16) & 0xffu), sp_ = lvl_ ? (E).pitch : img0Stride; \
+        const uint8_t *base_ = (lvl_ ? frameP + (E).off : frame0) + (size_t)((int)((E).xy >> 16) - 3) * sp_ + ((int)((E).xy & 0xffffu) - 3); \
+        const int nu_ = (int)((E).units & 0xffu), ntot_ = (int)((E).units >> 8), inv_ = (int)(E).inv; \
+        _Pragma("unroll") for (int k_ = 0; k_ < NS; k_++) { \
+            const int u_ = min(lane + 64 * k_, ntot_ - 1), r_ = __mul24(u_, inv_) >> 16, c_ = u_ - __mul24(r_, nu_); \
+            wv[k_] = load16u(base_ + (size_t)r_ * sp_ + 16 * c_); \
+            wo[k_] = lane + 64 * k_ < ntot_ ? r_ * P + 16 * c_ : -1; \
+        } } while (0)
+    OrbxFcCell e = cells[cFirst], en = cells[min(cFirst + 1, cEnd - 1)];
+    FC_REQUEST(e);
+    FC_STAMP(0);
+    for (int ci = cFirst; ci < cEnd; ci++) {
+    int pNc1 = 0, pNc2 = 0, pRetry = 0;
+    const int aw = (int)(e.dim & 0xffu), ah = (int)((e.dim >> 8) & 0xffu);
+    const bool valid = (e.dim >> 24) != 0;
+    const int x0 = (int)(e.xy & 0xffffu), y0 = (int)(e.xy >> 16);
+    const int lpitch = e.pitch, cellCap = (int)e.cap;
+    const uint32_t loff = e.off, slotOff = e.slot;
+    int *cnt = cellCount + (size_t)f * cellsPerFrame + ci;
+    {
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+            if (wo[k] >= 0) *(uint4 *)(inT + wo[k]) = wv[k];
         uint4 *z = (uint4 *)scT;
-        for (int i = lane; i < (ah + 2) * (P / 16); i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = lane; i < (ah + 2) * (SP / 16); i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // the next cell's window and the entry of the cell after it: in flight while this cell is computed (past the wave's last cell: that cell's
+    // window once more, unused)
+    e = en;
+    FC_REQUEST(e);
+    en = cells[min(ci + 2, cEnd - 1)];
+    if (!valid) {             // skipped / degenerate cell (:1101, :1112)
+        if (lane == 0) *cnt = 0;
+        continue;
     }
     __syncthreads();
-    const int minTh = g->minTh, iniTh = g->iniTh;
-    uint8_t *dbg = scoreDbg ? scoreDbg + (size_t)f * g->pyrBytes + lv.off : nullptr;
+    FC_STAMP(1);
+    uint8_t *dbg = scoreDbg ? scoreDbg + (size_t)f * pyrBytes + loff : nullptr;
     if (dbg)   // parity tap: pixels that fail the pre-test have score 0
-        for (int p = lane; p < aw * ah; p += 64) dbg[(size_t)(y0 + p / aw) * lv.pitch + (x0 + p % aw)] = 0;
+        for (int p = lane; p < aw * ah; p += 64) dbg[(size_t)(y0 + p / aw) * lpitch + (x0 + p % aw)] = 0;
 
     // ---- phase A ----
-    const int S = (aw + 15) >> 4;                                           // segments per row (1..SEGMAX)
+    const int S = (aw + 15) >> 4;                                           // segments per row (1..4)
     const int rpp = S == 1 ? 64 : S == 2 ? 32 : S == 3 ? 21 : 16;           // rows per pass
     const int rl = S == 1 ? lane : S == 2 ? (lane >> 1) : S == 3 ? ((lane * 43) >> 7) : (lane >> 2);
     const int seg = lane - rl * S, c0 = 16 * seg;
@@ -442,8 +480,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
     // the survivors (phase B) is ~40 % of the kernel - and scores below iniThFAST count as "not a corner", exactly what the
     // reference's first cv::FAST call sees; only when no iniThFAST keypoint survives the NMS does the cell run again at minThFAST.
     // (With the parity taps on, the single minThFAST pass writes the full score map.)
-    int nc = 0, th = dbg ? minTh : iniTh;
+    int nc = 0, th = dbg ? minTh : iniTh, base = 0;
     bool anyIni = false;
+    uint32_t *slot = cellSlots + (size_t)f * slotsPerFrame + slotOff;
     for (;;) {
     nc = 0;
     const uint32_t thrPk = (uint32_t)(th & 0xffff) * 0x00010001u;
@@ -476,17 +515,21 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
         }
         mask = (mask & 0x5555u) | ((mask >> 15) & 0xaaaau);
         mask = live ? (mask & colMask) : 0u;
+        if (PROF) { asm volatile("" :: "v"(mask)); FC_STAMP(th == iniTh || dbg ? 2 : 6); }
         const int cntL = __popc(mask);
-        const int incl = wave_incl_scan_i(cntL, lane);
-        int o = nc + incl - cntL;
+        const int incl = wave_incl_scan_dpp(cntL);
+        unsigned short *o = cand + (nc + incl - cntL);
+        const int code0 = (r << 6) | c0;
         while (mask) {
             const int bpos = __ffs(mask) - 1;
             mask &= mask - 1;
-            cand[o++] = (unsigned short)((r << 6) | (c0 + bpos));
+            *o++ = (unsigned short)(code0 + bpos);
         }
-        nc += __shfl(incl, 63);
+        nc += __builtin_amdgcn_readlane(incl, 63);
+        FC_STAMP(th == iniTh || dbg ? 3 : 7);
     }
     __syncthreads();
+    if (PROF) { if (th == iniTh || dbg) pNc1 = nc; else { pNc2 = nc; pRetry = 1; } }
 
     // ---- phase B: full FAST score of the surviving pixels ----
     for (int i = lane; i < nc; i += 64) {
@@ -513,46 +556,81 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxGeom *__restrict__ 
         // dark arc: all x < v - t  <=>  t < v - max(x);  bright arc: all x > v + t  <=>  t < min(x) - v;  score = largest such t
         int sco = max(v - minB, maxA - v) - 1;
         sco = sco >= th ? sco : 0;
-        scT[(r + 1) * P + c + 4] = (uint8_t)sco;
-        if (dbg) dbg[(size_t)(y0 + r) * lv.pitch + (x0 + c)] = (uint8_t)sco;
+        scT[(r + 1) * SP + c + 4] = (uint8_t)sco;
+        if (dbg) dbg[(size_t)(y0 + r) * lpitch + (x0 + c)] = (uint8_t)sco;
     }
     __syncthreads();
+    FC_STAMP(th == iniTh || dbg ? 4 : 8);
 
     // ---- phase C: strict 3x3 maxima, threshold choice, ordered emission ----
+    // A pass at iniThFAST sees scores below iniThFAST as zero, so every maximum it finds is an iniThFAST keypoint and all of them are kept; the retry at
+    // minThFAST runs only when there was none (a maximum of the first pass stays one: its neighbours only gained smaller scores... and a non-maximum
+    // stays none), so it keeps every maximum too: the maxima go to the cell's slot as they are found, in list (= raster) order by ballot.  (The parity
+    // tap's single minThFAST pass has both kinds in one pass: it flags them and emits afterwards.)
+    base = 0;
     anyIni = false;
-    for (int i = lane; i < nc; i += 64) {
-        const int code = cand[i], r = code >> 6, c = code & 63;
-        const uint8_t *sp = scT + (r + 1) * P + c + 4;
-        const int v = sp[0];
-        const bool nms = v > 0 && v > sp[-1] && v > sp[1] && v > sp[-P - 1] && v > sp[-P] && v > sp[-P + 1] && v > sp[P - 1] && v > sp[P] && v > sp[P + 1];
-        const bool ini = nms && v >= iniTh;
-        cand[i] = (unsigned short)(code | (nms ? 0x1000 : 0) | (ini ? 0x2000 : 0));   // own entry: no cross-lane hazard
-        anyIni = anyIni || ini;
-    }
-    anyIni = __any(anyIni);
-    if (anyIni || th == minTh) break;
-    th = minTh;           // :1132-1136: nothing at iniThFAST -> the whole cell again at minThFAST
-    __syncthreads();      // (single wave: orders the LDS list / score tile reuse)
-    }
-    const int keepBit = anyIni ? 0x2000 : 0x1000;   // iniThFAST keypoints exist -> the minThFAST retry is skipped (:1132)
-    uint32_t *slot = cellSlots + (size_t)f * g->slotsPerFrame + lv.slotBase + (size_t)cell * lv.cellCap;
-    int base = 0;
     for (int i0 = 0; i0 < nc; i0 += 64) {
         const int i = i0 + lane;
-        bool keep = false;
-        int code = 0;
-        if (i < nc) { code = cand[i]; keep = (code & keepBit) != 0; }
-        const unsigned long long m = __ballot(keep);
-        if (keep) {
-            const int r = (code >> 6) & 63, c = code & 63;
-            const uint32_t v = scT[(r + 1) * P + c + 4];
-            const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (idx < lv.cellCap) slot[idx] = (uint32_t)(x0 + c - ORBX_BORDER) | ((uint32_t)(y0 + r - ORBX_BORDER) << 12) | (v << 24);
+        bool nms = false, ini = false;
+        int code = 0, v = 0;
+        if (i < nc) {
+            code = cand[i];
+            const int r = code >> 6, c = code & 63;
+            const uint8_t *sp = scT + (r + 1) * SP + c + 4;
+            v = sp[0];
+            const int nb = max3i(max3i(sp[-1], sp[1], sp[-SP - 1]), max3i(sp[-SP], sp[-SP + 1], sp[SP - 1]), max(sp[SP], sp[SP + 1]));
+            nms = v > nb;                             // (v > nb >= 0: a zero score is never a maximum)
+            ini = nms && v >= iniTh;
         }
-        base += __popcll(m);
+        if (dbg) {
+            if (i < nc) cand[i] = (unsigned short)(code | (nms ? 0x1000 : 0) | (ini ? 0x2000 : 0));   // own entry: no cross-lane hazard
+            anyIni = anyIni || ini;
+        } else {
+            const unsigned long long m = __ballot(nms);
+            if (nms) {
+                const int r = code >> 6, c = code & 63;
+                const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (idx < cellCap) slot[idx] = (uint32_t)(x0 + c - ORBX_BORDER) | ((uint32_t)(y0 + r - ORBX_BORDER) << 12) | ((uint32_t)v << 24);
+            }
+            base += __popcll(m);
+        }
     }
-    if (lane == 0) *cnt = min(base, lv.cellCap);
+    if (dbg) anyIni = __any(anyIni); else anyIni = base > 0;
+    FC_STAMP(th == iniTh || dbg ? 5 : 9);
+    if (anyIni || th == minTh) break;
+    th = minTh;           // :1132-1136: nothing at iniThFAST -> the whole cell again at minThFAST (its phase B rewrites every score of the first pass)
+    __syncthreads();      // (single wave: orders the LDS list / score tile reuse)
+    }
+    if (dbg) {
+        const int keepBit = anyIni ? 0x2000 : 0x1000;   // iniThFAST keypoints exist -> the minThFAST retry is skipped (:1132)
+        base = 0;
+        for (int i0 = 0; i0 < nc; i0 += 64) {
+            const int i = i0 + lane;
+            bool keep = false;
+            int code = 0;
+            if (i < nc) { code = cand[i]; keep = (code & keepBit) != 0; }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int r = (code >> 6) & 63, c = code & 63;
+                const uint32_t v = scT[(r + 1) * SP + c + 4];
+                const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (idx < cellCap) slot[idx] = (uint32_t)(x0 + c - ORBX_BORDER) | ((uint32_t)(y0 + r - ORBX_BORDER) << 12) | (v << 24);
+            }
+            base += __popcll(m);
+        }
+    }
+    if (lane == 0) *cnt = min(base, cellCap);
+    __syncthreads();      // (the next cell's window and zeros overwrite the tiles)
+    FC_STAMP(10);
+    if (PROF && lane == 0) {      // one 16-word record per cell, no atomics (208k waves adding to the same words stall the loads of the waves behind them)
+        unsigned long long *rec = prof + 32 + ((size_t)f * cellsPerFrame + ci) * 16;
+        for (int i = 0; i < 12; i++) { rec[i] = pacc[i]; pacc[i] = 0; }
+        rec[12] = (unsigned long long)pRetry; rec[13] = (unsigned long long)pNc1; rec[14] = (unsigned long long)pNc2; rec[15] = (unsigned long long)min(base, cellCap);
+    }
+    }
 }
+#undef FC_STAMP
+#undef FC_REQUEST
 
 // ------------------------------------------------------------------------------------
 // Quadtree distribution (DistributeOctTree + DivideNode, src/ORBextractor.cc:635-703,
@@ -1188,41 +1266,28 @@ struct OdLevels {
     float scale[ORBX_MAX_LEVELS];
 };
 
-#define OD_WPB 4
+#define OD_WPB 4          /* keypoints per wave (= per workgroup) */
 #define OD_R 18
 #define OD_DW 10
 #define OD_ROWS (2 * OD_R + 1)
 #define OD_PATCH_DW (OD_ROWS * OD_DW)
 
-__global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels A, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
-                                                                 const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, OrbxLevelKp *__restrict__ lvlKp,
-                                                                 const int *__restrict__ lvlCnt, const int *__restrict__ outBase, orbx_keypoint *__restrict__ outKp,
-                                                                 uint8_t *__restrict__ outDesc, int *__restrict__ outCnt, const int *__restrict__ status,
-                                                                 int *__restrict__ outStatus)
+// One WAVE takes four consecutive keypoint slots of a frame (round 5; before: one wave per keypoint, four per workgroup, three workgroup barriers).
+// Nothing is shared between waves, so there is no barrier at all, and a wave's dependent chain - counts -> keypoint records -> pixels -> moments ->
+// angle -> samples -> stores, four memory levels - is paid once per four keypoints with all forty pixel loads of the four in flight together.  The
+// per-lane constants (the lane's four test pairs, its disc mask) sit in registers for the whole wave instead of being copied into LDS by every
+// workgroup; the angle and its libm-exact sin / cos are computed on lanes 0..3, one keypoint each, in one pass.
+__global__ __launch_bounds__(64) void k_orient_describe(const OdLevels A, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                                        const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, OrbxLevelKp *__restrict__ lvlKp,
+                                                        const int *__restrict__ lvlCnt, const int *__restrict__ outBase, orbx_keypoint *__restrict__ outKp,
+                                                        uint8_t *__restrict__ outDesc, int *__restrict__ outCnt, const int *__restrict__ status,
+                                                        int *__restrict__ outStatus)
 {
-    __shared__ uint32_t sPatch[OD_WPB][OD_PATCH_DW + 2];
-    __shared__ __attribute__((aligned(16))) float sPat[256][4];                  // test pair t as floats: x0, x1, y0, y1
-    __shared__ __attribute__((aligned(16))) uint32_t sDisc[64][4];               // byte masks of the disc: lane (row, half) x 4 dwords
-    __shared__ int sMom[OD_WPB][3];
-    __shared__ int sBase[ORBX_MAX_LEVELS];
-    __shared__ float sTrig[OD_WPB][3];
+    __shared__ __attribute__((aligned(16))) uint32_t sPatch[OD_WPB][OD_PATCH_DW + 2];
     XCD_REMAP_XY(bx, f);
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // uniform: the keypoint bookkeeping below is scalar work
-    if (threadIdx.x < 256) {     // once per workgroup: both constant tables into LDS
-        *(float4 *)sPat[threadIdx.x] = *(const float4 *)c_od.pat[threadIdx.x];
-        ((uint32_t *)sDisc)[threadIdx.x] = ((const uint32_t *)c_od.disc)[threadIdx.x];
-    }
-    const int slot = bx * OD_WPB + wv;
+    const int lane = threadIdx.x;
     const int *cnts = lvlCnt + f * A.nlevels;
-    // where each level's keypoints start in the frame's output list (level 0 .. n-1 in order, src/ORBextractor.cc:1577-1668): once per workgroup,
-    // lane = level, into LDS (k_blur's first workgroup used to leave it in global memory; the blur no longer has to run behind the quadtree for it)
-    if (!outBase && threadIdx.x < (unsigned)A.nlevels) {      // (batches: k_blur's first workgroup left the prefix in outBase)
-        int run = 0;
-        for (int i = 0; i < (int)threadIdx.x; i++) run += cnts[i];
-        sBase[threadIdx.x] = run;
-    }
-    if (bx == 0 && threadIdx.x == 0) {
+    if (bx == 0 && lane == 0) {
         int tot = 0;
         for (int i = 0; i < A.nlevels; i++) tot += cnts[i];
         outCnt[f] = tot;
@@ -1231,103 +1296,137 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
         outStatus[f] = status[f];
         if (f == 0) outStatus[gridDim.y] = status[gridDim.y];
     }
-    // Is the slot in use?  (Measured: requesting the keypoint record and the pixels BEFORE the counts are known - clamped coordinates for
-    // the ~7 % unused slots - shortens the dependent chain by one level but is 7 % slower: 0.242 vs 0.226 ms per 256 frames.)
-    bool inRange = slot < A.kpPerFrame;
-    int l = 0, kb = 0;
+    // the slots: level, index inside the level, in use?  (consecutive slots cross at most one level boundary each)
+    const int slot0 = bx * OD_WPB;
+    int lv[OD_WPB], idx[OD_WPB];
+    bool live[OD_WPB];
+    {
+        int l = 0;
 #pragma unroll
-    for (int i = 1; i < ORBX_MAX_LEVELS; i++) {      // (entries past the last level hold INT_MAX)
-        const bool ge = slot >= A.kpBase[i];
-        l += ge ? 1 : 0; kb = ge ? A.kpBase[i] : kb;
+        for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += slot0 >= A.kpBase[i] ? 1 : 0;      // (entries past the last level hold INT_MAX)
+#pragma unroll
+        for (int j = 0; j < OD_WPB; j++) {
+            const int slot = slot0 + j;
+            if (j > 0 && l + 1 < A.nlevels && slot >= A.kpBase[l + 1]) l++;
+            lv[j] = l; idx[j] = slot - A.kpBase[l];
+            live[j] = slot < A.kpPerFrame && idx[j] < cnts[l];
+        }
     }
-    const int idx = slot - kb;
-    inRange = inRange && idx < cnts[l];
-    const bool live = inRange;
-    const uint2 kraw = *(const uint2 *)&lvlKp[(size_t)f * A.kpPerFrame + (inRange ? slot : 0)];     // x | y << 16, score | pad: the first 8 bytes of OrbxLevelKp
-    const int kx = (int)(kraw.x & 0xffffu), ky = (int)(kraw.x >> 16);
-    const int ksc = (int)(kraw.y & 0xffu);
-    const int xa = (kx - OD_R) & ~3;
-    int m10 = 0, m01 = 0;
-    uint2 pw[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
-    uint4 wd = make_uint4(0u, 0u, 0u, 0u);
+    if (!(live[0] || live[1] || live[2] || live[3])) return;
+    // the lane's constants: its test pair of each of the four rounds (x0, x1, y0, y1 as floats) and the byte mask of its disc row segment
+    float4 pt[4];
+#pragma unroll
+    for (int rd = 0; rd < 4; rd++) pt[rd] = *(const float4 *)c_od.pat[64 * rd + lane];
+    const uint4 mk = *(const uint4 *)c_od.disc[lane];
+    // where the frame's output list starts for each level (k_blur's first workgroup left the prefix in outBase; combined single-frame calls: lane = level)
+    int runLane = 0;
+    if (!outBase && lane < A.nlevels)
+        for (int i = 0; i < lane; i++) runLane += cnts[i];
+    // ---- the keypoint records, then every pixel the four keypoints need, requested back to back ----
+    // (an unused slot stands in as the level's first describable pixel: unconditional loads keep forty registers of pixels free of selects and copies)
+    int kx[OD_WPB], ky[OD_WPB], ksc[OD_WPB];
+#pragma unroll
+    for (int j = 0; j < OD_WPB; j++) {
+        const uint2 kraw = *(const uint2 *)&lvlKp[(size_t)f * A.kpPerFrame + (live[j] ? slot0 + j : 0)];     // x | y << 16, score | pad: the first 8 bytes of OrbxLevelKp
+        const int x_ = __builtin_amdgcn_readfirstlane((int)(kraw.x & 0xffffu)), y_ = __builtin_amdgcn_readfirstlane((int)(kraw.x >> 16));
+        kx[j] = live[j] ? x_ : ORBX_EDGE; ky[j] = live[j] ? y_ : ORBX_EDGE;
+        ksc[j] = __builtin_amdgcn_readfirstlane((int)(kraw.y & 0xffu));
+    }
     const int r = lane >> 1, hf = lane & 1;      // disc row r, bytes x - 15 + 16 * half .. + 15 (19 <= x < w - 19: inside the level)
-    if (inRange) {
-        const int bp = A.pitch[l], up = l ? bp : img0Stride;
-        const uint8_t *unb = l ? pyr + (size_t)f * A.pyrBytes + A.off[l] : img0 + (size_t)f * img0FramePitch;
-        const uint8_t *bl = blur + (size_t)f * A.pyrBytes + A.off[l];
-        if (r < 31) __builtin_memcpy(&wd, unb + (size_t)(ky + r - 15) * up + (kx - 15 + 16 * hf), 16);     // ONE 16-byte load per lane
-        // patch: 37 rows x 5 aligned 8-byte units
+    // patch item t of the lane: row (item / 5), 8-byte column (item % 5); the same for every keypoint
+    int prow[3], pcol[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int item = min(lane + 64 * t, OD_ROWS * (OD_DW / 2) - 1);
+        prow[t] = (item * 205) >> 10; pcol[t] = 8 * (item - (OD_DW / 2) * prow[t]);
+    }
+    const int drow = min(r, 30) - 15, dcol = 16 * hf - 15;      // (lanes 62 / 63: row 30 again, masked out below)
+    uint4 wd[OD_WPB];
+    uint2 pw[OD_WPB][3];
+#pragma unroll
+    for (int j = 0; j < OD_WPB; j++) {
+        const int l = lv[j], bp = A.pitch[l], up = l ? bp : img0Stride;
+        const uint8_t *unb = (l ? pyr + (size_t)f * A.pyrBytes + A.off[l] : img0 + (size_t)f * img0FramePitch) + (size_t)ky[j] * up + kx[j];
+        const uint8_t *bl = blur + (size_t)f * A.pyrBytes + A.off[l] + (size_t)(ky[j] - OD_R) * bp + ((kx[j] - OD_R) & ~3);
+        wd[j] = load16u(unb + drow * up + dcol);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(1)));
+            const u32x2_u v = *(const u32x2_u *)(bl + prow[t] * bp + pcol[t]);
+            pw[j][t] = make_uint2(v.x, v.y);
+        }
+    }
+    // ---- integer moments of the discs: sum I and sum (u + 15) I of the lane's row segment as v_dot4_u32_u8 over the masked bytes ----
+    const uint32_t wb = hf ? 0x10101010u : 0u;
+    int m01[OD_WPB], m10[OD_WPB];
+#pragma unroll
+    for (int j = 0; j < OD_WPB; j++) {
+        uint32_t s1 = 0u, sw = 0u;
+        s1 = __builtin_amdgcn_udot4(wd[j].x & mk.x, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd[j].x & mk.x, 0x03020100u + wb, sw, false);
+        s1 = __builtin_amdgcn_udot4(wd[j].y & mk.y, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd[j].y & mk.y, 0x07060504u + wb, sw, false);
+        s1 = __builtin_amdgcn_udot4(wd[j].z & mk.z, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd[j].z & mk.z, 0x0b0a0908u + wb, sw, false);
+        s1 = __builtin_amdgcn_udot4(wd[j].w & mk.w, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd[j].w & mk.w, 0x0f0e0d0cu + wb, sw, false);
+        m10[j] = wave_sum_dpp((int)sw - 15 * (int)s1); m01[j] = wave_sum_dpp((r - 15) * (int)s1);        // totals as wave-uniform scalars (lanes 62 / 63: mask 0)
+    }
+    // ---- the blurred patches into LDS (37 rows x 40 bytes each) ----
+#pragma unroll
+    for (int j = 0; j < OD_WPB; j++)
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const int item = lane + 64 * t;
-            if (item < OD_ROWS * (OD_DW / 2)) {
-                const int pr = (item * 205) >> 10, pc = item - (OD_DW / 2) * pr;      // item / 5
-                __builtin_memcpy(&pw[t], bl + (size_t)(ky - OD_R + pr) * bp + xa + 8 * pc, 8);
+            if (item < OD_ROWS * (OD_DW / 2)) *(uint2 *)&sPatch[j][2 * item] = pw[j][t];
+        }
+    // ---- fastAtan2 and the libm-exact sin / cos: lane j = keypoint j ----
+    float ang = 0.f, sn = 0.f, cs = 1.f;
+    {
+        const float fy = (float)(lane == 0 ? m01[0] : lane == 1 ? m01[1] : lane == 2 ? m01[2] : m01[3]);
+        const float fx = (float)(lane == 0 ? m10[0] : lane == 1 ? m10[1] : lane == 2 ? m10[2] : m10[3]);
+        if (lane < OD_WPB) {
+            ang = fast_atan2_deg(fy, fx);
+            const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+            sincosf_glibc(ang * factorPI, sn, cs);
+            const bool lv_ = lane == 0 ? live[0] : lane == 1 ? live[1] : lane == 2 ? live[2] : live[3];
+            if (lv_) {
+                OrbxLevelKp *o = lvlKp + (size_t)f * A.kpPerFrame + slot0 + lane;
+                o->angle = ang; o->ca = cs; o->sb = sn;        // (read back by the stage taps and by nothing else)
             }
         }
     }
-    __syncthreads();           // the tables are in LDS (the pixel loads are in flight meanwhile)
-    if (inRange && r < 31) {
-        // integer moments of the row segment: sum I and sum (u + 15) I as v_dot4_u32_u8 over the masked bytes, u + 15 = c (left half) / c + 16 (right half)
-        const uint4 mk = *(const uint4 *)sDisc[lane];
-        const uint32_t wb = hf ? 0x10101010u : 0u;
-        uint32_t s1 = 0u, sw = 0u;
-        s1 = __builtin_amdgcn_udot4(wd.x & mk.x, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.x & mk.x, 0x03020100u + wb, sw, false);
-        s1 = __builtin_amdgcn_udot4(wd.y & mk.y, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.y & mk.y, 0x07060504u + wb, sw, false);
-        s1 = __builtin_amdgcn_udot4(wd.z & mk.z, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.z & mk.z, 0x0b0a0908u + wb, sw, false);
-        s1 = __builtin_amdgcn_udot4(wd.w & mk.w, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.w & mk.w, 0x0f0e0d0cu + wb, sw, false);
-        m10 = (int)sw - 15 * (int)s1;
-        m01 = (r - 15) * (int)s1;
-    }
-    m10 = wave_sum_dpp(m10); m01 = wave_sum_dpp(m01);        // totals as wave-uniform scalars
-    if (lane == 0) { sMom[wv][0] = m01; sMom[wv][1] = m10; sMom[wv][2] = live ? slot : -1; }
-    if (live) {
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int item = lane + 64 * t;
-            if (item < OD_ROWS * (OD_DW / 2)) *(uint2 *)&sPatch[wv][2 * item] = pw[t];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < OD_WPB && sMom[threadIdx.x][2] >= 0) {
-        const float ang = fast_atan2_deg((float)sMom[threadIdx.x][0], (float)sMom[threadIdx.x][1]);
-        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-        float sn, cs;
-        sincosf_glibc(ang * factorPI, sn, cs);
-        sTrig[threadIdx.x][0] = cs; sTrig[threadIdx.x][1] = sn; sTrig[threadIdx.x][2] = ang;
-        OrbxLevelKp *o = lvlKp + (size_t)f * A.kpPerFrame + sMom[threadIdx.x][2];
-        o->angle = ang; o->ca = cs; o->sb = sn;        // (read back by the stage taps and by nothing else)
-    }
-    __syncthreads();
-    if (!live) return;
-    const float a = sTrig[wv][0], b = sTrig[wv][1];
-    const uint8_t *pb = (const uint8_t *)sPatch[wv] + OD_R * (4 * OD_DW) + (kx - xa);     // the keypoint's own pixel
-    unsigned long long bits[4];
+    __syncthreads();           // (one wave: orders the patch stores before the sample reads)
     typedef float f2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int rd = 0; rd < 4; rd++) {
-        // both points of test pair 64 rd + lane at once (v_pk_mul_f32 / v_pk_add_f32: every product and sum is rounded on its own, exactly
-        // like the scalar expressions of src/ORBextractor.cc:192-193 compiled without contraction)
-        const float4 pt = *(const float4 *)sPat[64 * rd + lane];
-        const f2_t xs = {pt.x, pt.y}, ys = {pt.z, pt.w};
-        const f2_t rr = xs * b + ys * a, cc = xs * a - ys * b;
-        // cvRound of both coordinates, then row * 40 + column: small integers, exact in float
-        const int o0 = (int)__builtin_fmaf(__builtin_rintf(rr.x), (float)(4 * OD_DW), __builtin_rintf(cc.x));
-        const int o1 = (int)__builtin_fmaf(__builtin_rintf(rr.y), (float)(4 * OD_DW), __builtin_rintf(cc.y));
-        const int t0 = pb[o0], t1 = pb[o1];
-        bits[rd] = __ballot(t0 < t1);
-    }
-    const int outIdx = (outBase ? outBase[f * A.nlevels + l] : sBase[l]) + idx;      // (< outCap: the output capacity is the sum of the levels' capacities)
-    if (outIdx >= A.outCap) return;
-    unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * A.outCap + outIdx) * 32);
-    if (lane < 4) d64[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-    if (lane == 0) {
-        orbx_keypoint o;
-        const float sc = A.scale[l];
-        o.x = l ? (float)kx * sc : (float)kx;
-        o.y = l ? (float)ky * sc : (float)ky;
-        o.size = (float)A.patch[l]; o.angle = sTrig[wv][2]; o.response = (float)ksc; o.octave = l; o.class_id = -1;
-        outKp[(size_t)f * A.outCap + outIdx] = o;
+    for (int j = 0; j < OD_WPB; j++) {
+        if (!live[j]) continue;
+        const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cs), j)), b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sn), j));
+        const float angj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ang), j));
+        const int xa = (kx[j] - OD_R) & ~3;
+        const uint8_t *pb = (const uint8_t *)sPatch[j] + OD_R * (4 * OD_DW) + (kx[j] - xa);     // the keypoint's own pixel
+        unsigned long long bits[4];
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+            // both points of test pair 64 rd + lane at once (v_pk_mul_f32 / v_pk_add_f32: every product and sum is rounded on its own, exactly
+            // like the scalar expressions of src/ORBextractor.cc:192-193 compiled without contraction)
+            const f2_t xs = {pt[rd].x, pt[rd].y}, ys = {pt[rd].z, pt[rd].w};
+            const f2_t rr = xs * b + ys * a, cc = xs * a - ys * b;
+            // cvRound of both coordinates, then row * 40 + column: small integers, exact in float
+            const int o0 = (int)__builtin_fmaf(__builtin_rintf(rr.x), (float)(4 * OD_DW), __builtin_rintf(cc.x));
+            const int o1 = (int)__builtin_fmaf(__builtin_rintf(rr.y), (float)(4 * OD_DW), __builtin_rintf(cc.y));
+            const int t0 = pb[o0], t1 = pb[o1];
+            bits[rd] = __ballot(t0 < t1);
+        }
+        const int l = lv[j];
+        const int outIdx = (outBase ? outBase[f * A.nlevels + l] : __builtin_amdgcn_readlane(runLane, l)) + idx[j];      // (< outCap: the output capacity is the sum of the levels' capacities)
+        if (outIdx >= A.outCap) continue;
+        unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * A.outCap + outIdx) * 32);
+        if (lane < 4) d64[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        if (lane == 0) {
+            orbx_keypoint o;
+            const float sc = A.scale[l];
+            o.x = l ? (float)kx[j] * sc : (float)kx[j];
+            o.y = l ? (float)ky[j] * sc : (float)ky[j];
+            o.size = (float)A.patch[l]; o.angle = angj; o.response = (float)ksc[j]; o.octave = l; o.class_id = -1;
+            outKp[(size_t)f * A.outCap + outIdx] = o;
+        }
     }
 }
 
@@ -1476,18 +1575,29 @@ int orbx_launch_comb_finish(const OrbxLaunch &L)
                 L.img0FramePitch, L.combKpOff, L.combDescOff, 0);      // (the host pyramid copy rides in the quadtree's launch)
 }
 
+// developer tap (tools/fast_phases.py; not part of include/orbx.h): a device array of 32 u64 that the PROF instantiation of k_fast_cells adds
+// its per-phase shader cycles to; NULL = the product kernel
+static unsigned long long *g_fcProf = nullptr;
+extern "C" void orbx_debug_fast_cells_profile(unsigned long long *dev32) { g_fcProf = dev32; }
+
 int orbx_launch_fast_cells(const OrbxLaunch &L)
 {
-    dim3 grid((unsigned)L.geom->cellsPerFrame, (unsigned)L.batch);
-    const size_t ldsBytes = (size_t)L.geom->fcLdsBytes;
-#define FC_LAUNCH(SM) return emit(L, k_fast_cells<SM>, grid, dim3(64), ldsBytes, L.geomDev, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score, L.cellCount, L.cellSlots)
-    switch (L.geom->fcSegMax) {
-    case 1: FC_LAUNCH(1);
-    case 2: FC_LAUNCH(2);
-    case 3: FC_LAUNCH(3);
-    default: FC_LAUNCH(4);
-    }
+    const OrbxGeom &g = *L.geom;
+    static const int kEnv = getenv("ORBX_FC_CELLS_PER_WAVE") ? atoi(getenv("ORBX_FC_CELLS_PER_WAVE")) : 0;      // (developer knob)
+    const int K = kEnv > 0 ? kEnv : ORBX_FC_CELLS_PER_WAVE;
+    dim3 grid((unsigned)((g.cellsPerFrame + K - 1) / K), (unsigned)L.batch);
+    const size_t ldsBytes = (size_t)g.fcLdsBytes;
+#define FC_ARGS L.fcCells, K, g.cellsPerFrame, g.slotsPerFrame, g.pyrBytes, g.iniTh, g.minTh, g.fcInBytes, g.fcScBytes, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score, L.cellCount, L.cellSlots
+#define FC_LAUNCH(PP, SS, NN) do { if (g_fcProf) return emit(L, k_fast_cells<PP, SS, NN, true>, grid, dim3(64), ldsBytes, FC_ARGS, g_fcProf); \
+    return emit(L, k_fast_cells<PP, SS, NN, false>, grid, dim3(64), ldsBytes, FC_ARGS, (unsigned long long *)nullptr); } while (0)
+#define FC_LAUNCH_P(PP, SS) switch (g.fcNS) { case 2: FC_LAUNCH(PP, SS, 2); case 3: FC_LAUNCH(PP, SS, 3); case 4: FC_LAUNCH(PP, SS, 4); default: FC_LAUNCH(PP, SS, 6); }
+    if (g.fcPitch == 48) FC_LAUNCH_P(48, 48)
+    if (g.fcPitch == 64) FC_LAUNCH_P(64, 48)
+    if (g.fcScPitch == 48) FC_LAUNCH_P(80, 48)
+    FC_LAUNCH_P(80, 80)
+#undef FC_LAUNCH_P
 #undef FC_LAUNCH
+#undef FC_ARGS
 }
 
 int orbx_launch_octree(const OrbxLaunch &L)
@@ -1556,6 +1666,6 @@ int orbx_launch_orient_describe(const OrbxLaunch &L)
     for (int l = 0; l < g.nlevels; l++) { A.kpBase[l] = g.lv[l].kpBase; A.off[l] = g.lv[l].off; A.pitch[l] = g.lv[l].pitch; A.patch[l] = g.lv[l].patchSize; A.scale[l] = g.lv[l].scale; }
     for (int i = 0; i < 16; i++)
         if (g.umax[i] != kUmax[i]) { orbx_set_error("disc half-widths differ from the compiled table"); return ORBX_ERR_STATE; }
-    return emit(L, k_orient_describe, grid, dim3(64 * OD_WPB), 0, A, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.combTab ? (const int *)nullptr : (const int *)L.outBase, L.outKp, L.outDesc,
+    return emit(L, k_orient_describe, grid, dim3(64), 0, A, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.combTab ? (const int *)nullptr : (const int *)L.outBase, L.outKp, L.outDesc,
                 L.outCnt, L.status, L.outStatus);
 }
