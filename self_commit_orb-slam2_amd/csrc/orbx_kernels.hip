@@ -1266,28 +1266,48 @@ struct OdLevels {
     float scale[ORBX_MAX_LEVELS];
 };
 
-#define OD_WPB 4          /* keypoints per wave (= per workgroup) */
+// Round 5, measured and NOT kept (profiles/r05_orient_describe_ablation.txt): (1) one wave per FOUR keypoints, no workgroup barriers, all forty pixel loads
+// of the four in flight together, the lane's test pairs and disc mask in registers: 0.204 vs 0.207 ms alone, 275k vs 279k frames/s in the pipeline;
+// (2) the level's keypoints visited in (128-byte column strip, row) order so that a wave's four patches share cache lines: no change.  The kernel is
+// bound by its two pixel loads, not by arithmetic or its dependent chain: without the sample loop 0.200 ms, without the moments / angle 0.204, without
+// the blurred-patch loads 0.114, without the disc load 0.122.  Its L2 misses (TCC_EA0_RDREQ 4.14 M x 128 B = 530 MB per 256 frames) are the two
+// pyramids fetched ONCE (2 x 243 MB: the patches of ~1000 keypoints cover every 128-byte line of a frame), at the ~2.5 TB/s that scattered 128-byte
+// lines reach here (TCC hit rate 81 %, L1 63 %); the byte-granular "algorithmic" 331 MB of SURVEY 8d is not reachable by any visiting order.
+#define OD_WPB 4
 #define OD_R 18
 #define OD_DW 10
 #define OD_ROWS (2 * OD_R + 1)
 #define OD_PATCH_DW (OD_ROWS * OD_DW)
 
-// One WAVE takes four consecutive keypoint slots of a frame (round 5; before: one wave per keypoint, four per workgroup, three workgroup barriers).
-// Nothing is shared between waves, so there is no barrier at all, and a wave's dependent chain - counts -> keypoint records -> pixels -> moments ->
-// angle -> samples -> stores, four memory levels - is paid once per four keypoints with all forty pixel loads of the four in flight together.  The
-// per-lane constants (the lane's four test pairs, its disc mask) sit in registers for the whole wave instead of being copied into LDS by every
-// workgroup; the angle and its libm-exact sin / cos are computed on lanes 0..3, one keypoint each, in one pass.
-__global__ __launch_bounds__(64) void k_orient_describe(const OdLevels A, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
-                                                        const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, OrbxLevelKp *__restrict__ lvlKp,
-                                                        const int *__restrict__ lvlCnt, const int *__restrict__ outBase, orbx_keypoint *__restrict__ outKp,
-                                                        uint8_t *__restrict__ outDesc, int *__restrict__ outCnt, const int *__restrict__ status,
-                                                        int *__restrict__ outStatus)
+__global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels A, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
+                                                                 const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur, OrbxLevelKp *__restrict__ lvlKp,
+                                                                 const int *__restrict__ lvlCnt, const int *__restrict__ outBase, orbx_keypoint *__restrict__ outKp,
+                                                                 uint8_t *__restrict__ outDesc, int *__restrict__ outCnt, const int *__restrict__ status,
+                                                                 int *__restrict__ outStatus)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t sPatch[OD_WPB][OD_PATCH_DW + 2];
+    __shared__ uint32_t sPatch[OD_WPB][OD_PATCH_DW + 2];
+    __shared__ __attribute__((aligned(16))) float sPat[256][4];                  // test pair t as floats: x0, x1, y0, y1
+    __shared__ __attribute__((aligned(16))) uint32_t sDisc[64][4];               // byte masks of the disc: lane (row, half) x 4 dwords
+    __shared__ int sMom[OD_WPB][3];
+    __shared__ int sBase[ORBX_MAX_LEVELS];
+    __shared__ float sTrig[OD_WPB][3];
     XCD_REMAP_XY(bx, f);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // uniform: the keypoint bookkeeping below is scalar work
+    if (threadIdx.x < 256) {     // once per workgroup: both constant tables into LDS
+        *(float4 *)sPat[threadIdx.x] = *(const float4 *)c_od.pat[threadIdx.x];
+        ((uint32_t *)sDisc)[threadIdx.x] = ((const uint32_t *)c_od.disc)[threadIdx.x];
+    }
+    const int slot = bx * OD_WPB + wv;
     const int *cnts = lvlCnt + f * A.nlevels;
-    if (bx == 0 && lane == 0) {
+    // where each level's keypoints start in the frame's output list (level 0 .. n-1 in order, src/ORBextractor.cc:1577-1668): once per workgroup,
+    // lane = level, into LDS (k_blur's first workgroup used to leave it in global memory; the blur no longer has to run behind the quadtree for it)
+    if (!outBase && threadIdx.x < (unsigned)A.nlevels) {      // (batches: k_blur's first workgroup left the prefix in outBase)
+        int run = 0;
+        for (int i = 0; i < (int)threadIdx.x; i++) run += cnts[i];
+        sBase[threadIdx.x] = run;
+    }
+    if (bx == 0 && threadIdx.x == 0) {
         int tot = 0;
         for (int i = 0; i < A.nlevels; i++) tot += cnts[i];
         outCnt[f] = tot;
@@ -1296,137 +1316,103 @@ __global__ __launch_bounds__(64) void k_orient_describe(const OdLevels A, const 
         outStatus[f] = status[f];
         if (f == 0) outStatus[gridDim.y] = status[gridDim.y];
     }
-    // the slots: level, index inside the level, in use?  (consecutive slots cross at most one level boundary each)
-    const int slot0 = bx * OD_WPB;
-    int lv[OD_WPB], idx[OD_WPB];
-    bool live[OD_WPB];
-    {
-        int l = 0;
+    // Is the slot in use?  (Measured: requesting the keypoint record and the pixels BEFORE the counts are known - clamped coordinates for
+    // the ~7 % unused slots - shortens the dependent chain by one level but is 7 % slower: 0.242 vs 0.226 ms per 256 frames.)
+    bool inRange = slot < A.kpPerFrame;
+    int l = 0, kb = 0;
 #pragma unroll
-        for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += slot0 >= A.kpBase[i] ? 1 : 0;      // (entries past the last level hold INT_MAX)
-#pragma unroll
-        for (int j = 0; j < OD_WPB; j++) {
-            const int slot = slot0 + j;
-            if (j > 0 && l + 1 < A.nlevels && slot >= A.kpBase[l + 1]) l++;
-            lv[j] = l; idx[j] = slot - A.kpBase[l];
-            live[j] = slot < A.kpPerFrame && idx[j] < cnts[l];
-        }
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++) {      // (entries past the last level hold INT_MAX)
+        const bool ge = slot >= A.kpBase[i];
+        l += ge ? 1 : 0; kb = ge ? A.kpBase[i] : kb;
     }
-    if (!(live[0] || live[1] || live[2] || live[3])) return;
-    // the lane's constants: its test pair of each of the four rounds (x0, x1, y0, y1 as floats) and the byte mask of its disc row segment
-    float4 pt[4];
-#pragma unroll
-    for (int rd = 0; rd < 4; rd++) pt[rd] = *(const float4 *)c_od.pat[64 * rd + lane];
-    const uint4 mk = *(const uint4 *)c_od.disc[lane];
-    // where the frame's output list starts for each level (k_blur's first workgroup left the prefix in outBase; combined single-frame calls: lane = level)
-    int runLane = 0;
-    if (!outBase && lane < A.nlevels)
-        for (int i = 0; i < lane; i++) runLane += cnts[i];
-    // ---- the keypoint records, then every pixel the four keypoints need, requested back to back ----
-    // (an unused slot stands in as the level's first describable pixel: unconditional loads keep forty registers of pixels free of selects and copies)
-    int kx[OD_WPB], ky[OD_WPB], ksc[OD_WPB];
-#pragma unroll
-    for (int j = 0; j < OD_WPB; j++) {
-        const uint2 kraw = *(const uint2 *)&lvlKp[(size_t)f * A.kpPerFrame + (live[j] ? slot0 + j : 0)];     // x | y << 16, score | pad: the first 8 bytes of OrbxLevelKp
-        const int x_ = __builtin_amdgcn_readfirstlane((int)(kraw.x & 0xffffu)), y_ = __builtin_amdgcn_readfirstlane((int)(kraw.x >> 16));
-        kx[j] = live[j] ? x_ : ORBX_EDGE; ky[j] = live[j] ? y_ : ORBX_EDGE;
-        ksc[j] = __builtin_amdgcn_readfirstlane((int)(kraw.y & 0xffu));
-    }
+    const int idx = slot - kb;
+    inRange = inRange && idx < cnts[l];
+    const bool live = inRange;
+    const uint2 kraw = *(const uint2 *)&lvlKp[(size_t)f * A.kpPerFrame + (inRange ? slot : 0)];     // x | y << 16, score | pad: the first 8 bytes of OrbxLevelKp
+    const int kx = (int)(kraw.x & 0xffffu), ky = (int)(kraw.x >> 16);
+    const int ksc = (int)(kraw.y & 0xffu);
+    const int xa = (kx - OD_R) & ~3;
+    int m10 = 0, m01 = 0;
+    uint2 pw[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    uint4 wd = make_uint4(0u, 0u, 0u, 0u);
     const int r = lane >> 1, hf = lane & 1;      // disc row r, bytes x - 15 + 16 * half .. + 15 (19 <= x < w - 19: inside the level)
-    // patch item t of the lane: row (item / 5), 8-byte column (item % 5); the same for every keypoint
-    int prow[3], pcol[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-        const int item = min(lane + 64 * t, OD_ROWS * (OD_DW / 2) - 1);
-        prow[t] = (item * 205) >> 10; pcol[t] = 8 * (item - (OD_DW / 2) * prow[t]);
-    }
-    const int drow = min(r, 30) - 15, dcol = 16 * hf - 15;      // (lanes 62 / 63: row 30 again, masked out below)
-    uint4 wd[OD_WPB];
-    uint2 pw[OD_WPB][3];
-#pragma unroll
-    for (int j = 0; j < OD_WPB; j++) {
-        const int l = lv[j], bp = A.pitch[l], up = l ? bp : img0Stride;
-        const uint8_t *unb = (l ? pyr + (size_t)f * A.pyrBytes + A.off[l] : img0 + (size_t)f * img0FramePitch) + (size_t)ky[j] * up + kx[j];
-        const uint8_t *bl = blur + (size_t)f * A.pyrBytes + A.off[l] + (size_t)(ky[j] - OD_R) * bp + ((kx[j] - OD_R) & ~3);
-        wd[j] = load16u(unb + drow * up + dcol);
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(1)));
-            const u32x2_u v = *(const u32x2_u *)(bl + prow[t] * bp + pcol[t]);
-            pw[j][t] = make_uint2(v.x, v.y);
-        }
-    }
-    // ---- integer moments of the discs: sum I and sum (u + 15) I of the lane's row segment as v_dot4_u32_u8 over the masked bytes ----
-    const uint32_t wb = hf ? 0x10101010u : 0u;
-    int m01[OD_WPB], m10[OD_WPB];
-#pragma unroll
-    for (int j = 0; j < OD_WPB; j++) {
-        uint32_t s1 = 0u, sw = 0u;
-        s1 = __builtin_amdgcn_udot4(wd[j].x & mk.x, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd[j].x & mk.x, 0x03020100u + wb, sw, false);
-        s1 = __builtin_amdgcn_udot4(wd[j].y & mk.y, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd[j].y & mk.y, 0x07060504u + wb, sw, false);
-        s1 = __builtin_amdgcn_udot4(wd[j].z & mk.z, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd[j].z & mk.z, 0x0b0a0908u + wb, sw, false);
-        s1 = __builtin_amdgcn_udot4(wd[j].w & mk.w, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd[j].w & mk.w, 0x0f0e0d0cu + wb, sw, false);
-        m10[j] = wave_sum_dpp((int)sw - 15 * (int)s1); m01[j] = wave_sum_dpp((r - 15) * (int)s1);        // totals as wave-uniform scalars (lanes 62 / 63: mask 0)
-    }
-    // ---- the blurred patches into LDS (37 rows x 40 bytes each) ----
-#pragma unroll
-    for (int j = 0; j < OD_WPB; j++)
+    if (inRange) {
+        const int bp = A.pitch[l], up = l ? bp : img0Stride;
+        const uint8_t *unb = l ? pyr + (size_t)f * A.pyrBytes + A.off[l] : img0 + (size_t)f * img0FramePitch;
+        const uint8_t *bl = blur + (size_t)f * A.pyrBytes + A.off[l];
+        if (r < 31) __builtin_memcpy(&wd, unb + (size_t)(ky + r - 15) * up + (kx - 15 + 16 * hf), 16);     // ONE 16-byte load per lane
+        // patch: 37 rows x 5 aligned 8-byte units
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const int item = lane + 64 * t;
-            if (item < OD_ROWS * (OD_DW / 2)) *(uint2 *)&sPatch[j][2 * item] = pw[j][t];
-        }
-    // ---- fastAtan2 and the libm-exact sin / cos: lane j = keypoint j ----
-    float ang = 0.f, sn = 0.f, cs = 1.f;
-    {
-        const float fy = (float)(lane == 0 ? m01[0] : lane == 1 ? m01[1] : lane == 2 ? m01[2] : m01[3]);
-        const float fx = (float)(lane == 0 ? m10[0] : lane == 1 ? m10[1] : lane == 2 ? m10[2] : m10[3]);
-        if (lane < OD_WPB) {
-            ang = fast_atan2_deg(fy, fx);
-            const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-            sincosf_glibc(ang * factorPI, sn, cs);
-            const bool lv_ = lane == 0 ? live[0] : lane == 1 ? live[1] : lane == 2 ? live[2] : live[3];
-            if (lv_) {
-                OrbxLevelKp *o = lvlKp + (size_t)f * A.kpPerFrame + slot0 + lane;
-                o->angle = ang; o->ca = cs; o->sb = sn;        // (read back by the stage taps and by nothing else)
+            if (item < OD_ROWS * (OD_DW / 2)) {
+                const int pr = (item * 205) >> 10, pc = item - (OD_DW / 2) * pr;      // item / 5
+                __builtin_memcpy(&pw[t], bl + (size_t)(ky - OD_R + pr) * bp + xa + 8 * pc, 8);
             }
         }
     }
-    __syncthreads();           // (one wave: orders the patch stores before the sample reads)
+    __syncthreads();           // the tables are in LDS (the pixel loads are in flight meanwhile)
+    if (inRange && r < 31) {
+        // integer moments of the row segment: sum I and sum (u + 15) I as v_dot4_u32_u8 over the masked bytes, u + 15 = c (left half) / c + 16 (right half)
+        const uint4 mk = *(const uint4 *)sDisc[lane];
+        const uint32_t wb = hf ? 0x10101010u : 0u;
+        uint32_t s1 = 0u, sw = 0u;
+        s1 = __builtin_amdgcn_udot4(wd.x & mk.x, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.x & mk.x, 0x03020100u + wb, sw, false);
+        s1 = __builtin_amdgcn_udot4(wd.y & mk.y, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.y & mk.y, 0x07060504u + wb, sw, false);
+        s1 = __builtin_amdgcn_udot4(wd.z & mk.z, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.z & mk.z, 0x0b0a0908u + wb, sw, false);
+        s1 = __builtin_amdgcn_udot4(wd.w & mk.w, 0x01010101u, s1, false); sw = __builtin_amdgcn_udot4(wd.w & mk.w, 0x0f0e0d0cu + wb, sw, false);
+        m10 = (int)sw - 15 * (int)s1;
+        m01 = (r - 15) * (int)s1;
+    }
+    m10 = wave_sum_dpp(m10); m01 = wave_sum_dpp(m01);        // totals as wave-uniform scalars
+    if (lane == 0) { sMom[wv][0] = m01; sMom[wv][1] = m10; sMom[wv][2] = live ? slot : -1; }
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int item = lane + 64 * t;
+            if (item < OD_ROWS * (OD_DW / 2)) *(uint2 *)&sPatch[wv][2 * item] = pw[t];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < OD_WPB && sMom[threadIdx.x][2] >= 0) {
+        const float ang = fast_atan2_deg((float)sMom[threadIdx.x][0], (float)sMom[threadIdx.x][1]);
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        float sn, cs;
+        sincosf_glibc(ang * factorPI, sn, cs);
+        sTrig[threadIdx.x][0] = cs; sTrig[threadIdx.x][1] = sn; sTrig[threadIdx.x][2] = ang;
+        OrbxLevelKp *o = lvlKp + (size_t)f * A.kpPerFrame + sMom[threadIdx.x][2];
+        o->angle = ang; o->ca = cs; o->sb = sn;        // (read back by the stage taps and by nothing else)
+    }
+    __syncthreads();
+    if (!live) return;
+    const float a = sTrig[wv][0], b = sTrig[wv][1];
+    const uint8_t *pb = (const uint8_t *)sPatch[wv] + OD_R * (4 * OD_DW) + (kx - xa);     // the keypoint's own pixel
+    unsigned long long bits[4];
     typedef float f2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int j = 0; j < OD_WPB; j++) {
-        if (!live[j]) continue;
-        const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cs), j)), b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sn), j));
-        const float angj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ang), j));
-        const int xa = (kx[j] - OD_R) & ~3;
-        const uint8_t *pb = (const uint8_t *)sPatch[j] + OD_R * (4 * OD_DW) + (kx[j] - xa);     // the keypoint's own pixel
-        unsigned long long bits[4];
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
-            // both points of test pair 64 rd + lane at once (v_pk_mul_f32 / v_pk_add_f32: every product and sum is rounded on its own, exactly
-            // like the scalar expressions of src/ORBextractor.cc:192-193 compiled without contraction)
-            const f2_t xs = {pt[rd].x, pt[rd].y}, ys = {pt[rd].z, pt[rd].w};
-            const f2_t rr = xs * b + ys * a, cc = xs * a - ys * b;
-            // cvRound of both coordinates, then row * 40 + column: small integers, exact in float
-            const int o0 = (int)__builtin_fmaf(__builtin_rintf(rr.x), (float)(4 * OD_DW), __builtin_rintf(cc.x));
-            const int o1 = (int)__builtin_fmaf(__builtin_rintf(rr.y), (float)(4 * OD_DW), __builtin_rintf(cc.y));
-            const int t0 = pb[o0], t1 = pb[o1];
-            bits[rd] = __ballot(t0 < t1);
-        }
-        const int l = lv[j];
-        const int outIdx = (outBase ? outBase[f * A.nlevels + l] : __builtin_amdgcn_readlane(runLane, l)) + idx[j];      // (< outCap: the output capacity is the sum of the levels' capacities)
-        if (outIdx >= A.outCap) continue;
-        unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * A.outCap + outIdx) * 32);
-        if (lane < 4) d64[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-        if (lane == 0) {
-            orbx_keypoint o;
-            const float sc = A.scale[l];
-            o.x = l ? (float)kx[j] * sc : (float)kx[j];
-            o.y = l ? (float)ky[j] * sc : (float)ky[j];
-            o.size = (float)A.patch[l]; o.angle = angj; o.response = (float)ksc[j]; o.octave = l; o.class_id = -1;
-            outKp[(size_t)f * A.outCap + outIdx] = o;
-        }
+    for (int rd = 0; rd < 4; rd++) {
+        // both points of test pair 64 rd + lane at once (v_pk_mul_f32 / v_pk_add_f32: every product and sum is rounded on its own, exactly
+        // like the scalar expressions of src/ORBextractor.cc:192-193 compiled without contraction)
+        const float4 pt = *(const float4 *)sPat[64 * rd + lane];
+        const f2_t xs = {pt.x, pt.y}, ys = {pt.z, pt.w};
+        const f2_t rr = xs * b + ys * a, cc = xs * a - ys * b;
+        // cvRound of both coordinates, then row * 40 + column: small integers, exact in float
+        const int o0 = (int)__builtin_fmaf(__builtin_rintf(rr.x), (float)(4 * OD_DW), __builtin_rintf(cc.x));
+        const int o1 = (int)__builtin_fmaf(__builtin_rintf(rr.y), (float)(4 * OD_DW), __builtin_rintf(cc.y));
+        const int t0 = pb[o0], t1 = pb[o1];
+        bits[rd] = __ballot(t0 < t1);
+    }
+    const int outIdx = (outBase ? outBase[f * A.nlevels + l] : sBase[l]) + idx;      // (< outCap: the output capacity is the sum of the levels' capacities)
+    if (outIdx >= A.outCap) return;
+    unsigned long long *d64 = (unsigned long long *)(outDesc + ((size_t)f * A.outCap + outIdx) * 32);
+    if (lane < 4) d64[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+    if (lane == 0) {
+        orbx_keypoint o;
+        const float sc = A.scale[l];
+        o.x = l ? (float)kx * sc : (float)kx;
+        o.y = l ? (float)ky * sc : (float)ky;
+        o.size = (float)A.patch[l]; o.angle = sTrig[wv][2]; o.response = (float)ksc; o.octave = l; o.class_id = -1;
+        outKp[(size_t)f * A.outCap + outIdx] = o;
     }
 }
 
@@ -1666,6 +1652,6 @@ int orbx_launch_orient_describe(const OrbxLaunch &L)
     for (int l = 0; l < g.nlevels; l++) { A.kpBase[l] = g.lv[l].kpBase; A.off[l] = g.lv[l].off; A.pitch[l] = g.lv[l].pitch; A.patch[l] = g.lv[l].patchSize; A.scale[l] = g.lv[l].scale; }
     for (int i = 0; i < 16; i++)
         if (g.umax[i] != kUmax[i]) { orbx_set_error("disc half-widths differ from the compiled table"); return ORBX_ERR_STATE; }
-    return emit(L, k_orient_describe, grid, dim3(64), 0, A, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.combTab ? (const int *)nullptr : (const int *)L.outBase, L.outKp, L.outDesc,
+    return emit(L, k_orient_describe, grid, dim3(64 * OD_WPB), 0, A, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.blur, L.lvlKp, L.lvlCnt, L.combTab ? (const int *)nullptr : (const int *)L.outBase, L.outKp, L.outDesc,
                 L.outCnt, L.status, L.outStatus);
 }
