@@ -794,8 +794,10 @@ def bench_lba(a, orbx, torch, grp, dev_t, local, rank_info):
 
 
 def host_io_batch(orbx, a, local, seconds=1.0):
-    """orbx_extract_batch as the C ABI declares it for host callers: host image pointers in, host keypoint / descriptor arrays out, every call
-    synchronous - upload, the batch's launch set and the download of the whole result arena all inside the timed region (PCIe both ways)."""
+    """orbx_extract_batch as the C ABI declares it for host callers: host image pointers in, host keypoint / descriptor arrays out - upload, the
+    batch's launch set and the download of the results all inside the timed region (PCIe both ways).  Three forms: the synchronous call (chunks of
+    64 frames through the two-slot pipeline inside the call), orbx_extract_batch_begin / _end with two batches in flight (pageable frames), and the
+    same with the frames in pinned memory (read in place, no staging copy)."""
     W, H, B, nf = a.width, a.height, min(a.batch, 256), a.nfeatures
     ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local)
     frames = orbx.synth_sequence(991, B, W, H)
@@ -806,9 +808,32 @@ def host_io_batch(orbx, a, local, seconds=1.0):
         n += 1
     dt = time.perf_counter() - t0
     cap = ext.capacity
+    out = {"frames_per_s": round(n * B / dt, 1), "batch": B, "ms_per_batch": round(dt / n * 1e3, 3), "keypoints_per_frame": round(float(counts.mean()), 1),
+           "note": "host pointers in (pageable), host arrays out, synchronous: %d MB up and %d MB of result arrays down per call; the result arrays are reused" % ((B * W * H) >> 20, (B * cap * 60) >> 20)}
+
+    def piped(fr):
+        r2 = [res, tuple(np.zeros_like(x) for x in res)]
+        ext.extract_batch_begin(fr)
+        m, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < seconds:
+            ext.extract_batch_begin(fr)
+            ext.extract_batch_end(out=r2[m & 1])
+            m += 1
+        ext.extract_batch_end(out=r2[m & 1])
+        d1 = time.perf_counter() - t1
+        return {"frames_per_s": round((m + 1) * B / d1, 1), "ms_per_batch": round(d1 / (m + 1) * 1e3, 3)}
+    try:
+        out["pipelined"] = dict(piped(frames), note="orbx_extract_batch_begin / _end, two batches in flight, pageable frames staged on the copy pool")
+        import torch
+        pin = torch.empty((B, H, W), dtype=torch.uint8).pin_memory()
+        hp = pin.numpy()
+        for i in range(B):
+            hp[i] = frames[i]
+        out["pipelined_pinned"] = dict(piped([hp[i] for i in range(B)]), note="the same with the frames in pinned memory: read in place by the DMA engines")
+    except Exception as e:      # noqa: BLE001
+        out["pipelined_error"] = "%s: %s" % (type(e).__name__, e)
     ext.close()
-    return {"frames_per_s": round(n * B / dt, 1), "batch": B, "ms_per_batch": round(dt / n * 1e3, 3), "keypoints_per_frame": round(float(counts.mean()), 1),
-            "note": "host pointers in (pageable), host arrays out, synchronous: %d MB up and %d MB of result arrays down per call; the result arrays are reused" % ((B * W * H) >> 20, (B * cap * 60) >> 20)}
+    return out
 
 
 def main():

@@ -143,6 +143,16 @@ int orbx_extract_batch(orbx_extractor *h, const uint8_t *const *images, int batc
                        int height, int stride, orbx_keypoint *keypoints, uint8_t *descriptors,
                        int capacity, int *counts);
 
+/* The same call as a two-deep pipeline (SURVEY.md 8b's batch entry point with host pointers; replaces a loop of operator() calls,
+ * include/ORBextractor.h:110, src/Frame.cc:394).  _begin stages and uploads the frames (frames that already live in pinned or registered
+ * host memory are read in place), enqueues the batch's launch set and the read-back of its results, and returns without waiting; _end waits
+ * for the OLDEST begun batch and fills the caller's arrays exactly like orbx_extract_batch.  Up to two batches may be begun before the first
+ * _end: staging + upload of batch i+1 and the read-back of batch i-1 then run under the kernels of batch i.  The images of a batch must stay
+ * valid until its _begin returns (pinned / registered images: until its _end returns).  A third _begin, or an _end with nothing begun,
+ * returns ORBX_ERR_STATE.  orbx_extract_batch itself runs this pipeline over chunks of its batch (ORBX_HOST_BATCH_CHUNK frames, default 64). */
+int orbx_extract_batch_begin(orbx_extractor *h, const uint8_t *const *images, int batch, int width, int height, int stride);
+int orbx_extract_batch_end(orbx_extractor *h, orbx_keypoint *keypoints, uint8_t *descriptors, int capacity, int *counts);
+
 /* Device-resident batch: images_dev points to DEVICE memory, frame f at
  * images_dev + f*frame_pitch (rows `stride` bytes apart); the buffer spans batch*frame_pitch
  * bytes.  Runs asynchronously on the handle's stream; results stay in handle-owned device

@@ -70,6 +70,8 @@ def load_library():
     L.orbx_extractor_capacity.argtypes = [vp]
     L.orbx_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp]
     L.orbx_extract_batch.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp]
+    L.orbx_extract_batch_begin.argtypes = [vp, vp, ci, ci, ci, ci]
+    L.orbx_extract_batch_end.argtypes = [vp, vp, vp, ci, vp]
     L.orbx_extract_view_pyramid.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp]
     L.orbx_extractor_expect_partner.argtypes = [vp, vp]
     L.orbx_combiner_stats.argtypes = [vp, vp, vp, vp]
@@ -250,6 +252,31 @@ class ORBextractor:
             counts = np.zeros(B, np.int32)
         _check(self._L.orbx_extract_batch(self._h, arr, B, W, H, W, _ptr(kps), _ptr(desc), cap, _ptr(counts)))
         self._last_size = (W, H)
+        return kps, desc, counts
+
+    # --- the two-deep pipeline of host batches (orbx_extract_batch_begin / _end) ---
+    def extract_batch_begin(self, images):
+        """Stage + upload + launch set + read-back of one batch, nothing waited for; at most two batches between a begin and its end."""
+        B = len(images)
+        H, W = images[0].shape
+        arr = (ctypes.c_void_p * B)(*[im.ctypes.data for im in images])      # (the caller keeps `images` alive and contiguous until the call returns)
+        _check(self._L.orbx_extract_batch_begin(self._h, arr, B, W, H, images[0].strides[0]))
+        self._last_size = (W, H)
+        self._pipe_batches = getattr(self, "_pipe_batches", []) + [B]
+
+    def extract_batch_end(self, out=None):
+        """Results of the OLDEST begun batch, as extract_batch returns them."""
+        if not getattr(self, "_pipe_batches", None):
+            raise OrbxError(-5, "no batch has been begun")
+        B = self._pipe_batches.pop(0)
+        cap = self.capacity
+        if out is not None and out[0].shape == (B, cap) and out[1].shape == (B, cap, 32) and out[2].shape == (B,):
+            kps, desc, counts = out
+        else:
+            kps = np.zeros((B, cap), KEYPOINT_DTYPE)
+            desc = np.zeros((B, cap, 32), np.uint8)
+            counts = np.zeros(B, np.int32)
+        _check(self._L.orbx_extract_batch_end(self._h, _ptr(kps), _ptr(desc), cap, _ptr(counts)))
         return kps, desc, counts
 
     # --- device-resident path used by bench.py ---

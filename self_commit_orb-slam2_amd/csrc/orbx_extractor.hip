@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -135,6 +137,21 @@ struct orbx_extractor {
     bool hostPyrValid = false;        // ... and whether the last call filled it
     bool hostSynced = false;          // the last call was a synchronous single-frame call: complete when it returned, capacity word in hostOut[1]
     bool lastCombined = false;        // the last call ran on a shared engine: this handle's `blur` buffer (a parity tap) was not written
+    // Pipelined host batches (orbx_extract_batch_begin / _end, and orbx_extract_batch itself in chunks): two slots, each with its own pinned
+    // input, device input and pinned result buffer; uploads on upStream, read-backs on downStream, kernels on `stream`.
+    struct PipeSlot {
+        uint8_t *hostIn = nullptr; size_t hostInBytes = 0;
+        DevBuf<uint8_t> devIn;
+        uint8_t *hostRes = nullptr; size_t hostResBytes = 0;
+        const uint8_t **ptrTab = nullptr; size_t ptrTabBytes = 0;      // pinned: addresses of a batch's frames for k_gather_frames
+        hipEvent_t evUp = nullptr, evKern = nullptr, evDown = nullptr;
+        int batch = 0;
+        size_t offKp = 0, offDesc = 0, offSt = 0;
+    } pipe[2];
+    int pipeHead = 0, pipeCount = 0;  // oldest begun slot, number of begun and not yet ended batches (<= 2)
+    double pipeUs[4] = {0, 0, 0, 0};  // ORBX_PIPE_STATS=1: host microseconds in staging + enqueue, the launch set's enqueue, the wait for the read-back, the copy-out
+    long pipeCalls = 0;
+    hipStream_t upStream = nullptr, downStream = nullptr;
 };
 
 static bool plan_pyramid_tiles(orbx_extractor *h, std::vector<OrbxPyrTile> &out, int &tiles, int &bufBytes, int &tabBytes);      // (below; run_batch plans too)
@@ -502,21 +519,64 @@ static int host_copy_threads()
 {
     static const int n = [] {
         const char *e = getenv("ORBX_HOST_COPY_THREADS");
-        int v = e && *e ? atoi(e) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        int v = e && *e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
         return v < 1 ? 1 : v > 64 ? 64 : v;
     }();
     return n;
 }
-template <typename F> static void parallel_slices(int n, int nthreads, F fn)      // fn(begin, end) over [0, n) in nthreads contiguous slices; the caller takes the first
-{
-    nthreads = std::max(1, std::min(nthreads, n));
-    if (nthreads == 1) { fn(0, n); return; }
-    std::vector<std::thread> th;
-    th.reserve((size_t)nthreads - 1);
-    for (int t = 1; t < nthreads; t++) th.emplace_back(fn, (int)((long long)n * t / nthreads), (int)((long long)n * (t + 1) / nthreads));
-    fn(0, (int)((long long)n / nthreads));
-    for (auto &x : th) x.join();
-}
+// fn(begin, end) over [0, n) in nthreads contiguous slices on the process's copy pool (the caller takes the first slice).  The workers are created
+// once: a chunked host batch stages and copies out eight times per call, and eight thread creations per slice set cost more than the copies.
+struct CopyPool {
+    std::mutex m;                       // one job at a time (callers of different handles queue here; a job is a fraction of a millisecond)
+    std::mutex jm;
+    std::condition_variable cvWork, cvDone;
+    std::vector<std::thread> workers;
+    std::function<void(int, int)> job;
+    int n = 0, parts = 0, gen = 0, pending = 0;
+    bool stop = false;
+    void worker(int id)
+    {
+        int seen = 0;
+        for (;;) {
+            std::function<void(int, int)> fn;
+            int n_, parts_;
+            {
+                std::unique_lock<std::mutex> lk(jm);
+                cvWork.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; fn = job; n_ = n; parts_ = parts;
+            }
+            if (id < parts_) fn((int)((long long)n_ * id / parts_), (int)((long long)n_ * (id + 1) / parts_));
+            {
+                std::lock_guard<std::mutex> lk(jm);
+                if (--pending == 0) cvDone.notify_all();
+            }
+        }
+    }
+    void run(int n_, int nthreads, const std::function<void(int, int)> &fn)
+    {
+        nthreads = std::max(1, std::min(nthreads, n_));
+        if (nthreads == 1) { fn(0, n_); return; }
+        std::lock_guard<std::mutex> one(m);
+        {
+            std::lock_guard<std::mutex> lk(jm);
+            while ((int)workers.size() < nthreads - 1) { const int id = (int)workers.size() + 1; workers.emplace_back([this, id] { worker(id); }); }
+            job = fn; n = n_; parts = nthreads; pending = (int)workers.size(); gen++;
+        }
+        cvWork.notify_all();
+        fn(0, (int)((long long)n_ / nthreads));
+        std::unique_lock<std::mutex> lk(jm);
+        cvDone.wait(lk, [&] { return pending == 0; });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(jm); stop = true; }
+        cvWork.notify_all();
+        for (auto &t : workers) t.join();
+    }
+};
+static CopyPool &copy_pool() { static CopyPool *p = new CopyPool; return *p; }      // (never destroyed: handles may outlive static destruction order)
+template <typename F> static void parallel_slices(int n, int nthreads, F fn) { copy_pool().run(n, nthreads, std::function<void(int, int)>(fn)); }
 
 int upload(orbx_extractor *h, const uint8_t *const *images, int batch, int W, int H, int stride)
 {
@@ -668,6 +728,21 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *h)
     h->geomDev.release(); h->binDev.release(); h->rsDev.release(); h->fcDev.release(); h->ptDev.release(); h->pyr.release(); h->blur.release();
     if (h->hostStaging) { (void)hipHostFree(h->hostStaging); h->hostStaging = nullptr; h->hostStagingBytes = 0; }
     if (h->hostOut) { (void)hipHostFree(h->hostOut); h->hostOut = nullptr; h->hostOutBytes = 0; }
+    if (h->pipeCalls && getenv("ORBX_PIPE_STATS"))
+        fprintf(stderr, "[orbx] host batch pipeline, %ld batches: staging + upload enqueue %.0f us, launch set + read-back enqueue %.0f us, wait for the read-back %.0f us, copy-out %.0f us (means)\n",
+                h->pipeCalls, h->pipeUs[0] / h->pipeCalls, h->pipeUs[1] / h->pipeCalls, h->pipeUs[2] / h->pipeCalls, h->pipeUs[3] / h->pipeCalls);
+    if (h->upStream) { (void)hipStreamSynchronize(h->upStream); (void)hipStreamDestroy(h->upStream); }
+    if (h->downStream) { (void)hipStreamSynchronize(h->downStream); (void)hipStreamDestroy(h->downStream); }
+    for (int i = 0; i < 2; i++) {
+        orbx_extractor::PipeSlot &S = h->pipe[i];
+        if (S.hostIn) (void)hipHostFree(S.hostIn);
+        if (S.hostRes) (void)hipHostFree(S.hostRes);
+        if (S.ptrTab) (void)hipHostFree(S.ptrTab);
+        S.devIn.release();
+        if (S.evUp) (void)hipEventDestroy(S.evUp);
+        if (S.evKern) (void)hipEventDestroy(S.evKern);
+        if (S.evDown) (void)hipEventDestroy(S.evDown);
+    }
     h->score.release(); h->staging.release(); h->cellCount.release(); h->lvlCnt.release(); h->lvlBase.release();
     for (int b = 0; b < 2; b++) h->outArena[b].release();
     h->status.release(); h->cellSlots.release(); h->ptBuf.release(); h->labBuf.release(); h->lvlKp.release();
@@ -1495,6 +1570,180 @@ extern "C" int orbx_download_pyramid_all(orbx_extractor *h, int frame, uint8_t *
     return ORBX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Host batches as a pipeline (orbx_extract_batch(handle, const uint8_t* const* imgs, int B, ...) with host pointers in and host arrays
+// out).  A synchronous call that stages 75 MB, uploads them, runs the launch set and reads 16 MB back one after the other spends 4.3 ms per 256
+// frames of 640x480 where PCIe needs 1.5.  _begin stages the frames into the slot's pinned buffer on the copy pool (every thread sends its slice as
+// soon as it is staged; frames that already live in pinned / registered memory go straight from there), uploads on its own stream, enqueues the
+// launch set behind the upload and the read-back of counts x (28 + 32) bytes behind the launch set on a third stream, and returns; _end waits
+// for the OLDEST begun batch's read-back and fills the caller's arrays.  With two batches begun, the staging and upload of batch i+1 and the
+// read-back of batch i-1 overlap the kernels of batch i.  orbx_extract_batch runs the same pipeline over chunks of its batch.
+// ---------------------------------------------------------------------------------------------------------------------------
+static int pipe_streams(orbx_extractor *h)
+{
+    if (!h->upStream) ORBX_HIP_CHECK(hipStreamCreateWithFlags(&h->upStream, hipStreamNonBlocking));
+    if (!h->downStream) ORBX_HIP_CHECK(hipStreamCreateWithFlags(&h->downStream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        orbx_extractor::PipeSlot &S = h->pipe[i];
+        if (!S.evUp) ORBX_HIP_CHECK(hipEventCreateWithFlags(&S.evUp, hipEventDisableTiming));
+        if (!S.evKern) ORBX_HIP_CHECK(hipEventCreateWithFlags(&S.evKern, hipEventDisableTiming));
+        if (!S.evDown) ORBX_HIP_CHECK(hipEventCreateWithFlags(&S.evDown, hipEventDisableTiming));
+    }
+    return ORBX_OK;
+}
+
+static bool host_pointer_is_pinned(const void *p)      // hipHostMalloc'ed or hipHostRegister'ed memory: the DMA engines read it in place
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // (pageable memory: "invalid value")
+    return a.type == hipMemoryTypeHost;
+}
+
+extern "C" int orbx_extract_batch_begin(orbx_extractor *h, const uint8_t *const *images, int batch, int width, int height, int stride)
+{
+    if (!h || !images) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (batch <= 0 || stride < width) { orbx_set_error("bad batch / stride"); return ORBX_ERR_ARG; }
+    if (h->pipeCount >= 2) { orbx_set_error("two batches are already begun: call orbx_extract_batch_end first"); return ORBX_ERR_STATE; }
+    for (int f = 0; f < batch; f++)
+        if (!images[f]) { orbx_set_error("image %d is NULL", f); return ORBX_ERR_ARG; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    int rc = pipe_streams(h);
+    if (rc != ORBX_OK) return rc;
+    if (h->pipeCount > 0 && (!h->geomValid || h->geom.W != width || h->geom.H != height || batch > h->allocBatch)) {
+        // the handle's buffers are about to be rebuilt under a batch in flight: let it finish (its results wait in the slot's pinned buffer)
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->downStream));
+    }
+    if ((rc = ensure_geometry(h, width, height, batch)) != ORBX_OK) return rc;
+    const int W = width, H = height;
+    // rows travel PACKED (stride = width rounded up to 4): the padded device pitch of the resident path would put 10 % more bytes on PCIe, and a
+    // frame whose rows are already packed is staged with one memcpy; the kernels take any stride (256 spare bytes behind every frame)
+    const int dstStride = (int)align_up((size_t)W, 4);
+    size_t fp = align_up((size_t)dstStride * H + 256, 256);
+    orbx_extractor::PipeSlot &S = h->pipe[(h->pipeHead + h->pipeCount) & 1];      // free: whatever used it last has been ended
+    const auto tB0 = std::chrono::steady_clock::now();
+    const bool pinned = host_pointer_is_pinned(images[0]) && host_pointer_is_pinned(images[batch - 1] + (size_t)stride * (size_t)(H - 1) + (size_t)W - 1);
+    // packed frames back to back in pinned memory (one (B, H, W) array): the device layout takes the same frame pitch and the batch is ONE copy
+    bool oneCopy = pinned && stride == dstStride && ((size_t)stride * H) % 16 == 0;
+    for (int f = 1; f < batch && oneCopy; f++) oneCopy = images[f] == images[0] + (size_t)f * stride * H;
+    if (oneCopy) fp = (size_t)stride * H;
+    const size_t bytes = fp * (size_t)batch;
+    if ((rc = S.devIn.ensure(bytes + 256)) != ORBX_OK) return rc;      // (256 readable bytes behind the last frame)
+    bool gathered = false;
+    if (oneCopy) {
+        ORBX_HIP_CHECK(hipMemcpyAsync(S.devIn.p, images[0], bytes, hipMemcpyHostToDevice, h->upStream));
+        gathered = true;
+    } else if (pinned && (stride & 3) == 0) {
+        // one kernel reads the frames where they are (a table of their addresses in pinned memory): 256 two-dimensional copies cost 15 us of host time each
+        bool al4 = true, al16 = (stride & 15) == 0 && (dstStride & 15) == 0;
+        for (int f = 0; f < batch; f++) { al4 = al4 && ((uintptr_t)images[f] & 3) == 0; al16 = al16 && ((uintptr_t)images[f] & 15) == 0; }
+        if (al4) {
+            if ((size_t)batch * sizeof(void *) > S.ptrTabBytes) {
+                if (S.ptrTab) (void)hipHostFree(S.ptrTab);
+                S.ptrTab = nullptr; S.ptrTabBytes = 0;
+                const size_t nb = align_up((size_t)std::max(batch, h->cfg.max_batch) * sizeof(void *), 256);
+                ORBX_HIP_CHECK(hipHostMalloc((void **)&S.ptrTab, nb, hipHostMallocDefault));
+                S.ptrTabBytes = nb;
+            }
+            for (int f = 0; f < batch; f++) S.ptrTab[f] = images[f];
+            if ((rc = orbx_launch_gather_frames(h->upStream, (const uint8_t *const *)S.ptrTab, batch, W, H, stride, S.devIn.p, dstStride, fp, al16)) != ORBX_OK) return rc;
+            gathered = true;
+        }
+    }
+    if (gathered) {
+    } else if (pinned) {
+        for (int f = 0; f < batch; f++)
+            ORBX_HIP_CHECK(hipMemcpy2DAsync(S.devIn.p + fp * (size_t)f, (size_t)dstStride, images[f], (size_t)stride, (size_t)W, (size_t)H, hipMemcpyHostToDevice, h->upStream));
+    } else {
+        if (bytes > S.hostInBytes) {
+            if (S.hostIn) (void)hipHostFree(S.hostIn);
+            S.hostIn = nullptr; S.hostInBytes = 0;
+            ORBX_HIP_CHECK(hipHostMalloc((void **)&S.hostIn, bytes, hipHostMallocDefault));
+            S.hostInBytes = bytes;
+        }
+        std::atomic<int> failed{0};
+        const int dev = h->cfg.device;
+        parallel_slices(batch, batch >= 16 ? host_copy_threads() : 1, [&](int f0, int f1) {
+            // (measured and not kept: sending every four staged frames at once - 64 copies per batch from 16 threads queue on the runtime's lock: 98k instead of 145k frames/s)
+            for (int f = f0; f < f1; f++) {
+                uint8_t *dst = S.hostIn + fp * (size_t)f;
+                if (stride == dstStride) memcpy(dst, images[f], (size_t)dstStride * (size_t)(H - 1) + (size_t)W);
+                else for (int y = 0; y < H; y++) memcpy(dst + (size_t)y * dstStride, images[f] + (size_t)y * stride, (size_t)W);
+            }
+            if (f1 > f0 && (hipSetDevice(dev) != hipSuccess ||
+                            hipMemcpyAsync(S.devIn.p + fp * (size_t)f0, S.hostIn + fp * (size_t)f0, fp * (size_t)(f1 - f0), hipMemcpyHostToDevice, h->upStream) != hipSuccess))
+                failed.store(1);
+        });
+        if (failed.load()) { orbx_set_error("upload of the batch failed: %s", hipGetErrorString(hipGetLastError())); return ORBX_ERR_HIP; }
+    }
+    const auto tB1 = std::chrono::steady_clock::now();
+    ORBX_HIP_CHECK(hipEventRecord(S.evUp, h->upStream));
+    ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, S.evUp, 0));
+    if ((rc = run_batch(h, S.devIn.p, batch, W, H, dstStride, fp)) != ORBX_OK) return rc;
+    ORBX_HIP_CHECK(hipEventRecord(S.evKern, h->stream));
+    // read-back: counts and capacity words, then the keypoint / descriptor arrays of the batch's frames (the arena is laid out for allocBatch frames)
+    const int cap = h->geom.outCap, cb = h->cur;
+    const size_t B = (size_t)batch;
+    S.offSt = align_up(B * sizeof(int), 256); S.offKp = S.offSt + align_up((B + 1) * sizeof(int), 256);
+    S.offDesc = S.offKp + align_up(B * cap * sizeof(orbx_keypoint), 256);
+    const size_t resBytes = S.offDesc + B * cap * 32;
+    if (resBytes > S.hostResBytes) {
+        if (S.hostRes) (void)hipHostFree(S.hostRes);
+        S.hostRes = nullptr; S.hostResBytes = 0;
+        ORBX_HIP_CHECK(hipHostMalloc((void **)&S.hostRes, resBytes, hipHostMallocDefault));
+        S.hostResBytes = resBytes;
+    }
+    ORBX_HIP_CHECK(hipStreamWaitEvent(h->downStream, S.evKern, 0));
+    ORBX_HIP_CHECK(hipMemcpyAsync(S.hostRes, h->outCntP[cb], B * sizeof(int), hipMemcpyDeviceToHost, h->downStream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(S.hostRes + S.offSt, h->outStP[cb], B * sizeof(int), hipMemcpyDeviceToHost, h->downStream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(S.hostRes + S.offKp, h->outKpP[cb], B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->downStream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(S.hostRes + S.offDesc, h->outDescP[cb], B * cap * 32, hipMemcpyDeviceToHost, h->downStream));
+    ORBX_HIP_CHECK(hipEventRecord(S.evDown, h->downStream));
+    h->consumerEv[cb] = S.evDown;      // the batch after the next one overwrites this result buffer: only behind the read-back
+    S.batch = batch;
+    h->pipeCount++;
+    const auto tB2 = std::chrono::steady_clock::now();
+    h->pipeUs[0] += std::chrono::duration<double, std::micro>(tB1 - tB0).count(); h->pipeUs[1] += std::chrono::duration<double, std::micro>(tB2 - tB1).count();
+    h->pipeCalls++;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch_end(orbx_extractor *h, orbx_keypoint *keypoints, uint8_t *descriptors, int capacity, int *counts)
+{
+    if (!h || !counts) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (h->pipeCount <= 0) { orbx_set_error("no batch has been begun"); return ORBX_ERR_STATE; }
+    ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
+    orbx_extractor::PipeSlot &S = h->pipe[h->pipeHead];
+    h->pipeHead ^= 1; h->pipeCount--;          // the slot is handed back whatever happens below
+    const auto tE0 = std::chrono::steady_clock::now();
+    ORBX_HIP_CHECK(hipEventSynchronize(S.evDown));
+    const auto tE1 = std::chrono::steady_clock::now();
+    const int batch = S.batch, cap = h->geom.outCap;
+    const uint8_t *hp = S.hostRes;
+    const int *st = (const int *)(hp + S.offSt);
+    for (int f = 0; f < batch; f++)
+        if (st[f]) {
+            orbx_set_error("frame %d: device capacity error bits 0x%x (1: FAST candidates of a level, 2: quadtree node list, 4: level keypoints)", f, st[f]);
+            return ORBX_ERR_CAPACITY;
+        }
+    memcpy(counts, hp, (size_t)batch * sizeof(int));
+    for (int f = 0; f < batch; f++)
+        if (counts[f] > capacity) { orbx_set_error("frame %d has %d keypoints but the caller's capacity is %d", f, counts[f], capacity); return ORBX_ERR_CAPACITY; }
+    const size_t offKp = S.offKp, offDesc = S.offDesc;
+    parallel_slices(batch, batch >= 16 ? host_copy_threads() : 1, [&](int f0, int f1) {
+        for (int f = f0; f < f1; f++) {
+            const int n = counts[f];
+            if (n == 0) continue;
+            if (keypoints) memcpy(keypoints + (size_t)f * capacity, hp + offKp + (size_t)f * cap * sizeof(orbx_keypoint), (size_t)n * sizeof(orbx_keypoint));
+            if (descriptors) memcpy(descriptors + (size_t)f * capacity * 32, hp + offDesc + (size_t)f * cap * 32, (size_t)n * 32);
+        }
+    });
+    h->pipeUs[2] += std::chrono::duration<double, std::micro>(tE1 - tE0).count();
+    h->pipeUs[3] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tE1).count();
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *const *images, int batch, int width, int height, int stride,
                                   orbx_keypoint *keypoints, uint8_t *descriptors, int capacity, int *counts)
 {
@@ -1512,6 +1761,29 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *const *image
         memcpy(descriptors, h->hostOut + offDesc, (size_t)n * 32);
         return ORBX_OK;
     }
+    static const int chunk = env_int("ORBX_HOST_BATCH_CHUNK", 64, 0, 1 << 20);      // frames per pipeline stage (0: the round-4 path, one stage)
+    if (chunk > 0 && batch >= 2 * chunk && h->pipeCount == 0 && images) {
+        // the synchronous call as a pipeline over its own chunks: staging + upload of chunk c+1 and the read-back of chunk c-1 under the kernels of chunk c
+        int rc = ORBX_OK, begun = 0, ended = 0;
+        const int nch = (batch + chunk - 1) / chunk;
+        auto first = [&](int c) { return c * chunk; };
+        auto count = [&](int c) { return std::min(chunk, batch - c * chunk); };
+        while (ended < nch) {
+            while (rc == ORBX_OK && begun < nch && begun - ended < 2) {
+                rc = orbx_extract_batch_begin(h, images + first(begun), count(begun), width, height, stride);
+                if (rc == ORBX_OK) begun++;
+            }
+            if (begun == ended) break;      // (a begin failed with nothing in flight)
+            const int f0 = first(ended);
+            const int rce = orbx_extract_batch_end(h, keypoints ? keypoints + (size_t)f0 * capacity : nullptr, descriptors ? descriptors + (size_t)f0 * capacity * 32 : nullptr,
+                                                   capacity, counts + f0);
+            ended++;
+            if (rce != ORBX_OK && rc == ORBX_OK) rc = rce;      // (after an error nothing more is begun: drain what was, report the first error)
+            if (rc != ORBX_OK && begun == ended) break;
+        }
+        return rc;
+    }
+    if (h->pipeCount > 0) { orbx_set_error("orbx_extract_batch while batches begun with orbx_extract_batch_begin are in flight"); return ORBX_ERR_STATE; }
     int rc = upload(h, images, batch, width, height, stride);
     if (rc != ORBX_OK) return rc;
     rc = run_batch(h, h->staging.p, batch, width, height, h->stagingStride, h->stagingFramePitch);

@@ -145,6 +145,8 @@ int orbx_launch_fast_cells(const OrbxLaunch &L);   /* FAST score + cell NMS + em
 int orbx_launch_octree(const OrbxLaunch &L);
 int orbx_launch_blur(const OrbxLaunch &L);
 int orbx_launch_octree_blur(const OrbxLaunch &L, bool *fused);   /* combined single-frame calls: quadtree + host pyramid copy + blur in one launch */
+/* frames in pinned / registered host memory -> the device input layout, read in place by the kernel (pipelined host batches) */
+int orbx_launch_gather_frames(hipStream_t stream, const uint8_t *const *framesPinnedTab, int batch, int W, int H, int srcStride, uint8_t *dst, int dstStride, size_t framePitch, bool aligned16);
 int orbx_launch_orient_describe(const OrbxLaunch &L);   /* IC_Angle + rBRIEF + final KeyPoint in one pass (after the blur) */
 
 /* stream of an extractor handle (orbx_extractor.hip), so other handles can order work after it */

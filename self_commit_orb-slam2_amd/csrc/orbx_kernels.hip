@@ -1482,7 +1482,39 @@ __global__ __launch_bounds__(256) void k_comb_finish(const OrbxCombMember *__res
     }
 }
 
+// Pipelined host batches: frames that live in pinned / registered host memory are read where they are (PCIe reads issued by the kernel, many rows
+// in flight) and written at the device input layout; `tab` (pinned) holds their addresses.  T = uint4 when every frame and both strides are 16-byte
+// aligned, uint32_t otherwise (the caller checked 4-byte alignment).
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_frames(const uint8_t *const *__restrict__ tab, int W, int H, int srcStride, uint8_t *__restrict__ dst, int dstStride, size_t framePitch)
+{
+    const uint8_t *src = tab[blockIdx.y];
+    uint8_t *d = dst + (size_t)blockIdx.y * framePitch;
+    const int upr = (W + (int)sizeof(T) - 1) / (int)sizeof(T), n = upr * H;      // units per row (the last one may run into the row padding: stride >= width rounded up to 4)
+    for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < n; i += (int)(gridDim.x * 256)) {
+        const int r = i / upr, c = i - r * upr;
+        if ((c + 1) * (int)sizeof(T) <= srcStride || r + 1 < H) {
+            const T v = *(const T *)(src + (size_t)r * srcStride + (size_t)c * sizeof(T));
+            if ((c + 1) * (int)sizeof(T) <= dstStride) *(T *)(d + (size_t)r * dstStride + (size_t)c * sizeof(T)) = v;
+            else for (int k = 0; k < dstStride - c * (int)sizeof(T); k++) d[(size_t)r * dstStride + (size_t)c * sizeof(T) + k] = ((const uint8_t *)&v)[k];
+        } else {      // the last unit of the last row would read past the caller's buffer: bytes
+            for (int k = 0; c * (int)sizeof(T) + k < W; k++) d[(size_t)r * dstStride + (size_t)c * sizeof(T) + k] = src[(size_t)r * srcStride + (size_t)c * sizeof(T) + k];
+        }
+    }
+}
+
 }  // namespace
+
+int orbx_launch_gather_frames(hipStream_t stream, const uint8_t *const *tab, int batch, int W, int H, int srcStride, uint8_t *dst, int dstStride, size_t framePitch, bool aligned16)
+{
+    const int unit = aligned16 ? 16 : 4, n = (W + unit - 1) / unit * H;
+    const dim3 grid((unsigned)std::min(std::max((n + 1023) / 1024, 1), 64), (unsigned)batch);      // four units per thread in flight
+    if (aligned16) hipLaunchKernelGGL(k_gather_frames<uint4>, grid, dim3(256), 0, stream, tab, W, H, srcStride, dst, dstStride, framePitch);
+    else hipLaunchKernelGGL(k_gather_frames<uint32_t>, grid, dim3(256), 0, stream, tab, W, H, srcStride, dst, dstStride, framePitch);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { orbx_set_error("k_gather_frames launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+    return ORBX_OK;
+}
 
 // Every kernel of the extractor goes out through emit(): onto the stream (batches), or as a kernel node of a hipGraph under
 // construction (the single-frame graph of orbx_extractor.hip: L.graph set; the node depends on L.deps[0..ndeps) and is returned

@@ -1,0 +1,85 @@
+"""The host-to-host batch entry point as a pipeline: orbx_extract_batch_begin / _end and the chunked orbx_extract_batch,
+against the CPU restatement, bit for bit (keypoint fields as float bit patterns, descriptor bytes)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def kp_bits(k):
+    return np.stack([k[c].astype(np.float32) for c in ("x", "y", "size", "angle", "response", "octave", "class_id")], 1).view(np.uint32)
+
+
+def check(orc_rst, frames, kps, desc, counts):
+    for f, im in enumerate(frames):
+        ko, do = orc_rst.extract(im)
+        n = int(counts[f])
+        assert n == len(ko), "frame %d: %d keypoints, the oracle has %d" % (f, n, len(ko))
+        assert (kp_bits(kps[f, :n]) == ko.view(np.uint32)).all(), "frame %d keypoints" % f
+        assert (desc[f, :n] == do).all(), "frame %d descriptors" % f
+
+
+def test_eight_interleaved_batches_equal_the_oracle(orbx, oracle):
+    """begin(0), begin(1), end(0), begin(2), end(1), ... : eight batches of twelve distinct frames, two always in flight."""
+    W, H, nf, B, NB = 320, 240, 500, 12, 8
+    rst = oracle.restatement(nf)
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
+    batches = [[orbx.synth_frame(100 * b + i, W, H, orbx.SYNTH_LOW_TEXTURE if (b + i) % 7 == 3 else 0) for i in range(B)] for b in range(NB)]
+    results = []
+    ext.extract_batch_begin(batches[0])
+    for b in range(1, NB):
+        ext.extract_batch_begin(batches[b])
+        results.append(ext.extract_batch_end())
+    results.append(ext.extract_batch_end())
+    for b in range(NB):
+        check(rst, batches[b], *results[b])
+
+
+def test_third_begin_and_lonely_end_are_state_errors(orbx):
+    W, H, B = 320, 240, 4
+    ext = orbx.ORBextractor(500, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
+    fr = [orbx.synth_frame(i, W, H) for i in range(B)]
+    with pytest.raises(orbx.OrbxError):
+        ext.extract_batch_end()
+    ext.extract_batch_begin(fr)
+    ext.extract_batch_begin(fr)
+    with pytest.raises(orbx.OrbxError):
+        ext.extract_batch_begin(fr)
+    a = ext.extract_batch_end()
+    b = ext.extract_batch_end()
+    assert (a[2] == b[2]).all() and (a[1] == b[1]).all()
+    with pytest.raises(orbx.OrbxError):
+        ext.extract_batch_end()
+
+
+def test_chunked_synchronous_call_equals_the_single_stage_call(orbx, oracle, monkeypatch):
+    """orbx_extract_batch over 160 frames runs as three chunks (64 + 64 + 32) through the pipeline: identical to the oracle on a sample and to itself
+    across calls that reuse the slots."""
+    W, H, nf, B = 320, 240, 500, 160
+    rst = oracle.restatement(nf)
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
+    frames = [orbx.synth_frame(7000 + i, W, H, orbx.SYNTH_LOW_TEXTURE if i % 16 == 15 else 0) for i in range(B)]
+    k1, d1, c1 = ext.extract_batch(frames)
+    k2, d2, c2 = ext.extract_batch(frames[::-1])
+    assert (c1 == c2[::-1]).all() and (d1 == d2[::-1]).all()
+    sample = [0, 1, 63, 64, 65, 127, 128, 159]
+    check(rst, [frames[i] for i in sample], k1[sample], d1[sample], c1[sample])
+
+
+def test_pinned_frames_are_read_in_place(orbx, oracle):
+    """Frames in hipHostMalloc'ed memory skip the staging copy (hipPointerGetAttributes); ragged stride."""
+    import torch
+    W, H, nf, B = 322, 240, 500, 6
+    stride = 352
+    rst = oracle.restatement(nf)
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
+    pin = torch.empty((B, H, stride), dtype=torch.uint8).pin_memory()
+    host = pin.numpy()
+    frames = [orbx.synth_frame(40 + i, W, H) for i in range(B)]
+    for i in range(B):
+        host[i, :, :W] = frames[i]
+    views = [host[i, :, :W] for i in range(B)]
+    ext.extract_batch_begin(views)
+    check(rst, frames, *ext.extract_batch_end())
