@@ -719,9 +719,12 @@ extern "C" int orbx_extractor_create(const orbx_extractor_config *cfg, orbx_extr
     return ORBX_OK;
 }
 
+static void comb_detach(orbx_extractor *h);      // (the combiner, below)
+
 extern "C" void orbx_extractor_destroy(orbx_extractor *h)
 {
     if (!h) return;
+    if (h->comb && !h->isEngine) comb_detach(h);      // the last handle of an engine set takes the set with it
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     invalidate_single_graph(h);
@@ -1060,8 +1063,8 @@ static int build_single_graph(orbx_extractor *h)
 // ORBX_COMBINE_PARTNER_US=<microseconds> turns the wait on (a caller whose two calls arrive together, e.g. from a thread pool).
 static double comb_partner_us()
 {
-    const char *e = getenv("ORBX_COMBINE_PARTNER_US");
-    return e && *e ? atof(e) : 0.0;
+    static const double us = [] { const char *e = getenv("ORBX_COMBINE_PARTNER_US"); return e && *e ? atof(e) : 0.0; }();      // (read once: the leader polls this in its wait loop)
+    return us;
 }
 
 struct CombEngine {
@@ -1071,6 +1074,7 @@ struct CombEngine {
     hipGraph_t graph[COMB_MAX_LIMIT + 1] = {};
     hipGraphExec_t exec[COMB_MAX_LIMIT + 1] = {};
     bool planned = false;
+    bool pooledStream = false, highPrio = false;   // eng->stream came from (and goes back to) the process's engine-stream pool
     std::atomic<int> busy{0};                // taken (under Combiner::mu) by a leader, released by it without the lock
 };
 
@@ -1088,7 +1092,9 @@ struct CombBatch {
 
 struct Combiner {
     orbx_extractor_config cfg;               // of the members (max_batch / max sizes aside)
-    int W = 0, H = 0, maxB = 16, maxEngines = 2;
+    int W = 0, H = 0, maxB = 16;
+    std::atomic<int> maxEngines{2};          // lowered by a leader that could not build another engine, read by everybody
+    int users = 0;                           // handles attached to this engine set (under g_combMu): the set is released with the last one
     int dstStride = 0;
     size_t fp = 0, kpOff = 0, descOff = 0;
     std::mutex mu;
@@ -1105,6 +1111,29 @@ struct Combiner {
 
 static std::mutex g_combMu;
 static std::vector<Combiner *> g_combs;
+
+// engine streams, per device and priority class: created on demand, never destroyed (see comb_new_engine)
+static std::mutex g_streamPoolMu;
+static std::vector<hipStream_t> g_streamPool[64][2];
+static hipStream_t comb_stream_take(int device, bool high)
+{
+    std::lock_guard<std::mutex> lock(g_streamPoolMu);
+    std::vector<hipStream_t> &pool = g_streamPool[device & 63][high ? 1 : 0];
+    if (!pool.empty()) { hipStream_t s = pool.back(); pool.pop_back(); return s; }
+    hipStream_t s = nullptr;
+    if (high) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return s;
+    }
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return s;
+}
+static void comb_stream_give(int device, bool high, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lock(g_streamPoolMu);
+    g_streamPool[device & 63][high ? 1 : 0].push_back(s);
+}
 
 static inline void cpu_relax() { __builtin_ia32_pause(); }
 static inline double now_us()
@@ -1126,20 +1155,56 @@ static bool comb_cfg_equal(const orbx_extractor_config &a, const orbx_extractor_
            a.min_th_fast == b.min_th_fast && memcmp(a.gauss_taps, b.gauss_taps, sizeof(a.gauss_taps)) == 0;
 }
 
-// the shared engine set for h's configuration at W x H (created on first use; lives until the process ends)
+// a handle leaves its engine set (it moved to another image size, or is being destroyed); the LAST one takes the set with it: engines, graphs,
+// pinned tables - every distinct (size, configuration) a process ever saw used to keep up to two sixteen-frame engines until exit.
+// g_combMu held.  No call of a detached handle can be inside the set: a handle is inside only during its own synchronous call.
+static void comb_detach_locked(orbx_extractor *h)
+{
+    Combiner *c = h->comb;
+    h->comb = nullptr;
+    if (!c || --c->users > 0) return;
+    static const bool keep = getenv("ORBX_COMBINE_KEEP") && getenv("ORBX_COMBINE_KEEP")[0] == '1';      // (measurement switch: the round-4 behaviour, engine sets live until exit)
+    if (keep) return;
+    g_combs.erase(std::remove(g_combs.begin(), g_combs.end(), c), g_combs.end());
+    const int ne = c->nEngines.load();
+    for (int i = 0; i < ne; i++) {
+        CombEngine *E = c->engines[i];
+        if (!E) continue;
+        if (E->eng && E->eng->stream) { (void)hipSetDevice(E->eng->cfg.device); (void)hipStreamSynchronize(E->eng->stream); }
+        for (int n = 0; n <= COMB_MAX_LIMIT; n++) {
+            if (E->exec[n]) (void)hipGraphExecDestroy(E->exec[n]);
+            if (E->graph[n]) (void)hipGraphDestroy(E->graph[n]);
+        }
+        if (E->eng && E->pooledStream && E->eng->stream) { comb_stream_give(E->eng->cfg.device, E->highPrio, E->eng->stream); E->eng->stream = nullptr; }
+        if (E->eng) orbx_extractor_destroy(E->eng);
+        if (E->tab) (void)hipHostFree(E->tab);
+        delete E;
+    }
+    delete c;
+}
+
+static void comb_detach(orbx_extractor *h)
+{
+    std::lock_guard<std::mutex> lock(g_combMu);
+    comb_detach_locked(h);
+}
+
+// the shared engine set for h's configuration at W x H (created on first use; released with the last handle attached to it)
 static Combiner *combiner_for(orbx_extractor *h, int W, int H)
 {
     if (h->comb && h->comb->W == W && h->comb->H == H) return h->comb;
     std::lock_guard<std::mutex> lock(g_combMu);
+    if (h->comb) comb_detach_locked(h);
     for (Combiner *c : g_combs)
-        if (c->W == W && c->H == H && comb_cfg_equal(c->cfg, h->cfg)) return h->comb = c;
+        if (c->W == W && c->H == H && comb_cfg_equal(c->cfg, h->cfg)) { c->users++; return h->comb = c; }
     Combiner *c = new Combiner();
     c->cfg = h->cfg; c->W = W; c->H = H;
     c->maxB = env_int("ORBX_COMBINE_MAX", 16, 1, COMB_MAX_LIMIT);
-    c->maxEngines = env_int("ORBX_COMBINE_ENGINES", 2, 1, 8);
+    c->maxEngines.store(env_int("ORBX_COMBINE_ENGINES", 2, 1, 8));
     c->dstStride = (int)align_up((size_t)W + 16, 64);
     c->fp = align_up((size_t)c->dstStride * H + 256, 256);
     g_combs.push_back(c);
+    c->users = 1;
     return h->comb = c;
 }
 
@@ -1161,17 +1226,22 @@ static int comb_new_engine(Combiner *C, CombEngine **out)
         // overlap at all - was a matter of luck (measured: sets of one frame on two engines took 167-172 us each instead of 96 when they
         // shared a queue).  Streams of another PRIORITY come from a queue pool of their own: the second engine takes the high one.
         // ORBX_COMBINE_PRIO=0: plain streams for all.
+        // The engines' streams are POOLED per device and outlive their engine sets (an engine set is released with its last handle): which
+        // hardware queue a stream lands on depends on the streams alive when it is created, and a set rebuilt later in a process's life used to
+        // land differently - the stereo constructor took 370 instead of 245 us after an unrelated engine set had come and gone.
         const char *pe = getenv("ORBX_COMBINE_PRIO");
-        if (!(pe && pe[0] == '0') && C->nEngines.load() == 1) {
-            int lo = 0, hi = 0;
-            hipStream_t ps = nullptr;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, hi) == hipSuccess) {
-                (void)hipStreamDestroy(e->stream);
-                e->stream = ps;
-            }
+        const bool high = !(pe && pe[0] == '0') && C->nEngines.load() == 1;
+        hipStream_t ps = comb_stream_take(C->cfg.device, high);
+        if (ps) {
+            (void)hipStreamDestroy(e->stream);
+            e->stream = ps;
+            E->pooledStream = true; E->highPrio = high;
         }
     }
-    auto fail = [&](int code) { orbx_extractor_destroy(e); if (E->tab) (void)hipHostFree(E->tab); delete E; return code; };
+    auto fail = [&](int code) {
+        if (E->pooledStream && e->stream) { (void)hipStreamSynchronize(e->stream); comb_stream_give(C->cfg.device, E->highPrio, e->stream); e->stream = nullptr; }
+        orbx_extractor_destroy(e); if (E->tab) (void)hipHostFree(E->tab); delete E; return code;
+    };
     if ((rc = ensure_geometry(e, C->W, C->H, C->maxB)) != ORBX_OK) return fail(rc);
     if ((rc = e->staging.ensure(C->fp * (size_t)C->maxB)) != ORBX_OK) return fail(rc);
     if (hipHostMalloc((void **)&E->tab, sizeof(OrbxCombMember) * (size_t)C->maxB, hipHostMallocDefault) != hipSuccess) { orbx_set_error("hipHostMalloc (member table) failed"); return fail(ORBX_ERR_HIP); }
@@ -1206,7 +1276,8 @@ static int comb_build_graph(Combiner *C, CombEngine *E, int n)
     L.combTab = E->tabDev; L.combKpOff = C->kpOff; L.combDescOff = C->descOff;
     hipGraph_t g = nullptr;
     ORBX_HIP_CHECK(hipGraphCreate(&g, 0));
-    E->graph[n] = g;
+    // (a failure below must not leave a half-built graph behind - it would be found "built" without an executable and rebuilt on every set of this size)
+    struct GraphGuard { hipGraph_t g; bool keep; ~GraphGuard() { if (!keep && g) (void)hipGraphDestroy(g); } } guard = {g, false};
     L.graph = g;
     hipGraphNode_t cur = nullptr, nxt = nullptr;
     int rc;
@@ -1246,6 +1317,8 @@ static int comb_build_graph(Combiner *C, CombEngine *E, int n)
     L.deps[0] = cur; if ((rc = chain(orbx_launch_orient_describe(L))) != ORBX_OK) return rc;
     L.deps[0] = cur; if ((rc = chain(orbx_launch_comb_finish(L))) != ORBX_OK) return rc;
     ORBX_HIP_CHECK(hipGraphInstantiate(&E->exec[n], g, nullptr, nullptr, 0));
+    E->graph[n] = g;
+    guard.keep = true;
     return ORBX_OK;
 }
 
@@ -1286,7 +1359,7 @@ static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::uni
     // The leader polls WITHOUT the lock - a thread that re-takes a mutex in a loop starves the ones sleeping on it (the joiners) -: engines
     // are taken by compare-and-swap, the batch's size and pending partners are mirrored in atomics; the lock is taken once, to close the batch.
     lk.unlock();
-    for (;;) {
+    for (int idle = 0;;) {
         const int ne = C->nEngines.load(std::memory_order_acquire);
         CombEngine *cand = nullptr;
         for (int i = 0; i < ne && !cand; i++) if (!C->engines[i]->busy.load(std::memory_order_acquire)) cand = C->engines[i];
@@ -1295,7 +1368,8 @@ static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::uni
             // set size: the callers present share the engines - with E engines a set takes 1/E of them and leaves at once, so that the sets
             // of the others overlap it (16 threads on 2 engines: sets of 5-8 in flight side by side, 65k frames/s; one set of 16 at a time:
             // 45k; one engine: 42-52k).  A lone caller's share is itself: it never waits.
-            const int share = (C->active.load(std::memory_order_acquire) + C->maxEngines - 1) / C->maxEngines;
+            const int maxE = C->maxEngines.load(std::memory_order_relaxed);
+            const int share = (C->active.load(std::memory_order_acquire) + maxE - 1) / maxE;
             const int nNow = B->nNow.load(std::memory_order_acquire);
             const bool full = nNow >= C->maxB || (waiting == 0 && nNow >= std::max(1, share));
             const bool quiet = C->entering.load(std::memory_order_acquire) == 0 && waiting == 0;
@@ -1305,7 +1379,7 @@ static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::uni
                 if (cand->busy.compare_exchange_strong(expected, 1, std::memory_order_acq_rel)) { E = cand; break; }
                 continue;
             }
-        } else if (ne >= C->maxEngines) {
+        } else if (ne >= C->maxEngines.load(std::memory_order_relaxed)) {
             // every engine is busy and no more may be built: the leader's own frame goes up meanwhile, like the followers' (see the caller)
             orbx_extractor *me = B->m[0];
             const int up = B->uploaded[0].load(std::memory_order_relaxed);
@@ -1328,10 +1402,13 @@ static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::uni
                 snprintf(B->err, sizeof(B->err), "%s", orbx_last_error());
                 B->done.store(1, std::memory_order_release);
                 return;
-            } else C->maxEngines = ne;      // (no memory for another one: live with what exists)
+            } else C->maxEngines.store(ne, std::memory_order_relaxed);      // (no memory for another one: live with what exists)
             continue;
         }
-        cpu_relax();
+        // a set in flight takes 0.1 - 0.4 ms: spin that long (a sleeping thread wakes 50+ us late, and this wait IS the call's latency), then yield, and
+        // only when the engines are gone for milliseconds - an oversubscribed host - stop burning the core
+        if ((++idle & 63) != 0) cpu_relax();
+        else { const double w = now_us() - t0; if (w > 5000.0) std::this_thread::sleep_for(std::chrono::microseconds(50)); else if (w > 600.0) std::this_thread::yield(); }
     }
     lk.lock();
     C->open.reset();                    // later arrivals start the next batch (and elect its leader)
@@ -1375,7 +1452,7 @@ static bool comb_engine_free(const Combiner *C)
 {
     const int ne = C->nEngines.load(std::memory_order_acquire);
     for (int i = 0; i < ne; i++) if (!C->engines[i]->busy.load(std::memory_order_acquire)) return true;
-    return ne < C->maxEngines && ne == 0;      // (no engine yet: the first one is about to be built, nobody waits for a busy one)
+    return ne < C->maxEngines.load(std::memory_order_relaxed) && ne == 0;      // (no engine yet: the first one is about to be built, nobody waits for a busy one)
 }
 
 // One call through the combiner.  ORBX_ERR_STATE + combDisabled: the engines cannot be built here, the caller takes the handle's own path.
@@ -1434,7 +1511,11 @@ static int extract_single_combined(orbx_extractor *h, const uint8_t *image, int 
                 B->uploaded[slot].store(2, std::memory_order_release);
             // (on an error the state stays 1: the set reads the pinned copy, and this member's device copy is rewritten by nobody - flagged below)
         }
-        for (int spins = 0; !B->done.load(std::memory_order_acquire); spins++) { if (spins < 20000) cpu_relax(); else std::this_thread::yield(); }
+        const double tw0 = now_us();
+        for (int spins = 1; !B->done.load(std::memory_order_acquire); spins++) {      // (as the leader: spin for a set's duration, yield beyond it, sleep only after milliseconds)
+            if ((spins & 63) != 0) cpu_relax();
+            else { const double w = now_us() - tw0; if (w > 5000.0) std::this_thread::sleep_for(std::chrono::microseconds(50)); else if (w > 600.0) std::this_thread::yield(); }
+        }
         if (B->uploaded[slot].load() == 1) { orbx_set_error("upload of the frame failed"); h->cur ^= 1; return ORBX_ERR_HIP; }
     } else comb_lead(C, B, lk);
     if (B->rc != ORBX_OK) {

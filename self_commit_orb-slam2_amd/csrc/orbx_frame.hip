@@ -321,7 +321,8 @@ static int host_form(orbx_frame_ops *h, const orbx_frame_grid *grid, bool undist
                      int32_t *grid_offsets, int32_t *grid_indices)
 {
     ORBX_HIP_CHECK(hipSetDevice(h->device));
-    h->pending = 0;      // (the pinned buffer is reused: a frame begun with orbx_frame_finish_begin and not ended is dropped)
+    if (h->pending == 2) ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));      // a frame begun and never ended: its kernel may still be storing into the pinned buffer this call reuses
+    h->pending = 0;      // (... and that frame is dropped)
     const int cap = n > 0 ? n : 1;
     if (cap > 0xfff0) { orbx_set_error("feature capacity %d out of range", cap); return ORBX_ERR_CAPACITY; }
     const size_t A = 256, szKp = ((size_t)cap * sizeof(orbx_keypoint) + A - 1) / A * A, szIdx = ((size_t)cap * 4 + A - 1) / A * A, szOff = ((size_t)(NCELL + 1) * 4 + A - 1) / A * A;
@@ -360,6 +361,10 @@ static int host_form(orbx_frame_ops *h, const orbx_frame_grid *grid, bool undist
 extern "C" int orbx_frame_finish_begin(orbx_frame_ops *h, orbx_extractor *ext, const orbx_frame_grid *grid)
 {
     if (!h || !ext) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (h->pending == 2) {      // a frame begun and never ended: its kernel may still be storing into the pinned buffer (and its completion word) this call reuses
+        ORBX_HIP_CHECK(hipSetDevice(h->device));
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
     h->pending = 0;
     int st = 0;
     if (!orbx_extractor_host_complete_internal(ext, &st)) { orbx_set_error("the extractor's last call was not a completed single-frame call"); return ORBX_ERR_STATE; }

@@ -1602,7 +1602,9 @@ int orbx_launch_fast_cells(const OrbxLaunch &L)
 {
     const OrbxGeom &g = *L.geom;
     static const int kEnv = getenv("ORBX_FC_CELLS_PER_WAVE") ? atoi(getenv("ORBX_FC_CELLS_PER_WAVE")) : 0;      // (developer knob)
-    const int K = kEnv > 0 ? kEnv : ORBX_FC_CELLS_PER_WAVE;
+    // batches: four cells per wave (the next cell's window is fetched under the current cell's phases); single frames and the combiner's small launch
+    // sets: one - 815 waves per 640x480 frame do not fill the device, and four cells in a row are four times a cell's latency (111 vs 100 us per call)
+    const int K = kEnv > 0 ? kEnv : (L.batch >= 32 ? ORBX_FC_CELLS_PER_WAVE : 1);
     dim3 grid((unsigned)((g.cellsPerFrame + K - 1) / K), (unsigned)L.batch);
     const size_t ldsBytes = (size_t)g.fcLdsBytes;
 #define FC_ARGS L.fcCells, K, g.cellsPerFrame, g.slotsPerFrame, g.pyrBytes, g.iniTh, g.minTh, g.fcInBytes, g.fcScBytes, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score, L.cellCount, L.cellSlots

@@ -18,6 +18,7 @@
 #include "Frame.h"
 #include "KeyFrame.h"
 #include "orbx.h"
+#include "shim_error.h"
 
 static unsigned long gBoWCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_compute_bow_calls(void) { return gBoWCalls; }
@@ -86,8 +87,10 @@ DeviceVoc *DeviceVocabulary(const ORBVocabulary *voc)
     VocAccess::Flatten(*voc, parent, leaf, desc, weight);
     const int n = (int)parent.size();
     orbx_vocabulary *dv = 0;
-    if (orbx_vocabulary_create(0, voc->getBranchingFactor(), voc->getDepthLevels(), n, &parent[0], &leaf[0], &desc[0], &weight[0], &dv) != ORBX_OK)
-        throw std::runtime_error(std::string("ComputeBoW (orbx): ") + orbx_last_error());
+    if (orbx_vocabulary_create(orbx_shim::Device(), voc->getBranchingFactor(), voc->getDepthLevels(), n, &parent[0], &leaf[0], &desc[0], &weight[0], &dv) != ORBX_OK) {
+        orbx_shim::Fail("ComputeBoW");
+        return 0;      // (not cached: the next call tries again)
+    }
     DeviceVoc *d = it != gVocs.end() ? it->second : new DeviceVoc();
     d->h = dv; d->fp = fp;
     gVocs[voc] = d;
@@ -109,9 +112,9 @@ void Transform(const ORBVocabulary *voc, const cv::Mat &descriptors, DBoW2::BowV
     for (int i = 0; i < n; i++) memcpy(&flat[32 * (size_t)i], descriptors.ptr<unsigned char>(i), 32);
     {
         DeviceVoc *dv = DeviceVocabulary(voc);
+        if (!dv) return;      // empty vectors, as for an image without features
         std::unique_lock<std::mutex> call(dv->call);      // the whole call: upload, descent, download into OUR vectors
-        if (orbx_bow_transform(dv->h, &flat[0], n, levelsup, &word[0], &node[0], &weight[0]) != ORBX_OK)
-            throw std::runtime_error(std::string("ComputeBoW (orbx): ") + orbx_last_error());
+        if (orbx_bow_transform(dv->h, &flat[0], n, levelsup, &word[0], &node[0], &weight[0]) != ORBX_OK) { orbx_shim::Fail("ComputeBoW"); return; }
     }
     DBoW2::LNorm norm;
     const bool must = VocAccess::Scoring(*voc)->mustNormalize(norm);

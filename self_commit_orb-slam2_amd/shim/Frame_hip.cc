@@ -17,6 +17,7 @@
 
 #include "Frame.h"
 #include "orbx.h"
+#include "shim_error.h"
 
 #include <atomic>
 #include <cstdio>
@@ -140,12 +141,12 @@ orbx_frame_ops *FrameOpsFor(const cv::Mat &K, const cv::Mat &D)
 {
     orbx_camera cam;
     CamKey key;
-    if (!CameraOf(K, D, cam, key)) throw std::runtime_error("Frame (orbx): mDistCoef must hold 4 or 5 coefficients");
+    if (!CameraOf(K, D, cam, key)) { orbx_shim::Fail("Frame", "mDistCoef must hold 4 or 5 coefficients"); return 0; }
     std::lock_guard<std::mutex> lock(gOpsMutex);
     std::map<CamKey, orbx_frame_ops *>::iterator it = gOps.find(key);
     if (it != gOps.end()) return it->second;
     orbx_frame_ops *h = 0;
-    if (orbx_frame_ops_create(0, &cam, &h) != ORBX_OK) throw std::runtime_error(std::string("Frame (orbx): ") + orbx_last_error());
+    if (orbx_frame_ops_create(orbx_shim::Device(), &cam, &h) != ORBX_OK) { orbx_shim::Fail("Frame"); return 0; }      // (not cached: the next frame tries again)
     gOps[key] = h;
     return h;
 }
@@ -204,7 +205,7 @@ bool EnsureStereoMatcher(FrameAssist *A, orbx_extractor *hl)
     const int need = orbx_extractor_capacity(hl);
     if (A->stereo && A->stereoCap >= need) return true;
     if (A->stereo) { orbx_matcher_destroy(A->stereo); A->stereo = 0; }
-    if (orbx_matcher_create(0, need, 1, &A->stereo) != ORBX_OK) { A->stereo = 0; return false; }
+    if (orbx_matcher_create(orbx_shim::Device(), need, 1, &A->stereo) != ORBX_OK) { A->stereo = 0; return false; }
     A->stereoCap = need;
     return true;
 }
@@ -229,7 +230,7 @@ void PostExtract(void *vc, bool ok)
         CamKey key;
         if (CameraOf(F->mK, F->mDistCoef, cam, key)) {
             if (A->ops && !(A->opsKey == key)) { orbx_frame_ops_destroy(A->ops); A->ops = 0; }
-            if (!A->ops && orbx_frame_ops_create(0, &cam, &A->ops) == ORBX_OK) A->opsKey = key;
+            if (!A->ops && orbx_frame_ops_create(orbx_shim::Device(), &cam, &A->ops) == ORBX_OK) A->opsKey = key;
             const orbx_frame_grid g = {Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv};
             if (A->ops && orbx_frame_finish_begin(A->ops, F->mpORBextractorLeft->Handle(), &g) == ORBX_OK) { c->finishBegun = true; c->grid = g; }
         }
@@ -305,11 +306,16 @@ void Frame::ComputeStereoMatches()
     orbx_extractor *hl = mpORBextractorLeft->Handle(), *hr = mpORBextractorRight->Handle();
     if (begun) __atomic_add_fetch(&gEarlyStereo, 1, __ATOMIC_RELAXED);
     else {
-        if (!EnsureStereoMatcher(A, hl) || orbx_stereo_frame_begin(A->stereo, hl, hr, mbf, mb) != ORBX_OK)
-            throw std::runtime_error(std::string("Frame::ComputeStereoMatches (orbx): ") + orbx_last_error());
+        if (!EnsureStereoMatcher(A, hl) || orbx_stereo_frame_begin(A->stereo, hl, hr, mbf, mb) != ORBX_OK) {
+            orbx_shim::Fail("Frame::ComputeStereoMatches");      // no stereo match: mvuRight / mvDepth stay -1 (:1029-1030)
+            return;
+        }
     }
-    if (orbx_stereo_frame_end(A->stereo, &mvuRight[0], &mvDepth[0], N) != ORBX_OK)
-        throw std::runtime_error(std::string("Frame::ComputeStereoMatches (orbx): ") + orbx_last_error());
+    if (orbx_stereo_frame_end(A->stereo, &mvuRight[0], &mvDepth[0], N) != ORBX_OK) {
+        orbx_shim::Fail("Frame::ComputeStereoMatches");
+        mvuRight.assign((size_t)N, -1.0f); mvDepth.assign((size_t)N, -1.0f);
+        return;
+    }
     TRACE("ComputeStereoMatches returns");
 }
 
@@ -335,8 +341,11 @@ void Frame::UndistortKeyPoints()
     orbx_frame_ops *h = FrameOpsFor(mK, mDistCoef);
     {
         std::lock_guard<std::mutex> lock(gCallMutex);
-        if (orbx_frame_undistort(h, N > 0 ? &in[0] : 0, N, &out[0]) != ORBX_OK)
-            throw std::runtime_error(std::string("Frame::UndistortKeyPoints (orbx): ") + orbx_last_error());
+        if (orbx_frame_undistort(h, N > 0 ? &in[0] : 0, N, &out[0]) != ORBX_OK) {
+            orbx_shim::Fail("Frame::UndistortKeyPoints");
+            mvKeysUn = mvKeys;      // (the vector must hold N entries for everything behind it; the distorted positions, as in :921-925)
+            return;
+        }
     }
     mvKeysUn.resize(N);   // :938-946
     for (int i = 0; i < N; i++) {
@@ -354,8 +363,10 @@ void Frame::ComputeImageBounds(const cv::Mat &imLeft)
     float b[4];
     orbx_frame_ops *h = FrameOpsFor(mK, mDistCoef);
     std::lock_guard<std::mutex> lock(gCallMutex);
-    if (orbx_frame_image_bounds(h, imLeft.cols, imLeft.rows, b) != ORBX_OK)
-        throw std::runtime_error(std::string("Frame::ComputeImageBounds (orbx): ") + orbx_last_error());
+    if (orbx_frame_image_bounds(h, imLeft.cols, imLeft.rows, b) != ORBX_OK) {
+        orbx_shim::Fail("Frame::ComputeImageBounds");
+        b[0] = 0.0f; b[1] = (float)imLeft.cols; b[2] = 0.0f; b[3] = (float)imLeft.rows;      // the image itself (:986-991)
+    }
     mnMinX = b[0]; mnMaxX = b[1]; mnMinY = b[2]; mnMaxY = b[3];
 }
 
@@ -376,8 +387,10 @@ void Frame::AssignFeaturesToGrid()
     orbx_frame_ops *h = FrameOpsFor(mK, mDistCoef);
     {
         std::lock_guard<std::mutex> lock(gCallMutex);
-        if (orbx_frame_assign_grid(h, &g, N > 0 ? &in[0] : 0, N, &off[0], &idx[0]) != ORBX_OK)
-            throw std::runtime_error(std::string("Frame::AssignFeaturesToGrid (orbx): ") + orbx_last_error());
+        if (orbx_frame_assign_grid(h, &g, N > 0 ? &in[0] : 0, N, &off[0], &idx[0]) != ORBX_OK) {
+            orbx_shim::Fail("Frame::AssignFeaturesToGrid");      // the grid stays empty
+            return;
+        }
     }
     for (int x = 0; x < FRAME_GRID_COLS; x++)
         for (int y = 0; y < FRAME_GRID_ROWS; y++) {

@@ -15,6 +15,7 @@
 #include <stdexcept>
 
 #include "orbx.h"
+#include "shim_error.h"
 
 // Defined (non-zero) by shim/Frame_hip.cc: Frame::ComputeStereoMatches then reads the pyramid on the
 // device.  When that file is NOT linked - a build that swaps only the extractor and keeps the reference's
@@ -26,7 +27,7 @@ namespace ORB_SLAM2
 {
 
 static int gDevice = 0;
-void ORBextractor::SetDevice(int device) { gDevice = device; }
+void ORBextractor::SetDevice(int device) { gDevice = device; orbx_shim::Device() = device; }
 
 static bool EnvFatal() { const char *e = getenv("ORBX_SHIM_FATAL"); return e && e[0] == '1'; }
 bool ORBextractor::sbThrowOnError = EnvFatal();
@@ -35,6 +36,12 @@ bool ORBextractor::Fail(const char *what)
 {
     mLastError = std::string(what) + " failed: " + orbx_last_error();
     ++mnErrors;
+    {   // the process-wide channel of all shim files (shim_error.h)
+        orbx_shim::ErrorState &e = orbx_shim::Errors();
+        std::lock_guard<std::mutex> lock(e.m);
+        e.last = "ORBextractor (orbx): " + mLastError;
+        e.count.fetch_add(1);
+    }
     std::cerr << "ORBextractor (orbx): " << mLastError << std::endl;
     if (sbThrowOnError) throw std::runtime_error("ORBextractor (orbx): " + mLastError);
     return false;
@@ -43,9 +50,10 @@ bool ORBextractor::Fail(const char *what)
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : mbKeepHostPyramid(!(&orbx_shim_device_stereo_linked && orbx_shim_device_stereo_linked)), mpFrameAssist(0), mpFrameAssistFree(0), nfeatures(_nfeatures), scaleFactor(_scaleFactor),
       nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mpHandle(0), mMaxW(0), mMaxH(0), mLastW(0), mLastH(0), mPostFn(0), mPostCtx(0), mnErrors(0),
-      mbDead(false)
+      mbDead(false), mPyrState(PYR_NONE), mbPyrRead(false), mPyrLevels(0)
 {
     mvImagePyramid.resize(nlevels);
+    mvImagePyramid.mpOwner = this;
     // The tables come from the library so that getters and kernels can never disagree (no device needed for them).
     mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
     mnFeaturesPerLevel.resize(nlevels);
@@ -59,6 +67,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 ORBextractor::~ORBextractor()
 {
     if (mpFrameAssist && mpFrameAssistFree) mpFrameAssistFree(mpFrameAssist);      // (its handles read this extractor's buffers: first)
+    mPyrState = PYR_NONE;          // (the levels the caller may still hold are owning copies: nothing of theirs lives in the handle)
     if (mpHandle) orbx_extractor_destroy(mpHandle);
 }
 
@@ -66,7 +75,10 @@ bool ORBextractor::EnsureHandle(int width, int height)
 {
     if (mpHandle && width <= mMaxW && height <= mMaxH) return true;
     if (mbDead) return false;          // no device at construction: counted once per call in operator(), not re-opened per frame
-    if (mpHandle) { orbx_extractor_destroy(mpHandle); mpHandle = 0; }
+    if (mpHandle) {
+        if (mPyrState == PYR_IN_PINNED || mPyrState == PYR_ON_DEVICE) FillImagePyramid();      // the last frame's pyramid leaves the handle before the handle goes
+        orbx_extractor_destroy(mpHandle); mpHandle = 0;
+    }
     orbx_extractor_config cfg = orbx_extractor_config();
     cfg.nfeatures = nfeatures; cfg.scale_factor = (float)scaleFactor; cfg.nlevels = nlevels;
     cfg.ini_th_fast = iniThFAST; cfg.min_th_fast = minThFAST;
@@ -92,7 +104,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1);
     if (!EnsureHandle(image.cols, image.rows)) {
-        _keypoints.clear(); _descriptors.release();
+        _keypoints.clear(); _descriptors.release(); DropImagePyramid();
         if (mbDead) { ++mnErrors; if (sbThrowOnError) throw std::runtime_error("ORBextractor (orbx): " + mLastError); }
         return;
     }
@@ -102,8 +114,12 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     const unsigned char *desc = 0;
     int n = 0;
     orbx_host_pyramid pyr;
-    if (orbx_extract_view_pyramid(mpHandle, image.data, image.cols, image.rows, (int)image.step, &kps, &desc, &n, mbKeepHostPyramid ? &pyr : 0) != ORBX_OK) {
+    // the pyramid rides along when somebody read the previous frame's (the reference's stereo ComputeStereoMatches does, for every frame)
+    const bool bringPyramid = mbKeepHostPyramid && mbPyrRead;
+    mbPyrRead = false;
+    if (orbx_extract_view_pyramid(mpHandle, image.data, image.cols, image.rows, (int)image.step, &kps, &desc, &n, bringPyramid ? &pyr : 0) != ORBX_OK) {
         _keypoints.clear(); _descriptors.release();       // never the previous frame's data
+        DropImagePyramid();
         Fail("extract");
         return;
     }
@@ -129,13 +145,40 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
         _keypoints.assign(first, first + n);
     }
     mLastW = image.cols; mLastH = image.rows;
-    if (mbKeepHostPyramid) {
-        // the pyramid came back with the results (same launch set, same wait): the public member becomes VIEWS of the handle's pinned
-        // memory - level 0 is the staged copy of `image` -, valid until the next call, which is how long the reference's member holds a
-        // frame's pyramid too (ComputePyramid overwrites it, src/ORBextractor.cc:1680-1733)
-        for (int level = 0; level < nlevels && level < pyr.nlevels; ++level)
-            mvImagePyramid[level] = cv::Mat(pyr.height[level], pyr.width[level], CV_8UC1, (void *)pyr.level[level], (size_t)pyr.stride[level]);
+    // where this frame's pyramid is, for the first reader of mvImagePyramid (FillImagePyramid): in the handle's pinned memory (it came back with
+    // the results: same launch set, same wait), or still on the device only
+    if (bringPyramid) {
+        mPyrLevels = pyr.nlevels < nlevels ? pyr.nlevels : nlevels;
+        for (int level = 0; level < mPyrLevels; ++level) {
+            mPyrLevel[level] = pyr.level[level]; mPyrW[level] = pyr.width[level]; mPyrH[level] = pyr.height[level]; mPyrStride[level] = pyr.stride[level];
+        }
+        mPyrState = PYR_IN_PINNED;
+    } else mPyrState = PYR_ON_DEVICE;
+}
+
+void ORBextractor::DropImagePyramid()
+{
+    for (size_t level = 0; level < mvImagePyramid.mv.size(); ++level) mvImagePyramid.mv[level] = cv::Mat();
+    mPyrState = PYR_NONE;
+}
+
+// First access of mvImagePyramid after a call: every level a fresh owning cv::Mat (the reference assigns new Mats per call,
+// src/ORBextractor.cc:1687-1689: a level somebody kept from an earlier frame is not touched).
+void ORBextractor::FillImagePyramid()
+{
+    if (mPyrState == PYR_NONE || mPyrState == PYR_OWNED) return;
+    mbPyrRead = true;
+    if (mPyrState == PYR_IN_PINNED) {
+        for (int level = 0; level < mPyrLevels; ++level) {
+            cv::Mat m(mPyrH[level], mPyrW[level], CV_8UC1);
+            for (int y = 0; y < mPyrH[level]; y++) memcpy(m.ptr(y), mPyrLevel[level] + (size_t)y * (size_t)mPyrStride[level], (size_t)mPyrW[level]);
+            mvImagePyramid.mv[(size_t)level] = m;
+        }
+        mPyrState = PYR_OWNED;
+        return;
     }
+    mPyrState = PYR_OWNED;              // (whatever the download below does, it is not retried per access)
+    DownloadImagePyramid();
 }
 
 void ORBextractor::ExpectPartner(ORBextractor *other)
@@ -146,17 +189,19 @@ void ORBextractor::ExpectPartner(ORBextractor *other)
 void ORBextractor::DownloadImagePyramid()
 {
     if (!mpHandle || mLastW <= 0) return;
+    if (mPyrState == PYR_IN_PINNED) { FillImagePyramid(); return; }
     std::vector<unsigned char *> ptr((size_t)nlevels);
     std::vector<int> step((size_t)nlevels);
     for (int level = 0; level < nlevels; ++level) {
         int w = 0, h = 0;
         orbx_pyramid_level_size(mpHandle, mLastW, mLastH, level, &w, &h);
-        mvImagePyramid[level].release();             // (a view of the handle's pinned memory from the last call: an owning copy now)
-        mvImagePyramid[level].create(h, w, CV_8UC1);
-        ptr[(size_t)level] = mvImagePyramid[level].data;
-        step[(size_t)level] = (int)mvImagePyramid[level].step;
+        mvImagePyramid.mv[(size_t)level] = cv::Mat(h, w, CV_8UC1);      // (a fresh owning level, see FillImagePyramid)
+        ptr[(size_t)level] = mvImagePyramid.mv[(size_t)level].data;
+        step[(size_t)level] = (int)mvImagePyramid.mv[(size_t)level].step;
     }
-    if (orbx_download_pyramid_all(mpHandle, 0, &ptr[0], &step[0], nlevels) != ORBX_OK) Fail("pyramid");
+    mPyrState = PYR_OWNED;
+    mbPyrRead = true;
+    if (orbx_download_pyramid_all(mpHandle, 0, &ptr[0], &step[0], nlevels) != ORBX_OK) { DropImagePyramid(); Fail("pyramid"); }
 }
 
 } // namespace ORB_SLAM2

@@ -39,14 +39,34 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // Host copy of the image pyramid of the last frame.  The reference's only reader is Frame::ComputeStereoMatches
-    // (src/Frame.cc:1044,1248).  Safe by default: mbKeepHostPyramid starts TRUE - every call leaves the frame's pyramid in the member,
-    // as VIEWS of the handle's pinned memory that the launch set itself filled (levels >= 1; level 0 is the staged copy of the input):
-    // no second transfer, no second wait, no host copy; valid until the next call on this extractor -, exactly what a build that swaps
-    // only the extractor needs - and starts FALSE only when shim/Frame_hip.cc is linked into the same binary (it defines
-    // orbx_shim_device_stereo_linked): that ComputeStereoMatches reads the DEVICE pyramid.  Anything else that wants the images then
-    // calls DownloadImagePyramid() when it does (owning copies).
-    std::vector<cv::Mat> mvImagePyramid;
+    // Host copy of the image pyramid of the last frame: the reference's public `std::vector<cv::Mat> mvImagePyramid` (include/ORBextractor.h:161),
+    // whose only reader is Frame::ComputeStereoMatches (src/Frame.cc:1044, 1248, 1272, 1281: `mvImagePyramid[octave]`).  Here the member is a
+    // small vector-like class that fills itself on FIRST ACCESS after a call (operator[] / Levels()): every level becomes a freshly allocated,
+    // OWNING cv::Mat - as the reference's ComputePyramid leaves them (src/ORBextractor.cc:1687-1689): a level a caller keeps across calls stays
+    // valid and unchanged, and nothing points into the handle's memory.  Where the bytes come from:
+    //   mbKeepHostPyramid (TRUE unless shim/Frame_hip.cc is linked into the same binary - its ComputeStereoMatches reads the DEVICE pyramid) and
+    //   the pyramid was read after the previous call: the levels came back with the results of the same launch set (pinned memory of the handle,
+    //   no second transfer, no second wait) and the first access is one copy out of it;
+    //   otherwise (never read so far, or mbKeepHostPyramid false): nothing crosses PCIe per frame, and a first access downloads the frame's
+    //   pyramid then (one extra transfer, ~0.1 ms), after which the following calls bring it along again.
+    // A failed call leaves every level empty.  DownloadImagePyramid() forces the (owning) copies now.
+    class ImagePyramid
+    {
+    public:
+        ImagePyramid() : mpOwner(0) {}
+        cv::Mat &operator[](size_t level) { Fill(); return mv[level]; }
+        const cv::Mat &operator[](size_t level) const { const_cast<ImagePyramid *>(this)->Fill(); return mv[level]; }
+        size_t size() const { return mv.size(); }
+        bool empty() const { return mv.empty(); }
+        void resize(size_t n) { mv.resize(n); }
+        std::vector<cv::Mat> &Levels() { Fill(); return mv; }
+    private:
+        friend class ORBextractor;
+        void Fill() { if (mpOwner) mpOwner->FillImagePyramid(); }
+        std::vector<cv::Mat> mv;
+        ORBextractor *mpOwner;
+    };
+    ImagePyramid mvImagePyramid;
     bool mbKeepHostPyramid;
     void DownloadImagePyramid();
 
@@ -85,6 +105,13 @@ private:
     ORBextractor &operator=(const ORBextractor &);
     bool EnsureHandle(int width, int height);
     bool Fail(const char *what);
+    void FillImagePyramid();          // first access of mvImagePyramid after a call
+    void DropImagePyramid();          // every level empty, nothing pending (failed call, handle about to go)
+    enum { PYR_NONE = 0, PYR_IN_PINNED = 1, PYR_ON_DEVICE = 2, PYR_OWNED = 3 };
+    int mPyrState;                    // where the last frame's pyramid is
+    bool mbPyrRead;                   // ... and whether it was read since the last call (the next call then brings the pyramid along)
+    const unsigned char *mPyrLevel[12];
+    int mPyrW[12], mPyrH[12], mPyrStride[12], mPyrLevels;
 
     int nfeatures;
     double scaleFactor;

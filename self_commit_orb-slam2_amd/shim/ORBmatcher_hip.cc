@@ -29,6 +29,7 @@
 #include "ORBmatcher.h"
 #include "SearchLocalPoints.h"
 #include "orbx.h"
+#include "shim_error.h"
 
 // number of SearchByBoW calls served by this file (lets the drop-in test prove that the HIP
 // bodies, not the reference's, were linked)
@@ -111,8 +112,7 @@ orbx_matcher *Matcher(int need)
     if (tMatcher.h) { orbx_matcher_destroy(tMatcher.h); tMatcher.h = 0; }
     int cap = 4096;
     while (cap < need) cap *= 2;
-    if (orbx_matcher_create(0, cap, 1, &tMatcher.h) != ORBX_OK)
-        throw std::runtime_error(std::string("ORBmatcher (orbx): ") + orbx_last_error());
+    if (orbx_matcher_create(orbx_shim::Device(), cap, 1, &tMatcher.h) != ORBX_OK) { tMatcher.h = 0; tMatcher.cap = 0; orbx_shim::Fail("ORBmatcher"); return 0; }   // (the call that follows fails on the NULL handle)
     tMatcher.cap = cap;
     return tMatcher.h;
 }
@@ -157,7 +157,7 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
     std::vector<int32_t> match((size_t)NB);
     int32_t nmatches = 0;
     if (orbx_search_by_bow(Matcher(NA > NB ? NA : NB), &a, &b, &prm, &match[0], &nmatches) != ORBX_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchByBoW (orbx): ") + orbx_last_error());
+        { orbx_shim::Fail("ORBmatcher::SearchByBoW"); return 0; }
     for (int j = 0; j < NB; j++)
         if (match[(size_t)j] >= 0) vpMapPointMatches[(size_t)j] = vpMapPointsKF[(size_t)match[(size_t)j]];                   // :314
     return nmatches;
@@ -183,7 +183,7 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint
     std::vector<int32_t> match((size_t)NA);
     int32_t nmatches = 0;
     if (orbx_search_by_bow(Matcher(NA > NB ? NA : NB), &a, &b, &prm, &match[0], &nmatches) != ORBX_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchByBoW (orbx): ") + orbx_last_error());
+        { orbx_shim::Fail("ORBmatcher::SearchByBoW"); return 0; }
     for (int i = 0; i < NA; i++)
         if (match[(size_t)i] >= 0) vpMatches12[(size_t)i] = vpMapPoints2[(size_t)match[(size_t)i]];                           // :745
     return nmatches;
@@ -227,7 +227,7 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
     std::vector<int32_t> match((size_t)NA);
     int32_t nmatches = 0;
     if (orbx_search_for_triangulation(Matcher(NA > NB ? NA : NB), &a, &b, &prm, &match[0], &nmatches) != ORBX_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchForTriangulation (orbx): ") + orbx_last_error());
+        { orbx_shim::Fail("ORBmatcher::SearchForTriangulation"); return 0; }
     vMatchedPairs.reserve((size_t)nmatches);                                                                          // :1005-1014
     for (int i = 0; i < NA; i++)
         if (match[(size_t)i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match[(size_t)i]));
@@ -262,7 +262,7 @@ void FuseSearch(KeyFrame *pKF, FuseArrays &A, int n, int chi2Gate)
                            (float)pKF->mnMinX, (float)pKF->mnMinY};                                                         // what the window uses
     if (orbx_fuse_search(Matcher(N > n ? N : n), &kf, &pt, &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), chi2Gate, &A.bestIdx[0],
                          &A.bestDist[0]) != ORBX_OK)
-        throw std::runtime_error(std::string("ORBmatcher::Fuse (orbx): ") + orbx_last_error());
+        { orbx_shim::Fail("ORBmatcher::Fuse"); return; }
 }
 }  // namespace
 
@@ -551,7 +551,7 @@ int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector
                            (float)pKF->mnMinX, (float)pKF->mnMinY};
     int32_t nm = 0;
     if (orbx_area_search_greedy(Matcher(N > nPoints ? N : nPoints), &kf, &q, TH_LOW, &A.assigned[0], &A.dist[0], &nm) != ORBX_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbx): ") + orbx_last_error());
+        { orbx_shim::Fail("ORBmatcher::SearchByProjection"); return 0; }
     int nmatches = 0;
     for (int iMP = 0; iMP < nPoints; iMP++)                                                                                     // :505-509
         if (A.assigned[(size_t)iMP] >= 0) { vpMatched[(size_t)A.assigned[(size_t)iMP]] = vpPoints[(size_t)iMP]; nmatches++; }
@@ -607,7 +607,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
     orbx_area_queries q = {&A.u[0], &A.v[0], &A.radius[0], &A.lo[0], &A.hi[0], &A.active[0], &A.desc[0], &nPoints, nPoints, Frame::mnMinX, Frame::mnMinY};
     int32_t nm = 0;
     if (orbx_area_search_greedy(Matcher(N > nPoints ? N : nPoints), &fr, &q, ORBdist, &A.assigned[0], &A.dist[0], &nm) != ORBX_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbx): ") + orbx_last_error());
+        { orbx_shim::Fail("ORBmatcher::SearchByProjection"); return 0; }
     for (int i = 0; i < nPoints; i++) {                                         // :1819-1840, in the reference's order
         const int bestIdx2 = A.assigned[(size_t)i];
         if (bestIdx2 < 0) continue;
@@ -653,7 +653,7 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
     std::vector<int32_t> match((size_t)N1);
     int32_t nmatches = 0;
     if (orbx_search_for_initialization(Matcher(N1 > N2 ? N1 : N2), &f1, &f2, &prev[0], windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, &match[0], &nmatches) != ORBX_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchForInitialization (orbx): ") + orbx_last_error());
+        { orbx_shim::Fail("ORBmatcher::SearchForInitialization"); return 0; }
     for (int i1 = 0; i1 < N1; i1++) vnMatches12[(size_t)i1] = match[(size_t)i1];
     for (size_t i1 = 0, iend1 = vnMatches12.size(); i1 < iend1; i1++)           // :646-650
         if (vnMatches12[i1] >= 0) vbPrevMatched[i1] = F2.mvKeysUn[(size_t)vnMatches12[i1]].pt;
@@ -690,7 +690,7 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
     std::vector<int32_t> assigned((size_t)N);
     int32_t nmatches = 0;
     if (orbx_search_by_projection(Matcher(N), &fr, &pt, &F.mvScaleFactors[0], (int)F.mvScaleFactors.size(), th, mfNNratio, &assigned[0], &nmatches) != ORBX_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbx): ") + orbx_last_error());
+        { orbx_shim::Fail("ORBmatcher::SearchByProjection"); return 0; }
     for (int i = 0; i < N; i++)
         if (assigned[(size_t)i] >= 0) F.mvpMapPoints[(size_t)i] = vpMapPoints[(size_t)assigned[(size_t)i]];               // :165
     return nmatches;
@@ -731,7 +731,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     int32_t nmatches = 0;
     if (orbx_search_by_projection_last(Matcher(N > NL ? N : NL), &fr, &ls, &CurrentFrame.mvScaleFactors[0], (int)CurrentFrame.mvScaleFactors.size(), th,
                                        bMono ? 1 : 0, mbCheckOrientation ? 1 : 0, &assigned[0], &nmatches) != ORBX_OK)
-        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbx): ") + orbx_last_error());
+        { orbx_shim::Fail("ORBmatcher::SearchByProjection"); return 0; }
     // the reference writes mvpMapPoints[bestIdx2] = pMP as it goes and NULLs the pruned ones (:1688, :1718): features it never
     // touched keep what they held
     for (int i2 = 0; i2 < N; i2++) {
@@ -798,7 +798,7 @@ int SearchLocalPointsHIP(Frame &F, const std::vector<MapPoint *> &vpLocalMapPoin
     for (int r = 0; r < 4; r++)
         for (int c = 0; c < 4; c++) tcw[4 * r + c] = F.mTcw.at<float>(r, c);
     if (orbx_predict_scale_thresholds(F.mfLogScaleFactor, F.mnScaleLevels, ratioTh) != ORBX_OK)
-        throw std::runtime_error(std::string("SearchLocalPoints (orbx): ") + orbx_last_error());
+        { orbx_shim::Fail("SearchLocalPoints"); return 0; }
     int32_t nmatches = 0;
     {
         orbx_projection_frame fr = {N > 0 ? (const orbx_keypoint *)&F.mvKeysUn[0] : 0, N > 0 ? F.mDescriptors.data : 0, N > 0 ? &F.mvuRight[0] : 0, &occupied[0], &N, nFeat, 1,
@@ -807,7 +807,7 @@ int SearchLocalPointsHIP(Frame &F, const std::vector<MapPoint *> &vpLocalMapPoin
         orbx_local_points pts = {&pos[0], &nrm[0], &mx[0], &mn[0], &desc[0], &hasObs[0], M};
         if (orbx_search_local_points(Matcher(N > M ? N : M), &fr, &pose, &pts, &F.mvScaleFactors[0], (int)F.mvScaleFactors.size(), viewingCosLimit, (float)th, nnratio,
                                      &assigned[0], &nmatches, &inView[0], &px[0], &py[0], &pxr[0], &lvl[0], &vc[0]) != ORBX_OK)
-            throw std::runtime_error(std::string("SearchLocalPoints (orbx): ") + orbx_last_error());
+            { orbx_shim::Fail("SearchLocalPoints"); return 0; }
     }
     for (int k = 0; k < M; k++) {                                                   // what Frame::isInFrustum leaves in the MapPoint, :615, :721-731
         MapPoint *pMP = vpLocalMapPoints[(size_t)idx[(size_t)k]];

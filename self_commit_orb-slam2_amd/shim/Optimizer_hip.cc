@@ -19,6 +19,7 @@
 
 #include "Optimizer.h"   // the reference's include/Optimizer.h; shim/Optimizer.h where g2o / Eigen are not installed
 #include "orbx.h"
+#include "shim_error.h"
 
 static unsigned long gLbaCalls = 0, gPoseOptCalls = 0, gBaCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_bundle_adjustment_calls(void) { return gBaCalls; }
@@ -46,7 +47,7 @@ struct ThreadPoseOpt {
 };
 thread_local ThreadPoseOpt tPose;
 
-void Fail(const char *what) { throw std::runtime_error(std::string("Optimizer::") + what + " (orbx): " + orbx_last_error()); }
+bool Fail(const char *what) { return orbx_shim::Fail((std::string("Optimizer::") + what).c_str()); }
 // BundleAdjustment runs on a detached std::thread of LoopClosing (RunGlobalBundleAdjustment): an exception leaving it would end
 // the process in std::terminate.  A failed call reports and leaves the map exactly as it was (what a g2o run that made no
 // progress does as well).
@@ -140,13 +141,13 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
     if (!tLba.h || K > tLba.kf || P > tLba.pt || E > tLba.ed) {
         if (tLba.h) { orbx_lba_destroy(tLba.h); tLba.h = 0; }
         tLba.kf = std::max(2 * K, 64); tLba.pt = std::max(2 * P, 4096); tLba.ed = std::max(2 * E, 65536);
-        if (orbx_lba_create(0, tLba.kf, tLba.pt, tLba.ed, &tLba.h) != ORBX_OK) Fail("LocalBundleAdjustment");
+        if (orbx_lba_create(orbx_shim::Device(), tLba.kf, tLba.pt, tLba.ed, &tLba.h) != ORBX_OK) { tLba.h = 0; Fail("LocalBundleAdjustment"); return; }      // the map stays as it is
     }
     orbx_lba_problem prob = {K, &poses[0], &fixed[0], &intr[0], P, &points[0], E, &ep[0], &ek[0], &obs[0], &invS2[0]};
     std::vector<float> posesOut(poses.size()), pointsOut(points.size());
     std::vector<uint8_t> outlier((size_t)E);
     orbx_lba_result res = {&posesOut[0], &pointsOut[0], NULL, &outlier[0], {0}};
-    if (orbx_lba_solve(tLba.h, &prob, (const volatile uint8_t *)pbStopFlag, &res) != ORBX_OK) Fail("LocalBundleAdjustment");
+    if (orbx_lba_solve(tLba.h, &prob, (const volatile uint8_t *)pbStopFlag, &res) != ORBX_OK) { Fail("LocalBundleAdjustment"); return; }
     // ---- vToErase (:921-958) and write-back under the map mutex (:961-996)
     std::vector<std::pair<KeyFrame *, MapPoint *> > vToErase;
     for (int e = 0; e < E; e++)
@@ -233,7 +234,7 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame *> &vpKFs, const std
     if (!tLba.h || K > tLba.kf || P > tLba.pt || E > tLba.ed) {
         if (tLba.h) { orbx_lba_destroy(tLba.h); tLba.h = 0; }
         tLba.kf = std::max(2 * K, 64); tLba.pt = std::max(2 * P, 4096); tLba.ed = std::max(2 * E, 65536);
-        if (orbx_lba_create(0, tLba.kf, tLba.pt, tLba.ed, &tLba.h) != ORBX_OK) { Report("BundleAdjustment"); return; }
+        if (orbx_lba_create(orbx_shim::Device(), tLba.kf, tLba.pt, tLba.ed, &tLba.h) != ORBX_OK) { Report("BundleAdjustment"); return; }
     }
     orbx_lba_problem prob = {K, &poses[0], &fixed[0], &intr[0], P, &points[0], E, &ep[0], &ek[0], &obs[0], &invS2[0]};
     std::vector<float> posesOut(poses.size()), pointsOut(points.size());
@@ -292,7 +293,7 @@ int Optimizer::PoseOptimization(Frame *pFrame)
     if (!tPose.h || n > tPose.cap) {
         if (tPose.h) { orbx_pose_optimizer_destroy(tPose.h); tPose.h = 0; }
         tPose.cap = std::max(2 * n, 4096);
-        if (orbx_pose_optimizer_create(0, 1, tPose.cap, &tPose.h) != ORBX_OK) Fail("PoseOptimization");
+        if (orbx_pose_optimizer_create(orbx_shim::Device(), 1, tPose.cap, &tPose.h) != ORBX_OK) { tPose.h = 0; Fail("PoseOptimization"); return 0; }      // pose and outlier flags untouched, no inliers
     }
     float pose[16], cam[5] = {pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf}, poseOut[16];
     for (int r = 0; r < 4; r++)
@@ -300,7 +301,7 @@ int Optimizer::PoseOptimization(Frame *pFrame)
     orbx_pose_problem prob = {1, n, pose, cam, &n, &Xw[0], &obs[0], &invS2[0]};
     std::vector<uint8_t> outlier((size_t)n);
     int32_t inliers = 0;
-    if (orbx_pose_optimization(tPose.h, &prob, poseOut, &outlier[0], &inliers, NULL) != ORBX_OK) Fail("PoseOptimization");
+    if (orbx_pose_optimization(tPose.h, &prob, poseOut, &outlier[0], &inliers, NULL) != ORBX_OK) { Fail("PoseOptimization"); return 0; }
     for (int e = 0; e < n; e++) pFrame->mvbOutlier[(size_t)index[(size_t)e]] = outlier[(size_t)e] != 0;
     pFrame->SetPose(PoseMat(poseOut));                                                          // :598-601
     return inliers;

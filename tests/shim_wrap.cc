@@ -55,6 +55,31 @@ extern "C" int shim_pyramid_level_as_is(void *h, int level, unsigned char *dst, 
     return 0;
 }
 
+// A level somebody kept from an earlier frame (a cv::Mat header copy, as a caller of the reference may hold one: its levels are fresh Mats per
+// call, src/ORBextractor.cc:1687-1689) must still hold THAT frame after later calls, after the handle was rebuilt for a larger image, and after
+// the extractor is gone.  Returns the number of bytes of `expect` (level `level` of the first image, w x hgt) that the kept level no longer has.
+extern "C" long shim_kept_level_survives(int nf, const unsigned char *img1, const unsigned char *img2, int w, int hgt, const unsigned char *big, int bw, int bh, int level,
+                                         const unsigned char *expect, int ew, int eh)
+{
+    ORB_SLAM2::ORBextractor *e = new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7);
+    e->mbKeepHostPyramid = true;
+    std::vector<cv::KeyPoint> keys;
+    cv::Mat d;
+    cv::Mat a(hgt, w, CV_8UC1, (void *)img1, (size_t)w), b(hgt, w, CV_8UC1, (void *)img2, (size_t)w), c(bh, bw, CV_8UC1, (void *)big, (size_t)bw);
+    (*e)(a, cv::Mat(), keys, d);
+    cv::Mat kept = e->mvImagePyramid[(size_t)level];      // header copy: shares the level's buffer
+    (*e)(b, cv::Mat(), keys, d);
+    (void)e->mvImagePyramid[(size_t)level].rows;          // the next frame's pyramid is read too (a fresh set of levels)
+    (*e)(c, cv::Mat(), keys, d);                          // larger image: the liborbx handle is destroyed and rebuilt
+    (void)e->mvImagePyramid[0].rows;
+    delete e;
+    if (kept.cols != ew || kept.rows != eh) return -1;
+    long bad = 0;
+    for (int y = 0; y < eh; y++)
+        for (int x = 0; x < ew; x++) bad += kept.ptr(y)[x] != expect[(size_t)y * ew + x];
+    return bad;
+}
+
 // Latency of the reference's call shape, one frame per call on one thread (tools/latency_shim.py): mean / median microseconds of
 // `iters` calls of (*extractor)(im, cv::Mat(), keys, desc) cycling through `nimg` images; keep_pyr sets mbKeepHostPyramid.
 #include <algorithm>
@@ -71,6 +96,11 @@ extern "C" int shim_bench(void *h, const unsigned char *const *imgs, int nimg, i
         cv::Mat im(hgt, w, CV_8UC1, (void *)imgs[(i + 5) % nimg], (size_t)stride);
         const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         (*e)(im, cv::Mat(), keys, d);
+        if (keep_pyr == 1) {      // the pyramid is READ after every call, as the reference's stereo ComputeStereoMatches does (src/Frame.cc:1044, 1248): inside the timed span
+            unsigned acc = 0;
+            for (int l = 0; l < e->GetLevels(); l++) { const cv::Mat &m = e->mvImagePyramid[(size_t)l]; acc += (unsigned)m.rows + m.ptr(m.rows - 1)[m.cols - 1]; }
+            if (acc == 0xffffffffu) keys.clear();
+        }
         const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
         if (i >= 0) t[(size_t)i] = std::chrono::duration<double, std::micro>(t1 - t0).count();
     }
@@ -95,6 +125,12 @@ extern "C" double shim_bench_threads(int nthreads, int nf, const unsigned char *
         for (int i = 0; i < n; i++) {
             cv::Mat im(hgt, w, CV_8UC1, (void *)imgs[(i + t) % nimg], (size_t)stride);
             (*ex[(size_t)t])(im, cv::Mat(), keys, d);
+            if (keep_pyr == 1) {      // read every level after every call (see shim_bench); 2 = kept but never read
+                unsigned acc = 0;
+                ORB_SLAM2::ORBextractor *e = ex[(size_t)t];
+                for (int l = 0; l < e->GetLevels(); l++) { const cv::Mat &m = e->mvImagePyramid[(size_t)l]; acc += (unsigned)m.rows + m.ptr(m.rows - 1)[m.cols - 1]; }
+                if (acc == 0xffffffffu) keys.clear();
+            }
         }
     };
     { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t, 40); for (auto &x : th) x.join(); }   // warm-up (the launch-set graphs of the sizes this load produces are built on first use)

@@ -16,7 +16,8 @@ SO = ROOT / "tests" / "libshimtest.so"
 
 def build_shim():
     srcs = [ROOT / "tests" / "shim_wrap.cc", ROOT / "self_commit_orb-slam2_amd" / "shim" / "ORBextractor.cc"]
-    if SO.exists() and all(SO.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+    deps = srcs + [ROOT / "self_commit_orb-slam2_amd" / "shim" / "ORBextractor.h", ROOT / "self_commit_orb-slam2_amd" / "shim" / "shim_error.h"]
+    if SO.exists() and all(SO.stat().st_mtime >= s.stat().st_mtime for s in deps):
         return
     if shutil.which("g++") is None:
         pytest.skip("no g++ to build the shim test wrapper")
@@ -93,6 +94,24 @@ def test_host_pyramid_is_kept_unless_the_device_stereo_body_is_linked(orbx, orac
     hip = __import__("oracle_lib").slam_hip_lib()
     if hip is not None:
         assert hip.orbslam_extractor_keeps_host_pyramid() == 0
+
+
+@pytest.mark.gpu
+def test_a_kept_pyramid_level_outlives_later_calls_and_the_extractor(orbx, oracle):
+    """mvImagePyramid used to be views of the handle's pinned memory - silently overwritten by the next call, dangling once the
+    handle was rebuilt for a larger image or the extractor destroyed.  The levels are owning cv::Mats now (filled on first access)."""
+    orbx.load_library()
+    build_shim()
+    L = ctypes.CDLL(str(SO))
+    L.shim_kept_level_survives.restype = ctypes.c_long
+    L.shim_kept_level_survives.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    im1, im2, big = orbx.synth_frame(81, 640, 480), orbx.synth_frame(82, 640, 480), orbx.synth_frame(83, 1241, 376)
+    pyr = oracle.pyramid(oracle.restatement(1000), im1)
+    for level in (0, 3):
+        want = np.ascontiguousarray(pyr[level])
+        assert L.shim_kept_level_survives(1000, P(im1), P(im2), 640, 480, P(big), 1241, 376, level, P(want), want.shape[1], want.shape[0]) == 0, level
 
 
 def test_a_failed_call_returns_empty_outputs_and_is_countable(orbx):
