@@ -2447,7 +2447,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
     };
     // second half: factorisation and solve, update, errors, the decision, and - for the next trial - the restore of a rejected update and H, b
     // at the estimates the decision left.  *seqOut = the decision's sequence number.
-    auto trialSolve = [&](double *seqOut) -> int {
+    auto trialChol = [&]() -> int {
         if (nP6 > 0) {
             if (nP6 >= CHOL_MULTI_MIN_N) {
                 const int n = nP6;
@@ -2482,6 +2482,9 @@ int optimize(Ctx &c, int iterations, double stats[4])
             }
             LCHECK();
         }
+        return ORBX_OK;
+    };
+    auto trialRest = [&](double *seqOut) -> int {
         // (push() happens inside k_backsub_update, right before the estimates are changed)
         const unsigned gU = (unsigned)((std::max(K, 16 * P) + 255) / 256);
         hipLaunchKernelGGL(k_backsub_update, dim3(gU), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, (const int *)h->ptPi.p, h->bl.p,
@@ -2505,12 +2508,18 @@ int optimize(Ctx &c, int iterations, double stats[4])
     // the Schur half of trial t + 1 (~40 us of device work) when it starts to wait for that decision, and queues the solve half of t + 1 while
     // those run.  A stage that ends leaves those seven launches to fall through (~4 us each); a whole trial enqueued in advance would cost
     // twenty (measured: every trial of both stages up front, 15 per window where 9 are needed: 2.08 ms per window instead of 1.87).
+    // ORBX_LBA_SPEC_CHOL=1 (measured): the factorisation of trial t + 1 is queued speculatively too, so that the device never waits for
+    // the host's nine panel launches behind a decision; a stage that ends then lets nine more gated launches fall through.
+    static const bool specChol = getenv("ORBX_LBA_SPEC_CHOL") && getenv("ORBX_LBA_SPEC_CHOL")[0] == '1';
     int rct = trialSchur();
     if (rct) return rct;
+    if (specChol && (rct = trialChol()) != ORBX_OK) return rct;
     for (int t = 0;; t++) {
         double seqT = 0;
-        if ((rct = trialSolve(&seqT)) != ORBX_OK) return rct;
+        if (!specChol && (rct = trialChol()) != ORBX_OK) return rct;
+        if ((rct = trialRest(&seqT)) != ORBX_OK) return rct;
         if ((rct = trialSchur()) != ORBX_OK) return rct;      // of trial t + 1, speculatively
+        if (specChol && (rct = trialChol()) != ORBX_OK) return rct;
         int rcw = wait_seq(h, seqT, c.stop);
         if (rcw) return rcw;
         if (h->hostRed[13] != 0.0) break;      // done
