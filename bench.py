@@ -957,7 +957,8 @@ def main():
         dp, hb = dig["dropin"], dig["host_io_batch"]
         flat = {"dropin_us_1thread": dp.get("us_1thread"), "dropin_us_1thread_hostpyr": dp.get("us_1thread_hostpyr"),
                 "dropin_fps_8threads": dp.get("fps_8threads"), "dropin_fps_16threads": dp.get("fps_16threads"),
-                "dropin_fps_16threads_hostpyr": dp.get("fps_16threads_hostpyr"),
+                "dropin_fps_16threads_hostpyr": dp.get("fps_16threads_hostpyr"), "dropin_fps_16threads_hostpyr_views": dp.get("fps_16threads_hostpyr_views"),
+                "dropin_us_1thread_hostpyr_views": dp.get("us_1thread_hostpyr_views"),
                 "stereo_ctor_us_median": dp.get("stereo_frame_ctor_median_us"), "stereo_ctor_us_mean": dp.get("stereo_frame_ctor_us"),
                 "host_io_batch_fps": hb.get("frames_per_s"), "host_io_pipelined_fps": (hb.get("pipelined") or {}).get("frames_per_s"),
                 "host_io_pinned_fps": (hb.get("pipelined_pinned") or {}).get("frames_per_s"),

@@ -48,7 +48,7 @@ bool ORBextractor::Fail(const char *what)
 }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
-    : mbKeepHostPyramid(!(&orbx_shim_device_stereo_linked && orbx_shim_device_stereo_linked)), mpFrameAssist(0), mpFrameAssistFree(0), nfeatures(_nfeatures), scaleFactor(_scaleFactor),
+    : mbKeepHostPyramid(!(&orbx_shim_device_stereo_linked && orbx_shim_device_stereo_linked)), mbViewHostPyramid(false), mpFrameAssist(0), mpFrameAssistFree(0), nfeatures(_nfeatures), scaleFactor(_scaleFactor),
       nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mpHandle(0), mMaxW(0), mMaxH(0), mLastW(0), mLastH(0), mPostFn(0), mPostCtx(0), mnErrors(0),
       mbDead(false), mPyrState(PYR_NONE), mbPyrRead(false), mPyrLevels(0)
 {
@@ -67,6 +67,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 ORBextractor::~ORBextractor()
 {
     if (mpFrameAssist && mpFrameAssistFree) mpFrameAssistFree(mpFrameAssist);      // (its handles read this extractor's buffers: first)
+    if (mPyrState == PYR_VIEWS) DropImagePyramid();
     mPyrState = PYR_NONE;          // (the levels the caller may still hold are owning copies: nothing of theirs lives in the handle)
     if (mpHandle) orbx_extractor_destroy(mpHandle);
 }
@@ -76,7 +77,8 @@ bool ORBextractor::EnsureHandle(int width, int height)
     if (mpHandle && width <= mMaxW && height <= mMaxH) return true;
     if (mbDead) return false;          // no device at construction: counted once per call in operator(), not re-opened per frame
     if (mpHandle) {
-        if (mPyrState == PYR_IN_PINNED || mPyrState == PYR_ON_DEVICE) FillImagePyramid();      // the last frame's pyramid leaves the handle before the handle goes
+        if (mPyrState == PYR_VIEWS) DropImagePyramid();      // (opt-in views of the handle's pinned memory: emptied, never left dangling)
+        if (mPyrState == PYR_IN_PINNED || mPyrState == PYR_ON_DEVICE) { const bool v = mbViewHostPyramid; mbViewHostPyramid = false; FillImagePyramid(); mbViewHostPyramid = v; }      // the last frame's pyramid leaves the handle before the handle goes
         orbx_extractor_destroy(mpHandle); mpHandle = 0;
     }
     orbx_extractor_config cfg = orbx_extractor_config();
@@ -117,6 +119,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     // the pyramid rides along when somebody read the previous frame's (the reference's stereo ComputeStereoMatches does, for every frame)
     const bool bringPyramid = mbKeepHostPyramid && mbPyrRead;
     mbPyrRead = false;
+    if (mPyrState == PYR_VIEWS) DropImagePyramid();       // (the pinned memory behind the opt-in views is about to be rewritten)
     if (orbx_extract_view_pyramid(mpHandle, image.data, image.cols, image.rows, (int)image.step, &kps, &desc, &n, bringPyramid ? &pyr : 0) != ORBX_OK) {
         _keypoints.clear(); _descriptors.release();       // never the previous frame's data
         DropImagePyramid();
@@ -166,8 +169,14 @@ void ORBextractor::DropImagePyramid()
 // src/ORBextractor.cc:1687-1689: a level somebody kept from an earlier frame is not touched).
 void ORBextractor::FillImagePyramid()
 {
-    if (mPyrState == PYR_NONE || mPyrState == PYR_OWNED) return;
+    if (mPyrState == PYR_NONE || mPyrState == PYR_OWNED || mPyrState == PYR_VIEWS) return;
     mbPyrRead = true;
+    if (mPyrState == PYR_IN_PINNED && mbViewHostPyramid) {
+        for (int level = 0; level < mPyrLevels; ++level)
+            mvImagePyramid.mv[(size_t)level] = cv::Mat(mPyrH[level], mPyrW[level], CV_8UC1, (void *)mPyrLevel[level], (size_t)mPyrStride[level]);
+        mPyrState = PYR_VIEWS;
+        return;
+    }
     if (mPyrState == PYR_IN_PINNED) {
         for (int level = 0; level < mPyrLevels; ++level) {
             cv::Mat m(mPyrH[level], mPyrW[level], CV_8UC1);
@@ -189,7 +198,7 @@ void ORBextractor::ExpectPartner(ORBextractor *other)
 void ORBextractor::DownloadImagePyramid()
 {
     if (!mpHandle || mLastW <= 0) return;
-    if (mPyrState == PYR_IN_PINNED) { FillImagePyramid(); return; }
+    if (mPyrState == PYR_IN_PINNED) { const bool v = mbViewHostPyramid; mbViewHostPyramid = false; FillImagePyramid(); mbViewHostPyramid = v; return; }      // (owning copies, whatever the flag)
     std::vector<unsigned char *> ptr((size_t)nlevels);
     std::vector<int> step((size_t)nlevels);
     for (int level = 0; level < nlevels; ++level) {

@@ -89,6 +89,8 @@ extern "C" int shim_bench(void *h, const unsigned char *const *imgs, int nimg, i
 {
     ORB_SLAM2::ORBextractor *e = (ORB_SLAM2::ORBextractor *)h;
     e->mbKeepHostPyramid = keep_pyr != 0;
+    e->mbViewHostPyramid = keep_pyr == 3;      // 3: as 1 (read after every call) with the opt-in views instead of owning copies
+    if (keep_pyr == 3) keep_pyr = 1;
     std::vector<cv::KeyPoint> keys;
     cv::Mat d;
     std::vector<double> t((size_t)iters);
@@ -118,7 +120,8 @@ extern "C" int shim_bench(void *h, const unsigned char *const *imgs, int nimg, i
 extern "C" double shim_bench_threads(int nthreads, int nf, const unsigned char *const *imgs, int nimg, int w, int hgt, int stride, int iters, int keep_pyr)
 {
     std::vector<ORB_SLAM2::ORBextractor *> ex;
-    for (int t = 0; t < nthreads; t++) { ex.push_back(new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7)); ex.back()->mbKeepHostPyramid = keep_pyr != 0; }
+    for (int t = 0; t < nthreads; t++) { ex.push_back(new ORB_SLAM2::ORBextractor(nf, 1.2f, 8, 20, 7)); ex.back()->mbKeepHostPyramid = keep_pyr != 0; ex.back()->mbViewHostPyramid = keep_pyr == 3; }
+    if (keep_pyr == 3) keep_pyr = 1;
     auto work = [&](int t, int n) {
         std::vector<cv::KeyPoint> keys;
         cv::Mat d;

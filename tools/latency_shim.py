@@ -42,10 +42,10 @@ def one_thread(orbx, L, W, H, nf, iters):
     h = ctypes.c_void_p(L.shim_create(nf, 1.2, 8, 20, 7))
     frames = orbx.synth_sequence(7, 8, W, H)
     arr = (ctypes.c_void_p * 8)(*[f.ctypes.data for f in frames])
-    for keep in (0, 1, 2):      # 0: no host pyramid; 1: mbKeepHostPyramid and every level READ after every call (src/Frame.cc:1044, 1248); 2: kept, never read (lazy: nothing moves)
+    for keep in (0, 1, 2, 3):      # 0: no host pyramid; 1: mbKeepHostPyramid and every level READ after every call (src/Frame.cc:1044, 1248); 2: kept, never read (lazy: nothing moves); 3: as 1 with mbViewHostPyramid
         mean, med, nk = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
         L.shim_bench(h, arr, 8, W, H, W, iters, keep, ctypes.byref(mean), ctypes.byref(med), ctypes.byref(nk))
-        rows.append({"call": "ORBextractor::operator() via shim (C++)", "size": "%dx%d" % (W, H), "nfeatures": nf, "host_pyramid": keep == 1, "host_pyramid_unread": keep == 2,
+        rows.append({"call": "ORBextractor::operator() via shim (C++)", "size": "%dx%d" % (W, H), "nfeatures": nf, "host_pyramid": keep in (1, 3), "host_pyramid_unread": keep == 2, "host_pyramid_views": keep == 3,
                      "combiner": os.environ.get("ORBX_COMBINE", "1") != "0", "mean_us": round(mean.value, 1), "median_us": round(med.value, 1),
                      "frames_per_s_one_thread": round(1e6 / mean.value, 1), "keypoints": nk.value})
     L.shim_destroy(h)
@@ -60,7 +60,8 @@ def threads(orbx, L, nts, iters, keeps=(0, 1)):
         for nt in nts:
             fps = L.shim_bench_threads(nt, 1000, arr, 8, 640, 480, 640, iters, keep)
             rows.append({"call": "ORBextractor::operator() via shim (C++), one extractor per thread", "size": "640x480", "nfeatures": 1000, "threads": nt,
-                         "host_pyramid": keep == 1, "host_pyramid_unread": keep == 2, "combiner": os.environ.get("ORBX_COMBINE", "1") != "0", "frames_per_s": round(fps, 1)})
+                         "host_pyramid": keep in (1, 3), "host_pyramid_unread": keep == 2, "host_pyramid_views": keep == 3, "combiner": os.environ.get("ORBX_COMBINE", "1") != "0",
+                         "frames_per_s": round(fps, 1)})
     return rows
 
 
@@ -134,8 +135,7 @@ def measure(orbx, quick=False):
     if not quick:
         rows += one_thread(orbx, L, 1241, 376, 2000, it1)
     rows += threads(orbx, L, (8, 16) if quick else (1, 2, 4, 8, 16), itn, keeps=(0,) if quick else (0, 1))
-    if quick:
-        rows += threads(orbx, L, (16,), itn, keeps=(1,))
+    rows += threads(orbx, L, (16,), itn, keeps=(1, 3) if quick else (3,))
     try:
         rows += stereo_frame(orbx, 100 if quick else 300, 0 if quick else 8)
     except Exception as e:      # noqa: BLE001  (the drop-in library is only there when oracle/_ref was built)
@@ -155,10 +155,12 @@ def measure(orbx, quick=False):
                 return r
         return {}
     dig = {"us_1thread": pick(size="640x480", host_pyramid=False, host_pyramid_unread=False, combiner=True).get("mean_us"),
-           "us_1thread_hostpyr": pick(size="640x480", host_pyramid=True, combiner=True).get("mean_us"),
+           "us_1thread_hostpyr": pick(size="640x480", host_pyramid=True, host_pyramid_views=False, combiner=True).get("mean_us"),
+           "us_1thread_hostpyr_views": pick(size="640x480", host_pyramid=True, host_pyramid_views=True, combiner=True).get("mean_us"),
            "fps_8threads": pick(threads=8, host_pyramid=False, host_pyramid_unread=False, combiner=True).get("frames_per_s"),
            "fps_16threads": pick(threads=16, host_pyramid=False, host_pyramid_unread=False, combiner=True).get("frames_per_s"),
-           "fps_16threads_hostpyr": pick(threads=16, host_pyramid=True, combiner=True).get("frames_per_s"),
+           "fps_16threads_hostpyr": pick(threads=16, host_pyramid=True, host_pyramid_views=False, combiner=True).get("frames_per_s"),
+           "fps_16threads_hostpyr_views": pick(threads=16, host_pyramid=True, host_pyramid_views=True, combiner=True).get("frames_per_s"),
            "stereo_frame_ctor_us": pick(library="liborbslam_hip.so (drop-in)", combiner=True).get("mean_us"),
            "stereo_frame_ctor_median_us": pick(library="liborbslam_hip.so (drop-in)", combiner=True).get("median_us"),
            "source": "tools/latency_shim.py: C++ loops over the reference's call shapes (tests/shim_wrap.cc, oracle/refslam_wrap.cc)"}
