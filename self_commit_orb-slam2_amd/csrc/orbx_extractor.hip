@@ -1843,6 +1843,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *const *image
         return ORBX_OK;
     }
     static const int chunk = env_int("ORBX_HOST_BATCH_CHUNK", 64, 0, 1 << 20);      // frames per pipeline stage (0: the round-4 path, one stage)
+    if (batch > h->cfg.max_batch) { orbx_set_error("batch %d exceeds the handle's configured maximum %d", batch, h->cfg.max_batch); return ORBX_ERR_CAPACITY; }
     if (chunk > 0 && batch >= 2 * chunk && h->pipeCount == 0 && images) {
         // the synchronous call as a pipeline over its own chunks: staging + upload of chunk c+1 and the read-back of chunk c-1 under the kernels of chunk c
         int rc = ORBX_OK, begun = 0, ended = 0;
