@@ -298,8 +298,8 @@ int build_geometry(orbx_extractor *h, int W, int H)
         slots += lv.nCols * lv.nRows * lv.cellCap;
         lv.quota = h->quota[(size_t)l];
         lv.nIni = (int)roundf((float)(maxBX - minB) / (maxBY - minB));
-        if (lv.nIni < 1 || lv.nIni > 4) {
-            orbx_set_error("aspect ratio of level %d (%dx%d) gives %d initial quadtree nodes; supported: 1..4", l, lv.w, lv.h, lv.nIni);
+        if (lv.nIni < 1 || lv.nIni > ORBX_MAX_INI) {      // (0: a window more than twice as high as wide - the reference indexes an empty vector there, :766)
+            orbx_set_error("aspect ratio of level %d (%dx%d) gives %d initial quadtree nodes; supported: 1..%d", l, lv.w, lv.h, lv.nIni, ORBX_MAX_INI);
             return ORBX_ERR_ARG;
         }
         const float hX = (float)(maxBX - minB) / lv.nIni;

@@ -14,6 +14,7 @@
 #define ORBX_HALF_PATCH 15    /* HALF_PATCH_SIZE, :92 */
 #define ORBX_PATCH 31         /* PATCH_SIZE, :91 */
 #define ORBX_CELL_W 30        /* W, :1060 */
+#define ORBX_MAX_INI 8        /* initial quadtree nodes = round(window width / height), :719: levels up to 8.5 times as wide as high */
 
 /* error bits written by kernels into the per-frame status word */
 #define ORBX_DEV_ERR_PTCAP 1   /* (unused since the quadtree's point arrays are sized for the worst case) */
@@ -29,8 +30,8 @@ struct OrbxLevel {
     int slotBase;           /* first u32 of the level inside a frame's candidate slots    */
     int cellCap;            /* u32 entries per cell slot                                  */
     int quota;              /* mnFeaturesPerLevel[level]                                  */
-    int nIni;               /* initial quadtree nodes (1..4)                              */
-    int iniX[5];            /* their x bounds                                             */
+    int nIni;               /* initial quadtree nodes (1..ORBX_MAX_INI)                   */
+    int iniX[ORBX_MAX_INI + 1]; /* their x bounds                                         */
     int binOff;             /* offset of this level's x -> initial-node table (u8)        */
     int kpBase, kpCap;      /* slice of the per-frame level-keypoint array                */
     int blurTileBase, blurTilesX, blurTilesY;

@@ -734,7 +734,7 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
     __shared__ unsigned short byProc[NODECAP];      // careful rounds: processing rank -> node
     __shared__ unsigned char sel[NODECAP];          // node is split in this round
     __shared__ int wsA[16], wsB[16];
-    __shared__ int sh_misc[8];
+    __shared__ int sh_misc[4 + ORBX_MAX_INI];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const OrbxLevel &lv = g->lv[l];
@@ -749,7 +749,7 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
     const int *cc = cellCount + (size_t)f * g->cellsPerFrame + lv.cellBase;
     int *cellOff = (int *)lab;        // scratch: labels are written after the gather
     for (int i = tid; i < ncell; i += BT) cellOff[i] = cc[i];
-    if (tid < 8) sh_misc[tid] = 0;
+    if (tid < 4 + ORBX_MAX_INI) sh_misc[tid] = 0;
     __syncthreads();
     const int M = block_exscan<BT>(cellOff, ncell, wsA);
     {
@@ -769,28 +769,36 @@ __device__ __forceinline__ void octree_body(const OrbxGeom *__restrict__ g, cons
     int cur = 0, nn = 0, ncand = 0;
     {
         const uint8_t *bin = binTab + lv.binOff;
-        int c4[4] = {0, 0, 0, 0};
+        const int nIni = lv.nIni;      // 1 .. ORBX_MAX_INI initial nodes (round(width / height) of the level's detection window, :719)
+        int c8[ORBX_MAX_INI] = {};
         for (int j0 = 0; j0 < M; j0 += BT) {
             const int j = j0 + tid;
             const int q = j < M ? (int)bin[pts[j] & 0xfff] : -1;
 #pragma unroll
-            for (int Q = 0; Q < 4; Q++) c4[Q] += __popcll(__ballot(q == Q));
+            for (int Q = 0; Q < ORBX_MAX_INI; Q++) if (Q < nIni) c8[Q] += __popcll(__ballot(q == Q));
         }
         if (lane == 0)
 #pragma unroll
-            for (int Q = 0; Q < 4; Q++) if (c4[Q]) atomicAdd(&sh_misc[4 + Q], c4[Q]);
+            for (int Q = 0; Q < ORBX_MAX_INI; Q++) if (c8[Q]) atomicAdd(&sh_misc[4 + Q], c8[Q]);
         __syncthreads();
-        int idx[4], k = 0;
-        for (int Q = 0; Q < 4; Q++) { idx[Q] = -1; if (Q < lv.nIni && sh_misc[4 + Q] > 0) idx[Q] = k++; }
+        int idx[ORBX_MAX_INI], k = 0;
+#pragma unroll
+        for (int Q = 0; Q < ORBX_MAX_INI; Q++) { idx[Q] = -1; if (Q < nIni && sh_misc[4 + Q] > 0) idx[Q] = k++; }
         nn = k;
-        if (tid < 4 && idx[tid] >= 0) {
-            OtBox b;
-            b.x0 = (short)lv.iniX[tid]; b.x1 = (short)lv.iniX[tid + 1]; b.y0 = 0; b.y1 = (short)(lv.h - 2 * ORBX_BORDER);
-            box[0][idx[tid]] = b; cnt[0][idx[tid]] = sh_misc[4 + tid];
-            qc[0][idx[tid]][0] = qc[0][idx[tid]][1] = qc[0][idx[tid]][2] = qc[0][idx[tid]][3] = 0u;
+        {
+            int myIdx = -1;
+#pragma unroll
+            for (int Q = 0; Q < ORBX_MAX_INI; Q++) myIdx = tid == Q ? idx[Q] : myIdx;
+            if (tid < ORBX_MAX_INI && myIdx >= 0) {
+                OtBox b;
+                b.x0 = (short)lv.iniX[tid]; b.x1 = (short)lv.iniX[tid + 1]; b.y0 = 0; b.y1 = (short)(lv.h - 2 * ORBX_BORDER);
+                box[0][myIdx] = b; cnt[0][myIdx] = sh_misc[4 + tid];
+                qc[0][myIdx][0] = qc[0][myIdx][1] = qc[0][myIdx][2] = qc[0][myIdx][3] = 0u;
+            }
+            if (tid < ORBX_MAX_INI) wsB[4 + tid] = myIdx;      // bin -> node (a runtime-indexed register array would live in scratch memory)
         }
-        for (int Q = 0; Q < 4; Q++) if (idx[Q] >= 0 && sh_misc[4 + Q] > 1) ncand++;
-        if (tid < 4) wsB[4 + tid] = idx[tid];      // bin -> node (a runtime-indexed register array would live in scratch memory)
+#pragma unroll
+        for (int Q = 0; Q < ORBX_MAX_INI; Q++) if (idx[Q] >= 0 && sh_misc[4 + Q] > 1) ncand++;
         __syncthreads();
         for (int j = tid; j < M; j += BT) {
             const uint32_t p = pts[j];

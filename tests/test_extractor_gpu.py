@@ -308,3 +308,24 @@ def test_the_handles_own_graph_still_serves_single_frames(orbx, monkeypatch):
         assert all((pyr[l] == ref.mvImagePyramid(l)).all() for l in range(8))
     assert ext.combiner_stats()[1] == 0
     ext.close(); ref.close()
+
+
+@pytest.mark.parametrize("W,H,nini,nl", [(1000, 230, 5, 4), (1241, 230, 6, 4), (1400, 200, 8, 2)])
+def test_wide_images_with_five_to_eight_initial_quadtree_nodes(orbx, oracle, W, H, nini, nl):
+    """DistributeOctTree starts from round(width / height) root nodes (src/ORBextractor.cc:719-766): panoramic images give more than the four of
+    the usual camera formats.  Batch and single-frame paths against the restatement, bit for bit."""
+    assert round((W - 32) / (H - 32)) == nini
+    nf = 800
+    rst = oracle.restatement(nf, 1.2, nl)
+    ext = orbx.ORBextractor(nf, 1.2, nl, 20, 7, max_width=W, max_height=H, max_batch=2)
+    frames = [orbx.synth_frame(300 + nini, W, H), orbx.synth_frame(310 + nini, W, H, orbx.SYNTH_LOW_TEXTURE)]
+    kps, desc, counts = ext.extract_batch(frames)
+    one = orbx.ORBextractor(nf, 1.2, nl, 20, 7, max_width=W, max_height=H)
+    for f, im in enumerate(frames):
+        ko, do = rst.extract(im)
+        n = int(counts[f])
+        assert n == len(ko) and n > 100
+        assert (kp_matrix(kps[f, :n]).view(np.uint32) == ko.view(np.uint32)).all() and (desc[f, :n] == do).all()
+        k1, d1 = one(im)
+        assert len(k1) == n and (kp_matrix(k1).view(np.uint32) == ko.view(np.uint32)).all() and (d1 == do).all()
+    ext.close(); one.close()

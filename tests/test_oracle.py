@@ -113,6 +113,21 @@ def test_restatement_equals_compiled_reference(orbx, oracle, W, H, nf, seeds):
         assert k1.shape == k2.shape and (k1.view(np.uint32) == k2.view(np.uint32)).all() and (d1 == d2).all()
 
 
+@pytest.mark.parametrize("W,H,nl", [(1000, 230, 4), (1241, 230, 4), (1400, 200, 2)])
+def test_restatement_equals_compiled_reference_on_wide_images(orbx, oracle, W, H, nl):
+    """Five to eight initial quadtree nodes (round(width / height) of the detection window, src/ORBextractor.cc:719): the restatement the GPU
+    tests of these geometries compare with is pinned to the compiled reference here."""
+    ref = oracle.reference(800, 1.2, nl)
+    if ref is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rst = oracle.restatement(800, 1.2, nl)
+    for s in (41, 43):
+        im = orbx.synth_frame(s, W, H, orbx.SYNTH_LOW_TEXTURE if s % 4 == 3 else 0)
+        k1, d1 = ref.extract(im)
+        k2, d2 = rst.extract(im)
+        assert len(k1) > 100 and k1.shape == k2.shape and (k1.view(np.uint32) == k2.view(np.uint32)).all() and (d1 == d2).all()
+
+
 def test_octree_array_form_equals_std_list(oracle):
     """Random candidate sets (ties at the careful-round break are the
     norm): array-form quadtree == DistributeOctTree of the compiled reference."""
