@@ -145,7 +145,7 @@ struct orbx_extractor {
         uint8_t *hostRes = nullptr; size_t hostResBytes = 0;
         const uint8_t **ptrTab = nullptr; size_t ptrTabBytes = 0;      // pinned: addresses of a batch's frames for k_gather_frames
         hipEvent_t evUp = nullptr, evKern = nullptr, evDown = nullptr;
-        int batch = 0;
+        int batch = 0, cap = 0;          // frames and per-frame capacity of the batch the slot holds (the handle's geometry may change before its _end)
         size_t offKp = 0, offDesc = 0, offSt = 0;
     } pipe[2];
     int pipeHead = 0, pipeCount = 0;  // oldest begun slot, number of begun and not yet ended batches (<= 2)
@@ -1782,7 +1782,7 @@ extern "C" int orbx_extract_batch_begin(orbx_extractor *h, const uint8_t *const 
     ORBX_HIP_CHECK(hipMemcpyAsync(S.hostRes + S.offDesc, h->outDescP[cb], B * cap * 32, hipMemcpyDeviceToHost, h->downStream));
     ORBX_HIP_CHECK(hipEventRecord(S.evDown, h->downStream));
     h->consumerEv[cb] = S.evDown;      // the batch after the next one overwrites this result buffer: only behind the read-back
-    S.batch = batch;
+    S.batch = batch; S.cap = cap;
     h->pipeCount++;
     const auto tB2 = std::chrono::steady_clock::now();
     h->pipeUs[0] += std::chrono::duration<double, std::micro>(tB1 - tB0).count(); h->pipeUs[1] += std::chrono::duration<double, std::micro>(tB2 - tB1).count();
@@ -1800,7 +1800,7 @@ extern "C" int orbx_extract_batch_end(orbx_extractor *h, orbx_keypoint *keypoint
     const auto tE0 = std::chrono::steady_clock::now();
     ORBX_HIP_CHECK(hipEventSynchronize(S.evDown));
     const auto tE1 = std::chrono::steady_clock::now();
-    const int batch = S.batch, cap = h->geom.outCap;
+    const int batch = S.batch, cap = S.cap;
     const uint8_t *hp = S.hostRes;
     const int *st = (const int *)(hp + S.offSt);
     for (int f = 0; f < batch; f++)

@@ -83,3 +83,16 @@ def test_pinned_frames_are_read_in_place(orbx, oracle):
     views = [host[i, :, :W] for i in range(B)]
     ext.extract_batch_begin(views)
     check(rst, frames, *ext.extract_batch_end())
+
+
+def test_a_batch_of_another_geometry_may_be_begun_before_the_first_is_ended(orbx, oracle):
+    """begin(320x240), begin(400x300), end, end on one handle: the second begin rebuilds the handle's geometry while the first batch's results wait
+    in their slot (with the capacity they were produced at)."""
+    rst = oracle.restatement(500)
+    ext = orbx.ORBextractor(500, 1.2, 8, 20, 7, max_width=400, max_height=300, max_batch=4)
+    a = [orbx.synth_frame(60 + i, 320, 240) for i in range(4)]
+    b = [orbx.synth_frame(70 + i, 400, 300) for i in range(3)]
+    ext.extract_batch_begin(a)
+    ext.extract_batch_begin(b)
+    check(rst, a, *ext.extract_batch_end())
+    check(rst, b, *ext.extract_batch_end())
