@@ -1501,7 +1501,7 @@ __global__ __launch_bounds__(256) void k_gather_frames(const uint8_t *const *__r
     const int upr = (W + (int)sizeof(T) - 1) / (int)sizeof(T), n = upr * H;      // units per row (the last one may run into the row padding: stride >= width rounded up to 4)
     for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < n; i += (int)(gridDim.x * 256)) {
         const int r = i / upr, c = i - r * upr;
-        if ((c + 1) * (int)sizeof(T) <= srcStride || r + 1 < H) {
+        if (r + 1 < H || (c + 1) * (int)sizeof(T) <= W) {      // (a unit that runs past the pixels of the LAST row would leave the caller's buffer)
             const T v = *(const T *)(src + (size_t)r * srcStride + (size_t)c * sizeof(T));
             if ((c + 1) * (int)sizeof(T) <= dstStride) *(T *)(d + (size_t)r * dstStride + (size_t)c * sizeof(T)) = v;
             else for (int k = 0; k < dstStride - c * (int)sizeof(T); k++) d[(size_t)r * dstStride + (size_t)c * sizeof(T) + k] = ((const uint8_t *)&v)[k];
