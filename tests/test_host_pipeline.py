@@ -96,3 +96,52 @@ def test_a_batch_of_another_geometry_may_be_begun_before_the_first_is_ended(orbx
     ext.extract_batch_begin(b)
     check(rst, a, *ext.extract_batch_end())
     check(rst, b, *ext.extract_batch_end())
+
+
+def test_random_begin_end_schedule(orbx, oracle):
+    """Sixty batches of random size (1 .. 40 frames), geometry (two sizes), memory kind (pageable / pinned, packed or ragged stride) and schedule (one or
+    two batches begun before an end) on ONE handle; every batch's counts and a sample of its frames against the oracle."""
+    import torch
+    rng = np.random.default_rng(5)
+    rst = oracle.restatement(500)
+    GEOM = [(320, 240), (402, 300)]
+    ext = orbx.ORBextractor(500, 1.2, 8, 20, 7, max_width=402, max_height=300, max_batch=40)
+    pool = {g: [orbx.synth_frame(500 + 10 * gi + i, g[0], g[1], orbx.SYNTH_LOW_TEXTURE if i == 5 else 0) for i in range(8)] for gi, g in enumerate(GEOM)}
+    want = {g: [rst.extract(im) for im in pool[g]] for g in GEOM}
+    keep = []          # pinned tensors stay alive until their batch is ended
+    pending = []
+
+    def begin():
+        g = GEOM[int(rng.integers(0, 2))]
+        B = int(rng.integers(1, 41))
+        ids = rng.integers(0, 8, B)
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            views = [pool[g][i] for i in ids]
+        else:
+            stride = g[0] if kind == 1 else g[0] + int(rng.integers(1, 9)) * 4
+            t = torch.empty((B, g[1], stride), dtype=torch.uint8).pin_memory()
+            h = t.numpy()
+            for k, i in enumerate(ids):
+                h[k, :, :g[0]] = pool[g][i]
+            keep.append(t)
+            views = [h[k, :, :g[0]] for k in range(B)]
+        ext.extract_batch_begin(views)
+        pending.append((g, ids))
+
+    def end():
+        g, ids = pending.pop(0)
+        kps, desc, counts = ext.extract_batch_end()
+        assert len(counts) == len(ids)
+        for k in {0, len(ids) - 1, len(ids) // 2}:
+            ko, do = want[g][ids[k]]
+            n = int(counts[k])
+            assert n == len(ko) and (kp_bits(kps[k, :n]) == ko.view(np.uint32)).all() and (desc[k, :n] == do).all(), (g, k)
+        assert all(int(counts[k]) == len(want[g][ids[k]][0]) for k in range(len(ids)))
+
+    for _ in range(60):
+        begin()
+        if len(pending) == 2 or rng.random() < 0.4:
+            end()
+    while pending:
+        end()
