@@ -404,9 +404,9 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v)
 // NS = 16-byte units of a cell's window per lane (window rows x units per row <= 64 NS), K (an argument) = cells per wave.
 // A wave takes K consecutive cells of a frame through the phases one after the other; everything it needs to know about a cell is ONE 32-byte table
 // entry (OrbxFcCell, built with the geometry: the v1 prologue - a chain of ~12 dependent scalar loads through OrbxGeom and three integer divisions - was
-// 28 % of a wave's lifetime, profiles/r05a_fast_phases.txt), and the window of cell k+1 is requested before the phases of cell k run and stored into LDS
+// 28 % of a wave's lifetime, profiles/r05_fast_phases.txt), and the window of cell k+1 is requested before the phases of cell k run and stored into LDS
 // after them (v1: three dependent load -> store round trips per cell, 18 % of the lifetime).
-template <int P, int SP, int NS, bool PROF = false>
+template <int P, int SP, int NS, bool PROF = false, bool DBG = false>      // DBG: the parity tap (score map of a single minThFAST pass); the product instantiation carries none of it
 __global__ __launch_bounds__(64) void k_fast_cells(const OrbxFcCell *__restrict__ cells, int K, int cellsPerFrame, int slotsPerFrame, size_t pyrBytes, int iniTh, int minTh,
                                                    int inBytes, int scBytes, const uint8_t *__restrict__ img0, int img0Stride, size_t img0FramePitch,
                                                    const uint8_t *__restrict__ pyr, uint8_t *__restrict__ scoreDbg, int *__restrict__ cellCount,
@@ -426,16 +426,22 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxFcCell *__restrict_
     // row); unit u = (row u / nu, column u % nu), all of a lane's units requested back to back.  (Skipped cells carry a 1 x 1 area: their loads are
     // valid and unused - unconditional loads keep the units in registers; behind a branch the compiler parks them in scratch memory and waits.)
     uint4 wv[NS];
-    int wo[NS];               // where each unit goes in the LDS window (-1: none), kept from the request to the store
+    int wo[NS], ur[NS], uc[NS];      // per unit of the lane: LDS offset in the window (-1: none), window row, 16-byte column: recomputed only when a cell's window shape differs from the previous one's
+    uint32_t shape = 0xffffffffu;
 #define FC_REQUEST(E) do { \
         const int lvl_ = (int)(((E).dim >> 16) & 0xffu), sp_ = lvl_ ? (E).pitch : img0Stride; \
         const uint8_t *base_ = (lvl_ ? frameP + (E).off : frame0) + (size_t)((int)((E).xy >> 16) - 3) * sp_ + ((int)((E).xy & 0xffffu) - 3); \
-        const int nu_ = (int)((E).units & 0xffu), ntot_ = (int)((E).units >> 8), inv_ = (int)(E).inv; \
-        _Pragma("unroll") for (int k_ = 0; k_ < NS; k_++) { \
-            const int u_ = min(lane + 64 * k_, ntot_ - 1), r_ = __mul24(u_, inv_) >> 16, c_ = u_ - __mul24(r_, nu_); \
-            wv[k_] = load16u(base_ + (size_t)r_ * sp_ + 16 * c_); \
-            wo[k_] = lane + 64 * k_ < ntot_ ? r_ * P + 16 * c_ : -1; \
-        } } while (0)
+        if ((E).units != shape) { \
+            shape = (E).units; \
+            const int nu_ = (int)((E).units & 0xffu), ntot_ = (int)((E).units >> 8), inv_ = (int)(E).inv; \
+            _Pragma("unroll") for (int k_ = 0; k_ < NS; k_++) { \
+                const int u_ = min(lane + 64 * k_, ntot_ - 1); \
+                ur[k_] = __mul24(u_, inv_) >> 16; uc[k_] = 16 * (u_ - __mul24(ur[k_], nu_)); \
+                wo[k_] = lane + 64 * k_ < ntot_ ? ur[k_] * P + uc[k_] : -1; \
+            } \
+        } \
+        _Pragma("unroll") for (int k_ = 0; k_ < NS; k_++) wv[k_] = load16u(base_ + (size_t)ur[k_] * sp_ + uc[k_]); \
+    } while (0)
     OrbxFcCell e = cells[cFirst], en = cells[min(cFirst + 1, cEnd - 1)];
     FC_REQUEST(e);
     FC_STAMP(0);
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxFcCell *__restrict_
     }
     __syncthreads();
     FC_STAMP(1);
-    uint8_t *dbg = scoreDbg ? scoreDbg + (size_t)f * pyrBytes + loff : nullptr;
+    uint8_t *dbg = DBG && scoreDbg ? scoreDbg + (size_t)f * pyrBytes + loff : nullptr;
     if (dbg)   // parity tap: pixels that fail the pre-test have score 0
         for (int p = lane; p < aw * ah; p += 64) dbg[(size_t)(y0 + p / aw) * lpitch + (x0 + p % aw)] = 0;
 
@@ -1306,7 +1312,6 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
         *(float4 *)sPat[threadIdx.x] = *(const float4 *)c_od.pat[threadIdx.x];
         ((uint32_t *)sDisc)[threadIdx.x] = ((const uint32_t *)c_od.disc)[threadIdx.x];
     }
-    const int slot = bx * OD_WPB + wv;
     const int *cnts = lvlCnt + f * A.nlevels;
     // where each level's keypoints start in the frame's output list (level 0 .. n-1 in order, src/ORBextractor.cc:1577-1668): once per workgroup,
     // lane = level, into LDS (k_blur's first workgroup used to leave it in global memory; the blur no longer has to run behind the quadtree for it)
@@ -1324,6 +1329,10 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
         outStatus[f] = status[f];
         if (f == 0) outStatus[gridDim.y] = status[gridDim.y];
     }
+    // (Measured and not kept: a workgroup taking TWO groups of four slots in a row, the table copies and the prologue paid once per eight keypoints: 63.2 M
+    // instead of 67.9 M vector instructions, but 0.230 instead of 0.207 ms alone and 271k instead of 282k frames/s - the kernel lives on the number of
+    // workgroups that have their pixel loads in flight.)
+    const int slot = bx * OD_WPB + wv;
     // Is the slot in use?  (Measured: requesting the keypoint record and the pixels BEFORE the counts are known - clamped coordinates for
     // the ~7 % unused slots - shortens the dependent chain by one level but is 7 % slower: 0.242 vs 0.226 ms per 256 frames.)
     bool inRange = slot < A.kpPerFrame;
@@ -1616,8 +1625,9 @@ int orbx_launch_fast_cells(const OrbxLaunch &L)
     dim3 grid((unsigned)((g.cellsPerFrame + K - 1) / K), (unsigned)L.batch);
     const size_t ldsBytes = (size_t)g.fcLdsBytes;
 #define FC_ARGS L.fcCells, K, g.cellsPerFrame, g.slotsPerFrame, g.pyrBytes, g.iniTh, g.minTh, g.fcInBytes, g.fcScBytes, L.img0, L.img0Stride, L.img0FramePitch, L.pyr, L.score, L.cellCount, L.cellSlots
-#define FC_LAUNCH(PP, SS, NN) do { if (g_fcProf) return emit(L, k_fast_cells<PP, SS, NN, true>, grid, dim3(64), ldsBytes, FC_ARGS, g_fcProf); \
-    return emit(L, k_fast_cells<PP, SS, NN, false>, grid, dim3(64), ldsBytes, FC_ARGS, (unsigned long long *)nullptr); } while (0)
+#define FC_LAUNCH(PP, SS, NN) do { if (L.score) return emit(L, k_fast_cells<PP, SS, NN, false, true>, grid, dim3(64), ldsBytes, FC_ARGS, (unsigned long long *)nullptr); \
+    if (g_fcProf) return emit(L, k_fast_cells<PP, SS, NN, true, false>, grid, dim3(64), ldsBytes, FC_ARGS, g_fcProf); \
+    return emit(L, k_fast_cells<PP, SS, NN, false, false>, grid, dim3(64), ldsBytes, FC_ARGS, (unsigned long long *)nullptr); } while (0)
 #define FC_LAUNCH_P(PP, SS) switch (g.fcNS) { case 2: FC_LAUNCH(PP, SS, 2); case 3: FC_LAUNCH(PP, SS, 3); case 4: FC_LAUNCH(PP, SS, 4); default: FC_LAUNCH(PP, SS, 6); }
     if (g.fcPitch == 48) FC_LAUNCH_P(48, 48)
     if (g.fcPitch == 64) FC_LAUNCH_P(64, 48)
