@@ -369,6 +369,10 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
 }
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(a, min(b, c)); }   // v_min3_i32
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(a, max(b, c)); }   // v_max3_i32
+// The three-operand forms spelt out: left to itself the compiler shares min(x[k], x[k+1]) between neighbouring arcs and ends up with 62 two-operand + 40
+// three-operand instructions for the 9-arc extrema of a survivor where 80 three-operand ones do (profiles/r05_fast_phases.txt: phase B is a fifth of the kernel).
+__device__ __forceinline__ int min3u_asm(int a, int b, int c) { int r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int max3u_asm(int a, int b, int c) { int r; asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // bytes (b, b+1) of the 24-byte window row W[0..5] as a u16 pair; b is a compile-time constant <= 20
 #define FC_PAIR(W, b) __builtin_amdgcn_perm((W)[((b) >> 2) + 1 > 5 ? 5 : ((b) >> 2) + 1], (W)[(b) >> 2], \
@@ -548,16 +552,16 @@ __global__ __launch_bounds__(64) void k_fast_cells(const OrbxFcCell *__restrict_
         int a3[16], b3[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            a3[k] = min3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
-            b3[k] = max3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+            a3[k] = min3u_asm(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+            b3[k] = max3u_asm(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
         }
         int maxA = 0, minB = 255;   // max over the 16 arcs of min(x), min over the arcs of max(x)
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
-            const int a9 = min3i(a3[k], a3[(k + 3) & 15], a3[(k + 6) & 15]), a9n = min3i(a3[k + 1], a3[(k + 4) & 15], a3[(k + 7) & 15]);
-            const int b9 = max3i(b3[k], b3[(k + 3) & 15], b3[(k + 6) & 15]), b9n = max3i(b3[k + 1], b3[(k + 4) & 15], b3[(k + 7) & 15]);
-            maxA = max3i(maxA, a9, a9n);
-            minB = min3i(minB, b9, b9n);
+            const int a9 = min3u_asm(a3[k], a3[(k + 3) & 15], a3[(k + 6) & 15]), a9n = min3u_asm(a3[k + 1], a3[(k + 4) & 15], a3[(k + 7) & 15]);
+            const int b9 = max3u_asm(b3[k], b3[(k + 3) & 15], b3[(k + 6) & 15]), b9n = max3u_asm(b3[k + 1], b3[(k + 4) & 15], b3[(k + 7) & 15]);
+            maxA = k == 0 ? max(a9, a9n) : max3u_asm(maxA, a9, a9n);
+            minB = k == 0 ? min(b9, b9n) : min3u_asm(minB, b9, b9n);
         }
         // dark arc: all x < v - t  <=>  t < v - max(x);  bright arc: all x > v + t  <=>  t < min(x) - v;  score = largest such t
         int sco = max(v - minB, maxA - v) - 1;
