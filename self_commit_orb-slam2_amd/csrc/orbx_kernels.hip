@@ -1063,12 +1063,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 // vertical in 32, (sum + 2^15) >> 16.
 // ONE WAVE per 64x32 output tile.  The 80-byte x 38-row input window is staged in LDS with
 // 16-byte loads; lane = (4-column group, 8-row group) then runs BOTH passes in registers:
-//   horizontal, 14 rows x 4 px: taps 0..3 . bytes + taps 4..6 . bytes = two v_dot4_u32_u8 on byte
-//     windows cut out with v_alignbyte_b32;
-//   vertical, 8 rows x 4 px: vertically adjacent 16-bit sums of a column paired by one
-//     v_perm_b32, four v_dot2_u32_u16 per output, the +2^15 rounding rides in the accumulator.
+//   horizontal, 14 rows x 4 px: two or three v_dot4_u32_u8 per pixel on the window words as loaded (the TAPS are
+//     shifted to the pixel's byte position, not the data), the sums of rows (2m, 2m+1) of a column packed into one word;
+//   vertical, 8 rows x 4 px: four v_dot2_u32_u16 per output on those row pairs (even and odd output rows differ in the
+//     tap pairs, not in the data), the +2^15 rounding rides in the accumulator.
 // Taps are <= 255 and sum to <= 257 (checked at handle creation): the 16-bit sums cannot saturate.
-// ~19 VALU lane-instructions per pixel; algorithmic traffic 2 bytes/pixel, the halo makes the
+// ~14 VALU lane-instructions per pixel; algorithmic traffic 2 bytes/pixel, the halo makes the
 // read side 1.48x.
 // ------------------------------------------------------------------------------------
 #define BT_W 64
@@ -1167,37 +1167,42 @@ __device__ __forceinline__ void blur_body(const OrbxGeom *__restrict__ g, const 
     const uint32_t B0 = (k0 << 16) | (k1 << 24), B1 = k2 | (k3 << 8) | (k4 << 16) | (k5 << 24), B2 = k6;                           // j = 1: w0, w1, w2
     const uint32_t C0 = k0 << 24, C1 = k1 | (k2 << 8) | (k3 << 16) | (k4 << 24), C2 = k5 | (k6 << 8);                              // j = 2: w0, w1, w2
     const uint32_t D1 = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), D2 = k4 | (k5 << 8) | (k6 << 16);                                // j = 3: w1, w2
-    uint32_t c0[14], c1[14];
+    // the 16-bit sums of two vertically adjacent rows (2m, 2m + 1) of a column share a word: exactly the operand pairs of the vertical pass below
+    uint32_t hp[4][7];
 #pragma unroll
-    for (int r = 0; r < 14; r++) {
-        const uint32_t *pw = in + (8 * rg + r) * (BT_P / 4) + gq + 1;
-        const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
-        const uint32_t o0 = __builtin_amdgcn_udot4(w1, A1, __builtin_amdgcn_udot4(w0, A0, 0u, false), false);
-        const uint32_t o1 = __builtin_amdgcn_udot4(w2, B2, __builtin_amdgcn_udot4(w1, B1, __builtin_amdgcn_udot4(w0, B0, 0u, false), false), false);
-        const uint32_t o2 = __builtin_amdgcn_udot4(w2, C2, __builtin_amdgcn_udot4(w1, C1, __builtin_amdgcn_udot4(w0, C0, 0u, false), false), false);
-        const uint32_t o3 = __builtin_amdgcn_udot4(w2, D2, __builtin_amdgcn_udot4(w1, D1, 0u, false), false);
-        c0[r] = o0 | (o1 << 16);
-        c1[r] = o2 | (o3 << 16);
+    for (int m = 0; m < 7; m++) {
+        uint32_t o[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const uint32_t *pw = in + (8 * rg + 2 * m + s) * (BT_P / 4) + gq + 1;
+            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+            o[s][0] = __builtin_amdgcn_udot4(w1, A1, __builtin_amdgcn_udot4(w0, A0, 0u, false), false);
+            o[s][1] = __builtin_amdgcn_udot4(w2, B2, __builtin_amdgcn_udot4(w1, B1, __builtin_amdgcn_udot4(w0, B0, 0u, false), false), false);
+            o[s][2] = __builtin_amdgcn_udot4(w2, C2, __builtin_amdgcn_udot4(w1, C1, __builtin_amdgcn_udot4(w0, C0, 0u, false), false), false);
+            o[s][3] = __builtin_amdgcn_udot4(w2, D2, __builtin_amdgcn_udot4(w1, D1, 0u, false), false);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) hp[j][m] = o[0][j] | (o[1][j] << 16);
     }
-    // ---- vertical ----
-    const uint32_t V01 = k0 | (k1 << 16), V23 = k2 | (k3 << 16), V45 = k4 | (k5 << 16), V6 = k6;
+    // ---- vertical: output row q = 2t takes rows 2t .. 2t+6 = pairs t .. t+3 with the taps (k0,k1) (k2,k3) (k4,k5) (k6,0); row q = 2t+1 takes rows
+    // 2t+1 .. 2t+7 = the SAME pairs with the taps (0,k0) (k1,k2) (k3,k4) (k5,k6): the taps move (scalar registers), not the data.  (Until round 5 every
+    // output row had its own (h[q+2i], h[q+2i+1]) pairs, cut out of column-paired words by 14 v_perm_b32 per column: 56 of the kernel's ~500 instructions.)
+    const uint32_t E0 = k0 | (k1 << 16), E1 = k2 | (k3 << 16), E2 = k4 | (k5 << 16), E3 = k6;
+    const uint32_t O0 = k0 << 16, O1 = k1 | (k2 << 16), O2 = k3 | (k4 << 16), O3 = k5 | (k6 << 16);
     uint32_t outw[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) outw[q] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t selp = (j & 1) ? 0x07060302u : 0x05040100u;   // (h[r], h[r+1]) of column j as a u16 pair
-        uint32_t P[14];
-#pragma unroll
-        for (int k = 0; k < 13; k++) P[k] = (j < 2) ? __builtin_amdgcn_perm(c0[k + 1], c0[k], selp) : __builtin_amdgcn_perm(c1[k + 1], c1[k], selp);
-        P[13] = (j < 2) ? __builtin_amdgcn_perm(c0[13], c0[13], selp) : __builtin_amdgcn_perm(c1[13], c1[13], selp);
         // (sum + 32768) >> 16 is byte 2 of the sum, and with taps that add up to at most 256 it cannot exceed 255 (65280 * 256 + 32768 <
         // 2^24): ONE v_perm_b32 drops that byte into byte j of the output word (shift, clamp and shift-or before).  Taps summing to 257
         // (the configuration allows them) keep the clamp.
         const uint32_t selo = j == 0 ? 0x03020106u : j == 1 ? 0x03020600u : j == 2 ? 0x03060100u : 0x06020100u;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const uint32_t sum = udot2(P[q + 6], V6, udot2(P[q + 4], V45, udot2(P[q + 2], V23, udot2(P[q], V01, 32768u))));
+            const int t = q >> 1;
+            const uint32_t sum = (q & 1) ? udot2(hp[j][t + 3], O3, udot2(hp[j][t + 2], O2, udot2(hp[j][t + 1], O1, udot2(hp[j][t], O0, 32768u))))
+                                         : udot2(hp[j][t + 3], E3, udot2(hp[j][t + 2], E2, udot2(hp[j][t + 1], E1, udot2(hp[j][t], E0, 32768u))));
             if (CLAMP) outw[q] |= min(sum >> 16, 255u) << (8 * j);
             else outw[q] = __builtin_amdgcn_perm(sum, outw[q], selo);
         }

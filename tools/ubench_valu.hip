@@ -18,11 +18,17 @@ __device__ __forceinline__ unsigned pkmin(unsigned a, unsigned b) { union { unsi
 __device__ __forceinline__ unsigned udot2(unsigned a, unsigned b, unsigned c) { union { unsigned u; u16x2 v; } x, y; x.u = a; y.u = b; return __builtin_amdgcn_udot2(x.v, y.v, c, false); }
 
 enum { OP_BCNT = 0, OP_XOR, OP_ADD, OP_MIN3, OP_PKMIN, OP_PERM, OP_ALIGN, OP_DOT4, OP_DOT2, OP_SAD, OP_LSHLOR, OP_MAD24, OP_FADD, OP_FFMA, OP_PKFMA,
-       OP_AND, OP_LSHL, OP_MIN, OP_MED3, OP_BFE, OP_ADD3, OP_LSHLADD, OP_ANDOR, OP_PKSUB, OP_PKMAX, OP_MULLO, OP_SUB, OP_COUNT };
+       OP_AND, OP_LSHL, OP_MIN, OP_MED3, OP_BFE, OP_ADD3, OP_LSHLADD, OP_ANDOR, OP_PKSUB, OP_PKMAX, OP_MULLO, OP_SUB,
+       OP_FMIN, OP_FMAX, OP_PKMINH, OP_PKMAXH, OP_PKADDU16, OP_PKADDH, OP_OR, OP_MOV, OP_LSHR, OP_MAXU, OP_MINH, OP_MINU16, OP_NOT, OP_CVTUB, OP_FMUL, OP_PKFMAH, OP_MAX3F, OP_ALIGNBIT,
+       OP_MIN3U16, OP_MAX3U16, OP_MED3U16, OP_MAXU16, OP_MAXI16, OP_SUBU16, OP_ADDU16, OP_MADU16, OP_LSHLB16, OP_CNDMASK, OP_ADDC, OP_BFI, OP_MINI32, OP_MINU16SDWA, OP_ADDSDWA, OP_MULU16, OP_MIN3F16, OP_CMPCND, OP_COUNT };
 static const char *kNames[OP_COUNT] = {"v_bcnt_u32_b32", "v_xor_b32", "v_add_u32", "v_min3_u32", "v_pk_min_u16", "v_perm_b32", "v_alignbyte_b32", "v_dot4_u32_u8", "v_dot2_u32_u16",
                                        "v_sad_u8", "v_lshl_or_b32", "v_mad_u32_u24", "v_add_f32", "v_fma_f32", "v_pk_fma_f32",
                                        "v_and_b32", "v_lshlrev_b32", "v_min_u32", "v_med3_i32", "v_bfe_u32", "v_add3_u32", "v_lshl_add_u32", "v_and_or_b32", "v_pk_sub_i16", "v_pk_max_i16",
-                                       "v_mul_lo_u32", "v_sub_u32"};
+                                       "v_mul_lo_u32", "v_sub_u32",
+                                       "v_min_f32", "v_max_f32", "v_pk_min_f16", "v_pk_max_f16", "v_pk_add_u16", "v_pk_add_f16", "v_or_b32", "v_mov_b32", "v_lshrrev_b32", "v_max_u32",
+                                       "v_min_f16", "v_min_u16", "v_not_b32", "v_cvt_f32_ubyte0", "v_mul_f32", "v_pk_fma_f16", "v_max3_f32", "v_alignbit_b32",
+                                       "v_min3_u16", "v_max3_u16", "v_med3_u16", "v_max_u16", "v_max_i16", "v_sub_u16", "v_add_u16", "v_mad_u16", "v_lshlrev_b16", "v_cndmask_b32", "v_addc_co_u32",
+                                       "v_bfi_b32", "v_min_i32", "v_min_u16_sdwa(bytes)", "v_add_u32_sdwa(bytes)", "v_mul_lo_u16", "v_min3_f16", "v_cmp_gt_u16+v_cndmask"};
 
 // every class is ONE named instruction (inline asm: the optimiser neither folds the chains nor picks another opcode)
 #define ASM2(NAME) { unsigned r; asm volatile(NAME " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -55,6 +61,42 @@ template <int OP> __device__ __forceinline__ unsigned op(unsigned a, unsigned b,
     if (OP == OP_PKMAX) ASM2("v_pk_max_i16")
     if (OP == OP_MULLO) ASM2("v_mul_lo_u32")
     if (OP == OP_SUB) ASM2("v_sub_u32")
+    if (OP == OP_FMIN) ASM2("v_min_f32")
+    if (OP == OP_FMAX) ASM2("v_max_f32")
+    if (OP == OP_PKMINH) ASM2("v_pk_min_f16")
+    if (OP == OP_PKMAXH) ASM2("v_pk_max_f16")
+    if (OP == OP_PKADDU16) ASM2("v_pk_add_u16")
+    if (OP == OP_PKADDH) ASM2("v_pk_add_f16")
+    if (OP == OP_OR) ASM2("v_or_b32")
+    if (OP == OP_MOV) { unsigned r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(a)); return r; }
+    if (OP == OP_LSHR) { unsigned r; asm volatile("v_lshrrev_b32 %0, 1, %1" : "=v"(r) : "v"(a)); return r; }
+    if (OP == OP_MAXU) ASM2("v_max_u32")
+    if (OP == OP_MINH) ASM2("v_min_f16")
+    if (OP == OP_MINU16) ASM2("v_min_u16")
+    if (OP == OP_NOT) { unsigned r; asm volatile("v_not_b32 %0, %1" : "=v"(r) : "v"(a)); return r; }
+    if (OP == OP_CVTUB) { unsigned r; asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(a)); return r; }
+    if (OP == OP_FMUL) ASM2("v_mul_f32")
+    if (OP == OP_PKFMAH) ASM3("v_pk_fma_f16")
+    if (OP == OP_MAX3F) ASM3("v_max3_f32")
+    if (OP == OP_MIN3U16) ASM3("v_min3_u16")
+    if (OP == OP_MAX3U16) ASM3("v_max3_u16")
+    if (OP == OP_MED3U16) ASM3("v_med3_u16")
+    if (OP == OP_MAXU16) ASM2("v_max_u16")
+    if (OP == OP_MAXI16) ASM2("v_max_i16")
+    if (OP == OP_SUBU16) ASM2("v_sub_u16")
+    if (OP == OP_ADDU16) ASM2("v_add_u16")
+    if (OP == OP_MADU16) ASM3("v_mad_u16")
+    if (OP == OP_LSHLB16) { unsigned r; asm volatile("v_lshlrev_b16 %0, 3, %1" : "=v"(r) : "v"(a)); return r; }
+    if (OP == OP_CNDMASK) { unsigned r; asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(r) : "v"(a), "v"(b) : "vcc"); return r; }
+    if (OP == OP_ADDC) { unsigned r; asm volatile("v_addc_co_u32 %0, vcc, %1, %2, vcc" : "=v"(r) : "v"(a), "v"(b) : "vcc"); return r; }
+    if (OP == OP_BFI) ASM3("v_bfi_b32")
+    if (OP == OP_MINI32) ASM2("v_min_i32")
+    if (OP == OP_MINU16SDWA) { unsigned r; asm volatile("v_min_u16_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    if (OP == OP_ADDSDWA) { unsigned r; asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    if (OP == OP_MULU16) ASM2("v_mul_lo_u16")
+    if (OP == OP_MIN3F16) ASM3("v_min3_f16")
+    if (OP == OP_CMPCND) { unsigned r; asm volatile("v_cmp_gt_u16 vcc, %1, %2\n\tv_cndmask_b32 %0, %1, %2, vcc" : "=v"(r) : "v"(a), "v"(b) : "vcc"); return r; }
+    if (OP == OP_ALIGNBIT) { unsigned r; asm volatile("v_alignbit_b32 %0, %1, %2, 1" : "=v"(r) : "v"(a), "v"(b)); return r; }
     return a;
 }
 __device__ __forceinline__ unsigned long long pkfma(unsigned long long a, unsigned long long b, unsigned long long c)
@@ -143,5 +185,13 @@ int main()
     run<OP_AND>(out, stamps, host); run<OP_LSHL>(out, stamps, host); run<OP_MIN>(out, stamps, host); run<OP_MED3>(out, stamps, host); run<OP_BFE>(out, stamps, host);
     run<OP_ADD3>(out, stamps, host); run<OP_LSHLADD>(out, stamps, host); run<OP_ANDOR>(out, stamps, host); run<OP_PKSUB>(out, stamps, host); run<OP_PKMAX>(out, stamps, host);
     run<OP_MULLO>(out, stamps, host); run<OP_SUB>(out, stamps, host);
+    run<OP_FMIN>(out, stamps, host); run<OP_FMAX>(out, stamps, host); run<OP_PKMINH>(out, stamps, host); run<OP_PKMAXH>(out, stamps, host); run<OP_PKADDU16>(out, stamps, host);
+    run<OP_PKADDH>(out, stamps, host); run<OP_OR>(out, stamps, host); run<OP_MOV>(out, stamps, host); run<OP_LSHR>(out, stamps, host); run<OP_MAXU>(out, stamps, host);
+    run<OP_MINH>(out, stamps, host); run<OP_MINU16>(out, stamps, host); run<OP_NOT>(out, stamps, host); run<OP_CVTUB>(out, stamps, host); run<OP_FMUL>(out, stamps, host);
+    run<OP_PKFMAH>(out, stamps, host); run<OP_MAX3F>(out, stamps, host); run<OP_ALIGNBIT>(out, stamps, host);
+    run<OP_MIN3U16>(out, stamps, host); run<OP_MAX3U16>(out, stamps, host); run<OP_MED3U16>(out, stamps, host); run<OP_MAXU16>(out, stamps, host); run<OP_MAXI16>(out, stamps, host);
+    run<OP_SUBU16>(out, stamps, host); run<OP_ADDU16>(out, stamps, host); run<OP_MADU16>(out, stamps, host); run<OP_LSHLB16>(out, stamps, host); run<OP_CNDMASK>(out, stamps, host);
+    run<OP_ADDC>(out, stamps, host); run<OP_BFI>(out, stamps, host); run<OP_MINI32>(out, stamps, host); run<OP_MINU16SDWA>(out, stamps, host); run<OP_ADDSDWA>(out, stamps, host);
+    run<OP_MULU16>(out, stamps, host); run<OP_MIN3F16>(out, stamps, host); run<OP_CMPCND>(out, stamps, host);
     return 0;
 }
