@@ -452,8 +452,8 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
     alg = algorithmic_bytes(W, H, K)
     merge_orient(alg, stage_ms, alone_ms)
     if mt is not None:
-        stage_ms["match_distances"] = float(match_split[0])   # k_bow_order + k_bow_topk
-        stage_ms["match_replay"] = float(match_split[1])      # k_bow_greedy (sequential greedy assignment, latency bound)
+        stage_ms["match_distances"] = float(match_split[0])   # k_bow_topk
+        stage_ms["match_replay"] = float(match_split[1])      # k_bow_order + k_bow_greedy (sequential greedy assignment, latency bound)
         alone_ms["match_distances"], alone_ms["match_replay"] = float(alone_match[0]), float(alone_match[1])
         alg["match_distances"] = alg.pop("match")
         alg["match_replay"] = 8 * int(K)                      # reads the candidate lists' heads, writes one result per query

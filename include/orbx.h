@@ -550,7 +550,7 @@ int orbx_stereo_match(orbx_matcher *m, const orbx_feature_set *left_host, const 
  * the previous orbx_matcher_last_timing (at most the last 64 calls). */
 int orbx_matcher_last_timing(orbx_matcher *m, float *total_ms);
 /* Split of the SearchByBoW calls averaged by the previous orbx_matcher_last_timing: the distance /
- * candidate-list kernels (k_bow_order + k_bow_topk) and the greedy replay (k_bow_greedy). */
+ * candidate-list kernel (k_bow_topk) and the greedy replay with its preparation (k_bow_order + k_bow_greedy). */
 int orbx_matcher_last_kernel_timing(orbx_matcher *m, float *distance_ms, float *replay_ms);
 
 
