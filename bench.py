@@ -61,20 +61,23 @@ def close_handles():
 
 def valu_evidence():
     """VALU issue ceilings in G wave64-instructions/s for the chip (256 CUs x 4 SIMDs), with where they come from:
-    profiles/r04_valu_issue.txt = the raw output of tools/ubench_valu.hip on the MI355X (27 opcodes, cycles per wave-instruction per SIMD from the
-    kernel's duration, clock measured in the kernel): two classes, ~2.2 cycles (add / sub / and / xor / f32 add / fma) and ~4.1 cycles (shifts, min / max,
-    bcnt, perm, alignbyte, dot2 / dot4, sad, mad, bfe, three-operand and packed ops - what the byte kernels here are made of);
-    profiles/r04_valu_mix.json = the static opcode mix of every kernel priced with that table (tools/valu_mix.py).  The guide's figure
+    profiles/r05_valu_issue.txt = the raw output of tools/ubench_valu.hip on the MI355X (63 opcodes - 27 in round 4 -, cycles per wave-instruction per SIMD
+    from the kernel's duration, clock measured in the kernel): two classes, ~2.2 cycles (add / sub / and / or / xor / mov / v_lshrrev_b32 / f32 add, mul, fma,
+    the two-operand 16-bit integer forms, compares) and ~4.1 cycles (left shifts, 32-bit and f32 min / max, bcnt, perm, alignbyte, dot2 / dot4, sad, mad, bfe,
+    cndmask, three-operand and packed ops - what the byte kernels here are made of);
+    profiles/r05_valu_mix.json = the static opcode mix of every kernel priced with that table (tools/valu_mix.py).  The guide's figure
     (MI355X_MICROARCH.md, "Wave scheduling": 2 cycles per wave64 instruction) is carried beside them."""
     clk, c_half, c_full, mix = 2.4, 4.0, 2.2, {}
-    src = []
-    try:
-        d = json.loads((ROOT / "profiles" / "r04_valu_mix.json").read_text())
-        clk, c_half, c_full = float(d["clock_GHz_median"]), float(d["cycles_half_rate_class"]), float(d["cycles_full_rate_class"])
-        mix = {k: float(v["cycles_per_instr_static_mix"]) for k, v in d["kernels"].items()}
-        src = ["profiles/r04_valu_issue.txt (tools/ubench_valu.hip, raw)", "profiles/r04_valu_mix.json (tools/valu_mix.py)"]
-    except Exception:
-        src = ["built-in defaults: profiles/r04_valu_mix.json not readable"]
+    src = ["built-in defaults: profiles/r05_valu_mix.json / r04_valu_mix.json not readable"]
+    for tag in ("r05", "r04"):
+        try:
+            d = json.loads((ROOT / "profiles" / (tag + "_valu_mix.json")).read_text())
+            clk, c_half, c_full = float(d["clock_GHz_median"]), float(d["cycles_half_rate_class"]), float(d["cycles_full_rate_class"])
+            mix = {k: float(v["cycles_per_instr_static_mix"]) for k, v in d["kernels"].items()}
+            src = ["profiles/%s_valu_issue.txt (tools/ubench_valu.hip, raw)" % tag, "profiles/%s_valu_mix.json (tools/valu_mix.py)" % tag]
+            break
+        except Exception:
+            continue
     simds = 256 * 4
     return {"clock_GHz": clk, "cycles_half_rate_class": c_half, "cycles_full_rate_class": c_full, "mix": mix, "evidence": src,
             "peak_half_rate": simds * clk / c_half, "peak_full_rate": simds * clk / c_full, "peak_guide_2cycle": simds * 2.4 / 2.0}
@@ -504,8 +507,8 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
         peak_mix = tot / t_mix / 1e9 if t_mix > 0 else VALU_PEAK_GINST
         roofline_valu = {"bound": "valu_issue", "unit": "G wave-instr/s", "peak": round(VALU_PEAK_GINST, 1),
                          "achieved": round(rate, 2), "frac": round(rate / VALU_PEAK_GINST, 4),
-                         "peak_basis": "measured: %.2f cycles per wave64 instruction per SIMD for the half-rate class (shifts, min / max, bcnt, perm, alignbyte, dot2 / dot4, sad, "
-                                       "packed-16), %.2f for add / sub / and / xor / f32 add / fma, at %.2f GHz" % (VALU["cycles_half_rate_class"], VALU["cycles_full_rate_class"], VALU["clock_GHz"]),
+                         "peak_basis": "measured: %.2f cycles per wave64 instruction per SIMD for the half-rate class (left shifts, 32-bit min / max, bcnt, perm, alignbyte, dot2 / dot4, sad, "
+                                       "cndmask, packed-16), %.2f for add / sub / and / or / xor / mov / f32 add / fma / two-operand 16-bit, at %.2f GHz" % (VALU["cycles_half_rate_class"], VALU["cycles_full_rate_class"], VALU["clock_GHz"]),
                          "evidence": VALU["evidence"],
                          "peak_static_mix": round(peak_mix, 1), "frac_static_mix": round(rate / peak_mix, 4),
                          "peak_guide_2cycle": round(VALU["peak_guide_2cycle"], 1), "frac_guide_2cycle": round(rate / VALU["peak_guide_2cycle"], 4),

@@ -7,6 +7,7 @@
 //   class, cycles per wave-instruction per SIMD (from the kernel's duration), chip rate in G wave-instr/s, clock, the waves' own loop time
 // bench.py's roofline_valu takes its peak from this file's "integer byte/packed" classes; the guide's figure for
 // comparison is 2 cycles per wave64 instruction per SIMD (MI355X_MICROARCH.md, "Wave scheduling").
+// Round 5 added 36 opcodes (f32 / f16 min and max, the 16-bit integer forms with two and three operands, SDWA byte selects, v_cndmask, v_addc, ...).
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_valu tools/ubench_valu.hip && tools/ubench_valu
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -87,7 +88,7 @@ template <int OP> __device__ __forceinline__ unsigned op(unsigned a, unsigned b,
     if (OP == OP_ADDU16) ASM2("v_add_u16")
     if (OP == OP_MADU16) ASM3("v_mad_u16")
     if (OP == OP_LSHLB16) { unsigned r; asm volatile("v_lshlrev_b16 %0, 3, %1" : "=v"(r) : "v"(a)); return r; }
-    if (OP == OP_CNDMASK) { unsigned r; asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(r) : "v"(a), "v"(b) : "vcc"); return r; }
+    if (OP == OP_CNDMASK) { unsigned r; const unsigned long long sel = 0x5555aaaa3333ccccull; asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(sel)); return r; }
     if (OP == OP_ADDC) { unsigned r; asm volatile("v_addc_co_u32 %0, vcc, %1, %2, vcc" : "=v"(r) : "v"(a), "v"(b) : "vcc"); return r; }
     if (OP == OP_BFI) ASM3("v_bfi_b32")
     if (OP == OP_MINI32) ASM2("v_min_i32")
