@@ -490,6 +490,12 @@ def bench_extract_match(a, orbx, torch, grp, dev_t, local, rank_info):
                 "stage_ms_contended": {k: round(v, 4) for k, v in stage_ms.items()},
                 "stage_frac_of_hbm_peak_alone": {k: round(alg[k] * B / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in alone_ms.items() if alg.get(k, 0) > 0 and v > 0},
                 "measured_copy_GBs": round(copy_bw, 1), "frac_of_measured_copy": round(achieved / copy_bw, 5),
+                # the two longest kernels of the path (the detector and the matcher's distance kernel) are within a few per cent of each other: whichever
+                # is `kernel` above on this box, both are priced here (the matcher's is a popcount kernel: its bytes are 2 x 32 KB of descriptors per
+                # frame pair, its bound is VALU issue - roofline_valu -, its HBM fraction says nothing about it)
+                "longest_kernels_alone": {STAGE_KERNEL.get(k, k): {"avg_launch_ms": round(ref_ms[k], 4), "achieved": round(alg[k] * B / (ref_ms[k] * 1e-3) / 1e9, 2),
+                                                                   "frac": round(alg[k] * B / (ref_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                                          for k in sorted((k for k in ref_ms if alg.get(k, 0) > 0), key=lambda k: -ref_ms[k])[:3]},
                 "whole_path": {"algorithmic_bytes_per_frame": int(sum(alg.values())), "achieved": round(whole_gbs, 2), "frac": round(whole_gbs / HBM_PEAK_GBS, 5),
                                "note": "all stages' algorithmic bytes / wall time per step (the driver-visible rate)"}}
     # the bound the path actually runs into: VALU issue (integer byte arithmetic), from the committed SQ_INSTS_VALU pass
