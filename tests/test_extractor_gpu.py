@@ -329,3 +329,31 @@ def test_wide_images_with_five_to_eight_initial_quadtree_nodes(orbx, oracle, W, 
         k1, d1 = one(im)
         assert len(k1) == n and (kp_matrix(k1).view(np.uint32) == ko.view(np.uint32)).all() and (d1 == do).all()
     ext.close(); one.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("taps", [(19, 34, 48, 56, 48, 34, 18), (10, 30, 50, 76, 50, 30, 10), (4, 20, 60, 88, 52, 24, 8), (0, 0, 0, 255, 2, 0, 0)])
+def test_blur_with_configured_taps(orbx, oracle, taps):
+    """orbx_extractor_config::gauss_taps (include/orbx.h): the 7x7 blur in 8-bit fixed point with the caller's taps - a set that sums to 257 (the clamping
+    instantiation of k_blur / k_octree_blur: a white patch reaches 257 before the clamp), one that sums to 256, an asymmetric one (even and odd output rows of
+    the vertical pass use different tap pairs) and a near-identity.  Batch path and combined single-frame path against op_gauss7_u8 of the restatement."""
+    W, H, nf = 640, 480, 1000
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2, gauss_taps=taps)
+    ext.set_debug_taps(True)
+    rst = oracle.restatement(nf)
+    white = np.full((H, W), 255, np.uint8)
+    white[::37, ::41] = 0                 # (a few corners, so that every level has keypoints)
+    frames = [orbx.synth_frame(61, W, H), white]
+    ext.extract_batch(frames)
+    for f, im in enumerate(frames):
+        pyr = oracle.pyramid(rst, im)
+        for l in range(8):
+            want = oracle.blur(pyr[l], taps)
+            got = ext.mvImagePyramid(l, frame=f, blurred=True)
+            assert (got == want).all(), "batch path: frame %d level %d" % (f, l)
+    for im in frames:                     # the single-frame path (k_octree_blur in the combined launch set)
+        ext(im)
+        pyr = oracle.pyramid(rst, im)
+        for l in range(8):
+            assert (ext.mvImagePyramid(l, frame=0, blurred=True) == oracle.blur(pyr[l], taps)).all(), "single-frame path: level %d" % l
+    ext.close()
