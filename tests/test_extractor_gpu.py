@@ -351,9 +351,48 @@ def test_blur_with_configured_taps(orbx, oracle, taps):
             want = oracle.blur(pyr[l], taps)
             got = ext.mvImagePyramid(l, frame=f, blurred=True)
             assert (got == want).all(), "batch path: frame %d level %d" % (f, l)
-    for im in frames:                     # the single-frame path (k_octree_blur in the combined launch set)
-        ext(im)
+    kps, desc, counts = ext.extract_batch(frames)
+    # the single-frame paths: a one-frame handle with the taps on (its own graph: k_octree + k_blur, the blurred levels can be read back), and without
+    # them (the combined launch set: k_octree_blur, whose blurred pyramid stays on the shared engine - its descriptors must be the batch path's)
+    one = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=1, gauss_taps=taps)
+    for f, im in enumerate(frames):
+        k1, d1 = one(im)
+        n = int(counts[f])
+        assert len(k1) == n and (kp_matrix(k1).view(np.uint32) == kp_matrix(kps[f, :n]).view(np.uint32)).all() and (d1 == desc[f, :n]).all(), "combined single-frame path, frame %d" % f
+    one.set_debug_taps(True)
+    for im in frames:
+        one(im)
         pyr = oracle.pyramid(rst, im)
         for l in range(8):
-            assert (ext.mvImagePyramid(l, frame=0, blurred=True) == oracle.blur(pyr[l], taps)).all(), "single-frame path: level %d" % l
+            assert (one.mvImagePyramid(l, frame=0, blurred=True) == oracle.blur(pyr[l], taps)).all(), "single-frame path: level %d" % l
+    one.close()
+    ext.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,nf", [(640, 480, 1000), (752, 480, 2000)])
+def test_white_noise_and_saturated_frames(orbx, oracle, W, H, nf):
+    """Inputs at the ends of the detector's range: uniform white noise (a third of all pixels pass the compass pre-test: the exact-score phase runs its
+    maximum number of passes per cell, the candidate lists are at their densest), a two-level noise image (every arc maximal), a frame of isolated
+    single-pixel spikes (each one the only keypoint of its cell) - batch path and single-frame path against the restatement."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    noise = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    two = np.where(rng.integers(0, 2, (H, W)) > 0, 255, 0).astype(np.uint8)
+    spikes = np.full((H, W), 90, np.uint8)
+    spikes[20::31, 23::29] = 200
+    frames = [noise, two, spikes]
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=len(frames))
+    rst = oracle.restatement(nf)
+    kps, desc, counts = ext.extract_batch(frames)
+    for f, im in enumerate(frames):
+        ko, do = rst.extract(im)
+        n = int(counts[f])
+        assert n == len(ko), "frame %d: %d keypoints, the restatement finds %d" % (f, n, len(ko))
+        assert (kp_matrix(kps[f, :n]).view(np.uint32) == ko.view(np.uint32)).all() and (desc[f, :n] == do).all(), "frame %d" % f
+    one = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=1)      # (a one-frame handle: the combined single-frame launch set)
+    for f, im in enumerate(frames):
+        ko, do = rst.extract(im)
+        k1, d1 = one(im)
+        assert len(k1) == len(ko) and (kp_matrix(k1).view(np.uint32) == ko.view(np.uint32)).all() and (d1 == do).all(), "single-frame path, frame %d" % f
+    one.close()
     ext.close()
