@@ -138,14 +138,20 @@ int orbx_extract(orbx_extractor *h, const uint8_t *image, int width, int height,
 
 /* Batched form: `batch` independent frames of identical size.  Frame f writes
  * keypoints[f*capacity ...], descriptors[f*capacity*32 ...], counts[f].
- * Equivalent to `batch` operator() calls; the frames are data-parallel on the GPU. */
+ * Equivalent to `batch` operator() calls; the frames are data-parallel on the GPU.
+ * A batch of 2 x ORBX_HOST_BATCH_CHUNK frames (environment, default 64; 0 = never) or more runs as a pipeline over chunks (staging / upload of
+ * chunk c+1 and read-back of chunk c-1 under the kernels of chunk c).  The caller's arrays receive the whole batch either way, but after a
+ * CHUNKED call the handle's device buffers hold only its last chunk: every "last batch" device-side view below (orbx_batch_results_device,
+ * orbx_batch_status_device, orbx_extractor_status, orbx_batch_download, orbx_download_pyramid*, the debug taps, and the matcher / frame-finish
+ * entry points that read the extractor's last batch) then returns ORBX_ERR_STATE instead of indexing a chunk.  Callers that want the results on
+ * the device use orbx_upload_frames + orbx_extract_batch_device (or set ORBX_HOST_BATCH_CHUNK=0). */
 int orbx_extract_batch(orbx_extractor *h, const uint8_t *const *images, int batch, int width,
                        int height, int stride, orbx_keypoint *keypoints, uint8_t *descriptors,
                        int capacity, int *counts);
 
 /* The same call as a two-deep pipeline (SURVEY.md 8b's batch entry point with host pointers; replaces a loop of operator() calls,
- * include/ORBextractor.h:110, src/Frame.cc:394).  _begin stages and uploads the frames (frames that already live in pinned or registered
- * host memory are read in place), enqueues the batch's launch set and the read-back of its results, and returns without waiting; _end waits
+ * include/ORBextractor.h:110, src/Frame.cc:394).  _begin stages and uploads the frames (a batch whose frames ALL live in pinned or registered
+ * host memory - every byte of every frame, checked per frame - is read in place; one pageable frame and the whole batch is staged), enqueues the batch's launch set and the read-back of its results, and returns without waiting; _end waits
  * for the OLDEST begun batch and fills the caller's arrays exactly like orbx_extract_batch.  Up to two batches may be begun before the first
  * _end: staging + upload of batch i+1 and the read-back of batch i-1 then run under the kernels of batch i.  The images of a batch must stay
  * valid until its _begin returns (pinned / registered images: until its _end returns).  A third _begin, or an _end with nothing begun,
@@ -162,7 +168,8 @@ int orbx_extract_batch_end(orbx_extractor *h, orbx_keypoint *keypoints, uint8_t 
 int orbx_extract_batch_device(orbx_extractor *h, const void *images_dev, int batch, int width,
                               int height, int stride, size_t frame_pitch);
 /* Device pointers of the last batch's results: keypoints[f*cap + i], descriptors
- * [(f*cap + i)*32], counts[f]; *capacity = per-frame capacity of those arrays. */
+ * [(f*cap + i)*32], counts[f]; *capacity = per-frame capacity of those arrays.  "Last batch" = the last orbx_extract_batch_device /
+ * single-frame / un-chunked host call (ORBX_ERR_STATE after a chunked orbx_extract_batch, see there). */
 int orbx_batch_results_device(orbx_extractor *h, const orbx_keypoint **keypoints_dev,
                               const uint8_t **descriptors_dev, const int32_t **counts_dev,
                               int *capacity);

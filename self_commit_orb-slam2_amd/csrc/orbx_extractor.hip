@@ -111,6 +111,7 @@ struct orbx_extractor {
     int allocBatch = 0;
     // last run
     int lastBatch = 0;
+    bool lastChunked = false;         // the last call was a host batch pipelined in chunks: the device holds its LAST chunk only, lastBatch = 0 (no device-side view)
     const uint8_t *lastImg0 = nullptr;
     int lastStride = 0;
     size_t lastFramePitch = 0;
@@ -510,7 +511,7 @@ int run_batch(orbx_extractor *h, const uint8_t *img0Dev, int batch, int W, int H
     if ((rc = orbx_launch_orient_describe(L)) != ORBX_OK) return rc;
     if (prof) { ORBX_HIP_CHECK(hipEventRecord(ev[ST_DESC + 1], h->stream)); h->profCount++; }
     h->lastBatch = batch; h->lastImg0 = img0Dev; h->lastStride = stride; h->lastFramePitch = framePitch;
-    h->lastCombined = false; h->hostSynced = false;
+    h->lastCombined = false; h->hostSynced = false; h->lastChunked = false;
     return ORBX_OK;
 }
 
@@ -626,6 +627,15 @@ int upload(orbx_extractor *h, const uint8_t *const *images, int batch, int W, in
 
 }  // namespace
 
+static int no_batch_error(const orbx_extractor *h)
+{
+    if (h->lastChunked)
+        orbx_set_error("the last call was a host batch pipelined in chunks (orbx_extract_batch with batch >= 2 x ORBX_HOST_BATCH_CHUNK): its results went to the caller's "
+                       "arrays and the device keeps the last chunk only - for device-side results use orbx_upload_frames + orbx_extract_batch_device, or ORBX_HOST_BATCH_CHUNK=0");
+    else orbx_set_error("no batch has been extracted yet");
+    return ORBX_ERR_STATE;
+}
+
 hipStream_t orbx_extractor_stream_internal(orbx_extractor *h) { return h ? h->stream : nullptr; }
 /* true: the handle's last call was a synchronous single-frame call - its results are complete (no event to wait for) and *status is its
  * capacity word, read from the pinned result arena */
@@ -641,7 +651,7 @@ void orbx_extractor_set_pyramid_consumer_event_internal(orbx_extractor *h, hipEv
 int orbx_extractor_last_batch_view_internal(orbx_extractor *h, OrbxLastBatchView *v)
 {
     if (!h || !v) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
-    if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
+    if (!h->lastBatch) return no_batch_error(h);
     v->batch = h->lastBatch; v->nlevels = h->geom.nlevels; v->cap = h->geom.outCap;
     v->kp = h->outKpP[h->cur]; v->desc = h->outDescP[h->cur]; v->counts = h->outCntP[h->cur];
     v->img0 = h->lastImg0; v->img0Stride = h->lastStride; v->img0FramePitch = h->lastFramePitch;
@@ -820,7 +830,7 @@ extern "C" int orbx_batch_results_device(orbx_extractor *h, const orbx_keypoint 
                                          const int32_t **counts_dev, int *capacity)
 {
     if (!h) { orbx_set_error("NULL handle"); return ORBX_ERR_ARG; }
-    if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
+    if (!h->lastBatch) return no_batch_error(h);
     if (keypoints_dev) *keypoints_dev = h->outKpP[h->cur];
     if (descriptors_dev) *descriptors_dev = h->outDescP[h->cur];
     if (counts_dev) *counts_dev = h->outCntP[h->cur];
@@ -831,7 +841,7 @@ extern "C" int orbx_batch_results_device(orbx_extractor *h, const orbx_keypoint 
 extern "C" int orbx_extractor_status(orbx_extractor *h, int32_t *bits)
 {
     if (!h || !bits) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
-    if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
+    if (!h->lastBatch) return no_batch_error(h);
     ORBX_HIP_CHECK(hipSetDevice(h->cfg.device));
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     int v = 0;
@@ -843,7 +853,7 @@ extern "C" int orbx_extractor_status(orbx_extractor *h, int32_t *bits)
 extern "C" int orbx_batch_status_device(orbx_extractor *h, const int32_t **status_dev, int *batch)
 {
     if (!h || !status_dev) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
-    if (!h->lastBatch) { orbx_set_error("no batch has been extracted yet"); return ORBX_ERR_STATE; }
+    if (!h->lastBatch) return no_batch_error(h);
     *status_dev = h->outStP[h->cur];
     if (batch) *batch = h->lastBatch;
     return ORBX_OK;
@@ -1681,6 +1691,47 @@ static bool host_pointer_is_pinned(const void *p)      // hipHostMalloc'ed or hi
     return a.type == hipMemoryTypeHost;
 }
 
+// Whether EVERY byte of every frame of a batch lies in pinned / registered host memory (k_gather_frames and the DMA engines dereference the
+// frames where they are: one pageable frame in the middle of a pinned batch is a GPU memory fault, not an error code).  The runtime is asked
+// for the allocation range around a frame's first byte once per distinct allocation (a pool of 256 frames in one hipHostMalloc costs one
+// query); a frame has to lie inside ONE such range from its first to its last byte.  When the runtime does not report ranges, the first and the
+// last byte of every frame are queried.  The answer is only good for this call (memory may be unregistered between calls): nothing is kept.
+static bool host_frames_all_pinned(const uint8_t *const *images, int batch, size_t frameBytes)
+{
+    struct Range { uintptr_t lo, hi; };
+    Range known[8];
+    int nk = 0;
+    for (int f = 0; f < batch; f++) {
+        const uintptr_t a = (uintptr_t)images[f], b = a + frameBytes;      // [a, b)
+        bool inside = false;
+        for (int k = 0; k < nk && !inside; k++) inside = a >= known[k].lo && b <= known[k].hi;
+        if (inside) continue;
+        if (!host_pointer_is_pinned(images[f])) return false;
+        void *base = nullptr;
+        size_t size = 0;
+        if (hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)images[f]) == hipSuccess &&
+            hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, (hipDeviceptr_t)images[f]) == hipSuccess && base && size &&
+            (uintptr_t)base <= a && a < (uintptr_t)base + size) {
+            if (b > (uintptr_t)base + size) {
+                // the frame runs past the end of this allocation: the rest may be another registration right behind it, or pageable memory
+                if (!host_pointer_is_pinned((const void *)(b - 1))) return false;
+                void *base2 = nullptr;
+                if (hipPointerGetAttribute(&base2, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)(b - 1)) != hipSuccess || (uintptr_t)base2 != (uintptr_t)base + size) {
+                    (void)hipGetLastError();
+                    return false;      // (a gap between two registrations cannot be ruled out: stage the batch)
+                }
+                continue;
+            }
+            if (nk < 8) known[nk++] = Range{(uintptr_t)base, (uintptr_t)base + size};
+            else known[f & 7] = Range{(uintptr_t)base, (uintptr_t)base + size};
+        } else {
+            (void)hipGetLastError();
+            if (!host_pointer_is_pinned((const void *)(b - 1))) return false;
+        }
+    }
+    return true;
+}
+
 extern "C" int orbx_extract_batch_begin(orbx_extractor *h, const uint8_t *const *images, int batch, int width, int height, int stride)
 {
     if (!h || !images) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
@@ -1704,7 +1755,11 @@ extern "C" int orbx_extract_batch_begin(orbx_extractor *h, const uint8_t *const 
     size_t fp = align_up((size_t)dstStride * H + 256, 256);
     orbx_extractor::PipeSlot &S = h->pipe[(h->pipeHead + h->pipeCount) & 1];      // free: whatever used it last has been ended
     const auto tB0 = std::chrono::steady_clock::now();
-    const bool pinned = host_pointer_is_pinned(images[0]) && host_pointer_is_pinned(images[batch - 1] + (size_t)stride * (size_t)(H - 1) + (size_t)W - 1);
+    // decided per frame: a batch with ONE pageable frame between pinned ones is staged as a whole (the gather kernel and the DMA engines would fault on it)
+    static const bool forceStage = getenv("ORBX_HOST_FORCE_STAGE") && getenv("ORBX_HOST_FORCE_STAGE")[0] == '1';
+    const bool pinned = !forceStage && host_frames_all_pinned(images, batch, (size_t)stride * (size_t)(H - 1) + (size_t)W);
+    // an error return below, once copies are enqueued, first lets them finish: the slot's pinned input (or the caller's frames) and devIn are reused / freed by the next call
+    auto drain = [&](int code) { (void)hipStreamSynchronize(h->upStream); (void)hipStreamSynchronize(h->stream); return code; };
     // packed frames back to back in pinned memory (one (B, H, W) array): the device layout takes the same frame pitch and the batch is ONE copy
     bool oneCopy = pinned && stride == dstStride && ((size_t)stride * H) % 16 == 0;
     for (int f = 1; f < batch && oneCopy; f++) oneCopy = images[f] == images[0] + (size_t)f * stride * H;
@@ -1728,14 +1783,17 @@ extern "C" int orbx_extract_batch_begin(orbx_extractor *h, const uint8_t *const 
                 S.ptrTabBytes = nb;
             }
             for (int f = 0; f < batch; f++) S.ptrTab[f] = images[f];
-            if ((rc = orbx_launch_gather_frames(h->upStream, (const uint8_t *const *)S.ptrTab, batch, W, H, stride, S.devIn.p, dstStride, fp, al16)) != ORBX_OK) return rc;
+            if ((rc = orbx_launch_gather_frames(h->upStream, (const uint8_t *const *)S.ptrTab, batch, W, H, stride, S.devIn.p, dstStride, fp, al16)) != ORBX_OK) return drain(rc);
             gathered = true;
         }
     }
     if (gathered) {
     } else if (pinned) {
         for (int f = 0; f < batch; f++)
-            ORBX_HIP_CHECK(hipMemcpy2DAsync(S.devIn.p + fp * (size_t)f, (size_t)dstStride, images[f], (size_t)stride, (size_t)W, (size_t)H, hipMemcpyHostToDevice, h->upStream));
+            if (hipMemcpy2DAsync(S.devIn.p + fp * (size_t)f, (size_t)dstStride, images[f], (size_t)stride, (size_t)W, (size_t)H, hipMemcpyHostToDevice, h->upStream) != hipSuccess) {
+                orbx_set_error("upload of frame %d failed: %s", f, hipGetErrorString(hipGetLastError()));
+                return drain(ORBX_ERR_HIP);
+            }
     } else {
         if (bytes > S.hostInBytes) {
             if (S.hostIn) (void)hipHostFree(S.hostIn);
@@ -1756,13 +1814,15 @@ extern "C" int orbx_extract_batch_begin(orbx_extractor *h, const uint8_t *const 
                             hipMemcpyAsync(S.devIn.p + fp * (size_t)f0, S.hostIn + fp * (size_t)f0, fp * (size_t)(f1 - f0), hipMemcpyHostToDevice, h->upStream) != hipSuccess))
                 failed.store(1);
         });
-        if (failed.load()) { orbx_set_error("upload of the batch failed: %s", hipGetErrorString(hipGetLastError())); return ORBX_ERR_HIP; }
+        if (failed.load()) { orbx_set_error("upload of the batch failed: %s", hipGetErrorString(hipGetLastError())); return drain(ORBX_ERR_HIP); }
     }
     const auto tB1 = std::chrono::steady_clock::now();
-    ORBX_HIP_CHECK(hipEventRecord(S.evUp, h->upStream));
-    ORBX_HIP_CHECK(hipStreamWaitEvent(h->stream, S.evUp, 0));
-    if ((rc = run_batch(h, S.devIn.p, batch, W, H, dstStride, fp)) != ORBX_OK) return rc;
-    ORBX_HIP_CHECK(hipEventRecord(S.evKern, h->stream));
+    if (hipEventRecord(S.evUp, h->upStream) != hipSuccess || hipStreamWaitEvent(h->stream, S.evUp, 0) != hipSuccess) {
+        orbx_set_error("ordering the launch set behind the upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return drain(ORBX_ERR_HIP);
+    }
+    if ((rc = run_batch(h, S.devIn.p, batch, W, H, dstStride, fp)) != ORBX_OK) return drain(rc);
+    if (hipEventRecord(S.evKern, h->stream) != hipSuccess) { orbx_set_error("hipEventRecord: %s", hipGetErrorString(hipGetLastError())); return drain(ORBX_ERR_HIP); }
     // read-back: counts and capacity words, then the keypoint / descriptor arrays of the batch's frames (the arena is laid out for allocBatch frames)
     const int cap = h->geom.outCap, cb = h->cur;
     const size_t B = (size_t)batch;
@@ -1772,15 +1832,23 @@ extern "C" int orbx_extract_batch_begin(orbx_extractor *h, const uint8_t *const 
     if (resBytes > S.hostResBytes) {
         if (S.hostRes) (void)hipHostFree(S.hostRes);
         S.hostRes = nullptr; S.hostResBytes = 0;
-        ORBX_HIP_CHECK(hipHostMalloc((void **)&S.hostRes, resBytes, hipHostMallocDefault));
+        if (hipHostMalloc((void **)&S.hostRes, resBytes, hipHostMallocDefault) != hipSuccess) {
+            S.hostRes = nullptr;
+            orbx_set_error("hipHostMalloc of %zu result bytes failed: %s", resBytes, hipGetErrorString(hipGetLastError()));
+            return drain(ORBX_ERR_HIP);
+        }
         S.hostResBytes = resBytes;
     }
-    ORBX_HIP_CHECK(hipStreamWaitEvent(h->downStream, S.evKern, 0));
-    ORBX_HIP_CHECK(hipMemcpyAsync(S.hostRes, h->outCntP[cb], B * sizeof(int), hipMemcpyDeviceToHost, h->downStream));
-    ORBX_HIP_CHECK(hipMemcpyAsync(S.hostRes + S.offSt, h->outStP[cb], B * sizeof(int), hipMemcpyDeviceToHost, h->downStream));
-    ORBX_HIP_CHECK(hipMemcpyAsync(S.hostRes + S.offKp, h->outKpP[cb], B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->downStream));
-    ORBX_HIP_CHECK(hipMemcpyAsync(S.hostRes + S.offDesc, h->outDescP[cb], B * cap * 32, hipMemcpyDeviceToHost, h->downStream));
-    ORBX_HIP_CHECK(hipEventRecord(S.evDown, h->downStream));
+    if (hipStreamWaitEvent(h->downStream, S.evKern, 0) != hipSuccess ||
+        hipMemcpyAsync(S.hostRes, h->outCntP[cb], B * sizeof(int), hipMemcpyDeviceToHost, h->downStream) != hipSuccess ||
+        hipMemcpyAsync(S.hostRes + S.offSt, h->outStP[cb], B * sizeof(int), hipMemcpyDeviceToHost, h->downStream) != hipSuccess ||
+        hipMemcpyAsync(S.hostRes + S.offKp, h->outKpP[cb], B * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->downStream) != hipSuccess ||
+        hipMemcpyAsync(S.hostRes + S.offDesc, h->outDescP[cb], B * cap * 32, hipMemcpyDeviceToHost, h->downStream) != hipSuccess ||
+        hipEventRecord(S.evDown, h->downStream) != hipSuccess) {
+        orbx_set_error("read-back of the batch could not be enqueued: %s", hipGetErrorString(hipGetLastError()));
+        (void)hipStreamSynchronize(h->downStream);
+        return drain(ORBX_ERR_HIP);
+    }
     h->consumerEv[cb] = S.evDown;      // the batch after the next one overwrites this result buffer: only behind the read-back
     S.batch = batch; S.cap = cap;
     h->pipeCount++;
@@ -1863,6 +1931,8 @@ extern "C" int orbx_extract_batch(orbx_extractor *h, const uint8_t *const *image
             if (rce != ORBX_OK && rc == ORBX_OK) rc = rce;      // (after an error nothing more is begun: drain what was, report the first error)
             if (rc != ORBX_OK && begun == ended) break;
         }
+        // the handle's device buffers (results, pyramid, status) now hold the last chunk: no device-side view of this call (include/orbx.h, orbx_extract_batch)
+        h->lastBatch = 0; h->lastChunked = true;
         return rc;
     }
     if (h->pipeCount > 0) { orbx_set_error("orbx_extract_batch while batches begun with orbx_extract_batch_begin are in flight"); return ORBX_ERR_STATE; }

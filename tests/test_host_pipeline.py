@@ -145,3 +145,82 @@ def test_random_begin_end_schedule(orbx, oracle):
             end()
     while pending:
         end()
+
+
+def test_mixed_pinned_and_pageable_frames_in_one_batch(orbx, oracle):
+    """Pinned - pageable - pinned (and every other arrangement of two memory kinds over five frames that has a pageable frame strictly inside, at the
+    front or at the back): the gather kernel / the DMA engines must never be handed the pageable frame's address (round-5 advice: the decision looked
+    at the first byte of the first frame and the last byte of the last frame only).  Also a frame whose LAST rows leave a registered range."""
+    import torch
+    W, H, nf, B = 320, 240, 500, 5
+    rst = oracle.restatement(nf)
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
+    frames = [orbx.synth_frame(900 + i, W, H) for i in range(B)]
+    want = [rst.extract(im) for im in frames]
+    pin = torch.empty((B, H, W), dtype=torch.uint8).pin_memory()
+    ph = pin.numpy()
+    for i in range(B):
+        ph[i] = frames[i]
+    for mask in (0b00100, 0b01010, 0b00001, 0b10000, 0b01110, 0b11111, 0b00000):
+        views = [frames[i] if (mask >> i) & 1 else ph[i] for i in range(B)]
+        ext.extract_batch_begin(views)
+        kps, desc, counts = ext.extract_batch_end()
+        for i in range(B):
+            ko, do = want[i]
+            n = int(counts[i])
+            assert n == len(ko) and (kp_bits(kps[i, :n]) == ko.view(np.uint32)).all() and (desc[i, :n] == do).all(), (bin(mask), i)
+    # two separate pinned allocations and a frame view that starts in pinned memory and ends in pageable memory cannot be built from numpy without
+    # copying; what can: the frames of one batch spread over THREE pinned allocations (more distinct ranges than one query answers)
+    pins = [torch.empty((H, W), dtype=torch.uint8).pin_memory() for _ in range(B)]
+    for i in range(B):
+        pins[i].numpy()[:] = frames[i]
+    ext.extract_batch_begin([p.numpy() for p in pins])
+    kps, desc, counts = ext.extract_batch_end()
+    for i in range(B):
+        ko, do = want[i]
+        n = int(counts[i])
+        assert n == len(ko) and (kp_bits(kps[i, :n]) == ko.view(np.uint32)).all() and (desc[i, :n] == do).all(), i
+
+
+def test_registered_range_that_ends_inside_a_frame(orbx, oracle):
+    """hipHostRegister over the first frame and a half of a pageable two-frame array: frame 1 starts in registered memory and ends in pageable memory -
+    the batch must be staged (first-byte-only checks would hand the device an address it cannot read to the end)."""
+    W, H, nf = 320, 240, 500
+    rst = oracle.restatement(nf)
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2)
+    hip = ctypes.CDLL("libamdhip64.so")
+    page = 4096
+    raw = np.zeros(2 * W * H + 2 * page, np.uint8)
+    off = (-raw.ctypes.data) % page
+    arr = raw[off:off + 2 * W * H].reshape(2, H, W)
+    frames = [orbx.synth_frame(950 + i, W, H) for i in range(2)]
+    arr[0] = frames[0]; arr[1] = frames[1]
+    nreg = (W * H + W * H // 2) // page * page
+    assert hip.hipHostRegister(ctypes.c_void_p(arr.ctypes.data), ctypes.c_size_t(nreg), 0) == 0
+    try:
+        ext.extract_batch_begin([arr[0], arr[1]])
+        check(rst, frames, *ext.extract_batch_end())
+    finally:
+        assert hip.hipHostUnregister(ctypes.c_void_p(arr.ctypes.data)) == 0
+    # the same array, no longer registered: pageable, staged
+    ext.extract_batch_begin([arr[0], arr[1]])
+    check(rst, frames, *ext.extract_batch_end())
+
+
+def test_device_views_after_a_chunked_host_batch_are_state_errors(orbx):
+    """A host batch that ran in chunks leaves only its last chunk on the device: the "last batch" device views refuse (ORBX_ERR_STATE) instead of
+    indexing frame f of the last chunk; a device-resident call afterwards makes them valid again."""
+    W, H, nf, B = 320, 240, 300, 130
+    ext = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
+    frames = [orbx.synth_frame(8000 + (i % 7), W, H) for i in range(B)]
+    kps, desc, counts = ext.extract_batch(frames)
+    assert (counts > 0).all()
+    with pytest.raises(orbx.OrbxError) as e:
+        ext.results_device()
+    assert e.value.code == -5 and "chunk" in str(e.value)
+    with pytest.raises(orbx.OrbxError):
+        ext.mvImagePyramid(1, frame=0)
+    dev = ext.upload(frames[:8])
+    ext.run_device(*dev)
+    k2, d2, c2 = ext.download(8)
+    assert (c2 == counts[:8]).all() and (d2[:, :] == desc[:8]).all()
