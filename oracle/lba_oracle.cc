@@ -261,6 +261,14 @@ bool ldlt_solve(std::vector<double> &S, int n, const double *b, double *x)
 
 struct Stats { int iters, trials; double chi0, chi1, lambda; };
 
+// Test input "the caller's stop flag is raised while trial k of the call is being decided" (lo_set_stop_after_trials): g2o reads the force-stop
+// flag at the end of every Levenberg trial (optimization_algorithm_levenberg.cpp:146, `!_optimizer->terminate()`), before every iteration
+// (sparse_optimizer.cpp:370) and LocalBundleAdjustment reads it between its stages (src/Optimizer.cc:869-871).  With k > 0 the run owns a flag
+// that becomes 1 right after the k-th trial of the call (counted across both stages) has been accepted or rejected, i.e. before the first of those
+// three reads that follows it.
+static thread_local int g_stop_after = 0, g_trials_total = 0;
+static thread_local volatile uint8_t g_own_stop = 0;
+
 // SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg on the edges of level 0
 int optimize(Problem &p, int iterations, const volatile uint8_t *stop, Stats *st)
 {
@@ -416,6 +424,7 @@ int optimize(Problem &p, int iterations, const volatile uint8_t *stop, Stats *st
             }
             qmax++;
             if (st) st->trials++;
+            if (g_stop_after > 0 && ++g_trials_total >= g_stop_after) g_own_stop = 1;
         } while (rho < 0 && qmax < 10 && !(stop && *stop));
         done++;
         if (st) { st->iters = done; st->chi1 = currentChi; st->lambda = lambda; }
@@ -436,6 +445,9 @@ int optimize(Problem &p, int iterations, const volatile uint8_t *stop, Stats *st
 // classification, then 10 iterations without kernels on the inliers.
 // optional FP64 taps of the final state (set by lo_ba_f64 around a run): poses K x 12 (R row-major, t), points P x 3
 static thread_local double *g_poses_d = nullptr, *g_points_d = nullptr;
+
+/* k > 0: the following runs on this thread see their stop flag raised right after their k-th Levenberg trial; 0: back to the caller's flag */
+LO_API void lo_set_stop_after_trials(int k) { g_stop_after = k > 0 ? k : 0; }
 
 static int run_ba(int K, const float *poses, const uint8_t *fixed, const float *intr, int P, const float *points, int E, const int32_t *edge_point,
                   const int32_t *edge_kf, const float *edge_obs, const float *edge_inv_sigma2, const volatile uint8_t *stop, int iters1, bool robust1,
@@ -465,6 +477,7 @@ static int run_ba(int K, const float *poses, const uint8_t *fixed, const float *
     p.deltaMono = thMono; p.deltaStereo = thStereo;
     p.dsqrMono = (float)(p.deltaMono * p.deltaMono); p.dsqrStereo = (float)(p.deltaStereo * p.deltaStereo);
     Stats s1 = {0, 0, 0, 0, 0}, s2 = {0, 0, 0, 0, 0};
+    if (g_stop_after > 0) { g_own_stop = 0; g_trials_total = 0; stop = &g_own_stop; }      // (lo_set_stop_after_trials: the run's own flag)
     if (!(stop && *stop)) {
         p.robust = robust1;
         optimize(p, iters1, stop, &s1);                              // :863-864 (LBA), :247 (BundleAdjustment)

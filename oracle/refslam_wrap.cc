@@ -1371,6 +1371,22 @@ bool by_id_kf(KeyFrame *a, KeyFrame *b) { return a->mnId < b->mnId; }
 double hash_as_double(uint64_t h) { return (double)(h >> 12); }      // 52 bits: exact in a double
 }  // namespace
 
+// Per-frame wall times of the calls of one tracked frame, as Examples/Monocular/mono_tum.cc:81-95 takes them (steady_clock around the work, no
+// pacing): buf[8 * i + {0..7}] = milliseconds of frame i in {Frame constructor, ComputeBoW, SearchByBoW, PoseOptimization #1, SearchLocalPoints,
+// PoseOptimization #2, keyframe insertion, LocalBundleAdjustment}.  0..5 are the tracking thread's (their sum = the reference's "tracking time" of
+// the frame), 6..7 the local mapper's.  The hashes the parity test records are computed outside the timed spans.  NULL: no timing (the default).
+static double *g_seq_times = nullptr;
+static int g_seq_times_cap = 0;
+ORBSLAM_API void orbslam_sequence_timing(double *buf, int capacityFrames) { g_seq_times = buf; g_seq_times_cap = buf ? capacityFrames : 0; }
+namespace {
+struct SeqSpan {
+    double *dst;
+    std::chrono::steady_clock::time_point t0;
+    SeqSpan(int frame, int slot) : dst(g_seq_times && frame < g_seq_times_cap ? g_seq_times + 8 * (size_t)frame + slot : nullptr), t0(std::chrono::steady_clock::now()) {}
+    ~SeqSpan() { if (dst) *dst += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
 ORBSLAM_API int orbslam_sequence(const uint8_t *const *images, int nframes, int w, int h, int stride, int nfeatures, void *vocHandle, float fx, float fy, float cx,
                                  float cy, float planeZ, int kfEvery, const double *force, const float *forceLbaKf, const float *forceLbaPt, double *rec, float *lbaKf,
                                  float *lbaPt, int maxKf, int maxPt, int *nLbaEvents)
@@ -1418,10 +1434,12 @@ ORBSLAM_API int orbslam_sequence(const uint8_t *const *images, int nframes, int 
     for (int i = 0; i < nframes; i++) {
         double *r = rec + 64 * (size_t)i;
         for (int q = 0; q < 64; q++) r[q] = 0;
+        if (g_seq_times && i < g_seq_times_cap) for (int q = 0; q < 8; q++) g_seq_times[8 * (size_t)i + q] = 0;
         cv::Mat I(h, w, CV_8UC1, (void *)images[i], (size_t)stride);
         Frame F;
         {
             CallerArena arena;
+            SeqSpan sp(i, 0);
             F = Frame(I, (double)i, ex, voc, K, dist, 40.0f, 40.0f);
         }
         uint64_t hk = 1469598103934665603ull;
@@ -1439,7 +1457,7 @@ ORBSLAM_API int orbslam_sequence(const uint8_t *const *images, int nframes, int 
                 }
             r[52] = hash_as_double(hg);
         }
-        F.ComputeBoW();
+        { SeqSpan sp(i, 1); F.ComputeBoW(); }
         uint64_t hb = 1469598103934665603ull;
         for (DBoW2::BowVector::const_iterator it = F.mBowVec.begin(); it != F.mBowVec.end(); ++it) { hb = fnv(hb, &it->first, sizeof(it->first)); hb = fnv(hb, &it->second, sizeof(it->second)); }
         for (DBoW2::FeatureVector::const_iterator it = F.mFeatVec.begin(); it != F.mFeatVec.end(); ++it) {
@@ -1457,14 +1475,19 @@ ORBSLAM_API int orbslam_sequence(const uint8_t *const *images, int nframes, int 
         F.SetPose(lastPose);
         F.mpReferenceKF = refKF;
         // ---- TrackReferenceKeyFrame
-        ORBmatcher matcher(0.7f, true);
-        std::vector<MapPoint *> vm;
-        const int nm = matcher.SearchByBoW(refKF, F, vm);
-        F.mvpMapPoints = vm;
+        int nm;
+        {
+            SeqSpan sp(i, 2);
+            ORBmatcher matcher(0.7f, true);
+            std::vector<MapPoint *> vm;
+            nm = matcher.SearchByBoW(refKF, F, vm);
+            F.mvpMapPoints = vm;
+        }
         uint64_t hm = 1469598103934665603ull;
         for (int j = 0; j < F.N; j++) { const long id = F.mvpMapPoints[(size_t)j] ? (long)F.mvpMapPoints[(size_t)j]->mnId : -1; hm = fnv(hm, &id, sizeof(id)); }
         r[5] = nm; r[6] = hash_as_double(hm);
-        const int in1 = Optimizer::PoseOptimization(&F);
+        int in1;
+        { SeqSpan sp(i, 3); in1 = Optimizer::PoseOptimization(&F); }
         r[7] = in1;
         pose_rec(F.mTcw, r + 8);                                 // r[8..23]
         uint64_t ho = 1469598103934665603ull;
@@ -1494,6 +1517,7 @@ ORBSLAM_API int orbslam_sequence(const uint8_t *const *images, int nframes, int 
             r[53] = hash_as_double(hp);
         }
         int nm2 = 0;
+        SeqSpan *spLocal = new SeqSpan(i, 4);
 #ifdef ORBSLAM_HIP
         nm2 = SearchLocalPointsHIP(F, local, 1);
 #else
@@ -1516,6 +1540,7 @@ ORBSLAM_API int orbslam_sequence(const uint8_t *const *images, int nframes, int 
             nm2 = m2.SearchByProjection(F, local, 1);
         }
 #endif
+        delete spLocal;
         uint64_t h2 = 1469598103934665603ull;
         for (int j = 0; j < F.N; j++) { const long id = F.mvpMapPoints[(size_t)j] ? (long)F.mvpMapPoints[(size_t)j]->mnId : -1; h2 = fnv(h2, &id, sizeof(id)); }
         uint64_t hv = 1469598103934665603ull;
@@ -1525,7 +1550,8 @@ ORBSLAM_API int orbslam_sequence(const uint8_t *const *images, int nframes, int 
             if (v) { hv = fnv(hv, &local[q]->mTrackProjX, 4); hv = fnv(hv, &local[q]->mTrackProjY, 4); hv = fnv(hv, &local[q]->mnTrackScaleLevel, 4); }
         }
         r[25] = nm2; r[26] = hash_as_double(h2); r[27] = hash_as_double(hv); r[28] = (double)local.size();
-        const int in2 = Optimizer::PoseOptimization(&F);
+        int in2;
+        { SeqSpan sp(i, 5); in2 = Optimizer::PoseOptimization(&F); }
         r[29] = in2;
         pose_rec(F.mTcw, r + 30);                                // r[30..45]
         uint64_t ho2 = 1469598103934665603ull;
@@ -1537,9 +1563,10 @@ ORBSLAM_API int orbslam_sequence(const uint8_t *const *images, int nframes, int 
         lastPose = F.mTcw.clone();
         // ---- a keyframe and the local bundle adjustment (src/LocalMapping.cc:123)
         if (kfEvery > 0 && i % kfEvery == 0 && events < 64) {
-            KeyFrame *pKF = add_keyframe(F);
+            KeyFrame *pKF;
+            { SeqSpan sp(i, 6); pKF = add_keyframe(F); }
             bool stop = false;
-            Optimizer::LocalBundleAdjustment(pKF, &stop, &map);
+            { SeqSpan sp(i, 7); Optimizer::LocalBundleAdjustment(pKF, &stop, &map); }
             std::vector<KeyFrame *> kfs = map.GetAllKeyFrames();
             std::sort(kfs.begin(), kfs.end(), by_id_kf);
             std::vector<MapPoint *> pts = map.GetAllMapPoints();

@@ -2217,6 +2217,9 @@ struct orbx_lba {
     int *hostStop = nullptr, *hostStopDev = nullptr;   // pinned: the caller's stop flag as the device sees it (the waiting host keeps it current)
     double *hostRedDev = nullptr;        // device view of hostRed
     double seq = 0;                      // last sequence number handed out (k_stage_index, k_lm_begin, k_lm_decide)
+    // test hook (ORBX_LBA_TEST_STOP_AFTER_DECISIONS=k, read per call): the CALLER's stop flag is raised - as another thread of the caller would -
+    // when the host has seen the k-th trial decision of the call; from there on the library's own mirroring has to carry it to the device
+    int dbgStopAfter = 0, dbgDecisions = 0;
     double *hostRed = nullptr;   // pinned: {chi, -, diag max, -, scale_p, scale_l, okFlag (as int)} of a trial, read back with ONE synchronisation
 };
 
@@ -2522,6 +2525,7 @@ int optimize(Ctx &c, int iterations, double stats[4])
         if (specChol && (rct = trialChol()) != ORBX_OK) return rct;
         int rcw = wait_seq(h, seqT, c.stop);
         if (rcw) return rcw;
+        if (h->dbgStopAfter > 0 && c.stop && ++h->dbgDecisions == h->dbgStopAfter) *const_cast<volatile uint8_t *>(c.stop) = 1;      // (test hook, see the handle)
         if (h->hostRed[13] != 0.0) break;      // done
         if (t >= 10 * iterations + 10) { orbx_set_error("LBA: the Levenberg loop did not terminate"); return ORBX_ERR_STATE; }
     }
@@ -2542,6 +2546,7 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     ORBX_HIP_CHECK(hipSetDevice(h->device));
     for (int i = 0; i < 8; i++) res->stats[i] = 0;
     h->flops = 0;
+    { const char *e = getenv("ORBX_LBA_TEST_STOP_AFTER_DECISIONS"); h->dbgStopAfter = e && *e ? atoi(e) : 0; h->dbgDecisions = 0; }
     // ---- host marshalling: float boundary -> double state (Converter::toSE3Quat / toVector3d), written straight into ONE pinned
     // buffer (copies from pageable vectors are staged and synchronous: a dozen of them cost 0.3 ms of a 5 ms call) ----
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };

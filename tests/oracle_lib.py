@@ -191,8 +191,16 @@ def descriptor_distance(orc, a, b):
 
 
 # ---- LocalBundleAdjustment restatement (oracle/lba_oracle.cc) ----
-def local_bundle_adjustment(orc, w, stop=None):
+def local_bundle_adjustment(orc, w, stop=None, stop_after_trials=0):
+    """stop_after_trials = k > 0: the run sees its stop flag raised right after its k-th Levenberg trial (counted over both stages), i.e. before
+    the first read of the flag that follows that trial (oracle/lba_oracle.cc: lo_set_stop_after_trials)."""
     lib = orc.lib
+    if stop_after_trials:
+        lib.lo_set_stop_after_trials(int(stop_after_trials))
+        try:
+            return local_bundle_adjustment(orc, w, stop=None)
+        finally:
+            lib.lo_set_stop_after_trials(0)
     K, P, E = w["K"], w["P"], w["E"]
     poses_out = np.zeros((K, 16), np.float32)
     points_out = np.zeros((P, 3), np.float32)

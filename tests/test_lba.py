@@ -281,3 +281,120 @@ def test_lba_is_reproducible(orbx, cfg, runs):
         assert (got["poses"].view(np.uint32) == first["poses"].view(np.uint32)).all() and (got["points"].view(np.uint32) == first["points"].view(np.uint32)).all(), run
         assert (np.asarray(got["chi2"], np.float64).view(np.uint64) == np.asarray(first["chi2"], np.float64).view(np.uint64)).all() and (got["outlier"] == first["outlier"]).all(), run
     opt.close()
+
+
+# ---- the stop flag raised DURING a solve (src/Optimizer.cc:858-871, optimization_algorithm_levenberg.cpp:98-146, sparse_optimizer.cpp:370) ----
+STOP_WINDOWS = [dict(K=50, P=5000, seed=12345),
+                dict(K=12, P=400, seed=6, n_fixed=2, pose_noise=(np.deg2rad(12.0), 0.5), point_noise=0.4, stereo_frac=0.3)]      # (the second one rejects trials)
+
+
+@pytest.mark.parametrize("cfg", STOP_WINDOWS)
+def test_oracle_stop_after_trial_k(orbx, oracle, cfg):
+    """The oracle's test input: trials are counted over both stages; a flag raised after trial k ends the iteration and the stage there (the rejected
+    trial's estimates restored), skips the second stage when it comes during the first (:869-871), still classifies and writes back; k at or beyond
+    the natural number of trials changes nothing."""
+    w = orbx.lba_synth.make_window(**cfg)
+    free = oracle_lib.local_bundle_adjustment(oracle, w)
+    t1, t2 = int(free["stats"][1]), int(free["stats"][5])
+    assert t1 >= 2 and t2 >= 2
+    prev = None
+    for k in range(1, t1 + t2 + 2):
+        r = oracle_lib.local_bundle_adjustment(oracle, w, stop_after_trials=k)
+        s = r["stats"]
+        if k <= t1:
+            assert s[1] == k and s[4] == 0 and s[5] == 0, (k, s)          # stopped inside (or at the end of) stage one: stage two never starts
+        elif k < t1 + t2:
+            assert s[1] == t1 and s[5] == k - t1, (k, s)
+        else:
+            for key in ("poses", "points", "chi2", "outlier", "stats"):
+                assert (np.asarray(r[key]) == np.asarray(free[key])).all(), (k, key)
+        assert np.isfinite(r["poses"]).all() and r["chi2"].sum() > 0                 # the outlier pass and the write-back ran
+        if prev is not None and k <= t1 + t2:
+            assert not (np.array_equal(prev["points"], r["points"]) and np.array_equal(prev["stats"], r["stats"])), k      # every trial leaves a trace
+        prev = r
+    # the flag set before the call still means "nothing happens" with the counter armed elsewhere (thread-local, reset)
+    r0 = oracle_lib.local_bundle_adjustment(oracle, w)
+    assert (r0["stats"] == free["stats"]).all()
+
+
+def _same_bits(a, b):
+    return all((np.ascontiguousarray(a[k]).view(np.uint8) == np.ascontiguousarray(b[k]).view(np.uint8)).all() for k in ("poses", "points", "chi2", "outlier")) and \
+        (np.asarray(a["stats"]) == np.asarray(b["stats"])).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", STOP_WINDOWS)
+def test_lba_stop_flag_raised_during_the_solve(orbx, oracle, cfg, monkeypatch):
+    """The caller's flag goes up while the host waits for trial decisions (test hook: when the host has seen the j-th decision of the call, the
+    CALLER's byte is written, as the tracking thread's InsertKeyFrame would, src/LocalMapping.cc:123 / mbAbortBA).  From there the product's own
+    mechanism carries it: wait_seq mirrors the byte into the pinned word, k_lm_decide reads it with the next decision or the one after.  The
+    result must be the oracle's, stopped after the trial the product reports it stopped at (<= 1e-5, same trial counts); that trial is j + 1 or
+    j + 2 (or the stage's natural end); stage two is skipped when the stop lands in stage one; the outlier pass and the write-back run; and the
+    next call on the same handle is bit-identical to a fresh handle's."""
+    w = orbx.lba_synth.make_window(**cfg)
+    free_want = oracle_lib.local_bundle_adjustment(oracle, w)
+    t1, t2 = int(free_want["stats"][1]), int(free_want["stats"][5])
+    fresh = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000)
+    free_got = fresh.LocalBundleAdjustment(w)
+    fresh.close()
+    _compare(free_got, free_want, w)
+    opt = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000)
+    stopped_somewhere = 0
+    for j in list(range(1, t1 + t2)):
+        monkeypatch.setenv("ORBX_LBA_TEST_STOP_AFTER_DECISIONS", str(j))
+        flag = np.zeros(1, np.uint8)
+        got = opt.LocalBundleAdjustment(w, stop_flag=flag)
+        monkeypatch.delenv("ORBX_LBA_TEST_STOP_AFTER_DECISIONS")
+        assert flag[0] == 1, j
+        s = got["stats"]
+        T = int(s[1] + s[5])
+        assert j <= T <= min(j + 2, t1 + t2), (j, s)
+        if j < t1:
+            assert T <= t1 and s[4] == 0 and s[5] == 0, (j, s)         # raised in stage one with a trial to go: stage two must not start (:869-871)
+        want = oracle_lib.local_bundle_adjustment(oracle, w, stop_after_trials=T)
+        _compare(got, want, w)
+        assert np.isfinite(got["poses"]).all() and got["chi2"].sum() > 0
+        stopped_somewhere += T < t1 + t2
+        # the handle is clean again: an un-stopped call equals a fresh handle's to the bit (hostStop reset, LM state, accumulators)
+        flag[0] = 0
+        again = opt.LocalBundleAdjustment(w, stop_flag=flag)
+        assert _same_bits(again, free_got), j
+    assert stopped_somewhere >= t1 + t2 - 3
+    opt.close()
+
+
+@pytest.mark.gpu
+def test_lba_stop_flag_raised_by_another_thread(orbx, oracle):
+    """No hook: a second thread raises the flag some hundred microseconds into the call (ctypes releases the GIL).  Wherever it lands, the result is
+    the oracle's stopped after exactly the number of trials the product reports."""
+    import threading
+    w = orbx.lba_synth.make_window(K=50, P=5000, seed=12345)
+    free_want = oracle_lib.local_bundle_adjustment(oracle, w)
+    total = int(free_want["stats"][1] + free_want["stats"][5])
+    opt = orbx.Optimizer(max_keyframes=64, max_points=6000, max_edges=80000)
+    opt.LocalBundleAdjustment(w)
+    landed = set()
+    libc = ctypes.CDLL("libc.so.6")
+    for delay_us in (200, 400, 600, 800, 1000, 1200, 1400, 1700, 2000, 2400, 2800, 3300):
+        flag = np.zeros(1, np.uint8)
+        go = threading.Event()
+
+        def raiser():
+            go.wait()
+            libc.usleep(delay_us)      # (a foreign call: the GIL is free while it sleeps, the main thread marshals and enters orbx_lba_solve meanwhile)
+            flag[0] = 1
+        th = threading.Thread(target=raiser)
+        th.start()
+        go.set()
+        got = opt.LocalBundleAdjustment(w, stop_flag=flag)
+        th.join()
+        s = got["stats"]
+        T = int(s[1] + s[5])
+        landed.add(T)
+        if T == 0:      # before the first decision: the reference's own result is undefined there (e->chi2() of errors never computed); the estimates must be untouched
+            assert np.allclose(got["points"], w["points"])
+            continue
+        want = oracle_lib.local_bundle_adjustment(oracle, w, stop_after_trials=T) if T < total else free_want
+        _compare(got, want, w)
+    assert len(landed) >= 2, landed      # (the delays span the call: the flag must have landed at different trials)
+    opt.close()

@@ -100,6 +100,66 @@ def stereo_frame(orbx, iters_hip, iters_ref):
     return rows
 
 
+TRACK_CALLS = ("Frame::Frame(mono) = ExtractORB + UndistortKeyPoints + AssignFeaturesToGrid", "Frame::ComputeBoW", "ORBmatcher::SearchByBoW(KF, F)",
+               "Optimizer::PoseOptimization #1", "Tracking::SearchLocalPoints (isInFrustum + SearchByProjection)", "Optimizer::PoseOptimization #2",
+               "KeyFrame insertion (local mapper)", "Optimizer::LocalBundleAdjustment (local mapper)")
+
+
+def tracking(orbx, runs_hip=3, runs_ref=1, nframes=30, kf_every=5):
+    """The reference's OWN metric for the drop-in: per-frame tracking time (Examples/Monocular/mono_tum.cc:81-95, 114-122: steady_clock around the
+    frame's work, median and mean over the sequence, no pacing) of the call chain src/Tracking.cc makes for a tracked frame - the monocular Frame
+    constructor (src/Frame.cc:394), ComputeBoW, SearchByBoW (src/Tracking.cc:1195), PoseOptimization, SearchLocalPoints (:1765-1829), PoseOptimization -
+    on real Frame / KeyFrame / MapPoint / Map objects (oracle/refslam_wrap.cc: orbslam_sequence, the loop tests/test_sequence_dropin.py proves
+    identical in both libraries), every kf_every-th frame a KeyFrame + LocalBundleAdjustment (timed apart: the local mapper's thread).  640x480,
+    1000 features, 30 translating views of one plane; the first run of a library warms it up (graphs, engines, statics) and is not counted."""
+    import numpy as np
+    import oracle_lib
+    import tempfile
+    W, H, NF = 640, 480, 1000
+    MAXKF, MAXPT = 16, 16384
+    frames = orbx.synth_sequence(4242, nframes, W, H, views_per_scene=nframes, step=(3, 1), low_texture_every=0)
+    rows = []
+    with tempfile.TemporaryDirectory() as td:
+        voc = orbx.voc_synth.make_vocabulary(10, 4, 5)
+        path = Path(td) / "voc.txt"
+        orbx.voc_synth.write_text(voc, path)
+        for name, lib, runs in (("liborbslam_hip.so (drop-in)", oracle_lib.slam_hip_lib(), runs_hip), ("liborbslam.so (reference CPU path on cvshim)", oracle_lib.slam_lib(), runs_ref)):
+            if lib is None or runs <= 0 or not hasattr(lib, "orbslam_sequence_timing"):
+                continue
+            V = oracle_lib.RefVocabulary(path, lib)
+            arr = (ctypes.c_void_p * nframes)(*[f.ctypes.data for f in frames])
+            rec = np.zeros((nframes, 64), np.float64)
+            kf = np.zeros((64, MAXKF, 17), np.float32)
+            pt = np.zeros((64, MAXPT, 4), np.float32)
+            ne = ctypes.c_int(0)
+            P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            lib.orbslam_sequence.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p] + [ctypes.c_float] * 5 + [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int] * 2 + [ctypes.c_void_p]
+            lib.orbslam_sequence_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            times = []
+            for run in range(runs + (1 if "hip" in name else 0)):
+                t = np.zeros((nframes, 8), np.float64)
+                lib.orbslam_sequence_timing(P(t), nframes)
+                rc = lib.orbslam_sequence(arr, nframes, W, H, W, NF, V.h, 500.0, 500.0, 320.0, 240.0, 2.0, kf_every, None, None, None, P(rec), P(kf), P(pt), MAXKF, MAXPT, ctypes.byref(ne))
+                lib.orbslam_sequence_timing(None, 0)
+                if rc != 0:
+                    raise RuntimeError("orbslam_sequence rc %d" % rc)
+                if "hip" in name and run == 0:
+                    continue
+                times.append(t[1:])                      # frame 0 builds the initial map: not a tracked frame
+            t = np.concatenate(times)
+            track = t[:, :6].sum(1)
+            kfr = t[:, 7] > 0
+            rows.append({"kind": "track", "call": "tracked frame: Frame ctor -> ComputeBoW -> SearchByBoW -> PoseOptimization -> SearchLocalPoints -> PoseOptimization", "library": name,
+                         "size": "%dx%d" % (W, H), "nfeatures": NF, "frames": int(len(track)), "track_ms_median": round(float(np.median(track)), 4),
+                         "track_ms_mean": round(float(track.mean()), 4), "track_ms_p90": round(float(np.quantile(track, 0.9)), 4),
+                         "matches_bow_mean": round(float(rec[1:, 5].mean()), 1), "inliers_final_mean": round(float(rec[1:, 29].mean()), 1), "map_points_mean": round(float(rec[1:, 28].mean()), 1),
+                         "breakdown_ms_median": {TRACK_CALLS[i]: round(float(np.median(t[:, i])), 4) for i in range(6)},
+                         "local_mapper_ms_median": {TRACK_CALLS[i]: round(float(np.median(t[kfr, i])), 4) for i in (6, 7)} if kfr.any() else {},
+                         "allocator_note": "the sequence loop builds every Frame inside a CallerArena (the bump allocator the parity tests use): the quadtree's pointer tie (src/ORBextractor.cc:948) "
+                                           "resolves the same way in both libraries, keypoint counts are identical"})
+    return rows
+
+
 def trace_stereo(orbx):
     """Timeline of the drop-in stereo constructor (marks set by shim/Frame_hip.cc and oracle/refslam_wrap.cc), last frames of a short run."""
     import oracle_lib
@@ -140,6 +200,10 @@ def measure(orbx, quick=False):
         rows += stereo_frame(orbx, 100 if quick else 300, 0 if quick else 8)
     except Exception as e:      # noqa: BLE001  (the drop-in library is only there when oracle/_ref was built)
         rows.append({"call": "stereo Frame constructor", "error": repr(e)})
+    try:
+        rows += tracking(orbx, 2 if quick else 4, 1)
+    except Exception as e:      # noqa: BLE001
+        rows.append({"call": "tracked frame", "error": repr(e)})
     if not quick:
         os.environ["ORBX_COMBINE"] = "0"      # read when a handle is created: the round-3 behaviour (one graph per handle) beside the combiner's
         try:
@@ -163,6 +227,12 @@ def measure(orbx, quick=False):
            "fps_16threads_hostpyr_views": pick(threads=16, host_pyramid=True, host_pyramid_views=True, combiner=True).get("frames_per_s"),
            "stereo_frame_ctor_us": pick(library="liborbslam_hip.so (drop-in)", combiner=True).get("mean_us"),
            "stereo_frame_ctor_median_us": pick(library="liborbslam_hip.so (drop-in)", combiner=True).get("median_us"),
+           "track_ms_median": pick(kind="track", library="liborbslam_hip.so (drop-in)").get("track_ms_median"),
+           "track_ms_mean": pick(kind="track", library="liborbslam_hip.so (drop-in)").get("track_ms_mean"),
+           "ref_track_ms_median": pick(kind="track", library="liborbslam.so (reference CPU path on cvshim)").get("track_ms_median"),
+           "ref_track_ms_mean": pick(kind="track", library="liborbslam.so (reference CPU path on cvshim)").get("track_ms_mean"),
+           "track_breakdown_ms": pick(kind="track", library="liborbslam_hip.so (drop-in)").get("breakdown_ms_median"),
+           "lba_in_loop_ms": (pick(kind="track", library="liborbslam_hip.so (drop-in)").get("local_mapper_ms_median") or {}).get(TRACK_CALLS[7]),
            "source": "tools/latency_shim.py: C++ loops over the reference's call shapes (tests/shim_wrap.cc, oracle/refslam_wrap.cc)"}
     return {"rows": rows, "digest": dig}
 
