@@ -22,14 +22,10 @@ namespace {
 
 struct VocNode { int32_t childStart, childCount, word, pad; };   // word >= 0: leaf
 
-__global__ __launch_bounds__(256) void k_bow_transform(const VocNode *__restrict__ nodes, const int32_t *__restrict__ childList,
-                                                       const uint4 *__restrict__ childDesc, const double *__restrict__ nodeWeight, int nidLevel,
-                                                       const uint8_t *__restrict__ desc, const int32_t *__restrict__ counts, int cap, int32_t *__restrict__ word,
-                                                       int32_t *__restrict__ node, double *__restrict__ weight)
+__device__ __forceinline__ void bow_descend(const VocNode *__restrict__ nodes, const int32_t *__restrict__ childList, const uint4 *__restrict__ childDesc,
+                                            const double *__restrict__ nodeWeight, int nidLevel, const uint8_t *__restrict__ desc, int cap, int32_t *__restrict__ word,
+                                            int32_t *__restrict__ node, double *__restrict__ weight, int f, int i)
 {
-    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    const int n = counts ? min(counts[f], cap) : cap;
-    if (i >= n) return;
     const uint4 *dp = (const uint4 *)(desc + ((size_t)f * cap + i) * 32);
     const uint4 a0 = dp[0], a1 = dp[1];
     int cur = 0, level = 0, nid = 0;
@@ -54,6 +50,19 @@ __global__ __launch_bounds__(256) void k_bow_transform(const VocNode *__restrict
     node[o] = w > 0 ? nid : -1;   // features whose word has weight 0 are not filed in the FeatureVector (:1160-1166)
 }
 
+// pubFlag != nullptr: the host-array call - word / node / weight are MAPPED host memory and the last workgroup raises the call's sequence word behind them
+__global__ __launch_bounds__(256) void k_bow_transform(const VocNode *__restrict__ nodes, const int32_t *__restrict__ childList,
+                                                       const uint4 *__restrict__ childDesc, const double *__restrict__ nodeWeight, int nidLevel,
+                                                       const uint8_t *__restrict__ desc, const int32_t *__restrict__ counts, int cap, int32_t *__restrict__ word,
+                                                       int32_t *__restrict__ node, double *__restrict__ weight, unsigned *pubCounter, unsigned long long *pubFlag,
+                                                       unsigned long long pubSeq)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = counts ? min(counts[f], cap) : cap;
+    if (i < n) bow_descend(nodes, childList, childDesc, nodeWeight, nidLevel, desc, cap, word, node, weight, f, i);
+    if (pubFlag) orbx_publish(pubCounter, pubFlag, pubSeq, gridDim.x * gridDim.y);
+}
+
 }  // namespace
 
 struct orbx_vocabulary {
@@ -67,7 +76,7 @@ struct orbx_vocabulary {
     OrbxDevBuf<int32_t> word[2], node[2];
     OrbxDevBuf<double> weight[2];
     int cur = 0, lastBatch = 0, lastCap = 0;
-    OrbxDevBuf<uint8_t> hostDesc;
+    OrbxCallBox box;   // host-array form: descriptors in, word / node / weight out through mapped pinned memory
 };
 
 extern "C" int orbx_vocabulary_create(int device, int k, int L, int num_nodes, const int32_t *parent, const uint8_t *is_leaf, const uint8_t *descriptors,
@@ -121,7 +130,7 @@ extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v)
     if (!v) return;
     (void)hipSetDevice(v->device);
     if (v->stream) { (void)hipStreamSynchronize(v->stream); (void)hipStreamDestroy(v->stream); }
-    v->nodes.release(); v->childList.release(); v->childDesc.release(); v->nodeWeight.release(); v->hostDesc.release();
+    v->nodes.release(); v->childList.release(); v->childDesc.release(); v->nodeWeight.release(); v->box.release();
     for (int b = 0; b < 2; b++) { v->word[b].release(); v->node[b].release(); v->weight[b].release(); }
     delete v;
 }
@@ -136,7 +145,7 @@ static int launch_transform(orbx_vocabulary *v, hipStream_t stream, const uint8_
     const size_t n = (size_t)batch * cap;
     if ((rc = v->word[b].ensure(n)) || (rc = v->node[b].ensure(n)) || (rc = v->weight[b].ensure(n))) return rc;
     hipLaunchKernelGGL(k_bow_transform, dim3((unsigned)((cap + 255) / 256), (unsigned)batch), dim3(256), 0, stream, v->nodes.p, v->childList.p, v->childDesc.p,
-                       v->nodeWeight.p, v->L - levelsup, desc, counts, cap, v->word[b].p, v->node[b].p, v->weight[b].p);
+                       v->nodeWeight.p, v->L - levelsup, desc, counts, cap, v->word[b].p, v->node[b].p, v->weight[b].p, (unsigned *)nullptr, (unsigned long long *)nullptr, 0ull);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     v->lastBatch = batch; v->lastCap = cap;
@@ -179,14 +188,26 @@ extern "C" int orbx_bow_download(orbx_vocabulary *v, orbx_extractor *ext, int ba
     return ORBX_OK;
 }
 
+// Host-array form (Frame::ComputeBoW / KeyFrame::ComputeBoW through shim/BoW_hip.cc): ONE kernel that reads the descriptors from mapped pinned memory
+// (32 bytes per thread, each once) and writes word / node / weight into mapped pinned memory; no copy engine, no stream synchronisation (OrbxCallBox).
 extern "C" int orbx_bow_transform(orbx_vocabulary *v, const uint8_t *descriptors, int n, int levelsup, int32_t *word, int32_t *node, double *weight)
 {
     if (!v || (n > 0 && !descriptors)) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     if (n <= 0) return ORBX_OK;
     ORBX_HIP_CHECK(hipSetDevice(v->device));
-    int rc = v->hostDesc.ensure((size_t)n * 32);
+    OrbxCallBox &bx = v->box;
+    const size_t N = (size_t)n, offNode = bx.padded(N * 4), offW = offNode + bx.padded(N * 4);
+    int rc = bx.begin(bx.padded(N * 32), offW + bx.padded(N * 8), v->stream);
     if (rc != ORBX_OK) return rc;
-    ORBX_HIP_CHECK(hipMemcpyAsync(v->hostDesc.p, descriptors, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
-    if ((rc = launch_transform(v, v->stream, v->hostDesc.p, nullptr, 1, n, levelsup)) != ORBX_OK) return rc;
-    return orbx_bow_download(v, nullptr, 1, word, node, weight);
+    const uint8_t *dDesc = bx.put(descriptors, N * 32);
+    const unsigned long long seq = bx.arm();
+    hipLaunchKernelGGL(k_bow_transform, dim3((unsigned)((n + 255) / 256), 1u), dim3(256), 0, v->stream, v->nodes.p, v->childList.p, v->childDesc.p, v->nodeWeight.p, v->L - levelsup,
+                       dDesc, (const int32_t *)nullptr, n, bx.outDev<int32_t>(0), bx.outDev<int32_t>(offNode), bx.outDev<double>(offW), bx.counter, bx.flagDev, seq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+    if ((rc = bx.wait(v->stream)) != ORBX_OK) return rc;
+    if (word) memcpy(word, bx.outHost<int32_t>(0), N * 4);
+    if (node) memcpy(node, bx.outHost<int32_t>(offNode), N * 4);
+    if (weight) memcpy(weight, bx.outHost<double>(offW), N * 8);
+    return ORBX_OK;
 }

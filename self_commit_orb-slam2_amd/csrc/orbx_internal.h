@@ -215,6 +215,117 @@ struct OrbxHostStage {
     void release() { if (host) (void)hipHostFree(host); host = nullptr; hostBytes = 0; used = 0; dev.release(); }
 };
 
+/* One small synchronous host call WITHOUT a copy engine and WITHOUT a stream synchronisation.  Measured around an 11 us kernel
+ * (tools/ubench_call.hip, profiles/r06_call_floor.txt): pageable upload + hipStreamSynchronize + two hipMemcpy downloads = 63 us; inputs in MAPPED pinned
+ * memory read in place by the kernel, results written by the kernel into mapped pinned memory, a sequence word raised behind them by the last workgroup
+ * and polled by the host = 22 us.  (hipMemcpyAsync from pinned memory alone costs 17 us of stream time before the kernel starts.)
+ *   begin(in, out) sizes the two mapped buffers (grow-only) and waits for a call that was abandoned half way;
+ *   put(src, n)    copies a host array into the input buffer and returns the address the DEVICE reads it at (each byte should be read once: inputs that
+ *                  several workgroups read again and again are copied to device memory by the first kernel of the chain);
+ *   outDev / outHost(off) address the result buffer from both sides;
+ *   arm() hands out the sequence number the chain's last kernel publishes with orbx_publish(); wait() spins until it shows up. */
+struct OrbxCallBox {
+    uint8_t *in = nullptr, *inDev = nullptr;
+    size_t inBytes = 0, used = 0;
+    uint8_t *out = nullptr, *outDevP = nullptr;
+    size_t outBytes = 0;
+    unsigned long long *flag = nullptr, *flagDev = nullptr;      /* mapped: the last published sequence number */
+    unsigned *counter = nullptr;                                 /* device: arrivals of the publishing kernel's workgroups (0 between calls) */
+    unsigned long long seq = 0;
+    bool pending = false;
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    int grow(uint8_t **host, uint8_t **dev, size_t *have, size_t want)
+    {
+        if (want <= *have) return ORBX_OK;
+        if (*host) (void)hipHostFree(*host);
+        *host = nullptr; *dev = nullptr; *have = 0;
+        want = padded(want + want / 2);
+        ORBX_HIP_CHECK(hipHostMalloc((void **)host, want, hipHostMallocMapped));
+        ORBX_HIP_CHECK(hipHostGetDevicePointer((void **)dev, *host, 0));
+        *have = want;
+        return ORBX_OK;
+    }
+    int begin(size_t inTotal, size_t outTotal, hipStream_t st)
+    {
+        if (pending) { ORBX_HIP_CHECK(hipStreamSynchronize(st)); pending = false; }      /* (a call that returned an error before its wait()) */
+        used = 0;
+        int rc;
+        if ((rc = grow(&in, &inDev, &inBytes, inTotal ? inTotal : 256)) != ORBX_OK) return rc;
+        if ((rc = grow(&out, &outDevP, &outBytes, outTotal ? outTotal : 256)) != ORBX_OK) return rc;
+        if (!flag) {
+            ORBX_HIP_CHECK(hipHostMalloc((void **)&flag, 64, hipHostMallocMapped));
+            ORBX_HIP_CHECK(hipHostGetDevicePointer((void **)&flagDev, flag, 0));
+            *flag = 0;
+            ORBX_HIP_CHECK(hipMalloc((void **)&counter, 64));
+            ORBX_HIP_CHECK(hipMemset(counter, 0, 64));
+        }
+        return ORBX_OK;
+    }
+    template <typename T> const T *put(const T *src, size_t count)
+    {
+        const T *d = (const T *)(inDev + used);
+        if (src && count) memcpy(in + used, src, count * sizeof(T));
+        used += padded(count * sizeof(T));
+        return d;
+    }
+    template <typename T> T *hostIn(const T *devAddr) { return (T *)(in + ((const uint8_t *)devAddr - inDev)); }      /* where put() placed an array, host side */
+    template <typename T> T *outDev(size_t off) { return (T *)(outDevP + off); }
+    template <typename T> const T *outHost(size_t off) const { return (const T *)(out + off); }
+    unsigned long long arm() { pending = true; return ++seq; }
+    /* spins on the sequence word; the stream is queried now and then so that a failed launch becomes an error instead of a hang */
+    int wait(hipStream_t st)
+    {
+        const unsigned long long want = seq;
+        for (unsigned spins = 1;; spins++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= want) break;
+            if ((spins & 0x3fff) == 0) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= want) break;
+                    pending = false;
+                    orbx_set_error("the stream drained without the call's results");
+                    return ORBX_ERR_HIP;
+                }
+                if (q != hipErrorNotReady) { pending = false; orbx_set_error("%s", hipGetErrorString(q)); return ORBX_ERR_HIP; }
+            }
+            __builtin_ia32_pause();
+        }
+        pending = false;
+        return ORBX_OK;
+    }
+    void release()
+    {
+        if (in) (void)hipHostFree(in);
+        if (out) (void)hipHostFree(out);
+        if (flag) (void)hipHostFree(flag);
+        if (counter) (void)hipFree(counter);
+        in = out = nullptr; flag = nullptr; counter = nullptr; inBytes = outBytes = 0;
+    }
+};
+
+#ifdef __HIPCC__
+/* End of the LAST kernel of an OrbxCallBox chain, called by every thread of every workgroup after its last store of results (to mapped host memory):
+ * the workgroup that arrives last raises the sequence word with system scope behind everybody's stores (agent-scope release per workgroup, acquire +
+ * system-scope release by the last one; a per-thread __threadfence_system costs 3 us more per call, profiles/r06_call_floor.txt). */
+__device__ __forceinline__ void orbx_publish(unsigned *counter, unsigned long long *flag, unsigned long long seq, unsigned nblocks)
+{
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (nblocks <= 1 || __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) {
+            if (nblocks > 1) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+/* The inputs of a single host call that the kernels behind read MANY times: copied ONCE from mapped pinned memory into the handle's device arena
+ * (uint4 units; ~25 GB/s across PCIe: 64 KB in ~4 us - a hipMemcpyAsync from the same pinned buffer costs 17 us of stream time). */
+static __global__ __launch_bounds__(256) void k_stage_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+#endif
+
 /* Device view of the LAST batch of an extractor: results + the unblurred pyramid (what the
  * reference keeps in ORBextractor::mvImagePyramid, read by Frame::ComputeStereoMatches). */
 struct OrbxLastBatchView {

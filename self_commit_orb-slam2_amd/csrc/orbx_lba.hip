@@ -1851,6 +1851,10 @@ struct PoseOptDev {
     uint8_t *outlier;        // [B*cap]  pFrame->mvbOutlier of those features
     int32_t *ret;            // [B] nInitialCorrespondences - nBad
     double *stats;           // [B*8] per round: iterations, final (robustified) chi2
+    // the host call's completion (OrbxCallBox): the outputs above are mapped pinned memory, the last frame's workgroup raises the sequence word
+    unsigned *pubCounter;
+    unsigned long long *pubFlag;
+    unsigned long long pubSeq;
 };
 
 #define PO_NRED 28   /* 21 upper-triangle entries of H + 6 of b + chi2 */
@@ -1941,6 +1945,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         if (tid < n) outl[tid] = 0;
         if (tid < 16) P.poseOut[16 * (size_t)f + tid] = p0[tid];
         if (tid == 0) P.ret[f] = 0;
+        if (P.pubFlag) orbx_publish(P.pubCounter, P.pubFlag, P.pubSeq, gridDim.x);
         return;
     }
     float xw[NE][3], ob[NE][3], is2[NE];
@@ -2187,6 +2192,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o[4 * i + j] = (float)R[3 * i + j]; o[4 * i + 3] = (float)pose.t[i]; }
         o[12] = o[13] = o[14] = 0.f; o[15] = 1.f;
     }
+    if (P.pubFlag) orbx_publish(P.pubCounter, P.pubFlag, P.pubSeq, gridDim.x);
 }
 
 }  // namespace
@@ -2703,7 +2709,7 @@ extern "C" int orbx_bundle_adjustment(orbx_lba *h, const orbx_lba_problem *p, in
 struct orbx_pose_optimizer {
     int device = 0, maxFrames = 0, maxFeatures = 0;
     hipStream_t stream = nullptr;
-    OrbxHostStage hostStage;   // inputs of a call in one pinned copy; the kernel writes the results straight into the same pinned buffer
+    OrbxCallBox box;   // inputs of a call in mapped pinned memory (read in place), results written by the kernel into mapped pinned memory, sequence word
 };
 
 extern "C" int orbx_pose_optimizer_create(int device, int max_frames, int max_features, orbx_pose_optimizer **out)
@@ -2726,7 +2732,7 @@ extern "C" void orbx_pose_optimizer_destroy(orbx_pose_optimizer *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    h->hostStage.release();
+    h->box.release();
     delete h;
 }
 
@@ -2738,23 +2744,18 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     ORBX_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     const size_t N = (size_t)B * cap;
-    OrbxHostStage &hs = h->hostStage;
-    const size_t inBytes = hs.padded((size_t)B * 64) + hs.padded((size_t)B * 20) + hs.padded((size_t)B * 4) + 2 * hs.padded(N * 12) + hs.padded(N * 4);
-    const size_t outBytes = hs.padded((size_t)B * 64) + hs.padded(N) + hs.padded((size_t)B * 4) + hs.padded((size_t)B * 64);
-    ORBX_HIP_CHECK(hipStreamSynchronize(st));
-    int rcs = hs.begin(inBytes > outBytes ? inBytes : outBytes);
+    // No copy engine, no stream synchronisation (OrbxCallBox): every input is read exactly once, into the registers of the thread that owns the edge, straight
+    // from mapped pinned memory; pose / flags / inlier count / statistics are written into mapped pinned memory and the last workgroup raises the sequence word.
+    OrbxCallBox &bx = h->box;
+    const size_t inBytes = bx.padded((size_t)B * 64) + bx.padded((size_t)B * 20) + bx.padded((size_t)B * 4) + 2 * bx.padded(N * 12) + bx.padded(N * 4);
+    const size_t q1 = bx.padded((size_t)B * 64), q2 = q1 + bx.padded(N), q3 = q2 + bx.padded((size_t)B * 4), outBytes = q3 + bx.padded((size_t)B * 64);
+    int rcs = bx.begin(inBytes, outBytes, st);
     if (rcs != ORBX_OK) return rcs;
-    const float *dPose = hs.put(p->poses, (size_t)B * 16), *dCam = hs.put(p->cameras, (size_t)B * 5);
-    const int32_t *dCnt = hs.put(p->counts, (size_t)B);
-    const float *dXw = hs.put(p->world_points, N * 3), *dObs = hs.put(p->observations, N * 3), *dInv = hs.put(p->inv_sigma2, N);
-    if ((rcs = hs.flush(st)) != ORBX_OK) return rcs;
-    // the results are written by the kernel straight into the pinned staging buffer (a few hundred bytes per frame over the fabric, behind the
-    // inputs, which the device has copied out of it by then): four device-to-host copies less on a 0.25 ms call
-    uint8_t *o0 = hs.host, *o1 = o0 + hs.padded((size_t)B * 64), *o2 = o1 + hs.padded(N), *o3 = o2 + hs.padded((size_t)B * 4);
-    uint8_t *hostDev = nullptr;
-    ORBX_HIP_CHECK(hipHostGetDevicePointer((void **)&hostDev, hs.host, 0));
-    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, (float *)(hostDev + (o0 - hs.host)), hostDev + (o1 - hs.host), (int32_t *)(hostDev + (o2 - hs.host)),
-                    (double *)(hostDev + (o3 - hs.host))};
+    const float *dPose = bx.put(p->poses, (size_t)B * 16), *dCam = bx.put(p->cameras, (size_t)B * 5);
+    const int32_t *dCnt = bx.put(p->counts, (size_t)B);
+    const float *dXw = bx.put(p->world_points, N * 3), *dObs = bx.put(p->observations, N * 3), *dInv = bx.put(p->inv_sigma2, N);
+    const uint8_t *o0 = bx.outHost<uint8_t>(0), *o1 = bx.outHost<uint8_t>(q1), *o2 = bx.outHost<uint8_t>(q2), *o3 = bx.outHost<uint8_t>(q3);
+    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, bx.outDev<float>(0), bx.outDev<uint8_t>(q1), bx.outDev<int32_t>(q2), bx.outDev<double>(q3), bx.counter, bx.flagDev, bx.arm()};
     const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);   // deltaMono / deltaStereo are floats (:389-390)
     Huber hub;
     hub.dMono = thMono; hub.dStereo = thStereo;
@@ -2769,9 +2770,9 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     else hipLaunchKernelGGL(k_pose_opt<32>, dim3((unsigned)B), dim3(256), 0, st, D, hub);      // up to 8192 correspondences: 32 per thread, one wave per SIMD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
-    ORBX_HIP_CHECK(hipStreamSynchronize(st));
+    if ((rcs = bx.wait(st)) != ORBX_OK) return rcs;
     if (poses_out) memcpy(poses_out, o0, (size_t)B * 64);
-    if (outlier)      // entries past a frame's count are not written by the kernel (the pinned buffer still holds input bytes there): they read 0
+    if (outlier)      // entries past a frame's count are not written by the kernel: they read 0
         for (int f = 0; f < B; f++) {
             const size_t c = (size_t)std::min(std::max((int)p->counts[f], 0), cap);
             memcpy(outlier + (size_t)f * cap, o1 + (size_t)f * cap, c);

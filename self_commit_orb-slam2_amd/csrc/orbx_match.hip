@@ -398,6 +398,145 @@ __global__ __launch_bounds__(256, 3) void k_bow_topk_mfma(FeatDev A, FeatDev B, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The SINGLE-PAIR geometry (ORBmatcher::SearchByBoW as src/Tracking.cc:1195, 2073 call it: one KeyFrame against one Frame, ~1000 x 1000).
+// k_bow_topk above gives a pair ceil(nA / 256) workgroups that each walk ALL of B: four workgroups on 256 CUs, 100 us for one pair where 256 pairs
+// take 216.  Here the B range is split as well: a workgroup is 64 A features (lane = feature, its descriptor in 8 VGPRs) x 4 waves, wave w of
+// workgroup (rb, y) scans B slice 4 y + w (`per` features, staged in the wave's corner of LDS, read as broadcasts) and keeps its top-TOPK per lane;
+// the four waves merge in LDS, the workgroup stores a partial list, and the LAST workgroup of a row block to arrive (a counter per row block) merges
+// the SY partial lists into the final one.  Keys carry the B index (dist << 16 | j), so the smallest TOPK of the union of the slices' lists ARE the
+// lists k_bow_topk produces: the replay below sees identical input.  The processing order of the A features (k_bow_order: rank by (node id, index),
+// 46 us for one pair with its 1000-step loop over global memory) is computed by further workgroups of the SAME launch: 32 features x 8 segments per
+// workgroup, node ids in LDS.
+// ---------------------------------------------------------------------------------------------
+#define SPLIT_ROWS 64
+#define SPLIT_TILE 64      /* B features a wave stages at a time */
+template <bool FILTER>
+__global__ __launch_bounds__(256) void k_bow_topk_split(FeatDev A, FeatDev B, int mode, uint32_t dcut, int nRowBlocks, int SY, int per, uint32_t *part,
+                                                        unsigned *__restrict__ rowCounter, uint32_t *__restrict__ topk, int32_t *__restrict__ order)
+{
+    __shared__ uint4 sB[4][SPLIT_TILE * 2];
+    __shared__ int32_t sG[4][SPLIT_TILE];
+    __shared__ uint32_t sK[3][SPLIT_ROWS][TOPK + 1];      // (+1: the lanes of a wave write rows 9 words apart - conflict free)
+    __shared__ int sLast;
+    const int nA = min(A.counts[0], A.cap), nB = min(B.counts[0], B.cap);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if ((int)blockIdx.x >= nRowBlocks * SY) {
+        // ---- processing order: rank of feature i = #{k : (g[k], k) < (g[i], i)}; 32 features per workgroup, 8 lanes share a feature
+        __shared__ int32_t sGr[4096];
+        const int ob = (int)blockIdx.x - nRowBlocks * SY, i = ob * 32 + (tid >> 3), seg = tid & 7;
+        if (!A.groups) { if (seg == 0 && i < nA) order[i] = i; return; }
+        const int gi = i < nA ? A.groups[i] : 0;
+        int rank = 0;
+        for (int t0 = 0; t0 < nA; t0 += 4096) {
+            const int tn = min(4096, nA - t0);
+            __syncthreads();
+            for (int k = tid; k < tn; k += 256) sGr[k] = A.groups[t0 + k];
+            __syncthreads();
+            for (int k = seg; k < tn; k += 8) { const int gk = sGr[k]; rank += (gk < gi) || (gk == gi && t0 + k < i); }
+        }
+        rank += __shfl_xor(rank, 1); rank += __shfl_xor(rank, 2); rank += __shfl_xor(rank, 4);
+        if (seg == 0 && i < nA) order[rank] = i;
+        return;
+    }
+    const int rb = (int)blockIdx.x % nRowBlocks, y = (int)blockIdx.x / nRowBlocks;
+    const int row = rb * SPLIT_ROWS + lane;
+    const bool live = row < nA;
+    const uint32_t sentinel = dcut << 16;
+    uint32_t a[8], kk[TOPK];
+    {
+        const uint4 *da = (const uint4 *)(A.desc + (size_t)(live ? row : nA - 1) * 32);
+        const uint4 lo = da[0], hi = da[1];
+        a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
+    }
+    const int gA = (FILTER && A.groups) ? A.groups[live ? row : nA - 1] : 0;
+    const bool act = live && !(FILTER && gA < 0);      // unfiled A features keep empty lists
+#pragma unroll
+    for (int q = 0; q < TOPK; q++) kk[q] = act ? sentinel : 0u;      // inactive rows never insert
+    uint32_t th = kk[TOPK - 1] >> 16;
+    const int j0 = (y * 4 + wv) * per, j1 = min(nB, j0 + per);
+    const uint4 *gD = (const uint4 *)B.desc;
+    for (int t0 = j0; t0 < j0 + per; t0 += SPLIT_TILE) {      // (the same trip count in every wave: the barriers below are uniform)
+        const int nt = max(0, min(SPLIT_TILE, j1 - t0));
+        __syncthreads();
+        for (int t = lane; t < 2 * nt; t += 64) sB[wv][t] = gD[2 * (size_t)t0 + t];
+        if (FILTER && lane < nt) {
+            int gq = B.groups ? B.groups[t0 + lane] : 0;
+            if (gq < 0) gq = (int)0x80000000;                                    // not filed in the FeatureVector: never matched
+            if (mode >= 1 && B.valid && !B.valid[t0 + lane]) gq = (int)0x80000000;
+            sG[wv][lane] = gq;
+        }
+        __syncthreads();
+        for (int j = 0; j < nt; j++) {
+            const uint4 lo = sB[wv][2 * j], hi = sB[wv][2 * j + 1];      // wave-uniform address: LDS broadcast
+            uint32_t d = bcnt_acc(a[0] ^ lo.x, 0u);
+            d = bcnt_acc(a[1] ^ lo.y, d); d = bcnt_acc(a[2] ^ lo.z, d); d = bcnt_acc(a[3] ^ lo.w, d);
+            d = bcnt_acc(a[4] ^ hi.x, d); d = bcnt_acc(a[5] ^ hi.y, d); d = bcnt_acc(a[6] ^ hi.z, d); d = bcnt_acc(a[7] ^ hi.w, d);
+            if (FILTER) d = sG[wv][j] == gA ? d : 0xffffu;
+            // scan order inside a slice is ascending j: an equal distance with a later j has the larger key, only d < th can enter (as in k_bow_topk)
+            const uint32_t key = d < th ? (d << 16) | (uint32_t)(t0 + j) : 0xffffffffu;
+            if (__any(key < kk[TOPK - 1])) { topk_insert(kk, key); th = kk[TOPK - 1] >> 16; }
+        }
+    }
+    // the four waves' lists of a feature -> one (wave 0)
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+        for (int q = 0; q < TOPK; q++) sK[wv - 1][lane][q] = kk[q];
+    }
+    __syncthreads();
+    if (wv == 0) {
+        for (int w = 0; w < 3; w++)
+#pragma unroll
+            for (int q = 0; q < TOPK; q++) { const uint32_t key = sK[w][lane][q]; if (__any(key < kk[TOPK - 1])) topk_insert(kk, key); }
+    }
+    if (SY == 1) {
+        if (wv == 0 && live) {
+            uint32_t *out = topk + (size_t)row * TOPK;
+#pragma unroll
+            for (int q = 0; q < TOPK; q++) out[q] = (!act || kk[q] >= sentinel) ? KEY_EMPTY : kk[q];
+        }
+        return;
+    }
+    const size_t nRowsPad = (size_t)nRowBlocks * SPLIT_ROWS;
+    if (wv == 0) {
+        uint4 *po = (uint4 *)(part + ((size_t)y * nRowsPad + row) * TOPK);
+        po[0] = make_uint4(kk[0], kk[1], kk[2], kk[3]); po[1] = make_uint4(kk[4], kk[5], kk[6], kk[7]);
+        __threadfence();      // the partial list is visible to the device before the arrival is counted
+    }
+    __syncthreads();
+    if (tid == 0) sLast = atomicAdd(&rowCounter[rb], 1u) == (unsigned)(SY - 1);
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();          // (acquire side: the other workgroups' partial lists)
+    // the last workgroup of the row block: wave w merges the partial lists y = w, w + 4, ...; then the waves merge as above
+#pragma unroll
+    for (int q = 0; q < TOPK; q++) kk[q] = act ? sentinel : 0u;
+    for (int yy = wv; yy < SY; yy += 4) {
+        const uint4 *pi = (const uint4 *)(part + ((size_t)yy * nRowsPad + row) * TOPK);
+        const uint4 lo = pi[0], hi = pi[1];
+        const uint32_t keys[TOPK] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int q = 0; q < TOPK; q++) if (__any(keys[q] < kk[TOPK - 1])) topk_insert(kk, keys[q]);
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int q = 0; q < TOPK; q++) sK[wv - 1][lane][q] = kk[q];
+    }
+    __syncthreads();
+    if (wv == 0) {
+        for (int w = 0; w < 3; w++)
+#pragma unroll
+            for (int q = 0; q < TOPK; q++) { const uint32_t key = sK[w][lane][q]; if (__any(key < kk[TOPK - 1])) topk_insert(kk, key); }
+        if (live) {
+            uint32_t *out = topk + (size_t)row * TOPK;
+#pragma unroll
+            for (int q = 0; q < TOPK; q++) out[q] = (!act || kk[q] >= sentinel) ? KEY_EMPTY : kk[q];
+        }
+    }
+    if (tid == 0) rowCounter[rb] = 0;      // ready for the next call
+}
+
 // greedy replay + rotation histogram + three-maxima pruning; one workgroup per pair.
 //
 // The reference's pass over the A features is sequential only through the "already matched" flag
@@ -415,7 +554,8 @@ __global__ __launch_bounds__(256, 3) void k_bow_topk_mfma(FeatDev A, FeatDev B, 
 #define GREEDY_THREADS 1024   /* a row per thread for up to 1024 features: every round of the fixed point is one parallel sweep */
 __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDev B, const int32_t *__restrict__ pairsA, const int32_t *__restrict__ pairsB, int mode,
                                                     float nnratio, int checkOri, const uint32_t *__restrict__ topk, const int32_t *__restrict__ order,
-                                                    int32_t *__restrict__ matches, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride, TriDev T)
+                                                    int32_t *__restrict__ matches, int32_t *__restrict__ dists, int32_t *__restrict__ nmatches, int stride, TriDev T,
+                                                    int32_t *__restrict__ pubMatches, unsigned long long *pubFlag, unsigned long long pubSeq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int hist[HISTO_LENGTH];
@@ -576,6 +716,13 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
     }
     __syncthreads();
     if (tid == 0) nmatches[p] = sTotal - sRemoved;
+    if (pubFlag) {
+        // the single-pair host call: the match list and the count go straight into the caller's mapped pinned buffer, the sequence word behind them
+        const int nOut = mode == 0 ? nB : nA;
+        for (int s2 = tid; s2 < nOut; s2 += GREEDY_THREADS) pubMatches[s2] = mout[s2];
+        if (tid == 0) pubMatches[nOut] = sTotal - sRemoved;
+        orbx_publish(nullptr, pubFlag, pubSeq, 1u);
+    }
 }
 
 // Hamming stage of Frame::ComputeStereoMatches: one wave per left keypoint, lanes over the
@@ -1060,7 +1207,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->pairsA.release(); m->pairsB.release(); m->order.release(); m->matches.release(); m->dists.release(); m->nmatches.release();
-    m->hostStage.release(); m->projDec.release(); m->projQueue.release();
+    m->hostStage.release(); m->projDec.release(); m->projQueue.release(); m->box.release(); m->arena.release(); m->topkPart.release(); m->rowCounter.release();
     m->topk.release(); m->scales.release(); m->uright.release(); m->depth.release(); m->sad.release(); m->stRowStart.release(); m->stRowList.release();
     m->topk64.release(); m->pkp.release(); m->producerStatus.release();
     for (int q = 0; q < 2; q++) { m->pf[q].release(); m->pb[q].release(); m->pi32[q].release(); }
@@ -1197,7 +1344,7 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_feature_set
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
     if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
     hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(GREEDY_THREADS), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, params->mode, params->nn_ratio,
-                       params->check_orientation, m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride, TriDev());
+                       params->check_orientation, m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride, TriDev(), (int32_t *)nullptr, (unsigned long long *)nullptr, 0ull);
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
     m->profCount++;
@@ -1544,11 +1691,85 @@ int stage_host(orbx_matcher *m, int side, const orbx_feature_set *h, orbx_featur
 }
 }  // namespace orbx_match
 
+// One pair from host arrays, the call src/Tracking.cc:1195 / 2073 make through shim/ORBmatcher_hip.cc.  No copy engine, no stream synchronisation
+// (OrbxCallBox): the arrays go into mapped pinned memory, k_stage_copy reads them once into the handle's arena, k_bow_topk_split (B split over the
+// chip, the processing order in the same launch) and k_bow_greedy follow, the replay writes the match list into mapped pinned memory and raises the
+// call's sequence word.  204 us -> see profiles/r06_latency_calls.txt.  ORBX_BOW_SINGLE_SPLIT=0: the round-5 path (stage, the batch kernels, download).
+static int search_by_bow_single(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b, const orbx_bow_params *prm, int32_t *matches, int32_t *nmatches)
+{
+    const int nA = a->counts[0], nB = b->counts[0];
+    OrbxCallBox &bx = m->box;
+    const size_t NA = (size_t)nA, NB = (size_t)nB;
+    const int nOut = prm->mode == 0 ? nB : nA;
+    const size_t inBytes = bx.padded(NA * sizeof(orbx_keypoint)) + bx.padded(NA * 32) + bx.padded(NA * 4) + bx.padded(NA) + bx.padded(NB * sizeof(orbx_keypoint)) + bx.padded(NB * 32) +
+                           bx.padded(NB * 4) + bx.padded(NB) + bx.padded(8);
+    int rc = bx.begin(inBytes, bx.padded(((size_t)nOut + 1) * 4), m->stream);
+    if (rc != ORBX_OK) return rc;
+    if ((rc = m->arena.ensure(inBytes)) != ORBX_OK) return rc;
+    uint8_t *const ar = m->arena.p;
+    auto dev = [&](const void *boxAddr) { return ar + ((const uint8_t *)boxAddr - bx.inDev); };      // the same offsets in the device arena
+    const int32_t cnt[2] = {nA, nB};
+    FeatDev A, B;
+    A.kp = (const orbx_keypoint *)dev(bx.put(a->keypoints, NA)); A.desc = dev(bx.put(a->descriptors, NA * 32));
+    const void *ga = bx.put(a->groups, a->groups ? NA : 0), *va = bx.put(a->valid, a->valid ? NA : 0);
+    B.kp = (const orbx_keypoint *)dev(bx.put(b->keypoints, NB)); B.desc = dev(bx.put(b->descriptors, NB * 32));
+    const void *gb = bx.put(b->groups, b->groups ? NB : 0), *vb = bx.put(b->valid, b->valid ? NB : 0);
+    const int32_t *dc = (const int32_t *)dev(bx.put(cnt, 2));
+    A.groups = a->groups ? (const int32_t *)dev(ga) : nullptr; A.valid = a->valid ? dev(va) : nullptr; A.counts = dc; A.cap = nA;
+    B.groups = b->groups ? (const int32_t *)dev(gb) : nullptr; B.valid = b->valid ? dev(vb) : nullptr; B.counts = dc + 1; B.cap = nB;
+    const size_t n16 = bx.used / 16;
+    hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 512)), dim3(256), 0, m->stream, (const uint4 *)bx.inDev, (uint4 *)ar, n16);
+    MLAUNCH_CHECK();
+    uint32_t dcut = TH_LOW + 1;
+    while (dcut < 257 && !(prm->nn_ratio * (float)dcut > (float)TH_LOW)) dcut++;
+    const bool filter = b->groups != nullptr || (prm->mode == 1 && b->valid != nullptr);
+    // geometry: 64 A features per workgroup; B slices so that ~2 x 256 workgroups exist and a wave still has >= 16 features to scan
+    const int nRowBlocks = (nA + SPLIT_ROWS - 1) / SPLIT_ROWS;
+    int SY = std::max(1, std::min(16, 512 / nRowBlocks));
+    SY = std::max(1, std::min(SY, (nB + 63) / 64));
+    const int per = (((nB + 4 * SY - 1) / (4 * SY)) + 3) & ~3;
+    const int nOrder = (nA + 31) / 32;
+    const size_t partWords = (size_t)SY * nRowBlocks * SPLIT_ROWS * TOPK;
+    if ((rc = m->topkPart.ensure(partWords)) != ORBX_OK) return rc;
+    if ((size_t)nRowBlocks > m->rowCounter.n) {
+        if ((rc = m->rowCounter.ensure((size_t)std::max(nRowBlocks, 1024))) != ORBX_OK) return rc;
+        ORBX_HIP_CHECK(hipMemsetAsync(m->rowCounter.p, 0, m->rowCounter.n * sizeof(unsigned), m->stream));
+    }
+    if ((rc = m->topk.ensure(NA * TOPK)) != ORBX_OK || (rc = m->order.ensure(NA)) != ORBX_OK) return rc;
+    const dim3 grid((unsigned)(nRowBlocks * SY + nOrder));
+    if (filter) hipLaunchKernelGGL(k_bow_topk_split<true>, grid, dim3(256), 0, m->stream, A, B, prm->mode, dcut, nRowBlocks, SY, per, m->topkPart.p, m->rowCounter.p, m->topk.p, m->order.p);
+    else hipLaunchKernelGGL(k_bow_topk_split<false>, grid, dim3(256), 0, m->stream, A, B, prm->mode, dcut, nRowBlocks, SY, per, m->topkPart.p, m->rowCounter.p, m->topk.p, m->order.p);
+    MLAUNCH_CHECK();
+    const size_t ldsGreedy = NB * 4 + NA * 4 + (size_t)((nA + 7) & ~7) * 2 * 2;
+    if (ldsGreedy > 160 * 1024) { orbx_set_error("feature count %d too large for the LDS tile", nA); return ORBX_ERR_CAPACITY; }
+    if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
+    if (!m->sfZero.p) {
+        if ((rc = m->sfZero.ensure(4)) != ORBX_OK) return rc;
+        ORBX_HIP_CHECK(hipMemsetAsync(m->sfZero.p, 0, 4 * sizeof(int32_t), m->stream));
+    }
+    const int stride = m->maxFeatures;
+    const unsigned long long seq = bx.arm();
+    hipLaunchKernelGGL(k_bow_greedy, dim3(1), dim3(GREEDY_THREADS), ldsGreedy, m->stream, A, B, (const int32_t *)m->sfZero.p, (const int32_t *)m->sfZero.p, prm->mode, prm->nn_ratio,
+                       prm->check_orientation, m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride, TriDev(), bx.outDev<int32_t>(0), bx.flagDev, seq);
+    MLAUNCH_CHECK();
+    m->lastPairs = 1; m->lastStride = stride;
+    if ((rc = bx.wait(m->stream)) != ORBX_OK) return rc;
+    const int32_t *res = bx.outHost<int32_t>(0);
+    if (nOut > 0) memcpy(matches, res, (size_t)nOut * 4);
+    *nmatches = res[nOut];
+    return ORBX_OK;
+}
+
 extern "C" int orbx_search_by_bow(orbx_matcher *m, const orbx_feature_set *a_host, const orbx_feature_set *b_host, const orbx_bow_params *params,
                                   int32_t *matches, int32_t *nmatches)
 {
     if (!m || !matches || !nmatches) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (!params || (params->mode != 0 && params->mode != 1)) { orbx_set_error("bad bow params"); return ORBX_ERR_ARG; }
     ORBX_HIP_CHECK(hipSetDevice(m->device));
+    static const bool split = !(getenv("ORBX_BOW_SINGLE_SPLIT") && getenv("ORBX_BOW_SINGLE_SPLIT")[0] == '0');
+    if (split && a_host && b_host && a_host->keypoints && a_host->descriptors && a_host->counts && b_host->keypoints && b_host->descriptors && b_host->counts &&
+        a_host->counts[0] > 0 && b_host->counts[0] > 0 && a_host->counts[0] <= m->maxFeatures && b_host->counts[0] <= m->maxFeatures)
+        return search_by_bow_single(m, a_host, b_host, params, matches, nmatches);
     orbx_feature_set da, db;
     int rc;
     if ((rc = stage_host(m, 0, a_host, &da)) != ORBX_OK || (rc = stage_host(m, 1, b_host, &db)) != ORBX_OK) return rc;
@@ -1595,7 +1816,7 @@ extern "C" int orbx_search_for_triangulation_device(orbx_matcher *m, const orbx_
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature capacity %d too large for the LDS tile", a->capacity); return ORBX_ERR_CAPACITY; }
     if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
     hipLaunchKernelGGL(k_bow_greedy, dim3((unsigned)npairs), dim3(GREEDY_THREADS), ldsGreedy, m->stream, A, B, m->pairsA.p, m->pairsB.p, 2, 0.0f, params->check_orientation,
-                       m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride, T);
+                       m->topk.p, m->order.p, m->matches.p, m->dists.p, m->nmatches.p, stride, T, (int32_t *)nullptr, (unsigned long long *)nullptr, 0ull);
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
     m->profCount++;

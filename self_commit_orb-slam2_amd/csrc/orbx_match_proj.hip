@@ -31,22 +31,26 @@ struct ProjPointsDev { const float *px, *py, *pxr; const int32_t *level; const f
 // gate + key of feature idx for one map point; KEY64_EMPTY when the feature is not a candidate
 struct ProjQuery { float x, y, rr, xr; int minLevel, maxLevel, cx0, cx1, cy0, cy1; bool any; unsigned long long d[4]; };
 
-__device__ __forceinline__ ProjQuery proj_query(const ProjFrameDev &F, const ProjPointsDev &P, size_t pi, const float *scaleFactors, float th)
+__device__ __forceinline__ ProjQuery proj_query_vals(const ProjFrameDev &F, float px, float py, float pxr, int lvl, float viewCos, const uint8_t *desc32, const float *scaleFactors, float th)
 {
     ProjQuery q;
-    const int lvl = P.level[pi];
-    float r = (double)P.viewCos[pi] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos, :178-185
+    float r = (double)viewCos > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos, :178-185
     if (th != 1.0f) r *= th;
-    q.x = P.px[pi]; q.y = P.py[pi]; q.xr = P.pxr[pi];
+    q.x = px; q.y = py; q.xr = pxr;
     q.rr = r * scaleFactors[lvl];
     q.minLevel = lvl - 1; q.maxLevel = lvl;
     const int nMinCellX = max(0, (int)floorf((q.x - F.minX - q.rr) * F.gwInv)), nMaxCellX = min(GRID_COLS - 1, (int)ceilf((q.x - F.minX + q.rr) * F.gwInv));
     const int nMinCellY = max(0, (int)floorf((q.y - F.minY - q.rr) * F.ghInv)), nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((q.y - F.minY + q.rr) * F.ghInv));
     q.any = !(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0);
     q.cx0 = nMinCellX; q.cx1 = nMaxCellX; q.cy0 = nMinCellY; q.cy1 = nMaxCellY;
-    const unsigned long long *dp = (const unsigned long long *)(P.desc + pi * 32);
+    const unsigned long long *dp = (const unsigned long long *)desc32;
     q.d[0] = dp[0]; q.d[1] = dp[1]; q.d[2] = dp[2]; q.d[3] = dp[3];
     return q;
+}
+
+__device__ __forceinline__ ProjQuery proj_query(const ProjFrameDev &F, const ProjPointsDev &P, size_t pi, const float *scaleFactors, float th)
+{
+    return proj_query_vals(F, P.px[pi], P.py[pi], P.pxr[pi], P.level[pi], P.viewCos[pi], P.desc + pi * 32, scaleFactors, th);
 }
 
 __device__ __forceinline__ unsigned long long proj_key(const ProjFrameDev &F, size_t fbase, int idx, const ProjQuery &q)
@@ -64,16 +68,9 @@ __device__ __forceinline__ unsigned long long proj_key(const ProjFrameDev &F, si
     return ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)idx;
 }
 
-__global__ __launch_bounds__(256) void k_proj_topk(ProjFrameDev F, ProjPointsDev P, const float *__restrict__ scaleFactors, float th,
-                                                   unsigned long long *__restrict__ topk)
+// the TOPK smallest keys of one map point's query over the frame's features (one wave, lanes over the features) -> out[0..TOPK)
+__device__ __forceinline__ void proj_topk_wave(const ProjFrameDev &F, size_t fbase, int n, const ProjQuery &q, int lane, unsigned long long *out)
 {
-    const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
-    if (i >= m) return;
-    const size_t pi = (size_t)f * P.cap + i, fbase = (size_t)f * F.cap;
-    unsigned long long *out = topk + pi * TOPK;
-    if (!P.inView[pi]) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
-    const ProjQuery q = proj_query(F, P, pi, scaleFactors, th);
     unsigned long long kk[TOPK];
 #pragma unroll
     for (int t = 0; t < TOPK; t++) kk[t] = KEY64_EMPTY;
@@ -99,6 +96,19 @@ __global__ __launch_bounds__(256) void k_proj_topk(ProjFrameDev F, ProjPointsDev
     }
 }
 
+__global__ __launch_bounds__(256) void k_proj_topk(ProjFrameDev F, ProjPointsDev P, const float *__restrict__ scaleFactors, float th,
+                                                   unsigned long long *__restrict__ topk)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
+    if (i >= m) return;
+    const size_t pi = (size_t)f * P.cap + i, fbase = (size_t)f * F.cap;
+    unsigned long long *out = topk + pi * TOPK;
+    if (!P.inView[pi]) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
+    const ProjQuery q = proj_query(F, P, pi, scaleFactors, th);
+    proj_topk_wave(F, fbase, n, q, lane, out);
+}
+
 // Replay of the reference's sequential pass over the map points (src/ORBmatcher.cc:70-175).  The pass is
 // sequential only through F.mvpMapPoints: a feature that already holds a MapPoint WITH observations is
 // skipped (:110-112), and an accepted point writes itself into its best feature (:169).  As in
@@ -115,7 +125,8 @@ __global__ __launch_bounds__(256) void k_proj_topk(ProjFrameDev F, ProjPointsDev
 __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_greedy(ProjFrameDev F, ProjPointsDev P, const float *__restrict__ scaleFactors, float th, float nnratio,
                                                                      const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
                                                                      int32_t *__restrict__ nmatches, int stride, uint32_t *__restrict__ decBuf,
-                                                                     uint32_t *__restrict__ queueBuf)
+                                                                     uint32_t *__restrict__ queueBuf, int32_t *__restrict__ pubAssigned, unsigned long long *pubFlag,
+                                                                     unsigned long long pubSeq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int sChanged, sQueued, sTotal;
@@ -212,6 +223,12 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_greedy(ProjFrameDe
     __syncthreads();
     for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) if (owner[j]) aout[j] = (int32_t)owner[j] - 1;
     if (tid == 0) nmatches[f] = sTotal;
+    if (pubFlag) {
+        // the single-frame host call: assigned[0..n) and the count straight into the caller's mapped pinned buffer, the sequence word behind them
+        for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) pubAssigned[j] = owner[j] ? (int32_t)owner[j] - 1 : -1;
+        if (tid == 0) pubAssigned[n] = sTotal;
+        orbx_publish(nullptr, pubFlag, pubSeq, 1u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1110,7 +1127,7 @@ static int proj_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjPointsD
     if ((rc = m->projDec.ensure((size_t)nframes * P.cap)) != ORBX_OK || (rc = m->projQueue.ensure((size_t)nframes * P.cap)) != ORBX_OK) return rc;
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_proj_greedy, dim3((unsigned)nframes), dim3(PROJ_GREEDY_THREADS), lds, m->stream, F, P, m->scales.p, th, nnratio, m->topk64.p, m->matches.p,
-                       m->nmatches.p, stride, m->projDec.p, m->projQueue.p);
+                       m->nmatches.p, stride, m->projDec.p, m->projQueue.p, (int32_t *)nullptr, (unsigned long long *)nullptr, 0ull);
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
     m->profCount++;
@@ -1283,14 +1300,9 @@ struct FrustumDev {
 };
 struct MapPointsDev { const float *pos, *normal, *maxDist, *minDist; const int32_t *counts; int cap; };
 
-__global__ __launch_bounds__(256) void k_is_in_frustum(FrustumDev Fr, MapPointsDev M, float *__restrict__ projX, float *__restrict__ projY, float *__restrict__ projXR,
-                                                       int32_t *__restrict__ level, float *__restrict__ viewCosOut, uint8_t *__restrict__ inView)
+// Frame::isInFrustum for point pi of frame f: false = not in view (:615); true: the mTrack* values (:721-731)
+__device__ __forceinline__ bool frustum_point(const FrustumDev &Fr, const MapPointsDev &M, int f, size_t pi, float &u, float &v, float &ur, int &lvlOut, float &viewCosOut)
 {
-    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    const int m = min(M.counts[f], M.cap);
-    if (i >= m) return;
-    const size_t pi = (size_t)f * M.cap + i;
-    inView[pi] = 0;                                                              // :615
     const float *T = Fr.tcw + 16 * (size_t)f, *P = M.pos + 3 * pi;
     float Pc[3], Ow[3];
 #pragma unroll
@@ -1304,25 +1316,67 @@ __global__ __launch_bounds__(256) void k_is_in_frustum(FrustumDev Fr, MapPointsD
         o = o + (-T[2 * 4 + r]) * T[2 * 4 + 3];
         Ow[r] = o;
     }
-    if (Pc[2] < 0.0f) return;                                                    // :635
+    if (Pc[2] < 0.0f) return false;                                              // :635
     const float invz = 1.0f / Pc[2];
-    const float u = Fr.fx * Pc[0] * invz + Fr.cx, v = Fr.fy * Pc[1] * invz + Fr.cy;
-    if (u < Fr.minX || u > Fr.maxX) return;                                      // :653-656
-    if (v < Fr.minY || v > Fr.maxY) return;
+    u = Fr.fx * Pc[0] * invz + Fr.cx; v = Fr.fy * Pc[1] * invz + Fr.cy;
+    if (u < Fr.minX || u > Fr.maxX) return false;                                // :653-656
+    if (v < Fr.minY || v > Fr.maxY) return false;
     const float maxDistance = 1.2f * M.maxDist[pi], minDistance = 0.8f * M.minDist[pi];   // Get{Max,Min}DistanceInvariance, src/MapPoint.cc:523-533
     const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
     const float dist = (float)sqrt((double)PO[0] * (double)PO[0] + (double)PO[1] * (double)PO[1] + (double)PO[2] * (double)PO[2]);   // cv::norm, :677
-    if (dist < minDistance || dist > maxDistance) return;                        // :680
+    if (dist < minDistance || dist > maxDistance) return false;                  // :680
     const float *Pn = M.normal + 3 * pi;
     const double dot = (double)PO[0] * (double)Pn[0] + (double)PO[1] * (double)Pn[1] + (double)PO[2] * (double)Pn[2];
     const float viewCos = (float)(dot / (double)dist);                           // :697
-    if (viewCos < Fr.cosLimit) return;
+    if (viewCos < Fr.cosLimit) return false;
     const float ratio = M.maxDist[pi] / dist;                                    // MapPoint::PredictScale, src/MapPoint.cc:571-586
     int lvl = Fr.nlevels - 1;
     for (int k = Fr.nlevels - 2; k >= 0; k--)
         if (!(ratio > Fr.ratioTh[k])) lvl = k;
-    inView[pi] = 1;
-    projX[pi] = u; projXR[pi] = u - Fr.mbf * invz; projY[pi] = v; level[pi] = lvl; viewCosOut[pi] = viewCos;   // :721-731
+    ur = u - Fr.mbf * invz; lvlOut = lvl; viewCosOut = viewCos;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_is_in_frustum(FrustumDev Fr, MapPointsDev M, float *__restrict__ projX, float *__restrict__ projY, float *__restrict__ projXR,
+                                                       int32_t *__restrict__ level, float *__restrict__ viewCosOut, uint8_t *__restrict__ inView)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int m = min(M.counts[f], M.cap);
+    if (i >= m) return;
+    const size_t pi = (size_t)f * M.cap + i;
+    float u = 0, v = 0, ur = 0, vc = 0;
+    int lvl = 0;
+    const bool in = frustum_point(Fr, M, f, pi, u, v, ur, lvl, vc);
+    inView[pi] = in ? 1 : 0;
+    if (in) { projX[pi] = u; projXR[pi] = ur; projY[pi] = v; level[pi] = lvl; viewCosOut[pi] = vc; }   // :721-731
+}
+
+// Tracking::SearchLocalPoints for ONE frame from host arrays (orbx_search_local_points): the frustum test and the candidate lists in one launch.  One
+// wave per map point: every lane evaluates the point's frustum test (the same few dozen operations in all lanes; the point's position / normal /
+// distances are read from MAPPED host memory, once per wave), lane 0 stores the mTrack* values for the replay's rescans (device) and for the caller
+// (mapped host), then the wave scans the frame's features for the point's TOPK keys as k_proj_topk does.
+struct FrustumHostOut { float *px, *py, *pxr, *vc; int32_t *lvl; uint8_t *inView; };
+__global__ __launch_bounds__(256) void k_frustum_topk(FrustumDev Fr, MapPointsDev M, ProjFrameDev F, const uint8_t *__restrict__ pdesc, const float *__restrict__ scaleFactors, float th,
+                                                      float *__restrict__ dPx, float *__restrict__ dPy, float *__restrict__ dPxr, int32_t *__restrict__ dLvl, float *__restrict__ dVc,
+                                                      uint8_t *__restrict__ dIn, FrustumHostOut H, unsigned long long *__restrict__ topk)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(F.counts[0], F.cap), m = min(M.counts[0], M.cap);
+    if (i >= m) return;
+    unsigned long long *out = topk + (size_t)i * TOPK;
+    float u = 0, v = 0, ur = 0, vc = 0;
+    int lvl = 0;
+    const bool in = frustum_point(Fr, M, 0, (size_t)i, u, v, ur, lvl, vc);
+    if (lane == 0) {
+        dIn[i] = in ? 1 : 0; H.inView[i] = in ? 1 : 0;
+        if (in) {
+            dPx[i] = u; dPy[i] = v; dPxr[i] = ur; dLvl[i] = lvl; dVc[i] = vc;
+            H.px[i] = u; H.py[i] = v; H.pxr[i] = ur; H.lvl[i] = lvl; H.vc[i] = vc;
+        }
+    }
+    if (!in) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
+    const ProjQuery q = proj_query_vals(F, u, v, ur, lvl, vc, pdesc + (size_t)i * 32, scaleFactors, th);
+    proj_topk_wave(F, 0, n, q, lane, out);
 }
 
 // largest float r with ceil(log((double)r) / (double)log_scale_factor) <= k, for k = 0 .. nlevels-2 (host, libm)
@@ -1455,51 +1509,75 @@ extern "C" int orbx_search_local_points(orbx_matcher *m, const orbx_projection_f
     }
     if (n > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
     ORBX_HIP_CHECK(hipSetDevice(m->device));
+    // No copy engine, no stream synchronisation (OrbxCallBox).  What EVERY wave of the chain reads - the frame's keypoints, descriptors, uRight, occupied
+    // flags, the points' observation flags, the scale factors - is copied once into the device arena by k_stage_copy; what is read once per map point -
+    // position, normal, distance range, descriptor - stays in mapped pinned memory and is read there.  k_frustum_topk (frustum test + candidate lists,
+    // the mTrack* values to the device for the replay and to the caller's mapped buffer), then k_proj_greedy, which writes assigned[] + the count into
+    // the mapped buffer and raises the sequence word.
     int rc;
     hipStream_t st = m->stream;
-    OrbxHostStage &hs = m->hostStage;
+    OrbxCallBox &bx = m->box;
     const size_t N = (size_t)n, M = (size_t)mm;
-    const size_t inBytes = hs.padded(N * sizeof(orbx_keypoint)) + hs.padded(N * 32) + hs.padded(N * 4) + hs.padded(N) + hs.padded(8) + hs.padded(64) + 2 * hs.padded(M * 12) +
-                           2 * hs.padded(M * 4) + hs.padded(M * 32) + hs.padded(M);
-    const size_t offLvl = hs.padded(M * 16), offIn = offLvl + hs.padded(M * 4), offAs = offIn + hs.padded(M), offNm = offAs + hs.padded(N * 4), outBytes = offNm + hs.padded(4);
-    ORBX_HIP_CHECK(hipStreamSynchronize(st));
-    if ((rc = hs.begin(inBytes > outBytes ? inBytes : outBytes)) != ORBX_OK) return rc;
+    const size_t inBytes = bx.padded(N * sizeof(orbx_keypoint)) + bx.padded(N * 32) + bx.padded(N * 4) + bx.padded(N) + bx.padded(8) + bx.padded(64) + bx.padded(M) + bx.padded(64 * 4) +
+                           2 * bx.padded(M * 12) + 2 * bx.padded(M * 4) + bx.padded(M * 32);
+    const size_t offPy = bx.padded(M * 4), offPxr = 2 * offPy, offVc = 3 * offPy, offLvl = 4 * offPy, offIn = offLvl + bx.padded(M * 4), offAs = offIn + bx.padded(M),
+                 outBytes = offAs + bx.padded((N + 1) * 4);
+    if ((rc = bx.begin(inBytes, outBytes, st)) != ORBX_OK) return rc;
     const int32_t cnt[2] = {n, mm};
-    const orbx_keypoint *dKp = hs.put(fr->keypoints_un, N);
-    const uint8_t *dDesc = hs.put(fr->descriptors, N * 32);
-    const float *dUr = hs.put(fr->u_right, N);
-    const uint8_t *dOcc = hs.put(fr->occupied, N);
-    const int32_t *dCnt = hs.put(cnt, 2);
-    orbx_frustum_frame fd = *pose;
-    fd.tcw = hs.put(pose->tcw, 16); fd.nframes = 1;
-    orbx_map_points pd;
-    pd.world_pos = hs.put(pt->world_pos, M * 3);
-    pd.normal = hs.put(pt->normal, M * 3);
-    pd.max_distance = hs.put(pt->max_distance, M);
-    pd.min_distance = hs.put(pt->min_distance, M);
-    pd.counts = dCnt + 1;
-    pd.capacity = mm;
-    const uint8_t *dPd = hs.put(pt->descriptors, M * 32), *dObs = hs.put(pt->has_observations, M);
-    if ((rc = hs.flush(st)) != ORBX_OK) return rc;
-    if ((rc = orbx_is_in_frustum_device(m, &fd, &pd, viewing_cos_limit)) != ORBX_OK) return rc;
-    ProjFrameDev F = {dKp, dDesc, dUr, fr->occupied ? dOcc : nullptr, dCnt, n, fr->min_x, fr->min_y, fr->grid_width_inv, fr->grid_height_inv};
-    ProjPointsDev P = {m->frProj.p, m->frProj.p + M, m->frProj.p + 2 * M, m->frLevel.p, m->frProj.p + 3 * M, m->frInView.p, pt->has_observations ? dObs : nullptr, dPd, dCnt + 1, mm};
-    if ((rc = proj_launch(m, F, P, 1, scale_factors, nlevels, th, nn_ratio)) != ORBX_OK) return rc;
-    uint8_t *hp = hs.host;        // stream order: the kernels have consumed the uploaded inputs before these copies land in the same pinned buffer
-    ORBX_HIP_CHECK(hipMemcpyAsync(hp, m->frProj.p, M * 16, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(hp + offLvl, m->frLevel.p, M * 4, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(hp + offIn, m->frInView.p, M, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(hp + offAs, m->matches.p, N * 4, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(hp + offNm, m->nmatches.p, 4, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_CHECK(hipStreamSynchronize(st));
-    const float *pp = (const float *)hp;
-    if (proj_x) memcpy(proj_x, pp, M * 4);
-    if (proj_y) memcpy(proj_y, pp + M, M * 4);
-    if (proj_xr) memcpy(proj_xr, pp + 2 * M, M * 4);
-    if (view_cos) memcpy(view_cos, pp + 3 * M, M * 4);
-    if (scale_level) memcpy(scale_level, hp + offLvl, M * 4);
-    memcpy(in_view, hp + offIn, M);
-    memcpy(assigned, hp + offAs, N * 4);
-    if (nmatches) memcpy(nmatches, hp + offNm, 4);
+    // --- staged part (first in the buffer)
+    const void *bKp = bx.put(fr->keypoints_un, N), *bDesc = bx.put(fr->descriptors, N * 32), *bUr = bx.put(fr->u_right, N), *bOcc = bx.put(fr->occupied, fr->occupied ? N : 0);
+    const void *bCnt = bx.put(cnt, 2), *bTcw = bx.put(pose->tcw, 16), *bObs = bx.put(pt->has_observations, pt->has_observations ? M : 0), *bSc = bx.put(scale_factors, (size_t)nlevels);
+    const size_t staged = bx.used;
+    // --- read in place
+    const float *zPos = bx.put(pt->world_pos, M * 3), *zNrm = bx.put(pt->normal, M * 3), *zMax = bx.put(pt->max_distance, M), *zMin = bx.put(pt->min_distance, M);
+    const uint8_t *zDesc = bx.put(pt->descriptors, M * 32);
+    if ((rc = m->arena.ensure(staged)) != ORBX_OK) return rc;
+    uint8_t *const ar = m->arena.p;
+    auto dev = [&](const void *boxAddr) { return ar + ((const uint8_t *)boxAddr - bx.inDev); };
+    const size_t n16 = staged / 16;
+    hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 512)), dim3(256), 0, st, (const uint4 *)bx.inDev, (uint4 *)ar, n16);
+    MLAUNCH_CHECK();
+    if ((rc = m->frProj.ensure(4 * M)) || (rc = m->frLevel.ensure(M)) || (rc = m->frInView.ensure(M)) || (rc = m->topk64.ensure(M * TOPK)) || (rc = m->projDec.ensure(M)) ||
+        (rc = m->projQueue.ensure(M))) return rc;
+    const int32_t *dCnt = (const int32_t *)dev(bCnt);
+    FrustumDev Fr;
+    Fr.tcw = (const float *)dev(bTcw); Fr.fx = pose->fx; Fr.fy = pose->fy; Fr.cx = pose->cx; Fr.cy = pose->cy; Fr.mbf = pose->mbf;
+    Fr.minX = pose->min_x; Fr.maxX = pose->max_x; Fr.minY = pose->min_y; Fr.maxY = pose->max_y; Fr.cosLimit = viewing_cos_limit; Fr.nlevels = pose->nlevels;
+    for (int k = 0; k < ORBX_MAX_LEVELS; k++) Fr.ratioTh[k] = k + 1 < pose->nlevels ? pose->ratio_thresholds[k] : 0.0f;
+    MapPointsDev Mp = {zPos, zNrm, zMax, zMin, dCnt + 1, mm};
+    ProjFrameDev F = {(const orbx_keypoint *)dev(bKp), dev(bDesc), (const float *)dev(bUr), fr->occupied ? dev(bOcc) : nullptr, dCnt, n, fr->min_x, fr->min_y, fr->grid_width_inv,
+                      fr->grid_height_inv};
+    const float *dScales = (const float *)dev(bSc);
+    FrustumHostOut Ho = {bx.outDev<float>(0), bx.outDev<float>(offPy), bx.outDev<float>(offPxr), bx.outDev<float>(offVc), bx.outDev<int32_t>(offLvl), bx.outDev<uint8_t>(offIn)};
+    hipLaunchKernelGGL(k_frustum_topk, dim3((unsigned)((mm + 3) / 4)), dim3(256), 0, st, Fr, Mp, F, zDesc, dScales, th, m->frProj.p, m->frProj.p + M, m->frProj.p + 2 * M, m->frLevel.p,
+                       m->frProj.p + 3 * M, m->frInView.p, Ho, m->topk64.p);
+    MLAUNCH_CHECK();
+    m->frCount = M;
+    ProjPointsDev P = {m->frProj.p, m->frProj.p + M, m->frProj.p + 2 * M, m->frLevel.p, m->frProj.p + 3 * M, m->frInView.p, pt->has_observations ? dev(bObs) : nullptr, zDesc, dCnt + 1, mm};
+    const size_t lds = (size_t)n * 6 + 16;
+    if (lds > 160 * 1024) { orbx_set_error("feature count %d too large for the LDS tile of the projection replay", n); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int stride = m->maxFeatures;
+    const unsigned long long seq = bx.arm();
+    hipLaunchKernelGGL(k_proj_greedy, dim3(1), dim3(PROJ_GREEDY_THREADS), lds, st, F, P, dScales, th, nn_ratio, m->topk64.p, m->matches.p, m->nmatches.p, stride, m->projDec.p,
+                       m->projQueue.p, bx.outDev<int32_t>(offAs), bx.flagDev, seq);
+    MLAUNCH_CHECK();
+    m->lastPairs = 1; m->lastStride = stride;
+    if ((rc = bx.wait(st)) != ORBX_OK) return rc;
+    memcpy(in_view, bx.outHost<uint8_t>(offIn), M);
+    // (the mTrack* values of a point that is not in view are not written by the kernel: the caller's arrays keep what they held, as with the reference's members)
+    const float *hx = bx.outHost<float>(0), *hy = bx.outHost<float>(offPy), *hxr = bx.outHost<float>(offPxr), *hvc = bx.outHost<float>(offVc);
+    const int32_t *hl = bx.outHost<int32_t>(offLvl);
+    for (int k = 0; k < mm; k++)
+        if (in_view[k]) {
+            if (proj_x) proj_x[k] = hx[k];
+            if (proj_y) proj_y[k] = hy[k];
+            if (proj_xr) proj_xr[k] = hxr[k];
+            if (view_cos) view_cos[k] = hvc[k];
+            if (scale_level) scale_level[k] = hl[k];
+        }
+    const int32_t *as = bx.outHost<int32_t>(offAs);
+    memcpy(assigned, as, N * 4);
+    if (nmatches) *nmatches = as[n];
     return ORBX_OK;
 }

@@ -108,13 +108,19 @@ void Transform(const ORBVocabulary *voc, const cv::Mat &descriptors, DBoW2::BowV
     const int n = descriptors.rows;
     std::vector<int32_t> word((size_t)(n > 0 ? n : 1)), node((size_t)(n > 0 ? n : 1));
     std::vector<double> weight((size_t)(n > 0 ? n : 1));
-    std::vector<unsigned char> flat((size_t)(n > 0 ? n : 1) * 32);
-    for (int i = 0; i < n; i++) memcpy(&flat[32 * (size_t)i], descriptors.ptr<unsigned char>(i), 32);
+    // (the library copies the descriptors into its mapped pinned buffer itself: a continuous matrix - what the extractor and KeyFrame's clone produce - goes as it is)
+    std::vector<unsigned char> flat;
+    const unsigned char *rows = descriptors.data;
+    if (n > 0 && !(descriptors.isContinuous() && descriptors.cols == 32)) {
+        flat.resize((size_t)n * 32);
+        for (int i = 0; i < n; i++) memcpy(&flat[32 * (size_t)i], descriptors.ptr<unsigned char>(i), 32);
+        rows = &flat[0];
+    }
     {
         DeviceVoc *dv = DeviceVocabulary(voc);
         if (!dv) return;      // empty vectors, as for an image without features
         std::unique_lock<std::mutex> call(dv->call);      // the whole call: upload, descent, download into OUR vectors
-        if (orbx_bow_transform(dv->h, &flat[0], n, levelsup, &word[0], &node[0], &weight[0]) != ORBX_OK) { orbx_shim::Fail("ComputeBoW"); return; }
+        if (orbx_bow_transform(dv->h, rows, n, levelsup, &word[0], &node[0], &weight[0]) != ORBX_OK) { orbx_shim::Fail("ComputeBoW"); return; }
     }
     DBoW2::LNorm norm;
     const bool must = VocAccess::Scoring(*voc)->mustNormalize(norm);
