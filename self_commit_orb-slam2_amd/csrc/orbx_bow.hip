@@ -24,7 +24,7 @@ struct VocNode { int32_t childStart, childCount, word, pad; };   // word >= 0: l
 
 __device__ __forceinline__ void bow_descend(const VocNode *__restrict__ nodes, const int32_t *__restrict__ childList, const uint4 *__restrict__ childDesc,
                                             const double *__restrict__ nodeWeight, int nidLevel, const uint8_t *__restrict__ desc, int cap, int32_t *__restrict__ word,
-                                            int32_t *__restrict__ node, double *__restrict__ weight, int f, int i)
+                                            int32_t *__restrict__ node, double *__restrict__ weight, int f, int i, int &wordOut, int &nodeOut)
 {
     const uint4 *dp = (const uint4 *)(desc + ((size_t)f * cap + i) * 32);
     const uint4 a0 = dp[0], a1 = dp[1];
@@ -45,22 +45,62 @@ __device__ __forceinline__ void bow_descend(const VocNode *__restrict__ nodes, c
     }
     const double w = nodeWeight[cur];
     const size_t o = (size_t)f * cap + i;
-    word[o] = nd.word;
+    wordOut = nd.word;
+    nodeOut = w > 0 ? nid : -1;   // features whose word has weight 0 are not filed in the FeatureVector (:1160-1166)
+    word[o] = wordOut;
     weight[o] = w;
-    node[o] = w > 0 ? nid : -1;   // features whose word has weight 0 are not filed in the FeatureVector (:1160-1166)
+    node[o] = nodeOut;
 }
 
 // pubFlag != nullptr: the host-array call - word / node / weight are MAPPED host memory and the last workgroup raises the call's sequence word behind them
 __global__ __launch_bounds__(256) void k_bow_transform(const VocNode *__restrict__ nodes, const int32_t *__restrict__ childList,
                                                        const uint4 *__restrict__ childDesc, const double *__restrict__ nodeWeight, int nidLevel,
                                                        const uint8_t *__restrict__ desc, const int32_t *__restrict__ counts, int cap, int32_t *__restrict__ word,
-                                                       int32_t *__restrict__ node, double *__restrict__ weight, unsigned *pubCounter, unsigned long long *pubFlag,
-                                                       unsigned long long pubSeq)
+                                                       int32_t *__restrict__ node, double *__restrict__ weight, int32_t *__restrict__ wordDev, int32_t *__restrict__ nodeDev,
+                                                       unsigned *pubCounter, unsigned long long *pubFlag, unsigned long long pubSeq)
 {
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const int n = counts ? min(counts[f], cap) : cap;
-    if (i < n) bow_descend(nodes, childList, childDesc, nodeWeight, nidLevel, desc, cap, word, node, weight, f, i);
+    if (i < n) {
+        int w = 0, nd = 0;
+        bow_descend(nodes, childList, childDesc, nodeWeight, nidLevel, desc, cap, word, node, weight, f, i, w, nd);
+        if (wordDev) { wordDev[i] = w; nodeDev[i] = nd; }      // (host-array call, one frame: a device copy for k_bow_ranks - word / node are mapped host memory there)
+    }
     if (pubFlag) orbx_publish(pubCounter, pubFlag, pubSeq, gridDim.x * gridDim.y);
+}
+
+// The orders of orbx_bow_transform_sorted: rank of feature i among the filed features by (word, i) and by (node, i); 32 features per workgroup, the 8
+// lanes of a feature share the scan of the keys (staged in LDS).  Features that are not filed (weight 0: node -1) rank behind all others and are not
+// written.  The last workgroup to arrive raises the call's sequence word (the transform's own results were written by the kernel before).
+__global__ __launch_bounds__(256) void k_bow_ranks(const int32_t *__restrict__ word, const int32_t *__restrict__ node, int n, int32_t *__restrict__ byWord,
+                                                   int32_t *__restrict__ byNode, int32_t *__restrict__ filedOut, unsigned *pubCounter, unsigned long long *pubFlag,
+                                                   unsigned long long pubSeq)
+{
+    __shared__ int32_t sW[2048], sN[2048];
+    const int tid = threadIdx.x, i = blockIdx.x * 32 + (tid >> 3), seg = tid & 7;
+    const bool live = i < n;
+    const int ni = live ? node[i] : -1, wi = live ? word[i] : 0;
+    const bool filedI = live && ni >= 0;
+    int rw = 0, rn = 0, filed = 0;
+    for (int t0 = 0; t0 < n; t0 += 2048) {
+        const int tn = min(2048, n - t0);
+        __syncthreads();
+        for (int k = tid; k < tn; k += 256) { const int nk = node[t0 + k]; sN[k] = nk; sW[k] = nk >= 0 ? word[t0 + k] : 0x7fffffff; }
+        __syncthreads();
+        for (int k = seg; k < tn; k += 8) {
+            const int nk = sN[k], wk = sW[k];
+            const bool fk = nk >= 0, before = t0 + k < i;
+            filed += fk ? 1 : 0;
+            rw += (fk && (wk < wi || (wk == wi && before))) ? 1 : 0;
+            rn += (fk && (nk < ni || (nk == ni && before))) ? 1 : 0;
+        }
+    }
+    rw += __shfl_xor(rw, 1); rw += __shfl_xor(rw, 2); rw += __shfl_xor(rw, 4);
+    rn += __shfl_xor(rn, 1); rn += __shfl_xor(rn, 2); rn += __shfl_xor(rn, 4);
+    filed += __shfl_xor(filed, 1); filed += __shfl_xor(filed, 2); filed += __shfl_xor(filed, 4);
+    if (seg == 0 && filedI) { byWord[rw] = i; byNode[rn] = i; }
+    if (blockIdx.x == 0 && tid == 0) *filedOut = filed;
+    orbx_publish(pubCounter, pubFlag, pubSeq, gridDim.x);
 }
 
 }  // namespace
@@ -145,7 +185,7 @@ static int launch_transform(orbx_vocabulary *v, hipStream_t stream, const uint8_
     const size_t n = (size_t)batch * cap;
     if ((rc = v->word[b].ensure(n)) || (rc = v->node[b].ensure(n)) || (rc = v->weight[b].ensure(n))) return rc;
     hipLaunchKernelGGL(k_bow_transform, dim3((unsigned)((cap + 255) / 256), (unsigned)batch), dim3(256), 0, stream, v->nodes.p, v->childList.p, v->childDesc.p,
-                       v->nodeWeight.p, v->L - levelsup, desc, counts, cap, v->word[b].p, v->node[b].p, v->weight[b].p, (unsigned *)nullptr, (unsigned long long *)nullptr, 0ull);
+                       v->nodeWeight.p, v->L - levelsup, desc, counts, cap, v->word[b].p, v->node[b].p, v->weight[b].p, (int32_t *)nullptr, (int32_t *)nullptr, (unsigned *)nullptr, (unsigned long long *)nullptr, 0ull);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     v->lastBatch = batch; v->lastCap = cap;
@@ -188,26 +228,54 @@ extern "C" int orbx_bow_download(orbx_vocabulary *v, orbx_extractor *ext, int ba
     return ORBX_OK;
 }
 
-// Host-array form (Frame::ComputeBoW / KeyFrame::ComputeBoW through shim/BoW_hip.cc): ONE kernel that reads the descriptors from mapped pinned memory
-// (32 bytes per thread, each once) and writes word / node / weight into mapped pinned memory; no copy engine, no stream synchronisation (OrbxCallBox).
-extern "C" int orbx_bow_transform(orbx_vocabulary *v, const uint8_t *descriptors, int n, int levelsup, int32_t *word, int32_t *node, double *weight)
+// Host-array form (Frame::ComputeBoW / KeyFrame::ComputeBoW through shim/BoW_hip.cc): the descent kernel reads the descriptors from mapped pinned memory
+// (32 bytes per thread, each once) and writes word / node / weight into mapped pinned memory (and word / node into device memory for the ranking
+// kernel of the _sorted form); no copy engine, no stream synchronisation (OrbxCallBox).
+static int bow_transform_host(orbx_vocabulary *v, const uint8_t *descriptors, int n, int levelsup, int32_t *word, int32_t *node, double *weight, int32_t *by_word, int32_t *by_node,
+                              int32_t *filed)
 {
     if (!v || (n > 0 && !descriptors)) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    if (filed) *filed = 0;
     if (n <= 0) return ORBX_OK;
     ORBX_HIP_CHECK(hipSetDevice(v->device));
     OrbxCallBox &bx = v->box;
-    const size_t N = (size_t)n, offNode = bx.padded(N * 4), offW = offNode + bx.padded(N * 4);
-    int rc = bx.begin(bx.padded(N * 32), offW + bx.padded(N * 8), v->stream);
+    const bool sorted = by_word && by_node && filed;
+    const size_t N = (size_t)n, offNode = bx.padded(N * 4), offW = offNode + bx.padded(N * 4), offBW = offW + bx.padded(N * 8), offBN = offBW + bx.padded(N * 4),
+                 offF = offBN + bx.padded(N * 4);
+    int rc = bx.begin(bx.padded(N * 32), offF + bx.padded(4), v->stream);
     if (rc != ORBX_OK) return rc;
     const uint8_t *dDesc = bx.put(descriptors, N * 32);
     const unsigned long long seq = bx.arm();
+    if (sorted && ((rc = v->word[0].ensure(N)) || (rc = v->node[0].ensure(N)))) return rc;
     hipLaunchKernelGGL(k_bow_transform, dim3((unsigned)((n + 255) / 256), 1u), dim3(256), 0, v->stream, v->nodes.p, v->childList.p, v->childDesc.p, v->nodeWeight.p, v->L - levelsup,
-                       dDesc, (const int32_t *)nullptr, n, bx.outDev<int32_t>(0), bx.outDev<int32_t>(offNode), bx.outDev<double>(offW), bx.counter, bx.flagDev, seq);
+                       dDesc, (const int32_t *)nullptr, n, bx.outDev<int32_t>(0), bx.outDev<int32_t>(offNode), bx.outDev<double>(offW), sorted ? v->word[0].p : (int32_t *)nullptr,
+                       sorted ? v->node[0].p : (int32_t *)nullptr, bx.counter, sorted ? (unsigned long long *)nullptr : bx.flagDev, seq);
+    if (sorted)
+        hipLaunchKernelGGL(k_bow_ranks, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, v->stream, (const int32_t *)v->word[0].p, (const int32_t *)v->node[0].p, n, bx.outDev<int32_t>(offBW),
+                           bx.outDev<int32_t>(offBN), bx.outDev<int32_t>(offF), bx.counter, bx.flagDev, seq);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     if ((rc = bx.wait(v->stream)) != ORBX_OK) return rc;
     if (word) memcpy(word, bx.outHost<int32_t>(0), N * 4);
     if (node) memcpy(node, bx.outHost<int32_t>(offNode), N * 4);
     if (weight) memcpy(weight, bx.outHost<double>(offW), N * 8);
+    if (sorted) {
+        const int nf = *bx.outHost<int32_t>(offF);
+        *filed = nf;
+        memcpy(by_word, bx.outHost<int32_t>(offBW), (size_t)nf * 4);
+        memcpy(by_node, bx.outHost<int32_t>(offBN), (size_t)nf * 4);
+    }
     return ORBX_OK;
+}
+
+extern "C" int orbx_bow_transform(orbx_vocabulary *v, const uint8_t *descriptors, int n, int levelsup, int32_t *word, int32_t *node, double *weight)
+{
+    return bow_transform_host(v, descriptors, n, levelsup, word, node, weight, nullptr, nullptr, nullptr);
+}
+
+extern "C" int orbx_bow_transform_sorted(orbx_vocabulary *v, const uint8_t *descriptors, int n, int levelsup, int32_t *word, int32_t *node, double *weight, int32_t *by_word,
+                                         int32_t *by_node, int32_t *filed)
+{
+    if (!by_word || !by_node || !filed) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    return bow_transform_host(v, descriptors, n, levelsup, word, node, weight, by_word, by_node, filed);
 }

@@ -102,12 +102,14 @@ DeviceVoc *DeviceVocabulary(const ORBVocabulary *voc)
 void Transform(const ORBVocabulary *voc, const cv::Mat &descriptors, DBoW2::BowVector &v, DBoW2::FeatureVector &fv, int levelsup)
 {
     __atomic_add_fetch(&gBoWCalls, 1, __ATOMIC_RELAXED);
+    orbx_shim::Mark("ComputeBoW enters");
     v.clear();
     fv.clear();
     if (voc->empty()) return;
     const int n = descriptors.rows;
-    std::vector<int32_t> word((size_t)(n > 0 ? n : 1)), node((size_t)(n > 0 ? n : 1));
+    std::vector<int32_t> word((size_t)(n > 0 ? n : 1)), node((size_t)(n > 0 ? n : 1)), byWord((size_t)(n > 0 ? n : 1)), byNode((size_t)(n > 0 ? n : 1));
     std::vector<double> weight((size_t)(n > 0 ? n : 1));
+    int32_t filed = 0;
     // (the library copies the descriptors into its mapped pinned buffer itself: a continuous matrix - what the extractor and KeyFrame's clone produce - goes as it is)
     std::vector<unsigned char> flat;
     const unsigned char *rows = descriptors.data;
@@ -119,18 +121,32 @@ void Transform(const ORBVocabulary *voc, const cv::Mat &descriptors, DBoW2::BowV
     {
         DeviceVoc *dv = DeviceVocabulary(voc);
         if (!dv) return;      // empty vectors, as for an image without features
-        std::unique_lock<std::mutex> call(dv->call);      // the whole call: upload, descent, download into OUR vectors
-        if (orbx_bow_transform(dv->h, rows, n, levelsup, &word[0], &node[0], &weight[0]) != ORBX_OK) { orbx_shim::Fail("ComputeBoW"); return; }
+        std::unique_lock<std::mutex> call(dv->call);      // the whole call: descent, ranking, results into OUR vectors
+        if (orbx_bow_transform_sorted(dv->h, rows, n, levelsup, &word[0], &node[0], &weight[0], &byWord[0], &byNode[0], &filed) != ORBX_OK) { orbx_shim::Fail("ComputeBoW"); return; }
     }
+    orbx_shim::Mark("ComputeBoW device call returned");
     DBoW2::LNorm norm;
     const bool must = VocAccess::Scoring(*voc)->mustNormalize(norm);
     const DBoW2::WeightingType wt = voc->getWeightingType();
     const bool tf = wt == DBoW2::TF || wt == DBoW2::TF_IDF;
-    for (int i = 0; i < n; i++) {
-        if (weight[(size_t)i] > 0) {
-            if (tf) v.addWeight((DBoW2::WordId)word[(size_t)i], weight[(size_t)i]);          // :1160
-            else v.addIfNotExist((DBoW2::WordId)word[(size_t)i], weight[(size_t)i]);         // :1187
-            fv.addFeature((DBoW2::NodeId)node[(size_t)i], (unsigned int)i);                  // :1161
+    // The reference's loop over the features (:1146-1196) does v.addWeight / v.addIfNotExist (word) and fv.addFeature (node, i) for every feature with a
+    // positive weight, in feature order: a tree search per call.  The same maps from the device's two orders: keys arrive ascending, so every new key goes
+    // in at the end of the map; the weights of a word are added in feature order (addWeight's sums, bit for bit), addIfNotExist keeps the first, and a
+    // node's feature list is appended in feature order.
+    {
+        DBoW2::BowVector::iterator vit = v.end();
+        for (int k = 0; k < filed; k++) {
+            const int i = byWord[(size_t)k];
+            const DBoW2::WordId w = (DBoW2::WordId)word[(size_t)i];
+            if (vit == v.end() || vit->first != w) vit = v.insert(v.end(), DBoW2::BowVector::value_type(w, weight[(size_t)i]));      // :1160 / :1187 (new word)
+            else if (tf) vit->second += weight[(size_t)i];                                                                          // addWeight on an existing word
+        }
+        DBoW2::FeatureVector::iterator fit = fv.end();
+        for (int k = 0; k < filed; k++) {
+            const int i = byNode[(size_t)k];
+            const DBoW2::NodeId nd = (DBoW2::NodeId)node[(size_t)i];
+            if (fit == fv.end() || fit->first != nd) fit = fv.insert(fv.end(), DBoW2::FeatureVector::value_type(nd, std::vector<unsigned int>()));
+            fit->second.push_back((unsigned int)i);                                                                                  // :1161
         }
     }
     if (tf && !v.empty() && !must) {                                                          // :1165-1171
@@ -138,6 +154,7 @@ void Transform(const ORBVocabulary *voc, const cv::Mat &descriptors, DBoW2::BowV
         for (DBoW2::BowVector::iterator vit = v.begin(); vit != v.end(); vit++) vit->second /= nd;
     }
     if (must) v.normalize(norm);                                                              // :1196
+    orbx_shim::Mark("ComputeBoW returns");
 }
 }  // namespace
 

@@ -65,12 +65,12 @@ extern "C" __attribute__((visibility("default"))) int orbx_shim_profile(int idx,
 // orbx_shim_trace_dump prints them relative to the first one.  Off: one relaxed load per mark.
 static std::atomic<int> gTraceOn(0), gTraceN(0);
 struct TraceEv { const char *name; double us; unsigned long tid; };
-static TraceEv gTrace[1024];
+static TraceEv gTrace[8192];
 extern "C" __attribute__((visibility("default"))) void orbx_shim_trace_mark(const char *name)
 {
     if (!gTraceOn.load(std::memory_order_relaxed)) return;
     const int i = gTraceN.fetch_add(1);
-    if (i >= 1024) return;
+    if (i >= 8192) return;
     gTrace[i].name = name;
     gTrace[i].us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     gTrace[i].tid = (unsigned long)std::hash<std::thread::id>()(std::this_thread::get_id()) % 1000;
@@ -79,7 +79,7 @@ extern "C" __attribute__((visibility("default"))) void orbx_shim_trace(int on) {
 extern "C" __attribute__((visibility("default"))) int orbx_shim_trace_dump(char *buf, int cap)
 {
     int n = gTraceN.load(), o = 0;
-    if (n > 1024) n = 1024;
+    if (n > 8192) n = 8192;
     for (int i = 0; i < n && o < cap - 96; i++)
         o += snprintf(buf + o, (size_t)(cap - o), "%9.1f us  [thread %03lu]  %s\n", gTrace[i].us - gTrace[0].us, gTrace[i].tid, gTrace[i].name);
     if (cap > 0) buf[o < cap ? o : cap - 1] = 0;

@@ -28,6 +28,7 @@
 
 #include "ORBmatcher.h"
 #include "SearchLocalPoints.h"
+#include "MapPointAccess.h"
 #include "orbx.h"
 #include "shim_error.h"
 
@@ -142,6 +143,7 @@ int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
 int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches)
 {
     __atomic_add_fetch(&gSearchByBoWCalls, 1, __ATOMIC_RELAXED);
+    orbx_shim::Mark("SearchByBoW enters");
     const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();                 // :232 (locks inside)
     vpMapPointMatches = std::vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));         // :236
     const int NA = (int)vpMapPointsKF.size(), NB = F.N;
@@ -156,10 +158,13 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
     orbx_bow_params prm = {mfNNratio, mbCheckOrientation ? 1 : 0, 0};
     std::vector<int32_t> match((size_t)NB);
     int32_t nmatches = 0;
+    orbx_shim::Mark("SearchByBoW marshalled");
     if (orbx_search_by_bow(Matcher(NA > NB ? NA : NB), &a, &b, &prm, &match[0], &nmatches) != ORBX_OK)
         { orbx_shim::Fail("ORBmatcher::SearchByBoW"); return 0; }
+    orbx_shim::Mark("SearchByBoW device call returned");
     for (int j = 0; j < NB; j++)
         if (match[(size_t)j] >= 0) vpMapPointMatches[(size_t)j] = vpMapPointsKF[(size_t)match[(size_t)j]];                   // :314
+    orbx_shim::Mark("SearchByBoW returns");
     return nmatches;
 }
 
@@ -761,34 +766,30 @@ struct MapPointDistances : public MapPoint {
 int SearchLocalPointsHIP(Frame &F, const std::vector<MapPoint *> &vpLocalMapPoints, int th, float nnratio, float viewingCosLimit)
 {
     __atomic_add_fetch(&gLocalPointsCalls, 1, __ATOMIC_RELAXED);
+    orbx_shim::Mark("SearchLocalPoints enters");
     for (std::vector<MapPoint *>::iterator vit = F.mvpMapPoints.begin(), vend = F.mvpMapPoints.end(); vit != vend; vit++) {     // step 1, :1765-1784
         MapPoint *pMP = *vit;
         if (!pMP) continue;
-        if (pMP->isBad()) *vit = static_cast<MapPoint *>(NULL);
-        else { pMP->IncreaseVisible(); pMP->mnLastFrameSeen = F.mnId; pMP->mbTrackInView = false; }
+        if (MapPointAccess::BadElseIncreaseVisible(pMP)) *vit = static_cast<MapPoint *>(NULL);      // isBad() ? drop : IncreaseVisible(), one visit
+        else { pMP->mnLastFrameSeen = F.mnId; pMP->mbTrackInView = false; }
     }
-    // step 2 (:1791-1811): the points Frame::isInFrustum would be asked about, in list order
+    // step 2 (:1791-1811): the points Frame::isInFrustum would be asked about, in list order, and what it and SearchByProjection read from them -
+    // one visit per point under its two mutexes (shim/MapPointAccess.h) instead of seven getter calls and three cv::Mat clones
+    const size_t L = vpLocalMapPoints.size();
     std::vector<int> idx;
-    idx.reserve(vpLocalMapPoints.size());
-    for (size_t i = 0; i < vpLocalMapPoints.size(); i++) {
+    idx.reserve(L);
+    std::vector<float> pos(L * 3 + 3), nrm(L * 3 + 3), mx(L + 1), mn(L + 1);
+    std::vector<uint8_t> desc(L * 32 + 32), hasObs(L + 1);
+    for (size_t i = 0; i < L; i++) {
         MapPoint *pMP = vpLocalMapPoints[i];
         if (pMP->mnLastFrameSeen == F.mnId) continue;
-        if (pMP->isBad()) continue;
+        const size_t k = idx.size();
+        if (!MapPointAccess::Snapshot(pMP, &pos[3 * k], &nrm[3 * k], mx[k], mn[k], hasObs[k], &desc[32 * k])) continue;      // isBad()
         idx.push_back((int)i);
     }
     const int M = (int)idx.size(), N = F.N;
     if (M == 0) return 0;
-    std::vector<float> pos((size_t)M * 3), nrm((size_t)M * 3), mx((size_t)M), mn((size_t)M);
-    std::vector<uint8_t> desc((size_t)M * 32), hasObs((size_t)M);
-    for (int k = 0; k < M; k++) {
-        MapPoint *pMP = vpLocalMapPoints[(size_t)idx[(size_t)k]];
-        const cv::Mat P = pMP->GetWorldPos(), Pn = pMP->GetNormal();
-        for (int c = 0; c < 3; c++) { pos[3 * (size_t)k + c] = P.at<float>(c); nrm[3 * (size_t)k + c] = Pn.at<float>(c); }
-        MapPointDistances::Get(pMP, mx[(size_t)k], mn[(size_t)k]);
-        hasObs[(size_t)k] = pMP->Observations() > 0 ? 1 : 0;
-        const cv::Mat d = pMP->GetDescriptor();
-        memcpy(&desc[32 * (size_t)k], d.ptr<unsigned char>(), 32);
-    }
+    orbx_shim::Mark("SearchLocalPoints: map points marshalled");
     const int nFeat = N > 0 ? N : 1;
     std::vector<uint8_t> occupied((size_t)nFeat, 0), inView((size_t)M, 0);
     for (int i = 0; i < N; i++) occupied[(size_t)i] = (F.mvpMapPoints[(size_t)i] && F.mvpMapPoints[(size_t)i]->Observations() > 0) ? 1 : 0;   // src/ORBmatcher.cc:110-112
@@ -805,10 +806,12 @@ int SearchLocalPointsHIP(Frame &F, const std::vector<MapPoint *> &vpLocalMapPoin
                                     Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv};
         orbx_frustum_frame pose = {tcw, Frame::fx, Frame::fy, Frame::cx, Frame::cy, F.mbf, Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY, ratioTh, F.mnScaleLevels, 1};
         orbx_local_points pts = {&pos[0], &nrm[0], &mx[0], &mn[0], &desc[0], &hasObs[0], M};
+        orbx_shim::Mark("SearchLocalPoints: frame marshalled");
         if (orbx_search_local_points(Matcher(N > M ? N : M), &fr, &pose, &pts, &F.mvScaleFactors[0], (int)F.mvScaleFactors.size(), viewingCosLimit, (float)th, nnratio,
                                      &assigned[0], &nmatches, &inView[0], &px[0], &py[0], &pxr[0], &lvl[0], &vc[0]) != ORBX_OK)
             { orbx_shim::Fail("SearchLocalPoints"); return 0; }
     }
+    orbx_shim::Mark("SearchLocalPoints: device call returned");
     for (int k = 0; k < M; k++) {                                                   // what Frame::isInFrustum leaves in the MapPoint, :615, :721-731
         MapPoint *pMP = vpLocalMapPoints[(size_t)idx[(size_t)k]];
         pMP->mbTrackInView = inView[(size_t)k] != 0;
@@ -819,6 +822,7 @@ int SearchLocalPointsHIP(Frame &F, const std::vector<MapPoint *> &vpLocalMapPoin
     }
     for (int i = 0; i < N; i++)
         if (assigned[(size_t)i] >= 0) F.mvpMapPoints[(size_t)i] = vpLocalMapPoints[(size_t)idx[(size_t)assigned[(size_t)i]]];     // src/ORBmatcher.cc:165
+    orbx_shim::Mark("SearchLocalPoints returns");
     return nmatches;
 }
 

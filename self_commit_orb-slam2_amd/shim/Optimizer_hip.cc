@@ -20,6 +20,7 @@
 #include "Optimizer.h"   // the reference's include/Optimizer.h; shim/Optimizer.h where g2o / Eigen are not installed
 #include "orbx.h"
 #include "shim_error.h"
+#include "MapPointAccess.h"
 
 static unsigned long gLbaCalls = 0, gPoseOptCalls = 0, gBaCalls = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_bundle_adjustment_calls(void) { return gBaCalls; }
@@ -271,9 +272,11 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame *> &vpKFs, const std
 int Optimizer::PoseOptimization(Frame *pFrame)
 {
     __atomic_add_fetch(&gPoseOptCalls, 1, __ATOMIC_RELAXED);
+    orbx_shim::Mark("PoseOptimization enters");
     const int N = pFrame->N;
     std::vector<int> index;   // features that have a MapPoint, in feature order (:396-500)
     std::vector<float> Xw, obs, invS2;
+    index.reserve((size_t)N); Xw.reserve(3 * (size_t)N); obs.reserve(3 * (size_t)N); invS2.reserve((size_t)N);
     {
         std::unique_lock<std::mutex> lock(MapPoint::mGlobalMutex);
         for (int i = 0; i < N; i++) {
@@ -281,9 +284,10 @@ int Optimizer::PoseOptimization(Frame *pFrame)
             if (!pMP) continue;
             pFrame->mvbOutlier[(size_t)i] = false;
             const cv::KeyPoint &kpUn = pFrame->mvKeysUn[(size_t)i];
-            const cv::Mat X = pMP->GetWorldPos();
+            float X[3];
+            MapPointAccess::WorldPos(pMP, X);      // GetWorldPos() without the cv::Mat clone
             index.push_back(i);
-            for (int k = 0; k < 3; k++) Xw.push_back(X.at<float>(k));
+            for (int k = 0; k < 3; k++) Xw.push_back(X[k]);
             obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(pFrame->mvuRight[(size_t)i]);
             invS2.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
         }
@@ -301,9 +305,12 @@ int Optimizer::PoseOptimization(Frame *pFrame)
     orbx_pose_problem prob = {1, n, pose, cam, &n, &Xw[0], &obs[0], &invS2[0]};
     std::vector<uint8_t> outlier((size_t)n);
     int32_t inliers = 0;
+    orbx_shim::Mark("PoseOptimization marshalled");
     if (orbx_pose_optimization(tPose.h, &prob, poseOut, &outlier[0], &inliers, NULL) != ORBX_OK) { Fail("PoseOptimization"); return 0; }
+    orbx_shim::Mark("PoseOptimization device call returned");
     for (int e = 0; e < n; e++) pFrame->mvbOutlier[(size_t)index[(size_t)e]] = outlier[(size_t)e] != 0;
     pFrame->SetPose(PoseMat(poseOut));                                                          // :598-601
+    orbx_shim::Mark("PoseOptimization returns");
     return inliers;
 }
 

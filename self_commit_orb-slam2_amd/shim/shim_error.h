@@ -52,6 +52,10 @@ inline bool Fail(const char *where, const char *detail = 0)
 }
 }  // namespace orbx_shim
 
+// Timeline marks (shim/Frame_hip.cc defines the recorder; a build without that file has none): orbx_shim::Mark("name") costs one relaxed load when off.
+extern "C" __attribute__((weak)) void orbx_shim_trace_mark(const char *name);
+namespace orbx_shim { inline void Mark(const char *name) { if (orbx_shim_trace_mark) orbx_shim_trace_mark(name); } }
+
 extern "C" {
 __attribute__((weak, visibility("default"))) long orbx_shim_error_count(void) { return orbx_shim::Errors().count.load(); }
 // the last message, copied into the caller's buffer (always terminated); returns its full length
