@@ -1855,6 +1855,7 @@ struct PoseOptDev {
     unsigned *pubCounter;
     unsigned long long *pubFlag;
     unsigned long long pubSeq;
+    unsigned long long *prof;   // PROF instantiation only: [32] phase cycles / counts
 };
 
 #define PO_NRED 28   /* 21 upper-triangle entries of H + 6 of b + chi2 */
@@ -1873,6 +1874,31 @@ __device__ inline void po_edge_error(const DPose &T, const double in[5], const f
         const double u = Xc[0] * invz * in[0] + in[2], v = Xc[1] * invz * in[1] + in[3];
         out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v; out[2] = (double)obs[2] - (u - in[4] * (double)invz);
     }
+}
+
+// The same two functions without control flow: the loops over a thread's edges are unrolled into ONE basic block, so that the scheduler interleaves the
+// edges' dependent FP64 chains (one wave per SIMD: nothing else hides the ~8 cycles between dependent instructions; build 5260 -> see
+// profiles/r06_pose_opt_phases.txt).  Values are those of po_edge_error / huber_rho bit for bit (the mono branch's double reciprocal, the stereo branch's
+// float one; both sides of the Huber test evaluated, one selected).
+__device__ __forceinline__ void po_edge_error_nb(const DPose &T, const double in[5], const float *Xw, const float *obs, bool stereo, double out[3])
+{
+    const double X[3] = {(double)Xw[0], (double)Xw[1], (double)Xw[2]};
+    double Xc[3];
+    pose_map(T, X, Xc);
+    const double izd = fast_rcp(Xc[2]);
+    const double iz = stereo ? (double)(float)izd : izd;
+    const double u = Xc[0] * iz * in[0] + in[2], v = Xc[1] * iz * in[1] + in[3];
+    out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v;
+    const double o2 = (double)obs[2] - (u - in[4] * iz);
+    out[2] = stereo ? o2 : 0.0;
+}
+__device__ __forceinline__ void huber_rho_nb(const Huber &h, bool stereo, double chi, double &rho0, double &rho1)
+{
+    const double delta = stereo ? h.dStereo : h.dMono, dsqr = stereo ? h.dsqrStereo : h.dsqrMono;
+    const double s = sqrt(chi);
+    const bool in = chi <= dsqr;
+    rho0 = in ? chi : 2 * s * delta - dsqr;
+    rho1 = in ? 1. : delta / s;
 }
 
 template <int N> __device__ inline void po_block_reduce(double (&v)[N], double (*red)[PO_NRED], int tid)
@@ -1922,9 +1948,14 @@ __device__ __forceinline__ void po_block_reduce28(const double (&v)[PO_NRED], do
 // NE = edges per thread: the correspondences of a frame and their _error live in REGISTERS for the whole call (thread t owns edges
 // t, t + 256, ...): the 40 build / 40+ error passes of a call do no global memory access at all (each one waited ~1 us for its loads
 // and the per-edge divisions before: 4.4 + 2.3 us of a 13 us iteration).
-template <int NE>
+// PROF (tools/pose_opt_phases.py, never in a product launch): thread 0 reads s_memtime at the phase boundaries of the loop and adds the wall cycles between
+// consecutive stamps (barrier waits included) to P.prof[0..15], the number of times a phase ran to P.prof[16..31].
+#define PO_STAMP(i) do { if (PROF && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tPrev; pcnt[i] += 1; tPrev = t_; } } while (0)
+template <int NE, bool PROF>
 __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
 {
+    unsigned long long pacc[PROF ? 16 : 1] = {}, pcnt[PROF ? 16 : 1] = {}, tPrev = 0;
+    (void)pacc; (void)pcnt; (void)tPrev;
     __shared__ double redT[28 * PO_TP];
     __shared__ double part28[28][9];
     __shared__ DPose pose, savePose;
@@ -1951,15 +1982,35 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
     float xw[NE][3], ob[NE][3], is2[NE];
     double er[NE][3];
     unsigned outM = 0;            // bit j: edge tid + 256 j is an outlier (level 1)
+    if (NE <= 8) {
+        // The inputs may be MAPPED HOST memory (the single-frame host call): a thread's own edges are 12-byte records 3 KB apart, seven loads per edge
+        // across PCIe (+11 us per call).  Read them as flat float arrays, coalesced, into LDS (the reduction tile is free until the first build:
+        // 7 n floats <= 14784 for n <= 2048) and pick the thread's edges from there.
+        float *stg = (float *)redT;
+        for (int k = tid; k < 3 * n; k += 256) { stg[k] = Xw[k]; stg[3 * n + k] = obs[k]; }
+        for (int k = tid; k < n; k += 256) stg[6 * n + k] = invS2[k];
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NE; j++) {
-        const int e = tid + 256 * j;
-        const bool live = e < n;
+        for (int j = 0; j < NE; j++) {
+            const int e = tid + 256 * j;
+            const bool live = e < n;
 #pragma unroll
-        for (int i = 0; i < 3; i++) { xw[j][i] = live ? Xw[3 * e + i] : 0.f; ob[j][i] = live ? obs[3 * e + i] : 0.f; er[j][i] = 0; }
-        is2[j] = live ? invS2[e] : 0.f;
+            for (int i = 0; i < 3; i++) { xw[j][i] = live ? stg[3 * e + i] : 0.f; ob[j][i] = live ? stg[3 * n + 3 * e + i] : 0.f; er[j][i] = 0; }
+            is2[j] = live ? stg[6 * n + e] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NE; j++) {
+            const int e = tid + 256 * j;
+            const bool live = e < n;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { xw[j][i] = live ? Xw[3 * e + i] : 0.f; ob[j][i] = live ? obs[3 * e + i] : 0.f; er[j][i] = 0; }
+            is2[j] = live ? invS2[e] : 0.f;
+        }
     }
     __syncthreads();
+    if (PROF && threadIdx.x == 0) tPrev = __builtin_amdgcn_s_memtime();
+    PO_STAMP(0);      // (zero: the stamp's own cost shows up in phase 0's count)
     for (int round = 0; round < 4; round++) {
         const bool robust = round < 3;   // kernels are removed while classifying after the third round (:547-548)
         if (tid == 0) {                  // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw)), :520
@@ -1982,6 +2033,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         }
         int itersDone = 0;
         double lastChi = 0;
+        PO_STAMP(1);      // round setup: estimate reset, active-edge count
         for (int it = 0; it < 10 && nAct > 0; it++) {
             if (!sIterOk) break;
             // ---- computeActiveErrors + robust chi2, buildSystem
@@ -1991,7 +2043,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
             for (int k = 0; k < PO_NRED; k++) acc[k] = 0;
 #pragma unroll
             for (int j = 0; j < NE; j++) {
-                if (tid + 256 * j >= n || ((outM >> j) & 1u)) continue;
+                if (tid + 256 * j >= n || ((outM >> j) & 1u)) continue;      // (measured: this pass without control flow is no faster - it is bound by issue, not by latency - and pays for dead slots)
                 const bool st = !(ob[j][2] < 0);
                 double r[3];
                 po_edge_error(T, in, xw[j], ob[j], st, r);
@@ -2012,45 +2064,54 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                 J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2;
                 // rows 0, 1 and - for a stereo edge - 2, summed in that order from 0 like the reference's loop over the
                 // error dimension; everything unrolled so that J / acc are registers (a runtime row count puts J into
-                // scratch memory and costs ~40k cycles per edge)
+                // scratch memory and costs ~40k cycles per edge).
+                // J[4], J[9] and J[16] are exact zeros: a product with one of them is +-0.0, and adding +-0.0 to a sum that starts at +0.0 leaves its
+                // bits alone (finite operands) - those 33 of the 81 product terms are not computed (known at compile time: the loops are unrolled).
                 const double W = r1 * w;
                 {
                     int k = 0;
 #pragma unroll
                     for (int i = 0; i < 6; i++)
 #pragma unroll
-                        for (int j = i; j < 6; j++, k++) {
+                        for (int jj = i; jj < 6; jj++, k++) {
                             double sacc = 0;
-                            sacc += J[i] * W * J[j];
-                            sacc += J[6 + i] * W * J[6 + j];
-                            if (st) sacc += J[12 + i] * W * J[12 + j];
+                            if (i != 4 && jj != 4) sacc += J[i] * W * J[jj];
+                            if (i != 3 && jj != 3) sacc += J[6 + i] * W * J[6 + jj];
+                            if (st && i != 4 && jj != 4) sacc += J[12 + i] * W * J[12 + jj];
                             acc[k] += sacc;
                         }
                 }
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     double sacc = 0;
-                    sacc += J[i] * (-w * r[0] * r1);
-                    sacc += J[6 + i] * (-w * r[1] * r1);
-                    if (st) sacc += J[12 + i] * (-w * r[2] * r1);
+                    if (i != 4) sacc += J[i] * (-w * r[0] * r1);
+                    if (i != 3) sacc += J[6 + i] * (-w * r[1] * r1);
+                    if (st && i != 4) sacc += J[12 + i] * (-w * r[2] * r1);
                     acc[21 + i] += sacc;
                 }
             }
+            PO_STAMP(2);      // build: errors, Jacobians, the thread's 28 sums
             po_block_reduce28(acc, redT, part28, red, tid);
-            if (tid == 0) {      // (only thread 0 reads sH / sb / sLambda; sCur is read by everybody behind the barrier of the first trial)
-                int k = 0;
-                for (int i = 0; i < 6; i++)
-                    for (int j = i; j < 6; j++, k++) { sH[6 * i + j] = red[0][k]; sH[6 * j + i] = red[0][k]; }
-                for (int i = 0; i < 6; i++) sb[i] = red[0][21 + i];
+            PO_STAMP(3);      // reduce28
+            // H (both triangles), b, the current chi2 and - first iteration - lambda out of the 28 sums: 43 threads, one value each (one thread doing all of
+            // it was 770 cycles of every iteration); thread 0 reads them behind the barrier
+            if (tid < 36) {
+                const int i = tid / 6, j = tid - 6 * i, a = i < j ? i : j, b = i < j ? j : i;
+                sH[tid] = red[0][a * 6 - a * (a - 1) / 2 + (b - a)];
+            } else if (tid < 42) sb[tid - 36] = red[0][21 + tid - 36];
+            else if (tid == 42) {
                 sCur = red[0][27];
-                if (it == 0) {   // computeLambdaInit (:166-180)
+                if (it == 0) {   // computeLambdaInit (:166-180): the diagonal sits at k = 0, 6, 11, 15, 18, 20 of the upper triangle
                     double mx = 0;
-                    for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(sH[7 * i]));
+                    mx = fmax(mx, fabs(red[0][0])); mx = fmax(mx, fabs(red[0][6])); mx = fmax(mx, fabs(red[0][11]));
+                    mx = fmax(mx, fabs(red[0][15])); mx = fmax(mx, fabs(red[0][18])); mx = fmax(mx, fabs(red[0][20]));
                     sLambda = 1e-5 * mx; sNi = 2;
                 }
             }
+            __syncthreads();
             const double iniChi = red[0][27];
             int qmax = 0;
+            PO_STAMP(4);      // H / b to LDS, lambda init
             do {
                 if (tid == 0) {
                     savePose = pose;   // push()
@@ -2103,24 +2164,29 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                         for (int i = 0; i < 6; i++) sx[i] = xx[i];
                     }
                     sOk = ok ? 1 : 0;
+                    if (PROF) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[5] += t_ - tPrev; pcnt[5] += 1; tPrev = t_; }      // 6x6 LDL^T solve (one thread)
                     pose_oplus(pose, sx);   // g2o applies the (possibly stale) x even when the solve failed; pop() restores
+                    if (PROF) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[6] += t_ - tPrev; pcnt[6] += 1; tPrev = t_; }      // oplus (one thread)
                 }
                 __syncthreads();
+                PO_STAMP(7);      // barrier behind the solve (the other waves wait here the whole time)
                 const DPose T2 = pose;
                 double cacc[1] = {0};
 #pragma unroll
                 for (int j = 0; j < NE; j++) {
-                    if (tid + 256 * j >= n || ((outM >> j) & 1u)) continue;
+                    const bool on = tid + 256 * j < n && !((outM >> j) & 1u);      // (no control flow per edge, as in the build)
                     const bool st = !(ob[j][2] < 0);
                     double r[3];
-                    po_edge_error(T2, in, xw[j], ob[j], st, r);
-                    er[j][0] = r[0]; er[j][1] = r[1]; er[j][2] = r[2];
+                    po_edge_error_nb(T2, in, xw[j], ob[j], st, r);
+                    er[j][0] = on ? r[0] : er[j][0]; er[j][1] = on ? r[1] : er[j][1]; er[j][2] = on ? r[2] : er[j][2];
                     const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * (double)is2[j];
                     double r0 = chi, r1 = 1;
-                    if (robust) huber_rho(hub, st, chi, r0, r1);
-                    cacc[0] += r0;
+                    if (robust) huber_rho_nb(hub, st, chi, r0, r1);
+                    cacc[0] += on ? r0 : 0.0;
                 }
+                PO_STAMP(8);      // error pass at the trial pose
                 po_block_reduce(cacc, red, tid);
+                PO_STAMP(9);      // reduce (chi2)
                 if (tid == 0) {
                     double tempChi = red[0][0];
                     if (!sOk) tempChi = 1.7976931348623157e308;
@@ -2143,6 +2209,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     sRho = rho;
                 }
                 __syncthreads();
+                PO_STAMP(10);     // decision (one thread) + barrier
                 qmax++;
             } while (sRho < 0 && qmax < 10);
             itersDone++;
@@ -2155,6 +2222,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                 }
             }
             __syncthreads();
+            PO_STAMP(11);     // end of iteration: stall test + barrier
         }
         if (tid == 0) { P.stats[8 * (size_t)f + 2 * round] = itersDone; P.stats[8 * (size_t)f + 2 * round + 1] = lastChi; }
         // ---- classification (:526-587): outliers are re-evaluated at the final pose, inliers keep their last _error
@@ -2180,6 +2248,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
             if (tid == 0) P.ret[f] = n - (int)red[0][0];
             __syncthreads();
         }
+        PO_STAMP(12);     // classification of the round
         if (n < 10) break;   // optimizer.edges().size() < 10, :589-590
     }
 #pragma unroll
@@ -2192,8 +2261,11 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o[4 * i + j] = (float)R[3 * i + j]; o[4 * i + 3] = (float)pose.t[i]; }
         o[12] = o[13] = o[14] = 0.f; o[15] = 1.f;
     }
+    PO_STAMP(13);         // flags + pose out
+    if (PROF && tid == 0 && P.prof) for (int i = 0; i < 16; i++) { atomicAdd(&P.prof[i], pacc[i]); atomicAdd(&P.prof[16 + i], pcnt[i]); }
     if (P.pubFlag) orbx_publish(P.pubCounter, P.pubFlag, P.pubSeq, gridDim.x);
 }
+#undef PO_STAMP
 
 }  // namespace
 
@@ -2736,6 +2808,10 @@ extern "C" void orbx_pose_optimizer_destroy(orbx_pose_optimizer *h)
     delete h;
 }
 
+// developer tap (tools/pose_opt_phases.py; not part of include/orbx.h): a device array of 32 u64 the PROF instantiation of k_pose_opt adds its phase cycles / counts to
+static unsigned long long *g_poProf = nullptr;
+extern "C" void orbx_debug_pose_opt_profile(unsigned long long *dev32) { g_poProf = dev32; }
+
 extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_problem *p, float *poses_out, uint8_t *outlier, int32_t *inliers, double *stats)
 {
     if (!h || !p || !p->poses || !p->cameras || !p->counts || !p->world_points || !p->observations || !p->inv_sigma2) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
@@ -2755,7 +2831,7 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     const int32_t *dCnt = bx.put(p->counts, (size_t)B);
     const float *dXw = bx.put(p->world_points, N * 3), *dObs = bx.put(p->observations, N * 3), *dInv = bx.put(p->inv_sigma2, N);
     const uint8_t *o0 = bx.outHost<uint8_t>(0), *o1 = bx.outHost<uint8_t>(q1), *o2 = bx.outHost<uint8_t>(q2), *o3 = bx.outHost<uint8_t>(q3);
-    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, bx.outDev<float>(0), bx.outDev<uint8_t>(q1), bx.outDev<int32_t>(q2), bx.outDev<double>(q3), bx.counter, bx.flagDev, bx.arm()};
+    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, bx.outDev<float>(0), bx.outDev<uint8_t>(q1), bx.outDev<int32_t>(q2), bx.outDev<double>(q3), bx.counter, bx.flagDev, bx.arm(), g_poProf};
     const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);   // deltaMono / deltaStereo are floats (:389-390)
     Huber hub;
     hub.dMono = thMono; hub.dStereo = thStereo;
@@ -2763,11 +2839,17 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     int maxCount = 0;
     for (int i = 0; i < B; i++) maxCount = std::max(maxCount, std::min((int)p->counts[i], cap));
     if (maxCount > 256 * 32) { orbx_set_error("%d correspondences in a frame exceed the pose optimizer's limit %d", maxCount, 256 * 32); return ORBX_ERR_CAPACITY; }
-    if (maxCount <= 256 * 2) hipLaunchKernelGGL(k_pose_opt<2>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
-    else if (maxCount <= 256 * 4) hipLaunchKernelGGL(k_pose_opt<4>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
-    else if (maxCount <= 256 * 8) hipLaunchKernelGGL(k_pose_opt<8>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
-    else if (maxCount <= 256 * 16) hipLaunchKernelGGL(k_pose_opt<16>, dim3((unsigned)B), dim3(256), 0, st, D, hub);
-    else hipLaunchKernelGGL(k_pose_opt<32>, dim3((unsigned)B), dim3(256), 0, st, D, hub);      // up to 8192 correspondences: 32 per thread, one wave per SIMD
+    // edges per thread = ceil(count / 256) up to 4 (a thread's dead slots cost what live ones do in the error pass), then 8 / 16 / 32
+    if (g_poProf && maxCount <= 256 * 2) hipLaunchKernelGGL((k_pose_opt<2, true>), dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (g_poProf && maxCount <= 256 * 3) hipLaunchKernelGGL((k_pose_opt<3, true>), dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (g_poProf && maxCount <= 256 * 4) hipLaunchKernelGGL((k_pose_opt<4, true>), dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (maxCount <= 256) hipLaunchKernelGGL((k_pose_opt<1, false>), dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (maxCount <= 256 * 2) hipLaunchKernelGGL((k_pose_opt<2, false>), dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (maxCount <= 256 * 3) hipLaunchKernelGGL((k_pose_opt<3, false>), dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (maxCount <= 256 * 4) hipLaunchKernelGGL((k_pose_opt<4, false>), dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (maxCount <= 256 * 8) hipLaunchKernelGGL((k_pose_opt<8, false>), dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else if (maxCount <= 256 * 16) hipLaunchKernelGGL((k_pose_opt<16, false>), dim3((unsigned)B), dim3(256), 0, st, D, hub);
+    else hipLaunchKernelGGL((k_pose_opt<32, false>), dim3((unsigned)B), dim3(256), 0, st, D, hub);      // up to 8192 correspondences: 32 per thread, one wave per SIMD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     if ((rcs = bx.wait(st)) != ORBX_OK) return rcs;

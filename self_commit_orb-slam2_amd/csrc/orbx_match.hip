@@ -401,46 +401,73 @@ __global__ __launch_bounds__(256, 3) void k_bow_topk_mfma(FeatDev A, FeatDev B, 
 // ---------------------------------------------------------------------------------------------
 // The SINGLE-PAIR geometry (ORBmatcher::SearchByBoW as src/Tracking.cc:1195, 2073 call it: one KeyFrame against one Frame, ~1000 x 1000).
 // k_bow_topk above gives a pair ceil(nA / 256) workgroups that each walk ALL of B: four workgroups on 256 CUs, 100 us for one pair where 256 pairs
-// take 216.  Here the B range is split as well: a workgroup is 64 A features (lane = feature, its descriptor in 8 VGPRs) x 4 waves, wave w of
-// workgroup (rb, y) scans B slice 4 y + w (`per` features, staged in the wave's corner of LDS, read as broadcasts) and keeps its top-TOPK per lane;
-// the four waves merge in LDS, the workgroup stores a partial list, and the LAST workgroup of a row block to arrive (a counter per row block) merges
-// the SY partial lists into the final one.  Keys carry the B index (dist << 16 | j), so the smallest TOPK of the union of the slices' lists ARE the
-// lists k_bow_topk produces: the replay below sees identical input.  The processing order of the A features (k_bow_order: rank by (node id, index),
-// 46 us for one pair with its 1000-step loop over global memory) is computed by further workgroups of the SAME launch: 32 features x 8 segments per
-// workgroup, node ids in LDS.
+// take 216.  Here a workgroup is 16 A features: lane (r, s) of a wave = feature r of the wave's four x B slice s of sixteen.  All of B sits in the
+// workgroup's LDS (descriptors + node ids, 36 bytes per feature); a lane scans its slice with its feature's descriptor in 8 VGPRs and keeps its
+// top-TOPK, then the sixteen lanes of a feature merge their lists with four rounds of butterfly exchanges - no partial lists in memory, no atomics,
+// no second pass.  Keys carry the B index (dist << 16 | j), so the smallest TOPK of the union of the slices' lists ARE the lists k_bow_topk produces:
+// the replay below sees identical input.  A slice's descriptors start 16 bytes further into the 128-byte bank window than its neighbour's: the
+// sixteen addresses of a step fall on eight bank groups (2-way), the four features of a wave share each read.
+// The processing order of the A features (k_bow_order: rank by (node id, index), 46 us for one pair with its 1000-step loop over global memory) is
+// computed by further workgroups of the SAME launch: 32 features x 8 lanes per workgroup, node ids in LDS, four per read.
 // ---------------------------------------------------------------------------------------------
-#define SPLIT_ROWS 64
-#define SPLIT_TILE 64      /* B features a wave stages at a time */
+#define PAIR_ROWS 16        /* A features per workgroup */
+#define PAIR_SLICES 16      /* B slices = lanes per A feature */
 template <bool FILTER>
-__global__ __launch_bounds__(256) void k_bow_topk_split(FeatDev A, FeatDev B, int mode, uint32_t dcut, int nRowBlocks, int SY, int per, uint32_t *part,
-                                                        unsigned *__restrict__ rowCounter, uint32_t *__restrict__ topk, int32_t *__restrict__ order)
+__global__ __launch_bounds__(256) void k_bow_topk_pair(FeatDev A, FeatDev B, int mode, uint32_t dcut, int nRowBlocks, int per, uint32_t *__restrict__ topk,
+                                                       int32_t *__restrict__ order)
 {
-    __shared__ uint4 sB[4][SPLIT_TILE * 2];
-    __shared__ int32_t sG[4][SPLIT_TILE];
-    __shared__ uint32_t sK[3][SPLIT_ROWS][TOPK + 1];      // (+1: the lanes of a wave write rows 9 words apart - conflict free)
-    __shared__ int sLast;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemP[];
     const int nA = min(A.counts[0], A.cap), nB = min(B.counts[0], B.cap);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if ((int)blockIdx.x >= nRowBlocks * SY) {
+    if ((int)blockIdx.x >= nRowBlocks) {
         // ---- processing order: rank of feature i = #{k : (g[k], k) < (g[i], i)}; 32 features per workgroup, 8 lanes share a feature
-        __shared__ int32_t sGr[4096];
-        const int ob = (int)blockIdx.x - nRowBlocks * SY, i = ob * 32 + (tid >> 3), seg = tid & 7;
+        int32_t *sGr = (int32_t *)smemP;      // [4096]
+        const int ob = (int)blockIdx.x - nRowBlocks, i = ob * 32 + (tid >> 3), seg = tid & 7;
         if (!A.groups) { if (seg == 0 && i < nA) order[i] = i; return; }
         const int gi = i < nA ? A.groups[i] : 0;
         int rank = 0;
         for (int t0 = 0; t0 < nA; t0 += 4096) {
-            const int tn = min(4096, nA - t0);
+            const int tn = min(4096, nA - t0), tn4 = (tn + 3) & ~3;
             __syncthreads();
-            for (int k = tid; k < tn; k += 256) sGr[k] = A.groups[t0 + k];
+            for (int k = tid; k < tn4; k += 256) sGr[k] = k < tn ? A.groups[t0 + k] : 0x7fffffff;      // (padding ranks behind everything)
             __syncthreads();
-            for (int k = seg; k < tn; k += 8) { const int gk = sGr[k]; rank += (gk < gi) || (gk == gi && t0 + k < i); }
+#pragma unroll 4
+            for (int k = 4 * seg; k < tn4; k += 32) {
+                const int4 g4 = *(const int4 *)&sGr[k];
+                const int kk = t0 + k;
+                rank += (g4.x < gi) || (g4.x == gi && kk < i);
+                rank += (g4.y < gi) || (g4.y == gi && kk + 1 < i);
+                rank += (g4.z < gi) || (g4.z == gi && kk + 2 < i);
+                rank += (g4.w < gi) || (g4.w == gi && kk + 3 < i);
+            }
         }
         rank += __shfl_xor(rank, 1); rank += __shfl_xor(rank, 2); rank += __shfl_xor(rank, 4);
         if (seg == 0 && i < nA) order[rank] = i;
         return;
     }
-    const int rb = (int)blockIdx.x % nRowBlocks, y = (int)blockIdx.x / nRowBlocks;
-    const int row = rb * SPLIT_ROWS + lane;
+    // LDS: slice s of B = `per` descriptors at sliceBase(s) = s * (per * 32 + 16) bytes; then the node ids [16 * per] (0x80000000 = excluded)
+    const int slicePitch = per * 32 + 16;
+    unsigned char *sDesc = smemP;
+    int32_t *sG = (int32_t *)(smemP + (size_t)PAIR_SLICES * slicePitch);
+    {
+        const uint4 *gD = (const uint4 *)B.desc;
+        for (int t = tid; t < 2 * PAIR_SLICES * per; t += 256) {      // uint4 unit t: descriptor t >> 1 of the padded list, half t & 1
+            const int j = t >> 1, sl = j / per, jj = j - sl * per;
+            *(uint4 *)(sDesc + (size_t)sl * slicePitch + (size_t)jj * 32 + (t & 1) * 16) = j < nB ? gD[t] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (FILTER)
+            for (int j = tid; j < PAIR_SLICES * per; j += 256) {
+                int gq = (int)0x80000000;
+                if (j < nB) {
+                    gq = B.groups ? B.groups[j] : 0;
+                    if (gq < 0) gq = (int)0x80000000;                                    // not filed in the FeatureVector: never matched
+                    if (mode >= 1 && B.valid && !B.valid[j]) gq = (int)0x80000000;
+                }
+                sG[j] = gq;
+            }
+    }
+    const int r = lane >> 4, sl = lane & 15;
+    const int row = (int)blockIdx.x * PAIR_ROWS + wv * 4 + r;
     const bool live = row < nA;
     const uint32_t sentinel = dcut << 16;
     uint32_t a[8], kk[TOPK];
@@ -454,87 +481,35 @@ __global__ __launch_bounds__(256) void k_bow_topk_split(FeatDev A, FeatDev B, in
 #pragma unroll
     for (int q = 0; q < TOPK; q++) kk[q] = act ? sentinel : 0u;      // inactive rows never insert
     uint32_t th = kk[TOPK - 1] >> 16;
-    const int j0 = (y * 4 + wv) * per, j1 = min(nB, j0 + per);
-    const uint4 *gD = (const uint4 *)B.desc;
-    for (int t0 = j0; t0 < j0 + per; t0 += SPLIT_TILE) {      // (the same trip count in every wave: the barriers below are uniform)
-        const int nt = max(0, min(SPLIT_TILE, j1 - t0));
-        __syncthreads();
-        for (int t = lane; t < 2 * nt; t += 64) sB[wv][t] = gD[2 * (size_t)t0 + t];
-        if (FILTER && lane < nt) {
-            int gq = B.groups ? B.groups[t0 + lane] : 0;
-            if (gq < 0) gq = (int)0x80000000;                                    // not filed in the FeatureVector: never matched
-            if (mode >= 1 && B.valid && !B.valid[t0 + lane]) gq = (int)0x80000000;
-            sG[wv][lane] = gq;
-        }
-        __syncthreads();
-        for (int j = 0; j < nt; j++) {
-            const uint4 lo = sB[wv][2 * j], hi = sB[wv][2 * j + 1];      // wave-uniform address: LDS broadcast
-            uint32_t d = bcnt_acc(a[0] ^ lo.x, 0u);
-            d = bcnt_acc(a[1] ^ lo.y, d); d = bcnt_acc(a[2] ^ lo.z, d); d = bcnt_acc(a[3] ^ lo.w, d);
-            d = bcnt_acc(a[4] ^ hi.x, d); d = bcnt_acc(a[5] ^ hi.y, d); d = bcnt_acc(a[6] ^ hi.z, d); d = bcnt_acc(a[7] ^ hi.w, d);
-            if (FILTER) d = sG[wv][j] == gA ? d : 0xffffu;
-            // scan order inside a slice is ascending j: an equal distance with a later j has the larger key, only d < th can enter (as in k_bow_topk)
-            const uint32_t key = d < th ? (d << 16) | (uint32_t)(t0 + j) : 0xffffffffu;
-            if (__any(key < kk[TOPK - 1])) { topk_insert(kk, key); th = kk[TOPK - 1] >> 16; }
-        }
-    }
-    // the four waves' lists of a feature -> one (wave 0)
     __syncthreads();
-    if (wv > 0) {
-#pragma unroll
-        for (int q = 0; q < TOPK; q++) sK[wv - 1][lane][q] = kk[q];
+    const unsigned char *myB = sDesc + (size_t)sl * slicePitch;
+    const int j0 = sl * per, jn = max(0, min(per, nB - j0));      // this lane's slice: B features j0 .. j0 + jn
+    for (int j = 0; j < per; j++) {                               // (uniform trip count; a step beyond the slice's end compares against zero padding and is masked)
+        const uint4 lo = *(const uint4 *)(myB + (size_t)j * 32), hi = *(const uint4 *)(myB + (size_t)j * 32 + 16);
+        uint32_t d = bcnt_acc(a[0] ^ lo.x, 0u);
+        d = bcnt_acc(a[1] ^ lo.y, d); d = bcnt_acc(a[2] ^ lo.z, d); d = bcnt_acc(a[3] ^ lo.w, d);
+        d = bcnt_acc(a[4] ^ hi.x, d); d = bcnt_acc(a[5] ^ hi.y, d); d = bcnt_acc(a[6] ^ hi.z, d); d = bcnt_acc(a[7] ^ hi.w, d);
+        if (FILTER) d = sG[j0 + j] == gA ? d : 0xffffu;
+        // scan order inside a slice is ascending j: an equal distance with a later j has the larger key, only d < th can enter (as in k_bow_topk)
+        const uint32_t key = (j < jn && d < th) ? (d << 16) | (uint32_t)(j0 + j) : 0xffffffffu;
+        if (__any(key < kk[TOPK - 1])) { topk_insert(kk, key); th = kk[TOPK - 1] >> 16; }
     }
-    __syncthreads();
-    if (wv == 0) {
-        for (int w = 0; w < 3; w++)
+    // the sixteen slices of a feature: butterfly over the lane bits 1, 2, 4, 8 - after round m every lane holds the TOPK of its group of 2^(m+1) slices
 #pragma unroll
-            for (int q = 0; q < TOPK; q++) { const uint32_t key = sK[w][lane][q]; if (__any(key < kk[TOPK - 1])) topk_insert(kk, key); }
+    for (int m = 1; m < PAIR_SLICES; m <<= 1) {
+        uint32_t other[TOPK];
+#pragma unroll
+        for (int q = 0; q < TOPK; q++) other[q] = (uint32_t)__shfl_xor((int)kk[q], m);
+#pragma unroll
+        for (int q = 0; q < TOPK; q++) if (__any(other[q] < kk[TOPK - 1])) topk_insert(kk, other[q]);
     }
-    if (SY == 1) {
-        if (wv == 0 && live) {
-            uint32_t *out = topk + (size_t)row * TOPK;
+    if (sl == 0 && live) {
+        uint4 *out = (uint4 *)(topk + (size_t)row * TOPK);
+        uint32_t o[TOPK];
 #pragma unroll
-            for (int q = 0; q < TOPK; q++) out[q] = (!act || kk[q] >= sentinel) ? KEY_EMPTY : kk[q];
-        }
-        return;
+        for (int q = 0; q < TOPK; q++) o[q] = (!act || kk[q] >= sentinel) ? KEY_EMPTY : kk[q];
+        out[0] = make_uint4(o[0], o[1], o[2], o[3]); out[1] = make_uint4(o[4], o[5], o[6], o[7]);
     }
-    const size_t nRowsPad = (size_t)nRowBlocks * SPLIT_ROWS;
-    if (wv == 0) {
-        uint4 *po = (uint4 *)(part + ((size_t)y * nRowsPad + row) * TOPK);
-        po[0] = make_uint4(kk[0], kk[1], kk[2], kk[3]); po[1] = make_uint4(kk[4], kk[5], kk[6], kk[7]);
-        __threadfence();      // the partial list is visible to the device before the arrival is counted
-    }
-    __syncthreads();
-    if (tid == 0) sLast = atomicAdd(&rowCounter[rb], 1u) == (unsigned)(SY - 1);
-    __syncthreads();
-    if (!sLast) return;
-    __threadfence();          // (acquire side: the other workgroups' partial lists)
-    // the last workgroup of the row block: wave w merges the partial lists y = w, w + 4, ...; then the waves merge as above
-#pragma unroll
-    for (int q = 0; q < TOPK; q++) kk[q] = act ? sentinel : 0u;
-    for (int yy = wv; yy < SY; yy += 4) {
-        const uint4 *pi = (const uint4 *)(part + ((size_t)yy * nRowsPad + row) * TOPK);
-        const uint4 lo = pi[0], hi = pi[1];
-        const uint32_t keys[TOPK] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-        for (int q = 0; q < TOPK; q++) if (__any(keys[q] < kk[TOPK - 1])) topk_insert(kk, keys[q]);
-    }
-    if (wv > 0) {
-#pragma unroll
-        for (int q = 0; q < TOPK; q++) sK[wv - 1][lane][q] = kk[q];
-    }
-    __syncthreads();
-    if (wv == 0) {
-        for (int w = 0; w < 3; w++)
-#pragma unroll
-            for (int q = 0; q < TOPK; q++) { const uint32_t key = sK[w][lane][q]; if (__any(key < kk[TOPK - 1])) topk_insert(kk, key); }
-        if (live) {
-            uint32_t *out = topk + (size_t)row * TOPK;
-#pragma unroll
-            for (int q = 0; q < TOPK; q++) out[q] = (!act || kk[q] >= sentinel) ? KEY_EMPTY : kk[q];
-        }
-    }
-    if (tid == 0) rowCounter[rb] = 0;      // ready for the next call
 }
 
 // greedy replay + rotation histogram + three-maxima pruning; one workgroup per pair.
@@ -1207,7 +1182,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->pairsA.release(); m->pairsB.release(); m->order.release(); m->matches.release(); m->dists.release(); m->nmatches.release();
-    m->hostStage.release(); m->projDec.release(); m->projQueue.release(); m->box.release(); m->arena.release(); m->topkPart.release(); m->rowCounter.release();
+    m->hostStage.release(); m->projDec.release(); m->projQueue.release(); m->box.release(); m->arena.release();
     m->topk.release(); m->scales.release(); m->uright.release(); m->depth.release(); m->sad.release(); m->stRowStart.release(); m->stRowList.release();
     m->topk64.release(); m->pkp.release(); m->producerStatus.release();
     for (int q = 0; q < 2; q++) { m->pf[q].release(); m->pb[q].release(); m->pi32[q].release(); }
@@ -1692,7 +1667,7 @@ int stage_host(orbx_matcher *m, int side, const orbx_feature_set *h, orbx_featur
 }  // namespace orbx_match
 
 // One pair from host arrays, the call src/Tracking.cc:1195 / 2073 make through shim/ORBmatcher_hip.cc.  No copy engine, no stream synchronisation
-// (OrbxCallBox): the arrays go into mapped pinned memory, k_stage_copy reads them once into the handle's arena, k_bow_topk_split (B split over the
+// (OrbxCallBox): the arrays go into mapped pinned memory, k_stage_copy reads them once into the handle's arena, k_bow_topk_pair (B split over the
 // chip, the processing order in the same launch) and k_bow_greedy follow, the replay writes the match list into mapped pinned memory and raises the
 // call's sequence word.  204 us -> see profiles/r06_latency_calls.txt.  ORBX_BOW_SINGLE_SPLIT=0: the round-5 path (stage, the batch kernels, download).
 static int search_by_bow_single(orbx_matcher *m, const orbx_feature_set *a, const orbx_feature_set *b, const orbx_bow_params *prm, int32_t *matches, int32_t *nmatches)
@@ -1723,22 +1698,19 @@ static int search_by_bow_single(orbx_matcher *m, const orbx_feature_set *a, cons
     uint32_t dcut = TH_LOW + 1;
     while (dcut < 257 && !(prm->nn_ratio * (float)dcut > (float)TH_LOW)) dcut++;
     const bool filter = b->groups != nullptr || (prm->mode == 1 && b->valid != nullptr);
-    // geometry: 64 A features per workgroup; B slices so that ~2 x 256 workgroups exist and a wave still has >= 16 features to scan
-    const int nRowBlocks = (nA + SPLIT_ROWS - 1) / SPLIT_ROWS;
-    int SY = std::max(1, std::min(16, 512 / nRowBlocks));
-    SY = std::max(1, std::min(SY, (nB + 63) / 64));
-    const int per = (((nB + 4 * SY - 1) / (4 * SY)) + 3) & ~3;
-    const int nOrder = (nA + 31) / 32;
-    const size_t partWords = (size_t)SY * nRowBlocks * SPLIT_ROWS * TOPK;
-    if ((rc = m->topkPart.ensure(partWords)) != ORBX_OK) return rc;
-    if ((size_t)nRowBlocks > m->rowCounter.n) {
-        if ((rc = m->rowCounter.ensure((size_t)std::max(nRowBlocks, 1024))) != ORBX_OK) return rc;
-        ORBX_HIP_CHECK(hipMemsetAsync(m->rowCounter.p, 0, m->rowCounter.n * sizeof(unsigned), m->stream));
-    }
+    // geometry: 16 A features per workgroup (4 per wave x 16 B slices), all of B in the workgroup's LDS; the order's workgroups behind them
+    const int nRowBlocks = (nA + PAIR_ROWS - 1) / PAIR_ROWS, nOrder = (nA + 31) / 32;
+    const int per = (nB + PAIR_SLICES - 1) / PAIR_SLICES;
+    const size_t ldsPair = std::max((size_t)PAIR_SLICES * ((size_t)per * 32 + 16) + (size_t)PAIR_SLICES * per * 4, (size_t)4096 * 4);
     if ((rc = m->topk.ensure(NA * TOPK)) != ORBX_OK || (rc = m->order.ensure(NA)) != ORBX_OK) return rc;
-    const dim3 grid((unsigned)(nRowBlocks * SY + nOrder));
-    if (filter) hipLaunchKernelGGL(k_bow_topk_split<true>, grid, dim3(256), 0, m->stream, A, B, prm->mode, dcut, nRowBlocks, SY, per, m->topkPart.p, m->rowCounter.p, m->topk.p, m->order.p);
-    else hipLaunchKernelGGL(k_bow_topk_split<false>, grid, dim3(256), 0, m->stream, A, B, prm->mode, dcut, nRowBlocks, SY, per, m->topkPart.p, m->rowCounter.p, m->topk.p, m->order.p);
+    const dim3 grid((unsigned)(nRowBlocks + nOrder));
+    if (filter) {
+        if (ldsPair > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_topk_pair<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsPair));
+        hipLaunchKernelGGL(k_bow_topk_pair<true>, grid, dim3(256), ldsPair, m->stream, A, B, prm->mode, dcut, nRowBlocks, per, m->topk.p, m->order.p);
+    } else {
+        if (ldsPair > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_topk_pair<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsPair));
+        hipLaunchKernelGGL(k_bow_topk_pair<false>, grid, dim3(256), ldsPair, m->stream, A, B, prm->mode, dcut, nRowBlocks, per, m->topk.p, m->order.p);
+    }
     MLAUNCH_CHECK();
     const size_t ldsGreedy = NB * 4 + NA * 4 + (size_t)((nA + 7) & ~7) * 2 * 2;
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature count %d too large for the LDS tile", nA); return ORBX_ERR_CAPACITY; }
@@ -1768,7 +1740,7 @@ extern "C" int orbx_search_by_bow(orbx_matcher *m, const orbx_feature_set *a_hos
     ORBX_HIP_CHECK(hipSetDevice(m->device));
     static const bool split = !(getenv("ORBX_BOW_SINGLE_SPLIT") && getenv("ORBX_BOW_SINGLE_SPLIT")[0] == '0');
     if (split && a_host && b_host && a_host->keypoints && a_host->descriptors && a_host->counts && b_host->keypoints && b_host->descriptors && b_host->counts &&
-        a_host->counts[0] > 0 && b_host->counts[0] > 0 && a_host->counts[0] <= m->maxFeatures && b_host->counts[0] <= m->maxFeatures)
+        a_host->counts[0] > 0 && b_host->counts[0] > 0 && a_host->counts[0] <= m->maxFeatures && b_host->counts[0] <= std::min(m->maxFeatures, 4000))      // (B in LDS: 36 bytes per feature)
         return search_by_bow_single(m, a_host, b_host, params, matches, nmatches);
     orbx_feature_set da, db;
     int rc;

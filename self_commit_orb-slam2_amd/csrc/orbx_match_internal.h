@@ -69,8 +69,6 @@ struct orbx_matcher {
     OrbxHostStage hostStage;     // host-array entry points: all inputs of a call in one pinned buffer, one copy
     OrbxCallBox box;             // single-call host entry points of the tracking thread: mapped pinned inputs / results + sequence word (no copy engine, no stream sync)
     OrbxDevBuf<uint8_t> arena;   // ... their inputs on the device, copied there once by k_stage_copy (same offsets as in box.in)
-    OrbxDevBuf<uint32_t> topkPart;      // k_bow_topk_split: the B slices' partial candidate lists
-    OrbxDevBuf<unsigned> rowCounter;    // ... arrivals per row block (0 between calls)
     OrbxDevBuf<int32_t> sad;
     OrbxDevBuf<int32_t> stRowStart, stRowList;   // ComputeStereoMatches: vRowIndices of the right frames (k_stereo_rows)
     hipEvent_t evDep2 = nullptr, evPyr[2] = {nullptr, nullptr};
