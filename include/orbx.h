@@ -596,6 +596,19 @@ int orbx_bow_transform(orbx_vocabulary *v, const uint8_t *descriptors, int n, in
  * i.e. gets the reference's maps bit for bit without ~2000 tree searches (shim/BoW_hip.cc: 66 -> 20 us per frame).  The orders are ranked on the device. */
 int orbx_bow_transform_sorted(orbx_vocabulary *v, const uint8_t *descriptors, int n, int levelsup, int32_t *word, int32_t *node, double *weight,
                               int32_t *by_word, int32_t *by_node, int32_t *filed);
+/* Latency form for the ONE frame that `ext`'s last single-frame call extracted (Frame::ComputeBoW of the frame the constructor has just built,
+ * src/Frame.cc:880-896 behind :394-456): the descriptors are read where the extractor left them on the device - nothing is uploaded - and the call
+ * can be begun the moment the extraction is complete, long before the tracking thread asks for the BowVector.  A job owns its stream, result
+ * buffers and pinned memory and only READS the vocabulary: any number of jobs and orbx_bow_transform* calls may use one vocabulary concurrently
+ * (the vocabulary must outlive its jobs).  _begin returns at once; _end waits and hands out pointers INTO the job's pinned memory, valid until the
+ * next call on the job: word / node / weight per feature, the two orders of orbx_bow_transform_sorted, *filed and the feature count *n.
+ * `ext` must not be called between _begin and the completion of the job's kernels (~20 us). */
+typedef struct orbx_bow_job orbx_bow_job;
+int orbx_bow_job_create(orbx_vocabulary *v, orbx_bow_job **out);
+void orbx_bow_job_destroy(orbx_bow_job *j);
+int orbx_bow_job_begin(orbx_bow_job *j, orbx_extractor *ext, int levelsup);
+int orbx_bow_job_end(orbx_bow_job *j, const int32_t **word, const int32_t **node, const double **weight, const int32_t **by_word, const int32_t **by_node,
+                     int32_t *filed, int32_t *n);
 
 
 /* ------------------------------------------------------------------------------------

@@ -281,3 +281,89 @@ extern "C" int orbx_bow_transform_sorted(orbx_vocabulary *v, const uint8_t *desc
     if (!by_word || !by_node || !filed) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
     return bow_transform_host(v, descriptors, n, levelsup, word, node, weight, by_word, by_node, filed);
 }
+
+// ---- the latency form (include/orbx.h: orbx_bow_job_*) ----
+struct orbx_bow_job {
+    orbx_vocabulary *v = nullptr;
+    hipStream_t stream = nullptr;
+    OrbxCallBox box;
+    OrbxDevBuf<int32_t> word, node;
+    int pendingN = -1;      // -1: nothing begun
+    size_t offNode = 0, offW = 0, offBW = 0, offBN = 0, offF = 0;
+};
+
+extern "C" int orbx_bow_job_create(orbx_vocabulary *v, orbx_bow_job **out)
+{
+    if (!v || !out) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    *out = nullptr;
+    ORBX_HIP_CHECK(hipSetDevice(v->device));
+    orbx_bow_job *j = new orbx_bow_job();
+    j->v = v;
+    if (hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking) != hipSuccess) { delete j; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
+    *out = j;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_bow_job_destroy(orbx_bow_job *j)
+{
+    if (!j) return;
+    (void)hipSetDevice(j->v->device);
+    if (j->stream) { (void)hipStreamSynchronize(j->stream); (void)hipStreamDestroy(j->stream); }
+    j->box.release(); j->word.release(); j->node.release();
+    delete j;
+}
+
+extern "C" int orbx_bow_job_begin(orbx_bow_job *j, orbx_extractor *ext, int levelsup)
+{
+    if (!j || !ext) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    j->pendingN = -1;
+    int st = 0;
+    if (!orbx_extractor_host_complete_internal(ext, &st)) { orbx_set_error("the extractor's last call was not a completed single-frame call"); return ORBX_ERR_STATE; }
+    if (st) { orbx_set_error("the extractor call these features come from overflowed a device capacity (bits 0x%x): results are not the reference's", st); return ORBX_ERR_CAPACITY; }
+    OrbxLastBatchView view;
+    int rc = orbx_extractor_last_batch_view_internal(ext, &view);
+    if (rc != ORBX_OK) return rc;
+    orbx_vocabulary *v = j->v;
+    ORBX_HIP_CHECK(hipSetDevice(v->device));
+    const int n = orbx_extractor_host_count_internal(ext), cap = view.cap;
+    if (n < 0 || n > cap) { orbx_set_error("feature count %d out of range", n); return ORBX_ERR_CAPACITY; }
+    if (n == 0) { j->pendingN = 0; return ORBX_OK; }
+    OrbxCallBox &bx = j->box;
+    const size_t N = (size_t)n;
+    j->offNode = bx.padded(N * 4); j->offW = j->offNode + bx.padded(N * 4); j->offBW = j->offW + bx.padded(N * 8); j->offBN = j->offBW + bx.padded(N * 4); j->offF = j->offBN + bx.padded(N * 4);
+    if ((rc = bx.begin(0, j->offF + bx.padded(4), j->stream)) != ORBX_OK) return rc;
+    if ((rc = j->word.ensure(N)) || (rc = j->node.ensure(N))) return rc;
+    const unsigned long long seq = bx.arm();
+    // (frame 0 of the view, n features: `cap` = n for the kernel's indexing - one frame, feature i at i)
+    hipLaunchKernelGGL(k_bow_transform, dim3((unsigned)((n + 255) / 256), 1u), dim3(256), 0, j->stream, v->nodes.p, v->childList.p, v->childDesc.p, v->nodeWeight.p, v->L - levelsup,
+                       view.desc, (const int32_t *)nullptr, n, bx.outDev<int32_t>(0), bx.outDev<int32_t>(j->offNode), bx.outDev<double>(j->offW), j->word.p, j->node.p, bx.counter,
+                       (unsigned long long *)nullptr, seq);
+    hipLaunchKernelGGL(k_bow_ranks, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, j->stream, (const int32_t *)j->word.p, (const int32_t *)j->node.p, n, bx.outDev<int32_t>(j->offBW),
+                       bx.outDev<int32_t>(j->offBN), bx.outDev<int32_t>(j->offF), bx.counter, bx.flagDev, seq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { orbx_set_error("kernel launch failed: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
+    j->pendingN = n;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_bow_job_end(orbx_bow_job *j, const int32_t **word, const int32_t **node, const double **weight, const int32_t **by_word, const int32_t **by_node,
+                                int32_t *filed, int32_t *n)
+{
+    if (!j || !filed || !n) { orbx_set_error("NULL argument"); return ORBX_ERR_ARG; }
+    const int pn = j->pendingN;
+    j->pendingN = -1;
+    if (pn < 0) { orbx_set_error("no job has been begun"); return ORBX_ERR_STATE; }
+    *n = pn; *filed = 0;
+    if (pn == 0) return ORBX_OK;
+    ORBX_HIP_CHECK(hipSetDevice(j->v->device));
+    int rc = j->box.wait(j->stream);
+    if (rc != ORBX_OK) return rc;
+    const OrbxCallBox &bx = j->box;
+    if (word) *word = bx.outHost<int32_t>(0);
+    if (node) *node = bx.outHost<int32_t>(j->offNode);
+    if (weight) *weight = bx.outHost<double>(j->offW);
+    if (by_word) *by_word = bx.outHost<int32_t>(j->offBW);
+    if (by_node) *by_node = bx.outHost<int32_t>(j->offBN);
+    *filed = *bx.outHost<int32_t>(j->offF);
+    return ORBX_OK;
+}

@@ -556,6 +556,8 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
         }
     }
     for (int s = tid; s < stride; s += GREEDY_THREADS) { mout[s] = -1; dout[s] = 256; }
+    uint4 myK0 = make_uint4(0u, 0u, 0u, 0u), myK1 = myK0, othK0 = myK0, othK1 = myK0;
+    bool haveKeys = false;
     for (;;) {
         for (int j = tid; j < nB; j += GREEDY_THREADS) owner[j] = 0xffffffffu;
         if (tid == 0) { sChanged = 0; sQueued = 0; }
@@ -569,7 +571,9 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
         for (int r = tid; r < nA; r += GREEDY_THREADS) {
             const int i = sOrd[r];
             if (i == 0xffff) continue;
-            const uint4 q0 = tk[i * 2], q1 = tk[i * 2 + 1];
+            // (rank tid's list stays in registers across the rounds: a round was two dependent L2 round trips per rank)
+            if (r != tid || !haveKeys) { const uint4 q0 = tk[i * 2], q1 = tk[i * 2 + 1]; if (r == tid) { myK0 = q0; myK1 = q1; haveKeys = true; } else { othK0 = q0; othK1 = q1; } }
+            const uint4 q0 = r == tid ? myK0 : othK0, q1 = r == tid ? myK1 : othK1;
             const uint32_t keys[TOPK] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
             uint32_t bestKey = KEY_EMPTY;
             int best2 = 256, nfree = 0;

@@ -153,6 +153,8 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_greedy(ProjFrameDe
         if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) return PROJ_NONE;
         return (uint32_t)bestIdx;
     };
+    ulonglong2 ka0 = make_ulonglong2(0ull, 0ull), ka1 = ka0, ka2 = ka0, ka3 = ka0, kb0 = ka0, kb1 = ka0, kb2 = ka0, kb3 = ka0;
+    int have = 0, inv = 0;
     for (;;) {
         __syncthreads();
         for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = 0xffffffffu;
@@ -165,9 +167,24 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_greedy(ProjFrameDe
         __syncthreads();
         bool changed = false;
         for (int r = tid; r < m; r += PROJ_GREEDY_THREADS) {
-            if (!P.inView[pbase + r]) continue;
-            const ulonglong2 *lp = (const ulonglong2 *)(tk + (size_t)r * TOPK);
-            const ulonglong2 q0 = lp[0], q1 = lp[1], q2 = lp[2], q3 = lp[3];
+            const int slot = (r - tid) / PROJ_GREEDY_THREADS;      // the thread's first two points keep their lists (and in-view flags) in registers across the rounds
+            if (slot < 2 && !(have & (1 << slot))) {
+                const bool iv = P.inView[pbase + r] != 0;
+                inv = iv ? (inv | (1 << slot)) : inv;
+                if (iv) {
+                    const ulonglong2 *lp = (const ulonglong2 *)(tk + (size_t)r * TOPK);
+                    if (slot == 0) { ka0 = lp[0]; ka1 = lp[1]; ka2 = lp[2]; ka3 = lp[3]; } else { kb0 = lp[0]; kb1 = lp[1]; kb2 = lp[2]; kb3 = lp[3]; }
+                }
+                have |= 1 << slot;
+            }
+            ulonglong2 q0, q1, q2, q3;
+            if (slot == 0) { if (!(inv & 1)) continue; q0 = ka0; q1 = ka1; q2 = ka2; q3 = ka3; }
+            else if (slot == 1) { if (!(inv & 2)) continue; q0 = kb0; q1 = kb1; q2 = kb2; q3 = kb3; }
+            else {
+                if (!P.inView[pbase + r]) continue;
+                const ulonglong2 *lp = (const ulonglong2 *)(tk + (size_t)r * TOPK);
+                q0 = lp[0]; q1 = lp[1]; q2 = lp[2]; q3 = lp[3];
+            }
             const unsigned long long keys[TOPK] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
             unsigned long long k1 = KEY64_EMPTY, k2 = KEY64_EMPTY;
             int nfree = 0;

@@ -20,8 +20,11 @@
 #include "orbx.h"
 #include "shim_error.h"
 
-static unsigned long gBoWCalls = 0;
+static unsigned long gBoWCalls = 0, gEarlyBoW = 0;
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_compute_bow_calls(void) { return gBoWCalls; }
+extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_early_bow(void) { return gEarlyBoW; }      // ComputeBoW calls served by a job the constructor began
+// shim/Frame_hip.cc (when it is part of the build): the job it began for frame `frameId` of `leftExtractor` with nFeatures features, or NULL; one shot
+extern "C" __attribute__((weak)) void *orbx_shim_early_bow_take(void *leftExtractor, long frameId, int nFeatures);
 
 namespace ORB_SLAM2
 {
@@ -66,7 +69,7 @@ struct VocAccess : public ORBVocabulary {
 // One device vocabulary per ORBVocabulary object.  An orbx_vocabulary handle is NOT re-entrant (its scratch / result buffers are
 // member state, like every orbx handle: "one call at a time per handle", include/orbx.h), but Tracking (Frame::ComputeBoW) and
 // LocalMapping / LoopClosing (KeyFrame::ComputeBoW) share the vocabulary: `call` serialises the orbx_bow_transform calls on it.
-struct DeviceVoc { orbx_vocabulary *h; unsigned long long fp; std::mutex call; DeviceVoc() : h(0), fp(0) {} };
+struct DeviceVoc { orbx_vocabulary *h; unsigned long long fp, generation; std::mutex call; DeviceVoc() : h(0), fp(0), generation(0) {} };
 std::mutex gVocMutex;
 std::map<const ORBVocabulary *, DeviceVoc *> gVocs;
 
@@ -92,9 +95,44 @@ DeviceVoc *DeviceVocabulary(const ORBVocabulary *voc)
         return 0;      // (not cached: the next call tries again)
     }
     DeviceVoc *d = it != gVocs.end() ? it->second : new DeviceVoc();
-    d->h = dv; d->fp = fp;
+    d->h = dv; d->fp = fp; d->generation++;
     gVocs[voc] = d;
     return d;
+}
+
+// The reference's loop over the features (TemplatedVocabulary.h:1146-1196) from the device's results: word / node / weight per feature and the two key orders.
+void FillMaps(const ORBVocabulary *voc, const int32_t *word, const int32_t *node, const double *weight, const int32_t *byWord, const int32_t *byNode, int filed,
+              DBoW2::BowVector &v, DBoW2::FeatureVector &fv)
+{
+    DBoW2::LNorm norm;
+    const bool must = VocAccess::Scoring(*voc)->mustNormalize(norm);
+    const DBoW2::WeightingType wt = voc->getWeightingType();
+    const bool tf = wt == DBoW2::TF || wt == DBoW2::TF_IDF;
+    // The reference's loop over the features (:1146-1196) does v.addWeight / v.addIfNotExist (word) and fv.addFeature (node, i) for every feature with a
+    // positive weight, in feature order: a tree search per call.  The same maps from the device's two orders: keys arrive ascending, so every new key goes
+    // in at the end of the map; the weights of a word are added in feature order (addWeight's sums, bit for bit), addIfNotExist keeps the first, and a
+    // node's feature list is appended in feature order.
+    {
+        DBoW2::BowVector::iterator vit = v.end();
+        for (int k = 0; k < filed; k++) {
+            const int i = byWord[k];
+            const DBoW2::WordId w = (DBoW2::WordId)word[i];
+            if (vit == v.end() || vit->first != w) vit = v.insert(v.end(), DBoW2::BowVector::value_type(w, weight[i]));      // :1160 / :1187 (new word)
+            else if (tf) vit->second += weight[i];                                                                          // addWeight on an existing word
+        }
+        DBoW2::FeatureVector::iterator fit = fv.end();
+        for (int k = 0; k < filed; k++) {
+            const int i = byNode[k];
+            const DBoW2::NodeId nd = (DBoW2::NodeId)node[i];
+            if (fit == fv.end() || fit->first != nd) fit = fv.insert(fv.end(), DBoW2::FeatureVector::value_type(nd, std::vector<unsigned int>()));
+            fit->second.push_back((unsigned int)i);                                                                                  // :1161
+        }
+    }
+    if (tf && !v.empty() && !must) {                                                          // :1165-1171
+        const double nd = v.size();
+        for (DBoW2::BowVector::iterator vit = v.begin(); vit != v.end(); vit++) vit->second /= nd;
+    }
+    if (must) v.normalize(norm);                                                              // :1196
 }
 
 // TemplatedVocabulary::transform(features, v, fv, levelsup), :1127-1196, with the per-feature
@@ -125,42 +163,51 @@ void Transform(const ORBVocabulary *voc, const cv::Mat &descriptors, DBoW2::BowV
         if (orbx_bow_transform_sorted(dv->h, rows, n, levelsup, &word[0], &node[0], &weight[0], &byWord[0], &byNode[0], &filed) != ORBX_OK) { orbx_shim::Fail("ComputeBoW"); return; }
     }
     orbx_shim::Mark("ComputeBoW device call returned");
-    DBoW2::LNorm norm;
-    const bool must = VocAccess::Scoring(*voc)->mustNormalize(norm);
-    const DBoW2::WeightingType wt = voc->getWeightingType();
-    const bool tf = wt == DBoW2::TF || wt == DBoW2::TF_IDF;
-    // The reference's loop over the features (:1146-1196) does v.addWeight / v.addIfNotExist (word) and fv.addFeature (node, i) for every feature with a
-    // positive weight, in feature order: a tree search per call.  The same maps from the device's two orders: keys arrive ascending, so every new key goes
-    // in at the end of the map; the weights of a word are added in feature order (addWeight's sums, bit for bit), addIfNotExist keeps the first, and a
-    // node's feature list is appended in feature order.
-    {
-        DBoW2::BowVector::iterator vit = v.end();
-        for (int k = 0; k < filed; k++) {
-            const int i = byWord[(size_t)k];
-            const DBoW2::WordId w = (DBoW2::WordId)word[(size_t)i];
-            if (vit == v.end() || vit->first != w) vit = v.insert(v.end(), DBoW2::BowVector::value_type(w, weight[(size_t)i]));      // :1160 / :1187 (new word)
-            else if (tf) vit->second += weight[(size_t)i];                                                                          // addWeight on an existing word
-        }
-        DBoW2::FeatureVector::iterator fit = fv.end();
-        for (int k = 0; k < filed; k++) {
-            const int i = byNode[(size_t)k];
-            const DBoW2::NodeId nd = (DBoW2::NodeId)node[(size_t)i];
-            if (fit == fv.end() || fit->first != nd) fit = fv.insert(fv.end(), DBoW2::FeatureVector::value_type(nd, std::vector<unsigned int>()));
-            fit->second.push_back((unsigned int)i);                                                                                  // :1161
-        }
-    }
-    if (tf && !v.empty() && !must) {                                                          // :1165-1171
-        const double nd = v.size();
-        for (DBoW2::BowVector::iterator vit = v.begin(); vit != v.end(); vit++) vit->second /= nd;
-    }
-    if (must) v.normalize(norm);                                                              // :1196
+    FillMaps(voc, &word[0], &node[0], &weight[0], &byWord[0], &byNode[0], filed, v, fv);
     orbx_shim::Mark("ComputeBoW returns");
 }
 }  // namespace
 
+}  // namespace ORB_SLAM2
+
+// for shim/Frame_hip.cc: the device copy of `voc` (an ORBVocabulary *) and the number of times it has been (re)built for that address
+extern "C" __attribute__((visibility("default"))) orbx_vocabulary *orbx_shim_device_vocabulary(const void *voc, unsigned long long *generation)
+{
+    const ORB_SLAM2::ORBVocabulary *v = (const ORB_SLAM2::ORBVocabulary *)voc;
+    if (!v || v->empty()) return 0;
+    ORB_SLAM2::DeviceVoc *d = ORB_SLAM2::DeviceVocabulary(v);
+    if (!d) return 0;
+    if (generation) *generation = d->generation;
+    return d->h;
+}
+
+namespace ORB_SLAM2
+{
+
 void Frame::ComputeBoW()
 {
-    if (mBowVec.empty()) Transform(mpORBvocabulary, mDescriptors, mBowVec, mFeatVec, 4);      // src/Frame.cc:883-894
+    if (!mBowVec.empty()) return;      // src/Frame.cc:883
+    // the descent of THIS frame's descriptors may have been started from inside its constructor, on the device-resident features the moment the
+    // extraction was complete (shim/Frame_hip.cc: PostExtract -> orbx_bow_job_begin): then only the maps are left to fill
+    if (orbx_shim_early_bow_take && mpORBvocabulary && !mpORBvocabulary->empty()) {
+        orbx_bow_job *job = (orbx_bow_job *)orbx_shim_early_bow_take(mpORBextractorLeft, (long)mnId, N);
+        if (job) {
+            orbx_shim::Mark("ComputeBoW enters (begun by the constructor)");
+            const int32_t *word = 0, *node = 0, *byWord = 0, *byNode = 0;
+            const double *weight = 0;
+            int32_t filed = 0, n = 0;
+            if (orbx_bow_job_end(job, &word, &node, &weight, &byWord, &byNode, &filed, &n) == ORBX_OK && n == N) {
+                __atomic_add_fetch(&gBoWCalls, 1, __ATOMIC_RELAXED);
+                __atomic_add_fetch(&gEarlyBoW, 1, __ATOMIC_RELAXED);
+                orbx_shim::Mark("ComputeBoW device call returned");
+                mBowVec.clear(); mFeatVec.clear();
+                if (n > 0) FillMaps(mpORBvocabulary, word, node, weight, byWord, byNode, filed, mBowVec, mFeatVec);
+                orbx_shim::Mark("ComputeBoW returns");
+                return;
+            }
+        }
+    }
+    Transform(mpORBvocabulary, mDescriptors, mBowVec, mFeatVec, 4);      // :883-894
 }
 
 void KeyFrame::ComputeBoW()

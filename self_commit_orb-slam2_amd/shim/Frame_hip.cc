@@ -97,6 +97,9 @@ extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_image_
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_assign_grid_calls(void) { return gGridCalls; }
 extern "C" __attribute__((visibility("default"))) unsigned long orbx_shim_compute_stereo_matches_calls(void) { return gStereoCalls; }
 
+// shim/BoW_hip.cc (when it is part of the build): the device copy of an ORBVocabulary
+extern "C" __attribute__((weak)) orbx_vocabulary *orbx_shim_device_vocabulary(const void *voc, unsigned long long *generation);
+
 namespace ORB_SLAM2
 {
 
@@ -177,8 +180,14 @@ struct FrameAssist {
     const Frame *finishFor;          // the frame whose mvKeysUn / mGrid were filled by ExtractORB
     int finishN;
     orbx_frame_grid finishGrid;
-    FrameAssist() : arrivals(0), pairFailed(0), stereo(0), stereoCap(0), stereoFor(0), ops(0), finishFor(0), finishN(0) { memset(&opsKey, 0, sizeof(opsKey)); memset(&finishGrid, 0, sizeof(finishGrid)); }
-    ~FrameAssist() { if (stereo) orbx_matcher_destroy(stereo); if (ops) orbx_frame_ops_destroy(ops); }
+    // Frame::ComputeBoW's vocabulary descent, begun on the device-resident descriptors the moment the left image is done (orbx_bow_job_begin);
+    // Frame::ComputeBoW (shim/BoW_hip.cc) collects it through orbx_shim_early_bow_take - by frame id, the constructor's object is a temporary
+    orbx_bow_job *bowJob;
+    orbx_vocabulary *bowVoc;
+    unsigned long long bowGen;
+    long bowForId;                   // -1: none
+    FrameAssist() : arrivals(0), pairFailed(0), stereo(0), stereoCap(0), stereoFor(0), ops(0), finishFor(0), finishN(0), bowJob(0), bowVoc(0), bowGen(0), bowForId(-1) { memset(&opsKey, 0, sizeof(opsKey)); memset(&finishGrid, 0, sizeof(finishGrid)); }
+    ~FrameAssist() { if (stereo) orbx_matcher_destroy(stereo); if (ops) orbx_frame_ops_destroy(ops); if (bowJob) orbx_bow_job_destroy(bowJob); }
 };
 void FreeAssist(void *p) { delete (FrameAssist *)p; }
 std::mutex gAssistMutex;
@@ -235,6 +244,16 @@ void PostExtract(void *vc, bool ok)
             if (A->ops && orbx_frame_finish_begin(A->ops, F->mpORBextractorLeft->Handle(), &g) == ORBX_OK) { c->finishBegun = true; c->grid = g; }
         }
     }
+    if (c->flag == 0 && ok && F->mpORBvocabulary && orbx_shim_device_vocabulary) {      // Frame::ComputeBoW's descent: begun here, collected there
+        unsigned long long gen = 0;
+        orbx_vocabulary *dv = orbx_shim_device_vocabulary((const void *)F->mpORBvocabulary, &gen);
+        if (dv) {
+            if (A->bowJob && (A->bowVoc != dv || A->bowGen != gen)) { orbx_bow_job_destroy(A->bowJob); A->bowJob = 0; }
+            if (!A->bowJob && orbx_bow_job_create(dv, &A->bowJob) == ORBX_OK) { A->bowVoc = dv; A->bowGen = gen; }
+            if (A->bowJob && orbx_bow_job_begin(A->bowJob, F->mpORBextractorLeft->Handle(), 4) == ORBX_OK) A->bowForId = (long)F->mnId;
+            TRACE("left: BoW descent launched");
+        }
+    }
     if (F->mpORBextractorRight) {      // the stereo constructor: two calls per frame, the second one to finish starts the match
         if (!ok) A->pairFailed.store(1);
         if (A->arrivals.fetch_add(1) == 1) {
@@ -247,6 +266,22 @@ void PostExtract(void *vc, bool ok)
     }
 }
 }  // namespace
+
+}  // namespace ORB_SLAM2
+
+// for shim/BoW_hip.cc: the vocabulary job begun for frame `frameId` (nFeatures features) by the constructor that used `leftExtractor`, or NULL; one shot
+extern "C" __attribute__((visibility("default"))) void *orbx_shim_early_bow_take(void *leftExtractor, long frameId, int nFeatures)
+{
+    if (!leftExtractor || !ORB_SLAM2::EarlyStart()) return 0;
+    ORB_SLAM2::FrameAssist *A = (ORB_SLAM2::FrameAssist *)__atomic_load_n(&((ORB_SLAM2::ORBextractor *)leftExtractor)->mpFrameAssist, __ATOMIC_ACQUIRE);
+    if (!A || !A->bowJob || A->bowForId < 0 || A->bowForId != frameId) return 0;
+    A->bowForId = -1;
+    (void)nFeatures;      // (checked by the caller against the job's own count)
+    return A->bowJob;
+}
+
+namespace ORB_SLAM2
+{
 
 // ---------------------------------------------------------------------------------------------
 //     void Frame::ExtractORB(int flag, const cv::Mat &im)                     src/Frame.cc:494-512
@@ -264,7 +299,7 @@ void Frame::ExtractORB(int flag, const cv::Mat &im)
     PostCtx ctx = {this, flag, 0, false, {0.0f, 0.0f, 0.0f, 0.0f}};
     if (EarlyStart() && mpORBextractorLeft && ex) {
         ctx.A = AssistOf(mpORBextractorLeft);
-        if (flag == 0) { ctx.A->finishFor = 0; ctx.A->stereoFor = 0; }      // (whatever an abandoned constructor left behind)
+        if (flag == 0) { ctx.A->finishFor = 0; ctx.A->stereoFor = 0; ctx.A->bowForId = -1; }      // (whatever an abandoned constructor left behind)
         ex->SetPostExtract(&PostExtract, &ctx);
     }
     if (mpORBextractorLeft && mpORBextractorRight)
