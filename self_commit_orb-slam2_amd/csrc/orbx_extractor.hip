@@ -1084,6 +1084,9 @@ struct CombEngine {
     hipGraph_t graph[COMB_MAX_LIMIT + 1] = {};
     hipGraphExec_t exec[COMB_MAX_LIMIT + 1] = {};
     bool planned = false;
+    unsigned *syncDev = nullptr;             // device: arrivals of k_comb_finish + the count of completed launch sets
+    unsigned long long *flag = nullptr, *flagDev = nullptr;   // mapped host: that count as the host sees it (behind the set's results)
+    unsigned long long launched = 0;         // launch sets enqueued on this engine so far (what the leader waits for)
     bool pooledStream = false, highPrio = false;   // eng->stream came from (and goes back to) the process's engine-stream pool
     std::atomic<int> busy{0};                // taken (under Combiner::mu) by a leader, released by it without the lock
 };
@@ -1188,6 +1191,8 @@ static void comb_detach_locked(orbx_extractor *h)
         if (E->eng && E->pooledStream && E->eng->stream) { comb_stream_give(E->eng->cfg.device, E->highPrio, E->eng->stream); E->eng->stream = nullptr; }
         if (E->eng) orbx_extractor_destroy(E->eng);
         if (E->tab) (void)hipHostFree(E->tab);
+        if (E->flag) (void)hipHostFree(E->flag);
+        if (E->syncDev) (void)hipFree(E->syncDev);
         delete E;
     }
     delete c;
@@ -1250,7 +1255,7 @@ static int comb_new_engine(Combiner *C, CombEngine **out)
     }
     auto fail = [&](int code) {
         if (E->pooledStream && e->stream) { (void)hipStreamSynchronize(e->stream); comb_stream_give(C->cfg.device, E->highPrio, e->stream); e->stream = nullptr; }
-        orbx_extractor_destroy(e); if (E->tab) (void)hipHostFree(E->tab); delete E; return code;
+        orbx_extractor_destroy(e); if (E->tab) (void)hipHostFree(E->tab); if (E->flag) (void)hipHostFree(E->flag); if (E->syncDev) (void)hipFree(E->syncDev); delete E; return code;
     };
     if ((rc = ensure_geometry(e, C->W, C->H, C->maxB)) != ORBX_OK) return fail(rc);
     if ((rc = e->staging.ensure(C->fp * (size_t)C->maxB)) != ORBX_OK) return fail(rc);
@@ -1258,6 +1263,9 @@ static int comb_new_engine(Combiner *C, CombEngine **out)
     void *dp = nullptr;
     if (hipHostGetDevicePointer(&dp, E->tab, 0) != hipSuccess) { orbx_set_error("hipHostGetDevicePointer (member table) failed"); return fail(ORBX_ERR_HIP); }
     E->tabDev = (const OrbxCombMember *)dp;
+    if (hipMalloc((void **)&E->syncDev, 64) != hipSuccess || hipMemset(E->syncDev, 0, 64) != hipSuccess || hipHostMalloc((void **)&E->flag, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&E->flagDev, E->flag, 0) != hipSuccess) { orbx_set_error("completion word of the engine could not be allocated"); return fail(ORBX_ERR_HIP); }
+    *E->flag = 0;
     // the members' arenas have the one-frame layout (ensure_geometry with batch 1): same capacity, same offsets for all of them
     C->kpOff = align_up(3 * sizeof(int), 256);
     C->descOff = C->kpOff + align_up((size_t)e->geom.outCap * sizeof(orbx_keypoint), 256);
@@ -1283,7 +1291,7 @@ static int comb_build_graph(Combiner *C, CombEngine *E, int n)
     }
     OrbxLaunch L;
     fill_launch(e, L, e->staging.p, n, C->dstStride, C->fp, 0);
-    L.combTab = E->tabDev; L.combKpOff = C->kpOff; L.combDescOff = C->descOff;
+    L.combTab = E->tabDev; L.combKpOff = C->kpOff; L.combDescOff = C->descOff; L.combSync = E->syncDev; L.combFlag = E->flagDev;
     hipGraph_t g = nullptr;
     ORBX_HIP_CHECK(hipGraphCreate(&g, 0));
     // (a failure below must not leave a half-built graph behind - it would be found "built" without an executable and rebuilt on every set of this size)
@@ -1441,7 +1449,21 @@ static void comb_lead(Combiner *C, const std::shared_ptr<CombBatch> &B, std::uni
         const double tL = now_us();
         hipError_t he = hipGraphLaunch(E->exec[n], E->eng->stream);
         const double tY = now_us();
-        if (he == hipSuccess) he = hipStreamSynchronize(E->eng->stream);
+        if (he == hipSuccess) {
+            // the set's last kernel raises the engine's completion count in pinned memory behind its last result: polled (a stream synchronisation
+            // returns ~10 us after the device is done); the stream is asked only when that takes implausibly long
+            const unsigned long long want = ++E->launched;
+            static const bool poll = !(getenv("ORBX_COMBINE_POLL") && getenv("ORBX_COMBINE_POLL")[0] == '0');
+            bool arrived = false;
+            // (sets of several members = many calling threads, the throughput case: measured with 16 threads, polling leaders cost 40 % of the frames/s -
+            // the runtime retires a stream's finished commands inside its synchronisation call, and sixteen spinning hosts do not leave it the cores)
+            if (poll && n <= 2)
+                for (unsigned spins = 1; !(arrived = __atomic_load_n(E->flag, __ATOMIC_ACQUIRE) >= want); spins++) {
+                    cpu_relax();
+                    if ((spins & 0xfff) == 0 && now_us() - tY > 20000.0) break;
+                }
+            if (!arrived) he = hipStreamSynchronize(E->eng->stream);
+        }
         const long usS = (long)(now_us() - tY);
         C->usLaunch.fetch_add((long)(tY - tL), std::memory_order_relaxed); C->usSync.fetch_add(usS, std::memory_order_relaxed);
         C->setsByN[n].fetch_add(1, std::memory_order_relaxed); C->usByN[n].fetch_add(usS, std::memory_order_relaxed);

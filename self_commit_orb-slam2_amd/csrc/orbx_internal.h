@@ -130,6 +130,8 @@ struct OrbxLaunch {
     /* graph construction (single-frame call): when `graph` is set, a launcher adds a kernel node that depends on deps[0..ndeps)
      * and returns it in *node instead of launching on `stream` */
     const OrbxCombMember *combTab = nullptr;      /* combined single-frame batches: member table (pinned host memory) */
+    unsigned *combSync = nullptr;                 /* ... device: [0] arrivals of k_comb_finish's workgroups, [2..3] launch sets completed so far (u64) */
+    unsigned long long *combFlag = nullptr;       /* ... mapped host: the same count, stored behind a set's last result - what the leader polls instead of synchronising the stream */
     size_t combKpOff = 0, combDescOff = 0;        /* one-frame arena layout of the members */
     const OrbxPyrTile *pyrTiles = nullptr; int pyrTileCount = 0, pyrTileBuf = 0, pyrTileTab = 0;   /* k_pyramid_tiles plan (single-frame call): bytes of one of its two LDS image buffers, bytes of its LDS table slices */
     hipGraph_t graph = nullptr;

@@ -1472,7 +1472,8 @@ __global__ __launch_bounds__(256) void k_comb_upload(const OrbxCombMember *__res
 // pyramid copy behind the public mvImagePyramid).  Only the frame's real keypoints are moved, not the arena's capacity.
 __global__ __launch_bounds__(256) void k_comb_finish(const OrbxCombMember *__restrict__ tab, const int *__restrict__ engCnt, const int *__restrict__ engSt,
                                                      const orbx_keypoint *__restrict__ engKp, const uint8_t *__restrict__ engDesc, int cap, const uint8_t *__restrict__ engPyr,
-                                                     size_t pyrBytes, const uint8_t *__restrict__ engImg, size_t framePitch, size_t kpOff, size_t descOff, int hostPyrHere)
+                                                     size_t pyrBytes, const uint8_t *__restrict__ engImg, size_t framePitch, size_t kpOff, size_t descOff, int hostPyrHere,
+                                                     unsigned *sync, unsigned long long *hostFlag)
 {
     const int f = blockIdx.y;
     const OrbxCombMember m = tab[f];
@@ -1505,6 +1506,21 @@ __global__ __launch_bounds__(256) void k_comb_finish(const OrbxCombMember *__res
         const uint4 *s = (const uint4 *)(engImg + (size_t)f * framePitch);
         uint4 *d = (uint4 *)m.devImg;
         if (d) for (size_t i = tid; i < (framePitch >> 4); i += stride) d[i] = s[i];
+    }
+    if (hostFlag) {
+        // completion of the launch set, for the leader that polls pinned memory instead of synchronising the stream (the graph's arguments are fixed:
+        // the count of completed sets lives on the device): the last workgroup to arrive raises it behind everybody's stores
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (__hip_atomic_fetch_add(sync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1) {
+                __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long *cnt = (unsigned long long *)(sync + 2);
+                const unsigned long long done = *cnt + 1;
+                *cnt = done;
+                __hip_atomic_store(hostFlag, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -1616,7 +1632,7 @@ int orbx_launch_comb_finish(const OrbxLaunch &L)
     const size_t units = (L.geom->pyrBytes + L.img0FramePitch) >> 4;
     const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((units + 511) / 512, 1), 256);
     return emit(L, k_comb_finish, dim3(blocks, (unsigned)L.batch), dim3(256), 0, L.combTab, L.outCnt, L.outStatus, L.outKp, L.outDesc, L.geom->outCap, L.pyr, L.geom->pyrBytes, L.img0,
-                L.img0FramePitch, L.combKpOff, L.combDescOff, 0);      // (the host pyramid copy rides in the quadtree's launch)
+                L.img0FramePitch, L.combKpOff, L.combDescOff, 0, L.combSync, L.combFlag);      // (the host pyramid copy rides in the quadtree's launch)
 }
 
 // developer tap (tools/fast_phases.py; not part of include/orbx.h): a device array of 32 u64 that the PROF instantiation of k_fast_cells adds
