@@ -53,15 +53,33 @@ public:
     // mbViewHostPyramid (default FALSE; opt-in for a caller that reads the levels before its next call and keeps none of them): the levels
     // are VIEWS of the handle's pinned memory instead of copies (0.64 MB and ~45 us less per 640x480 frame) - overwritten by the next call,
     // emptied by the extractor before its handle is rebuilt or destroyed; a header copy a caller made of such a level is the caller's risk.
+    // It binds like the member it replaces: `std::vector<cv::Mat> &v = ex.mvImagePyramid;` (conversion, filling first), range-for / begin() / end(),
+    // at(), front() / back(), size() / empty() / resize() / clear(); every accessor that hands out a level fills first.
     class ImagePyramid
     {
     public:
+        typedef std::vector<cv::Mat>::iterator iterator;
+        typedef std::vector<cv::Mat>::const_iterator const_iterator;
+        typedef cv::Mat value_type;
         ImagePyramid() : mpOwner(0) {}
         cv::Mat &operator[](size_t level) { Fill(); return mv[level]; }
         const cv::Mat &operator[](size_t level) const { const_cast<ImagePyramid *>(this)->Fill(); return mv[level]; }
+        cv::Mat &at(size_t level) { Fill(); return mv.at(level); }
+        const cv::Mat &at(size_t level) const { const_cast<ImagePyramid *>(this)->Fill(); return mv.at(level); }
+        cv::Mat &front() { Fill(); return mv.front(); }
+        cv::Mat &back() { Fill(); return mv.back(); }
+        const cv::Mat &front() const { const_cast<ImagePyramid *>(this)->Fill(); return mv.front(); }
+        const cv::Mat &back() const { const_cast<ImagePyramid *>(this)->Fill(); return mv.back(); }
+        iterator begin() { Fill(); return mv.begin(); }
+        iterator end() { Fill(); return mv.end(); }
+        const_iterator begin() const { const_cast<ImagePyramid *>(this)->Fill(); return mv.begin(); }
+        const_iterator end() const { const_cast<ImagePyramid *>(this)->Fill(); return mv.end(); }
         size_t size() const { return mv.size(); }
         bool empty() const { return mv.empty(); }
         void resize(size_t n) { mv.resize(n); }
+        void clear() { if (mpOwner) mpOwner->DropImagePyramid(); for (size_t i = 0; i < mv.size(); i++) mv[i] = cv::Mat(); }      // (the levels stay: nlevels is the extractor's)
+        operator std::vector<cv::Mat> &() { Fill(); return mv; }
+        operator const std::vector<cv::Mat> &() const { const_cast<ImagePyramid *>(this)->Fill(); return mv; }
         std::vector<cv::Mat> &Levels() { Fill(); return mv; }
     private:
         friend class ORBextractor;

@@ -2,6 +2,7 @@
 // built against oracle/cvshim (this box has no OpenCV) + liborbx.so.  The calling code is the
 // reference's own call shape, Frame::ExtractORB (src/Frame.cc:503): (*extractor)(im, cv::Mat(), keys, desc).
 #include <cstring>
+#include <stdexcept>
 #include <vector>
 
 #include "ORBextractor.h"
@@ -40,6 +41,35 @@ extern "C" int shim_pyramid_level(void *h, int level, unsigned char *dst, int *w
     *w = m.cols; *hgt = m.rows;
     for (int y = 0; y < m.rows; y++) memcpy(dst + (size_t)y * m.cols, m.ptr(y), (size_t)m.cols);
     return 0;
+}
+
+// The member binds like the reference's `std::vector<cv::Mat> mvImagePyramid` (include/ORBextractor.h:161): a reference to the vector, iteration, at(),
+// front() / back(), size() / empty() - each of them sees the CURRENT frame's levels.  Returns a checksum over all the routes (they must agree), < 0 on a mismatch.
+static long level_sum(const cv::Mat &m) { long s = m.rows * 131 + m.cols; for (int y = 0; y < m.rows; y += 7) s += m.ptr(y)[(y * 3) % (m.cols > 0 ? m.cols : 1)]; return s; }
+extern "C" long shim_pyramid_binds_like_a_vector(void *h)
+{
+    ORB_SLAM2::ORBextractor *e = (ORB_SLAM2::ORBextractor *)h;
+    std::vector<cv::Mat> &v = e->mvImagePyramid;                      // what a caller written against the reference does
+    const std::vector<cv::Mat> &cv_ = e->mvImagePyramid;
+    long a = 0, b = 0, c = 0, d = 0;
+    for (size_t l = 0; l < v.size(); l++) a += level_sum(v[l]);
+    for (auto &m : e->mvImagePyramid) b += level_sum(m);
+    for (ORB_SLAM2::ORBextractor::ImagePyramid::const_iterator it = e->mvImagePyramid.begin(); it != e->mvImagePyramid.end(); ++it) c += level_sum(*it);
+    for (size_t l = 0; l < e->mvImagePyramid.size(); l++) d += level_sum(e->mvImagePyramid.at(l));
+    if (a != b || a != c || a != d || cv_.size() != v.size() || e->mvImagePyramid.empty()) return -1;
+    if (level_sum(e->mvImagePyramid.front()) != level_sum(v[0]) || level_sum(e->mvImagePyramid.back()) != level_sum(v[v.size() - 1])) return -2;
+    try { (void)e->mvImagePyramid.at(v.size()); return -3; } catch (const std::out_of_range &) {}
+    return a;
+}
+// ... and none of that needs a device to COMPILE and link (the CPU test): an extractor that never ran has nlevels empty levels
+extern "C" int shim_pyramid_of_a_fresh_extractor(void *h)
+{
+    ORB_SLAM2::ORBextractor *e = (ORB_SLAM2::ORBextractor *)h;
+    std::vector<cv::Mat> &v = e->mvImagePyramid;
+    int n = 0;
+    for (auto &m : e->mvImagePyramid) n += m.empty() ? 1 : 100;
+    e->mvImagePyramid.clear();
+    return (int)v.size() * 1000 + n;
 }
 
 extern "C" int shim_levels(void *h) { return ((ORB_SLAM2::ORBextractor *)h)->GetLevels(); }

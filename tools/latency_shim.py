@@ -88,7 +88,11 @@ def stereo_frame(orbx, iters_hip, iters_ref):
                                        ctypes.byref(nl), ctypes.byref(nm))
         rows.append({"call": "Frame::Frame(imLeft, imRight, ...) = 2 x ExtractORB on two threads + ComputeStereoMatches", "library": name, "size": "%dx%d" % (W, H),
                      "nfeatures": nf, "combiner": os.environ.get("ORBX_COMBINE", "1") != "0", "mean_us": round(mean.value, 1), "median_us": round(med.value, 1),
-                     "keypoints_left": nl.value, "stereo_matches": nm.value})
+                     "keypoints_left": nl.value, "stereo_matches": nm.value,
+                     "allocator_note": "this constructor loop runs WITHOUT the CallerArena of the parity tests: the quadtree's tie between equally large nodes is decided by "
+                                       "their addresses in the reference (src/ORBextractor.cc:948), i.e. by the allocator - on plain malloc the all-reference library keeps ~0.1 % other "
+                                       "keypoints (and a few other stereo matches) than under the bump allocator the drop-in's rule restates (tests/test_tie_rule.py); inside the arena both "
+                                       "libraries agree to the bit (tests/test_dropin_slam.py)"})
         if prof:      # mean microseconds per constructor inside every replaced member function (ExtractORB: per call, two concurrent calls per frame)
             br = {}
             for i, nm_ in enumerate(("ExtractORB_per_call", "UndistortKeyPoints", "ComputeStereoMatches", "ComputeImageBounds", "AssignFeaturesToGrid")):
