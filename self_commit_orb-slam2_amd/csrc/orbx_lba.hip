@@ -569,6 +569,7 @@ __global__ __launch_bounds__(256) void k_sum_poses_fin(LbaDev d, const double *_
 struct LmState {
     double lambda, ni, currentChi, iniChi, rho, chi0, tempChi;
     int it, qmax, nBad, ok, done, lastRejected, relin, trials, iters, maxIters;
+    unsigned arrive;      // workgroups of k_errors_decide that have stored their share of chi2 (0 between launches)
 };
 
 __device__ __forceinline__ double wave_sum(double x)
@@ -587,22 +588,30 @@ __device__ __forceinline__ void lm_mirror(const LmState *st, double *host, doubl
 }
 
 // start of optimize(maxIters): chi2 of the start (k_errors' partial sums, in block order), computeLambdaInit (:166-180: tau = 1e-5 times
-// the largest diagonal entry, from k_diag_max), counters cleared
-__global__ __launch_bounds__(256) void k_lm_begin(LmState *st, const double *partChi, int nChi, const double *diagMax, int maxIters, const volatile int *stopHost, double *host,
-                                                  double seq, unsigned long long *scaleBits)
+// the largest diagonal entry of H), counters cleared
+__global__ __launch_bounds__(256) void k_lm_begin(LmState *st, const double *partChi, int nChi, const double *Hpp, int nPose, const double *Hll, int nPt, int maxIters,
+                                                  const volatile int *stopHost, double *host, double seq, unsigned long long *scaleBits)
 {
-    __shared__ double sw[4];
+    __shared__ double sw[4], sm[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 6) scaleBits[tid] = 0ull;      // (the maxima of the Schur scale: raised by the next k_schur_setup)
     double v0 = 0;
     for (int i = tid; i < nChi; i += 256) v0 += partChi[i];
     v0 = wave_sum(v0);
-    if (lane == 0) sw[wave] = v0;
+    // computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180): max |diagonal entry| over the pose and landmark blocks (a launch of its own,
+    // k_diag_max, until round 6: a maximum does not care who computes it)
+    double b = 0;
+    for (int i = tid; i < 6 * nPose; i += 256) b = fmax(b, fabs(Hpp[(size_t)(i / 6) * 36 + 7 * (i % 6)]));
+    for (int i = tid; i < 3 * nPt; i += 256) b = fmax(b, fabs(Hll[(size_t)(i / 3) * 9 + 4 * (i % 3)]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = fmax(b, __shfl_xor(b, o));
+    if (lane == 0) { sw[wave] = v0; sm[wave] = b; }
     __syncthreads();
     if (tid == 0) {
         const double chi = sw[0] + sw[1] + sw[2] + sw[3];
-        st->lambda = 1e-5 * diagMax[2]; st->ni = 2; st->currentChi = chi; st->iniChi = chi; st->chi0 = chi; st->tempChi = chi; st->rho = 0;
-        st->it = 0; st->qmax = 0; st->nBad = 0; st->ok = 1; st->lastRejected = 0; st->relin = 0; st->trials = 0; st->iters = 0; st->maxIters = maxIters;
+        const double diagMax = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+        st->lambda = 1e-5 * diagMax; st->ni = 2; st->currentChi = chi; st->iniChi = chi; st->chi0 = chi; st->tempChi = chi; st->rho = 0;
+        st->it = 0; st->qmax = 0; st->nBad = 0; st->ok = 1; st->lastRejected = 0; st->relin = 0; st->trials = 0; st->iters = 0; st->maxIters = maxIters; st->arrive = 0;
         st->done = (maxIters <= 0 || (stopHost && *stopHost)) ? 1 : 0;
         lm_mirror(st, host, seq, 0.0, 0.0, 1.0);
     }
@@ -657,18 +666,15 @@ __device__ __forceinline__ int lm_decide_thread0(LmState *st, double tempChi, do
 
 // end of a trial: partChi / partL = the per-workgroup shares of activeRobustChi2 and of sum xl (lambda xl + bl) (k_errors, k_backsub_update),
 // added in block order; xp (lambda xp + bp) summed here; okFlag = the factorisation's.
-__global__ __launch_bounds__(256) void k_lm_decide(LmState *st, const double *partChi, int nChi, const double *partL, int nL, const double *xp, const double *bp, int nP6,
-                                                   const int *okFlag, const volatile int *stopHost, double *host, double seq, LbaDev d, const DPose *poseBak, const double *ptBak,
-                                                   unsigned long long *scaleBits)
+// (the body of a whole workgroup of 256 threads; `done` stages have been dealt with by the caller)
+__device__ __forceinline__ void lm_decide_block(LmState *st, const double *partChi, int nChi, const double *partL, int nL, const double *xp, const double *bp, int nP6,
+                                                const int *okFlag, const volatile int *stopHost, double *host, double seq, const LbaDev &d, const DPose *poseBak, const double *ptBak,
+                                                unsigned long long *scaleBits)
 {
     __shared__ double sw[3][4];
     __shared__ int sRejected;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 6) scaleBits[tid] = 0ull;      // (the maxima of the Schur scale: raised again by the next k_schur_setup)
-    if (st->done) {      // a trial the stage did not need: only the sequence number moves (the host may be waiting for this very launch)
-        if (tid == 0) { __threadfence_system(); __hip_atomic_store(host + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-        return;
-    }
     const double lambda = st->lambda;
     double v0 = 0, v1 = 0, v2 = 0;
     for (int i = tid; i < nChi; i += 256) v0 += partChi[i];
@@ -691,6 +697,62 @@ __global__ __launch_bounds__(256) void k_lm_decide(LmState *st, const double *pa
         for (int g = tid; g < d.K; g += 256) d.pose[g] = poseBak[g];
         for (int g = tid; g < 3 * d.P; g += 256) d.pt[g] = ptBak[g];
     }
+}
+
+__global__ __launch_bounds__(256) void k_lm_decide(LmState *st, const double *partChi, int nChi, const double *partL, int nL, const double *xp, const double *bp, int nP6,
+                                                   const int *okFlag, const volatile int *stopHost, double *host, double seq, LbaDev d, const DPose *poseBak, const double *ptBak,
+                                                   unsigned long long *scaleBits)
+{
+    if (st->done) {      // a trial the stage did not need: only the sequence number moves (the host may be waiting for this very launch)
+        if (threadIdx.x < 6) scaleBits[threadIdx.x] = 0ull;
+        if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(host + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        return;
+    }
+    lm_decide_block(st, partChi, nChi, partL, nL, xp, bp, nP6, okFlag, stopHost, host, seq, d, poseBak, ptBak, scaleBits);
+}
+
+// k_errors and k_lm_decide of a trial as ONE launch: every workgroup stores its share of activeRobustChi2 (partChi[blockIdx.x], as k_errors does) and
+// counts itself in; the workgroup that arrives last takes the decision - it adds the shares in BLOCK order, so the sums do not depend on who arrives
+// when - and takes a rejected update back.  One launch and one kernel boundary (~6 us) less per trial.
+__global__ __launch_bounds__(256) void k_errors_decide(LbaDev d, Huber h, int robust, double *partChi, LmState *st, const double *partL, int nL, const double *xp, const double *bp,
+                                                       int nP6, const int *okFlag, const volatile int *stopHost, double *host, double seq, const DPose *poseBak, const double *ptBak,
+                                                       unsigned long long *scaleBits)
+{
+    __shared__ double swE[4];
+    __shared__ int sLast;
+    if (st->done) {      // a trial the stage did not need: only the sequence number moves (the host may be waiting for this very launch)
+        if (blockIdx.x == 0) {
+            if (threadIdx.x < 6) scaleBits[threadIdx.x] = 0ull;
+            if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(host + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
+        return;
+    }
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double r0 = 0;
+    if (e < d.E) {
+        if (!d.active[e]) d.rchi[e] = 0;   // _error of inactive edges stays as last computed
+        else {
+            double r[3];
+            edge_error(d, e, r, nullptr);
+            d.err[3 * (size_t)e] = r[0]; d.err[3 * (size_t)e + 1] = r[1]; d.err[3 * (size_t)e + 2] = r[2];
+            const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * d.info[e];
+            double r1 = 1;
+            r0 = chi;
+            if (robust) huber_rho(h, d.stereo[e] != 0, chi, r0, r1);
+            d.rchi[e] = r0;
+        }
+    }
+    const double t = block_sum256(r0, swE);
+    if (threadIdx.x == 0) {
+        partChi[blockIdx.x] = t;
+        __threadfence();      // the share (and this workgroup's _error / chi2 stores) before the arrival
+        sLast = atomicAdd(&st->arrive, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();          // (acquire side: everybody's shares)
+    if (threadIdx.x == 0) st->arrive = 0;
+    lm_decide_block(st, partChi, (int)gridDim.x, partL, nL, xp, bp, nP6, okFlag, stopHost, host, seq, d, poseBak, ptBak, scaleBits);
 }
 
 // The marshalled inputs of a call arrive as ONE host-to-device copy of the pinned staging buffer; this kernel distributes the segments
@@ -901,19 +963,6 @@ __global__ __launch_bounds__(256) void k_restore(LbaDev d, const DPose *poseBak,
     if (g < 3 * d.P) d.pt[g] = ptBak[g];
 }
 
-// computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180): out[2] = max |diagonal entry| over the pose and landmark blocks
-__global__ __launch_bounds__(1024) void k_diag_max(const double *Hpp, int nPose, const double *Hll, int nPt, double *out)
-{
-    __shared__ double m[1024];
-    double b = 0;
-    for (int i = threadIdx.x; i < 6 * nPose; i += 1024) b = fmax(b, fabs(Hpp[(size_t)(i / 6) * 36 + 7 * (i % 6)]));
-    for (int i = threadIdx.x; i < 3 * nPt; i += 1024) b = fmax(b, fabs(Hll[(size_t)(i / 3) * 9 + 4 * (i % 3)]));
-    m[threadIdx.x] = b;
-    __syncthreads();
-    for (int k = 512; k > 0; k >>= 1) { if ((int)threadIdx.x < k) m[threadIdx.x] = fmax(m[threadIdx.x], m[threadIdx.x + k]); __syncthreads(); }
-    if (threadIdx.x == 0) out[2] = m[0];
-}
-
 // S = blockdiag(Hpp) + lambda*I ; bs = bp   (setLambda + "_Hpp->add(_Hschur)", block_solver.hpp:363-365, 564-589)
 // e->chi2() from the stored _error and isDepthPositive() from the CURRENT estimates (src/Optimizer.cc:880-958): flag = outlier
 // poseOut / ptOut (final call): the estimates copied next to the flags, so that ONE device-to-host copy brings everything back
@@ -1009,7 +1058,7 @@ __device__ __forceinline__ int schur_q(unsigned long long bits)
     return (e + 2) >> 1;      // = ceil((e + 1) / 2): 2^(2q) >= 2^(e + 1) > h
 }
 
-// The ordered add of the keyframe partial sums (= k_sum_poses_fin, which the start of a stage still launches on its own for k_diag_max)
+// The ordered add of the keyframe partial sums (= k_sum_poses_fin, which the start of a stage still launches on its own: k_lm_begin reads Hpp's diagonal)
 // as the first workgroups of k_schur_setup: Hpp / b_p of every free pose from the SP_SPLIT partial results, and the scale maxima.
 __device__ __forceinline__ void schur_poses_part(int block, const LbaDev &d, const double *__restrict__ part, int spSplit, double *__restrict__ Hpp, double *__restrict__ bp,
                                                  unsigned long long *scaleBits)
@@ -1394,10 +1443,18 @@ __device__ __forceinline__ double pivot_rsqrt(double x)
 //   the other blocks  the REST of the previous panel's trailing update, block columns > p, one 32x32 tile each.
 // The two kinds touch disjoint parts of S and only read L[:, p-1], so they need no order between them: the trailing update no
 // longer sits between two panels (15 dependent launches per factorisation become 8) and runs while the panel's serial chain does.
+// PROF (tools/chol_phases.py, never in a product launch): thread 0 of the first panel workgroup adds the wall cycles (s_memtime) between its phase boundaries to prof[0..7],
+// the passes to prof[8..15]: 0 staging, 1 previous panel's update (MFMA), 2 diagonal block (wave 0), 3 wait for the panel rows (wave 1), 4 stores.
+//   inside the diagonal block, summed over its 8 blocks of four columns: 5 the pivot chain (readlanes, 4 x rsq + Newton, the 4 x 4 part), 6 own entries + publishing the four columns
+//   through LDS, 7 the rank-4 update of the rest of the block.
+#define CH_STAMP(i) do { if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tPrev; pcnt[i] += 1; tPrev = __builtin_amdgcn_s_memtime(); } } while (0)
+template <bool PROF>
 __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, double *__restrict__ L, int n, int p0, int nPW, int T1, double *ywork, double *ysol, int *okFlag,
-                                                   double *__restrict__ diagInv /* 1 / L[i][i], for the substitution kernel */, const int *gate, int want)
+                                                   double *__restrict__ diagInv /* 1 / L[i][i], for the substitution kernel */, const int *gate, int want, unsigned long long *prof)
 {
-    if (gate && *gate != want) return;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
+    if (gate && *gate != want) return;
+    unsigned long long tPrev = PROF ? __builtin_amdgcn_s_memtime() : 0ull, pacc[PROF ? 8 : 1] = {}, pcnt[PROF ? 8 : 1] = {};
+    (void)tPrev; (void)pacc; (void)pcnt;      // device-side LM: this launch belongs to a trial the stage no longer needs (or to a branch not taken)
     __shared__ double Ld[CNB][CNB + 1];      // diagonal block in, L11 (lower incl. diagonal) out      | update role: la
     __shared__ double Tt[64][CNB + 1];       // 63 rows of the panel below + the right-hand side (row 63) | update role: lb (first 32 rows)
     __shared__ __attribute__((aligned(16))) double LpD[CNB][CNB + 2];     // previous panel, rows of this diagonal block; afterwards the column exchange buffer of the block factorisation
@@ -1480,6 +1537,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
         }
     }
     __syncthreads();
+    CH_STAMP(0);
     if (hasPrev) {
         // own part of the previous panel's update on the matrix cores: C -= A B^T as v_mfma_f64_16x16x4_f64 (layout checked by
         // tools/ubench_mfma_f64.hip: A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16], D lane l element v = D[4 v + l / 16][l % 16]).
@@ -1511,6 +1569,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
         }
     }
     if (hasPrev) __syncthreads();
+    CH_STAMP(1);
     if (wave == 0) {
         // THE DIAGONAL BLOCK on one wave, no barrier inside, blocked by four columns.  Lane = (row r, half hf) keeps A[r][16 hf .. 16 hf + 15] in
         // registers.  Per block the 4x4 diagonal part travels by v_readlane and is factored redundantly by every lane (wave-uniform scalars), every
@@ -1552,6 +1611,8 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
                     for (int m = k + 1; m <= i; m++) d[i][m] = __builtin_fma(-d[i][k], d[m][k], d[i][m]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            unsigned long long tA = 0;
+            if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { tA = __builtin_amdgcn_s_memtime(); pacc[5] += tA - tPrev; pcnt[5] += 1; }
 #pragma unroll
             for (int k = 0; k < 4; k++) invOwn = lane == c0 + k ? inv[k] : invOwn;      // lane c collects 1 / L[c][c] (no store on the chain)
             // own entries against the block (rows of the block itself reproduce d[][] in their lower part)
@@ -1576,6 +1637,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
             if (lane == 0) __hip_atomic_store(&xReady, cb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // block cb is published
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[6] += t_ - tA; pcnt[6] += 1; tPrev = t_; }
             if (cb == CNB / 4 - 1) break;        // nothing left to update
             // ---- region B: the rest of the diagonal block (no fence needed: the LDS executes the instructions of a wave in order)
             const double2 lr01 = *(const double2 *)cb4[r], lr23 = *(const double2 *)(cb4[r] + 2);
@@ -1586,11 +1648,13 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
                 a[q] = __builtin_fma(-lr23.y, m23.y, __builtin_fma(-lr23.x, m23.x, __builtin_fma(-lr01.y, m01.y, __builtin_fma(-lr01.x, m01.x, a[q]))));
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (PROF && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[7] += t_ - tPrev; pcnt[7] += 1; tPrev = t_; }
         }
 #pragma unroll
         for (int q = 0; q < 16; q++) if (16 * hf + q <= r) Ld[r][16 * hf + q] = a[q];
         if (bad && lane == 0) sBad = 1;
         if (blockIdx.x == 0 && lane < CNB) diagInv[p0 + lane] = invOwn;      // (the buffer is padded to a multiple of 32)
+        CH_STAMP(2);
     } else if (wave == 1) {
         // THE PANEL ROWS on a second wave (another SIMD): lane = panel row with its 32 entries in registers, lane 63 the right-hand side.  It follows
         // the diagonal block's wave one block behind: as soon as block cb is published (its four columns of L11 in cbx[cb], the factored 4x4 part and
@@ -1629,6 +1693,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
         if (ywLive) ywork[r0 + lane] = yw - ((dot[0] + dot[1]) + (dot[2] + dot[3]));
     }
     __syncthreads();
+    CH_STAMP(3);
     for (int idx = tid; idx < CHOL_RPW * CNB; idx += 256) {
         const int r = idx >> 5, c = idx & 31;
         if (r0 + r < n && c < nb) L[(size_t)(r0 + r) * n + p0 + c] = Tt[r][c];
@@ -1641,7 +1706,13 @@ __global__ __launch_bounds__(256) void k_chol_step(double *__restrict__ S, doubl
         if (tid < nb) ysol[p0 + tid] = Tt[CHOL_RPW][tid];
         if (sBad && tid == 0) *okFlag = 0;   // not positive definite: the results are discarded by the host
     }
+    if (PROF) {
+        __syncthreads();
+        CH_STAMP(4);
+        if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < 8; i++) { atomicAdd(&prof[i], pacc[i]); atomicAdd(&prof[8 + i], pcnt[i]); }
+    }
 }
+#undef CH_STAMP
 
 // L^T x = y, panels from the last to the first; x in LDS
 // XG = true (n > CHOL_LDS_X): the vector lives in x itself; one workgroup, so __syncthreads() orders the accesses, and they are made
@@ -2372,6 +2443,9 @@ namespace {
         if (e_ != hipSuccess) { orbx_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); return ORBX_ERR_HIP; } \
     } while (0)
 
+// developer tap (tools/chol_phases.py; not part of include/orbx.h): a device array of 16 u64 the PROF instantiation of k_chol_step adds its phase cycles / passes to
+static unsigned long long *g_cholProf = nullptr;
+
 struct Ctx {
     orbx_lba *h;
     LbaDev d;
@@ -2486,10 +2560,9 @@ int optimize(Ctx &c, int iterations, double stats[4])
             hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K, (unsigned)c.spSplit), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->spPart.p, c.spSplit, (const int *)nullptr, 0);
         }
         hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p, c.spSplit, (const int *)nullptr, 0);
-        hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(1024), 0, h->stream, h->Hpp.p, nPose, h->Hll.p, nPt, h->red.p);
         const double seq = (h->seq += 1.0);
-        hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(256), 0, h->stream, st, (const double *)h->partChi.p, (int)gE, (const double *)h->red.p, iterations, (const volatile int *)h->hostStopDev,
-                           h->hostRedDev, seq, h->scaleBits.p);
+        hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(256), 0, h->stream, st, (const double *)h->partChi.p, (int)gE, (const double *)h->Hpp.p, nPose, (const double *)h->Hll.p, nPt, iterations,
+                           (const volatile int *)h->hostStopDev, h->hostRedDev, seq, h->scaleBits.p);
         LCHECK();
     }
     // ---- one Levenberg trial in two halves
@@ -2536,8 +2609,10 @@ int optimize(Ctx &c, int iterations, double stats[4])
                     const int nb = std::min(CNB, n - p0), below = n - p0 - nb;
                     const int nPW = std::max(1, (below + CHOL_RPW - 1) / CHOL_RPW);
                     const int T1 = p0 > 0 ? (n - p0 + CNB - 1) / CNB - 1 : 0;        // tile rows / columns beyond block column p that still await the previous panel's update
-                    hipLaunchKernelGGL(k_chol_step, dim3((unsigned)(nPW + T1 * T1)), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0, nPW, std::max(T1, 1), h->ywork.p,
-                                       h->ysol.p, h->okFlag.p, h->diagInv.p, gDone, 0);
+                    if (g_cholProf) hipLaunchKernelGGL(k_chol_step<true>, dim3((unsigned)(nPW + T1 * T1)), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0, nPW, std::max(T1, 1), h->ywork.p,
+                                                       h->ysol.p, h->okFlag.p, h->diagInv.p, gDone, 0, g_cholProf);
+                    else hipLaunchKernelGGL(k_chol_step<false>, dim3((unsigned)(nPW + T1 * T1)), dim3(256), 0, h->stream, h->S.p, h->Lmat.p, n, p0, nPW, std::max(T1, 1), h->ywork.p,
+                                            h->ysol.p, h->okFlag.p, h->diagInv.p, gDone, 0, (unsigned long long *)nullptr);
                 }
                 if (n <= 128) hipLaunchKernelGGL(k_chol_backsub_reg<4>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p, gDone, 0);
                 else if (n <= 224) hipLaunchKernelGGL(k_chol_backsub_reg<7>, dim3(1), dim3(1024), 0, h->stream, h->Lmat.p, h->ysol.p, h->diagInv.p, n, h->xp.p, gDone, 0);
@@ -2571,13 +2646,21 @@ int optimize(Ctx &c, int iterations, double stats[4])
         hipLaunchKernelGGL(k_backsub_update, dim3(gU), dim3(256), 0, h->stream, c.d, h->ptStart.p, h->ptEdges.p, (const int *)h->ptPi.p, h->bl.p,
                            h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p, 0.0, h->partL.p, lam, gDone, 0);
         LCHECK();
-        hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p, gDone, 0);
-        LCHECK();
         const double seq = (h->seq += 1.0);
-        hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(256), 0, h->stream, st, (const double *)h->partChi.p, (int)gE, (const double *)h->partL.p, (int)gU, (const double *)h->xp.p,
-                           (const double *)h->bp.p, nP6, nP6 > 0 ? (const int *)h->okFlag.p : (const int *)nullptr, (const volatile int *)h->hostStopDev, h->hostRedDev, seq, c.d,
-                           (const DPose *)h->poseBak.p, (const double *)h->ptBak.p, h->scaleBits.p);
-        LCHECK();
+        static const bool mergeDecide = !(getenv("ORBX_LBA_MERGE_DECIDE") && getenv("ORBX_LBA_MERGE_DECIDE")[0] == '0');      // (measurement switch: the two launches of round 5)
+        if (mergeDecide) {
+            hipLaunchKernelGGL(k_errors_decide, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p, st, (const double *)h->partL.p, (int)gU, (const double *)h->xp.p,
+                               (const double *)h->bp.p, nP6, nP6 > 0 ? (const int *)h->okFlag.p : (const int *)nullptr, (const volatile int *)h->hostStopDev, h->hostRedDev, seq,
+                               (const DPose *)h->poseBak.p, (const double *)h->ptBak.p, h->scaleBits.p);
+            LCHECK();
+        } else {
+            hipLaunchKernelGGL(k_errors, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p, gDone, 0);
+            LCHECK();
+            hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(256), 0, h->stream, st, (const double *)h->partChi.p, (int)gE, (const double *)h->partL.p, (int)gU, (const double *)h->xp.p,
+                               (const double *)h->bp.p, nP6, nP6 > 0 ? (const int *)h->okFlag.p : (const int *)nullptr, (const volatile int *)h->hostStopDev, h->hostRedDev, seq, c.d,
+                               (const DPose *)h->poseBak.p, (const double *)h->ptBak.p, h->scaleBits.p);
+            LCHECK();
+        }
         // (a rejected update is taken back inside k_lm_decide); H and b at the new estimates behind an accepted trial
         int rcl = linearize();
         if (rcl) return rcl;
@@ -2765,6 +2848,8 @@ static int lba_run(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_
     for (int i = 0; i < 3 * P; i++) res->points[i] = (float)pt[i];
     return ORBX_OK;
 }
+
+extern "C" void orbx_debug_chol_step_profile(unsigned long long *dev16) { g_cholProf = dev16; }
 
 extern "C" int orbx_lba_solve(orbx_lba *h, const orbx_lba_problem *p, const volatile uint8_t *stop, orbx_lba_result *res)
 {
