@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256) void k_proj_last_topk(ProjFrameDev F, ProjLast
 __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_last_greedy(ProjFrameDev F, ProjLastDev L, const float *__restrict__ scaleFactors, float th, int bMono,
                                                                           int checkOri, const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
                                                                           int32_t *__restrict__ nmatches, int stride, uint32_t *__restrict__ decBuf,
-                                                                          uint32_t *__restrict__ queueBuf)
+                                                                          uint32_t *__restrict__ queueBuf, int32_t *__restrict__ pubAssigned, unsigned long long *pubFlag,
+                                                                          unsigned long long pubSeq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int hist[HISTO_LENGTH];
@@ -473,6 +474,12 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_last_greedy(ProjFr
     }
     __syncthreads();
     if (tid == 0) nmatches[f] = sTotal - sRemoved;
+    if (pubFlag) {
+        // the single-frame host call: assigned[0..n) and the count straight into the caller's mapped pinned buffer, the sequence word behind them
+        for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) pubAssigned[j] = aout[j];
+        if (tid == 0) pubAssigned[n] = sTotal - sRemoved;
+        orbx_publish(nullptr, pubFlag, pubSeq, 1u);
+    }
 }
 
 }  // namespace
@@ -1182,29 +1189,53 @@ extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_projection_
     if (n > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
     ORBX_HIP_CHECK(hipSetDevice(m->device));
     int rc;
-    // all thirteen input arrays through one pinned buffer and one copy
+    // no copy engine, no stream synchronisation (OrbxCallBox): all thirteen input arrays through mapped pinned memory, one pass of k_stage_copy to the
+    // device arena (the frame's arrays are read by every wave, the points' by the replay's rounds), the two kernels, results + sequence word from the replay
     hipStream_t st = m->stream;
-    OrbxHostStage &hs = m->hostStage;
+    OrbxCallBox &bx = m->box;
     const size_t N = (size_t)n, M = (size_t)mm;
-    const size_t total = hs.padded(N * sizeof(orbx_keypoint)) + hs.padded(N * 32) + hs.padded(N * 4) + hs.padded(N) + hs.padded(8) + 5 * hs.padded(M * 4) +
-                         hs.padded(M * 32) + 2 * hs.padded(M);
-    if ((rc = hs.begin(total)) != ORBX_OK) return rc;
+    const size_t total = bx.padded(N * sizeof(orbx_keypoint)) + bx.padded(N * 32) + bx.padded(N * 4) + bx.padded(N) + bx.padded(8) + 5 * bx.padded(M * 4) +
+                         bx.padded(M * 32) + 2 * bx.padded(M) + bx.padded(64 * 4);
+    if (!scale_factors || nlevels < 1 || nlevels > 64) { orbx_set_error("bad scale factor table"); return ORBX_ERR_ARG; }
+    if (!fr->keypoints_un || !fr->descriptors || !fr->u_right || !pt->proj_x || !pt->proj_y || !pt->proj_xr || !pt->scale_level || !pt->view_cos || !pt->in_view || !pt->descriptors) {
+        orbx_set_error("NULL array in the projection arguments");
+        return ORBX_ERR_ARG;
+    }
+    if ((rc = bx.begin(total, bx.padded((N + 1) * 4), st)) != ORBX_OK) return rc;
     const int32_t cnt[2] = {n, mm};
-    const orbx_keypoint *dKp = hs.put(fr->keypoints_un, N);
-    const uint8_t *dDesc = hs.put(fr->descriptors, N * 32);
-    const float *dUr = hs.put(fr->u_right, N);
-    const uint8_t *dOcc = hs.put(fr->occupied, N);
-    const int32_t *dCnt = hs.put(cnt, 2);
-    const float *dPx = hs.put(pt->proj_x, M), *dPy = hs.put(pt->proj_y, M), *dPxr = hs.put(pt->proj_xr, M), *dCos = hs.put(pt->view_cos, M);
-    const int32_t *dLvl = hs.put(pt->scale_level, M);
-    const uint8_t *dPd = hs.put(pt->descriptors, M * 32), *dIn = hs.put(pt->in_view, M), *dObs = hs.put(pt->has_observations, M);
-    if ((rc = hs.flush(st)) != ORBX_OK) return rc;
-    ProjFrameDev F = {dKp, dDesc, dUr, fr->occupied ? dOcc : nullptr, dCnt, n, fr->min_x, fr->min_y, fr->grid_width_inv, fr->grid_height_inv};
-    ProjPointsDev P = {dPx, dPy, dPxr, dLvl, dCos, dIn, pt->has_observations ? dObs : nullptr, dPd, dCnt + 1, mm};
-    if ((rc = proj_launch(m, F, P, 1, scale_factors, nlevels, th, nn_ratio)) != ORBX_OK) return rc;
-    ORBX_HIP_CHECK(hipStreamSynchronize(st));
-    ORBX_HIP_CHECK(hipMemcpy(assigned, m->matches.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    const void *bKp = bx.put(fr->keypoints_un, N), *bDesc = bx.put(fr->descriptors, N * 32), *bUr = bx.put(fr->u_right, N), *bOcc = bx.put(fr->occupied, fr->occupied ? N : 0);
+    const void *bCnt = bx.put(cnt, 2);
+    const void *bPx = bx.put(pt->proj_x, M), *bPy = bx.put(pt->proj_y, M), *bPxr = bx.put(pt->proj_xr, M), *bCos = bx.put(pt->view_cos, M), *bLvl = bx.put(pt->scale_level, M);
+    const void *bPd = bx.put(pt->descriptors, M * 32), *bIn = bx.put(pt->in_view, M), *bObs = bx.put(pt->has_observations, pt->has_observations ? M : 0);
+    const void *bSc = bx.put(scale_factors, (size_t)nlevels);
+    if ((rc = m->arena.ensure(bx.used)) != ORBX_OK) return rc;
+    uint8_t *const ar = m->arena.p;
+    auto dev = [&](const void *boxAddr) { return ar + ((const uint8_t *)boxAddr - bx.inDev); };
+    const size_t n16 = bx.used / 16;
+    hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 512)), dim3(256), 0, st, (const uint4 *)bx.inDev, (uint4 *)ar, n16);
+    MLAUNCH_CHECK();
+    const int32_t *dCnt = (const int32_t *)dev(bCnt);
+    const float *dScales = (const float *)dev(bSc);
+    ProjFrameDev F = {(const orbx_keypoint *)dev(bKp), dev(bDesc), (const float *)dev(bUr), fr->occupied ? dev(bOcc) : nullptr, dCnt, n, fr->min_x, fr->min_y, fr->grid_width_inv,
+                      fr->grid_height_inv};
+    ProjPointsDev P = {(const float *)dev(bPx), (const float *)dev(bPy), (const float *)dev(bPxr), (const int32_t *)dev(bLvl), (const float *)dev(bCos), dev(bIn),
+                       pt->has_observations ? dev(bObs) : nullptr, dev(bPd), dCnt + 1, mm};
+    if ((rc = m->topk64.ensure(M * TOPK)) != ORBX_OK || (rc = m->projDec.ensure(M)) != ORBX_OK || (rc = m->projQueue.ensure(M)) != ORBX_OK) return rc;
+    hipLaunchKernelGGL(k_proj_topk, dim3((unsigned)((mm + 3) / 4), 1u), dim3(256), 0, st, F, P, dScales, th, m->topk64.p);
+    MLAUNCH_CHECK();
+    const size_t lds = (size_t)n * 6 + 16;
+    if (lds > 160 * 1024) { orbx_set_error("feature count %d too large for the LDS tile of the projection replay", n); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int stride = m->maxFeatures;
+    const unsigned long long seq = bx.arm();
+    hipLaunchKernelGGL(k_proj_greedy, dim3(1), dim3(PROJ_GREEDY_THREADS), lds, st, F, P, dScales, th, nn_ratio, m->topk64.p, m->matches.p, m->nmatches.p, stride, m->projDec.p,
+                       m->projQueue.p, bx.outDev<int32_t>(0), bx.flagDev, seq);
+    MLAUNCH_CHECK();
+    m->lastPairs = 1; m->lastStride = stride;
+    if ((rc = bx.wait(st)) != ORBX_OK) return rc;
+    const int32_t *as = bx.outHost<int32_t>(0);
+    memcpy(assigned, as, N * 4);
+    if (nmatches) *nmatches = as[n];
     return ORBX_OK;
 }
 
@@ -1228,7 +1259,7 @@ static int proj_last_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjLa
     if ((rc = m->projDec.ensure((size_t)nframes * L.cap)) != ORBX_OK || (rc = m->projQueue.ensure((size_t)nframes * L.cap)) != ORBX_OK) return rc;
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_last_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_proj_last_greedy, dim3((unsigned)nframes), dim3(PROJ_GREEDY_THREADS), lds, m->stream, F, L, m->scales.p, th, b_mono, check_ori, m->topk64.p,
-                       m->matches.p, m->nmatches.p, stride, m->projDec.p, m->projQueue.p);
+                       m->matches.p, m->nmatches.p, stride, m->projDec.p, m->projQueue.p, (int32_t *)nullptr, (unsigned long long *)nullptr, 0ull);
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
     m->profCount++;
@@ -1264,37 +1295,52 @@ extern "C" int orbx_search_by_projection_last(orbx_matcher *m, const orbx_projec
     if (n <= 0 || nl <= 0) return ORBX_OK;
     if (n > m->maxFeatures) { orbx_set_error("%d features exceed the matcher's max_features %d", n, m->maxFeatures); return ORBX_ERR_CAPACITY; }
     ORBX_HIP_CHECK(hipSetDevice(m->device));
+    // The matcher of Tracking::TrackWithMotionModel, once per tracked frame: no copy engine, no stream synchronisation (OrbxCallBox).  Both sides go into
+    // mapped pinned memory, k_stage_copy brings them to the device arena in one pass (every wave of the candidate kernel reads the frame's features; the
+    // replay reads the last frame's flags and angles round after round), k_proj_last_topk, then k_proj_last_greedy, which writes assigned[] + the count
+    // into the mapped buffer and raises the sequence word.  (Fourteen pageable uploads, a synchronisation and two blocking downloads before.)
     int rc;
-    // staging: frame side as in orbx_search_by_projection; last side: pf[1] = pos(3) | angle(1) | tcw cur(16) | tcw last(16), pi32[1] = octave,
-    // pb[1] = descriptors(32) | valid(1) | has_obs(1)
-    if ((rc = m->pkp.ensure((size_t)n)) || (rc = m->hd[0].ensure((size_t)n * 32)) || (rc = m->pf[0].ensure((size_t)n)) || (rc = m->pb[0].ensure((size_t)n)) ||
-        (rc = m->pi32[0].ensure(2)) || (rc = m->pf[1].ensure((size_t)nl * 4 + 32)) || (rc = m->pi32[1].ensure((size_t)nl)) || (rc = m->pb[1].ensure((size_t)nl * 34)))
-        return rc;
     hipStream_t st = m->stream;
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pkp.p, fr->keypoints_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->hd[0].p, fr->descriptors, (size_t)n * 32, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pf[0].p, fr->u_right, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    if (fr->occupied) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[0].p, fr->occupied, (size_t)n, hipMemcpyHostToDevice, st));
+    OrbxCallBox &bx = m->box;
+    const size_t N = (size_t)n, NL = (size_t)nl;
+    const size_t inBytes = bx.padded(N * sizeof(orbx_keypoint)) + bx.padded(N * 32) + bx.padded(N * 4) + bx.padded(N) + bx.padded(8) + bx.padded(NL * 12) + bx.padded(NL * 4) + 2 * bx.padded(64) +
+                           bx.padded(NL * 4) + bx.padded(NL * 32) + 2 * bx.padded(NL) + bx.padded(64 * 4);
+    if (!scale_factors || nlevels < 1 || nlevels > 64) { orbx_set_error("bad scale factor table"); return ORBX_ERR_ARG; }
+    if (nl > 65535) { orbx_set_error("bad capacities (features %d, last %d)", n, nl); return ORBX_ERR_CAPACITY; }
+    if ((rc = bx.begin(inBytes, bx.padded((N + 1) * 4), st)) != ORBX_OK) return rc;
     const int32_t cnt[2] = {n, nl};
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[0].p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
-    float *pf = m->pf[1].p;
-    ORBX_HIP_CHECK(hipMemcpyAsync(pf, ls->world_pos, (size_t)nl * 12, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(pf + 3 * (size_t)nl, ls->angle, (size_t)nl * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(pf + 4 * (size_t)nl, ls->tcw_current, 64, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(pf + 4 * (size_t)nl + 16, ls->tcw_last, 64, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pi32[1].p, ls->octave, (size_t)nl * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p, ls->descriptors, (size_t)nl * 32, hipMemcpyHostToDevice, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)nl * 32, ls->valid, (size_t)nl, hipMemcpyHostToDevice, st));
-    if (ls->has_observations) ORBX_HIP_CHECK(hipMemcpyAsync(m->pb[1].p + (size_t)nl * 33, ls->has_observations, (size_t)nl, hipMemcpyHostToDevice, st));
-    ProjFrameDev F = {m->pkp.p, m->hd[0].p, m->pf[0].p, fr->occupied ? m->pb[0].p : nullptr, m->pi32[0].p, n, fr->min_x, fr->min_y, fr->grid_width_inv,
+    const void *bKp = bx.put(fr->keypoints_un, N), *bDesc = bx.put(fr->descriptors, N * 32), *bUr = bx.put(fr->u_right, N), *bOcc = bx.put(fr->occupied, fr->occupied ? N : 0);
+    const void *bCnt = bx.put(cnt, 2), *bPos = bx.put(ls->world_pos, NL * 3), *bAng = bx.put(ls->angle, NL), *bTc = bx.put(ls->tcw_current, 16), *bTl = bx.put(ls->tcw_last, 16);
+    const void *bOct = bx.put(ls->octave, NL), *bLd = bx.put(ls->descriptors, NL * 32), *bVal = bx.put(ls->valid, NL), *bObs = bx.put(ls->has_observations, ls->has_observations ? NL : 0);
+    const void *bSc = bx.put(scale_factors, (size_t)nlevels);
+    if ((rc = m->arena.ensure(bx.used)) != ORBX_OK) return rc;
+    uint8_t *const ar = m->arena.p;
+    auto dev = [&](const void *boxAddr) { return ar + ((const uint8_t *)boxAddr - bx.inDev); };
+    const size_t n16 = bx.used / 16;
+    hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 512)), dim3(256), 0, st, (const uint4 *)bx.inDev, (uint4 *)ar, n16);
+    MLAUNCH_CHECK();
+    const int32_t *dCnt = (const int32_t *)dev(bCnt);
+    const float *dScales = (const float *)dev(bSc);
+    ProjFrameDev F = {(const orbx_keypoint *)dev(bKp), dev(bDesc), (const float *)dev(bUr), fr->occupied ? dev(bOcc) : nullptr, dCnt, n, fr->min_x, fr->min_y, fr->grid_width_inv,
                       fr->grid_height_inv};
-    ProjLastDev L = {m->pb[1].p + (size_t)nl * 32, pf, m->pb[1].p, ls->has_observations ? m->pb[1].p + (size_t)nl * 33 : nullptr, m->pi32[1].p,
-                     pf + 3 * (size_t)nl, m->pi32[0].p + 1, nl, pf + 4 * (size_t)nl, pf + 4 * (size_t)nl + 16, ls->fx, ls->fy, ls->cx, ls->cy, ls->mbf, ls->mb,
-                     ls->max_x, ls->max_y};
-    if ((rc = proj_last_launch(m, F, L, 1, scale_factors, nlevels, th, b_mono, check_orientation)) != ORBX_OK) return rc;
-    ORBX_HIP_CHECK(hipStreamSynchronize(st));
-    ORBX_HIP_CHECK(hipMemcpy(assigned, m->matches.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (nmatches) ORBX_HIP_CHECK(hipMemcpy(nmatches, m->nmatches.p, 4, hipMemcpyDeviceToHost));
+    ProjLastDev L = {dev(bVal), (const float *)dev(bPos), dev(bLd), ls->has_observations ? dev(bObs) : nullptr, (const int32_t *)dev(bOct), (const float *)dev(bAng), dCnt + 1, nl,
+                     (const float *)dev(bTc), (const float *)dev(bTl), ls->fx, ls->fy, ls->cx, ls->cy, ls->mbf, ls->mb, ls->max_x, ls->max_y};
+    if ((rc = m->topk64.ensure(NL * TOPK)) != ORBX_OK || (rc = m->projDec.ensure(NL)) != ORBX_OK || (rc = m->projQueue.ensure(NL)) != ORBX_OK) return rc;
+    hipLaunchKernelGGL(k_proj_last_topk, dim3((unsigned)((nl + 3) / 4), 1u), dim3(256), 0, st, F, L, dScales, th, b_mono, m->topk64.p);
+    MLAUNCH_CHECK();
+    const size_t lds = (size_t)n * 5 + 16;
+    if (lds > 160 * 1024) { orbx_set_error("capacities too large for the LDS tile"); return ORBX_ERR_CAPACITY; }
+    if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_last_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int stride = m->maxFeatures;
+    const unsigned long long seq = bx.arm();
+    hipLaunchKernelGGL(k_proj_last_greedy, dim3(1), dim3(PROJ_GREEDY_THREADS), lds, st, F, L, dScales, th, b_mono, check_orientation, m->topk64.p, m->matches.p, m->nmatches.p, stride,
+                       m->projDec.p, m->projQueue.p, bx.outDev<int32_t>(0), bx.flagDev, seq);
+    MLAUNCH_CHECK();
+    m->lastPairs = 1; m->lastStride = stride;
+    if ((rc = bx.wait(st)) != ORBX_OK) return rc;
+    const int32_t *as = bx.outHost<int32_t>(0);
+    memcpy(assigned, as, N * 4);
+    if (nmatches) *nmatches = as[n];
     return ORBX_OK;
 }
 
@@ -1355,17 +1401,20 @@ __device__ __forceinline__ bool frustum_point(const FrustumDev &Fr, const MapPoi
 }
 
 __global__ __launch_bounds__(256) void k_is_in_frustum(FrustumDev Fr, MapPointsDev M, float *__restrict__ projX, float *__restrict__ projY, float *__restrict__ projXR,
-                                                       int32_t *__restrict__ level, float *__restrict__ viewCosOut, uint8_t *__restrict__ inView)
+                                                       int32_t *__restrict__ level, float *__restrict__ viewCosOut, uint8_t *__restrict__ inView, unsigned *pubCounter,
+                                                       unsigned long long *pubFlag, unsigned long long pubSeq)
 {
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const int m = min(M.counts[f], M.cap);
-    if (i >= m) return;
-    const size_t pi = (size_t)f * M.cap + i;
-    float u = 0, v = 0, ur = 0, vc = 0;
-    int lvl = 0;
-    const bool in = frustum_point(Fr, M, f, pi, u, v, ur, lvl, vc);
-    inView[pi] = in ? 1 : 0;
-    if (in) { projX[pi] = u; projXR[pi] = ur; projY[pi] = v; level[pi] = lvl; viewCosOut[pi] = vc; }   // :721-731
+    if (i < m) {
+        const size_t pi = (size_t)f * M.cap + i;
+        float u = 0, v = 0, ur = 0, vc = 0;
+        int lvl = 0;
+        const bool in = frustum_point(Fr, M, f, pi, u, v, ur, lvl, vc);
+        inView[pi] = in ? 1 : 0;
+        if (in) { projX[pi] = u; projXR[pi] = ur; projY[pi] = v; level[pi] = lvl; viewCosOut[pi] = vc; }   // :721-731
+    }
+    if (pubFlag) orbx_publish(pubCounter, pubFlag, pubSeq, gridDim.x * gridDim.y);      // (host-array call: the outputs are mapped host memory)
 }
 
 // Tracking::SearchLocalPoints for ONE frame from host arrays (orbx_search_local_points): the frustum test and the candidate lists in one launch.  One
@@ -1435,7 +1484,7 @@ extern "C" int orbx_is_in_frustum_device(orbx_matcher *m, const orbx_frustum_fra
     for (int k = 0; k < ORBX_MAX_LEVELS; k++) Fr.ratioTh[k] = k + 1 < frame->nlevels ? frame->ratio_thresholds[k] : 0.0f;
     MapPointsDev M = {points->world_pos, points->normal, points->max_distance, points->min_distance, points->counts, points->capacity};
     hipLaunchKernelGGL(k_is_in_frustum, dim3((unsigned)((points->capacity + 255) / 256), (unsigned)frame->nframes), dim3(256), 0, m->stream, Fr, M, m->frProj.p,
-                       m->frProj.p + n, m->frProj.p + 2 * n, m->frLevel.p, m->frProj.p + 3 * n, m->frInView.p);
+                       m->frProj.p + n, m->frProj.p + 2 * n, m->frLevel.p, m->frProj.p + 3 * n, m->frInView.p, (unsigned *)nullptr, (unsigned long long *)nullptr, 0ull);
     MLAUNCH_CHECK();
     m->frCount = n;
     return ORBX_OK;
@@ -1465,38 +1514,46 @@ extern "C" int orbx_is_in_frustum(orbx_matcher *m, const orbx_frustum_frame *fra
     if (mm <= 0) return ORBX_OK;
     ORBX_HIP_CHECK(hipSetDevice(m->device));
     int rc;
-    // inputs through the pinned staging buffer and one copy; the results come back into the same pinned buffer
-    // (three copies that need no bounce buffer) and are handed out from there
+    // no copy engine, no stream synchronisation (OrbxCallBox): every input is read once, where it lies in mapped pinned memory; the kernel writes the
+    // mTrack* values into mapped pinned memory and its last workgroup raises the sequence word
+    if (!frame_host->tcw || !frame_host->ratio_thresholds || !points_host->world_pos || !points_host->normal || !points_host->max_distance || !points_host->min_distance) {
+        orbx_set_error("NULL array in the frustum arguments");
+        return ORBX_ERR_ARG;
+    }
+    if (frame_host->nlevels < 1 || frame_host->nlevels > ORBX_MAX_LEVELS) { orbx_set_error("bad frustum sizes"); return ORBX_ERR_CAPACITY; }
     hipStream_t st = m->stream;
-    OrbxHostStage &hs = m->hostStage;
+    OrbxCallBox &bx = m->box;
     const size_t n = (size_t)mm;
-    const size_t inBytes = hs.padded(64) + 2 * hs.padded(n * 12) + 2 * hs.padded(n * 4) + hs.padded(4), outBytes = hs.padded(n * 16) + hs.padded(n * 4) + hs.padded(n);
-    ORBX_HIP_CHECK(hipStreamSynchronize(st));
-    if ((rc = hs.begin(inBytes > outBytes ? inBytes : outBytes)) != ORBX_OK) return rc;
+    const size_t inBytes = bx.padded(64) + 2 * bx.padded(n * 12) + 2 * bx.padded(n * 4) + bx.padded(4);
+    const size_t oY = bx.padded(n * 4), oXr = 2 * oY, oVc = 3 * oY, oL = 4 * oY, oIn = oL + bx.padded(n * 4), outBytes = oIn + bx.padded(n);
+    if ((rc = bx.begin(inBytes, outBytes, st)) != ORBX_OK) return rc;
     const int32_t cnt = mm;
-    orbx_frustum_frame fd = *frame_host;
-    fd.tcw = hs.put(frame_host->tcw, 16); fd.nframes = 1;
-    orbx_map_points pd;
-    pd.world_pos = hs.put(points_host->world_pos, n * 3);
-    pd.normal = hs.put(points_host->normal, n * 3);
-    pd.max_distance = hs.put(points_host->max_distance, n);
-    pd.min_distance = hs.put(points_host->min_distance, n);
-    pd.counts = hs.put(&cnt, 1);
-    pd.capacity = mm;
-    if ((rc = hs.flush(st)) != ORBX_OK) return rc;
-    if ((rc = orbx_is_in_frustum_device(m, &fd, &pd, viewing_cos_limit)) != ORBX_OK) return rc;
-    uint8_t *hp = hs.host, *hl = hp + hs.padded(n * 16), *hv = hl + hs.padded(n * 4);
-    ORBX_HIP_CHECK(hipMemcpyAsync(hp, m->frProj.p, n * 16, hipMemcpyDeviceToHost, st));     // stream order: after the kernel, which has consumed the inputs
-    ORBX_HIP_CHECK(hipMemcpyAsync(hl, m->frLevel.p, n * 4, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_CHECK(hipMemcpyAsync(hv, m->frInView.p, n, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_CHECK(hipStreamSynchronize(st));
-    const float *pp = (const float *)hp;
-    if (proj_x) memcpy(proj_x, pp, n * 4);
-    if (proj_y) memcpy(proj_y, pp + n, n * 4);
-    if (proj_xr) memcpy(proj_xr, pp + 2 * n, n * 4);
-    if (view_cos) memcpy(view_cos, pp + 3 * n, n * 4);
-    if (scale_level) memcpy(scale_level, hl, n * 4);
-    memcpy(in_view, hv, n);
+    FrustumDev Fr;
+    Fr.tcw = bx.put(frame_host->tcw, 16);
+    Fr.fx = frame_host->fx; Fr.fy = frame_host->fy; Fr.cx = frame_host->cx; Fr.cy = frame_host->cy; Fr.mbf = frame_host->mbf;
+    Fr.minX = frame_host->min_x; Fr.maxX = frame_host->max_x; Fr.minY = frame_host->min_y; Fr.maxY = frame_host->max_y; Fr.cosLimit = viewing_cos_limit; Fr.nlevels = frame_host->nlevels;
+    for (int k = 0; k < ORBX_MAX_LEVELS; k++) Fr.ratioTh[k] = k + 1 < frame_host->nlevels ? frame_host->ratio_thresholds[k] : 0.0f;
+    MapPointsDev M;
+    M.pos = bx.put(points_host->world_pos, n * 3); M.normal = bx.put(points_host->normal, n * 3);
+    M.maxDist = bx.put(points_host->max_distance, n); M.minDist = bx.put(points_host->min_distance, n);
+    M.counts = bx.put(&cnt, 1); M.cap = mm;
+    const unsigned long long seq = bx.arm();
+    hipLaunchKernelGGL(k_is_in_frustum, dim3((unsigned)((mm + 255) / 256), 1u), dim3(256), 0, st, Fr, M, bx.outDev<float>(0), bx.outDev<float>(oY), bx.outDev<float>(oXr), bx.outDev<int32_t>(oL),
+                       bx.outDev<float>(oVc), bx.outDev<uint8_t>(oIn), bx.counter, bx.flagDev, seq);
+    MLAUNCH_CHECK();
+    if ((rc = bx.wait(st)) != ORBX_OK) return rc;
+    memcpy(in_view, bx.outHost<uint8_t>(oIn), n);
+    // (the mTrack* values of a point that is not in view are not written by the kernel: the caller's arrays keep what they held, as the reference's members do)
+    const float *hx = bx.outHost<float>(0), *hy = bx.outHost<float>(oY), *hxr = bx.outHost<float>(oXr), *hvc = bx.outHost<float>(oVc);
+    const int32_t *hl = bx.outHost<int32_t>(oL);
+    for (int k = 0; k < mm; k++)
+        if (in_view[k]) {
+            if (proj_x) proj_x[k] = hx[k];
+            if (proj_y) proj_y[k] = hy[k];
+            if (proj_xr) proj_xr[k] = hxr[k];
+            if (view_cos) view_cos[k] = hvc[k];
+            if (scale_level) scale_level[k] = hl[k];
+        }
     return ORBX_OK;
 }
 
