@@ -338,6 +338,23 @@ int build_geometry(orbx_extractor *h, int W, int H)
     // window rows: the widest window (aw + 6 rounded up to 16) and the widest pre-test read (16 * segments + 8); score rows: aw + 6
     g.fcPitch = maxWCell <= 32 ? 48 : maxWCell <= 48 ? 64 : 80;
     g.fcScPitch = maxWCell <= 42 ? 48 : 80;
+    {
+        // The kernel is instantiated on (window pitch, score pitch) = (48, 48), (64, 48), (80, 48) or (80, 80).  A score row of pitch SP holds the area's
+        // columns -1 .. aw (a zero ring), so SP = 48 needs aw + 2 <= 48 for EVERY cell - not "wCell <= 42": wide cells exist whose area is narrower (a level of
+        // one column of cells).  The widest area of this geometry decides (round-5 advice: (64, 80) used to run the SP = 48 instantiation on the strength
+        // of that unstated fact).
+        int maxAw = 1;
+        for (int l = 0; l < nl; l++) {
+            const OrbxLevel &lv = g.lv[l];
+            const int maxBX = lv.w - ORBX_BORDER;
+            for (int cj = 0; cj < lv.nCols; cj++) {
+                const int iniX = ORBX_BORDER + cj * lv.wCell, maxX = std::min(iniX + lv.wCell + 6, maxBX);
+                maxAw = std::max(maxAw, (maxX - 3) - (iniX + 3));
+            }
+        }
+        g.fcScPitch = maxAw + 2 <= 48 ? 48 : 80;
+        if (g.fcScPitch == 80) g.fcPitch = 80;      // (there is no (48 | 64, 80) instantiation)
+    }
     { const char *pe = getenv("ORBX_FC_PITCH"); if (pe && atoi(pe) == 80 && g.fcPitch == 64) g.fcPitch = 80; }      // (developer knob)
     {
         const int units = (maxHCell + 6) * ((maxWCell + 6 + 15) / 16), ns = (units + 63) / 64;      // 16-byte window units per lane

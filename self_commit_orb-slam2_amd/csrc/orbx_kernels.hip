@@ -47,6 +47,9 @@ constexpr OdTables make_od_tables()
 __constant__ OdTables c_od = make_od_tables();
 
 // FAST-16 circle, OpenCV order (reference call sites src/ORBextractor.cc:1126,1135)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "orbx_kernels.hip uses gfx9 DPP row_bcast controls and v_min3_u32 / v_max3_u32 inline assembly: build for gfx950 (--offload-arch=gfx950)"
+#endif
 #define FAST_DX(k) ((k) == 0 ? 0 : (k) == 1 ? 1 : (k) == 2 ? 2 : (k) <= 5 ? 3 : (k) == 6 ? 2 : (k) == 7 ? 1 : (k) == 8 ? 0 : (k) == 9 ? -1 : (k) == 10 ? -2 : (k) <= 13 ? -3 : (k) == 14 ? -2 : -1)
 #define FAST_DY(k) ((k) <= 1 ? 3 : (k) == 2 ? 2 : (k) == 3 ? 1 : (k) == 4 ? 0 : (k) == 5 ? -1 : (k) == 6 ? -2 : (k) <= 9 ? -3 : (k) == 10 ? -2 : (k) == 11 ? -1 : (k) == 12 ? 0 : (k) == 13 ? 1 : (k) == 14 ? 2 : 3)
 
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256) void k_pyramid_tiles(const OrbxGeom *__restric
 //   C  strict 3x3 maximum inside the cell (zero ring = "not a corner of this sub-image"),
 //      iniThFAST survivors or - when the cell has none - all of them (:1132), ordered __ballot
 //      compaction into the cell's slot.
-// VALU bound (profiles/): ~1.05k wave-instructions per cell.
+// VALU bound: ~570 wave-instructions per cell (119.0 M per launch of 208,640 cells: profiles/r05_fast_phases.txt, r05_valu_issue.txt; 1.05k in round 3).
 // ------------------------------------------------------------------------------------
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
@@ -1654,9 +1657,11 @@ int orbx_launch_fast_cells(const OrbxLaunch &L)
     if (g_fcProf) return emit(L, k_fast_cells<PP, SS, NN, true, false>, grid, dim3(64), ldsBytes, FC_ARGS, g_fcProf); \
     return emit(L, k_fast_cells<PP, SS, NN, false, false>, grid, dim3(64), ldsBytes, FC_ARGS, (unsigned long long *)nullptr); } while (0)
 #define FC_LAUNCH_P(PP, SS) switch (g.fcNS) { case 2: FC_LAUNCH(PP, SS, 2); case 3: FC_LAUNCH(PP, SS, 3); case 4: FC_LAUNCH(PP, SS, 4); default: FC_LAUNCH(PP, SS, 6); }
-    if (g.fcPitch == 48) FC_LAUNCH_P(48, 48)
-    if (g.fcPitch == 64) FC_LAUNCH_P(64, 48)
-    if (g.fcScPitch == 48) FC_LAUNCH_P(80, 48)
+    // (build_geometry guarantees: score pitch 80 only with window pitch 80, and score pitch 48 only when every area is at most 46 wide)
+    if (g.fcPitch == 48 && g.fcScPitch == 48) FC_LAUNCH_P(48, 48)
+    if (g.fcPitch == 64 && g.fcScPitch == 48) FC_LAUNCH_P(64, 48)
+    if (g.fcPitch == 80 && g.fcScPitch == 48) FC_LAUNCH_P(80, 48)
+    if (g.fcPitch != 80 || g.fcScPitch != 80) { orbx_set_error("detector LDS pitches %d / %d have no kernel instantiation", g.fcPitch, g.fcScPitch); return ORBX_ERR_STATE; }
     FC_LAUNCH_P(80, 80)
 #undef FC_LAUNCH_P
 #undef FC_LAUNCH

@@ -1424,9 +1424,12 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
 
 // The panel step: nothing goes through synchronised column steps (a version with the 32x32 block in LDS and two workgroup barriers
 // per column took 31 us per panel; a wave factoring the block in registers with one v_readlane pair per multiply-add and a second wave
-// eliminating the rows afterwards 17; the blocked one-wave elimination inside k_chol_step below 7.9 of the 12.6 us a panel launch takes
-// - s_memrealtime, round 3: staging 1.3, MFMA update 1.5, elimination 7.85, store 1.1; the panel rows' share of the elimination is 1-2 us,
-// the rest is the diagonal block's chain of 8 x (4 pivots, exchange through LDS, rank-4 update)).
+// eliminating the rows afterwards 17; the blocked one-wave elimination with the panel rows inside it 7.9, with the rows on a wave of their own 5).
+// Where a launch's ~9 us go now (tools/chol_phases.py, s_memtime on the first panel workgroup, profiles/r06_chol_phases.txt, 21.5k cycles between
+// the first and the last stamp): staging 3.6k (17 %), the previous panel's update on the matrix cores 3.0k (14 %), the diagonal block 12.4k (57 %),
+// waiting for the panel rows' wave 0.1k, stores 2.4k (11 %).  Inside the diagonal block, per block of four pivots: the pivot chain ~645 cycles
+// (~160 per pivot: readlanes, v_rsq_f64 + Newton, the 4 x 4 part), own entries + publishing the four columns through LDS ~570, the rank-4 update of
+// the rest ~250 - the 32-pivot chain itself is 2.2 us of a 72-launch, 0.7 ms share of the window.
 // 1 / sqrt(x) for the pivots: v_rsq_f64 (~26 bits) + one Newton step y += y/2 (1 - x y^2), instead of the library routine: every
 // dependent FP64 operation on the pivot chain costs ~16 cycles, and the factor is not part of the bit-level contract (1e-5 vs g2o)
 __device__ __forceinline__ double pivot_rsqrt(double x)
