@@ -1626,14 +1626,16 @@ int orbx_launch_pyramid_tiles(const OrbxLaunch &L)
 int orbx_launch_comb_upload(const OrbxLaunch &L, uint8_t *stagingDev)
 {
     const size_t units = L.img0FramePitch >> 4;
-    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((units + 1023) / 1024, 1), 256);      // four 16-byte units per thread
+    // one 16-byte unit per thread (four until round 6: 19 workgroups per 640x480 frame kept too few reads in flight across PCIe - 17 us for 307 KB)
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((units + 255) / 256, 1), 256);
     return emit(L, k_comb_upload, dim3(blocks, (unsigned)L.batch), dim3(256), 0, L.combTab, stagingDev, L.img0FramePitch);
 }
 
 int orbx_launch_comb_finish(const OrbxLaunch &L)
 {
     const size_t units = (L.geom->pyrBytes + L.img0FramePitch) >> 4;
-    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((units + 511) / 512, 1), 256);
+    // (every workgroup ends with an agent-scope release - a write-back of its XCD's L2 - before it counts itself in: few, fat workgroups)
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((units + 2047) / 2048, 1), 64);
     return emit(L, k_comb_finish, dim3(blocks, (unsigned)L.batch), dim3(256), 0, L.combTab, L.outCnt, L.outStatus, L.outKp, L.outDesc, L.geom->outCap, L.pyr, L.geom->pyrBytes, L.img0,
                 L.img0FramePitch, L.combKpOff, L.combDescOff, 0, L.combSync, L.combFlag);      // (the host pyramid copy rides in the quadtree's launch)
 }

@@ -588,29 +588,22 @@ __device__ __forceinline__ void lm_mirror(const LmState *st, double *host, doubl
 }
 
 // start of optimize(maxIters): chi2 of the start (k_errors' partial sums, in block order), computeLambdaInit (:166-180: tau = 1e-5 times
-// the largest diagonal entry of H), counters cleared
-__global__ __launch_bounds__(256) void k_lm_begin(LmState *st, const double *partChi, int nChi, const double *Hpp, int nPose, const double *Hll, int nPt, int maxIters,
-                                                  const volatile int *stopHost, double *host, double seq, unsigned long long *scaleBits)
+// the largest diagonal entry, from k_diag_max), counters cleared
+__global__ __launch_bounds__(256) void k_lm_begin(LmState *st, const double *partChi, int nChi, const double *diagMax, int maxIters, const volatile int *stopHost, double *host,
+                                                  double seq, unsigned long long *scaleBits)
 {
-    __shared__ double sw[4], sm[4];
+    // (measured and not kept, round 6: the maximum of k_diag_max computed here, by these 256 threads - 21.5 us instead of 4.5 + 7.2 for the two launches)
+    __shared__ double sw[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 6) scaleBits[tid] = 0ull;      // (the maxima of the Schur scale: raised by the next k_schur_setup)
     double v0 = 0;
     for (int i = tid; i < nChi; i += 256) v0 += partChi[i];
     v0 = wave_sum(v0);
-    // computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180): max |diagonal entry| over the pose and landmark blocks (a launch of its own,
-    // k_diag_max, until round 6: a maximum does not care who computes it)
-    double b = 0;
-    for (int i = tid; i < 6 * nPose; i += 256) b = fmax(b, fabs(Hpp[(size_t)(i / 6) * 36 + 7 * (i % 6)]));
-    for (int i = tid; i < 3 * nPt; i += 256) b = fmax(b, fabs(Hll[(size_t)(i / 3) * 9 + 4 * (i % 3)]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) b = fmax(b, __shfl_xor(b, o));
-    if (lane == 0) { sw[wave] = v0; sm[wave] = b; }
+    if (lane == 0) sw[wave] = v0;
     __syncthreads();
     if (tid == 0) {
         const double chi = sw[0] + sw[1] + sw[2] + sw[3];
-        const double diagMax = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
-        st->lambda = 1e-5 * diagMax; st->ni = 2; st->currentChi = chi; st->iniChi = chi; st->chi0 = chi; st->tempChi = chi; st->rho = 0;
+        st->lambda = 1e-5 * diagMax[2]; st->ni = 2; st->currentChi = chi; st->iniChi = chi; st->chi0 = chi; st->tempChi = chi; st->rho = 0;
         st->it = 0; st->qmax = 0; st->nBad = 0; st->ok = 1; st->lastRejected = 0; st->relin = 0; st->trials = 0; st->iters = 0; st->maxIters = maxIters; st->arrive = 0;
         st->done = (maxIters <= 0 || (stopHost && *stopHost)) ? 1 : 0;
         lm_mirror(st, host, seq, 0.0, 0.0, 1.0);
@@ -963,6 +956,19 @@ __global__ __launch_bounds__(256) void k_restore(LbaDev d, const DPose *poseBak,
     if (g < 3 * d.P) d.pt[g] = ptBak[g];
 }
 
+// computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180): out[2] = max |diagonal entry| over the pose and landmark blocks
+__global__ __launch_bounds__(1024) void k_diag_max(const double *Hpp, int nPose, const double *Hll, int nPt, double *out)
+{
+    __shared__ double m[1024];
+    double b = 0;
+    for (int i = threadIdx.x; i < 6 * nPose; i += 1024) b = fmax(b, fabs(Hpp[(size_t)(i / 6) * 36 + 7 * (i % 6)]));
+    for (int i = threadIdx.x; i < 3 * nPt; i += 1024) b = fmax(b, fabs(Hll[(size_t)(i / 3) * 9 + 4 * (i % 3)]));
+    m[threadIdx.x] = b;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) { if ((int)threadIdx.x < k) m[threadIdx.x] = fmax(m[threadIdx.x], m[threadIdx.x + k]); __syncthreads(); }
+    if (threadIdx.x == 0) out[2] = m[0];
+}
+
 // S = blockdiag(Hpp) + lambda*I ; bs = bp   (setLambda + "_Hpp->add(_Hschur)", block_solver.hpp:363-365, 564-589)
 // e->chi2() from the stored _error and isDepthPositive() from the CURRENT estimates (src/Optimizer.cc:880-958): flag = outlier
 // poseOut / ptOut (final call): the estimates copied next to the flags, so that ONE device-to-host copy brings everything back
@@ -1058,7 +1064,7 @@ __device__ __forceinline__ int schur_q(unsigned long long bits)
     return (e + 2) >> 1;      // = ceil((e + 1) / 2): 2^(2q) >= 2^(e + 1) > h
 }
 
-// The ordered add of the keyframe partial sums (= k_sum_poses_fin, which the start of a stage still launches on its own: k_lm_begin reads Hpp's diagonal)
+// The ordered add of the keyframe partial sums (= k_sum_poses_fin, which the start of a stage still launches on its own for k_diag_max)
 // as the first workgroups of k_schur_setup: Hpp / b_p of every free pose from the SP_SPLIT partial results, and the scale maxima.
 __device__ __forceinline__ void schur_poses_part(int block, const LbaDev &d, const double *__restrict__ part, int spSplit, double *__restrict__ Hpp, double *__restrict__ bp,
                                                  unsigned long long *scaleBits)
@@ -2563,9 +2569,10 @@ int optimize(Ctx &c, int iterations, double stats[4])
             hipLaunchKernelGGL(k_sum_poses, dim3((unsigned)K, (unsigned)c.spSplit), dim3(256), 0, h->stream, c.d, h->kfStart.p, h->kfEdges.p, h->spPart.p, c.spSplit, (const int *)nullptr, 0);
         }
         hipLaunchKernelGGL(k_sum_poses_fin, dim3((unsigned)((32 * K + 255) / 256)), dim3(256), 0, h->stream, c.d, (const double *)h->spPart.p, h->Hpp.p, h->bp.p, c.spSplit, (const int *)nullptr, 0);
+        hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(1024), 0, h->stream, h->Hpp.p, nPose, h->Hll.p, nPt, h->red.p);
         const double seq = (h->seq += 1.0);
-        hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(256), 0, h->stream, st, (const double *)h->partChi.p, (int)gE, (const double *)h->Hpp.p, nPose, (const double *)h->Hll.p, nPt, iterations,
-                           (const volatile int *)h->hostStopDev, h->hostRedDev, seq, h->scaleBits.p);
+        hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(256), 0, h->stream, st, (const double *)h->partChi.p, (int)gE, (const double *)h->red.p, iterations, (const volatile int *)h->hostStopDev,
+                           h->hostRedDev, seq, h->scaleBits.p);
         LCHECK();
     }
     // ---- one Levenberg trial in two halves
@@ -2650,7 +2657,9 @@ int optimize(Ctx &c, int iterations, double stats[4])
                            h->Dinv.p, h->xp.p, h->xl.p, h->poseBak.p, h->ptBak.p, 0.0, h->partL.p, lam, gDone, 0);
         LCHECK();
         const double seq = (h->seq += 1.0);
-        static const bool mergeDecide = !(getenv("ORBX_LBA_MERGE_DECIDE") && getenv("ORBX_LBA_MERGE_DECIDE")[0] == '0');      // (measurement switch: the two launches of round 5)
+        // ORBX_LBA_MERGE_DECIDE=1 (measured, round 6: profiles/r06_lba_merge_decide.txt): one launch instead of two, nine launches less per window - and 14.7 us per
+        // trial instead of 4.9 + 6.4 + a kernel boundary: the last arriver's fences cost what the boundary did.  Not the default.
+        static const bool mergeDecide = getenv("ORBX_LBA_MERGE_DECIDE") && getenv("ORBX_LBA_MERGE_DECIDE")[0] == '1';
         if (mergeDecide) {
             hipLaunchKernelGGL(k_errors_decide, dim3(gE), dim3(256), 0, h->stream, c.d, c.hub, c.robust, h->partChi.p, st, (const double *)h->partL.p, (int)gU, (const double *)h->xp.p,
                                (const double *)h->bp.p, nP6, nP6 > 0 ? (const int *)h->okFlag.p : (const int *)nullptr, (const volatile int *)h->hostStopDev, h->hostRedDev, seq,
