@@ -185,6 +185,38 @@ __device__ inline void pose_oplus(DPose &T, const double d[6])
     T = N;
 }
 
+// The same update for k_pose_opt, where it sits on a ONE-THREAD section of every Levenberg trial (1460 cycles of a 7100-cycle trial: sqrt, sincos, a
+// reciprocal, R, Quaternion(R) with its sqrt and reciprocal, two normalisations - a chain of ~110 dependent FP64 operations).  For |omega|^2 < 0.25 the
+// five functions of theta^2 the update needs - sin(t/2)/t, cos(t/2), sin t / t, (1 - cos t) / t^2, (t - sin t) / t^3 - are their Taylor polynomials (seven
+// terms: below 1e-17 relative), evaluated side by side, and the rotation's quaternion is (cos(t/2), omega sin(t/2)/t) directly: mathematically the
+// Quaternion(R) of se3quat.h:223-255, rounded differently in the last bits (the estimates are not part of the bit-level contract: 1e-5 vs g2o).  Larger
+// steps take pose_oplus.
+__device__ inline void pose_oplus_small(DPose &T, const double d[6])
+{
+    const double *om = d, *up = d + 3;
+    const double x = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    if (!(x < 0.25)) { pose_oplus(T, d); return; }
+    // Horner in x = theta^2; coefficients = 1 / (2^(2k+1) (2k+1)!), 1 / (4^k (2k)!), 1 / (2k+1)!, 1 / (2k+2)!, 1 / (2k+3)!  with alternating signs
+    const double sh = 0.5 + x * (-1.0 / 48 + x * (1.0 / 3840 + x * (-1.0 / 645120 + x * (1.0 / 185794560 + x * (-1.0 / 81749606400.0 + x * (1.0 / 51011754393600.0))))));
+    const double ch = 1.0 + x * (-1.0 / 8 + x * (1.0 / 384 + x * (-1.0 / 46080 + x * (1.0 / 10321920 + x * (-1.0 / 3715891200.0 + x * (1.0 / 1961990553600.0))))));
+    const double b = 0.5 + x * (-1.0 / 24 + x * (1.0 / 720 + x * (-1.0 / 40320 + x * (1.0 / 3628800 + x * (-1.0 / 479001600.0 + x * (1.0 / 87178291200.0))))));
+    const double c = 1.0 / 6 + x * (-1.0 / 120 + x * (1.0 / 5040 + x * (-1.0 / 362880 + x * (1.0 / 39916800 + x * (-1.0 / 6227020800.0 + x * (1.0 / 1307674368000.0))))));
+    DPose E;
+    E.q.x = om[0] * sh; E.q.y = om[1] * sh; E.q.z = om[2] * sh; E.q.w = ch;
+    quat_normalize_pos(E.q);
+    // t = V u, V = I + b Omega + c Omega^2: Omega u = om x u, Omega^2 u = om x (om x u)
+    const double c1[3] = {om[1] * up[2] - om[2] * up[1], om[2] * up[0] - om[0] * up[2], om[0] * up[1] - om[1] * up[0]};
+    const double c2[3] = {om[1] * c1[2] - om[2] * c1[1], om[2] * c1[0] - om[0] * c1[2], om[0] * c1[1] - om[1] * c1[0]};
+    for (int i = 0; i < 3; i++) E.t[i] = up[i] + b * c1[i] + c * c2[i];
+    double rt[3];
+    quat_rot(E.q, T.t, rt);
+    DPose N;
+    for (int i = 0; i < 3; i++) N.t[i] = E.t[i] + rt[i];
+    N.q = quat_mul(E.q, T.q);
+    quat_normalize_pos(N.q);
+    T = N;
+}
+
 struct LbaDev {   // device views, all sized by the handle
     int K, P, E;
     DPose *pose;
@@ -2245,7 +2277,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     }
                     sOk = ok ? 1 : 0;
                     if (PROF) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[5] += t_ - tPrev; pcnt[5] += 1; tPrev = t_; }      // 6x6 LDL^T solve (one thread)
-                    pose_oplus(pose, sx);   // g2o applies the (possibly stale) x even when the solve failed; pop() restores
+                    pose_oplus_small(pose, sx);   // g2o applies the (possibly stale) x even when the solve failed; pop() restores
                     if (PROF) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[6] += t_ - tPrev; pcnt[6] += 1; tPrev = t_; }      // oplus (one thread)
                 }
                 __syncthreads();
