@@ -854,6 +854,9 @@ class Vocabulary:
         _check(L.orbx_vocabulary_create(device, int(voc["k"]), int(voc["L"]), len(par), _ptr(par), _ptr(leaf), _ptr(desc), _ptr(wt), ctypes.byref(self._h)))
 
     def close(self):
+        if getattr(self, "_job", None) is not None and self._job.value:      # (a job only reads the vocabulary and must go first)
+            self._L.orbx_bow_job_destroy(self._job)
+            self._job = None
         if getattr(self, "_h", None):
             self._L.orbx_vocabulary_destroy(self._h)
             self._h = None
@@ -874,6 +877,40 @@ class Vocabulary:
         w, nd, wt = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
         _check(self._L.orbx_bow_transform(self._h, _ptr(d), n, levelsup, _ptr(w), _ptr(nd), _ptr(wt)))
         return w[:n], nd[:n], wt[:n]
+
+    def transform_sorted(self, descriptors, levelsup=4):
+        """transform() plus the two orders of its std::map fills: (word, node, weight, by_word, by_node) - by_word[k] / by_node[k] = the feature that is
+        k-th by (word id, index) / (node id, index) among the filed features (orbx_bow_transform_sorted)."""
+        d = np.ascontiguousarray(descriptors, np.uint8)
+        n = len(d)
+        w, nd, wt = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+        bw, bn = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        filed = ctypes.c_int32()
+        self._L.orbx_bow_transform_sorted.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
+        _check(self._L.orbx_bow_transform_sorted(self._h, _ptr(d), n, levelsup, _ptr(w), _ptr(nd), _ptr(wt), _ptr(bw), _ptr(bn), ctypes.byref(filed)))
+        return w[:n], nd[:n], wt[:n], bw[:filed.value], bn[:filed.value]
+
+    def job_transform(self, extractor, levelsup=4):
+        """The latency form (orbx_bow_job_begin / _end) on the features `extractor`'s last single-frame call left on the device: same five arrays."""
+        L = self._L
+        vp = ctypes.c_void_p
+        L.orbx_bow_job_create.argtypes = [vp, ctypes.POINTER(vp)]
+        L.orbx_bow_job_destroy.argtypes = [vp]
+        L.orbx_bow_job_destroy.restype = None
+        L.orbx_bow_job_begin.argtypes = [vp, vp, ctypes.c_int]
+        L.orbx_bow_job_end.argtypes = [vp] + [ctypes.POINTER(vp)] * 5 + [ctypes.POINTER(ctypes.c_int32)] * 2
+        if getattr(self, "_job", None) is None:
+            self._job = vp()
+            _check(L.orbx_bow_job_create(self._h, ctypes.byref(self._job)))
+        _check(L.orbx_bow_job_begin(self._job, extractor._h, levelsup))
+        ptrs = [vp() for _ in range(5)]
+        filed, n = ctypes.c_int32(), ctypes.c_int32()
+        _check(L.orbx_bow_job_end(self._job, *[ctypes.byref(q) for q in ptrs], ctypes.byref(filed), ctypes.byref(n)))
+        if n.value == 0:
+            return tuple(np.zeros(0, t) for t in (np.int32, np.int32, np.float64, np.int32, np.int32))
+        view = lambda q, t, k: np.ctypeslib.as_array(ctypes.cast(q, ctypes.POINTER(t)), (k,)).copy()
+        return (view(ptrs[0], ctypes.c_int32, n.value), view(ptrs[1], ctypes.c_int32, n.value), view(ptrs[2], ctypes.c_double, n.value),
+                view(ptrs[3], ctypes.c_int32, filed.value), view(ptrs[4], ctypes.c_int32, filed.value))
 
     def transform_device(self, extractor, levelsup=4):
         _check(self._L.orbx_bow_transform_device(self._h, extractor._h, levelsup))
