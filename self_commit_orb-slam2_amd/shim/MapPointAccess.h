@@ -9,8 +9,11 @@
 #ifndef ORBX_SHIM_MAP_POINT_ACCESS_H
 #define ORBX_SHIM_MAP_POINT_ACCESS_H
 
+#include <map>
 #include <mutex>
 #include <string.h>
+#include <utility>
+#include <vector>
 
 #include "MapPoint.h"
 
@@ -47,6 +50,14 @@ struct MapPointAccess : public MapPoint {
         if (q->mbBad) return true;
         q->mnVisible += 1;
         return false;
+    }
+    // GetObservations() without the std::map copy (a node allocation per observer and point): the observers in the map's order, into a vector the caller reuses
+    static void Observations(MapPoint *p, std::vector<std::pair<KeyFrame *, size_t> > &out)
+    {
+        MapPointAccess *q = static_cast<MapPointAccess *>(p);
+        out.clear();
+        std::unique_lock<std::mutex> lock(q->mMutexFeatures);
+        for (std::map<KeyFrame *, size_t>::const_iterator it = q->mObservations.begin(); it != q->mObservations.end(); ++it) out.push_back(*it);
     }
     // isBad() and Observations() > 0 in one visit: 0 = bad, 1 = good without observations, 2 = good with
     static int GoodAndObserved(MapPoint *p)

@@ -88,9 +88,10 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
         }
     }
     std::list<KeyFrame *> lFixedCameras;
+    std::vector<std::pair<KeyFrame *, size_t> > observations;      // (GetObservations() copies a std::map per point: the observers in the same order, into one reused vector)
     for (std::list<MapPoint *>::iterator lit = lLocalMapPoints.begin(); lit != lLocalMapPoints.end(); lit++) {
-        std::map<KeyFrame *, size_t> observations = (*lit)->GetObservations();
-        for (std::map<KeyFrame *, size_t>::iterator mit = observations.begin(); mit != observations.end(); mit++) {
+        MapPointAccess::Observations(*lit, observations);
+        for (std::vector<std::pair<KeyFrame *, size_t> >::iterator mit = observations.begin(); mit != observations.end(); mit++) {
             KeyFrame *pKFi = mit->first;
             if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
                 pKFi->mnBAFixedForKF = pKF->mnId;
@@ -121,10 +122,9 @@ void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap
     std::vector<int32_t> ep, ek;
     std::vector<std::pair<KeyFrame *, MapPoint *> > edgeOwner;
     for (size_t l = 0; l < mps.size(); l++) {
-        const cv::Mat X = mps[l]->GetWorldPos();
-        for (int i = 0; i < 3; i++) points[3 * l + i] = X.at<float>(i);
-        const std::map<KeyFrame *, size_t> observations = mps[l]->GetObservations();
-        for (std::map<KeyFrame *, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); mit++) {
+        MapPointAccess::WorldPos(mps[l], &points[3 * l]);
+        MapPointAccess::Observations(mps[l], observations);
+        for (std::vector<std::pair<KeyFrame *, size_t> >::const_iterator mit = observations.begin(); mit != observations.end(); mit++) {
             KeyFrame *pKFi = mit->first;
             if (pKFi->isBad()) continue;                                                        // :783
             const std::map<KeyFrame *, int>::const_iterator kit = kfIndex.find(pKFi);
