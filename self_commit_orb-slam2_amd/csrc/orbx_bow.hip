@@ -285,6 +285,7 @@ extern "C" int orbx_bow_transform_sorted(orbx_vocabulary *v, const uint8_t *desc
 // ---- the latency form (include/orbx.h: orbx_bow_job_*) ----
 struct orbx_bow_job {
     orbx_vocabulary *v = nullptr;
+    int device = 0;                 // (its own copy: a job may be destroyed after its vocabulary - the shim does, when a vocabulary object was replaced at the same address)
     hipStream_t stream = nullptr;
     OrbxCallBox box;
     OrbxDevBuf<int32_t> word, node;
@@ -298,7 +299,7 @@ extern "C" int orbx_bow_job_create(orbx_vocabulary *v, orbx_bow_job **out)
     *out = nullptr;
     ORBX_HIP_CHECK(hipSetDevice(v->device));
     orbx_bow_job *j = new orbx_bow_job();
-    j->v = v;
+    j->v = v; j->device = v->device;
     if (hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking) != hipSuccess) { delete j; orbx_set_error("hipStreamCreate failed"); return ORBX_ERR_HIP; }
     *out = j;
     return ORBX_OK;
@@ -307,7 +308,7 @@ extern "C" int orbx_bow_job_create(orbx_vocabulary *v, orbx_bow_job **out)
 extern "C" void orbx_bow_job_destroy(orbx_bow_job *j)
 {
     if (!j) return;
-    (void)hipSetDevice(j->v->device);
+    (void)hipSetDevice(j->device);
     if (j->stream) { (void)hipStreamSynchronize(j->stream); (void)hipStreamDestroy(j->stream); }
     j->box.release(); j->word.release(); j->node.release();
     delete j;
@@ -355,7 +356,7 @@ extern "C" int orbx_bow_job_end(orbx_bow_job *j, const int32_t **word, const int
     if (pn < 0) { orbx_set_error("no job has been begun"); return ORBX_ERR_STATE; }
     *n = pn; *filed = 0;
     if (pn == 0) return ORBX_OK;
-    ORBX_HIP_CHECK(hipSetDevice(j->v->device));
+    ORBX_HIP_CHECK(hipSetDevice(j->device));
     int rc = j->box.wait(j->stream);
     if (rc != ORBX_OK) return rc;
     const OrbxCallBox &bx = j->box;
