@@ -2123,26 +2123,22 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
     __syncthreads();
     if (PROF && threadIdx.x == 0) tPrev = __builtin_amdgcn_s_memtime();
     PO_STAMP(0);      // (zero: the stamp's own cost shows up in phase 0's count)
+    // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw)) (:520) is the same estimate in every round: converted once (a sqrt, a reciprocal and a normalisation
+    // on one thread, ~1500 cycles, were repeated four times).  The number of active edges of a round is n minus the outliers the previous round's
+    // classification counted (a block reduction of its own until round 6).
+    __shared__ DPose pose0;
+    if (tid == 0) {
+        double R[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = (double)p0[4 * i + j];
+        pose0.q = quat_from_R(R);
+        quat_normalize_pos(pose0.q);
+        for (int i = 0; i < 3; i++) pose0.t[i] = (double)p0[4 * i + 3];
+    }
+    int nAct = n;      // (round 0: no outliers yet)
     for (int round = 0; round < 4; round++) {
         const bool robust = round < 3;   // kernels are removed while classifying after the third round (:547-548)
-        if (tid == 0) {                  // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw)), :520
-            double R[9];
-            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = (double)p0[4 * i + j];
-            pose.q = quat_from_R(R);
-            quat_normalize_pos(pose.q);
-            for (int i = 0; i < 3; i++) pose.t[i] = (double)p0[4 * i + 3];
-            sIterOk = 1; sNBad = 0;
-        }
+        if (tid == 0) { pose = pose0; sIterOk = 1; sNBad = 0; }
         __syncthreads();
-        int nAct = 0;
-#pragma unroll
-        for (int j = 0; j < NE; j++) nAct += (tid + 256 * j < n && !((outM >> j) & 1u)) ? 1 : 0;
-        {
-            double v[1] = {(double)nAct};
-            po_block_reduce(v, red, tid);
-            nAct = (int)red[0][0];
-            __syncthreads();
-        }
         int itersDone = 0;
         double lastChi = 0;
         PO_STAMP(1);      // round setup: estimate reset, active-edge count
@@ -2319,6 +2315,15 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                         pose = savePose;   // pop()
                     }
                     sRho = rho;
+                    // the iteration's termination tests ride on the decision of its LAST trial (a section and a barrier of their own until round 6)
+                    const int q1 = qmax + 1;
+                    if (!(rho < 0 && q1 < 10)) {
+                        if (q1 == 10 || rho == 0) sIterOk = 0;
+                        else {
+                            if ((iniChi - sCur) * 1e3 < iniChi) sNBad++; else sNBad = 0;
+                            if (sNBad >= 3) sIterOk = 0;
+                        }
+                    }
                 }
                 __syncthreads();
                 PO_STAMP(10);     // decision (one thread) + barrier
@@ -2326,15 +2331,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
             } while (sRho < 0 && qmax < 10);
             itersDone++;
             lastChi = sCur;
-            if (tid == 0) {
-                if (qmax == 10 || sRho == 0) sIterOk = 0;
-                else {
-                    if ((iniChi - sCur) * 1e3 < iniChi) sNBad++; else sNBad = 0;
-                    if (sNBad >= 3) sIterOk = 0;
-                }
-            }
-            __syncthreads();
-            PO_STAMP(11);     // end of iteration: stall test + barrier
+            PO_STAMP(11);     // end of iteration
         }
         if (tid == 0) { P.stats[8 * (size_t)f + 2 * round] = itersDone; P.stats[8 * (size_t)f + 2 * round + 1] = lastChi; }
         // ---- classification (:526-587): outliers are re-evaluated at the final pose, inliers keep their last _error
@@ -2357,7 +2354,8 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         {
             double v[1] = {(double)nb};
             po_block_reduce(v, red, tid);
-            if (tid == 0) P.ret[f] = n - (int)red[0][0];
+            nAct = n - (int)red[0][0];      // the next round's active edges (every thread reads the sum)
+            if (tid == 0) P.ret[f] = nAct;
             __syncthreads();
         }
         PO_STAMP(12);     // classification of the round
