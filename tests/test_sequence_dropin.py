@@ -93,3 +93,7 @@ def test_thirty_frames_in_both_libraries(orbx, tmp_path):
     # the HIP bodies were the ones that ran
     hip.orbx_shim_extract_orb_calls.restype = ctypes.c_ulong
     assert hip.orbx_shim_extract_orb_calls() >= 30
+    # ... and Frame::ComputeBoW of every frame was served by the descent its constructor began on the device-resident descriptors (shim/Frame_hip.cc:
+    # PostExtract -> orbx_bow_job_begin; the BowVector / FeatureVector hashes above are those of the reference's own transform())
+    hip.orbx_shim_early_bow.restype = ctypes.c_ulong
+    assert hip.orbx_shim_early_bow() >= 30
