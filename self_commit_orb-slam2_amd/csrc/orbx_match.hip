@@ -401,17 +401,18 @@ __global__ __launch_bounds__(256, 3) void k_bow_topk_mfma(FeatDev A, FeatDev B, 
 // ---------------------------------------------------------------------------------------------
 // The SINGLE-PAIR geometry (ORBmatcher::SearchByBoW as src/Tracking.cc:1195, 2073 call it: one KeyFrame against one Frame, ~1000 x 1000).
 // k_bow_topk above gives a pair ceil(nA / 256) workgroups that each walk ALL of B: four workgroups on 256 CUs, 100 us for one pair where 256 pairs
-// take 216.  Here a workgroup is 16 A features: lane (r, s) of a wave = feature r of the wave's four x B slice s of sixteen.  All of B sits in the
-// workgroup's LDS (descriptors + node ids, 36 bytes per feature); a lane scans its slice with its feature's descriptor in 8 VGPRs and keeps its
-// top-TOPK, then the sixteen lanes of a feature merge their lists with four rounds of butterfly exchanges - no partial lists in memory, no atomics,
-// no second pass.  Keys carry the B index (dist << 16 | j), so the smallest TOPK of the union of the slices' lists ARE the lists k_bow_topk produces:
-// the replay below sees identical input.  A slice's descriptors start 16 bytes further into the 128-byte bank window than its neighbour's: the
-// sixteen addresses of a step fall on eight bank groups (2-way), the four features of a wave share each read.
+// take 216.  Here a WAVE is one A feature: lane s scans slice s of B - 64 slices, ~16 features each for a 1000-feature frame -, a workgroup is four A
+// features (252 workgroups for 1005: the chip).  All of B sits in the workgroup's LDS (descriptors + node ids, 36 bytes per feature); a lane scans its slice
+// with its feature's descriptor in 8 VGPRs and keeps its top-TOPK, then the lanes of a feature merge their lists with six rounds of butterfly exchanges -
+// no partial lists in memory, no atomics, no second pass.  Keys carry the B index (dist << 16 | j), so the smallest TOPK of the union of the slices'
+// lists ARE the lists k_bow_topk produces: the replay below sees identical input.  A slice's descriptors start 16 bytes further into the 256-byte bank
+// window than its neighbour's.  (Measured on the tracked-frame loop: 16 slices x 16 features per workgroup 15.3 us, 32 x 8 13.0 us, 64 x 4 9.6 us - the
+// scan is one wave per SIMD waiting on its own LDS reads and inserts, so its length is what counts.)
 // The processing order of the A features (k_bow_order: rank by (node id, index), 46 us for one pair with its 1000-step loop over global memory) is
 // computed by further workgroups of the SAME launch: 32 features x 8 lanes per workgroup, node ids in LDS, four per read.
 // ---------------------------------------------------------------------------------------------
-#define PAIR_ROWS 16        /* A features per workgroup */
-#define PAIR_SLICES 16      /* B slices = lanes per A feature */
+#define PAIR_SLICES 64                     /* B slices = lanes per A feature */
+#define PAIR_ROWS (4 * (64 / PAIR_SLICES))   /* A features per workgroup (four waves) */
 template <bool FILTER>
 __global__ __launch_bounds__(256) void k_bow_topk_pair(FeatDev A, FeatDev B, int mode, uint32_t dcut, int nRowBlocks, int per, uint32_t *__restrict__ topk,
                                                        int32_t *__restrict__ order)
@@ -445,38 +446,63 @@ __global__ __launch_bounds__(256) void k_bow_topk_pair(FeatDev A, FeatDev B, int
         if (seg == 0 && i < nA) order[rank] = i;
         return;
     }
-    // LDS: slice s of B = `per` descriptors at sliceBase(s) = s * (per * 32 + 16) bytes; then the node ids [16 * per] (0x80000000 = excluded)
+    // LDS: slice s of B = `per` descriptors at sliceBase(s) = s * (per * 32 + 16) bytes; then the node ids [PAIR_SLICES * per] (0x80000000 = excluded)
     const int slicePitch = per * 32 + 16;
     unsigned char *sDesc = smemP;
     int32_t *sG = (int32_t *)(smemP + (size_t)PAIR_SLICES * slicePitch);
-    {
-        const uint4 *gD = (const uint4 *)B.desc;
-        for (int t = tid; t < 2 * PAIR_SLICES * per; t += 256) {      // uint4 unit t: descriptor t >> 1 of the padded list, half t & 1
-            const int j = t >> 1, sl = j / per, jj = j - sl * per;
-            *(uint4 *)(sDesc + (size_t)sl * slicePitch + (size_t)jj * 32 + (t & 1) * 16) = j < nB ? gD[t] : make_uint4(0u, 0u, 0u, 0u);
-        }
-        if (FILTER)
-            for (int j = tid; j < PAIR_SLICES * per; j += 256) {
-                int gq = (int)0x80000000;
-                if (j < nB) {
-                    gq = B.groups ? B.groups[j] : 0;
-                    if (gq < 0) gq = (int)0x80000000;                                    // not filed in the FeatureVector: never matched
-                    if (mode >= 1 && B.valid && !B.valid[j]) gq = (int)0x80000000;
-                }
-                sG[j] = gq;
-            }
-    }
-    const int r = lane >> 4, sl = lane & 15;
-    const int row = (int)blockIdx.x * PAIR_ROWS + wv * 4 + r;
+    // this lane's KeyFrame feature first: its loads are in flight while B is staged
+    const int r = lane / PAIR_SLICES, sl = lane % PAIR_SLICES;
+    const int row = (int)blockIdx.x * PAIR_ROWS + wv * (64 / PAIR_SLICES) + r;
     const bool live = row < nA;
-    const uint32_t sentinel = dcut << 16;
-    uint32_t a[8], kk[TOPK];
+    uint4 aLo, aHi;
     {
         const uint4 *da = (const uint4 *)(A.desc + (size_t)(live ? row : nA - 1) * 32);
-        const uint4 lo = da[0], hi = da[1];
-        a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
+        aLo = da[0]; aHi = da[1];
     }
     const int gA = (FILTER && A.groups) ? A.groups[live ? row : nA - 1] : 0;
+    {
+        // B -> LDS, four 16-byte units per thread per step with all four loads requested before the first store (a load-store loop is one L2 round trip
+        // per unit: eight in a row for 1000 features, most of this kernel's 16 us); unconditional loads from clamped addresses, masked afterwards
+        const uint4 *gD = (const uint4 *)B.desc;
+        const int total = 2 * PAIR_SLICES * per, last = 2 * nB - 1;
+        for (int t0 = tid; t0 < total; t0 += 4 * 256) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = gD[min(t0 + 256 * u, last)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + 256 * u;
+                if (t < total) {
+                    const int j = t >> 1, sl2 = j / per, jj = j - sl2 * per;
+                    *(uint4 *)(sDesc + (size_t)sl2 * slicePitch + (size_t)jj * 32 + (t & 1) * 16) = j < nB ? v[u] : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+        }
+        if (FILTER) {
+            const int totalG = PAIR_SLICES * per;
+            for (int j0 = tid; j0 < totalG; j0 += 4 * 256) {
+                int g[4], vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = min(j0 + 256 * u, nB - 1);
+                    g[u] = B.groups ? B.groups[j] : 0;
+                    vv[u] = (mode >= 1 && B.valid) ? (int)B.valid[j] : 1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + 256 * u;
+                    if (j < totalG) {
+                        int gq = g[u];
+                        if (j >= nB || gq < 0 || !vv[u]) gq = (int)0x80000000;      // padding; not filed in the FeatureVector; no valid MapPoint (mode 1): never matched
+                        sG[j] = gq;
+                    }
+                }
+            }
+        }
+    }
+    const uint32_t sentinel = dcut << 16;
+    uint32_t a[8], kk[TOPK];
+    a[0] = aLo.x; a[1] = aLo.y; a[2] = aLo.z; a[3] = aLo.w; a[4] = aHi.x; a[5] = aHi.y; a[6] = aHi.z; a[7] = aHi.w;
     const bool act = live && !(FILTER && gA < 0);      // unfiled A features keep empty lists
 #pragma unroll
     for (int q = 0; q < TOPK; q++) kk[q] = act ? sentinel : 0u;      // inactive rows never insert
@@ -494,7 +520,7 @@ __global__ __launch_bounds__(256) void k_bow_topk_pair(FeatDev A, FeatDev B, int
         const uint32_t key = (j < jn && d < th) ? (d << 16) | (uint32_t)(j0 + j) : 0xffffffffu;
         if (__any(key < kk[TOPK - 1])) { topk_insert(kk, key); th = kk[TOPK - 1] >> 16; }
     }
-    // the sixteen slices of a feature: butterfly over the lane bits 1, 2, 4, 8 - after round m every lane holds the TOPK of its group of 2^(m+1) slices
+    // the slices of a feature: butterfly over the lane bits 1, 2, 4, ... - after round m every lane holds the TOPK of its group of 2^(m+1) slices
 #pragma unroll
     for (int m = 1; m < PAIR_SLICES; m <<= 1) {
         uint32_t other[TOPK];
@@ -534,7 +560,7 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int hist[HISTO_LENGTH];
-    __shared__ int sChanged, sQueued, sTotal, sRemoved;
+    __shared__ int sChangedP[2], sQueued, sTotal, sRemoved;
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, fa = pairsA[p], fb = pairsB[p];
     const int nA = min(A.counts[fa], A.cap), nB = min(B.counts[fb], B.cap);
     // LDS: owner[B.cap] | dec[A.cap] (KEY_EMPTY = no match, else dist << 16 | b, later | rotation bin << 26) | order (u16) | rescan queue (u16)
@@ -542,25 +568,41 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
     uint32_t *dec = owner + B.cap;
     unsigned short *sOrd = (unsigned short *)(dec + A.cap);
     unsigned short *queue = sOrd + ((A.cap + 7) & ~7);
+    // the single-pair host call (pubFlag: the latency of this ONE workgroup is the call's): the B angles and the match list live in LDS as well - angB[B.cap] |
+    // res[max(A.cap, B.cap)] behind the queue (the host sizes the allocation) -, so that the epilogue waits for no global load and reads nothing back that it
+    // has just stored; the A angle of a thread's own rank is requested with the rank
+    float *sAngB = pubFlag ? (float *)(queue + ((A.cap + 7) & ~7)) : nullptr;
+    int32_t *sRes = pubFlag ? (int32_t *)(sAngB + B.cap) : nullptr;
     int32_t *mout = matches + (size_t)p * stride, *dout = dists + (size_t)p * stride;
     const uint4 *tk = (const uint4 *)(topk + (size_t)p * stride * TOPK);
+    const orbx_keypoint *kA = A.kp + (size_t)fa * A.cap, *kB = B.kp + (size_t)fb * B.cap;
     if (tid < HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) { sTotal = 0; sRemoved = 0; }
+    float angA0 = 0.0f;
     {
         const int32_t *ord = order + (size_t)p * stride;
         for (int r = tid; r < nA; r += GREEDY_THREADS) {
             int i = ord[r];
+            if (pubFlag && r == tid) angA0 = kA[i].angle;
             if (A.valid && !A.valid[(size_t)fa * A.cap + i]) i = 0xffff;
             sOrd[r] = (unsigned short)i;
             dec[r] = KEY_EMPTY;
         }
     }
+    if (pubFlag) {
+        for (int j = tid; j < nB; j += GREEDY_THREADS) sAngB[j] = kB[j].angle;
+        const int nOut0 = mode == 0 ? nB : nA;
+        for (int s2 = tid; s2 < nOut0; s2 += GREEDY_THREADS) sRes[s2] = -1;
+    }
     for (int s = tid; s < stride; s += GREEDY_THREADS) { mout[s] = -1; dout[s] = 256; }
     uint4 myK0 = make_uint4(0u, 0u, 0u, 0u), myK1 = myK0, othK0 = myK0, othK1 = myK0;
     bool haveKeys = false;
-    for (;;) {
-        for (int j = tid; j < nB; j += GREEDY_THREADS) owner[j] = 0xffffffffu;
-        if (tid == 0) { sChanged = 0; sQueued = 0; }
+    // A round = claims (atomicMin), decisions, rarely rescans: three barriers (a fourth behind rescans).  The "changed" flag alternates between two words so
+    // that the next round may clear its own while this round's is still being read; owner[] and the queue counter are reset for the NEXT round behind the
+    // barrier that ends this round's reads of them.
+    for (int j = tid; j < nB; j += GREEDY_THREADS) owner[j] = 0xffffffffu;
+    if (tid == 0) { sChangedP[0] = 0; sChangedP[1] = 0; sQueued = 0; }
+    for (int par = 0;; par ^= 1) {
         __syncthreads();
         for (int r = tid; r < nA; r += GREEDY_THREADS) {
             const uint32_t d = dec[r];
@@ -575,19 +617,42 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
             if (r != tid || !haveKeys) { const uint4 q0 = tk[i * 2], q1 = tk[i * 2 + 1]; if (r == tid) { myK0 = q0; myK1 = q1; haveKeys = true; } else { othK0 = q0; othK1 = q1; } }
             const uint4 q0 = r == tid ? myK0 : othK0, q1 = r == tid ? myK1 : othK1;
             const uint32_t keys[TOPK] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            uint32_t bestKey = KEY_EMPTY;
-            int best2 = 256, nfree = 0;
+            // The first two free candidates in list order, without a branch per candidate (a loop of "test, then read owner[]" is eight dependent LDS round
+            // trips behind eight branches): four owner words are requested together (word 0 for an empty slot), then the four slots are walked BACKWARDS
+            // with two selects each - what remains in (k1, k2) are the first two free.  The second half of the list is looked at only by a rank that found
+            // fewer than two free candidates in the first (sixteen waves share one CU's LDS and issue slots: the rounds are this kernel's duration).
+            auto half = [&](const int k0, uint32_t &h1, uint32_t &h2) -> int {
+                uint32_t bi[4], ow[4];
 #pragma unroll
-            for (int k = 0; k < TOPK; k++) {
-                const uint32_t key = keys[k];
-                const uint32_t bidx = mode == 2 ? 0xffffu - (key & 0xffffu) : (key & 0xffffu);   // mode 2 keys carry 0xffff - j
-                const bool fr = key != KEY_EMPTY && owner[bidx] >= (uint32_t)r;
-                if (fr) {
-                    if (nfree == 0) bestKey = (key & 0xffff0000u) | bidx;
-                    else if (nfree == 1) best2 = (int)(key >> 16);
-                    nfree++;
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t low = keys[k0 + k] & 0xffffu;
+                    bi[k] = keys[k0 + k] == KEY_EMPTY ? 0u : (mode == 2 ? 0xffffu - low : low);   // mode 2 keys carry 0xffff - j
                 }
+#pragma unroll
+                for (int k = 0; k < 4; k++) ow[k] = owner[bi[k]];
+                int nf = 0;
+                h1 = KEY_EMPTY; h2 = KEY_EMPTY;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {
+                    const bool fr = keys[k0 + k] != KEY_EMPTY && ow[k] >= (uint32_t)r;
+                    const uint32_t packed = (keys[k0 + k] & 0xffff0000u) | bi[k];
+                    h2 = fr ? h1 : h2;
+                    h1 = fr ? packed : h1;
+                    nf += fr ? 1 : 0;
+                }
+                return nf;
+            };
+            uint32_t k1, k2;
+            int nfree = half(0, k1, k2);
+            if (nfree < 2 && (keys[4] & keys[5] & keys[6] & keys[7]) != KEY_EMPTY) {
+                uint32_t j1, j2;
+                const int nb = half(4, j1, j2);
+                k2 = nfree == 1 ? j1 : j2;
+                k1 = nfree == 1 ? k1 : j1;
+                nfree += nb;
             }
+            const uint32_t bestKey = k1;
+            const int best2 = nfree >= 2 ? (int)(k2 >> 16) : 256;
             // mode 2 (SearchForTriangulation) has no ratio test: the best free candidate decides alone
             if (nfree < (mode == 2 ? 1 : 2) && keys[TOPK - 1] != KEY_EMPTY) { queue[atomicAdd(&sQueued, 1)] = (unsigned short)r; continue; }
             uint32_t nd = KEY_EMPTY;
@@ -601,7 +666,7 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
             }
             if (nd != dec[r]) { dec[r] = nd; changed = true; }
         }
-        if (changed) sChanged = 1;
+        if (changed) sChangedP[par] = 1;
         __syncthreads();
         // exact rescans: one wave per queued rank, lanes over the B features of its node
         const int nq = sQueued;
@@ -638,15 +703,15 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
                     if (pass && (float)best1 < nnratio * (float)best2) nd = bestKey;
                 }
             }
-            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChanged = 1; }
+            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChangedP[par] = 1; }
         }
-        __syncthreads();
-        const int again = sChanged;
-        __syncthreads();
+        if (nq) __syncthreads();      // (uniform: every thread read the same count behind the barrier above)
+        const int again = sChangedP[par];
         if (!again) break;
+        for (int j = tid; j < nB; j += GREEDY_THREADS) owner[j] = 0xffffffffu;
+        if (tid == 0) { sChangedP[par ^ 1] = 0; sQueued = 0; }
     }
     // ---- results + rotation histogram (src/ORBmatcher.cc:318-332, 750-758) ----
-    const orbx_keypoint *kA = A.kp + (size_t)fa * A.cap, *kB = B.kp + (size_t)fb * B.cap;
     const float factor = HISTO_LENGTH / 360.0f;
     int total = 0;
     for (int r = tid; r < nA; r += GREEDY_THREADS) {
@@ -654,9 +719,10 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
         if (d == KEY_EMPTY) continue;
         const int i = sOrd[r], bj = (int)(d & 0xffff), slot = mode == 0 ? bj : i;
         mout[slot] = mode == 0 ? i : bj; dout[slot] = (int)(d >> 16);
+        if (sRes) sRes[slot] = mode == 0 ? i : bj;
         total++;
         if (checkOri) {
-            float rot = kA[i].angle - kB[bj].angle;
+            float rot = ((pubFlag && r == tid) ? angA0 : kA[i].angle) - (sAngB ? sAngB[bj] : kB[bj].angle);
             if (rot < 0.0f) rot += 360.0f;
             int bin = (int)roundf(rot * factor);
             if (bin == HISTO_LENGTH) bin = 0;
@@ -670,15 +736,8 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
     __syncthreads();
     if (checkOri) {
         // ComputeThreeMaxima, src/ORBmatcher.cc:1866-1908
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int b = 0; b < HISTO_LENGTH; b++) {
-            const int s = hist[b];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
-            else if (s > max3) { max3 = s; ind3 = b; }
-        }
-        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        int ind1, ind2, ind3;
+        three_maxima_wave(hist, lane, ind1, ind2, ind3);
         int removed = 0;
         for (int r = tid; r < nA; r += GREEDY_THREADS) {       // same rank -> thread mapping as the writes above
             const uint32_t d = dec[r];
@@ -687,6 +746,7 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
             if (b != ind1 && b != ind2 && b != ind3) {
                 const int slot = mode == 0 ? (int)(d & 0xffff) : (int)sOrd[r];
                 mout[slot] = -1; dout[slot] = 256; removed++;
+                if (sRes) sRes[slot] = -1;
             }
         }
 #pragma unroll
@@ -698,7 +758,7 @@ __global__ __launch_bounds__(GREEDY_THREADS) void k_bow_greedy(FeatDev A, FeatDe
     if (pubFlag) {
         // the single-pair host call: the match list and the count go straight into the caller's mapped pinned buffer, the sequence word behind them
         const int nOut = mode == 0 ? nB : nA;
-        for (int s2 = tid; s2 < nOut; s2 += GREEDY_THREADS) pubMatches[s2] = mout[s2];
+        for (int s2 = tid; s2 < nOut; s2 += GREEDY_THREADS) pubMatches[s2] = sRes[s2];
         if (tid == 0) pubMatches[nOut] = sTotal - sRemoved;
         orbx_publish(nullptr, pubFlag, pubSeq, 1u);
     }
@@ -1716,7 +1776,7 @@ static int search_by_bow_single(orbx_matcher *m, const orbx_feature_set *a, cons
         hipLaunchKernelGGL(k_bow_topk_pair<false>, grid, dim3(256), ldsPair, m->stream, A, B, prm->mode, dcut, nRowBlocks, per, m->topk.p, m->order.p);
     }
     MLAUNCH_CHECK();
-    const size_t ldsGreedy = NB * 4 + NA * 4 + (size_t)((nA + 7) & ~7) * 2 * 2;
+    const size_t ldsGreedy = NB * 4 + NA * 4 + (size_t)((nA + 7) & ~7) * 2 * 2 + NB * 4 + std::max(NA, NB) * 4;      // (+ the B angles and the match list: k_bow_greedy with pubFlag)
     if (ldsGreedy > 160 * 1024) { orbx_set_error("feature count %d too large for the LDS tile", nA); return ORBX_ERR_CAPACITY; }
     if (ldsGreedy > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_bow_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsGreedy));
     if (!m->sfZero.p) {

@@ -38,6 +38,29 @@ __device__ __forceinline__ int hamming256(const unsigned long long a[4], unsigne
     return __popcll(a[0] ^ b0) + __popcll(a[1] ^ b1) + __popcll(a[2] ^ b2) + __popcll(a[3] ^ b3);
 }
 
+// ComputeThreeMaxima (src/ORBmatcher.cc:1866-1908) of a rotation histogram in LDS, by one wave with a bin per lane: the scan's strict comparisons in
+// ascending bin order pick the three largest counts, equal counts in bin order, an empty bin never - i.e. the three largest keys count << 5 | (31 - bin)
+// among the non-empty bins.  (Every thread walking the thirty bins itself is ~360 instructions; with sixteen waves on one CU that was 3.5 us of the
+// replay kernels.)  Every wave of a workgroup may call it: same result.
+__device__ __forceinline__ void three_maxima_wave(const int *hist, int lane, int &ind1, int &ind2, int &ind3)
+{
+    const int c = lane < HISTO_LENGTH ? hist[lane] : 0;
+    uint32_t key = c > 0 ? ((uint32_t)c << 5) | (uint32_t)(31 - lane) : 0u;
+    uint32_t top[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t v = key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t u = __shfl_xor(v, o); v = u > v ? u : v; }
+        top[k] = v;
+        if (key == v) key = 0u;
+    }
+    const int max1 = (int)(top[0] >> 5), max2 = (int)(top[1] >> 5), max3 = (int)(top[2] >> 5);
+    ind1 = top[0] ? 31 - (int)(top[0] & 31u) : -1; ind2 = top[1] ? 31 - (int)(top[1] & 31u) : -1; ind3 = top[2] ? 31 - (int)(top[2] & 31u) : -1;
+    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
 struct ProjFrameDev { const orbx_keypoint *kp; const uint8_t *desc; const float *uRight; const uint8_t *occupied; const int32_t *counts; int cap;
                       float minX, minY, gwInv, ghInv; };
 

@@ -43,8 +43,10 @@ __device__ __forceinline__ ProjQuery proj_query_vals(const ProjFrameDev &F, floa
     const int nMinCellY = max(0, (int)floorf((q.y - F.minY - q.rr) * F.ghInv)), nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((q.y - F.minY + q.rr) * F.ghInv));
     q.any = !(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0);
     q.cx0 = nMinCellX; q.cx1 = nMaxCellX; q.cy0 = nMinCellY; q.cy1 = nMaxCellY;
-    const unsigned long long *dp = (const unsigned long long *)desc32;
-    q.d[0] = dp[0]; q.d[1] = dp[1]; q.d[2] = dp[2]; q.d[3] = dp[3];
+    if (desc32) {      // (nullptr: the caller holds the descriptor already)
+        const unsigned long long *dp = (const unsigned long long *)desc32;
+        q.d[0] = dp[0]; q.d[1] = dp[1]; q.d[2] = dp[2]; q.d[3] = dp[3];
+    } else q.d[0] = q.d[1] = q.d[2] = q.d[3] = 0ull;
     return q;
 }
 
@@ -53,37 +55,108 @@ __device__ __forceinline__ ProjQuery proj_query(const ProjFrameDev &F, const Pro
     return proj_query_vals(F, P.px[pi], P.py[pi], P.pxr[pi], P.level[pi], P.viewCos[pi], P.desc + pi * 32, scaleFactors, th);
 }
 
-__device__ __forceinline__ unsigned long long proj_key(const ProjFrameDev &F, size_t fbase, int idx, const ProjQuery &q)
+// the window / level / stereo gates of one (query, feature) pair - everything of proj_key that does not need the descriptor; -> passes, and the feature's grid cell
+__device__ __forceinline__ bool proj_gate(const ProjFrameDev &F, const ProjQuery &q, float kx, float ky, int octave, float ur, int &cx, int &cy)
 {
-    const orbx_keypoint k = F.kp[fbase + idx];
-    const int cx = (int)roundf((k.x - F.minX) * F.gwInv), cy = (int)roundf((k.y - F.minY) * F.ghInv);   // PosInGrid, :866-867
-    if (cx < q.cx0 || cx > q.cx1 || cy < q.cy0 || cy > q.cy1) return KEY64_EMPTY;   // (also: feature outside the grid)
-    if (k.octave < q.minLevel || (q.maxLevel >= 0 && k.octave > q.maxLevel)) return KEY64_EMPTY;   // GetFeaturesInArea bCheckLevels, :814-822
-    const float distx = k.x - q.x, disty = k.y - q.y;
-    if (!(fabsf(distx) < q.rr && fabsf(disty) < q.rr)) return KEY64_EMPTY;
-    const float ur = F.uRight[fbase + idx];
-    if (ur > 0) { const float er = fabsf(q.xr - ur); if (er > q.rr) return KEY64_EMPTY; }
+    cx = (int)roundf((kx - F.minX) * F.gwInv); cy = (int)roundf((ky - F.minY) * F.ghInv);   // PosInGrid, :866-867
+    if (cx < q.cx0 || cx > q.cx1 || cy < q.cy0 || cy > q.cy1) return false;   // (also: feature outside the grid)
+    if (octave < q.minLevel || (q.maxLevel >= 0 && octave > q.maxLevel)) return false;   // GetFeaturesInArea bCheckLevels, :814-822
+    const float distx = kx - q.x, disty = ky - q.y;
+    if (!(fabsf(distx) < q.rr && fabsf(disty) < q.rr)) return false;
+    if (ur > 0) { const float er = fabsf(q.xr - ur); if (er > q.rr) return false; }
+    return true;
+}
+
+__device__ __forceinline__ unsigned long long proj_key_of(const ProjFrameDev &F, size_t fbase, int idx, int cx, int cy, const ProjQuery &q)
+{
     const unsigned long long *db = (const unsigned long long *)(F.desc + (fbase + idx) * 32);
     const int dist = hamming256(q.d, db[0], db[1], db[2], db[3]);
     return ((unsigned long long)dist << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned long long)idx;
 }
 
+__device__ __forceinline__ unsigned long long proj_key(const ProjFrameDev &F, size_t fbase, int idx, const ProjQuery &q)
+{
+    const orbx_keypoint k = F.kp[fbase + idx];
+    int cx, cy;
+    if (!proj_gate(F, q, k.x, k.y, k.octave, F.uRight[fbase + idx], cx, cy)) return KEY64_EMPTY;
+    return proj_key_of(F, fbase, idx, cx, cy, q);
+}
+
 // the TOPK smallest keys of one map point's query over the frame's features (one wave, lanes over the features) -> out[0..TOPK)
-__device__ __forceinline__ void proj_topk_wave(const ProjFrameDev &F, size_t fbase, int n, const ProjQuery &q, int lane, unsigned long long *out)
+// Round 6.  Every wave of these kernels walks ALL features of its frame (a 1000-feature frame x 1900 map points = 1.9 M gate evaluations per call), so the
+// walk is kept to what rejects almost everything: (1) only the window test |x - u| < r, |y - v| < r (src/Frame.cc:832-840; the reference applies it last,
+// the result is the conjunction either way) on the coordinates of PT_BATCH features per lane, requested together (clamped, unconditional loads); (2) the
+// features inside the window - a handful - are queued in the wave's corner of LDS by ballot; (3) the queue is worked off one candidate per lane: the
+// remaining gates (grid cell window, level, stereo), then ONE round of descriptor loads; (4) with at most 64 candidates in all - every lane holds one key or
+// none - a key's place in the list is the number of smaller keys (one scalar broadcast per candidate) instead of TOPK wave-wide minima.  Keys are unique
+// (the feature index is part of the key), so which lane holds which key is immaterial: the lists are those of the plain loop.
+#define PT_BATCH 8
+#define PT_QUEUE 256      /* candidates queued per wave before they are worked off */
+__device__ __forceinline__ void proj_insert(unsigned long long (&kk)[TOPK], unsigned long long key)
+{
+    if (key < kk[TOPK - 1]) {
+        kk[TOPK - 1] = key;
+#pragma unroll
+        for (int t = TOPK - 1; t > 0; t--)
+            if (kk[t] < kk[t - 1]) { const unsigned long long v = kk[t - 1]; kk[t - 1] = kk[t]; kk[t] = v; }
+    }
+}
+__device__ __forceinline__ void proj_topk_wave(const ProjFrameDev &F, size_t fbase, int n, const ProjQuery &q, int lane, unsigned long long *out, uint32_t *queue /* LDS, PT_QUEUE words of this wave */)
 {
     unsigned long long kk[TOPK];
 #pragma unroll
     for (int t = 0; t < TOPK; t++) kk[t] = KEY64_EMPTY;
-    if (q.any)
-        for (int idx = lane; idx < n; idx += 64) {
-            const unsigned long long key = proj_key(F, fbase, idx, q);
-            if (key < kk[TOPK - 1]) {
-                kk[TOPK - 1] = key;
+    int drained = 0, rounds = 0;      // wave-uniform: candidates worked off, in how many rounds
+    if (q.any) {
+        int nq = 0;      // wave-uniform
+        auto drain = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (one wave: its LDS instructions execute in order; this keeps the compiler from moving the reads up)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int c0 = 0; c0 < nq; c0 += 64) {
+                if (c0 + lane < nq) proj_insert(kk, proj_key(F, fbase, (int)queue[c0 + lane], q));
+                rounds++;
+            }
+            drained += nq;
+            nq = 0;
+            __builtin_amdgcn_wave_barrier();      // (the queue is rewritten from its start)
+        };
+        for (int base = 0; base < n; base += 64 * PT_BATCH) {
+            float kx[PT_BATCH], ky[PT_BATCH];
 #pragma unroll
-                for (int t = TOPK - 1; t > 0; t--)
-                    if (kk[t] < kk[t - 1]) { const unsigned long long v = kk[t - 1]; kk[t - 1] = kk[t]; kk[t] = v; }
+            for (int u = 0; u < PT_BATCH; u++) {
+                const int c = min(base + lane + 64 * u, n - 1);
+                const orbx_keypoint *kp = F.kp + fbase + c;
+                kx[u] = kp->x; ky[u] = kp->y;
+            }
+#pragma unroll
+            for (int u = 0; u < PT_BATCH; u++) {
+                const int idx = base + lane + 64 * u;
+                const bool pass = idx < n && fabsf(kx[u] - q.x) < q.rr && fabsf(ky[u] - q.y) < q.rr;
+                const unsigned long long mask = __ballot(pass);
+                if (mask) {
+                    const int cnt = __popcll(mask);
+                    if (nq + cnt > PT_QUEUE) drain();
+                    if (pass) queue[nq + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+                    nq += cnt;
+                }
             }
         }
+        if (nq) drain();
+    }
+    if (rounds <= 1) {
+        // every lane holds at most one key (kk[0]): its place = the number of smaller keys among the `drained` lanes that were given a candidate
+        const unsigned long long key = kk[0];
+        int rank = 0;
+        for (int t = 0; t < drained; t++) {
+            const unsigned long long v = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), t) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, t);
+            rank += v < key ? 1 : 0;
+        }
+        const int nv = __popcll(__ballot(key != KEY64_EMPTY));
+        if (key != KEY64_EMPTY && rank < TOPK) out[rank] = key;
+        if (lane < TOPK && lane >= nv) out[lane] = KEY64_EMPTY;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < TOPK; k++) {
         const unsigned long long mn = wave_min_u64(kk[0]);
@@ -99,6 +172,7 @@ __device__ __forceinline__ void proj_topk_wave(const ProjFrameDev &F, size_t fba
 __global__ __launch_bounds__(256) void k_proj_topk(ProjFrameDev F, ProjPointsDev P, const float *__restrict__ scaleFactors, float th,
                                                    unsigned long long *__restrict__ topk)
 {
+    __shared__ uint32_t sQueue[4][PT_QUEUE];
     const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
     if (i >= m) return;
@@ -106,7 +180,7 @@ __global__ __launch_bounds__(256) void k_proj_topk(ProjFrameDev F, ProjPointsDev
     unsigned long long *out = topk + pi * TOPK;
     if (!P.inView[pi]) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
     const ProjQuery q = proj_query(F, P, pi, scaleFactors, th);
-    proj_topk_wave(F, fbase, n, q, lane, out);
+    proj_topk_wave(F, fbase, n, q, lane, out, sQueue[threadIdx.x >> 6]);
 }
 
 // Replay of the reference's sequential pass over the map points (src/ORBmatcher.cc:70-175).  The pass is
@@ -126,21 +200,25 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_greedy(ProjFrameDe
                                                                      const unsigned long long *__restrict__ topk, int32_t *__restrict__ assigned,
                                                                      int32_t *__restrict__ nmatches, int stride, uint32_t *__restrict__ decBuf,
                                                                      uint32_t *__restrict__ queueBuf, int32_t *__restrict__ pubAssigned, unsigned long long *pubFlag,
-                                                                     unsigned long long pubSeq)
+                                                                     unsigned long long pubSeq, int decLds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int sChanged, sQueued, sTotal;
+    __shared__ int sChangedP[2], sQueued, sTotal;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = min(F.counts[f], F.cap), m = min(P.counts[f], P.cap);
     uint32_t *owner = (uint32_t *)smem;                          // [cap]
     unsigned char *occ = smem + (size_t)F.cap * 4;               // [cap] 1 = the feature holds a MapPoint with observations on entry
     unsigned char *oct = occ + F.cap;                            // [cap] octave of the feature
     const size_t fbase = (size_t)f * F.cap, pbase = (size_t)f * P.cap;
-    uint32_t *dec = decBuf + pbase, *queue = queueBuf + pbase;   // chosen feature of every point / rescan queue (global: P.cap is not bounded by LDS)
+    // chosen feature of every point / rescan queue: global (P.cap is not bounded by LDS) - except in the single-frame host call, whose ONE workgroup's latency
+    // is the call's: decLds != 0 = the host found room for dec[m] and the points' observation flags in LDS (at that byte offset), and a round of the fixed
+    // point touches no global memory at all (the lists of a thread's first two points are in its registers)
+    uint32_t *dec = decLds ? (uint32_t *)(smem + decLds) : decBuf + pbase, *queue = queueBuf + pbase;
+    unsigned char *sObs = decLds ? (unsigned char *)(dec + P.cap) : nullptr;
     int32_t *aout = assigned + (size_t)f * stride;
     for (int i = tid; i < stride; i += PROJ_GREEDY_THREADS) aout[i] = -1;
     for (int i = tid; i < n; i += PROJ_GREEDY_THREADS) { occ[i] = F.occupied ? F.occupied[fbase + i] : 0; oct[i] = (unsigned char)F.kp[fbase + i].octave; }
-    for (int r = tid; r < m; r += PROJ_GREEDY_THREADS) dec[r] = PROJ_NONE;
+    for (int r = tid; r < m; r += PROJ_GREEDY_THREADS) { dec[r] = PROJ_NONE; if (sObs) sObs[r] = P.hasObs ? P.hasObs[pbase + r] : 1; }
     if (tid == 0) sTotal = 0;
     const unsigned long long *tk = topk + pbase * TOPK;
     // acceptance of the best / second best free candidate (:150-168)
@@ -155,14 +233,16 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_greedy(ProjFrameDe
     };
     ulonglong2 ka0 = make_ulonglong2(0ull, 0ull), ka1 = ka0, ka2 = ka0, ka3 = ka0, kb0 = ka0, kb1 = ka0, kb2 = ka0, kb3 = ka0;
     int have = 0, inv = 0;
-    for (;;) {
-        __syncthreads();
-        for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = 0xffffffffu;
-        if (tid == 0) { sChanged = 0; sQueued = 0; }
+    // A round = claims, decisions, rarely rescans: three barriers (a fourth behind rescans); the "changed" flag alternates between two words, owner[] and the
+    // queue counter are reset for the next round behind the barrier that ends this round's reads of them (as in k_bow_greedy)
+    __syncthreads();
+    for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = occ[j] ? 0u : 0xffffffffu;      // owner: 0 = holds a MapPoint with observations on entry, else lowest claiming rank + 1
+    if (tid == 0) { sChangedP[0] = 0; sChangedP[1] = 0; sQueued = 0; }
+    for (int par = 0;; par ^= 1) {
         __syncthreads();
         for (int r = tid; r < m; r += PROJ_GREEDY_THREADS) {
             const uint32_t d = dec[r];
-            if (d != PROJ_NONE && (!P.hasObs || P.hasObs[pbase + r])) atomicMin(&owner[d], (uint32_t)r);
+            if (d != PROJ_NONE && (sObs ? sObs[r] != 0 : (!P.hasObs || P.hasObs[pbase + r]))) atomicMin(&owner[d], (uint32_t)r + 1u);
         }
         __syncthreads();
         bool changed = false;
@@ -186,22 +266,38 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_greedy(ProjFrameDe
                 q0 = lp[0]; q1 = lp[1]; q2 = lp[2]; q3 = lp[3];
             }
             const unsigned long long keys[TOPK] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
-            unsigned long long k1 = KEY64_EMPTY, k2 = KEY64_EMPTY;
-            int nfree = 0;
+            // the first two free candidates in list order without a branch per candidate: the eight owner words requested together (slot 0 for an empty
+            // entry), then the list walked backwards with selects - (k1, k2) end as the first two free (free for r: owner >= r + 1, see the initialisation)
+            auto half = [&](const int k0, unsigned long long &h1, unsigned long long &h2) -> int {
+                uint32_t ow[4];
 #pragma unroll
-            for (int k = 0; k < TOPK; k++) {
-                const unsigned long long key = keys[k];
-                const int idx = (int)(key & 0xffff);
-                if (key != KEY64_EMPTY && !occ[idx] && owner[idx] >= (uint32_t)r) {
-                    if (nfree == 0) k1 = key; else if (nfree == 1) k2 = key;
-                    nfree++;
+                for (int k = 0; k < 4; k++) ow[k] = owner[keys[k0 + k] == KEY64_EMPTY ? 0u : (uint32_t)(keys[k0 + k] & 0xffffu)];
+                int nf = 0;
+                h1 = KEY64_EMPTY; h2 = KEY64_EMPTY;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {
+                    const bool fr = keys[k0 + k] != KEY64_EMPTY && ow[k] > (uint32_t)r;
+                    h2 = fr ? h1 : h2;
+                    h1 = fr ? keys[k0 + k] : h1;
+                    nf += fr ? 1 : 0;
                 }
+                return nf;
+            };
+            unsigned long long k1, k2;
+            int nfree = half(0, k1, k2);
+            if (nfree < 2 && (keys[4] & keys[5] & keys[6] & keys[7]) != KEY64_EMPTY) {      // the second half of the list only for a point that needs it
+                unsigned long long j1, j2;
+                const int nb = half(4, j1, j2);
+                k2 = nfree == 1 ? j1 : j2;
+                k1 = nfree == 1 ? k1 : j1;
+                nfree += nb;
             }
+            if (nfree < 2) k2 = KEY64_EMPTY;
             if (nfree < 2 && keys[TOPK - 1] != KEY64_EMPTY) { queue[atomicAdd(&sQueued, 1)] = (uint32_t)r; continue; }   // full list, exhausted
             const uint32_t nd = decide(k1, k2);
             if (nd != dec[r]) { dec[r] = nd; changed = true; }
         }
-        if (changed) sChanged = 1;
+        if (changed) sChangedP[par] = 1;
         __syncthreads();
         // exact rescans: one wave per queued point, the two smallest keys among the features that are free for it
         const int nq = sQueued;
@@ -211,7 +307,7 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_greedy(ProjFrameDe
             unsigned long long a = KEY64_EMPTY, b = KEY64_EMPTY;
             if (q.any)
                 for (int x = lane; x < n; x += 64) {
-                    if (occ[x] || owner[x] < (uint32_t)r) continue;
+                    if (owner[x] <= (uint32_t)r) continue;
                     const unsigned long long kx = proj_key(F, fbase, x, q);
                     if (kx < a) { b = a; a = kx; } else if (kx < b) b = kx;
                 }
@@ -219,11 +315,13 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_greedy(ProjFrameDe
             if (a == k1) a = b;
             const unsigned long long k2 = wave_min_u64(a);
             const uint32_t nd = decide(k1, k2);
-            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChanged = 1; }
+            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChangedP[par] = 1; }
         }
-        __syncthreads();
-        const int again = sChanged;
+        if (nq) __syncthreads();      // (uniform)
+        const int again = sChangedP[par];
         if (!again) break;
+        for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = occ[j] ? 0u : 0xffffffffu;
+        if (tid == 0) { sChangedP[par ^ 1] = 0; sQueued = 0; }
     }
     // F.mvpMapPoints[bestIdx] = pMP in rank order: the last point that chose a feature keeps it
     __syncthreads();
@@ -315,6 +413,7 @@ __device__ __forceinline__ bool proj_last_query(const ProjFrameDev &F, const Pro
 __global__ __launch_bounds__(256) void k_proj_last_topk(ProjFrameDev F, ProjLastDev L, const float *__restrict__ scaleFactors, float th, int bMono,
                                                         unsigned long long *__restrict__ topk)
 {
+    __shared__ uint32_t sQueue[4][PT_QUEUE];
     const int f = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = min(F.counts[f], F.cap), nl = min(L.counts[f], L.cap);
     if (i >= nl) return;
@@ -324,28 +423,7 @@ __global__ __launch_bounds__(256) void k_proj_last_topk(ProjFrameDev F, ProjLast
     proj_motion(L.tcwCur + 16 * (size_t)f, L.tcwLast + 16 * (size_t)f, L.mb, bMono, bForward, bBackward);
     ProjQuery q;
     if (!proj_last_query(F, L, f, li, scaleFactors, th, bForward, bBackward, q)) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
-    unsigned long long kk[TOPK];
-#pragma unroll
-    for (int t = 0; t < TOPK; t++) kk[t] = KEY64_EMPTY;
-    for (int idx = lane; idx < n; idx += 64) {
-        const unsigned long long key = proj_key(F, fbase, idx, q);
-        if (key < kk[TOPK - 1]) {
-            kk[TOPK - 1] = key;
-#pragma unroll
-            for (int t = TOPK - 1; t > 0; t--)
-                if (kk[t] < kk[t - 1]) { const unsigned long long v = kk[t - 1]; kk[t - 1] = kk[t]; kk[t] = v; }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < TOPK; k++) {
-        const unsigned long long mn = wave_min_u64(kk[0]);
-        if (kk[0] == mn && mn != KEY64_EMPTY) {
-#pragma unroll
-            for (int t = 0; t < TOPK - 1; t++) kk[t] = kk[t + 1];
-            kk[TOPK - 1] = KEY64_EMPTY;
-        }
-        if (lane == 0) out[k] = mn;
-    }
+    proj_topk_wave(F, fbase, n, q, lane, out, sQueue[threadIdx.x >> 6]);
 }
 
 // The same parallel fixed point as k_proj_greedy (the pass over the last frame's points is sequential only
@@ -452,15 +530,8 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_last_greedy(ProjFr
     for (int j = tid; j < stride; j += PROJ_GREEDY_THREADS) aout[j] = (j < n && owner[j]) ? (int32_t)owner[j] - 1 : -1;
     __syncthreads();
     if (checkOri) {
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int b = 0; b < HISTO_LENGTH; b++) {
-            const int sN = hist[b];
-            if (sN > max1) { max3 = max2; max2 = max1; max1 = sN; ind3 = ind2; ind2 = ind1; ind1 = b; }
-            else if (sN > max2) { max3 = max2; max2 = sN; ind3 = ind2; ind2 = b; }
-            else if (sN > max3) { max3 = sN; ind3 = b; }
-        }
-        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        int ind1, ind2, ind3;
+        three_maxima_wave(hist, lane, ind1, ind2, ind3);
         int removed = 0;
         for (int r = tid; r < nl; r += PROJ_GREEDY_THREADS) {      // same point -> thread mapping as the pass above
             const uint32_t d = dec[r];
@@ -1039,15 +1110,8 @@ __global__ __launch_bounds__(256) void k_search_init(FeatDev A, ProjFrameDev F2,
     __syncthreads();
     if (checkOri) {
         // ComputeThreeMaxima over the counts of ALL accepted events (an overridden match stays in its bin, :606)
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int b = 0; b < HISTO_LENGTH; b++) {
-            const int sN = hist[b];
-            if (sN > max1) { max3 = max2; max2 = max1; max1 = sN; ind3 = ind2; ind2 = ind1; ind1 = b; }
-            else if (sN > max2) { max3 = max2; max2 = sN; ind3 = ind2; ind2 = b; }
-            else if (sN > max3) { max3 = sN; ind3 = b; }
-        }
-        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        int ind1, ind2, ind3;
+        three_maxima_wave(hist, lane, ind1, ind2, ind3);
         __threadfence_block();
         int removed = 0;
         for (int i = tid; i < n1; i += 256) {
@@ -1151,7 +1215,7 @@ static int proj_launch(orbx_matcher *m, const ProjFrameDev &F, const ProjPointsD
     if ((rc = m->projDec.ensure((size_t)nframes * P.cap)) != ORBX_OK || (rc = m->projQueue.ensure((size_t)nframes * P.cap)) != ORBX_OK) return rc;
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_proj_greedy, dim3((unsigned)nframes), dim3(PROJ_GREEDY_THREADS), lds, m->stream, F, P, m->scales.p, th, nnratio, m->topk64.p, m->matches.p,
-                       m->nmatches.p, stride, m->projDec.p, m->projQueue.p, (int32_t *)nullptr, (unsigned long long *)nullptr, 0ull);
+                       m->nmatches.p, stride, m->projDec.p, m->projQueue.p, (int32_t *)nullptr, (unsigned long long *)nullptr, 0ull, 0);
     MLAUNCH_CHECK();
     ORBX_HIP_CHECK(hipEventRecord(m->ev1[slot], m->stream));
     m->profCount++;
@@ -1223,13 +1287,15 @@ extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_projection_
     if ((rc = m->topk64.ensure(M * TOPK)) != ORBX_OK || (rc = m->projDec.ensure(M)) != ORBX_OK || (rc = m->projQueue.ensure(M)) != ORBX_OK) return rc;
     hipLaunchKernelGGL(k_proj_topk, dim3((unsigned)((mm + 3) / 4), 1u), dim3(256), 0, st, F, P, dScales, th, m->topk64.p);
     MLAUNCH_CHECK();
-    const size_t lds = (size_t)n * 6 + 16;
+    size_t lds = (size_t)n * 6 + 16;
     if (lds > 160 * 1024) { orbx_set_error("feature count %d too large for the LDS tile of the projection replay", n); return ORBX_ERR_CAPACITY; }
+    int decLds = 0;      // dec[mm] + the observation flags behind the feature tile, when they fit (k_proj_greedy)
+    if (((lds + 15) & ~(size_t)15) + M * 5 <= 150 * 1024) { decLds = (int)((lds + 15) & ~(size_t)15); lds = (size_t)decLds + M * 5; }
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int stride = m->maxFeatures;
     const unsigned long long seq = bx.arm();
     hipLaunchKernelGGL(k_proj_greedy, dim3(1), dim3(PROJ_GREEDY_THREADS), lds, st, F, P, dScales, th, nn_ratio, m->topk64.p, m->matches.p, m->nmatches.p, stride, m->projDec.p,
-                       m->projQueue.p, bx.outDev<int32_t>(0), bx.flagDev, seq);
+                       m->projQueue.p, bx.outDev<int32_t>(0), bx.flagDev, seq, decLds);
     MLAUNCH_CHECK();
     m->lastPairs = 1; m->lastStride = stride;
     if ((rc = bx.wait(st)) != ORBX_OK) return rc;
@@ -1363,10 +1429,10 @@ struct FrustumDev {
 };
 struct MapPointsDev { const float *pos, *normal, *maxDist, *minDist; const int32_t *counts; int cap; };
 
-// Frame::isInFrustum for point pi of frame f: false = not in view (:615); true: the mTrack* values (:721-731)
-__device__ __forceinline__ bool frustum_point(const FrustumDev &Fr, const MapPointsDev &M, int f, size_t pi, float &u, float &v, float &ur, int &lvlOut, float &viewCosOut)
+// Frame::isInFrustum for one point from its values: false = not in view (:615); true: the mTrack* values (:721-731)
+__device__ __forceinline__ bool frustum_eval(const FrustumDev &Fr, const float *T, const float P[3], const float Pn[3], float maxD, float minD, float &u, float &v, float &ur,
+                                             int &lvlOut, float &viewCosOut)
 {
-    const float *T = Fr.tcw + 16 * (size_t)f, *P = M.pos + 3 * pi;
     float Pc[3], Ow[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -1384,20 +1450,28 @@ __device__ __forceinline__ bool frustum_point(const FrustumDev &Fr, const MapPoi
     u = Fr.fx * Pc[0] * invz + Fr.cx; v = Fr.fy * Pc[1] * invz + Fr.cy;
     if (u < Fr.minX || u > Fr.maxX) return false;                                // :653-656
     if (v < Fr.minY || v > Fr.maxY) return false;
-    const float maxDistance = 1.2f * M.maxDist[pi], minDistance = 0.8f * M.minDist[pi];   // Get{Max,Min}DistanceInvariance, src/MapPoint.cc:523-533
+    const float maxDistance = 1.2f * maxD, minDistance = 0.8f * minD;            // Get{Max,Min}DistanceInvariance, src/MapPoint.cc:523-533
     const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
     const float dist = (float)sqrt((double)PO[0] * (double)PO[0] + (double)PO[1] * (double)PO[1] + (double)PO[2] * (double)PO[2]);   // cv::norm, :677
     if (dist < minDistance || dist > maxDistance) return false;                  // :680
-    const float *Pn = M.normal + 3 * pi;
     const double dot = (double)PO[0] * (double)Pn[0] + (double)PO[1] * (double)Pn[1] + (double)PO[2] * (double)Pn[2];
     const float viewCos = (float)(dot / (double)dist);                           // :697
     if (viewCos < Fr.cosLimit) return false;
-    const float ratio = M.maxDist[pi] / dist;                                    // MapPoint::PredictScale, src/MapPoint.cc:571-586
+    const float ratio = maxD / dist;                                             // MapPoint::PredictScale, src/MapPoint.cc:571-586
     int lvl = Fr.nlevels - 1;
     for (int k = Fr.nlevels - 2; k >= 0; k--)
         if (!(ratio > Fr.ratioTh[k])) lvl = k;
     ur = u - Fr.mbf * invz; lvlOut = lvl; viewCosOut = viewCos;
     return true;
+}
+
+// ... for point pi of frame f, its values requested together (the early exits used to put each array's load behind the previous test)
+__device__ __forceinline__ bool frustum_point(const FrustumDev &Fr, const MapPointsDev &M, int f, size_t pi, float &u, float &v, float &ur, int &lvlOut, float &viewCosOut)
+{
+    const float *Pp = M.pos + 3 * pi, *Np = M.normal + 3 * pi;
+    const float P[3] = {Pp[0], Pp[1], Pp[2]}, Pn[3] = {Np[0], Np[1], Np[2]};
+    const float maxD = M.maxDist[pi], minD = M.minDist[pi];
+    return frustum_eval(Fr, Fr.tcw + 16 * (size_t)f, P, Pn, maxD, minD, u, v, ur, lvlOut, viewCosOut);
 }
 
 __global__ __launch_bounds__(256) void k_is_in_frustum(FrustumDev Fr, MapPointsDev M, float *__restrict__ projX, float *__restrict__ projY, float *__restrict__ projXR,
@@ -1426,13 +1500,20 @@ __global__ __launch_bounds__(256) void k_frustum_topk(FrustumDev Fr, MapPointsDe
                                                       float *__restrict__ dPx, float *__restrict__ dPy, float *__restrict__ dPxr, int32_t *__restrict__ dLvl, float *__restrict__ dVc,
                                                       uint8_t *__restrict__ dIn, FrustumHostOut H, unsigned long long *__restrict__ topk)
 {
+    __shared__ uint32_t sQueue[4][PT_QUEUE];
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = min(F.counts[0], F.cap), m = min(M.counts[0], M.cap);
     if (i >= m) return;
     unsigned long long *out = topk + (size_t)i * TOPK;
+    // everything the wave needs of its point, requested up front (one round trip to memory instead of four: position, distances, normal, descriptor)
+    const float *Pp = M.pos + 3 * (size_t)i, *Np = M.normal + 3 * (size_t)i;
+    const float Pv[3] = {Pp[0], Pp[1], Pp[2]}, Nv[3] = {Np[0], Np[1], Np[2]};
+    const float maxD = M.maxDist[i], minD = M.minDist[i];
+    const unsigned long long *dq = (const unsigned long long *)(pdesc + (size_t)i * 32);
+    const unsigned long long dq0 = dq[0], dq1 = dq[1], dq2 = dq[2], dq3 = dq[3];
     float u = 0, v = 0, ur = 0, vc = 0;
     int lvl = 0;
-    const bool in = frustum_point(Fr, M, 0, (size_t)i, u, v, ur, lvl, vc);
+    const bool in = frustum_eval(Fr, Fr.tcw, Pv, Nv, maxD, minD, u, v, ur, lvl, vc);
     if (lane == 0) {
         dIn[i] = in ? 1 : 0; H.inView[i] = in ? 1 : 0;
         if (in) {
@@ -1441,8 +1522,9 @@ __global__ __launch_bounds__(256) void k_frustum_topk(FrustumDev Fr, MapPointsDe
         }
     }
     if (!in) { if (lane < TOPK) out[lane] = KEY64_EMPTY; return; }
-    const ProjQuery q = proj_query_vals(F, u, v, ur, lvl, vc, pdesc + (size_t)i * 32, scaleFactors, th);
-    proj_topk_wave(F, 0, n, q, lane, out);
+    ProjQuery q = proj_query_vals(F, u, v, ur, lvl, vc, nullptr, scaleFactors, th);
+    q.d[0] = dq0; q.d[1] = dq1; q.d[2] = dq2; q.d[3] = dq3;
+    proj_topk_wave(F, 0, n, q, lane, out, sQueue[threadIdx.x >> 6]);
 }
 
 // largest float r with ceil(log((double)r) / (double)log_scale_factor) <= k, for k = 0 .. nlevels-2 (host, libm)
@@ -1601,13 +1683,14 @@ extern "C" int orbx_search_local_points(orbx_matcher *m, const orbx_projection_f
     // --- staged part (first in the buffer)
     const void *bKp = bx.put(fr->keypoints_un, N), *bDesc = bx.put(fr->descriptors, N * 32), *bUr = bx.put(fr->u_right, N), *bOcc = bx.put(fr->occupied, fr->occupied ? N : 0);
     const void *bCnt = bx.put(cnt, 2), *bTcw = bx.put(pose->tcw, 16), *bObs = bx.put(pt->has_observations, pt->has_observations ? M : 0), *bSc = bx.put(scale_factors, (size_t)nlevels);
+    const float *bPos = bx.put(pt->world_pos, M * 3), *bNrm = bx.put(pt->normal, M * 3), *bMax = bx.put(pt->max_distance, M), *bMin = bx.put(pt->min_distance, M);
+    const uint8_t *bPd = bx.put(pt->descriptors, M * 32);
     const size_t staged = bx.used;
-    // --- read in place
-    const float *zPos = bx.put(pt->world_pos, M * 3), *zNrm = bx.put(pt->normal, M * 3), *zMax = bx.put(pt->max_distance, M), *zMin = bx.put(pt->min_distance, M);
-    const uint8_t *zDesc = bx.put(pt->descriptors, M * 32);
     if ((rc = m->arena.ensure(staged)) != ORBX_OK) return rc;
     uint8_t *const ar = m->arena.p;
     auto dev = [&](const void *boxAddr) { return ar + ((const uint8_t *)boxAddr - bx.inDev); };
+    const float *zPos = (const float *)dev(bPos), *zNrm = (const float *)dev(bNrm), *zMax = (const float *)dev(bMax), *zMin = (const float *)dev(bMin);
+    const uint8_t *zDesc = dev(bPd);
     const size_t n16 = staged / 16;
     hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 512)), dim3(256), 0, st, (const uint4 *)bx.inDev, (uint4 *)ar, n16);
     MLAUNCH_CHECK();
@@ -1628,13 +1711,15 @@ extern "C" int orbx_search_local_points(orbx_matcher *m, const orbx_projection_f
     MLAUNCH_CHECK();
     m->frCount = M;
     ProjPointsDev P = {m->frProj.p, m->frProj.p + M, m->frProj.p + 2 * M, m->frLevel.p, m->frProj.p + 3 * M, m->frInView.p, pt->has_observations ? dev(bObs) : nullptr, zDesc, dCnt + 1, mm};
-    const size_t lds = (size_t)n * 6 + 16;
+    size_t lds = (size_t)n * 6 + 16;
     if (lds > 160 * 1024) { orbx_set_error("feature count %d too large for the LDS tile of the projection replay", n); return ORBX_ERR_CAPACITY; }
+    int decLds = 0;      // dec[mm] + the observation flags behind the feature tile, when they fit (k_proj_greedy)
+    if (((lds + 15) & ~(size_t)15) + M * 5 <= 150 * 1024) { decLds = (int)((lds + 15) & ~(size_t)15); lds = (size_t)decLds + M * 5; }
     if (lds > 48 * 1024) ORBX_HIP_CHECK(hipFuncSetAttribute((const void *)k_proj_greedy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int stride = m->maxFeatures;
     const unsigned long long seq = bx.arm();
     hipLaunchKernelGGL(k_proj_greedy, dim3(1), dim3(PROJ_GREEDY_THREADS), lds, st, F, P, dScales, th, nn_ratio, m->topk64.p, m->matches.p, m->nmatches.p, stride, m->projDec.p,
-                       m->projQueue.p, bx.outDev<int32_t>(offAs), bx.flagDev, seq);
+                       m->projQueue.p, bx.outDev<int32_t>(offAs), bx.flagDev, seq, decLds);
     MLAUNCH_CHECK();
     m->lastPairs = 1; m->lastStride = stride;
     if ((rc = bx.wait(st)) != ORBX_OK) return rc;
