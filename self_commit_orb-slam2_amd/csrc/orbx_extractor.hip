@@ -1280,7 +1280,9 @@ static int comb_new_engine(Combiner *C, CombEngine **out)
     void *dp = nullptr;
     if (hipHostGetDevicePointer(&dp, E->tab, 0) != hipSuccess) { orbx_set_error("hipHostGetDevicePointer (member table) failed"); return fail(ORBX_ERR_HIP); }
     E->tabDev = (const OrbxCombMember *)dp;
-    if (hipMalloc((void **)&E->syncDev, 64) != hipSuccess || hipMemset(E->syncDev, 0, 64) != hipSuccess || hipHostMalloc((void **)&E->flag, 64, hipHostMallocMapped) != hipSuccess ||
+    // (behind the 64 bytes of counters: the device's copy of the member table, made by the set's first kernel for its last one)
+    const size_t syncBytes = 64 + sizeof(OrbxCombMember) * (size_t)C->maxB;
+    if (hipMalloc((void **)&E->syncDev, syncBytes) != hipSuccess || hipMemset(E->syncDev, 0, syncBytes) != hipSuccess || hipHostMalloc((void **)&E->flag, 64, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&E->flagDev, E->flag, 0) != hipSuccess) { orbx_set_error("completion word of the engine could not be allocated"); return fail(ORBX_ERR_HIP); }
     *E->flag = 0;
     // the members' arenas have the one-frame layout (ensure_geometry with batch 1): same capacity, same offsets for all of them
@@ -1308,7 +1310,7 @@ static int comb_build_graph(Combiner *C, CombEngine *E, int n)
     }
     OrbxLaunch L;
     fill_launch(e, L, e->staging.p, n, C->dstStride, C->fp, 0);
-    L.combTab = E->tabDev; L.combKpOff = C->kpOff; L.combDescOff = C->descOff; L.combSync = E->syncDev; L.combFlag = E->flagDev;
+    L.combTab = E->tabDev; L.combTabCopy = (OrbxCombMember *)((uint8_t *)E->syncDev + 64); L.combKpOff = C->kpOff; L.combDescOff = C->descOff; L.combSync = E->syncDev; L.combFlag = E->flagDev;
     hipGraph_t g = nullptr;
     ORBX_HIP_CHECK(hipGraphCreate(&g, 0));
     // (a failure below must not leave a half-built graph behind - it would be found "built" without an executable and rebuilt on every set of this size)

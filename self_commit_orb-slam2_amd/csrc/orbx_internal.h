@@ -130,6 +130,7 @@ struct OrbxLaunch {
     /* graph construction (single-frame call): when `graph` is set, a launcher adds a kernel node that depends on deps[0..ndeps)
      * and returns it in *node instead of launching on `stream` */
     const OrbxCombMember *combTab = nullptr;      /* combined single-frame batches: member table (pinned host memory) */
+    OrbxCombMember *combTabCopy = nullptr;        /* ... its copy in device memory: written by k_comb_upload, read by k_comb_finish */
     unsigned *combSync = nullptr;                 /* ... device: [0] arrivals of k_comb_finish's workgroups, [2..3] launch sets completed so far (u64) */
     unsigned long long *combFlag = nullptr;       /* ... mapped host: the same count, stored behind a set's last result - what the leader polls instead of synchronising the stream */
     size_t combKpOff = 0, combDescOff = 0;        /* one-frame arena layout of the members */

@@ -1456,8 +1456,12 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_describe(const OdLevels 
 // 640x480 frame, but 66 us for eight, with the whole chain waiting behind them - or, when the member had to wait for the engine anyway
 // and uploaded its frame meanwhile on its own stream (DMA, overlapping the previous launch set), the member's device copy.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_comb_upload(const OrbxCombMember *__restrict__ tab, uint8_t *__restrict__ staging, size_t framePitch)
+// It also leaves a copy of the member's table entry in device memory for k_comb_finish (whose first act was a PCIe round trip for it).
+__global__ __launch_bounds__(256) void k_comb_upload(const OrbxCombMember *__restrict__ tab, OrbxCombMember *__restrict__ tabCopy, uint8_t *__restrict__ staging, size_t framePitch)
 {
+    static_assert(sizeof(OrbxCombMember) % 8 == 0, "the table entry is copied in 8-byte words");
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(OrbxCombMember) / 8)
+        ((unsigned long long *)&tabCopy[blockIdx.y])[threadIdx.x] = ((const unsigned long long *)&tab[blockIdx.y])[threadIdx.x];
     const uint4 *src = (const uint4 *)tab[blockIdx.y].srcImg;
     uint4 *dst = (uint4 *)(staging + (size_t)blockIdx.y * framePitch);
     const size_t n = framePitch >> 4, stride = (size_t)gridDim.x * 256;
@@ -1628,7 +1632,7 @@ int orbx_launch_comb_upload(const OrbxLaunch &L, uint8_t *stagingDev)
     const size_t units = L.img0FramePitch >> 4;
     // one 16-byte unit per thread (four until round 6: 19 workgroups per 640x480 frame kept too few reads in flight across PCIe - 17 us for 307 KB)
     const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((units + 255) / 256, 1), 256);
-    return emit(L, k_comb_upload, dim3(blocks, (unsigned)L.batch), dim3(256), 0, L.combTab, stagingDev, L.img0FramePitch);
+    return emit(L, k_comb_upload, dim3(blocks, (unsigned)L.batch), dim3(256), 0, L.combTab, L.combTabCopy, stagingDev, L.img0FramePitch);
 }
 
 int orbx_launch_comb_finish(const OrbxLaunch &L)
@@ -1636,7 +1640,7 @@ int orbx_launch_comb_finish(const OrbxLaunch &L)
     const size_t units = (L.geom->pyrBytes + L.img0FramePitch) >> 4;
     // (every workgroup ends with an agent-scope release - a write-back of its XCD's L2 - before it counts itself in: few, fat workgroups)
     const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((units + 2047) / 2048, 1), 64);
-    return emit(L, k_comb_finish, dim3(blocks, (unsigned)L.batch), dim3(256), 0, L.combTab, L.outCnt, L.outStatus, L.outKp, L.outDesc, L.geom->outCap, L.pyr, L.geom->pyrBytes, L.img0,
+    return emit(L, k_comb_finish, dim3(blocks, (unsigned)L.batch), dim3(256), 0, (const OrbxCombMember *)L.combTabCopy, L.outCnt, L.outStatus, L.outKp, L.outDesc, L.geom->outCap, L.pyr, L.geom->pyrBytes, L.img0,
                 L.img0FramePitch, L.combKpOff, L.combDescOff, 0, L.combSync, L.combFlag);      // (the host pyramid copy rides in the quadtree's launch)
 }
 

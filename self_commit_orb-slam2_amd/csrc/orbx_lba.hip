@@ -1968,6 +1968,10 @@ struct PoseOptDev {
     unsigned long long *pubFlag;
     unsigned long long pubSeq;
     unsigned long long *prof;   // PROF instantiation only: [32] phase cycles / counts
+    // the single-frame host call: count, camera and pose travel in the kernel arguments (read from the mapped buffer they are two dependent PCIe round trips
+    // - the count, then everything sized by it - at the head of a kernel the caller is waiting for)
+    int one, count0;
+    float cam0[5], pose00[16];
 };
 
 #define PO_NRED 28   /* 21 upper-triangle entries of H + 6 of b + chi2 */
@@ -2076,13 +2080,14 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
     __shared__ double sLambda, sNi, sCur, sRho;
     __shared__ int sOk, sIterOk, sNBad;
     const int f = blockIdx.x, tid = threadIdx.x;
-    const int n = min(P.counts[f], P.cap);
+    const int n = min(P.one ? P.count0 : P.counts[f], P.cap);
     const size_t base = (size_t)f * P.cap;
     const float *Xw = P.Xw + base * 3, *obs = P.obs + base * 3, *invS2 = P.invS2 + base;
     uint8_t *outl = P.outlier + base;
     double in[5];
-    for (int i = 0; i < 5; i++) in[i] = (double)P.cam[5 * (size_t)f + i];
-    const float *p0 = P.pose0 + 16 * (size_t)f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) in[i] = (double)(P.one ? P.cam0[i] : P.cam[5 * (size_t)f + i]);
+    const float *p0 = P.pose0 + 16 * (size_t)f;      // (the by-value copy is read with constant indices only: a pointer into the argument block would put it on the stack)
     if (tid < 8) P.stats[8 * (size_t)f + tid] = 0;
     if (n < 3) {   // :509-510
         if (tid < n) outl[tid] = 0;
@@ -2129,10 +2134,15 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
     __shared__ DPose pose0;
     if (tid == 0) {
         double R[9];
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = (double)p0[4 * i + j];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) R[3 * i + j] = (double)(P.one ? P.pose00[4 * i + j] : p0[4 * i + j]);
+        }
         pose0.q = quat_from_R(R);
         quat_normalize_pos(pose0.q);
-        for (int i = 0; i < 3; i++) pose0.t[i] = (double)p0[4 * i + 3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) pose0.t[i] = (double)(P.one ? P.pose00[4 * i + 3] : p0[4 * i + 3]);
     }
     int nAct = n;      // (round 0: no outliers yet)
     for (int round = 0; round < 4; round++) {
@@ -2958,7 +2968,9 @@ extern "C" int orbx_pose_optimization(orbx_pose_optimizer *h, const orbx_pose_pr
     const int32_t *dCnt = bx.put(p->counts, (size_t)B);
     const float *dXw = bx.put(p->world_points, N * 3), *dObs = bx.put(p->observations, N * 3), *dInv = bx.put(p->inv_sigma2, N);
     const uint8_t *o0 = bx.outHost<uint8_t>(0), *o1 = bx.outHost<uint8_t>(q1), *o2 = bx.outHost<uint8_t>(q2), *o3 = bx.outHost<uint8_t>(q3);
-    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, bx.outDev<float>(0), bx.outDev<uint8_t>(q1), bx.outDev<int32_t>(q2), bx.outDev<double>(q3), bx.counter, bx.flagDev, bx.arm(), g_poProf};
+    PoseOptDev D = {dPose, dCam, dXw, dObs, dInv, dCnt, cap, bx.outDev<float>(0), bx.outDev<uint8_t>(q1), bx.outDev<int32_t>(q2), bx.outDev<double>(q3), bx.counter, bx.flagDev, bx.arm(), g_poProf,
+                    B == 1 ? 1 : 0, p->counts[0], {}, {}};
+    if (B == 1) { memcpy(D.cam0, p->cameras, sizeof D.cam0); memcpy(D.pose00, p->poses, sizeof D.pose00); }
     const float thMono = (float)sqrt(5.991), thStereo = (float)sqrt(7.815);   // deltaMono / deltaStereo are floats (:389-390)
     Huber hub;
     hub.dMono = thMono; hub.dStereo = thStereo;
