@@ -437,7 +437,7 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_last_greedy(ProjFr
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int hist[HISTO_LENGTH];
-    __shared__ int sTotal, sRemoved, sChanged, sQueued;
+    __shared__ int sTotal, sRemoved, sChangedP[2], sQueued;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = min(F.counts[f], F.cap), nl = min(L.counts[f], L.cap);
     uint32_t *owner = (uint32_t *)smem;                     // [cap] lowest observation-carrying point choosing the feature; later: its final holder
@@ -452,34 +452,54 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_last_greedy(ProjFr
     bool bForward, bBackward;
     proj_motion(L.tcwCur + 16 * (size_t)f, L.tcwLast + 16 * (size_t)f, L.mb, bMono, bForward, bBackward);
     const unsigned long long *tk = topk + lbase * TOPK;
-    for (;;) {
-        __syncthreads();
-        for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = 0xffffffffu;
-        if (tid == 0) { sChanged = 0; sQueued = 0; }
+    // Rounds as in k_proj_greedy: owner = 0 for a feature that holds a MapPoint with observations on entry, else (lowest claiming point + 1); the lists of a
+    // thread's first two points stay in its registers; the first free candidate by four owner words requested together and a backward walk with selects
+    // (the second half of the list only when the first holds none); three barriers per round, a fourth behind rescans.
+    ulonglong2 ka0 = make_ulonglong2(KEY64_EMPTY, KEY64_EMPTY), ka1 = ka0, ka2 = ka0, ka3 = ka0, kb0 = ka0, kb1 = ka0, kb2 = ka0, kb3 = ka0;
+    int have = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = occ[j] ? 0u : 0xffffffffu;
+    if (tid == 0) { sChangedP[0] = 0; sChangedP[1] = 0; sQueued = 0; }
+    for (int par = 0;; par ^= 1) {
         __syncthreads();
         for (int r = tid; r < nl; r += PROJ_GREEDY_THREADS) {
             const uint32_t d = dec[r];
-            if (d != PROJ_NONE && (!L.hasObs || L.hasObs[lbase + r])) atomicMin(&owner[d], (uint32_t)r);
+            if (d != PROJ_NONE && (!L.hasObs || L.hasObs[lbase + r])) atomicMin(&owner[d], (uint32_t)r + 1u);
         }
         __syncthreads();
         bool changed = false;
         for (int r = tid; r < nl; r += PROJ_GREEDY_THREADS) {
-            const ulonglong2 *lp = (const ulonglong2 *)(tk + (size_t)r * TOPK);
-            const ulonglong2 q0 = lp[0], q1 = lp[1], q2 = lp[2], q3 = lp[3];
+            const int slot = (r - tid) / PROJ_GREEDY_THREADS;
+            ulonglong2 q0, q1, q2, q3;
+            if (slot < 2) {
+                if (!(have & (1 << slot))) {
+                    const ulonglong2 *lp = (const ulonglong2 *)(tk + (size_t)r * TOPK);
+                    if (slot == 0) { ka0 = lp[0]; ka1 = lp[1]; ka2 = lp[2]; ka3 = lp[3]; } else { kb0 = lp[0]; kb1 = lp[1]; kb2 = lp[2]; kb3 = lp[3]; }
+                    have |= 1 << slot;
+                }
+                if (slot == 0) { q0 = ka0; q1 = ka1; q2 = ka2; q3 = ka3; } else { q0 = kb0; q1 = kb1; q2 = kb2; q3 = kb3; }
+            } else {
+                const ulonglong2 *lp = (const ulonglong2 *)(tk + (size_t)r * TOPK);
+                q0 = lp[0]; q1 = lp[1]; q2 = lp[2]; q3 = lp[3];
+            }
             const unsigned long long keys[TOPK] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
             if (keys[0] == KEY64_EMPTY) continue;                       // skipped point or empty window
-            unsigned long long k1 = KEY64_EMPTY;
+            auto half = [&](const int k0) -> unsigned long long {
+                uint32_t ow[4];
 #pragma unroll
-            for (int k = TOPK - 1; k >= 0; k--) {
-                const unsigned long long key = keys[k];
-                const int idx = (int)(key & 0xffff);
-                if (key != KEY64_EMPTY && !occ[idx] && owner[idx] >= (uint32_t)r) k1 = key;   // ends on the first free entry
-            }
+                for (int k = 0; k < 4; k++) ow[k] = owner[keys[k0 + k] == KEY64_EMPTY ? 0u : (uint32_t)(keys[k0 + k] & 0xffffu)];
+                unsigned long long h1 = KEY64_EMPTY;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) h1 = (keys[k0 + k] != KEY64_EMPTY && ow[k] > (uint32_t)r) ? keys[k0 + k] : h1;      // ends on the first free entry
+                return h1;
+            };
+            unsigned long long k1 = half(0);
+            if (k1 == KEY64_EMPTY && (keys[4] & keys[5] & keys[6] & keys[7]) != KEY64_EMPTY) k1 = half(4);
             if (k1 == KEY64_EMPTY && keys[TOPK - 1] != KEY64_EMPTY) { queue[atomicAdd(&sQueued, 1)] = (uint32_t)r; continue; }   // full list, all taken
             const uint32_t nd = (k1 != KEY64_EMPTY && (int)(k1 >> 32) <= TH_HIGH) ? (uint32_t)(k1 & 0xffff) : PROJ_NONE;
             if (nd != dec[r]) { dec[r] = nd; changed = true; }
         }
-        if (changed) sChanged = 1;
+        if (changed) sChangedP[par] = 1;
         __syncthreads();
         const int nq = sQueued;
         for (int qi = wv; qi < nq; qi += PROJ_GREEDY_THREADS / 64) {
@@ -488,17 +508,19 @@ __global__ __launch_bounds__(PROJ_GREEDY_THREADS) void k_proj_last_greedy(ProjFr
             unsigned long long a = KEY64_EMPTY;
             if (proj_last_query(F, L, f, lbase + r, scaleFactors, th, bForward, bBackward, q))
                 for (int x = lane; x < n; x += 64) {
-                    if (occ[x] || owner[x] < (uint32_t)r) continue;
+                    if (owner[x] <= (uint32_t)r) continue;
                     const unsigned long long kx = proj_key(F, fbase, x, q);
                     a = kx < a ? kx : a;
                 }
             const unsigned long long k1 = wave_min_u64(a);
             const uint32_t nd = (k1 != KEY64_EMPTY && (int)(k1 >> 32) <= TH_HIGH) ? (uint32_t)(k1 & 0xffff) : PROJ_NONE;
-            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChanged = 1; }
+            if (lane == 0 && nd != dec[r]) { dec[r] = nd; sChangedP[par] = 1; }
         }
-        __syncthreads();
-        const int again = sChanged;
+        if (nq) __syncthreads();      // (uniform)
+        const int again = sChangedP[par];
         if (!again) break;
+        for (int j = tid; j < n; j += PROJ_GREEDY_THREADS) owner[j] = occ[j] ? 0u : 0xffffffffu;
+        if (tid == 0) { sChangedP[par ^ 1] = 0; sQueued = 0; }
     }
     // CurrentFrame.mvpMapPoints[bestIdx2] = pMP in point order: the last chooser holds the feature (owner := holder + 1, 0 = none)
     __syncthreads();

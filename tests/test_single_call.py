@@ -121,3 +121,28 @@ def test_many_kinds_of_calls_share_one_matcher_handle(orbx, oracle):
             got = mt.SearchByProjectionLast(dict(fl, kps=_struct_kps(orbx, fl["kps7"])), lastd, 7.0, True)
             assert got[0] == ln and (got[1] == lm).all(), (rnd, n, "projection last")
     mt.close()
+
+
+@pytest.mark.parametrize("layout", ["four_way_tie", "tie_for_third", "second_below_a_tenth", "third_below_a_tenth", "one_bin", "wrap_bin"])
+def test_three_maxima_ties_and_the_tenth_rule(orbx, oracle, layout):
+    """ComputeThreeMaxima (src/ORBmatcher.cc:1866-1908) inside the replay kernels is one wave with a bin per lane: the three largest counts, EQUAL counts in bin
+    order (the sequential scan's strict comparisons), bins below a tenth of the largest dropped.  Distinct descriptors match 1:1, so the histogram is whatever
+    the angles say: exact ties among the top bins, a tie for the third place, both branches of the tenth rule, a single bin, and the bin that wraps (30 -> 0)."""
+    rng = np.random.default_rng(11)
+    bins = {"four_way_tie": {3: 30, 7: 30, 12: 30, 20: 30}, "tie_for_third": {1: 50, 5: 40, 9: 20, 14: 20, 22: 20}, "second_below_a_tenth": {4: 100, 8: 9, 15: 9},
+            "third_below_a_tenth": {2: 100, 6: 50, 11: 9, 13: 9}, "one_bin": {17: 64}, "wrap_bin": {0: 40, 29: 40, 10: 40, 11: 39}}[layout]
+    n = sum(bins.values())
+    dA = _rand_desc(rng, n)
+    kA = _kps(rng, n, orbx)
+    kB = kA.copy()
+    rot = np.concatenate([np.full(c, 12.0 * b + (354.5 if (layout == "wrap_bin" and b == 0) else 0.0), np.float32) for b, c in bins.items()])   # bin = round(rot / 12); 354.5 / 12 rounds to 30 -> 0
+    rot = rot[rng.permutation(n)]
+    kA["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    kB["angle"] = ((kA["angle"].astype(np.float64) - rot) % 360).astype(np.float32)
+    mt = orbx.ORBmatcher(0.9, True, max_features=1200)
+    for mode in (0, 1):
+        want_n, want = oracle_lib.search_by_bow(oracle, mode, kA, dA, kB, dA, 0.9, True)
+        got_n, got = mt.SearchByBoW(kA, dA, kB, dA, mode=mode)
+        assert got_n == want_n and (got == want).all(), (layout, mode)
+        assert 0 < want_n < n or layout in ("one_bin",), (layout, want_n)      # the pruning did something (a single bin keeps everything)
+    mt.close()
