@@ -59,7 +59,7 @@ def _scene(orbx, seed, m=2500, clutter=600):
     k7, desc = k7[perm], desc[perm]
     u_right = np.where(rng.random(n) < 0.4, k7[:, 0] - rng.uniform(1, 30, n), -1).astype(np.float32)
     pre = np.full(n, -1, np.int32)                                            # features that already hold a MapPoint (TrackWithMotionModel's matches)
-    held = rng.choice(n, n // 8, replace=False)
+    held = rng.choice(n, min(n // 8, m), replace=False)
     pre[held] = rng.choice(m, len(held), replace=False)
     bad = (rng.random(m) < 0.05).astype(np.uint8)
     has_obs = (rng.random(m) < 0.9).astype(np.uint8)
@@ -140,3 +140,27 @@ def test_chained_call_equals_the_two_calls(orbx, seed, th):
         assert (fv["level"][ok] == two["level"][ok]).all()
         n2, a2 = mt.SearchByProjection(frame, dict(two, desc=sc["src_desc"], has_obs=sc["has_obs"]), th)
         assert nm == n2 and (assigned == a2).all() and nm > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref libraries not built (need /root/reference)")
+@pytest.mark.parametrize("seed,m,clutter,th", [(31, 1, 0, 1), (32, 3, 5, 3), (33, 65, 64, 1), (34, 300, 3000, 8), (35, 900, 2500, 5), (36, 4000, 100, 1), (37, 2500, 600, 8),
+                                               (38, 64, 0, 3), (39, 1200, 1200, 2), (40, 2000, 3500, 8)])
+def test_search_local_points_sizes_and_crowded_windows(orbx, seed, m, clutter, th):
+    """The same comparison over shapes the three seeds above do not reach: one or a few map points, a frame without clutter, more map points than features and the
+    reverse, and search windows (th = 5, 8: a radius of up to 114 px) that hold hundreds of features - the candidate walk of k_frustum_topk queues more than a wave's
+    worth (rank counting does not apply) and more than its LDS queue takes (worked off in the middle of the scan), the replay meets full lists and rescans."""
+    orbx.load_library()
+    ref, hip = oracle_lib.slam_lib(), oracle_lib.slam_hip_lib()
+    fr, sc = _scene(orbx, seed, m=m, clutter=clutter)
+    if len(fr["k7"]) == 0:
+        pytest.skip("the scene has no feature at all")
+    want, got = _call(ref, fr, sc, th), _call(hip, fr, sc, th)
+    assert got["nm"] == want["nm"], (seed, m, clutter, th)
+    assert (got["assigned"] == want["assigned"]).all()
+    asked = sc["bad"] == 0
+    assert (got["in_view"][asked] == want["in_view"][asked]).all() and (got["visible"] == want["visible"]).all()
+    ok = (want["in_view"] == 1) & asked
+    for k in ("proj_x", "proj_y", "proj_xr", "view_cos"):
+        assert (got[k][ok].view(np.uint32) == want[k][ok].view(np.uint32)).all(), k
+    assert (got["level"][ok] == want["level"][ok]).all()
