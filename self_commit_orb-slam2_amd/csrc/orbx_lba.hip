@@ -194,26 +194,46 @@ __device__ inline void pose_oplus(DPose &T, const double d[6])
 __device__ inline void pose_oplus_small(DPose &T, const double d[6])
 {
     const double *om = d, *up = d + 3;
-    const double x = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    const double x = __builtin_fma(om[2], om[2], __builtin_fma(om[1], om[1], om[0] * om[0]));
     if (!(x < 0.25)) { pose_oplus(T, d); return; }
-    // Horner in x = theta^2; coefficients = 1 / (2^(2k+1) (2k+1)!), 1 / (4^k (2k)!), 1 / (2k+1)!, 1 / (2k+2)!, 1 / (2k+3)!  with alternating signs
-    const double sh = 0.5 + x * (-1.0 / 48 + x * (1.0 / 3840 + x * (-1.0 / 645120 + x * (1.0 / 185794560 + x * (-1.0 / 81749606400.0 + x * (1.0 / 51011754393600.0))))));
-    const double ch = 1.0 + x * (-1.0 / 8 + x * (1.0 / 384 + x * (-1.0 / 46080 + x * (1.0 / 10321920 + x * (-1.0 / 3715891200.0 + x * (1.0 / 1961990553600.0))))));
-    const double b = 0.5 + x * (-1.0 / 24 + x * (1.0 / 720 + x * (-1.0 / 40320 + x * (1.0 / 3628800 + x * (-1.0 / 479001600.0 + x * (1.0 / 87178291200.0))))));
-    const double c = 1.0 / 6 + x * (-1.0 / 120 + x * (1.0 / 5040 + x * (-1.0 / 362880 + x * (1.0 / 39916800 + x * (-1.0 / 6227020800.0 + x * (1.0 / 1307674368000.0))))));
-    DPose E;
-    E.q.x = om[0] * sh; E.q.y = om[1] * sh; E.q.z = om[2] * sh; E.q.w = ch;
-    quat_normalize_pos(E.q);
+    // Horner in x = theta^2; coefficients = 1 / (2^(2k+1) (2k+1)!), 1 / (4^k (2k)!), 1 / (2k+2)!, 1 / (2k+3)! with alternating signs.  The four chains advance
+    // together, one fused multiply-add each per step (written as four nested expressions the compiler evaluated them one after the other: +200 cycles); all
+    // products of this function are fused multiply-adds - it is a chain of dependent FP64 operations on one lane, ~8 cycles each, that every trial waits for.
+    static const double C[4][7] = {{0.5, -1.0 / 48, 1.0 / 3840, -1.0 / 645120, 1.0 / 185794560, -1.0 / 81749606400.0, 1.0 / 51011754393600.0},
+                                   {1.0, -1.0 / 8, 1.0 / 384, -1.0 / 46080, 1.0 / 10321920, -1.0 / 3715891200.0, 1.0 / 1961990553600.0},
+                                   {0.5, -1.0 / 24, 1.0 / 720, -1.0 / 40320, 1.0 / 3628800, -1.0 / 479001600.0, 1.0 / 87178291200.0},
+                                   {1.0 / 6, -1.0 / 120, 1.0 / 5040, -1.0 / 362880, 1.0 / 39916800, -1.0 / 6227020800.0, 1.0 / 1307674368000.0}};
+    double pl[4] = {C[0][6], C[1][6], C[2][6], C[3][6]};
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) pl[t] = __builtin_fma(x, pl[t], C[t][k]);
+    }
+    const double sh = pl[0], ch = pl[1], b = pl[2], c = pl[3];
+    // the rotation's quaternion (cos(t/2), omega sin(t/2)/t): a unit quaternion to 1e-16 as it stands (SE3Quat's normalisation of it would multiply by
+    // 1 +- 1 ulp - a reciprocal square root on this chain for nothing; the product below is normalised), ch > 0 here: no sign flip
+    DQuat e;
+    e.x = om[0] * sh; e.y = om[1] * sh; e.z = om[2] * sh; e.w = ch;
     // t = V u, V = I + b Omega + c Omega^2: Omega u = om x u, Omega^2 u = om x (om x u)
-    const double c1[3] = {om[1] * up[2] - om[2] * up[1], om[2] * up[0] - om[0] * up[2], om[0] * up[1] - om[1] * up[0]};
-    const double c2[3] = {om[1] * c1[2] - om[2] * c1[1], om[2] * c1[0] - om[0] * c1[2], om[0] * c1[1] - om[1] * c1[0]};
-    for (int i = 0; i < 3; i++) E.t[i] = up[i] + b * c1[i] + c * c2[i];
-    double rt[3];
-    quat_rot(E.q, T.t, rt);
+    const double c1[3] = {__builtin_fma(om[1], up[2], -(om[2] * up[1])), __builtin_fma(om[2], up[0], -(om[0] * up[2])), __builtin_fma(om[0], up[1], -(om[1] * up[0]))};
+    const double c2[3] = {__builtin_fma(om[1], c1[2], -(om[2] * c1[1])), __builtin_fma(om[2], c1[0], -(om[0] * c1[2])), __builtin_fma(om[0], c1[1], -(om[1] * c1[0]))};
+    // exp(d) * T: rotation of T.t by e, + t
+    const double *v = T.t;
+    const double ux = 2 * __builtin_fma(e.y, v[2], -(e.z * v[1])), uy = 2 * __builtin_fma(e.z, v[0], -(e.x * v[2])), uz = 2 * __builtin_fma(e.x, v[1], -(e.y * v[0]));
     DPose N;
-    for (int i = 0; i < 3; i++) N.t[i] = E.t[i] + rt[i];
-    N.q = quat_mul(E.q, T.q);
-    quat_normalize_pos(N.q);
+    N.t[0] = __builtin_fma(c, c2[0], __builtin_fma(b, c1[0], up[0])) + (__builtin_fma(e.w, ux, v[0]) + __builtin_fma(e.y, uz, -(e.z * uy)));
+    N.t[1] = __builtin_fma(c, c2[1], __builtin_fma(b, c1[1], up[1])) + (__builtin_fma(e.w, uy, v[1]) + __builtin_fma(e.z, ux, -(e.x * uz)));
+    N.t[2] = __builtin_fma(c, c2[2], __builtin_fma(b, c1[2], up[2])) + (__builtin_fma(e.w, uz, v[2]) + __builtin_fma(e.x, uy, -(e.y * ux)));
+    const DQuat &g = T.q;
+    N.q.w = __builtin_fma(-e.z, g.z, __builtin_fma(-e.y, g.y, __builtin_fma(-e.x, g.x, e.w * g.w)));
+    N.q.x = __builtin_fma(-e.z, g.y, __builtin_fma(e.y, g.z, __builtin_fma(e.x, g.w, e.w * g.x)));
+    N.q.y = __builtin_fma(-e.x, g.z, __builtin_fma(e.z, g.x, __builtin_fma(e.y, g.w, e.w * g.y)));
+    N.q.z = __builtin_fma(-e.y, g.x, __builtin_fma(e.x, g.y, __builtin_fma(e.z, g.w, e.w * g.z)));
+    {
+        double ni = fast_rsqrt(__builtin_fma(N.q.w, N.q.w, __builtin_fma(N.q.z, N.q.z, __builtin_fma(N.q.y, N.q.y, N.q.x * N.q.x))));
+        ni = N.q.w < 0 ? -ni : ni;      // SE3Quat::normalizeRotation: w >= 0
+        N.q.x *= ni; N.q.y *= ni; N.q.z *= ni; N.q.w *= ni;
+    }
     T = N;
 }
 
@@ -1976,19 +1996,30 @@ struct PoseOptDev {
 
 #define PO_NRED 28   /* 21 upper-triangle entries of H + 6 of b + chi2 */
 
+// pose_map for k_pose_opt with fused multiply-adds (21 + 3 instead of 30 + 3 operations per point; the kernel's passes over the edges are bound by
+// instruction issue).  The reference's own build contracts these expressions wherever its compiler's -march has FMA; the estimates are held to 1e-5.
+__device__ __forceinline__ void po_pose_map(const DPose &T, const double v[3], double o[3])
+{
+    const DQuat &q = T.q;
+    const double ux = 2 * __builtin_fma(q.y, v[2], -(q.z * v[1])), uy = 2 * __builtin_fma(q.z, v[0], -(q.x * v[2])), uz = 2 * __builtin_fma(q.x, v[1], -(q.y * v[0]));
+    o[0] = (__builtin_fma(q.w, ux, v[0]) + __builtin_fma(q.y, uz, -(q.z * uy))) + T.t[0];
+    o[1] = (__builtin_fma(q.w, uy, v[1]) + __builtin_fma(q.z, ux, -(q.x * uz))) + T.t[1];
+    o[2] = (__builtin_fma(q.w, uz, v[2]) + __builtin_fma(q.x, uy, -(q.y * ux))) + T.t[2];
+}
+
 __device__ inline void po_edge_error(const DPose &T, const double in[5], const float *Xw, const float *obs, bool stereo, double out[3])
 {
     const double X[3] = {(double)Xw[0], (double)Xw[1], (double)Xw[2]};
     double Xc[3];
-    pose_map(T, X, Xc);
+    po_pose_map(T, X, Xc);
     if (!stereo) {   // EdgeSE3ProjectXYZOnlyPose::computeError / cam_project (types_six_dof_expmap.h:150-157, .cpp:290-296)
         const double iz = fast_rcp(Xc[2]);      // (<= 1 ulp from the reference's two divisions; 40 error passes of ~3 edges per thread in series)
-        const double u = Xc[0] * iz * in[0] + in[2], v = Xc[1] * iz * in[1] + in[3];
+        const double u = __builtin_fma(Xc[0] * iz, in[0], in[2]), v = __builtin_fma(Xc[1] * iz, in[1], in[3]);
         out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v; out[2] = 0;
     } else {         // EdgeStereoSE3ProjectXYZOnlyPose (.cpp:299-306): float invz, double bf
         const float invz = (float)fast_rcp(Xc[2]);
-        const double u = Xc[0] * invz * in[0] + in[2], v = Xc[1] * invz * in[1] + in[3];
-        out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v; out[2] = (double)obs[2] - (u - in[4] * (double)invz);
+        const double u = __builtin_fma(Xc[0] * invz, in[0], in[2]), v = __builtin_fma(Xc[1] * invz, in[1], in[3]);
+        out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v; out[2] = (double)obs[2] - __builtin_fma(-in[4], (double)invz, u);
     }
 }
 
@@ -2000,63 +2031,89 @@ __device__ __forceinline__ void po_edge_error_nb(const DPose &T, const double in
 {
     const double X[3] = {(double)Xw[0], (double)Xw[1], (double)Xw[2]};
     double Xc[3];
-    pose_map(T, X, Xc);
+    po_pose_map(T, X, Xc);
     const double izd = fast_rcp(Xc[2]);
     const double iz = stereo ? (double)(float)izd : izd;
-    const double u = Xc[0] * iz * in[0] + in[2], v = Xc[1] * iz * in[1] + in[3];
+    const double u = __builtin_fma(Xc[0] * iz, in[0], in[2]), v = __builtin_fma(Xc[1] * iz, in[1], in[3]);
     out[0] = (double)obs[0] - u; out[1] = (double)obs[1] - v;
-    const double o2 = (double)obs[2] - (u - in[4] * iz);
+    const double o2 = (double)obs[2] - __builtin_fma(-in[4], iz, u);
     out[2] = stereo ? o2 : 0.0;
 }
 __device__ __forceinline__ void huber_rho_nb(const Huber &h, bool stereo, double chi, double &rho0, double &rho1)
 {
+    // sqrt(chi) and delta / sqrt(chi) from ONE v_rsq_f64 + two Newton steps (<= 1 ulp) instead of an IEEE square root and an IEEE division - ~80 of the
+    // ~250 instructions an edge costs in these issue-bound passes; chi = 0: the products are NaN, and not selected
     const double delta = stereo ? h.dStereo : h.dMono, dsqr = stereo ? h.dsqrStereo : h.dsqrMono;
-    const double s = sqrt(chi);
+    const double rs = fast_rsqrt(chi), s = chi * rs;
     const bool in = chi <= dsqr;
-    rho0 = in ? chi : 2 * s * delta - dsqr;
-    rho1 = in ? 1. : delta / s;
+    rho0 = in ? chi : __builtin_fma(2 * s, delta, -dsqr);
+    rho1 = in ? 1. : delta * rs;
+}
+
+// a lane's value moved by a DPP control (two full-rate v_mov_b32_dpp, ~8 cycles of latency; __shfl_xor of a double is two ds_bpermute_b32 through the LDS
+// crossbar, ~130 cycles per step of a dependent chain)
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u & 0xffffffffu), CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// the wave's sum in every lane, in a fixed order: pairs, quads, half rows, rows (DPP butterflies), then the four rows' sums as scalar broadcasts
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += dpp_f64<0xb1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4e>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);     // row_half_mirror
+    v += dpp_f64<0x140>(v);     // row_mirror: every lane holds its row's sum
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return (r0 + r1) + (r2 + r3);
 }
 
 template <int N> __device__ inline void po_block_reduce(double (&v)[N], double (*red)[PO_NRED], int tid)
 {
-    // v[0..N) per thread -> red[0][0..N) summed over the workgroup (N is a template argument: v stays in registers)
+    // v[0..N) per thread -> v[0..N) of EVERY thread = the sums over the workgroup (N is a template argument: v stays in registers).  One barrier: the four
+    // waves' sums meet in red[wave][k] and every thread adds them itself, in the same order.  The caller keeps a barrier between two calls (red is reused).
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        double x = v[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        const double x = wave_sum_f64(v[k]);
         if (lane == 0) red[wave][k] = x;
     }
     __syncthreads();
-    if (tid < N) red[0][tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
 }
 
 // The 28 sums of an iteration (21 entries of H, 6 of b, chi2) through a transposed LDS tile instead of 28 x 6 double shuffles per thread
-// (6 us of an 11 us iteration): thread t stores its 28 values at [k][t], 224 threads add 32 consecutive entries each, 28 threads
-// add the 8 parts - fixed order, three barriers, no cross-lane traffic.  Index (k, t) -> k * 264 + (t >> 5) * 33 + (t & 31).
+// (6 us of an 11 us iteration): thread t stores its 28 values at [k][t], 224 threads add 32 consecutive entries each (four chains) and the 8 parts
+// of a sum - eight neighbouring lanes - meet by three DPP butterflies: fixed order, two barriers.  Index (k, t) -> k * 264 + (t >> 5) * 33 + (t & 31).
 #define PO_TP 264
-__device__ __forceinline__ void po_block_reduce28(const double (&v)[PO_NRED], double *redT, double (*part)[9], double (*red)[PO_NRED], int tid)
+__device__ __forceinline__ void po_block_reduce28(const double (&v)[PO_NRED], double *redT, double (*red)[PO_NRED], double *sH, double *sb, int tid)
 {
     const int slot = (tid >> 5) * 33 + (tid & 31);
 #pragma unroll
     for (int k = 0; k < 28; k++) redT[k * PO_TP + slot] = v[k];
     __syncthreads();
-    if (tid < 224) {
+    if (tid < 224) {      // (28 groups of 8 lanes: a group is entirely inside one half row of a wave, and entirely active)
         const int k = tid >> 3, p = tid & 7;
         const double *src = redT + k * PO_TP + p * 33;
-        double sacc = 0;
+        double s4[4] = {0, 0, 0, 0};      // four chains instead of one of 32 dependent additions
 #pragma unroll
-        for (int i = 0; i < 32; i++) sacc += src[i];
-        part[k][p] = sacc;
-    }
-    __syncthreads();
-    if (tid < 28) {
-        double sacc = 0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) sacc += part[tid][q];
-        red[0][tid] = sacc;
+        for (int i = 0; i < 32; i++) s4[i & 3] += src[i];
+        double sacc = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        // the eight parts of a sum sit in eight neighbouring lanes: three DPP butterflies instead of a trip through LDS and a barrier
+        sacc += dpp_f64<0xb1>(sacc);
+        sacc += dpp_f64<0x4e>(sacc);
+        sacc += dpp_f64<0x141>(sacc);
+        // the sums go where the solve reads them - H with both triangles (k = i * 6 - i (i - 1) / 2 + (j - i) of the upper one), b, and the chi2 for every thread
+        if (p == 0) {
+            if (k < 21) {
+                const int i = (k >= 6) + (k >= 11) + (k >= 15) + (k >= 18) + (k >= 20), j = i + (k - (i * 6 - i * (i - 1) / 2));
+                sH[6 * i + j] = sacc; sH[6 * j + i] = sacc;
+            } else if (k < 27) sb[k - 21] = sacc;
+            else red[0][27] = sacc;
+        }
     }
     __syncthreads();
 }
@@ -2073,7 +2130,6 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
     unsigned long long pacc[PROF ? 16 : 1] = {}, pcnt[PROF ? 16 : 1] = {}, tPrev = 0;
     (void)pacc; (void)pcnt; (void)tPrev;
     __shared__ double redT[28 * PO_TP];
-    __shared__ double part28[28][9];
     __shared__ DPose pose, savePose;
     __shared__ double red[4][PO_NRED];
     __shared__ double sH[36], sb[6], sx[6];
@@ -2167,71 +2223,82 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                 po_edge_error(T, in, xw[j], ob[j], st, r);
                 er[j][0] = r[0]; er[j][1] = r[1]; er[j][2] = r[2];
                 const double w = (double)is2[j];
-                const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * w;
+                const double chi = __builtin_fma(r[2], r[2], __builtin_fma(r[1], r[1], r[0] * r[0])) * w;
                 double r0 = chi, r1 = 1;
-                if (robust) huber_rho(hub, st, chi, r0, r1);
+                if (robust) huber_rho_nb(hub, st, chi, r0, r1);
                 acc[27] += r0;
                 // linearizeOplus (.cpp:266-288, 335-367)
                 const double X[3] = {(double)xw[j][0], (double)xw[j][1], (double)xw[j][2]};
                 double Xc[3];
-                pose_map(T, X, Xc);
-                const double x = Xc[0], y = Xc[1], invz = fast_rcp(Xc[2]), invz_2 = invz * invz, fx = in[0], fy = in[1], bf = in[4];
+                po_pose_map(T, X, Xc);
+                // (the Jacobian of .cpp:266-288 / 335-367 through a = x / z, b = y / z: 15 operations instead of 25 - the same quantities, products associated differently)
+                const double x = Xc[0], y = Xc[1], invz = fast_rcp(Xc[2]), fx = in[0], fy = in[1], bf = in[4];
+                const double a = x * invz, b = y * invz, ab = a * b, fxz = invz * fx, fyz = invz * fy, bz2 = bf * invz * invz;
                 double J[18];
-                J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
-                J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
-                J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2;
+                J[0] = ab * fx; J[1] = -(__builtin_fma(a, a, 1.0) * fx); J[2] = b * fx; J[3] = -fxz; J[4] = 0; J[5] = a * fxz;
+                J[6] = __builtin_fma(b, b, 1.0) * fy; J[7] = -(ab * fy); J[8] = -(a * fy); J[9] = 0; J[10] = -fyz; J[11] = b * fyz;
+                J[12] = __builtin_fma(-bz2, y, J[0]); J[13] = __builtin_fma(bz2, x, J[1]); J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - bz2;
                 // rows 0, 1 and - for a stereo edge - 2, summed in that order from 0 like the reference's loop over the
                 // error dimension; everything unrolled so that J / acc are registers (a runtime row count puts J into
                 // scratch memory and costs ~40k cycles per edge).
                 // J[4], J[9] and J[16] are exact zeros: a product with one of them is +-0.0, and adding +-0.0 to a sum that starts at +0.0 leaves its
                 // bits alone (finite operands) - those 33 of the 81 product terms are not computed (known at compile time: the loops are unrolled).
+                // The 48 (mono) / 75 (stereo) products go into the thread's sums as fused multiply-adds - one instruction per product instead of a multiply and
+                // up to two additions: this loop is a third of the call, and it is bound by instruction issue.  (Rounded differently in the last bits than
+                // g2o's Eigen expression; the estimates are held to 1e-5, not to bits.)
                 const double W = r1 * w;
+                double JW[12];
+#pragma unroll
+                for (int q = 0; q < 12; q++) JW[q] = J[q] * W;
                 {
                     int k = 0;
 #pragma unroll
                     for (int i = 0; i < 6; i++)
 #pragma unroll
                         for (int jj = i; jj < 6; jj++, k++) {
-                            double sacc = 0;
-                            if (i != 4 && jj != 4) sacc += J[i] * W * J[jj];
-                            if (i != 3 && jj != 3) sacc += J[6 + i] * W * J[6 + jj];
-                            if (st && i != 4 && jj != 4) sacc += J[12 + i] * W * J[12 + jj];
-                            acc[k] += sacc;
+                            if (i != 4 && jj != 4) acc[k] = __builtin_fma(JW[i], J[jj], acc[k]);
+                            if (i != 3 && jj != 3) acc[k] = __builtin_fma(JW[6 + i], J[6 + jj], acc[k]);
                         }
                 }
+                const double c0 = -w * r[0] * r1, c1 = -w * r[1] * r1;
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
-                    double sacc = 0;
-                    if (i != 4) sacc += J[i] * (-w * r[0] * r1);
-                    if (i != 3) sacc += J[6 + i] * (-w * r[1] * r1);
-                    if (st && i != 4) sacc += J[12 + i] * (-w * r[2] * r1);
-                    acc[21 + i] += sacc;
+                    if (i != 4) acc[21 + i] = __builtin_fma(J[i], c0, acc[21 + i]);
+                    if (i != 3) acc[21 + i] = __builtin_fma(J[6 + i], c1, acc[21 + i]);
+                }
+                if (st) {
+                    double JW2[6];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) JW2[q] = J[12 + q] * W;
+                    int k = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int jj = i; jj < 6; jj++, k++)
+                            if (i != 4 && jj != 4) acc[k] = __builtin_fma(JW2[i], J[12 + jj], acc[k]);
+                    const double c2 = -w * r[2] * r1;
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+                        if (i != 4) acc[21 + i] = __builtin_fma(J[12 + i], c2, acc[21 + i]);
                 }
             }
             PO_STAMP(2);      // build: errors, Jacobians, the thread's 28 sums
-            po_block_reduce28(acc, redT, part28, red, tid);
-            PO_STAMP(3);      // reduce28
-            // H (both triangles), b, the current chi2 and - first iteration - lambda out of the 28 sums: 43 threads, one value each (one thread doing all of
-            // it was 770 cycles of every iteration); thread 0 reads them behind the barrier
-            if (tid < 36) {
-                const int i = tid / 6, j = tid - 6 * i, a = i < j ? i : j, b = i < j ? j : i;
-                sH[tid] = red[0][a * 6 - a * (a - 1) / 2 + (b - a)];
-            } else if (tid < 42) sb[tid - 36] = red[0][21 + tid - 36];
-            else if (tid == 42) {
-                sCur = red[0][27];
-                if (it == 0) {   // computeLambdaInit (:166-180): the diagonal sits at k = 0, 6, 11, 15, 18, 20 of the upper triangle
-                    double mx = 0;
-                    mx = fmax(mx, fabs(red[0][0])); mx = fmax(mx, fabs(red[0][6])); mx = fmax(mx, fabs(red[0][11]));
-                    mx = fmax(mx, fabs(red[0][15])); mx = fmax(mx, fabs(red[0][18])); mx = fmax(mx, fabs(red[0][20]));
-                    sLambda = 1e-5 * mx; sNi = 2;
-                }
-            }
-            __syncthreads();
+            po_block_reduce28(acc, redT, red, sH, sb, tid);
+            PO_STAMP(3);      // reduce28 (H, b and the chi2 arrive where the solve reads them: the stage that copied them and its barrier are gone)
             const double iniChi = red[0][27];
             int qmax = 0;
-            PO_STAMP(4);      // H / b to LDS, lambda init
+            PO_STAMP(4);
             do {
                 if (tid == 0) {
+                    if (qmax == 0) {
+                        sCur = iniChi;
+                        if (it == 0) {   // computeLambdaInit (:166-180)
+                            double mx = 0;
+#pragma unroll
+                            for (int q = 0; q < 6; q++) mx = fmax(mx, fabs(sH[7 * q]));
+                            sLambda = 1e-5 * mx; sNi = 2;
+                        }
+                    }
                     savePose = pose;   // push()
                     // (H + lambda I) x = b by LDL^T; "isPositive" like LinearSolverDense (linear_solver_dense.h:99-103)
                     // every loop fully unrolled, no early exit: A / Dg / xx stay in registers (with runtime indices they live in
@@ -2245,10 +2312,13 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     double Dg[6], Di[6];   // pivots and their reciprocals (6 divisions instead of 21 on this one-thread chain)
                     bool ok = true;
 #pragma unroll
+                    // (fused multiply-adds with the row's L D products formed once: this chain of dependent FP64 operations on ONE lane is ~8 cycles per
+                    // operation, and every trial waits for it)
                     for (int j = 0; j < 6; j++) {
+                        double LD[6];      // L[j][k] D[k], k < j
                         double dj = A[7 * j];
 #pragma unroll
-                        for (int k = 0; k < j; k++) dj -= A[6 * j + k] * A[6 * j + k] * Dg[k];
+                        for (int k = 0; k < j; k++) { LD[k] = A[6 * j + k] * Dg[k]; dj = __builtin_fma(-A[6 * j + k], LD[k], dj); }
                         ok = ok && (dj > 0) && isfinite(dj);
                         Dg[j] = dj;
                         Di[j] = fast_rcp(dj);
@@ -2256,7 +2326,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                         for (int i = j + 1; i < 6; i++) {
                             double lij = A[6 * i + j];
 #pragma unroll
-                            for (int k = 0; k < j; k++) lij -= A[6 * i + k] * A[6 * j + k] * Dg[k];
+                            for (int k = 0; k < j; k++) lij = __builtin_fma(-A[6 * i + k], LD[k], lij);
                             A[6 * i + j] = lij * Di[j];
                         }
                     }
@@ -2265,7 +2335,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     for (int i = 0; i < 6; i++) {
                         double sacc = sb[i];
 #pragma unroll
-                        for (int k = 0; k < i; k++) sacc -= A[6 * i + k] * xx[k];
+                        for (int k = 0; k < i; k++) sacc = __builtin_fma(-A[6 * i + k], xx[k], sacc);
                         xx[i] = sacc;
                     }
 #pragma unroll
@@ -2274,7 +2344,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     for (int i = 5; i >= 0; i--) {
                         double sacc = xx[i];
 #pragma unroll
-                        for (int k = i + 1; k < 6; k++) sacc -= A[6 * k + i] * xx[k];
+                        for (int k = i + 1; k < 6; k++) sacc = __builtin_fma(-A[6 * k + i], xx[k], sacc);
                         xx[i] = sacc;
                     }
                     if (ok) {
@@ -2297,7 +2367,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     double r[3];
                     po_edge_error_nb(T2, in, xw[j], ob[j], st, r);
                     er[j][0] = on ? r[0] : er[j][0]; er[j][1] = on ? r[1] : er[j][1]; er[j][2] = on ? r[2] : er[j][2];
-                    const double chi = (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * (double)is2[j];
+                    const double chi = __builtin_fma(r[2], r[2], __builtin_fma(r[1], r[1], r[0] * r[0])) * (double)is2[j];
                     double r0 = chi, r1 = 1;
                     if (robust) huber_rho_nb(hub, st, chi, r0, r1);
                     cacc[0] += on ? r0 : 0.0;
@@ -2306,12 +2376,13 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                 po_block_reduce(cacc, red, tid);
                 PO_STAMP(9);      // reduce (chi2)
                 if (tid == 0) {
-                    double tempChi = red[0][0];
+                    double tempChi = cacc[0];
                     if (!sOk) tempChi = 1.7976931348623157e308;
                     double rho = sCur - tempChi, scale = 0;
-                    for (int j = 0; j < 6; j++) scale += sx[j] * (sLambda * sx[j] + sb[j]);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) scale = __builtin_fma(sx[j], __builtin_fma(sLambda, sx[j], sb[j]), scale);
                     scale += 1e-3;
-                    rho /= scale;
+                    rho *= fast_rcp(scale);      // (<= 1 ulp from the division; rho's sign and 2 rho - 1 are what is used)
                     if (rho > 0 && isfinite(tempChi)) {
                         const double t2r = 2 * rho - 1;
                         double alpha = 1. - t2r * t2r * t2r;      // (pow(x, 3) in the reference; the library call costs ~0.5 us on this one-thread section)
@@ -2364,7 +2435,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
         {
             double v[1] = {(double)nb};
             po_block_reduce(v, red, tid);
-            nAct = n - (int)red[0][0];      // the next round's active edges (every thread reads the sum)
+            nAct = n - (int)v[0];      // the next round's active edges (every thread holds the sum)
             if (tid == 0) P.ret[f] = nAct;
             __syncthreads();
         }

@@ -17,9 +17,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from test_pose_optimization import make_frame  # noqa: E402
 
-NAMES = ["(stamp cost)", "round setup: estimate reset, active-edge count", "build: errors, Jacobians, 28 sums per thread", "reduce28 (transposed LDS tile, 3 barriers)",
+NAMES = ["(stamp cost)", "round setup: estimate reset, active-edge count", "build: errors, Jacobians, 28 sums per thread", "reduce28 (transposed LDS tile, 2 barriers)",
          "H / b to LDS, lambda init (thread 0)", "6x6 LDL^T solve (thread 0)", "pose oplus = SE3 exp (thread 0)", "barrier behind the solve",
-         "error pass at the trial pose", "reduce chi2 (shuffles + 2 barriers)", "decision (thread 0) + barrier", "end of iteration: stall test + barrier",
+         "error pass at the trial pose", "reduce chi2 (DPP + 1 barrier)       ", "decision (thread 0) + barrier", "end of iteration: stall test + barrier",
          "classification of the round", "flags + pose out"]
 L = orbx.load_library()
 L.orbx_debug_pose_opt_profile.argtypes = [ctypes.c_void_p]
