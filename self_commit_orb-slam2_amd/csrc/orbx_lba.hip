@@ -55,6 +55,13 @@ __host__ __device__ __forceinline__ double fast_rcp(double x)
     return 1.0 / x;
 #endif
 }
+// one Newton step (~2^-50: v_rcp_f64 delivers ~26 bits): the pivots of k_pose_opt's 6x6 solve and the gain ratio's denominator, on a one-lane chain where every
+// FP64 instruction is ~8 cycles
+__device__ __forceinline__ double fast_rcp1(double x)
+{
+    const double y = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
 __host__ __device__ __forceinline__ double fast_rsqrt(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2312,8 +2319,10 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                     double Dg[6], Di[6];   // pivots and their reciprocals (6 divisions instead of 21 on this one-thread chain)
                     bool ok = true;
 #pragma unroll
-                    // (fused multiply-adds with the row's L D products formed once: this chain of dependent FP64 operations on ONE lane is ~8 cycles per
-                    // operation, and every trial waits for it)
+                    // (fused multiply-adds with the row's L D products formed once: on ONE lane every FP64 instruction of this section costs ~8 cycles, dependent or
+                    // not, and every trial waits for it.  Measured against it: the same system by 3x3 blocks with cofactor inverses - two reciprocals on the chain
+                    // instead of six, ~150 instead of ~160 instructions -: 1780 cycles against 1650, no gain; lanes as rows with v_readlane broadcasts: priced at
+                    // ~1300, the broadcasts and selects eat what the shorter instruction stream saves.)
                     for (int j = 0; j < 6; j++) {
                         double LD[6];      // L[j][k] D[k], k < j
                         double dj = A[7 * j];
@@ -2321,7 +2330,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
                         for (int k = 0; k < j; k++) { LD[k] = A[6 * j + k] * Dg[k]; dj = __builtin_fma(-A[6 * j + k], LD[k], dj); }
                         ok = ok && (dj > 0) && isfinite(dj);
                         Dg[j] = dj;
-                        Di[j] = fast_rcp(dj);
+                        Di[j] = fast_rcp1(dj);
 #pragma unroll
                         for (int i = j + 1; i < 6; i++) {
                             double lij = A[6 * i + j];
@@ -2382,7 +2391,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptDev P, Huber hub)
 #pragma unroll
                     for (int j = 0; j < 6; j++) scale = __builtin_fma(sx[j], __builtin_fma(sLambda, sx[j], sb[j]), scale);
                     scale += 1e-3;
-                    rho *= fast_rcp(scale);      // (<= 1 ulp from the division; rho's sign and 2 rho - 1 are what is used)
+                    rho *= fast_rcp1(scale);      // (a few ulp from the division; rho's sign and 2 rho - 1 are what is used)
                     if (rho > 0 && isfinite(tempChi)) {
                         const double t2r = 2 * rho - 1;
                         double alpha = 1. - t2r * t2r * t2r;      // (pow(x, 3) in the reference; the library call costs ~0.5 us on this one-thread section)
