@@ -120,12 +120,17 @@ void FillMaps(const ORBVocabulary *voc, const int32_t *word, const int32_t *node
             if (vit == v.end() || vit->first != w) vit = v.insert(v.end(), DBoW2::BowVector::value_type(w, weight[i]));      // :1160 / :1187 (new word)
             else if (tf) vit->second += weight[i];                                                                          // addWeight on an existing word
         }
-        DBoW2::FeatureVector::iterator fit = fv.end();
-        for (int k = 0; k < filed; k++) {
-            const int i = byNode[k];
-            const DBoW2::NodeId nd = (DBoW2::NodeId)node[i];
-            if (fit == fv.end() || fit->first != nd) fit = fv.insert(fv.end(), DBoW2::FeatureVector::value_type(nd, std::vector<unsigned int>()));
-            fit->second.push_back((unsigned int)i);                                                                                  // :1161
+        // a node's features are one run of byNode: its vector is made at its final size (appending one feature at a time reallocates it four or five times
+        // per node - ORBvoc at levelsup 4 files a frame's features under ~100 nodes)
+        for (int k = 0; k < filed;) {
+            const DBoW2::NodeId nd = (DBoW2::NodeId)node[byNode[k]];
+            int e = k + 1;
+            while (e < filed && (DBoW2::NodeId)node[byNode[e]] == nd) e++;
+            DBoW2::FeatureVector::iterator fit = fv.insert(fv.end(), DBoW2::FeatureVector::value_type(nd, std::vector<unsigned int>()));
+            std::vector<unsigned int> &lst = fit->second;
+            lst.resize((size_t)(e - k));
+            for (int q = k; q < e; q++) lst[(size_t)(q - k)] = (unsigned int)byNode[q];                                                 // :1161, in feature order
+            k = e;
         }
     }
     if (tf && !v.empty() && !must) {                                                          // :1165-1171
